@@ -1,0 +1,281 @@
+"""ctypes view of include/bsgpu.h.
+
+The same declarations serve the product library (prefix ``bsgpu_``, loaded by
+:mod:`beam_slam_amd.gpu`) and — in tests only — the CPU oracle (prefix ``bso_``), because the
+oracle deliberately exports the same entry points.  Nothing in this module computes anything.
+"""
+import ctypes as C
+
+import numpy as np
+
+OK = 0
+ERR_INVALID, ERR_DEVICE, ERR_UNSUPPORTED, ERR_NUMERIC = -1, -2, -3, -4
+
+MANIFOLD_EUCLIDEAN, MANIFOLD_QUAT_RIGHT = 0, 1
+LOSS_TRIVIAL, LOSS_CAUCHY, LOSS_HUBER = 0, 1, 2
+
+F_REPROJ = 0
+F_REPROJ_ONLINE_CALIB = 1
+F_IMU_DELTA = 2
+F_IMU_PRIOR = 3
+F_RELPOSE_EXT = 4
+F_RELPOSE = 5
+F_ABSPOSE = 6
+F_ABS_VEC3 = 7
+F_REL_VEC3 = 8
+F_GRAVITY = 9
+F_NUM_TYPES = 10
+
+LINEAR_AUTO, LINEAR_SCHUR_CHOLESKY, LINEAR_PCG = 0, 1, 2
+CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
+
+
+class Options(C.Structure):
+    _fields_ = [
+        ("max_num_iterations", C.c_int32),
+        ("linear_solver_type", C.c_int32),
+        ("jacobi_scaling", C.c_int32),
+        ("max_num_consecutive_invalid_steps", C.c_int32),
+        ("max_solver_time_in_seconds", C.c_double),
+        ("function_tolerance", C.c_double),
+        ("gradient_tolerance", C.c_double),
+        ("parameter_tolerance", C.c_double),
+        ("initial_trust_region_radius", C.c_double),
+        ("max_trust_region_radius", C.c_double),
+        ("min_trust_region_radius", C.c_double),
+        ("min_relative_decrease", C.c_double),
+        ("min_lm_diagonal", C.c_double),
+        ("max_lm_diagonal", C.c_double),
+        ("pcg_max_iterations", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("pcg_tolerance", C.c_double),
+    ]
+
+
+class Summary(C.Structure):
+    _fields_ = [
+        ("termination_type", C.c_int32),
+        ("is_solution_usable", C.c_int32),
+        ("num_iterations", C.c_int32),
+        ("num_successful_steps", C.c_int32),
+        ("num_unsuccessful_steps", C.c_int32),
+        ("num_parameters_tangent", C.c_int32),
+        ("num_residuals", C.c_int32),
+        ("linear_solver_used", C.c_int32),
+        ("num_linear_solves", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("initial_cost", C.c_double),
+        ("final_cost", C.c_double),
+        ("fixed_cost", C.c_double),
+        ("total_time_in_seconds", C.c_double),
+        ("device_time_in_seconds", C.c_double),
+        ("time_eval_seconds", C.c_double),
+        ("time_assemble_seconds", C.c_double),
+        ("time_linear_solve_seconds", C.c_double),
+        ("message", C.c_char * 160),
+    ]
+
+
+class Iteration(C.Structure):
+    _fields_ = [
+        ("iteration", C.c_int32),
+        ("step_is_valid", C.c_int32),
+        ("step_is_successful", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("cost", C.c_double),
+        ("cost_change", C.c_double),
+        ("gradient_max_norm", C.c_double),
+        ("gradient_norm", C.c_double),
+        ("step_norm", C.c_double),
+        ("relative_decrease", C.c_double),
+        ("trust_region_radius", C.c_double),
+        ("model_cost_change", C.c_double),
+    ]
+
+
+class Camera(C.Structure):
+    _fields_ = [
+        ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+        ("R_cam_baselink", C.c_double * 9),
+        ("t_cam_baselink", C.c_double * 3),
+    ]
+
+
+#: every symbol include/bsgpu.h declares (without prefix); tests check the library exports them all
+SYMBOLS = [
+    "nidx", "nconst", "nres", "options_default", "options_vio", "create", "create_error", "destroy",
+    "last_error", "abi_version", "clear", "set_blocks", "set_values", "set_cameras", "add_factors",
+    "finalize", "solve", "get_blocks", "reset_values", "num_iterations_recorded", "get_iteration",
+    "evaluate", "num_residuals", "num_parameters_tangent", "tangent_offset", "covariance",
+    "time_reproj_jacobian_ms", "reproj_jacobian_bytes",
+]
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_bp = C.POINTER(C.c_uint8)
+
+
+def _ptr(a, typ):
+    return None if a is None else a.ctypes.data_as(typ)
+
+
+class SolverError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"[{code}] {msg}")
+        self.code = code
+
+
+class Solver:
+    """Thin handle over one context of a library exporting the bsgpu.h entry points."""
+
+    def __init__(self, lib, prefix, device=0):
+        self._lib, self._p = lib, prefix
+        f = self._f
+        f("create").restype = C.c_void_p
+        f("create").argtypes = [C.c_int]
+        f("destroy").argtypes = [C.c_void_p]
+        f("last_error").restype = C.c_char_p
+        f("last_error").argtypes = [C.c_void_p]
+        f("set_blocks").argtypes = [C.c_void_p, C.c_int32, _dp, _ip, _bp, _bp, _bp]
+        f("set_values").argtypes = [C.c_void_p, _dp, C.c_int64]
+        f("set_cameras").argtypes = [C.c_void_p, C.c_int32, C.POINTER(Camera)]
+        f("add_factors").argtypes = [C.c_void_p, C.c_int32, C.c_int32, _ip, _dp, _ip, _dp]
+        f("finalize").argtypes = [C.c_void_p]
+        f("clear").argtypes = [C.c_void_p]
+        f("solve").argtypes = [C.c_void_p, C.POINTER(Options), C.POINTER(Summary)]
+        f("get_blocks").argtypes = [C.c_void_p, _dp, C.c_int64]
+        f("reset_values").argtypes = [C.c_void_p]
+        f("num_iterations_recorded").argtypes = [C.c_void_p]
+        f("get_iteration").argtypes = [C.c_void_p, C.c_int32, C.POINTER(Iteration)]
+        f("evaluate").argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
+        f("num_residuals").argtypes = [C.c_void_p]
+        f("num_parameters_tangent").argtypes = [C.c_void_p]
+        f("tangent_offset").argtypes = [C.c_void_p, C.c_int32]
+        f("covariance").argtypes = [C.c_void_p, C.c_int32, C.c_int32, _dp]
+        f("options_default").argtypes = [C.POINTER(Options)]
+        f("options_vio").argtypes = [C.POINTER(Options)]
+        self._ctx = f("create")(device)
+        if not self._ctx:
+            why = ""
+            try:
+                ce = f("create_error")
+                ce.restype = C.c_char_p
+                why = ce().decode()
+            except AttributeError:
+                pass
+            raise SolverError(ERR_DEVICE, f"{prefix}create({device}) failed: {why}")
+        self._nvalues = 0
+
+    def _f(self, name):
+        return getattr(self._lib, self._p + name)
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise SolverError(rc, self._f("last_error")(self._ctx).decode())
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._f("destroy")(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- options ---------------------------------------------------------------------------
+    def options_default(self):
+        o = Options()
+        self._f("options_default")(C.byref(o))
+        return o
+
+    def options_vio(self):
+        o = Options()
+        self._f("options_vio")(C.byref(o))
+        return o
+
+    # -- problem ---------------------------------------------------------------------------
+    def clear(self):
+        self._chk(self._f("clear")(self._ctx))
+
+    def set_blocks(self, values, offset, size, manifold, is_const):
+        values = np.ascontiguousarray(values, np.float64)
+        offset = np.ascontiguousarray(offset, np.int32)
+        size = np.ascontiguousarray(size, np.uint8)
+        manifold = np.ascontiguousarray(manifold, np.uint8)
+        is_const = np.ascontiguousarray(is_const, np.uint8)
+        self._nvalues = values.size
+        self._chk(self._f("set_blocks")(self._ctx, offset.size, _ptr(values, _dp), _ptr(offset, _ip),
+                                        _ptr(size, _bp), _ptr(manifold, _bp), _ptr(is_const, _bp)))
+
+    def set_values(self, values):
+        values = np.ascontiguousarray(values, np.float64)
+        self._chk(self._f("set_values")(self._ctx, _ptr(values, _dp), values.size))
+
+    def set_cameras(self, cams):
+        arr = (Camera * len(cams))(*cams)
+        self._chk(self._f("set_cameras")(self._ctx, len(cams), arr))
+
+    def add_factors(self, ftype, block_idx, consts, loss_kind=None, loss_a=None):
+        block_idx = np.ascontiguousarray(block_idx, np.int32)
+        consts = np.ascontiguousarray(consts, np.float64)
+        n = block_idx.shape[0] if block_idx.ndim == 2 else 0
+        if loss_kind is not None:
+            loss_kind = np.ascontiguousarray(np.broadcast_to(loss_kind, (n,)), np.int32)
+        if loss_a is not None:
+            loss_a = np.ascontiguousarray(np.broadcast_to(loss_a, (n,)), np.float64)
+        self._chk(self._f("add_factors")(self._ctx, ftype, n, _ptr(block_idx, _ip), _ptr(consts, _dp),
+                                         _ptr(loss_kind, _ip), _ptr(loss_a, _dp)))
+
+    def finalize(self):
+        self._chk(self._f("finalize")(self._ctx))
+
+    # -- solve -----------------------------------------------------------------------------
+    def solve(self, options=None):
+        o = options if options is not None else self.options_default()
+        s = Summary()
+        self._chk(self._f("solve")(self._ctx, C.byref(o), C.byref(s)))
+        return s
+
+    def get_blocks(self):
+        out = np.empty(self._nvalues, np.float64)
+        self._chk(self._f("get_blocks")(self._ctx, _ptr(out, _dp), out.size))
+        return out
+
+    def reset_values(self):
+        self._chk(self._f("reset_values")(self._ctx))
+
+    def iterations(self):
+        n = self._f("num_iterations_recorded")(self._ctx)
+        out = []
+        for i in range(n):
+            it = Iteration()
+            self._chk(self._f("get_iteration")(self._ctx, i, C.byref(it)))
+            out.append(it)
+        return out
+
+    # -- evaluate --------------------------------------------------------------------------
+    def num_residuals(self):
+        return self._f("num_residuals")(self._ctx)
+
+    def num_parameters_tangent(self):
+        return self._f("num_parameters_tangent")(self._ctx)
+
+    def tangent_offset(self, block):
+        return self._f("tangent_offset")(self._ctx, block)
+
+    def evaluate(self, residuals=True, gradient=True, jacobian=False):
+        self.finalize()
+        m, n = self.num_residuals(), self.num_parameters_tangent()
+        cost = C.c_double(0.0)
+        r = np.zeros(m) if residuals else None
+        g = np.zeros(n) if gradient else None
+        J = np.zeros((m, n)) if jacobian else None
+        self._chk(self._f("evaluate")(self._ctx, C.byref(cost), _ptr(r, _dp), _ptr(g, _dp), _ptr(J, _dp)))
+        return cost.value, r, g, J
+
+    def covariance(self, block_a, block_b, ta=3, tb=3):
+        out = np.zeros((ta, tb))
+        self._chk(self._f("covariance")(self._ctx, block_a, block_b, _ptr(out, _dp)))
+        return out

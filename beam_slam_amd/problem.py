@@ -1,0 +1,115 @@
+"""Flat factor-graph IR (the payload of include/bsgpu.h) as numpy arrays.
+
+This is the Python mirror of what ``fuse_graphs::HashGraph::createProblem`` hands to Ceres
+(SURVEY.md Appendix B): a parameter-block table plus per-type factor tables.  It only stores and
+forwards data; all arithmetic happens behind the C-ABI.
+"""
+import numpy as np
+
+from . import capi
+
+NIDX = {capi.F_REPROJ: 4, capi.F_REPROJ_ONLINE_CALIB: 6, capi.F_IMU_DELTA: 10, capi.F_IMU_PRIOR: 5,
+        capi.F_RELPOSE_EXT: 6, capi.F_RELPOSE: 4, capi.F_ABSPOSE: 2, capi.F_ABS_VEC3: 1,
+        capi.F_REL_VEC3: 2, capi.F_GRAVITY: 1}
+NCONST = {capi.F_REPROJ: 3, capi.F_REPROJ_ONLINE_CALIB: 3, capi.F_IMU_DELTA: 287, capi.F_IMU_PRIOR: 241,
+          capi.F_RELPOSE_EXT: 43, capi.F_RELPOSE: 43, capi.F_ABSPOSE: 43, capi.F_ABS_VEC3: 12,
+          capi.F_REL_VEC3: 12, capi.F_GRAVITY: 7}
+NRES = {capi.F_REPROJ: 2, capi.F_REPROJ_ONLINE_CALIB: 2, capi.F_IMU_DELTA: 15, capi.F_IMU_PRIOR: 15,
+        capi.F_RELPOSE_EXT: 6, capi.F_RELPOSE: 6, capi.F_ABSPOSE: 6, capi.F_ABS_VEC3: 3,
+        capi.F_REL_VEC3: 3, capi.F_GRAVITY: 2}
+
+
+class Problem:
+    def __init__(self):
+        self._values = []
+        self.offset, self.size, self.manifold, self.is_const = [], [], [], []
+        self._nvalues = 0
+        self.cameras = []
+        self.factors = {}  # type -> list of (idx, consts, loss_kind, loss_a)
+        self.meta = {}
+
+    # -- blocks ----------------------------------------------------------------------------
+    def add_block(self, values, manifold=capi.MANIFOLD_EUCLIDEAN, const=False):
+        v = np.asarray(values, np.float64).ravel()
+        self.offset.append(self._nvalues)
+        self.size.append(v.size)
+        self.manifold.append(manifold)
+        self.is_const.append(1 if const else 0)
+        self._values.append(v)
+        self._nvalues += v.size
+        return len(self.offset) - 1
+
+    def add_blocks(self, values2d, manifold=capi.MANIFOLD_EUCLIDEAN, const=False):
+        """Adds n blocks of equal size at once; returns their indices."""
+        v = np.ascontiguousarray(values2d, np.float64)
+        n, k = v.shape
+        first = len(self.offset)
+        self.offset.extend((self._nvalues + k * np.arange(n)).tolist())
+        self.size.extend([k] * n)
+        self.manifold.extend([manifold] * n)
+        self.is_const.extend([1 if const else 0] * n)
+        self._values.append(v.ravel())
+        self._nvalues += n * k
+        return np.arange(first, first + n, dtype=np.int32)
+
+    def add_quat(self, q_wxyz, const=False):
+        return self.add_block(q_wxyz, capi.MANIFOLD_QUAT_RIGHT, const)
+
+    @property
+    def values(self):
+        if len(self._values) != 1:
+            self._values = [np.concatenate(self._values) if self._values else np.zeros(0)]
+        return self._values[0]
+
+    @values.setter
+    def values(self, v):
+        v = np.ascontiguousarray(v, np.float64)
+        assert v.size == self._nvalues
+        self._values = [v.copy()]
+
+    @property
+    def n_blocks(self):
+        return len(self.offset)
+
+    def block(self, b, values=None):
+        v = self.values if values is None else values
+        return v[self.offset[b]:self.offset[b] + self.size[b]]
+
+    # -- cameras / factors -----------------------------------------------------------------
+    def add_camera(self, fx, fy, cx, cy, R_cam_baselink, t_cam_baselink):
+        c = capi.Camera()
+        c.fx, c.fy, c.cx, c.cy = fx, fy, cx, cy
+        c.R_cam_baselink[:] = list(np.asarray(R_cam_baselink, float).ravel())
+        c.t_cam_baselink[:] = list(np.asarray(t_cam_baselink, float).ravel())
+        self.cameras.append(c)
+        return len(self.cameras) - 1
+
+    def add_factors(self, ftype, idx, consts, loss_kind=capi.LOSS_TRIVIAL, loss_a=1.0):
+        idx = np.atleast_2d(np.asarray(idx, np.int32))
+        consts = np.atleast_2d(np.asarray(consts, np.float64))
+        assert idx.shape[1] == NIDX[ftype], (idx.shape, NIDX[ftype])
+        assert consts.shape == (idx.shape[0], NCONST[ftype]), (consts.shape, NCONST[ftype])
+        n = idx.shape[0]
+        lk = np.ascontiguousarray(np.broadcast_to(np.asarray(loss_kind, np.int32), (n,)))
+        la = np.ascontiguousarray(np.broadcast_to(np.asarray(loss_a, np.float64), (n,)))
+        self.factors.setdefault(ftype, []).append((idx, consts, lk, la))
+
+    def n_factors(self, ftype=None):
+        if ftype is None:
+            return sum(self.n_factors(t) for t in self.factors)
+        return sum(f[0].shape[0] for f in self.factors.get(ftype, []))
+
+    def n_residuals(self):
+        return sum(self.n_factors(t) * NRES[t] for t in self.factors)
+
+    # -- hand over -------------------------------------------------------------------------
+    def load(self, solver):
+        """Pushes the whole problem through the C-ABI into `solver` (a capi.Solver)."""
+        solver.clear()
+        solver.set_blocks(self.values, self.offset, self.size, self.manifold, self.is_const)
+        if self.cameras:
+            solver.set_cameras(self.cameras)
+        for t in sorted(self.factors):
+            for idx, consts, lk, la in self.factors[t]:
+                solver.add_factors(t, idx, consts, lk, la)
+        return solver

@@ -1,0 +1,322 @@
+/*
+ * bsgpu.h — C-ABI of the MI355X-native fixed-lag-smoother solve path.
+ *
+ * This is the drop-in boundary for the ONE call the reference's optimizer makes
+ * on its hot path:
+ *
+ *     summary_ = graph_->optimize(params_.solver_options);
+ *         (reference: bs_optimizers/src/fixed_lag_smoother.cpp:281, and the ten
+ *          other optimize()/optimizeFor() call sites listed in SURVEY.md §3.4)
+ *
+ * In the reference that call walks a fuse_core::Graph, builds a ceres::Problem
+ * (AddParameterBlock / SetParameterBlockConstant / AddResidualBlock) and runs
+ * ceres::Solve.  Nothing like a C interface exists there (it is C++ virtuals all
+ * the way down), so the entry points below are what a fuse_core::Graph
+ * implementation would bind to hand the flattened problem to the GPU:
+ *
+ *   bsgpu_set_blocks        <- Graph::createProblem: AddParameterBlock(data,size,
+ *                              localParameterization) + SetParameterBlockConstant
+ *                              for holdConstant() variables
+ *   bsgpu_set_cameras       <- the (K, T_cam_baselink) pair every
+ *                              EuclideanReprojectionConstraint carries
+ *                              (bs_constraints/.../euclidean_reprojection_constraint.h:80-84)
+ *   bsgpu_add_factors       <- AddResidualBlock(c.costFunction(), c.lossFunction(), blocks)
+ *   bsgpu_solve             <- ceres::Solve(options, &problem, &summary)
+ *   bsgpu_get_blocks        <- variables updated in place through Variable::data()
+ *   bsgpu_get_iteration     <- summary.iterations[i]
+ *   bsgpu_evaluate          <- ceres::Problem::Evaluate (used by the reference's tests,
+ *                              bs_constraints/tests/euclidean_reprojection_test.cpp:150-180)
+ *   bsgpu_covariance        <- Graph::getCovariance (bs_publishers/src/odometry_3d_publisher.cpp:82)
+ *
+ * Plain C types only: pointers, sizes, POD structs.  Host buffers are
+ * caller-owned and copied on set/add; device memory is owned by the context.
+ * All arithmetic is IEEE double, like the reference.
+ *
+ * Threading: a context is single-caller (the reference holds
+ * optimization_mutex_ around optimize(), fixed_lag_smoother.cpp:185).
+ *
+ * Error model: every call returns BSGPU_OK (0) or a negative code;
+ * bsgpu_last_error() returns a human-readable message for the last failure on
+ * the context.  "NO_CONVERGENCE" is not an error (fixed_lag_smoother.cpp:284-285);
+ * an unusable solution is reported through summary.is_solution_usable == 0 so
+ * the caller can take the reference's fatal path (fixed_lag_smoother.cpp:286-295).
+ */
+#ifndef BSGPU_H_
+#define BSGPU_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BSGPU_ABI_VERSION 1
+
+/* ---- return codes --------------------------------------------------------- */
+enum {
+  BSGPU_OK = 0,
+  BSGPU_ERR_INVALID = -1,     /* bad argument / inconsistent problem          */
+  BSGPU_ERR_DEVICE = -2,      /* HIP runtime failure or no device             */
+  BSGPU_ERR_UNSUPPORTED = -3, /* problem shape the GPU path does not cover    */
+  BSGPU_ERR_NUMERIC = -4      /* non-finite values / fatal linear-solver error */
+};
+
+/* ---- manifold kinds (fuse_core::Variable::localParameterization()) -------- */
+enum {
+  BSGPU_MANIFOLD_EUCLIDEAN = 0, /* nullptr parameterisation                    */
+  BSGPU_MANIFOLD_QUAT_RIGHT = 1 /* fuse_variables::Orientation3DLocalParameterization:
+                                   x (+) d = x (x) AngleAxisToQuaternion(d),
+                                   (w,x,y,z) storage; restated in-tree by
+                                   bs_constraints/src/jacobians.cpp:24-35,144-158 */
+};
+
+/* ---- loss kinds (fuse_core::Loss -> ceres::LossFunction) ------------------ */
+enum {
+  BSGPU_LOSS_TRIVIAL = 0,
+  BSGPU_LOSS_CAUCHY = 1, /* ceres::CauchyLoss(a): rho(s) = a^2 log(1 + s/a^2)  */
+  BSGPU_LOSS_HUBER = 2   /* ceres::HuberLoss(a)                                */
+};
+
+/* ---- factor types ----------------------------------------------------------
+ * For every type: `block_idx` is n x BSGPU_NIDX(type) int32 (row-major) of
+ * indices into the block table, in the constraint's variables() order;
+ * `consts` is n x BSGPU_NCONST(type) doubles (row-major).
+ */
+enum {
+  /* bs_constraints::EuclideanReprojectionConstraint
+   *   (visual/euclidean_reprojection_function.h:28-179, SizedCostFunction<2,4,3,3>)
+   *   idx   : q_WORLD_BASELINK, t_WORLD_BASELINK, P_WORLD, camera-table index
+   *   consts: u, v (pixel), w (sqrt information = w * I2)                      */
+  BSGPU_F_REPROJ = 0,
+  /* bs_constraints::EuclideanReprojectionConstraintOnlineCalib
+   *   (visual/euclidean_reprojection_functor_online_calib.h:16-83, AutoDiff<2,4,3,3,4,3>)
+   *   idx   : q_WB, t_WB, P, q_BASELINK_CAM, p_BASELINK_CAM, camera-table index (K only)
+   *   consts: u, v, w
+   *   The two extrinsic blocks must be constant (bs_variables::Orientation3D /
+   *   Position3D::holdConstant() == true, bs_variables/src/orientation_3d.cpp:39-41). */
+  BSGPU_F_REPROJ_ONLINE_CALIB = 1,
+  /* bs_constraints::RelativeImuState3DStampedConstraint
+   *   (inertial/normal_delta_imu_state_3d_cost_functor.h:18-141, AutoDiff<15, 4,3,3,3,3, 4,3,3,3,3>)
+   *   idx   : (q,p,v,bg,ba)_i, (q,p,v,bg,ba)_j
+   *   consts: dt, dq[4 wxyz], dp[3], dv[3], dq_dbg[9], dp_dbg[9], dp_dba[9],
+   *           dv_dbg[9], dv_dba[9] (3x3 row-major), bg_lin[3], ba_lin[3],
+   *           A[225] (15x15 row-major = info_weight * sqrt_inv_cov)             */
+  BSGPU_F_IMU_DELTA = 2,
+  /* bs_constraints::AbsoluteImuState3DStampedConstraint
+   *   (inertial/normal_prior_imu_state_3d_cost_functor.h:28-90, AutoDiff<15,4,3,3,3,3>)
+   *   idx   : q,p,v,bg,ba        consts: b[16] (q wxyz,p,v,bg,ba), A[225]      */
+  BSGPU_F_IMU_PRIOR = 3,
+  /* bs_constraints::RelativePose3DStampedWithExtrinsicsConstraint
+   *   (relative_pose/delta_pose_3d_with_extrinsics_cost_functor.h:19-109, AutoDiff<6,3,4,3,4,3,4>)
+   *   idx   : p1,q1,p2,q2,p_ext,q_ext   consts: d[7] (x,y,z,qw,qx,qy,qz), A[36] */
+  BSGPU_F_RELPOSE_EXT = 4,
+  /* fuse_constraints::RelativePose3DStampedConstraint (NormalDeltaPose3DCostFunctor)
+   *   idx   : p1,q1,p2,q2        consts: d[7], A[36]                           */
+  BSGPU_F_RELPOSE = 5,
+  /* fuse_constraints::AbsolutePose3DStampedConstraint and
+   * bs_constraints::AbsolutePose3DConstraint (global/absolute_pose_3d_constraint.cpp:12-52)
+   *   idx   : p,q                consts: b[7] (x,y,z,qw,qx,qy,qz), A[36]       */
+  BSGPU_F_ABSPOSE = 6,
+  /* fuse_constraints::AbsoluteConstraint<V> for 3-vectors (global/absolute_constraint.h:10-25)
+   *   idx   : x                  consts: b[3], A[9];  r = A (x - b)             */
+  BSGPU_F_ABS_VEC3 = 7,
+  /* fuse_constraints::RelativeConstraint<V> (relative_pose/relative_constraints.h:12-19)
+   *   idx   : x1,x2              consts: d[3], A[9];  r = A ((x2 - x1) - d)     */
+  BSGPU_F_REL_VEC3 = 8,
+  /* bs_constraints::GravityAlignmentStampedConstraint
+   *   (global/gravity_alignment_cost_functor.h:32-82, AutoDiff<2,4>)
+   *   idx   : q                  consts: g_b[3], A[4] (2x2 row-major)          */
+  BSGPU_F_GRAVITY = 9,
+  BSGPU_F_NUM_TYPES = 10
+};
+
+/* number of int32 per factor in block_idx / doubles per factor in consts /
+ * residual rows, for a type; -1 for an unknown type */
+int bsgpu_nidx(int type);
+int bsgpu_nconst(int type);
+int bsgpu_nres(int type);
+
+/* ---- linear solver choice (ceres::Solver::Options::linear_solver_type) ----- */
+enum {
+  BSGPU_LINEAR_AUTO = 0,         /* exact path whenever the reduced system fits */
+  BSGPU_LINEAR_SCHUR_CHOLESKY = 1, /* landmark Schur complement + dense FP64
+                                      Cholesky of the reduced system: the exact
+                                      (SPARSE_NORMAL_CHOLESKY-equivalent) step   */
+  BSGPU_LINEAR_PCG = 2           /* block-Jacobi PCG on the block-sparse normal
+                                      equations (inexact; pose-graph sized problems) */
+};
+
+/* ---- termination (ceres::TerminationType) ---------------------------------- */
+enum {
+  BSGPU_CONVERGENCE = 0,
+  BSGPU_NO_CONVERGENCE = 1,
+  BSGPU_FAILURE = 2
+};
+
+/* mirrors the ceres::Solver::Options fields the reference sets
+ * (beam_slam_launch/config/vio.yaml:7-17) plus the Ceres defaults it relies on */
+typedef struct bsgpu_options {
+  int32_t max_num_iterations;           /* vio.yaml:13 -> 10; Ceres default 50  */
+  int32_t linear_solver_type;           /* BSGPU_LINEAR_*                       */
+  int32_t jacobi_scaling;               /* Ceres default 1                      */
+  int32_t max_num_consecutive_invalid_steps; /* Ceres default 5                 */
+  double max_solver_time_in_seconds;    /* vio.yaml:14 -> 0.05; <=0 = unlimited */
+  double function_tolerance;            /* vio.yaml:17 -> 1.5e-7; default 1e-6  */
+  double gradient_tolerance;            /* vio.yaml:15 -> 1.5e-7; default 1e-10 */
+  double parameter_tolerance;           /* vio.yaml:16 -> 1.5e-7; default 1e-8  */
+  double initial_trust_region_radius;   /* 1e4                                  */
+  double max_trust_region_radius;       /* 1e16                                 */
+  double min_trust_region_radius;       /* 1e-32                                */
+  double min_relative_decrease;         /* 1e-3                                 */
+  double min_lm_diagonal;               /* 1e-6                                 */
+  double max_lm_diagonal;               /* 1e32                                 */
+  int32_t pcg_max_iterations;           /* BSGPU_LINEAR_PCG only                */
+  int32_t reserved0;
+  double pcg_tolerance;                 /* relative residual                    */
+} bsgpu_options;
+
+/* fills `o` with Ceres' defaults */
+void bsgpu_options_default(bsgpu_options* o);
+/* fills `o` with the solver options the reference ships for VIO
+ * (beam_slam_launch/config/vio.yaml:7-17) */
+void bsgpu_options_vio(bsgpu_options* o);
+
+/* mirrors the ceres::Solver::Summary fields the reference reads back
+ * (fixed_lag_smoother.cpp:286,705-716) */
+typedef struct bsgpu_summary {
+  int32_t termination_type;      /* BSGPU_CONVERGENCE / NO_CONVERGENCE / FAILURE */
+  int32_t is_solution_usable;    /* Summary::IsSolutionUsable()                  */
+  int32_t num_iterations;        /* iterations.size() - 1 (iteration 0 = initial evaluation) */
+  int32_t num_successful_steps;
+  int32_t num_unsuccessful_steps;
+  int32_t num_parameters_tangent; /* columns of the reduced problem              */
+  int32_t num_residuals;
+  int32_t linear_solver_used;    /* BSGPU_LINEAR_*                               */
+  int32_t num_linear_solves;     /* trust-region steps computed (incl. the one a
+                                    parameter/function-tolerance exit does not
+                                    record in `iterations`): the unit of the
+                                    "LM iterations/s" metric                     */
+  int32_t reserved0;
+  double initial_cost;
+  double final_cost;
+  double fixed_cost;             /* cost of residual blocks with only constant blocks */
+  double total_time_in_seconds;  /* wall clock of bsgpu_solve                    */
+  double device_time_in_seconds; /* HIP-event time of the LM loop on the stream  */
+  double time_eval_seconds;      /* host-timed phase splits (sum <= total)       */
+  double time_assemble_seconds;
+  double time_linear_solve_seconds;
+  char message[160];
+} bsgpu_summary;
+
+/* one entry of ceres::Solver::Summary::iterations */
+typedef struct bsgpu_iteration {
+  int32_t iteration;
+  int32_t step_is_valid;
+  int32_t step_is_successful;
+  int32_t reserved0;
+  double cost;
+  double cost_change;
+  double gradient_max_norm;
+  double gradient_norm;
+  double step_norm;
+  double relative_decrease;
+  double trust_region_radius;
+  double model_cost_change;
+} bsgpu_iteration;
+
+/* one camera-table entry: K (skew-free) and T_cam_baselink */
+typedef struct bsgpu_camera {
+  double fx, fy, cx, cy;
+  double R_cam_baselink[9]; /* row-major */
+  double t_cam_baselink[3];
+} bsgpu_camera;
+
+typedef struct bsgpu_ctx bsgpu_ctx;
+
+/* ---- life cycle ------------------------------------------------------------ */
+/* Creates a context on HIP device `device`.  Returns NULL when no HIP device is
+ * usable (there is no CPU fallback); bsgpu_create_error() then says why.       */
+bsgpu_ctx* bsgpu_create(int device);
+const char* bsgpu_create_error(void);
+void bsgpu_destroy(bsgpu_ctx* ctx);
+const char* bsgpu_last_error(const bsgpu_ctx* ctx);
+int bsgpu_abi_version(void);
+
+/* ---- problem definition ---------------------------------------------------- */
+/* Drops blocks, cameras and factors (Graph::clear()). */
+int bsgpu_clear(bsgpu_ctx* ctx);
+
+/* Parameter-block table.  `values` is the concatenation of all blocks' ambient
+ * coordinates; block b occupies values[offset[b] .. offset[b]+size[b]).
+ * manifold[b] in BSGPU_MANIFOLD_*, is_const[b] != 0 <=> SetParameterBlockConstant.
+ * Block order defines the deterministic variable index:
+ * tangent columns are numbered in block order, pose-side blocks first, then the
+ * landmark blocks eliminated by the Schur complement.                           */
+int bsgpu_set_blocks(bsgpu_ctx* ctx, int32_t n_blocks, const double* values,
+                     const int32_t* offset, const uint8_t* size,
+                     const uint8_t* manifold, const uint8_t* is_const);
+
+/* Overwrites the current block values (same layout as bsgpu_set_blocks). */
+int bsgpu_set_values(bsgpu_ctx* ctx, const double* values, int64_t n_values);
+
+int bsgpu_set_cameras(bsgpu_ctx* ctx, int32_t n_cameras, const bsgpu_camera* cams);
+
+/* Appends n factors of one type.  loss_kind / loss_a may be NULL (trivial loss).
+ * Factor order (type-major, then insertion order) defines the residual index.   */
+int bsgpu_add_factors(bsgpu_ctx* ctx, int32_t type, int32_t n,
+                      const int32_t* block_idx, const double* consts,
+                      const int32_t* loss_kind, const double* loss_a);
+
+/* ---- solve ----------------------------------------------------------------- */
+/* Uploads / builds the device-side structure (sorted factor tables, CSR of the
+ * reduced system).  Called implicitly by bsgpu_solve when the problem changed;
+ * exposed so a caller can keep it out of a timed region.                        */
+int bsgpu_finalize(bsgpu_ctx* ctx);
+
+/* Levenberg-Marquardt (Ceres TrustRegionMinimizer semantics) on the device.
+ * On return the best accepted point is the context's current value set.         */
+int bsgpu_solve(bsgpu_ctx* ctx, const bsgpu_options* options, bsgpu_summary* summary);
+
+/* Copies the current values back (device -> host), layout of bsgpu_set_blocks.  */
+int bsgpu_get_blocks(bsgpu_ctx* ctx, double* values, int64_t n_values);
+
+/* Restores the device-resident values to what bsgpu_set_blocks/set_values last
+ * uploaded (device-to-device) — lets a benchmark re-solve the same window
+ * without touching PCIe.                                                        */
+int bsgpu_reset_values(bsgpu_ctx* ctx);
+
+int bsgpu_num_iterations_recorded(const bsgpu_ctx* ctx);
+int bsgpu_get_iteration(const bsgpu_ctx* ctx, int32_t i, bsgpu_iteration* out);
+
+/* ---- evaluation (ceres::Problem::Evaluate) --------------------------------- */
+/* Evaluates at the current values with the robust-loss corrector applied.
+ * Any output may be NULL.
+ *   cost      : 1/2 sum rho(|r|^2)                          (1 double)
+ *   residuals : num_residuals doubles, factor order = type-major insertion order
+ *   gradient  : num_parameters_tangent doubles (J^T r)
+ *   jacobian  : dense row-major num_residuals x num_parameters_tangent (only for
+ *               small problems: refuses above 64M entries)                      */
+int bsgpu_evaluate(bsgpu_ctx* ctx, double* cost, double* residuals,
+                   double* gradient, double* jacobian);
+int bsgpu_num_residuals(const bsgpu_ctx* ctx);
+int bsgpu_num_parameters_tangent(const bsgpu_ctx* ctx);
+/* tangent offset of block b in the reduced problem, -1 for constant blocks */
+int bsgpu_tangent_offset(const bsgpu_ctx* ctx, int32_t block);
+
+/* ---- covariance (Graph::getCovariance) ------------------------------------- */
+/* Marginal covariance block (tangent space) between two pose-side blocks at the
+ * current values: out is ts(block_a) x ts(block_b) row-major.                   */
+int bsgpu_covariance(bsgpu_ctx* ctx, int32_t block_a, int32_t block_b, double* out);
+
+/* ---- measurement helpers (used by bench.py only) --------------------------- */
+/* Launches the Jacobian-evaluation kernel of the reprojection factors `reps`
+ * times on the context's stream between two HIP events and returns the average
+ * milliseconds per launch (<0 on error).                                        */
+double bsgpu_time_reproj_jacobian_ms(bsgpu_ctx* ctx, int32_t reps);
+/* Algorithmic bytes one launch of that kernel moves. */
+int64_t bsgpu_reproj_jacobian_bytes(const bsgpu_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BSGPU_H_ */
