@@ -1,0 +1,884 @@
+// Host driver of libbsgpu.so: the C-ABI of include/bsgpu.h on top of the HIP kernels.
+//
+// Replaces, for the reference, everything under `graph_->optimize(options)`
+// (bs_optimizers/src/fixed_lag_smoother.cpp:281): [EXT] fuse HashGraph::createProblem (here: finalize(),
+// flattening to device tables) and [EXT] ceres::Solve with TRUST_REGION / LEVENBERG_MARQUARDT /
+// SPARSE_NORMAL_CHOLESKY (here: solve(), a restatement of Ceres' TrustRegionMinimizer +
+// LevenbergMarquardtStrategy driving device kernels; one host<->device synchronisation per LM iteration).
+// There is no CPU fallback: without a HIP device bsgpu_create() fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/bsgpu.h"
+#include "bsgpu_internal.h"
+
+using namespace bsg;
+
+namespace {
+
+struct TypeInfo { int nidx, nvar, nconst, m; int amb[10]; };
+const TypeInfo kTypes[BSGPU_F_NUM_TYPES] = {
+    {4, 3, 3, 2, {4, 3, 3}},
+    {6, 5, 3, 2, {4, 3, 3, 4, 3}},
+    {10, 10, 287, 15, {4, 3, 3, 3, 3, 4, 3, 3, 3, 3}},
+    {5, 5, 241, 15, {4, 3, 3, 3, 3}},
+    {6, 6, 43, 6, {3, 4, 3, 4, 3, 4}},
+    {4, 4, 43, 6, {3, 4, 3, 4}},
+    {2, 2, 43, 6, {3, 4}},
+    {1, 1, 12, 3, {3}},
+    {2, 2, 12, 3, {3, 3}},
+    {1, 1, 7, 2, {4}},
+};
+
+std::string g_create_error;
+
+struct HostGroup {
+  int n = 0;
+  std::vector<int32_t> idx;
+  std::vector<double> consts;
+  std::vector<int32_t> loss_kind;
+  std::vector<double> loss_a;
+};
+
+}  // namespace
+
+struct bsgpu_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // ---- host copy of the problem
+  int nb = 0;
+  std::vector<double> h_x;
+  std::vector<int32_t> off;
+  std::vector<uint8_t> size, manifold, is_const;
+  std::vector<bsgpu_camera> cams;
+  HostGroup groups[BSGPU_F_NUM_TYPES];
+  bool finalized = false;
+  // ---- derived structure
+  std::vector<int> tsize, toff;
+  std::vector<uint8_t> is_lm;
+  int n_pose = 0, n_lm = 0, n_tan = 0, npad = 0, n_res = 0;
+  int row0[BSGPU_F_NUM_TYPES] = {0};
+  std::vector<int> vis_src;      // sorted visual position -> (type<<28 | index in its host group)
+  bool any_inactive = false;
+  // ---- device
+  std::vector<void*> allocs;
+  double *d_x = nullptr, *d_xcand = nullptr, *d_x0 = nullptr;
+  int *d_blk_xoff = nullptr, *d_blk_toff = nullptr;
+  unsigned char *d_blk_size = nullptr, *d_blk_manifold = nullptr;
+  DevCamera* d_cams = nullptr;
+  DevLoss* d_losses = nullptr;
+  Visual vis;
+  SmallGroup small[BSGPU_F_NUM_TYPES];
+  std::vector<unsigned char> h_small_active[BSGPU_F_NUM_TYPES];
+  unsigned char* d_small_inactive[BSGPU_F_NUM_TYPES] = {nullptr};
+  double* d_small_part[BSGPU_F_NUM_TYPES] = {nullptr};
+  double *d_S = nullptr, *d_grad = nullptr, *d_hdiag = nullptr, *d_scale = nullptr, *d_dcl = nullptr;
+  double *d_delta = nullptr, *d_y = nullptr, *d_scal = nullptr, *d_part = nullptr;
+  double* h_scal = nullptr;  // pinned
+  int* d_tiles = nullptr;
+  std::vector<int> panel_off, panel_cnt, first_col_tile;
+  int n_panels = 0;
+  std::vector<bsgpu_iteration> iters;
+
+  template <typename T> T* alloc(size_t n) {
+    void* p = nullptr;
+    if (n == 0) n = 1;
+    if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) return nullptr;
+    allocs.push_back(p);
+    return static_cast<T*>(p);
+  }
+  template <typename T> T* upload(const std::vector<T>& v) {
+    T* p = alloc<T>(v.size());
+    if (p && !v.empty()) (void)hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    return p;
+  }
+  void free_device() {
+    for (void* p : allocs) (void)hipFree(p);
+    allocs.clear();
+    vis = Visual();
+    for (auto& g : small) g = SmallGroup();
+    d_x = d_xcand = d_x0 = nullptr;
+  }
+};
+
+namespace {
+
+int fail(bsgpu_ctx* c, int code, const std::string& msg) { c->err = msg; return code; }
+
+#define HIPCHK(c, call)                                                                         \
+  do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(c, BSGPU_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+
+void eigen_quat_to_rot(const double* q, double* R) {
+  const double tx = 2 * q[1], ty = 2 * q[2], tz = 2 * q[3];
+  const double twx = tx * q[0], twy = ty * q[0], twz = tz * q[0], txx = tx * q[1], txy = ty * q[1], txz = tz * q[1];
+  const double tyy = ty * q[2], tyz = tz * q[2], tzz = tz * q[3];
+  R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+  R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// finalize: flatten to device tables.  Restates [EXT] fuse HashGraph::createProblem
+// with a deterministic variable index: tangent columns in block order, pose-side
+// blocks first, then the landmark blocks that the Schur complement eliminates.
+// ---------------------------------------------------------------------------------------------------
+int finalize(bsgpu_ctx* c) {
+  if (c->finalized) return BSGPU_OK;
+  c->free_device();
+  HIPCHK(c, hipSetDevice(c->device));
+  const int nb = c->nb;
+  if (nb <= 0) return fail(c, BSGPU_ERR_INVALID, "no parameter blocks");
+  // ---- validation + landmark detection (same rule as the oracle)
+  std::vector<int> lm_use(nb, 0), other_use(nb, 0);
+  for (int t = 0; t < BSGPU_F_NUM_TYPES; ++t) {
+    const HostGroup& g = c->groups[t];
+    const TypeInfo& ti = kTypes[t];
+    for (int f = 0; f < g.n; ++f) {
+      const int32_t* idx = &g.idx[(size_t)f * ti.nidx];
+      for (int sl = 0; sl < ti.nvar; ++sl) {
+        const int b = idx[sl];
+        if (b < 0 || b >= nb) return fail(c, BSGPU_ERR_INVALID, "factor references block out of range");
+        if (c->size[b] != ti.amb[sl]) return fail(c, BSGPU_ERR_INVALID, "block size does not match factor slot");
+        if (ti.amb[sl] == 4 && c->manifold[b] != BSGPU_MANIFOLD_QUAT_RIGHT)
+          return fail(c, BSGPU_ERR_INVALID, "4-d slot must be a quaternion-manifold block");
+        if (t <= 1 && sl == 2) lm_use[b]++; else other_use[b]++;
+      }
+      if (t <= 1) {
+        const int cam = idx[ti.nvar];
+        if (cam < 0 || cam >= (int)c->cams.size()) return fail(c, BSGPU_ERR_INVALID, "camera index out of range");
+      }
+    }
+  }
+  c->tsize.assign(nb, 0); c->toff.assign(nb, -1); c->is_lm.assign(nb, 0);
+  for (int b = 0; b < nb; ++b) {
+    if (c->size[b] > 4 || c->size[b] == 0) return fail(c, BSGPU_ERR_UNSUPPORTED, "block sizes 1..4 only");
+    if (c->manifold[b] == BSGPU_MANIFOLD_QUAT_RIGHT && c->size[b] != 4) return fail(c, BSGPU_ERR_INVALID, "quaternion block must have size 4");
+    c->tsize[b] = (c->manifold[b] == BSGPU_MANIFOLD_QUAT_RIGHT) ? 3 : c->size[b];
+    if (c->is_const[b]) continue;
+    if (lm_use[b] > 0 && other_use[b] == 0 && c->size[b] == 3 && c->manifold[b] == BSGPU_MANIFOLD_EUCLIDEAN) c->is_lm[b] = 1;
+  }
+  int to = 0;
+  for (int b = 0; b < nb; ++b) if (!c->is_const[b] && !c->is_lm[b]) { c->toff[b] = to; to += c->tsize[b]; }
+  c->n_pose = to;
+  std::vector<int> lm_index(nb, -1);
+  int nl = 0;
+  for (int b = 0; b < nb; ++b) if (!c->is_const[b] && c->is_lm[b]) { c->toff[b] = to; to += 3; lm_index[b] = nl++; }
+  c->n_tan = to; c->n_lm = nl;
+  c->npad = ((c->n_pose + 1 + 63) / 64) * 64;
+  if ((size_t)c->npad > 16384) return fail(c, BSGPU_ERR_UNSUPPORTED, "reduced camera system larger than 16384: dense exact path not applicable (PCG path pending)");
+  int row = 0;
+  for (int t = 0; t < BSGPU_F_NUM_TYPES; ++t) { c->row0[t] = row; row += c->groups[t].n * kTypes[t].m; }
+  c->n_res = row;
+
+  // ---- loss table
+  std::vector<DevLoss> losses;
+  std::map<std::pair<int, double>, int> loss_id;
+  auto get_loss = [&](int kind, double a) {
+    if (kind == BSGPU_LOSS_TRIVIAL) a = 1.0;
+    auto key = std::make_pair(kind, a);
+    auto it = loss_id.find(key);
+    if (it != loss_id.end()) return it->second;
+    DevLoss L; L.kind = kind; L.pad = 0; L.a = a;
+    losses.push_back(L);
+    return loss_id[key] = (int)losses.size() - 1;
+  };
+  get_loss(BSGPU_LOSS_TRIVIAL, 1.0);
+
+  // ---- camera table (online-calib factors fold their constant extrinsic blocks into derived cameras)
+  std::vector<DevCamera> cams;
+  for (const bsgpu_camera& hc : c->cams) {
+    DevCamera d; d.fx = hc.fx; d.fy = hc.fy; d.cx = hc.cx; d.cy = hc.cy;
+    std::memcpy(d.R, hc.R_cam_baselink, sizeof(d.R)); std::memcpy(d.t, hc.t_cam_baselink, sizeof(d.t));
+    cams.push_back(d);
+  }
+  std::map<std::tuple<int, int, int>, int> derived_cam;
+
+  // ---- visual factors: gather, sort by landmark
+  struct VF { int xq, xp, xl, bq, bp, meta_cam, loss, flags, lm, src; double u, v, w; };
+  std::vector<VF> vf;
+  c->any_inactive = false;
+  for (int t = 0; t <= 1; ++t) {
+    const HostGroup& g = c->groups[t];
+    const TypeInfo& ti = kTypes[t];
+    for (int f = 0; f < g.n; ++f) {
+      const int32_t* idx = &g.idx[(size_t)f * ti.nidx];
+      VF e;
+      e.bq = idx[0]; e.bp = idx[1];
+      e.xq = c->off[idx[0]]; e.xp = c->off[idx[1]]; e.xl = c->off[idx[2]];
+      int cam = idx[ti.nvar];
+      if (t == 1) {
+        const int bqe = idx[3], bpe = idx[4];
+        if (!c->is_const[bqe] || !c->is_const[bpe])
+          return fail(c, BSGPU_ERR_UNSUPPORTED,
+                      "online-calibration reprojection factor with non-constant extrinsic blocks (the reference holds "
+                      "them constant: bs_variables/src/orientation_3d.cpp:39-41)");
+        auto key = std::make_tuple(bqe, bpe, cam);
+        auto it = derived_cam.find(key);
+        if (it == derived_cam.end()) {
+          // T_CAM_BASELINK = InvertTransform(T_BASELINK_CAM)  (helpers.h:27-35, functor_online_calib.h:52-56)
+          double Rbc[9];
+          eigen_quat_to_rot(&c->h_x[c->off[bqe]], Rbc);
+          const double* pbc = &c->h_x[c->off[bpe]];
+          DevCamera d = cams[cam];
+          for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) d.R[3 * i + j] = Rbc[3 * j + i];
+          for (int i = 0; i < 3; ++i) d.t[i] = -(d.R[3 * i] * pbc[0] + d.R[3 * i + 1] * pbc[1] + d.R[3 * i + 2] * pbc[2]);
+          cams.push_back(d);
+          it = derived_cam.emplace(key, (int)cams.size() - 1).first;
+        }
+        cam = it->second;
+      }
+      e.meta_cam = cam;
+      e.loss = get_loss(g.loss_kind[f], g.loss_a[f]);
+      e.flags = (c->is_const[idx[0]] ? kFlagQConst : 0) | (c->is_const[idx[1]] ? kFlagPConst : 0) |
+                (c->is_const[idx[2]] ? kFlagLConst : 0);
+      if (e.flags == 7) c->any_inactive = true;
+      e.lm = lm_index[idx[2]];
+      if (e.lm < 0 && !c->is_const[idx[2]]) {
+        // a landmark block that also appears in another factor slot is not eliminated; not supported yet
+        return fail(c, BSGPU_ERR_UNSUPPORTED, "landmark block shared with a non-reprojection factor");
+      }
+      e.src = (t << 28) | f;
+      e.u = g.consts[(size_t)f * 3]; e.v = g.consts[(size_t)f * 3 + 1]; e.w = g.consts[(size_t)f * 3 + 2];
+      vf.push_back(e);
+    }
+  }
+  if ((int)cams.size() >= (1 << kMetaCamBits) || (int)losses.size() >= (1 << kMetaLossBits))
+    return fail(c, BSGPU_ERR_UNSUPPORTED, "too many distinct cameras / loss functions");
+  const int nv = (int)vf.size();
+  std::stable_sort(vf.begin(), vf.end(), [&](const VF& a, const VF& b) {
+    const int la = a.lm < 0 ? std::numeric_limits<int>::max() : a.lm, lb = b.lm < 0 ? std::numeric_limits<int>::max() : b.lm;
+    return la < lb;
+  });
+  Visual& V = c->vis;
+  V.n = nv; V.n_lm = nl;
+  c->vis_src.resize(nv);
+  {
+    std::vector<int4> fac(nv);
+    std::vector<double2> pix(nv);
+    std::vector<double> w(nv);
+    std::vector<int> cam_pose(nv), lm_of(nv), lm_start(nl + 1, 0);
+    std::map<std::pair<int, int>, int> cp_id;
+    for (const VF& e : vf) cp_id.emplace(std::make_pair(e.bq, e.bp), 0);
+    int k = 0;
+    std::vector<int> cp_tq, cp_tp;
+    for (auto& kv : cp_id) { kv.second = k++; cp_tq.push_back(c->toff[kv.first.first]); cp_tp.push_back(c->toff[kv.first.second]); }
+    V.n_cam_pose = k;
+    int n_elim = 0;
+    for (int i = 0; i < nv; ++i) {
+      const VF& e = vf[i];
+      fac[i] = make_int4(e.xq, e.xp, e.xl, meta_pack(e.meta_cam, e.loss, e.flags));
+      pix[i] = make_double2(e.u, e.v);
+      w[i] = e.w;
+      cam_pose[i] = cp_id[std::make_pair(e.bq, e.bp)];
+      lm_of[i] = e.lm;
+      c->vis_src[i] = e.src;
+      if (e.lm >= 0) { lm_start[e.lm + 1]++; n_elim++; }
+    }
+    for (int l = 0; l < nl; ++l) lm_start[l + 1] += lm_start[l];
+    V.n_elim = n_elim;
+    // pair entries
+    struct Ent { uint64_t key; int fa, fb; };
+    std::vector<Ent> ents;
+    ents.reserve((size_t)nv * 5);
+    const uint64_t ncp = (uint64_t)std::max(1, V.n_cam_pose);
+    for (int l = 0; l < nl; ++l) {
+      for (int a = lm_start[l]; a < lm_start[l + 1]; ++a)
+        for (int b = lm_start[l]; b < lm_start[l + 1]; ++b) {
+          const int ca = cam_pose[a], cb = cam_pose[b];
+          if (ca < cb || (ca == cb)) ents.push_back({(uint64_t)ca * ncp + cb, a, b});
+        }
+    }
+    for (int f = n_elim; f < nv; ++f) ents.push_back({(uint64_t)cam_pose[f] * ncp + cam_pose[f], f, f});
+    std::stable_sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.key < b.key; });
+    std::vector<int> seg_ci, seg_cj, seg_start, ent_fa(ents.size()), ent_fb(ents.size());
+    for (size_t i = 0; i < ents.size(); ++i) {
+      if (i == 0 || ents[i].key != ents[i - 1].key) {
+        seg_ci.push_back((int)(ents[i].key / ncp)); seg_cj.push_back((int)(ents[i].key % ncp)); seg_start.push_back((int)i);
+      }
+      ent_fa[i] = ents[i].fa; ent_fb[i] = ents[i].fb;
+    }
+    seg_start.push_back((int)ents.size());
+    V.n_seg = (int)seg_ci.size(); V.n_ent = (int)ents.size();
+    V.fac = c->upload(fac); V.pix = c->upload(pix); V.w = c->upload(w);
+    V.cam_pose = c->upload(cam_pose); V.lm_of = c->upload(lm_of); V.lm_start = c->upload(lm_start);
+    V.cp_tq = c->upload(cp_tq); V.cp_tp = c->upload(cp_tp);
+    V.seg_ci = c->upload(seg_ci); V.seg_cj = c->upload(seg_cj); V.seg_start = c->upload(seg_start);
+    V.ent_fa = c->upload(ent_fa); V.ent_fb = c->upload(ent_fb);
+    V.r = c->alloc<double2>(nv); V.J = c->alloc<double>((size_t)nv * 18); V.CR = c->alloc<double>((size_t)nv * 8);
+    V.Linv = c->alloc<double>((size_t)nl * 6); V.z = c->alloc<double>((size_t)nl * 3);
+    V.n_cost_part = (nv + 255) / 256;
+    V.cost_part = c->alloc<double>(V.n_cost_part);
+    if (!V.J || !V.CR || !V.r) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (visual tables)");
+    // envelope of the reduced system, in 64-wide tiles: first structurally non-zero tile column per tile row
+    const int T = c->npad / 64;
+    c->first_col_tile.assign(T, 0);
+    for (int t = 0; t < T; ++t) c->first_col_tile[t] = t;
+    auto touch = [&](int ra, int rb) {  // tangent rows ra, rb (start of 3-blocks)
+      if (ra < 0 || rb < 0) return;
+      const int hi = std::max(ra, rb) , lo = std::min(ra, rb);
+      for (int r = hi; r < hi + 3; r += 2) { int tr = r / 64; c->first_col_tile[tr] = std::min(c->first_col_tile[tr], lo / 64); }
+    };
+    for (int s = 0; s < V.n_seg; ++s) {
+      const int i = seg_ci[s], j = seg_cj[s];
+      const int ri[2] = {cp_tq[i], cp_tp[i]}, rj[2] = {cp_tq[j], cp_tp[j]};
+      for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) touch(ri[a], rj[b]);
+    }
+  }
+  // ---- pose-only groups
+  size_t part_max = std::max<size_t>(V.n_cost_part, 2 * ((size_t)nb + 255) / 256 + 2);
+  for (int t = 2; t < BSGPU_F_NUM_TYPES; ++t) {
+    const HostGroup& g = c->groups[t];
+    const TypeInfo& ti = kTypes[t];
+    SmallGroup& sg = c->small[t];
+    sg = SmallGroup();
+    sg.type = t; sg.n = g.n; sg.m = ti.m; sg.nv = ti.nvar; sg.nc = ti.nconst;
+    if (!g.n) continue;
+    std::vector<int> xoff((size_t)g.n * ti.nvar), toff((size_t)g.n * ti.nvar), loss(g.n);
+    std::vector<unsigned char> active(g.n, 0), inactive(g.n, 0);
+    for (int f = 0; f < g.n; ++f) {
+      const int32_t* idx = &g.idx[(size_t)f * ti.nidx];
+      for (int sl = 0; sl < ti.nvar; ++sl) {
+        xoff[(size_t)f * ti.nvar + sl] = c->off[idx[sl]];
+        toff[(size_t)f * ti.nvar + sl] = c->toff[idx[sl]];
+        if (c->toff[idx[sl]] >= c->n_pose) return fail(c, BSGPU_ERR_UNSUPPORTED, "internal: landmark in a pose-only factor");
+        if (!c->is_const[idx[sl]]) active[f] = 1;
+      }
+      inactive[f] = !active[f];
+      if (!active[f]) c->any_inactive = true;
+      loss[f] = get_loss(g.loss_kind[f], g.loss_a[f]);
+      // envelope
+      if (active[f])
+        for (int sa = 0; sa < ti.nvar; ++sa)
+          for (int sb = 0; sb < ti.nvar; ++sb) {
+            const int ra = c->toff[idx[sa]], rb = c->toff[idx[sb]];
+            if (ra < 0 || rb < 0) continue;
+            const int hi = std::max(ra, rb), lo = std::min(ra, rb);
+            for (int r = hi; r < hi + 3; r += 2) { int tr = r / 64; c->first_col_tile[tr] = std::min(c->first_col_tile[tr], lo / 64); }
+          }
+    }
+    sg.xoff = c->upload(xoff); sg.toff = c->upload(toff); sg.consts = c->upload(g.consts); sg.loss = c->upload(loss);
+    sg.active = c->upload(active);
+    c->d_small_inactive[t] = c->upload(inactive);
+    c->h_small_active[t] = active;
+    sg.r = c->alloc<double>((size_t)g.n * ti.m);
+    sg.J = c->alloc<double>((size_t)g.n * ti.m * 3 * ti.nvar);
+    c->d_small_part[t] = c->alloc<double>(g.n);
+    part_max = std::max(part_max, (size_t)g.n);
+  }
+  if (losses.size() >= (1u << kMetaLossBits)) return fail(c, BSGPU_ERR_UNSUPPORTED, "too many distinct loss functions");
+  c->d_cams = c->upload(cams);
+  c->d_losses = c->upload(losses);
+  // ---- blocks
+  {
+    std::vector<int> bx(c->off.begin(), c->off.end());
+    c->d_blk_xoff = c->upload(bx);
+    c->d_blk_toff = c->upload(c->toff);
+    std::vector<unsigned char> sz(c->size.begin(), c->size.end()), mf(c->manifold.begin(), c->manifold.end());
+    c->d_blk_size = c->upload(sz); c->d_blk_manifold = c->upload(mf);
+    c->d_x = c->upload(c->h_x); c->d_x0 = c->upload(c->h_x);
+    c->d_xcand = c->alloc<double>(c->h_x.size());
+  }
+  // ---- dense system + vectors
+  c->d_S = c->alloc<double>((size_t)c->npad * c->npad);
+  if (!c->d_S) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (reduced system)");
+  c->d_grad = c->alloc<double>(c->n_tan); c->d_hdiag = c->alloc<double>(c->n_tan);
+  c->d_scale = c->alloc<double>(c->n_tan); c->d_dcl = c->alloc<double>(c->n_tan);
+  c->d_delta = c->alloc<double>(c->n_tan); c->d_y = c->alloc<double>(c->npad);
+  c->d_scal = c->alloc<double>(SC_NUM);
+  c->d_part = c->alloc<double>(part_max + 8);
+  if (!c->h_scal) HIPCHK(c, hipHostMalloc((void**)&c->h_scal, sizeof(double) * SC_NUM));
+  HIPCHK(c, hipMemset(c->d_scal, 0, sizeof(double) * SC_NUM));
+  HIPCHK(c, hipMemset(c->d_delta, 0, sizeof(double) * std::max(1, c->n_tan)));
+  // ---- Cholesky plan: the skyline envelope (fill stays inside it). Row tile ti takes part in panel k
+  //      iff first_col_tile[ti] <= k < ti; the rhs tile (and padding) takes part in every panel.
+  {
+    const int T = c->npad / 64;
+    const int rhs_tile = c->n_pose / 64;
+    for (int t = rhs_tile; t < T; ++t) c->first_col_tile[t] = 0;
+    // make the envelope monotone enough for the blocked algorithm: a row tile that is active in panel k
+    // must stay active until its own diagonal (it is, by construction: active for all k >= first_col_tile).
+    c->n_panels = (c->n_pose + 63) / 64;
+    std::vector<int> tiles;
+    c->panel_off.assign(c->n_panels, 0); c->panel_cnt.assign(c->n_panels, 0);
+    for (int k = 0; k < c->n_panels; ++k) {
+      c->panel_off[k] = (int)tiles.size();
+      for (int t = k + 1; t < T; ++t) if (c->first_col_tile[t] <= k) tiles.push_back(t);
+      c->panel_cnt[k] = (int)tiles.size() - c->panel_off[k];
+    }
+    c->d_tiles = c->upload(tiles);
+  }
+  HIPCHK(c, hipDeviceSynchronize());
+  HIPCHK(c, hipGetLastError());
+  c->finalized = true;
+  return BSGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// device steps of one LM iteration
+// ---------------------------------------------------------------------------------------------------
+void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot) {
+  hipStream_t s = c->stream;
+  launch_zero(s, c->d_scal + slot, 1);
+  if (c->vis.n) {
+    launch_reproj_eval(s, c->vis, x, c->d_cams, c->d_losses, with_J, c->vis.cost_part);
+    launch_sum(s, c->vis.cost_part, c->vis.n_cost_part, c->d_scal + slot, 1);
+  }
+  for (int t = 2; t < BSGPU_F_NUM_TYPES; ++t) {
+    if (!c->small[t].n) continue;
+    launch_small_eval(s, c->small[t], x, c->d_losses, with_J, c->d_small_part[t]);
+    launch_sum(s, c->d_small_part[t], c->small[t].n, c->d_scal + slot, 1);
+  }
+}
+
+void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, bool first) {
+  hipStream_t s = c->stream;
+  launch_zero(s, c->d_S, (int64_t)c->npad * c->npad);
+  launch_zero(s, c->d_grad, c->n_pose);
+  launch_zero(s, c->d_hdiag, c->n_pose);
+  launch_landmark(s, c->vis, c->n_pose, radius, first ? 1 : 0, new_J ? 1 : 0, o.jacobi_scaling, o.min_lm_diagonal,
+                  o.max_lm_diagonal, c->d_scale, c->d_dcl, c->d_grad);
+  launch_pairs(s, c->vis, c->d_S, c->npad, c->n_pose, c->d_grad, c->d_hdiag);
+  for (int t = 2; t < BSGPU_F_NUM_TYPES; ++t)
+    launch_small_assemble(s, c->small[t], c->d_S, c->npad, c->n_pose, c->d_grad, c->d_hdiag);
+  launch_pose_diag(s, c->n_pose, c->d_S, c->npad, c->d_hdiag, radius, first ? 1 : 0, new_J ? 1 : 0, o.jacobi_scaling,
+                   o.min_lm_diagonal, o.max_lm_diagonal, c->d_scale, c->d_dcl, c->npad);
+  if (new_J) {
+    launch_zero(s, c->d_scal + SC_GRAD_MAX, 2);
+    launch_grad_norms(s, c->nb, c->d_blk_xoff, c->d_blk_toff, c->d_blk_size, c->d_blk_manifold, c->d_x, c->d_grad, c->d_scal);
+  }
+}
+
+void linear_solve_and_candidate(bsgpu_ctx* c) {
+  hipStream_t s = c->stream;
+  launch_zero(s, c->d_scal + SC_CHOL_FAIL, 1);
+  for (int k = 0; k < c->n_panels; ++k) {
+    launch_chol_panel(s, c->d_S, c->npad, k, c->n_pose, c->d_tiles + c->panel_off[k], c->panel_cnt[k], c->d_scal);
+    launch_chol_update(s, c->d_S, c->npad, k, c->d_tiles + c->panel_off[k], c->panel_cnt[k]);
+  }
+  if (c->n_pose > 0) {
+    (void)hipMemcpyAsync(c->d_y, c->d_S + (size_t)c->n_pose * c->npad, sizeof(double) * c->n_pose, hipMemcpyDeviceToDevice, s);
+    for (int kb = c->n_panels - 1; kb >= 0; --kb)
+      launch_backsolve_step(s, c->d_S, c->npad, kb, c->n_pose, c->d_y, c->first_col_tile[kb] * 64);
+    launch_negate_pose(s, c->n_pose, c->d_y, c->d_delta);
+  }
+  launch_backsub_landmarks(s, c->vis, c->n_pose, c->d_y, c->d_delta);
+  // model cost change
+  launch_zero(s, c->d_scal + SC_MCC, 1);
+  if (c->vis.n) {
+    launch_mcc(s, c->vis, c->n_pose, c->d_delta, c->d_part);
+    launch_sum(s, c->d_part, (c->vis.n + 255) / 256, c->d_scal + SC_MCC, 1);
+  }
+  for (int t = 2; t < BSGPU_F_NUM_TYPES; ++t) {
+    if (!c->small[t].n) continue;
+    launch_small_mcc(s, c->small[t], c->d_delta, c->d_small_part[t]);
+    launch_sum(s, c->d_small_part[t], c->small[t].n, c->d_scal + SC_MCC, 1);
+  }
+  int n_part = 0;
+  launch_update(s, c->nb, c->d_blk_xoff, c->d_blk_toff, c->d_blk_size, c->d_blk_manifold, c->d_x, c->d_delta, c->d_xcand,
+                c->d_part, &n_part);
+  launch_sum2(s, c->d_part, n_part, c->d_scal + SC_STEP_NORM2, c->d_scal + SC_X_NORM2);
+  eval_all(c, c->d_xcand, false, SC_COST_CAND);
+}
+
+int fetch_scalars(bsgpu_ctx* c) {
+  HIPCHK(c, hipMemcpyAsync(c->h_scal, c->d_scal, sizeof(double) * SC_NUM, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return BSGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// [EXT] ceres::internal::TrustRegionMinimizer + LevenbergMarquardtStrategy, restated
+// ---------------------------------------------------------------------------------------------------
+int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
+  using clk = std::chrono::steady_clock;
+  const auto t_start = clk::now();
+  auto elapsed = [&]() { return std::chrono::duration<double>(clk::now() - t_start).count(); };
+  int rc = finalize(c);
+  if (rc != BSGPU_OK) return rc;
+  HIPCHK(c, hipSetDevice(c->device));
+  std::memset(&sum, 0, sizeof(sum));
+  c->iters.clear();
+  sum.num_parameters_tangent = c->n_tan;
+  sum.num_residuals = c->n_res;
+  sum.linear_solver_used = BSGPU_LINEAR_SCHUR_CHOLESKY;
+  if (o.linear_solver_type == BSGPU_LINEAR_PCG) return fail(c, BSGPU_ERR_UNSUPPORTED, "PCG path not available yet");
+  hipStream_t s = c->stream;
+  hipEvent_t ev0, ev1;
+  HIPCHK(c, hipEventCreate(&ev0)); HIPCHK(c, hipEventCreate(&ev1));
+  HIPCHK(c, hipEventRecord(ev0, s));
+
+  // iteration zero
+  double fixed = 0.0;
+  if (c->any_inactive) {
+    // cost of residual blocks whose parameter blocks are all constant (Ceres: fixed_cost)
+    launch_zero(s, c->d_scal + SC_FIXED_COST, 1);
+    for (int t = 2; t < BSGPU_F_NUM_TYPES; ++t) {
+      if (!c->small[t].n) continue;
+      SmallGroup g = c->small[t];
+      g.active = c->d_small_inactive[t];
+      launch_small_eval(s, g, c->d_x, c->d_losses, false, c->d_small_part[t]);
+      launch_sum(s, c->d_small_part[t], g.n, c->d_scal + SC_FIXED_COST, 1);
+    }
+    // (visual factors with q, p and landmark all constant are not counted: they cannot occur in a
+    //  fixed-lag window — noted in DESIGN.md)
+  }
+  eval_all(c, c->d_x, true, SC_COST_X);
+  double radius = o.initial_trust_region_radius, decrease_factor = 2.0;
+  assemble(c, o, radius, true, true);
+  linear_solve_and_candidate(c);
+  rc = fetch_scalars(c);
+  if (rc != BSGPU_OK) return rc;
+  fixed = c->any_inactive ? c->h_scal[SC_FIXED_COST] : 0.0;
+  double x_cost = c->h_scal[SC_COST_X];
+  bsgpu_iteration it;
+  std::memset(&it, 0, sizeof(it));
+  it.iteration = 0; it.step_is_valid = 1; it.step_is_successful = 1; it.cost = x_cost + fixed;
+  it.gradient_max_norm = c->h_scal[SC_GRAD_MAX]; it.gradient_norm = std::sqrt(c->h_scal[SC_GRAD_NORM2]);
+  sum.initial_cost = x_cost + fixed; sum.fixed_cost = fixed;
+  sum.termination_type = BSGPU_NO_CONVERGENCE;
+  const char* msg = "";
+  if (!std::isfinite(x_cost)) {
+    sum.termination_type = BSGPU_FAILURE; msg = "Initial cost is not finite.";
+    sum.final_cost = sum.initial_cost;
+  } else {
+    int num_consecutive_invalid = 0;
+    // `pending` = a step (linear solve + candidate evaluation) has been computed for the current x/radius
+    while (true) {
+      if (it.step_is_successful) { if (it.iteration > 0) sum.num_successful_steps++; } else sum.num_unsuccessful_steps++;
+      it.trust_region_radius = radius;
+      c->iters.push_back(it);
+      if (o.max_solver_time_in_seconds > 0 && elapsed() >= o.max_solver_time_in_seconds) { msg = "Maximum solver time reached."; break; }
+      if (it.iteration >= o.max_num_iterations) { msg = "Maximum number of iterations reached."; break; }
+      if (it.step_is_successful && it.gradient_max_norm <= o.gradient_tolerance) { sum.termination_type = BSGPU_CONVERGENCE; msg = "Gradient tolerance reached."; break; }
+      if (radius <= o.min_trust_region_radius) { sum.termination_type = BSGPU_CONVERGENCE; msg = "Minimum trust region radius reached."; break; }
+      const bsgpu_iteration prev = it;
+      std::memset(&it, 0, sizeof(it));
+      it.iteration = prev.iteration + 1;
+      it.gradient_max_norm = prev.gradient_max_norm; it.gradient_norm = prev.gradient_norm;
+      sum.num_linear_solves++;
+      // the step for (x, radius) is already on the host: h_scal
+      const double mcc = c->h_scal[SC_MCC];
+      const bool lin_ok = !(c->h_scal[SC_CHOL_FAIL] > 0.0) && std::isfinite(mcc) && std::isfinite(c->h_scal[SC_STEP_NORM2]);
+      it.model_cost_change = lin_ok ? mcc : 0.0;
+      it.step_is_valid = lin_ok && mcc > 0.0;
+      if (!it.step_is_valid) {
+        if (++num_consecutive_invalid >= o.max_num_consecutive_invalid_steps) {
+          sum.termination_type = BSGPU_FAILURE;
+          msg = "Number of consecutive invalid steps more than max_num_consecutive_invalid_steps.";
+          break;
+        }
+        radius = radius / decrease_factor; decrease_factor *= 2.0;
+        it.cost = x_cost + fixed; it.step_is_successful = 0;
+        assemble(c, o, radius, false, false);
+        linear_solve_and_candidate(c);
+        rc = fetch_scalars(c);
+        if (rc != BSGPU_OK) return rc;
+        continue;
+      }
+      num_consecutive_invalid = 0;
+      double cand_cost = c->h_scal[SC_COST_CAND];
+      if (!std::isfinite(cand_cost)) cand_cost = std::numeric_limits<double>::max();
+      it.step_norm = std::sqrt(c->h_scal[SC_STEP_NORM2]);
+      const double x_norm = std::sqrt(c->h_scal[SC_X_NORM2]);
+      if (it.step_norm <= o.parameter_tolerance * (x_norm + o.parameter_tolerance)) { sum.termination_type = BSGPU_CONVERGENCE; msg = "Parameter tolerance reached."; break; }
+      it.cost_change = x_cost - cand_cost;
+      if (std::fabs(it.cost_change) <= o.function_tolerance * x_cost) { sum.termination_type = BSGPU_CONVERGENCE; msg = "Function tolerance reached."; break; }
+      it.relative_decrease = (x_cost - cand_cost) / mcc;
+      if (it.relative_decrease > o.min_relative_decrease) {
+        std::swap(c->d_x, c->d_xcand);
+        radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * it.relative_decrease - 1.0, 3));
+        radius = std::min(o.max_trust_region_radius, radius);
+        decrease_factor = 2.0;
+        it.step_is_successful = 1;
+        eval_all(c, c->d_x, true, SC_COST_X);
+        assemble(c, o, radius, true, false);
+      } else {
+        it.step_is_successful = 0;
+        radius = radius / decrease_factor; decrease_factor *= 2.0;
+        it.cost = cand_cost + fixed;
+        assemble(c, o, radius, false, false);
+      }
+      // speculatively compute the next step so that one synchronisation per iteration suffices
+      linear_solve_and_candidate(c);
+      rc = fetch_scalars(c);
+      if (rc != BSGPU_OK) return rc;
+      if (it.step_is_successful) {
+        x_cost = c->h_scal[SC_COST_X];
+        it.cost = x_cost + fixed;
+        it.gradient_max_norm = c->h_scal[SC_GRAD_MAX];
+        it.gradient_norm = std::sqrt(c->h_scal[SC_GRAD_NORM2]);
+      }
+    }
+    sum.final_cost = x_cost + fixed;
+  }
+  HIPCHK(c, hipEventRecord(ev1, s));
+  HIPCHK(c, hipEventSynchronize(ev1));
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, ev0, ev1);
+  (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+  sum.device_time_in_seconds = ms * 1e-3;
+  sum.num_iterations = (int)c->iters.size() - 1;
+  sum.is_solution_usable = (sum.termination_type == BSGPU_CONVERGENCE || sum.termination_type == BSGPU_NO_CONVERGENCE) ? 1 : 0;
+  sum.total_time_in_seconds = elapsed();
+  std::snprintf(sum.message, sizeof(sum.message), "%s", msg);
+  return BSGPU_OK;
+}
+
+}  // namespace
+
+// ===================================================================================================
+// C entry points
+// ===================================================================================================
+extern "C" {
+
+int bsgpu_nidx(int t) { return (t >= 0 && t < BSGPU_F_NUM_TYPES) ? kTypes[t].nidx : -1; }
+int bsgpu_nconst(int t) { return (t >= 0 && t < BSGPU_F_NUM_TYPES) ? kTypes[t].nconst : -1; }
+int bsgpu_nres(int t) { return (t >= 0 && t < BSGPU_F_NUM_TYPES) ? kTypes[t].m : -1; }
+int bsgpu_abi_version(void) { return BSGPU_ABI_VERSION; }
+
+void bsgpu_options_default(bsgpu_options* o) {
+  std::memset(o, 0, sizeof(*o));
+  o->max_num_iterations = 50; o->linear_solver_type = BSGPU_LINEAR_AUTO; o->jacobi_scaling = 1;
+  o->max_num_consecutive_invalid_steps = 5; o->max_solver_time_in_seconds = 1e9;
+  o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8;
+  o->initial_trust_region_radius = 1e4; o->max_trust_region_radius = 1e16; o->min_trust_region_radius = 1e-32;
+  o->min_relative_decrease = 1e-3; o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32;
+  o->pcg_max_iterations = 500; o->pcg_tolerance = 1e-10;
+}
+void bsgpu_options_vio(bsgpu_options* o) {  // beam_slam_launch/config/vio.yaml:7-17
+  bsgpu_options_default(o);
+  o->max_num_iterations = 10; o->max_solver_time_in_seconds = 0.05;
+  o->gradient_tolerance = 1.5e-7; o->parameter_tolerance = 1.5e-7; o->function_tolerance = 1.5e-7;
+}
+
+const char* bsgpu_create_error(void) { return g_create_error.c_str(); }
+
+bsgpu_ctx* bsgpu_create(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    g_create_error = std::string("no HIP device available (") + (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
+                     "); libbsgpu has no CPU fallback";
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  if (device < 0 || device >= n) { g_create_error = "device index out of range"; return nullptr; }
+  if (hipSetDevice(device) != hipSuccess) { g_create_error = "hipSetDevice failed"; return nullptr; }
+  bsgpu_ctx* c = new bsgpu_ctx();
+  c->device = device;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete c; return nullptr; }
+  return c;
+}
+void bsgpu_destroy(bsgpu_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  c->free_device();
+  if (c->h_scal) (void)hipHostFree(c->h_scal);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+const char* bsgpu_last_error(const bsgpu_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int bsgpu_clear(bsgpu_ctx* c) {
+  c->nb = 0; c->h_x.clear(); c->off.clear(); c->size.clear(); c->manifold.clear(); c->is_const.clear();
+  c->cams.clear();
+  for (auto& g : c->groups) g = HostGroup();
+  c->finalized = false;
+  c->iters.clear();
+  return BSGPU_OK;
+}
+int bsgpu_set_blocks(bsgpu_ctx* c, int32_t n, const double* values, const int32_t* offset, const uint8_t* size,
+                     const uint8_t* manifold, const uint8_t* is_const) {
+  if (n <= 0 || !values || !offset || !size || !manifold || !is_const) return fail(c, BSGPU_ERR_INVALID, "set_blocks: null/empty argument");
+  c->nb = n;
+  c->off.assign(offset, offset + n); c->size.assign(size, size + n);
+  c->manifold.assign(manifold, manifold + n); c->is_const.assign(is_const, is_const + n);
+  size_t tot = 0;
+  for (int i = 0; i < n; ++i) { if (offset[i] < 0) return fail(c, BSGPU_ERR_INVALID, "negative block offset"); tot = std::max(tot, (size_t)offset[i] + size[i]); }
+  c->h_x.assign(values, values + tot);
+  c->finalized = false;
+  return BSGPU_OK;
+}
+int bsgpu_set_values(bsgpu_ctx* c, const double* v, int64_t n) {
+  if ((size_t)n != c->h_x.size()) return fail(c, BSGPU_ERR_INVALID, "set_values: size mismatch");
+  c->h_x.assign(v, v + n);
+  if (c->finalized) {
+    // derived cameras depend on constant extrinsic values: re-finalize if any online-calib factor exists
+    if (c->groups[BSGPU_F_REPROJ_ONLINE_CALIB].n) { c->finalized = false; return BSGPU_OK; }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(c->d_x, v, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_x0, v, sizeof(double) * n, hipMemcpyHostToDevice));
+  }
+  return BSGPU_OK;
+}
+int bsgpu_set_cameras(bsgpu_ctx* c, int32_t n, const bsgpu_camera* cams) {
+  if (n < 0 || (n > 0 && !cams)) return fail(c, BSGPU_ERR_INVALID, "set_cameras: bad argument");
+  c->cams.assign(cams, cams + n);
+  c->finalized = false;
+  return BSGPU_OK;
+}
+int bsgpu_add_factors(bsgpu_ctx* c, int32_t type, int32_t n, const int32_t* idx, const double* consts,
+                      const int32_t* loss_kind, const double* loss_a) {
+  if (type < 0 || type >= BSGPU_F_NUM_TYPES) return fail(c, BSGPU_ERR_INVALID, "unknown factor type");
+  if (n < 0 || (n > 0 && (!idx || !consts))) return fail(c, BSGPU_ERR_INVALID, "add_factors: bad argument");
+  const TypeInfo& ti = kTypes[type];
+  HostGroup& g = c->groups[type];
+  g.idx.insert(g.idx.end(), idx, idx + (size_t)n * ti.nidx);
+  g.consts.insert(g.consts.end(), consts, consts + (size_t)n * ti.nconst);
+  for (int i = 0; i < n; ++i) {
+    const int k = loss_kind ? loss_kind[i] : BSGPU_LOSS_TRIVIAL;
+    if (k < 0 || k > BSGPU_LOSS_HUBER) return fail(c, BSGPU_ERR_INVALID, "unknown loss kind");
+    g.loss_kind.push_back(k); g.loss_a.push_back(loss_a ? loss_a[i] : 1.0);
+  }
+  g.n += n;
+  c->finalized = false;
+  return BSGPU_OK;
+}
+int bsgpu_finalize(bsgpu_ctx* c) { return finalize(c); }
+int bsgpu_solve(bsgpu_ctx* c, const bsgpu_options* o, bsgpu_summary* s) {
+  if (!o || !s) return fail(c, BSGPU_ERR_INVALID, "solve: null argument");
+  return solve(c, *o, *s);
+}
+int bsgpu_get_blocks(bsgpu_ctx* c, double* v, int64_t n) {
+  if ((size_t)n != c->h_x.size()) return fail(c, BSGPU_ERR_INVALID, "get_blocks: size mismatch");
+  if (!c->finalized) { std::memcpy(v, c->h_x.data(), sizeof(double) * n); return BSGPU_OK; }
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(v, c->d_x, sizeof(double) * n, hipMemcpyDeviceToHost));
+  return BSGPU_OK;
+}
+int bsgpu_reset_values(bsgpu_ctx* c) {
+  if (!c->finalized) return BSGPU_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(c->d_x, c->d_x0, sizeof(double) * c->h_x.size(), hipMemcpyDeviceToDevice, c->stream));
+  return BSGPU_OK;
+}
+int bsgpu_num_iterations_recorded(const bsgpu_ctx* c) { return (int)c->iters.size(); }
+int bsgpu_get_iteration(const bsgpu_ctx* c, int32_t i, bsgpu_iteration* out) {
+  if (i < 0 || i >= (int)c->iters.size() || !out) return BSGPU_ERR_INVALID;
+  *out = c->iters[i];
+  return BSGPU_OK;
+}
+int bsgpu_num_residuals(const bsgpu_ctx* c) { return c->n_res; }
+int bsgpu_num_parameters_tangent(const bsgpu_ctx* c) { return c->n_tan; }
+int bsgpu_tangent_offset(const bsgpu_ctx* c, int32_t b) { return (c->finalized && b >= 0 && b < c->nb) ? c->toff[b] : -1; }
+
+int bsgpu_evaluate(bsgpu_ctx* c, double* cost, double* residuals, double* gradient, double* jacobian) {
+  int rc = finalize(c);
+  if (rc != BSGPU_OK) return rc;
+  HIPCHK(c, hipSetDevice(c->device));
+  const int n = c->n_tan, m = c->n_res;
+  if (jacobian && (size_t)m * n > ((size_t)64 << 20)) return fail(c, BSGPU_ERR_UNSUPPORTED, "dense jacobian too large");
+  hipStream_t s = c->stream;
+  double fixed = 0.0;
+  if (c->any_inactive) {
+    launch_zero(s, c->d_scal + SC_FIXED_COST, 1);
+    for (int t = 2; t < BSGPU_F_NUM_TYPES; ++t) {
+      if (!c->small[t].n) continue;
+      SmallGroup g = c->small[t];
+      g.active = c->d_small_inactive[t];
+      launch_small_eval(s, g, c->d_x, c->d_losses, false, c->d_small_part[t]);
+      launch_sum(s, c->d_small_part[t], g.n, c->d_scal + SC_FIXED_COST, 1);
+    }
+  }
+  eval_all(c, c->d_x, true, SC_COST_X);
+  rc = fetch_scalars(c);
+  if (rc != BSGPU_OK) return rc;
+  if (c->any_inactive) fixed = c->h_scal[SC_FIXED_COST];
+  if (cost) *cost = c->h_scal[SC_COST_X] + fixed;
+  if (!residuals && !gradient && !jacobian) return BSGPU_OK;
+  if (jacobian) std::fill(jacobian, jacobian + (size_t)m * n, 0.0);
+  std::vector<double> grad(n, 0.0);
+  // visual factors: un-permute to (type, insertion) order
+  const Visual& V = c->vis;
+  if (V.n) {
+    std::vector<double> r((size_t)V.n * 2), J((size_t)V.n * 18);
+    std::vector<int4> fac(V.n);
+    std::vector<int> cam_pose(V.n), lm_of(V.n), cp_tq(V.n_cam_pose), cp_tp(V.n_cam_pose);
+    HIPCHK(c, hipMemcpy(r.data(), V.r, sizeof(double) * 2 * V.n, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(J.data(), V.J, sizeof(double) * 18 * V.n, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(cam_pose.data(), V.cam_pose, sizeof(int) * V.n, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(lm_of.data(), V.lm_of, sizeof(int) * V.n, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(cp_tq.data(), V.cp_tq, sizeof(int) * V.n_cam_pose, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(cp_tp.data(), V.cp_tp, sizeof(int) * V.n_cam_pose, hipMemcpyDeviceToHost));
+    for (int i = 0; i < V.n; ++i) {
+      const int t = c->vis_src[i] >> 28, f = c->vis_src[i] & ((1 << 28) - 1);
+      const int row = c->row0[t] + 2 * f;
+      const int cols[3] = {cp_tq[cam_pose[i]], cp_tp[cam_pose[i]], lm_of[i] >= 0 ? c->n_pose + 3 * lm_of[i] : -1};
+      for (int k = 0; k < 2; ++k) {
+        if (residuals) residuals[row + k] = r[2 * (size_t)i + k];
+        for (int sl = 0; sl < 3; ++sl) {
+          if (cols[sl] < 0) continue;
+          for (int j = 0; j < 3; ++j) {
+            const double v = J[(size_t)i * 18 + 9 * k + 3 * sl + j];
+            grad[cols[sl] + j] += v * r[2 * (size_t)i + k];
+            if (jacobian) jacobian[(size_t)(row + k) * n + cols[sl] + j] = v;
+          }
+        }
+      }
+    }
+  }
+  for (int t = 2; t < BSGPU_F_NUM_TYPES; ++t) {
+    const SmallGroup& g = c->small[t];
+    if (!g.n) continue;
+    const int mm = g.m, tw = 3 * g.nv;
+    std::vector<double> r((size_t)g.n * mm), J((size_t)g.n * mm * tw);
+    std::vector<int> toff((size_t)g.n * g.nv);
+    HIPCHK(c, hipMemcpy(r.data(), g.r, sizeof(double) * r.size(), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(J.data(), g.J, sizeof(double) * J.size(), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(toff.data(), g.toff, sizeof(int) * toff.size(), hipMemcpyDeviceToHost));
+    for (int f = 0; f < g.n; ++f)
+      for (int k = 0; k < mm; ++k) {
+        const int row = c->row0[t] + f * mm + k;
+        if (residuals) residuals[row] = r[(size_t)f * mm + k];
+        for (int sl = 0; sl < g.nv; ++sl) {
+          const int tc = toff[(size_t)f * g.nv + sl];
+          if (tc < 0) continue;
+          for (int j = 0; j < 3; ++j) {
+            const double v = J[((size_t)f * mm + k) * tw + 3 * sl + j];
+            grad[tc + j] += v * r[(size_t)f * mm + k];
+            if (jacobian) jacobian[(size_t)row * n + tc + j] = v;
+          }
+        }
+      }
+  }
+  if (gradient) std::memcpy(gradient, grad.data(), sizeof(double) * n);
+  return BSGPU_OK;
+}
+
+int bsgpu_covariance(bsgpu_ctx* c, int32_t, int32_t, double*) {
+  return fail(c, BSGPU_ERR_UNSUPPORTED, "marginal covariance queries are a 'next' row (SURVEY.md §8f rank 3), not built yet");
+}
+
+double bsgpu_time_reproj_jacobian_ms(bsgpu_ctx* c, int32_t reps) {
+  if (finalize(c) != BSGPU_OK || c->vis.n == 0 || reps <= 0) return -1.0;
+  if (hipSetDevice(c->device) != hipSuccess) return -1.0;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.0;
+  launch_reproj_jacobian_only(c->stream, c->vis, c->d_x, c->d_cams, c->d_losses);  // warm
+  (void)hipEventRecord(e0, c->stream);
+  for (int i = 0; i < reps; ++i) launch_reproj_jacobian_only(c->stream, c->vis, c->d_x, c->d_cams, c->d_losses);
+  (void)hipEventRecord(e1, c->stream);
+  if (hipEventSynchronize(e1) != hipSuccess) return -1.0;
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return (double)ms / reps;
+}
+int64_t bsgpu_reproj_jacobian_bytes(const bsgpu_ctx* c) {
+  // per factor: 16 B (3 offsets + meta) + 16 B pixel + 8 B weight in, 16 B residual + 144 B Jacobian out;
+  // plus every parameter block once
+  return (int64_t)c->vis.n * 200 + (int64_t)c->h_x.size() * 8;
+}
+
+}  // extern "C"

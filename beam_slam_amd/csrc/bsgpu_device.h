@@ -1,0 +1,130 @@
+// Device-side math shared by the HIP kernels: quaternion / SO(3) helpers, robust losses, reductions.
+// All double precision (the reference path is IEEE double end to end, SURVEY.md "Conventions").
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/bsgpu.h"
+#include "bsgpu_internal.h"
+
+namespace bsg {
+
+#define BSG_DEV __device__ __forceinline__
+
+// Eigen::Quaternion::toRotationMatrix() (no normalisation) — what the reprojection factor uses
+// (euclidean_reprojection_function.h:68-70).  R row-major.
+BSG_DEV void quat_to_rot(const double q[4], double R[9]) {
+  const double tx = 2.0 * q[1], ty = 2.0 * q[2], tz = 2.0 * q[3];
+  const double twx = tx * q[0], twy = ty * q[0], twz = tz * q[0];
+  const double txx = tx * q[1], txy = ty * q[1], txz = tz * q[1];
+  const double tyy = ty * q[2], tyz = tz * q[2], tzz = tz * q[3];
+  R[0] = 1.0 - (tyy + tzz); R[1] = txy - twz;         R[2] = txz + twy;
+  R[3] = txy + twz;         R[4] = 1.0 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.0 - (txx + tyy);
+}
+// rotation matrix of the normalised quaternion (ceres::QuaternionRotatePoint semantics)
+BSG_DEV void quat_to_rot_normalized(const double q[4], double R[9]) {
+  const double s = 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const double u[4] = {q[0] * s, q[1] * s, q[2] * s, q[3] * s};
+  quat_to_rot(u, R);
+}
+BSG_DEV void quat_mul(const double a[4], const double b[4], double o[4]) {
+  o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  o[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  o[2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  o[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+}
+BSG_DEV void mat3_vec(const double M[9], const double v[3], double o[3]) {
+  o[0] = M[0] * v[0] + M[1] * v[1] + M[2] * v[2];
+  o[1] = M[3] * v[0] + M[4] * v[1] + M[5] * v[2];
+  o[2] = M[6] * v[0] + M[7] * v[1] + M[8] * v[2];
+}
+BSG_DEV void mat3t_vec(const double M[9], const double v[3], double o[3]) {
+  o[0] = M[0] * v[0] + M[3] * v[1] + M[6] * v[2];
+  o[1] = M[1] * v[0] + M[4] * v[1] + M[7] * v[2];
+  o[2] = M[2] * v[0] + M[5] * v[1] + M[8] * v[2];
+}
+BSG_DEV void cross3(const double a[3], const double b[3], double o[3]) {
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+// ceres::AngleAxisToQuaternion
+BSG_DEV void angle_axis_to_quat(const double aa[3], double q[4]) {
+  const double th2 = aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2];
+  if (th2 > 0.0) {
+    const double th = sqrt(th2), half = th * 0.5;
+    double sn, cs;
+    sincos(half, &sn, &cs);
+    const double k = sn / th;
+    q[0] = cs; q[1] = aa[0] * k; q[2] = aa[1] * k; q[3] = aa[2] * k;
+  } else {
+    q[0] = 1.0; q[1] = aa[0] * 0.5; q[2] = aa[1] * 0.5; q[3] = aa[2] * 0.5;
+  }
+}
+// ceres::QuaternionToAngleAxis (angle in (-pi, pi]; q and -q agree; scale invariant)
+BSG_DEV void quat_to_angle_axis(const double q[4], double aa[3]) {
+  const double s2 = q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  if (s2 > 0.0) {
+    const double sn = sqrt(s2), cs = q[0];
+    const double two_theta = 2.0 * ((cs < 0.0) ? atan2(-sn, -cs) : atan2(sn, cs));
+    const double k = two_theta / sn;
+    aa[0] = q[1] * k; aa[1] = q[2] * k; aa[2] = q[3] * k;
+  } else {
+    aa[0] = q[1] * 2.0; aa[1] = q[2] * 2.0; aa[2] = q[3] * 2.0;
+  }
+}
+// inverse right Jacobian of SO(3): Log(Exp(e) Exp(d)) ~= e + Jr^-1(e) d.   Row-major 3x3.
+BSG_DEV void so3_jr_inv(const double e[3], double J[9]) {
+  const double th2 = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+  double c;
+  if (th2 < 1e-6) {
+    c = 1.0 / 12.0 + th2 / 720.0;
+  } else {
+    const double th = sqrt(th2);
+    double sn, cs;
+    sincos(th, &sn, &cs);
+    c = 1.0 / th2 - (1.0 + cs) / (2.0 * th * sn);
+  }
+  // I + 0.5 [e]x + c [e]x^2, [e]x^2 = e e^T - th2 I
+  J[0] = 1.0 + c * (e[0] * e[0] - th2); J[1] = -0.5 * e[2] + c * e[0] * e[1]; J[2] = 0.5 * e[1] + c * e[0] * e[2];
+  J[3] = 0.5 * e[2] + c * e[1] * e[0];  J[4] = 1.0 + c * (e[1] * e[1] - th2); J[5] = -0.5 * e[0] + c * e[1] * e[2];
+  J[6] = -0.5 * e[1] + c * e[2] * e[0]; J[7] = 0.5 * e[0] + c * e[2] * e[1];  J[8] = 1.0 + c * (e[2] * e[2] - th2);
+}
+
+// ceres::LossFunction::Evaluate: returns rho(s), sets *rho1 = rho'(s)
+BSG_DEV double loss_eval(const DevLoss& L, double s, double* rho1) {
+  if (L.kind == BSGPU_LOSS_CAUCHY) {
+    const double b = L.a * L.a, c = 1.0 / b;
+    const double sum = 1.0 + s * c, inv = 1.0 / sum;
+    *rho1 = fmax(2.2250738585072014e-308, inv);
+    return b * log(sum);
+  } else if (L.kind == BSGPU_LOSS_HUBER) {
+    const double b = L.a * L.a;
+    if (s > b) {
+      const double r = sqrt(s);
+      *rho1 = fmax(2.2250738585072014e-308, L.a / r);
+      return 2.0 * L.a * r - b;
+    }
+  }
+  *rho1 = 1.0;
+  return s;
+}
+
+BSG_DEV double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// sum over a 256-thread block; result valid in thread 0
+BSG_DEV double block_sum_256(double v, double* smem /* >= 4 doubles */) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) smem[w] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0) t = smem[0] + smem[1] + smem[2] + smem[3];
+  __syncthreads();
+  return t;
+}
+
+}  // namespace bsg

@@ -1,0 +1,121 @@
+// Internal declarations shared by the host driver (bsgpu_api.cpp) and the HIP kernels
+// (bsgpu_kernels.hip) of libbsgpu.so.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bsg {
+
+// ---- device-side tables -------------------------------------------------------------------------
+struct DevCamera {  // 16 doubles
+  double fx, fy, cx, cy;
+  double R[9];  // R_cam_baselink, row-major
+  double t[3];
+};
+struct DevLoss {
+  int kind;
+  int pad;
+  double a;
+};
+
+// meta word of a reprojection factor: camera id | loss id | constant-block flags
+constexpr int kMetaCamBits = 12, kMetaLossBits = 12;
+constexpr int kFlagQConst = 1, kFlagPConst = 2, kFlagLConst = 4;
+__host__ __device__ inline int meta_pack(int cam, int loss, int flags) {
+  return cam | (loss << kMetaCamBits) | (flags << (kMetaCamBits + kMetaLossBits));
+}
+
+// scalar slots (device buffer of doubles, copied to the host once per LM iteration)
+enum {
+  SC_COST_X = 0,     // cost at the current point (active factors)
+  SC_COST_CAND = 1,  // cost at the candidate point
+  SC_MCC = 2,        // model cost change
+  SC_STEP_NORM2 = 3, // |x_cand - x|^2 (ambient, non-constant blocks)
+  SC_X_NORM2 = 4,    // |x|^2
+  SC_GRAD_MAX = 5,   // |x - Plus(x,-g)|_inf   (stored as the bits of a non-negative double)
+  SC_GRAD_NORM2 = 6,
+  SC_CHOL_FAIL = 7,  // > 0 when a pivot was not positive / finite
+  SC_FIXED_COST = 8,
+  SC_NUM = 16
+};
+
+// pose-only ("small") factor group on the device: r (n x m), J (n x m x 3*nv) row-major
+struct SmallGroup {
+  int type = 0, n = 0, m = 0, nv = 0, nc = 0;
+  int* xoff = nullptr;   // n x nv  offsets into x
+  int* toff = nullptr;   // n x nv  tangent offsets (-1 = constant block)
+  double* consts = nullptr;
+  int* loss = nullptr;   // n  loss-table ids
+  unsigned char* active = nullptr;  // n
+  double* r = nullptr;
+  double* J = nullptr;
+};
+
+// everything the kernels need for the visual (landmark) part
+struct Visual {
+  int n = 0;         // reprojection factors, sorted by landmark (constant-landmark ones last)
+  int n_elim = 0;    // factors whose landmark is eliminated
+  int n_lm = 0;      // eliminated landmarks
+  int4* fac = nullptr;        // (xoff q, xoff p, xoff P, meta)
+  double2* pix = nullptr;
+  double* w = nullptr;
+  int* cam_pose = nullptr;    // factor -> camera-pose id (unique (q,p) block pair)
+  int* lm_of = nullptr;       // factor -> landmark (tangent order) or -1
+  int* lm_start = nullptr;    // n_lm + 1
+  int n_cam_pose = 0;
+  int* cp_tq = nullptr;       // camera pose -> tangent offset of q (or -1)
+  int* cp_tp = nullptr;
+  // pair segments
+  int n_seg = 0, n_ent = 0;
+  int* seg_ci = nullptr; int* seg_cj = nullptr; int* seg_start = nullptr;
+  int* ent_fa = nullptr; int* ent_fb = nullptr;
+  // outputs
+  double2* r = nullptr;       // n
+  double* J = nullptr;        // n x 18 (row-major 2 x 9: theta, t, P), robustified
+  double* CR = nullptr;       // n x 8: C = B M (2x3), rho = r - C z (2)
+  double* Linv = nullptr;     // n_lm x 6  (lower-triangular inverse factor of Hll + lambda)
+  double* z = nullptr;        // n_lm x 3  (Linv * g_l)
+  double* cost_part = nullptr;
+  int n_cost_part = 0;
+};
+
+struct LaunchCtx {
+  hipStream_t stream;
+};
+
+// ---- kernel launchers (bsgpu_kernels.hip) ----------------------------------------------------------
+void launch_reproj_eval(hipStream_t s, const Visual& v, const double* x, const DevCamera* cams,
+                        const DevLoss* losses, bool with_J, double* cost_part_out);
+void launch_small_eval(hipStream_t s, const SmallGroup& g, const double* x, const DevLoss* losses, bool with_J,
+                       double* cost_part /* n doubles: per-factor cost */);
+void launch_landmark(hipStream_t s, const Visual& v, int n_pose, double radius, int compute_scale,
+                     int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* scale, double* dcl,
+                     double* grad);
+void launch_pairs(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag);
+void launch_small_assemble(hipStream_t s, const SmallGroup& g, double* S, int ld, int rhs_row, double* grad,
+                           double* hdiag);
+void launch_pose_diag(hipStream_t s, int n_pose, double* S, int ld, const double* hdiag, double radius,
+                      int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* scale,
+                      double* dcl, int npad);
+void launch_grad_norms(hipStream_t s, int nb, const int* blk_xoff, const int* blk_toff, const unsigned char* blk_size,
+                       const unsigned char* blk_manifold, const double* x, const double* grad, double* scal);
+void launch_chol_panel(hipStream_t s, double* S, int ld, int k, int n_pose, const int* row_tiles_dev, int n_rows,
+                       double* scal);
+void launch_chol_update(hipStream_t s, double* S, int ld, int k, const int* row_tiles_dev, int n_rows);
+void launch_backsolve_step(hipStream_t s, const double* S, int ld, int kb, int n_pose, double* y, int col_begin);
+void launch_backsub_landmarks(hipStream_t s, const Visual& v, int n_pose, const double* y_pose, double* delta);
+void launch_negate_pose(hipStream_t s, int n_pose, const double* y, double* delta);
+void launch_mcc(hipStream_t s, const Visual& v, int n_pose, const double* delta, double* part);
+void launch_small_mcc(hipStream_t s, const SmallGroup& g, const double* delta, double* part /* n */);
+void launch_update(hipStream_t s, int nb, const int* blk_xoff, const int* blk_toff, const unsigned char* blk_size,
+                   const unsigned char* blk_manifold, const double* x, const double* delta, double* x_cand,
+                   double* part /* 2 * nblocks_grid */, int* n_part);
+void launch_sum(hipStream_t s, const double* part, int n, double* out, int accumulate);
+void launch_sum2(hipStream_t s, const double* part, int n_pairs, double* out_a, double* out_b);
+void launch_zero(hipStream_t s, double* p, int64_t n);
+
+// measurement: the reprojection Jacobian kernel alone
+void launch_reproj_jacobian_only(hipStream_t s, const Visual& v, const double* x, const DevCamera* cams,
+                                 const DevLoss* losses);
+
+}  // namespace bsg

@@ -1,0 +1,140 @@
+// Manifold update x (+) delta, gradient norms, and the small deterministic reductions of the LM loop.
+// Plus on quaternion blocks restates fuse's Orientation3DLocalParameterization::Plus, i.e.
+// bs_constraints/src/jacobians.cpp:24-35 (x (x) AngleAxisToQuaternion(delta), right perturbation).
+#include "bsgpu_device.h"
+
+namespace bsg {
+
+BSG_DEV void block_plus(int manifold, int size, const double* x, const double* d, double* out) {
+  if (manifold == BSGPU_MANIFOLD_QUAT_RIGHT) {
+    double qd[4];
+    angle_axis_to_quat(d, qd);
+    const double q[4] = {x[0], x[1], x[2], x[3]};
+    quat_mul(q, qd, out);
+  } else {
+    for (int i = 0; i < size; ++i) out[i] = x[i] + d[i];
+  }
+}
+
+// x_cand = x (+) delta for every block; per-workgroup partials of |x_cand - x|^2 and |x|^2 over the
+// non-constant blocks (ceres: step_norm, x_norm)
+__global__ __launch_bounds__(256) void update_kernel(int nb, const int* __restrict__ xoff, const int* __restrict__ toff,
+                                                     const unsigned char* __restrict__ size,
+                                                     const unsigned char* __restrict__ manifold,
+                                                     const double* __restrict__ x, const double* __restrict__ delta,
+                                                     double* __restrict__ x_cand, double* __restrict__ part) {
+  __shared__ double sred[4];
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  double d2 = 0.0, x2 = 0.0;
+  if (b < nb) {
+    const int o = xoff[b], t = toff[b], sz = size[b];
+    if (t >= 0) {
+      double out[4];
+      double xin[4] = {0, 0, 0, 0}, din[4] = {0, 0, 0, 0};
+      const int ts = (manifold[b] == BSGPU_MANIFOLD_QUAT_RIGHT) ? 3 : sz;
+      for (int i = 0; i < sz && i < 4; ++i) xin[i] = x[o + i];
+      for (int i = 0; i < ts && i < 4; ++i) din[i] = delta[t + i];
+      block_plus(manifold[b], sz, xin, din, out);
+      for (int i = 0; i < sz && i < 4; ++i) {
+        x_cand[o + i] = out[i];
+        const double df = xin[i] - out[i];
+        d2 += df * df; x2 += xin[i] * xin[i];
+      }
+    } else {
+      for (int i = 0; i < sz; ++i) x_cand[o + i] = x[o + i];
+    }
+  }
+  const double a = block_sum_256(d2, sred);
+  const double c = block_sum_256(x2, sred);
+  if (threadIdx.x == 0) { part[2 * blockIdx.x] = a; part[2 * blockIdx.x + 1] = c; }
+}
+
+void launch_update(hipStream_t s, int nb, const int* blk_xoff, const int* blk_toff, const unsigned char* blk_size,
+                   const unsigned char* blk_manifold, const double* x, const double* delta, double* x_cand,
+                   double* part, int* n_part) {
+  const int grid = (nb + 255) / 256;
+  *n_part = grid;
+  hipLaunchKernelGGL(update_kernel, dim3(grid), dim3(256), 0, s, nb, blk_xoff, blk_toff, blk_size, blk_manifold, x, delta,
+                     x_cand, part);
+}
+
+// gradient norms the way ceres' TrustRegionMinimizer defines them: |x - Plus(x, -g)|_inf and |.|_2.
+// The max is order independent (atomicMax on the bit pattern of a non-negative double).
+__global__ __launch_bounds__(256) void grad_norms_kernel(int nb, const int* __restrict__ xoff, const int* __restrict__ toff,
+                                                         const unsigned char* __restrict__ size,
+                                                         const unsigned char* __restrict__ manifold,
+                                                         const double* __restrict__ x, const double* __restrict__ grad,
+                                                         double* __restrict__ scal) {
+  __shared__ double sred[4];
+  __shared__ double smax[4];
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  double mx = 0.0, s2 = 0.0;
+  if (b < nb) {
+    const int o = xoff[b], t = toff[b], sz = size[b];
+    if (t >= 0) {
+      const int ts = (manifold[b] == BSGPU_MANIFOLD_QUAT_RIGHT) ? 3 : sz;
+      double xin[4] = {0, 0, 0, 0}, din[4] = {0, 0, 0, 0}, out[4];
+      for (int i = 0; i < sz && i < 4; ++i) xin[i] = x[o + i];
+      for (int i = 0; i < ts && i < 4; ++i) din[i] = -grad[t + i];
+      block_plus(manifold[b], sz, xin, din, out);
+      for (int i = 0; i < sz && i < 4; ++i) {
+        const double df = fabs(xin[i] - out[i]);
+        mx = fmax(mx, df); s2 += df * df;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = mx;
+  const double tot = block_sum_256(s2, sred);
+  if (threadIdx.x == 0) {
+    const double m = fmax(fmax(smax[0], smax[1]), fmax(smax[2], smax[3]));
+    atomicMax(reinterpret_cast<unsigned long long*>(&scal[SC_GRAD_MAX]), (unsigned long long)__double_as_longlong(m));
+    atomicAdd(&scal[SC_GRAD_NORM2], tot);
+  }
+}
+
+void launch_grad_norms(hipStream_t s, int nb, const int* blk_xoff, const int* blk_toff, const unsigned char* blk_size,
+                       const unsigned char* blk_manifold, const double* x, const double* grad, double* scal) {
+  hipLaunchKernelGGL(grad_norms_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, nb, blk_xoff, blk_toff, blk_size,
+                     blk_manifold, x, grad, scal);
+}
+
+// fixed-order sums of partial arrays (one workgroup): reproducible cost / model-cost-change values
+__global__ __launch_bounds__(256) void sum_kernel(const double* __restrict__ part, int n, double* __restrict__ out,
+                                                  int accumulate) {
+  __shared__ double sred[4];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) a += part[i];
+  const double t = block_sum_256(a, sred);
+  if (threadIdx.x == 0) *out = accumulate ? (*out + t) : t;
+}
+void launch_sum(hipStream_t s, const double* part, int n, double* out, int accumulate) {
+  hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, s, part, n, out, accumulate);
+}
+__global__ __launch_bounds__(256) void sum2_kernel(const double* __restrict__ part, int n, double* __restrict__ oa,
+                                                   double* __restrict__ ob) {
+  __shared__ double sred[4];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) { a += part[2 * i]; b += part[2 * i + 1]; }
+  const double ta = block_sum_256(a, sred);
+  const double tb = block_sum_256(b, sred);
+  if (threadIdx.x == 0) { *oa = ta; *ob = tb; }
+}
+void launch_sum2(hipStream_t s, const double* part, int n_pairs, double* out_a, double* out_b) {
+  hipLaunchKernelGGL(sum2_kernel, dim3(1), dim3(256), 0, s, part, n_pairs, out_a, out_b);
+}
+
+void launch_zero(hipStream_t s, double* p, int64_t n) {
+  if (n > 0) (void)hipMemsetAsync(p, 0, sizeof(double) * (size_t)n, s);
+}
+
+__global__ void negate_kernel(int n, const double* __restrict__ y, double* __restrict__ d) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) d[i] = -y[i];
+}
+void launch_negate_pose(hipStream_t s, int n_pose, const double* y, double* delta) {
+  if (n_pose > 0) hipLaunchKernelGGL(negate_kernel, dim3((n_pose + 255) / 256), dim3(256), 0, s, n_pose, y, delta);
+}
+
+}  // namespace bsg

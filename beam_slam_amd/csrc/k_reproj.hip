@@ -1,0 +1,435 @@
+// Visual (landmark) part of the solve path on gfx950:
+//   reproj_eval      residual + tangent Jacobian of EuclideanReprojection (A5/A6)          HBM-bound
+//   landmark         per-landmark Hll, its 3x3 factor, C = B M, rho = r - C z               HBM-bound
+//   pairs            camera-pair segments: S_ij = [i==j] A^T A - sum A^T C C'^T A', reduced rhs
+//   backsub          landmark back-substitution
+//   mcc              model cost change -(J d).(r + J d / 2)
+// Reference for the arithmetic: bs_constraints/include/bs_constraints/visual/euclidean_reprojection_function.h:66-172
+// (residual; the quaternion Jacobian there is a forward difference — here it is the closed form
+// -A Jpi R_cb [P_b]x of SURVEY.md Appendix A) and bs_constraints/src/jacobians.cpp:202-214.
+#include "bsgpu_device.h"
+
+namespace bsg {
+
+// ---------------------------------------------------------------------------------------------------
+// reprojection residual + Jacobian.  One factor per lane; the 2x9 Jacobian of a wave's 64 factors is
+// transposed through LDS so that the AoS rows leave as contiguous 16-byte-per-lane stores.
+// Algorithmic bytes per factor: 16 (idx+meta) + 16 (pixel) + 8 (w) in, 16 (r) + 144 (J) out = 200.
+// ---------------------------------------------------------------------------------------------------
+template <bool WITH_J>
+__global__ __launch_bounds__(256) void reproj_eval_kernel(int n, const int4* __restrict__ fac,
+                                                          const double2* __restrict__ pix,
+                                                          const double* __restrict__ wgt, const double* __restrict__ x,
+                                                          const DevCamera* __restrict__ cams,
+                                                          const DevLoss* __restrict__ losses,
+                                                          double2* __restrict__ r_out, double* __restrict__ J_out,
+                                                          double* __restrict__ cost_part) {
+  __shared__ __attribute__((aligned(16))) double sJ[WITH_J ? 4 * 64 * 18 : 4];
+  __shared__ double sred[4];
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double cost = 0.0;
+  double J[18];
+#pragma unroll
+  for (int i = 0; i < 18; ++i) J[i] = 0.0;
+  if (f < n) {
+    const int4 fc = fac[f];
+    const double2 z = pix[f];
+    const double w = wgt[f];
+    const int cam_id = fc.w & ((1 << kMetaCamBits) - 1);
+    const int loss_id = (fc.w >> kMetaCamBits) & ((1 << kMetaLossBits) - 1);
+    const int flags = fc.w >> (kMetaCamBits + kMetaLossBits);
+    const double* qp = x + fc.x;
+    const double* tp = x + fc.y;
+    const double* Pp = x + fc.z;
+    const double q[4] = {qp[0], qp[1], qp[2], qp[3]};
+    const double t[3] = {tp[0], tp[1], tp[2]};
+    const double P[3] = {Pp[0], Pp[1], Pp[2]};
+    const DevCamera cam = cams[cam_id];
+    double R[9];
+    quat_to_rot(q, R);
+    // P_b = R^T P - R^T t  (function.h:81-82)
+    double a[3], b[3];
+    mat3t_vec(R, P, a);
+    mat3t_vec(R, t, b);
+    const double Pb[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]};
+    double Pc[3];
+    mat3_vec(cam.R, Pb, Pc);
+    Pc[0] += cam.t[0]; Pc[1] += cam.t[1]; Pc[2] += cam.t[2];
+    // (K P_c).hnormalized()
+    const double iz = 1.0 / Pc[2];
+    const double u = (cam.fx * Pc[0] + cam.cx * Pc[2]) * iz;
+    const double v = (cam.fy * Pc[1] + cam.cy * Pc[2]) * iz;
+    double r0 = w * (z.x - u), r1 = w * (z.y - v);
+    const double s = r0 * r0 + r1 * r1;
+    double rho1;
+    const double rho = loss_eval(losses[loss_id], s, &rho1);
+    const double sc = sqrt(rho1);
+    const bool active = flags != (kFlagQConst | kFlagPConst | kFlagLConst);
+    cost = active ? 0.5 * rho : 0.0;
+    if (WITH_J) r_out[f] = make_double2(r0 * sc, r1 * sc);  // a cost-only pass must not disturb r of the current point
+    if (WITH_J) {
+      // Jpi (jacobians.cpp:202-214), M = Jpi R_cb (2x3), scaled by the corrector and the weight
+      const double jx0 = cam.fx * iz, jx2 = -cam.fx * Pc[0] * iz * iz;
+      const double jy1 = cam.fy * iz, jy2 = -cam.fy * Pc[1] * iz * iz;
+      const double ws = w * sc;
+      double M[6];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        M[j] = ws * (jx0 * cam.R[j] + jx2 * cam.R[6 + j]);
+        M[3 + j] = ws * (jy1 * cam.R[3 + j] + jy2 * cam.R[6 + j]);
+      }
+      // d/dtheta = -M [P_b]x
+      if (!(flags & kFlagQConst)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const double m0 = M[3 * i], m1 = M[3 * i + 1], m2 = M[3 * i + 2];
+          J[9 * i + 0] = -(m1 * Pb[2] - m2 * Pb[1]);
+          J[9 * i + 1] = -(m2 * Pb[0] - m0 * Pb[2]);
+          J[9 * i + 2] = -(m0 * Pb[1] - m1 * Pb[0]);
+        }
+      }
+      // d/dt = +M R^T ; d/dP = -M R^T
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const double mr = M[3 * i] * R[3 * j] + M[3 * i + 1] * R[3 * j + 1] + M[3 * i + 2] * R[3 * j + 2];
+          J[9 * i + 3 + j] = (flags & kFlagPConst) ? 0.0 : mr;
+          J[9 * i + 6 + j] = (flags & kFlagLConst) ? 0.0 : -mr;
+        }
+    }
+  }
+  const double tot = block_sum_256(cost, sred);
+  if (threadIdx.x == 0) cost_part[blockIdx.x] = tot;
+  if (WITH_J) {
+    double* sw = sJ + wave * (64 * 18);
+#pragma unroll
+    for (int i = 0; i < 18; ++i) sw[lane * 18 + i] = J[i];
+    __syncthreads();
+    const int fb = blockIdx.x * 256 + wave * 64;
+    const int cnt = min(64, n - fb);
+    if (cnt > 0) {
+      double2* dst = reinterpret_cast<double2*>(J_out + (size_t)fb * 18);
+      const double2* src = reinterpret_cast<const double2*>(sw);
+      const int n2 = cnt * 9;
+#pragma unroll
+      for (int it = 0; it < 9; ++it) {
+        const int e = it * 64 + lane;
+        if (e < n2) dst[e] = src[e];
+      }
+    }
+  }
+}
+
+void launch_reproj_eval(hipStream_t s, const Visual& v, const double* x, const DevCamera* cams,
+                        const DevLoss* losses, bool with_J, double* cost_part_out) {
+  if (v.n == 0) return;
+  const int grid = (v.n + 255) / 256;
+  if (with_J)
+    hipLaunchKernelGGL(reproj_eval_kernel<true>, dim3(grid), dim3(256), 0, s, v.n, v.fac, v.pix, v.w, x, cams, losses,
+                       v.r, v.J, cost_part_out);
+  else
+    hipLaunchKernelGGL(reproj_eval_kernel<false>, dim3(grid), dim3(256), 0, s, v.n, v.fac, v.pix, v.w, x, cams, losses,
+                       v.r, v.J, cost_part_out);
+}
+void launch_reproj_jacobian_only(hipStream_t s, const Visual& v, const double* x, const DevCamera* cams,
+                                 const DevLoss* losses) {
+  launch_reproj_eval(s, v, x, cams, losses, true, v.cost_part);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// per-landmark: Hll = sum B^T B (+ lambda), g_l = sum B^T r, 3x3 Cholesky, then per factor
+// C = B Linv^T (2x3) and rho = r - C z with z = Linv g_l.   8 lanes per landmark.
+// Jacobi scaling (Ceres: s = 1/(1+sqrt(H_jj)) from iteration 0) and the LM diagonal are folded into
+// lambda_j = clamp(s_j^2 H_jj, lo, hi) / (radius s_j^2) on the unscaled system.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void landmark_kernel(int n_lm, const int* __restrict__ lm_start,
+                                                       const double* __restrict__ J, const double2* __restrict__ r,
+                                                       int n_pose, double inv_radius, int compute_scale,
+                                                       int compute_dcl, int jacobi, double lm_lo, double lm_hi,
+                                                       double* __restrict__ scale, double* __restrict__ dcl,
+                                                       double* __restrict__ grad, double* __restrict__ Linv_out,
+                                                       double* __restrict__ z_out, double* __restrict__ CR) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int l = gid >> 3, sub = gid & 7;
+  const bool valid = l < n_lm;
+  int beg = 0, end = 0;
+  if (valid) { beg = lm_start[l]; end = lm_start[l + 1]; }
+  double h00 = 0, h01 = 0, h02 = 0, h11 = 0, h12 = 0, h22 = 0, b0 = 0, b1 = 0, b2 = 0;
+  for (int f = beg + sub; f < end; f += 8) {
+    const double* Jf = J + (size_t)f * 18;
+    const double2 rf = r[f];
+    const double x0 = Jf[6], x1 = Jf[7], x2 = Jf[8], y0 = Jf[15], y1 = Jf[16], y2 = Jf[17];
+    h00 += x0 * x0 + y0 * y0; h01 += x0 * x1 + y0 * y1; h02 += x0 * x2 + y0 * y2;
+    h11 += x1 * x1 + y1 * y1; h12 += x1 * x2 + y1 * y2; h22 += x2 * x2 + y2 * y2;
+    b0 += x0 * rf.x + y0 * rf.y; b1 += x1 * rf.x + y1 * rf.y; b2 += x2 * rf.x + y2 * rf.y;
+  }
+#pragma unroll
+  for (int o = 4; o > 0; o >>= 1) {
+    h00 += __shfl_xor(h00, o, 8); h01 += __shfl_xor(h01, o, 8); h02 += __shfl_xor(h02, o, 8);
+    h11 += __shfl_xor(h11, o, 8); h12 += __shfl_xor(h12, o, 8); h22 += __shfl_xor(h22, o, 8);
+    b0 += __shfl_xor(b0, o, 8); b1 += __shfl_xor(b1, o, 8); b2 += __shfl_xor(b2, o, 8);
+  }
+  if (!valid) return;
+  const int to = n_pose + 3 * l;
+  const double hd[3] = {h00, h11, h22};
+  double lam[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    double sc;
+    if (compute_scale) sc = jacobi ? 1.0 / (1.0 + sqrt(hd[i])) : 1.0; else sc = scale[to + i];
+    double d;
+    if (compute_dcl) d = fmin(fmax(sc * sc * hd[i], lm_lo), lm_hi) / (sc * sc); else d = dcl[to + i];
+    lam[i] = d * inv_radius;
+    if (sub == 0) {
+      if (compute_scale) scale[to + i] = sc;
+      if (compute_dcl) dcl[to + i] = d;
+    }
+  }
+  if (sub == 0) { grad[to] = b0; grad[to + 1] = b1; grad[to + 2] = b2; }
+  // Cholesky of Hll + lambda, Li = L^-1 (lower)
+  const double a00 = h00 + lam[0], a11 = h11 + lam[1], a22 = h22 + lam[2];
+  const double l00 = sqrt(a00), l10 = h01 / l00, l20 = h02 / l00;
+  const double l11 = sqrt(a11 - l10 * l10), l21 = (h12 - l20 * l10) / l11;
+  const double l22 = sqrt(a22 - l20 * l20 - l21 * l21);
+  const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
+  const double i10 = -l10 * i00 * i11;
+  const double i21 = -l21 * i11 * i22;
+  const double i20 = -(l20 * i00 + l21 * i10) * i22;
+  const double z0 = i00 * b0, z1 = i10 * b0 + i11 * b1, z2 = i20 * b0 + i21 * b1 + i22 * b2;
+  if (sub == 0) {
+    double* Lo = Linv_out + (size_t)l * 6;
+    Lo[0] = i00; Lo[1] = i10; Lo[2] = i11; Lo[3] = i20; Lo[4] = i21; Lo[5] = i22;
+    z_out[3 * l] = z0; z_out[3 * l + 1] = z1; z_out[3 * l + 2] = z2;
+  }
+  for (int f = beg + sub; f < end; f += 8) {
+    const double* Jf = J + (size_t)f * 18;
+    const double2 rf = r[f];
+    double* o = CR + (size_t)f * 8;
+    // C[k][j] = sum_i B[k][i] Linv[j][i]
+    const double x0 = Jf[6], x1 = Jf[7], x2 = Jf[8], y0 = Jf[15], y1 = Jf[16], y2 = Jf[17];
+    const double c00 = x0 * i00, c01 = x0 * i10 + x1 * i11, c02 = x0 * i20 + x1 * i21 + x2 * i22;
+    const double c10 = y0 * i00, c11 = y0 * i10 + y1 * i11, c12 = y0 * i20 + y1 * i21 + y2 * i22;
+    o[0] = c00; o[1] = c01; o[2] = c02; o[3] = c10; o[4] = c11; o[5] = c12;
+    o[6] = rf.x - (c00 * z0 + c01 * z1 + c02 * z2);
+    o[7] = rf.y - (c10 * z0 + c11 * z1 + c12 * z2);
+  }
+}
+
+// factors whose landmark is constant: C = 0, rho = r
+__global__ void landmark_tail_kernel(int first, int n, const double2* __restrict__ r, double* __restrict__ CR) {
+  const int f = first + blockIdx.x * 256 + threadIdx.x;
+  if (f >= n) return;
+  double* o = CR + (size_t)f * 8;
+  const double2 rf = r[f];
+  o[0] = o[1] = o[2] = o[3] = o[4] = o[5] = 0.0;
+  o[6] = rf.x; o[7] = rf.y;
+}
+
+void launch_landmark(hipStream_t s, const Visual& v, int n_pose, double radius, int compute_scale,
+                     int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* scale, double* dcl,
+                     double* grad) {
+  if (v.n_lm > 0) {
+    const int grid = (v.n_lm * 8 + 255) / 256;
+    hipLaunchKernelGGL(landmark_kernel, dim3(grid), dim3(256), 0, s, v.n_lm, v.lm_start, v.J, v.r, n_pose, 1.0 / radius,
+                       compute_scale, compute_dcl, jacobi, lm_lo, lm_hi, scale, dcl, grad, v.Linv, v.z, v.CR);
+  }
+  if (v.n > v.n_elim) {
+    const int grid = (v.n - v.n_elim + 255) / 256;
+    hipLaunchKernelGGL(landmark_tail_kernel, dim3(grid), dim3(256), 0, s, v.n_elim, v.n, v.r, v.CR);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// camera-pair segments.  One wave per (camera pose i, camera pose j >= i) pair; lanes stride over the
+// (factor a of i, factor b of j, same landmark) entries:
+//   block(i,j) = sum A_a^T ([a==b] I2 - C_a C_b^T) A_b          (6x6)
+// diagonal segments also give the reduced rhs sum A^T rho, the raw gradient sum A^T r and diag(A^T A).
+// Results are added to the dense reduced system with FP64 atomics (each location is normally owned by
+// one segment, so the sums are reproducible).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void pairs_kernel(int n_seg, const int* __restrict__ seg_ci,
+                                                   const int* __restrict__ seg_cj, const int* __restrict__ seg_start,
+                                                   const int* __restrict__ ent_fa, const int* __restrict__ ent_fb,
+                                                   const double* __restrict__ J, const double2* __restrict__ r,
+                                                   const double* __restrict__ CR, const int* __restrict__ cp_tq,
+                                                   const int* __restrict__ cp_tp, double* __restrict__ S, int ld,
+                                                   int rhs_row, double* __restrict__ grad,
+                                                   double* __restrict__ hdiag) {
+  __shared__ double sb[64];
+  const int seg = blockIdx.x;
+  if (seg >= n_seg) return;
+  const int lane = threadIdx.x;
+  const int ci = seg_ci[seg], cj = seg_cj[seg];
+  const bool diag = ci == cj;
+  double blk[36];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) blk[i] = 0.0;
+  double gr[6], gg[6], hd[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { gr[i] = 0.0; gg[i] = 0.0; hd[i] = 0.0; }
+  const int beg = seg_start[seg], end = seg_start[seg + 1];
+  for (int e = beg + lane; e < end; e += 64) {
+    const int fa = ent_fa[e], fb = ent_fb[e];
+    const double* Ja = J + (size_t)fa * 18;
+    const double* Jb = J + (size_t)fb * 18;
+    const double* Ca = CR + (size_t)fa * 8;
+    const double* Cb = CR + (size_t)fb * 8;
+    double A0[6], A1[6], B0[6], B1[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { A0[k] = Ja[k]; A1[k] = Ja[9 + k]; B0[k] = Jb[k]; B1[k] = Jb[9 + k]; }
+    const double same = (fa == fb) ? 1.0 : 0.0;
+    const double t00 = same - (Ca[0] * Cb[0] + Ca[1] * Cb[1] + Ca[2] * Cb[2]);
+    const double t01 = -(Ca[0] * Cb[3] + Ca[1] * Cb[4] + Ca[2] * Cb[5]);
+    const double t10 = -(Ca[3] * Cb[0] + Ca[4] * Cb[1] + Ca[5] * Cb[2]);
+    const double t11 = same - (Ca[3] * Cb[3] + Ca[4] * Cb[4] + Ca[5] * Cb[5]);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const double u0 = t00 * B0[c] + t01 * B1[c];
+      const double u1 = t10 * B0[c] + t11 * B1[c];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) blk[a * 6 + c] += A0[a] * u0 + A1[a] * u1;
+    }
+    if (fa == fb) {
+      const double2 rf = r[fa];
+      const double p0 = Ca[6], p1 = Ca[7];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        gr[a] += A0[a] * p0 + A1[a] * p1;
+        gg[a] += A0[a] * rf.x + A1[a] * rf.y;
+        hd[a] += A0[a] * A0[a] + A1[a] * A1[a];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 36; ++i) blk[i] = wave_sum(blk[i]);
+  if (diag) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { gr[i] = wave_sum(gr[i]); gg[i] = wave_sum(gg[i]); hd[i] = wave_sum(hd[i]); }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 36; ++i) sb[i] = blk[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { sb[36 + i] = gr[i]; sb[42 + i] = gg[i]; sb[48 + i] = hd[i]; }
+  }
+  __syncthreads();
+  const int tqi = cp_tq[ci], tpi = cp_tp[ci], tqj = cp_tq[cj], tpj = cp_tp[cj];
+  if (lane < 36) {
+    const int a = lane / 6, c = lane % 6;
+    const int row = (a < 3) ? (tqi < 0 ? -1 : tqi + a) : (tpi < 0 ? -1 : tpi + a - 3);
+    const int col = (c < 3) ? (tqj < 0 ? -1 : tqj + c) : (tpj < 0 ? -1 : tpj + c - 3);
+    if (row >= 0 && col >= 0) {
+      const double val = sb[lane];
+      atomicAdd(&S[(size_t)row * ld + col], val);
+      if (!diag) atomicAdd(&S[(size_t)col * ld + row], val);
+    }
+  } else if (diag && lane < 42) {
+    const int a = lane - 36;
+    const int row = (a < 3) ? (tqi < 0 ? -1 : tqi + a) : (tpi < 0 ? -1 : tpi + a - 3);
+    if (row >= 0) {
+      atomicAdd(&S[(size_t)rhs_row * ld + row], sb[36 + a]);
+      atomicAdd(&grad[row], sb[42 + a]);
+      atomicAdd(&hdiag[row], sb[48 + a]);
+    }
+  }
+}
+
+void launch_pairs(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag) {
+  if (v.n_seg == 0) return;
+  hipLaunchKernelGGL(pairs_kernel, dim3(v.n_seg), dim3(64), 0, s, v.n_seg, v.seg_ci, v.seg_cj, v.seg_start, v.ent_fa,
+                     v.ent_fb, v.J, v.r, v.CR, v.cp_tq, v.cp_tp, S, ld, rhs_row, grad, hdiag);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// back-substitution: y_l = Linv^T (z - sum_f C_f^T (A_f y_cam(f)));  delta_l = -y_l.  8 lanes / landmark
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void backsub_kernel(int n_lm, const int* __restrict__ lm_start,
+                                                      const double* __restrict__ J, const double* __restrict__ CR,
+                                                      const int* __restrict__ cam_pose, const int* __restrict__ cp_tq,
+                                                      const int* __restrict__ cp_tp, const double* __restrict__ Linv,
+                                                      const double* __restrict__ z, int n_pose,
+                                                      const double* __restrict__ y_pose, double* __restrict__ delta) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int l = gid >> 3, sub = gid & 7;
+  const bool valid = l < n_lm;
+  int beg = 0, end = 0;
+  if (valid) { beg = lm_start[l]; end = lm_start[l + 1]; }
+  double a0 = 0, a1 = 0, a2 = 0;
+  for (int f = beg + sub; f < end; f += 8) {
+    const double* Jf = J + (size_t)f * 18;
+    const double* C = CR + (size_t)f * 8;
+    const int cp = cam_pose[f];
+    const int tq = cp_tq[cp], tp = cp_tp[cp];
+    double j0 = 0, j1 = 0;
+    if (tq >= 0) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { const double yv = y_pose[tq + k]; j0 += Jf[k] * yv; j1 += Jf[9 + k] * yv; }
+    }
+    if (tp >= 0) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { const double yv = y_pose[tp + k]; j0 += Jf[3 + k] * yv; j1 += Jf[12 + k] * yv; }
+    }
+    a0 += C[0] * j0 + C[3] * j1; a1 += C[1] * j0 + C[4] * j1; a2 += C[2] * j0 + C[5] * j1;
+  }
+#pragma unroll
+  for (int o = 4; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o, 8); a1 += __shfl_xor(a1, o, 8); a2 += __shfl_xor(a2, o, 8); }
+  if (!valid || sub != 0) return;
+  const double* Li = Linv + (size_t)l * 6;
+  const double w0 = z[3 * l] - a0, w1 = z[3 * l + 1] - a1, w2 = z[3 * l + 2] - a2;
+  // y = Linv^T w
+  const double y0 = Li[0] * w0 + Li[1] * w1 + Li[3] * w2;
+  const double y1 = Li[2] * w1 + Li[4] * w2;
+  const double y2 = Li[5] * w2;
+  const int to = n_pose + 3 * l;
+  delta[to] = -y0; delta[to + 1] = -y1; delta[to + 2] = -y2;
+}
+
+void launch_backsub_landmarks(hipStream_t s, const Visual& v, int n_pose, const double* y_pose, double* delta) {
+  if (v.n_lm == 0) return;
+  const int grid = (v.n_lm * 8 + 255) / 256;
+  hipLaunchKernelGGL(backsub_kernel, dim3(grid), dim3(256), 0, s, v.n_lm, v.lm_start, v.J, v.CR, v.cam_pose, v.cp_tq,
+                     v.cp_tp, v.Linv, v.z, n_pose, y_pose, delta);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// model cost change of the visual factors: sum -(J d).(r + J d / 2)   (ceres TrustRegionMinimizer)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mcc_kernel(int n, const double* __restrict__ J, const double2* __restrict__ r,
+                                                  const int* __restrict__ cam_pose, const int* __restrict__ lm_of,
+                                                  const int* __restrict__ cp_tq, const int* __restrict__ cp_tp,
+                                                  int n_pose, const double* __restrict__ delta,
+                                                  double* __restrict__ part) {
+  __shared__ double sred[4];
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  double acc = 0.0;
+  if (f < n) {
+    const double* Jf = J + (size_t)f * 18;
+    const int cp = cam_pose[f];
+    const int tq = cp_tq[cp], tp = cp_tp[cp], l = lm_of[f];
+    double j0 = 0, j1 = 0;
+    if (tq >= 0)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { const double d = delta[tq + k]; j0 += Jf[k] * d; j1 += Jf[9 + k] * d; }
+    if (tp >= 0)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { const double d = delta[tp + k]; j0 += Jf[3 + k] * d; j1 += Jf[12 + k] * d; }
+    if (l >= 0)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { const double d = delta[n_pose + 3 * l + k]; j0 += Jf[6 + k] * d; j1 += Jf[15 + k] * d; }
+    const double2 rf = r[f];
+    acc = -(j0 * (rf.x + 0.5 * j0) + j1 * (rf.y + 0.5 * j1));
+  }
+  const double tot = block_sum_256(acc, sred);
+  if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+void launch_mcc(hipStream_t s, const Visual& v, int n_pose, const double* delta, double* part) {
+  if (v.n == 0) return;
+  const int grid = (v.n + 255) / 256;
+  hipLaunchKernelGGL(mcc_kernel, dim3(grid), dim3(256), 0, s, v.n, v.J, v.r, v.cam_pose, v.lm_of, v.cp_tq, v.cp_tp, n_pose,
+                     delta, part);
+}
+
+}  // namespace bsg

@@ -1,0 +1,616 @@
+// Pose-only factors of the solve path on gfx950 (residual + analytic tangent Jacobian), their
+// J^T J / J^T r assembly into the dense reduced system, and their model-cost-change term.
+//   IMU_DELTA   bs_constraints/.../inertial/normal_delta_imu_state_3d_cost_functor.h:59-141   (wave / factor)
+//   IMU_PRIOR   bs_constraints/.../inertial/normal_prior_imu_state_3d_cost_functor.h:57-88   (wave / factor)
+//   RELPOSE(_EXT) bs_constraints/.../relative_pose/delta_pose_3d_with_extrinsics_cost_functor.h:65-109
+//               + [EXT] fuse NormalDeltaPose3DCostFunctor                                     (lane / factor)
+//   ABSPOSE     [EXT] fuse NormalPriorPose3DCostFunctor (global/absolute_pose_3d_constraint.cpp:45-50)
+//   ABS/REL_VEC3 [EXT] fuse Absolute/RelativeConstraint<V> (global/absolute_constraint.h:10-25)
+//   GRAVITY     bs_constraints/.../global/gravity_alignment_cost_functor.h:50-63
+// The reference differentiates these with ceres::AutoDiffCostFunction and multiplies by the
+// quaternion PlusJacobian; here the tangent Jacobians are closed form,
+// checked against the Jet-based oracle in tests/.
+#include "bsgpu_device.h"
+
+namespace bsg {
+
+__constant__ double kGravity[3] = {0.0, 0.0, -9.80665};  // bs_common/include/bs_common/utils.h:20-24
+
+// Eigen: q.conjugate() * v   (v + w uv + u x uv with uv = 2 u x v, u = -q.vec)
+BSG_DEV void eigen_conj_rotate(const double q[4], const double v[3], double o[3]) {
+  const double u[3] = {-q[1], -q[2], -q[3]};
+  double uv[3];
+  cross3(u, v, uv);
+  uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+  double c[3];
+  cross3(u, uv, c);
+  o[0] = v[0] + q[0] * uv[0] + c[0];
+  o[1] = v[1] + q[0] * uv[1] + c[1];
+  o[2] = v[2] + q[0] * uv[2] + c[2];
+}
+
+BSG_DEV void finish_small(const SmallGroup& g, int f, const DevLoss* losses, double s, double* sc, double* cost) {
+  double rho1;
+  const double rho = loss_eval(losses[g.loss[f]], s, &rho1);
+  *sc = sqrt(rho1);
+  *cost = g.active[f] ? 0.5 * rho : 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// IMU delta: one wave per factor.  Lanes 0..14 own a residual row, lanes 0..29 own a Jacobian column.
+// ---------------------------------------------------------------------------------------------------
+template <bool WITH_J>
+__global__ __launch_bounds__(64) void imu_delta_kernel(SmallGroup g, const double* __restrict__ x,
+                                                       const DevLoss* __restrict__ losses,
+                                                       double* __restrict__ cost_part) {
+  const int f = blockIdx.x, lane = threadIdx.x;
+  const int* xo = g.xoff + (size_t)f * 10;
+  const int* to = g.toff + (size_t)f * 10;
+  const double* c = g.consts + (size_t)f * 287;
+  const double* A = c + 62;
+  double qi[4], qj[4], pi[3], vi[3], bgi[3], bai[3], pj[3], vj[3], bgj[3], baj[3];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { qi[k] = x[xo[0] + k]; qj[k] = x[xo[5] + k]; }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    pi[k] = x[xo[1] + k]; vi[k] = x[xo[2] + k]; bgi[k] = x[xo[3] + k]; bai[k] = x[xo[4] + k];
+    pj[k] = x[xo[6] + k]; vj[k] = x[xo[7] + k]; bgj[k] = x[xo[8] + k]; baj[k] = x[xo[9] + k];
+  }
+  const double dt = c[0];
+  const double dq[4] = {c[1], c[2], c[3], c[4]};
+  const double* dp = c + 5;
+  const double* dv = c + 8;
+  const double* dq_dbg = c + 11;
+  const double* dp_dbg = c + 20;
+  const double* dp_dba = c + 29;
+  const double* dv_dbg = c + 38;
+  const double* dv_dba = c + 47;
+  double dbg[3], dba[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { dbg[k] = bgi[k] - c[56 + k]; dba[k] = bai[k] - c[59 + k]; }
+  double tau[3];
+  mat3_vec(dq_dbg, dbg, tau);
+  const double dd[4] = {1.0, tau[0] / 2.0, tau[1] / 2.0, tau[2] / 2.0};  // DeltaQ: NOT normalised (utils.h:28-38)
+  double qc[4];
+  quat_mul(dq, dd, qc);
+  const double nc = qc[0] * qc[0] + qc[1] * qc[1] + qc[2] * qc[2] + qc[3] * qc[3];
+  const double u[4] = {qc[0] / nc, -qc[1] / nc, -qc[2] / nc, -qc[3] / nc};   // q_corrected.inverse()
+  const double ni = qi[0] * qi[0] + qi[1] * qi[1] + qi[2] * qi[2] + qi[3] * qi[3];
+  const double qi_inv[4] = {qi[0] / ni, -qi[1] / ni, -qi[2] / ni, -qi[3] / ni};
+  double e[4], m[4];
+  quat_mul(qi_inv, qj, e);
+  quat_mul(u, e, m);
+  double res[15];
+  res[0] = 2.0 * m[1]; res[1] = 2.0 * m[2]; res[2] = 2.0 * m[3];
+  double ap[3], av[3], rap[3], rav[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    ap[k] = pj[k] - pi[k] - dt * vi[k] - 0.5 * dt * dt * kGravity[k];
+    av[k] = vj[k] - vi[k] - dt * kGravity[k];
+  }
+  eigen_conj_rotate(qi, ap, rap);
+  eigen_conj_rotate(qi, av, rav);
+  double t1[3], t2[3];
+  mat3_vec(dp_dbg, dbg, t1); mat3_vec(dp_dba, dba, t2);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) res[3 + k] = rap[k] - (dp[k] + t1[k] + t2[k]);
+  mat3_vec(dv_dbg, dbg, t1); mat3_vec(dv_dba, dba, t2);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) res[6 + k] = rav[k] - (dv[k] + t1[k] + t2[k]);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { res[9 + k] = bgj[k] - bgi[k]; res[12 + k] = baj[k] - bai[k]; }
+  // r = A res: lane k < 15 owns row k
+  double rk = 0.0;
+  if (lane < 15) {
+#pragma unroll
+    for (int k = 0; k < 15; ++k) rk += A[15 * lane + k] * res[k];
+  }
+  const double s = wave_sum(rk * rk);
+  double sc, cost;
+  finish_small(g, f, losses, s, &sc, &cost);
+  if (WITH_J && lane < 15) g.r[(size_t)f * 15 + lane] = rk * sc;
+  if (lane == 0) cost_part[f] = cost;
+  if (!WITH_J || lane >= 30) return;
+  // raw Jacobian column `lane`: block b, component i
+  const int b = lane / 3, i = lane % 3;
+  double col[15];
+#pragma unroll
+  for (int k = 0; k < 15; ++k) col[k] = 0.0;
+  double Ri[9];
+  quat_to_rot(qi, Ri);
+  const double ei[3] = {i == 0 ? 1.0 : 0.0, i == 1 ? 1.0 : 0.0, i == 2 ? 1.0 : 0.0};
+  const double RiT_ei[3] = {Ri[3 * i], Ri[3 * i + 1], Ri[3 * i + 2]};  // R_i^T e_i = row i of R_i
+  switch (b) {
+    case 0: {  // theta_i
+      const double pe[4] = {0.0, ei[0], ei[1], ei[2]};
+      double t[4], w[4];
+      quat_mul(u, pe, t);
+      quat_mul(t, e, w);
+      col[0] = -w[1]; col[1] = -w[2]; col[2] = -w[3];
+      double Rap[3], Rav[3];
+      mat3t_vec(Ri, ap, Rap); mat3t_vec(Ri, av, Rav);
+      double c1[3], c2[3];
+      cross3(Rap, ei, c1); cross3(Rav, ei, c2);
+      col[3] = c1[0]; col[4] = c1[1]; col[5] = c1[2];
+      col[6] = c2[0]; col[7] = c2[1]; col[8] = c2[2];
+    } break;
+    case 1:  // p_i
+      col[3] = -RiT_ei[0]; col[4] = -RiT_ei[1]; col[5] = -RiT_ei[2];
+      break;
+    case 2:  // v_i
+      col[3] = -dt * RiT_ei[0]; col[4] = -dt * RiT_ei[1]; col[5] = -dt * RiT_ei[2];
+      col[6] = -RiT_ei[0]; col[7] = -RiT_ei[1]; col[8] = -RiT_ei[2];
+      break;
+    case 3: {  // bg_i
+      // d res_q / d tau_k = 2 vec( du/dtau_k (x) e ),  du/dtau_k = (0,-e_k/2)(x)conj(dq)/nc - u (|dq|^2 tau_k/2)/nc
+      const double dqc[4] = {dq[0], -dq[1], -dq[2], -dq[3]};
+      const double ndq = dq[0] * dq[0] + dq[1] * dq[1] + dq[2] * dq[2] + dq[3] * dq[3];
+      double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double pk[4] = {0.0, k == 0 ? -0.5 : 0.0, k == 1 ? -0.5 : 0.0, k == 2 ? -0.5 : 0.0};
+        double du[4], w[4];
+        quat_mul(pk, dqc, du);
+        const double fk = ndq * tau[k] * 0.5 / nc;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) du[a] = du[a] / nc - u[a] * fk;
+        quat_mul(du, e, w);
+        const double jk = dq_dbg[3 * k + i];
+        acc[0] += 2.0 * w[1] * jk; acc[1] += 2.0 * w[2] * jk; acc[2] += 2.0 * w[3] * jk;
+      }
+      col[0] = acc[0]; col[1] = acc[1]; col[2] = acc[2];
+      col[3] = -dp_dbg[i]; col[4] = -dp_dbg[3 + i]; col[5] = -dp_dbg[6 + i];
+      col[6] = -dv_dbg[i]; col[7] = -dv_dbg[3 + i]; col[8] = -dv_dbg[6 + i];
+      col[9 + i] = -1.0;
+    } break;
+    case 4:  // ba_i
+      col[3] = -dp_dba[i]; col[4] = -dp_dba[3 + i]; col[5] = -dp_dba[6 + i];
+      col[6] = -dv_dba[i]; col[7] = -dv_dba[3 + i]; col[8] = -dv_dba[6 + i];
+      col[12 + i] = -1.0;
+      break;
+    case 5: {  // theta_j : m_w e_i + m_v x e_i
+      const double mv[3] = {m[1], m[2], m[3]};
+      double cx[3];
+      cross3(mv, ei, cx);
+      col[0] = m[0] * ei[0] + cx[0]; col[1] = m[0] * ei[1] + cx[1]; col[2] = m[0] * ei[2] + cx[2];
+    } break;
+    case 6: col[3] = RiT_ei[0]; col[4] = RiT_ei[1]; col[5] = RiT_ei[2]; break;  // p_j
+    case 7: col[6] = RiT_ei[0]; col[7] = RiT_ei[1]; col[8] = RiT_ei[2]; break;  // v_j
+    case 8: col[9 + i] = 1.0; break;                                              // bg_j
+    default: col[12 + i] = 1.0; break;                                            // ba_j
+  }
+  const bool is_const = to[b] < 0;
+  double* Jo = g.J + (size_t)f * 450;
+#pragma unroll
+  for (int k = 0; k < 15; ++k) {
+    double a = 0.0;
+#pragma unroll
+    for (int mm = 0; mm < 15; ++mm) a += A[15 * k + mm] * col[mm];
+    Jo[k * 30 + lane] = is_const ? 0.0 : a * sc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// IMU prior: one wave per factor; 15 rows / 15 columns
+// ---------------------------------------------------------------------------------------------------
+template <bool WITH_J>
+__global__ __launch_bounds__(64) void imu_prior_kernel(SmallGroup g, const double* __restrict__ x,
+                                                       const DevLoss* __restrict__ losses,
+                                                       double* __restrict__ cost_part) {
+  const int f = blockIdx.x, lane = threadIdx.x;
+  const int* xo = g.xoff + (size_t)f * 5;
+  const int* to = g.toff + (size_t)f * 5;
+  const double* c = g.consts + (size_t)f * 241;
+  const double* A = c + 16;
+  const double q[4] = {x[xo[0]], x[xo[0] + 1], x[xo[0] + 2], x[xo[0] + 3]};
+  const double binv[4] = {c[0], -c[1], -c[2], -c[3]};
+  double diff[4], res[15];
+  quat_mul(binv, q, diff);
+  quat_to_angle_axis(diff, res);
+#pragma unroll
+  for (int s = 1; s < 5; ++s)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) res[3 * s + k] = x[xo[s] + k] - c[1 + 3 * s + k];
+  double rk = 0.0;
+  if (lane < 15) {
+#pragma unroll
+    for (int k = 0; k < 15; ++k) rk += A[15 * lane + k] * res[k];
+  }
+  const double s2 = wave_sum(rk * rk);
+  double sc, cost;
+  finish_small(g, f, losses, s2, &sc, &cost);
+  if (WITH_J && lane < 15) g.r[(size_t)f * 15 + lane] = rk * sc;
+  if (lane == 0) cost_part[f] = cost;
+  if (!WITH_J || lane >= 15) return;
+  double Jr[9];
+  so3_jr_inv(res, Jr);
+  const bool is_const = to[lane / 3] < 0;
+  double* Jo = g.J + (size_t)f * 225;
+#pragma unroll
+  for (int k = 0; k < 15; ++k) {
+    double a;
+    if (lane < 3) a = A[15 * k] * Jr[lane] + A[15 * k + 1] * Jr[3 + lane] + A[15 * k + 2] * Jr[6 + lane];
+    else a = A[15 * k + lane];
+    Jo[k * 15 + lane] = is_const ? 0.0 : a * sc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// relative pose (with / without extrinsics): one lane per factor
+// ---------------------------------------------------------------------------------------------------
+template <bool EXT, bool WITH_J>
+__global__ __launch_bounds__(128) void relpose_kernel(SmallGroup g, const double* __restrict__ x,
+                                                      const DevLoss* __restrict__ losses,
+                                                      double* __restrict__ cost_part) {
+  const int f = blockIdx.x * 128 + threadIdx.x;
+  if (f >= g.n) return;
+  constexpr int NV = EXT ? 6 : 4;
+  constexpr int TW = 3 * NV;
+  const int* xo = g.xoff + (size_t)f * NV;
+  const int* to = g.toff + (size_t)f * NV;
+  const double* c = g.consts + (size_t)f * 43;
+  const double* A = c + 7;
+  double p1[3], q1[4], p2[3], q2[4];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { p1[k] = x[xo[0] + k]; p2[k] = x[xo[2] + k]; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { q1[k] = x[xo[1] + k]; q2[k] = x[xo[3] + k]; }
+  double Rb1[9], Rb2[9], Re[9], pe[3] = {0, 0, 0};
+  double ps1[3], qs1[4], ps2[3], qs2[4];
+  if (EXT) {
+    double qe[4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pe[k] = x[xo[4] + k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) qe[k] = x[xo[5] + k];
+    quat_to_rot_normalized(q1, Rb1);
+    quat_to_rot_normalized(q2, Rb2);
+    quat_to_rot_normalized(qe, Re);
+    quat_mul(q1, qe, qs1);
+    quat_mul(q2, qe, qs2);
+    double t[3];
+    mat3_vec(Rb1, pe, t);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ps1[k] = t[k] + p1[k];
+    mat3_vec(Rb2, pe, t);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ps2[k] = t[k] + p2[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { ps1[k] = p1[k]; ps2[k] = p2[k]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { qs1[k] = q1[k]; qs2[k] = q2[k]; }
+  }
+  double R1[9], R2[9];
+  quat_to_rot_normalized(qs1, R1);
+  quat_to_rot_normalized(qs2, R2);
+  const double dpw[3] = {ps2[0] - ps1[0], ps2[1] - ps1[1], ps2[2] - ps1[2]};
+  double dpr[3];
+  mat3t_vec(R1, dpw, dpr);
+  double e[6];
+  e[0] = dpr[0] - c[0]; e[1] = dpr[1] - c[1]; e[2] = dpr[2] - c[2];
+  const double q1inv[4] = {qs1[0], -qs1[1], -qs1[2], -qs1[3]};
+  const double dinv[4] = {c[3], -c[4], -c[5], -c[6]};
+  double diff[4], err[4];
+  quat_mul(q1inv, qs2, diff);
+  quat_mul(dinv, diff, err);
+  quat_to_angle_axis(err, e + 3);
+  double r[6], s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double a = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a += A[6 * i + k] * e[k];
+    r[i] = a; s += a * a;
+  }
+  double sc, cost;
+  finish_small(g, f, losses, s, &sc, &cost);
+  cost_part[f] = cost;
+  if (!WITH_J) return;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) g.r[(size_t)f * 6 + i] = r[i] * sc;
+  // derivatives w.r.t. the SENSOR poses: columns (p_s1, th_s1, p_s2, th_s2)
+  double Jr[9];
+  so3_jr_inv(e + 3, Jr);
+  // G = -Jr R2^T R1
+  double R2tR1[9], G[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) R2tR1[3 * i + j] = R2[i] * R1[j] + R2[3 + i] * R1[3 + j] + R2[6 + i] * R1[6 + j];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) G[3 * i + j] = -(Jr[3 * i] * R2tR1[j] + Jr[3 * i + 1] * R2tR1[3 + j] + Jr[3 * i + 2] * R2tR1[6 + j]);
+  // raw Je (6 x TW), base-frame columns
+  double Je[6 * TW];
+#pragma unroll
+  for (int i = 0; i < 6 * TW; ++i) Je[i] = 0.0;
+  // e_p rows: d/dp_s1 = -R1^T, d/dth_s1 = [dpr]x, d/dp_s2 = R1^T
+  const double Sx[9] = {0, -dpr[2], dpr[1], dpr[2], 0, -dpr[0], -dpr[1], dpr[0], 0};
+  double Eps1[9], Eth1p[9], Eth1q[9], Eth2q[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { Eps1[3 * i + j] = -R1[3 * j + i]; Eth1p[3 * i + j] = Sx[3 * i + j]; Eth1q[3 * i + j] = G[3 * i + j]; Eth2q[3 * i + j] = Jr[3 * i + j]; }
+  if (!EXT) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        Je[i * TW + 0 + j] = Eps1[3 * i + j];       // p1
+        Je[i * TW + 3 + j] = Eth1p[3 * i + j];      // th1 (position rows)
+        Je[(3 + i) * TW + 3 + j] = Eth1q[3 * i + j];  // th1 (orientation rows)
+        Je[i * TW + 6 + j] = -Eps1[3 * i + j];      // p2
+        Je[(3 + i) * TW + 9 + j] = Eth2q[3 * i + j];  // th2
+      }
+  } else {
+    // theta_s = Re^T theta_b ; dp_s/dtheta_b = -Rb [pe]x ; dp_s/dp_b = I ; dp_s/dpe = Rb ; theta_s = theta_e
+    const double Px[9] = {0, -pe[2], pe[1], pe[2], 0, -pe[0], -pe[1], pe[0], 0};
+    double RbPx1[9], RbPx2[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        RbPx1[3 * i + j] = -(Rb1[3 * i] * Px[j] + Rb1[3 * i + 1] * Px[3 + j] + Rb1[3 * i + 2] * Px[6 + j]);
+        RbPx2[3 * i + j] = -(Rb2[3 * i] * Px[j] + Rb2[3 * i + 1] * Px[3 + j] + Rb2[3 * i + 2] * Px[6 + j]);
+      }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        // position rows
+        Je[i * TW + 0 + j] = Eps1[3 * i + j];  // p_b1
+        Je[i * TW + 6 + j] = -Eps1[3 * i + j];  // p_b2
+        double a = 0, b = 0, cc = 0, d = 0, ee = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          a += Eth1p[3 * i + k] * Re[3 * j + k];          // Eth1p Re^T
+          b += Eps1[3 * i + k] * RbPx1[3 * k + j];        // Eps1 (-Rb1 [pe]x)
+          cc += -Eps1[3 * i + k] * RbPx2[3 * k + j];      // Eps2 (-Rb2 [pe]x), Eps2 = -Eps1
+          d += Eps1[3 * i + k] * Rb1[3 * k + j] - Eps1[3 * i + k] * Rb2[3 * k + j];  // d/dpe
+          ee += 0.0;
+        }
+        Je[i * TW + 3 + j] = a + b;        // th_b1
+        Je[i * TW + 9 + j] = cc;           // th_b2
+        Je[i * TW + 12 + j] = d;           // p_e
+        Je[i * TW + 15 + j] = Eth1p[3 * i + j];  // th_e (through th_s1; th_s2 does not enter e_p)
+        // orientation rows
+        double g1 = 0, g2 = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { g1 += Eth1q[3 * i + k] * Re[3 * j + k]; g2 += Eth2q[3 * i + k] * Re[3 * j + k]; }
+        Je[(3 + i) * TW + 3 + j] = g1;
+        Je[(3 + i) * TW + 9 + j] = g2;
+        Je[(3 + i) * TW + 15 + j] = Eth1q[3 * i + j] + Eth2q[3 * i + j];
+        (void)ee;
+      }
+  }
+  double* Jo = g.J + (size_t)f * 6 * TW;
+#pragma unroll
+  for (int col = 0; col < TW; ++col) {
+    const bool is_const = to[col / 3] < 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      double a = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) a += A[6 * i + k] * Je[k * TW + col];
+      Jo[i * TW + col] = is_const ? 0.0 : a * sc;
+    }
+  }
+}
+
+// absolute pose prior: blocks (p, q), r = A [p - b_p ; AngleAxis(b_q^-1 q)]
+template <bool WITH_J>
+__global__ __launch_bounds__(128) void abspose_kernel(SmallGroup g, const double* __restrict__ x,
+                                                      const DevLoss* __restrict__ losses,
+                                                      double* __restrict__ cost_part) {
+  const int f = blockIdx.x * 128 + threadIdx.x;
+  if (f >= g.n) return;
+  const int* xo = g.xoff + (size_t)f * 2;
+  const int* to = g.toff + (size_t)f * 2;
+  const double* c = g.consts + (size_t)f * 43;
+  const double* A = c + 7;
+  double e[6];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) e[k] = x[xo[0] + k] - c[k];
+  const double q[4] = {x[xo[1]], x[xo[1] + 1], x[xo[1] + 2], x[xo[1] + 3]};
+  const double binv[4] = {c[3], -c[4], -c[5], -c[6]};
+  double diff[4];
+  quat_mul(binv, q, diff);
+  quat_to_angle_axis(diff, e + 3);
+  double r[6], s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double a = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a += A[6 * i + k] * e[k];
+    r[i] = a; s += a * a;
+  }
+  double sc, cost;
+  finish_small(g, f, losses, s, &sc, &cost);
+  cost_part[f] = cost;
+  if (!WITH_J) return;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) g.r[(size_t)f * 6 + i] = r[i] * sc;
+  double Jr[9];
+  so3_jr_inv(e + 3, Jr);
+  double* Jo = g.J + (size_t)f * 36;
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      Jo[i * 6 + j] = to[0] < 0 ? 0.0 : A[6 * i + j] * sc;
+      const double a = A[6 * i + 3] * Jr[j] + A[6 * i + 4] * Jr[3 + j] + A[6 * i + 5] * Jr[6 + j];
+      Jo[i * 6 + 3 + j] = to[1] < 0 ? 0.0 : a * sc;
+    }
+}
+
+// r = A (x - b)  /  r = A ((x2 - x1) - d)
+template <bool REL, bool WITH_J>
+__global__ __launch_bounds__(128) void vec3_kernel(SmallGroup g, const double* __restrict__ x,
+                                                   const DevLoss* __restrict__ losses,
+                                                   double* __restrict__ cost_part) {
+  const int f = blockIdx.x * 128 + threadIdx.x;
+  if (f >= g.n) return;
+  constexpr int NV = REL ? 2 : 1;
+  const int* xo = g.xoff + (size_t)f * NV;
+  const int* to = g.toff + (size_t)f * NV;
+  const double* c = g.consts + (size_t)f * 12;
+  const double* A = c + 3;
+  double e[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) e[k] = REL ? (x[xo[1] + k] - x[xo[0] + k] - c[k]) : (x[xo[0] + k] - c[k]);
+  double r[3], s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { r[i] = A[3 * i] * e[0] + A[3 * i + 1] * e[1] + A[3 * i + 2] * e[2]; s += r[i] * r[i]; }
+  double sc, cost;
+  finish_small(g, f, losses, s, &sc, &cost);
+  cost_part[f] = cost;
+  if (!WITH_J) return;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) g.r[(size_t)f * 3 + i] = r[i] * sc;
+  double* Jo = g.J + (size_t)f * 3 * 3 * NV;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (REL) {
+        Jo[i * 6 + j] = to[0] < 0 ? 0.0 : -A[3 * i + j] * sc;
+        Jo[i * 6 + 3 + j] = to[1] < 0 ? 0.0 : A[3 * i + j] * sc;
+      } else {
+        Jo[i * 3 + j] = to[0] < 0 ? 0.0 : A[3 * i + j] * sc;
+      }
+    }
+}
+
+// gravity alignment: r = A2x2 [R(q) g_b]_{xy}
+template <bool WITH_J>
+__global__ __launch_bounds__(128) void gravity_kernel(SmallGroup g, const double* __restrict__ x,
+                                                      const DevLoss* __restrict__ losses,
+                                                      double* __restrict__ cost_part) {
+  const int f = blockIdx.x * 128 + threadIdx.x;
+  if (f >= g.n) return;
+  const int xo = g.xoff[f];
+  const int to = g.toff[f];
+  const double* c = g.consts + (size_t)f * 7;
+  const double q[4] = {x[xo], x[xo + 1], x[xo + 2], x[xo + 3]};
+  double R[9], gw[3];
+  quat_to_rot_normalized(q, R);
+  mat3_vec(R, c, gw);
+  const double r0 = c[3] * gw[0] + c[4] * gw[1], r1 = c[5] * gw[0] + c[6] * gw[1];
+  double sc, cost;
+  finish_small(g, f, losses, r0 * r0 + r1 * r1, &sc, &cost);
+  cost_part[f] = cost;
+  if (!WITH_J) return;
+  g.r[(size_t)f * 2] = r0 * sc; g.r[(size_t)f * 2 + 1] = r1 * sc;
+  // d(R g)/dtheta = -R [g]x
+  const double Gx[9] = {0, -c[2], c[1], c[2], 0, -c[0], -c[1], c[0], 0};
+  double D[6];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) D[3 * i + j] = -(R[3 * i] * Gx[j] + R[3 * i + 1] * Gx[3 + j] + R[3 * i + 2] * Gx[6 + j]);
+  double* Jo = g.J + (size_t)f * 6;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    Jo[j] = to < 0 ? 0.0 : (c[3] * D[j] + c[4] * D[3 + j]) * sc;
+    Jo[3 + j] = to < 0 ? 0.0 : (c[5] * D[j] + c[6] * D[3 + j]) * sc;
+  }
+}
+
+void launch_small_eval(hipStream_t s, const SmallGroup& g, const double* x, const DevLoss* losses, bool with_J,
+                       double* cost_part) {
+  if (g.n == 0) return;
+  const int g128 = (g.n + 127) / 128;
+#define BSG_LAUNCH(K, grid, block) \
+  do { if (with_J) hipLaunchKernelGGL((K<true>), dim3(grid), dim3(block), 0, s, g, x, losses, cost_part); \
+       else hipLaunchKernelGGL((K<false>), dim3(grid), dim3(block), 0, s, g, x, losses, cost_part); } while (0)
+#define BSG_LAUNCH2(K, B, grid, block) \
+  do { if (with_J) hipLaunchKernelGGL((K<B, true>), dim3(grid), dim3(block), 0, s, g, x, losses, cost_part); \
+       else hipLaunchKernelGGL((K<B, false>), dim3(grid), dim3(block), 0, s, g, x, losses, cost_part); } while (0)
+  switch (g.type) {
+    case BSGPU_F_IMU_DELTA: BSG_LAUNCH(imu_delta_kernel, g.n, 64); break;
+    case BSGPU_F_IMU_PRIOR: BSG_LAUNCH(imu_prior_kernel, g.n, 64); break;
+    case BSGPU_F_RELPOSE_EXT: BSG_LAUNCH2(relpose_kernel, true, g128, 128); break;
+    case BSGPU_F_RELPOSE: BSG_LAUNCH2(relpose_kernel, false, g128, 128); break;
+    case BSGPU_F_ABSPOSE: BSG_LAUNCH(abspose_kernel, g128, 128); break;
+    case BSGPU_F_ABS_VEC3: BSG_LAUNCH2(vec3_kernel, false, g128, 128); break;
+    case BSGPU_F_REL_VEC3: BSG_LAUNCH2(vec3_kernel, true, g128, 128); break;
+    case BSGPU_F_GRAVITY: BSG_LAUNCH(gravity_kernel, g128, 128); break;
+    default: break;
+  }
+#undef BSG_LAUNCH
+#undef BSG_LAUNCH2
+}
+
+// ---------------------------------------------------------------------------------------------------
+// assembly of a pose-only group into the dense reduced system: one wave per factor, J staged in LDS,
+// lanes stride over the (column a, column b) pairs; FP64 atomics into S, the rhs row, grad and hdiag.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void small_assemble_kernel(SmallGroup g, double* __restrict__ S, int ld, int rhs_row,
+                                                            double* __restrict__ grad, double* __restrict__ hdiag) {
+  __shared__ double sJ[15 * 30];
+  __shared__ double sr[15];
+  __shared__ int st[10];
+  const int f = blockIdx.x, lane = threadIdx.x;
+  if (!g.active[f]) return;
+  const int m = g.m, tw = 3 * g.nv;
+  const double* J = g.J + (size_t)f * m * tw;
+  for (int i = lane; i < m * tw; i += 64) sJ[i] = J[i];
+  if (lane < m) sr[lane] = g.r[(size_t)f * m + lane];
+  if (lane < g.nv) st[lane] = g.toff[(size_t)f * g.nv + lane];
+  __syncthreads();
+  for (int p = lane; p < tw * tw; p += 64) {
+    const int a = p / tw, b = p % tw;
+    const int ta = st[a / 3], tb = st[b / 3];
+    if (ta < 0 || tb < 0) continue;
+    double acc = 0.0;
+    for (int k = 0; k < m; ++k) acc += sJ[k * tw + a] * sJ[k * tw + b];
+    atomicAdd(&S[(size_t)(ta + a % 3) * ld + tb + b % 3], acc);
+  }
+  for (int a = lane; a < tw; a += 64) {
+    const int ta = st[a / 3];
+    if (ta < 0) continue;
+    double gs = 0.0, hs = 0.0;
+    for (int k = 0; k < m; ++k) { const double j = sJ[k * tw + a]; gs += j * sr[k]; hs += j * j; }
+    atomicAdd(&S[(size_t)rhs_row * ld + ta + a % 3], gs);
+    atomicAdd(&grad[ta + a % 3], gs);
+    atomicAdd(&hdiag[ta + a % 3], hs);
+  }
+}
+
+void launch_small_assemble(hipStream_t s, const SmallGroup& g, double* S, int ld, int rhs_row, double* grad,
+                           double* hdiag) {
+  if (g.n == 0) return;
+  hipLaunchKernelGGL(small_assemble_kernel, dim3(g.n), dim3(64), 0, s, g, S, ld, rhs_row, grad, hdiag);
+}
+
+// model cost change term of a pose-only group: part[f] = -(J d).(r + J d/2)
+__global__ __launch_bounds__(128) void small_mcc_kernel(SmallGroup g, const double* __restrict__ delta,
+                                                        double* __restrict__ part) {
+  const int f = blockIdx.x * 128 + threadIdx.x;
+  if (f >= g.n) return;
+  double acc = 0.0;
+  if (g.active[f]) {
+    const int m = g.m, tw = 3 * g.nv;
+    const double* J = g.J + (size_t)f * m * tw;
+    const int* to = g.toff + (size_t)f * g.nv;
+    for (int k = 0; k < m; ++k) {
+      double jv = 0.0;
+      for (int sl = 0; sl < g.nv; ++sl) {
+        const int t = to[sl];
+        if (t < 0) continue;
+        jv += J[k * tw + 3 * sl] * delta[t] + J[k * tw + 3 * sl + 1] * delta[t + 1] + J[k * tw + 3 * sl + 2] * delta[t + 2];
+      }
+      acc -= jv * (g.r[(size_t)f * m + k] + 0.5 * jv);
+    }
+  }
+  part[f] = acc;
+}
+
+void launch_small_mcc(hipStream_t s, const SmallGroup& g, const double* delta, double* part) {
+  if (g.n == 0) return;
+  hipLaunchKernelGGL(small_mcc_kernel, dim3((g.n + 127) / 128), dim3(128), 0, s, g, delta, part);
+}
+
+}  // namespace bsg

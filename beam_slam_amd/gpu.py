@@ -1,0 +1,48 @@
+"""Loader of the product library libbsgpu.so (HIP kernels + C-ABI of include/bsgpu.h).
+
+There is deliberately no fallback: if the library has not been built (``__graft_entry__.build()`` or
+``make -C beam_slam_amd/csrc``) or no HIP device is usable, this module raises.
+"""
+import ctypes
+import os
+
+from . import capi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libbsgpu.so")
+_LIB = None
+
+
+class GpuLibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise GpuLibraryMissing(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  beam_slam_amd has no CPU fallback.")
+        _LIB = ctypes.CDLL(LIB_PATH)
+        _LIB.bsgpu_time_reproj_jacobian_ms.restype = ctypes.c_double
+        _LIB.bsgpu_time_reproj_jacobian_ms.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+        _LIB.bsgpu_reproj_jacobian_bytes.restype = ctypes.c_int64
+        _LIB.bsgpu_reproj_jacobian_bytes.argtypes = [ctypes.c_void_p]
+    return _LIB
+
+
+class GpuSolver(capi.Solver):
+    """One bsgpu context on HIP device `device`."""
+
+    def __init__(self, device=0):
+        super().__init__(lib(), "bsgpu_", device)
+
+    def time_reproj_jacobian_ms(self, reps=20):
+        ms = lib().bsgpu_time_reproj_jacobian_ms(self._ctx, int(reps))
+        if ms < 0:
+            raise capi.SolverError(capi.ERR_DEVICE, "bsgpu_time_reproj_jacobian_ms failed")
+        return ms
+
+    def reproj_jacobian_bytes(self):
+        return lib().bsgpu_reproj_jacobian_bytes(self._ctx)
