@@ -491,6 +491,7 @@ void linear_solve_and_candidate(bsgpu_ctx* c) {
 }
 
 int fetch_scalars(bsgpu_ctx* c) {
+  HIPCHK(c, hipGetLastError());  // a kernel that failed to launch must not pass silently
   HIPCHK(c, hipMemcpyAsync(c->h_scal, c->d_scal, sizeof(double) * SC_NUM, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return BSGPU_OK;

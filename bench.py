@@ -1,0 +1,148 @@
+#!/usr/bin/env python
+"""bench.py — LM iterations/s and ms per graph solve on the 200-keyframe x 50k-landmark VIO window.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one full graph solve (bsgpu_solve) of BASELINE.json config 2 — the 200 KF x 50 k
+landmark synthetic visual-inertial window of SURVEY.md §8d — from its device-resident initial guess
+with the solver options the reference ships (beam_slam_launch/config/vio.yaml:7-17: <= 10 LM
+iterations, tolerances 1.5e-7; the 0.05 s wall-clock clip is lifted so every step does the same
+work).  Inputs are resident in HBM before the timed region (bsgpu_finalize + bsgpu_reset_values
+are device-side).  value = LM iterations (trust-region steps computed) of all ranks / wall time.
+
+N > 1: one process per GPU (launched by torch.distributed.run); every rank solves its own
+independent window (BASELINE config 5: seeds +10 + rank) — the path shards by window, there is no
+data-path collective; torch.distributed (RCCL) is used for the barriers and the max-over-ranks.
+
+The JSON line also carries
+  roofline     — the reprojection Jacobian-evaluation kernel: algorithmic bytes / HIP-event time
+  cpu_baseline — the CPU oracle (own restatement, kind "port") on the same window, rank 0, N=1
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--n-kf", type=int, default=200)
+    ap.add_argument("--n-lm", type=int, default=50000)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from beam_slam_amd import synthetic
+    from beam_slam_amd.gpu import GpuSolver
+
+    # ---- workload: C2 at N=1, C5 instances (independent C2-shaped windows) at N>1 ----------------
+    if world == 1:
+        pr = synthetic.vio_window(n_kf=args.n_kf, n_lm=args.n_lm, seed=20250620)
+        workload = "C2: %d-keyframe x %d-landmark VIO window" % (args.n_kf, args.n_lm)
+    else:
+        pr = synthetic.vio_window(n_kf=args.n_kf, n_lm=args.n_lm, seed=20250620 + 10 + rank)
+        workload = "C5: %d independent C2 windows (%d KF x %d landmarks each)" % (world, args.n_kf, args.n_lm)
+    g = GpuSolver(local_rank)
+    pr.load(g)
+    g.finalize()
+    opt = g.options_vio()
+    opt.max_solver_time_in_seconds = 0.0  # every step does the full <= 10 iterations
+
+    def barrier():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def one_step():
+        g.reset_values()
+        return g.solve(opt)
+
+    for _ in range(args.warmup):
+        s = one_step()
+    barrier()
+    t0 = time.perf_counter()
+    n_it = 0
+    dev_s = 0.0
+    for _ in range(args.steps):
+        s = one_step()           # bsgpu_solve returns after its final stream synchronisation
+        n_it += s.num_linear_solves
+        dev_s += s.device_time_in_seconds
+    barrier()
+    dt = time.perf_counter() - t0
+
+    tot_it, max_dt = float(n_it), dt
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        k = torch.tensor([float(n_it)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(k, op=dist.ReduceOp.SUM)
+        tot_it, max_dt = float(k.item()), float(t.item())
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant HBM-bound kernel: reprojection Jacobian evaluation ---------
+        reps = 50
+        ms = g.time_reproj_jacobian_ms(reps)          # HIP events on the solver's own stream
+        nbytes = g.reproj_jacobian_bytes()
+        achieved = nbytes / (ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "reproj_eval_kernel<true>", "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "bytes_per_launch": int(nbytes), "ms_per_launch": round(ms, 5), "traffic": None}
+        out = {
+            "metric": "LM iterations/sec + ms/graph-solve, 200KF x 50k-landmark VIO window",
+            "value": round(tot_it / max_dt, 2), "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * max_dt / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": workload, "n_obs": int(pr.meta["n_obs"]), "n_imu_factors": int(pr.meta["n_imu"]),
+                       "lm_iterations_per_solve": round(n_it / args.steps, 2),
+                       "solver_options": "vio.yaml:7-17, max_solver_time lifted",
+                       "final_cost": s.final_cost, "initial_cost": s.initial_cost,
+                       "device_ms_per_solve": round(1e3 * dev_s / args.steps, 3),
+                       "parallelism": "1 window per GPU, no collective" if world > 1 else "single GPU"},
+            "roofline": roofline,
+        }
+        # ---- CPU baseline: the oracle on the same window (bounded: one solve, same options) ------
+        if world == 1 and not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            from oracle import Oracle
+            o = Oracle()
+            pr.load(o)
+            t1 = time.perf_counter()
+            so = o.solve(opt)
+            cpu_dt = time.perf_counter() - t1
+            out["cpu_baseline"] = {
+                "value": round(so.num_linear_solves / cpu_dt, 3), "unit": "LM iterations/s", "cores": o.threads,
+                "kind": "port", "ms_per_solve": round(1e3 * cpu_dt, 1), "final_cost": so.final_cost,
+                "sample": "one full solve (%d LM iterations) of the same window, OpenMP oracle" % so.num_linear_solves}
+            out["config"]["final_cost_rel_diff_vs_cpu"] = abs(s.final_cost - so.final_cost) / so.final_cost
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+if __name__ == "__main__":
+    main()

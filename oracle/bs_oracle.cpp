@@ -342,7 +342,11 @@ static double evaluate(Ctx& c, const double* x, bool want_J, double* fixed_cost)
     for (int f = 0; f < g.n; ++f) {
       const int32_t* idx = &g.idx[(size_t)f * ti.nidx];
       const double* k = &g.consts[(size_t)f * ti.nconst];
-      double* r = &g.r[(size_t)f * m];
+      // a cost-only evaluation (the candidate point) must not disturb residuals_/jacobian_ of the
+      // current point: Ceres evaluates the candidate into scratch (TrustRegionMinimizer::
+      // ComputeCandidatePointAndEvaluateCost passes NULL for residuals/jacobian)
+      double r_scratch[15];
+      double* r = want_J ? &g.r[(size_t)f * m] : r_scratch;
       double* J = want_J ? &g.J[(size_t)f * m * tw] : nullptr;
       eval_factor(c, t, idx, k, x, r, J, tw);
       double s = 0;

@@ -26,17 +26,38 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         _LIB = ctypes.CDLL(build())
         _LIB.bso_quat_plus.argtypes = [ctypes.POINTER(ctypes.c_double)] * 3
         _LIB.bso_plus_jacobian.argtypes = [ctypes.POINTER(ctypes.c_double)] * 2
     return _LIB
 
 
+def usable_cpus(cap=64):
+    """CPUs this process may really use: affinity mask and cgroup quota both count (an OpenMP team
+    larger than that spins on descheduled threads and crawls)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, min(n, cap))
+
+
 class Oracle(capi.Solver):
     def __init__(self, threads=None):
         super().__init__(lib(), "bso_")
-        if threads:
-            lib().bso_set_num_threads(self._ctx, int(threads))
+        self.threads = int(threads) if threads else usable_cpus()
+        lib().bso_set_num_threads(ctypes.c_void_p(self._ctx), self.threads)
 
     def set_reproj_mode(self, mode):
         """0 closed-form Jacobian, 1 the reference's forward-difference quaternion Jacobian
