@@ -12,6 +12,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -86,6 +87,11 @@ struct bsgpu_ctx {
   double *d_delta = nullptr, *d_y = nullptr, *d_scal = nullptr, *d_part = nullptr;
   double* h_scal = nullptr;  // pinned
   int* d_tiles = nullptr;
+  int *d_panel_off = nullptr, *d_panel_cnt = nullptr;
+  double* d_Vinv = nullptr;
+  double* d_Lp = nullptr;  // shadow of S holding the off-diagonal L panels (k_chol.hip)
+  std::vector<int> h_tiles;
+  bool chol_v1 = false;
   std::vector<int> panel_off, panel_cnt, first_col_tile;
   int n_panels = 0;
   std::vector<bsgpu_iteration> iters;
@@ -302,7 +308,7 @@ int finalize(bsgpu_ctx* c) {
     std::stable_sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.key < b.key; });
     std::vector<int> seg_ci, seg_cj, seg_start, ent_fa(ents.size()), ent_fb(ents.size());
     for (size_t i = 0; i < ents.size(); ++i) {
-      if (i == 0 || ents[i].key != ents[i - 1].key) {
+      if (i == 0 || ents[i].key != ents[i - 1].key || (int)i - seg_start.back() >= 256) {
         seg_ci.push_back((int)(ents[i].key / ncp)); seg_cj.push_back((int)(ents[i].key % ncp)); seg_start.push_back((int)i);
       }
       ent_fa[i] = ents[i].fa; ent_fb[i] = ents[i].fb;
@@ -372,8 +378,8 @@ int finalize(bsgpu_ctx* c) {
     c->h_small_active[t] = active;
     sg.r = c->alloc<double>((size_t)g.n * ti.m);
     sg.J = c->alloc<double>((size_t)g.n * ti.m * 3 * ti.nvar);
-    c->d_small_part[t] = c->alloc<double>(g.n);
-    part_max = std::max(part_max, (size_t)g.n);
+    c->d_small_part[t] = c->alloc<double>((size_t)g.n * ti.m);
+    part_max = std::max(part_max, (size_t)g.n * ti.m);
   }
   if (losses.size() >= (1u << kMetaLossBits)) return fail(c, BSGPU_ERR_UNSUPPORTED, "too many distinct loss functions");
   c->d_cams = c->upload(cams);
@@ -416,6 +422,12 @@ int finalize(bsgpu_ctx* c) {
       c->panel_cnt[k] = (int)tiles.size() - c->panel_off[k];
     }
     c->d_tiles = c->upload(tiles);
+    c->h_tiles = tiles;
+    c->d_panel_off = c->upload(c->panel_off);
+    c->d_panel_cnt = c->upload(c->panel_cnt);
+    c->d_Vinv = c->alloc<double>((size_t)std::max(1, c->n_panels) * 1024);
+    c->chol_v1 = getenv("BSGPU_CHOL_V1") != nullptr;
+    if (!c->chol_v1) { c->d_Lp = c->alloc<double>((size_t)c->npad * c->npad); if (!c->d_Lp) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (L panels)"); }
   }
   HIPCHK(c, hipDeviceSynchronize());
   HIPCHK(c, hipGetLastError());
@@ -458,17 +470,81 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
   }
 }
 
+// Cholesky of the (padded, rhs-augmented) reduced system in S and the solve L^T y = y'.
+void dense_factor_solve(hipStream_t s, bool v1, double* S, double* Lp, double* Vinv, int npad, int n_pose, int n_panels,
+                        const std::vector<int>& h_tiles, const std::vector<int>& panel_off, const std::vector<int>& panel_cnt,
+                        const std::vector<int>& first_col_tile, const int* d_tiles, const int* d_panel_off,
+                        const int* d_panel_cnt, double* y, double* scal) {
+  if (v1) {
+    for (int k = 0; k < n_panels; ++k) {
+      launch_chol_panel(s, S, npad, k, n_pose, d_tiles + panel_off[k], panel_cnt[k], scal);
+      launch_chol_update(s, S, npad, k, d_tiles + panel_off[k], panel_cnt[k]);
+    }
+  } else if (n_panels > 0) {
+    launch_chol_potrf_tile(s, S, npad, 0, n_pose, Vinv, scal);
+    for (int k = 0; k < n_panels; ++k) {
+      const int cnt = panel_cnt[k];
+      const bool la = (k + 1 < n_panels) && cnt > 0 && h_tiles[panel_off[k]] == k + 1;
+      launch_chol_panel_step(s, S, Lp, npad, k, n_pose, d_tiles + panel_off[k], cnt, la ? 1 : 0, Vinv, scal);
+      if (k + 1 < n_panels && !la) launch_chol_potrf_tile(s, S, npad, k + 1, n_pose, Vinv, scal);
+    }
+  }
+  // y' = the rhs row after forward substitution.  Version 2 publishes off-diagonal L panels (the rhs
+  // row included) in the shadow matrix Lp; only the part inside the rhs row's own diagonal tile is in S.
+  const int rhs_col0 = std::min(n_pose, (n_pose / 64) * 64);
+  if (v1 || rhs_col0 == 0) {
+    (void)hipMemcpyAsync(y, S + (size_t)n_pose * npad, sizeof(double) * n_pose, hipMemcpyDeviceToDevice, s);
+  } else {
+    (void)hipMemcpyAsync(y, Lp + (size_t)n_pose * npad, sizeof(double) * rhs_col0, hipMemcpyDeviceToDevice, s);
+    if (n_pose > rhs_col0)
+      (void)hipMemcpyAsync(y + rhs_col0, S + (size_t)n_pose * npad + rhs_col0, sizeof(double) * (n_pose - rhs_col0),
+                           hipMemcpyDeviceToDevice, s);
+  }
+  if (v1) {
+    for (int kb = n_panels - 1; kb >= 0; --kb) launch_backsolve_step(s, S, npad, kb, n_pose, y, first_col_tile[kb] * 64);
+  } else {
+    launch_chol_backsolve(s, S, Lp, npad, n_panels, n_pose, d_tiles, d_panel_off, d_panel_cnt, y);
+  }
+}
+
 void linear_solve_and_candidate(bsgpu_ctx* c) {
   hipStream_t s = c->stream;
   launch_zero(s, c->d_scal + SC_CHOL_FAIL, 1);
-  for (int k = 0; k < c->n_panels; ++k) {
-    launch_chol_panel(s, c->d_S, c->npad, k, c->n_pose, c->d_tiles + c->panel_off[k], c->panel_cnt[k], c->d_scal);
-    launch_chol_update(s, c->d_S, c->npad, k, c->d_tiles + c->panel_off[k], c->panel_cnt[k]);
+  std::vector<double> dbgS;
+  const bool dbg = getenv("BSGPU_CHOL_CHECK") != nullptr && c->n_pose > 0 && c->n_pose <= 4000;
+  if (dbg) {
+    (void)hipStreamSynchronize(s);
+    dbgS.resize((size_t)c->npad * c->npad);
+    (void)hipMemcpy(dbgS.data(), c->d_S, sizeof(double) * dbgS.size(), hipMemcpyDeviceToHost);
   }
   if (c->n_pose > 0) {
-    (void)hipMemcpyAsync(c->d_y, c->d_S + (size_t)c->n_pose * c->npad, sizeof(double) * c->n_pose, hipMemcpyDeviceToDevice, s);
-    for (int kb = c->n_panels - 1; kb >= 0; --kb)
-      launch_backsolve_step(s, c->d_S, c->npad, kb, c->n_pose, c->d_y, c->first_col_tile[kb] * 64);
+    dense_factor_solve(s, c->chol_v1, c->d_S, c->d_Lp, c->d_Vinv, c->npad, c->n_pose, c->n_panels, c->h_tiles, c->panel_off,
+                       c->panel_cnt, c->first_col_tile, c->d_tiles, c->d_panel_off, c->d_panel_cnt, c->d_y, c->d_scal);
+    if (dbg) {
+      (void)hipStreamSynchronize(s);
+      const int n = c->n_pose, ld = c->npad;
+      std::vector<double> y(n), L(dbgS), b(n);
+      double flag = 0;
+      (void)hipMemcpy(y.data(), c->d_y, sizeof(double) * n, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(&flag, c->d_scal + SC_CHOL_FAIL, sizeof(double), hipMemcpyDeviceToHost);
+      for (int i = 0; i < n; ++i) b[i] = dbgS[(size_t)n * ld + i];
+      bool ok = true;
+      double minpiv = 1e300;
+      for (int j = 0; j < n && ok; ++j) {
+        double d = L[(size_t)j * ld + j];
+        for (int p = 0; p < j; ++p) d -= L[(size_t)j * ld + p] * L[(size_t)j * ld + p];
+        if (!(d > 0)) { ok = false; std::fprintf(stderr, "[chol-check] host pivot %d = %g\n", j, d); break; }
+        minpiv = std::min(minpiv, d);
+        d = std::sqrt(d); L[(size_t)j * ld + j] = d;
+        for (int i = j + 1; i < n; ++i) { double v = L[(size_t)i * ld + j]; for (int p = 0; p < j; ++p) v -= L[(size_t)i * ld + p] * L[(size_t)j * ld + p]; L[(size_t)i * ld + j] = v / d; }
+      }
+      for (int i = 0; i < n; ++i) { double v = b[i]; for (int p = 0; p < i; ++p) v -= L[(size_t)i * ld + p] * b[p]; b[i] = v / L[(size_t)i * ld + i]; }
+      for (int i = n - 1; i >= 0; --i) { double v = b[i]; for (int p = i + 1; p < n; ++p) v -= L[(size_t)p * ld + i] * b[p]; b[i] = v / L[(size_t)i * ld + i]; }
+      double md = 0, mx = 0; int nan = 0;
+      for (int i = 0; i < n; ++i) { if (!std::isfinite(y[i])) nan++; else md = std::max(md, std::fabs(y[i] - b[i])); mx = std::max(mx, std::fabs(b[i])); }
+      double sym = 0; for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) sym = std::max(sym, std::fabs(dbgS[(size_t)i * ld + j] - dbgS[(size_t)j * ld + i]));
+      std::fprintf(stderr, "[chol-check] n=%d flag=%g host_ok=%d minpiv=%.3e nan=%d maxdiff=%.3e max|y|=%.3e asym=%.3e\n", n, flag, (int)ok, minpiv, nan, md, mx, sym);
+    }
     launch_negate_pose(s, c->n_pose, c->d_y, c->d_delta);
   }
   launch_backsub_landmarks(s, c->vis, c->n_pose, c->d_y, c->d_delta);
@@ -481,7 +557,7 @@ void linear_solve_and_candidate(bsgpu_ctx* c) {
   for (int t = 2; t < BSGPU_F_NUM_TYPES; ++t) {
     if (!c->small[t].n) continue;
     launch_small_mcc(s, c->small[t], c->d_delta, c->d_small_part[t]);
-    launch_sum(s, c->d_small_part[t], c->small[t].n, c->d_scal + SC_MCC, 1);
+    launch_sum(s, c->d_small_part[t], c->small[t].n * c->small[t].m, c->d_scal + SC_MCC, 1);
   }
   int n_part = 0;
   launch_update(s, c->nb, c->d_blk_xoff, c->d_blk_toff, c->d_blk_size, c->d_blk_manifold, c->d_x, c->d_delta, c->d_xcand,
@@ -880,6 +956,53 @@ int64_t bsgpu_reproj_jacobian_bytes(const bsgpu_ctx* c) {
   // per factor: 16 B (3 offsets + meta) + 16 B pixel + 8 B weight in, 16 B residual + 144 B Jacobian out;
   // plus every parameter block once
   return (int64_t)c->vis.n * 200 + (int64_t)c->h_x.size() * 8;
+}
+
+// Stand-alone dense SPD solve A x = b through the same kernels the reduced camera system uses
+// (test + measurement hook for the MFMA path).  Host pointers in and out.
+int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, double* x, int32_t use_v1, double* ms_out) {
+  if (n <= 0 || !A || !b || !x) return BSGPU_ERR_INVALID;
+  if (hipSetDevice(device) != hipSuccess) return BSGPU_ERR_DEVICE;
+  const int npad = ((n + 1 + 63) / 64) * 64, T = npad / 64, n_panels = (n + 63) / 64;
+  std::vector<double> hS((size_t)npad * npad, 0.0);
+  for (int i = 0; i < n; ++i) std::memcpy(&hS[(size_t)i * npad], A + (size_t)i * n, sizeof(double) * n);
+  std::memcpy(&hS[(size_t)n * npad], b, sizeof(double) * n);
+  for (int i = n; i < npad; ++i) hS[(size_t)i * npad + i] = 1.0;
+  std::vector<int> tiles, panel_off(n_panels), panel_cnt(n_panels), fct(T, 0);
+  for (int k = 0; k < n_panels; ++k) { panel_off[k] = (int)tiles.size(); for (int t = k + 1; t < T; ++t) tiles.push_back(t); panel_cnt[k] = (int)tiles.size() - panel_off[k]; }
+  double *dS = nullptr, *dLp = nullptr, *dV = nullptr, *dy = nullptr, *dscal = nullptr;
+  int *dt = nullptr, *dpo = nullptr, *dpc = nullptr;
+  hipStream_t s;
+  if (hipStreamCreate(&s) != hipSuccess) return BSGPU_ERR_DEVICE;
+  bool ok = hipMalloc(&dS, sizeof(double) * hS.size()) == hipSuccess && hipMalloc(&dLp, sizeof(double) * hS.size()) == hipSuccess &&
+            hipMalloc(&dV, sizeof(double) * 1024 * n_panels) == hipSuccess && hipMalloc(&dy, sizeof(double) * npad) == hipSuccess &&
+            hipMalloc(&dscal, sizeof(double) * SC_NUM) == hipSuccess && hipMalloc(&dt, sizeof(int) * (tiles.size() + 1)) == hipSuccess &&
+            hipMalloc(&dpo, sizeof(int) * n_panels) == hipSuccess && hipMalloc(&dpc, sizeof(int) * n_panels) == hipSuccess;
+  int rc = BSGPU_OK;
+  if (ok) {
+    (void)hipMemcpy(dS, hS.data(), sizeof(double) * hS.size(), hipMemcpyHostToDevice);
+    (void)hipMemcpy(dt, tiles.data(), sizeof(int) * tiles.size(), hipMemcpyHostToDevice);
+    (void)hipMemcpy(dpo, panel_off.data(), sizeof(int) * n_panels, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dpc, panel_cnt.data(), sizeof(int) * n_panels, hipMemcpyHostToDevice);
+    (void)hipMemset(dscal, 0, sizeof(double) * SC_NUM);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, s);
+    dense_factor_solve(s, use_v1 != 0, dS, dLp, dV, npad, n, n_panels, tiles, panel_off, panel_cnt, fct, dt, dpo, dpc, dy, dscal);
+    (void)hipEventRecord(e1, s);
+    if (hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess) rc = BSGPU_ERR_DEVICE;
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (ms_out) *ms_out = ms;
+    double hscal[SC_NUM];
+    (void)hipMemcpy(hscal, dscal, sizeof(hscal), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(x, dy, sizeof(double) * n, hipMemcpyDeviceToHost);
+    if (rc == BSGPU_OK && hscal[SC_CHOL_FAIL] > 0.0) rc = BSGPU_ERR_NUMERIC;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  } else rc = BSGPU_ERR_DEVICE;
+  (void)hipFree(dS); (void)hipFree(dLp); (void)hipFree(dV); (void)hipFree(dy); (void)hipFree(dscal); (void)hipFree(dt); (void)hipFree(dpo); (void)hipFree(dpc);
+  (void)hipStreamDestroy(s);
+  return rc;
 }
 
 }  // extern "C"

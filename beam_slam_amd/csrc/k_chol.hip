@@ -1,0 +1,340 @@
+// Blocked FP64 Cholesky of the reduced camera system on gfx950, version 2: one kernel per 64-wide panel.
+//
+//   chol_potrf_tile   factor one 64x64 diagonal tile (used for tile 0 and for tiles no panel step
+//                     reaches); writes L and the inverses of its four 16x16 diagonal blocks
+//   chol_panel_step   workgroup (i, j), j <= i, over the row tiles the envelope keeps active in panel k:
+//                       X_i = A_ik L_kk^-T, X_j = A_jk L_kk^-T   (block substitution, MFMA)
+//                       C_ij -= X_i X_j^T                          (MFMA)
+//                     the workgroup that owns tile (k+1, k+1) factors it right away (look-ahead), so the
+//                     dependent chain potrf -> trsm -> update -> potrf costs one launch per panel
+//   chol_backsolve    L^T y = y' in ONE workgroup marching up the panels (y' = rhs row carried through
+//                     the factorisation as row n_pose)
+//
+// All matrix products run on v_mfma_f64_16x16x4_f64:  a = A[lane&15][lane>>4], b = B[lane>>4][lane&15],
+// d[reg] = D[(lane>>4) + 4 reg][lane&15].  The 16x16 diagonal blocks are factored in registers of one
+// wave (row per lane, v_readlane broadcasts), the only scalar dependent chain left.
+#include "bsgpu_device.h"
+
+namespace bsg {
+
+namespace {
+
+constexpr int NB = 64;
+constexpr int LDT = 66;  // LDS row pitch of a 64x64 tile: conflict-free ds_read_b64 for the MFMA fragments
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+BSG_DEV double readlane_d(double v, int src_lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
+// D += sign * A B^T over k in [0, K): A rows = 16 rows at sA (pitch lda), B rows = 16 rows at sB (pitch ldb)
+template <int K>
+BSG_DEV double4_t mfma_abt(double4_t acc, const double* sA, int lda, const double* sB, int ldb, double sign, int lane) {
+  const int r = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int k = 0; k < K; k += 4) {
+    const double a = sign * sA[r * lda + k + kq];
+    const double b = sB[r * ldb + k + kq];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+  return acc;
+}
+BSG_DEV double4_t load_d(const double* s, int ld, int lane) {
+  double4_t v;
+  const int r0 = lane >> 4, c = lane & 15;
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) v[reg] = s[(r0 + 4 * reg) * ld + c];
+  return v;
+}
+BSG_DEV void store_d(double* s, int ld, int lane, double4_t v) {
+  const int r0 = lane >> 4, c = lane & 15;
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) s[(r0 + 4 * reg) * ld + c] = v[reg];
+}
+
+// Factor the 64x64 tile in sC (lower triangle meaningful, pitch LDT) in place; the four inverse
+// diagonal blocks go to sV (4 x 16 x 16, row-major, lower).  Whole workgroup (256 threads).
+// Returns (in every thread) whether a non-positive / non-finite pivot was met.
+BSG_DEV bool potrf64_lds(double* sC, double* sV, double* sInvD /* 16 */, int tid, int nreal) {
+  const int lane = tid & 63, wave = tid >> 6;
+  bool bad = false;
+#pragma unroll 1
+  for (int b = 0; b < 4; ++b) {
+    double* D = sC + (16 * b) * LDT + 16 * b;
+    if (wave == 0) {
+      // (1) 16x16 diagonal block in registers: lane r (r = lane & 15) owns row r
+      const int r = lane & 15;
+      double a[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) a[c] = D[r * LDT + c];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        // columns >= nreal (rhs row, padding) are unit pivots: the rhs row's own diagonal entry has
+        // collected -|y'|^2 from the trailing updates and must not be used
+        const double d = (16 * b + j < nreal) ? readlane_d(a[j], j) : 1.0;
+        if (16 * b + j >= nreal) a[j] = (r == j) ? 1.0 : 0.0;
+        if (!(d > 0.0) || !(d < 1.7e308)) bad = true;
+        const double inv = 1.0 / sqrt(d);
+        if (lane == 0) sInvD[j] = inv;
+        a[j] = a[j] * inv;
+#pragma unroll
+        for (int c = j + 1; c < 16; ++c) {
+          const double lc = readlane_d(a[j], c);
+          a[c] -= a[j] * lc;
+        }
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) D[r * LDT + c] = (c <= r) ? a[c] : 0.0;
+      }
+      __builtin_amdgcn_wave_barrier();
+      // (2) rows below: X L_bb^T = A, one lane per row (at most 48), L_bb broadcast from LDS
+      const int nbelow = 16 * (3 - b);
+      if (lane < nbelow) {
+        double* Xr = sC + (16 * (b + 1) + lane) * LDT + 16 * b;
+        double x[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) x[c] = Xr[c];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          double s = x[j];
+#pragma unroll
+          for (int p = 0; p < j; ++p) s -= x[p] * D[j * LDT + p];
+          x[j] = s * sInvD[j];
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) Xr[c] = x[c];
+      }
+    }
+    __syncthreads();
+    // (3) trailing update C_rc -= X_rb X_cb^T for b < c <= r <= 3 (MFMA, one 16x16 block per wave pass)
+    const int nb = 3 - b;
+    const int npairs = nb * (nb + 1) / 2;
+    for (int p = wave; p < npairs; p += 4) {
+      int rr = 0, acc_cnt = 0;
+      while (acc_cnt + rr + 1 <= p) { acc_cnt += rr + 1; ++rr; }
+      const int cc = p - acc_cnt;
+      const int R = b + 1 + rr, Cc = b + 1 + cc;
+      double* Cblk = sC + (16 * R) * LDT + 16 * Cc;
+      double4_t acc = load_d(Cblk, LDT, lane);
+      acc = mfma_abt<16>(acc, sC + (16 * R) * LDT + 16 * b, LDT, sC + (16 * Cc) * LDT + 16 * b, LDT, -1.0, lane);
+      store_d(Cblk, LDT, lane, acc);
+    }
+    __syncthreads();
+  }
+  // inverses of the four diagonal blocks: wave w, lane c < 16 solves L_ww v = e_c
+  if (lane < 16) {
+    const double* D = sC + (16 * wave) * LDT + 16 * wave;
+    double v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      double s = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < i; ++k) s -= D[i * LDT + k] * v[k];
+      v[i] = s / D[i * LDT + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sV[wave * 256 + i * 16 + lane] = v[i];
+  }
+  __syncthreads();
+  return __syncthreads_or(bad ? 1 : 0) != 0;
+}
+
+// columns >= nreal of a diagonal tile (rhs row, padding) become unit pivots with nothing below
+BSG_DEV void mask_unreal_columns(double* sC, int nreal, int tid) {
+  if (nreal >= NB) return;
+  for (int i = tid; i < NB * NB; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    if (c >= nreal && c <= r) sC[r * LDT + c] = (r == c) ? 1.0 : 0.0;
+  }
+}
+
+BSG_DEV void write_factor(double* S, int ld, int t, const double* sC, const double* sV, double* Vinv, int tid) {
+  for (int i = tid; i < NB * NB; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    if (c <= r) S[(size_t)(t * NB + r) * ld + t * NB + c] = sC[r * LDT + c];
+  }
+  for (int i = tid; i < 4 * 256; i += 256) Vinv[(size_t)t * 1024 + i] = sV[i];
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void chol_potrf_tile_kernel(double* __restrict__ S, int ld, int t, int n_pose,
+                                                              double* __restrict__ Vinv, double* __restrict__ scal) {
+  __shared__ double sC[NB * LDT];
+  __shared__ double sV[4 * 256];
+  __shared__ double sInvD[16];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < NB * NB; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    sC[r * LDT + c] = (c <= r) ? S[(size_t)(t * NB + r) * ld + t * NB + c] : 0.0;
+  }
+  __syncthreads();
+  mask_unreal_columns(sC, min(NB, max(0, n_pose - t * NB)), tid);
+  __syncthreads();
+  const bool bad = potrf64_lds(sC, sV, sInvD, tid, min(NB, max(0, n_pose - t * NB)));
+  if (bad && tid == 0) scal[SC_CHOL_FAIL] = 1.0;
+  write_factor(S, ld, t, sC, sV, Vinv, tid);
+}
+
+// X = A L^-T by 16-column block substitution, in place in sA (64 x 64, pitch LDT); wave w owns rows
+// 16w..16w+15.  sL = L_kk (pitch LDT), sV = its inverse diagonal blocks, sT = 4 x (16 x 17) scratch.
+BSG_DEV void trsm_tile(double* sA, const double* sL, const double* sV, double* sT, int lane, int wave) {
+  double* rows = sA + (16 * wave) * LDT;
+  double* T = sT + wave * (16 * 17);
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    double4_t acc = load_d(rows + 16 * b, LDT, lane);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c < b) acc = mfma_abt<16>(acc, rows + 16 * c, LDT, sL + (16 * b) * LDT + 16 * c, LDT, -1.0, lane);
+    store_d(T, 17, lane, acc);
+    __builtin_amdgcn_wave_barrier();
+    double4_t x = {0.0, 0.0, 0.0, 0.0};
+    x = mfma_abt<16>(x, T, 17, sV + b * 256, 16, 1.0, lane);
+    __builtin_amdgcn_wave_barrier();
+    store_d(rows + 16 * b, LDT, lane, x);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+__global__ __launch_bounds__(256) void chol_panel_step_kernel(double* __restrict__ S, double* __restrict__ Lp, int ld,
+                                                              int k, int n_pose, const int* __restrict__ row_tiles,
+                                                              int lookahead, double* __restrict__ Vinv,
+                                                              double* __restrict__ scal) {
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (bj > bi) return;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* sXi = smem;                 // 64 x LDT
+  double* sXj = sXi + NB * LDT;       // 64 x LDT
+  double* sL = sXj + NB * LDT;        // 64 x LDT
+  double* sV = sL + NB * LDT;         // 4 x 256
+  double* sT = sV + 4 * 256;          // 4 x 16 x 17
+  double* sInvD = sT + 4 * 16 * 17;   // 16
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ti = row_tiles[bi], tj = row_tiles[bj];
+  const int ri = ti * NB, rj = tj * NB, c0 = k * NB;
+  const bool diag = bi == bj;
+  for (int i = tid; i < NB * NB; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    sXi[r * LDT + c] = S[(size_t)(ri + r) * ld + c0 + c];
+    if (!diag) sXj[r * LDT + c] = S[(size_t)(rj + r) * ld + c0 + c];
+    sL[r * LDT + c] = (c <= r) ? S[(size_t)(c0 + r) * ld + c0 + c] : 0.0;
+  }
+  for (int i = tid; i < 4 * 256; i += 256) sV[i] = Vinv[(size_t)k * 1024 + i];
+  __syncthreads();
+  trsm_tile(sXi, sL, sV, sT, lane, wave);
+  if (!diag) trsm_tile(sXj, sL, sV, sT, lane, wave);
+  __syncthreads();
+  const double* Xj = diag ? sXi : sXj;
+  // C_ij -= X_i X_j^T ; wave w owns rows 16w.. of the 64x64 tile
+  double4_t acc[4];
+  const int crow = lane >> 4, ccol = lane & 15;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg)
+      acc[t][reg] = S[(size_t)(ri + 16 * wave + crow + 4 * reg) * ld + rj + 16 * t + ccol];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    acc[t] = mfma_abt<64>(acc[t], sXi + (16 * wave) * LDT, LDT, Xj + (16 * t) * LDT, LDT, -1.0, lane);
+  const bool factor_next = diag && lookahead && ti == k + 1;
+  if (!factor_next) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg)
+        S[(size_t)(ri + 16 * wave + crow + 4 * reg) * ld + rj + 16 * t + ccol] = acc[t][reg];
+  }
+  if (diag) {
+    // this workgroup publishes the L panel of its row tile — into the shadow matrix Lp, NOT in place:
+    // the other workgroups of this launch still read A(i, k) from S
+    for (int i = tid; i < NB * NB; i += 256) {
+      const int r = i >> 6, c = i & 63;
+      Lp[(size_t)(ri + r) * ld + c0 + c] = sXi[r * LDT + c];
+    }
+  }
+  if (factor_next) {
+    // look-ahead: tile (k+1, k+1) is final now — factor it here instead of in a launch of its own
+    __syncthreads();
+    double* sC = sXj;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) store_d(sC + (16 * wave) * LDT + 16 * t, LDT, lane, acc[t]);
+    __syncthreads();
+    for (int i = tid; i < NB * NB; i += 256) { const int r = i >> 6, c = i & 63; if (c > r) sC[r * LDT + c] = 0.0; }
+    mask_unreal_columns(sC, min(NB, max(0, n_pose - ti * NB)), tid);
+    __syncthreads();
+    const bool bad = potrf64_lds(sC, sV, sInvD, tid, min(NB, max(0, n_pose - ti * NB)));
+    if (bad && tid == 0) scal[SC_CHOL_FAIL] = 1.0;
+    write_factor(S, ld, ti, sC, sV, Vinv, tid);
+  }
+}
+
+constexpr size_t kPanelStepLds = sizeof(double) * (3 * NB * LDT + 4 * 256 + 4 * 16 * 17 + 16);
+
+void launch_chol_potrf_tile(hipStream_t s, double* S, int ld, int t, int n_pose, double* Vinv, double* scal) {
+  hipLaunchKernelGGL(chol_potrf_tile_kernel, dim3(1), dim3(256), 0, s, S, ld, t, n_pose, Vinv, scal);
+}
+void launch_chol_panel_step(hipStream_t s, double* S, double* Lp, int ld, int k, int n_pose, const int* row_tiles_dev,
+                            int n_rows, int lookahead, double* Vinv, double* scal) {
+  if (n_rows <= 0) return;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_panel_step_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPanelStepLds);
+  hipLaunchKernelGGL(chol_panel_step_kernel, dim3(n_rows, n_rows), dim3(256), kPanelStepLds, s, S, Lp, ld, k, n_pose,
+                     row_tiles_dev, lookahead, Vinv, scal);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward substitution in one workgroup.  For kb = last panel .. 0:
+//   rhs = y'[kb] - sum_{t in rows(kb)} L(t, kb)^T y[t]   (coalesced row reads, 4 row groups)
+//   solve L_kk^T y_kb = rhs                                (one wave, shuffle chain)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void chol_backsolve_kernel(const double* __restrict__ S, const double* __restrict__ Lp,
+                                                             int ld, int n_panels, int n_pose,
+                                                             const int* __restrict__ tiles, const int* __restrict__ panel_off,
+                                                             const int* __restrict__ panel_cnt, double* __restrict__ y) {
+  __shared__ double sL[NB * (NB + 1)];
+  __shared__ double sp[4][NB];
+  const int tid = threadIdx.x, c = tid & 63, part = tid >> 6;
+  for (int kb = n_panels - 1; kb >= 0; --kb) {
+    const int c0 = kb * NB;
+    for (int i = tid; i < NB * NB; i += 256) {
+      const int r = i >> 6, cc = i & 63;
+      sL[r * (NB + 1) + cc] = (cc <= r) ? S[(size_t)(c0 + r) * ld + c0 + cc] : 0.0;
+    }
+    double acc = 0.0;
+    const int cnt = panel_cnt[kb], off = panel_off[kb];
+    for (int q = 0; q < cnt; ++q) {
+      const int r0 = tiles[off + q] * NB;
+#pragma unroll 4
+      for (int r = part; r < NB; r += 4) {
+        const int row = r0 + r;
+        if (row < n_pose) acc += Lp[(size_t)row * ld + c0 + c] * y[row];
+      }
+    }
+    sp[part][c] = acc;
+    __syncthreads();
+    if (tid < NB) {
+      double yv = (c0 + tid < n_pose) ? (y[c0 + tid] - (sp[0][tid] + sp[1][tid] + sp[2][tid] + sp[3][tid])) : 0.0;
+      for (int j = NB - 1; j >= 0; --j) {
+        const double yj = __shfl(yv, j, 64) / sL[j * (NB + 1) + j];
+        if (tid == j) yv = yj;
+        if (tid < j) yv -= sL[j * (NB + 1) + tid] * yj;
+      }
+      if (c0 + tid < n_pose) y[c0 + tid] = yv;
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+
+void launch_chol_backsolve(hipStream_t s, const double* S, const double* Lp, int ld, int n_panels, int n_pose,
+                           const int* tiles, const int* panel_off, const int* panel_cnt, double* y) {
+  if (n_panels <= 0) return;
+  hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1), dim3(256), 0, s, S, Lp, ld, n_panels, n_pose, tiles, panel_off,
+                     panel_cnt, y);
+}
+
+}  // namespace bsg

@@ -272,13 +272,24 @@ __global__ __launch_bounds__(64) void pairs_kernel(int n_seg, const int* __restr
   const int beg = seg_start[seg], end = seg_start[seg + 1];
   for (int e = beg + lane; e < end; e += 64) {
     const int fa = ent_fa[e], fb = ent_fb[e];
-    const double* Ja = J + (size_t)fa * 18;
-    const double* Jb = J + (size_t)fb * 18;
-    const double* Ca = CR + (size_t)fa * 8;
-    const double* Cb = CR + (size_t)fb * 8;
-    double A0[6], A1[6], B0[6], B1[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) { A0[k] = Ja[k]; A1[k] = Ja[9 + k]; B0[k] = Jb[k]; B1[k] = Jb[9 + k]; }
+    // 16-byte loads of the AoS rows: J row = 9 double2 (A = elements 0..5 and 9..14), CR row = 4 double2
+    const double2* Ja = reinterpret_cast<const double2*>(J + (size_t)fa * 18);
+    const double2* Jb = reinterpret_cast<const double2*>(J + (size_t)fb * 18);
+    const double2* Ca2 = reinterpret_cast<const double2*>(CR + (size_t)fa * 8);
+    const double2* Cb2 = reinterpret_cast<const double2*>(CR + (size_t)fb * 8);
+    double A0[6], A1[6], B0[6], B1[6], Ca[8], Cb[6];
+    {
+      const double2 a0 = Ja[0], a1 = Ja[1], a2 = Ja[2], a4 = Ja[4], a5 = Ja[5], a6 = Ja[6], a7 = Ja[7];
+      A0[0] = a0.x; A0[1] = a0.y; A0[2] = a1.x; A0[3] = a1.y; A0[4] = a2.x; A0[5] = a2.y;
+      A1[0] = a4.y; A1[1] = a5.x; A1[2] = a5.y; A1[3] = a6.x; A1[4] = a6.y; A1[5] = a7.x;
+      const double2 b0 = Jb[0], b1 = Jb[1], b2 = Jb[2], b4 = Jb[4], b5 = Jb[5], b6 = Jb[6], b7 = Jb[7];
+      B0[0] = b0.x; B0[1] = b0.y; B0[2] = b1.x; B0[3] = b1.y; B0[4] = b2.x; B0[5] = b2.y;
+      B1[0] = b4.y; B1[1] = b5.x; B1[2] = b5.y; B1[3] = b6.x; B1[4] = b6.y; B1[5] = b7.x;
+      const double2 c0 = Ca2[0], c1 = Ca2[1], c2 = Ca2[2], c3 = Ca2[3];
+      Ca[0] = c0.x; Ca[1] = c0.y; Ca[2] = c1.x; Ca[3] = c1.y; Ca[4] = c2.x; Ca[5] = c2.y; Ca[6] = c3.x; Ca[7] = c3.y;
+      const double2 d0 = Cb2[0], d1 = Cb2[1], d2 = Cb2[2];
+      Cb[0] = d0.x; Cb[1] = d0.y; Cb[2] = d1.x; Cb[3] = d1.y; Cb[4] = d2.x; Cb[5] = d2.y;
+    }
     const double same = (fa == fb) ? 1.0 : 0.0;
     const double t00 = same - (Ca[0] * Cb[0] + Ca[1] * Cb[1] + Ca[2] * Cb[2]);
     const double t01 = -(Ca[0] * Cb[3] + Ca[1] * Cb[4] + Ca[2] * Cb[5]);

@@ -585,32 +585,33 @@ void launch_small_assemble(hipStream_t s, const SmallGroup& g, double* S, int ld
   hipLaunchKernelGGL(small_assemble_kernel, dim3(g.n), dim3(64), 0, s, g, S, ld, rhs_row, grad, hdiag);
 }
 
-// model cost change term of a pose-only group: part[f] = -(J d).(r + J d/2)
+// model cost change term of a pose-only group, one lane per residual row:
+//   part[f*m + k] = -(J_k d) (r_k + J_k d / 2)
 __global__ __launch_bounds__(128) void small_mcc_kernel(SmallGroup g, const double* __restrict__ delta,
                                                         double* __restrict__ part) {
-  const int f = blockIdx.x * 128 + threadIdx.x;
-  if (f >= g.n) return;
+  const int id = blockIdx.x * 128 + threadIdx.x;
+  const int m = g.m;
+  if (id >= g.n * m) return;
+  const int f = id / m, k = id - f * m;
   double acc = 0.0;
   if (g.active[f]) {
-    const int m = g.m, tw = 3 * g.nv;
-    const double* J = g.J + (size_t)f * m * tw;
+    const int tw = 3 * g.nv;
+    const double* J = g.J + ((size_t)f * m + k) * tw;
     const int* to = g.toff + (size_t)f * g.nv;
-    for (int k = 0; k < m; ++k) {
-      double jv = 0.0;
-      for (int sl = 0; sl < g.nv; ++sl) {
-        const int t = to[sl];
-        if (t < 0) continue;
-        jv += J[k * tw + 3 * sl] * delta[t] + J[k * tw + 3 * sl + 1] * delta[t + 1] + J[k * tw + 3 * sl + 2] * delta[t + 2];
-      }
-      acc -= jv * (g.r[(size_t)f * m + k] + 0.5 * jv);
+    double jv = 0.0;
+    for (int sl = 0; sl < g.nv; ++sl) {
+      const int t = to[sl];
+      if (t < 0) continue;
+      jv += J[3 * sl] * delta[t] + J[3 * sl + 1] * delta[t + 1] + J[3 * sl + 2] * delta[t + 2];
     }
+    acc = -jv * (g.r[(size_t)f * m + k] + 0.5 * jv);
   }
-  part[f] = acc;
+  part[id] = acc;
 }
 
 void launch_small_mcc(hipStream_t s, const SmallGroup& g, const double* delta, double* part) {
   if (g.n == 0) return;
-  hipLaunchKernelGGL(small_mcc_kernel, dim3((g.n + 127) / 128), dim3(128), 0, s, g, delta, part);
+  hipLaunchKernelGGL(small_mcc_kernel, dim3((g.n * g.m + 127) / 128), dim3(128), 0, s, g, delta, part);
 }
 
 }  // namespace bsg

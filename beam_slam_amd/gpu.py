@@ -29,7 +29,23 @@ def lib():
         _LIB.bsgpu_time_reproj_jacobian_ms.argtypes = [ctypes.c_void_p, ctypes.c_int32]
         _LIB.bsgpu_reproj_jacobian_bytes.restype = ctypes.c_int64
         _LIB.bsgpu_reproj_jacobian_bytes.argtypes = [ctypes.c_void_p]
+        _LIB.bsgpu_dense_solve.argtypes = [ctypes.c_int, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_int32, ctypes.POINTER(ctypes.c_double)]
     return _LIB
+
+
+def dense_solve(A, b, device=0, use_v1=False):
+    """A x = b (SPD) through the reduced-camera-system kernels; returns (x, milliseconds)."""
+    import numpy as np
+    A = np.ascontiguousarray(A, np.float64)
+    b = np.ascontiguousarray(b, np.float64)
+    x = np.empty_like(b)
+    ms = ctypes.c_double(0.0)
+    rc = lib().bsgpu_dense_solve(device, A.shape[0], A.ctypes.data, b.ctypes.data, x.ctypes.data, 1 if use_v1 else 0,
+                                 ctypes.byref(ms))
+    if rc != 0:
+        raise capi.SolverError(rc, "bsgpu_dense_solve failed")
+    return x, ms.value
 
 
 class GpuSolver(capi.Solver):

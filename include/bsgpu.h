@@ -316,6 +316,12 @@ double bsgpu_time_reproj_jacobian_ms(bsgpu_ctx* ctx, int32_t reps);
 /* Algorithmic bytes one launch of that kernel moves. */
 int64_t bsgpu_reproj_jacobian_bytes(const bsgpu_ctx* ctx);
 
+/* Stand-alone dense SPD solve A x = b (row-major n x n, host pointers) through the kernels the
+ * reduced camera system uses after Schur elimination — test and measurement hook for the FP64
+ * MFMA Cholesky.  use_v1 != 0 selects the first-generation kernels.  ms_out: HIP-event time.    */
+int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, double* x,
+                      int32_t use_v1, double* ms_out);
+
 #ifdef __cplusplus
 }
 #endif
