@@ -181,7 +181,7 @@ int finalize(bsgpu_ctx* c) {
   for (int b = 0; b < nb; ++b) if (!c->is_const[b] && c->is_lm[b]) { c->toff[b] = to; to += 3; lm_index[b] = nl++; }
   c->n_tan = to; c->n_lm = nl;
   c->npad = ((c->n_pose + 1 + 63) / 64) * 64;
-  if ((size_t)c->npad > 16384) return fail(c, BSGPU_ERR_UNSUPPORTED, "reduced camera system larger than 16384: dense exact path not applicable (PCG path pending)");
+  if ((size_t)c->npad > 12288) return fail(c, BSGPU_ERR_UNSUPPORTED, "reduced camera system larger than 12288: dense exact path not applicable (PCG path pending)");
   int row = 0;
   for (int t = 0; t < BSGPU_F_NUM_TYPES; ++t) { c->row0[t] = row; row += c->groups[t].n * kTypes[t].m; }
   c->n_res = row;
@@ -425,7 +425,7 @@ int finalize(bsgpu_ctx* c) {
     c->h_tiles = tiles;
     c->d_panel_off = c->upload(c->panel_off);
     c->d_panel_cnt = c->upload(c->panel_cnt);
-    c->d_Vinv = c->alloc<double>((size_t)std::max(1, c->n_panels) * 1024);
+    c->d_Vinv = c->alloc<double>((size_t)std::max(1, c->n_panels) * chol_vinv_stride());
     c->chol_v1 = getenv("BSGPU_CHOL_V1") != nullptr;
     if (!c->chol_v1) { c->d_Lp = c->alloc<double>((size_t)c->npad * c->npad); if (!c->d_Lp) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (L panels)"); }
   }
@@ -503,7 +503,7 @@ void dense_factor_solve(hipStream_t s, bool v1, double* S, double* Lp, double* V
   if (v1) {
     for (int kb = n_panels - 1; kb >= 0; --kb) launch_backsolve_step(s, S, npad, kb, n_pose, y, first_col_tile[kb] * 64);
   } else {
-    launch_chol_backsolve(s, S, Lp, npad, n_panels, n_pose, d_tiles, d_panel_off, d_panel_cnt, y);
+    launch_chol_backsolve(s, S, Lp, Vinv, npad, n_panels, n_pose, d_tiles, d_panel_off, d_panel_cnt, y);
   }
 }
 
@@ -975,7 +975,7 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
   hipStream_t s;
   if (hipStreamCreate(&s) != hipSuccess) return BSGPU_ERR_DEVICE;
   bool ok = hipMalloc(&dS, sizeof(double) * hS.size()) == hipSuccess && hipMalloc(&dLp, sizeof(double) * hS.size()) == hipSuccess &&
-            hipMalloc(&dV, sizeof(double) * 1024 * n_panels) == hipSuccess && hipMalloc(&dy, sizeof(double) * npad) == hipSuccess &&
+            hipMalloc(&dV, sizeof(double) * chol_vinv_stride() * n_panels) == hipSuccess && hipMalloc(&dy, sizeof(double) * npad) == hipSuccess &&
             hipMalloc(&dscal, sizeof(double) * SC_NUM) == hipSuccess && hipMalloc(&dt, sizeof(int) * (tiles.size() + 1)) == hipSuccess &&
             hipMalloc(&dpo, sizeof(int) * n_panels) == hipSuccess && hipMalloc(&dpc, sizeof(int) * n_panels) == hipSuccess;
   int rc = BSGPU_OK;

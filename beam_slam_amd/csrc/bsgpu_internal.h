@@ -107,8 +107,9 @@ void launch_backsolve_step(hipStream_t s, const double* S, int ld, int kb, int n
 void launch_chol_potrf_tile(hipStream_t s, double* S, int ld, int t, int n_pose, double* Vinv, double* scal);
 void launch_chol_panel_step(hipStream_t s, double* S, double* Lp, int ld, int k, int n_pose, const int* row_tiles_dev,
                             int n_rows, int lookahead, double* Vinv, double* scal);
-void launch_chol_backsolve(hipStream_t s, const double* S, const double* Lp, int ld, int n_panels, int n_pose,
-                           const int* tiles, const int* panel_off, const int* panel_cnt, double* y);
+void launch_chol_backsolve(hipStream_t s, const double* S, const double* Lp, const double* Vinv, int ld, int n_panels,
+                           int n_pose, const int* tiles, const int* panel_off, const int* panel_cnt, double* y);
+int chol_vinv_stride();
 void launch_backsub_landmarks(hipStream_t s, const Visual& v, int n_pose, const double* y_pose, double* delta);
 void launch_negate_pose(hipStream_t s, int n_pose, const double* y, double* delta);
 void launch_mcc(hipStream_t s, const Visual& v, int n_pose, const double* delta, double* part);

@@ -20,7 +20,8 @@ namespace bsg {
 namespace {
 
 constexpr int NB = 64;
-constexpr int LDT = 66;  // LDS row pitch of a 64x64 tile: conflict-free ds_read_b64 for the MFMA fragments
+constexpr int LDT = 66;
+constexpr int kVinvStride = 1024 + 64;  // per tile: 4 inverse 16x16 diagonal blocks + 64 reciprocal pivots  // LDS row pitch of a 64x64 tile: conflict-free ds_read_b64 for the MFMA fragments
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 BSG_DEV double readlane_d(double v, int src_lane) {
@@ -54,58 +55,56 @@ BSG_DEV void store_d(double* s, int ld, int lane, double4_t v) {
   for (int reg = 0; reg < 4; ++reg) s[(r0 + 4 * reg) * ld + c] = v[reg];
 }
 
+// 1/sqrt(d) to double precision: v_rsq_f64 seed (~2^-26) + two Newton steps, all FMA — keeps the
+// per-column dependent chain of the factorisation short (an IEEE sqrt + divide costs ~3x as much)
+BSG_DEV double fast_rsqrt(double d) {
+  double y = __builtin_amdgcn_rsq(d);
+  double t = fma(-d * y, y, 1.0);           // 1 - d y^2
+  y = fma(y * t, fma(t, 0.375, 0.5), y);    // y (1 + t/2 + 3 t^2/8)
+  t = fma(-d * y, y, 1.0);
+  y = fma(y * t, 0.5, y);
+  return y;
+}
+
 // Factor the 64x64 tile in sC (lower triangle meaningful, pitch LDT) in place; the four inverse
-// diagonal blocks go to sV (4 x 16 x 16, row-major, lower).  Whole workgroup (256 threads).
+// diagonal blocks go to sV (4 x 16 x 16, row-major, lower), the 64 reciprocal pivots to sInvD.
+// Whole workgroup (256 threads).  Columns >= nreal (rhs row, padding) are unit pivots.
 // Returns (in every thread) whether a non-positive / non-finite pivot was met.
-BSG_DEV bool potrf64_lds(double* sC, double* sV, double* sInvD /* 16 */, int tid, int nreal) {
+BSG_DEV bool potrf64_lds(double* sC, double* sV, double* sInvD /* 64 */, int tid, int nreal) {
   const int lane = tid & 63, wave = tid >> 6;
   bool bad = false;
 #pragma unroll 1
   for (int b = 0; b < 4; ++b) {
-    double* D = sC + (16 * b) * LDT + 16 * b;
     if (wave == 0) {
-      // (1) 16x16 diagonal block in registers: lane r (r = lane & 15) owns row r
-      const int r = lane & 15;
+      // (1)+(2) right-looking elimination of block column b in registers of one wave: lane l owns tile
+      // row 16b + l (the 16 diagonal-block rows first, then every row below), 16 entries each.  The
+      // pivot row entries travel by v_readlane from lanes 0..15; rows below get their triangular
+      // solve from the very same updates.
+      const int nrows = NB - 16 * b;
+      const int row = 16 * b + ((lane < nrows) ? lane : 0);
+      double* R = sC + row * LDT + 16 * b;
       double a[16];
 #pragma unroll
-      for (int c = 0; c < 16; ++c) a[c] = D[r * LDT + c];
+      for (int c = 0; c < 16; ++c) a[c] = R[c];
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        // columns >= nreal (rhs row, padding) are unit pivots: the rhs row's own diagonal entry has
-        // collected -|y'|^2 from the trailing updates and must not be used
-        const double d = (16 * b + j < nreal) ? readlane_d(a[j], j) : 1.0;
-        if (16 * b + j >= nreal) a[j] = (r == j) ? 1.0 : 0.0;
+        const bool real = (16 * b + j) < nreal;
+        // the rhs row's own diagonal entry has collected -|y'|^2 from the trailing updates: unit pivot
+        const double d = real ? readlane_d(a[j], j) : 1.0;
+        if (!real) a[j] = (lane == j) ? 1.0 : 0.0;
         if (!(d > 0.0) || !(d < 1.7e308)) bad = true;
-        const double inv = 1.0 / sqrt(d);
-        if (lane == 0) sInvD[j] = inv;
+        const double inv = real ? fast_rsqrt(d) : 1.0;
+        if (lane == 0) sInvD[16 * b + j] = inv;
         a[j] = a[j] * inv;
 #pragma unroll
         for (int c = j + 1; c < 16; ++c) {
           const double lc = readlane_d(a[j], c);
-          a[c] -= a[j] * lc;
+          a[c] = fma(-a[j], lc, a[c]);
         }
       }
-      if (lane < 16) {
+      if (lane < nrows) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) D[r * LDT + c] = (c <= r) ? a[c] : 0.0;
-      }
-      __builtin_amdgcn_wave_barrier();
-      // (2) rows below: X L_bb^T = A, one lane per row (at most 48), L_bb broadcast from LDS
-      const int nbelow = 16 * (3 - b);
-      if (lane < nbelow) {
-        double* Xr = sC + (16 * (b + 1) + lane) * LDT + 16 * b;
-        double x[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) x[c] = Xr[c];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          double s = x[j];
-#pragma unroll
-          for (int p = 0; p < j; ++p) s -= x[p] * D[j * LDT + p];
-          x[j] = s * sInvD[j];
-        }
-#pragma unroll
-        for (int c = 0; c < 16; ++c) Xr[c] = x[c];
+        for (int c = 0; c < 16; ++c) R[c] = (lane >= 16 || c <= lane) ? a[c] : 0.0;
       }
     }
     __syncthreads();
@@ -116,10 +115,10 @@ BSG_DEV bool potrf64_lds(double* sC, double* sV, double* sInvD /* 16 */, int tid
       int rr = 0, acc_cnt = 0;
       while (acc_cnt + rr + 1 <= p) { acc_cnt += rr + 1; ++rr; }
       const int cc = p - acc_cnt;
-      const int R = b + 1 + rr, Cc = b + 1 + cc;
-      double* Cblk = sC + (16 * R) * LDT + 16 * Cc;
+      const int Rb = b + 1 + rr, Cc = b + 1 + cc;
+      double* Cblk = sC + (16 * Rb) * LDT + 16 * Cc;
       double4_t acc = load_d(Cblk, LDT, lane);
-      acc = mfma_abt<16>(acc, sC + (16 * R) * LDT + 16 * b, LDT, sC + (16 * Cc) * LDT + 16 * b, LDT, -1.0, lane);
+      acc = mfma_abt<16>(acc, sC + (16 * Rb) * LDT + 16 * b, LDT, sC + (16 * Cc) * LDT + 16 * b, LDT, -1.0, lane);
       store_d(Cblk, LDT, lane, acc);
     }
     __syncthreads();
@@ -132,8 +131,8 @@ BSG_DEV bool potrf64_lds(double* sC, double* sV, double* sInvD /* 16 */, int tid
     for (int i = 0; i < 16; ++i) {
       double s = (i == lane) ? 1.0 : 0.0;
 #pragma unroll
-      for (int k = 0; k < i; ++k) s -= D[i * LDT + k] * v[k];
-      v[i] = s / D[i * LDT + i];
+      for (int k = 0; k < i; ++k) s = fma(-D[i * LDT + k], v[k], s);
+      v[i] = s * sInvD[16 * wave + i];
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) sV[wave * 256 + i * 16 + lane] = v[i];
@@ -151,12 +150,14 @@ BSG_DEV void mask_unreal_columns(double* sC, int nreal, int tid) {
   }
 }
 
-BSG_DEV void write_factor(double* S, int ld, int t, const double* sC, const double* sV, double* Vinv, int tid) {
+BSG_DEV void write_factor(double* S, int ld, int t, const double* sC, const double* sV, const double* sInvD, double* Vinv,
+                          int tid) {
   for (int i = tid; i < NB * NB; i += 256) {
     const int r = i >> 6, c = i & 63;
     if (c <= r) S[(size_t)(t * NB + r) * ld + t * NB + c] = sC[r * LDT + c];
   }
-  for (int i = tid; i < 4 * 256; i += 256) Vinv[(size_t)t * 1024 + i] = sV[i];
+  for (int i = tid; i < 4 * 256; i += 256) Vinv[(size_t)t * kVinvStride + i] = sV[i];
+  if (tid < NB) Vinv[(size_t)t * kVinvStride + 1024 + tid] = sInvD[tid];
 }
 
 }  // namespace
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(256) void chol_potrf_tile_kernel(double* __restrict
                                                               double* __restrict__ Vinv, double* __restrict__ scal) {
   __shared__ double sC[NB * LDT];
   __shared__ double sV[4 * 256];
-  __shared__ double sInvD[16];
+  __shared__ double sInvD[NB];
   const int tid = threadIdx.x;
   for (int i = tid; i < NB * NB; i += 256) {
     const int r = i >> 6, c = i & 63;
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(256) void chol_potrf_tile_kernel(double* __restrict
   __syncthreads();
   const bool bad = potrf64_lds(sC, sV, sInvD, tid, min(NB, max(0, n_pose - t * NB)));
   if (bad && tid == 0) scal[SC_CHOL_FAIL] = 1.0;
-  write_factor(S, ld, t, sC, sV, Vinv, tid);
+  write_factor(S, ld, t, sC, sV, sInvD, Vinv, tid);
 }
 
 // X = A L^-T by 16-column block substitution, in place in sA (64 x 64, pitch LDT); wave w owns rows
@@ -212,18 +213,27 @@ __global__ __launch_bounds__(256) void chol_panel_step_kernel(double* __restrict
   double* sL = sXj + NB * LDT;        // 64 x LDT
   double* sV = sL + NB * LDT;         // 4 x 256
   double* sT = sV + 4 * 256;          // 4 x 16 x 17
-  double* sInvD = sT + 4 * 16 * 17;   // 16
+  double* sInvD = sT + 4 * 16 * 17;   // 64
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ti = row_tiles[bi], tj = row_tiles[bj];
   const int ri = ti * NB, rj = tj * NB, c0 = k * NB;
   const bool diag = bi == bj;
-  for (int i = tid; i < NB * NB; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    sXi[r * LDT + c] = S[(size_t)(ri + r) * ld + c0 + c];
-    if (!diag) sXj[r * LDT + c] = S[(size_t)(rj + r) * ld + c0 + c];
-    sL[r * LDT + c] = (c <= r) ? S[(size_t)(c0 + r) * ld + c0 + c] : 0.0;
+  // 16-byte loads (ld, c0 and the LDS pitch are all multiples of 2 doubles).  The upper triangle of
+  // L_kk in S holds stale values; trsm_tile only reads its strictly-lower 16x16 blocks.
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int i = tid + 256 * q;
+    const int r = i >> 5, c2 = (i & 31) * 2;
+    *reinterpret_cast<double2*>(&sXi[r * LDT + c2]) = *reinterpret_cast<const double2*>(&S[(size_t)(ri + r) * ld + c0 + c2]);
+    if (!diag)
+      *reinterpret_cast<double2*>(&sXj[r * LDT + c2]) = *reinterpret_cast<const double2*>(&S[(size_t)(rj + r) * ld + c0 + c2]);
+    *reinterpret_cast<double2*>(&sL[r * LDT + c2]) = *reinterpret_cast<const double2*>(&S[(size_t)(c0 + r) * ld + c0 + c2]);
   }
-  for (int i = tid; i < 4 * 256; i += 256) sV[i] = Vinv[(size_t)k * 1024 + i];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int i = (tid + 256 * q) * 2;
+    *reinterpret_cast<double2*>(&sV[i]) = *reinterpret_cast<const double2*>(&Vinv[(size_t)k * kVinvStride + i]);
+  }
   __syncthreads();
   trsm_tile(sXi, sL, sV, sT, lane, wave);
   if (!diag) trsm_tile(sXj, sL, sV, sT, lane, wave);
@@ -251,9 +261,11 @@ __global__ __launch_bounds__(256) void chol_panel_step_kernel(double* __restrict
   if (diag) {
     // this workgroup publishes the L panel of its row tile — into the shadow matrix Lp, NOT in place:
     // the other workgroups of this launch still read A(i, k) from S
-    for (int i = tid; i < NB * NB; i += 256) {
-      const int r = i >> 6, c = i & 63;
-      Lp[(size_t)(ri + r) * ld + c0 + c] = sXi[r * LDT + c];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = tid + 256 * q;
+      const int r = i >> 5, c2 = (i & 31) * 2;
+      *reinterpret_cast<double2*>(&Lp[(size_t)(ri + r) * ld + c0 + c2]) = *reinterpret_cast<const double2*>(&sXi[r * LDT + c2]);
     }
   }
   if (factor_next) {
@@ -268,11 +280,11 @@ __global__ __launch_bounds__(256) void chol_panel_step_kernel(double* __restrict
     __syncthreads();
     const bool bad = potrf64_lds(sC, sV, sInvD, tid, min(NB, max(0, n_pose - ti * NB)));
     if (bad && tid == 0) scal[SC_CHOL_FAIL] = 1.0;
-    write_factor(S, ld, ti, sC, sV, Vinv, tid);
+    write_factor(S, ld, ti, sC, sV, sInvD, Vinv, tid);
   }
 }
 
-constexpr size_t kPanelStepLds = sizeof(double) * (3 * NB * LDT + 4 * 256 + 4 * 16 * 17 + 16);
+constexpr size_t kPanelStepLds = sizeof(double) * (3 * NB * LDT + 4 * 256 + 4 * 16 * 17 + 64);
 
 void launch_chol_potrf_tile(hipStream_t s, double* S, int ld, int t, int n_pose, double* Vinv, double* scal) {
   hipLaunchKernelGGL(chol_potrf_tile_kernel, dim3(1), dim3(256), 0, s, S, ld, t, n_pose, Vinv, scal);
@@ -287,54 +299,76 @@ void launch_chol_panel_step(hipStream_t s, double* S, double* Lp, int ld, int k,
 }
 
 // ---------------------------------------------------------------------------------------------------
-// backward substitution in one workgroup.  For kb = last panel .. 0:
-//   rhs = y'[kb] - sum_{t in rows(kb)} L(t, kb)^T y[t]   (coalesced row reads, 4 row groups)
-//   solve L_kk^T y_kb = rhs                                (one wave, shuffle chain)
+// backward substitution in ONE workgroup of 1024 threads; y lives in LDS for the whole march.
+// For kb = last panel .. 0:
+//   rhs = y'[kb] - sum_{t in rows(kb)} L(t, kb)^T y[t]   (16 row groups x 64 columns, loads issued up front)
+//   solve L_kk^T y_kb = rhs                                (one wave, v_readlane chain, reciprocal pivots)
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void chol_backsolve_kernel(const double* __restrict__ S, const double* __restrict__ Lp,
-                                                             int ld, int n_panels, int n_pose,
-                                                             const int* __restrict__ tiles, const int* __restrict__ panel_off,
-                                                             const int* __restrict__ panel_cnt, double* __restrict__ y) {
-  __shared__ double sL[NB * (NB + 1)];
-  __shared__ double sp[4][NB];
+constexpr int kBackMaxN = 8192;  // y in LDS (64 KB)
+
+__global__ __launch_bounds__(1024) void chol_backsolve_kernel(const double* __restrict__ S, const double* __restrict__ Lp,
+                                                              const double* __restrict__ Vinv, int ld, int n_panels,
+                                                              int n_pose, const int* __restrict__ tiles,
+                                                              const int* __restrict__ panel_off,
+                                                              const int* __restrict__ panel_cnt, double* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* sy = smem;                         // npad entries (rows >= n_pose are zero)
+  double* sL = sy + ((n_panels + 1) * NB);   // 64 x 65
+  double* sp = sL + NB * (NB + 1);           // 16 x 64
   const int tid = threadIdx.x, c = tid & 63, part = tid >> 6;
+  const int ny = (n_panels + 1) * NB;
+  for (int i = tid; i < ny; i += 1024) sy[i] = (i < n_pose) ? y[i] : 0.0;
+  __syncthreads();
   for (int kb = n_panels - 1; kb >= 0; --kb) {
     const int c0 = kb * NB;
-    for (int i = tid; i < NB * NB; i += 256) {
+    // diagonal tile -> LDS (4 loads per thread, independent)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = tid + 1024 * q;
       const int r = i >> 6, cc = i & 63;
       sL[r * (NB + 1) + cc] = (cc <= r) ? S[(size_t)(c0 + r) * ld + c0 + cc] : 0.0;
     }
+    // off-diagonal part: thread (part, c) covers rows part*4 .. part*4+3 of every active row tile
     double acc = 0.0;
     const int cnt = panel_cnt[kb], off = panel_off[kb];
     for (int q = 0; q < cnt; ++q) {
-      const int r0 = tiles[off + q] * NB;
-#pragma unroll 4
-      for (int r = part; r < NB; r += 4) {
-        const int row = r0 + r;
-        if (row < n_pose) acc += Lp[(size_t)row * ld + c0 + c] * y[row];
-      }
+      const int r0 = tiles[off + q] * NB + 4 * part;
+      const double l0 = Lp[(size_t)(r0 + 0) * ld + c0 + c], l1 = Lp[(size_t)(r0 + 1) * ld + c0 + c];
+      const double l2 = Lp[(size_t)(r0 + 2) * ld + c0 + c], l3 = Lp[(size_t)(r0 + 3) * ld + c0 + c];
+      acc = fma(l0, sy[r0], acc); acc = fma(l1, sy[r0 + 1], acc);
+      acc = fma(l2, sy[r0 + 2], acc); acc = fma(l3, sy[r0 + 3], acc);
     }
-    sp[part][c] = acc;
+    sp[part * NB + c] = acc;
     __syncthreads();
     if (tid < NB) {
-      double yv = (c0 + tid < n_pose) ? (y[c0 + tid] - (sp[0][tid] + sp[1][tid] + sp[2][tid] + sp[3][tid])) : 0.0;
+      double sum = 0.0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) sum += sp[q * NB + tid];
+      double yv = sy[c0 + tid] - sum;
+      const double invd = Vinv[(size_t)kb * kVinvStride + 1024 + tid];
+#pragma unroll
       for (int j = NB - 1; j >= 0; --j) {
-        const double yj = __shfl(yv, j, 64) / sL[j * (NB + 1) + j];
+        const double yj = readlane_d(yv, j) * readlane_d(invd, j);
         if (tid == j) yv = yj;
-        if (tid < j) yv -= sL[j * (NB + 1) + tid] * yj;
+        if (tid < j) yv = fma(-sL[j * (NB + 1) + tid], yj, yv);
       }
-      if (c0 + tid < n_pose) y[c0 + tid] = yv;
+      if (c0 + tid < n_pose) sy[c0 + tid] = yv; else sy[c0 + tid] = 0.0;
     }
-    __threadfence_block();
     __syncthreads();
   }
+  for (int i = tid; i < n_pose; i += 1024) y[i] = sy[i];
 }
 
-void launch_chol_backsolve(hipStream_t s, const double* S, const double* Lp, int ld, int n_panels, int n_pose,
-                           const int* tiles, const int* panel_off, const int* panel_cnt, double* y) {
+void launch_chol_backsolve(hipStream_t s, const double* S, const double* Lp, const double* Vinv, int ld, int n_panels,
+                           int n_pose, const int* tiles, const int* panel_off, const int* panel_cnt, double* y) {
   if (n_panels <= 0) return;
-  hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1), dim3(256), 0, s, S, Lp, ld, n_panels, n_pose, tiles, panel_off,
+  const size_t lds = sizeof(double) * ((size_t)(n_panels + 1) * NB + NB * (NB + 1) + 16 * NB);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+  hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1), dim3(1024), lds, s, S, Lp, Vinv, ld, n_panels, n_pose, tiles, panel_off,
                      panel_cnt, y);
 }
+
+int chol_vinv_stride() { return kVinvStride; }
 
 }  // namespace bsg
