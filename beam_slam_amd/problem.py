@@ -102,6 +102,34 @@ class Problem:
     def n_residuals(self):
         return sum(self.n_factors(t) * NRES[t] for t in self.factors)
 
+    # -- (de)serialisation: small fixtures under tests/golden/ ----------------------------------
+    def to_arrays(self):
+        d = dict(values=self.values, offset=np.asarray(self.offset, np.int32), size=np.asarray(self.size, np.uint8),
+                 manifold=np.asarray(self.manifold, np.uint8), is_const=np.asarray(self.is_const, np.uint8))
+        d["cameras"] = np.array([[c.fx, c.fy, c.cx, c.cy, *c.R_cam_baselink, *c.t_cam_baselink] for c in self.cameras]).reshape(-1, 16)
+        for t, chunks in self.factors.items():
+            d[f"f{t}_idx"] = np.concatenate([c[0] for c in chunks])
+            d[f"f{t}_consts"] = np.concatenate([c[1] for c in chunks])
+            d[f"f{t}_loss_kind"] = np.concatenate([c[2] for c in chunks])
+            d[f"f{t}_loss_a"] = np.concatenate([c[3] for c in chunks])
+        return d
+
+    @classmethod
+    def from_arrays(cls, d):
+        pr = cls()
+        pr._values = [np.asarray(d["values"], np.float64).copy()]
+        pr._nvalues = pr._values[0].size
+        pr.offset = [int(v) for v in d["offset"]]
+        pr.size = [int(v) for v in d["size"]]
+        pr.manifold = [int(v) for v in d["manifold"]]
+        pr.is_const = [int(v) for v in d["is_const"]]
+        for row in np.asarray(d["cameras"]).reshape(-1, 16):
+            pr.add_camera(row[0], row[1], row[2], row[3], row[4:13], row[13:16])
+        for t in range(capi.F_NUM_TYPES):
+            if f"f{t}_idx" in d:
+                pr.add_factors(t, d[f"f{t}_idx"], d[f"f{t}_consts"], d[f"f{t}_loss_kind"], d[f"f{t}_loss_a"])
+        return pr
+
     # -- hand over -------------------------------------------------------------------------
     def load(self, solver):
         """Pushes the whole problem through the C-ABI into `solver` (a capi.Solver)."""

@@ -337,7 +337,10 @@ def vio_window(n_kf=200, n_lm=50000, seed=20250620, kf_rate=10.0, imu_rate=200.0
     n_obs = obs_l.size
     idx = np.stack([kf_blocks[obs_k, 0], kf_blocks[obs_k, 1], lm_blocks[obs_l], np.full(n_obs, cam, np.int32)], axis=1)
     consts = np.concatenate([uv, np.full((n_obs, 1), w_reproj)], axis=1)
-    pr.add_factors(capi.F_REPROJ, idx, consts, capi.LOSS_CAUCHY, cauchy_a * w_reproj)  # a = 5 w: visual_odometry_params.h:77-80
+    if cauchy_a is None:
+        pr.add_factors(capi.F_REPROJ, idx, consts)
+    else:
+        pr.add_factors(capi.F_REPROJ, idx, consts, capi.LOSS_CAUCHY, cauchy_a * w_reproj)  # a = 5 w: visual_odometry_params.h:77-80
     if imu_fac:
         idx = np.concatenate([kf_blocks[:-1], kf_blocks[1:]], axis=1)
         pr.add_factors(capi.F_IMU_DELTA, idx, np.stack(imu_fac))

@@ -52,7 +52,7 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from beam_slam_amd import synthetic
+    from beam_slam_amd import sharding, synthetic
     from beam_slam_amd.gpu import GpuSolver
 
     # ---- workload: C2 at N=1, C5 instances (independent C2-shaped windows) at N>1 ----------------
@@ -60,7 +60,8 @@ def main():
         pr = synthetic.vio_window(n_kf=args.n_kf, n_lm=args.n_lm, seed=20250620)
         workload = "C2: %d-keyframe x %d-landmark VIO window" % (args.n_kf, args.n_lm)
     else:
-        pr = synthetic.vio_window(n_kf=args.n_kf, n_lm=args.n_lm, seed=20250620 + 10 + rank)
+        (window,) = sharding.assign_windows(world, world, rank)     # one window per GPU
+        pr = synthetic.vio_window(n_kf=args.n_kf, n_lm=args.n_lm, seed=sharding.window_seed(20250620, window))
         workload = "C5: %d independent C2 windows (%d KF x %d landmarks each)" % (world, args.n_kf, args.n_lm)
     g = GpuSolver(local_rank)
     pr.load(g)
@@ -93,12 +94,7 @@ def main():
 
     tot_it, max_dt = float(n_it), dt
     if dist is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        k = torch.tensor([float(n_it)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(k, op=dist.ReduceOp.SUM)
-        tot_it, max_dt = float(k.item()), float(t.item())
+        tot_it, max_dt = sharding.aggregate(dist, n_it, dt, device="cuda")
 
     out = None
     if rank == 0:
