@@ -20,8 +20,8 @@ from helpers import mixed_problem  # noqa: E402
 from oracle import Oracle  # noqa: E402
 
 CASES = {
-    "mixed_all_types_seed0": (lambda: mixed_problem(0), 12),
-    "mixed_all_types_seed7_const": (lambda: mixed_problem(7, hold_first=True), 12),
+    "all_types_seed0": (lambda: mixed_problem(0, consistent=True), 25),
+    "all_types_seed7_const": (lambda: mixed_problem(7, hold_first=True, consistent=True), 25),
     "vio_window_6kf_60lm": (lambda: synthetic.vio_window(n_kf=6, n_lm=60, seed=101, track_min=3, track_max=6), 25),
     "lio_window_12kf": (lambda: synthetic.lio_window(n_kf=12, n_rel=80, seed=102), 25),
     "pose_graph_40": (lambda: synthetic.pose_graph(n_pose=40, n_loop=80, seed=103), 25),
