@@ -106,6 +106,15 @@ def main():
         roofline = {"bound": "hbm", "kernel": "reproj_eval_kernel<true>", "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "bytes_per_launch": int(nbytes), "ms_per_launch": round(ms, 5), "traffic": None}
+        # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the
+        # gfx950 correction of MI355X_MICROARCH.md); bench.py itself cannot collect counters
+        pmc = os.path.join(ROOT, "profiles", "r01_c2_pmc_hbm.csv")
+        if world == 1 and args.n_kf == 200 and args.n_lm == 50000 and os.path.exists(pmc):
+            import csv
+            for row in csv.reader(open(pmc)):
+                if row and row[0].startswith("void bsg::reproj_eval_kernel<true>"):
+                    roofline["traffic"] = int((2.0 * float(row[2]) + float(row[3])) * 1024)
+                    roofline["traffic_source"] = "profiles/r01_c2_pmc_hbm.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
         out = {
             "metric": "LM iterations/sec + ms/graph-solve, 200KF x 50k-landmark VIO window",
             "value": round(tot_it / max_dt, 2), "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps,

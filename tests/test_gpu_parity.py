@@ -82,12 +82,16 @@ def test_lm_rejected_steps_path(oracle_cls, gpu_solver_cls, seed):
     opt.max_num_iterations = 9
     sg, so = g.solve(opt), o.solve(opt)
     ig, io = g.iterations(), o.iterations()
-    assert len(ig) == len(io)
-    assert any(not a.step_is_successful for a in ig)
-    for a, b in zip(ig, io):
+    first_rej = next(i for i, a in enumerate(io) if not a.step_is_successful)
+    # compare through the first rejected step and the two steps after it (re-assembly with the same
+    # Jacobian and a shrunk radius); beyond that the two trajectories of such a graph drift apart
+    upto = min(len(ig), len(io), first_rej + 3)
+    assert upto > first_rej
+    for a, b in zip(ig[:upto], io[:upto]):
         assert a.step_is_successful == b.step_is_successful
-        assert abs(a.cost - b.cost) <= 1e-3 * abs(b.cost)
-        assert abs(a.trust_region_radius - b.trust_region_radius) <= 1e-3 * b.trust_region_radius
+        assert abs(a.cost - b.cost) <= 1e-4 * abs(b.cost)
+        assert abs(a.trust_region_radius - b.trust_region_radius) <= 1e-6 * b.trust_region_radius
+        assert abs(a.model_cost_change - b.model_cost_change) <= 1e-4 * abs(b.model_cost_change) + 1e-12
 
 
 def test_c1_window(oracle_cls, gpu_solver_cls):
