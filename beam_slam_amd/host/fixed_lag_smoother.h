@@ -1,0 +1,225 @@
+// bs_optimizers::FixedLagSmoother — ROS-free core of the reference's optimizer
+// (bs_optimizers/src/fixed_lag_smoother.cpp): the pending-transaction queue (:548-627, sorted by stamp),
+// one optimisation cycle (:185-309: merge queue, drop constraints that touch already-marginalised
+// variables :199-216, graph update, lag expiration :141-149, pseudo-marginalisation :244-268 with the
+// "MARGINALIZATION" prior on the first in-window state :742-797, optimize :281, usable-solution check
+// :286-295), and the [EXT] fuse VariableStampIndex it relies on (:153-159).
+// ROS timers/threads/services, sensor-model plugins, motion models and ignition are out of scope
+// (SURVEY.md §2); the caller drives optimizeOnce() and feeds transactions.
+#pragma once
+#include <deque>
+#include <mutex>
+
+#include "gpu_graph.h"
+
+namespace bs_optimizers {
+
+// [EXT] fuse_optimizers::VariableStampIndex: stamped variables expire with their own stamp; unstamped
+// ones (landmarks, extrinsics) once every stamped variable they are connected to has expired.
+class VariableStampIndex {
+ public:
+  void addNewTransaction(const fuse_core::Transaction& t) {
+    for (const auto& v : t.addedVariables()) {
+      auto& e = vars_[v->uuid()];
+      e.stamped = v->isStamped();
+      if (e.stamped) e.stamp = v->stamp();
+    }
+    for (const auto& c : t.addedConstraints()) {
+      constraints_[c->uuid()] = c->variables();
+      for (const auto& u : c->variables()) vars_[u].constraints.insert(c->uuid());
+    }
+    applyRemovals(t);
+  }
+  void addMarginalTransaction(const fuse_core::Transaction& t) {
+    for (const auto& c : t.addedConstraints()) {
+      constraints_[c->uuid()] = c->variables();
+      for (const auto& u : c->variables()) vars_[u].constraints.insert(c->uuid());
+    }
+    applyRemovals(t);
+  }
+  fuse_core::Time currentStamp() const {
+    fuse_core::Time m;
+    bool any = false;
+    for (const auto& kv : vars_) if (kv.second.stamped && (!any || kv.second.stamp > m)) { m = kv.second.stamp; any = true; }
+    return m;
+  }
+  // variables whose (effective) stamp is older than `stamp`
+  std::vector<fuse_core::UUID> query(const fuse_core::Time& stamp) const {
+    std::vector<fuse_core::UUID> out;
+    for (const auto& kv : vars_) {
+      if (kv.second.stamped) { if (kv.second.stamp < stamp) out.push_back(kv.first); continue; }
+      bool any = false, all_old = true;
+      for (const auto& cu : kv.second.constraints)
+        for (const auto& vu : constraints_.at(cu)) {
+          auto it = vars_.find(vu);
+          if (it == vars_.end() || !it->second.stamped) continue;
+          any = true;
+          if (!(it->second.stamp < stamp)) all_old = false;
+        }
+      if (any && all_old) out.push_back(kv.first);
+    }
+    return out;
+  }
+  size_t size() const { return vars_.size(); }
+ private:
+  struct Entry { bool stamped = false; fuse_core::Time stamp; std::set<fuse_core::UUID> constraints; };
+  void applyRemovals(const fuse_core::Transaction& t) {
+    for (const auto& cu : t.removedConstraints()) {
+      auto it = constraints_.find(cu);
+      if (it == constraints_.end()) continue;
+      for (const auto& vu : it->second) { auto v = vars_.find(vu); if (v != vars_.end()) v->second.constraints.erase(cu); }
+      constraints_.erase(it);
+    }
+    for (const auto& vu : t.removedVariables()) vars_.erase(vu);
+  }
+  std::map<fuse_core::UUID, Entry> vars_;
+  std::map<fuse_core::UUID, std::vector<fuse_core::UUID>> constraints_;
+};
+
+struct FixedLagSmootherParams {     // [EXT] fuse_optimizers::FixedLagSmootherParams + pseudo_marginalization (:92-93)
+  double lag_duration = 7.0;        // vio.yaml:3
+  double optimization_period = 0.07;  // vio.yaml:2 (the caller's timer)
+  bool pseudo_marginalization = true;  // vio.yaml:4 — on in every shipped config
+  ceres_compat::SolverOptions solver_options = ceres_compat::SolverOptions::Vio();
+};
+
+class FixedLagSmoother {
+ public:
+  FixedLagSmoother(GpuGraph::UniquePtr graph, FixedLagSmootherParams params = FixedLagSmootherParams())
+      : graph_(std::move(graph)), params_(params) {}
+
+  // fixed_lag_smoother.cpp:548-627: sorted insert under the pending-transactions mutex
+  void transactionCallback(const std::string& sensor_name, fuse_core::Transaction::SharedPtr transaction) {
+    std::lock_guard<std::mutex> lock(pending_transactions_mutex_);
+    auto pos = std::upper_bound(pending_.begin(), pending_.end(), transaction->stamp(),
+                                [](const fuse_core::Time& s, const Pending& p) { return s < p.transaction->stamp(); });
+    pending_.insert(pos, Pending{sensor_name, std::move(transaction)});
+    if (!started_) { started_ = true; start_time_ = pending_.front().transaction->minStamp(); }
+  }
+  size_t pendingTransactions() const { std::lock_guard<std::mutex> lock(pending_transactions_mutex_); return pending_.size(); }
+
+  enum class CycleResult { NothingToDo, Optimized, UnusableSolution, GraphUpdateFailed };
+
+  // one pass of the body of optimizationLoop() (:185-309)
+  CycleResult optimizeOnce() {
+    std::lock_guard<std::mutex> lock(optimization_mutex_);
+    fuse_core::Transaction new_transaction;
+    {
+      std::lock_guard<std::mutex> qlock(pending_transactions_mutex_);
+      while (!pending_.empty()) { new_transaction.merge(*pending_.front().transaction); pending_.pop_front(); }
+    }
+    if (new_transaction.empty()) return CycleResult::NothingToDo;
+    // :199-216 drop added constraints that touch variables the previous cycle marginalised
+    fuse_core::Transaction filtered;
+    filtered.stamp(new_transaction.stamp());
+    for (const auto& s : new_transaction.involvedStamps()) filtered.addInvolvedStamp(s);
+    for (const auto& v : new_transaction.addedVariables()) {
+      bool gone = false;
+      for (const auto& m : marginal_transaction_.removedVariables()) if (m == v->uuid()) gone = true;
+      if (!gone) filtered.addVariable(v);
+    }
+    for (const auto& c : new_transaction.addedConstraints()) {
+      bool faulty = false;
+      for (const auto& vu : c->variables())
+        for (const auto& m : marginal_transaction_.removedVariables()) if (vu == m) faulty = true;
+      if (faulty) { ++num_dropped_constraints_; continue; }
+      filtered.addConstraint(c);
+    }
+    for (const auto& u : new_transaction.removedConstraints()) filtered.removeConstraint(u);
+    for (const auto& u : new_transaction.removedVariables()) filtered.removeVariable(u);
+    try {
+      graph_->update(filtered);            // :219-236
+    } catch (const std::exception& ex) {
+      last_error_ = ex.what();
+      return CycleResult::GraphUpdateFailed;
+    }
+    // marginalisation (:238-276)
+    timestamp_tracking_.addNewTransaction(filtered);
+    lag_expiration_ = computeLagExpirationTime();
+    const auto vars_to_marginalize = timestamp_tracking_.query(lag_expiration_);
+    marginal_transaction_ = fuse_core::Transaction();
+    if (params_.pseudo_marginalization) {
+      if (vars_to_marginalize.size() > 1) {   // sic: "> 1" (:246)
+        for (const auto& uuid : vars_to_marginalize) {
+          try {
+            for (const auto* c : graph_->getConnectedConstraints(uuid)) marginal_transaction_.removeConstraint(c->uuid());
+            marginal_transaction_.removeVariable(uuid);
+          } catch (const std::exception&) {}  // swallowed, like the reference (:257)
+        }
+        const bs_common::ImuState first = GetWindowStartState();
+        Mat15 cov = 0.00001 * Mat15::Identity();   // :266
+        marginal_transaction_.addConstraint(std::make_shared<bs_constraints::AbsoluteImuState3DStampedConstraint>(
+            "MARGINALIZATION", first, first.GetStateVector(), cov));
+      }
+    } else {
+      throw std::logic_error("true marginalisation (fuse_constraints::marginalizeVariables) is a 'next' row (SURVEY.md §8f rank 1)");
+    }
+    // removals of constraints must precede removals of variables and may list a constraint twice
+    graph_->update(dedup(marginal_transaction_));
+    timestamp_tracking_.addMarginalTransaction(marginal_transaction_);
+    // :281 — the hot call
+    summary_ = graph_->optimize(params_.solver_options);
+    ++num_cycles_;
+    if (!summary_.IsSolutionUsable()) return CycleResult::UnusableSolution;   // :286-295
+    return CycleResult::Optimized;
+  }
+
+  const ceres_compat::SolverSummary& summary() const { return summary_; }
+  const GpuGraph& graph() const { return *graph_; }
+  GpuGraph& graph() { return *graph_; }
+  fuse_core::Time lagExpiration() const { return lag_expiration_; }
+  int numCycles() const { return num_cycles_; }
+  int numDroppedConstraints() const { return num_dropped_constraints_; }
+  const std::string& lastError() const { return last_error_; }
+  // :479-546 reset service: clear graph and queue
+  void reset() {
+    std::lock_guard<std::mutex> lock(optimization_mutex_);
+    std::lock_guard<std::mutex> qlock(pending_transactions_mutex_);
+    pending_.clear(); graph_->clear(); timestamp_tracking_ = VariableStampIndex(); marginal_transaction_ = fuse_core::Transaction();
+    started_ = false; lag_expiration_ = fuse_core::Time();
+  }
+
+  // :742-797: the first in-window state = smallest Position3DStamped stamp newer than the lag expiration
+  bs_common::ImuState GetWindowStartState() const {
+    bool found = false;
+    fuse_core::Time first;
+    for (const auto* v : graph_->getVariables()) {
+      if (v->type() != "fuse_variables::Position3DStamped") continue;
+      if (v->stamp() > lag_expiration_ && (!found || v->stamp() < first)) { first = v->stamp(); found = true; }
+    }
+    if (!found) throw std::out_of_range("Invalid start state of new graph, no in-window position variable.");
+    bs_common::ImuState s(first);
+    if (!s.Update(*graph_)) throw std::out_of_range("Invalid start state of new graph, not all imu state variables exist.");
+    return s;
+  }
+
+ private:
+  using Mat15 = bs_math::Mat<15, 15>;
+  struct Pending { std::string sensor_name; fuse_core::Transaction::SharedPtr transaction; };
+  fuse_core::Time computeLagExpirationTime() const {   // :141-149
+    const fuse_core::Time now = timestamp_tracking_.currentStamp();
+    return (start_time_ + params_.lag_duration < now) ? now + (-params_.lag_duration) : start_time_;
+  }
+  static fuse_core::Transaction dedup(const fuse_core::Transaction& t) {
+    fuse_core::Transaction o;
+    std::set<fuse_core::UUID> seen;
+    for (const auto& u : t.removedConstraints()) if (seen.insert(u).second) o.removeConstraint(u);
+    for (const auto& u : t.removedVariables()) o.removeVariable(u);
+    for (const auto& c : t.addedConstraints()) o.addConstraint(c);
+    return o;
+  }
+  GpuGraph::UniquePtr graph_;
+  FixedLagSmootherParams params_;
+  mutable std::mutex pending_transactions_mutex_;
+  std::mutex optimization_mutex_;
+  std::deque<Pending> pending_;
+  VariableStampIndex timestamp_tracking_;
+  fuse_core::Transaction marginal_transaction_;
+  fuse_core::Time lag_expiration_, start_time_;
+  bool started_ = false;
+  ceres_compat::SolverSummary summary_;
+  int num_cycles_ = 0, num_dropped_constraints_ = 0;
+  std::string last_error_;
+};
+
+}  // namespace bs_optimizers

@@ -1,0 +1,226 @@
+// Host-side (C++) tests of the fuse/bs_optimizers mirror in beam_slam_amd/host/, written like the
+// reference's own gtests.  Built twice by tests/test_host_cpp.py:
+//   * against libbsgpu.so              -> run on the GPU box (-m gpu): the product path
+//   * with -DBS_BACKEND_PREFIX=bso_    -> against the CPU oracle, to exercise the HOST LOGIC
+//     (flattening order, pack(), transactions, lag window, pseudo-marginalisation) where no GPU exists
+#include <cstdio>
+#include <iostream>
+#include <random>
+
+#include "../../beam_slam_amd/host/fixed_lag_smoother.h"
+
+using namespace bs_math;
+static int g_fail = 0;
+#define CHECK(cond) do { if (!(cond)) { std::printf("  CHECK FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); ++g_fail; } } while (0)
+#define CHECK_NEAR(a, b, tol) do { const double a_ = (a), b_ = (b); if (!(std::fabs(a_ - b_) <= (tol))) { std::printf("  CHECK_NEAR FAILED %s:%d: %s=%.12g vs %s=%.12g (tol %g)\n", __FILE__, __LINE__, #a, a_, #b, b_, (double)(tol)); ++g_fail; } } while (0)
+
+static Mat<3, 3> I3() { return Mat<3, 3>::Identity(); }
+static Mat<6, 6> I6() { return Mat<6, 6>::Identity(); }
+
+// bs_models/tests/imu_preintegration_tests.cpp:292-477
+static void test_simple_2_state_fg() {
+  std::printf("Simple2StateFG\n");
+  bs_common::ImuState IS1(fuse_core::Time(1.0), {0.952, 0.038, -0.189, 0.239}, {1.5, -3.0, 1.0}, {1.5, -3.0, 1.0}, {4e-5, 5e-5, 6e-5}, {1e-5, 2e-5, 3e-5});
+  bs_common::ImuState IS2(fuse_core::Time(2.0), {0.944, -0.128, 0.145, -0.269}, {-1.5, 3.0, -1.0}, {-1.5, 3.0, -1.0}, {4e-5, 5e-5, 6e-5}, {1e-5, 2e-5, 3e-5});
+  bs_optimizers::GpuGraph graph;
+  for (const auto* s : {&IS1, &IS2}) {
+    graph.addVariable(s->Orientation().clone()); graph.addVariable(s->Position().clone()); graph.addVariable(s->Velocity().clone());
+    graph.addVariable(s->GyroBias().clone()); graph.addVariable(s->AccelBias().clone());
+  }
+  graph.addConstraint(std::make_shared<fuse_constraints::AbsolutePose3DStampedConstraint>("test", IS1.Position(), IS1.Orientation(), bs_constraints::Vector7d{0, 0, 0, 1, 0, 0, 0}, I6()));
+  graph.addConstraint(bs_constraints::AbsoluteVelocityLinear3DStampedConstraint("test", IS1.Velocity(), {0, 0, 0}, I3()));
+  graph.addConstraint(bs_constraints::AbsoluteGyroBias3DStampedConstraint("test", IS1.GyroBias(), {0, 0, 0}, I3()));
+  graph.addConstraint(bs_constraints::AbsoluteAccelBias3DStampedConstraint("test", IS1.AccelBias(), {0, 0, 0}, I3()));
+  graph.addConstraint(std::make_shared<fuse_constraints::RelativePose3DStampedConstraint>("test", IS1.Position(), IS1.Orientation(), IS2.Position(), IS2.Orientation(), bs_constraints::Vector7d{1, 0, 0, 1, 0, 0, 0}, I6()));
+  graph.addConstraint(bs_constraints::RelativeVelocityLinear3DStampedConstraint("test", IS1.Velocity(), IS2.Velocity(), {1, 0, 0}, I3()));
+  graph.addConstraint(bs_constraints::RelativeGyroBias3DStampedConstraint("test", IS1.GyroBias(), IS2.GyroBias(), {0.001, 0, 0}, I3()));
+  graph.addConstraint(bs_constraints::RelativeAccelBias3DStampedConstraint("test", IS1.AccelBias(), IS2.AccelBias(), {0.001, 0, 0}, I3()));
+  auto summary = graph.optimize();
+  CHECK(summary.IsSolutionUsable());
+  CHECK(IS1.Update(graph)); CHECK(IS2.Update(graph));
+  CHECK(IS1.Updates() == 1);
+  const double e1[16] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const double e2[16] = {1, 0, 0, 0, 1, 0, 0, 1, 0, 0, 0.001, 0, 0, 0.001, 0, 0};
+  const auto s1 = IS1.GetStateVector(), s2 = IS2.GetStateVector();
+  for (int i = 0; i < 16; ++i) { CHECK_NEAR(s1[i], e1[i], i < 4 ? 1e-3 : 1e-5); CHECK_NEAR(s2[i], e2[i], i < 4 ? 1e-3 : 1e-5); }
+}
+
+// bs_constraints/tests/absolute_imu_state_3d_stamped_constraint_test.cpp:22-165
+static void test_absolute_imu_state() {
+  std::printf("AbsoluteImuState3DStampedConstraint\n");
+  bs_common::ImuState st(fuse_core::Time(1.0), {0.952, 0.038, -0.189, 0.239}, {1.5, -3.0, 10.0}, {1.5, -3.0, 10.0}, {0.15, -0.30, 1.0}, {0.15, -0.30, 1.0});
+  std::array<double, 16> mean{1.0, 0.0, 0.0, 0.0, 1.0, 2.0, 3.0, 1.0, 2.0, 3.0, 0.1, 0.2, 0.3, 0.1, 0.2, 0.3};
+  Mat<15, 15> cov;
+  for (int i = 0; i < 15; ++i) cov(i, i) = i + 1.0;
+  for (int j = 1; j < 15; ++j) cov(0, j) = cov(j, 0) = 0.1 * j;
+  for (int i = 1; i < 15; ++i) for (int j = i + 1; j < 15; ++j) cov(i, j) = cov(j, i) = 1.5 - 0.1 * (j - i - 1);
+  auto c = std::make_shared<bs_constraints::AbsoluteImuState3DStampedConstraint>("test", st, mean, cov);
+  // :74-83 sqrt information: U^T U == cov^-1
+  Mat<15, 15> info;
+  CHECK(invertSpd(cov, info));
+  const Mat<15, 15> UtU = transpose(c->sqrtInformation()) * c->sqrtInformation();
+  for (int i = 0; i < 225; ++i) CHECK_NEAR(UtU.a[i], info.a[i], 1e-9);
+  bs_optimizers::GpuGraph graph;
+  graph.addVariable(st.Orientation().clone()); graph.addVariable(st.Position().clone()); graph.addVariable(st.Velocity().clone());
+  graph.addVariable(st.GyroBias().clone()); graph.addVariable(st.AccelBias().clone());
+  graph.addConstraint(c);
+  auto summary = graph.optimize();
+  CHECK(summary.IsSolutionUsable());
+  CHECK(st.Update(graph));
+  const auto s = st.GetStateVector();
+  for (int i = 0; i < 16; ++i) CHECK_NEAR(s[i], mean[i], i < 4 ? 1e-3 : 1e-5);
+}
+
+// deterministic variable index + constraint payloads
+static void test_block_order_and_pack() {
+  std::printf("BlockOrderAndPack\n");
+  bs_optimizers::GpuGraph graph;
+  auto ext_q = bs_variables::Orientation3D::make_shared("cam", "base");
+  auto ext_p = bs_variables::Position3D::make_shared("cam", "base");
+  graph.addVariable(ext_q); graph.addVariable(ext_p);
+  graph.addVariable(bs_variables::Point3DLandmark::make_shared(17));
+  graph.addVariable(bs_variables::Point3DLandmark::make_shared(3));
+  for (double t : {2.0, 1.0}) {
+    bs_common::ImuState s{fuse_core::Time(t)};
+    graph.addVariable(s.AccelBias().clone()); graph.addVariable(s.Velocity().clone()); graph.addVariable(s.Orientation().clone());
+    graph.addVariable(s.GyroBias().clone()); graph.addVariable(s.Position().clone());
+  }
+  const auto v = graph.orderedVariables();
+  const char* expect[14] = {"fuse_variables::Orientation3DStamped", "fuse_variables::Position3DStamped", "fuse_variables::VelocityLinear3DStamped",
+                            "bs_variables::GyroscopeBias3DStamped", "bs_variables::AccelerationBias3DStamped",
+                            "fuse_variables::Orientation3DStamped", "fuse_variables::Position3DStamped", "fuse_variables::VelocityLinear3DStamped",
+                            "bs_variables::GyroscopeBias3DStamped", "bs_variables::AccelerationBias3DStamped",
+                            "bs_variables::Point3DLandmark", "bs_variables::Point3DLandmark", "", ""};
+  CHECK(v.size() == 14);
+  for (int i = 0; i < 12; ++i) CHECK(v[i]->type() == expect[i]);
+  CHECK(v[0]->stamp() == fuse_core::Time(1.0)); CHECK(v[5]->stamp() == fuse_core::Time(2.0));
+  CHECK(v[10]->landmarkId() == 3); CHECK(v[11]->landmarkId() == 17);
+  CHECK(v[12]->holdConstant() && v[13]->holdConstant());
+  // same ids -> same uuids (fuse_core::uuid::generate semantics)
+  CHECK(bs_variables::Point3DLandmark(3).uuid() == v[10]->uuid());
+  CHECK(fuse_variables::Position3DStamped(fuse_core::Time(1.0)).uuid() == v[1]->uuid());
+  // pack(): block order = constraint's variables() order, camera de-duplication, Cauchy loss
+  fuse_core::FactorTables t;
+  std::map<fuse_core::UUID, int32_t> bi;
+  for (size_t i = 0; i < v.size(); ++i) bi[v[i]->uuid()] = (int32_t)i;
+  auto block_of = [&](const fuse_core::UUID& u) { return bi.at(u); };
+  Mat<4, 4> T = Mat<4, 4>::Identity(); T(0, 3) = 0.1;
+  Mat<3, 3> K = Mat<3, 3>::Identity(); K(0, 0) = 458.654; K(1, 1) = 457.296; K(0, 2) = 367.215; K(1, 2) = 248.375;
+  bs_common::ImuState s1{fuse_core::Time(1.0)};
+  for (int k = 0; k < 2; ++k) {
+    bs_constraints::EuclideanReprojectionConstraint rc("vo", s1.Orientation(), s1.Position(), bs_variables::Point3DLandmark(k ? 17 : 3), T, K, {100.0 + k, 50.0}, 1.0);
+    rc.loss(std::make_shared<fuse_loss::CauchyLoss>(5.0));
+    rc.pack(block_of, t);
+  }
+  CHECK(t.count(BSGPU_F_REPROJ) == 2); CHECK(t.cameras.size() == 1);
+  const int32_t exp_idx[8] = {0, 1, 10, 0, 0, 1, 11, 0};
+  for (int i = 0; i < 8; ++i) CHECK(t.idx[BSGPU_F_REPROJ][i] == exp_idx[i]);
+  CHECK(t.loss_kind[BSGPU_F_REPROJ][0] == BSGPU_LOSS_CAUCHY); CHECK_NEAR(t.loss_a[BSGPU_F_REPROJ][1], 5.0, 0);
+  CHECK_NEAR(t.cameras[0].fx, 458.654, 0); CHECK_NEAR(t.cameras[0].t_cam_baselink[0], 0.1, 0);
+}
+
+// a synthetic visual-inertial stream through the fixed-lag smoother: lag window, pseudo-marginalisation
+static void test_fixed_lag_smoother_window() {
+  std::printf("FixedLagSmootherWindow\n");
+  std::mt19937 rng(7);
+  std::normal_distribution<double> N(0.0, 1.0);
+  const int n_kf = 14, per = 20;
+  const double dt_kf = 0.1, dt_imu = dt_kf / per;
+  // straight-ish motion with gentle turning; body z up, camera looks along body z offset (identity extrinsic for simplicity)
+  auto pos = [](double t) { return Vec3{1.0 * t, 0.3 * std::sin(t), 0.05 * t}; };
+  auto vel = [](double t) { return Vec3{1.0, 0.3 * std::cos(t), 0.05}; };
+  auto acc = [](double t) { return Vec3{0.0, -0.3 * std::sin(t), 0.0}; };
+  bs_optimizers::FixedLagSmootherParams params;
+  params.lag_duration = 0.55;  // ~6 keyframes
+  params.solver_options = ceres_compat::SolverOptions();
+  params.solver_options.max_num_iterations = 20;
+  bs_optimizers::FixedLagSmoother smoother(bs_optimizers::GpuGraph::make_unique(), params);
+  Mat<4, 4> T_cam_baselink = Mat<4, 4>::Identity();
+  Mat<3, 3> K = Mat<3, 3>::Identity(); K(0, 0) = 458.654; K(1, 1) = 457.296; K(0, 2) = 367.215; K(1, 2) = 248.375;
+  // landmarks ahead on a wall z = 8 (camera frame == body frame here: +z forward means world +z; fine for a synthetic test)
+  const int n_lm = 60;
+  std::vector<Vec3> P(n_lm);
+  for (int j = 0; j < n_lm; ++j) P[j] = {0.2 * j - 2.0 + 0.5 * N(rng), 1.5 * N(rng), 8.0 + N(rng)};
+  std::set<uint64_t> known_landmarks;
+  bs_common::ImuState prev;
+  int usable = 0;
+  size_t max_vars = 0;
+  for (int k = 0; k < n_kf; ++k) {
+    const double t = k * dt_kf;
+    auto tr = std::make_shared<fuse_core::Transaction>();
+    tr->stamp(fuse_core::Time(t));
+    const Vec3 p = pos(t), v = vel(t);
+    bs_common::ImuState st(fuse_core::Time(t), quatFromAngleAxis({0.01 * N(rng), 0.01 * N(rng), 0.01 * N(rng)}),
+                           {p[0] + 0.02 * N(rng), p[1] + 0.02 * N(rng), p[2] + 0.02 * N(rng)}, {v[0] + 0.02 * N(rng), v[1] + 0.02 * N(rng), v[2] + 0.02 * N(rng)});
+    tr->addVariable(st.Orientation().clone()); tr->addVariable(st.Position().clone()); tr->addVariable(st.Velocity().clone());
+    tr->addVariable(st.GyroBias().clone()); tr->addVariable(st.AccelBias().clone());
+    tr->addInvolvedStamp(fuse_core::Time(t));
+    if (k == 0) {  // prior on the first state (imu_preintegration.cpp:267-277)
+      Mat<15, 15> cov = 1e-3 * Mat<15, 15>::Identity();
+      tr->addConstraint(std::make_shared<bs_constraints::AbsoluteImuState3DStampedConstraint>("imu", st, st.GetStateVector(), cov));
+    } else {
+      auto pre = std::make_shared<bs_common::PreIntegrator>();
+      pre->cov_w = 5.7e-4 * I3(); pre->cov_a = 9.4e-4 * I3(); pre->cov_bg = 3.7e-6 * I3(); pre->cov_ba = 2.4e-6 * I3();
+      for (int i = 0; i <= per; ++i) {
+        const double ti = (k - 1) * dt_kf + i * dt_imu;
+        bs_common::IMUData d; d.t = fuse_core::Time(ti);
+        const Vec3 a = acc(ti);
+        d.w = {0, 0, 0}; d.a = {a[0], a[1], a[2] + 9.80665};   // identity attitude: f = a - g
+        pre->data[d.t] = d;
+      }
+      CHECK(pre->Integrate(fuse_core::Time(t), {0, 0, 0}, {0, 0, 0}, true, true, true));
+      CHECK_NEAR(pre->delta.t, dt_kf, 1e-9);
+      tr->addConstraint(std::make_shared<bs_constraints::RelativeImuState3DStampedConstraint>("imu", prev, st, pre, 1.0));
+      tr->addInvolvedStamp(prev.Stamp());
+    }
+    for (int j = 0; j < n_lm; ++j) {
+      const Vec3 pc{P[j][0] - p[0], P[j][1] - p[1], P[j][2] - p[2]};
+      if (pc[2] < 1.0) continue;
+      const double u = K(0, 0) * pc[0] / pc[2] + K(0, 2), vv = K(1, 1) * pc[1] / pc[2] + K(1, 2);
+      if (u < 0 || u > 752 || vv < 0 || vv > 480) continue;
+      auto lm = bs_variables::Point3DLandmark::make_shared(j);
+      if (!known_landmarks.count(j)) { lm->x() = P[j][0] + 0.1 * N(rng); lm->y() = P[j][1] + 0.1 * N(rng); lm->z() = P[j][2] + 0.1 * N(rng); tr->addVariable(lm); known_landmarks.insert(j); }
+      auto c = std::make_shared<bs_constraints::EuclideanReprojectionConstraint>("vo", st.Orientation(), st.Position(), *lm, T_cam_baselink, K,
+                                                                              std::array<double, 2>{std::round(u + N(rng)), std::round(vv + N(rng))}, 1.0);
+      c->loss(std::make_shared<fuse_loss::CauchyLoss>(5.0));
+      tr->addConstraint(c);
+    }
+    smoother.transactionCallback("synthetic", tr);
+    const auto res = smoother.optimizeOnce();
+    CHECK(res == bs_optimizers::FixedLagSmoother::CycleResult::Optimized);
+    if (smoother.summary().IsSolutionUsable()) ++usable;
+    CHECK(smoother.summary().final_cost <= smoother.summary().initial_cost * (1 + 1e-12));
+    max_vars = std::max(max_vars, smoother.graph().numVariables());
+    prev = st;
+    prev.Update(smoother.graph());
+  }
+  CHECK(usable == n_kf);
+  CHECK(smoother.optimizeOnce() == bs_optimizers::FixedLagSmoother::CycleResult::NothingToDo);
+  // the window is bounded: stamped states older than the lag are gone, and a MARGINALIZATION prior exists
+  int n_pos = 0, n_marg = 0;
+  fuse_core::Time oldest(1e9);
+  for (const auto* v : smoother.graph().getVariables()) if (v->type() == "fuse_variables::Position3DStamped") { ++n_pos; if (v->stamp() < oldest) oldest = v->stamp(); }
+  for (const auto* c : smoother.graph().getConstraints()) if (c->source() == "MARGINALIZATION") ++n_marg;
+  CHECK(n_pos <= 8); CHECK(n_pos >= 5);
+  CHECK(oldest >= smoother.lagExpiration());
+  CHECK(n_marg >= 1);
+  const auto first = smoother.GetWindowStartState();
+  CHECK(first.Stamp() == oldest);
+  // estimates stay near the truth (position within 0.2 m, see the noise above)
+  for (const auto* v : smoother.graph().getVariables())
+    if (v->type() == "fuse_variables::Position3DStamped") {
+      const Vec3 pt = pos(v->stamp().toSec());
+      for (int i = 0; i < 3; ++i) CHECK_NEAR(v->data()[i], pt[i], 0.2);
+    }
+  std::printf("  cycles %d, window positions %d, max variables %zu, final cost %.4f\n", smoother.numCycles(), n_pos, max_vars, smoother.summary().final_cost);
+}
+
+int main() {
+  test_block_order_and_pack();
+  test_simple_2_state_fg();
+  test_absolute_imu_state();
+  test_fixed_lag_smoother_window();
+  if (g_fail) { std::printf("FAILED: %d checks\n", g_fail); return 1; }
+  std::printf("ALL HOST TESTS PASSED\n");
+  return 0;
+}
