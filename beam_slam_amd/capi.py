@@ -63,7 +63,7 @@ class Summary(C.Structure):
         ("num_residuals", C.c_int32),
         ("linear_solver_used", C.c_int32),
         ("num_linear_solves", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("num_inner_iterations", C.c_int32),
         ("initial_cost", C.c_double),
         ("final_cost", C.c_double),
         ("fixed_cost", C.c_double),

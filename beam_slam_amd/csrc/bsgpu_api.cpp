@@ -95,6 +95,13 @@ struct bsgpu_ctx {
   std::vector<int> panel_off, panel_cnt, first_col_tile;
   int n_panels = 0;
   std::vector<bsgpu_iteration> iters;
+  // block-sparse PCG path
+  bool dense_ok = true, bsr_built = false, use_pcg = false;
+  int nbr = 0, nblk = 0, pcg_iters_total = 0;
+  int *d_row_ptr = nullptr, *d_col = nullptr, *d_diag_slot = nullptr;
+  int* d_slots[BSGPU_F_NUM_TYPES] = {nullptr};
+  double *d_val = nullptr, *d_Minv = nullptr, *d_rhs = nullptr, *d_px = nullptr, *d_pr = nullptr, *d_pz = nullptr, *d_pp = nullptr,
+         *d_pq = nullptr, *d_ppart = nullptr, *d_ppart2 = nullptr, *d_psc = nullptr;
 
   template <typename T> T* alloc(size_t n) {
     void* p = nullptr;
@@ -114,6 +121,7 @@ struct bsgpu_ctx {
     vis = Visual();
     for (auto& g : small) g = SmallGroup();
     d_x = d_xcand = d_x0 = nullptr;
+    bsr_built = false;
   }
 };
 
@@ -181,7 +189,7 @@ int finalize(bsgpu_ctx* c) {
   for (int b = 0; b < nb; ++b) if (!c->is_const[b] && c->is_lm[b]) { c->toff[b] = to; to += 3; lm_index[b] = nl++; }
   c->n_tan = to; c->n_lm = nl;
   c->npad = ((c->n_pose + 1 + 63) / 64) * 64;
-  if ((size_t)c->npad > 12288) return fail(c, BSGPU_ERR_UNSUPPORTED, "reduced camera system larger than 12288: dense exact path not applicable (PCG path pending)");
+  c->dense_ok = (size_t)c->npad <= 12288;   // above: block-sparse PCG path only (pose-only problems)
   int row = 0;
   for (int t = 0; t < BSGPU_F_NUM_TYPES; ++t) { c->row0[t] = row; row += c->groups[t].n * kTypes[t].m; }
   c->n_res = row;
@@ -395,8 +403,10 @@ int finalize(bsgpu_ctx* c) {
     c->d_xcand = c->alloc<double>(c->h_x.size());
   }
   // ---- dense system + vectors
-  c->d_S = c->alloc<double>((size_t)c->npad * c->npad);
-  if (!c->d_S) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (reduced system)");
+  if (c->dense_ok) {
+    c->d_S = c->alloc<double>((size_t)c->npad * c->npad);
+    if (!c->d_S) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (reduced system)");
+  }
   c->d_grad = c->alloc<double>(c->n_tan); c->d_hdiag = c->alloc<double>(c->n_tan);
   c->d_scale = c->alloc<double>(c->n_tan); c->d_dcl = c->alloc<double>(c->n_tan);
   c->d_delta = c->alloc<double>(c->n_tan); c->d_y = c->alloc<double>(c->npad);
@@ -427,7 +437,7 @@ int finalize(bsgpu_ctx* c) {
     c->d_panel_cnt = c->upload(c->panel_cnt);
     c->d_Vinv = c->alloc<double>((size_t)std::max(1, c->n_panels) * chol_vinv_stride());
     c->chol_v1 = getenv("BSGPU_CHOL_V1") != nullptr;
-    if (!c->chol_v1) { c->d_Lp = c->alloc<double>((size_t)c->npad * c->npad); if (!c->d_Lp) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (L panels)"); }
+    if (!c->chol_v1 && c->dense_ok) { c->d_Lp = c->alloc<double>((size_t)c->npad * c->npad); if (!c->d_Lp) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (L panels)"); }
   }
   HIPCHK(c, hipDeviceSynchronize());
   HIPCHK(c, hipGetLastError());
@@ -438,6 +448,104 @@ int finalize(bsgpu_ctx* c) {
 // ---------------------------------------------------------------------------------------------------
 // device steps of one LM iteration
 // ---------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------
+// block-sparse structure of the pose-only normal equations (3x3 blocks), built on first use
+// ---------------------------------------------------------------------------------------------------
+int build_bsr(bsgpu_ctx* c) {
+  if (c->bsr_built) return BSGPU_OK;
+  if (c->vis.n > 0) return fail(c, BSGPU_ERR_UNSUPPORTED, "PCG path covers pose-only problems; landmark problems use the Schur + dense path");
+  if (c->n_pose % 3 != 0) return fail(c, BSGPU_ERR_UNSUPPORTED, "PCG path needs 3-dimensional tangent blocks");
+  const int nbr = c->n_pose / 3;
+  std::vector<uint64_t> keys;
+  for (int b = 0; b < nbr; ++b) keys.push_back(((uint64_t)b << 32) | (uint32_t)b);
+  for (int t = 2; t < BSGPU_F_NUM_TYPES; ++t) {
+    const HostGroup& g = c->groups[t];
+    const TypeInfo& ti = kTypes[t];
+    for (int f = 0; f < g.n; ++f) {
+      if (!c->h_small_active[t][f]) continue;
+      const int32_t* idx = &g.idx[(size_t)f * ti.nidx];
+      for (int sa = 0; sa < ti.nvar; ++sa) for (int sb = 0; sb < ti.nvar; ++sb) {
+        const int ra = c->toff[idx[sa]], rb = c->toff[idx[sb]];
+        if (ra < 0 || rb < 0) continue;
+        keys.push_back(((uint64_t)(ra / 3) << 32) | (uint32_t)(rb / 3));
+      }
+    }
+  }
+  std::sort(keys.begin(), keys.end());
+  keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+  const int nblk = (int)keys.size();
+  std::vector<int> row_ptr(nbr + 1, 0), col(nblk), diag_slot(nbr, -1);
+  for (int i = 0; i < nblk; ++i) {
+    const int r = (int)(keys[i] >> 32), cc = (int)(keys[i] & 0xffffffffu);
+    row_ptr[r + 1]++; col[i] = cc;
+    if (r == cc) diag_slot[r] = i;
+  }
+  for (int r = 0; r < nbr; ++r) row_ptr[r + 1] += row_ptr[r];
+  for (int t = 2; t < BSGPU_F_NUM_TYPES; ++t) {
+    const HostGroup& g = c->groups[t];
+    const TypeInfo& ti = kTypes[t];
+    if (!g.n) continue;
+    std::vector<int> slots((size_t)g.n * ti.nvar * ti.nvar, -1);
+    for (int f = 0; f < g.n; ++f) {
+      const int32_t* idx = &g.idx[(size_t)f * ti.nidx];
+      for (int sa = 0; sa < ti.nvar; ++sa) for (int sb = 0; sb < ti.nvar; ++sb) {
+        const int ra = c->toff[idx[sa]], rb = c->toff[idx[sb]];
+        if (ra < 0 || rb < 0 || !c->h_small_active[t][f]) continue;
+        const uint64_t key = ((uint64_t)(ra / 3) << 32) | (uint32_t)(rb / 3);
+        slots[((size_t)f * ti.nvar + sa) * ti.nvar + sb] = (int)(std::lower_bound(keys.begin(), keys.end(), key) - keys.begin());
+      }
+    }
+    c->d_slots[t] = c->upload(slots);
+  }
+  c->nbr = nbr; c->nblk = nblk;
+  c->d_row_ptr = c->upload(row_ptr); c->d_col = c->upload(col); c->d_diag_slot = c->upload(diag_slot);
+  c->d_val = c->alloc<double>((size_t)nblk * 9); c->d_Minv = c->alloc<double>((size_t)nbr * 9);
+  c->d_rhs = c->alloc<double>(c->n_pose);
+  c->d_px = c->alloc<double>(c->n_pose); c->d_pr = c->alloc<double>(c->n_pose); c->d_pz = c->alloc<double>(c->n_pose);
+  c->d_pp = c->alloc<double>(c->n_pose); c->d_pq = c->alloc<double>(c->n_pose);
+  c->d_ppart = c->alloc<double>((size_t)(nbr * 16 + 255) / 256 + 8); c->d_ppart2 = c->alloc<double>(2 * ((size_t)(nbr + 255) / 256) + 8);
+  c->d_psc = c->alloc<double>(pcg_num_scalars());
+  if (!c->d_val || !c->d_pq || !c->d_psc) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (block-sparse system)");
+  c->bsr_built = true;
+  return BSGPU_OK;
+}
+
+void assemble_pcg(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, bool first) {
+  hipStream_t s = c->stream;
+  launch_zero(s, c->d_val, (int64_t)c->nblk * 9);
+  launch_zero(s, c->d_rhs, c->n_pose);
+  launch_zero(s, c->d_grad, c->n_pose);
+  launch_zero(s, c->d_hdiag, c->n_pose);
+  for (int t = 2; t < BSGPU_F_NUM_TYPES; ++t)
+    launch_bsr_assemble(s, c->small[t], c->d_slots[t], c->d_val, c->d_rhs, c->d_grad, c->d_hdiag);
+  launch_bsr_finish_diag(s, c->nbr, c->d_diag_slot, c->d_val, c->d_hdiag, radius, first ? 1 : 0, new_J ? 1 : 0, o.jacobi_scaling,
+                         o.min_lm_diagonal, o.max_lm_diagonal, c->d_scale, c->d_dcl, c->d_Minv);
+  if (new_J) {
+    launch_zero(s, c->d_scal + SC_GRAD_MAX, 2);
+    launch_grad_norms(s, c->nb, c->d_blk_xoff, c->d_blk_toff, c->d_blk_size, c->d_blk_manifold, c->d_x, c->d_grad, c->d_scal);
+  }
+}
+
+// (H + Lambda) y = g by block-Jacobi PCG; the stop test lives on the device, the host looks at it every 20 iterations
+void pcg_solve(bsgpu_ctx* c, const bsgpu_options& o) {
+  hipStream_t s = c->stream;
+  launch_pcg_init(s, c->nbr, c->d_rhs, c->d_Minv, c->d_px, c->d_pr, c->d_pz, c->d_pp, c->d_ppart2, c->d_psc);
+  const double tol2 = o.pcg_tolerance * o.pcg_tolerance;
+  const int max_it = o.pcg_max_iterations > 0 ? o.pcg_max_iterations : 2000;
+  double h[8];
+  for (int it = 0; it < max_it;) {
+    const int chunk = std::min(20, max_it - it);
+    for (int k = 0; k < chunk; ++k)
+      launch_pcg_iteration(s, c->nbr, c->d_row_ptr, c->d_col, c->d_val, c->d_Minv, c->d_px, c->d_pr, c->d_pz, c->d_pp, c->d_pq,
+                           c->d_ppart, c->d_ppart2, c->d_psc, tol2);
+    it += chunk;
+    (void)hipMemcpyAsync(h, c->d_psc, sizeof(double) * pcg_num_scalars(), hipMemcpyDeviceToHost, s);
+    (void)hipStreamSynchronize(s);
+    if (h[pcg_done_slot()] != 0.0) break;
+  }
+  c->pcg_iters_total += (int)h[pcg_iters_slot()];
+}
+
 void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot) {
   hipStream_t s = c->stream;
   launch_zero(s, c->d_scal + slot, 1);
@@ -453,6 +561,7 @@ void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot) {
 }
 
 void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, bool first) {
+  if (c->use_pcg) { assemble_pcg(c, o, radius, new_J, first); return; }
   hipStream_t s = c->stream;
   launch_zero(s, c->d_S, (int64_t)c->npad * c->npad);
   launch_zero(s, c->d_grad, c->n_pose);
@@ -507,44 +616,15 @@ void dense_factor_solve(hipStream_t s, bool v1, double* S, double* Lp, double* V
   }
 }
 
-void linear_solve_and_candidate(bsgpu_ctx* c) {
+void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
   hipStream_t s = c->stream;
   launch_zero(s, c->d_scal + SC_CHOL_FAIL, 1);
-  std::vector<double> dbgS;
-  const bool dbg = getenv("BSGPU_CHOL_CHECK") != nullptr && c->n_pose > 0 && c->n_pose <= 4000;
-  if (dbg) {
-    (void)hipStreamSynchronize(s);
-    dbgS.resize((size_t)c->npad * c->npad);
-    (void)hipMemcpy(dbgS.data(), c->d_S, sizeof(double) * dbgS.size(), hipMemcpyDeviceToHost);
-  }
-  if (c->n_pose > 0) {
+  if (c->use_pcg) {
+    pcg_solve(c, o);
+    launch_negate_pose(s, c->n_pose, c->d_px, c->d_delta);
+  } else if (c->n_pose > 0) {
     dense_factor_solve(s, c->chol_v1, c->d_S, c->d_Lp, c->d_Vinv, c->npad, c->n_pose, c->n_panels, c->h_tiles, c->panel_off,
                        c->panel_cnt, c->first_col_tile, c->d_tiles, c->d_panel_off, c->d_panel_cnt, c->d_y, c->d_scal);
-    if (dbg) {
-      (void)hipStreamSynchronize(s);
-      const int n = c->n_pose, ld = c->npad;
-      std::vector<double> y(n), L(dbgS), b(n);
-      double flag = 0;
-      (void)hipMemcpy(y.data(), c->d_y, sizeof(double) * n, hipMemcpyDeviceToHost);
-      (void)hipMemcpy(&flag, c->d_scal + SC_CHOL_FAIL, sizeof(double), hipMemcpyDeviceToHost);
-      for (int i = 0; i < n; ++i) b[i] = dbgS[(size_t)n * ld + i];
-      bool ok = true;
-      double minpiv = 1e300;
-      for (int j = 0; j < n && ok; ++j) {
-        double d = L[(size_t)j * ld + j];
-        for (int p = 0; p < j; ++p) d -= L[(size_t)j * ld + p] * L[(size_t)j * ld + p];
-        if (!(d > 0)) { ok = false; std::fprintf(stderr, "[chol-check] host pivot %d = %g\n", j, d); break; }
-        minpiv = std::min(minpiv, d);
-        d = std::sqrt(d); L[(size_t)j * ld + j] = d;
-        for (int i = j + 1; i < n; ++i) { double v = L[(size_t)i * ld + j]; for (int p = 0; p < j; ++p) v -= L[(size_t)i * ld + p] * L[(size_t)j * ld + p]; L[(size_t)i * ld + j] = v / d; }
-      }
-      for (int i = 0; i < n; ++i) { double v = b[i]; for (int p = 0; p < i; ++p) v -= L[(size_t)i * ld + p] * b[p]; b[i] = v / L[(size_t)i * ld + i]; }
-      for (int i = n - 1; i >= 0; --i) { double v = b[i]; for (int p = i + 1; p < n; ++p) v -= L[(size_t)p * ld + i] * b[p]; b[i] = v / L[(size_t)i * ld + i]; }
-      double md = 0, mx = 0; int nan = 0;
-      for (int i = 0; i < n; ++i) { if (!std::isfinite(y[i])) nan++; else md = std::max(md, std::fabs(y[i] - b[i])); mx = std::max(mx, std::fabs(b[i])); }
-      double sym = 0; for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) sym = std::max(sym, std::fabs(dbgS[(size_t)i * ld + j] - dbgS[(size_t)j * ld + i]));
-      std::fprintf(stderr, "[chol-check] n=%d flag=%g host_ok=%d minpiv=%.3e nan=%d maxdiff=%.3e max|y|=%.3e asym=%.3e\n", n, flag, (int)ok, minpiv, nan, md, mx, sym);
-    }
     launch_negate_pose(s, c->n_pose, c->d_y, c->d_delta);
   }
   launch_backsub_landmarks(s, c->vis, c->n_pose, c->d_y, c->d_delta);
@@ -587,8 +667,12 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
   c->iters.clear();
   sum.num_parameters_tangent = c->n_tan;
   sum.num_residuals = c->n_res;
-  sum.linear_solver_used = BSGPU_LINEAR_SCHUR_CHOLESKY;
-  if (o.linear_solver_type == BSGPU_LINEAR_PCG) return fail(c, BSGPU_ERR_UNSUPPORTED, "PCG path not available yet");
+  c->use_pcg = (o.linear_solver_type == BSGPU_LINEAR_PCG) || (o.linear_solver_type == BSGPU_LINEAR_AUTO && !c->dense_ok);
+  if (!c->use_pcg && !c->dense_ok)
+    return fail(c, BSGPU_ERR_UNSUPPORTED, "reduced system larger than 12288: the dense exact path does not apply; use BSGPU_LINEAR_AUTO or BSGPU_LINEAR_PCG");
+  if (c->use_pcg) { rc = build_bsr(c); if (rc != BSGPU_OK) return rc; }
+  c->pcg_iters_total = 0;
+  sum.linear_solver_used = c->use_pcg ? BSGPU_LINEAR_PCG : BSGPU_LINEAR_SCHUR_CHOLESKY;
   hipStream_t s = c->stream;
   hipEvent_t ev0, ev1;
   HIPCHK(c, hipEventCreate(&ev0)); HIPCHK(c, hipEventCreate(&ev1));
@@ -612,7 +696,7 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
   eval_all(c, c->d_x, true, SC_COST_X);
   double radius = o.initial_trust_region_radius, decrease_factor = 2.0;
   assemble(c, o, radius, true, true);
-  linear_solve_and_candidate(c);
+  linear_solve_and_candidate(c, o);
   rc = fetch_scalars(c);
   if (rc != BSGPU_OK) return rc;
   fixed = c->any_inactive ? c->h_scal[SC_FIXED_COST] : 0.0;
@@ -657,7 +741,7 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
         radius = radius / decrease_factor; decrease_factor *= 2.0;
         it.cost = x_cost + fixed; it.step_is_successful = 0;
         assemble(c, o, radius, false, false);
-        linear_solve_and_candidate(c);
+        linear_solve_and_candidate(c, o);
         rc = fetch_scalars(c);
         if (rc != BSGPU_OK) return rc;
         continue;
@@ -686,7 +770,7 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
         assemble(c, o, radius, false, false);
       }
       // speculatively compute the next step so that one synchronisation per iteration suffices
-      linear_solve_and_candidate(c);
+      linear_solve_and_candidate(c, o);
       rc = fetch_scalars(c);
       if (rc != BSGPU_OK) return rc;
       if (it.step_is_successful) {
@@ -705,6 +789,7 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
   (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
   sum.device_time_in_seconds = ms * 1e-3;
   sum.num_iterations = (int)c->iters.size() - 1;
+  sum.num_inner_iterations = c->pcg_iters_total;
   sum.is_solution_usable = (sum.termination_type == BSGPU_CONVERGENCE || sum.termination_type == BSGPU_NO_CONVERGENCE) ? 1 : 0;
   sum.total_time_in_seconds = elapsed();
   std::snprintf(sum.message, sizeof(sum.message), "%s", msg);

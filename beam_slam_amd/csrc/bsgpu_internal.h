@@ -110,6 +110,20 @@ void launch_chol_panel_step(hipStream_t s, double* S, double* Lp, int ld, int k,
 void launch_chol_backsolve(hipStream_t s, const double* S, const double* Lp, const double* Vinv, int ld, int n_panels,
                            int n_pose, const int* tiles, const int* panel_off, const int* panel_cnt, double* y);
 int chol_vinv_stride();
+// block-sparse PCG path (k_pcg.hip)
+void launch_bsr_assemble(hipStream_t s, const SmallGroup& g, const int* slots, double* val, double* rhs, double* grad,
+                         double* hdiag);
+void launch_bsr_finish_diag(hipStream_t s, int nbr, const int* diag_slot, double* val, const double* hdiag, double radius,
+                            int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* scale,
+                            double* dcl, double* Minv);
+void launch_pcg_init(hipStream_t s, int nbr, const double* b, const double* Minv, double* x, double* r, double* z, double* p,
+                     double* part, double* sc);
+void launch_pcg_iteration(hipStream_t s, int nbr, const int* row_ptr, const int* col, const double* val, const double* Minv,
+                          double* x, double* r, double* z, double* p, double* q, double* part_pq, double* part, double* sc,
+                          double tol2);
+int pcg_num_scalars();
+int pcg_done_slot();
+int pcg_iters_slot();
 void launch_backsub_landmarks(hipStream_t s, const Visual& v, int n_pose, const double* y_pose, double* delta);
 void launch_negate_pose(hipStream_t s, int n_pose, const double* y, double* delta);
 void launch_mcc(hipStream_t s, const Visual& v, int n_pose, const double* delta, double* part);

@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--n-kf", type=int, default=200)
     ap.add_argument("--n-lm", type=int, default=50000)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"],
+                    help="c2 (default) is the headline; c3 / c4 are the other BASELINE configs, for BASELINE.md")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -56,7 +58,13 @@ def main():
     from beam_slam_amd.gpu import GpuSolver
 
     # ---- workload: C2 at N=1, C5 instances (independent C2-shaped windows) at N>1 ----------------
-    if world == 1:
+    if args.workload == "c3":
+        pr = synthetic.c3()
+        workload = "C3: LIO window, 100 keyframes, 20000 relative-pose(+extrinsics) + 99 IMU factors"
+    elif args.workload == "c4":
+        pr = synthetic.c4()
+        workload = "C4: global-mapper pose graph, 5000 poses, 50000 constraints (block-sparse PCG path)"
+    elif world == 1:
         pr = synthetic.vio_window(n_kf=args.n_kf, n_lm=args.n_lm, seed=20250620)
         workload = "C2: %d-keyframe x %d-landmark VIO window" % (args.n_kf, args.n_lm)
     else:
@@ -68,6 +76,9 @@ def main():
     g.finalize()
     opt = g.options_vio()
     opt.max_solver_time_in_seconds = 0.0  # every step does the full <= 10 iterations
+    if args.workload == "c4":             # the global mapper passes default ceres options
+        opt = g.options_default()
+        opt.max_num_iterations = 10
 
     def barrier():
         if dist is not None:
@@ -100,16 +111,19 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant HBM-bound kernel: reprojection Jacobian evaluation ---------
         reps = 50
-        ms = g.time_reproj_jacobian_ms(reps)          # HIP events on the solver's own stream
-        nbytes = g.reproj_jacobian_bytes()
-        achieved = nbytes / (ms * 1e-3) / 1e9
+        has_vis = pr.n_factors(0) > 0
+        ms = g.time_reproj_jacobian_ms(reps) if has_vis else float("nan")   # HIP events on the solver's own stream
+        nbytes = g.reproj_jacobian_bytes() if has_vis else 0
+        achieved = nbytes / (ms * 1e-3) / 1e9 if has_vis else 0.0
         roofline = {"bound": "hbm", "kernel": "reproj_eval_kernel<true>", "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "bytes_per_launch": int(nbytes), "ms_per_launch": round(ms, 5), "traffic": None}
         # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the
         # gfx950 correction of MI355X_MICROARCH.md); bench.py itself cannot collect counters
         pmc = os.path.join(ROOT, "profiles", "r01_c2_pmc_hbm.csv")
-        if world == 1 and args.n_kf == 200 and args.n_lm == 50000 and os.path.exists(pmc):
+        if not has_vis:
+            roofline = None   # C3 / C4 have no reprojection factors: the headline roofline kernel does not run
+        elif world == 1 and args.workload == "c2" and args.n_kf == 200 and args.n_lm == 50000 and os.path.exists(pmc):
             import csv
             for row in csv.reader(open(pmc)):
                 if row and row[0].startswith("void bsg::reproj_eval_kernel<true>"):
@@ -120,7 +134,8 @@ def main():
             "value": round(tot_it / max_dt, 2), "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * max_dt / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": workload, "n_obs": int(pr.meta["n_obs"]), "n_imu_factors": int(pr.meta["n_imu"]),
+            "config": {"workload": workload, "n_obs": int(pr.meta.get("n_obs", 0)), "n_imu_factors": int(pr.meta.get("n_imu", 0)),
+                       "pcg_iterations_per_solve": s.num_inner_iterations,
                        "lm_iterations_per_solve": round(n_it / args.steps, 2),
                        "solver_options": "vio.yaml:7-17, max_solver_time lifted",
                        "final_cost": s.final_cost, "initial_cost": s.initial_cost,
@@ -129,7 +144,7 @@ def main():
             "roofline": roofline,
         }
         # ---- CPU baseline: the oracle on the same window (bounded: one solve, same options) ------
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload != "c4":
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             from oracle import Oracle
             o = Oracle()

@@ -196,7 +196,7 @@ typedef struct bsgpu_summary {
                                     parameter/function-tolerance exit does not
                                     record in `iterations`): the unit of the
                                     "LM iterations/s" metric                     */
-  int32_t reserved0;
+  int32_t num_inner_iterations;  /* PCG iterations summed over the LM steps (0 on the exact path) */
   double initial_cost;
   double final_cost;
   double fixed_cost;             /* cost of residual blocks with only constant blocks */

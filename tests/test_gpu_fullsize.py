@@ -68,6 +68,52 @@ def test_c2_solve_properties(c2, gpu_solver_cls):
     assert (s2.final_cost - s3.final_cost) <= 1e-4 * s2.final_cost
 
 
+def test_c3_lio_window_full_size(oracle_cls, gpu_solver_cls):
+    """BASELINE config 3: 100 keyframes, 20 000 relative-pose(+constant extrinsics) factors + 99 IMU factors
+    (1 500 tangent dims, exact path); the oracle solves it in seconds."""
+    pr = synthetic.c3()
+    g, o = gpu_solver_cls(0), oracle_cls()
+    pr.load(g); pr.load(o)
+    cg, rg, gg, _ = g.evaluate()
+    co, ro, go, _ = o.evaluate()
+    assert abs(cg - co) <= 1e-12 * co
+    assert np.abs(rg - ro).max() <= 1e-9 * max(1.0, np.abs(ro).max())
+    assert np.abs(gg - go).max() <= 1e-9 * np.abs(go).max()
+    opt = g.options_default()
+    opt.max_num_iterations = 15
+    sg, so = g.solve(opt), o.solve(opt)
+    assert sg.termination_type == so.termination_type
+    assert abs(sg.final_cost - so.final_cost) <= 1e-6 * so.final_cost
+    assert np.abs(g.get_blocks() - o.get_blocks()).max() < 1e-6
+
+
+def test_c4_pose_graph_full_size(gpu_solver_cls):
+    """BASELINE config 4: 5 000 poses, 50 000 constraints, 30 000 tangent dims — beyond the dense path, solved
+    with the block-sparse PCG path.  No exact CPU solution exists at this size (the oracle would need a
+    30 000^2 dense factorisation): size-independent properties only."""
+    pr = synthetic.c4()
+    g = gpu_solver_cls(0)
+    pr.load(g)
+    opt = g.options_default()
+    opt.max_num_iterations = 12
+    opt.pcg_tolerance = 1e-10
+    opt.pcg_max_iterations = 2000
+    s = g.solve(opt)
+    assert s.linear_solver_used == capi.LINEAR_PCG
+    assert s.num_parameters_tangent == 30000 and s.num_residuals == 6 * 50000 + 6
+    assert s.is_solution_usable == 1
+    costs = [i.cost for i in g.iterations() if i.step_is_successful]
+    assert all(b <= a for a, b in zip(costs, costs[1:]))
+    assert s.final_cost < 0.5 * s.initial_cost
+    assert s.num_inner_iterations > 0
+    # poses move towards the ground truth
+    x = g.get_blocks()
+    blocks, p_true = pr.meta["blocks"], pr.meta["p_true"]
+    err0 = np.linalg.norm(np.array([pr.block(int(b), pr.values) for b in blocks[:, 0]]) - p_true, axis=1).mean()
+    err1 = np.linalg.norm(np.array([pr.block(int(b), x) for b in blocks[:, 0]]) - p_true, axis=1).mean()
+    assert err1 < 0.5 * err0
+
+
 def test_factor_order_invariance(gpu_solver_cls):
     """Shuffling the insertion order of the reprojection factors changes the residual index only."""
     pr = synthetic.vio_window(n_kf=30, n_lm=3000, seed=77)

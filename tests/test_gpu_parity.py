@@ -146,6 +146,34 @@ def test_pose_graph_small(oracle_cls, gpu_solver_cls):
     assert np.abs(g.get_blocks() - o.get_blocks()).max() < 1e-6
 
 
+def test_pcg_path_matches_exact_oracle(oracle_cls, gpu_solver_cls):
+    """Block-Jacobi PCG on the block-sparse normal equations (the C4 path) against the exact oracle on a pose
+    graph both can solve: same accept/reject pattern, final cost within the north-star 1e-6."""
+    pr = synthetic.pose_graph(n_pose=400, n_loop=1200, seed=21)
+    g, o = _pair(pr, oracle_cls, gpu_solver_cls)
+    opt = g.options_default()
+    opt.max_num_iterations = 12
+    opt.linear_solver_type = capi.LINEAR_PCG
+    opt.pcg_tolerance = 1e-12
+    opt.pcg_max_iterations = 3000
+    sg = g.solve(opt)
+    opt.linear_solver_type = capi.LINEAR_AUTO
+    so = o.solve(opt)
+    assert sg.linear_solver_used == capi.LINEAR_PCG and sg.num_inner_iterations > 0
+    assert [i.step_is_successful for i in g.iterations()] == [i.step_is_successful for i in o.iterations()]
+    for a, b in zip(g.iterations(), o.iterations()):
+        if a.step_is_successful:
+            assert abs(a.cost - b.cost) <= 1e-7 * b.cost
+    assert abs(sg.final_cost - so.final_cost) <= 1e-6 * so.final_cost
+    assert np.abs(g.get_blocks() - o.get_blocks()).max() < 1e-5
+    # and against the HIP exact path on the same graph
+    g2 = gpu_solver_cls(0)
+    pr.load(g2)
+    opt.linear_solver_type = capi.LINEAR_SCHUR_CHOLESKY
+    s2 = g2.solve(opt)
+    assert abs(sg.final_cost - s2.final_cost) <= 1e-6 * s2.final_cost
+
+
 def test_errors_are_loud(gpu_solver_cls):
     pr = mixed_problem(0)
     g = gpu_solver_cls(0)
