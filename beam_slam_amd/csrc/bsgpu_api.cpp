@@ -82,7 +82,13 @@ struct bsgpu_ctx {
   SmallGroup small[BSGPU_F_NUM_TYPES];
   std::vector<unsigned char> h_small_active[BSGPU_F_NUM_TYPES];
   unsigned char* d_small_inactive[BSGPU_F_NUM_TYPES] = {nullptr};
-  double* d_small_part[BSGPU_F_NUM_TYPES] = {nullptr};
+  double* d_small_part[BSGPU_F_NUM_TYPES] = {nullptr};       // per-factor cost at the current point
+  double* d_small_part_cand[BSGPU_F_NUM_TYPES] = {nullptr};  // ... at the candidate
+  double* d_small_part_mcc[BSGPU_F_NUM_TYPES] = {nullptr};   // per-row model-cost-change terms
+  ReduceEntry* d_reduce = nullptr;
+  int n_reduce = 0;
+  double* d_part_upd = nullptr;
+  int n_part_upd = 0;
   double *d_S = nullptr, *d_grad = nullptr, *d_hdiag = nullptr, *d_scale = nullptr, *d_dcl = nullptr;
   double *d_delta = nullptr, *d_y = nullptr, *d_scal = nullptr, *d_part = nullptr;
   double* h_scal = nullptr;  // pinned
@@ -95,6 +101,11 @@ struct bsgpu_ctx {
   std::vector<int> panel_off, panel_cnt, first_col_tile;
   int n_panels = 0;
   std::vector<bsgpu_iteration> iters;
+  // captured LM-step sequences (hipGraph): iteration zero / after an accepted step / after a rejected step
+  hipGraphExec_t g_first = nullptr, g_accept = nullptr, g_reject = nullptr;
+  bool graphs_tried = false, graphs_ok = false, use_graphs = true;
+  bsgpu_options graph_opts{};
+  double* h_radius = nullptr;  // pinned
   // block-sparse PCG path
   bool dense_ok = true, bsr_built = false, use_pcg = false;
   int nbr = 0, nblk = 0, pcg_iters_total = 0;
@@ -122,6 +133,11 @@ struct bsgpu_ctx {
     for (auto& g : small) g = SmallGroup();
     d_x = d_xcand = d_x0 = nullptr;
     bsr_built = false;
+    destroy_graphs();
+  }
+  void destroy_graphs() {
+    for (hipGraphExec_t* g : {&g_first, &g_accept, &g_reject}) if (*g) { (void)hipGraphExecDestroy(*g); *g = nullptr; }
+    graphs_tried = graphs_ok = false;
   }
 };
 
@@ -332,6 +348,8 @@ int finalize(bsgpu_ctx* c) {
     V.Linv = c->alloc<double>((size_t)nl * 6); V.z = c->alloc<double>((size_t)nl * 3);
     V.n_cost_part = (nv + 255) / 256;
     V.cost_part = c->alloc<double>(V.n_cost_part);
+    V.cost_part_cand = c->alloc<double>(V.n_cost_part);
+    V.mcc_part = c->alloc<double>(V.n_cost_part);
     if (!V.J || !V.CR || !V.r) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (visual tables)");
     // envelope of the reduced system, in 64-wide tiles: first structurally non-zero tile column per tile row
     const int T = c->npad / 64;
@@ -387,6 +405,8 @@ int finalize(bsgpu_ctx* c) {
     sg.r = c->alloc<double>((size_t)g.n * ti.m);
     sg.J = c->alloc<double>((size_t)g.n * ti.m * 3 * ti.nvar);
     c->d_small_part[t] = c->alloc<double>((size_t)g.n * ti.m);
+    c->d_small_part_cand[t] = c->alloc<double>(g.n);
+    c->d_small_part_mcc[t] = c->alloc<double>((size_t)g.n * ti.m);
     part_max = std::max(part_max, (size_t)g.n * ti.m);
   }
   if (losses.size() >= (1u << kMetaLossBits)) return fail(c, BSGPU_ERR_UNSUPPORTED, "too many distinct loss functions");
@@ -413,6 +433,9 @@ int finalize(bsgpu_ctx* c) {
   c->d_scal = c->alloc<double>(SC_NUM);
   c->d_part = c->alloc<double>(part_max + 8);
   if (!c->h_scal) HIPCHK(c, hipHostMalloc((void**)&c->h_scal, sizeof(double) * SC_NUM));
+  if (!c->h_radius) HIPCHK(c, hipHostMalloc((void**)&c->h_radius, sizeof(double)));
+  chol_prepare();
+  c->use_graphs = getenv("BSGPU_NO_GRAPH") == nullptr;
   HIPCHK(c, hipMemset(c->d_scal, 0, sizeof(double) * SC_NUM));
   HIPCHK(c, hipMemset(c->d_delta, 0, sizeof(double) * std::max(1, c->n_tan)));
   // ---- Cholesky plan: the skyline envelope (fill stays inside it). Row tile ti takes part in panel k
@@ -438,6 +461,26 @@ int finalize(bsgpu_ctx* c) {
     c->d_Vinv = c->alloc<double>((size_t)std::max(1, c->n_panels) * chol_vinv_stride());
     c->chol_v1 = getenv("BSGPU_CHOL_V1") != nullptr;
     if (!c->chol_v1 && c->dense_ok) { c->d_Lp = c->alloc<double>((size_t)c->npad * c->npad); if (!c->d_Lp) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (L panels)"); }
+  }
+  {
+    c->n_part_upd = (nb + 255) / 256;
+    c->d_part_upd = c->alloc<double>(2 * (size_t)c->n_part_upd + 2);
+    std::vector<ReduceEntry> tab;
+    if (c->vis.n) {
+      tab.push_back({c->vis.cost_part, c->vis.n_cost_part, 1, 0, SC_COST_X});
+      tab.push_back({c->vis.cost_part_cand, c->vis.n_cost_part, 1, 0, SC_COST_CAND});
+      tab.push_back({c->vis.mcc_part, c->vis.n_cost_part, 1, 0, SC_MCC});
+    }
+    for (int t = 2; t < BSGPU_F_NUM_TYPES; ++t) {
+      if (!c->small[t].n) continue;
+      tab.push_back({c->d_small_part[t], c->small[t].n, 1, 0, SC_COST_X});
+      tab.push_back({c->d_small_part_cand[t], c->small[t].n, 1, 0, SC_COST_CAND});
+      tab.push_back({c->d_small_part_mcc[t], c->small[t].n * c->small[t].m, 1, 0, SC_MCC});
+    }
+    tab.push_back({c->d_part_upd, c->n_part_upd, 2, 0, SC_STEP_NORM2});
+    tab.push_back({c->d_part_upd, c->n_part_upd, 2, 1, SC_X_NORM2});
+    c->n_reduce = (int)tab.size();
+    c->d_reduce = c->upload(tab);
   }
   HIPCHK(c, hipDeviceSynchronize());
   HIPCHK(c, hipGetLastError());
@@ -546,32 +589,30 @@ void pcg_solve(bsgpu_ctx* c, const bsgpu_options& o) {
   c->pcg_iters_total += (int)h[pcg_iters_slot()];
 }
 
+// residuals (+ Jacobians) of every factor group; per-group cost partials go to the arrays the
+// end-of-step reduction sums (current point: slot SC_COST_X, candidate: SC_COST_CAND)
 void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot) {
   hipStream_t s = c->stream;
-  launch_zero(s, c->d_scal + slot, 1);
-  if (c->vis.n) {
-    launch_reproj_eval(s, c->vis, x, c->d_cams, c->d_losses, with_J, c->vis.cost_part);
-    launch_sum(s, c->vis.cost_part, c->vis.n_cost_part, c->d_scal + slot, 1);
-  }
-  for (int t = 2; t < BSGPU_F_NUM_TYPES; ++t) {
-    if (!c->small[t].n) continue;
-    launch_small_eval(s, c->small[t], x, c->d_losses, with_J, c->d_small_part[t]);
-    launch_sum(s, c->d_small_part[t], c->small[t].n, c->d_scal + slot, 1);
-  }
+  const bool cand = slot == SC_COST_CAND;
+  if (c->vis.n) launch_reproj_eval(s, c->vis, x, c->d_cams, c->d_losses, with_J, cand ? c->vis.cost_part_cand : c->vis.cost_part);
+  for (int t = 2; t < BSGPU_F_NUM_TYPES; ++t)
+    if (c->small[t].n) launch_small_eval(s, c->small[t], x, c->d_losses, with_J, cand ? c->d_small_part_cand[t] : c->d_small_part[t]);
 }
+void final_reduce(bsgpu_ctx* c) { launch_final_reduce(c->stream, c->d_reduce, c->n_reduce, SC_X_NORM2 + 1, c->d_scal); }
 
 void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, bool first) {
   if (c->use_pcg) { assemble_pcg(c, o, radius, new_J, first); return; }
   hipStream_t s = c->stream;
+  if (new_J) launch_zero(s, c->d_scal + SC_GRAD_MAX, 3); else launch_zero(s, c->d_scal + SC_CHOL_FAIL, 1);  // GRAD_MAX, GRAD_NORM2, CHOL_FAIL
   launch_zero(s, c->d_S, (int64_t)c->npad * c->npad);
   launch_zero(s, c->d_grad, c->n_pose);
   launch_zero(s, c->d_hdiag, c->n_pose);
-  launch_landmark(s, c->vis, c->n_pose, radius, first ? 1 : 0, new_J ? 1 : 0, o.jacobi_scaling, o.min_lm_diagonal,
+  launch_landmark(s, c->vis, c->n_pose, c->d_scal + SC_RADIUS, first ? 1 : 0, new_J ? 1 : 0, o.jacobi_scaling, o.min_lm_diagonal,
                   o.max_lm_diagonal, c->d_scale, c->d_dcl, c->d_grad);
   launch_pairs(s, c->vis, c->d_S, c->npad, c->n_pose, c->d_grad, c->d_hdiag);
   for (int t = 2; t < BSGPU_F_NUM_TYPES; ++t)
     launch_small_assemble(s, c->small[t], c->d_S, c->npad, c->n_pose, c->d_grad, c->d_hdiag);
-  launch_pose_diag(s, c->n_pose, c->d_S, c->npad, c->d_hdiag, radius, first ? 1 : 0, new_J ? 1 : 0, o.jacobi_scaling,
+  launch_pose_diag(s, c->n_pose, c->d_S, c->npad, c->d_hdiag, c->d_scal + SC_RADIUS, first ? 1 : 0, new_J ? 1 : 0, o.jacobi_scaling,
                    o.min_lm_diagonal, o.max_lm_diagonal, c->d_scale, c->d_dcl, c->npad);
   if (new_J) {
     launch_zero(s, c->d_scal + SC_GRAD_MAX, 2);
@@ -618,7 +659,6 @@ void dense_factor_solve(hipStream_t s, bool v1, double* S, double* Lp, double* V
 
 void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
   hipStream_t s = c->stream;
-  launch_zero(s, c->d_scal + SC_CHOL_FAIL, 1);
   if (c->use_pcg) {
     pcg_solve(c, o);
     launch_negate_pose(s, c->n_pose, c->d_px, c->d_delta);
@@ -628,22 +668,66 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
     launch_negate_pose(s, c->n_pose, c->d_y, c->d_delta);
   }
   launch_backsub_landmarks(s, c->vis, c->n_pose, c->d_y, c->d_delta);
-  // model cost change
-  launch_zero(s, c->d_scal + SC_MCC, 1);
-  if (c->vis.n) {
-    launch_mcc(s, c->vis, c->n_pose, c->d_delta, c->d_part);
-    launch_sum(s, c->d_part, (c->vis.n + 255) / 256, c->d_scal + SC_MCC, 1);
-  }
-  for (int t = 2; t < BSGPU_F_NUM_TYPES; ++t) {
-    if (!c->small[t].n) continue;
-    launch_small_mcc(s, c->small[t], c->d_delta, c->d_small_part[t]);
-    launch_sum(s, c->d_small_part[t], c->small[t].n * c->small[t].m, c->d_scal + SC_MCC, 1);
-  }
+  // model cost change terms, candidate point and its cost: partial arrays only, summed once at the end
+  if (c->vis.n) launch_mcc(s, c->vis, c->n_pose, c->d_delta, c->vis.mcc_part);
+  for (int t = 2; t < BSGPU_F_NUM_TYPES; ++t)
+    if (c->small[t].n) launch_small_mcc(s, c->small[t], c->d_delta, c->d_small_part_mcc[t]);
   int n_part = 0;
   launch_update(s, c->nb, c->d_blk_xoff, c->d_blk_toff, c->d_blk_size, c->d_blk_manifold, c->d_x, c->d_delta, c->d_xcand,
-                c->d_part, &n_part);
-  launch_sum2(s, c->d_part, n_part, c->d_scal + SC_STEP_NORM2, c->d_scal + SC_X_NORM2);
+                c->d_part_upd, &n_part);
   eval_all(c, c->d_xcand, false, SC_COST_CAND);
+  final_reduce(c);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// one LM step = [x <- x_cand] [evaluate J] assemble -> factor -> back-substitute -> candidate -> cost.
+// The three variants are captured once per finalized problem as hipGraphs and replayed: the host-side
+// launch cost (~4.5 us per kernel, > 100 kernels per step) otherwise bounds the iteration rate.
+// ---------------------------------------------------------------------------------------------------
+enum StepKind { STEP_FIRST = 0, STEP_ACCEPT = 1, STEP_REJECT = 2 };
+
+void enqueue_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius) {
+  hipStream_t s = c->stream;
+  if (kind == STEP_ACCEPT)
+    (void)hipMemcpyAsync(c->d_x, c->d_xcand, sizeof(double) * c->h_x.size(), hipMemcpyDeviceToDevice, s);
+  if (kind != STEP_REJECT) eval_all(c, c->d_x, true, SC_COST_X);
+  assemble(c, o, radius, kind != STEP_REJECT, kind == STEP_FIRST);
+  linear_solve_and_candidate(c, o);
+}
+
+bool same_graph_options(const bsgpu_options& a, const bsgpu_options& b) {
+  return a.jacobi_scaling == b.jacobi_scaling && a.min_lm_diagonal == b.min_lm_diagonal && a.max_lm_diagonal == b.max_lm_diagonal;
+}
+
+void build_graphs(bsgpu_ctx* c, const bsgpu_options& o) {
+  if (c->graphs_tried && same_graph_options(o, c->graph_opts)) return;
+  c->destroy_graphs();
+  c->graphs_tried = true;
+  c->graph_opts = o;
+  if (!c->use_graphs || c->use_pcg) return;   // the PCG path synchronises inside a step: stays eager
+  hipGraphExec_t* execs[3] = {&c->g_first, &c->g_accept, &c->g_reject};
+  for (int kind = 0; kind < 3; ++kind) {
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return; }
+    enqueue_step(c, o, kind, 1.0);
+    if (hipStreamEndCapture(c->stream, &graph) != hipSuccess || !graph) { (void)hipGetLastError(); c->destroy_graphs(); c->graphs_tried = true; return; }
+    const hipError_t e = hipGraphInstantiate(execs[kind], graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) { (void)hipGetLastError(); c->destroy_graphs(); c->graphs_tried = true; return; }
+  }
+  c->graphs_ok = true;
+}
+
+void run_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius) {
+  *c->h_radius = radius;
+  (void)hipMemcpyAsync(c->d_scal + SC_RADIUS, c->h_radius, sizeof(double), hipMemcpyHostToDevice, c->stream);
+  if (c->graphs_ok) {
+    hipGraphExec_t g = kind == STEP_FIRST ? c->g_first : kind == STEP_ACCEPT ? c->g_accept : c->g_reject;
+    if (hipGraphLaunch(g, c->stream) == hipSuccess) return;
+    (void)hipGetLastError();
+    c->graphs_ok = false;   // fall back to eager launches of the same kernels
+  }
+  enqueue_step(c, o, kind, radius);
 }
 
 int fetch_scalars(bsgpu_ctx* c) {
@@ -693,10 +777,9 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
     // (visual factors with q, p and landmark all constant are not counted: they cannot occur in a
     //  fixed-lag window — noted in DESIGN.md)
   }
-  eval_all(c, c->d_x, true, SC_COST_X);
   double radius = o.initial_trust_region_radius, decrease_factor = 2.0;
-  assemble(c, o, radius, true, true);
-  linear_solve_and_candidate(c, o);
+  build_graphs(c, o);
+  run_step(c, o, STEP_FIRST, radius);
   rc = fetch_scalars(c);
   if (rc != BSGPU_OK) return rc;
   fixed = c->any_inactive ? c->h_scal[SC_FIXED_COST] : 0.0;
@@ -740,8 +823,7 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
         }
         radius = radius / decrease_factor; decrease_factor *= 2.0;
         it.cost = x_cost + fixed; it.step_is_successful = 0;
-        assemble(c, o, radius, false, false);
-        linear_solve_and_candidate(c, o);
+        run_step(c, o, STEP_REJECT, radius);
         rc = fetch_scalars(c);
         if (rc != BSGPU_OK) return rc;
         continue;
@@ -756,21 +838,18 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
       if (std::fabs(it.cost_change) <= o.function_tolerance * x_cost) { sum.termination_type = BSGPU_CONVERGENCE; msg = "Function tolerance reached."; break; }
       it.relative_decrease = (x_cost - cand_cost) / mcc;
       if (it.relative_decrease > o.min_relative_decrease) {
-        std::swap(c->d_x, c->d_xcand);
         radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * it.relative_decrease - 1.0, 3));
         radius = std::min(o.max_trust_region_radius, radius);
         decrease_factor = 2.0;
         it.step_is_successful = 1;
-        eval_all(c, c->d_x, true, SC_COST_X);
-        assemble(c, o, radius, true, false);
+        // the next step is computed speculatively so that one synchronisation per iteration suffices
+        run_step(c, o, STEP_ACCEPT, radius);
       } else {
         it.step_is_successful = 0;
         radius = radius / decrease_factor; decrease_factor *= 2.0;
         it.cost = cand_cost + fixed;
-        assemble(c, o, radius, false, false);
+        run_step(c, o, STEP_REJECT, radius);
       }
-      // speculatively compute the next step so that one synchronisation per iteration suffices
-      linear_solve_and_candidate(c, o);
       rc = fetch_scalars(c);
       if (rc != BSGPU_OK) return rc;
       if (it.step_is_successful) {
@@ -846,6 +925,7 @@ void bsgpu_destroy(bsgpu_ctx* c) {
   (void)hipSetDevice(c->device);
   c->free_device();
   if (c->h_scal) (void)hipHostFree(c->h_scal);
+  if (c->h_radius) (void)hipHostFree(c->h_radius);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -954,6 +1034,7 @@ int bsgpu_evaluate(bsgpu_ctx* c, double* cost, double* residuals, double* gradie
     }
   }
   eval_all(c, c->d_x, true, SC_COST_X);
+  final_reduce(c);
   rc = fetch_scalars(c);
   if (rc != BSGPU_OK) return rc;
   if (c->any_inactive) fixed = c->h_scal[SC_FIXED_COST];
@@ -1048,6 +1129,7 @@ int64_t bsgpu_reproj_jacobian_bytes(const bsgpu_ctx* c) {
 int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, double* x, int32_t use_v1, double* ms_out) {
   if (n <= 0 || !A || !b || !x) return BSGPU_ERR_INVALID;
   if (hipSetDevice(device) != hipSuccess) return BSGPU_ERR_DEVICE;
+  chol_prepare();
   const int npad = ((n + 1 + 63) / 64) * 64, T = npad / 64, n_panels = (n + 63) / 64;
   std::vector<double> hS((size_t)npad * npad, 0.0);
   for (int i = 0; i < n; ++i) std::memcpy(&hS[(size_t)i * npad], A + (size_t)i * n, sizeof(double) * n);

@@ -36,6 +36,7 @@ enum {
   SC_GRAD_NORM2 = 6,
   SC_CHOL_FAIL = 7,  // > 0 when a pivot was not positive / finite
   SC_FIXED_COST = 8,
+  SC_RADIUS = 12,    // trust-region radius of the step being computed (written by the host before each step)
   SC_NUM = 16
 };
 
@@ -75,8 +76,16 @@ struct Visual {
   double* CR = nullptr;       // n x 8: C = B M (2x3), rho = r - C z (2)
   double* Linv = nullptr;     // n_lm x 6  (lower-triangular inverse factor of Hll + lambda)
   double* z = nullptr;        // n_lm x 3  (Linv * g_l)
-  double* cost_part = nullptr;
+  double* cost_part = nullptr;       // per-workgroup cost partials at the current point
+  double* cost_part_cand = nullptr;  // ... at the candidate point
+  double* mcc_part = nullptr;        // per-workgroup model-cost-change partials
   int n_cost_part = 0;
+};
+
+// entry of the end-of-step reduction table (k_misc.hip: final_reduce_kernel)
+struct ReduceEntry {
+  const double* ptr;
+  int n, stride, offset, slot;
 };
 
 struct LaunchCtx {
@@ -88,13 +97,13 @@ void launch_reproj_eval(hipStream_t s, const Visual& v, const double* x, const D
                         const DevLoss* losses, bool with_J, double* cost_part_out);
 void launch_small_eval(hipStream_t s, const SmallGroup& g, const double* x, const DevLoss* losses, bool with_J,
                        double* cost_part /* n doubles: per-factor cost */);
-void launch_landmark(hipStream_t s, const Visual& v, int n_pose, double radius, int compute_scale,
+void launch_landmark(hipStream_t s, const Visual& v, int n_pose, const double* radius_ptr, int compute_scale,
                      int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* scale, double* dcl,
                      double* grad);
 void launch_pairs(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag);
 void launch_small_assemble(hipStream_t s, const SmallGroup& g, double* S, int ld, int rhs_row, double* grad,
                            double* hdiag);
-void launch_pose_diag(hipStream_t s, int n_pose, double* S, int ld, const double* hdiag, double radius,
+void launch_pose_diag(hipStream_t s, int n_pose, double* S, int ld, const double* hdiag, const double* radius_ptr,
                       int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* scale,
                       double* dcl, int npad);
 void launch_grad_norms(hipStream_t s, int nb, const int* blk_xoff, const int* blk_toff, const unsigned char* blk_size,
@@ -110,6 +119,7 @@ void launch_chol_panel_step(hipStream_t s, double* S, double* Lp, int ld, int k,
 void launch_chol_backsolve(hipStream_t s, const double* S, const double* Lp, const double* Vinv, int ld, int n_panels,
                            int n_pose, const int* tiles, const int* panel_off, const int* panel_cnt, double* y);
 int chol_vinv_stride();
+void chol_prepare();  // one-time function attributes (kept out of captured sequences)
 // block-sparse PCG path (k_pcg.hip)
 void launch_bsr_assemble(hipStream_t s, const SmallGroup& g, const int* slots, double* val, double* rhs, double* grad,
                          double* hdiag);
@@ -134,6 +144,7 @@ void launch_update(hipStream_t s, int nb, const int* blk_xoff, const int* blk_to
 void launch_sum(hipStream_t s, const double* part, int n, double* out, int accumulate);
 void launch_sum2(hipStream_t s, const double* part, int n_pairs, double* out_a, double* out_b);
 void launch_zero(hipStream_t s, double* p, int64_t n);
+void launch_final_reduce(hipStream_t s, const ReduceEntry* entries, int n_entries, int n_slots, double* scal);
 
 // measurement: the reprojection Jacobian kernel alone
 void launch_reproj_jacobian_only(hipStream_t s, const Visual& v, const double* x, const DevCamera* cams,

@@ -292,8 +292,6 @@ void launch_chol_potrf_tile(hipStream_t s, double* S, int ld, int t, int n_pose,
 void launch_chol_panel_step(hipStream_t s, double* S, double* Lp, int ld, int k, int n_pose, const int* row_tiles_dev,
                             int n_rows, int lookahead, double* Vinv, double* scal) {
   if (n_rows <= 0) return;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_panel_step_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPanelStepLds);
   hipLaunchKernelGGL(chol_panel_step_kernel, dim3(n_rows, n_rows), dim3(256), kPanelStepLds, s, S, Lp, ld, k, n_pose,
                      row_tiles_dev, lookahead, Vinv, scal);
 }
@@ -304,7 +302,7 @@ void launch_chol_panel_step(hipStream_t s, double* S, double* Lp, int ld, int k,
 //   rhs = y'[kb] - sum_{t in rows(kb)} L(t, kb)^T y[t]   (16 row groups x 64 columns, loads issued up front)
 //   solve L_kk^T y_kb = rhs                                (one wave, v_readlane chain, reciprocal pivots)
 // ---------------------------------------------------------------------------------------------------
-constexpr int kBackMaxN = 8192;  // y in LDS (64 KB)
+
 
 __global__ __launch_bounds__(1024) void chol_backsolve_kernel(const double* __restrict__ S, const double* __restrict__ Lp,
                                                               const double* __restrict__ Vinv, int ld, int n_panels,
@@ -363,12 +361,16 @@ void launch_chol_backsolve(hipStream_t s, const double* S, const double* Lp, con
                            int n_pose, const int* tiles, const int* panel_off, const int* panel_cnt, double* y) {
   if (n_panels <= 0) return;
   const size_t lds = sizeof(double) * ((size_t)(n_panels + 1) * NB + NB * (NB + 1) + 16 * NB);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
   hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1), dim3(1024), lds, s, S, Lp, Vinv, ld, n_panels, n_pose, tiles, panel_off,
                      panel_cnt, y);
 }
 
 int chol_vinv_stride() { return kVinvStride; }
+void chol_prepare() {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_panel_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)kPanelStepLds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+}
 
 }  // namespace bsg

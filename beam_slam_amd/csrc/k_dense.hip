@@ -13,10 +13,11 @@ namespace bsg {
 constexpr int NB = 64;
 
 __global__ void pose_diag_kernel(int n_pose, double* __restrict__ S, int ld, const double* __restrict__ hdiag,
-                                 double inv_radius, int compute_scale, int compute_dcl, int jacobi, double lm_lo,
+                                 const double* __restrict__ radius_ptr, int compute_scale, int compute_dcl, int jacobi, double lm_lo,
                                  double lm_hi, double* __restrict__ scale, double* __restrict__ dcl, int npad) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= npad) return;
+  const double inv_radius = 1.0 / radius_ptr[0];
   if (j < n_pose) {
     const double h = hdiag[j];
     double sc = compute_scale ? (jacobi ? 1.0 / (1.0 + sqrt(h)) : 1.0) : scale[j];
@@ -29,10 +30,10 @@ __global__ void pose_diag_kernel(int n_pose, double* __restrict__ S, int ld, con
   }
 }
 
-void launch_pose_diag(hipStream_t s, int n_pose, double* S, int ld, const double* hdiag, double radius,
+void launch_pose_diag(hipStream_t s, int n_pose, double* S, int ld, const double* hdiag, const double* radius_ptr,
                       int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* scale,
                       double* dcl, int npad) {
-  hipLaunchKernelGGL(pose_diag_kernel, dim3((npad + 255) / 256), dim3(256), 0, s, n_pose, S, ld, hdiag, 1.0 / radius,
+  hipLaunchKernelGGL(pose_diag_kernel, dim3((npad + 255) / 256), dim3(256), 0, s, n_pose, S, ld, hdiag, radius_ptr,
                      compute_scale, compute_dcl, jacobi, lm_lo, lm_hi, scale, dcl, npad);
 }
 

@@ -125,6 +125,29 @@ void launch_sum2(hipStream_t s, const double* part, int n_pairs, double* out_a, 
   hipLaunchKernelGGL(sum2_kernel, dim3(1), dim3(256), 0, s, part, n_pairs, out_a, out_b);
 }
 
+// One launch at the end of an LM step: workgroup `slot` adds up, in a fixed order, every partial array
+// registered for that scalar (costs of the factor groups, model-cost-change terms, step / x norms).
+__global__ __launch_bounds__(256) void final_reduce_kernel(const ReduceEntry* __restrict__ entries, int n_entries,
+                                                           double* __restrict__ scal) {
+  __shared__ double sred[4];
+  const int slot = blockIdx.x;
+  double acc = 0.0;
+  bool any = false;
+  for (int e = 0; e < n_entries; ++e) {
+    const ReduceEntry en = entries[e];
+    if (en.slot != slot) continue;
+    any = true;
+    double a = 0.0;
+    for (int i = threadIdx.x; i < en.n; i += 256) a += en.ptr[(size_t)i * en.stride + en.offset];
+    acc += a;
+  }
+  const double t = block_sum_256(acc, sred);
+  if (threadIdx.x == 0 && any) scal[slot] = t;
+}
+void launch_final_reduce(hipStream_t s, const ReduceEntry* entries, int n_entries, int n_slots, double* scal) {
+  if (n_entries > 0) hipLaunchKernelGGL(final_reduce_kernel, dim3(n_slots), dim3(256), 0, s, entries, n_entries, scal);
+}
+
 void launch_zero(hipStream_t s, double* p, int64_t n) {
   if (n > 0) (void)hipMemsetAsync(p, 0, sizeof(double) * (size_t)n, s);
 }

@@ -146,7 +146,7 @@ void launch_reproj_jacobian_only(hipStream_t s, const Visual& v, const double* x
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void landmark_kernel(int n_lm, const int* __restrict__ lm_start,
                                                        const double* __restrict__ J, const double2* __restrict__ r,
-                                                       int n_pose, double inv_radius, int compute_scale,
+                                                       int n_pose, const double* __restrict__ radius_ptr, int compute_scale,
                                                        int compute_dcl, int jacobi, double lm_lo, double lm_hi,
                                                        double* __restrict__ scale, double* __restrict__ dcl,
                                                        double* __restrict__ grad, double* __restrict__ Linv_out,
@@ -154,6 +154,7 @@ __global__ __launch_bounds__(256) void landmark_kernel(int n_lm, const int* __re
   const int gid = blockIdx.x * 256 + threadIdx.x;
   const int l = gid >> 3, sub = gid & 7;
   const bool valid = l < n_lm;
+  const double inv_radius = 1.0 / radius_ptr[0];   // device-resident so that a captured graph can be replayed
   int beg = 0, end = 0;
   if (valid) { beg = lm_start[l]; end = lm_start[l + 1]; }
   double h00 = 0, h01 = 0, h02 = 0, h11 = 0, h12 = 0, h22 = 0, b0 = 0, b1 = 0, b2 = 0;
@@ -227,12 +228,12 @@ __global__ void landmark_tail_kernel(int first, int n, const double2* __restrict
   o[6] = rf.x; o[7] = rf.y;
 }
 
-void launch_landmark(hipStream_t s, const Visual& v, int n_pose, double radius, int compute_scale,
+void launch_landmark(hipStream_t s, const Visual& v, int n_pose, const double* radius_ptr, int compute_scale,
                      int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* scale, double* dcl,
                      double* grad) {
   if (v.n_lm > 0) {
     const int grid = (v.n_lm * 8 + 255) / 256;
-    hipLaunchKernelGGL(landmark_kernel, dim3(grid), dim3(256), 0, s, v.n_lm, v.lm_start, v.J, v.r, n_pose, 1.0 / radius,
+    hipLaunchKernelGGL(landmark_kernel, dim3(grid), dim3(256), 0, s, v.n_lm, v.lm_start, v.J, v.r, n_pose, radius_ptr,
                        compute_scale, compute_dcl, jacobi, lm_lo, lm_hi, scale, dcl, grad, v.Linv, v.z, v.CR);
   }
   if (v.n > v.n_elim) {

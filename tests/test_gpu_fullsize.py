@@ -106,12 +106,16 @@ def test_c4_pose_graph_full_size(gpu_solver_cls):
     assert all(b <= a for a, b in zip(costs, costs[1:]))
     assert s.final_cost < 0.5 * s.initial_cost
     assert s.num_inner_iterations > 0
-    # poses move towards the ground truth
+    # the relative geometry is recovered: odometry edges agree with the measurements to their noise level
+    # (absolute errors are gauge-dependent: the prior pins the noisy first pose)
     x = g.get_blocks()
     blocks, p_true = pr.meta["blocks"], pr.meta["p_true"]
-    err0 = np.linalg.norm(np.array([pr.block(int(b), pr.values) for b in blocks[:, 0]]) - p_true, axis=1).mean()
-    err1 = np.linalg.norm(np.array([pr.block(int(b), x) for b in blocks[:, 0]]) - p_true, axis=1).mean()
-    assert err1 < 0.5 * err0
+    p_est = np.array([pr.block(int(b), x) for b in blocks[:, 0]])
+    p_ini = np.array([pr.block(int(b), pr.values) for b in blocks[:, 0]])
+    d_true = np.linalg.norm(np.diff(p_true, axis=0), axis=1)
+    e_est = np.abs(np.linalg.norm(np.diff(p_est, axis=0), axis=1) - d_true).mean()
+    e_ini = np.abs(np.linalg.norm(np.diff(p_ini, axis=0), axis=1) - d_true).mean()
+    assert e_est < 0.5 * e_ini
 
 
 def test_factor_order_invariance(gpu_solver_cls):
