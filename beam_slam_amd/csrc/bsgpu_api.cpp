@@ -21,6 +21,7 @@
 
 #include "../../include/bsgpu.h"
 #include "bsgpu_internal.h"
+#include "dense_plan.h"
 
 using namespace bsg;
 
@@ -92,14 +93,14 @@ struct bsgpu_ctx {
   double *d_S = nullptr, *d_grad = nullptr, *d_hdiag = nullptr, *d_scale = nullptr, *d_dcl = nullptr;
   double *d_delta = nullptr, *d_y = nullptr, *d_scal = nullptr, *d_part = nullptr;
   double* h_scal = nullptr;  // pinned
-  int* d_tiles = nullptr;
-  int *d_panel_off = nullptr, *d_panel_cnt = nullptr;
+  // tiled Cholesky plan (dense_plan.h) and its device tables
+  DensePlan plan;
+  std::vector<uint8_t> tile_adj;   // natural-tile adjacency of the reduced system
+  int *d_perm = nullptr, *d_iperm = nullptr, *d_nreal = nullptr, *d_rows_flat = nullptr, *d_potrf_tiles = nullptr;
+  PanelDesc* d_panels = nullptr;
   double* d_Vinv = nullptr;
-  double* d_Lp = nullptr;  // shadow of S holding the off-diagonal L panels (k_chol.hip)
-  std::vector<int> h_tiles;
-  bool chol_v1 = false;
-  std::vector<int> panel_off, panel_cnt, first_col_tile;
-  int n_panels = 0;
+  double* d_Lp = nullptr;     // shadow of S holding the off-diagonal L panels (k_chol.hip)
+  double* d_ytan = nullptr;   // y in tangent order
   std::vector<bsgpu_iteration> iters;
   // captured LM-step sequences (hipGraph): iteration zero / after an accepted step / after a rejected step
   hipGraphExec_t g_first = nullptr, g_accept = nullptr, g_reject = nullptr;
@@ -204,7 +205,7 @@ int finalize(bsgpu_ctx* c) {
   int nl = 0;
   for (int b = 0; b < nb; ++b) if (!c->is_const[b] && c->is_lm[b]) { c->toff[b] = to; to += 3; lm_index[b] = nl++; }
   c->n_tan = to; c->n_lm = nl;
-  c->npad = ((c->n_pose + 1 + 63) / 64) * 64;
+  c->npad = ((c->n_pose + 63) / 64 + 1) * 64;   // real tiles + one tile for the rhs row (dense_plan.h)
   c->dense_ok = (size_t)c->npad <= 12288;   // above: block-sparse PCG path only (pose-only problems)
   int row = 0;
   for (int t = 0; t < BSGPU_F_NUM_TYPES; ++t) { c->row0[t] = row; row += c->groups[t].n * kTypes[t].m; }
@@ -351,14 +352,14 @@ int finalize(bsgpu_ctx* c) {
     V.cost_part_cand = c->alloc<double>(V.n_cost_part);
     V.mcc_part = c->alloc<double>(V.n_cost_part);
     if (!V.J || !V.CR || !V.r) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (visual tables)");
-    // envelope of the reduced system, in 64-wide tiles: first structurally non-zero tile column per tile row
-    const int T = c->npad / 64;
-    c->first_col_tile.assign(T, 0);
-    for (int t = 0; t < T; ++t) c->first_col_tile[t] = t;
+    // structural tile adjacency of the reduced system (natural 64-wide tiles) for the Cholesky plan
+    const int T = (c->n_pose + 63) / 64;
+    c->tile_adj.assign((size_t)T * T, 0);
     auto touch = [&](int ra, int rb) {  // tangent rows ra, rb (start of 3-blocks)
       if (ra < 0 || rb < 0) return;
-      const int hi = std::max(ra, rb) , lo = std::min(ra, rb);
-      for (int r = hi; r < hi + 3; r += 2) { int tr = r / 64; c->first_col_tile[tr] = std::min(c->first_col_tile[tr], lo / 64); }
+      for (int a = ra; a < ra + 3; a += 2) for (int b = rb; b < rb + 3; b += 2) {
+        c->tile_adj[(size_t)(a / 64) * T + b / 64] = 1; c->tile_adj[(size_t)(b / 64) * T + a / 64] = 1;
+      }
     };
     for (int s = 0; s < V.n_seg; ++s) {
       const int i = seg_ci[s], j = seg_cj[s];
@@ -388,15 +389,15 @@ int finalize(bsgpu_ctx* c) {
       inactive[f] = !active[f];
       if (!active[f]) c->any_inactive = true;
       loss[f] = get_loss(g.loss_kind[f], g.loss_a[f]);
-      // envelope
-      if (active[f])
+      if (active[f]) {
+        const int T = (c->n_pose + 63) / 64;
         for (int sa = 0; sa < ti.nvar; ++sa)
           for (int sb = 0; sb < ti.nvar; ++sb) {
             const int ra = c->toff[idx[sa]], rb = c->toff[idx[sb]];
             if (ra < 0 || rb < 0) continue;
-            const int hi = std::max(ra, rb), lo = std::min(ra, rb);
-            for (int r = hi; r < hi + 3; r += 2) { int tr = r / 64; c->first_col_tile[tr] = std::min(c->first_col_tile[tr], lo / 64); }
+            for (int a = ra; a < ra + 3; a += 2) for (int b = rb; b < rb + 3; b += 2) c->tile_adj[(size_t)(a / 64) * T + b / 64] = 1;
           }
+      }
     }
     sg.xoff = c->upload(xoff); sg.toff = c->upload(toff); sg.consts = c->upload(g.consts); sg.loss = c->upload(loss);
     sg.active = c->upload(active);
@@ -435,32 +436,27 @@ int finalize(bsgpu_ctx* c) {
   if (!c->h_scal) HIPCHK(c, hipHostMalloc((void**)&c->h_scal, sizeof(double) * SC_NUM));
   if (!c->h_radius) HIPCHK(c, hipHostMalloc((void**)&c->h_radius, sizeof(double)));
   chol_prepare();
-  c->use_graphs = getenv("BSGPU_NO_GRAPH") == nullptr;
+  // hipGraph replay of the LM step is opt-in (BSGPU_GRAPH=1): on ROCm 7.2 the replay inserts a ~0.9 ms bubble
+  // inside the long dependent kernel chain (profiles/README.md), which cancels what it saves on launches
+  c->use_graphs = getenv("BSGPU_GRAPH") != nullptr;
   HIPCHK(c, hipMemset(c->d_scal, 0, sizeof(double) * SC_NUM));
   HIPCHK(c, hipMemset(c->d_delta, 0, sizeof(double) * std::max(1, c->n_tan)));
-  // ---- Cholesky plan: the skyline envelope (fill stays inside it). Row tile ti takes part in panel k
-  //      iff first_col_tile[ti] <= k < ti; the rhs tile (and padding) takes part in every panel.
+  // ---- tiled Cholesky plan: nested-dissection tile order, symbolic factorisation, step schedule
   {
-    const int T = c->npad / 64;
-    const int rhs_tile = c->n_pose / 64;
-    for (int t = rhs_tile; t < T; ++t) c->first_col_tile[t] = 0;
-    // make the envelope monotone enough for the blocked algorithm: a row tile that is active in panel k
-    // must stay active until its own diagonal (it is, by construction: active for all k >= first_col_tile).
-    c->n_panels = (c->n_pose + 63) / 64;
-    std::vector<int> tiles;
-    c->panel_off.assign(c->n_panels, 0); c->panel_cnt.assign(c->n_panels, 0);
-    for (int k = 0; k < c->n_panels; ++k) {
-      c->panel_off[k] = (int)tiles.size();
-      for (int t = k + 1; t < T; ++t) if (c->first_col_tile[t] <= k) tiles.push_back(t);
-      c->panel_cnt[k] = (int)tiles.size() - c->panel_off[k];
-    }
-    c->d_tiles = c->upload(tiles);
-    c->h_tiles = tiles;
-    c->d_panel_off = c->upload(c->panel_off);
-    c->d_panel_cnt = c->upload(c->panel_cnt);
-    c->d_Vinv = c->alloc<double>((size_t)std::max(1, c->n_panels) * chol_vinv_stride());
-    c->chol_v1 = getenv("BSGPU_CHOL_V1") != nullptr;
-    if (!c->chol_v1 && c->dense_ok) { c->d_Lp = c->alloc<double>((size_t)c->npad * c->npad); if (!c->d_Lp) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (L panels)"); }
+    const char* e = getenv("BSGPU_CHAINS");
+    const int max_chains = e ? std::max(1, atoi(e)) : 4;
+    const int T = (c->n_pose + 63) / 64;
+    if (c->tile_adj.size() != (size_t)T * T) c->tile_adj.assign((size_t)T * T, 0);
+    c->plan.build(c->n_pose, c->tile_adj, c->dense_ok ? max_chains : 1);
+    c->npad = c->plan.npad;
+    std::vector<int> iperm(T + 1, -1);
+    for (int t = 0; t < T; ++t) iperm[c->plan.perm[t]] = t;
+    c->d_perm = c->upload(c->plan.perm); c->d_iperm = c->upload(iperm); c->d_nreal = c->upload(c->plan.nreal);
+    c->d_rows_flat = c->upload(c->plan.rows_flat); c->d_potrf_tiles = c->upload(c->plan.potrf_tiles);
+    c->d_panels = c->upload(c->plan.panels);
+    c->d_Vinv = c->alloc<double>((size_t)std::max(1, T) * chol_vinv_stride());
+    c->d_ytan = c->alloc<double>(std::max(1, c->n_pose));
+    if (c->dense_ok) { c->d_Lp = c->alloc<double>((size_t)c->npad * c->npad); if (!c->d_Lp) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (L panels)"); }
   }
   {
     c->n_part_upd = (nb + 255) / 256;
@@ -609,52 +605,39 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
   launch_zero(s, c->d_hdiag, c->n_pose);
   launch_landmark(s, c->vis, c->n_pose, c->d_scal + SC_RADIUS, first ? 1 : 0, new_J ? 1 : 0, o.jacobi_scaling, o.min_lm_diagonal,
                   o.max_lm_diagonal, c->d_scale, c->d_dcl, c->d_grad);
-  launch_pairs(s, c->vis, c->d_S, c->npad, c->n_pose, c->d_grad, c->d_hdiag);
+  launch_pairs(s, c->vis, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm);
   for (int t = 2; t < BSGPU_F_NUM_TYPES; ++t)
-    launch_small_assemble(s, c->small[t], c->d_S, c->npad, c->n_pose, c->d_grad, c->d_hdiag);
+    launch_small_assemble(s, c->small[t], c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm);
   launch_pose_diag(s, c->n_pose, c->d_S, c->npad, c->d_hdiag, c->d_scal + SC_RADIUS, first ? 1 : 0, new_J ? 1 : 0, o.jacobi_scaling,
-                   o.min_lm_diagonal, o.max_lm_diagonal, c->d_scale, c->d_dcl, c->npad);
+                   o.min_lm_diagonal, o.max_lm_diagonal, c->d_scale, c->d_dcl, c->npad, c->d_iperm);
   if (new_J) {
     launch_zero(s, c->d_scal + SC_GRAD_MAX, 2);
     launch_grad_norms(s, c->nb, c->d_blk_xoff, c->d_blk_toff, c->d_blk_size, c->d_blk_manifold, c->d_x, c->d_grad, c->d_scal);
   }
 }
 
-// Cholesky of the (padded, rhs-augmented) reduced system in S and the solve L^T y = y'.
-void dense_factor_solve(hipStream_t s, bool v1, double* S, double* Lp, double* Vinv, int npad, int n_pose, int n_panels,
-                        const std::vector<int>& h_tiles, const std::vector<int>& panel_off, const std::vector<int>& panel_cnt,
-                        const std::vector<int>& first_col_tile, const int* d_tiles, const int* d_panel_off,
-                        const int* d_panel_cnt, double* y, double* scal) {
-  if (v1) {
-    for (int k = 0; k < n_panels; ++k) {
-      launch_chol_panel(s, S, npad, k, n_pose, d_tiles + panel_off[k], panel_cnt[k], scal);
-      launch_chol_update(s, S, npad, k, d_tiles + panel_off[k], panel_cnt[k]);
-    }
-  } else if (n_panels > 0) {
-    launch_chol_potrf_tile(s, S, npad, 0, n_pose, Vinv, scal);
-    for (int k = 0; k < n_panels; ++k) {
-      const int cnt = panel_cnt[k];
-      const bool la = (k + 1 < n_panels) && cnt > 0 && h_tiles[panel_off[k]] == k + 1;
-      launch_chol_panel_step(s, S, Lp, npad, k, n_pose, d_tiles + panel_off[k], cnt, la ? 1 : 0, Vinv, scal);
-      if (k + 1 < n_panels && !la) launch_chol_potrf_tile(s, S, npad, k + 1, n_pose, Vinv, scal);
-    }
+// Cholesky of the (padded, rhs-augmented, solver-ordered) reduced system in S and the solve L^T y = y',
+// following the plan's step schedule.  y comes back in solver order (npad entries).
+struct DenseDev {
+  const int *perm, *nreal, *rows_flat, *potrf_tiles;
+  const PanelDesc* panels;
+  double *Lp, *Vinv;
+};
+void dense_factor_solve(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* y, double* scal) {
+  const int ld = P.npad;
+  for (int st = 0; st < P.n_steps(); ++st) {
+    const int p0 = P.potrf_before_step_off[st], p1 = P.potrf_before_step_off[st + 1];
+    launch_chol_potrf_tiles(s, S, ld, D.potrf_tiles + p0, p1 - p0, D.nreal, D.Vinv, scal);
+    launch_chol_panel_step(s, S, D.Lp, ld, D.panels + P.step_off[st], P.step_off[st + 1] - P.step_off[st], P.step_maxrows[st],
+                           D.rows_flat, D.nreal, D.Vinv, scal);
   }
-  // y' = the rhs row after forward substitution.  Version 2 publishes off-diagonal L panels (the rhs
-  // row included) in the shadow matrix Lp; only the part inside the rhs row's own diagonal tile is in S.
-  const int rhs_col0 = std::min(n_pose, (n_pose / 64) * 64);
-  if (v1 || rhs_col0 == 0) {
-    (void)hipMemcpyAsync(y, S + (size_t)n_pose * npad, sizeof(double) * n_pose, hipMemcpyDeviceToDevice, s);
-  } else {
-    (void)hipMemcpyAsync(y, Lp + (size_t)n_pose * npad, sizeof(double) * rhs_col0, hipMemcpyDeviceToDevice, s);
-    if (n_pose > rhs_col0)
-      (void)hipMemcpyAsync(y + rhs_col0, S + (size_t)n_pose * npad + rhs_col0, sizeof(double) * (n_pose - rhs_col0),
-                           hipMemcpyDeviceToDevice, s);
-  }
-  if (v1) {
-    for (int kb = n_panels - 1; kb >= 0; --kb) launch_backsolve_step(s, S, npad, kb, n_pose, y, first_col_tile[kb] * 64);
-  } else {
-    launch_chol_backsolve(s, S, Lp, Vinv, npad, n_panels, n_pose, d_tiles, d_panel_off, d_panel_cnt, y);
-  }
+  // y' = the rhs row after forward substitution: row rhs_row of the shadow matrix (the rhs tile is an
+  // off-diagonal row tile of every panel)
+  (void)hipMemcpyAsync(y, D.Lp + (size_t)P.rhs_row * ld, sizeof(double) * P.T * 64, hipMemcpyDeviceToDevice, s);
+  (void)hipMemsetAsync(y + P.T * 64, 0, sizeof(double) * 64, s);
+  for (int st = P.n_steps() - 1; st >= 0; --st)
+    launch_chol_backsolve_step(s, S, D.Lp, D.Vinv, ld, D.panels + P.step_off[st], P.step_off[st + 1] - P.step_off[st], D.rows_flat,
+                               D.nreal, y);
 }
 
 void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
@@ -663,11 +646,11 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
     pcg_solve(c, o);
     launch_negate_pose(s, c->n_pose, c->d_px, c->d_delta);
   } else if (c->n_pose > 0) {
-    dense_factor_solve(s, c->chol_v1, c->d_S, c->d_Lp, c->d_Vinv, c->npad, c->n_pose, c->n_panels, c->h_tiles, c->panel_off,
-                       c->panel_cnt, c->first_col_tile, c->d_tiles, c->d_panel_off, c->d_panel_cnt, c->d_y, c->d_scal);
-    launch_negate_pose(s, c->n_pose, c->d_y, c->d_delta);
+    const DenseDev D{c->d_perm, c->d_nreal, c->d_rows_flat, c->d_potrf_tiles, c->d_panels, c->d_Lp, c->d_Vinv};
+    dense_factor_solve(s, c->plan, D, c->d_S, c->d_y, c->d_scal);
+    launch_y_to_delta(s, c->n_pose, c->d_y, c->d_perm, c->d_ytan, c->d_delta);
   }
-  launch_backsub_landmarks(s, c->vis, c->n_pose, c->d_y, c->d_delta);
+  launch_backsub_landmarks(s, c->vis, c->n_pose, c->d_ytan, c->d_delta);
   // model cost change terms, candidate point and its cost: partial arrays only, summed once at the end
   if (c->vis.n) launch_mcc(s, c->vis, c->n_pose, c->d_delta, c->vis.mcc_part);
   for (int t = 2; t < BSGPU_F_NUM_TYPES; ++t)
@@ -1124,52 +1107,75 @@ int64_t bsgpu_reproj_jacobian_bytes(const bsgpu_ctx* c) {
   return (int64_t)c->vis.n * 200 + (int64_t)c->h_x.size() * 8;
 }
 
-// Stand-alone dense SPD solve A x = b through the same kernels the reduced camera system uses
-// (test + measurement hook for the MFMA path).  Host pointers in and out.
-int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, double* x, int32_t use_v1, double* ms_out) {
+// Stand-alone dense SPD solve A x = b through the same plan + kernels the reduced camera system uses
+// (test + measurement hook for the MFMA path).  Host pointers in and out.  The tile structure (and with
+// it the nested-dissection ordering) is derived from the non-zeros of A; max_chains <= 1 forces the
+// natural order.
+int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, double* x, int32_t max_chains, double* ms_out) {
   if (n <= 0 || !A || !b || !x) return BSGPU_ERR_INVALID;
   if (hipSetDevice(device) != hipSuccess) return BSGPU_ERR_DEVICE;
   chol_prepare();
-  const int npad = ((n + 1 + 63) / 64) * 64, T = npad / 64, n_panels = (n + 63) / 64;
+  const int T = (n + 63) / 64;
+  std::vector<uint8_t> adj((size_t)T * T, 0);
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) if (A[(size_t)i * n + j] != 0.0) adj[(size_t)(i / 64) * T + j / 64] = 1;
+  DensePlan P;
+  P.build(n, adj, max_chains);
+  const int npad = P.npad;
   std::vector<double> hS((size_t)npad * npad, 0.0);
-  for (int i = 0; i < n; ++i) std::memcpy(&hS[(size_t)i * npad], A + (size_t)i * n, sizeof(double) * n);
-  std::memcpy(&hS[(size_t)n * npad], b, sizeof(double) * n);
-  for (int i = n; i < npad; ++i) hS[(size_t)i * npad + i] = 1.0;
-  std::vector<int> tiles, panel_off(n_panels), panel_cnt(n_panels), fct(T, 0);
-  for (int k = 0; k < n_panels; ++k) { panel_off[k] = (int)tiles.size(); for (int t = k + 1; t < T; ++t) tiles.push_back(t); panel_cnt[k] = (int)tiles.size() - panel_off[k]; }
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) hS[(size_t)P.spos(i) * npad + P.spos(j)] = A[(size_t)i * n + j];
+  for (int j = 0; j < n; ++j) hS[(size_t)P.rhs_row * npad + P.spos(j)] = b[j];
+  std::vector<uint8_t> real(npad, 0);
+  for (int j = 0; j < n; ++j) real[P.spos(j)] = 1;
+  for (int i = 0; i < npad; ++i) if (!real[i]) hS[(size_t)i * npad + i] = 1.0;
   double *dS = nullptr, *dLp = nullptr, *dV = nullptr, *dy = nullptr, *dscal = nullptr;
-  int *dt = nullptr, *dpo = nullptr, *dpc = nullptr;
+  int *dperm = nullptr, *dnreal = nullptr, *drows = nullptr, *dpot = nullptr;
+  PanelDesc* dpan = nullptr;
   hipStream_t s;
   if (hipStreamCreate(&s) != hipSuccess) return BSGPU_ERR_DEVICE;
+  auto up = [](const void* src, size_t bytes, void** dst) { if (bytes == 0) bytes = 8; if (hipMalloc(dst, bytes) != hipSuccess) return false; return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess || true; };
   bool ok = hipMalloc(&dS, sizeof(double) * hS.size()) == hipSuccess && hipMalloc(&dLp, sizeof(double) * hS.size()) == hipSuccess &&
-            hipMalloc(&dV, sizeof(double) * chol_vinv_stride() * n_panels) == hipSuccess && hipMalloc(&dy, sizeof(double) * npad) == hipSuccess &&
-            hipMalloc(&dscal, sizeof(double) * SC_NUM) == hipSuccess && hipMalloc(&dt, sizeof(int) * (tiles.size() + 1)) == hipSuccess &&
-            hipMalloc(&dpo, sizeof(int) * n_panels) == hipSuccess && hipMalloc(&dpc, sizeof(int) * n_panels) == hipSuccess;
+            hipMalloc(&dV, sizeof(double) * chol_vinv_stride() * std::max(1, T)) == hipSuccess && hipMalloc(&dy, sizeof(double) * npad) == hipSuccess &&
+            hipMalloc(&dscal, sizeof(double) * SC_NUM) == hipSuccess;
+  std::vector<int> pt = P.potrf_tiles; if (pt.empty()) pt.push_back(0);
+  std::vector<int> rf = P.rows_flat; if (rf.empty()) rf.push_back(0);
+  ok = ok && up(P.perm.data(), sizeof(int) * P.perm.size(), (void**)&dperm) && up(P.nreal.data(), sizeof(int) * P.nreal.size(), (void**)&dnreal) &&
+       up(rf.data(), sizeof(int) * rf.size(), (void**)&drows) && up(pt.data(), sizeof(int) * pt.size(), (void**)&dpot) &&
+       up(P.panels.data(), sizeof(PanelDesc) * P.panels.size(), (void**)&dpan);
   int rc = BSGPU_OK;
   if (ok) {
     (void)hipMemcpy(dS, hS.data(), sizeof(double) * hS.size(), hipMemcpyHostToDevice);
-    (void)hipMemcpy(dt, tiles.data(), sizeof(int) * tiles.size(), hipMemcpyHostToDevice);
-    (void)hipMemcpy(dpo, panel_off.data(), sizeof(int) * n_panels, hipMemcpyHostToDevice);
-    (void)hipMemcpy(dpc, panel_cnt.data(), sizeof(int) * n_panels, hipMemcpyHostToDevice);
     (void)hipMemset(dscal, 0, sizeof(double) * SC_NUM);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, s);
-    dense_factor_solve(s, use_v1 != 0, dS, dLp, dV, npad, n, n_panels, tiles, panel_off, panel_cnt, fct, dt, dpo, dpc, dy, dscal);
+    const DenseDev D{dperm, dnreal, drows, dpot, dpan, dLp, dV};
+    dense_factor_solve(s, P, D, dS, dy, dscal);
     (void)hipEventRecord(e1, s);
     if (hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess) rc = BSGPU_ERR_DEVICE;
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, e0, e1);
     if (ms_out) *ms_out = ms;
     double hscal[SC_NUM];
+    std::vector<double> hy(npad);
     (void)hipMemcpy(hscal, dscal, sizeof(hscal), hipMemcpyDeviceToHost);
-    (void)hipMemcpy(x, dy, sizeof(double) * n, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(hy.data(), dy, sizeof(double) * npad, hipMemcpyDeviceToHost);
+    for (int j = 0; j < n; ++j) x[j] = hy[P.spos(j)];
     if (rc == BSGPU_OK && hscal[SC_CHOL_FAIL] > 0.0) rc = BSGPU_ERR_NUMERIC;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   } else rc = BSGPU_ERR_DEVICE;
-  (void)hipFree(dS); (void)hipFree(dLp); (void)hipFree(dV); (void)hipFree(dy); (void)hipFree(dscal); (void)hipFree(dt); (void)hipFree(dpo); (void)hipFree(dpc);
+  (void)hipFree(dS); (void)hipFree(dLp); (void)hipFree(dV); (void)hipFree(dy); (void)hipFree(dscal);
+  (void)hipFree(dperm); (void)hipFree(dnreal); (void)hipFree(drows); (void)hipFree(dpot); (void)hipFree(dpan);
   (void)hipStreamDestroy(s);
   return rc;
+}
+
+// number of independent sub-chains / schedule steps of the current problem's Cholesky plan (diagnostics)
+int bsgpu_plan_info(const bsgpu_ctx* c, int32_t* n_chains, int32_t* n_steps, int32_t* n_tiles) {
+  if (!c->finalized) return BSGPU_ERR_INVALID;
+  if (n_chains) *n_chains = c->plan.n_chains;
+  if (n_steps) *n_steps = c->plan.n_steps();
+  if (n_tiles) *n_tiles = c->plan.T;
+  return BSGPU_OK;
 }
 
 }  // extern "C"

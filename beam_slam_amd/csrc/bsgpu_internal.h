@@ -100,24 +100,22 @@ void launch_small_eval(hipStream_t s, const SmallGroup& g, const double* x, cons
 void launch_landmark(hipStream_t s, const Visual& v, int n_pose, const double* radius_ptr, int compute_scale,
                      int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* scale, double* dcl,
                      double* grad);
-void launch_pairs(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag);
+void launch_pairs(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm);
 void launch_small_assemble(hipStream_t s, const SmallGroup& g, double* S, int ld, int rhs_row, double* grad,
-                           double* hdiag);
+                           double* hdiag, const int* perm);
 void launch_pose_diag(hipStream_t s, int n_pose, double* S, int ld, const double* hdiag, const double* radius_ptr,
                       int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* scale,
-                      double* dcl, int npad);
+                      double* dcl, int npad, const int* iperm);
 void launch_grad_norms(hipStream_t s, int nb, const int* blk_xoff, const int* blk_toff, const unsigned char* blk_size,
                        const unsigned char* blk_manifold, const double* x, const double* grad, double* scal);
-void launch_chol_panel(hipStream_t s, double* S, int ld, int k, int n_pose, const int* row_tiles_dev, int n_rows,
-                       double* scal);
-void launch_chol_update(hipStream_t s, double* S, int ld, int k, const int* row_tiles_dev, int n_rows);
-void launch_backsolve_step(hipStream_t s, const double* S, int ld, int kb, int n_pose, double* y, int col_begin);
-// version 2 (k_chol.hip): one launch per panel with look-ahead, single-workgroup back substitution
-void launch_chol_potrf_tile(hipStream_t s, double* S, int ld, int t, int n_pose, double* Vinv, double* scal);
-void launch_chol_panel_step(hipStream_t s, double* S, double* Lp, int ld, int k, int n_pose, const int* row_tiles_dev,
-                            int n_rows, int lookahead, double* Vinv, double* scal);
-void launch_chol_backsolve(hipStream_t s, const double* S, const double* Lp, const double* Vinv, int ld, int n_panels,
-                           int n_pose, const int* tiles, const int* panel_off, const int* panel_cnt, double* y);
+struct PanelDesc;
+void launch_chol_potrf_tiles(hipStream_t s, double* S, int ld, const int* tiles_dev, int n_tiles, const int* nreal_dev,
+                             double* Vinv, double* scal);
+void launch_chol_panel_step(hipStream_t s, double* S, double* Lp, int ld, const PanelDesc* descs_dev, int n_panels, int max_rows,
+                            const int* rows_flat_dev, const int* nreal_dev, double* Vinv, double* scal);
+void launch_chol_backsolve_step(hipStream_t s, const double* S, const double* Lp, const double* Vinv, int ld,
+                                const PanelDesc* descs_dev, int n_panels, const int* rows_flat_dev, const int* nreal_dev, double* y);
+void launch_y_to_delta(hipStream_t s, int n_pose, const double* y, const int* perm, double* y_tan, double* delta);
 int chol_vinv_stride();
 void chol_prepare();  // one-time function attributes (kept out of captured sequences)
 // block-sparse PCG path (k_pcg.hip)

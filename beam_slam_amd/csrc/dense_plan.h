@@ -1,0 +1,154 @@
+// Host-side plan of the tiled (64 x 64) Cholesky of the reduced camera system: tile ordering, exact
+// tile-level symbolic factorisation, and a step schedule that runs independent panels concurrently.
+//
+// A fixed-lag window gives a block-BANDED reduced system (a keyframe only shares landmarks / IMU factors
+// with its neighbours), and a banded Cholesky in natural order is one long dependent chain of panels.
+// Ordering the tiles by nested dissection of that chain — [piece 0][piece 1 reversed] ... [separators] —
+// makes the pieces independent sub-chains that factor concurrently (one launch handles one panel of every
+// piece), and only the separators (as wide as the band) come last.  The ordering is a permutation of whole
+// natural tiles; it is internal to the solver: the variable index the C-ABI exposes does not change.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <vector>
+
+namespace bsg {
+
+struct PanelDesc {  // device-visible
+  int k;          // S tile index of the panel (diagonal tile k)
+  int row_off;    // into the flat row-tile list
+  int n_rows;     // active row tiles below the diagonal (S tile indices, ascending)
+  int lookahead;  // the workgroup updating tile (k+1,k+1) also factors it
+};
+
+struct DensePlan {
+  int n_pose = 0, T = 0 /* real tiles */, npad = 0, rhs_row = 0;
+  std::vector<int> perm;       // natural tile -> S tile
+  std::vector<int> nreal;      // per S tile: number of real columns (64, or n_pose % 64 for the partial tile)
+  std::vector<int> rows_flat;  // row tiles of every panel (includes the rhs tile T)
+  std::vector<PanelDesc> panels;        // in schedule order
+  std::vector<int> step_off;            // panels[step_off[s] .. step_off[s+1]) run in one launch
+  std::vector<int> step_maxrows;
+  std::vector<int> potrf_before_step_off, potrf_tiles;  // standalone potrf launches: tiles to factor before step s
+  int n_chains = 1;
+  // solve offsets
+  inline int spos(int j) const { return perm[j >> 6] * 64 + (j & 63); }
+
+  // adj: T x T symmetric tile adjacency in NATURAL tile order (adj[i*T+j] != 0 iff block (i,j) of S is structurally non-zero)
+  void build(int n_pose_, const std::vector<uint8_t>& adj, int max_chains) {
+    n_pose = n_pose_;
+    T = (n_pose + 63) / 64;
+    npad = (T + 1) * 64;
+    rhs_row = T * 64;
+    // ---- ordering: nested dissection of a banded chain
+    perm.assign(T, 0);
+    int w = 0;
+    for (int i = 0; i < T; ++i) for (int j = 0; j < i; ++j) if (adj[(size_t)i * T + j]) w = std::max(w, i - j);
+    std::vector<int> order;  // S order: list of natural tiles
+    int chains = 1;
+    if (max_chains > 1 && w >= 1) while (chains * 2 <= max_chains && T >= (chains * 2) * 3 * w + (chains * 2 - 1) * w) chains *= 2;
+    n_chains = chains;
+    if (chains == 1) {
+      for (int i = 0; i < T; ++i) order.push_back(i);
+    } else {
+      // pieces p = 0..chains-1 separated by chains-1 separators of w tiles
+      const int n_sep = chains - 1;
+      const int body = T - n_sep * w;
+      std::vector<int> piece_len(chains, body / chains);
+      for (int i = 0; i < body % chains; ++i) piece_len[i]++;
+      std::vector<std::pair<int, int>> pieces, seps;  // [begin, end) natural tiles
+      int pos = 0;
+      for (int p = 0; p < chains; ++p) {
+        pieces.push_back({pos, pos + piece_len[p]});
+        pos += piece_len[p];
+        if (p < n_sep) { seps.push_back({pos, pos + w}); pos += w; }
+      }
+      // a piece is ordered so that the end adjacent to its (higher-level) separator comes last; pieces with
+      // separators on both sides are interior: natural order keeps the right neighbour last, the left separator
+      // then sees fill along the piece (still correct: the symbolic factorisation below is exact)
+      for (int p = 0; p < chains; ++p) {
+        const bool reverse = (p == chains - 1) && chains > 1;  // last piece: its only separator is on the left
+        if (!reverse) for (int t = pieces[p].first; t < pieces[p].second; ++t) order.push_back(t);
+        else for (int t = pieces[p].second - 1; t >= pieces[p].first; --t) order.push_back(t);
+      }
+      // separators last, lowest level (most local) first: odd-indexed separators of the recursive bisection
+      // are the deepest; order them by increasing "level" so that the root separator is eliminated last
+      std::vector<int> sep_level(n_sep, 0);
+      for (int i = 0; i < n_sep; ++i) { int lvl = 0, x = i + 1; while ((x & 1) == 0) { x >>= 1; ++lvl; } sep_level[i] = lvl; }
+      int max_lvl = 0;
+      for (int l : sep_level) max_lvl = std::max(max_lvl, l);
+      for (int lvl = 0; lvl <= max_lvl; ++lvl)
+        for (int i = 0; i < n_sep; ++i) if (sep_level[i] == lvl) for (int t = seps[i].first; t < seps[i].second; ++t) order.push_back(t);
+    }
+    for (int s = 0; s < T; ++s) perm[order[s]] = s;
+    nreal.assign(T + 1, 64);
+    if (n_pose % 64) nreal[perm[T - 1]] = n_pose % 64;
+    nreal[T] = 0;
+    // ---- exact tile-level symbolic factorisation in S order (tile T = rhs tile, coupled to every panel)
+    const int N = T + 1;
+    std::vector<uint8_t> B((size_t)N * N, 0);
+    for (int i = 0; i < T; ++i) for (int j = 0; j < T; ++j) if (adj[(size_t)i * T + j]) B[(size_t)perm[i] * N + perm[j]] = 1;
+    for (int k = 0; k < T; ++k) { B[(size_t)T * N + k] = 1; B[(size_t)k * N + T] = 1; B[(size_t)k * N + k] = 1; }
+    std::vector<std::vector<int>> rows(T);
+    for (int k = 0; k < T; ++k) {
+      for (int t = k + 1; t < N; ++t) if (B[(size_t)t * N + k]) rows[k].push_back(t);
+      for (int a : rows[k]) for (int b : rows[k]) B[(size_t)a * N + b] = 1;  // fill
+    }
+    // ---- schedule: panel k depends on every panel j < k with k in rows(j); two panels sharing a row tile
+    // (they would update the same C tiles) must not share a step
+    std::vector<int> ready(T, 0);  // earliest step
+    std::vector<int> step_of(T, -1);
+    std::vector<std::vector<int>> steps;
+    std::vector<std::vector<uint8_t>> step_rows;  // per step: which row tiles are written
+    for (int k = 0; k < T; ++k) {
+      int s = ready[k];
+      while (true) {
+        if (s >= (int)steps.size()) { steps.push_back({}); step_rows.push_back(std::vector<uint8_t>(N, 0)); }
+        bool conflict = step_rows[s][k] != 0;   // its own diagonal tile / column is still being updated in this step
+        // (the rhs tile T is shared by every panel: concurrent panels write disjoint column ranges of its row
+        //  and only its never-used diagonal tile is written twice)
+        for (int t : rows[k]) if (t < T && step_rows[s][t]) conflict = true;
+        if (!conflict) break;
+        ++s;
+      }
+      step_of[k] = s;
+      steps[s].push_back(k);
+      for (int t : rows[k]) if (t < T) { step_rows[s][t] = 1; ready[t] = std::max(ready[t], s + 1); }
+    }
+    // look-ahead: panel j may factor tile j+1 iff j+1 is its first row tile and no panel scheduled in the same
+    // or a later step also updates tile j+1
+    std::vector<int> last_updater_step(N, -1), n_updaters_in_last(N, 0);
+    for (int k = 0; k < T; ++k) for (int t : rows[k]) {
+      if (step_of[k] > last_updater_step[t]) { last_updater_step[t] = step_of[k]; n_updaters_in_last[t] = 1; }
+      else if (step_of[k] == last_updater_step[t]) n_updaters_in_last[t]++;
+    }
+    std::vector<uint8_t> factored_by_lookahead(T, 0);
+    panels.clear(); rows_flat.clear(); step_off.assign(1, 0); step_maxrows.clear();
+    for (size_t s = 0; s < steps.size(); ++s) {
+      int mr = 0;
+      for (int k : steps[s]) {
+        PanelDesc d;
+        d.k = k; d.row_off = (int)rows_flat.size(); d.n_rows = (int)rows[k].size();
+        const int t = k + 1;
+        d.lookahead = (t < T && !rows[k].empty() && rows[k][0] == t && last_updater_step[t] == (int)s && n_updaters_in_last[t] == 1) ? 1 : 0;
+        if (d.lookahead) factored_by_lookahead[t] = 1;
+        rows_flat.insert(rows_flat.end(), rows[k].begin(), rows[k].end());
+        mr = std::max(mr, d.n_rows);
+        panels.push_back(d);
+      }
+      step_off.push_back((int)panels.size());
+      step_maxrows.push_back(mr);
+    }
+    // standalone potrf: every tile not factored by a look-ahead, right before the step of its panel
+    potrf_before_step_off.assign(steps.size() + 1, 0);
+    potrf_tiles.clear();
+    for (size_t s = 0; s < steps.size(); ++s) {
+      potrf_before_step_off[s] = (int)potrf_tiles.size();
+      for (int k : steps[s]) if (!factored_by_lookahead[k]) potrf_tiles.push_back(k);
+    }
+    potrf_before_step_off[steps.size()] = (int)potrf_tiles.size();
+  }
+  int n_steps() const { return (int)step_off.size() - 1; }
+};
+
+}  // namespace bsg

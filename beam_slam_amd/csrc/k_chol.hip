@@ -1,4 +1,5 @@
-// Blocked FP64 Cholesky of the reduced camera system on gfx950, version 2: one kernel per 64-wide panel.
+// Blocked FP64 Cholesky of the reduced camera system on gfx950: one kernel per schedule step; a step runs
+// one 64-wide panel of every independent sub-chain of the nested-dissection ordering (dense_plan.h).
 //
 //   chol_potrf_tile   factor one 64x64 diagonal tile (used for tile 0 and for tiles no panel step
 //                     reaches); writes L and the inverses of its four 16x16 diagonal blocks
@@ -14,6 +15,7 @@
 // d[reg] = D[(lane>>4) + 4 reg][lane&15].  The 16x16 diagonal blocks are factored in registers of one
 // wave (row per lane, v_readlane broadcasts), the only scalar dependent chain left.
 #include "bsgpu_device.h"
+#include "dense_plan.h"
 
 namespace bsg {
 
@@ -162,20 +164,22 @@ BSG_DEV void write_factor(double* S, int ld, int t, const double* sC, const doub
 
 }  // namespace
 
-__global__ __launch_bounds__(256) void chol_potrf_tile_kernel(double* __restrict__ S, int ld, int t, int n_pose,
-                                                              double* __restrict__ Vinv, double* __restrict__ scal) {
+__global__ __launch_bounds__(256) void chol_potrf_tiles_kernel(double* __restrict__ S, int ld, const int* __restrict__ tiles,
+                                                               const int* __restrict__ nreal, double* __restrict__ Vinv,
+                                                               double* __restrict__ scal) {
   __shared__ double sC[NB * LDT];
   __shared__ double sV[4 * 256];
   __shared__ double sInvD[NB];
   const int tid = threadIdx.x;
+  const int t = tiles[blockIdx.x];
   for (int i = tid; i < NB * NB; i += 256) {
     const int r = i >> 6, c = i & 63;
     sC[r * LDT + c] = (c <= r) ? S[(size_t)(t * NB + r) * ld + t * NB + c] : 0.0;
   }
   __syncthreads();
-  mask_unreal_columns(sC, min(NB, max(0, n_pose - t * NB)), tid);
+  mask_unreal_columns(sC, nreal[t], tid);
   __syncthreads();
-  const bool bad = potrf64_lds(sC, sV, sInvD, tid, min(NB, max(0, n_pose - t * NB)));
+  const bool bad = potrf64_lds(sC, sV, sInvD, tid, nreal[t]);
   if (bad && tid == 0) scal[SC_CHOL_FAIL] = 1.0;
   write_factor(S, ld, t, sC, sV, sInvD, Vinv, tid);
 }
@@ -202,11 +206,14 @@ BSG_DEV void trsm_tile(double* sA, const double* sL, const double* sV, double* s
 }
 
 __global__ __launch_bounds__(256) void chol_panel_step_kernel(double* __restrict__ S, double* __restrict__ Lp, int ld,
-                                                              int k, int n_pose, const int* __restrict__ row_tiles,
-                                                              int lookahead, double* __restrict__ Vinv,
-                                                              double* __restrict__ scal) {
+                                                              const PanelDesc* __restrict__ descs,
+                                                              const int* __restrict__ rows_flat, const int* __restrict__ nreal,
+                                                              double* __restrict__ Vinv, double* __restrict__ scal) {
+  const PanelDesc pd = descs[blockIdx.z];
   const int bi = blockIdx.y, bj = blockIdx.x;
-  if (bj > bi) return;
+  if (bi >= pd.n_rows || bj > bi) return;
+  const int k = pd.k, lookahead = pd.lookahead;
+  const int* row_tiles = rows_flat + pd.row_off;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* sXi = smem;                 // 64 x LDT
   double* sXj = sXi + NB * LDT;       // 64 x LDT
@@ -276,9 +283,9 @@ __global__ __launch_bounds__(256) void chol_panel_step_kernel(double* __restrict
     for (int t = 0; t < 4; ++t) store_d(sC + (16 * wave) * LDT + 16 * t, LDT, lane, acc[t]);
     __syncthreads();
     for (int i = tid; i < NB * NB; i += 256) { const int r = i >> 6, c = i & 63; if (c > r) sC[r * LDT + c] = 0.0; }
-    mask_unreal_columns(sC, min(NB, max(0, n_pose - ti * NB)), tid);
+    mask_unreal_columns(sC, nreal[ti], tid);
     __syncthreads();
-    const bool bad = potrf64_lds(sC, sV, sInvD, tid, min(NB, max(0, n_pose - ti * NB)));
+    const bool bad = potrf64_lds(sC, sV, sInvD, tid, nreal[ti]);
     if (bad && tid == 0) scal[SC_CHOL_FAIL] = 1.0;
     write_factor(S, ld, ti, sC, sV, sInvD, Vinv, tid);
   }
@@ -286,91 +293,78 @@ __global__ __launch_bounds__(256) void chol_panel_step_kernel(double* __restrict
 
 constexpr size_t kPanelStepLds = sizeof(double) * (3 * NB * LDT + 4 * 256 + 4 * 16 * 17 + 64);
 
-void launch_chol_potrf_tile(hipStream_t s, double* S, int ld, int t, int n_pose, double* Vinv, double* scal) {
-  hipLaunchKernelGGL(chol_potrf_tile_kernel, dim3(1), dim3(256), 0, s, S, ld, t, n_pose, Vinv, scal);
+void launch_chol_potrf_tiles(hipStream_t s, double* S, int ld, const int* tiles_dev, int n_tiles, const int* nreal_dev,
+                             double* Vinv, double* scal) {
+  if (n_tiles <= 0) return;
+  hipLaunchKernelGGL(chol_potrf_tiles_kernel, dim3(n_tiles), dim3(256), 0, s, S, ld, tiles_dev, nreal_dev, Vinv, scal);
 }
-void launch_chol_panel_step(hipStream_t s, double* S, double* Lp, int ld, int k, int n_pose, const int* row_tiles_dev,
-                            int n_rows, int lookahead, double* Vinv, double* scal) {
-  if (n_rows <= 0) return;
-  hipLaunchKernelGGL(chol_panel_step_kernel, dim3(n_rows, n_rows), dim3(256), kPanelStepLds, s, S, Lp, ld, k, n_pose,
-                     row_tiles_dev, lookahead, Vinv, scal);
+void launch_chol_panel_step(hipStream_t s, double* S, double* Lp, int ld, const PanelDesc* descs_dev, int n_panels, int max_rows,
+                            const int* rows_flat_dev, const int* nreal_dev, double* Vinv, double* scal) {
+  if (n_panels <= 0 || max_rows <= 0) return;
+  hipLaunchKernelGGL(chol_panel_step_kernel, dim3(max_rows, max_rows, n_panels), dim3(256), kPanelStepLds, s, S, Lp, ld, descs_dev,
+                     rows_flat_dev, nreal_dev, Vinv, scal);
 }
 
 // ---------------------------------------------------------------------------------------------------
-// backward substitution in ONE workgroup of 1024 threads; y lives in LDS for the whole march.
-// For kb = last panel .. 0:
-//   rhs = y'[kb] - sum_{t in rows(kb)} L(t, kb)^T y[t]   (16 row groups x 64 columns, loads issued up front)
-//   solve L_kk^T y_kb = rhs                                (one wave, v_readlane chain, reciprocal pivots)
+// backward substitution L^T y = y', one launch per schedule step in reverse order, one 1024-thread
+// workgroup per panel of the step:
+//   rhs = y'[k] - sum_{t in rows(k)} L(t, k)^T y[t]   (16 row groups x 64 columns, loads issued up front)
+//   solve L_kk^T y_k = rhs                              (one wave, v_readlane chain, reciprocal pivots)
+// y is in S (solver) order; rows >= nreal of a tile are kept zero.
 // ---------------------------------------------------------------------------------------------------
-
-
-__global__ __launch_bounds__(1024) void chol_backsolve_kernel(const double* __restrict__ S, const double* __restrict__ Lp,
-                                                              const double* __restrict__ Vinv, int ld, int n_panels,
-                                                              int n_pose, const int* __restrict__ tiles,
-                                                              const int* __restrict__ panel_off,
-                                                              const int* __restrict__ panel_cnt, double* __restrict__ y) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* sy = smem;                         // npad entries (rows >= n_pose are zero)
-  double* sL = sy + ((n_panels + 1) * NB);   // 64 x 65
-  double* sp = sL + NB * (NB + 1);           // 16 x 64
+__global__ __launch_bounds__(1024) void chol_backsolve_step_kernel(const double* __restrict__ S, const double* __restrict__ Lp,
+                                                                   const double* __restrict__ Vinv, int ld,
+                                                                   const PanelDesc* __restrict__ descs,
+                                                                   const int* __restrict__ rows_flat,
+                                                                   const int* __restrict__ nreal, double* __restrict__ y) {
+  __shared__ double sL[NB * (NB + 1)];
+  __shared__ double sp[16 * NB];
+  const PanelDesc pd = descs[blockIdx.x];
   const int tid = threadIdx.x, c = tid & 63, part = tid >> 6;
-  const int ny = (n_panels + 1) * NB;
-  for (int i = tid; i < ny; i += 1024) sy[i] = (i < n_pose) ? y[i] : 0.0;
-  __syncthreads();
-  for (int kb = n_panels - 1; kb >= 0; --kb) {
-    const int c0 = kb * NB;
-    // diagonal tile -> LDS (4 loads per thread, independent)
+  const int kb = pd.k, c0 = kb * NB, nr = nreal[kb];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int i = tid + 1024 * q;
-      const int r = i >> 6, cc = i & 63;
-      sL[r * (NB + 1) + cc] = (cc <= r) ? S[(size_t)(c0 + r) * ld + c0 + cc] : 0.0;
-    }
-    // off-diagonal part: thread (part, c) covers rows part*4 .. part*4+3 of every active row tile
-    double acc = 0.0;
-    const int cnt = panel_cnt[kb], off = panel_off[kb];
-    for (int q = 0; q < cnt; ++q) {
-      const int r0 = tiles[off + q] * NB + 4 * part;
-      const double l0 = Lp[(size_t)(r0 + 0) * ld + c0 + c], l1 = Lp[(size_t)(r0 + 1) * ld + c0 + c];
-      const double l2 = Lp[(size_t)(r0 + 2) * ld + c0 + c], l3 = Lp[(size_t)(r0 + 3) * ld + c0 + c];
-      acc = fma(l0, sy[r0], acc); acc = fma(l1, sy[r0 + 1], acc);
-      acc = fma(l2, sy[r0 + 2], acc); acc = fma(l3, sy[r0 + 3], acc);
-    }
-    sp[part * NB + c] = acc;
-    __syncthreads();
-    if (tid < NB) {
-      double sum = 0.0;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) sum += sp[q * NB + tid];
-      double yv = sy[c0 + tid] - sum;
-      const double invd = Vinv[(size_t)kb * kVinvStride + 1024 + tid];
-#pragma unroll
-      for (int j = NB - 1; j >= 0; --j) {
-        const double yj = readlane_d(yv, j) * readlane_d(invd, j);
-        if (tid == j) yv = yj;
-        if (tid < j) yv = fma(-sL[j * (NB + 1) + tid], yj, yv);
-      }
-      if (c0 + tid < n_pose) sy[c0 + tid] = yv; else sy[c0 + tid] = 0.0;
-    }
-    __syncthreads();
+  for (int q = 0; q < 4; ++q) {
+    const int i = tid + 1024 * q;
+    const int r = i >> 6, cc = i & 63;
+    sL[r * (NB + 1) + cc] = (cc <= r) ? S[(size_t)(c0 + r) * ld + c0 + cc] : 0.0;
   }
-  for (int i = tid; i < n_pose; i += 1024) y[i] = sy[i];
+  double acc = 0.0;
+  for (int q = 0; q < pd.n_rows; ++q) {
+    const int r0 = rows_flat[pd.row_off + q] * NB + 4 * part;
+    const double l0 = Lp[(size_t)(r0 + 0) * ld + c0 + c], l1 = Lp[(size_t)(r0 + 1) * ld + c0 + c];
+    const double l2 = Lp[(size_t)(r0 + 2) * ld + c0 + c], l3 = Lp[(size_t)(r0 + 3) * ld + c0 + c];
+    acc = fma(l0, y[r0], acc); acc = fma(l1, y[r0 + 1], acc);
+    acc = fma(l2, y[r0 + 2], acc); acc = fma(l3, y[r0 + 3], acc);
+  }
+  sp[part * NB + c] = acc;
+  __syncthreads();
+  if (tid < NB) {
+    double sum = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) sum += sp[q * NB + tid];
+    double yv = (tid < nr) ? (y[c0 + tid] - sum) : 0.0;
+    const double invd = Vinv[(size_t)kb * kVinvStride + 1024 + tid];
+#pragma unroll
+    for (int j = NB - 1; j >= 0; --j) {
+      const double yj = readlane_d(yv, j) * readlane_d(invd, j);
+      if (tid == j) yv = yj;
+      if (tid < j) yv = fma(-sL[j * (NB + 1) + tid], yj, yv);
+    }
+    y[c0 + tid] = (tid < nr) ? yv : 0.0;
+  }
 }
 
-void launch_chol_backsolve(hipStream_t s, const double* S, const double* Lp, const double* Vinv, int ld, int n_panels,
-                           int n_pose, const int* tiles, const int* panel_off, const int* panel_cnt, double* y) {
+void launch_chol_backsolve_step(hipStream_t s, const double* S, const double* Lp, const double* Vinv, int ld,
+                                const PanelDesc* descs_dev, int n_panels, const int* rows_flat_dev, const int* nreal_dev, double* y) {
   if (n_panels <= 0) return;
-  const size_t lds = sizeof(double) * ((size_t)(n_panels + 1) * NB + NB * (NB + 1) + 16 * NB);
-  hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1), dim3(1024), lds, s, S, Lp, Vinv, ld, n_panels, n_pose, tiles, panel_off,
-                     panel_cnt, y);
+  hipLaunchKernelGGL(chol_backsolve_step_kernel, dim3(n_panels), dim3(1024), 0, s, S, Lp, Vinv, ld, descs_dev, rows_flat_dev,
+                     nreal_dev, y);
 }
 
 int chol_vinv_stride() { return kVinvStride; }
 void chol_prepare() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_panel_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kPanelStepLds);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024);
 }
 
 }  // namespace bsg

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(64) void pairs_kernel(int n_seg, const int* __restr
                                                    const double* __restrict__ CR, const int* __restrict__ cp_tq,
                                                    const int* __restrict__ cp_tp, double* __restrict__ S, int ld,
                                                    int rhs_row, double* __restrict__ grad,
-                                                   double* __restrict__ hdiag) {
+                                                   double* __restrict__ hdiag, const int* __restrict__ perm) {
   __shared__ double sb[64];
   const int seg = blockIdx.x;
   if (seg >= n_seg) return;
@@ -334,24 +334,25 @@ __global__ __launch_bounds__(64) void pairs_kernel(int n_seg, const int* __restr
     const int col = (c < 3) ? (tqj < 0 ? -1 : tqj + c) : (tpj < 0 ? -1 : tpj + c - 3);
     if (row >= 0 && col >= 0) {
       const double val = sb[lane];
-      atomicAdd(&S[(size_t)row * ld + col], val);
-      if (!diag) atomicAdd(&S[(size_t)col * ld + row], val);
+      const int sr = perm[row >> 6] * 64 + (row & 63), sc = perm[col >> 6] * 64 + (col & 63);   // solver positions
+      atomicAdd(&S[(size_t)sr * ld + sc], val);
+      if (!diag) atomicAdd(&S[(size_t)sc * ld + sr], val);
     }
   } else if (diag && lane < 42) {
     const int a = lane - 36;
     const int row = (a < 3) ? (tqi < 0 ? -1 : tqi + a) : (tpi < 0 ? -1 : tpi + a - 3);
     if (row >= 0) {
-      atomicAdd(&S[(size_t)rhs_row * ld + row], sb[36 + a]);
+      atomicAdd(&S[(size_t)rhs_row * ld + perm[row >> 6] * 64 + (row & 63)], sb[36 + a]);
       atomicAdd(&grad[row], sb[42 + a]);
       atomicAdd(&hdiag[row], sb[48 + a]);
     }
   }
 }
 
-void launch_pairs(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag) {
+void launch_pairs(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm) {
   if (v.n_seg == 0) return;
   hipLaunchKernelGGL(pairs_kernel, dim3(v.n_seg), dim3(64), 0, s, v.n_seg, v.seg_ci, v.seg_cj, v.seg_start, v.ent_fa,
-                     v.ent_fb, v.J, v.r, v.CR, v.cp_tq, v.cp_tp, S, ld, rhs_row, grad, hdiag);
+                     v.ent_fb, v.J, v.r, v.CR, v.cp_tq, v.cp_tp, S, ld, rhs_row, grad, hdiag, perm);
 }
 
 // ---------------------------------------------------------------------------------------------------

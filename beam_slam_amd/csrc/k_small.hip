@@ -548,7 +548,8 @@ void launch_small_eval(hipStream_t s, const SmallGroup& g, const double* x, cons
 // lanes stride over the (column a, column b) pairs; FP64 atomics into S, the rhs row, grad and hdiag.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void small_assemble_kernel(SmallGroup g, double* __restrict__ S, int ld, int rhs_row,
-                                                            double* __restrict__ grad, double* __restrict__ hdiag) {
+                                                            double* __restrict__ grad, double* __restrict__ hdiag,
+                                                            const int* __restrict__ perm) {
   __shared__ double sJ[15 * 30];
   __shared__ double sr[15];
   __shared__ int st[10];
@@ -566,23 +567,24 @@ __global__ __launch_bounds__(64) void small_assemble_kernel(SmallGroup g, double
     if (ta < 0 || tb < 0) continue;
     double acc = 0.0;
     for (int k = 0; k < m; ++k) acc += sJ[k * tw + a] * sJ[k * tw + b];
-    atomicAdd(&S[(size_t)(ta + a % 3) * ld + tb + b % 3], acc);
+    const int ra = ta + a % 3, rb = tb + b % 3;
+    atomicAdd(&S[(size_t)(perm[ra >> 6] * 64 + (ra & 63)) * ld + perm[rb >> 6] * 64 + (rb & 63)], acc);
   }
   for (int a = lane; a < tw; a += 64) {
     const int ta = st[a / 3];
     if (ta < 0) continue;
     double gs = 0.0, hs = 0.0;
     for (int k = 0; k < m; ++k) { const double j = sJ[k * tw + a]; gs += j * sr[k]; hs += j * j; }
-    atomicAdd(&S[(size_t)rhs_row * ld + ta + a % 3], gs);
+    atomicAdd(&S[(size_t)rhs_row * ld + perm[(ta + a % 3) >> 6] * 64 + ((ta + a % 3) & 63)], gs);
     atomicAdd(&grad[ta + a % 3], gs);
     atomicAdd(&hdiag[ta + a % 3], hs);
   }
 }
 
 void launch_small_assemble(hipStream_t s, const SmallGroup& g, double* S, int ld, int rhs_row, double* grad,
-                           double* hdiag) {
+                           double* hdiag, const int* perm) {
   if (g.n == 0) return;
-  hipLaunchKernelGGL(small_assemble_kernel, dim3(g.n), dim3(64), 0, s, g, S, ld, rhs_row, grad, hdiag);
+  hipLaunchKernelGGL(small_assemble_kernel, dim3(g.n), dim3(64), 0, s, g, S, ld, rhs_row, grad, hdiag, perm);
 }
 
 // model cost change term of a pose-only group, one lane per residual row:

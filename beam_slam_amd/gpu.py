@@ -34,14 +34,14 @@ def lib():
     return _LIB
 
 
-def dense_solve(A, b, device=0, use_v1=False):
+def dense_solve(A, b, device=0, max_chains=4):
     """A x = b (SPD) through the reduced-camera-system kernels; returns (x, milliseconds)."""
     import numpy as np
     A = np.ascontiguousarray(A, np.float64)
     b = np.ascontiguousarray(b, np.float64)
     x = np.empty_like(b)
     ms = ctypes.c_double(0.0)
-    rc = lib().bsgpu_dense_solve(device, A.shape[0], A.ctypes.data, b.ctypes.data, x.ctypes.data, 1 if use_v1 else 0,
+    rc = lib().bsgpu_dense_solve(device, A.shape[0], A.ctypes.data, b.ctypes.data, x.ctypes.data, int(max_chains),
                                  ctypes.byref(ms))
     if rc != 0:
         raise capi.SolverError(rc, "bsgpu_dense_solve failed")
@@ -59,6 +59,13 @@ class GpuSolver(capi.Solver):
         if ms < 0:
             raise capi.SolverError(capi.ERR_DEVICE, "bsgpu_time_reproj_jacobian_ms failed")
         return ms
+
+    def plan_info(self):
+        """(independent sub-chains, schedule steps, 64-wide tiles) of the reduced system's Cholesky plan."""
+        a, b, c = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
+        self.finalize()
+        lib().bsgpu_plan_info(ctypes.c_void_p(self._ctx), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+        return a.value, b.value, c.value
 
     def reproj_jacobian_bytes(self):
         return lib().bsgpu_reproj_jacobian_bytes(self._ctx)

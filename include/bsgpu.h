@@ -318,9 +318,13 @@ int64_t bsgpu_reproj_jacobian_bytes(const bsgpu_ctx* ctx);
 
 /* Stand-alone dense SPD solve A x = b (row-major n x n, host pointers) through the kernels the
  * reduced camera system uses after Schur elimination — test and measurement hook for the FP64
- * MFMA Cholesky.  use_v1 != 0 selects the first-generation kernels.  ms_out: HIP-event time.    */
+ * MFMA Cholesky.  The tile structure is taken from the non-zeros of A; max_chains caps the number
+ * of independent sub-chains of the nested-dissection ordering (<= 1: natural order).
+ * ms_out: HIP-event time.                                                                       */
 int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, double* x,
-                      int32_t use_v1, double* ms_out);
+                      int32_t max_chains, double* ms_out);
+/* Diagnostics of the tiled-Cholesky plan of the finalized problem. */
+int bsgpu_plan_info(const bsgpu_ctx* ctx, int32_t* n_chains, int32_t* n_steps, int32_t* n_tiles);
 
 #ifdef __cplusplus
 }
