@@ -98,6 +98,8 @@ struct bsgpu_ctx {
   std::vector<uint8_t> tile_adj;   // natural-tile adjacency of the reduced system
   int *d_perm = nullptr, *d_iperm = nullptr, *d_nreal = nullptr, *d_rows_flat = nullptr, *d_potrf_tiles = nullptr;
   PanelDesc* d_panels = nullptr;
+  PanelDesc* d_bs_sep_panels = nullptr;
+  int *d_panel_of_tile = nullptr, *d_chain_begin = nullptr, *d_chain_end = nullptr;
   double* d_Vinv = nullptr;
   double* d_Lp = nullptr;     // shadow of S holding the off-diagonal L panels (k_chol.hip)
   double* d_ytan = nullptr;   // y in tangent order
@@ -454,6 +456,8 @@ int finalize(bsgpu_ctx* c) {
     c->d_perm = c->upload(c->plan.perm); c->d_iperm = c->upload(iperm); c->d_nreal = c->upload(c->plan.nreal);
     c->d_rows_flat = c->upload(c->plan.rows_flat); c->d_potrf_tiles = c->upload(c->plan.potrf_tiles);
     c->d_panels = c->upload(c->plan.panels);
+    c->d_bs_sep_panels = c->upload(c->plan.bs_sep_panels); c->d_panel_of_tile = c->upload(c->plan.panel_of_tile);
+    c->d_chain_begin = c->upload(c->plan.chain_begin); c->d_chain_end = c->upload(c->plan.chain_end);
     c->d_Vinv = c->alloc<double>((size_t)std::max(1, T) * chol_vinv_stride());
     c->d_ytan = c->alloc<double>(std::max(1, c->n_pose));
     if (c->dense_ok) { c->d_Lp = c->alloc<double>((size_t)c->npad * c->npad); if (!c->d_Lp) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (L panels)"); }
@@ -622,6 +626,8 @@ struct DenseDev {
   const int *perm, *nreal, *rows_flat, *potrf_tiles;
   const PanelDesc* panels;
   double *Lp, *Vinv;
+  const PanelDesc* bs_sep_panels;
+  const int *panel_of_tile, *chain_begin, *chain_end;
 };
 void dense_factor_solve(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* y, double* scal) {
   const int ld = P.npad;
@@ -635,9 +641,12 @@ void dense_factor_solve(hipStream_t s, const DensePlan& P, const DenseDev& D, do
   // off-diagonal row tile of every panel)
   (void)hipMemcpyAsync(y, D.Lp + (size_t)P.rhs_row * ld, sizeof(double) * P.T * 64, hipMemcpyDeviceToDevice, s);
   (void)hipMemsetAsync(y + P.T * 64, 0, sizeof(double) * 64, s);
-  for (int st = P.n_steps() - 1; st >= 0; --st)
-    launch_chol_backsolve_step(s, S, D.Lp, D.Vinv, ld, D.panels + P.step_off[st], P.step_off[st + 1] - P.step_off[st], D.rows_flat,
-                               D.nreal, y);
+  // separators (the top of the elimination tree) step by step, then every independent piece in one launch
+  for (size_t g = 0; g + 1 < P.bs_sep_step_off.size(); ++g)
+    launch_chol_backsolve_step(s, S, D.Lp, D.Vinv, ld, D.bs_sep_panels + P.bs_sep_step_off[g], P.bs_sep_step_off[g + 1] - P.bs_sep_step_off[g],
+                               D.rows_flat, D.nreal, y);
+  launch_chol_backsolve_chains(s, S, D.Lp, D.Vinv, ld, D.panels, D.panel_of_tile, D.chain_begin, D.chain_end, (int)P.chain_begin.size(),
+                               D.rows_flat, D.nreal, y);
 }
 
 void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
@@ -646,7 +655,8 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
     pcg_solve(c, o);
     launch_negate_pose(s, c->n_pose, c->d_px, c->d_delta);
   } else if (c->n_pose > 0) {
-    const DenseDev D{c->d_perm, c->d_nreal, c->d_rows_flat, c->d_potrf_tiles, c->d_panels, c->d_Lp, c->d_Vinv};
+    const DenseDev D{c->d_perm, c->d_nreal, c->d_rows_flat, c->d_potrf_tiles, c->d_panels, c->d_Lp, c->d_Vinv,
+                     c->d_bs_sep_panels, c->d_panel_of_tile, c->d_chain_begin, c->d_chain_end};
     dense_factor_solve(s, c->plan, D, c->d_S, c->d_y, c->d_scal);
     launch_y_to_delta(s, c->n_pose, c->d_y, c->d_perm, c->d_ytan, c->d_delta);
   }
@@ -1129,10 +1139,14 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
   for (int i = 0; i < npad; ++i) if (!real[i]) hS[(size_t)i * npad + i] = 1.0;
   double *dS = nullptr, *dLp = nullptr, *dV = nullptr, *dy = nullptr, *dscal = nullptr;
   int *dperm = nullptr, *dnreal = nullptr, *drows = nullptr, *dpot = nullptr;
-  PanelDesc* dpan = nullptr;
+  PanelDesc *dpan = nullptr, *dsep = nullptr;
+  int *dpot2 = nullptr, *dcb = nullptr, *dce = nullptr;
   hipStream_t s;
   if (hipStreamCreate(&s) != hipSuccess) return BSGPU_ERR_DEVICE;
-  auto up = [](const void* src, size_t bytes, void** dst) { if (bytes == 0) bytes = 8; if (hipMalloc(dst, bytes) != hipSuccess) return false; return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess || true; };
+  auto up = [](const void* src, size_t bytes, void** dst) {
+    if (hipMalloc(dst, bytes ? bytes : 8) != hipSuccess) return false;
+    return bytes == 0 || hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
+  };
   bool ok = hipMalloc(&dS, sizeof(double) * hS.size()) == hipSuccess && hipMalloc(&dLp, sizeof(double) * hS.size()) == hipSuccess &&
             hipMalloc(&dV, sizeof(double) * chol_vinv_stride() * std::max(1, T)) == hipSuccess && hipMalloc(&dy, sizeof(double) * npad) == hipSuccess &&
             hipMalloc(&dscal, sizeof(double) * SC_NUM) == hipSuccess;
@@ -1140,7 +1154,10 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
   std::vector<int> rf = P.rows_flat; if (rf.empty()) rf.push_back(0);
   ok = ok && up(P.perm.data(), sizeof(int) * P.perm.size(), (void**)&dperm) && up(P.nreal.data(), sizeof(int) * P.nreal.size(), (void**)&dnreal) &&
        up(rf.data(), sizeof(int) * rf.size(), (void**)&drows) && up(pt.data(), sizeof(int) * pt.size(), (void**)&dpot) &&
-       up(P.panels.data(), sizeof(PanelDesc) * P.panels.size(), (void**)&dpan);
+       up(P.panels.data(), sizeof(PanelDesc) * P.panels.size(), (void**)&dpan) &&
+       up(P.bs_sep_panels.data(), sizeof(PanelDesc) * P.bs_sep_panels.size(), (void**)&dsep) &&
+       up(P.panel_of_tile.data(), sizeof(int) * P.panel_of_tile.size(), (void**)&dpot2) &&
+       up(P.chain_begin.data(), sizeof(int) * P.chain_begin.size(), (void**)&dcb) && up(P.chain_end.data(), sizeof(int) * P.chain_end.size(), (void**)&dce);
   int rc = BSGPU_OK;
   if (ok) {
     (void)hipMemcpy(dS, hS.data(), sizeof(double) * hS.size(), hipMemcpyHostToDevice);
@@ -1148,7 +1165,7 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, s);
-    const DenseDev D{dperm, dnreal, drows, dpot, dpan, dLp, dV};
+    const DenseDev D{dperm, dnreal, drows, dpot, dpan, dLp, dV, dsep, dpot2, dcb, dce};
     dense_factor_solve(s, P, D, dS, dy, dscal);
     (void)hipEventRecord(e1, s);
     if (hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess) rc = BSGPU_ERR_DEVICE;
@@ -1165,6 +1182,7 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
   } else rc = BSGPU_ERR_DEVICE;
   (void)hipFree(dS); (void)hipFree(dLp); (void)hipFree(dV); (void)hipFree(dy); (void)hipFree(dscal);
   (void)hipFree(dperm); (void)hipFree(dnreal); (void)hipFree(drows); (void)hipFree(dpot); (void)hipFree(dpan);
+  (void)hipFree(dsep); (void)hipFree(dpot2); (void)hipFree(dcb); (void)hipFree(dce);
   (void)hipStreamDestroy(s);
   return rc;
 }

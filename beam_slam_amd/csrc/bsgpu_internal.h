@@ -115,6 +115,9 @@ void launch_chol_panel_step(hipStream_t s, double* S, double* Lp, int ld, const 
                             const int* rows_flat_dev, const int* nreal_dev, double* Vinv, double* scal);
 void launch_chol_backsolve_step(hipStream_t s, const double* S, const double* Lp, const double* Vinv, int ld,
                                 const PanelDesc* descs_dev, int n_panels, const int* rows_flat_dev, const int* nreal_dev, double* y);
+void launch_chol_backsolve_chains(hipStream_t s, const double* S, const double* Lp, const double* Vinv, int ld,
+                                  const PanelDesc* panels_dev, const int* panel_of_tile_dev, const int* chain_begin_dev,
+                                  const int* chain_end_dev, int n_chains, const int* rows_flat_dev, const int* nreal_dev, double* y);
 void launch_y_to_delta(hipStream_t s, int n_pose, const double* y, const int* perm, double* y_tan, double* delta);
 int chol_vinv_stride();
 void chol_prepare();  // one-time function attributes (kept out of captured sequences)

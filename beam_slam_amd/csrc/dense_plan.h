@@ -31,6 +31,11 @@ struct DensePlan {
   std::vector<int> step_maxrows;
   std::vector<int> potrf_before_step_off, potrf_tiles;  // standalone potrf launches: tiles to factor before step s
   int n_chains = 1;
+  // back-substitution: separator panels step by step (reverse), then every independent piece walked by one workgroup
+  std::vector<int> panel_of_tile;                 // S tile -> index into panels
+  std::vector<PanelDesc> bs_sep_panels;           // separator panels, grouped by step, latest step first
+  std::vector<int> bs_sep_step_off;
+  std::vector<int> chain_begin, chain_end;        // per piece: S tiles [begin, end)
   // solve offsets
   inline int spos(int j) const { return perm[j >> 6] * 64 + (j & 63); }
 
@@ -45,11 +50,13 @@ struct DensePlan {
     int w = 0;
     for (int i = 0; i < T; ++i) for (int j = 0; j < i; ++j) if (adj[(size_t)i * T + j]) w = std::max(w, i - j);
     std::vector<int> order;  // S order: list of natural tiles
+    chain_begin.clear(); chain_end.clear();
     int chains = 1;
     if (max_chains > 1 && w >= 1) while (chains * 2 <= max_chains && T >= (chains * 2) * 3 * w + (chains * 2 - 1) * w) chains *= 2;
     n_chains = chains;
     if (chains == 1) {
       for (int i = 0; i < T; ++i) order.push_back(i);
+      chain_begin.push_back(0); chain_end.push_back(T);
     } else {
       // pieces p = 0..chains-1 separated by chains-1 separators of w tiles
       const int n_sep = chains - 1;
@@ -67,6 +74,7 @@ struct DensePlan {
       // separators on both sides are interior: natural order keeps the right neighbour last, the left separator
       // then sees fill along the piece (still correct: the symbolic factorisation below is exact)
       for (int p = 0; p < chains; ++p) {
+        chain_begin.push_back((int)order.size()); chain_end.push_back((int)order.size() + piece_len[p]);
         const bool reverse = (p == chains - 1) && chains > 1;  // last piece: its only separator is on the left
         if (!reverse) for (int t = pieces[p].first; t < pieces[p].second; ++t) order.push_back(t);
         else for (int t = pieces[p].second - 1; t >= pieces[p].first; --t) order.push_back(t);
@@ -147,6 +155,16 @@ struct DensePlan {
       for (int k : steps[s]) if (!factored_by_lookahead[k]) potrf_tiles.push_back(k);
     }
     potrf_before_step_off[steps.size()] = (int)potrf_tiles.size();
+    // ---- back-substitution plan
+    panel_of_tile.assign(T, 0);
+    for (size_t i = 0; i < panels.size(); ++i) panel_of_tile[panels[i].k] = (int)i;
+    const int sep_begin = chain_end.empty() ? T : chain_end.back();
+    bs_sep_panels.clear(); bs_sep_step_off.assign(1, 0);
+    for (int st = (int)steps.size() - 1; st >= 0; --st) {
+      bool any = false;
+      for (int i = step_off[st]; i < step_off[st + 1]; ++i) if (panels[i].k >= sep_begin) { bs_sep_panels.push_back(panels[i]); any = true; }
+      if (any) bs_sep_step_off.push_back((int)bs_sep_panels.size());
+    }
   }
   int n_steps() const { return (int)step_off.size() - 1; }
 };

@@ -312,15 +312,10 @@ void launch_chol_panel_step(hipStream_t s, double* S, double* Lp, int ld, const 
 //   solve L_kk^T y_k = rhs                              (one wave, v_readlane chain, reciprocal pivots)
 // y is in S (solver) order; rows >= nreal of a tile are kept zero.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void chol_backsolve_step_kernel(const double* __restrict__ S, const double* __restrict__ Lp,
-                                                                   const double* __restrict__ Vinv, int ld,
-                                                                   const PanelDesc* __restrict__ descs,
-                                                                   const int* __restrict__ rows_flat,
-                                                                   const int* __restrict__ nreal, double* __restrict__ y) {
-  __shared__ double sL[NB * (NB + 1)];
-  __shared__ double sp[16 * NB];
-  const PanelDesc pd = descs[blockIdx.x];
-  const int tid = threadIdx.x, c = tid & 63, part = tid >> 6;
+BSG_DEV void backsolve_panel(const PanelDesc pd, const double* __restrict__ S, const double* __restrict__ Lp,
+                             const double* __restrict__ Vinv, int ld, const int* __restrict__ rows_flat,
+                             const int* __restrict__ nreal, double* __restrict__ y, double* sL, double* sp, int tid) {
+  const int c = tid & 63, part = tid >> 6;
   const int kb = pd.k, c0 = kb * NB, nr = nreal[kb];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -354,11 +349,49 @@ __global__ __launch_bounds__(1024) void chol_backsolve_step_kernel(const double*
   }
 }
 
+__global__ __launch_bounds__(1024) void chol_backsolve_step_kernel(const double* __restrict__ S, const double* __restrict__ Lp,
+                                                                   const double* __restrict__ Vinv, int ld,
+                                                                   const PanelDesc* __restrict__ descs,
+                                                                   const int* __restrict__ rows_flat,
+                                                                   const int* __restrict__ nreal, double* __restrict__ y) {
+  __shared__ double sL[NB * (NB + 1)];
+  __shared__ double sp[16 * NB];
+  backsolve_panel(descs[blockIdx.x], S, Lp, Vinv, ld, rows_flat, nreal, y, sL, sp, threadIdx.x);
+}
+
+// one workgroup per independent piece of the nested-dissection ordering, walking its panels from the
+// separator end down to its first tile (everything a piece depends on — its separators — is solved already)
+__global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double* __restrict__ S, const double* __restrict__ Lp,
+                                                                    const double* __restrict__ Vinv, int ld,
+                                                                    const PanelDesc* __restrict__ panels,
+                                                                    const int* __restrict__ panel_of_tile,
+                                                                    const int* __restrict__ chain_begin,
+                                                                    const int* __restrict__ chain_end,
+                                                                    const int* __restrict__ rows_flat,
+                                                                    const int* __restrict__ nreal, double* __restrict__ y) {
+  __shared__ double sL[NB * (NB + 1)];
+  __shared__ double sp[16 * NB];
+  const int b = chain_begin[blockIdx.x], e = chain_end[blockIdx.x];
+  for (int k = e - 1; k >= b; --k) {
+    backsolve_panel(panels[panel_of_tile[k]], S, Lp, Vinv, ld, rows_flat, nreal, y, sL, sp, threadIdx.x);
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+
 void launch_chol_backsolve_step(hipStream_t s, const double* S, const double* Lp, const double* Vinv, int ld,
                                 const PanelDesc* descs_dev, int n_panels, const int* rows_flat_dev, const int* nreal_dev, double* y) {
   if (n_panels <= 0) return;
   hipLaunchKernelGGL(chol_backsolve_step_kernel, dim3(n_panels), dim3(1024), 0, s, S, Lp, Vinv, ld, descs_dev, rows_flat_dev,
                      nreal_dev, y);
+}
+
+void launch_chol_backsolve_chains(hipStream_t s, const double* S, const double* Lp, const double* Vinv, int ld,
+                                  const PanelDesc* panels_dev, const int* panel_of_tile_dev, const int* chain_begin_dev,
+                                  const int* chain_end_dev, int n_chains, const int* rows_flat_dev, const int* nreal_dev, double* y) {
+  if (n_chains <= 0) return;
+  hipLaunchKernelGGL(chol_backsolve_chain_kernel, dim3(n_chains), dim3(1024), 0, s, S, Lp, Vinv, ld, panels_dev, panel_of_tile_dev,
+                     chain_begin_dev, chain_end_dev, rows_flat_dev, nreal_dev, y);
 }
 
 int chol_vinv_stride() { return kVinvStride; }
