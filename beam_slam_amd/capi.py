@@ -24,7 +24,9 @@ F_ABSPOSE = 6
 F_ABS_VEC3 = 7
 F_REL_VEC3 = 8
 F_GRAVITY = 9
-F_NUM_TYPES = 10
+F_IDP_REPROJ = 10
+F_IDP_REPROJ_UNARY = 11
+F_NUM_TYPES = 12
 
 LINEAR_AUTO, LINEAR_SCHUR_CHOLESKY, LINEAR_PCG = 0, 1, 2
 CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2

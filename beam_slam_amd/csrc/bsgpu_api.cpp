@@ -39,7 +39,10 @@ const TypeInfo kTypes[BSGPU_F_NUM_TYPES] = {
     {1, 1, 12, 3, {3}},
     {2, 2, 12, 3, {3, 3}},
     {1, 1, 7, 2, {4}},
+    {6, 5, 6, 2, {4, 3, 4, 3, 1}},
+    {4, 3, 6, 2, {4, 3, 1}},
 };
+inline bool has_camera(int t) { return t <= 1 || t == BSGPU_F_IDP_REPROJ || t == BSGPU_F_IDP_REPROJ_UNARY; }
 
 std::string g_create_error;
 
@@ -186,7 +189,7 @@ int finalize(bsgpu_ctx* c) {
           return fail(c, BSGPU_ERR_INVALID, "4-d slot must be a quaternion-manifold block");
         if (t <= 1 && sl == 2) lm_use[b]++; else other_use[b]++;
       }
-      if (t <= 1) {
+      if (has_camera(t)) {
         const int cam = idx[ti.nvar];
         if (cam < 0 || cam >= (int)c->cams.size()) return fail(c, BSGPU_ERR_INVALID, "camera index out of range");
       }
@@ -377,6 +380,7 @@ int finalize(bsgpu_ctx* c) {
     SmallGroup& sg = c->small[t];
     sg = SmallGroup();
     sg.type = t; sg.n = g.n; sg.m = ti.m; sg.nv = ti.nvar; sg.nc = ti.nconst;
+    sg.w_last = ti.amb[ti.nvar - 1] == 4 ? 3 : ti.amb[ti.nvar - 1];
     if (!g.n) continue;
     std::vector<int> xoff((size_t)g.n * ti.nvar), toff((size_t)g.n * ti.nvar), loss(g.n);
     std::vector<unsigned char> active(g.n, 0), inactive(g.n, 0);
@@ -397,12 +401,18 @@ int finalize(bsgpu_ctx* c) {
           for (int sb = 0; sb < ti.nvar; ++sb) {
             const int ra = c->toff[idx[sa]], rb = c->toff[idx[sb]];
             if (ra < 0 || rb < 0) continue;
-            for (int a = ra; a < ra + 3; a += 2) for (int b = rb; b < rb + 3; b += 2) c->tile_adj[(size_t)(a / 64) * T + b / 64] = 1;
+            const int wa = c->tsize[idx[sa]], wb = c->tsize[idx[sb]];
+            for (int a = ra; a < ra + wa; a += std::max(1, wa - 1)) for (int b = rb; b < rb + wb; b += std::max(1, wb - 1)) c->tile_adj[(size_t)(a / 64) * T + b / 64] = 1;
           }
       }
     }
     sg.xoff = c->upload(xoff); sg.toff = c->upload(toff); sg.consts = c->upload(g.consts); sg.loss = c->upload(loss);
     sg.active = c->upload(active);
+    if (has_camera(t)) {
+      std::vector<int> camv(g.n);
+      for (int f = 0; f < g.n; ++f) camv[f] = g.idx[(size_t)f * ti.nidx + ti.nvar];
+      sg.cam = c->upload(camv);
+    }
     c->d_small_inactive[t] = c->upload(inactive);
     c->h_small_active[t] = active;
     sg.r = c->alloc<double>((size_t)g.n * ti.m);
@@ -414,6 +424,7 @@ int finalize(bsgpu_ctx* c) {
   }
   if (losses.size() >= (1u << kMetaLossBits)) return fail(c, BSGPU_ERR_UNSUPPORTED, "too many distinct loss functions");
   c->d_cams = c->upload(cams);
+  for (int t = 2; t < BSGPU_F_NUM_TYPES; ++t) c->small[t].cams = c->d_cams;
   c->d_losses = c->upload(losses);
   // ---- blocks
   {
@@ -497,7 +508,8 @@ int finalize(bsgpu_ctx* c) {
 int build_bsr(bsgpu_ctx* c) {
   if (c->bsr_built) return BSGPU_OK;
   if (c->vis.n > 0) return fail(c, BSGPU_ERR_UNSUPPORTED, "PCG path covers pose-only problems; landmark problems use the Schur + dense path");
-  if (c->n_pose % 3 != 0) return fail(c, BSGPU_ERR_UNSUPPORTED, "PCG path needs 3-dimensional tangent blocks");
+  for (int b = 0; b < c->nb; ++b)
+    if (!c->is_const[b] && c->tsize[b] != 3) return fail(c, BSGPU_ERR_UNSUPPORTED, "PCG path needs 3-dimensional tangent blocks");
   const int nbr = c->n_pose / 3;
   std::vector<uint64_t> keys;
   for (int b = 0; b < nbr; ++b) keys.push_back(((uint64_t)b << 32) | (uint32_t)b);
@@ -1080,7 +1092,7 @@ int bsgpu_evaluate(bsgpu_ctx* c, double* cost, double* residuals, double* gradie
         for (int sl = 0; sl < g.nv; ++sl) {
           const int tc = toff[(size_t)f * g.nv + sl];
           if (tc < 0) continue;
-          for (int j = 0; j < 3; ++j) {
+          for (int j = 0; j < (sl == g.nv - 1 ? g.w_last : 3); ++j) {
             const double v = J[((size_t)f * mm + k) * tw + 3 * sl + j];
             grad[tc + j] += v * r[(size_t)f * mm + k];
             if (jacobian) jacobian[(size_t)row * n + tc + j] = v;

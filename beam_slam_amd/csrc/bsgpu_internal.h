@@ -50,6 +50,9 @@ struct SmallGroup {
   unsigned char* active = nullptr;  // n
   double* r = nullptr;
   double* J = nullptr;
+  int w_last = 3;        // tangent width of the LAST slot (1 for the inverse-depth scalar); J keeps 3 columns per slot
+  int* cam = nullptr;    // n  camera-table ids (types that project through a camera)
+  const DevCamera* cams = nullptr;
 };
 
 // everything the kernels need for the visual (landmark) part

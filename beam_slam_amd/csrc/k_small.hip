@@ -518,6 +518,114 @@ __global__ __launch_bounds__(128) void gravity_kernel(SmallGroup g, const double
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// A7 inverse-depth reprojection (bs_constraints/visual/inversedepth_reprojection_functor.h:57-125 and
+// ..._functor_unary.h:36-72), one lane per factor.  With T_cam_baselink = (R_cb, t_cb), bearing m, inverse
+// depth rho, anchor pose (R_a, p_a) and measurement pose (R_m, p_m):
+//   a_b = R_cb^T (m - rho t_cb)            rho-scaled point in the anchor baselink frame
+//   v   = R_m^T (R_a a_b + rho (p_a - p_m))          ... in the measurement baselink frame
+//   c   = R_cb v + rho t_cb                           = [R|t]_(cm<-ca) (m; rho)
+//   r   = w (z - (fx c0/c2 + cx, fy c1/c2 + cy))
+// Tangent Jacobians (right perturbation R <- R Exp(d)):
+//   dc/dtheta_a = -R_cb R_m^T R_a [a_b]x     dc/dp_a = rho R_cb R_m^T
+//   dc/dtheta_m =  R_cb [v]x                 dc/dp_m = -rho R_cb R_m^T
+//   dc/drho     =  R_cb R_m^T (p_a - p_m - R_a R_cb^T t_cb) + t_cb
+// J layout: 2 x 15 (binary: theta_a, p_a, theta_m, p_m, [rho 0 0]) or 2 x 9 (unary: all zero — the unary
+// functor uses T = I, its residual is constant in every block).
+// ---------------------------------------------------------------------------------------------------
+template <bool UNARY, bool WITH_J>
+__global__ __launch_bounds__(128) void idp_kernel(SmallGroup g, const double* __restrict__ x,
+                                                  const DevLoss* __restrict__ losses,
+                                                  double* __restrict__ cost_part) {
+  const int f = blockIdx.x * 128 + threadIdx.x;
+  if (f >= g.n) return;
+  constexpr int NV = UNARY ? 3 : 5;
+  const int* xo = g.xoff + (size_t)f * NV;
+  const int* to = g.toff + (size_t)f * NV;
+  const double* k = g.consts + (size_t)f * 6;
+  const DevCamera cam = g.cams[g.cam[f]];
+  const double w = k[2], m[3] = {k[3], k[4], k[5]};
+  double c[3], rho = 0.0;
+  double Ra[9], Rm[9], ab[3], v[3], dpm[3];
+  if (UNARY) {
+    c[0] = m[0]; c[1] = m[1]; c[2] = m[2];
+  } else {
+    rho = x[xo[4]];
+    const double qa[4] = {x[xo[0]], x[xo[0] + 1], x[xo[0] + 2], x[xo[0] + 3]};
+    const double qm[4] = {x[xo[2]], x[xo[2] + 1], x[xo[2] + 2], x[xo[2] + 3]};
+    quat_to_rot(qa, Ra);
+    quat_to_rot(qm, Rm);
+    const double mt[3] = {m[0] - rho * cam.t[0], m[1] - rho * cam.t[1], m[2] - rho * cam.t[2]};
+    mat3t_vec(cam.R, mt, ab);
+    double wv[3];
+    mat3_vec(Ra, ab, wv);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { dpm[i] = x[xo[1] + i] - x[xo[3] + i]; wv[i] += rho * dpm[i]; }
+    mat3t_vec(Rm, wv, v);
+    mat3_vec(cam.R, v, c);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) c[i] += rho * cam.t[i];
+  }
+  const double iz = 1.0 / c[2];
+  const double r0 = w * (k[0] - (cam.fx * c[0] * iz + cam.cx)), r1 = w * (k[1] - (cam.fy * c[1] * iz + cam.cy));
+  double sc, cost;
+  finish_small(g, f, losses, r0 * r0 + r1 * r1, &sc, &cost);
+  cost_part[f] = cost;
+  if (!WITH_J) return;
+  g.r[(size_t)f * 2] = r0 * sc; g.r[(size_t)f * 2 + 1] = r1 * sc;
+  double* Jo = g.J + (size_t)f * 2 * 3 * NV;
+  if (UNARY) {
+#pragma unroll
+    for (int i = 0; i < 2 * 3 * NV; ++i) Jo[i] = 0.0;
+    return;
+  }
+  // M = -w sc dpi/dc R_cb   (2 x 3): dr/d* = M dv/d*  (+ the t_cb term for rho)
+  const double P[6] = {cam.fx * iz, 0.0, -cam.fx * c[0] * iz * iz, 0.0, cam.fy * iz, -cam.fy * c[1] * iz * iz};
+  double M[6], MRmt[6], MRmtRa[6];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      M[3 * i + j] = -w * sc * (P[3 * i] * cam.R[j] + P[3 * i + 1] * cam.R[3 + j] + P[3 * i + 2] * cam.R[6 + j]);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)   // M R_m^T
+      MRmt[3 * i + j] = M[3 * i] * Rm[3 * j] + M[3 * i + 1] * Rm[3 * j + 1] + M[3 * i + 2] * Rm[3 * j + 2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)   // M R_m^T R_a
+      MRmtRa[3 * i + j] = MRmt[3 * i] * Ra[j] + MRmt[3 * i + 1] * Ra[3 + j] + MRmt[3 * i + 2] * Ra[6 + j];
+  // d(a_b)/drho = -R_cb^T t_cb
+  double dab[3];
+  mat3t_vec(cam.R, cam.t, dab);
+  double Radab[3];
+  mat3_vec(Ra, dab, Radab);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const double* A = MRmtRa + 3 * i;   // row of M R_m^T R_a : times -[a_b]x
+    const double* B = M + 3 * i;        // row of M           : times  [v]x
+    // row * [u]x = (row x u) with sign: (row [u]x)_j = sum_k row_k eps(k, j, l) u_l... written out:
+    const double ja[3] = {-(A[1] * ab[2] - A[2] * ab[1]), -(A[2] * ab[0] - A[0] * ab[2]), -(A[0] * ab[1] - A[1] * ab[0])};
+    const double jm[3] = {B[1] * v[2] - B[2] * v[1], B[2] * v[0] - B[0] * v[2], B[0] * v[1] - B[1] * v[0]};
+    double* Ji = Jo + 15 * i;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      Ji[j] = to[0] < 0 ? 0.0 : ja[j];
+      Ji[3 + j] = to[1] < 0 ? 0.0 : rho * MRmt[3 * i + j];
+      Ji[6 + j] = to[2] < 0 ? 0.0 : jm[j];
+      Ji[9 + j] = to[3] < 0 ? 0.0 : -rho * MRmt[3 * i + j];
+    }
+    double jr = 0.0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) jr += MRmt[3 * i + j] * (dpm[j] - Radab[j]);
+    jr += -w * sc * (P[3 * i] * cam.t[0] + P[3 * i + 1] * cam.t[1] + P[3 * i + 2] * cam.t[2]);
+    Ji[12] = to[4] < 0 ? 0.0 : jr;
+    Ji[13] = 0.0; Ji[14] = 0.0;
+  }
+}
+
 void launch_small_eval(hipStream_t s, const SmallGroup& g, const double* x, const DevLoss* losses, bool with_J,
                        double* cost_part) {
   if (g.n == 0) return;
@@ -537,6 +645,8 @@ void launch_small_eval(hipStream_t s, const SmallGroup& g, const double* x, cons
     case BSGPU_F_ABS_VEC3: BSG_LAUNCH2(vec3_kernel, false, g128, 128); break;
     case BSGPU_F_REL_VEC3: BSG_LAUNCH2(vec3_kernel, true, g128, 128); break;
     case BSGPU_F_GRAVITY: BSG_LAUNCH(gravity_kernel, g128, 128); break;
+    case BSGPU_F_IDP_REPROJ: BSG_LAUNCH2(idp_kernel, false, g128, 128); break;
+    case BSGPU_F_IDP_REPROJ_UNARY: BSG_LAUNCH2(idp_kernel, true, g128, 128); break;
     default: break;
   }
 #undef BSG_LAUNCH
@@ -561,16 +671,17 @@ __global__ __launch_bounds__(64) void small_assemble_kernel(SmallGroup g, double
   if (lane < m) sr[lane] = g.r[(size_t)f * m + lane];
   if (lane < g.nv) st[lane] = g.toff[(size_t)f * g.nv + lane];
   __syncthreads();
+  const int wcut = 3 * (g.nv - 1) + g.w_last;   // columns >= wcut are the padding of a narrow last slot
   for (int p = lane; p < tw * tw; p += 64) {
     const int a = p / tw, b = p % tw;
     const int ta = st[a / 3], tb = st[b / 3];
-    if (ta < 0 || tb < 0) continue;
+    if (ta < 0 || tb < 0 || a >= wcut || b >= wcut) continue;
     double acc = 0.0;
     for (int k = 0; k < m; ++k) acc += sJ[k * tw + a] * sJ[k * tw + b];
     const int ra = ta + a % 3, rb = tb + b % 3;
     atomicAdd(&S[(size_t)(perm[ra >> 6] * 64 + (ra & 63)) * ld + perm[rb >> 6] * 64 + (rb & 63)], acc);
   }
-  for (int a = lane; a < tw; a += 64) {
+  for (int a = lane; a < wcut; a += 64) {
     const int ta = st[a / 3];
     if (ta < 0) continue;
     double gs = 0.0, hs = 0.0;
@@ -604,6 +715,7 @@ __global__ __launch_bounds__(128) void small_mcc_kernel(SmallGroup g, const doub
     for (int sl = 0; sl < g.nv; ++sl) {
       const int t = to[sl];
       if (t < 0) continue;
+      if (sl == g.nv - 1 && g.w_last < 3) { for (int i = 0; i < g.w_last; ++i) jv += J[3 * sl + i] * delta[t + i]; continue; }
       jv += J[3 * sl] * delta[t] + J[3 * sl + 1] * delta[t + 1] + J[3 * sl + 2] * delta[t + 2];
     }
     acc = -jv * (g.r[(size_t)f * m + k] + 0.5 * jv);

@@ -177,6 +177,33 @@ class Point3DLandmark : public fuse_variables::FixedSizeVariable<3> {
  private:
   uint64_t id_;
 };
+// bs_variables/include/bs_variables/inverse_depth_landmark.h:22-60, src/inverse_depth_landmark.cpp:14-27:
+// one scalar (the inverse depth) + a constant unit bearing in the anchor camera; uuid from the landmark id
+class InverseDepthLandmark : public fuse_variables::FixedSizeVariable<1> {
+ public:
+  using SharedPtr = std::shared_ptr<InverseDepthLandmark>;
+  InverseDepthLandmark(uint64_t id, const bs_math::Vec3& bearing, const fuse_core::Time& anchor_stamp)
+      : FixedSizeVariable<1>(fuse_core::uuid::generate("bs_variables::InverseDepthLandmark", id)), id_(id), bearing_(bearing),
+        anchor_stamp_(anchor_stamp) {
+    const double norm = std::sqrt(bearing[0] * bearing[0] + bearing[1] * bearing[1] + bearing[2] * bearing[2]);
+    if (norm < 1.0 - 1e-10 || norm > 1.0 + 1e-10) throw std::runtime_error("Invalid bearing vector, norm must equal 1.0.");
+  }
+  static SharedPtr make_shared(uint64_t id, const bs_math::Vec3& b, const fuse_core::Time& t) { return std::make_shared<InverseDepthLandmark>(id, b, t); }
+  std::string type() const override { return "bs_variables::InverseDepthLandmark"; }
+  fuse_core::Variable::SharedPtr clone() const override { return std::make_shared<InverseDepthLandmark>(*this); }
+  bool isLandmark() const override { return true; }
+  uint64_t landmarkId() const override { return id_; }
+  uint64_t id() const { return id_; }
+  double& inverse_depth() { return data_[0]; }
+  const double& inverse_depth() const { return data_[0]; }
+  bs_math::Vec3 camera_t_point() const { const double d = 1.0 / data_[0]; return bs_math::Vec3{d * bearing_[0], d * bearing_[1], d * bearing_[2]}; }
+  const bs_math::Vec3& bearing() const { return bearing_; }
+  const fuse_core::Time& anchorStamp() const { return anchor_stamp_; }
+ private:
+  uint64_t id_;
+  bs_math::Vec3 bearing_;
+  fuse_core::Time anchor_stamp_;
+};
 // unstamped extrinsic blocks: holdConstant() == true (bs_variables/src/orientation_3d.cpp:39-41, position_3d.cpp:34);
 // uuid from child+parent frame (orientation_3d.cpp:17-18)
 class Orientation3D : public fuse_variables::FixedSizeVariable<4> {

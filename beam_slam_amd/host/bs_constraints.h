@@ -49,6 +49,70 @@ class EuclideanReprojectionConstraint : public fuse_core::Constraint {
   double weight_;
 };
 
+// bs_constraints/src/visual/inversedepth_reprojection_constraint.cpp:14-49 (AutoDiff<2,4,3,4,3,1>):
+// anchor pose, measurement pose, inverse-depth landmark; sqrt information = weight * I2
+class InverseDepthReprojectionConstraint : public fuse_core::Constraint {
+ public:
+  InverseDepthReprojectionConstraint(const std::string& source, const fuse_variables::Orientation3DStamped& o_WORLD_BASELINKa,
+                                     const fuse_variables::Position3DStamped& p_WORLD_BASELINKa,
+                                     const fuse_variables::Orientation3DStamped& o_WORLD_BASELINKm,
+                                     const fuse_variables::Position3DStamped& p_WORLD_BASELINKm,
+                                     const bs_variables::InverseDepthLandmark& idp, const Mat<4, 4>& T_cam_baselink,
+                                     const Mat<3, 3>& intrinsic_matrix, const std::array<double, 2>& measurement,
+                                     double reprojection_information_weight = 1.0)
+      : Constraint(source, {o_WORLD_BASELINKa.uuid(), p_WORLD_BASELINKa.uuid(), o_WORLD_BASELINKm.uuid(),
+                            p_WORLD_BASELINKm.uuid(), idp.uuid()}),
+        T_cam_baselink_(T_cam_baselink), intrinsic_matrix_(intrinsic_matrix), pixel_(measurement), bearing_(idp.bearing()),
+        weight_(reprojection_information_weight) {}
+  std::string type() const override { return "bs_constraints::InverseDepthReprojectionConstraint"; }
+  const std::array<double, 2>& pixel() const { return pixel_; }
+  void pack(const BlockOf& block_of, fuse_core::FactorTables& t) const override {
+    appendBlocks(*this, block_of, t.idx[BSGPU_F_IDP_REPROJ]);
+    t.idx[BSGPU_F_IDP_REPROJ].push_back(t.cameraId(makeCamera(intrinsic_matrix_, T_cam_baselink_)));
+    auto& c = t.consts[BSGPU_F_IDP_REPROJ];
+    c.push_back(pixel_[0]); c.push_back(pixel_[1]); c.push_back(weight_);
+    for (int i = 0; i < 3; ++i) c.push_back(bearing_[i]);
+    t.pushLoss(BSGPU_F_IDP_REPROJ, loss());
+  }
+  SharedPtr clone() const override { return std::make_shared<InverseDepthReprojectionConstraint>(*this); }
+ protected:
+  Mat<4, 4> T_cam_baselink_;
+  Mat<3, 3> intrinsic_matrix_;
+  std::array<double, 2> pixel_;
+  Vec3 bearing_;
+  double weight_;
+};
+
+// bs_constraints/src/visual/inversedepth_reprojection_constraint_unary.cpp:15-53 (AutoDiff<2,4,3,1>):
+// the observation made from the anchor keyframe itself
+class InverseDepthReprojectionConstraintUnary : public fuse_core::Constraint {
+ public:
+  InverseDepthReprojectionConstraintUnary(const std::string& source, const fuse_variables::Orientation3DStamped& o_WORLD_BASELINKa,
+                                          const fuse_variables::Position3DStamped& p_WORLD_BASELINKa,
+                                          const bs_variables::InverseDepthLandmark& idp, const Mat<4, 4>& T_cam_baselink,
+                                          const Mat<3, 3>& intrinsic_matrix, const std::array<double, 2>& measurement,
+                                          double reprojection_information_weight = 1.0)
+      : Constraint(source, {o_WORLD_BASELINKa.uuid(), p_WORLD_BASELINKa.uuid(), idp.uuid()}), T_cam_baselink_(T_cam_baselink),
+        intrinsic_matrix_(intrinsic_matrix), pixel_(measurement), bearing_(idp.bearing()), weight_(reprojection_information_weight) {}
+  std::string type() const override { return "bs_constraints::InverseDepthReprojectionConstraintUnary"; }
+  const std::array<double, 2>& pixel() const { return pixel_; }
+  void pack(const BlockOf& block_of, fuse_core::FactorTables& t) const override {
+    appendBlocks(*this, block_of, t.idx[BSGPU_F_IDP_REPROJ_UNARY]);
+    t.idx[BSGPU_F_IDP_REPROJ_UNARY].push_back(t.cameraId(makeCamera(intrinsic_matrix_, T_cam_baselink_)));
+    auto& c = t.consts[BSGPU_F_IDP_REPROJ_UNARY];
+    c.push_back(pixel_[0]); c.push_back(pixel_[1]); c.push_back(weight_);
+    for (int i = 0; i < 3; ++i) c.push_back(bearing_[i]);
+    t.pushLoss(BSGPU_F_IDP_REPROJ_UNARY, loss());
+  }
+  SharedPtr clone() const override { return std::make_shared<InverseDepthReprojectionConstraintUnary>(*this); }
+ protected:
+  Mat<4, 4> T_cam_baselink_;
+  Mat<3, 3> intrinsic_matrix_;
+  std::array<double, 2> pixel_;
+  Vec3 bearing_;
+  double weight_;
+};
+
 // bs_constraints/src/visual/euclidean_reprojection_constraint_online_calib.cpp (functor_online_calib.h:16-83)
 class EuclideanReprojectionConstraintOnlineCalib : public fuse_core::Constraint {
  public:

@@ -10,13 +10,13 @@ from . import capi
 
 NIDX = {capi.F_REPROJ: 4, capi.F_REPROJ_ONLINE_CALIB: 6, capi.F_IMU_DELTA: 10, capi.F_IMU_PRIOR: 5,
         capi.F_RELPOSE_EXT: 6, capi.F_RELPOSE: 4, capi.F_ABSPOSE: 2, capi.F_ABS_VEC3: 1,
-        capi.F_REL_VEC3: 2, capi.F_GRAVITY: 1}
+        capi.F_REL_VEC3: 2, capi.F_GRAVITY: 1, capi.F_IDP_REPROJ: 6, capi.F_IDP_REPROJ_UNARY: 4}
 NCONST = {capi.F_REPROJ: 3, capi.F_REPROJ_ONLINE_CALIB: 3, capi.F_IMU_DELTA: 287, capi.F_IMU_PRIOR: 241,
           capi.F_RELPOSE_EXT: 43, capi.F_RELPOSE: 43, capi.F_ABSPOSE: 43, capi.F_ABS_VEC3: 12,
-          capi.F_REL_VEC3: 12, capi.F_GRAVITY: 7}
+          capi.F_REL_VEC3: 12, capi.F_GRAVITY: 7, capi.F_IDP_REPROJ: 6, capi.F_IDP_REPROJ_UNARY: 6}
 NRES = {capi.F_REPROJ: 2, capi.F_REPROJ_ONLINE_CALIB: 2, capi.F_IMU_DELTA: 15, capi.F_IMU_PRIOR: 15,
         capi.F_RELPOSE_EXT: 6, capi.F_RELPOSE: 6, capi.F_ABSPOSE: 6, capi.F_ABS_VEC3: 3,
-        capi.F_REL_VEC3: 3, capi.F_GRAVITY: 2}
+        capi.F_REL_VEC3: 3, capi.F_GRAVITY: 2, capi.F_IDP_REPROJ: 2, capi.F_IDP_REPROJ_UNARY: 2}
 
 
 class Problem:

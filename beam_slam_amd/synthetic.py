@@ -369,6 +369,77 @@ def c2(seed=20250620):
 # ---------------------------------------------------------------------------------------------
 # C3: lidar-inertial window — relative-pose factors with (constant) extrinsics + IMU factors
 # ---------------------------------------------------------------------------------------------
+def idp_window(n_kf=8, n_lm=60, seed=20250623, kf_rate=10.0, track_min=3, track_max=6, pixel_sigma=0.5,
+               w_reproj=1.0, cauchy_a=5.0, sigma_rot=0.01, sigma_pos=0.03, sigma_rho=0.02, with_unary=True,
+               unit_bearing=True):
+    """Visual window with inverse-depth landmarks (use_idp: true, config/vo/vo_params.json:4): every landmark is a
+    scalar rho anchored at the first keyframe that sees it, with a constant bearing m in the anchor camera
+    (point in the anchor camera = m / rho, bs_variables/include/bs_variables/inverse_depth_landmark.h:41-45);
+    the anchor observation is the unary constraint, every later one the binary constraint.
+    The first keyframe carries a pose prior and the second a position prior, both at the generating poses
+    (they fix the gauge and the scale)."""
+    rng = np.random.default_rng(seed)
+    dt_kf = 1.0 / kf_rate
+    traj = Lissajous(duration=max(n_kf * dt_kf, 2.0))
+    t_kf = np.arange(n_kf) * dt_kf
+    R_true = np.stack([traj.rot(t) for t in t_kf])
+    q_true = np.stack([rot_to_quat(R) for R in R_true])
+    p_true = np.stack([traj.pos(t) for t in t_kf])
+    R_cb, t_cb = _t_cam_baselink()
+    track_max = min(track_max, n_kf)
+    track_min = min(track_min, track_max)
+    L = rng.integers(track_min, track_max + 1, n_lm)
+    k0 = (rng.random(n_lm) * (n_kf - L + 1)).astype(np.int64)
+    u0 = rng.uniform(0.2, 0.8, n_lm) * IMG_W
+    v0 = rng.uniform(0.2, 0.8, n_lm) * IMG_H
+    depth = rng.uniform(3.0, 12.0, n_lm)
+    ray = np.stack([(u0 - CX) / FX, (v0 - CY) / FY, np.ones(n_lm)], axis=1)
+    Pc = ray * depth[:, None]
+    if unit_bearing:
+        bearing = ray / np.linalg.norm(ray, axis=1, keepdims=True)   # unit direction, rho = 1 / range
+        rho_true = 1.0 / np.linalg.norm(Pc, axis=1)
+    else:
+        bearing = ray                                                # [mx, my, 1], rho = 1 / z
+        rho_true = 1.0 / depth
+    Pb = (Pc - t_cb) @ R_cb
+    P_true = np.einsum('nij,nj->ni', R_true[k0], Pb) + p_true[k0]
+
+    pr = Problem()
+    kf_blocks = np.empty((n_kf, 2), np.int32)
+    for i in range(n_kf):
+        kf_blocks[i, 0] = pr.add_quat(_perturb_quat(q_true[i], rng, sigma_rot))
+        kf_blocks[i, 1] = pr.add_block(p_true[i] + rng.normal(0, sigma_pos, 3))
+    rho_blocks = np.array([pr.add_block([r * (1.0 + rng.normal(0, sigma_rho))]) for r in rho_true], np.int32)
+    cam = pr.add_camera(FX, FY, CX, CY, R_cb, t_cb)
+    bin_idx, bin_c, un_idx, un_c = [], [], [], []
+    for l in range(n_lm):
+        for k in range(k0[l], k0[l] + L[l]):
+            Pck = R_cb @ (R_true[k].T @ (P_true[l] - p_true[k])) + t_cb
+            if Pck[2] < 0.5:
+                continue
+            uv = np.array([FX * Pck[0] / Pck[2] + CX, FY * Pck[1] / Pck[2] + CY]) + rng.normal(0, pixel_sigma, 2)
+            c = np.concatenate([uv, [w_reproj], bearing[l]])
+            if k == k0[l]:
+                if with_unary:
+                    un_idx.append([kf_blocks[k, 0], kf_blocks[k, 1], rho_blocks[l], cam]); un_c.append(c)
+            else:
+                bin_idx.append([kf_blocks[k0[l], 0], kf_blocks[k0[l], 1], kf_blocks[k, 0], kf_blocks[k, 1], rho_blocks[l], cam])
+                bin_c.append(c)
+    loss = (capi.LOSS_TRIVIAL, 1.0) if cauchy_a is None else (capi.LOSS_CAUCHY, cauchy_a * w_reproj)
+    pr.add_factors(capi.F_IDP_REPROJ, np.array(bin_idx, np.int32), np.array(bin_c), *loss)
+    if un_idx:
+        pr.add_factors(capi.F_IDP_REPROJ_UNARY, np.array(un_idx, np.int32), np.array(un_c), *loss)
+    A = sqrt_information_upper(1e-4 * np.eye(6))
+    b = np.concatenate([p_true[0], q_true[0]])
+    pr.add_factors(capi.F_ABSPOSE, [[kf_blocks[0, 1], kf_blocks[0, 0]]], [np.concatenate([b, A.ravel()])])
+    if n_kf > 1:
+        A3 = sqrt_information_upper(1e-6 * np.eye(3))
+        pr.add_factors(capi.F_ABS_VEC3, [[kf_blocks[1, 1]]], [np.concatenate([p_true[1], A3.ravel()])])
+    pr.meta = dict(kind="idp_window", n_kf=n_kf, n_lm=n_lm, seed=seed, kf_blocks=kf_blocks, rho_blocks=rho_blocks,
+                   q_true=q_true, p_true=p_true, rho_true=rho_true, n_binary=len(bin_idx), n_unary=len(un_idx))
+    return pr
+
+
 def lio_window(n_kf=100, n_rel=20000, seed=20250621, w_lidar=1.0, w_inertial=1e-2, max_gap=10):
     rng = np.random.default_rng(seed)
     base = vio_window(n_kf=n_kf, n_lm=0, seed=seed, w_inertial=w_inertial)

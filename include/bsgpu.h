@@ -127,7 +127,25 @@ enum {
    *   (global/gravity_alignment_cost_functor.h:32-82, AutoDiff<2,4>)
    *   idx   : q                  consts: g_b[3], A[4] (2x2 row-major)          */
   BSGPU_F_GRAVITY = 9,
-  BSGPU_F_NUM_TYPES = 10
+  /* bs_constraints::InverseDepthReprojectionConstraint
+   *   (visual/inversedepth_reprojection_functor.h:15-136, AutoDiff<2,4,3,4,3,1>;
+   *    src/visual/inversedepth_reprojection_constraint.cpp:14-49)
+   *   idx   : q_WORLD_BASELINKa, p_WORLD_BASELINKa (anchor), q_WORLD_BASELINKm,
+   *           p_WORLD_BASELINKm (measurement), rho (bs_variables::InverseDepthLandmark,
+   *           size 1), camera-table index
+   *   consts: u, v (pixel), w (sqrt information = w * I2), m[3] (bearing of the
+   *           landmark in the anchor camera, InverseDepthLandmark::bearing())
+   *   The inverse-depth scalar stays in the reduced system (it is not Schur-
+   *   eliminated); use_idp is off in every shipped configuration.              */
+  BSGPU_F_IDP_REPROJ = 10,
+  /* bs_constraints::InverseDepthReprojectionConstraintUnary
+   *   (visual/inversedepth_reprojection_functor_unary.h:14-85, AutoDiff<2,4,3,1>)
+   *   idx   : q_WORLD_BASELINKa, p_WORLD_BASELINKa, rho, camera-table index
+   *   consts: u, v, w, m[3]
+   *   The observation in the anchor frame: the residual is constant in every
+   *   block (zero Jacobian), it only contributes to the cost.                  */
+  BSGPU_F_IDP_REPROJ_UNARY = 11,
+  BSGPU_F_NUM_TYPES = 12
 };
 
 /* number of int32 per factor in block_idx / doubles per factor in consts /

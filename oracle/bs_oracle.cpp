@@ -53,7 +53,13 @@ static const TypeInfo kTypes[BSGPU_F_NUM_TYPES] = {
     /* ABS_VEC3      */ {1, 1, 12, 3, {3}},
     /* REL_VEC3      */ {2, 2, 12, 3, {3, 3}},
     /* GRAVITY       */ {1, 1, 7, 2, {4}},
+    /* IDP_REPROJ    */ {6, 5, 6, 2, {4, 3, 4, 3, 1}},
+    /* IDP_UNARY     */ {4, 3, 6, 2, {4, 3, 1}},
 };
+// tangent width of a slot.  J rows are laid out with slot sl starting at column 3*sl: a slot narrower than 3
+// (the inverse-depth scalar) is only ever the LAST slot of its type, so that offset stays valid.
+static inline int tsz(const TypeInfo& ti, int sl) { return ti.amb[sl] == 4 ? 3 : ti.amb[sl]; }
+static inline bool has_camera(int type) { return type <= 1 || type == BSGPU_F_IDP_REPROJ || type == BSGPU_F_IDP_REPROJ_UNARY; }
 
 struct Group {
   int type = 0;
@@ -145,6 +151,8 @@ static void eval_functor(const Ctx& c, int type, const int32_t* idx, const doubl
     case BSGPU_F_ABS_VEC3: AbsVec3Residual(k, s.p[0], r); break;
     case BSGPU_F_REL_VEC3: RelVec3Residual(k, s.p[0], s.p[1], r); break;
     case BSGPU_F_GRAVITY: GravityResidual(k, s.p[0], r); break;
+    case BSGPU_F_IDP_REPROJ: InverseDepthReprojResidual(c.cams[idx[5]], k, s.p[0], s.p[1], s.p[2], s.p[3], s.p[4], r); break;
+    case BSGPU_F_IDP_REPROJ_UNARY: InverseDepthReprojUnaryResidual(c.cams[idx[3]], k, s.p[0], s.p[1], s.p[2], r); break;
     default: break;
   }
 }
@@ -298,7 +306,9 @@ static void eval_factor(const Ctx& c, int type, const int32_t* idx, const double
     case 6: autodiff<6>(c, type, idx, k, x, r, Jamb); break;
     case 7: autodiff<7>(c, type, idx, k, x, r, Jamb); break;
     case 10: autodiff<10>(c, type, idx, k, x, r, Jamb); break;
+    case 8: autodiff<8>(c, type, idx, k, x, r, Jamb); break;
     case 14: autodiff<14>(c, type, idx, k, x, r, Jamb); break;
+    case 15: autodiff<15>(c, type, idx, k, x, r, Jamb); break;
     case 16: autodiff<16>(c, type, idx, k, x, r, Jamb); break;
     case 17: autodiff<17>(c, type, idx, k, x, r, Jamb); break;
     case 21: autodiff<21>(c, type, idx, k, x, r, Jamb); break;
@@ -393,7 +403,7 @@ static int finalize(Ctx& c) {
         if (c.size[b] != ti.amb[sl]) { c.err = "block size does not match factor slot"; return BSGPU_ERR_INVALID; }
         if ((t == BSGPU_F_REPROJ || t == BSGPU_F_REPROJ_ONLINE_CALIB) && sl == 2) lm_use[b]++; else other_use[b]++;
       }
-      if (t == BSGPU_F_REPROJ || t == BSGPU_F_REPROJ_ONLINE_CALIB) {
+      if (has_camera(t)) {
         const int cam = idx[ti.nvar];
         if (cam < 0 || cam >= (int)c.cams.size()) { c.err = "camera index out of range"; return BSGPU_ERR_INVALID; }
       }
@@ -596,14 +606,14 @@ static bool solve_normal(Ctx& c, const double* D2, double* y, LinSys& ls) {
       const double* r = &g.r[(size_t)f * m];
       for (int sa = 0; sa < ti.nvar; ++sa) {
         if (cols[sa] < 0) continue;
-        for (int ia = 0; ia < 3; ++ia) {
+        for (int ia = 0; ia < tsz(ti, sa); ++ia) {
           const int ca = sa * 3 + ia;
           double gsum = 0;
           for (int k = 0; k < m; ++k) gsum += J[k * tw + ca] * r[k];
           ls.bp[cols[sa] + ia] += gsum;
           for (int sb = 0; sb < ti.nvar; ++sb) {
             if (cols[sb] < 0) continue;
-            for (int ib = 0; ib < 3; ++ib) {
+            for (int ib = 0; ib < tsz(ti, sb); ++ib) {
               const int cb = sb * 3 + ib;
               double s = 0;
               for (int k = 0; k < m; ++k) s += J[k * tw + ca] * J[k * tw + cb];
@@ -779,7 +789,7 @@ static void gradient_of(Ctx& c, double* grad) {
     const double* r = &g.r[(size_t)f * m];
     for (int sl = 0; sl < ti.nvar; ++sl) {
       if (cols[sl] < 0) continue;
-      for (int i = 0; i < 3; ++i) {
+      for (int i = 0; i < tsz(ti, sl); ++i) {
         double s = 0;
         for (int k = 0; k < m; ++k) s += J[k * tw + 3 * sl + i] * r[k];
         grad[cols[sl] + i] += s;
@@ -794,7 +804,7 @@ static void colnorm2_of(Ctx& c, double* n2) {
     const double* J = &g.J[(size_t)f * m * tw];
     for (int sl = 0; sl < ti.nvar; ++sl) {
       if (cols[sl] < 0) continue;
-      for (int i = 0; i < 3; ++i) {
+      for (int i = 0; i < tsz(ti, sl); ++i) {
         double s = 0;
         for (int k = 0; k < m; ++k) s += J[k * tw + 3 * sl + i] * J[k * tw + 3 * sl + i];
         n2[cols[sl] + i] += s;
@@ -808,7 +818,7 @@ static void scale_columns(Ctx& c, const double* sc) {
     double* J = &g.J[(size_t)f * m * tw];
     for (int sl = 0; sl < ti.nvar; ++sl) {
       if (cols[sl] < 0) continue;
-      for (int i = 0; i < 3; ++i)
+      for (int i = 0; i < tsz(ti, sl); ++i)
         for (int k = 0; k < m; ++k) J[k * tw + 3 * sl + i] *= sc[cols[sl] + i];
     }
   });
@@ -824,7 +834,7 @@ static double model_cost_change_of(Ctx& c, const double* v) {
       double jv = 0;
       for (int sl = 0; sl < ti.nvar; ++sl) {
         if (cols[sl] < 0) continue;
-        for (int i = 0; i < 3; ++i) jv += J[k * tw + 3 * sl + i] * v[cols[sl] + i];
+        for (int i = 0; i < tsz(ti, sl); ++i) jv += J[k * tw + 3 * sl + i] * v[cols[sl] + i];
       }
       acc -= jv * (r[k] + jv / 2.0);
     }
@@ -1096,7 +1106,7 @@ int bso_evaluate(Ctx* c, double* cost, double* residuals, double* gradient, doub
         for (int k = 0; k < ti.m; ++k)
           for (int sl = 0; sl < ti.nvar; ++sl) {
             if (cols[sl] < 0) continue;
-            for (int i = 0; i < 3; ++i)
+            for (int i = 0; i < bso::tsz(ti, sl); ++i)
               jacobian[(size_t)(g.row0 + f * ti.m + k) * c->n_tan + cols[sl] + i] = g.J[((size_t)f * ti.m + k) * g.tw + 3 * sl + i];
           }
       }

@@ -190,6 +190,72 @@ inline void ReprojOnlineCalibResidual(const Camera& cam, const double pix[2], do
 //   consts layout (bsgpu.h BSGPU_F_IMU_DELTA): dt, dq[4], dp[3], dv[3], dq_dbg[9], dp_dbg[9],
 //   dp_dba[9], dv_dbg[9], dv_dba[9], bg_lin[3], ba_lin[3], A[225]
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// A7: bs_constraints/include/bs_constraints/visual/inversedepth_reprojection_functor.h:57-125
+//   blocks: q_WORLD_BASELINKa[4], p_WORLD_BASELINKa[3], q_WORLD_BASELINKm[4], p_WORLD_BASELINKm[3], rho[1]
+//   consts: pixel u,v; w (sqrt information = w*I2, inversedepth_reprojection_constraint.cpp:33-34); bearing m[3]
+// Rigid transforms are kept as (R row-major 3x3, t) pairs; compose/invert follow helpers.h:14-35.
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct Rigid { T R[9]; T t[3]; };
+template <typename T> inline Rigid<T> RigidCompose(const Rigid<T>& A, const Rigid<T>& B) {  // A * B
+  Rigid<T> C;
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) C.R[3 * i + j] = A.R[3 * i] * B.R[j] + A.R[3 * i + 1] * B.R[3 + j] + A.R[3 * i + 2] * B.R[6 + j];
+    C.t[i] = A.R[3 * i] * B.t[0] + A.R[3 * i + 1] * B.t[1] + A.R[3 * i + 2] * B.t[2] + A.t[i];
+  }
+  return C;
+}
+template <typename T> inline Rigid<T> RigidInverse(const Rigid<T>& A) {  // helpers.h:27-35
+  Rigid<T> C;
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) C.R[3 * i + j] = A.R[3 * j + i];
+    C.t[i] = -(A.R[i] * A.t[0] + A.R[3 + i] * A.t[1] + A.R[6 + i] * A.t[2]);
+  }
+  return C;
+}
+template <typename T> inline Rigid<T> RigidFromQP(const T* q, const T* p) {  // helpers.h:14-25
+  Rigid<T> C;
+  EigenQuatToRot(q, C.R);
+  C.t[0] = p[0]; C.t[1] = p[1]; C.t[2] = p[2];
+  return C;
+}
+template <typename T> inline Rigid<T> CameraExtrinsic(const Camera& cam) {  // T_cam_baselink as T
+  Rigid<T> C;
+  for (int i = 0; i < 9; ++i) C.R[i] = T(cam.R_cb[i]);
+  for (int i = 0; i < 3; ++i) C.t[i] = T(cam.t_cb[i]);
+  return C;
+}
+// (K [R|t] (m; rho)).hnormalized(), residual = w (pixel - reproj)   (functor.h:107-121)
+template <typename T>
+inline void ProjectBearing(const Camera& cam, const double* k, const Rigid<T>& T_cm_ca, const T& rho, T r[2]) {
+  T c[3];
+  for (int i = 0; i < 3; ++i)
+    c[i] = T_cm_ca.R[3 * i] * T(k[3]) + T_cm_ca.R[3 * i + 1] * T(k[4]) + T_cm_ca.R[3 * i + 2] * T(k[5]) + T_cm_ca.t[i] * rho;
+  const T hx = T(cam.fx) * c[0] + T(cam.cx) * c[2];
+  const T hy = T(cam.fy) * c[1] + T(cam.cy) * c[2];
+  r[0] = T(k[2]) * (T(k[0]) - hx / c[2]);
+  r[1] = T(k[2]) * (T(k[1]) - hy / c[2]);
+}
+template <typename T>
+inline void InverseDepthReprojResidual(const Camera& cam, const double* k, const T* qa, const T* pa, const T* qm,
+                                       const T* pm, const T* rho, T r[2]) {
+  const Rigid<T> T_BASELINK_CAM = RigidInverse(CameraExtrinsic<T>(cam));                    // functor.h:64-65
+  const Rigid<T> T_WORLD_CAMERAa = RigidCompose(RigidFromQP(qa, pa), T_BASELINK_CAM);       // :68-71
+  const Rigid<T> T_WORLD_CAMERAm = RigidCompose(RigidFromQP(qm, pm), T_BASELINK_CAM);       // :74-77
+  const Rigid<T> T_CAMERAm_CAMERAa = RigidCompose(RigidInverse(T_WORLD_CAMERAm), T_WORLD_CAMERAa);  // :80-81
+  ProjectBearing(cam, k, T_CAMERAm_CAMERAa, rho[0], r);
+}
+// A7 unary: inversedepth_reprojection_functor_unary.h:36-72 — the observation made in the anchor frame itself:
+// T_CAMERAm_CAMERAa = I, so the residual does not depend on any parameter block (all Jacobians are zero).
+template <typename T>
+inline void InverseDepthReprojUnaryResidual(const Camera& cam, const double* k, const T* /*qa*/, const T* /*pa*/,
+                                            const T* rho, T r[2]) {
+  Rigid<T> I;
+  for (int i = 0; i < 9; ++i) I.R[i] = T(i % 4 == 0 ? 1.0 : 0.0);
+  for (int i = 0; i < 3; ++i) I.t[i] = T(0.0);
+  ProjectBearing(cam, k, I, rho[0], r);
+}
+
 static const double kGravityWorld[3] = {0.0, 0.0, -9.80665};  // bs_common/include/bs_common/utils.h:20-24
 
 template <typename T>

@@ -5,7 +5,7 @@ from the oracle AFTER it passed the reference's own known-answer tests (tests/te
 and the finite-difference / scipy cross-checks.  Each .npz holds the inputs (flat IR) and the expected
 outputs: cost, residuals, gradient, per-iteration LM costs / radii / accept flags, final values.
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [case ...]      (no arguments: every case)
 """
 import os
 import sys
@@ -25,11 +25,14 @@ CASES = {
     "vio_window_6kf_60lm": (lambda: synthetic.vio_window(n_kf=6, n_lm=60, seed=101, track_min=3, track_max=6), 25),
     "lio_window_12kf": (lambda: synthetic.lio_window(n_kf=12, n_rel=80, seed=102), 25),
     "pose_graph_40": (lambda: synthetic.pose_graph(n_pose=40, n_loop=80, seed=103), 25),
+    "idp_window_8kf_60lm": (lambda: synthetic.idp_window(n_kf=8, n_lm=60, seed=104), 25),
 }
 
 
 def main():
     for name, (make, iters) in CASES.items():
+        if len(sys.argv) > 1 and name not in sys.argv[1:]:
+            continue
         pr = make()
         o = Oracle(threads=1)
         pr.load(o)

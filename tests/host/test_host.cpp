@@ -119,6 +119,77 @@ static void test_block_order_and_pack() {
   CHECK_NEAR(t.cameras[0].fx, 458.654, 0); CHECK_NEAR(t.cameras[0].t_cam_baselink[0], 0.1, 0);
 }
 
+// inverse-depth landmarks (use_idp) through the host mirror — bearing validation
+// (bs_variables/src/inverse_depth_landmark.cpp:21-26), anchor (unary) + later (binary) observations, recovery of the
+// generating inverse depths with the two anchor poses held by priors
+static void test_inverse_depth_window() {
+  std::printf("InverseDepthWindow\n");
+  bool threw = false;
+  try { bs_variables::InverseDepthLandmark bad(1, Vec3{0.1, 0.2, 1.0}, fuse_core::Time(0.0)); } catch (const std::runtime_error&) { threw = true; }
+  CHECK(threw);
+  std::mt19937 rng(11);
+  std::normal_distribution<double> N(0.0, 1.0);
+  std::uniform_real_distribution<double> U(0.0, 1.0);
+  Mat<4, 4> T = Mat<4, 4>::Identity(); T(0, 3) = 0.05; T(1, 3) = -0.02;
+  Mat<3, 3> K = Mat<3, 3>::Identity(); K(0, 0) = 458.654; K(1, 1) = 457.296; K(0, 2) = 367.215; K(1, 2) = 248.375;
+  const int n_kf = 4, n_lm = 25;
+  bs_optimizers::GpuGraph graph;
+  std::vector<fuse_variables::Orientation3DStamped::SharedPtr> qs;
+  std::vector<fuse_variables::Position3DStamped::SharedPtr> ps;
+  std::vector<Vec3> p_true;
+  for (int k = 0; k < n_kf; ++k) {
+    auto q = fuse_variables::Orientation3DStamped::make_shared(fuse_core::Time(1.0 + 0.1 * k));
+    auto p = fuse_variables::Position3DStamped::make_shared(fuse_core::Time(1.0 + 0.1 * k));
+    p_true.push_back(Vec3{0.4 * k, 0.1 * k * k, 0.05 * k});
+    q->data()[0] = 1.0;   // identity attitude (truth), positions start perturbed
+    for (int i = 0; i < 3; ++i) p->data()[i] = p_true[k][i] + (k >= 2 ? 0.03 * N(rng) : 0.0);
+    graph.addVariable(q); graph.addVariable(p);
+    qs.push_back(q); ps.push_back(p);
+  }
+  // gauge + scale: tight priors on the first two poses
+  Mat<6, 6> cov6 = Mat<6, 6>::Identity(); for (int i = 0; i < 6; ++i) cov6(i, i) = 1e-8;
+  for (int k = 0; k < 2; ++k)
+    graph.addConstraint(std::make_shared<fuse_constraints::AbsolutePose3DStampedConstraint>(
+        "prior", *ps[k], *qs[k], bs_constraints::Vector7d{p_true[k][0], p_true[k][1], p_true[k][2], 1, 0, 0, 0}, cov6));
+  std::vector<bs_variables::InverseDepthLandmark::SharedPtr> lms;
+  std::vector<double> rho_true;
+  for (int l = 0; l < n_lm; ++l) {
+    // point in the anchor (kf 0) camera; camera = baselink shifted by T_cam_baselink's translation, attitude identity
+    const double z = 4.0 + 6.0 * U(rng), x = (U(rng) - 0.5) * 0.8 * z, y = (U(rng) - 0.5) * 0.5 * z;
+    const double n = std::sqrt(x * x + y * y + z * z);
+    auto lm = std::make_shared<bs_variables::InverseDepthLandmark>((uint64_t)(100 + l), Vec3{x / n, y / n, z / n}, fuse_core::Time(1.0));
+    rho_true.push_back(1.0 / n);
+    lm->inverse_depth() = (1.0 / n) * (1.0 + 0.1 * N(rng));
+    graph.addVariable(lm);
+    lms.push_back(lm);
+    for (int k = 0; k < n_kf; ++k) {
+      // P_cam_k = P_cam_0 + (p_0 - p_k)  (identity attitudes, same extrinsic)
+      const double px = x + p_true[0][0] - p_true[k][0], py = y + p_true[0][1] - p_true[k][1], pz = z + p_true[0][2] - p_true[k][2];
+      const std::array<double, 2> uv = {K(0, 0) * px / pz + K(0, 2), K(1, 1) * py / pz + K(1, 2)};
+      if (k == 0) {
+        auto c = std::make_shared<bs_constraints::InverseDepthReprojectionConstraintUnary>("vo", *qs[0], *ps[0], *lm, T, K, uv, 1.0);
+        graph.addConstraint(c);
+      } else {
+        auto c = std::make_shared<bs_constraints::InverseDepthReprojectionConstraint>("vo", *qs[0], *ps[0], *qs[k], *ps[k], *lm, T, K, uv, 1.0);
+        c->loss(std::make_shared<fuse_loss::CauchyLoss>(5.0));
+        graph.addConstraint(c);
+      }
+    }
+  }
+  auto summary = graph.optimize();
+  CHECK(summary.IsSolutionUsable());
+  CHECK(summary.final_cost < 1e-6 * std::max(1.0, summary.initial_cost));
+  for (int l = 0; l < n_lm; ++l) {
+    const auto& v = graph.getVariable(lms[l]->uuid());
+    CHECK_NEAR(v.data()[0], rho_true[l], 1e-5);
+  }
+  for (int k = 2; k < n_kf; ++k) {
+    const auto& v = graph.getVariable(ps[k]->uuid());
+    for (int i = 0; i < 3; ++i) CHECK_NEAR(v.data()[i], p_true[k][i], 1e-4);
+  }
+  std::printf("  cost %.4e -> %.4e in %d iterations\n", summary.initial_cost, summary.final_cost, (int)summary.iterations.size() - 1);
+}
+
 // a synthetic visual-inertial stream through the fixed-lag smoother: lag window, pseudo-marginalisation
 static void test_fixed_lag_smoother_window() {
   std::printf("FixedLagSmootherWindow\n");
@@ -219,6 +290,7 @@ int main() {
   test_block_order_and_pack();
   test_simple_2_state_fg();
   test_absolute_imu_state();
+  test_inverse_depth_window();
   test_fixed_lag_smoother_window();
   if (g_fail) { std::printf("FAILED: %d checks\n", g_fail); return 1; }
   std::printf("ALL HOST TESTS PASSED\n");

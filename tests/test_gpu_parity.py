@@ -72,6 +72,48 @@ def test_lm_trajectory_all_factor_types(oracle_cls, gpu_solver_cls, seed):
     assert np.abs(g.get_blocks() - o.get_blocks()).max() < 1e-7
 
 
+@pytest.mark.parametrize("unit_bearing", [True, False])
+@pytest.mark.parametrize("cauchy", [None, 5.0])
+def test_inverse_depth_reprojection_factors(oracle_cls, gpu_solver_cls, unit_bearing, cauchy):
+    """A7: binary + unary inverse-depth reprojection constraints (closed-form HIP Jacobian vs the oracle's Jets),
+    1-dimensional rho blocks in the reduced system, whole LM trajectory."""
+    pr = synthetic.idp_window(n_kf=8, n_lm=80, seed=11, cauchy_a=cauchy, unit_bearing=unit_bearing)
+    g, o = _pair(pr, oracle_cls, gpu_solver_cls)
+    assert [g.tangent_offset(b) for b in range(pr.n_blocks)] == [o.tangent_offset(b) for b in range(pr.n_blocks)]
+    cg, rg, gg, Jg = g.evaluate(jacobian=True)
+    co, ro, go, Jo = o.evaluate(jacobian=True)
+    assert np.abs(rg - ro).max() <= 1e-9 * max(1.0, np.abs(ro).max())
+    assert np.abs(Jg - Jo).max() <= 1e-9 * max(1.0, np.abs(Jo).max())
+    assert np.all(Jg[:, np.abs(Jo).max(axis=0) == 0.0] == 0.0)     # untouched columns stay exactly zero
+    assert np.all(Jg[-2 * pr.meta["n_unary"]:] == 0.0)              # unary rows: zero Jacobian
+    assert abs(cg - co) <= 1e-12 * abs(co)
+    assert np.abs(gg - go).max() <= 1e-9 * max(1.0, np.abs(go).max())
+    sg, so = g.solve(), o.solve()
+    ig, io = g.iterations(), o.iterations()
+    assert sg.termination_type == so.termination_type == capi.CONVERGENCE
+    assert [i.step_is_successful for i in ig] == [i.step_is_successful for i in io]
+    for a, b in zip(ig, io):
+        assert abs(a.cost - b.cost) <= 1e-8 * abs(b.cost)
+    assert abs(sg.final_cost - so.final_cost) <= 1e-6 * so.final_cost
+    assert np.abs(g.get_blocks() - o.get_blocks()).max() < 1e-6
+    # the estimate moved towards the generating inverse depths
+    x = g.get_blocks()
+    rho = np.array([x[pr.offset[b]] for b in pr.meta["rho_blocks"]])
+    rho0 = np.array([pr.values[pr.offset[b]] for b in pr.meta["rho_blocks"]])
+    assert np.abs(rho - pr.meta["rho_true"]).mean() < np.abs(rho0 - pr.meta["rho_true"]).mean()
+
+
+def test_inverse_depth_with_constant_anchor(oracle_cls, gpu_solver_cls):
+    pr = synthetic.idp_window(n_kf=6, n_lm=40, seed=12)
+    kf = pr.meta["kf_blocks"]
+    pr.is_const[int(kf[0, 0])] = 1; pr.is_const[int(kf[0, 1])] = 1
+    g, o = _pair(pr, oracle_cls, gpu_solver_cls)
+    Jg, Jo = g.evaluate(jacobian=True)[3], o.evaluate(jacobian=True)[3]
+    assert Jg.shape == Jo.shape and np.abs(Jg - Jo).max() <= 1e-9 * np.abs(Jo).max()
+    sg, so = g.solve(), o.solve()
+    assert abs(sg.final_cost - so.final_cost) <= 1e-6 * so.final_cost
+
+
 @pytest.mark.parametrize("seed", [0, 7])
 def test_lm_rejected_steps_path(oracle_cls, gpu_solver_cls, seed):
     """Random (inconsistent) measurements: a badly conditioned, wandering LM path with rejected steps.

@@ -5,7 +5,7 @@ eps 1e-8 forward / tolerance 1e-6), and the three reprojection Jacobian variants
 import numpy as np
 import pytest
 
-from beam_slam_amd import capi
+from beam_slam_amd import capi, synthetic
 from helpers import manifold_plus, mixed_problem
 
 
@@ -84,3 +84,54 @@ def test_oracle_robust_loss_corrector(oracle_cls):
         + 0.5 * (rn[off + 6 * k:] ** 2).sum()
     assert np.isclose(cl, total, rtol=1e-12)
     assert other_l > 0
+
+
+@pytest.mark.parametrize("unit_bearing", [True, False])
+def test_oracle_inverse_depth_reprojection(oracle_cls, unit_bearing):
+    """A7 (inversedepth_reprojection_functor.h:57-125, ..._unary.h:36-72): autodiff Jacobian vs central differences,
+    the unary constraint has zero Jacobian, and at the generating state the residual is the pixel noise."""
+    pr = synthetic.idp_window(n_kf=6, n_lm=30, seed=5, cauchy_a=None, unit_bearing=unit_bearing)
+    o = oracle_cls()
+    pr.load(o)
+    cost, r, g, J = o.evaluate(jacobian=True)
+    Jfd = _fd_jacobian(o, pr)
+    assert np.abs(J - Jfd).max() / np.abs(Jfd).max() < 2e-7
+    # residual rows are grouped by factor type in enum order: pose prior (6), position prior (3), binary, unary
+    r0, nb, nu = 9, 2 * pr.meta["n_binary"], 2 * pr.meta["n_unary"]
+    assert J.shape[0] == r0 + nb + nu
+    assert nu > 0 and np.all(J[r0 + nb:] == 0.0)
+    # ground truth: residuals = w * pixel noise (sigma 0.5 px)
+    vals = pr.values.copy()
+    kf = pr.meta["kf_blocks"]
+    for i in range(kf.shape[0]):
+        vals[pr.offset[kf[i, 0]]:pr.offset[kf[i, 0]] + 4] = pr.meta["q_true"][i]
+        vals[pr.offset[kf[i, 1]]:pr.offset[kf[i, 1]] + 3] = pr.meta["p_true"][i]
+    for b, rho in zip(pr.meta["rho_blocks"], pr.meta["rho_true"]):
+        vals[pr.offset[b]] = rho
+    o.set_values(vals)
+    r_true = o.evaluate(gradient=False)[1][r0:]
+    assert np.abs(r_true).max() < 5 * 0.5 and 0.3 < r_true.std() < 0.7
+
+
+def test_oracle_inverse_depth_binary_equals_unary_at_anchor(oracle_cls):
+    """With the measurement pose equal to the anchor pose T_CAMERAm_CAMERAa = I, so the binary functor
+    (functor.h:80-81) must give the unary functor's residual (functor_unary.h:41-42)."""
+    from beam_slam_amd.problem import Problem
+    rng = np.random.default_rng(3)
+    pr = Problem()
+    R_cb, t_cb = synthetic._t_cam_baselink()
+    cam = pr.add_camera(synthetic.FX, synthetic.FY, synthetic.CX, synthetic.CY, R_cb, t_cb)
+    q = synthetic.quat_from_aa(rng.normal(0, 0.4, 3)); p = rng.normal(0, 1, 3)
+    qa, pa = pr.add_quat(q), pr.add_block(p)
+    qm, pm = pr.add_quat(q), pr.add_block(p)
+    rho = pr.add_block([0.21])
+    c = np.array([300.0, 200.0, 1.3, 0.1, -0.05, 0.99])
+    pr.add_factors(capi.F_IDP_REPROJ, [[qa, pa, qm, pm, rho, cam]], [c])
+    pr.add_factors(capi.F_IDP_REPROJ_UNARY, [[qa, pa, rho, cam]], [c])
+    o = oracle_cls()
+    pr.load(o)
+    r = o.evaluate(gradient=False)[1]
+    m = c[3:]
+    expect = 1.3 * (c[:2] - np.array([synthetic.FX * m[0] / m[2] + synthetic.CX, synthetic.FY * m[1] / m[2] + synthetic.CY]))
+    assert np.allclose(r[2:], expect, rtol=1e-14)                      # unary
+    assert np.allclose(r[:2], expect, rtol=1e-12, atol=1e-10)          # binary with T = I
