@@ -641,7 +641,7 @@ struct DenseDev {
   const PanelDesc* bs_sep_panels;
   const int *panel_of_tile, *chain_begin, *chain_end;
 };
-void dense_factor_solve(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* y, double* scal) {
+void dense_factor(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* scal) {
   const int ld = P.npad;
   for (int st = 0; st < P.n_steps(); ++st) {
     const int p0 = P.potrf_before_step_off[st], p1 = P.potrf_before_step_off[st + 1];
@@ -649,6 +649,10 @@ void dense_factor_solve(hipStream_t s, const DensePlan& P, const DenseDev& D, do
     launch_chol_panel_step(s, S, D.Lp, ld, D.panels + P.step_off[st], P.step_off[st + 1] - P.step_off[st], P.step_maxrows[st],
                            D.rows_flat, D.nreal, D.Vinv, scal);
   }
+}
+void dense_factor_solve(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* y, double* scal) {
+  const int ld = P.npad;
+  dense_factor(s, P, D, S, scal);
   // y' = the rhs row after forward substitution: row rhs_row of the shadow matrix (the rhs tile is an
   // off-diagonal row tile of every panel)
   (void)hipMemcpyAsync(y, D.Lp + (size_t)P.rhs_row * ld, sizeof(double) * P.T * 64, hipMemcpyDeviceToDevice, s);
@@ -1104,8 +1108,51 @@ int bsgpu_evaluate(bsgpu_ctx* c, double* cost, double* residuals, double* gradie
   return BSGPU_OK;
 }
 
-int bsgpu_covariance(bsgpu_ctx* c, int32_t, int32_t, double*) {
-  return fail(c, BSGPU_ERR_UNSUPPORTED, "marginal covariance queries are a 'next' row (SURVEY.md §8f rank 3), not built yet");
+// Graph::getCovariance for pose-side blocks: Sigma_pp = (H_pp - H_pl H_ll^-1 H_lp)^-1 = S^-1 at the current values,
+// without LM damping (what ceres::Covariance computes from the robustified J^T J, landmarks marginalised).
+// One undamped assembly + one factorisation; the unit vectors of both blocks ride along as rows of the rhs tile.
+int bsgpu_covariance(bsgpu_ctx* c, int32_t ba, int32_t bb, double* out) {
+  if (!out) return fail(c, BSGPU_ERR_INVALID, "null argument");
+  int rc = finalize(c);
+  if (rc != BSGPU_OK) return rc;
+  if (ba < 0 || bb < 0 || ba >= c->nb || bb >= c->nb) return fail(c, BSGPU_ERR_INVALID, "covariance: block out of range");
+  if (c->toff[ba] < 0 || c->toff[bb] < 0) return fail(c, BSGPU_ERR_INVALID, "covariance: constant block");
+  if (c->is_lm[ba] || c->is_lm[bb])
+    return fail(c, BSGPU_ERR_UNSUPPORTED, "covariance: landmark blocks are eliminated; only pose-side blocks can be queried");
+  if (!c->dense_ok) return fail(c, BSGPU_ERR_UNSUPPORTED, "covariance: reduced system above the dense limit (block-sparse PCG path has no factor)");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  bsgpu_options o;
+  bsgpu_options_default(&o);
+  const bool was_pcg = c->use_pcg;
+  c->use_pcg = false;
+  *c->h_radius = 1e300;   // Lambda / radius -> 0: undamped normal equations
+  (void)hipMemcpyAsync(c->d_scal + SC_RADIUS, c->h_radius, sizeof(double), hipMemcpyHostToDevice, s);
+  eval_all(c, c->d_x, true, SC_COST_X);
+  assemble(c, o, 1e300, true, true);
+  c->use_pcg = was_pcg;
+  const int ta = c->tsize[ba], tb = c->tsize[bb];
+  std::vector<int> cols;
+  for (int i = 0; i < ta; ++i) cols.push_back(c->plan.spos(c->toff[ba] + i));
+  const int row_b0 = (ba == bb) ? 0 : ta;
+  if (ba != bb) for (int j = 0; j < tb; ++j) cols.push_back(c->plan.spos(c->toff[bb] + j));
+  int* d_cols = nullptr;
+  double* d_out = nullptr;
+  HIPCHK(c, hipMalloc((void**)&d_cols, sizeof(int) * cols.size()));
+  if (hipMalloc((void**)&d_out, sizeof(double) * ta * tb) != hipSuccess) { (void)hipFree(d_cols); return fail(c, BSGPU_ERR_DEVICE, "out of device memory"); }
+  (void)hipMemcpyAsync(d_cols, cols.data(), sizeof(int) * cols.size(), hipMemcpyHostToDevice, s);
+  launch_cov_units(s, c->d_S, c->npad, c->plan.rhs_row, d_cols, (int)cols.size());
+  const DenseDev D{c->d_perm, c->d_nreal, c->d_rows_flat, c->d_potrf_tiles, c->d_panels, c->d_Lp, c->d_Vinv,
+                   c->d_bs_sep_panels, c->d_panel_of_tile, c->d_chain_begin, c->d_chain_end};
+  dense_factor(s, c->plan, D, c->d_S, c->d_scal);
+  launch_cov_dots(s, c->d_Lp, c->npad, c->plan.rhs_row, c->plan.T * 64, ta, row_b0, tb, d_out);
+  (void)hipMemcpyAsync(out, d_out, sizeof(double) * ta * tb, hipMemcpyDeviceToHost, s);
+  rc = fetch_scalars(c);
+  (void)hipFree(d_cols); (void)hipFree(d_out);
+  if (rc != BSGPU_OK) return rc;
+  if (c->h_scal[SC_CHOL_FAIL] > 0.0 || !std::isfinite(out[0]))
+    return fail(c, BSGPU_ERR_NUMERIC, "covariance: J^T J is singular at the current values (gauge freedom or unobserved block)");
+  return BSGPU_OK;
 }
 
 double bsgpu_time_reproj_jacobian_ms(bsgpu_ctx* c, int32_t reps) {

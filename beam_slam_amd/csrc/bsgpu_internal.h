@@ -122,6 +122,8 @@ void launch_chol_backsolve_chains(hipStream_t s, const double* S, const double* 
                                   const PanelDesc* panels_dev, const int* panel_of_tile_dev, const int* chain_begin_dev,
                                   const int* chain_end_dev, int n_chains, const int* rows_flat_dev, const int* nreal_dev, double* y);
 void launch_y_to_delta(hipStream_t s, int n_pose, const double* y, const int* perm, double* y_tan, double* delta);
+void launch_cov_units(hipStream_t s, double* S, int ld, int rhs_row, const int* cols_dev, int n);
+void launch_cov_dots(hipStream_t s, const double* Lp, int ld, int rhs_row, int n_cols, int ta, int row_b0, int tb, double* out);
 int chol_vinv_stride();
 void chol_prepare();  // one-time function attributes (kept out of captured sequences)
 // block-sparse PCG path (k_pcg.hip)

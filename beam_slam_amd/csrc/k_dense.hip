@@ -3,6 +3,7 @@
 //                padding / rhs positions.  S is in SOLVER order: position = perm[tile] * 64 + offset
 //                (dense_plan.h); hdiag / scale / dcl stay in tangent order.
 //   y_to_delta   y (solver order) -> y_tan, delta = -y (tangent order)
+//   cov_*        marginal covariance blocks from forward-substituted unit vectors (bsgpu_covariance)
 // Stands in, together with k_chol.hip, for the reference's SPARSE_NORMAL_CHOLESKY step ([EXT] Ceres,
 // beam_slam_launch/config/vio.yaml:9) after Schur elimination of the landmarks.
 #include "bsgpu_device.h"
@@ -48,6 +49,31 @@ __global__ void y_to_delta_kernel(int n_pose, const double* __restrict__ y, cons
 }
 void launch_y_to_delta(hipStream_t s, int n_pose, const double* y, const int* perm, double* y_tan, double* delta) {
   if (n_pose > 0) hipLaunchKernelGGL(y_to_delta_kernel, dim3((n_pose + 255) / 256), dim3(256), 0, s, n_pose, y, perm, y_tan, delta);
+}
+
+// ---- marginal covariance of pose-side blocks: Sigma = S^-1 (undamped).  Unit vectors ride through the
+// factorisation as rows of the rhs tile (z_k = L^-1 e_k lands in the shadow matrix); Sigma(i,j) = z_i . z_j.
+__global__ void cov_units_kernel(double* __restrict__ S, int ld, int rhs_row, const int* __restrict__ cols, int n) {
+  const int k = threadIdx.x;
+  if (k < n) S[(size_t)(rhs_row + k) * ld + cols[k]] = 1.0;
+}
+__global__ __launch_bounds__(256) void cov_dots_kernel(const double* __restrict__ Lp, int ld, int rhs_row, int n_cols, int row_b0,
+                                                       int tb, double* __restrict__ out) {
+  __shared__ double sred[4];
+  const int i = blockIdx.x / tb, j = blockIdx.x % tb;
+  const double* za = Lp + (size_t)(rhs_row + i) * ld;
+  const double* zb = Lp + (size_t)(rhs_row + row_b0 + j) * ld;
+  double acc = 0.0;
+  for (int k = threadIdx.x; k < n_cols; k += 256) acc = fma(za[k], zb[k], acc);
+  const double t = block_sum_256(acc, sred);
+  if (threadIdx.x == 0) out[blockIdx.x] = t;
+}
+void launch_cov_units(hipStream_t s, double* S, int ld, int rhs_row, const int* cols_dev, int n) {
+  (void)hipMemsetAsync(S + (size_t)rhs_row * ld, 0, sizeof(double) * 64 * (size_t)ld, s);
+  hipLaunchKernelGGL(cov_units_kernel, dim3(1), dim3(64), 0, s, S, ld, rhs_row, cols_dev, n);
+}
+void launch_cov_dots(hipStream_t s, const double* Lp, int ld, int rhs_row, int n_cols, int ta, int row_b0, int tb, double* out) {
+  hipLaunchKernelGGL(cov_dots_kernel, dim3(ta * tb), dim3(256), 0, s, Lp, ld, rhs_row, n_cols, row_b0, tb, out);
 }
 
 }  // namespace bsg

@@ -30,6 +30,7 @@ int BS_API(solve)(bsgpu_ctx*, const bsgpu_options*, bsgpu_summary*);
 int BS_API(get_blocks)(bsgpu_ctx*, double*, int64_t);
 void BS_API(options_default)(bsgpu_options*);
 int BS_API(nidx)(int);
+int BS_API(covariance)(bsgpu_ctx*, int32_t, int32_t, double*);
 }
 
 namespace ceres_compat {  // the ceres::Solver fields the reference sets (vio.yaml:7-17) and reads (fixed_lag_smoother.cpp:286,705-716)
@@ -163,31 +164,42 @@ class GpuGraph {
     return v;
   }
 
-  ceres_compat::SolverSummary optimize(const ceres_compat::SolverOptions& o = ceres_compat::SolverOptions()) {
-    const auto t0 = std::chrono::steady_clock::now();
-    const auto vars = orderedVariables();
+  // Flat IR of the current graph (variables at their current values) loaded into the back-end context
+  struct Flat {
+    std::vector<const fuse_core::Variable*> vars;
     std::vector<double> values;
     std::vector<int32_t> offset;
     std::vector<uint8_t> size, manifold, is_const;
     std::map<fuse_core::UUID, int32_t> block_index;
-    for (const auto* v : vars) {
-      block_index[v->uuid()] = (int32_t)offset.size();
-      offset.push_back((int32_t)values.size());
-      size.push_back((uint8_t)v->size());
-      manifold.push_back((uint8_t)v->manifold());
-      is_const.push_back((v->holdConstant() || on_hold_.count(v->uuid())) ? 1 : 0);
-      values.insert(values.end(), v->data(), v->data() + v->size());
+  };
+  bool flatten(Flat& f) {
+    f.vars = orderedVariables();
+    for (const auto* v : f.vars) {
+      f.block_index[v->uuid()] = (int32_t)f.offset.size();
+      f.offset.push_back((int32_t)f.values.size());
+      f.size.push_back((uint8_t)v->size());
+      f.manifold.push_back((uint8_t)v->manifold());
+      f.is_const.push_back((v->holdConstant() || on_hold_.count(v->uuid())) ? 1 : 0);
+      f.values.insert(f.values.end(), v->data(), v->data() + v->size());
     }
+    if (f.offset.empty()) return false;
     fuse_core::FactorTables t;
-    auto block_of = [&](const fuse_core::UUID& u) { return block_index.at(u); };
+    auto block_of = [&](const fuse_core::UUID& u) { return f.block_index.at(u); };
     for (auto& kv : constraints_) kv.second->pack(block_of, t);
-    ceres_compat::SolverSummary s;
-    if (offset.empty()) { s.termination_type = ceres_compat::CONVERGENCE; s.message = "empty graph"; return s; }
     check(BS_API(clear)(ctx_));
-    check(BS_API(set_blocks)(ctx_, (int32_t)offset.size(), values.data(), offset.data(), size.data(), manifold.data(), is_const.data()));
+    check(BS_API(set_blocks)(ctx_, (int32_t)f.offset.size(), f.values.data(), f.offset.data(), f.size.data(), f.manifold.data(), f.is_const.data()));
     if (!t.cameras.empty()) check(BS_API(set_cameras)(ctx_, (int32_t)t.cameras.size(), t.cameras.data()));
     for (int ty = 0; ty < BSGPU_F_NUM_TYPES; ++ty)
       if (t.count(ty)) check(BS_API(add_factors)(ctx_, ty, t.count(ty), t.idx[ty].data(), t.consts[ty].data(), t.loss_kind[ty].data(), t.loss_a[ty].data()));
+    return true;
+  }
+
+  ceres_compat::SolverSummary optimize(const ceres_compat::SolverOptions& o = ceres_compat::SolverOptions()) {
+    const auto t0 = std::chrono::steady_clock::now();
+    Flat f;
+    ceres_compat::SolverSummary s;
+    if (!flatten(f)) { s.termination_type = ceres_compat::CONVERGENCE; s.message = "empty graph"; return s; }
+    auto& vars = f.vars; auto& values = f.values; auto& offset = f.offset; auto& size = f.size;
     bsgpu_options bo;
     BS_API(options_default)(&bo);
     bo.max_num_iterations = o.max_num_iterations; bo.max_solver_time_in_seconds = o.max_solver_time_in_seconds;
@@ -212,6 +224,26 @@ class GpuGraph {
     return optimize(o);
   }
   const bsgpu_summary& lastBackendSummary() const { return last_summary_; }
+
+  // fuse_core::Graph::getCovariance(covariance_requests, covariance_matrices) in tangent space (the form
+  // bs_publishers/src/odometry_3d_publisher.cpp:82 consumes): one row-major localSize(a) x localSize(b) matrix per
+  // requested pair, marginal covariance at the variables' current values.  Pose-side variables only: landmarks are
+  // eliminated by the solver (throws, like fuse does for an uncomputable request).
+  void getCovariance(const std::vector<std::pair<fuse_core::UUID, fuse_core::UUID>>& covariance_requests,
+                     std::vector<std::vector<double>>& covariance_matrices) {
+    Flat f;
+    covariance_matrices.clear();
+    if (covariance_requests.empty()) return;
+    if (!flatten(f)) throw std::runtime_error("getCovariance: empty graph");
+    for (const auto& rq : covariance_requests) {
+      const auto a = f.block_index.find(rq.first), b = f.block_index.find(rq.second);
+      if (a == f.block_index.end() || b == f.block_index.end()) throw std::out_of_range("getCovariance: variable not in graph");
+      const size_t ta = variables_.at(rq.first)->localSize(), tb = variables_.at(rq.second)->localSize();
+      std::vector<double> m(ta * tb);
+      check(BS_API(covariance)(ctx_, a->second, b->second, m.data()));
+      covariance_matrices.push_back(std::move(m));
+    }
+  }
 
  private:
   void check(int rc) { if (rc != BSGPU_OK) throw std::runtime_error(std::string("bsgpu: ") + BS_API(last_error)(ctx_)); }

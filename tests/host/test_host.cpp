@@ -69,6 +69,16 @@ static void test_absolute_imu_state() {
   CHECK(st.Update(graph));
   const auto s = st.GetStateVector();
   for (int i = 0; i < 16; ++i) CHECK_NEAR(s[i], mean[i], i < 4 ? 1e-3 : 1e-5);
+  // :167-297 covariance of the optimised state in tangent space == the prior covariance (1e-5)
+  const fuse_core::UUID ids[5] = {st.Orientation().uuid(), st.Position().uuid(), st.Velocity().uuid(), st.GyroBias().uuid(), st.AccelBias().uuid()};
+  std::vector<std::pair<fuse_core::UUID, fuse_core::UUID>> requests;
+  for (int i = 0; i < 5; ++i) for (int j = i; j < 5; ++j) requests.push_back({ids[i], ids[j]});
+  std::vector<std::vector<double>> blocks;
+  graph.getCovariance(requests, blocks);
+  CHECK(blocks.size() == requests.size());
+  size_t k = 0;
+  for (int i = 0; i < 5; ++i) for (int j = i; j < 5; ++j, ++k)
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) CHECK_NEAR(blocks[k][3 * a + b], cov(3 * i + a, 3 * j + b), 1e-5);
 }
 
 // deterministic variable index + constraint payloads

@@ -225,3 +225,56 @@ def test_errors_are_loud(gpu_solver_cls):
     with pytest.raises(capi.SolverError):
         g.add_factors(capi.F_ABS_VEC3, np.array([[10 ** 6]], np.int32), np.zeros((1, 12)))
         g.finalize()
+
+
+def test_covariance_blocks_match_oracle(oracle_cls, gpu_solver_cls):
+    """bsgpu_covariance (Graph::getCovariance, bs_publishers/src/odometry_3d_publisher.cpp:82): marginal covariance of
+    pose-side blocks = blocks of (J^T J)^-1 with the landmarks marginalised.  The oracle inverts the full J^T J."""
+    pr = mixed_problem(4, n_state=4, n_lm=20, consistent=True)
+    g, o = _pair(pr, oracle_cls, gpu_solver_cls)
+    g.solve(); o.set_values(g.get_blocks())
+    st = pr.meta["states"]
+    pairs = [(st[0, 0], st[0, 0]), (st[0, 0], st[0, 1]), (st[1, 1], st[3, 0]), (st[2, 2], st[2, 4]), (st[3, 3], st[0, 1]), (st[3, 1], st[3, 1])]
+    for a, b in pairs:
+        cg, co = g.covariance(int(a), int(b)), o.covariance(int(a), int(b))
+        assert np.abs(cg - co).max() <= 1e-8 * max(np.abs(co).max(), np.sqrt(np.abs(o.covariance(int(a), int(a))).max() * np.abs(o.covariance(int(b), int(b))).max()))
+    # symmetric, and a later solve is not disturbed by the query
+    assert np.allclose(g.covariance(int(st[1, 1]), int(st[3, 0])), g.covariance(int(st[3, 0]), int(st[1, 1])).T, rtol=1e-10, atol=1e-16)
+    c0 = g.solve().final_cost
+    assert abs(c0 - o.solve().final_cost) <= 1e-6 * c0
+
+
+def test_covariance_reference_kat(gpu_solver_cls):
+    """bs_constraints/tests/absolute_imu_state_3d_stamped_constraint_test.cpp:167-297 through the HIP path."""
+    from test_oracle_reference_kats import _kat1_problem, kat1_cov
+    pr, b = _kat1_problem()
+    g = gpu_solver_cls(0)
+    pr.load(g)
+    assert g.solve().is_solution_usable == 1
+    cov = np.zeros((15, 15))
+    for i in range(5):
+        for j in range(5):
+            cov[3 * i:3 * i + 3, 3 * j:3 * j + 3] = g.covariance(b[i], b[j])
+    assert np.abs(cov - kat1_cov()).max() < 1e-5
+
+
+def test_covariance_errors(gpu_solver_cls):
+    pr = synthetic.vio_window(n_kf=5, n_lm=40, seed=3, track_min=3, track_max=5)
+    g = gpu_solver_cls(0)
+    pr.load(g)
+    g.solve()
+    with pytest.raises(capi.SolverError) as e:
+        g.covariance(int(pr.meta["lm_blocks"][0]), int(pr.meta["lm_blocks"][0]))
+    assert e.value.code == capi.ERR_UNSUPPORTED
+    kf = pr.meta["kf_blocks"]
+    c = g.covariance(int(kf[2, 1]), int(kf[2, 1]))     # the window has a prior on the first state: well posed
+    assert np.all(np.linalg.eigvalsh(0.5 * (c + c.T)) > 0)
+    # a gauge-free graph has a singular J^T J: loud numeric error, like ceres::Covariance::Compute returning false
+    pg = synthetic.pose_graph(n_pose=12, n_loop=10, seed=4)
+    assert pg.n_factors(capi.F_ABSPOSE) == 1
+    pg.factors.pop(capi.F_ABSPOSE)
+    g2 = gpu_solver_cls(0)
+    pg.load(g2)
+    with pytest.raises(capi.SolverError) as e2:
+        g2.covariance(0, 0)
+    assert e2.value.code == capi.ERR_NUMERIC
