@@ -28,7 +28,11 @@ using namespace bsg;
 namespace {
 
 struct TypeInfo { int nidx, nvar, nconst, m; int amb[10]; };
-const TypeInfo kTypes[BSGPU_F_NUM_TYPES] = {
+// internal group: reprojection factors whose landmark block is NOT eliminated (it also appears in another kind of
+// factor, e.g. a marginal prior): they are evaluated and assembled like the pose-only groups, slots (q, p, P)
+constexpr int T_REPROJ_DENSE = BSGPU_F_NUM_TYPES;
+constexpr int kNumInternal = BSGPU_F_NUM_TYPES + 1;
+const TypeInfo kTypes[kNumInternal] = {
     {4, 3, 3, 2, {4, 3, 3}},
     {6, 5, 3, 2, {4, 3, 3, 4, 3}},
     {10, 10, 287, 15, {4, 3, 3, 3, 3, 4, 3, 3, 3, 3}},
@@ -41,8 +45,9 @@ const TypeInfo kTypes[BSGPU_F_NUM_TYPES] = {
     {1, 1, 7, 2, {4}},
     {6, 5, 6, 2, {4, 3, 4, 3, 1}},
     {4, 3, 6, 2, {4, 3, 1}},
+    {4, 3, 3, 2, {4, 3, 3}},   // T_REPROJ_DENSE: idx q, p, P, (derived) camera; consts u, v, w
 };
-inline bool has_camera(int t) { return t <= 1 || t == BSGPU_F_IDP_REPROJ || t == BSGPU_F_IDP_REPROJ_UNARY; }
+inline bool has_camera(int t) { return t <= 1 || t == BSGPU_F_IDP_REPROJ || t == BSGPU_F_IDP_REPROJ_UNARY || t == T_REPROJ_DENSE; }
 
 std::string g_create_error;
 
@@ -66,7 +71,7 @@ struct bsgpu_ctx {
   std::vector<int32_t> off;
   std::vector<uint8_t> size, manifold, is_const;
   std::vector<bsgpu_camera> cams;
-  HostGroup groups[BSGPU_F_NUM_TYPES];
+  HostGroup groups[kNumInternal];
   bool finalized = false;
   // ---- derived structure
   std::vector<int> tsize, toff;
@@ -74,6 +79,8 @@ struct bsgpu_ctx {
   int n_pose = 0, n_lm = 0, n_tan = 0, npad = 0, n_res = 0;
   int row0[BSGPU_F_NUM_TYPES] = {0};
   std::vector<int> vis_src;      // sorted visual position -> (type<<28 | index in its host group)
+  std::vector<int> dense_src;    // T_REPROJ_DENSE factor -> (type<<28 | index in its host group)
+  std::vector<uint8_t> no_elim;  // per block: never Schur-eliminate (set by the marginalisation sub-problem)
   bool any_inactive = false;
   // ---- device
   std::vector<void*> allocs;
@@ -83,12 +90,12 @@ struct bsgpu_ctx {
   DevCamera* d_cams = nullptr;
   DevLoss* d_losses = nullptr;
   Visual vis;
-  SmallGroup small[BSGPU_F_NUM_TYPES];
-  std::vector<unsigned char> h_small_active[BSGPU_F_NUM_TYPES];
-  unsigned char* d_small_inactive[BSGPU_F_NUM_TYPES] = {nullptr};
-  double* d_small_part[BSGPU_F_NUM_TYPES] = {nullptr};       // per-factor cost at the current point
-  double* d_small_part_cand[BSGPU_F_NUM_TYPES] = {nullptr};  // ... at the candidate
-  double* d_small_part_mcc[BSGPU_F_NUM_TYPES] = {nullptr};   // per-row model-cost-change terms
+  SmallGroup small[kNumInternal];
+  std::vector<unsigned char> h_small_active[kNumInternal];
+  unsigned char* d_small_inactive[kNumInternal] = {nullptr};
+  double* d_small_part[kNumInternal] = {nullptr};       // per-factor cost at the current point
+  double* d_small_part_cand[kNumInternal] = {nullptr};  // ... at the candidate
+  double* d_small_part_mcc[kNumInternal] = {nullptr};   // per-row model-cost-change terms
   ReduceEntry* d_reduce = nullptr;
   int n_reduce = 0;
   double* d_part_upd = nullptr;
@@ -116,7 +123,7 @@ struct bsgpu_ctx {
   bool dense_ok = true, bsr_built = false, use_pcg = false;
   int nbr = 0, nblk = 0, pcg_iters_total = 0;
   int *d_row_ptr = nullptr, *d_col = nullptr, *d_diag_slot = nullptr;
-  int* d_slots[BSGPU_F_NUM_TYPES] = {nullptr};
+  int* d_slots[kNumInternal] = {nullptr};
   double *d_val = nullptr, *d_Minv = nullptr, *d_rhs = nullptr, *d_px = nullptr, *d_pr = nullptr, *d_pz = nullptr, *d_pp = nullptr,
          *d_pq = nullptr, *d_ppart = nullptr, *d_ppart2 = nullptr, *d_psc = nullptr;
 
@@ -201,7 +208,8 @@ int finalize(bsgpu_ctx* c) {
     if (c->manifold[b] == BSGPU_MANIFOLD_QUAT_RIGHT && c->size[b] != 4) return fail(c, BSGPU_ERR_INVALID, "quaternion block must have size 4");
     c->tsize[b] = (c->manifold[b] == BSGPU_MANIFOLD_QUAT_RIGHT) ? 3 : c->size[b];
     if (c->is_const[b]) continue;
-    if (lm_use[b] > 0 && other_use[b] == 0 && c->size[b] == 3 && c->manifold[b] == BSGPU_MANIFOLD_EUCLIDEAN) c->is_lm[b] = 1;
+    if (lm_use[b] > 0 && other_use[b] == 0 && c->size[b] == 3 && c->manifold[b] == BSGPU_MANIFOLD_EUCLIDEAN &&
+        !(b < (int)c->no_elim.size() && c->no_elim[b])) c->is_lm[b] = 1;
   }
   int to = 0;
   for (int b = 0; b < nb; ++b) if (!c->is_const[b] && !c->is_lm[b]) { c->toff[b] = to; to += c->tsize[b]; }
@@ -243,6 +251,8 @@ int finalize(bsgpu_ctx* c) {
   struct VF { int xq, xp, xl, bq, bp, meta_cam, loss, flags, lm, src; double u, v, w; };
   std::vector<VF> vf;
   c->any_inactive = false;
+  c->groups[T_REPROJ_DENSE] = HostGroup();
+  c->dense_src.clear();
   for (int t = 0; t <= 1; ++t) {
     const HostGroup& g = c->groups[t];
     const TypeInfo& ti = kTypes[t];
@@ -279,11 +289,18 @@ int finalize(bsgpu_ctx* c) {
                 (c->is_const[idx[2]] ? kFlagLConst : 0);
       if (e.flags == 7) c->any_inactive = true;
       e.lm = lm_index[idx[2]];
-      if (e.lm < 0 && !c->is_const[idx[2]]) {
-        // a landmark block that also appears in another factor slot is not eliminated; not supported yet
-        return fail(c, BSGPU_ERR_UNSUPPORTED, "landmark block shared with a non-reprojection factor");
-      }
       e.src = (t << 28) | f;
+      if (e.lm < 0 && !c->is_const[idx[2]]) {
+        // the landmark block is not eliminated (it is shared with another kind of factor): pose-only style group
+        HostGroup& dg = c->groups[T_REPROJ_DENSE];
+        const int32_t di[4] = {idx[0], idx[1], idx[2], cam};
+        dg.idx.insert(dg.idx.end(), di, di + 4);
+        dg.consts.insert(dg.consts.end(), &g.consts[(size_t)f * 3], &g.consts[(size_t)f * 3] + 3);
+        dg.loss_kind.push_back(g.loss_kind[f]); dg.loss_a.push_back(g.loss_a[f]);
+        dg.n++;
+        c->dense_src.push_back(e.src);
+        continue;
+      }
       e.u = g.consts[(size_t)f * 3]; e.v = g.consts[(size_t)f * 3 + 1]; e.w = g.consts[(size_t)f * 3 + 2];
       vf.push_back(e);
     }
@@ -374,7 +391,7 @@ int finalize(bsgpu_ctx* c) {
   }
   // ---- pose-only groups
   size_t part_max = std::max<size_t>(V.n_cost_part, 2 * ((size_t)nb + 255) / 256 + 2);
-  for (int t = 2; t < BSGPU_F_NUM_TYPES; ++t) {
+  for (int t = 2; t < kNumInternal; ++t) {
     const HostGroup& g = c->groups[t];
     const TypeInfo& ti = kTypes[t];
     SmallGroup& sg = c->small[t];
@@ -424,7 +441,7 @@ int finalize(bsgpu_ctx* c) {
   }
   if (losses.size() >= (1u << kMetaLossBits)) return fail(c, BSGPU_ERR_UNSUPPORTED, "too many distinct loss functions");
   c->d_cams = c->upload(cams);
-  for (int t = 2; t < BSGPU_F_NUM_TYPES; ++t) c->small[t].cams = c->d_cams;
+  for (int t = 2; t < kNumInternal; ++t) c->small[t].cams = c->d_cams;
   c->d_losses = c->upload(losses);
   // ---- blocks
   {
@@ -482,7 +499,7 @@ int finalize(bsgpu_ctx* c) {
       tab.push_back({c->vis.cost_part_cand, c->vis.n_cost_part, 1, 0, SC_COST_CAND});
       tab.push_back({c->vis.mcc_part, c->vis.n_cost_part, 1, 0, SC_MCC});
     }
-    for (int t = 2; t < BSGPU_F_NUM_TYPES; ++t) {
+    for (int t = 2; t < kNumInternal; ++t) {
       if (!c->small[t].n) continue;
       tab.push_back({c->d_small_part[t], c->small[t].n, 1, 0, SC_COST_X});
       tab.push_back({c->d_small_part_cand[t], c->small[t].n, 1, 0, SC_COST_CAND});
@@ -513,7 +530,7 @@ int build_bsr(bsgpu_ctx* c) {
   const int nbr = c->n_pose / 3;
   std::vector<uint64_t> keys;
   for (int b = 0; b < nbr; ++b) keys.push_back(((uint64_t)b << 32) | (uint32_t)b);
-  for (int t = 2; t < BSGPU_F_NUM_TYPES; ++t) {
+  for (int t = 2; t < kNumInternal; ++t) {
     const HostGroup& g = c->groups[t];
     const TypeInfo& ti = kTypes[t];
     for (int f = 0; f < g.n; ++f) {
@@ -536,7 +553,7 @@ int build_bsr(bsgpu_ctx* c) {
     if (r == cc) diag_slot[r] = i;
   }
   for (int r = 0; r < nbr; ++r) row_ptr[r + 1] += row_ptr[r];
-  for (int t = 2; t < BSGPU_F_NUM_TYPES; ++t) {
+  for (int t = 2; t < kNumInternal; ++t) {
     const HostGroup& g = c->groups[t];
     const TypeInfo& ti = kTypes[t];
     if (!g.n) continue;
@@ -571,7 +588,7 @@ void assemble_pcg(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_
   launch_zero(s, c->d_rhs, c->n_pose);
   launch_zero(s, c->d_grad, c->n_pose);
   launch_zero(s, c->d_hdiag, c->n_pose);
-  for (int t = 2; t < BSGPU_F_NUM_TYPES; ++t)
+  for (int t = 2; t < kNumInternal; ++t)
     launch_bsr_assemble(s, c->small[t], c->d_slots[t], c->d_val, c->d_rhs, c->d_grad, c->d_hdiag);
   launch_bsr_finish_diag(s, c->nbr, c->d_diag_slot, c->d_val, c->d_hdiag, radius, first ? 1 : 0, new_J ? 1 : 0, o.jacobi_scaling,
                          o.min_lm_diagonal, o.max_lm_diagonal, c->d_scale, c->d_dcl, c->d_Minv);
@@ -607,7 +624,7 @@ void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot) {
   hipStream_t s = c->stream;
   const bool cand = slot == SC_COST_CAND;
   if (c->vis.n) launch_reproj_eval(s, c->vis, x, c->d_cams, c->d_losses, with_J, cand ? c->vis.cost_part_cand : c->vis.cost_part);
-  for (int t = 2; t < BSGPU_F_NUM_TYPES; ++t)
+  for (int t = 2; t < kNumInternal; ++t)
     if (c->small[t].n) launch_small_eval(s, c->small[t], x, c->d_losses, with_J, cand ? c->d_small_part_cand[t] : c->d_small_part[t]);
 }
 void final_reduce(bsgpu_ctx* c) { launch_final_reduce(c->stream, c->d_reduce, c->n_reduce, SC_X_NORM2 + 1, c->d_scal); }
@@ -622,7 +639,7 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
   launch_landmark(s, c->vis, c->n_pose, c->d_scal + SC_RADIUS, first ? 1 : 0, new_J ? 1 : 0, o.jacobi_scaling, o.min_lm_diagonal,
                   o.max_lm_diagonal, c->d_scale, c->d_dcl, c->d_grad);
   launch_pairs(s, c->vis, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm);
-  for (int t = 2; t < BSGPU_F_NUM_TYPES; ++t)
+  for (int t = 2; t < kNumInternal; ++t)
     launch_small_assemble(s, c->small[t], c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm);
   launch_pose_diag(s, c->n_pose, c->d_S, c->npad, c->d_hdiag, c->d_scal + SC_RADIUS, first ? 1 : 0, new_J ? 1 : 0, o.jacobi_scaling,
                    o.min_lm_diagonal, o.max_lm_diagonal, c->d_scale, c->d_dcl, c->npad, c->d_iperm);
@@ -679,7 +696,7 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
   launch_backsub_landmarks(s, c->vis, c->n_pose, c->d_ytan, c->d_delta);
   // model cost change terms, candidate point and its cost: partial arrays only, summed once at the end
   if (c->vis.n) launch_mcc(s, c->vis, c->n_pose, c->d_delta, c->vis.mcc_part);
-  for (int t = 2; t < BSGPU_F_NUM_TYPES; ++t)
+  for (int t = 2; t < kNumInternal; ++t)
     if (c->small[t].n) launch_small_mcc(s, c->small[t], c->d_delta, c->d_small_part_mcc[t]);
   int n_part = 0;
   launch_update(s, c->nb, c->d_blk_xoff, c->d_blk_toff, c->d_blk_size, c->d_blk_manifold, c->d_x, c->d_delta, c->d_xcand,
@@ -776,7 +793,7 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
   if (c->any_inactive) {
     // cost of residual blocks whose parameter blocks are all constant (Ceres: fixed_cost)
     launch_zero(s, c->d_scal + SC_FIXED_COST, 1);
-    for (int t = 2; t < BSGPU_F_NUM_TYPES; ++t) {
+    for (int t = 2; t < kNumInternal; ++t) {
       if (!c->small[t].n) continue;
       SmallGroup g = c->small[t];
       g.active = c->d_small_inactive[t];
@@ -944,6 +961,7 @@ int bsgpu_clear(bsgpu_ctx* c) {
   c->nb = 0; c->h_x.clear(); c->off.clear(); c->size.clear(); c->manifold.clear(); c->is_const.clear();
   c->cams.clear();
   for (auto& g : c->groups) g = HostGroup();
+  c->no_elim.clear();
   c->finalized = false;
   c->iters.clear();
   return BSGPU_OK;
@@ -1034,7 +1052,7 @@ int bsgpu_evaluate(bsgpu_ctx* c, double* cost, double* residuals, double* gradie
   double fixed = 0.0;
   if (c->any_inactive) {
     launch_zero(s, c->d_scal + SC_FIXED_COST, 1);
-    for (int t = 2; t < BSGPU_F_NUM_TYPES; ++t) {
+    for (int t = 2; t < kNumInternal; ++t) {
       if (!c->small[t].n) continue;
       SmallGroup g = c->small[t];
       g.active = c->d_small_inactive[t];
@@ -1080,7 +1098,7 @@ int bsgpu_evaluate(bsgpu_ctx* c, double* cost, double* residuals, double* gradie
       }
     }
   }
-  for (int t = 2; t < BSGPU_F_NUM_TYPES; ++t) {
+  for (int t = 2; t < kNumInternal; ++t) {
     const SmallGroup& g = c->small[t];
     if (!g.n) continue;
     const int mm = g.m, tw = 3 * g.nv;
@@ -1091,7 +1109,8 @@ int bsgpu_evaluate(bsgpu_ctx* c, double* cost, double* residuals, double* gradie
     HIPCHK(c, hipMemcpy(toff.data(), g.toff, sizeof(int) * toff.size(), hipMemcpyDeviceToHost));
     for (int f = 0; f < g.n; ++f)
       for (int k = 0; k < mm; ++k) {
-        const int row = c->row0[t] + f * mm + k;
+        const int row = (t == T_REPROJ_DENSE) ? c->row0[c->dense_src[f] >> 28] + 2 * (c->dense_src[f] & ((1 << 28) - 1)) + k
+                                              : c->row0[t] + f * mm + k;
         if (residuals) residuals[row] = r[(size_t)f * mm + k];
         for (int sl = 0; sl < g.nv; ++sl) {
           const int tc = toff[(size_t)f * g.nv + sl];

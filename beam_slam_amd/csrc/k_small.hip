@@ -626,6 +626,61 @@ __global__ __launch_bounds__(128) void idp_kernel(SmallGroup g, const double* __
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Euclidean reprojection with a landmark block that is NOT eliminated (slots q, p, P; J 2 x 9 like the
+// visual tables of k_reproj.hip, same closed form: euclidean_reprojection_function.h:66-172)
+// ---------------------------------------------------------------------------------------------------
+template <bool WITH_J>
+__global__ __launch_bounds__(128) void reproj_dense_kernel(SmallGroup g, const double* __restrict__ x,
+                                                           const DevLoss* __restrict__ losses,
+                                                           double* __restrict__ cost_part) {
+  const int f = blockIdx.x * 128 + threadIdx.x;
+  if (f >= g.n) return;
+  const int* xo = g.xoff + (size_t)f * 3;
+  const int* to = g.toff + (size_t)f * 3;
+  const double* k = g.consts + (size_t)f * 3;
+  const DevCamera cam = g.cams[g.cam[f]];
+  const double q[4] = {x[xo[0]], x[xo[0] + 1], x[xo[0] + 2], x[xo[0] + 3]};
+  const double t[3] = {x[xo[1]], x[xo[1] + 1], x[xo[1] + 2]};
+  const double P[3] = {x[xo[2]], x[xo[2] + 1], x[xo[2] + 2]};
+  double R[9], a[3], b[3], Pc[3];
+  quat_to_rot(q, R);
+  mat3t_vec(R, P, a);
+  mat3t_vec(R, t, b);
+  const double Pb[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]};
+  mat3_vec(cam.R, Pb, Pc);
+  Pc[0] += cam.t[0]; Pc[1] += cam.t[1]; Pc[2] += cam.t[2];
+  const double iz = 1.0 / Pc[2], w = k[2];
+  const double r0 = w * (k[0] - (cam.fx * Pc[0] + cam.cx * Pc[2]) * iz), r1 = w * (k[1] - (cam.fy * Pc[1] + cam.cy * Pc[2]) * iz);
+  double sc, cost;
+  finish_small(g, f, losses, r0 * r0 + r1 * r1, &sc, &cost);
+  cost_part[f] = cost;
+  if (!WITH_J) return;
+  g.r[(size_t)f * 2] = r0 * sc; g.r[(size_t)f * 2 + 1] = r1 * sc;
+  const double jx0 = cam.fx * iz, jx2 = -cam.fx * Pc[0] * iz * iz, jy1 = cam.fy * iz, jy2 = -cam.fy * Pc[1] * iz * iz;
+  const double ws = w * sc;
+  double M[6];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    M[j] = ws * (jx0 * cam.R[j] + jx2 * cam.R[6 + j]);
+    M[3 + j] = ws * (jy1 * cam.R[3 + j] + jy2 * cam.R[6 + j]);
+  }
+  double* Jo = g.J + (size_t)f * 18;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const double m0 = M[3 * i], m1 = M[3 * i + 1], m2 = M[3 * i + 2];
+    Jo[9 * i + 0] = to[0] < 0 ? 0.0 : -(m1 * Pb[2] - m2 * Pb[1]);
+    Jo[9 * i + 1] = to[0] < 0 ? 0.0 : -(m2 * Pb[0] - m0 * Pb[2]);
+    Jo[9 * i + 2] = to[0] < 0 ? 0.0 : -(m0 * Pb[1] - m1 * Pb[0]);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const double mr = m0 * R[3 * j] + m1 * R[3 * j + 1] + m2 * R[3 * j + 2];
+      Jo[9 * i + 3 + j] = to[1] < 0 ? 0.0 : mr;
+      Jo[9 * i + 6 + j] = to[2] < 0 ? 0.0 : -mr;
+    }
+  }
+}
+
 void launch_small_eval(hipStream_t s, const SmallGroup& g, const double* x, const DevLoss* losses, bool with_J,
                        double* cost_part) {
   if (g.n == 0) return;
@@ -647,6 +702,7 @@ void launch_small_eval(hipStream_t s, const SmallGroup& g, const double* x, cons
     case BSGPU_F_GRAVITY: BSG_LAUNCH(gravity_kernel, g128, 128); break;
     case BSGPU_F_IDP_REPROJ: BSG_LAUNCH2(idp_kernel, false, g128, 128); break;
     case BSGPU_F_IDP_REPROJ_UNARY: BSG_LAUNCH2(idp_kernel, true, g128, 128); break;
+    case BSGPU_F_NUM_TYPES /* internal: reprojection with a non-eliminated landmark */: BSG_LAUNCH(reproj_dense_kernel, g128, 128); break;
     default: break;
   }
 #undef BSG_LAUNCH

@@ -490,6 +490,16 @@ static int finalize(Ctx& c) {
     Group& g1 = c.groups[1];
     for (int f = 0; f < g1.n; ++f)
       if (!c.is_const[g1.idx[(size_t)f * 6 + 3]] || !c.is_const[g1.idx[(size_t)f * 6 + 4]]) c.owner_parallel_ok = false;
+    // a landmark block that is not eliminated (shared with another kind of factor) is a pose-side row written by
+    // several owners
+    for (int t = 0; t < 2; ++t) {
+      Group& g = c.groups[t];
+      const TypeInfo& ti = kTypes[t];
+      for (int f = 0; f < g.n; ++f) {
+        const int b = g.idx[(size_t)f * ti.nidx + 2];
+        if (!c.is_const[b] && !c.is_lm[b]) c.owner_parallel_ok = false;
+      }
+    }
   }
   c.finalized = true;
   return BSGPU_OK;
@@ -656,7 +666,8 @@ static bool solve_normal(Ctx& c, const double* D2, double* y, LinSys& ls) {
     const int32_t* idx = &g.idx[(size_t)f * ti.nidx];
     int n = 0, ct = 0;
     for (int sl = 0; sl < ti.nvar; ++sl) {
-      if (sl != 2) { cols[n] = c.toff[idx[sl]]; jc[n] = ct; ++n; }
+      // slot 2 (the landmark) counts as a pose-side slot when its block is not eliminated
+      if (sl != 2 || (c.toff[idx[2]] >= 0 && c.toff[idx[2]] < c.n_pose)) { cols[n] = c.toff[idx[sl]]; jc[n] = ct; ++n; }
       ct += 3;
     }
     return n;
@@ -671,7 +682,7 @@ static bool solve_normal(Ctx& c, const double* D2, double* y, LinSys& ls) {
       const int tw = g.tw;
       const double* J = &g.J[(size_t)f * 2 * tw];
       const double* r = &g.r[(size_t)f * 2];
-      int cols[4], jc[4];
+      int cols[5], jc[5];
       const int ns = pose_cols_of(t, f, cols, jc);
       // J_p^T J_p and J_p^T r
       for (int sa = 0; sa < ns; ++sa) {
@@ -692,7 +703,7 @@ static bool solve_normal(Ctx& c, const double* D2, double* y, LinSys& ls) {
       if (l < 0) continue;  // constant landmark: no elimination
       // W = Hpl Hll^-1, Hpl(3ns x 3) = J_p^T J_l
       const double* Hi = &ls.Hll_inv[(size_t)l * 9];
-      double W[12][3];
+      double W[15][3];
       for (int sa = 0; sa < ns; ++sa)
         for (int ia = 0; ia < 3; ++ia) {
           const int ca = jc[sa] + ia;
@@ -713,7 +724,7 @@ static bool solve_normal(Ctx& c, const double* D2, double* y, LinSys& ls) {
         Group& g2 = c.groups[t2];
         const int tw2 = g2.tw;
         const double* J2 = &g2.J[(size_t)f2 * 2 * tw2];
-        int cols2[4], jc2[4];
+        int cols2[5], jc2[5];
         const int ns2 = pose_cols_of(t2, f2, cols2, jc2);
         for (int sb = 0; sb < ns2; ++sb) {
           if (cols2[sb] < 0) continue;
@@ -747,7 +758,7 @@ static bool solve_normal(Ctx& c, const double* D2, double* y, LinSys& ls) {
       Group& g = c.groups[t];
       const int tw = g.tw;
       const double* J = &g.J[(size_t)f * 2 * tw];
-      int cols[4], jc[4];
+      int cols[5], jc[5];
       const int ns = pose_cols_of(t, f, cols, jc);
       // (J_p y_p) then J_l^T (.)
       double jy[2] = {0, 0};

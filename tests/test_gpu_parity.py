@@ -278,3 +278,32 @@ def test_covariance_errors(gpu_solver_cls):
     with pytest.raises(capi.SolverError) as e2:
         g2.covariance(0, 0)
     assert e2.value.code == capi.ERR_NUMERIC
+
+
+@pytest.mark.parametrize("online_calib", [False, True])
+def test_landmark_blocks_shared_with_other_factors(oracle_cls, gpu_solver_cls, online_calib):
+    """A landmark block that also appears in a non-reprojection factor (here a position prior; after true
+    marginalisation: the dense marginal prior) is not Schur-eliminated: its reprojection factors take the
+    pose-only route.  Same variable index, Jacobian and LM trajectory as the oracle."""
+    pr = mixed_problem(9, n_state=4, n_lm=16, consistent=True)
+    lms = [int(b) for b in pr.meta["landmarks"][:6]]
+    for b in lms:
+        A = synthetic.sqrt_information_upper(0.01 * np.eye(3))
+        pr.add_factors(capi.F_ABS_VEC3, [[b]], [np.concatenate([pr.block(b) + 0.02, A.ravel()])])
+    if not online_calib:
+        pr.factors.pop(capi.F_REPROJ_ONLINE_CALIB, None)
+    g, o = _pair(pr, oracle_cls, gpu_solver_cls)
+    assert [g.tangent_offset(b) for b in range(pr.n_blocks)] == [o.tangent_offset(b) for b in range(pr.n_blocks)]
+    cg, rg, gg, Jg = g.evaluate(jacobian=True)
+    co, ro, go, Jo = o.evaluate(jacobian=True)
+    assert np.abs(rg - ro).max() <= 1e-9 * max(1.0, np.abs(ro).max())
+    assert np.abs(Jg - Jo).max() <= 1e-9 * max(1.0, np.abs(Jo).max())
+    assert abs(cg - co) <= 1e-12 * abs(co)
+    assert np.abs(gg - go).max() <= 1e-9 * max(1.0, np.abs(go).max())
+    sg, so = g.solve(), o.solve()
+    ig, io = g.iterations(), o.iterations()
+    assert [i.step_is_successful for i in ig] == [i.step_is_successful for i in io]
+    for a, b in zip(ig, io):
+        assert abs(a.cost - b.cost) <= 1e-8 * abs(b.cost)
+    assert abs(sg.final_cost - so.final_cost) <= 1e-6 * so.final_cost
+    assert np.abs(g.get_blocks() - o.get_blocks()).max() < 1e-7

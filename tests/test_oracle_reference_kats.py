@@ -192,14 +192,22 @@ def test_kat5_two_node_pose_graph_returns_to_truth(oracle_cls, seed):
 
 
 # --- independent optimiser: scipy on the same residual function ------------------------------------
-def test_oracle_optimum_matches_scipy(oracle_cls):
+@pytest.mark.parametrize("landmark_priors", [0, 5])
+def test_oracle_optimum_matches_scipy(oracle_cls, landmark_priors):
     """scipy.optimize.least_squares (trf, 2-point... with the oracle's Jacobian) reaches the same optimum
-    and final cost as the oracle's Ceres-style LM on a small visual-inertial window."""
+    and final cost as the oracle's Ceres-style LM on a small visual-inertial window.  With landmark_priors > 0 some
+    landmark blocks also carry a position prior, so they are NOT Schur-eliminated (they stay in the reduced system)."""
     pr = synthetic.vio_window(n_kf=4, n_lm=30, seed=3, track_min=2, track_max=4, cauchy_a=None)  # trivial loss: scipy minimises 1/2 |r|^2
+    for b in pr.meta["lm_blocks"][:landmark_priors]:
+        A = sqrt_information_upper(0.04 * np.eye(3))
+        pr.add_factors(capi.F_ABS_VEC3, [[int(b)]], [np.concatenate([pr.block(int(b)) + 0.05, A.ravel()])])
     o = oracle_cls()
     pr.load(o)
     n = o.num_parameters_tangent() if o.finalize() is None else 0
     x0 = pr.values.copy()
+    if landmark_priors:   # shared landmark blocks sit on the pose side of the variable index
+        n_pose = min(o.tangent_offset(int(b)) for b in pr.meta["lm_blocks"][landmark_priors:])
+        assert all(o.tangent_offset(int(b)) < n_pose for b in pr.meta["lm_blocks"][:landmark_priors])
 
     def fun(delta):
         o.set_values(manifold_plus(pr, x0, delta, o.tangent_offset))
