@@ -106,9 +106,9 @@ class Camera(C.Structure):
 #: every symbol include/bsgpu.h declares (without prefix); tests check the library exports them all
 SYMBOLS = [
     "nidx", "nconst", "nres", "options_default", "options_vio", "create", "create_error", "destroy",
-    "last_error", "abi_version", "clear", "set_blocks", "set_values", "set_cameras", "add_factors",
+    "last_error", "abi_version", "clear", "set_blocks", "set_values", "set_cameras", "add_factors", "add_marginal",
     "finalize", "solve", "get_blocks", "reset_values", "num_iterations_recorded", "get_iteration",
-    "evaluate", "num_residuals", "num_parameters_tangent", "tangent_offset", "covariance",
+    "evaluate", "num_residuals", "num_parameters_tangent", "tangent_offset", "covariance", "marginalize", "get_marginal",
     "time_reproj_jacobian_ms", "reproj_jacobian_bytes", "dense_solve", "plan_info",
 ]
 
@@ -142,6 +142,9 @@ class Solver:
         f("set_values").argtypes = [C.c_void_p, _dp, C.c_int64]
         f("set_cameras").argtypes = [C.c_void_p, C.c_int32, C.POINTER(Camera)]
         f("add_factors").argtypes = [C.c_void_p, C.c_int32, C.c_int32, _ip, _dp, _ip, _dp]
+        f("add_marginal").argtypes = [C.c_void_p, C.c_int32, _ip, C.c_int32, _dp, _dp, _dp]
+        f("marginalize").argtypes = [C.c_void_p, C.c_int32, _ip, _ip, _ip, _ip]
+        f("get_marginal").argtypes = [C.c_void_p, _ip, _dp, _dp, _dp]
         f("finalize").argtypes = [C.c_void_p]
         f("clear").argtypes = [C.c_void_p]
         f("solve").argtypes = [C.c_void_p, C.POINTER(Options), C.POINTER(Summary)]
@@ -229,6 +232,29 @@ class Solver:
             loss_a = np.ascontiguousarray(np.broadcast_to(loss_a, (n,)), np.float64)
         self._chk(self._f("add_factors")(self._ctx, ftype, n, _ptr(block_idx, _ip), _ptr(consts, _dp),
                                          _ptr(loss_kind, _ip), _ptr(loss_a, _dp)))
+
+    def add_marginal(self, blocks, A, b, xbar):
+        """fuse_constraints::MarginalConstraint: r = b + sum_i A_i (x_i [-] xbar_i)."""
+        blocks = np.ascontiguousarray(blocks, np.int32)
+        A = np.ascontiguousarray(np.atleast_2d(A), np.float64)
+        b = np.ascontiguousarray(b, np.float64)
+        xbar = np.ascontiguousarray(xbar, np.float64)
+        assert A.shape[0] == b.size
+        self._chk(self._f("add_marginal")(self._ctx, blocks.size, _ptr(blocks, _ip), A.shape[0], _ptr(A, _dp), _ptr(b, _dp),
+                                          _ptr(xbar, _dp)))
+
+    def marginalize(self, blocks, sizes):
+        """fuse_constraints::marginalizeVariables at the current values: returns (kept_blocks, A, b, xbar), the payload
+        of the MarginalConstraint that replaces every factor touching `blocks`.  `sizes` = ambient block sizes."""
+        blocks = np.ascontiguousarray(blocks, np.int32)
+        nk, nr, nc = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        self._chk(self._f("marginalize")(self._ctx, blocks.size, _ptr(blocks, _ip), C.byref(nk), C.byref(nr), C.byref(nc)))
+        kept = np.zeros(nk.value, np.int32)
+        self._chk(self._f("get_marginal")(self._ctx, _ptr(kept, _ip), None, None, None))
+        A = np.zeros((nr.value, nc.value)); b = np.zeros(nr.value)
+        xbar = np.zeros(int(sum(sizes[k] for k in kept)))
+        self._chk(self._f("get_marginal")(self._ctx, _ptr(kept, _ip), _ptr(A, _dp), _ptr(b, _dp), _ptr(xbar, _dp)))
+        return kept, A, b, xbar
 
     def finalize(self):
         self._chk(self._f("finalize")(self._ctx))

@@ -51,6 +51,12 @@ inline bool has_camera(int t) { return t <= 1 || t == BSGPU_F_IDP_REPROJ || t ==
 
 std::string g_create_error;
 
+struct HostMarginal {
+  std::vector<int32_t> blocks;
+  int rows = 0, cols = 0;
+  std::vector<double> A, b, xbar;
+};
+
 struct HostGroup {
   int n = 0;
   std::vector<int32_t> idx;
@@ -79,6 +85,10 @@ struct bsgpu_ctx {
   int n_pose = 0, n_lm = 0, n_tan = 0, npad = 0, n_res = 0;
   int row0[BSGPU_F_NUM_TYPES] = {0};
   std::vector<int> vis_src;      // sorted visual position -> (type<<28 | index in its host group)
+  std::vector<HostMarginal> marginals;
+  struct MargCtx { MargDev dev; int row0 = 0; bool active = true; double *part = nullptr, *part_cand = nullptr, *part_mcc = nullptr; };
+  std::vector<MargCtx> marg;
+  struct MargResult { std::vector<int32_t> kept; int rows = 0, cols = 0; std::vector<double> A, b, xbar; bool valid = false; } marg_result;
   std::vector<int> dense_src;    // T_REPROJ_DENSE factor -> (type<<28 | index in its host group)
   std::vector<uint8_t> no_elim;  // per block: never Schur-eliminate (set by the marginalisation sub-problem)
   bool any_inactive = false;
@@ -202,6 +212,11 @@ int finalize(bsgpu_ctx* c) {
       }
     }
   }
+  for (const HostMarginal& mg : c->marginals)
+    for (int b : mg.blocks) {
+      if (b < 0 || b >= nb) return fail(c, BSGPU_ERR_INVALID, "marginal factor references block out of range");
+      other_use[b]++;
+    }
   c->tsize.assign(nb, 0); c->toff.assign(nb, -1); c->is_lm.assign(nb, 0);
   for (int b = 0; b < nb; ++b) {
     if (c->size[b] > 4 || c->size[b] == 0) return fail(c, BSGPU_ERR_UNSUPPORTED, "block sizes 1..4 only");
@@ -222,6 +237,7 @@ int finalize(bsgpu_ctx* c) {
   c->dense_ok = (size_t)c->npad <= 12288;   // above: block-sparse PCG path only (pose-only problems)
   int row = 0;
   for (int t = 0; t < BSGPU_F_NUM_TYPES; ++t) { c->row0[t] = row; row += c->groups[t].n * kTypes[t].m; }
+  for (const HostMarginal& mg : c->marginals) row += mg.rows;
   c->n_res = row;
 
   // ---- loss table
@@ -439,6 +455,44 @@ int finalize(bsgpu_ctx* c) {
     c->d_small_part_mcc[t] = c->alloc<double>((size_t)g.n * ti.m);
     part_max = std::max(part_max, (size_t)g.n * ti.m);
   }
+  // ---- dense linear priors (marginal factors)
+  c->marg.clear();
+  {
+    int mrow = 0;
+    for (int t = 0; t < BSGPU_F_NUM_TYPES; ++t) mrow += c->groups[t].n * kTypes[t].m;
+    const int T = (c->n_pose + 63) / 64;
+    for (const HostMarginal& mg : c->marginals) {
+      bsgpu_ctx::MargCtx mc;
+      std::vector<int> bx, bs, bq, bc, ba, col_t, col_blk;
+      int cols = 0, amb = 0;
+      mc.active = false;
+      for (size_t i = 0; i < mg.blocks.size(); ++i) {
+        const int b = mg.blocks[i];
+        bx.push_back(c->off[b]); bs.push_back(c->size[b]); bq.push_back(c->manifold[b] == BSGPU_MANIFOLD_QUAT_RIGHT ? 1 : 0);
+        bc.push_back(cols); ba.push_back(amb);
+        for (int k = 0; k < c->tsize[b]; ++k) { col_t.push_back(c->is_const[b] ? -1 : c->toff[b] + k); col_blk.push_back((int)i); }
+        cols += c->tsize[b]; amb += c->size[b];
+        if (!c->is_const[b]) mc.active = true;
+      }
+      if (cols != mg.cols || amb != (int)mg.xbar.size()) return fail(c, BSGPU_ERR_INVALID, "marginal factor: A / xbar sizes do not match its blocks");
+      for (int t : col_t) if (t >= c->n_pose) return fail(c, BSGPU_ERR_UNSUPPORTED, "internal: eliminated block in a marginal factor");
+      if (!mc.active) c->any_inactive = true;
+      MargDev& d = mc.dev;
+      d.rows = mg.rows; d.cols = cols; d.nblk = (int)mg.blocks.size();
+      d.blk_xoff = c->upload(bx); d.blk_size = c->upload(bs); d.blk_quat = c->upload(bq); d.blk_col = c->upload(bc); d.blk_amb = c->upload(ba);
+      d.col_t = c->upload(col_t); d.col_blk = c->upload(col_blk);
+      d.A = c->upload(mg.A); d.b = c->upload(mg.b); d.xbar = c->upload(mg.xbar);
+      d.delta = c->alloc<double>(cols); d.D = c->alloc<double>((size_t)d.nblk);
+      d.r = c->alloc<double>(mg.rows); d.J = c->alloc<double>((size_t)mg.rows * cols);
+      mc.part = c->alloc<double>(mg.rows); mc.part_cand = c->alloc<double>(mg.rows); mc.part_mcc = c->alloc<double>(mg.rows);
+      if (!d.J || !mc.part_mcc) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (marginal factor)");
+      mc.row0 = mrow; mrow += mg.rows;
+      part_max = std::max(part_max, (size_t)mg.rows);
+      if (mc.active)   // a dense prior couples every pair of its blocks
+        for (int ta : col_t) for (int tb : col_t) if (ta >= 0 && tb >= 0) c->tile_adj[(size_t)(ta / 64) * T + tb / 64] = 1;
+      c->marg.push_back(mc);
+    }
+  }
   if (losses.size() >= (1u << kMetaLossBits)) return fail(c, BSGPU_ERR_UNSUPPORTED, "too many distinct loss functions");
   c->d_cams = c->upload(cams);
   for (int t = 2; t < kNumInternal; ++t) c->small[t].cams = c->d_cams;
@@ -505,6 +559,12 @@ int finalize(bsgpu_ctx* c) {
       tab.push_back({c->d_small_part_cand[t], c->small[t].n, 1, 0, SC_COST_CAND});
       tab.push_back({c->d_small_part_mcc[t], c->small[t].n * c->small[t].m, 1, 0, SC_MCC});
     }
+    for (const auto& mc : c->marg) {
+      if (!mc.active) continue;
+      tab.push_back({mc.part, mc.dev.rows, 1, 0, SC_COST_X});
+      tab.push_back({mc.part_cand, mc.dev.rows, 1, 0, SC_COST_CAND});
+      tab.push_back({mc.part_mcc, mc.dev.rows, 1, 0, SC_MCC});
+    }
     tab.push_back({c->d_part_upd, c->n_part_upd, 2, 0, SC_STEP_NORM2});
     tab.push_back({c->d_part_upd, c->n_part_upd, 2, 1, SC_X_NORM2});
     c->n_reduce = (int)tab.size();
@@ -525,6 +585,7 @@ int finalize(bsgpu_ctx* c) {
 int build_bsr(bsgpu_ctx* c) {
   if (c->bsr_built) return BSGPU_OK;
   if (c->vis.n > 0) return fail(c, BSGPU_ERR_UNSUPPORTED, "PCG path covers pose-only problems; landmark problems use the Schur + dense path");
+  if (!c->marginals.empty()) return fail(c, BSGPU_ERR_UNSUPPORTED, "PCG path does not take dense marginal factors");
   for (int b = 0; b < c->nb; ++b)
     if (!c->is_const[b] && c->tsize[b] != 3) return fail(c, BSGPU_ERR_UNSUPPORTED, "PCG path needs 3-dimensional tangent blocks");
   const int nbr = c->n_pose / 3;
@@ -626,6 +687,8 @@ void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot) {
   if (c->vis.n) launch_reproj_eval(s, c->vis, x, c->d_cams, c->d_losses, with_J, cand ? c->vis.cost_part_cand : c->vis.cost_part);
   for (int t = 2; t < kNumInternal; ++t)
     if (c->small[t].n) launch_small_eval(s, c->small[t], x, c->d_losses, with_J, cand ? c->d_small_part_cand[t] : c->d_small_part[t]);
+  for (const auto& mc : c->marg)
+    if (mc.active) launch_marg_eval(s, mc.dev, x, with_J, cand ? mc.part_cand : mc.part);
 }
 void final_reduce(bsgpu_ctx* c) { launch_final_reduce(c->stream, c->d_reduce, c->n_reduce, SC_X_NORM2 + 1, c->d_scal); }
 
@@ -641,6 +704,8 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
   launch_pairs(s, c->vis, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm);
   for (int t = 2; t < kNumInternal; ++t)
     launch_small_assemble(s, c->small[t], c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm);
+  for (const auto& mc : c->marg)
+    if (mc.active) launch_marg_assemble(s, mc.dev, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm);
   launch_pose_diag(s, c->n_pose, c->d_S, c->npad, c->d_hdiag, c->d_scal + SC_RADIUS, first ? 1 : 0, new_J ? 1 : 0, o.jacobi_scaling,
                    o.min_lm_diagonal, o.max_lm_diagonal, c->d_scale, c->d_dcl, c->npad, c->d_iperm);
   if (new_J) {
@@ -698,6 +763,8 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
   if (c->vis.n) launch_mcc(s, c->vis, c->n_pose, c->d_delta, c->vis.mcc_part);
   for (int t = 2; t < kNumInternal; ++t)
     if (c->small[t].n) launch_small_mcc(s, c->small[t], c->d_delta, c->d_small_part_mcc[t]);
+  for (const auto& mc : c->marg)
+    if (mc.active) launch_marg_mcc(s, mc.dev, c->d_delta, mc.part_mcc);
   int n_part = 0;
   launch_update(s, c->nb, c->d_blk_xoff, c->d_blk_toff, c->d_blk_size, c->d_blk_manifold, c->d_x, c->d_delta, c->d_xcand,
                 c->d_part_upd, &n_part);
@@ -799,6 +866,11 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
       g.active = c->d_small_inactive[t];
       launch_small_eval(s, g, c->d_x, c->d_losses, false, c->d_small_part[t]);
       launch_sum(s, c->d_small_part[t], g.n, c->d_scal + SC_FIXED_COST, 1);
+    }
+    for (const auto& mc : c->marg) {
+      if (mc.active) continue;
+      launch_marg_eval(s, mc.dev, c->d_x, false, mc.part);
+      launch_sum(s, mc.part, mc.dev.rows, c->d_scal + SC_FIXED_COST, 1);
     }
     // (visual factors with q, p and landmark all constant are not counted: they cannot occur in a
     //  fixed-lag window — noted in DESIGN.md)
@@ -961,6 +1033,7 @@ int bsgpu_clear(bsgpu_ctx* c) {
   c->nb = 0; c->h_x.clear(); c->off.clear(); c->size.clear(); c->manifold.clear(); c->is_const.clear();
   c->cams.clear();
   for (auto& g : c->groups) g = HostGroup();
+  c->marginals.clear();
   c->no_elim.clear();
   c->finalized = false;
   c->iters.clear();
@@ -1013,6 +1086,24 @@ int bsgpu_add_factors(bsgpu_ctx* c, int32_t type, int32_t n, const int32_t* idx,
   c->finalized = false;
   return BSGPU_OK;
 }
+int bsgpu_add_marginal(bsgpu_ctx* c, int32_t n_blocks, const int32_t* blocks, int32_t n_rows, const double* A, const double* b,
+                       const double* xbar) {
+  if (n_blocks <= 0 || n_rows <= 0 || !blocks || !A || !b || !xbar) return fail(c, BSGPU_ERR_INVALID, "add_marginal: bad arguments");
+  HostMarginal mg;
+  mg.blocks.assign(blocks, blocks + n_blocks);
+  int cols = 0, amb = 0;
+  for (int i = 0; i < n_blocks; ++i) {
+    const int bl = blocks[i];
+    if (bl < 0 || bl >= c->nb) return fail(c, BSGPU_ERR_INVALID, "add_marginal: block out of range (set_blocks first)");
+    cols += (c->manifold[bl] == BSGPU_MANIFOLD_QUAT_RIGHT) ? 3 : c->size[bl];
+    amb += c->size[bl];
+  }
+  mg.rows = n_rows; mg.cols = cols;
+  mg.A.assign(A, A + (size_t)n_rows * cols); mg.b.assign(b, b + n_rows); mg.xbar.assign(xbar, xbar + amb);
+  c->marginals.push_back(std::move(mg));
+  c->finalized = false;
+  return BSGPU_OK;
+}
 int bsgpu_finalize(bsgpu_ctx* c) { return finalize(c); }
 int bsgpu_solve(bsgpu_ctx* c, const bsgpu_options* o, bsgpu_summary* s) {
   if (!o || !s) return fail(c, BSGPU_ERR_INVALID, "solve: null argument");
@@ -1058,6 +1149,11 @@ int bsgpu_evaluate(bsgpu_ctx* c, double* cost, double* residuals, double* gradie
       g.active = c->d_small_inactive[t];
       launch_small_eval(s, g, c->d_x, c->d_losses, false, c->d_small_part[t]);
       launch_sum(s, c->d_small_part[t], g.n, c->d_scal + SC_FIXED_COST, 1);
+    }
+    for (const auto& mc : c->marg) {
+      if (mc.active) continue;
+      launch_marg_eval(s, mc.dev, c->d_x, false, mc.part);
+      launch_sum(s, mc.part, mc.dev.rows, c->d_scal + SC_FIXED_COST, 1);
     }
   }
   eval_all(c, c->d_x, true, SC_COST_X);
@@ -1123,7 +1219,167 @@ int bsgpu_evaluate(bsgpu_ctx* c, double* cost, double* residuals, double* gradie
         }
       }
   }
+  for (const auto& mc : c->marg) {
+    const MargDev& d = mc.dev;
+    std::vector<double> r(d.rows), J((size_t)d.rows * d.cols);
+    std::vector<int> col_t(d.cols);
+    if (!mc.active) {   // evaluated only in the fixed-cost pass: fill r / J now
+      launch_marg_eval(s, d, c->d_x, true, mc.part);
+      HIPCHK(c, hipStreamSynchronize(s));
+    }
+    HIPCHK(c, hipMemcpy(r.data(), d.r, sizeof(double) * r.size(), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(J.data(), d.J, sizeof(double) * J.size(), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(col_t.data(), d.col_t, sizeof(int) * col_t.size(), hipMemcpyDeviceToHost));
+    for (int k = 0; k < d.rows; ++k) {
+      if (residuals) residuals[mc.row0 + k] = r[k];
+      for (int a = 0; a < d.cols; ++a) {
+        if (col_t[a] < 0) continue;
+        const double v = J[(size_t)k * d.cols + a];
+        grad[col_t[a]] += v * r[k];
+        if (jacobian) jacobian[(size_t)(mc.row0 + k) * n + col_t[a]] = v;
+      }
+    }
+  }
   if (gradient) std::memcpy(gradient, grad.data(), sizeof(double) * n);
+  return BSGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// [EXT] fuse_constraints::marginalizeVariables on the device.  The factors that touch the marginalised blocks form a
+// sub-problem (own context, same kernels): its landmark-only marginalised blocks leave through the landmark Schur
+// complement, the undamped reduced system is gathered into [marginalised | kept] order and a single-workgroup
+// positive-semi-definite Cholesky yields both the Schur complement onto the kept blocks and its factor.
+// ---------------------------------------------------------------------------------------------------
+int bsgpu_marginalize(bsgpu_ctx* c, int32_t n_marg, const int32_t* marg_blocks, int32_t* n_kept, int32_t* n_rows, int32_t* n_cols) {
+  if (!marg_blocks || n_marg <= 0 || !n_kept || !n_rows || !n_cols) return fail(c, BSGPU_ERR_INVALID, "marginalize: bad arguments");
+  int rc = finalize(c);
+  if (rc != BSGPU_OK) return rc;
+  c->marg_result = bsgpu_ctx::MargResult();
+  const int nb = c->nb;
+  std::vector<uint8_t> is_marg(nb, 0), used(nb, 0);
+  for (int i = 0; i < n_marg; ++i) {
+    const int b = marg_blocks[i];
+    if (b < 0 || b >= nb) return fail(c, BSGPU_ERR_INVALID, "marginalize: block out of range");
+    if (c->is_const[b]) return fail(c, BSGPU_ERR_INVALID, "marginalize: constant block");
+    is_marg[b] = 1;
+  }
+  // current values
+  std::vector<double> xcur(c->h_x.size());
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpy(xcur.data(), c->d_x, sizeof(double) * xcur.size(), hipMemcpyDeviceToHost));
+  // connected factors
+  bsgpu_ctx* sub = bsgpu_create(c->device);
+  if (!sub) return fail(c, BSGPU_ERR_DEVICE, "marginalize: cannot create the sub-problem context");
+  struct Guard { bsgpu_ctx* p; ~Guard() { bsgpu_destroy(p); } } guard{sub};
+  int n_connected = 0;
+  std::vector<std::vector<int>> pick(BSGPU_F_NUM_TYPES);
+  for (int t = 0; t < BSGPU_F_NUM_TYPES; ++t) {
+    const HostGroup& g = c->groups[t];
+    const TypeInfo& ti = kTypes[t];
+    for (int f = 0; f < g.n; ++f) {
+      const int32_t* idx = &g.idx[(size_t)f * ti.nidx];
+      bool touch = false;
+      for (int sl = 0; sl < ti.nvar; ++sl) touch = touch || is_marg[idx[sl]];
+      if (!touch) continue;
+      pick[t].push_back(f);
+      for (int sl = 0; sl < ti.nvar; ++sl) used[idx[sl]] = 1;
+      ++n_connected;
+    }
+  }
+  std::vector<int> pick_marg;
+  for (size_t i = 0; i < c->marginals.size(); ++i) {
+    bool touch = false;
+    for (int b : c->marginals[i].blocks) touch = touch || is_marg[b];
+    if (!touch) continue;
+    pick_marg.push_back((int)i);
+    for (int b : c->marginals[i].blocks) used[b] = 1;
+    ++n_connected;
+  }
+  if (!n_connected) return fail(c, BSGPU_ERR_INVALID, "marginalize: no factor touches the blocks to marginalise");
+  std::vector<uint8_t> sub_const(nb), no_elim(nb, 0);
+  std::vector<int32_t> kept;
+  for (int b = 0; b < nb; ++b) {
+    sub_const[b] = (c->is_const[b] || !used[b]) ? 1 : 0;
+    if (used[b] && !c->is_const[b] && !is_marg[b]) { kept.push_back(b); no_elim[b] = 1; }
+  }
+  auto subfail = [&](int code) { return fail(c, code, std::string("marginalize (sub-problem): ") + sub->err); };
+  std::vector<int32_t> off(c->off.begin(), c->off.end());
+  std::vector<uint8_t> size8(c->size.begin(), c->size.end()), man8(c->manifold.begin(), c->manifold.end());
+  if ((rc = bsgpu_set_blocks(sub, nb, xcur.data(), off.data(), size8.data(), man8.data(), sub_const.data())) != BSGPU_OK) return subfail(rc);
+  if (!c->cams.empty() && (rc = bsgpu_set_cameras(sub, (int32_t)c->cams.size(), c->cams.data())) != BSGPU_OK) return subfail(rc);
+  for (int t = 0; t < BSGPU_F_NUM_TYPES; ++t) {
+    if (pick[t].empty()) continue;
+    const HostGroup& g = c->groups[t];
+    const TypeInfo& ti = kTypes[t];
+    std::vector<int32_t> idx, lk;
+    std::vector<double> cs, la;
+    for (int f : pick[t]) {
+      idx.insert(idx.end(), &g.idx[(size_t)f * ti.nidx], &g.idx[(size_t)f * ti.nidx] + ti.nidx);
+      cs.insert(cs.end(), &g.consts[(size_t)f * ti.nconst], &g.consts[(size_t)f * ti.nconst] + ti.nconst);
+      lk.push_back(g.loss_kind[f]); la.push_back(g.loss_a[f]);
+    }
+    if ((rc = bsgpu_add_factors(sub, t, (int32_t)pick[t].size(), idx.data(), cs.data(), lk.data(), la.data())) != BSGPU_OK) return subfail(rc);
+  }
+  for (int i : pick_marg) {
+    const HostMarginal& mg = c->marginals[i];
+    if ((rc = bsgpu_add_marginal(sub, (int32_t)mg.blocks.size(), mg.blocks.data(), mg.rows, mg.A.data(), mg.b.data(), mg.xbar.data())) != BSGPU_OK) return subfail(rc);
+  }
+  sub->no_elim = no_elim;
+  if ((rc = finalize(sub)) != BSGPU_OK) return subfail(rc);
+  if (!sub->dense_ok) return fail(c, BSGPU_ERR_UNSUPPORTED, "marginalize: the connected sub-problem exceeds the dense limit");
+  // order: marginalised pose-side dims first, kept dims after (both in block order)
+  std::vector<int> spos;
+  int m = 0;
+  for (int b = 0; b < nb; ++b) if (is_marg[b] && !sub->is_lm[b] && sub->toff[b] >= 0) for (int k = 0; k < sub->tsize[b]; ++k, ++m) spos.push_back(sub->plan.spos(sub->toff[b] + k));
+  int kdim = 0;
+  for (int b : kept) for (int k = 0; k < sub->tsize[b]; ++k, ++kdim) spos.push_back(sub->plan.spos(sub->toff[b] + k));
+  const int n = m + kdim;
+  if (n != sub->n_pose) return fail(c, BSGPU_ERR_UNSUPPORTED, "internal: marginalisation order does not cover the reduced system");
+  if (n > 8000) return fail(c, BSGPU_ERR_UNSUPPORTED, "marginalize: more than 8000 connected dimensions");
+  if (kdim == 0) { *n_kept = 0; *n_rows = 0; *n_cols = 0; c->marg_result.valid = true; return BSGPU_OK; }
+  // undamped normal equations of the sub-problem at the current values
+  hipStream_t s = sub->stream;
+  bsgpu_options o;
+  bsgpu_options_default(&o);
+  *sub->h_radius = 1e300;
+  (void)hipMemcpyAsync(sub->d_scal + SC_RADIUS, sub->h_radius, sizeof(double), hipMemcpyHostToDevice, s);
+  eval_all(sub, sub->d_x, true, SC_COST_X);
+  sub->use_pcg = false;
+  assemble(sub, o, 1e300, true, true);
+  int* d_spos = sub->upload(spos);
+  double* d_M = sub->alloc<double>((size_t)n * n);
+  double* d_g = sub->alloc<double>(n);
+  double* d_diag0 = sub->alloc<double>(n);
+  int* d_ok = sub->alloc<int>(n);
+  double* d_A = sub->alloc<double>((size_t)kdim * kdim);
+  double* d_b = sub->alloc<double>(kdim);
+  double* d_status = sub->alloc<double>(2);
+  if (!d_M || !d_A || !d_status) return fail(c, BSGPU_ERR_DEVICE, "marginalize: out of device memory");
+  launch_marg_schur(s, sub->d_S, sub->npad, sub->plan.rhs_row, d_spos, n, m, 1e-11, d_M, d_g, d_diag0, d_ok, d_status, d_A, d_b);
+  double status[2] = {0, 0};
+  (void)hipMemcpyAsync(status, d_status, sizeof(status), hipMemcpyDeviceToHost, s);
+  if ((rc = fetch_scalars(sub)) != BSGPU_OK) return subfail(rc);
+  if (sub->h_scal[SC_CHOL_FAIL] > 0.0 || status[1] > 0.0)
+    return fail(c, BSGPU_ERR_NUMERIC, "marginalize: the blocks to marginalise are not fully constrained by the factors that touch them");
+  bsgpu_ctx::MargResult& R = c->marg_result;
+  R.kept = kept; R.rows = (int)status[0]; R.cols = kdim;
+  R.A.resize((size_t)R.rows * kdim); R.b.resize(R.rows);
+  if (R.rows) {
+    HIPCHK(c, hipMemcpy(R.A.data(), d_A, sizeof(double) * R.A.size(), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(R.b.data(), d_b, sizeof(double) * R.rows, hipMemcpyDeviceToHost));
+  }
+  for (int b : kept) R.xbar.insert(R.xbar.end(), &xcur[c->off[b]], &xcur[c->off[b]] + c->size[b]);
+  R.valid = true;
+  *n_kept = (int32_t)kept.size(); *n_rows = R.rows; *n_cols = kdim;
+  return BSGPU_OK;
+}
+int bsgpu_get_marginal(const bsgpu_ctx* c, int32_t* kept_blocks, double* A, double* b, double* xbar) {
+  if (!c->marg_result.valid) return BSGPU_ERR_INVALID;
+  const auto& R = c->marg_result;
+  if (kept_blocks) std::memcpy(kept_blocks, R.kept.data(), sizeof(int32_t) * R.kept.size());
+  if (A) std::memcpy(A, R.A.data(), sizeof(double) * R.A.size());
+  if (b) std::memcpy(b, R.b.data(), sizeof(double) * R.b.size());
+  if (xbar) std::memcpy(xbar, R.xbar.data(), sizeof(double) * R.xbar.size());
   return BSGPU_OK;
 }
 

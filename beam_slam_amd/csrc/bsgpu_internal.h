@@ -55,6 +55,25 @@ struct SmallGroup {
   const DevCamera* cams = nullptr;
 };
 
+// dense linear prior factor ([EXT] fuse_constraints::MarginalConstraint) on the device (k_marg.hip)
+struct MargDev {
+  int rows = 0, cols = 0, nblk = 0;
+  const int* blk_xoff = nullptr;  // per block: offset into x
+  const int* blk_size = nullptr;  //            ambient size
+  const int* blk_quat = nullptr;  //            1 = quaternion manifold
+  const int* blk_col = nullptr;   //            first tangent column inside the factor
+  const int* blk_amb = nullptr;   //            offset into xbar
+  const int* col_t = nullptr;     // per column: tangent index, -1 for a constant block
+  const int* col_blk = nullptr;   //             block (position inside the factor)
+  const double* A = nullptr;      // rows x cols row-major
+  const double* b = nullptr;
+  const double* xbar = nullptr;
+  double* delta = nullptr;        // cols   x [-] xbar
+  double* D = nullptr;            // nblk: |x|^2 of quaternion blocks
+  double* r = nullptr;            // rows
+  double* J = nullptr;            // rows x cols (tangent)
+};
+
 // everything the kernels need for the visual (landmark) part
 struct Visual {
   int n = 0;         // reprojection factors, sorted by landmark (constant-landmark ones last)
@@ -122,8 +141,13 @@ void launch_chol_backsolve_chains(hipStream_t s, const double* S, const double* 
                                   const PanelDesc* panels_dev, const int* panel_of_tile_dev, const int* chain_begin_dev,
                                   const int* chain_end_dev, int n_chains, const int* rows_flat_dev, const int* nreal_dev, double* y);
 void launch_y_to_delta(hipStream_t s, int n_pose, const double* y, const int* perm, double* y_tan, double* delta);
+void launch_marg_schur(hipStream_t s, const double* S, int ld, int rhs_row, const int* spos_dev, int n, int m, double rel_tol,
+                       double* M, double* g, double* diag0, int* pivot_ok, double* status, double* A, double* b);
 void launch_cov_units(hipStream_t s, double* S, int ld, int rhs_row, const int* cols_dev, int n);
 void launch_cov_dots(hipStream_t s, const double* Lp, int ld, int rhs_row, int n_cols, int ta, int row_b0, int tb, double* out);
+void launch_marg_eval(hipStream_t s, const MargDev& m, const double* x, bool with_J, double* cost_part /* rows */);
+void launch_marg_assemble(hipStream_t s, const MargDev& m, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm);
+void launch_marg_mcc(hipStream_t s, const MargDev& m, const double* delta_tan, double* part /* rows */);
 int chol_vinv_stride();
 void chol_prepare();  // one-time function attributes (kept out of captured sequences)
 // block-sparse PCG path (k_pcg.hip)

@@ -26,6 +26,7 @@ class Problem:
         self._nvalues = 0
         self.cameras = []
         self.factors = {}  # type -> list of (idx, consts, loss_kind, loss_a)
+        self.marginals = []  # (blocks, A, b, xbar): fuse_constraints::MarginalConstraint payloads
         self.meta = {}
 
     # -- blocks ----------------------------------------------------------------------------
@@ -94,13 +95,21 @@ class Problem:
         la = np.ascontiguousarray(np.broadcast_to(np.asarray(loss_a, np.float64), (n,)))
         self.factors.setdefault(ftype, []).append((idx, consts, lk, la))
 
+    def add_marginal(self, blocks, A, b, xbar):
+        """Dense linear prior r = b + sum_i A_i (x_i [-] xbar_i) over `blocks` (include/bsgpu.h: bsgpu_add_marginal)."""
+        blocks = np.asarray(blocks, np.int32).ravel()
+        A = np.atleast_2d(np.asarray(A, np.float64))
+        cols = sum(3 if self.manifold[b_] == capi.MANIFOLD_QUAT_RIGHT else self.size[b_] for b_ in blocks)
+        assert A.shape[1] == cols and np.size(b) == A.shape[0] and np.size(xbar) == sum(self.size[b_] for b_ in blocks)
+        self.marginals.append((blocks, A, np.asarray(b, np.float64).ravel(), np.asarray(xbar, np.float64).ravel()))
+
     def n_factors(self, ftype=None):
         if ftype is None:
             return sum(self.n_factors(t) for t in self.factors)
         return sum(f[0].shape[0] for f in self.factors.get(ftype, []))
 
     def n_residuals(self):
-        return sum(self.n_factors(t) * NRES[t] for t in self.factors)
+        return sum(self.n_factors(t) * NRES[t] for t in self.factors) + sum(m[1].shape[0] for m in self.marginals)
 
     # -- (de)serialisation: small fixtures under tests/golden/ ----------------------------------
     def to_arrays(self):
@@ -112,6 +121,8 @@ class Problem:
             d[f"f{t}_consts"] = np.concatenate([c[1] for c in chunks])
             d[f"f{t}_loss_kind"] = np.concatenate([c[2] for c in chunks])
             d[f"f{t}_loss_a"] = np.concatenate([c[3] for c in chunks])
+        for i, (blocks, A, b, xbar) in enumerate(self.marginals):
+            d[f"m{i}_blocks"], d[f"m{i}_A"], d[f"m{i}_b"], d[f"m{i}_xbar"] = blocks, A, b, xbar
         return d
 
     @classmethod
@@ -128,7 +139,46 @@ class Problem:
         for t in range(capi.F_NUM_TYPES):
             if f"f{t}_idx" in d:
                 pr.add_factors(t, d[f"f{t}_idx"], d[f"f{t}_consts"], d[f"f{t}_loss_kind"], d[f"f{t}_loss_a"])
+        i = 0
+        while f"m{i}_blocks" in d:
+            pr.add_marginal(d[f"m{i}_blocks"], d[f"m{i}_A"], d[f"m{i}_b"], d[f"m{i}_xbar"])
+            i += 1
         return pr
+
+    # -- true marginalisation (the transaction fuse_constraints::marginalizeVariables returns) -------
+    def connected_factors(self, blocks):
+        """(type, chunk, row) of every fixed-size factor and index of every marginal factor touching `blocks`."""
+        bs = set(int(b) for b in blocks)
+        nvar = {t: NIDX[t] - (1 if t in (capi.F_REPROJ, capi.F_REPROJ_ONLINE_CALIB, capi.F_IDP_REPROJ, capi.F_IDP_REPROJ_UNARY) else 0)
+                for t in NIDX}
+        fixed = [(t, ci, r) for t, chunks in self.factors.items() for ci, ch in enumerate(chunks)
+                 for r in range(ch[0].shape[0]) if bs & set(int(v) for v in ch[0][r, :nvar[t]])]
+        marg = [i for i, m in enumerate(self.marginals) if bs & set(int(v) for v in m[0])]
+        return fixed, marg
+
+    def marginalized(self, blocks, kept, A, b, xbar, values=None):
+        """New Problem: the factors touching `blocks` removed, those blocks frozen (they no longer take part), the
+        dense prior (kept, A, b, xbar) added; block indices are unchanged."""
+        fixed, marg = self.connected_factors(blocks)
+        drop = {}
+        for t, ci, r in fixed:
+            drop.setdefault((t, ci), set()).add(r)
+        out = Problem()
+        out._values = [(self.values if values is None else np.asarray(values, np.float64)).copy()]
+        out._nvalues = self._nvalues
+        out.offset, out.size, out.manifold = list(self.offset), list(self.size), list(self.manifold)
+        out.is_const = [1 if i in set(int(v) for v in blocks) else c for i, c in enumerate(self.is_const)]
+        out.cameras = list(self.cameras)
+        for t, chunks in self.factors.items():
+            for ci, (idx, consts, lk, la) in enumerate(chunks):
+                keep = np.array([r not in drop.get((t, ci), ()) for r in range(idx.shape[0])], bool)
+                if keep.any():
+                    out.factors.setdefault(t, []).append((idx[keep], consts[keep], lk[keep], la[keep]))
+        out.marginals = [m for i, m in enumerate(self.marginals) if i not in marg]
+        if A.shape[0]:
+            out.add_marginal(kept, A, b, xbar)
+        out.meta = dict(self.meta)
+        return out
 
     # -- hand over -------------------------------------------------------------------------
     def load(self, solver):
@@ -140,4 +190,6 @@ class Problem:
         for t in sorted(self.factors):
             for idx, consts, lk, la in self.factors[t]:
                 solver.add_factors(t, idx, consts, lk, la)
+        for blocks, A, b, xbar in self.marginals:
+            solver.add_marginal(blocks, A, b, xbar)
         return solver

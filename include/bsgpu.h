@@ -289,6 +289,18 @@ int bsgpu_add_factors(bsgpu_ctx* ctx, int32_t type, int32_t n,
 /* Uploads / builds the device-side structure (sorted factor tables, CSR of the
  * reduced system).  Called implicitly by bsgpu_solve when the problem changed;
  * exposed so a caller can keep it out of a timed region.                        */
+/* Dense linear prior: [EXT] fuse_constraints::MarginalConstraint, what fuse_constraints::marginalizeVariables
+ * adds to the graph (bs_optimizers/src/fixed_lag_smoother.cpp:270-271, `pseudo_marginalization: false`):
+ *     r = b + sum_i A_i (x_i [-] xbar_i),    [-] = LocalParameterization::Minus(xbar_i, x_i)
+ *   blocks : n_blocks indices into the block table (set_blocks first)
+ *   A      : n_rows x (sum of the blocks' tangent sizes), row-major, columns in `blocks` order
+ *   b      : n_rows
+ *   xbar   : the blocks' linearisation points, concatenated (ambient sizes)
+ * Jacobian as fuse's MarginalCostFunction: A_i MinusJacobian(x_i), brought to the tangent space with
+ * PlusJacobian(x_i) (= A_i for a unit quaternion).  No loss function.  Its residual rows come after those of all fixed-size factor types, in
+ * insertion order.  Blocks it touches are never Schur-eliminated.                                            */
+int bsgpu_add_marginal(bsgpu_ctx* ctx, int32_t n_blocks, const int32_t* blocks, int32_t n_rows,
+                       const double* A, const double* b, const double* xbar);
 int bsgpu_finalize(bsgpu_ctx* ctx);
 
 /* Levenberg-Marquardt (Ceres TrustRegionMinimizer semantics) on the device.
@@ -320,6 +332,23 @@ int bsgpu_num_residuals(const bsgpu_ctx* ctx);
 int bsgpu_num_parameters_tangent(const bsgpu_ctx* ctx);
 /* tangent offset of block b in the reduced problem, -1 for constant blocks */
 int bsgpu_tangent_offset(const bsgpu_ctx* ctx, int32_t block);
+
+/* ---- true marginalisation ---------------------------------------------------
+ * [EXT] fuse_constraints::marginalizeVariables(source, vars_to_marginalize, graph)
+ * (bs_optimizers/src/fixed_lag_smoother.cpp:270-271, `pseudo_marginalization: false`) on the device:
+ * every factor that touches one of `marg_blocks` is linearised at the current values, the marginalised blocks are
+ * eliminated (Schur complement) and the result is the dense linear prior on the other non-constant blocks those
+ * factors touch, in the form bsgpu_add_marginal() takes (A upper-trapezoidal, A^T A = marginal information,
+ * A^T b = marginal gradient, xbar = current values of the kept blocks).  Directions of the kept blocks the
+ * eliminated factors carry no information about give no row (fuse's QR leaves a zero row there).
+ * The caller then removes those factors and the marginalised blocks and adds the prior — the transaction
+ * marginalizeVariables returns.  The context itself is not modified.
+ *   n_kept / n_rows / n_cols : out — number of kept blocks, rows and columns (sum of tangent sizes) of A     */
+int bsgpu_marginalize(bsgpu_ctx* ctx, int32_t n_marg, const int32_t* marg_blocks,
+                      int32_t* n_kept, int32_t* n_rows, int32_t* n_cols);
+/* Result of the last bsgpu_marginalize: kept_blocks[n_kept] (ascending), A[n_rows*n_cols] row-major (columns in
+ * kept_blocks order), b[n_rows], xbar[sum of the kept blocks' sizes].                                       */
+int bsgpu_get_marginal(const bsgpu_ctx* ctx, int32_t* kept_blocks, double* A, double* b, double* xbar);
 
 /* ---- covariance (Graph::getCovariance) ------------------------------------- */
 /* Marginal covariance block (tangent space) between two pose-side blocks at the

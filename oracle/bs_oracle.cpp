@@ -76,6 +76,22 @@ struct Group {
   int row0 = 0;                   // first residual row of this group
 };
 
+// [EXT] fuse_constraints::MarginalConstraint (what fuse_constraints::marginalizeVariables puts into the graph,
+// bs_optimizers/src/fixed_lag_smoother.cpp:270-271), restated from fuse's published MarginalCostFunction:
+//   r = b + sum_i A_i (x_i [-] xbar_i),   [-] = LocalParameterization::Minus(xbar_i, x_i)
+//   (quaternion: QuaternionToAngleAxis(xbar^-1 (x) x), bs_constraints/src/jacobians.cpp:37-50)
+//   ambient Jacobian A_i * MinusJacobian(x_i) (jacobians.cpp:160-174; fuse evaluates ComputeMinusJacobian at the
+//   current parameter value), so the tangent Jacobian MinusJacobian(x) PlusJacobian(x) A_i-weighted is A_i |x|^2
+struct Marginal {
+  std::vector<int32_t> blocks;
+  int rows = 0, cols = 0;            // cols = sum of tangent sizes
+  std::vector<double> A, b, xbar;    // A: rows x cols row-major
+  std::vector<int> col_t;            // per column: tangent index, -1 for a constant block
+  std::vector<double> r, J;          // evaluation outputs (J: rows x cols, tangent)
+  int row0 = 0;
+  bool active = true;
+};
+
 struct Iter {
   bsgpu_iteration it;
 };
@@ -92,6 +108,8 @@ struct Ctx {
   int n_tan = 0, n_pose = 0, n_lm = 0;
   std::vector<Camera> cams;
   Group groups[BSGPU_F_NUM_TYPES];
+  std::vector<Marginal> marginals;
+  struct MargResult { std::vector<int32_t> kept; int rows = 0, cols = 0; std::vector<double> A, b, xbar; bool valid = false; } marg_result;
   bool finalized = false;
   int num_res = 0;
   int reproj_mode = 0;  // 0 closed form, 1 reference FD quaternion Jacobian, 2 autodiff
@@ -381,6 +399,53 @@ static double evaluate(Ctx& c, const double* x, bool want_J, double* fixed_cost)
     }
     cost += gc; fixed += gf;
   }
+  for (Marginal& mg : c.marginals) {
+    std::vector<double> delta(mg.cols), r_scratch;
+    if (want_J) mg.J.assign((size_t)mg.rows * mg.cols, 0.0);
+    int ct = 0, ca = 0;
+    for (size_t i = 0; i < mg.blocks.size(); ++i) {
+      const int b = mg.blocks[i];
+      const double* xb = &mg.xbar[ca];
+      const double* xx = x + c.off[b];
+      if (c.manifold[b] == BSGPU_MANIFOLD_QUAT_RIGHT) {
+        double inv[4], d[4];
+        EigenQuatConj(xb, inv);           // jacobians.cpp:3-8,44-45 QuaternionInverse = conjugate
+        QuaternionProduct(inv, xx, d);
+        QuaternionToAngleAxis(d, &delta[ct]);
+        if (want_J) {
+          // ComputeMinusJacobian(parameters[i]): "the Jacobian of Minus(x1, x2) w.r.t. x2 evaluated at x1 = x2 = x"
+          const double M[12] = {-2 * xx[1], 2 * xx[0], 2 * xx[3], -2 * xx[2], -2 * xx[2], -2 * xx[3], 2 * xx[0], 2 * xx[1],
+                                -2 * xx[3], 2 * xx[2], -2 * xx[1], 2 * xx[0]};   // jacobians.cpp:160-174
+          double P[12];
+          plus_jacobian(xx, P);
+          double MP[9];
+          for (int a = 0; a < 3; ++a) for (int e = 0; e < 3; ++e) { double sacc = 0; for (int k = 0; k < 4; ++k) sacc += M[4 * a + k] * P[3 * k + e]; MP[3 * a + e] = sacc; }
+          for (int rr = 0; rr < mg.rows; ++rr)
+            for (int e = 0; e < 3; ++e) {
+              double sacc = 0;
+              for (int a = 0; a < 3; ++a) sacc += mg.A[(size_t)rr * mg.cols + ct + a] * MP[3 * a + e];
+              mg.J[(size_t)rr * mg.cols + ct + e] = sacc;
+            }
+        }
+        ct += 3; ca += 4;
+      } else {
+        const int sz = c.size[b];
+        for (int k = 0; k < sz; ++k) delta[ct + k] = xx[k] - xb[k];
+        if (want_J) for (int rr = 0; rr < mg.rows; ++rr) for (int k = 0; k < sz; ++k) mg.J[(size_t)rr * mg.cols + ct + k] = mg.A[(size_t)rr * mg.cols + ct + k];
+        ct += sz; ca += sz;
+      }
+    }
+    if (want_J) mg.r.assign(mg.rows, 0.0); else r_scratch.assign(mg.rows, 0.0);
+    double* r = want_J ? mg.r.data() : r_scratch.data();
+    double sacc = 0;
+    for (int rr = 0; rr < mg.rows; ++rr) {
+      double v = mg.b[rr];
+      for (int k = 0; k < mg.cols; ++k) v += mg.A[(size_t)rr * mg.cols + k] * delta[k];
+      r[rr] = v; sacc += v * v;
+    }
+    if (mg.active) cost += 0.5 * sacc; else fixed += 0.5 * sacc;
+    if (want_J) for (int k = 0; k < mg.cols; ++k) if (mg.col_t[k] < 0) for (int rr = 0; rr < mg.rows; ++rr) mg.J[(size_t)rr * mg.cols + k] = 0.0;
+  }
   if (fixed_cost) *fixed_cost = fixed;
   return cost;
 }
@@ -409,6 +474,11 @@ static int finalize(Ctx& c) {
       }
     }
   }
+  for (const Marginal& mg : c.marginals)
+    for (int b : mg.blocks) {
+      if (b < 0 || b >= c.nb) { c.err = "marginal factor references block out of range"; return BSGPU_ERR_INVALID; }
+      other_use[b]++;
+    }
   c.tsize.assign(c.nb, 0); c.toff.assign(c.nb, -1); c.is_lm.assign(c.nb, 0);
   c.pose_blocks.clear(); c.lm_blocks.clear();
   for (int b = 0; b < c.nb; ++b) {
@@ -440,6 +510,18 @@ static int finalize(Ctx& c) {
         if (!c.is_const[idx[sl]]) g.active[f] = 1;
       }
     }
+  }
+  for (Marginal& mg : c.marginals) {
+    int cols = 0, amb = 0;
+    mg.col_t.clear(); mg.active = false;
+    for (int b : mg.blocks) {
+      for (int k = 0; k < c.tsize[b]; ++k) mg.col_t.push_back(c.is_const[b] ? -1 : c.toff[b] + k);
+      cols += c.tsize[b]; amb += c.size[b];
+      if (!c.is_const[b]) mg.active = true;
+    }
+    if (cols != mg.cols || amb != (int)mg.xbar.size()) { c.err = "marginal factor: A / xbar sizes do not match its blocks"; return BSGPU_ERR_INVALID; }
+    mg.row0 = row; row += mg.rows;
+    mg.r.assign(mg.rows, 0.0); mg.J.assign((size_t)mg.rows * mg.cols, 0.0);
   }
   c.num_res = row;
   // landmark -> factors CSR, owner (q,p pair) -> factors CSR
@@ -634,6 +716,23 @@ static bool solve_normal(Ctx& c, const double* D2, double* y, LinSys& ls) {
       }
     }
   }
+  for (const Marginal& mg : c.marginals) {
+    if (!mg.active) continue;
+    for (int a = 0; a < mg.cols; ++a) {
+      const int ta = mg.col_t[a];
+      if (ta < 0) continue;
+      double gsum = 0;
+      for (int k = 0; k < mg.rows; ++k) gsum += mg.J[(size_t)k * mg.cols + a] * mg.r[k];
+      ls.bp[ta] += gsum;
+      for (int b = 0; b < mg.cols; ++b) {
+        const int tb = mg.col_t[b];
+        if (tb < 0) continue;
+        double sacc = 0;
+        for (int k = 0; k < mg.rows; ++k) sacc += mg.J[(size_t)k * mg.cols + a] * mg.J[(size_t)k * mg.cols + b];
+        S[(size_t)ta * np + tb] += sacc;
+      }
+    }
+  }
   auto lmfac = [&](int code, int& t, int& f) { t = code >> 28; f = code & ((1 << 28) - 1); };
   // landmark blocks: Hll, bl
 #pragma omp parallel for schedule(static) if (nl > 256)
@@ -807,6 +906,12 @@ static void gradient_of(Ctx& c, double* grad) {
       }
     }
   });
+  for (const Marginal& mg : c.marginals)
+    if (mg.active) for (int a = 0; a < mg.cols; ++a) if (mg.col_t[a] >= 0) {
+      double s = 0;
+      for (int k = 0; k < mg.rows; ++k) s += mg.J[(size_t)k * mg.cols + a] * mg.r[k];
+      grad[mg.col_t[a]] += s;
+    }
 }
 static void colnorm2_of(Ctx& c, double* n2) {
   std::fill(n2, n2 + c.n_tan, 0.0);
@@ -822,6 +927,12 @@ static void colnorm2_of(Ctx& c, double* n2) {
       }
     }
   });
+  for (const Marginal& mg : c.marginals)
+    if (mg.active) for (int a = 0; a < mg.cols; ++a) if (mg.col_t[a] >= 0) {
+      double s = 0;
+      for (int k = 0; k < mg.rows; ++k) s += mg.J[(size_t)k * mg.cols + a] * mg.J[(size_t)k * mg.cols + a];
+      n2[mg.col_t[a]] += s;
+    }
 }
 static void scale_columns(Ctx& c, const double* sc) {
   for_each_factor(c, [&](Group& g, const TypeInfo& ti, int f, const int* cols) {
@@ -833,6 +944,9 @@ static void scale_columns(Ctx& c, const double* sc) {
         for (int k = 0; k < m; ++k) J[k * tw + 3 * sl + i] *= sc[cols[sl] + i];
     }
   });
+  for (Marginal& mg : c.marginals)
+    if (mg.active) for (int a = 0; a < mg.cols; ++a) if (mg.col_t[a] >= 0)
+      for (int k = 0; k < mg.rows; ++k) mg.J[(size_t)k * mg.cols + a] *= sc[mg.col_t[a]];
 }
 // returns -(J v).(r + J v / 2)
 static double model_cost_change_of(Ctx& c, const double* v) {
@@ -850,6 +964,12 @@ static double model_cost_change_of(Ctx& c, const double* v) {
       acc -= jv * (r[k] + jv / 2.0);
     }
   });
+  for (const Marginal& mg : c.marginals)
+    if (mg.active) for (int k = 0; k < mg.rows; ++k) {
+      double jv = 0;
+      for (int a = 0; a < mg.cols; ++a) if (mg.col_t[a] >= 0) jv += mg.J[(size_t)k * mg.cols + a] * v[mg.col_t[a]];
+      acc -= jv * (mg.r[k] + jv / 2.0);
+    }
   return acc;
 }
 
@@ -1077,6 +1197,24 @@ int bso_add_factors(Ctx* c, int32_t type, int32_t n, const int32_t* idx, const d
   c->finalized = false;
   return BSGPU_OK;
 }
+int bso_add_marginal(Ctx* c, int32_t n_blocks, const int32_t* blocks, int32_t n_rows, const double* A, const double* b,
+                     const double* xbar) {
+  if (n_blocks <= 0 || n_rows <= 0 || !blocks || !A || !b || !xbar) { c->err = "add_marginal: bad arguments"; return BSGPU_ERR_INVALID; }
+  bso::Marginal mg;
+  mg.blocks.assign(blocks, blocks + n_blocks);
+  int cols = 0, amb = 0;
+  for (int i = 0; i < n_blocks; ++i) {
+    const int bl = blocks[i];
+    if (bl < 0 || bl >= c->nb) { c->err = "add_marginal: block out of range (set_blocks first)"; return BSGPU_ERR_INVALID; }
+    cols += (c->manifold[bl] == BSGPU_MANIFOLD_QUAT_RIGHT) ? 3 : c->size[bl];
+    amb += c->size[bl];
+  }
+  mg.rows = n_rows; mg.cols = cols;
+  mg.A.assign(A, A + (size_t)n_rows * cols); mg.b.assign(b, b + n_rows); mg.xbar.assign(xbar, xbar + amb);
+  c->marginals.push_back(std::move(mg));
+  c->finalized = false;
+  return BSGPU_OK;
+}
 int bso_finalize(Ctx* c) { return bso::finalize(*c); }
 int bso_solve(Ctx* c, const bsgpu_options* o, bsgpu_summary* s) { return bso::solve(*c, *o, *s); }
 int bso_get_blocks(Ctx* c, double* v, int64_t n) {
@@ -1104,6 +1242,7 @@ int bso_evaluate(Ctx* c, double* cost, double* residuals, double* gradient, doub
       bso::Group& g = c->groups[t];
       if (g.n) std::memcpy(residuals + g.row0, g.r.data(), sizeof(double) * g.r.size());
     }
+  if (residuals) for (const bso::Marginal& mg : c->marginals) std::memcpy(residuals + mg.row0, mg.r.data(), sizeof(double) * mg.rows);
   if (gradient) bso::gradient_of(*c, gradient);
   if (jacobian) {
     if ((size_t)c->num_res * c->n_tan > ((size_t)64 << 20)) { c->err = "dense jacobian too large"; return BSGPU_ERR_UNSUPPORTED; }
@@ -1122,6 +1261,10 @@ int bso_evaluate(Ctx* c, double* cost, double* residuals, double* gradient, doub
           }
       }
     }
+    for (const bso::Marginal& mg : c->marginals)
+      for (int k = 0; k < mg.rows; ++k)
+        for (int a = 0; a < mg.cols; ++a)
+          if (mg.col_t[a] >= 0) jacobian[(size_t)(mg.row0 + k) * c->n_tan + mg.col_t[a]] = mg.J[(size_t)k * mg.cols + a];
   }
   return BSGPU_OK;
 }
@@ -1150,6 +1293,153 @@ int bso_covariance(Ctx* c, int32_t ba, int32_t bb, double* out) {
     bso::cholesky_solve(H.data(), n, e.data());
     for (int i = 0; i < ta; ++i) out[i * tb + j] = e[c->toff[ba] + i];
   }
+  return BSGPU_OK;
+}
+
+// [EXT] fuse_constraints::marginalizeVariables, restated densely (test infrastructure): the factors touching the
+// marginalised blocks are linearised at the current values (robustified J, r), H = J^T J and g = J^T r are formed
+// over [marginalised | kept], the marginalised part is eliminated with a dense Cholesky, and the Schur complement
+// is factored with a COMPLETE-PIVOTING semi-definite Cholesky (a different algorithm from the device path, so
+// only A^T A and A^T b are comparable, which is all a MarginalConstraint's cost depends on).
+int bso_marginalize(Ctx* c, int32_t n_marg, const int32_t* marg_blocks, int32_t* n_kept, int32_t* n_rows, int32_t* n_cols) {
+  int rc = bso::finalize(*c);
+  if (rc != BSGPU_OK) return rc;
+  c->marg_result = Ctx::MargResult();
+  const int nb = c->nb;
+  std::vector<uint8_t> is_marg(nb, 0), used(nb, 0);
+  for (int i = 0; i < n_marg; ++i) {
+    const int b = marg_blocks[i];
+    if (b < 0 || b >= nb || c->is_const[b]) { c->err = "marginalize: bad block"; return BSGPU_ERR_INVALID; }
+    is_marg[b] = 1;
+  }
+  Ctx sub;
+  sub.nb = nb; sub.x = c->x; sub.x0 = c->x; sub.off = c->off; sub.size = c->size; sub.manifold = c->manifold; sub.cams = c->cams;
+  sub.reproj_mode = c->reproj_mode;
+  int n_connected = 0;
+  for (int t = 0; t < BSGPU_F_NUM_TYPES; ++t) {
+    const bso::Group& g = c->groups[t];
+    const bso::TypeInfo& ti = bso::kTypes[t];
+    bso::Group& sg = sub.groups[t];
+    sg.type = t;
+    for (int f = 0; f < g.n; ++f) {
+      const int32_t* idx = &g.idx[(size_t)f * ti.nidx];
+      bool touch = false;
+      for (int sl = 0; sl < ti.nvar; ++sl) touch = touch || is_marg[idx[sl]];
+      if (!touch) continue;
+      for (int sl = 0; sl < ti.nvar; ++sl) used[idx[sl]] = 1;
+      sg.idx.insert(sg.idx.end(), idx, idx + ti.nidx);
+      sg.consts.insert(sg.consts.end(), &g.consts[(size_t)f * ti.nconst], &g.consts[(size_t)f * ti.nconst] + ti.nconst);
+      sg.loss_kind.push_back(g.loss_kind[f]); sg.loss_a.push_back(g.loss_a[f]);
+      sg.n++; ++n_connected;
+    }
+  }
+  for (const bso::Marginal& mg : c->marginals) {
+    bool touch = false;
+    for (int b : mg.blocks) touch = touch || is_marg[b];
+    if (!touch) continue;
+    for (int b : mg.blocks) used[b] = 1;
+    bso::Marginal cp; cp.blocks = mg.blocks; cp.rows = mg.rows; cp.cols = mg.cols; cp.A = mg.A; cp.b = mg.b; cp.xbar = mg.xbar;
+    sub.marginals.push_back(cp);
+    ++n_connected;
+  }
+  if (!n_connected) { c->err = "marginalize: no factor touches the blocks to marginalise"; return BSGPU_ERR_INVALID; }
+  sub.is_const.assign(nb, 1);
+  std::vector<int32_t> kept;
+  for (int b = 0; b < nb; ++b) {
+    sub.is_const[b] = (c->is_const[b] || !used[b]) ? 1 : 0;
+    if (used[b] && !c->is_const[b] && !is_marg[b]) kept.push_back(b);
+  }
+  rc = bso::finalize(sub);
+  if (rc != BSGPU_OK) { c->err = "marginalize (sub-problem): " + sub.err; return rc; }
+  const int nt = sub.n_tan, nr = sub.num_res;
+  if ((size_t)nt > 6000) { c->err = "oracle marginalize: problem too large"; return BSGPU_ERR_UNSUPPORTED; }
+  std::vector<double> J((size_t)nr * nt), r(nr);
+  rc = bso_evaluate(&sub, nullptr, r.data(), nullptr, J.data());
+  if (rc != BSGPU_OK) { c->err = sub.err; return rc; }
+  // order
+  std::vector<int> order;
+  for (int b = 0; b < nb; ++b) if (is_marg[b] && sub.toff[b] >= 0) for (int k = 0; k < sub.tsize[b]; ++k) order.push_back(sub.toff[b] + k);
+  const int m = (int)order.size();
+  for (int b : kept) for (int k = 0; k < sub.tsize[b]; ++k) order.push_back(sub.toff[b] + k);
+  const int n = (int)order.size(), kd = n - m;
+  if (n != nt) { c->err = "internal: marginalisation order does not cover the sub-problem"; return BSGPU_ERR_UNSUPPORTED; }
+  std::vector<double> H((size_t)n * n, 0.0), g(n, 0.0);
+  for (int row = 0; row < nr; ++row) {
+    const double* Jr = &J[(size_t)row * nt];
+    for (int a = 0; a < n; ++a) {
+      const double ja = Jr[order[a]];
+      if (ja == 0.0) continue;
+      g[a] += ja * r[row];
+      for (int b2 = 0; b2 < n; ++b2) H[(size_t)a * n + b2] += ja * Jr[order[b2]];
+    }
+  }
+  // eliminate the first m variables (plain right-looking Cholesky steps; must be positive definite)
+  for (int j = 0; j < m; ++j) {
+    const double d = H[(size_t)j * n + j];
+    if (!(d > 0.0) || !std::isfinite(d)) { c->err = "marginalize: the blocks to marginalise are not fully constrained by the factors that touch them"; return BSGPU_ERR_NUMERIC; }
+    const double l = std::sqrt(d);
+    for (int i = j + 1; i < n; ++i) H[(size_t)i * n + j] /= l;
+    g[j] /= l;
+    for (int i = j + 1; i < n; ++i) {
+      const double lij = H[(size_t)i * n + j];
+      g[i] -= lij * g[j];
+      for (int k = j + 1; k <= i; ++k) H[(size_t)i * n + k] -= lij * H[(size_t)k * n + j];
+    }
+  }
+  // Schur complement (lower triangle valid) -> full symmetric kd x kd
+  std::vector<double> Sx((size_t)kd * kd), gs(kd);
+  double dmax = 0.0;
+  for (int i = 0; i < kd; ++i) {
+    gs[i] = g[m + i];
+    for (int k = 0; k <= i; ++k) Sx[(size_t)i * kd + k] = Sx[(size_t)k * kd + i] = H[(size_t)(m + i) * n + m + k];
+    dmax = std::max(dmax, Sx[(size_t)i * kd + i]);
+  }
+  // complete-pivoting semi-definite Cholesky: P S P^T = L L^T (rank rk)
+  std::vector<int> piv(kd);
+  for (int i = 0; i < kd; ++i) piv[i] = i;
+  std::vector<double> L((size_t)kd * kd, 0.0);   // row = step, column = original variable:  A = L (rk x kd) with A^T A = S
+  std::vector<double> diag(kd);
+  for (int i = 0; i < kd; ++i) diag[i] = Sx[(size_t)i * kd + i];
+  std::vector<double> bvec;
+  std::vector<double> work = Sx;    // updated in place (full symmetric)
+  std::vector<double> gw = gs;
+  int rk = 0;
+  std::vector<uint8_t> done(kd, 0);
+  for (int step = 0; step < kd; ++step) {
+    int p = -1; double best = 0.0;
+    for (int i = 0; i < kd; ++i) if (!done[i] && work[(size_t)i * kd + i] > best) { best = work[(size_t)i * kd + i]; p = i; }
+    if (p < 0 || best <= 1e-11 * dmax) break;
+    const double l = std::sqrt(best);
+    // row `rk` of A: a_p = l, a_i = work[i][p] / l for the not-yet-eliminated i
+    double* Ar = &L[(size_t)rk * kd];
+    Ar[p] = l;
+    for (int i = 0; i < kd; ++i) if (!done[i] && i != p) Ar[i] = work[(size_t)i * kd + p] / l;
+    const double bp = gw[p] / l;
+    bvec.push_back(bp);
+    done[p] = 1;
+    for (int i = 0; i < kd; ++i) {
+      if (done[i]) continue;
+      gw[i] -= Ar[i] * bp;
+      for (int k = 0; k < kd; ++k) if (!done[k]) work[(size_t)i * kd + k] -= Ar[i] * Ar[k];
+    }
+    ++rk;
+  }
+  Ctx::MargResult& R = c->marg_result;
+  R.kept = kept; R.rows = rk; R.cols = kd;
+  R.A.assign(L.begin(), L.begin() + (size_t)rk * kd);
+  R.b = bvec;
+  for (int b : kept) R.xbar.insert(R.xbar.end(), &c->x[c->off[b]], &c->x[c->off[b]] + c->size[b]);
+  R.valid = true;
+  *n_kept = (int32_t)kept.size(); *n_rows = rk; *n_cols = kd;
+  return BSGPU_OK;
+}
+int bso_get_marginal(const Ctx* c, int32_t* kept_blocks, double* A, double* b, double* xbar) {
+  if (!c->marg_result.valid) return BSGPU_ERR_INVALID;
+  const auto& R = c->marg_result;
+  if (kept_blocks) std::memcpy(kept_blocks, R.kept.data(), sizeof(int32_t) * R.kept.size());
+  if (A) std::memcpy(A, R.A.data(), sizeof(double) * R.A.size());
+  if (b) std::memcpy(b, R.b.data(), sizeof(double) * R.b.size());
+  if (xbar) std::memcpy(xbar, R.xbar.data(), sizeof(double) * R.xbar.size());
   return BSGPU_OK;
 }
 

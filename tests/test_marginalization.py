@@ -1,0 +1,229 @@
+"""True marginalisation: [EXT] fuse_constraints::marginalizeVariables + MarginalConstraint,
+selected by `pseudo_marginalization: false` (bs_optimizers/src/fixed_lag_smoother.cpp:269-272).
+
+The reference ships no test for it (it lives in fuse), so the oracle is pinned here by first principles:
+ * its prior equals the Schur complement computed with numpy from the dense Jacobian of the connected factors;
+ * marginalisation of a linear-Gaussian graph is exact: the kept variables reach the same optimum;
+ * at the linearisation point the marginalised graph has the gradient and Gauss-Newton Hessian of the full graph's
+   Schur complement.
+The HIP path (bsgpu_marginalize) is then compared with the oracle on A^T A, A^T b (a MarginalConstraint's cost only
+depends on those), the kept blocks and xbar — and on the LM trajectory of the marginalised window."""
+import numpy as np
+import pytest
+
+from beam_slam_amd import capi, synthetic
+from beam_slam_amd.problem import Problem
+
+
+def _window(seed=5, n_kf=6, n_lm=40):
+    pr = synthetic.vio_window(n_kf=n_kf, n_lm=n_lm, seed=seed, track_min=2, track_max=4)
+    kf, lmb = pr.meta["kf_blocks"], pr.meta["lm_blocks"]
+    idx = np.concatenate([c[0] for c in pr.factors[capi.F_REPROJ]])
+    # what VariableStampIndex::query returns for an expired first keyframe: its five state blocks and the landmarks
+    # that only it observes (fixed_lag_smoother.cpp:153-159)
+    excl = [int(l) for l in lmb if set(idx[idx[:, 2] == l][:, 0]) == {int(kf[0, 0])}]
+    return pr, [int(b) for b in kf[0]] + excl
+
+
+def _dense_schur(solver, pr, marg, rows):
+    """numpy reference: Schur complement of J^T J onto the kept variables, J restricted to `rows`."""
+    _, r, _, J = solver.evaluate(jacobian=True)
+    J, r = J[rows], r[rows]
+    touched = np.where(np.abs(J).max(axis=0) > 0)[0]
+    mcols = np.concatenate([np.arange(solver.tangent_offset(b), solver.tangent_offset(b) + (3 if pr.manifold[b] else pr.size[b])) for b in marg])
+    kcols = np.array([c for c in touched if c not in set(mcols)])
+    H, g = J.T @ J, J.T @ r
+    Hmm, Hkm, Hkk = H[np.ix_(mcols, mcols)], H[np.ix_(kcols, mcols)], H[np.ix_(kcols, kcols)]
+    W = np.linalg.solve(Hmm, Hkm.T)
+    return kcols, Hkk - Hkm @ W, g[kcols] - Hkm @ np.linalg.solve(Hmm, g[mcols])
+
+
+def _rows_of(pr, solver, marg):
+    fixed, _ = pr.connected_factors(marg)
+    from beam_slam_amd.problem import NRES
+    row0, rows = {}, []
+    acc = 0
+    for t in range(capi.F_NUM_TYPES):
+        row0[t] = acc
+        acc += pr.n_factors(t) * NRES[t]
+    for t, ci, r in fixed:
+        base = row0[t] + NRES[t] * (sum(ch[0].shape[0] for ch in pr.factors[t][:ci]) + r)
+        rows.extend(range(base, base + NRES[t]))
+    return np.array(sorted(rows))
+
+
+def test_oracle_prior_is_the_schur_complement(oracle_cls):
+    pr, marg = _window()
+    o = oracle_cls()
+    pr.load(o)
+    o.solve()
+    kept, A, b, xbar = o.marginalize(marg, pr.size)
+    kcols, S, g = _dense_schur(o, pr, marg, _rows_of(pr, o, marg))
+    cols = np.concatenate([np.arange(o.tangent_offset(int(k)), o.tangent_offset(int(k)) + (3 if pr.manifold[k] else pr.size[k])) for k in kept])
+    assert np.array_equal(np.sort(cols), np.sort(kcols))
+    perm = [list(kcols).index(c) for c in cols]
+    S, g = S[np.ix_(perm, perm)], g[perm]
+    assert np.abs(A.T @ A - S).max() <= 1e-9 * np.abs(S).max()
+    assert np.abs(A.T @ b - g).max() <= 1e-9 * max(1.0, np.abs(g).max())
+    assert A.shape[0] == np.linalg.matrix_rank(S, tol=1e-9 * np.abs(S).max())      # one row per informative direction
+    x = o.get_blocks()
+    assert np.array_equal(xbar, np.concatenate([pr.block(int(k), x) for k in kept]))
+
+
+def _linear_chain(seed=0, n=7):
+    rng = np.random.default_rng(seed)
+    pr = Problem()
+    truth = np.cumsum(rng.normal(0, 1, (n, 3)), axis=0)
+    blocks = [pr.add_block(truth[i] + rng.normal(0, 0.3, 3)) for i in range(n)]
+    A0 = synthetic.sqrt_information_upper(0.05 * np.eye(3))
+    pr.add_factors(capi.F_ABS_VEC3, [[blocks[0]]], [np.concatenate([truth[0] + rng.normal(0, 0.05, 3), A0.ravel()])])
+    pr.add_factors(capi.F_ABS_VEC3, [[blocks[3]]], [np.concatenate([truth[3] + rng.normal(0, 0.05, 3), A0.ravel()])])
+    for i in range(n - 1):
+        Ai = synthetic.sqrt_information_upper(np.diag(rng.uniform(0.01, 0.1, 3)))
+        pr.add_factors(capi.F_REL_VEC3, [[blocks[i], blocks[i + 1]]], [np.concatenate([truth[i + 1] - truth[i] + rng.normal(0, 0.05, 3), Ai.ravel()])])
+    for i in range(n - 2):
+        Ai = synthetic.sqrt_information_upper(np.diag(rng.uniform(0.05, 0.2, 3)))
+        pr.add_factors(capi.F_REL_VEC3, [[blocks[i], blocks[i + 2]]], [np.concatenate([truth[i + 2] - truth[i] + rng.normal(0, 0.1, 3), Ai.ravel()])])
+    return pr, blocks
+
+
+def _tight(solver):
+    opt = solver.options_default()
+    opt.function_tolerance = 1e-16; opt.gradient_tolerance = 1e-14; opt.parameter_tolerance = 1e-14
+    opt.max_num_iterations = 100
+    return opt
+
+
+def test_linear_gaussian_marginalisation_is_exact(oracle_cls):
+    pr, blocks = _linear_chain()
+    full = oracle_cls()
+    pr.load(full)
+    full.solve(_tight(full))
+    x_full = full.get_blocks()
+    o = oracle_cls()
+    pr.load(o)                         # marginalise at the INITIAL values: exact for a linear problem wherever it is done
+    marg = blocks[:2]
+    kept, A, b, xbar = o.marginalize(marg, pr.size)
+    assert list(kept) == blocks[2:4]   # the neighbours through the +1 / +2 edges
+    pm = pr.marginalized(marg, kept, A, b, xbar)
+    om = oracle_cls()
+    pm.load(om)
+    om.solve(_tight(om))
+    x_m = om.get_blocks()
+    for bl in blocks[2:]:
+        assert np.abs(pr.block(bl, x_m) - pr.block(bl, x_full)).max() < 1e-9
+    # a second marginalisation absorbs the first prior (sliding window): still exact
+    kept2, A2, b2, xbar2 = om.marginalize(blocks[2:3], pm.size)
+    pm2 = pm.marginalized(blocks[2:3], kept2, A2, b2, xbar2, values=x_m)
+    assert len(pm2.marginals) == 1
+    om2 = oracle_cls()
+    pm2.load(om2)
+    om2.solve(_tight(om2))
+    for bl in blocks[3:]:
+        assert np.abs(pr.block(bl, om2.get_blocks()) - pr.block(bl, x_full)).max() < 1e-9
+
+
+def test_marginalised_window_has_the_full_windows_schur_complement(oracle_cls):
+    pr, marg = _window(seed=8)
+    o = oracle_cls()
+    pr.load(o)
+    o.solve()
+    x = o.get_blocks()
+    kept, A, b, xbar = o.marginalize(marg, pr.size)
+    pm = pr.marginalized(marg, kept, A, b, xbar, values=x)
+    om = oracle_cls()
+    pm.load(om)
+    _, rm, gm, Jm = om.evaluate(jacobian=True)
+    _, rf, gf, Jf = o.evaluate(jacobian=True)
+    live = [b_ for b_ in range(pr.n_blocks) if om.tangent_offset(b_) >= 0]
+    mcols = np.concatenate([np.arange(o.tangent_offset(b_), o.tangent_offset(b_) + (3 if pr.manifold[b_] else pr.size[b_])) for b_ in marg])
+    kf = np.concatenate([np.arange(o.tangent_offset(b_), o.tangent_offset(b_) + (3 if pr.manifold[b_] else pr.size[b_])) for b_ in live])
+    km = np.concatenate([np.arange(om.tangent_offset(b_), om.tangent_offset(b_) + (3 if pr.manifold[b_] else pr.size[b_])) for b_ in live])
+    Hf, Hm = Jf.T @ Jf, Jm.T @ Jm
+    S = Hf[np.ix_(kf, kf)] - Hf[np.ix_(kf, mcols)] @ np.linalg.solve(Hf[np.ix_(mcols, mcols)], Hf[np.ix_(mcols, kf)])
+    g = gf[kf] - Hf[np.ix_(kf, mcols)] @ np.linalg.solve(Hf[np.ix_(mcols, mcols)], gf[mcols])
+    assert np.abs(Hm[np.ix_(km, km)] - S).max() <= 1e-8 * np.abs(S).max()
+    assert np.abs(gm[km] - g).max() <= 1e-8 * max(1.0, np.abs(g).max())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [5, 8])
+def test_hip_marginal_prior_matches_oracle(oracle_cls, gpu_solver_cls, seed):
+    pr, marg = _window(seed=seed)
+    o, g = oracle_cls(), gpu_solver_cls(0)
+    pr.load(o); pr.load(g)
+    o.solve()
+    g.set_values(o.get_blocks())
+    ko, Ao, bo, xo = o.marginalize(marg, pr.size)
+    kg, Ag, bg, xg = g.marginalize(marg, pr.size)
+    assert np.array_equal(ko, kg) and np.array_equal(xo, xg)
+    assert Ao.shape == Ag.shape
+    So, Sg = Ao.T @ Ao, Ag.T @ Ag
+    assert np.abs(Sg - So).max() <= 1e-8 * np.abs(So).max()
+    assert np.abs(Ag.T @ bg - Ao.T @ bo).max() <= 1e-8 * max(1.0, np.abs(Ao.T @ bo).max())
+    assert np.allclose(Ag, np.triu(Ag) if Ag.shape[0] == Ag.shape[1] else Ag)   # full rank: upper triangular factor
+    # the marginalised window solves identically on both sides, each with its own prior
+    x = o.get_blocks()
+    rng = np.random.default_rng(seed)
+    po, pg = pr.marginalized(marg, ko, Ao, bo, xo, values=x), pr.marginalized(marg, kg, Ag, bg, xg, values=x)
+    for p in (po, pg):   # move away from the linearisation point so that the solve has something to do
+        v = p.values.copy()
+        for b_ in pr.meta["kf_blocks"][2:, 1]:
+            v[p.offset[b_]:p.offset[b_] + 3] += rng.normal(0, 0.02, 3) if p is po else 0.0
+        p.values = v
+    pg.values = po.values
+    o2, g2 = oracle_cls(), gpu_solver_cls(0)
+    po.load(o2); pg.load(g2)
+    so, sg = o2.solve(), g2.solve()
+    assert abs(sg.initial_cost - so.initial_cost) <= 1e-6 * so.initial_cost      # note: the constant 1/2|b|^2 differs
+    assert [i.step_is_successful for i in g2.iterations()] == [i.step_is_successful for i in o2.iterations()]
+    assert np.abs(g2.get_blocks() - o2.get_blocks()).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_hip_marginal_factor_evaluation_matches_oracle(oracle_cls, gpu_solver_cls):
+    """bsgpu_add_marginal: residual, Jacobian, gradient, LM trajectory of a graph holding a dense prior over
+    quaternion, vector and (former) landmark blocks."""
+    from helpers import mixed_problem
+    pr = mixed_problem(4, n_state=4, n_lm=12, consistent=True)
+    st, lm = pr.meta["states"], pr.meta["landmarks"]
+    rng = np.random.default_rng(1)
+    blocks = [int(st[0, 0]), int(st[0, 1]), int(st[1, 3]), int(lm[0]), int(lm[1]), int(st[2, 0])]
+    A = rng.normal(0, 2, (12, 18)); b = rng.normal(0, 0.1, 12)
+    xbar = np.concatenate([synthetic.quat_mul(pr.block(bb), synthetic.quat_from_aa(rng.normal(0, 0.02, 3))) if pr.manifold[bb]
+                           else pr.block(bb) + rng.normal(0, 0.02, 3) for bb in blocks])
+    pr.add_marginal(blocks, A, b, xbar)
+    o, g = oracle_cls(), gpu_solver_cls(0)
+    pr.load(o); pr.load(g)
+    assert [g.tangent_offset(b_) for b_ in range(pr.n_blocks)] == [o.tangent_offset(b_) for b_ in range(pr.n_blocks)]
+    co, ro, go, Jo = o.evaluate(jacobian=True)
+    cg, rg, gg, Jg = g.evaluate(jacobian=True)
+    assert np.abs(rg - ro).max() <= 1e-9 * max(1.0, np.abs(ro).max())
+    assert np.abs(Jg - Jo).max() <= 1e-9 * max(1.0, np.abs(Jo).max())
+    assert abs(cg - co) <= 1e-12 * abs(co)
+    assert np.abs(gg - go).max() <= 1e-9 * max(1.0, np.abs(go).max())
+    so, sg = o.solve(), g.solve()
+    io, ig = o.iterations(), g.iterations()
+    assert [i.step_is_successful for i in ig] == [i.step_is_successful for i in io]
+    for a_, b_ in zip(ig, io):
+        assert abs(a_.cost - b_.cost) <= 1e-8 * abs(b_.cost)
+    assert abs(sg.final_cost - so.final_cost) <= 1e-6 * so.final_cost
+    assert np.abs(g.get_blocks() - o.get_blocks()).max() < 1e-7
+
+
+@pytest.mark.gpu
+def test_hip_marginalisation_errors(gpu_solver_cls):
+    pr, marg = _window()
+    g = gpu_solver_cls(0)
+    pr.load(g)
+    with pytest.raises(capi.SolverError) as e:
+        g.marginalize([pr.n_blocks + 3], pr.size)
+    assert e.value.code == capi.ERR_INVALID
+    # a landmark seen by a single keyframe has an unobservable depth: marginalising it alone is ill-posed
+    idx = np.concatenate([c[0] for c in pr.factors[capi.F_REPROJ]])
+    once = [int(l) for l in pr.meta["lm_blocks"] if (idx[:, 2] == l).sum() == 1]
+    if once:
+        with pytest.raises(capi.SolverError) as e2:
+            g.marginalize(once[:1], pr.size)
+        assert e2.value.code == capi.ERR_NUMERIC
