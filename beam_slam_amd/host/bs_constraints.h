@@ -262,6 +262,34 @@ class GravityAlignmentStampedConstraint : public fuse_core::Constraint {
 // bs_common/src/bs_common/utils.cpp:128-132, absolute_constraint.h:10-25, relative_constraints.h:12-19)
 // ---------------------------------------------------------------------------------------------------
 namespace fuse_constraints {
+// [EXT] fuse_constraints::MarginalConstraint — the dense linear prior fuse_constraints::marginalizeVariables leaves
+// behind (bs_optimizers/src/fixed_lag_smoother.cpp:270-271):  cost = 1/2 | b + sum_i A_i (x_i [-] x_bar_i) |^2.
+// A is stored as one rows x cols row-major matrix, columns in variables() order (tangent sizes).
+class MarginalConstraint : public fuse_core::Constraint {
+ public:
+  MarginalConstraint(const std::string& source, std::vector<fuse_core::UUID> variables, int rows, int cols, std::vector<double> A,
+                     std::vector<double> b, std::vector<double> x_bar)
+      : Constraint(source, std::move(variables)), rows_(rows), cols_(cols), A_(std::move(A)), b_(std::move(b)), x_bar_(std::move(x_bar)) {
+    if ((size_t)rows_ * cols_ != A_.size() || (size_t)rows_ != b_.size()) throw std::invalid_argument("MarginalConstraint: A / b sizes disagree");
+  }
+  std::string type() const override { return "fuse_constraints::MarginalConstraint"; }
+  int rows() const { return rows_; }
+  int cols() const { return cols_; }
+  const std::vector<double>& A() const { return A_; }
+  const std::vector<double>& b() const { return b_; }
+  const std::vector<double>& x_bar() const { return x_bar_; }
+  void pack(const bs_constraints::BlockOf& block_of, fuse_core::FactorTables& t) const override {
+    fuse_core::FactorTables::MarginalEntry e;
+    for (const auto& u : variables()) e.blocks.push_back(block_of(u));
+    e.rows = rows_; e.A = A_; e.b = b_; e.xbar = x_bar_;
+    t.marginals.push_back(std::move(e));
+  }
+  SharedPtr clone() const override { return std::make_shared<MarginalConstraint>(*this); }
+ private:
+  int rows_, cols_;
+  std::vector<double> A_, b_, x_bar_;
+};
+
 using bs_constraints::BlockOf; using bs_constraints::Vector7d; using bs_math::Mat; using bs_math::Vec3;
 
 class RelativePose3DStampedConstraint : public fuse_core::Constraint {

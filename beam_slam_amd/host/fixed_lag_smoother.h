@@ -151,8 +151,9 @@ class FixedLagSmoother {
         marginal_transaction_.addConstraint(std::make_shared<bs_constraints::AbsoluteImuState3DStampedConstraint>(
             "MARGINALIZATION", first, first.GetStateVector(), cov));
       }
-    } else {
-      throw std::logic_error("true marginalisation (fuse_constraints::marginalizeVariables) is a 'next' row (SURVEY.md §8f rank 1)");
+    } else if (!vars_to_marginalize.empty()) {
+      // :269-272 true marginalisation: Schur complement of the expired variables on the device -> one MarginalConstraint
+      marginal_transaction_ = fuse_constraints::marginalizeVariables("fixed_lag_smoother", vars_to_marginalize, *graph_);
     }
     // removals of constraints must precede removals of variables and may list a constraint twice
     graph_->update(dedup(marginal_transaction_));

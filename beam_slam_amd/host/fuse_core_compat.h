@@ -171,6 +171,8 @@ struct FactorTables {
   std::vector<double> consts[BSGPU_F_NUM_TYPES];
   std::vector<int32_t> loss_kind[BSGPU_F_NUM_TYPES];
   std::vector<double> loss_a[BSGPU_F_NUM_TYPES];
+  struct MarginalEntry { std::vector<int32_t> blocks; int rows = 0; std::vector<double> A, b, xbar; };
+  std::vector<MarginalEntry> marginals;   // dense linear priors (bsgpu_add_marginal)
   std::vector<bsgpu_camera> cameras;
   int32_t cameraId(const bsgpu_camera& c) {
     for (size_t i = 0; i < cameras.size(); ++i)

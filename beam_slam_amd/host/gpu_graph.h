@@ -31,6 +31,9 @@ int BS_API(get_blocks)(bsgpu_ctx*, double*, int64_t);
 void BS_API(options_default)(bsgpu_options*);
 int BS_API(nidx)(int);
 int BS_API(covariance)(bsgpu_ctx*, int32_t, int32_t, double*);
+int BS_API(add_marginal)(bsgpu_ctx*, int32_t, const int32_t*, int32_t, const double*, const double*, const double*);
+int BS_API(marginalize)(bsgpu_ctx*, int32_t, const int32_t*, int32_t*, int32_t*, int32_t*);
+int BS_API(get_marginal)(const bsgpu_ctx*, int32_t*, double*, double*, double*);
 }
 
 namespace ceres_compat {  // the ceres::Solver fields the reference sets (vio.yaml:7-17) and reads (fixed_lag_smoother.cpp:286,705-716)
@@ -191,6 +194,8 @@ class GpuGraph {
     if (!t.cameras.empty()) check(BS_API(set_cameras)(ctx_, (int32_t)t.cameras.size(), t.cameras.data()));
     for (int ty = 0; ty < BSGPU_F_NUM_TYPES; ++ty)
       if (t.count(ty)) check(BS_API(add_factors)(ctx_, ty, t.count(ty), t.idx[ty].data(), t.consts[ty].data(), t.loss_kind[ty].data(), t.loss_a[ty].data()));
+    for (const auto& m : t.marginals)
+      check(BS_API(add_marginal)(ctx_, (int32_t)m.blocks.size(), m.blocks.data(), m.rows, m.A.data(), m.b.data(), m.xbar.data()));
     return true;
   }
 
@@ -225,6 +230,47 @@ class GpuGraph {
   }
   const bsgpu_summary& lastBackendSummary() const { return last_summary_; }
 
+  // [EXT] fuse_constraints::marginalizeVariables(source, marginalized_variables, graph) (fixed_lag_smoother.cpp:270-271):
+  // the transaction that removes `to_marginalize` and every constraint touching them and adds ONE MarginalConstraint
+  // on the remaining variables those constraints touch, linearised at the variables' current values.  The Schur
+  // complement runs on the device (bsgpu_marginalize); variables no constraint touches are simply removed.
+  fuse_core::Transaction marginalizeVariables(const std::string& source, const std::vector<fuse_core::UUID>& to_marginalize) {
+    fuse_core::Transaction tr;
+    std::vector<fuse_core::UUID> constrained;
+    std::set<fuse_core::UUID> removed_constraints;
+    for (const auto& u : to_marginalize) {
+      if (!variableExists(u)) throw std::out_of_range("marginalizeVariables: variable not in graph");
+      const auto it = by_variable_.find(u);
+      if (it != by_variable_.end() && !it->second.empty()) {
+        constrained.push_back(u);
+        for (const auto& cu : it->second) if (removed_constraints.insert(cu).second) tr.removeConstraint(cu);
+      }
+      tr.removeVariable(u);
+    }
+    if (constrained.empty()) return tr;
+    Flat f;
+    if (!flatten(f)) return tr;
+    std::vector<int32_t> marg;
+    for (const auto& u : constrained) {
+      const int32_t b = f.block_index.at(u);
+      if (f.is_const[b]) throw std::logic_error("marginalizeVariables: variable is held constant");
+      marg.push_back(b);
+    }
+    int32_t n_kept = 0, n_rows = 0, n_cols = 0;
+    check(BS_API(marginalize)(ctx_, (int32_t)marg.size(), marg.data(), &n_kept, &n_rows, &n_cols));
+    if (n_rows == 0) return tr;
+    std::vector<int32_t> kept(n_kept);
+    check(BS_API(get_marginal)(ctx_, kept.data(), nullptr, nullptr, nullptr));
+    size_t amb = 0;
+    for (int32_t b : kept) amb += f.size[b];
+    std::vector<double> A((size_t)n_rows * n_cols), bvec(n_rows), xbar(amb);
+    check(BS_API(get_marginal)(ctx_, kept.data(), A.data(), bvec.data(), xbar.data()));
+    std::vector<fuse_core::UUID> kept_ids;
+    for (int32_t b : kept) kept_ids.push_back(f.vars[b]->uuid());
+    tr.addConstraint(std::make_shared<fuse_constraints::MarginalConstraint>(source, std::move(kept_ids), n_rows, n_cols, std::move(A), std::move(bvec), std::move(xbar)));
+    return tr;
+  }
+
   // fuse_core::Graph::getCovariance(covariance_requests, covariance_matrices) in tangent space (the form
   // bs_publishers/src/odometry_3d_publisher.cpp:82 consumes): one row-major localSize(a) x localSize(b) matrix per
   // requested pair, marginal covariance at the variables' current values.  Pose-side variables only: landmarks are
@@ -257,3 +303,11 @@ class GpuGraph {
 };
 
 }  // namespace bs_optimizers
+
+namespace fuse_constraints {
+// the reference's call shape: fuse_constraints::marginalizeVariables(ros::this_node::getName(), vars, *graph_)
+inline fuse_core::Transaction marginalizeVariables(const std::string& source, const std::vector<fuse_core::UUID>& marginalized_variables,
+                                                   bs_optimizers::GpuGraph& graph) {
+  return graph.marginalizeVariables(source, marginalized_variables);
+}
+}  // namespace fuse_constraints

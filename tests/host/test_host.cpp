@@ -200,9 +200,69 @@ static void test_inverse_depth_window() {
   std::printf("  cost %.4e -> %.4e in %d iterations\n", summary.initial_cost, summary.final_cost, (int)summary.iterations.size() - 1);
 }
 
+// [EXT] fuse_constraints::marginalizeVariables through the host mirror: on a linear-Gaussian chain marginalisation is
+// exact, so the remaining variables must reach the optimum of the full graph; a second marginalisation absorbs the
+// first MarginalConstraint (what a sliding window does every cycle).
+static void test_true_marginalization_linear_chain() {
+  std::printf("MarginalizeVariablesLinearChain\n");
+  std::mt19937 rng(3);
+  std::normal_distribution<double> N(0.0, 1.0);
+  const int n = 7;
+  std::vector<fuse_variables::VelocityLinear3DStamped::SharedPtr> v;
+  std::vector<fuse_core::Constraint::SharedPtr> cs;
+  std::vector<Vec3> truth(n);
+  for (int i = 0; i < n; ++i) {
+    truth[i] = Vec3{0.5 * i + 0.2 * N(rng), -0.3 * i + 0.2 * N(rng), 0.1 * i * i};
+    auto x = fuse_variables::VelocityLinear3DStamped::make_shared(fuse_core::Time(1.0 + i));
+    for (int k = 0; k < 3; ++k) x->data()[k] = truth[i][k] + 0.3 * N(rng);
+    v.push_back(x);
+  }
+  auto diag = [](double a, double b, double c) { Mat<3, 3> m; m(0, 0) = a; m(1, 1) = b; m(2, 2) = c; return m; };
+  cs.push_back(bs_constraints::AbsoluteVelocityLinear3DStampedConstraint("t", *v[0], Vec3{truth[0][0] + 0.05 * N(rng), truth[0][1], truth[0][2]}, diag(0.05, 0.04, 0.06)));
+  cs.push_back(bs_constraints::AbsoluteVelocityLinear3DStampedConstraint("t", *v[4], Vec3{truth[4][0], truth[4][1] + 0.05 * N(rng), truth[4][2]}, diag(0.03, 0.05, 0.05)));
+  for (int i = 0; i + 1 < n; ++i)
+    cs.push_back(bs_constraints::RelativeVelocityLinear3DStampedConstraint("t", *v[i], *v[i + 1], Vec3{truth[i + 1][0] - truth[i][0] + 0.05 * N(rng), truth[i + 1][1] - truth[i][1] + 0.05 * N(rng), truth[i + 1][2] - truth[i][2]}, diag(0.02, 0.05, 0.03)));
+  for (int i = 0; i + 2 < n; ++i)
+    cs.push_back(bs_constraints::RelativeVelocityLinear3DStampedConstraint("t", *v[i], *v[i + 2], Vec3{truth[i + 2][0] - truth[i][0], truth[i + 2][1] - truth[i][1] + 0.1 * N(rng), truth[i + 2][2] - truth[i][2] + 0.1 * N(rng)}, diag(0.1, 0.08, 0.12)));
+  ceres_compat::SolverOptions tight;
+  tight.function_tolerance = 1e-16; tight.gradient_tolerance = 1e-14; tight.parameter_tolerance = 1e-14; tight.max_num_iterations = 100;
+  bs_optimizers::GpuGraph full, graph;
+  for (auto* g : {&full, &graph}) { for (auto& x : v) g->addVariable(x->clone()); for (auto& c : cs) g->addConstraint(c->clone()); }
+  CHECK(full.optimize(tight).IsSolutionUsable());
+  // marginalise the two oldest variables BEFORE optimising (linear problem: exact wherever it is linearised)
+  auto tr = fuse_constraints::marginalizeVariables("test", {v[0]->uuid(), v[1]->uuid()}, graph);
+  CHECK(tr.removedVariables().size() == 2);
+  CHECK(tr.removedConstraints().size() == 5);     // prior on 0, edges 0-1, 1-2, 0-2, 1-3
+  CHECK(tr.addedConstraints().size() == 1);
+  if (tr.addedConstraints().size() == 1) {
+    const auto* mc = dynamic_cast<const fuse_constraints::MarginalConstraint*>(tr.addedConstraints()[0].get());
+    CHECK(mc != nullptr);
+    if (mc) { CHECK(mc->variables().size() == 2); CHECK(mc->cols() == 6); CHECK(mc->rows() == 6); CHECK(mc->variables()[0] == v[2]->uuid()); CHECK(mc->variables()[1] == v[3]->uuid()); }
+  }
+  graph.update(tr);
+  CHECK(graph.numVariables() == (size_t)n - 2);
+  CHECK(graph.optimize(tight).IsSolutionUsable());
+  for (int i = 2; i < n; ++i) for (int k = 0; k < 3; ++k) CHECK_NEAR(graph.getVariable(v[i]->uuid()).data()[k], full.getVariable(v[i]->uuid()).data()[k], 1e-8);
+  // slide once more: the previous MarginalConstraint is consumed and replaced
+  auto tr2 = fuse_constraints::marginalizeVariables("test", {v[2]->uuid()}, graph);
+  CHECK(tr2.addedConstraints().size() == 1);
+  graph.update(tr2);
+  int n_marginal = 0;
+  for (const auto* c : graph.getConstraints()) if (c->type() == "fuse_constraints::MarginalConstraint") ++n_marginal;
+  CHECK(n_marginal == 1);
+  CHECK(graph.optimize(tight).IsSolutionUsable());
+  for (int i = 3; i < n; ++i) for (int k = 0; k < 3; ++k) CHECK_NEAR(graph.getVariable(v[i]->uuid()).data()[k], full.getVariable(v[i]->uuid()).data()[k], 1e-8);
+  // a variable nothing constrains is just removed
+  auto lonely = fuse_variables::VelocityLinear3DStamped::make_shared(fuse_core::Time(99.0));
+  graph.addVariable(lonely);
+  auto tr3 = fuse_constraints::marginalizeVariables("test", {lonely->uuid()}, graph);
+  CHECK(tr3.addedConstraints().empty()); CHECK(tr3.removedVariables().size() == 1);
+}
+
 // a synthetic visual-inertial stream through the fixed-lag smoother: lag window, pseudo-marginalisation
-static void test_fixed_lag_smoother_window() {
-  std::printf("FixedLagSmootherWindow\n");
+// (fixed_lag_smoother.cpp:244-268) or, with pseudo_marginalization == false, true marginalisation (:269-272)
+static void test_fixed_lag_smoother_window(bool pseudo_marginalization) {
+  std::printf("FixedLagSmootherWindow (%s)\n", pseudo_marginalization ? "pseudo-marginalisation" : "true marginalisation");
   std::mt19937 rng(7);
   std::normal_distribution<double> N(0.0, 1.0);
   const int n_kf = 14, per = 20;
@@ -213,6 +273,7 @@ static void test_fixed_lag_smoother_window() {
   auto acc = [](double t) { return Vec3{0.0, -0.3 * std::sin(t), 0.0}; };
   bs_optimizers::FixedLagSmootherParams params;
   params.lag_duration = 0.55;  // ~6 keyframes
+  params.pseudo_marginalization = pseudo_marginalization;
   params.solver_options = ceres_compat::SolverOptions();
   params.solver_options.max_num_iterations = 20;
   bs_optimizers::FixedLagSmoother smoother(bs_optimizers::GpuGraph::make_unique(), params);
@@ -281,10 +342,15 @@ static void test_fixed_lag_smoother_window() {
   int n_pos = 0, n_marg = 0;
   fuse_core::Time oldest(1e9);
   for (const auto* v : smoother.graph().getVariables()) if (v->type() == "fuse_variables::Position3DStamped") { ++n_pos; if (v->stamp() < oldest) oldest = v->stamp(); }
-  for (const auto* c : smoother.graph().getConstraints()) if (c->source() == "MARGINALIZATION") ++n_marg;
+  int n_marginal_constraints = 0;
+  for (const auto* c : smoother.graph().getConstraints()) {
+    if (c->source() == "MARGINALIZATION") ++n_marg;
+    if (c->type() == "fuse_constraints::MarginalConstraint") ++n_marginal_constraints;
+  }
   CHECK(n_pos <= 8); CHECK(n_pos >= 5);
   CHECK(oldest >= smoother.lagExpiration());
-  CHECK(n_marg >= 1);
+  if (pseudo_marginalization) { CHECK(n_marg >= 1); CHECK(n_marginal_constraints == 0); }
+  else { CHECK(n_marg == 0); CHECK(n_marginal_constraints == 1); }   // every slide absorbs the previous prior
   const auto first = smoother.GetWindowStartState();
   CHECK(first.Stamp() == oldest);
   // estimates stay near the truth (position within 0.2 m, see the noise above)
@@ -301,7 +367,9 @@ int main() {
   test_simple_2_state_fg();
   test_absolute_imu_state();
   test_inverse_depth_window();
-  test_fixed_lag_smoother_window();
+  test_true_marginalization_linear_chain();
+  test_fixed_lag_smoother_window(true);
+  test_fixed_lag_smoother_window(false);
   if (g_fail) { std::printf("FAILED: %d checks\n", g_fail); return 1; }
   std::printf("ALL HOST TESTS PASSED\n");
   return 0;
