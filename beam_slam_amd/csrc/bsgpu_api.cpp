@@ -93,7 +93,9 @@ struct bsgpu_ctx {
   std::vector<uint8_t> no_elim;  // per block: never Schur-eliminate (set by the marginalisation sub-problem)
   bool any_inactive = false;
   // ---- device
-  std::vector<void*> allocs;
+  std::vector<std::pair<void*, size_t>> allocs;   // live device buffers (pointer, bytes)
+  std::multimap<size_t, void*> pool;              // released buffers kept for the next finalize()
+  size_t pool_bytes = 0;
   double *d_x = nullptr, *d_xcand = nullptr, *d_x0 = nullptr;
   int *d_blk_xoff = nullptr, *d_blk_toff = nullptr;
   unsigned char *d_blk_size = nullptr, *d_blk_manifold = nullptr;
@@ -137,12 +139,24 @@ struct bsgpu_ctx {
   double *d_val = nullptr, *d_Minv = nullptr, *d_rhs = nullptr, *d_px = nullptr, *d_pr = nullptr, *d_pz = nullptr, *d_pp = nullptr,
          *d_pq = nullptr, *d_ppart = nullptr, *d_ppart2 = nullptr, *d_psc = nullptr;
 
+  // device buffers are pooled across finalize() calls: a sliding window re-flattens every cycle with nearly the same
+  // sizes, and hipMalloc / hipFree (which synchronise) would otherwise cost milliseconds per cycle
   template <typename T> T* alloc(size_t n) {
     void* p = nullptr;
     if (n == 0) n = 1;
-    if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) return nullptr;
-    allocs.push_back(p);
+    const size_t bytes = (n * sizeof(T) + 255) & ~(size_t)255;
+    auto it = pool.lower_bound(bytes);
+    if (it != pool.end() && it->first <= bytes + bytes / 4 + 4096) { p = it->second; pool_bytes -= it->first; const size_t got = it->first; pool.erase(it); allocs.push_back({p, got}); return static_cast<T*>(p); }
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+      release_pool();   // give cached buffers back and retry once
+      if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    }
+    allocs.push_back({p, bytes});
     return static_cast<T*>(p);
+  }
+  void release_pool() {
+    for (auto& kv : pool) (void)hipFree(kv.second);
+    pool.clear(); pool_bytes = 0;
   }
   template <typename T> T* upload(const std::vector<T>& v) {
     T* p = alloc<T>(v.size());
@@ -150,8 +164,10 @@ struct bsgpu_ctx {
     return p;
   }
   void free_device() {
-    for (void* p : allocs) (void)hipFree(p);
+    if (stream) (void)hipStreamSynchronize(stream);   // nothing may still be using the buffers that go back to the pool
+    for (auto& a : allocs) { pool.emplace(a.second, a.first); pool_bytes += a.second; }
     allocs.clear();
+    if (pool_bytes > ((size_t)8 << 30)) release_pool();
     vis = Visual();
     for (auto& g : small) g = SmallGroup();
     d_x = d_xcand = d_x0 = nullptr;
@@ -187,8 +203,17 @@ void eigen_quat_to_rot(const double* q, double* R) {
 // ---------------------------------------------------------------------------------------------------
 int finalize(bsgpu_ctx* c) {
   if (c->finalized) return BSGPU_OK;
+  const bool timing = getenv("BSGPU_TIMING") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[bsgpu finalize] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+    t_prev = now;
+  };
   c->free_device();
   HIPCHK(c, hipSetDevice(c->device));
+  lap("free previous");
   const int nb = c->nb;
   if (nb <= 0) return fail(c, BSGPU_ERR_INVALID, "no parameter blocks");
   // ---- validation + landmark detection (same rule as the oracle)
@@ -240,17 +265,22 @@ int finalize(bsgpu_ctx* c) {
   for (const HostMarginal& mg : c->marginals) row += mg.rows;
   c->n_res = row;
 
+  lap("validate + index");
   // ---- loss table
   std::vector<DevLoss> losses;
   std::map<std::pair<int, double>, int> loss_id;
+  int last_kind = -1, last_id = -1;
+  double last_a = 0.0;
   auto get_loss = [&](int kind, double a) {
     if (kind == BSGPU_LOSS_TRIVIAL) a = 1.0;
+    if (kind == last_kind && a == last_a) return last_id;   // windows use a handful of distinct losses
+    last_kind = kind; last_a = a;
     auto key = std::make_pair(kind, a);
     auto it = loss_id.find(key);
-    if (it != loss_id.end()) return it->second;
+    if (it != loss_id.end()) return last_id = it->second;
     DevLoss L; L.kind = kind; L.pad = 0; L.a = a;
     losses.push_back(L);
-    return loss_id[key] = (int)losses.size() - 1;
+    return last_id = loss_id[key] = (int)losses.size() - 1;
   };
   get_loss(BSGPU_LOSS_TRIVIAL, 1.0);
 
@@ -321,13 +351,19 @@ int finalize(bsgpu_ctx* c) {
       vf.push_back(e);
     }
   }
+  lap("gather visual factors");
   if ((int)cams.size() >= (1 << kMetaCamBits) || (int)losses.size() >= (1 << kMetaLossBits))
     return fail(c, BSGPU_ERR_UNSUPPORTED, "too many distinct cameras / loss functions");
   const int nv = (int)vf.size();
-  std::stable_sort(vf.begin(), vf.end(), [&](const VF& a, const VF& b) {
-    const int la = a.lm < 0 ? std::numeric_limits<int>::max() : a.lm, lb = b.lm < 0 ? std::numeric_limits<int>::max() : b.lm;
-    return la < lb;
-  });
+  {  // stable counting sort by landmark (factors of constant landmarks, lm < 0, last)
+    std::vector<int> start(nl + 2, 0);
+    for (const VF& e : vf) start[(e.lm < 0 ? nl : e.lm) + 1]++;
+    for (int l = 0; l <= nl; ++l) start[l + 1] += start[l];
+    std::vector<VF> sorted(vf.size());
+    for (const VF& e : vf) sorted[start[e.lm < 0 ? nl : e.lm]++] = e;
+    vf.swap(sorted);
+  }
+  lap("sort by landmark");
   Visual& V = c->vis;
   V.n = nv; V.n_lm = nl;
   c->vis_src.resize(nv);
@@ -336,11 +372,26 @@ int finalize(bsgpu_ctx* c) {
     std::vector<double2> pix(nv);
     std::vector<double> w(nv);
     std::vector<int> cam_pose(nv), lm_of(nv), lm_start(nl + 1, 0);
-    std::map<std::pair<int, int>, int> cp_id;
-    for (const VF& e : vf) cp_id.emplace(std::make_pair(e.bq, e.bp), 0);
-    int k = 0;
-    std::vector<int> cp_tq, cp_tp;
-    for (auto& kv : cp_id) { kv.second = k++; cp_tq.push_back(c->toff[kv.first.first]); cp_tp.push_back(c->toff[kv.first.second]); }
+    // camera poses = distinct (q block, p block) pairs, numbered in ascending (q, p) order
+    std::vector<uint64_t> cp_keys;
+    {
+      std::vector<int> seen_p(nb, -1);   // fast path: a q block nearly always pairs with one p block
+      for (const VF& e : vf) if (seen_p[e.bq] != e.bp) { seen_p[e.bq] = e.bp; cp_keys.push_back(((uint64_t)e.bq << 32) | (uint32_t)e.bp); }
+      std::sort(cp_keys.begin(), cp_keys.end());
+      cp_keys.erase(std::unique(cp_keys.begin(), cp_keys.end()), cp_keys.end());
+    }
+    const int k = (int)cp_keys.size();
+    std::vector<int> cp_tq, cp_tp, cp_first(nb, -1);   // cp_first[bq] = first camera pose with that q block
+    for (int i = 0; i < k; ++i) {
+      const int bq = (int)(cp_keys[i] >> 32), bp = (int)(cp_keys[i] & 0xffffffffu);
+      cp_tq.push_back(c->toff[bq]); cp_tp.push_back(c->toff[bp]);
+      if (cp_first[bq] < 0) cp_first[bq] = i;
+    }
+    auto cp_of = [&](int bq, int bp) {
+      int i = cp_first[bq];
+      while ((int)(cp_keys[i] & 0xffffffffu) != bp) ++i;
+      return i;
+    };
     V.n_cam_pose = k;
     int n_elim = 0;
     for (int i = 0; i < nv; ++i) {
@@ -348,36 +399,64 @@ int finalize(bsgpu_ctx* c) {
       fac[i] = make_int4(e.xq, e.xp, e.xl, meta_pack(e.meta_cam, e.loss, e.flags));
       pix[i] = make_double2(e.u, e.v);
       w[i] = e.w;
-      cam_pose[i] = cp_id[std::make_pair(e.bq, e.bp)];
+      cam_pose[i] = cp_of(e.bq, e.bp);
       lm_of[i] = e.lm;
       c->vis_src[i] = e.src;
       if (e.lm >= 0) { lm_start[e.lm + 1]++; n_elim++; }
     }
     for (int l = 0; l < nl; ++l) lm_start[l + 1] += lm_start[l];
     V.n_elim = n_elim;
-    // pair entries
-    struct Ent { uint64_t key; int fa, fb; };
-    std::vector<Ent> ents;
-    ents.reserve((size_t)nv * 5);
+    lap("camera-pose ids");
+    // pair entries (factor a, factor b) of every landmark, grouped by camera-pose pair (ca <= cb); inside a group the
+    // order is landmark-major.  Two passes over the landmarks: count per pair key, then fill in place.
     const uint64_t ncp = (uint64_t)std::max(1, V.n_cam_pose);
-    for (int l = 0; l < nl; ++l) {
-      for (int a = lm_start[l]; a < lm_start[l + 1]; ++a)
-        for (int b = lm_start[l]; b < lm_start[l + 1]; ++b) {
-          const int ca = cam_pose[a], cb = cam_pose[b];
-          if (ca < cb || (ca == cb)) ents.push_back({(uint64_t)ca * ncp + cb, a, b});
+    std::vector<int> seg_ci, seg_cj, seg_start, ent_fa, ent_fb;
+    if (ncp * ncp <= (uint64_t)8 << 20) {
+      std::vector<int> start(ncp * ncp + 1, 0);
+      for (int l = 0; l < nl; ++l)
+        for (int a = lm_start[l]; a < lm_start[l + 1]; ++a) {
+          const uint64_t ra = (uint64_t)cam_pose[a] * ncp;
+          for (int b = lm_start[l]; b < lm_start[l + 1]; ++b) if (cam_pose[a] <= cam_pose[b]) start[ra + cam_pose[b] + 1]++;
         }
-    }
-    for (int f = n_elim; f < nv; ++f) ents.push_back({(uint64_t)cam_pose[f] * ncp + cam_pose[f], f, f});
-    std::stable_sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.key < b.key; });
-    std::vector<int> seg_ci, seg_cj, seg_start, ent_fa(ents.size()), ent_fb(ents.size());
-    for (size_t i = 0; i < ents.size(); ++i) {
-      if (i == 0 || ents[i].key != ents[i - 1].key || (int)i - seg_start.back() >= 256) {
-        seg_ci.push_back((int)(ents[i].key / ncp)); seg_cj.push_back((int)(ents[i].key % ncp)); seg_start.push_back((int)i);
+      for (int f = n_elim; f < nv; ++f) start[(uint64_t)cam_pose[f] * ncp + cam_pose[f] + 1]++;
+      for (size_t i = 0; i < ncp * ncp; ++i) start[i + 1] += start[i];
+      const size_t n_ent = (size_t)start[ncp * ncp];
+      ent_fa.resize(n_ent); ent_fb.resize(n_ent);
+      lap("count pair entries");
+      // segments (chunks of <= 256 entries of one pair) straight from the counts
+      for (uint64_t key = 0; key < ncp * ncp; ++key)
+        for (int p0 = start[key]; p0 < start[key + 1]; p0 += 256) { seg_ci.push_back((int)(key / ncp)); seg_cj.push_back((int)(key % ncp)); seg_start.push_back(p0); }
+      std::vector<int> pos(start.begin(), start.end() - 1);
+      for (int l = 0; l < nl; ++l)
+        for (int a = lm_start[l]; a < lm_start[l + 1]; ++a) {
+          const uint64_t ra = (uint64_t)cam_pose[a] * ncp;
+          for (int b = lm_start[l]; b < lm_start[l + 1]; ++b)
+            if (cam_pose[a] <= cam_pose[b]) { const int p = pos[ra + cam_pose[b]]++; ent_fa[p] = a; ent_fb[p] = b; }
+        }
+      for (int f = n_elim; f < nv; ++f) { const int p = pos[(uint64_t)cam_pose[f] * ncp + cam_pose[f]]++; ent_fa[p] = f; ent_fb[p] = f; }
+      lap("fill pair entries");
+    } else {   // very many camera poses: comparison sort of explicit entries
+      struct Ent { uint64_t key; int fa, fb; };
+      std::vector<Ent> ents;
+      ents.reserve((size_t)nv * 5);
+      for (int l = 0; l < nl; ++l)
+        for (int a = lm_start[l]; a < lm_start[l + 1]; ++a)
+          for (int b = lm_start[l]; b < lm_start[l + 1]; ++b)
+            if (cam_pose[a] <= cam_pose[b]) ents.push_back({(uint64_t)cam_pose[a] * ncp + cam_pose[b], a, b});
+      for (int f = n_elim; f < nv; ++f) ents.push_back({(uint64_t)cam_pose[f] * ncp + cam_pose[f], f, f});
+      std::stable_sort(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) { return x.key < y.key; });
+      ent_fa.resize(ents.size()); ent_fb.resize(ents.size());
+      for (size_t i = 0; i < ents.size(); ++i) {
+        if (i == 0 || ents[i].key != ents[i - 1].key || (int)i - seg_start.back() >= 256) {
+          seg_ci.push_back((int)(ents[i].key / ncp)); seg_cj.push_back((int)(ents[i].key % ncp)); seg_start.push_back((int)i);
+        }
+        ent_fa[i] = ents[i].fa; ent_fb[i] = ents[i].fb;
       }
-      ent_fa[i] = ents[i].fa; ent_fb[i] = ents[i].fb;
+      lap("sort pair entries");
     }
-    seg_start.push_back((int)ents.size());
-    V.n_seg = (int)seg_ci.size(); V.n_ent = (int)ents.size();
+    seg_start.push_back((int)ent_fa.size());
+    V.n_seg = (int)seg_ci.size(); V.n_ent = (int)ent_fa.size();
+    lap("segments");
     V.fac = c->upload(fac); V.pix = c->upload(pix); V.w = c->upload(w);
     V.cam_pose = c->upload(cam_pose); V.lm_of = c->upload(lm_of); V.lm_start = c->upload(lm_start);
     V.cp_tq = c->upload(cp_tq); V.cp_tp = c->upload(cp_tp);
@@ -405,6 +484,7 @@ int finalize(bsgpu_ctx* c) {
       for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) touch(ri[a], rj[b]);
     }
   }
+  lap("visual upload + alloc");
   // ---- pose-only groups
   size_t part_max = std::max<size_t>(V.n_cost_part, 2 * ((size_t)nb + 255) / 256 + 2);
   for (int t = 2; t < kNumInternal; ++t) {
@@ -497,6 +577,7 @@ int finalize(bsgpu_ctx* c) {
   c->d_cams = c->upload(cams);
   for (int t = 2; t < kNumInternal; ++t) c->small[t].cams = c->d_cams;
   c->d_losses = c->upload(losses);
+  lap("pose-only groups + priors");
   // ---- blocks
   {
     std::vector<int> bx(c->off.begin(), c->off.end());
@@ -525,6 +606,7 @@ int finalize(bsgpu_ctx* c) {
   c->use_graphs = getenv("BSGPU_GRAPH") != nullptr;
   HIPCHK(c, hipMemset(c->d_scal, 0, sizeof(double) * SC_NUM));
   HIPCHK(c, hipMemset(c->d_delta, 0, sizeof(double) * std::max(1, c->n_tan)));
+  lap("blocks + dense buffers");
   // ---- tiled Cholesky plan: nested-dissection tile order, symbolic factorisation, step schedule
   {
     const char* e = getenv("BSGPU_CHAINS");
@@ -570,8 +652,10 @@ int finalize(bsgpu_ctx* c) {
     c->n_reduce = (int)tab.size();
     c->d_reduce = c->upload(tab);
   }
+  lap("plan + reduce table");
   HIPCHK(c, hipDeviceSynchronize());
   HIPCHK(c, hipGetLastError());
+  lap("device sync");
   c->finalized = true;
   return BSGPU_OK;
 }
@@ -1022,6 +1106,7 @@ void bsgpu_destroy(bsgpu_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   c->free_device();
+  c->release_pool();
   if (c->h_scal) (void)hipHostFree(c->h_scal);
   if (c->h_radius) (void)hipHostFree(c->h_radius);
   if (c->stream) (void)hipStreamDestroy(c->stream);
