@@ -1515,6 +1515,66 @@ int bsgpu_covariance(bsgpu_ctx* c, int32_t ba, int32_t bb, double* out) {
   return BSGPU_OK;
 }
 
+int bsgpu_reprojection_errors(bsgpu_ctx* c, double* err) {
+  if (!err) return fail(c, BSGPU_ERR_INVALID, "null argument");
+  int rc = finalize(c);
+  if (rc != BSGPU_OK) return rc;
+  HIPCHK(c, hipSetDevice(c->device));
+  const Visual& V = c->vis;
+  const SmallGroup& D = c->small[T_REPROJ_DENSE];
+  const int n0 = c->groups[BSGPU_F_REPROJ].n;
+  if (V.n + D.n == 0) return BSGPU_OK;
+  double* d_out = nullptr;
+  HIPCHK(c, hipMalloc((void**)&d_out, sizeof(double) * (size_t)(V.n + D.n)));
+  launch_reproj_errors(c->stream, V, D, c->d_x, c->d_cams, d_out, d_out + V.n);
+  std::vector<double> h((size_t)V.n + D.n);
+  const hipError_t e = hipMemcpyAsync(h.data(), d_out, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream);
+  const hipError_t e2 = hipStreamSynchronize(c->stream);
+  (void)hipFree(d_out);
+  if (e != hipSuccess || e2 != hipSuccess) return fail(c, BSGPU_ERR_DEVICE, "reprojection_errors: device error");
+  auto slot = [&](int src) { const int t = src >> 28, f = src & ((1 << 28) - 1); return (t == BSGPU_F_REPROJ ? 0 : n0) + f; };
+  for (int i = 0; i < V.n; ++i) err[slot(c->vis_src[i])] = h[i];
+  for (int i = 0; i < D.n; ++i) err[slot(c->dense_src[i])] = h[(size_t)V.n + i];
+  return BSGPU_OK;
+}
+
+int bsgpu_preintegrate(int device, int32_t n, const int32_t* sample_start, const double* t, const double* w, const double* a,
+                       const double* t_end, const double* bg, const double* ba, const double* cov_w, const double* cov_a,
+                       const double* cov_bg, const double* cov_ba, double info_weight, double* consts_out) {
+  if (n <= 0 || !sample_start || !t || !w || !a || !t_end || !bg || !ba || !cov_w || !cov_a || !cov_bg || !cov_ba || !consts_out) return BSGPU_ERR_INVALID;
+  if (hipSetDevice(device) != hipSuccess) return BSGPU_ERR_DEVICE;
+  const int ns = sample_start[n];
+  if (ns <= 0) return BSGPU_ERR_INVALID;
+  std::vector<double> covs(36);
+  std::memcpy(&covs[0], cov_w, 72); std::memcpy(&covs[9], cov_a, 72); std::memcpy(&covs[18], cov_bg, 72); std::memcpy(&covs[27], cov_ba, 72);
+  std::vector<void*> bufs;
+  auto up = [&](const void* src, size_t bytes) -> void* {
+    void* d = nullptr;
+    if (hipMalloc(&d, bytes) != hipSuccess) return nullptr;
+    bufs.push_back(d);
+    if (src && hipMemcpy(d, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    return d;
+  };
+  int* d_ss = (int*)up(sample_start, sizeof(int) * (n + 1));
+  double* d_t = (double*)up(t, sizeof(double) * ns);
+  double* d_w = (double*)up(w, sizeof(double) * 3 * ns);
+  double* d_a = (double*)up(a, sizeof(double) * 3 * ns);
+  double* d_te = (double*)up(t_end, sizeof(double) * n);
+  double* d_bg = (double*)up(bg, sizeof(double) * 3 * n);
+  double* d_ba = (double*)up(ba, sizeof(double) * 3 * n);
+  double* d_cov = (double*)up(covs.data(), sizeof(double) * 36);
+  double* d_out = (double*)up(nullptr, sizeof(double) * 287 * (size_t)n);
+  int rc = BSGPU_OK;
+  if (!d_ss || !d_t || !d_w || !d_a || !d_te || !d_bg || !d_ba || !d_cov || !d_out) rc = BSGPU_ERR_DEVICE;
+  if (rc == BSGPU_OK) {
+    launch_preintegrate(nullptr, n, d_ss, d_t, d_w, d_a, d_te, d_bg, d_ba, d_cov, info_weight, d_out);
+    if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess ||
+        hipMemcpy(consts_out, d_out, sizeof(double) * 287 * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) rc = BSGPU_ERR_DEVICE;
+  }
+  for (void* p : bufs) (void)hipFree(p);
+  return rc;
+}
+
 double bsgpu_time_reproj_jacobian_ms(bsgpu_ctx* c, int32_t reps) {
   if (finalize(c) != BSGPU_OK || c->vis.n == 0 || reps <= 0) return -1.0;
   if (hipSetDevice(c->device) != hipSuccess) return -1.0;

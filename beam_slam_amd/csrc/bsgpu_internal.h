@@ -148,6 +148,10 @@ void launch_cov_dots(hipStream_t s, const double* Lp, int ld, int rhs_row, int n
 void launch_marg_eval(hipStream_t s, const MargDev& m, const double* x, bool with_J, double* cost_part /* rows */);
 void launch_marg_assemble(hipStream_t s, const MargDev& m, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm);
 void launch_marg_mcc(hipStream_t s, const MargDev& m, const double* delta_tan, double* part /* rows */);
+void launch_reproj_errors(hipStream_t s, const Visual& v, const SmallGroup& dense, const double* x, const DevCamera* cams, double* out_vis,
+                          double* out_dense);
+void launch_preintegrate(hipStream_t s, int n_int, const int* sample_start, const double* ts, const double* wm, const double* am,
+                         const double* t_end, const double* bg, const double* ba, const double* covs, double info_weight, double* out);
 int chol_vinv_stride();
 void chol_prepare();  // one-time function attributes (kept out of captured sequences)
 // block-sparse PCG path (k_pcg.hip)

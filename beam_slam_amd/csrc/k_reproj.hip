@@ -139,6 +139,47 @@ void launch_reproj_jacobian_only(hipStream_t s, const Visual& v, const double* x
 }
 
 // ---------------------------------------------------------------------------------------------------
+// plain pixel error |z - pi(T_cam_baselink T_baselink_world P)| of every reprojection factor at x: the screening
+// quantity of bs_models/src/visual_odometry.cpp:1247-1272 (ComputeAverageReprojection), un-weighted, no loss.
+// Points at or behind the camera give -1.
+// ---------------------------------------------------------------------------------------------------
+BSG_DEV double pixel_error(const double* __restrict__ x, int xq, int xp, int xl, const DevCamera& cam, double u, double v) {
+  const double q[4] = {x[xq], x[xq + 1], x[xq + 2], x[xq + 3]};
+  const double t[3] = {x[xp], x[xp + 1], x[xp + 2]};
+  const double P[3] = {x[xl], x[xl + 1], x[xl + 2]};
+  double R[9], a[3], b[3], Pc[3];
+  quat_to_rot(q, R);
+  mat3t_vec(R, P, a);
+  mat3t_vec(R, t, b);
+  const double Pb[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]};
+  mat3_vec(cam.R, Pb, Pc);
+  Pc[0] += cam.t[0]; Pc[1] += cam.t[1]; Pc[2] += cam.t[2];
+  if (!(Pc[2] > 0.0)) return -1.0;
+  const double du = u - (cam.fx * Pc[0] / Pc[2] + cam.cx), dv = v - (cam.fy * Pc[1] / Pc[2] + cam.cy);
+  return sqrt(du * du + dv * dv);
+}
+__global__ void reproj_error_kernel(int n, const int4* __restrict__ fac, const double2* __restrict__ pix, const double* __restrict__ x,
+                                    const DevCamera* __restrict__ cams, double* __restrict__ out) {
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= n) return;
+  const int4 fc = fac[f];
+  const double2 z = pix[f];
+  out[f] = pixel_error(x, fc.x, fc.y, fc.z, cams[fc.w & ((1 << kMetaCamBits) - 1)], z.x, z.y);
+}
+__global__ void reproj_error_small_kernel(SmallGroup g, const double* __restrict__ x, double* __restrict__ out) {
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= g.n) return;
+  const int* xo = g.xoff + (size_t)f * 3;
+  const double* k = g.consts + (size_t)f * 3;
+  out[f] = pixel_error(x, xo[0], xo[1], xo[2], g.cams[g.cam[f]], k[0], k[1]);
+}
+void launch_reproj_errors(hipStream_t s, const Visual& v, const SmallGroup& dense, const double* x, const DevCamera* cams, double* out_vis,
+                          double* out_dense) {
+  if (v.n) hipLaunchKernelGGL(reproj_error_kernel, dim3((v.n + 255) / 256), dim3(256), 0, s, v.n, v.fac, v.pix, x, cams, out_vis);
+  if (dense.n) hipLaunchKernelGGL(reproj_error_small_kernel, dim3((dense.n + 255) / 256), dim3(256), 0, s, dense, x, out_dense);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // per-landmark: Hll = sum B^T B (+ lambda), g_l = sum B^T r, 3x3 Cholesky, then per factor
 // C = B Linv^T (2x3) and rho = r - C z with z = Linv g_l.   8 lanes per landmark.
 // Jacobi scaling (Ceres: s = 1/(1+sqrt(H_jj)) from iteration 0) and the LM diagonal are folded into

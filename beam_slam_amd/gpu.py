@@ -48,11 +48,38 @@ def dense_solve(A, b, device=0, max_chains=4):
     return x, ms.value
 
 
+def preintegrate(sample_start, t, w, a, t_end, bg, ba, cov_w, cov_a, cov_bg, cov_ba, info_weight=1.0, device=0):
+    """bs_common::PreIntegrator::Integrate for a batch of intervals on the device -> (n, 287) BSGPU_F_IMU_DELTA consts."""
+    import numpy as np
+    f64 = lambda x: np.ascontiguousarray(x, np.float64)
+    ss = np.ascontiguousarray(sample_start, np.int32)
+    n = ss.size - 1
+    t, w, a, t_end, bg, ba = f64(t), f64(w), f64(a), f64(t_end), f64(bg), f64(ba)
+    covs = [f64(np.asarray(c, float) * (np.eye(3) if np.ndim(c) == 0 else 1.0)) for c in (cov_w, cov_a, cov_bg, cov_ba)]
+    out = np.empty((n, 287))
+    fn = lib().bsgpu_preintegrate
+    fn.argtypes = [ctypes.c_int, ctypes.c_int32] + [ctypes.c_void_p] * 11 + [ctypes.c_double, ctypes.c_void_p]
+    rc = fn(device, n, ss.ctypes.data, t.ctypes.data, w.ctypes.data, a.ctypes.data, t_end.ctypes.data, bg.ctypes.data, ba.ctypes.data,
+            covs[0].ctypes.data, covs[1].ctypes.data, covs[2].ctypes.data, covs[3].ctypes.data, float(info_weight), out.ctypes.data)
+    if rc != 0:
+        raise capi.SolverError(rc, "bsgpu_preintegrate failed")
+    return out
+
+
 class GpuSolver(capi.Solver):
     """One bsgpu context on HIP device `device`."""
 
     def __init__(self, device=0):
         super().__init__(lib(), "bsgpu_", device)
+
+    def reprojection_errors(self, n):
+        """Pixel error of the n reprojection factors (REPROJ then REPROJ_ONLINE_CALIB, insertion order) at the current values."""
+        import numpy as np
+        out = np.zeros(n)
+        fn = lib().bsgpu_reprojection_errors
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        self._chk(fn(self._ctx, out.ctypes.data))
+        return out
 
     def time_reproj_jacobian_ms(self, reps=20):
         ms = lib().bsgpu_time_reproj_jacobian_ms(self._ctx, int(reps))

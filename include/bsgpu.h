@@ -355,6 +355,24 @@ int bsgpu_get_marginal(const bsgpu_ctx* ctx, int32_t* kept_blocks, double* A, do
  * current values: out is ts(block_a) x ts(block_b) row-major.                   */
 int bsgpu_covariance(bsgpu_ctx* ctx, int32_t block_a, int32_t block_b, double* out);
 
+/* ---- factor producers either side of the solve ---------
+ * Pixel error |z - projection| of every reprojection factor (types REPROJ then REPROJ_ONLINE_CALIB, insertion
+ * order) at the current values, un-weighted and without loss — the screening quantity of
+ * bs_models/src/visual_odometry.cpp:1247-1272 (ComputeAverageReprojection).  -1 for a point not in front of the
+ * camera.  err: bsgpu_nfactors-sized, i.e. n(REPROJ) + n(REPROJ_ONLINE_CALIB) doubles.                          */
+int bsgpu_reprojection_errors(bsgpu_ctx* ctx, double* err);
+
+/* bs_common::PreIntegrator::Integrate (bs_common/src/bs_common/preintegrator.cpp:26-143) for a batch of keyframe
+ * intervals on the device: interval i integrates samples [sample_start[i], sample_start[i+1]) (time-ordered,
+ * t / gyro w[3] / accel a[3] per sample) up to t_end[i] with the bias estimates bg[3i..], ba[3i..], and the
+ * continuous-time noise covariances cov_w, cov_a, cov_bg, cov_ba (3x3 row-major each).
+ * consts_out: n_intervals x 287 doubles — the constant payload of BSGPU_F_IMU_DELTA (dt, dq, dp, dv, bias
+ * Jacobians, bias linearisation point, A = info_weight * sqrt_inv_cov), ready for bsgpu_add_factors.           */
+int bsgpu_preintegrate(int device, int32_t n_intervals, const int32_t* sample_start, const double* t, const double* w,
+                       const double* a, const double* t_end, const double* bg, const double* ba, const double* cov_w,
+                       const double* cov_a, const double* cov_bg, const double* cov_ba, double info_weight,
+                       double* consts_out);
+
 /* ---- measurement helpers (used by bench.py only) --------------------------- */
 /* Launches the Jacobian-evaluation kernel of the reprojection factors `reps`
  * times on the context's stream between two HIP events and returns the average

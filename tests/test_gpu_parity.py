@@ -307,3 +307,53 @@ def test_landmark_blocks_shared_with_other_factors(oracle_cls, gpu_solver_cls, o
         assert abs(a.cost - b.cost) <= 1e-8 * abs(b.cost)
     assert abs(sg.final_cost - so.final_cost) <= 1e-6 * so.final_cost
     assert np.abs(g.get_blocks() - o.get_blocks()).max() < 1e-7
+
+
+def test_device_preintegration_matches_host_restatement():
+    """bsgpu_preintegrate vs the numpy restatement of bs_common/src/bs_common/preintegrator.cpp (synthetic.PreIntegrator,
+    itself checked against the reference's Simple2StateFG KAT): delta, bias Jacobians and sqrt information."""
+    from beam_slam_amd import gpu
+    rng = np.random.default_rng(2)
+    traj = synthetic.Lissajous(duration=20.0)
+    n_int, per, dt = 23, 20, 0.005
+    t = np.arange(n_int * per + 1) * dt
+    bg_true, ba_true = rng.normal(0, 0.002, 3), rng.normal(0, 0.02, 3)
+    w = np.stack([traj.omega_body(x) + bg_true + rng.normal(0, 0.01, 3) for x in t])
+    a = np.stack([traj.rot(x).T @ (traj.acc(x) - synthetic.GRAVITY_WORLD) + ba_true + rng.normal(0, 0.05, 3) for x in t])
+    # intervals share their boundary sample; the last one ends between two samples (remainder step)
+    starts = np.array([i * per for i in range(n_int)] + [n_int * per + 1], np.int32)
+    ss, ts, ws, as_ = [0], [], [], []
+    t_end = []
+    for i in range(n_int):
+        sl = slice(i * per, (i + 1) * per + 1)
+        ts.append(t[sl]); ws.append(w[sl]); as_.append(a[sl])
+        ss.append(ss[-1] + per + 1)
+        t_end.append(t[(i + 1) * per] + (0.0021 if i == n_int - 1 else 0.0))
+    bg = rng.normal(0, 0.001, (n_int, 3)); ba = rng.normal(0, 0.01, (n_int, 3))
+    covs = (synthetic.COV_GYRO_NOISE, synthetic.COV_ACCEL_NOISE, synthetic.COV_GYRO_BIAS, synthetic.COV_ACCEL_BIAS)
+    out = gpu.preintegrate(np.array(ss, np.int32), np.concatenate(ts), np.concatenate(ws), np.concatenate(as_), t_end, bg, ba,
+                           *covs, info_weight=0.7)
+    pre = synthetic.PreIntegrator()
+    for i in range(n_int):
+        pre.integrate(ts[i], ws[i], as_[i], t_end[i], bg[i], ba[i])
+        ref = pre.pack(bg[i], ba[i], 0.7)
+        assert np.abs(out[i, :62] - ref[:62]).max() <= 1e-12 * max(1.0, np.abs(ref[:62]).max())
+        A, Ar = out[i, 62:].reshape(15, 15), ref[62:].reshape(15, 15)
+        assert np.abs(A - Ar).max() <= 1e-9 * np.abs(Ar).max()      # through cov^-1: condition number of the covariance
+        assert np.allclose(A, np.triu(A))
+
+
+def test_reprojection_error_screening(oracle_cls, gpu_solver_cls):
+    """bsgpu_reprojection_errors: |z - projection| per reprojection factor (visual_odometry.cpp:1247-1272), including the
+    factors of non-eliminated landmark blocks and the online-calibration type."""
+    pr = mixed_problem(3, n_state=4, n_lm=14, with_losses=False)
+    lm0 = int(pr.meta["landmarks"][0])
+    A = synthetic.sqrt_information_upper(0.01 * np.eye(3))
+    pr.add_factors(capi.F_ABS_VEC3, [[lm0]], [np.concatenate([pr.block(lm0), A.ravel()])])     # lm0 is no longer eliminated
+    g, o = _pair(pr, oracle_cls, gpu_solver_cls)
+    n0, n1 = pr.n_factors(capi.F_REPROJ), pr.n_factors(capi.F_REPROJ_ONLINE_CALIB)
+    err = g.reprojection_errors(n0 + n1)
+    r = o.evaluate(gradient=False)[1]
+    w = np.concatenate([np.concatenate([c[1][:, 2] for c in pr.factors[t]]) for t in (capi.F_REPROJ, capi.F_REPROJ_ONLINE_CALIB) if t in pr.factors])
+    expect = np.linalg.norm(r[:2 * (n0 + n1)].reshape(-1, 2), axis=1) / w            # trivial loss: r = w (z - u)
+    assert np.abs(err - expect).max() <= 1e-9 * max(1.0, expect.max())
