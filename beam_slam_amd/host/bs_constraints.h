@@ -7,10 +7,10 @@
 
 namespace bs_constraints {
 using bs_math::Mat; using bs_math::Quat; using bs_math::Vec3;
-using BlockOf = std::function<int32_t(const fuse_core::UUID&)>;
+using BlockOf = fuse_core::BlockOf;
 
 inline void appendBlocks(const fuse_core::Constraint& c, const BlockOf& block_of, std::vector<int32_t>& idx) {
-  for (const auto& u : c.variables()) idx.push_back(block_of(u));
+  for (size_t i = 0; i < c.variables().size(); ++i) idx.push_back(block_of(c, i));
 }
 template <int N> void appendMat(std::vector<double>& v, const Mat<N, N>& m) { v.insert(v.end(), m.a, m.a + N * N); }
 
@@ -280,7 +280,7 @@ class MarginalConstraint : public fuse_core::Constraint {
   const std::vector<double>& x_bar() const { return x_bar_; }
   void pack(const bs_constraints::BlockOf& block_of, fuse_core::FactorTables& t) const override {
     fuse_core::FactorTables::MarginalEntry e;
-    for (const auto& u : variables()) e.blocks.push_back(block_of(u));
+    for (size_t i = 0; i < variables().size(); ++i) e.blocks.push_back(block_of(*this, i));
     e.rows = rows_; e.A = A_; e.b = b_; e.xbar = x_bar_;
     t.marginals.push_back(std::move(e));
   }

@@ -129,6 +129,10 @@ class Variable {
   virtual int stateSlot() const { return 99; }       // q,p,v,bg,ba = 0..4 inside one keyframe
   virtual bool isLandmark() const { return false; }
   virtual uint64_t landmarkId() const { return 0; }
+  // position in the flat block table of the last flattening (set by the graph; lets constraints resolve their
+  // variables without a UUID lookup per slot)
+  int32_t flatIndex() const { return flat_index_; }
+  void flatIndex(int32_t i) const { flat_index_ = i; }
   virtual void print(std::ostream& s) const {
     s << type() << " uuid " << uuid() << " [";
     for (size_t i = 0; i < size(); ++i) s << (i ? ", " : "") << data()[i];
@@ -136,10 +140,25 @@ class Variable {
   }
  private:
   UUID uuid_;
+  mutable int32_t flat_index_ = -1;
 };
 
 // ---- Constraint ------------------------------------------------------------------------------------
 struct FactorTables;  // bs_constraints/gpu_pack (below)
+class Constraint;
+
+// Resolves the i-th variable of a constraint to its index in the flat block table: either through block indices the
+// graph resolved beforehand (the per-cycle path: no UUID lookups) or through a uuid -> index function.
+class BlockOf {
+ public:
+  explicit BlockOf(const int32_t* resolved) : resolved_(resolved) {}
+  template <class F, class = typename std::enable_if<std::is_convertible<decltype(std::declval<F&>()(std::declval<const UUID&>())), int32_t>::value>::type>
+  BlockOf(F fn) : fn_(std::move(fn)) {}
+  inline int32_t operator()(const Constraint& c, size_t i) const;
+ private:
+  const int32_t* resolved_ = nullptr;
+  std::function<int32_t(const UUID&)> fn_;
+};
 
 class Constraint {
  public:
@@ -151,12 +170,12 @@ class Constraint {
   const UUID& uuid() const { return uuid_; }
   const std::string& source() const { return source_; }
   const std::vector<UUID>& variables() const { return variables_; }  // = Ceres parameter-block order
-  Loss::SharedPtr loss() const { return loss_; }
+  const Loss::SharedPtr& loss() const { return loss_; }
   void loss(Loss::SharedPtr l) { loss_ = std::move(l); }
   virtual void print(std::ostream& s) const { s << type() << " source " << source_ << " uuid " << uuid_; }
   // The reference hands Ceres a heap-allocated CostFunction per call (costFunction()); the GPU path
   // needs the packed payload instead.
-  virtual void pack(const std::function<int32_t(const UUID&)>& block_of, FactorTables& out) const = 0;
+  virtual void pack(const BlockOf& block_of, FactorTables& out) const = 0;
   virtual SharedPtr clone() const = 0;
  protected:
   std::string source_;
@@ -164,6 +183,8 @@ class Constraint {
   std::vector<UUID> variables_;
   Loss::SharedPtr loss_;
 };
+
+inline int32_t BlockOf::operator()(const Constraint& c, size_t i) const { return resolved_ ? resolved_[i] : fn_(c.variables()[i]); }
 
 // flat per-type tables a Graph hands to bsgpu_add_factors
 struct FactorTables {

@@ -8,6 +8,8 @@
 // because no GPU exists where they run; that configuration is test infrastructure only.
 #pragma once
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 #include "bs_constraints.h"
 
@@ -79,7 +81,11 @@ class GpuGraph {
   GpuGraph& operator=(const GpuGraph&) = delete;
 
   // ---- fuse_core::Graph surface used by the reference ---------------------------------
-  void clear() { variables_.clear(); constraints_.clear(); by_variable_.clear(); on_hold_.clear(); }
+  void clear() {
+    variables_.clear(); constraints_.clear(); by_variable_.clear(); on_hold_.clear(); order_dirty_ = true;
+    for (auto& t : tables_) t = TypeTable();
+    marginal_rows_.clear();
+  }
   bool variableExists(const fuse_core::UUID& u) const { return variables_.count(u) != 0; }
   bool constraintExists(const fuse_core::UUID& u) const { return constraints_.count(u) != 0; }
   const fuse_core::Variable& getVariable(const fuse_core::UUID& u) const {
@@ -89,18 +95,19 @@ class GpuGraph {
   }
   fuse_core::Variable& getVariable(const fuse_core::UUID& u) { return const_cast<fuse_core::Variable&>(static_cast<const GpuGraph*>(this)->getVariable(u)); }
   std::vector<const fuse_core::Variable*> getVariables() const { std::vector<const fuse_core::Variable*> v; for (auto& kv : variables_) v.push_back(kv.second.get()); return v; }
-  std::vector<const fuse_core::Constraint*> getConstraints() const { std::vector<const fuse_core::Constraint*> v; for (auto& kv : constraints_) v.push_back(kv.second.get()); return v; }
+  std::vector<const fuse_core::Constraint*> getConstraints() const { std::vector<const fuse_core::Constraint*> v; for (auto& kv : constraints_) v.push_back(kv.second.c.get()); return v; }
   std::vector<const fuse_core::Constraint*> getConnectedConstraints(const fuse_core::UUID& var) const {
     if (!variableExists(var)) throw std::logic_error("getConnectedConstraints: variable not in graph");
     std::vector<const fuse_core::Constraint*> out;
     auto it = by_variable_.find(var);
-    if (it != by_variable_.end()) for (const auto& cu : it->second) out.push_back(constraints_.at(cu).get());
+    if (it != by_variable_.end()) for (const auto& cu : it->second) out.push_back(constraints_.at(cu).c.get());
     return out;
   }
   bool addVariable(fuse_core::Variable::SharedPtr v) {
     auto it = variables_.find(v->uuid());
     if (it != variables_.end()) { std::memcpy(it->second->data(), v->data(), v->size() * sizeof(double)); return false; }  // HashGraph: overwrite value
     variables_[v->uuid()] = std::move(v);
+    order_dirty_ = true;
     return true;
   }
   bool removeVariable(const fuse_core::UUID& u) {
@@ -109,19 +116,29 @@ class GpuGraph {
     auto cit = by_variable_.find(u);
     if (cit != by_variable_.end() && !cit->second.empty()) throw std::logic_error("removeVariable: variable still used by a constraint");
     by_variable_.erase(u); on_hold_.erase(u); variables_.erase(it);
+    order_dirty_ = true;
     return true;
   }
   bool addConstraint(fuse_core::Constraint::SharedPtr c) {
     if (constraints_.count(c->uuid())) return false;
-    for (const auto& u : c->variables()) if (!variableExists(u)) throw std::logic_error("addConstraint: constraint " + c->type() + " uses a variable that is not in the graph");
+    CEntry e;
+    for (const auto& u : c->variables()) {   // resolve the variables once: flatten() then needs no UUID lookup per slot
+      auto it = variables_.find(u);
+      if (it == variables_.end()) throw std::logic_error("addConstraint: constraint " + c->type() + " uses a variable that is not in the graph");
+      e.vars.push_back(it->second.get());
+    }
     for (const auto& u : c->variables()) by_variable_[u].insert(c->uuid());
-    constraints_[c->uuid()] = std::move(c);
+    const fuse_core::UUID id = c->uuid();
+    e.c = std::move(c);
+    appendRow(e, id);
+    constraints_.emplace(id, std::move(e));
     return true;
   }
   bool removeConstraint(const fuse_core::UUID& u) {
     auto it = constraints_.find(u);
     if (it == constraints_.end()) return false;
-    for (const auto& v : it->second->variables()) by_variable_[v].erase(u);
+    for (const auto& v : it->second.c->variables()) by_variable_[v].erase(u);
+    removeRow(it->second);
     constraints_.erase(it);
     return true;
   }
@@ -133,11 +150,33 @@ class GpuGraph {
     for (const auto& v : t.addedVariables()) addVariable(v->clone());
     for (const auto& c : t.addedConstraints()) addConstraint(c->clone());
   }
-  // Graph::clone(): deep copy of variables and constraints (fixed_lag_smoother.cpp:308 does this every cycle)
+  // Graph::clone() (fixed_lag_smoother.cpp:308 does this every cycle for the publishers): variables are deep-copied,
+  // the immutable constraints are shared, the packed tables are copied with their variable pointers remapped
   UniquePtr clone() const {
     UniquePtr g(new GpuGraph(device_));
-    for (auto& kv : variables_) g->variables_[kv.first] = kv.second->clone();
-    for (auto& kv : constraints_) g->constraints_[kv.first] = kv.second->clone();
+    std::vector<fuse_core::Variable*> copies;
+    copies.reserve(variables_.size());
+    auto hint = g->variables_.end();
+    for (auto& kv : variables_) {   // same key order: hinted insertion; the flat index carries old -> new
+      kv.second->flatIndex((int32_t)copies.size());
+      hint = g->variables_.emplace_hint(hint, kv.first, kv.second->clone());
+      copies.push_back(hint->second.get());
+    }
+    auto chint = g->constraints_.end();
+    for (auto& kv : constraints_) {
+      CEntry e;
+      e.c = kv.second.c;   // constraints are immutable once in a graph: the copy shares them (variables are deep-copied)
+      e.type = kv.second.type; e.row = kv.second.row;
+      for (const auto* v : kv.second.vars) e.vars.push_back(copies[v->flatIndex()]);
+      chint = g->constraints_.emplace_hint(chint, kv.first, std::move(e));
+    }
+    g->cameras_ = cameras_;
+    for (int ty = 0; ty < BSGPU_F_NUM_TYPES; ++ty) {
+      g->tables_[ty] = tables_[ty];
+      for (auto& v : g->tables_[ty].vars) v = copies[v->flatIndex()];
+    }
+    g->marginal_rows_ = marginal_rows_;
+    order_dirty_ = true;   // the flat indices were borrowed
     g->by_variable_ = by_variable_; g->on_hold_ = on_hold_;
     return g;
   }
@@ -147,7 +186,7 @@ class GpuGraph {
     s << "GpuGraph\n  variables:\n";
     for (auto& kv : variables_) { s << "   - "; kv.second->print(s); s << "\n"; }
     s << "  constraints:\n";
-    for (auto& kv : constraints_) { s << "   - "; kv.second->print(s); s << "\n"; }
+    for (auto& kv : constraints_) { s << "   - "; kv.second.c->print(s); s << "\n"; }
   }
 
   // ---- the hot call -----------------------------------------------------------------------------------
@@ -155,16 +194,27 @@ class GpuGraph {
   // keyframe (ImuState::GetStateVector, imu_state.cpp:348-354); then landmarks ascending by id
   // (graph_access.cpp:200-216); unstamped extrinsic blocks last.
   std::vector<const fuse_core::Variable*> orderedVariables() const {
-    std::vector<const fuse_core::Variable*> v = getVariables();
-    auto cls = [](const fuse_core::Variable* a) { return a->isStamped() ? 0 : a->isLandmark() ? 1 : 2; };
-    std::stable_sort(v.begin(), v.end(), [&](const fuse_core::Variable* a, const fuse_core::Variable* b) {
-      const int ca = cls(a), cb = cls(b);
-      if (ca != cb) return ca < cb;
-      if (ca == 0) { if (a->stamp() != b->stamp()) return a->stamp() < b->stamp(); if (a->stateSlot() != b->stateSlot()) return a->stateSlot() < b->stateSlot(); }
-      if (ca == 1 && a->landmarkId() != b->landmarkId()) return a->landmarkId() < b->landmarkId();
-      return a->uuid() < b->uuid();
+    if (!order_dirty_) return ordered_;
+    struct Key { int cls; int64_t a; int64_t b; const fuse_core::Variable* v; };
+    std::vector<Key> keys;
+    keys.reserve(variables_.size());
+    for (auto& kv : variables_) {
+      const fuse_core::Variable* v = kv.second.get();
+      Key k{2, 0, 0, v};
+      if (v->isStamped()) { k.cls = 0; k.a = v->stamp().ns; k.b = v->stateSlot(); }
+      else if (v->isLandmark()) { k.cls = 1; k.a = (int64_t)v->landmarkId(); }
+      keys.push_back(k);
+    }
+    // variables_ is uuid-ordered, so a stable sort on (class, stamp | id, slot) leaves ties in uuid order
+    std::stable_sort(keys.begin(), keys.end(), [](const Key& x, const Key& y) {
+      if (x.cls != y.cls) return x.cls < y.cls;
+      if (x.a != y.a) return x.cls == 1 ? (uint64_t)x.a < (uint64_t)y.a : x.a < y.a;
+      return x.b < y.b;
     });
-    return v;
+    ordered_.clear();
+    for (const Key& k : keys) ordered_.push_back(k.v);
+    order_dirty_ = false;
+    return ordered_;
   }
 
   // Flat IR of the current graph (variables at their current values) loaded into the back-end context
@@ -173,12 +223,21 @@ class GpuGraph {
     std::vector<double> values;
     std::vector<int32_t> offset;
     std::vector<uint8_t> size, manifold, is_const;
-    std::map<fuse_core::UUID, int32_t> block_index;
   };
+  int32_t blockIndexOf(const fuse_core::UUID& u) const { return variables_.at(u)->flatIndex(); }   // valid right after flatten()
   bool flatten(Flat& f) {
+    const bool timing = std::getenv("BS_HOST_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+      if (!timing) return;
+      const auto now = std::chrono::steady_clock::now();
+      std::fprintf(stderr, "[GpuGraph::flatten] %-24s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+      t_prev = now;
+    };
     f.vars = orderedVariables();
+    lap("block order");
     for (const auto* v : f.vars) {
-      f.block_index[v->uuid()] = (int32_t)f.offset.size();
+      v->flatIndex((int32_t)f.offset.size());
       f.offset.push_back((int32_t)f.values.size());
       f.size.push_back((uint8_t)v->size());
       f.manifold.push_back((uint8_t)v->manifold());
@@ -186,16 +245,34 @@ class GpuGraph {
       f.values.insert(f.values.end(), v->data(), v->data() + v->size());
     }
     if (f.offset.empty()) return false;
-    fuse_core::FactorTables t;
-    auto block_of = [&](const fuse_core::UUID& u) { return f.block_index.at(u); };
-    for (auto& kv : constraints_) kv.second->pack(block_of, t);
+    lap("block table");
+    // block indices of every packed row: the only per-cycle work on the factor side (constants, losses and camera ids
+    // were packed once, when the constraint entered the graph)
+    for (int ty = 0; ty < BSGPU_F_NUM_TYPES; ++ty) {
+      TypeTable& tb = tables_[ty];
+      if (!tb.rows) continue;
+      const int nidx = tb.nvar + (tb.has_cam ? 1 : 0);
+      tb.idx.resize((size_t)tb.rows * nidx);
+      for (size_t r = 0; r < tb.rows; ++r) {
+        for (int sl = 0; sl < tb.nvar; ++sl) tb.idx[r * nidx + sl] = tb.vars[r * tb.nvar + sl]->flatIndex();
+        if (tb.has_cam) tb.idx[r * nidx + tb.nvar] = tb.cam[r];
+      }
+    }
+    lap("block indices of factors");
     check(BS_API(clear)(ctx_));
     check(BS_API(set_blocks)(ctx_, (int32_t)f.offset.size(), f.values.data(), f.offset.data(), f.size.data(), f.manifold.data(), f.is_const.data()));
-    if (!t.cameras.empty()) check(BS_API(set_cameras)(ctx_, (int32_t)t.cameras.size(), t.cameras.data()));
-    for (int ty = 0; ty < BSGPU_F_NUM_TYPES; ++ty)
-      if (t.count(ty)) check(BS_API(add_factors)(ctx_, ty, t.count(ty), t.idx[ty].data(), t.consts[ty].data(), t.loss_kind[ty].data(), t.loss_a[ty].data()));
-    for (const auto& m : t.marginals)
-      check(BS_API(add_marginal)(ctx_, (int32_t)m.blocks.size(), m.blocks.data(), m.rows, m.A.data(), m.b.data(), m.xbar.data()));
+    if (!cameras_.empty()) check(BS_API(set_cameras)(ctx_, (int32_t)cameras_.size(), cameras_.data()));
+    for (int ty = 0; ty < BSGPU_F_NUM_TYPES; ++ty) {
+      const TypeTable& tb = tables_[ty];
+      if (tb.rows) check(BS_API(add_factors)(ctx_, ty, (int32_t)tb.rows, tb.idx.data(), tb.consts.data(), tb.loss_kind.data(), tb.loss_a.data()));
+    }
+    for (const auto& kv : marginal_rows_) {
+      const auto& m = kv.second;
+      std::vector<int32_t> blocks;
+      for (const auto* v : m.vars) blocks.push_back(v->flatIndex());
+      check(BS_API(add_marginal)(ctx_, (int32_t)blocks.size(), blocks.data(), m.e.rows, m.e.A.data(), m.e.b.data(), m.e.xbar.data()));
+    }
+    lap("hand-over (C-ABI copies)");
     return true;
   }
 
@@ -213,7 +290,7 @@ class GpuGraph {
     check(BS_API(solve)(ctx_, &bo, &bs));
     check(BS_API(get_blocks)(ctx_, values.data(), (int64_t)values.size()));
     for (size_t i = 0; i < vars.size(); ++i)   // Variable::data() updated in place, like Ceres does through the raw pointers
-      std::memcpy(variables_.at(vars[i]->uuid())->data(), values.data() + offset[i], size[i] * sizeof(double));
+      std::memcpy(const_cast<fuse_core::Variable*>(vars[i])->data(), values.data() + offset[i], size[i] * sizeof(double));
     s.termination_type = bs.termination_type == BSGPU_CONVERGENCE ? ceres_compat::CONVERGENCE
                        : bs.termination_type == BSGPU_NO_CONVERGENCE ? ceres_compat::NO_CONVERGENCE : ceres_compat::FAILURE;
     s.initial_cost = bs.initial_cost; s.final_cost = bs.final_cost;
@@ -252,7 +329,7 @@ class GpuGraph {
     if (!flatten(f)) return tr;
     std::vector<int32_t> marg;
     for (const auto& u : constrained) {
-      const int32_t b = f.block_index.at(u);
+      const int32_t b = blockIndexOf(u);
       if (f.is_const[b]) throw std::logic_error("marginalizeVariables: variable is held constant");
       marg.push_back(b);
     }
@@ -282,11 +359,11 @@ class GpuGraph {
     if (covariance_requests.empty()) return;
     if (!flatten(f)) throw std::runtime_error("getCovariance: empty graph");
     for (const auto& rq : covariance_requests) {
-      const auto a = f.block_index.find(rq.first), b = f.block_index.find(rq.second);
-      if (a == f.block_index.end() || b == f.block_index.end()) throw std::out_of_range("getCovariance: variable not in graph");
+      if (!variableExists(rq.first) || !variableExists(rq.second)) throw std::out_of_range("getCovariance: variable not in graph");
+      const int32_t a = blockIndexOf(rq.first), b = blockIndexOf(rq.second);
       const size_t ta = variables_.at(rq.first)->localSize(), tb = variables_.at(rq.second)->localSize();
       std::vector<double> m(ta * tb);
-      check(BS_API(covariance)(ctx_, a->second, b->second, m.data()));
+      check(BS_API(covariance)(ctx_, a, b, m.data()));
       covariance_matrices.push_back(std::move(m));
     }
   }
@@ -296,7 +373,81 @@ class GpuGraph {
   int device_;
   bsgpu_ctx* ctx_;
   std::map<fuse_core::UUID, fuse_core::Variable::SharedPtr> variables_;
-  std::map<fuse_core::UUID, fuse_core::Constraint::SharedPtr> constraints_;
+  struct CEntry { fuse_core::Constraint::SharedPtr c; std::vector<const fuse_core::Variable*> vars; int type = -1; size_t row = 0; };
+  // Packed per-type factor tables, persisted across cycles: a constraint is packed ONCE, when it
+  // enters the graph; removal swaps the last row into the hole.  Row order therefore follows the transaction history.
+  struct TypeTable {
+    size_t rows = 0;
+    int nvar = 0;
+    bool has_cam = false;
+    std::vector<const fuse_core::Variable*> vars;   // rows x nvar
+    std::vector<int32_t> cam;                       // rows (camera-table id) when has_cam
+    std::vector<double> consts;
+    std::vector<int32_t> loss_kind;
+    std::vector<double> loss_a;
+    std::vector<fuse_core::UUID> owner;             // rows: the constraint of each row
+    std::vector<int32_t> idx;                       // scratch: rows x nidx, rebuilt by flatten()
+  };
+  struct MarginalRow { fuse_core::FactorTables::MarginalEntry e; std::vector<const fuse_core::Variable*> vars; };
+  void appendRow(CEntry& e, const fuse_core::UUID& id) {
+    fuse_core::FactorTables t1;
+    int32_t slots[64];
+    std::vector<int32_t> slots_big;
+    int32_t* sl = slots;
+    if (e.vars.size() > 64) { slots_big.resize(e.vars.size()); sl = slots_big.data(); }
+    for (size_t i = 0; i < e.vars.size(); ++i) sl[i] = (int32_t)i;
+    e.c->pack(fuse_core::BlockOf(sl), t1);
+    if (!t1.marginals.empty()) {
+      MarginalRow m; m.e = std::move(t1.marginals[0]); m.vars = e.vars;
+      marginal_rows_[id] = std::move(m);
+      e.type = -2;
+      return;
+    }
+    for (int ty = 0; ty < BSGPU_F_NUM_TYPES; ++ty) {
+      if (!t1.count(ty)) continue;
+      TypeTable& tb = tables_[ty];
+      const int nvar = (int)e.vars.size(), nidx = (int)t1.idx[ty].size();
+      if (!tb.rows && tb.vars.empty()) { tb.nvar = nvar; tb.has_cam = nidx > nvar; }
+      tb.vars.insert(tb.vars.end(), e.vars.begin(), e.vars.end());
+      if (tb.has_cam) {
+        const bsgpu_camera& c1 = t1.cameras.at(t1.idx[ty][nvar]);
+        int32_t cid = -1;
+        for (size_t i = 0; i < cameras_.size(); ++i) if (std::memcmp(&cameras_[i], &c1, sizeof(c1)) == 0) { cid = (int32_t)i; break; }
+        if (cid < 0) { cameras_.push_back(c1); cid = (int32_t)cameras_.size() - 1; }
+        tb.cam.push_back(cid);
+      }
+      tb.consts.insert(tb.consts.end(), t1.consts[ty].begin(), t1.consts[ty].end());
+      tb.loss_kind.push_back(t1.loss_kind[ty][0]); tb.loss_a.push_back(t1.loss_a[ty][0]);
+      tb.owner.push_back(id);
+      e.type = ty; e.row = tb.rows++;
+      return;
+    }
+  }
+  void removeRow(const CEntry& e) {
+    if (e.type == -2) { marginal_rows_.erase(e.c->uuid()); return; }
+    if (e.type < 0) return;
+    TypeTable& tb = tables_[e.type];
+    const size_t last = tb.rows - 1, r = e.row, nc = tb.consts.size() / tb.rows;
+    if (r != last) {
+      for (int sl = 0; sl < tb.nvar; ++sl) tb.vars[r * tb.nvar + sl] = tb.vars[last * tb.nvar + sl];
+      if (tb.has_cam) tb.cam[r] = tb.cam[last];
+      for (size_t k = 0; k < nc; ++k) tb.consts[r * nc + k] = tb.consts[last * nc + k];
+      tb.loss_kind[r] = tb.loss_kind[last]; tb.loss_a[r] = tb.loss_a[last];
+      tb.owner[r] = tb.owner[last];
+      constraints_.at(tb.owner[r]).row = r;
+    }
+    tb.vars.resize(last * tb.nvar);
+    if (tb.has_cam) tb.cam.pop_back();
+    tb.consts.resize(last * nc);
+    tb.loss_kind.pop_back(); tb.loss_a.pop_back(); tb.owner.pop_back();
+    tb.rows = last;
+  }
+  TypeTable tables_[BSGPU_F_NUM_TYPES];
+  std::vector<bsgpu_camera> cameras_;
+  std::map<fuse_core::UUID, MarginalRow> marginal_rows_;
+  std::map<fuse_core::UUID, CEntry> constraints_;
+  mutable std::vector<const fuse_core::Variable*> ordered_;   // cached deterministic block order
+  mutable bool order_dirty_ = true;
   std::map<fuse_core::UUID, std::set<fuse_core::UUID>> by_variable_;
   std::set<fuse_core::UUID> on_hold_;
   bsgpu_summary last_summary_{};

@@ -1,0 +1,68 @@
+// Times one optimisation cycle of the host mirror at the size of BASELINE config C2 (200 keyframes, 50 000 landmarks,
+// ~400 000 reprojection constraints): GpuGraph::flatten (ordering + pack + C-ABI hand-over) vs the device solve.
+// Run on the GPU box:  g++ -O2 -std=c++17 tests/host/bench_host.cpp -Lbeam_slam_amd/csrc -lbsgpu ... (scripts/bench_host.sh)
+#include <chrono>
+#include <cstdio>
+#include <random>
+
+#include "../../beam_slam_amd/host/fixed_lag_smoother.h"
+
+using namespace bs_math;
+using clk = std::chrono::steady_clock;
+static double ms(clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); }
+
+int main(int argc, char** argv) {
+  const int n_kf = argc > 1 ? atoi(argv[1]) : 200, n_lm = argc > 2 ? atoi(argv[2]) : 50000;
+  std::mt19937 rng(1);
+  std::normal_distribution<double> N(0.0, 1.0);
+  std::uniform_real_distribution<double> U(0.0, 1.0);
+  Mat<4, 4> T = Mat<4, 4>::Identity();
+  Mat<3, 3> K = Mat<3, 3>::Identity(); K(0, 0) = 458.654; K(1, 1) = 457.296; K(0, 2) = 367.215; K(1, 2) = 248.375;
+  bs_optimizers::GpuGraph graph;
+  const auto t0 = clk::now();
+  std::vector<bs_common::ImuState> st;
+  for (int k = 0; k < n_kf; ++k) {
+    bs_common::ImuState s(fuse_core::Time(0.1 * k), {1, 0, 0, 0}, {0.1 * k + 0.01 * N(rng), 0.01 * N(rng), 0.01 * N(rng)}, {1.0, 0, 0});
+    graph.addVariable(s.Orientation().clone()); graph.addVariable(s.Position().clone()); graph.addVariable(s.Velocity().clone());
+    graph.addVariable(s.GyroBias().clone()); graph.addVariable(s.AccelBias().clone());
+    st.push_back(s);
+  }
+  Mat<15, 15> cov = 1e-4 * Mat<15, 15>::Identity();
+  graph.addConstraint(std::make_shared<bs_constraints::AbsoluteImuState3DStampedConstraint>("prior", st[0], st[0].GetStateVector(), cov));
+  Mat<6, 6> c6 = 1e-2 * Mat<6, 6>::Identity();
+  for (int k = 0; k + 1 < n_kf; ++k)   // stand-in for the IMU chain: relative poses keep the window connected
+    graph.addConstraint(std::make_shared<fuse_constraints::RelativePose3DStampedConstraint>("odom", st[k].Position(), st[k].Orientation(), st[k + 1].Position(),
+                                                                                          st[k + 1].Orientation(), bs_constraints::Vector7d{0.1, 0, 0, 1, 0, 0, 0}, c6));
+  size_t n_obs = 0;
+  for (int j = 0; j < n_lm; ++j) {
+    const int len = 4 + (int)(U(rng) * 9), k0 = (int)(U(rng) * (n_kf - len));
+    const double z = 4.0 + 8.0 * U(rng), x0 = 0.1 * k0 + (U(rng) - 0.3) * 0.8 * z, y = (U(rng) - 0.5) * 0.6 * z;
+    auto lm = bs_variables::Point3DLandmark::make_shared(j);
+    lm->x() = x0 + 0.05 * N(rng); lm->y() = y + 0.05 * N(rng); lm->z() = z + 0.05 * N(rng);
+    graph.addVariable(lm);
+    for (int k = k0; k < k0 + len; ++k) {
+      const double px = x0 - 0.1 * k, u = K(0, 0) * px / z + K(0, 2), v = K(1, 1) * y / z + K(1, 2);
+      auto c = std::make_shared<bs_constraints::EuclideanReprojectionConstraint>("vo", st[k].Orientation(), st[k].Position(), *lm, T, K,
+                                                                              std::array<double, 2>{u + N(rng), v + N(rng)}, 1.0);
+      c->loss(std::make_shared<fuse_loss::CauchyLoss>(5.0));
+      graph.addConstraint(c);
+      ++n_obs;
+    }
+  }
+  const auto t1 = clk::now();
+  std::printf("graph: %zu variables, %zu constraints (%zu reprojection) built in %.0f ms\n", graph.numVariables(), graph.numConstraints(), n_obs, ms(t0, t1));
+  auto opts = ceres_compat::SolverOptions::Vio();
+  opts.max_solver_time_in_seconds = 1e9;
+  for (int rep = 0; rep < 4; ++rep) {
+    const auto a = clk::now();
+    auto s = graph.optimize(opts);
+    const auto b = clk::now();
+    const auto& bs = graph.lastBackendSummary();
+    std::printf("cycle %d: optimize() %.1f ms total | back-end solve %.1f ms (%d it) | host flatten + hand-over + finalize %.1f ms | cost %.4e -> %.4e\n", rep,
+                ms(a, b), 1e3 * bs.total_time_in_seconds, bs.num_iterations, ms(a, b) - 1e3 * bs.total_time_in_seconds, s.initial_cost, s.final_cost);
+    const auto c0 = clk::now();
+    auto copy = graph.clone();   // what fixed_lag_smoother.cpp:308 does every cycle for the publishers
+    std::printf("         Graph::clone() %.1f ms\n", ms(c0, clk::now()));
+  }
+  return 0;
+}

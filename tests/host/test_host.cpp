@@ -113,7 +113,7 @@ static void test_block_order_and_pack() {
   fuse_core::FactorTables t;
   std::map<fuse_core::UUID, int32_t> bi;
   for (size_t i = 0; i < v.size(); ++i) bi[v[i]->uuid()] = (int32_t)i;
-  auto block_of = [&](const fuse_core::UUID& u) { return bi.at(u); };
+  const fuse_core::BlockOf block_of([&](const fuse_core::UUID& u) { return bi.at(u); });
   Mat<4, 4> T = Mat<4, 4>::Identity(); T(0, 3) = 0.1;
   Mat<3, 3> K = Mat<3, 3>::Identity(); K(0, 0) = 458.654; K(1, 1) = 457.296; K(0, 2) = 367.215; K(1, 2) = 248.375;
   bs_common::ImuState s1{fuse_core::Time(1.0)};
