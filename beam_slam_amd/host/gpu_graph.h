@@ -82,7 +82,7 @@ class GpuGraph {
 
   // ---- fuse_core::Graph surface used by the reference ---------------------------------
   void clear() {
-    variables_.clear(); constraints_.clear(); by_variable_.clear(); on_hold_.clear(); order_dirty_ = true;
+    variables_.clear(); constraints_.clear(); by_variable_.clear(); connectivity_valid_ = true; on_hold_.clear(); order_dirty_ = true;
     for (auto& t : tables_) t = TypeTable();
     marginal_rows_.clear();
   }
@@ -99,6 +99,7 @@ class GpuGraph {
   std::vector<const fuse_core::Constraint*> getConnectedConstraints(const fuse_core::UUID& var) const {
     if (!variableExists(var)) throw std::logic_error("getConnectedConstraints: variable not in graph");
     std::vector<const fuse_core::Constraint*> out;
+    ensureConnectivity();
     auto it = by_variable_.find(var);
     if (it != by_variable_.end()) for (const auto& cu : it->second) out.push_back(constraints_.at(cu).c.get());
     return out;
@@ -113,6 +114,7 @@ class GpuGraph {
   bool removeVariable(const fuse_core::UUID& u) {
     auto it = variables_.find(u);
     if (it == variables_.end()) return false;
+    ensureConnectivity();
     auto cit = by_variable_.find(u);
     if (cit != by_variable_.end() && !cit->second.empty()) throw std::logic_error("removeVariable: variable still used by a constraint");
     by_variable_.erase(u); on_hold_.erase(u); variables_.erase(it);
@@ -127,6 +129,7 @@ class GpuGraph {
       if (it == variables_.end()) throw std::logic_error("addConstraint: constraint " + c->type() + " uses a variable that is not in the graph");
       e.vars.push_back(it->second.get());
     }
+    ensureConnectivity();
     for (const auto& u : c->variables()) by_variable_[u].insert(c->uuid());
     const fuse_core::UUID id = c->uuid();
     e.c = std::move(c);
@@ -137,6 +140,7 @@ class GpuGraph {
   bool removeConstraint(const fuse_core::UUID& u) {
     auto it = constraints_.find(u);
     if (it == constraints_.end()) return false;
+    ensureConnectivity();
     for (const auto& v : it->second.c->variables()) by_variable_[v].erase(u);
     removeRow(it->second);
     constraints_.erase(it);
@@ -177,7 +181,8 @@ class GpuGraph {
     }
     g->marginal_rows_ = marginal_rows_;
     order_dirty_ = true;   // the flat indices were borrowed
-    g->by_variable_ = by_variable_; g->on_hold_ = on_hold_;
+    g->connectivity_valid_ = false;   // variable -> constraints index of the copy: rebuilt on first use (publishers rarely need it)
+    g->on_hold_ = on_hold_;
     return g;
   }
   size_t numVariables() const { return variables_.size(); }
@@ -317,6 +322,7 @@ class GpuGraph {
     std::set<fuse_core::UUID> removed_constraints;
     for (const auto& u : to_marginalize) {
       if (!variableExists(u)) throw std::out_of_range("marginalizeVariables: variable not in graph");
+      ensureConnectivity();
       const auto it = by_variable_.find(u);
       if (it != by_variable_.end() && !it->second.empty()) {
         constrained.push_back(u);
@@ -373,7 +379,23 @@ class GpuGraph {
   int device_;
   bsgpu_ctx* ctx_;
   std::map<fuse_core::UUID, fuse_core::Variable::SharedPtr> variables_;
-  struct CEntry { fuse_core::Constraint::SharedPtr c; std::vector<const fuse_core::Variable*> vars; int type = -1; size_t row = 0; };
+  // resolved variables of one constraint: inline up to 10 (the IMU factor), heap only for wide marginal priors
+  struct VarList {
+    const fuse_core::Variable* inl[10];
+    std::vector<const fuse_core::Variable*> big;
+    uint32_t n = 0;
+    void push_back(const fuse_core::Variable* v) {
+      if (n < 10) inl[n] = v;
+      else { if (n == 10) big.assign(inl, inl + 10); big.push_back(v); }
+      ++n;
+    }
+    size_t size() const { return n; }
+    const fuse_core::Variable* const* data() const { return n <= 10 ? inl : big.data(); }
+    const fuse_core::Variable* operator[](size_t i) const { return data()[i]; }
+    const fuse_core::Variable* const* begin() const { return data(); }
+    const fuse_core::Variable* const* end() const { return data() + n; }
+  };
+  struct CEntry { fuse_core::Constraint::SharedPtr c; VarList vars; int type = -1; size_t row = 0; };
   // Packed per-type factor tables, persisted across cycles: a constraint is packed ONCE, when it
   // enters the graph; removal swaps the last row into the hole.  Row order therefore follows the transaction history.
   struct TypeTable {
@@ -398,7 +420,7 @@ class GpuGraph {
     for (size_t i = 0; i < e.vars.size(); ++i) sl[i] = (int32_t)i;
     e.c->pack(fuse_core::BlockOf(sl), t1);
     if (!t1.marginals.empty()) {
-      MarginalRow m; m.e = std::move(t1.marginals[0]); m.vars = e.vars;
+      MarginalRow m; m.e = std::move(t1.marginals[0]); m.vars.assign(e.vars.begin(), e.vars.end());
       marginal_rows_[id] = std::move(m);
       e.type = -2;
       return;
@@ -448,7 +470,14 @@ class GpuGraph {
   std::map<fuse_core::UUID, CEntry> constraints_;
   mutable std::vector<const fuse_core::Variable*> ordered_;   // cached deterministic block order
   mutable bool order_dirty_ = true;
-  std::map<fuse_core::UUID, std::set<fuse_core::UUID>> by_variable_;
+  void ensureConnectivity() const {
+    if (connectivity_valid_) return;
+    by_variable_.clear();
+    for (const auto& kv : constraints_) for (const auto& u : kv.second.c->variables()) by_variable_[u].insert(kv.first);
+    connectivity_valid_ = true;
+  }
+  mutable std::map<fuse_core::UUID, std::set<fuse_core::UUID>> by_variable_;
+  mutable bool connectivity_valid_ = true;
   std::set<fuse_core::UUID> on_hold_;
   bsgpu_summary last_summary_{};
 };
