@@ -821,8 +821,7 @@ void dense_factor_solve(hipStream_t s, const DensePlan& P, const DenseDev& D, do
   dense_factor(s, P, D, S, scal);
   // y' = the rhs row after forward substitution: row rhs_row of the shadow matrix (the rhs tile is an
   // off-diagonal row tile of every panel)
-  (void)hipMemcpyAsync(y, D.Lp + (size_t)P.rhs_row * ld, sizeof(double) * P.T * 64, hipMemcpyDeviceToDevice, s);
-  (void)hipMemsetAsync(y + P.T * 64, 0, sizeof(double) * 64, s);
+  launch_copy(s, D.Lp + (size_t)P.rhs_row * ld, y, (int64_t)P.T * 64, 64);
   // separators (the top of the elimination tree) step by step, then every independent piece in one launch
   for (size_t g = 0; g + 1 < P.bs_sep_step_off.size(); ++g)
     launch_chol_backsolve_step(s, S, D.Lp, D.Vinv, ld, D.bs_sep_panels + P.bs_sep_step_off[g], P.bs_sep_step_off[g + 1] - P.bs_sep_step_off[g],
@@ -866,7 +865,7 @@ enum StepKind { STEP_FIRST = 0, STEP_ACCEPT = 1, STEP_REJECT = 2 };
 void enqueue_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius) {
   hipStream_t s = c->stream;
   if (kind == STEP_ACCEPT)
-    (void)hipMemcpyAsync(c->d_x, c->d_xcand, sizeof(double) * c->h_x.size(), hipMemcpyDeviceToDevice, s);
+    launch_copy(s, c->d_xcand, c->d_x, (int64_t)c->h_x.size(), 0);
   if (kind != STEP_REJECT) eval_all(c, c->d_x, true, SC_COST_X);
   assemble(c, o, radius, kind != STEP_REJECT, kind == STEP_FIRST);
   linear_solve_and_candidate(c, o);
@@ -893,6 +892,7 @@ void build_graphs(bsgpu_ctx* c, const bsgpu_options& o) {
     if (e != hipSuccess) { (void)hipGetLastError(); c->destroy_graphs(); c->graphs_tried = true; return; }
   }
   c->graphs_ok = true;
+  if (getenv("BSGPU_TIMING")) fprintf(stderr, "[bsgpu] LM step captured as hipGraphs\n");
 }
 
 void run_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius) {

@@ -1,6 +1,9 @@
 // Manifold update x (+) delta, gradient norms, and the small deterministic reductions of the LM loop.
 // Plus on quaternion blocks restates fuse's Orientation3DLocalParameterization::Plus, i.e.
 // bs_constraints/src/jacobians.cpp:24-35 (x (x) AngleAxisToQuaternion(delta), right perturbation).
+#include <algorithm>
+#include <cstdint>
+
 #include "bsgpu_device.h"
 
 namespace bsg {
@@ -148,8 +151,36 @@ void launch_final_reduce(hipStream_t s, const ReduceEntry* entries, int n_entrie
   if (n_entries > 0) hipLaunchKernelGGL(final_reduce_kernel, dim3(n_slots), dim3(256), 0, s, entries, n_entries, scal);
 }
 
+// plain kernels instead of hipMemsetAsync / hipMemcpyAsync for the buffers of an LM step: the runtime's fill / copy
+// paths cost ~5.6 us each on the dependent chain (profiles/), and as graph nodes they are what stalls a captured step
+__global__ __launch_bounds__(256) void zero_kernel(double2* __restrict__ p2, int64_t n2, double* __restrict__ tail, int ntail) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += stride) p2[i] = make_double2(0.0, 0.0);
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0.0;
+}
 void launch_zero(hipStream_t s, double* p, int64_t n) {
-  if (n > 0) (void)hipMemsetAsync(p, 0, sizeof(double) * (size_t)n, s);
+  if (n <= 0) return;
+  // p comes from hipMalloc (256-byte aligned) or from an even offset into such a buffer in every caller but the
+  // scalar slots: handle a misaligned head by falling back to scalar stores for tiny ranges
+  if ((reinterpret_cast<uintptr_t>(p) & 15) != 0 || n < 2) {
+    hipLaunchKernelGGL(zero_kernel, dim3(1), dim3(256), 0, s, nullptr, 0, p, (int)std::min<int64_t>(n, 256));
+    if (n > 256) (void)hipMemsetAsync(p + 256, 0, sizeof(double) * (size_t)(n - 256), s);
+    return;
+  }
+  const int64_t n2 = n / 2;
+  const int grid = (int)std::min<int64_t>((n2 + 255) / 256, 2048);
+  hipLaunchKernelGGL(zero_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<double2*>(p), n2, p + 2 * n2, (int)(n - 2 * n2));
+}
+__global__ __launch_bounds__(256) void copy_kernel(const double* __restrict__ src, double* __restrict__ dst, int64_t n, int nzero_after) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+  if (blockIdx.x == 0 && (int)threadIdx.x < nzero_after) dst[n + threadIdx.x] = 0.0;
+}
+// dst[0..n) = src[0..n), then nzero_after zeros
+void launch_copy(hipStream_t s, const double* src, double* dst, int64_t n, int nzero_after) {
+  if (n <= 0) return;
+  const int grid = (int)std::min<int64_t>((n + 255) / 256, 1024);
+  hipLaunchKernelGGL(copy_kernel, dim3(grid), dim3(256), 0, s, src, dst, n, nzero_after);
 }
 
 __global__ void negate_kernel(int n, const double* __restrict__ y, double* __restrict__ d) {
