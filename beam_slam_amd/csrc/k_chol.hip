@@ -62,8 +62,8 @@ BSG_DEV void store_d(double* s, int ld, int lane, double4_t v) {
 BSG_DEV double fast_rsqrt(double d) {
   double y = __builtin_amdgcn_rsq(d);
   double t = fma(-d * y, y, 1.0);           // 1 - d y^2
-  y = fma(y * t, fma(t, 0.375, 0.5), y);    // y (1 + t/2 + 3 t^2/8)
-  t = fma(-d * y, y, 1.0);
+  y = fma(y * t, fma(t, 0.375, 0.5), y);    // y (1 + t/2 + 3 t^2/8): cubic, 2^-26 -> below 2^-53
+  t = fma(-d * y, y, 1.0);                  // one linear step takes out the rounding of the cubic one
   y = fma(y * t, 0.5, y);
   return y;
 }
@@ -72,34 +72,52 @@ BSG_DEV double fast_rsqrt(double d) {
 // diagonal blocks go to sV (4 x 16 x 16, row-major, lower), the 64 reciprocal pivots to sInvD.
 // Whole workgroup (256 threads).  Columns >= nreal (rhs row, padding) are unit pivots.
 // Returns (in every thread) whether a non-positive / non-finite pivot was met.
-BSG_DEV bool potrf64_lds(double* sC, double* sV, double* sInvD /* 64 */, int tid, int nreal) {
+template <bool PROBE = false>
+BSG_DEV bool potrf64_lds(double* sC, double* sV, double* sInvD /* 64 */, int tid, int nreal, long long* ts = nullptr) {
   const int lane = tid & 63, wave = tid >> 6;
   bool bad = false;
+  int nts = 0;
+  auto stamp = [&]() { if (PROBE && tid == 0) ts[nts++] = wall_clock64(); };
+  stamp();
 #pragma unroll 1
   for (int b = 0; b < 4; ++b) {
     if (wave == 0) {
       // (1)+(2) right-looking elimination of block column b in registers of one wave: lane l owns tile
       // row 16b + l (the 16 diagonal-block rows first, then every row below), 16 entries each.  The
       // pivot row entries travel by v_readlane from lanes 0..15; rows below get their triangular
-      // solve from the very same updates.
+      // solve from the very same updates.  Straight-line code (selects, no branches) and the NEXT pivot's
+      // reciprocal square root started before the remaining updates of the current one, so that its
+      // dependent chain overlaps with their issue slots.
       const int nrows = NB - 16 * b;
       const int row = 16 * b + ((lane < nrows) ? lane : 0);
       double* R = sC + row * LDT + 16 * b;
       double a[16];
 #pragma unroll
       for (int c = 0; c < 16; ++c) a[c] = R[c];
+      // the rhs row's own diagonal entry has collected -|y'|^2 from the trailing updates: unit pivot
+      // columns >= nreal: pivot forced to 1 by a select on d (rsqrt(1) == 1 exactly), no branch anywhere
+      bool real = (16 * b) < nreal;
+      double draw = readlane_d(a[0], 0);
+      double d = real ? draw : 1.0;
+      if (!(d > 0.0) || !(d < 1.7e308)) bad = true;
+      double inv = fast_rsqrt(d);
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const bool real = (16 * b + j) < nreal;
-        // the rhs row's own diagonal entry has collected -|y'|^2 from the trailing updates: unit pivot
-        const double d = real ? readlane_d(a[j], j) : 1.0;
-        if (!real) a[j] = (lane == j) ? 1.0 : 0.0;
-        if (!(d > 0.0) || !(d < 1.7e308)) bad = true;
-        const double inv = real ? fast_rsqrt(d) : 1.0;
+        const double unit = (lane == j) ? 1.0 : 0.0;
+        a[j] = real ? a[j] : unit;
         if (lane == 0) sInvD[16 * b + j] = inv;
         a[j] = a[j] * inv;
+        if (j < 15) {
+          const double l1 = readlane_d(a[j], j + 1);
+          a[j + 1] = fma(-a[j], l1, a[j + 1]);
+          real = (16 * b + j + 1) < nreal;
+          draw = readlane_d(a[j + 1], j + 1);
+          d = real ? draw : 1.0;
+          if (!(d > 0.0) || !(d < 1.7e308)) bad = true;
+          inv = fast_rsqrt(d);
+        }
 #pragma unroll
-        for (int c = j + 1; c < 16; ++c) {
+        for (int c = j + 2; c < 16; ++c) {
           const double lc = readlane_d(a[j], c);
           a[c] = fma(-a[j], lc, a[c]);
         }
@@ -110,6 +128,7 @@ BSG_DEV bool potrf64_lds(double* sC, double* sV, double* sInvD /* 64 */, int tid
       }
     }
     __syncthreads();
+    stamp();
     // (3) trailing update C_rc -= X_rb X_cb^T for b < c <= r <= 3 (MFMA, one 16x16 block per wave pass)
     const int nb = 3 - b;
     const int npairs = nb * (nb + 1) / 2;
@@ -124,6 +143,7 @@ BSG_DEV bool potrf64_lds(double* sC, double* sV, double* sInvD /* 64 */, int tid
       store_d(Cblk, LDT, lane, acc);
     }
     __syncthreads();
+    stamp();
   }
   // inverses of the four diagonal blocks: wave w, lane c < 16 solves L_ww v = e_c
   if (lane < 16) {
@@ -140,6 +160,7 @@ BSG_DEV bool potrf64_lds(double* sC, double* sV, double* sInvD /* 64 */, int tid
     for (int i = 0; i < 16; ++i) sV[wave * 256 + i * 16 + lane] = v[i];
   }
   __syncthreads();
+  stamp();
   return __syncthreads_or(bad ? 1 : 0) != 0;
 }
 
@@ -154,11 +175,18 @@ BSG_DEV void mask_unreal_columns(double* sC, int nreal, int tid) {
 
 BSG_DEV void write_factor(double* S, int ld, int t, const double* sC, const double* sV, const double* sInvD, double* Vinv,
                           int tid) {
-  for (int i = tid; i < NB * NB; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    if (c <= r) S[(size_t)(t * NB + r) * ld + t * NB + c] = sC[r * LDT + c];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int i = tid + 256 * q;
+    const int r = i >> 5, c2 = (i & 31) * 2;
+    if (c2 + 1 <= r) *reinterpret_cast<double2*>(&S[(size_t)(t * NB + r) * ld + t * NB + c2]) = *reinterpret_cast<const double2*>(&sC[r * LDT + c2]);
+    else if (c2 <= r) S[(size_t)(t * NB + r) * ld + t * NB + c2] = sC[r * LDT + c2];
   }
-  for (int i = tid; i < 4 * 256; i += 256) Vinv[(size_t)t * kVinvStride + i] = sV[i];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int i = (tid + 256 * q) * 2;
+    *reinterpret_cast<double2*>(&Vinv[(size_t)t * kVinvStride + i]) = *reinterpret_cast<const double2*>(&sV[i]);
+  }
   if (tid < NB) Vinv[(size_t)t * kVinvStride + 1024 + tid] = sInvD[tid];
 }
 
@@ -172,9 +200,21 @@ __global__ __launch_bounds__(256) void chol_potrf_tiles_kernel(double* __restric
   __shared__ double sInvD[NB];
   const int tid = threadIdx.x;
   const int t = tiles[blockIdx.x];
-  for (int i = tid; i < NB * NB; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    sC[r * LDT + c] = (c <= r) ? S[(size_t)(t * NB + r) * ld + t * NB + c] : 0.0;
+  // all sixteen 16-byte loads of a thread are issued before the first one is consumed (a loop with the
+  // triangle test inside serialises them: 16 round trips to L2 / HBM, ~7 us for a 32 KB tile)
+  double2 v[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int i = tid + 256 * q;
+    const int r = i >> 5, c2 = (i & 31) * 2;
+    v[q] = *reinterpret_cast<const double2*>(&S[(size_t)(t * NB + r) * ld + t * NB + c2]);
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int i = tid + 256 * q;
+    const int r = i >> 5, c2 = (i & 31) * 2;
+    sC[r * LDT + c2] = (c2 <= r) ? v[q].x : 0.0;
+    sC[r * LDT + c2 + 1] = (c2 + 1 <= r) ? v[q].y : 0.0;
   }
   __syncthreads();
   mask_unreal_columns(sC, nreal[t], tid);

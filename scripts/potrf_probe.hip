@@ -1,0 +1,39 @@
+// One-off probe: wall-clock stamps (100 MHz counter) inside potrf64_lds.  hipcc --offload-arch=gfx950 -O3 -I include -I beam_slam_amd/csrc scripts/potrf_probe.hip -o /tmp/potrf_probe
+#include <cstdio>
+#include <vector>
+#include <hip/hip_runtime.h>
+#include "../beam_slam_amd/csrc/k_chol.hip"
+namespace bsg {
+__global__ __launch_bounds__(256) void probe_kernel(double* S, int ld, long long* ts) {
+  __shared__ double sC[NB * LDT];
+  __shared__ double sV[4 * 256];
+  __shared__ double sInvD[NB];
+  const int tid = threadIdx.x;
+  long long t0 = wall_clock64();
+  for (int i = tid; i < NB * NB; i += 256) { const int r = i >> 6, c = i & 63; sC[r * LDT + c] = (c <= r) ? S[(size_t)r * ld + c] : 0.0; }
+  __syncthreads();
+  if (tid == 0) ts[0] = t0;
+  potrf64_lds<true>(sC, sV, sInvD, tid, 64, ts + 1);
+  for (int i = tid; i < NB * NB; i += 256) { const int r = i >> 6, c = i & 63; if (c <= r) S[(size_t)r * ld + c] = sC[r * LDT + c]; }
+  __syncthreads();
+  if (tid == 0) ts[15] = wall_clock64();
+}
+}
+int main() {
+  const int n = 64;
+  std::vector<double> A(n * n);
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) A[i * n + j] = (i == j ? 70.0 : 0.0) + 1.0 / (1 + abs(i - j));
+  double* d; long long* ts;
+  hipMalloc(&d, sizeof(double) * n * n); hipMalloc(&ts, sizeof(long long) * 16);
+  for (int rep = 0; rep < 3; ++rep) {
+    hipMemcpy(d, A.data(), sizeof(double) * n * n, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(bsg::probe_kernel, dim3(1), dim3(256), 0, 0, d, n, ts);
+    hipDeviceSynchronize();
+    long long h[16];
+    hipMemcpy(h, ts, sizeof(h), hipMemcpyDeviceToHost);
+    printf("rep %d (10 ns ticks since kernel start): load %lld |", rep, h[1] - h[0]);
+    for (int b = 0; b < 4; ++b) printf(" elim%d %lld upd%d %lld |", b, h[2 + 2 * b] - h[1 + 2 * b], b, h[3 + 2 * b] - h[2 + 2 * b]);
+    printf(" inverses %lld | store %lld | total %lld\n", h[10] - h[9], h[15] - h[10], h[15] - h[0]);
+  }
+  return 0;
+}
