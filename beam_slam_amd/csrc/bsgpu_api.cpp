@@ -84,6 +84,7 @@ struct bsgpu_ctx {
   std::vector<uint8_t> is_lm;
   int n_pose = 0, n_lm = 0, n_tan = 0, npad = 0, n_res = 0;
   int row0[BSGPU_F_NUM_TYPES] = {0};
+  bool vis_any_inactive = false; // some reprojection factor has q, p and landmark all constant
   std::vector<int> vis_src;      // sorted visual position -> (type<<28 | index in its host group)
   std::vector<HostMarginal> marginals;
   struct MargCtx { MargDev dev; int row0 = 0; bool active = true; double *part = nullptr, *part_cand = nullptr, *part_mcc = nullptr; };
@@ -297,6 +298,7 @@ int finalize(bsgpu_ctx* c) {
   struct VF { int xq, xp, xl, bq, bp, meta_cam, loss, flags, lm, src; double u, v, w; };
   std::vector<VF> vf;
   c->any_inactive = false;
+  c->vis_any_inactive = false;
   c->groups[T_REPROJ_DENSE] = HostGroup();
   c->dense_src.clear();
   for (int t = 0; t <= 1; ++t) {
@@ -333,7 +335,7 @@ int finalize(bsgpu_ctx* c) {
       e.loss = get_loss(g.loss_kind[f], g.loss_a[f]);
       e.flags = (c->is_const[idx[0]] ? kFlagQConst : 0) | (c->is_const[idx[1]] ? kFlagPConst : 0) |
                 (c->is_const[idx[2]] ? kFlagLConst : 0);
-      if (e.flags == 7) c->any_inactive = true;
+      if (e.flags == 7) { c->any_inactive = true; c->vis_any_inactive = true; }
       e.lm = lm_index[idx[2]];
       e.src = (t << 28) | f;
       if (e.lm < 0 && !c->is_const[idx[2]]) {
@@ -956,8 +958,10 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
       launch_marg_eval(s, mc.dev, c->d_x, false, mc.part);
       launch_sum(s, mc.part, mc.dev.rows, c->d_scal + SC_FIXED_COST, 1);
     }
-    // (visual factors with q, p and landmark all constant are not counted: they cannot occur in a
-    //  fixed-lag window — noted in DESIGN.md)
+    if (c->vis_any_inactive) {   // reprojection factors whose three blocks are all constant
+      launch_reproj_eval(s, c->vis, c->d_x, c->d_cams, c->d_losses, false, c->vis.cost_part_cand, true);
+      launch_sum(s, c->vis.cost_part_cand, c->vis.n_cost_part, c->d_scal + SC_FIXED_COST, 1);
+    }
   }
   double radius = o.initial_trust_region_radius, decrease_factor = 2.0;
   build_graphs(c, o);
@@ -1239,6 +1243,10 @@ int bsgpu_evaluate(bsgpu_ctx* c, double* cost, double* residuals, double* gradie
       if (mc.active) continue;
       launch_marg_eval(s, mc.dev, c->d_x, false, mc.part);
       launch_sum(s, mc.part, mc.dev.rows, c->d_scal + SC_FIXED_COST, 1);
+    }
+    if (c->vis_any_inactive) {   // reprojection factors whose three blocks are all constant
+      launch_reproj_eval(s, c->vis, c->d_x, c->d_cams, c->d_losses, false, c->vis.cost_part_cand, true);
+      launch_sum(s, c->vis.cost_part_cand, c->vis.n_cost_part, c->d_scal + SC_FIXED_COST, 1);
     }
   }
   eval_all(c, c->d_x, true, SC_COST_X);

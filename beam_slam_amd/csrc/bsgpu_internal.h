@@ -116,7 +116,7 @@ struct LaunchCtx {
 
 // ---- kernel launchers (bsgpu_kernels.hip) ----------------------------------------------------------
 void launch_reproj_eval(hipStream_t s, const Visual& v, const double* x, const DevCamera* cams,
-                        const DevLoss* losses, bool with_J, double* cost_part_out);
+                        const DevLoss* losses, bool with_J, double* cost_part_out, bool count_inactive = false);
 void launch_small_eval(hipStream_t s, const SmallGroup& g, const double* x, const DevLoss* losses, bool with_J,
                        double* cost_part /* n doubles: per-factor cost */);
 void launch_landmark(hipStream_t s, const Visual& v, int n_pose, const double* radius_ptr, int compute_scale,

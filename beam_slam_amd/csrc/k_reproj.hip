@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void reproj_eval_kernel(int n, const int4* __r
                                                           const DevCamera* __restrict__ cams,
                                                           const DevLoss* __restrict__ losses,
                                                           double2* __restrict__ r_out, double* __restrict__ J_out,
-                                                          double* __restrict__ cost_part) {
+                                                          double* __restrict__ cost_part, int count_inactive) {
   __shared__ __attribute__((aligned(16))) double sJ[WITH_J ? 4 * 64 * 18 : 4];
   __shared__ double sred[4];
   const int f = blockIdx.x * 256 + threadIdx.x;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void reproj_eval_kernel(int n, const int4* __r
     const double rho = loss_eval(losses[loss_id], s, &rho1);
     const double sc = sqrt(rho1);
     const bool active = flags != (kFlagQConst | kFlagPConst | kFlagLConst);
-    cost = active ? 0.5 * rho : 0.0;
+    cost = (active != (count_inactive != 0)) ? 0.5 * rho : 0.0;   // count_inactive: the fixed-cost pass (all three blocks constant)
     if (WITH_J) r_out[f] = make_double2(r0 * sc, r1 * sc);  // a cost-only pass must not disturb r of the current point
     if (WITH_J) {
       // Jpi (jacobians.cpp:202-214), M = Jpi R_cb (2x3), scaled by the corrector and the weight
@@ -123,19 +123,19 @@ __global__ __launch_bounds__(256) void reproj_eval_kernel(int n, const int4* __r
 }
 
 void launch_reproj_eval(hipStream_t s, const Visual& v, const double* x, const DevCamera* cams,
-                        const DevLoss* losses, bool with_J, double* cost_part_out) {
+                        const DevLoss* losses, bool with_J, double* cost_part_out, bool count_inactive) {
   if (v.n == 0) return;
   const int grid = (v.n + 255) / 256;
   if (with_J)
     hipLaunchKernelGGL(reproj_eval_kernel<true>, dim3(grid), dim3(256), 0, s, v.n, v.fac, v.pix, v.w, x, cams, losses,
-                       v.r, v.J, cost_part_out);
+                       v.r, v.J, cost_part_out, count_inactive ? 1 : 0);
   else
     hipLaunchKernelGGL(reproj_eval_kernel<false>, dim3(grid), dim3(256), 0, s, v.n, v.fac, v.pix, v.w, x, cams, losses,
-                       v.r, v.J, cost_part_out);
+                       v.r, v.J, cost_part_out, count_inactive ? 1 : 0);
 }
 void launch_reproj_jacobian_only(hipStream_t s, const Visual& v, const double* x, const DevCamera* cams,
                                  const DevLoss* losses) {
-  launch_reproj_eval(s, v, x, cams, losses, true, v.cost_part);
+  launch_reproj_eval(s, v, x, cams, losses, true, v.cost_part, false);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -1,0 +1,144 @@
+"""Degenerate shapes of the solve path, HIP vs oracle: empty / ragged inputs, everything constant, a single factor,
+landmarks seen once (rank-deficient H_ll kept solvable only by the LM diagonal), zero iterations, non-finite input,
+tile boundaries of the reduced system."""
+import numpy as np
+import pytest
+
+from beam_slam_amd import capi, synthetic
+from beam_slam_amd.problem import Problem
+from helpers import mixed_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(pr, oracle_cls, gpu_solver_cls):
+    g, o = gpu_solver_cls(0), oracle_cls()
+    pr.load(g); pr.load(o)
+    return g, o
+
+
+def _same_solve(g, o, opt=None, tol_x=1e-7):
+    sg, so = g.solve(opt), o.solve(opt)
+    assert sg.termination_type == so.termination_type
+    assert [i.step_is_successful for i in g.iterations()] == [i.step_is_successful for i in o.iterations()]
+    assert abs(sg.final_cost - so.final_cost) <= 1e-6 * max(so.final_cost, 1e-30)
+    assert np.abs(g.get_blocks() - o.get_blocks()).max() <= tol_x
+    return sg, so
+
+
+def test_blocks_without_factors_is_an_error_free_noop(oracle_cls, gpu_solver_cls):
+    pr = Problem()
+    pr.add_block([1.0, 2.0, 3.0]); pr.add_quat([1.0, 0, 0, 0])
+    g, o = _both(pr, oracle_cls, gpu_solver_cls)
+    sg, so = g.solve(), o.solve()
+    assert sg.termination_type == so.termination_type == capi.CONVERGENCE
+    assert sg.initial_cost == sg.final_cost == 0.0
+    assert np.array_equal(g.get_blocks(), pr.values)
+
+
+def test_no_blocks_at_all_is_rejected(gpu_solver_cls):
+    g = gpu_solver_cls(0)
+    with pytest.raises(capi.SolverError) as e:
+        g.finalize()
+    assert e.value.code == capi.ERR_INVALID
+
+
+def test_all_poses_constant_pure_triangulation(oracle_cls, gpu_solver_cls):
+    """Every pose block held constant: the reduced camera system is EMPTY (n_pose = 0), only landmarks move."""
+    pr = synthetic.vio_window(n_kf=5, n_lm=30, seed=9, track_min=3, track_max=5, with_imu=False)
+    for b in pr.meta["kf_blocks"].ravel():
+        pr.is_const[int(b)] = 1
+    g, o = _both(pr, oracle_cls, gpu_solver_cls)
+    g.finalize(); o.finalize()
+    assert g.num_parameters_tangent() == o.num_parameters_tangent() == 3 * 30
+    sg, so = _same_solve(g, o)
+    assert sg.final_cost < sg.initial_cost     # (the fixed, perturbed poses bound what triangulation alone can gain)
+    x = g.get_blocks()
+    for b in pr.meta["kf_blocks"].ravel():
+        assert np.array_equal(pr.block(int(b), x), pr.block(int(b)))
+
+
+def test_everything_constant_gives_fixed_cost_only(oracle_cls, gpu_solver_cls):
+    pr = mixed_problem(2, n_state=3, n_lm=6, consistent=True)
+    pr.is_const = [1] * pr.n_blocks
+    g, o = _both(pr, oracle_cls, gpu_solver_cls)
+    cg, co = g.evaluate(gradient=False)[0], o.evaluate(gradient=False)[0]
+    assert abs(cg - co) <= 1e-12 * co
+    sg, so = g.solve(), o.solve()
+    assert sg.num_parameters_tangent == so.num_parameters_tangent == 0
+    assert abs(sg.final_cost - so.final_cost) <= 1e-12 * so.final_cost and abs(sg.fixed_cost - so.fixed_cost) <= 1e-12 * so.fixed_cost
+    assert np.array_equal(g.get_blocks(), pr.values)
+
+
+def test_single_factor(oracle_cls, gpu_solver_cls):
+    pr = Problem()
+    b = pr.add_block([0.3, -0.2, 0.9])
+    A = synthetic.sqrt_information_upper(np.diag([0.1, 0.2, 0.3]))
+    pr.add_factors(capi.F_ABS_VEC3, [[b]], [np.concatenate([[1.0, 2.0, 3.0], A.ravel()])])
+    g, o = _both(pr, oracle_cls, gpu_solver_cls)
+    _same_solve(g, o, tol_x=1e-9)
+    assert np.abs(g.get_blocks() - [1.0, 2.0, 3.0]).max() < 1e-6
+
+
+def test_landmarks_seen_once_and_twice(oracle_cls, gpu_solver_cls):
+    """A landmark with ONE observation has a rank-2 H_ll: only the LM diagonal (min_lm_diagonal 1e-6) keeps its 3x3 system
+    solvable, exactly as in Ceres; ragged track lengths 1..5 in one window."""
+    pr = synthetic.vio_window(n_kf=6, n_lm=50, seed=21, track_min=1, track_max=5)
+    idx = np.concatenate([c[0] for c in pr.factors[capi.F_REPROJ]])
+    counts = np.bincount(idx[:, 2])[pr.meta["lm_blocks"]]
+    assert counts.min() == 1 and counts.max() >= 4
+    g, o = _both(pr, oracle_cls, gpu_solver_cls)
+    sg, so = g.solve(), o.solve()
+    assert sg.is_solution_usable == so.is_solution_usable == 1
+    assert abs(sg.final_cost - so.final_cost) <= 1e-6 * so.final_cost
+
+
+def test_zero_iterations(oracle_cls, gpu_solver_cls):
+    pr = mixed_problem(1, consistent=True)
+    g, o = _both(pr, oracle_cls, gpu_solver_cls)
+    opt = g.options_default()
+    opt.max_num_iterations = 0
+    sg, so = g.solve(opt), o.solve(opt)
+    assert sg.termination_type == so.termination_type == capi.NO_CONVERGENCE
+    assert sg.num_iterations == so.num_iterations == 0
+    assert abs(sg.final_cost - so.final_cost) <= 1e-12 * so.final_cost and sg.final_cost == sg.initial_cost
+    assert np.array_equal(g.get_blocks(), pr.values)
+
+
+def test_non_finite_input_fails_loudly(oracle_cls, gpu_solver_cls):
+    """NaN in a parameter block: ceres::Solve returns FAILURE / unusable solution (the reference's fatal path,
+    fixed_lag_smoother.cpp:286-295) — never a silent 'converged'."""
+    pr = mixed_problem(1, consistent=True)
+    v = pr.values.copy()
+    v[pr.offset[int(pr.meta["states"][1, 1])]] = np.nan
+    pr.values = v
+    g, o = _both(pr, oracle_cls, gpu_solver_cls)
+    sg, so = g.solve(), o.solve()
+    assert sg.termination_type == so.termination_type == capi.FAILURE
+    assert sg.is_solution_usable == so.is_solution_usable == 0
+
+
+@pytest.mark.parametrize("n_kf", [4, 5, 9])
+def test_reduced_system_at_tile_boundaries(oracle_cls, gpu_solver_cls, n_kf):
+    """15 tangent dims per keyframe: n_pose = 60 (inside one 64-wide tile), 75 (one full + one partial tile) and 135."""
+    pr = synthetic.vio_window(n_kf=n_kf, n_lm=40, seed=30 + n_kf, track_min=2, track_max=min(4, n_kf))
+    g, o = _both(pr, oracle_cls, gpu_solver_cls)
+    g.finalize()
+    assert g.tangent_offset(int(pr.meta["lm_blocks"][0])) == 15 * n_kf
+    _same_solve(g, o, tol_x=1e-6)
+
+
+def test_exactly_one_tile(oracle_cls, gpu_solver_cls):
+    """n_pose == 64 exactly: the last real column is the last column of a tile."""
+    pr = synthetic.vio_window(n_kf=4, n_lm=40, seed=77, track_min=2, track_max=4)      # 60 dims ...
+    extra = pr.add_block([0.1, 0.2, 0.3]); one = pr.add_block([0.5])                    # ... + 3 + 1
+    A3, A1 = synthetic.sqrt_information_upper(0.1 * np.eye(3)), np.array([[2.0]])
+    pr.add_factors(capi.F_ABS_VEC3, [[extra]], [np.concatenate([[0.0, 0.0, 0.0], A3.ravel()])])
+    # a 1-d block enters through a marginal (dense linear) prior: r = 2 (x - 0.25)
+    pr.add_marginal([one], A1, [0.0], [0.25])
+    g, o = _both(pr, oracle_cls, gpu_solver_cls)
+    g.finalize()
+    assert g.tangent_offset(int(pr.meta["lm_blocks"][0])) == 64
+    _same_solve(g, o, tol_x=1e-6)
+    x = g.get_blocks()
+    assert abs(x[pr.offset[one]] - 0.25) < 1e-9
