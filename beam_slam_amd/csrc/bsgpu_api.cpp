@@ -828,8 +828,10 @@ void dense_factor_solve(hipStream_t s, const DensePlan& P, const DenseDev& D, do
   for (size_t g = 0; g + 1 < P.bs_sep_step_off.size(); ++g)
     launch_chol_backsolve_step(s, S, D.Lp, D.Vinv, ld, D.bs_sep_panels + P.bs_sep_step_off[g], P.bs_sep_step_off[g + 1] - P.bs_sep_step_off[g],
                                D.rows_flat, D.nreal, y);
+  int max_len = 1;
+  for (size_t i = 0; i < P.chain_begin.size(); ++i) max_len = std::max(max_len, P.chain_end[i] - P.chain_begin[i]);
   launch_chol_backsolve_chains(s, S, D.Lp, D.Vinv, ld, D.panels, D.panel_of_tile, D.chain_begin, D.chain_end, (int)P.chain_begin.size(),
-                               D.rows_flat, D.nreal, y);
+                               D.rows_flat, D.nreal, y, P.npad, max_len);
 }
 
 void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {

@@ -352,24 +352,44 @@ void launch_chol_panel_step(hipStream_t s, double* S, double* Lp, int ld, const 
 //   solve L_kk^T y_k = rhs                              (one wave, v_readlane chain, reciprocal pivots)
 // y is in S (solver) order; rows >= nreal of a tile are kept zero.
 // ---------------------------------------------------------------------------------------------------
-BSG_DEV void backsolve_panel(const PanelDesc pd, const double* __restrict__ S, const double* __restrict__ Lp,
-                             const double* __restrict__ Vinv, int ld, const int* __restrict__ rows_flat,
-                             const int* __restrict__ nreal, double* __restrict__ y, double* sL, double* sp, int tid) {
+// The back-substitution is latency work: per panel a handful of dependent round trips to L2 / HBM.  So every load a
+// panel needs is put in flight at once — the L_kk tile, and the row-tile entries in chunks of CH tiles (a loop that
+// loads and consumes one row tile at a time pays one round trip per tile) — and the piece-walking kernel keeps y and
+// its panels' descriptors / row lists in LDS, so that nothing but L is fetched inside the walk.
+constexpr int kBsChunk = 6;
+BSG_DEV void backsolve_panel(int kb, const int* rows /* n_rows row tiles (LDS or global) */, int n_rows, int nr, const double* S,
+                             const double* Lp, const double* Vinv, int ld, const double* ysrc /* LDS copy or global y */,
+                             double* y, double* sy /* LDS copy of y to keep current, or nullptr */, double* sL, double* sp, int tid) {
   const int c = tid & 63, part = tid >> 6;
-  const int kb = pd.k, c0 = kb * NB, nr = nreal[kb];
+  const int c0 = kb * NB;
+  double dl[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int i = tid + 1024 * q;
     const int r = i >> 6, cc = i & 63;
-    sL[r * (NB + 1) + cc] = (cc <= r) ? S[(size_t)(c0 + r) * ld + c0 + cc] : 0.0;
+    dl[q] = (cc <= r) ? S[(size_t)(c0 + r) * ld + c0 + cc] : 0.0;
   }
+  const double invd = (tid < NB) ? Vinv[(size_t)kb * kVinvStride + 1024 + tid] : 0.0;
   double acc = 0.0;
-  for (int q = 0; q < pd.n_rows; ++q) {
-    const int r0 = rows_flat[pd.row_off + q] * NB + 4 * part;
-    const double l0 = Lp[(size_t)(r0 + 0) * ld + c0 + c], l1 = Lp[(size_t)(r0 + 1) * ld + c0 + c];
-    const double l2 = Lp[(size_t)(r0 + 2) * ld + c0 + c], l3 = Lp[(size_t)(r0 + 3) * ld + c0 + c];
-    acc = fma(l0, y[r0], acc); acc = fma(l1, y[r0 + 1], acc);
-    acc = fma(l2, y[r0 + 2], acc); acc = fma(l3, y[r0 + 3], acc);
+  for (int q0 = 0; q0 < n_rows; q0 += kBsChunk) {
+    double l[kBsChunk][4];
+    int r0[kBsChunk];
+#pragma unroll
+    for (int u = 0; u < kBsChunk; ++u) {
+      const bool ok = q0 + u < n_rows;
+      r0[u] = (ok ? rows[q0 + u] : kb) * NB + 4 * part;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) l[u][i] = ok ? Lp[(size_t)(r0[u] + i) * ld + c0 + c] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < kBsChunk; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc = fma(l[u][i], ysrc[r0[u] + i], acc);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = tid + 1024 * q;
+    sL[(i >> 6) * (NB + 1) + (i & 63)] = dl[q];
   }
   sp[part * NB + c] = acc;
   __syncthreads();
@@ -377,44 +397,64 @@ BSG_DEV void backsolve_panel(const PanelDesc pd, const double* __restrict__ S, c
     double sum = 0.0;
 #pragma unroll
     for (int q = 0; q < 16; ++q) sum += sp[q * NB + tid];
-    double yv = (tid < nr) ? (y[c0 + tid] - sum) : 0.0;
-    const double invd = Vinv[(size_t)kb * kVinvStride + 1024 + tid];
+    double yv = (tid < nr) ? (ysrc[c0 + tid] - sum) : 0.0;
 #pragma unroll
     for (int j = NB - 1; j >= 0; --j) {
       const double yj = readlane_d(yv, j) * readlane_d(invd, j);
       if (tid == j) yv = yj;
       if (tid < j) yv = fma(-sL[j * (NB + 1) + tid], yj, yv);
     }
-    y[c0 + tid] = (tid < nr) ? yv : 0.0;
+    yv = (tid < nr) ? yv : 0.0;
+    y[c0 + tid] = yv;
+    if (sy) sy[c0 + tid] = yv;
   }
 }
 
-__global__ __launch_bounds__(1024) void chol_backsolve_step_kernel(const double* __restrict__ S, const double* __restrict__ Lp,
-                                                                   const double* __restrict__ Vinv, int ld,
+__global__ __launch_bounds__(1024) void chol_backsolve_step_kernel(const double* S, const double* Lp, const double* Vinv, int ld,
                                                                    const PanelDesc* __restrict__ descs,
                                                                    const int* __restrict__ rows_flat,
-                                                                   const int* __restrict__ nreal, double* __restrict__ y) {
+                                                                   const int* __restrict__ nreal, double* y) {
   __shared__ double sL[NB * (NB + 1)];
   __shared__ double sp[16 * NB];
-  backsolve_panel(descs[blockIdx.x], S, Lp, Vinv, ld, rows_flat, nreal, y, sL, sp, threadIdx.x);
+  const PanelDesc pd = descs[blockIdx.x];
+  backsolve_panel(pd.k, rows_flat + pd.row_off, pd.n_rows, nreal[pd.k], S, Lp, Vinv, ld, y, y, nullptr, sL, sp, threadIdx.x);
 }
 
 // one workgroup per independent piece of the nested-dissection ordering, walking its panels from the
 // separator end down to its first tile (everything a piece depends on — its separators — is solved already)
-__global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double* __restrict__ S, const double* __restrict__ Lp,
-                                                                    const double* __restrict__ Vinv, int ld,
+constexpr int kBsMaxRows = 16;   // row lists up to this length are staged in LDS
+__global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double* S, const double* Lp, const double* Vinv, int ld,
                                                                     const PanelDesc* __restrict__ panels,
                                                                     const int* __restrict__ panel_of_tile,
                                                                     const int* __restrict__ chain_begin,
                                                                     const int* __restrict__ chain_end,
                                                                     const int* __restrict__ rows_flat,
-                                                                    const int* __restrict__ nreal, double* __restrict__ y) {
-  __shared__ double sL[NB * (NB + 1)];
-  __shared__ double sp[16 * NB];
-  const int b = chain_begin[blockIdx.x], e = chain_end[blockIdx.x];
+                                                                    const int* __restrict__ nreal, double* y, int npad, int max_len) {
+  extern __shared__ __attribute__((aligned(16))) double dyn[];
+  double* sL = dyn;                         // 64 x 65
+  double* sp = sL + NB * (NB + 1);          // 16 x 64
+  double* sy = sp + 16 * NB;                // npad
+  int* s_nrows = reinterpret_cast<int*>(sy + npad);   // max_len
+  int* s_rowoff = s_nrows + max_len;                  // max_len
+  int* s_nr = s_rowoff + max_len;                     // max_len
+  int* s_rows = s_nr + max_len;                       // max_len x kBsMaxRows
+  const int tid = threadIdx.x;
+  const int b = chain_begin[blockIdx.x], e = chain_end[blockIdx.x], len = e - b;
+  for (int i = tid; i < npad; i += 1024) sy[i] = y[i];
+  if (tid < len) {
+    const PanelDesc pd = panels[panel_of_tile[b + tid]];
+    s_nrows[tid] = pd.n_rows; s_rowoff[tid] = pd.row_off; s_nr[tid] = nreal[b + tid];
+  }
+  __syncthreads();
+  for (int i = tid; i < len * kBsMaxRows; i += 1024) {
+    const int p = i / kBsMaxRows, q = i % kBsMaxRows;
+    if (q < s_nrows[p]) s_rows[i] = rows_flat[s_rowoff[p] + q];
+  }
+  __syncthreads();
   for (int k = e - 1; k >= b; --k) {
-    backsolve_panel(panels[panel_of_tile[k]], S, Lp, Vinv, ld, rows_flat, nreal, y, sL, sp, threadIdx.x);
-    __threadfence_block();
+    const int p = k - b, n_rows = s_nrows[p];
+    const int* rows = (n_rows <= kBsMaxRows) ? (s_rows + p * kBsMaxRows) : (rows_flat + s_rowoff[p]);
+    backsolve_panel(k, rows, n_rows, s_nr[p], S, Lp, Vinv, ld, sy, y, sy, sL, sp, tid);
     __syncthreads();
   }
 }
@@ -428,16 +468,23 @@ void launch_chol_backsolve_step(hipStream_t s, const double* S, const double* Lp
 
 void launch_chol_backsolve_chains(hipStream_t s, const double* S, const double* Lp, const double* Vinv, int ld,
                                   const PanelDesc* panels_dev, const int* panel_of_tile_dev, const int* chain_begin_dev,
-                                  const int* chain_end_dev, int n_chains, const int* rows_flat_dev, const int* nreal_dev, double* y) {
+                                  const int* chain_end_dev, int n_chains, const int* rows_flat_dev, const int* nreal_dev, double* y,
+                                  int npad, int max_chain_len) {
   if (n_chains <= 0) return;
-  hipLaunchKernelGGL(chol_backsolve_chain_kernel, dim3(n_chains), dim3(1024), 0, s, S, Lp, Vinv, ld, panels_dev, panel_of_tile_dev,
-                     chain_begin_dev, chain_end_dev, rows_flat_dev, nreal_dev, y);
+  const size_t lds = chol_backsolve_chain_lds(npad, max_chain_len);
+  hipLaunchKernelGGL(chol_backsolve_chain_kernel, dim3(n_chains), dim3(1024), lds, s, S, Lp, Vinv, ld, panels_dev, panel_of_tile_dev,
+                     chain_begin_dev, chain_end_dev, rows_flat_dev, nreal_dev, y, npad, max_chain_len);
 }
 
+size_t chol_backsolve_chain_lds(int npad, int max_chain_len) {
+  return sizeof(double) * (NB * (NB + 1) + 16 * NB + (size_t)npad) + sizeof(int) * (size_t)max_chain_len * (3 + kBsMaxRows);
+}
 int chol_vinv_stride() { return kVinvStride; }
 void chol_prepare() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_panel_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kPanelStepLds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
 }
 
 }  // namespace bsg
