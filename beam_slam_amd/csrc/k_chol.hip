@@ -14,6 +14,8 @@
 // All matrix products run on v_mfma_f64_16x16x4_f64:  a = A[lane&15][lane>>4], b = B[lane>>4][lane&15],
 // d[reg] = D[(lane>>4) + 4 reg][lane&15].  The 16x16 diagonal blocks are factored in registers of one
 // wave (row per lane, v_readlane broadcasts), the only scalar dependent chain left.
+#include <cstring>
+
 #include "bsgpu_device.h"
 #include "dense_plan.h"
 
@@ -245,15 +247,31 @@ BSG_DEV void trsm_tile(double* sA, const double* sL, const double* sV, double* s
   }
 }
 
+// descriptors of the (few) panels of one step and their row-tile lists, passed BY VALUE: they arrive with the kernel
+// arguments instead of costing two dependent round trips to memory before the first tile load can be issued
+constexpr int kStepMaxPanels = 8, kStepMaxRows = 16;
+struct StepArgs {
+  int k[kStepMaxPanels], n_rows[kStepMaxPanels], lookahead[kStepMaxPanels];
+  int rows[kStepMaxPanels][kStepMaxRows];
+};
+
+template <bool KARG>
 __global__ __launch_bounds__(256) void chol_panel_step_kernel(double* __restrict__ S, double* __restrict__ Lp, int ld,
                                                               const PanelDesc* __restrict__ descs,
                                                               const int* __restrict__ rows_flat, const int* __restrict__ nreal,
-                                                              double* __restrict__ Vinv, double* __restrict__ scal) {
-  const PanelDesc pd = descs[blockIdx.z];
-  const int bi = blockIdx.y, bj = blockIdx.x;
-  if (bi >= pd.n_rows || bj > bi) return;
-  const int k = pd.k, lookahead = pd.lookahead;
-  const int* row_tiles = rows_flat + pd.row_off;
+                                                              double* __restrict__ Vinv, double* __restrict__ scal, StepArgs args) {
+  const int bi = blockIdx.y, bj = blockIdx.x, z = blockIdx.z;
+  int k, n_rows, lookahead, ti, tj;
+  if (KARG) {
+    k = args.k[z]; n_rows = args.n_rows[z]; lookahead = args.lookahead[z];
+    if (bi >= n_rows || bj > bi) return;
+    ti = args.rows[z][bi]; tj = args.rows[z][bj];
+  } else {
+    const PanelDesc pd = descs[z];
+    k = pd.k; n_rows = pd.n_rows; lookahead = pd.lookahead;
+    if (bi >= n_rows || bj > bi) return;
+    ti = rows_flat[pd.row_off + bi]; tj = rows_flat[pd.row_off + bj];
+  }
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* sXi = smem;                 // 64 x LDT
   double* sXj = sXi + NB * LDT;       // 64 x LDT
@@ -262,7 +280,6 @@ __global__ __launch_bounds__(256) void chol_panel_step_kernel(double* __restrict
   double* sT = sV + 4 * 256;          // 4 x 16 x 17
   double* sInvD = sT + 4 * 16 * 17;   // 64
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ti = row_tiles[bi], tj = row_tiles[bj];
   const int ri = ti * NB, rj = tj * NB, c0 = k * NB;
   const bool diag = bi == bj;
   // 16-byte loads (ld, c0 and the LDS pitch are all multiples of 2 doubles).  The upper triangle of
@@ -281,12 +298,7 @@ __global__ __launch_bounds__(256) void chol_panel_step_kernel(double* __restrict
     const int i = (tid + 256 * q) * 2;
     *reinterpret_cast<double2*>(&sV[i]) = *reinterpret_cast<const double2*>(&Vinv[(size_t)k * kVinvStride + i]);
   }
-  __syncthreads();
-  trsm_tile(sXi, sL, sV, sT, lane, wave);
-  if (!diag) trsm_tile(sXj, sL, sV, sT, lane, wave);
-  __syncthreads();
-  const double* Xj = diag ? sXi : sXj;
-  // C_ij -= X_i X_j^T ; wave w owns rows 16w.. of the 64x64 tile
+  // C_ij (wave w owns rows 16w.. of the 64x64 tile): fetched now, so that the round trip hides behind the solves
   double4_t acc[4];
   const int crow = lane >> 4, ccol = lane & 15;
 #pragma unroll
@@ -294,6 +306,12 @@ __global__ __launch_bounds__(256) void chol_panel_step_kernel(double* __restrict
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg)
       acc[t][reg] = S[(size_t)(ri + 16 * wave + crow + 4 * reg) * ld + rj + 16 * t + ccol];
+  __syncthreads();
+  trsm_tile(sXi, sL, sV, sT, lane, wave);
+  if (!diag) trsm_tile(sXj, sL, sV, sT, lane, wave);
+  __syncthreads();
+  const double* Xj = diag ? sXi : sXj;
+  // C_ij -= X_i X_j^T
 #pragma unroll
   for (int t = 0; t < 4; ++t)
     acc[t] = mfma_abt<64>(acc[t], sXi + (16 * wave) * LDT, LDT, Xj + (16 * t) * LDT, LDT, -1.0, lane);
@@ -339,10 +357,22 @@ void launch_chol_potrf_tiles(hipStream_t s, double* S, int ld, const int* tiles_
   hipLaunchKernelGGL(chol_potrf_tiles_kernel, dim3(n_tiles), dim3(256), 0, s, S, ld, tiles_dev, nreal_dev, Vinv, scal);
 }
 void launch_chol_panel_step(hipStream_t s, double* S, double* Lp, int ld, const PanelDesc* descs_dev, int n_panels, int max_rows,
-                            const int* rows_flat_dev, const int* nreal_dev, double* Vinv, double* scal) {
+                            const int* rows_flat_dev, const int* nreal_dev, double* Vinv, double* scal, const PanelDesc* descs_host,
+                            const int* rows_flat_host) {
   if (n_panels <= 0 || max_rows <= 0) return;
-  hipLaunchKernelGGL(chol_panel_step_kernel, dim3(max_rows, max_rows, n_panels), dim3(256), kPanelStepLds, s, S, Lp, ld, descs_dev,
-                     rows_flat_dev, nreal_dev, Vinv, scal);
+  StepArgs a;
+  std::memset(&a, 0, sizeof(a));
+  if (descs_host && rows_flat_host && n_panels <= kStepMaxPanels && max_rows <= kStepMaxRows) {
+    for (int p = 0; p < n_panels; ++p) {
+      a.k[p] = descs_host[p].k; a.n_rows[p] = descs_host[p].n_rows; a.lookahead[p] = descs_host[p].lookahead;
+      for (int q = 0; q < descs_host[p].n_rows; ++q) a.rows[p][q] = rows_flat_host[descs_host[p].row_off + q];
+    }
+    hipLaunchKernelGGL(chol_panel_step_kernel<true>, dim3(max_rows, max_rows, n_panels), dim3(256), kPanelStepLds, s, S, Lp, ld, descs_dev,
+                       rows_flat_dev, nreal_dev, Vinv, scal, a);
+  } else {
+    hipLaunchKernelGGL(chol_panel_step_kernel<false>, dim3(max_rows, max_rows, n_panels), dim3(256), kPanelStepLds, s, S, Lp, ld, descs_dev,
+                       rows_flat_dev, nreal_dev, Vinv, scal, a);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -481,7 +511,9 @@ size_t chol_backsolve_chain_lds(int npad, int max_chain_len) {
 }
 int chol_vinv_stride() { return kVinvStride; }
 void chol_prepare() {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_panel_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_panel_step_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)kPanelStepLds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_panel_step_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kPanelStepLds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024);
