@@ -255,12 +255,16 @@ struct StepArgs {
   int rows[kStepMaxPanels][kStepMaxRows];
 };
 
-template <bool KARG>
+template <bool KARG, bool PROBE = false>
 __global__ __launch_bounds__(256) void chol_panel_step_kernel(double* __restrict__ S, double* __restrict__ Lp, int ld,
                                                               const PanelDesc* __restrict__ descs,
                                                               const int* __restrict__ rows_flat, const int* __restrict__ nreal,
-                                                              double* __restrict__ Vinv, double* __restrict__ scal, StepArgs args) {
+                                                              double* __restrict__ Vinv, double* __restrict__ scal, StepArgs args,
+                                                              long long* probe_ts = nullptr) {
   const int bi = blockIdx.y, bj = blockIdx.x, z = blockIdx.z;
+  int nts = 0;   // PROBE: wall-clock stamps of workgroup (0,0) for scripts/potrf_probe.hip
+  auto stamp = [&]() { if (PROBE && bi == 0 && bj == 0 && threadIdx.x == 0) probe_ts[nts++] = wall_clock64(); };
+  stamp();
   int k, n_rows, lookahead, ti, tj;
   if (KARG) {
     k = args.k[z]; n_rows = args.n_rows[z]; lookahead = args.lookahead[z];
@@ -307,14 +311,17 @@ __global__ __launch_bounds__(256) void chol_panel_step_kernel(double* __restrict
     for (int reg = 0; reg < 4; ++reg)
       acc[t][reg] = S[(size_t)(ri + 16 * wave + crow + 4 * reg) * ld + rj + 16 * t + ccol];
   __syncthreads();
+  stamp();
   trsm_tile(sXi, sL, sV, sT, lane, wave);
   if (!diag) trsm_tile(sXj, sL, sV, sT, lane, wave);
   __syncthreads();
+  stamp();
   const double* Xj = diag ? sXi : sXj;
   // C_ij -= X_i X_j^T
 #pragma unroll
   for (int t = 0; t < 4; ++t)
     acc[t] = mfma_abt<64>(acc[t], sXi + (16 * wave) * LDT, LDT, Xj + (16 * t) * LDT, LDT, -1.0, lane);
+  stamp();
   const bool factor_next = diag && lookahead && ti == k + 1;
   if (!factor_next) {
 #pragma unroll
@@ -343,9 +350,12 @@ __global__ __launch_bounds__(256) void chol_panel_step_kernel(double* __restrict
     for (int i = tid; i < NB * NB; i += 256) { const int r = i >> 6, c = i & 63; if (c > r) sC[r * LDT + c] = 0.0; }
     mask_unreal_columns(sC, nreal[ti], tid);
     __syncthreads();
+    stamp();
     const bool bad = potrf64_lds(sC, sV, sInvD, tid, nreal[ti]);
+    stamp();
     if (bad && tid == 0) scal[SC_CHOL_FAIL] = 1.0;
     write_factor(S, ld, ti, sC, sV, sInvD, Vinv, tid);
+    if (PROBE) { __syncthreads(); stamp(); }
   }
 }
 
