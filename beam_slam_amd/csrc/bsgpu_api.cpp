@@ -615,7 +615,8 @@ int finalize(bsgpu_ctx* c) {
     const int max_chains = e ? std::max(1, atoi(e)) : 4;
     const int T = (c->n_pose + 63) / 64;
     if (c->tile_adj.size() != (size_t)T * T) c->tile_adj.assign((size_t)T * T, 0);
-    c->plan.build(c->n_pose, c->tile_adj, c->dense_ok ? max_chains : 1);
+    const char* e2 = getenv("BSGPU_MIN_PIECE");
+    c->plan.build(c->n_pose, c->tile_adj, c->dense_ok ? max_chains : 1, e2 ? std::max(1, atoi(e2)) : 3);
     c->npad = c->plan.npad;
     std::vector<int> iperm(T + 1, -1);
     for (int t = 0; t < T; ++t) iperm[c->plan.perm[t]] = t;

@@ -40,7 +40,7 @@ struct DensePlan {
   inline int spos(int j) const { return perm[j >> 6] * 64 + (j & 63); }
 
   // adj: T x T symmetric tile adjacency in NATURAL tile order (adj[i*T+j] != 0 iff block (i,j) of S is structurally non-zero)
-  void build(int n_pose_, const std::vector<uint8_t>& adj, int max_chains) {
+  void build(int n_pose_, const std::vector<uint8_t>& adj, int max_chains, int min_piece_w = 3 /* minimum piece length in units of the band width */) {
     n_pose = n_pose_;
     T = (n_pose + 63) / 64;
     npad = (T + 1) * 64;
@@ -52,7 +52,7 @@ struct DensePlan {
     std::vector<int> order;  // S order: list of natural tiles
     chain_begin.clear(); chain_end.clear();
     int chains = 1;
-    if (max_chains > 1 && w >= 1) while (chains * 2 <= max_chains && T >= (chains * 2) * 3 * w + (chains * 2 - 1) * w) chains *= 2;
+    if (max_chains > 1 && w >= 1) while (chains * 2 <= max_chains && T >= (chains * 2) * min_piece_w * w + (chains * 2 - 1) * w) chains *= 2;
     n_chains = chains;
     if (chains == 1) {
       for (int i = 0; i < T; ++i) order.push_back(i);

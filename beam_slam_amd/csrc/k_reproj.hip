@@ -300,7 +300,11 @@ __global__ __launch_bounds__(64) void pairs_kernel(int n_seg, const int* __restr
                                                    int rhs_row, double* __restrict__ grad,
                                                    double* __restrict__ hdiag, const int* __restrict__ perm) {
   __shared__ double sb[64];
-  const int seg = blockIdx.x;
+  // XCD-aware mapping: consecutive workgroup ids go round-robin over the 8 XCDs, each with its own L2.  Segments are
+  // ordered by camera pair (ca, cb), and all segments of one ca gather the same J / CR rows, so every XCD takes a
+  // CONTIGUOUS range of segments: the rows of a camera are then pulled into one L2 instead of eight.
+  const int per_xcd = gridDim.x >> 3;
+  const int seg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (seg >= n_seg) return;
   const int lane = threadIdx.x;
   const int ci = seg_ci[seg], cj = seg_cj[seg];
@@ -392,7 +396,7 @@ __global__ __launch_bounds__(64) void pairs_kernel(int n_seg, const int* __restr
 
 void launch_pairs(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm) {
   if (v.n_seg == 0) return;
-  hipLaunchKernelGGL(pairs_kernel, dim3(v.n_seg), dim3(64), 0, s, v.n_seg, v.seg_ci, v.seg_cj, v.seg_start, v.ent_fa,
+  hipLaunchKernelGGL(pairs_kernel, dim3(8 * ((v.n_seg + 7) / 8)), dim3(64), 0, s, v.n_seg, v.seg_ci, v.seg_cj, v.seg_start, v.ent_fa,
                      v.ent_fb, v.J, v.r, v.CR, v.cp_tq, v.cp_tp, S, ld, rhs_row, grad, hdiag, perm);
 }
 
