@@ -612,11 +612,12 @@ int finalize(bsgpu_ctx* c) {
   // ---- tiled Cholesky plan: nested-dissection tile order, symbolic factorisation, step schedule
   {
     const char* e = getenv("BSGPU_CHAINS");
-    const int max_chains = e ? std::max(1, atoi(e)) : 4;
+    const int max_chains = e ? std::max(1, atoi(e)) : 16;
     const int T = (c->n_pose + 63) / 64;
     if (c->tile_adj.size() != (size_t)T * T) c->tile_adj.assign((size_t)T * T, 0);
     const char* e2 = getenv("BSGPU_MIN_PIECE");
-    c->plan.build(c->n_pose, c->tile_adj, c->dense_ok ? max_chains : 1, e2 ? std::max(1, atoi(e2)) : 3);
+    const char* e3 = getenv("BSGPU_SHARED");   // panels of one step may update the same tiles (atomics): on unless BSGPU_SHARED=0
+    c->plan.build(c->n_pose, c->tile_adj, c->dense_ok ? max_chains : 1, e2 ? std::max(1, atoi(e2)) : 1, !(e3 && atoi(e3) == 0));
     c->npad = c->plan.npad;
     std::vector<int> iperm(T + 1, -1);
     for (int t = 0; t < T; ++t) iperm[c->plan.perm[t]] = t;
@@ -1619,7 +1620,11 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
   std::vector<uint8_t> adj((size_t)T * T, 0);
   for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) if (A[(size_t)i * n + j] != 0.0) adj[(size_t)(i / 64) * T + j / 64] = 1;
   DensePlan P;
-  P.build(n, adj, max_chains);
+  {
+    const char* e2 = getenv("BSGPU_MIN_PIECE");
+    const char* e3 = getenv("BSGPU_SHARED");
+    P.build(n, adj, std::max(1, (int)max_chains), e2 ? std::max(1, atoi(e2)) : 1, !(e3 && atoi(e3) == 0));
+  }
   const int npad = P.npad;
   std::vector<double> hS((size_t)npad * npad, 0.0);
   for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) hS[(size_t)P.spos(i) * npad + P.spos(j)] = A[(size_t)i * n + j];

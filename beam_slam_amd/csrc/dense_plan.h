@@ -19,6 +19,8 @@ struct PanelDesc {  // device-visible
   int row_off;    // into the flat row-tile list
   int n_rows;     // active row tiles below the diagonal (S tile indices, ascending)
   int lookahead;  // the workgroup updating tile (k+1,k+1) also factors it
+  int shared_mask;  // bit q: row tile q of this panel is also a row tile of another panel of the same step, so tiles
+                    // (i, j) with both bits set are accumulated with atomics (two panels update them concurrently)
 };
 
 struct DensePlan {
@@ -40,7 +42,8 @@ struct DensePlan {
   inline int spos(int j) const { return perm[j >> 6] * 64 + (j & 63); }
 
   // adj: T x T symmetric tile adjacency in NATURAL tile order (adj[i*T+j] != 0 iff block (i,j) of S is structurally non-zero)
-  void build(int n_pose_, const std::vector<uint8_t>& adj, int max_chains, int min_piece_w = 3 /* minimum piece length in units of the band width */) {
+  void build(int n_pose_, const std::vector<uint8_t>& adj, int max_chains, int min_piece_w = 1 /* minimum piece length in units of the band width */,
+             bool allow_shared = true /* panels of one step may update the same tiles (atomics) */) {
     n_pose = n_pose_;
     T = (n_pose + 63) / 64;
     npad = (T + 1) * 64;
@@ -115,13 +118,14 @@ struct DensePlan {
         bool conflict = step_rows[s][k] != 0;   // its own diagonal tile / column is still being updated in this step
         // (the rhs tile T is shared by every panel: concurrent panels write disjoint column ranges of its row
         //  and only its never-used diagonal tile is written twice)
-        for (int t : rows[k]) if (t < T && step_rows[s][t]) conflict = true;
+        if (!allow_shared) for (int t : rows[k]) if (t < T && step_rows[s][t]) conflict = true;
+        if (allow_shared && (int)steps[s].size() >= 16) conflict = true;   // descriptor table of a launch (k_chol.hip: kStepMaxPanels)
         if (!conflict) break;
         ++s;
       }
       step_of[k] = s;
       steps[s].push_back(k);
-      for (int t : rows[k]) if (t < T) { step_rows[s][t] = 1; ready[t] = std::max(ready[t], s + 1); }
+      for (int t : rows[k]) if (t < T) { if (step_rows[s][t] < 255) step_rows[s][t]++; ready[t] = std::max(ready[t], s + 1); }
     }
     // look-ahead: panel j may factor tile j+1 iff j+1 is its first row tile and no panel scheduled in the same
     // or a later step also updates tile j+1
@@ -139,6 +143,11 @@ struct DensePlan {
         d.k = k; d.row_off = (int)rows_flat.size(); d.n_rows = (int)rows[k].size();
         const int t = k + 1;
         d.lookahead = (t < T && !rows[k].empty() && rows[k][0] == t && last_updater_step[t] == (int)s && n_updaters_in_last[t] == 1) ? 1 : 0;
+        d.shared_mask = 0;
+        for (size_t q = 0; q < rows[k].size(); ++q) {   // bits 0..30 exact, bit 31 = any later row (conservative)
+          const int rt = rows[k][q];
+          if ((rt < T && step_rows[s][rt] > 1) || (rt == T && steps[s].size() > 1 && allow_shared)) d.shared_mask |= (int)(1u << (q < 31 ? q : 31));
+        }
         if (d.lookahead) factored_by_lookahead[t] = 1;
         rows_flat.insert(rows_flat.end(), rows[k].begin(), rows[k].end());
         mr = std::max(mr, d.n_rows);

@@ -62,12 +62,12 @@ BSG_DEV void store_d(double* s, int ld, int lane, double4_t v) {
 // 1/sqrt(d) to double precision: v_rsq_f64 seed (~2^-26) + two Newton steps, all FMA — keeps the
 // per-column dependent chain of the factorisation short (an IEEE sqrt + divide costs ~3x as much)
 BSG_DEV double fast_rsqrt(double d) {
-  double y = __builtin_amdgcn_rsq(d);
-  double t = fma(-d * y, y, 1.0);           // 1 - d y^2
-  y = fma(y * t, fma(t, 0.375, 0.5), y);    // y (1 + t/2 + 3 t^2/8): cubic, 2^-26 -> below 2^-53
-  t = fma(-d * y, y, 1.0);                  // one linear step takes out the rounding of the cubic one
-  y = fma(y * t, 0.5, y);
-  return y;
+  // v_rsq_f64 seed (relative error ~2^-26) + ONE cubically convergent step, all FMA: the result is within a few ulp.
+  // A second (linear) clean-up step would make it almost correctly rounded, but this sits on the dependent chain of
+  // every pivot of the factorisation, and the reduced system is assembled with more round-off than that.
+  const double y = __builtin_amdgcn_rsq(d);
+  const double t = fma(-d * y, y, 1.0);         // 1 - d y^2
+  return fma(y * t, fma(t, 0.375, 0.5), y);     // y (1 + t/2 + 3 t^2/8)
 }
 
 // Factor the 64x64 tile in sC (lower triangle meaningful, pitch LDT) in place; the four inverse
@@ -249,9 +249,9 @@ BSG_DEV void trsm_tile(double* sA, const double* sL, const double* sV, double* s
 
 // descriptors of the (few) panels of one step and their row-tile lists, passed BY VALUE: they arrive with the kernel
 // arguments instead of costing two dependent round trips to memory before the first tile load can be issued
-constexpr int kStepMaxPanels = 8, kStepMaxRows = 16;
+constexpr int kStepMaxPanels = 16, kStepMaxRows = 16;
 struct StepArgs {
-  int k[kStepMaxPanels], n_rows[kStepMaxPanels], lookahead[kStepMaxPanels];
+  int k[kStepMaxPanels], n_rows[kStepMaxPanels], lookahead[kStepMaxPanels], shared_mask[kStepMaxPanels];
   int rows[kStepMaxPanels][kStepMaxRows];
 };
 
@@ -265,14 +265,14 @@ __global__ __launch_bounds__(256) void chol_panel_step_kernel(double* __restrict
   int nts = 0;   // PROBE: wall-clock stamps of workgroup (0,0) for scripts/potrf_probe.hip
   auto stamp = [&]() { if (PROBE && bi == 0 && bj == 0 && threadIdx.x == 0) probe_ts[nts++] = wall_clock64(); };
   stamp();
-  int k, n_rows, lookahead, ti, tj;
+  int k, n_rows, lookahead, ti, tj, shared_mask;
   if (KARG) {
-    k = args.k[z]; n_rows = args.n_rows[z]; lookahead = args.lookahead[z];
+    k = args.k[z]; n_rows = args.n_rows[z]; lookahead = args.lookahead[z]; shared_mask = args.shared_mask[z];
     if (bi >= n_rows || bj > bi) return;
     ti = args.rows[z][bi]; tj = args.rows[z][bj];
   } else {
     const PanelDesc pd = descs[z];
-    k = pd.k; n_rows = pd.n_rows; lookahead = pd.lookahead;
+    k = pd.k; n_rows = pd.n_rows; lookahead = pd.lookahead; shared_mask = pd.shared_mask;
     if (bi >= n_rows || bj > bi) return;
     ti = rows_flat[pd.row_off + bi]; tj = rows_flat[pd.row_off + bj];
   }
@@ -303,13 +303,15 @@ __global__ __launch_bounds__(256) void chol_panel_step_kernel(double* __restrict
     *reinterpret_cast<double2*>(&sV[i]) = *reinterpret_cast<const double2*>(&Vinv[(size_t)k * kVinvStride + i]);
   }
   // C_ij (wave w owns rows 16w.. of the 64x64 tile): fetched now, so that the round trip hides behind the solves
+  // (a tile another panel of this step also updates is accumulated with atomics: start from zero)
+  const bool shared_tile = ((shared_mask >> (bi < 31 ? bi : 31)) & 1) && ((shared_mask >> (bj < 31 ? bj : 31)) & 1);
   double4_t acc[4];
   const int crow = lane >> 4, ccol = lane & 15;
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg)
-      acc[t][reg] = S[(size_t)(ri + 16 * wave + crow + 4 * reg) * ld + rj + 16 * t + ccol];
+      acc[t][reg] = shared_tile ? 0.0 : S[(size_t)(ri + 16 * wave + crow + 4 * reg) * ld + rj + 16 * t + ccol];
   __syncthreads();
   stamp();
   trsm_tile(sXi, sL, sV, sT, lane, wave);
@@ -327,8 +329,10 @@ __global__ __launch_bounds__(256) void chol_panel_step_kernel(double* __restrict
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg)
-        S[(size_t)(ri + 16 * wave + crow + 4 * reg) * ld + rj + 16 * t + ccol] = acc[t][reg];
+      for (int reg = 0; reg < 4; ++reg) {
+        double* dst = &S[(size_t)(ri + 16 * wave + crow + 4 * reg) * ld + rj + 16 * t + ccol];
+        if (shared_tile) atomicAdd(dst, acc[t][reg]); else *dst = acc[t][reg];
+      }
   }
   if (diag) {
     // this workgroup publishes the L panel of its row tile — into the shadow matrix Lp, NOT in place:
@@ -375,6 +379,7 @@ void launch_chol_panel_step(hipStream_t s, double* S, double* Lp, int ld, const 
   if (descs_host && rows_flat_host && n_panels <= kStepMaxPanels && max_rows <= kStepMaxRows) {
     for (int p = 0; p < n_panels; ++p) {
       a.k[p] = descs_host[p].k; a.n_rows[p] = descs_host[p].n_rows; a.lookahead[p] = descs_host[p].lookahead;
+      a.shared_mask[p] = descs_host[p].shared_mask;
       for (int q = 0; q < descs_host[p].n_rows; ++q) a.rows[p][q] = rows_flat_host[descs_host[p].row_off + q];
     }
     hipLaunchKernelGGL(chol_panel_step_kernel<true>, dim3(max_rows, max_rows, n_panels), dim3(256), kPanelStepLds, s, S, Lp, ld, descs_dev,
