@@ -43,3 +43,14 @@ def test_host_on_gpu_through_libbsgpu(tmp_path):
     cdir = os.path.join(ROOT, "beam_slam_amd", "csrc")
     exe = _build(tmp_path, ["-L" + cdir, "-lbsgpu", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + cdir, "-Wl,-rpath,/opt/rocm/lib"])
     _run(exe)
+
+
+def test_cholesky_plan_executed_on_the_host(tmp_path):
+    """beam_slam_amd/csrc/dense_plan.h (tile order, symbolic fill, concurrent-panel schedule with shared tiles, look-ahead,
+    back-substitution plan) executed with the device kernels' semantics by tests/host/test_plan.cpp."""
+    exe = str(tmp_path / "test_plan")
+    out = subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", os.path.join(ROOT, "tests", "host", "test_plan.cpp"), "-o", exe],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-4000:]
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0 and "ALL PLAN TESTS PASSED" in run.stdout, run.stdout[-4000:]
