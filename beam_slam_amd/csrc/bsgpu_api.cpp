@@ -814,8 +814,7 @@ struct DenseDev {
 void dense_factor(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* scal) {
   const int ld = P.npad;
   for (int st = 0; st < P.n_steps(); ++st) {
-    const int p0 = P.potrf_before_step_off[st], p1 = P.potrf_before_step_off[st + 1];
-    launch_chol_potrf_tiles(s, S, ld, D.potrf_tiles + p0, p1 - p0, D.nreal, D.Vinv, scal);
+    // (tiles no look-ahead factors are factored inside the panel step itself: PanelDesc::self_potrf)
     launch_chol_panel_step(s, S, D.Lp, ld, D.panels + P.step_off[st], P.step_off[st + 1] - P.step_off[st], P.step_maxrows[st],
                            D.rows_flat, D.nreal, D.Vinv, scal, P.panels.data() + P.step_off[st], P.rows_flat.data());
   }

@@ -131,7 +131,7 @@ void launch_pose_diag(hipStream_t s, int n_pose, double* S, int ld, const double
 void launch_grad_norms(hipStream_t s, int nb, const int* blk_xoff, const int* blk_toff, const unsigned char* blk_size,
                        const unsigned char* blk_manifold, const double* x, const double* grad, double* scal);
 struct PanelDesc;
-void launch_chol_potrf_tiles(hipStream_t s, double* S, int ld, const int* tiles_dev, int n_tiles, const int* nreal_dev,
+void launch_chol_potrf_tiles(hipStream_t s, double* S, double* Lp, int ld, const int* tiles_dev, int n_tiles, const int* nreal_dev,
                              double* Vinv, double* scal);
 void launch_chol_panel_step(hipStream_t s, double* S, double* Lp, int ld, const PanelDesc* descs_dev, int n_panels, int max_rows,
                             const int* rows_flat_dev, const int* nreal_dev, double* Vinv, double* scal,

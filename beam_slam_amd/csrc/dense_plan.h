@@ -19,6 +19,7 @@ struct PanelDesc {  // device-visible
   int row_off;    // into the flat row-tile list
   int n_rows;     // active row tiles below the diagonal (S tile indices, ascending)
   int lookahead;  // the workgroup updating tile (k+1,k+1) also factors it
+  int self_potrf;   // tile (k,k) is not factored by a look-ahead: the panel's workgroups factor it themselves
   int shared_mask;  // bit q: row tile q of this panel is also a row tile of another panel of the same step, so tiles
                     // (i, j) with both bits set are accumulated with atomics (two panels update them concurrently)
 };
@@ -164,6 +165,7 @@ struct DensePlan {
       for (int k : steps[s]) if (!factored_by_lookahead[k]) potrf_tiles.push_back(k);
     }
     potrf_before_step_off[steps.size()] = (int)potrf_tiles.size();
+    for (PanelDesc& d : panels) d.self_potrf = factored_by_lookahead[d.k] ? 0 : 1;
     // ---- back-substitution plan
     panel_of_tile.assign(T, 0);
     for (size_t i = 0; i < panels.size(); ++i) panel_of_tile[panels[i].k] = (int)i;

@@ -175,14 +175,23 @@ BSG_DEV void mask_unreal_columns(double* sC, int nreal, int tid) {
   }
 }
 
-BSG_DEV void write_factor(double* S, int ld, int t, const double* sC, const double* sV, const double* sInvD, double* Vinv,
+// L_tt goes to the shadow matrix Lp (what the back-substitution reads) and, when S is given, also in place into S
+// (what the NEXT panel step loads; not allowed when other workgroups of this launch still read the raw tile)
+BSG_DEV void write_factor(double* S, double* Lp, int ld, int t, const double* sC, const double* sV, const double* sInvD, double* Vinv,
                           int tid) {
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const int i = tid + 256 * q;
     const int r = i >> 5, c2 = (i & 31) * 2;
-    if (c2 + 1 <= r) *reinterpret_cast<double2*>(&S[(size_t)(t * NB + r) * ld + t * NB + c2]) = *reinterpret_cast<const double2*>(&sC[r * LDT + c2]);
-    else if (c2 <= r) S[(size_t)(t * NB + r) * ld + t * NB + c2] = sC[r * LDT + c2];
+    const size_t at = (size_t)(t * NB + r) * ld + t * NB + c2;
+    if (c2 + 1 <= r) {
+      const double2 v = *reinterpret_cast<const double2*>(&sC[r * LDT + c2]);
+      *reinterpret_cast<double2*>(&Lp[at]) = v;
+      if (S) *reinterpret_cast<double2*>(&S[at]) = v;
+    } else if (c2 <= r) {
+      Lp[at] = sC[r * LDT + c2];
+      if (S) S[at] = sC[r * LDT + c2];
+    }
   }
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
@@ -194,9 +203,9 @@ BSG_DEV void write_factor(double* S, int ld, int t, const double* sC, const doub
 
 }  // namespace
 
-__global__ __launch_bounds__(256) void chol_potrf_tiles_kernel(double* __restrict__ S, int ld, const int* __restrict__ tiles,
-                                                               const int* __restrict__ nreal, double* __restrict__ Vinv,
-                                                               double* __restrict__ scal) {
+__global__ __launch_bounds__(256) void chol_potrf_tiles_kernel(double* __restrict__ S, double* __restrict__ Lp, int ld,
+                                                               const int* __restrict__ tiles, const int* __restrict__ nreal,
+                                                               double* __restrict__ Vinv, double* __restrict__ scal) {
   __shared__ double sC[NB * LDT];
   __shared__ double sV[4 * 256];
   __shared__ double sInvD[NB];
@@ -223,7 +232,7 @@ __global__ __launch_bounds__(256) void chol_potrf_tiles_kernel(double* __restric
   __syncthreads();
   const bool bad = potrf64_lds(sC, sV, sInvD, tid, nreal[t]);
   if (bad && tid == 0) scal[SC_CHOL_FAIL] = 1.0;
-  write_factor(S, ld, t, sC, sV, sInvD, Vinv, tid);
+  write_factor(S, Lp, ld, t, sC, sV, sInvD, Vinv, tid);
 }
 
 // X = A L^-T by 16-column block substitution, in place in sA (64 x 64, pitch LDT); wave w owns rows
@@ -251,7 +260,7 @@ BSG_DEV void trsm_tile(double* sA, const double* sL, const double* sV, double* s
 // arguments instead of costing two dependent round trips to memory before the first tile load can be issued
 constexpr int kStepMaxPanels = 16, kStepMaxRows = 16;
 struct StepArgs {
-  int k[kStepMaxPanels], n_rows[kStepMaxPanels], lookahead[kStepMaxPanels], shared_mask[kStepMaxPanels];
+  int k[kStepMaxPanels], n_rows[kStepMaxPanels], lookahead[kStepMaxPanels], shared_mask[kStepMaxPanels], self_potrf[kStepMaxPanels];
   int rows[kStepMaxPanels][kStepMaxRows];
 };
 
@@ -265,14 +274,14 @@ __global__ __launch_bounds__(256) void chol_panel_step_kernel(double* __restrict
   int nts = 0;   // PROBE: wall-clock stamps of workgroup (0,0) for scripts/potrf_probe.hip
   auto stamp = [&]() { if (PROBE && bi == 0 && bj == 0 && threadIdx.x == 0) probe_ts[nts++] = wall_clock64(); };
   stamp();
-  int k, n_rows, lookahead, ti, tj, shared_mask;
+  int k, n_rows, lookahead, ti, tj, shared_mask, self_potrf;
   if (KARG) {
-    k = args.k[z]; n_rows = args.n_rows[z]; lookahead = args.lookahead[z]; shared_mask = args.shared_mask[z];
+    k = args.k[z]; n_rows = args.n_rows[z]; lookahead = args.lookahead[z]; shared_mask = args.shared_mask[z]; self_potrf = args.self_potrf[z];
     if (bi >= n_rows || bj > bi) return;
     ti = args.rows[z][bi]; tj = args.rows[z][bj];
   } else {
     const PanelDesc pd = descs[z];
-    k = pd.k; n_rows = pd.n_rows; lookahead = pd.lookahead; shared_mask = pd.shared_mask;
+    k = pd.k; n_rows = pd.n_rows; lookahead = pd.lookahead; shared_mask = pd.shared_mask; self_potrf = pd.self_potrf;
     if (bi >= n_rows || bj > bi) return;
     ti = rows_flat[pd.row_off + bi]; tj = rows_flat[pd.row_off + bj];
   }
@@ -297,10 +306,12 @@ __global__ __launch_bounds__(256) void chol_panel_step_kernel(double* __restrict
       *reinterpret_cast<double2*>(&sXj[r * LDT + c2]) = *reinterpret_cast<const double2*>(&S[(size_t)(rj + r) * ld + c0 + c2]);
     *reinterpret_cast<double2*>(&sL[r * LDT + c2]) = *reinterpret_cast<const double2*>(&S[(size_t)(c0 + r) * ld + c0 + c2]);
   }
+  if (!self_potrf) {
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int i = (tid + 256 * q) * 2;
-    *reinterpret_cast<double2*>(&sV[i]) = *reinterpret_cast<const double2*>(&Vinv[(size_t)k * kVinvStride + i]);
+    for (int q = 0; q < 2; ++q) {
+      const int i = (tid + 256 * q) * 2;
+      *reinterpret_cast<double2*>(&sV[i]) = *reinterpret_cast<const double2*>(&Vinv[(size_t)k * kVinvStride + i]);
+    }
   }
   // C_ij (wave w owns rows 16w.. of the 64x64 tile): fetched now, so that the round trip hides behind the solves
   // (a tile another panel of this step also updates is accumulated with atomics: start from zero)
@@ -313,6 +324,19 @@ __global__ __launch_bounds__(256) void chol_panel_step_kernel(double* __restrict
     for (int reg = 0; reg < 4; ++reg)
       acc[t][reg] = shared_tile ? 0.0 : S[(size_t)(ri + 16 * wave + crow + 4 * reg) * ld + rj + 16 * t + ccol];
   __syncthreads();
+  if (self_potrf) {
+    // tile (k, k) was not factored by a look-ahead (several panels updated it last, or it is the head of a piece):
+    // every workgroup of the panel factors its own copy instead of waiting for a launch that does it once;
+    // workgroup (0, 0) publishes the factor for the back-substitution (to the shadow matrix: the others still read S)
+    mask_unreal_columns(sL, nreal[k], tid);
+    __syncthreads();
+    const bool bad0 = potrf64_lds(sL, sV, sInvD, tid, nreal[k]);
+    if (bi == 0 && bj == 0) {
+      if (bad0 && tid == 0) scal[SC_CHOL_FAIL] = 1.0;
+      write_factor(nullptr, Lp, ld, k, sL, sV, sInvD, Vinv, tid);
+    }
+    __syncthreads();
+  }
   stamp();
   trsm_tile(sXi, sL, sV, sT, lane, wave);
   if (!diag) trsm_tile(sXj, sL, sV, sT, lane, wave);
@@ -355,20 +379,20 @@ __global__ __launch_bounds__(256) void chol_panel_step_kernel(double* __restrict
     mask_unreal_columns(sC, nreal[ti], tid);
     __syncthreads();
     stamp();
-    const bool bad = potrf64_lds(sC, sV, sInvD, tid, nreal[ti]);
+    const bool bad = potrf64_lds<PROBE>(sC, sV, sInvD, tid, nreal[ti], PROBE ? probe_ts + 8 : nullptr);
     stamp();
     if (bad && tid == 0) scal[SC_CHOL_FAIL] = 1.0;
-    write_factor(S, ld, ti, sC, sV, sInvD, Vinv, tid);
+    write_factor(S, Lp, ld, ti, sC, sV, sInvD, Vinv, tid);
     if (PROBE) { __syncthreads(); stamp(); }
   }
 }
 
 constexpr size_t kPanelStepLds = sizeof(double) * (3 * NB * LDT + 4 * 256 + 4 * 16 * 17 + 64);
 
-void launch_chol_potrf_tiles(hipStream_t s, double* S, int ld, const int* tiles_dev, int n_tiles, const int* nreal_dev,
+void launch_chol_potrf_tiles(hipStream_t s, double* S, double* Lp, int ld, const int* tiles_dev, int n_tiles, const int* nreal_dev,
                              double* Vinv, double* scal) {
   if (n_tiles <= 0) return;
-  hipLaunchKernelGGL(chol_potrf_tiles_kernel, dim3(n_tiles), dim3(256), 0, s, S, ld, tiles_dev, nreal_dev, Vinv, scal);
+  hipLaunchKernelGGL(chol_potrf_tiles_kernel, dim3(n_tiles), dim3(256), 0, s, S, Lp, ld, tiles_dev, nreal_dev, Vinv, scal);
 }
 void launch_chol_panel_step(hipStream_t s, double* S, double* Lp, int ld, const PanelDesc* descs_dev, int n_panels, int max_rows,
                             const int* rows_flat_dev, const int* nreal_dev, double* Vinv, double* scal, const PanelDesc* descs_host,
@@ -379,7 +403,7 @@ void launch_chol_panel_step(hipStream_t s, double* S, double* Lp, int ld, const 
   if (descs_host && rows_flat_host && n_panels <= kStepMaxPanels && max_rows <= kStepMaxRows) {
     for (int p = 0; p < n_panels; ++p) {
       a.k[p] = descs_host[p].k; a.n_rows[p] = descs_host[p].n_rows; a.lookahead[p] = descs_host[p].lookahead;
-      a.shared_mask[p] = descs_host[p].shared_mask;
+      a.shared_mask[p] = descs_host[p].shared_mask; a.self_potrf[p] = descs_host[p].self_potrf;
       for (int q = 0; q < descs_host[p].n_rows; ++q) a.rows[p][q] = rows_flat_host[descs_host[p].row_off + q];
     }
     hipLaunchKernelGGL(chol_panel_step_kernel<true>, dim3(max_rows, max_rows, n_panels), dim3(256), kPanelStepLds, s, S, Lp, ld, descs_dev,
@@ -412,7 +436,7 @@ BSG_DEV void backsolve_panel(int kb, const int* rows /* n_rows row tiles (LDS or
   for (int q = 0; q < 4; ++q) {
     const int i = tid + 1024 * q;
     const int r = i >> 6, cc = i & 63;
-    dl[q] = (cc <= r) ? S[(size_t)(c0 + r) * ld + c0 + cc] : 0.0;
+    dl[q] = (cc <= r) ? Lp[(size_t)(c0 + r) * ld + c0 + cc] : 0.0;
   }
   const double invd = (tid < NB) ? Vinv[(size_t)kb * kVinvStride + 1024 + tid] : 0.0;
   double acc = 0.0;

@@ -26,22 +26,25 @@ static void probe_panel_step() {
   for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) A[(size_t)i * n + j] = (i == j ? 200.0 : 0.0) + 1.0 / (1 + abs(i - j));
   double *S, *Lp, *V, *scal; long long* ts; int *tiles, *nreal;
   hipMalloc(&S, sizeof(double) * n * n); hipMalloc(&Lp, sizeof(double) * n * n); hipMalloc(&V, sizeof(double) * T * bsg::kVinvStride);
-  hipMalloc(&scal, 256); hipMalloc(&ts, 16 * 8); hipMalloc(&tiles, 16); hipMalloc(&nreal, 16);
+  hipMalloc(&scal, 256); hipMalloc(&ts, 32 * 8); hipMalloc(&tiles, 16); hipMalloc(&nreal, 16);
   int h_tiles[1] = {0}, h_nreal[3] = {64, 64, 64};
   hipMemcpy(tiles, h_tiles, 4, hipMemcpyHostToDevice); hipMemcpy(nreal, h_nreal, 12, hipMemcpyHostToDevice);
   bsg::chol_prepare();
   hipFuncSetAttribute(reinterpret_cast<const void*>(bsg::chol_panel_step_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bsg::kPanelStepLds);
   for (int rep = 0; rep < 3; ++rep) {
     hipMemcpy(S, A.data(), sizeof(double) * n * n, hipMemcpyHostToDevice);
-    hipLaunchKernelGGL(bsg::chol_potrf_tiles_kernel, dim3(1), dim3(256), 0, 0, S, n, tiles, nreal, V, scal);
+    hipLaunchKernelGGL(bsg::chol_potrf_tiles_kernel, dim3(1), dim3(256), 0, 0, S, Lp, n, tiles, nreal, V, scal);
     bsg::StepArgs a; memset(&a, 0, sizeof(a));
     a.k[0] = 0; a.n_rows[0] = 2; a.lookahead[0] = 1; a.rows[0][0] = 1; a.rows[0][1] = 2;
     hipLaunchKernelGGL((bsg::chol_panel_step_kernel<true, true>), dim3(2, 2, 1), dim3(256), bsg::kPanelStepLds, 0, S, Lp, n, nullptr, nullptr, nreal, V, scal, a, ts);
     hipDeviceSynchronize();
-    long long h[16];
+    long long h[32];
     hipMemcpy(h, ts, sizeof(h), hipMemcpyDeviceToHost);
     printf("panel step rep %d (10 ns ticks): loads %lld | trsm %lld | update mfma %lld | to-LDS+mask %lld | potrf %lld | write_factor %lld | total %lld\n", rep,
            h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[6] - h[0]);
+    printf("   potrf inside the panel step:");
+    for (int b = 0; b < 4; ++b) printf(" elim%d %lld upd%d %lld |", b, h[9 + 2 * b] - h[8 + 2 * b], b, h[10 + 2 * b] - h[9 + 2 * b]);
+    printf("\n");
   }
 }
 
