@@ -121,7 +121,6 @@ struct bsgpu_ctx {
   std::vector<uint8_t> tile_adj;   // natural-tile adjacency of the reduced system
   int *d_perm = nullptr, *d_iperm = nullptr, *d_nreal = nullptr, *d_rows_flat = nullptr, *d_potrf_tiles = nullptr;
   PanelDesc* d_panels = nullptr;
-  PanelDesc* d_bs_sep_panels = nullptr;
   int *d_panel_of_tile = nullptr, *d_chain_begin = nullptr, *d_chain_end = nullptr;
   double* d_Vinv = nullptr;
   double* d_Lp = nullptr;     // shadow of S holding the off-diagonal L panels (k_chol.hip)
@@ -619,12 +618,14 @@ int finalize(bsgpu_ctx* c) {
     const char* e3 = getenv("BSGPU_SHARED");   // panels of one step may update the same tiles (atomics): on unless BSGPU_SHARED=0
     c->plan.build(c->n_pose, c->tile_adj, c->dense_ok ? max_chains : 1, e2 ? std::max(1, atoi(e2)) : 1, !(e3 && atoi(e3) == 0));
     c->npad = c->plan.npad;
+    if (timing) fprintf(stderr, "[bsgpu finalize] Cholesky plan: %d tiles, %d pieces, %d panel steps, %d back-substitution launches\n", c->plan.T, c->plan.n_pieces,
+                        c->plan.n_steps(), (int)c->plan.bs_group_off.size() - 1);
     std::vector<int> iperm(T + 1, -1);
     for (int t = 0; t < T; ++t) iperm[c->plan.perm[t]] = t;
     c->d_perm = c->upload(c->plan.perm); c->d_iperm = c->upload(iperm); c->d_nreal = c->upload(c->plan.nreal);
     c->d_rows_flat = c->upload(c->plan.rows_flat); c->d_potrf_tiles = c->upload(c->plan.potrf_tiles);
     c->d_panels = c->upload(c->plan.panels);
-    c->d_bs_sep_panels = c->upload(c->plan.bs_sep_panels); c->d_panel_of_tile = c->upload(c->plan.panel_of_tile);
+    c->d_panel_of_tile = c->upload(c->plan.panel_of_tile);
     c->d_chain_begin = c->upload(c->plan.chain_begin); c->d_chain_end = c->upload(c->plan.chain_end);
     c->d_Vinv = c->alloc<double>((size_t)std::max(1, T) * chol_vinv_stride());
     c->d_ytan = c->alloc<double>(std::max(1, c->n_pose));
@@ -808,7 +809,6 @@ struct DenseDev {
   const int *perm, *nreal, *rows_flat, *potrf_tiles;
   const PanelDesc* panels;
   double *Lp, *Vinv;
-  const PanelDesc* bs_sep_panels;
   const int *panel_of_tile, *chain_begin, *chain_end;
 };
 void dense_factor(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* scal) {
@@ -825,14 +825,14 @@ void dense_factor_solve(hipStream_t s, const DensePlan& P, const DenseDev& D, do
   // y' = the rhs row after forward substitution: row rhs_row of the shadow matrix (the rhs tile is an
   // off-diagonal row tile of every panel)
   launch_copy(s, D.Lp + (size_t)P.rhs_row * ld, y, (int64_t)P.T * 64, 64);
-  // separators (the top of the elimination tree) step by step, then every independent piece in one launch
-  for (size_t g = 0; g + 1 < P.bs_sep_step_off.size(); ++g)
-    launch_chol_backsolve_step(s, S, D.Lp, D.Vinv, ld, D.bs_sep_panels + P.bs_sep_step_off[g], P.bs_sep_step_off[g + 1] - P.bs_sep_step_off[g],
-                               D.rows_flat, D.nreal, y);
-  int max_len = 1;
-  for (size_t i = 0; i < P.chain_begin.size(); ++i) max_len = std::max(max_len, P.chain_end[i] - P.chain_begin[i]);
-  launch_chol_backsolve_chains(s, S, D.Lp, D.Vinv, ld, D.panels, D.panel_of_tile, D.chain_begin, D.chain_end, (int)P.chain_begin.size(),
-                               D.rows_flat, D.nreal, y, P.npad, max_len);
+  // one launch per group of chains: root separator, the separator levels below it, then every piece (dense_plan.h)
+  for (size_t g = 0; g + 1 < P.bs_group_off.size(); ++g) {
+    const int c0 = P.bs_group_off[g], c1 = P.bs_group_off[g + 1];
+    int max_len = 1;
+    for (int i = c0; i < c1; ++i) max_len = std::max(max_len, P.chain_end[i] - P.chain_begin[i]);
+    launch_chol_backsolve_chains(s, S, D.Lp, D.Vinv, ld, D.panels, D.panel_of_tile, D.chain_begin + c0, D.chain_end + c0, c1 - c0,
+                                 D.rows_flat, D.nreal, y, P.npad, max_len);
+  }
 }
 
 void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
@@ -842,7 +842,7 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
     launch_negate_pose(s, c->n_pose, c->d_px, c->d_delta);
   } else if (c->n_pose > 0) {
     const DenseDev D{c->d_perm, c->d_nreal, c->d_rows_flat, c->d_potrf_tiles, c->d_panels, c->d_Lp, c->d_Vinv,
-                     c->d_bs_sep_panels, c->d_panel_of_tile, c->d_chain_begin, c->d_chain_end};
+                     c->d_panel_of_tile, c->d_chain_begin, c->d_chain_end};
     dense_factor_solve(s, c->plan, D, c->d_S, c->d_y, c->d_scal);
     launch_y_to_delta(s, c->n_pose, c->d_y, c->d_perm, c->d_ytan, c->d_delta);
   }
@@ -1514,7 +1514,7 @@ int bsgpu_covariance(bsgpu_ctx* c, int32_t ba, int32_t bb, double* out) {
   (void)hipMemcpyAsync(d_cols, cols.data(), sizeof(int) * cols.size(), hipMemcpyHostToDevice, s);
   launch_cov_units(s, c->d_S, c->npad, c->plan.rhs_row, d_cols, (int)cols.size());
   const DenseDev D{c->d_perm, c->d_nreal, c->d_rows_flat, c->d_potrf_tiles, c->d_panels, c->d_Lp, c->d_Vinv,
-                   c->d_bs_sep_panels, c->d_panel_of_tile, c->d_chain_begin, c->d_chain_end};
+                   c->d_panel_of_tile, c->d_chain_begin, c->d_chain_end};
   dense_factor(s, c->plan, D, c->d_S, c->d_scal);
   launch_cov_dots(s, c->d_Lp, c->npad, c->plan.rhs_row, c->plan.T * 64, ta, row_b0, tb, d_out);
   (void)hipMemcpyAsync(out, d_out, sizeof(double) * ta * tb, hipMemcpyDeviceToHost, s);
@@ -1649,7 +1649,6 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
   ok = ok && up(P.perm.data(), sizeof(int) * P.perm.size(), (void**)&dperm) && up(P.nreal.data(), sizeof(int) * P.nreal.size(), (void**)&dnreal) &&
        up(rf.data(), sizeof(int) * rf.size(), (void**)&drows) && up(pt.data(), sizeof(int) * pt.size(), (void**)&dpot) &&
        up(P.panels.data(), sizeof(PanelDesc) * P.panels.size(), (void**)&dpan) &&
-       up(P.bs_sep_panels.data(), sizeof(PanelDesc) * P.bs_sep_panels.size(), (void**)&dsep) &&
        up(P.panel_of_tile.data(), sizeof(int) * P.panel_of_tile.size(), (void**)&dpot2) &&
        up(P.chain_begin.data(), sizeof(int) * P.chain_begin.size(), (void**)&dcb) && up(P.chain_end.data(), sizeof(int) * P.chain_end.size(), (void**)&dce);
   int rc = BSGPU_OK;
@@ -1659,7 +1658,7 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, s);
-    const DenseDev D{dperm, dnreal, drows, dpot, dpan, dLp, dV, dsep, dpot2, dcb, dce};
+    const DenseDev D{dperm, dnreal, drows, dpot, dpan, dLp, dV, dpot2, dcb, dce};
     dense_factor_solve(s, P, D, dS, dy, dscal);
     (void)hipEventRecord(e1, s);
     if (hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess) rc = BSGPU_ERR_DEVICE;
@@ -1684,7 +1683,7 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
 // number of independent sub-chains / schedule steps of the current problem's Cholesky plan (diagnostics)
 int bsgpu_plan_info(const bsgpu_ctx* c, int32_t* n_chains, int32_t* n_steps, int32_t* n_tiles) {
   if (!c->finalized) return BSGPU_ERR_INVALID;
-  if (n_chains) *n_chains = c->plan.n_chains;
+  if (n_chains) *n_chains = c->plan.n_pieces;
   if (n_steps) *n_steps = c->plan.n_steps();
   if (n_tiles) *n_tiles = c->plan.T;
   return BSGPU_OK;

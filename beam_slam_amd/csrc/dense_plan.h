@@ -34,11 +34,14 @@ struct DensePlan {
   std::vector<int> step_maxrows;
   std::vector<int> potrf_before_step_off, potrf_tiles;  // standalone potrf launches: tiles to factor before step s
   int n_chains = 1;
-  // back-substitution: separator panels step by step (reverse), then every independent piece walked by one workgroup
+  // back-substitution: GROUPS of chains, one launch per group; a chain is a run of consecutive S tiles [begin, end) walked
+  // by one workgroup from its last tile down.  Root separator first, then the separators level by level (those of one
+  // level are independent), then all pieces at once.  Every row tile of a panel lies later in its own chain or in an
+  // earlier group (checked; if the structure does not allow it the groups fall back to the reverse step schedule).
   std::vector<int> panel_of_tile;                 // S tile -> index into panels
-  std::vector<PanelDesc> bs_sep_panels;           // separator panels, grouped by step, latest step first
-  std::vector<int> bs_sep_step_off;
-  std::vector<int> chain_begin, chain_end;        // per piece: S tiles [begin, end)
+  std::vector<int> chain_begin, chain_end;        // all chains, group after group
+  std::vector<int> bs_group_off;                  // chains [bs_group_off[g], bs_group_off[g+1]) run in launch g
+  int n_pieces = 1;
   // solve offsets
   inline int spos(int j) const { return perm[j >> 6] * 64 + (j & 63); }
 
@@ -54,13 +57,14 @@ struct DensePlan {
     int w = 0;
     for (int i = 0; i < T; ++i) for (int j = 0; j < i; ++j) if (adj[(size_t)i * T + j]) w = std::max(w, i - j);
     std::vector<int> order;  // S order: list of natural tiles
-    chain_begin.clear(); chain_end.clear();
+    std::vector<std::pair<int, int>> piece_ranges;                    // S tile ranges of the pieces
+    std::vector<std::vector<std::pair<int, int>>> sep_ranges_by_level;  // S tile ranges of the separators, per level
     int chains = 1;
     if (max_chains > 1 && w >= 1) while (chains * 2 <= max_chains && T >= (chains * 2) * min_piece_w * w + (chains * 2 - 1) * w) chains *= 2;
     n_chains = chains;
     if (chains == 1) {
       for (int i = 0; i < T; ++i) order.push_back(i);
-      chain_begin.push_back(0); chain_end.push_back(T);
+      piece_ranges.push_back({0, T});
     } else {
       // pieces p = 0..chains-1 separated by chains-1 separators of w tiles
       const int n_sep = chains - 1;
@@ -78,7 +82,7 @@ struct DensePlan {
       // separators on both sides are interior: natural order keeps the right neighbour last, the left separator
       // then sees fill along the piece (still correct: the symbolic factorisation below is exact)
       for (int p = 0; p < chains; ++p) {
-        chain_begin.push_back((int)order.size()); chain_end.push_back((int)order.size() + piece_len[p]);
+        piece_ranges.push_back({(int)order.size(), (int)order.size() + piece_len[p]});
         const bool reverse = (p == chains - 1) && chains > 1;  // last piece: its only separator is on the left
         if (!reverse) for (int t = pieces[p].first; t < pieces[p].second; ++t) order.push_back(t);
         else for (int t = pieces[p].second - 1; t >= pieces[p].first; --t) order.push_back(t);
@@ -89,8 +93,12 @@ struct DensePlan {
       for (int i = 0; i < n_sep; ++i) { int lvl = 0, x = i + 1; while ((x & 1) == 0) { x >>= 1; ++lvl; } sep_level[i] = lvl; }
       int max_lvl = 0;
       for (int l : sep_level) max_lvl = std::max(max_lvl, l);
+      sep_ranges_by_level.assign(max_lvl + 1, {});
       for (int lvl = 0; lvl <= max_lvl; ++lvl)
-        for (int i = 0; i < n_sep; ++i) if (sep_level[i] == lvl) for (int t = seps[i].first; t < seps[i].second; ++t) order.push_back(t);
+        for (int i = 0; i < n_sep; ++i) if (sep_level[i] == lvl) {
+          sep_ranges_by_level[lvl].push_back({(int)order.size(), (int)order.size() + (seps[i].second - seps[i].first)});
+          for (int t = seps[i].first; t < seps[i].second; ++t) order.push_back(t);
+        }
     }
     for (int s = 0; s < T; ++s) perm[order[s]] = s;
     nreal.assign(T + 1, 64);
@@ -169,12 +177,35 @@ struct DensePlan {
     // ---- back-substitution plan
     panel_of_tile.assign(T, 0);
     for (size_t i = 0; i < panels.size(); ++i) panel_of_tile[panels[i].k] = (int)i;
-    const int sep_begin = chain_end.empty() ? T : chain_end.back();
-    bs_sep_panels.clear(); bs_sep_step_off.assign(1, 0);
-    for (int st = (int)steps.size() - 1; st >= 0; --st) {
-      bool any = false;
-      for (int i = step_off[st]; i < step_off[st + 1]; ++i) if (panels[i].k >= sep_begin) { bs_sep_panels.push_back(panels[i]); any = true; }
-      if (any) bs_sep_step_off.push_back((int)bs_sep_panels.size());
+    n_pieces = (int)piece_ranges.size();
+    auto build_groups = [&](bool by_level) {
+      chain_begin.clear(); chain_end.clear(); bs_group_off.assign(1, 0);
+      if (by_level) {
+        for (int lvl = (int)sep_ranges_by_level.size() - 1; lvl >= 0; --lvl) {
+          for (const auto& r : sep_ranges_by_level[lvl]) { chain_begin.push_back(r.first); chain_end.push_back(r.second); }
+          if (!sep_ranges_by_level[lvl].empty()) bs_group_off.push_back((int)chain_begin.size());
+        }
+        for (const auto& r : piece_ranges) { chain_begin.push_back(r.first); chain_end.push_back(r.second); }
+        bs_group_off.push_back((int)chain_begin.size());
+      } else {   // reverse step schedule, one single-tile chain per panel (always valid)
+        for (int st = (int)steps.size() - 1; st >= 0; --st) {
+          for (int k : steps[st]) { chain_begin.push_back(k); chain_end.push_back(k + 1); }
+          bs_group_off.push_back((int)chain_begin.size());
+        }
+      }
+    };
+    build_groups(true);
+    {
+      std::vector<int> group_of(T, -1), chain_of(T, -1);
+      for (size_t g = 0; g + 1 < bs_group_off.size(); ++g)
+        for (int c = bs_group_off[g]; c < bs_group_off[g + 1]; ++c)
+          for (int t = chain_begin[c]; t < chain_end[c]; ++t) { group_of[t] = (int)g; chain_of[t] = c; }
+      bool ok = true;
+      for (int k = 0; k < T && ok; ++k) {
+        if (group_of[k] < 0) ok = false;
+        for (int t : rows[k]) if (t < T && !((chain_of[t] == chain_of[k] && t > k) || group_of[t] < group_of[k])) ok = false;
+      }
+      if (!ok) build_groups(false);
     }
   }
   int n_steps() const { return (int)step_off.size() - 1; }

@@ -113,21 +113,21 @@ static bool run_case(int n_pose, int band_tiles, int max_chains, int min_piece, 
     }
   };
   std::vector<int> solved(P.T, 0);
-  for (size_t g = 0; g + 1 < P.bs_sep_step_off.size(); ++g)
-    for (int i = P.bs_sep_step_off[g]; i < P.bs_sep_step_off[g + 1]; ++i) {
-      const PanelDesc& pd = P.bs_sep_panels[i];
-      for (int q = 0; q < pd.n_rows; ++q) { const int t = P.rows_flat[pd.row_off + q]; CHECK(t == P.T || solved[t]); }
-      solve_panel(pd.k, &P.rows_flat[pd.row_off], pd.n_rows);
-      solved[pd.k] = 1;
-    }
-  for (size_t c = 0; c < P.chain_begin.size(); ++c)
-    for (int k = P.chain_end[c] - 1; k >= P.chain_begin[c]; --k) {
-      const PanelDesc& pd = P.panels[P.panel_of_tile[k]];
-      CHECK(pd.k == k);
-      for (int q = 0; q < pd.n_rows; ++q) { const int t = P.rows_flat[pd.row_off + q]; CHECK(t == P.T || solved[t] || (t >= P.chain_begin[c] && t < P.chain_end[c] && t > k)); }
-      solve_panel(k, &P.rows_flat[pd.row_off], pd.n_rows);
-      solved[k] = 1;
-    }
+  for (size_t g = 0; g + 1 < P.bs_group_off.size(); ++g) {
+    std::vector<int> done_in_group;
+    for (int c = P.bs_group_off[g]; c < P.bs_group_off[g + 1]; ++c)   // chains of one group run concurrently: they may only
+      for (int k = P.chain_end[c] - 1; k >= P.chain_begin[c]; --k) {   // read tiles of EARLIER groups or of their own chain
+        const PanelDesc& pd = P.panels[P.panel_of_tile[k]];
+        CHECK(pd.k == k);
+        for (int q = 0; q < pd.n_rows; ++q) {
+          const int t = P.rows_flat[pd.row_off + q];
+          CHECK(t == P.T || solved[t] == 1 || (t >= P.chain_begin[c] && t < P.chain_end[c] && t > k));
+        }
+        solve_panel(k, &P.rows_flat[pd.row_off], pd.n_rows);
+        done_in_group.push_back(k);
+      }
+    for (int k : done_in_group) solved[k] = 1;
+  }
   for (int t = 0; t < P.T; ++t) CHECK(solved[t]);
   // residual of A x = b
   double err = 0, nb = 0;
@@ -138,7 +138,7 @@ static bool run_case(int n_pose, int band_tiles, int max_chains, int min_piece, 
   }
   const bool ok = err <= 1e-10 * std::max(1.0, nb);
   std::printf("n=%4d T=%2d band=%d chains<=%2d min_piece=%d shared=%d -> pieces=%d steps=%2d potrf launches=%d  residual %.2e %s\n", n_pose, P.T, band_tiles,
-              max_chains, min_piece, (int)shared, P.n_chains, P.n_steps(), (int)[&] { int n = 0; for (int s = 0; s < P.n_steps(); ++s) n += P.potrf_before_step_off[s + 1] > P.potrf_before_step_off[s]; return n; }(), err, ok ? "" : "FAILED");
+              max_chains, min_piece, (int)shared, P.n_pieces, P.n_steps(), (int)[&] { int n = 0; for (int s = 0; s < P.n_steps(); ++s) n += P.potrf_before_step_off[s + 1] > P.potrf_before_step_off[s]; return n; }(), err, ok ? "" : "FAILED");
   if (!ok) ++g_fail;
   return ok;
 }
