@@ -103,11 +103,13 @@ BSG_DEV bool potrf64_lds(double* sC, double* sV, double* sInvD /* 64 */, int tid
       double d = real ? draw : 1.0;
       if (!(d > 0.0) || !(d < 1.7e308)) bad = true;
       double inv = fast_rsqrt(d);
+      double my_inv = 0.0;   // lane j keeps pivot j's reciprocal: ONE store after the loop (a predicated LDS store per pivot
+                             // splits the loop into sixteen basic blocks, and the scheduler can no longer overlap anything)
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const double unit = (lane == j) ? 1.0 : 0.0;
         a[j] = real ? a[j] : unit;
-        if (lane == 0) sInvD[16 * b + j] = inv;
+        my_inv = (lane == j) ? inv : my_inv;
         a[j] = a[j] * inv;
         if (j < 15) {
           const double l1 = readlane_d(a[j], j + 1);
@@ -124,6 +126,7 @@ BSG_DEV bool potrf64_lds(double* sC, double* sV, double* sInvD /* 64 */, int tid
           a[c] = fma(-a[j], lc, a[c]);
         }
       }
+      if (lane < 16) sInvD[16 * b + lane] = my_inv;
       if (lane < nrows) {
 #pragma unroll
         for (int c = 0; c < 16; ++c) R[c] = (lane >= 16 || c <= lane) ? a[c] : 0.0;

@@ -19,6 +19,40 @@ __global__ __launch_bounds__(256) void probe_kernel(double* S, int ld, long long
   if (tid == 0) ts[15] = wall_clock64();
 }
 }
+namespace bsg {
+// same potrf, but in the LDS environment of the panel-step kernel: dynamic LDS of kPanelStepLds bytes, tile at the sXj offset
+__global__ __launch_bounds__(256) void probe_dyn_kernel(double* S, int ld, long long* ts) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* sC = smem;
+  double* sV = smem + NB * LDT;
+  double* sInvD = sV + 4 * 256;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < NB * NB; i += 256) { const int r = i >> 6, c = i & 63; sC[r * LDT + c] = (c <= r) ? S[(size_t)r * ld + c] : 0.0; }
+  __syncthreads();
+  potrf64_lds<true>(sC, sV, sInvD, tid, 64, ts);
+}
+}
+static void probe_dyn() {
+  const int n = 64;
+  std::vector<double> A(n * n);
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) A[i * n + j] = (i == j ? 70.0 : 0.0) + 1.0 / (1 + abs(i - j));
+  double* d; long long* ts;
+  hipMalloc(&d, sizeof(double) * n * n); hipMalloc(&ts, sizeof(long long) * 16);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(bsg::probe_dyn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const size_t need = sizeof(double) * (64 * 66 + 4 * 256 + 64);
+  for (size_t extra : {(size_t)0, (size_t)0, (size_t)16384, (size_t)24576, (size_t)32768, (size_t)49152, (size_t)65536, (size_t)98304, (size_t)120000}) {
+    const int rep = (int)(extra / 1024);
+    hipMemcpy(d, A.data(), sizeof(double) * n * n, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(bsg::probe_dyn_kernel, dim3(1), dim3(256), need + extra, 0, d, n, ts);
+    hipDeviceSynchronize();
+    long long h[16];
+    hipMemcpy(h, ts, sizeof(h), hipMemcpyDeviceToHost);
+    printf("dynamic-LDS potrf (%zu KB + %d KB):", need / 1024, rep);
+    for (int b = 0; b < 4; ++b) printf(" elim%d %lld upd%d %lld |", b, h[1 + 2 * b] - h[2 * b], b, h[2 + 2 * b] - h[1 + 2 * b]);
+    printf("\n");
+  }
+}
+
 static void probe_panel_step() {
   // 3 tiles: panel k = 0 with row tiles {1, 2}; workgroup (0,0) = tile (1,1): trsm + update + look-ahead potrf
   const int T = 3, n = T * 64;
@@ -49,6 +83,7 @@ static void probe_panel_step() {
 }
 
 int main() {
+  probe_dyn();
   probe_panel_step();
   const int n = 64;
   std::vector<double> A(n * n);
