@@ -97,26 +97,22 @@ BSG_DEV bool potrf64_lds(double* sC, double* sV, double* sInvD /* 64 */, int tid
 #pragma unroll
       for (int c = 0; c < 16; ++c) a[c] = R[c];
       // the rhs row's own diagonal entry has collected -|y'|^2 from the trailing updates: unit pivot
-      // columns >= nreal: pivot forced to 1 by a select on d (rsqrt(1) == 1 exactly), no branch anywhere
-      bool real = (16 * b) < nreal;
-      double draw = readlane_d(a[0], 0);
-      double d = real ? draw : 1.0;
+      // Columns >= nreal (padding of the last tile) need no special case here: their rows and columns are zero apart
+      // from a unit diagonal (pose_diag_kernel / mask_unreal_columns), nothing ever updates them, so the plain
+      // recurrence gives pivot 1 and an empty column.
+      double d = readlane_d(a[0], 0);
       if (!(d > 0.0) || !(d < 1.7e308)) bad = true;
       double inv = fast_rsqrt(d);
       double my_inv = 0.0;   // lane j keeps pivot j's reciprocal: ONE store after the loop (a predicated LDS store per pivot
                              // splits the loop into sixteen basic blocks, and the scheduler can no longer overlap anything)
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const double unit = (lane == j) ? 1.0 : 0.0;
-        a[j] = real ? a[j] : unit;
         my_inv = (lane == j) ? inv : my_inv;
         a[j] = a[j] * inv;
         if (j < 15) {
           const double l1 = readlane_d(a[j], j + 1);
           a[j + 1] = fma(-a[j], l1, a[j + 1]);
-          real = (16 * b + j + 1) < nreal;
-          draw = readlane_d(a[j + 1], j + 1);
-          d = real ? draw : 1.0;
+          d = readlane_d(a[j + 1], j + 1);
           if (!(d > 0.0) || !(d < 1.7e308)) bad = true;
           inv = fast_rsqrt(d);
         }
