@@ -369,14 +369,13 @@ __global__ __launch_bounds__(256) void chol_panel_step_kernel(double* __restrict
   }
   if (factor_next) {
     // look-ahead: tile (k+1, k+1) is final now — factor it here instead of in a launch of its own
-    __syncthreads();
+    // (this is a diagonal workgroup: sXj is free.  The strictly upper part of the tile is never read by the
+    //  factorisation, so it is left as the update produced it.)
     double* sC = sXj;
 #pragma unroll
     for (int t = 0; t < 4; ++t) store_d(sC + (16 * wave) * LDT + 16 * t, LDT, lane, acc[t]);
     __syncthreads();
-    for (int i = tid; i < NB * NB; i += 256) { const int r = i >> 6, c = i & 63; if (c > r) sC[r * LDT + c] = 0.0; }
-    mask_unreal_columns(sC, nreal[ti], tid);
-    __syncthreads();
+    if (nreal[ti] < NB) { mask_unreal_columns(sC, nreal[ti], tid); __syncthreads(); }
     stamp();
     const bool bad = potrf64_lds<PROBE>(sC, sV, sInvD, tid, nreal[ti], PROBE ? probe_ts + 8 : nullptr);
     stamp();
