@@ -743,7 +743,6 @@ void assemble_pcg(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_
   launch_bsr_finish_diag(s, c->nbr, c->d_diag_slot, c->d_val, c->d_hdiag, radius, first ? 1 : 0, new_J ? 1 : 0, o.jacobi_scaling,
                          o.min_lm_diagonal, o.max_lm_diagonal, c->d_scale, c->d_dcl, c->d_Minv);
   if (new_J) {
-    launch_zero(s, c->d_scal + SC_GRAD_MAX, 2);
     launch_grad_norms(s, c->nb, c->d_blk_xoff, c->d_blk_toff, c->d_blk_size, c->d_blk_manifold, c->d_x, c->d_grad, c->d_scal);
   }
 }
@@ -784,10 +783,9 @@ void final_reduce(bsgpu_ctx* c) { launch_final_reduce(c->stream, c->d_reduce, c-
 void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, bool first) {
   if (c->use_pcg) { assemble_pcg(c, o, radius, new_J, first); return; }
   hipStream_t s = c->stream;
-  if (new_J) launch_zero(s, c->d_scal + SC_GRAD_MAX, 3); else launch_zero(s, c->d_scal + SC_CHOL_FAIL, 1);  // GRAD_MAX, GRAD_NORM2, CHOL_FAIL
-  launch_zero(s, c->d_S, (int64_t)c->npad * c->npad);
-  launch_zero(s, c->d_grad, c->n_pose);
-  launch_zero(s, c->d_hdiag, c->n_pose);
+  // one launch clears the reduced system, gradient, diagonal and the scalars of this step (GRAD_MAX, GRAD_NORM2, CHOL_FAIL)
+  launch_zero_multi(s, c->d_S, (int64_t)c->npad * c->npad, c->d_grad, c->n_pose, c->d_hdiag, c->n_pose,
+                    new_J ? c->d_scal + SC_GRAD_MAX : c->d_scal + SC_CHOL_FAIL, new_J ? 3 : 1);
   launch_landmark(s, c->vis, c->n_pose, c->d_scal + SC_RADIUS, first ? 1 : 0, new_J ? 1 : 0, o.jacobi_scaling, o.min_lm_diagonal,
                   o.max_lm_diagonal, c->d_scale, c->d_dcl, c->d_grad);
   launch_pairs(s, c->vis, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm);
@@ -798,7 +796,6 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
   launch_pose_diag(s, c->n_pose, c->d_S, c->npad, c->d_hdiag, c->d_scal + SC_RADIUS, first ? 1 : 0, new_J ? 1 : 0, o.jacobi_scaling,
                    o.min_lm_diagonal, o.max_lm_diagonal, c->d_scale, c->d_dcl, c->npad, c->d_iperm);
   if (new_J) {
-    launch_zero(s, c->d_scal + SC_GRAD_MAX, 2);
     launch_grad_norms(s, c->nb, c->d_blk_xoff, c->d_blk_toff, c->d_blk_size, c->d_blk_manifold, c->d_x, c->d_grad, c->d_scal);
   }
 }

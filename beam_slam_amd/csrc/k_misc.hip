@@ -171,6 +171,21 @@ void launch_zero(hipStream_t s, double* p, int64_t n) {
   const int grid = (int)std::min<int64_t>((n2 + 255) / 256, 2048);
   hipLaunchKernelGGL(zero_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<double2*>(p), n2, p + 2 * n2, (int)(n - 2 * n2));
 }
+// one launch for the buffers an LM step clears: the (large, 16-byte aligned) reduced system plus up to three small arrays
+__global__ __launch_bounds__(256) void zero_multi_kernel(double2* __restrict__ big2, int64_t nbig2, double* __restrict__ a, int na,
+                                                         double* __restrict__ b, int nb, double* __restrict__ c, int nc) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (int64_t i = t; i < nbig2; i += stride) big2[i] = make_double2(0.0, 0.0);
+  for (int64_t i = t; i < na; i += stride) a[i] = 0.0;
+  for (int64_t i = t; i < nb; i += stride) b[i] = 0.0;
+  for (int64_t i = t; i < nc; i += stride) c[i] = 0.0;
+}
+void launch_zero_multi(hipStream_t s, double* big, int64_t nbig /* even, 16-byte aligned */, double* a, int na, double* b, int nb, double* c, int nc) {
+  const int64_t n2 = nbig / 2;
+  const int grid = (int)std::min<int64_t>(std::max<int64_t>((n2 + 255) / 256, 1), 2048);
+  hipLaunchKernelGGL(zero_multi_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<double2*>(big), n2, a, na, b, nb, c, nc);
+}
 __global__ __launch_bounds__(256) void copy_kernel(const double* __restrict__ src, double* __restrict__ dst, int64_t n, int nzero_after) {
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
