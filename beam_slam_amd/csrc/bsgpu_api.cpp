@@ -116,6 +116,8 @@ struct bsgpu_ctx {
   double *d_S = nullptr, *d_grad = nullptr, *d_hdiag = nullptr, *d_scale = nullptr, *d_dcl = nullptr;
   double *d_delta = nullptr, *d_y = nullptr, *d_scal = nullptr, *d_part = nullptr;
   double* h_scal = nullptr;  // pinned
+  double* h_scal_dev = nullptr;  // the same buffer as the device sees it (final_reduce mirrors the step's scalars there)
+  bool scal_mirrored = false;    // the last enqueued work ended with a final_reduce that filled the mirror
   // tiled Cholesky plan (dense_plan.h) and its device tables
   DensePlan plan;
   std::vector<uint8_t> tile_adj;   // natural-tile adjacency of the reduced system
@@ -599,7 +601,10 @@ int finalize(bsgpu_ctx* c) {
   c->d_delta = c->alloc<double>(c->n_tan); c->d_y = c->alloc<double>(c->npad);
   c->d_scal = c->alloc<double>(SC_NUM);
   c->d_part = c->alloc<double>(part_max + 8);
-  if (!c->h_scal) HIPCHK(c, hipHostMalloc((void**)&c->h_scal, sizeof(double) * SC_NUM));
+  if (!c->h_scal) {
+    HIPCHK(c, hipHostMalloc((void**)&c->h_scal, sizeof(double) * SC_NUM, hipHostMallocMapped));
+    if (hipHostGetDevicePointer((void**)&c->h_scal_dev, c->h_scal, 0) != hipSuccess) { (void)hipGetLastError(); c->h_scal_dev = nullptr; }
+  }
   if (!c->h_radius) HIPCHK(c, hipHostMalloc((void**)&c->h_radius, sizeof(double)));
   chol_prepare();
   // hipGraph replay of the LM step is opt-in (BSGPU_GRAPH=1): on ROCm 7.2 the replay inserts a ~0.9 ms bubble
@@ -778,14 +783,20 @@ void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot) {
   for (const auto& mc : c->marg)
     if (mc.active) launch_marg_eval(s, mc.dev, x, with_J, cand ? mc.part_cand : mc.part);
 }
-void final_reduce(bsgpu_ctx* c) { launch_final_reduce(c->stream, c->d_reduce, c->n_reduce, SC_X_NORM2 + 1, c->d_scal); }
+void final_reduce(bsgpu_ctx* c) {
+  launch_final_reduce(c->stream, c->d_reduce, c->n_reduce, SC_X_NORM2 + 1, c->d_scal, c->h_scal_dev);
+  c->scal_mirrored = c->h_scal_dev != nullptr && c->n_reduce > 0;
+}
 
 void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, bool first) {
   if (c->use_pcg) { assemble_pcg(c, o, radius, new_J, first); return; }
   hipStream_t s = c->stream;
   // one launch clears the reduced system, gradient, diagonal and the scalars of this step (GRAD_MAX, GRAD_NORM2, CHOL_FAIL)
+  // ... and carries the radius of this step (not under graph replay, whose kernel arguments are frozen)
   launch_zero_multi(s, c->d_S, (int64_t)c->npad * c->npad, c->d_grad, c->n_pose, c->d_hdiag, c->n_pose,
-                    new_J ? c->d_scal + SC_GRAD_MAX : c->d_scal + SC_CHOL_FAIL, new_J ? 3 : 1);
+                    new_J ? c->d_scal + SC_GRAD_MAX : c->d_scal + SC_CHOL_FAIL, new_J ? 3 : 1,
+                    c->use_graphs ? nullptr : c->d_scal + SC_RADIUS, radius);
+  c->scal_mirrored = false;
   launch_landmark(s, c->vis, c->n_pose, c->d_scal + SC_RADIUS, first ? 1 : 0, new_J ? 1 : 0, o.jacobi_scaling, o.min_lm_diagonal,
                   o.max_lm_diagonal, c->d_scale, c->d_dcl, c->d_grad);
   launch_pairs(s, c->vis, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm);
@@ -898,8 +909,10 @@ void build_graphs(bsgpu_ctx* c, const bsgpu_options& o) {
 }
 
 void run_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius) {
-  *c->h_radius = radius;
-  (void)hipMemcpyAsync(c->d_scal + SC_RADIUS, c->h_radius, sizeof(double), hipMemcpyHostToDevice, c->stream);
+  if (c->use_graphs) {   // replayed kernels read the radius from device memory
+    *c->h_radius = radius;
+    (void)hipMemcpyAsync(c->d_scal + SC_RADIUS, c->h_radius, sizeof(double), hipMemcpyHostToDevice, c->stream);
+  }
   if (c->graphs_ok) {
     hipGraphExec_t g = kind == STEP_FIRST ? c->g_first : kind == STEP_ACCEPT ? c->g_accept : c->g_reject;
     if (hipGraphLaunch(g, c->stream) == hipSuccess) return;
@@ -911,8 +924,9 @@ void run_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius) {
 
 int fetch_scalars(bsgpu_ctx* c) {
   HIPCHK(c, hipGetLastError());  // a kernel that failed to launch must not pass silently
-  HIPCHK(c, hipMemcpyAsync(c->h_scal, c->d_scal, sizeof(double) * SC_NUM, hipMemcpyDeviceToHost, c->stream));
+  if (!c->scal_mirrored) HIPCHK(c, hipMemcpyAsync(c->h_scal, c->d_scal, sizeof(double) * SC_NUM, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->scal_mirrored = false;
   return BSGPU_OK;
 }
 

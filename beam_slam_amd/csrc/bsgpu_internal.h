@@ -181,9 +181,10 @@ void launch_update(hipStream_t s, int nb, const int* blk_xoff, const int* blk_to
 void launch_sum(hipStream_t s, const double* part, int n, double* out, int accumulate);
 void launch_sum2(hipStream_t s, const double* part, int n_pairs, double* out_a, double* out_b);
 void launch_zero(hipStream_t s, double* p, int64_t n);
-void launch_zero_multi(hipStream_t s, double* big, int64_t nbig, double* a, int na, double* b, int nb, double* c, int nc);
+void launch_zero_multi(hipStream_t s, double* big, int64_t nbig, double* a, int na, double* b, int nb, double* c, int nc,
+                       double* radius_slot, double radius);
 void launch_copy(hipStream_t s, const double* src, double* dst, int64_t n, int nzero_after);
-void launch_final_reduce(hipStream_t s, const ReduceEntry* entries, int n_entries, int n_slots, double* scal);
+void launch_final_reduce(hipStream_t s, const ReduceEntry* entries, int n_entries, int n_slots, double* scal, double* host_scal);
 
 // measurement: the reprojection Jacobian kernel alone
 void launch_reproj_jacobian_only(hipStream_t s, const Visual& v, const double* x, const DevCamera* cams,

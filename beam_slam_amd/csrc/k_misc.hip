@@ -130,10 +130,14 @@ void launch_sum2(hipStream_t s, const double* part, int n_pairs, double* out_a, 
 
 // One launch at the end of an LM step: workgroup `slot` adds up, in a fixed order, every partial array
 // registered for that scalar (costs of the factor groups, model-cost-change terms, step / x norms).
-__global__ __launch_bounds__(256) void final_reduce_kernel(const ReduceEntry* __restrict__ entries, int n_entries,
-                                                           double* __restrict__ scal) {
+__global__ __launch_bounds__(256) void final_reduce_kernel(const ReduceEntry* __restrict__ entries, int n_entries, int n_slots,
+                                                           double* __restrict__ scal, double* __restrict__ host_scal) {
   __shared__ double sred[4];
   const int slot = blockIdx.x;
+  if (slot == n_slots) {   // the scalars earlier kernels of the step produced (gradient norms, Cholesky flag, ...) -> host mirror
+    if (host_scal) for (int i = n_slots + threadIdx.x; i < SC_NUM; i += 256) host_scal[i] = scal[i];
+    return;
+  }
   double acc = 0.0;
   bool any = false;
   for (int e = 0; e < n_entries; ++e) {
@@ -145,10 +149,15 @@ __global__ __launch_bounds__(256) void final_reduce_kernel(const ReduceEntry* __
     acc += a;
   }
   const double t = block_sum_256(acc, sred);
-  if (threadIdx.x == 0 && any) scal[slot] = t;
+  if (threadIdx.x == 0) {
+    if (any) scal[slot] = t;
+    // mirror in pinned host memory: the host reads the step's scalars right after the stream drains, without a
+    // device-to-host copy of its own on the dependent path
+    if (host_scal) host_scal[slot] = any ? t : scal[slot];
+  }
 }
-void launch_final_reduce(hipStream_t s, const ReduceEntry* entries, int n_entries, int n_slots, double* scal) {
-  if (n_entries > 0) hipLaunchKernelGGL(final_reduce_kernel, dim3(n_slots), dim3(256), 0, s, entries, n_entries, scal);
+void launch_final_reduce(hipStream_t s, const ReduceEntry* entries, int n_entries, int n_slots, double* scal, double* host_scal) {
+  if (n_entries > 0) hipLaunchKernelGGL(final_reduce_kernel, dim3(n_slots + 1), dim3(256), 0, s, entries, n_entries, n_slots, scal, host_scal);
 }
 
 // plain kernels instead of hipMemsetAsync / hipMemcpyAsync for the buffers of an LM step: the runtime's fill / copy
@@ -173,18 +182,21 @@ void launch_zero(hipStream_t s, double* p, int64_t n) {
 }
 // one launch for the buffers an LM step clears: the (large, 16-byte aligned) reduced system plus up to three small arrays
 __global__ __launch_bounds__(256) void zero_multi_kernel(double2* __restrict__ big2, int64_t nbig2, double* __restrict__ a, int na,
-                                                         double* __restrict__ b, int nb, double* __restrict__ c, int nc) {
+                                                         double* __restrict__ b, int nb, double* __restrict__ c, int nc,
+                                                         double* __restrict__ radius_slot, double radius) {
   const int64_t stride = (int64_t)gridDim.x * 256;
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (radius_slot && t == 0) *radius_slot = radius;   // the step's trust-region radius rides in as a kernel argument
   for (int64_t i = t; i < nbig2; i += stride) big2[i] = make_double2(0.0, 0.0);
   for (int64_t i = t; i < na; i += stride) a[i] = 0.0;
   for (int64_t i = t; i < nb; i += stride) b[i] = 0.0;
   for (int64_t i = t; i < nc; i += stride) c[i] = 0.0;
 }
-void launch_zero_multi(hipStream_t s, double* big, int64_t nbig /* even, 16-byte aligned */, double* a, int na, double* b, int nb, double* c, int nc) {
+void launch_zero_multi(hipStream_t s, double* big, int64_t nbig /* even, 16-byte aligned */, double* a, int na, double* b, int nb, double* c, int nc,
+                       double* radius_slot, double radius) {
   const int64_t n2 = nbig / 2;
   const int grid = (int)std::min<int64_t>(std::max<int64_t>((n2 + 255) / 256, 1), 2048);
-  hipLaunchKernelGGL(zero_multi_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<double2*>(big), n2, a, na, b, nb, c, nc);
+  hipLaunchKernelGGL(zero_multi_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<double2*>(big), n2, a, na, b, nb, c, nc, radius_slot, radius);
 }
 __global__ __launch_bounds__(256) void copy_kernel(const double* __restrict__ src, double* __restrict__ dst, int64_t n, int nzero_after) {
   const int64_t stride = (int64_t)gridDim.x * 256;
