@@ -800,8 +800,7 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
   launch_landmark(s, c->vis, c->n_pose, c->d_scal + SC_RADIUS, first ? 1 : 0, new_J ? 1 : 0, o.jacobi_scaling, o.min_lm_diagonal,
                   o.max_lm_diagonal, c->d_scale, c->d_dcl, c->d_grad);
   launch_pairs(s, c->vis, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm);
-  for (int t = 2; t < kNumInternal; ++t)
-    launch_small_assemble(s, c->small[t], c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm);
+  launch_small_assemble_set(s, c->small + 2, kNumInternal - 2, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm);
   for (const auto& mc : c->marg)
     if (mc.active) launch_marg_assemble(s, mc.dev, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm);
   launch_pose_diag(s, c->n_pose, c->d_S, c->npad, c->d_hdiag, c->d_scal + SC_RADIUS, first ? 1 : 0, new_J ? 1 : 0, o.jacobi_scaling,
@@ -857,8 +856,7 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
   launch_backsub_landmarks(s, c->vis, c->n_pose, c->d_ytan, c->d_delta);
   // model cost change terms, candidate point and its cost: partial arrays only, summed once at the end
   if (c->vis.n) launch_mcc(s, c->vis, c->n_pose, c->d_delta, c->vis.mcc_part);
-  for (int t = 2; t < kNumInternal; ++t)
-    if (c->small[t].n) launch_small_mcc(s, c->small[t], c->d_delta, c->d_small_part_mcc[t]);
+  launch_small_mcc_set(s, c->small + 2, c->d_small_part_mcc + 2, kNumInternal - 2, c->d_delta);
   for (const auto& mc : c->marg)
     if (mc.active) launch_marg_mcc(s, mc.dev, c->d_delta, mc.part_mcc);
   int n_part = 0;

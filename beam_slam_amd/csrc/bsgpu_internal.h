@@ -55,6 +55,15 @@ struct SmallGroup {
   const DevCamera* cams = nullptr;
 };
 
+// several pose-only groups handed to one launch
+constexpr int kSetMax = 4;
+struct SmallGroupSet {
+  SmallGroup g[kSetMax];
+  double* part[kSetMax];
+  int first[kSetMax + 1];   // first workgroup of every group; first[n] = grid size
+  int n;
+};
+
 // dense linear prior factor ([EXT] fuse_constraints::MarginalConstraint) on the device (k_marg.hip)
 struct MargDev {
   int rows = 0, cols = 0, nblk = 0;
@@ -123,8 +132,8 @@ void launch_landmark(hipStream_t s, const Visual& v, int n_pose, const double* r
                      int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* scale, double* dcl,
                      double* grad);
 void launch_pairs(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm);
-void launch_small_assemble(hipStream_t s, const SmallGroup& g, double* S, int ld, int rhs_row, double* grad,
-                           double* hdiag, const int* perm);
+void launch_small_assemble_set(hipStream_t s, const SmallGroup* groups, int n_groups, double* S, int ld, int rhs_row, double* grad,
+                               double* hdiag, const int* perm);
 void launch_pose_diag(hipStream_t s, int n_pose, double* S, int ld, const double* hdiag, const double* radius_ptr,
                       int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* scale,
                       double* dcl, int npad, const int* iperm);
@@ -174,7 +183,7 @@ int pcg_iters_slot();
 void launch_backsub_landmarks(hipStream_t s, const Visual& v, int n_pose, const double* y_pose, double* delta);
 void launch_negate_pose(hipStream_t s, int n_pose, const double* y, double* delta);
 void launch_mcc(hipStream_t s, const Visual& v, int n_pose, const double* delta, double* part);
-void launch_small_mcc(hipStream_t s, const SmallGroup& g, const double* delta, double* part /* n */);
+void launch_small_mcc_set(hipStream_t s, const SmallGroup* groups, double* const* parts, int n_groups, const double* delta);
 void launch_update(hipStream_t s, int nb, const int* blk_xoff, const int* blk_toff, const unsigned char* blk_size,
                    const unsigned char* blk_manifold, const double* x, const double* delta, double* x_cand,
                    double* part /* 2 * nblocks_grid */, int* n_part);

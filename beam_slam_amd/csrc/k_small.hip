@@ -713,13 +713,18 @@ void launch_small_eval(hipStream_t s, const SmallGroup& g, const double* x, cons
 // assembly of a pose-only group into the dense reduced system: one wave per factor, J staged in LDS,
 // lanes stride over the (column a, column b) pairs; FP64 atomics into S, the rhs row, grad and hdiag.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void small_assemble_kernel(SmallGroup g, double* __restrict__ S, int ld, int rhs_row,
+// up to kSetMax groups per launch (a window has two or three pose-only factor types, some with a single factor: one
+// launch each would cost more in dispatch than in work)
+__global__ __launch_bounds__(64) void small_assemble_kernel(SmallGroupSet set, double* __restrict__ S, int ld, int rhs_row,
                                                             double* __restrict__ grad, double* __restrict__ hdiag,
                                                             const int* __restrict__ perm) {
   __shared__ double sJ[15 * 30];
   __shared__ double sr[15];
   __shared__ int st[10];
-  const int f = blockIdx.x, lane = threadIdx.x;
+  int gi = 0;
+  while (gi + 1 < set.n && (int)blockIdx.x >= set.first[gi + 1]) ++gi;
+  const SmallGroup& g = set.g[gi];
+  const int f = blockIdx.x - set.first[gi], lane = threadIdx.x;
   if (!g.active[f]) return;
   const int m = g.m, tw = 3 * g.nv;
   const double* J = g.J + (size_t)f * m * tw;
@@ -748,17 +753,34 @@ __global__ __launch_bounds__(64) void small_assemble_kernel(SmallGroup g, double
   }
 }
 
-void launch_small_assemble(hipStream_t s, const SmallGroup& g, double* S, int ld, int rhs_row, double* grad,
-                           double* hdiag, const int* perm) {
-  if (g.n == 0) return;
-  hipLaunchKernelGGL(small_assemble_kernel, dim3(g.n), dim3(64), 0, s, g, S, ld, rhs_row, grad, hdiag, perm);
+void launch_small_assemble_set(hipStream_t s, const SmallGroup* groups, int n_groups, double* S, int ld, int rhs_row, double* grad,
+                               double* hdiag, const int* perm) {
+  SmallGroupSet set;
+  set.n = 0;
+  int blocks = 0;
+  auto flush = [&]() {
+    if (!set.n) return;
+    set.first[set.n] = blocks;
+    hipLaunchKernelGGL(small_assemble_kernel, dim3(blocks), dim3(64), 0, s, set, S, ld, rhs_row, grad, hdiag, perm);
+    set.n = 0; blocks = 0;
+  };
+  for (int i = 0; i < n_groups; ++i) {
+    if (!groups[i].n) continue;
+    set.g[set.n] = groups[i]; set.first[set.n] = blocks; set.part[set.n] = nullptr;
+    blocks += groups[i].n; ++set.n;
+    if (set.n == kSetMax) flush();
+  }
+  flush();
 }
 
 // model cost change term of a pose-only group, one lane per residual row:
 //   part[f*m + k] = -(J_k d) (r_k + J_k d / 2)
-__global__ __launch_bounds__(128) void small_mcc_kernel(SmallGroup g, const double* __restrict__ delta,
-                                                        double* __restrict__ part) {
-  const int id = blockIdx.x * 128 + threadIdx.x;
+__global__ __launch_bounds__(128) void small_mcc_kernel(SmallGroupSet set, const double* __restrict__ delta) {
+  int gi = 0;
+  while (gi + 1 < set.n && (int)blockIdx.x >= set.first[gi + 1]) ++gi;
+  const SmallGroup& g = set.g[gi];
+  double* part = set.part[gi];
+  const int id = (blockIdx.x - set.first[gi]) * 128 + threadIdx.x;
   const int m = g.m;
   if (id >= g.n * m) return;
   const int f = id / m, k = id - f * m;
@@ -779,9 +801,23 @@ __global__ __launch_bounds__(128) void small_mcc_kernel(SmallGroup g, const doub
   part[id] = acc;
 }
 
-void launch_small_mcc(hipStream_t s, const SmallGroup& g, const double* delta, double* part) {
-  if (g.n == 0) return;
-  hipLaunchKernelGGL(small_mcc_kernel, dim3((g.n * g.m + 127) / 128), dim3(128), 0, s, g, delta, part);
+void launch_small_mcc_set(hipStream_t s, const SmallGroup* groups, double* const* parts, int n_groups, const double* delta) {
+  SmallGroupSet set;
+  set.n = 0;
+  int blocks = 0;
+  auto flush = [&]() {
+    if (!set.n) return;
+    set.first[set.n] = blocks;
+    hipLaunchKernelGGL(small_mcc_kernel, dim3(blocks), dim3(128), 0, s, set, delta);
+    set.n = 0; blocks = 0;
+  };
+  for (int i = 0; i < n_groups; ++i) {
+    if (!groups[i].n) continue;
+    set.g[set.n] = groups[i]; set.first[set.n] = blocks; set.part[set.n] = parts[i];
+    blocks += (groups[i].n * groups[i].m + 127) / 128; ++set.n;
+    if (set.n == kSetMax) flush();
+  }
+  flush();
 }
 
 }  // namespace bsg
