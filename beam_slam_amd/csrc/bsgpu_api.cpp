@@ -121,7 +121,7 @@ struct bsgpu_ctx {
   // tiled Cholesky plan (dense_plan.h) and its device tables
   DensePlan plan;
   std::vector<uint8_t> tile_adj;   // natural-tile adjacency of the reduced system
-  int *d_perm = nullptr, *d_iperm = nullptr, *d_nreal = nullptr, *d_rows_flat = nullptr, *d_potrf_tiles = nullptr;
+  int *d_perm = nullptr, *d_iperm = nullptr, *d_nreal = nullptr, *d_rows_flat = nullptr;
   PanelDesc* d_panels = nullptr;
   int *d_panel_of_tile = nullptr, *d_chain_begin = nullptr, *d_chain_end = nullptr;
   double* d_Vinv = nullptr;
@@ -628,7 +628,7 @@ int finalize(bsgpu_ctx* c) {
     std::vector<int> iperm(T + 1, -1);
     for (int t = 0; t < T; ++t) iperm[c->plan.perm[t]] = t;
     c->d_perm = c->upload(c->plan.perm); c->d_iperm = c->upload(iperm); c->d_nreal = c->upload(c->plan.nreal);
-    c->d_rows_flat = c->upload(c->plan.rows_flat); c->d_potrf_tiles = c->upload(c->plan.potrf_tiles);
+    c->d_rows_flat = c->upload(c->plan.rows_flat);
     c->d_panels = c->upload(c->plan.panels);
     c->d_panel_of_tile = c->upload(c->plan.panel_of_tile);
     c->d_chain_begin = c->upload(c->plan.chain_begin); c->d_chain_end = c->upload(c->plan.chain_end);
@@ -813,7 +813,7 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
 // Cholesky of the (padded, rhs-augmented, solver-ordered) reduced system in S and the solve L^T y = y',
 // following the plan's step schedule.  y comes back in solver order (npad entries).
 struct DenseDev {
-  const int *perm, *nreal, *rows_flat, *potrf_tiles;
+  const int *perm, *nreal, *rows_flat;
   const PanelDesc* panels;
   double *Lp, *Vinv;
   const int *panel_of_tile, *chain_begin, *chain_end;
@@ -848,7 +848,7 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
     pcg_solve(c, o);
     launch_negate_pose(s, c->n_pose, c->d_px, c->d_delta);
   } else if (c->n_pose > 0) {
-    const DenseDev D{c->d_perm, c->d_nreal, c->d_rows_flat, c->d_potrf_tiles, c->d_panels, c->d_Lp, c->d_Vinv,
+    const DenseDev D{c->d_perm, c->d_nreal, c->d_rows_flat, c->d_panels, c->d_Lp, c->d_Vinv,
                      c->d_panel_of_tile, c->d_chain_begin, c->d_chain_end};
     dense_factor_solve(s, c->plan, D, c->d_S, c->d_y, c->d_scal);
     launch_y_to_delta(s, c->n_pose, c->d_y, c->d_perm, c->d_ytan, c->d_delta);
@@ -1522,7 +1522,7 @@ int bsgpu_covariance(bsgpu_ctx* c, int32_t ba, int32_t bb, double* out) {
   if (hipMalloc((void**)&d_out, sizeof(double) * ta * tb) != hipSuccess) { (void)hipFree(d_cols); return fail(c, BSGPU_ERR_DEVICE, "out of device memory"); }
   (void)hipMemcpyAsync(d_cols, cols.data(), sizeof(int) * cols.size(), hipMemcpyHostToDevice, s);
   launch_cov_units(s, c->d_S, c->npad, c->plan.rhs_row, d_cols, (int)cols.size());
-  const DenseDev D{c->d_perm, c->d_nreal, c->d_rows_flat, c->d_potrf_tiles, c->d_panels, c->d_Lp, c->d_Vinv,
+  const DenseDev D{c->d_perm, c->d_nreal, c->d_rows_flat, c->d_panels, c->d_Lp, c->d_Vinv,
                    c->d_panel_of_tile, c->d_chain_begin, c->d_chain_end};
   dense_factor(s, c->plan, D, c->d_S, c->d_scal);
   launch_cov_dots(s, c->d_Lp, c->npad, c->plan.rhs_row, c->plan.T * 64, ta, row_b0, tb, d_out);
@@ -1641,7 +1641,7 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
   for (int j = 0; j < n; ++j) real[P.spos(j)] = 1;
   for (int i = 0; i < npad; ++i) if (!real[i]) hS[(size_t)i * npad + i] = 1.0;
   double *dS = nullptr, *dLp = nullptr, *dV = nullptr, *dy = nullptr, *dscal = nullptr;
-  int *dperm = nullptr, *dnreal = nullptr, *drows = nullptr, *dpot = nullptr;
+  int *dperm = nullptr, *dnreal = nullptr, *drows = nullptr;
   PanelDesc *dpan = nullptr, *dsep = nullptr;
   int *dpot2 = nullptr, *dcb = nullptr, *dce = nullptr;
   hipStream_t s;
@@ -1653,10 +1653,9 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
   bool ok = hipMalloc(&dS, sizeof(double) * hS.size()) == hipSuccess && hipMalloc(&dLp, sizeof(double) * hS.size()) == hipSuccess &&
             hipMalloc(&dV, sizeof(double) * chol_vinv_stride() * std::max(1, T)) == hipSuccess && hipMalloc(&dy, sizeof(double) * npad) == hipSuccess &&
             hipMalloc(&dscal, sizeof(double) * SC_NUM) == hipSuccess;
-  std::vector<int> pt = P.potrf_tiles; if (pt.empty()) pt.push_back(0);
   std::vector<int> rf = P.rows_flat; if (rf.empty()) rf.push_back(0);
   ok = ok && up(P.perm.data(), sizeof(int) * P.perm.size(), (void**)&dperm) && up(P.nreal.data(), sizeof(int) * P.nreal.size(), (void**)&dnreal) &&
-       up(rf.data(), sizeof(int) * rf.size(), (void**)&drows) && up(pt.data(), sizeof(int) * pt.size(), (void**)&dpot) &&
+       up(rf.data(), sizeof(int) * rf.size(), (void**)&drows) &&
        up(P.panels.data(), sizeof(PanelDesc) * P.panels.size(), (void**)&dpan) &&
        up(P.panel_of_tile.data(), sizeof(int) * P.panel_of_tile.size(), (void**)&dpot2) &&
        up(P.chain_begin.data(), sizeof(int) * P.chain_begin.size(), (void**)&dcb) && up(P.chain_end.data(), sizeof(int) * P.chain_end.size(), (void**)&dce);
@@ -1667,7 +1666,7 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, s);
-    const DenseDev D{dperm, dnreal, drows, dpot, dpan, dLp, dV, dpot2, dcb, dce};
+    const DenseDev D{dperm, dnreal, drows, dpan, dLp, dV, dpot2, dcb, dce};
     dense_factor_solve(s, P, D, dS, dy, dscal);
     (void)hipEventRecord(e1, s);
     if (hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess) rc = BSGPU_ERR_DEVICE;
@@ -1683,7 +1682,7 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   } else rc = BSGPU_ERR_DEVICE;
   (void)hipFree(dS); (void)hipFree(dLp); (void)hipFree(dV); (void)hipFree(dy); (void)hipFree(dscal);
-  (void)hipFree(dperm); (void)hipFree(dnreal); (void)hipFree(drows); (void)hipFree(dpot); (void)hipFree(dpan);
+  (void)hipFree(dperm); (void)hipFree(dnreal); (void)hipFree(drows); (void)hipFree(dpan);
   (void)hipFree(dsep); (void)hipFree(dpot2); (void)hipFree(dcb); (void)hipFree(dce);
   (void)hipStreamDestroy(s);
   return rc;

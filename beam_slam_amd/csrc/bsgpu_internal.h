@@ -145,8 +145,6 @@ void launch_chol_potrf_tiles(hipStream_t s, double* S, double* Lp, int ld, const
 void launch_chol_panel_step(hipStream_t s, double* S, double* Lp, int ld, const PanelDesc* descs_dev, int n_panels, int max_rows,
                             const int* rows_flat_dev, const int* nreal_dev, double* Vinv, double* scal,
                             const PanelDesc* descs_host = nullptr, const int* rows_flat_host = nullptr);
-void launch_chol_backsolve_step(hipStream_t s, const double* S, const double* Lp, const double* Vinv, int ld,
-                                const PanelDesc* descs_dev, int n_panels, const int* rows_flat_dev, const int* nreal_dev, double* y);
 void launch_chol_backsolve_chains(hipStream_t s, const double* S, const double* Lp, const double* Vinv, int ld,
                                   const PanelDesc* panels_dev, const int* panel_of_tile_dev, const int* chain_begin_dev,
                                   const int* chain_end_dev, int n_chains, const int* rows_flat_dev, const int* nreal_dev, double* y,
@@ -188,7 +186,6 @@ void launch_update(hipStream_t s, int nb, const int* blk_xoff, const int* blk_to
                    const unsigned char* blk_manifold, const double* x, const double* delta, double* x_cand,
                    double* part /* 2 * nblocks_grid */, int* n_part);
 void launch_sum(hipStream_t s, const double* part, int n, double* out, int accumulate);
-void launch_sum2(hipStream_t s, const double* part, int n_pairs, double* out_a, double* out_b);
 void launch_zero(hipStream_t s, double* p, int64_t n);
 void launch_zero_multi(hipStream_t s, double* big, int64_t nbig, double* a, int na, double* b, int nb, double* c, int nc,
                        double* radius_slot, double radius);

@@ -477,18 +477,8 @@ BSG_DEV void backsolve_panel(int kb, const int* rows /* n_rows row tiles (LDS or
   }
 }
 
-__global__ __launch_bounds__(1024) void chol_backsolve_step_kernel(const double* S, const double* Lp, const double* Vinv, int ld,
-                                                                   const PanelDesc* __restrict__ descs,
-                                                                   const int* __restrict__ rows_flat,
-                                                                   const int* __restrict__ nreal, double* y) {
-  __shared__ double sL[NB * (NB + 1)];
-  __shared__ double sp[16 * NB];
-  const PanelDesc pd = descs[blockIdx.x];
-  backsolve_panel(pd.k, rows_flat + pd.row_off, pd.n_rows, nreal[pd.k], S, Lp, Vinv, ld, y, y, nullptr, sL, sp, threadIdx.x);
-}
-
-// one workgroup per independent piece of the nested-dissection ordering, walking its panels from the
-// separator end down to its first tile (everything a piece depends on — its separators — is solved already)
+// one workgroup per chain (a separator, or a piece of the nested-dissection ordering), walking its panels from its last
+// tile down to its first; everything a chain depends on outside itself was solved by an earlier launch (dense_plan.h)
 constexpr int kBsMaxRows = 16;   // row lists up to this length are staged in LDS
 __global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double* S, const double* Lp, const double* Vinv, int ld,
                                                                     const PanelDesc* __restrict__ panels,
@@ -524,13 +514,6 @@ __global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double
     backsolve_panel(k, rows, n_rows, s_nr[p], S, Lp, Vinv, ld, sy, y, sy, sL, sp, tid);
     __syncthreads();
   }
-}
-
-void launch_chol_backsolve_step(hipStream_t s, const double* S, const double* Lp, const double* Vinv, int ld,
-                                const PanelDesc* descs_dev, int n_panels, const int* rows_flat_dev, const int* nreal_dev, double* y) {
-  if (n_panels <= 0) return;
-  hipLaunchKernelGGL(chol_backsolve_step_kernel, dim3(n_panels), dim3(1024), 0, s, S, Lp, Vinv, ld, descs_dev, rows_flat_dev,
-                     nreal_dev, y);
 }
 
 void launch_chol_backsolve_chains(hipStream_t s, const double* S, const double* Lp, const double* Vinv, int ld,

@@ -115,19 +115,6 @@ __global__ __launch_bounds__(256) void sum_kernel(const double* __restrict__ par
 void launch_sum(hipStream_t s, const double* part, int n, double* out, int accumulate) {
   hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, s, part, n, out, accumulate);
 }
-__global__ __launch_bounds__(256) void sum2_kernel(const double* __restrict__ part, int n, double* __restrict__ oa,
-                                                   double* __restrict__ ob) {
-  __shared__ double sred[4];
-  double a = 0.0, b = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) { a += part[2 * i]; b += part[2 * i + 1]; }
-  const double ta = block_sum_256(a, sred);
-  const double tb = block_sum_256(b, sred);
-  if (threadIdx.x == 0) { *oa = ta; *ob = tb; }
-}
-void launch_sum2(hipStream_t s, const double* part, int n_pairs, double* out_a, double* out_b) {
-  hipLaunchKernelGGL(sum2_kernel, dim3(1), dim3(256), 0, s, part, n_pairs, out_a, out_b);
-}
-
 // One launch at the end of an LM step: workgroup `slot` adds up, in a fixed order, every partial array
 // registered for that scalar (costs of the factor groups, model-cost-change terms, step / x norms).
 __global__ __launch_bounds__(256) void final_reduce_kernel(const ReduceEntry* __restrict__ entries, int n_entries, int n_slots,
