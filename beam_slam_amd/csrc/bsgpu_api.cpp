@@ -86,6 +86,7 @@ struct bsgpu_ctx {
   int row0[BSGPU_F_NUM_TYPES] = {0};
   bool vis_any_inactive = false; // some reprojection factor has q, p and landmark all constant
   std::vector<int> vis_src;      // sorted visual position -> (type<<28 | index in its host group)
+  int* d_vis_src = nullptr;      // ... on the device when the window was flattened there (downloaded on demand)
   std::vector<HostMarginal> marginals;
   struct MargCtx { MargDev dev; int row0 = 0; bool active = true; double *part = nullptr, *part_cand = nullptr, *part_mcc = nullptr; };
   std::vector<MargCtx> marg;
@@ -295,13 +296,19 @@ int finalize(bsgpu_ctx* c) {
   }
   std::map<std::tuple<int, int, int>, int> derived_cam;
 
-  // ---- visual factors: gather, sort by landmark
-  struct VF { int xq, xp, xl, bq, bp, meta_cam, loss, flags, lm, src; double u, v, w; };
-  std::vector<VF> vf;
+  // ---- visual factors: camera-pose ids, factors sorted by landmark, pair entries, tile adjacency.
+  // Large plain windows are flattened on the device (k_flatten.hip); everything else — and any window the device
+  // path declines (online calibration, landmark blocks shared with other factors, more than 8 distinct losses, an
+  // orientation block paired with two position blocks) — takes the host path below.  BSGPU_FLATTEN=host|device forces one.
   c->any_inactive = false;
   c->vis_any_inactive = false;
   c->groups[T_REPROJ_DENSE] = HostGroup();
   c->dense_src.clear();
+  c->vis_src.clear();
+  c->d_vis_src = nullptr;
+  auto host_visual = [&]() -> int {
+  struct VF { int xq, xp, xl, bq, bp, meta_cam, loss, flags, lm, src; double u, v, w; };
+  std::vector<VF> vf;
   for (int t = 0; t <= 1; ++t) {
     const HostGroup& g = c->groups[t];
     const TypeInfo& ti = kTypes[t];
@@ -465,13 +472,6 @@ int finalize(bsgpu_ctx* c) {
     V.cp_tq = c->upload(cp_tq); V.cp_tp = c->upload(cp_tp);
     V.seg_ci = c->upload(seg_ci); V.seg_cj = c->upload(seg_cj); V.seg_start = c->upload(seg_start);
     V.ent_fa = c->upload(ent_fa); V.ent_fb = c->upload(ent_fb);
-    V.r = c->alloc<double2>(nv); V.J = c->alloc<double>((size_t)nv * 18); V.CR = c->alloc<double>((size_t)nv * 8);
-    V.Linv = c->alloc<double>((size_t)nl * 6); V.z = c->alloc<double>((size_t)nl * 3);
-    V.n_cost_part = (nv + 255) / 256;
-    V.cost_part = c->alloc<double>(V.n_cost_part);
-    V.cost_part_cand = c->alloc<double>(V.n_cost_part);
-    V.mcc_part = c->alloc<double>(V.n_cost_part);
-    if (!V.J || !V.CR || !V.r) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (visual tables)");
     // structural tile adjacency of the reduced system (natural 64-wide tiles) for the Cholesky plan
     const int T = (c->n_pose + 63) / 64;
     c->tile_adj.assign((size_t)T * T, 0);
@@ -486,6 +486,51 @@ int finalize(bsgpu_ctx* c) {
       const int ri[2] = {cp_tq[i], cp_tp[i]}, rj[2] = {cp_tq[j], cp_tp[j]};
       for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) touch(ri[a], rj[b]);
     }
+  }
+    return BSGPU_OK;
+  };
+  bool flattened_on_device = false;
+  {
+    const char* fe = getenv("BSGPU_FLATTEN");
+    const bool force_dev = fe && !strcmp(fe, "device"), force_host = fe && !strcmp(fe, "host");
+    const HostGroup& g0 = c->groups[BSGPU_F_REPROJ];
+    if (!force_host && c->groups[BSGPU_F_REPROJ_ONLINE_CALIB].n == 0 && g0.n > 0 && (force_dev || g0.n >= 20000)) {
+      // distinct losses of the reprojection factors (a window has one or two)
+      bool ok = true;
+      for (int f = 0; f < g0.n && ok; ++f) { get_loss(g0.loss_kind[f], g0.loss_a[f]); ok = losses.size() <= 8; }
+      if (ok) {
+        std::vector<int> bx(c->off.begin(), c->off.end());
+        std::vector<unsigned char> bc(c->is_const.begin(), c->is_const.end());
+        const int* d_bx = c->upload(bx); const int* d_bt = c->upload(c->toff);
+        const unsigned char* d_bc = c->upload(bc); const int* d_bl = c->upload(lm_index);
+        const int T = (c->n_pose + 63) / 64;
+        bool all_const = false;
+        auto dalloc = [&](size_t bytes) -> void* { return c->alloc<unsigned char>(bytes); };
+        const int st = flatten_visual_device(c->stream, dalloc, g0.n, g0.idx.data(), g0.consts.data(), g0.loss_kind.data(), g0.loss_a.data(),
+                                             losses, nb, d_bx, d_bt, d_bc, d_bl, nl, T, c->vis, &c->d_vis_src, c->tile_adj, &all_const);
+        if (st < 0) return fail(c, BSGPU_ERR_DEVICE, "device error while flattening the reprojection factors");
+        if (st == 0) {
+          flattened_on_device = true;
+          if (all_const) { c->any_inactive = true; c->vis_any_inactive = true; }
+          if (c->vis.n_cam_pose >= (1 << 20)) return fail(c, BSGPU_ERR_UNSUPPORTED, "too many camera poses");
+        } else {
+          c->vis = Visual();
+        }
+      }
+    }
+  }
+  if (flattened_on_device) lap("flatten on device");
+  else { const int rc_host = host_visual(); if (rc_host != BSGPU_OK) return rc_host; }
+  Visual& V = c->vis;
+  {
+    const int nv = V.n;
+    V.r = c->alloc<double2>(nv); V.J = c->alloc<double>((size_t)nv * 18); V.CR = c->alloc<double>((size_t)nv * 8);
+    V.Linv = c->alloc<double>((size_t)nl * 6); V.z = c->alloc<double>((size_t)nl * 3);
+    V.n_cost_part = (nv + 255) / 256;
+    V.cost_part = c->alloc<double>(V.n_cost_part);
+    V.cost_part_cand = c->alloc<double>(V.n_cost_part);
+    V.mcc_part = c->alloc<double>(V.n_cost_part);
+    if (!V.J || !V.CR || !V.r) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (visual tables)");
   }
   lap("visual upload + alloc");
   // ---- pose-only groups
@@ -920,6 +965,14 @@ void run_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius) {
   enqueue_step(c, o, kind, radius);
 }
 
+// sorted visual position -> source factor: built on the host, or downloaded on first use when the device flattened the window
+int ensure_vis_src(bsgpu_ctx* c) {
+  if ((int)c->vis_src.size() == c->vis.n || !c->d_vis_src) return BSGPU_OK;
+  c->vis_src.resize(c->vis.n);
+  HIPCHK(c, hipMemcpy(c->vis_src.data(), c->d_vis_src, sizeof(int) * (size_t)c->vis.n, hipMemcpyDeviceToHost));
+  return BSGPU_OK;
+}
+
 int fetch_scalars(bsgpu_ctx* c) {
   HIPCHK(c, hipGetLastError());  // a kernel that failed to launch must not pass silently
   if (!c->scal_mirrored) HIPCHK(c, hipMemcpyAsync(c->h_scal, c->d_scal, sizeof(double) * SC_NUM, hipMemcpyDeviceToHost, c->stream));
@@ -1272,6 +1325,7 @@ int bsgpu_evaluate(bsgpu_ctx* c, double* cost, double* residuals, double* gradie
   std::vector<double> grad(n, 0.0);
   // visual factors: un-permute to (type, insertion) order
   const Visual& V = c->vis;
+  if ((rc = ensure_vis_src(c)) != BSGPU_OK) return rc;
   if (V.n) {
     std::vector<double> r((size_t)V.n * 2), J((size_t)V.n * 18);
     std::vector<int4> fac(V.n);
@@ -1541,6 +1595,7 @@ int bsgpu_reprojection_errors(bsgpu_ctx* c, double* err) {
   if (rc != BSGPU_OK) return rc;
   HIPCHK(c, hipSetDevice(c->device));
   const Visual& V = c->vis;
+  if ((rc = ensure_vis_src(c)) != BSGPU_OK) return rc;
   const SmallGroup& D = c->small[T_REPROJ_DENSE];
   const int n0 = c->groups[BSGPU_F_REPROJ].n;
   if (V.n + D.n == 0) return BSGPU_OK;

@@ -4,6 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <functional>
+#include <vector>
+
 namespace bsg {
 
 // ---- device-side tables -------------------------------------------------------------------------
@@ -162,6 +165,11 @@ void launch_reproj_errors(hipStream_t s, const Visual& v, const SmallGroup& dens
                           double* out_dense);
 void launch_preintegrate(hipStream_t s, int n_int, const int* sample_start, const double* ts, const double* wm, const double* am,
                          const double* t_end, const double* bg, const double* ba, const double* covs, double info_weight, double* out);
+// device-side flattening of the reprojection factors (k_flatten.hip): 0 = done, 1 = take the host path, < 0 = device error
+int flatten_visual_device(hipStream_t s, const std::function<void*(size_t)>& dalloc, int n, const int* h_idx, const double* h_consts,
+                          const int* h_loss_kind, const double* h_loss_a, const std::vector<DevLoss>& losses, int nb, const int* d_blk_xoff,
+                          const int* d_blk_toff, const unsigned char* d_blk_const, const int* d_blk_lm, int nl, int T, Visual& V,
+                          int** d_vis_src, std::vector<unsigned char>& tile_adj, bool* any_all_const);
 int chol_vinv_stride();
 void chol_prepare();  // one-time function attributes (kept out of captured sequences)
 // block-sparse PCG path (k_pcg.hip)

@@ -142,3 +142,52 @@ def test_exactly_one_tile(oracle_cls, gpu_solver_cls):
     _same_solve(g, o, tol_x=1e-6)
     x = g.get_blocks()
     assert abs(x[pr.offset[one]] - 0.25) < 1e-9
+
+
+@pytest.mark.parametrize("make", ["vio", "const_landmarks", "held_poses"])
+def test_device_and_host_flattening_build_the_same_tables(oracle_cls, gpu_solver_cls, make, monkeypatch):
+    """k_flatten.hip (rocPRIM sorts / scans on the raw factor table) against the host loops of finalize(): same factor
+    order, camera-pose ids, pair entries and tile adjacency => bit-identical evaluation and LM trajectory."""
+    pr = synthetic.vio_window(n_kf=9, n_lm=300, seed=41, track_min=1, track_max=6)
+    if make == "const_landmarks":
+        for b in pr.meta["lm_blocks"][::7]:
+            pr.is_const[int(b)] = 1
+    if make == "held_poses":
+        for b in pr.meta["kf_blocks"][0]:
+            pr.is_const[int(b)] = 1
+    out = {}
+    for mode in ("host", "device"):
+        monkeypatch.setenv("BSGPU_FLATTEN", mode)
+        g = gpu_solver_cls(0)
+        pr.load(g)
+        cost, r, grad, J = g.evaluate(jacobian=True)
+        err = g.reprojection_errors(pr.n_factors(capi.F_REPROJ))
+        s = g.solve()
+        out[mode] = (cost, r, grad, J, [i.cost for i in g.iterations()], g.get_blocks(), err)
+    monkeypatch.delenv("BSGPU_FLATTEN")
+    h, d = out["host"], out["device"]
+    assert h[0] == d[0] and np.array_equal(h[1], d[1]) and np.array_equal(h[3], d[3])          # evaluation: bit-identical
+    assert np.allclose(h[2], d[2], rtol=1e-13, atol=1e-9)                                       # (host-side sum of J^T r)
+    assert len(h[4]) == len(d[4]) and np.allclose(h[4], d[4], rtol=1e-10)                       # atomics in the Cholesky: not bitwise
+    assert np.abs(h[5] - d[5]).max() < 1e-8
+    assert np.array_equal(h[6], d[6])
+    o = oracle_cls()
+    pr.load(o)
+    assert abs(o.solve().final_cost - d[4][-1]) <= 1e-6 * d[4][-1]
+
+
+def test_device_flattening_declines_what_it_does_not_cover(oracle_cls, gpu_solver_cls, monkeypatch):
+    """Landmark blocks shared with another factor and online-calibration factors take the host path even when the device
+    path is forced; the result is the oracle's either way."""
+    monkeypatch.setenv("BSGPU_FLATTEN", "device")
+    pr = mixed_problem(9, n_state=4, n_lm=16, consistent=True)        # has online-calibration factors
+    lm0 = int(pr.meta["landmarks"][0])
+    A = synthetic.sqrt_information_upper(0.01 * np.eye(3))
+    pr.add_factors(capi.F_ABS_VEC3, [[lm0]], [np.concatenate([pr.block(lm0), A.ravel()])])
+    g, o = _both(pr, oracle_cls, gpu_solver_cls)
+    _same_solve(g, o)
+    pr2 = synthetic.vio_window(n_kf=6, n_lm=80, seed=42, track_min=2, track_max=5)   # plain reprojection + shared landmark
+    lm1 = int(pr2.meta["lm_blocks"][3])
+    pr2.add_factors(capi.F_ABS_VEC3, [[lm1]], [np.concatenate([pr2.block(lm1), A.ravel()])])
+    g2, o2 = _both(pr2, oracle_cls, gpu_solver_cls)
+    _same_solve(g2, o2, tol_x=1e-6)
