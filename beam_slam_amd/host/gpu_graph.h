@@ -82,7 +82,7 @@ class GpuGraph {
 
   // ---- fuse_core::Graph surface used by the reference ---------------------------------
   void clear() {
-    variables_.clear(); constraints_.clear(); by_variable_.clear(); connectivity_valid_ = true; on_hold_.clear(); order_dirty_ = true;
+    variables_.clear(); constraints_.clear(); by_variable_.clear(); connectivity_valid_ = true; on_hold_.clear(); ordered_.clear();
     for (auto& t : tables_) t = TypeTable();
     marginal_rows_.clear();
   }
@@ -107,8 +107,9 @@ class GpuGraph {
   bool addVariable(fuse_core::Variable::SharedPtr v) {
     auto it = variables_.find(v->uuid());
     if (it != variables_.end()) { std::memcpy(it->second->data(), v->data(), v->size() * sizeof(double)); return false; }  // HashGraph: overwrite value
+    const fuse_core::Variable* raw = v.get();
     variables_[v->uuid()] = std::move(v);
-    order_dirty_ = true;
+    ordered_.insert(std::upper_bound(ordered_.begin(), ordered_.end(), raw, orderBefore), raw);
     return true;
   }
   bool removeVariable(const fuse_core::UUID& u) {
@@ -117,8 +118,13 @@ class GpuGraph {
     ensureConnectivity();
     auto cit = by_variable_.find(u);
     if (cit != by_variable_.end() && !cit->second.empty()) throw std::logic_error("removeVariable: variable still used by a constraint");
+    {
+      const fuse_core::Variable* raw = it->second.get();
+      auto pos = std::lower_bound(ordered_.begin(), ordered_.end(), raw, orderBefore);
+      while (pos != ordered_.end() && *pos != raw) ++pos;   // (equal keys cannot occur: the uuid breaks every tie)
+      if (pos != ordered_.end()) ordered_.erase(pos);
+    }
     by_variable_.erase(u); on_hold_.erase(u); variables_.erase(it);
-    order_dirty_ = true;
     return true;
   }
   bool addConstraint(fuse_core::Constraint::SharedPtr c) {
@@ -180,7 +186,8 @@ class GpuGraph {
       for (auto& v : g->tables_[ty].vars) v = copies[v->flatIndex()];
     }
     g->marginal_rows_ = marginal_rows_;
-    order_dirty_ = true;   // the flat indices were borrowed
+    g->ordered_.reserve(ordered_.size());
+    for (const auto* v : ordered_) g->ordered_.push_back(copies[v->flatIndex()]);   // same order in the copy
     g->connectivity_valid_ = false;   // variable -> constraints index of the copy: rebuilt on first use (publishers rarely need it)
     g->on_hold_ = on_hold_;
     return g;
@@ -198,29 +205,9 @@ class GpuGraph {
   // Deterministic block order: keyframes ascending by stamp, (q,p,v,bg,ba) inside one
   // keyframe (ImuState::GetStateVector, imu_state.cpp:348-354); then landmarks ascending by id
   // (graph_access.cpp:200-216); unstamped extrinsic blocks last.
-  std::vector<const fuse_core::Variable*> orderedVariables() const {
-    if (!order_dirty_) return ordered_;
-    struct Key { int cls; int64_t a; int64_t b; const fuse_core::Variable* v; };
-    std::vector<Key> keys;
-    keys.reserve(variables_.size());
-    for (auto& kv : variables_) {
-      const fuse_core::Variable* v = kv.second.get();
-      Key k{2, 0, 0, v};
-      if (v->isStamped()) { k.cls = 0; k.a = v->stamp().ns; k.b = v->stateSlot(); }
-      else if (v->isLandmark()) { k.cls = 1; k.a = (int64_t)v->landmarkId(); }
-      keys.push_back(k);
-    }
-    // variables_ is uuid-ordered, so a stable sort on (class, stamp | id, slot) leaves ties in uuid order
-    std::stable_sort(keys.begin(), keys.end(), [](const Key& x, const Key& y) {
-      if (x.cls != y.cls) return x.cls < y.cls;
-      if (x.a != y.a) return x.cls == 1 ? (uint64_t)x.a < (uint64_t)y.a : x.a < y.a;
-      return x.b < y.b;
-    });
-    ordered_.clear();
-    for (const Key& k : keys) ordered_.push_back(k.v);
-    order_dirty_ = false;
-    return ordered_;
-  }
+  // The order is kept incrementally: a variable is inserted at its sorted position when it enters the graph and erased
+  // when it leaves (a sliding window adds and drops a few hundred variables per cycle out of tens of thousands).
+  const std::vector<const fuse_core::Variable*>& orderedVariables() const { return ordered_; }
 
   // Flat IR of the current graph (variables at their current values) loaded into the back-end context
   struct Flat {
@@ -468,8 +455,17 @@ class GpuGraph {
   std::vector<bsgpu_camera> cameras_;
   std::map<fuse_core::UUID, MarginalRow> marginal_rows_;
   std::map<fuse_core::UUID, CEntry> constraints_;
-  mutable std::vector<const fuse_core::Variable*> ordered_;   // cached deterministic block order
-  mutable bool order_dirty_ = true;
+  // (class: stamped / landmark / other, stamp | landmark id, state slot, uuid) — SURVEY.md §8a A17
+  static bool orderBefore(const fuse_core::Variable* x, const fuse_core::Variable* y) {
+    const int cx = x->isStamped() ? 0 : x->isLandmark() ? 1 : 2, cy = y->isStamped() ? 0 : y->isLandmark() ? 1 : 2;
+    if (cx != cy) return cx < cy;
+    if (cx == 0) {
+      if (x->stamp() != y->stamp()) return x->stamp() < y->stamp();
+      if (x->stateSlot() != y->stateSlot()) return x->stateSlot() < y->stateSlot();
+    } else if (cx == 1 && x->landmarkId() != y->landmarkId()) return x->landmarkId() < y->landmarkId();
+    return x->uuid() < y->uuid();
+  }
+  std::vector<const fuse_core::Variable*> ordered_;   // deterministic block order, maintained on insertion / removal
   void ensureConnectivity() const {
     if (connectivity_valid_) return;
     by_variable_.clear();

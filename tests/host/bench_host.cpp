@@ -58,7 +58,7 @@ int main(int argc, char** argv) {
     auto s = graph.optimize(opts);
     const auto b = clk::now();
     const auto& bs = graph.lastBackendSummary();
-    std::printf("cycle %d: optimize() %.1f ms total | back-end solve %.1f ms (%d it) | host flatten + hand-over + finalize %.1f ms | cost %.4e -> %.4e\n", rep,
+    std::printf("cycle %d: optimize() %.1f ms total | back-end (finalize + solve) %.1f ms (%d it) | host flatten + hand-over %.1f ms | cost %.4e -> %.4e\n", rep,
                 ms(a, b), 1e3 * bs.total_time_in_seconds, bs.num_iterations, ms(a, b) - 1e3 * bs.total_time_in_seconds, s.initial_cost, s.final_cost);
     const auto c0 = clk::now();
     auto copy = graph.clone();   // what fixed_lag_smoother.cpp:308 does every cycle for the publishers
