@@ -109,7 +109,7 @@ SYMBOLS = [
     "last_error", "abi_version", "clear", "set_blocks", "set_values", "set_cameras", "add_factors", "add_marginal",
     "finalize", "solve", "get_blocks", "reset_values", "num_iterations_recorded", "get_iteration",
     "evaluate", "num_residuals", "num_parameters_tangent", "tangent_offset", "covariance", "marginalize", "get_marginal",
-    "reprojection_errors", "preintegrate", "time_reproj_jacobian_ms", "reproj_jacobian_bytes", "dense_solve", "plan_info",
+    "reprojection_errors", "preintegrate", "triangulate", "time_reproj_jacobian_ms", "reproj_jacobian_bytes", "dense_solve", "plan_info",
 ]
 
 _dp = C.POINTER(C.c_double)

@@ -1650,6 +1650,57 @@ int bsgpu_preintegrate(int device, int32_t n, const int32_t* sample_start, const
   return rc;
 }
 
+int bsgpu_triangulate(bsgpu_ctx* c, int32_t n_tracks, const int32_t* track_start, const int32_t* q_block, const int32_t* p_block,
+                      const double* pixels, int32_t camera, int32_t truncate_pixels, double max_dist, double max_reproj, double* points,
+                      int32_t* status) {
+  if (n_tracks < 0 || !track_start || !points || !status) return fail(c, BSGPU_ERR_INVALID, "null argument");
+  if (n_tracks == 0) return BSGPU_OK;
+  const int n_obs = track_start[n_tracks];
+  if (track_start[0] != 0 || n_obs < 0 || (n_obs > 0 && (!q_block || !p_block || !pixels)))
+    return fail(c, BSGPU_ERR_INVALID, "triangulate: malformed track table");
+  if (camera < 0 || camera >= (int)c->cams.size()) return fail(c, BSGPU_ERR_INVALID, "camera index out of range");
+  std::vector<int32_t> pose_off((size_t)2 * n_obs);
+  for (int i = 0; i < n_tracks; ++i)
+    if (track_start[i + 1] < track_start[i]) return fail(c, BSGPU_ERR_INVALID, "triangulate: track_start must be non-decreasing");
+  for (int o = 0; o < n_obs; ++o) {
+    const int qb = q_block[o], pb = p_block[o];
+    if (qb < 0 || qb >= c->nb || pb < 0 || pb >= c->nb) return fail(c, BSGPU_ERR_INVALID, "triangulate: block out of range");
+    if (c->size[qb] != 4 || c->size[pb] != 3) return fail(c, BSGPU_ERR_INVALID, "triangulate: view blocks must be (orientation[4], position[3])");
+    pose_off[2 * (size_t)o] = c->off[qb];
+    pose_off[2 * (size_t)o + 1] = c->off[pb];
+  }
+  int rc = finalize(c);
+  if (rc != BSGPU_OK) return rc;
+  HIPCHK(c, hipSetDevice(c->device));
+  const bsgpu_camera& hc = c->cams[camera];
+  DevCamera cam;
+  cam.fx = hc.fx; cam.fy = hc.fy; cam.cx = hc.cx; cam.cy = hc.cy;
+  std::memcpy(cam.R, hc.R_cam_baselink, sizeof(cam.R));
+  std::memcpy(cam.t, hc.t_cam_baselink, sizeof(cam.t));
+  int *d_start = nullptr, *d_status = nullptr;
+  int2* d_off = nullptr;
+  double2* d_pix = nullptr;
+  double* d_pts = nullptr;
+  auto release = [&]() { (void)hipFree(d_start); (void)hipFree(d_status); (void)hipFree(d_off); (void)hipFree(d_pix); (void)hipFree(d_pts); };
+  hipError_t e = hipMalloc((void**)&d_start, sizeof(int) * ((size_t)n_tracks + 1));
+  if (e == hipSuccess) e = hipMalloc((void**)&d_status, sizeof(int) * (size_t)n_tracks);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_pts, sizeof(double) * 3 * (size_t)n_tracks);
+  if (e == hipSuccess && n_obs) e = hipMalloc((void**)&d_off, sizeof(int2) * (size_t)n_obs);
+  if (e == hipSuccess && n_obs) e = hipMalloc((void**)&d_pix, sizeof(double2) * (size_t)n_obs);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_start, track_start, sizeof(int) * ((size_t)n_tracks + 1), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess && n_obs) e = hipMemcpyAsync(d_off, pose_off.data(), sizeof(int2) * (size_t)n_obs, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess && n_obs) e = hipMemcpyAsync(d_pix, pixels, sizeof(double2) * (size_t)n_obs, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    launch_triangulate(c->stream, n_tracks, d_start, d_off, d_pix, c->d_x, cam, truncate_pixels != 0, max_dist, max_reproj, d_pts, d_status);
+    e = hipMemcpyAsync(points, d_pts, sizeof(double) * 3 * (size_t)n_tracks, hipMemcpyDeviceToHost, c->stream);
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(status, d_status, sizeof(int) * (size_t)n_tracks, hipMemcpyDeviceToHost, c->stream);
+  const hipError_t e2 = hipStreamSynchronize(c->stream);
+  release();
+  if (e != hipSuccess || e2 != hipSuccess) return fail(c, BSGPU_ERR_DEVICE, "triangulate: device error");
+  return BSGPU_OK;
+}
+
 double bsgpu_time_reproj_jacobian_ms(bsgpu_ctx* c, int32_t reps) {
   if (finalize(c) != BSGPU_OK || c->vis.n == 0 || reps <= 0) return -1.0;
   if (hipSetDevice(c->device) != hipSuccess) return -1.0;

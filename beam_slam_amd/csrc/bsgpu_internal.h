@@ -165,6 +165,8 @@ void launch_reproj_errors(hipStream_t s, const Visual& v, const SmallGroup& dens
                           double* out_dense);
 void launch_preintegrate(hipStream_t s, int n_int, const int* sample_start, const double* ts, const double* wm, const double* am,
                          const double* t_end, const double* bg, const double* ba, const double* covs, double info_weight, double* out);
+void launch_triangulate(hipStream_t s, int n_tracks, const int* track_start, const int2* pose_off, const double2* pix, const double* x,
+                        const DevCamera& cam, bool truncate, double max_dist, double max_reproj, double* points, int* status);
 // device-side flattening of the reprojection factors (k_flatten.hip): 0 = done, 1 = take the host path, < 0 = device error
 int flatten_visual_device(hipStream_t s, const std::function<void*(size_t)>& dalloc, int n, const int* h_idx, const double* h_consts,
                           const int* h_loss_kind, const double* h_loss_a, const std::vector<DevLoss>& losses, int nb, const int* d_blk_xoff,

@@ -81,6 +81,21 @@ class GpuSolver(capi.Solver):
         self._chk(fn(self._ctx, out.ctypes.data))
         return out
 
+    def triangulate(self, track_start, q_block, p_block, pixels, camera=0, truncate_pixels=True, max_dist=-1.0, max_reproj=-1.0):
+        """bsgpu_triangulate: DLT triangulation of a batch of feature tracks at the current values -> (points (n,3), status (n,))."""
+        import numpy as np
+        ts = np.ascontiguousarray(track_start, np.int32)
+        qb, pb = np.ascontiguousarray(q_block, np.int32), np.ascontiguousarray(p_block, np.int32)
+        px = np.ascontiguousarray(pixels, np.float64)
+        n = ts.size - 1
+        pts, st = np.zeros((n, 3)), np.zeros(n, np.int32)
+        fn = lib().bsgpu_triangulate
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_int32] + [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_int32, ctypes.c_double,
+                                                                                  ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
+        self._chk(fn(self._ctx, n, ts.ctypes.data, qb.ctypes.data, pb.ctypes.data, px.ctypes.data, int(camera), int(bool(truncate_pixels)),
+                     float(max_dist), float(max_reproj), pts.ctypes.data, st.ctypes.data))
+        return pts, st
+
     def time_reproj_jacobian_ms(self, reps=20):
         ms = lib().bsgpu_time_reproj_jacobian_ms(self._ctx, int(reps))
         if ms < 0:

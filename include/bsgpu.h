@@ -373,6 +373,21 @@ int bsgpu_preintegrate(int device, int32_t n_intervals, const int32_t* sample_st
                        const double* cov_a, const double* cov_bg, const double* cov_ba, double info_weight,
                        double* consts_out);
 
+/* Landmark triangulation for a batch of feature tracks at the context's CURRENT values (after a solve: the values the
+ * solve left on the device) — VisualOdometry::TriangulateLandmark (bs_models/src/visual_odometry.cpp:532-610) and
+ * SLAMInitialization::TriangulateLandmark (bs_models/src/slam_initialization.cpp:699-701), i.e. the [EXT]
+ * beam_cv::Triangulation::TriangulatePoint(cam, T_cam_world, pixels, max_dist, max_reprojection) call they make.
+ * Track i holds views [track_start[i], track_start[i+1]); view o is seen from the keyframe whose orientation /
+ * position blocks are q_block[o] / p_block[o] with the measured pixel pixels[2o..2o+1]; `camera` indexes the
+ * bsgpu_set_cameras table (K and T_cam_baselink).  truncate_pixels != 0 reproduces the reference's
+ * `m.value.cast<int>()` (visual_odometry.cpp:547).  max_dist / max_reproj <= 0 disable that check (the
+ * `track_lost_` call at visual_odometry.cpp:600 passes neither; vo_params.json:2-3 ships 30 m / 20 px).
+ * points: n_tracks x 3 (world frame); status: n_tracks, 0 = triangulated, 1 = fewer than 2 views (:572),
+ * 2 = behind a camera, 3 = farther than max_dist, 4 = re-projection above max_reproj, 5 = point at infinity.   */
+int bsgpu_triangulate(bsgpu_ctx* ctx, int32_t n_tracks, const int32_t* track_start, const int32_t* q_block,
+                      const int32_t* p_block, const double* pixels, int32_t camera, int32_t truncate_pixels,
+                      double max_dist, double max_reproj, double* points, int32_t* status);
+
 /* ---- measurement helpers (used by bench.py only) --------------------------- */
 /* Launches the Jacobian-evaluation kernel of the reprojection factors `reps`
  * times on the context's stream between two HIP events and returns the average

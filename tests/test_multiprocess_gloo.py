@@ -31,8 +31,9 @@ WORKER = textwrap.dedent("""
     w = torch.ones(4, dtype=torch.float64)
     if rank == 1: w[3] = 0.0          # rank 1 does not hold pose 3
     pc, qc = sharding.consensus_poses(dist, p, q, w)
-    print("RESULT " + json.dumps(dict(rank=rank, wins=wins, seeds=seeds, work=work, t=t, pc=pc.tolist(), qc=qc.tolist(),
-                                      p=p.tolist(), q=q.tolist())), flush=True)
+    # one file per rank: both ranks share the launcher's stdout pipe and long lines written to it can interleave
+    with open(os.path.join(sys.argv[1], "result_%%d.json" %% rank), "w") as fh:
+        json.dump(dict(rank=rank, wins=wins, seeds=seeds, work=work, t=t, pc=pc.tolist(), qc=qc.tolist(), p=p.tolist(), q=q.tolist()), fh)
     dist.destroy_process_group()
 """)
 
@@ -48,12 +49,11 @@ def test_two_rank_sharding_aggregation_and_consensus(tmp_path):
     script.write_text(WORKER % ROOT)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), str(script)]
+           "--master-port", str(_free_port()), str(script), str(tmp_path)]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     import json
-    res = sorted((json.loads(l[7:]) for l in out.stdout.splitlines() if l.startswith("RESULT ")), key=lambda r: r["rank"])
-    assert len(res) == 2
+    res = [json.loads((tmp_path / ("result_%d.json" % r)).read_text()) for r in range(2)]
     # sharding: disjoint cover of the 5 windows, BASELINE config-5 seeds
     assert res[0]["wins"] == [0, 2, 4] and res[1]["wins"] == [1, 3]
     assert res[0]["seeds"] == [20250630, 20250632, 20250634]
