@@ -106,7 +106,7 @@ class Camera(C.Structure):
 #: every symbol include/bsgpu.h declares (without prefix); tests check the library exports them all
 SYMBOLS = [
     "nidx", "nconst", "nres", "options_default", "options_vio", "create", "create_error", "destroy",
-    "last_error", "abi_version", "clear", "set_blocks", "set_values", "set_cameras", "add_factors", "add_marginal",
+    "last_error", "abi_version", "clear", "set_blocks", "set_values", "set_cameras", "add_factors", "add_factors_indirect", "add_marginal",
     "finalize", "solve", "get_blocks", "reset_values", "num_iterations_recorded", "get_iteration",
     "evaluate", "num_residuals", "num_parameters_tangent", "tangent_offset", "covariance", "marginalize", "get_marginal",
     "reprojection_errors", "preintegrate", "triangulate", "time_reproj_jacobian_ms", "reproj_jacobian_bytes", "dense_solve", "plan_info",

@@ -1186,7 +1186,7 @@ const char* bsgpu_last_error(const bsgpu_ctx* c) { return c ? c->err.c_str() : "
 int bsgpu_clear(bsgpu_ctx* c) {
   c->nb = 0; c->h_x.clear(); c->off.clear(); c->size.clear(); c->manifold.clear(); c->is_const.clear();
   c->cams.clear();
-  for (auto& g : c->groups) g = HostGroup();
+  for (auto& g : c->groups) { g.n = 0; g.idx.clear(); g.consts.clear(); g.loss_kind.clear(); g.loss_a.clear(); }   // (capacity kept: a window is re-described every cycle)
   c->marginals.clear();
   c->no_elim.clear();
   c->finalized = false;
@@ -1236,6 +1236,37 @@ int bsgpu_add_factors(bsgpu_ctx* c, int32_t type, int32_t n, const int32_t* idx,
     if (k < 0 || k > BSGPU_LOSS_HUBER) return fail(c, BSGPU_ERR_INVALID, "unknown loss kind");
     g.loss_kind.push_back(k); g.loss_a.push_back(loss_a ? loss_a[i] : 1.0);
   }
+  g.n += n;
+  c->finalized = false;
+  return BSGPU_OK;
+}
+int bsgpu_add_factors_indirect(bsgpu_ctx* c, int32_t type, int32_t n, const int32_t* slot_idx, int32_t n_slots, const int32_t* slot_to_block,
+                               const double* consts, const int32_t* loss_kind, const double* loss_a) {
+  if (type < 0 || type >= BSGPU_F_NUM_TYPES) return fail(c, BSGPU_ERR_INVALID, "unknown factor type");
+  if (n < 0 || n_slots < 0 || (n > 0 && (!slot_idx || !consts || !slot_to_block))) return fail(c, BSGPU_ERR_INVALID, "add_factors_indirect: bad argument");
+  const TypeInfo& ti = kTypes[type];
+  HostGroup& g = c->groups[type];
+  for (int i = 0; i < n; ++i) {
+    const int k = loss_kind ? loss_kind[i] : BSGPU_LOSS_TRIVIAL;
+    if (k < 0 || k > BSGPU_LOSS_HUBER) return fail(c, BSGPU_ERR_INVALID, "unknown loss kind");
+  }
+  const size_t base = g.idx.size(), nidx = (size_t)ti.nidx, nvar = (size_t)ti.nvar;
+  g.idx.resize(base + (size_t)n * nidx);
+  int32_t* dst = g.idx.data() + base;
+  bool bad = false;
+  for (size_t f = 0; f < (size_t)n; ++f) {
+    for (size_t k = 0; k < nvar; ++k) {
+      const int32_t s = slot_idx[f * nidx + k];
+      const int32_t b = ((uint32_t)s < (uint32_t)n_slots) ? slot_to_block[s] : -1;
+      bad |= b < 0;
+      dst[f * nidx + k] = b;
+    }
+    for (size_t k = nvar; k < nidx; ++k) dst[f * nidx + k] = slot_idx[f * nidx + k];
+  }
+  if (bad) { g.idx.resize(base); return fail(c, BSGPU_ERR_INVALID, "add_factors_indirect: slot out of range or not mapped to a block"); }
+  g.consts.insert(g.consts.end(), consts, consts + (size_t)n * ti.nconst);
+  if (loss_kind) g.loss_kind.insert(g.loss_kind.end(), loss_kind, loss_kind + n); else g.loss_kind.insert(g.loss_kind.end(), n, BSGPU_LOSS_TRIVIAL);
+  if (loss_a) g.loss_a.insert(g.loss_a.end(), loss_a, loss_a + n); else g.loss_a.insert(g.loss_a.end(), n, 1.0);
   g.n += n;
   c->finalized = false;
   return BSGPU_OK;

@@ -7,6 +7,8 @@
 // of this host logic compile the same header with -DBS_BACKEND_PREFIX=bso_ against the test oracle,
 // because no GPU exists where they run; that configuration is test infrastructure only.
 #pragma once
+#include <algorithm>
+#include <array>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -28,6 +30,7 @@ int BS_API(clear)(bsgpu_ctx*);
 int BS_API(set_blocks)(bsgpu_ctx*, int32_t, const double*, const int32_t*, const uint8_t*, const uint8_t*, const uint8_t*);
 int BS_API(set_cameras)(bsgpu_ctx*, int32_t, const bsgpu_camera*);
 int BS_API(add_factors)(bsgpu_ctx*, int32_t, int32_t, const int32_t*, const double*, const int32_t*, const double*);
+int BS_API(add_factors_indirect)(bsgpu_ctx*, int32_t, int32_t, const int32_t*, int32_t, const int32_t*, const double*, const int32_t*, const double*);
 int BS_API(solve)(bsgpu_ctx*, const bsgpu_options*, bsgpu_summary*);
 int BS_API(get_blocks)(bsgpu_ctx*, double*, int64_t);
 void BS_API(options_default)(bsgpu_options*);
@@ -67,7 +70,75 @@ struct SolverSummary {
 };
 }  // namespace ceres_compat
 
+// granularity of the copy-on-write sharing between a graph and its clones (small values only make sense in tests)
+#ifndef BS_GRAPH_COW_BUCKETS
+#define BS_GRAPH_COW_BUCKETS 2048
+#endif
+#ifndef BS_GRAPH_COW_CHUNK
+#define BS_GRAPH_COW_CHUNK 1024
+#endif
+
 namespace bs_optimizers {
+
+namespace detail {
+// uuid -> slot index whose copy is O(buckets): every bucket is a small sorted vector behind a shared_ptr, a graph copy
+// shares the buckets and whoever mutates one first copies that bucket only (copy-on-write).
+class CowIndex {
+ public:
+  struct Item { fuse_core::UUID key; int32_t val; };
+  int32_t find(const fuse_core::UUID& k) const {
+    const auto& b = buckets_[bucketOf(k)];
+    if (!b) return -1;
+    auto it = std::lower_bound(b->begin(), b->end(), k, [](const Item& a, const fuse_core::UUID& x) { return a.key < x; });
+    return (it != b->end() && it->key == k) ? it->val : -1;
+  }
+  void insert(const fuse_core::UUID& k, int32_t v) {
+    auto& b = mut(bucketOf(k));
+    b.insert(std::lower_bound(b.begin(), b.end(), k, [](const Item& a, const fuse_core::UUID& x) { return a.key < x; }), Item{k, v});
+    ++size_;
+  }
+  void erase(const fuse_core::UUID& k) {
+    auto& b = mut(bucketOf(k));
+    auto it = std::lower_bound(b.begin(), b.end(), k, [](const Item& a, const fuse_core::UUID& x) { return a.key < x; });
+    if (it != b.end() && it->key == k) { b.erase(it); --size_; }
+  }
+  size_t size() const { return size_; }
+  void clear() { for (auto& b : buckets_) b.reset(); size_ = 0; }
+ private:
+  static constexpr size_t kBuckets = BS_GRAPH_COW_BUCKETS;
+  static size_t bucketOf(const fuse_core::UUID& k) { return (size_t)((k.hi ^ (k.lo * 0x9e3779b97f4a7c15ull)) >> 17) % kBuckets; }
+  std::vector<Item>& mut(size_t i) {
+    auto& b = buckets_[i];
+    if (!b) b = std::make_shared<std::vector<Item>>();
+    else if (b.use_count() > 1) b = std::make_shared<std::vector<Item>>(*b);
+    return *b;
+  }
+  std::array<std::shared_ptr<std::vector<Item>>, kBuckets> buckets_;
+  size_t size_ = 0;
+};
+// slot -> T in chunks behind shared_ptrs, copy-on-write per chunk (same idea as CowIndex)
+template <class T>
+class CowChunks {
+ public:
+  static constexpr size_t kChunk = BS_GRAPH_COW_CHUNK;
+  size_t size() const { return size_; }
+  const T& operator[](size_t i) const { return (*chunks_[i / kChunk])[i % kChunk]; }
+  T& mut(size_t i) {
+    auto& c = chunks_[i / kChunk];
+    if (c.use_count() > 1) c = std::make_shared<std::array<T, kChunk>>(*c);
+    return (*c)[i % kChunk];
+  }
+  void push_back(T v) {
+    if (size_ % kChunk == 0 && size_ / kChunk == chunks_.size()) chunks_.push_back(std::make_shared<std::array<T, kChunk>>());
+    mut(size_) = std::move(v);
+    ++size_;
+  }
+  void clear() { chunks_.clear(); size_ = 0; }
+ private:
+  std::vector<std::shared_ptr<std::array<T, kChunk>>> chunks_;
+  size_t size_ = 0;
+};
+}  // namespace detail
 
 class GpuGraph {
  public:
@@ -76,129 +147,162 @@ class GpuGraph {
   explicit GpuGraph(int device = 0) : device_(device), ctx_(BS_API(create)(device)) {
     if (!ctx_) throw std::runtime_error("GpuGraph: no usable back-end (libbsgpu has no CPU fallback)");
   }
+ private:
+  struct DeferContext {};
+  GpuGraph(int device, DeferContext) : device_(device), ctx_(nullptr) {}   // clone(): a snapshot that is only read never opens a device context
+ public:
   ~GpuGraph() { if (ctx_) BS_API(destroy)(ctx_); }
   GpuGraph(const GpuGraph&) = delete;
   GpuGraph& operator=(const GpuGraph&) = delete;
 
   // ---- fuse_core::Graph surface used by the reference ---------------------------------
   void clear() {
-    variables_.clear(); constraints_.clear(); by_variable_.clear(); connectivity_valid_ = true; on_hold_.clear(); ordered_.clear();
-    for (auto& t : tables_) t = TypeTable();
-    marginal_rows_.clear();
+    vslots_.clear(); vfree_.clear(); vindex_.clear(); vmeta_.clear(); ordered_.clear(); on_hold_.clear();
+    cptr_.clear(); ctype_.clear(); crow_.clear(); cfree_.clear(); cindex_.clear();
+    for (auto& t : tables_) t.reset();
+    cameras_.clear(); marginal_rows_.clear();
+    conn_.clear(); connectivity_valid_ = true;
   }
-  bool variableExists(const fuse_core::UUID& u) const { return variables_.count(u) != 0; }
-  bool constraintExists(const fuse_core::UUID& u) const { return constraints_.count(u) != 0; }
+  bool variableExists(const fuse_core::UUID& u) const { return vindex_.find(u) >= 0; }
+  bool constraintExists(const fuse_core::UUID& u) const { return cindex_.find(u) >= 0; }
   const fuse_core::Variable& getVariable(const fuse_core::UUID& u) const {
-    auto it = variables_.find(u);
-    if (it == variables_.end()) throw std::out_of_range("variable not in graph");
-    return *it->second;
+    const int32_t s = vindex_.find(u);
+    if (s < 0) throw std::out_of_range("variable not in graph");
+    return *vslots_[s];
   }
   fuse_core::Variable& getVariable(const fuse_core::UUID& u) { return const_cast<fuse_core::Variable&>(static_cast<const GpuGraph*>(this)->getVariable(u)); }
-  std::vector<const fuse_core::Variable*> getVariables() const { std::vector<const fuse_core::Variable*> v; for (auto& kv : variables_) v.push_back(kv.second.get()); return v; }
-  std::vector<const fuse_core::Constraint*> getConstraints() const { std::vector<const fuse_core::Constraint*> v; for (auto& kv : constraints_) v.push_back(kv.second.c.get()); return v; }
+  std::vector<const fuse_core::Variable*> getVariables() const {
+    std::vector<const fuse_core::Variable*> v;
+    v.reserve(vindex_.size());
+    for (const auto& p : vslots_) if (p) v.push_back(p.get());
+    return v;
+  }
+  std::vector<const fuse_core::Constraint*> getConstraints() const {
+    std::vector<const fuse_core::Constraint*> v;
+    v.reserve(cindex_.size());
+    for (size_t i = 0; i < cptr_.size(); ++i) if (ctype_[i] != kFree) v.push_back(cptr_[i].get());
+    return v;
+  }
   std::vector<const fuse_core::Constraint*> getConnectedConstraints(const fuse_core::UUID& var) const {
-    if (!variableExists(var)) throw std::logic_error("getConnectedConstraints: variable not in graph");
-    std::vector<const fuse_core::Constraint*> out;
+    const int32_t s = vindex_.find(var);
+    if (s < 0) throw std::logic_error("getConnectedConstraints: variable not in graph");
     ensureConnectivity();
-    auto it = by_variable_.find(var);
-    if (it != by_variable_.end()) for (const auto& cu : it->second) out.push_back(constraints_.at(cu).c.get());
+    std::vector<const fuse_core::Constraint*> out;
+    for (int32_t cs : conn_[s]) out.push_back(cptr_[cs].get());
     return out;
   }
   bool addVariable(fuse_core::Variable::SharedPtr v) {
-    auto it = variables_.find(v->uuid());
-    if (it != variables_.end()) { std::memcpy(it->second->data(), v->data(), v->size() * sizeof(double)); return false; }  // HashGraph: overwrite value
-    const fuse_core::Variable* raw = v.get();
-    variables_[v->uuid()] = std::move(v);
-    ordered_.insert(std::upper_bound(ordered_.begin(), ordered_.end(), raw, orderBefore), raw);
+    const int32_t have = vindex_.find(v->uuid());
+    if (have >= 0) { std::memcpy(vslots_[have]->data(), v->data(), v->size() * sizeof(double)); return false; }  // HashGraph: overwrite value
+    int32_t s;
+    if (!vfree_.empty()) { s = vfree_.back(); vfree_.pop_back(); }
+    else { s = (int32_t)vslots_.size(); vslots_.emplace_back(); vmeta_.emplace_back(); if (connectivity_valid_) conn_.emplace_back(); }
+    vmeta_[s] = VMeta{(uint8_t)v->size(), (uint8_t)v->manifold(), (uint8_t)(v->holdConstant() ? 1 : 0)};
+    vindex_.insert(v->uuid(), s);
+    vslots_[s] = std::move(v);
+    ordered_.insert(std::upper_bound(ordered_.begin(), ordered_.end(), s, [this](int32_t a, int32_t b) { return orderBefore(vslots_[a].get(), vslots_[b].get()); }), s);
     return true;
   }
   bool removeVariable(const fuse_core::UUID& u) {
-    auto it = variables_.find(u);
-    if (it == variables_.end()) return false;
+    const int32_t s = vindex_.find(u);
+    if (s < 0) return false;
     ensureConnectivity();
-    auto cit = by_variable_.find(u);
-    if (cit != by_variable_.end() && !cit->second.empty()) throw std::logic_error("removeVariable: variable still used by a constraint");
+    if (!conn_[s].empty()) throw std::logic_error("removeVariable: variable still used by a constraint");
     {
-      const fuse_core::Variable* raw = it->second.get();
-      auto pos = std::lower_bound(ordered_.begin(), ordered_.end(), raw, orderBefore);
-      while (pos != ordered_.end() && *pos != raw) ++pos;   // (equal keys cannot occur: the uuid breaks every tie)
+      auto pos = std::lower_bound(ordered_.begin(), ordered_.end(), s, [this](int32_t a, int32_t b) { return orderBefore(vslots_[a].get(), vslots_[b].get()); });
+      while (pos != ordered_.end() && *pos != s) ++pos;   // (equal keys cannot occur: the uuid breaks every tie)
       if (pos != ordered_.end()) ordered_.erase(pos);
     }
-    by_variable_.erase(u); on_hold_.erase(u); variables_.erase(it);
+    on_hold_.erase(u); vindex_.erase(u);
+    vslots_[s].reset();
+    vfree_.push_back(s);
     return true;
   }
   bool addConstraint(fuse_core::Constraint::SharedPtr c) {
-    if (constraints_.count(c->uuid())) return false;
-    CEntry e;
+    if (cindex_.find(c->uuid()) >= 0) return false;
+    std::vector<int32_t> vars;
+    vars.reserve(c->variables().size());
     for (const auto& u : c->variables()) {   // resolve the variables once: flatten() then needs no UUID lookup per slot
-      auto it = variables_.find(u);
-      if (it == variables_.end()) throw std::logic_error("addConstraint: constraint " + c->type() + " uses a variable that is not in the graph");
-      e.vars.push_back(it->second.get());
+      const int32_t s = vindex_.find(u);
+      if (s < 0) throw std::logic_error("addConstraint: constraint " + c->type() + " uses a variable that is not in the graph");
+      vars.push_back(s);
     }
+    int32_t cs;
+    if (!cfree_.empty()) { cs = cfree_.back(); cfree_.pop_back(); }
+    else { cs = (int32_t)cptr_.size(); cptr_.push_back(nullptr); ctype_.push_back(kFree); crow_.push_back(0); }
     ensureConnectivity();
-    for (const auto& u : c->variables()) by_variable_[u].insert(c->uuid());
-    const fuse_core::UUID id = c->uuid();
-    e.c = std::move(c);
-    appendRow(e, id);
-    constraints_.emplace(id, std::move(e));
+    for (int32_t s : vars) if (std::find(conn_[s].begin(), conn_[s].end(), cs) == conn_[s].end()) conn_[s].push_back(cs);
+    cindex_.insert(c->uuid(), cs);
+    appendRow(*c, cs, vars);
+    cptr_.mut(cs) = std::move(c);
     return true;
   }
   bool removeConstraint(const fuse_core::UUID& u) {
-    auto it = constraints_.find(u);
-    if (it == constraints_.end()) return false;
+    const int32_t cs = cindex_.find(u);
+    if (cs < 0) return false;
     ensureConnectivity();
-    for (const auto& v : it->second.c->variables()) by_variable_[v].erase(u);
-    removeRow(it->second);
-    constraints_.erase(it);
+    forEachVariableOf(cs, [&](int32_t s) { auto& l = conn_[s]; auto it = std::find(l.begin(), l.end(), cs); if (it != l.end()) { *it = l.back(); l.pop_back(); } });
+    removeRow(cs);
+    cindex_.erase(u);
+    cptr_.mut(cs).reset();
+    ctype_[cs] = kFree;
+    cfree_.push_back(cs);
     return true;
   }
   void holdVariable(const fuse_core::UUID& u, bool hold = true) { if (hold) on_hold_.insert(u); else on_hold_.erase(u); }
   // Graph::update(transaction): removals first, then additions ([EXT] fuse_core::Graph::update)
   void update(const fuse_core::Transaction& t) {
+    const bool timing = std::getenv("BS_HOST_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+      if (!timing) return;
+      const auto now = std::chrono::steady_clock::now();
+      std::fprintf(stderr, "[GpuGraph::update] %-24s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+      t_prev = now;
+    };
     for (const auto& u : t.removedConstraints()) removeConstraint(u);
+    lap("remove constraints");
     for (const auto& u : t.removedVariables()) removeVariable(u);
+    lap("remove variables");
     for (const auto& v : t.addedVariables()) addVariable(v->clone());
+    lap("add variables");
     for (const auto& c : t.addedConstraints()) addConstraint(c->clone());
+    lap("add constraints");
   }
-  // Graph::clone() (fixed_lag_smoother.cpp:308 does this every cycle for the publishers): variables are deep-copied,
-  // the immutable constraints are shared, the packed tables are copied with their variable pointers remapped
+  // Graph::clone() (fixed_lag_smoother.cpp:308 does this every cycle for the publishers).  Variables are deep-copied (the
+  // solve writes them).  Everything on the constraint side is immutable between transactions and is SHARED with the copy
+  // behind copy-on-write handles — the constraints themselves, the uuid indices, the packed per-type tables — so the
+  // copy costs O(variables), and the first transaction applied afterwards pays one flat copy of what it touches.  This
+  // is possible because the packed tables name variables by graph-local slot, and a copy keeps the slot numbering.
   UniquePtr clone() const {
-    UniquePtr g(new GpuGraph(device_));
-    std::vector<fuse_core::Variable*> copies;
-    copies.reserve(variables_.size());
-    auto hint = g->variables_.end();
-    for (auto& kv : variables_) {   // same key order: hinted insertion; the flat index carries old -> new
-      kv.second->flatIndex((int32_t)copies.size());
-      hint = g->variables_.emplace_hint(hint, kv.first, kv.second->clone());
-      copies.push_back(hint->second.get());
-    }
-    auto chint = g->constraints_.end();
-    for (auto& kv : constraints_) {
-      CEntry e;
-      e.c = kv.second.c;   // constraints are immutable once in a graph: the copy shares them (variables are deep-copied)
-      e.type = kv.second.type; e.row = kv.second.row;
-      for (const auto* v : kv.second.vars) e.vars.push_back(copies[v->flatIndex()]);
-      chint = g->constraints_.emplace_hint(chint, kv.first, std::move(e));
-    }
+    const bool timing = std::getenv("BS_HOST_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+      if (!timing) return;
+      const auto now = std::chrono::steady_clock::now();
+      std::fprintf(stderr, "[GpuGraph::clone] %-24s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+      t_prev = now;
+    };
+    UniquePtr g(new GpuGraph(device_, DeferContext{}));
+    g->vslots_.resize(vslots_.size());
+    for (size_t i = 0; i < vslots_.size(); ++i) if (vslots_[i]) g->vslots_[i] = vslots_[i]->clone();
+    g->vfree_ = vfree_; g->vindex_ = vindex_; g->vmeta_ = vmeta_; g->ordered_ = ordered_; g->on_hold_ = on_hold_;
+    lap("variables");
+    g->cptr_ = cptr_; g->ctype_ = ctype_; g->crow_ = crow_; g->cfree_ = cfree_; g->cindex_ = cindex_;
+    for (int ty = 0; ty < BSGPU_F_NUM_TYPES; ++ty) g->tables_[ty] = tables_[ty];
     g->cameras_ = cameras_;
-    for (int ty = 0; ty < BSGPU_F_NUM_TYPES; ++ty) {
-      g->tables_[ty] = tables_[ty];
-      for (auto& v : g->tables_[ty].vars) v = copies[v->flatIndex()];
-    }
     g->marginal_rows_ = marginal_rows_;
-    g->ordered_.reserve(ordered_.size());
-    for (const auto* v : ordered_) g->ordered_.push_back(copies[v->flatIndex()]);   // same order in the copy
     g->connectivity_valid_ = false;   // variable -> constraints index of the copy: rebuilt on first use (publishers rarely need it)
-    g->on_hold_ = on_hold_;
+    lap("constraints (shared)");
     return g;
   }
-  size_t numVariables() const { return variables_.size(); }
-  size_t numConstraints() const { return constraints_.size(); }
+  size_t numVariables() const { return vindex_.size(); }
+  size_t numConstraints() const { return cindex_.size(); }
   void print(std::ostream& s) const {
     s << "GpuGraph\n  variables:\n";
-    for (auto& kv : variables_) { s << "   - "; kv.second->print(s); s << "\n"; }
+    for (const auto* v : getVariables()) { s << "   - "; v->print(s); s << "\n"; }
     s << "  constraints:\n";
-    for (auto& kv : constraints_) { s << "   - "; kv.second.c->print(s); s << "\n"; }
+    for (const auto* c : getConstraints()) { s << "   - "; c->print(s); s << "\n"; }
   }
 
   // ---- the hot call -----------------------------------------------------------------------------------
@@ -207,7 +311,12 @@ class GpuGraph {
   // (graph_access.cpp:200-216); unstamped extrinsic blocks last.
   // The order is kept incrementally: a variable is inserted at its sorted position when it enters the graph and erased
   // when it leaves (a sliding window adds and drops a few hundred variables per cycle out of tens of thousands).
-  const std::vector<const fuse_core::Variable*>& orderedVariables() const { return ordered_; }
+  std::vector<const fuse_core::Variable*> orderedVariables() const {
+    std::vector<const fuse_core::Variable*> v;
+    v.reserve(ordered_.size());
+    for (int32_t s : ordered_) v.push_back(vslots_[s].get());
+    return v;
+  }
 
   // Flat IR of the current graph (variables at their current values) loaded into the back-end context
   struct Flat {
@@ -215,8 +324,9 @@ class GpuGraph {
     std::vector<double> values;
     std::vector<int32_t> offset;
     std::vector<uint8_t> size, manifold, is_const;
+    std::vector<int32_t> slot_to_block;   // graph-local variable slot -> block index (-1: free slot)
   };
-  int32_t blockIndexOf(const fuse_core::UUID& u) const { return variables_.at(u)->flatIndex(); }   // valid right after flatten()
+  int32_t blockIndexOf(const fuse_core::UUID& u) const { return getVariable(u).flatIndex(); }   // valid right after flatten()
   bool flatten(Flat& f) {
     const bool timing = std::getenv("BS_HOST_TIMING") != nullptr;
     auto t_prev = std::chrono::steady_clock::now();
@@ -226,43 +336,41 @@ class GpuGraph {
       std::fprintf(stderr, "[GpuGraph::flatten] %-24s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
       t_prev = now;
     };
-    f.vars = orderedVariables();
-    lap("block order");
-    for (const auto* v : f.vars) {
-      v->flatIndex((int32_t)f.offset.size());
-      f.offset.push_back((int32_t)f.values.size());
-      f.size.push_back((uint8_t)v->size());
-      f.manifold.push_back((uint8_t)v->manifold());
-      f.is_const.push_back((v->holdConstant() || on_hold_.count(v->uuid())) ? 1 : 0);
-      f.values.insert(f.values.end(), v->data(), v->data() + v->size());
+    const size_t nb = ordered_.size();
+    if (!nb) return false;
+    f.vars.resize(nb); f.offset.resize(nb); f.size.resize(nb); f.manifold.resize(nb); f.is_const.resize(nb);
+    f.slot_to_block.assign(vslots_.size(), -1);
+    size_t nval = 0;
+    for (size_t i = 0; i < nb; ++i) { f.offset[i] = (int32_t)nval; nval += vmeta_[ordered_[i]].size; }
+    f.values.resize(nval);
+    for (size_t i = 0; i < nb; ++i) {
+      const int32_t s = ordered_[i];
+      const VMeta& m = vmeta_[s];
+      const fuse_core::Variable* v = vslots_[s].get();
+      f.vars[i] = v;
+      v->flatIndex((int32_t)i);
+      f.slot_to_block[s] = (int32_t)i;
+      f.size[i] = m.size; f.manifold[i] = m.manifold; f.is_const[i] = m.hold_constant;
+      std::memcpy(&f.values[f.offset[i]], v->data(), m.size * sizeof(double));
     }
-    if (f.offset.empty()) return false;
+    for (const auto& u : on_hold_) { const int32_t s = vindex_.find(u); if (s >= 0) f.is_const[f.slot_to_block[s]] = 1; }
     lap("block table");
-    // block indices of every packed row: the only per-cycle work on the factor side (constants, losses and camera ids
-    // were packed once, when the constraint entered the graph)
+    // The packed rows name their variables by slot and were written once, when the constraint entered the graph: the only
+    // per-cycle translation, slot -> block index, happens inside the back-end's copy (bsgpu_add_factors_indirect).
+    check(BS_API(clear)(ctx()));
+    check(BS_API(set_blocks)(ctx(), (int32_t)nb, f.values.data(), f.offset.data(), f.size.data(), f.manifold.data(), f.is_const.data()));
+    if (!cameras_.empty()) check(BS_API(set_cameras)(ctx(), (int32_t)cameras_.size(), cameras_.data()));
     for (int ty = 0; ty < BSGPU_F_NUM_TYPES; ++ty) {
-      TypeTable& tb = tables_[ty];
-      if (!tb.rows) continue;
-      const int nidx = tb.nvar + (tb.has_cam ? 1 : 0);
-      tb.idx.resize((size_t)tb.rows * nidx);
-      for (size_t r = 0; r < tb.rows; ++r) {
-        for (int sl = 0; sl < tb.nvar; ++sl) tb.idx[r * nidx + sl] = tb.vars[r * tb.nvar + sl]->flatIndex();
-        if (tb.has_cam) tb.idx[r * nidx + tb.nvar] = tb.cam[r];
-      }
-    }
-    lap("block indices of factors");
-    check(BS_API(clear)(ctx_));
-    check(BS_API(set_blocks)(ctx_, (int32_t)f.offset.size(), f.values.data(), f.offset.data(), f.size.data(), f.manifold.data(), f.is_const.data()));
-    if (!cameras_.empty()) check(BS_API(set_cameras)(ctx_, (int32_t)cameras_.size(), cameras_.data()));
-    for (int ty = 0; ty < BSGPU_F_NUM_TYPES; ++ty) {
-      const TypeTable& tb = tables_[ty];
-      if (tb.rows) check(BS_API(add_factors)(ctx_, ty, (int32_t)tb.rows, tb.idx.data(), tb.consts.data(), tb.loss_kind.data(), tb.loss_a.data()));
+      const TypeTable* tb = tables_[ty].get();
+      if (tb && tb->rows)
+        check(BS_API(add_factors_indirect)(ctx(), ty, (int32_t)tb->rows, tb->idx.data(), (int32_t)f.slot_to_block.size(), f.slot_to_block.data(),
+                                           tb->consts.data(), tb->loss_kind.data(), tb->loss_a.data()));
     }
     for (const auto& kv : marginal_rows_) {
       const auto& m = kv.second;
       std::vector<int32_t> blocks;
-      for (const auto* v : m.vars) blocks.push_back(v->flatIndex());
-      check(BS_API(add_marginal)(ctx_, (int32_t)blocks.size(), blocks.data(), m.e.rows, m.e.A.data(), m.e.b.data(), m.e.xbar.data()));
+      for (int32_t s : m.vars) blocks.push_back(f.slot_to_block[s]);
+      check(BS_API(add_marginal)(ctx(), (int32_t)blocks.size(), blocks.data(), m.e.rows, m.e.A.data(), m.e.b.data(), m.e.xbar.data()));
     }
     lap("hand-over (C-ABI copies)");
     return true;
@@ -279,8 +387,8 @@ class GpuGraph {
     bo.max_num_iterations = o.max_num_iterations; bo.max_solver_time_in_seconds = o.max_solver_time_in_seconds;
     bo.function_tolerance = o.function_tolerance; bo.gradient_tolerance = o.gradient_tolerance; bo.parameter_tolerance = o.parameter_tolerance;
     bsgpu_summary bs;
-    check(BS_API(solve)(ctx_, &bo, &bs));
-    check(BS_API(get_blocks)(ctx_, values.data(), (int64_t)values.size()));
+    check(BS_API(solve)(ctx(), &bo, &bs));
+    check(BS_API(get_blocks)(ctx(), values.data(), (int64_t)values.size()));
     for (size_t i = 0; i < vars.size(); ++i)   // Variable::data() updated in place, like Ceres does through the raw pointers
       std::memcpy(const_cast<fuse_core::Variable*>(vars[i])->data(), values.data() + offset[i], size[i] * sizeof(double));
     s.termination_type = bs.termination_type == BSGPU_CONVERGENCE ? ceres_compat::CONVERGENCE
@@ -306,14 +414,14 @@ class GpuGraph {
   fuse_core::Transaction marginalizeVariables(const std::string& source, const std::vector<fuse_core::UUID>& to_marginalize) {
     fuse_core::Transaction tr;
     std::vector<fuse_core::UUID> constrained;
-    std::set<fuse_core::UUID> removed_constraints;
+    std::set<int32_t> removed_constraints;
+    ensureConnectivity();
     for (const auto& u : to_marginalize) {
-      if (!variableExists(u)) throw std::out_of_range("marginalizeVariables: variable not in graph");
-      ensureConnectivity();
-      const auto it = by_variable_.find(u);
-      if (it != by_variable_.end() && !it->second.empty()) {
+      const int32_t s = vindex_.find(u);
+      if (s < 0) throw std::out_of_range("marginalizeVariables: variable not in graph");
+      if (!conn_[s].empty()) {
         constrained.push_back(u);
-        for (const auto& cu : it->second) if (removed_constraints.insert(cu).second) tr.removeConstraint(cu);
+        for (int32_t cs : conn_[s]) if (removed_constraints.insert(cs).second) tr.removeConstraint(cptr_[cs]->uuid());
       }
       tr.removeVariable(u);
     }
@@ -327,14 +435,14 @@ class GpuGraph {
       marg.push_back(b);
     }
     int32_t n_kept = 0, n_rows = 0, n_cols = 0;
-    check(BS_API(marginalize)(ctx_, (int32_t)marg.size(), marg.data(), &n_kept, &n_rows, &n_cols));
+    check(BS_API(marginalize)(ctx(), (int32_t)marg.size(), marg.data(), &n_kept, &n_rows, &n_cols));
     if (n_rows == 0) return tr;
     std::vector<int32_t> kept(n_kept);
-    check(BS_API(get_marginal)(ctx_, kept.data(), nullptr, nullptr, nullptr));
+    check(BS_API(get_marginal)(ctx(), kept.data(), nullptr, nullptr, nullptr));
     size_t amb = 0;
     for (int32_t b : kept) amb += f.size[b];
     std::vector<double> A((size_t)n_rows * n_cols), bvec(n_rows), xbar(amb);
-    check(BS_API(get_marginal)(ctx_, kept.data(), A.data(), bvec.data(), xbar.data()));
+    check(BS_API(get_marginal)(ctx(), kept.data(), A.data(), bvec.data(), xbar.data()));
     std::vector<fuse_core::UUID> kept_ids;
     for (int32_t b : kept) kept_ids.push_back(f.vars[b]->uuid());
     tr.addConstraint(std::make_shared<fuse_constraints::MarginalConstraint>(source, std::move(kept_ids), n_rows, n_cols, std::move(A), std::move(bvec), std::move(xbar)));
@@ -354,9 +462,9 @@ class GpuGraph {
     for (const auto& rq : covariance_requests) {
       if (!variableExists(rq.first) || !variableExists(rq.second)) throw std::out_of_range("getCovariance: variable not in graph");
       const int32_t a = blockIndexOf(rq.first), b = blockIndexOf(rq.second);
-      const size_t ta = variables_.at(rq.first)->localSize(), tb = variables_.at(rq.second)->localSize();
+      const size_t ta = getVariable(rq.first).localSize(), tb = getVariable(rq.second).localSize();
       std::vector<double> m(ta * tb);
-      check(BS_API(covariance)(ctx_, a, b, m.data()));
+      check(BS_API(covariance)(ctx(), a, b, m.data()));
       covariance_matrices.push_back(std::move(m));
     }
   }
@@ -365,96 +473,19 @@ class GpuGraph {
   void check(int rc) { if (rc != BSGPU_OK) throw std::runtime_error(std::string("bsgpu: ") + BS_API(last_error)(ctx_)); }
   int device_;
   bsgpu_ctx* ctx_;
-  std::map<fuse_core::UUID, fuse_core::Variable::SharedPtr> variables_;
-  // resolved variables of one constraint: inline up to 10 (the IMU factor), heap only for wide marginal priors
-  struct VarList {
-    const fuse_core::Variable* inl[10];
-    std::vector<const fuse_core::Variable*> big;
-    uint32_t n = 0;
-    void push_back(const fuse_core::Variable* v) {
-      if (n < 10) inl[n] = v;
-      else { if (n == 10) big.assign(inl, inl + 10); big.push_back(v); }
-      ++n;
-    }
-    size_t size() const { return n; }
-    const fuse_core::Variable* const* data() const { return n <= 10 ? inl : big.data(); }
-    const fuse_core::Variable* operator[](size_t i) const { return data()[i]; }
-    const fuse_core::Variable* const* begin() const { return data(); }
-    const fuse_core::Variable* const* end() const { return data() + n; }
-  };
-  struct CEntry { fuse_core::Constraint::SharedPtr c; VarList vars; int type = -1; size_t row = 0; };
-  // Packed per-type factor tables, persisted across cycles (SURVEY.md §8f rank 2): a constraint is packed ONCE, when it
-  // enters the graph; removal swaps the last row into the hole.  Row order therefore follows the transaction history.
-  struct TypeTable {
-    size_t rows = 0;
-    int nvar = 0;
-    bool has_cam = false;
-    std::vector<const fuse_core::Variable*> vars;   // rows x nvar
-    std::vector<int32_t> cam;                       // rows (camera-table id) when has_cam
-    std::vector<double> consts;
-    std::vector<int32_t> loss_kind;
-    std::vector<double> loss_a;
-    std::vector<fuse_core::UUID> owner;             // rows: the constraint of each row
-    std::vector<int32_t> idx;                       // scratch: rows x nidx, rebuilt by flatten()
-  };
-  struct MarginalRow { fuse_core::FactorTables::MarginalEntry e; std::vector<const fuse_core::Variable*> vars; };
-  void appendRow(CEntry& e, const fuse_core::UUID& id) {
-    fuse_core::FactorTables t1;
-    int32_t slots[64];
-    std::vector<int32_t> slots_big;
-    int32_t* sl = slots;
-    if (e.vars.size() > 64) { slots_big.resize(e.vars.size()); sl = slots_big.data(); }
-    for (size_t i = 0; i < e.vars.size(); ++i) sl[i] = (int32_t)i;
-    e.c->pack(fuse_core::BlockOf(sl), t1);
-    if (!t1.marginals.empty()) {
-      MarginalRow m; m.e = std::move(t1.marginals[0]); m.vars.assign(e.vars.begin(), e.vars.end());
-      marginal_rows_[id] = std::move(m);
-      e.type = -2;
-      return;
-    }
-    for (int ty = 0; ty < BSGPU_F_NUM_TYPES; ++ty) {
-      if (!t1.count(ty)) continue;
-      TypeTable& tb = tables_[ty];
-      const int nvar = (int)e.vars.size(), nidx = (int)t1.idx[ty].size();
-      if (!tb.rows && tb.vars.empty()) { tb.nvar = nvar; tb.has_cam = nidx > nvar; }
-      tb.vars.insert(tb.vars.end(), e.vars.begin(), e.vars.end());
-      if (tb.has_cam) {
-        const bsgpu_camera& c1 = t1.cameras.at(t1.idx[ty][nvar]);
-        int32_t cid = -1;
-        for (size_t i = 0; i < cameras_.size(); ++i) if (std::memcmp(&cameras_[i], &c1, sizeof(c1)) == 0) { cid = (int32_t)i; break; }
-        if (cid < 0) { cameras_.push_back(c1); cid = (int32_t)cameras_.size() - 1; }
-        tb.cam.push_back(cid);
-      }
-      tb.consts.insert(tb.consts.end(), t1.consts[ty].begin(), t1.consts[ty].end());
-      tb.loss_kind.push_back(t1.loss_kind[ty][0]); tb.loss_a.push_back(t1.loss_a[ty][0]);
-      tb.owner.push_back(id);
-      e.type = ty; e.row = tb.rows++;
-      return;
-    }
+  bsgpu_ctx* ctx() {
+    if (!ctx_ && !(ctx_ = BS_API(create)(device_))) throw std::runtime_error("GpuGraph: no usable back-end (libbsgpu has no CPU fallback)");
+    return ctx_;
   }
-  void removeRow(const CEntry& e) {
-    if (e.type == -2) { marginal_rows_.erase(e.c->uuid()); return; }
-    if (e.type < 0) return;
-    TypeTable& tb = tables_[e.type];
-    const size_t last = tb.rows - 1, r = e.row, nc = tb.consts.size() / tb.rows;
-    if (r != last) {
-      for (int sl = 0; sl < tb.nvar; ++sl) tb.vars[r * tb.nvar + sl] = tb.vars[last * tb.nvar + sl];
-      if (tb.has_cam) tb.cam[r] = tb.cam[last];
-      for (size_t k = 0; k < nc; ++k) tb.consts[r * nc + k] = tb.consts[last * nc + k];
-      tb.loss_kind[r] = tb.loss_kind[last]; tb.loss_a[r] = tb.loss_a[last];
-      tb.owner[r] = tb.owner[last];
-      constraints_.at(tb.owner[r]).row = r;
-    }
-    tb.vars.resize(last * tb.nvar);
-    if (tb.has_cam) tb.cam.pop_back();
-    tb.consts.resize(last * nc);
-    tb.loss_kind.pop_back(); tb.loss_a.pop_back(); tb.owner.pop_back();
-    tb.rows = last;
-  }
-  TypeTable tables_[BSGPU_F_NUM_TYPES];
-  std::vector<bsgpu_camera> cameras_;
-  std::map<fuse_core::UUID, MarginalRow> marginal_rows_;
-  std::map<fuse_core::UUID, CEntry> constraints_;
+
+  // ---- variables: graph-local slots (stable while the variable is in the graph, kept by clone()) ---------------------
+  struct VMeta { uint8_t size, manifold, hold_constant; };
+  std::vector<fuse_core::Variable::SharedPtr> vslots_;   // slot -> variable (null: free slot)
+  std::vector<VMeta> vmeta_;                              // slot -> what flatten() needs without touching the object
+  std::vector<int32_t> vfree_;
+  detail::CowIndex vindex_;                               // uuid -> slot
+  std::vector<int32_t> ordered_;                          // slots in the deterministic block order, maintained on insertion / removal
+  std::set<fuse_core::UUID> on_hold_;
   // (class: stamped / landmark / other, stamp | landmark id, state slot, uuid) — SURVEY.md §8a A17
   static bool orderBefore(const fuse_core::Variable* x, const fuse_core::Variable* y) {
     const int cx = x->isStamped() ? 0 : x->isLandmark() ? 1 : 2, cy = y->isStamped() ? 0 : y->isLandmark() ? 1 : 2;
@@ -465,16 +496,110 @@ class GpuGraph {
     } else if (cx == 1 && x->landmarkId() != y->landmarkId()) return x->landmarkId() < y->landmarkId();
     return x->uuid() < y->uuid();
   }
-  std::vector<const fuse_core::Variable*> ordered_;   // deterministic block order, maintained on insertion / removal
+
+  // ---- constraints: slots + packed per-type tables, all shareable with a clone ---------------------------------------
+  // Packed per-type factor tables, persisted across cycles (SURVEY.md §8f rank 2): a constraint is packed ONCE, when it
+  // enters the graph; removal swaps the last row into the hole.  Row order therefore follows the transaction history.
+  // idx holds, per row, the variable SLOTS (then the camera-table id for the camera types) in the column layout of
+  // bsgpu_add_factors, so the table is handed to the back-end as it is.
+  struct TypeTable {
+    size_t rows = 0;
+    int nvar = 0, nidx = 0;
+    std::vector<int32_t> idx;          // rows x nidx
+    std::vector<double> consts;
+    std::vector<int32_t> loss_kind;
+    std::vector<double> loss_a;
+    std::vector<int32_t> owner;        // rows: constraint slot of each row
+  };
+  static constexpr int32_t kFree = -3, kMarginal = -2, kUnpacked = -1;
+  struct MarginalRow { fuse_core::FactorTables::MarginalEntry e; std::vector<int32_t> vars; };
+  detail::CowChunks<fuse_core::Constraint::SharedPtr> cptr_;   // constraint slot -> constraint
+  std::vector<int32_t> ctype_;                                  // constraint slot -> factor type | kFree | kMarginal | kUnpacked
+  std::vector<uint32_t> crow_;                                  // constraint slot -> row in its type's table
+  std::vector<int32_t> cfree_;
+  detail::CowIndex cindex_;                                     // uuid -> constraint slot
+  std::shared_ptr<TypeTable> tables_[BSGPU_F_NUM_TYPES];        // copy-on-write (tableMut)
+  std::vector<bsgpu_camera> cameras_;
+  std::map<int32_t, MarginalRow> marginal_rows_;                // by constraint slot
+  fuse_core::FactorTables pack_scratch_;
+  std::vector<int32_t> slot_scratch_;
+  TypeTable& tableMut(int ty) {
+    auto& t = tables_[ty];
+    if (!t) t = std::make_shared<TypeTable>();
+    else if (t.use_count() > 1) t = std::make_shared<TypeTable>(*t);
+    return *t;
+  }
+  template <class F>
+  void forEachVariableOf(int32_t cs, F fn) const {
+    const int ty = ctype_[cs];
+    if (ty >= 0) { const TypeTable& tb = *tables_[ty]; for (int k = 0; k < tb.nvar; ++k) fn(tb.idx[(size_t)crow_[cs] * tb.nidx + k]); }
+    else if (ty == kMarginal) for (int32_t s : marginal_rows_.at(cs).vars) fn(s);
+    else if (ty == kUnpacked) for (const auto& u : cptr_[cs]->variables()) { const int32_t s = vindex_.find(u); if (s >= 0) fn(s); }
+  }
+  void appendRow(const fuse_core::Constraint& c, int32_t cs, const std::vector<int32_t>& vars) {
+    fuse_core::FactorTables& t1 = pack_scratch_;   // (reused: a transaction packs thousands of constraints)
+    for (int ty = 0; ty < BSGPU_F_NUM_TYPES; ++ty) { t1.idx[ty].clear(); t1.consts[ty].clear(); t1.loss_kind[ty].clear(); t1.loss_a[ty].clear(); }
+    t1.marginals.clear(); t1.cameras.clear();
+    std::vector<int32_t>& sl = slot_scratch_;
+    sl.resize(vars.size());
+    for (size_t i = 0; i < sl.size(); ++i) sl[i] = (int32_t)i;
+    c.pack(fuse_core::BlockOf(sl.data()), t1);
+    ctype_[cs] = kUnpacked;
+    if (!t1.marginals.empty()) {
+      MarginalRow m; m.e = std::move(t1.marginals[0]); m.vars = vars;
+      marginal_rows_[cs] = std::move(m);
+      ctype_[cs] = kMarginal;
+      return;
+    }
+    for (int ty = 0; ty < BSGPU_F_NUM_TYPES; ++ty) {
+      if (!t1.count(ty)) continue;
+      TypeTable& tb = tableMut(ty);
+      const int nvar = (int)vars.size(), nidx = (int)t1.idx[ty].size();
+      if (!tb.rows && tb.idx.empty()) { tb.nvar = nvar; tb.nidx = nidx; }
+      tb.idx.insert(tb.idx.end(), vars.begin(), vars.end());
+      if (nidx > nvar) {   // camera types: the row's last column is the id in the graph-wide camera table
+        const bsgpu_camera& c1 = t1.cameras.at(t1.idx[ty][nvar]);
+        int32_t cid = -1;
+        for (size_t i = 0; i < cameras_.size(); ++i) if (std::memcmp(&cameras_[i], &c1, sizeof(c1)) == 0) { cid = (int32_t)i; break; }
+        if (cid < 0) { cameras_.push_back(c1); cid = (int32_t)cameras_.size() - 1; }
+        tb.idx.push_back(cid);
+      }
+      tb.consts.insert(tb.consts.end(), t1.consts[ty].begin(), t1.consts[ty].end());
+      tb.loss_kind.push_back(t1.loss_kind[ty][0]); tb.loss_a.push_back(t1.loss_a[ty][0]);
+      tb.owner.push_back(cs);
+      ctype_[cs] = ty; crow_[cs] = (uint32_t)tb.rows++;
+      return;
+    }
+  }
+  void removeRow(int32_t cs) {
+    const int ty = ctype_[cs];
+    if (ty == kMarginal) { marginal_rows_.erase(cs); return; }
+    if (ty < 0) return;
+    TypeTable& tb = tableMut(ty);
+    const size_t last = tb.rows - 1, r = crow_[cs], nc = tb.consts.size() / tb.rows, ni = (size_t)tb.nidx;
+    if (r != last) {
+      for (size_t k = 0; k < ni; ++k) tb.idx[r * ni + k] = tb.idx[last * ni + k];
+      for (size_t k = 0; k < nc; ++k) tb.consts[r * nc + k] = tb.consts[last * nc + k];
+      tb.loss_kind[r] = tb.loss_kind[last]; tb.loss_a[r] = tb.loss_a[last];
+      tb.owner[r] = tb.owner[last];
+      crow_[tb.owner[r]] = (uint32_t)r;
+    }
+    tb.idx.resize(last * ni);
+    tb.consts.resize(last * nc);
+    tb.loss_kind.pop_back(); tb.loss_a.pop_back(); tb.owner.pop_back();
+    tb.rows = last;
+  }
+  // variable slot -> constraint slots: maintained incrementally once built; a clone rebuilds it on first use from the tables
   void ensureConnectivity() const {
     if (connectivity_valid_) return;
-    by_variable_.clear();
-    for (const auto& kv : constraints_) for (const auto& u : kv.second.c->variables()) by_variable_[u].insert(kv.first);
+    conn_.assign(vslots_.size(), {});
+    for (size_t cs = 0; cs < ctype_.size(); ++cs)
+      if (ctype_[cs] != kFree)
+        forEachVariableOf((int32_t)cs, [&](int32_t s) { auto& l = conn_[s]; if (std::find(l.begin(), l.end(), (int32_t)cs) == l.end()) l.push_back((int32_t)cs); });
     connectivity_valid_ = true;
   }
-  mutable std::map<fuse_core::UUID, std::set<fuse_core::UUID>> by_variable_;
+  mutable std::vector<std::vector<int32_t>> conn_;
   mutable bool connectivity_valid_ = true;
-  std::set<fuse_core::UUID> on_hold_;
   bsgpu_summary last_summary_{};
 };
 

@@ -284,6 +284,15 @@ int bsgpu_set_cameras(bsgpu_ctx* ctx, int32_t n_cameras, const bsgpu_camera* cam
 int bsgpu_add_factors(bsgpu_ctx* ctx, int32_t type, int32_t n,
                       const int32_t* block_idx, const double* consts,
                       const int32_t* loss_kind, const double* loss_a);
+/* bsgpu_add_factors for a caller that keeps its factor tables across solves: the block-index columns of `slot_idx` hold
+ * caller-side variable slots (stable for the lifetime of a variable) and are translated through
+ * slot_to_block[n_slots] (slot -> index in the current bsgpu_set_blocks table) while the rows are copied in; camera
+ * columns are copied as they are.  A slot outside [0, n_slots) or mapped to a negative block is an error.  This is what
+ * lets bs_optimizers::GpuGraph (beam_slam_amd/host/gpu_graph.h) hand over its persistent packed tables unchanged
+ * every cycle although the block order shifts when the window slides.                    */
+int bsgpu_add_factors_indirect(bsgpu_ctx* ctx, int32_t type, int32_t n, const int32_t* slot_idx, int32_t n_slots,
+                               const int32_t* slot_to_block, const double* consts, const int32_t* loss_kind,
+                               const double* loss_a);
 
 /* ---- solve ----------------------------------------------------------------- */
 /* Uploads / builds the device-side structure (sorted factor tables, CSR of the

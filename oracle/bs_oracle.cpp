@@ -1197,6 +1197,19 @@ int bso_add_factors(Ctx* c, int32_t type, int32_t n, const int32_t* idx, const d
   c->finalized = false;
   return BSGPU_OK;
 }
+int bso_add_factors_indirect(Ctx* c, int32_t type, int32_t n, const int32_t* slot_idx, int32_t n_slots, const int32_t* slot_to_block,
+                             const double* consts, const int32_t* loss_kind, const double* loss_a) {
+  if (type < 0 || type >= BSGPU_F_NUM_TYPES) { c->err = "unknown factor type"; return BSGPU_ERR_INVALID; }
+  const bso::TypeInfo& ti = bso::kTypes[type];
+  std::vector<int32_t> idx(slot_idx, slot_idx + (size_t)n * ti.nidx);
+  for (int f = 0; f < n; ++f)
+    for (int k = 0; k < ti.nvar; ++k) {
+      const int32_t s = idx[(size_t)f * ti.nidx + k];
+      if (s < 0 || s >= n_slots || slot_to_block[s] < 0) { c->err = "add_factors_indirect: slot out of range or not mapped to a block"; return BSGPU_ERR_INVALID; }
+      idx[(size_t)f * ti.nidx + k] = slot_to_block[s];
+    }
+  return bso_add_factors(c, type, n, idx.data(), consts, loss_kind, loss_a);
+}
 int bso_add_marginal(Ctx* c, int32_t n_blocks, const int32_t* blocks, int32_t n_rows, const double* A, const double* b,
                      const double* xbar) {
   if (n_blocks <= 0 || n_rows <= 0 || !blocks || !A || !b || !xbar) { c->err = "add_marginal: bad arguments"; return BSGPU_ERR_INVALID; }

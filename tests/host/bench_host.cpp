@@ -53,7 +53,12 @@ int main(int argc, char** argv) {
   std::printf("graph: %zu variables, %zu constraints (%zu reprojection) built in %.0f ms\n", graph.numVariables(), graph.numConstraints(), n_obs, ms(t0, t1));
   auto opts = ceres_compat::SolverOptions::Vio();
   opts.max_solver_time_in_seconds = 1e9;
-  for (int rep = 0; rep < 4; ++rep) {
+  bs_optimizers::GpuGraph::UniquePtr snapshot;   // what the publishers hold: the previous cycle's clone stays alive across the next update
+  std::vector<uint64_t> recent_lm;
+  for (int j = n_lm - 3000; j < n_lm; ++j) recent_lm.push_back(j);
+  uint64_t next_lm = n_lm;
+  int oldest = 0;
+  for (int rep = 0; rep < 6; ++rep) {
     const auto a = clk::now();
     auto s = graph.optimize(opts);
     const auto b = clk::now();
@@ -61,8 +66,49 @@ int main(int argc, char** argv) {
     std::printf("cycle %d: optimize() %.1f ms total | back-end (finalize + solve) %.1f ms (%d it) | host flatten + hand-over %.1f ms | cost %.4e -> %.4e\n", rep,
                 ms(a, b), 1e3 * bs.total_time_in_seconds, bs.num_iterations, ms(a, b) - 1e3 * bs.total_time_in_seconds, s.initial_cost, s.final_cost);
     const auto c0 = clk::now();
-    auto copy = graph.clone();   // what fixed_lag_smoother.cpp:308 does every cycle for the publishers
-    std::printf("         Graph::clone() %.1f ms\n", ms(c0, clk::now()));
+    snapshot = graph.clone();   // what fixed_lag_smoother.cpp:308 does every cycle for the publishers
+    const auto c1 = clk::now();
+    // the window slides by one keyframe: the oldest state and everything attached to it leave, a new keyframe with
+    // 250 new landmarks (seen from the last 4 keyframes) and 1000 observations of recent landmarks enters
+    fuse_core::Transaction tr;
+    for (const auto* c : graph.getConnectedConstraints(st[oldest].Orientation().uuid())) tr.removeConstraint(c->uuid());
+    for (const auto* c : graph.getConnectedConstraints(st[oldest].Velocity().uuid())) tr.removeConstraint(c->uuid());
+    tr.removeVariable(st[oldest].Orientation().uuid()); tr.removeVariable(st[oldest].Position().uuid()); tr.removeVariable(st[oldest].Velocity().uuid());
+    tr.removeVariable(st[oldest].GyroBias().uuid()); tr.removeVariable(st[oldest].AccelBias().uuid());
+    ++oldest;
+    const int k = (int)st.size();
+    st.emplace_back(fuse_core::Time(0.1 * k), std::array<double, 4>{1, 0, 0, 0}, std::array<double, 3>{0.1 * k, 0, 0}, std::array<double, 3>{1.0, 0, 0});
+    tr.addVariable(st[k].Orientation().clone()); tr.addVariable(st[k].Position().clone()); tr.addVariable(st[k].Velocity().clone());
+    tr.addVariable(st[k].GyroBias().clone()); tr.addVariable(st[k].AccelBias().clone());
+    tr.addConstraint(std::make_shared<fuse_constraints::RelativePose3DStampedConstraint>("odom", st[k - 1].Position(), st[k - 1].Orientation(), st[k].Position(),
+                                                                                       st[k].Orientation(), bs_constraints::Vector7d{0.1, 0, 0, 1, 0, 0, 0}, c6));
+    auto observe = [&](const bs_variables::Point3DLandmark& lm, double X, double Y, double Z, int kf) {
+      const double px = X - 0.1 * kf, u = K(0, 0) * px / Z + K(0, 2), v = K(1, 1) * Y / Z + K(1, 2);
+      auto c = std::make_shared<bs_constraints::EuclideanReprojectionConstraint>("vo", st[kf].Orientation(), st[kf].Position(), lm, T, K,
+                                                                              std::array<double, 2>{u + N(rng), v + N(rng)}, 1.0);
+      c->loss(std::make_shared<fuse_loss::CauchyLoss>(5.0));
+      tr.addConstraint(c);
+    };
+    for (int j = 0; j < 250; ++j) {
+      const double z = 4.0 + 8.0 * U(rng), x0 = 0.1 * k + (U(rng) - 0.3) * 0.8 * z, y = (U(rng) - 0.5) * 0.6 * z;
+      auto lm = bs_variables::Point3DLandmark::make_shared(next_lm++);
+      lm->x() = x0; lm->y() = y; lm->z() = z;
+      tr.addVariable(lm);
+      for (int kf = k - 3; kf <= k; ++kf) observe(*lm, x0, y, z, kf);
+      recent_lm.push_back(lm->id());
+    }
+    for (int j = 0; j < 1000; ++j) {
+      const uint64_t id = recent_lm[recent_lm.size() - 1 - (size_t)(U(rng) * 2500)];
+      const auto& lm = static_cast<const bs_variables::Point3DLandmark&>(graph.variableExists(bs_variables::Point3DLandmark(id).uuid())
+                                                                         ? graph.getVariable(bs_variables::Point3DLandmark(id).uuid())
+                                                                         : *tr.addedVariables()[5 + (id - (next_lm - 250))]);
+      observe(lm, lm.data()[0], lm.data()[1], lm.data()[2], k);
+    }
+    const auto c2 = clk::now();
+    graph.update(tr);
+    const auto c3 = clk::now();
+    std::printf("         Graph::clone() %.1f ms | transaction built in %.1f ms (-%zu +%zu constraints) | Graph::update() %.1f ms with the snapshot alive -> %zu constraints\n",
+                ms(c0, c1), ms(c1, c2), tr.removedConstraints().size(), tr.addedConstraints().size(), ms(c2, c3), graph.numConstraints());
   }
   return 0;
 }

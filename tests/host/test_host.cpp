@@ -7,6 +7,8 @@
 #include <iostream>
 #include <random>
 
+#define BS_GRAPH_COW_BUCKETS 8   // small copy-on-write granules: every test graph spans several chunks / fills every bucket
+#define BS_GRAPH_COW_CHUNK 16
 #include "../../beam_slam_amd/host/fixed_lag_smoother.h"
 
 using namespace bs_math;
@@ -362,12 +364,87 @@ static void test_fixed_lag_smoother_window(bool pseudo_marginalization) {
   std::printf("  cycles %d, window positions %d, max variables %zu, final cost %.4f\n", smoother.numCycles(), n_pos, max_vars, smoother.summary().final_cost);
 }
 
+// Graph::clone() (fixed_lag_smoother.cpp:308): the copy shares the constraint side with the original behind
+// copy-on-write handles (gpu_graph.h) — it must still behave as a deep copy: transactions applied to either side
+// afterwards are invisible to the other, both sides stay solvable, and a chain of clones keeps that up.
+static void test_clone_is_an_independent_snapshot() {
+  std::printf("CloneIsAnIndependentSnapshot\n");
+  std::mt19937 rng(7);
+  std::normal_distribution<double> N(0.0, 1.0);
+  bs_optimizers::GpuGraph graph;
+  std::vector<bs_common::ImuState> st;
+  Mat<6, 6> c6 = 1e-2 * I6();
+  auto add_state = [&](bs_optimizers::GpuGraph& g, int k) {
+    while ((int)st.size() <= k) st.emplace_back(fuse_core::Time(0.1 * st.size()), std::array<double, 4>{1, 0, 0, 0},
+                                                std::array<double, 3>{0.1 * st.size() + 0.02 * N(rng), 0.02 * N(rng), 0.02 * N(rng)}, std::array<double, 3>{1, 0, 0});
+    g.addVariable(st[k].Orientation().clone()); g.addVariable(st[k].Position().clone());
+  };
+  std::vector<fuse_core::UUID> odom;
+  auto add_odom = [&](bs_optimizers::GpuGraph& g, int k) {
+    auto c = std::make_shared<fuse_constraints::RelativePose3DStampedConstraint>("odom", st[k].Position(), st[k].Orientation(), st[k + 1].Position(),
+                                                                               st[k + 1].Orientation(), bs_constraints::Vector7d{0.1, 0, 0, 1, 0, 0, 0}, c6);
+    if ((int)odom.size() <= k) odom.resize(k + 1);
+    odom[k] = c->uuid();
+    g.addConstraint(c);
+  };
+  const int n = 120;   // 7 chunks of constraint slots, every index bucket populated
+  for (int k = 0; k < n; ++k) add_state(graph, k);
+  graph.addConstraint(std::make_shared<fuse_constraints::AbsolutePose3DStampedConstraint>("prior", st[0].Position(), st[0].Orientation(),
+                                                                                        bs_constraints::Vector7d{0, 0, 0, 1, 0, 0, 0}, 1e-4 * I6()));
+  for (int k = 0; k + 1 < n; ++k) add_odom(graph, k);
+  auto snap = graph.clone();
+  CHECK(snap->numVariables() == graph.numVariables() && snap->numConstraints() == graph.numConstraints());
+  // slide the original: drop the 40 oldest odometry factors and states 0..39 keep only a new prior on state 40; extend by 30 states
+  {
+    fuse_core::Transaction tr;
+    for (const auto* c : graph.getConnectedConstraints(st[0].Position().uuid())) tr.removeConstraint(c->uuid());
+    for (int k = 1; k < 40; ++k) tr.removeConstraint(odom[k]);
+    for (int k = 0; k < 40; ++k) { tr.removeVariable(st[k].Position().uuid()); tr.removeVariable(st[k].Orientation().uuid()); }
+    graph.update(tr);
+    graph.addConstraint(std::make_shared<fuse_constraints::AbsolutePose3DStampedConstraint>("prior", st[40].Position(), st[40].Orientation(),
+                                                                                          bs_constraints::Vector7d{4.0, 0, 0, 1, 0, 0, 0}, 1e-4 * I6()));
+    for (int k = n; k < n + 30; ++k) { add_state(graph, k); add_odom(graph, k - 1); }
+  }
+  CHECK(graph.numVariables() == 2u * (n - 40 + 30)); CHECK(graph.numConstraints() == (size_t)(n - 1 - 40 + 30 + 1));
+  // the snapshot is untouched
+  CHECK(snap->numVariables() == 2u * n); CHECK(snap->numConstraints() == (size_t)n);
+  CHECK(snap->variableExists(st[0].Position().uuid()) && !graph.variableExists(st[0].Position().uuid()));
+  CHECK(snap->constraintExists(odom[5]) && !graph.constraintExists(odom[5]));
+  CHECK(!snap->variableExists(st[n + 3].Position().uuid()) && graph.variableExists(st[n + 3].Position().uuid()));
+  CHECK(snap->getConnectedConstraints(st[0].Position().uuid()).size() == 2);           // prior + first odometry factor
+  CHECK(graph.getConnectedConstraints(st[40].Position().uuid()).size() == 2);          // new prior + odometry 40 -> 41
+  CHECK(snap->getConnectedConstraints(st[40].Position().uuid()).size() == 2);          // odometry 39 -> 40 and 40 -> 41
+  CHECK(snap->getConstraints().size() == (size_t)n && graph.getConstraints().size() == graph.numConstraints());
+  // both sides solve their own problem: chain anchored at x = 0 (snapshot) resp. x = 4.0 at state 40 (original)
+  auto s_snap = snap->optimize();
+  auto s_orig = graph.optimize();
+  CHECK(s_snap.IsSolutionUsable() && s_orig.IsSolutionUsable());
+  CHECK_NEAR(snap->getVariable(st[100].Position().uuid()).data()[0], 0.1 * 100, 1e-3);
+  CHECK_NEAR(graph.getVariable(st[100].Position().uuid()).data()[0], 4.0 + 0.1 * 60, 1e-3);
+  CHECK_NEAR(graph.getVariable(st[n + 29].Position().uuid()).data()[0], 4.0 + 0.1 * (n + 29 - 40), 1e-3);
+  CHECK_NEAR(snap->getVariable(st[100].Position().uuid()).data()[0] - graph.getVariable(st[100].Position().uuid()).data()[0], 0.0, 1e-3);
+  // a clone of the clone, mutated, leaves its parent alone; removing a variable that is still used keeps throwing
+  auto snap2 = snap->clone();
+  snap2->removeConstraint(odom[n - 2]);
+  CHECK(snap->constraintExists(odom[n - 2]) && !snap2->constraintExists(odom[n - 2]));
+  bool threw = false;
+  try { snap2->removeVariable(st[7].Position().uuid()); } catch (const std::logic_error&) { threw = true; }
+  CHECK(threw);
+  snap.reset();                      // the parent goes first: the child keeps what it shares alive
+  CHECK(snap2->numConstraints() == (size_t)n - 1);
+  CHECK(snap2->getConnectedConstraints(st[n - 1].Position().uuid()).empty());
+  // the lone last state is now unconstrained: the back-end refuses nothing (it is simply not moved), the rest solves
+  snap2->removeVariable(st[n - 1].Position().uuid()); snap2->removeVariable(st[n - 1].Orientation().uuid());
+  CHECK(snap2->optimize().IsSolutionUsable());
+}
+
 int main() {
   test_block_order_and_pack();
   test_simple_2_state_fg();
   test_absolute_imu_state();
   test_inverse_depth_window();
   test_true_marginalization_linear_chain();
+  test_clone_is_an_independent_snapshot();
   test_fixed_lag_smoother_window(true);
   test_fixed_lag_smoother_window(false);
   if (g_fail) { std::printf("FAILED: %d checks\n", g_fail); return 1; }
