@@ -162,8 +162,14 @@ class FixedLagSmoother {
     summary_ = graph_->optimize(params_.solver_options);
     ++num_cycles_;
     if (!summary_.IsSolutionUsable()) return CycleResult::UnusableSolution;   // :286-295
+    // :305-308 notify(new_transaction, graph_->clone()): the publishers / sensor models get the transaction and a snapshot
+    // of the optimised graph ([EXT] fuse_optimizers::Optimizer::notify).  The snapshot shares the constraint side with
+    // graph_ copy-on-write (gpu_graph.h), so handing one out every cycle costs O(variables).
+    if (notify_) notify_(std::make_shared<const fuse_core::Transaction>(std::move(filtered)), std::shared_ptr<const GpuGraph>(graph_->clone()));
     return CycleResult::Optimized;
   }
+  using NotifyCallback = std::function<void(std::shared_ptr<const fuse_core::Transaction>, std::shared_ptr<const GpuGraph>)>;
+  void setNotifyCallback(NotifyCallback cb) { notify_ = std::move(cb); }
 
   const ceres_compat::SolverSummary& summary() const { return summary_; }
   const GpuGraph& graph() const { return *graph_; }
@@ -210,6 +216,7 @@ class FixedLagSmoother {
     return o;
   }
   GpuGraph::UniquePtr graph_;
+  NotifyCallback notify_;
   FixedLagSmootherParams params_;
   mutable std::mutex pending_transactions_mutex_;
   std::mutex optimization_mutex_;

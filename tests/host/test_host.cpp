@@ -279,6 +279,12 @@ static void test_fixed_lag_smoother_window(bool pseudo_marginalization) {
   params.solver_options = ceres_compat::SolverOptions();
   params.solver_options.max_num_iterations = 20;
   bs_optimizers::FixedLagSmoother smoother(bs_optimizers::GpuGraph::make_unique(), params);
+  // notify(transaction, graph->clone()) (fixed_lag_smoother.cpp:308): a publisher keeps every snapshot it was handed
+  struct Seen { std::shared_ptr<const bs_optimizers::GpuGraph> graph; size_t n_var, n_con, n_added; };
+  std::vector<Seen> seen;
+  smoother.setNotifyCallback([&](std::shared_ptr<const fuse_core::Transaction> tr, std::shared_ptr<const bs_optimizers::GpuGraph> g) {
+    seen.push_back(Seen{g, g->numVariables(), g->numConstraints(), tr->addedConstraints().size()});
+  });
   Mat<4, 4> T_cam_baselink = Mat<4, 4>::Identity();
   Mat<3, 3> K = Mat<3, 3>::Identity(); K(0, 0) = 458.654; K(1, 1) = 457.296; K(0, 2) = 367.215; K(1, 2) = 248.375;
   // landmarks ahead on a wall z = 8 (camera frame == body frame here: +z forward means world +z; fine for a synthetic test)
@@ -339,6 +345,12 @@ static void test_fixed_lag_smoother_window(bool pseudo_marginalization) {
     prev.Update(smoother.graph());
   }
   CHECK(usable == n_kf);
+  CHECK((int)seen.size() == n_kf);
+  for (const auto& sn : seen) {   // later cycles slid the window and re-solved: the old snapshots did not move
+    CHECK(sn.graph->numVariables() == sn.n_var && sn.graph->numConstraints() == sn.n_con && sn.n_added > 0);
+    CHECK(sn.graph->getConstraints().size() == sn.n_con);
+  }
+  CHECK(seen.front().graph->numVariables() < seen.back().graph->numVariables());
   CHECK(smoother.optimizeOnce() == bs_optimizers::FixedLagSmoother::CycleResult::NothingToDo);
   // the window is bounded: stamped states older than the lag are gone, and a MARGINALIZATION prior exists
   int n_pos = 0, n_marg = 0;
