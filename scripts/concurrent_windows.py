@@ -1,0 +1,31 @@
+"""Aggregate LM iterations/s of several independent windows solved concurrently on ONE GPU: one bsgpu context (own HIP
+stream) per host thread — the shape of the reference's local + global mapper processes and of submap refinement
+(bs_models/src/lib/global_mapping/submap_refinement.cpp:35-115), on a single device.  Not the bench.py metric."""
+import os, sys, threading, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from beam_slam_amd import synthetic
+from beam_slam_amd.gpu import GpuSolver
+
+n_kf, n_lm, steps = 200, 50000, 20
+counts = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
+windows = [synthetic.vio_window(n_kf=n_kf, n_lm=n_lm, seed=20250630 + i) for i in range(max(counts))]
+solvers = []
+for pr in windows:
+    g = GpuSolver(0); pr.load(g); g.finalize()
+    solvers.append(g)
+opt = solvers[0].options_vio(); opt.max_solver_time_in_seconds = 0.0
+for n in counts:
+    its = [0] * n
+    barrier = threading.Barrier(n + 1)
+    def work(i):
+        g = solvers[i]
+        for _ in range(3): g.reset_values(); g.solve(opt)
+        barrier.wait()
+        for _ in range(steps):
+            g.reset_values(); its[i] += g.solve(opt).num_linear_solves
+        barrier.wait()
+    th = [threading.Thread(target=work, args=(i,)) for i in range(n)]
+    for t in th: t.start()
+    barrier.wait(); t0 = time.perf_counter(); barrier.wait(); dt = time.perf_counter() - t0
+    for t in th: t.join()
+    print("%d concurrent windows: %.0f LM it/s aggregate, %.2f ms per solve per window" % (n, sum(its) / dt, 1e3 * dt / steps), flush=True)

@@ -68,6 +68,34 @@ def test_c2_solve_properties(c2, gpu_solver_cls):
     assert (s2.final_cost - s3.final_cost) <= 1e-4 * s2.final_cost
 
 
+def test_window_near_the_largest_supported_size(gpu_solver_cls):
+    """800 keyframes x 80 000 landmarks (~640 k observations): the reduced camera system has 12 000 dimensions, just under
+    the 12 288 the dense Schur path takes (188 tiles, 21 panel steps).  No CPU comparison at this size (the oracle's dense
+    factorisation takes minutes): size-independent properties, and the same window one step over the limit is refused
+    with an explanation instead of being attempted."""
+    pr = synthetic.vio_window(n_kf=800, n_lm=80000, seed=77)
+    g = gpu_solver_cls(0)
+    pr.load(g)
+    opt = g.options_vio()
+    opt.max_solver_time_in_seconds = 0.0
+    s = g.solve(opt)
+    assert s.is_solution_usable == 1 and s.linear_solver_used == capi.LINEAR_SCHUR_CHOLESKY
+    costs = [i.cost for i in g.iterations() if i.step_is_successful]
+    assert all(b <= a for a, b in zip(costs, costs[1:])) and s.final_cost < 0.01 * s.initial_cost
+    x = g.get_blocks()
+    p_err = np.array([pr.block(int(b), x) for b in pr.meta["kf_blocks"][:, 1]]) - pr.meta["p_true"]
+    assert np.abs(p_err).max() < 0.1                                  # metres; the start is 0.05 m sigma off the truth
+    g.reset_values()
+    s2 = g.solve(opt)
+    assert abs(s2.final_cost - s.final_cost) <= 1e-12 * s.final_cost   # deterministic
+    big = synthetic.vio_window(n_kf=830, n_lm=2000, seed=78)
+    g2 = gpu_solver_cls(0)
+    big.load(g2)
+    with pytest.raises(capi.SolverError) as e:
+        g2.solve(opt)
+    assert e.value.code == capi.ERR_UNSUPPORTED and "window too large" in str(e.value)
+
+
 def test_c3_lio_window_full_size(oracle_cls, gpu_solver_cls):
     """BASELINE config 3: 100 keyframes, 20 000 relative-pose(+constant extrinsics) factors + 99 IMU factors
     (1 500 tangent dims, exact path); the oracle solves it in seconds."""
