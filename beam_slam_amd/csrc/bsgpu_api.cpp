@@ -143,7 +143,7 @@ struct bsgpu_ctx {
   int nbr = 0, nblk = 0, pcg_iters_total = 0;
   int *d_row_ptr = nullptr, *d_col = nullptr, *d_diag_slot = nullptr;
   int* d_slots[kNumInternal] = {nullptr};
-  double *d_val = nullptr, *d_Minv = nullptr, *d_rhs = nullptr, *d_px = nullptr, *d_pr = nullptr, *d_pz = nullptr, *d_pp = nullptr,
+  double *d_val = nullptr, *d_Minv = nullptr, *d_rhs = nullptr, *d_px = nullptr, *d_pr = nullptr, *d_pz = nullptr, *d_pp = nullptr, *d_pp1 = nullptr,
          *d_pq = nullptr, *d_ppart = nullptr, *d_ppart2 = nullptr, *d_psc = nullptr;
 
   // device buffers are pooled across finalize() calls: a sliding window re-flattens every cycle with nearly the same
@@ -780,8 +780,8 @@ int build_bsr(bsgpu_ctx* c) {
   c->d_val = c->alloc<double>((size_t)nblk * 9); c->d_Minv = c->alloc<double>((size_t)nbr * 9);
   c->d_rhs = c->alloc<double>(c->n_pose);
   c->d_px = c->alloc<double>(c->n_pose); c->d_pr = c->alloc<double>(c->n_pose); c->d_pz = c->alloc<double>(c->n_pose);
-  c->d_pp = c->alloc<double>(c->n_pose); c->d_pq = c->alloc<double>(c->n_pose);
-  c->d_ppart = c->alloc<double>((size_t)(nbr * 16 + 255) / 256 + 8); c->d_ppart2 = c->alloc<double>(2 * ((size_t)(nbr + 255) / 256) + 8);
+  c->d_pp = c->alloc<double>(c->n_pose); c->d_pp1 = c->alloc<double>(c->n_pose); c->d_pq = c->alloc<double>(c->n_pose);
+  c->d_ppart = c->alloc<double>((size_t)pcg_spmv_grid(nbr) + 8); c->d_ppart2 = c->alloc<double>(4 * ((size_t)(nbr + 255) / 256) + 8);
   c->d_psc = c->alloc<double>(pcg_num_scalars());
   if (!c->d_val || !c->d_pq || !c->d_psc) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (block-sparse system)");
   c->bsr_built = true;
@@ -806,15 +806,15 @@ void assemble_pcg(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_
 // (H + Lambda) y = g by block-Jacobi PCG; the stop test lives on the device, the host looks at it every 20 iterations
 void pcg_solve(bsgpu_ctx* c, const bsgpu_options& o) {
   hipStream_t s = c->stream;
-  launch_pcg_init(s, c->nbr, c->d_rhs, c->d_Minv, c->d_px, c->d_pr, c->d_pz, c->d_pp, c->d_ppart2, c->d_psc);
+  launch_pcg_init(s, c->nbr, c->d_rhs, c->d_Minv, c->d_px, c->d_pr, c->d_pz, c->d_pp, c->d_pp1, c->d_ppart2, c->d_psc);
   const double tol2 = o.pcg_tolerance * o.pcg_tolerance;
   const int max_it = o.pcg_max_iterations > 0 ? o.pcg_max_iterations : 2000;
   double h[8];
   for (int it = 0; it < max_it;) {
     const int chunk = std::min(20, max_it - it);
     for (int k = 0; k < chunk; ++k)
-      launch_pcg_iteration(s, c->nbr, c->d_row_ptr, c->d_col, c->d_val, c->d_Minv, c->d_px, c->d_pr, c->d_pz, c->d_pp, c->d_pq,
-                           c->d_ppart, c->d_ppart2, c->d_psc, tol2);
+      launch_pcg_iteration(s, it + k, c->nbr, c->d_row_ptr, c->d_col, c->d_val, c->d_Minv, c->d_px, c->d_pr, c->d_pz, c->d_pp, c->d_pp1,
+                           c->d_pq, c->d_ppart, c->d_ppart2, c->d_psc, tol2);
     it += chunk;
     (void)hipMemcpyAsync(h, c->d_psc, sizeof(double) * pcg_num_scalars(), hipMemcpyDeviceToHost, s);
     (void)hipStreamSynchronize(s);

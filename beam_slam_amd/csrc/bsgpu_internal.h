@@ -180,10 +180,11 @@ void launch_bsr_assemble(hipStream_t s, const SmallGroup& g, const int* slots, d
 void launch_bsr_finish_diag(hipStream_t s, int nbr, const int* diag_slot, double* val, const double* hdiag, double radius,
                             int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* scale,
                             double* dcl, double* Minv);
-void launch_pcg_init(hipStream_t s, int nbr, const double* b, const double* Minv, double* x, double* r, double* z, double* p,
+int pcg_spmv_grid(int nbr);   // workgroups (= p.q partials) of one SpMV launch
+void launch_pcg_init(hipStream_t s, int nbr, const double* b, const double* Minv, double* x, double* r, double* z, double* p0, double* p1,
                      double* part, double* sc);
-void launch_pcg_iteration(hipStream_t s, int nbr, const int* row_ptr, const int* col, const double* val, const double* Minv,
-                          double* x, double* r, double* z, double* p, double* q, double* part_pq, double* part, double* sc,
+void launch_pcg_iteration(hipStream_t s, int k, int nbr, const int* row_ptr, const int* col, const double* val, const double* Minv,
+                          double* x, double* r, double* z, double* p0, double* p1, double* q, double* part_pq, double* part, double* sc,
                           double tol2);
 int pcg_num_scalars();
 int pcg_done_slot();

@@ -8,9 +8,8 @@
 //
 //   bsr_assemble        wave / factor: J^T J blocks -> atomics into the BSR values (slots precomputed)
 //   bsr_finish_diag     LM diagonal (Jacobi scaling folded in, as in the dense path) + 3x3 block inverses
-//   pcg_spmv_dot        q = A p  (16 lanes / block row) and partials of p.q
+//   pcg_spmv            beta, stop test and p = z + beta p folded in; q = A p (one wave / block row), partials of p.q
 //   pcg_update          alpha from the partials; x += a p; r -= a q; z = M^-1 r; partials of r.z, r.r
-//   pcg_direction       beta from the partials; p = z + beta p; bookkeeping scalars (device-resident)
 // HBM-bound: one PCG iteration streams the BSR values once (C4: 30 MB) plus six n-vectors.
 #include "bsgpu_device.h"
 
@@ -93,10 +92,43 @@ void launch_bsr_finish_diag(hipStream_t s, int nbr, const int* diag_slot, double
                      compute_scale, compute_dcl, jacobi, lm_lo, lm_hi, scale, dcl, Minv);
 }
 
-// x = 0, r = b, z = M^-1 r, p = z; scalars: rz, rr0
+// One PCG iteration is TWO launches (a third of the time of an iteration is otherwise the ~5 us dependency latency of
+// each extra launch; the SpMV itself streams 30 MB in ~6 us):
+//   S_k (pcg_spmv_kernel)    every workgroup reduces the r.z / r.r partials of iteration k itself (same order => same
+//                            bits everywhere), so beta_k and the stop test need no launch of their own; the direction
+//                            p_k = z_k + beta_k p_{k-1} is formed on the fly for the gathered columns and stored for the
+//                            workgroup's own rows into the OTHER p buffer (rows are gathered by other workgroups while
+//                            they are written, hence the double buffer); q = A p_k, partials of p_k.q
+//   U_k (pcg_update_kernel)  alpha_k = rz_k / (p_k.q) from the partials; x += alpha p_k; r -= alpha q; z = M^-1 r;
+//                            partials of r.z, r.r for iteration k+1 into the other half of `part` (S_{k+1} needs both
+//                            rz_{k+1} and rz_k)
+// The stop flag is sticky in the device scalars (written by workgroup 0 of S_k, read from the next launch on), the
+// host looks at it every 20 iterations.
+struct PcgTotals { double rz, rr; };
+// sum of the (r.z, r.r) partials, by the calling WAVE (every lane gets the totals; same order everywhere => same bits)
+BSG_DEV PcgTotals pcg_totals_wave(const double* __restrict__ part, int n_part) {
+  const int lane = threadIdx.x & 63;
+  double a = 0, c = 0;
+  for (int i = lane; i < n_part; i += 64) { a += part[2 * i]; c += part[2 * i + 1]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
+  PcgTotals t;
+  t.rz = a; t.rr = c;
+  return t;
+}
+BSG_DEV PcgTotals pcg_totals(const double* __restrict__ part, int n_part, double* sred) {
+  double a = 0, c = 0;
+  for (int i = threadIdx.x; i < n_part; i += 256) { a += part[2 * i]; c += part[2 * i + 1]; }
+  PcgTotals t;
+  t.rz = block_sum_256(a, sred);
+  t.rr = block_sum_256(c, sred);
+  return t;
+}
+
+// x = 0, r = b, z = M^-1 r, both p buffers = 0 (p_0 = z_0 + 0 * p_{-1}); partials of r.z, r.r for iteration 0
 __global__ __launch_bounds__(256) void pcg_init_kernel(int nbr, const double* __restrict__ b, const double* __restrict__ Minv,
                                                        double* __restrict__ x, double* __restrict__ r, double* __restrict__ z,
-                                                       double* __restrict__ p, double* __restrict__ part) {
+                                                       double* __restrict__ p0, double* __restrict__ p1, double* __restrict__ part) {
   __shared__ double sred[4];
   const int br = blockIdx.x * 256 + threadIdx.x;
   double rz = 0.0, rr = 0.0;
@@ -104,10 +136,10 @@ __global__ __launch_bounds__(256) void pcg_init_kernel(int nbr, const double* __
     const double r0 = b[3 * br], r1 = b[3 * br + 1], r2 = b[3 * br + 2];
     const double* M = Minv + (size_t)br * 9;
     const double z0 = M[0] * r0 + M[1] * r1 + M[2] * r2, z1 = M[3] * r0 + M[4] * r1 + M[5] * r2, z2 = M[6] * r0 + M[7] * r1 + M[8] * r2;
-    x[3 * br] = 0; x[3 * br + 1] = 0; x[3 * br + 2] = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { x[3 * br + i] = 0; p0[3 * br + i] = 0; p1[3 * br + i] = 0; }
     r[3 * br] = r0; r[3 * br + 1] = r1; r[3 * br + 2] = r2;
     z[3 * br] = z0; z[3 * br + 1] = z1; z[3 * br + 2] = z2;
-    p[3 * br] = z0; p[3 * br + 1] = z1; p[3 * br + 2] = z2;
     rz = r0 * z0 + r1 * z1 + r2 * z2; rr = r0 * r0 + r1 * r1 + r2 * r2;
   }
   const double a = block_sum_256(rz, sred), c = block_sum_256(rr, sred);
@@ -115,61 +147,73 @@ __global__ __launch_bounds__(256) void pcg_init_kernel(int nbr, const double* __
 }
 __global__ void pcg_init_scalars_kernel(const double* __restrict__ part, int np, double* __restrict__ sc) {
   __shared__ double sred[4];
-  double a = 0, c = 0;
-  for (int i = threadIdx.x; i < np; i += 256) { a += part[2 * i]; c += part[2 * i + 1]; }
-  const double ta = block_sum_256(a, sred), tc = block_sum_256(c, sred);
-  if (threadIdx.x == 0) { sc[PC_RZ] = ta; sc[PC_RR] = tc; sc[PC_RR0] = tc; sc[PC_DONE] = (tc == 0.0) ? 1.0 : 0.0; sc[PC_ITERS] = 0.0; }
+  const PcgTotals t = pcg_totals(part, np, sred);
+  if (threadIdx.x == 0) { sc[PC_RZ] = t.rz; sc[PC_RR] = t.rr; sc[PC_RR0] = t.rr; sc[PC_DONE] = (t.rr == 0.0) ? 1.0 : 0.0; sc[PC_ITERS] = 0.0; }
 }
 
-// q = A p, 16 lanes per block row; partials of p.q per workgroup
-__global__ __launch_bounds__(256) void pcg_spmv_dot_kernel(int nbr, const int* __restrict__ row_ptr, const int* __restrict__ col,
-                                                           const double* __restrict__ val, const double* __restrict__ p,
-                                                           double* __restrict__ q, double* __restrict__ part,
-                                                           const double* __restrict__ sc) {
+constexpr int kSpmvLanes = 16;
+// S_k
+__global__ __launch_bounds__(256) void pcg_spmv_kernel(int nbr, const int* __restrict__ row_ptr, const int* __restrict__ col,
+                                                       const double* __restrict__ val, const double* __restrict__ z,
+                                                       const double* __restrict__ p_prev, double* __restrict__ p_cur,
+                                                       double* __restrict__ q, const double* __restrict__ part_cur,
+                                                       const double* __restrict__ part_prev, int n_part, int first,
+                                                       double* __restrict__ part_pq, double* __restrict__ sc, double tol2) {
   __shared__ double sred[4];
+  // every wave derives beta_k and the stop test itself from the partials (a few dozen numbers): no workgroup barrier
+  const PcgTotals cur = pcg_totals_wave(part_cur, n_part);
+  const double rz_prev = first ? 0.0 : pcg_totals_wave(part_prev, n_part).rz;
+  const bool done = sc[PC_DONE] != 0.0 || !(cur.rr > tol2 * sc[PC_RR0]) || !(cur.rz > 0.0);
+  const double beta = (!first && rz_prev != 0.0) ? cur.rz / rz_prev : 0.0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (done) sc[PC_DONE] = 1.0;
+    else { sc[PC_ITERS] += 1.0; sc[PC_RZ] = cur.rz; sc[PC_RR] = cur.rr; }
+  }
+  // kLanes lanes per block row (a row of C4 has ~40 blocks of 72 bytes)
   const int gid = blockIdx.x * 256 + threadIdx.x;
-  const int br = gid >> 4, sub = gid & 15;
+  const int br = gid / kSpmvLanes, sub = gid % kSpmvLanes;
   double a0 = 0, a1 = 0, a2 = 0, pq = 0;
-  const bool done = sc[PC_DONE] != 0.0;
   if (br < nbr && !done) {
-    for (int e = row_ptr[br] + sub; e < row_ptr[br + 1]; e += 16) {
+    for (int e = row_ptr[br] + sub; e < row_ptr[br + 1]; e += kSpmvLanes) {
       const double* B = val + (size_t)e * 9;
       const int c = 3 * col[e];
-      const double p0 = p[c], p1 = p[c + 1], p2 = p[c + 2];
+      const double p0 = z[c] + beta * p_prev[c], p1 = z[c + 1] + beta * p_prev[c + 1], p2 = z[c + 2] + beta * p_prev[c + 2];
       a0 += B[0] * p0 + B[1] * p1 + B[2] * p2;
       a1 += B[3] * p0 + B[4] * p1 + B[5] * p2;
       a2 += B[6] * p0 + B[7] * p1 + B[8] * p2;
     }
   }
 #pragma unroll
-  for (int o = 8; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o, 16); a1 += __shfl_xor(a1, o, 16); a2 += __shfl_xor(a2, o, 16); }
+  for (int o = kSpmvLanes / 2; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o, kSpmvLanes); a1 += __shfl_xor(a1, o, kSpmvLanes); a2 += __shfl_xor(a2, o, kSpmvLanes); }
   if (br < nbr && sub == 0 && !done) {
-    q[3 * br] = a0; q[3 * br + 1] = a1; q[3 * br + 2] = a2;
-    pq = a0 * p[3 * br] + a1 * p[3 * br + 1] + a2 * p[3 * br + 2];
+    const int c = 3 * br;
+    const double p0 = z[c] + beta * p_prev[c], p1 = z[c + 1] + beta * p_prev[c + 1], p2 = z[c + 2] + beta * p_prev[c + 2];
+    p_cur[c] = p0; p_cur[c + 1] = p1; p_cur[c + 2] = p2;
+    q[c] = a0; q[c + 1] = a1; q[c + 2] = a2;
+    pq = a0 * p0 + a1 * p1 + a2 * p2;
   }
   const double t = block_sum_256(pq, sred);
-  if (threadIdx.x == 0) part[blockIdx.x] = t;
+  if (threadIdx.x == 0) part_pq[blockIdx.x] = t;
 }
 
-// alpha = rz / (p.q) (each workgroup reduces the partials itself); x += alpha p; r -= alpha q; z = M^-1 r;
-// partials of r.z and r.r
+// U_k
 __global__ __launch_bounds__(256) void pcg_update_kernel(int nbr, const double* __restrict__ part_pq, int n_part_pq,
                                                          const double* __restrict__ Minv, const double* __restrict__ p,
                                                          const double* __restrict__ q, double* __restrict__ x,
                                                          double* __restrict__ r, double* __restrict__ z,
-                                                         double* __restrict__ part, const double* __restrict__ sc) {
+                                                         double* __restrict__ part_next, const double* __restrict__ sc) {
   __shared__ double sred[4];
   __shared__ double s_alpha;
   double a = 0;
   for (int i = threadIdx.x; i < n_part_pq; i += 256) a += part_pq[i];
   const double pq = block_sum_256(a, sred);
-  if (threadIdx.x == 0) s_alpha = (pq > 0.0) ? sc[PC_RZ] / pq : 0.0;
+  if (threadIdx.x == 0) s_alpha = (pq > 0.0) ? sc[PC_RZ] / pq : 0.0;   // sc[PC_RZ] = rz_k, stored by S_k
   __syncthreads();
-  const bool done = sc[PC_DONE] != 0.0;
+  if (sc[PC_DONE] != 0.0) return;   // (uniform; the partials of the stopping iteration stay as they are)
   const double alpha = s_alpha;
   const int br = blockIdx.x * 256 + threadIdx.x;
   double rz = 0.0, rr = 0.0;
-  if (br < nbr && !done) {
+  if (br < nbr) {
     double rv[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) { x[3 * br + i] += alpha * p[3 * br + i]; rv[i] = r[3 * br + i] - alpha * q[3 * br + i]; r[3 * br + i] = rv[i]; }
@@ -179,58 +223,30 @@ __global__ __launch_bounds__(256) void pcg_update_kernel(int nbr, const double* 
     rz = rv[0] * z0 + rv[1] * z1 + rv[2] * z2; rr = rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2];
   }
   const double t1 = block_sum_256(rz, sred), t2 = block_sum_256(rr, sred);
-  if (threadIdx.x == 0) { part[2 * blockIdx.x] = t1; part[2 * blockIdx.x + 1] = t2; }
+  if (threadIdx.x == 0) { part_next[2 * blockIdx.x] = t1; part_next[2 * blockIdx.x + 1] = t2; }
 }
 
-// beta = rz_new / rz; p = z + beta p.  Workgroup 0 also updates the device scalars and the stop flag.
-__global__ __launch_bounds__(256) void pcg_direction_kernel(int nbr, const double* __restrict__ part, int n_part,
-                                                            const double* __restrict__ z, double* __restrict__ p,
-                                                            double* __restrict__ sc_rw, double tol2) {
-  __shared__ double sred[4];
-  __shared__ double s_beta;
-  double a = 0, c = 0;
-  for (int i = threadIdx.x; i < n_part; i += 256) { a += part[2 * i]; c += part[2 * i + 1]; }
-  const double rz_new = block_sum_256(a, sred);
-  const double rr_new = block_sum_256(c, sred);
-  const bool done = sc_rw[PC_DONE] != 0.0;
-  if (threadIdx.x == 0) s_beta = (sc_rw[PC_RZ] != 0.0) ? rz_new / sc_rw[PC_RZ] : 0.0;
-  __syncthreads();
-  const double beta = s_beta;
-  const int br = blockIdx.x * 256 + threadIdx.x;
-  if (br < nbr && !done) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) p[3 * br + i] = z[3 * br + i] + beta * p[3 * br + i];
-  }
-  // the scalars are read by every workgroup above: update them only after the whole grid has read them —
-  // which is guaranteed by doing it in a separate tiny launch (pcg_scalars_kernel) instead of here
-  (void)rr_new; (void)tol2;
-}
-__global__ void pcg_scalars_kernel(const double* __restrict__ part, int n_part, double* __restrict__ sc, double tol2) {
-  __shared__ double sred[4];
-  double a = 0, c = 0;
-  for (int i = threadIdx.x; i < n_part; i += 256) { a += part[2 * i]; c += part[2 * i + 1]; }
-  const double rz_new = block_sum_256(a, sred), rr_new = block_sum_256(c, sred);
-  if (threadIdx.x == 0 && sc[PC_DONE] == 0.0) {
-    sc[PC_RZ] = rz_new; sc[PC_RR] = rr_new; sc[PC_ITERS] += 1.0;
-    if (!(rr_new > tol2 * sc[PC_RR0]) || !(rz_new > 0.0)) sc[PC_DONE] = 1.0;
-  }
-}
-
-void launch_pcg_init(hipStream_t s, int nbr, const double* b, const double* Minv, double* x, double* r, double* z, double* p,
+int pcg_spmv_grid(int nbr);
+void launch_pcg_init(hipStream_t s, int nbr, const double* b, const double* Minv, double* x, double* r, double* z, double* p0, double* p1,
                      double* part, double* sc) {
   const int grid = (nbr + 255) / 256;
-  hipLaunchKernelGGL(pcg_init_kernel, dim3(grid), dim3(256), 0, s, nbr, b, Minv, x, r, z, p, part);
+  hipLaunchKernelGGL(pcg_init_kernel, dim3(grid), dim3(256), 0, s, nbr, b, Minv, x, r, z, p0, p1, part);
   hipLaunchKernelGGL(pcg_init_scalars_kernel, dim3(1), dim3(256), 0, s, part, grid, sc);
 }
-void launch_pcg_iteration(hipStream_t s, int nbr, const int* row_ptr, const int* col, const double* val, const double* Minv,
-                          double* x, double* r, double* z, double* p, double* q, double* part_pq, double* part, double* sc,
+// iteration k (0-based since the init): p buffers and the two halves of `part` (each 2 * ceil(nbr / 256) doubles) alternate
+void launch_pcg_iteration(hipStream_t s, int k, int nbr, const int* row_ptr, const int* col, const double* val, const double* Minv,
+                          double* x, double* r, double* z, double* p0, double* p1, double* q, double* part_pq, double* part, double* sc,
                           double tol2) {
-  const int g16 = (nbr * 16 + 255) / 256, g1 = (nbr + 255) / 256;
-  hipLaunchKernelGGL(pcg_spmv_dot_kernel, dim3(g16), dim3(256), 0, s, nbr, row_ptr, col, val, p, q, part_pq, sc);
-  hipLaunchKernelGGL(pcg_update_kernel, dim3(g1), dim3(256), 0, s, nbr, part_pq, g16, Minv, p, q, x, r, z, part, sc);
-  hipLaunchKernelGGL(pcg_direction_kernel, dim3(g1), dim3(256), 0, s, nbr, part, g1, z, p, sc, tol2);
-  hipLaunchKernelGGL(pcg_scalars_kernel, dim3(1), dim3(256), 0, s, part, g1, sc, tol2);
+  const int g16 = pcg_spmv_grid(nbr), g1 = (nbr + 255) / 256;
+  double* p_cur = (k & 1) ? p1 : p0;
+  double* p_prev = (k & 1) ? p0 : p1;
+  double* part_cur = part + (size_t)(k & 1) * 2 * g1;
+  double* part_other = part + (size_t)((k + 1) & 1) * 2 * g1;
+  hipLaunchKernelGGL(pcg_spmv_kernel, dim3(g16), dim3(256), 0, s, nbr, row_ptr, col, val, z, p_prev, p_cur, q, part_cur, part_other, g1,
+                     k == 0 ? 1 : 0, part_pq, sc, tol2);
+  hipLaunchKernelGGL(pcg_update_kernel, dim3(g1), dim3(256), 0, s, nbr, part_pq, g16, Minv, p_cur, q, x, r, z, part_other, sc);
 }
+int pcg_spmv_grid(int nbr) { return (int)(((size_t)nbr * kSpmvLanes + 255) / 256); }
 int pcg_num_scalars() { return PC_NUM; }
 int pcg_done_slot() { return PC_DONE; }
 int pcg_iters_slot() { return PC_ITERS; }
