@@ -190,6 +190,17 @@ struct bsgpu_ctx {
 namespace {
 
 int fail(bsgpu_ctx* c, int code, const std::string& msg) { c->err = msg; return code; }
+// No C++ exception crosses the C-ABI: every entry point is a function-try-block that ends here.
+int api_exception(bsgpu_ctx* c) noexcept {
+  int code = BSGPU_ERR_INVALID;
+  const char* what = "unexpected exception";
+  try { throw; }
+  catch (const std::bad_alloc&) { code = BSGPU_ERR_DEVICE; what = "out of host memory"; }
+  catch (const std::exception& e) { what = e.what(); try { if (c) c->err = std::string("internal error: ") + what; } catch (...) {} return code; }
+  catch (...) {}
+  try { if (c) c->err = what; } catch (...) {}
+  return code;
+}
 
 #define HIPCHK(c, call)                                                                         \
   do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(c, BSGPU_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
@@ -1161,7 +1172,7 @@ void bsgpu_options_vio(bsgpu_options* o) {  // beam_slam_launch/config/vio.yaml:
 
 const char* bsgpu_create_error(void) { return g_create_error.c_str(); }
 
-bsgpu_ctx* bsgpu_create(int device) {
+bsgpu_ctx* bsgpu_create(int device) try {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0) {
@@ -1176,7 +1187,7 @@ bsgpu_ctx* bsgpu_create(int device) {
   c->device = device;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete c; return nullptr; }
   return c;
-}
+} catch (...) { try { g_create_error = "out of host memory"; } catch (...) {} return nullptr; }
 void bsgpu_destroy(bsgpu_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
@@ -1189,7 +1200,8 @@ void bsgpu_destroy(bsgpu_ctx* c) {
 }
 const char* bsgpu_last_error(const bsgpu_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
-int bsgpu_clear(bsgpu_ctx* c) {
+int bsgpu_clear(bsgpu_ctx* c) try {
+  if (!c) return BSGPU_ERR_INVALID;
   c->nb = 0; c->h_x.clear(); c->off.clear(); c->size.clear(); c->manifold.clear(); c->is_const.clear();
   c->cams.clear();
   for (auto& g : c->groups) { g.n = 0; g.idx.clear(); g.consts.clear(); g.loss_kind.clear(); g.loss_a.clear(); }   // (capacity kept: a window is re-described every cycle)
@@ -1198,9 +1210,10 @@ int bsgpu_clear(bsgpu_ctx* c) {
   c->finalized = false;
   c->iters.clear();
   return BSGPU_OK;
-}
+} catch (...) { return api_exception(c); }
 int bsgpu_set_blocks(bsgpu_ctx* c, int32_t n, const double* values, const int32_t* offset, const uint8_t* size,
-                     const uint8_t* manifold, const uint8_t* is_const) {
+                     const uint8_t* manifold, const uint8_t* is_const) try {
+  if (!c) return BSGPU_ERR_INVALID;
   if (n <= 0 || !values || !offset || !size || !manifold || !is_const) return fail(c, BSGPU_ERR_INVALID, "set_blocks: null/empty argument");
   c->nb = n;
   c->off.assign(offset, offset + n); c->size.assign(size, size + n);
@@ -1210,8 +1223,9 @@ int bsgpu_set_blocks(bsgpu_ctx* c, int32_t n, const double* values, const int32_
   c->h_x.assign(values, values + tot);
   c->finalized = false;
   return BSGPU_OK;
-}
-int bsgpu_set_values(bsgpu_ctx* c, const double* v, int64_t n) {
+} catch (...) { return api_exception(c); }
+int bsgpu_set_values(bsgpu_ctx* c, const double* v, int64_t n) try {
+  if (!c) return BSGPU_ERR_INVALID;
   if ((size_t)n != c->h_x.size()) return fail(c, BSGPU_ERR_INVALID, "set_values: size mismatch");
   c->h_x.assign(v, v + n);
   if (c->finalized) {
@@ -1222,15 +1236,17 @@ int bsgpu_set_values(bsgpu_ctx* c, const double* v, int64_t n) {
     HIPCHK(c, hipMemcpy(c->d_x0, v, sizeof(double) * n, hipMemcpyHostToDevice));
   }
   return BSGPU_OK;
-}
-int bsgpu_set_cameras(bsgpu_ctx* c, int32_t n, const bsgpu_camera* cams) {
+} catch (...) { return api_exception(c); }
+int bsgpu_set_cameras(bsgpu_ctx* c, int32_t n, const bsgpu_camera* cams) try {
+  if (!c) return BSGPU_ERR_INVALID;
   if (n < 0 || (n > 0 && !cams)) return fail(c, BSGPU_ERR_INVALID, "set_cameras: bad argument");
   c->cams.assign(cams, cams + n);
   c->finalized = false;
   return BSGPU_OK;
-}
+} catch (...) { return api_exception(c); }
 int bsgpu_add_factors(bsgpu_ctx* c, int32_t type, int32_t n, const int32_t* idx, const double* consts,
-                      const int32_t* loss_kind, const double* loss_a) {
+                      const int32_t* loss_kind, const double* loss_a) try {
+  if (!c) return BSGPU_ERR_INVALID;
   if (type < 0 || type >= BSGPU_F_NUM_TYPES) return fail(c, BSGPU_ERR_INVALID, "unknown factor type");
   if (n < 0 || (n > 0 && (!idx || !consts))) return fail(c, BSGPU_ERR_INVALID, "add_factors: bad argument");
   const TypeInfo& ti = kTypes[type];
@@ -1245,9 +1261,10 @@ int bsgpu_add_factors(bsgpu_ctx* c, int32_t type, int32_t n, const int32_t* idx,
   g.n += n;
   c->finalized = false;
   return BSGPU_OK;
-}
+} catch (...) { return api_exception(c); }
 int bsgpu_add_factors_indirect(bsgpu_ctx* c, int32_t type, int32_t n, const int32_t* slot_idx, int32_t n_slots, const int32_t* slot_to_block,
-                               const double* consts, const int32_t* loss_kind, const double* loss_a) {
+                               const double* consts, const int32_t* loss_kind, const double* loss_a) try {
+  if (!c) return BSGPU_ERR_INVALID;
   if (type < 0 || type >= BSGPU_F_NUM_TYPES) return fail(c, BSGPU_ERR_INVALID, "unknown factor type");
   if (n < 0 || n_slots < 0 || (n > 0 && (!slot_idx || !consts || !slot_to_block))) return fail(c, BSGPU_ERR_INVALID, "add_factors_indirect: bad argument");
   const TypeInfo& ti = kTypes[type];
@@ -1276,9 +1293,10 @@ int bsgpu_add_factors_indirect(bsgpu_ctx* c, int32_t type, int32_t n, const int3
   g.n += n;
   c->finalized = false;
   return BSGPU_OK;
-}
+} catch (...) { return api_exception(c); }
 int bsgpu_add_marginal(bsgpu_ctx* c, int32_t n_blocks, const int32_t* blocks, int32_t n_rows, const double* A, const double* b,
-                       const double* xbar) {
+                       const double* xbar) try {
+  if (!c) return BSGPU_ERR_INVALID;
   if (n_blocks <= 0 || n_rows <= 0 || !blocks || !A || !b || !xbar) return fail(c, BSGPU_ERR_INVALID, "add_marginal: bad arguments");
   HostMarginal mg;
   mg.blocks.assign(blocks, blocks + n_blocks);
@@ -1294,37 +1312,42 @@ int bsgpu_add_marginal(bsgpu_ctx* c, int32_t n_blocks, const int32_t* blocks, in
   c->marginals.push_back(std::move(mg));
   c->finalized = false;
   return BSGPU_OK;
-}
-int bsgpu_finalize(bsgpu_ctx* c) { return finalize(c); }
-int bsgpu_solve(bsgpu_ctx* c, const bsgpu_options* o, bsgpu_summary* s) {
+} catch (...) { return api_exception(c); }
+int bsgpu_finalize(bsgpu_ctx* c) try { return c ? finalize(c) : BSGPU_ERR_INVALID; } catch (...) { return api_exception(c); }
+int bsgpu_solve(bsgpu_ctx* c, const bsgpu_options* o, bsgpu_summary* s) try {
+  if (!c) return BSGPU_ERR_INVALID;
   if (!o || !s) return fail(c, BSGPU_ERR_INVALID, "solve: null argument");
   return solve(c, *o, *s);
-}
-int bsgpu_get_blocks(bsgpu_ctx* c, double* v, int64_t n) {
+} catch (...) { return api_exception(c); }
+int bsgpu_get_blocks(bsgpu_ctx* c, double* v, int64_t n) try {
+  if (!c) return BSGPU_ERR_INVALID;
   if ((size_t)n != c->h_x.size()) return fail(c, BSGPU_ERR_INVALID, "get_blocks: size mismatch");
   if (!c->finalized) { std::memcpy(v, c->h_x.data(), sizeof(double) * n); return BSGPU_OK; }
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(v, c->d_x, sizeof(double) * n, hipMemcpyDeviceToHost));
   return BSGPU_OK;
-}
-int bsgpu_reset_values(bsgpu_ctx* c) {
+} catch (...) { return api_exception(c); }
+int bsgpu_reset_values(bsgpu_ctx* c) try {
+  if (!c) return BSGPU_ERR_INVALID;
   if (!c->finalized) return BSGPU_OK;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipMemcpyAsync(c->d_x, c->d_x0, sizeof(double) * c->h_x.size(), hipMemcpyDeviceToDevice, c->stream));
   return BSGPU_OK;
-}
-int bsgpu_num_iterations_recorded(const bsgpu_ctx* c) { return (int)c->iters.size(); }
-int bsgpu_get_iteration(const bsgpu_ctx* c, int32_t i, bsgpu_iteration* out) {
+} catch (...) { return api_exception(c); }
+int bsgpu_num_iterations_recorded(const bsgpu_ctx* c) { return c ? (int)c->iters.size() : 0; }
+int bsgpu_get_iteration(const bsgpu_ctx* c, int32_t i, bsgpu_iteration* out) try {
+  if (!c) return BSGPU_ERR_INVALID;
   if (i < 0 || i >= (int)c->iters.size() || !out) return BSGPU_ERR_INVALID;
   *out = c->iters[i];
   return BSGPU_OK;
-}
-int bsgpu_num_residuals(const bsgpu_ctx* c) { return c->n_res; }
-int bsgpu_num_parameters_tangent(const bsgpu_ctx* c) { return c->n_tan; }
-int bsgpu_tangent_offset(const bsgpu_ctx* c, int32_t b) { return (c->finalized && b >= 0 && b < c->nb) ? c->toff[b] : -1; }
+} catch (...) { return api_exception(const_cast<bsgpu_ctx*>(c)); }
+int bsgpu_num_residuals(const bsgpu_ctx* c) { return c ? c->n_res : -1; }
+int bsgpu_num_parameters_tangent(const bsgpu_ctx* c) { return c ? c->n_tan : -1; }
+int bsgpu_tangent_offset(const bsgpu_ctx* c, int32_t b) { return (c && c->finalized && b >= 0 && b < c->nb) ? c->toff[b] : -1; }
 
-int bsgpu_evaluate(bsgpu_ctx* c, double* cost, double* residuals, double* gradient, double* jacobian) {
+int bsgpu_evaluate(bsgpu_ctx* c, double* cost, double* residuals, double* gradient, double* jacobian) try {
+  if (!c) return BSGPU_ERR_INVALID;
   int rc = finalize(c);
   if (rc != BSGPU_OK) return rc;
   HIPCHK(c, hipSetDevice(c->device));
@@ -1438,7 +1461,7 @@ int bsgpu_evaluate(bsgpu_ctx* c, double* cost, double* residuals, double* gradie
   }
   if (gradient) std::memcpy(gradient, grad.data(), sizeof(double) * n);
   return BSGPU_OK;
-}
+} catch (...) { return api_exception(c); }
 
 // ---------------------------------------------------------------------------------------------------
 // [EXT] fuse_constraints::marginalizeVariables on the device.  The factors that touch the marginalised blocks form a
@@ -1446,7 +1469,8 @@ int bsgpu_evaluate(bsgpu_ctx* c, double* cost, double* residuals, double* gradie
 // complement, the undamped reduced system is gathered into [marginalised | kept] order and a single-workgroup
 // positive-semi-definite Cholesky yields both the Schur complement onto the kept blocks and its factor.
 // ---------------------------------------------------------------------------------------------------
-int bsgpu_marginalize(bsgpu_ctx* c, int32_t n_marg, const int32_t* marg_blocks, int32_t* n_kept, int32_t* n_rows, int32_t* n_cols) {
+int bsgpu_marginalize(bsgpu_ctx* c, int32_t n_marg, const int32_t* marg_blocks, int32_t* n_kept, int32_t* n_rows, int32_t* n_cols) try {
+  if (!c) return BSGPU_ERR_INVALID;
   if (!marg_blocks || n_marg <= 0 || !n_kept || !n_rows || !n_cols) return fail(c, BSGPU_ERR_INVALID, "marginalize: bad arguments");
   int rc = finalize(c);
   if (rc != BSGPU_OK) return rc;
@@ -1568,8 +1592,9 @@ int bsgpu_marginalize(bsgpu_ctx* c, int32_t n_marg, const int32_t* marg_blocks, 
   R.valid = true;
   *n_kept = (int32_t)kept.size(); *n_rows = R.rows; *n_cols = kdim;
   return BSGPU_OK;
-}
-int bsgpu_get_marginal(const bsgpu_ctx* c, int32_t* kept_blocks, double* A, double* b, double* xbar) {
+} catch (...) { return api_exception(c); }
+int bsgpu_get_marginal(const bsgpu_ctx* c, int32_t* kept_blocks, double* A, double* b, double* xbar) try {
+  if (!c) return BSGPU_ERR_INVALID;
   if (!c->marg_result.valid) return BSGPU_ERR_INVALID;
   const auto& R = c->marg_result;
   if (kept_blocks) std::memcpy(kept_blocks, R.kept.data(), sizeof(int32_t) * R.kept.size());
@@ -1577,12 +1602,13 @@ int bsgpu_get_marginal(const bsgpu_ctx* c, int32_t* kept_blocks, double* A, doub
   if (b) std::memcpy(b, R.b.data(), sizeof(double) * R.b.size());
   if (xbar) std::memcpy(xbar, R.xbar.data(), sizeof(double) * R.xbar.size());
   return BSGPU_OK;
-}
+} catch (...) { return api_exception(const_cast<bsgpu_ctx*>(c)); }
 
 // Graph::getCovariance for pose-side blocks: Sigma_pp = (H_pp - H_pl H_ll^-1 H_lp)^-1 = S^-1 at the current values,
 // without LM damping (what ceres::Covariance computes from the robustified J^T J, landmarks marginalised).
 // One undamped assembly + one factorisation; the unit vectors of both blocks ride along as rows of the rhs tile.
-int bsgpu_covariance(bsgpu_ctx* c, int32_t ba, int32_t bb, double* out) {
+int bsgpu_covariance(bsgpu_ctx* c, int32_t ba, int32_t bb, double* out) try {
+  if (!c) return BSGPU_ERR_INVALID;
   if (!out) return fail(c, BSGPU_ERR_INVALID, "null argument");
   int rc = finalize(c);
   if (rc != BSGPU_OK) return rc;
@@ -1624,9 +1650,10 @@ int bsgpu_covariance(bsgpu_ctx* c, int32_t ba, int32_t bb, double* out) {
   if (c->h_scal[SC_CHOL_FAIL] > 0.0 || !std::isfinite(out[0]))
     return fail(c, BSGPU_ERR_NUMERIC, "covariance: J^T J is singular at the current values (gauge freedom or unobserved block)");
   return BSGPU_OK;
-}
+} catch (...) { return api_exception(c); }
 
-int bsgpu_reprojection_errors(bsgpu_ctx* c, double* err) {
+int bsgpu_reprojection_errors(bsgpu_ctx* c, double* err) try {
+  if (!c) return BSGPU_ERR_INVALID;
   if (!err) return fail(c, BSGPU_ERR_INVALID, "null argument");
   int rc = finalize(c);
   if (rc != BSGPU_OK) return rc;
@@ -1648,11 +1675,11 @@ int bsgpu_reprojection_errors(bsgpu_ctx* c, double* err) {
   for (int i = 0; i < V.n; ++i) err[slot(c->vis_src[i])] = h[i];
   for (int i = 0; i < D.n; ++i) err[slot(c->dense_src[i])] = h[(size_t)V.n + i];
   return BSGPU_OK;
-}
+} catch (...) { return api_exception(c); }
 
 int bsgpu_preintegrate(int device, int32_t n, const int32_t* sample_start, const double* t, const double* w, const double* a,
                        const double* t_end, const double* bg, const double* ba, const double* cov_w, const double* cov_a,
-                       const double* cov_bg, const double* cov_ba, double info_weight, double* consts_out) {
+                       const double* cov_bg, const double* cov_ba, double info_weight, double* consts_out) try {
   if (n <= 0 || !sample_start || !t || !w || !a || !t_end || !bg || !ba || !cov_w || !cov_a || !cov_bg || !cov_ba || !consts_out) return BSGPU_ERR_INVALID;
   if (hipSetDevice(device) != hipSuccess) return BSGPU_ERR_DEVICE;
   const int ns = sample_start[n];
@@ -1685,11 +1712,12 @@ int bsgpu_preintegrate(int device, int32_t n, const int32_t* sample_start, const
   }
   for (void* p : bufs) (void)hipFree(p);
   return rc;
-}
+} catch (...) { return api_exception(nullptr); }
 
 int bsgpu_triangulate(bsgpu_ctx* c, int32_t n_tracks, const int32_t* track_start, const int32_t* q_block, const int32_t* p_block,
                       const double* pixels, int32_t camera, int32_t truncate_pixels, double max_dist, double max_reproj, double* points,
-                      int32_t* status) {
+                      int32_t* status) try {
+  if (!c) return BSGPU_ERR_INVALID;
   if (n_tracks < 0 || !track_start || !points || !status) return fail(c, BSGPU_ERR_INVALID, "null argument");
   if (n_tracks == 0) return BSGPU_OK;
   const int n_obs = track_start[n_tracks];
@@ -1736,9 +1764,10 @@ int bsgpu_triangulate(bsgpu_ctx* c, int32_t n_tracks, const int32_t* track_start
   release();
   if (e != hipSuccess || e2 != hipSuccess) return fail(c, BSGPU_ERR_DEVICE, "triangulate: device error");
   return BSGPU_OK;
-}
+} catch (...) { return api_exception(c); }
 
 double bsgpu_time_reproj_jacobian_ms(bsgpu_ctx* c, int32_t reps) {
+  if (!c) return -1.0;
   if (finalize(c) != BSGPU_OK || c->vis.n == 0 || reps <= 0) return -1.0;
   if (hipSetDevice(c->device) != hipSuccess) return -1.0;
   hipEvent_t e0, e1;
@@ -1754,6 +1783,7 @@ double bsgpu_time_reproj_jacobian_ms(bsgpu_ctx* c, int32_t reps) {
   return (double)ms / reps;
 }
 int64_t bsgpu_reproj_jacobian_bytes(const bsgpu_ctx* c) {
+  if (!c) return -1;
   // per factor: 16 B (3 offsets + meta) + 16 B pixel + 8 B weight in, 16 B residual + 144 B Jacobian out;
   // plus every parameter block once
   return (int64_t)c->vis.n * 200 + (int64_t)c->h_x.size() * 8;
@@ -1763,7 +1793,7 @@ int64_t bsgpu_reproj_jacobian_bytes(const bsgpu_ctx* c) {
 // (test + measurement hook for the MFMA path).  Host pointers in and out.  The tile structure (and with
 // it the nested-dissection ordering) is derived from the non-zeros of A; max_chains <= 1 forces the
 // natural order.
-int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, double* x, int32_t max_chains, double* ms_out) {
+int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, double* x, int32_t max_chains, double* ms_out) try {
   if (n <= 0 || !A || !b || !x) return BSGPU_ERR_INVALID;
   if (hipSetDevice(device) != hipSuccess) return BSGPU_ERR_DEVICE;
   chol_prepare();
@@ -1829,15 +1859,16 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
   (void)hipFree(dsep); (void)hipFree(dpot2); (void)hipFree(dcb); (void)hipFree(dce);
   (void)hipStreamDestroy(s);
   return rc;
-}
+} catch (...) { return api_exception(nullptr); }
 
 // number of independent sub-chains / schedule steps of the current problem's Cholesky plan (diagnostics)
-int bsgpu_plan_info(const bsgpu_ctx* c, int32_t* n_chains, int32_t* n_steps, int32_t* n_tiles) {
+int bsgpu_plan_info(const bsgpu_ctx* c, int32_t* n_chains, int32_t* n_steps, int32_t* n_tiles) try {
+  if (!c) return BSGPU_ERR_INVALID;
   if (!c->finalized) return BSGPU_ERR_INVALID;
   if (n_chains) *n_chains = c->plan.n_pieces;
   if (n_steps) *n_steps = c->plan.n_steps();
   if (n_tiles) *n_tiles = c->plan.T;
   return BSGPU_OK;
-}
+} catch (...) { return api_exception(const_cast<bsgpu_ctx*>(c)); }
 
 }  // extern "C"

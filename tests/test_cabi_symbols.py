@@ -70,3 +70,25 @@ def test_options_presets():
     assert o.gradient_tolerance == o.parameter_tolerance == o.function_tolerance == 1.5e-7
     lib.bsgpu_options_default(ctypes.byref(o))
     assert o.max_num_iterations == 50 and o.initial_trust_region_radius == 1e4 and o.min_relative_decrease == 1e-3
+
+
+def test_null_context_is_an_error_not_a_crash():
+    """Every context-taking entry point refuses a NULL context with BSGPU_ERR_INVALID (no compute, so no GPU needed)."""
+    lib = gpu.lib()
+    null = ctypes.c_void_p(None)
+    z = ctypes.c_void_p(None)
+    for name, args in [("clear", ()), ("finalize", ()), ("reset_values", ()), ("set_values", (z, ctypes.c_int64(0))),
+                       ("set_cameras", (ctypes.c_int32(0), z)), ("get_blocks", (z, ctypes.c_int64(0))),
+                       ("covariance", (ctypes.c_int32(0), ctypes.c_int32(0), z)), ("reprojection_errors", (z,)),
+                       ("add_factors", (ctypes.c_int32(0), ctypes.c_int32(0), z, z, z, z))]:
+        fn = getattr(lib, "bsgpu_" + name)
+        saved = fn.argtypes
+        fn.argtypes, fn.restype = None, ctypes.c_int     # (capi installs typed prototypes; raw NULLs here)
+        try:
+            assert fn(null, *args) == capi.ERR_INVALID, name
+        finally:
+            fn.argtypes = saved
+    lib.bsgpu_last_error.restype = ctypes.c_char_p
+    assert lib.bsgpu_last_error(null) == b"null context"
+    assert lib.bsgpu_num_residuals(null) == -1 and lib.bsgpu_tangent_offset(null, 0) == -1
+    lib.bsgpu_destroy(null)     # no-op
