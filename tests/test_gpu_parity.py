@@ -343,6 +343,42 @@ def test_device_preintegration_matches_host_restatement():
         assert np.allclose(A, np.triu(A))
 
 
+def test_kat6_zero_noise_preintegration_through_the_device(gpu_solver_cls):
+    """bs_models/tests/imu_preintegration_tests.cpp:444-700 (ImuPreintegration_ZeroNoiseConstantBias) as a property, through
+    the product path: bsgpu_preintegrate on mid-point IMU samples with ZERO noise covariances (the degenerate-covariance
+    guards of preintegrator.cpp:117-143 fire), PredictState, prior + pre-integrated factor solved by the HIP path — the end
+    state is the ground truth within the reference's {1e-6, 1e-3, 1e-3} (test_utils.h:77-81)."""
+    from beam_slam_amd import gpu
+    from test_oracle_reference_kats import imu_ground_truth, predict_state, _state_error
+    from beam_slam_amd.synthetic import rot_to_quat, sqrt_information_upper
+    from beam_slam_amd.problem import Problem
+    bg, ba = np.array([1e-3, 2e-3, 3e-3]), np.array([1e-3, 2e-3, 3e-3])
+    traj, t, w, a = imu_ground_truth(200.0, 10.0, bg, ba)
+    out = gpu.preintegrate(np.array([0, t.size], np.int32), t, w, a, [10.0], bg[None], ba[None], 0.0, 0.0, 0.0, 0.0)
+    pre = synthetic.PreIntegrator(0.0, 0.0, 0.0, 0.0)
+    pre.integrate(t, w, a, 10.0, bg, ba)
+    ref = pre.pack(bg, ba)
+    assert np.abs(out[0, :62] - ref[:62]).max() <= 1e-11 * max(1.0, np.abs(ref[:62]).max())     # 2 000 sequential increments
+    A = out[0, 62:].reshape(15, 15)
+    assert np.abs(A - ref[62:].reshape(15, 15)).max() <= 1e-9 * np.abs(ref[62:]).max()
+    assert np.allclose(np.diag(A)[:9], 1.0 / np.sqrt(1e-5)) and np.allclose(np.diag(A)[9:], 1.0 / np.sqrt(1e-9))   # the guards' cov_tol / bias_cov_tol
+    pre.t, pre.q, pre.p, pre.v = out[0, 0], out[0, 1:5], out[0, 5:8], out[0, 8:11]
+    q, p, v = predict_state(pre, rot_to_quat(traj.rot(0.0)), traj.pos(0.0), traj.vel(0.0))
+    pr = Problem()
+    s1 = [pr.add_quat(rot_to_quat(traj.rot(0.0))), pr.add_block(traj.pos(0.0)), pr.add_block(traj.vel(0.0)), pr.add_block(bg), pr.add_block(ba)]
+    s2 = [pr.add_quat(q), pr.add_block(p), pr.add_block(v), pr.add_block(bg), pr.add_block(ba)]
+    mean = np.concatenate([pr.block(b) for b in s1])
+    pr.add_factors(capi.F_IMU_PRIOR, [s1], [np.concatenate([mean, sqrt_information_upper(1e-9 * np.eye(15)).ravel()])])
+    pr.add_factors(capi.F_IMU_DELTA, [s1 + s2], [out[0]])
+    g = gpu_solver_cls(0)
+    pr.load(g)
+    s = g.solve()
+    assert s.is_solution_usable == 1 and s.final_cost < 1e-12
+    x = g.get_blocks()
+    e = _state_error(traj, 10.0, pr.block(s2[0], x), pr.block(s2[1], x), pr.block(s2[2], x))
+    assert e[0] < 1e-6 and e[1] < 1e-3 and e[2] < 1e-3
+
+
 def test_reprojection_error_screening(oracle_cls, gpu_solver_cls):
     """bsgpu_reprojection_errors: |z - projection| per reprojection factor (visual_odometry.cpp:1247-1272), including the
     factors of non-eliminated landmark blocks and the online-calibration type."""

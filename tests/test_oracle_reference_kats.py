@@ -231,3 +231,62 @@ def test_oracle_optimum_matches_scipy(oracle_cls, landmark_priors):
     opt.max_num_iterations = 100
     s = o.solve(opt)
     assert abs(s.final_cost - res.cost) <= 1e-6 * res.cost
+
+
+# --- bs_models/tests/imu_preintegration_tests.cpp:444-700  ImuPreintegration_ZeroNoiseConstantBias.BaseFunctionality ---------
+# The reference drives PreIntegrator + PredictState + prior + RelativeImuState factor with IMU data sampled from a RANDOM
+# basalt spline (not reproducible), at the MIDDLE of every sample interval (:109-123), with zero noise covariances and
+# constant biases, and expects the end state to come back to the ground truth within {1e-6 (q), 1e-3 (p), 1e-3 (v)}
+# (test_utils.h:77-81) before and after graph.optimize().  Reusable as a property on a smooth trajectory of our own.
+def imu_ground_truth(rate_hz, t_end, bg, ba):
+    traj = synthetic.Lissajous(20.0)
+    dt = 1.0 / rate_hz
+    t = np.arange(0.0, t_end + dt / 2, dt)
+    w = np.stack([traj.omega_body(x + dt / 2) for x in t]) + bg                                                   # :111-117
+    a = np.stack([traj.rot(x + dt / 2).T @ (traj.acc(x + dt / 2) - synthetic.GRAVITY_WORLD) for x in t]) + ba
+    return traj, t, w, a
+
+
+def predict_state(pre, q, p, v):
+    """ImuPreintegration::PredictState (bs_models/src/lib/imu/imu_preintegration.cpp:225-243)."""
+    R, g, T = quat_to_rot(q), synthetic.GRAVITY_WORLD, pre.t
+    return rot_to_quat(R @ quat_to_rot(pre.q)), p + v * T + 0.5 * g * T * T + R @ pre.p, v + g * T + R @ pre.v
+
+
+def _state_error(traj, t, q, p, v):
+    qt = rot_to_quat(traj.rot(t))
+    return np.abs(q * np.sign(q @ qt) - qt).max(), np.abs(p - traj.pos(t)).max(), np.abs(v - traj.vel(t)).max()
+
+
+def test_kat6_preintegration_of_midpoint_samples_returns_to_ground_truth(oracle_cls):
+    bg, ba = np.array([1e-3, 2e-3, 3e-3]), np.array([1e-3, 2e-3, 3e-3])
+    errs = {}
+    for rate in (100.0, 200.0):      # the reference test's 100 Hz and the rate its calibration declares (test_utils.h:93)
+        traj, t, w, a = imu_ground_truth(rate, 10.0, bg, ba)
+        pre = synthetic.PreIntegrator(0.0, 0.0, 0.0, 0.0)     # zero noise: imu_preintegration_tests.cpp:478-482
+        pre.integrate(t, w, a, 10.0, bg, ba)
+        assert abs(pre.t - 10.0) < 1e-9
+        q, p, v = predict_state(pre, rot_to_quat(traj.rot(0.0)), traj.pos(0.0), traj.vel(0.0))
+        errs[rate] = _state_error(traj, 10.0, q, p, v)
+    assert errs[200.0][0] < 1e-6 and errs[200.0][1] < 1e-3 and errs[200.0][2] < 1e-3            # test_utils.h:79
+    # the integration (mid-point rotation, :82-88) is second order in the sample interval
+    for k in range(3):
+        assert 3.5 < errs[100.0][k] / errs[200.0][k] < 4.5
+    # prior on the first state (cov_prior_noise 1e-9, imu_preintegration.h:36) + the pre-integrated factor; the end state
+    # starts at the prediction (imu_preintegration.cpp:290-296) and stays at the ground truth through the optimisation
+    pr = Problem()
+    s1 = [pr.add_quat(rot_to_quat(traj.rot(0.0))), pr.add_block(traj.pos(0.0)), pr.add_block(traj.vel(0.0)), pr.add_block(bg), pr.add_block(ba)]
+    s2 = [pr.add_quat(q), pr.add_block(p), pr.add_block(v), pr.add_block(bg), pr.add_block(ba)]
+    mean = np.concatenate([pr.block(b) for b in s1])
+    pr.add_factors(capi.F_IMU_PRIOR, [s1], [np.concatenate([mean, sqrt_information_upper(1e-9 * np.eye(15)).ravel()])])
+    pr.add_factors(capi.F_IMU_DELTA, [s1 + s2], [pre.pack(bg, ba)])
+    o = oracle_cls()
+    pr.load(o)
+    s = o.solve()
+    assert s.is_solution_usable == 1 and s.final_cost < 1e-12
+    x = o.get_blocks()
+    e = _state_error(traj, 10.0, pr.block(s2[0], x), pr.block(s2[1], x), pr.block(s2[2], x))
+    assert e[0] < 1e-6 and e[1] < 1e-3 and e[2] < 1e-3
+    assert np.abs(pr.block(s2[3], x) - bg).max() < 1e-9 and np.abs(pr.block(s2[4], x) - ba).max() < 1e-9
+    e1 = _state_error(traj, 0.0, pr.block(s1[0], x), pr.block(s1[1], x), pr.block(s1[2], x))
+    assert max(e1) < 1e-9
