@@ -840,8 +840,15 @@ void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot) {
   hipStream_t s = c->stream;
   const bool cand = slot == SC_COST_CAND;
   if (c->vis.n) launch_reproj_eval(s, c->vis, x, c->d_cams, c->d_losses, with_J, cand ? c->vis.cost_part_cand : c->vis.cost_part);
-  for (int t = 2; t < kNumInternal; ++t)
+  const bool imu_pair = c->small[BSGPU_F_IMU_DELTA].n > 0 && c->small[BSGPU_F_IMU_PRIOR].n > 0;
+  if (imu_pair)
+    launch_imu_eval(s, c->small[BSGPU_F_IMU_DELTA], c->small[BSGPU_F_IMU_PRIOR], x, c->d_losses, with_J,
+                    cand ? c->d_small_part_cand[BSGPU_F_IMU_DELTA] : c->d_small_part[BSGPU_F_IMU_DELTA],
+                    cand ? c->d_small_part_cand[BSGPU_F_IMU_PRIOR] : c->d_small_part[BSGPU_F_IMU_PRIOR]);
+  for (int t = 2; t < kNumInternal; ++t) {
+    if (imu_pair && (t == BSGPU_F_IMU_DELTA || t == BSGPU_F_IMU_PRIOR)) continue;
     if (c->small[t].n) launch_small_eval(s, c->small[t], x, c->d_losses, with_J, cand ? c->d_small_part_cand[t] : c->d_small_part[t]);
+  }
   for (const auto& mc : c->marg)
     if (mc.active) launch_marg_eval(s, mc.dev, x, with_J, cand ? mc.part_cand : mc.part);
 }
@@ -893,14 +900,16 @@ void dense_factor_solve(hipStream_t s, const DensePlan& P, const DenseDev& D, do
   dense_factor(s, P, D, S, scal);
   // y' = the rhs row after forward substitution: row rhs_row of the shadow matrix (the rhs tile is an
   // off-diagonal row tile of every panel)
-  launch_copy(s, D.Lp + (size_t)P.rhs_row * ld, y, (int64_t)P.T * 64, 64);
+  const double* rhs_row = D.Lp + (size_t)P.rhs_row * ld;
+  const bool single_root = P.bs_group_off.size() > 1 && P.bs_group_off[1] - P.bs_group_off[0] == 1;
+  if (!single_root) launch_copy(s, rhs_row, y, (int64_t)P.T * 64, 64);   // (a single root chain copies it itself on the way)
   // one launch per group of chains: root separator, the separator levels below it, then every piece (dense_plan.h)
   for (size_t g = 0; g + 1 < P.bs_group_off.size(); ++g) {
     const int c0 = P.bs_group_off[g], c1 = P.bs_group_off[g + 1];
     int max_len = 1;
     for (int i = c0; i < c1; ++i) max_len = std::max(max_len, P.chain_end[i] - P.chain_begin[i]);
     launch_chol_backsolve_chains(s, S, D.Lp, D.Vinv, ld, D.panels, D.panel_of_tile, D.chain_begin + c0, D.chain_end + c0, c1 - c0,
-                                 D.rows_flat, D.nreal, y, P.npad, max_len);
+                                 D.rows_flat, D.nreal, y, P.npad, max_len, (g == 0 && single_root) ? rhs_row : nullptr);
   }
 }
 
@@ -937,8 +946,12 @@ enum StepKind { STEP_FIRST = 0, STEP_ACCEPT = 1, STEP_REJECT = 2 };
 
 void enqueue_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius) {
   hipStream_t s = c->stream;
-  if (kind == STEP_ACCEPT)
-    launch_copy(s, c->d_xcand, c->d_x, (int64_t)c->h_x.size(), 0);
+  if (kind == STEP_ACCEPT) {
+    // the accepted candidate becomes the current point: a pointer swap (every launch takes x as an argument; the next update
+    // rewrites all of the other buffer) — except under graph replay, whose kernel arguments are frozen
+    if (c->use_graphs) launch_copy(s, c->d_xcand, c->d_x, (int64_t)c->h_x.size(), 0);
+    else std::swap(c->d_x, c->d_xcand);
+  }
   if (kind != STEP_REJECT) eval_all(c, c->d_x, true, SC_COST_X);
   assemble(c, o, radius, kind != STEP_REJECT, kind == STEP_FIRST);
   linear_solve_and_candidate(c, o);

@@ -129,6 +129,8 @@ struct LaunchCtx {
 // ---- kernel launchers (bsgpu_kernels.hip) ----------------------------------------------------------
 void launch_reproj_eval(hipStream_t s, const Visual& v, const double* x, const DevCamera* cams,
                         const DevLoss* losses, bool with_J, double* cost_part_out, bool count_inactive = false);
+void launch_imu_eval(hipStream_t s, const SmallGroup& delta, const SmallGroup& prior, const double* x, const DevLoss* losses, bool with_J,
+                     double* part_delta, double* part_prior);
 void launch_small_eval(hipStream_t s, const SmallGroup& g, const double* x, const DevLoss* losses, bool with_J,
                        double* cost_part /* n doubles: per-factor cost */);
 void launch_landmark(hipStream_t s, const Visual& v, int n_pose, const double* radius_ptr, int compute_scale,
@@ -151,7 +153,7 @@ void launch_chol_panel_step(hipStream_t s, double* S, double* Lp, int ld, const 
 void launch_chol_backsolve_chains(hipStream_t s, const double* S, const double* Lp, const double* Vinv, int ld,
                                   const PanelDesc* panels_dev, const int* panel_of_tile_dev, const int* chain_begin_dev,
                                   const int* chain_end_dev, int n_chains, const int* rows_flat_dev, const int* nreal_dev, double* y,
-                                  int npad, int max_chain_len);
+                                  int npad, int max_chain_len, const double* y_init = nullptr);
 size_t chol_backsolve_chain_lds(int npad, int max_chain_len);
 void launch_y_to_delta(hipStream_t s, int n_pose, const double* y, const int* perm, double* y_tan, double* delta);
 void launch_marg_schur(hipStream_t s, const double* S, int ld, int rhs_row, const int* spos_dev, int n, int m, double rel_tol,

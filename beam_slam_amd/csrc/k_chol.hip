@@ -486,7 +486,8 @@ __global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double
                                                                     const int* __restrict__ chain_begin,
                                                                     const int* __restrict__ chain_end,
                                                                     const int* __restrict__ rows_flat,
-                                                                    const int* __restrict__ nreal, double* y, int npad, int max_len) {
+                                                                    const int* __restrict__ nreal, double* y, int npad, int max_len,
+                                                                    const double* __restrict__ y_init) {
   extern __shared__ __attribute__((aligned(16))) double dyn[];
   double* sL = dyn;                         // 64 x 65
   double* sp = sL + NB * (NB + 1);          // 16 x 64
@@ -497,7 +498,9 @@ __global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double
   int* s_rows = s_nr + max_len;                       // max_len x kBsMaxRows
   const int tid = threadIdx.x;
   const int b = chain_begin[blockIdx.x], e = chain_end[blockIdx.x], len = e - b;
-  for (int i = tid; i < npad; i += 1024) sy[i] = y[i];
+  // y_init (first launch of a solve, a single chain): the forward-substituted rhs row of the factor, copied to y on the way
+  if (y_init) { for (int i = tid; i < npad; i += 1024) { const double v = (i < npad - NB) ? y_init[i] : 0.0; sy[i] = v; y[i] = v; } }   // (the last tile is the rhs tile itself)
+  else { for (int i = tid; i < npad; i += 1024) sy[i] = y[i]; }
   if (tid < len) {
     const PanelDesc pd = panels[panel_of_tile[b + tid]];
     s_nrows[tid] = pd.n_rows; s_rowoff[tid] = pd.row_off; s_nr[tid] = nreal[b + tid];
@@ -519,11 +522,11 @@ __global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double
 void launch_chol_backsolve_chains(hipStream_t s, const double* S, const double* Lp, const double* Vinv, int ld,
                                   const PanelDesc* panels_dev, const int* panel_of_tile_dev, const int* chain_begin_dev,
                                   const int* chain_end_dev, int n_chains, const int* rows_flat_dev, const int* nreal_dev, double* y,
-                                  int npad, int max_chain_len) {
+                                  int npad, int max_chain_len, const double* y_init) {
   if (n_chains <= 0) return;
   const size_t lds = chol_backsolve_chain_lds(npad, max_chain_len);
   hipLaunchKernelGGL(chol_backsolve_chain_kernel, dim3(n_chains), dim3(1024), lds, s, S, Lp, Vinv, ld, panels_dev, panel_of_tile_dev,
-                     chain_begin_dev, chain_end_dev, rows_flat_dev, nreal_dev, y, npad, max_chain_len);
+                     chain_begin_dev, chain_end_dev, rows_flat_dev, nreal_dev, y, npad, max_chain_len, n_chains == 1 ? y_init : nullptr);
 }
 
 size_t chol_backsolve_chain_lds(int npad, int max_chain_len) {

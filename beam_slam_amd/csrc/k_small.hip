@@ -40,10 +40,9 @@ BSG_DEV void finish_small(const SmallGroup& g, int f, const DevLoss* losses, dou
 // IMU delta: one wave per factor.  Lanes 0..14 own a residual row, lanes 0..29 own a Jacobian column.
 // ---------------------------------------------------------------------------------------------------
 template <bool WITH_J>
-__global__ __launch_bounds__(64) void imu_delta_kernel(SmallGroup g, const double* __restrict__ x,
-                                                       const DevLoss* __restrict__ losses,
-                                                       double* __restrict__ cost_part) {
-  const int f = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void imu_delta_body(const SmallGroup& g, const int f, const double* __restrict__ x,
+                                               const DevLoss* __restrict__ losses, double* __restrict__ cost_part) {
+  const int lane = threadIdx.x;
   const int* xo = g.xoff + (size_t)f * 10;
   const int* to = g.toff + (size_t)f * 10;
   const double* c = g.consts + (size_t)f * 287;
@@ -194,10 +193,9 @@ __global__ __launch_bounds__(64) void imu_delta_kernel(SmallGroup g, const doubl
 // IMU prior: one wave per factor; 15 rows / 15 columns
 // ---------------------------------------------------------------------------------------------------
 template <bool WITH_J>
-__global__ __launch_bounds__(64) void imu_prior_kernel(SmallGroup g, const double* __restrict__ x,
-                                                       const DevLoss* __restrict__ losses,
-                                                       double* __restrict__ cost_part) {
-  const int f = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void imu_prior_body(const SmallGroup& g, const int f, const double* __restrict__ x,
+                                               const DevLoss* __restrict__ losses, double* __restrict__ cost_part) {
+  const int lane = threadIdx.x;
   const int* xo = g.xoff + (size_t)f * 5;
   const int* to = g.toff + (size_t)f * 5;
   const double* c = g.consts + (size_t)f * 241;
@@ -233,6 +231,31 @@ __global__ __launch_bounds__(64) void imu_prior_kernel(SmallGroup g, const doubl
     else a = A[15 * k + lane];
     Jo[k * 15 + lane] = is_const ? 0.0 : a * sc;
   }
+}
+
+template <bool WITH_J>
+__global__ __launch_bounds__(64) void imu_delta_kernel(SmallGroup g, const double* __restrict__ x, const DevLoss* __restrict__ losses,
+                                                       double* __restrict__ cost_part) {
+  imu_delta_body<WITH_J>(g, blockIdx.x, x, losses, cost_part);
+}
+template <bool WITH_J>
+__global__ __launch_bounds__(64) void imu_prior_kernel(SmallGroup g, const double* __restrict__ x, const DevLoss* __restrict__ losses,
+                                                       double* __restrict__ cost_part) {
+  imu_prior_body<WITH_J>(g, blockIdx.x, x, losses, cost_part);
+}
+// both IMU factor types of a visual-inertial window (n-1 pre-integrated factors, one or two priors) in ONE launch: a launch
+// of its own for the single prior costs more in dispatch than in work
+template <bool WITH_J>
+__global__ __launch_bounds__(64) void imu_eval_kernel(SmallGroup delta, SmallGroup prior, const double* __restrict__ x,
+                                                      const DevLoss* __restrict__ losses, double* __restrict__ part_delta,
+                                                      double* __restrict__ part_prior) {
+  if ((int)blockIdx.x < delta.n) imu_delta_body<WITH_J>(delta, blockIdx.x, x, losses, part_delta);
+  else imu_prior_body<WITH_J>(prior, blockIdx.x - delta.n, x, losses, part_prior);
+}
+void launch_imu_eval(hipStream_t s, const SmallGroup& delta, const SmallGroup& prior, const double* x, const DevLoss* losses, bool with_J,
+                     double* part_delta, double* part_prior) {
+  if (with_J) hipLaunchKernelGGL(imu_eval_kernel<true>, dim3(delta.n + prior.n), dim3(64), 0, s, delta, prior, x, losses, part_delta, part_prior);
+  else hipLaunchKernelGGL(imu_eval_kernel<false>, dim3(delta.n + prior.n), dim3(64), 0, s, delta, prior, x, losses, part_delta, part_prior);
 }
 
 // ---------------------------------------------------------------------------------------------------
