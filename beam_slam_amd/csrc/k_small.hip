@@ -40,7 +40,7 @@ BSG_DEV void finish_small(const SmallGroup& g, int f, const DevLoss* losses, dou
 // IMU delta: one wave per factor.  Lanes 0..14 own a residual row, lanes 0..29 own a Jacobian column.
 // ---------------------------------------------------------------------------------------------------
 template <bool WITH_J>
-__device__ __forceinline__ void imu_delta_body(const SmallGroup& g, const int f, const double* __restrict__ x,
+__device__ __forceinline__ void imu_delta_body(const SmallGroup g, const int f, const double* __restrict__ x,
                                                const DevLoss* __restrict__ losses, double* __restrict__ cost_part) {
   const int lane = threadIdx.x;
   const int* xo = g.xoff + (size_t)f * 10;
@@ -193,7 +193,7 @@ __device__ __forceinline__ void imu_delta_body(const SmallGroup& g, const int f,
 // IMU prior: one wave per factor; 15 rows / 15 columns
 // ---------------------------------------------------------------------------------------------------
 template <bool WITH_J>
-__device__ __forceinline__ void imu_prior_body(const SmallGroup& g, const int f, const double* __restrict__ x,
+__device__ __forceinline__ void imu_prior_body(const SmallGroup g, const int f, const double* __restrict__ x,
                                                const DevLoss* __restrict__ losses, double* __restrict__ cost_part) {
   const int lane = threadIdx.x;
   const int* xo = g.xoff + (size_t)f * 5;
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(64) void imu_prior_kernel(SmallGroup g, const doubl
   imu_prior_body<WITH_J>(g, blockIdx.x, x, losses, cost_part);
 }
 // both IMU factor types of a visual-inertial window (n-1 pre-integrated factors, one or two priors) in ONE launch: a launch
-// of its own for the single prior costs more in dispatch than in work
+// of its own for the single prior costs more in dispatch than in work (see the Makefile note on this file's flags)
 template <bool WITH_J>
 __global__ __launch_bounds__(64) void imu_eval_kernel(SmallGroup delta, SmallGroup prior, const double* __restrict__ x,
                                                       const DevLoss* __restrict__ losses, double* __restrict__ part_delta,
