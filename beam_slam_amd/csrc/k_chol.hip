@@ -416,7 +416,7 @@ void launch_chol_panel_step(hipStream_t s, double* S, double* Lp, int ld, const 
 // backward substitution L^T y = y', one launch per schedule step in reverse order, one 1024-thread
 // workgroup per panel of the step:
 //   rhs = y'[k] - sum_{t in rows(k)} L(t, k)^T y[t]   (16 row groups x 64 columns, loads issued up front)
-//   solve L_kk^T y_k = rhs                              (one wave, v_readlane chain, reciprocal pivots)
+//   solve L_kk^T y_k = rhs                              (one wave, four 16-row block steps with the diagonal-block inverses)
 // y is in S (solver) order; rows >= nreal of a tile are kept zero.
 // ---------------------------------------------------------------------------------------------------
 // The back-substitution is latency work: per panel a handful of dependent round trips to L2 / HBM.  So every load a
@@ -424,59 +424,8 @@ void launch_chol_panel_step(hipStream_t s, double* S, double* Lp, int ld, const 
 // loads and consumes one row tile at a time pays one round trip per tile) — and the piece-walking kernel keeps y and
 // its panels' descriptors / row lists in LDS, so that nothing but L is fetched inside the walk.
 constexpr int kBsChunk = 6;
-BSG_DEV void backsolve_panel(int kb, const int* rows /* n_rows row tiles (LDS or global) */, int n_rows, int nr, const double* S,
-                             const double* Lp, const double* Vinv, int ld, const double* ysrc /* LDS copy or global y */,
-                             double* y, double* sy /* LDS copy of y to keep current, or nullptr */, double* sL, double* sp, int tid) {
-  const int c = tid & 63, part = tid >> 6;
-  const int c0 = kb * NB;
-  double dl[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int i = tid + 1024 * q;
-    const int r = i >> 6, cc = i & 63;
-    dl[q] = (cc <= r) ? Lp[(size_t)(c0 + r) * ld + c0 + cc] : 0.0;
-  }
-  const double invd = (tid < NB) ? Vinv[(size_t)kb * kVinvStride + 1024 + tid] : 0.0;
-  double acc = 0.0;
-  for (int q0 = 0; q0 < n_rows; q0 += kBsChunk) {
-    double l[kBsChunk][4];
-    int r0[kBsChunk];
-#pragma unroll
-    for (int u = 0; u < kBsChunk; ++u) {
-      const bool ok = q0 + u < n_rows;
-      r0[u] = (ok ? rows[q0 + u] : kb) * NB + 4 * part;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) l[u][i] = ok ? Lp[(size_t)(r0[u] + i) * ld + c0 + c] : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < kBsChunk; ++u)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc = fma(l[u][i], ysrc[r0[u] + i], acc);
-  }
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int i = tid + 1024 * q;
-    sL[(i >> 6) * (NB + 1) + (i & 63)] = dl[q];
-  }
-  sp[part * NB + c] = acc;
-  __syncthreads();
-  if (tid < NB) {
-    double sum = 0.0;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) sum += sp[q * NB + tid];
-    double yv = (tid < nr) ? (ysrc[c0 + tid] - sum) : 0.0;
-#pragma unroll
-    for (int j = NB - 1; j >= 0; --j) {
-      const double yj = readlane_d(yv, j) * readlane_d(invd, j);
-      if (tid == j) yv = yj;
-      if (tid < j) yv = fma(-sL[j * (NB + 1) + tid], yj, yv);
-    }
-    yv = (tid < nr) ? yv : 0.0;
-    y[c0 + tid] = yv;
-    if (sy) sy[c0 + tid] = yv;
-  }
-}
-
+// workgroup barrier that orders LDS traffic only: global loads issued before it stay in flight across it
+BSG_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // one workgroup per chain (a separator, or a piece of the nested-dissection ordering), walking its panels from its last
 // tile down to its first; everything a chain depends on outside itself was solved by an earlier launch (dense_plan.h)
 constexpr int kBsMaxRows = 16;   // row lists up to this length are staged in LDS
@@ -491,7 +440,8 @@ __global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double
   extern __shared__ __attribute__((aligned(16))) double dyn[];
   double* sL = dyn;                         // 64 x 65
   double* sp = sL + NB * (NB + 1);          // 16 x 64
-  double* sy = sp + 16 * NB;                // npad
+  double* sV = sp + 16 * NB;                // 4 x 16 x 16: inverses of the diagonal 16x16 blocks of L_kk
+  double* sy = sV + 1024;                   // npad
   int* s_nrows = reinterpret_cast<int*>(sy + npad);   // max_len
   int* s_rowoff = s_nrows + max_len;                  // max_len
   int* s_nr = s_rowoff + max_len;                     // max_len
@@ -511,11 +461,94 @@ __global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double
     if (q < s_nrows[p]) s_rows[i] = rows_flat[s_rowoff[p] + q];
   }
   __syncthreads();
-  for (int k = e - 1; k >= b; --k) {
-    const int p = k - b, n_rows = s_nrows[p];
+  // Software pipeline over the chain: the tiles of panel k-1 do not depend on y, so their loads are issued BEFORE the
+  // barrier + 64-pivot triangular solve of panel k and are in flight underneath it (the barrier is an LDS-only one: a
+  // __syncthreads() would wait for those loads).  Registers: the loaded values of panel k are dead (consumed into the
+  // partial sums / copied to LDS) by the time the loads of panel k-1 are issued, so one set suffices.
+  const int c = tid & 63, part = tid >> 6;
+  double dl[4], l[kBsChunk][4], vinv = 0.0;
+  int r0[kBsChunk];
+  auto issue = [&](int k) {
+    const int p = k - b, n_rows = s_nrows[p], c0 = k * NB;
     const int* rows = (n_rows <= kBsMaxRows) ? (s_rows + p * kBsMaxRows) : (rows_flat + s_rowoff[p]);
-    backsolve_panel(k, rows, n_rows, s_nr[p], S, Lp, Vinv, ld, sy, y, sy, sL, sp, tid);
-    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = tid + 1024 * q;
+      const int r = i >> 6, cc = i & 63;
+      dl[q] = (cc <= r) ? Lp[(size_t)(c0 + r) * ld + c0 + cc] : 0.0;
+    }
+    vinv = Vinv[(size_t)k * kVinvStride + tid];
+#pragma unroll
+    for (int u = 0; u < kBsChunk; ++u) {
+      const bool ok = u < n_rows;
+      r0[u] = (ok ? rows[u] : k) * NB + 4 * part;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) l[u][i] = ok ? Lp[(size_t)(r0[u] + i) * ld + c0 + c] : 0.0;
+    }
+  };
+  if (len > 0) issue(e - 1);
+  for (int k = e - 1; k >= b; --k) {
+    const int p = k - b, n_rows = s_nrows[p], nr = s_nr[p], c0 = k * NB;
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < kBsChunk; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc = fma(l[u][i], sy[r0[u] + i], acc);
+    if (n_rows > kBsChunk) {   // (wide separators only)
+      const int* rows = (n_rows <= kBsMaxRows) ? (s_rows + p * kBsMaxRows) : (rows_flat + s_rowoff[p]);
+      for (int q0 = kBsChunk; q0 < n_rows; q0 += 2) {
+        double l2[2][4];
+        int r2[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const bool ok = q0 + u < n_rows;
+          r2[u] = (ok ? rows[q0 + u] : k) * NB + 4 * part;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) l2[u][i] = ok ? Lp[(size_t)(r2[u] + i) * ld + c0 + c] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc = fma(l2[u][i], sy[r2[u] + i], acc);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = tid + 1024 * q;
+      sL[(i >> 6) * (NB + 1) + (i & 63)] = dl[q];
+    }
+    sp[part * NB + c] = acc;
+    sV[tid] = vinv;
+    if (k > b) issue(k - 1);
+    lds_barrier();
+    if (tid < NB) {
+      // L_kk^T y = t on one wave, lane = row.  Blocked by 16 with the inverses of the diagonal blocks (V_b = L_bb^-1, kept
+      // by the factorisation for its own triangular solves): four dependent block steps of independent loads and
+      // straight-line FMAs, instead of 64 dependent pivots each with its own LDS round trip and branch.
+      double sum = 0.0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) sum += sp[q * NB + tid];
+      double v = (tid < nr) ? (sy[c0 + tid] - sum) : 0.0;
+      const int blk = tid >> 4, li = tid & 15;
+#pragma unroll
+      for (int bb = 3; bb >= 0; --bb) {
+        double yb = 0.0;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) yb = fma(sV[bb * 256 + m * 16 + li], readlane_d(v, 16 * bb + m), yb);   // (V_b^T t_b)_i
+        v = (blk == bb) ? yb : v;
+        if (bb > 0) {
+#pragma unroll
+          for (int m = 0; m < 16; ++m) {
+            const double upd = fma(-sL[(16 * bb + m) * (NB + 1) + tid], readlane_d(v, 16 * bb + m), v);
+            v = (tid < 16 * bb) ? upd : v;
+          }
+        }
+      }
+      v = (tid < nr) ? v : 0.0;
+      y[c0 + tid] = v;
+      sy[c0 + tid] = v;
+    }
+    lds_barrier();
   }
 }
 
@@ -530,7 +563,7 @@ void launch_chol_backsolve_chains(hipStream_t s, const double* S, const double* 
 }
 
 size_t chol_backsolve_chain_lds(int npad, int max_chain_len) {
-  return sizeof(double) * (NB * (NB + 1) + 16 * NB + (size_t)npad) + sizeof(int) * (size_t)max_chain_len * (3 + kBsMaxRows);
+  return sizeof(double) * (NB * (NB + 1) + 16 * NB + 1024 + (size_t)npad) + sizeof(int) * (size_t)max_chain_len * (3 + kBsMaxRows);
 }
 int chol_vinv_stride() { return kVinvStride; }
 void chol_prepare() {
