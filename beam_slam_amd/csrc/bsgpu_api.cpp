@@ -709,7 +709,7 @@ int finalize(bsgpu_ctx* c) {
       if (!c->small[t].n) continue;
       tab.push_back({c->d_small_part[t], c->small[t].n, 1, 0, SC_COST_X});
       tab.push_back({c->d_small_part_cand[t], c->small[t].n, 1, 0, SC_COST_CAND});
-      tab.push_back({c->d_small_part_mcc[t], c->small[t].n * c->small[t].m, 1, 0, SC_MCC});
+      tab.push_back({c->d_small_part_mcc[t], (c->small[t].n * c->small[t].m + 127) / 128, 1, 0, SC_MCC});   // one partial per workgroup of small_mcc_kernel
     }
     for (const auto& mc : c->marg) {
       if (!mc.active) continue;

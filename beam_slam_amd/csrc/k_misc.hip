@@ -131,9 +131,16 @@ __global__ __launch_bounds__(256) void final_reduce_kernel(const ReduceEntry* __
     const ReduceEntry en = entries[e];
     if (en.slot != slot) continue;
     any = true;
-    double a = 0.0;
-    for (int i = threadIdx.x; i < en.n; i += 256) a += en.ptr[(size_t)i * en.stride + en.offset];
-    acc += a;
+    // eight independent partial sums per thread: with one, every load waits for the previous add — a per-factor array of a
+    // 20 000-factor group then costs 80 dependent round trips (115 us on C3) instead of 10
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int i = threadIdx.x;
+    for (; i + 7 * 256 < en.n; i += 8 * 256) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += en.ptr[(size_t)(i + 256 * u) * en.stride + en.offset];
+    }
+    for (; i < en.n; i += 256) a[0] += en.ptr[(size_t)i * en.stride + en.offset];
+    acc += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   }
   const double t = block_sum_256(acc, sred);
   if (threadIdx.x == 0) {

@@ -803,25 +803,32 @@ __global__ __launch_bounds__(128) void small_mcc_kernel(SmallGroupSet set, const
   while (gi + 1 < set.n && (int)blockIdx.x >= set.first[gi + 1]) ++gi;
   const SmallGroup& g = set.g[gi];
   double* part = set.part[gi];
-  const int id = (blockIdx.x - set.first[gi]) * 128 + threadIdx.x;
+  const int wg = blockIdx.x - set.first[gi];
+  const int id = wg * 128 + threadIdx.x;
   const int m = g.m;
-  if (id >= g.n * m) return;
-  const int f = id / m, k = id - f * m;
   double acc = 0.0;
-  if (g.active[f]) {
-    const int tw = 3 * g.nv;
-    const double* J = g.J + ((size_t)f * m + k) * tw;
-    const int* to = g.toff + (size_t)f * g.nv;
-    double jv = 0.0;
-    for (int sl = 0; sl < g.nv; ++sl) {
-      const int t = to[sl];
-      if (t < 0) continue;
-      if (sl == g.nv - 1 && g.w_last < 3) { for (int i = 0; i < g.w_last; ++i) jv += J[3 * sl + i] * delta[t + i]; continue; }
-      jv += J[3 * sl] * delta[t] + J[3 * sl + 1] * delta[t + 1] + J[3 * sl + 2] * delta[t + 2];
+  if (id < g.n * m) {
+    const int f = id / m, k = id - f * m;
+    if (g.active[f]) {
+      const int tw = 3 * g.nv;
+      const double* J = g.J + ((size_t)f * m + k) * tw;
+      const int* to = g.toff + (size_t)f * g.nv;
+      double jv = 0.0;
+      for (int sl = 0; sl < g.nv; ++sl) {
+        const int t = to[sl];
+        if (t < 0) continue;
+        if (sl == g.nv - 1 && g.w_last < 3) { for (int i = 0; i < g.w_last; ++i) jv += J[3 * sl + i] * delta[t + i]; continue; }
+        jv += J[3 * sl] * delta[t] + J[3 * sl + 1] * delta[t + 1] + J[3 * sl + 2] * delta[t + 2];
+      }
+      acc = -jv * (g.r[(size_t)f * m + k] + 0.5 * jv);
     }
-    acc = -jv * (g.r[(size_t)f * m + k] + 0.5 * jv);
   }
-  part[id] = acc;
+  // one partial per workgroup (a 20 000-factor group has 120 000 rows: the end-of-step reduction should not walk them)
+  __shared__ double s2[2];
+  const double w = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s2[threadIdx.x >> 6] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) part[wg] = s2[0] + s2[1];
 }
 
 void launch_small_mcc_set(hipStream_t s, const SmallGroup* groups, double* const* parts, int n_groups, const double* delta) {

@@ -11,7 +11,7 @@ for (s0, e0, n0), (s1, e1, n1) in zip(ev, ev[1:]):
     g = max(0, s1 - e0)
     gaps[n1] += g; gapn[n1] += 1
 for s, e, n in ev: dur[n] += e - s; cnt[n] += 1
-n_it = cnt.get("landmark_kernel", 1)
+n_it = cnt.get(sys.argv[2] if len(sys.argv) > 2 else "landmark_kernel", 1)   # a kernel launched once per LM iteration
 print("kernels %d, LM iterations %d, span %.1f us/it, busy %.1f us/it, idle %.1f us/it" % (len(ev), n_it, span / n_it / 1e3, busy / n_it / 1e3, (span - busy) / n_it / 1e3))
 print("%-44s %8s %10s %10s" % ("kernel", "calls/it", "busy us/it", "gap-before us/it"))
 for n, d in dur.most_common(30):
