@@ -138,6 +138,8 @@ struct bsgpu_ctx {
   bool graphs_tried = false, graphs_ok = false, use_graphs = true;
   bsgpu_options graph_opts{};
   double* h_radius = nullptr;  // pinned
+  double* h_pcg = nullptr;     // pinned: two read-backs of the PCG scalars in flight (pcg_solve)
+  hipEvent_t pcg_ev[2] = {nullptr, nullptr};
   // block-sparse PCG path
   bool dense_ok = true, bsr_built = false, use_pcg = false;
   int nbr = 0, nblk = 0, pcg_iters_total = 0;
@@ -820,18 +822,55 @@ void pcg_solve(bsgpu_ctx* c, const bsgpu_options& o) {
   launch_pcg_init(s, c->nbr, c->d_rhs, c->d_Minv, c->d_px, c->d_pr, c->d_pz, c->d_pp, c->d_pp1, c->d_ppart2, c->d_psc);
   const double tol2 = o.pcg_tolerance * o.pcg_tolerance;
   const int max_it = o.pcg_max_iterations > 0 ? o.pcg_max_iterations : 2000;
-  double h[8];
-  for (int it = 0; it < max_it;) {
-    const int chunk = std::min(20, max_it - it);
-    for (int k = 0; k < chunk; ++k)
-      launch_pcg_iteration(s, it + k, c->nbr, c->d_row_ptr, c->d_col, c->d_val, c->d_Minv, c->d_px, c->d_pr, c->d_pz, c->d_pp, c->d_pp1,
+  const int ns = pcg_num_scalars();
+  if (!c->h_pcg && hipHostMalloc((void**)&c->h_pcg, sizeof(double) * 2 * ns) != hipSuccess) { c->h_pcg = nullptr; (void)hipGetLastError(); }
+  for (hipEvent_t& e : c->pcg_ev)
+    if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; (void)hipGetLastError(); }
+  const bool pipelined = c->h_pcg && c->pcg_ev[0] && c->pcg_ev[1];
+  // The stop flag lives on the device and is sticky; the host looks at it once per chunk of iterations.  The read-back of
+  // chunk n is waited for only after chunk n+1 has been enqueued, so the stream never drains while the host decides
+  // (a blocking check per chunk left the device idle ~28 us each time); the iterations enqueued past convergence see the
+  // flag and do nothing.
+  const int kChunk = 12;
+  double last[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto enqueue_chunk = [&](int it0, int n, int slot) {
+    for (int k = 0; k < n; ++k)
+      launch_pcg_iteration(s, it0 + k, c->nbr, c->d_row_ptr, c->d_col, c->d_val, c->d_Minv, c->d_px, c->d_pr, c->d_pz, c->d_pp, c->d_pp1,
                            c->d_pq, c->d_ppart, c->d_ppart2, c->d_psc, tol2);
-    it += chunk;
-    (void)hipMemcpyAsync(h, c->d_psc, sizeof(double) * pcg_num_scalars(), hipMemcpyDeviceToHost, s);
-    (void)hipStreamSynchronize(s);
-    if (h[pcg_done_slot()] != 0.0) break;
+    if (pipelined) {
+      (void)hipMemcpyAsync(c->h_pcg + slot * ns, c->d_psc, sizeof(double) * ns, hipMemcpyDeviceToHost, s);
+      (void)hipEventRecord(c->pcg_ev[slot], s);
+    }
+  };
+  if (!pipelined) {
+    for (int it = 0; it < max_it;) {
+      const int chunk = std::min(20, max_it - it);
+      enqueue_chunk(it, chunk, 0);
+      it += chunk;
+      (void)hipMemcpyAsync(last, c->d_psc, sizeof(double) * ns, hipMemcpyDeviceToHost, s);
+      (void)hipStreamSynchronize(s);
+      if (last[pcg_done_slot()] != 0.0) break;
+    }
+  } else {
+    int it = std::min(kChunk, max_it), slot = 0;
+    enqueue_chunk(0, it, slot);
+    for (;;) {
+      int next_n = std::min(kChunk, max_it - it);
+      if (next_n > 0) enqueue_chunk(it, next_n, slot ^ 1);
+      (void)hipEventSynchronize(c->pcg_ev[slot]);
+      std::memcpy(last, c->h_pcg + slot * ns, sizeof(double) * ns);
+      if (last[pcg_done_slot()] != 0.0 || next_n <= 0) {
+        if (next_n > 0) {   // the chunk in flight: let it drain so that its read-back does not land in a later solve's slot
+          (void)hipEventSynchronize(c->pcg_ev[slot ^ 1]);
+          std::memcpy(last, c->h_pcg + (slot ^ 1) * ns, sizeof(double) * ns);
+        }
+        break;
+      }
+      it += next_n;
+      slot ^= 1;
+    }
   }
-  c->pcg_iters_total += (int)h[pcg_iters_slot()];
+  c->pcg_iters_total += (int)last[pcg_iters_slot()];
 }
 
 // residuals (+ Jacobians) of every factor group; per-group cost partials go to the arrays the
@@ -1208,6 +1247,8 @@ void bsgpu_destroy(bsgpu_ctx* c) {
   c->release_pool();
   if (c->h_scal) (void)hipHostFree(c->h_scal);
   if (c->h_radius) (void)hipHostFree(c->h_radius);
+  if (c->h_pcg) (void)hipHostFree(c->h_pcg);
+  for (hipEvent_t e : c->pcg_ev) if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
