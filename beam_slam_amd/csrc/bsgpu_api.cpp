@@ -983,7 +983,10 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
 // ---------------------------------------------------------------------------------------------------
 enum StepKind { STEP_FIRST = 0, STEP_ACCEPT = 1, STEP_REJECT = 2 };
 
-void enqueue_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius) {
+// gradient_only: the iteration budget is used up — the point just accepted still needs its cost and gradient norms for the
+// iteration record, but no step will be taken from it: evaluation + assembly (which produces the gradient), no factorisation,
+// no candidate
+void enqueue_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius, bool gradient_only = false) {
   hipStream_t s = c->stream;
   if (kind == STEP_ACCEPT) {
     // the accepted candidate becomes the current point: a pointer swap (every launch takes x as an argument; the next update
@@ -993,6 +996,7 @@ void enqueue_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius)
   }
   if (kind != STEP_REJECT) eval_all(c, c->d_x, true, SC_COST_X);
   assemble(c, o, radius, kind != STEP_REJECT, kind == STEP_FIRST);
+  if (gradient_only) { final_reduce(c); return; }
   linear_solve_and_candidate(c, o);
 }
 
@@ -1020,18 +1024,18 @@ void build_graphs(bsgpu_ctx* c, const bsgpu_options& o) {
   if (getenv("BSGPU_TIMING")) fprintf(stderr, "[bsgpu] LM step captured as hipGraphs\n");
 }
 
-void run_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius) {
+void run_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius, bool gradient_only = false) {
   if (c->use_graphs) {   // replayed kernels read the radius from device memory
     *c->h_radius = radius;
     (void)hipMemcpyAsync(c->d_scal + SC_RADIUS, c->h_radius, sizeof(double), hipMemcpyHostToDevice, c->stream);
   }
-  if (c->graphs_ok) {
+  if (c->graphs_ok && !gradient_only) {
     hipGraphExec_t g = kind == STEP_FIRST ? c->g_first : kind == STEP_ACCEPT ? c->g_accept : c->g_reject;
     if (hipGraphLaunch(g, c->stream) == hipSuccess) return;
     (void)hipGetLastError();
     c->graphs_ok = false;   // fall back to eager launches of the same kernels
   }
-  enqueue_step(c, o, kind, radius);
+  enqueue_step(c, o, kind, radius, gradient_only);
 }
 
 // sorted visual position -> source factor: built on the host, or downloaded on first use when the device flattened the window
@@ -1143,6 +1147,7 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
         }
         radius = radius / decrease_factor; decrease_factor *= 2.0;
         it.cost = x_cost + fixed; it.step_is_successful = 0;
+        if (it.iteration >= o.max_num_iterations) continue;   // the loop ends at its top: a step from here would never be looked at
         run_step(c, o, STEP_REJECT, radius);
         rc = fetch_scalars(c);
         if (rc != BSGPU_OK) return rc;
@@ -1157,17 +1162,20 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
       it.cost_change = x_cost - cand_cost;
       if (std::fabs(it.cost_change) <= o.function_tolerance * x_cost) { sum.termination_type = BSGPU_CONVERGENCE; msg = "Function tolerance reached."; break; }
       it.relative_decrease = (x_cost - cand_cost) / mcc;
+      const bool last_iteration = it.iteration >= o.max_num_iterations;
       if (it.relative_decrease > o.min_relative_decrease) {
         radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * it.relative_decrease - 1.0, 3));
         radius = std::min(o.max_trust_region_radius, radius);
         decrease_factor = 2.0;
         it.step_is_successful = 1;
-        // the next step is computed speculatively so that one synchronisation per iteration suffices
-        run_step(c, o, STEP_ACCEPT, radius);
+        // the next step is computed right away so that one synchronisation per iteration suffices; when this was the last
+        // iteration the budget allows, only the accepted point's cost and gradient are (a full step would be thrown away)
+        run_step(c, o, STEP_ACCEPT, radius, last_iteration);
       } else {
         it.step_is_successful = 0;
         radius = radius / decrease_factor; decrease_factor *= 2.0;
         it.cost = cand_cost + fixed;
+        if (last_iteration) continue;
         run_step(c, o, STEP_REJECT, radius);
       }
       rc = fetch_scalars(c);
