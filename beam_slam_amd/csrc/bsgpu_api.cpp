@@ -140,8 +140,11 @@ struct bsgpu_ctx {
   double* h_radius = nullptr;  // pinned
   double* h_pcg = nullptr;     // pinned: two read-backs of the PCG scalars in flight (pcg_solve)
   hipEvent_t pcg_ev[2] = {nullptr, nullptr};
+  hipEvent_t ev_reduce = nullptr;   // recorded after the end-of-step reduction: what the host waits for (work may be queued behind it)
+  bool ev_reduce_pending = false;
   // block-sparse PCG path
   bool dense_ok = true, bsr_built = false, use_pcg = false;
+  bool spec_J = false;   // residuals + Jacobians currently hold the CANDIDATE's (evaluated ahead of the accept/reject decision)
   int nbr = 0, nblk = 0, pcg_iters_total = 0;
   int *d_row_ptr = nullptr, *d_col = nullptr, *d_diag_slot = nullptr;
   int* d_slots[kNumInternal] = {nullptr};
@@ -894,6 +897,8 @@ void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot) {
 void final_reduce(bsgpu_ctx* c) {
   launch_final_reduce(c->stream, c->d_reduce, c->n_reduce, SC_X_NORM2 + 1, c->d_scal, c->h_scal_dev);
   c->scal_mirrored = c->h_scal_dev != nullptr && c->n_reduce > 0;
+  if (!c->ev_reduce && hipEventCreateWithFlags(&c->ev_reduce, hipEventDisableTiming) != hipSuccess) { c->ev_reduce = nullptr; (void)hipGetLastError(); }
+  c->ev_reduce_pending = c->scal_mirrored && c->ev_reduce && hipEventRecord(c->ev_reduce, c->stream) == hipSuccess;
 }
 
 void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, bool first) {
@@ -994,10 +999,21 @@ void enqueue_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius,
     if (c->use_graphs) launch_copy(s, c->d_xcand, c->d_x, (int64_t)c->h_x.size(), 0);
     else std::swap(c->d_x, c->d_xcand);
   }
-  if (kind != STEP_REJECT) eval_all(c, c->d_x, true, SC_COST_X);
+  // Jacobians at the current point: new for a first / accepted step — unless they were evaluated ahead at the candidate that has
+  // just been accepted (below) — and to be restored for a rejected one if that evaluation overwrote them
+  const bool have_J = (kind == STEP_ACCEPT && c->spec_J) || (kind == STEP_REJECT && !c->spec_J);
+  if (!have_J) eval_all(c, c->d_x, true, SC_COST_X);
+  c->spec_J = false;
   assemble(c, o, radius, kind != STEP_REJECT, kind == STEP_FIRST);
   if (gradient_only) { final_reduce(c); return; }
   linear_solve_and_candidate(c, o);
+  // The host now waits for this step's scalars and decides; in the common case (accepted) the next thing the device needs is the
+  // residuals and Jacobians at the candidate: evaluated ahead, underneath the host round trip (~26 us per iteration otherwise
+  // idle).  A rejected step pays for it with a re-evaluation at the current point (above).
+  if (!c->use_graphs) {
+    eval_all(c, c->d_xcand, true, SC_COST_X);
+    c->spec_J = true;
+  }
 }
 
 bool same_graph_options(const bsgpu_options& a, const bsgpu_options& b) {
@@ -1048,9 +1064,13 @@ int ensure_vis_src(bsgpu_ctx* c) {
 
 int fetch_scalars(bsgpu_ctx* c) {
   HIPCHK(c, hipGetLastError());  // a kernel that failed to launch must not pass silently
-  if (!c->scal_mirrored) HIPCHK(c, hipMemcpyAsync(c->h_scal, c->d_scal, sizeof(double) * SC_NUM, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->scal_mirrored = false;
+  if (c->scal_mirrored && c->ev_reduce_pending) {
+    HIPCHK(c, hipEventSynchronize(c->ev_reduce));   // the step's scalars are in the pinned mirror; kernels queued behind the reduction keep running
+  } else {
+    if (!c->scal_mirrored) HIPCHK(c, hipMemcpyAsync(c->h_scal, c->d_scal, sizeof(double) * SC_NUM, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  c->scal_mirrored = false; c->ev_reduce_pending = false;
   return BSGPU_OK;
 }
 
@@ -1195,6 +1215,7 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
   (void)hipEventElapsedTime(&ms, ev0, ev1);
   (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
   sum.device_time_in_seconds = ms * 1e-3;
+  c->scal_mirrored = false; c->ev_reduce_pending = false; c->spec_J = false;   // (the stream has drained: nothing of this solve is pending)
   sum.num_iterations = (int)c->iters.size() - 1;
   sum.num_inner_iterations = c->pcg_iters_total;
   sum.is_solution_usable = (sum.termination_type == BSGPU_CONVERGENCE || sum.termination_type == BSGPU_NO_CONVERGENCE) ? 1 : 0;
@@ -1257,6 +1278,7 @@ void bsgpu_destroy(bsgpu_ctx* c) {
   if (c->h_radius) (void)hipHostFree(c->h_radius);
   if (c->h_pcg) (void)hipHostFree(c->h_pcg);
   for (hipEvent_t e : c->pcg_ev) if (e) (void)hipEventDestroy(e);
+  if (c->ev_reduce) (void)hipEventDestroy(c->ev_reduce);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
