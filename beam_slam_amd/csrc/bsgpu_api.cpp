@@ -128,7 +128,7 @@ struct bsgpu_ctx {
   std::vector<uint8_t> tile_adj;   // natural-tile adjacency of the reduced system
   int *d_perm = nullptr, *d_iperm = nullptr, *d_nreal = nullptr, *d_rows_flat = nullptr;
   PanelDesc* d_panels = nullptr;
-  int *d_panel_of_tile = nullptr, *d_chain_begin = nullptr, *d_chain_end = nullptr;
+  int *d_panel_of_tile = nullptr, *d_chain_begin = nullptr, *d_chain_end = nullptr, *d_tile_sync = nullptr;
   double* d_Vinv = nullptr;
   double* d_Lp = nullptr;     // shadow of S holding the off-diagonal L panels (k_chol.hip)
   double* d_ytan = nullptr;   // y in tangent order
@@ -696,6 +696,7 @@ int finalize(bsgpu_ctx* c) {
     c->d_rows_flat = c->upload(c->plan.rows_flat);
     c->d_panels = c->upload(c->plan.panels);
     c->d_panel_of_tile = c->upload(c->plan.panel_of_tile);
+    c->d_tile_sync = c->upload(c->plan.tile_sync);
     c->d_chain_begin = c->upload(c->plan.chain_begin); c->d_chain_end = c->upload(c->plan.chain_end);
     c->d_Vinv = c->alloc<double>((size_t)std::max(1, T) * chol_vinv_stride());
     c->d_ytan = c->alloc<double>(std::max(1, c->n_pose));
@@ -930,13 +931,14 @@ struct DenseDev {
   const PanelDesc* panels;
   double *Lp, *Vinv;
   const int *panel_of_tile, *chain_begin, *chain_end;
+  int* tile_sync;   // [expected arrivals | arrival counters] per tile (dense_plan.h)
 };
 void dense_factor(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* scal) {
   const int ld = P.npad;
   for (int st = 0; st < P.n_steps(); ++st) {
     // (tiles no look-ahead factors are factored inside the panel step itself: PanelDesc::self_potrf)
     launch_chol_panel_step(s, S, D.Lp, ld, D.panels + P.step_off[st], P.step_off[st + 1] - P.step_off[st], P.step_maxrows[st],
-                           D.rows_flat, D.nreal, D.Vinv, scal, P.panels.data() + P.step_off[st], P.rows_flat.data());
+                           D.rows_flat, D.nreal, D.Vinv, scal, D.tile_sync, P.panels.data() + P.step_off[st], P.rows_flat.data());
   }
 }
 void dense_factor_solve(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* y, double* scal) {
@@ -964,7 +966,7 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
     launch_negate_pose(s, c->n_pose, c->d_px, c->d_delta);
   } else if (c->n_pose > 0) {
     const DenseDev D{c->d_perm, c->d_nreal, c->d_rows_flat, c->d_panels, c->d_Lp, c->d_Vinv,
-                     c->d_panel_of_tile, c->d_chain_begin, c->d_chain_end};
+                     c->d_panel_of_tile, c->d_chain_begin, c->d_chain_end, c->d_tile_sync};
     dense_factor_solve(s, c->plan, D, c->d_S, c->d_y, c->d_scal);
     launch_y_to_delta(s, c->n_pose, c->d_y, c->d_perm, c->d_ytan, c->d_delta);
   }
@@ -1724,7 +1726,7 @@ int bsgpu_covariance(bsgpu_ctx* c, int32_t ba, int32_t bb, double* out) try {
   (void)hipMemcpyAsync(d_cols, cols.data(), sizeof(int) * cols.size(), hipMemcpyHostToDevice, s);
   launch_cov_units(s, c->d_S, c->npad, c->plan.rhs_row, d_cols, (int)cols.size());
   const DenseDev D{c->d_perm, c->d_nreal, c->d_rows_flat, c->d_panels, c->d_Lp, c->d_Vinv,
-                   c->d_panel_of_tile, c->d_chain_begin, c->d_chain_end};
+                   c->d_panel_of_tile, c->d_chain_begin, c->d_chain_end, c->d_tile_sync};
   dense_factor(s, c->plan, D, c->d_S, c->d_scal);
   launch_cov_dots(s, c->d_Lp, c->npad, c->plan.rhs_row, c->plan.T * 64, ta, row_b0, tb, d_out);
   (void)hipMemcpyAsync(out, d_out, sizeof(double) * ta * tb, hipMemcpyDeviceToHost, s);
@@ -1900,7 +1902,7 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
   double *dS = nullptr, *dLp = nullptr, *dV = nullptr, *dy = nullptr, *dscal = nullptr;
   int *dperm = nullptr, *dnreal = nullptr, *drows = nullptr;
   PanelDesc *dpan = nullptr, *dsep = nullptr;
-  int *dpot2 = nullptr, *dcb = nullptr, *dce = nullptr;
+  int *dpot2 = nullptr, *dcb = nullptr, *dce = nullptr, *dsync = nullptr;
   hipStream_t s;
   if (hipStreamCreate(&s) != hipSuccess) return BSGPU_ERR_DEVICE;
   auto up = [](const void* src, size_t bytes, void** dst) {
@@ -1915,7 +1917,8 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
        up(rf.data(), sizeof(int) * rf.size(), (void**)&drows) &&
        up(P.panels.data(), sizeof(PanelDesc) * P.panels.size(), (void**)&dpan) &&
        up(P.panel_of_tile.data(), sizeof(int) * P.panel_of_tile.size(), (void**)&dpot2) &&
-       up(P.chain_begin.data(), sizeof(int) * P.chain_begin.size(), (void**)&dcb) && up(P.chain_end.data(), sizeof(int) * P.chain_end.size(), (void**)&dce);
+       up(P.chain_begin.data(), sizeof(int) * P.chain_begin.size(), (void**)&dcb) && up(P.chain_end.data(), sizeof(int) * P.chain_end.size(), (void**)&dce) &&
+       up(P.tile_sync.data(), sizeof(int) * P.tile_sync.size(), (void**)&dsync);
   int rc = BSGPU_OK;
   if (ok) {
     (void)hipMemcpy(dS, hS.data(), sizeof(double) * hS.size(), hipMemcpyHostToDevice);
@@ -1923,7 +1926,7 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, s);
-    const DenseDev D{dperm, dnreal, drows, dpan, dLp, dV, dpot2, dcb, dce};
+    const DenseDev D{dperm, dnreal, drows, dpan, dLp, dV, dpot2, dcb, dce, dsync};
     dense_factor_solve(s, P, D, dS, dy, dscal);
     (void)hipEventRecord(e1, s);
     if (hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess) rc = BSGPU_ERR_DEVICE;
@@ -1940,7 +1943,7 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
   } else rc = BSGPU_ERR_DEVICE;
   (void)hipFree(dS); (void)hipFree(dLp); (void)hipFree(dV); (void)hipFree(dy); (void)hipFree(dscal);
   (void)hipFree(dperm); (void)hipFree(dnreal); (void)hipFree(drows); (void)hipFree(dpan);
-  (void)hipFree(dsep); (void)hipFree(dpot2); (void)hipFree(dcb); (void)hipFree(dce);
+  (void)hipFree(dsep); (void)hipFree(dpot2); (void)hipFree(dcb); (void)hipFree(dce); (void)hipFree(dsync);
   (void)hipStreamDestroy(s);
   return rc;
 } catch (...) { return api_exception(nullptr); }

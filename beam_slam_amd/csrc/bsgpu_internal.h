@@ -148,7 +148,7 @@ struct PanelDesc;
 void launch_chol_potrf_tiles(hipStream_t s, double* S, double* Lp, int ld, const int* tiles_dev, int n_tiles, const int* nreal_dev,
                              double* Vinv, double* scal);
 void launch_chol_panel_step(hipStream_t s, double* S, double* Lp, int ld, const PanelDesc* descs_dev, int n_panels, int max_rows,
-                            const int* rows_flat_dev, const int* nreal_dev, double* Vinv, double* scal,
+                            const int* rows_flat_dev, const int* nreal_dev, double* Vinv, double* scal, int* tile_sync_dev,
                             const PanelDesc* descs_host = nullptr, const int* rows_flat_host = nullptr);
 void launch_chol_backsolve_chains(hipStream_t s, const double* S, const double* Lp, const double* Vinv, int ld,
                                   const PanelDesc* panels_dev, const int* panel_of_tile_dev, const int* chain_begin_dev,

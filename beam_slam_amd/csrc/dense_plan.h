@@ -18,8 +18,9 @@ struct PanelDesc {  // device-visible
   int k;          // S tile index of the panel (diagonal tile k)
   int row_off;    // into the flat row-tile list
   int n_rows;     // active row tiles below the diagonal (S tile indices, ascending)
-  int lookahead;  // the workgroup updating tile (k+1,k+1) also factors it
-  int self_potrf;   // tile (k,k) is not factored by a look-ahead: the panel's workgroups factor it themselves
+  int final_mask; // bit q (q < 31): row tile q receives its LAST update in this step; the diagonal workgroup (q, q) of the panel that
+                  // arrives last among that tile's updaters of the step (tile_sync) factors it right there (look-ahead)
+  int self_potrf;   // tile (k,k) is not factored by a look-ahead (it is never updated: the head of a piece): the panel's workgroups do it
   int shared_mask;  // bit q: row tile q of this panel is also a row tile of another panel of the same step, so tiles
                     // (i, j) with both bits set are accumulated with atomics (two panels update them concurrently)
 };
@@ -28,6 +29,7 @@ struct DensePlan {
   int n_pose = 0, T = 0 /* real tiles */, npad = 0, rhs_row = 0;
   std::vector<int> perm;       // natural tile -> S tile
   std::vector<int> nreal;      // per S tile: number of real columns (64, or n_pose % 64 for the partial tile)
+  std::vector<int> tile_sync;  // device image, 2 x (T + 1): [expected arrivals per tile | arrival counters (zero; the last arriver resets its own)]
   std::vector<int> rows_flat;  // row tiles of every panel (includes the rhs tile T)
   std::vector<PanelDesc> panels;        // in schedule order
   std::vector<int> step_off;            // panels[step_off[s] .. step_off[s+1]) run in one launch
@@ -136,28 +138,33 @@ struct DensePlan {
       steps[s].push_back(k);
       for (int t : rows[k]) if (t < T) { if (step_rows[s][t] < 255) step_rows[s][t]++; ready[t] = std::max(ready[t], s + 1); }
     }
-    // look-ahead: panel j may factor tile j+1 iff j+1 is its first row tile and no panel scheduled in the same
-    // or a later step also updates tile j+1
+    // look-ahead: a tile is final once the last step that updates it has run.  Every panel of that step which has the tile
+    // as a row updates its diagonal block from its diagonal workgroup; the one that arrives last (a counter per tile, or
+    // trivially the only one) factors the tile on the spot, so that the step that uses it as a panel starts from the factor.
     std::vector<int> last_updater_step(N, -1), n_updaters_in_last(N, 0);
     for (int k = 0; k < T; ++k) for (int t : rows[k]) {
       if (step_of[k] > last_updater_step[t]) { last_updater_step[t] = step_of[k]; n_updaters_in_last[t] = 1; }
       else if (step_of[k] == last_updater_step[t]) n_updaters_in_last[t]++;
     }
+    std::vector<uint8_t> arrival_ok(N, 1);   // every updater of the tile's last step can name it in its 31-bit mask
+    for (int k = 0; k < T; ++k)
+      for (size_t q = 0; q < rows[k].size(); ++q) if (step_of[k] == last_updater_step[rows[k][q]] && q >= 31) arrival_ok[rows[k][q]] = 0;
     std::vector<uint8_t> factored_by_lookahead(T, 0);
+    tile_sync.assign(2 * (size_t)N, 0);
+    for (int t = 0; t < T; ++t) if (last_updater_step[t] >= 0 && arrival_ok[t]) { factored_by_lookahead[t] = 1; tile_sync[t] = n_updaters_in_last[t]; }
     panels.clear(); rows_flat.clear(); step_off.assign(1, 0); step_maxrows.clear();
     for (size_t s = 0; s < steps.size(); ++s) {
       int mr = 0;
       for (int k : steps[s]) {
         PanelDesc d;
         d.k = k; d.row_off = (int)rows_flat.size(); d.n_rows = (int)rows[k].size();
-        const int t = k + 1;
-        d.lookahead = (t < T && !rows[k].empty() && rows[k][0] == t && last_updater_step[t] == (int)s && n_updaters_in_last[t] == 1) ? 1 : 0;
+        d.final_mask = 0;
         d.shared_mask = 0;
         for (size_t q = 0; q < rows[k].size(); ++q) {   // bits 0..30 exact, bit 31 = any later row (conservative)
           const int rt = rows[k][q];
           if ((rt < T && step_rows[s][rt] > 1) || (rt == T && steps[s].size() > 1 && allow_shared)) d.shared_mask |= (int)(1u << (q < 31 ? q : 31));
+          if (rt < T && q < 31 && factored_by_lookahead[rt] && last_updater_step[rt] == (int)s) d.final_mask |= (int)(1u << q);
         }
-        if (d.lookahead) factored_by_lookahead[t] = 1;
         rows_flat.insert(rows_flat.end(), rows[k].begin(), rows[k].end());
         mr = std::max(mr, d.n_rows);
         panels.push_back(d);

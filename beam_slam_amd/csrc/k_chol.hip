@@ -259,7 +259,7 @@ BSG_DEV void trsm_tile(double* sA, const double* sL, const double* sV, double* s
 // arguments instead of costing two dependent round trips to memory before the first tile load can be issued
 constexpr int kStepMaxPanels = 16, kStepMaxRows = 16;
 struct StepArgs {
-  int k[kStepMaxPanels], n_rows[kStepMaxPanels], lookahead[kStepMaxPanels], shared_mask[kStepMaxPanels], self_potrf[kStepMaxPanels];
+  int k[kStepMaxPanels], n_rows[kStepMaxPanels], final_mask[kStepMaxPanels], shared_mask[kStepMaxPanels], self_potrf[kStepMaxPanels];
   int rows[kStepMaxPanels][kStepMaxRows];
 };
 
@@ -267,20 +267,20 @@ template <bool KARG, bool PROBE = false>
 __global__ __launch_bounds__(256) void chol_panel_step_kernel(double* __restrict__ S, double* __restrict__ Lp, int ld,
                                                               const PanelDesc* __restrict__ descs,
                                                               const int* __restrict__ rows_flat, const int* __restrict__ nreal,
-                                                              double* __restrict__ Vinv, double* __restrict__ scal, StepArgs args,
+                                                              double* __restrict__ Vinv, double* __restrict__ scal, int* tile_sync, StepArgs args,
                                                               long long* probe_ts = nullptr) {
   const int bi = blockIdx.y, bj = blockIdx.x, z = blockIdx.z;
   int nts = 0;   // PROBE: wall-clock stamps of workgroup (0,0) for scripts/potrf_probe.hip
   auto stamp = [&]() { if (PROBE && bi == 0 && bj == 0 && threadIdx.x == 0) probe_ts[nts++] = wall_clock64(); };
   stamp();
-  int k, n_rows, lookahead, ti, tj, shared_mask, self_potrf;
+  int k, n_rows, final_mask, ti, tj, shared_mask, self_potrf;
   if (KARG) {
-    k = args.k[z]; n_rows = args.n_rows[z]; lookahead = args.lookahead[z]; shared_mask = args.shared_mask[z]; self_potrf = args.self_potrf[z];
+    k = args.k[z]; n_rows = args.n_rows[z]; final_mask = args.final_mask[z]; shared_mask = args.shared_mask[z]; self_potrf = args.self_potrf[z];
     if (bi >= n_rows || bj > bi) return;
     ti = args.rows[z][bi]; tj = args.rows[z][bj];
   } else {
     const PanelDesc pd = descs[z];
-    k = pd.k; n_rows = pd.n_rows; lookahead = pd.lookahead; shared_mask = pd.shared_mask; self_potrf = pd.self_potrf;
+    k = pd.k; n_rows = pd.n_rows; final_mask = pd.final_mask; shared_mask = pd.shared_mask; self_potrf = pd.self_potrf;
     if (bi >= n_rows || bj > bi) return;
     ti = rows_flat[pd.row_off + bi]; tj = rows_flat[pd.row_off + bj];
   }
@@ -347,8 +347,13 @@ __global__ __launch_bounds__(256) void chol_panel_step_kernel(double* __restrict
   for (int t = 0; t < 4; ++t)
     acc[t] = mfma_abt<64>(acc[t], sXi + (16 * wave) * LDT, LDT, Xj + (16 * t) * LDT, LDT, -1.0, lane);
   stamp();
-  const bool factor_next = diag && lookahead && ti == k + 1;
-  if (!factor_next) {
+  // Tile (ti, ti) receives its last update in this step (dense_plan.h: final_mask): whoever completes it factors it here, so
+  // that the step using it as a panel starts from the factor.  A sole updater does so from its registers; with several
+  // updaters (atomics) the one that arrives last does, from memory.
+  const bool final_tile = diag && bi < 31 && ((final_mask >> bi) & 1);
+  const int n_expect = final_tile ? tile_sync[ti] : 0;
+  const bool factor_regs = final_tile && n_expect == 1;
+  if (!factor_regs) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -367,13 +372,35 @@ __global__ __launch_bounds__(256) void chol_panel_step_kernel(double* __restrict
       *reinterpret_cast<double2*>(&Lp[(size_t)(ri + r) * ld + c0 + c2]) = *reinterpret_cast<const double2*>(&sXi[r * LDT + c2]);
     }
   }
-  if (factor_next) {
-    // look-ahead: tile (k+1, k+1) is final now — factor it here instead of in a launch of its own
-    // (this is a diagonal workgroup: sXj is free.  The strictly upper part of the tile is never read by the
-    //  factorisation, so it is left as the update produced it.)
-    double* sC = sXj;
+  bool factor_now = factor_regs;
+  double* sC = sXj;   // (a diagonal workgroup: sXj is free)
+  if (final_tile && n_expect > 1) {
+    // arrival: every thread's atomics device-visible, then one count per workgroup; the last one resets the counter for the
+    // next factorisation and reads the finished tile past its (possibly stale) L2 lines
+    __shared__ int s_last;
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+      int* arrive = tile_sync + (ld / NB) + ti;
+      const int last = atomicAdd(arrive, 1) == n_expect - 1;
+      if (last) atomicExch(arrive, 0);
+      s_last = last;
+    }
+    __syncthreads();
+    if (s_last) {
+      __threadfence();
+      for (int i = tid; i < NB * NB; i += 256) {
+        const int r = i >> 6, cc = i & 63;
+        sC[r * LDT + cc] = (cc <= r) ? __hip_atomic_load(&S[(size_t)(ri + r) * ld + ri + cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      }
+      factor_now = true;
+    }
+  } else if (factor_regs) {
+    // (the strictly upper part of the tile is never read by the factorisation, so it is left as the update produced it)
 #pragma unroll
     for (int t = 0; t < 4; ++t) store_d(sC + (16 * wave) * LDT + 16 * t, LDT, lane, acc[t]);
+  }
+  if (factor_now) {
     __syncthreads();
     if (nreal[ti] < NB) { mask_unreal_columns(sC, nreal[ti], tid); __syncthreads(); }
     stamp();
@@ -393,22 +420,22 @@ void launch_chol_potrf_tiles(hipStream_t s, double* S, double* Lp, int ld, const
   hipLaunchKernelGGL(chol_potrf_tiles_kernel, dim3(n_tiles), dim3(256), 0, s, S, Lp, ld, tiles_dev, nreal_dev, Vinv, scal);
 }
 void launch_chol_panel_step(hipStream_t s, double* S, double* Lp, int ld, const PanelDesc* descs_dev, int n_panels, int max_rows,
-                            const int* rows_flat_dev, const int* nreal_dev, double* Vinv, double* scal, const PanelDesc* descs_host,
-                            const int* rows_flat_host) {
+                            const int* rows_flat_dev, const int* nreal_dev, double* Vinv, double* scal, int* tile_sync_dev,
+                            const PanelDesc* descs_host, const int* rows_flat_host) {
   if (n_panels <= 0 || max_rows <= 0) return;
   StepArgs a;
   std::memset(&a, 0, sizeof(a));
   if (descs_host && rows_flat_host && n_panels <= kStepMaxPanels && max_rows <= kStepMaxRows) {
     for (int p = 0; p < n_panels; ++p) {
-      a.k[p] = descs_host[p].k; a.n_rows[p] = descs_host[p].n_rows; a.lookahead[p] = descs_host[p].lookahead;
+      a.k[p] = descs_host[p].k; a.n_rows[p] = descs_host[p].n_rows; a.final_mask[p] = descs_host[p].final_mask;
       a.shared_mask[p] = descs_host[p].shared_mask; a.self_potrf[p] = descs_host[p].self_potrf;
       for (int q = 0; q < descs_host[p].n_rows; ++q) a.rows[p][q] = rows_flat_host[descs_host[p].row_off + q];
     }
     hipLaunchKernelGGL(chol_panel_step_kernel<true>, dim3(max_rows, max_rows, n_panels), dim3(256), kPanelStepLds, s, S, Lp, ld, descs_dev,
-                       rows_flat_dev, nreal_dev, Vinv, scal, a);
+                       rows_flat_dev, nreal_dev, Vinv, scal, tile_sync_dev, a);
   } else {
     hipLaunchKernelGGL(chol_panel_step_kernel<false>, dim3(max_rows, max_rows, n_panels), dim3(256), kPanelStepLds, s, S, Lp, ld, descs_dev,
-                       rows_flat_dev, nreal_dev, Vinv, scal, a);
+                       rows_flat_dev, nreal_dev, Vinv, scal, tile_sync_dev, a);
   }
 }
 

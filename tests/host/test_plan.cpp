@@ -82,7 +82,8 @@ static bool run_case(int n_pose, int band_tiles, int max_chains, int min_piece, 
         for (int i = 0; i < 64; ++i) for (int j = 0; j < 64; ++j) { double s = 0; for (int k = 0; k < 64; ++k) s += X[qi][i * 64 + k] * X[qj][j * 64 + k]; u.d[i * 64 + j] = -s; }
         upds.push_back(std::move(u));
       }
-      if (pd.lookahead) { CHECK(pd.n_rows > 0 && P.rows_flat[pd.row_off] == pd.k + 1); lookahead_tiles.push_back(pd.k + 1); }
+      for (int q = 0; q < pd.n_rows && q < 31; ++q)   // tiles that receive their last update in this step: one arrival per panel that has them
+        if ((pd.final_mask >> q) & 1) { const int t = P.rows_flat[pd.row_off + q]; CHECK(t < P.T); lookahead_tiles.push_back(t); }
     }
     // a tile written by more than one panel of this step must be flagged shared by all of them (else the device loses an update)
     std::vector<int> writers((size_t)NT * NT, 0), nonshared((size_t)NT * NT, 0);
@@ -92,7 +93,19 @@ static bool run_case(int n_pose, int band_tiles, int max_chains, int min_piece, 
       if (u.ti == P.T && u.tj == P.T) continue;   // the rhs tile's own diagonal is never used
       for (int i = 0; i < 64; ++i) for (int j = 0; j < 64; ++j) S(u.ti * 64 + i, u.tj * 64 + j) += u.d[i * 64 + j];
     }
-    for (int t : lookahead_tiles) { CHECK(writers[(size_t)t * NT + t] == 1); potrf_tile(t); }
+    // the last arriver factors the tile: the arrivals of the step must be exactly what the device waits for (tile_sync), the
+    // tile must never be updated again, and every updater must have announced it
+    std::sort(lookahead_tiles.begin(), lookahead_tiles.end());
+    for (size_t i = 0; i < lookahead_tiles.size();) {
+      const int t = lookahead_tiles[i];
+      size_t j = i;
+      while (j < lookahead_tiles.size() && lookahead_tiles[j] == t) ++j;
+      CHECK((int)(j - i) == P.tile_sync[t]);
+      CHECK(writers[(size_t)t * NT + t] == (int)(j - i));
+      CHECK(P.tile_sync[(size_t)(P.T + 1) + t] == 0);
+      potrf_tile(t);
+      i = j;
+    }
   }
   for (int t = 0; t < P.T; ++t) CHECK(factored[t] == 1);
   // back-substitution following the plan: separators step by step, then the pieces
