@@ -79,7 +79,7 @@ struct bsgpu_ctx {
   int nb = 0;
   std::vector<double> h_x;
   std::vector<int32_t> off;
-  std::vector<uint8_t> size, manifold, is_const;
+  std::vector<uint8_t> size, manifold, is_const, is_const_in;   // is_const_in: as given; is_const: + blocks no factor touches
   std::vector<bsgpu_camera> cams;
   HostGroup groups[kNumInternal];
   bool finalized = false;
@@ -158,12 +158,16 @@ struct bsgpu_ctx {
     if (n == 0) n = 1;
     const size_t bytes = (n * sizeof(T) + 255) & ~(size_t)255;
     auto it = pool.lower_bound(bytes);
-    if (it != pool.end() && it->first <= bytes + bytes / 4 + 4096) { p = it->second; pool_bytes -= it->first; const size_t got = it->first; pool.erase(it); allocs.push_back({p, got}); return static_cast<T*>(p); }
-    if (hipMalloc(&p, bytes) != hipSuccess) {
-      release_pool();   // give cached buffers back and retry once
-      if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    if (it != pool.end() && it->first <= bytes + bytes / 2 + 4096) { p = it->second; pool_bytes -= it->first; const size_t got = it->first; pool.erase(it); allocs.push_back({p, got}); return static_cast<T*>(p); }
+    // a window that slides grows and shrinks by a fraction of a percent per cycle: headroom on the larger buffers, so that the
+    // next cycle's slightly larger request finds this one in the pool instead of going to hipMalloc again (HBM is not scarce)
+    size_t want = bytes > ((size_t)64 << 10) ? ((bytes + bytes / 8 + 255) & ~(size_t)255) : bytes;
+    if (hipMalloc(&p, want) != hipSuccess) {
+      release_pool();   // give cached buffers back and retry once, without the headroom
+      want = bytes;
+      if (hipMalloc(&p, want) != hipSuccess) return nullptr;
     }
-    allocs.push_back({p, bytes});
+    allocs.push_back({p, want});
     return static_cast<T*>(p);
   }
   void release_pool() {
@@ -265,6 +269,10 @@ int finalize(bsgpu_ctx* c) {
       if (b < 0 || b >= nb) return fail(c, BSGPU_ERR_INVALID, "marginal factor references block out of range");
       other_use[b]++;
     }
+  // a parameter block no residual block touches is not part of the problem ([EXT] Ceres drops unused parameter blocks from the
+  // reduced program; fuse's graph keeps e.g. landmarks whose last observation left the window): treated like a constant block
+  if (c->is_const_in.size() != (size_t)nb) c->is_const_in = c->is_const;
+  for (int b = 0; b < nb; ++b) c->is_const[b] = (c->is_const_in[b] || lm_use[b] + other_use[b] == 0) ? 1 : 0;
   c->tsize.assign(nb, 0); c->toff.assign(nb, -1); c->is_lm.assign(nb, 0);
   for (int b = 0; b < nb; ++b) {
     if (c->size[b] > 4 || c->size[b] == 0) return fail(c, BSGPU_ERR_UNSUPPORTED, "block sizes 1..4 only");
@@ -1288,7 +1296,7 @@ const char* bsgpu_last_error(const bsgpu_ctx* c) { return c ? c->err.c_str() : "
 
 int bsgpu_clear(bsgpu_ctx* c) try {
   if (!c) return BSGPU_ERR_INVALID;
-  c->nb = 0; c->h_x.clear(); c->off.clear(); c->size.clear(); c->manifold.clear(); c->is_const.clear();
+  c->nb = 0; c->h_x.clear(); c->off.clear(); c->size.clear(); c->manifold.clear(); c->is_const.clear(); c->is_const_in.clear();
   c->cams.clear();
   for (auto& g : c->groups) { g.n = 0; g.idx.clear(); g.consts.clear(); g.loss_kind.clear(); g.loss_a.clear(); }   // (capacity kept: a window is re-described every cycle)
   c->marginals.clear();
@@ -1303,7 +1311,7 @@ int bsgpu_set_blocks(bsgpu_ctx* c, int32_t n, const double* values, const int32_
   if (n <= 0 || !values || !offset || !size || !manifold || !is_const) return fail(c, BSGPU_ERR_INVALID, "set_blocks: null/empty argument");
   c->nb = n;
   c->off.assign(offset, offset + n); c->size.assign(size, size + n);
-  c->manifold.assign(manifold, manifold + n); c->is_const.assign(is_const, is_const + n);
+  c->manifold.assign(manifold, manifold + n); c->is_const.assign(is_const, is_const + n); c->is_const_in = c->is_const;
   size_t tot = 0;
   for (int i = 0; i < n; ++i) { if (offset[i] < 0) return fail(c, BSGPU_ERR_INVALID, "negative block offset"); tot = std::max(tot, (size_t)offset[i] + size[i]); }
   c->h_x.assign(values, values + tot);

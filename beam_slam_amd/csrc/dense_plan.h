@@ -56,8 +56,19 @@ struct DensePlan {
     rhs_row = T * 64;
     // ---- ordering: nested dissection of a banded chain
     perm.assign(T, 0);
+    // band width used to cut the chain into pieces and separators: the distance below which 95 % of the coupled tile pairs lie,
+    // not the maximum — one long feature track or a loop closure couples two far-apart keyframes, and sizing the separators
+    // for it would leave a single piece (a serial chain of T panels).  The symbolic factorisation below is exact for ANY
+    // ordering, so couplings wider than w only add their own fill and dependencies where they occur.
     int w = 0;
-    for (int i = 0; i < T; ++i) for (int j = 0; j < i; ++j) if (adj[(size_t)i * T + j]) w = std::max(w, i - j);
+    {
+      std::vector<int> dist;
+      for (int i = 0; i < T; ++i) for (int j = 0; j < i; ++j) if (adj[(size_t)i * T + j]) dist.push_back(i - j);
+      if (!dist.empty()) {
+        std::sort(dist.begin(), dist.end());
+        w = dist[std::min(dist.size() - 1, (size_t)(0.95 * (double)dist.size()))];
+      }
+    }
     std::vector<int> order;  // S order: list of natural tiles
     std::vector<std::pair<int, int>> piece_ranges;                    // S tile ranges of the pieces
     std::vector<std::vector<std::pair<int, int>>> sep_ranges_by_level;  // S tile ranges of the separators, per level

@@ -101,7 +101,7 @@ struct Ctx {
   int nb = 0;
   std::vector<double> x, x0;
   std::vector<int32_t> off;
-  std::vector<uint8_t> size, manifold, is_const;
+  std::vector<uint8_t> size, manifold, is_const, is_const_in;   // is_const_in: as given; is_const: + blocks no factor touches
   std::vector<int> tsize, toff;
   std::vector<uint8_t> is_lm;
   std::vector<int> pose_blocks, lm_blocks;  // in tangent order
@@ -479,6 +479,10 @@ static int finalize(Ctx& c) {
       if (b < 0 || b >= c.nb) { c.err = "marginal factor references block out of range"; return BSGPU_ERR_INVALID; }
       other_use[b]++;
     }
+  // a parameter block no residual block touches is not part of the problem ([EXT] Ceres drops unused parameter blocks from the
+  // reduced program; fuse's graph keeps e.g. landmarks whose last observation left the window): treated like a constant block
+  if (c.is_const_in.size() != (size_t)c.nb) c.is_const_in = c.is_const;
+  for (int b = 0; b < c.nb; ++b) c.is_const[b] = (c.is_const_in[b] || lm_use[b] + other_use[b] == 0) ? 1 : 0;
   c.tsize.assign(c.nb, 0); c.toff.assign(c.nb, -1); c.is_lm.assign(c.nb, 0);
   c.pose_blocks.clear(); c.lm_blocks.clear();
   for (int b = 0; b < c.nb; ++b) {
@@ -1164,7 +1168,7 @@ int bso_set_blocks(Ctx* c, int32_t n, const double* values, const int32_t* offse
                    const uint8_t* manifold, const uint8_t* is_const) {
   c->nb = n;
   c->off.assign(offset, offset + n); c->size.assign(size, size + n);
-  c->manifold.assign(manifold, manifold + n); c->is_const.assign(is_const, is_const + n);
+  c->manifold.assign(manifold, manifold + n); c->is_const.assign(is_const, is_const + n); c->is_const_in = c->is_const;
   size_t tot = 0;
   for (int i = 0; i < n; ++i) tot = std::max(tot, (size_t)offset[i] + size[i]);
   c->x.assign(values, values + tot); c->x0 = c->x;

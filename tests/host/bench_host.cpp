@@ -34,12 +34,14 @@ int main(int argc, char** argv) {
     graph.addConstraint(std::make_shared<fuse_constraints::RelativePose3DStampedConstraint>("odom", st[k].Position(), st[k].Orientation(), st[k + 1].Position(),
                                                                                           st[k + 1].Orientation(), bs_constraints::Vector7d{0.1, 0, 0, 1, 0, 0, 0}, c6));
   size_t n_obs = 0;
+  std::vector<int> lm_last_kf(n_lm, 0);
   for (int j = 0; j < n_lm; ++j) {
     const int len = 4 + (int)(U(rng) * 9), k0 = (int)(U(rng) * (n_kf - len));
     const double z = 4.0 + 8.0 * U(rng), x0 = 0.1 * k0 + (U(rng) - 0.3) * 0.8 * z, y = (U(rng) - 0.5) * 0.6 * z;
     auto lm = bs_variables::Point3DLandmark::make_shared(j);
     lm->x() = x0 + 0.05 * N(rng); lm->y() = y + 0.05 * N(rng); lm->z() = z + 0.05 * N(rng);
     graph.addVariable(lm);
+    lm_last_kf[j] = k0 + len - 1;
     for (int k = k0; k < k0 + len; ++k) {
       const double px = x0 - 0.1 * k, u = K(0, 0) * px / z + K(0, 2), v = K(1, 1) * y / z + K(1, 2);
       auto c = std::make_shared<bs_constraints::EuclideanReprojectionConstraint>("vo", st[k].Orientation(), st[k].Position(), *lm, T, K,
@@ -54,8 +56,8 @@ int main(int argc, char** argv) {
   auto opts = ceres_compat::SolverOptions::Vio();
   opts.max_solver_time_in_seconds = 1e9;
   bs_optimizers::GpuGraph::UniquePtr snapshot;   // what the publishers hold: the previous cycle's clone stays alive across the next update
-  std::vector<uint64_t> recent_lm;
-  for (int j = n_lm - 3000; j < n_lm; ++j) recent_lm.push_back(j);
+  std::vector<uint64_t> recent_lm;   // landmarks the newest keyframes see: the ones a new keyframe can still observe
+  for (size_t j = 0; j < lm_last_kf.size(); ++j) if (lm_last_kf[j] >= n_kf - 4) recent_lm.push_back(j);
   uint64_t next_lm = n_lm;
   int oldest = 0;
   for (int rep = 0; rep < 6; ++rep) {
@@ -98,7 +100,7 @@ int main(int argc, char** argv) {
       recent_lm.push_back(lm->id());
     }
     for (int j = 0; j < 1000; ++j) {
-      const uint64_t id = recent_lm[recent_lm.size() - 1 - (size_t)(U(rng) * 2500)];
+      const uint64_t id = recent_lm[recent_lm.size() - 1 - (size_t)(U(rng) * std::min<size_t>(2500, recent_lm.size()))];
       const auto& lm = static_cast<const bs_variables::Point3DLandmark&>(graph.variableExists(bs_variables::Point3DLandmark(id).uuid())
                                                                          ? graph.getVariable(bs_variables::Point3DLandmark(id).uuid())
                                                                          : *tr.addedVariables()[5 + (id - (next_lm - 250))]);

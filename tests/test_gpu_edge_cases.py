@@ -36,6 +36,40 @@ def test_blocks_without_factors_is_an_error_free_noop(oracle_cls, gpu_solver_cls
     assert np.array_equal(g.get_blocks(), pr.values)
 
 
+def test_blocks_no_factor_touches_are_left_out_of_the_problem(oracle_cls, gpu_solver_cls):
+    """A sliding window leaves variables behind that no constraint touches any more — landmarks whose last observation was
+    marginalised, states of sensor models that are switched off.  [EXT] Ceres drops such parameter blocks from the reduced
+    program; here they get no tangent columns (like constant blocks), keep their values, and neither make the covariance
+    singular nor cost tiles of the reduced system."""
+    pr = synthetic.vio_window(n_kf=6, n_lm=40, seed=9)
+    n0 = pr.n_blocks
+    orphan_lm = [pr.add_block([50.0 + i, -3.0, 7.0]) for i in range(5)]          # landmark-shaped blocks without observations
+    orphan_q = pr.add_quat([0.5, 0.5, 0.5, 0.5])                                 # an unused pose
+    g, o = _both(pr, oracle_cls, gpu_solver_cls)
+    g.finalize(); o.finalize()
+    offs = [g.tangent_offset(b) for b in range(pr.n_blocks)]
+    assert offs == [o.tangent_offset(b) for b in range(pr.n_blocks)]
+    assert all(offs[b] == -1 for b in orphan_lm + [orphan_q]) and g.num_parameters_tangent() == o.num_parameters_tangent()
+    ref = synthetic.vio_window(n_kf=6, n_lm=40, seed=9)                          # the same window without the orphans
+    r = gpu_solver_cls(0)
+    ref.load(r)
+    r.finalize()
+    assert g.num_parameters_tangent() == r.num_parameters_tangent()
+    sg, so = _same_solve(g, o)
+    sr = r.solve()
+    assert sg.num_iterations == sr.num_iterations and abs(sg.final_cost - sr.final_cost) <= 1e-12 * sr.final_cost
+    x = g.get_blocks()
+    for b in orphan_lm + [orphan_q]:
+        assert np.array_equal(pr.block(b, x), pr.block(b))                        # untouched
+    assert np.abs(x[:ref.values.size] - r.get_blocks()).max() <= 1e-12
+    kf = pr.meta["kf_blocks"]
+    cg, co = g.covariance(int(kf[2, 1]), int(kf[3, 1])), o.covariance(int(kf[2, 1]), int(kf[3, 1]))
+    assert np.all(np.isfinite(cg)) and np.abs(cg - co).max() <= 1e-6 * np.abs(co).max()
+    with pytest.raises(capi.SolverError):
+        g.covariance(orphan_lm[0], orphan_lm[0])                                  # not part of the problem
+    assert n0 + 6 == pr.n_blocks
+
+
 def test_no_blocks_at_all_is_rejected(gpu_solver_cls):
     g = gpu_solver_cls(0)
     with pytest.raises(capi.SolverError) as e:
