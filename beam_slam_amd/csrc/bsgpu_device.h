@@ -115,6 +115,23 @@ BSG_DEV double wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// 64 wave-wide sums at once: on entry every lane holds its own v[0..63]; on exit lane l holds in v[0] the sum over all lanes of
+// v[l].  Each butterfly step exchanges the half of the values the lane does not keep, so the whole reduction costs 63
+// exchange-adds per lane instead of 64 x 6 for 64 separate wave_sum()s — and pairs the lanes exactly as wave_sum() does
+// (l with l ^ 32, then ^ 16, ...), i.e. it produces the same bits.
+BSG_DEV void wave_sum_transpose64(double (&v)[64]) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 32, h = 32; o > 0; o >>= 1, h >>= 1) {
+    const bool upper = (lane & o) != 0;
+#pragma unroll
+    for (int i = 0; i < h; ++i) {
+      const double lo = v[i], hi = v[i + h];
+      const double recv = __shfl_xor(upper ? lo : hi, o, 64);
+      v[i] = (upper ? hi : lo) + recv;
+    }
+  }
+}
 // sum over a 256-thread block; result valid in thread 0
 BSG_DEV double block_sum_256(double v, double* smem /* >= 4 doubles */) {
   v = wave_sum(v);

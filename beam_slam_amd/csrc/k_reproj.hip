@@ -299,7 +299,6 @@ __global__ __launch_bounds__(64) void pairs_kernel(int n_seg, const int* __restr
                                                    const int* __restrict__ cp_tp, double* __restrict__ S, int ld,
                                                    int rhs_row, double* __restrict__ grad,
                                                    double* __restrict__ hdiag, const int* __restrict__ perm) {
-  __shared__ double sb[64];
   // XCD-aware mapping: consecutive workgroup ids go round-robin over the 8 XCDs, each with its own L2.  Segments are
   // ordered by camera pair (ca, cb), and all segments of one ca gather the same J / CR rows, so every XCD takes a
   // CONTIGUOUS range of segments: the rows of a camera are then pulled into one L2 instead of eight.
@@ -359,37 +358,34 @@ __global__ __launch_bounds__(64) void pairs_kernel(int n_seg, const int* __restr
       }
     }
   }
+  // all 54 sums in one transposed butterfly: lane l ends up with the total of value l (0..35 the block, 36.. the three 6-vectors
+  // of a diagonal segment) — the same bits as 54 separate wave_sum()s at a sixth of the exchanges, and no LDS round trip
+  double v[64];
 #pragma unroll
-  for (int i = 0; i < 36; ++i) blk[i] = wave_sum(blk[i]);
-  if (diag) {
+  for (int i = 0; i < 36; ++i) v[i] = blk[i];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { gr[i] = wave_sum(gr[i]); gg[i] = wave_sum(gg[i]); hd[i] = wave_sum(hd[i]); }
-  }
-  if (lane == 0) {
+  for (int i = 0; i < 6; ++i) { v[36 + i] = gr[i]; v[42 + i] = gg[i]; v[48 + i] = hd[i]; }
 #pragma unroll
-    for (int i = 0; i < 36; ++i) sb[i] = blk[i];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) { sb[36 + i] = gr[i]; sb[42 + i] = gg[i]; sb[48 + i] = hd[i]; }
-  }
-  __syncthreads();
+  for (int i = 54; i < 64; ++i) v[i] = 0.0;
+  wave_sum_transpose64(v);
+  const double total = v[0];
   const int tqi = cp_tq[ci], tpi = cp_tp[ci], tqj = cp_tq[cj], tpj = cp_tp[cj];
   if (lane < 36) {
     const int a = lane / 6, c = lane % 6;
     const int row = (a < 3) ? (tqi < 0 ? -1 : tqi + a) : (tpi < 0 ? -1 : tpi + a - 3);
     const int col = (c < 3) ? (tqj < 0 ? -1 : tqj + c) : (tpj < 0 ? -1 : tpj + c - 3);
     if (row >= 0 && col >= 0) {
-      const double val = sb[lane];
       const int sr = perm[row >> 6] * 64 + (row & 63), sc = perm[col >> 6] * 64 + (col & 63);   // solver positions
-      atomicAdd(&S[(size_t)sr * ld + sc], val);
-      if (!diag) atomicAdd(&S[(size_t)sc * ld + sr], val);
+      atomicAdd(&S[(size_t)sr * ld + sc], total);
+      if (!diag) atomicAdd(&S[(size_t)sc * ld + sr], total);
     }
-  } else if (diag && lane < 42) {
-    const int a = lane - 36;
+  } else if (diag && lane < 54) {
+    const int a = (lane - 36) % 6, which = (lane - 36) / 6;   // 0: reduced rhs, 1: raw gradient, 2: diag(A^T A)
     const int row = (a < 3) ? (tqi < 0 ? -1 : tqi + a) : (tpi < 0 ? -1 : tpi + a - 3);
     if (row >= 0) {
-      atomicAdd(&S[(size_t)rhs_row * ld + perm[row >> 6] * 64 + (row & 63)], sb[36 + a]);
-      atomicAdd(&grad[row], sb[42 + a]);
-      atomicAdd(&hdiag[row], sb[48 + a]);
+      if (which == 0) atomicAdd(&S[(size_t)rhs_row * ld + perm[row >> 6] * 64 + (row & 63)], total);
+      else if (which == 1) atomicAdd(&grad[row], total);
+      else atomicAdd(&hdiag[row], total);
     }
   }
 }
