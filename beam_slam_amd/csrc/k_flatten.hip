@@ -1,6 +1,6 @@
 // Device-side flattening of the reprojection factors of a window (the per-cycle rebuild that the
 // reference does on the host in HashGraph::createProblem): what the Schur kernels need — factors sorted by landmark,
-// camera-pose ids, per-landmark ranges, the (factor a, factor b) pair entries grouped by camera pair in chunks of 256,
+// camera-pose ids, per-landmark ranges, the (factor a, factor b) pair entries grouped by camera pair in chunks of kPairChunk,
 // the tile adjacency of the reduced system — is built from the RAW factor table with rocPRIM sorts and scans instead of
 // host loops over 400 k factors and 2 M pair entries.  It produces exactly the tables of the host path (same order:
 // both sorts are stable), which stays as the general path (online-calibration factors, landmark blocks shared with
@@ -117,7 +117,7 @@ __global__ void fl_split_kernel(int n, const unsigned long long* __restrict__ ke
 }
 __global__ void fl_segflag_kernel(int n, const int* __restrict__ run_start, unsigned char* __restrict__ flag) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) flag[i] = ((i - run_start[i]) & 255) == 0;
+  if (i < n) flag[i] = ((i - run_start[i]) & (kPairChunk - 1)) == 0;
 }
 __global__ void fl_seg_kernel(int n_seg, int n_ent, int* __restrict__ seg_start, const unsigned long long* __restrict__ key,
                               unsigned long long ncp, int* __restrict__ seg_ci, int* __restrict__ seg_cj, const int* __restrict__ cp_tq,
