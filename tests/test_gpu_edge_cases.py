@@ -225,3 +225,31 @@ def test_device_flattening_declines_what_it_does_not_cover(oracle_cls, gpu_solve
     pr2.add_factors(capi.F_ABS_VEC3, [[lm1]], [np.concatenate([pr2.block(lm1), A.ravel()])])
     g2, o2 = _both(pr2, oracle_cls, gpu_solver_cls)
     _same_solve(g2, o2, tol_x=1e-6)
+
+
+def test_contexts_release_their_device_memory(gpu_solver_cls):
+    """create / describe / solve / covariance / marginalise / destroy, many times: device memory in use does not creep (pooled
+    buffers, pinned scalars, events and streams all go back)."""
+    import torch
+    pr = synthetic.vio_window(n_kf=12, n_lm=300, seed=4)
+    kf = pr.meta["kf_blocks"]
+
+    def cycle():
+        g = gpu_solver_cls(0)
+        pr.load(g)
+        g.solve()
+        g.covariance(int(kf[3, 1]), int(kf[3, 1]))
+        g.marginalize([int(b) for b in kf[0]], pr.size)
+        pr.load(g)              # re-describe and re-flatten in the same context (pool reuse)
+        g.solve()
+        g.close()
+
+    for _ in range(3):
+        cycle()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(40):
+        cycle()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 32 << 20, "device memory in use grew by %.1f MB over 40 context lifetimes" % ((free0 - free1) / 2**20)
