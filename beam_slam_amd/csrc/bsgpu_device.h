@@ -110,6 +110,25 @@ BSG_DEV double loss_eval(const DevLoss& L, double s, double* rho1) {
   return s;
 }
 
+// LM diagonal of pose-side column at solver position i (k_dense.hip pose_diag_kernel, and fused with the gradient norms in
+// k_misc.hip): Jacobi scale / clamped diagonal where H_jj is known, unit pivots on the rhs row and the padding
+BSG_DEV void pose_diag_element(int i, int n_pose, double* __restrict__ S, int ld, const double* __restrict__ hdiag, double inv_radius,
+                               int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* __restrict__ scale,
+                               double* __restrict__ dcl, const int* __restrict__ iperm) {
+  const int nat = iperm[i >> 6];                          // natural tile, or -1 for the rhs tile
+  const int j = nat < 0 ? n_pose : nat * 64 + (i & 63);   // tangent index
+  if (j < n_pose) {
+    const double h = hdiag[j];
+    double sc = compute_scale ? (jacobi ? 1.0 / (1.0 + sqrt(h)) : 1.0) : scale[j];
+    double d = compute_dcl ? fmin(fmax(sc * sc * h, lm_lo), lm_hi) / (sc * sc) : dcl[j];
+    if (compute_scale) scale[j] = sc;
+    if (compute_dcl) dcl[j] = d;
+    S[(size_t)i * ld + i] += d * inv_radius;
+  } else {
+    S[(size_t)i * ld + i] = 1.0;  // rhs row / padding: unit pivot, never used as a real pivot
+  }
+}
+
 BSG_DEV double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

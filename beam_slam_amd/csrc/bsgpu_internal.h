@@ -148,6 +148,10 @@ void launch_pose_diag(hipStream_t s, int n_pose, double* S, int ld, const double
                       double* dcl, int npad, const int* iperm);
 void launch_grad_norms(hipStream_t s, int nb, const int* blk_xoff, const int* blk_toff, const unsigned char* blk_size,
                        const unsigned char* blk_manifold, const double* x, const double* grad, double* scal);
+void launch_grad_norms_pose_diag(hipStream_t s, int nb, const int* blk_xoff, const int* blk_toff, const unsigned char* blk_size,
+                                 const unsigned char* blk_manifold, const double* x, const double* grad, double* scal, int n_pose, double* S,
+                                 int ld, const double* hdiag, const double* radius_ptr, int compute_scale, int compute_dcl, int jacobi,
+                                 double lm_lo, double lm_hi, double* scale, double* dcl, int npad, const int* iperm);
 struct PanelDesc;
 void launch_chol_potrf_tiles(hipStream_t s, double* S, double* Lp, int ld, const int* tiles_dev, int n_tiles, const int* nreal_dev,
                              double* Vinv, double* scal);

@@ -19,20 +19,7 @@ __global__ void pose_diag_kernel(int n_pose, double* __restrict__ S, int ld, con
                                  const int* __restrict__ iperm) {
   const int i = blockIdx.x * 256 + threadIdx.x;   // solver position
   if (i >= npad) return;
-  const double inv_radius = 1.0 / radius_ptr[0];
-  const int tile = i >> 6;
-  const int nat = iperm[tile];                    // natural tile, or -1 for the rhs tile
-  const int j = nat < 0 ? n_pose : nat * 64 + (i & 63);   // tangent index
-  if (j < n_pose) {
-    const double h = hdiag[j];
-    double sc = compute_scale ? (jacobi ? 1.0 / (1.0 + sqrt(h)) : 1.0) : scale[j];
-    double d = compute_dcl ? fmin(fmax(sc * sc * h, lm_lo), lm_hi) / (sc * sc) : dcl[j];
-    if (compute_scale) scale[j] = sc;
-    if (compute_dcl) dcl[j] = d;
-    S[(size_t)i * ld + i] += d * inv_radius;
-  } else {
-    S[(size_t)i * ld + i] = 1.0;  // rhs row / padding: unit pivot, never used as a real pivot
-  }
+  pose_diag_element(i, n_pose, S, ld, hdiag, 1.0 / radius_ptr[0], compute_scale, compute_dcl, jacobi, lm_lo, lm_hi, scale, dcl, iperm);
 }
 
 void launch_pose_diag(hipStream_t s, int n_pose, double* S, int ld, const double* hdiag, const double* radius_ptr,

@@ -63,14 +63,22 @@ void launch_update(hipStream_t s, int nb, const int* blk_xoff, const int* blk_to
 
 // gradient norms the way ceres' TrustRegionMinimizer defines them: |x - Plus(x, -g)|_inf and |.|_2.
 // The max is order independent (atomicMax on the bit pattern of a non-negative double).
+struct PoseDiagArgs {   // the pose_diag_kernel arguments, for the launch that does both (an accepted / first step)
+  int n_pose, ld, compute_scale, compute_dcl, jacobi, npad;
+  double* S; const double* hdiag; const double* radius_ptr; double lm_lo, lm_hi; double* scale; double* dcl; const int* iperm;
+};
+template <bool WITH_DIAG>
 __global__ __launch_bounds__(256) void grad_norms_kernel(int nb, const int* __restrict__ xoff, const int* __restrict__ toff,
                                                          const unsigned char* __restrict__ size,
                                                          const unsigned char* __restrict__ manifold,
                                                          const double* __restrict__ x, const double* __restrict__ grad,
-                                                         double* __restrict__ scal) {
+                                                         double* __restrict__ scal, PoseDiagArgs pd) {
   __shared__ double sred[4];
   __shared__ double smax[4];
   const int b = blockIdx.x * 256 + threadIdx.x;
+  if (WITH_DIAG && b < pd.npad)   // independent of the norms: the LM diagonal of the reduced system rides in the same launch
+    pose_diag_element(b, pd.n_pose, pd.S, pd.ld, pd.hdiag, 1.0 / pd.radius_ptr[0], pd.compute_scale, pd.compute_dcl, pd.jacobi, pd.lm_lo,
+                      pd.lm_hi, pd.scale, pd.dcl, pd.iperm);
   double mx = 0.0, s2 = 0.0;
   if (b < nb) {
     const int o = xoff[b], t = toff[b], sz = size[b];
@@ -99,8 +107,19 @@ __global__ __launch_bounds__(256) void grad_norms_kernel(int nb, const int* __re
 
 void launch_grad_norms(hipStream_t s, int nb, const int* blk_xoff, const int* blk_toff, const unsigned char* blk_size,
                        const unsigned char* blk_manifold, const double* x, const double* grad, double* scal) {
-  hipLaunchKernelGGL(grad_norms_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, nb, blk_xoff, blk_toff, blk_size,
-                     blk_manifold, x, grad, scal);
+  hipLaunchKernelGGL(grad_norms_kernel<false>, dim3((nb + 255) / 256), dim3(256), 0, s, nb, blk_xoff, blk_toff, blk_size,
+                     blk_manifold, x, grad, scal, PoseDiagArgs{});
+}
+// gradient norms + pose_diag in one launch (both follow the assembly and are independent of each other)
+void launch_grad_norms_pose_diag(hipStream_t s, int nb, const int* blk_xoff, const int* blk_toff, const unsigned char* blk_size,
+                                 const unsigned char* blk_manifold, const double* x, const double* grad, double* scal, int n_pose, double* S,
+                                 int ld, const double* hdiag, const double* radius_ptr, int compute_scale, int compute_dcl, int jacobi,
+                                 double lm_lo, double lm_hi, double* scale, double* dcl, int npad, const int* iperm) {
+  PoseDiagArgs pd;
+  pd.n_pose = n_pose; pd.ld = ld; pd.compute_scale = compute_scale; pd.compute_dcl = compute_dcl; pd.jacobi = jacobi; pd.npad = npad;
+  pd.S = S; pd.hdiag = hdiag; pd.radius_ptr = radius_ptr; pd.lm_lo = lm_lo; pd.lm_hi = lm_hi; pd.scale = scale; pd.dcl = dcl; pd.iperm = iperm;
+  const int grid = (std::max(nb, npad) + 255) / 256;
+  hipLaunchKernelGGL(grad_norms_kernel<true>, dim3(grid), dim3(256), 0, s, nb, blk_xoff, blk_toff, blk_size, blk_manifold, x, grad, scal, pd);
 }
 
 // fixed-order sums of partial arrays (one workgroup): reproducible cost / model-cost-change values

@@ -230,7 +230,14 @@ def test_device_flattening_declines_what_it_does_not_cover(oracle_cls, gpu_solve
 def test_contexts_release_their_device_memory(gpu_solver_cls):
     """create / describe / solve / covariance / marginalise / destroy, many times: device memory in use does not creep (pooled
     buffers, pinned scalars, events and streams all go back)."""
-    import torch
+    import ctypes
+    hip = ctypes.CDLL("/opt/rocm/lib/libamdhip64.so")      # the runtime libbsgpu itself is linked against (torch brings its own)
+
+    def free_bytes():
+        free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        assert hip.hipDeviceSynchronize() == 0 and hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        return free.value
+
     pr = synthetic.vio_window(n_kf=12, n_lm=300, seed=4)
     kf = pr.meta["kf_blocks"]
 
@@ -246,10 +253,8 @@ def test_contexts_release_their_device_memory(gpu_solver_cls):
 
     for _ in range(3):
         cycle()
-    torch.cuda.synchronize()
-    free0 = torch.cuda.mem_get_info()[0]
+    free0 = free_bytes()
     for _ in range(40):
         cycle()
-    torch.cuda.synchronize()
-    free1 = torch.cuda.mem_get_info()[0]
+    free1 = free_bytes()
     assert free0 - free1 < 32 << 20, "device memory in use grew by %.1f MB over 40 context lifetimes" % ((free0 - free1) / 2**20)
