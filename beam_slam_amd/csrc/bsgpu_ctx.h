@@ -1,0 +1,229 @@
+// Host-side state of one libbsgpu context and the internal entry points of the three host translation units:
+//   bsgpu_finalize.cpp  flattening of the described problem to device tables ([EXT] fuse HashGraph::createProblem)
+//   bsgpu_solve.cpp     the LM loop and its step ([EXT] ceres TrustRegionMinimizer + LevenbergMarquardtStrategy)
+//   bsgpu_api.cpp       the C-ABI of include/bsgpu.h
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/bsgpu.h"
+#include "bsgpu_internal.h"
+#include "dense_plan.h"
+
+
+namespace bsg {
+
+
+struct TypeInfo { int nidx, nvar, nconst, m; int amb[10]; };
+// internal group: reprojection factors whose landmark block is NOT eliminated (it also appears in another kind of
+// factor, e.g. a marginal prior): they are evaluated and assembled like the pose-only groups, slots (q, p, P)
+constexpr int T_REPROJ_DENSE = BSGPU_F_NUM_TYPES;
+constexpr int kNumInternal = BSGPU_F_NUM_TYPES + 1;
+const TypeInfo kTypes[kNumInternal] = {
+    {4, 3, 3, 2, {4, 3, 3}},
+    {6, 5, 3, 2, {4, 3, 3, 4, 3}},
+    {10, 10, 287, 15, {4, 3, 3, 3, 3, 4, 3, 3, 3, 3}},
+    {5, 5, 241, 15, {4, 3, 3, 3, 3}},
+    {6, 6, 43, 6, {3, 4, 3, 4, 3, 4}},
+    {4, 4, 43, 6, {3, 4, 3, 4}},
+    {2, 2, 43, 6, {3, 4}},
+    {1, 1, 12, 3, {3}},
+    {2, 2, 12, 3, {3, 3}},
+    {1, 1, 7, 2, {4}},
+    {6, 5, 6, 2, {4, 3, 4, 3, 1}},
+    {4, 3, 6, 2, {4, 3, 1}},
+    {4, 3, 3, 2, {4, 3, 3}},   // T_REPROJ_DENSE: idx q, p, P, (derived) camera; consts u, v, w
+};
+inline bool has_camera(int t) { return t <= 1 || t == BSGPU_F_IDP_REPROJ || t == BSGPU_F_IDP_REPROJ_UNARY || t == T_REPROJ_DENSE; }
+
+
+struct HostMarginal {
+  std::vector<int32_t> blocks;
+  int rows = 0, cols = 0;
+  std::vector<double> A, b, xbar;
+};
+
+// Largest reduced (pose-side) system the dense tiled Cholesky takes: the back-substitution keeps the whole solution vector in LDS
+// (k_chol.hip: sy[npad] next to the 64x64 tiles, 160 KB per CU).  C2 needs 3 008; 12 288 = 819 keyframes of 15-d states.
+constexpr size_t kDenseLimit = 12288;
+
+struct HostGroup {
+  int n = 0;
+  std::vector<int32_t> idx;
+  std::vector<double> consts;
+  std::vector<int32_t> loss_kind;
+  std::vector<double> loss_a;
+};
+
+
+}  // namespace bsg
+
+using namespace bsg;   // (internal header: included by the three host translation units only)
+
+struct bsgpu_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // ---- host copy of the problem
+  int nb = 0;
+  std::vector<double> h_x;
+  std::vector<int32_t> off;
+  std::vector<uint8_t> size, manifold, is_const, is_const_in;   // is_const_in: as given; is_const: + blocks no factor touches
+  std::vector<bsgpu_camera> cams;
+  HostGroup groups[kNumInternal];
+  bool finalized = false;
+  // ---- derived structure
+  std::vector<int> tsize, toff;
+  std::vector<uint8_t> is_lm;
+  int n_pose = 0, n_lm = 0, n_tan = 0, npad = 0, n_res = 0;
+  int row0[BSGPU_F_NUM_TYPES] = {0};
+  bool vis_any_inactive = false; // some reprojection factor has q, p and landmark all constant
+  std::vector<int> vis_src;      // sorted visual position -> (type<<28 | index in its host group)
+  int* d_vis_src = nullptr;      // ... on the device when the window was flattened there (downloaded on demand)
+  std::vector<HostMarginal> marginals;
+  struct MargCtx { MargDev dev; int row0 = 0; bool active = true; double *part = nullptr, *part_cand = nullptr, *part_mcc = nullptr; };
+  std::vector<MargCtx> marg;
+  struct MargResult { std::vector<int32_t> kept; int rows = 0, cols = 0; std::vector<double> A, b, xbar; bool valid = false; } marg_result;
+  std::vector<int> dense_src;    // T_REPROJ_DENSE factor -> (type<<28 | index in its host group)
+  std::vector<uint8_t> no_elim;  // per block: never Schur-eliminate (set by the marginalisation sub-problem)
+  bool any_inactive = false;
+  // ---- device
+  std::vector<std::pair<void*, size_t>> allocs;   // live device buffers (pointer, bytes)
+  std::multimap<size_t, void*> pool;              // released buffers kept for the next finalize()
+  size_t pool_bytes = 0;
+  double *d_x = nullptr, *d_xcand = nullptr, *d_x0 = nullptr;
+  int *d_blk_xoff = nullptr, *d_blk_toff = nullptr;
+  unsigned char *d_blk_size = nullptr, *d_blk_manifold = nullptr;
+  DevCamera* d_cams = nullptr;
+  DevLoss* d_losses = nullptr;
+  Visual vis;
+  SmallGroup small[kNumInternal];
+  std::vector<unsigned char> h_small_active[kNumInternal];
+  unsigned char* d_small_inactive[kNumInternal] = {nullptr};
+  double* d_small_part[kNumInternal] = {nullptr};       // per-factor cost at the current point
+  double* d_small_part_cand[kNumInternal] = {nullptr};  // ... at the candidate
+  double* d_small_part_mcc[kNumInternal] = {nullptr};   // per-row model-cost-change terms
+  ReduceEntry* d_reduce = nullptr;
+  int n_reduce = 0;
+  double* d_part_upd = nullptr;
+  int n_part_upd = 0;
+  double *d_S = nullptr, *d_grad = nullptr, *d_hdiag = nullptr, *d_scale = nullptr, *d_dcl = nullptr;
+  double *d_delta = nullptr, *d_y = nullptr, *d_scal = nullptr, *d_part = nullptr;
+  double* h_scal = nullptr;  // pinned
+  double* h_scal_dev = nullptr;  // the same buffer as the device sees it (final_reduce mirrors the step's scalars there)
+  bool scal_mirrored = false;    // the last enqueued work ended with a final_reduce that filled the mirror
+  // tiled Cholesky plan (dense_plan.h) and its device tables
+  DensePlan plan;
+  std::vector<uint8_t> tile_adj;   // natural-tile adjacency of the reduced system
+  int *d_perm = nullptr, *d_iperm = nullptr, *d_nreal = nullptr, *d_rows_flat = nullptr;
+  PanelDesc* d_panels = nullptr;
+  int *d_panel_of_tile = nullptr, *d_chain_begin = nullptr, *d_chain_end = nullptr, *d_tile_sync = nullptr;
+  double* d_Vinv = nullptr;
+  double* d_Lp = nullptr;     // shadow of S holding the off-diagonal L panels (k_chol.hip)
+  double* d_ytan = nullptr;   // y in tangent order
+  std::vector<bsgpu_iteration> iters;
+  // captured LM-step sequences (hipGraph): iteration zero / after an accepted step / after a rejected step
+  hipGraphExec_t g_first = nullptr, g_accept = nullptr, g_reject = nullptr;
+  bool graphs_tried = false, graphs_ok = false, use_graphs = true;
+  bsgpu_options graph_opts{};
+  double* h_radius = nullptr;  // pinned
+  double* h_pcg = nullptr;     // pinned: two read-backs of the PCG scalars in flight (pcg_solve)
+  hipEvent_t pcg_ev[2] = {nullptr, nullptr};
+  hipEvent_t ev_reduce = nullptr;   // recorded after the end-of-step reduction: what the host waits for (work may be queued behind it)
+  bool ev_reduce_pending = false;
+  // block-sparse PCG path
+  bool dense_ok = true, bsr_built = false, use_pcg = false;
+  bool spec_J = false;   // residuals + Jacobians currently hold the CANDIDATE's (evaluated ahead of the accept/reject decision)
+  int nbr = 0, nblk = 0, pcg_iters_total = 0;
+  int *d_row_ptr = nullptr, *d_col = nullptr, *d_diag_slot = nullptr;
+  int* d_slots[kNumInternal] = {nullptr};
+  double *d_val = nullptr, *d_Minv = nullptr, *d_rhs = nullptr, *d_px = nullptr, *d_pr = nullptr, *d_pz = nullptr, *d_pp = nullptr, *d_pp1 = nullptr,
+         *d_pq = nullptr, *d_ppart = nullptr, *d_ppart2 = nullptr, *d_psc = nullptr;
+
+  // device buffers are pooled across finalize() calls: a sliding window re-flattens every cycle with nearly the same
+  // sizes, and hipMalloc / hipFree (which synchronise) would otherwise cost milliseconds per cycle
+  template <typename T> T* alloc(size_t n) {
+    void* p = nullptr;
+    if (n == 0) n = 1;
+    const size_t bytes = (n * sizeof(T) + 255) & ~(size_t)255;
+    auto it = pool.lower_bound(bytes);
+    if (it != pool.end() && it->first <= bytes + bytes / 2 + 4096) { p = it->second; pool_bytes -= it->first; const size_t got = it->first; pool.erase(it); allocs.push_back({p, got}); return static_cast<T*>(p); }
+    // a window that slides grows and shrinks by a fraction of a percent per cycle: headroom on the larger buffers, so that the
+    // next cycle's slightly larger request finds this one in the pool instead of going to hipMalloc again (HBM is not scarce)
+    size_t want = bytes > ((size_t)64 << 10) ? ((bytes + bytes / 8 + 255) & ~(size_t)255) : bytes;
+    if (hipMalloc(&p, want) != hipSuccess) {
+      release_pool();   // give cached buffers back and retry once, without the headroom
+      want = bytes;
+      if (hipMalloc(&p, want) != hipSuccess) return nullptr;
+    }
+    allocs.push_back({p, want});
+    return static_cast<T*>(p);
+  }
+  void release_pool() {
+    for (auto& kv : pool) (void)hipFree(kv.second);
+    pool.clear(); pool_bytes = 0;
+  }
+  template <typename T> T* upload(const std::vector<T>& v) {
+    T* p = alloc<T>(v.size());
+    if (p && !v.empty()) (void)hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    return p;
+  }
+  void free_device() {
+    if (stream) (void)hipStreamSynchronize(stream);   // nothing may still be using the buffers that go back to the pool
+    for (auto& a : allocs) { pool.emplace(a.second, a.first); pool_bytes += a.second; }
+    allocs.clear();
+    if (pool_bytes > ((size_t)8 << 30)) release_pool();
+    vis = Visual();
+    for (auto& g : small) g = SmallGroup();
+    d_x = d_xcand = d_x0 = nullptr;
+    bsr_built = false;
+    destroy_graphs();
+  }
+  void destroy_graphs() {
+    for (hipGraphExec_t* g : {&g_first, &g_accept, &g_reject}) if (*g) { (void)hipGraphExecDestroy(*g); *g = nullptr; }
+    graphs_tried = graphs_ok = false;
+  }
+};
+
+
+namespace bsg {
+
+inline int fail(bsgpu_ctx* c, int code, const std::string& msg) { c->err = msg; return code; }
+int api_exception(bsgpu_ctx* c) noexcept;   // bsgpu_api.cpp: where every entry point's function-try-block ends
+
+#define HIPCHK(c, call)                                                                         \
+  do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(c, BSGPU_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+
+// bsgpu_finalize.cpp
+int finalize(bsgpu_ctx* c);
+int build_bsr(bsgpu_ctx* c);
+// bsgpu_solve.cpp
+int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum);
+void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot);
+void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, bool first);
+void final_reduce(bsgpu_ctx* c);
+int fetch_scalars(bsgpu_ctx* c);
+int ensure_vis_src(bsgpu_ctx* c);
+// Cholesky of the (padded, rhs-augmented, solver-ordered) reduced system in S and the solve L^T y = y', following the plan's
+// step schedule; y comes back in solver order (npad entries)
+struct DenseDev {
+  const int *perm, *nreal, *rows_flat;
+  const PanelDesc* panels;
+  double *Lp, *Vinv;
+  const int *panel_of_tile, *chain_begin, *chain_end;
+  int* tile_sync;   // [expected arrivals | arrival counters] per tile (dense_plan.h)
+};
+void dense_factor(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* scal);
+void dense_factor_solve(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* y, double* scal);
+
+}  // namespace bsg

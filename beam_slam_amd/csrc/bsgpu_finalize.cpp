@@ -1,0 +1,609 @@
+// finalize(): flattening of the described problem to device tables — what [EXT] fuse HashGraph::createProblem does for the
+// reference's `graph_->optimize()` (bs_optimizers/src/fixed_lag_smoother.cpp:281), with a deterministic variable index.
+#include "bsgpu_ctx.h"
+
+namespace bsg {
+
+namespace {
+void eigen_quat_to_rot(const double* q, double* R) {
+  const double tx = 2 * q[1], ty = 2 * q[2], tz = 2 * q[3];
+  const double twx = tx * q[0], twy = ty * q[0], twz = tz * q[0], txx = tx * q[1], txy = ty * q[1], txz = tz * q[1];
+  const double tyy = ty * q[2], tyz = tz * q[2], tzz = tz * q[3];
+  R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+  R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+// finalize: flatten to device tables.  Restates [EXT] fuse HashGraph::createProblem
+// with a deterministic variable index: tangent columns in block order, pose-side
+// blocks first, then the landmark blocks that the Schur complement eliminates.
+// ---------------------------------------------------------------------------------------------------
+int finalize(bsgpu_ctx* c) {
+  if (c->finalized) return BSGPU_OK;
+  const bool timing = getenv("BSGPU_TIMING") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[bsgpu finalize] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+    t_prev = now;
+  };
+  c->free_device();
+  HIPCHK(c, hipSetDevice(c->device));
+  lap("free previous");
+  const int nb = c->nb;
+  if (nb <= 0) return fail(c, BSGPU_ERR_INVALID, "no parameter blocks");
+  // ---- validation + landmark detection (same rule as the oracle)
+  std::vector<int> lm_use(nb, 0), other_use(nb, 0);
+  for (int t = 0; t < BSGPU_F_NUM_TYPES; ++t) {
+    const HostGroup& g = c->groups[t];
+    const TypeInfo& ti = kTypes[t];
+    for (int f = 0; f < g.n; ++f) {
+      const int32_t* idx = &g.idx[(size_t)f * ti.nidx];
+      for (int sl = 0; sl < ti.nvar; ++sl) {
+        const int b = idx[sl];
+        if (b < 0 || b >= nb) return fail(c, BSGPU_ERR_INVALID, "factor references block out of range");
+        if (c->size[b] != ti.amb[sl]) return fail(c, BSGPU_ERR_INVALID, "block size does not match factor slot");
+        if (ti.amb[sl] == 4 && c->manifold[b] != BSGPU_MANIFOLD_QUAT_RIGHT)
+          return fail(c, BSGPU_ERR_INVALID, "4-d slot must be a quaternion-manifold block");
+        if (t <= 1 && sl == 2) lm_use[b]++; else other_use[b]++;
+      }
+      if (has_camera(t)) {
+        const int cam = idx[ti.nvar];
+        if (cam < 0 || cam >= (int)c->cams.size()) return fail(c, BSGPU_ERR_INVALID, "camera index out of range");
+      }
+    }
+  }
+  for (const HostMarginal& mg : c->marginals)
+    for (int b : mg.blocks) {
+      if (b < 0 || b >= nb) return fail(c, BSGPU_ERR_INVALID, "marginal factor references block out of range");
+      other_use[b]++;
+    }
+  // a parameter block no residual block touches is not part of the problem ([EXT] Ceres drops unused parameter blocks from the
+  // reduced program; fuse's graph keeps e.g. landmarks whose last observation left the window): treated like a constant block
+  if (c->is_const_in.size() != (size_t)nb) c->is_const_in = c->is_const;
+  for (int b = 0; b < nb; ++b) c->is_const[b] = (c->is_const_in[b] || lm_use[b] + other_use[b] == 0) ? 1 : 0;
+  c->tsize.assign(nb, 0); c->toff.assign(nb, -1); c->is_lm.assign(nb, 0);
+  for (int b = 0; b < nb; ++b) {
+    if (c->size[b] > 4 || c->size[b] == 0) return fail(c, BSGPU_ERR_UNSUPPORTED, "block sizes 1..4 only");
+    if (c->manifold[b] == BSGPU_MANIFOLD_QUAT_RIGHT && c->size[b] != 4) return fail(c, BSGPU_ERR_INVALID, "quaternion block must have size 4");
+    c->tsize[b] = (c->manifold[b] == BSGPU_MANIFOLD_QUAT_RIGHT) ? 3 : c->size[b];
+    if (c->is_const[b]) continue;
+    if (lm_use[b] > 0 && other_use[b] == 0 && c->size[b] == 3 && c->manifold[b] == BSGPU_MANIFOLD_EUCLIDEAN &&
+        !(b < (int)c->no_elim.size() && c->no_elim[b])) c->is_lm[b] = 1;
+  }
+  int to = 0;
+  for (int b = 0; b < nb; ++b) if (!c->is_const[b] && !c->is_lm[b]) { c->toff[b] = to; to += c->tsize[b]; }
+  c->n_pose = to;
+  std::vector<int> lm_index(nb, -1);
+  int nl = 0;
+  for (int b = 0; b < nb; ++b) if (!c->is_const[b] && c->is_lm[b]) { c->toff[b] = to; to += 3; lm_index[b] = nl++; }
+  c->n_tan = to; c->n_lm = nl;
+  c->npad = ((c->n_pose + 63) / 64 + 1) * 64;   // real tiles + one tile for the rhs row (dense_plan.h)
+  c->dense_ok = (size_t)c->npad <= kDenseLimit;   // above: block-sparse PCG path only (pose-only problems)
+  int row = 0;
+  for (int t = 0; t < BSGPU_F_NUM_TYPES; ++t) { c->row0[t] = row; row += c->groups[t].n * kTypes[t].m; }
+  for (const HostMarginal& mg : c->marginals) row += mg.rows;
+  c->n_res = row;
+
+  lap("validate + index");
+  // ---- loss table
+  std::vector<DevLoss> losses;
+  std::map<std::pair<int, double>, int> loss_id;
+  int last_kind = -1, last_id = -1;
+  double last_a = 0.0;
+  auto get_loss = [&](int kind, double a) {
+    if (kind == BSGPU_LOSS_TRIVIAL) a = 1.0;
+    if (kind == last_kind && a == last_a) return last_id;   // windows use a handful of distinct losses
+    last_kind = kind; last_a = a;
+    auto key = std::make_pair(kind, a);
+    auto it = loss_id.find(key);
+    if (it != loss_id.end()) return last_id = it->second;
+    DevLoss L; L.kind = kind; L.pad = 0; L.a = a;
+    losses.push_back(L);
+    return last_id = loss_id[key] = (int)losses.size() - 1;
+  };
+  get_loss(BSGPU_LOSS_TRIVIAL, 1.0);
+
+  // ---- camera table (online-calib factors fold their constant extrinsic blocks into derived cameras)
+  std::vector<DevCamera> cams;
+  for (const bsgpu_camera& hc : c->cams) {
+    DevCamera d; d.fx = hc.fx; d.fy = hc.fy; d.cx = hc.cx; d.cy = hc.cy;
+    std::memcpy(d.R, hc.R_cam_baselink, sizeof(d.R)); std::memcpy(d.t, hc.t_cam_baselink, sizeof(d.t));
+    cams.push_back(d);
+  }
+  std::map<std::tuple<int, int, int>, int> derived_cam;
+
+  // ---- visual factors: camera-pose ids, factors sorted by landmark, pair entries, tile adjacency.
+  // Large plain windows are flattened on the device (k_flatten.hip); everything else — and any window the device
+  // path declines (online calibration, landmark blocks shared with other factors, more than 8 distinct losses, an
+  // orientation block paired with two position blocks) — takes the host path below.  BSGPU_FLATTEN=host|device forces one.
+  c->any_inactive = false;
+  c->vis_any_inactive = false;
+  c->groups[T_REPROJ_DENSE] = HostGroup();
+  c->dense_src.clear();
+  c->vis_src.clear();
+  c->d_vis_src = nullptr;
+  auto host_visual = [&]() -> int {
+  struct VF { int xq, xp, xl, bq, bp, meta_cam, loss, flags, lm, src; double u, v, w; };
+  std::vector<VF> vf;
+  for (int t = 0; t <= 1; ++t) {
+    const HostGroup& g = c->groups[t];
+    const TypeInfo& ti = kTypes[t];
+    for (int f = 0; f < g.n; ++f) {
+      const int32_t* idx = &g.idx[(size_t)f * ti.nidx];
+      VF e;
+      e.bq = idx[0]; e.bp = idx[1];
+      e.xq = c->off[idx[0]]; e.xp = c->off[idx[1]]; e.xl = c->off[idx[2]];
+      int cam = idx[ti.nvar];
+      if (t == 1) {
+        const int bqe = idx[3], bpe = idx[4];
+        if (!c->is_const[bqe] || !c->is_const[bpe])
+          return fail(c, BSGPU_ERR_UNSUPPORTED,
+                      "online-calibration reprojection factor with non-constant extrinsic blocks (the reference holds "
+                      "them constant: bs_variables/src/orientation_3d.cpp:39-41)");
+        auto key = std::make_tuple(bqe, bpe, cam);
+        auto it = derived_cam.find(key);
+        if (it == derived_cam.end()) {
+          // T_CAM_BASELINK = InvertTransform(T_BASELINK_CAM)  (helpers.h:27-35, functor_online_calib.h:52-56)
+          double Rbc[9];
+          eigen_quat_to_rot(&c->h_x[c->off[bqe]], Rbc);
+          const double* pbc = &c->h_x[c->off[bpe]];
+          DevCamera d = cams[cam];
+          for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) d.R[3 * i + j] = Rbc[3 * j + i];
+          for (int i = 0; i < 3; ++i) d.t[i] = -(d.R[3 * i] * pbc[0] + d.R[3 * i + 1] * pbc[1] + d.R[3 * i + 2] * pbc[2]);
+          cams.push_back(d);
+          it = derived_cam.emplace(key, (int)cams.size() - 1).first;
+        }
+        cam = it->second;
+      }
+      e.meta_cam = cam;
+      e.loss = get_loss(g.loss_kind[f], g.loss_a[f]);
+      e.flags = (c->is_const[idx[0]] ? kFlagQConst : 0) | (c->is_const[idx[1]] ? kFlagPConst : 0) |
+                (c->is_const[idx[2]] ? kFlagLConst : 0);
+      if (e.flags == 7) { c->any_inactive = true; c->vis_any_inactive = true; }
+      e.lm = lm_index[idx[2]];
+      e.src = (t << 28) | f;
+      if (e.lm < 0 && !c->is_const[idx[2]]) {
+        // the landmark block is not eliminated (it is shared with another kind of factor): pose-only style group
+        HostGroup& dg = c->groups[T_REPROJ_DENSE];
+        const int32_t di[4] = {idx[0], idx[1], idx[2], cam};
+        dg.idx.insert(dg.idx.end(), di, di + 4);
+        dg.consts.insert(dg.consts.end(), &g.consts[(size_t)f * 3], &g.consts[(size_t)f * 3] + 3);
+        dg.loss_kind.push_back(g.loss_kind[f]); dg.loss_a.push_back(g.loss_a[f]);
+        dg.n++;
+        c->dense_src.push_back(e.src);
+        continue;
+      }
+      e.u = g.consts[(size_t)f * 3]; e.v = g.consts[(size_t)f * 3 + 1]; e.w = g.consts[(size_t)f * 3 + 2];
+      vf.push_back(e);
+    }
+  }
+  lap("gather visual factors");
+  if ((int)cams.size() >= (1 << kMetaCamBits) || (int)losses.size() >= (1 << kMetaLossBits))
+    return fail(c, BSGPU_ERR_UNSUPPORTED, "too many distinct cameras / loss functions");
+  const int nv = (int)vf.size();
+  {  // stable counting sort by landmark (factors of constant landmarks, lm < 0, last)
+    std::vector<int> start(nl + 2, 0);
+    for (const VF& e : vf) start[(e.lm < 0 ? nl : e.lm) + 1]++;
+    for (int l = 0; l <= nl; ++l) start[l + 1] += start[l];
+    std::vector<VF> sorted(vf.size());
+    for (const VF& e : vf) sorted[start[e.lm < 0 ? nl : e.lm]++] = e;
+    vf.swap(sorted);
+  }
+  lap("sort by landmark");
+  Visual& V = c->vis;
+  V.n = nv; V.n_lm = nl;
+  c->vis_src.resize(nv);
+  {
+    std::vector<int4> fac(nv);
+    std::vector<double2> pix(nv);
+    std::vector<double> w(nv);
+    std::vector<int> cam_pose(nv), lm_of(nv), lm_start(nl + 1, 0);
+    // camera poses = distinct (q block, p block) pairs, numbered in ascending (q, p) order
+    std::vector<uint64_t> cp_keys;
+    {
+      std::vector<int> seen_p(nb, -1);   // fast path: a q block nearly always pairs with one p block
+      for (const VF& e : vf) if (seen_p[e.bq] != e.bp) { seen_p[e.bq] = e.bp; cp_keys.push_back(((uint64_t)e.bq << 32) | (uint32_t)e.bp); }
+      std::sort(cp_keys.begin(), cp_keys.end());
+      cp_keys.erase(std::unique(cp_keys.begin(), cp_keys.end()), cp_keys.end());
+    }
+    const int k = (int)cp_keys.size();
+    std::vector<int> cp_tq, cp_tp, cp_first(nb, -1);   // cp_first[bq] = first camera pose with that q block
+    for (int i = 0; i < k; ++i) {
+      const int bq = (int)(cp_keys[i] >> 32), bp = (int)(cp_keys[i] & 0xffffffffu);
+      cp_tq.push_back(c->toff[bq]); cp_tp.push_back(c->toff[bp]);
+      if (cp_first[bq] < 0) cp_first[bq] = i;
+    }
+    auto cp_of = [&](int bq, int bp) {
+      int i = cp_first[bq];
+      while ((int)(cp_keys[i] & 0xffffffffu) != bp) ++i;
+      return i;
+    };
+    V.n_cam_pose = k;
+    int n_elim = 0;
+    for (int i = 0; i < nv; ++i) {
+      const VF& e = vf[i];
+      fac[i] = make_int4(e.xq, e.xp, e.xl, meta_pack(e.meta_cam, e.loss, e.flags));
+      pix[i] = make_double2(e.u, e.v);
+      w[i] = e.w;
+      cam_pose[i] = cp_of(e.bq, e.bp);
+      lm_of[i] = e.lm;
+      c->vis_src[i] = e.src;
+      if (e.lm >= 0) { lm_start[e.lm + 1]++; n_elim++; }
+    }
+    for (int l = 0; l < nl; ++l) lm_start[l + 1] += lm_start[l];
+    V.n_elim = n_elim;
+    lap("camera-pose ids");
+    // pair entries (factor a, factor b) of every landmark, grouped by camera-pose pair (ca <= cb); inside a group the
+    // order is landmark-major.  Two passes over the landmarks: count per pair key, then fill in place.
+    const uint64_t ncp = (uint64_t)std::max(1, V.n_cam_pose);
+    std::vector<int> seg_ci, seg_cj, seg_start, ent_fa, ent_fb;
+    if (ncp * ncp <= (uint64_t)8 << 20) {
+      std::vector<int> start(ncp * ncp + 1, 0);
+      for (int l = 0; l < nl; ++l)
+        for (int a = lm_start[l]; a < lm_start[l + 1]; ++a) {
+          const uint64_t ra = (uint64_t)cam_pose[a] * ncp;
+          for (int b = lm_start[l]; b < lm_start[l + 1]; ++b) if (cam_pose[a] <= cam_pose[b]) start[ra + cam_pose[b] + 1]++;
+        }
+      for (int f = n_elim; f < nv; ++f) start[(uint64_t)cam_pose[f] * ncp + cam_pose[f] + 1]++;
+      for (size_t i = 0; i < ncp * ncp; ++i) start[i + 1] += start[i];
+      const size_t n_ent = (size_t)start[ncp * ncp];
+      ent_fa.resize(n_ent); ent_fb.resize(n_ent);
+      lap("count pair entries");
+      // segments (chunks of <= kPairChunk entries of one pair) straight from the counts
+      for (uint64_t key = 0; key < ncp * ncp; ++key)
+        for (int p0 = start[key]; p0 < start[key + 1]; p0 += kPairChunk) { seg_ci.push_back((int)(key / ncp)); seg_cj.push_back((int)(key % ncp)); seg_start.push_back(p0); }
+      std::vector<int> pos(start.begin(), start.end() - 1);
+      for (int l = 0; l < nl; ++l)
+        for (int a = lm_start[l]; a < lm_start[l + 1]; ++a) {
+          const uint64_t ra = (uint64_t)cam_pose[a] * ncp;
+          for (int b = lm_start[l]; b < lm_start[l + 1]; ++b)
+            if (cam_pose[a] <= cam_pose[b]) { const int p = pos[ra + cam_pose[b]]++; ent_fa[p] = a; ent_fb[p] = b; }
+        }
+      for (int f = n_elim; f < nv; ++f) { const int p = pos[(uint64_t)cam_pose[f] * ncp + cam_pose[f]]++; ent_fa[p] = f; ent_fb[p] = f; }
+      lap("fill pair entries");
+    } else {   // very many camera poses: comparison sort of explicit entries
+      struct Ent { uint64_t key; int fa, fb; };
+      std::vector<Ent> ents;
+      ents.reserve((size_t)nv * 5);
+      for (int l = 0; l < nl; ++l)
+        for (int a = lm_start[l]; a < lm_start[l + 1]; ++a)
+          for (int b = lm_start[l]; b < lm_start[l + 1]; ++b)
+            if (cam_pose[a] <= cam_pose[b]) ents.push_back({(uint64_t)cam_pose[a] * ncp + cam_pose[b], a, b});
+      for (int f = n_elim; f < nv; ++f) ents.push_back({(uint64_t)cam_pose[f] * ncp + cam_pose[f], f, f});
+      std::stable_sort(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) { return x.key < y.key; });
+      ent_fa.resize(ents.size()); ent_fb.resize(ents.size());
+      for (size_t i = 0; i < ents.size(); ++i) {
+        if (i == 0 || ents[i].key != ents[i - 1].key || (int)i - seg_start.back() >= kPairChunk) {
+          seg_ci.push_back((int)(ents[i].key / ncp)); seg_cj.push_back((int)(ents[i].key % ncp)); seg_start.push_back((int)i);
+        }
+        ent_fa[i] = ents[i].fa; ent_fb[i] = ents[i].fb;
+      }
+      lap("sort pair entries");
+    }
+    seg_start.push_back((int)ent_fa.size());
+    V.n_seg = (int)seg_ci.size(); V.n_ent = (int)ent_fa.size();
+    lap("segments");
+    V.fac = c->upload(fac); V.pix = c->upload(pix); V.w = c->upload(w);
+    V.cam_pose = c->upload(cam_pose); V.lm_of = c->upload(lm_of); V.lm_start = c->upload(lm_start);
+    V.cp_tq = c->upload(cp_tq); V.cp_tp = c->upload(cp_tp);
+    V.seg_ci = c->upload(seg_ci); V.seg_cj = c->upload(seg_cj); V.seg_start = c->upload(seg_start);
+    V.ent_fa = c->upload(ent_fa); V.ent_fb = c->upload(ent_fb);
+    // structural tile adjacency of the reduced system (natural 64-wide tiles) for the Cholesky plan
+    const int T = (c->n_pose + 63) / 64;
+    c->tile_adj.assign((size_t)T * T, 0);
+    auto touch = [&](int ra, int rb) {  // tangent rows ra, rb (start of 3-blocks)
+      if (ra < 0 || rb < 0) return;
+      for (int a = ra; a < ra + 3; a += 2) for (int b = rb; b < rb + 3; b += 2) {
+        c->tile_adj[(size_t)(a / 64) * T + b / 64] = 1; c->tile_adj[(size_t)(b / 64) * T + a / 64] = 1;
+      }
+    };
+    for (int s = 0; s < V.n_seg; ++s) {
+      const int i = seg_ci[s], j = seg_cj[s];
+      const int ri[2] = {cp_tq[i], cp_tp[i]}, rj[2] = {cp_tq[j], cp_tp[j]};
+      for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) touch(ri[a], rj[b]);
+    }
+  }
+    return BSGPU_OK;
+  };
+  bool flattened_on_device = false;
+  {
+    const char* fe = getenv("BSGPU_FLATTEN");
+    const bool force_dev = fe && !strcmp(fe, "device"), force_host = fe && !strcmp(fe, "host");
+    const HostGroup& g0 = c->groups[BSGPU_F_REPROJ];
+    if (!force_host && c->groups[BSGPU_F_REPROJ_ONLINE_CALIB].n == 0 && g0.n > 0 && (force_dev || g0.n >= 20000)) {
+      // distinct losses of the reprojection factors (a window has one or two)
+      bool ok = true;
+      for (int f = 0; f < g0.n && ok; ++f) { get_loss(g0.loss_kind[f], g0.loss_a[f]); ok = losses.size() <= 8; }
+      if (ok) {
+        std::vector<int> bx(c->off.begin(), c->off.end());
+        std::vector<unsigned char> bc(c->is_const.begin(), c->is_const.end());
+        const int* d_bx = c->upload(bx); const int* d_bt = c->upload(c->toff);
+        const unsigned char* d_bc = c->upload(bc); const int* d_bl = c->upload(lm_index);
+        const int T = (c->n_pose + 63) / 64;
+        bool all_const = false;
+        auto dalloc = [&](size_t bytes) -> void* { return c->alloc<unsigned char>(bytes); };
+        const int st = flatten_visual_device(c->stream, dalloc, g0.n, g0.idx.data(), g0.consts.data(), g0.loss_kind.data(), g0.loss_a.data(),
+                                             losses, nb, d_bx, d_bt, d_bc, d_bl, nl, T, c->vis, &c->d_vis_src, c->tile_adj, &all_const);
+        if (st < 0) return fail(c, BSGPU_ERR_DEVICE, "device error while flattening the reprojection factors");
+        if (st == 0) {
+          flattened_on_device = true;
+          if (all_const) { c->any_inactive = true; c->vis_any_inactive = true; }
+          if (c->vis.n_cam_pose >= (1 << 20)) return fail(c, BSGPU_ERR_UNSUPPORTED, "too many camera poses");
+        } else {
+          c->vis = Visual();
+        }
+      }
+    }
+  }
+  if (flattened_on_device) lap("flatten on device");
+  else { const int rc_host = host_visual(); if (rc_host != BSGPU_OK) return rc_host; }
+  Visual& V = c->vis;
+  {
+    const int nv = V.n;
+    V.r = c->alloc<double2>(nv); V.J = c->alloc<double>((size_t)nv * 18); V.CR = c->alloc<double>((size_t)nv * 8);
+    V.Linv = c->alloc<double>((size_t)nl * 6); V.z = c->alloc<double>((size_t)nl * 3);
+    V.n_cost_part = (nv + 255) / 256;
+    V.cost_part = c->alloc<double>(V.n_cost_part);
+    V.cost_part_cand = c->alloc<double>(V.n_cost_part);
+    V.mcc_part = c->alloc<double>(V.n_cost_part);
+    if (!V.J || !V.CR || !V.r) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (visual tables)");
+  }
+  lap("visual upload + alloc");
+  // ---- pose-only groups
+  size_t part_max = std::max<size_t>(V.n_cost_part, 2 * ((size_t)nb + 255) / 256 + 2);
+  for (int t = 2; t < kNumInternal; ++t) {
+    const HostGroup& g = c->groups[t];
+    const TypeInfo& ti = kTypes[t];
+    SmallGroup& sg = c->small[t];
+    sg = SmallGroup();
+    sg.type = t; sg.n = g.n; sg.m = ti.m; sg.nv = ti.nvar; sg.nc = ti.nconst;
+    sg.w_last = ti.amb[ti.nvar - 1] == 4 ? 3 : ti.amb[ti.nvar - 1];
+    if (!g.n) continue;
+    std::vector<int> xoff((size_t)g.n * ti.nvar), toff((size_t)g.n * ti.nvar), loss(g.n);
+    std::vector<unsigned char> active(g.n, 0), inactive(g.n, 0);
+    for (int f = 0; f < g.n; ++f) {
+      const int32_t* idx = &g.idx[(size_t)f * ti.nidx];
+      for (int sl = 0; sl < ti.nvar; ++sl) {
+        xoff[(size_t)f * ti.nvar + sl] = c->off[idx[sl]];
+        toff[(size_t)f * ti.nvar + sl] = c->toff[idx[sl]];
+        if (c->toff[idx[sl]] >= c->n_pose) return fail(c, BSGPU_ERR_UNSUPPORTED, "internal: landmark in a pose-only factor");
+        if (!c->is_const[idx[sl]]) active[f] = 1;
+      }
+      inactive[f] = !active[f];
+      if (!active[f]) c->any_inactive = true;
+      loss[f] = get_loss(g.loss_kind[f], g.loss_a[f]);
+      if (active[f]) {
+        const int T = (c->n_pose + 63) / 64;
+        for (int sa = 0; sa < ti.nvar; ++sa)
+          for (int sb = 0; sb < ti.nvar; ++sb) {
+            const int ra = c->toff[idx[sa]], rb = c->toff[idx[sb]];
+            if (ra < 0 || rb < 0) continue;
+            const int wa = c->tsize[idx[sa]], wb = c->tsize[idx[sb]];
+            for (int a = ra; a < ra + wa; a += std::max(1, wa - 1)) for (int b = rb; b < rb + wb; b += std::max(1, wb - 1)) c->tile_adj[(size_t)(a / 64) * T + b / 64] = 1;
+          }
+      }
+    }
+    sg.xoff = c->upload(xoff); sg.toff = c->upload(toff); sg.consts = c->upload(g.consts); sg.loss = c->upload(loss);
+    sg.active = c->upload(active);
+    if (has_camera(t)) {
+      std::vector<int> camv(g.n);
+      for (int f = 0; f < g.n; ++f) camv[f] = g.idx[(size_t)f * ti.nidx + ti.nvar];
+      sg.cam = c->upload(camv);
+    }
+    c->d_small_inactive[t] = c->upload(inactive);
+    c->h_small_active[t] = active;
+    sg.r = c->alloc<double>((size_t)g.n * ti.m);
+    sg.J = c->alloc<double>((size_t)g.n * ti.m * 3 * ti.nvar);
+    c->d_small_part[t] = c->alloc<double>((size_t)g.n * ti.m);
+    c->d_small_part_cand[t] = c->alloc<double>(g.n);
+    c->d_small_part_mcc[t] = c->alloc<double>((size_t)g.n * ti.m);
+    part_max = std::max(part_max, (size_t)g.n * ti.m);
+  }
+  // ---- dense linear priors (marginal factors)
+  c->marg.clear();
+  {
+    int mrow = 0;
+    for (int t = 0; t < BSGPU_F_NUM_TYPES; ++t) mrow += c->groups[t].n * kTypes[t].m;
+    const int T = (c->n_pose + 63) / 64;
+    for (const HostMarginal& mg : c->marginals) {
+      bsgpu_ctx::MargCtx mc;
+      std::vector<int> bx, bs, bq, bc, ba, col_t, col_blk;
+      int cols = 0, amb = 0;
+      mc.active = false;
+      for (size_t i = 0; i < mg.blocks.size(); ++i) {
+        const int b = mg.blocks[i];
+        bx.push_back(c->off[b]); bs.push_back(c->size[b]); bq.push_back(c->manifold[b] == BSGPU_MANIFOLD_QUAT_RIGHT ? 1 : 0);
+        bc.push_back(cols); ba.push_back(amb);
+        for (int k = 0; k < c->tsize[b]; ++k) { col_t.push_back(c->is_const[b] ? -1 : c->toff[b] + k); col_blk.push_back((int)i); }
+        cols += c->tsize[b]; amb += c->size[b];
+        if (!c->is_const[b]) mc.active = true;
+      }
+      if (cols != mg.cols || amb != (int)mg.xbar.size()) return fail(c, BSGPU_ERR_INVALID, "marginal factor: A / xbar sizes do not match its blocks");
+      for (int t : col_t) if (t >= c->n_pose) return fail(c, BSGPU_ERR_UNSUPPORTED, "internal: eliminated block in a marginal factor");
+      if (!mc.active) c->any_inactive = true;
+      MargDev& d = mc.dev;
+      d.rows = mg.rows; d.cols = cols; d.nblk = (int)mg.blocks.size();
+      d.blk_xoff = c->upload(bx); d.blk_size = c->upload(bs); d.blk_quat = c->upload(bq); d.blk_col = c->upload(bc); d.blk_amb = c->upload(ba);
+      d.col_t = c->upload(col_t); d.col_blk = c->upload(col_blk);
+      d.A = c->upload(mg.A); d.b = c->upload(mg.b); d.xbar = c->upload(mg.xbar);
+      d.delta = c->alloc<double>(cols); d.D = c->alloc<double>((size_t)d.nblk);
+      d.r = c->alloc<double>(mg.rows); d.J = c->alloc<double>((size_t)mg.rows * cols);
+      mc.part = c->alloc<double>(mg.rows); mc.part_cand = c->alloc<double>(mg.rows); mc.part_mcc = c->alloc<double>(mg.rows);
+      if (!d.J || !mc.part_mcc) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (marginal factor)");
+      mc.row0 = mrow; mrow += mg.rows;
+      part_max = std::max(part_max, (size_t)mg.rows);
+      if (mc.active)   // a dense prior couples every pair of its blocks
+        for (int ta : col_t) for (int tb : col_t) if (ta >= 0 && tb >= 0) c->tile_adj[(size_t)(ta / 64) * T + tb / 64] = 1;
+      c->marg.push_back(mc);
+    }
+  }
+  if (losses.size() >= (1u << kMetaLossBits)) return fail(c, BSGPU_ERR_UNSUPPORTED, "too many distinct loss functions");
+  c->d_cams = c->upload(cams);
+  for (int t = 2; t < kNumInternal; ++t) c->small[t].cams = c->d_cams;
+  c->d_losses = c->upload(losses);
+  lap("pose-only groups + priors");
+  // ---- blocks
+  {
+    std::vector<int> bx(c->off.begin(), c->off.end());
+    c->d_blk_xoff = c->upload(bx);
+    c->d_blk_toff = c->upload(c->toff);
+    std::vector<unsigned char> sz(c->size.begin(), c->size.end()), mf(c->manifold.begin(), c->manifold.end());
+    c->d_blk_size = c->upload(sz); c->d_blk_manifold = c->upload(mf);
+    c->d_x = c->upload(c->h_x); c->d_x0 = c->upload(c->h_x);
+    c->d_xcand = c->alloc<double>(c->h_x.size());
+  }
+  // ---- dense system + vectors
+  if (c->dense_ok) {
+    c->d_S = c->alloc<double>((size_t)c->npad * c->npad);
+    if (!c->d_S) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (reduced system)");
+  }
+  c->d_grad = c->alloc<double>(c->n_tan); c->d_hdiag = c->alloc<double>(c->n_tan);
+  c->d_scale = c->alloc<double>(c->n_tan); c->d_dcl = c->alloc<double>(c->n_tan);
+  c->d_delta = c->alloc<double>(c->n_tan); c->d_y = c->alloc<double>(c->npad);
+  c->d_scal = c->alloc<double>(SC_NUM);
+  c->d_part = c->alloc<double>(part_max + 8);
+  if (!c->h_scal) {
+    HIPCHK(c, hipHostMalloc((void**)&c->h_scal, sizeof(double) * SC_NUM, hipHostMallocMapped));
+    if (hipHostGetDevicePointer((void**)&c->h_scal_dev, c->h_scal, 0) != hipSuccess) { (void)hipGetLastError(); c->h_scal_dev = nullptr; }
+  }
+  if (!c->h_radius) HIPCHK(c, hipHostMalloc((void**)&c->h_radius, sizeof(double)));
+  chol_prepare();
+  // hipGraph replay of the LM step is opt-in (BSGPU_GRAPH=1): on ROCm 7.2 the replay inserts a ~0.9 ms bubble
+  // inside the long dependent kernel chain (profiles/README.md), which cancels what it saves on launches
+  c->use_graphs = getenv("BSGPU_GRAPH") != nullptr;
+  HIPCHK(c, hipMemset(c->d_scal, 0, sizeof(double) * SC_NUM));
+  HIPCHK(c, hipMemset(c->d_delta, 0, sizeof(double) * std::max(1, c->n_tan)));
+  lap("blocks + dense buffers");
+  // ---- tiled Cholesky plan: nested-dissection tile order, symbolic factorisation, step schedule
+  {
+    const char* e = getenv("BSGPU_CHAINS");
+    const int max_chains = e ? std::max(1, atoi(e)) : 16;
+    const int T = (c->n_pose + 63) / 64;
+    if (c->tile_adj.size() != (size_t)T * T) c->tile_adj.assign((size_t)T * T, 0);
+    const char* e2 = getenv("BSGPU_MIN_PIECE");
+    const char* e3 = getenv("BSGPU_SHARED");   // panels of one step may update the same tiles (atomics): on unless BSGPU_SHARED=0
+    c->plan.build(c->n_pose, c->tile_adj, c->dense_ok ? max_chains : 1, e2 ? std::max(1, atoi(e2)) : 1, !(e3 && atoi(e3) == 0));
+    c->npad = c->plan.npad;
+    if (timing) fprintf(stderr, "[bsgpu finalize] Cholesky plan: %d tiles, %d pieces, %d panel steps, %d back-substitution launches\n", c->plan.T, c->plan.n_pieces,
+                        c->plan.n_steps(), (int)c->plan.bs_group_off.size() - 1);
+    std::vector<int> iperm(T + 1, -1);
+    for (int t = 0; t < T; ++t) iperm[c->plan.perm[t]] = t;
+    c->d_perm = c->upload(c->plan.perm); c->d_iperm = c->upload(iperm); c->d_nreal = c->upload(c->plan.nreal);
+    c->d_rows_flat = c->upload(c->plan.rows_flat);
+    c->d_panels = c->upload(c->plan.panels);
+    c->d_panel_of_tile = c->upload(c->plan.panel_of_tile);
+    c->d_tile_sync = c->upload(c->plan.tile_sync);
+    c->d_chain_begin = c->upload(c->plan.chain_begin); c->d_chain_end = c->upload(c->plan.chain_end);
+    c->d_Vinv = c->alloc<double>((size_t)std::max(1, T) * chol_vinv_stride());
+    c->d_ytan = c->alloc<double>(std::max(1, c->n_pose));
+    if (c->dense_ok) { c->d_Lp = c->alloc<double>((size_t)c->npad * c->npad); if (!c->d_Lp) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (L panels)"); }
+  }
+  {
+    c->n_part_upd = (nb + 255) / 256;
+    c->d_part_upd = c->alloc<double>(2 * (size_t)c->n_part_upd + 2);
+    std::vector<ReduceEntry> tab;
+    if (c->vis.n) {
+      tab.push_back({c->vis.cost_part, c->vis.n_cost_part, 1, 0, SC_COST_X});
+      tab.push_back({c->vis.cost_part_cand, c->vis.n_cost_part, 1, 0, SC_COST_CAND});
+      tab.push_back({c->vis.mcc_part, c->vis.n_cost_part, 1, 0, SC_MCC});
+    }
+    for (int t = 2; t < kNumInternal; ++t) {
+      if (!c->small[t].n) continue;
+      tab.push_back({c->d_small_part[t], c->small[t].n, 1, 0, SC_COST_X});
+      tab.push_back({c->d_small_part_cand[t], c->small[t].n, 1, 0, SC_COST_CAND});
+      tab.push_back({c->d_small_part_mcc[t], (c->small[t].n * c->small[t].m + 127) / 128, 1, 0, SC_MCC});   // one partial per workgroup of small_mcc_kernel
+    }
+    for (const auto& mc : c->marg) {
+      if (!mc.active) continue;
+      tab.push_back({mc.part, mc.dev.rows, 1, 0, SC_COST_X});
+      tab.push_back({mc.part_cand, mc.dev.rows, 1, 0, SC_COST_CAND});
+      tab.push_back({mc.part_mcc, mc.dev.rows, 1, 0, SC_MCC});
+    }
+    tab.push_back({c->d_part_upd, c->n_part_upd, 2, 0, SC_STEP_NORM2});
+    tab.push_back({c->d_part_upd, c->n_part_upd, 2, 1, SC_X_NORM2});
+    c->n_reduce = (int)tab.size();
+    c->d_reduce = c->upload(tab);
+  }
+  lap("plan + reduce table");
+  HIPCHK(c, hipDeviceSynchronize());
+  HIPCHK(c, hipGetLastError());
+  lap("device sync");
+  c->finalized = true;
+  return BSGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// device steps of one LM iteration
+// ---------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------
+// block-sparse structure of the pose-only normal equations (3x3 blocks), built on first use
+// ---------------------------------------------------------------------------------------------------
+int build_bsr(bsgpu_ctx* c) {
+  if (c->bsr_built) return BSGPU_OK;
+  if (c->vis.n > 0)
+    return fail(c, BSGPU_ERR_UNSUPPORTED, c->dense_ok ? "PCG path covers pose-only problems; landmark problems use the Schur + dense path"
+                                                      : "window too large: the reduced camera system exceeds the 12288 dimensions of the dense Schur path (819 keyframes of 15-d states) and the PCG path covers pose-only problems");
+  if (!c->marginals.empty()) return fail(c, BSGPU_ERR_UNSUPPORTED, "PCG path does not take dense marginal factors");
+  for (int b = 0; b < c->nb; ++b)
+    if (!c->is_const[b] && c->tsize[b] != 3) return fail(c, BSGPU_ERR_UNSUPPORTED, "PCG path needs 3-dimensional tangent blocks");
+  const int nbr = c->n_pose / 3;
+  std::vector<uint64_t> keys;
+  for (int b = 0; b < nbr; ++b) keys.push_back(((uint64_t)b << 32) | (uint32_t)b);
+  for (int t = 2; t < kNumInternal; ++t) {
+    const HostGroup& g = c->groups[t];
+    const TypeInfo& ti = kTypes[t];
+    for (int f = 0; f < g.n; ++f) {
+      if (!c->h_small_active[t][f]) continue;
+      const int32_t* idx = &g.idx[(size_t)f * ti.nidx];
+      for (int sa = 0; sa < ti.nvar; ++sa) for (int sb = 0; sb < ti.nvar; ++sb) {
+        const int ra = c->toff[idx[sa]], rb = c->toff[idx[sb]];
+        if (ra < 0 || rb < 0) continue;
+        keys.push_back(((uint64_t)(ra / 3) << 32) | (uint32_t)(rb / 3));
+      }
+    }
+  }
+  std::sort(keys.begin(), keys.end());
+  keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+  const int nblk = (int)keys.size();
+  std::vector<int> row_ptr(nbr + 1, 0), col(nblk), diag_slot(nbr, -1);
+  for (int i = 0; i < nblk; ++i) {
+    const int r = (int)(keys[i] >> 32), cc = (int)(keys[i] & 0xffffffffu);
+    row_ptr[r + 1]++; col[i] = cc;
+    if (r == cc) diag_slot[r] = i;
+  }
+  for (int r = 0; r < nbr; ++r) row_ptr[r + 1] += row_ptr[r];
+  for (int t = 2; t < kNumInternal; ++t) {
+    const HostGroup& g = c->groups[t];
+    const TypeInfo& ti = kTypes[t];
+    if (!g.n) continue;
+    std::vector<int> slots((size_t)g.n * ti.nvar * ti.nvar, -1);
+    for (int f = 0; f < g.n; ++f) {
+      const int32_t* idx = &g.idx[(size_t)f * ti.nidx];
+      for (int sa = 0; sa < ti.nvar; ++sa) for (int sb = 0; sb < ti.nvar; ++sb) {
+        const int ra = c->toff[idx[sa]], rb = c->toff[idx[sb]];
+        if (ra < 0 || rb < 0 || !c->h_small_active[t][f]) continue;
+        const uint64_t key = ((uint64_t)(ra / 3) << 32) | (uint32_t)(rb / 3);
+        slots[((size_t)f * ti.nvar + sa) * ti.nvar + sb] = (int)(std::lower_bound(keys.begin(), keys.end(), key) - keys.begin());
+      }
+    }
+    c->d_slots[t] = c->upload(slots);
+  }
+  c->nbr = nbr; c->nblk = nblk;
+  c->d_row_ptr = c->upload(row_ptr); c->d_col = c->upload(col); c->d_diag_slot = c->upload(diag_slot);
+  c->d_val = c->alloc<double>((size_t)nblk * 9); c->d_Minv = c->alloc<double>((size_t)nbr * 9);
+  c->d_rhs = c->alloc<double>(c->n_pose);
+  c->d_px = c->alloc<double>(c->n_pose); c->d_pr = c->alloc<double>(c->n_pose); c->d_pz = c->alloc<double>(c->n_pose);
+  c->d_pp = c->alloc<double>(c->n_pose); c->d_pp1 = c->alloc<double>(c->n_pose); c->d_pq = c->alloc<double>(c->n_pose);
+  c->d_ppart = c->alloc<double>((size_t)pcg_spmv_grid(nbr) + 8); c->d_ppart2 = c->alloc<double>(4 * ((size_t)(nbr + 255) / 256) + 8);
+  c->d_psc = c->alloc<double>(pcg_num_scalars());
+  if (!c->d_val || !c->d_pq || !c->d_psc) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (block-sparse system)");
+  c->bsr_built = true;
+  return BSGPU_OK;
+}
+
+}  // namespace bsg

@@ -1,4 +1,4 @@
-// Internal declarations shared by the host driver (bsgpu_api.cpp) and the HIP kernels
+// Internal declarations shared by the host driver (bsgpu_finalize.cpp, bsgpu_solve.cpp, bsgpu_api.cpp) and the HIP kernels
 // (bsgpu_kernels.hip) of libbsgpu.so.  gfx950 only.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -1,0 +1,422 @@
+// solve(): [EXT] ceres::Solve with TRUST_REGION / LEVENBERG_MARQUARDT / SPARSE_NORMAL_CHOLESKY as the reference configures it
+// (beam_slam_launch/config/vio.yaml:7-17) — a restatement of Ceres' TrustRegionMinimizer + LevenbergMarquardtStrategy that drives
+// the device kernels: one host<->device round trip per LM iteration, hidden under the evaluation at the candidate.
+#include "bsgpu_ctx.h"
+
+namespace bsg {
+
+void assemble_pcg(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, bool first) {
+  hipStream_t s = c->stream;
+  launch_zero(s, c->d_val, (int64_t)c->nblk * 9);
+  launch_zero(s, c->d_rhs, c->n_pose);
+  launch_zero(s, c->d_grad, c->n_pose);
+  launch_zero(s, c->d_hdiag, c->n_pose);
+  for (int t = 2; t < kNumInternal; ++t)
+    launch_bsr_assemble(s, c->small[t], c->d_slots[t], c->d_val, c->d_rhs, c->d_grad, c->d_hdiag);
+  launch_bsr_finish_diag(s, c->nbr, c->d_diag_slot, c->d_val, c->d_hdiag, radius, first ? 1 : 0, new_J ? 1 : 0, o.jacobi_scaling,
+                         o.min_lm_diagonal, o.max_lm_diagonal, c->d_scale, c->d_dcl, c->d_Minv);
+  if (new_J) {
+    launch_grad_norms(s, c->nb, c->d_blk_xoff, c->d_blk_toff, c->d_blk_size, c->d_blk_manifold, c->d_x, c->d_grad, c->d_scal);
+  }
+}
+
+// (H + Lambda) y = g by block-Jacobi PCG; the stop test lives on the device, the host looks at it every 20 iterations
+void pcg_solve(bsgpu_ctx* c, const bsgpu_options& o) {
+  hipStream_t s = c->stream;
+  launch_pcg_init(s, c->nbr, c->d_rhs, c->d_Minv, c->d_px, c->d_pr, c->d_pz, c->d_pp, c->d_pp1, c->d_ppart2, c->d_psc);
+  const double tol2 = o.pcg_tolerance * o.pcg_tolerance;
+  const int max_it = o.pcg_max_iterations > 0 ? o.pcg_max_iterations : 2000;
+  const int ns = pcg_num_scalars();
+  if (!c->h_pcg && hipHostMalloc((void**)&c->h_pcg, sizeof(double) * 2 * ns) != hipSuccess) { c->h_pcg = nullptr; (void)hipGetLastError(); }
+  for (hipEvent_t& e : c->pcg_ev)
+    if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; (void)hipGetLastError(); }
+  const bool pipelined = c->h_pcg && c->pcg_ev[0] && c->pcg_ev[1];
+  // The stop flag lives on the device and is sticky; the host looks at it once per chunk of iterations.  The read-back of
+  // chunk n is waited for only after chunk n+1 has been enqueued, so the stream never drains while the host decides
+  // (a blocking check per chunk left the device idle ~28 us each time); the iterations enqueued past convergence see the
+  // flag and do nothing.
+  const int kChunk = 12;
+  double last[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto enqueue_chunk = [&](int it0, int n, int slot) {
+    for (int k = 0; k < n; ++k)
+      launch_pcg_iteration(s, it0 + k, c->nbr, c->d_row_ptr, c->d_col, c->d_val, c->d_Minv, c->d_px, c->d_pr, c->d_pz, c->d_pp, c->d_pp1,
+                           c->d_pq, c->d_ppart, c->d_ppart2, c->d_psc, tol2);
+    if (pipelined) {
+      (void)hipMemcpyAsync(c->h_pcg + slot * ns, c->d_psc, sizeof(double) * ns, hipMemcpyDeviceToHost, s);
+      (void)hipEventRecord(c->pcg_ev[slot], s);
+    }
+  };
+  if (!pipelined) {
+    for (int it = 0; it < max_it;) {
+      const int chunk = std::min(20, max_it - it);
+      enqueue_chunk(it, chunk, 0);
+      it += chunk;
+      (void)hipMemcpyAsync(last, c->d_psc, sizeof(double) * ns, hipMemcpyDeviceToHost, s);
+      (void)hipStreamSynchronize(s);
+      if (last[pcg_done_slot()] != 0.0) break;
+    }
+  } else {
+    int it = std::min(kChunk, max_it), slot = 0;
+    enqueue_chunk(0, it, slot);
+    for (;;) {
+      int next_n = std::min(kChunk, max_it - it);
+      if (next_n > 0) enqueue_chunk(it, next_n, slot ^ 1);
+      (void)hipEventSynchronize(c->pcg_ev[slot]);
+      std::memcpy(last, c->h_pcg + slot * ns, sizeof(double) * ns);
+      if (last[pcg_done_slot()] != 0.0 || next_n <= 0) {
+        if (next_n > 0) {   // the chunk in flight: let it drain so that its read-back does not land in a later solve's slot
+          (void)hipEventSynchronize(c->pcg_ev[slot ^ 1]);
+          std::memcpy(last, c->h_pcg + (slot ^ 1) * ns, sizeof(double) * ns);
+        }
+        break;
+      }
+      it += next_n;
+      slot ^= 1;
+    }
+  }
+  c->pcg_iters_total += (int)last[pcg_iters_slot()];
+}
+
+// residuals (+ Jacobians) of every factor group; per-group cost partials go to the arrays the
+// end-of-step reduction sums (current point: slot SC_COST_X, candidate: SC_COST_CAND)
+void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot) {
+  hipStream_t s = c->stream;
+  const bool cand = slot == SC_COST_CAND;
+  if (c->vis.n) launch_reproj_eval(s, c->vis, x, c->d_cams, c->d_losses, with_J, cand ? c->vis.cost_part_cand : c->vis.cost_part);
+  const bool imu_pair = c->small[BSGPU_F_IMU_DELTA].n > 0 && c->small[BSGPU_F_IMU_PRIOR].n > 0;
+  if (imu_pair)
+    launch_imu_eval(s, c->small[BSGPU_F_IMU_DELTA], c->small[BSGPU_F_IMU_PRIOR], x, c->d_losses, with_J,
+                    cand ? c->d_small_part_cand[BSGPU_F_IMU_DELTA] : c->d_small_part[BSGPU_F_IMU_DELTA],
+                    cand ? c->d_small_part_cand[BSGPU_F_IMU_PRIOR] : c->d_small_part[BSGPU_F_IMU_PRIOR]);
+  for (int t = 2; t < kNumInternal; ++t) {
+    if (imu_pair && (t == BSGPU_F_IMU_DELTA || t == BSGPU_F_IMU_PRIOR)) continue;
+    if (c->small[t].n) launch_small_eval(s, c->small[t], x, c->d_losses, with_J, cand ? c->d_small_part_cand[t] : c->d_small_part[t]);
+  }
+  for (const auto& mc : c->marg)
+    if (mc.active) launch_marg_eval(s, mc.dev, x, with_J, cand ? mc.part_cand : mc.part);
+}
+void final_reduce(bsgpu_ctx* c) {
+  launch_final_reduce(c->stream, c->d_reduce, c->n_reduce, SC_X_NORM2 + 1, c->d_scal, c->h_scal_dev);
+  c->scal_mirrored = c->h_scal_dev != nullptr && c->n_reduce > 0;
+  if (!c->ev_reduce && hipEventCreateWithFlags(&c->ev_reduce, hipEventDisableTiming) != hipSuccess) { c->ev_reduce = nullptr; (void)hipGetLastError(); }
+  c->ev_reduce_pending = c->scal_mirrored && c->ev_reduce && hipEventRecord(c->ev_reduce, c->stream) == hipSuccess;
+}
+
+void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, bool first) {
+  if (c->use_pcg) { assemble_pcg(c, o, radius, new_J, first); return; }
+  hipStream_t s = c->stream;
+  // one launch clears the reduced system, gradient, diagonal and the scalars of this step (GRAD_MAX, GRAD_NORM2, CHOL_FAIL)
+  // ... and carries the radius of this step (not under graph replay, whose kernel arguments are frozen)
+  launch_zero_multi(s, c->d_S, (int64_t)c->npad * c->npad, c->d_grad, c->n_pose, c->d_hdiag, c->n_pose,
+                    new_J ? c->d_scal + SC_GRAD_MAX : c->d_scal + SC_CHOL_FAIL, new_J ? 3 : 1,
+                    c->use_graphs ? nullptr : c->d_scal + SC_RADIUS, radius);
+  c->scal_mirrored = false;
+  launch_landmark(s, c->vis, c->n_pose, c->d_scal + SC_RADIUS, first ? 1 : 0, new_J ? 1 : 0, o.jacobi_scaling, o.min_lm_diagonal,
+                  o.max_lm_diagonal, c->d_scale, c->d_dcl, c->d_grad);
+  launch_pairs(s, c->vis, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm);
+  launch_small_assemble_set(s, c->small + 2, kNumInternal - 2, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm);
+  for (const auto& mc : c->marg)
+    if (mc.active) launch_marg_assemble(s, mc.dev, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm);
+  if (new_J)   // the LM diagonal and the gradient norms both follow the assembly and do not depend on each other: one launch
+    launch_grad_norms_pose_diag(s, c->nb, c->d_blk_xoff, c->d_blk_toff, c->d_blk_size, c->d_blk_manifold, c->d_x, c->d_grad, c->d_scal,
+                                c->n_pose, c->d_S, c->npad, c->d_hdiag, c->d_scal + SC_RADIUS, first ? 1 : 0, 1, o.jacobi_scaling,
+                                o.min_lm_diagonal, o.max_lm_diagonal, c->d_scale, c->d_dcl, c->npad, c->d_iperm);
+  else
+    launch_pose_diag(s, c->n_pose, c->d_S, c->npad, c->d_hdiag, c->d_scal + SC_RADIUS, 0, 0, o.jacobi_scaling,
+                     o.min_lm_diagonal, o.max_lm_diagonal, c->d_scale, c->d_dcl, c->npad, c->d_iperm);
+}
+
+void dense_factor(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* scal) {
+  const int ld = P.npad;
+  for (int st = 0; st < P.n_steps(); ++st) {
+    // (tiles no look-ahead factors are factored inside the panel step itself: PanelDesc::self_potrf)
+    launch_chol_panel_step(s, S, D.Lp, ld, D.panels + P.step_off[st], P.step_off[st + 1] - P.step_off[st], P.step_maxrows[st],
+                           D.rows_flat, D.nreal, D.Vinv, scal, D.tile_sync, P.panels.data() + P.step_off[st], P.rows_flat.data());
+  }
+}
+void dense_factor_solve(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* y, double* scal) {
+  const int ld = P.npad;
+  dense_factor(s, P, D, S, scal);
+  // y' = the rhs row after forward substitution: row rhs_row of the shadow matrix (the rhs tile is an
+  // off-diagonal row tile of every panel)
+  const double* rhs_row = D.Lp + (size_t)P.rhs_row * ld;
+  const bool single_root = P.bs_group_off.size() > 1 && P.bs_group_off[1] - P.bs_group_off[0] == 1;
+  if (!single_root) launch_copy(s, rhs_row, y, (int64_t)P.T * 64, 64);   // (a single root chain copies it itself on the way)
+  // one launch per group of chains: root separator, the separator levels below it, then every piece (dense_plan.h)
+  for (size_t g = 0; g + 1 < P.bs_group_off.size(); ++g) {
+    const int c0 = P.bs_group_off[g], c1 = P.bs_group_off[g + 1];
+    int max_len = 1;
+    for (int i = c0; i < c1; ++i) max_len = std::max(max_len, P.chain_end[i] - P.chain_begin[i]);
+    launch_chol_backsolve_chains(s, S, D.Lp, D.Vinv, ld, D.panels, D.panel_of_tile, D.chain_begin + c0, D.chain_end + c0, c1 - c0,
+                                 D.rows_flat, D.nreal, y, P.npad, max_len, (g == 0 && single_root) ? rhs_row : nullptr);
+  }
+}
+
+void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
+  hipStream_t s = c->stream;
+  if (c->use_pcg) {
+    pcg_solve(c, o);
+    launch_negate_pose(s, c->n_pose, c->d_px, c->d_delta);
+  } else if (c->n_pose > 0) {
+    const DenseDev D{c->d_perm, c->d_nreal, c->d_rows_flat, c->d_panels, c->d_Lp, c->d_Vinv,
+                     c->d_panel_of_tile, c->d_chain_begin, c->d_chain_end, c->d_tile_sync};
+    dense_factor_solve(s, c->plan, D, c->d_S, c->d_y, c->d_scal);
+    launch_y_to_delta(s, c->n_pose, c->d_y, c->d_perm, c->d_ytan, c->d_delta);
+  }
+  launch_backsub_landmarks(s, c->vis, c->n_pose, c->d_ytan, c->d_delta);
+  // model cost change terms, candidate point and its cost: partial arrays only, summed once at the end
+  if (c->vis.n) launch_mcc(s, c->vis, c->n_pose, c->d_delta, c->vis.mcc_part);
+  launch_small_mcc_set(s, c->small + 2, c->d_small_part_mcc + 2, kNumInternal - 2, c->d_delta);
+  for (const auto& mc : c->marg)
+    if (mc.active) launch_marg_mcc(s, mc.dev, c->d_delta, mc.part_mcc);
+  int n_part = 0;
+  launch_update(s, c->nb, c->d_blk_xoff, c->d_blk_toff, c->d_blk_size, c->d_blk_manifold, c->d_x, c->d_delta, c->d_xcand,
+                c->d_part_upd, &n_part);
+  eval_all(c, c->d_xcand, false, SC_COST_CAND);
+  final_reduce(c);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// one LM step = [x <- x_cand] [evaluate J] assemble -> factor -> back-substitute -> candidate -> cost.
+// The three variants are captured once per finalized problem as hipGraphs and replayed: the host-side
+// launch cost (~4.5 us per kernel, > 100 kernels per step) otherwise bounds the iteration rate.
+// ---------------------------------------------------------------------------------------------------
+enum StepKind { STEP_FIRST = 0, STEP_ACCEPT = 1, STEP_REJECT = 2 };
+
+// gradient_only: the iteration budget is used up — the point just accepted still needs its cost and gradient norms for the
+// iteration record, but no step will be taken from it: evaluation + assembly (which produces the gradient), no factorisation,
+// no candidate
+void enqueue_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius, bool gradient_only = false) {
+  hipStream_t s = c->stream;
+  if (kind == STEP_ACCEPT) {
+    // the accepted candidate becomes the current point: a pointer swap (every launch takes x as an argument; the next update
+    // rewrites all of the other buffer) — except under graph replay, whose kernel arguments are frozen
+    if (c->use_graphs) launch_copy(s, c->d_xcand, c->d_x, (int64_t)c->h_x.size(), 0);
+    else std::swap(c->d_x, c->d_xcand);
+  }
+  // Jacobians at the current point: new for a first / accepted step — unless they were evaluated ahead at the candidate that has
+  // just been accepted (below) — and to be restored for a rejected one if that evaluation overwrote them
+  const bool have_J = (kind == STEP_ACCEPT && c->spec_J) || (kind == STEP_REJECT && !c->spec_J);
+  if (!have_J) eval_all(c, c->d_x, true, SC_COST_X);
+  c->spec_J = false;
+  assemble(c, o, radius, kind != STEP_REJECT, kind == STEP_FIRST);
+  if (gradient_only) { final_reduce(c); return; }
+  linear_solve_and_candidate(c, o);
+  // The host now waits for this step's scalars and decides; in the common case (accepted) the next thing the device needs is the
+  // residuals and Jacobians at the candidate: evaluated ahead, underneath the host round trip (~26 us per iteration otherwise
+  // idle).  A rejected step pays for it with a re-evaluation at the current point (above).
+  if (!c->use_graphs) {
+    eval_all(c, c->d_xcand, true, SC_COST_X);
+    c->spec_J = true;
+  }
+}
+
+bool same_graph_options(const bsgpu_options& a, const bsgpu_options& b) {
+  return a.jacobi_scaling == b.jacobi_scaling && a.min_lm_diagonal == b.min_lm_diagonal && a.max_lm_diagonal == b.max_lm_diagonal;
+}
+
+void build_graphs(bsgpu_ctx* c, const bsgpu_options& o) {
+  if (c->graphs_tried && same_graph_options(o, c->graph_opts)) return;
+  c->destroy_graphs();
+  c->graphs_tried = true;
+  c->graph_opts = o;
+  if (!c->use_graphs || c->use_pcg) return;   // the PCG path synchronises inside a step: stays eager
+  hipGraphExec_t* execs[3] = {&c->g_first, &c->g_accept, &c->g_reject};
+  for (int kind = 0; kind < 3; ++kind) {
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return; }
+    enqueue_step(c, o, kind, 1.0);
+    if (hipStreamEndCapture(c->stream, &graph) != hipSuccess || !graph) { (void)hipGetLastError(); c->destroy_graphs(); c->graphs_tried = true; return; }
+    const hipError_t e = hipGraphInstantiate(execs[kind], graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) { (void)hipGetLastError(); c->destroy_graphs(); c->graphs_tried = true; return; }
+  }
+  c->graphs_ok = true;
+  if (getenv("BSGPU_TIMING")) fprintf(stderr, "[bsgpu] LM step captured as hipGraphs\n");
+}
+
+void run_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius, bool gradient_only = false) {
+  if (c->use_graphs) {   // replayed kernels read the radius from device memory
+    *c->h_radius = radius;
+    (void)hipMemcpyAsync(c->d_scal + SC_RADIUS, c->h_radius, sizeof(double), hipMemcpyHostToDevice, c->stream);
+  }
+  if (c->graphs_ok && !gradient_only) {
+    hipGraphExec_t g = kind == STEP_FIRST ? c->g_first : kind == STEP_ACCEPT ? c->g_accept : c->g_reject;
+    if (hipGraphLaunch(g, c->stream) == hipSuccess) return;
+    (void)hipGetLastError();
+    c->graphs_ok = false;   // fall back to eager launches of the same kernels
+  }
+  enqueue_step(c, o, kind, radius, gradient_only);
+}
+
+// sorted visual position -> source factor: built on the host, or downloaded on first use when the device flattened the window
+int ensure_vis_src(bsgpu_ctx* c) {
+  if ((int)c->vis_src.size() == c->vis.n || !c->d_vis_src) return BSGPU_OK;
+  c->vis_src.resize(c->vis.n);
+  HIPCHK(c, hipMemcpy(c->vis_src.data(), c->d_vis_src, sizeof(int) * (size_t)c->vis.n, hipMemcpyDeviceToHost));
+  return BSGPU_OK;
+}
+
+int fetch_scalars(bsgpu_ctx* c) {
+  HIPCHK(c, hipGetLastError());  // a kernel that failed to launch must not pass silently
+  if (c->scal_mirrored && c->ev_reduce_pending) {
+    HIPCHK(c, hipEventSynchronize(c->ev_reduce));   // the step's scalars are in the pinned mirror; kernels queued behind the reduction keep running
+  } else {
+    if (!c->scal_mirrored) HIPCHK(c, hipMemcpyAsync(c->h_scal, c->d_scal, sizeof(double) * SC_NUM, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  c->scal_mirrored = false; c->ev_reduce_pending = false;
+  return BSGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// [EXT] ceres::internal::TrustRegionMinimizer + LevenbergMarquardtStrategy, restated
+// ---------------------------------------------------------------------------------------------------
+int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
+  using clk = std::chrono::steady_clock;
+  const auto t_start = clk::now();
+  auto elapsed = [&]() { return std::chrono::duration<double>(clk::now() - t_start).count(); };
+  int rc = finalize(c);
+  if (rc != BSGPU_OK) return rc;
+  HIPCHK(c, hipSetDevice(c->device));
+  std::memset(&sum, 0, sizeof(sum));
+  c->iters.clear();
+  sum.num_parameters_tangent = c->n_tan;
+  sum.num_residuals = c->n_res;
+  c->use_pcg = (o.linear_solver_type == BSGPU_LINEAR_PCG) || (o.linear_solver_type == BSGPU_LINEAR_AUTO && !c->dense_ok);
+  if (!c->use_pcg && !c->dense_ok)
+    return fail(c, BSGPU_ERR_UNSUPPORTED, "reduced system larger than 12288: the dense exact path does not apply; use BSGPU_LINEAR_AUTO or BSGPU_LINEAR_PCG");
+  if (c->use_pcg) { rc = build_bsr(c); if (rc != BSGPU_OK) return rc; }
+  c->pcg_iters_total = 0;
+  sum.linear_solver_used = c->use_pcg ? BSGPU_LINEAR_PCG : BSGPU_LINEAR_SCHUR_CHOLESKY;
+  hipStream_t s = c->stream;
+  hipEvent_t ev0, ev1;
+  HIPCHK(c, hipEventCreate(&ev0)); HIPCHK(c, hipEventCreate(&ev1));
+  HIPCHK(c, hipEventRecord(ev0, s));
+
+  // iteration zero
+  double fixed = 0.0;
+  if (c->any_inactive) {
+    // cost of residual blocks whose parameter blocks are all constant (Ceres: fixed_cost)
+    launch_zero(s, c->d_scal + SC_FIXED_COST, 1);
+    for (int t = 2; t < kNumInternal; ++t) {
+      if (!c->small[t].n) continue;
+      SmallGroup g = c->small[t];
+      g.active = c->d_small_inactive[t];
+      launch_small_eval(s, g, c->d_x, c->d_losses, false, c->d_small_part[t]);
+      launch_sum(s, c->d_small_part[t], g.n, c->d_scal + SC_FIXED_COST, 1);
+    }
+    for (const auto& mc : c->marg) {
+      if (mc.active) continue;
+      launch_marg_eval(s, mc.dev, c->d_x, false, mc.part);
+      launch_sum(s, mc.part, mc.dev.rows, c->d_scal + SC_FIXED_COST, 1);
+    }
+    if (c->vis_any_inactive) {   // reprojection factors whose three blocks are all constant
+      launch_reproj_eval(s, c->vis, c->d_x, c->d_cams, c->d_losses, false, c->vis.cost_part_cand, true);
+      launch_sum(s, c->vis.cost_part_cand, c->vis.n_cost_part, c->d_scal + SC_FIXED_COST, 1);
+    }
+  }
+  double radius = o.initial_trust_region_radius, decrease_factor = 2.0;
+  build_graphs(c, o);
+  run_step(c, o, STEP_FIRST, radius);
+  rc = fetch_scalars(c);
+  if (rc != BSGPU_OK) return rc;
+  fixed = c->any_inactive ? c->h_scal[SC_FIXED_COST] : 0.0;
+  double x_cost = c->h_scal[SC_COST_X];
+  bsgpu_iteration it;
+  std::memset(&it, 0, sizeof(it));
+  it.iteration = 0; it.step_is_valid = 1; it.step_is_successful = 1; it.cost = x_cost + fixed;
+  it.gradient_max_norm = c->h_scal[SC_GRAD_MAX]; it.gradient_norm = std::sqrt(c->h_scal[SC_GRAD_NORM2]);
+  sum.initial_cost = x_cost + fixed; sum.fixed_cost = fixed;
+  sum.termination_type = BSGPU_NO_CONVERGENCE;
+  const char* msg = "";
+  if (!std::isfinite(x_cost)) {
+    sum.termination_type = BSGPU_FAILURE; msg = "Initial cost is not finite.";
+    sum.final_cost = sum.initial_cost;
+  } else {
+    int num_consecutive_invalid = 0;
+    // `pending` = a step (linear solve + candidate evaluation) has been computed for the current x/radius
+    while (true) {
+      if (it.step_is_successful) { if (it.iteration > 0) sum.num_successful_steps++; } else sum.num_unsuccessful_steps++;
+      it.trust_region_radius = radius;
+      c->iters.push_back(it);
+      if (o.max_solver_time_in_seconds > 0 && elapsed() >= o.max_solver_time_in_seconds) { msg = "Maximum solver time reached."; break; }
+      if (it.iteration >= o.max_num_iterations) { msg = "Maximum number of iterations reached."; break; }
+      if (it.step_is_successful && it.gradient_max_norm <= o.gradient_tolerance) { sum.termination_type = BSGPU_CONVERGENCE; msg = "Gradient tolerance reached."; break; }
+      if (radius <= o.min_trust_region_radius) { sum.termination_type = BSGPU_CONVERGENCE; msg = "Minimum trust region radius reached."; break; }
+      const bsgpu_iteration prev = it;
+      std::memset(&it, 0, sizeof(it));
+      it.iteration = prev.iteration + 1;
+      it.gradient_max_norm = prev.gradient_max_norm; it.gradient_norm = prev.gradient_norm;
+      sum.num_linear_solves++;
+      // the step for (x, radius) is already on the host: h_scal
+      const double mcc = c->h_scal[SC_MCC];
+      const bool lin_ok = !(c->h_scal[SC_CHOL_FAIL] > 0.0) && std::isfinite(mcc) && std::isfinite(c->h_scal[SC_STEP_NORM2]);
+      it.model_cost_change = lin_ok ? mcc : 0.0;
+      it.step_is_valid = lin_ok && mcc > 0.0;
+      if (!it.step_is_valid) {
+        if (++num_consecutive_invalid >= o.max_num_consecutive_invalid_steps) {
+          sum.termination_type = BSGPU_FAILURE;
+          msg = "Number of consecutive invalid steps more than max_num_consecutive_invalid_steps.";
+          break;
+        }
+        radius = radius / decrease_factor; decrease_factor *= 2.0;
+        it.cost = x_cost + fixed; it.step_is_successful = 0;
+        if (it.iteration >= o.max_num_iterations) continue;   // the loop ends at its top: a step from here would never be looked at
+        run_step(c, o, STEP_REJECT, radius);
+        rc = fetch_scalars(c);
+        if (rc != BSGPU_OK) return rc;
+        continue;
+      }
+      num_consecutive_invalid = 0;
+      double cand_cost = c->h_scal[SC_COST_CAND];
+      if (!std::isfinite(cand_cost)) cand_cost = std::numeric_limits<double>::max();
+      it.step_norm = std::sqrt(c->h_scal[SC_STEP_NORM2]);
+      const double x_norm = std::sqrt(c->h_scal[SC_X_NORM2]);
+      if (it.step_norm <= o.parameter_tolerance * (x_norm + o.parameter_tolerance)) { sum.termination_type = BSGPU_CONVERGENCE; msg = "Parameter tolerance reached."; break; }
+      it.cost_change = x_cost - cand_cost;
+      if (std::fabs(it.cost_change) <= o.function_tolerance * x_cost) { sum.termination_type = BSGPU_CONVERGENCE; msg = "Function tolerance reached."; break; }
+      it.relative_decrease = (x_cost - cand_cost) / mcc;
+      const bool last_iteration = it.iteration >= o.max_num_iterations;
+      if (it.relative_decrease > o.min_relative_decrease) {
+        radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * it.relative_decrease - 1.0, 3));
+        radius = std::min(o.max_trust_region_radius, radius);
+        decrease_factor = 2.0;
+        it.step_is_successful = 1;
+        // the next step is computed right away so that one synchronisation per iteration suffices; when this was the last
+        // iteration the budget allows, only the accepted point's cost and gradient are (a full step would be thrown away)
+        run_step(c, o, STEP_ACCEPT, radius, last_iteration);
+      } else {
+        it.step_is_successful = 0;
+        radius = radius / decrease_factor; decrease_factor *= 2.0;
+        it.cost = cand_cost + fixed;
+        if (last_iteration) continue;
+        run_step(c, o, STEP_REJECT, radius);
+      }
+      rc = fetch_scalars(c);
+      if (rc != BSGPU_OK) return rc;
+      if (it.step_is_successful) {
+        x_cost = c->h_scal[SC_COST_X];
+        it.cost = x_cost + fixed;
+        it.gradient_max_norm = c->h_scal[SC_GRAD_MAX];
+        it.gradient_norm = std::sqrt(c->h_scal[SC_GRAD_NORM2]);
+      }
+    }
+    sum.final_cost = x_cost + fixed;
+  }
+  HIPCHK(c, hipEventRecord(ev1, s));
+  HIPCHK(c, hipEventSynchronize(ev1));
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, ev0, ev1);
+  (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+  sum.device_time_in_seconds = ms * 1e-3;
+  c->scal_mirrored = false; c->ev_reduce_pending = false; c->spec_J = false;   // (the stream has drained: nothing of this solve is pending)
+  sum.num_iterations = (int)c->iters.size() - 1;
+  sum.num_inner_iterations = c->pcg_iters_total;
+  sum.is_solution_usable = (sum.termination_type == BSGPU_CONVERGENCE || sum.termination_type == BSGPU_NO_CONVERGENCE) ? 1 : 0;
+  sum.total_time_in_seconds = elapsed();
+  std::snprintf(sum.message, sizeof(sum.message), "%s", msg);
+  return BSGPU_OK;
+}
+
+}  // namespace bsg
