@@ -98,6 +98,8 @@ void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot) {
 void final_reduce(bsgpu_ctx* c) {
   launch_final_reduce(c->stream, c->d_reduce, c->n_reduce, SC_X_NORM2 + 1, c->d_scal, c->h_scal_dev);
   c->scal_mirrored = c->h_scal_dev != nullptr && c->n_reduce > 0;
+  // (not under graph capture / replay: an event recorded while capturing is a graph node, not something the host can wait on)
+  if (c->use_graphs) { c->ev_reduce_pending = false; return; }
   if (!c->ev_reduce && hipEventCreateWithFlags(&c->ev_reduce, hipEventDisableTiming) != hipSuccess) { c->ev_reduce = nullptr; (void)hipGetLastError(); }
   c->ev_reduce_pending = c->scal_mirrored && c->ev_reduce && hipEventRecord(c->ev_reduce, c->stream) == hipSuccess;
 }

@@ -41,6 +41,8 @@ def _random_case(seed):
 def test_random_structure(oracle_cls, gpu_solver_cls, seed, monkeypatch):
     if seed % 8 == 4:
         monkeypatch.setenv("BSGPU_FLATTEN", "device")     # small windows through the device-side flattening as well
+    if seed % 8 == 6:
+        monkeypatch.setenv("BSGPU_GRAPH", "1")            # the LM step replayed as captured hipGraphs (off by default)
     pr = _random_case(seed)
     g, o = gpu_solver_cls(0), oracle_cls()
     pr.load(g); pr.load(o)
