@@ -127,7 +127,8 @@ struct bsgpu_ctx {
   std::vector<uint8_t> tile_adj;   // natural-tile adjacency of the reduced system
   int *d_perm = nullptr, *d_iperm = nullptr, *d_nreal = nullptr, *d_rows_flat = nullptr;
   PanelDesc* d_panels = nullptr;
-  int *d_panel_of_tile = nullptr, *d_chain_begin = nullptr, *d_chain_end = nullptr, *d_tile_sync = nullptr;
+  int *d_panel_of_tile = nullptr, *d_chain_begin = nullptr, *d_chain_end = nullptr, *d_tile_sync = nullptr, *d_touched = nullptr;
+  int n_touched = 0;
   double* d_Vinv = nullptr;
   double* d_Lp = nullptr;     // shadow of S holding the off-diagonal L panels (k_chol.hip)
   double* d_ytan = nullptr;   // y in tangent order

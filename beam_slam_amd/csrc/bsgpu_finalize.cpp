@@ -461,6 +461,8 @@ int finalize(bsgpu_ctx* c) {
   if (c->dense_ok) {
     c->d_S = c->alloc<double>((size_t)c->npad * c->npad);
     if (!c->d_S) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (reduced system)");
+    // cleared once here (the buffer comes from the pool); a step then clears only the tiles anything writes (plan.touched_tiles)
+    launch_zero(c->stream, c->d_S, (int64_t)c->npad * c->npad);
   }
   c->d_grad = c->alloc<double>(c->n_tan); c->d_hdiag = c->alloc<double>(c->n_tan);
   c->d_scale = c->alloc<double>(c->n_tan); c->d_dcl = c->alloc<double>(c->n_tan);
@@ -498,6 +500,7 @@ int finalize(bsgpu_ctx* c) {
     c->d_panels = c->upload(c->plan.panels);
     c->d_panel_of_tile = c->upload(c->plan.panel_of_tile);
     c->d_tile_sync = c->upload(c->plan.tile_sync);
+    c->d_touched = c->upload(c->plan.touched_tiles); c->n_touched = (int)c->plan.touched_tiles.size();
     c->d_chain_begin = c->upload(c->plan.chain_begin); c->d_chain_end = c->upload(c->plan.chain_end);
     c->d_Vinv = c->alloc<double>((size_t)std::max(1, T) * chol_vinv_stride());
     c->d_ytan = c->alloc<double>(std::max(1, c->n_pose));

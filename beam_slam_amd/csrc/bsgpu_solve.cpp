@@ -109,9 +109,9 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
   hipStream_t s = c->stream;
   // one launch clears the reduced system, gradient, diagonal and the scalars of this step (GRAD_MAX, GRAD_NORM2, CHOL_FAIL)
   // ... and carries the radius of this step (not under graph replay, whose kernel arguments are frozen)
-  launch_zero_multi(s, c->d_S, (int64_t)c->npad * c->npad, c->d_grad, c->n_pose, c->d_hdiag, c->n_pose,
-                    new_J ? c->d_scal + SC_GRAD_MAX : c->d_scal + SC_CHOL_FAIL, new_J ? 3 : 1,
-                    c->use_graphs ? nullptr : c->d_scal + SC_RADIUS, radius);
+  launch_zero_tiles_multi(s, c->d_S, c->npad, c->d_touched, c->n_touched, c->d_grad, c->n_pose, c->d_hdiag, c->n_pose,
+                          new_J ? c->d_scal + SC_GRAD_MAX : c->d_scal + SC_CHOL_FAIL, new_J ? 3 : 1,
+                          c->use_graphs ? nullptr : c->d_scal + SC_RADIUS, radius);
   c->scal_mirrored = false;
   launch_landmark(s, c->vis, c->n_pose, c->d_scal + SC_RADIUS, first ? 1 : 0, new_J ? 1 : 0, o.jacobi_scaling, o.min_lm_diagonal,
                   o.max_lm_diagonal, c->d_scale, c->d_dcl, c->d_grad);

@@ -29,6 +29,8 @@ struct DensePlan {
   int n_pose = 0, T = 0 /* real tiles */, npad = 0, rhs_row = 0;
   std::vector<int> perm;       // natural tile -> S tile
   std::vector<int> nreal;      // per S tile: number of real columns (64, or n_pose % 64 for the partial tile)
+  std::vector<int> touched_tiles;  // every tile (i * (T + 1) + j, both triangles) an assembly or the factorisation may write: the
+                                   // structural blocks, their fill, the rhs row and column, the diagonal — what a step has to clear
   std::vector<int> tile_sync;  // device image, 2 x (T + 1): [expected arrivals per tile | arrival counters (zero; the last arriver resets its own)]
   std::vector<int> rows_flat;  // row tiles of every panel (includes the rhs tile T)
   std::vector<PanelDesc> panels;        // in schedule order
@@ -127,6 +129,8 @@ struct DensePlan {
       for (int t = k + 1; t < N; ++t) if (B[(size_t)t * N + k]) rows[k].push_back(t);
       for (int a : rows[k]) for (int b : rows[k]) B[(size_t)a * N + b] = 1;  // fill
     }
+    touched_tiles.clear();
+    for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) if (B[(size_t)i * N + j] || B[(size_t)j * N + i] || i == j) touched_tiles.push_back(i * N + j);
     // ---- schedule: panel k depends on every panel j < k with k in rows(j); two panels sharing a row tile
     // (they would update the same C tiles) must not share a step
     std::vector<int> ready(T, 0);  // earliest step

@@ -205,6 +205,30 @@ __global__ __launch_bounds__(256) void zero_multi_kernel(double2* __restrict__ b
   for (int64_t i = t; i < nb; i += stride) b[i] = 0.0;
   for (int64_t i = t; i < nc; i += stride) c[i] = 0.0;
 }
+// the same for a reduced system of which only the listed 64x64 tiles are ever written (dense_plan.h: touched_tiles): a banded
+// window touches a fraction of the dense square (C2: 30 %; an 800-keyframe window: 7 %), the rest stays zero from finalize()
+__global__ __launch_bounds__(256) void zero_tiles_multi_kernel(double* __restrict__ S, int ld, const int* __restrict__ tiles, int n_tiles,
+                                                               double* __restrict__ a, int na, double* __restrict__ b, int nb,
+                                                               double* __restrict__ c, int nc, double* __restrict__ radius_slot, double radius) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+  if (radius_slot && t == 0) *radius_slot = radius;
+  const int nt = ld >> 6;
+  for (int q = blockIdx.x; q < n_tiles; q += gridDim.x) {
+    const int ti = tiles[q] / nt, tj = tiles[q] - ti * nt;
+    double2* base = reinterpret_cast<double2*>(S + (size_t)ti * 64 * ld + (size_t)tj * 64);
+    const int r0 = threadIdx.x >> 5, c2 = threadIdx.x & 31;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) base[(size_t)(r0 + 8 * p) * (ld >> 1) + c2] = make_double2(0.0, 0.0);
+  }
+  for (int64_t i = t; i < na; i += stride) a[i] = 0.0;
+  for (int64_t i = t; i < nb; i += stride) b[i] = 0.0;
+  for (int64_t i = t; i < nc; i += stride) c[i] = 0.0;
+}
+void launch_zero_tiles_multi(hipStream_t s, double* S, int ld, const int* tiles_dev, int n_tiles, double* a, int na, double* b, int nb, double* c,
+                             int nc, double* radius_slot, double radius) {
+  const int grid = std::max(1, std::min(n_tiles, 2048));
+  hipLaunchKernelGGL(zero_tiles_multi_kernel, dim3(grid), dim3(256), 0, s, S, ld, tiles_dev, n_tiles, a, na, b, nb, c, nc, radius_slot, radius);
+}
 void launch_zero_multi(hipStream_t s, double* big, int64_t nbig /* even, 16-byte aligned */, double* a, int na, double* b, int nb, double* c, int nc,
                        double* radius_slot, double radius) {
   const int64_t n2 = nbig / 2;
