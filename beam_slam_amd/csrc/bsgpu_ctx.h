@@ -225,6 +225,8 @@ struct DenseDev {
   int* tile_sync;   // [expected arrivals | arrival counters] per tile (dense_plan.h)
 };
 void dense_factor(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* scal);
-void dense_factor_solve(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* y, double* scal);
+// (iperm / y_tan / delta given: the back-substitution also writes the solution in tangent order and the step -y)
+void dense_factor_solve(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* y, double* scal, const int* iperm = nullptr,
+                        int n_pose = 0, double* y_tan = nullptr, double* delta = nullptr);
 
 }  // namespace bsg

@@ -136,7 +136,8 @@ void dense_factor(hipStream_t s, const DensePlan& P, const DenseDev& D, double* 
                            D.rows_flat, D.nreal, D.Vinv, scal, D.tile_sync, P.panels.data() + P.step_off[st], P.rows_flat.data());
   }
 }
-void dense_factor_solve(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* y, double* scal) {
+void dense_factor_solve(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* y, double* scal, const int* iperm, int n_pose,
+                        double* y_tan, double* delta) {
   const int ld = P.npad;
   dense_factor(s, P, D, S, scal);
   // y' = the rhs row after forward substitution: row rhs_row of the shadow matrix (the rhs tile is an
@@ -150,7 +151,7 @@ void dense_factor_solve(hipStream_t s, const DensePlan& P, const DenseDev& D, do
     int max_len = 1;
     for (int i = c0; i < c1; ++i) max_len = std::max(max_len, P.chain_end[i] - P.chain_begin[i]);
     launch_chol_backsolve_chains(s, S, D.Lp, D.Vinv, ld, D.panels, D.panel_of_tile, D.chain_begin + c0, D.chain_end + c0, c1 - c0,
-                                 D.rows_flat, D.nreal, y, P.npad, max_len, (g == 0 && single_root) ? rhs_row : nullptr);
+                                 D.rows_flat, D.nreal, y, P.npad, max_len, (g == 0 && single_root) ? rhs_row : nullptr, iperm, n_pose, y_tan, delta);
   }
 }
 
@@ -162,8 +163,7 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
   } else if (c->n_pose > 0) {
     const DenseDev D{c->d_perm, c->d_nreal, c->d_rows_flat, c->d_panels, c->d_Lp, c->d_Vinv,
                      c->d_panel_of_tile, c->d_chain_begin, c->d_chain_end, c->d_tile_sync};
-    dense_factor_solve(s, c->plan, D, c->d_S, c->d_y, c->d_scal);
-    launch_y_to_delta(s, c->n_pose, c->d_y, c->d_perm, c->d_ytan, c->d_delta);
+    dense_factor_solve(s, c->plan, D, c->d_S, c->d_y, c->d_scal, c->d_iperm, c->n_pose, c->d_ytan, c->d_delta);
   }
   launch_backsub_landmarks(s, c->vis, c->n_pose, c->d_ytan, c->d_delta);
   // model cost change terms, candidate point and its cost: partial arrays only, summed once at the end

@@ -463,7 +463,8 @@ __global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double
                                                                     const int* __restrict__ chain_end,
                                                                     const int* __restrict__ rows_flat,
                                                                     const int* __restrict__ nreal, double* y, int npad, int max_len,
-                                                                    const double* __restrict__ y_init) {
+                                                                    const double* __restrict__ y_init, const int* __restrict__ iperm,
+                                                                    int n_pose, double* __restrict__ y_tan, double* __restrict__ delta) {
   extern __shared__ __attribute__((aligned(16))) double dyn[];
   double* sL = dyn;                         // 64 x 65
   double* sp = sL + NB * (NB + 1);          // 16 x 64
@@ -574,6 +575,10 @@ __global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double
       v = (tid < nr) ? v : 0.0;
       y[c0 + tid] = v;
       sy[c0 + tid] = v;
+      if (y_tan) {   // the solution in tangent (natural) order and the step -y, written where the tile is solved
+        const int j = iperm[k] * NB + tid;
+        if (j < n_pose) { y_tan[j] = v; delta[j] = -v; }
+      }
     }
     lds_barrier();
   }
@@ -582,11 +587,13 @@ __global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double
 void launch_chol_backsolve_chains(hipStream_t s, const double* S, const double* Lp, const double* Vinv, int ld,
                                   const PanelDesc* panels_dev, const int* panel_of_tile_dev, const int* chain_begin_dev,
                                   const int* chain_end_dev, int n_chains, const int* rows_flat_dev, const int* nreal_dev, double* y,
-                                  int npad, int max_chain_len, const double* y_init) {
+                                  int npad, int max_chain_len, const double* y_init, const int* iperm_dev, int n_pose, double* y_tan,
+                                  double* delta) {
   if (n_chains <= 0) return;
   const size_t lds = chol_backsolve_chain_lds(npad, max_chain_len);
   hipLaunchKernelGGL(chol_backsolve_chain_kernel, dim3(n_chains), dim3(1024), lds, s, S, Lp, Vinv, ld, panels_dev, panel_of_tile_dev,
-                     chain_begin_dev, chain_end_dev, rows_flat_dev, nreal_dev, y, npad, max_chain_len, n_chains == 1 ? y_init : nullptr);
+                     chain_begin_dev, chain_end_dev, rows_flat_dev, nreal_dev, y, npad, max_chain_len, n_chains == 1 ? y_init : nullptr, iperm_dev, n_pose,
+                     y_tan, delta);
 }
 
 size_t chol_backsolve_chain_lds(int npad, int max_chain_len) {
