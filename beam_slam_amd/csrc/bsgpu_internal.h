@@ -164,7 +164,6 @@ void launch_chol_backsolve_chains(hipStream_t s, const double* S, const double* 
                                   int npad, int max_chain_len, const double* y_init = nullptr, const int* iperm_dev = nullptr, int n_pose = 0,
                                   double* y_tan = nullptr, double* delta = nullptr);
 size_t chol_backsolve_chain_lds(int npad, int max_chain_len);
-void launch_y_to_delta(hipStream_t s, int n_pose, const double* y, const int* perm, double* y_tan, double* delta);
 void launch_marg_schur(hipStream_t s, const double* S, int ld, int rhs_row, const int* spos_dev, int n, int m, double rel_tol,
                        double* M, double* g, double* diag0, int* pivot_ok, double* status, double* A, double* b);
 void launch_cov_units(hipStream_t s, double* S, int ld, int rhs_row, const int* cols_dev, int n);
@@ -211,8 +210,6 @@ void launch_sum(hipStream_t s, const double* part, int n, double* out, int accum
 void launch_zero(hipStream_t s, double* p, int64_t n);
 void launch_zero_tiles_multi(hipStream_t s, double* S, int ld, const int* tiles_dev, int n_tiles, double* a, int na, double* b, int nb, double* c,
                              int nc, double* radius_slot, double radius);
-void launch_zero_multi(hipStream_t s, double* big, int64_t nbig, double* a, int na, double* b, int nb, double* c, int nc,
-                       double* radius_slot, double radius);
 void launch_copy(hipStream_t s, const double* src, double* dst, int64_t n, int nzero_after);
 void launch_final_reduce(hipStream_t s, const ReduceEntry* entries, int n_entries, int n_slots, double* scal, double* host_scal);
 

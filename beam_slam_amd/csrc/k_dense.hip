@@ -2,7 +2,6 @@
 //   pose_diag    LM diagonal (Ceres' Jacobi scaling folded in) onto the diagonal of S, unit pivots on the
 //                padding / rhs positions.  S is in SOLVER order: position = perm[tile] * 64 + offset
 //                (dense_plan.h); hdiag / scale / dcl stay in tangent order.
-//   y_to_delta   y (solver order) -> y_tan, delta = -y (tangent order)
 //   marg_*       gather of the reduced system into [marginalised | kept] order and its positive-SEMI-definite
 //                Cholesky: Schur complement onto the kept variables and the factor of the marginal prior
 //                (bsgpu_marginalize)
@@ -27,18 +26,6 @@ void launch_pose_diag(hipStream_t s, int n_pose, double* S, int ld, const double
                       double* dcl, int npad, const int* iperm) {
   hipLaunchKernelGGL(pose_diag_kernel, dim3((npad + 255) / 256), dim3(256), 0, s, n_pose, S, ld, hdiag, radius_ptr,
                      compute_scale, compute_dcl, jacobi, lm_lo, lm_hi, scale, dcl, npad, iperm);
-}
-
-__global__ void y_to_delta_kernel(int n_pose, const double* __restrict__ y, const int* __restrict__ perm,
-                                  double* __restrict__ y_tan, double* __restrict__ delta) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n_pose) return;
-  const double v = y[perm[j >> 6] * 64 + (j & 63)];
-  y_tan[j] = v;
-  delta[j] = -v;
-}
-void launch_y_to_delta(hipStream_t s, int n_pose, const double* y, const int* perm, double* y_tan, double* delta) {
-  if (n_pose > 0) hipLaunchKernelGGL(y_to_delta_kernel, dim3((n_pose + 255) / 256), dim3(256), 0, s, n_pose, y, perm, y_tan, delta);
 }
 
 // ---- true marginalisation (fuse_constraints::marginalizeVariables, fixed_lag_smoother.cpp:270-271) --------------

@@ -193,20 +193,9 @@ void launch_zero(hipStream_t s, double* p, int64_t n) {
   const int grid = (int)std::min<int64_t>((n2 + 255) / 256, 2048);
   hipLaunchKernelGGL(zero_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<double2*>(p), n2, p + 2 * n2, (int)(n - 2 * n2));
 }
-// one launch for the buffers an LM step clears: the (large, 16-byte aligned) reduced system plus up to three small arrays
-__global__ __launch_bounds__(256) void zero_multi_kernel(double2* __restrict__ big2, int64_t nbig2, double* __restrict__ a, int na,
-                                                         double* __restrict__ b, int nb, double* __restrict__ c, int nc,
-                                                         double* __restrict__ radius_slot, double radius) {
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (radius_slot && t == 0) *radius_slot = radius;   // the step's trust-region radius rides in as a kernel argument
-  for (int64_t i = t; i < nbig2; i += stride) big2[i] = make_double2(0.0, 0.0);
-  for (int64_t i = t; i < na; i += stride) a[i] = 0.0;
-  for (int64_t i = t; i < nb; i += stride) b[i] = 0.0;
-  for (int64_t i = t; i < nc; i += stride) c[i] = 0.0;
-}
-// the same for a reduced system of which only the listed 64x64 tiles are ever written (dense_plan.h: touched_tiles): a banded
-// window touches a fraction of the dense square (C2: 30 %; an 800-keyframe window: 7 %), the rest stays zero from finalize()
+// one launch for what an LM step clears: up to three small arrays and the reduced system — of which only the listed 64x64 tiles
+// are ever written (dense_plan.h: touched_tiles): a banded window touches a fraction of the dense square (C2: 30 %; an
+// 800-keyframe window: 7 %), the rest stays zero from finalize().  The step's trust-region radius rides in as an argument.
 __global__ __launch_bounds__(256) void zero_tiles_multi_kernel(double* __restrict__ S, int ld, const int* __restrict__ tiles, int n_tiles,
                                                                double* __restrict__ a, int na, double* __restrict__ b, int nb,
                                                                double* __restrict__ c, int nc, double* __restrict__ radius_slot, double radius) {
@@ -228,12 +217,6 @@ void launch_zero_tiles_multi(hipStream_t s, double* S, int ld, const int* tiles_
                              int nc, double* radius_slot, double radius) {
   const int grid = std::max(1, std::min(n_tiles, 2048));
   hipLaunchKernelGGL(zero_tiles_multi_kernel, dim3(grid), dim3(256), 0, s, S, ld, tiles_dev, n_tiles, a, na, b, nb, c, nc, radius_slot, radius);
-}
-void launch_zero_multi(hipStream_t s, double* big, int64_t nbig /* even, 16-byte aligned */, double* a, int na, double* b, int nb, double* c, int nc,
-                       double* radius_slot, double radius) {
-  const int64_t n2 = nbig / 2;
-  const int grid = (int)std::min<int64_t>(std::max<int64_t>((n2 + 255) / 256, 1), 2048);
-  hipLaunchKernelGGL(zero_multi_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<double2*>(big), n2, a, na, b, nb, c, nc, radius_slot, radius);
 }
 __global__ __launch_bounds__(256) void copy_kernel(const double* __restrict__ src, double* __restrict__ dst, int64_t n, int nzero_after) {
   const int64_t stride = (int64_t)gridDim.x * 256;
