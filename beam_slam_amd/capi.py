@@ -233,6 +233,23 @@ class Solver:
         self._chk(self._f("add_factors")(self._ctx, ftype, n, _ptr(block_idx, _ip), _ptr(consts, _dp),
                                          _ptr(loss_kind, _ip), _ptr(loss_a, _dp)))
 
+    def add_factors_indirect(self, ftype, slot_idx, slot_to_block, consts, loss_kind=None, loss_a=None):
+        """add_factors for a caller that keeps its tables across solves: the block columns of slot_idx hold caller-side variable
+        slots, translated through slot_to_block on the way in (camera columns are not translated)."""
+        slot_idx = np.ascontiguousarray(slot_idx, np.int32)
+        slot_to_block = np.ascontiguousarray(slot_to_block, np.int32)
+        consts = np.ascontiguousarray(consts, np.float64)
+        n = slot_idx.shape[0] if slot_idx.ndim == 2 else 0
+        if loss_kind is not None:
+            loss_kind = np.ascontiguousarray(np.broadcast_to(loss_kind, (n,)), np.int32)
+        if loss_a is not None:
+            loss_a = np.ascontiguousarray(np.broadcast_to(loss_a, (n,)), np.float64)
+        fn = self._f("add_factors_indirect")
+        fn.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _ip, C.c_int32, _ip, _dp, _ip, _dp]
+        fn.restype = C.c_int
+        self._chk(fn(self._ctx, ftype, n, _ptr(slot_idx, _ip), slot_to_block.size, _ptr(slot_to_block, _ip), _ptr(consts, _dp),
+                     _ptr(loss_kind, _ip), _ptr(loss_a, _dp)))
+
     def add_marginal(self, blocks, A, b, xbar):
         """fuse_constraints::MarginalConstraint: r = b + sum_i A_i (x_i [-] xbar_i)."""
         blocks = np.ascontiguousarray(blocks, np.int32)
