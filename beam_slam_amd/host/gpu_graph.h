@@ -72,7 +72,7 @@ struct SolverSummary {
 
 // granularity of the copy-on-write sharing between a graph and its clones (small values only make sense in tests)
 #ifndef BS_GRAPH_COW_BUCKETS
-#define BS_GRAPH_COW_BUCKETS 2048
+#define BS_GRAPH_COW_BUCKETS 16384
 #endif
 #ifndef BS_GRAPH_COW_CHUNK
 #define BS_GRAPH_COW_CHUNK 1024
@@ -231,7 +231,10 @@ class GpuGraph {
     if (!cfree_.empty()) { cs = cfree_.back(); cfree_.pop_back(); }
     else { cs = (int32_t)cptr_.size(); cptr_.push_back(nullptr); ctype_.push_back(kFree); crow_.push_back(0); }
     ensureConnectivity();
-    for (int32_t s : vars) if (std::find(conn_[s].begin(), conn_[s].end(), cs) == conn_[s].end()) conn_[s].push_back(cs);
+    // (a constraint is new to every list; only a variable it names twice must not get it twice — checked within `vars`, not by
+    //  scanning the variable's list: a keyframe pose carries thousands of constraints)
+    for (size_t i = 0; i < vars.size(); ++i)
+      if (std::find(vars.begin(), vars.begin() + i, vars[i]) == vars.begin() + i) conn_[vars[i]].push_back(cs);
     cindex_.insert(c->uuid(), cs);
     appendRow(*c, cs, vars);
     cptr_.mut(cs) = std::move(c);
@@ -526,7 +529,14 @@ class GpuGraph {
   TypeTable& tableMut(int ty) {
     auto& t = tables_[ty];
     if (!t) t = std::make_shared<TypeTable>();
-    else if (t.use_count() > 1) t = std::make_shared<TypeTable>(*t);
+    else if (t.use_count() > 1) {
+      // copy-on-write: the copy gets head-room, or the transaction's first append would reallocate (and copy) everything again
+      auto n = std::make_shared<TypeTable>();
+      n->rows = t->rows; n->nvar = t->nvar; n->nidx = t->nidx;
+      auto grow = [](auto& dst, const auto& src) { dst.reserve(src.size() + src.size() / 8 + 64); dst.assign(src.begin(), src.end()); };
+      grow(n->idx, t->idx); grow(n->consts, t->consts); grow(n->loss_kind, t->loss_kind); grow(n->loss_a, t->loss_a); grow(n->owner, t->owner);
+      t = std::move(n);
+    }
     return *t;
   }
   template <class F>
