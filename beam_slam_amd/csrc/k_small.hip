@@ -733,12 +733,12 @@ void launch_small_eval(hipStream_t s, const SmallGroup& g, const double* x, cons
 }
 
 // ---------------------------------------------------------------------------------------------------
-// assembly of a pose-only group into the dense reduced system: one wave per factor, J staged in LDS,
+// assembly of a pose-only group into the dense reduced system: one workgroup (four waves) per factor, J staged in LDS,
 // lanes stride over the (column a, column b) pairs; FP64 atomics into S, the rhs row, grad and hdiag.
 // ---------------------------------------------------------------------------------------------------
 // up to kSetMax groups per launch (a window has two or three pose-only factor types, some with a single factor: one
 // launch each would cost more in dispatch than in work)
-__global__ __launch_bounds__(64) void small_assemble_kernel(SmallGroupSet set, double* __restrict__ S, int ld, int rhs_row,
+__global__ __launch_bounds__(256) void small_assemble_kernel(SmallGroupSet set, double* __restrict__ S, int ld, int rhs_row,
                                                             double* __restrict__ grad, double* __restrict__ hdiag,
                                                             const int* __restrict__ perm) {
   __shared__ double sJ[15 * 30];
@@ -751,12 +751,12 @@ __global__ __launch_bounds__(64) void small_assemble_kernel(SmallGroupSet set, d
   if (!g.active[f]) return;
   const int m = g.m, tw = 3 * g.nv;
   const double* J = g.J + (size_t)f * m * tw;
-  for (int i = lane; i < m * tw; i += 64) sJ[i] = J[i];
+  for (int i = lane; i < m * tw; i += 256) sJ[i] = J[i];
   if (lane < m) sr[lane] = g.r[(size_t)f * m + lane];
   if (lane < g.nv) st[lane] = g.toff[(size_t)f * g.nv + lane];
   __syncthreads();
   const int wcut = 3 * (g.nv - 1) + g.w_last;   // columns >= wcut are the padding of a narrow last slot
-  for (int p = lane; p < tw * tw; p += 64) {
+  for (int p = lane; p < tw * tw; p += 256) {   // (an IMU factor has 900 column pairs: four waves share them)
     const int a = p / tw, b = p % tw;
     const int ta = st[a / 3], tb = st[b / 3];
     if (ta < 0 || tb < 0 || a >= wcut || b >= wcut) continue;
@@ -765,7 +765,7 @@ __global__ __launch_bounds__(64) void small_assemble_kernel(SmallGroupSet set, d
     const int ra = ta + a % 3, rb = tb + b % 3;
     atomicAdd(&S[(size_t)(perm[ra >> 6] * 64 + (ra & 63)) * ld + perm[rb >> 6] * 64 + (rb & 63)], acc);
   }
-  for (int a = lane; a < wcut; a += 64) {
+  for (int a = lane; a < wcut; a += 256) {
     const int ta = st[a / 3];
     if (ta < 0) continue;
     double gs = 0.0, hs = 0.0;
@@ -784,7 +784,7 @@ void launch_small_assemble_set(hipStream_t s, const SmallGroup* groups, int n_gr
   auto flush = [&]() {
     if (!set.n) return;
     set.first[set.n] = blocks;
-    hipLaunchKernelGGL(small_assemble_kernel, dim3(blocks), dim3(64), 0, s, set, S, ld, rhs_row, grad, hdiag, perm);
+    hipLaunchKernelGGL(small_assemble_kernel, dim3(blocks), dim3(256), 0, s, set, S, ld, rhs_row, grad, hdiag, perm);
     set.n = 0; blocks = 0;
   };
   for (int i = 0; i < n_groups; ++i) {
