@@ -288,7 +288,7 @@ int bsgpu_evaluate(bsgpu_ctx* c, double* cost, double* residuals, double* gradie
         for (int sl = 0; sl < 3; ++sl) {
           if (cols[sl] < 0) continue;
           for (int j = 0; j < 3; ++j) {
-            const double v = J[(size_t)i * 18 + 9 * k + 3 * sl + j];
+            const double v = J[(size_t)i * 18 + (sl < 2 ? 6 * k + 3 * sl + j : 12 + 3 * k + j)];   // stored row: [A row 0 | A row 1 | B row 0 | B row 1]
             grad[cols[sl] + j] += v * r[2 * (size_t)i + k];
             if (jacobian) jacobian[(size_t)(row + k) * n + cols[sl] + j] = v;
           }

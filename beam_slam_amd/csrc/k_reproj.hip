@@ -105,7 +105,9 @@ __global__ __launch_bounds__(256) void reproj_eval_kernel(int n, const int4* __r
   if (WITH_J) {
     double* sw = sJ + wave * (64 * 18);
 #pragma unroll
-    for (int i = 0; i < 18; ++i) sw[lane * 18 + i] = J[i];
+    // stored row: [A row 0 (q, p: 6) | A row 1 (6) | B row 0 (landmark: 3) | B row 1 (3)] — the pose part contiguous for the pair
+    // kernel and the back-substitution, the landmark part contiguous for the landmark kernel (J[] above is [q p l | q p l])
+    for (int i = 0; i < 18; ++i) { const int rw = i / 9, cl = i % 9; sw[lane * 18 + (cl < 6 ? 6 * rw + cl : 12 + 3 * rw + (cl - 6))] = J[i]; }
     __syncthreads();
     const int fb = blockIdx.x * 256 + wave * 64;
     const int cnt = min(64, n - fb);
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(256) void landmark_kernel(int n_lm, const int* __re
   for (int f = beg + sub; f < end; f += 8) {
     const double* Jf = J + (size_t)f * 18;
     const double2 rf = r[f];
-    const double x0 = Jf[6], x1 = Jf[7], x2 = Jf[8], y0 = Jf[15], y1 = Jf[16], y2 = Jf[17];
+    const double x0 = Jf[12], x1 = Jf[13], x2 = Jf[14], y0 = Jf[15], y1 = Jf[16], y2 = Jf[17];
     h00 += x0 * x0 + y0 * y0; h01 += x0 * x1 + y0 * y1; h02 += x0 * x2 + y0 * y2;
     h11 += x1 * x1 + y1 * y1; h12 += x1 * x2 + y1 * y2; h22 += x2 * x2 + y2 * y2;
     b0 += x0 * rf.x + y0 * rf.y; b1 += x1 * rf.x + y1 * rf.y; b2 += x2 * rf.x + y2 * rf.y;
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(256) void landmark_kernel(int n_lm, const int* __re
     const double2 rf = r[f];
     double* o = CR + (size_t)f * 8;
     // C[k][j] = sum_i B[k][i] Linv[j][i]
-    const double x0 = Jf[6], x1 = Jf[7], x2 = Jf[8], y0 = Jf[15], y1 = Jf[16], y2 = Jf[17];
+    const double x0 = Jf[12], x1 = Jf[13], x2 = Jf[14], y0 = Jf[15], y1 = Jf[16], y2 = Jf[17];
     const double c00 = x0 * i00, c01 = x0 * i10 + x1 * i11, c02 = x0 * i20 + x1 * i21 + x2 * i22;
     const double c10 = y0 * i00, c11 = y0 * i10 + y1 * i11, c12 = y0 * i20 + y1 * i21 + y2 * i22;
     o[0] = c00; o[1] = c01; o[2] = c02; o[3] = c10; o[4] = c11; o[5] = c12;
@@ -317,19 +319,19 @@ __global__ __launch_bounds__(64) void pairs_kernel(int n_seg, const int* __restr
   const int beg = seg_start[seg], end = seg_start[seg + 1];
   for (int e = beg + lane; e < end; e += 64) {
     const int fa = ent_fa[e], fb = ent_fb[e];
-    // 16-byte loads of the AoS rows: J row = 9 double2 (A = elements 0..5 and 9..14), CR row = 4 double2
+    // 16-byte loads of the AoS rows: J row = 9 double2 (A = the first six, see reproj_eval_kernel), CR row = 4 double2
     const double2* Ja = reinterpret_cast<const double2*>(J + (size_t)fa * 18);
     const double2* Jb = reinterpret_cast<const double2*>(J + (size_t)fb * 18);
     const double2* Ca2 = reinterpret_cast<const double2*>(CR + (size_t)fa * 8);
     const double2* Cb2 = reinterpret_cast<const double2*>(CR + (size_t)fb * 8);
     double A0[6], A1[6], B0[6], B1[6], Ca[8], Cb[6];
     {
-      const double2 a0 = Ja[0], a1 = Ja[1], a2 = Ja[2], a4 = Ja[4], a5 = Ja[5], a6 = Ja[6], a7 = Ja[7];
+      const double2 a0 = Ja[0], a1 = Ja[1], a2 = Ja[2], a3 = Ja[3], a4 = Ja[4], a5 = Ja[5];
       A0[0] = a0.x; A0[1] = a0.y; A0[2] = a1.x; A0[3] = a1.y; A0[4] = a2.x; A0[5] = a2.y;
-      A1[0] = a4.y; A1[1] = a5.x; A1[2] = a5.y; A1[3] = a6.x; A1[4] = a6.y; A1[5] = a7.x;
-      const double2 b0 = Jb[0], b1 = Jb[1], b2 = Jb[2], b4 = Jb[4], b5 = Jb[5], b6 = Jb[6], b7 = Jb[7];
+      A1[0] = a3.x; A1[1] = a3.y; A1[2] = a4.x; A1[3] = a4.y; A1[4] = a5.x; A1[5] = a5.y;
+      const double2 b0 = Jb[0], b1 = Jb[1], b2 = Jb[2], b3 = Jb[3], b4 = Jb[4], b5 = Jb[5];
       B0[0] = b0.x; B0[1] = b0.y; B0[2] = b1.x; B0[3] = b1.y; B0[4] = b2.x; B0[5] = b2.y;
-      B1[0] = b4.y; B1[1] = b5.x; B1[2] = b5.y; B1[3] = b6.x; B1[4] = b6.y; B1[5] = b7.x;
+      B1[0] = b3.x; B1[1] = b3.y; B1[2] = b4.x; B1[3] = b4.y; B1[4] = b5.x; B1[5] = b5.y;
       const double2 c0 = Ca2[0], c1 = Ca2[1], c2 = Ca2[2], c3 = Ca2[3];
       Ca[0] = c0.x; Ca[1] = c0.y; Ca[2] = c1.x; Ca[3] = c1.y; Ca[4] = c2.x; Ca[5] = c2.y; Ca[6] = c3.x; Ca[7] = c3.y;
       const double2 d0 = Cb2[0], d1 = Cb2[1], d2 = Cb2[2];
@@ -419,11 +421,11 @@ __global__ __launch_bounds__(256) void backsub_kernel(int n_lm, const int* __res
     double j0 = 0, j1 = 0;
     if (tq >= 0) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { const double yv = y_pose[tq + k]; j0 += Jf[k] * yv; j1 += Jf[9 + k] * yv; }
+      for (int k = 0; k < 3; ++k) { const double yv = y_pose[tq + k]; j0 += Jf[k] * yv; j1 += Jf[6 + k] * yv; }
     }
     if (tp >= 0) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { const double yv = y_pose[tp + k]; j0 += Jf[3 + k] * yv; j1 += Jf[12 + k] * yv; }
+      for (int k = 0; k < 3; ++k) { const double yv = y_pose[tp + k]; j0 += Jf[3 + k] * yv; j1 += Jf[9 + k] * yv; }
     }
     a0 += C[0] * j0 + C[3] * j1; a1 += C[1] * j0 + C[4] * j1; a2 += C[2] * j0 + C[5] * j1;
   }
@@ -465,13 +467,13 @@ __global__ __launch_bounds__(256) void mcc_kernel(int n, const double* __restric
     double j0 = 0, j1 = 0;
     if (tq >= 0)
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { const double d = delta[tq + k]; j0 += Jf[k] * d; j1 += Jf[9 + k] * d; }
+      for (int k = 0; k < 3; ++k) { const double d = delta[tq + k]; j0 += Jf[k] * d; j1 += Jf[6 + k] * d; }
     if (tp >= 0)
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { const double d = delta[tp + k]; j0 += Jf[3 + k] * d; j1 += Jf[12 + k] * d; }
+      for (int k = 0; k < 3; ++k) { const double d = delta[tp + k]; j0 += Jf[3 + k] * d; j1 += Jf[9 + k] * d; }
     if (l >= 0)
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { const double d = delta[n_pose + 3 * l + k]; j0 += Jf[6 + k] * d; j1 += Jf[15 + k] * d; }
+      for (int k = 0; k < 3; ++k) { const double d = delta[n_pose + 3 * l + k]; j0 += Jf[12 + k] * d; j1 += Jf[15 + k] * d; }
     const double2 rf = r[f];
     acc = -(j0 * (rf.x + 0.5 * j0) + j1 * (rf.y + 0.5 * j1));
   }
