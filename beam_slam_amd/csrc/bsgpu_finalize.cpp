@@ -350,7 +350,7 @@ int finalize(bsgpu_ctx* c) {
     V.n_cost_part = (nv + 255) / 256;
     V.cost_part = c->alloc<double>(V.n_cost_part);
     V.cost_part_cand = c->alloc<double>(V.n_cost_part);
-    V.mcc_part = c->alloc<double>(V.n_cost_part);
+    V.mcc_part = c->alloc<double>(std::max(1, backsub_mcc_groups(V)));
     if (!V.J || !V.CR || !V.r) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (visual tables)");
   }
   lap("visual upload + alloc");
@@ -513,7 +513,7 @@ int finalize(bsgpu_ctx* c) {
     if (c->vis.n) {
       tab.push_back({c->vis.cost_part, c->vis.n_cost_part, 1, 0, SC_COST_X});
       tab.push_back({c->vis.cost_part_cand, c->vis.n_cost_part, 1, 0, SC_COST_CAND});
-      tab.push_back({c->vis.mcc_part, c->vis.n_cost_part, 1, 0, SC_MCC});
+      tab.push_back({c->vis.mcc_part, backsub_mcc_groups(c->vis), 1, 0, SC_MCC});   // one partial per workgroup of backsub_mcc_kernel
     }
     for (int t = 2; t < kNumInternal; ++t) {
       if (!c->small[t].n) continue;

@@ -199,9 +199,9 @@ void launch_pcg_iteration(hipStream_t s, int k, int nbr, const int* row_ptr, con
 int pcg_num_scalars();
 int pcg_done_slot();
 int pcg_iters_slot();
-void launch_backsub_landmarks(hipStream_t s, const Visual& v, int n_pose, const double* y_pose, double* delta);
+int backsub_mcc_groups(const Visual& v);   // workgroups (= model-cost partials) of launch_backsub_mcc
+void launch_backsub_mcc(hipStream_t s, const Visual& v, int n_pose, const double* y_pose, double* delta, double* mcc_part);
 void launch_negate_pose(hipStream_t s, int n_pose, const double* y, double* delta);
-void launch_mcc(hipStream_t s, const Visual& v, int n_pose, const double* delta, double* part);
 void launch_small_mcc_set(hipStream_t s, const SmallGroup* groups, double* const* parts, int n_groups, const double* delta);
 void launch_update(hipStream_t s, int nb, const int* blk_xoff, const int* blk_toff, const unsigned char* blk_size,
                    const unsigned char* blk_manifold, const double* x, const double* delta, double* x_cand,

@@ -165,9 +165,8 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
                      c->d_panel_of_tile, c->d_chain_begin, c->d_chain_end, c->d_tile_sync};
     dense_factor_solve(s, c->plan, D, c->d_S, c->d_y, c->d_scal, c->d_iperm, c->n_pose, c->d_ytan, c->d_delta);
   }
-  launch_backsub_landmarks(s, c->vis, c->n_pose, c->d_ytan, c->d_delta);
-  // model cost change terms, candidate point and its cost: partial arrays only, summed once at the end
-  if (c->vis.n) launch_mcc(s, c->vis, c->n_pose, c->d_delta, c->vis.mcc_part);
+  // landmark back-substitution + the model-cost-change terms of the visual factors (partial arrays only, summed once at the end)
+  launch_backsub_mcc(s, c->vis, c->n_pose, c->d_ytan, c->d_delta, c->vis.mcc_part);
   launch_small_mcc_set(s, c->small + 2, c->d_small_part_mcc + 2, kNumInternal - 2, c->d_delta);
   for (const auto& mc : c->marg)
     if (mc.active) launch_marg_mcc(s, mc.dev, c->d_delta, mc.part_mcc);

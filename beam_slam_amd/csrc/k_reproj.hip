@@ -399,93 +399,85 @@ void launch_pairs(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row
 }
 
 // ---------------------------------------------------------------------------------------------------
-// back-substitution: y_l = Linv^T (z - sum_f C_f^T (A_f y_cam(f)));  delta_l = -y_l.  8 lanes / landmark
+// back-substitution: y_l = Linv^T (z - sum_f C_f^T (A_f y_cam(f)));  delta_l = -y_l.  8 lanes / landmark.
+// The same lanes then add up the model cost change of the landmark's factors, sum -(J d).(r + J d / 2) (ceres
+// TrustRegionMinimizer) with J d = -(A y_cam + B y_l): the rows are still in L1 and a launch of its own is saved.  Factors whose
+// landmark is constant (f >= n_elim) are handled one per lane by the workgroups after the landmark ones.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void backsub_kernel(int n_lm, const int* __restrict__ lm_start,
-                                                      const double* __restrict__ J, const double* __restrict__ CR,
-                                                      const int* __restrict__ cam_pose, const int* __restrict__ cp_tq,
-                                                      const int* __restrict__ cp_tp, const double* __restrict__ Linv,
-                                                      const double* __restrict__ z, int n_pose,
-                                                      const double* __restrict__ y_pose, double* __restrict__ delta) {
-  const int gid = blockIdx.x * 256 + threadIdx.x;
-  const int l = gid >> 3, sub = gid & 7;
-  const bool valid = l < n_lm;
-  int beg = 0, end = 0;
-  if (valid) { beg = lm_start[l]; end = lm_start[l + 1]; }
-  double a0 = 0, a1 = 0, a2 = 0;
-  for (int f = beg + sub; f < end; f += 8) {
-    const double* Jf = J + (size_t)f * 18;
-    const double* C = CR + (size_t)f * 8;
-    const int cp = cam_pose[f];
-    const int tq = cp_tq[cp], tp = cp_tp[cp];
-    double j0 = 0, j1 = 0;
-    if (tq >= 0) {
+BSG_DEV void pose_part(const double* __restrict__ Jf, int tq, int tp, const double* __restrict__ y_pose, double& j0, double& j1) {
+  j0 = 0.0; j1 = 0.0;
+  if (tq >= 0) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { const double yv = y_pose[tq + k]; j0 += Jf[k] * yv; j1 += Jf[6 + k] * yv; }
-    }
-    if (tp >= 0) {
-#pragma unroll
-      for (int k = 0; k < 3; ++k) { const double yv = y_pose[tp + k]; j0 += Jf[3 + k] * yv; j1 += Jf[9 + k] * yv; }
-    }
-    a0 += C[0] * j0 + C[3] * j1; a1 += C[1] * j0 + C[4] * j1; a2 += C[2] * j0 + C[5] * j1;
+    for (int k = 0; k < 3; ++k) { const double yv = y_pose[tq + k]; j0 += Jf[k] * yv; j1 += Jf[6 + k] * yv; }
   }
+  if (tp >= 0) {
 #pragma unroll
-  for (int o = 4; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o, 8); a1 += __shfl_xor(a1, o, 8); a2 += __shfl_xor(a2, o, 8); }
-  if (!valid || sub != 0) return;
-  const double* Li = Linv + (size_t)l * 6;
-  const double w0 = z[3 * l] - a0, w1 = z[3 * l + 1] - a1, w2 = z[3 * l + 2] - a2;
-  // y = Linv^T w
-  const double y0 = Li[0] * w0 + Li[1] * w1 + Li[3] * w2;
-  const double y1 = Li[2] * w1 + Li[4] * w2;
-  const double y2 = Li[5] * w2;
-  const int to = n_pose + 3 * l;
-  delta[to] = -y0; delta[to + 1] = -y1; delta[to + 2] = -y2;
+    for (int k = 0; k < 3; ++k) { const double yv = y_pose[tp + k]; j0 += Jf[3 + k] * yv; j1 += Jf[9 + k] * yv; }
+  }
 }
-
-void launch_backsub_landmarks(hipStream_t s, const Visual& v, int n_pose, const double* y_pose, double* delta) {
-  if (v.n_lm == 0) return;
-  const int grid = (v.n_lm * 8 + 255) / 256;
-  hipLaunchKernelGGL(backsub_kernel, dim3(grid), dim3(256), 0, s, v.n_lm, v.lm_start, v.J, v.CR, v.cam_pose, v.cp_tq,
-                     v.cp_tp, v.Linv, v.z, n_pose, y_pose, delta);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// model cost change of the visual factors: sum -(J d).(r + J d / 2)   (ceres TrustRegionMinimizer)
-// ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void mcc_kernel(int n, const double* __restrict__ J, const double2* __restrict__ r,
-                                                  const int* __restrict__ cam_pose, const int* __restrict__ lm_of,
-                                                  const int* __restrict__ cp_tq, const int* __restrict__ cp_tp,
-                                                  int n_pose, const double* __restrict__ delta,
-                                                  double* __restrict__ part) {
+__global__ __launch_bounds__(256) void backsub_mcc_kernel(int n_lm, int n_lm_groups, int n_elim, int n, const int* __restrict__ lm_start,
+                                                          const double* __restrict__ J, const double2* __restrict__ r,
+                                                          const double* __restrict__ CR, const int* __restrict__ cam_pose,
+                                                          const int* __restrict__ cp_tq, const int* __restrict__ cp_tp,
+                                                          const double* __restrict__ Linv, const double* __restrict__ z, int n_pose,
+                                                          const double* __restrict__ y_pose, double* __restrict__ delta,
+                                                          double* __restrict__ mcc_part) {
   __shared__ double sred[4];
-  const int f = blockIdx.x * 256 + threadIdx.x;
   double acc = 0.0;
-  if (f < n) {
-    const double* Jf = J + (size_t)f * 18;
-    const int cp = cam_pose[f];
-    const int tq = cp_tq[cp], tp = cp_tp[cp], l = lm_of[f];
-    double j0 = 0, j1 = 0;
-    if (tq >= 0)
+  if ((int)blockIdx.x < n_lm_groups) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int l = gid >> 3, sub = gid & 7;
+    const bool valid = l < n_lm;
+    int beg = 0, end = 0;
+    if (valid) { beg = lm_start[l]; end = lm_start[l + 1]; }
+    double a0 = 0, a1 = 0, a2 = 0;
+    for (int f = beg + sub; f < end; f += 8) {
+      const double* C = CR + (size_t)f * 8;
+      const int cp = cam_pose[f];
+      double j0, j1;
+      pose_part(J + (size_t)f * 18, cp_tq[cp], cp_tp[cp], y_pose, j0, j1);
+      a0 += C[0] * j0 + C[3] * j1; a1 += C[1] * j0 + C[4] * j1; a2 += C[2] * j0 + C[5] * j1;
+    }
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { const double d = delta[tq + k]; j0 += Jf[k] * d; j1 += Jf[6 + k] * d; }
-    if (tp >= 0)
-#pragma unroll
-      for (int k = 0; k < 3; ++k) { const double d = delta[tp + k]; j0 += Jf[3 + k] * d; j1 += Jf[9 + k] * d; }
-    if (l >= 0)
-#pragma unroll
-      for (int k = 0; k < 3; ++k) { const double d = delta[n_pose + 3 * l + k]; j0 += Jf[12 + k] * d; j1 += Jf[15 + k] * d; }
-    const double2 rf = r[f];
-    acc = -(j0 * (rf.x + 0.5 * j0) + j1 * (rf.y + 0.5 * j1));
+    for (int o = 4; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o, 8); a1 += __shfl_xor(a1, o, 8); a2 += __shfl_xor(a2, o, 8); }
+    if (valid) {   // (every one of the 8 lanes holds the sums)
+      const double* Li = Linv + (size_t)l * 6;
+      const double w0 = z[3 * l] - a0, w1 = z[3 * l + 1] - a1, w2 = z[3 * l + 2] - a2;
+      // y = Linv^T w
+      const double y0 = Li[0] * w0 + Li[1] * w1 + Li[3] * w2;
+      const double y1 = Li[2] * w1 + Li[4] * w2;
+      const double y2 = Li[5] * w2;
+      if (sub == 0) { const int to = n_pose + 3 * l; delta[to] = -y0; delta[to + 1] = -y1; delta[to + 2] = -y2; }
+      for (int f = beg + sub; f < end; f += 8) {
+        const double* Jf = J + (size_t)f * 18;
+        const int cp = cam_pose[f];
+        double j0, j1;
+        pose_part(Jf, cp_tq[cp], cp_tp[cp], y_pose, j0, j1);
+        const double d0 = -(j0 + Jf[12] * y0 + Jf[13] * y1 + Jf[14] * y2), d1 = -(j1 + Jf[15] * y0 + Jf[16] * y1 + Jf[17] * y2);
+        const double2 rf = r[f];
+        acc -= d0 * (rf.x + 0.5 * d0) + d1 * (rf.y + 0.5 * d1);
+      }
+    }
+  } else {
+    const int f = n_elim + ((int)blockIdx.x - n_lm_groups) * 256 + (int)threadIdx.x;
+    if (f < n) {
+      const int cp = cam_pose[f];
+      double j0, j1;
+      pose_part(J + (size_t)f * 18, cp_tq[cp], cp_tp[cp], y_pose, j0, j1);
+      const double2 rf = r[f];
+      acc = -((-j0) * (rf.x - 0.5 * j0) + (-j1) * (rf.y - 0.5 * j1));
+    }
   }
   const double tot = block_sum_256(acc, sred);
-  if (threadIdx.x == 0) part[blockIdx.x] = tot;
+  if (threadIdx.x == 0) mcc_part[blockIdx.x] = tot;
 }
 
-void launch_mcc(hipStream_t s, const Visual& v, int n_pose, const double* delta, double* part) {
-  if (v.n == 0) return;
-  const int grid = (v.n + 255) / 256;
-  hipLaunchKernelGGL(mcc_kernel, dim3(grid), dim3(256), 0, s, v.n, v.J, v.r, v.cam_pose, v.lm_of, v.cp_tq, v.cp_tp, n_pose,
-                     delta, part);
+int backsub_mcc_groups(const Visual& v) { return (v.n_lm * 8 + 255) / 256 + (v.n - v.n_elim + 255) / 256; }
+void launch_backsub_mcc(hipStream_t s, const Visual& v, int n_pose, const double* y_pose, double* delta, double* mcc_part) {
+  const int g_lm = (v.n_lm * 8 + 255) / 256, grid = backsub_mcc_groups(v);
+  if (grid == 0) return;
+  hipLaunchKernelGGL(backsub_mcc_kernel, dim3(grid), dim3(256), 0, s, v.n_lm, g_lm, v.n_elim, v.n, v.lm_start, v.J, v.r, v.CR, v.cam_pose,
+                     v.cp_tq, v.cp_tp, v.Linv, v.z, n_pose, y_pose, delta, mcc_part);
 }
 
 }  // namespace bsg
