@@ -296,21 +296,33 @@ __global__ __launch_bounds__(256) void chol_panel_step_kernel(double* __restrict
   const bool diag = bi == bj;
   // 16-byte loads (ld, c0 and the LDS pitch are all multiples of 2 doubles).  The upper triangle of
   // L_kk in S holds stale values; trsm_tile only reads its strictly-lower 16x16 blocks.
+  // ALL loads of the prologue are issued before the first LDS store: written as load-store pairs (with a branch on `diag` in
+  // between) the compiler waited for every load before the next one went out — two dozen dependent round trips to L2 / HBM,
+  // 5.7 us of a 24 us step (scripts/potrf_probe.hip); in flight together they cost one.  Unconditional on purpose: a diagonal
+  // workgroup has rj == ri and never reads sXj before it reuses it, a self-factoring panel overwrites sV; branches around
+  // the loads would keep the staging arrays out of registers (scratch).
+  {
+    double2 vXi[8], vL[8], vXj[8], vV[2];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int i = tid + 256 * q;
-    const int r = i >> 5, c2 = (i & 31) * 2;
-    *reinterpret_cast<double2*>(&sXi[r * LDT + c2]) = *reinterpret_cast<const double2*>(&S[(size_t)(ri + r) * ld + c0 + c2]);
-    if (!diag)
-      *reinterpret_cast<double2*>(&sXj[r * LDT + c2]) = *reinterpret_cast<const double2*>(&S[(size_t)(rj + r) * ld + c0 + c2]);
-    *reinterpret_cast<double2*>(&sL[r * LDT + c2]) = *reinterpret_cast<const double2*>(&S[(size_t)(c0 + r) * ld + c0 + c2]);
-  }
-  if (!self_potrf) {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int i = (tid + 256 * q) * 2;
-      *reinterpret_cast<double2*>(&sV[i]) = *reinterpret_cast<const double2*>(&Vinv[(size_t)k * kVinvStride + i]);
+    for (int q = 0; q < 8; ++q) {
+      const int i = tid + 256 * q;
+      const int r = i >> 5, c2 = (i & 31) * 2;
+      vXi[q] = *reinterpret_cast<const double2*>(&S[(size_t)(ri + r) * ld + c0 + c2]);
+      vL[q] = *reinterpret_cast<const double2*>(&S[(size_t)(c0 + r) * ld + c0 + c2]);
+      vXj[q] = *reinterpret_cast<const double2*>(&S[(size_t)(rj + r) * ld + c0 + c2]);
     }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) vV[q] = *reinterpret_cast<const double2*>(&Vinv[(size_t)k * kVinvStride + (tid + 256 * q) * 2]);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = tid + 256 * q;
+      const int r = i >> 5, c2 = (i & 31) * 2;
+      *reinterpret_cast<double2*>(&sXi[r * LDT + c2]) = vXi[q];
+      *reinterpret_cast<double2*>(&sL[r * LDT + c2]) = vL[q];
+      *reinterpret_cast<double2*>(&sXj[r * LDT + c2]) = vXj[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) *reinterpret_cast<double2*>(&sV[(tid + 256 * q) * 2]) = vV[q];
   }
   // C_ij (wave w owns rows 16w.. of the 64x64 tile): fetched now, so that the round trip hides behind the solves
   // (a tile another panel of this step also updates is accumulated with atomics: start from zero)

@@ -58,10 +58,12 @@ static void probe_panel_step() {
   const int T = 3, n = T * 64;
   std::vector<double> A((size_t)n * n, 0.0);
   for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) A[(size_t)i * n + j] = (i == j ? 200.0 : 0.0) + 1.0 / (1 + abs(i - j));
-  double *S, *Lp, *V, *scal; long long* ts; int *tiles, *nreal;
+  double *S, *Lp, *V, *scal; long long* ts; int *tiles, *nreal, *tile_sync;
   hipMalloc(&S, sizeof(double) * n * n); hipMalloc(&Lp, sizeof(double) * n * n); hipMalloc(&V, sizeof(double) * T * bsg::kVinvStride);
-  hipMalloc(&scal, 256); hipMalloc(&ts, 32 * 8); hipMalloc(&tiles, 16); hipMalloc(&nreal, 16);
+  hipMalloc(&scal, 256); hipMalloc(&ts, 32 * 8); hipMalloc(&tiles, 16); hipMalloc(&nreal, 16); hipMalloc(&tile_sync, 64);
   int h_tiles[1] = {0}, h_nreal[3] = {64, 64, 64};
+  int h_sync[6] = {0, 1, 0, 0, 0, 0};   // [expected arrivals per tile | counters]: tile 1 gets its last (and only) update in this step
+  hipMemcpy(tile_sync, h_sync, sizeof(h_sync), hipMemcpyHostToDevice);
   hipMemcpy(tiles, h_tiles, 4, hipMemcpyHostToDevice); hipMemcpy(nreal, h_nreal, 12, hipMemcpyHostToDevice);
   bsg::chol_prepare();
   hipFuncSetAttribute(reinterpret_cast<const void*>(bsg::chol_panel_step_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bsg::kPanelStepLds);
@@ -69,8 +71,8 @@ static void probe_panel_step() {
     hipMemcpy(S, A.data(), sizeof(double) * n * n, hipMemcpyHostToDevice);
     hipLaunchKernelGGL(bsg::chol_potrf_tiles_kernel, dim3(1), dim3(256), 0, 0, S, Lp, n, tiles, nreal, V, scal);
     bsg::StepArgs a; memset(&a, 0, sizeof(a));
-    a.k[0] = 0; a.n_rows[0] = 2; a.lookahead[0] = 1; a.rows[0][0] = 1; a.rows[0][1] = 2;
-    hipLaunchKernelGGL((bsg::chol_panel_step_kernel<true, true>), dim3(2, 2, 1), dim3(256), bsg::kPanelStepLds, 0, S, Lp, n, nullptr, nullptr, nreal, V, scal, a, ts);
+    a.k[0] = 0; a.n_rows[0] = 2; a.final_mask[0] = 1; a.rows[0][0] = 1; a.rows[0][1] = 2;
+    hipLaunchKernelGGL((bsg::chol_panel_step_kernel<true, true>), dim3(2, 2, 1), dim3(256), bsg::kPanelStepLds, 0, S, Lp, n, nullptr, nullptr, nreal, V, scal, tile_sync, a, ts);
     hipDeviceSynchronize();
     long long h[32];
     hipMemcpy(h, ts, sizeof(h), hipMemcpyDeviceToHost);
