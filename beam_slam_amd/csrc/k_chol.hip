@@ -400,10 +400,20 @@ __global__ __launch_bounds__(256) void chol_panel_step_kernel(double* __restrict
     }
     __syncthreads();
     if (s_last) {
-      __threadfence();
-      for (int i = tid; i < NB * NB; i += 256) {
-        const int r = i >> 6, cc = i & 63;
-        sC[r * LDT + cc] = (cc <= r) ? __hip_atomic_load(&S[(size_t)(ri + r) * ld + ri + cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      __threadfence();   // acquire at agent scope: invalidates what this XCD's caches may hold of the tile; the other updaters released
+                         // their atomics with the fence before their arrival.  Plain 16-byte loads, all in flight, after it.
+      double2 vt[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int i = tid + 256 * q;
+        vt[q] = *reinterpret_cast<const double2*>(&S[(size_t)(ri + (i >> 5)) * ld + ri + (i & 31) * 2]);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int i = tid + 256 * q;
+        const int r = i >> 5, c2 = (i & 31) * 2;
+        sC[r * LDT + c2] = (c2 <= r) ? vt[q].x : 0.0;
+        sC[r * LDT + c2 + 1] = (c2 + 1 <= r) ? vt[q].y : 0.0;
       }
       factor_now = true;
     }
