@@ -67,7 +67,11 @@ __global__ __launch_bounds__(256) void reproj_eval_kernel(int n, const int4* __r
     const double sc = sqrt(rho1);
     const bool active = flags != (kFlagQConst | kFlagPConst | kFlagLConst);
     cost = (active != (count_inactive != 0)) ? 0.5 * rho : 0.0;   // count_inactive: the fixed-cost pass (all three blocks constant)
-    if (WITH_J) r_out[f] = make_double2(r0 * sc, r1 * sc);  // a cost-only pass must not disturb r of the current point
+    if (WITH_J) {   // (a cost-only pass must not disturb r of the current point)
+      typedef double d2_t __attribute__((ext_vector_type(2)));
+      const d2_t rv = {r0 * sc, r1 * sc};
+      __builtin_nontemporal_store(rv, reinterpret_cast<d2_t*>(r_out) + f);
+    }
     if (WITH_J) {
       // Jpi (jacobians.cpp:202-214), M = Jpi R_cb (2x3), scaled by the corrector and the weight
       const double jx0 = cam.fx * iz, jx2 = -cam.fx * Pc[0] * iz * iz;
@@ -112,13 +116,14 @@ __global__ __launch_bounds__(256) void reproj_eval_kernel(int n, const int4* __r
     const int fb = blockIdx.x * 256 + wave * 64;
     const int cnt = min(64, n - fb);
     if (cnt > 0) {
-      double2* dst = reinterpret_cast<double2*>(J_out + (size_t)fb * 18);
-      const double2* src = reinterpret_cast<const double2*>(sw);
+      typedef double d2_t __attribute__((ext_vector_type(2)));
+      d2_t* dst = reinterpret_cast<d2_t*>(J_out + (size_t)fb * 18);
+      const d2_t* src = reinterpret_cast<const d2_t*>(sw);
       const int n2 = cnt * 9;
 #pragma unroll
       for (int it = 0; it < 9; ++it) {
         const int e = it * 64 + lane;
-        if (e < n2) dst[e] = src[e];
+        if (e < n2) __builtin_nontemporal_store(src[e], &dst[e]);   // streamed: 58 MB that no cache will hold until the next kernel
       }
     }
   }
