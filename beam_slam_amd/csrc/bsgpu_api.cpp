@@ -523,7 +523,7 @@ int bsgpu_covariance(bsgpu_ctx* c, int32_t ba, int32_t bb, double* out) try {
   (void)hipMemcpyAsync(d_cols, cols.data(), sizeof(int) * cols.size(), hipMemcpyHostToDevice, s);
   launch_cov_units(s, c->d_S, c->npad, c->plan.rhs_row, d_cols, (int)cols.size());
   const DenseDev D{c->d_perm, c->d_nreal, c->d_rows_flat, c->d_panels, c->d_Lp, c->d_Vinv,
-                   c->d_panel_of_tile, c->d_chain_begin, c->d_chain_end, c->d_tile_sync};
+                   c->d_bs_desc, c->d_chain_begin, c->d_chain_end, c->d_tile_sync};
   dense_factor(s, c->plan, D, c->d_S, c->d_scal);
   launch_cov_dots(s, c->d_Lp, c->npad, c->plan.rhs_row, c->plan.T * 64, ta, row_b0, tb, d_out);
   (void)hipMemcpyAsync(out, d_out, sizeof(double) * ta * tb, hipMemcpyDeviceToHost, s);
@@ -713,7 +713,7 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
   ok = ok && up(P.perm.data(), sizeof(int) * P.perm.size(), (void**)&dperm) && up(P.nreal.data(), sizeof(int) * P.nreal.size(), (void**)&dnreal) &&
        up(rf.data(), sizeof(int) * rf.size(), (void**)&drows) &&
        up(P.panels.data(), sizeof(PanelDesc) * P.panels.size(), (void**)&dpan) &&
-       up(P.panel_of_tile.data(), sizeof(int) * P.panel_of_tile.size(), (void**)&dpot2) &&
+       up(P.bs_desc.data(), sizeof(int) * P.bs_desc.size(), (void**)&dpot2) &&
        up(P.chain_begin.data(), sizeof(int) * P.chain_begin.size(), (void**)&dcb) && up(P.chain_end.data(), sizeof(int) * P.chain_end.size(), (void**)&dce) &&
        up(P.tile_sync.data(), sizeof(int) * P.tile_sync.size(), (void**)&dsync);
   int rc = BSGPU_OK;

@@ -127,7 +127,7 @@ struct bsgpu_ctx {
   std::vector<uint8_t> tile_adj;   // natural-tile adjacency of the reduced system
   int *d_perm = nullptr, *d_iperm = nullptr, *d_nreal = nullptr, *d_rows_flat = nullptr;
   PanelDesc* d_panels = nullptr;
-  int *d_panel_of_tile = nullptr, *d_chain_begin = nullptr, *d_chain_end = nullptr, *d_tile_sync = nullptr, *d_touched = nullptr;
+  int *d_bs_desc = nullptr, *d_chain_begin = nullptr, *d_chain_end = nullptr, *d_tile_sync = nullptr, *d_touched = nullptr;
   int n_touched = 0;
   double* d_Vinv = nullptr;
   double* d_Lp = nullptr;     // shadow of S holding the off-diagonal L panels (k_chol.hip)
@@ -221,7 +221,7 @@ struct DenseDev {
   const int *perm, *nreal, *rows_flat;
   const PanelDesc* panels;
   double *Lp, *Vinv;
-  const int *panel_of_tile, *chain_begin, *chain_end;
+  const int *bs_desc, *chain_begin, *chain_end;   // bs_desc: DensePlan::bs_desc on the device
   int* tile_sync;   // [expected arrivals | arrival counters] per tile (dense_plan.h)
 };
 void dense_factor(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* scal);

@@ -498,7 +498,7 @@ int finalize(bsgpu_ctx* c) {
     c->d_perm = c->upload(c->plan.perm); c->d_iperm = c->upload(iperm); c->d_nreal = c->upload(c->plan.nreal);
     c->d_rows_flat = c->upload(c->plan.rows_flat);
     c->d_panels = c->upload(c->plan.panels);
-    c->d_panel_of_tile = c->upload(c->plan.panel_of_tile);
+    c->d_bs_desc = c->upload(c->plan.bs_desc);
     c->d_tile_sync = c->upload(c->plan.tile_sync);
     c->d_touched = c->upload(c->plan.touched_tiles); c->n_touched = (int)c->plan.touched_tiles.size();
     c->d_chain_begin = c->upload(c->plan.chain_begin); c->d_chain_end = c->upload(c->plan.chain_end);

@@ -159,8 +159,8 @@ void launch_chol_panel_step(hipStream_t s, double* S, double* Lp, int ld, const 
                             const int* rows_flat_dev, const int* nreal_dev, double* Vinv, double* scal, int* tile_sync_dev,
                             const PanelDesc* descs_host = nullptr, const int* rows_flat_host = nullptr);
 void launch_chol_backsolve_chains(hipStream_t s, const double* S, const double* Lp, const double* Vinv, int ld,
-                                  const PanelDesc* panels_dev, const int* panel_of_tile_dev, const int* chain_begin_dev,
-                                  const int* chain_end_dev, int n_chains, const int* rows_flat_dev, const int* nreal_dev, double* y,
+                                  const int* bs_desc_dev, const int* chain_begin_dev,
+                                  const int* chain_end_dev, int n_chains, const int* rows_flat_dev, double* y,
                                   int npad, int max_chain_len, const double* y_init = nullptr, const int* iperm_dev = nullptr, int n_pose = 0,
                                   double* y_tan = nullptr, double* delta = nullptr);
 size_t chol_backsolve_chain_lds(int npad, int max_chain_len);

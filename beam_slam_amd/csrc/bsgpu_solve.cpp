@@ -150,8 +150,8 @@ void dense_factor_solve(hipStream_t s, const DensePlan& P, const DenseDev& D, do
     const int c0 = P.bs_group_off[g], c1 = P.bs_group_off[g + 1];
     int max_len = 1;
     for (int i = c0; i < c1; ++i) max_len = std::max(max_len, P.chain_end[i] - P.chain_begin[i]);
-    launch_chol_backsolve_chains(s, S, D.Lp, D.Vinv, ld, D.panels, D.panel_of_tile, D.chain_begin + c0, D.chain_end + c0, c1 - c0,
-                                 D.rows_flat, D.nreal, y, P.npad, max_len, (g == 0 && single_root) ? rhs_row : nullptr, iperm, n_pose, y_tan, delta);
+    launch_chol_backsolve_chains(s, S, D.Lp, D.Vinv, ld, D.bs_desc, D.chain_begin + c0, D.chain_end + c0, c1 - c0,
+                                 D.rows_flat, y, P.npad, max_len, (g == 0 && single_root) ? rhs_row : nullptr, iperm, n_pose, y_tan, delta);
   }
 }
 
@@ -162,7 +162,7 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
     launch_negate_pose(s, c->n_pose, c->d_px, c->d_delta);
   } else if (c->n_pose > 0) {
     const DenseDev D{c->d_perm, c->d_nreal, c->d_rows_flat, c->d_panels, c->d_Lp, c->d_Vinv,
-                     c->d_panel_of_tile, c->d_chain_begin, c->d_chain_end, c->d_tile_sync};
+                     c->d_bs_desc, c->d_chain_begin, c->d_chain_end, c->d_tile_sync};
     dense_factor_solve(s, c->plan, D, c->d_S, c->d_y, c->d_scal, c->d_iperm, c->n_pose, c->d_ytan, c->d_delta);
   }
   // landmark back-substitution + the model-cost-change terms of the visual factors (partial arrays only, summed once at the end)

@@ -46,6 +46,11 @@ struct DensePlan {
   std::vector<int> chain_begin, chain_end;        // all chains, group after group
   std::vector<int> bs_group_off;                  // chains [bs_group_off[g], bs_group_off[g+1]) run in launch g
   int n_pieces = 1;
+  // per S tile, what the back-substitution needs of its panel in ONE contiguous record (kBsDescInts ints): n_rows, offset of
+  // its row list in rows_flat, number of real columns, and the first kBsDescRows row tiles themselves — a chain's workgroup
+  // fetches the records of its tiles in one coalesced round instead of three dependent ones (tile -> panel -> row list)
+  static constexpr int kBsDescRows = 16, kBsDescInts = 3 + kBsDescRows;
+  std::vector<int> bs_desc;
   // solve offsets
   inline int spos(int j) const { return perm[j >> 6] * 64 + (j & 63); }
 
@@ -200,6 +205,13 @@ struct DensePlan {
     panel_of_tile.assign(T, 0);
     for (size_t i = 0; i < panels.size(); ++i) panel_of_tile[panels[i].k] = (int)i;
     n_pieces = (int)piece_ranges.size();
+    bs_desc.assign((size_t)std::max(1, T) * kBsDescInts, 0);
+    for (int k = 0; k < T; ++k) {
+      const PanelDesc& d = panels[panel_of_tile[k]];
+      int* r = &bs_desc[(size_t)k * kBsDescInts];
+      r[0] = d.n_rows; r[1] = d.row_off; r[2] = nreal[k];
+      for (int q = 0; q < d.n_rows && q < kBsDescRows; ++q) r[3 + q] = rows_flat[d.row_off + q];
+    }
     auto build_groups = [&](bool by_level) {
       chain_begin.clear(); chain_end.clear(); bs_group_off.assign(1, 0);
       if (by_level) {

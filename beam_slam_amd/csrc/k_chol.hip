@@ -477,14 +477,12 @@ constexpr int kBsChunk = 6;
 BSG_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // one workgroup per chain (a separator, or a piece of the nested-dissection ordering), walking its panels from its last
 // tile down to its first; everything a chain depends on outside itself was solved by an earlier launch (dense_plan.h)
-constexpr int kBsMaxRows = 16;   // row lists up to this length are staged in LDS
+constexpr int kBsMaxRows = DensePlan::kBsDescRows;   // row lists up to this length are staged in LDS
 __global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double* S, const double* Lp, const double* Vinv, int ld,
-                                                                    const PanelDesc* __restrict__ panels,
-                                                                    const int* __restrict__ panel_of_tile,
+                                                                    const int* __restrict__ bs_desc,
                                                                     const int* __restrict__ chain_begin,
                                                                     const int* __restrict__ chain_end,
-                                                                    const int* __restrict__ rows_flat,
-                                                                    const int* __restrict__ nreal, double* y, int npad, int max_len,
+                                                                    const int* __restrict__ rows_flat, double* y, int npad, int max_len,
                                                                     const double* __restrict__ y_init, const int* __restrict__ iperm,
                                                                     int n_pose, double* __restrict__ y_tan, double* __restrict__ delta) {
   extern __shared__ __attribute__((aligned(16))) double dyn[];
@@ -501,14 +499,11 @@ __global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double
   // y_init (first launch of a solve, a single chain): the forward-substituted rhs row of the factor, copied to y on the way
   if (y_init) { for (int i = tid; i < npad; i += 1024) { const double v = (i < npad - NB) ? y_init[i] : 0.0; sy[i] = v; y[i] = v; } }   // (the last tile is the rhs tile itself)
   else { for (int i = tid; i < npad; i += 1024) sy[i] = y[i]; }
-  if (tid < len) {
-    const PanelDesc pd = panels[panel_of_tile[b + tid]];
-    s_nrows[tid] = pd.n_rows; s_rowoff[tid] = pd.row_off; s_nr[tid] = nreal[b + tid];
-  }
-  __syncthreads();
-  for (int i = tid; i < len * kBsMaxRows; i += 1024) {
-    const int p = i / kBsMaxRows, q = i % kBsMaxRows;
-    if (q < s_nrows[p]) s_rows[i] = rows_flat[s_rowoff[p] + q];
+  // the records of this chain's tiles (DensePlan::bs_desc: one coalesced round, not tile -> panel -> row list)
+  for (int i = tid; i < len * DensePlan::kBsDescInts; i += 1024) {
+    const int p = i / DensePlan::kBsDescInts, q = i - p * DensePlan::kBsDescInts;
+    const int v = bs_desc[(size_t)b * DensePlan::kBsDescInts + i];
+    if (q == 0) s_nrows[p] = v; else if (q == 1) s_rowoff[p] = v; else if (q == 2) s_nr[p] = v; else s_rows[p * kBsMaxRows + (q - 3)] = v;
   }
   __syncthreads();
   // Software pipeline over the chain: the tiles of panel k-1 do not depend on y, so their loads are issued BEFORE the
@@ -607,14 +602,14 @@ __global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double
 }
 
 void launch_chol_backsolve_chains(hipStream_t s, const double* S, const double* Lp, const double* Vinv, int ld,
-                                  const PanelDesc* panels_dev, const int* panel_of_tile_dev, const int* chain_begin_dev,
-                                  const int* chain_end_dev, int n_chains, const int* rows_flat_dev, const int* nreal_dev, double* y,
+                                  const int* bs_desc_dev, const int* chain_begin_dev,
+                                  const int* chain_end_dev, int n_chains, const int* rows_flat_dev, double* y,
                                   int npad, int max_chain_len, const double* y_init, const int* iperm_dev, int n_pose, double* y_tan,
                                   double* delta) {
   if (n_chains <= 0) return;
   const size_t lds = chol_backsolve_chain_lds(npad, max_chain_len);
-  hipLaunchKernelGGL(chol_backsolve_chain_kernel, dim3(n_chains), dim3(1024), lds, s, S, Lp, Vinv, ld, panels_dev, panel_of_tile_dev,
-                     chain_begin_dev, chain_end_dev, rows_flat_dev, nreal_dev, y, npad, max_chain_len, n_chains == 1 ? y_init : nullptr, iperm_dev, n_pose,
+  hipLaunchKernelGGL(chol_backsolve_chain_kernel, dim3(n_chains), dim3(1024), lds, s, S, Lp, Vinv, ld, bs_desc_dev,
+                     chain_begin_dev, chain_end_dev, rows_flat_dev, y, npad, max_chain_len, n_chains == 1 ? y_init : nullptr, iperm_dev, n_pose,
                      y_tan, delta);
 }
 
