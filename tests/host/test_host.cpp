@@ -4,8 +4,11 @@
 //   * with -DBS_BACKEND_PREFIX=bso_    -> against the CPU oracle, to exercise the HOST LOGIC
 //     (flattening order, pack(), transactions, lag window, pseudo-marginalisation) where no GPU exists
 #include <cstdio>
+#include <algorithm>
 #include <iostream>
+#include <map>
 #include <random>
+#include <set>
 
 #define BS_GRAPH_COW_BUCKETS 8   // small copy-on-write granules: every test graph spans several chunks / fills every bucket
 #define BS_GRAPH_COW_CHUNK 16
@@ -450,6 +453,185 @@ static void test_clone_is_an_independent_snapshot() {
   CHECK(snap2->optimize().IsSolutionUsable());
 }
 
+// Randomised bookkeeping test of GpuGraph (no counterpart in the reference, whose HashGraph is [EXT] fuse): a family of graphs —
+// an original and clones of clones — takes random transactions; each is checked against a plain std::map model of what it
+// should hold, and its packed factor tables (kept incrementally behind copy-on-write handles) against a graph rebuilt from
+// scratch out of the model: same initial cost, same solve.
+namespace {
+struct ModelGraph {
+  std::map<fuse_core::UUID, fuse_core::Variable::SharedPtr> vars;          // prototypes (values are read from the graph under test)
+  std::map<fuse_core::UUID, fuse_core::Constraint::SharedPtr> cons;
+  size_t usesOf(const fuse_core::UUID& v) const {
+    size_t n = 0;
+    for (const auto& c : cons) n += std::count(c.second->variables().begin(), c.second->variables().end(), v) ? 1 : 0;
+    return n;
+  }
+};
+}  // namespace
+static void check_against_model(bs_optimizers::GpuGraph& g, const ModelGraph& m, const std::vector<fuse_core::UUID>& graveyard, bool solve) {
+  CHECK(g.numVariables() == m.vars.size());
+  CHECK(g.numConstraints() == m.cons.size());
+  CHECK(g.getVariables().size() == m.vars.size());
+  CHECK(g.orderedVariables().size() == m.vars.size());
+  {
+    std::set<fuse_core::UUID> have;
+    for (const auto* c : g.getConstraints()) have.insert(c->uuid());
+    CHECK(have.size() == m.cons.size());
+    for (const auto& c : m.cons) CHECK(have.count(c.first) == 1 && g.constraintExists(c.first));
+  }
+  for (const auto& v : m.vars) {
+    CHECK(g.variableExists(v.first));
+    if (!g.variableExists(v.first)) continue;
+    std::set<fuse_core::UUID> conn;
+    for (const auto* c : g.getConnectedConstraints(v.first)) conn.insert(c->uuid());
+    CHECK(conn.size() == m.usesOf(v.first));
+    for (const auto& u : conn) {
+      auto it = m.cons.find(u);
+      CHECK(it != m.cons.end() && std::count(it->second->variables().begin(), it->second->variables().end(), v.first) > 0);
+    }
+  }
+  for (const auto& u : graveyard) {
+    if (!m.vars.count(u)) CHECK(!g.variableExists(u));
+    if (!m.cons.count(u)) CHECK(!g.constraintExists(u));
+  }
+  {
+    const auto ord = g.orderedVariables();   // keyframe-major, (q, p, v, ...) inside a keyframe
+    for (size_t i = 1; i < ord.size(); ++i)
+      CHECK(ord[i - 1]->stamp() < ord[i]->stamp() || (!(ord[i]->stamp() < ord[i - 1]->stamp()) && ord[i - 1]->stateSlot() <= ord[i]->stateSlot()));
+  }
+  if (!solve || m.cons.empty()) return;
+  bs_optimizers::GpuGraph fresh;
+  for (const auto& v : m.vars) {
+    auto c = v.second->clone();
+    std::memcpy(c->data(), g.getVariable(v.first).data(), c->size() * sizeof(double));
+    fresh.addVariable(c);
+  }
+  for (auto it = m.cons.rbegin(); it != m.cons.rend(); ++it) fresh.addConstraint(it->second);   // some other order than the graph saw
+  ceres_compat::SolverOptions o;
+  o.max_num_iterations = 4;
+  const auto a = g.optimize(o), b = fresh.optimize(o);
+  CHECK(a.IsSolutionUsable() && b.IsSolutionUsable());
+  CHECK_NEAR(a.initial_cost, b.initial_cost, 1e-12 * std::max(1.0, b.initial_cost));
+  CHECK_NEAR(a.final_cost, b.final_cost, 1e-7 * std::max(1.0, b.initial_cost));
+  for (const auto& v : m.vars)
+    for (size_t k = 0; k < v.second->size(); ++k) CHECK_NEAR(g.getVariable(v.first).data()[k], fresh.getVariable(v.first).data()[k], 1e-6);
+}
+static void test_random_transactions_against_model() {
+  std::printf("RandomTransactionsAgainstModel\n");
+  std::mt19937 rng(20250620);
+  std::normal_distribution<double> N(0.0, 1.0);
+  auto U = [&](size_t n) { return (size_t)(rng() % n); };
+  struct Member { bs_optimizers::GpuGraph::UniquePtr g; ModelGraph m; };
+  std::vector<Member> family;
+  family.push_back(Member{bs_optimizers::GpuGraph::UniquePtr(new bs_optimizers::GpuGraph()), ModelGraph()});
+  std::vector<fuse_core::UUID> graveyard;
+  int next_stamp = 0;
+  const Mat<3, 3> c3 = 0.25 * I3();
+  const Mat<6, 6> c6 = 0.25 * I6();
+  auto pick_of_type = [&](const ModelGraph& m, const std::string& type, fuse_core::Variable::SharedPtr& out) {
+    std::vector<fuse_core::Variable::SharedPtr> c;
+    for (const auto& v : m.vars) if (v.second->type() == type) c.push_back(v.second);
+    if (c.empty()) return false;
+    out = c[U(c.size())];
+    return true;
+  };
+  auto random_constraint = [&](const ModelGraph& m) -> fuse_core::Constraint::SharedPtr {
+    using fuse_variables::VelocityLinear3DStamped; using fuse_variables::Position3DStamped; using fuse_variables::Orientation3DStamped;
+    fuse_core::Variable::SharedPtr a, b;
+    const Vec3 d{N(rng), N(rng), N(rng)};
+    switch (U(4)) {
+      case 0:
+        if (!pick_of_type(m, "fuse_variables::VelocityLinear3DStamped", a)) return nullptr;
+        return bs_constraints::AbsoluteVelocityLinear3DStampedConstraint("rnd" + std::to_string(rng()), static_cast<VelocityLinear3DStamped&>(*a), d, c3);
+      case 1:
+        if (!pick_of_type(m, "fuse_variables::VelocityLinear3DStamped", a) || !pick_of_type(m, "fuse_variables::VelocityLinear3DStamped", b) || a == b) return nullptr;
+        return bs_constraints::RelativeVelocityLinear3DStampedConstraint("rnd" + std::to_string(rng()), static_cast<VelocityLinear3DStamped&>(*a),
+                                                                         static_cast<VelocityLinear3DStamped&>(*b), d, c3);
+      case 2: {
+        if (!pick_of_type(m, "fuse_variables::Position3DStamped", a)) return nullptr;
+        const auto q = m.vars.find(fuse_core::uuid::generate("fuse_variables::Orientation3DStamped", a->stamp()));
+        if (q == m.vars.end()) return nullptr;
+        return std::make_shared<fuse_constraints::AbsolutePose3DStampedConstraint>("rnd" + std::to_string(rng()), static_cast<Position3DStamped&>(*a),
+                   static_cast<Orientation3DStamped&>(*q->second), bs_constraints::Vector7d{d[0], d[1], d[2], 1, 0, 0, 0}, c6);
+      }
+      default: {
+        if (!pick_of_type(m, "fuse_variables::Position3DStamped", a) || !pick_of_type(m, "fuse_variables::Position3DStamped", b) || a == b) return nullptr;
+        const auto qa = m.vars.find(fuse_core::uuid::generate("fuse_variables::Orientation3DStamped", a->stamp()));
+        const auto qb = m.vars.find(fuse_core::uuid::generate("fuse_variables::Orientation3DStamped", b->stamp()));
+        if (qa == m.vars.end() || qb == m.vars.end()) return nullptr;
+        return std::make_shared<fuse_constraints::RelativePose3DStampedConstraint>("rnd" + std::to_string(rng()), static_cast<Position3DStamped&>(*a),
+                   static_cast<Orientation3DStamped&>(*qa->second), static_cast<Position3DStamped&>(*b), static_cast<Orientation3DStamped&>(*qb->second),
+                   bs_constraints::Vector7d{d[0], d[1], d[2], 1, 0, 0, 0}, c6);
+      }
+    }
+  };
+  const int rounds = 500;
+  size_t max_vars = 0, max_cons = 0, n_clones = 0, n_drops = 0;
+  for (int round = 0; round < rounds; ++round) {
+    Member& mb = family[U(family.size())];
+    // one random transaction: removals of constraints, of variables nothing uses any more, then additions
+    fuse_core::Transaction tr;
+    ModelGraph after = mb.m;
+    const size_t n_rc = after.cons.empty() ? 0 : U(std::min<size_t>(after.cons.size(), after.cons.size() > 150 ? 40 : 5) + 1);
+    for (size_t k = 0; k < n_rc && !after.cons.empty(); ++k) {
+      auto it = after.cons.begin(); std::advance(it, U(after.cons.size()));
+      tr.removeConstraint(it->first); graveyard.push_back(it->first); after.cons.erase(it);
+    }
+    {
+      std::vector<fuse_core::UUID> unused;
+      for (const auto& v : after.vars) if (after.usesOf(v.first) == 0) unused.push_back(v.first);
+      for (const auto& u : unused) if (U(3) == 0) { tr.removeVariable(u); graveyard.push_back(u); after.vars.erase(u); }
+    }
+    const size_t n_av = U(7);
+    for (size_t k = 0; k < n_av; ++k) {
+      const fuse_core::Time stamp(0.01 * (U(2) && next_stamp > 4 ? (int)U(next_stamp) : next_stamp++));   // also between older stamps, also re-adds
+      std::vector<fuse_core::Variable::SharedPtr> vs;
+      if (U(2)) vs.push_back(fuse_variables::VelocityLinear3DStamped::make_shared(stamp));
+      else { vs.push_back(fuse_variables::Orientation3DStamped::make_shared(stamp)); vs.push_back(fuse_variables::Position3DStamped::make_shared(stamp)); }
+      for (auto& v : vs) {
+        if (after.vars.count(v->uuid())) continue;        // (a re-add would overwrite the value: keep the model simple)
+        if (v->size() == 3) for (int i = 0; i < 3; ++i) v->data()[i] = N(rng);
+        tr.addVariable(v); after.vars[v->uuid()] = v;
+      }
+    }
+    const size_t n_ac = U(16);
+    for (size_t k = 0; k < n_ac; ++k) {
+      auto c = random_constraint(after);
+      if (!c) continue;
+      tr.addConstraint(c); after.cons[c->uuid()] = c;
+    }
+    mb.g->update(tr);
+    mb.m = std::move(after);
+    max_vars = std::max(max_vars, mb.m.vars.size()); max_cons = std::max(max_cons, mb.m.cons.size());
+    check_against_model(*mb.g, mb.m, graveyard, round % 9 == 0);
+    // family events: clone (of any member), drop a member (parents before children, too), verify a bystander
+    if (U(4) == 0 && family.size() < 5) {
+      Member& src = family[U(family.size())];
+      Member cl{src.g->clone(), src.m};
+      family.push_back(std::move(cl));
+      ++n_clones;
+      check_against_model(*family.back().g, family.back().m, graveyard, false);
+    } else if (U(7) == 0 && family.size() > 1) {
+      family.erase(family.begin() + U(family.size()));
+      ++n_drops;
+    }
+    Member& other = family[U(family.size())];
+    check_against_model(*other.g, other.m, graveyard, round % 13 == 0);
+    if (graveyard.size() > 400) graveyard.erase(graveyard.begin(), graveyard.begin() + 200);
+    if (g_fail) { std::printf("  (first failure in round %d, family of %zu)\n", round, family.size()); return; }
+  }
+  std::printf("  %d transactions, %zu clones, %zu graphs dropped, largest graph %zu variables / %zu constraints\n", rounds, n_clones, n_drops, max_vars, max_cons);
+  // removing a variable that is in use throws and leaves the graph as it was
+  for (auto& mb : family) {
+    if (mb.m.cons.empty()) continue;
+    const auto& c = *mb.m.cons.begin()->second;
+    bool threw = false;
+    try { mb.g->removeVariable(c.variables()[0]); } catch (const std::logic_error&) { threw = true; }
+    CHECK(threw);
+    check_against_model(*mb.g, mb.m, graveyard, true);
+  }
+}
+
 int main() {
   test_block_order_and_pack();
   test_simple_2_state_fg();
@@ -457,6 +639,7 @@ int main() {
   test_inverse_depth_window();
   test_true_marginalization_linear_chain();
   test_clone_is_an_independent_snapshot();
+  test_random_transactions_against_model();
   test_fixed_lag_smoother_window(true);
   test_fixed_lag_smoother_window(false);
   if (g_fail) { std::printf("FAILED: %d checks\n", g_fail); return 1; }
