@@ -258,3 +258,49 @@ def test_contexts_release_their_device_memory(gpu_solver_cls):
         cycle()
     free1 = free_bytes()
     assert free0 - free1 < 32 << 20, "device memory in use grew by %.1f MB over 40 context lifetimes" % ((free0 - free1) / 2**20)
+
+
+def test_contexts_on_concurrent_host_threads(gpu_solver_cls):
+    """One context per host thread, all on one device (the reference runs its local smoother, global mapper and submap
+    refinement side by side, submap_refinement.cpp:35-115): create, load, finalize, solve, read back and destroy concurrently;
+    every thread must get what a lone context gets for the same window — nothing in the library may be shared between
+    contexts except the device."""
+    import threading
+    cases = [synthetic.vio_window(n_kf=40, n_lm=900, seed=1),            # Schur path, several tiles
+             synthetic.lio_window(n_kf=60, n_rel=500, seed=2),           # pose-only dense path
+             synthetic.pose_graph(n_pose=2200, n_loop=3000, seed=3),     # above the dense limit: PCG path
+             mixed_problem(4, n_state=5, n_lm=30, consistent=True, with_losses=True, hold_first=True),
+             synthetic.vio_window(n_kf=12, n_lm=200, seed=5, cauchy_a=None),
+             synthetic.idp_window(n_kf=8, n_lm=60, seed=6)]
+
+    def run(pr, rounds):
+        out = []
+        for _ in range(rounds):
+            g = gpu_solver_cls(0)
+            pr.load(g); g.finalize()
+            opt = g.options_default(); opt.max_num_iterations = 5
+            s = g.solve(opt)
+            out.append((s.termination_type, [i.step_is_successful for i in g.iterations()], s.final_cost, g.get_blocks()))
+            del g
+        return out
+
+    alone = [run(pr, 1)[0] for pr in cases]
+    results, errors = [None] * len(cases), []
+
+    def work(i):
+        try:
+            results[i] = run(cases[i], 4)
+        except Exception as e:      # noqa: BLE001 — reported below, from the main thread
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(cases))]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    assert not errors, errors
+    for i, (term, acc, cost, x) in enumerate(alone):
+        for term_c, acc_c, cost_c, x_c in results[i]:
+            assert term_c == term and acc_c == acc
+            # (run-to-run: FP64 atomics, and the PCG window stops its inner solves at a 1e-10 relative residual — DESIGN.md §4)
+            assert abs(cost_c - cost) <= 1e-7 * max(abs(cost), 1e-30), (i, cost_c, cost)
+            # (the unconverged, ill-conditioned PCG window alone repeats its values to ~1e-6 only, sequentially as well)
+            assert np.abs(x_c - x).max() <= (1e-4 if i == 2 else 1e-6), i
