@@ -211,7 +211,7 @@ int build_bsr(bsgpu_ctx* c);
 // bsgpu_solve.cpp
 int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum);
 void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot);
-void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, bool first);
+void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, bool first, bool gradient_only = false);
 void final_reduce(bsgpu_ctx* c);
 int fetch_scalars(bsgpu_ctx* c);
 int ensure_vis_src(bsgpu_ctx* c);

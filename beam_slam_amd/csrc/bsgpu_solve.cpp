@@ -104,7 +104,9 @@ void final_reduce(bsgpu_ctx* c) {
   c->ev_reduce_pending = c->scal_mirrored && c->ev_reduce && hipEventRecord(c->ev_reduce, c->stream) == hipSuccess;
 }
 
-void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, bool first) {
+// gradient_only: the caller wants the gradient (and its norms) of the current point and will not factorise — the
+// camera-pair blocks of the reduced system, four fifths of the pair kernel's work, are skipped
+void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, bool first, bool gradient_only) {
   if (c->use_pcg) { assemble_pcg(c, o, radius, new_J, first); return; }
   hipStream_t s = c->stream;
   // one launch clears the reduced system, gradient, diagonal and the scalars of this step (GRAD_MAX, GRAD_NORM2, CHOL_FAIL)
@@ -115,7 +117,7 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
   c->scal_mirrored = false;
   launch_landmark(s, c->vis, c->n_pose, c->d_scal + SC_RADIUS, first ? 1 : 0, new_J ? 1 : 0, o.jacobi_scaling, o.min_lm_diagonal,
                   o.max_lm_diagonal, c->d_scale, c->d_dcl, c->d_grad);
-  launch_pairs(s, c->vis, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm);
+  launch_pairs(s, c->vis, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm, gradient_only);
   launch_small_assemble_set(s, c->small + 2, kNumInternal - 2, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm);
   for (const auto& mc : c->marg)
     if (mc.active) launch_marg_assemble(s, mc.dev, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm);
@@ -200,7 +202,7 @@ void enqueue_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius,
   const bool have_J = (kind == STEP_ACCEPT && c->spec_J) || (kind == STEP_REJECT && !c->spec_J);
   if (!have_J) eval_all(c, c->d_x, true, SC_COST_X);
   c->spec_J = false;
-  assemble(c, o, radius, kind != STEP_REJECT, kind == STEP_FIRST);
+  assemble(c, o, radius, kind != STEP_REJECT, kind == STEP_FIRST, gradient_only);
   if (gradient_only) { final_reduce(c); return; }
   linear_solve_and_candidate(c, o);
   // The host now waits for this step's scalars and decides; in the common case (accepted) the next thing the device needs is the

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(64) void pairs_kernel(int n_seg, const int* __restr
                                                    const double* __restrict__ CR, const int* __restrict__ cp_tq,
                                                    const int* __restrict__ cp_tp, double* __restrict__ S, int ld,
                                                    int rhs_row, double* __restrict__ grad,
-                                                   double* __restrict__ hdiag, const int* __restrict__ perm) {
+                                                   double* __restrict__ hdiag, const int* __restrict__ perm, int grad_only) {
   // XCD-aware mapping: consecutive workgroup ids go round-robin over the 8 XCDs, each with its own L2.  Segments are
   // ordered by camera pair (ca, cb), and all segments of one ca gather the same J / CR rows, so every XCD takes a
   // CONTIGUOUS range of segments: the rows of a camera are then pulled into one L2 instead of eight.
@@ -315,6 +315,7 @@ __global__ __launch_bounds__(64) void pairs_kernel(int n_seg, const int* __restr
   const int lane = threadIdx.x;
   const int ci = seg_ci[seg], cj = seg_cj[seg];
   const bool diag = ci == cj;
+  if (grad_only && !diag) return;   // (end of a solve: only the gradient of the accepted point is wanted, bsgpu_solve.cpp)
   double blk[36];
 #pragma unroll
   for (int i = 0; i < 36; ++i) blk[i] = 0.0;
@@ -397,10 +398,11 @@ __global__ __launch_bounds__(64) void pairs_kernel(int n_seg, const int* __restr
   }
 }
 
-void launch_pairs(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm) {
+void launch_pairs(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm,
+                  bool grad_only) {
   if (v.n_seg == 0) return;
   hipLaunchKernelGGL(pairs_kernel, dim3(8 * ((v.n_seg + 7) / 8)), dim3(64), 0, s, v.n_seg, v.seg_ci, v.seg_cj, v.seg_start, v.ent_fa,
-                     v.ent_fb, v.J, v.r, v.CR, v.cp_tq, v.cp_tp, S, ld, rhs_row, grad, hdiag, perm);
+                     v.ent_fb, v.J, v.r, v.CR, v.cp_tq, v.cp_tp, S, ld, rhs_row, grad, hdiag, perm, grad_only ? 1 : 0);
 }
 
 // ---------------------------------------------------------------------------------------------------

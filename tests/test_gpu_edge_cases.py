@@ -231,6 +231,9 @@ def test_contexts_release_their_device_memory(gpu_solver_cls):
     """create / describe / solve / covariance / marginalise / destroy, many times: device memory in use does not creep (pooled
     buffers, pinned scalars, events and streams all go back)."""
     import ctypes
+    import os
+    if os.environ.get("PYTEST_XDIST_WORKER"):
+        pytest.skip("reads the device-wide free memory: meaningless next to other test processes (-n)")
     hip = ctypes.CDLL("/opt/rocm/lib/libamdhip64.so")      # the runtime libbsgpu itself is linked against (torch brings its own)
 
     def free_bytes():
