@@ -523,7 +523,7 @@ int bsgpu_covariance(bsgpu_ctx* c, int32_t ba, int32_t bb, double* out) try {
   (void)hipMemcpyAsync(d_cols, cols.data(), sizeof(int) * cols.size(), hipMemcpyHostToDevice, s);
   launch_cov_units(s, c->d_S, c->npad, c->plan.rhs_row, d_cols, (int)cols.size());
   const DenseDev D{c->d_perm, c->d_nreal, c->d_rows_flat, c->d_panels, c->d_Lp, c->d_Vinv,
-                   c->d_bs_desc, c->d_chain_begin, c->d_chain_end, c->d_tile_sync};
+                   c->d_bs_desc, c->d_chain_begin, c->d_chain_end, c->d_tile_sync, c->d_ftasks, c->d_fsync};
   dense_factor(s, c->plan, D, c->d_S, c->d_scal);
   launch_cov_dots(s, c->d_Lp, c->npad, c->plan.rhs_row, c->plan.T * 64, ta, row_b0, tb, d_out);
   (void)hipMemcpyAsync(out, d_out, sizeof(double) * ta * tb, hipMemcpyDeviceToHost, s);
@@ -699,7 +699,10 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
   double *dS = nullptr, *dLp = nullptr, *dV = nullptr, *dy = nullptr, *dscal = nullptr;
   int *dperm = nullptr, *dnreal = nullptr, *drows = nullptr;
   PanelDesc *dpan = nullptr, *dsep = nullptr;
-  int *dpot2 = nullptr, *dcb = nullptr, *dce = nullptr, *dsync = nullptr;
+  int *dpot2 = nullptr, *dcb = nullptr, *dce = nullptr, *dsync = nullptr, *dfsync = nullptr;
+  FusedTask* dft = nullptr;
+  const char* ef = getenv("BSGPU_CHOL_FUSED");
+  const bool fused = !(ef && atoi(ef) == 0) && !P.ftasks.empty();
   hipStream_t s;
   if (hipStreamCreate(&s) != hipSuccess) return BSGPU_ERR_DEVICE;
   auto up = [](const void* src, size_t bytes, void** dst) {
@@ -716,6 +719,10 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
        up(P.bs_desc.data(), sizeof(int) * P.bs_desc.size(), (void**)&dpot2) &&
        up(P.chain_begin.data(), sizeof(int) * P.chain_begin.size(), (void**)&dcb) && up(P.chain_end.data(), sizeof(int) * P.chain_end.size(), (void**)&dce) &&
        up(P.tile_sync.data(), sizeof(int) * P.tile_sync.size(), (void**)&dsync);
+  if (ok && fused) {
+    const std::vector<int> zeros((size_t)P.fused_sync_words, 0);
+    ok = up(P.ftasks.data(), sizeof(FusedTask) * P.ftasks.size(), (void**)&dft) && up(zeros.data(), sizeof(int) * zeros.size(), (void**)&dfsync);
+  }
   int rc = BSGPU_OK;
   if (ok) {
     (void)hipMemcpy(dS, hS.data(), sizeof(double) * hS.size(), hipMemcpyHostToDevice);
@@ -723,7 +730,7 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, s);
-    const DenseDev D{dperm, dnreal, drows, dpan, dLp, dV, dpot2, dcb, dce, dsync};
+    const DenseDev D{dperm, dnreal, drows, dpan, dLp, dV, dpot2, dcb, dce, dsync, dft, dfsync};
     dense_factor_solve(s, P, D, dS, dy, dscal);
     (void)hipEventRecord(e1, s);
     if (hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess) rc = BSGPU_ERR_DEVICE;
@@ -741,6 +748,7 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
   (void)hipFree(dS); (void)hipFree(dLp); (void)hipFree(dV); (void)hipFree(dy); (void)hipFree(dscal);
   (void)hipFree(dperm); (void)hipFree(dnreal); (void)hipFree(drows); (void)hipFree(dpan);
   (void)hipFree(dsep); (void)hipFree(dpot2); (void)hipFree(dcb); (void)hipFree(dce); (void)hipFree(dsync);
+  (void)hipFree(dft); (void)hipFree(dfsync);
   (void)hipStreamDestroy(s);
   return rc;
 } catch (...) { return api_exception(nullptr); }

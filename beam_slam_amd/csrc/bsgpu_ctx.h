@@ -129,6 +129,8 @@ struct bsgpu_ctx {
   PanelDesc* d_panels = nullptr;
   int *d_bs_desc = nullptr, *d_chain_begin = nullptr, *d_chain_end = nullptr, *d_tile_sync = nullptr, *d_touched = nullptr;
   int n_touched = 0;
+  FusedTask* d_ftasks = nullptr;   // fused single-launch factorisation: task list and its counters (k_chol.hip chol_fused_kernel)
+  int* d_fsync = nullptr;
   double* d_Vinv = nullptr;
   double* d_Lp = nullptr;     // shadow of S holding the off-diagonal L panels (k_chol.hip)
   double* d_ytan = nullptr;   // y in tangent order
@@ -223,6 +225,8 @@ struct DenseDev {
   double *Lp, *Vinv;
   const int *bs_desc, *chain_begin, *chain_end;   // bs_desc: DensePlan::bs_desc on the device
   int* tile_sync;   // [expected arrivals | arrival counters] per tile (dense_plan.h)
+  const FusedTask* ftasks = nullptr;   // fused single-launch factorisation (null: the launch-per-step path)
+  int* fsync = nullptr;
 };
 void dense_factor(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* scal);
 // (iperm / y_tan / delta given: the back-substitution also writes the solution in tangent order and the step -y)

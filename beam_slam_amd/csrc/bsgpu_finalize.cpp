@@ -500,6 +500,15 @@ int finalize(bsgpu_ctx* c) {
     c->d_panels = c->upload(c->plan.panels);
     c->d_bs_desc = c->upload(c->plan.bs_desc);
     c->d_tile_sync = c->upload(c->plan.tile_sync);
+    {
+      // fused single-launch factorisation (default; BSGPU_CHOL_FUSED=0 keeps the launch-per-step path): task list + zeroed counters
+      const char* ef = getenv("BSGPU_CHOL_FUSED");
+      c->d_ftasks = nullptr; c->d_fsync = nullptr;
+      if (!(ef && atoi(ef) == 0) && !c->plan.ftasks.empty()) {
+        c->d_ftasks = c->upload(c->plan.ftasks);
+        c->d_fsync = c->upload(std::vector<int>((size_t)c->plan.fused_sync_words, 0));
+      }
+    }
     c->d_touched = c->upload(c->plan.touched_tiles); c->n_touched = (int)c->plan.touched_tiles.size();
     c->d_chain_begin = c->upload(c->plan.chain_begin); c->d_chain_end = c->upload(c->plan.chain_end);
     c->d_Vinv = c->alloc<double>((size_t)std::max(1, T) * chol_vinv_stride());

@@ -132,6 +132,10 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
 
 void dense_factor(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* scal) {
   const int ld = P.npad;
+  if (D.ftasks && D.fsync) {   // the whole factorisation in one launch
+    launch_chol_fused(s, S, D.Lp, ld, D.ftasks, (int)P.ftasks.size(), D.nreal, D.Vinv, scal, D.fsync, P.fused_sync_words);
+    return;
+  }
   for (int st = 0; st < P.n_steps(); ++st) {
     // (tiles no look-ahead factors are factored inside the panel step itself: PanelDesc::self_potrf)
     launch_chol_panel_step(s, S, D.Lp, ld, D.panels + P.step_off[st], P.step_off[st + 1] - P.step_off[st], P.step_maxrows[st],
@@ -164,7 +168,7 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
     launch_negate_pose(s, c->n_pose, c->d_px, c->d_delta);
   } else if (c->n_pose > 0) {
     const DenseDev D{c->d_perm, c->d_nreal, c->d_rows_flat, c->d_panels, c->d_Lp, c->d_Vinv,
-                     c->d_bs_desc, c->d_chain_begin, c->d_chain_end, c->d_tile_sync};
+                     c->d_bs_desc, c->d_chain_begin, c->d_chain_end, c->d_tile_sync, c->d_ftasks, c->d_fsync};
     dense_factor_solve(s, c->plan, D, c->d_S, c->d_y, c->d_scal, c->d_iperm, c->n_pose, c->d_ytan, c->d_delta);
   }
   // landmark back-substitution + the model-cost-change terms of the visual factors (partial arrays only, summed once at the end)

@@ -25,6 +25,22 @@ struct PanelDesc {  // device-visible
                     // (i, j) with both bits set are accumulated with atomics (two panels update them concurrently)
 };
 
+// One unit of work of the fused (single-launch) factorisation, k_chol.hip chol_fused_kernel: workgroup-sized, pulled from a
+// device-side queue in list order.  The list is a topological order of the tile dependencies (every counter a task waits
+// for is advanced by tasks EARLIER in the list), so a queue that hands tasks out in order cannot deadlock whatever the
+// residency of the grid.
+struct FusedTask {  // device-visible, 32 bytes
+  int k;        // panel (S tile index of the diagonal tile); for a potrf-only task: the tile to factor
+  int ti, tj;   // row tiles of the update C(ti, tj) -= X_ti X_tj^T, ti >= tj
+  int flags;    // kFusedPotrfOnly
+  int tot_i;    // number of updates tile (ti, k) receives in the whole factorisation: it is final (readable) at that count
+  int tot_j;    // ... tile (tj, k)
+  int need_c;   // number of updates of tile (ti, tj) by earlier tasks: this task's turn comes at exactly that count
+                // (updates of one tile are applied in list order: no atomics, bit-reproducible factor); -1: no update (rhs x rhs)
+  int tot_c;    // total number of updates of tile (ti, tj): the task that applies the last one of a diagonal tile factors it
+};
+constexpr int kFusedPotrfOnly = 1;
+
 struct DensePlan {
   int n_pose = 0, T = 0 /* real tiles */, npad = 0, rhs_row = 0;
   std::vector<int> perm;       // natural tile -> S tile
@@ -51,6 +67,10 @@ struct DensePlan {
   // fetches the records of its tiles in one coalesced round instead of three dependent ones (tile -> panel -> row list)
   static constexpr int kBsDescRows = 16, kBsDescInts = 3 + kBsDescRows;
   std::vector<int> bs_desc;
+  // fused single-launch factorisation (k_chol.hip chol_fused_kernel)
+  std::vector<FusedTask> ftasks;
+  int fused_sync_words = 0;   // ints of device scratch: [queue head | abort | exited workgroups | pad | potrf_done (T+1) | update counts (T+1)^2]
+  double fused_flops = 0.0;   // FP64 flops of the planned factorisation (trsm + rank-64 updates + potrf of every touched tile), for the MFMA roofline
   // solve offsets
   inline int spos(int j) const { return perm[j >> 6] * 64 + (j & 63); }
 
@@ -201,6 +221,35 @@ struct DensePlan {
     }
     potrf_before_step_off[steps.size()] = (int)potrf_tiles.size();
     for (PanelDesc& d : panels) d.self_potrf = factored_by_lookahead[d.k] ? 0 : 1;
+    // ---- task list of the fused factorisation: potrf-only tasks for the tiles nothing ever updates (heads of pieces), then the
+    // (panel, i, j) updates step by step.  Updates of one tile are applied in list order (need_c), so no two of them race.
+    {
+      ftasks.clear();
+      std::vector<int> tot((size_t)N * N, 0), seen((size_t)N * N, 0);
+      for (int k = 0; k < T; ++k) for (int a : rows[k]) for (int b : rows[k]) if (b <= a && !(a == T && b == T)) tot[(size_t)a * N + b]++;
+      for (int t = 0; t < T; ++t) if (tot[(size_t)t * N + t] == 0) { FusedTask f{t, t, t, kFusedPotrfOnly, 0, 0, -1, 0}; ftasks.push_back(f); }
+      fused_flops = 0.0;
+      const double tile3 = 64.0 * 64.0 * 64.0;
+      for (size_t s = 0; s < steps.size(); ++s) {
+        std::vector<FusedTask> st;
+        for (int k : steps[s]) {
+          fused_flops += tile3 / 3.0 + tile3 * (double)rows[k].size();   // potrf(k) + one triangular solve per row tile
+          for (int a : rows[k]) for (int b : rows[k]) {
+            if (b > a) continue;
+            FusedTask f{k, a, b, 0, tot[(size_t)a * N + k], tot[(size_t)b * N + k], -1, 0};
+            if (!(a == T && b == T)) { f.tot_c = tot[(size_t)a * N + b]; fused_flops += (a == b ? 1.0 : 2.0) * tile3; }
+            st.push_back(f);
+          }
+        }
+        // inside a step: the tiles the next panels need first (smallest column, then row) come first
+        std::stable_sort(st.begin(), st.end(), [](const FusedTask& x, const FusedTask& y) { return x.tj != y.tj ? x.tj < y.tj : x.ti < y.ti; });
+        for (FusedTask& f : st) {
+          if (!(f.ti == T && f.tj == T)) f.need_c = seen[(size_t)f.ti * N + f.tj]++;
+          ftasks.push_back(f);
+        }
+      }
+      fused_sync_words = 4 + N + N * N;
+    }
     // ---- back-substitution plan
     panel_of_tile.assign(T, 0);
     for (size_t i = 0; i < panels.size(); ++i) panel_of_tile[panels[i].k] = (int)i;

@@ -462,6 +462,241 @@ void launch_chol_panel_step(hipStream_t s, double* S, double* Lp, int ld, const 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The whole factorisation in ONE launch: a persistent grid pulls the plan's tasks (dense_plan.h FusedTask) from a device-side
+// queue in list order and synchronises through per-tile counters instead of kernel boundaries.
+//
+//   task (k; ti, tj):  wait  L_kk published, tiles (ti,k) and (tj,k) final, and its turn on tile (ti,tj)
+//                      X_i = A_ik L_kk^-T, X_j = A_jk L_kk^-T, C_ij -= X_i X_j^T          (as chol_panel_step_kernel)
+//                      publish C_ij, advance the tile's counter; whoever applies the LAST update of a diagonal tile holds the
+//                      finished tile in registers and factors it on the spot (look-ahead) and publishes L + its block inverses
+//
+// Updates of one tile are applied in list order (FusedTask::need_c), so there are no atomics on matrix data and the factor is
+// bit-reproducible.  Hand-off between workgroups (MI355X: eight XCDs with private L2s, L1 never refreshed by other CUs):
+// producers store write-through (sc1) and drain (s_waitcnt vmcnt(0)) before ONE lane advances the counter with an agent-scope
+// atomic; consumers poll the counters with relaxed agent-scope loads from one lane and then read the tiles with sc1 loads.
+// Dead-lock freedom: the queue hands tasks out in list order and every counter a task waits for is advanced by earlier tasks, so
+// the earliest unfinished task is always held by a running workgroup whose dependencies are complete — whatever the residency
+// of the grid.  Every wait is bounded (wall clock): on a time-out the factorisation is flagged failed (SC_CHOL_FAIL) and drains.
+// The last workgroup to leave re-zeroes the queue head and the counters: the next launch starts from a clean slate.
+// ---------------------------------------------------------------------------------------------------
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+BSG_DEV double2 ld16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16 /* sc1 */);
+  double2 d; __builtin_memcpy(&d, &v, 16); return d;
+}
+BSG_DEV double ld8_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 16);
+  double d; __builtin_memcpy(&d, &v, 8); return d;
+}
+BSG_DEV void st16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, double2 d) {
+  u32x4_t v; __builtin_memcpy(&v, &d, 16);
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, 16);
+}
+BSG_DEV void st8_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, double d) {
+  u32x2_t v; __builtin_memcpy(&v, &d, 8);
+  __builtin_amdgcn_raw_buffer_store_b64(v, r, byte_off, 0, 16);
+}
+BSG_DEV int ld_flag(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// one lane: wait until *p == want (counters only ever grow towards it); false on abort / time-out
+BSG_DEV bool wait_count(const int* p, int want, int* abort_w, long long deadline) {
+  for (;;) {
+    if (ld_flag(p) >= want) return true;
+    if (ld_flag(abort_w) != 0) return false;
+    if ((long long)wall_clock64() > deadline) { __hip_atomic_store(abort_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+// L_tt, its block inverses and reciprocal pivots to Lp / Vinv, write-through (read by other workgroups of this launch)
+BSG_DEV void write_factor_sc1(__amdgpu_buffer_rsrc_t rLp, __amdgpu_buffer_rsrc_t rV, int ld, int t, const double* sC, const double* sV,
+                              const double* sInvD, int tid) {
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int i = tid + 256 * q;
+    const int r = i >> 5, c2 = (i & 31) * 2;
+    const unsigned at = (unsigned)(((size_t)(t * NB + r) * ld + t * NB + c2) * sizeof(double));
+    if (c2 <= r) {   // (the element right of the diagonal rides along: the strictly upper part of the tile is never read)
+      st16_sc1(rLp, at, *reinterpret_cast<const double2*>(&sC[r * LDT + c2]));
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int i = (tid + 256 * q) * 2;
+    st16_sc1(rV, (unsigned)(((size_t)t * kVinvStride + i) * sizeof(double)), *reinterpret_cast<const double2*>(&sV[i]));
+  }
+  if (tid < NB) st8_sc1(rV, (unsigned)(((size_t)t * kVinvStride + 1024 + tid) * sizeof(double)), sInvD[tid]);
+}
+
+constexpr long long kFusedTimeoutTicks = 100000000LL / 4;   // s_memrealtime runs at 100 MHz: a quarter of a second
+
+__global__ __launch_bounds__(256) void chol_fused_kernel(double* __restrict__ S, double* __restrict__ Lp, int ld,
+                                                          const FusedTask* __restrict__ tasks, int n_tasks,
+                                                          const int* __restrict__ nreal, double* __restrict__ Vinv, int n_vinv_tiles,
+                                                          double* __restrict__ scal, int* sync, int n_sync_words) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* sXi = smem;                 // 64 x LDT
+  double* sXj = sXi + NB * LDT;       // 64 x LDT
+  double* sL = sXj + NB * LDT;        // 64 x LDT
+  double* sV = sL + NB * LDT;         // 4 x 256
+  double* sT = sV + 4 * 256;          // 4 x 16 x 17
+  double* sInvD = sT + 4 * 16 * 17;   // 64
+  int* s_ctl = reinterpret_cast<int*>(sInvD + NB);   // 4 ints
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = ld / NB, T = N - 1;
+  int* head = sync; int* abort_w = sync + 1; int* exited = sync + 2;
+  int* potrf_done = sync + 4; int* upd = sync + 4 + N;
+  const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(S, 0, (int)((size_t)ld * ld * sizeof(double)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rLp = __builtin_amdgcn_make_buffer_rsrc(Lp, 0, (int)((size_t)ld * ld * sizeof(double)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(Vinv, 0, (int)((size_t)n_vinv_tiles * kVinvStride * sizeof(double)), 0x00020000);
+  const long long deadline = (long long)wall_clock64() + kFusedTimeoutTicks;
+  const int crow = lane >> 4, ccol = lane & 15;
+  for (;;) {
+    if (tid == 0) s_ctl[0] = atomicAdd(head, 1);
+    __syncthreads();
+    const int t = s_ctl[0];
+    if (t >= n_tasks) break;
+    const FusedTask tk = tasks[t];
+    const int k = tk.k;
+    if (tk.flags & kFusedPotrfOnly) {
+      // a tile nothing updates (the head of a piece): as assembled, from the previous launches
+      double2 v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int i = tid + 256 * q;
+        v[q] = *reinterpret_cast<const double2*>(&S[(size_t)(k * NB + (i >> 5)) * ld + k * NB + (i & 31) * 2]);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int i = tid + 256 * q;
+        const int r = i >> 5, c2 = (i & 31) * 2;
+        sXj[r * LDT + c2] = (c2 <= r) ? v[q].x : 0.0;
+        sXj[r * LDT + c2 + 1] = (c2 + 1 <= r) ? v[q].y : 0.0;
+      }
+      __syncthreads();
+      if (nreal[k] < NB) { mask_unreal_columns(sXj, nreal[k], tid); __syncthreads(); }
+      const bool bad = potrf64_lds(sXj, sV, sInvD, tid, nreal[k]);
+      if (bad && tid == 0) scal[SC_CHOL_FAIL] = 1.0;
+      write_factor_sc1(rLp, rV, ld, k, sXj, sV, sInvD, tid);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(&potrf_done[k], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      continue;
+    }
+    const int ti = tk.ti, tj = tk.tj;
+    const bool diag = ti == tj;
+    const bool do_update = tk.need_c >= 0;
+    if (tid == 0) {
+      bool ok = wait_count(&potrf_done[k], 1, abort_w, deadline);
+      ok = ok && wait_count(&upd[ti * N + k], tk.tot_i, abort_w, deadline);
+      if (!diag) ok = ok && wait_count(&upd[tj * N + k], tk.tot_j, abort_w, deadline);
+      if (do_update) ok = ok && wait_count(&upd[ti * N + tj], tk.need_c, abort_w, deadline);
+      s_ctl[1] = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_ctl[1]) break;
+    const int ri = ti * NB, rj = tj * NB, c0 = k * NB;
+    {
+      double2 vXi[8], vL[8], vXj[8], vV[2];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int i = tid + 256 * q;
+        const int r = i >> 5, c2 = (i & 31) * 2;
+        vXi[q] = ld16_sc1(rS, (unsigned)(((size_t)(ri + r) * ld + c0 + c2) * sizeof(double)));
+        vL[q] = ld16_sc1(rLp, (unsigned)(((size_t)(c0 + r) * ld + c0 + c2) * sizeof(double)));
+        vXj[q] = ld16_sc1(rS, (unsigned)(((size_t)(rj + r) * ld + c0 + c2) * sizeof(double)));
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) vV[q] = ld16_sc1(rV, (unsigned)(((size_t)k * kVinvStride + (tid + 256 * q) * 2) * sizeof(double)));
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int i = tid + 256 * q;
+        const int r = i >> 5, c2 = (i & 31) * 2;
+        *reinterpret_cast<double2*>(&sXi[r * LDT + c2]) = vXi[q];
+        *reinterpret_cast<double2*>(&sL[r * LDT + c2]) = vL[q];
+        *reinterpret_cast<double2*>(&sXj[r * LDT + c2]) = vXj[q];
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) *reinterpret_cast<double2*>(&sV[(tid + 256 * q) * 2]) = vV[q];
+    }
+    double4_t acc[4];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg)
+        acc[tt][reg] = do_update ? ld8_sc1(rS, (unsigned)(((size_t)(ri + 16 * wave + crow + 4 * reg) * ld + rj + 16 * tt + ccol) * sizeof(double))) : 0.0;
+    __syncthreads();
+    trsm_tile(sXi, sL, sV, sT, lane, wave);
+    if (!diag) trsm_tile(sXj, sL, sV, sT, lane, wave);
+    __syncthreads();
+    const double* Xj = diag ? sXi : sXj;
+    if (do_update) {
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+        acc[tt] = mfma_abt<64>(acc[tt], sXi + (16 * wave) * LDT, LDT, Xj + (16 * tt) * LDT, LDT, -1.0, lane);
+    }
+    const bool last_update = do_update && tk.need_c + 1 == tk.tot_c;
+    const bool factor_now = last_update && diag && ti < T;
+    if (do_update && !factor_now) {
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+          st8_sc1(rS, (unsigned)(((size_t)(ri + 16 * wave + crow + 4 * reg) * ld + rj + 16 * tt + ccol) * sizeof(double)), acc[tt][reg]);
+    }
+    if (diag) {
+      // the L panel of this row tile, for the back-substitution (a later launch: plain stores)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int i = tid + 256 * q;
+        const int r = i >> 5, c2 = (i & 31) * 2;
+        *reinterpret_cast<double2*>(&Lp[(size_t)(ri + r) * ld + c0 + c2]) = *reinterpret_cast<const double2*>(&sXi[r * LDT + c2]);
+      }
+    }
+    if (factor_now) {
+      double* sC = sXj;
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) store_d(sC + (16 * wave) * LDT + 16 * tt, LDT, lane, acc[tt]);
+      __syncthreads();
+      if (nreal[ti] < NB) { mask_unreal_columns(sC, nreal[ti], tid); __syncthreads(); }
+      const bool bad = potrf64_lds(sC, sV, sInvD, tid, nreal[ti]);
+      if (bad && tid == 0) scal[SC_CHOL_FAIL] = 1.0;
+      write_factor_sc1(rLp, rV, ld, ti, sC, sV, sInvD, tid);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      if (do_update) atomicAdd(&upd[ti * N + tj], 1);
+      if (factor_now) __hip_atomic_store(&potrf_done[ti], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  // leave: the last workgroup out re-zeroes the queue and the counters for the next factorisation
+  __syncthreads();
+  if (tid == 0) {
+    if (ld_flag(abort_w) != 0) scal[SC_CHOL_FAIL] = 2.0;
+    s_ctl[2] = (atomicAdd(exited, 1) == (int)gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (s_ctl[2]) {
+    for (int i = tid; i < n_sync_words; i += 256) __hip_atomic_store(&sync[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+constexpr size_t kFusedLds = sizeof(double) * (3 * NB * LDT + 4 * 256 + 4 * 16 * 17 + 64) + 16;
+
+void launch_chol_fused(hipStream_t s, double* S, double* Lp, int ld, const FusedTask* tasks_dev, int n_tasks, const int* nreal_dev,
+                       double* Vinv, double* scal, int* sync_dev, int n_sync_words) {
+  if (n_tasks <= 0) return;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0; hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n_cu = pr.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+  }
+  const int grid = std::max(1, std::min(n_tasks, n_cu));   // one workgroup per CU (118 KB of LDS each)
+  hipLaunchKernelGGL(chol_fused_kernel, dim3(grid), dim3(256), kFusedLds, s, S, Lp, ld, tasks_dev, n_tasks, nreal_dev, Vinv, ld / NB - 1, scal,
+                     sync_dev, n_sync_words);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // backward substitution L^T y = y', one launch per schedule step in reverse order, one 1024-thread
 // workgroup per panel of the step:
 //   rhs = y'[k] - sum_{t in rows(k)} L(t, k)^T y[t]   (16 row groups x 64 columns, loads issued up front)
@@ -624,6 +859,7 @@ void chol_prepare() {
                             (int)kPanelStepLds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds);
 }
 
 }  // namespace bsg
