@@ -14,7 +14,9 @@
 // All matrix products run on v_mfma_f64_16x16x4_f64:  a = A[lane&15][lane>>4], b = B[lane>>4][lane&15],
 // d[reg] = D[(lane>>4) + 4 reg][lane&15].  The 16x16 diagonal blocks are factored in registers of one
 // wave (row per lane, v_readlane broadcasts), the only scalar dependent chain left.
+#include <chrono>
 #include <cstring>
+#include <thread>
 
 #include "bsgpu_device.h"
 #include "dense_plan.h"
@@ -253,6 +255,40 @@ BSG_DEV void trsm_tile(double* sA, const double* sL, const double* sV, double* s
     store_d(rows + 16 * b, LDT, lane, x);
     __builtin_amdgcn_wave_barrier();
   }
+}
+
+// The same solve with nothing but constants read from LDS on the dependent path: the strip is kept TRANSPOSED in accumulator
+// registers.  With Y_b = X_b^T (16 x 16: row = column inside block b, column = row of the strip)
+//     Y_b = V_b (A_b^T - sum_{c<b} L_bc Y_c)
+// and the MFMA result layout d[reg] = D[(lane >> 4) + 4 reg][lane & 15] is exactly the B-operand layout of the next product
+// (K slice kk <-> register kk), so a solved block feeds the updates of the later blocks — and an updated block its own solve —
+// straight from registers; the A operands (V_b, -L_bc) are constants of the panel.  40 MFMAs per 16-row strip and no LDS round
+// trip between them (trsm_tile: a store / barrier / reload per block; 3.3 us per tile against 1.2 us, scripts/chol_probe.py).
+BSG_DEV void trsm_tile_t(double* sA, const double* sL, const double* sV, int lane, int wave) {
+  double* rows = sA + (16 * wave) * LDT;
+  const int n = lane & 15, q = lane >> 4;
+  double4_t acc[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) acc[b][reg] = rows[n * LDT + 16 * b + q + 4 * reg];   // A_b^T in result layout
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    double4_t y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) y = __builtin_amdgcn_mfma_f64_16x16x4f64(sV[b * 256 + n * 16 + 4 * kk + q], acc[b][kk], y, 0, 0, 0);
+#pragma unroll
+    for (int c = b + 1; c < 4; ++c)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(-sL[(16 * c + n) * LDT + 16 * b + 4 * kk + q], y[kk], acc[c], 0, 0, 0);
+    acc[b] = y;
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) rows[n * LDT + 16 * b + q + 4 * reg] = acc[b][reg];
 }
 
 // descriptors of the (few) panels of one step and their row-tile lists, passed BY VALUE: they arrive with the kernel
@@ -529,32 +565,64 @@ BSG_DEV void write_factor_sc1(__amdgpu_buffer_rsrc_t rLp, __amdgpu_buffer_rsrc_t
 
 constexpr long long kFusedTimeoutTicks = 100000000LL / 4;   // s_memrealtime runs at 100 MHz: a quarter of a second
 
-__global__ __launch_bounds__(256) void chol_fused_kernel(double* __restrict__ S, double* __restrict__ Lp, int ld,
-                                                          const FusedTask* __restrict__ tasks, int n_tasks,
-                                                          const int* __restrict__ nreal, double* __restrict__ Vinv, int n_vinv_tiles,
-                                                          double* __restrict__ scal, int* sync, int n_sync_words) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
+// a value every lane holds identically, moved to scalar registers (the compiler cannot see that it is uniform once it has been
+// through memory or a function argument: buffer descriptors built from it would otherwise be applied lane by lane)
+template <typename P> BSG_DEV P* uniform_ptr(P* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<P*>(((unsigned long long)hi << 32) | lo);
+}
+BSG_DEV long long uniform_i64(long long v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+struct FusedCtx {
+  double *S, *Lp, *Vinv, *scal;
+  const FusedTask* tasks;
+  const int* nreal;
+  int ld, n_vinv_tiles;
+  int *abort_w, *potrf_done, *upd;
+  long long deadline;
+  long long* probe_ts;
+  volatile int* trace;
+};
+// One task of the fused factorisation; returns false when a wait was aborted (wave-uniform).
+// NB: this body must not sit inside a loop of the kernel.  A persistent workgroup looping over the queue was the first design: with
+// the body inlined the structuriser folded the one-lane sections (dependency polls, publishes) into the loop's exit masks, the loop
+// around the barriers became a divergent one and a workgroup span for ever inside the potrf-only branch (found with rocgdb,
+// scripts/gdb_hang.sh); called out of line (noinline) it was correct but ~2 us slower per task (pointers through scratch, worse
+// register allocation of the potrf).  One task per workgroup needs no loop at all.
+template <bool PROBE>
+BSG_DEV bool chol_fused_task(const FusedCtx& C, int t, double* smem, long long t_deq) {
+  double* const S = uniform_ptr(C.S); double* const Lp = uniform_ptr(C.Lp); double* const scal = uniform_ptr(C.scal);
+  const int* const nreal = uniform_ptr(C.nreal); const FusedTask* const tasks = uniform_ptr(C.tasks);
+  const int ld = __builtin_amdgcn_readfirstlane(C.ld);
+  int* const abort_w = uniform_ptr(C.abort_w); int* const potrf_done = uniform_ptr(C.potrf_done); int* const upd = uniform_ptr(C.upd);
+  const long long deadline = uniform_i64(C.deadline);
+  long long* const probe_ts = uniform_ptr(C.probe_ts); volatile int* const trace = uniform_ptr(C.trace);
+  t = __builtin_amdgcn_readfirstlane(t);
+  smem = uniform_ptr(smem);
   double* sXi = smem;                 // 64 x LDT
   double* sXj = sXi + NB * LDT;       // 64 x LDT
   double* sL = sXj + NB * LDT;        // 64 x LDT
   double* sV = sL + NB * LDT;         // 4 x 256
-  double* sT = sV + 4 * 256;          // 4 x 16 x 17
+  double* sT = sV + 4 * 256;          // 4 x 16 x 17 (the LDS round-trip solve only)
   double* sInvD = sT + 4 * 16 * 17;   // 64
   int* s_ctl = reinterpret_cast<int*>(sInvD + NB);   // 4 ints
+  (void)sT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int N = ld / NB, T = N - 1;
-  int* head = sync; int* abort_w = sync + 1; int* exited = sync + 2;
-  int* potrf_done = sync + 4; int* upd = sync + 4 + N;
   const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(S, 0, (int)((size_t)ld * ld * sizeof(double)), 0x00020000);
   const __amdgpu_buffer_rsrc_t rLp = __builtin_amdgcn_make_buffer_rsrc(Lp, 0, (int)((size_t)ld * ld * sizeof(double)), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(Vinv, 0, (int)((size_t)n_vinv_tiles * kVinvStride * sizeof(double)), 0x00020000);
-  const long long deadline = (long long)wall_clock64() + kFusedTimeoutTicks;
+  const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(C.Vinv), 0, (int)((size_t)__builtin_amdgcn_readfirstlane(C.n_vinv_tiles) * kVinvStride * sizeof(double)), 0x00020000);
   const int crow = lane >> 4, ccol = lane & 15;
-  for (;;) {
-    if (tid == 0) s_ctl[0] = atomicAdd(head, 1);
-    __syncthreads();
-    const int t = s_ctl[0];
-    if (t >= n_tasks) break;
+  bool ok_all = true;
+    auto stamp = [&](int slot) {
+      if (PROBE && tid == 0) probe_ts[(size_t)t * 8 + slot] = wall_clock64();
+      if (PROBE && trace && tid == 0) { trace[blockIdx.x * 2] = slot; trace[blockIdx.x * 2 + 1] = t; }
+    };
+    if (PROBE && tid == 0) { probe_ts[(size_t)t * 8] = t_deq; probe_ts[(size_t)t * 8 + 7] = blockIdx.x; }
+    stamp(1);
     const FusedTask tk = tasks[t];
     const int k = tk.k;
     if (tk.flags & kFusedPotrfOnly) {
@@ -574,26 +642,32 @@ __global__ __launch_bounds__(256) void chol_fused_kernel(double* __restrict__ S,
       }
       __syncthreads();
       if (nreal[k] < NB) { mask_unreal_columns(sXj, nreal[k], tid); __syncthreads(); }
+      stamp(4);
       const bool bad = potrf64_lds(sXj, sV, sInvD, tid, nreal[k]);
+      stamp(5);
       if (bad && tid == 0) scal[SC_CHOL_FAIL] = 1.0;
       write_factor_sc1(rLp, rV, ld, k, sXj, sV, sInvD, tid);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) __hip_atomic_store(&potrf_done[k], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      continue;
-    }
+      stamp(6);
+    } else {
     const int ti = tk.ti, tj = tk.tj;
     const bool diag = ti == tj;
     const bool do_update = tk.need_c >= 0;
+    // dependencies of the SOLVES: L_kk and the two panel tiles.  The turn on the C tile is waited for later, after the product
+    // X_i X_j^T has been formed: with several updaters of one tile (separator tiles: every panel of both neighbouring pieces) only
+    // the read-modify-write of the tile is serialised, not the solves and the product.
     if (tid == 0) {
       bool ok = wait_count(&potrf_done[k], 1, abort_w, deadline);
       ok = ok && wait_count(&upd[ti * N + k], tk.tot_i, abort_w, deadline);
       if (!diag) ok = ok && wait_count(&upd[tj * N + k], tk.tot_j, abort_w, deadline);
-      if (do_update) ok = ok && wait_count(&upd[ti * N + tj], tk.need_c, abort_w, deadline);
       s_ctl[1] = ok ? 1 : 0;
     }
     __syncthreads();
-    if (!s_ctl[1]) break;
+    if (__builtin_amdgcn_readfirstlane(s_ctl[1]) == 0) { ok_all = false; }
+    else {
+    stamp(2);
     const int ri = ti * NB, rj = tj * NB, c0 = k * NB;
     {
       double2 vXi[8], vL[8], vXj[8], vV[2];
@@ -618,30 +692,20 @@ __global__ __launch_bounds__(256) void chol_fused_kernel(double* __restrict__ S,
 #pragma unroll
       for (int q = 0; q < 2; ++q) *reinterpret_cast<double2*>(&sV[(tid + 256 * q) * 2]) = vV[q];
     }
+    __syncthreads();
+    stamp(3);
+    trsm_tile_t(sXi, sL, sV, lane, wave);
+    if (!diag) trsm_tile_t(sXj, sL, sV, lane, wave);
+    __syncthreads();
+    stamp(4);
+    const double* Xj = diag ? sXi : sXj;
     double4_t acc[4];
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg)
-        acc[tt][reg] = do_update ? ld8_sc1(rS, (unsigned)(((size_t)(ri + 16 * wave + crow + 4 * reg) * ld + rj + 16 * tt + ccol) * sizeof(double))) : 0.0;
-    __syncthreads();
-    trsm_tile(sXi, sL, sV, sT, lane, wave);
-    if (!diag) trsm_tile(sXj, sL, sV, sT, lane, wave);
-    __syncthreads();
-    const double* Xj = diag ? sXi : sXj;
+    for (int tt = 0; tt < 4; ++tt) acc[tt] = double4_t{0.0, 0.0, 0.0, 0.0};
     if (do_update) {
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt)
         acc[tt] = mfma_abt<64>(acc[tt], sXi + (16 * wave) * LDT, LDT, Xj + (16 * tt) * LDT, LDT, -1.0, lane);
-    }
-    const bool last_update = do_update && tk.need_c + 1 == tk.tot_c;
-    const bool factor_now = last_update && diag && ti < T;
-    if (do_update && !factor_now) {
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg)
-          st8_sc1(rS, (unsigned)(((size_t)(ri + 16 * wave + crow + 4 * reg) * ld + rj + 16 * tt + ccol) * sizeof(double)), acc[tt][reg]);
     }
     if (diag) {
       // the L panel of this row tile, for the back-substitution (a later launch: plain stores)
@@ -650,6 +714,32 @@ __global__ __launch_bounds__(256) void chol_fused_kernel(double* __restrict__ S,
         const int i = tid + 256 * q;
         const int r = i >> 5, c2 = (i & 31) * 2;
         *reinterpret_cast<double2*>(&Lp[(size_t)(ri + r) * ld + c0 + c2]) = *reinterpret_cast<const double2*>(&sXi[r * LDT + c2]);
+      }
+    }
+    const bool last_update = do_update && tk.need_c + 1 == tk.tot_c;
+    const bool factor_now = last_update && diag && ti < T;
+    bool turn_ok = true;
+    if (do_update && tk.need_c > 0) {
+      // this task's turn on the tile: every earlier update of it has been published
+      if (tid == 0) s_ctl[1] = wait_count(&upd[ti * N + tj], tk.need_c, abort_w, deadline) ? 1 : 0;
+      __syncthreads();
+      turn_ok = __builtin_amdgcn_readfirstlane(s_ctl[1]) != 0;
+    }
+    if (!turn_ok) { ok_all = false; }
+    else {
+    stamp(5);
+    if (do_update) {
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+          acc[tt][reg] += ld8_sc1(rS, (unsigned)(((size_t)(ri + 16 * wave + crow + 4 * reg) * ld + rj + 16 * tt + ccol) * sizeof(double)));
+      if (!factor_now) {
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg)
+            st8_sc1(rS, (unsigned)(((size_t)(ri + 16 * wave + crow + 4 * reg) * ld + rj + 16 * tt + ccol) * sizeof(double)), acc[tt][reg]);
       }
     }
     if (factor_now) {
@@ -668,16 +758,50 @@ __global__ __launch_bounds__(256) void chol_fused_kernel(double* __restrict__ S,
       if (do_update) atomicAdd(&upd[ti * N + tj], 1);
       if (factor_now) __hip_atomic_store(&potrf_done[ti], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-  }
+    stamp(6);
+    }   // turn_ok
+    }   // dependencies met
+    }   // update task
+  return ok_all;
+}
+
+template <bool PROBE>
+__global__ __launch_bounds__(256) void chol_fused_kernel(double* __restrict__ S, double* __restrict__ Lp, int ld,
+                                                          const FusedTask* __restrict__ tasks, int n_tasks,
+                                                          const int* __restrict__ nreal, double* __restrict__ Vinv, int n_vinv_tiles,
+                                                          double* __restrict__ scal, int* sync, int n_sync_words,
+                                                          long long* probe_ts = nullptr /* PROBE: n_tasks x 8 wall-clock stamps */,
+                                                          volatile int* trace = nullptr /* PROBE: per workgroup (checkpoint, task) in host memory */) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  int* s_ctl = reinterpret_cast<int*>(smem + 3 * NB * LDT + 4 * 256 + 4 * 16 * 17 + NB);   // 4 ints behind the tiles (chol_fused_task)
+  const int tid = threadIdx.x;
+  const int N = ld / NB;
+  int* head = sync; int* abort_w = sync + 1; int* exited = sync + 2;
+  FusedCtx C;
+  C.S = S; C.Lp = Lp; C.Vinv = Vinv; C.scal = scal; C.tasks = tasks; C.nreal = nreal; C.ld = ld; C.n_vinv_tiles = n_vinv_tiles;
+  C.abort_w = abort_w; C.potrf_done = sync + 4; C.upd = sync + 4 + N;
+  C.deadline = (long long)wall_clock64() + kFusedTimeoutTicks;
+  C.probe_ts = probe_ts; C.trace = trace;
+  // ONE task per workgroup, taken from a ticket counter: the k-th workgroup to start running gets task k, so the tasks are started in
+  // list order whatever order the hardware dispatches the grid in — every counter a task waits for is advanced by a task that was
+  // started earlier (no dead-lock, whatever the residency).  No loop: see chol_fused_task.
+  long long t_deq = 0;
+  if (PROBE) t_deq = wall_clock64();
+  if (tid == 0) s_ctl[0] = atomicAdd(head, 1);
+  __syncthreads();
+  const int t = __builtin_amdgcn_readfirstlane(s_ctl[0]);
+  if (t < n_tasks) (void)chol_fused_task<PROBE>(C, t, smem, t_deq);
   // leave: the last workgroup out re-zeroes the queue and the counters for the next factorisation
   __syncthreads();
+  if (PROBE && trace && tid == 0) trace[blockIdx.x * 2] = 100;
   if (tid == 0) {
     if (ld_flag(abort_w) != 0) scal[SC_CHOL_FAIL] = 2.0;
     s_ctl[2] = (atomicAdd(exited, 1) == (int)gridDim.x - 1) ? 1 : 0;
   }
   __syncthreads();
-  if (s_ctl[2]) {
-    for (int i = tid; i < n_sync_words; i += 256) __hip_atomic_store(&sync[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (__builtin_amdgcn_readfirstlane(s_ctl[2]) != 0) {
+    const int nw = n_sync_words < 0 ? -n_sync_words : n_sync_words;
+    for (int i = tid; i < nw; i += 256) __hip_atomic_store(&sync[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 constexpr size_t kFusedLds = sizeof(double) * (3 * NB * LDT + 4 * 256 + 4 * 16 * 17 + 64) + 16;
@@ -691,9 +815,86 @@ void launch_chol_fused(hipStream_t s, double* S, double* Lp, int ld, const Fused
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n_cu = pr.multiProcessorCount;
     if (n_cu <= 0) n_cu = 256;
   }
-  const int grid = std::max(1, std::min(n_tasks, n_cu));   // one workgroup per CU (118 KB of LDS each)
-  hipLaunchKernelGGL(chol_fused_kernel, dim3(grid), dim3(256), kFusedLds, s, S, Lp, ld, tasks_dev, n_tasks, nreal_dev, Vinv, ld / NB - 1, scal,
-                     sync_dev, n_sync_words);
+  (void)n_cu;
+  const int grid = n_tasks;   // one workgroup per task (118 KB of LDS each: one per CU is resident, the rest queue behind them)
+  // BSGPU_CHOL_PROBE=<file>: the 20th factorisation of the process runs the stamped variant and dumps, per task, the wall-clock
+  // stamps (100 MHz) dequeue / got task / dependencies met / tiles in LDS / solves done / update done / published, and its workgroup
+  static const char* probe_file = getenv("BSGPU_CHOL_PROBE");
+  static int probe_calls = 0;
+  if (getenv("BSGPU_CHOL_WATCH")) {   // debugging a stuck factorisation: a watchdog copies the counters out on its own stream after 3 s
+    static int* w_sync = nullptr; static int w_words = 0, w_ld = 0;
+    static bool started = false;
+    w_sync = sync_dev; w_words = n_sync_words < 0 ? -n_sync_words : n_sync_words; w_ld = ld;
+    if (!started) {
+      started = true;
+      std::thread([&]() {
+        hipStream_t ws; (void)hipStreamCreateWithFlags(&ws, hipStreamNonBlocking);
+        for (;;) {
+          std::this_thread::sleep_for(std::chrono::seconds(3));
+          std::vector<int> h(w_words);
+          (void)hipMemcpyAsync(h.data(), w_sync, sizeof(int) * w_words, hipMemcpyDeviceToHost, ws);
+          (void)hipStreamSynchronize(ws);
+          const int N = w_ld / 64;
+          fprintf(stderr, "[chol watch] head %d abort %d exited %d | potrf_done:", h[0], h[1], h[2]);
+          for (int i = 0; i < N; ++i) fprintf(stderr, " %d", h[4 + i]);
+          fprintf(stderr, " | upd:");
+          for (int i = 0; i < N; ++i) for (int j = 0; j <= i; ++j) if (h[4 + N + i * N + j]) fprintf(stderr, " (%d,%d)=%d", i, j, h[4 + N + i * N + j]);
+          fprintf(stderr, "\n");
+        }
+      }).detach();
+    }
+  }
+  if (getenv("BSGPU_CHOL_TRACE")) {   // debugging a stuck factorisation: checkpoints in host memory, dumped by a watchdog after 3 s
+    static volatile int* trace = nullptr;
+    static int trace_grid = 0;
+    static long long* ts_dummy = nullptr;
+    if (!trace) {
+      (void)hipHostMalloc((void**)&trace, sizeof(int) * 2 * 1024, hipHostMallocMapped);
+      for (int i = 0; i < 2048; ++i) trace[i] = -1;
+      std::thread([&]() {
+        for (;;) {
+          std::this_thread::sleep_for(std::chrono::seconds(3));
+          fprintf(stderr, "[chol trace] grid %d:", trace_grid);
+          for (int i = 0; i < trace_grid && i < 1024; ++i) fprintf(stderr, " wg%d:cp%d,t%d", i, trace[2 * i], trace[2 * i + 1]);
+          fprintf(stderr, "\n");
+        }
+      }).detach();
+    }
+    if (ts_dummy) (void)hipFree(ts_dummy);
+    (void)hipMalloc((void**)&ts_dummy, sizeof(long long) * 8 * (size_t)n_tasks);
+    trace_grid = grid;
+    for (int i = 0; i < 2048; ++i) trace[i] = -1;
+    fprintf(stderr, "[chol trace] launch: %d tasks, grid %d, ld %d\n", n_tasks, grid, ld);
+    hipLaunchKernelGGL(chol_fused_kernel<false>, dim3(grid), dim3(256), kFusedLds, s, S, Lp, ld, tasks_dev, n_tasks, nreal_dev, Vinv, ld / NB - 1,
+                       scal, sync_dev, n_sync_words, ts_dummy, trace);
+    return;
+  }
+  if (probe_file && ++probe_calls == 20) {
+    long long* ts = nullptr;
+    std::vector<long long> h((size_t)n_tasks * 8, 0);
+    std::vector<FusedTask> ht(n_tasks);
+    if (hipMalloc((void**)&ts, sizeof(long long) * h.size()) == hipSuccess) {
+      (void)hipMemset(ts, 0, sizeof(long long) * h.size());
+      hipLaunchKernelGGL(chol_fused_kernel<true>, dim3(grid), dim3(256), kFusedLds, s, S, Lp, ld, tasks_dev, n_tasks, nreal_dev, Vinv, ld / NB - 1,
+                         scal, sync_dev, n_sync_words, ts);
+      (void)hipStreamSynchronize(s);
+      (void)hipMemcpy(h.data(), ts, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
+      (void)hipMemcpy(ht.data(), tasks_dev, sizeof(FusedTask) * ht.size(), hipMemcpyDeviceToHost);
+      (void)hipFree(ts);
+      if (FILE* f = fopen(probe_file, "w")) {
+        fprintf(f, "# task k ti tj flags need_c tot_c | t_dequeue t_got t_deps t_loaded t_solved t_updated t_published wg\n");
+        for (int i = 0; i < n_tasks; ++i) {
+          fprintf(f, "%d %d %d %d %d %d %d", i, ht[i].k, ht[i].ti, ht[i].tj, ht[i].flags, ht[i].need_c, ht[i].tot_c);
+          for (int q = 0; q < 8; ++q) fprintf(f, " %lld", h[(size_t)i * 8 + q]);
+          fprintf(f, "\n");
+        }
+        fclose(f);
+      }
+      return;
+    }
+  }
+  hipLaunchKernelGGL(chol_fused_kernel<false>, dim3(grid), dim3(256), kFusedLds, s, S, Lp, ld, tasks_dev, n_tasks, nreal_dev, Vinv, ld / NB - 1, scal,
+                     sync_dev, n_sync_words, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -859,7 +1060,8 @@ void chol_prepare() {
                             (int)kPanelStepLds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds);
 }
 
 }  // namespace bsg
