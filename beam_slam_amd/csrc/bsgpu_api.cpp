@@ -22,7 +22,20 @@ int api_exception(bsgpu_ctx* c) noexcept {
   try { if (c) c->err = what; } catch (...) {}
   return code;
 }
-std::string g_create_error;   // why the last bsgpu_create() returned NULL (bsgpu_create_error)
+thread_local std::string g_create_error;   // why this thread's last bsgpu_create() returned NULL (bsgpu_create_error); contexts may be
+                                           // created from several host threads at once (and by every bsgpu_marginalize)
+// The description of a finalized problem is about to change (factors / marginals / cameras added): the next finalize() re-uploads
+// the host copy of the values, so the point the device has reached (a solve's result) is brought back first — a solve, add_factors,
+// solve / get_blocks sequence continues from the optimised point ("the best accepted point is the context's current value set").
+int invalidate_keep_values(bsgpu_ctx* c) {
+  if (c->finalized && c->d_x && !c->h_x.empty()) {
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(c->h_x.data(), c->d_x, sizeof(double) * c->h_x.size(), hipMemcpyDeviceToHost));
+  }
+  c->finalized = false;
+  return BSGPU_OK;
+}
 }  // namespace bsg
 
 // ===================================================================================================
@@ -124,8 +137,7 @@ int bsgpu_set_cameras(bsgpu_ctx* c, int32_t n, const bsgpu_camera* cams) try {
   if (!c) return BSGPU_ERR_INVALID;
   if (n < 0 || (n > 0 && !cams)) return fail(c, BSGPU_ERR_INVALID, "set_cameras: bad argument");
   c->cams.assign(cams, cams + n);
-  c->finalized = false;
-  return BSGPU_OK;
+  return invalidate_keep_values(c);
 } catch (...) { return api_exception(c); }
 int bsgpu_add_factors(bsgpu_ctx* c, int32_t type, int32_t n, const int32_t* idx, const double* consts,
                       const int32_t* loss_kind, const double* loss_a) try {
@@ -142,8 +154,7 @@ int bsgpu_add_factors(bsgpu_ctx* c, int32_t type, int32_t n, const int32_t* idx,
     g.loss_kind.push_back(k); g.loss_a.push_back(loss_a ? loss_a[i] : 1.0);
   }
   g.n += n;
-  c->finalized = false;
-  return BSGPU_OK;
+  return invalidate_keep_values(c);
 } catch (...) { return api_exception(c); }
 int bsgpu_add_factors_indirect(bsgpu_ctx* c, int32_t type, int32_t n, const int32_t* slot_idx, int32_t n_slots, const int32_t* slot_to_block,
                                const double* consts, const int32_t* loss_kind, const double* loss_a) try {
@@ -174,8 +185,7 @@ int bsgpu_add_factors_indirect(bsgpu_ctx* c, int32_t type, int32_t n, const int3
   if (loss_kind) g.loss_kind.insert(g.loss_kind.end(), loss_kind, loss_kind + n); else g.loss_kind.insert(g.loss_kind.end(), n, BSGPU_LOSS_TRIVIAL);
   if (loss_a) g.loss_a.insert(g.loss_a.end(), loss_a, loss_a + n); else g.loss_a.insert(g.loss_a.end(), n, 1.0);
   g.n += n;
-  c->finalized = false;
-  return BSGPU_OK;
+  return invalidate_keep_values(c);
 } catch (...) { return api_exception(c); }
 int bsgpu_add_marginal(bsgpu_ctx* c, int32_t n_blocks, const int32_t* blocks, int32_t n_rows, const double* A, const double* b,
                        const double* xbar) try {
@@ -193,8 +203,7 @@ int bsgpu_add_marginal(bsgpu_ctx* c, int32_t n_blocks, const int32_t* blocks, in
   mg.rows = n_rows; mg.cols = cols;
   mg.A.assign(A, A + (size_t)n_rows * cols); mg.b.assign(b, b + n_rows); mg.xbar.assign(xbar, xbar + amb);
   c->marginals.push_back(std::move(mg));
-  c->finalized = false;
-  return BSGPU_OK;
+  return invalidate_keep_values(c);
 } catch (...) { return api_exception(c); }
 int bsgpu_finalize(bsgpu_ctx* c) try { return c ? finalize(c) : BSGPU_ERR_INVALID; } catch (...) { return api_exception(c); }
 int bsgpu_solve(bsgpu_ctx* c, const bsgpu_options* o, bsgpu_summary* s) try {

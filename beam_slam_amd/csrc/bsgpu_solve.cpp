@@ -367,7 +367,7 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
           msg = "Number of consecutive invalid steps more than max_num_consecutive_invalid_steps.";
           break;
         }
-        radius = radius / decrease_factor; decrease_factor *= 2.0;
+        radius *= 0.5;   // [EXT] LevenbergMarquardtStrategy::StepIsInvalid(): the radius is halved, decrease_factor_ is untouched
         it.cost = x_cost + fixed; it.step_is_successful = 0;
         if (it.iteration >= o.max_num_iterations) continue;   // the loop ends at its top: a step from here would never be looked at
         run_step(c, o, STEP_REJECT, radius);

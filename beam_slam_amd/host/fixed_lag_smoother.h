@@ -4,8 +4,12 @@
 // variables :199-216, graph update, lag expiration :141-149, pseudo-marginalisation :244-268 with the
 // "MARGINALIZATION" prior on the first in-window state :742-797, optimize :281, usable-solution check
 // :286-295), and the [EXT] fuse VariableStampIndex it relies on (:153-159).
-// ROS timers/threads/services, sensor-model plugins, motion models and ignition are out of scope
-// (SURVEY.md §2); the caller drives optimizeOnce() and feeds transactions.
+// The queue rules of transactionCallback (:548-627) and processQueue (:335-477) are mirrored: ignition sensors start the
+// optimizer and get their first transaction processed on its own, transactions older than the start / the lag window are
+// purged, a transaction whose motion models cannot be generated yet is retried until `transaction_timeout` and blocks the
+// later transactions of its sensor meanwhile.  Sensor-model and motion-model PLUGINS themselves are out of scope:
+// a sensor is a name + its ignition flag (registerSensorModel), the motion models are one callback (setMotionModelCallback,
+// [EXT] fuse_optimizers::Optimizer::applyMotionModels).  ROS timers / threads / services: the caller drives optimizeOnce().
 #pragma once
 #include <deque>
 #include <mutex>
@@ -80,6 +84,8 @@ struct FixedLagSmootherParams {     // [EXT] fuse_optimizers::FixedLagSmootherPa
   double lag_duration = 7.0;        // vio.yaml:3
   double optimization_period = 0.07;  // vio.yaml:2 (the caller's timer)
   bool pseudo_marginalization = true;  // vio.yaml:4 — on in every shipped config
+  double transaction_timeout = 0.1;    // [EXT] fuse_optimizers::FixedLagSmootherParams default: how long a transaction whose motion
+                                       // models cannot be generated is kept for another try (fixed_lag_smoother.cpp:454-470)
   ceres_compat::SolverOptions solver_options = ceres_compat::SolverOptions::Vio();
 };
 
@@ -88,13 +94,42 @@ class FixedLagSmoother {
   FixedLagSmoother(GpuGraph::UniquePtr graph, FixedLagSmootherParams params = FixedLagSmootherParams())
       : graph_(std::move(graph)), params_(params) {}
 
-  // fixed_lag_smoother.cpp:548-627: sorted insert under the pending-transactions mutex
+  // [EXT] fuse_optimizers::Optimizer loads the sensor models from the parameter server; here: a name and its `ignition` flag.
+  // With no ignition sensor registered the optimizer starts at once (autostart(), :125-137) — also the behaviour when nothing is
+  // registered at all.
+  void registerSensorModel(const std::string& name, bool ignition) { sensor_models_[name] = ignition; }
+  // [EXT] Optimizer::applyMotionModels(sensor, transaction): generates the motion-model constraints between the stamps the
+  // transaction involves and merges them into it; false = not possible yet (e.g. the IMU buffer does not cover the stamp)
+  using MotionModelCallback = std::function<bool(const std::string&, fuse_core::Transaction&)>;
+  void setMotionModelCallback(MotionModelCallback cb) { motion_models_ = std::move(cb); }
+  bool started() const { return started_; }
+
+  // fixed_lag_smoother.cpp:548-627.  The queue is kept oldest-first (the reference keeps it newest-first and works from the back).
   void transactionCallback(const std::string& sensor_name, fuse_core::Transaction::SharedPtr transaction) {
+    autostart();
+    const fuse_core::Time max_time = transaction->maxStamp();
+    if (started_ && max_time < start_time_) return;                         // :552-561 before the start time: ignored
     std::lock_guard<std::mutex> lock(pending_transactions_mutex_);
     auto pos = std::upper_bound(pending_.begin(), pending_.end(), transaction->stamp(),
                                 [](const fuse_core::Time& s, const Pending& p) { return s < p.transaction->stamp(); });
-    pending_.insert(pos, Pending{sensor_name, std::move(transaction)});
-    if (!started_) { started_ = true; start_time_ = pending_.front().transaction->minStamp(); }
+    pos = pending_.insert(pos, Pending{sensor_name, std::move(transaction)});
+    if (started_) return;
+    if (isIgnition(sensor_name)) {                                           // :584-611
+      started_ = true; ignited_ = true;
+      start_time_ = pos->transaction->minStamp();
+      const fuse_core::Time min_time = start_time_;
+      pending_.erase(std::remove_if(pending_.begin(), pending_.end(),
+                                    [&](const Pending& p) {
+                                      return p.sensor_name != sensor_name &&
+                                             (p.transaction->minStamp() < min_time || !(max_time < p.transaction->maxStamp()));
+                                    }),
+                     pending_.end());
+    } else {                                                                 // :612-626 bounded queue while waiting for an ignition sensor
+      const fuse_core::Time last_pending_time = pending_.back().transaction->stamp();
+      const fuse_core::Time purge_time = last_pending_time + (-params_.transaction_timeout);
+      if (fuse_core::Time() + params_.transaction_timeout < last_pending_time)
+        while (!pending_.empty() && pending_.front().transaction->maxStamp() < purge_time) pending_.pop_front();
+    }
   }
   size_t pendingTransactions() const { std::lock_guard<std::mutex> lock(pending_transactions_mutex_); return pending_.size(); }
 
@@ -103,12 +138,11 @@ class FixedLagSmoother {
   // one pass of the body of optimizationLoop() (:185-309)
   CycleResult optimizeOnce() {
     std::lock_guard<std::mutex> lock(optimization_mutex_);
+    autostart();
+    if (!started_) return CycleResult::NothingToDo;                          // :312-316 no ignition transaction yet
     fuse_core::Transaction new_transaction;
-    {
-      std::lock_guard<std::mutex> qlock(pending_transactions_mutex_);
-      while (!pending_.empty()) { new_transaction.merge(*pending_.front().transaction); pending_.pop_front(); }
-    }
-    if (new_transaction.empty()) return CycleResult::NothingToDo;
+    processQueue(new_transaction, lag_expiration_);                          // :194
+    if (new_transaction.empty()) return CycleResult::NothingToDo;            // :197
     // :199-216 drop added constraints that touch variables the previous cycle marginalised
     fuse_core::Transaction filtered;
     filtered.stamp(new_transaction.stamp());
@@ -183,8 +217,60 @@ class FixedLagSmoother {
     std::lock_guard<std::mutex> lock(optimization_mutex_);
     std::lock_guard<std::mutex> qlock(pending_transactions_mutex_);
     pending_.clear(); graph_->clear(); timestamp_tracking_ = VariableStampIndex(); marginal_transaction_ = fuse_core::Transaction();
-    started_ = false; lag_expiration_ = fuse_core::Time();
+    started_ = false; ignited_ = false; lag_expiration_ = fuse_core::Time(); start_time_ = fuse_core::Time();
   }
+
+  // fixed_lag_smoother.cpp:335-477
+  void processQueue(fuse_core::Transaction& transaction, const fuse_core::Time& lag_expiration) {
+    std::lock_guard<std::mutex> lock(pending_transactions_mutex_);
+    if (pending_.empty()) return;
+    if (ignited_) {
+      // the transaction that started things up is the oldest one; it is processed on its own so that the motion models see an
+      // optimised first state before the other queued transactions are attached to it (:344-356)
+      ignited_ = false;
+      Pending& element = pending_.front();
+      if (!isIgnition(element.sensor_name)) {
+        ++num_queue_errors_;                                                 // :364-371 logged; processed with the others below
+      } else {
+        if (applyMotionModels(element.sensor_name, *element.transaction)) {
+          transaction.merge(*element.transaction, true);
+          pending_.pop_front();
+        } else {
+          // :380-414 an ignition transaction that cannot be processed is dropped with everything older than the NEXT ignition
+          // transaction; without one the optimizer goes back to "not started"
+          ++num_queue_errors_;
+          pending_.pop_front();
+          auto next = std::find_if(pending_.begin(), pending_.end(), [this](const Pending& p) { return isIgnition(p.sensor_name); });
+          if (next == pending_.end()) started_ = false;
+          else { pending_.erase(pending_.begin(), next); ignited_ = true; }
+        }
+        return;
+      }
+    }
+    const fuse_core::Time current_time = pending_.back().transaction->stamp();   // the most recent stamp (:424)
+    std::vector<std::string> sensor_blacklist;
+    for (auto it = pending_.begin(); it != pending_.end();) {                // oldest first, like the reference's reverse walk
+      const fuse_core::Time min_stamp = it->transaction->minStamp();
+      if (min_stamp < lag_expiration) {
+        ++num_expired_transactions_;                                         // :431-444 older than the lag window
+        it = pending_.erase(it);
+      } else if (std::find(sensor_blacklist.begin(), sensor_blacklist.end(), it->sensor_name) != sensor_blacklist.end()) {
+        ++it;                                                                // :445-448
+      } else if (applyMotionModels(it->sensor_name, *it->transaction)) {
+        transaction.merge(*it->transaction, true);                           // :449-453
+        it = pending_.erase(it);
+      } else if (it->transaction->maxStamp() + params_.transaction_timeout < current_time) {
+        ++num_timed_out_transactions_;                                       // :454-470
+        it = pending_.erase(it);
+      } else {
+        sensor_blacklist.push_back(it->sensor_name);                         // :471-474 try again next cycle, keep the sensor's order
+        ++it;
+      }
+    }
+  }
+  int numExpiredTransactions() const { return num_expired_transactions_; }
+  int numTimedOutTransactions() const { return num_timed_out_transactions_; }
+  int numQueueErrors() const { return num_queue_errors_; }
 
   // :742-797: the first in-window state = smallest Position3DStamped stamp newer than the lag expiration
   bs_common::ImuState GetWindowStartState() const {
@@ -215,8 +301,19 @@ class FixedLagSmoother {
     for (const auto& c : t.addedConstraints()) o.addConstraint(c);
     return o;
   }
+  bool isIgnition(const std::string& sensor) const { auto it = sensor_models_.find(sensor); return it != sensor_models_.end() && it->second; }
+  bool applyMotionModels(const std::string& sensor, fuse_core::Transaction& t) const { return motion_models_ ? motion_models_(sensor, t) : true; }
+  void autostart() {   // :125-137: no ignition sensor configured -> start immediately, start time 0
+    if (started_) return;
+    for (const auto& kv : sensor_models_) if (kv.second) return;
+    started_ = true; start_time_ = fuse_core::Time();
+  }
   GpuGraph::UniquePtr graph_;
   NotifyCallback notify_;
+  MotionModelCallback motion_models_;
+  std::map<std::string, bool> sensor_models_;
+  bool ignited_ = false;
+  int num_expired_transactions_ = 0, num_timed_out_transactions_ = 0, num_queue_errors_ = 0;
   FixedLagSmootherParams params_;
   mutable std::mutex pending_transactions_mutex_;
   std::mutex optimization_mutex_;

@@ -3,9 +3,9 @@
 // the host (UUID maps, like HashGraph [EXT]); optimize() flattens to the IR of include/bsgpu.h with the
 // deterministic block order of SURVEY.md §8a A17 and runs the solve on the GPU through the C-ABI.
 //
-// Back-end selection: the product builds against libbsgpu (prefix bsgpu_).  The CPU-side unit tests
-// of this host logic compile the same header with -DBS_BACKEND_PREFIX=bso_ against the test oracle,
-// because no GPU exists where they run; that configuration is test infrastructure only.
+// The back-end is libbsgpu through the C-ABI of include/bsgpu.h, nothing else.  (The CPU-only unit tests of this host logic
+// re-point the bsgpu_* names at the test oracle from OUTSIDE this header: tests/host/oracle_backend.h, force-included by
+// tests/test_host_cpp.py — the product tree knows nothing about the oracle.)
 #pragma once
 #include <algorithm>
 #include <array>
@@ -14,32 +14,6 @@
 #include <cstdlib>
 
 #include "bs_constraints.h"
-
-#ifndef BS_BACKEND_PREFIX
-#define BS_BACKEND_PREFIX bsgpu_
-#endif
-#define BS_CAT2(a, b) a##b
-#define BS_CAT(a, b) BS_CAT2(a, b)
-#define BS_API(name) BS_CAT(BS_BACKEND_PREFIX, name)
-
-extern "C" {  // declarations for the oracle-prefixed build (identical signatures; bsgpu_* come from bsgpu.h)
-bsgpu_ctx* BS_API(create)(int);
-void BS_API(destroy)(bsgpu_ctx*);
-const char* BS_API(last_error)(const bsgpu_ctx*);
-int BS_API(clear)(bsgpu_ctx*);
-int BS_API(set_blocks)(bsgpu_ctx*, int32_t, const double*, const int32_t*, const uint8_t*, const uint8_t*, const uint8_t*);
-int BS_API(set_cameras)(bsgpu_ctx*, int32_t, const bsgpu_camera*);
-int BS_API(add_factors)(bsgpu_ctx*, int32_t, int32_t, const int32_t*, const double*, const int32_t*, const double*);
-int BS_API(add_factors_indirect)(bsgpu_ctx*, int32_t, int32_t, const int32_t*, int32_t, const int32_t*, const double*, const int32_t*, const double*);
-int BS_API(solve)(bsgpu_ctx*, const bsgpu_options*, bsgpu_summary*);
-int BS_API(get_blocks)(bsgpu_ctx*, double*, int64_t);
-void BS_API(options_default)(bsgpu_options*);
-int BS_API(nidx)(int);
-int BS_API(covariance)(bsgpu_ctx*, int32_t, int32_t, double*);
-int BS_API(add_marginal)(bsgpu_ctx*, int32_t, const int32_t*, int32_t, const double*, const double*, const double*);
-int BS_API(marginalize)(bsgpu_ctx*, int32_t, const int32_t*, int32_t*, int32_t*, int32_t*);
-int BS_API(get_marginal)(const bsgpu_ctx*, int32_t*, double*, double*, double*);
-}
 
 namespace ceres_compat {  // the ceres::Solver fields the reference sets (vio.yaml:7-17) and reads (fixed_lag_smoother.cpp:286,705-716)
 enum TerminationType { CONVERGENCE = 0, NO_CONVERGENCE = 1, FAILURE = 2 };
@@ -144,14 +118,14 @@ class GpuGraph {
  public:
   using UniquePtr = std::unique_ptr<GpuGraph>;
   static UniquePtr make_unique(int device = 0) { return UniquePtr(new GpuGraph(device)); }
-  explicit GpuGraph(int device = 0) : device_(device), ctx_(BS_API(create)(device)) {
+  explicit GpuGraph(int device = 0) : device_(device), ctx_(bsgpu_create(device)) {
     if (!ctx_) throw std::runtime_error("GpuGraph: no usable back-end (libbsgpu has no CPU fallback)");
   }
  private:
   struct DeferContext {};
   GpuGraph(int device, DeferContext) : device_(device), ctx_(nullptr) {}   // clone(): a snapshot that is only read never opens a device context
  public:
-  ~GpuGraph() { if (ctx_) BS_API(destroy)(ctx_); }
+  ~GpuGraph() { if (ctx_) bsgpu_destroy(ctx_); }
   GpuGraph(const GpuGraph&) = delete;
   GpuGraph& operator=(const GpuGraph&) = delete;
 
@@ -360,20 +334,20 @@ class GpuGraph {
     lap("block table");
     // The packed rows name their variables by slot and were written once, when the constraint entered the graph: the only
     // per-cycle translation, slot -> block index, happens inside the back-end's copy (bsgpu_add_factors_indirect).
-    check(BS_API(clear)(ctx()));
-    check(BS_API(set_blocks)(ctx(), (int32_t)nb, f.values.data(), f.offset.data(), f.size.data(), f.manifold.data(), f.is_const.data()));
-    if (!cameras_.empty()) check(BS_API(set_cameras)(ctx(), (int32_t)cameras_.size(), cameras_.data()));
+    check(bsgpu_clear(ctx()));
+    check(bsgpu_set_blocks(ctx(), (int32_t)nb, f.values.data(), f.offset.data(), f.size.data(), f.manifold.data(), f.is_const.data()));
+    if (!cameras_.empty()) check(bsgpu_set_cameras(ctx(), (int32_t)cameras_.size(), cameras_.data()));
     for (int ty = 0; ty < BSGPU_F_NUM_TYPES; ++ty) {
       const TypeTable* tb = tables_[ty].get();
       if (tb && tb->rows)
-        check(BS_API(add_factors_indirect)(ctx(), ty, (int32_t)tb->rows, tb->idx.data(), (int32_t)f.slot_to_block.size(), f.slot_to_block.data(),
+        check(bsgpu_add_factors_indirect(ctx(), ty, (int32_t)tb->rows, tb->idx.data(), (int32_t)f.slot_to_block.size(), f.slot_to_block.data(),
                                            tb->consts.data(), tb->loss_kind.data(), tb->loss_a.data()));
     }
     for (const auto& kv : marginal_rows_) {
       const auto& m = kv.second;
       std::vector<int32_t> blocks;
       for (int32_t s : m.vars) blocks.push_back(f.slot_to_block[s]);
-      check(BS_API(add_marginal)(ctx(), (int32_t)blocks.size(), blocks.data(), m.e.rows, m.e.A.data(), m.e.b.data(), m.e.xbar.data()));
+      check(bsgpu_add_marginal(ctx(), (int32_t)blocks.size(), blocks.data(), m.e.rows, m.e.A.data(), m.e.b.data(), m.e.xbar.data()));
     }
     lap("hand-over (C-ABI copies)");
     return true;
@@ -386,14 +360,26 @@ class GpuGraph {
     if (!flatten(f)) { s.termination_type = ceres_compat::CONVERGENCE; s.message = "empty graph"; return s; }
     auto& vars = f.vars; auto& values = f.values; auto& offset = f.offset; auto& size = f.size;
     bsgpu_options bo;
-    BS_API(options_default)(&bo);
+    bsgpu_options_default(&bo);
     bo.max_num_iterations = o.max_num_iterations; bo.max_solver_time_in_seconds = o.max_solver_time_in_seconds;
     bo.function_tolerance = o.function_tolerance; bo.gradient_tolerance = o.gradient_tolerance; bo.parameter_tolerance = o.parameter_tolerance;
     bsgpu_summary bs;
-    check(BS_API(solve)(ctx(), &bo, &bs));
-    check(BS_API(get_blocks)(ctx(), values.data(), (int64_t)values.size()));
-    for (size_t i = 0; i < vars.size(); ++i)   // Variable::data() updated in place, like Ceres does through the raw pointers
-      std::memcpy(const_cast<fuse_core::Variable*>(vars[i])->data(), values.data() + offset[i], size[i] * sizeof(double));
+    std::memset(&bs, 0, sizeof(bs));
+    const int rc = bsgpu_solve(ctx(), &bo, &bs);
+    if (rc != BSGPU_OK) {
+      // a back-end error is what Ceres reports as a FAILURE summary (the caller — FixedLagSmoother::optimizationLoop, fixed_lag_smoother.cpp:281-292 —
+      // looks at the summary, it does not catch); the variables keep their values, as with !IsSolutionUsable()
+      s.termination_type = ceres_compat::FAILURE;
+      s.message = std::string("back-end error: ") + bsgpu_last_error(ctx());
+      s.total_time_in_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      last_summary_ = bs;
+      return s;
+    }
+    if (bs.is_solution_usable) {   // [EXT] ceres::Solver: parameter blocks are written back only if IsSolutionUsable()
+      check(bsgpu_get_blocks(ctx(), values.data(), (int64_t)values.size()));
+      for (size_t i = 0; i < vars.size(); ++i)   // Variable::data() updated in place, like Ceres does through the raw pointers
+        std::memcpy(const_cast<fuse_core::Variable*>(vars[i])->data(), values.data() + offset[i], size[i] * sizeof(double));
+    }
     s.termination_type = bs.termination_type == BSGPU_CONVERGENCE ? ceres_compat::CONVERGENCE
                        : bs.termination_type == BSGPU_NO_CONVERGENCE ? ceres_compat::NO_CONVERGENCE : ceres_compat::FAILURE;
     s.initial_cost = bs.initial_cost; s.final_cost = bs.final_cost;
@@ -438,14 +424,14 @@ class GpuGraph {
       marg.push_back(b);
     }
     int32_t n_kept = 0, n_rows = 0, n_cols = 0;
-    check(BS_API(marginalize)(ctx(), (int32_t)marg.size(), marg.data(), &n_kept, &n_rows, &n_cols));
+    check(bsgpu_marginalize(ctx(), (int32_t)marg.size(), marg.data(), &n_kept, &n_rows, &n_cols));
     if (n_rows == 0) return tr;
     std::vector<int32_t> kept(n_kept);
-    check(BS_API(get_marginal)(ctx(), kept.data(), nullptr, nullptr, nullptr));
+    check(bsgpu_get_marginal(ctx(), kept.data(), nullptr, nullptr, nullptr));
     size_t amb = 0;
     for (int32_t b : kept) amb += f.size[b];
     std::vector<double> A((size_t)n_rows * n_cols), bvec(n_rows), xbar(amb);
-    check(BS_API(get_marginal)(ctx(), kept.data(), A.data(), bvec.data(), xbar.data()));
+    check(bsgpu_get_marginal(ctx(), kept.data(), A.data(), bvec.data(), xbar.data()));
     std::vector<fuse_core::UUID> kept_ids;
     for (int32_t b : kept) kept_ids.push_back(f.vars[b]->uuid());
     tr.addConstraint(std::make_shared<fuse_constraints::MarginalConstraint>(source, std::move(kept_ids), n_rows, n_cols, std::move(A), std::move(bvec), std::move(xbar)));
@@ -467,17 +453,17 @@ class GpuGraph {
       const int32_t a = blockIndexOf(rq.first), b = blockIndexOf(rq.second);
       const size_t ta = getVariable(rq.first).localSize(), tb = getVariable(rq.second).localSize();
       std::vector<double> m(ta * tb);
-      check(BS_API(covariance)(ctx(), a, b, m.data()));
+      check(bsgpu_covariance(ctx(), a, b, m.data()));
       covariance_matrices.push_back(std::move(m));
     }
   }
 
  private:
-  void check(int rc) { if (rc != BSGPU_OK) throw std::runtime_error(std::string("bsgpu: ") + BS_API(last_error)(ctx_)); }
+  void check(int rc) { if (rc != BSGPU_OK) throw std::runtime_error(std::string("bsgpu: ") + bsgpu_last_error(ctx_)); }
   int device_;
   bsgpu_ctx* ctx_;
   bsgpu_ctx* ctx() {
-    if (!ctx_ && !(ctx_ = BS_API(create)(device_))) throw std::runtime_error("GpuGraph: no usable back-end (libbsgpu has no CPU fallback)");
+    if (!ctx_ && !(ctx_ = bsgpu_create(device_))) throw std::runtime_error("GpuGraph: no usable back-end (libbsgpu has no CPU fallback)");
     return ctx_;
   }
 

@@ -1082,7 +1082,9 @@ static int solve(Ctx& c, const bsgpu_options& o, bsgpu_summary& sum) {
         sum.termination_type = BSGPU_FAILURE; msg = "Number of consecutive invalid steps more than max_num_consecutive_invalid_steps.";
         break;
       }
-      radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
+      // [EXT] LevenbergMarquardtStrategy::StepIsInvalid(): radius_ *= 0.5, decrease_factor_ untouched (only StepRejected grows it);
+      // the diagonal is recomputed — from the same Jacobian, i.e. to the same values
+      radius *= 0.5; reuse_diagonal = true;
       it.cost = x_cost + fixed; it.step_is_successful = 0;
       continue;
     }

@@ -1,7 +1,7 @@
 // Host-side (C++) tests of the fuse/bs_optimizers mirror in beam_slam_amd/host/, written like the
 // reference's own gtests.  Built twice by tests/test_host_cpp.py:
 //   * against libbsgpu.so              -> run on the GPU box (-m gpu): the product path
-//   * with -DBS_BACKEND_PREFIX=bso_    -> against the CPU oracle, to exercise the HOST LOGIC
+//   * with -include oracle_backend.h   -> against the CPU oracle, to exercise the HOST LOGIC
 //     (flattening order, pack(), transactions, lag window, pseudo-marginalisation) where no GPU exists
 #include <cstdio>
 #include <algorithm>
@@ -632,6 +632,102 @@ static void test_random_transactions_against_model() {
   }
 }
 
+
+// the pending-transaction queue rules of fixed_lag_smoother.cpp:335-477 (processQueue) and :548-627 (transactionCallback): ignition,
+// purge of pre-ignition transactions, transactions older than the lag window, motion-model failure -> retry until transaction_timeout
+static void test_process_queue_rules() {
+  std::printf("ProcessQueueRules\n");
+  using FLS = bs_optimizers::FixedLagSmoother;
+  auto make_tr = [](double t, double x) {   // one stamped position with an absolute prior: a transaction that can be optimised on its own
+    auto tr = std::make_shared<fuse_core::Transaction>();
+    tr->stamp(fuse_core::Time(t)); tr->addInvolvedStamp(fuse_core::Time(t));
+    auto p = fuse_variables::Position3DStamped::make_shared(fuse_core::Time(t));
+    p->x() = x; p->y() = 0; p->z() = 0;
+    tr->addVariable(p);
+    Mat<3, 3> cov = 1e-2 * Mat<3, 3>::Identity();
+    tr->addConstraint(std::make_shared<fuse_constraints::AbsoluteVec3Constraint>("fuse_constraints::AbsolutePosition3DStampedConstraint", "src", *p,
+                                                                                 Vec3{x + 0.5, 0, 0}, cov));
+    return tr;
+  };
+  bs_optimizers::FixedLagSmootherParams params;
+  params.lag_duration = 1.0; params.transaction_timeout = 0.25; params.pseudo_marginalization = false;
+  {  // (1) with an ignition sensor registered nothing happens before its first transaction; older transactions of others are purged
+    FLS s(bs_optimizers::GpuGraph::make_unique(), params);
+    s.registerSensorModel("slam_init", true); s.registerSensorModel("vo", false);
+    s.transactionCallback("vo", make_tr(0.10, 1.0));
+    s.transactionCallback("vo", make_tr(0.20, 2.0));
+    CHECK(!s.started()); CHECK(s.pendingTransactions() == 2);
+    CHECK(s.optimizeOnce() == FLS::CycleResult::NothingToDo);               // optimizerTimerCallback: not started
+    s.transactionCallback("vo", make_tr(0.60, 3.0));                         // purge_time = 0.60 - 0.25: the 0.10 and 0.20 ones go
+    CHECK(s.pendingTransactions() == 1);
+    s.transactionCallback("slam_init", make_tr(1.00, 4.0));                  // ignition: start time 1.00, the 0.60 one is older -> purged
+    CHECK(s.started()); CHECK(s.pendingTransactions() == 1);
+    s.transactionCallback("vo", make_tr(0.90, 9.0));                         // before the start time: ignored (:552-561)
+    CHECK(s.pendingTransactions() == 1);
+    s.transactionCallback("vo", make_tr(1.10, 5.0));
+    s.transactionCallback("vo", make_tr(1.20, 6.0));
+    CHECK(s.optimizeOnce() == FLS::CycleResult::Optimized);                  // the ignition transaction alone (:344-356)
+    CHECK(s.graph().numVariables() == 1); CHECK(s.pendingTransactions() == 2);
+    CHECK(s.optimizeOnce() == FLS::CycleResult::Optimized);                  // then the rest together
+    CHECK(s.graph().numVariables() == 3); CHECK(s.pendingTransactions() == 0);
+  }
+  {  // (2) an ignition transaction whose motion models fail is dropped; without another one the optimizer un-starts (:380-404)
+    FLS s(bs_optimizers::GpuGraph::make_unique(), params);
+    s.registerSensorModel("slam_init", true); s.registerSensorModel("vo", false);
+    bool fail_ignition = true;
+    s.setMotionModelCallback([&](const std::string& sensor, fuse_core::Transaction&) { return !(fail_ignition && sensor == "slam_init"); });
+    s.transactionCallback("slam_init", make_tr(1.00, 1.0));
+    s.transactionCallback("vo", make_tr(1.10, 2.0));
+    CHECK(s.started());
+    CHECK(s.optimizeOnce() == FLS::CycleResult::NothingToDo);
+    CHECK(!s.started()); CHECK(s.numQueueErrors() == 1); CHECK(s.pendingTransactions() == 1);
+    // ... with a second ignition transaction queued, everything older than IT is purged and it is tried next cycle (:405-414)
+    s.transactionCallback("slam_init", make_tr(1.20, 3.0));                  // re-ignites; the 1.10 "vo" one is older -> purged at once
+    CHECK(s.started()); CHECK(s.pendingTransactions() == 1);
+    s.transactionCallback("slam_init", make_tr(1.30, 4.0));
+    CHECK(s.optimizeOnce() == FLS::CycleResult::NothingToDo);                // 1.20 fails again; 1.30 is the next ignition transaction
+    CHECK(s.started()); CHECK(s.pendingTransactions() == 1);
+    fail_ignition = false;
+    CHECK(s.optimizeOnce() == FLS::CycleResult::Optimized);
+    CHECK(s.graph().numVariables() == 1); CHECK(s.pendingTransactions() == 0);
+  }
+  {  // (3) no ignition sensor: autostart; a motion-model failure blocks the LATER transactions of that sensor only and is retried
+     //     until transaction_timeout; transactions older than the lag window are dropped (:424-476)
+    FLS s(bs_optimizers::GpuGraph::make_unique(), params);
+    s.registerSensorModel("vo", false); s.registerSensorModel("lo", false);
+    double imu_covers_until = 2.05;   // the "IMU buffer": a motion model can be generated up to this stamp
+    s.setMotionModelCallback([&](const std::string& sensor, fuse_core::Transaction& t) {
+      if (sensor == "vo" && std::fabs(t.maxStamp().toSec() - 2.10) < 1e-9) return false;   // falls into a gap of the IMU stream: never possible
+      return t.maxStamp().toSec() <= imu_covers_until;
+    });
+    s.transactionCallback("vo", make_tr(2.00, 1.0));
+    s.transactionCallback("vo", make_tr(2.10, 2.0));                         // no motion model possible
+    s.transactionCallback("vo", make_tr(2.04, 3.0));                         // covered, but queued behind nothing: processed (older than 2.10)
+    s.transactionCallback("lo", make_tr(2.02, 4.0));
+    CHECK(s.started());
+    CHECK(s.optimizeOnce() == FLS::CycleResult::Optimized);
+    CHECK(s.graph().numVariables() == 3); CHECK(s.pendingTransactions() == 1);   // 2.10 waits
+    s.transactionCallback("vo", make_tr(2.20, 5.0));                         // behind the blocked 2.10 of the same sensor: must wait too
+    s.transactionCallback("lo", make_tr(2.21, 6.0));
+    imu_covers_until = 2.05;
+    const auto r = s.optimizeOnce();
+    CHECK(r == FLS::CycleResult::NothingToDo);                               // vo blocked at 2.10; lo's 2.21 not covered either (and not timed out)
+    CHECK(s.pendingTransactions() == 3); CHECK(s.numTimedOutTransactions() == 0);
+    s.transactionCallback("lo", make_tr(2.40, 7.0));                         // current time 2.40: 2.10 + 0.25 < 2.40 -> the 2.10 one has timed out
+    imu_covers_until = 2.30;
+    CHECK(s.optimizeOnce() == FLS::CycleResult::Optimized);
+    CHECK(s.numTimedOutTransactions() == 1);
+    CHECK(s.graph().numVariables() == 5);                                    // + 2.20, 2.21
+    CHECK(s.pendingTransactions() == 1);                                     // 2.40 still waits for the IMU
+    // lag window: the graph's newest stamp is 2.21, lag 1.0 -> expiration 1.21; a late transaction about t = 1.0 is dropped
+    s.transactionCallback("vo", make_tr(1.00, 8.0));
+    imu_covers_until = 10.0;
+    CHECK(s.optimizeOnce() == FLS::CycleResult::Optimized);
+    CHECK(s.numExpiredTransactions() == 1);
+    CHECK(s.pendingTransactions() == 0);
+  }
+}
+
 int main() {
   test_block_order_and_pack();
   test_simple_2_state_fg();
@@ -640,6 +736,7 @@ int main() {
   test_true_marginalization_linear_chain();
   test_clone_is_an_independent_snapshot();
   test_random_transactions_against_model();
+  test_process_queue_rules();
   test_fixed_lag_smoother_window(true);
   test_fixed_lag_smoother_window(false);
   if (g_fail) { std::printf("FAILED: %d checks\n", g_fail); return 1; }

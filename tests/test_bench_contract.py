@@ -1,0 +1,39 @@
+"""bench.py's own contract, executed on the GPU box: the single-process line, and the torch.distributed (RCCL) path that the
+driver uses for N > 1 — forced at world size 1 (BSGPU_BENCH_FORCE_DIST=1: init_process_group("nccl"), barriers, the max-over-ranks
+all-reduce), so that the multi-GPU code is at least executed where one GPU exists."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _bench(extra_env, *args):
+    env = dict(os.environ, **extra_env)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", *args],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    return json.loads(line)
+
+
+def test_bench_line_small_window():
+    r = _bench({}, "--n-kf", "40", "--n-lm", "4000")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline"):
+        assert key in r, key
+    assert r["n_gpus"] == 1 and r["steps"] == 2 and r["value"] > 0 and r["dtype"] == "f64"
+    assert r["roofline"]["bound"] == "hbm" and 0 < r["roofline"]["frac"] < 1.5
+
+
+def test_bench_rccl_path_world_size_one():
+    env = {"BSGPU_BENCH_FORCE_DIST": "1", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1",
+           "MASTER_PORT": "29533", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    r = _bench(env, "--n-kf", "40", "--n-lm", "4000")
+    assert r["n_gpus"] == 1 and r["value"] > 0
+    single = _bench({}, "--n-kf", "40", "--n-lm", "4000")
+    assert abs(r["config"]["final_cost"] - single["config"]["final_cost"]) <= 1e-9 * single["config"]["final_cost"]

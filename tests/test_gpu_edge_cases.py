@@ -307,3 +307,23 @@ def test_contexts_on_concurrent_host_threads(gpu_solver_cls):
             assert abs(cost_c - cost) <= 1e-7 * max(abs(cost), 1e-30), (i, cost_c, cost)
             # (the unconverged, ill-conditioned PCG window alone repeats its values to ~1e-6 only, sequentially as well)
             assert np.abs(x_c - x).max() <= (1e-4 if i == 2 else 1e-6), i
+
+
+def test_values_survive_a_change_of_the_problem_description(oracle_cls, gpu_solver_cls):
+    """solve, add_factors, get_blocks / solve: "on return the best accepted point is the context's current value set" (bsgpu.h) also
+    when the description changes afterwards — the next finalize() must start from the optimised point, not from the values that
+    were handed over before the first solve (the host copy was never refreshed)."""
+    pr = synthetic.vio_window(n_kf=6, n_lm=60, seed=4)
+    g = gpu_solver_cls(0)
+    pr.load(g)
+    s1 = g.solve()
+    x1 = g.get_blocks()
+    assert s1.final_cost < s1.initial_cost and np.abs(x1 - pr.values).max() > 1e-6
+    # a prior on a keyframe position, centred on the solved value, re-opens the description (finalized -> false)
+    blk = int(pr.meta["kf_blocks"][2, 1])
+    consts = np.concatenate([pr.block(blk, x1), np.eye(3).ravel()])[None, :]
+    g.add_factors(capi.F_ABS_VEC3, np.array([[blk]], np.int32), consts)
+    assert np.array_equal(g.get_blocks(), x1)                   # not finalized: the host copy — which must be the solved point
+    s2 = g.solve()
+    assert abs(s2.initial_cost - s1.final_cost) <= 1e-9 * s1.final_cost     # the prior is satisfied at x1: same cost, same point
+    assert np.abs(g.get_blocks() - x1).max() < 1e-6

@@ -3,7 +3,7 @@ are a C++ program written like the reference's gtests (tests/host/test_host.cpp)
 
 CPU run: the HOST LOGIC (deterministic block order, pack(), transactions, lag window,
 pseudo-marginalisation, KATs through GpuGraph::optimize) is exercised with the header compiled against
-the test oracle (-DBS_BACKEND_PREFIX=bso_), because no GPU exists here.
+the test oracle (tests/host/oracle_backend.h force-included), because no GPU exists here.
 GPU run (-m gpu): the same program linked against the product library libbsgpu.so."""
 import os
 import subprocess
@@ -33,7 +33,7 @@ def test_host_logic_against_oracle_backend(tmp_path):
     from oracle import build
     build()
     odir = os.path.join(ROOT, "oracle")
-    exe = _build(tmp_path, ["-DBS_BACKEND_PREFIX=bso_", "-L" + odir, "-lbs_oracle", "-Wl,-rpath," + odir])
+    exe = _build(tmp_path, ["-include", os.path.join(ROOT, "tests", "host", "oracle_backend.h"), "-L" + odir, "-lbs_oracle", "-Wl,-rpath," + odir])
     out = _run(exe)
     assert "FixedLagSmootherWindow" in out
 
