@@ -674,6 +674,11 @@ double bsgpu_time_reproj_jacobian_ms(bsgpu_ctx* c, int32_t reps) {
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return (double)ms / reps;
 }
+int bsgpu_profile_step(bsgpu_ctx* c, const bsgpu_options* o, int32_t reps, double* ms_out, double* work_out) try {
+  if (!c) return BSGPU_ERR_INVALID;
+  if (!o || !ms_out || reps <= 0) return fail(c, BSGPU_ERR_INVALID, "profile_step: bad argument");
+  return profile_step(c, *o, reps, ms_out, work_out);
+} catch (...) { return api_exception(c); }
 int64_t bsgpu_reproj_jacobian_bytes(const bsgpu_ctx* c) {
   if (!c) return -1;
   // per factor: 16 B (3 offsets + meta) + 16 B pixel + 8 B weight in, 16 B residual + 144 B Jacobian out;

@@ -56,6 +56,11 @@ struct HostMarginal {
 // Largest reduced (pose-side) system the dense tiled Cholesky takes: the back-substitution keeps the whole solution vector in LDS
 // (k_chol.hip: sy[npad] next to the 64x64 tiles, 160 KB per CU).  C2 needs 3 008; 12 288 = 819 keyframes of 15-d states.
 constexpr size_t kDenseLimit = 12288;
+// Windows WITH eliminated landmarks have no other exact path (the block-sparse PCG covers pose-only graphs), and their reduced system
+// is block-banded: above kDenseLimit the same tiled factorisation runs with the back-substitution's solution vector in global
+// memory instead of LDS (slower per panel, no size cliff).  The bound is what the dense tile storage costs: 2 x npad^2 doubles
+// (S and its shadow) = 2 x 19 GB at 49 152 — HBM is 288 GB.
+constexpr size_t kDenseLimitLandmarks = 49152;
 
 struct HostGroup {
   int n = 0;
@@ -146,6 +151,8 @@ struct bsgpu_ctx {
   bool ev_reduce_pending = false;
   // block-sparse PCG path
   bool dense_ok = true, bsr_built = false, use_pcg = false;
+  // in-situ phase timing (bsgpu_profile_step): when non-null, the step records one of these events at every phase boundary
+  hipEvent_t* prof_events = nullptr;
   bool spec_J = false;   // residuals + Jacobians currently hold the CANDIDATE's (evaluated ahead of the accept/reject decision)
   int nbr = 0, nblk = 0, pcg_iters_total = 0;
   int *d_row_ptr = nullptr, *d_col = nullptr, *d_diag_slot = nullptr;
@@ -201,6 +208,8 @@ struct bsgpu_ctx {
 
 namespace bsg {
 
+// phases of one LM step, in enqueue order (include/bsgpu.h BSGPU_PHASE_*)
+inline void phase_mark(bsgpu_ctx* c, int phase) { if (c->prof_events) (void)hipEventRecord(c->prof_events[phase + 1], c->stream); }
 inline int fail(bsgpu_ctx* c, int code, const std::string& msg) { c->err = msg; return code; }
 int api_exception(bsgpu_ctx* c) noexcept;   // bsgpu_api.cpp: where every entry point's function-try-block ends
 
@@ -230,7 +239,10 @@ struct DenseDev {
 };
 void dense_factor(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* scal);
 // (iperm / y_tan / delta given: the back-substitution also writes the solution in tangent order and the step -y)
+void dense_backsolve(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* y, const int* iperm = nullptr,
+                     int n_pose = 0, double* y_tan = nullptr, double* delta = nullptr);
 void dense_factor_solve(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* y, double* scal, const int* iperm = nullptr,
                         int n_pose = 0, double* y_tan = nullptr, double* delta = nullptr);
+int profile_step(bsgpu_ctx* c, const bsgpu_options& o, int reps, double* ms_out, double* work_out);
 
 }  // namespace bsg

@@ -83,7 +83,7 @@ int finalize(bsgpu_ctx* c) {
   for (int b = 0; b < nb; ++b) if (!c->is_const[b] && c->is_lm[b]) { c->toff[b] = to; to += 3; lm_index[b] = nl++; }
   c->n_tan = to; c->n_lm = nl;
   c->npad = ((c->n_pose + 63) / 64 + 1) * 64;   // real tiles + one tile for the rhs row (dense_plan.h)
-  c->dense_ok = (size_t)c->npad <= kDenseLimit;   // above: block-sparse PCG path only (pose-only problems)
+  c->dense_ok = (size_t)c->npad <= kDenseLimit || (nl > 0 && (size_t)c->npad <= kDenseLimitLandmarks);   // else: block-sparse PCG (pose-only problems)
   int row = 0;
   for (int t = 0; t < BSGPU_F_NUM_TYPES; ++t) { c->row0[t] = row; row += c->groups[t].n * kTypes[t].m; }
   for (const HostMarginal& mg : c->marginals) row += mg.rows;
@@ -559,7 +559,7 @@ int build_bsr(bsgpu_ctx* c) {
   if (c->bsr_built) return BSGPU_OK;
   if (c->vis.n > 0)
     return fail(c, BSGPU_ERR_UNSUPPORTED, c->dense_ok ? "PCG path covers pose-only problems; landmark problems use the Schur + dense path"
-                                                      : "window too large: the reduced camera system exceeds the 12288 dimensions of the dense Schur path (819 keyframes of 15-d states) and the PCG path covers pose-only problems");
+                                                      : "window too large: the reduced camera system exceeds the 49152 dimensions of the tiled Schur path (3 276 keyframes of 15-d states) and the PCG path covers pose-only problems");
   if (!c->marginals.empty()) return fail(c, BSGPU_ERR_UNSUPPORTED, "PCG path does not take dense marginal factors");
   for (int b = 0; b < c->nb; ++b)
     if (!c->is_const[b] && c->tsize[b] != 3) return fail(c, BSGPU_ERR_UNSUPPORTED, "PCG path needs 3-dimensional tangent blocks");

@@ -83,6 +83,7 @@ void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot) {
   hipStream_t s = c->stream;
   const bool cand = slot == SC_COST_CAND;
   if (c->vis.n) launch_reproj_eval(s, c->vis, x, c->d_cams, c->d_losses, with_J, cand ? c->vis.cost_part_cand : c->vis.cost_part);
+  if (with_J) phase_mark(c, BSGPU_PHASE_EVAL_REPROJ);
   const bool imu_pair = c->small[BSGPU_F_IMU_DELTA].n > 0 && c->small[BSGPU_F_IMU_PRIOR].n > 0;
   if (imu_pair)
     launch_imu_eval(s, c->small[BSGPU_F_IMU_DELTA], c->small[BSGPU_F_IMU_PRIOR], x, c->d_losses, with_J,
@@ -94,6 +95,7 @@ void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot) {
   }
   for (const auto& mc : c->marg)
     if (mc.active) launch_marg_eval(s, mc.dev, x, with_J, cand ? mc.part_cand : mc.part);
+  if (with_J) phase_mark(c, BSGPU_PHASE_EVAL_OTHER);
 }
 void final_reduce(bsgpu_ctx* c) {
   launch_final_reduce(c->stream, c->d_reduce, c->n_reduce, SC_X_NORM2 + 1, c->d_scal, c->h_scal_dev);
@@ -117,7 +119,9 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
   c->scal_mirrored = false;
   launch_landmark(s, c->vis, c->n_pose, c->d_scal + SC_RADIUS, first ? 1 : 0, new_J ? 1 : 0, o.jacobi_scaling, o.min_lm_diagonal,
                   o.max_lm_diagonal, c->d_scale, c->d_dcl, c->d_grad);
+  phase_mark(c, BSGPU_PHASE_LANDMARK);
   launch_pairs(s, c->vis, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm, gradient_only);
+  phase_mark(c, BSGPU_PHASE_PAIRS);
   launch_small_assemble_set(s, c->small + 2, kNumInternal - 2, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm);
   for (const auto& mc : c->marg)
     if (mc.active) launch_marg_assemble(s, mc.dev, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm);
@@ -128,6 +132,7 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
   else
     launch_pose_diag(s, c->n_pose, c->d_S, c->npad, c->d_hdiag, c->d_scal + SC_RADIUS, 0, 0, o.jacobi_scaling,
                      o.min_lm_diagonal, o.max_lm_diagonal, c->d_scale, c->d_dcl, c->npad, c->d_iperm);
+  phase_mark(c, BSGPU_PHASE_ASSEMBLE_OTHER);
 }
 
 void dense_factor(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* scal) {
@@ -144,8 +149,12 @@ void dense_factor(hipStream_t s, const DensePlan& P, const DenseDev& D, double* 
 }
 void dense_factor_solve(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* y, double* scal, const int* iperm, int n_pose,
                         double* y_tan, double* delta) {
-  const int ld = P.npad;
   dense_factor(s, P, D, S, scal);
+  dense_backsolve(s, P, D, S, y, iperm, n_pose, y_tan, delta);
+}
+void dense_backsolve(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* y, const int* iperm, int n_pose, double* y_tan,
+                     double* delta) {
+  const int ld = P.npad;
   // y' = the rhs row after forward substitution: row rhs_row of the shadow matrix (the rhs tile is an
   // off-diagonal row tile of every panel)
   const double* rhs_row = D.Lp + (size_t)P.rhs_row * ld;
@@ -169,18 +178,23 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
   } else if (c->n_pose > 0) {
     const DenseDev D{c->d_perm, c->d_nreal, c->d_rows_flat, c->d_panels, c->d_Lp, c->d_Vinv,
                      c->d_bs_desc, c->d_chain_begin, c->d_chain_end, c->d_tile_sync, c->d_ftasks, c->d_fsync};
-    dense_factor_solve(s, c->plan, D, c->d_S, c->d_y, c->d_scal, c->d_iperm, c->n_pose, c->d_ytan, c->d_delta);
+    dense_factor(s, c->plan, D, c->d_S, c->d_scal);
+    phase_mark(c, BSGPU_PHASE_FACTOR);
+    dense_backsolve(s, c->plan, D, c->d_S, c->d_y, c->d_iperm, c->n_pose, c->d_ytan, c->d_delta);
+    phase_mark(c, BSGPU_PHASE_BACKSOLVE);
   }
   // landmark back-substitution + the model-cost-change terms of the visual factors (partial arrays only, summed once at the end)
   launch_backsub_mcc(s, c->vis, c->n_pose, c->d_ytan, c->d_delta, c->vis.mcc_part);
   launch_small_mcc_set(s, c->small + 2, c->d_small_part_mcc + 2, kNumInternal - 2, c->d_delta);
   for (const auto& mc : c->marg)
     if (mc.active) launch_marg_mcc(s, mc.dev, c->d_delta, mc.part_mcc);
+  phase_mark(c, BSGPU_PHASE_BACKSUB);
   int n_part = 0;
   launch_update(s, c->nb, c->d_blk_xoff, c->d_blk_toff, c->d_blk_size, c->d_blk_manifold, c->d_x, c->d_delta, c->d_xcand,
                 c->d_part_upd, &n_part);
   eval_all(c, c->d_xcand, false, SC_COST_CAND);
   final_reduce(c);
+  phase_mark(c, BSGPU_PHASE_CANDIDATE);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -213,9 +227,60 @@ void enqueue_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius,
   // residuals and Jacobians at the candidate: evaluated ahead, underneath the host round trip (~26 us per iteration otherwise
   // idle).  A rejected step pays for it with a re-evaluation at the current point (above).
   if (!c->use_graphs) {
+    hipEvent_t* const prof = c->prof_events;   // (bsgpu_profile_step times the step up to here: this evaluation belongs to the next one)
+    c->prof_events = nullptr;
     eval_all(c, c->d_xcand, true, SC_COST_X);
+    c->prof_events = prof;
     c->spec_J = true;
   }
+}
+
+// Measurement (bsgpu_profile_step): `reps` full LM steps from the current point — exactly what solve() enqueues for an accepted
+// step (Jacobians, assembly, factorisation, back-substitution, candidate, its cost) — with a HIP event at every phase boundary on
+// the solver's stream; every step is taken as accepted, at a fixed radius.  ms_out / work_out: BSGPU_PHASE_NUM entries.
+int profile_step(bsgpu_ctx* c, const bsgpu_options& o, int reps, double* ms_out, double* work_out) {
+  int rc = finalize(c);
+  if (rc != BSGPU_OK) return rc;
+  if (c->use_pcg || !c->dense_ok || c->use_graphs) return fail(c, BSGPU_ERR_UNSUPPORTED, "profile_step: dense Schur path, eager launches only");
+  HIPCHK(c, hipSetDevice(c->device));
+  c->use_pcg = false;
+  const int ne = BSGPU_PHASE_NUM + 1;
+  std::vector<hipEvent_t> ev((size_t)reps * ne);
+  for (auto& e : ev) HIPCHK(c, hipEventCreate(&e));
+  const double radius = o.initial_trust_region_radius;
+  c->spec_J = false;
+  enqueue_step(c, o, STEP_FIRST, radius);   // warm-up: scale / diagonal arrays initialised, a candidate exists
+  for (int r = 0; r < reps; ++r) {
+    c->spec_J = false;                      // the Jacobian evaluation is part of what is timed
+    c->prof_events = ev.data() + (size_t)r * ne;
+    (void)hipEventRecord(c->prof_events[0], c->stream);
+    enqueue_step(c, o, STEP_ACCEPT, radius);
+    c->prof_events = nullptr;
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->scal_mirrored = false; c->ev_reduce_pending = false; c->spec_J = false;
+  for (int p = 0; p < BSGPU_PHASE_NUM; ++p) ms_out[p] = 0.0;
+  for (int r = 0; r < reps; ++r)
+    for (int p = 0; p < BSGPU_PHASE_NUM; ++p) {
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, ev[(size_t)r * ne + p], ev[(size_t)r * ne + p + 1]);
+      ms_out[p] += (double)ms / reps;
+    }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  if (work_out) {
+    const double n = (double)c->vis.n, ne_ = (double)c->vis.n_elim, nl = (double)c->vis.n_lm, nent = (double)c->vis.n_ent;
+    for (int p = 0; p < BSGPU_PHASE_NUM; ++p) work_out[p] = 0.0;
+    work_out[BSGPU_PHASE_EVAL_REPROJ] = n * 200.0 + 8.0 * (double)c->h_x.size();      // bytes (bsgpu_reproj_jacobian_bytes)
+    work_out[BSGPU_PHASE_LANDMARK] = ne_ * (48.0 + 16.0 + 64.0) + nl * 72.0;          // landmark part of J + r in, CR out; Linv + z per landmark
+    work_out[BSGPU_PHASE_PAIRS] = ne_ * (96.0 + 64.0) + nent * 8.0;                   // every pose part of J and CR row once + the entry list
+    work_out[BSGPU_PHASE_FACTOR] = c->plan.fused_flops;                               // FP64 flops of the planned factorisation
+    work_out[BSGPU_PHASE_BACKSUB] = n * (144.0 + 16.0) + ne_ * 64.0 + nl * 72.0;      // J, r, CR once; Linv + z per landmark
+    work_out[BSGPU_PHASE_CANDIDATE] = n * 40.0 + 3.0 * 8.0 * (double)c->h_x.size();   // candidate cost: 40 B / factor + the block update
+  }
+  // the timed steps moved the point: back to where the context was finalized
+  HIPCHK(c, hipMemcpyAsync(c->d_x, c->d_x0, sizeof(double) * c->h_x.size(), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return BSGPU_OK;
 }
 
 bool same_graph_options(const bsgpu_options& a, const bsgpu_options& b) {
@@ -292,7 +357,7 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
   sum.num_residuals = c->n_res;
   c->use_pcg = (o.linear_solver_type == BSGPU_LINEAR_PCG) || (o.linear_solver_type == BSGPU_LINEAR_AUTO && !c->dense_ok);
   if (!c->use_pcg && !c->dense_ok)
-    return fail(c, BSGPU_ERR_UNSUPPORTED, "reduced system larger than 12288: the dense exact path does not apply; use BSGPU_LINEAR_AUTO or BSGPU_LINEAR_PCG");
+    return fail(c, BSGPU_ERR_UNSUPPORTED, "reduced system above the limit of the tiled exact path (12288 pose-only, 49152 with landmarks); use BSGPU_LINEAR_AUTO or BSGPU_LINEAR_PCG");
   if (c->use_pcg) { rc = build_bsr(c); if (rc != BSGPU_OK) return rc; }
   c->pcg_iters_total = 0;
   sum.linear_solver_used = c->use_pcg ? BSGPU_LINEAR_PCG : BSGPU_LINEAR_SCHUR_CHOLESKY;

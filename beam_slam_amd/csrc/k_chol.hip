@@ -914,6 +914,7 @@ BSG_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::
 // one workgroup per chain (a separator, or a piece of the nested-dissection ordering), walking its panels from its last
 // tile down to its first; everything a chain depends on outside itself was solved by an earlier launch (dense_plan.h)
 constexpr int kBsMaxRows = DensePlan::kBsDescRows;   // row lists up to this length are staged in LDS
+template <bool Y_IN_LDS>
 __global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double* S, const double* Lp, const double* Vinv, int ld,
                                                                     const int* __restrict__ bs_desc,
                                                                     const int* __restrict__ chain_begin,
@@ -921,12 +922,16 @@ __global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double
                                                                     const int* __restrict__ rows_flat, double* y, int npad, int max_len,
                                                                     const double* __restrict__ y_init, const int* __restrict__ iperm,
                                                                     int n_pose, double* __restrict__ y_tan, double* __restrict__ delta) {
+  constexpr bool y_in_lds = Y_IN_LDS;
   extern __shared__ __attribute__((aligned(16))) double dyn[];
   double* sL = dyn;                         // 64 x 65
   double* sp = sL + NB * (NB + 1);          // 16 x 64
   double* sV = sp + 16 * NB;                // 4 x 16 x 16: inverses of the diagonal 16x16 blocks of L_kk
-  double* sy = sV + 1024;                   // npad
-  int* s_nrows = reinterpret_cast<int*>(sy + npad);   // max_len
+  // the solution vector: in LDS next to the tiles when it fits (npad <= 12 288) — otherwise the walk reads and writes y itself (a
+  // row is read only after the workgroup that solved it — this one, or one of an earlier launch — has written it; L1 is per CU
+  // and write-through, and no line of y holds rows of two tiles)
+  double* sy = y_in_lds ? sV + 1024 : y;    // npad
+  int* s_nrows = reinterpret_cast<int*>(sV + 1024 + (y_in_lds ? npad : 0));   // max_len
   int* s_rowoff = s_nrows + max_len;                  // max_len
   int* s_nr = s_rowoff + max_len;                     // max_len
   int* s_rows = s_nr + max_len;                       // max_len x kBsMaxRows
@@ -934,7 +939,7 @@ __global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double
   const int b = chain_begin[blockIdx.x], e = chain_end[blockIdx.x], len = e - b;
   // y_init (first launch of a solve, a single chain): the forward-substituted rhs row of the factor, copied to y on the way
   if (y_init) { for (int i = tid; i < npad; i += 1024) { const double v = (i < npad - NB) ? y_init[i] : 0.0; sy[i] = v; y[i] = v; } }   // (the last tile is the rhs tile itself)
-  else { for (int i = tid; i < npad; i += 1024) sy[i] = y[i]; }
+  else if (y_in_lds) { for (int i = tid; i < npad; i += 1024) sy[i] = y[i]; }
   // the records of this chain's tiles (DensePlan::bs_desc: one coalesced round, not tile -> panel -> row list)
   for (int i = tid; i < len * DensePlan::kBsDescInts; i += 1024) {
     const int p = i / DensePlan::kBsDescInts, q = i - p * DensePlan::kBsDescInts;
@@ -1001,7 +1006,7 @@ __global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double
     sp[part * NB + c] = acc;
     sV[tid] = vinv;
     if (k > b) issue(k - 1);
-    lds_barrier();
+    if (y_in_lds) lds_barrier(); else __syncthreads();
     if (tid < NB) {
       // L_kk^T y = t on one wave, lane = row.  Blocked by 16 with the inverses of the diagonal blocks (V_b = L_bb^-1, kept
       // by the factorisation for its own triangular solves): four dependent block steps of independent loads and
@@ -1027,13 +1032,13 @@ __global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double
       }
       v = (tid < nr) ? v : 0.0;
       y[c0 + tid] = v;
-      sy[c0 + tid] = v;
+      if (y_in_lds) sy[c0 + tid] = v;
       if (y_tan) {   // the solution in tangent (natural) order and the step -y, written where the tile is solved
         const int j = iperm[k] * NB + tid;
         if (j < n_pose) { y_tan[j] = v; delta[j] = -v; }
       }
     }
-    lds_barrier();
+    if (y_in_lds) lds_barrier(); else __syncthreads();   // (global y: the stores must have left the wave before the other waves read them)
   }
 }
 
@@ -1043,10 +1048,18 @@ void launch_chol_backsolve_chains(hipStream_t s, const double* S, const double* 
                                   int npad, int max_chain_len, const double* y_init, const int* iperm_dev, int n_pose, double* y_tan,
                                   double* delta) {
   if (n_chains <= 0) return;
-  const size_t lds = chol_backsolve_chain_lds(npad, max_chain_len);
-  hipLaunchKernelGGL(chol_backsolve_chain_kernel, dim3(n_chains), dim3(1024), lds, s, S, Lp, Vinv, ld, bs_desc_dev,
-                     chain_begin_dev, chain_end_dev, rows_flat_dev, y, npad, max_chain_len, n_chains == 1 ? y_init : nullptr, iperm_dev, n_pose,
-                     y_tan, delta);
+  size_t lds = chol_backsolve_chain_lds(npad, max_chain_len);
+  const char* fg = getenv("BSGPU_BACKSOLVE_GLOBAL_Y");   // (tests: force the path windows above 12 288 reduced dimensions take)
+  const int y_in_lds = (lds <= (size_t)160 * 1024 && !(fg && atoi(fg) != 0)) ? 1 : 0;
+  if (!y_in_lds) lds = chol_backsolve_chain_lds(0, max_chain_len);
+  if (y_in_lds)
+    hipLaunchKernelGGL(chol_backsolve_chain_kernel<true>, dim3(n_chains), dim3(1024), lds, s, S, Lp, Vinv, ld, bs_desc_dev,
+                       chain_begin_dev, chain_end_dev, rows_flat_dev, y, npad, max_chain_len, n_chains == 1 ? y_init : nullptr, iperm_dev, n_pose,
+                       y_tan, delta);
+  else
+    hipLaunchKernelGGL(chol_backsolve_chain_kernel<false>, dim3(n_chains), dim3(1024), lds, s, S, Lp, Vinv, ld, bs_desc_dev,
+                       chain_begin_dev, chain_end_dev, rows_flat_dev, y, npad, max_chain_len, n_chains == 1 ? y_init : nullptr, iperm_dev, n_pose,
+                       y_tan, delta);
 }
 
 size_t chol_backsolve_chain_lds(int npad, int max_chain_len) {
@@ -1058,7 +1071,9 @@ void chol_prepare() {
                             (int)kPanelStepLds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_panel_step_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kPanelStepLds);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_chain_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_chain_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds);

@@ -102,6 +102,19 @@ class GpuSolver(capi.Solver):
             raise capi.SolverError(capi.ERR_DEVICE, "bsgpu_time_reproj_jacobian_ms failed")
         return ms
 
+    PHASES = ("eval_reproj", "eval_other", "landmark", "pairs", "assemble_other", "factor", "backsolve", "backsub", "candidate")
+
+    def profile_step(self, options=None, reps=10):
+        """bsgpu_profile_step: {phase: (mean ms, algorithmic work)} of a full LM step timed in situ with HIP events (bytes; flops for
+        'factor')."""
+        import numpy as np
+        opt = options if options is not None else self.options_default()
+        ms, work = np.zeros(len(self.PHASES)), np.zeros(len(self.PHASES))
+        fn = lib().bsgpu_profile_step
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+        self._chk(fn(self._ctx, ctypes.byref(opt), int(reps), ms.ctypes.data, work.ctypes.data))
+        return {name: (float(ms[i]), float(work[i])) for i, name in enumerate(self.PHASES)}
+
     def plan_info(self):
         """(independent sub-chains, schedule steps, 64-wide tiles) of the reduced system's Cholesky plan."""
         a, b, c = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)

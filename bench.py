@@ -15,7 +15,10 @@ independent window (BASELINE config 5: seeds +10 + rank) — the path shards by 
 data-path collective; torch.distributed (RCCL) is used for the barriers and the max-over-ranks.
 
 The JSON line also carries
-  roofline     — the reprojection Jacobian-evaluation kernel: algorithmic bytes / HIP-event time
+  roofline     — the reprojection Jacobian-evaluation kernel: algorithmic bytes / HIP-event time measured in situ (inside real LM
+                 steps), plus the same kernel on a working set above the 256 MiB Infinity Cache (past_l3)
+  roofline_mfma, kernels, phases_us_per_lm_step — the Cholesky of the reduced camera system against the FP64 MFMA peak, the other
+                 HBM-bound kernels of a step, and where an LM step's time goes (bsgpu_profile_step)
   cpu_baseline — the CPU oracle (own restatement, kind "port") on the same window, rank 0, N=1
 """
 import argparse
@@ -27,7 +30,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+HBM_COPY_GBS = 6290.0      # ... measured copy peak (the achievable streaming rate)
+MFMA_F64_PEAK_TF = 78.6    # ... dense FP64 MFMA (v_mfma_f64_16x16x4_f64: 64 cycles / instruction / SIMD)
 
 
 def main():
@@ -38,6 +43,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--n-kf", type=int, default=200)
     ap.add_argument("--n-lm", type=int, default=50000)
+    ap.add_argument("--no-past-l3", dest="past_l3", action="store_false",
+                    help="skip the Jacobian-evaluation measurement on the 800 KF x 300k-landmark window (working set above the Infinity Cache)")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"],
                     help="c2 (default) is the headline; c3 / c4 are the other BASELINE configs, for BASELINE.md")
     args = ap.parse_args()
@@ -109,40 +116,85 @@ def main():
 
     out = None
     if rank == 0:
-        # ---- roofline of the dominant HBM-bound kernel: reprojection Jacobian evaluation ---------
-        reps = 50
+        # ---- rooflines, all measured IN SITU: HIP events at the phase boundaries of real LM steps on the solver's stream
+        # (bsgpu_profile_step); the kernel-trace average of the same kernels is in profiles/r02_*_kernel_stats.csv
         has_vis = pr.n_factors(0) > 0
-        ms = g.time_reproj_jacobian_ms(reps) if has_vis else float("nan")   # HIP events on the solver's own stream
-        nbytes = g.reproj_jacobian_bytes() if has_vis else 0
-        achieved = nbytes / (ms * 1e-3) / 1e9 if has_vis else 0.0
-        roofline = {"bound": "hbm", "kernel": "reproj_eval_kernel<true>", "achieved": round(achieved, 1),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "bytes_per_launch": int(nbytes), "ms_per_launch": round(ms, 5), "traffic": None}
-        # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the
-        # gfx950 correction of MI355X_MICROARCH.md); bench.py itself cannot collect counters
-        pmc = os.path.join(ROOT, "profiles", "r01_c2_pmc_hbm.csv")
-        if not has_vis:
-            roofline = None   # C3 / C4 have no reprojection factors: the headline roofline kernel does not run
-        elif world == 1 and args.workload == "c2" and args.n_kf == 200 and args.n_lm == 50000 and os.path.exists(pmc):
-            import csv
-            for row in csv.reader(open(pmc)):
-                if row and row[0].startswith("void bsg::reproj_eval_kernel<true>"):
-                    roofline["traffic"] = int((2.0 * float(row[2]) + float(row[3])) * 1024)
-                    roofline["traffic_source"] = "profiles/r01_c2_pmc_hbm.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+        roofline = roofline_mfma = kernels = phases = None
+        if has_vis and not (args.workload == "c4"):
+            prof = g.profile_step(opt, reps=20)
+            phases = {k: round(1e3 * v[0], 2) for k, v in prof.items()}          # microseconds per LM step
+            ms, nbytes = prof["eval_reproj"]
+            achieved = nbytes / (ms * 1e-3) / 1e9
+            working_set_mb = nbytes / 1e6
+            roofline = {"bound": "hbm", "kernel": "reproj_eval_kernel<true>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_measured_copy_peak": round(achieved / HBM_COPY_GBS, 4),
+                        "bytes_per_launch": int(nbytes), "ms_per_launch": round(ms, 5),
+                        "timing": "in situ: HIP events around the launch inside 20 full LM steps (bsgpu_profile_step)",
+                        "working_set_mb": round(working_set_mb, 1),
+                        "cache_residency": "below the 256 MiB Infinity Cache: the stream is MALL/fabric traffic, see past_l3" if working_set_mb < 256 else "above the 256 MiB Infinity Cache",
+                        "traffic": None}
+            # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the gfx950 correction of
+            # MI355X_MICROARCH.md); bench.py itself cannot collect counters
+            pmc = os.path.join(ROOT, "profiles", "r02_c2_pmc_hbm.csv")
+            if not os.path.exists(pmc):
+                pmc = os.path.join(ROOT, "profiles", "r01_c2_pmc_hbm.csv")
+            if world == 1 and args.workload == "c2" and args.n_kf == 200 and args.n_lm == 50000 and os.path.exists(pmc):
+                import csv
+                for row in csv.reader(open(pmc)):
+                    if row and row[0].startswith("void bsg::reproj_eval_kernel<true>"):
+                        roofline["traffic"] = int((2.0 * float(row[2]) + float(row[3])) * 1024)
+                        roofline["traffic_source"] = os.path.relpath(pmc, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+            ms_f, flops = prof["factor"]
+            tf = flops / (ms_f * 1e-3) / 1e12
+            roofline_mfma = {"bound": "mfma", "kernel": "chol_fused_kernel (+ chol_backsolve_chain_kernel: %.1f us)" % (1e3 * prof["backsolve"][0]),
+                             "achieved": round(tf, 3), "peak": MFMA_F64_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F64_PEAK_TF, 4),
+                             "flops_per_launch": int(flops), "ms_per_launch": round(ms_f, 5),
+                             "note": "dependent chain of ~13 panel steps (64-pivot scalar chain each): latency-bound, not MFMA-bound; DESIGN.md §3.2"}
+            kernels = []
+            for name, kern in (("landmark", "landmark_kernel (+ clear)"), ("pairs", "pairs_kernel"), ("backsub", "backsub_mcc_kernel (+ small_mcc)"),
+                               ("candidate", "update + reproj_eval_kernel<false> + reduction")):
+                ms_k, by = prof[name]
+                kernels.append({"phase": name, "kernel": kern, "us": round(1e3 * ms_k, 2), "algorithmic_bytes": int(by),
+                                "achieved_gbs": round(by / (ms_k * 1e-3) / 1e9, 1), "frac_hbm": round(by / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+            if args.past_l3 and world == 1 and args.workload == "c2":
+                # the same kernel on a working set the Infinity Cache cannot hold: 800 keyframes x 300 000 landmarks, ~2.4 M observations
+                # (J + r ~ 385 MB per evaluation); Jacobian evaluation only (50 launches, HIP events) — nothing is solved
+                big = synthetic.vio_window(n_kf=800, n_lm=300000, seed=20250621)
+                gb = GpuSolver(local_rank)
+                big.load(gb)
+                gb.finalize()
+                ms_b = gb.time_reproj_jacobian_ms(20)
+                nb_b = gb.reproj_jacobian_bytes()
+                ach_b = nb_b / (ms_b * 1e-3) / 1e9
+                roofline["past_l3"] = {"workload": "800 KF x 300000 landmarks, %d observations" % big.n_factors(0), "bytes_per_launch": int(nb_b),
+                                       "ms_per_launch": round(ms_b, 5), "achieved": round(ach_b, 1), "frac": round(ach_b / HBM_PEAK_GBS, 4),
+                                       "frac_of_measured_copy_peak": round(ach_b / HBM_COPY_GBS, 4),
+                                       "timing": "20 back-to-back launches between two HIP events (each launch streams more than the cache holds)"}
+                gb.close()
+        metric = {"c2": "LM iterations/sec + ms/graph-solve, 200KF x 50k-landmark VIO window",
+                  "c3": "LM iterations/sec + ms/graph-solve, LIO fixed-lag window (100 KF, 20k relative-pose + IMU factors)",
+                  "c4": "LM iterations/sec + ms/graph-solve, global-mapper pose graph (5k poses, 50k constraints)"}[args.workload]
+        solver_options = {"c2": "vio.yaml:7-17 (<= 10 iterations, tolerances 1.5e-7), max_solver_time lifted",
+                          "c3": "vio.yaml:7-17 (<= 10 iterations, tolerances 1.5e-7), max_solver_time lifted",
+                          "c4": "default ceres::Solver::Options as the global mapper passes them (SURVEY.md §3.4), max_num_iterations 10"}[args.workload]
         out = {
-            "metric": "LM iterations/sec + ms/graph-solve, 200KF x 50k-landmark VIO window",
+            "metric": metric,
             "value": round(tot_it / max_dt, 2), "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * max_dt / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "n_obs": int(pr.meta.get("n_obs", 0)), "n_imu_factors": int(pr.meta.get("n_imu", 0)),
                        "pcg_iterations_per_solve": s.num_inner_iterations,
                        "lm_iterations_per_solve": round(n_it / args.steps, 2),
-                       "solver_options": "vio.yaml:7-17, max_solver_time lifted",
+                       "solver_options": solver_options,
                        "final_cost": s.final_cost, "initial_cost": s.initial_cost,
                        "device_ms_per_solve": round(1e3 * dev_s / args.steps, 3),
                        "parallelism": "1 window per GPU, no collective" if world > 1 else "single GPU"},
             "roofline": roofline,
         }
+        if roofline_mfma:
+            out["roofline_mfma"] = roofline_mfma
+            out["kernels"] = kernels
+            out["phases_us_per_lm_step"] = phases
         # ---- CPU baseline: the oracle on the same window (bounded: one solve, same options) ------
         if world == 1 and not args.no_cpu_baseline and args.workload != "c4":
             sys.path.insert(0, os.path.join(ROOT, "oracle"))

@@ -404,6 +404,23 @@ int bsgpu_triangulate(bsgpu_ctx* ctx, int32_t n_tracks, const int32_t* track_sta
 double bsgpu_time_reproj_jacobian_ms(bsgpu_ctx* ctx, int32_t reps);
 /* Algorithmic bytes one launch of that kernel moves. */
 int64_t bsgpu_reproj_jacobian_bytes(const bsgpu_ctx* ctx);
+/* Measurement: the phases of a full LM step timed IN SITU — `reps` steps exactly as bsgpu_solve enqueues them for an accepted step
+ * (dense Schur path), a HIP event at every phase boundary on the solver's stream.  ms_out[BSGPU_PHASE_NUM]: mean milliseconds
+ * per phase; work_out[BSGPU_PHASE_NUM] (may be NULL): the algorithmic work of the phase's dominant kernel — bytes, or FP64 flops
+ * for BSGPU_PHASE_FACTOR — 0 where none is defined.  The values return to those of the last finalize. */
+enum {
+  BSGPU_PHASE_EVAL_REPROJ = 0,    /* reproj_eval_kernel<true>: residuals + Jacobians of the reprojection factors */
+  BSGPU_PHASE_EVAL_OTHER = 1,     /* IMU / relative-pose / prior factors */
+  BSGPU_PHASE_LANDMARK = 2,       /* clear + landmark_kernel: H_ll, its Cholesky, C and rho per factor */
+  BSGPU_PHASE_PAIRS = 3,          /* pairs_kernel: camera-pair blocks of the reduced system */
+  BSGPU_PHASE_ASSEMBLE_OTHER = 4, /* pose-only factors, LM diagonal, gradient norms */
+  BSGPU_PHASE_FACTOR = 5,         /* Cholesky of the reduced camera system (FP64 MFMA) */
+  BSGPU_PHASE_BACKSOLVE = 6,      /* L^T y = y' */
+  BSGPU_PHASE_BACKSUB = 7,        /* landmark back-substitution + model-cost terms */
+  BSGPU_PHASE_CANDIDATE = 8,      /* x [+] delta, cost at the candidate, end-of-step reduction */
+  BSGPU_PHASE_NUM = 9
+};
+int bsgpu_profile_step(bsgpu_ctx* ctx, const bsgpu_options* options, int32_t reps, double* ms_out, double* work_out);
 
 /* Stand-alone dense SPD solve A x = b (row-major n x n, host pointers) through the kernels the
  * reduced camera system uses after Schur elimination — test and measurement hook for the FP64

@@ -106,12 +106,40 @@ def test_window_near_the_largest_supported_size(gpu_solver_cls):
     g.reset_values()
     s2 = g.solve(opt)
     assert abs(s2.final_cost - s.final_cost) <= 1e-12 * s.final_cost   # deterministic
-    big = synthetic.vio_window(n_kf=830, n_lm=2000, seed=78)
+    # one step over what the LDS-resident back-substitution takes (12 288): the same tiled factorisation with the solution vector in
+    # global memory — no size cliff for windows with landmarks (round 1 refused this window)
+    big = synthetic.vio_window(n_kf=830, n_lm=83000, seed=78)
     g2 = gpu_solver_cls(0)
     big.load(g2)
-    with pytest.raises(capi.SolverError) as e:
-        g2.solve(opt)
-    assert e.value.code == capi.ERR_UNSUPPORTED and "window too large" in str(e.value)
+    s3 = g2.solve(opt)
+    assert s3.num_parameters_tangent == 830 * 15 + 3 * 83000
+    assert s3.is_solution_usable == 1 and s3.linear_solver_used == capi.LINEAR_SCHUR_CHOLESKY
+    costs = [i.cost for i in g2.iterations() if i.step_is_successful]
+    assert all(b <= a for a, b in zip(costs, costs[1:])) and s3.final_cost < 0.01 * s3.initial_cost
+    x = g2.get_blocks()
+    p_err = np.array([big.block(int(b), x) for b in big.meta["kf_blocks"][:, 1]]) - big.meta["p_true"]
+    assert np.abs(p_err).max() < 0.15
+
+
+def test_window_above_the_lds_limit_matches_the_lds_path(gpu_solver_cls, monkeypatch):
+    """The global-memory back-substitution against the LDS-resident one on the SAME window: a 300-keyframe window solved normally and
+    with BSGPU_BACKSOLVE_GLOBAL_Y=1 (which forces the path windows above 12 288 reduced dimensions take) — same iterations, same
+    costs and values to round-off."""
+    pr = synthetic.vio_window(n_kf=300, n_lm=6000, seed=79)
+    res = []
+    for force in ("0", "1"):
+        monkeypatch.setenv("BSGPU_BACKSOLVE_GLOBAL_Y", force)
+        g = gpu_solver_cls(0)
+        pr.load(g)
+        opt = g.options_vio()
+        opt.max_solver_time_in_seconds = 0.0
+        s = g.solve(opt)
+        res.append((s, [i.cost for i in g.iterations()], g.get_blocks()))
+    (s0, c0, x0), (s1, c1, x1) = res
+    assert s0.num_iterations == s1.num_iterations and len(c0) == len(c1)
+    assert np.allclose(c0, c1, rtol=1e-10, atol=0)
+    assert abs(s0.final_cost - s1.final_cost) <= 1e-10 * s0.final_cost
+    assert np.abs(x0 - x1).max() < 1e-8
 
 
 def test_c3_lio_window_full_size(oracle_cls, gpu_solver_cls):
@@ -146,6 +174,12 @@ def test_c4_evaluation_matches_oracle(oracle_cls, gpu_solver_cls):
     assert np.abs(rg - ro).max() <= 1e-9 * max(1.0, np.abs(ro).max())
     assert np.abs(gg - go).max() <= 1e-9 * np.abs(go).max()
     assert [g.tangent_offset(b) for b in range(0, pr.n_blocks, 97)] == [o.tangent_offset(b) for b in range(0, pr.n_blocks, 97)]
+    # a pose-only graph of this size has no exact path (30 000 dense dimensions, fill from the loop closures): asking for one is refused
+    opt = g.options_default()
+    opt.linear_solver_type = capi.LINEAR_SCHUR_CHOLESKY
+    with pytest.raises(capi.SolverError) as e:
+        g.solve(opt)
+    assert e.value.code == capi.ERR_UNSUPPORTED
 
 
 def test_c4_pose_graph_full_size(gpu_solver_cls):
