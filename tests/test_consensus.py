@@ -1,0 +1,163 @@
+"""Shared-pose consensus wired to the solver (beam_slam_amd/sharding.py consensus_by_marginals): two submaps that overlap in a boundary
+keyframe, each solved by its own context, exchanging only the consensus all-reduce over the shared state and their small marginal
+priors on it — the result must be the optimum of the MERGED graph (north_star: "RCCL over xGMI only for shared-pose consensus"; the reference's
+independent units: bs_models/src/lib/global_mapping/submap_refinement.cpp:35-115).
+CPU: the oracle as the per-window solver (in one process, and as two gloo ranks); -m gpu: two libbsgpu contexts on one device."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+from beam_slam_amd import capi, sharding, synthetic
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def two_submaps(seed=3, n_kf=11, cut=5):
+    """One visual-inertial window cut into two submaps that share the keyframe `cut` and nothing else: landmarks are local to a
+    submap (as in the reference's global map, where every submap owns its landmarks), so a landmark seen from both sides exists
+    once per submap.  Returns (merged Problem — the graph both submaps together describe —, factor -> part)."""
+    pr = synthetic.vio_window(n_kf=n_kf, n_lm=130, seed=seed)
+    kf = pr.meta["kf_blocks"]
+    kf_of_q = {int(kf[k, 0]): k for k in range(kf.shape[0])}
+    part = {}
+    for t, chunks in pr.factors.items():
+        for ci, (idx, consts, lk, la) in enumerate(chunks):
+            if t == capi.F_REPROJ:
+                k = np.array([kf_of_q[int(q)] for q in idx[:, 0]])
+                p = np.where(k <= cut, 0, 1)
+                # landmarks observed from both sides: the second submap gets its own copy (same initial value)
+                both = np.intersect1d(idx[p == 0, 2], idx[p == 1, 2])
+                for lm in both:
+                    copy = pr.add_block(pr.block(int(lm)).copy())
+                    idx[(p == 1) & (idx[:, 2] == lm), 2] = copy
+                # a landmark needs two views inside its submap (its depth is unobservable otherwise): single views are dropped
+                lms, counts = np.unique(idx[:, 2], return_counts=True)
+                keep = ~np.isin(idx[:, 2], lms[counts < 2])
+                pr.factors[t][ci] = (idx[keep], consts[keep], lk[keep], la[keep])
+                p = p[keep]
+            elif t == capi.F_IMU_DELTA:
+                k1 = np.array([kf_of_q[int(q)] for q in idx[:, 5]])      # the later state of the pair
+                p = np.where(k1 <= cut, 0, 1)
+            else:
+                p = np.zeros(idx.shape[0], int)                           # the prior on the first state
+            part[(t, ci)] = p
+    return pr, part
+
+
+def tight(solver):
+    """Inner solves to convergence (the consensus rounds cannot agree better than the windows are solved)."""
+    opt = solver.options_default()
+    opt.max_num_iterations = 50
+    opt.function_tolerance = 1e-14; opt.gradient_tolerance = 1e-14; opt.parameter_tolerance = 1e-14
+    return opt
+
+
+def merged_and_parts(seed=3):
+    pr, part = two_submaps(seed)
+    subs, n_shared, is_quat, holders = sharding.partition_problem(pr, part, 2)
+    return pr, subs, n_shared, is_quat, holders
+
+
+def check_against_merged(pr, subs, z, merged_solver_cls, rel_tol):
+    """Cost of the merged graph at the consensus solution (shared blocks from z, private blocks from their window) against the
+    merged window's own optimum."""
+    m = merged_solver_cls() if merged_solver_cls.__name__ == "Oracle" else merged_solver_cls(0)
+    pr.load(m)
+    opt = m.options_default()
+    opt.max_num_iterations = 100
+    opt.function_tolerance = 1e-14; opt.gradient_tolerance = 1e-14; opt.parameter_tolerance = 1e-14
+    best = m.solve(opt)
+    x = pr.values.copy()
+    for sub in subs:
+        for l, gb in enumerate(sub.global_of_local):
+            x[pr.offset[gb]:pr.offset[gb] + pr.size[gb]] = sub.problem.block(l)
+    for sub in subs:                                   # shared blocks: the consensus value itself
+        for l, s in zip(sub.shared_local, sub.shared_id):
+            gb = sub.global_of_local[l]
+            x[pr.offset[gb]:pr.offset[gb] + pr.size[gb]] = z[s, :pr.size[gb]]
+    m.set_values(x)
+    cost = m.evaluate(residuals=False, gradient=False)[0]
+    assert abs(cost - best.final_cost) <= rel_tol * best.final_cost, (cost, best.final_cost)
+    return cost, best.final_cost
+
+
+def test_partition_adds_up(oracle_cls):
+    pr, subs, n_shared, is_quat, holders = merged_and_parts()
+    assert n_shared == 5 and holders.all() and is_quat.sum() == 1       # the five state blocks of the boundary keyframe
+    o = oracle_cls(); pr.load(o)
+    total = o.evaluate(residuals=False, gradient=False)[0]
+    parts = 0.0
+    for sub in subs:
+        oi = oracle_cls(); sub.problem.load(oi)
+        parts += oi.evaluate(residuals=False, gradient=False)[0]
+    assert abs(parts - total) <= 1e-12 * total            # the halves' objectives are the merged objective
+    assert pr.n_factors() == sum(s.problem.n_factors() for s in subs)
+
+
+def test_consensus_reaches_the_merged_optimum_oracle(oracle_cls):
+    pr, subs, n_shared, is_quat, _ = merged_and_parts()
+    solvers = [oracle_cls(), oracle_cls()]
+    z, hist = sharding.consensus_by_marginals(solvers, subs, n_shared, is_quat, rounds=8, options=tight(solvers[0]))
+    assert hist[-1][1] < 1e-7 and hist[3][1] < 1e-3 * hist[1][1]            # agreement on the shared state; Gauss-Newton-like contraction
+    check_against_merged(pr, subs, z, oracle_cls, 1e-9)                     # (north_star bar: 1e-6)
+
+
+@pytest.mark.gpu
+def test_consensus_two_contexts_on_one_gpu(oracle_cls, gpu_solver_cls):
+    """Two libbsgpu contexts = two overlapping half-windows: within 1e-6 relative cost of the ORACLE's solve of the merged window."""
+    pr, subs, n_shared, is_quat, _ = merged_and_parts()
+    solvers = [gpu_solver_cls(0), gpu_solver_cls(0)]
+    z, hist = sharding.consensus_by_marginals(solvers, subs, n_shared, is_quat, rounds=8, options=tight(solvers[0]))
+    assert hist[-1][1] < 1e-7
+    check_against_merged(pr, subs, z, oracle_cls, 1e-8)                     # (north_star bar: 1e-6)
+
+
+WORKER = textwrap.dedent("""
+    import os, sys, json
+    import numpy as np
+    import torch, torch.distributed as dist
+    sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "oracle")); sys.path.insert(0, os.path.join(%r, "tests"))
+    from beam_slam_amd import sharding
+    from oracle import Oracle
+    import test_consensus as tc
+    dist.init_process_group("gloo")
+    rank = dist.get_rank()
+    pr, subs, n_shared, is_quat, _ = tc.merged_and_parts()
+    def all_reduce(a):
+        t = torch.from_numpy(np.ascontiguousarray(a, np.float64).copy())
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.numpy()
+    o = Oracle()
+    z, hist = sharding.consensus_by_marginals([o], [subs[rank]], n_shared, is_quat, rounds=8, options=tc.tight(o), all_reduce=all_reduce,
+                                              part_ids=[rank], n_parts=2)
+    np.save(os.path.join(sys.argv[1], "x_%%d.npy" %% rank), subs[rank].problem.values)
+    with open(os.path.join(sys.argv[1], "r_%%d.json" %% rank), "w") as fh:
+        json.dump(dict(z=z.tolist(), hist=hist[-1], n_outer=len(hist)), fh)
+    dist.destroy_process_group()
+""")
+
+
+def test_consensus_two_gloo_ranks(tmp_path, oracle_cls):
+    """One window per rank, world size 2 (gloo here, RCCL on the GPU box): the only collective is the consensus all-reduce."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % (ROOT, ROOT, ROOT))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script), str(tmp_path)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = [json.loads((tmp_path / ("r_%d.json" % r)).read_text()) for r in range(2)]
+    z0, z1 = np.array(res[0]["z"]), np.array(res[1]["z"])
+    assert np.array_equal(z0, z1)                                   # the consensus is identical on both ranks
+    pr, subs, n_shared, is_quat, _ = merged_and_parts()
+    for r in range(2):
+        subs[r].problem.values = np.load(tmp_path / ("x_%d.npy" % r))
+    check_against_merged(pr, subs, z0, oracle_cls, 1e-9)

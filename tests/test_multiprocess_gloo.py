@@ -29,7 +29,9 @@ WORKER = textwrap.dedent("""
     p = torch.tensor(p_true + 0.01 * prng.normal(size=(4, 3)))
     q = sharding._quat_mul(q_true, sharding._quat_exp(torch.tensor(0.01 * prng.normal(size=(4, 3)))))
     w = torch.ones(4, dtype=torch.float64)
-    if rank == 1: w[3] = 0.0          # rank 1 does not hold pose 3
+    if rank == 1: w[3] = 0.0          # rank 1 does not hold pose 3 ...
+    if rank == 1: q[3] = float("nan"); p[3] = float("nan")     # ... and passes a placeholder there
+    if rank == 0: w[2] = 0.0; q[2] = 0.0                       # rank 0 (no special role) does not hold pose 2: a zero quaternion
     pc, qc = sharding.consensus_poses(dist, p, q, w)
     # one file per rank: both ranks share the launcher's stdout pipe and long lines written to it can interleave
     with open(os.path.join(sys.argv[1], "result_%%d.json" %% rank), "w") as fh:
@@ -65,13 +67,15 @@ def test_two_rank_sharding_aggregation_and_consensus(tmp_path):
     qc0, qc1 = np.array(res[0]["qc"]), np.array(res[1]["qc"])
     assert np.array_equal(pc0, pc1) and np.array_equal(qc0, qc1)
     p0, p1 = np.array(res[0]["p"]), np.array(res[1]["p"])
-    exp_p = np.vstack([(p0[:3] + p1[:3]) / 2, p0[3:4]])
+    exp_p = np.vstack([(p0[:2] + p1[:2]) / 2, p1[2:3], p0[3:4]])
     assert np.abs(pc0 - exp_p).max() < 1e-14
-    q0 = np.array(res[0]["q"])
-    assert np.abs(qc0[3] - q0[3]).max() < 1e-14          # pose 3 only known to rank 0
+    q0, q1 = np.array(res[0]["q"]), np.array(res[1]["q"])
+    same = lambda a, b: min(np.abs(a - b).max(), np.abs(a + b).max())
+    assert same(qc0[3], q0[3]) < 1e-14                    # pose 3 only known to rank 0 (rank 1 passed NaN)
+    assert same(qc0[2], q1[2]) < 1e-14                    # pose 2 only known to rank 1 (rank 0 passed a zero quaternion)
+    assert np.isfinite(qc0).all() and np.isfinite(pc0).all()
     assert np.abs(np.linalg.norm(qc0, axis=1) - 1).max() < 1e-14
     # the consensus orientation lies between the two estimates
-    q1 = np.array(res[1]["q"])
-    for i in range(3):
+    for i in range(2):
         d01 = 1 - abs(q0[i] @ q1[i]); d0c = 1 - abs(q0[i] @ qc0[i]); d1c = 1 - abs(q1[i] @ qc0[i])
         assert d0c < d01 and d1c < d01
