@@ -279,11 +279,11 @@ int bsgpu_evaluate(bsgpu_ctx* c, double* cost, double* residuals, double* gradie
   const Visual& V = c->vis;
   if ((rc = ensure_vis_src(c)) != BSGPU_OK) return rc;
   if (V.n) {
-    std::vector<double> r((size_t)V.n * 2), J((size_t)V.n * 18);
+    std::vector<double> r((size_t)V.n * 2), J((size_t)V.n * (kJAStride + 6));
     std::vector<int4> fac(V.n);
     std::vector<int> cam_pose(V.n), lm_of(V.n), cp_tq(V.n_cam_pose), cp_tp(V.n_cam_pose);
     HIPCHK(c, hipMemcpy(r.data(), V.r, sizeof(double) * 2 * V.n, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(J.data(), V.J, sizeof(double) * 18 * V.n, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(J.data(), V.J, sizeof(double) * (kJAStride + 6) * V.n, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(cam_pose.data(), V.cam_pose, sizeof(int) * V.n, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(lm_of.data(), V.lm_of, sizeof(int) * V.n, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(cp_tq.data(), V.cp_tq, sizeof(int) * V.n_cam_pose, hipMemcpyDeviceToHost));
@@ -297,7 +297,8 @@ int bsgpu_evaluate(bsgpu_ctx* c, double* cost, double* residuals, double* gradie
         for (int sl = 0; sl < 3; ++sl) {
           if (cols[sl] < 0) continue;
           for (int j = 0; j < 3; ++j) {
-            const double v = J[(size_t)i * 18 + (sl < 2 ? 6 * k + 3 * sl + j : 12 + 3 * k + j)];   // stored row: [A row 0 | A row 1 | B row 0 | B row 1]
+            // stored: pose parts [n][A row 0 | A row 1] first, then the landmark parts [n][B row 0 | B row 1]
+            const double v = sl < 2 ? J[(size_t)i * kJAStride + 6 * k + 3 * sl + j] : J[(size_t)V.n * kJAStride + (size_t)i * 6 + 3 * k + j];
             grad[cols[sl] + j] += v * r[2 * (size_t)i + k];
             if (jacobian) jacobian[(size_t)(row + k) * n + cols[sl] + j] = v;
           }

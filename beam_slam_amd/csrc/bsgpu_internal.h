@@ -21,6 +21,10 @@ struct DevLoss {
   double a;
 };
 
+// row pitch (doubles) of the pose part of the reprojection Jacobian.  (Padding the rows to one 128-byte line each, pitch 16, was
+// tried for the pair kernel's gathers: no gain there, and the evaluation kernel's partial-line streaming stores went 18 -> 31 us.)
+constexpr int kJAStride = 12;
+
 // entries of one camera pair are cut into segments of at most this many (one single-wave workgroup of pairs_kernel each);
 // a power of two.  Host and device flattening must agree (their tables are compared bit for bit).
 constexpr int kPairChunk = 128;
@@ -110,7 +114,9 @@ struct Visual {
   int* ent_fa = nullptr; int* ent_fb = nullptr;
   // outputs
   double2* r = nullptr;       // n
-  double* J = nullptr;        // n x 18 (row-major 2 x 9: theta, t, P), robustified
+  double* J = nullptr;        // robustified Jacobian, split by consumer: pose part n x 12 ([A row 0 (theta, t: 6) | A row 1]) ...
+  double* JB = nullptr;       // ... and landmark part n x 6 ([B row 0 | B row 1]) = J + 12 n: the landmark kernel streams 48 B per factor
+                              // instead of dragging 144-byte rows through for a third of their bytes
   double* CR = nullptr;       // n x 8: C = B M (2x3), rho = r - C z (2)
   double* Linv = nullptr;     // n_lm x 6  (lower-triangular inverse factor of Hll + lambda)
   double* z = nullptr;        // n_lm x 3  (Linv * g_l)

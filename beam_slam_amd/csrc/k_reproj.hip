@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void reproj_eval_kernel(int n, const int4* __r
                                                           const DevCamera* __restrict__ cams,
                                                           const DevLoss* __restrict__ losses,
                                                           double2* __restrict__ r_out, double* __restrict__ J_out,
-                                                          double* __restrict__ cost_part, int count_inactive) {
+                                                          double* __restrict__ JB_out, double* __restrict__ cost_part, int count_inactive) {
   __shared__ __attribute__((aligned(16))) double sJ[WITH_J ? 4 * 64 * 18 : 4];
   __shared__ double sred[4];
   const int f = blockIdx.x * 256 + threadIdx.x;
@@ -116,14 +116,20 @@ __global__ __launch_bounds__(256) void reproj_eval_kernel(int n, const int4* __r
     const int fb = blockIdx.x * 256 + wave * 64;
     const int cnt = min(64, n - fb);
     if (cnt > 0) {
+      // two contiguous streams per wave: 96 B of pose part and 48 B of landmark part per factor, 16 B per lane and store
       typedef double d2_t __attribute__((ext_vector_type(2)));
-      d2_t* dst = reinterpret_cast<d2_t*>(J_out + (size_t)fb * 18);
+      d2_t* dstA = reinterpret_cast<d2_t*>(J_out + (size_t)fb * kJAStride);
+      d2_t* dstB = reinterpret_cast<d2_t*>(JB_out + (size_t)fb * 6);
       const d2_t* src = reinterpret_cast<const d2_t*>(sw);
-      const int n2 = cnt * 9;
 #pragma unroll
-      for (int it = 0; it < 9; ++it) {
+      for (int it = 0; it < 6; ++it) {
         const int e = it * 64 + lane;
-        if (e < n2) __builtin_nontemporal_store(src[e], &dst[e]);   // streamed: 58 MB that no cache will hold until the next kernel
+        if (e < cnt * 6) __builtin_nontemporal_store(src[(e / 6) * 9 + (e % 6)], &dstA[(e / 6) * (kJAStride / 2) + (e % 6)]);   // streamed: no cache holds 58 MB until the next kernel
+      }
+#pragma unroll
+      for (int it = 0; it < 3; ++it) {
+        const int e = it * 64 + lane;
+        if (e < cnt * 3) __builtin_nontemporal_store(src[(e / 3) * 9 + 6 + (e % 3)], &dstB[e]);
       }
     }
   }
@@ -135,10 +141,10 @@ void launch_reproj_eval(hipStream_t s, const Visual& v, const double* x, const D
   const int grid = (v.n + 255) / 256;
   if (with_J)
     hipLaunchKernelGGL(reproj_eval_kernel<true>, dim3(grid), dim3(256), 0, s, v.n, v.fac, v.pix, v.w, x, cams, losses,
-                       v.r, v.J, cost_part_out, count_inactive ? 1 : 0);
+                       v.r, v.J, v.JB, cost_part_out, count_inactive ? 1 : 0);
   else
     hipLaunchKernelGGL(reproj_eval_kernel<false>, dim3(grid), dim3(256), 0, s, v.n, v.fac, v.pix, v.w, x, cams, losses,
-                       v.r, v.J, cost_part_out, count_inactive ? 1 : 0);
+                       v.r, v.J, v.JB, cost_part_out, count_inactive ? 1 : 0);
 }
 void launch_reproj_jacobian_only(hipStream_t s, const Visual& v, const double* x, const DevCamera* cams,
                                  const DevLoss* losses) {
@@ -193,7 +199,7 @@ void launch_reproj_errors(hipStream_t s, const Visual& v, const SmallGroup& dens
 // lambda_j = clamp(s_j^2 H_jj, lo, hi) / (radius s_j^2) on the unscaled system.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void landmark_kernel(int n_lm, const int* __restrict__ lm_start,
-                                                       const double* __restrict__ J, const double2* __restrict__ r,
+                                                       const double* __restrict__ JB, const double2* __restrict__ r,
                                                        int n_pose, const double* __restrict__ radius_ptr, int compute_scale,
                                                        int compute_dcl, int jacobi, double lm_lo, double lm_hi,
                                                        double* __restrict__ scale, double* __restrict__ dcl,
@@ -207,9 +213,9 @@ __global__ __launch_bounds__(256) void landmark_kernel(int n_lm, const int* __re
   if (valid) { beg = lm_start[l]; end = lm_start[l + 1]; }
   double h00 = 0, h01 = 0, h02 = 0, h11 = 0, h12 = 0, h22 = 0, b0 = 0, b1 = 0, b2 = 0;
   for (int f = beg + sub; f < end; f += 8) {
-    const double* Jf = J + (size_t)f * 18;
+    const double* Jf = JB + (size_t)f * 6;
     const double2 rf = r[f];
-    const double x0 = Jf[12], x1 = Jf[13], x2 = Jf[14], y0 = Jf[15], y1 = Jf[16], y2 = Jf[17];
+    const double x0 = Jf[0], x1 = Jf[1], x2 = Jf[2], y0 = Jf[3], y1 = Jf[4], y2 = Jf[5];
     h00 += x0 * x0 + y0 * y0; h01 += x0 * x1 + y0 * y1; h02 += x0 * x2 + y0 * y2;
     h11 += x1 * x1 + y1 * y1; h12 += x1 * x2 + y1 * y2; h22 += x2 * x2 + y2 * y2;
     b0 += x0 * rf.x + y0 * rf.y; b1 += x1 * rf.x + y1 * rf.y; b2 += x2 * rf.x + y2 * rf.y;
@@ -253,11 +259,11 @@ __global__ __launch_bounds__(256) void landmark_kernel(int n_lm, const int* __re
     z_out[3 * l] = z0; z_out[3 * l + 1] = z1; z_out[3 * l + 2] = z2;
   }
   for (int f = beg + sub; f < end; f += 8) {
-    const double* Jf = J + (size_t)f * 18;
+    const double* Jf = JB + (size_t)f * 6;
     const double2 rf = r[f];
     double* o = CR + (size_t)f * 8;
     // C[k][j] = sum_i B[k][i] Linv[j][i]
-    const double x0 = Jf[12], x1 = Jf[13], x2 = Jf[14], y0 = Jf[15], y1 = Jf[16], y2 = Jf[17];
+    const double x0 = Jf[0], x1 = Jf[1], x2 = Jf[2], y0 = Jf[3], y1 = Jf[4], y2 = Jf[5];
     const double c00 = x0 * i00, c01 = x0 * i10 + x1 * i11, c02 = x0 * i20 + x1 * i21 + x2 * i22;
     const double c10 = y0 * i00, c11 = y0 * i10 + y1 * i11, c12 = y0 * i20 + y1 * i21 + y2 * i22;
     o[0] = c00; o[1] = c01; o[2] = c02; o[3] = c10; o[4] = c11; o[5] = c12;
@@ -281,7 +287,7 @@ void launch_landmark(hipStream_t s, const Visual& v, int n_pose, const double* r
                      double* grad) {
   if (v.n_lm > 0) {
     const int grid = (v.n_lm * 8 + 255) / 256;
-    hipLaunchKernelGGL(landmark_kernel, dim3(grid), dim3(256), 0, s, v.n_lm, v.lm_start, v.J, v.r, n_pose, radius_ptr,
+    hipLaunchKernelGGL(landmark_kernel, dim3(grid), dim3(256), 0, s, v.n_lm, v.lm_start, v.JB, v.r, n_pose, radius_ptr,
                        compute_scale, compute_dcl, jacobi, lm_lo, lm_hi, scale, dcl, grad, v.Linv, v.z, v.CR);
   }
   if (v.n > v.n_elim) {
@@ -325,9 +331,9 @@ __global__ __launch_bounds__(64) void pairs_kernel(int n_seg, const int* __restr
   const int beg = seg_start[seg], end = seg_start[seg + 1];
   for (int e = beg + lane; e < end; e += 64) {
     const int fa = ent_fa[e], fb = ent_fb[e];
-    // 16-byte loads of the AoS rows: J row = 9 double2 (A = the first six, see reproj_eval_kernel), CR row = 4 double2
-    const double2* Ja = reinterpret_cast<const double2*>(J + (size_t)fa * 18);
-    const double2* Jb = reinterpret_cast<const double2*>(J + (size_t)fb * 18);
+    // 16-byte loads of the AoS rows: pose part of J = 6 double2 (see reproj_eval_kernel), CR row = 4 double2
+    const double2* Ja = reinterpret_cast<const double2*>(J + (size_t)fa * kJAStride);
+    const double2* Jb = reinterpret_cast<const double2*>(J + (size_t)fb * kJAStride);
     const double2* Ca2 = reinterpret_cast<const double2*>(CR + (size_t)fa * 8);
     const double2* Cb2 = reinterpret_cast<const double2*>(CR + (size_t)fb * 8);
     double A0[6], A1[6], B0[6], B1[6], Ca[8], Cb[6];
@@ -423,7 +429,8 @@ BSG_DEV void pose_part(const double* __restrict__ Jf, int tq, int tp, const doub
   }
 }
 __global__ __launch_bounds__(256) void backsub_mcc_kernel(int n_lm, int n_lm_groups, int n_elim, int n, const int* __restrict__ lm_start,
-                                                          const double* __restrict__ J, const double2* __restrict__ r,
+                                                          const double* __restrict__ J, const double* __restrict__ JB,
+                                                          const double2* __restrict__ r,
                                                           const double* __restrict__ CR, const int* __restrict__ cam_pose,
                                                           const int* __restrict__ cp_tq, const int* __restrict__ cp_tp,
                                                           const double* __restrict__ Linv, const double* __restrict__ z, int n_pose,
@@ -442,7 +449,7 @@ __global__ __launch_bounds__(256) void backsub_mcc_kernel(int n_lm, int n_lm_gro
       const double* C = CR + (size_t)f * 8;
       const int cp = cam_pose[f];
       double j0, j1;
-      pose_part(J + (size_t)f * 18, cp_tq[cp], cp_tp[cp], y_pose, j0, j1);
+      pose_part(J + (size_t)f * kJAStride, cp_tq[cp], cp_tp[cp], y_pose, j0, j1);
       a0 += C[0] * j0 + C[3] * j1; a1 += C[1] * j0 + C[4] * j1; a2 += C[2] * j0 + C[5] * j1;
     }
 #pragma unroll
@@ -456,11 +463,12 @@ __global__ __launch_bounds__(256) void backsub_mcc_kernel(int n_lm, int n_lm_gro
       const double y2 = Li[5] * w2;
       if (sub == 0) { const int to = n_pose + 3 * l; delta[to] = -y0; delta[to + 1] = -y1; delta[to + 2] = -y2; }
       for (int f = beg + sub; f < end; f += 8) {
-        const double* Jf = J + (size_t)f * 18;
+        const double* Jf = J + (size_t)f * kJAStride;
+        const double* Bf = JB + (size_t)f * 6;
         const int cp = cam_pose[f];
         double j0, j1;
         pose_part(Jf, cp_tq[cp], cp_tp[cp], y_pose, j0, j1);
-        const double d0 = -(j0 + Jf[12] * y0 + Jf[13] * y1 + Jf[14] * y2), d1 = -(j1 + Jf[15] * y0 + Jf[16] * y1 + Jf[17] * y2);
+        const double d0 = -(j0 + Bf[0] * y0 + Bf[1] * y1 + Bf[2] * y2), d1 = -(j1 + Bf[3] * y0 + Bf[4] * y1 + Bf[5] * y2);
         const double2 rf = r[f];
         acc -= d0 * (rf.x + 0.5 * d0) + d1 * (rf.y + 0.5 * d1);
       }
@@ -470,7 +478,7 @@ __global__ __launch_bounds__(256) void backsub_mcc_kernel(int n_lm, int n_lm_gro
     if (f < n) {
       const int cp = cam_pose[f];
       double j0, j1;
-      pose_part(J + (size_t)f * 18, cp_tq[cp], cp_tp[cp], y_pose, j0, j1);
+      pose_part(J + (size_t)f * kJAStride, cp_tq[cp], cp_tp[cp], y_pose, j0, j1);
       const double2 rf = r[f];
       acc = -((-j0) * (rf.x - 0.5 * j0) + (-j1) * (rf.y - 0.5 * j1));
     }
@@ -483,7 +491,7 @@ int backsub_mcc_groups(const Visual& v) { return (v.n_lm * 8 + 255) / 256 + (v.n
 void launch_backsub_mcc(hipStream_t s, const Visual& v, int n_pose, const double* y_pose, double* delta, double* mcc_part) {
   const int g_lm = (v.n_lm * 8 + 255) / 256, grid = backsub_mcc_groups(v);
   if (grid == 0) return;
-  hipLaunchKernelGGL(backsub_mcc_kernel, dim3(grid), dim3(256), 0, s, v.n_lm, g_lm, v.n_elim, v.n, v.lm_start, v.J, v.r, v.CR, v.cam_pose,
+  hipLaunchKernelGGL(backsub_mcc_kernel, dim3(grid), dim3(256), 0, s, v.n_lm, g_lm, v.n_elim, v.n, v.lm_start, v.J, v.JB, v.r, v.CR, v.cam_pose,
                      v.cp_tq, v.cp_tp, v.Linv, v.z, n_pose, y_pose, delta, mcc_part);
 }
 
