@@ -10,6 +10,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 
 namespace bsg {
@@ -96,6 +97,7 @@ struct DensePlan {
         w = dist[std::min(dist.size() - 1, (size_t)(0.95 * (double)dist.size()))];
       }
     }
+    if (const char* ew = getenv("BSGPU_BAND_W")) w = std::max(1, atoi(ew));   // (experiments: separator width in tiles)
     std::vector<int> order;  // S order: list of natural tiles
     std::vector<std::pair<int, int>> piece_ranges;                    // S tile ranges of the pieces
     std::vector<std::vector<std::pair<int, int>>> sep_ranges_by_level;  // S tile ranges of the separators, per level
