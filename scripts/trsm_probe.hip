@@ -15,8 +15,26 @@ __global__ __launch_bounds__(256) void probe(const double* A, const double* L, d
   potrf64_lds(sC, sV, sInvD, tid, 64);
   for (int i = tid; i < NB * NB; i += 256) { const int r = i >> 6, c = i & 63; sL[r * LDT + c] = sC[r * LDT + c]; }
   __syncthreads();
+  long long tw0 = 0, tw1 = 0;
+  if (variant == 2) {
+    __syncthreads();
+    tw0 = wall_clock64();
+    tile_inverse_w(sL, sV, sC, lane, wave);
+    __syncthreads();
+    tw1 = wall_clock64();
+    if (tid == 0) ts[2] = tw1 - tw0;
+  }
   long long t0 = wall_clock64();
-  if (variant == 0) trsm_tile(sX, sL, sV, sT, lane, wave); else trsm_tile_t(sX, sL, sV, lane, wave);
+  if (variant == 0) trsm_tile(sX, sL, sV, sT, lane, wave);
+  else if (variant == 1) trsm_tile_t(sX, sL, sV, lane, wave);
+  else {
+    double4_t y[4];
+    trsm_gemm_w(sX, sC, lane, wave, y);
+    const int n = lane & 15, q = lane >> 4;
+    double* rows = sX + (16 * wave) * LDT;
+    __builtin_amdgcn_wave_barrier();
+    for (int b = 0; b < 4; ++b) for (int reg = 0; reg < 4; ++reg) rows[n * LDT + 16 * b + q + 4 * reg] = y[b][reg];
+  }
   __syncthreads();
   long long t1 = wall_clock64();
   double4_t acc[4];
@@ -38,12 +56,13 @@ int main() {
   hipMemcpy(dA, A.data(), 8 * n * n, hipMemcpyHostToDevice); hipMemcpy(dL, L.data(), 8 * n * n, hipMemcpyHostToDevice);
   const size_t lds = sizeof(double) * (3 * 64 * 66 + 1024 + 4 * 16 * 17 + 64 + 64 * 66);
   hipFuncSetAttribute(reinterpret_cast<const void*>(bsg::probe), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  for (int variant = 0; variant < 2; ++variant)
+  for (int variant = 0; variant < 3; ++variant)
     for (int rep = 0; rep < 3; ++rep) {
       hipLaunchKernelGGL(bsg::probe, dim3(1), dim3(256), lds, 0, dA, dL, dX, ts, variant);
       hipDeviceSynchronize();
-      long long h[2]; hipMemcpy(h, ts, 16, hipMemcpyDeviceToHost);
-      hipMemcpy(variant ? X1.data() : X0.data(), dX, 8 * n * n, hipMemcpyDeviceToHost);
+      long long h[3]; hipMemcpy(h, ts, 24, hipMemcpyDeviceToHost);
+      if (variant == 2) printf("   tile_inverse_w %lld ticks\n", h[2]);
+      hipMemcpy(variant == 0 ? X0.data() : X1.data(), dX, 8 * n * n, hipMemcpyDeviceToHost);
       printf("variant %d rep %d: trsm %lld ticks (10 ns)  update %lld ticks\n", variant, rep, h[0], h[1]);
     }
   double md = 0; for (int i = 0; i < n * n; ++i) md = fmax(md, fabs(X0[i] - X1[i]));
