@@ -291,67 +291,6 @@ BSG_DEV void trsm_tile_t(double* sA, const double* sL, const double* sV, int lan
     for (int reg = 0; reg < 4; ++reg) rows[n * LDT + 16 * b + q + 4 * reg] = acc[b][reg];
 }
 
-// W = L^-1 of a factored 64x64 tile (full lower-triangular inverse, 16x16 blocks) from L (sL) and the inverses of its diagonal blocks
-// (sV), into sW (pitch LDT; blocks above the diagonal are not written).  With W a panel's triangular solves become plain products
-// X = A W^T whose four accumulator chains are independent (trsm_gemm_w): 1.6 us per tile against 3.0 / 3.3 for the substitution
-// forms (scripts/trsm_probe.hip).  Wave j builds block column j top-down — W_jj = V_j, W_ij = -V_i sum_{k=j..i-1} L_ik W_kj — out of its
-// own registers: the MFMA result layout of W_kj is the B-operand layout of the next product.  Wave 3 only copies V_3.
-BSG_DEV void tile_inverse_w(const double* sL, const double* sV, double* sW, int lane, int wave) {
-  const int n = lane & 15, q = lane >> 4, j = wave;
-  double4_t w[4];   // W_kj for k = j .. 3 (index k), result layout: w[k][reg] = W_kj[q + 4 reg][n]
-#pragma unroll
-  for (int reg = 0; reg < 4; ++reg) w[0][reg] = 0.0;
-  // W_jj = V_j
-  double4_t wjj;
-#pragma unroll
-  for (int reg = 0; reg < 4; ++reg) wjj[reg] = sV[j * 256 + (q + 4 * reg) * 16 + n];
-#pragma unroll
-  for (int jj = 0; jj < 4; ++jj) if (jj == j) w[jj] = wjj;
-#pragma unroll
-  for (int i = 1; i < 4; ++i) {
-    if (i <= j) continue;   // (wave-uniform)
-    double4_t t = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (k < j || k >= i) continue;
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
-        t = __builtin_amdgcn_mfma_f64_16x16x4f64(sL[(16 * i + n) * LDT + 16 * k + 4 * kk + q], w[k][kk], t, 0, 0, 0);
-    }
-    double4_t r = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) r = __builtin_amdgcn_mfma_f64_16x16x4f64(-sV[i * 256 + n * 16 + 4 * kk + q], t[kk], r, 0, 0, 0);
-    w[i] = r;
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (i < j) continue;
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) sW[(16 * i + q + 4 * reg) * LDT + 16 * j + n] = w[i][reg];
-  }
-}
-// X strip = A strip W^T: Y_b = X_b^T = sum_{c<=b} W_bc A_c^T — four independent accumulator chains, B operands (A^T) from registers,
-// A operands (W) from LDS.  y[b][reg] = X[row n of the strip][16 b + q + 4 reg]: exactly the A-operand layout of the rank-64 update
-// (K slice 4 b + reg), so the solved strip feeds C -= X_i X_j^T without touching LDS.
-BSG_DEV void trsm_gemm_w(const double* sA, const double* sW, int lane, int wave, double4_t (&y)[4]) {
-  const double* rows = sA + (16 * wave) * LDT;
-  const int n = lane & 15, q = lane >> 4;
-  double4_t at[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) at[c][reg] = rows[n * LDT + 16 * c + q + 4 * reg];   // A_c^T in B-operand layout (K slice reg)
-#pragma unroll
-  for (int b = 0; b < 4; ++b) y[b] = double4_t{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-      for (int b = c; b < 4; ++b)
-        y[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(sW[(16 * b + n) * LDT + 16 * c + 4 * kk + q], at[c][kk], y[b], 0, 0, 0);
-}
-
 // descriptors of the (few) panels of one step and their row-tile lists, passed BY VALUE: they arrive with the kernel
 // arguments instead of costing two dependent round trips to memory before the first tile load can be issued
 constexpr int kStepMaxPanels = 16, kStepMaxRows = 16;
