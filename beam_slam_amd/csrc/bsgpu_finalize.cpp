@@ -606,8 +606,19 @@ int build_bsr(bsgpu_ctx* c) {
     c->d_slots[t] = c->upload(slots);
   }
   c->nbr = nbr; c->nblk = nblk;
+  // the preconditioner pairs consecutive block rows (2m, 2m+1) — position and orientation of one pose in the pose-graph layouts —
+  // into 6x6 diagonal blocks: slot of the coupling block (2m, 2m+1), -1 if the two rows are not coupled (or 2m+1 does not exist)
+  const int npair = (nbr + 1) / 2;
+  std::vector<int> pair_slot(npair, -1);
+  for (int m = 0; m < npair; ++m) {
+    if (2 * m + 1 >= nbr) continue;
+    const uint64_t key = ((uint64_t)(2 * m) << 32) | (uint32_t)(2 * m + 1);
+    auto it = std::lower_bound(keys.begin(), keys.end(), key);
+    if (it != keys.end() && *it == key) pair_slot[m] = (int)(it - keys.begin());
+  }
   c->d_row_ptr = c->upload(row_ptr); c->d_col = c->upload(col); c->d_diag_slot = c->upload(diag_slot);
-  c->d_val = c->alloc<double>((size_t)nblk * 9); c->d_Minv = c->alloc<double>((size_t)nbr * 9);
+  c->d_pair_slot = c->upload(pair_slot);
+  c->d_val = c->alloc<double>((size_t)nblk * 9); c->d_Minv = c->alloc<double>((size_t)npair * 36);
   c->d_rhs = c->alloc<double>(c->n_pose);
   c->d_px = c->alloc<double>(c->n_pose); c->d_pr = c->alloc<double>(c->n_pose); c->d_pz = c->alloc<double>(c->n_pose);
   c->d_pp = c->alloc<double>(c->n_pose); c->d_pp1 = c->alloc<double>(c->n_pose); c->d_pq = c->alloc<double>(c->n_pose);

@@ -197,7 +197,7 @@ void chol_prepare();  // one-time function attributes (kept out of captured sequ
 // block-sparse PCG path (k_pcg.hip)
 void launch_bsr_assemble(hipStream_t s, const SmallGroup& g, const int* slots, double* val, double* rhs, double* grad,
                          double* hdiag);
-void launch_bsr_finish_diag(hipStream_t s, int nbr, const int* diag_slot, double* val, const double* hdiag, double radius,
+void launch_bsr_finish_diag(hipStream_t s, int nbr, const int* diag_slot, const int* pair_slot, double* val, const double* hdiag, double radius,
                             int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* scale,
                             double* dcl, double* Minv);
 int pcg_spmv_grid(int nbr);   // workgroups (= p.q partials) of one SpMV launch

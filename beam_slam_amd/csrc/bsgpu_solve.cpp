@@ -13,7 +13,7 @@ void assemble_pcg(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_
   launch_zero(s, c->d_hdiag, c->n_pose);
   for (int t = 2; t < kNumInternal; ++t)
     launch_bsr_assemble(s, c->small[t], c->d_slots[t], c->d_val, c->d_rhs, c->d_grad, c->d_hdiag);
-  launch_bsr_finish_diag(s, c->nbr, c->d_diag_slot, c->d_val, c->d_hdiag, radius, first ? 1 : 0, new_J ? 1 : 0, o.jacobi_scaling,
+  launch_bsr_finish_diag(s, c->nbr, c->d_diag_slot, c->d_pair_slot, c->d_val, c->d_hdiag, radius, first ? 1 : 0, new_J ? 1 : 0, o.jacobi_scaling,
                          o.min_lm_diagonal, o.max_lm_diagonal, c->d_scale, c->d_dcl, c->d_Minv);
   if (new_J) {
     launch_grad_norms(s, c->nb, c->d_blk_xoff, c->d_blk_toff, c->d_blk_size, c->d_blk_manifold, c->d_x, c->d_grad, c->d_scal);

@@ -7,7 +7,8 @@
 // final-cost tolerance.  Every tangent block of the pose-only factor types has size 3, hence 3x3 blocks.
 //
 //   bsr_assemble        wave / factor: J^T J blocks -> atomics into the BSR values (slots precomputed)
-//   bsr_finish_diag     LM diagonal (Jacobi scaling folded in, as in the dense path) + 3x3 block inverses
+//   bsr_finish_diag     LM diagonal (Jacobi scaling folded in, as in the dense path) + inverses of the 6x6 diagonal blocks of
+//                       consecutive block-row pairs (position + orientation of a pose)
 //   pcg_spmv            beta, stop test and p = z + beta p folded in; q = A p (one wave / block row), partials of p.q
 //   pcg_update          alpha from the partials; x += a p; r -= a q; z = M^-1 r; partials of r.z, r.r
 // HBM-bound: one PCG iteration streams the BSR values once (C4: 30 MB) plus six n-vectors.
@@ -57,16 +58,12 @@ void launch_bsr_assemble(hipStream_t s, const SmallGroup& g, const int* slots, d
   hipLaunchKernelGGL(bsr_assemble_kernel, dim3(g.n), dim3(64), 0, s, g, slots, val, rhs, grad, hdiag);
 }
 
-// per block row: scale / clamped LM diagonal (same algebra as pose_diag_kernel), add lambda to the diagonal
-// block, invert it for the block-Jacobi preconditioner
-__global__ __launch_bounds__(256) void bsr_finish_diag_kernel(int nbr, const int* __restrict__ diag_slot, double* __restrict__ val,
-                                                              const double* __restrict__ hdiag, double inv_radius,
-                                                              int compute_scale, int compute_dcl, int jacobi, double lm_lo,
-                                                              double lm_hi, double* __restrict__ scale, double* __restrict__ dcl,
-                                                              double* __restrict__ Minv) {
-  const int br = blockIdx.x * 256 + threadIdx.x;
-  if (br >= nbr) return;
-  double* D = val + (size_t)diag_slot[br] * 9;
+// per PAIR of block rows (2m, 2m+1): scale / clamped LM diagonal (same algebra as pose_diag_kernel), lambda added to the two
+// diagonal blocks, and the inverse of the 6x6 block [[D_a, B], [B^T, D_b]] for the block-Jacobi preconditioner (B = the coupling
+// block of the two rows — position and orientation of one pose in a pose graph; 0 when the rows are not coupled, which leaves two
+// 3x3 inverses).  3x3 blocks alone took ~315 iterations per LM step on the 5 000-pose graph (profiles/r02_c4_kernel_stats.csv).
+BSG_DEV void lm_diag_block(int br, double* __restrict__ D, const double* __restrict__ hdiag, double inv_radius, int compute_scale,
+                           int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* __restrict__ scale, double* __restrict__ dcl) {
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int j = 3 * br + i;
@@ -77,19 +74,108 @@ __global__ __launch_bounds__(256) void bsr_finish_diag_kernel(int nbr, const int
     if (compute_dcl) dcl[j] = d;
     D[4 * i] += d * inv_radius;
   }
-  const double a = D[0], b = D[1], c = D[2], d = D[4], e = D[5], f = D[8];
-  const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
-  const double id = 1.0 / (a * c00 + b * c01 + c * c02);
-  double* M = Minv + (size_t)br * 9;
-  M[0] = c00 * id; M[1] = c01 * id; M[2] = c02 * id;
-  M[3] = M[1]; M[4] = (a * f - c * c) * id; M[5] = (b * c - a * e) * id;
-  M[6] = M[2]; M[7] = M[5]; M[8] = (a * d - b * b) * id;
 }
-void launch_bsr_finish_diag(hipStream_t s, int nbr, const int* diag_slot, double* val, const double* hdiag, double radius,
+__global__ __launch_bounds__(256) void bsr_finish_diag_kernel(int nbr, const int* __restrict__ diag_slot, const int* __restrict__ pair_slot,
+                                                              double* __restrict__ val, const double* __restrict__ hdiag, double inv_radius,
+                                                              int compute_scale, int compute_dcl, int jacobi, double lm_lo,
+                                                              double lm_hi, double* __restrict__ scale, double* __restrict__ dcl,
+                                                              double* __restrict__ Minv) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  const int npair = (nbr + 1) / 2;
+  if (m >= npair) return;
+  const int ra = 2 * m, rb = 2 * m + 1;
+  const bool has_b = rb < nbr;
+  double* Da = val + (size_t)diag_slot[ra] * 9;
+  lm_diag_block(ra, Da, hdiag, inv_radius, compute_scale, compute_dcl, jacobi, lm_lo, lm_hi, scale, dcl);
+  double A[36];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) A[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) A[i * 6 + j] = Da[i * 3 + j];
+  if (has_b) {
+    double* Db = val + (size_t)diag_slot[rb] * 9;
+    lm_diag_block(rb, Db, hdiag, inv_radius, compute_scale, compute_dcl, jacobi, lm_lo, lm_hi, scale, dcl);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) A[(3 + i) * 6 + 3 + j] = Db[i * 3 + j];
+    const int ps = pair_slot[m];
+    if (ps >= 0) {
+      const double* B = val + (size_t)ps * 9;   // block (2m, 2m+1)
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { A[i * 6 + 3 + j] = B[i * 3 + j]; A[(3 + j) * 6 + i] = B[i * 3 + j]; }
+    }
+  } else {
+#pragma unroll
+    for (int i = 3; i < 6; ++i) A[i * 6 + i] = 1.0;
+  }
+  // 6x6 SPD inverse: Cholesky A = L L^T, W = L^-1, A^-1 = W^T W
+  double L[36];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) L[i] = 0.0;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double d = A[j * 6 + j];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) if (k < j) d -= L[j * 6 + k] * L[j * 6 + k];
+    const double ljj = sqrt(d), inv = 1.0 / ljj;
+    L[j * 6 + j] = ljj;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      if (i <= j) continue;
+      double v = A[i * 6 + j];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) if (k < j) v -= L[i * 6 + k] * L[j * 6 + k];
+      L[i * 6 + j] = v * inv;
+    }
+  }
+  double W[36];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) W[i] = 0.0;
+#pragma unroll
+  for (int cix = 0; cix < 6; ++cix) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      if (i < cix) continue;
+      double v = (i == cix) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) if (k >= cix && k < i) v -= L[i * 6 + k] * W[k * 6 + cix];
+      W[i * 6 + cix] = v / L[i * 6 + i];
+    }
+  }
+  double* M = Minv + (size_t)m * 36;
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      double v = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) if (k >= i && k >= j) v += W[k * 6 + i] * W[k * 6 + j];
+      M[i * 6 + j] = v;
+    }
+}
+void launch_bsr_finish_diag(hipStream_t s, int nbr, const int* diag_slot, const int* pair_slot, double* val, const double* hdiag, double radius,
                             int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* scale,
                             double* dcl, double* Minv) {
-  hipLaunchKernelGGL(bsr_finish_diag_kernel, dim3((nbr + 255) / 256), dim3(256), 0, s, nbr, diag_slot, val, hdiag, 1.0 / radius,
+  const int npair = (nbr + 1) / 2;
+  hipLaunchKernelGGL(bsr_finish_diag_kernel, dim3((npair + 255) / 256), dim3(256), 0, s, nbr, diag_slot, pair_slot, val, hdiag, 1.0 / radius,
                      compute_scale, compute_dcl, jacobi, lm_lo, lm_hi, scale, dcl, Minv);
+}
+
+// z = M^-1 r for the pair of block rows (2m, 2m+1) (rows >= nbr do not exist: their r is taken as 0 and nothing is written)
+BSG_DEV void precond_pair(const double* __restrict__ Minv, int m, const double rv[6], double zv[6]) {
+  const double* M = Minv + (size_t)m * 36;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double v = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) v += M[i * 6 + j] * rv[j];
+    zv[i] = v;
+  }
 }
 
 // One PCG iteration is TWO launches (a third of the time of an iteration is otherwise the ~5 us dependency latency of
@@ -125,22 +211,27 @@ BSG_DEV PcgTotals pcg_totals(const double* __restrict__ part, int n_part, double
   return t;
 }
 
-// x = 0, r = b, z = M^-1 r, both p buffers = 0 (p_0 = z_0 + 0 * p_{-1}); partials of r.z, r.r for iteration 0
+// x = 0, r = b, z = M^-1 r, both p buffers = 0 (p_0 = z_0 + 0 * p_{-1}); partials of r.z, r.r for iteration 0.  One thread per
+// pair of block rows (the preconditioner's 6x6 blocks).
 __global__ __launch_bounds__(256) void pcg_init_kernel(int nbr, const double* __restrict__ b, const double* __restrict__ Minv,
                                                        double* __restrict__ x, double* __restrict__ r, double* __restrict__ z,
                                                        double* __restrict__ p0, double* __restrict__ p1, double* __restrict__ part) {
   __shared__ double sred[4];
-  const int br = blockIdx.x * 256 + threadIdx.x;
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  const int n = 3 * nbr;
   double rz = 0.0, rr = 0.0;
-  if (br < nbr) {
-    const double r0 = b[3 * br], r1 = b[3 * br + 1], r2 = b[3 * br + 2];
-    const double* M = Minv + (size_t)br * 9;
-    const double z0 = M[0] * r0 + M[1] * r1 + M[2] * r2, z1 = M[3] * r0 + M[4] * r1 + M[5] * r2, z2 = M[6] * r0 + M[7] * r1 + M[8] * r2;
+  if (2 * m < nbr) {
+    double rv[6], zv[6];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { x[3 * br + i] = 0; p0[3 * br + i] = 0; p1[3 * br + i] = 0; }
-    r[3 * br] = r0; r[3 * br + 1] = r1; r[3 * br + 2] = r2;
-    z[3 * br] = z0; z[3 * br + 1] = z1; z[3 * br + 2] = z2;
-    rz = r0 * z0 + r1 * z1 + r2 * z2; rr = r0 * r0 + r1 * r1 + r2 * r2;
+    for (int i = 0; i < 6; ++i) rv[i] = (6 * m + i < n) ? b[6 * m + i] : 0.0;
+    precond_pair(Minv, m, rv, zv);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      if (6 * m + i >= n) continue;
+      x[6 * m + i] = 0; p0[6 * m + i] = 0; p1[6 * m + i] = 0;
+      r[6 * m + i] = rv[i]; z[6 * m + i] = zv[i];
+      rz += rv[i] * zv[i]; rr += rv[i] * rv[i];
+    }
   }
   const double a = block_sum_256(rz, sred), c = block_sum_256(rr, sred);
   if (threadIdx.x == 0) { part[2 * blockIdx.x] = a; part[2 * blockIdx.x + 1] = c; }
@@ -211,16 +302,24 @@ __global__ __launch_bounds__(256) void pcg_update_kernel(int nbr, const double* 
   __syncthreads();
   if (sc[PC_DONE] != 0.0) return;   // (uniform; the partials of the stopping iteration stay as they are)
   const double alpha = s_alpha;
-  const int br = blockIdx.x * 256 + threadIdx.x;
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  const int n = 3 * nbr;
   double rz = 0.0, rr = 0.0;
-  if (br < nbr) {
-    double rv[3];
+  if (2 * m < nbr) {
+    double rv[6], zv[6];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { x[3 * br + i] += alpha * p[3 * br + i]; rv[i] = r[3 * br + i] - alpha * q[3 * br + i]; r[3 * br + i] = rv[i]; }
-    const double* M = Minv + (size_t)br * 9;
-    const double z0 = M[0] * rv[0] + M[1] * rv[1] + M[2] * rv[2], z1 = M[3] * rv[0] + M[4] * rv[1] + M[5] * rv[2], z2 = M[6] * rv[0] + M[7] * rv[1] + M[8] * rv[2];
-    z[3 * br] = z0; z[3 * br + 1] = z1; z[3 * br + 2] = z2;
-    rz = rv[0] * z0 + rv[1] * z1 + rv[2] * z2; rr = rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2];
+    for (int i = 0; i < 6; ++i) {
+      const int j = 6 * m + i;
+      if (j < n) { x[j] += alpha * p[j]; rv[i] = r[j] - alpha * q[j]; r[j] = rv[i]; } else rv[i] = 0.0;
+    }
+    precond_pair(Minv, m, rv, zv);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int j = 6 * m + i;
+      if (j >= n) continue;
+      z[j] = zv[i];
+      rz += rv[i] * zv[i]; rr += rv[i] * rv[i];
+    }
   }
   const double t1 = block_sum_256(rz, sred), t2 = block_sum_256(rr, sred);
   if (threadIdx.x == 0) { part_next[2 * blockIdx.x] = t1; part_next[2 * blockIdx.x + 1] = t2; }
@@ -229,7 +328,7 @@ __global__ __launch_bounds__(256) void pcg_update_kernel(int nbr, const double* 
 int pcg_spmv_grid(int nbr);
 void launch_pcg_init(hipStream_t s, int nbr, const double* b, const double* Minv, double* x, double* r, double* z, double* p0, double* p1,
                      double* part, double* sc) {
-  const int grid = (nbr + 255) / 256;
+  const int grid = ((nbr + 1) / 2 + 255) / 256;
   hipLaunchKernelGGL(pcg_init_kernel, dim3(grid), dim3(256), 0, s, nbr, b, Minv, x, r, z, p0, p1, part);
   hipLaunchKernelGGL(pcg_init_scalars_kernel, dim3(1), dim3(256), 0, s, part, grid, sc);
 }
@@ -237,7 +336,7 @@ void launch_pcg_init(hipStream_t s, int nbr, const double* b, const double* Minv
 void launch_pcg_iteration(hipStream_t s, int k, int nbr, const int* row_ptr, const int* col, const double* val, const double* Minv,
                           double* x, double* r, double* z, double* p0, double* p1, double* q, double* part_pq, double* part, double* sc,
                           double tol2) {
-  const int g16 = pcg_spmv_grid(nbr), g1 = (nbr + 255) / 256;
+  const int g16 = pcg_spmv_grid(nbr), g1 = ((nbr + 1) / 2 + 255) / 256;
   double* p_cur = (k & 1) ? p1 : p0;
   double* p_prev = (k & 1) ? p0 : p1;
   double* part_cur = part + (size_t)(k & 1) * 2 * g1;
