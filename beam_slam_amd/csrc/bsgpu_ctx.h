@@ -118,6 +118,13 @@ struct bsgpu_ctx {
   double* d_small_part[kNumInternal] = {nullptr};       // per-factor cost at the current point
   double* d_small_part_cand[kNumInternal] = {nullptr};  // ... at the candidate
   double* d_small_part_mcc[kNumInternal] = {nullptr};   // per-row model-cost-change terms
+  // pose-only factors assembled without per-factor atomics: every 3x3 block (row block, column block) of J^T J they touch is a
+  // SEGMENT of (factor, slot a, slot b) contributions, summed by one wave in a fixed order (k_small.hip small_assemble_seg_kernel)
+  SmallGroup* d_small_groups = nullptr;   // the groups, as the kernel indexes them by internal type
+  SmallGroup small_factorwise[kNumInternal];   // the groups assembled one workgroup per factor instead (n = 0 for the others)
+  int n_sa_seg = 0;
+  int *d_sa_seg_start = nullptr, *d_sa_seg_ra = nullptr, *d_sa_seg_rb = nullptr;
+  int2* d_sa_contrib = nullptr;
   ReduceEntry* d_reduce = nullptr;
   int n_reduce = 0;
   double* d_part_upd = nullptr;

@@ -404,6 +404,55 @@ int finalize(bsgpu_ctx* c) {
     c->d_small_part_mcc[t] = c->alloc<double>((size_t)g.n * ti.m);
     part_max = std::max(part_max, (size_t)g.n * ti.m);
   }
+  // ---- how the pose-only factors are assembled.  Where many factors of a type add into the same 3x3 blocks of J^T J (C3: 20 000
+  // relative-pose factors over 100 keyframes and ONE extrinsics variable) per-factor atomics serialise on those addresses; such a type
+  // is assembled by SEGMENTS instead: for every block (tangent offsets ra, rb) the (factor, slot a, slot b) contributions to it, in
+  // (type, factor) order, cut into chunks of at most kSegChunk that sixteen lanes sum before one atomic add per entry.  A type
+  // whose blocks get only a few contributions each (an IMU chain: one or two) keeps the workgroup-per-factor kernel, which reads J once.
+  {
+    constexpr int kSegChunk = 64;
+    struct Contrib { int ra, rb, tf, ss; };
+    std::vector<Contrib> cl;
+    for (int t = 0; t < kNumInternal; ++t) { c->small_factorwise[t] = c->small[t]; if (t < 2) c->small_factorwise[t].n = 0; }
+    for (int t = 2; t < kNumInternal; ++t) {
+      const SmallGroup& sg = c->small[t];
+      if (!sg.n) continue;
+      const int nv = sg.nv;
+      std::vector<int> toffs((size_t)sg.n * nv);
+      HIPCHK(c, hipMemcpy(toffs.data(), sg.toff, sizeof(int) * toffs.size(), hipMemcpyDeviceToHost));
+      const size_t first = cl.size();
+      for (int f = 0; f < sg.n; ++f) {
+        if (!c->h_small_active[t][f]) continue;
+        for (int sa = 0; sa < nv; ++sa) for (int sb = 0; sb < nv; ++sb) {
+          const int ra = toffs[(size_t)f * nv + sa], rb = toffs[(size_t)f * nv + sb];
+          if (ra < 0 || rb < 0) continue;
+          cl.push_back({ra, rb, (t << 24) | f, (sa << 8) | sb});
+        }
+      }
+      std::vector<long long> blocks;
+      blocks.reserve(cl.size() - first);
+      for (size_t i = first; i < cl.size(); ++i) blocks.push_back((long long)cl[i].ra << 32 | (unsigned)cl[i].rb);
+      std::sort(blocks.begin(), blocks.end());
+      const size_t n_blocks = std::unique(blocks.begin(), blocks.end()) - blocks.begin();
+      if (n_blocks && (cl.size() - first) >= 4 * n_blocks) c->small_factorwise[t].n = 0;   // by segments
+      else cl.resize(first);                                                                // by factors
+    }
+    std::stable_sort(cl.begin(), cl.end(), [](const Contrib& a, const Contrib& b) { return a.ra != b.ra ? a.ra < b.ra : a.rb < b.rb; });
+    std::vector<int> seg_start, seg_ra, seg_rb;
+    std::vector<int2> contrib(cl.size());
+    for (size_t i = 0; i < cl.size(); ++i) {
+      if (i == 0 || cl[i].ra != cl[i - 1].ra || cl[i].rb != cl[i - 1].rb || (int)i - seg_start.back() >= kSegChunk) {
+        seg_start.push_back((int)i); seg_ra.push_back(cl[i].ra); seg_rb.push_back(cl[i].rb);
+      }
+      contrib[i] = make_int2(cl[i].tf, cl[i].ss);
+    }
+    seg_start.push_back((int)cl.size());
+    c->n_sa_seg = (int)seg_ra.size();
+    c->d_sa_seg_start = c->upload(seg_start); c->d_sa_seg_ra = c->upload(seg_ra); c->d_sa_seg_rb = c->upload(seg_rb);
+    c->d_sa_contrib = c->upload(contrib);
+    std::vector<SmallGroup> groups(c->small, c->small + kNumInternal);
+    c->d_small_groups = c->upload(groups);
+  }
   // ---- dense linear priors (marginal factors)
   c->marg.clear();
   {

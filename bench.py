@@ -120,6 +120,9 @@ def main():
         # (bsgpu_profile_step); the kernel-trace average of the same kernels is in profiles/r02_*_kernel_stats.csv
         has_vis = pr.n_factors(0) > 0
         roofline = roofline_mfma = kernels = phases = None
+        if args.workload == "c3":          # no visual factors: phases and the factorisation's figure only
+            prof = g.profile_step(opt, reps=20)
+            phases = {k: round(1e3 * v[0], 2) for k, v in prof.items()}
         if has_vis and not (args.workload == "c4"):
             prof = g.profile_step(opt, reps=20)
             phases = {k: round(1e3 * v[0], 2) for k, v in prof.items()}          # microseconds per LM step
@@ -191,6 +194,8 @@ def main():
                        "parallelism": "1 window per GPU, no collective" if world > 1 else "single GPU"},
             "roofline": roofline,
         }
+        if phases and not roofline_mfma:
+            out["phases_us_per_lm_step"] = phases
         if roofline_mfma:
             out["roofline_mfma"] = roofline_mfma
             out["kernels"] = kernels
