@@ -28,7 +28,7 @@ F_IDP_REPROJ = 10
 F_IDP_REPROJ_UNARY = 11
 F_NUM_TYPES = 12
 
-LINEAR_AUTO, LINEAR_SCHUR_CHOLESKY, LINEAR_PCG = 0, 1, 2
+LINEAR_AUTO, LINEAR_SCHUR_CHOLESKY, LINEAR_PCG, LINEAR_SCHUR_PCG = 0, 1, 2, 3
 CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
 
 

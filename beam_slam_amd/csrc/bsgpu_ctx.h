@@ -158,6 +158,13 @@ struct bsgpu_ctx {
   bool ev_reduce_pending = false;
   // block-sparse PCG path
   bool dense_ok = true, bsr_built = false, use_pcg = false;
+  // PCG on the assembled reduced camera system (BSGPU_LINEAR_SCHUR_PCG): tile rows of S in CSR form, inverses of the diagonal tiles,
+  // the CG vectors in solver order (built on first use, build_spcg())
+  bool use_spcg = false, spcg_built = false;
+  int n_schunks = 0;
+  int *d_schunk_row = nullptr, *d_schunk_ptr = nullptr, *d_srow_chunk_ptr = nullptr, *d_tcol = nullptr;
+  double *d_sMinv = nullptr, *d_sx = nullptr, *d_sr = nullptr, *d_sz = nullptr, *d_sp0 = nullptr, *d_sp1 = nullptr, *d_sq = nullptr,
+         *d_spart_pq = nullptr, *d_spart = nullptr, *d_ssc = nullptr;
   // in-situ phase timing (bsgpu_profile_step): when non-null, the step records one of these events at every phase boundary
   hipEvent_t* prof_events = nullptr;
   bool spec_J = false;   // residuals + Jacobians currently hold the CANDIDATE's (evaluated ahead of the accept/reject decision)
@@ -203,7 +210,7 @@ struct bsgpu_ctx {
     vis = Visual();
     for (auto& g : small) g = SmallGroup();
     d_x = d_xcand = d_x0 = nullptr;
-    bsr_built = false;
+    bsr_built = false; spcg_built = false;
     destroy_graphs();
   }
   void destroy_graphs() {
@@ -226,6 +233,7 @@ int api_exception(bsgpu_ctx* c) noexcept;   // bsgpu_api.cpp: where every entry 
 // bsgpu_finalize.cpp
 int finalize(bsgpu_ctx* c);
 int build_bsr(bsgpu_ctx* c);
+int build_spcg(bsgpu_ctx* c);
 // bsgpu_solve.cpp
 int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum);
 void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot);

@@ -678,4 +678,37 @@ int build_bsr(bsgpu_ctx* c) {
   return BSGPU_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// PCG on the reduced camera system: the tile rows of S (what the assembly writes, without the rhs row / column), built on first use
+// ---------------------------------------------------------------------------------------------------
+int build_spcg(bsgpu_ctx* c) {
+  if (c->spcg_built) return BSGPU_OK;
+  if (!c->dense_ok || !c->d_S) return fail(c, BSGPU_ERR_UNSUPPORTED, "BSGPU_LINEAR_SCHUR_PCG works on the assembled reduced camera system: the window exceeds its limit");
+  const int T = c->plan.T, N = T + 1;
+  std::vector<int> row_ptr(T + 1, 0), col;
+  for (int t : c->plan.touched_tiles) { const int i = t / N, j = t % N; if (i < T && j < T) row_ptr[i + 1]++; }
+  for (int i = 0; i < T; ++i) row_ptr[i + 1] += row_ptr[i];
+  col.resize(row_ptr[T]);
+  std::vector<int> pos(row_ptr.begin(), row_ptr.end() - 1);
+  for (int t : c->plan.touched_tiles) { const int i = t / N, j = t % N; if (i < T && j < T) col[pos[i]++] = j; }
+  // chunks of at most spcg_chunk_tiles() tiles of one row: one workgroup of the matrix-vector product each
+  std::vector<int> chunk_row, chunk_ptr, row_chunk_ptr(T + 1, 0);
+  for (int i = 0; i < T; ++i) {
+    for (int e = row_ptr[i]; e < row_ptr[i + 1]; e += spcg_chunk_tiles()) { chunk_row.push_back(i); chunk_ptr.push_back(e); }
+    row_chunk_ptr[i + 1] = (int)chunk_row.size();
+  }
+  chunk_ptr.push_back(row_ptr[T]);
+  c->n_schunks = (int)chunk_row.size();
+  c->d_schunk_row = c->upload(chunk_row); c->d_schunk_ptr = c->upload(chunk_ptr); c->d_srow_chunk_ptr = c->upload(row_chunk_ptr);
+  c->d_tcol = c->upload(col);
+  const size_t n = (size_t)T * 64;
+  c->d_sMinv = c->alloc<double>((size_t)T * 4096);
+  c->d_sx = c->alloc<double>(n); c->d_sr = c->alloc<double>(n); c->d_sz = c->alloc<double>(n); c->d_sp0 = c->alloc<double>(n);
+  c->d_sp1 = c->alloc<double>(n); c->d_sq = c->alloc<double>((size_t)c->n_schunks * 64);
+  c->d_spart_pq = c->alloc<double>((size_t)c->n_schunks + 8); c->d_spart = c->alloc<double>(4 * (size_t)T + 8); c->d_ssc = c->alloc<double>(pcg_num_scalars());
+  if (!c->d_sMinv || !c->d_sq || !c->d_ssc) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (PCG on the reduced system)");
+  c->spcg_built = true;
+  return BSGPU_OK;
+}
+
 }  // namespace bsg

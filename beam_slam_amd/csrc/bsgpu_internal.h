@@ -209,6 +209,15 @@ void launch_pcg_iteration(hipStream_t s, int k, int nbr, const int* row_ptr, con
                           double* x, double* r, double* z, double* p0, double* p1, double* q, double* part_pq, double* part, double* sc,
                           double tol2);
 int pcg_num_scalars();
+// PCG on the assembled reduced camera system (tiles of S), k_pcg.hip
+void launch_spcg_prepare(hipStream_t s, int T, const double* S, int ld, double* Minv);
+void launch_spcg_init(hipStream_t s, int T, const double* b, const double* Minv, double* x, double* r, double* z, double* p0, double* p1,
+                      double* part, double* sc);
+void launch_spcg_iteration(hipStream_t s, int k, int T, const double* S, int ld, int n_chunks, const int* chunk_row, const int* chunk_ptr,
+                           const int* row_chunk_ptr, const int* tcol, const double* Minv, double* x, double* r, double* z, double* p0,
+                           double* p1, double* qpart, double* part_pq, double* part, double* sc, double tol2);
+int spcg_chunk_tiles();
+void launch_spcg_finish(hipStream_t s, int T, const double* x, const int* iperm, int n_pose, double* y_tan, double* delta);
 int pcg_done_slot();
 int pcg_iters_slot();
 int backsub_mcc_groups(const Visual& v);   // workgroups (= model-cost partials) of launch_backsub_mcc

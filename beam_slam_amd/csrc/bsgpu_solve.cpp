@@ -77,6 +77,63 @@ void pcg_solve(bsgpu_ctx* c, const bsgpu_options& o) {
   c->pcg_iters_total += (int)last[pcg_iters_slot()];
 }
 
+// S y = rhs on the assembled reduced camera system by block-Jacobi PCG (ITERATIVE_SCHUR + SCHUR_JACOBI): same pipelined stop test
+void spcg_solve(bsgpu_ctx* c, const bsgpu_options& o) {
+  hipStream_t s = c->stream;
+  const int T = c->plan.T, ld = c->npad;
+  const double* b = c->d_S + (size_t)c->plan.rhs_row * ld;
+  launch_spcg_prepare(s, T, c->d_S, ld, c->d_sMinv);
+  launch_spcg_init(s, T, b, c->d_sMinv, c->d_sx, c->d_sr, c->d_sz, c->d_sp0, c->d_sp1, c->d_spart, c->d_ssc);
+  const double tol2 = o.pcg_tolerance * o.pcg_tolerance;
+  const int max_it = o.pcg_max_iterations > 0 ? o.pcg_max_iterations : 2000;
+  const int ns = pcg_num_scalars();
+  if (!c->h_pcg && hipHostMalloc((void**)&c->h_pcg, sizeof(double) * 2 * ns) != hipSuccess) { c->h_pcg = nullptr; (void)hipGetLastError(); }
+  for (hipEvent_t& e : c->pcg_ev)
+    if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; (void)hipGetLastError(); }
+  const bool pipelined = c->h_pcg && c->pcg_ev[0] && c->pcg_ev[1];
+  const int kChunk = 12;
+  double last[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto enqueue_chunk = [&](int it0, int n, int slot) {
+    for (int k = 0; k < n; ++k)
+      launch_spcg_iteration(s, it0 + k, T, c->d_S, ld, c->n_schunks, c->d_schunk_row, c->d_schunk_ptr, c->d_srow_chunk_ptr, c->d_tcol, c->d_sMinv,
+                            c->d_sx, c->d_sr, c->d_sz, c->d_sp0, c->d_sp1, c->d_sq, c->d_spart_pq, c->d_spart, c->d_ssc, tol2);
+    if (pipelined) {
+      (void)hipMemcpyAsync(c->h_pcg + slot * ns, c->d_ssc, sizeof(double) * ns, hipMemcpyDeviceToHost, s);
+      (void)hipEventRecord(c->pcg_ev[slot], s);
+    }
+  };
+  if (!pipelined) {
+    for (int it = 0; it < max_it;) {
+      const int chunk = std::min(20, max_it - it);
+      enqueue_chunk(it, chunk, 0);
+      it += chunk;
+      (void)hipMemcpyAsync(last, c->d_ssc, sizeof(double) * ns, hipMemcpyDeviceToHost, s);
+      (void)hipStreamSynchronize(s);
+      if (last[pcg_done_slot()] != 0.0) break;
+    }
+  } else {
+    int it = std::min(kChunk, max_it), slot = 0;
+    enqueue_chunk(0, it, slot);
+    for (;;) {
+      int next_n = std::min(kChunk, max_it - it);
+      if (next_n > 0) enqueue_chunk(it, next_n, slot ^ 1);
+      (void)hipEventSynchronize(c->pcg_ev[slot]);
+      std::memcpy(last, c->h_pcg + slot * ns, sizeof(double) * ns);
+      if (last[pcg_done_slot()] != 0.0 || next_n <= 0) {
+        if (next_n > 0) {
+          (void)hipEventSynchronize(c->pcg_ev[slot ^ 1]);
+          std::memcpy(last, c->h_pcg + (slot ^ 1) * ns, sizeof(double) * ns);
+        }
+        break;
+      }
+      it += next_n;
+      slot ^= 1;
+    }
+  }
+  c->pcg_iters_total += (int)last[pcg_iters_slot()];
+  launch_spcg_finish(s, T, c->d_sx, c->d_iperm, c->n_pose, c->d_ytan, c->d_delta);
+}
+
 // residuals (+ Jacobians) of every factor group; per-group cost partials go to the arrays the
 // end-of-step reduction sums (current point: slot SC_COST_X, candidate: SC_COST_CAND)
 void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot) {
@@ -177,6 +234,10 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
   if (c->use_pcg) {
     pcg_solve(c, o);
     launch_negate_pose(s, c->n_pose, c->d_px, c->d_delta);
+  } else if (c->use_spcg && c->n_pose > 0) {
+    spcg_solve(c, o);
+    phase_mark(c, BSGPU_PHASE_FACTOR);
+    phase_mark(c, BSGPU_PHASE_BACKSOLVE);
   } else if (c->n_pose > 0) {
     const DenseDev D{c->d_perm, c->d_nreal, c->d_rows_flat, c->d_panels, c->d_Lp, c->d_Vinv,
                      c->d_bs_desc, c->d_chain_begin, c->d_chain_end, c->d_tile_sync, c->d_ftasks, c->d_fsync};
@@ -286,7 +347,8 @@ int profile_step(bsgpu_ctx* c, const bsgpu_options& o, int reps, double* ms_out,
 }
 
 bool same_graph_options(const bsgpu_options& a, const bsgpu_options& b) {
-  return a.jacobi_scaling == b.jacobi_scaling && a.min_lm_diagonal == b.min_lm_diagonal && a.max_lm_diagonal == b.max_lm_diagonal;
+  return a.jacobi_scaling == b.jacobi_scaling && a.min_lm_diagonal == b.min_lm_diagonal && a.max_lm_diagonal == b.max_lm_diagonal &&
+         a.linear_solver_type == b.linear_solver_type;
 }
 
 void build_graphs(bsgpu_ctx* c, const bsgpu_options& o) {
@@ -294,7 +356,7 @@ void build_graphs(bsgpu_ctx* c, const bsgpu_options& o) {
   c->destroy_graphs();
   c->graphs_tried = true;
   c->graph_opts = o;
-  if (!c->use_graphs || c->use_pcg) return;   // the PCG path synchronises inside a step: stays eager
+  if (!c->use_graphs || c->use_pcg || c->use_spcg) return;   // the PCG path synchronises inside a step: stays eager
   hipGraphExec_t* execs[3] = {&c->g_first, &c->g_accept, &c->g_reject};
   for (int kind = 0; kind < 3; ++kind) {
     hipGraph_t graph = nullptr;
@@ -361,8 +423,10 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
   if (!c->use_pcg && !c->dense_ok)
     return fail(c, BSGPU_ERR_UNSUPPORTED, "reduced system above the limit of the tiled exact path (12288 pose-only, 49152 with landmarks); use BSGPU_LINEAR_AUTO or BSGPU_LINEAR_PCG");
   if (c->use_pcg) { rc = build_bsr(c); if (rc != BSGPU_OK) return rc; }
+  c->use_spcg = !c->use_pcg && o.linear_solver_type == BSGPU_LINEAR_SCHUR_PCG;
+  if (c->use_spcg) { rc = build_spcg(c); if (rc != BSGPU_OK) return rc; }
   c->pcg_iters_total = 0;
-  sum.linear_solver_used = c->use_pcg ? BSGPU_LINEAR_PCG : BSGPU_LINEAR_SCHUR_CHOLESKY;
+  sum.linear_solver_used = c->use_pcg ? BSGPU_LINEAR_PCG : c->use_spcg ? BSGPU_LINEAR_SCHUR_PCG : BSGPU_LINEAR_SCHUR_CHOLESKY;
   hipStream_t s = c->stream;
   hipEvent_t ev0, ev1;
   HIPCHK(c, hipEventCreate(&ev0)); HIPCHK(c, hipEventCreate(&ev1));

@@ -325,6 +325,176 @@ __global__ __launch_bounds__(256) void pcg_update_kernel(int nbr, const double* 
   if (threadIdx.x == 0) { part_next[2 * blockIdx.x] = t1; part_next[2 * blockIdx.x + 1] = t2; }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// PCG on the REDUCED camera system (Ceres: ITERATIVE_SCHUR with the SCHUR_JACOBI preconditioner the reference's
+// beam_slam_launch/config/optimization/ceres_config.json:11-12 names).  The operator is the assembled Schur complement itself — the
+// 64x64 tiles of S that the assembly writes (solver order, both triangles; DensePlan::touched_tiles without the rhs row/column) —
+// the preconditioner the inverses of its diagonal tiles (block-Jacobi with 64-wide blocks: about four keyframes each, a superset
+// of Ceres' per-camera blocks).  Same two-launch iteration as above; one workgroup per tile row, every sum in a fixed order.
+// ---------------------------------------------------------------------------------------------------
+// Minv[I] = S(I,I)^-1 by Gauss-Jordan in LDS (SPD + LM damping: no pivoting; padding rows are unit rows and stay so)
+__global__ __launch_bounds__(256) void spcg_tile_inverse_kernel(const double* __restrict__ S, int ld, double* __restrict__ Minv) {
+  __shared__ double a[64 * 65];
+  __shared__ double colk[64];
+  const int I = blockIdx.x, tid = threadIdx.x, r = tid >> 2, qd = tid & 3;
+  for (int i = tid; i < 4096; i += 256) a[(i >> 6) * 65 + (i & 63)] = S[(size_t)(I * 64 + (i >> 6)) * ld + I * 64 + (i & 63)];
+  __syncthreads();
+  for (int k = 0; k < 64; ++k) {
+    const double inv = 1.0 / a[k * 65 + k];
+    if (tid < 64) colk[tid] = a[tid * 65 + k];
+    __syncthreads();
+    if (r == k) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { const int cc = 16 * qd + j; a[k * 65 + cc] = (cc == k) ? inv : a[k * 65 + cc] * inv; }
+    }
+    __syncthreads();
+    if (r != k) {
+      const double f = colk[r];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { const int cc = 16 * qd + j; a[r * 65 + cc] = (cc == k) ? -f * inv : a[r * 65 + cc] - f * a[k * 65 + cc]; }
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < 4096; i += 256) Minv[(size_t)I * 4096 + i] = a[(i >> 6) * 65 + (i & 63)];
+}
+// y_r = sum_c M[r][c] v[c] for the calling workgroup's 64x64 tile M (row-major, leading dimension ldm) and the 64-vector v in LDS:
+// four lanes per row, sixteen columns each; every lane of a row's quad returns the row's sum
+BSG_DEV double tile_row_dot(const double* __restrict__ M, int ldm, const double* v) {
+  const int r = threadIdx.x >> 2, qd = threadIdx.x & 3;
+  const double4* row = reinterpret_cast<const double4*>(M + (size_t)r * ldm + 16 * qd);
+  const double4 m0 = row[0], m1 = row[1], m2 = row[2], m3 = row[3];
+  const double* w = v + 16 * qd;
+  double acc = m0.x * w[0] + m0.y * w[1] + m0.z * w[2] + m0.w * w[3];
+  acc += m1.x * w[4] + m1.y * w[5] + m1.z * w[6] + m1.w * w[7];
+  acc += m2.x * w[8] + m2.y * w[9] + m2.z * w[10] + m2.w * w[11];
+  acc += m3.x * w[12] + m3.y * w[13] + m3.z * w[14] + m3.w * w[15];
+  acc += __shfl_xor(acc, 1, 64);
+  acc += __shfl_xor(acc, 2, 64);
+  return acc;
+}
+// x = 0, r = b (the rhs row of S), z = Minv r, p buffers = 0; partials of r.z and r.r
+__global__ __launch_bounds__(256) void spcg_init_kernel(const double* __restrict__ b, const double* __restrict__ Minv, double* __restrict__ x,
+                                                        double* __restrict__ r, double* __restrict__ z, double* __restrict__ p0,
+                                                        double* __restrict__ p1, double* __restrict__ part) {
+  __shared__ double sv[64];
+  __shared__ double sred[4];
+  const int I = blockIdx.x, tid = threadIdx.x;
+  if (tid < 64) { const double v = b[I * 64 + tid]; sv[tid] = v; r[I * 64 + tid] = v; x[I * 64 + tid] = 0.0; p0[I * 64 + tid] = 0.0; p1[I * 64 + tid] = 0.0; }
+  __syncthreads();
+  const double zr = tile_row_dot(Minv + (size_t)I * 4096, 64, sv);
+  double rz = 0.0, rr = 0.0;
+  if ((tid & 3) == 0) { const double rv = sv[tid >> 2]; z[I * 64 + (tid >> 2)] = zr; rz = rv * zr; rr = rv * rv; }
+  const double t1 = block_sum_256(rz, sred), t2 = block_sum_256(rr, sred);
+  if (tid == 0) { part[2 * I] = t1; part[2 * I + 1] = t2; }
+}
+// S_k: beta_k and the stop test from the partials; one workgroup per CHUNK of up to kSpcgChunk tiles of one tile row I (a separator
+// row of a nested-dissection order has dozens of tiles: a workgroup per row would walk them one memory round trip at a time).
+// p_k = z_k + beta_k p_{k-1} is formed for the gathered tiles; the chunk's part of q_I goes to qpart[chunk] and its part of
+// p_I . q_I to part_pq[chunk] — p.q needs no complete q; the owner of the row's first chunk stores p_I.
+constexpr int kSpcgChunk = 4;
+__global__ __launch_bounds__(256) void spcg_matvec_kernel(const double* __restrict__ S, int ld, const int* __restrict__ chunk_row,
+                                                          const int* __restrict__ chunk_ptr, const int* __restrict__ tcol,
+                                                          const double* __restrict__ z, const double* __restrict__ p_prev,
+                                                          double* __restrict__ p_cur, double* __restrict__ qpart,
+                                                          const double* __restrict__ part_cur, const double* __restrict__ part_prev,
+                                                          int n_part, int first, double* __restrict__ part_pq, double* __restrict__ sc,
+                                                          double tol2) {
+  __shared__ double sp[kSpcgChunk][64];
+  __shared__ double sred[4];
+  const PcgTotals cur = pcg_totals_wave(part_cur, n_part);
+  const double rz_prev = first ? 0.0 : pcg_totals_wave(part_prev, n_part).rz;
+  const bool done = sc[PC_DONE] != 0.0 || !(cur.rr > tol2 * sc[PC_RR0]) || !(cur.rz > 0.0);
+  const double beta = (!first && rz_prev != 0.0) ? cur.rz / rz_prev : 0.0;
+  const int ch = blockIdx.x, tid = threadIdx.x;
+  if (ch == 0 && tid == 0) {
+    if (done) sc[PC_DONE] = 1.0;
+    else { sc[PC_ITERS] += 1.0; sc[PC_RZ] = cur.rz; sc[PC_RR] = cur.rr; }
+  }
+  if (done) { if (tid == 0) part_pq[ch] = 0.0; return; }
+  const int I = chunk_row[ch], e0 = chunk_ptr[ch], e1 = chunk_ptr[ch + 1];
+  {
+    const int u = tid >> 6, c = tid & 63;   // (256 threads: the four vectors at once)
+    if (e0 + u < e1) { const int J = tcol[e0 + u]; sp[u][c] = z[J * 64 + c] + beta * p_prev[J * 64 + c]; }
+  }
+  __syncthreads();
+  double acc = 0.0;
+#pragma unroll
+  for (int u = 0; u < kSpcgChunk; ++u)
+    if (e0 + u < e1) acc += tile_row_dot(S + (size_t)(I * 64) * ld + tcol[e0 + u] * 64, ld, sp[u]);
+  double pq = 0.0;
+  if ((tid & 3) == 0) {
+    const int j = I * 64 + (tid >> 2);
+    const double pv = z[j] + beta * p_prev[j];
+    if (ch == 0 || chunk_row[ch - 1] != I) p_cur[j] = pv;
+    qpart[(size_t)ch * 64 + (tid >> 2)] = acc;
+    pq = pv * acc;
+  }
+  const double t = block_sum_256(pq, sred);
+  if (tid == 0) part_pq[ch] = t;
+}
+// U_k: alpha_k from the p.q partials; q_I = the sum of the row's chunk parts (in order); x += alpha p, r -= alpha q, z = Minv r;
+// partials of r.z, r.r for iteration k + 1
+__global__ __launch_bounds__(256) void spcg_update_kernel(const double* __restrict__ part_pq, int n_chunks, const int* __restrict__ row_chunk_ptr,
+                                                          const double* __restrict__ qpart, const double* __restrict__ Minv,
+                                                          const double* __restrict__ p, double* __restrict__ x, double* __restrict__ r,
+                                                          double* __restrict__ z, double* __restrict__ part_next, const double* __restrict__ sc) {
+  __shared__ double sv[64];
+  __shared__ double sred[4];
+  __shared__ double s_alpha;
+  double a = 0;
+  for (int i = threadIdx.x; i < n_chunks; i += 256) a += part_pq[i];
+  const double pq = block_sum_256(a, sred);
+  if (threadIdx.x == 0) s_alpha = (pq > 0.0) ? sc[PC_RZ] / pq : 0.0;
+  __syncthreads();
+  if (sc[PC_DONE] != 0.0) return;
+  const double alpha = s_alpha;
+  const int I = blockIdx.x, tid = threadIdx.x;
+  if (tid < 64) {
+    const int j = I * 64 + tid;
+    double qv = 0.0;
+    for (int ch = row_chunk_ptr[I]; ch < row_chunk_ptr[I + 1]; ++ch) qv += qpart[(size_t)ch * 64 + tid];
+    x[j] += alpha * p[j];
+    const double rv = r[j] - alpha * qv;
+    r[j] = rv; sv[tid] = rv;
+  }
+  __syncthreads();
+  const double zr = tile_row_dot(Minv + (size_t)I * 4096, 64, sv);
+  double rz = 0.0, rr = 0.0;
+  if ((tid & 3) == 0) { const double rv = sv[tid >> 2]; z[I * 64 + (tid >> 2)] = zr; rz = rv * zr; rr = rv * rv; }
+  const double t1 = block_sum_256(rz, sred), t2 = block_sum_256(rr, sred);
+  if (tid == 0) { part_next[2 * I] = t1; part_next[2 * I + 1] = t2; }
+}
+// the solution (solver order) as the step in natural order: y_tan = x, delta = -x
+__global__ __launch_bounds__(64) void spcg_finish_kernel(const double* __restrict__ x, const int* __restrict__ iperm, int n_pose,
+                                                         double* __restrict__ y_tan, double* __restrict__ delta) {
+  const int j = iperm[blockIdx.x] * 64 + threadIdx.x;
+  if (j < n_pose) { const double v = x[blockIdx.x * 64 + threadIdx.x]; y_tan[j] = v; delta[j] = -v; }
+}
+void launch_spcg_prepare(hipStream_t s, int T, const double* S, int ld, double* Minv) {
+  hipLaunchKernelGGL(spcg_tile_inverse_kernel, dim3(T), dim3(256), 0, s, S, ld, Minv);
+}
+void launch_spcg_init(hipStream_t s, int T, const double* b, const double* Minv, double* x, double* r, double* z, double* p0, double* p1,
+                      double* part, double* sc) {
+  hipLaunchKernelGGL(spcg_init_kernel, dim3(T), dim3(256), 0, s, b, Minv, x, r, z, p0, p1, part);
+  hipLaunchKernelGGL(pcg_init_scalars_kernel, dim3(1), dim3(256), 0, s, part, T, sc);
+}
+// iteration k: p buffers and the two halves of `part` (2 T doubles each) alternate
+void launch_spcg_iteration(hipStream_t s, int k, int T, const double* S, int ld, int n_chunks, const int* chunk_row, const int* chunk_ptr,
+                           const int* row_chunk_ptr, const int* tcol, const double* Minv, double* x, double* r, double* z, double* p0,
+                           double* p1, double* qpart, double* part_pq, double* part, double* sc, double tol2) {
+  double* p_cur = (k & 1) ? p1 : p0;
+  double* p_prev = (k & 1) ? p0 : p1;
+  double* part_cur = part + (size_t)(k & 1) * 2 * T;
+  double* part_other = part + (size_t)((k + 1) & 1) * 2 * T;
+  hipLaunchKernelGGL(spcg_matvec_kernel, dim3(n_chunks), dim3(256), 0, s, S, ld, chunk_row, chunk_ptr, tcol, z, p_prev, p_cur, qpart, part_cur,
+                     part_other, T, k == 0 ? 1 : 0, part_pq, sc, tol2);
+  hipLaunchKernelGGL(spcg_update_kernel, dim3(T), dim3(256), 0, s, part_pq, n_chunks, row_chunk_ptr, qpart, Minv, p_cur, x, r, z, part_other, sc);
+}
+int spcg_chunk_tiles() { return kSpcgChunk; }
+void launch_spcg_finish(hipStream_t s, int T, const double* x, const int* iperm, int n_pose, double* y_tan, double* delta) {
+  hipLaunchKernelGGL(spcg_finish_kernel, dim3(T), dim3(64), 0, s, x, iperm, n_pose, y_tan, delta);
+}
+
 int pcg_spmv_grid(int nbr);
 void launch_pcg_init(hipStream_t s, int nbr, const double* b, const double* Minv, double* x, double* r, double* z, double* p0, double* p1,
                      double* part, double* sc) {

@@ -160,8 +160,13 @@ enum {
   BSGPU_LINEAR_SCHUR_CHOLESKY = 1, /* landmark Schur complement + dense FP64
                                       Cholesky of the reduced system: the exact
                                       (SPARSE_NORMAL_CHOLESKY-equivalent) step   */
-  BSGPU_LINEAR_PCG = 2           /* block-Jacobi PCG on the block-sparse normal
+  BSGPU_LINEAR_PCG = 2,          /* block-Jacobi PCG on the block-sparse normal
                                       equations (inexact; pose-graph sized problems) */
+  BSGPU_LINEAR_SCHUR_PCG = 3     /* landmark Schur complement + block-Jacobi PCG on the
+                                      reduced camera system (Ceres ITERATIVE_SCHUR with
+                                      SCHUR_JACOBI, the preconditioner named by
+                                      beam_slam_launch/config/optimization/ceres_config.json:12;
+                                      inexact: pcg_tolerance / pcg_max_iterations)        */
 };
 
 /* ---- termination (ceres::TerminationType) ---------------------------------- */
