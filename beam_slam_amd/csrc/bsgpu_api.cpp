@@ -739,13 +739,19 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
     ok = up(P.ftasks.data(), sizeof(FusedTask) * P.ftasks.size(), (void**)&dft) && up(zeros.data(), sizeof(int) * zeros.size(), (void**)&dfsync);
   }
   int rc = BSGPU_OK;
+  int *dbc = nullptr, *drc = nullptr, *dbu = nullptr, *dbur = nullptr;
   if (ok) {
     (void)hipMemcpy(dS, hS.data(), sizeof(double) * hS.size(), hipMemcpyHostToDevice);
     (void)hipMemset(dscal, 0, sizeof(double) * SC_NUM);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, s);
-    const DenseDev D{dperm, dnreal, drows, dpan, dLp, dV, dpot2, dcb, dce, dsync, dft, dfsync};
+    DenseDev D{dperm, dnreal, drows, dpan, dLp, dV, dpot2, dcb, dce, dsync, dft, dfsync};
+    if (P.bs_level_sync && !getenv("BSGPU_BACKSOLVE_LEGACY") &&
+        up(P.bs_desc_chain.data(), sizeof(int) * P.bs_desc_chain.size(), (void**)&dbc) && up(P.rows_flat_chain.data(), sizeof(int) * P.rows_flat_chain.size(), (void**)&drc) &&
+        up(P.bs_upd.data(), sizeof(int) * P.bs_upd.size(), (void**)&dbu) && up(P.bs_upd_rows.data(), sizeof(int) * P.bs_upd_rows.size(), (void**)&dbur)) {
+      D.bs_desc_chain = dbc; D.rows_flat_chain = drc; D.bs_upd = dbu; D.bs_upd_rows = dbur;
+    }
     dense_factor_solve(s, P, D, dS, dy, dscal);
     (void)hipEventRecord(e1, s);
     if (hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess) rc = BSGPU_ERR_DEVICE;
@@ -764,6 +770,7 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
   (void)hipFree(dperm); (void)hipFree(dnreal); (void)hipFree(drows); (void)hipFree(dpan);
   (void)hipFree(dsep); (void)hipFree(dpot2); (void)hipFree(dcb); (void)hipFree(dce); (void)hipFree(dsync);
   (void)hipFree(dft); (void)hipFree(dfsync);
+  (void)hipFree(dbc); (void)hipFree(drc); (void)hipFree(dbu); (void)hipFree(dbur);
   (void)hipStreamDestroy(s);
   return rc;
 } catch (...) { return api_exception(nullptr); }

@@ -139,6 +139,7 @@ struct bsgpu_ctx {
   std::vector<uint8_t> tile_adj;   // natural-tile adjacency of the reduced system
   int *d_perm = nullptr, *d_iperm = nullptr, *d_nreal = nullptr, *d_rows_flat = nullptr;
   PanelDesc* d_panels = nullptr;
+  int *d_bs_desc_chain = nullptr, *d_rows_flat_chain = nullptr, *d_bs_upd = nullptr, *d_bs_upd_rows = nullptr;
   int *d_bs_desc = nullptr, *d_chain_begin = nullptr, *d_chain_end = nullptr, *d_tile_sync = nullptr, *d_touched = nullptr;
   int n_touched = 0;
   FusedTask* d_ftasks = nullptr;   // fused single-launch factorisation: task list and its counters (k_chol.hip chol_fused_kernel)
@@ -251,6 +252,8 @@ struct DenseDev {
   int* tile_sync;   // [expected arrivals | arrival counters] per tile (dense_plan.h)
   const FusedTask* ftasks = nullptr;   // fused single-launch factorisation (null: the launch-per-step path)
   int* fsync = nullptr;
+  // level-synchronous back-substitution (DensePlan::bs_level_sync): chain-only panel records and the between-group update items
+  const int *bs_desc_chain = nullptr, *rows_flat_chain = nullptr, *bs_upd = nullptr, *bs_upd_rows = nullptr;
 };
 void dense_factor(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* scal);
 // (iperm / y_tan / delta given: the back-substitution also writes the solution in tangent order and the step -y)

@@ -548,6 +548,11 @@ int finalize(bsgpu_ctx* c) {
     c->d_rows_flat = c->upload(c->plan.rows_flat);
     c->d_panels = c->upload(c->plan.panels);
     c->d_bs_desc = c->upload(c->plan.bs_desc);
+    c->d_bs_desc_chain = c->d_rows_flat_chain = c->d_bs_upd = c->d_bs_upd_rows = nullptr;
+    if (c->plan.bs_level_sync && !getenv("BSGPU_BACKSOLVE_LEGACY")) {
+      c->d_bs_desc_chain = c->upload(c->plan.bs_desc_chain); c->d_rows_flat_chain = c->upload(c->plan.rows_flat_chain);
+      c->d_bs_upd = c->upload(c->plan.bs_upd); c->d_bs_upd_rows = c->upload(c->plan.bs_upd_rows);
+    }
     c->d_tile_sync = c->upload(c->plan.tile_sync);
     {
       // fused single-launch factorisation (default; BSGPU_CHOL_FUSED=0 keeps the launch-per-step path): task list + zeroed counters

@@ -174,7 +174,8 @@ void launch_chol_backsolve_chains(hipStream_t s, const double* S, const double* 
                                   const int* bs_desc_dev, const int* chain_begin_dev,
                                   const int* chain_end_dev, int n_chains, const int* rows_flat_dev, double* y,
                                   int npad, int max_chain_len, const double* y_init = nullptr, const int* iperm_dev = nullptr, int n_pose = 0,
-                                  double* y_tan = nullptr, double* delta = nullptr);
+                                  double* y_tan = nullptr, double* delta = nullptr, int max_rows = 0);
+void launch_chol_backsolve_update(hipStream_t s, const double* Lp, int ld, const int* items_dev, int n_items, const int* upd_rows_dev, double* y);
 size_t chol_backsolve_chain_lds(int npad, int max_chain_len);
 void launch_marg_schur(hipStream_t s, const double* S, int ld, int rhs_row, const int* spos_dev, int n, int m, double rel_tol,
                        double* M, double* g, double* diag0, int* pivot_ok, double* status, double* A, double* b);

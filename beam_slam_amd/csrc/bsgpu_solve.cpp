@@ -219,13 +219,21 @@ void dense_backsolve(hipStream_t s, const DensePlan& P, const DenseDev& D, doubl
   const double* rhs_row = D.Lp + (size_t)P.rhs_row * ld;
   const bool single_root = P.bs_group_off.size() > 1 && P.bs_group_off[1] - P.bs_group_off[0] == 1;
   if (!single_root) launch_copy(s, rhs_row, y, (int64_t)P.T * 64, 64);   // (a single root chain copies it itself on the way)
-  // one launch per group of chains: root separator, the separator levels below it, then every piece (dense_plan.h)
-  for (size_t g = 0; g + 1 < P.bs_group_off.size(); ++g) {
+  // one launch per group of chains: root separator, the separator levels below it, then every piece (dense_plan.h); level-synchronous
+  // form: the chains walk their own row tiles only, and between two groups one wide launch applies the finished group to the rest
+  const bool level_sync = P.bs_level_sync && D.bs_desc_chain && D.bs_upd;
+  const int G = (int)P.bs_group_off.size() - 1;
+  for (int g = 0; g < G; ++g) {
     const int c0 = P.bs_group_off[g], c1 = P.bs_group_off[g + 1];
     int max_len = 1;
     for (int i = c0; i < c1; ++i) max_len = std::max(max_len, P.chain_end[i] - P.chain_begin[i]);
-    launch_chol_backsolve_chains(s, S, D.Lp, D.Vinv, ld, D.bs_desc, D.chain_begin + c0, D.chain_end + c0, c1 - c0,
-                                 D.rows_flat, y, P.npad, max_len, (g == 0 && single_root) ? rhs_row : nullptr, iperm, n_pose, y_tan, delta);
+    launch_chol_backsolve_chains(s, S, D.Lp, D.Vinv, ld, level_sync ? D.bs_desc_chain : D.bs_desc, D.chain_begin + c0, D.chain_end + c0, c1 - c0,
+                                 level_sync ? D.rows_flat_chain : D.rows_flat, y, P.npad, max_len, (g == 0 && single_root) ? rhs_row : nullptr, iperm,
+                                 n_pose, y_tan, delta, level_sync ? P.bs_group_maxrows[g] : 0);
+    if (level_sync && g + 1 < G) {
+      const int i0 = P.bs_upd_off[g], i1 = P.bs_upd_off[g + 1];
+      launch_chol_backsolve_update(s, D.Lp, ld, D.bs_upd + 3 * (size_t)i0, i1 - i0, D.bs_upd_rows, y);
+    }
   }
 }
 
@@ -240,7 +248,8 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
     phase_mark(c, BSGPU_PHASE_BACKSOLVE);
   } else if (c->n_pose > 0) {
     const DenseDev D{c->d_perm, c->d_nreal, c->d_rows_flat, c->d_panels, c->d_Lp, c->d_Vinv,
-                     c->d_bs_desc, c->d_chain_begin, c->d_chain_end, c->d_tile_sync, c->d_ftasks, c->d_fsync};
+                     c->d_bs_desc, c->d_chain_begin, c->d_chain_end, c->d_tile_sync, c->d_ftasks, c->d_fsync,
+                     c->d_bs_desc_chain, c->d_rows_flat_chain, c->d_bs_upd, c->d_bs_upd_rows};
     dense_factor(s, c->plan, D, c->d_S, c->d_scal);
     phase_mark(c, BSGPU_PHASE_FACTOR);
     dense_backsolve(s, c->plan, D, c->d_S, c->d_y, c->d_iperm, c->n_pose, c->d_ytan, c->d_delta);

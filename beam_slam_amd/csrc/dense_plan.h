@@ -291,8 +291,47 @@ struct DensePlan {
         for (int t : rows[k]) if (t < T && !((chain_of[t] == chain_of[k] && t > k) || group_of[t] < group_of[k])) ok = false;
       }
       if (!ok) build_groups(false);
+      bs_level_sync = false;
+      bs_desc_chain.clear(); rows_flat_chain.clear(); bs_upd.clear(); bs_upd_rows.clear(); bs_upd_off.assign(1, 0);
+      if (ok && bs_group_off.size() > 2) {
+        bs_desc_chain.assign((size_t)std::max(1, T) * kBsDescInts, 0);
+        for (int k = 0; k < T; ++k) {
+          int* r = &bs_desc_chain[(size_t)k * kBsDescInts];
+          const int off = (int)rows_flat_chain.size();
+          for (int t : rows[k]) if (t < T && chain_of[t] == chain_of[k]) rows_flat_chain.push_back(t);
+          const int n = (int)rows_flat_chain.size() - off;
+          r[0] = n; r[1] = off; r[2] = nreal[k];
+          for (int q = 0; q < n && q < kBsDescRows; ++q) r[3 + q] = rows_flat_chain[off + q];
+        }
+        const int G = (int)bs_group_off.size() - 1;
+        for (int g = 0; g + 1 < G; ++g) {
+          for (int k = 0; k < T; ++k) {
+            if (group_of[k] <= g) continue;
+            const int off = (int)bs_upd_rows.size();
+            for (int t : rows[k]) if (t < T && group_of[t] == g) bs_upd_rows.push_back(t);
+            const int n = (int)bs_upd_rows.size() - off;
+            if (n > 0) { bs_upd.push_back(k); bs_upd.push_back(off); bs_upd.push_back(n); }
+          }
+          bs_upd_off.push_back((int)bs_upd.size() / 3);
+        }
+        bs_group_maxrows.assign(G, 0);
+        for (int k = 0; k < T; ++k) bs_group_maxrows[group_of[k]] = std::max(bs_group_maxrows[group_of[k]], bs_desc_chain[(size_t)k * kBsDescInts]);
+        if (rows_flat_chain.empty()) rows_flat_chain.push_back(0);
+        if (bs_upd_rows.empty()) bs_upd_rows.push_back(0);
+        if (bs_upd.empty()) { bs_upd.assign(3, 0); }
+        bs_level_sync = true;
+      }
     }
   }
+  // Level-synchronous back-substitution (by-level groups only): a chain's workgroup walks its panels with the row tiles of ITS OWN
+  // chain only (bs_desc_chain / rows_flat_chain, same record format as bs_desc); what the chains of group g contribute to the panels
+  // of later groups — y_k -= sum_{t in group g} L(t,k)^T y_t — is applied between two groups by one workgroup per target panel
+  // (bs_upd: {k, offset into bs_upd_rows, count} per item, items of group g in [bs_upd_off[g], bs_upd_off[g+1])).  Those products
+  // are two thirds of the factor's entries and depend on nothing inside the later chains: as a wide launch they stream at the
+  // chip's bandwidth instead of at one workgroup's latency.
+  bool bs_level_sync = false;
+  std::vector<int> bs_desc_chain, rows_flat_chain, bs_upd, bs_upd_rows, bs_upd_off;
+  std::vector<int> bs_group_maxrows;   // per group: the most own-chain row tiles of any of its panels (level-synchronous form)
   int n_steps() const { return (int)step_off.size() - 1; }
 };
 

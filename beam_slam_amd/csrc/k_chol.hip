@@ -909,12 +909,22 @@ void launch_chol_fused(hipStream_t s, double* S, double* Lp, int ld, const Fused
 // loads and consumes one row tile at a time pays one round trip per tile) — and the piece-walking kernel keeps y and
 // its panels' descriptors / row lists in LDS, so that nothing but L is fetched inside the walk.
 constexpr int kBsChunk = 6;
+constexpr int kBsChunkDeep = 3;   // row tiles per panel of the two-panel-deep walk (chol_backsolve_chain_kernel)
 // workgroup barrier that orders LDS traffic only: global loads issued before it stay in flight across it
 BSG_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // one workgroup per chain (a separator, or a piece of the nested-dissection ordering), walking its panels from its last
 // tile down to its first; everything a chain depends on outside itself was solved by an earlier launch (dense_plan.h)
 constexpr int kBsMaxRows = DensePlan::kBsDescRows;   // row lists up to this length are staged in LDS
-template <bool Y_IN_LDS>
+// CH: row tiles of a panel whose entries are loaded up front (further ones go through the two-at-a-time loop, each a round trip).
+// DEEP: the loads of TWO panels ahead are in flight (two register sets, the walk unrolled by two) — for chains whose panels have
+// at most CH row tiles each (the level-synchronous form of a banded window: CH = 3), where a step is otherwise as long as one
+// memory round trip although its arithmetic takes a third of that.
+template <int CH>
+struct BsPanelRegs {
+  double dl[4], l[CH][4], vinv;
+  int r0[CH];
+};
+template <bool Y_IN_LDS, int CH, bool DEEP>
 __global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double* S, const double* Lp, const double* Vinv, int ld,
                                                                     const int* __restrict__ bs_desc,
                                                                     const int* __restrict__ chain_begin,
@@ -947,42 +957,39 @@ __global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double
     if (q == 0) s_nrows[p] = v; else if (q == 1) s_rowoff[p] = v; else if (q == 2) s_nr[p] = v; else s_rows[p * kBsMaxRows + (q - 3)] = v;
   }
   __syncthreads();
-  // Software pipeline over the chain: the tiles of panel k-1 do not depend on y, so their loads are issued BEFORE the
-  // barrier + 64-pivot triangular solve of panel k and are in flight underneath it (the barrier is an LDS-only one: a
-  // __syncthreads() would wait for those loads).  Registers: the loaded values of panel k are dead (consumed into the
-  // partial sums / copied to LDS) by the time the loads of panel k-1 are issued, so one set suffices.
+  // Software pipeline over the chain: the tiles of panel k-1 (k-2 with DEEP) do not depend on y, so their loads are issued BEFORE
+  // the barrier + 64-pivot triangular solve of panel k and are in flight underneath it (the barrier is an LDS-only one: a
+  // __syncthreads() would wait for those loads).
   const int c = tid & 63, part = tid >> 6;
-  double dl[4], l[kBsChunk][4], vinv = 0.0;
-  int r0[kBsChunk];
-  auto issue = [&](int k) {
+  auto issue = [&](int k, BsPanelRegs<CH>& R) {
     const int p = k - b, n_rows = s_nrows[p], c0 = k * NB;
     const int* rows = (n_rows <= kBsMaxRows) ? (s_rows + p * kBsMaxRows) : (rows_flat + s_rowoff[p]);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int i = tid + 1024 * q;
       const int r = i >> 6, cc = i & 63;
-      dl[q] = (cc <= r) ? Lp[(size_t)(c0 + r) * ld + c0 + cc] : 0.0;
+      R.dl[q] = (cc <= r) ? Lp[(size_t)(c0 + r) * ld + c0 + cc] : 0.0;
     }
-    vinv = Vinv[(size_t)k * kVinvStride + tid];
+    R.vinv = Vinv[(size_t)k * kVinvStride + tid];
 #pragma unroll
-    for (int u = 0; u < kBsChunk; ++u) {
+    for (int u = 0; u < CH; ++u) {
       const bool ok = u < n_rows;
-      r0[u] = (ok ? rows[u] : k) * NB + 4 * part;
+      R.r0[u] = (ok ? rows[u] : k) * NB + 4 * part;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) l[u][i] = ok ? Lp[(size_t)(r0[u] + i) * ld + c0 + c] : 0.0;
+      for (int i = 0; i < 4; ++i) R.l[u][i] = ok ? Lp[(size_t)(R.r0[u] + i) * ld + c0 + c] : 0.0;
     }
   };
-  if (len > 0) issue(e - 1);
-  for (int k = e - 1; k >= b; --k) {
+  // one panel: R holds its loaded entries; `next` (>= b, or < b for none) is the panel whose loads go out into R once R is consumed
+  auto step = [&](int k, BsPanelRegs<CH>& R, int next) {
     const int p = k - b, n_rows = s_nrows[p], nr = s_nr[p], c0 = k * NB;
     double acc = 0.0;
 #pragma unroll
-    for (int u = 0; u < kBsChunk; ++u)
+    for (int u = 0; u < CH; ++u)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc = fma(l[u][i], sy[r0[u] + i], acc);
-    if (n_rows > kBsChunk) {   // (wide separators only)
+      for (int i = 0; i < 4; ++i) acc = fma(R.l[u][i], sy[R.r0[u] + i], acc);
+    if (n_rows > CH) {   // (wide separators / dense windows only)
       const int* rows = (n_rows <= kBsMaxRows) ? (s_rows + p * kBsMaxRows) : (rows_flat + s_rowoff[p]);
-      for (int q0 = kBsChunk; q0 < n_rows; q0 += 2) {
+      for (int q0 = CH; q0 < n_rows; q0 += 2) {
         double l2[2][4];
         int r2[2];
 #pragma unroll
@@ -1001,11 +1008,11 @@ __global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int i = tid + 1024 * q;
-      sL[(i >> 6) * (NB + 1) + (i & 63)] = dl[q];
+      sL[(i >> 6) * (NB + 1) + (i & 63)] = R.dl[q];
     }
     sp[part * NB + c] = acc;
-    sV[tid] = vinv;
-    if (k > b) issue(k - 1);
+    sV[tid] = R.vinv;
+    if (next >= b) issue(next, R);
     if (y_in_lds) lds_barrier(); else __syncthreads();
     if (tid < NB) {
       // L_kk^T y = t on one wave, lane = row.  Blocked by 16 with the inverses of the diagonal blocks (V_b = L_bb^-1, kept
@@ -1039,6 +1046,19 @@ __global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double
       }
     }
     if (y_in_lds) lds_barrier(); else __syncthreads();   // (global y: the stores must have left the wave before the other waves read them)
+  };
+  if (DEEP) {
+    BsPanelRegs<CH> A, B;
+    if (len > 0) issue(e - 1, A);
+    if (len > 1) issue(e - 2, B);
+    for (int k = e - 1; k >= b; k -= 2) {
+      step(k, A, k - 2);
+      if (k - 1 >= b) step(k - 1, B, k - 3);
+    }
+  } else {
+    BsPanelRegs<CH> A;
+    if (len > 0) issue(e - 1, A);
+    for (int k = e - 1; k >= b; --k) step(k, A, k - 1);
   }
 }
 
@@ -1046,20 +1066,60 @@ void launch_chol_backsolve_chains(hipStream_t s, const double* S, const double* 
                                   const int* bs_desc_dev, const int* chain_begin_dev,
                                   const int* chain_end_dev, int n_chains, const int* rows_flat_dev, double* y,
                                   int npad, int max_chain_len, const double* y_init, const int* iperm_dev, int n_pose, double* y_tan,
-                                  double* delta) {
+                                  double* delta, int max_rows) {
   if (n_chains <= 0) return;
   size_t lds = chol_backsolve_chain_lds(npad, max_chain_len);
   const char* fg = getenv("BSGPU_BACKSOLVE_GLOBAL_Y");   // (tests: force the path windows above 12 288 reduced dimensions take)
   const int y_in_lds = (lds <= (size_t)160 * 1024 && !(fg && atoi(fg) != 0)) ? 1 : 0;
   if (!y_in_lds) lds = chol_backsolve_chain_lds(0, max_chain_len);
-  if (y_in_lds)
-    hipLaunchKernelGGL(chol_backsolve_chain_kernel<true>, dim3(n_chains), dim3(1024), lds, s, S, Lp, Vinv, ld, bs_desc_dev,
-                       chain_begin_dev, chain_end_dev, rows_flat_dev, y, npad, max_chain_len, n_chains == 1 ? y_init : nullptr, iperm_dev, n_pose,
-                       y_tan, delta);
-  else
-    hipLaunchKernelGGL(chol_backsolve_chain_kernel<false>, dim3(n_chains), dim3(1024), lds, s, S, Lp, Vinv, ld, bs_desc_dev,
-                       chain_begin_dev, chain_end_dev, rows_flat_dev, y, npad, max_chain_len, n_chains == 1 ? y_init : nullptr, iperm_dev, n_pose,
-                       y_tan, delta);
+  // max_rows: the most row tiles any panel of these chains has (0: unknown).  Few enough: the two-panel-deep variant.
+  static const bool no_deep = getenv("BSGPU_BACKSOLVE_NO_DEEP") != nullptr;
+  const bool deep = max_rows > 0 && max_rows <= kBsChunkDeep && max_chain_len > 1 && !no_deep;
+#define BSG_LAUNCH_CHAIN(YL, CH, DEEP)                                                                                                    \
+  hipLaunchKernelGGL((chol_backsolve_chain_kernel<YL, CH, DEEP>), dim3(n_chains), dim3(1024), lds, s, S, Lp, Vinv, ld, bs_desc_dev,      \
+                     chain_begin_dev, chain_end_dev, rows_flat_dev, y, npad, max_chain_len, n_chains == 1 ? y_init : nullptr, iperm_dev, \
+                     n_pose, y_tan, delta)
+  if (y_in_lds) { if (deep) BSG_LAUNCH_CHAIN(true, kBsChunkDeep, true); else BSG_LAUNCH_CHAIN(true, kBsChunk, false); }
+  else { if (deep) BSG_LAUNCH_CHAIN(false, kBsChunkDeep, true); else BSG_LAUNCH_CHAIN(false, kBsChunk, false); }
+#undef BSG_LAUNCH_CHAIN
+}
+
+// Between two groups of chains (level-synchronous back-substitution, dense_plan.h): y_k -= sum_t L(t,k)^T y_t over the row tiles t
+// of panel k that the group just solved.  One 1024-thread workgroup per target panel, the same thread layout as the walk (16 row
+// groups x 64 columns), the tiles' entries loaded kBsChunk tiles at a time; nothing here depends on anything but finished y.
+__global__ __launch_bounds__(1024) void chol_backsolve_update_kernel(const double* __restrict__ Lp, int ld, const int* __restrict__ items,
+                                                                     const int* __restrict__ upd_rows, double* __restrict__ y) {
+  __shared__ double sp[16 * NB];
+  const int tid = threadIdx.x, c = tid & 63, part = tid >> 6;
+  const int k = items[3 * blockIdx.x], off = items[3 * blockIdx.x + 1], n = items[3 * blockIdx.x + 2];
+  const int c0 = k * NB;
+  double acc = 0.0;
+  for (int q0 = 0; q0 < n; q0 += kBsChunk) {
+    double l[kBsChunk][4], yv[kBsChunk][4];
+#pragma unroll
+    for (int u = 0; u < kBsChunk; ++u) {
+      const bool ok = q0 + u < n;
+      const int r0 = (ok ? upd_rows[off + q0 + u] : k) * NB + 4 * part;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { l[u][i] = ok ? Lp[(size_t)(r0 + i) * ld + c0 + c] : 0.0; yv[u][i] = ok ? y[r0 + i] : 0.0; }
+    }
+#pragma unroll
+    for (int u = 0; u < kBsChunk; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc = fma(l[u][i], yv[u][i], acc);
+  }
+  sp[part * NB + c] = acc;
+  __syncthreads();
+  if (tid < NB) {
+    double sum = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) sum += sp[q * NB + tid];
+    y[c0 + tid] -= sum;
+  }
+}
+void launch_chol_backsolve_update(hipStream_t s, const double* Lp, int ld, const int* items_dev, int n_items, const int* upd_rows_dev, double* y) {
+  if (n_items <= 0) return;
+  hipLaunchKernelGGL(chol_backsolve_update_kernel, dim3(n_items), dim3(1024), 0, s, Lp, ld, items_dev, upd_rows_dev, y);
 }
 
 size_t chol_backsolve_chain_lds(int npad, int max_chain_len) {
@@ -1071,9 +1131,11 @@ void chol_prepare() {
                             (int)kPanelStepLds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_panel_step_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kPanelStepLds);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_chain_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_chain_kernel<true, kBsChunkDeep, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_chain_kernel<false, kBsChunkDeep, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_chain_kernel<true, kBsChunk, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_chain_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_chain_kernel<false, kBsChunk, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds);
