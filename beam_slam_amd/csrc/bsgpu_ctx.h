@@ -140,11 +140,13 @@ struct bsgpu_ctx {
   int *d_perm = nullptr, *d_iperm = nullptr, *d_nreal = nullptr, *d_rows_flat = nullptr;
   PanelDesc* d_panels = nullptr;
   int *d_bs_desc_chain = nullptr, *d_rows_flat_chain = nullptr, *d_bs_upd = nullptr, *d_bs_upd_rows = nullptr;
+  int *d_bs_chain_group = nullptr, *d_bs_grp_nchains = nullptr, *d_bs_grp_nitems = nullptr, *d_bs_items4 = nullptr, *d_bs_tile_updated = nullptr, *d_bs_sync = nullptr;
   int *d_bs_desc = nullptr, *d_chain_begin = nullptr, *d_chain_end = nullptr, *d_tile_sync = nullptr, *d_touched = nullptr;
   int n_touched = 0;
   FusedTask* d_ftasks = nullptr;   // fused single-launch factorisation: task list and its counters (k_chol.hip chol_fused_kernel)
   int* d_fsync = nullptr;
   double* d_Vinv = nullptr;
+  double* d_Winv = nullptr;
   double* d_Lp = nullptr;     // shadow of S holding the off-diagonal L panels (k_chol.hip)
   double* d_ytan = nullptr;   // y in tangent order
   std::vector<bsgpu_iteration> iters;
@@ -254,6 +256,11 @@ struct DenseDev {
   int* fsync = nullptr;
   // level-synchronous back-substitution (DensePlan::bs_level_sync): chain-only panel records and the between-group update items
   const int *bs_desc_chain = nullptr, *rows_flat_chain = nullptr, *bs_upd = nullptr, *bs_upd_rows = nullptr;
+  // ... and its single-launch form
+  const int *bs_chain_group = nullptr, *bs_grp_nchains = nullptr, *bs_grp_nitems = nullptr, *bs_items4 = nullptr, *bs_tile_updated = nullptr;
+  int* bs_sync = nullptr;
+  double* scal = nullptr;
+  double* Winv = nullptr;   // per tile: the full inverse of its factor (written by the fused factorisation, read by the single-launch back-substitution)
 };
 void dense_factor(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* scal);
 // (iperm / y_tan / delta given: the back-substitution also writes the solution in tangent order and the step -y)

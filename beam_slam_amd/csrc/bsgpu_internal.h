@@ -164,7 +164,7 @@ void launch_grad_norms_pose_diag(hipStream_t s, int nb, const int* blk_xoff, con
 struct PanelDesc;
 struct FusedTask;
 void launch_chol_fused(hipStream_t s, double* S, double* Lp, int ld, const FusedTask* tasks_dev, int n_tasks, const int* nreal_dev,
-                       double* Vinv, double* scal, int* sync_dev, int n_sync_words);
+                       double* Vinv, double* scal, int* sync_dev, int n_sync_words, double* Winv = nullptr);
 void launch_chol_potrf_tiles(hipStream_t s, double* S, double* Lp, int ld, const int* tiles_dev, int n_tiles, const int* nreal_dev,
                              double* Vinv, double* scal);
 void launch_chol_panel_step(hipStream_t s, double* S, double* Lp, int ld, const PanelDesc* descs_dev, int n_panels, int max_rows,
@@ -176,6 +176,11 @@ void launch_chol_backsolve_chains(hipStream_t s, const double* S, const double* 
                                   int npad, int max_chain_len, const double* y_init = nullptr, const int* iperm_dev = nullptr, int n_pose = 0,
                                   double* y_tan = nullptr, double* delta = nullptr, int max_rows = 0);
 void launch_chol_backsolve_update(hipStream_t s, const double* Lp, int ld, const int* items_dev, int n_items, const int* upd_rows_dev, double* y);
+bool launch_chol_backsolve_fused(hipStream_t s, const double* Lp, const double* Winv, int ld, const int* bs_desc_dev, const int* chain_begin_dev,
+                                 const int* chain_end_dev, const int* rows_flat_dev, int n_chains, const int* chain_group_dev,
+                                 const int* grp_nchains_dev, const int* grp_nitems_dev, int G, const int* items_dev, int n_items,
+                                 const int* upd_rows_dev, const int* tile_updated_dev, double* y, int npad, int max_chain_len, int max_rows,
+                                 const double* y_init, const int* iperm_dev, int n_pose, double* y_tan, double* delta, int* sync_dev, double* scal);
 size_t chol_backsolve_chain_lds(int npad, int max_chain_len);
 void launch_marg_schur(hipStream_t s, const double* S, int ld, int rhs_row, const int* spos_dev, int n, int m, double rel_tol,
                        double* M, double* g, double* diag0, int* pivot_ok, double* status, double* A, double* b);

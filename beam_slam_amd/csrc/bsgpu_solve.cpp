@@ -197,7 +197,7 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
 void dense_factor(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* scal) {
   const int ld = P.npad;
   if (D.ftasks && D.fsync) {   // the whole factorisation in one launch
-    launch_chol_fused(s, S, D.Lp, ld, D.ftasks, (int)P.ftasks.size(), D.nreal, D.Vinv, scal, D.fsync, P.fused_sync_words);
+    launch_chol_fused(s, S, D.Lp, ld, D.ftasks, (int)P.ftasks.size(), D.nreal, D.Vinv, scal, D.fsync, P.fused_sync_words, D.Winv);
     return;
   }
   for (int st = 0; st < P.n_steps(); ++st) {
@@ -218,11 +218,21 @@ void dense_backsolve(hipStream_t s, const DensePlan& P, const DenseDev& D, doubl
   // off-diagonal row tile of every panel)
   const double* rhs_row = D.Lp + (size_t)P.rhs_row * ld;
   const bool single_root = P.bs_group_off.size() > 1 && P.bs_group_off[1] - P.bs_group_off[0] == 1;
-  if (!single_root) launch_copy(s, rhs_row, y, (int64_t)P.T * 64, 64);   // (a single root chain copies it itself on the way)
   // one launch per group of chains: root separator, the separator levels below it, then every piece (dense_plan.h); level-synchronous
   // form: the chains walk their own row tiles only, and between two groups one wide launch applies the finished group to the rest
   const bool level_sync = P.bs_level_sync && D.bs_desc_chain && D.bs_upd;
   const int G = (int)P.bs_group_off.size() - 1;
+  if (level_sync && D.bs_items4 && D.bs_sync && D.scal && D.Winv && D.ftasks && D.fsync) {   // (the fused factorisation writes the tile inverses)   // everything in one launch, if its workgroups can all be resident
+    int max_len = 1, max_rows = 0;
+    for (size_t i = 0; i < P.chain_begin.size(); ++i) max_len = std::max(max_len, P.chain_end[i] - P.chain_begin[i]);
+    for (int g = 0; g < G; ++g) max_rows = std::max(max_rows, P.bs_group_maxrows[g]);
+    if (launch_chol_backsolve_fused(s, D.Lp, D.Winv, ld, D.bs_desc_chain, D.chain_begin, D.chain_end, D.rows_flat_chain, (int)P.chain_begin.size(),
+                                    D.bs_chain_group, D.bs_grp_nchains, D.bs_grp_nitems, G, D.bs_items4, (int)P.bs_upd.size() / 3 * (P.bs_upd_off.back() > 0 ? 1 : 0),
+                                    D.bs_upd_rows, D.bs_tile_updated, y, P.npad, max_len, std::max(1, max_rows), rhs_row, iperm, n_pose, y_tan, delta,
+                                    D.bs_sync, D.scal))
+      return;
+  }
+  if (!single_root) launch_copy(s, rhs_row, y, (int64_t)P.T * 64, 64);   // (a single root chain copies it itself on the way)
   for (int g = 0; g < G; ++g) {
     const int c0 = P.bs_group_off[g], c1 = P.bs_group_off[g + 1];
     int max_len = 1;
@@ -249,7 +259,8 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
   } else if (c->n_pose > 0) {
     const DenseDev D{c->d_perm, c->d_nreal, c->d_rows_flat, c->d_panels, c->d_Lp, c->d_Vinv,
                      c->d_bs_desc, c->d_chain_begin, c->d_chain_end, c->d_tile_sync, c->d_ftasks, c->d_fsync,
-                     c->d_bs_desc_chain, c->d_rows_flat_chain, c->d_bs_upd, c->d_bs_upd_rows};
+                     c->d_bs_desc_chain, c->d_rows_flat_chain, c->d_bs_upd, c->d_bs_upd_rows,
+                     c->d_bs_chain_group, c->d_bs_grp_nchains, c->d_bs_grp_nitems, c->d_bs_items4, c->d_bs_tile_updated, c->d_bs_sync, c->d_scal, c->d_Winv};
     dense_factor(s, c->plan, D, c->d_S, c->d_scal);
     phase_mark(c, BSGPU_PHASE_FACTOR);
     dense_backsolve(s, c->plan, D, c->d_S, c->d_y, c->d_iperm, c->n_pose, c->d_ytan, c->d_delta);

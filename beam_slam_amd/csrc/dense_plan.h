@@ -314,6 +314,23 @@ struct DensePlan {
           }
           bs_upd_off.push_back((int)bs_upd.size() / 3);
         }
+        bs_chain_group.assign(chain_begin.size(), 0); bs_grp_nchains.assign(G, 0); bs_grp_nitems.assign(G, 0);
+        for (int g = 0; g < G; ++g) {
+          bs_grp_nchains[g] = bs_group_off[g + 1] - bs_group_off[g];
+          for (int c = bs_group_off[g]; c < bs_group_off[g + 1]; ++c) bs_chain_group[c] = g;
+        }
+        bs_tile_updated.assign(std::max(1, T), 0);
+        bs_items4.clear();
+        for (int g = 0; g + 1 < G; ++g) {
+          bs_grp_nitems[g] = bs_upd_off[g + 1] - bs_upd_off[g];
+          for (int i = bs_upd_off[g]; i < bs_upd_off[g + 1]; ++i) {
+            const int k = bs_upd[3 * i];
+            bs_items4.push_back(k); bs_items4.push_back(bs_upd[3 * i + 1]); bs_items4.push_back(bs_upd[3 * i + 2]);
+            bs_items4.push_back(g | ((bs_tile_updated[k] ? 0 : 1) << 16));
+            bs_tile_updated[k] = 1;
+          }
+        }
+        if (bs_items4.empty()) bs_items4.assign(4, 0);
         bs_group_maxrows.assign(G, 0);
         for (int k = 0; k < T; ++k) bs_group_maxrows[group_of[k]] = std::max(bs_group_maxrows[group_of[k]], bs_desc_chain[(size_t)k * kBsDescInts]);
         if (rows_flat_chain.empty()) rows_flat_chain.push_back(0);
@@ -331,6 +348,7 @@ struct DensePlan {
   // chip's bandwidth instead of at one workgroup's latency.
   bool bs_level_sync = false;
   std::vector<int> bs_desc_chain, rows_flat_chain, bs_upd, bs_upd_rows, bs_upd_off;
+  std::vector<int> bs_chain_group, bs_grp_nchains, bs_grp_nitems, bs_items4, bs_tile_updated;   // single-launch form (k_chol.hip chol_backsolve_fused_kernel)
   std::vector<int> bs_group_maxrows;   // per group: the most own-chain row tiles of any of its panels (level-synchronous form)
   int n_steps() const { return (int)step_off.size() - 1; }
 };

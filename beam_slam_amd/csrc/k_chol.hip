@@ -576,8 +576,59 @@ BSG_DEV long long uniform_i64(long long v) {
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
   return (long long)(((unsigned long long)hi << 32) | lo);
 }
+// W = L^-1 of a factored 64x64 tile (full lower-triangular inverse, 16x16 blocks) from L (sL) and the inverses of its diagonal blocks
+// (sV), into sW (pitch LDT; blocks above the diagonal are not written).  Wave j builds block column j top-down — W_jj = V_j,
+// W_ij = -V_i sum_{k=j..i-1} L_ik W_kj — out of its own registers: the MFMA result layout of W_kj is the B-operand layout of the
+// next product.  Wave 3 only copies V_3.  The back-substitution multiplies by W^T instead of solving with L_kk^T (bs_chain_walk).
+BSG_DEV void tile_inverse_w(const double* sL, const double* sV, double* sW, int lane, int wave) {
+  const int n = lane & 15, q = lane >> 4, j = wave;
+  double4_t w[4];   // W_kj for k = j .. 3 (index k), result layout: w[k][reg] = W_kj[q + 4 reg][n]
+#pragma unroll
+  for (int k = 0; k < 4; ++k) w[k] = double4_t{0.0, 0.0, 0.0, 0.0};
+  double4_t wjj;
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) wjj[reg] = sV[j * 256 + (q + 4 * reg) * 16 + n];
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) if (jj == j) w[jj] = wjj;
+#pragma unroll
+  for (int i = 1; i < 4; ++i) {
+    if (i <= j) continue;   // (wave-uniform)
+    double4_t t = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k < j || k >= i) continue;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        t = __builtin_amdgcn_mfma_f64_16x16x4f64(sL[(16 * i + n) * LDT + 16 * k + 4 * kk + q], w[k][kk], t, 0, 0, 0);
+    }
+    double4_t r = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) r = __builtin_amdgcn_mfma_f64_16x16x4f64(-sV[i * 256 + n * 16 + 4 * kk + q], t[kk], r, 0, 0, 0);
+    w[i] = r;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i < j) continue;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) sW[(16 * i + q + 4 * reg) * LDT + 16 * j + n] = w[i][reg];
+  }
+}
+// ... and out to Winv[t] (row-major 64 x 64, zero above the diagonal blocks): read by a later launch, plain stores
+BSG_DEV void publish_tile_inverse(const double* sL, const double* sV, double* sW, double* __restrict__ Wt, int tid) {
+  tile_inverse_w(sL, sV, sW, tid & 63, tid >> 6);
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int i = tid + 256 * q;
+    const int r = i >> 5, c2 = (i & 31) * 2;
+    double2 v = *reinterpret_cast<const double2*>(&sW[r * LDT + c2]);
+    if ((c2 >> 4) > (r >> 4)) { v.x = 0.0; v.y = 0.0; }
+    *reinterpret_cast<double2*>(&Wt[r * NB + c2]) = v;
+  }
+}
 struct FusedCtx {
   double *S, *Lp, *Vinv, *scal;
+  double* Winv;   // per tile: the full inverse of its factor, for the back-substitution (null: not wanted)
   const FusedTask* tasks;
   const int* nreal;
   int ld, n_vinv_tiles;
@@ -600,6 +651,7 @@ BSG_DEV bool chol_fused_task(const FusedCtx& C, int t, double* smem, long long t
   int* const abort_w = uniform_ptr(C.abort_w); int* const potrf_done = uniform_ptr(C.potrf_done); int* const upd = uniform_ptr(C.upd);
   const long long deadline = uniform_i64(C.deadline);
   long long* const probe_ts = uniform_ptr(C.probe_ts); volatile int* const trace = uniform_ptr(C.trace);
+  double* const Winv = uniform_ptr(C.Winv);
   t = __builtin_amdgcn_readfirstlane(t);
   smem = uniform_ptr(smem);
   double* sXi = smem;                 // 64 x LDT
@@ -651,6 +703,8 @@ BSG_DEV bool chol_fused_task(const FusedCtx& C, int t, double* smem, long long t
       __syncthreads();
       if (tid == 0) __hip_atomic_store(&potrf_done[k], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       stamp(6);
+      // (nobody waits for this: the tile's full inverse, for the back-substitution)
+      if (Winv && k < T) publish_tile_inverse(sXj, sV, sXi, Winv + (size_t)k * NB * NB, tid);
     } else {
     const int ti = tk.ti, tj = tk.tj;
     const bool diag = ti == tj;
@@ -759,6 +813,7 @@ BSG_DEV bool chol_fused_task(const FusedCtx& C, int t, double* smem, long long t
       if (factor_now) __hip_atomic_store(&potrf_done[ti], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     stamp(6);
+    if (factor_now && Winv) publish_tile_inverse(sXj, sV, sXi, Winv + (size_t)ti * NB * NB, tid);
     }   // turn_ok
     }   // dependencies met
     }   // update task
@@ -769,7 +824,7 @@ template <bool PROBE>
 __global__ __launch_bounds__(256) void chol_fused_kernel(double* __restrict__ S, double* __restrict__ Lp, int ld,
                                                           const FusedTask* __restrict__ tasks, int n_tasks,
                                                           const int* __restrict__ nreal, double* __restrict__ Vinv, int n_vinv_tiles,
-                                                          double* __restrict__ scal, int* sync, int n_sync_words,
+                                                          double* __restrict__ scal, int* sync, int n_sync_words, double* Winv,
                                                           long long* probe_ts = nullptr /* PROBE: n_tasks x 8 wall-clock stamps */,
                                                           volatile int* trace = nullptr /* PROBE: per workgroup (checkpoint, task) in host memory */) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -779,6 +834,7 @@ __global__ __launch_bounds__(256) void chol_fused_kernel(double* __restrict__ S,
   int* head = sync; int* abort_w = sync + 1; int* exited = sync + 2;
   FusedCtx C;
   C.S = S; C.Lp = Lp; C.Vinv = Vinv; C.scal = scal; C.tasks = tasks; C.nreal = nreal; C.ld = ld; C.n_vinv_tiles = n_vinv_tiles;
+  C.Winv = Winv;
   C.abort_w = abort_w; C.potrf_done = sync + 4; C.upd = sync + 4 + N;
   C.deadline = (long long)wall_clock64() + kFusedTimeoutTicks;
   C.probe_ts = probe_ts; C.trace = trace;
@@ -807,7 +863,7 @@ __global__ __launch_bounds__(256) void chol_fused_kernel(double* __restrict__ S,
 constexpr size_t kFusedLds = sizeof(double) * (3 * NB * LDT + 4 * 256 + 4 * 16 * 17 + 64) + 16;
 
 void launch_chol_fused(hipStream_t s, double* S, double* Lp, int ld, const FusedTask* tasks_dev, int n_tasks, const int* nreal_dev,
-                       double* Vinv, double* scal, int* sync_dev, int n_sync_words) {
+                       double* Vinv, double* scal, int* sync_dev, int n_sync_words, double* Winv) {
   if (n_tasks <= 0) return;
   static int n_cu = 0;
   if (n_cu == 0) {
@@ -866,7 +922,7 @@ void launch_chol_fused(hipStream_t s, double* S, double* Lp, int ld, const Fused
     for (int i = 0; i < 2048; ++i) trace[i] = -1;
     fprintf(stderr, "[chol trace] launch: %d tasks, grid %d, ld %d\n", n_tasks, grid, ld);
     hipLaunchKernelGGL(chol_fused_kernel<false>, dim3(grid), dim3(256), kFusedLds, s, S, Lp, ld, tasks_dev, n_tasks, nreal_dev, Vinv, ld / NB - 1,
-                       scal, sync_dev, n_sync_words, ts_dummy, trace);
+                       scal, sync_dev, n_sync_words, Winv, ts_dummy, trace);
     return;
   }
   if (probe_file && ++probe_calls == 20) {
@@ -876,7 +932,7 @@ void launch_chol_fused(hipStream_t s, double* S, double* Lp, int ld, const Fused
     if (hipMalloc((void**)&ts, sizeof(long long) * h.size()) == hipSuccess) {
       (void)hipMemset(ts, 0, sizeof(long long) * h.size());
       hipLaunchKernelGGL(chol_fused_kernel<true>, dim3(grid), dim3(256), kFusedLds, s, S, Lp, ld, tasks_dev, n_tasks, nreal_dev, Vinv, ld / NB - 1,
-                         scal, sync_dev, n_sync_words, ts);
+                         scal, sync_dev, n_sync_words, Winv, ts);
       (void)hipStreamSynchronize(s);
       (void)hipMemcpy(h.data(), ts, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
       (void)hipMemcpy(ht.data(), tasks_dev, sizeof(FusedTask) * ht.size(), hipMemcpyDeviceToHost);
@@ -894,7 +950,7 @@ void launch_chol_fused(hipStream_t s, double* S, double* Lp, int ld, const Fused
     }
   }
   hipLaunchKernelGGL(chol_fused_kernel<false>, dim3(grid), dim3(256), kFusedLds, s, S, Lp, ld, tasks_dev, n_tasks, nreal_dev, Vinv, ld / NB - 1, scal,
-                     sync_dev, n_sync_words, nullptr);
+                     sync_dev, n_sync_words, Winv, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -924,14 +980,21 @@ struct BsPanelRegs {
   double dl[4], l[CH][4], vinv;
   int r0[CH];
 };
-template <bool Y_IN_LDS, int CH, bool DEEP>
-__global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double* S, const double* Lp, const double* Vinv, int ld,
-                                                                    const int* __restrict__ bs_desc,
-                                                                    const int* __restrict__ chain_begin,
-                                                                    const int* __restrict__ chain_end,
-                                                                    const int* __restrict__ rows_flat, double* y, int npad, int max_len,
-                                                                    const double* __restrict__ y_init, const int* __restrict__ iperm,
-                                                                    int n_pose, double* __restrict__ y_tan, double* __restrict__ delta) {
+// what the single-launch form (chol_backsolve_fused_kernel) adds to a chain's walk: the turn to wait for, where y is shared
+struct BsFused {
+  int* abort_w;            // sticky failure flag
+  const int* wait_word;    // null: nothing to wait for (the root group); else the walk starts when *wait_word >= wait_count
+  int wait_count;
+  int* done_word;          // bumped once the chain's y is out
+  const int* tile_updated; // per tile: an earlier phase has written y there (else the start value is y_init)
+  long long deadline;
+  long long* ts;           // debugging: 16 wall-clock stamps per workgroup (BSGPU_BACKSOLVE_PROBE), or null
+};
+template <bool Y_IN_LDS, int CH, bool DEEP, bool FUSED, bool USE_W>
+BSG_DEV void bs_chain_walk(const double* Lp, const double* Vinv /* USE_W: the tiles' full inverses, 64 x 64 row-major each */, int ld, const int* __restrict__ bs_desc, int b, int e,
+                           const int* __restrict__ rows_flat, double* y, int npad, int max_len, const double* __restrict__ y_init,
+                           const int* __restrict__ iperm, int n_pose, double* __restrict__ y_tan, double* __restrict__ delta,
+                           const BsFused& F) {
   constexpr bool y_in_lds = Y_IN_LDS;
   extern __shared__ __attribute__((aligned(16))) double dyn[];
   double* sL = dyn;                         // 64 x 65
@@ -946,10 +1009,14 @@ __global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double
   int* s_nr = s_rowoff + max_len;                     // max_len
   int* s_rows = s_nr + max_len;                       // max_len x kBsMaxRows
   const int tid = threadIdx.x;
-  const int b = chain_begin[blockIdx.x], e = chain_end[blockIdx.x], len = e - b;
-  // y_init (first launch of a solve, a single chain): the forward-substituted rhs row of the factor, copied to y on the way
-  if (y_init) { for (int i = tid; i < npad; i += 1024) { const double v = (i < npad - NB) ? y_init[i] : 0.0; sy[i] = v; y[i] = v; } }   // (the last tile is the rhs tile itself)
-  else if (y_in_lds) { for (int i = tid; i < npad; i += 1024) sy[i] = y[i]; }
+  const int len = e - b;
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y, 0, (int)((size_t)npad * sizeof(double)), 0x00020000);
+  (void)ry;
+  if (!FUSED) {
+    // y_init (first launch of a solve, a single chain): the forward-substituted rhs row of the factor, copied to y on the way
+    if (y_init) { for (int i = tid; i < npad; i += 1024) { const double v = (i < npad - NB) ? y_init[i] : 0.0; sy[i] = v; y[i] = v; } }   // (the last tile is the rhs tile itself)
+    else if (y_in_lds) { for (int i = tid; i < npad; i += 1024) sy[i] = y[i]; }
+  }
   // the records of this chain's tiles (DensePlan::bs_desc: one coalesced round, not tile -> panel -> row list)
   for (int i = tid; i < len * DensePlan::kBsDescInts; i += 1024) {
     const int p = i / DensePlan::kBsDescInts, q = i - p * DensePlan::kBsDescInts;
@@ -964,13 +1031,19 @@ __global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double
   auto issue = [&](int k, BsPanelRegs<CH>& R) {
     const int p = k - b, n_rows = s_nrows[p], c0 = k * NB;
     const int* rows = (n_rows <= kBsMaxRows) ? (s_rows + p * kBsMaxRows) : (rows_flat + s_rowoff[p]);
+    if (USE_W) {   // W = L_kk^-1 in the layout of the row tiles: rows 4 part .. 4 part + 3, column c
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int i = tid + 1024 * q;
-      const int r = i >> 6, cc = i & 63;
-      R.dl[q] = (cc <= r) ? Lp[(size_t)(c0 + r) * ld + c0 + cc] : 0.0;
+      for (int q = 0; q < 4; ++q) R.dl[q] = Vinv[(size_t)k * NB * NB + (4 * part + q) * NB + c];
+      R.vinv = 0.0;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = tid + 1024 * q;
+        const int r = i >> 6, cc = i & 63;
+        R.dl[q] = (cc <= r) ? Lp[(size_t)(c0 + r) * ld + c0 + cc] : 0.0;
+      }
+      R.vinv = Vinv[(size_t)k * kVinvStride + tid];
     }
-    R.vinv = Vinv[(size_t)k * kVinvStride + tid];
 #pragma unroll
     for (int u = 0; u < CH; ++u) {
       const bool ok = u < n_rows;
@@ -1005,6 +1078,37 @@ __global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double
           for (int i = 0; i < 4; ++i) acc = fma(l2[u][i], sy[r2[u] + i], acc);
       }
     }
+    if (USE_W) {
+      // y_k = W^T (y'_k - sum): two 16-part reductions, every thread busy, no dependent chain (the substitution with L_kk^T below
+      // is ~130 dependent FMAs of one wave, each behind its own LDS read: 2.6 - 4.4 us a panel against ~1)
+      const double w0 = R.dl[0], w1 = R.dl[1], w2 = R.dl[2], w3 = R.dl[3];
+      sp[part * NB + c] = acc;
+      if (next >= b) issue(next, R);
+      if (y_in_lds) lds_barrier(); else __syncthreads();
+      double* st = sL;   // 64 doubles
+      if (tid < NB) {
+        double sum = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sum += sp[q * NB + tid];
+        st[tid] = (tid < nr) ? (sy[c0 + tid] - sum) : 0.0;
+      }
+      if (y_in_lds) lds_barrier(); else __syncthreads();
+      const double a2 = w0 * st[4 * part] + w1 * st[4 * part + 1] + w2 * st[4 * part + 2] + w3 * st[4 * part + 3];
+      sp[part * NB + c] = a2;
+      if (y_in_lds) lds_barrier(); else __syncthreads();
+      if (tid < NB) {
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v += sp[q * NB + tid];
+        v = (tid < nr) ? v : 0.0;
+        if (FUSED) st8_sc1(ry, (unsigned)((c0 + tid) * sizeof(double)), v); else y[c0 + tid] = v;
+        if (y_in_lds) sy[c0 + tid] = v;
+        if (y_tan) {
+          const int j = iperm[k] * NB + tid;
+          if (j < n_pose) { y_tan[j] = v; delta[j] = -v; }
+        }
+      }
+    } else {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int i = tid + 1024 * q;
@@ -1038,28 +1142,220 @@ __global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double
         }
       }
       v = (tid < nr) ? v : 0.0;
-      y[c0 + tid] = v;
+      if (FUSED) st8_sc1(ry, (unsigned)((c0 + tid) * sizeof(double)), v); else y[c0 + tid] = v;
       if (y_in_lds) sy[c0 + tid] = v;
       if (y_tan) {   // the solution in tangent (natural) order and the step -y, written where the tile is solved
         const int j = iperm[k] * NB + tid;
         if (j < n_pose) { y_tan[j] = v; delta[j] = -v; }
       }
     }
+    }
     if (y_in_lds) lds_barrier(); else __syncthreads();   // (global y: the stores must have left the wave before the other waves read them)
   };
+  // (single launch) the first loads are out; now wait for the turn, then take the chain's start values: what the earlier phases left
+  // in y (write-through stores, read past this CU's caches), or the rhs row where nothing has been applied yet
+  int n_stamp = 4;
+  auto stamp = [&](int slot) { if (FUSED && F.ts && tid == 0) F.ts[(size_t)blockIdx.x * 16 + slot] = wall_clock64(); };
+  auto fused_enter = [&]() {
+    if (!FUSED) return true;
+    stamp(1);
+    int* s_ok = reinterpret_cast<int*>(s_rows + (size_t)max_len * kBsMaxRows);
+    if (tid == 0) *s_ok = (!F.wait_word || wait_count(F.wait_word, F.wait_count, F.abort_w, F.deadline)) ? 1 : 0;
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane(*s_ok) == 0) return false;
+    stamp(2);
+    for (int i = b * NB + tid; i < e * NB; i += 1024)
+      sy[i] = F.tile_updated[i >> 6] ? ld8_sc1(ry, (unsigned)(i * sizeof(double))) : y_init[i];
+    __syncthreads();
+    stamp(3);
+    return true;
+  };
+  bool entered = true;
   if (DEEP) {
     BsPanelRegs<CH> A, B;
     if (len > 0) issue(e - 1, A);
     if (len > 1) issue(e - 2, B);
-    for (int k = e - 1; k >= b; k -= 2) {
-      step(k, A, k - 2);
-      if (k - 1 >= b) step(k - 1, B, k - 3);
-    }
+    entered = fused_enter();
+    if (entered)
+      for (int k = e - 1; k >= b; k -= 2) {
+        step(k, A, k - 2);
+        if (n_stamp < 12) stamp(n_stamp++);
+        if (k - 1 >= b) { step(k - 1, B, k - 3); if (n_stamp < 12) stamp(n_stamp++); }
+      }
   } else {
     BsPanelRegs<CH> A;
     if (len > 0) issue(e - 1, A);
-    for (int k = e - 1; k >= b; --k) step(k, A, k - 1);
+    entered = fused_enter();
+    if (entered)
+      for (int k = e - 1; k >= b; --k) step(k, A, k - 1);
   }
+  if (FUSED) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0 && entered) atomicAdd(F.done_word, 1);
+    stamp(12);
+  }
+}
+template <bool Y_IN_LDS, int CH, bool DEEP>
+__global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double* S, const double* Lp, const double* Vinv, int ld,
+                                                                    const int* __restrict__ bs_desc,
+                                                                    const int* __restrict__ chain_begin,
+                                                                    const int* __restrict__ chain_end,
+                                                                    const int* __restrict__ rows_flat, double* y, int npad, int max_len,
+                                                                    const double* __restrict__ y_init, const int* __restrict__ iperm,
+                                                                    int n_pose, double* __restrict__ y_tan, double* __restrict__ delta) {
+  (void)S;
+  const BsFused none{};
+  bs_chain_walk<Y_IN_LDS, CH, DEEP, false, false>(Lp, Vinv, ld, bs_desc, chain_begin[blockIdx.x], chain_end[blockIdx.x], rows_flat, y, npad, max_len,
+                                           y_init, iperm, n_pose, y_tan, delta, none);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The whole level-synchronous back-substitution in ONE launch: a workgroup per chain and one per (phase, target panel) update item,
+// all resident at once (the launcher checks the grid against the number of CUs), each doing what does not depend on y — its records,
+// the loads of its first tiles — before it waits for its turn:
+//   chains of group g     wait for done_upd[g-1] == items of phase g-1   (nothing for the root group)
+//   items of phase g      wait for done_chain[g] == chains of group g
+// y travels between workgroups with write-through stores and loads that pass the CU's caches (as the factor does in
+// chol_fused_kernel); waits are bounded (abort flag + deadline -> SC_CHOL_FAIL = 2); the last workgroup out clears the counters.
+// Seven launches of 13 + 5 us each become one: the prologues overlap and a hand-over costs ~2 us instead of a launch boundary.
+// sync: [0] abort, [1] exited, [2 .. 2+G) done_chain, [2+G .. 2+2G) done_upd
+// ---------------------------------------------------------------------------------------------------
+template <int CH, bool DEEP>
+__global__ __launch_bounds__(1024) void chol_backsolve_fused_kernel(const double* Lp, const double* Winv, int ld, const int* __restrict__ bs_desc,
+                                                                    const int* __restrict__ chain_begin, const int* __restrict__ chain_end,
+                                                                    const int* __restrict__ rows_flat, int n_chains, const int* __restrict__ chain_group,
+                                                                    const int* __restrict__ grp_nchains, const int* __restrict__ grp_nitems, int G,
+                                                                    const int* __restrict__ items /* (k, off, n, phase | first << 16) */,
+                                                                    const int* __restrict__ upd_rows, const int* __restrict__ tile_updated,
+                                                                    double* y, int npad, int max_len, const double* __restrict__ y_init,
+                                                                    const int* __restrict__ iperm, int n_pose, double* __restrict__ y_tan,
+                                                                    double* __restrict__ delta, int* sync, double* __restrict__ scal, long long* ts) {
+  const int tid = threadIdx.x;
+  if (ts && tid == 0) ts[(size_t)blockIdx.x * 16] = wall_clock64();
+  int* abort_w = sync; int* exited = sync + 1; int* done_chain = sync + 2; int* done_upd = sync + 2 + G;
+  const long long deadline = (long long)wall_clock64() + kFusedTimeoutTicks;
+  if ((int)blockIdx.x < n_chains) {
+    const int ch = blockIdx.x, g = chain_group[ch];
+    BsFused F;
+    F.abort_w = abort_w; F.deadline = deadline; F.tile_updated = tile_updated;
+    F.wait_word = g > 0 ? done_upd + (g - 1) : nullptr;
+    F.wait_count = g > 0 ? grp_nitems[g - 1] : 0;
+    F.done_word = done_chain + g; F.ts = ts;
+    bs_chain_walk<true, CH, DEEP, true, true>(Lp, Winv, ld, bs_desc, chain_begin[ch], chain_end[ch], rows_flat, y, npad, max_len, y_init, iperm, n_pose,
+                                        y_tan, delta, F);
+  } else {
+    // an update item: y_k = (y_k or the rhs row) - sum_t L(t,k)^T y_t over the row tiles t of panel k that group `phase` solved
+    extern __shared__ __attribute__((aligned(16))) double dyn[];
+    double* sp = dyn;                                   // 16 x 64
+    int* s_ok = reinterpret_cast<int*>(dyn + 16 * NB);
+    const int* it = items + 4 * ((size_t)blockIdx.x - n_chains);
+    const int k = it[0], off = it[1], n = it[2], phase = it[3] & 0xffff, first = it[3] >> 16;
+    const int c = tid & 63, part = tid >> 6, c0 = k * NB;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y, 0, (int)((size_t)npad * sizeof(double)), 0x00020000);
+    double l[kBsChunk][4];
+    int r0[kBsChunk];
+#pragma unroll
+    for (int u = 0; u < kBsChunk; ++u) {
+      const bool ok = u < n;
+      r0[u] = (ok ? upd_rows[off + u] : k) * NB + 4 * part;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) l[u][i] = ok ? Lp[(size_t)(r0[u] + i) * ld + c0 + c] : 0.0;
+    }
+    if (ts && tid == 0) ts[(size_t)blockIdx.x * 16 + 1] = wall_clock64();
+    if (tid == 0) *s_ok = wait_count(done_chain + phase, grp_nchains[phase], abort_w, deadline) ? 1 : 0;
+    __syncthreads();
+    if (ts && tid == 0) ts[(size_t)blockIdx.x * 16 + 2] = wall_clock64();
+    const bool ok_turn = __builtin_amdgcn_readfirstlane(*s_ok) != 0;
+    if (ok_turn) {
+      double acc = 0.0;
+#pragma unroll
+      for (int u = 0; u < kBsChunk; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc = fma(l[u][i], (u < n) ? ld8_sc1(ry, (unsigned)((r0[u] + i) * sizeof(double))) : 0.0, acc);
+      for (int q0 = kBsChunk; q0 < n; q0 += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (q0 + u >= n) continue;
+          const int r2 = upd_rows[off + q0 + u] * NB + 4 * part;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc = fma(Lp[(size_t)(r2 + i) * ld + c0 + c], ld8_sc1(ry, (unsigned)((r2 + i) * sizeof(double))), acc);
+        }
+      }
+      sp[part * NB + c] = acc;
+      __syncthreads();
+      if (tid < NB) {
+        double sum = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sum += sp[q * NB + tid];
+        const double base = first ? y_init[c0 + tid] : ld8_sc1(ry, (unsigned)((c0 + tid) * sizeof(double)));
+        st8_sc1(ry, (unsigned)((c0 + tid) * sizeof(double)), base - sum);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) atomicAdd(done_upd + phase, 1);
+      if (ts && tid == 0) ts[(size_t)blockIdx.x * 16 + 12] = wall_clock64();
+    }
+  }
+  // leave: the last workgroup out clears the counters for the next solve
+  __syncthreads();
+  __shared__ int s_last;
+  if (tid == 0) {
+    if (ld_flag(abort_w) != 0) scal[SC_CHOL_FAIL] = 2.0;
+    s_last = (atomicAdd(exited, 1) == (int)gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (s_last) for (int i = tid; i < 2 + 2 * G; i += 1024) __hip_atomic_store(&sync[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// false: not launched (the grid would not be resident at once, or y does not fit LDS) — the caller takes the launch-per-level path
+bool launch_chol_backsolve_fused(hipStream_t s, const double* Lp, const double* Winv, int ld, const int* bs_desc_dev, const int* chain_begin_dev,
+                                 const int* chain_end_dev, const int* rows_flat_dev, int n_chains, const int* chain_group_dev,
+                                 const int* grp_nchains_dev, const int* grp_nitems_dev, int G, const int* items_dev, int n_items,
+                                 const int* upd_rows_dev, const int* tile_updated_dev, double* y, int npad, int max_chain_len, int max_rows,
+                                 const double* y_init, const int* iperm_dev, int n_pose, double* y_tan, double* delta, int* sync_dev, double* scal) {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0; hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n_cu = pr.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+  }
+  static const bool off = getenv("BSGPU_BACKSOLVE_FUSED") && atoi(getenv("BSGPU_BACKSOLVE_FUSED")) == 0;
+  const size_t lds = chol_backsolve_chain_lds(npad, max_chain_len) + 16;
+  if (off || !Winv || n_chains + n_items > n_cu || lds > (size_t)160 * 1024 - 256 /* (4 bytes of static LDS) */ || getenv("BSGPU_BACKSOLVE_GLOBAL_Y")) return false;
+  const bool deep = max_rows > 0 && max_rows <= kBsChunkDeep && max_chain_len > 1;
+  // BSGPU_BACKSOLVE_PROBE=<file>: the 20th solve of the process is stamped (100 MHz wall clock): per workgroup start / loads out /
+  // turn / start values / after each panel / done
+  static const char* probe_file = getenv("BSGPU_BACKSOLVE_PROBE");
+  static int probe_calls = 0;
+  long long* ts = nullptr;
+  const int grid = n_chains + n_items;
+  if (probe_file && ++probe_calls == 20) { (void)hipMalloc((void**)&ts, sizeof(long long) * 16 * grid); (void)hipMemsetAsync(ts, 0, sizeof(long long) * 16 * grid, s); }
+  if (deep)
+    hipLaunchKernelGGL((chol_backsolve_fused_kernel<kBsChunkDeep, true>), dim3(n_chains + n_items), dim3(1024), lds, s, Lp, Winv, ld, bs_desc_dev,
+                       chain_begin_dev, chain_end_dev, rows_flat_dev, n_chains, chain_group_dev, grp_nchains_dev, grp_nitems_dev, G, items_dev,
+                       upd_rows_dev, tile_updated_dev, y, npad, max_chain_len, y_init, iperm_dev, n_pose, y_tan, delta, sync_dev, scal, ts);
+  else
+    hipLaunchKernelGGL((chol_backsolve_fused_kernel<kBsChunk, false>), dim3(n_chains + n_items), dim3(1024), lds, s, Lp, Winv, ld, bs_desc_dev,
+                       chain_begin_dev, chain_end_dev, rows_flat_dev, n_chains, chain_group_dev, grp_nchains_dev, grp_nitems_dev, G, items_dev,
+                       upd_rows_dev, tile_updated_dev, y, npad, max_chain_len, y_init, iperm_dev, n_pose, y_tan, delta, sync_dev, scal, ts);
+  if (ts) {
+    std::vector<long long> h((size_t)16 * grid);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h.data(), ts, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
+    (void)hipFree(ts);
+    if (FILE* f = fopen(probe_file, "w")) {
+      long long t0 = 0;
+      for (int i = 0; i < grid; ++i) if (h[(size_t)i * 16] && (!t0 || h[(size_t)i * 16] < t0)) t0 = h[(size_t)i * 16];
+      fprintf(f, "# workgroup role | stamps in us from the first start: start, loads out, turn, start values, panels..., done(12)\n");
+      for (int i = 0; i < grid; ++i) {
+        fprintf(f, "%d %s", i, i < n_chains ? "chain" : "update");
+        for (int q = 0; q < 13; ++q) fprintf(f, " %.2f", h[(size_t)i * 16 + q] ? (h[(size_t)i * 16 + q] - t0) / 100.0 : -1.0);
+        fprintf(f, "\n");
+      }
+      fclose(f);
+    }
+  }
+  return true;
 }
 
 void launch_chol_backsolve_chains(hipStream_t s, const double* S, const double* Lp, const double* Vinv, int ld,
@@ -1137,6 +1433,8 @@ void chol_prepare() {
                             160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_chain_kernel<false, kBsChunk, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_fused_kernel<kBsChunkDeep, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_fused_kernel<kBsChunk, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds);
 }
