@@ -684,7 +684,7 @@ int build_bsr(bsgpu_ctx* c) {
   c->d_rhs = c->alloc<double>(c->n_pose);
   c->d_px = c->alloc<double>(c->n_pose); c->d_pr = c->alloc<double>(c->n_pose); c->d_pz = c->alloc<double>(c->n_pose);
   c->d_pp = c->alloc<double>(c->n_pose); c->d_pp1 = c->alloc<double>(c->n_pose); c->d_pq = c->alloc<double>(c->n_pose);
-  c->d_ppart = c->alloc<double>((size_t)pcg_spmv_grid(nbr) + 8); c->d_ppart2 = c->alloc<double>(4 * ((size_t)(nbr + 255) / 256) + 8);
+  c->d_ppart = c->alloc<double>((size_t)pcg_spmv_grid(nbr) + 8); c->d_ppart2 = c->alloc<double>(4 * (size_t)pcg_rows_grid(nbr) + 8);
   c->d_psc = c->alloc<double>(pcg_num_scalars());
   if (!c->d_val || !c->d_pq || !c->d_psc) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (block-sparse system)");
   c->bsr_built = true;

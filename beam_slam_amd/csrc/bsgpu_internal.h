@@ -215,6 +215,7 @@ void launch_pcg_iteration(hipStream_t s, int k, int nbr, const int* row_ptr, con
                           double* x, double* r, double* z, double* p0, double* p1, double* q, double* part_pq, double* part, double* sc,
                           double tol2);
 int pcg_num_scalars();
+int pcg_rows_grid(int nbr);
 // PCG on the assembled reduced camera system (tiles of S), k_pcg.hip
 void launch_spcg_prepare(hipStream_t s, int T, const double* S, int ld, double* Minv);
 void launch_spcg_init(hipStream_t s, int T, const double* b, const double* Minv, double* x, double* r, double* z, double* p0, double* p1,

@@ -167,17 +167,6 @@ void launch_bsr_finish_diag(hipStream_t s, int nbr, const int* diag_slot, const 
 }
 
 // z = M^-1 r for the pair of block rows (2m, 2m+1) (rows >= nbr do not exist: their r is taken as 0 and nothing is written)
-BSG_DEV void precond_pair(const double* __restrict__ Minv, int m, const double rv[6], double zv[6]) {
-  const double* M = Minv + (size_t)m * 36;
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    double v = 0.0;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) v += M[i * 6 + j] * rv[j];
-    zv[i] = v;
-  }
-}
-
 // One PCG iteration is TWO launches (a third of the time of an iteration is otherwise the ~5 us dependency latency of
 // each extra launch; the SpMV itself streams 30 MB in ~6 us):
 //   S_k (pcg_spmv_kernel)    every workgroup reduces the r.z / r.r partials of iteration k itself (same order => same
@@ -211,27 +200,26 @@ BSG_DEV PcgTotals pcg_totals(const double* __restrict__ part, int n_part, double
   return t;
 }
 
-// x = 0, r = b, z = M^-1 r, both p buffers = 0 (p_0 = z_0 + 0 * p_{-1}); partials of r.z, r.r for iteration 0.  One thread per
-// pair of block rows (the preconditioner's 6x6 blocks).
+// x = 0, r = b, z = M^-1 r, both p buffers = 0 (p_0 = z_0 + 0 * p_{-1}); partials of r.z, r.r for iteration 0.  One thread per ROW
+// (six threads share a 6x6 block of the preconditioner: a thread per block left 2 500 threads on the chip for C4 and read its 288
+// bytes of the block alone); 252 = 42 x 6 rows per workgroup, so that no block straddles two workgroups.
+constexpr int kPcgRowsPerWg = 252;
 __global__ __launch_bounds__(256) void pcg_init_kernel(int nbr, const double* __restrict__ b, const double* __restrict__ Minv,
                                                        double* __restrict__ x, double* __restrict__ r, double* __restrict__ z,
                                                        double* __restrict__ p0, double* __restrict__ p1, double* __restrict__ part) {
   __shared__ double sred[4];
-  const int m = blockIdx.x * 256 + threadIdx.x;
   const int n = 3 * nbr;
+  const int j = blockIdx.x * kPcgRowsPerWg + threadIdx.x;
   double rz = 0.0, rr = 0.0;
-  if (2 * m < nbr) {
-    double rv[6], zv[6];
+  if (threadIdx.x < kPcgRowsPerWg && j < n) {
+    const int m = j / 6, i = j - 6 * m, base = 6 * m;
+    const double* M = Minv + (size_t)m * 36 + 6 * i;
+    double zv = 0.0;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) rv[i] = (6 * m + i < n) ? b[6 * m + i] : 0.0;
-    precond_pair(Minv, m, rv, zv);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      if (6 * m + i >= n) continue;
-      x[6 * m + i] = 0; p0[6 * m + i] = 0; p1[6 * m + i] = 0;
-      r[6 * m + i] = rv[i]; z[6 * m + i] = zv[i];
-      rz += rv[i] * zv[i]; rr += rv[i] * rv[i];
-    }
+    for (int k = 0; k < 6; ++k) zv += M[k] * ((base + k < n) ? b[base + k] : 0.0);
+    const double rv = b[j];
+    x[j] = 0; p0[j] = 0; p1[j] = 0; r[j] = rv; z[j] = zv;
+    rz = rv * zv; rr = rv * rv;
   }
   const double a = block_sum_256(rz, sred), c = block_sum_256(rr, sred);
   if (threadIdx.x == 0) { part[2 * blockIdx.x] = a; part[2 * blockIdx.x + 1] = c; }
@@ -287,7 +275,7 @@ __global__ __launch_bounds__(256) void pcg_spmv_kernel(int nbr, const int* __res
   if (threadIdx.x == 0) part_pq[blockIdx.x] = t;
 }
 
-// U_k
+// U_k (one thread per row, as pcg_init_kernel)
 __global__ __launch_bounds__(256) void pcg_update_kernel(int nbr, const double* __restrict__ part_pq, int n_part_pq,
                                                          const double* __restrict__ Minv, const double* __restrict__ p,
                                                          const double* __restrict__ q, double* __restrict__ x,
@@ -302,29 +290,31 @@ __global__ __launch_bounds__(256) void pcg_update_kernel(int nbr, const double* 
   __syncthreads();
   if (sc[PC_DONE] != 0.0) return;   // (uniform; the partials of the stopping iteration stay as they are)
   const double alpha = s_alpha;
-  const int m = blockIdx.x * 256 + threadIdx.x;
   const int n = 3 * nbr;
-  double rz = 0.0, rr = 0.0;
-  if (2 * m < nbr) {
-    double rv[6], zv[6];
+  const int j = blockIdx.x * kPcgRowsPerWg + threadIdx.x;
+  const bool live = threadIdx.x < kPcgRowsPerWg && j < n;
+  double rz = 0.0, rr = 0.0, rv = 0.0, zv = 0.0;
+  if (live) {
+    const int m = j / 6, i = j - 6 * m, base = 6 * m;
+    const double* M = Minv + (size_t)m * 36 + 6 * i;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int j = 6 * m + i;
-      if (j < n) { x[j] += alpha * p[j]; rv[i] = r[j] - alpha * q[j]; r[j] = rv[i]; } else rv[i] = 0.0;
+    for (int k = 0; k < 6; ++k) {
+      const double rk = (base + k < n) ? r[base + k] - alpha * q[base + k] : 0.0;   // (the block's six rows: same workgroup, read before the barrier)
+      zv += M[k] * rk;
+      rv = (k == i) ? rk : rv;
     }
-    precond_pair(Minv, m, rv, zv);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int j = 6 * m + i;
-      if (j >= n) continue;
-      z[j] = zv[i];
-      rz += rv[i] * zv[i]; rr += rv[i] * rv[i];
-    }
+  }
+  __syncthreads();
+  if (live) {
+    x[j] += alpha * p[j];
+    r[j] = rv; z[j] = zv;
+    rz = rv * zv; rr = rv * rv;
   }
   const double t1 = block_sum_256(rz, sred), t2 = block_sum_256(rr, sred);
   if (threadIdx.x == 0) { part_next[2 * blockIdx.x] = t1; part_next[2 * blockIdx.x + 1] = t2; }
 }
 
+int pcg_rows_grid(int nbr) { return (3 * nbr + kPcgRowsPerWg - 1) / kPcgRowsPerWg; }
 // ---------------------------------------------------------------------------------------------------
 // PCG on the REDUCED camera system (Ceres: ITERATIVE_SCHUR with the SCHUR_JACOBI preconditioner the reference's
 // beam_slam_launch/config/optimization/ceres_config.json:11-12 names).  The operator is the assembled Schur complement itself — the
@@ -498,7 +488,7 @@ void launch_spcg_finish(hipStream_t s, int T, const double* x, const int* iperm,
 int pcg_spmv_grid(int nbr);
 void launch_pcg_init(hipStream_t s, int nbr, const double* b, const double* Minv, double* x, double* r, double* z, double* p0, double* p1,
                      double* part, double* sc) {
-  const int grid = ((nbr + 1) / 2 + 255) / 256;
+  const int grid = pcg_rows_grid(nbr);
   hipLaunchKernelGGL(pcg_init_kernel, dim3(grid), dim3(256), 0, s, nbr, b, Minv, x, r, z, p0, p1, part);
   hipLaunchKernelGGL(pcg_init_scalars_kernel, dim3(1), dim3(256), 0, s, part, grid, sc);
 }
@@ -506,7 +496,7 @@ void launch_pcg_init(hipStream_t s, int nbr, const double* b, const double* Minv
 void launch_pcg_iteration(hipStream_t s, int k, int nbr, const int* row_ptr, const int* col, const double* val, const double* Minv,
                           double* x, double* r, double* z, double* p0, double* p1, double* q, double* part_pq, double* part, double* sc,
                           double tol2) {
-  const int g16 = pcg_spmv_grid(nbr), g1 = ((nbr + 1) / 2 + 255) / 256;
+  const int g16 = pcg_spmv_grid(nbr), g1 = pcg_rows_grid(nbr);
   double* p_cur = (k & 1) ? p1 : p0;
   double* p_prev = (k & 1) ? p0 : p1;
   double* part_cur = part + (size_t)(k & 1) * 2 * g1;
