@@ -27,7 +27,7 @@ constexpr int kJAStride = 12;
 
 // entries of one camera pair are cut into segments of at most this many (one single-wave workgroup of pairs_kernel each);
 // a power of two.  Host and device flattening must agree (their tables are compared bit for bit).
-constexpr int kPairChunk = 128;
+constexpr int kPairChunk = 256;
 
 // meta word of a reprojection factor: camera id | loss id | constant-block flags
 constexpr int kMetaCamBits = 12, kMetaLossBits = 12;
