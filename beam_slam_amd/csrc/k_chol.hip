@@ -543,6 +543,23 @@ BSG_DEV bool wait_count(const int* p, int want, int* abort_w, long long deadline
     __builtin_amdgcn_s_sleep(1);
   }
 }
+// one WAVE: wait until every flag in [lo, hi) is set (each written once, by a different workgroup: a counter word that 18-25 workgroups
+// on eight XCDs add to costs its waiter ~2.7 us after the last add, a flag per writer ~1); false on abort / time-out (wave-uniform)
+BSG_DEV bool wait_flags(const int* flags, int lo, int hi, int* abort_w, long long deadline) {
+  const int lane = threadIdx.x & 63;
+  for (;;) {
+    int ok = 1;
+    for (int i = lo + lane; i < hi; i += 64) ok &= (ld_flag(flags + i) != 0) ? 1 : 0;
+    if (__all(ok)) return true;
+    int stop = 0;
+    if (lane == 0) {
+      if (ld_flag(abort_w) != 0) stop = 1;
+      else if ((long long)wall_clock64() > deadline) { __hip_atomic_store(abort_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); stop = 1; }
+    }
+    if (__builtin_amdgcn_readfirstlane(stop)) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
 // L_tt, its block inverses and reciprocal pivots to Lp / Vinv, write-through (read by other workgroups of this launch)
 BSG_DEV void write_factor_sc1(__amdgpu_buffer_rsrc_t rLp, __amdgpu_buffer_rsrc_t rV, int ld, int t, const double* sC, const double* sV,
                               const double* sInvD, int tid) {
@@ -983,8 +1000,8 @@ struct BsPanelRegs {
 // what the single-launch form (chol_backsolve_fused_kernel) adds to a chain's walk: the turn to wait for, where y is shared
 struct BsFused {
   int* abort_w;            // sticky failure flag
-  const int* wait_word;    // null: nothing to wait for (the root group); else the walk starts when *wait_word >= wait_count
-  int wait_count;
+  const int* wait_flags;   // null: nothing to wait for (the root group); else the walk starts when every flag in [wait_lo, wait_hi) is set
+  int wait_lo, wait_hi;
   int* done_word;          // bumped once the chain's y is out
   const int* tile_updated; // per tile: an earlier phase has written y there (else the start value is y_init)
   long long deadline;
@@ -1160,7 +1177,10 @@ BSG_DEV void bs_chain_walk(const double* Lp, const double* Vinv /* USE_W: the ti
     if (!FUSED) return true;
     stamp(1);
     int* s_ok = reinterpret_cast<int*>(s_rows + (size_t)max_len * kBsMaxRows);
-    if (tid == 0) *s_ok = (!F.wait_word || wait_count(F.wait_word, F.wait_count, F.abort_w, F.deadline)) ? 1 : 0;
+    if (tid < 64) {   // (the first wave polls, a flag per lane)
+      const bool ok = !F.wait_flags || wait_flags(F.wait_flags, F.wait_lo, F.wait_hi, F.abort_w, F.deadline);
+      if (tid == 0) *s_ok = ok ? 1 : 0;
+    }
     __syncthreads();
     if (__builtin_amdgcn_readfirstlane(*s_ok) == 0) return false;
     stamp(2);
@@ -1214,12 +1234,12 @@ __global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double
 // The whole level-synchronous back-substitution in ONE launch: a workgroup per chain and one per (phase, target panel) update item,
 // all resident at once (the launcher checks the grid against the number of CUs), each doing what does not depend on y — its records,
 // the loads of its first tiles — before it waits for its turn:
-//   chains of group g     wait for done_upd[g-1] == items of phase g-1   (nothing for the root group)
+//   chains of group g     wait for the flags of every item of phase g-1   (nothing for the root group)
 //   items of phase g      wait for done_chain[g] == chains of group g
 // y travels between workgroups with write-through stores and loads that pass the CU's caches (as the factor does in
 // chol_fused_kernel); waits are bounded (abort flag + deadline -> SC_CHOL_FAIL = 2); the last workgroup out clears the counters.
 // Seven launches of 13 + 5 us each become one: the prologues overlap and a hand-over costs ~2 us instead of a launch boundary.
-// sync: [0] abort, [1] exited, [2 .. 2+G) done_chain, [2+G .. 2+2G) done_upd
+// sync: [0] abort, [1] exited, [2 .. 2+G) done_chain (counters: at most eight writers), [2+G .. 2+G+n_items) one flag per update item
 // ---------------------------------------------------------------------------------------------------
 template <int CH, bool DEEP>
 __global__ __launch_bounds__(1024) void chol_backsolve_fused_kernel(const double* Lp, const double* Winv, int ld, const int* __restrict__ bs_desc,
@@ -1233,14 +1253,17 @@ __global__ __launch_bounds__(1024) void chol_backsolve_fused_kernel(const double
                                                                     double* __restrict__ delta, int* sync, double* __restrict__ scal, long long* ts) {
   const int tid = threadIdx.x;
   if (ts && tid == 0) ts[(size_t)blockIdx.x * 16] = wall_clock64();
-  int* abort_w = sync; int* exited = sync + 1; int* done_chain = sync + 2; int* done_upd = sync + 2 + G;
+  int* abort_w = sync; int* exited = sync + 1; int* done_chain = sync + 2; int* item_flag = sync + 2 + G;
+  const int n_items_total = (int)gridDim.x - n_chains;
   const long long deadline = (long long)wall_clock64() + kFusedTimeoutTicks;
   if ((int)blockIdx.x < n_chains) {
     const int ch = blockIdx.x, g = chain_group[ch];
     BsFused F;
     F.abort_w = abort_w; F.deadline = deadline; F.tile_updated = tile_updated;
-    F.wait_word = g > 0 ? done_upd + (g - 1) : nullptr;
-    F.wait_count = g > 0 ? grp_nitems[g - 1] : 0;
+    int lo = 0;
+    for (int q = 0; q + 1 < g; ++q) lo += grp_nitems[q];
+    F.wait_flags = g > 0 ? item_flag : nullptr;
+    F.wait_lo = lo; F.wait_hi = g > 0 ? lo + grp_nitems[g - 1] : 0;
     F.done_word = done_chain + g; F.ts = ts;
     bs_chain_walk<true, CH, DEEP, true, true>(Lp, Winv, ld, bs_desc, chain_begin[ch], chain_end[ch], rows_flat, y, npad, max_len, y_init, iperm, n_pose,
                                         y_tan, delta, F);
@@ -1269,6 +1292,8 @@ __global__ __launch_bounds__(1024) void chol_backsolve_fused_kernel(const double
     const bool ok_turn = __builtin_amdgcn_readfirstlane(*s_ok) != 0;
     if (ok_turn) {
       double acc = 0.0;
+      double base = 0.0;   // (requested with the row values, not after the reduction: one round trip less)
+      if (tid < NB) base = first ? y_init[c0 + tid] : ld8_sc1(ry, (unsigned)((c0 + tid) * sizeof(double)));
 #pragma unroll
       for (int u = 0; u < kBsChunk; ++u)
 #pragma unroll
@@ -1288,12 +1313,11 @@ __global__ __launch_bounds__(1024) void chol_backsolve_fused_kernel(const double
         double sum = 0.0;
 #pragma unroll
         for (int q = 0; q < 16; ++q) sum += sp[q * NB + tid];
-        const double base = first ? y_init[c0 + tid] : ld8_sc1(ry, (unsigned)((c0 + tid) * sizeof(double)));
         st8_sc1(ry, (unsigned)((c0 + tid) * sizeof(double)), base - sum);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tid == 0) atomicAdd(done_upd + phase, 1);
+      if (tid == 0) __hip_atomic_store(item_flag + ((int)blockIdx.x - n_chains), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (ts && tid == 0) ts[(size_t)blockIdx.x * 16 + 12] = wall_clock64();
     }
   }
@@ -1305,7 +1329,7 @@ __global__ __launch_bounds__(1024) void chol_backsolve_fused_kernel(const double
     s_last = (atomicAdd(exited, 1) == (int)gridDim.x - 1) ? 1 : 0;
   }
   __syncthreads();
-  if (s_last) for (int i = tid; i < 2 + 2 * G; i += 1024) __hip_atomic_store(&sync[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (s_last) for (int i = tid; i < 2 + G + n_items_total; i += 1024) __hip_atomic_store(&sync[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // false: not launched (the grid would not be resident at once, or y does not fit LDS) — the caller takes the launch-per-level path
 bool launch_chol_backsolve_fused(hipStream_t s, const double* Lp, const double* Winv, int ld, const int* bs_desc_dev, const int* chain_begin_dev,
