@@ -550,13 +550,14 @@ int finalize(bsgpu_ctx* c) {
     c->d_bs_desc = c->upload(c->plan.bs_desc);
     c->d_bs_desc_chain = c->d_rows_flat_chain = c->d_bs_upd = c->d_bs_upd_rows = nullptr;
     c->d_Winv = nullptr;
-    c->d_bs_chain_group = c->d_bs_grp_nchains = c->d_bs_grp_nitems = c->d_bs_items4 = c->d_bs_tile_updated = c->d_bs_sync = nullptr;
+    c->d_bs_chain_group = c->d_bs_grp_nchains = c->d_bs_grp_nitems = c->d_bs_items4 = c->d_bs_tile_updated = c->d_bs_sync = c->d_bs_order = nullptr;
     if (c->plan.bs_level_sync && !getenv("BSGPU_BACKSOLVE_LEGACY")) {
       c->d_bs_desc_chain = c->upload(c->plan.bs_desc_chain); c->d_rows_flat_chain = c->upload(c->plan.rows_flat_chain);
       c->d_bs_upd = c->upload(c->plan.bs_upd); c->d_bs_upd_rows = c->upload(c->plan.bs_upd_rows);
       c->d_bs_chain_group = c->upload(c->plan.bs_chain_group); c->d_bs_grp_nchains = c->upload(c->plan.bs_grp_nchains);
       c->d_bs_grp_nitems = c->upload(c->plan.bs_grp_nitems); c->d_bs_items4 = c->upload(c->plan.bs_items4);
       c->d_bs_tile_updated = c->upload(c->plan.bs_tile_updated);
+      c->d_bs_order = c->upload(c->plan.bs_order);
       c->d_bs_sync = c->upload(std::vector<int>(2 + c->plan.bs_grp_nchains.size() + c->plan.bs_items4.size() / 4 + 8, 0));
       c->d_Winv = c->alloc<double>((size_t)std::max(1, T) * 4096);
       if (c->d_Winv) HIPCHK(c, hipMemset(c->d_Winv, 0, sizeof(double) * (size_t)std::max(1, T) * 4096));   // (the blocks above the diagonal stay zero)

@@ -180,7 +180,8 @@ bool launch_chol_backsolve_fused(hipStream_t s, const double* Lp, const double* 
                                  const int* chain_end_dev, const int* rows_flat_dev, int n_chains, const int* chain_group_dev,
                                  const int* grp_nchains_dev, const int* grp_nitems_dev, int G, const int* items_dev, int n_items,
                                  const int* upd_rows_dev, const int* tile_updated_dev, double* y, int npad, int max_chain_len, int max_rows,
-                                 const double* y_init, const int* iperm_dev, int n_pose, double* y_tan, double* delta, int* sync_dev, double* scal);
+                                 const double* y_init, const int* iperm_dev, int n_pose, double* y_tan, double* delta, int* sync_dev, double* scal,
+                                 const int* order_dev);
 size_t chol_backsolve_chain_lds(int npad, int max_chain_len);
 void launch_marg_schur(hipStream_t s, const double* S, int ld, int rhs_row, const int* spos_dev, int n, int m, double rel_tol,
                        double* M, double* g, double* diag0, int* pivot_ok, double* status, double* A, double* b);

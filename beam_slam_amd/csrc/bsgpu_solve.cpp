@@ -229,7 +229,7 @@ void dense_backsolve(hipStream_t s, const DensePlan& P, const DenseDev& D, doubl
     if (launch_chol_backsolve_fused(s, D.Lp, D.Winv, ld, D.bs_desc_chain, D.chain_begin, D.chain_end, D.rows_flat_chain, (int)P.chain_begin.size(),
                                     D.bs_chain_group, D.bs_grp_nchains, D.bs_grp_nitems, G, D.bs_items4, (int)P.bs_upd.size() / 3 * (P.bs_upd_off.back() > 0 ? 1 : 0),
                                     D.bs_upd_rows, D.bs_tile_updated, y, P.npad, max_len, std::max(1, max_rows), rhs_row, iperm, n_pose, y_tan, delta,
-                                    D.bs_sync, D.scal))
+                                    D.bs_sync, D.scal, D.bs_order))
       return;
   }
   if (!single_root) launch_copy(s, rhs_row, y, (int64_t)P.T * 64, 64);   // (a single root chain copies it itself on the way)
@@ -260,7 +260,7 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
     const DenseDev D{c->d_perm, c->d_nreal, c->d_rows_flat, c->d_panels, c->d_Lp, c->d_Vinv,
                      c->d_bs_desc, c->d_chain_begin, c->d_chain_end, c->d_tile_sync, c->d_ftasks, c->d_fsync,
                      c->d_bs_desc_chain, c->d_rows_flat_chain, c->d_bs_upd, c->d_bs_upd_rows,
-                     c->d_bs_chain_group, c->d_bs_grp_nchains, c->d_bs_grp_nitems, c->d_bs_items4, c->d_bs_tile_updated, c->d_bs_sync, c->d_scal, c->d_Winv};
+                     c->d_bs_chain_group, c->d_bs_grp_nchains, c->d_bs_grp_nitems, c->d_bs_items4, c->d_bs_tile_updated, c->d_bs_sync, c->d_scal, c->d_Winv, c->d_bs_order};
     dense_factor(s, c->plan, D, c->d_S, c->d_scal);
     phase_mark(c, BSGPU_PHASE_FACTOR);
     dense_backsolve(s, c->plan, D, c->d_S, c->d_y, c->d_iperm, c->n_pose, c->d_ytan, c->d_delta);

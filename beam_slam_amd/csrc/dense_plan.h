@@ -330,6 +330,11 @@ struct DensePlan {
             bs_tile_updated[k] = 1;
           }
         }
+        bs_order.clear();
+        for (int g = 0; g < G; ++g) {
+          for (int c = bs_group_off[g]; c < bs_group_off[g + 1]; ++c) bs_order.push_back(c);
+          if (g + 1 < G) for (int i = bs_upd_off[g]; i < bs_upd_off[g + 1]; ++i) bs_order.push_back((int)chain_begin.size() + i);
+        }
         if (bs_items4.empty()) bs_items4.assign(4, 0);
         bs_group_maxrows.assign(G, 0);
         for (int k = 0; k < T; ++k) bs_group_maxrows[group_of[k]] = std::max(bs_group_maxrows[group_of[k]], bs_desc_chain[(size_t)k * kBsDescInts]);
@@ -348,7 +353,8 @@ struct DensePlan {
   // chip's bandwidth instead of at one workgroup's latency.
   bool bs_level_sync = false;
   std::vector<int> bs_desc_chain, rows_flat_chain, bs_upd, bs_upd_rows, bs_upd_off;
-  std::vector<int> bs_chain_group, bs_grp_nchains, bs_grp_nitems, bs_items4, bs_tile_updated;   // single-launch form (k_chol.hip chol_backsolve_fused_kernel)
+  std::vector<int> bs_chain_group, bs_grp_nchains, bs_grp_nitems, bs_items4, bs_tile_updated;
+  std::vector<int> bs_order;   // ticket -> workgroup role (chain index, or n_chains + item index) in dependency order: chains of group 0, items of phase 0, chains of group 1, ...   // single-launch form (k_chol.hip chol_backsolve_fused_kernel)
   std::vector<int> bs_group_maxrows;   // per group: the most own-chain row tiles of any of its panels (level-synchronous form)
   int n_steps() const { return (int)step_off.size() - 1; }
 };

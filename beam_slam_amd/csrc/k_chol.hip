@@ -1006,6 +1006,7 @@ struct BsFused {
   const int* tile_updated; // per tile: an earlier phase has written y there (else the start value is y_init)
   long long deadline;
   long long* ts;           // debugging: 16 wall-clock stamps per workgroup (BSGPU_BACKSOLVE_PROBE), or null
+  int ts_row;
 };
 template <bool Y_IN_LDS, int CH, bool DEEP, bool FUSED, bool USE_W>
 BSG_DEV void bs_chain_walk(const double* Lp, const double* Vinv /* USE_W: the tiles' full inverses, 64 x 64 row-major each */, int ld, const int* __restrict__ bs_desc, int b, int e,
@@ -1172,7 +1173,7 @@ BSG_DEV void bs_chain_walk(const double* Lp, const double* Vinv /* USE_W: the ti
   // (single launch) the first loads are out; now wait for the turn, then take the chain's start values: what the earlier phases left
   // in y (write-through stores, read past this CU's caches), or the rhs row where nothing has been applied yet
   int n_stamp = 4;
-  auto stamp = [&](int slot) { if (FUSED && F.ts && tid == 0) F.ts[(size_t)blockIdx.x * 16 + slot] = wall_clock64(); };
+  auto stamp = [&](int slot) { if (FUSED && F.ts && tid == 0) F.ts[(size_t)F.ts_row * 16 + slot] = wall_clock64(); };
   auto fused_enter = [&]() {
     if (!FUSED) return true;
     stamp(1);
@@ -1250,21 +1251,28 @@ __global__ __launch_bounds__(1024) void chol_backsolve_fused_kernel(const double
                                                                     const int* __restrict__ upd_rows, const int* __restrict__ tile_updated,
                                                                     double* y, int npad, int max_len, const double* __restrict__ y_init,
                                                                     const int* __restrict__ iperm, int n_pose, double* __restrict__ y_tan,
-                                                                    double* __restrict__ delta, int* sync, double* __restrict__ scal, long long* ts) {
+                                                                    double* __restrict__ delta, int* sync, double* __restrict__ scal, long long* ts, const int* __restrict__ order) {
   const int tid = threadIdx.x;
-  if (ts && tid == 0) ts[(size_t)blockIdx.x * 16] = wall_clock64();
   int* abort_w = sync; int* exited = sync + 1; int* done_chain = sync + 2; int* item_flag = sync + 2 + G;
   const int n_items_total = (int)gridDim.x - n_chains;
+  // roles are handed out by a ticket in dependency order (the k-th workgroup to START gets role order[k]): whoever a workgroup waits
+  // for holds an earlier ticket and is therefore running — no dead-lock even when the grid is not resident at once (several
+  // contexts sharing the GPU), as in chol_fused_kernel
+  __shared__ int s_role;
+  if (tid == 0) s_role = order[atomicAdd(sync + 2 + G + n_items_total, 1)];
+  __syncthreads();
+  const int bid = __builtin_amdgcn_readfirstlane(s_role);
+  if (ts && tid == 0) ts[(size_t)bid * 16] = wall_clock64();
   const long long deadline = (long long)wall_clock64() + kFusedTimeoutTicks;
-  if ((int)blockIdx.x < n_chains) {
-    const int ch = blockIdx.x, g = chain_group[ch];
+  if (bid < n_chains) {
+    const int ch = bid, g = chain_group[ch];
     BsFused F;
     F.abort_w = abort_w; F.deadline = deadline; F.tile_updated = tile_updated;
     int lo = 0;
     for (int q = 0; q + 1 < g; ++q) lo += grp_nitems[q];
     F.wait_flags = g > 0 ? item_flag : nullptr;
     F.wait_lo = lo; F.wait_hi = g > 0 ? lo + grp_nitems[g - 1] : 0;
-    F.done_word = done_chain + g; F.ts = ts;
+    F.done_word = done_chain + g; F.ts = ts; F.ts_row = bid;
     bs_chain_walk<true, CH, DEEP, true, true>(Lp, Winv, ld, bs_desc, chain_begin[ch], chain_end[ch], rows_flat, y, npad, max_len, y_init, iperm, n_pose,
                                         y_tan, delta, F);
   } else {
@@ -1272,7 +1280,7 @@ __global__ __launch_bounds__(1024) void chol_backsolve_fused_kernel(const double
     extern __shared__ __attribute__((aligned(16))) double dyn[];
     double* sp = dyn;                                   // 16 x 64
     int* s_ok = reinterpret_cast<int*>(dyn + 16 * NB);
-    const int* it = items + 4 * ((size_t)blockIdx.x - n_chains);
+    const int* it = items + 4 * ((size_t)bid - n_chains);
     const int k = it[0], off = it[1], n = it[2], phase = it[3] & 0xffff, first = it[3] >> 16;
     const int c = tid & 63, part = tid >> 6, c0 = k * NB;
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y, 0, (int)((size_t)npad * sizeof(double)), 0x00020000);
@@ -1285,10 +1293,10 @@ __global__ __launch_bounds__(1024) void chol_backsolve_fused_kernel(const double
 #pragma unroll
       for (int i = 0; i < 4; ++i) l[u][i] = ok ? Lp[(size_t)(r0[u] + i) * ld + c0 + c] : 0.0;
     }
-    if (ts && tid == 0) ts[(size_t)blockIdx.x * 16 + 1] = wall_clock64();
+    if (ts && tid == 0) ts[(size_t)bid * 16 + 1] = wall_clock64();
     if (tid == 0) *s_ok = wait_count(done_chain + phase, grp_nchains[phase], abort_w, deadline) ? 1 : 0;
     __syncthreads();
-    if (ts && tid == 0) ts[(size_t)blockIdx.x * 16 + 2] = wall_clock64();
+    if (ts && tid == 0) ts[(size_t)bid * 16 + 2] = wall_clock64();
     const bool ok_turn = __builtin_amdgcn_readfirstlane(*s_ok) != 0;
     if (ok_turn) {
       double acc = 0.0;
@@ -1317,8 +1325,8 @@ __global__ __launch_bounds__(1024) void chol_backsolve_fused_kernel(const double
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tid == 0) __hip_atomic_store(item_flag + ((int)blockIdx.x - n_chains), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (ts && tid == 0) ts[(size_t)blockIdx.x * 16 + 12] = wall_clock64();
+      if (tid == 0) __hip_atomic_store(item_flag + (bid - n_chains), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (ts && tid == 0) ts[(size_t)bid * 16 + 12] = wall_clock64();
     }
   }
   // leave: the last workgroup out clears the counters for the next solve
@@ -1329,14 +1337,15 @@ __global__ __launch_bounds__(1024) void chol_backsolve_fused_kernel(const double
     s_last = (atomicAdd(exited, 1) == (int)gridDim.x - 1) ? 1 : 0;
   }
   __syncthreads();
-  if (s_last) for (int i = tid; i < 2 + G + n_items_total; i += 1024) __hip_atomic_store(&sync[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (s_last) for (int i = tid; i < 2 + G + n_items_total + 1; i += 1024) __hip_atomic_store(&sync[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // false: not launched (the grid would not be resident at once, or y does not fit LDS) — the caller takes the launch-per-level path
 bool launch_chol_backsolve_fused(hipStream_t s, const double* Lp, const double* Winv, int ld, const int* bs_desc_dev, const int* chain_begin_dev,
                                  const int* chain_end_dev, const int* rows_flat_dev, int n_chains, const int* chain_group_dev,
                                  const int* grp_nchains_dev, const int* grp_nitems_dev, int G, const int* items_dev, int n_items,
                                  const int* upd_rows_dev, const int* tile_updated_dev, double* y, int npad, int max_chain_len, int max_rows,
-                                 const double* y_init, const int* iperm_dev, int n_pose, double* y_tan, double* delta, int* sync_dev, double* scal) {
+                                 const double* y_init, const int* iperm_dev, int n_pose, double* y_tan, double* delta, int* sync_dev, double* scal,
+                                 const int* order_dev) {
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0; hipDeviceProp_t pr;
@@ -1345,7 +1354,9 @@ bool launch_chol_backsolve_fused(hipStream_t s, const double* Lp, const double* 
   }
   static const bool off = getenv("BSGPU_BACKSOLVE_FUSED") && atoi(getenv("BSGPU_BACKSOLVE_FUSED")) == 0;
   const size_t lds = chol_backsolve_chain_lds(npad, max_chain_len) + 16;
-  if (off || !Winv || n_chains + n_items > n_cu || lds > (size_t)160 * 1024 - 256 /* (4 bytes of static LDS) */ || getenv("BSGPU_BACKSOLVE_GLOBAL_Y")) return false;
+  (void)n_cu;   // (roles are ticketed in dependency order: the grid need not be resident at once; beyond ~2 workgroups per CU the
+                // launch-per-level form is the better one)
+  if (off || !Winv || !order_dev || n_chains + n_items > 2 * n_cu || lds > (size_t)160 * 1024 - 256 /* (4 bytes of static LDS) */ || getenv("BSGPU_BACKSOLVE_GLOBAL_Y")) return false;
   const bool deep = max_rows > 0 && max_rows <= kBsChunkDeep && max_chain_len > 1;
   // BSGPU_BACKSOLVE_PROBE=<file>: the 20th solve of the process is stamped (100 MHz wall clock): per workgroup start / loads out /
   // turn / start values / after each panel / done
@@ -1357,11 +1368,11 @@ bool launch_chol_backsolve_fused(hipStream_t s, const double* Lp, const double* 
   if (deep)
     hipLaunchKernelGGL((chol_backsolve_fused_kernel<kBsChunkDeep, true>), dim3(n_chains + n_items), dim3(1024), lds, s, Lp, Winv, ld, bs_desc_dev,
                        chain_begin_dev, chain_end_dev, rows_flat_dev, n_chains, chain_group_dev, grp_nchains_dev, grp_nitems_dev, G, items_dev,
-                       upd_rows_dev, tile_updated_dev, y, npad, max_chain_len, y_init, iperm_dev, n_pose, y_tan, delta, sync_dev, scal, ts);
+                       upd_rows_dev, tile_updated_dev, y, npad, max_chain_len, y_init, iperm_dev, n_pose, y_tan, delta, sync_dev, scal, ts, order_dev);
   else
     hipLaunchKernelGGL((chol_backsolve_fused_kernel<kBsChunk, false>), dim3(n_chains + n_items), dim3(1024), lds, s, Lp, Winv, ld, bs_desc_dev,
                        chain_begin_dev, chain_end_dev, rows_flat_dev, n_chains, chain_group_dev, grp_nchains_dev, grp_nitems_dev, G, items_dev,
-                       upd_rows_dev, tile_updated_dev, y, npad, max_chain_len, y_init, iperm_dev, n_pose, y_tan, delta, sync_dev, scal, ts);
+                       upd_rows_dev, tile_updated_dev, y, npad, max_chain_len, y_init, iperm_dev, n_pose, y_tan, delta, sync_dev, scal, ts, order_dev);
   if (ts) {
     std::vector<long long> h((size_t)16 * grid);
     (void)hipStreamSynchronize(s);
