@@ -337,10 +337,13 @@ __global__ __launch_bounds__(64) void pairs_kernel(int n_seg, const int* __restr
   extern __shared__ __attribute__((aligned(16))) double2 slab[];   // [64][6] A_a | [64][6] A_b | [64][4] C_a | [64][3] C_b | 2 x 64 ints
   double2* sAa = slab; double2* sAb = sAa + 64 * 6; double2* sCa = sAb + 64 * 6; double2* sCb = sCa + 64 * 4;
   int* sfa = reinterpret_cast<int*>(sCb + 64 * 3); int* sfb = sfa + 64;
+  // (the entry indices of the NEXT stride are requested while this one is gathered and summed: one round trip less per stride)
+  int fa_n = ent_fa[min(beg + lane, end - 1)], fb_n = ent_fb[min(beg + lane, end - 1)];
   for (int e0 = beg; e0 < end; e0 += 64) {
     const int e = e0 + lane;
     const bool live = e < end;
-    const int fa = live ? ent_fa[e] : ent_fa[beg], fb = live ? ent_fb[e] : ent_fb[beg];
+    const int fa = fa_n, fb = fb_n;
+    if (e0 + 64 < end) { fa_n = ent_fa[min(e + 64, end - 1)]; fb_n = ent_fb[min(e + 64, end - 1)]; }
     sfa[lane] = fa; sfb[lane] = fb;
     __builtin_amdgcn_wave_barrier();
     {
