@@ -265,10 +265,14 @@ template <bool EXT, bool WITH_J>
 __global__ __launch_bounds__(128) void relpose_kernel(SmallGroup g, const double* __restrict__ x,
                                                       const DevLoss* __restrict__ losses,
                                                       double* __restrict__ cost_part) {
-  const int f = blockIdx.x * 128 + threadIdx.x;
-  if (f >= g.n) return;
   constexpr int NV = EXT ? 6 : 4;
   constexpr int TW = 3 * NV;
+  // (Jacobian rows leave through LDS: a lane per factor storing its 864-byte Jacobian 8 bytes at a time touches 64 cache lines per
+  // store instruction — 44 us for C3's 20 000 factors; see the end of the kernel)
+  __shared__ __attribute__((aligned(16))) double sJ[WITH_J ? 2 * 64 * TW : 2];
+  const int f_raw = blockIdx.x * 128 + threadIdx.x;
+  const bool live = f_raw < g.n;
+  const int f = live ? f_raw : g.n - 1;   // (idle lanes of the last workgroup redo the last factor and store nothing)
   const int* xo = g.xoff + (size_t)f * NV;
   const int* to = g.toff + (size_t)f * NV;
   const double* c = g.consts + (size_t)f * 43;
@@ -328,10 +332,12 @@ __global__ __launch_bounds__(128) void relpose_kernel(SmallGroup g, const double
   }
   double sc, cost;
   finish_small(g, f, losses, s, &sc, &cost);
-  cost_part[f] = cost;
+  if (live) cost_part[f] = cost;
   if (!WITH_J) return;
+  if (live) {
 #pragma unroll
-  for (int i = 0; i < 6; ++i) g.r[(size_t)f * 6 + i] = r[i] * sc;
+    for (int i = 0; i < 6; ++i) g.r[(size_t)f * 6 + i] = r[i] * sc;
+  }
   // derivatives w.r.t. the SENSOR poses: columns (p_s1, th_s1, p_s2, th_s2)
   double Jr[9];
   so3_jr_inv(e + 3, Jr);
@@ -408,17 +414,30 @@ __global__ __launch_bounds__(128) void relpose_kernel(SmallGroup g, const double
         (void)ee;
       }
   }
-  double* Jo = g.J + (size_t)f * 6 * TW;
+  // row i of every factor of the wave -> LDS -> 16-byte stores, TW / 2 lanes per factor (the row's 144 / 96 bytes are contiguous in J)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* sw = sJ + wave * (64 * TW);
+  const int f0 = blockIdx.x * 128 + wave * 64;
+  const int cnt = min(64, g.n - f0);
+  typedef double d2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
-  for (int col = 0; col < TW; ++col) {
-    const bool is_const = to[col / 3] < 0;
+  for (int i = 0; i < 6; ++i) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int col = 0; col < TW; ++col) {
+      const bool is_const = to[col / 3] < 0;
       double a = 0.0;
 #pragma unroll
       for (int k = 0; k < 6; ++k) a += A[6 * i + k] * Je[k * TW + col];
-      Jo[i * TW + col] = is_const ? 0.0 : a * sc;
+      sw[lane * TW + col] = is_const ? 0.0 : a * sc;
     }
+    __builtin_amdgcn_wave_barrier();
+    const d2_t* src = reinterpret_cast<const d2_t*>(sw);
+#pragma unroll
+    for (int it = 0; it < TW / 2; ++it) {
+      const int p = it * 64 + lane, fi = p / (TW / 2), piece = p - fi * (TW / 2);
+      if (fi < cnt) *reinterpret_cast<d2_t*>(g.J + ((size_t)(f0 + fi) * 6 + i) * TW + 2 * piece) = src[p];
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
