@@ -490,11 +490,16 @@ __global__ __launch_bounds__(256) void backsub_mcc_kernel(int n_lm, int n_lm_gro
     int beg = 0, end = 0;
     if (valid) { beg = lm_start[l]; end = lm_start[l + 1]; }
     double a0 = 0, a1 = 0, a2 = 0;
-    for (int f = beg + sub; f < end; f += 8) {
+    // (A y_cam of the lane's first two factors stays in registers for the second pass: a track longer than 16 views is rare, and
+    // recomputing it costs the row again plus a three-deep chain of dependent gathers — camera pose id, its tangent offsets, y)
+    double jk0[2] = {0.0, 0.0}, jk1[2] = {0.0, 0.0};
+    int it = 0;
+    for (int f = beg + sub; f < end; f += 8, ++it) {
       const double* C = CR + (size_t)f * 8;
       const int cp = cam_pose[f];
       double j0, j1;
       pose_part(J + (size_t)f * kJAStride, cp_tq[cp], cp_tp[cp], y_pose, j0, j1);
+      if (it == 0) { jk0[0] = j0; jk1[0] = j1; } else if (it == 1) { jk0[1] = j0; jk1[1] = j1; }
       a0 += C[0] * j0 + C[3] * j1; a1 += C[1] * j0 + C[4] * j1; a2 += C[2] * j0 + C[5] * j1;
     }
 #pragma unroll
@@ -507,12 +512,13 @@ __global__ __launch_bounds__(256) void backsub_mcc_kernel(int n_lm, int n_lm_gro
       const double y1 = Li[2] * w1 + Li[4] * w2;
       const double y2 = Li[5] * w2;
       if (sub == 0) { const int to = n_pose + 3 * l; delta[to] = -y0; delta[to + 1] = -y1; delta[to + 2] = -y2; }
-      for (int f = beg + sub; f < end; f += 8) {
-        const double* Jf = J + (size_t)f * kJAStride;
+      it = 0;
+      for (int f = beg + sub; f < end; f += 8, ++it) {
         const double* Bf = JB + (size_t)f * 6;
-        const int cp = cam_pose[f];
         double j0, j1;
-        pose_part(Jf, cp_tq[cp], cp_tp[cp], y_pose, j0, j1);
+        if (it == 0) { j0 = jk0[0]; j1 = jk1[0]; }
+        else if (it == 1) { j0 = jk0[1]; j1 = jk1[1]; }
+        else { const int cp = cam_pose[f]; pose_part(J + (size_t)f * kJAStride, cp_tq[cp], cp_tp[cp], y_pose, j0, j1); }
         const double d0 = -(j0 + Bf[0] * y0 + Bf[1] * y1 + Bf[2] * y2), d1 = -(j1 + Bf[3] * y0 + Bf[4] * y1 + Bf[5] * y2);
         const double2 rf = r[f];
         acc -= d0 * (rf.x + 0.5 * d0) + d1 * (rf.y + 0.5 * d1);
