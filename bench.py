@@ -149,7 +149,7 @@ def main():
                         roofline["traffic_source"] = os.path.relpath(pmc, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
             ms_f, flops = prof["factor"]
             tf = flops / (ms_f * 1e-3) / 1e12
-            roofline_mfma = {"bound": "mfma", "kernel": "chol_fused_kernel (+ chol_backsolve_chain_kernel: %.1f us)" % (1e3 * prof["backsolve"][0]),
+            roofline_mfma = {"bound": "mfma", "kernel": "chol_fused_kernel (+ chol_backsolve_fused_kernel: %.1f us)" % (1e3 * prof["backsolve"][0]),
                              "achieved": round(tf, 3), "peak": MFMA_F64_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F64_PEAK_TF, 4),
                              "flops_per_launch": int(flops), "ms_per_launch": round(ms_f, 5),
                              "note": "dependent chain of ~13 panel steps (64-pivot scalar chain each): latency-bound, not MFMA-bound; DESIGN.md §3.2"}
