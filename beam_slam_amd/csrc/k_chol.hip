@@ -76,7 +76,7 @@ BSG_DEV double fast_rsqrt(double d) {
 // diagonal blocks go to sV (4 x 16 x 16, row-major, lower), the 64 reciprocal pivots to sInvD.
 // Whole workgroup (256 threads).  Columns >= nreal (rhs row, padding) are unit pivots.
 // Returns (in every thread) whether a non-positive / non-finite pivot was met.
-template <bool PROBE = false>
+template <bool PROBE = false, int NT = 256>
 BSG_DEV bool potrf64_lds(double* sC, double* sV, double* sInvD /* 64 */, int tid, int nreal, long long* ts = nullptr) {
   const int lane = tid & 63, wave = tid >> 6;
   bool bad = false;
@@ -135,7 +135,7 @@ BSG_DEV bool potrf64_lds(double* sC, double* sV, double* sInvD /* 64 */, int tid
     // (3) trailing update C_rc -= X_rb X_cb^T for b < c <= r <= 3 (MFMA, one 16x16 block per wave pass)
     const int nb = 3 - b;
     const int npairs = nb * (nb + 1) / 2;
-    for (int p = wave; p < npairs; p += 4) {
+    for (int p = wave; p < npairs; p += NT / 64) {
       int rr = 0, acc_cnt = 0;
       while (acc_cnt + rr + 1 <= p) { acc_cnt += rr + 1; ++rr; }
       const int cc = p - acc_cnt;
@@ -149,7 +149,7 @@ BSG_DEV bool potrf64_lds(double* sC, double* sV, double* sInvD /* 64 */, int tid
     stamp();
   }
   // inverses of the four diagonal blocks: wave w, lane c < 16 solves L_ww v = e_c
-  if (lane < 16) {
+  if (wave < 4 && lane < 16) {
     const double* D = sC + (16 * wave) * LDT + 16 * wave;
     double v[16];
 #pragma unroll
@@ -168,9 +168,10 @@ BSG_DEV bool potrf64_lds(double* sC, double* sV, double* sInvD /* 64 */, int tid
 }
 
 // columns >= nreal of a diagonal tile (rhs row, padding) become unit pivots with nothing below
+template <int NT = 256>
 BSG_DEV void mask_unreal_columns(double* sC, int nreal, int tid) {
   if (nreal >= NB) return;
-  for (int i = tid; i < NB * NB; i += 256) {
+  for (int i = tid; i < NB * NB; i += NT) {
     const int r = i >> 6, c = i & 63;
     if (c >= nreal && c <= r) sC[r * LDT + c] = (r == c) ? 1.0 : 0.0;
   }
@@ -561,11 +562,12 @@ BSG_DEV bool wait_flags(const int* flags, int lo, int hi, int* abort_w, long lon
   }
 }
 // L_tt, its block inverses and reciprocal pivots to Lp / Vinv, write-through (read by other workgroups of this launch)
+template <int NT = 256>
 BSG_DEV void write_factor_sc1(__amdgpu_buffer_rsrc_t rLp, __amdgpu_buffer_rsrc_t rV, int ld, int t, const double* sC, const double* sV,
                               const double* sInvD, int tid) {
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int i = tid + 256 * q;
+  for (int q = 0; q < 2048 / NT; ++q) {
+    const int i = tid + NT * q;
     const int r = i >> 5, c2 = (i & 31) * 2;
     const unsigned at = (unsigned)(((size_t)(t * NB + r) * ld + t * NB + c2) * sizeof(double));
     if (c2 <= r) {   // (the element right of the diagonal rides along: the strictly upper part of the tile is never read)
@@ -573,8 +575,8 @@ BSG_DEV void write_factor_sc1(__amdgpu_buffer_rsrc_t rLp, __amdgpu_buffer_rsrc_t
     }
   }
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int i = (tid + 256 * q) * 2;
+  for (int q = 0; q < 512 / NT; ++q) {
+    const int i = (tid + NT * q) * 2;
     st16_sc1(rV, (unsigned)(((size_t)t * kVinvStride + i) * sizeof(double)), *reinterpret_cast<const double2*>(&sV[i]));
   }
   if (tid < NB) st8_sc1(rV, (unsigned)(((size_t)t * kVinvStride + 1024 + tid) * sizeof(double)), sInvD[tid]);
@@ -631,12 +633,13 @@ BSG_DEV void tile_inverse_w(const double* sL, const double* sV, double* sW, int 
   }
 }
 // ... and out to Winv[t] (row-major 64 x 64, zero above the diagonal blocks): read by a later launch, plain stores
+template <int NT = 256>
 BSG_DEV void publish_tile_inverse(const double* sL, const double* sV, double* sW, double* __restrict__ Wt, int tid) {
-  tile_inverse_w(sL, sV, sW, tid & 63, tid >> 6);
+  if ((tid >> 6) < 4) tile_inverse_w(sL, sV, sW, tid & 63, tid >> 6);
   __syncthreads();
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int i = tid + 256 * q;
+  for (int q = 0; q < 2048 / NT; ++q) {
+    const int i = tid + NT * q;
     const int r = i >> 5, c2 = (i & 31) * 2;
     double2 v = *reinterpret_cast<const double2*>(&sW[r * LDT + c2]);
     if ((c2 >> 4) > (r >> 4)) { v.x = 0.0; v.y = 0.0; }
@@ -660,8 +663,12 @@ struct FusedCtx {
 // around the barriers became a divergent one and a workgroup span for ever inside the potrf-only branch (found with rocgdb,
 // scripts/gdb_hang.sh); called out of line (noinline) it was correct but ~2 us slower per task (pointers through scratch, worse
 // register allocation of the potrf).  One task per workgroup needs no loop at all.
-template <bool PROBE>
+// NT threads: 256, or 512 — the rank-64 update is then two 16x16 blocks per wave instead of four, the two panel strips of an
+// off-diagonal task are solved side by side and the trailing updates inside the 64x64 potrf have eight waves
+template <bool PROBE, int NT>
 BSG_DEV bool chol_fused_task(const FusedCtx& C, int t, double* smem, long long t_deq) {
+  constexpr int NQ = 2048 / NT;          // 16-byte pieces of a 64x64 tile per thread
+  constexpr int TPW = 16 / (NT / 64);    // 16x16 blocks of the update per wave
   double* const S = uniform_ptr(C.S); double* const Lp = uniform_ptr(C.Lp); double* const scal = uniform_ptr(C.scal);
   const int* const nreal = uniform_ptr(C.nreal); const FusedTask* const tasks = uniform_ptr(C.tasks);
   const int ld = __builtin_amdgcn_readfirstlane(C.ld);
@@ -685,6 +692,7 @@ BSG_DEV bool chol_fused_task(const FusedCtx& C, int t, double* smem, long long t
   const __amdgpu_buffer_rsrc_t rLp = __builtin_amdgcn_make_buffer_rsrc(Lp, 0, (int)((size_t)ld * ld * sizeof(double)), 0x00020000);
   const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(C.Vinv), 0, (int)((size_t)__builtin_amdgcn_readfirstlane(C.n_vinv_tiles) * kVinvStride * sizeof(double)), 0x00020000);
   const int crow = lane >> 4, ccol = lane & 15;
+  const int rs = wave & 3, tt0 = (wave >> 2) * TPW;   // this wave's row strip and first column block of the update
   bool ok_all = true;
     auto stamp = [&](int slot) {
       if (PROBE && tid == 0) probe_ts[(size_t)t * 8 + slot] = wall_clock64();
@@ -696,32 +704,32 @@ BSG_DEV bool chol_fused_task(const FusedCtx& C, int t, double* smem, long long t
     const int k = tk.k;
     if (tk.flags & kFusedPotrfOnly) {
       // a tile nothing updates (the head of a piece): as assembled, from the previous launches
-      double2 v[8];
+      double2 v[NQ];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int i = tid + 256 * q;
+      for (int q = 0; q < NQ; ++q) {
+        const int i = tid + NT * q;
         v[q] = *reinterpret_cast<const double2*>(&S[(size_t)(k * NB + (i >> 5)) * ld + k * NB + (i & 31) * 2]);
       }
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int i = tid + 256 * q;
+      for (int q = 0; q < NQ; ++q) {
+        const int i = tid + NT * q;
         const int r = i >> 5, c2 = (i & 31) * 2;
         sXj[r * LDT + c2] = (c2 <= r) ? v[q].x : 0.0;
         sXj[r * LDT + c2 + 1] = (c2 + 1 <= r) ? v[q].y : 0.0;
       }
       __syncthreads();
-      if (nreal[k] < NB) { mask_unreal_columns(sXj, nreal[k], tid); __syncthreads(); }
+      if (nreal[k] < NB) { mask_unreal_columns<NT>(sXj, nreal[k], tid); __syncthreads(); }
       stamp(4);
-      const bool bad = potrf64_lds(sXj, sV, sInvD, tid, nreal[k]);
+      const bool bad = potrf64_lds<false, NT>(sXj, sV, sInvD, tid, nreal[k]);
       stamp(5);
       if (bad && tid == 0) scal[SC_CHOL_FAIL] = 1.0;
-      write_factor_sc1(rLp, rV, ld, k, sXj, sV, sInvD, tid);
+      write_factor_sc1<NT>(rLp, rV, ld, k, sXj, sV, sInvD, tid);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) __hip_atomic_store(&potrf_done[k], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       stamp(6);
       // (nobody waits for this: the tile's full inverse, for the back-substitution)
-      if (Winv && k < T) publish_tile_inverse(sXj, sV, sXi, Winv + (size_t)k * NB * NB, tid);
+      if (Winv && k < T) publish_tile_inverse<NT>(sXj, sV, sXi, Winv + (size_t)k * NB * NB, tid);
     } else {
     const int ti = tk.ti, tj = tk.tj;
     const bool diag = ti == tj;
@@ -741,48 +749,53 @@ BSG_DEV bool chol_fused_task(const FusedCtx& C, int t, double* smem, long long t
     stamp(2);
     const int ri = ti * NB, rj = tj * NB, c0 = k * NB;
     {
-      double2 vXi[8], vL[8], vXj[8], vV[2];
+      double2 vXi[NQ], vL[NQ], vXj[NQ], vV[512 / NT];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int i = tid + 256 * q;
+      for (int q = 0; q < NQ; ++q) {
+        const int i = tid + NT * q;
         const int r = i >> 5, c2 = (i & 31) * 2;
         vXi[q] = ld16_sc1(rS, (unsigned)(((size_t)(ri + r) * ld + c0 + c2) * sizeof(double)));
         vL[q] = ld16_sc1(rLp, (unsigned)(((size_t)(c0 + r) * ld + c0 + c2) * sizeof(double)));
         vXj[q] = ld16_sc1(rS, (unsigned)(((size_t)(rj + r) * ld + c0 + c2) * sizeof(double)));
       }
 #pragma unroll
-      for (int q = 0; q < 2; ++q) vV[q] = ld16_sc1(rV, (unsigned)(((size_t)k * kVinvStride + (tid + 256 * q) * 2) * sizeof(double)));
+      for (int q = 0; q < 512 / NT; ++q) vV[q] = ld16_sc1(rV, (unsigned)(((size_t)k * kVinvStride + (tid + NT * q) * 2) * sizeof(double)));
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int i = tid + 256 * q;
+      for (int q = 0; q < NQ; ++q) {
+        const int i = tid + NT * q;
         const int r = i >> 5, c2 = (i & 31) * 2;
         *reinterpret_cast<double2*>(&sXi[r * LDT + c2]) = vXi[q];
         *reinterpret_cast<double2*>(&sL[r * LDT + c2]) = vL[q];
         *reinterpret_cast<double2*>(&sXj[r * LDT + c2]) = vXj[q];
       }
 #pragma unroll
-      for (int q = 0; q < 2; ++q) *reinterpret_cast<double2*>(&sV[(tid + 256 * q) * 2]) = vV[q];
+      for (int q = 0; q < 512 / NT; ++q) *reinterpret_cast<double2*>(&sV[(tid + NT * q) * 2]) = vV[q];
     }
     __syncthreads();
     stamp(3);
-    trsm_tile_t(sXi, sL, sV, lane, wave);
-    if (!diag) trsm_tile_t(sXj, sL, sV, lane, wave);
+    if (NT == 256) {
+      trsm_tile_t(sXi, sL, sV, lane, wave);
+      if (!diag) trsm_tile_t(sXj, sL, sV, lane, wave);
+    } else {   // (waves 0-3: the strips of X_i; waves 4-7: those of X_j, at the same time)
+      if (wave < 4) trsm_tile_t(sXi, sL, sV, lane, wave);
+      else if (!diag) trsm_tile_t(sXj, sL, sV, lane, wave - 4);
+    }
     __syncthreads();
     stamp(4);
     const double* Xj = diag ? sXi : sXj;
-    double4_t acc[4];
+    double4_t acc[TPW];
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) acc[tt] = double4_t{0.0, 0.0, 0.0, 0.0};
+    for (int u = 0; u < TPW; ++u) acc[u] = double4_t{0.0, 0.0, 0.0, 0.0};
     if (do_update) {
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt)
-        acc[tt] = mfma_abt<64>(acc[tt], sXi + (16 * wave) * LDT, LDT, Xj + (16 * tt) * LDT, LDT, -1.0, lane);
+      for (int u = 0; u < TPW; ++u)
+        acc[u] = mfma_abt<64>(acc[u], sXi + (16 * rs) * LDT, LDT, Xj + (16 * (tt0 + u)) * LDT, LDT, -1.0, lane);
     }
     if (diag) {
       // the L panel of this row tile, for the back-substitution (a later launch: plain stores)
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int i = tid + 256 * q;
+      for (int q = 0; q < NQ; ++q) {
+        const int i = tid + NT * q;
         const int r = i >> 5, c2 = (i & 31) * 2;
         *reinterpret_cast<double2*>(&Lp[(size_t)(ri + r) * ld + c0 + c2]) = *reinterpret_cast<const double2*>(&sXi[r * LDT + c2]);
       }
@@ -801,27 +814,27 @@ BSG_DEV bool chol_fused_task(const FusedCtx& C, int t, double* smem, long long t
     stamp(5);
     if (do_update) {
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt)
+      for (int u = 0; u < TPW; ++u)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg)
-          acc[tt][reg] += ld8_sc1(rS, (unsigned)(((size_t)(ri + 16 * wave + crow + 4 * reg) * ld + rj + 16 * tt + ccol) * sizeof(double)));
+          acc[u][reg] += ld8_sc1(rS, (unsigned)(((size_t)(ri + 16 * rs + crow + 4 * reg) * ld + rj + 16 * (tt0 + u) + ccol) * sizeof(double)));
       if (!factor_now) {
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
+        for (int u = 0; u < TPW; ++u)
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg)
-            st8_sc1(rS, (unsigned)(((size_t)(ri + 16 * wave + crow + 4 * reg) * ld + rj + 16 * tt + ccol) * sizeof(double)), acc[tt][reg]);
+            st8_sc1(rS, (unsigned)(((size_t)(ri + 16 * rs + crow + 4 * reg) * ld + rj + 16 * (tt0 + u) + ccol) * sizeof(double)), acc[u][reg]);
       }
     }
     if (factor_now) {
       double* sC = sXj;
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt) store_d(sC + (16 * wave) * LDT + 16 * tt, LDT, lane, acc[tt]);
+      for (int u = 0; u < TPW; ++u) store_d(sC + (16 * rs) * LDT + 16 * (tt0 + u), LDT, lane, acc[u]);
       __syncthreads();
-      if (nreal[ti] < NB) { mask_unreal_columns(sC, nreal[ti], tid); __syncthreads(); }
-      const bool bad = potrf64_lds(sC, sV, sInvD, tid, nreal[ti]);
+      if (nreal[ti] < NB) { mask_unreal_columns<NT>(sC, nreal[ti], tid); __syncthreads(); }
+      const bool bad = potrf64_lds<false, NT>(sC, sV, sInvD, tid, nreal[ti]);
       if (bad && tid == 0) scal[SC_CHOL_FAIL] = 1.0;
-      write_factor_sc1(rLp, rV, ld, ti, sC, sV, sInvD, tid);
+      write_factor_sc1<NT>(rLp, rV, ld, ti, sC, sV, sInvD, tid);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -830,15 +843,15 @@ BSG_DEV bool chol_fused_task(const FusedCtx& C, int t, double* smem, long long t
       if (factor_now) __hip_atomic_store(&potrf_done[ti], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     stamp(6);
-    if (factor_now && Winv) publish_tile_inverse(sXj, sV, sXi, Winv + (size_t)ti * NB * NB, tid);
+    if (factor_now && Winv) publish_tile_inverse<NT>(sXj, sV, sXi, Winv + (size_t)ti * NB * NB, tid);
     }   // turn_ok
     }   // dependencies met
     }   // update task
   return ok_all;
 }
 
-template <bool PROBE>
-__global__ __launch_bounds__(256) void chol_fused_kernel(double* __restrict__ S, double* __restrict__ Lp, int ld,
+template <bool PROBE, int NT>
+__global__ __launch_bounds__(NT) void chol_fused_kernel(double* __restrict__ S, double* __restrict__ Lp, int ld,
                                                           const FusedTask* __restrict__ tasks, int n_tasks,
                                                           const int* __restrict__ nreal, double* __restrict__ Vinv, int n_vinv_tiles,
                                                           double* __restrict__ scal, int* sync, int n_sync_words, double* Winv,
@@ -863,7 +876,7 @@ __global__ __launch_bounds__(256) void chol_fused_kernel(double* __restrict__ S,
   if (tid == 0) s_ctl[0] = atomicAdd(head, 1);
   __syncthreads();
   const int t = __builtin_amdgcn_readfirstlane(s_ctl[0]);
-  if (t < n_tasks) (void)chol_fused_task<PROBE>(C, t, smem, t_deq);
+  if (t < n_tasks) (void)chol_fused_task<PROBE, NT>(C, t, smem, t_deq);
   // leave: the last workgroup out re-zeroes the queue and the counters for the next factorisation
   __syncthreads();
   if (PROBE && trace && tid == 0) trace[blockIdx.x * 2] = 100;
@@ -874,9 +887,10 @@ __global__ __launch_bounds__(256) void chol_fused_kernel(double* __restrict__ S,
   __syncthreads();
   if (__builtin_amdgcn_readfirstlane(s_ctl[2]) != 0) {
     const int nw = n_sync_words < 0 ? -n_sync_words : n_sync_words;
-    for (int i = tid; i < nw; i += 256) __hip_atomic_store(&sync[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = tid; i < nw; i += NT) __hip_atomic_store(&sync[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
+constexpr int kFusedThreads = 512;
 constexpr size_t kFusedLds = sizeof(double) * (3 * NB * LDT + 4 * 256 + 4 * 16 * 17 + 64) + 16;
 
 void launch_chol_fused(hipStream_t s, double* S, double* Lp, int ld, const FusedTask* tasks_dev, int n_tasks, const int* nreal_dev,
@@ -938,7 +952,7 @@ void launch_chol_fused(hipStream_t s, double* S, double* Lp, int ld, const Fused
     trace_grid = grid;
     for (int i = 0; i < 2048; ++i) trace[i] = -1;
     fprintf(stderr, "[chol trace] launch: %d tasks, grid %d, ld %d\n", n_tasks, grid, ld);
-    hipLaunchKernelGGL(chol_fused_kernel<false>, dim3(grid), dim3(256), kFusedLds, s, S, Lp, ld, tasks_dev, n_tasks, nreal_dev, Vinv, ld / NB - 1,
+    hipLaunchKernelGGL((chol_fused_kernel<false, kFusedThreads>), dim3(grid), dim3(kFusedThreads), kFusedLds, s, S, Lp, ld, tasks_dev, n_tasks, nreal_dev, Vinv, ld / NB - 1,
                        scal, sync_dev, n_sync_words, Winv, ts_dummy, trace);
     return;
   }
@@ -948,7 +962,7 @@ void launch_chol_fused(hipStream_t s, double* S, double* Lp, int ld, const Fused
     std::vector<FusedTask> ht(n_tasks);
     if (hipMalloc((void**)&ts, sizeof(long long) * h.size()) == hipSuccess) {
       (void)hipMemset(ts, 0, sizeof(long long) * h.size());
-      hipLaunchKernelGGL(chol_fused_kernel<true>, dim3(grid), dim3(256), kFusedLds, s, S, Lp, ld, tasks_dev, n_tasks, nreal_dev, Vinv, ld / NB - 1,
+      hipLaunchKernelGGL((chol_fused_kernel<true, kFusedThreads>), dim3(grid), dim3(kFusedThreads), kFusedLds, s, S, Lp, ld, tasks_dev, n_tasks, nreal_dev, Vinv, ld / NB - 1,
                          scal, sync_dev, n_sync_words, Winv, ts);
       (void)hipStreamSynchronize(s);
       (void)hipMemcpy(h.data(), ts, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
@@ -966,7 +980,7 @@ void launch_chol_fused(hipStream_t s, double* S, double* Lp, int ld, const Fused
       return;
     }
   }
-  hipLaunchKernelGGL(chol_fused_kernel<false>, dim3(grid), dim3(256), kFusedLds, s, S, Lp, ld, tasks_dev, n_tasks, nreal_dev, Vinv, ld / NB - 1, scal,
+  hipLaunchKernelGGL((chol_fused_kernel<false, kFusedThreads>), dim3(grid), dim3(kFusedThreads), kFusedLds, s, S, Lp, ld, tasks_dev, n_tasks, nreal_dev, Vinv, ld / NB - 1, scal,
                      sync_dev, n_sync_words, Winv, nullptr);
 }
 
@@ -1470,8 +1484,8 @@ void chol_prepare() {
                             160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_fused_kernel<kBsChunkDeep, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_fused_kernel<kBsChunk, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_fused_kernel<false, kFusedThreads>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_fused_kernel<true, kFusedThreads>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds);
 }
 
 }  // namespace bsg
