@@ -143,9 +143,15 @@ void launch_imu_eval(hipStream_t s, const SmallGroup& delta, const SmallGroup& p
                      double* part_delta, double* part_prior);
 void launch_small_eval(hipStream_t s, const SmallGroup& g, const double* x, const DevLoss* losses, bool with_J,
                        double* cost_part /* n doubles: per-factor cost */);
+// what an LM step clears before its assembly (zero_tiles_multi_kernel's arguments); rides in the landmark launch as extra workgroups
+struct ZeroStep {
+  double* S = nullptr; int ld = 0; const int* tiles = nullptr; int n_tiles = 0;
+  double* a = nullptr; int na = 0; double* b = nullptr; int nb = 0; double* c = nullptr; int nc = 0;
+  double* radius_slot = nullptr; double radius = 0.0;
+};
 void launch_landmark(hipStream_t s, const Visual& v, int n_pose, const double* radius_ptr, int compute_scale,
                      int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* scale, double* dcl,
-                     double* grad);
+                     double* grad, const ZeroStep* zero = nullptr, double radius_val = 0.0);
 void launch_pairs(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm,
                   bool grad_only = false);
 void launch_small_assemble_set(hipStream_t s, const SmallGroup* groups, int n_groups, double* S, int ld, int rhs_row, double* grad,

@@ -170,12 +170,17 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
   hipStream_t s = c->stream;
   // one launch clears the reduced system, gradient, diagonal and the scalars of this step (GRAD_MAX, GRAD_NORM2, CHOL_FAIL)
   // ... and carries the radius of this step (not under graph replay, whose kernel arguments are frozen)
-  launch_zero_tiles_multi(s, c->d_S, c->npad, c->d_touched, c->n_touched, c->d_grad, c->n_pose, c->d_hdiag, c->n_pose,
-                          new_J ? c->d_scal + SC_GRAD_MAX : c->d_scal + SC_CHOL_FAIL, new_J ? 3 : 1,
-                          c->use_graphs ? nullptr : c->d_scal + SC_RADIUS, radius);
+  ZeroStep zs;
+  zs.S = c->d_S; zs.ld = c->npad; zs.tiles = c->d_touched; zs.n_tiles = c->n_touched;
+  zs.a = c->d_grad; zs.na = c->n_pose; zs.b = c->d_hdiag; zs.nb = c->n_pose;
+  zs.c = new_J ? c->d_scal + SC_GRAD_MAX : c->d_scal + SC_CHOL_FAIL; zs.nc = new_J ? 3 : 1;
+  zs.radius_slot = c->use_graphs ? nullptr : c->d_scal + SC_RADIUS; zs.radius = radius;
+  // (with landmarks and eager launches the clearing rides in the landmark launch: independent work, one launch less on the path)
+  const bool merged = c->vis.n_lm > 0 && !c->use_graphs;
+  if (!merged) launch_zero_tiles_multi(s, zs.S, zs.ld, zs.tiles, zs.n_tiles, zs.a, zs.na, zs.b, zs.nb, zs.c, zs.nc, zs.radius_slot, zs.radius);
   c->scal_mirrored = false;
-  launch_landmark(s, c->vis, c->n_pose, c->d_scal + SC_RADIUS, first ? 1 : 0, new_J ? 1 : 0, o.jacobi_scaling, o.min_lm_diagonal,
-                  o.max_lm_diagonal, c->d_scale, c->d_dcl, c->d_grad);
+  launch_landmark(s, c->vis, c->n_pose, merged ? nullptr : c->d_scal + SC_RADIUS, first ? 1 : 0, new_J ? 1 : 0, o.jacobi_scaling, o.min_lm_diagonal,
+                  o.max_lm_diagonal, c->d_scale, c->d_dcl, c->d_grad, merged ? &zs : nullptr, radius);
   phase_mark(c, BSGPU_PHASE_LANDMARK);
   launch_pairs(s, c->vis, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm, gradient_only);
   phase_mark(c, BSGPU_PHASE_PAIRS);

@@ -204,11 +204,32 @@ __global__ __launch_bounds__(256) void landmark_kernel(int n_lm, const int* __re
                                                        int compute_dcl, int jacobi, double lm_lo, double lm_hi,
                                                        double* __restrict__ scale, double* __restrict__ dcl,
                                                        double* __restrict__ grad, double* __restrict__ Linv_out,
-                                                       double* __restrict__ z_out, double* __restrict__ CR) {
+                                                       double* __restrict__ z_out, double* __restrict__ CR, int lm_blocks, ZeroStep zs,
+                                                       double radius_val) {
+  if ((int)blockIdx.x >= lm_blocks) {
+    // the step's clearing (tiles of S the assembly writes, pose gradient, diag(J^T J), the step's scalars, the radius slot) as extra
+    // workgroups of this launch: nothing here is read or written by the landmark workgroups (they get the radius as an argument),
+    // and a launch of its own cost 6 us on the dependent path
+    const int zb = (int)blockIdx.x - lm_blocks, nzb = (int)gridDim.x - lm_blocks;
+    const int64_t t = (int64_t)zb * 256 + threadIdx.x, stride = (int64_t)nzb * 256;
+    if (zs.radius_slot && t == 0) *zs.radius_slot = zs.radius;
+    const int nt = zs.ld >> 6;
+    for (int q = zb; q < zs.n_tiles; q += nzb) {
+      const int ti = zs.tiles[q] / nt, tj = zs.tiles[q] - ti * nt;
+      double2* base = reinterpret_cast<double2*>(zs.S + (size_t)ti * 64 * zs.ld + (size_t)tj * 64);
+      const int r0 = threadIdx.x >> 5, c2 = threadIdx.x & 31;
+#pragma unroll
+      for (int p = 0; p < 8; ++p) base[(size_t)(r0 + 8 * p) * (zs.ld >> 1) + c2] = make_double2(0.0, 0.0);
+    }
+    for (int64_t i = t; i < zs.na; i += stride) zs.a[i] = 0.0;
+    for (int64_t i = t; i < zs.nb; i += stride) zs.b[i] = 0.0;
+    for (int64_t i = t; i < zs.nc; i += stride) zs.c[i] = 0.0;
+    return;
+  }
   const int gid = blockIdx.x * 256 + threadIdx.x;
   const int l = gid >> 3, sub = gid & 7;
   const bool valid = l < n_lm;
-  const double inv_radius = 1.0 / radius_ptr[0];   // device-resident so that a captured graph can be replayed
+  const double inv_radius = 1.0 / (radius_ptr ? radius_ptr[0] : radius_val);   // (device-resident under graph replay, whose arguments are frozen)
   int beg = 0, end = 0;
   if (valid) { beg = lm_start[l]; end = lm_start[l + 1]; }
   double h00 = 0, h01 = 0, h02 = 0, h11 = 0, h12 = 0, h22 = 0, b0 = 0, b1 = 0, b2 = 0;
@@ -284,11 +305,13 @@ __global__ void landmark_tail_kernel(int first, int n, const double2* __restrict
 
 void launch_landmark(hipStream_t s, const Visual& v, int n_pose, const double* radius_ptr, int compute_scale,
                      int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* scale, double* dcl,
-                     double* grad) {
+                     double* grad, const ZeroStep* zero, double radius_val) {
   if (v.n_lm > 0) {
     const int grid = (v.n_lm * 8 + 255) / 256;
-    hipLaunchKernelGGL(landmark_kernel, dim3(grid), dim3(256), 0, s, v.n_lm, v.lm_start, v.JB, v.r, n_pose, radius_ptr,
-                       compute_scale, compute_dcl, jacobi, lm_lo, lm_hi, scale, dcl, grad, v.Linv, v.z, v.CR);
+    const int zero_blocks = zero ? std::max(1, std::min(zero->n_tiles, 1024)) : 0;
+    hipLaunchKernelGGL(landmark_kernel, dim3(grid + zero_blocks), dim3(256), 0, s, v.n_lm, v.lm_start, v.JB, v.r, n_pose, radius_ptr,
+                       compute_scale, compute_dcl, jacobi, lm_lo, lm_hi, scale, dcl, grad, v.Linv, v.z, v.CR, grid, zero ? *zero : ZeroStep(),
+                       radius_val);
   }
   if (v.n > v.n_elim) {
     const int grid = (v.n - v.n_elim + 255) / 256;
