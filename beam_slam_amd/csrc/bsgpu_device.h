@@ -163,4 +163,38 @@ BSG_DEV double block_sum_256(double v, double* smem /* >= 4 doubles */) {
   return t;
 }
 
+// model cost change term of pose-only groups, one lane per residual row: part[unit] = sum over the unit's 128 rows of
+// -(J_k d) (r_k + J_k d / 2).  `unit` = 128-row unit over the set (SmallGroupSet::first), t128 = thread within the unit, s2 = 2 doubles
+// of LDS private to the unit's two waves.  Shared by small_mcc_kernel and backsub_mcc_kernel (which runs the units as extra workgroups).
+BSG_DEV void small_mcc_unit(const SmallGroupSet& set, int unit, int t128, const double* __restrict__ delta, double* s2) {
+  int gi = 0;
+  while (gi + 1 < set.n && unit >= set.first[gi + 1]) ++gi;
+  const SmallGroup& g = set.g[gi];
+  double* part = set.part[gi];
+  const int wg = unit - set.first[gi];
+  const int id = wg * 128 + t128;
+  const int m = g.m;
+  double acc = 0.0;
+  if (id < g.n * m) {
+    const int f = id / m, k = id - f * m;
+    if (g.active[f]) {
+      const int tw = 3 * g.nv;
+      const double* J = g.J + ((size_t)f * m + k) * tw;
+      const int* to = g.toff + (size_t)f * g.nv;
+      double jv = 0.0;
+      for (int sl = 0; sl < g.nv; ++sl) {
+        const int t = to[sl];
+        if (t < 0) continue;
+        if (sl == g.nv - 1 && g.w_last < 3) { for (int i = 0; i < g.w_last; ++i) jv += J[3 * sl + i] * delta[t + i]; continue; }
+        jv += J[3 * sl] * delta[t] + J[3 * sl + 1] * delta[t + 1] + J[3 * sl + 2] * delta[t + 2];
+      }
+      acc = -jv * (g.r[(size_t)f * m + k] + 0.5 * jv);
+    }
+  }
+  const double w = wave_sum(acc);
+  if ((t128 & 63) == 0) s2[t128 >> 6] = w;
+  __syncthreads();
+  if (t128 == 0) part[wg] = s2[0] + s2[1];
+}
+
 }  // namespace bsg

@@ -235,7 +235,9 @@ void launch_spcg_finish(hipStream_t s, int T, const double* x, const int* iperm,
 int pcg_done_slot();
 int pcg_iters_slot();
 int backsub_mcc_groups(const Visual& v);   // workgroups (= model-cost partials) of launch_backsub_mcc
-void launch_backsub_mcc(hipStream_t s, const Visual& v, int n_pose, const double* y_pose, double* delta, double* mcc_part);
+void launch_backsub_mcc(hipStream_t s, const Visual& v, int n_pose, const double* y_pose, double* delta, double* mcc_part,
+                        const SmallGroupSet* small = nullptr, int n_small_units = 0);
+int small_mcc_first_set(const SmallGroup* groups, double* const* parts, int n_groups, SmallGroupSet* set, int* n_taken);
 void launch_negate_pose(hipStream_t s, int n_pose, const double* y, double* delta);
 void launch_small_mcc_set(hipStream_t s, const SmallGroup* groups, double* const* parts, int n_groups, const double* delta);
 void launch_update(hipStream_t s, int nb, const int* blk_xoff, const int* blk_toff, const unsigned char* blk_size,

@@ -272,8 +272,16 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
     phase_mark(c, BSGPU_PHASE_BACKSOLVE);
   }
   // landmark back-substitution + the model-cost-change terms of the visual factors (partial arrays only, summed once at the end)
-  launch_backsub_mcc(s, c->vis, c->n_pose, c->d_ytan, c->d_delta, c->vis.mcc_part);
-  launch_small_mcc_set(s, c->small + 2, c->d_small_part_mcc + 2, kNumInternal - 2, c->d_delta);
+  {
+    // (the model-cost terms of the first pose-only groups ride in the back-substitution launch; further groups, or all of them when
+    // there is no visual launch, go by themselves)
+    SmallGroupSet set;
+    int taken = 0, units = 0;
+    if (backsub_mcc_groups(c->vis) > 0) units = small_mcc_first_set(c->small + 2, c->d_small_part_mcc + 2, kNumInternal - 2, &set, &taken);
+    launch_backsub_mcc(s, c->vis, c->n_pose, c->d_ytan, c->d_delta, c->vis.mcc_part, units > 0 ? &set : nullptr, units);
+    if (units == 0) taken = 0;
+    launch_small_mcc_set(s, c->small + 2 + taken, c->d_small_part_mcc + 2 + taken, kNumInternal - 2 - taken, c->d_delta);
+  }
   for (const auto& mc : c->marg)
     if (mc.active) launch_marg_mcc(s, mc.dev, c->d_delta, mc.part_mcc);
   phase_mark(c, BSGPU_PHASE_BACKSUB);

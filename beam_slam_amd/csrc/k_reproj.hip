@@ -503,8 +503,15 @@ __global__ __launch_bounds__(256) void backsub_mcc_kernel(int n_lm, int n_lm_gro
                                                           const int* __restrict__ cp_tq, const int* __restrict__ cp_tp,
                                                           const double* __restrict__ Linv, const double* __restrict__ z, int n_pose,
                                                           const double* __restrict__ y_pose, double* __restrict__ delta,
-                                                          double* __restrict__ mcc_part) {
+                                                          double* __restrict__ mcc_part, int n_vis_blocks, SmallGroupSet small, int n_small_units) {
   __shared__ double sred[4];
+  if ((int)blockIdx.x >= n_vis_blocks) {
+    // the model-cost terms of the pose-only factors (they need the pose step only) as extra workgroups: two 128-row units each
+    const int unit = 2 * ((int)blockIdx.x - n_vis_blocks) + ((int)threadIdx.x >> 7);
+    if (unit < n_small_units) small_mcc_unit(small, unit, threadIdx.x & 127, delta, sred + 2 * (threadIdx.x >> 7));
+    else __syncthreads();
+    return;
+  }
   double acc = 0.0;
   if ((int)blockIdx.x < n_lm_groups) {
     const int gid = blockIdx.x * 256 + threadIdx.x;
@@ -562,11 +569,13 @@ __global__ __launch_bounds__(256) void backsub_mcc_kernel(int n_lm, int n_lm_gro
 }
 
 int backsub_mcc_groups(const Visual& v) { return (v.n_lm * 8 + 255) / 256 + (v.n - v.n_elim + 255) / 256; }
-void launch_backsub_mcc(hipStream_t s, const Visual& v, int n_pose, const double* y_pose, double* delta, double* mcc_part) {
+void launch_backsub_mcc(hipStream_t s, const Visual& v, int n_pose, const double* y_pose, double* delta, double* mcc_part,
+                        const SmallGroupSet* small, int n_small_units) {
   const int g_lm = (v.n_lm * 8 + 255) / 256, grid = backsub_mcc_groups(v);
   if (grid == 0) return;
-  hipLaunchKernelGGL(backsub_mcc_kernel, dim3(grid), dim3(256), 0, s, v.n_lm, g_lm, v.n_elim, v.n, v.lm_start, v.J, v.JB, v.r, v.CR, v.cam_pose,
-                     v.cp_tq, v.cp_tp, v.Linv, v.z, n_pose, y_pose, delta, mcc_part);
+  const int extra = small ? (n_small_units + 1) / 2 : 0;
+  hipLaunchKernelGGL(backsub_mcc_kernel, dim3(grid + extra), dim3(256), 0, s, v.n_lm, g_lm, v.n_elim, v.n, v.lm_start, v.J, v.JB, v.r, v.CR, v.cam_pose,
+                     v.cp_tq, v.cp_tp, v.Linv, v.z, n_pose, y_pose, delta, mcc_part, grid, small ? *small : SmallGroupSet(), small ? n_small_units : 0);
 }
 
 }  // namespace bsg

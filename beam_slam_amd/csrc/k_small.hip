@@ -900,38 +900,24 @@ void launch_small_assemble_set(hipStream_t s, const SmallGroup* groups, int n_gr
 // model cost change term of a pose-only group, one lane per residual row:
 //   part[f*m + k] = -(J_k d) (r_k + J_k d / 2)
 __global__ __launch_bounds__(128) void small_mcc_kernel(SmallGroupSet set, const double* __restrict__ delta) {
-  int gi = 0;
-  while (gi + 1 < set.n && (int)blockIdx.x >= set.first[gi + 1]) ++gi;
-  const SmallGroup& g = set.g[gi];
-  double* part = set.part[gi];
-  const int wg = blockIdx.x - set.first[gi];
-  const int id = wg * 128 + threadIdx.x;
-  const int m = g.m;
-  double acc = 0.0;
-  if (id < g.n * m) {
-    const int f = id / m, k = id - f * m;
-    if (g.active[f]) {
-      const int tw = 3 * g.nv;
-      const double* J = g.J + ((size_t)f * m + k) * tw;
-      const int* to = g.toff + (size_t)f * g.nv;
-      double jv = 0.0;
-      for (int sl = 0; sl < g.nv; ++sl) {
-        const int t = to[sl];
-        if (t < 0) continue;
-        if (sl == g.nv - 1 && g.w_last < 3) { for (int i = 0; i < g.w_last; ++i) jv += J[3 * sl + i] * delta[t + i]; continue; }
-        jv += J[3 * sl] * delta[t] + J[3 * sl + 1] * delta[t + 1] + J[3 * sl + 2] * delta[t + 2];
-      }
-      acc = -jv * (g.r[(size_t)f * m + k] + 0.5 * jv);
-    }
-  }
-  // one partial per workgroup (a 20 000-factor group has 120 000 rows: the end-of-step reduction should not walk them)
   __shared__ double s2[2];
-  const double w = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) s2[threadIdx.x >> 6] = w;
-  __syncthreads();
-  if (threadIdx.x == 0) part[wg] = s2[0] + s2[1];
+  small_mcc_unit(set, blockIdx.x, threadIdx.x, delta, s2);
 }
 
+// the first (up to kSetMax) non-empty groups as ONE set, for a caller that runs their units inside another launch (backsub_mcc_kernel);
+// returns the number of 128-row units, *n_taken = how many entries of `groups` it consumed
+int small_mcc_first_set(const SmallGroup* groups, double* const* parts, int n_groups, SmallGroupSet* set, int* n_taken) {
+  set->n = 0;
+  int blocks = 0, i = 0;
+  for (; i < n_groups && set->n < kSetMax; ++i) {
+    if (!groups[i].n) continue;
+    set->g[set->n] = groups[i]; set->first[set->n] = blocks; set->part[set->n] = parts[i];
+    blocks += (groups[i].n * groups[i].m + 127) / 128; ++set->n;
+  }
+  set->first[set->n] = blocks;
+  *n_taken = i;
+  return blocks;
+}
 void launch_small_mcc_set(hipStream_t s, const SmallGroup* groups, double* const* parts, int n_groups, const double* delta) {
   SmallGroupSet set;
   set.n = 0;
