@@ -160,6 +160,8 @@ struct bsgpu_ctx {
   hipEvent_t ev_reduce = nullptr;   // recorded after the end-of-step reduction: what the host waits for (work may be queued behind it)
   bool ev_reduce_pending = false;
   // block-sparse PCG path
+  std::vector<uint8_t> leaf_tile;   // per natural tile of the reduced system: made of inverse-depth landmarks only (finalize)
+  int n_leaf_tiles = 0;
   bool dense_ok = true, bsr_built = false, use_pcg = false;
   // PCG on the assembled reduced camera system (BSGPU_LINEAR_SCHUR_PCG): tile rows of S in CSR form, inverses of the diagonal tiles,
   // the CG vectors in solver order (built on first use, build_spcg())

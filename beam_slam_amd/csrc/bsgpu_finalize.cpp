@@ -37,7 +37,7 @@ int finalize(bsgpu_ctx* c) {
   const int nb = c->nb;
   if (nb <= 0) return fail(c, BSGPU_ERR_INVALID, "no parameter blocks");
   // ---- validation + landmark detection (same rule as the oracle)
-  std::vector<int> lm_use(nb, 0), other_use(nb, 0);
+  std::vector<int> lm_use(nb, 0), other_use(nb, 0), rho_use(nb, 0);   // rho_use: as the inverse-depth slot of an inverse-depth factor
   for (int t = 0; t < BSGPU_F_NUM_TYPES; ++t) {
     const HostGroup& g = c->groups[t];
     const TypeInfo& ti = kTypes[t];
@@ -50,6 +50,7 @@ int finalize(bsgpu_ctx* c) {
         if (ti.amb[sl] == 4 && c->manifold[b] != BSGPU_MANIFOLD_QUAT_RIGHT)
           return fail(c, BSGPU_ERR_INVALID, "4-d slot must be a quaternion-manifold block");
         if (t <= 1 && sl == 2) lm_use[b]++; else other_use[b]++;
+        if ((t == BSGPU_F_IDP_REPROJ || t == BSGPU_F_IDP_REPROJ_UNARY) && sl == ti.nvar - 1) rho_use[b]++;
       }
       if (has_camera(t)) {
         const int cam = idx[ti.nvar];
@@ -83,7 +84,25 @@ int finalize(bsgpu_ctx* c) {
   for (int b = 0; b < nb; ++b) if (!c->is_const[b] && c->is_lm[b]) { c->toff[b] = to; to += 3; lm_index[b] = nl++; }
   c->n_tan = to; c->n_lm = nl;
   c->npad = ((c->n_pose + 63) / 64 + 1) * 64;   // real tiles + one tile for the rhs row (dense_plan.h)
-  c->dense_ok = (size_t)c->npad <= kDenseLimit || (nl > 0 && (size_t)c->npad <= kDenseLimitLandmarks);   // else: block-sparse PCG (pose-only problems)
+  // leaf tiles of the reduced system: tiles made of inverse-depth landmarks only — scalar blocks that no factor couples to each other
+  // (an inverse-depth factor has one), so the tiled factorisation can eliminate them first (dense_plan.h build(): leaf)
+  c->leaf_tile.assign((c->n_pose + 63) / 64, 0);
+  {
+    const int T0 = (c->n_pose + 63) / 64;
+    std::vector<uint8_t> dim_leaf(c->n_pose, 0);
+    bool any = false;
+    for (int b = 0; b < nb; ++b)
+      if (!c->is_const[b] && !c->is_lm[b] && c->size[b] == 1 && rho_use[b] > 0 && rho_use[b] == other_use[b]) { dim_leaf[c->toff[b]] = 1; any = true; }
+    if (any)
+      for (int t = 0; t < T0; ++t) {
+        bool all = true;
+        for (int d = 64 * t; d < std::min(c->n_pose, 64 * t + 64) && all; ++d) all = dim_leaf[d] != 0;
+        c->leaf_tile[t] = all ? 1 : 0;
+      }
+    c->n_leaf_tiles = 0;
+    for (uint8_t v : c->leaf_tile) c->n_leaf_tiles += v;
+  }
+  c->dense_ok = (size_t)c->npad <= kDenseLimit || ((nl > 0 || c->n_leaf_tiles > 0) && (size_t)c->npad <= kDenseLimitLandmarks);   // else: block-sparse PCG (pose-only problems)
   int row = 0;
   for (int t = 0; t < BSGPU_F_NUM_TYPES; ++t) { c->row0[t] = row; row += c->groups[t].n * kTypes[t].m; }
   for (const HostMarginal& mg : c->marginals) row += mg.rows;
@@ -538,10 +557,11 @@ int finalize(bsgpu_ctx* c) {
     if (c->tile_adj.size() != (size_t)T * T) c->tile_adj.assign((size_t)T * T, 0);
     const char* e2 = getenv("BSGPU_MIN_PIECE");
     const char* e3 = getenv("BSGPU_SHARED");   // panels of one step may update the same tiles (atomics): on unless BSGPU_SHARED=0
-    c->plan.build(c->n_pose, c->tile_adj, c->dense_ok ? max_chains : 1, e2 ? std::max(1, atoi(e2)) : 1, !(e3 && atoi(e3) == 0));
+    const bool use_leaf = c->n_leaf_tiles > 0 && !getenv("BSGPU_NO_LEAF_TILES");
+    c->plan.build(c->n_pose, c->tile_adj, c->dense_ok ? max_chains : 1, e2 ? std::max(1, atoi(e2)) : 1, !(e3 && atoi(e3) == 0), use_leaf ? &c->leaf_tile : nullptr);
     c->npad = c->plan.npad;
-    if (timing) fprintf(stderr, "[bsgpu finalize] Cholesky plan: %d tiles, %d pieces, %d panel steps, %d back-substitution launches\n", c->plan.T, c->plan.n_pieces,
-                        c->plan.n_steps(), (int)c->plan.bs_group_off.size() - 1);
+    if (timing) fprintf(stderr, "[bsgpu finalize] Cholesky plan: %d tiles (%d leaf), %d pieces, %d panel steps, %d back-substitution launches\n", c->plan.T,
+                        c->plan.n_leaf_tiles, c->plan.n_pieces, c->plan.n_steps(), (int)c->plan.bs_group_off.size() - 1);
     std::vector<int> iperm(T + 1, -1);
     for (int t = 0; t < T; ++t) iperm[c->plan.perm[t]] = t;
     c->d_perm = c->upload(c->plan.perm); c->d_iperm = c->upload(iperm); c->d_nreal = c->upload(c->plan.nreal);

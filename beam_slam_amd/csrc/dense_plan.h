@@ -55,6 +55,7 @@ struct DensePlan {
   std::vector<int> step_maxrows;
   std::vector<int> potrf_before_step_off, potrf_tiles;  // standalone potrf launches: tiles to factor before step s
   int n_chains = 1;
+  int n_leaf_tiles = 0;   // tiles ordered first as one-panel pieces (build(): leaf)
   // back-substitution: GROUPS of chains, one launch per group; a chain is a run of consecutive S tiles [begin, end) walked
   // by one workgroup from its last tile down.  Root separator first, then the separators level by level (those of one
   // level are independent), then all pieces at once.  Every row tile of a panel lies later in its own chain or in an
@@ -76,13 +77,46 @@ struct DensePlan {
   inline int spos(int j) const { return perm[j >> 6] * 64 + (j & 63); }
 
   // adj: T x T symmetric tile adjacency in NATURAL tile order (adj[i*T+j] != 0 iff block (i,j) of S is structurally non-zero)
-  void build(int n_pose_, const std::vector<uint8_t>& adj, int max_chains, int min_piece_w = 1 /* minimum piece length in units of the band width */,
-             bool allow_shared = true /* panels of one step may update the same tiles (atomics) */) {
+  // leaf (optional, T flags): tiles that are coupled to no other leaf tile — a window's inverse-depth landmarks, thousands of scalar
+  // blocks that touch a few keyframes each.  They are ordered FIRST: eliminating them is the landmark Schur complement, carried out by
+  // the tile machinery (each is the head of a one-panel piece); the nested dissection below then orders the remaining (core) tiles on
+  // their adjacency INCLUDING the fill the leaves leave behind.  Without this a window with 20 000 such landmarks would be ordered as
+  // one banded chain with the landmarks last — poses eliminated into a dense 20 000-dimensional block.
+  void build(int n_pose_, const std::vector<uint8_t>& adj_in, int max_chains, int min_piece_w = 1 /* minimum piece length in units of the band width */,
+             bool allow_shared = true /* panels of one step may update the same tiles (atomics) */, const std::vector<uint8_t>* leaf = nullptr) {
     n_pose = n_pose_;
     T = (n_pose + 63) / 64;
     npad = (T + 1) * 64;
     rhs_row = T * 64;
-    // ---- ordering: nested dissection of a banded chain
+    const std::vector<uint8_t>& adj = adj_in;
+    // ---- leaf tiles (validated: mutually uncoupled) and the core sub-chain
+    std::vector<int> leaf_tiles, core;
+    {
+      std::vector<uint8_t> is_leaf(T, 0);
+      if (leaf && (int)leaf->size() == T) {
+        bool ok = true;
+        for (int i = 0; i < T && ok; ++i) if ((*leaf)[i]) for (int j = 0; j < T; ++j) if (j != i && (*leaf)[j] && adj[(size_t)i * T + j]) { ok = false; break; }
+        if (ok) for (int i = 0; i < T; ++i) is_leaf[i] = (*leaf)[i] ? 1 : 0;
+      }
+      for (int i = 0; i < T; ++i) (is_leaf[i] ? leaf_tiles : core).push_back(i);
+      if (core.empty()) { core = leaf_tiles; leaf_tiles.clear(); }
+    }
+    const int Tc = (int)core.size(), n_leaf = (int)leaf_tiles.size();
+    n_leaf_tiles = n_leaf;
+    // core adjacency in core index space, with the fill of the leaf elimination (two core tiles that share a leaf become coupled)
+    std::vector<uint8_t> adjc((size_t)Tc * Tc, 0);
+    {
+      std::vector<int> core_of(T, -1);
+      for (int i = 0; i < Tc; ++i) core_of[core[i]] = i;
+      for (int i = 0; i < Tc; ++i) for (int j = 0; j < Tc; ++j) adjc[(size_t)i * Tc + j] = adj[(size_t)core[i] * T + core[j]];
+      std::vector<int> nb;
+      for (int t : leaf_tiles) {
+        nb.clear();
+        for (int j = 0; j < T; ++j) if (core_of[j] >= 0 && (adj[(size_t)t * T + j] || adj[(size_t)j * T + t])) nb.push_back(core_of[j]);
+        for (int a : nb) for (int b : nb) adjc[(size_t)a * Tc + b] = 1;
+      }
+    }
+    // ---- ordering of the core: nested dissection of a banded chain
     perm.assign(T, 0);
     // band width used to cut the chain into pieces and separators: the distance below which 95 % of the coupled tile pairs lie,
     // not the maximum — one long feature track or a loop closure couples two far-apart keyframes, and sizing the separators
@@ -91,7 +125,7 @@ struct DensePlan {
     int w = 0;
     {
       std::vector<int> dist;
-      for (int i = 0; i < T; ++i) for (int j = 0; j < i; ++j) if (adj[(size_t)i * T + j]) dist.push_back(i - j);
+      for (int i = 0; i < Tc; ++i) for (int j = 0; j < i; ++j) if (adjc[(size_t)i * Tc + j]) dist.push_back(i - j);
       if (!dist.empty()) {
         std::sort(dist.begin(), dist.end());
         w = dist[std::min(dist.size() - 1, (size_t)(0.95 * (double)dist.size()))];
@@ -101,19 +135,21 @@ struct DensePlan {
     std::vector<int> order;  // S order: list of natural tiles
     std::vector<std::pair<int, int>> piece_ranges;                    // S tile ranges of the pieces
     std::vector<std::vector<std::pair<int, int>>> sep_ranges_by_level;  // S tile ranges of the separators, per level
+    std::vector<std::pair<int, int>> leaf_ranges;                     // S tile ranges (one tile each) of the leaf tiles
+    for (int t : leaf_tiles) { leaf_ranges.push_back({(int)order.size(), (int)order.size() + 1}); order.push_back(t); }
     int chains = 1;
-    if (max_chains > 1 && w >= 1) while (chains * 2 <= max_chains && T >= (chains * 2) * min_piece_w * w + (chains * 2 - 1) * w) chains *= 2;
+    if (max_chains > 1 && w >= 1) while (chains * 2 <= max_chains && Tc >= (chains * 2) * min_piece_w * w + (chains * 2 - 1) * w) chains *= 2;
     n_chains = chains;
     if (chains == 1) {
-      for (int i = 0; i < T; ++i) order.push_back(i);
-      piece_ranges.push_back({0, T});
+      piece_ranges.push_back({(int)order.size(), (int)order.size() + Tc});
+      for (int i = 0; i < Tc; ++i) order.push_back(core[i]);
     } else {
       // pieces p = 0..chains-1 separated by chains-1 separators of w tiles
       const int n_sep = chains - 1;
-      const int body = T - n_sep * w;
+      const int body = Tc - n_sep * w;
       std::vector<int> piece_len(chains, body / chains);
       for (int i = 0; i < body % chains; ++i) piece_len[i]++;
-      std::vector<std::pair<int, int>> pieces, seps;  // [begin, end) natural tiles
+      std::vector<std::pair<int, int>> pieces, seps;  // [begin, end) core tiles
       int pos = 0;
       for (int p = 0; p < chains; ++p) {
         pieces.push_back({pos, pos + piece_len[p]});
@@ -126,8 +162,8 @@ struct DensePlan {
       for (int p = 0; p < chains; ++p) {
         piece_ranges.push_back({(int)order.size(), (int)order.size() + piece_len[p]});
         const bool reverse = (p == chains - 1) && chains > 1;  // last piece: its only separator is on the left
-        if (!reverse) for (int t = pieces[p].first; t < pieces[p].second; ++t) order.push_back(t);
-        else for (int t = pieces[p].second - 1; t >= pieces[p].first; --t) order.push_back(t);
+        if (!reverse) for (int t = pieces[p].first; t < pieces[p].second; ++t) order.push_back(core[t]);
+        else for (int t = pieces[p].second - 1; t >= pieces[p].first; --t) order.push_back(core[t]);
       }
       // separators last, lowest level (most local) first: odd-indexed separators of the recursive bisection
       // are the deepest; order them by increasing "level" so that the root separator is eliminated last
@@ -139,7 +175,7 @@ struct DensePlan {
       for (int lvl = 0; lvl <= max_lvl; ++lvl)
         for (int i = 0; i < n_sep; ++i) if (sep_level[i] == lvl) {
           sep_ranges_by_level[lvl].push_back({(int)order.size(), (int)order.size() + (seps[i].second - seps[i].first)});
-          for (int t = seps[i].first; t < seps[i].second; ++t) order.push_back(t);
+          for (int t = seps[i].first; t < seps[i].second; ++t) order.push_back(core[t]);
         }
     }
     for (int s = 0; s < T; ++s) perm[order[s]] = s;
@@ -272,6 +308,10 @@ struct DensePlan {
         }
         for (const auto& r : piece_ranges) { chain_begin.push_back(r.first); chain_end.push_back(r.second); }
         bs_group_off.push_back((int)chain_begin.size());
+        if (!leaf_ranges.empty()) {   // the leaf tiles last: every row tile of theirs is a core tile, solved by then
+          for (const auto& r : leaf_ranges) { chain_begin.push_back(r.first); chain_end.push_back(r.second); }
+          bs_group_off.push_back((int)chain_begin.size());
+        }
       } else {   // reverse step schedule, one single-tile chain per panel (always valid)
         for (int st = (int)steps.size() - 1; st >= 0; --st) {
           for (int k : steps[st]) { chain_begin.push_back(k); chain_end.push_back(k + 1); }
