@@ -431,7 +431,20 @@ int finalize(bsgpu_ctx* c) {
   {
     constexpr int kSegChunk = 64;
     struct Contrib { int ra, rb, tf, ss; };
-    std::vector<Contrib> cl;
+    std::vector<Contrib> cl, tmp;
+    std::vector<int> cnt;
+    auto sort_by_block = [&](size_t lo, size_t hi) {   // cl[lo, hi) by (ra, rb), stable: LSD counting sort, rb then ra
+      const size_t n = hi - lo;
+      if (n < 2) return;
+      tmp.resize(n);
+      for (int pass = 0; pass < 2; ++pass) {
+        cnt.assign((size_t)c->n_pose + 2, 0);
+        for (size_t i = lo; i < hi; ++i) cnt[(pass == 0 ? cl[i].rb : cl[i].ra) + 1]++;
+        for (size_t k = 1; k < cnt.size(); ++k) cnt[k] += cnt[k - 1];
+        for (size_t i = lo; i < hi; ++i) tmp[cnt[pass == 0 ? cl[i].rb : cl[i].ra]++] = cl[i];
+        std::copy(tmp.begin(), tmp.begin() + n, cl.begin() + lo);
+      }
+    };
     for (int t = 0; t < kNumInternal; ++t) { c->small_factorwise[t] = c->small[t]; if (t < 2) c->small_factorwise[t].n = 0; }
     for (int t = 2; t < kNumInternal; ++t) {
       const SmallGroup& sg = c->small[t];
@@ -448,15 +461,14 @@ int finalize(bsgpu_ctx* c) {
           cl.push_back({ra, rb, (t << 24) | f, (sa << 8) | sb});
         }
       }
-      std::vector<long long> blocks;
-      blocks.reserve(cl.size() - first);
-      for (size_t i = first; i < cl.size(); ++i) blocks.push_back((long long)cl[i].ra << 32 | (unsigned)cl[i].rb);
-      std::sort(blocks.begin(), blocks.end());
-      const size_t n_blocks = std::unique(blocks.begin(), blocks.end()) - blocks.begin();
+      // (stable counting sorts on the two tangent offsets, not a comparison sort: an inverse-depth window brings 2 M contributions)
+      sort_by_block(first, cl.size());
+      size_t n_blocks = 0;
+      for (size_t i = first; i < cl.size(); ++i) if (i == first || cl[i].ra != cl[i - 1].ra || cl[i].rb != cl[i - 1].rb) ++n_blocks;
       if (n_blocks && (cl.size() - first) >= 4 * n_blocks) c->small_factorwise[t].n = 0;   // by segments
       else cl.resize(first);                                                                // by factors
     }
-    std::stable_sort(cl.begin(), cl.end(), [](const Contrib& a, const Contrib& b) { return a.ra != b.ra ? a.ra < b.ra : a.rb < b.rb; });
+    sort_by_block(0, cl.size());
     std::vector<int> seg_start, seg_ra, seg_rb;
     std::vector<int2> contrib(cl.size());
     for (size_t i = 0; i < cl.size(); ++i) {
