@@ -64,3 +64,28 @@ def test_twenty_thousand_inverse_depth_landmarks_solve(gpu_solver_cls):
     rho0 = np.array([pr.values[pr.offset[b]] for b in pr.meta["rho_blocks"]])
     assert np.abs(rho - pr.meta["rho_true"]).mean() < 0.5 * np.abs(rho0 - pr.meta["rho_true"]).mean()
     print("20000 inverse-depth landmarks x 60 keyframes: %d iterations in %.1f ms (incl. finalize)" % (s.num_iterations, 1e3 * dt))
+
+
+def test_covariance_marginal_and_iterative_step_with_leaf_tiles(oracle_cls, gpu_solver_cls):
+    """The other users of the tiled factorisation on a window whose landmark tiles are ordered first: marginal covariance blocks
+    (keyframe x keyframe and keyframe x landmark), and the iterative step on the same assembled system."""
+    pr = synthetic.idp_window(n_kf=8, n_lm=300, seed=23)
+    g, s = _solve(pr, gpu_solver_cls)
+    o = oracle_cls()
+    pr.load(o)
+    o.set_values(g.get_blocks())
+    kf, rho = pr.meta["kf_blocks"], pr.meta["rho_blocks"]
+    for a, b in [(kf[2, 0], kf[2, 0]), (kf[1, 1], kf[6, 0]), (kf[3, 1], rho[100]), (rho[250], rho[250]), (rho[10], rho[200])]:
+        cg, co = g.covariance(int(a), int(b)), o.covariance(int(a), int(b))
+        ref = np.sqrt(np.abs(o.covariance(int(a), int(a))).max() * np.abs(o.covariance(int(b), int(b))).max())
+        assert np.abs(cg - co).max() <= 1e-7 * max(np.abs(co).max(), ref)
+    g2 = gpu_solver_cls(0)
+    pr.load(g2)
+    opt = g2.options_default()
+    opt.max_num_iterations = 15
+    opt.linear_solver_type = capi.LINEAR_SCHUR_PCG
+    opt.pcg_tolerance = 1e-12
+    opt.pcg_max_iterations = 3000
+    s2 = g2.solve(opt)
+    assert s2.linear_solver_used == capi.LINEAR_SCHUR_PCG
+    assert abs(s2.final_cost - s.final_cost) <= 1e-8 * s.final_cost
