@@ -786,7 +786,24 @@ BSG_DEV bool chol_fused_task(const FusedCtx& C, int t, double* smem, long long t
     double4_t acc[TPW];
 #pragma unroll
     for (int u = 0; u < TPW; ++u) acc[u] = double4_t{0.0, 0.0, 0.0, 0.0};
+    // If it is already this task's turn on the C tile (on the critical path it always is: the task waited for L_kk far longer than
+    // the tile's earlier updaters took), the tile is requested NOW and the product accumulates onto it — its ~1 us of load latency
+    // disappears under the 256 MFMAs instead of following them.
+    bool c_early = false;
     if (do_update) {
+      if (tk.need_c == 0) c_early = true;
+      else {
+        if (tid == 0) s_ctl[3] = (ld_flag(&upd[ti * N + tj]) >= tk.need_c) ? 1 : 0;
+        __syncthreads();
+        c_early = __builtin_amdgcn_readfirstlane(s_ctl[3]) != 0;
+      }
+      if (c_early) {
+#pragma unroll
+        for (int u = 0; u < TPW; ++u)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg)
+            acc[u][reg] = ld8_sc1(rS, (unsigned)(((size_t)(ri + 16 * rs + crow + 4 * reg) * ld + rj + 16 * (tt0 + u) + ccol) * sizeof(double)));
+      }
 #pragma unroll
       for (int u = 0; u < TPW; ++u)
         acc[u] = mfma_abt<64>(acc[u], sXi + (16 * rs) * LDT, LDT, Xj + (16 * (tt0 + u)) * LDT, LDT, -1.0, lane);
@@ -803,7 +820,7 @@ BSG_DEV bool chol_fused_task(const FusedCtx& C, int t, double* smem, long long t
     const bool last_update = do_update && tk.need_c + 1 == tk.tot_c;
     const bool factor_now = last_update && diag && ti < T;
     bool turn_ok = true;
-    if (do_update && tk.need_c > 0) {
+    if (do_update && tk.need_c > 0 && !c_early) {
       // this task's turn on the tile: every earlier update of it has been published
       if (tid == 0) s_ctl[1] = wait_count(&upd[ti * N + tj], tk.need_c, abort_w, deadline) ? 1 : 0;
       __syncthreads();
@@ -813,11 +830,13 @@ BSG_DEV bool chol_fused_task(const FusedCtx& C, int t, double* smem, long long t
     else {
     stamp(5);
     if (do_update) {
+      if (!c_early) {
 #pragma unroll
-      for (int u = 0; u < TPW; ++u)
+        for (int u = 0; u < TPW; ++u)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg)
-          acc[u][reg] += ld8_sc1(rS, (unsigned)(((size_t)(ri + 16 * rs + crow + 4 * reg) * ld + rj + 16 * (tt0 + u) + ccol) * sizeof(double)));
+          for (int reg = 0; reg < 4; ++reg)
+            acc[u][reg] += ld8_sc1(rS, (unsigned)(((size_t)(ri + 16 * rs + crow + 4 * reg) * ld + rj + 16 * (tt0 + u) + ccol) * sizeof(double)));
+      }
       if (!factor_now) {
 #pragma unroll
         for (int u = 0; u < TPW; ++u)
