@@ -537,11 +537,13 @@ BSG_DEV void st8_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, double d) {
 BSG_DEV int ld_flag(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // one lane: wait until *p == want (counters only ever grow towards it); false on abort / time-out
 BSG_DEV bool wait_count(const int* p, int want, int* abort_w, long long deadline) {
-  for (;;) {
-    if (ld_flag(p) >= want) return true;
-    if (ld_flag(abort_w) != 0) return false;
-    if ((long long)wall_clock64() > deadline) { __hip_atomic_store(abort_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
-    __builtin_amdgcn_s_sleep(1);
+  // (both words are requested together and the wall clock is read every 32nd round: a round of the poll is ONE memory round trip,
+  // not three in a row — the waiter sees the counter ~0.5 us sooner)
+  for (unsigned it = 0;; ++it) {
+    const int v = ld_flag(p), a = ld_flag(abort_w);
+    if (v >= want) return true;
+    if (a != 0) return false;
+    if ((it & 31) == 31 && (long long)wall_clock64() > deadline) { __hip_atomic_store(abort_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
   }
 }
 // one WAVE: wait until every flag in [lo, hi) is set (each written once, by a different workgroup: a counter word that 18-25 workgroups
