@@ -758,7 +758,7 @@ BSG_DEV bool chol_fused_task(const FusedCtx& C, int t, double* smem, long long t
         const int r = i >> 5, c2 = (i & 31) * 2;
         vXi[q] = ld16_sc1(rS, (unsigned)(((size_t)(ri + r) * ld + c0 + c2) * sizeof(double)));
         vL[q] = ld16_sc1(rLp, (unsigned)(((size_t)(c0 + r) * ld + c0 + c2) * sizeof(double)));
-        vXj[q] = ld16_sc1(rS, (unsigned)(((size_t)(rj + r) * ld + c0 + c2) * sizeof(double)));
+        if (!diag) vXj[q] = ld16_sc1(rS, (unsigned)(((size_t)(rj + r) * ld + c0 + c2) * sizeof(double)));   // (a diagonal task has one panel tile)
       }
 #pragma unroll
       for (int q = 0; q < 512 / NT; ++q) vV[q] = ld16_sc1(rV, (unsigned)(((size_t)k * kVinvStride + (tid + NT * q) * 2) * sizeof(double)));
@@ -768,7 +768,7 @@ BSG_DEV bool chol_fused_task(const FusedCtx& C, int t, double* smem, long long t
         const int r = i >> 5, c2 = (i & 31) * 2;
         *reinterpret_cast<double2*>(&sXi[r * LDT + c2]) = vXi[q];
         *reinterpret_cast<double2*>(&sL[r * LDT + c2]) = vL[q];
-        *reinterpret_cast<double2*>(&sXj[r * LDT + c2]) = vXj[q];
+        if (!diag) *reinterpret_cast<double2*>(&sXj[r * LDT + c2]) = vXj[q];
       }
 #pragma unroll
       for (int q = 0; q < 512 / NT; ++q) *reinterpret_cast<double2*>(&sV[(tid + NT * q) * 2]) = vV[q];
@@ -809,15 +809,6 @@ BSG_DEV bool chol_fused_task(const FusedCtx& C, int t, double* smem, long long t
 #pragma unroll
       for (int u = 0; u < TPW; ++u)
         acc[u] = mfma_abt<64>(acc[u], sXi + (16 * rs) * LDT, LDT, Xj + (16 * (tt0 + u)) * LDT, LDT, -1.0, lane);
-    }
-    if (diag) {
-      // the L panel of this row tile, for the back-substitution (a later launch: plain stores)
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int i = tid + NT * q;
-        const int r = i >> 5, c2 = (i & 31) * 2;
-        *reinterpret_cast<double2*>(&Lp[(size_t)(ri + r) * ld + c0 + c2]) = *reinterpret_cast<const double2*>(&sXi[r * LDT + c2]);
-      }
     }
     const bool last_update = do_update && tk.need_c + 1 == tk.tot_c;
     const bool factor_now = last_update && diag && ti < T;
@@ -864,6 +855,17 @@ BSG_DEV bool chol_fused_task(const FusedCtx& C, int t, double* smem, long long t
       if (factor_now) __hip_atomic_store(&potrf_done[ti], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     stamp(6);
+    if (diag) {
+      // the L panel of this row tile, for the back-substitution: only a later launch reads it, so it leaves after the hand-over
+      // (plain stores; sX_i is still intact — the tile inverse below overwrites it afterwards)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int i = tid + NT * q;
+        const int r = i >> 5, c2 = (i & 31) * 2;
+        *reinterpret_cast<double2*>(&Lp[(size_t)(ri + r) * ld + c0 + c2]) = *reinterpret_cast<const double2*>(&sXi[r * LDT + c2]);
+      }
+      __syncthreads();
+    }
     if (factor_now && Winv) publish_tile_inverse<NT>(sXj, sV, sXi, Winv + (size_t)ti * NB * NB, tid);
     }   // turn_ok
     }   // dependencies met
