@@ -748,8 +748,20 @@ BSG_DEV bool chol_fused_task(const FusedCtx& C, int t, double* smem, long long t
       bool ok = wait_count(&upd[ti * N + k], tk.tot_i, abort_w, deadline);
       if (!diag) ok = ok && wait_count(&upd[tj * N + k], tk.tot_j, abort_w, deadline);
       s_ctl[1] = ok ? 1 : 0;
+      // ... and the C tile, if it is already this task's turn on it (on the critical path it is: the tile's earlier updaters are
+      // panels that finished long ago): its values wait in registers through the solves, and the product accumulates onto them
+      s_ctl[3] = (do_update && (tk.need_c == 0 || ld_flag(&upd[ti * N + tj]) >= tk.need_c)) ? 1 : 0;
     }
     __syncthreads();
+    const bool c_pre = __builtin_amdgcn_readfirstlane(s_ctl[3]) != 0;
+    double4_t cpre[TPW];
+    if (c_pre) {
+#pragma unroll
+      for (int u = 0; u < TPW; ++u)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+          cpre[u][reg] = ld8_sc1(rS, (unsigned)(((size_t)(ri + 16 * rs + crow + 4 * reg) * ld + rj + 16 * (tt0 + u) + ccol) * sizeof(double)));
+    }
     if (__builtin_amdgcn_readfirstlane(s_ctl[1]) != 0) {
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
@@ -800,11 +812,15 @@ BSG_DEV bool chol_fused_task(const FusedCtx& C, int t, double* smem, long long t
     double4_t acc[TPW];
 #pragma unroll
     for (int u = 0; u < TPW; ++u) acc[u] = double4_t{0.0, 0.0, 0.0, 0.0};
-    // If it is already this task's turn on the C tile (on the critical path it always is: the task waited for L_kk far longer than
-    // the tile's earlier updaters took), the tile is requested NOW and the product accumulates onto it — its ~1 us of load latency
-    // disappears under the 256 MFMAs instead of following them.
+    // The C tile: already in registers (requested before the wait for L_kk), or — if the turn had not come by then — one more look
+    // now: a tile requested here still travels under the 256 MFMAs instead of being waited for after them.
     bool c_early = false;
     if (do_update) {
+      if (c_pre) {
+        c_early = true;
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) acc[u] = cpre[u];
+      } else {
       if (tk.need_c == 0) c_early = true;
       else {
         if (tid == 0) s_ctl[3] = (ld_flag(&upd[ti * N + tj]) >= tk.need_c) ? 1 : 0;
@@ -817,6 +833,7 @@ BSG_DEV bool chol_fused_task(const FusedCtx& C, int t, double* smem, long long t
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg)
             acc[u][reg] = ld8_sc1(rS, (unsigned)(((size_t)(ri + 16 * rs + crow + 4 * reg) * ld + rj + 16 * (tt0 + u) + ccol) * sizeof(double)));
+      }
       }
 #pragma unroll
       for (int u = 0; u < TPW; ++u)
