@@ -17,12 +17,21 @@ static int g_fail = 0;
 
 struct Mat { int n; std::vector<double> a; double& operator()(int i, int j) { return a[(size_t)i * n + j]; } };
 
-static bool run_case(int n_pose, int band_tiles, int max_chains, int min_piece, bool shared, unsigned seed, int n_far = 0, int* n_pieces_out = nullptr) {
+static bool run_case(int n_pose, int band_tiles, int max_chains, int min_piece, bool shared, unsigned seed, int n_far = 0, int* n_pieces_out = nullptr,
+                     int n_leaf = 0 /* the last n_leaf tiles are coupled to core tiles only (inverse-depth landmark tiles) */) {
   std::mt19937 rng(seed);
   std::normal_distribution<double> N(0, 1);
   const int T = (n_pose + 63) / 64;
   std::vector<uint8_t> adj((size_t)T * T, 0);
-  for (int i = 0; i < T; ++i) for (int j = 0; j < T; ++j) if (std::abs(i - j) <= band_tiles) adj[(size_t)i * T + j] = 1;
+  const int Tc = T - n_leaf;
+  for (int i = 0; i < Tc; ++i) for (int j = 0; j < Tc; ++j) if (std::abs(i - j) <= band_tiles) adj[(size_t)i * T + j] = 1;
+  std::vector<uint8_t> leaf(T, 0);
+  for (int t = Tc; t < T; ++t) {   // a leaf tile: itself + a few neighbouring core tiles (the keyframes that see its landmarks)
+    leaf[t] = 1;
+    adj[(size_t)t * T + t] = 1;
+    const int c0 = (int)(rng() % Tc), span = 1 + (int)(rng() % 3);
+    for (int j = c0; j < std::min(Tc, c0 + span); ++j) adj[(size_t)t * T + j] = adj[(size_t)j * T + t] = 1;
+  }
   // long feature tracks / loop closures: a few tile pairs far outside the band
   for (int f = 0; f < n_far; ++f) { const int i = (int)(rng() % T), j = (int)(rng() % T); adj[(size_t)i * T + j] = adj[(size_t)j * T + i] = 1; }
   // SPD matrix with that tile structure (natural order)
@@ -33,7 +42,8 @@ static bool run_case(int n_pose, int band_tiles, int max_chains, int min_piece, 
   std::vector<double> b(n_pose);
   for (auto& v : b) v = N(rng);
   DensePlan P;
-  P.build(n_pose, adj, max_chains, min_piece, shared);
+  P.build(n_pose, adj, max_chains, min_piece, shared, n_leaf ? &leaf : nullptr);
+  if (n_leaf) CHECK(P.n_leaf_tiles == n_leaf);
   if (n_pieces_out) *n_pieces_out = P.n_pieces;
   const int np = P.npad, NT = P.T + 1;
   // S in solver order with the rhs as row rhs_row; unit pivots on padding
@@ -177,6 +187,12 @@ int main() {
     int pieces = 0;
     run_case(3000, 3, 16, 1, true, seed++, n_far, &pieces);
     CHECK(pieces >= 4);
+  }
+  // leaf tiles (inverse-depth landmarks): ordered first, the core dissected on its adjacency including their fill
+  for (int chains : {1, 4, 16}) {
+    run_case(64 * 30, 2, chains, 1, true, seed++, 0, nullptr, 18);
+    run_case(64 * 40 + 17, 3, chains, 1, true, seed++, 0, nullptr, 25);   // partial last (leaf) tile
+    run_case(64 * 12, 1, chains, 1, false, seed++, 0, nullptr, 9);
   }
   if (g_fail) { std::printf("FAILED: %d checks\n", g_fail); return 1; }
   std::printf("ALL PLAN TESTS PASSED\n");
