@@ -106,7 +106,8 @@ class Camera(C.Structure):
 #: every symbol include/bsgpu.h declares (without prefix); tests check the library exports them all
 SYMBOLS = [
     "nidx", "nconst", "nres", "options_default", "options_vio", "create", "create_error", "destroy",
-    "last_error", "abi_version", "clear", "set_blocks", "set_values", "set_cameras", "add_factors", "add_factors_indirect", "add_marginal",
+    "last_error", "abi_version", "clear", "set_blocks", "set_values", "set_cameras", "add_factors", "add_factors_indirect", "sync_factors_indirect",
+    "add_marginal",
     "finalize", "solve", "get_blocks", "reset_values", "num_iterations_recorded", "get_iteration",
     "evaluate", "num_residuals", "num_parameters_tangent", "tangent_offset", "covariance", "marginalize", "get_marginal",
     "reprojection_errors", "preintegrate", "triangulate", "time_reproj_jacobian_ms", "reproj_jacobian_bytes", "dense_solve", "plan_info",
@@ -250,6 +251,27 @@ class Solver:
         fn.restype = C.c_int
         self._chk(fn(self._ctx, ftype, n, _ptr(slot_idx, _ip), slot_to_block.size, _ptr(slot_to_block, _ip), _ptr(consts, _dp),
                      _ptr(loss_kind, _ip), _ptr(loss_a, _dp)))
+
+    def sync_factors_indirect(self, ftype, slot_idx, slot_to_block, consts, loss_kind=None, loss_a=None, changed_rows=None):
+        """add_factors_indirect for a type's WHOLE table plus the rows that differ from the table of the previous call for the type
+        (None: no promise, the table is read whole).  The back-end keeps slot-named host / device copies of the reprojection table
+        across clear() and patches them (include/bsgpu.h)."""
+        slot_idx = np.ascontiguousarray(slot_idx, np.int32)
+        slot_to_block = np.ascontiguousarray(slot_to_block, np.int32)
+        consts = np.ascontiguousarray(consts, np.float64)
+        n = slot_idx.shape[0] if slot_idx.ndim == 2 else 0
+        if loss_kind is not None:
+            loss_kind = np.ascontiguousarray(np.broadcast_to(loss_kind, (n,)), np.int32)
+        if loss_a is not None:
+            loss_a = np.ascontiguousarray(np.broadcast_to(loss_a, (n,)), np.float64)
+        if changed_rows is not None:
+            changed_rows = np.ascontiguousarray(changed_rows, np.int32)
+        fn = self._f("sync_factors_indirect")
+        fn.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _ip, C.c_int32, _ip, _dp, _ip, _dp, C.c_int32, _ip]
+        fn.restype = C.c_int
+        self._chk(fn(self._ctx, ftype, n, _ptr(slot_idx, _ip), slot_to_block.size, _ptr(slot_to_block, _ip), _ptr(consts, _dp),
+                     _ptr(loss_kind, _ip), _ptr(loss_a, _dp), -1 if changed_rows is None else changed_rows.size,
+                     _ptr(changed_rows, _ip) if changed_rows is not None and changed_rows.size else None))
 
     def add_marginal(self, blocks, A, b, xbar):
         """fuse_constraints::MarginalConstraint: r = b + sum_i A_i (x_i [-] xbar_i)."""

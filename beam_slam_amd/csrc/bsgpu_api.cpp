@@ -41,6 +41,41 @@ int invalidate_keep_values(bsgpu_ctx* c) {
 // ===================================================================================================
 // C entry points
 // ===================================================================================================
+// ---- bsgpu_sync_factors_indirect -------------------------------------------------------------------
+namespace bsg {
+// block-named host copy of the mirrored group, for the paths that walk the rows on the host
+int materialize_mirror(bsgpu_ctx* c) {
+  SlotMirror& m = c->mirror0;
+  if (!m.active || m.materialized) return BSGPU_OK;
+  HostGroup& g = c->groups[BSGPU_F_REPROJ];
+  g.idx.resize((size_t)m.n * 4);
+  for (size_t f = 0; f < (size_t)m.n; ++f) {
+    for (int k = 0; k < 3; ++k) {
+      const int32_t s = m.idx[4 * f + k];
+      const int32_t b = ((uint32_t)s < (uint32_t)m.n_slots) ? m.s2b[s] : -1;
+      if (b < 0) return fail(c, BSGPU_ERR_INVALID, "sync_factors_indirect: slot out of range or not mapped to a block");
+      g.idx[4 * f + k] = b;
+    }
+    g.idx[4 * f + 3] = m.idx[4 * f + 3];
+  }
+  g.consts = m.consts; g.loss_kind = m.loss_kind; g.loss_a = m.loss_a;
+  g.n = m.n;
+  m.materialized = true;
+  return BSGPU_OK;
+}
+namespace {
+inline void mirror_count(SlotMirror& m, size_t r, int d) {
+  const int32_t* row = &m.idx[4 * r];
+  auto bump = [&](std::vector<int32_t>& v, int32_t s) { if ((size_t)s >= v.size()) v.resize((size_t)s + 1 + v.size() / 4, 0); v[s] += d; };
+  bump(m.use_q, row[0]); bump(m.use_p, row[1]); bump(m.use_l, row[2]); bump(m.cam_use, row[3]);
+  int kind = m.loss_kind[r];
+  double a = kind == BSGPU_LOSS_TRIVIAL ? 1.0 : m.loss_a[r];
+  for (auto& u : m.loss_use) if (u.kind == kind && u.a == a) { u.rows += d; return; }
+  m.loss_use.push_back({kind, a, d});
+}
+}  // namespace
+}  // namespace bsg
+
 extern "C" {
 
 int bsgpu_nidx(int t) { return (t >= 0 && t < BSGPU_F_NUM_TYPES) ? kTypes[t].nidx : -1; }
@@ -87,6 +122,7 @@ void bsgpu_destroy(bsgpu_ctx* c) {
   c->free_device();
   c->release_pool();
   if (c->h_scal) (void)hipHostFree(c->h_scal);
+  c->mirror0.release_device();
   if (c->h_radius) (void)hipHostFree(c->h_radius);
   if (c->h_pcg) (void)hipHostFree(c->h_pcg);
   for (hipEvent_t e : c->pcg_ev) if (e) (void)hipEventDestroy(e);
@@ -101,6 +137,7 @@ int bsgpu_clear(bsgpu_ctx* c) try {
   c->nb = 0; c->h_x.clear(); c->off.clear(); c->size.clear(); c->manifold.clear(); c->is_const.clear(); c->is_const_in.clear();
   c->cams.clear();
   for (auto& g : c->groups) { g.n = 0; g.idx.clear(); g.consts.clear(); g.loss_kind.clear(); g.loss_a.clear(); }   // (capacity kept: a window is re-described every cycle)
+  c->mirror0.active = false; c->mirror0.materialized = false;   // (the mirror itself stays: the next sync call patches it)
   c->marginals.clear();
   c->no_elim.clear();
   c->finalized = false;
@@ -186,6 +223,139 @@ int bsgpu_add_factors_indirect(bsgpu_ctx* c, int32_t type, int32_t n, const int3
   if (loss_a) g.loss_a.insert(g.loss_a.end(), loss_a, loss_a + n); else g.loss_a.insert(g.loss_a.end(), n, 1.0);
   g.n += n;
   return invalidate_keep_values(c);
+} catch (...) { return api_exception(c); }
+
+int bsgpu_sync_factors_indirect(bsgpu_ctx* c, int32_t type, int32_t n, const int32_t* slot_idx, int32_t n_slots, const int32_t* slot_to_block,
+                                const double* consts, const int32_t* loss_kind, const double* loss_a, int32_t n_changed,
+                                const int32_t* changed_rows) try {
+  if (!c) return BSGPU_ERR_INVALID;
+  if (type < 0 || type >= BSGPU_F_NUM_TYPES) return fail(c, BSGPU_ERR_INVALID, "unknown factor type");
+  if (n < 0 || n_slots < 0 || (n > 0 && (!slot_idx || !consts || !slot_to_block)) || (n_changed > 0 && !changed_rows))
+    return fail(c, BSGPU_ERR_INVALID, "sync_factors_indirect: bad argument");
+  if (c->groups[type].n != 0) return fail(c, BSGPU_ERR_INVALID, "sync_factors_indirect: the type already has factors in this description (it takes the whole table)");
+  // only the reprojection table is mirrored; the other types are a few thousand rows: copied in as before
+  if (type != BSGPU_F_REPROJ) return bsgpu_add_factors_indirect(c, type, n, slot_idx, n_slots, slot_to_block, consts, loss_kind, loss_a);
+  SlotMirror& m = c->mirror0;
+  const bool force_full = getenv("BSGPU_SYNC_FULL") != nullptr, check = getenv("BSGPU_SYNC_CHECK") != nullptr;
+  const bool full = n_changed < 0 || !m.valid || force_full;
+  auto row_ok = [&](size_t r) {
+    const int32_t* row = slot_idx + 4 * r;
+    if (row[0] < 0 || row[1] < 0 || row[2] < 0 || row[3] < 0) return false;
+    const int k = loss_kind ? loss_kind[r] : BSGPU_LOSS_TRIVIAL;
+    return k >= 0 && k <= BSGPU_LOSS_HUBER;
+  };
+  auto copy_row = [&](size_t r) {
+    std::memcpy(&m.idx[4 * r], slot_idx + 4 * r, sizeof(int32_t) * 4);
+    std::memcpy(&m.consts[3 * r], consts + 3 * r, sizeof(double) * 3);
+    m.loss_kind[r] = loss_kind ? loss_kind[r] : BSGPU_LOSS_TRIVIAL;
+    m.loss_a[r] = loss_a ? loss_a[r] : 1.0;
+  };
+  m.valid = false;   // (until the patch is complete: an error below leaves no half-patched mirror behind)
+  m.dev_valid = m.dev_valid && !full;
+  if (full) {
+    for (size_t r = 0; r < (size_t)n; ++r) if (!row_ok(r)) return fail(c, BSGPU_ERR_INVALID, "sync_factors_indirect: negative slot / camera id or unknown loss kind");
+    m.idx.assign(slot_idx, slot_idx + (size_t)n * 4);
+    m.consts.assign(consts, consts + (size_t)n * 3);
+    if (loss_kind) m.loss_kind.assign(loss_kind, loss_kind + n); else m.loss_kind.assign(n, BSGPU_LOSS_TRIVIAL);
+    if (loss_a) m.loss_a.assign(loss_a, loss_a + n); else m.loss_a.assign(n, 1.0);
+    std::fill(m.use_q.begin(), m.use_q.end(), 0); std::fill(m.use_p.begin(), m.use_p.end(), 0); std::fill(m.use_l.begin(), m.use_l.end(), 0);
+    std::fill(m.cam_use.begin(), m.cam_use.end(), 0);
+    m.loss_use.clear();
+    m.n = n;
+    for (size_t r = 0; r < (size_t)n; ++r) mirror_count(m, r, +1);
+  } else {
+    const int old_n = m.n;
+    for (int i = 0; i < n_changed; ++i) {
+      const int32_t r = changed_rows[i];
+      if (r < 0 || r >= n) return fail(c, BSGPU_ERR_INVALID, "sync_factors_indirect: changed row out of range");
+      if (!row_ok((size_t)r)) return fail(c, BSGPU_ERR_INVALID, "sync_factors_indirect: negative slot / camera id or unknown loss kind");
+    }
+    for (int r = n; r < old_n; ++r) mirror_count(m, (size_t)r, -1);           // rows that left at the end of the table
+    m.idx.resize((size_t)n * 4, -1); m.consts.resize((size_t)n * 3); m.loss_kind.resize(n); m.loss_a.resize(n);
+    m.n = n;
+    size_t fresh = 0;                                                          // every row beyond the old table must be listed
+    for (int i = 0; i < n_changed; ++i) {
+      const size_t r = (size_t)changed_rows[i];
+      if (m.idx[4 * r] >= 0) mirror_count(m, r, -1); else ++fresh;
+      copy_row(r);
+      mirror_count(m, r, +1);
+    }
+    if (n > old_n && fresh != (size_t)(n - old_n)) return fail(c, BSGPU_ERR_INVALID, "sync_factors_indirect: a row appended since the last call is not in the changed list");
+  }
+  if (check) {
+    bool same = std::memcmp(m.idx.data(), slot_idx, sizeof(int32_t) * 4 * (size_t)n) == 0 && std::memcmp(m.consts.data(), consts, sizeof(double) * 3 * (size_t)n) == 0;
+    for (size_t r = 0; r < (size_t)n && same; ++r)
+      same = m.loss_kind[r] == (loss_kind ? loss_kind[r] : BSGPU_LOSS_TRIVIAL) && m.loss_a[r] == (loss_a ? loss_a[r] : 1.0);
+    if (!same) return fail(c, BSGPU_ERR_INVALID, "sync_factors_indirect: the changed list does not account for every difference to the previous table (BSGPU_SYNC_CHECK)");
+  }
+  m.n_slots = n_slots;
+  m.s2b.assign(slot_to_block, slot_to_block + n_slots);
+  m.valid = true; m.active = true; m.materialized = false;
+  HostGroup& g = c->groups[BSGPU_F_REPROJ];
+  g.n = n; g.idx.clear(); g.consts.clear(); g.loss_kind.clear(); g.loss_a.clear();
+  const int rc = invalidate_keep_values(c);
+  if (rc != BSGPU_OK) return rc;
+  // ---- device copy (what finalize() flattens from when the window is large enough for the device path)
+  if (n < kDeviceFlattenMin) { m.dev_valid = false; return BSGPU_OK; }
+  HIPCHK(c, hipSetDevice(c->device));
+  if ((size_t)n > m.d_cap) {
+    const size_t cap = (size_t)n + (size_t)n / 4 + 4096;
+    int32_t* ni = nullptr; double* nc = nullptr; int32_t* nk = nullptr; double* na = nullptr;
+    HIPCHK(c, hipMalloc((void**)&ni, sizeof(int32_t) * 4 * cap)); HIPCHK(c, hipMalloc((void**)&nc, sizeof(double) * 3 * cap));
+    HIPCHK(c, hipMalloc((void**)&nk, sizeof(int32_t) * cap)); HIPCHK(c, hipMalloc((void**)&na, sizeof(double) * cap));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (m.d_idx) (void)hipFree(m.d_idx);
+    if (m.d_consts) (void)hipFree(m.d_consts);
+    if (m.d_lk) (void)hipFree(m.d_lk);
+    if (m.d_la) (void)hipFree(m.d_la);
+    m.d_idx = ni; m.d_consts = nc; m.d_lk = nk; m.d_la = na; m.d_cap = cap;
+    m.dev_valid = false;   // (a grown table is re-sent whole: happens once per 25 % of growth)
+  }
+  if ((size_t)n_slots > m.d_s2b_cap) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (m.d_s2b) (void)hipFree(m.d_s2b);
+    m.d_s2b = nullptr; m.d_s2b_cap = 0;
+    const size_t cap = (size_t)n_slots + (size_t)n_slots / 4 + 1024;
+    HIPCHK(c, hipMalloc((void**)&m.d_s2b, sizeof(int32_t) * cap));
+    m.d_s2b_cap = cap;
+  }
+  if (!m.dev_valid) {
+    HIPCHK(c, hipMemcpyAsync(m.d_idx, m.idx.data(), sizeof(int32_t) * 4 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(m.d_consts, m.consts.data(), sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(m.d_lk, m.loss_kind.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(m.d_la, m.loss_a.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  } else if (n_changed > 0) {
+    // packed changed rows: [idx x 4 | rows | loss kind] ints, then [consts x 3 | loss a] doubles
+    const size_t nch = (size_t)n_changed;
+    const size_t bytes_i = sizeof(int32_t) * nch * 6, off_d = (bytes_i + 15) & ~(size_t)15, bytes = off_d + sizeof(double) * nch * 4;
+    if (bytes > m.stage_cap) {
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      if (m.h_stage) (void)hipHostFree(m.h_stage);
+      if (m.d_stage) (void)hipFree(m.d_stage);
+      m.h_stage = nullptr; m.d_stage = nullptr; m.stage_cap = 0;
+      const size_t cap = bytes * 2 + 4096;
+      HIPCHK(c, hipHostMalloc((void**)&m.h_stage, cap)); HIPCHK(c, hipMalloc((void**)&m.d_stage, cap));
+      m.stage_cap = cap;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // (the staging buffer of the previous call has long been consumed; this makes it certain)
+    int32_t* hi = reinterpret_cast<int32_t*>(m.h_stage);
+    double* hd = reinterpret_cast<double*>(m.h_stage + off_d);
+    for (size_t i = 0; i < nch; ++i) {
+      const size_t r = (size_t)changed_rows[i];
+      std::memcpy(hi + 4 * i, &m.idx[4 * r], sizeof(int32_t) * 4);
+      hi[4 * nch + i] = (int32_t)r;
+      hi[5 * nch + i] = m.loss_kind[r];
+      std::memcpy(hd + 3 * i, &m.consts[3 * r], sizeof(double) * 3);
+      hd[3 * nch + i] = m.loss_a[r];
+    }
+    HIPCHK(c, hipMemcpyAsync(m.d_stage, m.h_stage, bytes, hipMemcpyHostToDevice, c->stream));
+    const int32_t* di = reinterpret_cast<const int32_t*>(m.d_stage);
+    const double* dd = reinterpret_cast<const double*>(m.d_stage + off_d);
+    launch_patch_factor_rows(c->stream, n_changed, di + 4 * nch, di, dd, di + 5 * nch, dd + 3 * nch, m.d_idx, m.d_consts, m.d_lk, m.d_la);
+  }
+  HIPCHK(c, hipMemcpyAsync(m.d_s2b, m.s2b.data(), sizeof(int32_t) * (size_t)n_slots, hipMemcpyHostToDevice, c->stream));
+  m.dev_valid = true;
+  return BSGPU_OK;
 } catch (...) { return api_exception(c); }
 int bsgpu_add_marginal(bsgpu_ctx* c, int32_t n_blocks, const int32_t* blocks, int32_t n_rows, const double* A, const double* b,
                        const double* xbar) try {
@@ -367,6 +537,7 @@ int bsgpu_marginalize(bsgpu_ctx* c, int32_t n_marg, const int32_t* marg_blocks, 
   if (!marg_blocks || n_marg <= 0 || !n_kept || !n_rows || !n_cols) return fail(c, BSGPU_ERR_INVALID, "marginalize: bad arguments");
   int rc = finalize(c);
   if (rc != BSGPU_OK) return rc;
+  if ((rc = materialize_mirror(c)) != BSGPU_OK) return rc;   // (the factors touching the blocks are picked from the host rows)
   c->marg_result = bsgpu_ctx::MargResult();
   const int nb = c->nb;
   std::vector<uint8_t> is_marg(nb, 0), used(nb, 0);

@@ -61,6 +61,8 @@ constexpr size_t kDenseLimit = 12288;
 // memory instead of LDS (slower per panel, no size cliff).  The bound is what the dense tile storage costs: 2 x npad^2 doubles
 // (S and its shadow) = 2 x 19 GB at 49 152 — HBM is 288 GB.
 constexpr size_t kDenseLimitLandmarks = 49152;
+// windows with at least this many reprojection factors are flattened on the device (k_flatten.hip)
+constexpr int kDeviceFlattenMin = 20000;
 
 struct HostGroup {
   int n = 0;
@@ -68,6 +70,44 @@ struct HostGroup {
   std::vector<double> consts;
   std::vector<int32_t> loss_kind;
   std::vector<double> loss_a;
+};
+
+// The reprojection table of a caller that keeps it across solves and reports what changed (bsgpu_sync_factors_indirect,
+// SURVEY.md §8f rank 2): a host and a device copy NAMED BY CALLER SLOTS that outlive bsgpu_clear() and are patched row by row,
+// with per-slot use counts so that finalize() validates and classifies the blocks without a pass over 400 k rows.  The
+// block-named host copy of the group (groups[BSGPU_F_REPROJ].idx ...) is only materialised for the paths that need it
+// (host flattening, marginalisation).
+struct SlotMirror {
+  bool valid = false;          // holds the table of the last sync call
+  bool active = false;         // the current description's group is this table (bsgpu_clear resets)
+  bool materialized = false;   // groups[BSGPU_F_REPROJ] holds the translated copy
+  int n = 0, n_slots = 0;
+  std::vector<int32_t> idx;    // n x 4: q slot, p slot, landmark slot, camera id
+  std::vector<double> consts;  // n x 3
+  std::vector<int32_t> loss_kind;
+  std::vector<double> loss_a;
+  std::vector<int32_t> use_q, use_p, use_l;   // per slot: rows naming it as orientation / position / landmark
+  std::vector<int32_t> cam_use;               // per camera id
+  struct LossUse { int kind; double a; int64_t rows; };
+  std::vector<LossUse> loss_use;              // distinct losses of the rows
+  std::vector<int32_t> s2b;                   // slot -> block of the current description
+  // device copy (own allocations: they live across finalize() calls)
+  int32_t* d_idx = nullptr; double* d_consts = nullptr; int32_t* d_lk = nullptr; double* d_la = nullptr;
+  size_t d_cap = 0;
+  int32_t* d_s2b = nullptr; size_t d_s2b_cap = 0;
+  unsigned char* h_stage = nullptr; unsigned char* d_stage = nullptr; size_t stage_cap = 0;   // packed changed rows (pinned / device)
+  bool dev_valid = false;
+  void release_device() {
+    if (d_idx) (void)hipFree(d_idx);
+    if (d_consts) (void)hipFree(d_consts);
+    if (d_lk) (void)hipFree(d_lk);
+    if (d_la) (void)hipFree(d_la);
+    if (d_s2b) (void)hipFree(d_s2b);
+    if (d_stage) (void)hipFree(d_stage);
+    if (h_stage) (void)hipHostFree(h_stage);
+    d_idx = nullptr; d_consts = nullptr; d_lk = nullptr; d_la = nullptr; d_s2b = nullptr; d_stage = nullptr; h_stage = nullptr;
+    d_cap = d_s2b_cap = stage_cap = 0; dev_valid = false;
+  }
 };
 
 
@@ -86,6 +126,7 @@ struct bsgpu_ctx {
   std::vector<uint8_t> size, manifold, is_const, is_const_in;   // is_const_in: as given; is_const: + blocks no factor touches
   std::vector<bsgpu_camera> cams;
   HostGroup groups[kNumInternal];
+  SlotMirror mirror0;            // BSGPU_F_REPROJ through bsgpu_sync_factors_indirect
   bool finalized = false;
   // ---- derived structure
   std::vector<int> tsize, toff;
@@ -235,6 +276,8 @@ int api_exception(bsgpu_ctx* c) noexcept;   // bsgpu_api.cpp: where every entry 
 #define HIPCHK(c, call)                                                                         \
   do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(c, BSGPU_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
 
+// bsgpu_api.cpp
+int materialize_mirror(bsgpu_ctx* c);   // block-named host copy of the mirrored reprojection group
 // bsgpu_finalize.cpp
 int finalize(bsgpu_ctx* c);
 int build_bsr(bsgpu_ctx* c);

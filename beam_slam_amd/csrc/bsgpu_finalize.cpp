@@ -41,6 +41,25 @@ int finalize(bsgpu_ctx* c) {
   for (int t = 0; t < BSGPU_F_NUM_TYPES; ++t) {
     const HostGroup& g = c->groups[t];
     const TypeInfo& ti = kTypes[t];
+    if (t == BSGPU_F_REPROJ && c->mirror0.active && !c->mirror0.materialized) {
+      // the table lives in the slot-named mirror (bsgpu_sync_factors_indirect): the same checks and use counts from its per-slot
+      // counters — a pass over the slots, not over the rows
+      const SlotMirror& m = c->mirror0;
+      const size_t ns = std::max({m.use_q.size(), m.use_p.size(), m.use_l.size()});
+      for (size_t sl = 0; sl < ns; ++sl) {
+        const int uq = sl < m.use_q.size() ? m.use_q[sl] : 0, up = sl < m.use_p.size() ? m.use_p[sl] : 0, ul = sl < m.use_l.size() ? m.use_l[sl] : 0;
+        if (!(uq | up | ul)) continue;
+        const int b = sl < (size_t)m.n_slots ? m.s2b[sl] : -1;
+        if (b < 0 || b >= nb) return fail(c, BSGPU_ERR_INVALID, "sync_factors_indirect: slot out of range or not mapped to a block");
+        if (uq && (c->size[b] != 4 || c->manifold[b] != BSGPU_MANIFOLD_QUAT_RIGHT))
+          return fail(c, BSGPU_ERR_INVALID, c->size[b] != 4 ? "block size does not match factor slot" : "4-d slot must be a quaternion-manifold block");
+        if ((up || ul) && c->size[b] != 3) return fail(c, BSGPU_ERR_INVALID, "block size does not match factor slot");
+        other_use[b] += uq + up; lm_use[b] += ul;
+      }
+      for (size_t cam = 0; cam < m.cam_use.size(); ++cam)
+        if (m.cam_use[cam] > 0 && cam >= c->cams.size()) return fail(c, BSGPU_ERR_INVALID, "camera index out of range");
+      continue;
+    }
     for (int f = 0; f < g.n; ++f) {
       const int32_t* idx = &g.idx[(size_t)f * ti.nidx];
       for (int sl = 0; sl < ti.nvar; ++sl) {
@@ -147,6 +166,7 @@ int finalize(bsgpu_ctx* c) {
   c->vis_src.clear();
   c->d_vis_src = nullptr;
   auto host_visual = [&]() -> int {
+  { const int rc_m = materialize_mirror(c); if (rc_m != BSGPU_OK) return rc_m; }
   struct VF { int xq, xp, xl, bq, bp, meta_cam, loss, flags, lm, src; double u, v, w; };
   std::vector<VF> vf;
   for (int t = 0; t <= 1; ++t) {
@@ -334,10 +354,14 @@ int finalize(bsgpu_ctx* c) {
     const char* fe = getenv("BSGPU_FLATTEN");
     const bool force_dev = fe && !strcmp(fe, "device"), force_host = fe && !strcmp(fe, "host");
     const HostGroup& g0 = c->groups[BSGPU_F_REPROJ];
-    if (!force_host && c->groups[BSGPU_F_REPROJ_ONLINE_CALIB].n == 0 && g0.n > 0 && (force_dev || g0.n >= 20000)) {
+    SlotMirror& mir = c->mirror0;
+    const bool resident = mir.active && !mir.materialized && mir.dev_valid;
+    if (!force_host && c->groups[BSGPU_F_REPROJ_ONLINE_CALIB].n == 0 && g0.n > 0 && (force_dev || g0.n >= kDeviceFlattenMin)) {
       // distinct losses of the reprojection factors (a window has one or two)
       bool ok = true;
-      for (int f = 0; f < g0.n && ok; ++f) { get_loss(g0.loss_kind[f], g0.loss_a[f]); ok = losses.size() <= 8; }
+      if (mir.active && !mir.materialized && !resident) { const int rc_m = materialize_mirror(c); if (rc_m != BSGPU_OK) return rc_m; }
+      if (resident) { for (const auto& u : mir.loss_use) if (u.rows > 0 && ok) { get_loss(u.kind, u.a); ok = losses.size() <= 8; } }
+      else for (int f = 0; f < g0.n && ok; ++f) { get_loss(g0.loss_kind[f], g0.loss_a[f]); ok = losses.size() <= 8; }
       if (ok) {
         std::vector<int> bx(c->off.begin(), c->off.end());
         std::vector<unsigned char> bc(c->is_const.begin(), c->is_const.end());
@@ -346,8 +370,10 @@ int finalize(bsgpu_ctx* c) {
         const int T = (c->n_pose + 63) / 64;
         bool all_const = false;
         auto dalloc = [&](size_t bytes) -> void* { return c->alloc<unsigned char>(bytes); };
+        const FlattenResident res = {mir.d_idx, mir.d_consts, mir.d_lk, mir.d_la, mir.d_s2b};
         const int st = flatten_visual_device(c->stream, dalloc, g0.n, g0.idx.data(), g0.consts.data(), g0.loss_kind.data(), g0.loss_a.data(),
-                                             losses, nb, d_bx, d_bt, d_bc, d_bl, nl, T, c->vis, &c->d_vis_src, c->tile_adj, &all_const);
+                                             losses, nb, d_bx, d_bt, d_bc, d_bl, nl, T, c->vis, &c->d_vis_src, c->tile_adj, &all_const,
+                                             resident ? &res : nullptr);
         if (st < 0) return fail(c, BSGPU_ERR_DEVICE, "device error while flattening the reprojection factors");
         if (st == 0) {
           flattened_on_device = true;

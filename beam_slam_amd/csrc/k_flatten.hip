@@ -27,10 +27,13 @@ __global__ void fl_prep_kernel(int n, const int* __restrict__ idx /* n x 4 */, c
                                const unsigned char* __restrict__ blk_const, const int* __restrict__ blk_lm, int nl,
                                unsigned* __restrict__ key, int4* __restrict__ fac, double2* __restrict__ pix, double* __restrict__ w,
                                int* __restrict__ lm_of, int* __restrict__ bq_of, int* __restrict__ used_q, int* __restrict__ p_of_q,
-                               int* __restrict__ flags_out /* [0] fallback, [1] some factor fully constant */) {
+                               int* __restrict__ flags_out /* [0] fallback, [1] some factor fully constant */,
+                               const int* __restrict__ slot_map /* the idx columns hold caller slots (device-resident table) */) {
   const int f = blockIdx.x * 256 + threadIdx.x;
   if (f >= n) return;
-  const int bq = idx[4 * f], bp = idx[4 * f + 1], bl = idx[4 * f + 2], cam = idx[4 * f + 3];
+  const int4 row = reinterpret_cast<const int4*>(idx)[f];
+  const int bq = slot_map ? slot_map[row.x] : row.x, bp = slot_map ? slot_map[row.y] : row.y, bl = slot_map ? slot_map[row.z] : row.z;
+  const int cam = row.w;
   const int lm = blk_lm[bl];
   const int cq = blk_const[bq], cp = blk_const[bp], cl = blk_const[bl];
   if (lm < 0 && !cl) flags_out[0] = 1;           // a landmark block that is neither eliminated nor constant: host path
@@ -137,20 +140,40 @@ __global__ void fl_seg_kernel(int n_seg, int n_ent, int* __restrict__ seg_start,
   }
 }
 
+// changed rows of the device-resident slot-named table (bsgpu_sync_factors_indirect): packed (row, idx x 4, consts x 3, loss) -> place
+__global__ void fl_patch_kernel(int n_ch, const int* __restrict__ rows, const int4* __restrict__ idx4, const double* __restrict__ consts3,
+                                const int* __restrict__ lk, const double* __restrict__ la, int4* __restrict__ dst_idx,
+                                double* __restrict__ dst_consts, int* __restrict__ dst_lk, double* __restrict__ dst_la) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_ch) return;
+  const size_t r = (size_t)rows[i];
+  dst_idx[r] = idx4[i];
+  dst_consts[3 * r] = consts3[3 * i]; dst_consts[3 * r + 1] = consts3[3 * i + 1]; dst_consts[3 * r + 2] = consts3[3 * i + 2];
+  dst_lk[r] = lk[i]; dst_la[r] = la[i];
+}
+
 }  // namespace
+
+void launch_patch_factor_rows(hipStream_t s, int n_ch, const int* rows, const int* idx4, const double* consts3, const int* lk, const double* la,
+                              int* dst_idx, double* dst_consts, int* dst_lk, double* dst_la) {
+  if (n_ch <= 0) return;
+  hipLaunchKernelGGL(fl_patch_kernel, dim3((n_ch + 255) / 256), dim3(256), 0, s, n_ch, rows, reinterpret_cast<const int4*>(idx4), consts3, lk, la,
+                     reinterpret_cast<int4*>(dst_idx), dst_consts, dst_lk, dst_la);
+}
 
 // returns 0 = tables built, 1 = this window needs the host path, < 0 = device error
 int flatten_visual_device(hipStream_t s, const std::function<void*(size_t)>& dalloc, int n, const int* h_idx, const double* h_consts,
                           const int* h_loss_kind, const double* h_loss_a, const std::vector<DevLoss>& losses, int nb, const int* d_blk_xoff,
                           const int* d_blk_toff, const unsigned char* d_blk_const, const int* d_blk_lm, int nl, int T, Visual& V,
-                          int** d_vis_src, std::vector<unsigned char>& tile_adj, bool* any_all_const) {
+                          int** d_vis_src, std::vector<unsigned char>& tile_adj, bool* any_all_const, const FlattenResident* res) {
   auto A = [&](size_t bytes) { return dalloc(bytes ? bytes : 8); };
 #define FL_CHK(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); return -1; } } while (0)
   const int g256 = (n + 255) / 256;
-  int* d_idx = (int*)A(sizeof(int) * 4 * (size_t)n);
-  double* d_consts = (double*)A(sizeof(double) * 3 * (size_t)n);
-  int* d_lk = (int*)A(sizeof(int) * (size_t)n);
-  double* d_la = (double*)A(sizeof(double) * (size_t)n);
+  // (with a device-resident table — bsgpu_sync_factors_indirect — nothing is copied: the 20 MB of a C2 window stay where they are)
+  int* d_idx = res ? const_cast<int*>(res->idx) : (int*)A(sizeof(int) * 4 * (size_t)n);
+  double* d_consts = res ? const_cast<double*>(res->consts) : (double*)A(sizeof(double) * 3 * (size_t)n);
+  int* d_lk = res ? const_cast<int*>(res->loss_kind) : (int*)A(sizeof(int) * (size_t)n);
+  double* d_la = res ? const_cast<double*>(res->loss_a) : (double*)A(sizeof(double) * (size_t)n);
   const int n_loss = (int)losses.size();
   std::vector<int> tk(n_loss); std::vector<double> ta(n_loss);
   for (int i = 0; i < n_loss; ++i) { tk[i] = losses[i].kind; ta[i] = losses[i].a; }
@@ -164,17 +187,19 @@ int flatten_visual_device(hipStream_t s, const std::function<void*(size_t)>& dal
   int* d_flags = (int*)A(sizeof(int) * 4);
   if (!d_idx || !d_consts || !d_lk || !d_la || !d_key || !d_key2 || !d_fac0 || !d_pix0 || !d_w0 || !d_lm0 || !d_bq0 || !d_order ||
       !d_used || !d_pofq || !d_cpofq || !d_flags || !d_tk || !d_ta) return -1;
-  FL_CHK(hipMemcpyAsync(d_idx, h_idx, sizeof(int) * 4 * (size_t)n, hipMemcpyHostToDevice, s));
-  FL_CHK(hipMemcpyAsync(d_consts, h_consts, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
-  FL_CHK(hipMemcpyAsync(d_lk, h_loss_kind, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, s));
-  FL_CHK(hipMemcpyAsync(d_la, h_loss_a, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, s));
+  if (!res) {
+    FL_CHK(hipMemcpyAsync(d_idx, h_idx, sizeof(int) * 4 * (size_t)n, hipMemcpyHostToDevice, s));
+    FL_CHK(hipMemcpyAsync(d_consts, h_consts, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
+    FL_CHK(hipMemcpyAsync(d_lk, h_loss_kind, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, s));
+    FL_CHK(hipMemcpyAsync(d_la, h_loss_a, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, s));
+  }
   FL_CHK(hipMemcpyAsync(d_tk, tk.data(), sizeof(int) * n_loss, hipMemcpyHostToDevice, s));
   FL_CHK(hipMemcpyAsync(d_ta, ta.data(), sizeof(double) * n_loss, hipMemcpyHostToDevice, s));
   FL_CHK(hipMemsetAsync(d_used, 0, sizeof(int) * ((size_t)nb + 1), s));
   FL_CHK(hipMemsetAsync(d_pofq, 0xff, sizeof(int) * (size_t)nb, s));
   FL_CHK(hipMemsetAsync(d_flags, 0, sizeof(int) * 4, s));
   hipLaunchKernelGGL(fl_prep_kernel, dim3(g256), dim3(256), 0, s, n, d_idx, d_consts, d_lk, d_la, n_loss, d_tk, d_ta, d_blk_xoff, d_blk_const,
-                     d_blk_lm, nl, d_key, d_fac0, d_pix0, d_w0, d_lm0, d_bq0, d_used, d_pofq, d_flags);
+                     d_blk_lm, nl, d_key, d_fac0, d_pix0, d_w0, d_lm0, d_bq0, d_used, d_pofq, d_flags, res ? res->slot_map : nullptr);
   // camera-pose ids: exclusive scan of the used orientation blocks (ascending block index = the host's (q, p) order)
   size_t tmp_bytes = 0, need = 0;
   auto grow = [&](size_t b) { if (b > tmp_bytes) tmp_bytes = b; };

@@ -129,10 +129,6 @@ class Variable {
   virtual int stateSlot() const { return 99; }       // q,p,v,bg,ba = 0..4 inside one keyframe
   virtual bool isLandmark() const { return false; }
   virtual uint64_t landmarkId() const { return 0; }
-  // position in the flat block table of the last flattening (set by the graph; lets constraints resolve their
-  // variables without a UUID lookup per slot)
-  int32_t flatIndex() const { return flat_index_; }
-  void flatIndex(int32_t i) const { flat_index_ = i; }
   virtual void print(std::ostream& s) const {
     s << type() << " uuid " << uuid() << " [";
     for (size_t i = 0; i < size(); ++i) s << (i ? ", " : "") << data()[i];
@@ -140,7 +136,6 @@ class Variable {
   }
  private:
   UUID uuid_;
-  mutable int32_t flat_index_ = -1;
 };
 
 // ---- Constraint ------------------------------------------------------------------------------------

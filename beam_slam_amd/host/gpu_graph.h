@@ -131,9 +131,10 @@ class GpuGraph {
 
   // ---- fuse_core::Graph surface used by the reference ---------------------------------
   void clear() {
-    vslots_.clear(); vfree_.clear(); vindex_.clear(); vmeta_.clear(); ordered_.clear(); on_hold_.clear();
+    vslots_.clear(); vfree_.clear(); vindex_.clear(); vmeta_.clear(); vdata_.clear(); ordered_.clear(); on_hold_.clear();
     cptr_.clear(); ctype_.clear(); crow_.clear(); cfree_.clear(); cindex_.clear();
     for (auto& t : tables_) t.reset();
+    for (int ty = 0; ty < BSGPU_F_NUM_TYPES; ++ty) { dirty_[ty].clear(); synced_[ty] = false; }
     cameras_.clear(); marginal_rows_.clear();
     conn_.clear(); connectivity_valid_ = true;
   }
@@ -170,8 +171,9 @@ class GpuGraph {
     if (have >= 0) { std::memcpy(vslots_[have]->data(), v->data(), v->size() * sizeof(double)); return false; }  // HashGraph: overwrite value
     int32_t s;
     if (!vfree_.empty()) { s = vfree_.back(); vfree_.pop_back(); }
-    else { s = (int32_t)vslots_.size(); vslots_.emplace_back(); vmeta_.emplace_back(); if (connectivity_valid_) conn_.emplace_back(); }
+    else { s = (int32_t)vslots_.size(); vslots_.emplace_back(); vmeta_.emplace_back(); vdata_.emplace_back(); if (connectivity_valid_) conn_.emplace_back(); }
     vmeta_[s] = VMeta{(uint8_t)v->size(), (uint8_t)v->manifold(), (uint8_t)(v->holdConstant() ? 1 : 0)};
+    vdata_[s] = v->data();
     vindex_.insert(v->uuid(), s);
     vslots_[s] = std::move(v);
     ordered_.insert(std::upper_bound(ordered_.begin(), ordered_.end(), s, [this](int32_t a, int32_t b) { return orderBefore(vslots_[a].get(), vslots_[b].get()); }), s);
@@ -189,6 +191,7 @@ class GpuGraph {
     }
     on_hold_.erase(u); vindex_.erase(u);
     vslots_[s].reset();
+    vdata_[s] = nullptr;
     vfree_.push_back(s);
     return true;
   }
@@ -262,7 +265,8 @@ class GpuGraph {
     };
     UniquePtr g(new GpuGraph(device_, DeferContext{}));
     g->vslots_.resize(vslots_.size());
-    for (size_t i = 0; i < vslots_.size(); ++i) if (vslots_[i]) g->vslots_[i] = vslots_[i]->clone();
+    g->vdata_.assign(vslots_.size(), nullptr);
+    for (size_t i = 0; i < vslots_.size(); ++i) if (vslots_[i]) { g->vslots_[i] = vslots_[i]->clone(); g->vdata_[i] = g->vslots_[i]->data(); }
     g->vfree_ = vfree_; g->vindex_ = vindex_; g->vmeta_ = vmeta_; g->ordered_ = ordered_; g->on_hold_ = on_hold_;
     lap("variables");
     g->cptr_ = cptr_; g->ctype_ = ctype_; g->crow_ = crow_; g->cfree_ = cfree_; g->cindex_ = cindex_;
@@ -297,13 +301,17 @@ class GpuGraph {
 
   // Flat IR of the current graph (variables at their current values) loaded into the back-end context
   struct Flat {
-    std::vector<const fuse_core::Variable*> vars;
     std::vector<double> values;
     std::vector<int32_t> offset;
     std::vector<uint8_t> size, manifold, is_const;
     std::vector<int32_t> slot_to_block;   // graph-local variable slot -> block index (-1: free slot)
   };
-  int32_t blockIndexOf(const fuse_core::UUID& u) const { return getVariable(u).flatIndex(); }   // valid right after flatten()
+  // block index of a variable in the table of the last flatten() (valid until the next graph mutation)
+  int32_t blockIndexOf(const Flat& f, const fuse_core::UUID& u) const {
+    const int32_t s = vindex_.find(u);
+    if (s < 0) throw std::out_of_range("variable not in graph");
+    return f.slot_to_block[s];
+  }
   bool flatten(Flat& f) {
     const bool timing = std::getenv("BS_HOST_TIMING") != nullptr;
     auto t_prev = std::chrono::steady_clock::now();
@@ -315,33 +323,42 @@ class GpuGraph {
     };
     const size_t nb = ordered_.size();
     if (!nb) return false;
-    f.vars.resize(nb); f.offset.resize(nb); f.size.resize(nb); f.manifold.resize(nb); f.is_const.resize(nb);
+    f.offset.resize(nb); f.size.resize(nb); f.manifold.resize(nb); f.is_const.resize(nb);
     f.slot_to_block.assign(vslots_.size(), -1);
     size_t nval = 0;
     for (size_t i = 0; i < nb; ++i) { f.offset[i] = (int32_t)nval; nval += vmeta_[ordered_[i]].size; }
     f.values.resize(nval);
+    // The values live inside 51 000 separately allocated Variable objects: the loop is a chain of cache misses unless the
+    // objects are requested ahead.  Nothing is written into them (the block index of a variable is f.slot_to_block).
+    const int32_t* ord = ordered_.data();
+    constexpr size_t kAhead = 24;
     for (size_t i = 0; i < nb; ++i) {
-      const int32_t s = ordered_[i];
-      const VMeta& m = vmeta_[s];
-      const fuse_core::Variable* v = vslots_[s].get();
-      f.vars[i] = v;
-      v->flatIndex((int32_t)i);
+      if (i + kAhead < nb) __builtin_prefetch(vdata_[ord[i + kAhead]], 0, 0);
+      const int32_t s = ord[i];
+      const VMeta m = vmeta_[s];
       f.slot_to_block[s] = (int32_t)i;
       f.size[i] = m.size; f.manifold[i] = m.manifold; f.is_const[i] = m.hold_constant;
-      std::memcpy(&f.values[f.offset[i]], v->data(), m.size * sizeof(double));
+      const double* src = vdata_[s];
+      double* dst = &f.values[f.offset[i]];
+      for (int k = 0; k < m.size; ++k) dst[k] = src[k];
     }
     for (const auto& u : on_hold_) { const int32_t s = vindex_.find(u); if (s >= 0) f.is_const[f.slot_to_block[s]] = 1; }
     lap("block table");
-    // The packed rows name their variables by slot and were written once, when the constraint entered the graph: the only
-    // per-cycle translation, slot -> block index, happens inside the back-end's copy (bsgpu_add_factors_indirect).
+    // The packed rows name their variables by slot and were written once, when the constraint entered the graph.  The back-end
+    // keeps its own slot-named copy of the big tables across cycles (bsgpu_sync_factors_indirect) and is told which rows this
+    // graph has written since the last hand-over; slot -> block is translated on its side.
     check(bsgpu_clear(ctx()));
     check(bsgpu_set_blocks(ctx(), (int32_t)nb, f.values.data(), f.offset.data(), f.size.data(), f.manifold.data(), f.is_const.data()));
     if (!cameras_.empty()) check(bsgpu_set_cameras(ctx(), (int32_t)cameras_.size(), cameras_.data()));
     for (int ty = 0; ty < BSGPU_F_NUM_TYPES; ++ty) {
       const TypeTable* tb = tables_[ty].get();
-      if (tb && tb->rows)
-        check(bsgpu_add_factors_indirect(ctx(), ty, (int32_t)tb->rows, tb->idx.data(), (int32_t)f.slot_to_block.size(), f.slot_to_block.data(),
-                                           tb->consts.data(), tb->loss_kind.data(), tb->loss_a.data()));
+      if (!tb || !tb->rows) continue;   // (nothing to say: the change list keeps growing until the next call for the type)
+      std::vector<int32_t>& d = dirty_[ty];
+      d.erase(std::remove_if(d.begin(), d.end(), [&](int32_t r) { return (size_t)r >= tb->rows; }), d.end());   // rows that have left since
+      check(bsgpu_sync_factors_indirect(ctx(), ty, (int32_t)tb->rows, tb->idx.data(), (int32_t)f.slot_to_block.size(), f.slot_to_block.data(),
+                                          tb->consts.data(), tb->loss_kind.data(), tb->loss_a.data(), synced_[ty] ? (int32_t)d.size() : -1, d.data()));
+      synced_[ty] = true;
+      d.clear();
     }
     for (const auto& kv : marginal_rows_) {
       const auto& m = kv.second;
@@ -355,10 +372,10 @@ class GpuGraph {
 
   ceres_compat::SolverSummary optimize(const ceres_compat::SolverOptions& o = ceres_compat::SolverOptions()) {
     const auto t0 = std::chrono::steady_clock::now();
-    Flat f;
+    Flat& f = flat_;   // (kept between cycles: no 2 MB of fresh pages per call)
     ceres_compat::SolverSummary s;
     if (!flatten(f)) { s.termination_type = ceres_compat::CONVERGENCE; s.message = "empty graph"; return s; }
-    auto& vars = f.vars; auto& values = f.values; auto& offset = f.offset; auto& size = f.size;
+    auto& values = f.values; auto& offset = f.offset; auto& size = f.size;
     bsgpu_options bo;
     bsgpu_options_default(&bo);
     bo.max_num_iterations = o.max_num_iterations; bo.max_solver_time_in_seconds = o.max_solver_time_in_seconds;
@@ -377,8 +394,16 @@ class GpuGraph {
     }
     if (bs.is_solution_usable) {   // [EXT] ceres::Solver: parameter blocks are written back only if IsSolutionUsable()
       check(bsgpu_get_blocks(ctx(), values.data(), (int64_t)values.size()));
-      for (size_t i = 0; i < vars.size(); ++i)   // Variable::data() updated in place, like Ceres does through the raw pointers
-        std::memcpy(const_cast<fuse_core::Variable*>(vars[i])->data(), values.data() + offset[i], size[i] * sizeof(double));
+      const int32_t* ord = ordered_.data();
+      const size_t nb = ordered_.size();
+      constexpr size_t kAhead = 24;
+      for (size_t i = 0; i < nb; ++i) {   // Variable::data() updated in place, like Ceres does through the raw pointers
+        if (i + kAhead < nb) __builtin_prefetch(vdata_[ord[i + kAhead]], 1, 0);
+        if (f.is_const[i]) continue;       // (a constant block comes back as it went in)
+        double* dst = vdata_[ord[i]];
+        const double* src = values.data() + offset[i];
+        for (int k = 0; k < size[i]; ++k) dst[k] = src[k];
+      }
     }
     s.termination_type = bs.termination_type == BSGPU_CONVERGENCE ? ceres_compat::CONVERGENCE
                        : bs.termination_type == BSGPU_NO_CONVERGENCE ? ceres_compat::NO_CONVERGENCE : ceres_compat::FAILURE;
@@ -415,11 +440,11 @@ class GpuGraph {
       tr.removeVariable(u);
     }
     if (constrained.empty()) return tr;
-    Flat f;
+    Flat& f = flat_;
     if (!flatten(f)) return tr;
     std::vector<int32_t> marg;
     for (const auto& u : constrained) {
-      const int32_t b = blockIndexOf(u);
+      const int32_t b = blockIndexOf(f, u);
       if (f.is_const[b]) throw std::logic_error("marginalizeVariables: variable is held constant");
       marg.push_back(b);
     }
@@ -433,7 +458,7 @@ class GpuGraph {
     std::vector<double> A((size_t)n_rows * n_cols), bvec(n_rows), xbar(amb);
     check(bsgpu_get_marginal(ctx(), kept.data(), A.data(), bvec.data(), xbar.data()));
     std::vector<fuse_core::UUID> kept_ids;
-    for (int32_t b : kept) kept_ids.push_back(f.vars[b]->uuid());
+    for (int32_t b : kept) kept_ids.push_back(vslots_[ordered_[b]]->uuid());
     tr.addConstraint(std::make_shared<fuse_constraints::MarginalConstraint>(source, std::move(kept_ids), n_rows, n_cols, std::move(A), std::move(bvec), std::move(xbar)));
     return tr;
   }
@@ -444,13 +469,13 @@ class GpuGraph {
   // eliminated by the solver (throws, like fuse does for an uncomputable request).
   void getCovariance(const std::vector<std::pair<fuse_core::UUID, fuse_core::UUID>>& covariance_requests,
                      std::vector<std::vector<double>>& covariance_matrices) {
-    Flat f;
+    Flat& f = flat_;
     covariance_matrices.clear();
     if (covariance_requests.empty()) return;
     if (!flatten(f)) throw std::runtime_error("getCovariance: empty graph");
     for (const auto& rq : covariance_requests) {
       if (!variableExists(rq.first) || !variableExists(rq.second)) throw std::out_of_range("getCovariance: variable not in graph");
-      const int32_t a = blockIndexOf(rq.first), b = blockIndexOf(rq.second);
+      const int32_t a = blockIndexOf(f, rq.first), b = blockIndexOf(f, rq.second);
       const size_t ta = getVariable(rq.first).localSize(), tb = getVariable(rq.second).localSize();
       std::vector<double> m(ta * tb);
       check(bsgpu_covariance(ctx(), a, b, m.data()));
@@ -471,6 +496,7 @@ class GpuGraph {
   struct VMeta { uint8_t size, manifold, hold_constant; };
   std::vector<fuse_core::Variable::SharedPtr> vslots_;   // slot -> variable (null: free slot)
   std::vector<VMeta> vmeta_;                              // slot -> what flatten() needs without touching the object
+  std::vector<double*> vdata_;                            // slot -> Variable::data() (stable while the variable is in the graph)
   std::vector<int32_t> vfree_;
   detail::CowIndex vindex_;                               // uuid -> slot
   std::vector<int32_t> ordered_;                          // slots in the deterministic block order, maintained on insertion / removal
@@ -510,6 +536,15 @@ class GpuGraph {
   std::shared_ptr<TypeTable> tables_[BSGPU_F_NUM_TYPES];        // copy-on-write (tableMut)
   std::vector<bsgpu_camera> cameras_;
   std::map<int32_t, MarginalRow> marginal_rows_;                // by constraint slot
+  // rows of each table written since this graph's context last took the table (bsgpu_sync_factors_indirect's change list); a
+  // clone starts un-synced: its context, if it ever opens one, reads the tables whole
+  std::vector<int32_t> dirty_[BSGPU_F_NUM_TYPES];
+  bool synced_[BSGPU_F_NUM_TYPES] = {};
+  void markDirty(int ty, uint32_t row, size_t rows) {
+    if (!synced_[ty]) return;
+    dirty_[ty].push_back((int32_t)row);
+    if (dirty_[ty].size() > rows / 2 + 4096) { synced_[ty] = false; dirty_[ty].clear(); }   // (cheaper to re-read the table)
+  }
   fuse_core::FactorTables pack_scratch_;
   std::vector<int32_t> slot_scratch_;
   TypeTable& tableMut(int ty) {
@@ -564,6 +599,7 @@ class GpuGraph {
       tb.loss_kind.push_back(t1.loss_kind[ty][0]); tb.loss_a.push_back(t1.loss_a[ty][0]);
       tb.owner.push_back(cs);
       ctype_[cs] = ty; crow_[cs] = (uint32_t)tb.rows++;
+      markDirty(ty, crow_[cs], tb.rows);
       return;
     }
   }
@@ -579,6 +615,7 @@ class GpuGraph {
       tb.loss_kind[r] = tb.loss_kind[last]; tb.loss_a[r] = tb.loss_a[last];
       tb.owner[r] = tb.owner[last];
       crow_[tb.owner[r]] = (uint32_t)r;
+      markDirty(ty, (uint32_t)r, tb.rows);
     }
     tb.idx.resize(last * ni);
     tb.consts.resize(last * nc);
@@ -597,6 +634,7 @@ class GpuGraph {
   mutable std::vector<std::vector<int32_t>> conn_;
   mutable bool connectivity_valid_ = true;
   bsgpu_summary last_summary_{};
+  Flat flat_;
 };
 
 }  // namespace bs_optimizers

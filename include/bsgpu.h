@@ -298,6 +298,19 @@ int bsgpu_add_factors(bsgpu_ctx* ctx, int32_t type, int32_t n,
 int bsgpu_add_factors_indirect(bsgpu_ctx* ctx, int32_t type, int32_t n, const int32_t* slot_idx, int32_t n_slots,
                                const int32_t* slot_to_block, const double* consts, const int32_t* loss_kind,
                                const double* loss_a);
+/* bsgpu_add_factors_indirect for a type's WHOLE table (one call per type per description, before any other factors of the
+ * type) from a caller that also knows what changed: changed_rows[n_changed] lists every row r < n whose contents differ
+ * from row r of the table passed to the previous bsgpu_sync_factors_indirect call for this type on this context (rows
+ * beyond the previous table's end included; rows that left at the end need no mention).  n_changed < 0: no promise, the
+ * table is read whole (the first call).  For BSGPU_F_REPROJ the back-end keeps slot-named copies of the table on the host
+ * and on the device ACROSS bsgpu_clear() and patches them — a window that slides by one keyframe sends ~3 500 of 400 000
+ * rows, validation and landmark detection run on per-slot use counters, and bsgpu_finalize flattens from the resident
+ * device table (the per-cycle rebuild as a delta).  Other types are copied in as by
+ * bsgpu_add_factors_indirect.  A wrong change list is the caller's error: BSGPU_SYNC_CHECK=1 in the environment makes the
+ * call compare its copy with the table passed and fail on any difference; BSGPU_SYNC_FULL=1 ignores the lists.            */
+int bsgpu_sync_factors_indirect(bsgpu_ctx* ctx, int32_t type, int32_t n, const int32_t* slot_idx, int32_t n_slots,
+                                const int32_t* slot_to_block, const double* consts, const int32_t* loss_kind,
+                                const double* loss_a, int32_t n_changed, const int32_t* changed_rows);
 
 /* ---- solve ----------------------------------------------------------------- */
 /* Uploads / builds the device-side structure (sorted factor tables, CSR of the

@@ -121,6 +121,9 @@ struct Ctx {
   int n_owner = 0;
   std::vector<int> owner_start, owner_fac;  // CSR owner -> (type<<28|factor)
   bool owner_parallel_ok = true;
+  // bso_sync_factors_indirect: the table of the previous call per type (kept across bso_clear), to check the caller's change lists
+  struct SyncPrev { bool valid = false; std::vector<int32_t> idx, loss_kind; std::vector<double> consts, loss_a; };
+  std::vector<SyncPrev> sync_prev = std::vector<SyncPrev>(BSGPU_F_NUM_TYPES);
 };
 
 static inline void plus_jacobian(const double* q, double P[12]) {
@@ -1164,7 +1167,7 @@ Ctx* bso_create(int) { return new Ctx(); }
 void bso_destroy(Ctx* c) { delete c; }
 const char* bso_last_error(const Ctx* c) { return c->err.c_str(); }
 int bso_abi_version(void) { return BSGPU_ABI_VERSION; }
-int bso_clear(Ctx* c) { std::string e; *c = Ctx(); return BSGPU_OK; }
+int bso_clear(Ctx* c) { auto keep = std::move(c->sync_prev); *c = Ctx(); c->sync_prev = std::move(keep); return BSGPU_OK; }
 
 int bso_set_blocks(Ctx* c, int32_t n, const double* values, const int32_t* offset, const uint8_t* size,
                    const uint8_t* manifold, const uint8_t* is_const) {
@@ -1215,6 +1218,38 @@ int bso_add_factors_indirect(Ctx* c, int32_t type, int32_t n, const int32_t* slo
       idx[(size_t)f * ti.nidx + k] = slot_to_block[s];
     }
   return bso_add_factors(c, type, n, idx.data(), consts, loss_kind, loss_a);
+}
+// bsgpu_sync_factors_indirect (include/bsgpu.h): the oracle has nothing to patch — it takes the whole table — but it CHECKS the
+// caller's promise: every row not in the change list must equal the row of the previous call's table.
+int bso_sync_factors_indirect(Ctx* c, int32_t type, int32_t n, const int32_t* slot_idx, int32_t n_slots, const int32_t* slot_to_block,
+                              const double* consts, const int32_t* loss_kind, const double* loss_a, int32_t n_changed,
+                              const int32_t* changed_rows) {
+  if (type < 0 || type >= BSGPU_F_NUM_TYPES) { c->err = "unknown factor type"; return BSGPU_ERR_INVALID; }
+  if (c->groups[type].n != 0) { c->err = "sync_factors_indirect: the type already has factors in this description"; return BSGPU_ERR_INVALID; }
+  const bso::TypeInfo& ti = bso::kTypes[type];
+  Ctx::SyncPrev& pv = c->sync_prev[type];
+  const size_t ni = ti.nidx, nc = ti.nconst;
+  if (n_changed >= 0 && pv.valid) {
+    std::vector<uint8_t> listed(n, 0);
+    for (int i = 0; i < n_changed; ++i) {
+      if (changed_rows[i] < 0 || changed_rows[i] >= n) { c->err = "sync_factors_indirect: changed row out of range"; return BSGPU_ERR_INVALID; }
+      listed[changed_rows[i]] = 1;
+    }
+    const size_t old_n = pv.loss_kind.size();
+    for (size_t r = 0; r < (size_t)n; ++r) {
+      if (listed[r]) continue;
+      bool same = r < old_n;
+      for (size_t k = 0; k < ni && same; ++k) same = pv.idx[r * ni + k] == slot_idx[r * ni + k];
+      for (size_t k = 0; k < nc && same; ++k) same = pv.consts[r * nc + k] == consts[r * nc + k];
+      same = same && pv.loss_kind[r] == (loss_kind ? loss_kind[r] : 0) && pv.loss_a[r] == (loss_a ? loss_a[r] : 1.0);
+      if (!same) { c->err = "sync_factors_indirect: the changed list does not account for every difference to the previous table"; return BSGPU_ERR_INVALID; }
+    }
+  }
+  pv.idx.assign(slot_idx, slot_idx + (size_t)n * ni); pv.consts.assign(consts, consts + (size_t)n * nc);
+  pv.loss_kind.assign(n, 0); pv.loss_a.assign(n, 1.0);
+  for (int r = 0; r < n; ++r) { if (loss_kind) pv.loss_kind[r] = loss_kind[r]; if (loss_a) pv.loss_a[r] = loss_a[r]; }
+  pv.valid = true;
+  return bso_add_factors_indirect(c, type, n, slot_idx, n_slots, slot_to_block, consts, loss_kind, loss_a);
 }
 int bso_add_marginal(Ctx* c, int32_t n_blocks, const int32_t* blocks, int32_t n_rows, const double* A, const double* b,
                      const double* xbar) {

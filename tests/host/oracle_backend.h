@@ -7,6 +7,7 @@
 #define bsgpu_add_factors bso_add_factors
 #define bsgpu_add_factors_indirect bso_add_factors_indirect
 #define bsgpu_add_marginal bso_add_marginal
+#define bsgpu_sync_factors_indirect bso_sync_factors_indirect
 #define bsgpu_clear bso_clear
 #define bsgpu_covariance bso_covariance
 #define bsgpu_create bso_create

@@ -1,0 +1,242 @@
+"""bsgpu_sync_factors_indirect — the per-cycle rebuild as a delta: a caller that keeps its reprojection table
+across solves hands it over whole once and afterwards names the rows it has written; the back-end patches slot-named host / device
+copies that outlive clear().  A window that slides (rows swap-removed and appended, variable slots re-used, landmarks left without
+observations) must be, cycle after cycle, exactly the problem a fresh context gets from add_factors."""
+import numpy as np
+import pytest
+
+from beam_slam_amd import capi
+
+FX, FY, CX, CY = 458.654, 457.296, 367.215, 248.375
+
+
+class SlidingWindow:
+    """Caller side: stable variable slots (re-used when freed), one persistent table with swap-remove, a log of written rows."""
+
+    def __init__(self, rng, n_kf, lm_per_kf, obs_extra):
+        self.rng, self.lm_per_kf, self.obs_extra = rng, lm_per_kf, obs_extra
+        self.free_slots, self.n_slots = [], 0
+        self.values = {}                  # slot -> current value
+        self.kfs = []                     # (stamp k, q slot, p slot)
+        self.lms = {}                     # landmark id -> (slot, true point)
+        self.next_lm, self.next_kf = 0, 0
+        self.idx = np.zeros((0, 4), np.int32)
+        self.consts = np.zeros((0, 3))
+        self.loss_kind = np.zeros(0, np.int32)
+        self.loss_a = np.zeros(0)
+        self.row_kf = np.zeros(0, np.int64)    # owner keyframe stamp of each row
+        self.dirty = []
+        for _ in range(n_kf):
+            self.add_keyframe()
+
+    def _slot(self):
+        if self.free_slots:
+            return self.free_slots.pop()
+        self.n_slots += 1
+        return self.n_slots - 1
+
+    def _append(self, rows, consts, kf):
+        n0 = self.idx.shape[0]
+        self.idx = np.vstack([self.idx, rows]).astype(np.int32)
+        self.consts = np.vstack([self.consts, consts])
+        lk = np.where(self.rng.random(len(rows)) < 0.8, capi.LOSS_CAUCHY, capi.LOSS_TRIVIAL).astype(np.int32)
+        self.loss_kind = np.concatenate([self.loss_kind, lk])
+        self.loss_a = np.concatenate([self.loss_a, np.where(lk == capi.LOSS_CAUCHY, 5.0, 1.0)])
+        self.row_kf = np.concatenate([self.row_kf, kf])
+        self.dirty.extend(range(n0, n0 + len(rows)))
+
+    def add_keyframe(self):
+        k = self.next_kf
+        self.next_kf += 1
+        qs, ps = self._slot(), self._slot()
+        q = np.array([1.0, 0, 0, 0]) + 0.01 * self.rng.standard_normal(4)
+        self.values[qs] = q / np.linalg.norm(q)
+        self.values[ps] = np.array([0.1 * k, 0, 0]) + 0.01 * self.rng.standard_normal(3)
+        self.kfs.append((k, qs, ps))
+        rows, consts, owner = [], [], []
+
+        def observe(P, ls, kf=None):
+            kk, q_s, p_s = kf if kf is not None else (k, qs, ps)
+            px = P[0] - 0.1 * kk
+            rows.append((q_s, p_s, ls, 0))
+            consts.append((FX * px / P[2] + CX + self.rng.standard_normal(), FY * P[1] / P[2] + CY + self.rng.standard_normal(), 1.0))
+            owner.append(kk)
+
+        for _ in range(self.lm_per_kf):       # new landmarks, seen from the last three keyframes (and the later ones that pick them up)
+            z = 4.0 + 8.0 * self.rng.random()
+            P = np.array([0.1 * k + (self.rng.random() - 0.3) * 0.8 * z, (self.rng.random() - 0.5) * 0.6 * z, z])
+            ls = self._slot()
+            self.values[ls] = P + 0.05 * self.rng.standard_normal(3)
+            self.lms[self.next_lm] = (ls, P)
+            self.next_lm += 1
+            for kf in self.kfs[-3:]:
+                observe(P, ls, kf)
+        recent = [i for i in self.lms if i >= self.next_lm - 6 * self.lm_per_kf and i < self.next_lm - self.lm_per_kf]
+        if recent:
+            for i in self.rng.choice(recent, size=min(self.obs_extra, len(recent)), replace=False):
+                observe(self.lms[i][1], self.lms[i][0])
+        self._append(np.array(rows, np.int32), np.array(consts), np.array(owner))
+
+    def drop_oldest(self, free_landmarks):
+        k, qs, ps = self.kfs.pop(0)
+        for r in sorted(np.flatnonzero(self.row_kf == k), reverse=True):    # swap-remove, like gpu_graph.h removeRow
+            last = self.idx.shape[0] - 1
+            if r != last:
+                self.idx[r], self.consts[r] = self.idx[last], self.consts[last]
+                self.loss_kind[r], self.loss_a[r], self.row_kf[r] = self.loss_kind[last], self.loss_a[last], self.row_kf[last]
+                self.dirty.append(int(r))
+            self.idx, self.consts = self.idx[:last], self.consts[:last]
+            self.loss_kind, self.loss_a, self.row_kf = self.loss_kind[:last], self.loss_a[:last], self.row_kf[:last]
+        for s in (qs, ps):
+            del self.values[s]
+            self.free_slots.append(s)
+        if free_landmarks:                 # else: they stay as blocks no factor touches
+            used = set(self.idx[:, 2].tolist())
+            for i in [i for i, (ls, _) in self.lms.items() if ls not in used]:
+                ls = self.lms.pop(i)[0]
+                del self.values[ls]
+                self.free_slots.append(ls)
+
+    def blocks(self):
+        """deterministic block order: keyframes by stamp (q, p), then landmarks by id; the first keyframe is held constant"""
+        order = []
+        for k, qs, ps in self.kfs:
+            order += [(qs, 4, capi.MANIFOLD_QUAT_RIGHT), (ps, 3, capi.MANIFOLD_EUCLIDEAN)]
+        for i in sorted(self.lms):
+            order.append((self.lms[i][0], 3, capi.MANIFOLD_EUCLIDEAN))
+        s2b = np.full(self.n_slots + 3, -1, np.int32)
+        vals, off, size, man, const = [], [], [], [], []
+        o = 0
+        for b, (s, sz, m) in enumerate(order):
+            s2b[s] = b
+            vals.append(self.values[s]); off.append(o); size.append(sz); man.append(m); const.append(1 if b < 4 else 0)
+            o += sz
+        return np.concatenate(vals), np.array(off, np.int32), np.array(size, np.uint8), np.array(man, np.uint8), np.array(const, np.uint8), s2b
+
+    def camera(self):
+        c = capi.Camera()
+        c.fx, c.fy, c.cx, c.cy = FX, FY, CX, CY
+        c.R_cam_baselink[:] = [1, 0, 0, 0, 1, 0, 0, 0, 1]
+        c.t_cam_baselink[:] = [0, 0, 0]
+        return [c]
+
+    def take_dirty(self):
+        d = np.array([r for r in self.dirty if r < self.idx.shape[0]], np.int32)
+        self.dirty = []
+        return d
+
+
+def _describe(w, solver, s2b_blocks, synced, first):
+    vals, off, size, man, const, s2b = s2b_blocks
+    solver.clear()
+    solver.set_blocks(vals, off, size, man, const)
+    solver.set_cameras(w.camera())
+    if synced:
+        solver.sync_factors_indirect(capi.F_REPROJ, w.idx, s2b, w.consts, w.loss_kind, w.loss_a, None if first else w.take_dirty())
+        if first:
+            w.take_dirty()
+    else:
+        idx = w.idx.copy()
+        idx[:, :3] = s2b[idx[:, :3]]
+        solver.add_factors(capi.F_REPROJ, idx, w.consts, w.loss_kind, w.loss_a)
+
+
+def _cycles(cls, n_kf, lm_per_kf, obs_extra, n_cycles, bitwise_solve, monkeypatch):
+    monkeypatch.setenv("BSGPU_SYNC_CHECK", "1")
+    w = SlidingWindow(np.random.default_rng(7), n_kf, lm_per_kf, obs_extra)
+    a = cls() if cls.__name__ == "Oracle" else cls(0)
+    for cyc in range(n_cycles):
+        if cyc:
+            w.drop_oldest(free_landmarks=cyc % 2 == 1)
+            w.add_keyframe()
+        blocks = w.blocks()
+        b = cls() if cls.__name__ == "Oracle" else cls(0)      # the reference: a fresh context described row by row
+        _describe(w, a, blocks, True, cyc == 0)
+        _describe(w, b, blocks, False, False)
+        a.finalize(); b.finalize()
+        nb = blocks[1].size
+        assert [a.tangent_offset(i) for i in range(nb)] == [b.tangent_offset(i) for i in range(nb)]
+        ca, ra, ga, _ = a.evaluate()
+        cb, rb, gb, _ = b.evaluate()
+        assert abs(ca - cb) <= 1e-14 * cb and np.array_equal(ra, rb), cyc   # (same rows in the same order; the cost is summed by threads)
+        assert np.allclose(ga, gb, rtol=0, atol=1e-9 * max(1.0, np.abs(gb).max())), cyc
+        sa, sb = a.solve(), b.solve()
+        assert sa.termination_type == sb.termination_type
+        # (sums over threads / FP64 atomics differ in the last bits between two runs, and landmarks seen once have flat directions:
+        #  the solves are compared through their cost)
+        assert abs(sa.final_cost - sb.final_cost) <= 1e-8 * sb.final_cost, cyc
+        # the solve's result goes back into the caller's variables, as GpuGraph::optimize does
+        x = a.get_blocks()
+        for bi, (s, _, _) in enumerate([(int(np.flatnonzero(blocks[5] == i)[0]), 0, 0) for i in range(nb)]):
+            w.values[s] = x[blocks[1][bi]:blocks[1][bi] + blocks[2][bi]].copy()
+    return w, a
+
+
+def test_sync_equals_fresh_description_oracle(oracle_cls, monkeypatch):
+    _cycles(oracle_cls, 8, 40, 60, 5, True, monkeypatch)
+
+
+def test_sync_wrong_change_list_is_caught_by_the_oracle(oracle_cls):
+    w = SlidingWindow(np.random.default_rng(3), 6, 20, 30)
+    o = oracle_cls()
+    _describe(w, o, w.blocks(), True, True)
+    w.consts[5, 0] += 1.0                       # a row written behind the back of the change list
+    with pytest.raises(capi.SolverError):
+        _describe(w, o, w.blocks(), True, False)
+
+
+@pytest.mark.gpu
+def test_sync_equals_fresh_description_small_window(gpu_solver_cls, monkeypatch):
+    """below the device-flatten threshold: the mirror is materialised for the host path"""
+    _cycles(gpu_solver_cls, 8, 40, 60, 5, False, monkeypatch)
+
+
+@pytest.mark.gpu
+def test_sync_equals_fresh_description_resident_table(gpu_solver_cls, monkeypatch):
+    """>= 20 000 rows: finalize() flattens from the device-resident table, only the changed rows travel"""
+    w, _ = _cycles(gpu_solver_cls, 30, 500, 500, 4, False, monkeypatch)
+    assert w.idx.shape[0] >= 20000
+
+
+@pytest.mark.gpu
+def test_sync_rejects_bad_change_lists(gpu_solver_cls, monkeypatch):
+    w = SlidingWindow(np.random.default_rng(3), 6, 20, 30)
+    g = gpu_solver_cls(0)
+    blocks = w.blocks()
+    _describe(w, g, blocks, True, True)
+    g.finalize()
+    vals, off, size, man, const, s2b = blocks
+    n = w.idx.shape[0]
+    # appended rows that the list does not name
+    w.add_keyframe()
+    blocks = w.blocks()
+    vals, off, size, man, const, s2b = blocks
+    g.clear(); g.set_blocks(vals, off, size, man, const); g.set_cameras(w.camera())
+    with pytest.raises(capi.SolverError) as e:
+        g.sync_factors_indirect(capi.F_REPROJ, w.idx, s2b, w.consts, w.loss_kind, w.loss_a, np.array([0], np.int32))
+    assert e.value.code == capi.ERR_INVALID
+    # after a rejected call the next one is read whole whatever it lists, and the problem is the right one
+    g.sync_factors_indirect(capi.F_REPROJ, w.idx, s2b, w.consts, w.loss_kind, w.loss_a, np.array([], np.int32))
+    ref = gpu_solver_cls(0)
+    _describe(w, ref, blocks, False, False)
+    assert abs(g.evaluate()[0] - ref.evaluate()[0]) <= 1e-14 * ref.evaluate()[0]
+    # a listed row beyond the table
+    g.clear(); g.set_blocks(vals, off, size, man, const); g.set_cameras(w.camera())
+    with pytest.raises(capi.SolverError) as e:
+        g.sync_factors_indirect(capi.F_REPROJ, w.idx, s2b, w.consts, w.loss_kind, w.loss_a, np.array([w.idx.shape[0]], np.int32))
+    assert e.value.code == capi.ERR_INVALID
+    g.sync_factors_indirect(capi.F_REPROJ, w.idx, s2b, w.consts, w.loss_kind, w.loss_a, None)
+    # a silent change is caught when BSGPU_SYNC_CHECK is set
+    monkeypatch.setenv("BSGPU_SYNC_CHECK", "1")
+    w.consts[3, 1] += 2.0
+    g.clear(); g.set_blocks(vals, off, size, man, const); g.set_cameras(w.camera())
+    with pytest.raises(capi.SolverError):
+        g.sync_factors_indirect(capi.F_REPROJ, w.idx, s2b, w.consts, w.loss_kind, w.loss_a, np.array([], np.int32))
+    # a slot that is not mapped to a block
+    g2 = gpu_solver_cls(0)
+    bad = s2b.copy(); bad[w.idx[0, 2]] = -1
+    g2.clear(); g2.set_blocks(vals, off, size, man, const); g2.set_cameras(w.camera())
+    g2.sync_factors_indirect(capi.F_REPROJ, w.idx, bad, w.consts, w.loss_kind, w.loss_a, None)
+    with pytest.raises(capi.SolverError) as e:
+        g2.finalize()
+    assert e.value.code == capi.ERR_INVALID
