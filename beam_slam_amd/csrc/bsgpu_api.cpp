@@ -123,6 +123,7 @@ void bsgpu_destroy(bsgpu_ctx* c) {
   c->release_pool();
   if (c->h_scal) (void)hipHostFree(c->h_scal);
   c->mirror0.release_device();
+  if (c->h_arena) (void)hipHostFree(c->h_arena);
   if (c->h_radius) (void)hipHostFree(c->h_radius);
   if (c->h_pcg) (void)hipHostFree(c->h_pcg);
   for (hipEvent_t e : c->pcg_ev) if (e) (void)hipEventDestroy(e);

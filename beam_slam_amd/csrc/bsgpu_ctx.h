@@ -243,13 +243,30 @@ struct bsgpu_ctx {
     for (auto& kv : pool) (void)hipFree(kv.second);
     pool.clear(); pool_bytes = 0;
   }
+  // The ~40 small tables of a finalize() go through a pinned staging arena as asynchronous copies on the context's stream (every
+  // consumer is a kernel on that stream): a blocking hipMemcpy each cost ~15 us of round trip.  The arena is rewound when the
+  // stream has drained (free_device); what does not fit takes the blocking path.
+  unsigned char* h_arena = nullptr;
+  size_t arena_cap = 0, arena_off = 0;
   template <typename T> T* upload(const std::vector<T>& v) {
     T* p = alloc<T>(v.size());
-    if (p && !v.empty()) (void)hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    if (!p || v.empty()) return p;
+    const size_t bytes = v.size() * sizeof(T), need = (bytes + 63) & ~(size_t)63;
+    if (!h_arena && stream) {
+      if (hipHostMalloc((void**)&h_arena, (size_t)16 << 20) == hipSuccess) arena_cap = (size_t)16 << 20; else { (void)hipGetLastError(); h_arena = nullptr; }
+    }
+    if (h_arena && stream && bytes <= ((size_t)4 << 20) && arena_off + need <= arena_cap) {
+      std::memcpy(h_arena + arena_off, v.data(), bytes);
+      if (hipMemcpyAsync(p, h_arena + arena_off, bytes, hipMemcpyHostToDevice, stream) == hipSuccess) { arena_off += need; return p; }
+      (void)hipGetLastError();
+    }
+    if (stream) (void)hipStreamSynchronize(stream);   // (keeps the order with what is queued on the stream)
+    (void)hipMemcpy(p, v.data(), bytes, hipMemcpyHostToDevice);
     return p;
   }
   void free_device() {
     if (stream) (void)hipStreamSynchronize(stream);   // nothing may still be using the buffers that go back to the pool
+    arena_off = 0;
     for (auto& a : allocs) { pool.emplace(a.second, a.first); pool_bytes += a.second; }
     allocs.clear();
     if (pool_bytes > ((size_t)8 << 30)) release_pool();

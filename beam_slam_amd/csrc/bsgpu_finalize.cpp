@@ -477,6 +477,7 @@ int finalize(bsgpu_ctx* c) {
       if (!sg.n) continue;
       const int nv = sg.nv;
       std::vector<int> toffs((size_t)sg.n * nv);
+      HIPCHK(c, hipStreamSynchronize(c->stream));   // (the table went up asynchronously on the context's stream)
       HIPCHK(c, hipMemcpy(toffs.data(), sg.toff, sizeof(int) * toffs.size(), hipMemcpyDeviceToHost));
       const size_t first = cl.size();
       for (int f = 0; f < sg.n; ++f) {

@@ -13,6 +13,8 @@ static double ms(clk::time_point a, clk::time_point b) { return std::chrono::dur
 
 int main(int argc, char** argv) {
   const int n_kf = argc > 1 ? atoi(argv[1]) : 200, n_lm = argc > 2 ? atoi(argv[2]) : 50000;
+  const bool host_only = argc > 3 && std::string(argv[3]).rfind("host-only", 0) == 0;
+  const bool no_snapshot = argc > 3 && std::string(argv[3]) == "host-only-nosnap";   // clone / update timings without a solve (any back-end)
   std::mt19937 rng(1);
   std::normal_distribution<double> N(0.0, 1.0);
   std::uniform_real_distribution<double> U(0.0, 1.0);
@@ -62,13 +64,15 @@ int main(int argc, char** argv) {
   int oldest = 0;
   for (int rep = 0; rep < 6; ++rep) {
     const auto a = clk::now();
-    auto s = graph.optimize(opts);
+    ceres_compat::SolverSummary s;
+    if (!host_only) s = graph.optimize(opts);
     const auto b = clk::now();
     const auto& bs = graph.lastBackendSummary();
-    std::printf("cycle %d: optimize() %.1f ms total | back-end (finalize + solve) %.1f ms (%d it) | host flatten + hand-over %.1f ms | cost %.4e -> %.4e\n", rep,
+    if (!host_only) std::printf("cycle %d: optimize() %.1f ms total | back-end (finalize + solve) %.1f ms (%d it) | host flatten + hand-over %.1f ms | cost %.4e -> %.4e\n", rep,
                 ms(a, b), 1e3 * bs.total_time_in_seconds, bs.num_iterations, ms(a, b) - 1e3 * bs.total_time_in_seconds, s.initial_cost, s.final_cost);
     const auto c0 = clk::now();
     snapshot = graph.clone();   // what fixed_lag_smoother.cpp:308 does every cycle for the publishers
+    if (no_snapshot) snapshot.reset();
     const auto c1 = clk::now();
     // the window slides by one keyframe: the oldest state and everything attached to it leave, a new keyframe with
     // 250 new landmarks (seen from the last 4 keyframes) and 1000 observations of recent landmarks enters
