@@ -8,6 +8,7 @@
 // The pre-integrator runs on the host in the reference too (once per factor creation,
 // bs_models/src/lib/imu/imu_preintegration.cpp:245-318); it produces the constants of the IMU factor.
 #pragma once
+#include <new>
 #include <algorithm>
 #include <cmath>
 
@@ -109,6 +110,9 @@ inline Mat3 so3RightJacobian(const Vec3& w) {  // [EXT] beam::RightJacobianOfSO3
 // ---------------------------------------------------------------------------------------------------
 // variables
 // ---------------------------------------------------------------------------------------------------
+#define BS_CLONE_IN_PLACE(CLASS)                                          \
+  size_t cloneSize() const override { return sizeof(CLASS); }            \
+  fuse_core::Variable* cloneAt(void* mem) const override { return new (mem) CLASS(*this); }
 namespace fuse_variables {
 template <int N> class FixedSizeVariable : public fuse_core::Variable {
  public:
@@ -141,6 +145,7 @@ template <int N> class StampedVariable : public FixedSizeVariable<N> {
     static SharedPtr make_shared(const fuse_core::Time& stamp, const fuse_core::UUID& device = fuse_core::UUID()) { return std::make_shared<CLASS>(stamp, device); } \
     std::string type() const override { return TYPESTR; }                                                      \
     fuse_core::Variable::SharedPtr clone() const override { return std::make_shared<CLASS>(*this); }           \
+    BS_CLONE_IN_PLACE(CLASS)                                                                                   \
     EXTRA                                                                                                      \
   };
 BS_STAMPED_VARIABLE(fuse_variables, Orientation3DStamped, 4, 0, "fuse_variables::Orientation3DStamped",
@@ -170,6 +175,7 @@ class Point3DLandmark : public fuse_variables::FixedSizeVariable<3> {
   static SharedPtr make_shared(uint64_t id) { return std::make_shared<Point3DLandmark>(id); }
   std::string type() const override { return "bs_variables::Point3DLandmark"; }
   fuse_core::Variable::SharedPtr clone() const override { return std::make_shared<Point3DLandmark>(*this); }
+  BS_CLONE_IN_PLACE(Point3DLandmark)
   bool isLandmark() const override { return true; }
   uint64_t landmarkId() const override { return id_; }
   uint64_t id() const { return id_; }
@@ -191,6 +197,7 @@ class InverseDepthLandmark : public fuse_variables::FixedSizeVariable<1> {
   static SharedPtr make_shared(uint64_t id, const bs_math::Vec3& b, const fuse_core::Time& t) { return std::make_shared<InverseDepthLandmark>(id, b, t); }
   std::string type() const override { return "bs_variables::InverseDepthLandmark"; }
   fuse_core::Variable::SharedPtr clone() const override { return std::make_shared<InverseDepthLandmark>(*this); }
+  BS_CLONE_IN_PLACE(InverseDepthLandmark)
   bool isLandmark() const override { return true; }
   uint64_t landmarkId() const override { return id_; }
   uint64_t id() const { return id_; }
@@ -214,6 +221,7 @@ class Orientation3D : public fuse_variables::FixedSizeVariable<4> {
   static SharedPtr make_shared(const std::string& c, const std::string& p) { return std::make_shared<Orientation3D>(c, p); }
   std::string type() const override { return "bs_variables::Orientation3D"; }
   fuse_core::Variable::SharedPtr clone() const override { return std::make_shared<Orientation3D>(*this); }
+  BS_CLONE_IN_PLACE(Orientation3D)
   int manifold() const override { return BSGPU_MANIFOLD_QUAT_RIGHT; }
   size_t localSize() const override { return 3; }
   bool holdConstant() const override { return true; }
@@ -226,6 +234,7 @@ class Position3D : public fuse_variables::FixedSizeVariable<3> {
   static SharedPtr make_shared(const std::string& c, const std::string& p) { return std::make_shared<Position3D>(c, p); }
   std::string type() const override { return "bs_variables::Position3D"; }
   fuse_core::Variable::SharedPtr clone() const override { return std::make_shared<Position3D>(*this); }
+  BS_CLONE_IN_PLACE(Position3D)
   bool holdConstant() const override { return true; }
 };
 }  // namespace bs_variables

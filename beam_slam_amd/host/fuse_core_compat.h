@@ -123,6 +123,10 @@ class Variable {
   virtual int manifold() const { return BSGPU_MANIFOLD_EUCLIDEAN; }  // localParameterization() stand-in
   virtual bool holdConstant() const { return false; }
   virtual SharedPtr clone() const = 0;
+  // in-place copy for a graph that clones all its variables into ONE allocation (GpuGraph::clone): the bytes needed, and the copy
+  // constructed at `mem` (suitably aligned, at least cloneSize() bytes).  0 / nullptr: the type only offers clone().
+  virtual size_t cloneSize() const { return 0; }
+  virtual Variable* cloneAt(void* mem) const { (void)mem; return nullptr; }
   // ordering keys for the deterministic block index
   virtual bool isStamped() const { return false; }
   virtual Time stamp() const { return Time(); }
