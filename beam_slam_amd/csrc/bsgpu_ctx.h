@@ -215,6 +215,7 @@ struct bsgpu_ctx {
   hipEvent_t* prof_events = nullptr;
   bool spec_J = false;   // residuals + Jacobians currently hold the CANDIDATE's (evaluated ahead of the accept/reject decision)
   int nbr = 0, nblk = 0, pcg_iters_total = 0;
+  PcgPersistDev pcg_persist;     // G = 0: the launch-per-iteration path only
   int *d_row_ptr = nullptr, *d_col = nullptr, *d_diag_slot = nullptr, *d_pair_slot = nullptr;
   int* d_slots[kNumInternal] = {nullptr};
   double *d_val = nullptr, *d_Minv = nullptr, *d_rhs = nullptr, *d_px = nullptr, *d_pr = nullptr, *d_pz = nullptr, *d_pp = nullptr, *d_pp1 = nullptr,

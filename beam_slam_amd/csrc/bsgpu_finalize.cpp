@@ -747,6 +747,44 @@ int build_bsr(bsgpu_ctx* c) {
   c->d_ppart = c->alloc<double>((size_t)pcg_spmv_grid(nbr) + 8); c->d_ppart2 = c->alloc<double>(4 * (size_t)pcg_rows_grid(nbr) + 8);
   c->d_psc = c->alloc<double>(pcg_num_scalars());
   if (!c->d_val || !c->d_pq || !c->d_psc) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (block-sparse system)");
+  // ---- the solve as one persistent launch (k_pcg.hip pcg_persistent_kernel): contiguous ranges of block rows per workgroup, cut at
+  // even rows (a 6x6 preconditioner block stays in one workgroup) and balanced by non-zero blocks; the columns each range names
+  c->pcg_persist = PcgPersistDev();
+  if (!getenv("BSGPU_PCG_LAUNCHES") && nbr >= 64) {
+    int n_cu = 256;
+    { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, c->device) == hipSuccess && pr.multiProcessorCount > 0) n_cu = pr.multiProcessorCount; }
+    const int G = std::max(1, std::min({n_cu, 256, (nbr + 1) / 2}));
+    std::vector<int> wg_row(G + 1, 0);
+    const double total = (double)nblk + 4.0 * nbr;   // (a row costs its blocks plus the update's share)
+    int r = 0;
+    for (int g = 0; g < G; ++g) {
+      wg_row[g] = r;
+      const double want = total * (g + 1) / G;
+      while (r < nbr && ((double)row_ptr[r] + 4.0 * r < want || (r & 1))) ++r;
+      if (g == G - 1) r = nbr;
+    }
+    wg_row[G] = nbr;
+    std::vector<int> wg_colptr(G + 1, 0), wg_cols, lcol(nblk, 0), stamp(nbr, -1), local(nbr, 0);
+    int max_cols = 0, max_rows = 0;
+    for (int g = 0; g < G; ++g) {
+      std::vector<int> cols;
+      for (int e = row_ptr[wg_row[g]]; e < row_ptr[wg_row[g + 1]]; ++e) if (stamp[col[e]] != g) { stamp[col[e]] = g; cols.push_back(col[e]); }
+      std::sort(cols.begin(), cols.end());
+      for (size_t i = 0; i < cols.size(); ++i) local[cols[i]] = (int)i;
+      for (int e = row_ptr[wg_row[g]]; e < row_ptr[wg_row[g + 1]]; ++e) lcol[e] = local[col[e]];
+      wg_cols.insert(wg_cols.end(), cols.begin(), cols.end());
+      wg_colptr[g + 1] = (int)wg_cols.size();
+      max_cols = std::max(max_cols, (int)cols.size());
+      max_rows = std::max(max_rows, 3 * (wg_row[g + 1] - wg_row[g]));
+    }
+    if (max_rows <= pcg_persistent_max_rows() && pcg_persistent_lds(max_cols) <= 80 * 1024) {
+      PcgPersistDev& P = c->pcg_persist;
+      P.G = G; P.max_cols = max_cols;
+      P.wg_row = c->upload(wg_row); P.wg_colptr = c->upload(wg_colptr); P.wg_cols = c->upload(wg_cols); P.lcol = c->upload(lcol);
+      P.slots = c->alloc<unsigned long long>(6 * (size_t)G); P.abort_w = c->alloc<int>(2);
+      if (!P.wg_row || !P.lcol || !P.slots || !P.abort_w) P = PcgPersistDev();
+    }
+  }
   c->bsr_built = true;
   return BSGPU_OK;
 }

@@ -220,6 +220,17 @@ void launch_bsr_finish_diag(hipStream_t s, int nbr, const int* diag_slot, const 
                             int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* scale,
                             double* dcl, double* Minv);
 int pcg_spmv_grid(int nbr);   // workgroups (= p.q partials) of one SpMV launch
+// the whole PCG solve as one launch (k_pcg.hip pcg_persistent_kernel): per-workgroup row ranges and named-column lists
+struct PcgPersistDev {
+  int G = 0, max_cols = 0;
+  const int *wg_row = nullptr, *wg_colptr = nullptr, *wg_cols = nullptr, *lcol = nullptr;
+  unsigned long long* slots = nullptr;
+  int* abort_w = nullptr;
+};
+size_t pcg_persistent_lds(int max_cols);
+int pcg_persistent_max_rows();
+bool launch_pcg_persistent(hipStream_t s, const PcgPersistDev& P, int nbr, const int* row_ptr, const double* val, const double* Minv, const double* b,
+                           double* x, double* zg, double* sc, double tol2, int max_it);
 void launch_pcg_init(hipStream_t s, int nbr, const double* b, const double* Minv, double* x, double* r, double* z, double* p0, double* p1,
                      double* part, double* sc);
 void launch_pcg_iteration(hipStream_t s, int k, int nbr, const int* row_ptr, const int* col, const double* val, const double* Minv,

@@ -1,6 +1,8 @@
 // solve(): [EXT] ceres::Solve with TRUST_REGION / LEVENBERG_MARQUARDT / SPARSE_NORMAL_CHOLESKY as the reference configures it
 // (beam_slam_launch/config/vio.yaml:7-17) — a restatement of Ceres' TrustRegionMinimizer + LevenbergMarquardtStrategy that drives
 // the device kernels: one host<->device round trip per LM iteration, hidden under the evaluation at the candidate.
+#include <atomic>
+
 #include "bsgpu_ctx.h"
 
 namespace bsg {
@@ -21,8 +23,27 @@ void assemble_pcg(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_
 }
 
 // (H + Lambda) y = g by block-Jacobi PCG; the stop test lives on the device, the host looks at it every 20 iterations
+static std::atomic<int> g_pcg_persistent_in_flight{0};
 void pcg_solve(bsgpu_ctx* c, const bsgpu_options& o) {
   hipStream_t s = c->stream;
+  if (c->pcg_persist.G > 0) {
+    // one resident launch for the whole solve (k_pcg.hip).  Its workgroups wait for each other, so two of them must not share the
+    // device: a second solver thread of this process takes the launch-per-iteration path meanwhile, and a time-out inside the kernel
+    // (another process's) makes this context do so for good.
+    const double tol2p = o.pcg_tolerance * o.pcg_tolerance;
+    const int max_itp = o.pcg_max_iterations > 0 ? o.pcg_max_iterations : 2000;
+    const int ns = pcg_num_scalars();
+    int expected = 0;
+    if (g_pcg_persistent_in_flight.compare_exchange_strong(expected, 1)) {
+      double sc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      const bool launched = launch_pcg_persistent(s, c->pcg_persist, c->nbr, c->d_row_ptr, c->d_val, c->d_Minv, c->d_rhs, c->d_px, c->d_pz, c->d_psc, tol2p, max_itp);
+      bool ok = launched && hipMemcpyAsync(sc, c->d_psc, sizeof(double) * ns, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+      g_pcg_persistent_in_flight.store(0);
+      if (ok && sc[pcg_done_slot()] > 0.0) { c->pcg_iters_total += (int)sc[pcg_iters_slot()]; return; }
+      (void)hipGetLastError();
+      c->pcg_persist.G = 0;
+    }
+  }
   launch_pcg_init(s, c->nbr, c->d_rhs, c->d_Minv, c->d_px, c->d_pr, c->d_pz, c->d_pp, c->d_pp1, c->d_ppart2, c->d_psc);
   const double tol2 = o.pcg_tolerance * o.pcg_tolerance;
   const int max_it = o.pcg_max_iterations > 0 ? o.pcg_max_iterations : 2000;

@@ -315,6 +315,295 @@ __global__ __launch_bounds__(256) void pcg_update_kernel(int nbr, const double* 
 }
 
 int pcg_rows_grid(int nbr) { return (3 * nbr + kPcgRowsPerWg - 1) / kPcgRowsPerWg; }
+
+// ---------------------------------------------------------------------------------------------------
+// The whole PCG solve as ONE launch (round 2).  The two-launch iteration above spends ~5 us per launch on the dependent-launch
+// latency (208 iterations x 2 per LM step on C4); here a grid of at most one workgroup per CU stays resident, every workgroup owns
+// a contiguous range of block rows (whole 6x6 preconditioner blocks, balanced by non-zero blocks) and keeps x, r, p, q, z of its rows
+// in LDS for the whole solve.  What crosses workgroups per iteration is z (one sc1 store per row, gathered by the workgroups whose
+// blocks name the column) and the two dot products:
+//   * a workgroup keeps its own copy of p for the columns its blocks name (LDS): p_j = z_j + beta p_j is formed locally from the
+//     gathered z_j, so p itself never travels;
+//   * a dot product is a SLOT per workgroup in device memory, empty (all bits set) until its owner stores the partial: every
+//     workgroup polls all slots and sums them in slot order (the same bits everywhere) — partial and arrival are ONE 8-byte store,
+//     no counter, no atomics.  Three slot sets rotate; a workgroup re-empties its slot of the next set when it arrives (everybody
+//     has finished reading that set: they arrived at the barrier in between).
+// Two such barriers per iteration (p.q, then r.z / r.r).  Hand-off rules as in k_chol.hip (guide G16): stores that other workgroups
+// read are agent-scope (sc1, write-through), every storing thread fences before the workgroup barrier that precedes the slot store,
+// readers use agent-scope loads (no fences: an agent-scope fence writes back / invalidates the L2, and the matrix would be re-fetched every iteration).  Every poll is bounded by the wall clock: on a time-out (the grid not co-resident: another
+// persistent kernel on the device) the abort word is raised, the kernel drains with PC_DONE = -1 and the host runs the launch-per-
+// iteration path instead.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kPcgPersistThreads = 512;
+constexpr int kPcgPersistMaxRows = 504;          // scalar rows of one workgroup (one thread each in the update)
+constexpr unsigned long long kSlotEmpty = ~0ull;
+constexpr int kRegRows = 2, kRegBlocks = 4;     // register-resident blocks of a lane: rows of its 16-lane group x blocks of the row
+BSG_DEV double ld_agent(const double* p) {
+  const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __longlong_as_double((long long)v);
+}
+BSG_DEV void st_agent(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+struct PcgBarrier {
+  unsigned long long* slots;   // [3 sets][2 values][G]
+  int* abort_w;
+  int G;
+  long long deadline;
+  double* sbuf;                // LDS: 2 * G partials + 2 totals + 1 flag
+};
+// stores this workgroup's partial(s) for barrier `b` and returns the totals over all workgroups; false on abort (uniform)
+template <int NV>
+BSG_DEV bool pcg_grid_reduce(const PcgBarrier& B, int b, double v0, double v1, double& t0, double& t1) {
+  const int tid = threadIdx.x, G = B.G, wg = blockIdx.x;
+  const int set = b % 3, nxt = (b + 1) % 3;
+  unsigned long long* cur = B.slots + (size_t)set * 2 * G;
+  unsigned long long* nx = B.slots + (size_t)nxt * 2 * G;
+  if (tid == 0) {
+    __hip_atomic_store(nx + wg, kSlotEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(nx + G + wg, kSlotEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(cur + wg, (unsigned long long)__double_as_longlong(v0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (NV == 2) __hip_atomic_store(cur + G + wg, (unsigned long long)__double_as_longlong(v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  double* flag = B.sbuf + 2 * G + 2;
+  if (tid == 0) *flag = 0.0;
+  __syncthreads();
+  if (tid < G) {
+    unsigned long long a = kSlotEmpty, c = (NV == 2) ? kSlotEmpty : 0ull;
+    for (unsigned it = 0;; ++it) {
+      if (a == kSlotEmpty) a = __hip_atomic_load(cur + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (NV == 2 && c == kSlotEmpty) c = __hip_atomic_load(cur + G + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a != kSlotEmpty && c != kSlotEmpty) break;
+      if ((it & 15) == 15) {
+        if (__hip_atomic_load(B.abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { *flag = 1.0; break; }
+        if ((long long)wall_clock64() > B.deadline) { __hip_atomic_store(B.abort_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *flag = 1.0; break; }
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    B.sbuf[tid] = __longlong_as_double((long long)a);
+    B.sbuf[G + tid] = (NV == 2) ? __longlong_as_double((long long)c) : 0.0;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    double a = 0.0, c = 0.0;
+    for (int i = tid; i < G; i += 64) { a += B.sbuf[i]; c += B.sbuf[G + i]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
+    if (tid == 0) { B.sbuf[2 * G] = a; B.sbuf[2 * G + 1] = c; }
+  }
+  __syncthreads();
+  t0 = B.sbuf[2 * G]; t1 = B.sbuf[2 * G + 1];
+  const bool ok = *flag == 0.0;
+  __syncthreads();   // (sbuf is rewritten by the next reduction)
+  return ok;
+}
+BSG_DEV double block_sum_512(double v, double* smem /* >= 8 doubles */) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) smem[w] = v;
+  __syncthreads();
+  const double t = ((smem[0] + smem[1]) + (smem[2] + smem[3])) + ((smem[4] + smem[5]) + (smem[6] + smem[7]));
+  __syncthreads();
+  return t;
+}
+
+__global__ __launch_bounds__(kPcgPersistThreads) void pcg_persistent_kernel(
+    int nbr, const int* __restrict__ row_ptr, const double* __restrict__ val, const double* __restrict__ Minv, const double* __restrict__ b,
+    double* __restrict__ x, double* __restrict__ zg, const int* __restrict__ wg_row, const int* __restrict__ wg_colptr,
+    const int* __restrict__ wg_cols, const int* __restrict__ lcol, unsigned long long* __restrict__ slots, int* __restrict__ abort_w,
+    double* __restrict__ sc, double tol2, int max_it, long long timeout_ticks, int max_cols, long long* __restrict__ probe) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int tid = threadIdx.x, wg = blockIdx.x, G = gridDim.x;
+  double* sx = lds;                               // own rows: x, r, p, q, z
+  double* sr = sx + kPcgPersistMaxRows;
+  double* sp = sr + kPcgPersistMaxRows;
+  double* sq = sp + kPcgPersistMaxRows;
+  double* sz = sq + kPcgPersistMaxRows;
+  double* sred = sz + kPcgPersistMaxRows;         // 8
+  double* sbar = sred + 8;                        // 2 G + 3
+  double* pc = sbar + 2 * 256 + 4;                // p of the named columns: 3 * max_cols
+  const int r0 = wg_row[wg], r1 = wg_row[wg + 1], nrow = 3 * (r1 - r0), n = 3 * nbr;
+  const int c0 = wg_colptr[wg], nc = wg_colptr[wg + 1] - c0;
+  PcgBarrier B;
+  B.slots = slots; B.abort_w = abort_w; B.G = G; B.deadline = (long long)wall_clock64() + timeout_ticks; B.sbuf = sbar;
+  const int row = 3 * r0 + tid;                   // this thread's scalar row in the update
+  const bool live = tid < nrow;
+  const int m = row / 6, mi = row - 6 * m, mbase = 6 * m - 3 * r0;   // its 6x6 preconditioner block (inside the workgroup: r0 is even)
+  double Mrow[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) Mrow[k] = live ? Minv[(size_t)m * 36 + 6 * mi + k] : 0.0;
+  for (int i = tid; i < 3 * nc; i += kPcgPersistThreads) pc[i] = 0.0;
+  if (live) { sx[tid] = 0.0; sp[tid] = 0.0; sr[tid] = b[row]; }
+  __syncthreads();
+  double rz_p = 0.0, rr_p = 0.0;
+  if (live) {
+    double zv = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) zv += Mrow[k] * ((6 * m + k < n) ? sr[mbase + k] : 0.0);
+    sz[tid] = zv;
+    st_agent(zg + row, zv);
+    rz_p = sr[tid] * zv; rr_p = sr[tid] * sr[tid];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the z stores have left; no fence: its cache write-back / invalidate would evict the matrix)
+  double part0 = block_sum_512(rz_p, sred), part1 = block_sum_512(rr_p, sred);
+  // this lane's blocks of its group's first kRegRows rows, for the whole solve (a block missing from the row: zeros, column 0)
+  const int grp = tid >> 4, sub = tid & 15;
+  double rb[kRegRows][kRegBlocks][9];
+  int rl[kRegRows][kRegBlocks];
+#pragma unroll
+  for (int rr_ = 0; rr_ < kRegRows; ++rr_) {
+    const int br = r0 + grp + rr_ * (kPcgPersistThreads / 16);
+#pragma unroll
+    for (int k = 0; k < kRegBlocks; ++k) {
+      const int e = (br < r1) ? row_ptr[br] + sub + 16 * k : 0;
+      const bool have = br < r1 && e < row_ptr[br + 1];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) rb[rr_][k][i] = have ? val[(size_t)e * 9 + i] : 0.0;
+      rl[rr_][k] = have ? 3 * lcol[e] : 0;
+    }
+  }
+  int bar = 0, iters = 0;
+  double rz = 0.0, rr = 0.0, rz_prev = 0.0, rr0 = 0.0;
+  bool ok = true;
+  auto stamp = [&](int it, int k) { if (probe && wg == 0 && tid == 0 && it < 64) probe[it * 8 + k] = (long long)wall_clock64(); };
+  for (int it = 0;; ++it) {
+    stamp(it, 0);
+    ok = pcg_grid_reduce<2>(B, bar++, part0, part1, rz, rr);
+    if (!ok) break;
+    stamp(it, 1);
+    if (it == 0) rr0 = rr;
+    if (it >= max_it || !(rr > tol2 * rr0) || !(rz > 0.0)) break;
+    const double beta = (it > 0 && rz_prev != 0.0) ? rz / rz_prev : 0.0;
+    rz_prev = rz;
+    ++iters;
+    // p of the named columns from the published z (and of the own rows)
+    for (int cI = tid; cI < nc; cI += kPcgPersistThreads) {
+      const double* zc = zg + 3 * (size_t)wg_cols[c0 + cI];
+      const double z0 = ld_agent(zc), z1 = ld_agent(zc + 1), z2 = ld_agent(zc + 2);
+      pc[3 * cI] = z0 + beta * pc[3 * cI]; pc[3 * cI + 1] = z1 + beta * pc[3 * cI + 1]; pc[3 * cI + 2] = z2 + beta * pc[3 * cI + 2];
+    }
+    if (live) sp[tid] = sz[tid] + beta * sp[tid];
+    __syncthreads();
+    stamp(it, 2);
+    // q = A p for the own rows: 16 lanes per block row; the blocks come from registers (loaded once per solve), what does not fit
+    // (rows beyond kRegRows per lane group, blocks beyond 16 x kRegBlocks of a row) from memory as before
+    double pq = 0.0;
+    {
+      auto row_tail = [&](int br, int e_from, double& a0, double& a1, double& a2) {
+        for (int e = e_from; e < row_ptr[br + 1]; e += 16) {
+          const double* Bv = val + (size_t)e * 9;
+          const double* pv = pc + 3 * lcol[e];
+          const double p0 = pv[0], p1 = pv[1], p2 = pv[2];
+          a0 += Bv[0] * p0 + Bv[1] * p1 + Bv[2] * p2;
+          a1 += Bv[3] * p0 + Bv[4] * p1 + Bv[5] * p2;
+          a2 += Bv[6] * p0 + Bv[7] * p1 + Bv[8] * p2;
+        }
+      };
+      auto row_done = [&](int br, double a0, double a1, double a2) {
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o, 16); a1 += __shfl_xor(a1, o, 16); a2 += __shfl_xor(a2, o, 16); }
+        if (sub == 0) {
+          const int j = 3 * (br - r0);
+          sq[j] = a0; sq[j + 1] = a1; sq[j + 2] = a2;
+          pq += a0 * sp[j] + a1 * sp[j + 1] + a2 * sp[j + 2];
+        }
+      };
+#pragma unroll
+      for (int rr_ = 0; rr_ < kRegRows; ++rr_) {
+        const int br = r0 + grp + rr_ * (kPcgPersistThreads / 16);
+        if (br < r1) {
+          double a0 = 0, a1 = 0, a2 = 0;
+#pragma unroll
+          for (int k = 0; k < kRegBlocks; ++k) {
+            const double* pv = pc + rl[rr_][k];
+            const double p0 = pv[0], p1 = pv[1], p2 = pv[2];
+            a0 += rb[rr_][k][0] * p0 + rb[rr_][k][1] * p1 + rb[rr_][k][2] * p2;
+            a1 += rb[rr_][k][3] * p0 + rb[rr_][k][4] * p1 + rb[rr_][k][5] * p2;
+            a2 += rb[rr_][k][6] * p0 + rb[rr_][k][7] * p1 + rb[rr_][k][8] * p2;
+          }
+          row_tail(br, row_ptr[br] + sub + 16 * kRegBlocks, a0, a1, a2);
+          row_done(br, a0, a1, a2);
+        }
+      }
+      for (int br = r0 + grp + kRegRows * (kPcgPersistThreads / 16); br < r1; br += kPcgPersistThreads / 16) {
+        double a0 = 0, a1 = 0, a2 = 0;
+        row_tail(br, row_ptr[br] + sub, a0, a1, a2);
+        row_done(br, a0, a1, a2);
+      }
+    }
+    const double pq_wg = block_sum_512(pq, sred);
+    stamp(it, 3);
+    double pq_all = 0.0, unused = 0.0;
+    ok = pcg_grid_reduce<1>(B, bar++, pq_wg, 0.0, pq_all, unused);
+    if (!ok) break;
+    stamp(it, 4);
+    const double alpha = (pq_all > 0.0) ? rz / pq_all : 0.0;
+    // x += alpha p; r -= alpha q; z = M^-1 r; publish z; partials of r.z, r.r
+    if (live) { sx[tid] += alpha * sp[tid]; sr[tid] -= alpha * sq[tid]; }
+    __syncthreads();
+    rz_p = 0.0; rr_p = 0.0;
+    if (live) {
+      double zv = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) zv += Mrow[k] * ((6 * m + k < n) ? sr[mbase + k] : 0.0);
+      sz[tid] = zv;
+      st_agent(zg + row, zv);
+      rz_p = sr[tid] * zv; rr_p = sr[tid] * sr[tid];
+    }
+    part0 = block_sum_512(rz_p, sred);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the z stores have left — under the first sum; no fence: its cache write-back / invalidate would evict the matrix)
+    part1 = block_sum_512(rr_p, sred);                 // (its barriers order every thread's drain before the slot store)
+    stamp(it, 5);
+  }
+  if (live) x[row] = sx[tid];
+  if (wg == 0 && tid == 0) {
+    sc[PC_ITERS] = (double)iters; sc[PC_RZ] = rz; sc[PC_RR] = rr; sc[PC_RR0] = rr0;
+    sc[PC_DONE] = ok ? 1.0 : -1.0;
+  }
+}
+
+size_t pcg_persistent_lds(int max_cols) { return sizeof(double) * (5 * (size_t)kPcgPersistMaxRows + 8 + 2 * 256 + 4 + 3 * (size_t)max_cols); }
+int pcg_persistent_max_rows() { return kPcgPersistMaxRows; }
+bool launch_pcg_persistent(hipStream_t s, const PcgPersistDev& P, int nbr, const int* row_ptr, const double* val, const double* Minv, const double* b,
+                           double* x, double* zg, double* sc, double tol2, int max_it) {
+  const size_t lds = pcg_persistent_lds(P.max_cols);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(pcg_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) { (void)hipGetLastError(); return false; }
+    attr_set = true;
+  }
+  if (lds > 80 * 1024 || P.G < 1 || P.G > 256) return false;
+  if (hipMemsetAsync(P.slots, 0xff, sizeof(unsigned long long) * 6 * (size_t)P.G, s) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (hipMemsetAsync(P.abort_w, 0, sizeof(int) * 2, s) != hipSuccess) { (void)hipGetLastError(); return false; }
+  const long long timeout_ticks = 100000000LL / 5;   // s_memrealtime: 100 MHz; a fifth of a second for the whole solve
+  // BSGPU_PCG_PROBE=1: workgroup 0 stamps the phases of its first 64 iterations with the 100 MHz wall clock; printed once
+  static const bool want_probe = getenv("BSGPU_PCG_PROBE") != nullptr;
+  static long long* d_probe = nullptr;
+  static int probe_left = 3;
+  long long* probe = nullptr;
+  if (want_probe && probe_left > 0) {
+    if (!d_probe && hipMalloc((void**)&d_probe, sizeof(long long) * 512) != hipSuccess) { (void)hipGetLastError(); d_probe = nullptr; }
+    if (d_probe) { (void)hipMemsetAsync(d_probe, 0, sizeof(long long) * 512, s); probe = d_probe; }
+  }
+  hipLaunchKernelGGL(pcg_persistent_kernel, dim3(P.G), dim3(kPcgPersistThreads), lds, s, nbr, row_ptr, val, Minv, b, x, zg, P.wg_row, P.wg_colptr,
+                     P.wg_cols, P.lcol, P.slots, P.abort_w, sc, tol2, max_it, timeout_ticks, P.max_cols, probe);
+  if (probe) {
+    long long h[512];
+    if (hipMemcpyAsync(h, d_probe, sizeof(h), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess) {
+      double acc[6] = {0, 0, 0, 0, 0, 0}; int n = 0;
+      for (int it = 4; it < 63; ++it) {
+        if (!h[it * 8 + 5] || !h[(it + 1) * 8]) break;
+        for (int k = 0; k < 5; ++k) acc[k] += (double)(h[it * 8 + k + 1] - h[it * 8 + k]);
+        acc[5] += (double)(h[(it + 1) * 8] - h[it * 8]);
+        ++n;
+      }
+      if (n) fprintf(stderr, "[pcg probe] per iteration (us, workgroup 0, %d iterations): reduce rz %.2f | gather %.2f | spmv %.2f | reduce pq %.2f | update %.2f | total %.2f\n", n,
+                     acc[0] / n / 100, acc[1] / n / 100, acc[2] / n / 100, acc[3] / n / 100, acc[4] / n / 100, acc[5] / n / 100);
+    }
+    --probe_left;
+  }
+  return hipGetLastError() == hipSuccess;
+}
 // ---------------------------------------------------------------------------------------------------
 // PCG on the REDUCED camera system (Ceres: ITERATIVE_SCHUR with the SCHUR_JACOBI preconditioner the reference's
 // beam_slam_launch/config/optimization/ceres_config.json:11-12 names).  The operator is the assembled Schur complement itself — the
