@@ -766,23 +766,26 @@ int build_bsr(bsgpu_ctx* c) {
     wg_row[G] = nbr;
     std::vector<int> wg_colptr(G + 1, 0), wg_cols, lcol(nblk, 0), stamp(nbr, -1), local(nbr, 0);
     int max_cols = 0, max_rows = 0;
+    bool paired = true;
     for (int g = 0; g < G; ++g) {
       std::vector<int> cols;
       for (int e = row_ptr[wg_row[g]]; e < row_ptr[wg_row[g + 1]]; ++e) if (stamp[col[e]] != g) { stamp[col[e]] = g; cols.push_back(col[e]); }
       std::sort(cols.begin(), cols.end());
       for (size_t i = 0; i < cols.size(); ++i) local[cols[i]] = (int)i;
+      paired = paired && cols.size() % 2 == 0;
+      for (size_t i = 0; i + 1 < cols.size() && paired; i += 2) paired = (cols[i] & 1) == 0 && cols[i + 1] == cols[i] + 1;
       for (int e = row_ptr[wg_row[g]]; e < row_ptr[wg_row[g + 1]]; ++e) lcol[e] = local[col[e]];
       wg_cols.insert(wg_cols.end(), cols.begin(), cols.end());
       wg_colptr[g + 1] = (int)wg_cols.size();
       max_cols = std::max(max_cols, (int)cols.size());
       max_rows = std::max(max_rows, 3 * (wg_row[g + 1] - wg_row[g]));
     }
-    if (max_rows <= pcg_persistent_max_rows() && pcg_persistent_lds(max_cols) <= 80 * 1024) {
+    if (max_rows <= pcg_persistent_max_rows() && pcg_persistent_lds(max_cols) <= pcg_persistent_lds_limit()) {
       PcgPersistDev& P = c->pcg_persist;
-      P.G = G; P.max_cols = max_cols;
+      P.G = G; P.max_cols = max_cols; P.paired = paired ? 1 : 0;
       P.wg_row = c->upload(wg_row); P.wg_colptr = c->upload(wg_colptr); P.wg_cols = c->upload(wg_cols); P.lcol = c->upload(lcol);
-      P.slots = c->alloc<unsigned long long>(6 * (size_t)G); P.abort_w = c->alloc<int>(2);
-      if (!P.wg_row || !P.lcol || !P.slots || !P.abort_w) P = PcgPersistDev();
+      P.slots = c->alloc<unsigned long long>(pcg_persistent_slot_words(G)); P.abort_w = c->alloc<int>(2); P.zg = c->alloc<double>(pcg_persistent_z_words(nbr));
+      if (!P.wg_row || !P.lcol || !P.slots || !P.abort_w || !P.zg) P = PcgPersistDev();
     }
   }
   c->bsr_built = true;

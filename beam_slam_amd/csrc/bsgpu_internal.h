@@ -223,12 +223,17 @@ int pcg_spmv_grid(int nbr);   // workgroups (= p.q partials) of one SpMV launch
 // the whole PCG solve as one launch (k_pcg.hip pcg_persistent_kernel): per-workgroup row ranges and named-column lists
 struct PcgPersistDev {
   int G = 0, max_cols = 0;
+  int paired = 0;                // every named-column list consists of pairs (2m, 2m + 1): gathered 16 bytes at a time
   const int *wg_row = nullptr, *wg_colptr = nullptr, *wg_cols = nullptr, *lcol = nullptr;
   unsigned long long* slots = nullptr;
   int* abort_w = nullptr;
+  double* zg = nullptr;          // the published z: two sets of 3 nbr entries
 };
 size_t pcg_persistent_lds(int max_cols);
+size_t pcg_persistent_lds_limit();
 int pcg_persistent_max_rows();
+size_t pcg_persistent_slot_words(int G);
+size_t pcg_persistent_z_words(int nbr);
 bool launch_pcg_persistent(hipStream_t s, const PcgPersistDev& P, int nbr, const int* row_ptr, const double* val, const double* Minv, const double* b,
                            double* x, double* zg, double* sc, double tol2, int max_it);
 void launch_pcg_init(hipStream_t s, int nbr, const double* b, const double* Minv, double* x, double* r, double* z, double* p0, double* p1,

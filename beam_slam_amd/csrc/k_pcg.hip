@@ -337,7 +337,10 @@ int pcg_rows_grid(int nbr) { return (3 * nbr + kPcgRowsPerWg - 1) / kPcgRowsPerW
 constexpr int kPcgPersistThreads = 512;
 constexpr int kPcgPersistMaxRows = 504;          // scalar rows of one workgroup (one thread each in the update)
 constexpr unsigned long long kSlotEmpty = ~0ull;
-constexpr int kRegRows = 2, kRegBlocks = 4;     // register-resident blocks of a lane: rows of its 16-lane group x blocks of the row
+constexpr int kPcgSlotStride = 8, kPcgSlotStrideMax = 16;
+constexpr int kGatherPoses = 2;   // poses (pairs of block columns, 48 bytes = three 16-byte loads) of a thread in the in-flight gather   // 8-byte words between the slots of two workgroups
+constexpr int kRowLanes = 8;                     // lanes per block row in the product (64 rows at a time: a workgroup of C4 has ~40)
+constexpr int kRegRows = 1, kRegBlocks = 6;     // register-resident blocks of a lane: rows of its lane group x blocks of the row
 BSG_DEV double ld_agent(const double* p) {
   const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return __longlong_as_double((long long)v);
@@ -348,48 +351,65 @@ BSG_DEV void st_agent(double* p, double v) {
 struct PcgBarrier {
   unsigned long long* slots;   // [3 sets][2 values][G]
   int* abort_w;
-  int G;
+  int G, stride;               // slot of workgroup w at w * stride (in 8-byte words): writers of one line are serialised at the memory side
   long long deadline;
   double* sbuf;                // LDS: 2 * G partials + 2 totals + 1 flag
 };
 // stores this workgroup's partial(s) for barrier `b` and returns the totals over all workgroups; false on abort (uniform)
-template <int NV>
-BSG_DEV bool pcg_grid_reduce(const PcgBarrier& B, int b, double v0, double v1, double& t0, double& t1) {
+struct PcgNoSide {
+  BSG_DEV void issue(int) const {}
+  BSG_DEV bool poll() const { return true; }     // true: nothing outstanding
+  BSG_DEV void finish(int) const {}
+};
+// `side`: work whose loads travel with the looks at the slots (the gather of the published z: it needs the slots no more than the
+// slots need it) — issue() requests, poll() re-requests what was still empty and says whether anything is outstanding, finish() stores.
+// Slots and side job are polled in ONE loop: a round is one memory round trip whatever it waits for.
+template <int NV, class Side>
+BSG_DEV bool pcg_grid_reduce(const PcgBarrier& B, int b, double v0, double v1, double& t0, double& t1, Side& side) {
   const int tid = threadIdx.x, G = B.G, wg = blockIdx.x;
   const int set = b % 3, nxt = (b + 1) % 3;
-  unsigned long long* cur = B.slots + (size_t)set * 2 * G;
-  unsigned long long* nx = B.slots + (size_t)nxt * 2 * G;
+  const int S = B.stride;
+  unsigned long long* cur = B.slots + (size_t)set * 2 * G * S;
+  unsigned long long* nx = B.slots + (size_t)nxt * 2 * G * S;
   if (tid == 0) {
-    __hip_atomic_store(nx + wg, kSlotEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(nx + G + wg, kSlotEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(cur + wg, (unsigned long long)__double_as_longlong(v0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (NV == 2) __hip_atomic_store(cur + G + wg, (unsigned long long)__double_as_longlong(v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(cur + (size_t)wg * S, (unsigned long long)__double_as_longlong(v0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (NV == 2) __hip_atomic_store(cur + (size_t)(G + wg) * S, (unsigned long long)__double_as_longlong(v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(nx + (size_t)wg * S, kSlotEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(nx + (size_t)(G + wg) * S, kSlotEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   double* flag = B.sbuf + 2 * G + 2;
   if (tid == 0) *flag = 0.0;
   __syncthreads();
-  if (tid < G) {
-    unsigned long long a = kSlotEmpty, c = (NV == 2) ? kSlotEmpty : 0ull;
-    for (unsigned it = 0;; ++it) {
-      if (a == kSlotEmpty) a = __hip_atomic_load(cur + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (NV == 2 && c == kSlotEmpty) c = __hip_atomic_load(cur + G + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (a != kSlotEmpty && c != kSlotEmpty) break;
-      if ((it & 15) == 15) {
-        if (__hip_atomic_load(B.abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { *flag = 1.0; break; }
-        if ((long long)wall_clock64() > B.deadline) { __hip_atomic_store(B.abort_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *flag = 1.0; break; }
-      }
-      __builtin_amdgcn_s_sleep(1);
+  const bool poller = tid < G;
+  unsigned long long a = poller ? kSlotEmpty : 0ull, c = (poller && NV == 2) ? kSlotEmpty : 0ull;
+  if (poller) {
+    a = __hip_atomic_load(cur + (size_t)tid * S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (NV == 2) c = __hip_atomic_load(cur + (size_t)(G + tid) * S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  side.issue(tid);
+  for (unsigned it = 0;; ++it) {
+    const bool side_done = side.poll();
+    if (a != kSlotEmpty && c != kSlotEmpty && side_done) break;
+    if (a == kSlotEmpty) a = __hip_atomic_load(cur + (size_t)tid * S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (NV == 2 && c == kSlotEmpty) c = __hip_atomic_load(cur + (size_t)(G + tid) * S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((it & 15) == 15) {
+      if (__hip_atomic_load(B.abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { *flag = 1.0; break; }
+      if ((long long)wall_clock64() > B.deadline) { __hip_atomic_store(B.abort_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *flag = 1.0; break; }
     }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  if (poller) {
     B.sbuf[tid] = __longlong_as_double((long long)a);
     B.sbuf[G + tid] = (NV == 2) ? __longlong_as_double((long long)c) : 0.0;
   }
+  side.finish(tid);
   __syncthreads();
   if (tid < 64) {
-    double a = 0.0, c = 0.0;
-    for (int i = tid; i < G; i += 64) { a += B.sbuf[i]; c += B.sbuf[G + i]; }
+    double a2 = 0.0, c2 = 0.0;
+    for (int i = tid; i < G; i += 64) { a2 += B.sbuf[i]; c2 += B.sbuf[G + i]; }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
-    if (tid == 0) { B.sbuf[2 * G] = a; B.sbuf[2 * G + 1] = c; }
+    for (int o = 32; o > 0; o >>= 1) { a2 += __shfl_xor(a2, o, 64); c2 += __shfl_xor(c2, o, 64); }
+    if (tid == 0) { B.sbuf[2 * G] = a2; B.sbuf[2 * G + 1] = c2; }
   }
   __syncthreads();
   t0 = B.sbuf[2 * G]; t1 = B.sbuf[2 * G + 1];
@@ -411,7 +431,7 @@ __global__ __launch_bounds__(kPcgPersistThreads) void pcg_persistent_kernel(
     int nbr, const int* __restrict__ row_ptr, const double* __restrict__ val, const double* __restrict__ Minv, const double* __restrict__ b,
     double* __restrict__ x, double* __restrict__ zg, const int* __restrict__ wg_row, const int* __restrict__ wg_colptr,
     const int* __restrict__ wg_cols, const int* __restrict__ lcol, unsigned long long* __restrict__ slots, int* __restrict__ abort_w,
-    double* __restrict__ sc, double tol2, int max_it, long long timeout_ticks, int max_cols, long long* __restrict__ probe) {
+    double* __restrict__ sc, double tol2, int max_it, long long timeout_ticks, int max_cols, int paired, int slot_stride, long long* __restrict__ probe) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x, wg = blockIdx.x, G = gridDim.x;
   double* sx = lds;                               // own rows: x, r, p, q, z
@@ -422,10 +442,12 @@ __global__ __launch_bounds__(kPcgPersistThreads) void pcg_persistent_kernel(
   double* sred = sz + kPcgPersistMaxRows;         // 8
   double* sbar = sred + 8;                        // 2 G + 3
   double* pc = sbar + 2 * 256 + 4;                // p of the named columns: 3 * max_cols
+  double* zc = pc + 3 * max_cols;                 // their z as gathered: 3 * max_cols
   const int r0 = wg_row[wg], r1 = wg_row[wg + 1], nrow = 3 * (r1 - r0), n = 3 * nbr;
+  const size_t zset = 6 * (size_t)((nbr + 1) / 2);   // doubles of one z set (whole poses: a set starts 16-byte aligned)
   const int c0 = wg_colptr[wg], nc = wg_colptr[wg + 1] - c0;
   PcgBarrier B;
-  B.slots = slots; B.abort_w = abort_w; B.G = G; B.deadline = (long long)wall_clock64() + timeout_ticks; B.sbuf = sbar;
+  B.slots = slots; B.abort_w = abort_w; B.G = G; B.stride = slot_stride; B.deadline = (long long)wall_clock64() + timeout_ticks; B.sbuf = sbar;
   const int row = 3 * r0 + tid;                   // this thread's scalar row in the update
   const bool live = tid < nrow;
   const int m = row / 6, mi = row - 6 * m, mbase = 6 * m - 3 * r0;   // its 6x6 preconditioner block (inside the workgroup: r0 is even)
@@ -441,21 +463,86 @@ __global__ __launch_bounds__(kPcgPersistThreads) void pcg_persistent_kernel(
 #pragma unroll
     for (int k = 0; k < 6; ++k) zv += Mrow[k] * ((6 * m + k < n) ? sr[mbase + k] : 0.0);
     sz[tid] = zv;
-    st_agent(zg + row, zv);
+    st_agent(zg + row, zv);                         // z of iteration k lives in set k % 2 of zg (both sets start empty)
     rz_p = sr[tid] * zv; rr_p = sr[tid] * sr[tid];
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the z stores have left; no fence: its cache write-back / invalidate would evict the matrix)
   double part0 = block_sum_512(rz_p, sred), part1 = block_sum_512(rr_p, sred);
+  // the z of the named columns: an entry is empty (all bits set) until its owner has stored it
+  // The gather of the named columns' z.  The two block columns (2m, 2m + 1) of a pose are named together (`paired`: host check) and are
+  // 48 contiguous bytes of z: three 16-byte loads per pose.  (Measured: 8-byte loads 4.6 us for the phase, 16-byte 3.1; a 64-byte line
+  // per pose fetched by a quad — a third of the requests — 3.9: the phase moves ~25 MB of uncached sectors per iteration over the
+  // fabric, it is not bound by the request count.)  Unpaired lists and poses beyond kGatherPoses x 512: one 8-byte load per value
+  // after the reduction.
+  const __amdgpu_buffer_rsrc_t rz_res = __builtin_amdgcn_make_buffer_rsrc(zg, 0, (int)(sizeof(double) * 2 * zset), 0x00020000);
+  struct Gather {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    __amdgpu_buffer_rsrc_t res;
+    const int* cols; double* zc;
+    size_t set_base; int nc, paired;
+    unsigned long long v[kGatherPoses][6];
+    unsigned off[kGatherPoses];
+    int t;
+    BSG_DEV void load(int u, int k) {
+      const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(res, off[u] + 16 * k, 0, 16 /* sc1 */);
+      v[u][2 * k] = ((unsigned long long)w.y << 32) | w.x; v[u][2 * k + 1] = ((unsigned long long)w.w << 32) | w.z;
+    }
+    BSG_DEV void issue(int tid_) {
+      t = tid_;
+      const int np = nc >> 1;
+#pragma unroll
+      for (int u = 0; u < kGatherPoses; ++u) {
+        const int pi = t + u * kPcgPersistThreads;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v[u][k] = 0ull;
+        if (paired && pi < np) {
+          off[u] = (unsigned)((set_base + 3 * (size_t)cols[2 * pi]) * sizeof(double));
+#pragma unroll
+          for (int k = 0; k < 3; ++k) load(u, k);
+        }
+      }
+    }
+    BSG_DEV bool poll() {
+      bool all = true;
+#pragma unroll
+      for (int u = 0; u < kGatherPoses; ++u)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          if (v[u][2 * k] == kSlotEmpty || v[u][2 * k + 1] == kSlotEmpty) { load(u, k); all = false; }
+      return all;
+    }
+    BSG_DEV void finish(int) {
+      const int np = nc >> 1;
+#pragma unroll
+      for (int u = 0; u < kGatherPoses; ++u) {
+        const int pi = t + u * kPcgPersistThreads;
+        if (paired && pi < np) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) zc[6 * pi + k] = __longlong_as_double((long long)v[u][k]);
+        }
+      }
+    }
+  };
+  auto gather_rest = [&](int it_) {
+    const unsigned long long* zcur = reinterpret_cast<const unsigned long long*>(zg + (size_t)(it_ & 1) * zset);
+    const int first = paired ? 2 * kGatherPoses * kPcgPersistThreads : 0;
+    for (int cI = first + tid; cI < nc; cI += kPcgPersistThreads) {
+      const unsigned long long* zp = zcur + 3 * (size_t)wg_cols[c0 + cI];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) zc[3 * cI + k] = __longlong_as_double((long long)__hip_atomic_load(zp + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+  };
   // this lane's blocks of its group's first kRegRows rows, for the whole solve (a block missing from the row: zeros, column 0)
-  const int grp = tid >> 4, sub = tid & 15;
+  const int grp = tid / kRowLanes, sub = tid % kRowLanes;
+  constexpr int kRowGroups = kPcgPersistThreads / kRowLanes;
   double rb[kRegRows][kRegBlocks][9];
   int rl[kRegRows][kRegBlocks];
 #pragma unroll
   for (int rr_ = 0; rr_ < kRegRows; ++rr_) {
-    const int br = r0 + grp + rr_ * (kPcgPersistThreads / 16);
+    const int br = r0 + grp + rr_ * kRowGroups;
 #pragma unroll
     for (int k = 0; k < kRegBlocks; ++k) {
-      const int e = (br < r1) ? row_ptr[br] + sub + 16 * k : 0;
+      const int e = (br < r1) ? row_ptr[br] + sub + kRowLanes * k : 0;
       const bool have = br < r1 && e < row_ptr[br + 1];
 #pragma unroll
       for (int i = 0; i < 9; ++i) rb[rr_][k][i] = have ? val[(size_t)e * 9 + i] : 0.0;
@@ -468,29 +555,31 @@ __global__ __launch_bounds__(kPcgPersistThreads) void pcg_persistent_kernel(
   auto stamp = [&](int it, int k) { if (probe && wg == 0 && tid == 0 && it < 64) probe[it * 8 + k] = (long long)wall_clock64(); };
   for (int it = 0;; ++it) {
     stamp(it, 0);
-    ok = pcg_grid_reduce<2>(B, bar++, part0, part1, rz, rr);
+    {
+      Gather gth;
+      gth.res = rz_res; gth.cols = wg_cols + c0; gth.zc = zc; gth.set_base = (size_t)(it & 1) * zset; gth.nc = nc; gth.paired = paired;
+      ok = pcg_grid_reduce<2>(B, bar++, part0, part1, rz, rr, gth);
+    }
     if (!ok) break;
+    gather_rest(it);   // (every z is there: each workgroup stored its z before its slot)
     stamp(it, 1);
+    if (probe && it == 11 && tid == 0) probe[512 + 4 * wg + 3] = (long long)wall_clock64();
     if (it == 0) rr0 = rr;
     if (it >= max_it || !(rr > tol2 * rr0) || !(rz > 0.0)) break;
     const double beta = (it > 0 && rz_prev != 0.0) ? rz / rz_prev : 0.0;
     rz_prev = rz;
     ++iters;
     // p of the named columns from the published z (and of the own rows)
-    for (int cI = tid; cI < nc; cI += kPcgPersistThreads) {
-      const double* zc = zg + 3 * (size_t)wg_cols[c0 + cI];
-      const double z0 = ld_agent(zc), z1 = ld_agent(zc + 1), z2 = ld_agent(zc + 2);
-      pc[3 * cI] = z0 + beta * pc[3 * cI]; pc[3 * cI + 1] = z1 + beta * pc[3 * cI + 1]; pc[3 * cI + 2] = z2 + beta * pc[3 * cI + 2];
-    }
+    for (int i = tid; i < 3 * nc; i += kPcgPersistThreads) pc[i] = zc[i] + beta * pc[i];
     if (live) sp[tid] = sz[tid] + beta * sp[tid];
     __syncthreads();
     stamp(it, 2);
-    // q = A p for the own rows: 16 lanes per block row; the blocks come from registers (loaded once per solve), what does not fit
-    // (rows beyond kRegRows per lane group, blocks beyond 16 x kRegBlocks of a row) from memory as before
+    // q = A p for the own rows: kRowLanes lanes per block row; the blocks come from registers (loaded once per solve), what does not
+    // fit (rows beyond kRegRows per lane group, blocks beyond kRowLanes x kRegBlocks of a row) from memory as before
     double pq = 0.0;
     {
       auto row_tail = [&](int br, int e_from, double& a0, double& a1, double& a2) {
-        for (int e = e_from; e < row_ptr[br + 1]; e += 16) {
+        for (int e = e_from; e < row_ptr[br + 1]; e += kRowLanes) {
           const double* Bv = val + (size_t)e * 9;
           const double* pv = pc + 3 * lcol[e];
           const double p0 = pv[0], p1 = pv[1], p2 = pv[2];
@@ -501,7 +590,7 @@ __global__ __launch_bounds__(kPcgPersistThreads) void pcg_persistent_kernel(
       };
       auto row_done = [&](int br, double a0, double a1, double a2) {
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o, 16); a1 += __shfl_xor(a1, o, 16); a2 += __shfl_xor(a2, o, 16); }
+        for (int o = kRowLanes / 2; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o, kRowLanes); a1 += __shfl_xor(a1, o, kRowLanes); a2 += __shfl_xor(a2, o, kRowLanes); }
         if (sub == 0) {
           const int j = 3 * (br - r0);
           sq[j] = a0; sq[j + 1] = a1; sq[j + 2] = a2;
@@ -510,7 +599,7 @@ __global__ __launch_bounds__(kPcgPersistThreads) void pcg_persistent_kernel(
       };
 #pragma unroll
       for (int rr_ = 0; rr_ < kRegRows; ++rr_) {
-        const int br = r0 + grp + rr_ * (kPcgPersistThreads / 16);
+        const int br = r0 + grp + rr_ * kRowGroups;
         if (br < r1) {
           double a0 = 0, a1 = 0, a2 = 0;
 #pragma unroll
@@ -521,11 +610,11 @@ __global__ __launch_bounds__(kPcgPersistThreads) void pcg_persistent_kernel(
             a1 += rb[rr_][k][3] * p0 + rb[rr_][k][4] * p1 + rb[rr_][k][5] * p2;
             a2 += rb[rr_][k][6] * p0 + rb[rr_][k][7] * p1 + rb[rr_][k][8] * p2;
           }
-          row_tail(br, row_ptr[br] + sub + 16 * kRegBlocks, a0, a1, a2);
+          row_tail(br, row_ptr[br] + sub + kRowLanes * kRegBlocks, a0, a1, a2);
           row_done(br, a0, a1, a2);
         }
       }
-      for (int br = r0 + grp + kRegRows * (kPcgPersistThreads / 16); br < r1; br += kPcgPersistThreads / 16) {
+      for (int br = r0 + grp + kRegRows * kRowGroups; br < r1; br += kRowGroups) {
         double a0 = 0, a1 = 0, a2 = 0;
         row_tail(br, row_ptr[br] + sub, a0, a1, a2);
         row_done(br, a0, a1, a2);
@@ -533,10 +622,13 @@ __global__ __launch_bounds__(kPcgPersistThreads) void pcg_persistent_kernel(
     }
     const double pq_wg = block_sum_512(pq, sred);
     stamp(it, 3);
+    if (probe && it == 10 && tid == 0) probe[512 + 4 * wg] = (long long)wall_clock64();
     double pq_all = 0.0, unused = 0.0;
-    ok = pcg_grid_reduce<1>(B, bar++, pq_wg, 0.0, pq_all, unused);
+    PcgNoSide no_side;
+    ok = pcg_grid_reduce<1>(B, bar++, pq_wg, 0.0, pq_all, unused, no_side);
     if (!ok) break;
     stamp(it, 4);
+    if (probe && it == 10 && tid == 0) probe[512 + 4 * wg + 1] = (long long)wall_clock64();
     const double alpha = (pq_all > 0.0) ? rz / pq_all : 0.0;
     // x += alpha p; r -= alpha q; z = M^-1 r; publish z; partials of r.z, r.r
     if (live) { sx[tid] += alpha * sp[tid]; sr[tid] -= alpha * sq[tid]; }
@@ -547,13 +639,15 @@ __global__ __launch_bounds__(kPcgPersistThreads) void pcg_persistent_kernel(
 #pragma unroll
       for (int k = 0; k < 6; ++k) zv += Mrow[k] * ((6 * m + k < n) ? sr[mbase + k] : 0.0);
       sz[tid] = zv;
-      st_agent(zg + row, zv);
+      st_agent(zg + (size_t)((it + 1) & 1) * zset + row, zv);
+      st_agent(zg + (size_t)(it & 1) * zset + row, __longlong_as_double((long long)kSlotEmpty));   // (everybody has gathered z of this iteration: they arrived at the p.q barrier)
       rz_p = sr[tid] * zv; rr_p = sr[tid] * sr[tid];
     }
     part0 = block_sum_512(rz_p, sred);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the z stores have left — under the first sum; no fence: its cache write-back / invalidate would evict the matrix)
     part1 = block_sum_512(rr_p, sred);                 // (its barriers order every thread's drain before the slot store)
     stamp(it, 5);
+    if (probe && it == 10 && tid == 0) probe[512 + 4 * wg + 2] = (long long)wall_clock64();
   }
   if (live) x[row] = sx[tid];
   if (wg == 0 && tid == 0) {
@@ -562,18 +656,23 @@ __global__ __launch_bounds__(kPcgPersistThreads) void pcg_persistent_kernel(
   }
 }
 
-size_t pcg_persistent_lds(int max_cols) { return sizeof(double) * (5 * (size_t)kPcgPersistMaxRows + 8 + 2 * 256 + 4 + 3 * (size_t)max_cols); }
+size_t pcg_persistent_lds(int max_cols) { return sizeof(double) * (5 * (size_t)kPcgPersistMaxRows + 8 + 2 * 256 + 4 + 6 * (size_t)max_cols); }
+size_t pcg_persistent_lds_limit() { return 150 * 1024; }
 int pcg_persistent_max_rows() { return kPcgPersistMaxRows; }
+size_t pcg_persistent_z_words(int nbr) { return 2 * 6 * (size_t)((nbr + 1) / 2); }
+size_t pcg_persistent_slot_words(int G) { return 6 * (size_t)G * kPcgSlotStrideMax; }
 bool launch_pcg_persistent(hipStream_t s, const PcgPersistDev& P, int nbr, const int* row_ptr, const double* val, const double* Minv, const double* b,
                            double* x, double* zg, double* sc, double tol2, int max_it) {
   const size_t lds = pcg_persistent_lds(P.max_cols);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(pcg_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(pcg_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pcg_persistent_lds_limit()) != hipSuccess) { (void)hipGetLastError(); return false; }
     attr_set = true;
   }
-  if (lds > 80 * 1024 || P.G < 1 || P.G > 256) return false;
-  if (hipMemsetAsync(P.slots, 0xff, sizeof(unsigned long long) * 6 * (size_t)P.G, s) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (lds > pcg_persistent_lds_limit() || P.G < 1 || P.G > 256) return false;
+  if (hipMemsetAsync(zg, 0xff, sizeof(double) * pcg_persistent_z_words(nbr), s) != hipSuccess) { (void)hipGetLastError(); return false; }   // (both z sets empty)
+  static const int slot_stride = [] { const char* e = getenv("BSGPU_PCG_SLOT_STRIDE"); const int v = e ? atoi(e) : kPcgSlotStride; return (v >= 1 && v <= kPcgSlotStrideMax) ? v : kPcgSlotStride; }();
+  if (hipMemsetAsync(P.slots, 0xff, sizeof(unsigned long long) * 6 * (size_t)P.G * kPcgSlotStrideMax, s) != hipSuccess) { (void)hipGetLastError(); return false; }
   if (hipMemsetAsync(P.abort_w, 0, sizeof(int) * 2, s) != hipSuccess) { (void)hipGetLastError(); return false; }
   const long long timeout_ticks = 100000000LL / 5;   // s_memrealtime: 100 MHz; a fifth of a second for the whole solve
   // BSGPU_PCG_PROBE=1: workgroup 0 stamps the phases of its first 64 iterations with the 100 MHz wall clock; printed once
@@ -582,13 +681,13 @@ bool launch_pcg_persistent(hipStream_t s, const PcgPersistDev& P, int nbr, const
   static int probe_left = 3;
   long long* probe = nullptr;
   if (want_probe && probe_left > 0) {
-    if (!d_probe && hipMalloc((void**)&d_probe, sizeof(long long) * 512) != hipSuccess) { (void)hipGetLastError(); d_probe = nullptr; }
-    if (d_probe) { (void)hipMemsetAsync(d_probe, 0, sizeof(long long) * 512, s); probe = d_probe; }
+    if (!d_probe && hipMalloc((void**)&d_probe, sizeof(long long) * (512 + 1024)) != hipSuccess) { (void)hipGetLastError(); d_probe = nullptr; }
+    if (d_probe) { (void)hipMemsetAsync(d_probe, 0, sizeof(long long) * (512 + 1024), s); probe = d_probe; }
   }
   hipLaunchKernelGGL(pcg_persistent_kernel, dim3(P.G), dim3(kPcgPersistThreads), lds, s, nbr, row_ptr, val, Minv, b, x, zg, P.wg_row, P.wg_colptr,
-                     P.wg_cols, P.lcol, P.slots, P.abort_w, sc, tol2, max_it, timeout_ticks, P.max_cols, probe);
+                     P.wg_cols, P.lcol, P.slots, P.abort_w, sc, tol2, max_it, timeout_ticks, P.max_cols, P.paired, slot_stride, probe);
   if (probe) {
-    long long h[512];
+    long long h[512 + 1024];
     if (hipMemcpyAsync(h, d_probe, sizeof(h), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess) {
       double acc[6] = {0, 0, 0, 0, 0, 0}; int n = 0;
       for (int it = 4; it < 63; ++it) {
@@ -600,6 +699,14 @@ bool launch_pcg_persistent(hipStream_t s, const PcgPersistDev& P, int nbr, const
       if (n) fprintf(stderr, "[pcg probe] per iteration (us, workgroup 0, %d iterations): reduce rz %.2f | gather %.2f | spmv %.2f | reduce pq %.2f | update %.2f | total %.2f\n", n,
                      acc[0] / n / 100, acc[1] / n / 100, acc[2] / n / 100, acc[3] / n / 100, acc[4] / n / 100, acc[5] / n / 100);
     }
+      {   // spread over the workgroups at iteration 10: arrival at the p.q reduction, exit from it, arrival at the r.z reduction, exit from it
+        long long lo[4], hi[4];
+        for (int k = 0; k < 4; ++k) { lo[k] = 1LL << 62; hi[k] = 0; }
+        for (int g = 0; g < P.G; ++g) for (int k = 0; k < 4; ++k) { const long long v = h[512 + 4 * g + k]; if (v) { lo[k] = std::min(lo[k], v); hi[k] = std::max(hi[k], v); } }
+        fprintf(stderr, "[pcg probe] iteration 10 over %d workgroups (us from the first arrival at p.q): arrive p.q %.2f..%.2f | leave %.2f..%.2f | arrive r.z %.2f..%.2f | leave %.2f..%.2f\n",
+                P.G, 0.0, (hi[0] - lo[0]) / 100.0, (lo[1] - lo[0]) / 100.0, (hi[1] - lo[0]) / 100.0, (lo[2] - lo[0]) / 100.0, (hi[2] - lo[0]) / 100.0,
+                (lo[3] - lo[0]) / 100.0, (hi[3] - lo[0]) / 100.0);
+      }
     --probe_left;
   }
   return hipGetLastError() == hipSuccess;
