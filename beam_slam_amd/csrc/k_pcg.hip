@@ -338,6 +338,7 @@ constexpr int kPcgPersistThreads = 512;
 constexpr int kPcgPersistMaxRows = 504;          // scalar rows of one workgroup (one thread each in the update)
 constexpr unsigned long long kSlotEmpty = ~0ull;
 constexpr int kPcgSlotStride = 8, kPcgSlotStrideMax = 16;
+constexpr int kTailCap = 384;     // blocks of a workgroup beyond the register-resident ones that are kept in LDS (the rest: from memory)
 constexpr int kGatherPoses = 2;   // poses (pairs of block columns, 48 bytes = three 16-byte loads) of a thread in the in-flight gather   // 8-byte words between the slots of two workgroups
 constexpr int kRowLanes = 8;                     // lanes per block row in the product (64 rows at a time: a workgroup of C4 has ~40)
 constexpr int kRegRows = 1, kRegBlocks = 6;     // register-resident blocks of a lane: rows of its lane group x blocks of the row
@@ -443,6 +444,9 @@ __global__ __launch_bounds__(kPcgPersistThreads) void pcg_persistent_kernel(
   double* sbar = sred + 8;                        // 2 G + 3
   double* pc = sbar + 2 * 256 + 4;                // p of the named columns: 3 * max_cols
   double* zc = pc + 3 * max_cols;                 // their z as gathered: 3 * max_cols
+  double* tb = zc + 3 * max_cols;                 // blocks that do not fit the registers ("tails"): 9 * kTailCap
+  int* tl = reinterpret_cast<int*>(tb + 9 * kTailCap);   // ... their column offsets into pc: kTailCap
+  int* toff = tl + kTailCap;                      // first tail slot of each own block row: kPcgPersistMaxRows / 3 + 1
   const int r0 = wg_row[wg], r1 = wg_row[wg + 1], nrow = 3 * (r1 - r0), n = 3 * nbr;
   const size_t zset = 6 * (size_t)((nbr + 1) / 2);   // doubles of one z set (whole poses: a set starts 16-byte aligned)
   const int c0 = wg_colptr[wg], nc = wg_colptr[wg + 1] - c0;
@@ -549,6 +553,29 @@ __global__ __launch_bounds__(kPcgPersistThreads) void pcg_persistent_kernel(
       rl[rr_][k] = have ? 3 * lcol[e] : 0;
     }
   }
+  // the blocks the registers do not hold, into LDS (slot = toff[row] + position in the row's tail), as far as kTailCap goes
+  auto tail_start = [&](int br) {
+    const bool reg_row = (br - r0) < kRegRows * kRowGroups;
+    return min(row_ptr[br] + (reg_row ? kRowLanes * kRegBlocks : 0), row_ptr[br + 1]);
+  };
+  if (tid == 0) {
+    int o = 0;
+    for (int br = r0; br < r1; ++br) { toff[br - r0] = o; o += row_ptr[br + 1] - tail_start(br); }
+    toff[r1 - r0] = o;
+  }
+  __syncthreads();
+  for (int br = r0 + grp; br < r1; br += kRowGroups) {
+    const int ts = tail_start(br), o = toff[br - r0];
+    for (int e = ts + sub; e < row_ptr[br + 1]; e += kRowLanes) {
+      const int slot = o + (e - ts);
+      if (slot < kTailCap) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) tb[9 * slot + i] = val[(size_t)e * 9 + i];
+        tl[slot] = 3 * lcol[e];
+      }
+    }
+  }
+  __syncthreads();
   int bar = 0, iters = 0;
   double rz = 0.0, rr = 0.0, rz_prev = 0.0, rr0 = 0.0;
   bool ok = true;
@@ -561,7 +588,10 @@ __global__ __launch_bounds__(kPcgPersistThreads) void pcg_persistent_kernel(
       ok = pcg_grid_reduce<2>(B, bar++, part0, part1, rz, rr, gth);
     }
     if (!ok) break;
-    gather_rest(it);   // (every z is there: each workgroup stored its z before its slot)
+    if (!paired || nc > 2 * kGatherPoses * kPcgPersistThreads) {   // (workgroup-uniform)
+      gather_rest(it);   // (every z is there: each workgroup stored its z before its slot)
+      __syncthreads();   // (zc is read across threads below)
+    }
     stamp(it, 1);
     if (probe && it == 11 && tid == 0) probe[512 + 4 * wg + 3] = (long long)wall_clock64();
     if (it == 0) rr0 = rr;
@@ -579,9 +609,14 @@ __global__ __launch_bounds__(kPcgPersistThreads) void pcg_persistent_kernel(
     double pq = 0.0;
     {
       auto row_tail = [&](int br, int e_from, double& a0, double& a1, double& a2) {
-        for (int e = e_from; e < row_ptr[br + 1]; e += kRowLanes) {
-          const double* Bv = val + (size_t)e * 9;
-          const double* pv = pc + 3 * lcol[e];
+        const int e_end = row_ptr[br + 1];
+        if (e_from >= e_end) return;
+        const int ts = tail_start(br), o = toff[br - r0];
+        for (int e = e_from; e < e_end; e += kRowLanes) {
+          const int slot = o + (e - ts);
+          const bool in_lds = slot < kTailCap;
+          const double* Bv = in_lds ? tb + 9 * slot : val + (size_t)e * 9;
+          const double* pv = pc + (in_lds ? tl[slot] : 3 * lcol[e]);
           const double p0 = pv[0], p1 = pv[1], p2 = pv[2];
           a0 += Bv[0] * p0 + Bv[1] * p1 + Bv[2] * p2;
           a1 += Bv[3] * p0 + Bv[4] * p1 + Bv[5] * p2;
@@ -644,7 +679,7 @@ __global__ __launch_bounds__(kPcgPersistThreads) void pcg_persistent_kernel(
       rz_p = sr[tid] * zv; rr_p = sr[tid] * sr[tid];
     }
     part0 = block_sum_512(rz_p, sred);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the z stores have left — under the first sum; no fence: its cache write-back / invalidate would evict the matrix)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the z stores have left — under the first sum; no fence: its cache write-back / invalidate would evict what the L2 holds)
     part1 = block_sum_512(rr_p, sred);                 // (its barriers order every thread's drain before the slot store)
     stamp(it, 5);
     if (probe && it == 10 && tid == 0) probe[512 + 4 * wg + 2] = (long long)wall_clock64();
@@ -656,7 +691,9 @@ __global__ __launch_bounds__(kPcgPersistThreads) void pcg_persistent_kernel(
   }
 }
 
-size_t pcg_persistent_lds(int max_cols) { return sizeof(double) * (5 * (size_t)kPcgPersistMaxRows + 8 + 2 * 256 + 4 + 6 * (size_t)max_cols); }
+size_t pcg_persistent_lds(int max_cols) {
+  return sizeof(double) * (5 * (size_t)kPcgPersistMaxRows + 8 + 2 * 256 + 4 + 6 * (size_t)max_cols + 9 * (size_t)kTailCap) + sizeof(int) * ((size_t)kTailCap + kPcgPersistMaxRows / 3 + 2);
+}
 size_t pcg_persistent_lds_limit() { return 150 * 1024; }
 int pcg_persistent_max_rows() { return kPcgPersistMaxRows; }
 size_t pcg_persistent_z_words(int nbr) { return 2 * 6 * (size_t)((nbr + 1) / 2); }
