@@ -617,7 +617,7 @@ int finalize(bsgpu_ctx* c) {
       c->d_bs_grp_nitems = c->upload(c->plan.bs_grp_nitems); c->d_bs_items4 = c->upload(c->plan.bs_items4);
       c->d_bs_tile_updated = c->upload(c->plan.bs_tile_updated);
       c->d_bs_order = c->upload(c->plan.bs_order);
-      c->d_bs_sync = c->upload(std::vector<int>(2 + c->plan.bs_grp_nchains.size() + c->plan.bs_items4.size() / 4 + 8, 0));
+      c->d_bs_sync = c->upload(std::vector<int>(16 * (2 + c->plan.bs_grp_nchains.size() + c->plan.bs_items4.size() / 4 + 8), 0));   // (words a 64-byte line apart)
       c->d_Winv = c->alloc<double>((size_t)std::max(1, T) * 4096);
       if (c->d_Winv) HIPCHK(c, hipMemset(c->d_Winv, 0, sizeof(double) * (size_t)std::max(1, T) * 4096));   // (the blocks above the diagonal stay zero)
     }

@@ -71,7 +71,7 @@ struct DensePlan {
   std::vector<int> bs_desc;
   // fused single-launch factorisation (k_chol.hip chol_fused_kernel)
   std::vector<FusedTask> ftasks;
-  int fused_sync_words = 0;   // ints of device scratch: [queue head | abort | exited workgroups | pad | potrf_done (T+1) | update counts (T+1)^2]
+  int fused_sync_words = 0;   // ints of device scratch: ([queue head | abort | exited workgroups | potrf_done (T+1) | update counts (T+1)^2]) x 16
   double fused_flops = 0.0;   // FP64 flops of the planned factorisation (trsm + rank-64 updates + potrf of every touched tile), for the MFMA roofline
   // solve offsets
   inline int spos(int j) const { return perm[j >> 6] * 64 + (j & 63); }
@@ -286,7 +286,7 @@ struct DensePlan {
           ftasks.push_back(f);
         }
       }
-      fused_sync_words = 4 + N + N * N;
+      fused_sync_words = 16 * (3 + N + N * N);   // (every word a 64-byte line apart: k_chol.hip fused_sync_stride)
     }
     // ---- back-substitution plan
     panel_of_tile.assign(T, 0);

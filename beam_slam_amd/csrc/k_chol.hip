@@ -548,11 +548,11 @@ BSG_DEV bool wait_count(const int* p, int want, int* abort_w, long long deadline
 }
 // one WAVE: wait until every flag in [lo, hi) is set (each written once, by a different workgroup: a counter word that 18-25 workgroups
 // on eight XCDs add to costs its waiter ~2.7 us after the last add, a flag per writer ~1); false on abort / time-out (wave-uniform)
-BSG_DEV bool wait_flags(const int* flags, int lo, int hi, int* abort_w, long long deadline) {
+BSG_DEV bool wait_flags(const int* flags, int lo, int hi, int* abort_w, long long deadline, int stride = 1) {
   const int lane = threadIdx.x & 63;
   for (;;) {
     int ok = 1;
-    for (int i = lo + lane; i < hi; i += 64) ok &= (ld_flag(flags + i) != 0) ? 1 : 0;
+    for (int i = lo + lane; i < hi; i += 64) ok &= (ld_flag(flags + (size_t)i * stride) != 0) ? 1 : 0;
     if (__all(ok)) return true;
     int stop = 0;
     if (lane == 0) {
@@ -655,6 +655,8 @@ struct FusedCtx {
   const int* nreal;
   int ld, n_vinv_tiles;
   int *abort_w, *potrf_done, *upd;
+  int fs;   // ints between two words of the sync area (a cache line apart: words of one line that different workgroups write or add to are
+            // serialised at the memory side — measured on the PCG slots, k_pcg.hip — and the queue head / exit counter take ~2 000 atomics)
   long long deadline;
   long long* probe_ts;
   volatile int* trace;
@@ -675,6 +677,7 @@ BSG_DEV bool chol_fused_task(const FusedCtx& C, int t, double* smem, long long t
   const int* const nreal = uniform_ptr(C.nreal); const FusedTask* const tasks = uniform_ptr(C.tasks);
   const int ld = __builtin_amdgcn_readfirstlane(C.ld);
   int* const abort_w = uniform_ptr(C.abort_w); int* const potrf_done = uniform_ptr(C.potrf_done); int* const upd = uniform_ptr(C.upd);
+  const int fs = __builtin_amdgcn_readfirstlane(C.fs);
   const long long deadline = uniform_i64(C.deadline);
   long long* const probe_ts = uniform_ptr(C.probe_ts); volatile int* const trace = uniform_ptr(C.trace);
   double* const Winv = uniform_ptr(C.Winv);
@@ -728,7 +731,7 @@ BSG_DEV bool chol_fused_task(const FusedCtx& C, int t, double* smem, long long t
       write_factor_sc1<NT>(rLp, rV, ld, k, sXj, sV, sInvD, tid);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tid == 0) __hip_atomic_store(&potrf_done[k], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) __hip_atomic_store(&potrf_done[k * fs], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       stamp(6);
       // (nobody waits for this: the tile's full inverse, for the back-substitution)
       if (Winv && k < T) publish_tile_inverse<NT>(sXj, sV, sXi, Winv + (size_t)k * NB * NB, tid);
@@ -745,12 +748,12 @@ BSG_DEV bool chol_fused_task(const FusedCtx& C, int t, double* smem, long long t
     // workgroup waits for the factor, and only L_kk and its block inverses are requested after it (measured in one box, three runs
     // each way: 289 -> 277 us per factorisation).
     if (tid == 0) {
-      bool ok = wait_count(&upd[ti * N + k], tk.tot_i, abort_w, deadline);
-      if (!diag) ok = ok && wait_count(&upd[tj * N + k], tk.tot_j, abort_w, deadline);
+      bool ok = wait_count(&upd[(ti * N + k) * fs], tk.tot_i, abort_w, deadline);
+      if (!diag) ok = ok && wait_count(&upd[(tj * N + k) * fs], tk.tot_j, abort_w, deadline);
       s_ctl[1] = ok ? 1 : 0;
       // ... and the C tile, if it is already this task's turn on it (on the critical path it is: the tile's earlier updaters are
       // panels that finished long ago): its values wait in registers through the solves, and the product accumulates onto them
-      s_ctl[3] = (do_update && (tk.need_c == 0 || ld_flag(&upd[ti * N + tj]) >= tk.need_c)) ? 1 : 0;
+      s_ctl[3] = (do_update && (tk.need_c == 0 || ld_flag(&upd[(ti * N + tj) * fs]) >= tk.need_c)) ? 1 : 0;
     }
     __syncthreads();
     const bool c_pre = __builtin_amdgcn_readfirstlane(s_ctl[3]) != 0;
@@ -772,7 +775,7 @@ BSG_DEV bool chol_fused_task(const FusedCtx& C, int t, double* smem, long long t
       }
     }
     __syncthreads();   // (s_ctl[1] is rewritten below)
-    if (tid == 0) s_ctl[1] = (s_ctl[1] != 0 && wait_count(&potrf_done[k], 1, abort_w, deadline)) ? 1 : 0;
+    if (tid == 0) s_ctl[1] = (s_ctl[1] != 0 && wait_count(&potrf_done[k * fs], 1, abort_w, deadline)) ? 1 : 0;
     __syncthreads();
     if (__builtin_amdgcn_readfirstlane(s_ctl[1]) == 0) { ok_all = false; }
     else {
@@ -823,7 +826,7 @@ BSG_DEV bool chol_fused_task(const FusedCtx& C, int t, double* smem, long long t
       } else {
       if (tk.need_c == 0) c_early = true;
       else {
-        if (tid == 0) s_ctl[3] = (ld_flag(&upd[ti * N + tj]) >= tk.need_c) ? 1 : 0;
+        if (tid == 0) s_ctl[3] = (ld_flag(&upd[(ti * N + tj) * fs]) >= tk.need_c) ? 1 : 0;
         __syncthreads();
         c_early = __builtin_amdgcn_readfirstlane(s_ctl[3]) != 0;
       }
@@ -844,7 +847,7 @@ BSG_DEV bool chol_fused_task(const FusedCtx& C, int t, double* smem, long long t
     bool turn_ok = true;
     if (do_update && tk.need_c > 0 && !c_early) {
       // this task's turn on the tile: every earlier update of it has been published
-      if (tid == 0) s_ctl[1] = wait_count(&upd[ti * N + tj], tk.need_c, abort_w, deadline) ? 1 : 0;
+      if (tid == 0) s_ctl[1] = wait_count(&upd[(ti * N + tj) * fs], tk.need_c, abort_w, deadline) ? 1 : 0;
       __syncthreads();
       turn_ok = __builtin_amdgcn_readfirstlane(s_ctl[1]) != 0;
     }
@@ -880,8 +883,8 @@ BSG_DEV bool chol_fused_task(const FusedCtx& C, int t, double* smem, long long t
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-      if (do_update) atomicAdd(&upd[ti * N + tj], 1);
-      if (factor_now) __hip_atomic_store(&potrf_done[ti], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (do_update) atomicAdd(&upd[(ti * N + tj) * fs], 1);
+      if (factor_now) __hip_atomic_store(&potrf_done[ti * fs], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     stamp(6);
     if (diag) {
@@ -906,18 +909,18 @@ template <bool PROBE, int NT>
 __global__ __launch_bounds__(NT) void chol_fused_kernel(double* __restrict__ S, double* __restrict__ Lp, int ld,
                                                           const FusedTask* __restrict__ tasks, int n_tasks,
                                                           const int* __restrict__ nreal, double* __restrict__ Vinv, int n_vinv_tiles,
-                                                          double* __restrict__ scal, int* sync, int n_sync_words, double* Winv,
+                                                          double* __restrict__ scal, int* sync, int n_sync_words, double* Winv, int fs,
                                                           long long* probe_ts = nullptr /* PROBE: n_tasks x 8 wall-clock stamps */,
                                                           volatile int* trace = nullptr /* PROBE: per workgroup (checkpoint, task) in host memory */) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   int* s_ctl = reinterpret_cast<int*>(smem + 3 * NB * LDT + 4 * 256 + 4 * 16 * 17 + NB);   // 4 ints behind the tiles (chol_fused_task)
   const int tid = threadIdx.x;
   const int N = ld / NB;
-  int* head = sync; int* abort_w = sync + 1; int* exited = sync + 2;
+  int* head = sync; int* abort_w = sync + fs; int* exited = sync + 2 * fs;   // (layout: [head | abort | exited | potrf_done (N) | update counts (N x N)] x fs ints)
   FusedCtx C;
   C.S = S; C.Lp = Lp; C.Vinv = Vinv; C.scal = scal; C.tasks = tasks; C.nreal = nreal; C.ld = ld; C.n_vinv_tiles = n_vinv_tiles;
   C.Winv = Winv;
-  C.abort_w = abort_w; C.potrf_done = sync + 4; C.upd = sync + 4 + N;
+  C.abort_w = abort_w; C.potrf_done = sync + 3 * fs; C.upd = sync + (3 + N) * fs; C.fs = fs;
   C.deadline = (long long)wall_clock64() + kFusedTimeoutTicks;
   C.probe_ts = probe_ts; C.trace = trace;
   // ONE task per workgroup, taken from a ticket counter: the k-th workgroup to start running gets task k, so the tasks are started in
@@ -938,11 +941,16 @@ __global__ __launch_bounds__(NT) void chol_fused_kernel(double* __restrict__ S, 
   }
   __syncthreads();
   if (__builtin_amdgcn_readfirstlane(s_ctl[2]) != 0) {
-    const int nw = n_sync_words < 0 ? -n_sync_words : n_sync_words;
-    for (int i = tid; i < nw; i += NT) __hip_atomic_store(&sync[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int nw = 3 + N + N * N;
+    for (int i = tid; i < nw; i += NT) __hip_atomic_store(&sync[i * fs], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 constexpr int kFusedThreads = 512;
+// ints between two words of the sync area: 16 = a 64-byte line each (BSGPU_SYNC_STRIDE=1: packed, the first layout)
+int fused_sync_stride() {
+  static const int v = [] { const char* e = getenv("BSGPU_SYNC_STRIDE"); const int x = e ? atoi(e) : 16; return (x >= 1 && x <= 16) ? x : 16; }();
+  return v;
+}
 constexpr size_t kFusedLds = sizeof(double) * (3 * NB * LDT + 4 * 256 + 4 * 16 * 17 + 64) + 16;
 
 void launch_chol_fused(hipStream_t s, double* S, double* Lp, int ld, const FusedTask* tasks_dev, int n_tasks, const int* nreal_dev,
@@ -974,10 +982,11 @@ void launch_chol_fused(hipStream_t s, double* S, double* Lp, int ld, const Fused
           (void)hipMemcpyAsync(h.data(), w_sync, sizeof(int) * w_words, hipMemcpyDeviceToHost, ws);
           (void)hipStreamSynchronize(ws);
           const int N = w_ld / 64;
-          fprintf(stderr, "[chol watch] head %d abort %d exited %d | potrf_done:", h[0], h[1], h[2]);
-          for (int i = 0; i < N; ++i) fprintf(stderr, " %d", h[4 + i]);
+          const int fs = fused_sync_stride();
+          fprintf(stderr, "[chol watch] head %d abort %d exited %d | potrf_done:", h[0], h[fs], h[2 * fs]);
+          for (int i = 0; i < N; ++i) fprintf(stderr, " %d", h[(3 + i) * fs]);
           fprintf(stderr, " | upd:");
-          for (int i = 0; i < N; ++i) for (int j = 0; j <= i; ++j) if (h[4 + N + i * N + j]) fprintf(stderr, " (%d,%d)=%d", i, j, h[4 + N + i * N + j]);
+          for (int i = 0; i < N; ++i) for (int j = 0; j <= i; ++j) if (h[(3 + N + i * N + j) * fs]) fprintf(stderr, " (%d,%d)=%d", i, j, h[(3 + N + i * N + j) * fs]);
           fprintf(stderr, "\n");
         }
       }).detach();
@@ -1005,7 +1014,7 @@ void launch_chol_fused(hipStream_t s, double* S, double* Lp, int ld, const Fused
     for (int i = 0; i < 2048; ++i) trace[i] = -1;
     fprintf(stderr, "[chol trace] launch: %d tasks, grid %d, ld %d\n", n_tasks, grid, ld);
     hipLaunchKernelGGL((chol_fused_kernel<false, kFusedThreads>), dim3(grid), dim3(kFusedThreads), kFusedLds, s, S, Lp, ld, tasks_dev, n_tasks, nreal_dev, Vinv, ld / NB - 1,
-                       scal, sync_dev, n_sync_words, Winv, ts_dummy, trace);
+                       scal, sync_dev, n_sync_words, Winv, fused_sync_stride(), ts_dummy, trace);
     return;
   }
   if (probe_file && ++probe_calls == 20) {
@@ -1015,7 +1024,7 @@ void launch_chol_fused(hipStream_t s, double* S, double* Lp, int ld, const Fused
     if (hipMalloc((void**)&ts, sizeof(long long) * h.size()) == hipSuccess) {
       (void)hipMemset(ts, 0, sizeof(long long) * h.size());
       hipLaunchKernelGGL((chol_fused_kernel<true, kFusedThreads>), dim3(grid), dim3(kFusedThreads), kFusedLds, s, S, Lp, ld, tasks_dev, n_tasks, nreal_dev, Vinv, ld / NB - 1,
-                         scal, sync_dev, n_sync_words, Winv, ts);
+                         scal, sync_dev, n_sync_words, Winv, fused_sync_stride(), ts);
       (void)hipStreamSynchronize(s);
       (void)hipMemcpy(h.data(), ts, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
       (void)hipMemcpy(ht.data(), tasks_dev, sizeof(FusedTask) * ht.size(), hipMemcpyDeviceToHost);
@@ -1033,7 +1042,7 @@ void launch_chol_fused(hipStream_t s, double* S, double* Lp, int ld, const Fused
     }
   }
   hipLaunchKernelGGL((chol_fused_kernel<false, kFusedThreads>), dim3(grid), dim3(kFusedThreads), kFusedLds, s, S, Lp, ld, tasks_dev, n_tasks, nreal_dev, Vinv, ld / NB - 1, scal,
-                     sync_dev, n_sync_words, Winv, nullptr);
+                     sync_dev, n_sync_words, Winv, fused_sync_stride(), nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1067,7 +1076,7 @@ struct BsPanelRegs {
 struct BsFused {
   int* abort_w;            // sticky failure flag
   const int* wait_flags;   // null: nothing to wait for (the root group); else the walk starts when every flag in [wait_lo, wait_hi) is set
-  int wait_lo, wait_hi;
+  int wait_lo, wait_hi, flag_stride;
   int* done_word;          // bumped once the chain's y is out
   const int* tile_updated; // per tile: an earlier phase has written y there (else the start value is y_init)
   long long deadline;
@@ -1245,7 +1254,7 @@ BSG_DEV void bs_chain_walk(const double* Lp, const double* Vinv /* USE_W: the ti
     stamp(1);
     int* s_ok = reinterpret_cast<int*>(s_rows + (size_t)max_len * kBsMaxRows);
     if (tid < 64) {   // (the first wave polls, a flag per lane)
-      const bool ok = !F.wait_flags || wait_flags(F.wait_flags, F.wait_lo, F.wait_hi, F.abort_w, F.deadline);
+      const bool ok = !F.wait_flags || wait_flags(F.wait_flags, F.wait_lo, F.wait_hi, F.abort_w, F.deadline, F.flag_stride);
       if (tid == 0) *s_ok = ok ? 1 : 0;
     }
     __syncthreads();
@@ -1306,7 +1315,8 @@ __global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double
 // y travels between workgroups with write-through stores and loads that pass the CU's caches (as the factor does in
 // chol_fused_kernel); waits are bounded (abort flag + deadline -> SC_CHOL_FAIL = 2); the last workgroup out clears the counters.
 // Seven launches of 13 + 5 us each become one: the prologues overlap and a hand-over costs ~2 us instead of a launch boundary.
-// sync: [0] abort, [1] exited, [2 .. 2+G) done_chain (counters: at most eight writers), [2+G .. 2+G+n_items) one flag per update item
+// sync (words a cache line apart): [0] abort, [1] exited, [2 .. 2+G) done_chain (counters: at most eight writers), [2+G .. 2+G+n_items) one flag per
+// update item, then the ticket
 // ---------------------------------------------------------------------------------------------------
 template <int CH, bool DEEP>
 __global__ __launch_bounds__(1024) void chol_backsolve_fused_kernel(const double* Lp, const double* Winv, int ld, const int* __restrict__ bs_desc,
@@ -1317,15 +1327,16 @@ __global__ __launch_bounds__(1024) void chol_backsolve_fused_kernel(const double
                                                                     const int* __restrict__ upd_rows, const int* __restrict__ tile_updated,
                                                                     double* y, int npad, int max_len, const double* __restrict__ y_init,
                                                                     const int* __restrict__ iperm, int n_pose, double* __restrict__ y_tan,
-                                                                    double* __restrict__ delta, int* sync, double* __restrict__ scal, long long* ts, const int* __restrict__ order) {
+                                                                    double* __restrict__ delta, int* sync, double* __restrict__ scal, long long* ts, const int* __restrict__ order, int fs) {
   const int tid = threadIdx.x;
-  int* abort_w = sync; int* exited = sync + 1; int* done_chain = sync + 2; int* item_flag = sync + 2 + G;
+  // (every word of the sync area `fs` ints — a cache line — apart: see chol_fused_kernel)
+  int* abort_w = sync; int* exited = sync + fs; int* done_chain = sync + 2 * fs; int* item_flag = sync + (size_t)(2 + G) * fs;
   const int n_items_total = (int)gridDim.x - n_chains;
   // roles are handed out by a ticket in dependency order (the k-th workgroup to START gets role order[k]): whoever a workgroup waits
   // for holds an earlier ticket and is therefore running — no dead-lock even when the grid is not resident at once (several
   // contexts sharing the GPU), as in chol_fused_kernel
   __shared__ int s_role;
-  if (tid == 0) s_role = order[atomicAdd(sync + 2 + G + n_items_total, 1)];
+  if (tid == 0) s_role = order[atomicAdd(sync + (size_t)(2 + G + n_items_total) * fs, 1)];
   __syncthreads();
   const int bid = __builtin_amdgcn_readfirstlane(s_role);
   if (ts && tid == 0) ts[(size_t)bid * 16] = wall_clock64();
@@ -1336,9 +1347,9 @@ __global__ __launch_bounds__(1024) void chol_backsolve_fused_kernel(const double
     F.abort_w = abort_w; F.deadline = deadline; F.tile_updated = tile_updated;
     int lo = 0;
     for (int q = 0; q + 1 < g; ++q) lo += grp_nitems[q];
-    F.wait_flags = g > 0 ? item_flag : nullptr;
+    F.wait_flags = g > 0 ? item_flag : nullptr; F.flag_stride = fs;
     F.wait_lo = lo; F.wait_hi = g > 0 ? lo + grp_nitems[g - 1] : 0;
-    F.done_word = done_chain + g; F.ts = ts; F.ts_row = bid;
+    F.done_word = done_chain + (size_t)g * fs; F.ts = ts; F.ts_row = bid;
     bs_chain_walk<true, CH, DEEP, true, true>(Lp, Winv, ld, bs_desc, chain_begin[ch], chain_end[ch], rows_flat, y, npad, max_len, y_init, iperm, n_pose,
                                         y_tan, delta, F);
   } else {
@@ -1360,7 +1371,7 @@ __global__ __launch_bounds__(1024) void chol_backsolve_fused_kernel(const double
       for (int i = 0; i < 4; ++i) l[u][i] = ok ? Lp[(size_t)(r0[u] + i) * ld + c0 + c] : 0.0;
     }
     if (ts && tid == 0) ts[(size_t)bid * 16 + 1] = wall_clock64();
-    if (tid == 0) *s_ok = wait_count(done_chain + phase, grp_nchains[phase], abort_w, deadline) ? 1 : 0;
+    if (tid == 0) *s_ok = wait_count(done_chain + (size_t)phase * fs, grp_nchains[phase], abort_w, deadline) ? 1 : 0;
     __syncthreads();
     if (ts && tid == 0) ts[(size_t)bid * 16 + 2] = wall_clock64();
     const bool ok_turn = __builtin_amdgcn_readfirstlane(*s_ok) != 0;
@@ -1391,7 +1402,7 @@ __global__ __launch_bounds__(1024) void chol_backsolve_fused_kernel(const double
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tid == 0) __hip_atomic_store(item_flag + (bid - n_chains), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) __hip_atomic_store(item_flag + (size_t)(bid - n_chains) * fs, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (ts && tid == 0) ts[(size_t)bid * 16 + 12] = wall_clock64();
     }
   }
@@ -1403,7 +1414,7 @@ __global__ __launch_bounds__(1024) void chol_backsolve_fused_kernel(const double
     s_last = (atomicAdd(exited, 1) == (int)gridDim.x - 1) ? 1 : 0;
   }
   __syncthreads();
-  if (s_last) for (int i = tid; i < 2 + G + n_items_total + 1; i += 1024) __hip_atomic_store(&sync[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (s_last) for (int i = tid; i < 2 + G + n_items_total + 1; i += 1024) __hip_atomic_store(&sync[(size_t)i * fs], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // false: not launched (the grid would not be resident at once, or y does not fit LDS) — the caller takes the launch-per-level path
 bool launch_chol_backsolve_fused(hipStream_t s, const double* Lp, const double* Winv, int ld, const int* bs_desc_dev, const int* chain_begin_dev,
@@ -1434,11 +1445,11 @@ bool launch_chol_backsolve_fused(hipStream_t s, const double* Lp, const double* 
   if (deep)
     hipLaunchKernelGGL((chol_backsolve_fused_kernel<kBsChunkDeep, true>), dim3(n_chains + n_items), dim3(1024), lds, s, Lp, Winv, ld, bs_desc_dev,
                        chain_begin_dev, chain_end_dev, rows_flat_dev, n_chains, chain_group_dev, grp_nchains_dev, grp_nitems_dev, G, items_dev,
-                       upd_rows_dev, tile_updated_dev, y, npad, max_chain_len, y_init, iperm_dev, n_pose, y_tan, delta, sync_dev, scal, ts, order_dev);
+                       upd_rows_dev, tile_updated_dev, y, npad, max_chain_len, y_init, iperm_dev, n_pose, y_tan, delta, sync_dev, scal, ts, order_dev, fused_sync_stride());
   else
     hipLaunchKernelGGL((chol_backsolve_fused_kernel<kBsChunk, false>), dim3(n_chains + n_items), dim3(1024), lds, s, Lp, Winv, ld, bs_desc_dev,
                        chain_begin_dev, chain_end_dev, rows_flat_dev, n_chains, chain_group_dev, grp_nchains_dev, grp_nitems_dev, G, items_dev,
-                       upd_rows_dev, tile_updated_dev, y, npad, max_chain_len, y_init, iperm_dev, n_pose, y_tan, delta, sync_dev, scal, ts, order_dev);
+                       upd_rows_dev, tile_updated_dev, y, npad, max_chain_len, y_init, iperm_dev, n_pose, y_tan, delta, sync_dev, scal, ts, order_dev, fused_sync_stride());
   if (ts) {
     std::vector<long long> h((size_t)16 * grid);
     (void)hipStreamSynchronize(s);
