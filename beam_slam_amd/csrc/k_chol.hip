@@ -540,7 +540,10 @@ BSG_DEV bool wait_count(const int* p, int want, int* abort_w, long long deadline
   // (both words are requested together and the wall clock is read every 32nd round: a round of the poll is ONE memory round trip,
   // not three in a row — the waiter sees the counter ~0.5 us sooner)
   for (unsigned it = 0;; ++it) {
-    const int v = ld_flag(p), a = ld_flag(abort_w);
+    // (the abort word is ONE line that every waiting workgroup of the launch would read each round — hundreds of readers on one channel —
+    //  so it is looked at every eighth round, together with the counter: still one round trip)
+    const bool look = (it & 7) == 7;
+    const int v = ld_flag(p), a = look ? ld_flag(abort_w) : 0;
     if (v >= want) return true;
     if (a != 0) return false;
     if ((it & 31) == 31 && (long long)wall_clock64() > deadline) { __hip_atomic_store(abort_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
@@ -550,12 +553,13 @@ BSG_DEV bool wait_count(const int* p, int want, int* abort_w, long long deadline
 // on eight XCDs add to costs its waiter ~2.7 us after the last add, a flag per writer ~1); false on abort / time-out (wave-uniform)
 BSG_DEV bool wait_flags(const int* flags, int lo, int hi, int* abort_w, long long deadline, int stride = 1) {
   const int lane = threadIdx.x & 63;
+  unsigned rounds = 0;
   for (;;) {
     int ok = 1;
     for (int i = lo + lane; i < hi; i += 64) ok &= (ld_flag(flags + (size_t)i * stride) != 0) ? 1 : 0;
     if (__all(ok)) return true;
     int stop = 0;
-    if (lane == 0) {
+    if (lane == 0 && (++rounds & 7) == 0) {
       if (ld_flag(abort_w) != 0) stop = 1;
       else if ((long long)wall_clock64() > deadline) { __hip_atomic_store(abort_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); stop = 1; }
     }
