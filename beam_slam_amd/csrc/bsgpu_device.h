@@ -163,6 +163,45 @@ BSG_DEV double block_sum_256(double v, double* smem /* >= 4 doubles */) {
   return t;
 }
 
+// assembly of ONE factor of a pose-only group into the dense reduced system by the calling workgroup (`nthr` threads): J staged in LDS
+// (sJ >= 15 * 30 doubles, sr >= 15, st >= 10 ints), lanes stride over the (column a, column b) pairs; FP64 atomics into S, the rhs row,
+// grad and hdiag.  `unit` = workgroup index over the set (SmallGroupSet::first).  Shared by small_assemble_kernel (a launch of its own)
+// and pairs_kernel (whose extra workgroups do this work underneath the camera pairs: one launch less on the dependent path).
+BSG_DEV void small_assemble_unit(const SmallGroupSet& set, int unit, int lane, int nthr, double* sJ, double* sr, int* st, double* __restrict__ S, int ld,
+                                 int rhs_row, double* __restrict__ grad, double* __restrict__ hdiag, const int* __restrict__ perm) {
+  if (unit >= set.first[set.n]) return;   // (padding of the caller's grid)
+  int gi = 0;
+  while (gi + 1 < set.n && unit >= set.first[gi + 1]) ++gi;
+  const SmallGroup& g = set.g[gi];
+  const int f = unit - set.first[gi];
+  if (!g.active[f]) return;
+  const int m = g.m, tw = 3 * g.nv;
+  const double* J = g.J + (size_t)f * m * tw;
+  for (int i = lane; i < m * tw; i += nthr) sJ[i] = J[i];
+  if (lane < m) sr[lane] = g.r[(size_t)f * m + lane];
+  if (lane < g.nv) st[lane] = g.toff[(size_t)f * g.nv + lane];
+  __syncthreads();
+  const int wcut = 3 * (g.nv - 1) + g.w_last;   // columns >= wcut are the padding of a narrow last slot
+  for (int p = lane; p < tw * tw; p += nthr) {   // (an IMU factor has 900 column pairs)
+    const int a = p / tw, b = p % tw;
+    const int ta = st[a / 3], tb = st[b / 3];
+    if (ta < 0 || tb < 0 || a >= wcut || b >= wcut) continue;
+    double acc = 0.0;
+    for (int k = 0; k < m; ++k) acc += sJ[k * tw + a] * sJ[k * tw + b];
+    const int ra = ta + a % 3, rb = tb + b % 3;
+    atomicAdd(&S[(size_t)(perm[ra >> 6] * 64 + (ra & 63)) * ld + perm[rb >> 6] * 64 + (rb & 63)], acc);
+  }
+  for (int a = lane; a < wcut; a += nthr) {
+    const int ta = st[a / 3];
+    if (ta < 0) continue;
+    double gs = 0.0, hs = 0.0;
+    for (int k = 0; k < m; ++k) { const double j = sJ[k * tw + a]; gs += j * sr[k]; hs += j * j; }
+    atomicAdd(&S[(size_t)rhs_row * ld + perm[(ta + a % 3) >> 6] * 64 + ((ta + a % 3) & 63)], gs);
+    atomicAdd(&grad[ta + a % 3], gs);
+    atomicAdd(&hdiag[ta + a % 3], hs);
+  }
+}
+
 // model cost change term of pose-only groups, one lane per residual row: part[unit] = sum over the unit's 128 rows of
 // -(J_k d) (r_k + J_k d / 2).  `unit` = 128-row unit over the set (SmallGroupSet::first), t128 = thread within the unit, s2 = 2 doubles
 // of LDS private to the unit's two waves.  Shared by small_mcc_kernel and backsub_mcc_kernel (which runs the units as extra workgroups).

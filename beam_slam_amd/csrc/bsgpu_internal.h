@@ -153,7 +153,8 @@ void launch_landmark(hipStream_t s, const Visual& v, int n_pose, const double* r
                      int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* scale, double* dcl,
                      double* grad, const ZeroStep* zero = nullptr, double radius_val = 0.0);
 void launch_pairs(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm,
-                  bool grad_only = false);
+                  bool grad_only, const SmallGroupSet* small = nullptr, int n_small_units = 0);
+int small_assemble_first_set(const SmallGroup* groups, int n_groups, SmallGroupSet* set, int* n_taken);
 void launch_small_assemble_set(hipStream_t s, const SmallGroup* groups, int n_groups, double* S, int ld, int rhs_row, double* grad,
                                double* hdiag, const int* perm);
 void launch_small_assemble_seg(hipStream_t s, const SmallGroup* groups_dev, int n_seg, const int* seg_start, const int* seg_ra, const int* seg_rb,

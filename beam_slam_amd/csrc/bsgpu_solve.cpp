@@ -203,9 +203,16 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
   launch_landmark(s, c->vis, c->n_pose, merged ? nullptr : c->d_scal + SC_RADIUS, first ? 1 : 0, new_J ? 1 : 0, o.jacobi_scaling, o.min_lm_diagonal,
                   o.max_lm_diagonal, c->d_scale, c->d_dcl, c->d_grad, merged ? &zs : nullptr, radius);
   phase_mark(c, BSGPU_PHASE_LANDMARK);
-  launch_pairs(s, c->vis, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm, gradient_only);
-  phase_mark(c, BSGPU_PHASE_PAIRS);
-  launch_small_assemble_set(s, c->small_factorwise + 2, kNumInternal - 2, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm);
+  {
+    // (the factor-wise assembled pose-only groups ride in the pair launch when there is one; further groups, or all of them, go by themselves)
+    SmallGroupSet set;
+    int taken = 0, units = 0;
+    if (c->vis.n_seg > 0) units = small_assemble_first_set(c->small_factorwise + 2, kNumInternal - 2, &set, &taken);
+    if (units == 0) taken = 0;
+    launch_pairs(s, c->vis, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm, gradient_only, units > 0 ? &set : nullptr, units);
+    phase_mark(c, BSGPU_PHASE_PAIRS);
+    launch_small_assemble_set(s, c->small_factorwise + 2 + taken, kNumInternal - 2 - taken, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm);
+  }
   launch_small_assemble_seg(s, c->d_small_groups, c->n_sa_seg, c->d_sa_seg_start, c->d_sa_seg_ra, c->d_sa_seg_rb, c->d_sa_contrib, c->d_S, c->npad,
                             c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm);
   for (const auto& mc : c->marg)

@@ -334,12 +334,23 @@ __global__ __launch_bounds__(64) void pairs_kernel(int n_seg, const int* __restr
                                                    const double* __restrict__ CR, const int* __restrict__ cp_tq,
                                                    const int* __restrict__ cp_tp, double* __restrict__ S, int ld,
                                                    int rhs_row, double* __restrict__ grad,
-                                                   double* __restrict__ hdiag, const int* __restrict__ perm, int grad_only) {
+                                                   double* __restrict__ hdiag, const int* __restrict__ perm, int grad_only,
+                                                   int n_pair_blocks, SmallGroupSet small, int n_small_units) {
+  extern __shared__ __attribute__((aligned(16))) double2 slab[];   // [64][6] A_a | [64][6] A_b | [64][4] C_a | [64][3] C_b | 2 x 64 ints
+  if ((int)blockIdx.x < n_small_units) {
+    // the pose-only factors assembled one workgroup per factor (IMU: two or three hundred of them) as extra workgroups of this launch —
+    // the FIRST ones, so that they run underneath the pairs, not after them: independent atomics into the same system, and a launch of
+    // their own cost ~8 us on the dependent path
+    double* sJ = reinterpret_cast<double*>(slab);
+    small_assemble_unit(small, (int)blockIdx.x, threadIdx.x, 64, sJ, sJ + 15 * 30, reinterpret_cast<int*>(sJ + 15 * 30 + 16), S, ld, rhs_row, grad, hdiag, perm);
+    return;
+  }
   // XCD-aware mapping: consecutive workgroup ids go round-robin over the 8 XCDs, each with its own L2.  Segments are
   // ordered by camera pair (ca, cb), and all segments of one ca gather the same J / CR rows, so every XCD takes a
   // CONTIGUOUS range of segments: the rows of a camera are then pulled into one L2 instead of eight.
-  const int per_xcd = gridDim.x >> 3;
-  const int seg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int pb = (int)blockIdx.x - n_small_units;   // (n_small_units is a multiple of 8: the XCD round-robin is unchanged)
+  const int per_xcd = n_pair_blocks >> 3;
+  const int seg = (pb & 7) * per_xcd + (pb >> 3);
   if (seg >= n_seg) return;
   const int lane = threadIdx.x;
   const int ci = seg_ci[seg], cj = seg_cj[seg];
@@ -357,7 +368,6 @@ __global__ __launch_bounds__(64) void pairs_kernel(int n_seg, const int* __restr
   // nothing, halving the occupancy cost 27 %, rows laid out densely — 48 lines per load — gave exactly 3/4 of the time).  Six lanes
   // now fetch the six pieces of one 96-byte row (one or two lines), four / three lanes a C row, into the wave's LDS slab, and every
   // lane reads its entry's rows back from there: ~330 line look-ups per 64 entries instead of 1 216.
-  extern __shared__ __attribute__((aligned(16))) double2 slab[];   // [64][6] A_a | [64][6] A_b | [64][4] C_a | [64][3] C_b | 2 x 64 ints
   double2* sAa = slab; double2* sAb = sAa + 64 * 6; double2* sCa = sAb + 64 * 6; double2* sCb = sCa + 64 * 4;
   int* sfa = reinterpret_cast<int*>(sCb + 64 * 3); int* sfb = sfa + 64;
   // (the entry indices of the NEXT stride are requested while this one is gathered and summed: one round trip less per stride)
@@ -473,10 +483,15 @@ __global__ __launch_bounds__(64) void pairs_kernel(int n_seg, const int* __restr
 
 constexpr size_t kPairsLds = sizeof(double2) * 64 * (6 + 6 + 4 + 3) + sizeof(int) * 128;
 void launch_pairs(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm,
-                  bool grad_only) {
+                  bool grad_only, const SmallGroupSet* small, int n_small_units) {
   if (v.n_seg == 0) return;
-  hipLaunchKernelGGL(pairs_kernel, dim3(8 * ((v.n_seg + 7) / 8)), dim3(64), kPairsLds, s, v.n_seg, v.seg_ci, v.seg_cj, v.seg_start, v.ent_fa,
-                     v.ent_fb, v.J, v.r, v.CR, v.cp_tq, v.cp_tp, S, ld, rhs_row, grad, hdiag, perm, grad_only ? 1 : 0);
+  const int pair_blocks = 8 * ((v.n_seg + 7) / 8);
+  SmallGroupSet none;
+  none.n = 0;
+  const int small_blocks = small ? 8 * ((n_small_units + 7) / 8) : 0;   // (padded: idle workgroups return at once)
+  hipLaunchKernelGGL(pairs_kernel, dim3(pair_blocks + small_blocks), dim3(64), kPairsLds, s, v.n_seg, v.seg_ci, v.seg_cj, v.seg_start, v.ent_fa,
+                     v.ent_fb, v.J, v.r, v.CR, v.cp_tq, v.cp_tp, S, ld, rhs_row, grad, hdiag, perm, grad_only ? 1 : 0, pair_blocks, small ? *small : none,
+                     small_blocks);
 }
 
 // ---------------------------------------------------------------------------------------------------

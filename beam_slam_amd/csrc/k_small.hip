@@ -763,36 +763,7 @@ __global__ __launch_bounds__(256) void small_assemble_kernel(SmallGroupSet set, 
   __shared__ double sJ[15 * 30];
   __shared__ double sr[15];
   __shared__ int st[10];
-  int gi = 0;
-  while (gi + 1 < set.n && (int)blockIdx.x >= set.first[gi + 1]) ++gi;
-  const SmallGroup& g = set.g[gi];
-  const int f = blockIdx.x - set.first[gi], lane = threadIdx.x;
-  if (!g.active[f]) return;
-  const int m = g.m, tw = 3 * g.nv;
-  const double* J = g.J + (size_t)f * m * tw;
-  for (int i = lane; i < m * tw; i += 256) sJ[i] = J[i];
-  if (lane < m) sr[lane] = g.r[(size_t)f * m + lane];
-  if (lane < g.nv) st[lane] = g.toff[(size_t)f * g.nv + lane];
-  __syncthreads();
-  const int wcut = 3 * (g.nv - 1) + g.w_last;   // columns >= wcut are the padding of a narrow last slot
-  for (int p = lane; p < tw * tw; p += 256) {   // (an IMU factor has 900 column pairs: four waves share them)
-    const int a = p / tw, b = p % tw;
-    const int ta = st[a / 3], tb = st[b / 3];
-    if (ta < 0 || tb < 0 || a >= wcut || b >= wcut) continue;
-    double acc = 0.0;
-    for (int k = 0; k < m; ++k) acc += sJ[k * tw + a] * sJ[k * tw + b];
-    const int ra = ta + a % 3, rb = tb + b % 3;
-    atomicAdd(&S[(size_t)(perm[ra >> 6] * 64 + (ra & 63)) * ld + perm[rb >> 6] * 64 + (rb & 63)], acc);
-  }
-  for (int a = lane; a < wcut; a += 256) {
-    const int ta = st[a / 3];
-    if (ta < 0) continue;
-    double gs = 0.0, hs = 0.0;
-    for (int k = 0; k < m; ++k) { const double j = sJ[k * tw + a]; gs += j * sr[k]; hs += j * j; }
-    atomicAdd(&S[(size_t)rhs_row * ld + perm[(ta + a % 3) >> 6] * 64 + ((ta + a % 3) & 63)], gs);
-    atomicAdd(&grad[ta + a % 3], gs);
-    atomicAdd(&hdiag[ta + a % 3], hs);
-  }
+  small_assemble_unit(set, blockIdx.x, threadIdx.x, 256, sJ, sr, st, S, ld, rhs_row, grad, hdiag, perm);
 }
 
 // Assembly by SEGMENTS, for the factor types whose factors pile onto the same 3x3 blocks of J^T J (bsgpu_finalize.cpp decides and
@@ -877,6 +848,20 @@ void launch_small_assemble_seg(hipStream_t s, const SmallGroup* groups_dev, int 
                      rhs_row, grad, hdiag, perm);
 }
 
+// the first (up to kSetMax) non-empty groups as ONE set of one-factor units, for a caller that runs them inside another launch
+// (pairs_kernel); returns the number of units, *n_taken = how many entries of `groups` it consumed
+int small_assemble_first_set(const SmallGroup* groups, int n_groups, SmallGroupSet* set, int* n_taken) {
+  set->n = 0;
+  int blocks = 0, i = 0;
+  for (; i < n_groups && set->n < kSetMax; ++i) {
+    if (!groups[i].n) continue;
+    set->g[set->n] = groups[i]; set->first[set->n] = blocks; set->part[set->n] = nullptr;
+    blocks += groups[i].n; ++set->n;
+  }
+  set->first[set->n] = blocks;
+  *n_taken = i;
+  return blocks;
+}
 void launch_small_assemble_set(hipStream_t s, const SmallGroup* groups, int n_groups, double* S, int ld, int rhs_row, double* grad,
                                double* hdiag, const int* perm) {
   SmallGroupSet set;
