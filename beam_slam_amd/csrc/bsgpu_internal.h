@@ -158,7 +158,8 @@ int small_assemble_first_set(const SmallGroup* groups, int n_groups, SmallGroupS
 void launch_small_assemble_set(hipStream_t s, const SmallGroup* groups, int n_groups, double* S, int ld, int rhs_row, double* grad,
                                double* hdiag, const int* perm);
 void launch_small_assemble_seg(hipStream_t s, const SmallGroup* groups_dev, int n_seg, const int* seg_start, const int* seg_ra, const int* seg_rb,
-                               const int2* contrib, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm);
+                               const int2* contrib, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm,
+                               const SmallGroupSet* fw = nullptr, int n_fw_units = 0);
 void launch_pose_diag(hipStream_t s, int n_pose, double* S, int ld, const double* hdiag, const double* radius_ptr,
                       int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* scale,
                       double* dcl, int npad, const int* iperm);

@@ -780,9 +780,19 @@ __global__ __launch_bounds__(256) void small_assemble_seg_kernel(const SmallGrou
                                                                 const int* __restrict__ seg_start, const int* __restrict__ seg_ra,
                                                                 const int* __restrict__ seg_rb, const int2* __restrict__ contrib,
                                                                 double* __restrict__ S, int ld, int rhs_row, double* __restrict__ grad,
-                                                                double* __restrict__ hdiag, const int* __restrict__ perm) {
+                                                                double* __restrict__ hdiag, const int* __restrict__ perm, SmallGroupSet fw,
+                                                                int n_fw_units) {
+  if ((int)blockIdx.x < n_fw_units) {
+    // the groups assembled one workgroup per factor (the IMU factors of a lidar-inertial window), as the first workgroups of this launch
+    // instead of a launch of their own (as in pairs_kernel)
+    __shared__ double sJ[15 * 30];
+    __shared__ double sr[15];
+    __shared__ int st[10];
+    small_assemble_unit(fw, (int)blockIdx.x, threadIdx.x, 256, sJ, sr, st, S, ld, rhs_row, grad, hdiag, perm);
+    return;
+  }
   // sixteen lanes per segment (a segment of C3 has ~8 contributions, an IMU factor's blocks one or two: a whole wave per segment idles)
-  const int seg = blockIdx.x * 16 + (threadIdx.x >> 4), lane = threadIdx.x & 15;
+  const int seg = ((int)blockIdx.x - n_fw_units) * 16 + (threadIdx.x >> 4), lane = threadIdx.x & 15;
   if (seg >= n_seg) return;
   const int beg = seg_start[seg], end = seg_start[seg + 1];
   const int ra = seg_ra[seg], rb = seg_rb[seg];
@@ -842,10 +852,14 @@ __global__ __launch_bounds__(256) void small_assemble_seg_kernel(const SmallGrou
   }
 }
 void launch_small_assemble_seg(hipStream_t s, const SmallGroup* groups_dev, int n_seg, const int* seg_start, const int* seg_ra, const int* seg_rb,
-                               const int2* contrib, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm) {
+                               const int2* contrib, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm,
+                               const SmallGroupSet* fw, int n_fw_units) {
   if (n_seg <= 0) return;
-  hipLaunchKernelGGL(small_assemble_seg_kernel, dim3((n_seg + 15) / 16), dim3(256), 0, s, groups_dev, n_seg, seg_start, seg_ra, seg_rb, contrib, S, ld,
-                     rhs_row, grad, hdiag, perm);
+  SmallGroupSet none;
+  none.n = 0; none.first[0] = 0;
+  const int extra = fw ? n_fw_units : 0;
+  hipLaunchKernelGGL(small_assemble_seg_kernel, dim3((n_seg + 15) / 16 + extra), dim3(256), 0, s, groups_dev, n_seg, seg_start, seg_ra, seg_rb, contrib, S, ld,
+                     rhs_row, grad, hdiag, perm, fw ? *fw : none, extra);
 }
 
 // the first (up to kSetMax) non-empty groups as ONE set of one-factor units, for a caller that runs them inside another launch
