@@ -297,7 +297,10 @@ int bsgpu_sync_factors_indirect(bsgpu_ctx* c, int32_t type, int32_t n, const int
   const int rc = invalidate_keep_values(c);
   if (rc != BSGPU_OK) return rc;
   // ---- device copy (what finalize() flattens from when the window is large enough for the device path)
-  if (n < kDeviceFlattenMin) { m.dev_valid = false; return BSGPU_OK; }
+  {
+    const char* fe = getenv("BSGPU_FLATTEN");   // (forced device flattening — the tests — keeps the resident copy of a small window too)
+    if (n < kDeviceFlattenMin && !(fe && !strcmp(fe, "device") && n > 0)) { m.dev_valid = false; return BSGPU_OK; }
+  }
   HIPCHK(c, hipSetDevice(c->device));
   if ((size_t)n > m.d_cap) {
     const size_t cap = (size_t)n + (size_t)n / 4 + 4096;

@@ -199,6 +199,29 @@ def test_sync_equals_fresh_description_resident_table(gpu_solver_cls, monkeypatc
 
 
 @pytest.mark.gpu
+def test_resident_table_flattens_to_the_same_tables(gpu_solver_cls, monkeypatch):
+    """the tables finalize() builds from the patched device-resident table are those of a from-scratch flattening of the same rows:
+    residuals, the whole Jacobian and the screening errors bit for bit, cycle after cycle (small window, device flattening forced)"""
+    monkeypatch.setenv("BSGPU_FLATTEN", "device")
+    monkeypatch.setenv("BSGPU_SYNC_CHECK", "1")
+    w = SlidingWindow(np.random.default_rng(17), 7, 30, 40)
+    a = gpu_solver_cls(0)
+    for cyc in range(5):
+        if cyc:
+            w.drop_oldest(free_landmarks=cyc % 2 == 0)
+            w.add_keyframe()
+        blocks = w.blocks()
+        b = gpu_solver_cls(0)
+        _describe(w, a, blocks, True, cyc == 0)
+        _describe(w, b, blocks, False, False)
+        ca, ra, ga, Ja = a.evaluate(jacobian=True)
+        cb, rb, gb, Jb = b.evaluate(jacobian=True)
+        assert ca == cb and np.array_equal(ra, rb) and np.array_equal(Ja, Jb), cyc
+        n = w.idx.shape[0]
+        assert np.array_equal(a.reprojection_errors(n), b.reprojection_errors(n)), cyc
+
+
+@pytest.mark.gpu
 def test_sync_rejects_bad_change_lists(gpu_solver_cls, monkeypatch):
     w = SlidingWindow(np.random.default_rng(3), 6, 20, 30)
     g = gpu_solver_cls(0)
