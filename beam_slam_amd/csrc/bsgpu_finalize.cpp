@@ -784,8 +784,10 @@ int build_bsr(bsgpu_ctx* c) {
       PcgPersistDev& P = c->pcg_persist;
       P.G = G; P.max_cols = max_cols; P.paired = paired ? 1 : 0;
       P.wg_row = c->upload(wg_row); P.wg_colptr = c->upload(wg_colptr); P.wg_cols = c->upload(wg_cols); P.lcol = c->upload(lcol);
-      P.slots = c->alloc<unsigned long long>(pcg_persistent_slot_words(G)); P.abort_w = c->alloc<int>(2); P.zg = c->alloc<double>(pcg_persistent_z_words(nbr));
-      if (!P.wg_row || !P.lcol || !P.slots || !P.abort_w || !P.zg) P = PcgPersistDev();
+      const size_t sw = pcg_persistent_slot_words(G), zw = pcg_persistent_z_words(nbr);
+      P.slots = c->alloc<unsigned long long>(sw + zw + 2);
+      if (P.slots) { P.zg = reinterpret_cast<double*>(P.slots + sw); P.abort_w = reinterpret_cast<int*>(P.slots + sw + zw); P.sync_bytes = sizeof(unsigned long long) * (sw + zw + 2); }
+      if (!P.wg_row || !P.lcol || !P.slots) P = PcgPersistDev();
     }
   }
   c->bsr_built = true;

@@ -230,6 +230,7 @@ struct PcgPersistDev {
   unsigned long long* slots = nullptr;
   int* abort_w = nullptr;
   double* zg = nullptr;          // the published z: two sets of 3 nbr entries
+  size_t sync_bytes = 0;         // slots | z sets | abort word: one allocation, emptied (all bits set) by one fill per launch
 };
 size_t pcg_persistent_lds(int max_cols);
 size_t pcg_persistent_lds_limit();

@@ -394,7 +394,7 @@ BSG_DEV bool pcg_grid_reduce(const PcgBarrier& B, int b, double v0, double v1, d
     if (a == kSlotEmpty) a = __hip_atomic_load(cur + (size_t)tid * S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (NV == 2 && c == kSlotEmpty) c = __hip_atomic_load(cur + (size_t)(G + tid) * S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((it & 15) == 15) {
-      if (__hip_atomic_load(B.abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { *flag = 1.0; break; }
+      if (__hip_atomic_load(B.abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1) { *flag = 1.0; break; }   // (1 = raised; the word starts with all bits set, like the slots)
       if ((long long)wall_clock64() > B.deadline) { __hip_atomic_store(B.abort_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *flag = 1.0; break; }
     }
     __builtin_amdgcn_s_sleep(1);
@@ -707,10 +707,9 @@ bool launch_pcg_persistent(hipStream_t s, const PcgPersistDev& P, int nbr, const
     attr_set = true;
   }
   if (lds > pcg_persistent_lds_limit() || P.G < 1 || P.G > 256) return false;
-  if (hipMemsetAsync(zg, 0xff, sizeof(double) * pcg_persistent_z_words(nbr), s) != hipSuccess) { (void)hipGetLastError(); return false; }   // (both z sets empty)
   static const int slot_stride = [] { const char* e = getenv("BSGPU_PCG_SLOT_STRIDE"); const int v = e ? atoi(e) : kPcgSlotStride; return (v >= 1 && v <= kPcgSlotStrideMax) ? v : kPcgSlotStride; }();
-  if (hipMemsetAsync(P.slots, 0xff, sizeof(unsigned long long) * 6 * (size_t)P.G * kPcgSlotStrideMax, s) != hipSuccess) { (void)hipGetLastError(); return false; }
-  if (hipMemsetAsync(P.abort_w, 0, sizeof(int) * 2, s) != hipSuccess) { (void)hipGetLastError(); return false; }
+  // slots, both z sets and the abort word are ONE allocation (bsgpu_finalize.cpp), emptied by one fill: all bits set
+  if (hipMemsetAsync(P.slots, 0xff, P.sync_bytes, s) != hipSuccess) { (void)hipGetLastError(); return false; }
   const long long timeout_ticks = 100000000LL / 5;   // s_memrealtime: 100 MHz; a fifth of a second for the whole solve
   // BSGPU_PCG_PROBE=1: workgroup 0 stamps the phases of its first 64 iterations with the 100 MHz wall clock; printed once
   static const bool want_probe = getenv("BSGPU_PCG_PROBE") != nullptr;
