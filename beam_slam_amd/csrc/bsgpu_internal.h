@@ -268,6 +268,7 @@ void launch_update(hipStream_t s, int nb, const int* blk_xoff, const int* blk_to
                    double* part /* 2 * nblocks_grid */, int* n_part);
 void launch_sum(hipStream_t s, const double* part, int n, double* out, int accumulate);
 void launch_zero(hipStream_t s, double* p, int64_t n);
+void launch_zero4(hipStream_t s, double* p0, int64_t n0, double* p1, int64_t n1, double* p2, int64_t n2, double* p3, int64_t n3);
 void launch_zero_tiles_multi(hipStream_t s, double* S, int ld, const int* tiles_dev, int n_tiles, double* a, int na, double* b, int nb, double* c,
                              int nc, double* radius_slot, double radius);
 void launch_copy(hipStream_t s, const double* src, double* dst, int64_t n, int nzero_after);

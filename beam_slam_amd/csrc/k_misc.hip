@@ -218,6 +218,22 @@ void launch_zero_tiles_multi(hipStream_t s, double* S, int ld, const int* tiles_
   const int grid = std::max(1, std::min(n_tiles, 2048));
   hipLaunchKernelGGL(zero_tiles_multi_kernel, dim3(grid), dim3(256), 0, s, S, ld, tiles_dev, n_tiles, a, na, b, nb, c, nc, radius_slot, radius);
 }
+// up to four arrays cleared in ONE launch (the block-sparse path clears its matrix values, right-hand side, gradient and diagonal per step:
+// four launches of ~5 us each on the dependent path)
+__global__ __launch_bounds__(256) void zero4_kernel(double* __restrict__ p0, int64_t n0, double* __restrict__ p1, int64_t n1, double* __restrict__ p2,
+                                                    int64_t n2, double* __restrict__ p3, int64_t n3) {
+  const int64_t stride = (int64_t)gridDim.x * 256, t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (int64_t i = t; i < n0; i += stride) p0[i] = 0.0;
+  for (int64_t i = t; i < n1; i += stride) p1[i] = 0.0;
+  for (int64_t i = t; i < n2; i += stride) p2[i] = 0.0;
+  for (int64_t i = t; i < n3; i += stride) p3[i] = 0.0;
+}
+void launch_zero4(hipStream_t s, double* p0, int64_t n0, double* p1, int64_t n1, double* p2, int64_t n2, double* p3, int64_t n3) {
+  const int64_t nmax = std::max(std::max(n0, n1), std::max(n2, n3));
+  if (nmax <= 0) return;
+  const int grid = (int)std::min<int64_t>((nmax + 255) / 256, 2048);
+  hipLaunchKernelGGL(zero4_kernel, dim3(grid), dim3(256), 0, s, p0, n0, p1, n1, p2, n2, p3, n3);
+}
 __global__ __launch_bounds__(256) void copy_kernel(const double* __restrict__ src, double* __restrict__ dst, int64_t n, int nzero_after) {
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
