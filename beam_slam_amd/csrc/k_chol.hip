@@ -950,9 +950,9 @@ __global__ __launch_bounds__(NT) void chol_fused_kernel(double* __restrict__ S, 
   }
 }
 constexpr int kFusedThreads = 512;
-// ints between two words of the sync area: 16 = a 64-byte line each (BSGPU_SYNC_STRIDE=1: packed, the first layout)
+// ints between two words of the sync area: 16 = a 64-byte line each (BSGPU_FLAG_STRIDE=1: packed, the first layout)
 int fused_sync_stride() {
-  static const int v = [] { const char* e = getenv("BSGPU_SYNC_STRIDE"); const int x = e ? atoi(e) : 16; return (x >= 1 && x <= 16) ? x : 16; }();
+  static const int v = [] { const char* e = getenv("BSGPU_FLAG_STRIDE"); const int x = e ? atoi(e) : 16; return (x >= 1 && x <= 16) ? x : 16; }();
   return v;
 }
 constexpr size_t kFusedLds = sizeof(double) * (3 * NB * LDT + 4 * 256 + 4 * 16 * 17 + 64) + 16;
