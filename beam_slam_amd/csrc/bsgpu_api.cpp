@@ -183,6 +183,7 @@ int bsgpu_add_factors(bsgpu_ctx* c, int32_t type, int32_t n, const int32_t* idx,
   if (type < 0 || type >= BSGPU_F_NUM_TYPES) return fail(c, BSGPU_ERR_INVALID, "unknown factor type");
   if (n < 0 || (n > 0 && (!idx || !consts))) return fail(c, BSGPU_ERR_INVALID, "add_factors: bad argument");
   const TypeInfo& ti = kTypes[type];
+  if (type == BSGPU_F_REPROJ) { const int rc_m = materialize_mirror(c); if (rc_m != BSGPU_OK) return rc_m; }   // (rows appended to a synced table: the host copy first)
   HostGroup& g = c->groups[type];
   g.idx.insert(g.idx.end(), idx, idx + (size_t)n * ti.nidx);
   g.consts.insert(g.consts.end(), consts, consts + (size_t)n * ti.nconst);
@@ -200,6 +201,7 @@ int bsgpu_add_factors_indirect(bsgpu_ctx* c, int32_t type, int32_t n, const int3
   if (type < 0 || type >= BSGPU_F_NUM_TYPES) return fail(c, BSGPU_ERR_INVALID, "unknown factor type");
   if (n < 0 || n_slots < 0 || (n > 0 && (!slot_idx || !consts || !slot_to_block))) return fail(c, BSGPU_ERR_INVALID, "add_factors_indirect: bad argument");
   const TypeInfo& ti = kTypes[type];
+  if (type == BSGPU_F_REPROJ) { const int rc_m = materialize_mirror(c); if (rc_m != BSGPU_OK) return rc_m; }   // (rows appended to a synced table: the host copy first)
   HostGroup& g = c->groups[type];
   for (int i = 0; i < n; ++i) {
     const int k = loss_kind ? loss_kind[i] : BSGPU_LOSS_TRIVIAL;

@@ -222,6 +222,26 @@ def test_resident_table_flattens_to_the_same_tables(gpu_solver_cls, monkeypatch)
 
 
 @pytest.mark.gpu
+def test_rows_added_after_a_sync_join_the_table(gpu_solver_cls):
+    """add_factors for the synced type in the same description: the mirrored rows and the appended ones are one group"""
+    w = SlidingWindow(np.random.default_rng(23), 6, 25, 30)
+    blocks = w.blocks()
+    vals, off, size, man, const, s2b = blocks
+    n = w.idx.shape[0]
+    head, tail = slice(0, n - 40), slice(n - 40, n)
+    a = gpu_solver_cls(0)
+    a.clear(); a.set_blocks(vals, off, size, man, const); a.set_cameras(w.camera())
+    a.sync_factors_indirect(capi.F_REPROJ, w.idx[head], s2b, w.consts[head], w.loss_kind[head], w.loss_a[head], None)
+    idx_t = w.idx[tail].copy(); idx_t[:, :3] = s2b[idx_t[:, :3]]
+    a.add_factors(capi.F_REPROJ, idx_t, w.consts[tail], w.loss_kind[tail], w.loss_a[tail])
+    b = gpu_solver_cls(0)
+    _describe(w, b, blocks, False, False)
+    ca, ra, _, _ = a.evaluate()
+    cb, rb, _, _ = b.evaluate()
+    assert np.array_equal(ra, rb) and abs(ca - cb) <= 1e-14 * cb
+
+
+@pytest.mark.gpu
 def test_sync_rejects_bad_change_lists(gpu_solver_cls, monkeypatch):
     w = SlidingWindow(np.random.default_rng(3), 6, 20, 30)
     g = gpu_solver_cls(0)
