@@ -709,8 +709,9 @@ int bsgpu_covariance(bsgpu_ctx* c, int32_t ba, int32_t bb, double* out) try {
   if (hipMalloc((void**)&d_out, sizeof(double) * ta * tb) != hipSuccess) { (void)hipFree(d_cols); return fail(c, BSGPU_ERR_DEVICE, "out of device memory"); }
   (void)hipMemcpyAsync(d_cols, cols.data(), sizeof(int) * cols.size(), hipMemcpyHostToDevice, s);
   launch_cov_units(s, c->d_S, c->npad, c->plan.rhs_row, d_cols, (int)cols.size());
-  const DenseDev D{c->d_perm, c->d_nreal, c->d_rows_flat, c->d_panels, c->d_Lp, c->d_Vinv,
-                   c->d_bs_desc, c->d_chain_begin, c->d_chain_end, c->d_tile_sync, c->d_ftasks, c->d_fsync};
+  DenseDev D{c->d_perm, c->d_nreal, c->d_rows_flat, c->d_panels, c->d_Lp, c->d_Vinv,
+             c->d_bs_desc, c->d_chain_begin, c->d_chain_end, c->d_tile_sync, c->d_ftasks, c->d_fsync};
+  D.Winv = c->d_Winv; D.tile_tot = c->d_tile_tot;
   dense_factor(s, c->plan, D, c->d_S, c->d_scal);
   launch_cov_dots(s, c->d_Lp, c->npad, c->plan.rhs_row, c->plan.T * 64, ta, row_b0, tb, d_out);
   (void)hipMemcpyAsync(out, d_out, sizeof(double) * ta * tb, hipMemcpyDeviceToHost, s);
@@ -891,7 +892,8 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
   double *dS = nullptr, *dLp = nullptr, *dV = nullptr, *dy = nullptr, *dscal = nullptr;
   int *dperm = nullptr, *dnreal = nullptr, *drows = nullptr;
   PanelDesc *dpan = nullptr, *dsep = nullptr;
-  int *dpot2 = nullptr, *dcb = nullptr, *dce = nullptr, *dsync = nullptr, *dfsync = nullptr;
+  int *dpot2 = nullptr, *dcb = nullptr, *dce = nullptr, *dsync = nullptr, *dfsync = nullptr, *dtot = nullptr;
+  double* dW = nullptr;
   FusedTask* dft = nullptr;
   const char* ef = getenv("BSGPU_CHOL_FUSED");
   const bool fused = !(ef && atoi(ef) == 0) && !P.ftasks.empty();
@@ -913,7 +915,8 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
        up(P.tile_sync.data(), sizeof(int) * P.tile_sync.size(), (void**)&dsync);
   if (ok && fused) {
     const std::vector<int> zeros((size_t)P.fused_sync_words, 0);
-    ok = up(P.ftasks.data(), sizeof(FusedTask) * P.ftasks.size(), (void**)&dft) && up(zeros.data(), sizeof(int) * zeros.size(), (void**)&dfsync);
+    ok = up(P.ftasks.data(), sizeof(FusedTask) * P.ftasks.size(), (void**)&dft) && up(zeros.data(), sizeof(int) * zeros.size(), (void**)&dfsync) &&
+         up(P.tile_tot.data(), sizeof(int) * P.tile_tot.size(), (void**)&dtot) && hipMalloc((void**)&dW, sizeof(double) * 4096 * std::max(1, T)) == hipSuccess;
   }
   int rc = BSGPU_OK;
   int *dbc = nullptr, *drc = nullptr, *dbu = nullptr, *dbur = nullptr;
@@ -924,6 +927,7 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, s);
     DenseDev D{dperm, dnreal, drows, dpan, dLp, dV, dpot2, dcb, dce, dsync, dft, dfsync};
+    D.Winv = dW; D.tile_tot = dtot;
     if (P.bs_level_sync && !getenv("BSGPU_BACKSOLVE_LEGACY") &&
         up(P.bs_desc_chain.data(), sizeof(int) * P.bs_desc_chain.size(), (void**)&dbc) && up(P.rows_flat_chain.data(), sizeof(int) * P.rows_flat_chain.size(), (void**)&drc) &&
         up(P.bs_upd.data(), sizeof(int) * P.bs_upd.size(), (void**)&dbu) && up(P.bs_upd_rows.data(), sizeof(int) * P.bs_upd_rows.size(), (void**)&dbur)) {
@@ -946,7 +950,7 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
   (void)hipFree(dS); (void)hipFree(dLp); (void)hipFree(dV); (void)hipFree(dy); (void)hipFree(dscal);
   (void)hipFree(dperm); (void)hipFree(dnreal); (void)hipFree(drows); (void)hipFree(dpan);
   (void)hipFree(dsep); (void)hipFree(dpot2); (void)hipFree(dcb); (void)hipFree(dce); (void)hipFree(dsync);
-  (void)hipFree(dft); (void)hipFree(dfsync);
+  (void)hipFree(dft); (void)hipFree(dfsync); (void)hipFree(dtot); (void)hipFree(dW);
   (void)hipFree(dbc); (void)hipFree(drc); (void)hipFree(dbu); (void)hipFree(dbur);
   (void)hipStreamDestroy(s);
   return rc;

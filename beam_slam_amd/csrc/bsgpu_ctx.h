@@ -184,6 +184,7 @@ struct bsgpu_ctx {
   int *d_bs_chain_group = nullptr, *d_bs_grp_nchains = nullptr, *d_bs_grp_nitems = nullptr, *d_bs_items4 = nullptr, *d_bs_tile_updated = nullptr, *d_bs_sync = nullptr, *d_bs_order = nullptr;
   int *d_bs_desc = nullptr, *d_chain_begin = nullptr, *d_chain_end = nullptr, *d_tile_sync = nullptr, *d_touched = nullptr;
   int n_touched = 0;
+  int* d_tile_tot = nullptr;
   FusedTask* d_ftasks = nullptr;   // fused single-launch factorisation: task list and its counters (k_chol.hip chol_fused_kernel)
   int* d_fsync = nullptr;
   double* d_Vinv = nullptr;
@@ -325,6 +326,7 @@ struct DenseDev {
   double* scal = nullptr;
   double* Winv = nullptr;   // per tile: the full inverse of its factor (written by the fused factorisation, read by the single-launch back-substitution)
   const int* bs_order = nullptr;   // ticket -> role of the single-launch back-substitution (DensePlan::bs_order)
+  const int* tile_tot = nullptr;   // fused factorisation: update tasks per tile (DensePlan::tile_tot)
 };
 void dense_factor(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* scal);
 // (iperm / y_tan / delta given: the back-substitution also writes the solution in tangent order and the step -y)

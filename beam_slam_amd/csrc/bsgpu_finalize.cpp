@@ -618,17 +618,17 @@ int finalize(bsgpu_ctx* c) {
       c->d_bs_tile_updated = c->upload(c->plan.bs_tile_updated);
       c->d_bs_order = c->upload(c->plan.bs_order);
       c->d_bs_sync = c->upload(std::vector<int>(16 * (2 + c->plan.bs_grp_nchains.size() + c->plan.bs_items4.size() / 4 + 8), 0));   // (words a 64-byte line apart)
-      c->d_Winv = c->alloc<double>((size_t)std::max(1, T) * 4096);
-      if (c->d_Winv) HIPCHK(c, hipMemset(c->d_Winv, 0, sizeof(double) * (size_t)std::max(1, T) * 4096));   // (the blocks above the diagonal stay zero)
     }
     c->d_tile_sync = c->upload(c->plan.tile_sync);
     {
       // fused single-launch factorisation (default; BSGPU_CHOL_FUSED=0 keeps the launch-per-step path): task list + zeroed counters
       const char* ef = getenv("BSGPU_CHOL_FUSED");
-      c->d_ftasks = nullptr; c->d_fsync = nullptr;
+      c->d_ftasks = nullptr; c->d_fsync = nullptr; c->d_tile_tot = nullptr;
       if (!(ef && atoi(ef) == 0) && !c->plan.ftasks.empty()) {
         c->d_ftasks = c->upload(c->plan.ftasks);
+        c->d_tile_tot = c->upload(c->plan.tile_tot);
         c->d_fsync = c->upload(std::vector<int>((size_t)c->plan.fused_sync_words, 0));
+        c->d_Winv = c->alloc<double>((size_t)std::max(1, T) * 4096);   // (the chains write every entry of a tile's inverse, zeros above its diagonal blocks included)
       }
     }
     c->d_touched = c->upload(c->plan.touched_tiles); c->n_touched = (int)c->plan.touched_tiles.size();

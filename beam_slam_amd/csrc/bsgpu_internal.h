@@ -171,8 +171,8 @@ void launch_grad_norms_pose_diag(hipStream_t s, int nb, const int* blk_xoff, con
                                  double lm_lo, double lm_hi, double* scale, double* dcl, int npad, const int* iperm);
 struct PanelDesc;
 struct FusedTask;
-void launch_chol_fused(hipStream_t s, double* S, double* Lp, int ld, const FusedTask* tasks_dev, int n_tasks, const int* nreal_dev,
-                       double* Vinv, double* scal, int* sync_dev, int n_sync_words, double* Winv = nullptr);
+void launch_chol_fused(hipStream_t s, double* S, double* Lp, int ld, const FusedTask* tasks_dev, int n_tasks, const int* tile_tot_dev, const int* nreal_dev,
+                       double* Vinv, double* scal, int* sync_dev, double* Winv);
 void launch_chol_potrf_tiles(hipStream_t s, double* S, double* Lp, int ld, const int* tiles_dev, int n_tiles, const int* nreal_dev,
                              double* Vinv, double* scal);
 void launch_chol_panel_step(hipStream_t s, double* S, double* Lp, int ld, const PanelDesc* descs_dev, int n_panels, int max_rows,

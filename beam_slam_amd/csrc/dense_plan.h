@@ -29,18 +29,32 @@ struct PanelDesc {  // device-visible
 // One unit of work of the fused (single-launch) factorisation, k_chol.hip chol_fused_kernel: workgroup-sized, pulled from a
 // device-side queue in list order.  The list is a topological order of the tile dependencies (every counter a task waits
 // for is advanced by tasks EARLIER in the list), so a queue that hands tasks out in order cannot deadlock whatever the
-// residency of the grid.
+// residency of the grid.  Two kinds of task:
+//   chain   a run of <= kChainMaxTiles consecutive tiles of the ordering (a piece, a separator, or a part of one) is factored as
+//           ONE dense matrix inside one workgroup (chol_chain.h): potrf, the solves and the updates among its own tiles never leave
+//           the CU.  It waits until every tile of the chain has received its updates from outside (tile_tot), and sets potrf_done[k]
+//           for each of its tiles k as the tile's column (L, and the tile inverse W) leaves for memory.
+//   update  (k; ti, tj), ti >= tj outside the chain of k (tj may be a LATER tile of k's chain):
+//           C(ti, tj) -= X_ti X_tj^T with X_t = A(t, k) L_kk^-T.  X of a tile of k's own chain is read from the factor (the chain
+//           wrote it); X of an outside tile is either solved here, or — where that is off the critical path — read from what the
+//           DIAGONAL task (k; t, t) of that tile published (one solve per (k, t) instead of one per task).
 struct FusedTask {  // device-visible, 32 bytes
-  int k;        // panel (S tile index of the diagonal tile); for a potrf-only task: the tile to factor
-  int ti, tj;   // row tiles of the update C(ti, tj) -= X_ti X_tj^T, ti >= tj
-  int flags;    // kFusedPotrfOnly
-  int tot_i;    // number of updates tile (ti, k) receives in the whole factorisation: it is final (readable) at that count
+  int k;        // panel (S tile index of the diagonal tile); chain task: its first tile
+  int ti, tj;   // row tiles of the update C(ti, tj) -= X_ti X_tj^T, ti >= tj; chain task: number of tiles | bit mask of its non-zero tiles
+  int flags;    // kFused*
+  int tot_i;    // number of updates tile (ti, k) receives in the whole factorisation: it is final (readable) at that count,
+                // and X_ti is published (kFusedPublishX of the diagonal task) at that count + 1
   int tot_j;    // ... tile (tj, k)
   int need_c;   // number of updates of tile (ti, tj) by earlier tasks: this task's turn comes at exactly that count
                 // (updates of one tile are applied in list order: no atomics, bit-reproducible factor); -1: no update (rhs x rhs)
-  int tot_c;    // total number of updates of tile (ti, tj): the task that applies the last one of a diagonal tile factors it
+  int tot_c;    // total number of updates of tile (ti, tj)
 };
-constexpr int kFusedPotrfOnly = 1;
+constexpr int kFusedChain = 1;      // a chain task
+constexpr int kFusedXiLp = 2;       // X_ti is read from the factor once the diagonal task (k; ti, ti) has published it
+constexpr int kFusedXjLp = 4;       // ... X_tj
+constexpr int kFusedXjChain = 8;    // tj belongs to the chain of k: X_tj = L(tj, k) is out when potrf_done[k] is set
+constexpr int kFusedPublishX = 16;  // (diagonal task) X_ti goes to the factor write-through and the tile's counter is bumped once more
+constexpr int kChainMaxTiles = 3;   // == chain::kChainMaxTiles (chol_chain.h)
 
 struct DensePlan {
   int n_pose = 0, T = 0 /* real tiles */, npad = 0, rhs_row = 0;
@@ -71,6 +85,8 @@ struct DensePlan {
   std::vector<int> bs_desc;
   // fused single-launch factorisation (k_chol.hip chol_fused_kernel)
   std::vector<FusedTask> ftasks;
+  std::vector<int> tile_tot;          // (T+1)^2: number of update TASKS per tile (what a chain waits for before it reads its tiles)
+  std::vector<int> fchain_begin, fchain_len, fchain_of_tile;   // the chains of the fused factorisation
   int fused_sync_words = 0;   // ints of device scratch: ([queue head | abort | exited workgroups | potrf_done (T+1) | update counts (T+1)^2]) x 16
   double fused_flops = 0.0;   // FP64 flops of the planned factorisation (trsm + rank-64 updates + potrf of every touched tile), for the MFMA roofline
   // solve offsets
@@ -259,32 +275,91 @@ struct DensePlan {
     }
     potrf_before_step_off[steps.size()] = (int)potrf_tiles.size();
     for (PanelDesc& d : panels) d.self_potrf = factored_by_lookahead[d.k] ? 0 : 1;
-    // ---- task list of the fused factorisation: potrf-only tasks for the tiles nothing ever updates (heads of pieces), then the
-    // (panel, i, j) updates step by step.  Updates of one tile are applied in list order (need_c), so no two of them race.
+    // ---- task list of the fused factorisation (FusedTask): chains, then the update tasks of their panels, depth by depth
     {
-      ftasks.clear();
-      std::vector<int> tot((size_t)N * N, 0), seen((size_t)N * N, 0);
-      for (int k = 0; k < T; ++k) for (int a : rows[k]) for (int b : rows[k]) if (b <= a && !(a == T && b == T)) tot[(size_t)a * N + b]++;
-      for (int t = 0; t < T; ++t) if (tot[(size_t)t * N + t] == 0) { FusedTask f{t, t, t, kFusedPotrfOnly, 0, 0, -1, 0}; ftasks.push_back(f); }
+      ftasks.clear(); fchain_begin.clear(); fchain_len.clear();
+      fchain_of_tile.assign(N, -1);
+      auto add_range = [&](int b0, int e0) {
+        const int len = e0 - b0;
+        if (len <= 0) return;
+        const int nseg = (len + kChainMaxTiles - 1) / kChainMaxTiles;
+        int at = b0;
+        for (int sg = 0; sg < nseg; ++sg) {
+          const int l = len / nseg + (sg < len % nseg ? 1 : 0);
+          for (int t = at; t < at + l; ++t) fchain_of_tile[t] = (int)fchain_begin.size();
+          fchain_begin.push_back(at); fchain_len.push_back(l);
+          at += l;
+        }
+      };
+      for (const auto& r : leaf_ranges) add_range(r.first, r.second);
+      for (const auto& r : piece_ranges) add_range(r.first, r.second);
+      for (const auto& lv : sep_ranges_by_level) for (const auto& r : lv) add_range(r.first, r.second);
+      const int nch = (int)fchain_begin.size();
+      // depth of a chain: one more than the deepest chain that updates one of its tiles (S order is topological: rows(k) > k)
+      std::vector<int> order_ch(nch), depth(nch, 0);
+      for (int i = 0; i < nch; ++i) order_ch[i] = i;
+      std::sort(order_ch.begin(), order_ch.end(), [&](int x, int y) { return fchain_begin[x] < fchain_begin[y]; });
+      int max_depth = 0;
+      for (int ch : order_ch)
+        for (int k = fchain_begin[ch]; k < fchain_begin[ch] + fchain_len[ch]; ++k)
+          for (int t : rows[k]) if (t < T && fchain_of_tile[t] != ch) { depth[fchain_of_tile[t]] = std::max(depth[fchain_of_tile[t]], depth[ch] + 1); max_depth = std::max(max_depth, depth[fchain_of_tile[t]]); }
+      tile_tot.assign((size_t)N * N, 0);
+      std::vector<int> seen((size_t)N * N, 0);
       fused_flops = 0.0;
       const double tile3 = 64.0 * 64.0 * 64.0;
-      for (size_t s = 0; s < steps.size(); ++s) {
-        std::vector<FusedTask> st;
-        for (int k : steps[s]) {
-          fused_flops += tile3 / 3.0 + tile3 * (double)rows[k].size();   // potrf(k) + one triangular solve per row tile
-          for (int a : rows[k]) for (int b : rows[k]) {
-            if (b > a) continue;
-            FusedTask f{k, a, b, 0, tot[(size_t)a * N + k], tot[(size_t)b * N + k], -1, 0};
-            if (!(a == T && b == T)) { f.tot_c = tot[(size_t)a * N + b]; fused_flops += (a == b ? 1.0 : 2.0) * tile3; }
-            st.push_back(f);
-          }
-        }
-        // inside a step: the tiles the next panels need first (smallest column, then row) come first
-        std::stable_sort(st.begin(), st.end(), [](const FusedTask& x, const FusedTask& y) { return x.tj != y.tj ? x.tj < y.tj : x.ti < y.ti; });
-        for (FusedTask& f : st) {
-          if (!(f.ti == T && f.tj == T)) f.need_c = seen[(size_t)f.ti * N + f.tj]++;
+      for (int d = 0; d <= max_depth; ++d) {
+        for (int ch : order_ch) {
+          if (depth[ch] != d) continue;
+          const int b0 = fchain_begin[ch], l = fchain_len[ch];
+          unsigned present = 0;
+          for (int i = 0; i < l; ++i) for (int j = 0; j <= i; ++j) if (i == j || B[(size_t)(b0 + i) * N + b0 + j]) present |= 1u << (i * (i + 1) / 2 + j);
+          FusedTask f{b0, l, (int)present, kFusedChain, 0, 0, -1, 0};
           ftasks.push_back(f);
+          const double nn = 64.0 * l;
+          fused_flops += nn * nn * nn / 3.0;
         }
+        for (int qq = 0; qq < kChainMaxTiles; ++qq)
+          for (int ch : order_ch) {
+            if (depth[ch] != d || fchain_len[ch] <= qq) continue;
+            const int k = fchain_begin[ch] + qq, cend = fchain_begin[ch] + fchain_len[ch];
+            std::vector<FusedTask> st;
+            for (int a : rows[k]) {
+              if (a < cend) continue;                     // (both tiles inside the chain: the chain's own work)
+              fused_flops += tile3;                        // one triangular solve per outside row tile
+              for (int b2 : rows[k]) {
+                if (b2 > a) continue;
+                FusedTask f{k, a, b2, 0, 0, 0, -1, 0};
+                if (b2 < cend) f.flags |= kFusedXjChain;
+                if (a == b2) f.flags |= kFusedPublishX;
+                if (!(a == T && b2 == T)) fused_flops += (a == b2 ? 1.0 : 2.0) * tile3;
+                st.push_back(f);
+              }
+            }
+            // the diagonal tasks first (the others may read what they publish), then the tiles the next panels need first
+            std::stable_sort(st.begin(), st.end(), [](const FusedTask& x, const FusedTask& y) {
+              const bool dx = x.ti == x.tj, dy = y.ti == y.tj;
+              if (dx != dy) return dx;
+              return x.tj != y.tj ? x.tj < y.tj : x.ti < y.ti;
+            });
+            for (FusedTask& f : st) {
+              if (!(f.ti == T && f.tj == T)) { f.need_c = seen[(size_t)f.ti * N + f.tj]++; tile_tot[(size_t)f.ti * N + f.tj]++; }
+              ftasks.push_back(f);
+            }
+          }
+      }
+      static const bool fetch_x = !(getenv("BSGPU_CHOL_SOLVE_OWN") && atoi(getenv("BSGPU_CHOL_SOLVE_OWN")) != 0);
+      for (FusedTask& f : ftasks) {
+        if (f.flags & kFusedChain) continue;
+        f.tot_i = tile_tot[(size_t)f.ti * N + f.k];
+        f.tot_j = tile_tot[(size_t)f.tj * N + f.k];
+        f.tot_c = (f.need_c >= 0) ? tile_tot[(size_t)f.ti * N + f.tj] : 0;
+        if (f.ti == f.tj || !fetch_x) continue;
+        // An off-diagonal task reads the X its diagonal tasks publish unless it is the one a chain is waiting for last: the final
+        // update of a tile INSIDE a chain (then it solves its own strips and starts as soon as L_kk is out), or a task whose tj is
+        // in the chain of k (its target is the panel tile of the chain's NEXT panels)
+        const bool last_of_chain_tile = f.ti < T && fchain_of_tile[f.ti] == fchain_of_tile[f.tj] && f.need_c + 1 == f.tot_c;
+        if (last_of_chain_tile || (f.flags & kFusedXjChain)) continue;
+        f.flags |= kFusedXiLp | kFusedXjLp;
       }
       fused_sync_words = 16 * (3 + N + N * N);   // (every word a 64-byte line apart: k_chol.hip fused_sync_stride)
     }

@@ -19,6 +19,7 @@
 #include <thread>
 
 #include "bsgpu_device.h"
+#include "chol_chain.h"
 #include "dense_plan.h"
 
 namespace bsg {
@@ -567,27 +568,6 @@ BSG_DEV bool wait_flags(const int* flags, int lo, int hi, int* abort_w, long lon
     __builtin_amdgcn_s_sleep(1);
   }
 }
-// L_tt, its block inverses and reciprocal pivots to Lp / Vinv, write-through (read by other workgroups of this launch)
-template <int NT = 256>
-BSG_DEV void write_factor_sc1(__amdgpu_buffer_rsrc_t rLp, __amdgpu_buffer_rsrc_t rV, int ld, int t, const double* sC, const double* sV,
-                              const double* sInvD, int tid) {
-#pragma unroll
-  for (int q = 0; q < 2048 / NT; ++q) {
-    const int i = tid + NT * q;
-    const int r = i >> 5, c2 = (i & 31) * 2;
-    const unsigned at = (unsigned)(((size_t)(t * NB + r) * ld + t * NB + c2) * sizeof(double));
-    if (c2 <= r) {   // (the element right of the diagonal rides along: the strictly upper part of the tile is never read)
-      st16_sc1(rLp, at, *reinterpret_cast<const double2*>(&sC[r * LDT + c2]));
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < 512 / NT; ++q) {
-    const int i = (tid + NT * q) * 2;
-    st16_sc1(rV, (unsigned)(((size_t)t * kVinvStride + i) * sizeof(double)), *reinterpret_cast<const double2*>(&sV[i]));
-  }
-  if (tid < NB) st8_sc1(rV, (unsigned)(((size_t)t * kVinvStride + 1024 + tid) * sizeof(double)), sInvD[tid]);
-}
-
 constexpr long long kFusedTimeoutTicks = 100000000LL / 4;   // s_memrealtime runs at 100 MHz: a quarter of a second
 
 // a value every lane holds identically, moved to scalar registers (the compiler cannot see that it is uniform once it has been
@@ -601,61 +581,12 @@ BSG_DEV long long uniform_i64(long long v) {
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
   return (long long)(((unsigned long long)hi << 32) | lo);
 }
-// W = L^-1 of a factored 64x64 tile (full lower-triangular inverse, 16x16 blocks) from L (sL) and the inverses of its diagonal blocks
-// (sV), into sW (pitch LDT; blocks above the diagonal are not written).  Wave j builds block column j top-down — W_jj = V_j,
-// W_ij = -V_i sum_{k=j..i-1} L_ik W_kj — out of its own registers: the MFMA result layout of W_kj is the B-operand layout of the
-// next product.  Wave 3 only copies V_3.  The back-substitution multiplies by W^T instead of solving with L_kk^T (bs_chain_walk).
-BSG_DEV void tile_inverse_w(const double* sL, const double* sV, double* sW, int lane, int wave) {
-  const int n = lane & 15, q = lane >> 4, j = wave;
-  double4_t w[4];   // W_kj for k = j .. 3 (index k), result layout: w[k][reg] = W_kj[q + 4 reg][n]
-#pragma unroll
-  for (int k = 0; k < 4; ++k) w[k] = double4_t{0.0, 0.0, 0.0, 0.0};
-  double4_t wjj;
-#pragma unroll
-  for (int reg = 0; reg < 4; ++reg) wjj[reg] = sV[j * 256 + (q + 4 * reg) * 16 + n];
-#pragma unroll
-  for (int jj = 0; jj < 4; ++jj) if (jj == j) w[jj] = wjj;
-#pragma unroll
-  for (int i = 1; i < 4; ++i) {
-    if (i <= j) continue;   // (wave-uniform)
-    double4_t t = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (k < j || k >= i) continue;
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
-        t = __builtin_amdgcn_mfma_f64_16x16x4f64(sL[(16 * i + n) * LDT + 16 * k + 4 * kk + q], w[k][kk], t, 0, 0, 0);
-    }
-    double4_t r = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) r = __builtin_amdgcn_mfma_f64_16x16x4f64(-sV[i * 256 + n * 16 + 4 * kk + q], t[kk], r, 0, 0, 0);
-    w[i] = r;
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (i < j) continue;
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) sW[(16 * i + q + 4 * reg) * LDT + 16 * j + n] = w[i][reg];
-  }
-}
-// ... and out to Winv[t] (row-major 64 x 64, zero above the diagonal blocks): read by a later launch, plain stores
-template <int NT = 256>
-BSG_DEV void publish_tile_inverse(const double* sL, const double* sV, double* sW, double* __restrict__ Wt, int tid) {
-  if ((tid >> 6) < 4) tile_inverse_w(sL, sV, sW, tid & 63, tid >> 6);
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < 2048 / NT; ++q) {
-    const int i = tid + NT * q;
-    const int r = i >> 5, c2 = (i & 31) * 2;
-    double2 v = *reinterpret_cast<const double2*>(&sW[r * LDT + c2]);
-    if ((c2 >> 4) > (r >> 4)) { v.x = 0.0; v.y = 0.0; }
-    *reinterpret_cast<double2*>(&Wt[r * NB + c2]) = v;
-  }
-}
 struct FusedCtx {
   double *S, *Lp, *Vinv, *scal;
-  double* Winv;   // per tile: the full inverse of its factor, for the back-substitution (null: not wanted)
+  double* Winv;   // per tile: the full inverse of its factor: its diagonal 16x16 blocks are what the tasks' triangular solves multiply by,
+                  // the whole of it what the back-substitution multiplies by
   const FusedTask* tasks;
+  const int* tile_tot;
   const int* nreal;
   int ld, n_vinv_tiles;
   int *abort_w, *potrf_done, *upd;
@@ -663,177 +594,141 @@ struct FusedCtx {
             // serialised at the memory side — measured on the PCG slots, k_pcg.hip — and the queue head / exit counter take ~2 000 atomics)
   long long deadline;
   long long* probe_ts;
-  volatile int* trace;
 };
-// One task of the fused factorisation; returns false when a wait was aborted (wave-uniform).
-// NB: this body must not sit inside a loop of the kernel.  A persistent workgroup looping over the queue was the first design: with
-// the body inlined the structuriser folded the one-lane sections (dependency polls, publishes) into the loop's exit masks, the loop
-// around the barriers became a divergent one and a workgroup span for ever inside the potrf-only branch (found with rocgdb,
-// scripts/gdb_hang.sh); called out of line (noinline) it was correct but ~2 us slower per task (pointers through scratch, worse
-// register allocation of the potrf).  One task per workgroup needs no loop at all.
-// NT threads: 256, or 512 — the rank-64 update is then two 16x16 blocks per wave instead of four, the two panel strips of an
-// off-diagonal task are solved side by side and the trailing updates inside the 64x64 potrf have eight waves
+// One UPDATE task of the fused factorisation (dense_plan.h FusedTask); returns false when a wait was aborted (wave-uniform).
+// 512 threads: waves 0-3 solve the strips of X_i, waves 4-7 those of X_j at the same time; the rank-64 update is two 16x16 blocks
+// per wave.  Stamps (PROBE): 1 got task, 2 dependencies met, 3 tiles in LDS, 4 solves done, 5 product done and turn taken, 6 published.
 template <bool PROBE, int NT>
-BSG_DEV bool chol_fused_task(const FusedCtx& C, int t, double* smem, long long t_deq) {
+BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, double* smem) {
   constexpr int NQ = 2048 / NT;          // 16-byte pieces of a 64x64 tile per thread
   constexpr int TPW = 16 / (NT / 64);    // 16x16 blocks of the update per wave
-  double* const S = uniform_ptr(C.S); double* const Lp = uniform_ptr(C.Lp); double* const scal = uniform_ptr(C.scal);
-  const int* const nreal = uniform_ptr(C.nreal); const FusedTask* const tasks = uniform_ptr(C.tasks);
+  double* const S = uniform_ptr(C.S); double* const Lp = uniform_ptr(C.Lp);
   const int ld = __builtin_amdgcn_readfirstlane(C.ld);
   int* const abort_w = uniform_ptr(C.abort_w); int* const potrf_done = uniform_ptr(C.potrf_done); int* const upd = uniform_ptr(C.upd);
   const int fs = __builtin_amdgcn_readfirstlane(C.fs);
   const long long deadline = uniform_i64(C.deadline);
-  long long* const probe_ts = uniform_ptr(C.probe_ts); volatile int* const trace = uniform_ptr(C.trace);
-  double* const Winv = uniform_ptr(C.Winv);
-  t = __builtin_amdgcn_readfirstlane(t);
-  smem = uniform_ptr(smem);
+  long long* const probe_ts = uniform_ptr(C.probe_ts);
   double* sXi = smem;                 // 64 x LDT
   double* sXj = sXi + NB * LDT;       // 64 x LDT
   double* sL = sXj + NB * LDT;        // 64 x LDT
   double* sV = sL + NB * LDT;         // 4 x 256
-  double* sT = sV + 4 * 256;          // 4 x 16 x 17 (the LDS round-trip solve only)
-  double* sInvD = sT + 4 * 16 * 17;   // 64
-  int* s_ctl = reinterpret_cast<int*>(sInvD + NB);   // 4 ints
-  (void)sT;
+  int* s_ctl = reinterpret_cast<int*>(sV + 4 * 256);   // 4 ints
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int N = ld / NB, T = N - 1;
+  const int N = ld / NB;
   const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(S, 0, (int)((size_t)ld * ld * sizeof(double)), 0x00020000);
   const __amdgpu_buffer_rsrc_t rLp = __builtin_amdgcn_make_buffer_rsrc(Lp, 0, (int)((size_t)ld * ld * sizeof(double)), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(C.Vinv), 0, (int)((size_t)__builtin_amdgcn_readfirstlane(C.n_vinv_tiles) * kVinvStride * sizeof(double)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(C.Winv), 0, (int)((size_t)(N - 1) * 4096 * sizeof(double)), 0x00020000);
   const int crow = lane >> 4, ccol = lane & 15;
   const int rs = wave & 3, tt0 = (wave >> 2) * TPW;   // this wave's row strip and first column block of the update
-  bool ok_all = true;
-    auto stamp = [&](int slot) {
-      if (PROBE && tid == 0) probe_ts[(size_t)t * 8 + slot] = wall_clock64();
-      if (PROBE && trace && tid == 0) { trace[blockIdx.x * 2] = slot; trace[blockIdx.x * 2 + 1] = t; }
-    };
-    if (PROBE && tid == 0) { probe_ts[(size_t)t * 8] = t_deq; probe_ts[(size_t)t * 8 + 7] = blockIdx.x; }
-    stamp(1);
-    const FusedTask tk = tasks[t];
-    const int k = tk.k;
-    if (tk.flags & kFusedPotrfOnly) {
-      // a tile nothing updates (the head of a piece): as assembled, from the previous launches
-      double2 v[NQ];
+  auto stamp = [&](int slot) { if (PROBE && tid == 0) probe_ts[(size_t)t * 8 + slot] = wall_clock64(); };
+  stamp(1);
+  const int k = tk.k, ti = tk.ti, tj = tk.tj;
+  const bool diag = ti == tj;
+  const bool do_update = tk.need_c >= 0;
+  const bool solve_i = !(tk.flags & kFusedXiLp);
+  const bool solve_j = !diag && !(tk.flags & (kFusedXjLp | kFusedXjChain));
+  const bool need_L = solve_i || solve_j;
+  const int ri = ti * NB, rj = tj * NB, c0 = k * NB;
+  double2 vXi[NQ], vL[NQ], vXj[NQ], vV[512 / NT];
+  // The panel tiles first: they have usually had their last update long before L_kk is out, so their loads travel while the
+  // workgroup waits for the factor; only L_kk and its block inverses are requested after it.  A strip that is not solved here is
+  // read from the factor: X of an outside tile once its diagonal task has published it (the tile's counter one past its last
+  // update), X of a tile of k's own chain with potrf_done[k].
+  if (tid == 0) {
+    bool ok = wait_count(&upd[(ti * N + k) * fs], tk.tot_i + (solve_i ? 0 : 1), abort_w, deadline);
+    if (!diag && !(tk.flags & kFusedXjChain)) ok = ok && wait_count(&upd[(tj * N + k) * fs], tk.tot_j + (solve_j ? 0 : 1), abort_w, deadline);
+    s_ctl[1] = ok ? 1 : 0;
+    // ... and the C tile, if it is already this task's turn on it (on the critical path it is: the tile's earlier updaters are
+    // panels that finished long ago): its values wait in registers through the solves, and the product accumulates onto them
+    s_ctl[3] = (do_update && (tk.need_c == 0 || ld_flag(&upd[(ti * N + tj) * fs]) >= tk.need_c)) ? 1 : 0;
+  }
+  __syncthreads();
+  const bool c_pre = __builtin_amdgcn_readfirstlane(s_ctl[3]) != 0;
+  double4_t cpre[TPW];
+  if (c_pre) {
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int i = tid + NT * q;
-        v[q] = *reinterpret_cast<const double2*>(&S[(size_t)(k * NB + (i >> 5)) * ld + k * NB + (i & 31) * 2]);
-      }
+    for (int u = 0; u < TPW; ++u)
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int i = tid + NT * q;
-        const int r = i >> 5, c2 = (i & 31) * 2;
-        sXj[r * LDT + c2] = (c2 <= r) ? v[q].x : 0.0;
-        sXj[r * LDT + c2 + 1] = (c2 + 1 <= r) ? v[q].y : 0.0;
-      }
-      __syncthreads();
-      if (nreal[k] < NB) { mask_unreal_columns<NT>(sXj, nreal[k], tid); __syncthreads(); }
-      stamp(4);
-      const bool bad = potrf64_lds<false, NT>(sXj, sV, sInvD, tid, nreal[k]);
-      stamp(5);
-      if (bad && tid == 0) scal[SC_CHOL_FAIL] = 1.0;
-      write_factor_sc1<NT>(rLp, rV, ld, k, sXj, sV, sInvD, tid);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) __hip_atomic_store(&potrf_done[k * fs], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      stamp(6);
-      // (nobody waits for this: the tile's full inverse, for the back-substitution)
-      if (Winv && k < T) publish_tile_inverse<NT>(sXj, sV, sXi, Winv + (size_t)k * NB * NB, tid);
-    } else {
-    const int ti = tk.ti, tj = tk.tj;
-    const bool diag = ti == tj;
-    const bool do_update = tk.need_c >= 0;
-    // dependencies of the SOLVES: L_kk and the two panel tiles.  The turn on the C tile is waited for later, after the product
-    // X_i X_j^T has been formed: with several updaters of one tile (separator tiles: every panel of both neighbouring pieces) only
-    // the read-modify-write of the tile is serialised, not the solves and the product.
-    const int ri = ti * NB, rj = tj * NB, c0 = k * NB;
-    double2 vXi[NQ], vL[NQ], vXj[NQ], vV[512 / NT];
-    // The panel tiles first: they have usually had their last update long before L_kk is out, so their loads travel while the
-    // workgroup waits for the factor, and only L_kk and its block inverses are requested after it (measured in one box, three runs
-    // each way: 289 -> 277 us per factorisation).
-    if (tid == 0) {
-      bool ok = wait_count(&upd[(ti * N + k) * fs], tk.tot_i, abort_w, deadline);
-      if (!diag) ok = ok && wait_count(&upd[(tj * N + k) * fs], tk.tot_j, abort_w, deadline);
-      s_ctl[1] = ok ? 1 : 0;
-      // ... and the C tile, if it is already this task's turn on it (on the critical path it is: the tile's earlier updaters are
-      // panels that finished long ago): its values wait in registers through the solves, and the product accumulates onto them
-      s_ctl[3] = (do_update && (tk.need_c == 0 || ld_flag(&upd[(ti * N + tj) * fs]) >= tk.need_c)) ? 1 : 0;
-    }
+      for (int reg = 0; reg < 4; ++reg)
+        cpre[u][reg] = ld8_sc1(rS, (unsigned)(((size_t)(ri + 16 * rs + crow + 4 * reg) * ld + rj + 16 * (tt0 + u) + ccol) * sizeof(double)));
+  }
+  if (__builtin_amdgcn_readfirstlane(s_ctl[1]) == 0) return false;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int i = tid + NT * q;
+    const int r = i >> 5, c2 = (i & 31) * 2;
+    vXi[q] = ld16_sc1(solve_i ? rS : rLp, (unsigned)(((size_t)(ri + r) * ld + c0 + c2) * sizeof(double)));
+    if (!diag && !(tk.flags & kFusedXjChain)) vXj[q] = ld16_sc1(solve_j ? rS : rLp, (unsigned)(((size_t)(rj + r) * ld + c0 + c2) * sizeof(double)));
+  }
+  __syncthreads();   // (s_ctl[1] is rewritten below)
+  if (need_L || (tk.flags & kFusedXjChain)) {
+    if (tid == 0) s_ctl[1] = wait_count(&potrf_done[k * fs], 1, abort_w, deadline) ? 1 : 0;
     __syncthreads();
-    const bool c_pre = __builtin_amdgcn_readfirstlane(s_ctl[3]) != 0;
-    double4_t cpre[TPW];
-    if (c_pre) {
+    if (__builtin_amdgcn_readfirstlane(s_ctl[1]) == 0) return false;
+  }
+  stamp(2);
+  if (tk.flags & kFusedXjChain) {
 #pragma unroll
-      for (int u = 0; u < TPW; ++u)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg)
-          cpre[u][reg] = ld8_sc1(rS, (unsigned)(((size_t)(ri + 16 * rs + crow + 4 * reg) * ld + rj + 16 * (tt0 + u) + ccol) * sizeof(double)));
+    for (int q = 0; q < NQ; ++q) {
+      const int i = tid + NT * q;
+      vXj[q] = ld16_sc1(rLp, (unsigned)(((size_t)(rj + (i >> 5)) * ld + c0 + (i & 31) * 2) * sizeof(double)));
     }
-    if (__builtin_amdgcn_readfirstlane(s_ctl[1]) != 0) {
+  }
+  if (need_L) {
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int i = tid + NT * q;
-        const int r = i >> 5, c2 = (i & 31) * 2;
-        vXi[q] = ld16_sc1(rS, (unsigned)(((size_t)(ri + r) * ld + c0 + c2) * sizeof(double)));
-        if (!diag) vXj[q] = ld16_sc1(rS, (unsigned)(((size_t)(rj + r) * ld + c0 + c2) * sizeof(double)));   // (a diagonal task has one panel tile)
-      }
+    for (int q = 0; q < NQ; ++q) {
+      const int i = tid + NT * q;
+      vL[q] = ld16_sc1(rLp, (unsigned)(((size_t)(c0 + (i >> 5)) * ld + c0 + (i & 31) * 2) * sizeof(double)));
     }
-    __syncthreads();   // (s_ctl[1] is rewritten below)
-    if (tid == 0) s_ctl[1] = (s_ctl[1] != 0 && wait_count(&potrf_done[k * fs], 1, abort_w, deadline)) ? 1 : 0;
-    __syncthreads();
-    if (__builtin_amdgcn_readfirstlane(s_ctl[1]) == 0) { ok_all = false; }
-    else {
-    stamp(2);
-    {
+    // the inverses of the four diagonal 16x16 blocks of L_kk = the diagonal blocks of W_k: sV[b][i][c] = W[16 b + i][16 b + c]
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int i = tid + NT * q;
-        const int r = i >> 5, c2 = (i & 31) * 2;
-        vL[q] = ld16_sc1(rLp, (unsigned)(((size_t)(c0 + r) * ld + c0 + c2) * sizeof(double)));
-      }
-#pragma unroll
-      for (int q = 0; q < 512 / NT; ++q) vV[q] = ld16_sc1(rV, (unsigned)(((size_t)k * kVinvStride + (tid + NT * q) * 2) * sizeof(double)));
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int i = tid + NT * q;
-        const int r = i >> 5, c2 = (i & 31) * 2;
-        *reinterpret_cast<double2*>(&sXi[r * LDT + c2]) = vXi[q];
-        *reinterpret_cast<double2*>(&sL[r * LDT + c2]) = vL[q];
-        if (!diag) *reinterpret_cast<double2*>(&sXj[r * LDT + c2]) = vXj[q];
-      }
-#pragma unroll
-      for (int q = 0; q < 512 / NT; ++q) *reinterpret_cast<double2*>(&sV[(tid + NT * q) * 2]) = vV[q];
+    for (int q = 0; q < 512 / NT; ++q) {
+      const int i2 = (tid + NT * q) * 2;
+      const int b = i2 >> 8, i = (i2 >> 4) & 15, c = i2 & 15;
+      vV[q] = ld16_sc1(rW, (unsigned)(((size_t)k * 4096 + (16 * b + i) * 64 + 16 * b + c) * sizeof(double)));
     }
-    __syncthreads();
-    stamp(3);
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int i = tid + NT * q;
+    const int r = i >> 5, c2 = (i & 31) * 2;
+    *reinterpret_cast<double2*>(&sXi[r * LDT + c2]) = vXi[q];
+    if (need_L) *reinterpret_cast<double2*>(&sL[r * LDT + c2]) = vL[q];
+    if (!diag) *reinterpret_cast<double2*>(&sXj[r * LDT + c2]) = vXj[q];
+  }
+  if (need_L) {
+#pragma unroll
+    for (int q = 0; q < 512 / NT; ++q) *reinterpret_cast<double2*>(&sV[(tid + NT * q) * 2]) = vV[q];
+  }
+  __syncthreads();
+  stamp(3);
+  if (need_L) {
     if (NT == 256) {
-      trsm_tile_t(sXi, sL, sV, lane, wave);
-      if (!diag) trsm_tile_t(sXj, sL, sV, lane, wave);
+      if (solve_i) trsm_tile_t(sXi, sL, sV, lane, wave);
+      if (solve_j) trsm_tile_t(sXj, sL, sV, lane, wave);
     } else {   // (waves 0-3: the strips of X_i; waves 4-7: those of X_j, at the same time)
-      if (wave < 4) trsm_tile_t(sXi, sL, sV, lane, wave);
-      else if (!diag) trsm_tile_t(sXj, sL, sV, lane, wave - 4);
+      if (wave < 4) { if (solve_i) trsm_tile_t(sXi, sL, sV, lane, wave); }
+      else if (solve_j) trsm_tile_t(sXj, sL, sV, lane, wave - 4);
     }
     __syncthreads();
-    stamp(4);
-    const double* Xj = diag ? sXi : sXj;
-    double4_t acc[TPW];
+  }
+  stamp(4);
+  const double* Xj = diag ? sXi : sXj;
+  double4_t acc[TPW];
 #pragma unroll
-    for (int u = 0; u < TPW; ++u) acc[u] = double4_t{0.0, 0.0, 0.0, 0.0};
-    // The C tile: already in registers (requested before the wait for L_kk), or — if the turn had not come by then — one more look
-    // now: a tile requested here still travels under the 256 MFMAs instead of being waited for after them.
-    bool c_early = false;
-    if (do_update) {
-      if (c_pre) {
-        c_early = true;
+  for (int u = 0; u < TPW; ++u) acc[u] = double4_t{0.0, 0.0, 0.0, 0.0};
+  // The C tile: already in registers (requested before the wait for L_kk), or — if the turn had not come by then — one more look
+  // now: a tile requested here still travels under the 256 MFMAs instead of being waited for after them.
+  bool c_early = false;
+  if (do_update) {
+    if (c_pre) {
+      c_early = true;
 #pragma unroll
-        for (int u = 0; u < TPW; ++u) acc[u] = cpre[u];
-      } else {
-      if (tk.need_c == 0) c_early = true;
-      else {
-        if (tid == 0) s_ctl[3] = (ld_flag(&upd[(ti * N + tj) * fs]) >= tk.need_c) ? 1 : 0;
-        __syncthreads();
-        c_early = __builtin_amdgcn_readfirstlane(s_ctl[3]) != 0;
-      }
+      for (int u = 0; u < TPW; ++u) acc[u] = cpre[u];
+    } else {
+      if (tid == 0) s_ctl[3] = (ld_flag(&upd[(ti * N + tj) * fs]) >= tk.need_c) ? 1 : 0;
+      __syncthreads();
+      c_early = __builtin_amdgcn_readfirstlane(s_ctl[3]) != 0;
       if (c_early) {
 #pragma unroll
         for (int u = 0; u < TPW; ++u)
@@ -841,194 +736,160 @@ BSG_DEV bool chol_fused_task(const FusedCtx& C, int t, double* smem, long long t
           for (int reg = 0; reg < 4; ++reg)
             acc[u][reg] = ld8_sc1(rS, (unsigned)(((size_t)(ri + 16 * rs + crow + 4 * reg) * ld + rj + 16 * (tt0 + u) + ccol) * sizeof(double)));
       }
-      }
-#pragma unroll
-      for (int u = 0; u < TPW; ++u)
-        acc[u] = mfma_abt<64>(acc[u], sXi + (16 * rs) * LDT, LDT, Xj + (16 * (tt0 + u)) * LDT, LDT, -1.0, lane);
     }
-    const bool last_update = do_update && tk.need_c + 1 == tk.tot_c;
-    const bool factor_now = last_update && diag && ti < T;
-    bool turn_ok = true;
-    if (do_update && tk.need_c > 0 && !c_early) {
+#pragma unroll
+    for (int u = 0; u < TPW; ++u)
+      acc[u] = mfma_abt<64>(acc[u], sXi + (16 * rs) * LDT, LDT, Xj + (16 * (tt0 + u)) * LDT, LDT, -1.0, lane);
+    if (!c_early) {
       // this task's turn on the tile: every earlier update of it has been published
       if (tid == 0) s_ctl[1] = wait_count(&upd[(ti * N + tj) * fs], tk.need_c, abort_w, deadline) ? 1 : 0;
       __syncthreads();
-      turn_ok = __builtin_amdgcn_readfirstlane(s_ctl[1]) != 0;
+      if (__builtin_amdgcn_readfirstlane(s_ctl[1]) == 0) return false;
+#pragma unroll
+      for (int u = 0; u < TPW; ++u)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+          acc[u][reg] += ld8_sc1(rS, (unsigned)(((size_t)(ri + 16 * rs + crow + 4 * reg) * ld + rj + 16 * (tt0 + u) + ccol) * sizeof(double)));
     }
-    if (!turn_ok) { ok_all = false; }
-    else {
     stamp(5);
-    if (do_update) {
-      if (!c_early) {
 #pragma unroll
-        for (int u = 0; u < TPW; ++u)
+    for (int u = 0; u < TPW; ++u)
 #pragma unroll
-          for (int reg = 0; reg < 4; ++reg)
-            acc[u][reg] += ld8_sc1(rS, (unsigned)(((size_t)(ri + 16 * rs + crow + 4 * reg) * ld + rj + 16 * (tt0 + u) + ccol) * sizeof(double)));
-      }
-      if (!factor_now) {
+      for (int reg = 0; reg < 4; ++reg)
+        st8_sc1(rS, (unsigned)(((size_t)(ri + 16 * rs + crow + 4 * reg) * ld + rj + 16 * (tt0 + u) + ccol) * sizeof(double)), acc[u][reg]);
+  }
+  if (tk.flags & kFusedPublishX) {
+    // the L panel of this row tile: what the back-substitution reads, and what the off-diagonal tasks of this panel multiply with
 #pragma unroll
-        for (int u = 0; u < TPW; ++u)
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg)
-            st8_sc1(rS, (unsigned)(((size_t)(ri + 16 * rs + crow + 4 * reg) * ld + rj + 16 * (tt0 + u) + ccol) * sizeof(double)), acc[u][reg]);
-      }
+    for (int q = 0; q < NQ; ++q) {
+      const int i = tid + NT * q;
+      const int r = i >> 5, c2 = (i & 31) * 2;
+      st16_sc1(rLp, (unsigned)(((size_t)(ri + r) * ld + c0 + c2) * sizeof(double)), *reinterpret_cast<const double2*>(&sXi[r * LDT + c2]));
     }
-    if (factor_now) {
-      double* sC = sXj;
-#pragma unroll
-      for (int u = 0; u < TPW; ++u) store_d(sC + (16 * rs) * LDT + 16 * (tt0 + u), LDT, lane, acc[u]);
-      __syncthreads();
-      if (nreal[ti] < NB) { mask_unreal_columns<NT>(sC, nreal[ti], tid); __syncthreads(); }
-      const bool bad = potrf64_lds<false, NT>(sC, sV, sInvD, tid, nreal[ti]);
-      if (bad && tid == 0) scal[SC_CHOL_FAIL] = 1.0;
-      write_factor_sc1<NT>(rLp, rV, ld, ti, sC, sV, sInvD, tid);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-      if (do_update) atomicAdd(&upd[(ti * N + tj) * fs], 1);
-      if (factor_now) __hip_atomic_store(&potrf_done[ti * fs], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    stamp(6);
-    if (diag) {
-      // the L panel of this row tile, for the back-substitution: only a later launch reads it, so it leaves after the hand-over
-      // (plain stores; sX_i is still intact — the tile inverse below overwrites it afterwards)
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int i = tid + NT * q;
-        const int r = i >> 5, c2 = (i & 31) * 2;
-        *reinterpret_cast<double2*>(&Lp[(size_t)(ri + r) * ld + c0 + c2]) = *reinterpret_cast<const double2*>(&sXi[r * LDT + c2]);
-      }
-      __syncthreads();
-    }
-    if (factor_now && Winv) publish_tile_inverse<NT>(sXj, sV, sXi, Winv + (size_t)ti * NB * NB, tid);
-    }   // turn_ok
-    }   // dependencies met
-    }   // update task
-  return ok_all;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    if (do_update) atomicAdd(&upd[(ti * N + tj) * fs], 1);
+    if (tk.flags & kFusedPublishX) atomicAdd(&upd[(ti * N + k) * fs], 1);
+  }
+  stamp(6);
+  return true;
 }
 
-template <bool PROBE, int NT>
-__global__ __launch_bounds__(NT) void chol_fused_kernel(double* __restrict__ S, double* __restrict__ Lp, int ld,
-                                                          const FusedTask* __restrict__ tasks, int n_tasks,
-                                                          const int* __restrict__ nreal, double* __restrict__ Vinv, int n_vinv_tiles,
-                                                          double* __restrict__ scal, int* sync, int n_sync_words, double* Winv, int fs,
-                                                          long long* probe_ts = nullptr /* PROBE: n_tasks x 8 wall-clock stamps */,
-                                                          volatile int* trace = nullptr /* PROBE: per workgroup (checkpoint, task) in host memory */) {
+// A CHAIN task: wait for the chain's tiles to have received their updates from outside, then factor them as one dense matrix
+// (chol_chain.h).  Afterwards the block inverses of its tiles also go to Vinv (what the launch-per-level back-substitution of very
+// large windows reads; nobody in this launch does).
+template <bool PROBE>
+BSG_DEV bool chol_fused_chain(const FusedCtx& C, int t, const FusedTask& tk, double* smem) {
+  const int tid = threadIdx.x;
+  const int ld = __builtin_amdgcn_readfirstlane(C.ld), N = ld / NB, fs = __builtin_amdgcn_readfirstlane(C.fs);
+  const int b0 = tk.k, m = tk.ti;
+  int* const upd = uniform_ptr(C.upd); int* const abort_w = uniform_ptr(C.abort_w);
+  const int* const tile_tot = uniform_ptr(C.tile_tot);
+  const long long deadline = uniform_i64(C.deadline);
+  long long* const probe_ts = uniform_ptr(C.probe_ts);
+  int* s_ctl = reinterpret_cast<int*>(smem);
+  if (PROBE && tid == 0) probe_ts[(size_t)t * 8 + 1] = wall_clock64();
+  if (tid < 64) {   // one lane per tile of the chain
+    bool ok = true;
+    int ii = 0, jj = 0, left = tid;
+    while (ii < m && left > ii) { left -= ii + 1; ++ii; }
+    jj = left;
+    if (ii < m && ((unsigned)tk.tj >> tid) & 1u) {
+      const int a = b0 + ii, b = b0 + jj;
+      ok = wait_count(&upd[(a * N + b) * fs], tile_tot[(size_t)a * N + b], abort_w, deadline);
+    }
+    const int all_ok = __all(ok ? 1 : 0);
+    if (tid == 0) s_ctl[0] = all_ok;
+  }
+  __syncthreads();
+  const bool go = __builtin_amdgcn_readfirstlane(s_ctl[0]) != 0;
+  __syncthreads();
+  if (!go) return false;
+  if (PROBE && tid == 0) probe_ts[(size_t)t * 8 + 2] = wall_clock64();
+  chain::ChainArgs A;
+  A.S = uniform_ptr(C.S); A.Lp = uniform_ptr(C.Lp); A.Winv = uniform_ptr(C.Winv); A.ld = ld; A.c0 = b0; A.m = m; A.present = (unsigned)tk.tj;
+  A.nreal = uniform_ptr(C.nreal); A.tile_flag = uniform_ptr(C.potrf_done); A.flag_stride = fs;
+  A.Vinv = uniform_ptr(C.Vinv); A.vinv_stride = kVinvStride;
+  const bool bad = chain::chain_factor<false>(A, smem, nullptr);
+  if (bad && tid == 0) uniform_ptr(C.scal)[SC_CHOL_FAIL] = 1.0;
+  if (PROBE && tid == 0) probe_ts[(size_t)t * 8 + 6] = wall_clock64();
+  return true;
+}
+
+constexpr int kFusedThreads = 512;
+constexpr size_t kFusedLds = sizeof(double) * (3 * NB * LDT + 4 * 256 + 8) > sizeof(double) * chain::chain_lds_doubles() ? sizeof(double) * (3 * NB * LDT + 4 * 256 + 8)
+                                                                                                                   : sizeof(double) * chain::chain_lds_doubles();
+
+template <bool PROBE>
+__global__ __launch_bounds__(kFusedThreads) void chol_fused_kernel(double* __restrict__ S, double* __restrict__ Lp, int ld,
+                                                                    const FusedTask* __restrict__ tasks, int n_tasks, const int* __restrict__ tile_tot,
+                                                                    const int* __restrict__ nreal, double* __restrict__ Vinv,
+                                                                    double* __restrict__ scal, int* sync, double* Winv, int fs,
+                                                                    long long* probe_ts = nullptr /* PROBE: n_tasks x 8 wall-clock stamps */) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  int* s_ctl = reinterpret_cast<int*>(smem + 3 * NB * LDT + 4 * 256 + 4 * 16 * 17 + NB);   // 4 ints behind the tiles (chol_fused_task)
+  __shared__ int s_head[4];
   const int tid = threadIdx.x;
   const int N = ld / NB;
   int* head = sync; int* abort_w = sync + fs; int* exited = sync + 2 * fs;   // (layout: [head | abort | exited | potrf_done (N) | update counts (N x N)] x fs ints)
   FusedCtx C;
-  C.S = S; C.Lp = Lp; C.Vinv = Vinv; C.scal = scal; C.tasks = tasks; C.nreal = nreal; C.ld = ld; C.n_vinv_tiles = n_vinv_tiles;
+  C.S = S; C.Lp = Lp; C.Vinv = Vinv; C.scal = scal; C.tasks = tasks; C.tile_tot = tile_tot; C.nreal = nreal; C.ld = ld; C.n_vinv_tiles = N - 1;
   C.Winv = Winv;
   C.abort_w = abort_w; C.potrf_done = sync + 3 * fs; C.upd = sync + (3 + N) * fs; C.fs = fs;
   C.deadline = (long long)wall_clock64() + kFusedTimeoutTicks;
-  C.probe_ts = probe_ts; C.trace = trace;
+  C.probe_ts = probe_ts;
   // ONE task per workgroup, taken from a ticket counter: the k-th workgroup to start running gets task k, so the tasks are started in
   // list order whatever order the hardware dispatches the grid in — every counter a task waits for is advanced by a task that was
-  // started earlier (no dead-lock, whatever the residency).  No loop: see chol_fused_task.
+  // started earlier (no dead-lock, whatever the residency).
   long long t_deq = 0;
   if (PROBE) t_deq = wall_clock64();
-  if (tid == 0) s_ctl[0] = atomicAdd(head, 1);
+  if (tid == 0) s_head[0] = atomicAdd(head, 1);
   __syncthreads();
-  const int t = __builtin_amdgcn_readfirstlane(s_ctl[0]);
-  if (t < n_tasks) (void)chol_fused_task<PROBE, NT>(C, t, smem, t_deq);
+  const int t = __builtin_amdgcn_readfirstlane(s_head[0]);
+  if (t < n_tasks) {
+    if (PROBE && tid == 0) { probe_ts[(size_t)t * 8] = t_deq; probe_ts[(size_t)t * 8 + 7] = blockIdx.x; }
+    FusedTask tk = tasks[t];
+    tk.k = __builtin_amdgcn_readfirstlane(tk.k); tk.ti = __builtin_amdgcn_readfirstlane(tk.ti); tk.tj = __builtin_amdgcn_readfirstlane(tk.tj);
+    tk.flags = __builtin_amdgcn_readfirstlane(tk.flags); tk.tot_i = __builtin_amdgcn_readfirstlane(tk.tot_i); tk.tot_j = __builtin_amdgcn_readfirstlane(tk.tot_j);
+    tk.need_c = __builtin_amdgcn_readfirstlane(tk.need_c); tk.tot_c = __builtin_amdgcn_readfirstlane(tk.tot_c);
+    if (tk.flags & kFusedChain) (void)chol_fused_chain<PROBE>(C, t, tk, smem);
+    else (void)chol_fused_update<PROBE, kFusedThreads>(C, t, tk, smem);
+  }
   // leave: the last workgroup out re-zeroes the queue and the counters for the next factorisation
   __syncthreads();
-  if (PROBE && trace && tid == 0) trace[blockIdx.x * 2] = 100;
   if (tid == 0) {
     if (ld_flag(abort_w) != 0) scal[SC_CHOL_FAIL] = 2.0;
-    s_ctl[2] = (atomicAdd(exited, 1) == (int)gridDim.x - 1) ? 1 : 0;
+    s_head[2] = (atomicAdd(exited, 1) == (int)gridDim.x - 1) ? 1 : 0;
   }
   __syncthreads();
-  if (__builtin_amdgcn_readfirstlane(s_ctl[2]) != 0) {
+  if (__builtin_amdgcn_readfirstlane(s_head[2]) != 0) {
     const int nw = 3 + N + N * N;
-    for (int i = tid; i < nw; i += NT) __hip_atomic_store(&sync[i * fs], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = tid; i < nw; i += kFusedThreads) __hip_atomic_store(&sync[i * fs], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
-constexpr int kFusedThreads = 512;
 // ints between two words of the sync area: 16 = a 64-byte line each (BSGPU_FLAG_STRIDE=1: packed, the first layout)
 int fused_sync_stride() {
   static const int v = [] { const char* e = getenv("BSGPU_FLAG_STRIDE"); const int x = e ? atoi(e) : 16; return (x >= 1 && x <= 16) ? x : 16; }();
   return v;
 }
-constexpr size_t kFusedLds = sizeof(double) * (3 * NB * LDT + 4 * 256 + 4 * 16 * 17 + 64) + 16;
 
-void launch_chol_fused(hipStream_t s, double* S, double* Lp, int ld, const FusedTask* tasks_dev, int n_tasks, const int* nreal_dev,
-                       double* Vinv, double* scal, int* sync_dev, int n_sync_words, double* Winv) {
+void launch_chol_fused(hipStream_t s, double* S, double* Lp, int ld, const FusedTask* tasks_dev, int n_tasks, const int* tile_tot_dev, const int* nreal_dev,
+                       double* Vinv, double* scal, int* sync_dev, double* Winv) {
   if (n_tasks <= 0) return;
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0; hipDeviceProp_t pr;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n_cu = pr.multiProcessorCount;
-    if (n_cu <= 0) n_cu = 256;
-  }
-  (void)n_cu;
-  const int grid = n_tasks;   // one workgroup per task (118 KB of LDS each: one per CU is resident, the rest queue behind them)
+  const int grid = n_tasks;   // one workgroup per task (about 100 KB of LDS each: one per CU is resident, the rest queue behind them)
   // BSGPU_CHOL_PROBE=<file>: the 20th factorisation of the process runs the stamped variant and dumps, per task, the wall-clock
   // stamps (100 MHz) dequeue / got task / dependencies met / tiles in LDS / solves done / update done / published, and its workgroup
   static const char* probe_file = getenv("BSGPU_CHOL_PROBE");
   static int probe_calls = 0;
-  if (getenv("BSGPU_CHOL_WATCH")) {   // debugging a stuck factorisation: a watchdog copies the counters out on its own stream after 3 s
-    static int* w_sync = nullptr; static int w_words = 0, w_ld = 0;
-    static bool started = false;
-    w_sync = sync_dev; w_words = n_sync_words < 0 ? -n_sync_words : n_sync_words; w_ld = ld;
-    if (!started) {
-      started = true;
-      std::thread([&]() {
-        hipStream_t ws; (void)hipStreamCreateWithFlags(&ws, hipStreamNonBlocking);
-        for (;;) {
-          std::this_thread::sleep_for(std::chrono::seconds(3));
-          std::vector<int> h(w_words);
-          (void)hipMemcpyAsync(h.data(), w_sync, sizeof(int) * w_words, hipMemcpyDeviceToHost, ws);
-          (void)hipStreamSynchronize(ws);
-          const int N = w_ld / 64;
-          const int fs = fused_sync_stride();
-          fprintf(stderr, "[chol watch] head %d abort %d exited %d | potrf_done:", h[0], h[fs], h[2 * fs]);
-          for (int i = 0; i < N; ++i) fprintf(stderr, " %d", h[(3 + i) * fs]);
-          fprintf(stderr, " | upd:");
-          for (int i = 0; i < N; ++i) for (int j = 0; j <= i; ++j) if (h[(3 + N + i * N + j) * fs]) fprintf(stderr, " (%d,%d)=%d", i, j, h[(3 + N + i * N + j) * fs]);
-          fprintf(stderr, "\n");
-        }
-      }).detach();
-    }
-  }
-  if (getenv("BSGPU_CHOL_TRACE")) {   // debugging a stuck factorisation: checkpoints in host memory, dumped by a watchdog after 3 s
-    static volatile int* trace = nullptr;
-    static int trace_grid = 0;
-    static long long* ts_dummy = nullptr;
-    if (!trace) {
-      (void)hipHostMalloc((void**)&trace, sizeof(int) * 2 * 1024, hipHostMallocMapped);
-      for (int i = 0; i < 2048; ++i) trace[i] = -1;
-      std::thread([&]() {
-        for (;;) {
-          std::this_thread::sleep_for(std::chrono::seconds(3));
-          fprintf(stderr, "[chol trace] grid %d:", trace_grid);
-          for (int i = 0; i < trace_grid && i < 1024; ++i) fprintf(stderr, " wg%d:cp%d,t%d", i, trace[2 * i], trace[2 * i + 1]);
-          fprintf(stderr, "\n");
-        }
-      }).detach();
-    }
-    if (ts_dummy) (void)hipFree(ts_dummy);
-    (void)hipMalloc((void**)&ts_dummy, sizeof(long long) * 8 * (size_t)n_tasks);
-    trace_grid = grid;
-    for (int i = 0; i < 2048; ++i) trace[i] = -1;
-    fprintf(stderr, "[chol trace] launch: %d tasks, grid %d, ld %d\n", n_tasks, grid, ld);
-    hipLaunchKernelGGL((chol_fused_kernel<false, kFusedThreads>), dim3(grid), dim3(kFusedThreads), kFusedLds, s, S, Lp, ld, tasks_dev, n_tasks, nreal_dev, Vinv, ld / NB - 1,
-                       scal, sync_dev, n_sync_words, Winv, fused_sync_stride(), ts_dummy, trace);
-    return;
-  }
   if (probe_file && ++probe_calls == 20) {
     long long* ts = nullptr;
     std::vector<long long> h((size_t)n_tasks * 8, 0);
     std::vector<FusedTask> ht(n_tasks);
     if (hipMalloc((void**)&ts, sizeof(long long) * h.size()) == hipSuccess) {
       (void)hipMemset(ts, 0, sizeof(long long) * h.size());
-      hipLaunchKernelGGL((chol_fused_kernel<true, kFusedThreads>), dim3(grid), dim3(kFusedThreads), kFusedLds, s, S, Lp, ld, tasks_dev, n_tasks, nreal_dev, Vinv, ld / NB - 1,
-                         scal, sync_dev, n_sync_words, Winv, fused_sync_stride(), ts);
+      hipLaunchKernelGGL((chol_fused_kernel<true>), dim3(grid), dim3(kFusedThreads), kFusedLds, s, S, Lp, ld, tasks_dev, n_tasks, tile_tot_dev, nreal_dev, Vinv,
+                         scal, sync_dev, Winv, fused_sync_stride(), ts);
       (void)hipStreamSynchronize(s);
       (void)hipMemcpy(h.data(), ts, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
       (void)hipMemcpy(ht.data(), tasks_dev, sizeof(FusedTask) * ht.size(), hipMemcpyDeviceToHost);
@@ -1045,8 +906,8 @@ void launch_chol_fused(hipStream_t s, double* S, double* Lp, int ld, const Fused
       return;
     }
   }
-  hipLaunchKernelGGL((chol_fused_kernel<false, kFusedThreads>), dim3(grid), dim3(kFusedThreads), kFusedLds, s, S, Lp, ld, tasks_dev, n_tasks, nreal_dev, Vinv, ld / NB - 1, scal,
-                     sync_dev, n_sync_words, Winv, fused_sync_stride(), nullptr);
+  hipLaunchKernelGGL((chol_fused_kernel<false>), dim3(grid), dim3(kFusedThreads), kFusedLds, s, S, Lp, ld, tasks_dev, n_tasks, tile_tot_dev, nreal_dev, Vinv, scal,
+                     sync_dev, Winv, fused_sync_stride(), nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1551,8 +1412,8 @@ void chol_prepare() {
                             160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_fused_kernel<kBsChunkDeep, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_fused_kernel<kBsChunk, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_fused_kernel<false, kFusedThreads>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_fused_kernel<true, kFusedThreads>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds);
 }
 
 }  // namespace bsg

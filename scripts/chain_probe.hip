@@ -1,0 +1,125 @@
+// Stand-alone harness of the in-workgroup chain factorisation (beam_slam_amd/csrc/chol_chain.h): one workgroup factors a dense SPD
+// matrix of m tiles, the result is checked against a host Cholesky and the per-step shader-clock stamps are printed.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/chain_probe.hip -o scripts/chain_probe.bin && scripts/chain_probe.bin
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <hip/hip_runtime.h>
+#include "../beam_slam_amd/csrc/chol_chain.h"
+
+using namespace bsg::chain;
+
+template <int MAXM, int NW>
+__global__ __launch_bounds__(64 * NW) void probe_kernel(ChainArgs A, long long* ts, int* bad_out) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const bool bad = chain_factor<true>(A, smem, ts);
+  if (threadIdx.x == 0) *bad_out = bad ? 1 : 0;
+}
+
+template <int MAXM, int NW>
+static int run(int m, int nreal_last, int reps) {
+  const int n = 64 * m, ld = n + 64;
+  std::vector<double> A((size_t)ld * ld, 0.0), L((size_t)n * n, 0.0);
+  srand(7 + m);
+  // SPD: B B^T + n I with B random, then scaled rows to vary magnitudes
+  std::vector<double> B((size_t)n * n);
+  for (auto& v : B) v = (rand() / (double)RAND_MAX) - 0.5;
+  std::vector<int> nreal(m, 64);
+  nreal[m - 1] = nreal_last;
+  auto unreal = [&](int i) { return (i & 63) >= nreal[i >> 6]; };
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) {
+      double v;
+      if (j <= i) {
+        double s = (i == j) ? 0.05 * n : 0.0;
+        for (int k = 0; k < n; ++k) s += B[(size_t)i * n + k] * B[(size_t)j * n + k];
+        v = s * (1.0 + (i % 7)) * (1.0 + (j % 7));
+        if ((unreal(i) || unreal(j)) && i != j) v = 0.0;   // rows / columns of unreal columns are empty in the assembled system
+        if (unreal(i) && i == j) v = -3.0;                 // (whatever the assembly left on the diagonal: the factorisation puts a unit pivot there)
+      } else {
+        v = ((i >> 4) == (j >> 4)) ? 12345.0 : NAN;        // upper part: never read outside the diagonal 16x16 blocks (poison), arbitrary inside
+      }
+      A[(size_t)i * ld + j] = v;
+    }
+  // host reference (unit pivots for the unreal columns)
+  std::vector<double> M((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) M[(size_t)i * n + j] = (unreal(j) || unreal(i)) ? (i == j ? 1.0 : 0.0) : A[(size_t)i * ld + j];
+  for (int j = 0; j < n; ++j) {
+    double d = M[(size_t)j * n + j];
+    for (int k = 0; k < j; ++k) d -= L[(size_t)j * n + k] * L[(size_t)j * n + k];
+    const double l = std::sqrt(d);
+    L[(size_t)j * n + j] = l;
+    for (int i = j + 1; i < n; ++i) {
+      double s = M[(size_t)i * n + j];
+      for (int k = 0; k < j; ++k) s -= L[(size_t)i * n + k] * L[(size_t)j * n + k];
+      L[(size_t)i * n + j] = s / l;
+    }
+  }
+  double *dS, *dL, *dW; long long* dts; int *dflag, *dbad, *dnreal;
+  hipMalloc(&dS, sizeof(double) * A.size()); hipMalloc(&dL, sizeof(double) * A.size()); hipMalloc(&dW, sizeof(double) * 4096 * m);
+  hipMalloc(&dts, sizeof(long long) * 256); hipMalloc(&dflag, sizeof(int) * 16 * (m + 1)); hipMalloc(&dbad, sizeof(int)); hipMalloc(&dnreal, sizeof(int) * m);
+  hipMemcpy(dS, A.data(), sizeof(double) * A.size(), hipMemcpyHostToDevice);
+  hipMemcpy(dnreal, nreal.data(), sizeof(int) * m, hipMemcpyHostToDevice);
+  hipMemset(dL, 0, sizeof(double) * A.size()); hipMemset(dflag, 0, sizeof(int) * 16 * (m + 1)); hipMemset(dts, 0, sizeof(long long) * 256);
+  ChainArgs a;
+  a.S = dS; a.Lp = dL; a.Winv = dW; a.ld = ld; a.c0 = 0; a.m = m; a.present = 0xffffffffu; a.nreal = dnreal; a.tile_flag = dflag; a.flag_stride = 16; a.Vinv = nullptr; a.vinv_stride = 0;
+  const size_t lds = sizeof(double) * chain_lds_doubles();
+  hipFuncSetAttribute(reinterpret_cast<const void*>(probe_kernel<MAXM, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float best = 1e9f;
+  for (int r = 0; r < reps; ++r) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((probe_kernel<MAXM, NW>), dim3(1), dim3(64 * NW), lds, 0, a, dts, dbad);
+    hipEventRecord(e1);
+    if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed: %s\n", hipGetErrorString(hipGetLastError())); return 1; }
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) best = ms;
+  }
+  std::vector<double> hL(A.size()), hW((size_t)4096 * m);
+  std::vector<long long> hts(256);
+  int hbad = 0;
+  hipMemcpy(hL.data(), dL, sizeof(double) * A.size(), hipMemcpyDeviceToHost);
+  hipMemcpy(hW.data(), dW, sizeof(double) * hW.size(), hipMemcpyDeviceToHost);
+  hipMemcpy(hts.data(), dts, sizeof(long long) * 256, hipMemcpyDeviceToHost);
+  hipMemcpy(&hbad, dbad, sizeof(int), hipMemcpyDeviceToHost);
+  std::vector<int> hflag(16 * (m + 1));
+  hipMemcpy(hflag.data(), dflag, sizeof(int) * hflag.size(), hipMemcpyDeviceToHost);
+  double emax = 0.0, lmax = 0.0;
+  for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) {
+    emax = std::max(emax, std::fabs(hL[(size_t)i * ld + j] - L[(size_t)i * n + j]));
+    lmax = std::max(lmax, std::fabs(L[(size_t)i * n + j]));
+  }
+  // W L_kk = I per tile
+  double wmax = 0.0;
+  for (int k = 0; k < m; ++k)
+    for (int i = 0; i < 64; ++i) for (int j = 0; j < 64; ++j) {
+      double s = 0.0;
+      for (int t = 0; t < 64; ++t) s += hW[(size_t)k * 4096 + i * 64 + t] * ((t >= j) ? L[(size_t)(64 * k + t) * n + 64 * k + j] : 0.0);
+      wmax = std::max(wmax, std::fabs(s - (i == j ? 1.0 : 0.0)));
+      if (j > i && ((j >> 4) > (i >> 4)) && hW[(size_t)k * 4096 + i * 64 + j] != 0.0) wmax = std::max(wmax, 1.0);   // above the diagonal blocks: exactly zero
+    }
+  int flags_ok = 1;
+  for (int k = 0; k < m; ++k) flags_ok &= hflag[16 * k] == 1;
+  printf("MAXM %d NW %d m %d nreal_last %d: kernel %.2f us  max|L - ref| %.3e (max |L| %.3e)  max|W L - I| %.3e  bad %d flags %s\n", MAXM, NW, m, nreal_last, best * 1e3, emax, lmax,
+         wmax, hbad, flags_ok ? "ok" : "MISSING");
+  // stamps: [start, staged, then per step: after elimination, after update, ..., end]
+  const double mhz = 2400.0;   // shader clock (nominal); only differences matter
+  printf("  cycles: prologue %lld |", hts[1] - hts[0]);
+  for (int b = 0; b < 4 * m; ++b) printf(" %lld+%lld", hts[2 + 2 * b] - hts[1 + 2 * b], hts[3 + 2 * b] - hts[2 + 2 * b]);
+  printf(" | tail %lld | total %lld cycles = %.2f us at %.0f MHz\n", hts[2 + 8 * m] - hts[1 + 8 * m], hts[2 + 8 * m] - hts[0], (hts[2 + 8 * m] - hts[0]) / mhz, mhz);
+  const bool ok = emax <= 1e-10 * lmax && wmax < 1e-9 && !hbad && flags_ok;
+  hipFree(dS); hipFree(dL); hipFree(dW); hipFree(dts); hipFree(dflag); hipFree(dbad); hipFree(dnreal);
+  return ok ? 0 : 1;
+}
+
+int main() {
+  int fail = 0;
+  fail |= run<3, 8>(1, 64, 5);
+  fail |= run<3, 8>(2, 64, 5);
+  fail |= run<3, 8>(3, 64, 5);
+  fail |= run<3, 8>(3, 40, 3);
+  fail |= run<3, 8>(2, 17, 3);
+  printf(fail ? "FAILED\n" : "all ok\n");
+  return fail;
+}

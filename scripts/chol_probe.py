@@ -24,13 +24,12 @@ print("tasks %d, workgroups %d, span %.1f us" % (len(rows), len(set(r["wg"] for 
 potrf_by = {}
 upd_by = {}
 for r in rows:
-    if r["flags"] & 1:
-        potrf_by[r["k"]] = r
+    if r["flags"] & 1:   # a chain task: k = first tile, ti = number of tiles (its tiles' flags are set as it goes; the stamp is its end)
+        for t in range(r["k"], r["k"] + r["ti"]):
+            potrf_by[t] = r
     else:
         if r["need"] >= 0:
             upd_by[(r["ti"], r["tj"], r["need"] + 1)] = r
-            if r["ti"] == r["tj"] and r["need"] + 1 == r["tot"]:
-                potrf_by[r["ti"]] = r
 tot = collections.Counter()
 for r in rows:
     if not (r["flags"] & 1) and r["need"] >= 0:
@@ -38,8 +37,14 @@ for r in rows:
 
 
 def deps_of(r):
-    if r["flags"] & 1:
-        return []
+    if r["flags"] & 1:   # the last updates of the chain's own tiles
+        d = []
+        for a in range(r["k"], r["k"] + r["ti"]):
+            for b in range(r["k"], a + 1):
+                c = tot.get((a, b), 0)
+                if c and (a, b, c) in upd_by:
+                    d.append(("C(%d,%d)" % (a, b), upd_by[(a, b, c)]))
+        return d
     d = []
     if r["k"] in potrf_by:
         d.append(("L%d" % r["k"], potrf_by[r["k"]]))
@@ -65,7 +70,7 @@ print("  task      k  ti  tj  wg | deq   got  deps(wait) loaded solved product+t
 for r, name, dpub in path:
     hop = (r["deps"] - dpub) / 100.0 if dpub else 0.0
     print("  %4d %s %3d %3d %3d %3d | %6.1f %5.1f %6.1f %6.1f %6.1f %6.1f %7.1f | %-18s %8.1f %6.1f" % (
-        r["i"], "P" if r["flags"] & 1 else ("F" if (r["ti"] == r["tj"] and r["need"] + 1 == r["tot"]) else " "), r["k"], r["ti"], r["tj"], r["wg"],
+        r["i"], "C" if r["flags"] & 1 else ("x" if r["flags"] & 6 else " "), r["k"], r["ti"], r["tj"], r["wg"],
         us(r["deq"]), (r["got"] - r["deq"]) / 100.0, (r["deps"] - r["got"]) / 100.0 if r["deps"] else 0, (r["loaded"] - r["deps"]) / 100.0 if r["deps"] else 0,
         (r["solved"] - r["loaded"]) / 100.0 if r["loaded"] else 0, (r["updated"] - r["solved"]) / 100.0, (r["pub"] - r["updated"]) / 100.0, name,
         us(dpub) if dpub else 0, hop))
