@@ -86,6 +86,10 @@ BSG_CHAIN_DEV double elim_pivots(double (&ad)[16], double (&ab)[16], double d) {
   }
 }
 
+// workgroup barrier that orders LDS traffic only: global loads / stores issued before it stay in flight across it (__syncthreads()
+// waits for them: the chain's tile loads and the panels' stores would be paid at every step)
+BSG_CHAIN_DEV void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 BSG_CHAIN_DEV double2 lds_ld2(const double* p) { return *reinterpret_cast<const double2*>(p); }
 
 BSG_CHAIN_DEV void st16_wt(__amdgpu_buffer_rsrc_t r, unsigned byte_off, double2 d) {
@@ -186,14 +190,15 @@ struct ChainUpdater {
       stage<B, I + 1>(q, n);
     }
   }
-  template <int B> BSG_CHAIN_DEV void step(int q, int n) {
+  template <int B, class F> BSG_CHAIN_DEV void step(int q, int n, F& load_rest) {
     if constexpr (B < NCB) {
       if constexpr (B > 0) update_col<B - 1, B, 0>();   // phase A: column B takes its last update ...
       stage<B, 0>(q, n);                                 // ... and is staged
-      __syncthreads();
+      lds_sync();
+      if constexpr (B == 0) load_rest();                 // (the rest of the chain's tiles travel under the first elimination)
       if constexpr (B > 0) update_from<B - 1, B + 1>(); // phase B
-      __syncthreads();
-      step<B + 1>(q, n);
+      lds_sync();
+      step<B + 1>(q, n, load_rest);
     }
   }
 };
@@ -232,15 +237,17 @@ BSG_CHAIN_DEV void chain_update_waves(const ChainArgs& A, double* smem, int u, i
     }
     U.acc[SL::first(C) + I] = v;
   };
-  auto load_all = [&](auto self, auto Cc, auto Ic) {
-    constexpr int C = decltype(Cc)::value, I = decltype(Ic)::value;
-    if constexpr (C < NCB) {
-      if constexpr (I < SL::K(C)) { load_slot(Cc, Ic); self(self, Cc, std::integral_constant<int, I + 1>{}); }
-      else self(self, std::integral_constant<int, C + 1>{}, std::integral_constant<int, 0>{});
+  auto load_all = [&](auto self, auto Cc, auto Ic, auto Ce) {   // columns C .. CEND-1
+    constexpr int C = decltype(Cc)::value, I = decltype(Ic)::value, CEND = decltype(Ce)::value;
+    if constexpr (C < CEND) {
+      if constexpr (I < SL::K(C)) { load_slot(Cc, Ic); self(self, Cc, std::integral_constant<int, I + 1>{}, Ce); }
+      else self(self, std::integral_constant<int, C + 1>{}, std::integral_constant<int, 0>{}, Ce);
     }
   };
-  load_all(load_all, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-  U.template step<0>(q, n);
+  // column block 0 first: the first elimination only needs that one
+  load_all(load_all, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+  auto load_rest = [&]() { load_all(load_all, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, NCB>{}); };
+  U.template step<0>(q, n, load_rest);
 }
 
 template <bool PROBE>
@@ -290,7 +297,7 @@ BSG_CHAIN_DEV bool chain_factor(const ChainArgs& A, double* smem, long long* ts)
     for (int b = 0; b < NCB; ++b) {
       const int k = b >> 2, bq = b & 3;
       double* const P = (b & 1) ? Pbuf1 : Pbuf0;   // panel b
-      __syncthreads();
+      lds_sync();
       stamp();
       // phase B: row blocks b+1 .. NCB-1 of the chain, then the identity row blocks 0 .. bq; four per wave
       const int nc = NCB - 1 - b, nrb = nc + bq + 1;
@@ -322,7 +329,7 @@ BSG_CHAIN_DEV bool chain_factor(const ChainArgs& A, double* smem, long long* ts)
             *reinterpret_cast<double2*>(&P[(16 * b + n) * PP + 2 * c2]) = double2{(2 * c2 <= n) ? ad[2 * c2] : 0.0, (2 * c2 + 1 <= n) ? ad[2 * c2 + 1] : 0.0};
         }
       }
-      __syncthreads();
+      lds_sync();
       if (bq == 0 && b > 0 && tid == 0)   // (wave 3 drained the previous tile's stores before this barrier)
         __hip_atomic_store(&A.tile_flag[(size_t)(c0 + k - 1) * A.flag_stride], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       stamp();
@@ -352,13 +359,13 @@ BSG_CHAIN_DEV bool chain_factor(const ChainArgs& A, double* smem, long long* ts)
         if constexpr (BQ == 1) { w01 = wupd(w01, 0, 1); wstage(w01, 0); }
         if constexpr (BQ == 2) { w02 = wupd(w02, 0, 2); w12 = wupd(w12, 1, 2); wstage(w02, 0); wstage(w12, 1); }
         if constexpr (BQ == 3) { w03 = wupd(w03, 0, 3); w13 = wupd(w13, 1, 3); w23 = wupd(w23, 2, 3); wstage(w03, 0); wstage(w13, 1); wstage(w23, 2); }
-        __syncthreads();
+        lds_sync();
         // phase B: the live blocks take the update of panel b-1 (same tile); panel b-1 leaves
         if constexpr (BQ == 1) { w02 = wupd(w02, 0, 2); w03 = wupd(w03, 0, 3); }
         if constexpr (BQ == 2) { w03 = wupd(w03, 0, 3); w13 = wupd(w13, 1, 3); }
         if (b > 0) panel_out(b - 1, Pp, lane, 64);
         if (BQ == 0 && b > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the previous tile is out: the flag follows the barrier
-        __syncthreads();
+        lds_sync();
       };
       sub(std::integral_constant<int, 0>{}); sub(std::integral_constant<int, 1>{}); sub(std::integral_constant<int, 2>{}); sub(std::integral_constant<int, 3>{});
     }

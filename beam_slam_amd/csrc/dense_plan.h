@@ -347,6 +347,49 @@ struct DensePlan {
             }
           }
       }
+      // ---- ticket order: the list above is topological, but a chain sits behind EVERY update task of the depths below it, and a
+      // workgroup holds its CU from the moment it takes its ticket: hundreds of early tickets that can only wait would keep the next
+      // chain from even starting.  Re-order by the time a task can START — its dependencies' estimated finish times (list
+      // scheduling with nominal durations, unlimited workgroups) — which is again a topological order (a task starts after everything
+      // it waits for has finished), now one in which tickets are taken roughly when they can run.
+      {
+        const int nt = (int)ftasks.size();
+        const double dur_chain_tile = 11.0, dur_update = 8.0, dur_fetch = 5.0;   // microseconds, nominal
+        std::vector<double> fin_tile((size_t)N * N, 0.0), st_diag((size_t)N * N, 0.0), fin_potrf(N, 0.0), start(nt, 0.0);
+        for (int t = 0; t < nt; ++t) {   // (list order: every dependency of task t has been seen)
+          const FusedTask& f = ftasks[t];
+          if (f.flags & kFusedChain) {
+            double st = 0.0;
+            for (int i = 0; i < f.ti; ++i) for (int j = 0; j <= i; ++j) st = std::max(st, fin_tile[(size_t)(f.k + i) * N + f.k + j]);
+            start[t] = st;
+            for (int i = 0; i < f.ti; ++i) fin_potrf[f.k + i] = st + dur_chain_tile * (i + 1);
+          } else {
+            const bool diag = f.ti == f.tj;
+            double st = std::max(fin_potrf[f.k], fin_tile[(size_t)f.ti * N + f.k]);
+            if (!diag && !(f.flags & kFusedXjChain)) st = std::max(st, fin_tile[(size_t)f.tj * N + f.k]);
+            if (!diag) {   // (it may read what the diagonal tasks of its two tiles publish: it stays behind them)
+              st = std::max(st, st_diag[(size_t)f.ti * N + f.k]);
+              if (!(f.flags & kFusedXjChain)) st = std::max(st, st_diag[(size_t)f.tj * N + f.k]);
+            }
+            if (f.need_c >= 0) st = std::max(st, fin_tile[(size_t)f.ti * N + f.tj] - dur_update * 0.5);   // (the turn is only needed at the end)
+            start[t] = st;
+            const double fin = st + dur_update;
+            if (f.need_c >= 0) fin_tile[(size_t)f.ti * N + f.tj] = std::max(fin_tile[(size_t)f.ti * N + f.tj], fin);
+            if (diag) st_diag[(size_t)f.ti * N + f.k] = st;
+          }
+        }
+        (void)dur_fetch;
+        std::vector<int> ord(nt);
+        for (int t = 0; t < nt; ++t) ord[t] = t;
+        std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return start[x] < start[y]; });
+        // a stable sort by start time keeps every dependency in front: dep.finish <= start, dep.start < dep.finish; equal start times
+        // keep the list order.  The turns on a tile (need_c) follow the NEW order.
+        std::vector<FusedTask> nl(nt);
+        for (int t = 0; t < nt; ++t) nl[t] = ftasks[ord[t]];
+        std::fill(seen.begin(), seen.end(), 0);
+        for (FusedTask& f : nl) if (!(f.flags & kFusedChain) && f.need_c >= 0) f.need_c = seen[(size_t)f.ti * N + f.tj]++;
+        ftasks.swap(nl);
+      }
       static const bool fetch_x = !(getenv("BSGPU_CHOL_SOLVE_OWN") && atoi(getenv("BSGPU_CHOL_SOLVE_OWN")) != 0);
       for (FusedTask& f : ftasks) {
         if (f.flags & kFusedChain) continue;
