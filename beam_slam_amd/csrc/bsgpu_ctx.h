@@ -327,6 +327,7 @@ struct DenseDev {
   double* Winv = nullptr;   // per tile: the full inverse of its factor (written by the fused factorisation, read by the single-launch back-substitution)
   const int* bs_order = nullptr;   // ticket -> role of the single-launch back-substitution (DensePlan::bs_order)
   const int* tile_tot = nullptr;   // fused factorisation: update tasks per tile (DensePlan::tile_tot)
+  int rhs_rows = 0;                // rows of the rhs tile that are in use (the LM solve: 1); 0: every row may be
 };
 void dense_factor(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* scal);
 // (iperm / y_tan / delta given: the back-substitution also writes the solution in tangent order and the step -y)

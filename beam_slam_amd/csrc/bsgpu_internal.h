@@ -172,7 +172,7 @@ void launch_grad_norms_pose_diag(hipStream_t s, int nb, const int* blk_xoff, con
 struct PanelDesc;
 struct FusedTask;
 void launch_chol_fused(hipStream_t s, double* S, double* Lp, int ld, const FusedTask* tasks_dev, int n_tasks, const int* tile_tot_dev, const int* nreal_dev,
-                       double* Vinv, double* scal, int* sync_dev, double* Winv);
+                       double* Vinv, double* scal, int* sync_dev, double* Winv, int rhs_rows /* rows of the rhs tile in use; <= 0: all 64 */);
 void launch_chol_potrf_tiles(hipStream_t s, double* S, double* Lp, int ld, const int* tiles_dev, int n_tiles, const int* nreal_dev,
                              double* Vinv, double* scal);
 void launch_chol_panel_step(hipStream_t s, double* S, double* Lp, int ld, const PanelDesc* descs_dev, int n_panels, int max_rows,

@@ -233,7 +233,7 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
 void dense_factor(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* scal) {
   const int ld = P.npad;
   if (D.ftasks && D.fsync && D.tile_tot && D.Winv) {   // the whole factorisation in one launch
-    launch_chol_fused(s, S, D.Lp, ld, D.ftasks, (int)P.ftasks.size(), D.tile_tot, D.nreal, D.Vinv, scal, D.fsync, D.Winv);
+    launch_chol_fused(s, S, D.Lp, ld, D.ftasks, (int)P.ftasks.size(), D.tile_tot, D.nreal, D.Vinv, scal, D.fsync, D.Winv, D.rhs_rows);
     return;
   }
   for (int st = 0; st < P.n_steps(); ++st) {
@@ -296,7 +296,7 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
     const DenseDev D{c->d_perm, c->d_nreal, c->d_rows_flat, c->d_panels, c->d_Lp, c->d_Vinv,
                      c->d_bs_desc, c->d_chain_begin, c->d_chain_end, c->d_tile_sync, c->d_ftasks, c->d_fsync,
                      c->d_bs_desc_chain, c->d_rows_flat_chain, c->d_bs_upd, c->d_bs_upd_rows,
-                     c->d_bs_chain_group, c->d_bs_grp_nchains, c->d_bs_grp_nitems, c->d_bs_items4, c->d_bs_tile_updated, c->d_bs_sync, c->d_scal, c->d_Winv, c->d_bs_order, c->d_tile_tot};
+                     c->d_bs_chain_group, c->d_bs_grp_nchains, c->d_bs_grp_nitems, c->d_bs_items4, c->d_bs_tile_updated, c->d_bs_sync, c->d_scal, c->d_Winv, c->d_bs_order, c->d_tile_tot, 1};
     dense_factor(s, c->plan, D, c->d_S, c->d_scal);
     phase_mark(c, BSGPU_PHASE_FACTOR);
     dense_backsolve(s, c->plan, D, c->d_S, c->d_y, c->d_iperm, c->n_pose, c->d_ytan, c->d_delta);

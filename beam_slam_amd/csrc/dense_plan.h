@@ -381,7 +381,16 @@ struct DensePlan {
         (void)dur_fetch;
         std::vector<int> ord(nt);
         for (int t = 0; t < nt; ++t) ord[t] = t;
-        std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return start[x] < start[y]; });
+        // tasks that write a tile INSIDE a chain (what the next chain on the path waits for) take their tickets a little ahead of their
+        // turn: among tasks that become ready together they run first instead of queueing behind the hundreds whose results are needed
+        // later.  The head start is shorter than any task lasts, so a task still comes after everything it waits for.
+        std::vector<double> key(nt);
+        for (int t = 0; t < nt; ++t) {
+          const FusedTask& f = ftasks[t];
+          const bool into_chain = !(f.flags & kFusedChain) && f.ti < T && fchain_of_tile[f.ti] == fchain_of_tile[f.tj];
+          key[t] = start[t] - (into_chain ? 0.8 * dur_update : 0.0);
+        }
+        std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return key[x] < key[y]; });
         // a stable sort by start time keeps every dependency in front: dep.finish <= start, dep.start < dep.finish; equal start times
         // keep the list order.  The turns on a tile (need_c) follow the NEW order.
         std::vector<FusedTask> nl(nt);
@@ -400,7 +409,9 @@ struct DensePlan {
         // An off-diagonal task reads the X its diagonal tasks publish unless it is the one a chain is waiting for last: the final
         // update of a tile INSIDE a chain (then it solves its own strips and starts as soon as L_kk is out), or a task whose tj is
         // in the chain of k (its target is the panel tile of the chain's NEXT panels)
-        const bool last_of_chain_tile = f.ti < T && fchain_of_tile[f.ti] == fchain_of_tile[f.tj] && f.need_c + 1 == f.tot_c;
+        const int chk = fchain_of_tile[f.k];
+        const bool last_panel = f.k + 1 == fchain_begin[chk] + fchain_len[chk];   // (the last panels of BOTH sides of a separator finish together)
+        const bool last_of_chain_tile = f.ti < T && fchain_of_tile[f.ti] == fchain_of_tile[f.tj] && (f.need_c + 1 == f.tot_c || last_panel);
         if (last_of_chain_tile || (f.flags & kFusedXjChain)) continue;
         f.flags |= kFusedXiLp | kFusedXjLp;
       }

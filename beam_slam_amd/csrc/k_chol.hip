@@ -266,6 +266,8 @@ BSG_DEV void trsm_tile(double* sA, const double* sL, const double* sV, double* s
 // (K slice kk <-> register kk), so a solved block feeds the updates of the later blocks — and an updated block its own solve —
 // straight from registers; the A operands (V_b, -L_bc) are constants of the panel.  40 MFMAs per 16-row strip and no LDS round
 // trip between them (trsm_tile: a store / barrier / reload per block; 3.3 us per tile against 1.2 us, scripts/chol_probe.py).
+// (sV: block b at b * kVtPitch * 16, rows kVtPitch doubles apart: with 16 the sixteen lanes of a fragment read hit two banks)
+constexpr int kVtPitch = 18;
 BSG_DEV void trsm_tile_t(double* sA, const double* sL, const double* sV, int lane, int wave) {
   double* rows = sA + (16 * wave) * LDT;
   const int n = lane & 15, q = lane >> 4;
@@ -278,7 +280,7 @@ BSG_DEV void trsm_tile_t(double* sA, const double* sL, const double* sV, int lan
   for (int b = 0; b < 4; ++b) {
     double4_t y = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) y = __builtin_amdgcn_mfma_f64_16x16x4f64(sV[b * 256 + n * 16 + 4 * kk + q], acc[b][kk], y, 0, 0, 0);
+    for (int kk = 0; kk < 4; ++kk) y = __builtin_amdgcn_mfma_f64_16x16x4f64(sV[b * 16 * kVtPitch + n * kVtPitch + 4 * kk + q], acc[b][kk], y, 0, 0, 0);
 #pragma unroll
     for (int c = b + 1; c < 4; ++c)
 #pragma unroll
@@ -589,6 +591,7 @@ struct FusedCtx {
   const int* tile_tot;
   const int* nreal;
   int ld, n_vinv_tiles;
+  int rhs_strips;   // 16-row strips of the rhs tile that hold anything (1: the solve's single rhs row; 4: every row may be used)
   int *abort_w, *potrf_done, *upd;
   int fs;   // ints between two words of the sync area (a cache line apart: words of one line that different workgroups write or add to are
             // serialised at the memory side — measured on the PCG slots, k_pcg.hip — and the queue head / exit counter take ~2 000 atomics)
@@ -611,8 +614,8 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
   double* sXi = smem;                 // 64 x LDT
   double* sXj = sXi + NB * LDT;       // 64 x LDT
   double* sL = sXj + NB * LDT;        // 64 x LDT
-  double* sV = sL + NB * LDT;         // 4 x 256
-  int* s_ctl = reinterpret_cast<int*>(sV + 4 * 256);   // 4 ints
+  double* sV = sL + NB * LDT;         // 4 x 16 x kVtPitch
+  int* s_ctl = reinterpret_cast<int*>(sV + 4 * 16 * kVtPitch);   // 4 ints
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int N = ld / NB;
   const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(S, 0, (int)((size_t)ld * ld * sizeof(double)), 0x00020000);
@@ -629,6 +632,9 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
   const bool solve_j = !diag && !(tk.flags & (kFusedXjLp | kFusedXjChain));
   const bool need_L = solve_i || solve_j;
   const int ri = ti * NB, rj = tj * NB, c0 = k * NB;
+  // rows of the rhs tile (tile N-1 as row tile) beyond its used strips are zero and stay zero: no solve, no product, no traffic for them
+  const int strips_i = (ti == N - 1) ? __builtin_amdgcn_readfirstlane(C.rhs_strips) : 4;
+  const bool strip_on = rs < strips_i;
   double2 vXi[NQ], vL[NQ], vXj[NQ], vV[512 / NT];
   // The panel tiles first: they have usually had their last update long before L_kk is out, so their loads travel while the
   // workgroup waits for the factor; only L_kk and its block inverses are requested after it.  A strip that is not solved here is
@@ -645,7 +651,7 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
   __syncthreads();
   const bool c_pre = __builtin_amdgcn_readfirstlane(s_ctl[3]) != 0;
   double4_t cpre[TPW];
-  if (c_pre) {
+  if (c_pre && strip_on) {
 #pragma unroll
     for (int u = 0; u < TPW; ++u)
 #pragma unroll
@@ -698,16 +704,19 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
   }
   if (need_L) {
 #pragma unroll
-    for (int q = 0; q < 512 / NT; ++q) *reinterpret_cast<double2*>(&sV[(tid + NT * q) * 2]) = vV[q];
+    for (int q = 0; q < 512 / NT; ++q) {
+      const int i2 = (tid + NT * q) * 2;
+      *reinterpret_cast<double2*>(&sV[(i2 >> 8) * 16 * kVtPitch + ((i2 >> 4) & 15) * kVtPitch + (i2 & 15)]) = vV[q];
+    }
   }
   __syncthreads();
   stamp(3);
   if (need_L) {
     if (NT == 256) {
-      if (solve_i) trsm_tile_t(sXi, sL, sV, lane, wave);
+      if (solve_i && wave < strips_i) trsm_tile_t(sXi, sL, sV, lane, wave);
       if (solve_j) trsm_tile_t(sXj, sL, sV, lane, wave);
     } else {   // (waves 0-3: the strips of X_i; waves 4-7: those of X_j, at the same time)
-      if (wave < 4) { if (solve_i) trsm_tile_t(sXi, sL, sV, lane, wave); }
+      if (wave < 4) { if (solve_i && wave < strips_i) trsm_tile_t(sXi, sL, sV, lane, wave); }
       else if (solve_j) trsm_tile_t(sXj, sL, sV, lane, wave - 4);
     }
     __syncthreads();
@@ -723,13 +732,15 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
   if (do_update) {
     if (c_pre) {
       c_early = true;
+      if (strip_on) {
 #pragma unroll
-      for (int u = 0; u < TPW; ++u) acc[u] = cpre[u];
+        for (int u = 0; u < TPW; ++u) acc[u] = cpre[u];
+      }
     } else {
       if (tid == 0) s_ctl[3] = (ld_flag(&upd[(ti * N + tj) * fs]) >= tk.need_c) ? 1 : 0;
       __syncthreads();
       c_early = __builtin_amdgcn_readfirstlane(s_ctl[3]) != 0;
-      if (c_early) {
+      if (c_early && strip_on) {
 #pragma unroll
         for (int u = 0; u < TPW; ++u)
 #pragma unroll
@@ -737,26 +748,32 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
             acc[u][reg] = ld8_sc1(rS, (unsigned)(((size_t)(ri + 16 * rs + crow + 4 * reg) * ld + rj + 16 * (tt0 + u) + ccol) * sizeof(double)));
       }
     }
+    if (strip_on) {
 #pragma unroll
-    for (int u = 0; u < TPW; ++u)
-      acc[u] = mfma_abt<64>(acc[u], sXi + (16 * rs) * LDT, LDT, Xj + (16 * (tt0 + u)) * LDT, LDT, -1.0, lane);
+      for (int u = 0; u < TPW; ++u)
+        acc[u] = mfma_abt<64>(acc[u], sXi + (16 * rs) * LDT, LDT, Xj + (16 * (tt0 + u)) * LDT, LDT, -1.0, lane);
+    }
     if (!c_early) {
       // this task's turn on the tile: every earlier update of it has been published
       if (tid == 0) s_ctl[1] = wait_count(&upd[(ti * N + tj) * fs], tk.need_c, abort_w, deadline) ? 1 : 0;
       __syncthreads();
       if (__builtin_amdgcn_readfirstlane(s_ctl[1]) == 0) return false;
+      if (strip_on) {
+#pragma unroll
+        for (int u = 0; u < TPW; ++u)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg)
+            acc[u][reg] += ld8_sc1(rS, (unsigned)(((size_t)(ri + 16 * rs + crow + 4 * reg) * ld + rj + 16 * (tt0 + u) + ccol) * sizeof(double)));
+      }
+    }
+    stamp(5);
+    if (strip_on) {
 #pragma unroll
       for (int u = 0; u < TPW; ++u)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg)
-          acc[u][reg] += ld8_sc1(rS, (unsigned)(((size_t)(ri + 16 * rs + crow + 4 * reg) * ld + rj + 16 * (tt0 + u) + ccol) * sizeof(double)));
+          st8_sc1(rS, (unsigned)(((size_t)(ri + 16 * rs + crow + 4 * reg) * ld + rj + 16 * (tt0 + u) + ccol) * sizeof(double)), acc[u][reg]);
     }
-    stamp(5);
-#pragma unroll
-    for (int u = 0; u < TPW; ++u)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg)
-        st8_sc1(rS, (unsigned)(((size_t)(ri + 16 * rs + crow + 4 * reg) * ld + rj + 16 * (tt0 + u) + ccol) * sizeof(double)), acc[u][reg]);
   }
   if (tk.flags & kFusedPublishX) {
     // the L panel of this row tile: what the back-substitution reads, and what the off-diagonal tasks of this panel multiply with
@@ -819,14 +836,14 @@ BSG_DEV bool chol_fused_chain(const FusedCtx& C, int t, const FusedTask& tk, dou
 }
 
 constexpr int kFusedThreads = 512;
-constexpr size_t kFusedLds = sizeof(double) * (3 * NB * LDT + 4 * 256 + 8) > sizeof(double) * chain::chain_lds_doubles() ? sizeof(double) * (3 * NB * LDT + 4 * 256 + 8)
+constexpr size_t kFusedLds = sizeof(double) * (3 * NB * LDT + 4 * 16 * kVtPitch + 8) > sizeof(double) * chain::chain_lds_doubles() ? sizeof(double) * (3 * NB * LDT + 4 * 16 * kVtPitch + 8)
                                                                                                                    : sizeof(double) * chain::chain_lds_doubles();
 
 template <bool PROBE>
 __global__ __launch_bounds__(kFusedThreads) void chol_fused_kernel(double* __restrict__ S, double* __restrict__ Lp, int ld,
                                                                     const FusedTask* __restrict__ tasks, int n_tasks, const int* __restrict__ tile_tot,
                                                                     const int* __restrict__ nreal, double* __restrict__ Vinv,
-                                                                    double* __restrict__ scal, int* sync, double* Winv, int fs,
+                                                                    double* __restrict__ scal, int* sync, double* Winv, int fs, int rhs_strips,
                                                                     long long* probe_ts = nullptr /* PROBE: n_tasks x 8 wall-clock stamps */) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   __shared__ int s_head[4];
@@ -835,7 +852,7 @@ __global__ __launch_bounds__(kFusedThreads) void chol_fused_kernel(double* __res
   int* head = sync; int* abort_w = sync + fs; int* exited = sync + 2 * fs;   // (layout: [head | abort | exited | potrf_done (N) | update counts (N x N)] x fs ints)
   FusedCtx C;
   C.S = S; C.Lp = Lp; C.Vinv = Vinv; C.scal = scal; C.tasks = tasks; C.tile_tot = tile_tot; C.nreal = nreal; C.ld = ld; C.n_vinv_tiles = N - 1;
-  C.Winv = Winv;
+  C.Winv = Winv; C.rhs_strips = rhs_strips;
   C.abort_w = abort_w; C.potrf_done = sync + 3 * fs; C.upd = sync + (3 + N) * fs; C.fs = fs;
   C.deadline = (long long)wall_clock64() + kFusedTimeoutTicks;
   C.probe_ts = probe_ts;
@@ -875,7 +892,8 @@ int fused_sync_stride() {
 }
 
 void launch_chol_fused(hipStream_t s, double* S, double* Lp, int ld, const FusedTask* tasks_dev, int n_tasks, const int* tile_tot_dev, const int* nreal_dev,
-                       double* Vinv, double* scal, int* sync_dev, double* Winv) {
+                       double* Vinv, double* scal, int* sync_dev, double* Winv, int rhs_rows) {
+  const int rhs_strips = rhs_rows <= 0 ? 4 : std::min(4, (rhs_rows + 15) / 16);
   if (n_tasks <= 0) return;
   const int grid = n_tasks;   // one workgroup per task (about 100 KB of LDS each: one per CU is resident, the rest queue behind them)
   // BSGPU_CHOL_PROBE=<file>: the 20th factorisation of the process runs the stamped variant and dumps, per task, the wall-clock
@@ -889,7 +907,7 @@ void launch_chol_fused(hipStream_t s, double* S, double* Lp, int ld, const Fused
     if (hipMalloc((void**)&ts, sizeof(long long) * h.size()) == hipSuccess) {
       (void)hipMemset(ts, 0, sizeof(long long) * h.size());
       hipLaunchKernelGGL((chol_fused_kernel<true>), dim3(grid), dim3(kFusedThreads), kFusedLds, s, S, Lp, ld, tasks_dev, n_tasks, tile_tot_dev, nreal_dev, Vinv,
-                         scal, sync_dev, Winv, fused_sync_stride(), ts);
+                         scal, sync_dev, Winv, fused_sync_stride(), rhs_strips, ts);
       (void)hipStreamSynchronize(s);
       (void)hipMemcpy(h.data(), ts, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
       (void)hipMemcpy(ht.data(), tasks_dev, sizeof(FusedTask) * ht.size(), hipMemcpyDeviceToHost);
@@ -907,7 +925,7 @@ void launch_chol_fused(hipStream_t s, double* S, double* Lp, int ld, const Fused
     }
   }
   hipLaunchKernelGGL((chol_fused_kernel<false>), dim3(grid), dim3(kFusedThreads), kFusedLds, s, S, Lp, ld, tasks_dev, n_tasks, tile_tot_dev, nreal_dev, Vinv, scal,
-                     sync_dev, Winv, fused_sync_stride(), nullptr);
+                     sync_dev, Winv, fused_sync_stride(), rhs_strips, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------
