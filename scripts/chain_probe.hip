@@ -92,13 +92,17 @@ static int run(int m, int nreal_last, int reps) {
   }
   // W L_kk = I per tile
   double wmax = 0.0;
-  for (int k = 0; k < m; ++k)
+  for (int k = 0; k < m; ++k) {
+    double wk = 0.0; int wi = -1, wj = -1;
     for (int i = 0; i < 64; ++i) for (int j = 0; j < 64; ++j) {
       double s = 0.0;
       for (int t = 0; t < 64; ++t) s += hW[(size_t)k * 4096 + i * 64 + t] * ((t >= j) ? L[(size_t)(64 * k + t) * n + 64 * k + j] : 0.0);
+      if (std::fabs(s - (i == j ? 1.0 : 0.0)) > wk) { wk = std::fabs(s - (i == j ? 1.0 : 0.0)); wi = i; wj = j; }
       wmax = std::max(wmax, std::fabs(s - (i == j ? 1.0 : 0.0)));
       if (j > i && ((j >> 4) > (i >> 4)) && hW[(size_t)k * 4096 + i * 64 + j] != 0.0) wmax = std::max(wmax, 1.0);   // above the diagonal blocks: exactly zero
     }
+    if (wk > 1e-9) printf("   tile %d: max |W L - I| %.3e at (%d, %d)\n", k, wk, wi, wj);
+  }
   int flags_ok = 1;
   for (int k = 0; k < m; ++k) flags_ok &= hflag[16 * k] == 1;
   printf("MAXM %d NW %d m %d nreal_last %d: kernel %.2f us  max|L - ref| %.3e (max |L| %.3e)  max|W L - I| %.3e  bad %d flags %s\n", MAXM, NW, m, nreal_last, best * 1e3, emax, lmax,
