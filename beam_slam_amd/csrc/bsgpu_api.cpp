@@ -239,7 +239,10 @@ int bsgpu_sync_factors_indirect(bsgpu_ctx* c, int32_t type, int32_t n, const int
   // only the reprojection table is mirrored; the other types are a few thousand rows: copied in as before
   if (type != BSGPU_F_REPROJ) return bsgpu_add_factors_indirect(c, type, n, slot_idx, n_slots, slot_to_block, consts, loss_kind, loss_a);
   SlotMirror& m = c->mirror0;
-  const bool force_full = getenv("BSGPU_SYNC_FULL") != nullptr, check = getenv("BSGPU_SYNC_CHECK") != nullptr;
+  // the previous call's asynchronous copies read the mirror's host vectors (pageable memory), which are rewritten — and may be
+  // re-allocated — below: they must have left (the stream is idle between two cycles, this costs a few microseconds)
+  if (m.d_idx) { HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
+  static const bool force_full = getenv("BSGPU_SYNC_FULL") != nullptr, check = getenv("BSGPU_SYNC_CHECK") != nullptr;
   const bool full = n_changed < 0 || !m.valid || force_full;
   auto row_ok = [&](size_t r) {
     const int32_t* row = slot_idx + 4 * r;

@@ -546,6 +546,17 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
       if (it.iteration >= o.max_num_iterations) { msg = "Maximum number of iterations reached."; break; }
       if (it.step_is_successful && it.gradient_max_norm <= o.gradient_tolerance) { sum.termination_type = BSGPU_CONVERGENCE; msg = "Gradient tolerance reached."; break; }
       if (radius <= o.min_trust_region_radius) { sum.termination_type = BSGPU_CONVERGENCE; msg = "Minimum trust region radius reached."; break; }
+      if (c->h_scal[SC_CHOL_FAIL] == 2.0 && c->d_ftasks) {
+        // A wait inside one of the single-launch kernels (factorisation / back-substitution) timed out: the GPU is shared and their
+        // workgroups were not scheduled in time — not a numerical failure.  This context takes the launch-per-step path from
+        // here on, and the step is computed again at the same point and radius.
+        c->d_ftasks = nullptr;
+        if (getenv("BSGPU_TIMING")) fprintf(stderr, "[bsgpu] single-launch Cholesky timed out: launch-per-step path from here on\n");
+        run_step(c, o, STEP_REJECT, radius);
+        rc = fetch_scalars(c);
+        if (rc != BSGPU_OK) return rc;
+        continue;
+      }
       const bsgpu_iteration prev = it;
       std::memset(&it, 0, sizeof(it));
       it.iteration = prev.iteration + 1;

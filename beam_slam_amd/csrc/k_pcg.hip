@@ -12,6 +12,8 @@
 //   pcg_spmv            beta, stop test and p = z + beta p folded in; q = A p (one wave / block row), partials of p.q
 //   pcg_update          alpha from the partials; x += a p; r -= a q; z = M^-1 r; partials of r.z, r.r
 // HBM-bound: one PCG iteration streams the BSR values once (C4: 30 MB) plus six n-vectors.
+#include <atomic>
+
 #include "bsgpu_device.h"
 
 namespace bsg {
@@ -701,10 +703,14 @@ size_t pcg_persistent_slot_words(int G) { return 6 * (size_t)G * kPcgSlotStrideM
 bool launch_pcg_persistent(hipStream_t s, const PcgPersistDev& P, int nbr, const int* row_ptr, const double* val, const double* Minv, const double* b,
                            double* x, double* zg, double* sc, double tol2, int max_it) {
   const size_t lds = pcg_persistent_lds(P.max_cols);
-  static bool attr_set = false;
-  if (!attr_set) {
+  // (the attribute is per DEVICE: a context on a second GPU of the process needs it set there too)
+  static std::atomic<unsigned long long> attr_devices{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(attr_devices.load(std::memory_order_acquire) & bit)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(pcg_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pcg_persistent_lds_limit()) != hipSuccess) { (void)hipGetLastError(); return false; }
-    attr_set = true;
+    attr_devices.fetch_or(bit, std::memory_order_release);
   }
   if (lds > pcg_persistent_lds_limit() || P.G < 1 || P.G > 256) return false;
   static const int slot_stride = [] { const char* e = getenv("BSGPU_PCG_SLOT_STRIDE"); const int v = e ? atoi(e) : kPcgSlotStride; return (v >= 1 && v <= kPcgSlotStrideMax) ? v : kPcgSlotStride; }();

@@ -11,6 +11,7 @@
 // a sensor is a name + its ignition flag (registerSensorModel), the motion models are one callback (setMotionModelCallback,
 // [EXT] fuse_optimizers::Optimizer::applyMotionModels).  ROS timers / threads / services: the caller drives optimizeOnce().
 #pragma once
+#include <atomic>
 #include <deque>
 #include <mutex>
 
@@ -108,16 +109,19 @@ class FixedLagSmoother {
   void transactionCallback(const std::string& sensor_name, fuse_core::Transaction::SharedPtr transaction) {
     autostart();
     const fuse_core::Time max_time = transaction->maxStamp();
-    if (started_ && max_time < start_time_) return;                         // :552-561 before the start time: ignored
+    if (started_) {                                                          // :552-561 before the start time: ignored
+      std::lock_guard<std::mutex> tl(start_time_mutex_);
+      if (max_time < start_time_) return;
+    }
     std::lock_guard<std::mutex> lock(pending_transactions_mutex_);
     auto pos = std::upper_bound(pending_.begin(), pending_.end(), transaction->stamp(),
                                 [](const fuse_core::Time& s, const Pending& p) { return s < p.transaction->stamp(); });
     pos = pending_.insert(pos, Pending{sensor_name, std::move(transaction)});
     if (started_) return;
     if (isIgnition(sensor_name)) {                                           // :584-611
+      const fuse_core::Time min_time = pos->transaction->minStamp();
+      { std::lock_guard<std::mutex> tl(start_time_mutex_); start_time_ = min_time; }
       started_ = true; ignited_ = true;
-      start_time_ = pos->transaction->minStamp();
-      const fuse_core::Time min_time = start_time_;
       pending_.erase(std::remove_if(pending_.begin(), pending_.end(),
                                     [&](const Pending& p) {
                                       return p.sensor_name != sensor_name &&
@@ -217,7 +221,8 @@ class FixedLagSmoother {
     std::lock_guard<std::mutex> lock(optimization_mutex_);
     std::lock_guard<std::mutex> qlock(pending_transactions_mutex_);
     pending_.clear(); graph_->clear(); timestamp_tracking_ = VariableStampIndex(); marginal_transaction_ = fuse_core::Transaction();
-    started_ = false; ignited_ = false; lag_expiration_ = fuse_core::Time(); start_time_ = fuse_core::Time();
+    started_ = false; ignited_ = false; lag_expiration_ = fuse_core::Time();
+    { std::lock_guard<std::mutex> tl(start_time_mutex_); start_time_ = fuse_core::Time(); }
   }
 
   // fixed_lag_smoother.cpp:335-477
@@ -291,6 +296,7 @@ class FixedLagSmoother {
   struct Pending { std::string sensor_name; fuse_core::Transaction::SharedPtr transaction; };
   fuse_core::Time computeLagExpirationTime() const {   // :141-149
     const fuse_core::Time now = timestamp_tracking_.currentStamp();
+    std::lock_guard<std::mutex> tl(start_time_mutex_);
     return (start_time_ + params_.lag_duration < now) ? now + (-params_.lag_duration) : start_time_;
   }
   static fuse_core::Transaction dedup(const fuse_core::Transaction& t) {
@@ -306,7 +312,8 @@ class FixedLagSmoother {
   void autostart() {   // :125-137: no ignition sensor configured -> start immediately, start time 0
     if (started_) return;
     for (const auto& kv : sensor_models_) if (kv.second) return;
-    started_ = true; start_time_ = fuse_core::Time();
+    { std::lock_guard<std::mutex> tl(start_time_mutex_); start_time_ = fuse_core::Time(); }
+    started_ = true;
   }
   GpuGraph::UniquePtr graph_;
   NotifyCallback notify_;
@@ -320,8 +327,9 @@ class FixedLagSmoother {
   std::deque<Pending> pending_;
   VariableStampIndex timestamp_tracking_;
   fuse_core::Transaction marginal_transaction_;
-  fuse_core::Time lag_expiration_, start_time_;
-  bool started_ = false;
+  fuse_core::Time lag_expiration_, start_time_;   // start_time_: under start_time_mutex_ (the reference's start_time_mutex_)
+  mutable std::mutex start_time_mutex_;
+  std::atomic<bool> started_{false};   // (set by sensor threads in transactionCallback, read by the optimisation thread: the reference's std::atomic<bool>)
   ceres_compat::SolverSummary summary_;
   int num_cycles_ = 0, num_dropped_constraints_ = 0;
   std::string last_error_;

@@ -312,10 +312,6 @@ int bsgpu_sync_factors_indirect(bsgpu_ctx* ctx, int32_t type, int32_t n, const i
                                 const int32_t* slot_to_block, const double* consts, const int32_t* loss_kind,
                                 const double* loss_a, int32_t n_changed, const int32_t* changed_rows);
 
-/* ---- solve ----------------------------------------------------------------- */
-/* Uploads / builds the device-side structure (sorted factor tables, CSR of the
- * reduced system).  Called implicitly by bsgpu_solve when the problem changed;
- * exposed so a caller can keep it out of a timed region.                        */
 /* Dense linear prior: [EXT] fuse_constraints::MarginalConstraint, what fuse_constraints::marginalizeVariables
  * adds to the graph (bs_optimizers/src/fixed_lag_smoother.cpp:270-271, `pseudo_marginalization: false`):
  *     r = b + sum_i A_i (x_i [-] xbar_i),    [-] = LocalParameterization::Minus(xbar_i, x_i)
@@ -328,6 +324,12 @@ int bsgpu_sync_factors_indirect(bsgpu_ctx* ctx, int32_t type, int32_t n, const i
  * insertion order.  Blocks it touches are never Schur-eliminated.                                            */
 int bsgpu_add_marginal(bsgpu_ctx* ctx, int32_t n_blocks, const int32_t* blocks, int32_t n_rows,
                        const double* A, const double* b, const double* xbar);
+
+/* ---- solve ----------------------------------------------------------------- */
+/* Uploads / builds the device-side structure (sorted factor tables, the tile plan of the
+ * reduced system): what [EXT] fuse_core::Graph::optimize does in HashGraph::createProblem
+ * before ceres::Solve (bs_optimizers/src/fixed_lag_smoother.cpp:281).  Called implicitly by
+ * bsgpu_solve when the problem changed; exposed so a caller can keep it out of a timed region. */
 int bsgpu_finalize(bsgpu_ctx* ctx);
 
 /* Levenberg-Marquardt (Ceres TrustRegionMinimizer semantics) on the device.
