@@ -393,3 +393,62 @@ def test_reprojection_error_screening(oracle_cls, gpu_solver_cls):
     w = np.concatenate([np.concatenate([c[1][:, 2] for c in pr.factors[t]]) for t in (capi.F_REPROJ, capi.F_REPROJ_ONLINE_CALIB) if t in pr.factors])
     expect = np.linalg.norm(r[:2 * (n0 + n1)].reshape(-1, 2), axis=1) / w            # trivial loss: r = w (z - u)
     assert np.abs(err - expect).max() <= 1e-9 * max(1.0, expect.max())
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_imu_process_noise_with_pose_priors(oracle_cls, gpu_solver_cls, seed):
+    """bs_models/tests/imu_preintegration_tests.cpp:931-1049 (ImuPreintegration_ProccessNoiseConstantBias.MultipleTransactionsPosePriors)
+    as a property through the product path: IMU samples with constant biases AND white noise (EuRoC: gyro 0.0447, accel 0.0130 per
+    sample, :804-808), a key frame every second, each with a prior on its ground-truth pose (covariance 0.1 I, :987) and the
+    pre-integrated factor from the previous one (bsgpu_preintegrate; the reference's Params covariances stay at identity — the
+    `setIdentity() * x` of :784-787 discards the product); the graph is optimised after every key frame (:1016) and the optimised
+    states must be within the reference's tol {0.05, 0.05, 0.05, 0.01, 0.01} (:827, test_utils.h:55-75) of the ground truth."""
+    from beam_slam_amd import gpu
+    from test_oracle_reference_kats import imu_ground_truth, predict_state
+    from beam_slam_amd.synthetic import rot_to_quat, sqrt_information_upper
+    from beam_slam_amd.problem import Problem
+    rng = np.random.default_rng(seed)
+    bg, ba = rng.uniform(-1, 1, 3) / 100, rng.uniform(-1, 1, 3) / 10          # :780-781
+    T_END, RATE = 8, 100.0
+    traj, t, w, a = imu_ground_truth(RATE, float(T_END), bg, ba)
+    w = w + rng.normal(0.0, 0.044721359, w.shape)
+    a = a + rng.normal(0.0, 0.013026127, a.shape)
+    per = int(RATE)
+    first = np.arange(0, T_END + 1) * per
+    pre_all = gpu.preintegrate(first.astype(np.int32), t, w, a, np.arange(1.0, T_END + 1), np.tile(bg, (T_END, 1)), np.tile(ba, (T_END, 1)),
+                               1.0, 1.0, 1.0, 1.0)
+    pr = Problem()
+    q0, p0, v0 = rot_to_quat(traj.rot(0.0)), traj.pos(0.0), traj.vel(0.0)
+    states = [[pr.add_quat(q0), pr.add_block(p0), pr.add_block(v0), pr.add_block(bg), pr.add_block(ba)]]
+    mean = np.concatenate([pr.block(b) for b in states[0]])
+    pr.add_factors(capi.F_IMU_PRIOR, [states[0]], [np.concatenate([mean, sqrt_information_upper(1e-9 * np.eye(15)).ravel()])])   # imu_preintegration.h:36
+    A_pose = sqrt_information_upper(0.1 * np.eye(6))
+    g, o = gpu_solver_cls(0), oracle_cls()
+    q, p, v = q0, p0, v0
+    for k in range(1, T_END + 1):
+        pre = synthetic.PreIntegrator(1.0, 1.0, 1.0, 1.0)
+        pre.t, pre.q, pre.p, pre.v = pre_all[k - 1, 0], pre_all[k - 1, 1:5], pre_all[k - 1, 5:8], pre_all[k - 1, 8:11]
+        q, p, v = predict_state(pre, q, p, v)                                   # the predicted state is the new key frame's initial value (:1011)
+        s = [pr.add_quat(q), pr.add_block(p), pr.add_block(v), pr.add_block(bg), pr.add_block(ba)]
+        pr.add_factors(capi.F_IMU_DELTA, [states[-1] + s], [pre_all[k - 1]])
+        b = np.concatenate([traj.pos(float(k)), rot_to_quat(traj.rot(float(k)))])
+        pr.add_factors(capi.F_ABSPOSE, [[s[1], s[0]]], [np.concatenate([b, A_pose.ravel()])])
+        states.append(s)
+        pr.load(g)
+        sg = g.solve()
+        assert sg.is_solution_usable == 1
+        x = g.get_blocks()
+        pr.values = x                                                           # graph.optimize() writes the variables back
+        q, p, v = pr.block(s[0]), pr.block(s[1]), pr.block(s[2])
+    x = g.get_blocks()
+    for k, s in enumerate(states):
+        qt = rot_to_quat(traj.rot(float(k)))
+        qk = pr.block(s[0], x)
+        assert np.abs(qk * np.sign(qk @ qt) - qt).max() < 0.05
+        assert np.abs(pr.block(s[1], x) - traj.pos(float(k))).max() < 0.05
+        assert np.abs(pr.block(s[2], x) - traj.vel(float(k))).max() < 0.05
+        assert np.abs(pr.block(s[3], x) - bg).max() < 0.01 and np.abs(pr.block(s[4], x) - ba).max() < 0.01
+    # the same final graph through the oracle (from the values the last solve started at): same optimum
+    pr.load(o)
+    so = o.solve()
+    assert abs(sg.final_cost - so.final_cost) <= 1e-6 * so.final_cost + 1e-9
