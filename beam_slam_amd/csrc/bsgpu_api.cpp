@@ -856,6 +856,47 @@ double bsgpu_time_reproj_jacobian_ms(bsgpu_ctx* c, int32_t reps) {
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return (double)ms / reps;
 }
+// Residuals + Jacobians of EVERY factor type at the current values, `reps` times between two HIP events on the solver's stream
+// (what an LM iteration starts with; the measurement behind the evaluation roofline of windows without reprojection factors).
+double bsgpu_time_eval_ms(bsgpu_ctx* c, int32_t reps) {
+  if (!c) return -1.0;
+  if (finalize(c) != BSGPU_OK || reps <= 0) return -1.0;
+  if (hipSetDevice(c->device) != hipSuccess) return -1.0;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.0;
+  eval_all(c, c->d_x, true, SC_COST_X);   // warm
+  (void)hipEventRecord(e0, c->stream);
+  for (int i = 0; i < reps; ++i) eval_all(c, c->d_x, true, SC_COST_X);
+  (void)hipEventRecord(e1, c->stream);
+  if (hipEventSynchronize(e1) != hipSuccess) return -1.0;
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  c->spec_J = false;
+  return (double)ms / reps;
+}
+// ... and its algorithmic bytes: per factor indices + constants in, residual + tangent Jacobian out; every
+// parameter block once
+int64_t bsgpu_eval_bytes(const bsgpu_ctx* c) {
+  if (!c) return -1;
+  // (idx, consts, residuals, tangent Jacobian columns) per type, in doubles / ints as the tables hold them
+  static const struct { int idx, consts, res, jcols; } L[BSGPU_F_NUM_TYPES] = {
+      {4, 3, 2, 9}, {6, 3, 2, 9}, {10, 287, 15, 30}, {5, 241, 15, 15}, {6, 43, 6, 12}, {4, 43, 6, 12}, {2, 43, 6, 6}, {1, 12, 3, 3},
+      {2, 12, 3, 6}, {1, 7, 2, 3}, {6, 6, 2, 13}, {4, 6, 2, 7}};
+  int64_t b = (int64_t)c->vis.n * 200 + (int64_t)c->h_x.size() * 8;
+  for (int t = 2; t < BSGPU_F_NUM_TYPES && t < kNumInternal; ++t)
+    b += (int64_t)c->small[t].n * (4 * L[t].idx + 8 * (L[t].consts + L[t].res + L[t].res * L[t].jcols));
+  return b;
+}
+// block-sparse PCG path (pose graphs above the dense limit): block rows and non-zero 3x3 blocks of J^T J (0, 0 on the dense path)
+int bsgpu_bsr_info(bsgpu_ctx* c, int32_t* block_rows, int32_t* nnz_blocks) try {
+  if (!c) return BSGPU_ERR_INVALID;
+  const int rc = finalize(c);
+  if (rc != BSGPU_OK) return rc;
+  if (block_rows) *block_rows = c->use_pcg ? c->nbr : 0;
+  if (nnz_blocks) *nnz_blocks = c->use_pcg ? c->nblk : 0;
+  return BSGPU_OK;
+} catch (...) { return api_exception(c); }
 int bsgpu_profile_step(bsgpu_ctx* c, const bsgpu_options* o, int32_t reps, double* ms_out, double* work_out) try {
   if (!c) return BSGPU_ERR_INVALID;
   if (!o || !ms_out || reps <= 0) return fail(c, BSGPU_ERR_INVALID, "profile_step: bad argument");

@@ -27,6 +27,10 @@ def lib():
         _LIB = ctypes.CDLL(LIB_PATH)
         _LIB.bsgpu_time_reproj_jacobian_ms.restype = ctypes.c_double
         _LIB.bsgpu_time_reproj_jacobian_ms.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+        _LIB.bsgpu_time_eval_ms.restype = ctypes.c_double
+        _LIB.bsgpu_time_eval_ms.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+        _LIB.bsgpu_eval_bytes.restype = ctypes.c_int64
+        _LIB.bsgpu_eval_bytes.argtypes = [ctypes.c_void_p]
         _LIB.bsgpu_reproj_jacobian_bytes.restype = ctypes.c_int64
         _LIB.bsgpu_reproj_jacobian_bytes.argtypes = [ctypes.c_void_p]
         _LIB.bsgpu_dense_solve.argtypes = [ctypes.c_int, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
@@ -101,6 +105,22 @@ class GpuSolver(capi.Solver):
         if ms < 0:
             raise capi.SolverError(capi.ERR_DEVICE, "bsgpu_time_reproj_jacobian_ms failed")
         return ms
+
+    def time_eval_ms(self, reps=20):
+        """Mean milliseconds of one evaluation of residuals + Jacobians of every factor type (HIP events on the solver's stream)."""
+        ms = lib().bsgpu_time_eval_ms(self._ctx, int(reps))
+        if ms < 0:
+            raise capi.SolverError(capi.ERR_DEVICE, "bsgpu_time_eval_ms failed")
+        return ms
+
+    def eval_bytes(self):
+        return lib().bsgpu_eval_bytes(self._ctx)
+
+    def bsr_info(self):
+        """(block rows, non-zero 3x3 blocks) of the block-sparse PCG path; (0, 0) on the dense Schur path."""
+        a, b = ctypes.c_int32(0), ctypes.c_int32(0)
+        self._chk(lib().bsgpu_bsr_info(ctypes.c_void_p(self._ctx), ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
 
     PHASES = ("eval_reproj", "eval_other", "landmark", "pairs", "assemble_other", "factor", "backsolve", "backsub", "candidate")
 

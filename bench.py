@@ -33,6 +33,31 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 HBM_COPY_GBS = 6290.0      # ... measured copy peak (the achievable streaming rate)
 MFMA_F64_PEAK_TF = 78.6    # ... dense FP64 MFMA (v_mfma_f64_16x16x4_f64: 64 cycles / instruction / SIMD)
+MFMA_NOTE = ("latency-bound, not MFMA-bound: the critical path is the pivot chain of the chains on it (a leaf piece + one separator per "
+             "level, 16 pivots at a time inside one workgroup: chol_chain.h) plus one hand-over per level; DESIGN.md 3.2")
+
+
+def _attach_traffic(roofline, csv_name, kernel_prefix, nbytes):
+    """HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the gfx950 correction of
+    MI355X_MICROARCH.md; bench.py itself cannot collect counters).  The CSV row carries the algorithmic byte count the pass was
+    taken at: a different count now means the kernel or the workload changed, and the stale figure is not reported."""
+    import csv
+    pmc = os.path.join(ROOT, "profiles", csv_name)
+    if not os.path.exists(pmc):
+        return
+    for row in csv.reader(open(pmc)):
+        if row and kernel_prefix in row[0] and len(row) >= 4:
+            try:
+                fetch_kb, write_kb = float(row[2]), float(row[3])
+                recorded = int(float(row[4])) if len(row) >= 5 and row[4] else None
+            except ValueError:
+                continue
+            if recorded is not None and abs(recorded - nbytes) > 0.01 * nbytes:
+                roofline["traffic_stale"] = "profiles/%s was taken at %d algorithmic bytes per launch, this run moves %d" % (csv_name, recorded, int(nbytes))
+                return
+            roofline["traffic"] = int((2.0 * fetch_kb + write_kb) * 1024)
+            roofline["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % csv_name
+            return
 
 
 def main():
@@ -120,9 +145,31 @@ def main():
         # (bsgpu_profile_step); the kernel-trace average of the same kernels is in profiles/r02_*_kernel_stats.csv
         has_vis = pr.n_factors(0) > 0
         roofline = roofline_mfma = kernels = phases = None
-        if args.workload == "c3":          # no visual factors: phases and the factorisation's figure only
+        if args.workload in ("c3", "c4"):
+            # no reprojection factors: the roofline is that of the relative-pose evaluation (~990 B per factor),
+            # timed with HIP events on the solver's stream (20 back-to-back evaluations of every factor type of the window)
+            ms_e, nb_e = g.time_eval_ms(20), g.eval_bytes()
+            ach = nb_e / (ms_e * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": "relpose_kernel (+ imu_eval_kernel / abspose_kernel)", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "bytes_per_launch": int(nb_e), "ms_per_launch": round(ms_e, 5),
+                        "timing": "20 back-to-back evaluations (residuals + Jacobians of every factor type) between two HIP events on the solver's stream",
+                        "working_set_mb": round(nb_e / 1e6, 1), "cache_residency": "below the 256 MiB Infinity Cache", "traffic": None}
+            _attach_traffic(roofline, "r03_%s_pmc_hbm.csv" % args.workload, "relpose_kernel", nb_e)
+        if args.workload == "c3":          # dense Schur path without landmarks: phases and the factorisation's figure
             prof = g.profile_step(opt, reps=20)
             phases = {k: round(1e3 * v[0], 2) for k, v in prof.items()}
+            ms_f, flops = prof["factor"]
+            tf = flops / (ms_f * 1e-3) / 1e12
+            roofline_mfma = {"bound": "mfma", "kernel": "chol_fused_kernel (+ chol_backsolve_fused_kernel: %.1f us)" % (1e3 * prof["backsolve"][0]),
+                             "achieved": round(tf, 3), "peak": MFMA_F64_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F64_PEAK_TF, 4),
+                             "flops_per_launch": int(flops), "ms_per_launch": round(ms_f, 5), "note": MFMA_NOTE}
+            kernels = []
+        if args.workload == "c4":          # block-sparse PCG path: what an inner iteration moves
+            nbr, nnzb = g.bsr_info()
+            it_bytes = nnzb * (72 + 4) + 6 * 3 * nbr * 8      # the 3x3 blocks + their column indices, and x, r, p, q, z, M^-1 once each
+            pcg = {"block_rows": nbr, "nnz_blocks_3x3": nnzb, "bytes_per_inner_iteration": int(it_bytes),
+                   "inner_iterations_per_solve": int(s.num_inner_iterations),
+                   "note": "pcg_persistent_kernel keeps its blocks in registers: an inner iteration is latency (two cross-XCD reductions), not bandwidth"}
         if has_vis and not (args.workload == "c4"):
             prof = g.profile_step(opt, reps=20)
             phases = {k: round(1e3 * v[0], 2) for k, v in prof.items()}          # microseconds per LM step
@@ -136,23 +183,14 @@ def main():
                         "working_set_mb": round(working_set_mb, 1),
                         "cache_residency": "below the 256 MiB Infinity Cache: the stream is MALL/fabric traffic, see past_l3" if working_set_mb < 256 else "above the 256 MiB Infinity Cache",
                         "traffic": None}
-            # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the gfx950 correction of
-            # MI355X_MICROARCH.md); bench.py itself cannot collect counters
-            pmc = os.path.join(ROOT, "profiles", "r02_c2_pmc_hbm.csv")
-            if not os.path.exists(pmc):
-                pmc = os.path.join(ROOT, "profiles", "r01_c2_pmc_hbm.csv")
-            if world == 1 and args.workload == "c2" and args.n_kf == 200 and args.n_lm == 50000 and os.path.exists(pmc):
-                import csv
-                for row in csv.reader(open(pmc)):
-                    if row and row[0].startswith("void bsg::reproj_eval_kernel<true>"):
-                        roofline["traffic"] = int((2.0 * float(row[2]) + float(row[3])) * 1024)
-                        roofline["traffic_source"] = os.path.relpath(pmc, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+            if world == 1 and args.workload == "c2" and args.n_kf == 200 and args.n_lm == 50000:
+                _attach_traffic(roofline, "r03_c2_pmc_hbm.csv", "reproj_eval_kernel<true>", nbytes)
             ms_f, flops = prof["factor"]
             tf = flops / (ms_f * 1e-3) / 1e12
             roofline_mfma = {"bound": "mfma", "kernel": "chol_fused_kernel (+ chol_backsolve_fused_kernel: %.1f us)" % (1e3 * prof["backsolve"][0]),
                              "achieved": round(tf, 3), "peak": MFMA_F64_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F64_PEAK_TF, 4),
                              "flops_per_launch": int(flops), "ms_per_launch": round(ms_f, 5),
-                             "note": "dependent chain of ~13 panel steps (64-pivot scalar chain each): latency-bound, not MFMA-bound; DESIGN.md §3.2"}
+                             "note": MFMA_NOTE}
             kernels = []
             for name, kern in (("landmark", "landmark_kernel (+ clear)"), ("pairs", "pairs_kernel"), ("backsub", "backsub_mcc_kernel (+ small_mcc)"),
                                ("candidate", "update + reproj_eval_kernel<false> + reduction")):
@@ -198,10 +236,13 @@ def main():
             out["phases_us_per_lm_step"] = phases
         if roofline_mfma:
             out["roofline_mfma"] = roofline_mfma
-            out["kernels"] = kernels
+            if kernels:
+                out["kernels"] = kernels
             out["phases_us_per_lm_step"] = phases
+        if args.workload == "c4":
+            out["pcg"] = pcg
         # ---- CPU baseline: the oracle on the same window (bounded: one solve, same options) ------
-        if world == 1 and not args.no_cpu_baseline and args.workload != "c4":
+        if world == 1 and not args.no_cpu_baseline and args.workload != "c4":   # (C4 at full size: the oracle's dense solve does not finish in bench time)
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             from oracle import Oracle
             o = Oracle()

@@ -422,6 +422,14 @@ int bsgpu_triangulate(bsgpu_ctx* ctx, int32_t n_tracks, const int32_t* track_sta
  * times on the context's stream between two HIP events and returns the average
  * milliseconds per launch (<0 on error).                                        */
 double bsgpu_time_reproj_jacobian_ms(bsgpu_ctx* ctx, int32_t reps);
+/* The same for EVERY factor type of the problem (reprojection, IMU, relative / absolute pose, priors): mean milliseconds of one
+ * evaluation of residuals + Jacobians at the current values, and the algorithmic bytes of that evaluation (SURVEY.md 8(d):
+ * 196-200 B per reprojection factor, ~990 B per relative-pose factor, ~6.1 KB per IMU factor).  Measurement hooks: what
+ * CostFunction::Evaluate costs per LM iteration ([EXT] ceres::Problem::Evaluate inside fixed_lag_smoother.cpp:281).        */
+double bsgpu_time_eval_ms(bsgpu_ctx* ctx, int32_t reps);
+int64_t bsgpu_eval_bytes(const bsgpu_ctx* ctx);
+/* Block rows and non-zero 3x3 blocks of the block-sparse J^T J of the PCG path (both 0 on the dense Schur path).           */
+int bsgpu_bsr_info(bsgpu_ctx* ctx, int32_t* block_rows, int32_t* nnz_blocks);
 /* Algorithmic bytes one launch of that kernel moves. */
 int64_t bsgpu_reproj_jacobian_bytes(const bsgpu_ctx* ctx);
 /* Measurement: the phases of a full LM step timed IN SITU — `reps` steps exactly as bsgpu_solve enqueues them for an accepted step

@@ -1,10 +1,10 @@
 #!/bin/bash
-# rocprofv3 evidence for one round, run on the GPU box:   bash scripts/profile_all.sh r02
+# rocprofv3 evidence for one round, run on the GPU box:   bash scripts/profile_all.sh r03
 #   kernel-trace + stats for C2 / C3 / C4 (same command as the bench line, without the CPU baseline leg)
-#   PMC passes for C2, each in its OWN run with --kernel-trace only: HBM traffic (FETCH_SIZE, WRITE_SIZE) and MFMA utilisation
-#   (SQ_INSTS_VALU_MFMA_MOPS_F64, SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CYCLES / GRBM_GUI_ACTIVE where the counter exists)
+#   PMC passes, each in its OWN run with --kernel-trace only: HBM traffic (FETCH_SIZE, WRITE_SIZE) for C2 / C3 / C4 and for the
+#   past-the-Infinity-Cache window; MFMA utilisation (SQ_INSTS_VALU_MFMA_MOPS_F64, SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE ...) for C2 / C3
 # Summaries land in gpurun_out/prof_<round>/; the ones to be judged are copied to profiles/ by hand.
-ROUND=${1:-r02}
+ROUND=${1:-r03}
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$ROOT/gpurun_out/prof_$ROUND"
 mkdir -p "$OUT"
@@ -15,39 +15,71 @@ for w in c2 c3 c4; do
   f=$(find /tmp/kt_$w -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" "$OUT/${ROUND}_${w}_kernel_stats.csv"
 done
-for c in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE; do
-  rm -rf /tmp/pmc_$c
-  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o p -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-past-l3 > "$OUT/pmc_$c.log" 2>&1
+pmc() {   # pmc <tag> <counter> <command...>
+  local tag=$1 c=$2; shift 2
+  rm -rf /tmp/pmc_${tag}_$c
+  timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_${tag}_$c -o p -- "$@" > "$OUT/pmc_${tag}_$c.log" 2>&1
+}
+for w in c2 c3 c4; do
+  for c in FETCH_SIZE WRITE_SIZE; do pmc $w $c python "$ROOT/bench.py" --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-past-l3; done
+done
+for c in FETCH_SIZE WRITE_SIZE; do pmc pastl3 $c python "$ROOT/scripts/past_l3.py"; done
+for w in c2 c3; do
+  for c in SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE; do
+    pmc $w $c python "$ROOT/bench.py" --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-past-l3
+  done
 done
 python - "$OUT" "$ROUND" <<'PY'
-import csv, sys, collections, glob
+import csv, sys, collections, glob, json, os
 out, rnd = sys.argv[1], sys.argv[2]
-cs = ["FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU_MFMA_MOPS_F64", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"]
-acc = {c: collections.defaultdict(float) for c in cs}
-cnt = {c: collections.Counter() for c in cs}
-for c in cs:
-    fs = glob.glob("/tmp/pmc_%s/**/*counter_collection.csv" % c, recursive=True)
-    if not fs:
-        continue
-    for r in csv.DictReader(open(fs[0])):
-        if r["Counter_Name"] != c:
+def collect(tag, counters):
+    acc = {c: collections.defaultdict(float) for c in counters}
+    cnt = {c: collections.Counter() for c in counters}
+    for c in counters:
+        fs = glob.glob("/tmp/pmc_%s_%s/**/*counter_collection.csv" % (tag, c), recursive=True)
+        if not fs:
             continue
-        k = r["Kernel_Name"].split("(")[0]
-        acc[c][k] += float(r["Counter_Value"]); cnt[c][k] += 1
-keys = sorted(set(k for c in cs for k in acc[c]), key=lambda k: -(acc["FETCH_SIZE"].get(k, 0) + acc["WRITE_SIZE"].get(k, 0)))
-with open("%s/%s_c2_pmc_hbm.csv" % (out, rnd), "w") as f:
-    f.write("Kernel,Launches,avg_FETCH_SIZE_raw_KB,avg_WRITE_SIZE_raw_KB,note: gfx950 FETCH_SIZE reads 1/2 of a wide coalesced stream (MI355X_MICROARCH.md HBM section)\n")
-    for k in keys:
-        n = cnt["FETCH_SIZE"][k]
-        if n and k.strip():
-            f.write('"%s",%d,%.1f,%.1f\n' % (k, n, acc["FETCH_SIZE"][k] / n, acc["WRITE_SIZE"].get(k, 0.0) / max(1, cnt["WRITE_SIZE"][k])))
-with open("%s/%s_c2_pmc_mfma.csv" % (out, rnd), "w") as f:
-    f.write("Kernel,Launches,avg_SQ_INSTS_VALU_MFMA_MOPS_F64,avg_SQ_VALU_MFMA_BUSY_CYCLES,avg_SQ_BUSY_CYCLES,avg_SQ_INSTS_VALU,avg_GRBM_GUI_ACTIVE\n")
-    for k in sorted(set(k for c in cs[2:] for k in acc[c]), key=lambda k: -acc["SQ_VALU_MFMA_BUSY_CYCLES"].get(k, 0)):
-        n = max(cnt[c][k] for c in cs[2:])
-        if not n or not k.strip():
-            continue
-        f.write('"%s",%d,%s\n' % (k, n, ",".join("%.1f" % (acc[c][k] / max(1, cnt[c][k])) if cnt[c][k] else "" for c in cs[2:])))
-print(open("%s/%s_c2_pmc_mfma.csv" % (out, rnd)).read()[:1500])
+        for r in csv.DictReader(open(fs[0])):
+            if r["Counter_Name"] != c:
+                continue
+            k = r["Kernel_Name"].split("(")[0]
+            acc[c][k] += float(r["Counter_Value"]); cnt[c][k] += 1
+    return acc, cnt
+def bench_bytes(w):   # algorithmic bytes per launch of the roofline kernel, from the bench line of the kernel-trace run
+    try:
+        for line in open("%s/bench_%s.log" % (out, w)):
+            if line.startswith("{"):
+                return json.loads(line).get("roofline", {}).get("bytes_per_launch")
+    except Exception:
+        pass
+    return None
+roof_kernel = {"c2": "reproj_eval_kernel<true>", "c3": "relpose_kernel", "c4": "relpose_kernel", "pastl3": "reproj_eval_kernel<true>"}
+for tag in ("c2", "c3", "c4", "pastl3"):
+    acc, cnt = collect(tag, ["FETCH_SIZE", "WRITE_SIZE"])
+    keys = sorted(set(k for c in acc for k in acc[c]), key=lambda k: -(acc["FETCH_SIZE"].get(k, 0) + acc["WRITE_SIZE"].get(k, 0)))
+    nb = bench_bytes(tag) if tag != "pastl3" else None
+    if tag == "pastl3":
+        try:
+            nb = int(open("%s/pmc_pastl3_FETCH_SIZE.log" % out).read().split("observations, ")[1].split(" bytes")[0])
+        except Exception:
+            nb = None
+    with open("%s/%s_%s_pmc_hbm.csv" % (out, rnd, tag), "w") as f:
+        f.write("Kernel,Launches,avg_FETCH_SIZE_raw_KB,avg_WRITE_SIZE_raw_KB,algorithmic_bytes_per_launch,note: gfx950 FETCH_SIZE reads 1/2 of a wide coalesced stream (MI355X_MICROARCH.md HBM section); separate PMC passes\n")
+        for k in keys:
+            n = cnt["FETCH_SIZE"][k]
+            if n and k.strip():
+                ab = nb if (nb and roof_kernel[tag] in k) else ""
+                f.write('"%s",%d,%.1f,%.1f,%s\n' % (k, n, acc["FETCH_SIZE"][k] / n, acc["WRITE_SIZE"].get(k, 0.0) / max(1, cnt["WRITE_SIZE"][k]), ab))
+cs = ["SQ_INSTS_VALU_MFMA_MOPS_F64", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"]
+for tag in ("c2", "c3"):
+    acc, cnt = collect(tag, cs)
+    with open("%s/%s_%s_pmc_mfma.csv" % (out, rnd, tag), "w") as f:
+        f.write("Kernel,Launches," + ",".join("avg_" + c for c in cs) + "\n")
+        for k in sorted(set(k for c in cs for k in acc[c]), key=lambda k: -acc["SQ_VALU_MFMA_BUSY_CYCLES"].get(k, 0)):
+            n = max(cnt[c][k] for c in cs)
+            if not n or not k.strip():
+                continue
+            f.write('"%s",%d,%s\n' % (k, n, ",".join("%.1f" % (acc[c][k] / max(1, cnt[c][k])) if cnt[c][k] else "" for c in cs)))
+    print(open("%s/%s_%s_pmc_mfma.csv" % (out, rnd, tag)).read()[:1200])
 PY
 ls -la "$OUT"
