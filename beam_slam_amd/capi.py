@@ -111,7 +111,7 @@ SYMBOLS = [
     "finalize", "solve", "get_blocks", "reset_values", "num_iterations_recorded", "get_iteration",
     "evaluate", "num_residuals", "num_parameters_tangent", "tangent_offset", "covariance", "marginalize", "get_marginal",
     "reprojection_errors", "preintegrate", "triangulate", "time_reproj_jacobian_ms", "reproj_jacobian_bytes", "dense_solve", "plan_info",
-    "profile_step", "time_eval_ms", "eval_bytes", "bsr_info",
+    "profile_step", "time_eval_ms", "eval_bytes", "bsr_info", "covariance_joint", "update_marginal",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -175,6 +175,10 @@ class Solver:
 
     def _f(self, name):
         return getattr(self._lib, self._p + name)
+
+    def has(self, name):
+        """Whether the library behind this handle exports the entry point (the test oracle has only what its tests need)."""
+        return hasattr(self._lib, self._p + name)
 
     def _chk(self, rc):
         if rc != OK:
@@ -282,6 +286,23 @@ class Solver:
         assert A.shape[0] == b.size
         self._chk(self._f("add_marginal")(self._ctx, blocks.size, _ptr(blocks, _ip), A.shape[0], _ptr(A, _dp), _ptr(b, _dp),
                                           _ptr(xbar, _dp)))
+
+    def update_marginal(self, index, A, b, xbar):
+        """Replaces the payload of the index-th dense prior in place (bsgpu_update_marginal): no re-finalize."""
+        A = np.ascontiguousarray(A, np.float64); b = np.ascontiguousarray(b, np.float64); xbar = np.ascontiguousarray(xbar, np.float64)
+        fn = self._f("update_marginal")
+        fn.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, _dp]
+        self._chk(fn(self._ctx, int(index), A.ctypes.data_as(_dp), b.ctypes.data_as(_dp), xbar.ctypes.data_as(_dp)))
+
+    def covariance_joint(self, blocks, tangent_sizes):
+        """Joint marginal covariance (D x D, D = sum of tangent sizes <= 64) of several pose-side blocks (bsgpu_covariance_joint)."""
+        bl = np.ascontiguousarray(blocks, np.int32)
+        D = int(np.sum(tangent_sizes))
+        out = np.zeros((D, D))
+        fn = self._f("covariance_joint")
+        fn.argtypes = [C.c_void_p, C.c_int32, _ip, _dp]
+        self._chk(fn(self._ctx, int(bl.size), bl.ctypes.data_as(_ip), out.ctypes.data_as(_dp)))
+        return out
 
     def marginalize(self, blocks, sizes):
         """fuse_constraints::marginalizeVariables at the current values: returns (kept_blocks, A, b, xbar), the payload

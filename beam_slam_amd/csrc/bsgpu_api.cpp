@@ -679,16 +679,22 @@ int bsgpu_get_marginal(const bsgpu_ctx* c, int32_t* kept_blocks, double* A, doub
 
 // Graph::getCovariance for pose-side blocks: Sigma_pp = (H_pp - H_pl H_ll^-1 H_lp)^-1 = S^-1 at the current values,
 // without LM damping (what ceres::Covariance computes from the robustified J^T J, landmarks marginalised).
-// One undamped assembly + one factorisation; the unit vectors of both blocks ride along as rows of the rhs tile.
-int bsgpu_covariance(bsgpu_ctx* c, int32_t ba, int32_t bb, double* out) try {
-  if (!c) return BSGPU_ERR_INVALID;
-  if (!out) return fail(c, BSGPU_ERR_INVALID, "null argument");
+// One undamped assembly + one factorisation; the unit vectors of the blocks ride along as rows of the rhs tile.
+// `blocks` (distinct, pose-side, not constant): out = the joint covariance of their tangent coordinates, D x D row-major, D <= 64.
+static int covariance_of(bsgpu_ctx* c, const std::vector<int>& blocks, double* out) {
   int rc = finalize(c);
   if (rc != BSGPU_OK) return rc;
-  if (ba < 0 || bb < 0 || ba >= c->nb || bb >= c->nb) return fail(c, BSGPU_ERR_INVALID, "covariance: block out of range");
-  if (c->toff[ba] < 0 || c->toff[bb] < 0) return fail(c, BSGPU_ERR_INVALID, "covariance: constant block");
-  if (c->is_lm[ba] || c->is_lm[bb])
-    return fail(c, BSGPU_ERR_UNSUPPORTED, "covariance: landmark blocks are eliminated; only pose-side blocks can be queried");
+  std::vector<int> cols;
+  for (size_t i = 0; i < blocks.size(); ++i) {
+    const int bl = blocks[i];
+    if (bl < 0 || bl >= c->nb) return fail(c, BSGPU_ERR_INVALID, "covariance: block out of range");
+    for (size_t j = 0; j < i; ++j) if (blocks[j] == bl) return fail(c, BSGPU_ERR_INVALID, "covariance: block named twice");
+    if (c->toff[bl] < 0) return fail(c, BSGPU_ERR_INVALID, "covariance: constant block");
+    if (c->is_lm[bl]) return fail(c, BSGPU_ERR_UNSUPPORTED, "covariance: landmark blocks are eliminated; only pose-side blocks can be queried");
+    for (int k = 0; k < c->tsize[bl]; ++k) cols.push_back(c->plan.spos(c->toff[bl] + k));
+  }
+  const int D = (int)cols.size();
+  if (D <= 0 || D > 64) return fail(c, BSGPU_ERR_UNSUPPORTED, "covariance: the blocks' tangent dimensions must add up to 1..64 (one rhs tile)");
   if (!c->dense_ok) return fail(c, BSGPU_ERR_UNSUPPORTED, "covariance: reduced system above the dense limit (block-sparse PCG path has no factor)");
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t s = c->stream;
@@ -701,28 +707,63 @@ int bsgpu_covariance(bsgpu_ctx* c, int32_t ba, int32_t bb, double* out) try {
   eval_all(c, c->d_x, true, SC_COST_X);
   assemble(c, o, 1e300, true, true);
   c->use_pcg = was_pcg;
-  const int ta = c->tsize[ba], tb = c->tsize[bb];
-  std::vector<int> cols;
-  for (int i = 0; i < ta; ++i) cols.push_back(c->plan.spos(c->toff[ba] + i));
-  const int row_b0 = (ba == bb) ? 0 : ta;
-  if (ba != bb) for (int j = 0; j < tb; ++j) cols.push_back(c->plan.spos(c->toff[bb] + j));
+  c->spec_J = false;
   int* d_cols = nullptr;
   double* d_out = nullptr;
   HIPCHK(c, hipMalloc((void**)&d_cols, sizeof(int) * cols.size()));
-  if (hipMalloc((void**)&d_out, sizeof(double) * ta * tb) != hipSuccess) { (void)hipFree(d_cols); return fail(c, BSGPU_ERR_DEVICE, "out of device memory"); }
+  if (hipMalloc((void**)&d_out, sizeof(double) * D * D) != hipSuccess) { (void)hipFree(d_cols); return fail(c, BSGPU_ERR_DEVICE, "out of device memory"); }
   (void)hipMemcpyAsync(d_cols, cols.data(), sizeof(int) * cols.size(), hipMemcpyHostToDevice, s);
-  launch_cov_units(s, c->d_S, c->npad, c->plan.rhs_row, d_cols, (int)cols.size());
-  DenseDev D{c->d_perm, c->d_nreal, c->d_rows_flat, c->d_panels, c->d_Lp, c->d_Vinv,
-             c->d_bs_desc, c->d_chain_begin, c->d_chain_end, c->d_tile_sync, c->d_ftasks, c->d_fsync};
-  D.Winv = c->d_Winv; D.tile_tot = c->d_tile_tot;
-  dense_factor(s, c->plan, D, c->d_S, c->d_scal);
-  launch_cov_dots(s, c->d_Lp, c->npad, c->plan.rhs_row, c->plan.T * 64, ta, row_b0, tb, d_out);
-  (void)hipMemcpyAsync(out, d_out, sizeof(double) * ta * tb, hipMemcpyDeviceToHost, s);
+  launch_cov_units(s, c->d_S, c->npad, c->plan.rhs_row, d_cols, D);
+  DenseDev D0{c->d_perm, c->d_nreal, c->d_rows_flat, c->d_panels, c->d_Lp, c->d_Vinv,
+              c->d_bs_desc, c->d_chain_begin, c->d_chain_end, c->d_tile_sync, c->d_ftasks, c->d_fsync};
+  D0.Winv = c->d_Winv; D0.tile_tot = c->d_tile_tot; D0.rhs_rows = D;
+  dense_factor(s, c->plan, D0, c->d_S, c->d_scal);
+  launch_cov_dots(s, c->d_Lp, c->npad, c->plan.rhs_row, c->plan.T * 64, D, 0, D, d_out);
+  (void)hipMemcpyAsync(out, d_out, sizeof(double) * D * D, hipMemcpyDeviceToHost, s);
   rc = fetch_scalars(c);
   (void)hipFree(d_cols); (void)hipFree(d_out);
   if (rc != BSGPU_OK) return rc;
   if (c->h_scal[SC_CHOL_FAIL] > 0.0 || !std::isfinite(out[0]))
     return fail(c, BSGPU_ERR_NUMERIC, "covariance: J^T J is singular at the current values (gauge freedom or unobserved block)");
+  return BSGPU_OK;
+}
+int bsgpu_covariance(bsgpu_ctx* c, int32_t ba, int32_t bb, double* out) try {
+  if (!c) return BSGPU_ERR_INVALID;
+  if (!out) return fail(c, BSGPU_ERR_INVALID, "null argument");
+  int rc = finalize(c);
+  if (rc != BSGPU_OK) return rc;
+  if (ba < 0 || bb < 0 || ba >= c->nb || bb >= c->nb) return fail(c, BSGPU_ERR_INVALID, "covariance: block out of range");
+  if (ba == bb) return covariance_of(c, {ba}, out);
+  const int ta = c->tsize[ba], tb = c->tsize[bb];
+  std::vector<double> joint((size_t)(ta + tb) * (ta + tb));
+  rc = covariance_of(c, {ba, bb}, joint.data());
+  if (rc != BSGPU_OK) return rc;
+  for (int i = 0; i < ta; ++i) for (int j = 0; j < tb; ++j) out[i * tb + j] = joint[(size_t)i * (ta + tb) + ta + j];
+  return BSGPU_OK;
+} catch (...) { return api_exception(c); }
+int bsgpu_covariance_joint(bsgpu_ctx* c, int32_t n_blocks, const int32_t* blocks, double* out) try {
+  if (!c) return BSGPU_ERR_INVALID;
+  if (n_blocks <= 0 || !blocks || !out) return fail(c, BSGPU_ERR_INVALID, "covariance_joint: bad argument");
+  return covariance_of(c, std::vector<int>(blocks, blocks + n_blocks), out);
+} catch (...) { return api_exception(c); }
+
+// The payload of the index-th dense linear prior, replaced in place: the finalized device structure stays (same blocks, rows, columns).
+int bsgpu_update_marginal(bsgpu_ctx* c, int32_t index, const double* A, const double* b, const double* xbar) try {
+  if (!c) return BSGPU_ERR_INVALID;
+  if (index < 0 || index >= (int)c->marginals.size() || !A || !b || !xbar) return fail(c, BSGPU_ERR_INVALID, "update_marginal: bad argument");
+  HostMarginal& mg = c->marginals[index];
+  std::memcpy(mg.A.data(), A, sizeof(double) * mg.A.size());
+  std::memcpy(mg.b.data(), b, sizeof(double) * mg.b.size());
+  std::memcpy(mg.xbar.data(), xbar, sizeof(double) * mg.xbar.size());
+  if (!c->finalized) return BSGPU_OK;
+  if (index >= (int)c->marg.size()) return fail(c, BSGPU_ERR_INVALID, "update_marginal: device table out of step");
+  HIPCHK(c, hipSetDevice(c->device));
+  const MargDev& d = c->marg[index].dev;
+  HIPCHK(c, hipStreamSynchronize(c->stream));   // (kernels of an earlier step may still read the payload)
+  HIPCHK(c, hipMemcpy(const_cast<double*>(d.A), mg.A.data(), sizeof(double) * mg.A.size(), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(const_cast<double*>(d.b), mg.b.data(), sizeof(double) * mg.b.size(), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(const_cast<double*>(d.xbar), mg.xbar.data(), sizeof(double) * mg.xbar.size(), hipMemcpyHostToDevice));
+  c->spec_J = false;
   return BSGPU_OK;
 } catch (...) { return api_exception(c); }
 

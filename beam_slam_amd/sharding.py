@@ -237,7 +237,16 @@ def consensus_by_marginals(solvers, subs, n_shared, is_quat, rounds, options=Non
     red = (lambda a: a) if all_reduce is None else all_reduce
     part_ids = list(range(len(subs))) if part_ids is None else list(part_ids)
     n_parts = len(subs) if n_parts is None else int(n_parts)
-    dims = np.where(is_quat, 3, 3)                          # tangent width of every shared block
+    # LIMITATION: every part marginalises its own factors onto ALL of its shared blocks and a receiver can only apply
+    # a prior whose blocks it holds — exact when every window holds every shared block (two windows; a star around one key frame),
+    # NOT for a chain A - B - C, where A would never hear of C.  Chains and trees of windows: MessagePassing below.
+    for sub in subs:
+        if len(sub.shared_id) != n_shared:
+            raise NotImplementedError("consensus_by_marginals: a window does not hold every shared block (a chain / tree of windows): "
+                                      "use sharding.MessagePassing + message_passing_rounds")
+        if any(sub.problem.size[int(l)] not in (3, 4) for l in sub.shared_local):
+            raise ValueError("consensus_by_marginals: shared blocks must be 3-vectors or unit quaternions")
+    dims = np.where(is_quat, 3, 3)                          # tangent width of every shared block (checked above)
     col0 = np.concatenate([[0], np.cumsum(dims)])
     nd = int(col0[-1])
     amb = np.where(is_quat, 4, 3)
@@ -310,3 +319,213 @@ def consensus_by_marginals(solvers, subs, n_shared, is_quat, rounds, options=Non
             break
         priors = red(mine)                                    # the exchange of the marginal priors
     return z, history
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Consensus by MESSAGES (round 3): the same goal — overlapping windows / submaps, one per GPU, converge to the optimum of the
+# merged graph exchanging nothing but small summaries of their shared key frames — for any TREE of windows (a chain of submaps:
+# A - B - C ...), at window scale, with everything but the messages staying on the device:
+#     1. every rank solves its window: own factors + one dense prior per neighbour (the neighbour's message)           bsgpu_solve,
+#        warm-started; the context is finalized ONCE, the priors' contents are replaced in place                  bsgpu_update_marginal
+#     2. its BELIEF on the key frames it shares: their joint marginal covariance at the solution (one undamped
+#        factorisation, unit vectors in the rhs tile)                                                            bsgpu_covariance_joint
+#     3. the message to neighbour q = belief on what is shared with q, divided by q's own message (information form:
+#        Lambda_out = Lambda_belief - Lambda_in) — i.e. the marginal of own factors + EVERY OTHER neighbour's message, which is what
+#        makes a chain A - B - C exact: B's message to A carries what C told B
+#     4. the messages travel in ONE all-reduce (one slot per directed pair of neighbours; RCCL over xGMI on the GPU box)
+# On a tree this is Gaussian belief propagation with re-linearisation: exact for linear-Gaussian graphs after diameter-many rounds,
+# Gauss-Newton-like on ours.  consensus_by_marginals above averages the shared values and lets every part marginalise its own
+# factors only: exact for two parts, but a part that does not hold a prior's blocks skips it, so in a chain the ends never hear of
+# each other.  A block shared by MORE than two windows is not a tree edge: refused.
+# The reference refines its submaps one after the other and exchanges nothing (submap_refinement.cpp:35-115).
+# ---------------------------------------------------------------------------------------------------------------------------
+class MessagePassing:
+    """One window of the tree (this rank's).  `problem`: its local Problem; `neighbours`: {part id: [local blocks shared with it]}, the
+    blocks in the SAME order on both sides; `solver`: a capi.Solver (libbsgpu context, or the test oracle)."""
+
+    WEAK = 1e-3          # sqrt-information of the placeholder priors before the first messages arrive
+
+    def __init__(self, solver, problem, part_id, neighbours, options=None):
+        from . import capi
+        self.g, self.pr, self.pid, self.opt = solver, problem, int(part_id), options
+        self.nbr = sorted(int(q) for q in neighbours)
+        self.blocks = {q: [int(b) for b in neighbours[q]] for q in self.nbr}
+        self.is_quat = {q: np.array([problem.manifold[b] == capi.MANIFOLD_QUAT_RIGHT for b in self.blocks[q]]) for q in self.nbr}
+        self.amb = {q: np.array([problem.size[b] for b in self.blocks[q]]) for q in self.nbr}
+        self.D = {q: 3 * len(self.blocks[q]) for q in self.nbr}
+        for q in self.nbr:
+            if any(problem.size[b] not in (3, 4) for b in self.blocks[q]):
+                raise ValueError("MessagePassing: shared blocks must be 3-vectors or unit quaternions")
+        seen = [b for q in self.nbr for b in self.blocks[q]]
+        if len(seen) != len(set(seen)):
+            raise NotImplementedError("MessagePassing: a block shared with more than one neighbour is not an edge of a tree of windows")
+        # incoming messages (xbar ambient rows, Lambda, m): placeholders, weak and centred at the initial values
+        self.msg_in = {}
+        for q in self.nbr:
+            xbar = self._values_of(q, problem.values)
+            self.msg_in[q] = (xbar, (self.WEAK ** 2) * np.eye(self.D[q]), np.zeros(self.D[q]))
+        self._resident = solver.has("update_marginal") and solver.has("covariance_joint")
+        self._loaded = False
+        self.last_summary = None
+        self._x0 = problem.values.copy()
+
+    def reset(self):
+        """Back to the initial values and the placeholder messages (the device tables stay: a benchmark repeats the rounds)."""
+        self.pr.values = self._x0.copy()
+        for q in self.nbr:
+            self.msg_in[q] = (self._values_of(q, self._x0), (self.WEAK ** 2) * np.eye(self.D[q]), np.zeros(self.D[q]))
+        if self._loaded:
+            self.g.set_values(self._x0)
+
+    # -- helpers -------------------------------------------------------------------------------------------------------------
+    def _values_of(self, q, values):
+        x = np.zeros((len(self.blocks[q]), 4))
+        for i, b in enumerate(self.blocks[q]):
+            v = self.pr.block(b, values)
+            x[i, :v.size] = v
+        return x
+
+    @staticmethod
+    def _factor(Lam, m):
+        """(A, b) of the prior r = b + A d with A^T A = Lambda (projected onto the positive semi-definite cone), b = -A m."""
+        w, V = np.linalg.eigh(0.5 * (Lam + Lam.T))
+        A = (np.sqrt(np.maximum(w, 0.0))[:, None]) * V.T
+        return A, -A @ m
+
+    def _payload(self, q):
+        xbar, Lam, m = self.msg_in[q]
+        A, b = self._factor(Lam, m)
+        return A, b, np.concatenate([xbar[i, :self.amb[q][i]] for i in range(xbar.shape[0])])
+
+    def _load(self):
+        self.pr.marginals = []
+        for q in self.nbr:
+            A, b, xb = self._payload(q)
+            self.pr.add_marginal(self.blocks[q], A, b, xb)
+        self.pr.load(self.g)
+        self._loaded = True
+
+    def _push_messages(self):
+        if self._resident and self._loaded:
+            for i, q in enumerate(self.nbr):
+                self.g.update_marginal(i, *self._payload(q))
+        else:
+            self._load()
+
+    def _joint_covariance(self):
+        blocks = [b for q in self.nbr for b in self.blocks[q]]
+        if self.g.has("covariance_joint"):
+            return self.g.covariance_joint(blocks, [3] * len(blocks))
+        n = 3 * len(blocks)                                   # (the test oracle: pairwise blocks)
+        S = np.zeros((n, n))
+        for i, bi in enumerate(blocks):
+            for j, bj in enumerate(blocks):
+                if j >= i:
+                    S[3 * i:3 * i + 3, 3 * j:3 * j + 3] = self.g.covariance(bi, bj)
+                    S[3 * j:3 * j + 3, 3 * i:3 * i + 3] = S[3 * i:3 * i + 3, 3 * j:3 * j + 3].T
+        return S
+
+    # -- one round, this rank's half ---------------------------------------------------------------------------------------------
+    def solve_and_summarise(self):
+        """Steps 1-3.  Returns {q: (xbar, Lambda_out, m_out)}: the messages to the neighbours."""
+        self._push_messages()
+        self.last_summary = self.g.solve(self.opt)
+        values = self.g.get_blocks()
+        self.pr.values = values
+        out = {}
+        if not self.nbr:
+            return out
+        S = self._joint_covariance()
+        c = 0
+        for q in self.nbr:
+            D = self.D[q]
+            Lam_b = np.linalg.inv(S[c:c + D, c:c + D])
+            c += D
+            x = self._values_of(q, values)
+            xbar_in, Lam_in, m_in = self.msg_in[q]
+            shift = _boxminus(x, xbar_in, self.is_quat[q]).ravel()    # the incoming message, re-centred at this window's solution
+            m_rel = m_in - shift
+            Lam_out = Lam_b - Lam_in
+            w, V = np.linalg.eigh(0.5 * (Lam_out + Lam_out.T))
+            w = np.maximum(w, 0.0)
+            Lam_out = (V * w) @ V.T
+            winv = np.where(w > 1e-12 * max(w.max(), 1e-300), 1.0 / np.maximum(w, 1e-300), 0.0)
+            m_out = -((V * winv) @ V.T) @ (Lam_in @ m_rel)
+            out[q] = (x, Lam_out, m_out)
+        return out
+
+    def own_cost(self):
+        """Cost of this window's OWN factors at its current values (the solver's cost minus the priors' energies)."""
+        values = self.pr.values
+        e = 0.0
+        for q in self.nbr:
+            xbar, Lam, m = self.msg_in[q]
+            A, b = self._factor(Lam, m)
+            d = _boxminus(self._values_of(q, values), xbar, self.is_quat[q]).ravel()
+            r = b + A @ d
+            e += 0.5 * float(r @ r)
+        return self.last_summary.final_cost - e
+
+    def shared_values(self, q):
+        return self._values_of(q, self.pr.values)
+
+
+def message_passing_rounds(windows, rounds, all_reduce=None, n_parts=None, tol=1e-9, on_round=None):
+    """Runs the rounds for the windows THIS process holds (`windows`: list of MessagePassing; one per rank under torch.distributed,
+    all of them in a single-process test).  all_reduce(array) -> array: float64 SUM over all ranks (None: single process).
+    Returns history [(round, max |change of a shared value| over all windows, sum of own costs of this process' windows)]."""
+    red = (lambda a: a) if all_reduce is None else all_reduce
+    n_parts = (max(w.pid for w in windows) + 1) if n_parts is None else int(n_parts)
+    Dmax = 15
+    for w in windows:
+        for q in w.nbr:
+            Dmax = max(Dmax, w.D[q])
+    nblk = Dmax // 3
+    slot = 4 * nblk + Dmax * Dmax + Dmax + 1                 # xbar | Lambda | m | present
+    history = []
+    prev = {}
+    for rnd in range(rounds):
+        buf = np.zeros((n_parts, n_parts, slot))             # [sender, receiver]
+        stat = np.zeros(2 * n_parts)                          # [own cost per part | max shared change per part]
+        for w in windows:
+            msgs = w.solve_and_summarise()
+            for q, (x, Lam, m) in msgs.items():
+                D, nb = w.D[q], len(w.blocks[q])
+                s = np.zeros(slot)
+                s[:4 * nb] = x.ravel()
+                L = np.zeros((Dmax, Dmax)); L[:D, :D] = Lam
+                s[4 * nblk:4 * nblk + Dmax * Dmax] = L.ravel()
+                s[4 * nblk + Dmax * Dmax:4 * nblk + Dmax * Dmax + D] = m
+                s[-1] = 1.0
+                buf[w.pid, q] = s
+                key = (w.pid, q)
+                if key in prev:
+                    stat[n_parts + w.pid] = max(stat[n_parts + w.pid], float(np.abs(_boxminus(x, prev[key], w.is_quat[q])).max()))
+                else:
+                    stat[n_parts + w.pid] = np.inf
+                prev[key] = x
+            stat[w.pid] = w.own_cost()
+        buf = red(buf.ravel()).reshape(n_parts, n_parts, slot)  # the exchange: every rank filled its own rows only
+        stat_max = stat.copy(); stat_max[:n_parts] = 0.0
+        cost = red(np.concatenate([stat[:n_parts], np.zeros(n_parts)]))[:n_parts].sum()
+        # (the max over ranks as a sum of one-hot entries: every part's change sits in its own slot)
+        fin = np.where(np.isfinite(stat[n_parts:]), stat[n_parts:], 1e300)
+        change = red(np.concatenate([np.zeros(n_parts), fin]))[n_parts:]
+        dz = float(change.max()) if change.size else 0.0
+        dz = float("inf") if dz >= 1e299 else dz
+        for w in windows:
+            for q in w.nbr:
+                s = buf[q, w.pid]
+                if s[-1] < 0.5:
+                    continue
+                D, nb = w.D[q], len(w.blocks[q])
+                x = s[:4 * nb].reshape(nb, 4)
+                Lam = s[4 * nblk:4 * nblk + Dmax * Dmax].reshape(Dmax, Dmax)[:D, :D]
+                m = s[4 * nblk + Dmax * Dmax:4 * nblk + Dmax * Dmax + D]
+                w.msg_in[q] = (x.copy(), Lam.copy(), m.copy())
+        history.append((rnd, dz, float(cost)))
+        if on_round is not None:
+            on_round(rnd, dz, float(cost))
+        if dz < tol:
+            break
+    return history

@@ -266,18 +266,21 @@ def _perturb_quat(q, rng, sigma):
 # ---------------------------------------------------------------------------------------------
 def vio_window(n_kf=200, n_lm=50000, seed=20250620, kf_rate=10.0, imu_rate=200.0, track_min=4, track_max=12,
                pixel_sigma=1.0, w_reproj=1.0, cauchy_a=5.0, w_inertial=1.0, with_imu=True, sigma_rot=0.02,
-               sigma_pos=0.05, sigma_vel=0.05, sigma_lm=0.1):
-    """SURVEY.md §8d "C2 synthetic input".  Returns a Problem; p.meta holds ground truth."""
+               sigma_pos=0.05, sigma_vel=0.05, sigma_lm=0.1, kf0=0, first_prior=True, bias_seed=None):
+    """SURVEY.md §8d "C2 synthetic input".  Returns a Problem; p.meta holds ground truth.
+    kf0 / first_prior / bias_seed: the window starts at key frame kf0 of the (periodic) trajectory, has no prior on its first state,
+    and takes the IMU biases of another seed — neighbouring submaps of one trajectory that share a boundary key frame (chain_windows)."""
     rng = np.random.default_rng(seed)
     dt_kf = 1.0 / kf_rate
     traj = Lissajous(duration=n_kf * dt_kf)
-    t_kf = np.arange(n_kf) * dt_kf
+    t_kf = (kf0 + np.arange(n_kf)) * dt_kf
     R_true = np.stack([traj.rot(t) for t in t_kf])
     q_true = np.stack([rot_to_quat(R) for R in R_true])
     p_true = np.stack([traj.pos(t) for t in t_kf])
     v_true = np.stack([traj.vel(t) for t in t_kf])
-    bg_true = rng.normal(0, 0.002, 3)
-    ba_true = rng.normal(0, 0.02, 3)
+    rb = rng if bias_seed is None else np.random.default_rng(bias_seed)
+    bg_true = rb.normal(0, 0.002, 3)
+    ba_true = rb.normal(0, 0.02, 3)
     R_cb, t_cb = _t_cam_baselink()
 
     # ---- landmarks + observations -----------------------------------------------------------
@@ -306,7 +309,7 @@ def vio_window(n_kf=200, n_lm=50000, seed=20250620, kf_rate=10.0, imu_rate=200.0
     n_imu = (n_kf - 1) * per + 1
     imu_fac = []
     if with_imu and n_kf > 1:
-        t_imu = np.arange(n_imu) * dt_imu
+        t_imu = t_kf[0] + np.arange(n_imu) * dt_imu
         w_m = np.empty((n_imu, 3))
         a_m = np.empty((n_imu, 3))
         sg, sa = np.sqrt(COV_GYRO_NOISE / dt_imu), np.sqrt(COV_ACCEL_NOISE / dt_imu)
@@ -346,11 +349,12 @@ def vio_window(n_kf=200, n_lm=50000, seed=20250620, kf_rate=10.0, imu_rate=200.0
         pr.add_factors(capi.F_IMU_DELTA, idx, np.stack(imu_fac))
     # pseudo-marginalisation prior on the first state at its current estimate, cov 1e-5 I
     # (bs_optimizers/src/fixed_lag_smoother.cpp:244-268)
-    vals = pr.values
-    mean = np.concatenate([pr.block(int(b), vals) for b in kf_blocks[0]])
-    A = sqrt_information_upper(1e-5 * np.eye(15))
-    pr.add_factors(capi.F_IMU_PRIOR, kf_blocks[0][None, :], np.concatenate([mean, A.ravel()])[None, :])
-    pr.meta = dict(kind="vio_window", n_kf=n_kf, n_lm=n_lm, n_obs=int(n_obs), n_imu=len(imu_fac), seed=seed,
+    if first_prior:
+        vals = pr.values
+        mean = np.concatenate([pr.block(int(b), vals) for b in kf_blocks[0]])
+        A = sqrt_information_upper(1e-5 * np.eye(15))
+        pr.add_factors(capi.F_IMU_PRIOR, kf_blocks[0][None, :], np.concatenate([mean, A.ravel()])[None, :])
+    pr.meta = dict(kind="vio_window", n_kf=n_kf, n_lm=n_lm, n_obs=int(n_obs), n_imu=len(imu_fac), seed=seed, kf0=kf0,
                    kf_blocks=kf_blocks, lm_blocks=lm_blocks, q_true=q_true, p_true=p_true, v_true=v_true,
                    P_true=P_true, bg_true=bg_true, ba_true=ba_true)
     return pr
@@ -364,6 +368,54 @@ def c1(seed=20250620):
 def c2(seed=20250620):
     """BASELINE config 2: 200 keyframes x 50k landmarks, ~400k reprojection factors."""
     return vio_window(n_kf=200, n_lm=50000, seed=seed)
+
+
+def chain_window(rank, n_windows, n_kf=200, n_lm=50000, seed=20250620):
+    """Window `rank` of a chain of n_windows submaps of ONE trajectory: consecutive windows share their boundary key frame (the last
+    one of window r is the first one of window r + 1: its five blocks q, p, v, bg, ba exist in both) and nothing else — landmarks are
+    local to a submap, as in the reference's global map.  Only window 0 carries the prior on its first state.
+    meta["shared"]: {neighbour rank: the five LOCAL blocks of the key frame shared with it}."""
+    pr = vio_window(n_kf=n_kf, n_lm=n_lm, seed=seed + 10 + rank, kf0=rank * (n_kf - 1), first_prior=(rank == 0), bias_seed=seed)
+    kf = pr.meta["kf_blocks"]
+    shared = {}
+    if rank > 0:
+        shared[rank - 1] = [int(b) for b in kf[0]]
+    if rank + 1 < n_windows:
+        shared[rank + 1] = [int(b) for b in kf[-1]]
+    pr.meta["shared"] = shared
+    return pr
+
+
+def merge_chain(windows):
+    """The graph the windows of a chain describe TOGETHER: one Problem in which every shared key frame exists once (with the value the
+    earlier window holds).  Returns (merged Problem, [local block -> merged block per window])."""
+    from .problem import NIDX
+    cam_types = (capi.F_REPROJ, capi.F_REPROJ_ONLINE_CALIB, capi.F_IDP_REPROJ, capi.F_IDP_REPROJ_UNARY)
+    mp = Problem()
+    maps = []
+    for r, w in enumerate(windows):
+        m = -np.ones(w.n_blocks, np.int64)
+        if r > 0:
+            prev_last = windows[r - 1].meta["kf_blocks"][-1]
+            for lb, pb in zip(w.meta["kf_blocks"][0], prev_last):
+                m[int(lb)] = maps[r - 1][int(pb)]
+        vals = w.values
+        for b in range(w.n_blocks):
+            if m[b] >= 0:
+                continue
+            nb = mp.add_block(w.block(b, vals), const=bool(w.is_const[b]))
+            mp.manifold[nb] = w.manifold[b]
+            m[b] = nb
+        if r == 0:
+            mp.cameras = list(w.cameras)
+        for t, chunks in w.factors.items():
+            nvar = NIDX[t] - (1 if t in cam_types else 0)
+            for idx, consts, lk, la in chunks:
+                li = idx.copy()
+                li[:, :nvar] = m[li[:, :nvar]]
+                mp.add_factors(t, li, consts, lk, la)
+        maps.append(m)
+    return mp, maps
 
 
 # ---------------------------------------------------------------------------------------------

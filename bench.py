@@ -72,6 +72,10 @@ def main():
                     help="skip the Jacobian-evaluation measurement on the 800 KF x 300k-landmark window (working set above the Infinity Cache)")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"],
                     help="c2 (default) is the headline; c3 / c4 are the other BASELINE configs, for BASELINE.md")
+    ap.add_argument("--consensus", action="store_true",
+                    help="C5 with shared-pose consensus: the N windows are consecutive submaps of ONE trajectory, neighbours share their boundary "
+                         "key frame, and a step is the whole message-passing solve of the merged graph (beam_slam_amd/sharding.py); the messages "
+                         "are the only collective (RCCL all-reduce of a few KB per round)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -83,8 +87,14 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = os.environ.get("BSGPU_BENCH_BACKEND", "nccl")   # ("gloo": the tests run two ranks on ONE GPU, which RCCL refuses)
+        if os.environ.get("BSGPU_BENCH_SAME_DEVICE"):
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from beam_slam_amd import sharding, synthetic
     from beam_slam_amd.gpu import GpuSolver
@@ -96,6 +106,9 @@ def main():
     elif args.workload == "c4":
         pr = synthetic.c4()
         workload = "C4: global-mapper pose graph, 5000 poses, 50000 constraints (block-sparse PCG path)"
+    elif args.consensus:
+        pr = synthetic.chain_window(rank, world, n_kf=args.n_kf, n_lm=args.n_lm, seed=20250620)
+        workload = "C5 with shared-pose consensus: %d consecutive submaps (%d KF x %d landmarks each) of one trajectory, neighbours share a key frame" % (world, args.n_kf, args.n_lm)
     elif world == 1:
         pr = synthetic.vio_window(n_kf=args.n_kf, n_lm=args.n_lm, seed=20250620)
         workload = "C2: %d-keyframe x %d-landmark VIO window" % (args.n_kf, args.n_lm)
@@ -118,7 +131,42 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    cons = None
+    if args.consensus:
+        import numpy as np
+        opt.function_tolerance = 1e-12; opt.gradient_tolerance = 1e-12; opt.parameter_tolerance = 1e-12   # (the rounds cannot agree better than the windows are solved)
+        opt.max_num_iterations = 30
+        mp_win = sharding.MessagePassing(g, pr, rank, pr.meta["shared"], opt)
+        cons = {"rounds": 0, "round_ms": [], "lm_iterations": 0, "cost": 0.0, "dz": 0.0}
+        if dist is not None:
+            import torch
+            on_gpu = dist.get_backend() == "nccl"
+
+            def all_reduce(a):   # the exchange of the messages: ONE all-reduce (RCCL over xGMI on the GPU box)
+                t = torch.from_numpy(np.ascontiguousarray(a, np.float64).copy())
+                if on_gpu:
+                    t = t.cuda()
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                return t.cpu().numpy()
+        else:
+            all_reduce = None
+
     def one_step():
+        if cons is not None:
+            mp_win.reset()
+            t_r = [time.perf_counter()]
+            its = [0]
+
+            def on_round(rnd, dz, cost):
+                t_r.append(time.perf_counter())
+                its[0] += mp_win.last_summary.num_linear_solves
+            hist = sharding.message_passing_rounds([mp_win], 12, all_reduce=all_reduce, n_parts=world, tol=1e-8, on_round=on_round)
+            cons["rounds"] = len(hist); cons["cost"] = hist[-1][2]; cons["dz"] = hist[-1][1]
+            cons["round_ms"] = [round(1e3 * (b - a), 3) for a, b in zip(t_r[:-1], t_r[1:])]
+            cons["lm_iterations"] = its[0]
+            sm = mp_win.last_summary
+            sm.num_linear_solves = its[0]
+            return sm
         g.reset_values()
         return g.solve(opt)
 
@@ -143,7 +191,7 @@ def main():
     if rank == 0:
         # ---- rooflines, all measured IN SITU: HIP events at the phase boundaries of real LM steps on the solver's stream
         # (bsgpu_profile_step); the kernel-trace average of the same kernels is in profiles/r02_*_kernel_stats.csv
-        has_vis = pr.n_factors(0) > 0
+        has_vis = pr.n_factors(0) > 0 and not args.consensus
         roofline = roofline_mfma = kernels = phases = None
         if args.workload in ("c3", "c4"):
             # no reprojection factors: the roofline is that of the relative-pose evaluation (~990 B per factor),
@@ -218,6 +266,8 @@ def main():
         solver_options = {"c2": "vio.yaml:7-17 (<= 10 iterations, tolerances 1.5e-7), max_solver_time lifted",
                           "c3": "vio.yaml:7-17 (<= 10 iterations, tolerances 1.5e-7), max_solver_time lifted",
                           "c4": "default ceres::Solver::Options as the global mapper passes them (SURVEY.md §3.4), max_num_iterations 10"}[args.workload]
+        if args.consensus:
+            solver_options = {"c2": "default ceres::Solver::Options with tolerances 1e-12 and <= 30 iterations per window and round (the rounds cannot agree better than the windows are solved)"}
         out = {
             "metric": metric,
             "value": round(tot_it / max_dt, 2), "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps,
@@ -241,8 +291,13 @@ def main():
             out["phases_us_per_lm_step"] = phases
         if args.workload == "c4":
             out["pcg"] = pcg
+        if cons is not None:
+            out["consensus"] = {"rounds": cons["rounds"], "ms_per_round": cons["round_ms"], "merged_graph_cost": cons["cost"],
+                                "last_change_of_a_shared_value": cons["dz"], "lm_iterations_per_window": cons["lm_iterations"],
+                                "exchange": "one all-reduce per round: a 15 x 15 information matrix, its mean and the key frame's value per directed pair of neighbours",
+                                "note": "a step is the whole consensus solve from the initial values; value counts the LM iterations of all windows and rounds"}
         # ---- CPU baseline: the oracle on the same window (bounded: one solve, same options) ------
-        if world == 1 and not args.no_cpu_baseline and args.workload != "c4":   # (C4 at full size: the oracle's dense solve does not finish in bench time)
+        if world == 1 and not args.no_cpu_baseline and args.workload != "c4" and not args.consensus:   # (C4 at full size: the oracle's dense solve does not finish in bench time)
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             from oracle import Oracle
             o = Oracle()

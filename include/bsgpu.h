@@ -324,6 +324,11 @@ int bsgpu_sync_factors_indirect(bsgpu_ctx* ctx, int32_t type, int32_t n, const i
  * insertion order.  Blocks it touches are never Schur-eliminated.                                            */
 int bsgpu_add_marginal(bsgpu_ctx* ctx, int32_t n_blocks, const int32_t* blocks, int32_t n_rows,
                        const double* A, const double* b, const double* xbar);
+/* Replaces A, b and xbar of the index-th prior added with bsgpu_add_marginal (same blocks, same n_rows) IN PLACE: nothing is
+ * re-flattened, the device tables of a finalized problem stay.  For priors whose contents change from one solve to the next
+ * while the graph does not: [EXT] fuse_core::Graph::removeConstraint + addConstraint of a MarginalConstraint on the same
+ * variables.                                                                                                                   */
+int bsgpu_update_marginal(bsgpu_ctx* ctx, int32_t index, const double* A, const double* b, const double* xbar);
 
 /* ---- solve ----------------------------------------------------------------- */
 /* Uploads / builds the device-side structure (sorted factor tables, the tile plan of the
@@ -383,6 +388,11 @@ int bsgpu_get_marginal(const bsgpu_ctx* ctx, int32_t* kept_blocks, double* A, do
 /* Marginal covariance block (tangent space) between two pose-side blocks at the
  * current values: out is ts(block_a) x ts(block_b) row-major.                   */
 int bsgpu_covariance(bsgpu_ctx* ctx, int32_t block_a, int32_t block_b, double* out);
+/* The JOINT marginal covariance of several pose-side blocks (distinct, not constant; their tangent dimensions add up to D <= 64):
+ * out is D x D row-major, the blocks' tangent coordinates in the order given.  One undamped assembly + one factorisation, as
+ * bsgpu_covariance.  What a submap's summary of itself on its boundary key frames is made of (the unit of independence of
+ * bs_models/src/lib/global_mapping/submap_refinement.cpp:35-115; shared-pose consensus, beam_slam_amd/sharding.py).            */
+int bsgpu_covariance_joint(bsgpu_ctx* ctx, int32_t n_blocks, const int32_t* blocks, double* out);
 
 /* ---- factor producers either side of the solve ---------
  * Pixel error |z - projection| of every reprojection factor (types REPROJ then REPROJ_ONLINE_CALIB, insertion

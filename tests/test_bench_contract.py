@@ -37,3 +37,22 @@ def test_bench_rccl_path_world_size_one():
     assert r["n_gpus"] == 1 and r["value"] > 0
     single = _bench({}, "--n-kf", "40", "--n-lm", "4000")
     assert abs(r["config"]["final_cost"] - single["config"]["final_cost"]) <= 1e-9 * single["config"]["final_cost"]
+
+
+def test_bench_consensus_two_ranks_on_one_gpu():
+    """bench.py --consensus as the driver launches it for N = 2 (torch.distributed.run, one process per window), here with both
+    ranks on the one GPU of the box (gloo carries the messages: RCCL refuses two ranks on one device): the windows are consecutive
+    submaps sharing a key frame, the line reports the rounds, the time of each and the merged graph's cost."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    env = dict(os.environ, BSGPU_BENCH_BACKEND="gloo", BSGPU_BENCH_SAME_DEVICE="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--consensus", "--n-kf", "40", "--n-lm", "4000"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["n_gpus"] == 2 and r["value"] > 0 and "consensus" in r
+    c = r["consensus"]
+    assert 2 <= c["rounds"] <= 8 and len(c["ms_per_round"]) == c["rounds"] and c["last_change_of_a_shared_value"] < 1e-7
+    assert c["merged_graph_cost"] > 0

@@ -161,3 +161,132 @@ def test_consensus_two_gloo_ranks(tmp_path, oracle_cls):
     for r in range(2):
         subs[r].problem.values = np.load(tmp_path / ("x_%d.npy" % r))
     check_against_merged(pr, subs, z0, oracle_cls, 1e-9)
+
+
+# ---- consensus by messages (sharding.MessagePassing): any chain of windows, device-resident rounds -----------------------------
+def _merged_cost_of_chain(wins, mps, merged_solver):
+    """Cost of the MERGED graph at the windows' solutions (a shared key frame takes the value the earlier window holds)."""
+    mp, maps = synthetic.merge_chain(wins)
+    x = mp.values.copy()
+    for r in reversed(range(len(wins))):                # (earlier windows last: their value of a shared key frame wins)
+        v = mps[r].pr.values
+        for b in range(wins[r].n_blocks):
+            gb = int(maps[r][b])
+            x[mp.offset[gb]:mp.offset[gb] + mp.size[gb]] = wins[r].block(b, v)
+    mp.load(merged_solver)
+    merged_solver.set_values(x)
+    cost = merged_solver.evaluate(residuals=False, gradient=False)[0]
+    mp.load(merged_solver)
+    best = merged_solver.solve(tight(merged_solver))
+    return cost, best.final_cost
+
+
+def test_message_passing_chain_of_three_reaches_the_merged_optimum(oracle_cls):
+    """A - B - C: B's message to A must carry what C told B (the marginal-exchange loop above is exact for two parts
+    only).  Three submaps of one trajectory, each sharing one boundary key frame with its neighbour, only the first with a prior."""
+    wins = [synthetic.chain_window(r, 3, n_kf=7, n_lm=80, seed=5) for r in range(3)]
+    mps = []
+    for r, w in enumerate(wins):
+        o = oracle_cls()
+        mps.append(sharding.MessagePassing(o, w, r, w.meta["shared"], tight(o)))
+    hist = sharding.message_passing_rounds(mps, 14, tol=1e-9)
+    assert hist[-1][1] < 1e-7                                                     # the windows agree on their shared key frames
+    assert np.abs(mps[0].shared_values(1) - mps[1].shared_values(0)).max() < 1e-7
+    assert np.abs(mps[1].shared_values(2) - mps[2].shared_values(1)).max() < 1e-7
+    cost, best = _merged_cost_of_chain(wins, mps, oracle_cls())
+    assert abs(cost - best) <= 1e-7 * best, (cost, best)                          # (north_star bar: 1e-6)
+    assert abs(hist[-1][2] - best) <= 1e-7 * best                                 # the sum of the windows' own costs IS the merged cost
+
+
+def test_message_passing_refuses_a_block_shared_by_three(oracle_cls):
+    w = synthetic.chain_window(1, 3, n_kf=5, n_lm=40, seed=5)
+    sh = dict(w.meta["shared"])
+    sh[2] = sh[0]                                        # the same key frame named for two neighbours: not a tree edge
+    with pytest.raises(NotImplementedError):
+        sharding.MessagePassing(oracle_cls(), w, 1, sh)
+
+
+MP_WORKER = textwrap.dedent("""
+    import os, sys, json
+    import numpy as np
+    import torch, torch.distributed as dist
+    sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "oracle")); sys.path.insert(0, os.path.join(%r, "tests"))
+    from beam_slam_amd import sharding, synthetic
+    from oracle import Oracle
+    import test_consensus as tc
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    w = synthetic.chain_window(rank, world, n_kf=7, n_lm=80, seed=5)
+    def all_reduce(a):
+        t = torch.from_numpy(np.ascontiguousarray(a, np.float64).copy())
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.numpy()
+    o = Oracle()
+    mp = sharding.MessagePassing(o, w, rank, w.meta["shared"], tc.tight(o))
+    hist = sharding.message_passing_rounds([mp], 12, all_reduce=all_reduce, n_parts=world, tol=1e-9)
+    np.save(os.path.join(sys.argv[1], "mx_%%d.npy" %% rank), mp.pr.values)
+    with open(os.path.join(sys.argv[1], "m_%%d.json" %% rank), "w") as fh:
+        json.dump(dict(hist=hist), fh)
+    dist.destroy_process_group()
+""")
+
+
+def test_message_passing_two_gloo_ranks(tmp_path, oracle_cls):
+    """One window per rank, world size 2 (gloo here, RCCL on the GPU box): the only collective is the exchange of the messages."""
+    script = tmp_path / "mp_worker.py"
+    script.write_text(MP_WORKER % (ROOT, ROOT, ROOT))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script), str(tmp_path)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    h0 = json.loads((tmp_path / "m_0.json").read_text())["hist"]
+    h1 = json.loads((tmp_path / "m_1.json").read_text())["hist"]
+    assert h0 == h1 and h0[-1][1] < 1e-7 and len(h0) <= 8               # both ranks see the same rounds; two windows agree within a few
+    wins = [synthetic.chain_window(r, 2, n_kf=7, n_lm=80, seed=5) for r in range(2)]
+
+    class Held:                                                           # (the windows' solutions as the workers left them)
+        def __init__(self, pr): self.pr = pr
+    held = []
+    for r, w in enumerate(wins):
+        w.values = np.load(tmp_path / ("mx_%d.npy" % r))
+        held.append(Held(w))
+    cost, best = _merged_cost_of_chain(wins, held, oracle_cls())
+    assert abs(cost - best) <= 1e-7 * best and abs(h0[-1][2] - best) <= 1e-7 * best
+
+
+@pytest.mark.gpu
+def test_message_passing_two_half_windows_on_one_gpu(gpu_solver_cls):
+    """Two C2-sized halves (100 key frames x 25 000 landmarks each, sharing their boundary key frame) as two libbsgpu contexts on one
+    device: the merged graph's cost at the consensus solution is within 1e-6 of the single-context solve of the MERGED window, in at
+    most 6 rounds; a round's overhead on top of the solve (belief + messages in and out) is a few milliseconds, and nothing is
+    re-flattened between rounds (the priors are updated in place)."""
+    import time
+    wins = [synthetic.chain_window(r, 2, n_kf=100, n_lm=25000, seed=20250620) for r in range(2)]
+    mps = []
+    for r, w in enumerate(wins):
+        g = gpu_solver_cls(0)
+        opt = g.options_default(); opt.max_num_iterations = 30
+        opt.function_tolerance = 1e-12; opt.gradient_tolerance = 1e-12; opt.parameter_tolerance = 1e-12
+        mps.append(sharding.MessagePassing(g, w, r, w.meta["shared"], opt))
+    over = []
+    orig = sharding.MessagePassing.solve_and_summarise
+
+    def timed(self):
+        t0 = time.perf_counter()
+        out = orig(self)
+        over.append(time.perf_counter() - t0 - self.last_summary.total_time_in_seconds)
+        return out
+    sharding.MessagePassing.solve_and_summarise = timed
+    try:
+        hist = sharding.message_passing_rounds(mps, 6, tol=1e-8)
+    finally:
+        sharding.MessagePassing.solve_and_summarise = orig
+    m = gpu_solver_cls(0)
+    cost, best = _merged_cost_of_chain(wins, mps, m)
+    assert abs(cost - best) <= 1e-6 * best, (cost, best, hist)
+    assert len(hist) <= 6
+    per_round = sorted(over[2:])                                            # (the first round of each window includes finalize)
+    assert per_round[len(per_round) // 2] < 5e-3, per_round                 # median overhead per window and round
