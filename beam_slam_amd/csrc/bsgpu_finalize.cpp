@@ -1,7 +1,6 @@
 // finalize(): flattening of the described problem to device tables — what [EXT] fuse HashGraph::createProblem does for the
 // reference's `graph_->optimize()` (bs_optimizers/src/fixed_lag_smoother.cpp:281), with a deterministic variable index.
 #include "bsgpu_ctx.h"
-#include "band_plan.h"
 
 namespace bsg {
 
@@ -166,9 +165,6 @@ int finalize(bsgpu_ctx* c) {
   c->dense_src.clear();
   c->vis_src.clear();
   c->d_vis_src = nullptr;
-  // band landmarks on the matrix cores (k_reproj.hip: pairs_band_kernel) unless BSGPU_PAIRS_BAND=0 (every pair by entries: the cross-check)
-  const char* band_env = getenv("BSGPU_PAIRS_BAND");
-  const bool band_on = !(band_env && !strcmp(band_env, "0"));
   auto host_visual = [&]() -> int {
   { const int rc_m = materialize_mirror(c); if (rc_m != BSGPU_OK) return rc_m; }
   struct VF { int xq, xp, xl, bq, bp, meta_cam, loss, flags, lm, src; double u, v, w; };
@@ -281,15 +277,6 @@ int finalize(bsgpu_ctx* c) {
     for (int l = 0; l < nl; ++l) lm_start[l + 1] += lm_start[l];
     V.n_elim = n_elim;
     lap("camera-pose ids");
-    // band landmarks (band_plan.h): their pair entries shrink to (a, ~a), the products W_a W_b^T are pairs_band_kernel's
-    std::vector<int> b_cmin(nl, -1), b_mask(nl, 0);
-    std::vector<int4> b_rec;
-    if (band_on && nl > 0) band_classify_host(nl, lm_start.data(), cam_pose.data(), b_cmin, b_mask, b_rec);
-    BandUnits bu;
-    band_units(nl, b_cmin.data(), b_mask.data(), V.n_cam_pose, bu);
-    std::vector<int4> b_lm(bu.lm.size());
-    for (size_t i = 0; i < bu.lm.size(); ++i) b_lm[i] = b_rec[bu.lm[i]];
-    V.n_band_lm = (int)bu.lm.size(); V.n_band_units = (int)bu.unit_cam.size();
     // pair entries (factor a, factor b) of every landmark, grouped by camera-pose pair (ca <= cb); inside a group the
     // order is landmark-major.  Two passes over the landmarks: count per pair key, then fill in place.
     const uint64_t ncp = (uint64_t)std::max(1, V.n_cam_pose);
@@ -299,7 +286,6 @@ int finalize(bsgpu_ctx* c) {
       for (int l = 0; l < nl; ++l)
         for (int a = lm_start[l]; a < lm_start[l + 1]; ++a) {
           const uint64_t ra = (uint64_t)cam_pose[a] * ncp;
-          if (b_cmin[l] >= 0) { start[ra + cam_pose[a] + 1]++; continue; }
           for (int b = lm_start[l]; b < lm_start[l + 1]; ++b) if (cam_pose[a] <= cam_pose[b]) start[ra + cam_pose[b] + 1]++;
         }
       for (int f = n_elim; f < nv; ++f) start[(uint64_t)cam_pose[f] * ncp + cam_pose[f] + 1]++;
@@ -314,7 +300,6 @@ int finalize(bsgpu_ctx* c) {
       for (int l = 0; l < nl; ++l)
         for (int a = lm_start[l]; a < lm_start[l + 1]; ++a) {
           const uint64_t ra = (uint64_t)cam_pose[a] * ncp;
-          if (b_cmin[l] >= 0) { const int p = pos[ra + cam_pose[a]]++; ent_fa[p] = a; ent_fb[p] = ~a; continue; }
           for (int b = lm_start[l]; b < lm_start[l + 1]; ++b)
             if (cam_pose[a] <= cam_pose[b]) { const int p = pos[ra + cam_pose[b]]++; ent_fa[p] = a; ent_fb[p] = b; }
         }
@@ -325,11 +310,9 @@ int finalize(bsgpu_ctx* c) {
       std::vector<Ent> ents;
       ents.reserve((size_t)nv * 5);
       for (int l = 0; l < nl; ++l)
-        for (int a = lm_start[l]; a < lm_start[l + 1]; ++a) {
-          if (b_cmin[l] >= 0) { ents.push_back({(uint64_t)cam_pose[a] * ncp + cam_pose[a], a, ~a}); continue; }
+        for (int a = lm_start[l]; a < lm_start[l + 1]; ++a)
           for (int b = lm_start[l]; b < lm_start[l + 1]; ++b)
             if (cam_pose[a] <= cam_pose[b]) ents.push_back({(uint64_t)cam_pose[a] * ncp + cam_pose[b], a, b});
-        }
       for (int f = n_elim; f < nv; ++f) ents.push_back({(uint64_t)cam_pose[f] * ncp + cam_pose[f], f, f});
       std::stable_sort(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) { return x.key < y.key; });
       ent_fa.resize(ents.size()); ent_fb.resize(ents.size());
@@ -349,8 +332,6 @@ int finalize(bsgpu_ctx* c) {
     V.cp_tq = c->upload(cp_tq); V.cp_tp = c->upload(cp_tp);
     V.seg_ci = c->upload(seg_ci); V.seg_cj = c->upload(seg_cj); V.seg_start = c->upload(seg_start);
     V.ent_fa = c->upload(ent_fa); V.ent_fb = c->upload(ent_fb);
-    V.band_lm = c->upload(b_lm); V.band_unit_start = c->upload(bu.unit_start); V.band_unit_cam = c->upload(bu.unit_cam);
-    V.band_cam_units = c->upload(bu.cam_units);
     // structural tile adjacency of the reduced system (natural 64-wide tiles) for the Cholesky plan
     const int T = (c->n_pose + 63) / 64;
     c->tile_adj.assign((size_t)T * T, 0);
@@ -364,20 +345,6 @@ int finalize(bsgpu_ctx* c) {
       const int i = seg_ci[s], j = seg_cj[s];
       const int ri[2] = {cp_tq[i], cp_tp[i]}, rj[2] = {cp_tq[j], cp_tp[j]};
       for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) touch(ri[a], rj[b]);
-    }
-    if (V.n_band_lm > 0) {   // the camera-pose pairs of the band landmarks have no segments: distinct pairs first, then their tiles
-      std::vector<uint64_t> pairs;
-      for (const int l : bu.lm) {
-        for (int fa = lm_start[l]; fa < lm_start[l + 1]; ++fa)
-          for (int fb = fa + 1; fb < lm_start[l + 1]; ++fb) pairs.push_back(((uint64_t)cam_pose[fa] << 32) | (uint32_t)cam_pose[fb]);
-        if (pairs.size() > (1u << 20)) { std::sort(pairs.begin(), pairs.end()); pairs.erase(std::unique(pairs.begin(), pairs.end()), pairs.end()); }
-      }
-      std::sort(pairs.begin(), pairs.end()); pairs.erase(std::unique(pairs.begin(), pairs.end()), pairs.end());
-      for (uint64_t pr : pairs) {
-        const int i = (int)(pr >> 32), j = (int)(pr & 0xffffffffu);
-        const int ri[2] = {cp_tq[i], cp_tp[i]}, rj[2] = {cp_tq[j], cp_tp[j]};
-        for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) touch(ri[a], rj[b]);
-      }
     }
   }
     return BSGPU_OK;
@@ -406,7 +373,7 @@ int finalize(bsgpu_ctx* c) {
         const FlattenResident res = {mir.d_idx, mir.d_consts, mir.d_lk, mir.d_la, mir.d_s2b};
         const int st = flatten_visual_device(c->stream, dalloc, g0.n, g0.idx.data(), g0.consts.data(), g0.loss_kind.data(), g0.loss_a.data(),
                                              losses, nb, d_bx, d_bt, d_bc, d_bl, nl, T, c->vis, &c->d_vis_src, c->tile_adj, &all_const,
-                                             resident ? &res : nullptr, band_on);
+                                             resident ? &res : nullptr);
         if (st < 0) return fail(c, BSGPU_ERR_DEVICE, "device error while flattening the reprojection factors");
         if (st == 0) {
           flattened_on_device = true;
@@ -425,7 +392,6 @@ int finalize(bsgpu_ctx* c) {
     const int nv = V.n;
     V.r = c->alloc<double2>(nv); V.J = c->alloc<double>((size_t)nv * (kJAStride + 6)); V.JB = V.J ? V.J + (size_t)nv * kJAStride : nullptr; V.CR = c->alloc<double>((size_t)nv * 8);
     V.Linv = c->alloc<double>((size_t)nl * 6); V.z = c->alloc<double>((size_t)nl * 3);
-    if (V.n_band_units > 0) { V.band_part = c->alloc<double>((size_t)V.n_band_units * (kBandCams * (kBandCams + 1) / 2 * 36)); if (!V.band_part) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (band partials)"); }
     V.n_cost_part = (nv + 255) / 256;
     V.cost_part = c->alloc<double>(V.n_cost_part);
     V.cost_part_cand = c->alloc<double>(V.n_cost_part);

@@ -28,8 +28,6 @@ constexpr int kJAStride = 12;
 // entries of one camera pair are cut into segments of at most this many (one single-wave workgroup of pairs_kernel each);
 // a power of two.  Host and device flattening must agree (their tables are compared bit for bit).
 constexpr int kPairChunk = 256;
-constexpr int kBandCams = 13;     // a landmark seen only within this many consecutive camera poses is a "band" landmark (k_reproj.hip: pairs_band_kernel)
-constexpr int kBandPart = 128;    // landmarks per workgroup of that kernel, at most
 
 // meta word of a reprojection factor: camera id | loss id | constant-block flags
 constexpr int kMetaCamBits = 12, kMetaLossBits = 12;
@@ -113,13 +111,7 @@ struct Visual {
   // pair segments
   int n_seg = 0, n_ent = 0;
   int* seg_ci = nullptr; int* seg_cj = nullptr; int* seg_start = nullptr;
-  int* ent_fa = nullptr; int* ent_fb = nullptr;   // (fb = ~fa: the observation of a band landmark)
-  // band landmarks (band_plan.h): units = (first camera pose, part of its landmarks), landmarks as records (first factor row,
-  // mask of the camera-pose slots seen | observations << 16, slot of observation o in nibble o of z | w << 32)
-  int n_band_units = 0, n_band_lm = 0;
-  int* band_unit_start = nullptr; int* band_unit_cam = nullptr; int4* band_lm = nullptr;
-  int* band_cam_units = nullptr;        // camera pose k0 -> its first unit (n_cam_pose + 1)
-  double* band_part = nullptr;          // n_band_units x 91 x 36: the units' blocks ((slot bi >= slot bj) x 6 x 6)
+  int* ent_fa = nullptr; int* ent_fb = nullptr;
   // outputs
   double2* r = nullptr;       // n
   double* J = nullptr;        // robustified Jacobian, split by consumer: pose part n x 12 ([A row 0 (theta, t: 6) | A row 1]) ...
@@ -162,7 +154,6 @@ void launch_landmark(hipStream_t s, const Visual& v, int n_pose, const double* r
                      double* grad, const ZeroStep* zero = nullptr, double radius_val = 0.0);
 void launch_pairs(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm,
                   bool grad_only, const SmallGroupSet* small = nullptr, int n_small_units = 0);
-void launch_pairs_band(hipStream_t s, const Visual& v, double* S, int ld, const int* perm);
 int small_assemble_first_set(const SmallGroup* groups, int n_groups, SmallGroupSet* set, int* n_taken);
 void launch_small_assemble_set(hipStream_t s, const SmallGroup* groups, int n_groups, double* S, int ld, int rhs_row, double* grad,
                                double* hdiag, const int* perm);
@@ -221,8 +212,7 @@ void launch_patch_factor_rows(hipStream_t s, int n_ch, const int* rows, const in
 int flatten_visual_device(hipStream_t s, const std::function<void*(size_t)>& dalloc, int n, const int* h_idx, const double* h_consts,
                           const int* h_loss_kind, const double* h_loss_a, const std::vector<DevLoss>& losses, int nb, const int* d_blk_xoff,
                           const int* d_blk_toff, const unsigned char* d_blk_const, const int* d_blk_lm, int nl, int T, Visual& V,
-                          int** d_vis_src, std::vector<unsigned char>& tile_adj, bool* any_all_const, const FlattenResident* res = nullptr,
-                          bool band_enabled = true);
+                          int** d_vis_src, std::vector<unsigned char>& tile_adj, bool* any_all_const, const FlattenResident* res = nullptr);
 int chol_vinv_stride();
 void chol_prepare();  // one-time function attributes (kept out of captured sequences)
 // block-sparse PCG path (k_pcg.hip)

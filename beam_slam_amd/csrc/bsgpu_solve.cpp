@@ -207,7 +207,6 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
     if (c->vis.n_seg > 0) units = small_assemble_first_set(c->small_factorwise + 2, kNumInternal - 2, &set, &taken);
     if (units == 0) taken = 0;
     launch_pairs(s, c->vis, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm, gradient_only, units > 0 ? &set : nullptr, units);
-    if (!gradient_only) launch_pairs_band(s, c->vis, c->d_S, c->npad, c->d_perm);
     phase_mark(c, BSGPU_PHASE_PAIRS);
     // (... or, without a pair launch, in the launch of the segment-wise assembled groups)
     SmallGroupSet set2;

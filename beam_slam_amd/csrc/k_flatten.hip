@@ -16,7 +16,6 @@
 #include <vector>
 
 #include "bsgpu_device.h"
-#include "band_plan.h"
 
 namespace bsg {
 
@@ -81,77 +80,20 @@ __global__ void fl_gather_kernel(int n, const int* __restrict__ order, const int
   if (lm >= 0) atomicAdd(&lm_cnt[lm], 1);
 }
 
-// band landmarks (band_plan.h: band_classify_host is the same rule on the host): first camera pose or -1, mask of the slots seen, slot of
-// every factor
-__global__ void fl_band_kernel(int nl, const int* __restrict__ lm_start, const int* __restrict__ cam_pose, int enabled, int* __restrict__ cmin,
-                               int* __restrict__ mask, int4* __restrict__ rec) {
-  const int l = blockIdx.x * 256 + threadIdx.x;
-  if (l >= nl) return;
-  const int b = lm_start[l], e = lm_start[l + 1];
-  int lo = 0x7fffffff, hi = -1;
-  for (int f = b; f < e; ++f) { const int c = cam_pose[f]; lo = c < lo ? c : lo; hi = c > hi ? c : hi; }
-  bool ok = enabled && e - b >= 2 && e - b <= kBandCams && hi - lo < kBandCams;
-  unsigned m = 0;
-  unsigned long long nib = 0;
-  if (ok) for (int f = b; f < e; ++f) {
-    const unsigned bit = 1u << (cam_pose[f] - lo);
-    ok = ok && !(m & bit); m |= bit;
-    nib |= (unsigned long long)(cam_pose[f] - lo) << (4 * (f - b));
-  }
-  cmin[l] = ok ? lo : -1; mask[l] = ok ? (int)m : 0;
-  rec[l] = make_int4(b, (int)(m | ((unsigned)(e - b) << 16)), (int)(unsigned)nib, (int)(unsigned)(nib >> 32));
-}
-__global__ void fl_band_gather_kernel(int n, const int* __restrict__ order, const int4* __restrict__ rec, int4* __restrict__ out) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) out[i] = rec[order[i]];
-}
-// tile adjacency of the camera-pose pairs of the band landmarks (their pair entries are not generated: fl_seg_kernel does not see them)
-__global__ void fl_band_adj_kernel(int nl, const int* __restrict__ lm_start, const int* __restrict__ cam_pose, const int* __restrict__ cmin,
-                                   const int* __restrict__ cp_tq, const int* __restrict__ cp_tp, unsigned char* __restrict__ tile_adj, int T) {
-  const int l = blockIdx.x * 256 + threadIdx.x;
-  if (l >= nl || cmin[l] < 0) return;
-  for (int fa = lm_start[l]; fa < lm_start[l + 1]; ++fa)
-    for (int fb = fa + 1; fb < lm_start[l + 1]; ++fb) {
-      const int ci = cam_pose[fa], cj = cam_pose[fb];
-      const int ri[2] = {cp_tq[ci], cp_tp[ci]}, rj[2] = {cp_tq[cj], cp_tp[cj]};
-      for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) {
-        if (ri[a] < 0 || rj[b] < 0) continue;
-        for (int x = ri[a]; x < ri[a] + 3; x += 2) for (int y = rj[b]; y < rj[b] + 3; y += 2) {
-          unsigned char* p = &tile_adj[(size_t)(x / 64) * T + y / 64];
-          unsigned char* q = &tile_adj[(size_t)(y / 64) * T + x / 64];
-          if (!*p) *p = 1;
-          if (!*q) *q = 1;
-        }
-      }
-    }
-}
-
-// pair entries of a landmark: (a, b) over its factors with cam(a) <= cam(b), a-major (the host loop's order); of a band landmark only
-// (a, ~a)
-__global__ void fl_pair_count_kernel(int nl, const int* __restrict__ lm_start, const int* __restrict__ cam_pose, const int* __restrict__ cmin,
-                                     int* __restrict__ cnt) {
+// pair entries of a landmark: (a, b) over its factors with cam(a) <= cam(b), a-major (the host loop's order)
+__global__ void fl_pair_count_kernel(int nl, const int* __restrict__ lm_start, const int* __restrict__ cam_pose, int* __restrict__ cnt) {
   const int l = blockIdx.x * 256 + threadIdx.x;
   if (l >= nl) return;
   int n = 0;
-  if (cmin[l] >= 0) n = lm_start[l + 1] - lm_start[l];
-  else
-    for (int a = lm_start[l]; a < lm_start[l + 1]; ++a)
-      for (int b = lm_start[l]; b < lm_start[l + 1]; ++b) n += cam_pose[a] <= cam_pose[b];
+  for (int a = lm_start[l]; a < lm_start[l + 1]; ++a)
+    for (int b = lm_start[l]; b < lm_start[l + 1]; ++b) n += cam_pose[a] <= cam_pose[b];
   cnt[l] = n;
 }
-__global__ void fl_pair_gen_kernel(int nl, const int* __restrict__ lm_start, const int* __restrict__ cam_pose, const int* __restrict__ cmin,
-                                   const int* __restrict__ off, unsigned long long ncp, unsigned long long* __restrict__ key,
-                                   unsigned long long* __restrict__ val) {
+__global__ void fl_pair_gen_kernel(int nl, const int* __restrict__ lm_start, const int* __restrict__ cam_pose, const int* __restrict__ off,
+                                   unsigned long long ncp, unsigned long long* __restrict__ key, unsigned long long* __restrict__ val) {
   const int l = blockIdx.x * 256 + threadIdx.x;
   if (l >= nl) return;
   int o = off[l];
-  if (cmin[l] >= 0) {
-    for (int a = lm_start[l]; a < lm_start[l + 1]; ++a, ++o) {
-      key[o] = (unsigned long long)cam_pose[a] * ncp + (unsigned long long)cam_pose[a];
-      val[o] = ((unsigned long long)(unsigned)a << 32) | (unsigned)(~a);
-    }
-    return;
-  }
   for (int a = lm_start[l]; a < lm_start[l + 1]; ++a)
     for (int b = lm_start[l]; b < lm_start[l + 1]; ++b)
       if (cam_pose[a] <= cam_pose[b]) {
@@ -223,7 +165,7 @@ void launch_patch_factor_rows(hipStream_t s, int n_ch, const int* rows, const in
 int flatten_visual_device(hipStream_t s, const std::function<void*(size_t)>& dalloc, int n, const int* h_idx, const double* h_consts,
                           const int* h_loss_kind, const double* h_loss_a, const std::vector<DevLoss>& losses, int nb, const int* d_blk_xoff,
                           const int* d_blk_toff, const unsigned char* d_blk_const, const int* d_blk_lm, int nl, int T, Visual& V,
-                          int** d_vis_src, std::vector<unsigned char>& tile_adj, bool* any_all_const, const FlattenResident* res, bool band_enabled) {
+                          int** d_vis_src, std::vector<unsigned char>& tile_adj, bool* any_all_const, const FlattenResident* res) {
   auto A = [&](size_t bytes) { return dalloc(bytes ? bytes : 8); };
 #define FL_CHK(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); return -1; } } while (0)
   const int g256 = (n + 255) / 256;
@@ -295,30 +237,12 @@ int flatten_visual_device(hipStream_t s, const std::function<void*(size_t)>& dal
   size_t tmp2_bytes = need2 > tmp_bytes ? need2 : tmp_bytes;
   if (!d_tmp2) return -1;
   FL_CHK(rocprim::exclusive_scan(d_tmp2, tmp2_bytes, d_lmcnt, V.lm_start, 0, (size_t)nl + 1, rocprim::plus<int>(), s));
-  int *d_bcmin = (int*)A(sizeof(int) * ((size_t)nl + 1)), *d_bmask = (int*)A(sizeof(int) * ((size_t)nl + 1));
-  int4* d_brec = (int4*)A(sizeof(int4) * ((size_t)nl + 1));
-  if (!d_bcmin || !d_bmask || !d_brec) return -1;
-  std::vector<int> h_bcmin(nl), h_bmask(nl);
-  if (nl > 0) {
-    hipLaunchKernelGGL(fl_band_kernel, dim3((nl + 255) / 256), dim3(256), 0, s, nl, V.lm_start, V.cam_pose, band_enabled ? 1 : 0, d_bcmin, d_bmask, d_brec);
-    hipLaunchKernelGGL(fl_pair_count_kernel, dim3((nl + 255) / 256), dim3(256), 0, s, nl, V.lm_start, V.cam_pose, d_bcmin, d_pcnt);
-    FL_CHK(hipMemcpyAsync(h_bcmin.data(), d_bcmin, sizeof(int) * (size_t)nl, hipMemcpyDeviceToHost, s));
-    FL_CHK(hipMemcpyAsync(h_bmask.data(), d_bmask, sizeof(int) * (size_t)nl, hipMemcpyDeviceToHost, s));
-  }
+  if (nl > 0) hipLaunchKernelGGL(fl_pair_count_kernel, dim3((nl + 255) / 256), dim3(256), 0, s, nl, V.lm_start, V.cam_pose, d_pcnt);
   FL_CHK(rocprim::exclusive_scan(d_tmp2, tmp2_bytes, d_pcnt, d_poff, 0, (size_t)nl + 1, rocprim::plus<int>(), s));
   int h_nelim = 0, h_npairs = 0;
   FL_CHK(hipMemcpyAsync(&h_nelim, V.lm_start + nl, sizeof(int), hipMemcpyDeviceToHost, s));
   FL_CHK(hipMemcpyAsync(&h_npairs, d_poff + nl, sizeof(int), hipMemcpyDeviceToHost, s));
-  FL_CHK(hipStreamSynchronize(s));                                  // sync #2: entry count, band landmarks
-  // units of the band kernel: built on the host (a counting sort of the landmarks) while the device sorts the pair entries
-  BandUnits bu;
-  band_units(nl, h_bcmin.data(), h_bmask.data(), h_ncp, bu);
-  V.n_band_lm = (int)bu.lm.size(); V.n_band_units = (int)bu.unit_cam.size();
-  V.band_lm = (int4*)A(sizeof(int4) * bu.lm.size()); V.band_unit_start = (int*)A(sizeof(int) * bu.unit_start.size());
-  V.band_unit_cam = (int*)A(sizeof(int) * bu.unit_cam.size());
-  V.band_cam_units = (int*)A(sizeof(int) * bu.cam_units.size());
-  int* d_border = (int*)A(sizeof(int) * bu.lm.size());
-  if (!V.band_lm || !V.band_unit_start || !V.band_unit_cam || !V.band_cam_units || !d_border) return -1;
+  FL_CHK(hipStreamSynchronize(s));                                  // sync #2: entry count
   V.n_elim = h_nelim;
   const int n_ent = h_npairs + (n - h_nelim);
   V.n_ent = n_ent;
@@ -331,15 +255,7 @@ int flatten_visual_device(hipStream_t s, const std::function<void*(size_t)>& dal
   int* d_segsel = (int*)A(sizeof(int) * ((size_t)n_ent + 1));
   int* d_nseg = (int*)A(sizeof(int) * 2);
   if (!d_ek || !d_ev || !d_ek2 || !d_ev2 || !V.ent_fa || !V.ent_fb || !d_runidx || !d_runstart || !d_segflag || !d_segsel || !d_nseg) return -1;
-  if (nl > 0) hipLaunchKernelGGL(fl_pair_gen_kernel, dim3((nl + 255) / 256), dim3(256), 0, s, nl, V.lm_start, V.cam_pose, d_bcmin, d_poff, ncp, d_ek, d_ev);
-  // (pageable sources that live to the end of this function, past the last synchronisation)
-  if (!bu.lm.empty()) {
-    FL_CHK(hipMemcpyAsync(d_border, bu.lm.data(), sizeof(int) * bu.lm.size(), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(fl_band_gather_kernel, dim3(((int)bu.lm.size() + 255) / 256), dim3(256), 0, s, (int)bu.lm.size(), d_border, d_brec, V.band_lm);
-  }
-  FL_CHK(hipMemcpyAsync(V.band_unit_start, bu.unit_start.data(), sizeof(int) * bu.unit_start.size(), hipMemcpyHostToDevice, s));
-  FL_CHK(hipMemcpyAsync(V.band_cam_units, bu.cam_units.data(), sizeof(int) * bu.cam_units.size(), hipMemcpyHostToDevice, s));
-  if (!bu.unit_cam.empty()) FL_CHK(hipMemcpyAsync(V.band_unit_cam, bu.unit_cam.data(), sizeof(int) * bu.unit_cam.size(), hipMemcpyHostToDevice, s));
+  if (nl > 0) hipLaunchKernelGGL(fl_pair_gen_kernel, dim3((nl + 255) / 256), dim3(256), 0, s, nl, V.lm_start, V.cam_pose, d_poff, ncp, d_ek, d_ev);
   if (n > h_nelim) hipLaunchKernelGGL(fl_pair_tail_kernel, dim3((n - h_nelim + 255) / 256), dim3(256), 0, s, h_nelim, n, V.cam_pose, ncp, h_npairs, d_ek, d_ev);
   int kbits = 1;
   while (kbits < 64 && (ncp * ncp) >> kbits) ++kbits;
@@ -373,7 +289,6 @@ int flatten_visual_device(hipStream_t s, const std::function<void*(size_t)>& dal
   FL_CHK(hipMemsetAsync(d_adj, 0, (size_t)T * T + 8, s));
   hipLaunchKernelGGL(fl_seg_kernel, dim3((h_nseg + 256) / 256), dim3(256), 0, s, h_nseg, n_ent, V.seg_start, d_ek2, ncp, V.seg_ci, V.seg_cj, V.cp_tq,
                      V.cp_tp, d_adj, T);
-  if (V.n_band_lm > 0) hipLaunchKernelGGL(fl_band_adj_kernel, dim3((nl + 255) / 256), dim3(256), 0, s, nl, V.lm_start, V.cam_pose, d_bcmin, V.cp_tq, V.cp_tp, d_adj, T);
   tile_adj.assign((size_t)T * T, 0);
   if (T > 0) FL_CHK(hipMemcpyAsync(tile_adj.data(), d_adj, (size_t)T * T, hipMemcpyDeviceToHost, s));
   FL_CHK(hipStreamSynchronize(s));

@@ -7,8 +7,6 @@
 // Reference for the arithmetic: bs_constraints/include/bs_constraints/visual/euclidean_reprojection_function.h:66-172
 // (residual; the quaternion Jacobian there is a forward difference — here it is the closed form
 // -A Jpi R_cb [P_b]x of SURVEY.md Appendix A) and bs_constraints/src/jacobians.cpp:202-214.
-#include <atomic>
-
 #include "bsgpu_device.h"
 
 namespace bsg {
@@ -377,9 +375,7 @@ __global__ __launch_bounds__(64) void pairs_kernel(int n_seg, const int* __restr
   for (int e0 = beg; e0 < end; e0 += 64) {
     const int e = e0 + lane;
     const bool live = e < end;
-    const int fa = fa_n;
-    const bool band = fb_n < 0;                  // (a, ~a): the observation of a band landmark — its C C^T part is pairs_band_kernel's
-    const int fb = band ? ~fb_n : fb_n;
+    const int fa = fa_n, fb = fb_n;
     if (e0 + 64 < end) { fa_n = ent_fa[min(e + 64, end - 1)]; fb_n = ent_fb[min(e + 64, end - 1)]; }
     sfa[lane] = fa; sfb[lane] = fb;
     __builtin_amdgcn_wave_barrier();
@@ -431,11 +427,10 @@ __global__ __launch_bounds__(64) void pairs_kernel(int n_seg, const int* __restr
     __builtin_amdgcn_wave_barrier();   // (the slab is rewritten by the next stride)
     if (!live) continue;
     const double same = (fa == fb) ? 1.0 : 0.0;
-    double t00 = same - (Ca[0] * Cb[0] + Ca[1] * Cb[1] + Ca[2] * Cb[2]);
-    double t01 = -(Ca[0] * Cb[3] + Ca[1] * Cb[4] + Ca[2] * Cb[5]);
-    double t10 = -(Ca[3] * Cb[0] + Ca[4] * Cb[1] + Ca[5] * Cb[2]);
-    double t11 = same - (Ca[3] * Cb[3] + Ca[4] * Cb[4] + Ca[5] * Cb[5]);
-    if (band) { t00 = 1.0; t01 = 0.0; t10 = 0.0; t11 = 1.0; }
+    const double t00 = same - (Ca[0] * Cb[0] + Ca[1] * Cb[1] + Ca[2] * Cb[2]);
+    const double t01 = -(Ca[0] * Cb[3] + Ca[1] * Cb[4] + Ca[2] * Cb[5]);
+    const double t10 = -(Ca[3] * Cb[0] + Ca[4] * Cb[1] + Ca[5] * Cb[2]);
+    const double t11 = same - (Ca[3] * Cb[3] + Ca[4] * Cb[4] + Ca[5] * Cb[5]);
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
       const double u0 = t00 * B0[c] + t01 * B1[c];
@@ -497,232 +492,6 @@ void launch_pairs(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row
   hipLaunchKernelGGL(pairs_kernel, dim3(pair_blocks + small_blocks), dim3(64), kPairsLds, s, v.n_seg, v.seg_ci, v.seg_cj, v.seg_start, v.ent_fa,
                      v.ent_fb, v.J, v.r, v.CR, v.cp_tq, v.cp_tp, S, ld, rhs_row, grad, hdiag, perm, grad_only ? 1 : 0, pair_blocks, small ? *small : none,
                      small_blocks);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// band landmarks: the camera-pair blocks of landmarks whose observations lie within kBandCams consecutive camera poses (every
-// feature track of a sliding window), on the matrix cores.  With W_a = A_a^T C_a (6x3) the pair block is
-//   A_a^T ([a==b] I - C_a C_b^T) A_b = [a==b] A_a^T A_a - W_a W_b^T,
-// so a landmark whose first camera pose is k0 contributes -Z Z^T, Z = its W_a stacked at rows 6 (cam_a - k0) (78 x 3, zero rows where a
-// camera pose does not see it).  One workgroup per (k0, part of its landmarks): every wave takes landmarks in turn, reads the landmark's
-// CONTIGUOUS rows of A and C once (the pair entries of pairs_kernel gather 304 B per entry, 4.9 entries per observation — measured:
-// 0.55 GB per launch from the L2, TA busy 63 % of the kernel; here 160 B per observation), forms Z in the v_mfma_f64_16x16x4 operand
-// layout — the SAME registers serve as A and B operand of Z_ti Z_tj^T — and accumulates the lower tiles over its landmarks in the
-// instruction (K = 3 per landmark, the fourth k is zero).  The waves' tiles are summed in LDS and the workgroup adds the 78 x 78
-// lower triangle into S once.  The [a==b] A^T A terms, the gradient and diag(H) stay with pairs_kernel (entries (a, ~a): T = I).
-// ---------------------------------------------------------------------------------------------------
-constexpr int kBandTiles = 5;                                    // ceil(6 kBandCams / 16)
-constexpr int kBandAcc = kBandTiles * (kBandTiles + 1) / 2;      // lower tiles
-constexpr int kBandWaves = 4;
-constexpr int kBandPartSize = kBandCams * (kBandCams + 1) / 2 * 36;   // a unit's block in the partial buffer: (slot bi >= bj) x 6 x 6
-constexpr int kBandBatch = 4;                                    // landmarks a wave has in flight
-constexpr int kBandSlab = kBandCams * (12 + 8);                  // doubles per landmark: A rows [slot][12] | C rows [slot][8]
-constexpr size_t kBandLds = sizeof(double) * (kBandAcc * 256 > kBandWaves * kBandBatch * kBandSlab ? kBandAcc * 256 : kBandWaves * kBandBatch * kBandSlab);
-
-typedef double band_d4 __attribute__((ext_vector_type(4)));
-template <int TI>
-BSG_DEV void band_row(const double (&z)[kBandTiles], band_d4 (&acc)[kBandAcc]) {
-#pragma unroll
-  for (int tj = 0; tj <= TI; ++tj) acc[TI * (TI + 1) / 2 + tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(z[TI], z[tj], acc[TI * (TI + 1) / 2 + tj], 0, 0, 0);
-}
-
-// the operand elements W[m][k] = A[0][m] C[0][k] + A[1][m] C[1][k] of one K = 4 column set, for the T tile rows its landmarks span, read
-// in one go.  (With the reads behind a per-tile-row condition a set spent 880 cycles fetching its 4 T values, one round trip per tile
-// row, against 64 cycles per product; a switch over T around the products made the compiler copy the 60 accumulators per case; measured.)
-template <int T>
-BSG_DEV void band_operands(const double* __restrict__ slab, const int (&offA)[kBandTiles], const int (&offC)[kBandTiles], int dA, int dC,
-                           const int (&slot_of)[kBandTiles], unsigned mk, double (&z)[kBandTiles]) {
-#pragma unroll
-  for (int t = 0; t < kBandTiles; ++t) z[t] = 0.0;
-#pragma unroll
-  for (int t = 0; t < T; ++t) {
-    const double v = slab[offA[t] + dA] * slab[offC[t] + dC] + slab[offA[t] + dA + 6] * slab[offC[t] + dC + 3];
-    z[t] = ((mk >> slot_of[t]) & 1u) ? v : 0.0;
-  }
-}
-
-__global__ __launch_bounds__(64 * kBandWaves, 2) void pairs_band_kernel(int n_units, const int* __restrict__ unit_start, const int* __restrict__ unit_cam,
-                                                                     const int4* __restrict__ band_lm, const double* __restrict__ J,
-                                                                     const double* __restrict__ CR, double* __restrict__ part) {
-  extern __shared__ __attribute__((aligned(16))) double bsm[];
-  // (XCD-aware like pairs_kernel: consecutive k0 read neighbouring landmarks' rows and add into the same blocks of S)
-  const int per_xcd = (int)gridDim.x >> 3;
-  const int u = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
-  if (u >= n_units) return;
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int beg = unit_start[u], end = unit_start[u + 1];
-  double* slab = bsm + wave * (kBandBatch * kBandSlab);
-  // This lane's elements of the operand: row 16 t + (lane & 15) = (camera-pose slot, m) of tile row t, and of the K = 12 columns of a
-  // batch (four landmarks x 3) column 4 s + (lane >> 4) in set s — all four k of the instruction carry a product (a landmark per
-  // instruction would leave the fourth empty).
-  const int kq = lane >> 4;
-  int offA[kBandTiles], offC[kBandTiles], slot_of[kBandTiles];
-#pragma unroll
-  for (int t = 0; t < kBandTiles; ++t) {
-    const int row = 16 * t + (lane & 15), sl = row / 6, m = row - 6 * sl;
-    const bool real = sl < kBandCams;
-    slot_of[t] = real ? sl : 31;                       // (bit 31 of a mask is never set: the element stays zero)
-    offA[t] = real ? sl * 12 + m : 0; offC[t] = kBandCams * 12 + (real ? sl * 8 : 0);
-  }
-  int dA[3], dC[3];                                    // landmark (slab) and component of column 4 s + kq
-  bool first_of[3];
-#pragma unroll
-  for (int st = 0; st < 3; ++st) {
-    const int g = 4 * st + kq, d = g / 3, comp = g - 3 * d;
-    dA[st] = d * kBandSlab; dC[st] = d * kBandSlab + comp;
-    first_of[st] = d == (4 * st) / 3;                  // (a set spans two landmarks: (4 s) / 3 and the next)
-  }
-  // where this lane's pieces of a landmark's rows go: piece p of the A rows is double2 p % 6 of observation p / 6, of the C rows p & 3 of p >> 2
-  const int oa0 = lane / 6, pa0 = lane - 6 * oa0, oa1 = (lane + 64) / 6, pa1 = lane + 64 - 6 * oa1, oc = lane >> 2, pc = lane & 3;
-  band_d4 acc[kBandAcc];
-#pragma unroll
-  for (int i = 0; i < kBandAcc; ++i) acc[i] = band_d4{0.0, 0.0, 0.0, 0.0};
-  const double2* J2 = reinterpret_cast<const double2*>(J);
-  const double2* C2 = reinterpret_cast<const double2*>(CR);
-  // A wave takes kBandBatch landmarks at a time: the records of the batch after the next (scalar loads), the rows of the next batch and
-  // the products of this one are in flight together — with one landmark at a time the three dependent round trips (record, rows, LDS)
-  // of 0.3 us of products each were the whole run time (72 us; measured).
-  // (explicitly named registers and unconditional loads with the index clamped into the landmark's rows: arrays of loaded values went to
-  // scratch memory with a wait after every load — 10 us per batch, measured)
-  static_assert(kBandBatch == 4, "BAND_EACH names four landmarks");
-  typedef int rec_i4 __attribute__((ext_vector_type(4)));
-  typedef const rec_i4 __attribute__((address_space(4))) * rec_ptr;   // (constant address space: a uniform index is a scalar load)
-  const rec_ptr recs = (rec_ptr)(unsigned long long)band_lm;
-#define BAND_EACH(X) X(0) X(1) X(2) X(3)
-#define BAND_DECL(d) int4 rec##d, recn##d; double2 va0_##d, va1_##d, vc_##d;
-  BAND_EACH(BAND_DECL)
-  const int4 none = make_int4(0, 0, 0, 0);
-#define BAND_RECORD(r, b0, d) { const int i_ = (b0) + d * kBandWaves; const rec_i4 t_ = recs[i_ < end ? i_ : end - 1]; r##d = i_ < end ? make_int4(t_.x, t_.y, t_.z, t_.w) : none; }
-#define BAND_ROWS(d) {                                                                                            \
-    const int f0_ = rec##d.x, n_ = rec##d.y >> 16;                                                                \
-    va0_##d = J2[(size_t)f0_ * 6 + max(min(lane, 6 * n_ - 1), 0)];                                                \
-    va1_##d = J2[(size_t)f0_ * 6 + max(min(lane + 64, 6 * n_ - 1), 0)];                                           \
-    vc_##d = C2[(size_t)f0_ * 4 + max(min(lane, 4 * n_ - 1), 0)]; }
-#define BAND_REC0(d) BAND_RECORD(rec, base, d)
-#define BAND_REC1(d) BAND_RECORD(recn, base + kBandBatch * kBandWaves, d)
-#define BAND_REC2(d) BAND_RECORD(recn, base + 2 * kBandBatch * kBandWaves, d)
-  // the batch's rows into the slabs, every observation at its camera-pose slot; then the record of the next batch takes its place
-#define BAND_STAGE(d) {                                                                                           \
-    const int n_ = rec##d.y >> 16;                                                                                \
-    const unsigned long long nib = (unsigned long long)(unsigned)rec##d.z | ((unsigned long long)(unsigned)rec##d.w << 32); \
-    double2* sA = reinterpret_cast<double2*>(slab + d * kBandSlab);                                               \
-    double2* sC = sA + kBandCams * 6;                                                                             \
-    if (lane < 6 * n_) sA[(int)((nib >> (4 * oa0)) & 15) * 6 + pa0] = va0_##d;                                    \
-    if (lane + 64 < 6 * n_) sA[(int)((nib >> (4 * oa1)) & 15) * 6 + pa1] = va1_##d;                               \
-    if (lane < 4 * n_) sC[(int)((nib >> (4 * oc)) & 15) * 4 + pc] = vc_##d;                                       \
-    cur_mask[d] = (unsigned)rec##d.y & 0xffffu;                                                                   \
-    rec##d = recn##d; }
-  int base = beg + wave;
-  BAND_EACH(BAND_REC0)
-  BAND_EACH(BAND_ROWS)
-  BAND_EACH(BAND_REC1)
-  for (; base < end; base += kBandBatch * kBandWaves) {
-    unsigned cur_mask[kBandBatch];
-    BAND_EACH(BAND_STAGE)
-    BAND_EACH(BAND_ROWS)
-    BAND_EACH(BAND_REC2)
-    __builtin_amdgcn_wave_barrier();
-    const unsigned all = cur_mask[0] | cur_mask[1] | cur_mask[2] | cur_mask[3];
-    const int top = 32 - __builtin_clz(all | 1u);              // camera poses spanned by the batch (its landmarks are sorted by span)
-    const int T = (6 * top + 15) >> 4;                         // tile rows that hold something (wave-uniform)
-    unsigned mk[3];
-#pragma unroll
-    for (int st = 0; st < 3; ++st) mk[st] = first_of[st] ? cur_mask[(4 * st) / 3] : cur_mask[(4 * st) / 3 + 1];
-#pragma unroll
-    for (int st = 0; st < 3; ++st) {
-      double z[kBandTiles];
-      switch (T) {
-        case 1: band_operands<1>(slab, offA, offC, dA[st], dC[st], slot_of, mk[st], z); break;
-        case 2: band_operands<2>(slab, offA, offC, dA[st], dC[st], slot_of, mk[st], z); break;
-        case 3: band_operands<3>(slab, offA, offC, dA[st], dC[st], slot_of, mk[st], z); break;
-        case 4: band_operands<4>(slab, offA, offC, dA[st], dC[st], slot_of, mk[st], z); break;
-        default: band_operands<5>(slab, offA, offC, dA[st], dC[st], slot_of, mk[st], z); break;
-      }
-      band_row<0>(z, acc);
-      if (T > 1) { band_row<1>(z, acc);
-        if (T > 2) { band_row<2>(z, acc);
-          if (T > 3) { band_row<3>(z, acc);
-            if (T > 4) band_row<4>(z, acc); } } }
-    }
-    __builtin_amdgcn_wave_barrier();                            // (the slabs are rewritten by the next batch)
-  }
-#undef BAND_EACH
-#undef BAND_DECL
-#undef BAND_RECORD
-#undef BAND_ROWS
-#undef BAND_REC0
-#undef BAND_REC1
-#undef BAND_REC2
-#undef BAND_STAGE
-  // sum of the waves' tiles in LDS (ds_add_f64: every lane its own address); the workgroup's 78 x 78 block goes to its slot of the partial
-  // buffer with plain stores.  (Added into S from here — 5 000 FP64 atomics per workgroup, all workgroups ending together — the adds took
-  // 16 us of a 49 us kernel: they are performed beyond the L2s and the device takes ~75 G of them per second; measured.)
-  __syncthreads();
-  for (int q = threadIdx.x; q < kBandAcc * 256; q += 64 * kBandWaves) bsm[q] = 0.0;
-  __syncthreads();
-#pragma unroll
-  for (int a = 0; a < kBandAcc; ++a)
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg)
-      if (acc[a][reg] != 0.0) __hip_atomic_fetch_add(&bsm[a * 256 + reg * 64 + lane], acc[a][reg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  __syncthreads();
-  // ... block by block ((slot bi >= slot bj) x 6 x 6: what a thread of the reduction reads next to its neighbours)
-  double* out = part + (size_t)u * kBandPartSize;
-  for (int q = threadIdx.x; q < kBandPartSize; q += 64 * kBandWaves) {
-    const int blk = q / 36, mm = q - 36 * blk, ma = mm / 6, mb = mm - 6 * ma;
-    int bi = (int)((__builtin_sqrtf(8.0f * (float)blk + 1.0f) - 1.0f) * 0.5f);
-    bi += ((bi + 1) * (bi + 2) / 2 <= blk) ? 1 : 0; bi -= (bi * (bi + 1) / 2 > blk) ? 1 : 0;
-    const int bj = blk - bi * (bi + 1) / 2;
-    int R = 6 * bi + ma, C = 6 * bj + mb;
-    if (C > R) { const int t_ = R; R = C; C = t_; }                // (inside a diagonal block: its lower half, mirrored)
-    const int ti = R >> 4, tj = C >> 4, rin = R & 15, cin = C & 15;
-    out[q] = bsm[(ti * (ti + 1) / 2 + tj) * 256 + (rin >> 2) * 64 + (rin & 3) * 16 + cin];
-  }
-}
-
-// S -= the partial blocks: one thread per element (camera pose i, j = i + dj, mi, mj) of the band, summing over the units whose first
-// camera pose k0 lies in [j - (kBandCams - 1), i] in unit order (a fixed order: the same bits every run) and updating S and its mirror
-// element with plain read-modify-writes — nothing else writes S between the pair launch before and the factor-wise groups after.
-__global__ __launch_bounds__(256) void pairs_band_reduce_kernel(int n_cam_pose, const int* __restrict__ cam_units, const int* __restrict__ unit_cam, const double* __restrict__ part,
-                                                                const int* __restrict__ cp_tq, const int* __restrict__ cp_tp,
-                                                                double* __restrict__ S, int ld, const int* __restrict__ perm) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  const int i = e / (kBandCams * 36), rem = e - i * (kBandCams * 36), dj = rem / 36, mm = rem - 36 * dj, mi = mm / 6, mj = mm - 6 * mi;
-  const int j = i + dj;
-  if (i >= n_cam_pose || j >= n_cam_pose || (dj == 0 && mj > mi)) return;
-  const int bi = mi < 3 ? cp_tq[i] : cp_tp[i], bj = mj < 3 ? cp_tq[j] : cp_tp[j];
-  if (bi < 0 || bj < 0) return;
-  // (the units of consecutive k0 are consecutive: one range, every read independent of the others)
-  const int ub = cam_units[max(0, j - (kBandCams - 1))], ue = cam_units[i + 1];
-  double sum = 0.0;
-#pragma unroll 8
-  for (int uu = ub; uu < ue; ++uu) {
-    const int k0 = unit_cam[uu];
-    const int bi = j - k0, bj = i - k0;                           // (bi >= bj; element [mj][mi] of that block)
-    sum += part[(size_t)uu * kBandPartSize + (bi * (bi + 1) / 2 + bj) * 36 + mj * 6 + mi];
-  }
-  if (sum == 0.0) return;
-  const int ri = bi + (mi < 3 ? mi : mi - 3), rj = bj + (mj < 3 ? mj : mj - 3);
-  const int sr = perm[ri >> 6] * 64 + (ri & 63), sc = perm[rj >> 6] * 64 + (rj & 63);
-  S[(size_t)sr * ld + sc] -= sum;
-  if (sr != sc) S[(size_t)sc * ld + sr] -= sum;
-}
-
-void launch_pairs_band(hipStream_t s, const Visual& v, double* S, int ld, const int* perm) {
-  if (v.n_band_units == 0) return;
-  static std::atomic<unsigned> attr_set{0};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (!(attr_set.load() & (1u << (dev & 31)))) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pairs_band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBandLds);
-    attr_set.fetch_or(1u << (dev & 31));
-  }
-  const int grid = 8 * ((v.n_band_units + 7) / 8);
-  hipLaunchKernelGGL(pairs_band_kernel, dim3(grid), dim3(64 * kBandWaves), kBandLds, s, v.n_band_units, v.band_unit_start, v.band_unit_cam, v.band_lm,
-                     v.J, v.CR, v.band_part);
-  const int ne = v.n_cam_pose * kBandCams * 36;
-  hipLaunchKernelGGL(pairs_band_reduce_kernel, dim3((ne + 255) / 256), dim3(256), 0, s, v.n_cam_pose, v.band_cam_units, v.band_unit_cam, v.band_part, v.cp_tq, v.cp_tp,
-                     S, ld, perm);
 }
 
 // ---------------------------------------------------------------------------------------------------
