@@ -788,6 +788,51 @@ int build_bsr(bsgpu_ctx* c) {
       P.slots = c->alloc<unsigned long long>(sw + zw + 2);
       if (P.slots) { P.zg = reinterpret_cast<double*>(P.slots + sw); P.abort_w = reinterpret_cast<int*>(P.slots + sw + zw); P.sync_bytes = sizeof(unsigned long long) * (sw + zw + 2); }
       if (!P.wg_row || !P.lcol || !P.slots) P = PcgPersistDev();
+      // ---- the coarse space of the two-level preconditioner: the free poses.  A pose = a 3-vector block next to a quaternion block in
+      // a factor's variable list ((p, q) in the pose-graph types, (q, p) in the IMU ones); a pose that a one-pose factor holds (absolute
+      // pose, IMU prior) is anchored and stays out.  BSGPU_PCG_COARSE=0: block-Jacobi alone (the cross-check).
+      const char* ce = getenv("BSGPU_PCG_COARSE");
+      if (P.G > 0 && !(ce && !strcmp(ce, "0"))) {
+        std::vector<int> p_of_q(c->nb, -1);
+        std::vector<unsigned char> anchored(c->nb, 0);
+        for (int t = 2; t < kNumInternal; ++t) {
+          const HostGroup& g = c->groups[t];
+          const TypeInfo& ti = kTypes[t];
+          int pairs[8][2], np = 0;
+          for (int sl = 0; sl + 1 < ti.nvar && np < 8; ++sl) {
+            if (ti.amb[sl] == 3 && ti.amb[sl + 1] == 4) { pairs[np][0] = sl; pairs[np][1] = sl + 1; ++np; ++sl; }
+            else if (ti.amb[sl] == 4 && ti.amb[sl + 1] == 3) { pairs[np][0] = sl + 1; pairs[np][1] = sl; ++np; ++sl; }
+          }
+          for (int f = 0; f < g.n && np > 0; ++f) {
+            if (!c->h_small_active[t][f]) continue;
+            const int32_t* idx = &g.idx[(size_t)f * ti.nidx];
+            for (int k = 0; k < np; ++k) {
+              const int bp = idx[pairs[k][0]], bq = idx[pairs[k][1]];
+              if (p_of_q[bq] < 0) p_of_q[bq] = bp;
+              if (np == 1) { anchored[bq] = 1; anchored[bp] = 1; }
+            }
+          }
+        }
+        std::vector<int4> co;
+        double cen[3] = {0.0, 0.0, 0.0};
+        for (int bq = 0; bq < c->nb; ++bq) {
+          const int bp = p_of_q[bq];
+          if (bp < 0 || anchored[bq] || anchored[bp] || c->toff[bq] < 0 || c->toff[bp] < 0) continue;
+          co.push_back(make_int4(c->off[bp], c->off[bq], c->toff[bp], c->toff[bq]));
+          for (int k = 0; k < 3; ++k) cen[k] += c->h_x[c->off[bp] + k];
+        }
+        if (co.size() >= 2) {
+          for (int k = 0; k < 3; ++k) P.centre[k] = cen[k] / (double)co.size();
+          P.co = c->upload(co);
+          double* scratch = c->alloc<double>(pcg_coarse_scratch_doubles(nbr));
+          if (P.co && scratch && hipMemsetAsync(scratch, 0, sizeof(double) * pcg_coarse_scratch_doubles(nbr), c->stream) == hipSuccess) {
+            const size_t nw = (size_t)3 * nbr * 6;
+            P.W = scratch; P.E = scratch + nw; P.Einv = scratch + pcg_coarse_scratch_doubles(nbr) - 38;
+            P.counter = reinterpret_cast<unsigned*>(P.Einv + 36);
+            P.n_coarse = (int)co.size();
+          }
+        }
+      }
     }
   }
   c->bsr_built = true;

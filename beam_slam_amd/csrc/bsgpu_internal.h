@@ -231,7 +231,16 @@ struct PcgPersistDev {
   int* abort_w = nullptr;
   double* zg = nullptr;          // the published z: two sets of 3 nbr entries
   size_t sync_bytes = 0;         // slots | z sets | abort word: one allocation, emptied (all bits set) by one fill per launch
+  // two-level preconditioner (k_pcg.hip): the free poses (value offsets of p and q, tangent offsets of p and q), the centre the
+  // rotations go through, W (3 nbr x 6), E = W^T A W (accumulated per LM step), E^-1
+  int n_coarse = 0;
+  const int4* co = nullptr;
+  double centre[3] = {0.0, 0.0, 0.0};
+  double *W = nullptr, *E = nullptr, *Einv = nullptr;
+  unsigned* counter = nullptr;
 };
+size_t pcg_coarse_scratch_doubles(int nbr);
+void launch_pcg_coarse(hipStream_t s, const PcgPersistDev& P, int nbr, const int* row_ptr, const int* col, const double* val, const double* x);
 size_t pcg_persistent_lds(int max_cols);
 size_t pcg_persistent_lds_limit();
 int pcg_persistent_max_rows();

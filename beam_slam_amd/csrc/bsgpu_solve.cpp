@@ -33,10 +33,12 @@ void pcg_solve(bsgpu_ctx* c, const bsgpu_options& o) {
     int expected = 0;
     if (g_pcg_persistent_in_flight.compare_exchange_strong(expected, 1)) {
       double sc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      launch_pcg_coarse(s, c->pcg_persist, c->nbr, c->d_row_ptr, c->d_col, c->d_val, c->d_x);
       const bool launched = launch_pcg_persistent(s, c->pcg_persist, c->nbr, c->d_row_ptr, c->d_val, c->d_Minv, c->d_rhs, c->d_px, c->pcg_persist.zg, c->d_psc, tol2p, max_itp);
       bool ok = launched && hipMemcpyAsync(sc, c->d_psc, sizeof(double) * ns, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
       g_pcg_persistent_in_flight.store(0);
       if (ok && sc[pcg_done_slot()] > 0.0) { c->pcg_iters_total += (int)sc[pcg_iters_slot()]; return; }
+      fprintf(stderr, "[bsgpu] the resident PCG launch was given up (launched %d, done %g after %g iterations): launch-per-iteration path from here on\n", (int)launched, sc[pcg_done_slot()], sc[pcg_iters_slot()]);
       (void)hipGetLastError();
       c->pcg_persist.G = 0;
     }

@@ -339,7 +339,9 @@ int pcg_rows_grid(int nbr) { return (3 * nbr + kPcgRowsPerWg - 1) / kPcgRowsPerW
 constexpr int kPcgPersistThreads = 512;
 constexpr int kPcgPersistMaxRows = 504;          // scalar rows of one workgroup (one thread each in the update)
 constexpr unsigned long long kSlotEmpty = ~0ull;
-constexpr int kPcgSlotStride = 8, kPcgSlotStrideMax = 16;
+constexpr int kPcgSlotWords = 8;                // 8-byte words of a workgroup's slot: one 64-byte line (slots of different workgroups in one line
+                                                 // serialise at the memory side: 8-byte spacing 3.65 us per reduction, 64-byte 2.7; measured in round 2)
+constexpr int kPcgCoarse = 6;                   // coarse vectors of the two-level preconditioner (rigid motions of the whole graph)
 constexpr int kTailCap = 384;     // blocks of a workgroup beyond the register-resident ones that are kept in LDS (the rest: from memory)
 constexpr int kGatherPoses = 2;   // poses (pairs of block columns, 48 bytes = three 16-byte loads) of a thread in the in-flight gather   // 8-byte words between the slots of two workgroups
 constexpr int kRowLanes = 8;                     // lanes per block row in the product (64 rows at a time: a workgroup of C4 has ~40)
@@ -352,11 +354,12 @@ BSG_DEV void st_agent(double* p, double v) {
   __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 struct PcgBarrier {
-  unsigned long long* slots;   // [3 sets][2 values][G]
+  unsigned long long* slots;   // [3 sets][G workgroups][kPcgSlotWords]: the partials of one workgroup are ONE 64-byte line (one store request)
   int* abort_w;
-  int G, stride;               // slot of workgroup w at w * stride (in 8-byte words): writers of one line are serialised at the memory side
+  int G;
   long long deadline;
-  double* sbuf;                // LDS: 2 * G partials + 2 totals + 1 flag
+  double* sbuf;                // LDS: kPcgSlotWords * G partials + kPcgSlotWords (unused) + 1 flag
+  double* tot;                 // LDS: the totals of the last reduction (kPcgSlotWords)
 };
 // stores this workgroup's partial(s) for barrier `b` and returns the totals over all workgroups; false on abort (uniform)
 struct PcgNoSide {
@@ -367,58 +370,102 @@ struct PcgNoSide {
 // `side`: work whose loads travel with the looks at the slots (the gather of the published z: it needs the slots no more than the
 // slots need it) — issue() requests, poll() re-requests what was still empty and says whether anything is outstanding, finish() stores.
 // Slots and side job are polled in ONE loop: a round is one memory round trip whatever it waits for.
+// NV <= kPcgSlotWords values per workgroup (the p.q reduction of the two-level preconditioner carries W^T q with it: seven): lane v of
+// the first wave stores value v — one instruction, one line —, every looking thread reads the NV words of one workgroup with 16-byte
+// loads and wave v sums value v in slot order (the same bits everywhere).
+// The workgroup's partials are read from LDS (`part`, NV doubles) and the totals are left in LDS (B.tot): no registers held across the wait.
 template <int NV, class Side>
-BSG_DEV bool pcg_grid_reduce(const PcgBarrier& B, int b, double v0, double v1, double& t0, double& t1, Side& side) {
+BSG_DEV bool pcg_grid_reduce(const PcgBarrier& B, int b, const double* part, Side& side) {
+  static_assert(NV >= 1 && NV <= kPcgSlotWords, "a workgroup's partials are one line");
   const int tid = threadIdx.x, G = B.G, wg = blockIdx.x;
   const int set = b % 3, nxt = (b + 1) % 3;
-  const int S = B.stride;
-  unsigned long long* cur = B.slots + (size_t)set * 2 * G * S;
-  unsigned long long* nx = B.slots + (size_t)nxt * 2 * G * S;
-  if (tid == 0) {
-    __hip_atomic_store(cur + (size_t)wg * S, (unsigned long long)__double_as_longlong(v0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (NV == 2) __hip_atomic_store(cur + (size_t)(G + wg) * S, (unsigned long long)__double_as_longlong(v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(nx + (size_t)wg * S, kSlotEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(nx + (size_t)(G + wg) * S, kSlotEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned long long* cur = B.slots + (size_t)set * G * kPcgSlotWords;
+  unsigned long long* nx = B.slots + (size_t)nxt * G * kPcgSlotWords;
+  if (tid < kPcgSlotWords) {
+    if (tid < NV) __hip_atomic_store(cur + (size_t)wg * kPcgSlotWords + tid, (unsigned long long)__double_as_longlong(part[tid]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(nx + (size_t)wg * kPcgSlotWords + tid, kSlotEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  double* flag = B.sbuf + 2 * G + 2;
+  double* flag = B.sbuf + kPcgSlotWords * G + kPcgSlotWords;
   if (tid == 0) *flag = 0.0;
   __syncthreads();
+  // (8-byte agent-scope loads of every word.  16-byte sc1 buffer loads of the line — what the z gather uses — were tried here: a look
+  // that found the line empty could go on returning the stale line for ever, a different set of looking threads each run; the gather,
+  // whose lines are pushed out by its own traffic, has not shown it.  Watching ONE word of the line and fetching the others once it is
+  // there costs a second round trip (the seven-word reduction 4.65 us against 3.66), two looking threads per line changed nothing.
+  // Measured in round 3.)
   const bool poller = tid < G;
-  unsigned long long a = poller ? kSlotEmpty : 0ull, c = (poller && NV == 2) ? kSlotEmpty : 0ull;
-  if (poller) {
-    a = __hip_atomic_load(cur + (size_t)tid * S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (NV == 2) c = __hip_atomic_load(cur + (size_t)(G + tid) * S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  const unsigned long long* line = cur + (size_t)tid * kPcgSlotWords;
+  unsigned long long w[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) w[k] = poller ? __hip_atomic_load(line + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
   side.issue(tid);
+  bool aborted = false;
   for (unsigned it = 0;; ++it) {
     const bool side_done = side.poll();
-    if (a != kSlotEmpty && c != kSlotEmpty && side_done) break;
-    if (a == kSlotEmpty) a = __hip_atomic_load(cur + (size_t)tid * S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (NV == 2 && c == kSlotEmpty) c = __hip_atomic_load(cur + (size_t)(G + tid) * S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool have = true;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+      if (w[k] == kSlotEmpty) { have = false; w[k] = __hip_atomic_load(line + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    if (have && side_done) break;
     if ((it & 15) == 15) {
-      if (__hip_atomic_load(B.abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1) { *flag = 1.0; break; }   // (1 = raised; the word starts with all bits set, like the slots)
-      if ((long long)wall_clock64() > B.deadline) { __hip_atomic_store(B.abort_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *flag = 1.0; break; }
+      if (__hip_atomic_load(B.abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1) { aborted = true; break; }   // (1 = raised; the word starts with all bits set, like the slots)
+      if ((long long)wall_clock64() > B.deadline) { __hip_atomic_store(B.abort_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); aborted = true; break; }
     }
     __builtin_amdgcn_s_sleep(1);
   }
+  if (aborted) *flag = 1.0;
   if (poller) {
-    B.sbuf[tid] = __longlong_as_double((long long)a);
-    B.sbuf[G + tid] = (NV == 2) ? __longlong_as_double((long long)c) : 0.0;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) B.sbuf[k * G + tid] = __longlong_as_double((long long)w[k]);
   }
   side.finish(tid);
   __syncthreads();
-  if (tid < 64) {
-    double a2 = 0.0, c2 = 0.0;
-    for (int i = tid; i < G; i += 64) { a2 += B.sbuf[i]; c2 += B.sbuf[G + i]; }
+  {
+    const int wv = tid >> 6, ln = tid & 63;
+    if (wv < NV) {
+      double a2 = 0.0;
+      for (int i = ln; i < G; i += 64) a2 += B.sbuf[wv * G + i];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { a2 += __shfl_xor(a2, o, 64); c2 += __shfl_xor(c2, o, 64); }
-    if (tid == 0) { B.sbuf[2 * G] = a2; B.sbuf[2 * G + 1] = c2; }
+      for (int o = 32; o > 0; o >>= 1) a2 += __shfl_xor(a2, o, 64);
+      if (ln == 0) B.tot[wv] = a2;
+    }
   }
   __syncthreads();
-  t0 = B.sbuf[2 * G]; t1 = B.sbuf[2 * G + 1];
   const bool ok = *flag == 0.0;
   __syncthreads();   // (sbuf is rewritten by the next reduction)
   return ok;
+}
+// sums of NV <= 8 values over the 512 threads (smem >= 64 doubles), totals left in LDS (`out`).  In a wave the values are summed
+// TRANSPOSED (as wave_sum_transpose64): three exchange steps over the lane bits 0-2 leave lane l with the 8-lane partial of value l & 7
+// (4 + 2 + 1 exchanges), three plain steps over the bits 3-5 complete it — 10 exchanges instead of 6 per value; then thread k adds the
+// eight waves' sums of value k in one order.
+template <int NV>
+BSG_DEV void block_sum_vec(const double (&vin)[NV], double* smem, double* out /* LDS, NV */) {
+  static_assert(NV <= 8, "eight values per lane group");
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = k < NV ? vin[k] : 0.0;
+#pragma unroll
+  for (int o = 4, h = 4; h >= 1; o >>= 1, h >>= 1) {
+    const bool upper = (lane & o) != 0;
+#pragma unroll
+    for (int i = 0; i < h; ++i) {
+      const double lo = v[i], hi = v[i + h];
+      const double recv = __shfl_xor(upper ? lo : hi, o, 64);
+      v[i] = (upper ? hi : lo) + recv;
+    }
+  }
+  double t = v[0];
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) t += __shfl_xor(t, o, 64);
+  if (lane < 8) smem[w * 8 + lane] = t;
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    const int k = threadIdx.x;
+    out[k] = ((smem[k] + smem[8 + k]) + (smem[16 + k] + smem[24 + k])) + ((smem[32 + k] + smem[40 + k]) + (smem[48 + k] + smem[56 + k]));
+  }
+  __syncthreads();
 }
 BSG_DEV double block_sum_512(double v, double* smem /* >= 8 doubles */) {
   v = wave_sum(v);
@@ -434,7 +481,8 @@ __global__ __launch_bounds__(kPcgPersistThreads) void pcg_persistent_kernel(
     int nbr, const int* __restrict__ row_ptr, const double* __restrict__ val, const double* __restrict__ Minv, const double* __restrict__ b,
     double* __restrict__ x, double* __restrict__ zg, const int* __restrict__ wg_row, const int* __restrict__ wg_colptr,
     const int* __restrict__ wg_cols, const int* __restrict__ lcol, unsigned long long* __restrict__ slots, int* __restrict__ abort_w,
-    double* __restrict__ sc, double tol2, int max_it, long long timeout_ticks, int max_cols, int paired, int slot_stride, long long* __restrict__ probe) {
+    double* __restrict__ sc, double tol2, int max_it, long long timeout_ticks, int max_cols, int paired, const double* __restrict__ Wc,
+    const double* __restrict__ Einv, long long* __restrict__ probe) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x, wg = blockIdx.x, G = gridDim.x;
   double* sx = lds;                               // own rows: x, r, p, q, z
@@ -442,9 +490,15 @@ __global__ __launch_bounds__(kPcgPersistThreads) void pcg_persistent_kernel(
   double* sp = sr + kPcgPersistMaxRows;
   double* sq = sp + kPcgPersistMaxRows;
   double* sz = sq + kPcgPersistMaxRows;
-  double* sred = sz + kPcgPersistMaxRows;         // 8
-  double* sbar = sred + 8;                        // 2 G + 3
-  double* pc = sbar + 2 * 256 + 4;                // p of the named columns: 3 * max_cols
+  double* sred = sz + kPcgPersistMaxRows;         // 64 | E^-1
+  double* sE = sred + 64;       // 36 | W^T r (kPcgCoarse) | c = E^-1 W^T r (kPcgCoarse)
+  double* swr = sE + 36;
+  double* scc = swr + kPcgCoarse;
+  double* spart = scc + kPcgCoarse;               // this workgroup's partials of a reduction | the totals of the last one: 2 x kPcgSlotWords
+  double* stot = spart + kPcgSlotWords;
+  double* sW = stot + kPcgSlotWords;                  // the own rows of W: kPcgCoarse x kPcgPersistMaxRows (registers are taken: 54 of matrix blocks per lane)
+  double* sbar = sW + kPcgCoarse * kPcgPersistMaxRows;   // kPcgSlotWords G + kPcgSlotWords + 1
+  double* pc = sbar + kPcgSlotWords * 256 + kPcgSlotWords + 4;   // p of the named columns: 3 * max_cols
   double* zc = pc + 3 * max_cols;                 // their z as gathered: 3 * max_cols
   double* tb = zc + 3 * max_cols;                 // blocks that do not fit the registers ("tails"): 9 * kTailCap
   int* tl = reinterpret_cast<int*>(tb + 9 * kTailCap);   // ... their column offsets into pc: kTailCap
@@ -453,27 +507,65 @@ __global__ __launch_bounds__(kPcgPersistThreads) void pcg_persistent_kernel(
   const size_t zset = 6 * (size_t)((nbr + 1) / 2);   // doubles of one z set (whole poses: a set starts 16-byte aligned)
   const int c0 = wg_colptr[wg], nc = wg_colptr[wg + 1] - c0;
   PcgBarrier B;
-  B.slots = slots; B.abort_w = abort_w; B.G = G; B.stride = slot_stride; B.deadline = (long long)wall_clock64() + timeout_ticks; B.sbuf = sbar;
+  B.slots = slots; B.abort_w = abort_w; B.G = G; B.deadline = (long long)wall_clock64() + timeout_ticks; B.sbuf = sbar; B.tot = stot;
   const int row = 3 * r0 + tid;                   // this thread's scalar row in the update
   const bool live = tid < nrow;
   const int m = row / 6, mi = row - 6 * m, mbase = 6 * m - 3 * r0;   // its 6x6 preconditioner block (inside the workgroup: r0 is even)
   double Mrow[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) Mrow[k] = live ? Minv[(size_t)m * 36 + 6 * mi + k] : 0.0;
+  // Two-level preconditioner M^-1 = B^-1 + W E^-1 W^T (B: the 6x6 blocks, W: the kPcgCoarse rigid motions of the whole graph — what the
+  // anchor alone holds against, the six smallest eigenvalues of the block-Jacobi-preconditioned matrix —, E = W^T A W).  W^T r is kept
+  // by its recurrence W^T r -= alpha W^T q, and W^T q travels WITH p.q in the same 64-byte slot: no third reduction per iteration.
+  const bool coarse = Wc != nullptr;
+#pragma unroll
+  for (int k = 0; k < kPcgCoarse; ++k)
+    if (tid < kPcgPersistMaxRows) sW[k * kPcgPersistMaxRows + tid] = (coarse && live) ? Wc[(size_t)row * kPcgCoarse + k] : 0.0;
+  if (tid < 36) sE[tid] = coarse ? Einv[tid] : 0.0;
+  if (tid < 2 * kPcgCoarse) swr[tid] = 0.0;        // (swr | scc)
   for (int i = tid; i < 3 * nc; i += kPcgPersistThreads) pc[i] = 0.0;
   if (live) { sx[tid] = 0.0; sp[tid] = 0.0; sr[tid] = b[row]; }
   __syncthreads();
-  double rz_p = 0.0, rr_p = 0.0;
-  if (live) {
+  int bar = 0;
+  bool ok = true;
+  auto coarse_coeffs = [&](double alpha_, const double* tq) {   // W^T r -= alpha W^T q;  c = E^-1 (W^T r)   (uniform: two barriers)
+    if (tid < kPcgCoarse) swr[tid] -= alpha_ * tq[tid];
+    __syncthreads();
+    if (tid < kPcgCoarse) {
+      double a = 0.0;
+#pragma unroll
+      for (int k = 0; k < kPcgCoarse; ++k) a += sE[tid * kPcgCoarse + k] * swr[k];
+      scc[tid] = a;
+    }
+    __syncthreads();
+  };
+  auto coarse_z = [&]() {
+    double a = 0.0;
+#pragma unroll
+    for (int k = 0; k < kPcgCoarse; ++k) a += sW[k * kPcgPersistMaxRows + tid] * scc[k];
+    return a;
+  };
+  if (coarse) {   // W^T r of the start (r = b): one reduction more per solve
+    double v6[kPcgCoarse];
+#pragma unroll
+    for (int k = 0; k < kPcgCoarse; ++k) v6[k] = live ? sW[k * kPcgPersistMaxRows + tid] * sr[tid] : 0.0;
+    block_sum_vec<kPcgCoarse>(v6, sred, spart);
+    PcgNoSide no_side0;
+    ok = pcg_grid_reduce<kPcgCoarse>(B, bar++, spart, no_side0);
+    coarse_coeffs(-1.0, stot);
+  }
+  double part[2] = {0.0, 0.0};
+  if (live && tid < kPcgPersistMaxRows) {
     double zv = 0.0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) zv += Mrow[k] * ((6 * m + k < n) ? sr[mbase + k] : 0.0);
+    if (coarse) zv += coarse_z();
     sz[tid] = zv;
     st_agent(zg + row, zv);                         // z of iteration k lives in set k % 2 of zg (both sets start empty)
-    rz_p = sr[tid] * zv; rr_p = sr[tid] * sr[tid];
+    part[0] = sr[tid] * zv; part[1] = sr[tid] * sr[tid];
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the z stores have left; no fence: its cache write-back / invalidate would evict the matrix)
-  double part0 = block_sum_512(rz_p, sred), part1 = block_sum_512(rr_p, sred);
+  block_sum_vec<2>(part, sred, spart);
   // the z of the named columns: an entry is empty (all bits set) until its owner has stored it
   // The gather of the named columns' z.  The two block columns (2m, 2m + 1) of a pose are named together (`paired`: host check) and are
   // 48 contiguous bytes of z: three 16-byte loads per pose.  (Measured: 8-byte loads 4.6 us for the phase, 16-byte 3.1; a 64-byte line
@@ -578,16 +670,16 @@ __global__ __launch_bounds__(kPcgPersistThreads) void pcg_persistent_kernel(
     }
   }
   __syncthreads();
-  int bar = 0, iters = 0;
+  int iters = 0;
   double rz = 0.0, rr = 0.0, rz_prev = 0.0, rr0 = 0.0;
-  bool ok = true;
   auto stamp = [&](int it, int k) { if (probe && wg == 0 && tid == 0 && it < 64) probe[it * 8 + k] = (long long)wall_clock64(); };
-  for (int it = 0;; ++it) {
+  for (int it = 0; ok; ++it) {
     stamp(it, 0);
     {
       Gather gth;
       gth.res = rz_res; gth.cols = wg_cols + c0; gth.zc = zc; gth.set_base = (size_t)(it & 1) * zset; gth.nc = nc; gth.paired = paired;
-      ok = pcg_grid_reduce<2>(B, bar++, part0, part1, rz, rr, gth);
+      ok = pcg_grid_reduce<2>(B, bar++, spart, gth);
+      rz = stot[0]; rr = stot[1];
     }
     if (!ok) break;
     if (!paired || nc > 2 * kGatherPoses * kPcgPersistThreads) {   // (workgroup-uniform)
@@ -608,7 +700,6 @@ __global__ __launch_bounds__(kPcgPersistThreads) void pcg_persistent_kernel(
     stamp(it, 2);
     // q = A p for the own rows: kRowLanes lanes per block row; the blocks come from registers (loaded once per solve), what does not
     // fit (rows beyond kRegRows per lane group, blocks beyond kRowLanes x kRegBlocks of a row) from memory as before
-    double pq = 0.0;
     {
       auto row_tail = [&](int br, int e_from, double& a0, double& a1, double& a2) {
         const int e_end = row_ptr[br + 1];
@@ -631,7 +722,6 @@ __global__ __launch_bounds__(kPcgPersistThreads) void pcg_persistent_kernel(
         if (sub == 0) {
           const int j = 3 * (br - r0);
           sq[j] = a0; sq[j + 1] = a1; sq[j + 2] = a2;
-          pq += a0 * sp[j] + a1 * sp[j + 1] + a2 * sp[j + 2];
         }
       };
 #pragma unroll
@@ -657,32 +747,51 @@ __global__ __launch_bounds__(kPcgPersistThreads) void pcg_persistent_kernel(
         row_done(br, a0, a1, a2);
       }
     }
-    const double pq_wg = block_sum_512(pq, sred);
-    stamp(it, 3);
-    if (probe && it == 10 && tid == 0) probe[512 + 4 * wg] = (long long)wall_clock64();
-    double pq_all = 0.0, unused = 0.0;
-    PcgNoSide no_side;
-    ok = pcg_grid_reduce<1>(B, bar++, pq_wg, 0.0, pq_all, unused, no_side);
-    if (!ok) break;
+    __syncthreads();   // (q of the own rows is complete)
+    // p.q and W^T q: one partial each per workgroup, one slot line
+    double pq_all = 0.0;
+    if (coarse) {
+      double v7[1 + kPcgCoarse];
+      v7[0] = live ? sp[tid] * sq[tid] : 0.0;
+#pragma unroll
+      for (int k = 0; k < kPcgCoarse; ++k) v7[1 + k] = live ? sW[k * kPcgPersistMaxRows + tid] * sq[tid] : 0.0;
+      block_sum_vec<1 + kPcgCoarse>(v7, sred, spart);
+      stamp(it, 3);
+      if (probe && it == 10 && tid == 0) probe[512 + 4 * wg] = (long long)wall_clock64();
+      PcgNoSide no_side;
+      ok = pcg_grid_reduce<1 + kPcgCoarse>(B, bar++, spart, no_side);
+      if (!ok) break;
+      pq_all = stot[0];
+      coarse_coeffs((pq_all > 0.0) ? rz / pq_all : 0.0, stot + 1);
+    } else {
+      double v1[1] = {live ? sp[tid] * sq[tid] : 0.0};
+      block_sum_vec<1>(v1, sred, spart);
+      stamp(it, 3);
+      if (probe && it == 10 && tid == 0) probe[512 + 4 * wg] = (long long)wall_clock64();
+      PcgNoSide no_side;
+      ok = pcg_grid_reduce<1>(B, bar++, spart, no_side);
+      if (!ok) break;
+      pq_all = stot[0];
+    }
     stamp(it, 4);
     if (probe && it == 10 && tid == 0) probe[512 + 4 * wg + 1] = (long long)wall_clock64();
     const double alpha = (pq_all > 0.0) ? rz / pq_all : 0.0;
     // x += alpha p; r -= alpha q; z = M^-1 r; publish z; partials of r.z, r.r
     if (live) { sx[tid] += alpha * sp[tid]; sr[tid] -= alpha * sq[tid]; }
     __syncthreads();
-    rz_p = 0.0; rr_p = 0.0;
+    part[0] = 0.0; part[1] = 0.0;
     if (live) {
       double zv = 0.0;
 #pragma unroll
       for (int k = 0; k < 6; ++k) zv += Mrow[k] * ((6 * m + k < n) ? sr[mbase + k] : 0.0);
+      if (coarse) zv += coarse_z();
       sz[tid] = zv;
       st_agent(zg + (size_t)((it + 1) & 1) * zset + row, zv);
       st_agent(zg + (size_t)(it & 1) * zset + row, __longlong_as_double((long long)kSlotEmpty));   // (everybody has gathered z of this iteration: they arrived at the p.q barrier)
-      rz_p = sr[tid] * zv; rr_p = sr[tid] * sr[tid];
+      part[0] = sr[tid] * zv; part[1] = sr[tid] * sr[tid];
     }
-    part0 = block_sum_512(rz_p, sred);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the z stores have left — under the first sum; no fence: its cache write-back / invalidate would evict what the L2 holds)
-    part1 = block_sum_512(rr_p, sred);                 // (its barriers order every thread's drain before the slot store)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the z stores have left; no fence: its cache write-back / invalidate would evict what the L2 holds)
+    block_sum_vec<2>(part, sred, spart);               // (its barriers order every thread's drain before the slot store)
     stamp(it, 5);
     if (probe && it == 10 && tid == 0) probe[512 + 4 * wg + 2] = (long long)wall_clock64();
   }
@@ -693,13 +802,193 @@ __global__ __launch_bounds__(kPcgPersistThreads) void pcg_persistent_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The coarse space of the two-level preconditioner, rebuilt per LM step (the poses move): column a < 3 of W translates every free
+// pose along axis a, column 3 + a rotates the graph about axis a through the centre c — position rows e_a x (p - c), orientation rows
+// R^T e_a (the tangent of the quaternion blocks is the local one: q (+) d = q exp(d)).  Anchored poses (those an absolute factor
+// holds) and blocks that are not part of a pose keep zero rows.  Then A W (block rows x 6), E = W^T (A W) and its inverse.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pcg_coarse_w_kernel(int n_co, const int4* __restrict__ co /* x off p, x off q, tangent off p, q */,
+                                                           const double* __restrict__ x, double cx, double cy, double cz, double* __restrict__ W) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n_co) return;
+  const int4 o = co[k];
+  const double px = x[o.x] - cx, py = x[o.x + 1] - cy, pz = x[o.x + 2] - cz;
+  double R[9];
+  const double q[4] = {x[o.y], x[o.y + 1], x[o.y + 2], x[o.y + 3]};
+  quat_to_rot_normalized(q, R);
+  double* Wp = W + (size_t)o.z * kPcgCoarse;
+  double* Wq = W + (size_t)o.w * kPcgCoarse;
+  // e_a x p: a = 0: (0, -pz, py); a = 1: (pz, 0, -px); a = 2: (-py, px, 0)
+  const double lev[3][3] = {{0.0, -pz, py}, {pz, 0.0, -px}, {-py, px, 0.0}};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      Wp[i * kPcgCoarse + a] = (i == a) ? 1.0 : 0.0;
+      Wp[i * kPcgCoarse + 3 + a] = lev[a][i];
+      Wq[i * kPcgCoarse + a] = 0.0;
+      Wq[i * kPcgCoarse + 3 + a] = R[3 * a + i];       // (R^T e_a)_i = R[a][i]
+    }
+  }
+}
+// E = W^T A W without materialising A W: eight lanes per block row take the row's blocks in turn (3 x 6 partial sums of (A W)'s rows
+// each), the lane group's sums meet in its first lane, which adds W_row^T (A W)_row into the workgroup's 6 x 6 in LDS; one atomic add
+// per entry and workgroup into E; the last workgroup to finish inverts E (Cholesky with a pivot floor: a direction W does not span —
+// every pose anchored — drops out, pseudo-inverse) and clears the accumulator for the next LM step.
+constexpr int kCoarseRowLanes = 8;
+__global__ __launch_bounds__(256) void pcg_coarse_e_kernel(int nbr, const int* __restrict__ row_ptr, const int* __restrict__ col,
+                                                           const double* __restrict__ val, const double* __restrict__ W, double* __restrict__ E,
+                                                           unsigned* __restrict__ counter, double* __restrict__ Einv) {
+  __shared__ double sE[36];
+  __shared__ int last;
+  const int tid = threadIdx.x, sub = tid % kCoarseRowLanes;
+  const int br = (blockIdx.x * 256 + tid) / kCoarseRowLanes;
+  if (tid < 36) sE[tid] = 0.0;
+  __syncthreads();
+  double aw[3][kPcgCoarse];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int a = 0; a < kPcgCoarse; ++a) aw[i][a] = 0.0;
+  if (br < nbr) {
+    for (int e = row_ptr[br] + sub; e < row_ptr[br + 1]; e += kCoarseRowLanes) {
+      const double* Bv = val + (size_t)e * 9;
+      const double2* w2v = reinterpret_cast<const double2*>(W + (size_t)3 * col[e] * kPcgCoarse);   // (144-byte rows: 16-byte pieces)
+      double b9[9], w[3 * kPcgCoarse];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) b9[i] = Bv[i];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { const double2 t = w2v[i]; w[2 * i] = t.x; w[2 * i + 1] = t.y; }
+#pragma unroll
+      for (int a = 0; a < kPcgCoarse; ++a) {
+        const double w0 = w[a], w1 = w[kPcgCoarse + a], w2 = w[2 * kPcgCoarse + a];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) aw[i][a] += b9[3 * i] * w0 + b9[3 * i + 1] * w1 + b9[3 * i + 2] * w2;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = kCoarseRowLanes / 2; o > 0; o >>= 1)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int a = 0; a < kPcgCoarse; ++a) aw[i][a] += __shfl_xor(aw[i][a], o, kCoarseRowLanes);
+  // W_row^T (A W)_row of the lane group's row in its first lane, summed over the wave's eight rows by exchanges (into ONE LDS address per
+  // entry from eight lanes at once the adds serialised: 24 of the kernel's 42 us; measured), then one LDS add per wave and entry
+  double ec[36];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) ec[i] = 0.0;
+  if (br < nbr && sub == 0) {
+    const double* wr = W + (size_t)3 * br * kPcgCoarse;
+#pragma unroll
+    for (int a = 0; a < kPcgCoarse; ++a) {
+      const double w0 = wr[a], w1 = wr[kPcgCoarse + a], w2 = wr[2 * kPcgCoarse + a];
+#pragma unroll
+      for (int j = 0; j < kPcgCoarse; ++j) ec[a * kPcgCoarse + j] = w0 * aw[0][j] + w1 * aw[1][j] + w2 * aw[2][j];
+    }
+  }
+#pragma unroll
+  for (int o = kCoarseRowLanes; o < 64; o <<= 1)
+#pragma unroll
+    for (int i = 0; i < 36; ++i) ec[i] += __shfl_xor(ec[i], o, 64);
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int i = 0; i < 36; ++i) __hip_atomic_fetch_add(&sE[i], ec[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __syncthreads();
+  // (a partial per workgroup, summed by the last one in workgroup order: added into 36 shared addresses with atomics — 313 adds per
+  // address — the kernel took 42 us; measured)
+  // (agent-scope stores, drained before the count goes up; NO fence here: an agent-scope fence writes the L2 back and invalidates it, and
+  // 313 workgroups doing that made this kernel 45 us; the one workgroup that sums fences once)
+  if (tid < 36) __hip_atomic_store(&E[(size_t)blockIdx.x * 36 + tid], sE[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) last = (__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) ? 1 : 0;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  __shared__ double sP[7 * 36];
+  if (tid < 7 * 36) {
+    const int k = tid % 36, g0 = tid / 36;
+    double e = 0.0;
+    const double* Ev = E;      // (plain loads behind the fence: they overlap; agent-scope atomic loads were waited for one by one, 36 us)
+#pragma unroll 8
+    for (int g = g0; g < (int)gridDim.x; g += 7) e += Ev[(size_t)g * 36 + k];
+    sP[tid] = e;
+  }
+  __syncthreads();
+  if (tid < 36) sE[tid] = ((sP[tid] + sP[36 + tid]) + (sP[72 + tid] + sP[108 + tid])) + ((sP[144 + tid] + sP[180 + tid]) + sP[216 + tid]);
+  __syncthreads();
+  if (tid == 0) {
+    *counter = 0u;
+    // (every loop unrolled: the arrays stay in registers — with run-time loop bounds they lived in scratch memory and this thread alone
+    // took 30 us)
+    double A[36], L[36], Wi[36];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) A[i * 6 + j] = 0.5 * (sE[i * 6 + j] + sE[j * 6 + i]);
+    double dmax = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dmax = fmax(dmax, A[i * 6 + i]);
+    bool dead[6];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) { L[i] = 0.0; Wi[i] = 0.0; }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      double d = A[j * 6 + j];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) if (k < j) d -= L[j * 6 + k] * L[j * 6 + k];
+      dead[j] = !(d > 1e-12 * dmax) || !(dmax > 0.0);
+      const double ljj = dead[j] ? 1.0 : sqrt(d);
+      L[j * 6 + j] = ljj;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        if (i <= j) continue;
+        double v = A[i * 6 + j];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) if (k < j) v -= L[i * 6 + k] * L[j * 6 + k];
+        L[i * 6 + j] = dead[j] ? 0.0 : v / ljj;
+      }
+    }
+#pragma unroll
+    for (int cix = 0; cix < 6; ++cix) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        if (i < cix) continue;
+        double v = (i == cix) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) if (k >= cix && k < i) v -= L[i * 6 + k] * Wi[k * 6 + cix];
+        Wi[i * 6 + cix] = v / L[i * 6 + i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) if (k >= i && k >= j && !dead[k]) v += Wi[k * 6 + i] * Wi[k * 6 + j];
+        Einv[i * 6 + j] = (dead[i] || dead[j]) ? 0.0 : v;
+      }
+  }
+}
+size_t pcg_coarse_scratch_doubles(int nbr) { return (size_t)3 * nbr * kPcgCoarse + 36 * (size_t)((nbr * kCoarseRowLanes + 255) / 256) + 36 + 2; }
+void launch_pcg_coarse(hipStream_t s, const PcgPersistDev& P, int nbr, const int* row_ptr, const int* col, const double* val, const double* x) {
+  if (P.n_coarse <= 0) return;
+  hipLaunchKernelGGL(pcg_coarse_w_kernel, dim3((P.n_coarse + 255) / 256), dim3(256), 0, s, P.n_coarse, P.co, x, P.centre[0], P.centre[1], P.centre[2], P.W);
+  hipLaunchKernelGGL(pcg_coarse_e_kernel, dim3((nbr * kCoarseRowLanes + 255) / 256), dim3(256), 0, s, nbr, row_ptr, col, val, P.W, P.E, P.counter, P.Einv);
+}
+
 size_t pcg_persistent_lds(int max_cols) {
-  return sizeof(double) * (5 * (size_t)kPcgPersistMaxRows + 8 + 2 * 256 + 4 + 6 * (size_t)max_cols + 9 * (size_t)kTailCap) + sizeof(int) * ((size_t)kTailCap + kPcgPersistMaxRows / 3 + 2);
+  return sizeof(double) * ((5 + kPcgCoarse) * (size_t)kPcgPersistMaxRows + 64 + 36 + 2 * kPcgCoarse + 2 * kPcgSlotWords + kPcgSlotWords * 256 + kPcgSlotWords + 4 + 6 * (size_t)max_cols + 9 * (size_t)kTailCap) +
+         sizeof(int) * ((size_t)kTailCap + kPcgPersistMaxRows / 3 + 2);
 }
 size_t pcg_persistent_lds_limit() { return 150 * 1024; }
 int pcg_persistent_max_rows() { return kPcgPersistMaxRows; }
 size_t pcg_persistent_z_words(int nbr) { return 2 * 6 * (size_t)((nbr + 1) / 2); }
-size_t pcg_persistent_slot_words(int G) { return 6 * (size_t)G * kPcgSlotStrideMax; }
+size_t pcg_persistent_slot_words(int G) { return 3 * (size_t)G * kPcgSlotWords; }
 bool launch_pcg_persistent(hipStream_t s, const PcgPersistDev& P, int nbr, const int* row_ptr, const double* val, const double* Minv, const double* b,
                            double* x, double* zg, double* sc, double tol2, int max_it) {
   const size_t lds = pcg_persistent_lds(P.max_cols);
@@ -713,7 +1002,6 @@ bool launch_pcg_persistent(hipStream_t s, const PcgPersistDev& P, int nbr, const
     attr_devices.fetch_or(bit, std::memory_order_release);
   }
   if (lds > pcg_persistent_lds_limit() || P.G < 1 || P.G > 256) return false;
-  static const int slot_stride = [] { const char* e = getenv("BSGPU_PCG_SLOT_STRIDE"); const int v = e ? atoi(e) : kPcgSlotStride; return (v >= 1 && v <= kPcgSlotStrideMax) ? v : kPcgSlotStride; }();
   // slots, both z sets and the abort word are ONE allocation (bsgpu_finalize.cpp), emptied by one fill: all bits set
   if (hipMemsetAsync(P.slots, 0xff, P.sync_bytes, s) != hipSuccess) { (void)hipGetLastError(); return false; }
   const long long timeout_ticks = 100000000LL / 5;   // s_memrealtime: 100 MHz; a fifth of a second for the whole solve
@@ -727,7 +1015,7 @@ bool launch_pcg_persistent(hipStream_t s, const PcgPersistDev& P, int nbr, const
     if (d_probe) { (void)hipMemsetAsync(d_probe, 0, sizeof(long long) * (512 + 1024), s); probe = d_probe; }
   }
   hipLaunchKernelGGL(pcg_persistent_kernel, dim3(P.G), dim3(kPcgPersistThreads), lds, s, nbr, row_ptr, val, Minv, b, x, zg, P.wg_row, P.wg_colptr,
-                     P.wg_cols, P.lcol, P.slots, P.abort_w, sc, tol2, max_it, timeout_ticks, P.max_cols, P.paired, slot_stride, probe);
+                     P.wg_cols, P.lcol, P.slots, P.abort_w, sc, tol2, max_it, timeout_ticks, P.max_cols, P.paired, P.n_coarse > 0 ? P.W : nullptr, P.Einv, probe);
   if (probe) {
     long long h[512 + 1024];
     if (hipMemcpyAsync(h, d_probe, sizeof(h), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess) {

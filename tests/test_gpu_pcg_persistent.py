@@ -24,11 +24,14 @@ def _solve(gpu_solver_cls, pr, linear=capi.LINEAR_PCG, iters=8):
 
 
 def test_one_launch_equals_launch_per_iteration(gpu_solver_cls, monkeypatch):
+    """(with the block-Jacobi preconditioner alone, BSGPU_PCG_COARSE=0: the launch-per-iteration path has no coarse space)"""
     pr = synthetic.pose_graph(n_pose=600, n_loop=2500, seed=5)
+    monkeypatch.setenv("BSGPU_PCG_COARSE", "0")
     s1, x1, acc1 = _solve(gpu_solver_cls, pr)
     monkeypatch.setenv("BSGPU_PCG_LAUNCHES", "1")
     s2, x2, acc2 = _solve(gpu_solver_cls, pr)
     monkeypatch.delenv("BSGPU_PCG_LAUNCHES")
+    monkeypatch.delenv("BSGPU_PCG_COARSE")
     assert s1.linear_solver_used == s2.linear_solver_used == capi.LINEAR_PCG
     assert acc1 == acc2
     assert abs(s1.final_cost - s2.final_cost) <= 1e-9 * s2.final_cost
@@ -36,6 +39,29 @@ def test_one_launch_equals_launch_per_iteration(gpu_solver_cls, monkeypatch):
     assert np.abs(x1 - x2).max() < 1e-7
     s3, x3, _ = _solve(gpu_solver_cls, pr, capi.LINEAR_SCHUR_CHOLESKY)      # the exact step
     assert abs(s1.final_cost - s3.final_cost) <= 1e-7 * s3.final_cost
+
+
+def test_two_level_preconditioner(gpu_solver_cls, monkeypatch):
+    """M^-1 = block-Jacobi + W E^-1 W^T with W the six rigid motions of the free poses: the same LM trajectory as block-Jacobi alone and
+    as the exact step, in at most 60 % of the inner iterations (the six gauge-like modes the anchor alone holds are what costs them)"""
+    pr = synthetic.pose_graph(n_pose=600, n_loop=2500, seed=5)
+    s1, x1, acc1 = _solve(gpu_solver_cls, pr)
+    monkeypatch.setenv("BSGPU_PCG_COARSE", "0")
+    s2, x2, acc2 = _solve(gpu_solver_cls, pr)
+    monkeypatch.delenv("BSGPU_PCG_COARSE")
+    s3, x3, acc3 = _solve(gpu_solver_cls, pr, capi.LINEAR_SCHUR_CHOLESKY)
+    assert s1.linear_solver_used == capi.LINEAR_PCG
+    assert acc1 == acc2 == acc3
+    assert abs(s1.final_cost - s2.final_cost) <= 1e-9 * s2.final_cost
+    assert abs(s1.final_cost - s3.final_cost) <= 1e-7 * s3.final_cost
+    assert np.abs(x1 - x2).max() < 1e-7
+    assert 0 < s1.num_inner_iterations <= 0.6 * s2.num_inner_iterations
+    # no anchor at all (the prior left out): the gauge is held by the LM diagonal only, every pose is free
+    pr2 = synthetic.pose_graph(n_pose=400, n_loop=1500, seed=6)
+    del pr2.factors[capi.F_ABSPOSE]
+    s4, x4, acc4 = _solve(gpu_solver_cls, pr2)
+    s5, x5, acc5 = _solve(gpu_solver_cls, pr2, capi.LINEAR_SCHUR_CHOLESKY)
+    assert acc4 == acc5 and abs(s4.final_cost - s5.final_cost) <= 1e-7 * s5.final_cost
 
 
 def test_named_columns_that_are_not_pose_pairs(gpu_solver_cls):
