@@ -219,6 +219,9 @@ struct bsgpu_ctx {
   PcgPersistDev pcg_persist;     // G = 0: the launch-per-iteration path only
   int *d_row_ptr = nullptr, *d_col = nullptr, *d_diag_slot = nullptr, *d_pair_slot = nullptr;
   int* d_slots[kNumInternal] = {nullptr};
+  int n_bsr_seg = 0;               // shared blocks of the block-sparse system, by segments (k_pcg.hip bsr_assemble_seg_kernel)
+  int *d_bsr_seg_start = nullptr, *d_bsr_seg_slot = nullptr, *d_bsr_seg_row = nullptr;
+  int2* d_bsr_contrib = nullptr;
   double *d_val = nullptr, *d_Minv = nullptr, *d_rhs = nullptr, *d_px = nullptr, *d_pr = nullptr, *d_pz = nullptr, *d_pp = nullptr, *d_pp1 = nullptr,
          *d_pq = nullptr, *d_ppart = nullptr, *d_ppart2 = nullptr, *d_psc = nullptr;
 

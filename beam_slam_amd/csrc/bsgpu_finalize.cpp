@@ -711,6 +711,24 @@ int build_bsr(bsgpu_ctx* c) {
     if (r == cc) diag_slot[r] = i;
   }
   for (int r = 0; r < nbr; ++r) row_ptr[r + 1] += row_ptr[r];
+  // who writes which block: a block with ONE contribution (factor, slot a, slot b) off the diagonal is stored by that factor's wave
+  // (bsr_assemble_kernel); the others — every diagonal block — are summed by segments of at most 64 contributions
+  std::vector<int> n_contrib(nblk, 0);
+  auto slot_of = [&](int ra, int rb) { return (int)(std::lower_bound(keys.begin(), keys.end(), ((uint64_t)(ra / 3) << 32) | (uint32_t)(rb / 3)) - keys.begin()); };
+  for (int t = 2; t < kNumInternal; ++t) {
+    const HostGroup& g = c->groups[t];
+    const TypeInfo& ti = kTypes[t];
+    for (int f = 0; f < g.n; ++f) {
+      if (!c->h_small_active[t][f]) continue;
+      const int32_t* idx = &g.idx[(size_t)f * ti.nidx];
+      for (int sa = 0; sa < ti.nvar; ++sa) for (int sb = 0; sb < ti.nvar; ++sb) {
+        const int ra = c->toff[idx[sa]], rb = c->toff[idx[sb]];
+        if (ra >= 0 && rb >= 0) n_contrib[slot_of(ra, rb)]++;
+      }
+    }
+  }
+  struct SegContrib { int slot, tf, ss; };
+  std::vector<SegContrib> sc_list;
   for (int t = 2; t < kNumInternal; ++t) {
     const HostGroup& g = c->groups[t];
     const TypeInfo& ti = kTypes[t];
@@ -721,11 +739,29 @@ int build_bsr(bsgpu_ctx* c) {
       for (int sa = 0; sa < ti.nvar; ++sa) for (int sb = 0; sb < ti.nvar; ++sb) {
         const int ra = c->toff[idx[sa]], rb = c->toff[idx[sb]];
         if (ra < 0 || rb < 0 || !c->h_small_active[t][f]) continue;
-        const uint64_t key = ((uint64_t)(ra / 3) << 32) | (uint32_t)(rb / 3);
-        slots[((size_t)f * ti.nvar + sa) * ti.nvar + sb] = (int)(std::lower_bound(keys.begin(), keys.end(), key) - keys.begin());
+        const int sl = slot_of(ra, rb);
+        if (n_contrib[sl] == 1 && ra != rb) slots[((size_t)f * ti.nvar + sa) * ti.nvar + sb] = sl;
+        else sc_list.push_back({sl, (t << 24) | f, (sa << 8) | sb});
       }
     }
     c->d_slots[t] = c->upload(slots);
+  }
+  {
+    std::stable_sort(sc_list.begin(), sc_list.end(), [](const SegContrib& x, const SegContrib& y) { return x.slot < y.slot; });
+    std::vector<int> seg_start, seg_slot, seg_row;
+    std::vector<int2> contrib(sc_list.size());
+    for (size_t i = 0; i < sc_list.size(); ++i) {
+      if (i == 0 || sc_list[i].slot != sc_list[i - 1].slot || (int)i - seg_start.back() >= 64) {
+        seg_start.push_back((int)i); seg_slot.push_back(sc_list[i].slot);
+        const int r = (int)(keys[sc_list[i].slot] >> 32), cc = (int)(keys[sc_list[i].slot] & 0xffffffffu);
+        seg_row.push_back(r == cc ? 3 * r : -1);
+      }
+      contrib[i] = make_int2(sc_list[i].tf, sc_list[i].ss);
+    }
+    seg_start.push_back((int)sc_list.size());
+    c->n_bsr_seg = (int)seg_slot.size();
+    c->d_bsr_seg_start = c->upload(seg_start); c->d_bsr_seg_slot = c->upload(seg_slot); c->d_bsr_seg_row = c->upload(seg_row);
+    c->d_bsr_contrib = c->upload(contrib);
   }
   c->nbr = nbr; c->nblk = nblk;
   // the preconditioner pairs consecutive block rows (2m, 2m+1) — position and orientation of one pose in the pose-graph layouts —

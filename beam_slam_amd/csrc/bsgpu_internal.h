@@ -216,8 +216,9 @@ int flatten_visual_device(hipStream_t s, const std::function<void*(size_t)>& dal
 int chol_vinv_stride();
 void chol_prepare();  // one-time function attributes (kept out of captured sequences)
 // block-sparse PCG path (k_pcg.hip)
-void launch_bsr_assemble(hipStream_t s, const SmallGroup& g, const int* slots, double* val, double* rhs, double* grad,
-                         double* hdiag);
+void launch_bsr_assemble(hipStream_t s, const SmallGroup& g, const int* slots, double* val);
+void launch_bsr_assemble_seg(hipStream_t s, const SmallGroup* groups_dev, int n_seg, const int* seg_start, const int* seg_slot, const int* seg_row,
+                             const int2* contrib, double* val, double* rhs, double* grad, double* hdiag);
 void launch_bsr_finish_diag(hipStream_t s, int nbr, const int* diag_slot, const int* pair_slot, double* val, const double* hdiag, double radius,
                             int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* scale,
                             double* dcl, double* Minv);

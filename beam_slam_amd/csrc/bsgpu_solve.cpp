@@ -10,8 +10,9 @@ namespace bsg {
 void assemble_pcg(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, bool first) {
   hipStream_t s = c->stream;
   launch_zero4(s, c->d_val, (int64_t)c->nblk * 9, c->d_rhs, c->n_pose, c->d_grad, c->n_pose, c->d_hdiag, c->n_pose);
-  for (int t = 2; t < kNumInternal; ++t)
-    launch_bsr_assemble(s, c->small[t], c->d_slots[t], c->d_val, c->d_rhs, c->d_grad, c->d_hdiag);
+  for (int t = 2; t < kNumInternal; ++t) launch_bsr_assemble(s, c->small[t], c->d_slots[t], c->d_val);
+  launch_bsr_assemble_seg(s, c->d_small_groups, c->n_bsr_seg, c->d_bsr_seg_start, c->d_bsr_seg_slot, c->d_bsr_seg_row, c->d_bsr_contrib, c->d_val, c->d_rhs,
+                          c->d_grad, c->d_hdiag);
   launch_bsr_finish_diag(s, c->nbr, c->d_diag_slot, c->d_pair_slot, c->d_val, c->d_hdiag, radius, first ? 1 : 0, new_J ? 1 : 0, o.jacobi_scaling,
                          o.min_lm_diagonal, o.max_lm_diagonal, c->d_scale, c->d_dcl, c->d_Minv);
   if (new_J) {

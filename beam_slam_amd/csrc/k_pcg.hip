@@ -6,7 +6,8 @@
 // tolerance is tight enough (default 1e-10 relative) for the LM trajectory to agree to the stated
 // final-cost tolerance.  Every tangent block of the pose-only factor types has size 3, hence 3x3 blocks.
 //
-//   bsr_assemble        wave / factor: J^T J blocks -> atomics into the BSR values (slots precomputed)
+//   bsr_assemble        wave / factor: the J^T J blocks only that factor writes, plain stores (slots precomputed)
+//   bsr_assemble_seg    the shared blocks (all diagonal ones) by segments of <= 64 contributions, with gradient and diag(J^T J)
 //   bsr_finish_diag     LM diagonal (Jacobi scaling folded in, as in the dense path) + inverses of the 6x6 diagonal blocks of
 //                       consecutive block-row pairs (position + orientation of a pose)
 //   pcg_spmv            beta, stop test and p = z + beta p folded in; q = A p (one wave / block row), partials of p.q
@@ -21,19 +22,17 @@ namespace bsg {
 // device scalars of the PCG recurrence
 enum { PC_RZ = 0, PC_RR = 1, PC_RR0 = 2, PC_DONE = 3, PC_ITERS = 4, PC_PQ = 5, PC_NUM = 8 };
 
-__global__ __launch_bounds__(64) void bsr_assemble_kernel(SmallGroup g, const int* __restrict__ slots,
-                                                          double* __restrict__ val, double* __restrict__ rhs,
-                                                          double* __restrict__ grad, double* __restrict__ hdiag) {
+// Blocks that exactly ONE (factor, slot a, slot b) writes — the off-diagonal blocks of a pose graph, nearly all of them — are stored by
+// that factor's wave, without atomics (slots >= 0); the others (every diagonal block: a pose's ~20 constraints add into it) are summed by
+// segments, bsr_assemble_seg_kernel (their entries of `slots` are -1 here).  Factor-wise atomics for everything were 7.2 M FP64 atomics
+// per LM step on the 5 000-pose graph (95 us); now 0.3 M.
+__global__ __launch_bounds__(64) void bsr_assemble_kernel(SmallGroup g, const int* __restrict__ slots, double* __restrict__ val) {
   __shared__ double sJ[15 * 30];
-  __shared__ double sr[15];
-  __shared__ int st[10];
   const int f = blockIdx.x, lane = threadIdx.x;
   if (!g.active[f]) return;
   const int m = g.m, nv = g.nv, tw = 3 * nv;
   const double* J = g.J + (size_t)f * m * tw;
   for (int i = lane; i < m * tw; i += 64) sJ[i] = J[i];
-  if (lane < m) sr[lane] = g.r[(size_t)f * m + lane];
-  if (lane < nv) st[lane] = g.toff[(size_t)f * nv + lane];
   __syncthreads();
   const int* sl = slots + (size_t)f * nv * nv;
   for (int p = lane; p < tw * tw; p += 64) {
@@ -42,22 +41,81 @@ __global__ __launch_bounds__(64) void bsr_assemble_kernel(SmallGroup g, const in
     if (slot < 0) continue;
     double acc = 0.0;
     for (int k = 0; k < m; ++k) acc += sJ[k * tw + a] * sJ[k * tw + b];
-    atomicAdd(&val[(size_t)slot * 9 + (a % 3) * 3 + (b % 3)], acc);
-  }
-  for (int a = lane; a < tw; a += 64) {
-    const int ta = st[a / 3];
-    if (ta < 0) continue;
-    double gs = 0.0, hs = 0.0;
-    for (int k = 0; k < m; ++k) { const double j = sJ[k * tw + a]; gs += j * sr[k]; hs += j * j; }
-    atomicAdd(&rhs[ta + a % 3], gs);
-    atomicAdd(&grad[ta + a % 3], gs);
-    atomicAdd(&hdiag[ta + a % 3], hs);
+    val[(size_t)slot * 9 + (a % 3) * 3 + (b % 3)] = acc;
   }
 }
-void launch_bsr_assemble(hipStream_t s, const SmallGroup& g, const int* slots, double* val, double* rhs, double* grad,
-                         double* hdiag) {
+// the shared blocks: sixteen lanes per segment (the contributions (type, factor, slot a, slot b) to one block, at most 64 of them); a
+// diagonal block's segment also sums the gradient J^T r and diag(J^T J) of its three rows
+BSG_DEV double bsr_sum16(double v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__global__ __launch_bounds__(256) void bsr_assemble_seg_kernel(const SmallGroup* __restrict__ groups, int n_seg, const int* __restrict__ seg_start,
+                                                              const int* __restrict__ seg_slot, const int* __restrict__ seg_row,
+                                                              const int2* __restrict__ contrib, double* __restrict__ val, double* __restrict__ rhs,
+                                                              double* __restrict__ grad, double* __restrict__ hdiag) {
+  const int seg = (int)blockIdx.x * 16 + (threadIdx.x >> 4), lane = threadIdx.x & 15;
+  if (seg >= n_seg) return;
+  const int beg = seg_start[seg], end = seg_start[seg + 1];
+  const int row = seg_row[seg];                       // tangent row of a diagonal block, -1 otherwise
+  double acc[9], gs[3], hs[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) acc[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { gs[i] = 0.0; hs[i] = 0.0; }
+  for (int e = beg + lane; e < end; e += 16) {
+    const int2 cb = contrib[e];
+    const int t = cb.x >> 24, f = cb.x & ((1 << 24) - 1), sa = cb.y >> 8, sb = cb.y & 255;
+    const SmallGroup& g = groups[t];
+    const int m = g.m, tw = 3 * g.nv;
+    const double* J = g.J + (size_t)f * m * tw;
+    const double* r = g.r + (size_t)f * m;
+    const bool dg = row >= 0 && sa == sb;
+    for (int k = 0; k < m; ++k) {
+      const double a0 = J[k * tw + 3 * sa], a1 = J[k * tw + 3 * sa + 1], a2 = J[k * tw + 3 * sa + 2];
+      const double b0 = J[k * tw + 3 * sb], b1 = J[k * tw + 3 * sb + 1], b2 = J[k * tw + 3 * sb + 2];
+      acc[0] += a0 * b0; acc[1] += a0 * b1; acc[2] += a0 * b2;
+      acc[3] += a1 * b0; acc[4] += a1 * b1; acc[5] += a1 * b2;
+      acc[6] += a2 * b0; acc[7] += a2 * b1; acc[8] += a2 * b2;
+      if (dg) {
+        const double rk = r[k];
+        gs[0] += a0 * rk; gs[1] += a1 * rk; gs[2] += a2 * rk;
+        hs[0] += a0 * a0; hs[1] += a1 * a1; hs[2] += a2 * a2;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) acc[i] = bsr_sum16(acc[i]);
+  if (row >= 0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { gs[i] = bsr_sum16(gs[i]); hs[i] = bsr_sum16(hs[i]); }
+  }
+  const int slot = seg_slot[seg];
+  if (lane < 9) {
+    double v = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) v = (lane == i) ? acc[i] : v;
+    atomicAdd(&val[(size_t)slot * 9 + lane], v);     // (a block of more than 64 contributions has several segments)
+  } else if (row >= 0 && lane < 12) {
+    const int i = lane - 9;
+    double g0 = 0.0, h0 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { g0 = (i == q) ? gs[q] : g0; h0 = (i == q) ? hs[q] : h0; }
+    atomicAdd(&rhs[row + i], g0);
+    atomicAdd(&grad[row + i], g0);
+    atomicAdd(&hdiag[row + i], h0);
+  }
+}
+void launch_bsr_assemble(hipStream_t s, const SmallGroup& g, const int* slots, double* val) {
   if (g.n == 0) return;
-  hipLaunchKernelGGL(bsr_assemble_kernel, dim3(g.n), dim3(64), 0, s, g, slots, val, rhs, grad, hdiag);
+  hipLaunchKernelGGL(bsr_assemble_kernel, dim3(g.n), dim3(64), 0, s, g, slots, val);
+}
+void launch_bsr_assemble_seg(hipStream_t s, const SmallGroup* groups_dev, int n_seg, const int* seg_start, const int* seg_slot, const int* seg_row,
+                             const int2* contrib, double* val, double* rhs, double* grad, double* hdiag) {
+  if (n_seg <= 0) return;
+  hipLaunchKernelGGL(bsr_assemble_seg_kernel, dim3((n_seg + 15) / 16), dim3(256), 0, s, groups_dev, n_seg, seg_start, seg_slot, seg_row, contrib, val, rhs,
+                     grad, hdiag);
 }
 
 // per PAIR of block rows (2m, 2m+1): scale / clamped LM diagonal (same algebra as pose_diag_kernel), lambda added to the two

@@ -884,6 +884,86 @@ static bool solve_normal(Ctx& c, const double* D2, double* y, LinSys& ls) {
   return true;
 }
 
+// The same system for a pose-only graph too large for the dense factorisation (BASELINE config 4: 30 000 tangent dimensions), solved
+// to `tol` (relative residual) by conjugate gradients on the operator v -> J^T (J v) + D^2 v applied factor by factor, preconditioned with
+// the inverse diagonal.  Test infrastructure for the block-sparse PCG path of the HIP library (tests/test_gpu_fullsize.py): the step of
+// the reference's exact SPARSE_NORMAL_CHOLESKY (submap_pose_graph_optimization.cpp:144-146) to the accuracy of the tolerance.
+static bool solve_normal_cg(Ctx& c, const double* D2, double* y, double tol, int max_it, int* iters_out) {
+  const int n = c.n_tan;
+  if (c.n_lm > 0 || !c.marginals.empty()) return false;
+  std::vector<double> b(n, 0.0), diag(n, 0.0), r(n), z(n), p(n), q(n);
+  struct Fac { int t, f; };
+  std::vector<Fac> facs;
+  for (int t = 2; t < BSGPU_F_NUM_TYPES; ++t) for (int f = 0; f < c.groups[t].n; ++f) if (c.groups[t].active[f]) facs.push_back({t, f});
+  for (const Fac& fc : facs) {
+    Group& g = c.groups[fc.t];
+    const TypeInfo& ti = kTypes[fc.t];
+    const int m = ti.m, tw = g.tw;
+    int cols[10];
+    factor_cols(c, fc.t, &g.idx[(size_t)fc.f * ti.nidx], cols);
+    const double* J = &g.J[(size_t)fc.f * m * tw];
+    const double* rr = &g.r[(size_t)fc.f * m];
+    for (int sa = 0; sa < ti.nvar; ++sa) {
+      if (cols[sa] < 0) continue;
+      for (int ia = 0; ia < tsz(ti, sa); ++ia) {
+        double gs = 0, hs = 0;
+        for (int k = 0; k < m; ++k) { const double j = J[k * tw + sa * 3 + ia]; gs += j * rr[k]; hs += j * j; }
+        b[cols[sa] + ia] += gs; diag[cols[sa] + ia] += hs;
+      }
+    }
+  }
+  for (int i = 0; i < n; ++i) diag[i] += D2[i];
+  auto apply = [&](const std::vector<double>& v, std::vector<double>& out) {
+    for (int i = 0; i < n; ++i) out[i] = D2[i] * v[i];
+    for (const Fac& fc : facs) {
+      Group& g = c.groups[fc.t];
+      const TypeInfo& ti = kTypes[fc.t];
+      const int m = ti.m, tw = g.tw;
+      int cols[10];
+      factor_cols(c, fc.t, &g.idx[(size_t)fc.f * ti.nidx], cols);
+      const double* J = &g.J[(size_t)fc.f * m * tw];
+      double jv[16];
+      for (int k = 0; k < m; ++k) {
+        double a = 0;
+        for (int sa = 0; sa < ti.nvar; ++sa) if (cols[sa] >= 0) for (int ia = 0; ia < tsz(ti, sa); ++ia) a += J[k * tw + sa * 3 + ia] * v[cols[sa] + ia];
+        jv[k] = a;
+      }
+      for (int sa = 0; sa < ti.nvar; ++sa) if (cols[sa] >= 0) for (int ia = 0; ia < tsz(ti, sa); ++ia) {
+        double a = 0;
+        for (int k = 0; k < m; ++k) a += J[k * tw + sa * 3 + ia] * jv[k];
+        out[cols[sa] + ia] += a;
+      }
+    }
+  };
+  std::fill(y, y + n, 0.0);
+  r = b;
+  double bb = 0;
+  for (int i = 0; i < n; ++i) bb += b[i] * b[i];
+  if (bb == 0.0) { if (iters_out) *iters_out = 0; return true; }
+  double rz = 0;
+  for (int i = 0; i < n; ++i) { z[i] = diag[i] > 0 ? r[i] / diag[i] : r[i]; rz += r[i] * z[i]; }
+  p = z;
+  int it = 0;
+  for (; it < max_it; ++it) {
+    apply(p, q);
+    double pq = 0;
+    for (int i = 0; i < n; ++i) pq += p[i] * q[i];
+    if (!(pq > 0)) break;
+    const double alpha = rz / pq;
+    double rr2 = 0;
+    for (int i = 0; i < n; ++i) { y[i] += alpha * p[i]; r[i] -= alpha * q[i]; rr2 += r[i] * r[i]; }
+    if (rr2 <= tol * tol * bb) { ++it; break; }
+    double rz_new = 0;
+    for (int i = 0; i < n; ++i) { z[i] = diag[i] > 0 ? r[i] / diag[i] : r[i]; rz_new += r[i] * z[i]; }
+    const double beta = rz_new / rz;
+    rz = rz_new;
+    for (int i = 0; i < n; ++i) p[i] = z[i] + beta * p[i];
+  }
+  if (iters_out) *iters_out = it;
+  for (int i = 0; i < n; ++i) if (!std::isfinite(y[i])) return false;
+  return true;
+}
+
 // helpers over all factors: column squared norms, gradient, J*v
 template <typename Fn> static void for_each_factor(Ctx& c, Fn fn) {
   for (int t = 0; t < BSGPU_F_NUM_TYPES; ++t) {
@@ -1016,7 +1096,8 @@ static int solve(Ctx& c, const bsgpu_options& o, bsgpu_summary& sum) {
   sum.num_residuals = c.num_res;
   sum.linear_solver_used = BSGPU_LINEAR_SCHUR_CHOLESKY;
   const int n = c.n_tan;
-  if ((size_t)c.n_pose > 20000) { c.err = "oracle: reduced system too large for the dense exact path"; return BSGPU_ERR_UNSUPPORTED; }
+  const bool cg_ok = o.linear_solver_type == BSGPU_LINEAR_PCG && c.n_lm == 0 && c.marginals.empty();
+  if ((size_t)c.n_pose > 20000 && !cg_ok) { c.err = "oracle: reduced system too large for the dense exact path"; return BSGPU_ERR_UNSUPPORTED; }
   std::vector<double> x = c.x, cand(c.x.size()), grad(n), neg(n), scale(n, 1.0), diag(n), D2(n), step(n), delta(n), tmp(c.x.size());
   LinSys ls;
   double fixed = 0;
@@ -1069,7 +1150,14 @@ static int solve(Ctx& c, const bsgpu_options& o, bsgpu_summary& sum) {
       for (int i = 0; i < n; ++i) diag[i] = std::min(std::max(diag[i], o.min_lm_diagonal), o.max_lm_diagonal);
     }
     for (int i = 0; i < n; ++i) D2[i] = diag[i] / radius;  // lm_diagonal^2
-    bool lin_ok = solve_normal(c, D2.data(), step.data(), ls);
+    // (BSGPU_LINEAR_PCG on a pose-only graph: the exact step by conjugate gradients to pcg_tolerance — what a 30 000-dimensional
+    // pose graph can be checked against; everything else: landmark Schur complement + dense Cholesky)
+    const bool by_cg = o.linear_solver_type == BSGPU_LINEAR_PCG && c.n_lm == 0 && c.marginals.empty();
+    int cg_it = 0;
+    bool lin_ok = by_cg ? solve_normal_cg(c, D2.data(), step.data(), o.pcg_tolerance > 0 ? o.pcg_tolerance : 1e-12,
+                                          o.pcg_max_iterations > 0 ? o.pcg_max_iterations : 20000, &cg_it)
+                        : solve_normal(c, D2.data(), step.data(), ls);
+    if (by_cg) { sum.num_inner_iterations += cg_it; sum.linear_solver_used = BSGPU_LINEAR_PCG; }
     sum.num_linear_solves++;
     reuse_diagonal = true;
     double model_cost_change = 0;
