@@ -121,7 +121,10 @@ int finalize(bsgpu_ctx* c) {
     c->n_leaf_tiles = 0;
     for (uint8_t v : c->leaf_tile) c->n_leaf_tiles += v;
   }
-  c->dense_ok = (size_t)c->npad <= kDenseLimit || ((nl > 0 || c->n_leaf_tiles > 0) && (size_t)c->npad <= kDenseLimitLandmarks);   // else: block-sparse PCG (pose-only problems)
+  // (pose-only graphs above kDenseLimit go to the block-sparse PCG unless the exact factorisation is asked for — BSGPU_EXACT_POSE_GRAPH=1 at
+  // finalize(): the dense tile storage, 2 x npad^2 doubles, is not allocated on spec; C4 that way: DESIGN.md 3.3)
+  const bool exact_pose_graph = getenv("BSGPU_EXACT_POSE_GRAPH") != nullptr;
+  c->dense_ok = (size_t)c->npad <= kDenseLimit || ((nl > 0 || c->n_leaf_tiles > 0 || exact_pose_graph) && (size_t)c->npad <= kDenseLimitLandmarks);   // else: block-sparse PCG (pose-only problems)
   int row = 0;
   for (int t = 0; t < BSGPU_F_NUM_TYPES; ++t) { c->row0[t] = row; row += c->groups[t].n * kTypes[t].m; }
   for (const HostMarginal& mg : c->marginals) row += mg.rows;
@@ -624,7 +627,9 @@ int finalize(bsgpu_ctx* c) {
       // fused single-launch factorisation (default; BSGPU_CHOL_FUSED=0 keeps the launch-per-step path): task list + zeroed counters
       const char* ef = getenv("BSGPU_CHOL_FUSED");
       c->d_ftasks = nullptr; c->d_fsync = nullptr; c->d_tile_tot = nullptr;
-      if (!(ef && atoi(ef) == 0) && !c->plan.ftasks.empty()) {
+      // (above 12 M tasks — a DENSE system of more than ~26 000 dimensions, which only the exact option on a pose graph produces — the
+      // launch-per-step path runs: at 17 M tasks the fused kernel's factor came out wrong, cause not found; scripts/c4_exact.py)
+      if (!(ef && atoi(ef) == 0) && !c->plan.ftasks.empty() && c->plan.ftasks.size() <= ((size_t)12 << 20)) {
         c->d_ftasks = c->upload(c->plan.ftasks);
         c->d_tile_tot = c->upload(c->plan.tile_tot);
         c->d_fsync = c->upload(std::vector<int>((size_t)c->plan.fused_sync_words, 0));

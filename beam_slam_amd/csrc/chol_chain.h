@@ -232,7 +232,7 @@ BSG_CHAIN_DEV void chain_update_waves(const ChainArgs& A, double* smem, int u, i
       if ((A.present >> (ti * (ti + 1) / 2 + tj)) & 1u) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg)
-          v[reg] = ld8_wt(rS, (unsigned)(((size_t)(c0 * 64 + 16 * r + q + 4 * reg) * ld + c0 * 64 + 16 * C + n) * sizeof(double)));
+          v[reg] = ld8_wt(rS, (unsigned)(((size_t)(16 * r + q + 4 * reg) * ld + c0 * 64 + 16 * C + n) * sizeof(double)));
       }
     }
     U.acc[SL::first(C) + I] = v;
@@ -260,8 +260,9 @@ BSG_CHAIN_DEV bool chain_factor(const ChainArgs& A, double* smem, long long* ts)
   const int q = lane >> 4, n = lane & 15;
   const int m = __builtin_amdgcn_readfirstlane(A.m), c0 = __builtin_amdgcn_readfirstlane(A.c0), ld = __builtin_amdgcn_readfirstlane(A.ld);
   const int NCB = 4 * m;
-  const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(A.S), 0, (int)((size_t)ld * ld * sizeof(double)), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rL = __builtin_amdgcn_make_buffer_rsrc(A.Lp, 0, (int)((size_t)ld * ld * sizeof(double)), 0x00020000);
+  // (the resources start at the chain's first row: 32-bit sizes and offsets, and the matrix passes 4 GB at 23 170 dimensions)
+  const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(A.S) + (size_t)c0 * 64 * ld, 0, (int)((size_t)kChainMaxTiles * 64 * ld * sizeof(double)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rL = __builtin_amdgcn_make_buffer_rsrc(A.Lp + (size_t)c0 * 64 * ld, 0, (int)((size_t)kChainMaxTiles * 64 * ld * sizeof(double)), 0x00020000);
   const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(A.Winv + (size_t)c0 * 4096, 0, (int)((size_t)m * 4096 * sizeof(double)), 0x00020000);
   int nts = 0;
   auto stamp = [&]() { if (PROBE && tid == 0) ts[nts++] = (long long)__builtin_readcyclecounter(); };
@@ -273,7 +274,7 @@ BSG_CHAIN_DEV bool chain_factor(const ChainArgs& A, double* smem, long long* ts)
     const int total = (NCB - p) * 128;
     for (int i = t0; i < total; i += nthreads) {
       const int prow = 16 * p + (i >> 3), piece = i & 7;
-      st16_wt(rL, (unsigned)(((size_t)(c0 * 64 + prow) * ld + c0 * 64 + 16 * p + 2 * piece) * sizeof(double)), lds_ld2(&P[prow * PP + 2 * piece]));
+      st16_wt(rL, (unsigned)(((size_t)prow * ld + c0 * 64 + 16 * p + 2 * piece) * sizeof(double)), lds_ld2(&P[prow * PP + 2 * piece]));
     }
     // W[16 pq + c][j] = X[j][16 pq + c]: 16 rows x 64 columns of Winv[k], two columns per thread
     for (int i = t0; i < 512; i += nthreads) {

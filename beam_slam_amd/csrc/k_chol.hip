@@ -618,8 +618,11 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
   int* s_ctl = reinterpret_cast<int*>(sV + 4 * 16 * kVtPitch);   // 4 ints
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int N = ld / NB;
-  const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(S, 0, (int)((size_t)ld * ld * sizeof(double)), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rLp = __builtin_amdgcn_make_buffer_rsrc(Lp, 0, (int)((size_t)ld * ld * sizeof(double)), 0x00020000);
+  // (buffer resources per TILE ROW — 64 rows of S or of the factor: a resource counts its bytes and its offsets in 32 bits, and the
+  // matrix passes 4 GB at 23 170 dimensions; with one resource over the whole matrix every step above that size came out invalid)
+  auto tile_rows = [&](double* base, int row0) {
+    return __builtin_amdgcn_make_buffer_rsrc(base + (size_t)row0 * ld, 0, (int)((size_t)NB * ld * sizeof(double)), 0x00020000);
+  };
   const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(C.Winv), 0, (int)((size_t)(N - 1) * 4096 * sizeof(double)), 0x00020000);
   const int crow = lane >> 4, ccol = lane & 15;
   const int rs = wave & 3, tt0 = (wave >> 2) * TPW;   // this wave's row strip and first column block of the update
@@ -631,7 +634,8 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
   const bool solve_i = !(tk.flags & kFusedXiLp);
   const bool solve_j = !diag && !(tk.flags & (kFusedXjLp | kFusedXjChain));
   const bool need_L = solve_i || solve_j;
-  const int ri = ti * NB, rj = tj * NB, c0 = k * NB;
+  const int ri = __builtin_amdgcn_readfirstlane(ti * NB), rj = __builtin_amdgcn_readfirstlane(tj * NB), c0 = __builtin_amdgcn_readfirstlane(k * NB);
+  const __amdgpu_buffer_rsrc_t rS_i = tile_rows(S, ri), rS_j = tile_rows(S, rj), rL_i = tile_rows(Lp, ri), rL_j = tile_rows(Lp, rj), rL_c = tile_rows(Lp, c0);
   // rows of the rhs tile (tile N-1 as row tile) beyond its used strips are zero and stay zero: no solve, no product, no traffic for them
   const int strips_i = (ti == N - 1) ? __builtin_amdgcn_readfirstlane(C.rhs_strips) : 4;
   const bool strip_on = rs < strips_i;
@@ -656,15 +660,15 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
     for (int u = 0; u < TPW; ++u)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg)
-        cpre[u][reg] = ld8_sc1(rS, (unsigned)(((size_t)(ri + 16 * rs + crow + 4 * reg) * ld + rj + 16 * (tt0 + u) + ccol) * sizeof(double)));
+        cpre[u][reg] = ld8_sc1(rS_i, (unsigned)(((size_t)(16 * rs + crow + 4 * reg) * ld + rj + 16 * (tt0 + u) + ccol) * sizeof(double)));
   }
   if (__builtin_amdgcn_readfirstlane(s_ctl[1]) == 0) return false;
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     const int i = tid + NT * q;
     const int r = i >> 5, c2 = (i & 31) * 2;
-    vXi[q] = ld16_sc1(solve_i ? rS : rLp, (unsigned)(((size_t)(ri + r) * ld + c0 + c2) * sizeof(double)));
-    if (!diag && !(tk.flags & kFusedXjChain)) vXj[q] = ld16_sc1(solve_j ? rS : rLp, (unsigned)(((size_t)(rj + r) * ld + c0 + c2) * sizeof(double)));
+    vXi[q] = ld16_sc1(solve_i ? rS_i : rL_i, (unsigned)(((size_t)r * ld + c0 + c2) * sizeof(double)));
+    if (!diag && !(tk.flags & kFusedXjChain)) vXj[q] = ld16_sc1(solve_j ? rS_j : rL_j, (unsigned)(((size_t)r * ld + c0 + c2) * sizeof(double)));
   }
   __syncthreads();   // (s_ctl[1] is rewritten below)
   if (need_L || (tk.flags & kFusedXjChain)) {
@@ -677,14 +681,14 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int i = tid + NT * q;
-      vXj[q] = ld16_sc1(rLp, (unsigned)(((size_t)(rj + (i >> 5)) * ld + c0 + (i & 31) * 2) * sizeof(double)));
+      vXj[q] = ld16_sc1(rL_j, (unsigned)(((size_t)(i >> 5) * ld + c0 + (i & 31) * 2) * sizeof(double)));
     }
   }
   if (need_L) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int i = tid + NT * q;
-      vL[q] = ld16_sc1(rLp, (unsigned)(((size_t)(c0 + (i >> 5)) * ld + c0 + (i & 31) * 2) * sizeof(double)));
+      vL[q] = ld16_sc1(rL_c, (unsigned)(((size_t)(i >> 5) * ld + c0 + (i & 31) * 2) * sizeof(double)));
     }
     // the inverses of the four diagonal 16x16 blocks of L_kk = the diagonal blocks of W_k: sV[b][i][c] = W[16 b + i][16 b + c]
 #pragma unroll
@@ -745,7 +749,7 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
         for (int u = 0; u < TPW; ++u)
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg)
-            acc[u][reg] = ld8_sc1(rS, (unsigned)(((size_t)(ri + 16 * rs + crow + 4 * reg) * ld + rj + 16 * (tt0 + u) + ccol) * sizeof(double)));
+            acc[u][reg] = ld8_sc1(rS_i, (unsigned)(((size_t)(16 * rs + crow + 4 * reg) * ld + rj + 16 * (tt0 + u) + ccol) * sizeof(double)));
       }
     }
     if (strip_on) {
@@ -763,7 +767,7 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
         for (int u = 0; u < TPW; ++u)
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg)
-            acc[u][reg] += ld8_sc1(rS, (unsigned)(((size_t)(ri + 16 * rs + crow + 4 * reg) * ld + rj + 16 * (tt0 + u) + ccol) * sizeof(double)));
+            acc[u][reg] += ld8_sc1(rS_i, (unsigned)(((size_t)(16 * rs + crow + 4 * reg) * ld + rj + 16 * (tt0 + u) + ccol) * sizeof(double)));
       }
     }
     stamp(5);
@@ -772,7 +776,7 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
       for (int u = 0; u < TPW; ++u)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg)
-          st8_sc1(rS, (unsigned)(((size_t)(ri + 16 * rs + crow + 4 * reg) * ld + rj + 16 * (tt0 + u) + ccol) * sizeof(double)), acc[u][reg]);
+          st8_sc1(rS_i, (unsigned)(((size_t)(16 * rs + crow + 4 * reg) * ld + rj + 16 * (tt0 + u) + ccol) * sizeof(double)), acc[u][reg]);
     }
   }
   if (tk.flags & kFusedPublishX) {
@@ -781,7 +785,7 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
     for (int q = 0; q < NQ; ++q) {
       const int i = tid + NT * q;
       const int r = i >> 5, c2 = (i & 31) * 2;
-      st16_sc1(rLp, (unsigned)(((size_t)(ri + r) * ld + c0 + c2) * sizeof(double)), *reinterpret_cast<const double2*>(&sXi[r * LDT + c2]));
+      st16_sc1(rL_i, (unsigned)(((size_t)r * ld + c0 + c2) * sizeof(double)), *reinterpret_cast<const double2*>(&sXi[r * LDT + c2]));
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -854,7 +858,7 @@ __global__ __launch_bounds__(kFusedThreads) void chol_fused_kernel(double* __res
   C.S = S; C.Lp = Lp; C.Vinv = Vinv; C.scal = scal; C.tasks = tasks; C.tile_tot = tile_tot; C.nreal = nreal; C.ld = ld; C.n_vinv_tiles = N - 1;
   C.Winv = Winv; C.rhs_strips = rhs_strips;
   C.abort_w = abort_w; C.potrf_done = sync + 3 * fs; C.upd = sync + (3 + N) * fs; C.fs = fs;
-  C.deadline = (long long)wall_clock64() + kFusedTimeoutTicks;
+  C.deadline = (long long)wall_clock64() + kFusedTimeoutTicks + 20LL * n_tasks;   // (+ 0.2 us per task: a dense 30 000-dimensional factorisation is 17 M tasks and half a second)
   C.probe_ts = probe_ts;
   // ONE task per workgroup, taken from a ticket counter: the k-th workgroup to start running gets task k, so the tasks are started in
   // list order whatever order the hardware dispatches the grid in — every counter a task waits for is advanced by a task that was

@@ -269,3 +269,30 @@ def test_c4_full_solve_matches_oracle_cg(oracle_cls, gpu_solver_cls):
     assert np.abs(g.get_blocks() - o.get_blocks()).max() < 1e-5
     # the inner iterations the judge's bar names: at most 80 per LM step
     assert sg.num_inner_iterations <= 80 * sg.num_iterations
+
+
+@pytest.mark.parametrize("n_pose", [2200, 3900])
+def test_exact_option_on_pose_graphs_above_the_dense_limit(gpu_solver_cls, monkeypatch, n_pose):
+    """BSGPU_EXACT_POSE_GRAPH=1 at finalize(): the tiled factorisation instead of the block-sparse PCG on a pose-only graph of more than
+    12 288 dimensions — 13 200 and 23 400 here, the second with a reduced system of more than 4 GB (the size at which buffer resources
+    over the whole matrix wrapped around: every step came out invalid).  Same LM trajectory as the PCG path."""
+    pr = synthetic.pose_graph(n_pose, 9 * n_pose + 1, 20250622)
+    opt_kw = dict(max_num_iterations=2)
+    g = gpu_solver_cls(0)
+    pr.load(g)
+    o = g.options_default()
+    o.max_num_iterations = 2
+    sp = g.solve(o)
+    assert sp.linear_solver_used == capi.LINEAR_PCG
+    monkeypatch.setenv("BSGPU_EXACT_POSE_GRAPH", "1")
+    g2 = gpu_solver_cls(0)
+    pr.load(g2)
+    o2 = g2.options_default()
+    o2.max_num_iterations = 2
+    o2.linear_solver_type = capi.LINEAR_SCHUR_CHOLESKY
+    se = g2.solve(o2)
+    monkeypatch.delenv("BSGPU_EXACT_POSE_GRAPH")
+    assert se.linear_solver_used == capi.LINEAR_SCHUR_CHOLESKY
+    for a, b in zip(g.iterations(), g2.iterations()):
+        assert a.step_is_successful == b.step_is_successful and abs(a.cost - b.cost) <= 1e-7 * b.cost
+    assert np.abs(g.get_blocks() - g2.get_blocks()).max() < 1e-6
