@@ -12,6 +12,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 
 #include "bs_constraints.h"
 
@@ -125,16 +126,27 @@ class GpuGraph {
   struct DeferContext {};
   GpuGraph(int device, DeferContext) : device_(device), ctx_(nullptr) {}   // clone(): a snapshot that is only read never opens a device context
  public:
-  ~GpuGraph() { if (ctx_) bsgpu_destroy(ctx_); }
+  ~GpuGraph() {
+    if (ctx_) bsgpu_destroy(ctx_);
+    for (int ty = 0; ty < BSGPU_F_NUM_TYPES; ++ty)
+      if (undo_[ty]) { std::lock_guard<std::mutex> lk(tables_[ty]->mu); undo_[ty]->detached = true; }
+    // a snapshot taken from this graph may outlive it: what this graph owns goes to the generation the snapshots hold on to
+    if (gen_ && gen_.use_count() > 1) for (auto& c : cown_) if (c) gen_->graveyard.push_back(std::move(c));
+  }
   GpuGraph(const GpuGraph&) = delete;
   GpuGraph& operator=(const GpuGraph&) = delete;
 
   // ---- fuse_core::Graph surface used by the reference ---------------------------------
   void clear() {
     vslots_.clear(); vfree_.clear(); vindex_.clear(); vmeta_.clear(); vdata_.clear(); ordered_.clear(); on_hold_.clear();
+    for (auto& c : cown_) if (c) retire(std::move(c));
+    cown_.clear();
     cptr_.clear(); ctype_.clear(); crow_.clear(); cfree_.clear(); cindex_.clear();
-    for (auto& t : tables_) t.reset();
-    for (int ty = 0; ty < BSGPU_F_NUM_TYPES; ++ty) { dirty_[ty].clear(); synced_[ty] = false; }
+    for (int ty = 0; ty < BSGPU_F_NUM_TYPES; ++ty) {
+      if (undo_[ty]) { std::lock_guard<std::mutex> lk(tables_[ty]->mu); undo_[ty]->detached = true; }
+      undo_[ty].reset(); tables_[ty].reset();
+      dirty_[ty].clear(); synced_[ty] = false;
+    }
     cameras_.clear(); marginal_rows_.clear();
     conn_.clear(); connectivity_valid_ = true;
   }
@@ -155,7 +167,7 @@ class GpuGraph {
   std::vector<const fuse_core::Constraint*> getConstraints() const {
     std::vector<const fuse_core::Constraint*> v;
     v.reserve(cindex_.size());
-    for (size_t i = 0; i < cptr_.size(); ++i) if (ctype_[i] != kFree) v.push_back(cptr_[i].get());
+    for (size_t i = 0; i < cptr_.size(); ++i) if (ctype_[i] != kFree) v.push_back(cptr_[i]);
     return v;
   }
   std::vector<const fuse_core::Constraint*> getConnectedConstraints(const fuse_core::UUID& var) const {
@@ -163,7 +175,7 @@ class GpuGraph {
     if (s < 0) throw std::logic_error("getConnectedConstraints: variable not in graph");
     ensureConnectivity();
     std::vector<const fuse_core::Constraint*> out;
-    for (int32_t cs : conn_[s]) out.push_back(cptr_[cs].get());
+    for (int32_t cs : conn_[s]) out.push_back(cptr_[cs]);
     return out;
   }
   bool addVariable(fuse_core::Variable::SharedPtr v) {
@@ -172,7 +184,7 @@ class GpuGraph {
     int32_t s;
     if (!vfree_.empty()) { s = vfree_.back(); vfree_.pop_back(); }
     else { s = (int32_t)vslots_.size(); vslots_.emplace_back(); vmeta_.emplace_back(); vdata_.emplace_back(); if (connectivity_valid_) conn_.emplace_back(); }
-    vmeta_[s] = VMeta{(uint8_t)v->size(), (uint8_t)v->manifold(), (uint8_t)(v->holdConstant() ? 1 : 0)};
+    vmeta_[s] = VMeta{(uint8_t)v->size(), (uint8_t)v->manifold(), (uint8_t)(v->holdConstant() ? 1 : 0), (uint16_t)std::min<size_t>(v->cloneSize(), 65535)};
     vdata_[s] = v->data();
     vindex_.insert(v->uuid(), s);
     vslots_[s] = std::move(v);
@@ -207,6 +219,7 @@ class GpuGraph {
     int32_t cs;
     if (!cfree_.empty()) { cs = cfree_.back(); cfree_.pop_back(); }
     else { cs = (int32_t)cptr_.size(); cptr_.push_back(nullptr); ctype_.push_back(kFree); crow_.push_back(0); }
+    if (cown_.size() < cptr_.size()) cown_.resize(cptr_.size());
     ensureConnectivity();
     // (a constraint is new to every list; only a variable it names twice must not get it twice — checked within `vars`, not by
     //  scanning the variable's list: a keyframe pose carries thousands of constraints)
@@ -214,7 +227,8 @@ class GpuGraph {
       if (std::find(vars.begin(), vars.begin() + i, vars[i]) == vars.begin() + i) conn_[vars[i]].push_back(cs);
     cindex_.insert(c->uuid(), cs);
     appendRow(*c, cs, vars);
-    cptr_.mut(cs) = std::move(c);
+    cptr_.mut(cs) = c.get();
+    cown_[cs] = std::move(c);
     return true;
   }
   bool removeConstraint(const fuse_core::UUID& u) {
@@ -224,7 +238,8 @@ class GpuGraph {
     forEachVariableOf(cs, [&](int32_t s) { auto& l = conn_[s]; auto it = std::find(l.begin(), l.end(), cs); if (it != l.end()) { *it = l.back(); l.pop_back(); } });
     removeRow(cs);
     cindex_.erase(u);
-    cptr_.mut(cs).reset();
+    cptr_.mut(cs) = nullptr;
+    if ((size_t)cs < cown_.size() && cown_[cs]) retire(std::move(cown_[cs]));
     ctype_[cs] = kFree;
     cfree_.push_back(cs);
     return true;
@@ -269,27 +284,64 @@ class GpuGraph {
     {
       // The copies are constructed side by side in ONE allocation that they own together (aliasing shared_ptrs): 51 000 make_shared
       // calls — and as many frees when the snapshot is dropped — become one of each.  Types without cloneAt() are cloned one by one.
-      size_t bytes = 0;
-      for (size_t i = 0; i < vslots_.size(); ++i) {
-        if (i + 16 < vslots_.size()) __builtin_prefetch(vslots_[i + 16].get(), 0, 1);   // (separately allocated objects: requested ahead)
-        if (vslots_[i]) bytes += (vslots_[i]->cloneSize() + 15) & ~(size_t)15;
+      // Offsets from the slot table alone (the sizes were noted when the variables entered); the source objects are separate heap
+      // allocations and the copy pass is bound by the misses on them.
+      const size_t n = vslots_.size();
+      std::vector<uint32_t> off(n + 1, 0);
+      size_t live = 0;
+      for (size_t i = 0; i < n; ++i) {
+        const size_t sz = (vslots_[i] && vmeta_[i].clone_size && vmeta_[i].clone_size < 65535) ? vmeta_[i].clone_size : 0;
+        off[i + 1] = off[i] + (uint32_t)((sz + 15) & ~(size_t)15);
+        live += vslots_[i] ? 1 : 0;
       }
-      auto slab = std::make_shared<VariableSlab>(bytes);
-      slab->objects.reserve(vindex_.size());
-      size_t off = 0;
-      for (size_t i = 0; i < vslots_.size(); ++i) {
-        if (!vslots_[i]) continue;
-        const size_t sz = vslots_[i]->cloneSize();
-        fuse_core::Variable* o = sz ? vslots_[i]->cloneAt(slab->mem.get() + off) : nullptr;
-        if (o) { off += (sz + 15) & ~(size_t)15; slab->objects.push_back(o); g->vslots_[i] = fuse_core::Variable::SharedPtr(slab, o); }
-        else g->vslots_[i] = vslots_[i]->clone();
-        g->vdata_[i] = g->vslots_[i]->data();
+      auto slab = std::make_shared<VariableSlab>(off[n]);
+      slab->objects.assign(n, nullptr);
+      unsigned char* const mem = slab->mem.get();
+      GpuGraph* const gp = g.get();
+      auto copy_range = [&, gp](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+          if (i + 16 < hi) __builtin_prefetch(vslots_[i + 16].get(), 0, 1);
+          if (!vslots_[i]) continue;
+          fuse_core::Variable* o = off[i + 1] > off[i] ? vslots_[i]->cloneAt(mem + off[i]) : nullptr;
+          if (o) slab->objects[i] = o;
+          else gp->vslots_[i] = vslots_[i]->clone();
+        }
+      };
+      (void)live;
+      copy_range(0, n);   // (four threads were tried: 1.7 ms against 1.3 — the misses overlap well enough under one thread's prefetches)
+      // (the handles from ONE thread: they all count on the slab's control block)
+      for (size_t i = 0; i < n; ++i) {
+        if (slab->objects[i]) g->vslots_[i] = fuse_core::Variable::SharedPtr(slab, slab->objects[i]);
+        if (g->vslots_[i]) g->vdata_[i] = g->vslots_[i]->data();
       }
     }
     g->vfree_ = vfree_; g->vindex_ = vindex_; g->vmeta_ = vmeta_; g->ordered_ = ordered_; g->on_hold_ = on_hold_;
     lap("variables");
+    // the constraints are shared as RAW pointers (a chunk is copied with memcpy when either side writes to it — behind shared_ptrs
+    // every such copy was 1 024 atomic increments, 400 000 per cycle at C2, and as many decrements when the snapshot was dropped);
+    // what keeps them alive for the snapshot is the GENERATION it holds (see Generation below)
     g->cptr_ = cptr_; g->ctype_ = ctype_; g->crow_ = crow_; g->cfree_ = cfree_; g->cindex_ = cindex_;
-    for (int ty = 0; ty < BSGPU_F_NUM_TYPES; ++ty) g->tables_[ty] = tables_[ty];
+    g->keep_ = keep_;                 // (what this graph itself inherited)
+    g->keep_.push_back(gen_);         // everything this graph owns now or retires from now on
+    {
+      auto next = std::make_shared<Generation>();
+      gen_->next = next;
+      gen_ = std::move(next);
+    }
+    materialiseTables();              // (a snapshot that is cloned needs its own tables first)
+    for (int ty = 0; ty < BSGPU_F_NUM_TYPES; ++ty) {
+      if (!tables_[ty] || !tables_[ty]->rows) continue;
+      auto u = std::make_shared<TableUndo>();
+      u->rows = tables_[ty]->rows;
+      u->saved.assign(u->rows, 0);
+      {
+        std::lock_guard<std::mutex> lk(tables_[ty]->mu);
+        tables_[ty]->pruneWatchers();
+        tables_[ty]->watchers.push_back(u);
+      }
+      g->tables_[ty] = tables_[ty];
+      g->undo_[ty] = std::move(u);
+    }
     g->cameras_ = cameras_;
     g->marginal_rows_ = marginal_rows_;
     g->connectivity_valid_ = false;   // variable -> constraints index of the copy: rebuilt on first use (publishers rarely need it)
@@ -369,6 +421,7 @@ class GpuGraph {
     check(bsgpu_clear(ctx()));
     check(bsgpu_set_blocks(ctx(), (int32_t)nb, f.values.data(), f.offset.data(), f.size.data(), f.manifold.data(), f.is_const.data()));
     if (!cameras_.empty()) check(bsgpu_set_cameras(ctx(), (int32_t)cameras_.size(), cameras_.data()));
+    materialiseTables();
     for (int ty = 0; ty < BSGPU_F_NUM_TYPES; ++ty) {
       const TypeTable* tb = tables_[ty].get();
       if (!tb || !tb->rows) continue;   // (nothing to say: the change list keeps growing until the next call for the type)
@@ -514,14 +567,14 @@ class GpuGraph {
   // ---- variables: graph-local slots (stable while the variable is in the graph, kept by clone()) ---------------------
   struct VariableSlab {   // the variables of a clone(): one block, released (destructors first) with the last variable that lives in it
     explicit VariableSlab(size_t bytes) : mem(static_cast<unsigned char*>(::operator new(bytes ? bytes : 1, std::align_val_t(16)))) {}
-    ~VariableSlab() { for (fuse_core::Variable* o : objects) o->~Variable(); }
+    ~VariableSlab() { for (fuse_core::Variable* o : objects) if (o) o->~Variable(); }
     struct Free { void operator()(unsigned char* p) const { ::operator delete(p, std::align_val_t(16)); } };
     std::unique_ptr<unsigned char, Free> mem;
     std::vector<fuse_core::Variable*> objects;
     VariableSlab(const VariableSlab&) = delete;
     VariableSlab& operator=(const VariableSlab&) = delete;
   };
-  struct VMeta { uint8_t size, manifold, hold_constant; };
+  struct VMeta { uint8_t size, manifold, hold_constant; uint16_t clone_size; };   // clone_size: Variable::cloneSize() (0: clone() only)
   std::vector<fuse_core::Variable::SharedPtr> vslots_;   // slot -> variable (null: free slot)
   std::vector<VMeta> vmeta_;                              // slot -> what flatten() needs without touching the object
   std::vector<double*> vdata_;                            // slot -> Variable::data() (stable while the variable is in the graph)
@@ -545,6 +598,20 @@ class GpuGraph {
   // enters the graph; removal swaps the last row into the hole.  Row order therefore follows the transaction history.
   // idx holds, per row, the variable SLOTS (then the camera-table id for the camera types) in the column layout of
   // bsgpu_add_factors, so the table is handed to the back-end as it is.
+  // A snapshot (clone) does NOT get a copy of a table and the graph that goes on writing it does not copy it either (the 22 MB
+  // reprojection table of C2 was copied once per cycle, by whichever side wrote first): both name the SAME object and the snapshot
+  // registers an UNDO LOG with it.  Before the owner overwrites or truncates a row that existed when the snapshot was taken it saves the
+  // row's content there (first write wins); a snapshot that ever needs its tables — it is optimised, mutated, cloned or asked for its
+  // connectivity — rebuilds its version from the shared arrays + its log (materialiseTables) and owns a private table from then on.
+  // Writes by the owner, and the rebuild, take the table's mutex while a log is registered (the snapshot lives on another thread).
+  struct TableUndo {
+    size_t rows = 0;                   // rows of the table when the snapshot was taken
+    std::vector<uint8_t> saved;        // per such row: already in the log
+    std::vector<uint32_t> row;         // the log: row numbers and their contents at that time
+    std::vector<int32_t> idx, loss_kind, owner;
+    std::vector<double> consts, loss_a;
+    bool detached = false;             // the snapshot has its own table now, or is gone
+  };
   struct TypeTable {
     size_t rows = 0;
     int nvar = 0, nidx = 0;
@@ -553,15 +620,71 @@ class GpuGraph {
     std::vector<int32_t> loss_kind;
     std::vector<double> loss_a;
     std::vector<int32_t> owner;        // rows: constraint slot of each row
+    std::mutex mu;
+    std::vector<std::shared_ptr<TableUndo>> watchers;
+    // (owner side, mu held) row q is about to be overwritten or dropped
+    void save(size_t q) {
+      const size_t nc = rows ? consts.size() / rows : 0, ni = (size_t)nidx;
+      for (auto& w : watchers) {
+        if (w->detached || q >= w->rows || w->saved[q]) continue;
+        w->saved[q] = 1; w->row.push_back((uint32_t)q);
+        w->idx.insert(w->idx.end(), idx.begin() + q * ni, idx.begin() + (q + 1) * ni);
+        w->consts.insert(w->consts.end(), consts.begin() + q * nc, consts.begin() + (q + 1) * nc);
+        w->loss_kind.push_back(loss_kind[q]); w->loss_a.push_back(loss_a[q]); w->owner.push_back(owner[q]);
+      }
+    }
+    void pruneWatchers() { watchers.erase(std::remove_if(watchers.begin(), watchers.end(), [](const std::shared_ptr<TableUndo>& w) { return w->detached; }), watchers.end()); }
+  };
+  // tables given back by the last owner that dropped them, capacity kept (at most a handful; thread-safe: snapshots die on other threads)
+  class TablePool {
+   public:
+    static TablePool& instance() { static TablePool p; return p; }
+    std::shared_ptr<TypeTable> acquire(int ty) {   // (per factor type: the 22 MB reprojection table must not go to the prior's)
+      TypeTable* t = nullptr;
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        auto& f = free_[ty];
+        if (!f.empty()) { t = f.back().release(); f.pop_back(); }
+      }
+      if (!t) t = new TypeTable();
+      return std::shared_ptr<TypeTable>(t, [ty](TypeTable* p) { TablePool::instance().give_back(ty, p); });
+    }
+   private:
+    void give_back(int ty, TypeTable* p) {
+      std::unique_ptr<TypeTable> u(p);
+      u->rows = 0; u->idx.clear(); u->consts.clear(); u->loss_kind.clear(); u->loss_a.clear(); u->owner.clear(); u->watchers.clear();
+      std::lock_guard<std::mutex> lk(mu_);
+      if (free_[ty].size() < 2) free_[ty].push_back(std::move(u));
+    }
+    std::mutex mu_;
+    std::vector<std::unique_ptr<TypeTable>> free_[BSGPU_F_NUM_TYPES];
   };
   static constexpr int32_t kFree = -3, kMarginal = -2, kUnpacked = -1;
   struct MarginalRow { fuse_core::FactorTables::MarginalEntry e; std::vector<int32_t> vars; };
-  detail::CowChunks<fuse_core::Constraint::SharedPtr> cptr_;   // constraint slot -> constraint
+  detail::CowChunks<const fuse_core::Constraint*> cptr_;        // constraint slot -> constraint (raw: see cown_ / Generation)
+  // Ownership.  cown_[slot] owns the constraints THIS graph added; a snapshot (clone) owns nothing it inherited and instead holds the
+  // source's generation at the time of the copy.  A constraint the source removes later is retired into the source's CURRENT
+  // generation, and a generation keeps its successor alive — so everything a snapshot can still point to lives as long as the
+  // snapshot does, a constraint retired with no snapshot alive is released at once, and a source that dies first leaves what it
+  // owns to its last generation.
+  struct Generation {
+    std::vector<fuse_core::Constraint::SharedPtr> graveyard;
+    std::shared_ptr<Generation> next;
+    ~Generation() {   // (unlink iteratively: a long-lived snapshot can sit at the head of thousands of generations)
+      std::shared_ptr<Generation> n = std::move(next);
+      while (n && n.use_count() == 1) { std::shared_ptr<Generation> nn = std::move(n->next); n = std::move(nn); }
+    }
+  };
+  std::vector<fuse_core::Constraint::SharedPtr> cown_;
+  mutable std::shared_ptr<Generation> gen_ = std::make_shared<Generation>();
+  std::vector<std::shared_ptr<Generation>> keep_;
+  void retire(fuse_core::Constraint::SharedPtr c) { if (gen_.use_count() > 1) gen_->graveyard.push_back(std::move(c)); }
   std::vector<int32_t> ctype_;                                  // constraint slot -> factor type | kFree | kMarginal | kUnpacked
   std::vector<uint32_t> crow_;                                  // constraint slot -> row in its type's table
   std::vector<int32_t> cfree_;
   detail::CowIndex cindex_;                                     // uuid -> constraint slot
-  std::shared_ptr<TypeTable> tables_[BSGPU_F_NUM_TYPES];        // copy-on-write (tableMut)
+  mutable std::shared_ptr<TypeTable> tables_[BSGPU_F_NUM_TYPES];        // owned — or, while undo_[ty] is set, another graph's table to be read through the log
+  mutable std::shared_ptr<TableUndo> undo_[BSGPU_F_NUM_TYPES];          // (a snapshot that has not needed its tables yet)
   std::vector<bsgpu_camera> cameras_;
   std::map<int32_t, MarginalRow> marginal_rows_;                // by constraint slot
   // rows of each table written since this graph's context last took the table (bsgpu_sync_factors_indirect's change list); a
@@ -575,22 +698,46 @@ class GpuGraph {
   }
   fuse_core::FactorTables pack_scratch_;
   std::vector<int32_t> slot_scratch_;
-  TypeTable& tableMut(int ty) {
-    auto& t = tables_[ty];
-    if (!t) t = std::make_shared<TypeTable>();
-    else if (t.use_count() > 1) {
-      // copy-on-write: the copy gets head-room, or the transaction's first append would reallocate (and copy) everything again
-      auto n = std::make_shared<TypeTable>();
-      n->rows = t->rows; n->nvar = t->nvar; n->nidx = t->nidx;
-      auto grow = [](auto& dst, const auto& src) { dst.reserve(src.size() + src.size() / 8 + 64); dst.assign(src.begin(), src.end()); };
-      grow(n->idx, t->idx); grow(n->consts, t->consts); grow(n->loss_kind, t->loss_kind); grow(n->loss_a, t->loss_a); grow(n->owner, t->owner);
-      t = std::move(n);
+  // this graph's own version of every table it still reads through an undo log (const: a lazy copy, not a change of the graph)
+  void materialiseTables() const {
+    for (int ty = 0; ty < BSGPU_F_NUM_TYPES; ++ty) {
+      if (!undo_[ty]) continue;
+      std::shared_ptr<TypeTable> src = tables_[ty];
+      std::shared_ptr<TypeTable> n = TablePool::instance().acquire(ty);
+      {
+        std::lock_guard<std::mutex> lk(src->mu);
+        const TableUndo& u = *undo_[ty];
+        const size_t rows = u.rows, ni = (size_t)src->nidx, nc = src->rows ? src->consts.size() / src->rows : (u.row.empty() ? 0 : u.consts.size() / u.row.size());
+        n->rows = rows; n->nvar = src->nvar; n->nidx = src->nidx;
+        const size_t shared = std::min(rows, src->rows);   // (rows beyond the table's present size are all in the log)
+        n->idx.reserve(rows * ni + rows * ni / 8 + 64); n->consts.reserve(rows * nc + rows * nc / 8 + 64);
+        n->idx.assign(src->idx.begin(), src->idx.begin() + shared * ni); n->idx.resize(rows * ni);
+        n->consts.assign(src->consts.begin(), src->consts.begin() + shared * nc); n->consts.resize(rows * nc);
+        n->loss_kind.assign(src->loss_kind.begin(), src->loss_kind.begin() + shared); n->loss_kind.resize(rows);
+        n->loss_a.assign(src->loss_a.begin(), src->loss_a.begin() + shared); n->loss_a.resize(rows);
+        n->owner.assign(src->owner.begin(), src->owner.begin() + shared); n->owner.resize(rows);
+        for (size_t i = 0; i < u.row.size(); ++i) {
+          const size_t q = u.row[i];
+          std::copy(u.idx.begin() + i * ni, u.idx.begin() + (i + 1) * ni, n->idx.begin() + q * ni);
+          std::copy(u.consts.begin() + i * nc, u.consts.begin() + (i + 1) * nc, n->consts.begin() + q * nc);
+          n->loss_kind[q] = u.loss_kind[i]; n->loss_a[q] = u.loss_a[i]; n->owner[q] = u.owner[i];
+        }
+        undo_[ty]->detached = true;
+      }
+      tables_[ty] = std::move(n);
+      undo_[ty].reset();
     }
+  }
+  TypeTable& tableMut(int ty) {
+    materialiseTables();
+    auto& t = tables_[ty];
+    if (!t) t = TablePool::instance().acquire(ty);
     return *t;
   }
   template <class F>
   void forEachVariableOf(int32_t cs, F fn) const {
     const int ty = ctype_[cs];
+    if (ty >= 0 && undo_[ty]) materialiseTables();
     if (ty >= 0) { const TypeTable& tb = *tables_[ty]; for (int k = 0; k < tb.nvar; ++k) fn(tb.idx[(size_t)crow_[cs] * tb.nidx + k]); }
     else if (ty == kMarginal) for (int32_t s : marginal_rows_.at(cs).vars) fn(s);
     else if (ty == kUnpacked) for (const auto& u : cptr_[cs]->variables()) { const int32_t s = vindex_.find(u); if (s >= 0) fn(s); }
@@ -613,6 +760,8 @@ class GpuGraph {
     for (int ty = 0; ty < BSGPU_F_NUM_TYPES; ++ty) {
       if (!t1.count(ty)) continue;
       TypeTable& tb = tableMut(ty);
+      std::unique_lock<std::mutex> lk(tb.mu, std::defer_lock);
+      if (!tb.watchers.empty()) lk.lock();   // (an append may move the arrays a snapshot is reading; rows it adds are in no log)
       const int nvar = (int)vars.size(), nidx = (int)t1.idx[ty].size();
       if (!tb.rows && tb.idx.empty()) { tb.nvar = nvar; tb.nidx = nidx; }
       tb.idx.insert(tb.idx.end(), vars.begin(), vars.end());
@@ -637,6 +786,12 @@ class GpuGraph {
     if (ty < 0) return;
     TypeTable& tb = tableMut(ty);
     const size_t last = tb.rows - 1, r = crow_[cs], nc = tb.consts.size() / tb.rows, ni = (size_t)tb.nidx;
+    std::unique_lock<std::mutex> lk(tb.mu, std::defer_lock);
+    if (!tb.watchers.empty()) {
+      lk.lock();
+      tb.pruneWatchers();
+      tb.save(r); tb.save(last);       // what the snapshots still see in these two rows
+    }
     if (r != last) {
       for (size_t k = 0; k < ni; ++k) tb.idx[r * ni + k] = tb.idx[last * ni + k];
       for (size_t k = 0; k < nc; ++k) tb.consts[r * nc + k] = tb.consts[last * nc + k];
@@ -659,6 +814,7 @@ class GpuGraph {
         forEachVariableOf((int32_t)cs, [&](int32_t s) { auto& l = conn_[s]; if (std::find(l.begin(), l.end(), (int32_t)cs) == l.end()) l.push_back((int32_t)cs); });
     connectivity_valid_ = true;
   }
+  // (tables_ / undo_ are mutable: materialiseTables() is a lazy copy behind const accessors)
   mutable std::vector<std::vector<int32_t>> conn_;
   mutable bool connectivity_valid_ = true;
   bsgpu_summary last_summary_{};
