@@ -1,0 +1,71 @@
+"""The alternative code paths an environment variable selects in libbsgpu (the launch-per-step factorisation the fused kernel falls back
+to, the legacy / non-deep back-substitutions, other tile orders and chain lengths, packed flag words, own-strip solves, a full table
+hand-over ...): every one of them solves the same window to the same optimum as the default path.  One subprocess per setting — some of
+the switches are read once per process."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCRIPT = r"""
+import json, sys
+sys.path.insert(0, %r)
+import numpy as np
+from beam_slam_amd import synthetic
+from beam_slam_amd.gpu import GpuSolver
+pr = synthetic.vio_window(n_kf=90, n_lm=6000, seed=77)
+g = GpuSolver(0)
+pr.load(g)
+o = g.options_vio(); o.max_solver_time_in_seconds = 0.0; o.max_num_iterations = 6
+s = g.solve(o)
+x = g.get_blocks()
+print(json.dumps({"cost": s.final_cost, "it": s.num_iterations, "acc": [int(i.step_is_successful) for i in g.iterations()],
+                  "x": [float(v) for v in x[:2000:7]], "xn": float(np.abs(x).sum())}))
+""" % ROOT
+
+
+def _run(env_extra):
+    env = dict(os.environ)
+    env.update(env_extra)
+    out = subprocess.run([sys.executable, "-c", SCRIPT], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+@pytest.fixture(scope="module")
+def default_run():
+    return _run({})
+
+
+SETTINGS = [
+    {"BSGPU_CHOL_FUSED": "0"},                                   # launch-per-step factorisation (the fused kernel's fall-back)
+    {"BSGPU_BACKSOLVE_LEGACY": "1"},
+    {"BSGPU_BACKSOLVE_FUSED": "0"},
+    {"BSGPU_BACKSOLVE_NO_DEEP": "1"},
+    {"BSGPU_BACKSOLVE_GLOBAL_Y": "1"},                           # solution vector in global memory (windows above 12 288 dimensions)
+    {"BSGPU_CHOL_FUSED": "0", "BSGPU_BACKSOLVE_LEGACY": "1"},
+    {"BSGPU_CHAINS": "1"},
+    {"BSGPU_MIN_PIECE": "3"},
+    {"BSGPU_SHARED": "0"},
+    {"BSGPU_BAND_W": "2"},
+    {"BSGPU_BAND_W": "4"},
+    {"BSGPU_CHOL_SOLVE_OWN": "1"},
+    {"BSGPU_FLAG_STRIDE": "1"},
+    {"BSGPU_GRAPH": "1"},                                        # the LM step replayed as hipGraphs
+    {"BSGPU_FLATTEN": "device"},
+    {"BSGPU_FLATTEN": "host"},
+]
+
+
+@pytest.mark.parametrize("setting", SETTINGS, ids=lambda s: ",".join("%s=%s" % kv for kv in s.items()))
+def test_alternative_path_reaches_the_same_optimum(default_run, setting):
+    r = _run(setting)
+    d = default_run
+    assert r["it"] == d["it"] and r["acc"] == d["acc"]
+    assert abs(r["cost"] - d["cost"]) <= 1e-9 * d["cost"]
+    assert max(abs(a - b) for a, b in zip(r["x"], d["x"])) < 1e-7
