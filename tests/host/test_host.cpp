@@ -8,6 +8,7 @@
 #include <iostream>
 #include <map>
 #include <random>
+#include <thread>
 #include <set>
 
 #define BS_GRAPH_COW_BUCKETS 8   // small copy-on-write granules: every test graph spans several chunks / fills every bucket
@@ -633,6 +634,53 @@ static void test_random_transactions_against_model() {
 }
 
 
+// A snapshot is read on ANOTHER thread (the publishers') while the graph it was taken from goes on with the next transaction
+// (fixed_lag_smoother.cpp:308: notify(transaction, graph->clone()) and on to the next cycle).  The two share the packed tables through
+// an undo log (gpu_graph.h TableUndo): the snapshot's first look at its tables rebuilds its version under the table's mutex while the
+// owner is overwriting rows — checked against the model of what the snapshot must hold, 150 times.
+static void test_snapshot_read_while_the_graph_moves_on() {
+  std::printf("SnapshotReadWhileTheGraphMovesOn\n");
+  std::mt19937 rng(7);
+  std::normal_distribution<double> N(0.0, 1.0);
+  auto U = [&](size_t n) { return (size_t)(rng() % n); };
+  using fuse_variables::VelocityLinear3DStamped;
+  bs_optimizers::GpuGraph g;
+  ModelGraph m;
+  const Mat<3, 3> c3 = 0.25 * I3();
+  std::vector<fuse_core::Variable::SharedPtr> vs;
+  for (int k = 0; k < 120; ++k) {
+    auto v = VelocityLinear3DStamped::make_shared(fuse_core::Time(0.01 * k));
+    for (int i = 0; i < 3; ++i) v->data()[i] = N(rng);
+    vs.push_back(v); g.addVariable(v->clone()); m.vars[v->uuid()] = v;
+  }
+  int serial = 0;
+  auto new_constraint = [&]() -> fuse_core::Constraint::SharedPtr {
+    const size_t a = U(vs.size()), b = U(vs.size());
+    const Vec3 d{N(rng), N(rng), N(rng)};
+    if (a == b) return bs_constraints::AbsoluteVelocityLinear3DStampedConstraint("t" + std::to_string(serial++), static_cast<VelocityLinear3DStamped&>(*vs[a]), d, c3);
+    return bs_constraints::RelativeVelocityLinear3DStampedConstraint("t" + std::to_string(serial++), static_cast<VelocityLinear3DStamped&>(*vs[a]),
+                                                                     static_cast<VelocityLinear3DStamped&>(*vs[b]), d, c3);
+  };
+  for (int k = 0; k < 900; ++k) { auto c = new_constraint(); g.addConstraint(c); m.cons[c->uuid()] = c; }
+  const std::vector<fuse_core::UUID> none;
+  for (int round = 0; round < 150 && !g_fail; ++round) {
+    auto snap = g.clone();
+    const ModelGraph snap_model = m;
+    fuse_core::Transaction tr;
+    for (int k = 0; k < 40 && !m.cons.empty(); ++k) {
+      auto it = m.cons.begin(); std::advance(it, U(m.cons.size()));
+      tr.removeConstraint(it->first); m.cons.erase(it);
+    }
+    for (int k = 0; k < 45; ++k) { auto c = new_constraint(); tr.addConstraint(c); m.cons[c->uuid()] = c; }
+    std::thread reader([&]() { check_against_model(*snap, snap_model, none, round % 25 == 0); });
+    g.update(tr);
+    reader.join();
+    if (round % 10 == 0) check_against_model(g, m, none, true);
+    if (round % 3 == 0) { auto snap2 = snap->clone(); check_against_model(*snap2, snap_model, none, false); }   // a clone of a snapshot that has its own tables by now
+  }
+  check_against_model(g, m, none, true);
+}
+
 // the pending-transaction queue rules of fixed_lag_smoother.cpp:335-477 (processQueue) and :548-627 (transactionCallback): ignition,
 // purge of pre-ignition transactions, transactions older than the lag window, motion-model failure -> retry until transaction_timeout
 static void test_process_queue_rules() {
@@ -735,6 +783,7 @@ int main() {
   test_inverse_depth_window();
   test_true_marginalization_linear_chain();
   test_clone_is_an_independent_snapshot();
+  test_snapshot_read_while_the_graph_moves_on();
   test_random_transactions_against_model();
   test_process_queue_rules();
   test_fixed_lag_smoother_window(true);

@@ -16,7 +16,7 @@ SRC = os.path.join(ROOT, "tests", "host", "test_host.cpp")
 
 def _build(tmp_path, extra):
     exe = str(tmp_path / "test_host")
-    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wno-unused-function", SRC, "-o", exe] + extra
+    cmd = ["g++", "-std=c++17", "-O1", "-pthread", "-Wall", "-Wno-unused-function", SRC, "-o", exe] + extra
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-4000:]
     return exe
