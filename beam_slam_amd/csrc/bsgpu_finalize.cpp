@@ -488,6 +488,7 @@ int finalize(bsgpu_ctx* c) {
         for (int sa = 0; sa < nv; ++sa) for (int sb = 0; sb < nv; ++sb) {
           const int ra = toffs[(size_t)f * nv + sa], rb = toffs[(size_t)f * nv + sb];
           if (ra < 0 || rb < 0) continue;
+          if (ra < rb) continue;   // (the block above the diagonal is the transpose of the one below: the kernel writes both, §3 of DESIGN.md)
           cl.push_back({ra, rb, (t << 24) | f, (sa << 8) | sb});
         }
       }
@@ -495,7 +496,7 @@ int finalize(bsgpu_ctx* c) {
       sort_by_block(first, cl.size());
       size_t n_blocks = 0;
       for (size_t i = first; i < cl.size(); ++i) if (i == first || cl[i].ra != cl[i - 1].ra || cl[i].rb != cl[i - 1].rb) ++n_blocks;
-      if (n_blocks && (cl.size() - first) >= 4 * n_blocks) c->small_factorwise[t].n = 0;   // by segments
+      if (n_blocks && (cl.size() - first) >= 2 * n_blocks) c->small_factorwise[t].n = 0;   // by segments (lower blocks only: half the contributions of the full pattern)
       else cl.resize(first);                                                                // by factors
     }
     sort_by_block(0, cl.size());

@@ -837,7 +837,11 @@ __global__ __launch_bounds__(256) void small_assemble_seg_kernel(const SmallGrou
 #pragma unroll
     for (int i = 0; i < 9; ++i) v = (lane == i) ? acc[i] : v;
     const int rr = ra + lane / 3, cc = rb + lane % 3;
-    if (v != 0.0) atomicAdd(&S[(size_t)(perm[rr >> 6] * 64 + (rr & 63)) * ld + perm[cc >> 6] * 64 + (cc & 63)], v);
+    if (v != 0.0) {
+      const size_t pr = (size_t)(perm[rr >> 6] * 64 + (rr & 63)), pc = (size_t)(perm[cc >> 6] * 64 + (cc & 63));
+      atomicAdd(&S[pr * ld + pc], v);
+      if (!diag_seg) atomicAdd(&S[pc * ld + pr], v);   // (only the blocks on and below the diagonal have segments: the mirror image goes with them)
+    }
   } else if (diag_seg && lane < 12) {
     const int i = lane - 9;
     double g0 = 0.0, h0 = 0.0;
