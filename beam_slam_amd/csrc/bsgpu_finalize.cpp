@@ -628,9 +628,10 @@ int finalize(bsgpu_ctx* c) {
       // fused single-launch factorisation (default; BSGPU_CHOL_FUSED=0 keeps the launch-per-step path): task list + zeroed counters
       const char* ef = getenv("BSGPU_CHOL_FUSED");
       c->d_ftasks = nullptr; c->d_fsync = nullptr; c->d_tile_tot = nullptr;
-      // (above 12 M tasks — a DENSE system of more than ~26 000 dimensions, which only the exact option on a pose graph produces — the
-      // launch-per-step path runs: at 17 M tasks the fused kernel's factor came out wrong, cause not found; scripts/c4_exact.py)
-      if (!(ef && atoi(ef) == 0) && !c->plan.ftasks.empty() && c->plan.ftasks.size() <= ((size_t)12 << 20)) {
+      // (one workgroup of 512 threads per task, and a grid holds fewer than 2^32 threads: above 8.38 M tasks — a DENSE system of more than
+      // ~23 600 dimensions, which only the exact option on a pose graph produces — the launch is refused by the runtime, so the
+      // launch-per-step path runs there; scripts/c4_exact.py)
+      if (!(ef && atoi(ef) == 0) && !c->plan.ftasks.empty() && c->plan.ftasks.size() * 512 < ((size_t)1 << 32)) {
         c->d_ftasks = c->upload(c->plan.ftasks);
         c->d_tile_tot = c->upload(c->plan.tile_tot);
         c->d_fsync = c->upload(std::vector<int>((size_t)c->plan.fused_sync_words, 0));

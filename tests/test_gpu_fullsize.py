@@ -271,11 +271,12 @@ def test_c4_full_solve_matches_oracle_cg(oracle_cls, gpu_solver_cls):
     assert sg.num_inner_iterations <= 80 * sg.num_iterations
 
 
-@pytest.mark.parametrize("n_pose", [2200, 3900])
+@pytest.mark.parametrize("n_pose", [2200, 3900, 4300])
 def test_exact_option_on_pose_graphs_above_the_dense_limit(gpu_solver_cls, monkeypatch, n_pose):
     """BSGPU_EXACT_POSE_GRAPH=1 at finalize(): the tiled factorisation instead of the block-sparse PCG on a pose-only graph of more than
-    12 288 dimensions — 13 200 and 23 400 here, the second with a reduced system of more than 4 GB (the size at which buffer resources
-    over the whole matrix wrapped around: every step came out invalid).  Same LM trajectory as the PCG path."""
+    12 288 dimensions — 13 200, 23 400 and 25 800 here: the second with a reduced system of more than 4 GB (the size at which buffer
+    resources over the whole matrix wrapped around: every step came out invalid), the third with more tasks than a one-workgroup-per-task
+    grid can hold (2^32 threads: the launch-per-step factorisation runs).  Same LM trajectory as the PCG path."""
     pr = synthetic.pose_graph(n_pose, 9 * n_pose + 1, 20250622)
     opt_kw = dict(max_num_iterations=2)
     g = gpu_solver_cls(0)
