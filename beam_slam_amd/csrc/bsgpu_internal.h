@@ -182,7 +182,7 @@ void launch_chol_backsolve_chains(hipStream_t s, const double* S, const double* 
                                   const int* bs_desc_dev, const int* chain_begin_dev,
                                   const int* chain_end_dev, int n_chains, const int* rows_flat_dev, double* y,
                                   int npad, int max_chain_len, const double* y_init = nullptr, const int* iperm_dev = nullptr, int n_pose = 0,
-                                  double* y_tan = nullptr, double* delta = nullptr, int max_rows = 0);
+                                  double* y_tan = nullptr, double* delta = nullptr, int max_rows = 0, const double* Winv = nullptr);
 void launch_chol_backsolve_update(hipStream_t s, const double* Lp, int ld, const int* items_dev, int n_items, const int* upd_rows_dev, double* y);
 bool launch_chol_backsolve_fused(hipStream_t s, const double* Lp, const double* Winv, int ld, const int* bs_desc_dev, const int* chain_begin_dev,
                                  const int* chain_end_dev, const int* rows_flat_dev, int n_chains, const int* chain_group_dev,

@@ -271,6 +271,7 @@ void dense_backsolve(hipStream_t s, const DensePlan& P, const DenseDev& D, doubl
                                     D.bs_sync, D.scal, D.bs_order))
       return;
   }
+  const bool w_valid = D.ftasks && D.fsync && D.tile_tot && D.Winv;   // (dense_factor: the fused factorisation ran and left the tile inverses)
   if (!single_root) launch_copy(s, rhs_row, y, (int64_t)P.T * 64, 64);   // (a single root chain copies it itself on the way)
   for (int g = 0; g < G; ++g) {
     const int c0 = P.bs_group_off[g], c1 = P.bs_group_off[g + 1];
@@ -278,7 +279,7 @@ void dense_backsolve(hipStream_t s, const DensePlan& P, const DenseDev& D, doubl
     for (int i = c0; i < c1; ++i) max_len = std::max(max_len, P.chain_end[i] - P.chain_begin[i]);
     launch_chol_backsolve_chains(s, S, D.Lp, D.Vinv, ld, level_sync ? D.bs_desc_chain : D.bs_desc, D.chain_begin + c0, D.chain_end + c0, c1 - c0,
                                  level_sync ? D.rows_flat_chain : D.rows_flat, y, P.npad, max_len, (g == 0 && single_root) ? rhs_row : nullptr, iperm,
-                                 n_pose, y_tan, delta, level_sync ? P.bs_group_maxrows[g] : 0);
+                                 n_pose, y_tan, delta, level_sync ? P.bs_group_maxrows[g] : 0, w_valid ? D.Winv : nullptr);
     if (level_sync && g + 1 < G) {
       const int i0 = P.bs_upd_off[g], i1 = P.bs_upd_off[g + 1];
       launch_chol_backsolve_update(s, D.Lp, ld, D.bs_upd + 3 * (size_t)i0, i1 - i0, D.bs_upd_rows, y);

@@ -1179,8 +1179,8 @@ BSG_DEV void bs_chain_walk(const double* Lp, const double* Vinv /* USE_W: the ti
     stamp(12);
   }
 }
-template <bool Y_IN_LDS, int CH, bool DEEP>
-__global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double* S, const double* Lp, const double* Vinv, int ld,
+template <bool Y_IN_LDS, int CH, bool DEEP, bool USE_W>
+__global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double* S, const double* Lp, const double* Vinv /* USE_W: the tile inverses */, int ld,
                                                                     const int* __restrict__ bs_desc,
                                                                     const int* __restrict__ chain_begin,
                                                                     const int* __restrict__ chain_end,
@@ -1189,7 +1189,7 @@ __global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double
                                                                     int n_pose, double* __restrict__ y_tan, double* __restrict__ delta) {
   (void)S;
   const BsFused none{};
-  bs_chain_walk<Y_IN_LDS, CH, DEEP, false, false>(Lp, Vinv, ld, bs_desc, chain_begin[blockIdx.x], chain_end[blockIdx.x], rows_flat, y, npad, max_len,
+  bs_chain_walk<Y_IN_LDS, CH, DEEP, false, USE_W>(Lp, Vinv, ld, bs_desc, chain_begin[blockIdx.x], chain_end[blockIdx.x], rows_flat, y, npad, max_len,
                                            y_init, iperm, n_pose, y_tan, delta, none);
 }
 
@@ -1361,21 +1361,27 @@ void launch_chol_backsolve_chains(hipStream_t s, const double* S, const double* 
                                   const int* bs_desc_dev, const int* chain_begin_dev,
                                   const int* chain_end_dev, int n_chains, const int* rows_flat_dev, double* y,
                                   int npad, int max_chain_len, const double* y_init, const int* iperm_dev, int n_pose, double* y_tan,
-                                  double* delta, int max_rows) {
+                                  double* delta, int max_rows, const double* Winv) {
   if (n_chains <= 0) return;
   size_t lds = chol_backsolve_chain_lds(npad, max_chain_len);
+  // Winv (the tiles' full inverses, left by the fused factorisation): a panel's own solve is two 16-part reductions instead of a
+  // substitution with 64 dependent pivots (bs_chain_walk)
+  static const bool no_w = getenv("BSGPU_BACKSOLVE_NO_W") != nullptr;
+  if (no_w) Winv = nullptr;
   const char* fg = getenv("BSGPU_BACKSOLVE_GLOBAL_Y");   // (tests: force the path windows above 12 288 reduced dimensions take)
   const int y_in_lds = (lds <= (size_t)160 * 1024 && !(fg && atoi(fg) != 0)) ? 1 : 0;
   if (!y_in_lds) lds = chol_backsolve_chain_lds(0, max_chain_len);
   // max_rows: the most row tiles any panel of these chains has (0: unknown).  Few enough: the two-panel-deep variant.
   static const bool no_deep = getenv("BSGPU_BACKSOLVE_NO_DEEP") != nullptr;
   const bool deep = max_rows > 0 && max_rows <= kBsChunkDeep && max_chain_len > 1 && !no_deep;
-#define BSG_LAUNCH_CHAIN(YL, CH, DEEP)                                                                                                    \
-  hipLaunchKernelGGL((chol_backsolve_chain_kernel<YL, CH, DEEP>), dim3(n_chains), dim3(1024), lds, s, S, Lp, Vinv, ld, bs_desc_dev,      \
+#define BSG_LAUNCH_CHAIN_W(YL, CH, DEEP, W)                                                                                                \
+  hipLaunchKernelGGL((chol_backsolve_chain_kernel<YL, CH, DEEP, W>), dim3(n_chains), dim3(1024), lds, s, S, Lp, W ? Winv : Vinv, ld, bs_desc_dev, \
                      chain_begin_dev, chain_end_dev, rows_flat_dev, y, npad, max_chain_len, n_chains == 1 ? y_init : nullptr, iperm_dev, \
                      n_pose, y_tan, delta)
+#define BSG_LAUNCH_CHAIN(YL, CH, DEEP) do { if (Winv) BSG_LAUNCH_CHAIN_W(YL, CH, DEEP, true); else BSG_LAUNCH_CHAIN_W(YL, CH, DEEP, false); } while (0)
   if (y_in_lds) { if (deep) BSG_LAUNCH_CHAIN(true, kBsChunkDeep, true); else BSG_LAUNCH_CHAIN(true, kBsChunk, false); }
   else { if (deep) BSG_LAUNCH_CHAIN(false, kBsChunkDeep, true); else BSG_LAUNCH_CHAIN(false, kBsChunk, false); }
+#undef BSG_LAUNCH_CHAIN_W
 #undef BSG_LAUNCH_CHAIN
 }
 
@@ -1426,12 +1432,14 @@ void chol_prepare() {
                             (int)kPanelStepLds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_panel_step_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kPanelStepLds);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_chain_kernel<true, kBsChunkDeep, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_chain_kernel<false, kBsChunkDeep, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_chain_kernel<true, kBsChunk, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_chain_kernel<false, kBsChunk, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_chain_kernel<true, kBsChunkDeep, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_chain_kernel<true, kBsChunkDeep, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_chain_kernel<false, kBsChunkDeep, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_chain_kernel<false, kBsChunkDeep, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_chain_kernel<true, kBsChunk, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_chain_kernel<true, kBsChunk, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_chain_kernel<false, kBsChunk, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_chain_kernel<false, kBsChunk, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_fused_kernel<kBsChunkDeep, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_fused_kernel<kBsChunk, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds);

@@ -47,6 +47,8 @@ SETTINGS = [
     {"BSGPU_BACKSOLVE_LEGACY": "1"},
     {"BSGPU_BACKSOLVE_FUSED": "0"},
     {"BSGPU_BACKSOLVE_NO_DEEP": "1"},
+    {"BSGPU_BACKSOLVE_NO_W": "1"},
+    {"BSGPU_BACKSOLVE_FUSED": "0", "BSGPU_BACKSOLVE_NO_W": "1"},
     {"BSGPU_BACKSOLVE_GLOBAL_Y": "1"},                           # solution vector in global memory (windows above 12 288 dimensions)
     {"BSGPU_CHOL_FUSED": "0", "BSGPU_BACKSOLVE_LEGACY": "1"},
     {"BSGPU_CHAINS": "1"},
