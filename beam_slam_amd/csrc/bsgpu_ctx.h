@@ -153,6 +153,8 @@ struct bsgpu_ctx {
   DevCamera* d_cams = nullptr;
   DevLoss* d_losses = nullptr;
   Visual vis;
+  IdpElim idp;                   // inverse-depth landmarks eliminated on the landmark side (bsgpu_finalize.cpp, k_idp.hip)
+  int n_idp_lm = 0;
   SmallGroup small[kNumInternal];
   std::vector<unsigned char> h_small_active[kNumInternal];
   unsigned char* d_small_inactive[kNumInternal] = {nullptr};
@@ -276,6 +278,7 @@ struct bsgpu_ctx {
     allocs.clear();
     if (pool_bytes > ((size_t)8 << 30)) release_pool();
     vis = Visual();
+    idp = IdpElim();
     for (auto& g : small) g = SmallGroup();
     d_x = d_xcand = d_x0 = nullptr;
     bsr_built = false; spcg_built = false;

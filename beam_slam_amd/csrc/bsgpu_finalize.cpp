@@ -87,6 +87,7 @@ int finalize(bsgpu_ctx* c) {
   if (c->is_const_in.size() != (size_t)nb) c->is_const_in = c->is_const;
   for (int b = 0; b < nb; ++b) c->is_const[b] = (c->is_const_in[b] || lm_use[b] + other_use[b] == 0) ? 1 : 0;
   c->tsize.assign(nb, 0); c->toff.assign(nb, -1); c->is_lm.assign(nb, 0);
+  const bool idp_elim = !(getenv("BSGPU_IDP_ELIM") && atoi(getenv("BSGPU_IDP_ELIM")) == 0);
   for (int b = 0; b < nb; ++b) {
     if (c->size[b] > 4 || c->size[b] == 0) return fail(c, BSGPU_ERR_UNSUPPORTED, "block sizes 1..4 only");
     if (c->manifold[b] == BSGPU_MANIFOLD_QUAT_RIGHT && c->size[b] != 4) return fail(c, BSGPU_ERR_INVALID, "quaternion block must have size 4");
@@ -94,14 +95,32 @@ int finalize(bsgpu_ctx* c) {
     if (c->is_const[b]) continue;
     if (lm_use[b] > 0 && other_use[b] == 0 && c->size[b] == 3 && c->manifold[b] == BSGPU_MANIFOLD_EUCLIDEAN &&
         !(b < (int)c->no_elim.size() && c->no_elim[b])) c->is_lm[b] = 1;
+    // a scalar block whose every use is the inverse-depth slot of an inverse-depth factor: eliminated on the landmark side too
+    // (k_idp.hip; BSGPU_IDP_ELIM=0 keeps such blocks in the reduced system, as leaf tiles of the factorisation)
+    if (idp_elim && lm_use[b] == 0 && rho_use[b] > 0 && rho_use[b] == other_use[b] && c->size[b] == 1 &&
+        c->manifold[b] == BSGPU_MANIFOLD_EUCLIDEAN && !(b < (int)c->no_elim.size() && c->no_elim[b])) c->is_lm[b] = 2;
   }
   int to = 0;
   for (int b = 0; b < nb; ++b) if (!c->is_const[b] && !c->is_lm[b]) { c->toff[b] = to; to += c->tsize[b]; }
   c->n_pose = to;
   std::vector<int> lm_index(nb, -1);
   int nl = 0;
-  for (int b = 0; b < nb; ++b) if (!c->is_const[b] && c->is_lm[b]) { c->toff[b] = to; to += 3; lm_index[b] = nl++; }
-  c->n_tan = to; c->n_lm = nl;
+  for (int b = 0; b < nb; ++b) if (!c->is_const[b] && c->is_lm[b] == 1) { c->toff[b] = to; to += 3; lm_index[b] = nl++; }
+  // (the scalar landmarks last, one tangent column each: in a window without Euclidean landmarks the tangent order is then the block order)
+  std::vector<int> idp_index(nb, -1);
+  int n_rho = 0;
+  const int idp_to0 = to;
+  for (int b = 0; b < nb; ++b) if (!c->is_const[b] && c->is_lm[b] == 2) { c->toff[b] = to; to += 1; idp_index[b] = n_rho++; }
+  c->n_tan = to; c->n_lm = nl; c->n_idp_lm = n_rho;
+  // every binary inverse-depth factor has an eliminated landmark: the factors' own pose-pose terms are assembled with the elimination
+  // (idp_pairs_kernel) and the group leaves the generic pose-only assembly.  The unary factor's Jacobian is identically zero.
+  bool idp_direct = n_rho > 0 && !getenv("BSGPU_IDP_GENERIC_ASSEMBLY");
+  {
+    const HostGroup& g = c->groups[BSGPU_F_IDP_REPROJ];
+    const int ni = kTypes[BSGPU_F_IDP_REPROJ].nidx;
+    for (int f = 0; f < g.n && idp_direct; ++f) idp_direct = idp_index[g.idx[(size_t)f * ni + 4]] >= 0;
+  }
+  auto skip_generic_assembly = [&](int t) { return (t == BSGPU_F_IDP_REPROJ && idp_direct) || (t == BSGPU_F_IDP_REPROJ_UNARY && n_rho > 0); };
   c->npad = ((c->n_pose + 63) / 64 + 1) * 64;   // real tiles + one tile for the rhs row (dense_plan.h)
   // leaf tiles of the reduced system: tiles made of inverse-depth landmarks only — scalar blocks that no factor couples to each other
   // (an inverse-depth factor has one), so the tiled factorisation can eliminate them first (dense_plan.h build(): leaf)
@@ -124,7 +143,7 @@ int finalize(bsgpu_ctx* c) {
   // (pose-only graphs above kDenseLimit go to the block-sparse PCG unless the exact factorisation is asked for — BSGPU_EXACT_POSE_GRAPH=1 at
   // finalize(): the dense tile storage, 2 x npad^2 doubles, is not allocated on spec; C4 that way: DESIGN.md 3.3)
   const bool exact_pose_graph = getenv("BSGPU_EXACT_POSE_GRAPH") != nullptr;
-  c->dense_ok = (size_t)c->npad <= kDenseLimit || ((nl > 0 || c->n_leaf_tiles > 0 || exact_pose_graph) && (size_t)c->npad <= kDenseLimitLandmarks);   // else: block-sparse PCG (pose-only problems)
+  c->dense_ok = (size_t)c->npad <= kDenseLimit || ((nl + n_rho > 0 || c->n_leaf_tiles > 0 || exact_pose_graph) && (size_t)c->npad <= kDenseLimitLandmarks);   // else: block-sparse PCG (pose-only problems)
   int row = 0;
   for (int t = 0; t < BSGPU_F_NUM_TYPES; ++t) { c->row0[t] = row; row += c->groups[t].n * kTypes[t].m; }
   for (const HostMarginal& mg : c->marginals) row += mg.rows;
@@ -404,6 +423,7 @@ int finalize(bsgpu_ctx* c) {
   lap("visual upload + alloc");
   // ---- pose-only groups
   size_t part_max = std::max<size_t>(V.n_cost_part, 2 * ((size_t)nb + 255) / 256 + 2);
+  int* d_toff_asm[kNumInternal] = {nullptr};
   for (int t = 2; t < kNumInternal; ++t) {
     const HostGroup& g = c->groups[t];
     const TypeInfo& ti = kTypes[t];
@@ -419,24 +439,34 @@ int finalize(bsgpu_ctx* c) {
       for (int sl = 0; sl < ti.nvar; ++sl) {
         xoff[(size_t)f * ti.nvar + sl] = c->off[idx[sl]];
         toff[(size_t)f * ti.nvar + sl] = c->toff[idx[sl]];
-        if (c->toff[idx[sl]] >= c->n_pose) return fail(c, BSGPU_ERR_UNSUPPORTED, "internal: landmark in a pose-only factor");
+        if (c->toff[idx[sl]] >= c->n_pose && !(c->is_lm[idx[sl]] == 2 && sl == ti.nvar - 1 && (t == BSGPU_F_IDP_REPROJ || t == BSGPU_F_IDP_REPROJ_UNARY)))
+          return fail(c, BSGPU_ERR_UNSUPPORTED, "internal: landmark in a pose-only factor");
         if (!c->is_const[idx[sl]]) active[f] = 1;
       }
       inactive[f] = !active[f];
       if (!active[f]) c->any_inactive = true;
       loss[f] = get_loss(g.loss_kind[f], g.loss_a[f]);
-      if (active[f]) {
+      if (active[f] && !skip_generic_assembly(t)) {
         const int T = (c->n_pose + 63) / 64;
         for (int sa = 0; sa < ti.nvar; ++sa)
           for (int sb = 0; sb < ti.nvar; ++sb) {
             const int ra = c->toff[idx[sa]], rb = c->toff[idx[sb]];
-            if (ra < 0 || rb < 0) continue;
+            if (ra < 0 || rb < 0 || ra >= c->n_pose || rb >= c->n_pose) continue;   // (an eliminated inverse-depth slot is not in the reduced system)
             const int wa = c->tsize[idx[sa]], wb = c->tsize[idx[sb]];
             for (int a = ra; a < ra + wa; a += std::max(1, wa - 1)) for (int b = rb; b < rb + wb; b += std::max(1, wb - 1)) c->tile_adj[(size_t)(a / 64) * T + b / 64] = 1;
           }
       }
     }
     sg.xoff = c->upload(xoff); sg.toff = c->upload(toff); sg.consts = c->upload(g.consts); sg.loss = c->upload(loss);
+    // the assembly into the reduced system sees an eliminated inverse-depth slot as a constant one (the evaluation, the model cost change
+    // and bsgpu_evaluate keep the real column)
+    d_toff_asm[t] = nullptr;
+    if (n_rho > 0 && (t == BSGPU_F_IDP_REPROJ || t == BSGPU_F_IDP_REPROJ_UNARY)) {
+      std::vector<int> tm(toff);
+      bool any = false;
+      for (int& v : tm) if (v >= c->n_pose) { v = -1; any = true; }
+      if (any) d_toff_asm[t] = c->upload(tm);
+    }
     sg.active = c->upload(active);
     if (has_camera(t)) {
       std::vector<int> camv(g.n);
@@ -452,6 +482,7 @@ int finalize(bsgpu_ctx* c) {
     c->d_small_part_mcc[t] = c->alloc<double>((size_t)g.n * ti.m);
     part_max = std::max(part_max, (size_t)g.n * ti.m);
   }
+  lap("pose-only group tables");
   // ---- how the pose-only factors are assembled.  Where many factors of a type add into the same 3x3 blocks of J^T J (C3: 20 000
   // relative-pose factors over 100 keyframes and ONE extrinsics variable) per-factor atomics serialise on those addresses; such a type
   // is assembled by SEGMENTS instead: for every block (tangent offsets ra, rb) the (factor, slot a, slot b) contributions to it, in
@@ -474,14 +505,20 @@ int finalize(bsgpu_ctx* c) {
         std::copy(tmp.begin(), tmp.begin() + n, cl.begin() + lo);
       }
     };
-    for (int t = 0; t < kNumInternal; ++t) { c->small_factorwise[t] = c->small[t]; if (t < 2) c->small_factorwise[t].n = 0; }
+    for (int t = 0; t < kNumInternal; ++t) {
+      c->small_factorwise[t] = c->small[t];
+      if (t < 2) c->small_factorwise[t].n = 0;
+      if (d_toff_asm[t]) c->small_factorwise[t].toff = d_toff_asm[t];
+      if (skip_generic_assembly(t)) c->small_factorwise[t].n = 0;
+    }
     for (int t = 2; t < kNumInternal; ++t) {
       const SmallGroup& sg = c->small[t];
-      if (!sg.n) continue;
+      if (!sg.n || skip_generic_assembly(t)) continue;
       const int nv = sg.nv;
       std::vector<int> toffs((size_t)sg.n * nv);
       HIPCHK(c, hipStreamSynchronize(c->stream));   // (the table went up asynchronously on the context's stream)
       HIPCHK(c, hipMemcpy(toffs.data(), sg.toff, sizeof(int) * toffs.size(), hipMemcpyDeviceToHost));
+      for (int& v : toffs) if (v >= c->n_pose) v = -1;   // (eliminated inverse-depth slots: k_idp.hip)
       const size_t first = cl.size();
       for (int f = 0; f < sg.n; ++f) {
         if (!c->h_small_active[t][f]) continue;
@@ -514,6 +551,149 @@ int finalize(bsgpu_ctx* c) {
     c->d_sa_contrib = c->upload(contrib);
     std::vector<SmallGroup> groups(c->small, c->small + kNumInternal);
     c->d_small_groups = c->upload(groups);
+  }
+  lap("pose-only assembly lists");
+  // ---- inverse-depth landmarks eliminated on the landmark side (k_idp.hip): the binary factors sorted by landmark, the
+  // (landmark, camera pose) views, and the pair entries grouped by camera-pose pair — what host_visual() above builds for the
+  // Euclidean landmarks, one level up: a view stands for all factors of a landmark that involve that camera pose
+  c->idp = IdpElim();
+  if (n_rho > 0) {
+    const HostGroup& g = c->groups[BSGPU_F_IDP_REPROJ];
+    const TypeInfo& ti = kTypes[BSGPU_F_IDP_REPROJ];
+    IdpElim& E = c->idp;
+    E.n_lm = n_rho; E.to0 = idp_to0;
+    std::vector<int> lm_start(n_rho + 1, 0), order;
+    for (int f = 0; f < g.n; ++f) { const int l = idp_index[g.idx[(size_t)f * ti.nidx + 4]]; if (l >= 0) lm_start[l + 1]++; }
+    for (int l = 0; l < n_rho; ++l) lm_start[l + 1] += lm_start[l];
+    order.resize(lm_start[n_rho]);
+    {
+      std::vector<int> pos(lm_start.begin(), lm_start.end() - 1);
+      for (int f = 0; f < g.n; ++f) { const int l = idp_index[g.idx[(size_t)f * ti.nidx + 4]]; if (l >= 0) order[pos[l]++] = f; }
+    }
+    E.n_fac = (int)order.size();
+    // camera poses = distinct (q block, p block) pairs of either side, numbered in ascending (q, p) order
+    std::vector<uint64_t> cp_keys;
+    cp_keys.reserve(64);
+    {
+      std::vector<int> seen_p(nb, -1);
+      for (int f : order)
+        for (int side = 0; side < 2; ++side) {
+          const int bq = g.idx[(size_t)f * ti.nidx + 2 * side], bp = g.idx[(size_t)f * ti.nidx + 2 * side + 1];
+          if (seen_p[bq] != bp) { seen_p[bq] = bp; cp_keys.push_back(((uint64_t)bq << 32) | (uint32_t)bp); }
+        }
+      std::sort(cp_keys.begin(), cp_keys.end());
+      cp_keys.erase(std::unique(cp_keys.begin(), cp_keys.end()), cp_keys.end());
+    }
+    const int k = (int)cp_keys.size();
+    std::vector<int> cp_tq(k), cp_tp(k), cp_first(nb, -1);
+    for (int i = 0; i < k; ++i) {
+      const int bq = (int)(cp_keys[i] >> 32), bp = (int)(cp_keys[i] & 0xffffffffu);
+      cp_tq[i] = c->toff[bq]; cp_tp[i] = c->toff[bp];
+      if (cp_first[bq] < 0) cp_first[bq] = i;
+    }
+    auto cp_of = [&](int bq, int bp) { int i = cp_first[bq]; while ((int)(cp_keys[i] & 0xffffffffu) != bp) ++i; return i; };
+    E.n_cam_pose = k;
+    // views of every landmark (a landmark has a handful: linear search), and the factors' two views
+    std::vector<int> view_start(n_rho + 1, 0), view_cp;
+    std::vector<int2> fview(order.size());
+    view_cp.reserve(order.size() + n_rho);
+    for (int l = 0; l < n_rho; ++l) {
+      const int v0 = (int)view_cp.size();
+      for (int p = lm_start[l]; p < lm_start[l + 1]; ++p) {
+        const int f = order[p];
+        int vv[2];
+        for (int side = 0; side < 2; ++side) {
+          const int cp = cp_of(g.idx[(size_t)f * ti.nidx + 2 * side], g.idx[(size_t)f * ti.nidx + 2 * side + 1]);
+          int v = v0;
+          while (v < (int)view_cp.size() && view_cp[v] != cp) ++v;
+          if (v == (int)view_cp.size()) view_cp.push_back(cp);
+          vv[side] = v;
+        }
+        fview[p] = make_int2(vv[0], vv[1]);
+      }
+      view_start[l + 1] = (int)view_cp.size();
+    }
+    E.n_view = (int)view_cp.size();
+    // pair entries (view a, view b, code) of every landmark with cp(a) <= cp(b), grouped by camera-pose pair, landmark-major inside a
+    // group.  code (idp_pairs_kernel): the factor whose two poses are that view pair — its cross term A_a^T A_m rides on the entry —
+    // or -1; a further factor on the same view pair gets an entry of its own without the Schur term.
+    E.direct = idp_direct ? 1 : 0;
+    std::vector<int> view_lm(view_cp.size());
+    for (int l = 0; l < n_rho; ++l) for (int v = view_start[l]; v < view_start[l + 1]; ++v) view_lm[v] = l;
+    std::vector<int> first_code;
+    struct Extra { int a, b, code; };
+    std::vector<Extra> extras;
+    auto for_entries = [&](int l, auto&& fn) {   // the entries of landmark l, in a fixed order
+      const int v0 = view_start[l], nv = view_start[l + 1] - v0;
+      first_code.assign((size_t)nv * nv, -1);
+      extras.clear();
+      if (E.direct)
+        for (int p = lm_start[l]; p < lm_start[l + 1]; ++p) {
+          const int x = fview[p].x, y = fview[p].y;
+          if (x == y) continue;   // (both sides on one camera pose: in that view's own block)
+          const bool swap = view_cp[x] > view_cp[y];
+          const int a = swap ? y : x, b = swap ? x : y;
+          const int code = (p << 2) | (swap ? 2 : 0);
+          int& fc = first_code[(size_t)(a - v0) * nv + (b - v0)];
+          if (fc < 0) fc = code; else extras.push_back({a, b, code | 1});
+        }
+      for (int a = v0; a < v0 + nv; ++a)
+        for (int b = v0; b < v0 + nv; ++b)
+          if (view_cp[a] <= view_cp[b] && (a == b || view_cp[a] != view_cp[b] || a < b)) fn(a, b, first_code[(size_t)(a - v0) * nv + (b - v0)]);
+      for (const Extra& x : extras) fn(x.a, x.b, x.code);
+    };
+    const uint64_t ncp = (uint64_t)std::max(1, k);
+    std::vector<int> seg_ci, seg_cj, seg_start, ent_va, ent_vb, ent_code;
+    if (ncp * ncp <= (uint64_t)8 << 20) {
+      std::vector<int> start(ncp * ncp + 1, 0);
+      for (int l = 0; l < n_rho; ++l) for_entries(l, [&](int a, int b, int) { start[(uint64_t)view_cp[a] * ncp + view_cp[b] + 1]++; });
+      for (size_t i = 0; i < ncp * ncp; ++i) start[i + 1] += start[i];
+      ent_va.resize(start[ncp * ncp]); ent_vb.resize(start[ncp * ncp]); ent_code.resize(start[ncp * ncp]);
+      for (uint64_t key = 0; key < ncp * ncp; ++key)
+        for (int p0 = start[key]; p0 < start[key + 1]; p0 += kPairChunk) { seg_ci.push_back((int)(key / ncp)); seg_cj.push_back((int)(key % ncp)); seg_start.push_back(p0); }
+      std::vector<int> pos(start.begin(), start.end() - 1);
+      for (int l = 0; l < n_rho; ++l)
+        for_entries(l, [&](int a, int b, int code) { const int p = pos[(uint64_t)view_cp[a] * ncp + view_cp[b]]++; ent_va[p] = a; ent_vb[p] = b; ent_code[p] = code; });
+    } else {
+      struct Ent { uint64_t key; int va, vb, code; };
+      std::vector<Ent> ents;
+      for (int l = 0; l < n_rho; ++l) for_entries(l, [&](int a, int b, int code) { ents.push_back({(uint64_t)view_cp[a] * ncp + view_cp[b], a, b, code}); });
+      std::stable_sort(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) { return x.key < y.key; });
+      ent_va.resize(ents.size()); ent_vb.resize(ents.size()); ent_code.resize(ents.size());
+      for (size_t i = 0; i < ents.size(); ++i) {
+        if (i == 0 || ents[i].key != ents[i - 1].key || (int)i - seg_start.back() >= kPairChunk) {
+          seg_ci.push_back((int)(ents[i].key / ncp)); seg_cj.push_back((int)(ents[i].key % ncp)); seg_start.push_back((int)i);
+        }
+        ent_va[i] = ents[i].va; ent_vb[i] = ents[i].vb; ent_code[i] = ents[i].code;
+      }
+    }
+    seg_start.push_back((int)ent_va.size());
+    E.n_seg = (int)seg_ci.size(); E.n_ent = (int)ent_va.size();
+    // the fill of the elimination: every pair of camera poses that share a landmark
+    {
+      const int T = (c->n_pose + 63) / 64;
+      if (c->tile_adj.size() != (size_t)T * T) c->tile_adj.assign((size_t)T * T, 0);
+      auto touch = [&](int ra, int rb) {
+        if (ra < 0 || rb < 0) return;
+        for (int a = ra; a < ra + 3; a += 2) for (int b = rb; b < rb + 3; b += 2) {
+          c->tile_adj[(size_t)(a / 64) * T + b / 64] = 1; c->tile_adj[(size_t)(b / 64) * T + a / 64] = 1;
+        }
+      };
+      for (int sgi = 0; sgi < E.n_seg; ++sgi) {
+        const int i = seg_ci[sgi], j = seg_cj[sgi];
+        const int ri[2] = {cp_tq[i], cp_tp[i]}, rj[2] = {cp_tq[j], cp_tp[j]};
+        for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) touch(ri[a], rj[b]);
+      }
+    }
+    E.order = c->upload(order); E.lm_start = c->upload(lm_start); E.view_start = c->upload(view_start); E.fview = c->upload(fview);
+    E.cp_tq = c->upload(cp_tq); E.cp_tp = c->upload(cp_tp);
+    E.seg_ci = c->upload(seg_ci); E.seg_cj = c->upload(seg_cj); E.seg_start = c->upload(seg_start);
+    E.ent_va = c->upload(ent_va); E.ent_vb = c->upload(ent_vb); E.ent_code = c->upload(ent_code); E.view_lm = c->upload(view_lm);
+    if (E.direct) { E.VD = c->alloc<double>((size_t)std::max(1, E.n_view) * 48); if (!E.VD) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (inverse-depth landmark tables)"); }
+    E.U = c->alloc<double>((size_t)std::max(1, E.n_view) * 8); E.linv = c->alloc<double>(n_rho); E.z = c->alloc<double>(n_rho);
+    E.C = c->alloc<double>((size_t)std::max(1, E.n_fac) * 2);
+    if (!E.U || !E.linv || !E.z || !E.C) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (inverse-depth landmark tables)");
+    lap("inverse-depth landmark tables");
   }
   // ---- dense linear priors (marginal factors)
   c->marg.clear();

@@ -126,6 +126,38 @@ struct Visual {
   int n_cost_part = 0;
 };
 
+// inverse-depth landmarks eliminated on the landmark side (k_idp.hip): the binary inverse-depth factors (SmallGroup of
+// BSGPU_F_IDP_REPROJ: r, J 2 x 15 from idp_kernel) sorted by their scalar landmark; a VIEW is one (landmark, camera pose) pair — the
+// anchor pose once per landmark, every measurement pose once — and carries u = sum A^T c over the factors of the landmark that see it
+struct IdpElim {
+  int n_lm = 0;               // eliminated inverse-depth landmarks; tangent offset of landmark l = to0 + l
+  int to0 = 0;
+  int n_fac = 0;              // binary factors with an eliminated landmark, sorted by it
+  int n_view = 0;
+  int* order = nullptr;       // sorted position -> factor of the group
+  int* lm_start = nullptr;    // n_lm + 1, into order
+  int* view_start = nullptr;  // n_lm + 1, into the views
+  int2* fview = nullptr;      // sorted position -> (view of the anchor pose, view of the measurement pose)
+  int* view_lm = nullptr;     // view -> landmark
+  int direct = 0;             // 1: the factors' own pose-pose terms are assembled by idp_pairs_kernel (every binary factor is in `order`)
+  int n_cam_pose = 0;
+  int* cp_tq = nullptr;       // camera pose -> tangent offset of q / p (or -1)
+  int* cp_tp = nullptr;
+  int n_seg = 0, n_ent = 0;   // pair segments: entries (view a, view b) of one landmark, grouped by camera-pose pair (ci <= cj)
+  int* seg_ci = nullptr; int* seg_cj = nullptr; int* seg_start = nullptr;
+  int* ent_va = nullptr; int* ent_vb = nullptr; int* ent_code = nullptr;   // (code: idp_pairs_kernel)
+  double* U = nullptr;        // n_view x 8: u (6), z of the landmark, 0
+  double* VD = nullptr;       // n_view x 48 (direct): D = sum A^T A (36), sum A^T r (6), pad
+  double* linv = nullptr;     // n_lm: 1 / sqrt(h + lambda)
+  double* z = nullptr;        // n_lm: linv * g
+  double* C = nullptr;        // n_fac x 2: c = w linv  (w = d r / d rho)
+};
+void launch_idp_landmark(hipStream_t s, const IdpElim& e, const SmallGroup& g, const double* radius_ptr, double radius_val, int compute_scale,
+                         int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* scale, double* dcl, double* grad);
+void launch_idp_pairs(hipStream_t s, const IdpElim& e, const SmallGroup& g, double* S, int ld, int rhs_row, double* grad, double* hdiag,
+                      const int* perm, bool grad_only);
+void launch_idp_backsub(hipStream_t s, const IdpElim& e, const SmallGroup& g, const double* y_pose, double* delta);
+
 // entry of the end-of-step reduction table (k_misc.hip: final_reduce_kernel)
 struct ReduceEntry {
   const double* ptr;

@@ -202,6 +202,10 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
   c->scal_mirrored = false;
   launch_landmark(s, c->vis, c->n_pose, merged ? nullptr : c->d_scal + SC_RADIUS, first ? 1 : 0, new_J ? 1 : 0, o.jacobi_scaling, o.min_lm_diagonal,
                   o.max_lm_diagonal, c->d_scale, c->d_dcl, c->d_grad, merged ? &zs : nullptr, radius);
+  // (inverse-depth landmarks: their scalar elimination, k_idp.hip — after the clearing above, which rides in the landmark launch)
+  launch_idp_landmark(s, c->idp, c->small[BSGPU_F_IDP_REPROJ], c->use_graphs ? c->d_scal + SC_RADIUS : nullptr, radius, first ? 1 : 0, new_J ? 1 : 0,
+                      o.jacobi_scaling, o.min_lm_diagonal, o.max_lm_diagonal, c->d_scale, c->d_dcl, c->d_grad);
+  launch_idp_pairs(s, c->idp, c->small[BSGPU_F_IDP_REPROJ], c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm, gradient_only);
   phase_mark(c, BSGPU_PHASE_LANDMARK);
   {
     // (the factor-wise assembled pose-only groups ride in the pair launch when there is one; further groups, or all of them, go by themselves)
@@ -307,6 +311,7 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
     phase_mark(c, BSGPU_PHASE_BACKSOLVE);
   }
   // landmark back-substitution + the model-cost-change terms of the visual factors (partial arrays only, summed once at the end)
+  launch_idp_backsub(s, c->idp, c->small[BSGPU_F_IDP_REPROJ], c->d_ytan, c->d_delta);   // (before the pose-only groups' model-cost terms, which read the step of rho)
   {
     // (the model-cost terms of the first pose-only groups ride in the back-substitution launch; further groups, or all of them when
     // there is no visual launch, go by themselves)

