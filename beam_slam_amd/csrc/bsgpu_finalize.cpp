@@ -457,6 +457,7 @@ int finalize(bsgpu_ctx* c) {
           }
       }
     }
+    if (timing && g.n > 10000) lap("  group: per-factor loop");
     sg.xoff = c->upload(xoff); sg.toff = c->upload(toff); sg.consts = c->upload(g.consts); sg.loss = c->upload(loss);
     // the assembly into the reduced system sees an eliminated inverse-depth slot as a constant one (the evaluation, the model cost change
     // and bsgpu_evaluate keep the real column)
@@ -475,12 +476,14 @@ int finalize(bsgpu_ctx* c) {
     }
     c->d_small_inactive[t] = c->upload(inactive);
     c->h_small_active[t] = active;
+    if (timing && g.n > 10000) lap("  group: uploads");
     sg.r = c->alloc<double>((size_t)g.n * ti.m);
     sg.J = c->alloc<double>((size_t)g.n * ti.m * 3 * ti.nvar);
     c->d_small_part[t] = c->alloc<double>((size_t)g.n * ti.m);
     c->d_small_part_cand[t] = c->alloc<double>(g.n);
     c->d_small_part_mcc[t] = c->alloc<double>((size_t)g.n * ti.m);
     part_max = std::max(part_max, (size_t)g.n * ti.m);
+    if (timing && g.n > 10000) lap("  group: allocations");
   }
   lap("pose-only group tables");
   // ---- how the pose-only factors are assembled.  Where many factors of a type add into the same 3x3 blocks of J^T J (C3: 20 000
@@ -549,6 +552,7 @@ int finalize(bsgpu_ctx* c) {
     c->n_sa_seg = (int)seg_ra.size();
     c->d_sa_seg_start = c->upload(seg_start); c->d_sa_seg_ra = c->upload(seg_ra); c->d_sa_seg_rb = c->upload(seg_rb);
     c->d_sa_contrib = c->upload(contrib);
+    if (timing) lap("  lists: contributions");
     std::vector<SmallGroup> groups(c->small, c->small + kNumInternal);
     c->d_small_groups = c->upload(groups);
   }
@@ -643,6 +647,7 @@ int finalize(bsgpu_ctx* c) {
       for (const Extra& x : extras) fn(x.a, x.b, x.code);
     };
     const uint64_t ncp = (uint64_t)std::max(1, k);
+    constexpr int kIdpChunk = 128;   // entries per segment (one wave of idp_pairs_kernel; 64 .. 256 measured alike, 32 half as fast)
     std::vector<int> seg_ci, seg_cj, seg_start, ent_va, ent_vb, ent_code;
     if (ncp * ncp <= (uint64_t)8 << 20) {
       std::vector<int> start(ncp * ncp + 1, 0);
@@ -650,7 +655,7 @@ int finalize(bsgpu_ctx* c) {
       for (size_t i = 0; i < ncp * ncp; ++i) start[i + 1] += start[i];
       ent_va.resize(start[ncp * ncp]); ent_vb.resize(start[ncp * ncp]); ent_code.resize(start[ncp * ncp]);
       for (uint64_t key = 0; key < ncp * ncp; ++key)
-        for (int p0 = start[key]; p0 < start[key + 1]; p0 += kPairChunk) { seg_ci.push_back((int)(key / ncp)); seg_cj.push_back((int)(key % ncp)); seg_start.push_back(p0); }
+        for (int p0 = start[key]; p0 < start[key + 1]; p0 += kIdpChunk) { seg_ci.push_back((int)(key / ncp)); seg_cj.push_back((int)(key % ncp)); seg_start.push_back(p0); }
       std::vector<int> pos(start.begin(), start.end() - 1);
       for (int l = 0; l < n_rho; ++l)
         for_entries(l, [&](int a, int b, int code) { const int p = pos[(uint64_t)view_cp[a] * ncp + view_cp[b]]++; ent_va[p] = a; ent_vb[p] = b; ent_code[p] = code; });
@@ -661,7 +666,7 @@ int finalize(bsgpu_ctx* c) {
       std::stable_sort(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) { return x.key < y.key; });
       ent_va.resize(ents.size()); ent_vb.resize(ents.size()); ent_code.resize(ents.size());
       for (size_t i = 0; i < ents.size(); ++i) {
-        if (i == 0 || ents[i].key != ents[i - 1].key || (int)i - seg_start.back() >= kPairChunk) {
+        if (i == 0 || ents[i].key != ents[i - 1].key || (int)i - seg_start.back() >= kIdpChunk) {
           seg_ci.push_back((int)(ents[i].key / ncp)); seg_cj.push_back((int)(ents[i].key % ncp)); seg_start.push_back((int)i);
         }
         ent_va[i] = ents[i].va; ent_vb[i] = ents[i].vb; ent_code[i] = ents[i].code;
@@ -689,7 +694,22 @@ int finalize(bsgpu_ctx* c) {
     E.cp_tq = c->upload(cp_tq); E.cp_tp = c->upload(cp_tp);
     E.seg_ci = c->upload(seg_ci); E.seg_cj = c->upload(seg_cj); E.seg_start = c->upload(seg_start);
     E.ent_va = c->upload(ent_va); E.ent_vb = c->upload(ent_vb); E.ent_code = c->upload(ent_code); E.view_lm = c->upload(view_lm);
-    if (E.direct) { E.VD = c->alloc<double>((size_t)std::max(1, E.n_view) * 48); if (!E.VD) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (inverse-depth landmark tables)"); }
+    E.view_cp = c->upload(view_cp);
+    if (E.direct) {
+      // a view of exactly one factor side (every measurement view) needs no stored D: the pair kernel forms it from the factor's row
+      std::vector<int> cnt(view_cp.size(), 0), view_code(view_cp.size(), 0);
+      for (size_t p = 0; p < order.size(); ++p) {
+        const int x = fview[p].x, y = fview[p].y;
+        if (x == y) { cnt[x] += 2; continue; }
+        if (cnt[x]++ == 0) view_code[x] = (int)(p << 1); 
+        if (cnt[y]++ == 0) view_code[y] = (int)(p << 1) | 1;
+      }
+      int n_multi = 0;
+      for (size_t v = 0; v < view_cp.size(); ++v) if (cnt[v] != 1) view_code[v] = -(++n_multi);
+      E.view_code = c->upload(view_code);
+      E.VD = c->alloc<double>((size_t)std::max(1, n_multi) * 48);
+      if (!E.VD) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (inverse-depth landmark tables)");
+    }
     E.U = c->alloc<double>((size_t)std::max(1, E.n_view) * 8); E.linv = c->alloc<double>(n_rho); E.z = c->alloc<double>(n_rho);
     E.C = c->alloc<double>((size_t)std::max(1, E.n_fac) * 2);
     if (!E.U || !E.linv || !E.z || !E.C) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (inverse-depth landmark tables)");

@@ -139,6 +139,8 @@ struct IdpElim {
   int* view_start = nullptr;  // n_lm + 1, into the views
   int2* fview = nullptr;      // sorted position -> (view of the anchor pose, view of the measurement pose)
   int* view_lm = nullptr;     // view -> landmark
+  int* view_cp = nullptr;     // view -> camera pose
+  int* view_code = nullptr;   // (direct) view -> (sorted position << 1 | side) of its only factor, or -(row of VD + 1)
   int direct = 0;             // 1: the factors' own pose-pose terms are assembled by idp_pairs_kernel (every binary factor is in `order`)
   int n_cam_pose = 0;
   int* cp_tq = nullptr;       // camera pose -> tangent offset of q / p (or -1)
@@ -147,7 +149,7 @@ struct IdpElim {
   int* seg_ci = nullptr; int* seg_cj = nullptr; int* seg_start = nullptr;
   int* ent_va = nullptr; int* ent_vb = nullptr; int* ent_code = nullptr;   // (code: idp_pairs_kernel)
   double* U = nullptr;        // n_view x 8: u (6), z of the landmark, 0
-  double* VD = nullptr;       // n_view x 48 (direct): D = sum A^T A (36), sum A^T r (6), pad
+  double* VD = nullptr;       // (direct) one row of 48 per view of several factors: D = sum A^T A (36), sum A^T r (6), pad
   double* linv = nullptr;     // n_lm: 1 / sqrt(h + lambda)
   double* z = nullptr;        // n_lm: linv * g
   double* C = nullptr;        // n_fac x 2: c = w linv  (w = d r / d rho)
@@ -156,7 +158,7 @@ void launch_idp_landmark(hipStream_t s, const IdpElim& e, const SmallGroup& g, c
                          int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* scale, double* dcl, double* grad);
 void launch_idp_pairs(hipStream_t s, const IdpElim& e, const SmallGroup& g, double* S, int ld, int rhs_row, double* grad, double* hdiag,
                       const int* perm, bool grad_only);
-void launch_idp_backsub(hipStream_t s, const IdpElim& e, const SmallGroup& g, const double* y_pose, double* delta);
+void launch_idp_backsub(hipStream_t s, const IdpElim& e, const double* y_pose, double* delta);
 
 // entry of the end-of-step reduction table (k_misc.hip: final_reduce_kernel)
 struct ReduceEntry {

@@ -311,7 +311,7 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
     phase_mark(c, BSGPU_PHASE_BACKSOLVE);
   }
   // landmark back-substitution + the model-cost-change terms of the visual factors (partial arrays only, summed once at the end)
-  launch_idp_backsub(s, c->idp, c->small[BSGPU_F_IDP_REPROJ], c->d_ytan, c->d_delta);   // (before the pose-only groups' model-cost terms, which read the step of rho)
+  launch_idp_backsub(s, c->idp, c->d_ytan, c->d_delta);   // (before the pose-only groups' model-cost terms, which read the step of rho)
   {
     // (the model-cost terms of the first pose-only groups ride in the back-substitution launch; further groups, or all of them when
     // there is no visual launch, go by themselves)

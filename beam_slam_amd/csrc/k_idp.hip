@@ -61,6 +61,9 @@ __global__ __launch_bounds__(128) void idp_view_kernel(IdpElim e, SmallGroup g) 
   const int l = e.view_lm[v];
   const int beg = e.lm_start[l], end = e.lm_start[l + 1];
   const double z = e.z[l];
+  // (a view of one factor — every measurement view — keeps no D: the pair kernel forms A^T A from the factor's row, 96 bytes instead of 384)
+  const int vcode = e.direct ? e.view_code[v] : 0;
+  const bool multi = vcode < 0;
   double u[6], gr[6], D[36];
 #pragma unroll
   for (int k = 0; k < 6; ++k) { u[k] = 0.0; gr[k] = 0.0; }
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(128) void idp_view_kernel(IdpElim e, SmallGroup g) 
     const double c0 = e.C[2 * (size_t)p], c1 = e.C[2 * (size_t)p + 1];
 #pragma unroll
     for (int k = 0; k < 6; ++k) u[k] += A0[k] * c0 + A1[k] * c1;
-    if (e.direct) {
+    if (multi) {
       const double r0 = g.r[2 * (size_t)f], r1 = g.r[2 * (size_t)f + 1];
 #pragma unroll
       for (int a = 0; a < 6; ++a) {
@@ -92,8 +95,8 @@ __global__ __launch_bounds__(128) void idp_view_kernel(IdpElim e, SmallGroup g) 
 #pragma unroll
   for (int k = 0; k < 6; ++k) uo[k] = u[k];
   uo[6] = z; uo[7] = 0.0;
-  if (e.direct) {
-    double* o = e.VD + (size_t)v * 48;
+  if (multi) {
+    double* o = e.VD + (size_t)(-vcode - 1) * 48;
 #pragma unroll
     for (int k = 0; k < 36; ++k) o[k] = D[k];
 #pragma unroll
@@ -143,11 +146,28 @@ __global__ __launch_bounds__(64) void idp_pairs_kernel(IdpElim e, SmallGroup g, 
     }
     if (e.direct) {
       if (va == vb) {
-        const double* o = e.VD + (size_t)va * 48;
+        const int vc = e.view_code[va];
+        if (vc < 0) {
+          const double* o = e.VD + (size_t)(-vc - 1) * 48;
 #pragma unroll
-        for (int k = 0; k < 36; ++k) v[k] += o[k];
+          for (int k = 0; k < 36; ++k) v[k] += o[k];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) { const double gk = o[36 + k]; v[36 + k] += gk; v[42 + k] += gk; v[48 + k] += o[7 * k]; }
+          for (int k = 0; k < 6; ++k) { const double gk = o[36 + k]; v[36 + k] += gk; v[42 + k] += gk; v[48 + k] += o[7 * k]; }
+        } else {   // the view's only factor: (sorted position << 1) | side
+          const int f = e.order[vc >> 1], x0 = (vc & 1) ? 6 : 0;
+          const double* J = g.J + (size_t)f * 30;
+          const double r0 = g.r[2 * (size_t)f], r1 = g.r[2 * (size_t)f + 1];
+          double A0[6], A1[6];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) { A0[k] = J[x0 + k]; A1[k] = J[15 + x0 + k]; }
+#pragma unroll
+          for (int a = 0; a < 6; ++a) {
+            const double gk = A0[a] * r0 + A1[a] * r1;
+            v[36 + a] += gk; v[42 + a] += gk; v[48 + a] += A0[a] * A0[a] + A1[a] * A1[a];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) v[a * 6 + c] += A0[a] * A0[c] + A1[a] * A1[c];
+          }
+        }
       } else if (code >= 0) {
         const double* J = g.J + (size_t)e.order[code >> 2] * 30;
         const int xa = (code & 2) ? 6 : 0, xb = 6 - xa;   // columns of view a's / view b's pose inside the factor's row
@@ -190,31 +210,23 @@ void launch_idp_pairs(hipStream_t s, const IdpElim& e, const SmallGroup& g, doub
   hipLaunchKernelGGL(idp_pairs_kernel, dim3(e.n_seg), dim3(64), 0, s, e, g, S, ld, rhs_row, grad, hdiag, perm, grad_only ? 1 : 0);
 }
 
-__global__ __launch_bounds__(128) void idp_backsub_kernel(IdpElim e, SmallGroup g, const double* __restrict__ y_pose, double* __restrict__ delta) {
+// y_l = linv (z - sum_f c_f^T (A_a y_a + A_m y_m)) = linv (z - sum_v u_v . y_cam(v)): the views carry what the step of rho needs
+__global__ __launch_bounds__(128) void idp_backsub_kernel(IdpElim e, const double* __restrict__ y_pose, double* __restrict__ delta) {
   const int l = blockIdx.x * 128 + threadIdx.x;
   if (l >= e.n_lm) return;
-  const int beg = e.lm_start[l], end = e.lm_start[l + 1];
   double acc = 0.0;
-  for (int p = beg; p < end; ++p) {
-    const int f = e.order[p];
-    const double* J = g.J + (size_t)f * 30;
-    const int* to = g.toff + (size_t)f * 5;
-    double j0 = 0.0, j1 = 0.0;
-#pragma unroll
-    for (int sl = 0; sl < 4; ++sl) {
-      const int t = to[sl];
-      if (t < 0) continue;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) { const double yv = y_pose[t + k]; j0 += J[3 * sl + k] * yv; j1 += J[15 + 3 * sl + k] * yv; }
-    }
-    acc += e.C[2 * (size_t)p] * j0 + e.C[2 * (size_t)p + 1] * j1;
+  for (int v = e.view_start[l]; v < e.view_start[l + 1]; ++v) {
+    const double* u = e.U + (size_t)v * 8;
+    const int cp = e.view_cp[v], tq = e.cp_tq[cp], tp = e.cp_tp[cp];
+    if (tq >= 0) acc += u[0] * y_pose[tq] + u[1] * y_pose[tq + 1] + u[2] * y_pose[tq + 2];
+    if (tp >= 0) acc += u[3] * y_pose[tp] + u[4] * y_pose[tp + 1] + u[5] * y_pose[tp + 2];
   }
   delta[e.to0 + l] = -(e.linv[l] * (e.z[l] - acc));
 }
 
-void launch_idp_backsub(hipStream_t s, const IdpElim& e, const SmallGroup& g, const double* y_pose, double* delta) {
+void launch_idp_backsub(hipStream_t s, const IdpElim& e, const double* y_pose, double* delta) {
   if (e.n_lm <= 0) return;
-  hipLaunchKernelGGL(idp_backsub_kernel, dim3((e.n_lm + 127) / 128), dim3(128), 0, s, e, g, y_pose, delta);
+  hipLaunchKernelGGL(idp_backsub_kernel, dim3((e.n_lm + 127) / 128), dim3(128), 0, s, e, y_pose, delta);
 }
 
 }  // namespace bsg
