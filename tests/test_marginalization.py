@@ -182,6 +182,32 @@ def test_hip_marginal_prior_matches_oracle(oracle_cls, gpu_solver_cls, seed):
 
 
 @pytest.mark.gpu
+def test_hip_marginal_prior_of_an_inverse_depth_window_matches_oracle(oracle_cls, gpu_solver_cls):
+    """The first keyframe of an inverse-depth window expires together with the landmarks anchored at it: in the sub-problem those
+    scalars are eliminated on the landmark side (k_idp.hip).  An inverse-depth factor always holds its anchor, so the factors of the
+    landmarks anchored later are untouched: the prior couples the keyframes that saw the expiring landmarks."""
+    pr = synthetic.idp_window(n_kf=7, n_lm=120, seed=17)
+    kf, rho = pr.meta["kf_blocks"], pr.meta["rho_blocks"]
+    bi = np.concatenate([c[0] for c in pr.factors[capi.F_IDP_REPROJ]])
+    ui = np.concatenate([c[0] for c in pr.factors[capi.F_IDP_REPROJ_UNARY]])
+    anchored0 = sorted({int(r[4]) for r in bi if r[0] == kf[0, 0]} | {int(r[2]) for r in ui if r[0] == kf[0, 0]})
+    assert len(anchored0) >= 5
+    marg = [int(b) for b in kf[0]] + anchored0
+    o, g = oracle_cls(), gpu_solver_cls(0)
+    pr.load(o); pr.load(g)
+    o.solve()
+    g.set_values(o.get_blocks())
+    ko, Ao, bo, xo = o.marginalize(marg, pr.size)
+    kg, Ag, bg, xg = g.marginalize(marg, pr.size)
+    assert np.array_equal(ko, kg) and np.array_equal(xo, xg)
+    assert not set(int(k) for k in kg) & set(int(b) for b in rho)          # only keyframe blocks are kept
+    assert Ao.shape == Ag.shape
+    So, Sg = Ao.T @ Ao, Ag.T @ Ag
+    assert np.abs(Sg - So).max() <= 1e-8 * np.abs(So).max()
+    assert np.abs(Ag.T @ bg - Ao.T @ bo).max() <= 1e-8 * max(1.0, np.abs(Ao.T @ bo).max())
+
+
+@pytest.mark.gpu
 def test_hip_marginal_factor_evaluation_matches_oracle(oracle_cls, gpu_solver_cls):
     """bsgpu_add_marginal: residual, Jacobian, gradient, LM trajectory of a graph holding a dense prior over
     quaternion, vector and (former) landmark blocks."""
