@@ -135,8 +135,10 @@ enum {
    *           size 1), camera-table index
    *   consts: u, v (pixel), w (sqrt information = w * I2), m[3] (bearing of the
    *           landmark in the anchor camera, InverseDepthLandmark::bearing())
-   *   The inverse-depth scalar stays in the reduced system (it is not Schur-
-   *   eliminated); use_idp is off in every shipped configuration.              */
+   *   An inverse-depth scalar that only such factors use is eliminated on the
+   *   landmark side like a Euclidean landmark (csrc/k_idp.hip; its covariance
+   *   cannot be queried then; BSGPU_IDP_ELIM=0 at finalize keeps it in the
+   *   reduced system).  use_idp is off in every shipped configuration.         */
   BSGPU_F_IDP_REPROJ = 10,
   /* bs_constraints::InverseDepthReprojectionConstraintUnary
    *   (visual/inversedepth_reprojection_functor_unary.h:14-85, AutoDiff<2,4,3,1>)
