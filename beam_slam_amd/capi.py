@@ -111,7 +111,7 @@ SYMBOLS = [
     "finalize", "solve", "get_blocks", "reset_values", "num_iterations_recorded", "get_iteration",
     "evaluate", "num_residuals", "num_parameters_tangent", "tangent_offset", "covariance", "marginalize", "get_marginal",
     "reprojection_errors", "preintegrate", "triangulate", "time_reproj_jacobian_ms", "reproj_jacobian_bytes", "dense_solve", "plan_info",
-    "profile_step", "time_eval_ms", "eval_bytes", "bsr_info", "covariance_joint", "update_marginal",
+    "profile_step", "time_eval_ms", "eval_bytes", "bsr_info", "covariance_joint", "update_marginal", "solve_batch",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -326,6 +326,26 @@ class Solver:
         s = Summary()
         self._chk(self._f("solve")(self._ctx, C.byref(o), C.byref(s)))
         return s
+
+    @staticmethod
+    def solve_batch(solvers, options=None):
+        """bsgpu_solve_batch: the solvers' windows at once (a library thread per context); returns their summaries."""
+        n = len(solvers)
+        first = solvers[0]
+        opts = options if isinstance(options, (list, tuple)) else [options if options is not None else first.options_default()]
+        oa = (Options * len(opts))(*opts)
+        sa = (Summary * n)()
+        ca = (C.c_void_p * n)(*[sv._ctx for sv in solvers])
+        fn = first._f("solve_batch")
+        fn.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(Options), C.c_int32, C.POINTER(Summary)]
+        rc = fn(ca, n, oa, 1 if len(opts) > 1 else 0, sa)
+        if rc != OK:
+            for sv in solvers:
+                msg = sv._f("last_error")(sv._ctx).decode()
+                if msg:
+                    raise SolverError(rc, msg)
+            raise SolverError(rc, "solve_batch failed")
+        return list(sa)
 
     def get_blocks(self):
         out = np.empty(self._nvalues, np.float64)

@@ -6,6 +6,8 @@
 // SPARSE_NORMAL_CHOLESKY (solve(), bsgpu_solve.cpp: a restatement of Ceres' TrustRegionMinimizer +
 // LevenbergMarquardtStrategy driving device kernels).  This file: the entry points themselves.
 // There is no CPU fallback: without a HIP device bsgpu_create() fails.
+#include <thread>
+
 #include "bsgpu_ctx.h"
 
 using namespace bsg;
@@ -390,6 +392,26 @@ int bsgpu_solve(bsgpu_ctx* c, const bsgpu_options* o, bsgpu_summary* s) try {
   if (!o || !s) return fail(c, BSGPU_ERR_INVALID, "solve: null argument");
   return solve(c, *o, *s);
 } catch (...) { return api_exception(c); }
+int bsgpu_solve_batch(bsgpu_ctx* const* ctxs, int32_t n, const bsgpu_options* o, int32_t options_stride, bsgpu_summary* s) {
+  if (!ctxs || n <= 0 || !o || !s) return BSGPU_ERR_INVALID;
+  for (int i = 0; i < n; ++i) {
+    if (!ctxs[i]) return BSGPU_ERR_INVALID;
+    for (int j = 0; j < i; ++j) if (ctxs[j] == ctxs[i]) return fail(ctxs[i], BSGPU_ERR_INVALID, "solve_batch: the same context twice");
+  }
+  std::vector<int> rc(n, BSGPU_OK);
+  auto one = [&](int i) { rc[i] = bsgpu_solve(ctxs[i], o + (options_stride ? i : 0), s + i); };   // (bsgpu_solve catches everything)
+  std::vector<std::thread> th;
+  th.reserve(n - 1);
+  try {
+    for (int i = 1; i < n; ++i) th.emplace_back(one, i);
+  } catch (...) {   // no more threads: the rest in this one
+    for (int i = (int)th.size() + 1; i < n; ++i) one(i);
+  }
+  one(0);
+  for (auto& t : th) t.join();
+  for (int i = 0; i < n; ++i) if (rc[i] != BSGPU_OK) return rc[i];
+  return BSGPU_OK;
+}
 int bsgpu_get_blocks(bsgpu_ctx* c, double* v, int64_t n) try {
   if (!c) return BSGPU_ERR_INVALID;
   if ((size_t)n != c->h_x.size()) return fail(c, BSGPU_ERR_INVALID, "get_blocks: size mismatch");

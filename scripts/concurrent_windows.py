@@ -29,3 +29,17 @@ for n in counts:
     barrier.wait(); t0 = time.perf_counter(); barrier.wait(); dt = time.perf_counter() - t0
     for t in th: t.join()
     print("%d concurrent windows: %.0f LM it/s aggregate, %.2f ms per solve per window" % (n, sum(its) / dt, 1e3 * dt / steps), flush=True)
+
+# the same through the batched entry point (bsgpu_solve_batch: the library's threads, one call per round of solves)
+for n in counts:
+    sv = solvers[:n]
+    for _ in range(3):
+        for g in sv: g.reset_values()
+        GpuSolver.solve_batch(sv, opt)
+    its = 0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        for g in sv: g.reset_values()
+        its += sum(s.num_linear_solves for s in GpuSolver.solve_batch(sv, opt))
+    dt = time.perf_counter() - t0
+    print("%d windows per bsgpu_solve_batch call: %.0f LM it/s aggregate, %.2f ms per call" % (n, its / dt, 1e3 * dt / steps), flush=True)

@@ -263,6 +263,46 @@ def test_contexts_release_their_device_memory(gpu_solver_cls):
     assert free0 - free1 < 32 << 20, "device memory in use grew by %.1f MB over 40 context lifetimes" % ((free0 - free1) / 2**20)
 
 
+def test_solve_batch_equals_lone_solves(gpu_solver_cls):
+    """bsgpu_solve_batch: windows of different kinds (Schur, pose-only dense, PCG, inverse-depth) in one call give what each gives
+    alone; per-window options; a failing window reports its own error and the others still finish."""
+    cases = [synthetic.vio_window(n_kf=40, n_lm=900, seed=1), synthetic.lio_window(n_kf=60, n_rel=500, seed=2),
+             synthetic.pose_graph(n_pose=2200, n_loop=3000, seed=3), synthetic.idp_window(n_kf=8, n_lm=60, seed=6),
+             synthetic.vio_window(n_kf=12, n_lm=200, seed=5, cauchy_a=None)]
+    def fresh():
+        out = []
+        for pr in cases:
+            g = gpu_solver_cls(0); pr.load(g); out.append(g)
+        return out
+    alone = fresh()
+    opts = []
+    for i, g in enumerate(alone):
+        o = g.options_default(); o.max_num_iterations = 4 + i
+        opts.append(o)
+    lone = [g.solve(o) for g, o in zip(alone, opts)]
+    batch = fresh()
+    sums = gpu_solver_cls.solve_batch(batch, opts)
+    for g0, s0, g1, s1 in zip(alone, lone, batch, sums):
+        assert s1.num_iterations == s0.num_iterations and s1.termination_type == s0.termination_type
+        assert s1.linear_solver_used == s0.linear_solver_used
+        assert abs(s1.final_cost - s0.final_cost) <= 1e-9 * abs(s0.final_cost)
+        assert np.abs(g1.get_blocks() - g0.get_blocks()).max() < 1e-8
+    # one shared options entry
+    again = fresh()
+    shared = again[0].options_default(); shared.max_num_iterations = 3
+    for s in gpu_solver_cls.solve_batch(again, shared):
+        assert s.num_iterations <= 3
+    # a window the exact path must refuse (pose graph above the dense limit): its error, the others solved
+    mixed = fresh()
+    o_exact = mixed[0].options_default(); o_exact.linear_solver_type = capi.LINEAR_SCHUR_CHOLESKY; o_exact.max_num_iterations = 3
+    with pytest.raises(capi.SolverError) as e:
+        gpu_solver_cls.solve_batch(mixed, o_exact)
+    assert "limit" in str(e.value)
+    assert mixed[0].iterations() and mixed[1].iterations()
+    with pytest.raises(capi.SolverError):
+        gpu_solver_cls.solve_batch([mixed[0], mixed[0]], o_exact)
+
+
 def test_contexts_on_concurrent_host_threads(gpu_solver_cls):
     """One context per host thread, all on one device (the reference runs its local smoother, global mapper and submap
     refinement side by side, submap_refinement.cpp:35-115): create, load, finalize, solve, read back and destroy concurrently;
