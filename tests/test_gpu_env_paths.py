@@ -18,7 +18,7 @@ sys.path.insert(0, %r)
 import numpy as np
 from beam_slam_amd import synthetic
 from beam_slam_amd.gpu import GpuSolver
-pr = synthetic.vio_window(n_kf=90, n_lm=6000, seed=77)
+pr = synthetic.idp_window(n_kf=40, n_lm=3000, seed=78) if len(sys.argv) > 1 and sys.argv[1] == "idp" else synthetic.vio_window(n_kf=90, n_lm=6000, seed=77)
 g = GpuSolver(0)
 pr.load(g)
 o = g.options_vio(); o.max_solver_time_in_seconds = 0.0; o.max_num_iterations = 6
@@ -29,10 +29,10 @@ print(json.dumps({"cost": s.final_cost, "it": s.num_iterations, "acc": [int(i.st
 """ % ROOT
 
 
-def _run(env_extra):
+def _run(env_extra, window="vio"):
     env = dict(os.environ)
     env.update(env_extra)
-    out = subprocess.run([sys.executable, "-c", SCRIPT], capture_output=True, text=True, timeout=600, env=env)
+    out = subprocess.run([sys.executable, "-c", SCRIPT, window], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     return json.loads(out.stdout.strip().splitlines()[-1])
 
@@ -68,6 +68,31 @@ SETTINGS = [
 def test_alternative_path_reaches_the_same_optimum(default_run, setting):
     r = _run(setting)
     d = default_run
+    assert r["it"] == d["it"] and r["acc"] == d["acc"]
+    assert abs(r["cost"] - d["cost"]) <= 1e-9 * d["cost"]
+    assert max(abs(a - b) for a, b in zip(r["x"], d["x"])) < 1e-7
+
+
+# the inverse-depth window (landmark-side elimination, k_idp.hip) under the switches that change what runs around it
+IDP_SETTINGS = [
+    {"BSGPU_GRAPH": "1"},
+    {"BSGPU_CHOL_FUSED": "0", "BSGPU_BACKSOLVE_LEGACY": "1"},
+    {"BSGPU_BACKSOLVE_FUSED": "0"},
+    {"BSGPU_IDP_GENERIC_ASSEMBLY": "1"},
+    {"BSGPU_IDP_ELIM": "0"},
+    {"BSGPU_IDP_ELIM": "0", "BSGPU_NO_LEAF_TILES": "1"},
+]
+
+
+@pytest.fixture(scope="module")
+def default_idp_run():
+    return _run({}, "idp")
+
+
+@pytest.mark.parametrize("setting", IDP_SETTINGS, ids=lambda s: ",".join("%s=%s" % kv for kv in s.items()))
+def test_inverse_depth_window_under_alternative_paths(default_idp_run, setting):
+    r = _run(setting, "idp")
+    d = default_idp_run
     assert r["it"] == d["it"] and r["acc"] == d["acc"]
     assert abs(r["cost"] - d["cost"]) <= 1e-9 * d["cost"]
     assert max(abs(a - b) for a, b in zip(r["x"], d["x"])) < 1e-7
