@@ -177,6 +177,7 @@ int finalize(bsgpu_ctx* c) {
   }
   std::map<std::tuple<int, int, int>, int> derived_cam;
 
+  const bool sort_entries = getenv("BSGPU_PAIR_ENTRIES_SORT") != nullptr;   // (tests: the path windows of more than 2 896 camera poses take)
   // ---- visual factors: camera-pose ids, factors sorted by landmark, pair entries, tile adjacency.
   // Large plain windows are flattened on the device (k_flatten.hip); everything else — and any window the device
   // path declines (online calibration, landmark blocks shared with other factors, more than 8 distinct losses, an
@@ -303,7 +304,7 @@ int finalize(bsgpu_ctx* c) {
     // order is landmark-major.  Two passes over the landmarks: count per pair key, then fill in place.
     const uint64_t ncp = (uint64_t)std::max(1, V.n_cam_pose);
     std::vector<int> seg_ci, seg_cj, seg_start, ent_fa, ent_fb;
-    if (ncp * ncp <= (uint64_t)8 << 20) {
+    if (ncp * ncp <= (uint64_t)8 << 20 && !sort_entries) {
       std::vector<int> start(ncp * ncp + 1, 0);
       for (int l = 0; l < nl; ++l)
         for (int a = lm_start[l]; a < lm_start[l + 1]; ++a) {
@@ -649,7 +650,7 @@ int finalize(bsgpu_ctx* c) {
     const uint64_t ncp = (uint64_t)std::max(1, k);
     constexpr int kIdpChunk = 128;   // entries per segment (one wave of idp_pairs_kernel; 64 .. 256 measured alike, 32 half as fast)
     std::vector<int> seg_ci, seg_cj, seg_start, ent_va, ent_vb, ent_code;
-    if (ncp * ncp <= (uint64_t)8 << 20) {
+    if (ncp * ncp <= (uint64_t)8 << 20 && !sort_entries) {
       std::vector<int> start(ncp * ncp + 1, 0);
       for (int l = 0; l < n_rho; ++l) for_entries(l, [&](int a, int b, int) { start[(uint64_t)view_cp[a] * ncp + view_cp[b] + 1]++; });
       for (size_t i = 0; i < ncp * ncp; ++i) start[i + 1] += start[i];

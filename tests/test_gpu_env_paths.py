@@ -61,6 +61,7 @@ SETTINGS = [
     {"BSGPU_GRAPH": "1"},                                        # the LM step replayed as hipGraphs
     {"BSGPU_FLATTEN": "device"},
     {"BSGPU_FLATTEN": "host"},
+    {"BSGPU_FLATTEN": "host", "BSGPU_PAIR_ENTRIES_SORT": "1"},    # pair entries by a comparison sort (windows of > 2 896 camera poses)
 ]
 
 
@@ -81,6 +82,7 @@ IDP_SETTINGS = [
     {"BSGPU_IDP_GENERIC_ASSEMBLY": "1"},
     {"BSGPU_IDP_ELIM": "0"},
     {"BSGPU_IDP_ELIM": "0", "BSGPU_NO_LEAF_TILES": "1"},
+    {"BSGPU_PAIR_ENTRIES_SORT": "1"},
 ]
 
 
