@@ -160,10 +160,19 @@ void spcg_solve(bsgpu_ctx* c, const bsgpu_options& o) {
 void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot) {
   hipStream_t s = c->stream;
   const bool cand = slot == SC_COST_CAND;
-  if (c->vis.n) launch_reproj_eval(s, c->vis, x, c->d_cams, c->d_losses, with_J, cand ? c->vis.cost_part_cand : c->vis.cost_part);
-  if (with_J) phase_mark(c, BSGPU_PHASE_EVAL_REPROJ);
   const bool imu_pair = c->small[BSGPU_F_IMU_DELTA].n > 0 && c->small[BSGPU_F_IMU_PRIOR].n > 0;
-  if (imu_pair)
+  // (a visual-inertial window: the IMU factors ride in the reprojection launch — the cost-only pass always, the pass with Jacobians
+  // unless BSGPU_EVAL_MERGE=0: there the IMU body's registers cost the reprojection kernel a wave of occupancy per SIMD)
+  static const int merge_mode = getenv("BSGPU_EVAL_MERGE") ? atoi(getenv("BSGPU_EVAL_MERGE")) : 2;   // 0: never, 1: cost-only passes, 2: both
+  const bool merged = imu_pair && c->vis.n > 0 && (with_J ? merge_mode >= 2 : merge_mode >= 1);
+  if (merged)
+    launch_visual_imu_eval(s, c->vis, c->small[BSGPU_F_IMU_DELTA], c->small[BSGPU_F_IMU_PRIOR], x, c->d_cams, c->d_losses, with_J,
+                           cand ? c->vis.cost_part_cand : c->vis.cost_part,
+                           cand ? c->d_small_part_cand[BSGPU_F_IMU_DELTA] : c->d_small_part[BSGPU_F_IMU_DELTA],
+                           cand ? c->d_small_part_cand[BSGPU_F_IMU_PRIOR] : c->d_small_part[BSGPU_F_IMU_PRIOR]);
+  else if (c->vis.n) launch_reproj_eval(s, c->vis, x, c->d_cams, c->d_losses, with_J, cand ? c->vis.cost_part_cand : c->vis.cost_part);
+  if (with_J) phase_mark(c, BSGPU_PHASE_EVAL_REPROJ);
+  if (imu_pair && !merged)
     launch_imu_eval(s, c->small[BSGPU_F_IMU_DELTA], c->small[BSGPU_F_IMU_PRIOR], x, c->d_losses, with_J,
                     cand ? c->d_small_part_cand[BSGPU_F_IMU_DELTA] : c->d_small_part[BSGPU_F_IMU_DELTA],
                     cand ? c->d_small_part_cand[BSGPU_F_IMU_PRIOR] : c->d_small_part[BSGPU_F_IMU_PRIOR]);

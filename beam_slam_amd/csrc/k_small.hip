@@ -11,6 +11,7 @@
 // quaternion PlusJacobian; here the tangent Jacobians are closed form,
 // checked against the Jet-based oracle in tests/.
 #include "bsgpu_device.h"
+#include "reproj_body.h"
 
 namespace bsg {
 
@@ -41,8 +42,7 @@ BSG_DEV void finish_small(const SmallGroup& g, int f, const DevLoss* losses, dou
 // ---------------------------------------------------------------------------------------------------
 template <bool WITH_J>
 __device__ __forceinline__ void imu_delta_body(const SmallGroup g, const int f, const double* __restrict__ x,
-                                               const DevLoss* __restrict__ losses, double* __restrict__ cost_part) {
-  const int lane = threadIdx.x;
+                                               const DevLoss* __restrict__ losses, double* __restrict__ cost_part, const int lane) {
   const int* xo = g.xoff + (size_t)f * 10;
   const int* to = g.toff + (size_t)f * 10;
   const double* c = g.consts + (size_t)f * 287;
@@ -194,8 +194,7 @@ __device__ __forceinline__ void imu_delta_body(const SmallGroup g, const int f, 
 // ---------------------------------------------------------------------------------------------------
 template <bool WITH_J>
 __device__ __forceinline__ void imu_prior_body(const SmallGroup g, const int f, const double* __restrict__ x,
-                                               const DevLoss* __restrict__ losses, double* __restrict__ cost_part) {
-  const int lane = threadIdx.x;
+                                               const DevLoss* __restrict__ losses, double* __restrict__ cost_part, const int lane) {
   const int* xo = g.xoff + (size_t)f * 5;
   const int* to = g.toff + (size_t)f * 5;
   const double* c = g.consts + (size_t)f * 241;
@@ -236,12 +235,12 @@ __device__ __forceinline__ void imu_prior_body(const SmallGroup g, const int f, 
 template <bool WITH_J>
 __global__ __launch_bounds__(64) void imu_delta_kernel(SmallGroup g, const double* __restrict__ x, const DevLoss* __restrict__ losses,
                                                        double* __restrict__ cost_part) {
-  imu_delta_body<WITH_J>(g, blockIdx.x, x, losses, cost_part);
+  imu_delta_body<WITH_J>(g, blockIdx.x, x, losses, cost_part, threadIdx.x);
 }
 template <bool WITH_J>
 __global__ __launch_bounds__(64) void imu_prior_kernel(SmallGroup g, const double* __restrict__ x, const DevLoss* __restrict__ losses,
                                                        double* __restrict__ cost_part) {
-  imu_prior_body<WITH_J>(g, blockIdx.x, x, losses, cost_part);
+  imu_prior_body<WITH_J>(g, blockIdx.x, x, losses, cost_part, threadIdx.x);
 }
 // both IMU factor types of a visual-inertial window (n-1 pre-integrated factors, one or two priors) in ONE launch: a launch
 // of its own for the single prior costs more in dispatch than in work (see the Makefile note on this file's flags)
@@ -249,8 +248,37 @@ template <bool WITH_J>
 __global__ __launch_bounds__(64) void imu_eval_kernel(SmallGroup delta, SmallGroup prior, const double* __restrict__ x,
                                                       const DevLoss* __restrict__ losses, double* __restrict__ part_delta,
                                                       double* __restrict__ part_prior) {
-  if ((int)blockIdx.x < delta.n) imu_delta_body<WITH_J>(delta, blockIdx.x, x, losses, part_delta);
-  else imu_prior_body<WITH_J>(prior, blockIdx.x - delta.n, x, losses, part_prior);
+  if ((int)blockIdx.x < delta.n) imu_delta_body<WITH_J>(delta, blockIdx.x, x, losses, part_delta, threadIdx.x);
+  else imu_prior_body<WITH_J>(prior, blockIdx.x - delta.n, x, losses, part_prior, threadIdx.x);
+}
+// ... and, in a window that also has reprojection factors, both of them as the first workgroups of the reprojection evaluation (four
+// factors, a wave each, per 256-thread workgroup): 5 us (cost only) / 10 us (with Jacobians) of a launch that nothing but the launch
+// order made wait for the reprojection factors.
+template <bool WITH_J>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void visual_imu_eval_kernel(SmallGroup delta, SmallGroup prior, double* __restrict__ part_delta,
+                                                              double* __restrict__ part_prior, int n_imu_blocks, int n, const int4* __restrict__ fac,
+                                                              const double2* __restrict__ pix, const double* __restrict__ wgt,
+                                                              const double* __restrict__ x, const DevCamera* __restrict__ cams,
+                                                              const DevLoss* __restrict__ losses, double2* __restrict__ r_out,
+                                                              double* __restrict__ J_out, double* __restrict__ JB_out,
+                                                              double* __restrict__ cost_part, int count_inactive) {
+  if ((int)blockIdx.x < n_imu_blocks) {
+    const int f = 4 * (int)blockIdx.x + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (f < delta.n) imu_delta_body<WITH_J>(delta, f, x, losses, part_delta, lane);
+    else if (f < delta.n + prior.n) imu_prior_body<WITH_J>(prior, f - delta.n, x, losses, part_prior, lane);
+    return;
+  }
+  reproj_eval_body<WITH_J>((int)blockIdx.x - n_imu_blocks, n, fac, pix, wgt, x, cams, losses, r_out, J_out, JB_out, cost_part, count_inactive);
+}
+void launch_visual_imu_eval(hipStream_t s, const Visual& v, const SmallGroup& delta, const SmallGroup& prior, const double* x, const DevCamera* cams,
+                            const DevLoss* losses, bool with_J, double* cost_part_vis, double* part_delta, double* part_prior) {
+  const int n_imu_blocks = (delta.n + prior.n + 3) / 4, grid = n_imu_blocks + (v.n + 255) / 256;
+  if (with_J)
+    hipLaunchKernelGGL(visual_imu_eval_kernel<true>, dim3(grid), dim3(256), 0, s, delta, prior, part_delta, part_prior, n_imu_blocks, v.n, v.fac, v.pix, v.w,
+                       x, cams, losses, v.r, v.J, v.JB, cost_part_vis, 0);
+  else
+    hipLaunchKernelGGL(visual_imu_eval_kernel<false>, dim3(grid), dim3(256), 0, s, delta, prior, part_delta, part_prior, n_imu_blocks, v.n, v.fac, v.pix, v.w,
+                       x, cams, losses, v.r, v.J, v.JB, cost_part_vis, 0);
 }
 void launch_imu_eval(hipStream_t s, const SmallGroup& delta, const SmallGroup& prior, const double* x, const DevLoss* losses, bool with_J,
                      double* part_delta, double* part_prior) {

@@ -96,7 +96,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from beam_slam_amd import sharding, synthetic
+    from beam_slam_amd import capi, sharding, synthetic
     from beam_slam_amd.gpu import GpuSolver
 
     # ---- workload: C2 at N=1, C5 instances (independent C2-shaped windows) at N>1 ----------------
@@ -224,15 +224,21 @@ def main():
             ms, nbytes = prof["eval_reproj"]
             achieved = nbytes / (ms * 1e-3) / 1e9
             working_set_mb = nbytes / 1e6
-            roofline = {"bound": "hbm", "kernel": "reproj_eval_kernel<true>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # (a window that also has IMU factors evaluates them as the first workgroups of the same launch: k_small.hip)
+            merged_imu = pr.n_factors(capi.F_IMU_DELTA) > 0 and pr.n_factors(capi.F_IMU_PRIOR) > 0 and os.environ.get("BSGPU_EVAL_MERGE", "2") == "2"
+            eval_kernel = "visual_imu_eval_kernel<true>" if merged_imu else "reproj_eval_kernel<true>"
+            roofline = {"bound": "hbm", "kernel": eval_kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_measured_copy_peak": round(achieved / HBM_COPY_GBS, 4),
                         "bytes_per_launch": int(nbytes), "ms_per_launch": round(ms, 5),
                         "timing": "in situ: HIP events around the launch inside 20 full LM steps (bsgpu_profile_step)",
                         "working_set_mb": round(working_set_mb, 1),
                         "cache_residency": "below the 256 MiB Infinity Cache: the stream is MALL/fabric traffic, see past_l3" if working_set_mb < 256 else "above the 256 MiB Infinity Cache",
                         "traffic": None}
+            if merged_imu:
+                roofline["kernel_note"] = ("the reprojection factors' evaluation (the bytes counted) plus the window's %d IMU factors as the launch's first workgroups "
+                                           "(~6.1 KB each, not counted)" % (pr.n_factors(capi.F_IMU_DELTA) + pr.n_factors(capi.F_IMU_PRIOR)))
             if world == 1 and args.workload == "c2" and args.n_kf == 200 and args.n_lm == 50000:
-                _attach_traffic(roofline, "r03_c2_pmc_hbm.csv", "reproj_eval_kernel<true>", nbytes)
+                _attach_traffic(roofline, "r03_c2_pmc_hbm.csv", eval_kernel, nbytes)
             ms_f, flops = prof["factor"]
             tf = flops / (ms_f * 1e-3) / 1e12
             roofline_mfma = {"bound": "mfma", "kernel": "chol_fused_kernel (+ chol_backsolve_fused_kernel: %.1f us)" % (1e3 * prof["backsolve"][0]),
@@ -241,7 +247,7 @@ def main():
                              "note": MFMA_NOTE}
             kernels = []
             for name, kern in (("landmark", "landmark_kernel (+ clear)"), ("pairs", "pairs_kernel"), ("backsub", "backsub_mcc_kernel (+ small_mcc)"),
-                               ("candidate", "update + reproj_eval_kernel<false> + reduction")):
+                               ("candidate", "update + visual_imu_eval_kernel<false> / reproj_eval_kernel<false> + reduction")):
                 ms_k, by = prof[name]
                 kernels.append({"phase": name, "kernel": kern, "us": round(1e3 * ms_k, 2), "algorithmic_bytes": int(by),
                                 "achieved_gbs": round(by / (ms_k * 1e-3) / 1e9, 1), "frac_hbm": round(by / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})

@@ -61,7 +61,9 @@ SETTINGS = [
     {"BSGPU_GRAPH": "1"},                                        # the LM step replayed as hipGraphs
     {"BSGPU_FLATTEN": "device"},
     {"BSGPU_FLATTEN": "host"},
-    {"BSGPU_FLATTEN": "host", "BSGPU_PAIR_ENTRIES_SORT": "1"},    # pair entries by a comparison sort (windows of > 2 896 camera poses)
+    {"BSGPU_FLATTEN": "host", "BSGPU_PAIR_ENTRIES_SORT": "1"},
+    {"BSGPU_EVAL_MERGE": "0"},                                   # the IMU factors evaluated by a launch of their own
+    {"BSGPU_EVAL_MERGE": "1"},                                   # ... in the passes with Jacobians only    # pair entries by a comparison sort (windows of > 2 896 camera poses)
 ]
 
 
