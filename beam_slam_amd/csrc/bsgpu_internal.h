@@ -175,6 +175,8 @@ void launch_reproj_eval(hipStream_t s, const Visual& v, const double* x, const D
                         const DevLoss* losses, bool with_J, double* cost_part_out, bool count_inactive = false);
 void launch_visual_imu_eval(hipStream_t s, const Visual& v, const SmallGroup& delta, const SmallGroup& prior, const double* x, const DevCamera* cams,
                             const DevLoss* losses, bool with_J, double* cost_part_vis, double* part_delta, double* part_prior);
+void launch_relpose_imu_eval(hipStream_t s, const SmallGroup& g, const SmallGroup& delta, const SmallGroup& prior, const double* x,
+                             const DevLoss* losses, bool with_J, double* cost_part, double* part_delta, double* part_prior);
 void launch_imu_eval(hipStream_t s, const SmallGroup& delta, const SmallGroup& prior, const double* x, const DevLoss* losses, bool with_J,
                      double* part_delta, double* part_prior);
 void launch_small_eval(hipStream_t s, const SmallGroup& g, const double* x, const DevLoss* losses, bool with_J,

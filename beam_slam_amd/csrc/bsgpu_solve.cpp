@@ -172,12 +172,22 @@ void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot) {
                            cand ? c->d_small_part_cand[BSGPU_F_IMU_PRIOR] : c->d_small_part[BSGPU_F_IMU_PRIOR]);
   else if (c->vis.n) launch_reproj_eval(s, c->vis, x, c->d_cams, c->d_losses, with_J, cand ? c->vis.cost_part_cand : c->vis.cost_part);
   if (with_J) phase_mark(c, BSGPU_PHASE_EVAL_REPROJ);
-  if (imu_pair && !merged)
+  // (a lidar-inertial window: they ride in the relative-pose evaluation instead)
+  int rel_t = -1;
+  if (imu_pair && !merged && (with_J ? merge_mode >= 2 : merge_mode >= 1))
+    for (int t : {(int)BSGPU_F_RELPOSE_EXT, (int)BSGPU_F_RELPOSE}) if (rel_t < 0 && c->small[t].n > 0) rel_t = t;
+  if (rel_t >= 0)
+    launch_relpose_imu_eval(s, c->small[rel_t], c->small[BSGPU_F_IMU_DELTA], c->small[BSGPU_F_IMU_PRIOR], x, c->d_losses, with_J,
+                            cand ? c->d_small_part_cand[rel_t] : c->d_small_part[rel_t],
+                            cand ? c->d_small_part_cand[BSGPU_F_IMU_DELTA] : c->d_small_part[BSGPU_F_IMU_DELTA],
+                            cand ? c->d_small_part_cand[BSGPU_F_IMU_PRIOR] : c->d_small_part[BSGPU_F_IMU_PRIOR]);
+  if (imu_pair && !merged && rel_t < 0)
     launch_imu_eval(s, c->small[BSGPU_F_IMU_DELTA], c->small[BSGPU_F_IMU_PRIOR], x, c->d_losses, with_J,
                     cand ? c->d_small_part_cand[BSGPU_F_IMU_DELTA] : c->d_small_part[BSGPU_F_IMU_DELTA],
                     cand ? c->d_small_part_cand[BSGPU_F_IMU_PRIOR] : c->d_small_part[BSGPU_F_IMU_PRIOR]);
   for (int t = 2; t < kNumInternal; ++t) {
     if (imu_pair && (t == BSGPU_F_IMU_DELTA || t == BSGPU_F_IMU_PRIOR)) continue;
+    if (t == rel_t) continue;
     if (c->small[t].n) launch_small_eval(s, c->small[t], x, c->d_losses, with_J, cand ? c->d_small_part_cand[t] : c->d_small_part[t]);
   }
   for (const auto& mc : c->marg)

@@ -290,15 +290,14 @@ void launch_imu_eval(hipStream_t s, const SmallGroup& delta, const SmallGroup& p
 // relative pose (with / without extrinsics): one lane per factor
 // ---------------------------------------------------------------------------------------------------
 template <bool EXT, bool WITH_J>
-__global__ __launch_bounds__(128) void relpose_kernel(SmallGroup g, const double* __restrict__ x,
-                                                      const DevLoss* __restrict__ losses,
-                                                      double* __restrict__ cost_part) {
+__device__ __forceinline__ void relpose_body(const SmallGroup g, const double* __restrict__ x, const DevLoss* __restrict__ losses,
+                                             double* __restrict__ cost_part, const int block) {
   constexpr int NV = EXT ? 6 : 4;
   constexpr int TW = 3 * NV;
   // (Jacobian rows leave through LDS: a lane per factor storing its 864-byte Jacobian 8 bytes at a time touches 64 cache lines per
   // store instruction — 44 us for C3's 20 000 factors; see the end of the kernel)
   __shared__ __attribute__((aligned(16))) double sJ[WITH_J ? 2 * 64 * TW : 2];
-  const int f_raw = blockIdx.x * 128 + threadIdx.x;
+  const int f_raw = block * 128 + threadIdx.x;
   const bool live = f_raw < g.n;
   const int f = live ? f_raw : g.n - 1;   // (idle lanes of the last workgroup redo the last factor and store nothing)
   const int* xo = g.xoff + (size_t)f * NV;
@@ -445,7 +444,7 @@ __global__ __launch_bounds__(128) void relpose_kernel(SmallGroup g, const double
   // row i of every factor of the wave -> LDS -> 16-byte stores, TW / 2 lanes per factor (the row's 144 / 96 bytes are contiguous in J)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double* sw = sJ + wave * (64 * TW);
-  const int f0 = blockIdx.x * 128 + wave * 64;
+  const int f0 = block * 128 + wave * 64;
   const int cnt = min(64, g.n - f0);
   typedef double d2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
@@ -467,6 +466,35 @@ __global__ __launch_bounds__(128) void relpose_kernel(SmallGroup g, const double
     }
     __builtin_amdgcn_wave_barrier();
   }
+}
+template <bool EXT, bool WITH_J>
+__global__ __launch_bounds__(128) void relpose_kernel(SmallGroup g, const double* __restrict__ x, const DevLoss* __restrict__ losses,
+                                                      double* __restrict__ cost_part) {
+  relpose_body<EXT, WITH_J>(g, x, losses, cost_part, (int)blockIdx.x);
+}
+// a lidar-inertial window: the IMU factors (a wave each) as the first workgroups of the relative-pose evaluation, instead of a launch of
+// their own behind it (as visual_imu_eval_kernel does for a visual-inertial window)
+template <bool EXT, bool WITH_J>
+__global__ __launch_bounds__(128) void relpose_imu_eval_kernel(SmallGroup delta, SmallGroup prior, double* __restrict__ part_delta,
+                                                               double* __restrict__ part_prior, int n_imu_blocks, SmallGroup g,
+                                                               const double* __restrict__ x, const DevLoss* __restrict__ losses,
+                                                               double* __restrict__ cost_part) {
+  if ((int)blockIdx.x < n_imu_blocks) {
+    const int f = 2 * (int)blockIdx.x + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (f < delta.n) imu_delta_body<WITH_J>(delta, f, x, losses, part_delta, lane);
+    else if (f < delta.n + prior.n) imu_prior_body<WITH_J>(prior, f - delta.n, x, losses, part_prior, lane);
+    return;
+  }
+  relpose_body<EXT, WITH_J>(g, x, losses, cost_part, (int)blockIdx.x - n_imu_blocks);
+}
+void launch_relpose_imu_eval(hipStream_t s, const SmallGroup& g, const SmallGroup& delta, const SmallGroup& prior, const double* x,
+                             const DevLoss* losses, bool with_J, double* cost_part, double* part_delta, double* part_prior) {
+  const int n_imu_blocks = (delta.n + prior.n + 1) / 2, grid = n_imu_blocks + (g.n + 127) / 128;
+  const bool ext = g.type == BSGPU_F_RELPOSE_EXT;
+#define BSG_LAUNCH_RI(E, W) hipLaunchKernelGGL((relpose_imu_eval_kernel<E, W>), dim3(grid), dim3(128), 0, s, delta, prior, part_delta, part_prior, n_imu_blocks, g, x, losses, cost_part)
+  if (ext) { if (with_J) BSG_LAUNCH_RI(true, true); else BSG_LAUNCH_RI(true, false); }
+  else { if (with_J) BSG_LAUNCH_RI(false, true); else BSG_LAUNCH_RI(false, false); }
+#undef BSG_LAUNCH_RI
 }
 
 // absolute pose prior: blocks (p, q), r = A [p - b_p ; AngleAxis(b_q^-1 q)]

@@ -53,7 +53,7 @@ def bench_bytes(w):   # algorithmic bytes per launch of the roofline kernel, fro
     except Exception:
         pass
     return None
-roof_kernel = {"c2": "visual_imu_eval_kernel<true>", "c3": "relpose_kernel", "c4": "relpose_kernel", "pastl3": "reproj_eval_kernel<true>"}
+roof_kernel = {"c2": "visual_imu_eval_kernel<true>", "c3": "relpose_imu_eval_kernel", "c4": "relpose_kernel", "pastl3": "reproj_eval_kernel<true>"}
 for tag in ("c2", "c3", "c4", "pastl3"):
     acc, cnt = collect(tag, ["FETCH_SIZE", "WRITE_SIZE"])
     keys = sorted(set(k for c in acc for k in acc[c]), key=lambda k: -(acc["FETCH_SIZE"].get(k, 0) + acc["WRITE_SIZE"].get(k, 0)))
