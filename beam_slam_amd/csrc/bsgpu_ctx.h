@@ -171,6 +171,8 @@ struct bsgpu_ctx {
   ReduceEntry* d_reduce = nullptr;
   int n_reduce = 0;
   double* d_part_upd = nullptr;
+  double* d_gpart = nullptr;     // grad_norms_kernel: (max, sum of squares) per workgroup
+  int n_gpart = 0;
   int n_part_upd = 0;
   double *d_S = nullptr, *d_grad = nullptr, *d_hdiag = nullptr, *d_scale = nullptr, *d_dcl = nullptr;
   double *d_delta = nullptr, *d_y = nullptr, *d_scal = nullptr, *d_part = nullptr;

@@ -866,6 +866,11 @@ int finalize(bsgpu_ctx* c) {
       tab.push_back({mc.part_cand, mc.dev.rows, 1, 0, SC_COST_CAND});
       tab.push_back({mc.part_mcc, mc.dev.rows, 1, 0, SC_MCC});
     }
+    c->n_gpart = (std::max(c->nb, c->npad) + 255) / 256;
+    c->d_gpart = c->alloc<double>(2 * (size_t)c->n_gpart);
+    HIPCHK(c, hipMemsetAsync(c->d_gpart, 0, sizeof(double) * 2 * (size_t)c->n_gpart, c->stream));
+    tab.push_back({c->d_gpart, c->n_gpart, 2, 0, SC_GRAD_MAX, 1});
+    tab.push_back({c->d_gpart, c->n_gpart, 2, 1, SC_GRAD_NORM2});
     tab.push_back({c->d_part_upd, c->n_part_upd, 2, 0, SC_STEP_NORM2});
     tab.push_back({c->d_part_upd, c->n_part_upd, 2, 1, SC_X_NORM2});
     c->n_reduce = (int)tab.size();

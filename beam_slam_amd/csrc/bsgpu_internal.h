@@ -43,7 +43,7 @@ enum {
   SC_MCC = 2,        // model cost change
   SC_STEP_NORM2 = 3, // |x_cand - x|^2 (ambient, non-constant blocks)
   SC_X_NORM2 = 4,    // |x|^2
-  SC_GRAD_MAX = 5,   // |x - Plus(x,-g)|_inf   (stored as the bits of a non-negative double)
+  SC_GRAD_MAX = 5,   // |x - Plus(x,-g)|_inf   (5, 6: from the per-workgroup partials of grad_norms_kernel, by the end-of-step reduction)
   SC_GRAD_NORM2 = 6,
   SC_CHOL_FAIL = 7,  // > 0 when a pivot was not positive / finite
   SC_FIXED_COST = 8,
@@ -164,6 +164,7 @@ void launch_idp_backsub(hipStream_t s, const IdpElim& e, const double* y_pose, d
 struct ReduceEntry {
   const double* ptr;
   int n, stride, offset, slot;
+  int op = 0;   // 0: sum, 1: maximum (of non-negative values)
 };
 
 struct LaunchCtx {
@@ -202,9 +203,9 @@ void launch_pose_diag(hipStream_t s, int n_pose, double* S, int ld, const double
                       int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* scale,
                       double* dcl, int npad, const int* iperm);
 void launch_grad_norms(hipStream_t s, int nb, const int* blk_xoff, const int* blk_toff, const unsigned char* blk_size,
-                       const unsigned char* blk_manifold, const double* x, const double* grad, double* scal);
+                       const unsigned char* blk_manifold, const double* x, const double* grad, double* gpart /* 2 per workgroup: max, sum of squares */);
 void launch_grad_norms_pose_diag(hipStream_t s, int nb, const int* blk_xoff, const int* blk_toff, const unsigned char* blk_size,
-                                 const unsigned char* blk_manifold, const double* x, const double* grad, double* scal, int n_pose, double* S,
+                                 const unsigned char* blk_manifold, const double* x, const double* grad, double* gpart, int n_pose, double* S,
                                  int ld, const double* hdiag, const double* radius_ptr, int compute_scale, int compute_dcl, int jacobi,
                                  double lm_lo, double lm_hi, double* scale, double* dcl, int npad, const int* iperm);
 struct PanelDesc;

@@ -16,7 +16,7 @@ void assemble_pcg(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_
   launch_bsr_finish_diag(s, c->nbr, c->d_diag_slot, c->d_pair_slot, c->d_val, c->d_hdiag, radius, first ? 1 : 0, new_J ? 1 : 0, o.jacobi_scaling,
                          o.min_lm_diagonal, o.max_lm_diagonal, c->d_scale, c->d_dcl, c->d_Minv);
   if (new_J) {
-    launch_grad_norms(s, c->nb, c->d_blk_xoff, c->d_blk_toff, c->d_blk_size, c->d_blk_manifold, c->d_x, c->d_grad, c->d_scal);
+    launch_grad_norms(s, c->nb, c->d_blk_xoff, c->d_blk_toff, c->d_blk_size, c->d_blk_manifold, c->d_x, c->d_grad, c->d_gpart);
   }
 }
 
@@ -195,7 +195,7 @@ void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot) {
   if (with_J) phase_mark(c, BSGPU_PHASE_EVAL_OTHER);
 }
 void final_reduce(bsgpu_ctx* c) {
-  launch_final_reduce(c->stream, c->d_reduce, c->n_reduce, SC_X_NORM2 + 1, c->d_scal, c->h_scal_dev);
+  launch_final_reduce(c->stream, c->d_reduce, c->n_reduce, SC_GRAD_NORM2 + 1, c->d_scal, c->h_scal_dev);
   c->scal_mirrored = c->h_scal_dev != nullptr && c->n_reduce > 0;
   // (not under graph capture / replay: an event recorded while capturing is a graph node, not something the host can wait on)
   if (c->use_graphs) { c->ev_reduce_pending = false; return; }
@@ -247,7 +247,7 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
   for (const auto& mc : c->marg)
     if (mc.active) launch_marg_assemble(s, mc.dev, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm);
   if (new_J)   // the LM diagonal and the gradient norms both follow the assembly and do not depend on each other: one launch
-    launch_grad_norms_pose_diag(s, c->nb, c->d_blk_xoff, c->d_blk_toff, c->d_blk_size, c->d_blk_manifold, c->d_x, c->d_grad, c->d_scal,
+    launch_grad_norms_pose_diag(s, c->nb, c->d_blk_xoff, c->d_blk_toff, c->d_blk_size, c->d_blk_manifold, c->d_x, c->d_grad, c->d_gpart,
                                 c->n_pose, c->d_S, c->npad, c->d_hdiag, c->d_scal + SC_RADIUS, first ? 1 : 0, 1, o.jacobi_scaling,
                                 o.min_lm_diagonal, o.max_lm_diagonal, c->d_scale, c->d_dcl, c->npad, c->d_iperm);
   else

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void grad_norms_kernel(int nb, const int* __re
                                                          const unsigned char* __restrict__ size,
                                                          const unsigned char* __restrict__ manifold,
                                                          const double* __restrict__ x, const double* __restrict__ grad,
-                                                         double* __restrict__ scal, PoseDiagArgs pd) {
+                                                         double* __restrict__ gpart, PoseDiagArgs pd) {
   __shared__ double sred[4];
   __shared__ double smax[4];
   const int b = blockIdx.x * 256 + threadIdx.x;
@@ -99,27 +99,28 @@ __global__ __launch_bounds__(256) void grad_norms_kernel(int nb, const int* __re
   if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = mx;
   const double tot = block_sum_256(s2, sred);
   if (threadIdx.x == 0) {
-    const double m = fmax(fmax(smax[0], smax[1]), fmax(smax[2], smax[3]));
-    atomicMax(reinterpret_cast<unsigned long long*>(&scal[SC_GRAD_MAX]), (unsigned long long)__double_as_longlong(m));
-    atomicAdd(&scal[SC_GRAD_NORM2], tot);
+    // per-workgroup partials, reduced in a fixed order by final_reduce_kernel (two same-address atomics per workgroup — 400 of them
+    // on C2 — were most of this kernel's 9 us, and made the norm's last bits depend on their order)
+    gpart[2 * blockIdx.x] = fmax(fmax(smax[0], smax[1]), fmax(smax[2], smax[3]));
+    gpart[2 * blockIdx.x + 1] = tot;
   }
 }
 
 void launch_grad_norms(hipStream_t s, int nb, const int* blk_xoff, const int* blk_toff, const unsigned char* blk_size,
-                       const unsigned char* blk_manifold, const double* x, const double* grad, double* scal) {
+                       const unsigned char* blk_manifold, const double* x, const double* grad, double* gpart) {
   hipLaunchKernelGGL(grad_norms_kernel<false>, dim3((nb + 255) / 256), dim3(256), 0, s, nb, blk_xoff, blk_toff, blk_size,
-                     blk_manifold, x, grad, scal, PoseDiagArgs{});
+                     blk_manifold, x, grad, gpart, PoseDiagArgs{});
 }
 // gradient norms + pose_diag in one launch (both follow the assembly and are independent of each other)
 void launch_grad_norms_pose_diag(hipStream_t s, int nb, const int* blk_xoff, const int* blk_toff, const unsigned char* blk_size,
-                                 const unsigned char* blk_manifold, const double* x, const double* grad, double* scal, int n_pose, double* S,
+                                 const unsigned char* blk_manifold, const double* x, const double* grad, double* gpart, int n_pose, double* S,
                                  int ld, const double* hdiag, const double* radius_ptr, int compute_scale, int compute_dcl, int jacobi,
                                  double lm_lo, double lm_hi, double* scale, double* dcl, int npad, const int* iperm) {
   PoseDiagArgs pd;
   pd.n_pose = n_pose; pd.ld = ld; pd.compute_scale = compute_scale; pd.compute_dcl = compute_dcl; pd.jacobi = jacobi; pd.npad = npad;
   pd.S = S; pd.hdiag = hdiag; pd.radius_ptr = radius_ptr; pd.lm_lo = lm_lo; pd.lm_hi = lm_hi; pd.scale = scale; pd.dcl = dcl; pd.iperm = iperm;
   const int grid = (std::max(nb, npad) + 255) / 256;
-  hipLaunchKernelGGL(grad_norms_kernel<true>, dim3(grid), dim3(256), 0, s, nb, blk_xoff, blk_toff, blk_size, blk_manifold, x, grad, scal, pd);
+  hipLaunchKernelGGL(grad_norms_kernel<true>, dim3(grid), dim3(256), 0, s, nb, blk_xoff, blk_toff, blk_size, blk_manifold, x, grad, gpart, pd);
 }
 
 // fixed-order sums of partial arrays (one workgroup): reproducible cost / model-cost-change values
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(1024) void final_reduce_kernel(const ReduceEntry* _
     return;
   }
   double acc = 0.0;
-  bool any = false;
+  bool any = false, is_max = false;
   for (int e = 0; e < n_entries; ++e) {
     const ReduceEntry en = entries[e];
     if (en.slot != slot) continue;
@@ -159,16 +160,26 @@ __global__ __launch_bounds__(1024) void final_reduce_kernel(const ReduceEntry* _
 #pragma unroll
       for (int u = 0; u < 4; ++u) a[u] += en.ptr[(size_t)(i + 1024 * u) * en.stride + en.offset];
     }
+    if (en.op == 1) {   // (a maximum: one entry per slot)
+      is_max = true;
+      for (; i < en.n; i += 1024) acc = fmax(acc, en.ptr[(size_t)i * en.stride + en.offset]);
+      continue;
+    }
     for (; i < en.n; i += 1024) a[0] += en.ptr[(size_t)i * en.stride + en.offset];
     acc += (a[0] + a[1]) + (a[2] + a[3]);
   }
-  acc = wave_sum(acc);
+  if (is_max) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc = fmax(acc, __shfl_xor(acc, o, 64));
+  } else {
+    acc = wave_sum(acc);
+  }
   if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {
     double t = 0.0;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) t += sred[w];
+    for (int w = 0; w < 16; ++w) t = is_max ? fmax(t, sred[w]) : t + sred[w];
     if (any) scal[slot] = t;
     // mirror in pinned host memory: the host reads the step's scalars right after the stream drains, without a
     // device-to-host copy of its own on the dependent path
