@@ -18,8 +18,14 @@ def build(force=False):
     so = os.path.join(_HERE, "libbs_oracle.so")
     srcs = [os.path.join(_HERE, f) for f in ("bs_oracle.cpp", "functors.h", "jet.h")] + \
            [os.path.join(os.path.dirname(_HERE), "include", "bsgpu.h")]
-    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    def stale():
+        return force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if stale():
+        import fcntl
+        with open(os.path.join(_HERE, ".build.lock"), "w") as lock:   # (pytest-xdist workers: one builds, the others wait and find it fresh)
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if stale():
+                subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so
 
 
