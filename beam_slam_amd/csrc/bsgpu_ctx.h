@@ -205,6 +205,9 @@ struct bsgpu_ctx {
   hipEvent_t pcg_ev[2] = {nullptr, nullptr};
   hipEvent_t ev_reduce = nullptr;   // recorded after the end-of-step reduction: what the host waits for (work may be queued behind it)
   bool ev_reduce_pending = false;
+  int* d_reduce_counter = nullptr;  // final_reduce_kernel's ticket (the last workgroup stamps the host mirror with reduce_seq)
+  double reduce_seq = 0.0;          // sequence number of the last end-of-step reduction enqueued
+  bool seq_pending = false;         // ... and the host may poll for it instead of waiting for an event
   // block-sparse PCG path
   std::vector<uint8_t> leaf_tile;   // per natural tile of the reduced system: made of inverse-depth landmarks only (finalize)
   int n_leaf_tiles = 0;

@@ -875,6 +875,8 @@ int finalize(bsgpu_ctx* c) {
     tab.push_back({c->d_part_upd, c->n_part_upd, 2, 1, SC_X_NORM2});
     c->n_reduce = (int)tab.size();
     c->d_reduce = c->upload(tab);
+    c->d_reduce_counter = c->alloc<int>(1);
+    if (c->d_reduce_counter) HIPCHK(c, hipMemsetAsync(c->d_reduce_counter, 0, sizeof(int), c->stream));
   }
   lap("plan + reduce table");
   HIPCHK(c, hipDeviceSynchronize());

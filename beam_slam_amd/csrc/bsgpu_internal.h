@@ -48,6 +48,7 @@ enum {
   SC_CHOL_FAIL = 7,  // > 0 when a pivot was not positive / finite
   SC_FIXED_COST = 8,
   SC_RADIUS = 12,    // trust-region radius of the step being computed (written by the host before each step)
+  SC_SEQ = 15,       // (host mirror only) sequence number of the end-of-step reduction that filled the mirror
   SC_NUM = 16
 };
 
@@ -321,7 +322,8 @@ void launch_zero4(hipStream_t s, double* p0, int64_t n0, double* p1, int64_t n1,
 void launch_zero_tiles_multi(hipStream_t s, double* S, int ld, const int* tiles_dev, int n_tiles, double* a, int na, double* b, int nb, double* c,
                              int nc, double* radius_slot, double radius);
 void launch_copy(hipStream_t s, const double* src, double* dst, int64_t n, int nzero_after);
-void launch_final_reduce(hipStream_t s, const ReduceEntry* entries, int n_entries, int n_slots, double* scal, double* host_scal);
+void launch_final_reduce(hipStream_t s, const ReduceEntry* entries, int n_entries, int n_slots, double* scal, double* host_scal,
+                         int* counter = nullptr, double seq = 0.0);
 
 // measurement: the reprojection Jacobian kernel alone
 void launch_reproj_jacobian_only(hipStream_t s, const Visual& v, const double* x, const DevCamera* cams,

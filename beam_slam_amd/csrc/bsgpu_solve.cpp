@@ -195,8 +195,14 @@ void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot) {
   if (with_J) phase_mark(c, BSGPU_PHASE_EVAL_OTHER);
 }
 void final_reduce(bsgpu_ctx* c) {
-  launch_final_reduce(c->stream, c->d_reduce, c->n_reduce, SC_GRAD_NORM2 + 1, c->d_scal, c->h_scal_dev);
+  // (BSGPU_SCALARS_EVENT=1: the host waits for an event recorded behind the reduction instead of polling the mirror's stamp)
+  static const bool by_event = getenv("BSGPU_SCALARS_EVENT") != nullptr;
+  const bool stamp = !c->use_graphs && !by_event && c->h_scal_dev != nullptr && c->d_reduce_counter != nullptr && c->n_reduce > 0;
+  if (stamp) c->reduce_seq += 1.0;
+  launch_final_reduce(c->stream, c->d_reduce, c->n_reduce, SC_GRAD_NORM2 + 1, c->d_scal, c->h_scal_dev, stamp ? c->d_reduce_counter : nullptr, c->reduce_seq);
   c->scal_mirrored = c->h_scal_dev != nullptr && c->n_reduce > 0;
+  c->seq_pending = stamp;
+  if (stamp) { c->ev_reduce_pending = false; return; }
   // (not under graph capture / replay: an event recorded while capturing is a graph node, not something the host can wait on)
   if (c->use_graphs) { c->ev_reduce_pending = false; return; }
   if (!c->ev_reduce && hipEventCreateWithFlags(&c->ev_reduce, hipEventDisableTiming) != hipSuccess) { c->ev_reduce = nullptr; (void)hipGetLastError(); }
@@ -487,13 +493,27 @@ int ensure_vis_src(bsgpu_ctx* c) {
 
 int fetch_scalars(bsgpu_ctx* c) {
   HIPCHK(c, hipGetLastError());  // a kernel that failed to launch must not pass silently
-  if (c->scal_mirrored && c->ev_reduce_pending) {
+  if (c->scal_mirrored && c->seq_pending) {
+    // the step's scalars are complete in the pinned mirror once its stamp shows this reduction's number; kernels queued behind the
+    // reduction keep running.  (A device fault never stamps: after two seconds the stream is asked.)
+    const volatile double* stamp = &c->h_scal[SC_SEQ];
+    const auto t0 = std::chrono::steady_clock::now();
+    long spins = 0;
+    while (__atomic_load_n(reinterpret_cast<const volatile uint64_t*>(stamp), __ATOMIC_ACQUIRE) != *reinterpret_cast<const uint64_t*>(&c->reduce_seq)) {
+      __builtin_ia32_pause();
+      if ((++spins & 0xfff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (*stamp != c->reduce_seq) return fail(c, BSGPU_ERR_DEVICE, "the end-of-step reduction did not report (device fault?)");
+        break;
+      }
+    }
+  } else if (c->scal_mirrored && c->ev_reduce_pending) {
     HIPCHK(c, hipEventSynchronize(c->ev_reduce));   // the step's scalars are in the pinned mirror; kernels queued behind the reduction keep running
   } else {
     if (!c->scal_mirrored) HIPCHK(c, hipMemcpyAsync(c->h_scal, c->d_scal, sizeof(double) * SC_NUM, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
-  c->scal_mirrored = false; c->ev_reduce_pending = false;
+  c->scal_mirrored = false; c->ev_reduce_pending = false; c->seq_pending = false;
   return BSGPU_OK;
 }
 

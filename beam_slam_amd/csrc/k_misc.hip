@@ -137,12 +137,28 @@ void launch_sum(hipStream_t s, const double* part, int n, double* out, int accum
 }
 // One launch at the end of an LM step: workgroup `slot` adds up, in a fixed order, every partial array
 // registered for that scalar (costs of the factor groups, model-cost-change terms, step / x norms).
+// The host does not wait for an event behind this kernel (recording one costs the next kernel ~6 us of dispatch bubble): the LAST
+// workgroup to finish — all host-side writes of a workgroup are thread 0's, fenced at system scope before it takes its ticket —
+// stamps the mirror with the launch's sequence number, which the host polls (bsgpu_solve.cpp: fetch_scalars).
+BSG_DEV void final_reduce_done(double* host_scal, int* counter, double seq) {
+  if (!counter) return;
+  __threadfence_system();
+  const int prev = __hip_atomic_fetch_add(counter, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  if (prev == (int)gridDim.x - 1) {
+    __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    if (host_scal) __hip_atomic_store(&host_scal[SC_SEQ], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
 __global__ __launch_bounds__(1024) void final_reduce_kernel(const ReduceEntry* __restrict__ entries, int n_entries, int n_slots,
-                                                            double* __restrict__ scal, double* __restrict__ host_scal) {
+                                                            double* __restrict__ scal, double* __restrict__ host_scal, int* counter, double seq) {
   __shared__ double sred[16];
   const int slot = blockIdx.x;
   if (slot == n_slots) {   // the scalars earlier kernels of the step produced (gradient norms, Cholesky flag, ...) -> host mirror
-    if (host_scal) for (int i = n_slots + threadIdx.x; i < SC_NUM; i += 1024) host_scal[i] = scal[i];
+    if (threadIdx.x == 0) {
+      if (host_scal) for (int i = n_slots; i < SC_SEQ; ++i) host_scal[i] = scal[i];
+      final_reduce_done(host_scal, counter, seq);
+    }
     return;
   }
   double acc = 0.0;
@@ -184,10 +200,13 @@ __global__ __launch_bounds__(1024) void final_reduce_kernel(const ReduceEntry* _
     // mirror in pinned host memory: the host reads the step's scalars right after the stream drains, without a
     // device-to-host copy of its own on the dependent path
     if (host_scal) host_scal[slot] = any ? t : scal[slot];
+    final_reduce_done(host_scal, counter, seq);
   }
 }
-void launch_final_reduce(hipStream_t s, const ReduceEntry* entries, int n_entries, int n_slots, double* scal, double* host_scal) {
-  if (n_entries > 0) hipLaunchKernelGGL(final_reduce_kernel, dim3(n_slots + 1), dim3(1024), 0, s, entries, n_entries, n_slots, scal, host_scal);
+void launch_final_reduce(hipStream_t s, const ReduceEntry* entries, int n_entries, int n_slots, double* scal, double* host_scal, int* counter,
+                         double seq) {
+  if (n_entries > 0)
+    hipLaunchKernelGGL(final_reduce_kernel, dim3(n_slots + 1), dim3(1024), 0, s, entries, n_entries, n_slots, scal, host_scal, counter, seq);
 }
 
 // plain kernels instead of hipMemsetAsync / hipMemcpyAsync for the buffers of an LM step: the runtime's fill / copy
