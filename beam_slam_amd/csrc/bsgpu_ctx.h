@@ -174,6 +174,10 @@ struct bsgpu_ctx {
   double* d_gpart = nullptr;     // grad_norms_kernel: (max, sum of squares) per workgroup
   int n_gpart = 0;
   int n_part_upd = 0;
+  // the update riding in the landmark back-substitution (windows with eliminated Euclidean landmarks): UpdateRide's tables
+  int n_upd_blocks = 0;
+  int* d_upd_blocks = nullptr;
+  int* d_lm_xoff = nullptr;
   double *d_S = nullptr, *d_grad = nullptr, *d_hdiag = nullptr, *d_scale = nullptr, *d_dcl = nullptr;
   double *d_delta = nullptr, *d_y = nullptr, *d_scal = nullptr, *d_part = nullptr;
   double* h_scal = nullptr;  // pinned

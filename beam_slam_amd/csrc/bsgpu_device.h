@@ -151,6 +151,39 @@ BSG_DEV void wave_sum_transpose64(double (&v)[64]) {
     }
   }
 }
+// x (+) delta on one block: fuse's Orientation3DLocalParameterization::Plus on quaternion blocks (bs_constraints/src/jacobians.cpp:24-35:
+// x (x) AngleAxisToQuaternion(delta), right perturbation), a sum elsewhere
+BSG_DEV void block_plus(int manifold, int size, const double* x, const double* d, double* out) {
+  if (manifold == BSGPU_MANIFOLD_QUAT_RIGHT) {
+    double qd[4];
+    angle_axis_to_quat(d, qd);
+    const double q[4] = {x[0], x[1], x[2], x[3]};
+    quat_mul(q, qd, out);
+  } else {
+    for (int i = 0; i < size; ++i) out[i] = x[i] + d[i];
+  }
+}
+// the candidate of block b (a constant block: a copy) and its terms of |x_cand - x|^2 and |x|^2
+BSG_DEV void update_block(int b, const int* __restrict__ xoff, const int* __restrict__ toff, const unsigned char* __restrict__ size,
+                          const unsigned char* __restrict__ manifold, const double* __restrict__ x, const double* __restrict__ delta,
+                          double* __restrict__ x_cand, double& d2, double& x2) {
+  const int o = xoff[b], t = toff[b], sz = size[b];
+  if (t >= 0) {
+    double out[4];
+    double xin[4] = {0, 0, 0, 0}, din[4] = {0, 0, 0, 0};
+    const int ts = (manifold[b] == BSGPU_MANIFOLD_QUAT_RIGHT) ? 3 : sz;
+    for (int i = 0; i < sz && i < 4; ++i) xin[i] = x[o + i];
+    for (int i = 0; i < ts && i < 4; ++i) din[i] = delta[t + i];
+    block_plus(manifold[b], sz, xin, din, out);
+    for (int i = 0; i < sz && i < 4; ++i) {
+      x_cand[o + i] = out[i];
+      const double df = xin[i] - out[i];
+      d2 += df * df; x2 += xin[i] * xin[i];
+    }
+  } else {
+    for (int i = 0; i < sz; ++i) x_cand[o + i] = x[o + i];
+  }
+}
 // sum over a 256-thread block; result valid in thread 0
 BSG_DEV double block_sum_256(double v, double* smem /* >= 4 doubles */) {
   v = wave_sum(v);

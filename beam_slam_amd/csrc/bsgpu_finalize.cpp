@@ -847,6 +847,21 @@ int finalize(bsgpu_ctx* c) {
   }
   {
     c->n_part_upd = (nb + 255) / 256;
+    c->n_upd_blocks = 0; c->d_upd_blocks = nullptr; c->d_lm_xoff = nullptr;
+    if (c->vis.n_lm > 0 && !getenv("BSGPU_UPDATE_SEPARATE")) {
+      // the candidate update rides in the landmark back-substitution (k_reproj.hip: backsub_mcc_kernel): the eliminated Euclidean landmarks
+      // are updated by the lanes that compute their step, every other block by extra workgroups of that launch
+      std::vector<int> others, lm_xoff(c->vis.n_lm, 0);
+      for (int b = 0; b < nb; ++b) {
+        if (!c->is_const[b] && c->is_lm[b] == 1) lm_xoff[lm_index[b]] = c->off[b];
+        else others.push_back(b);
+      }
+      if (!others.empty()) {
+        c->n_upd_blocks = (int)others.size();
+        c->d_upd_blocks = c->upload(others); c->d_lm_xoff = c->upload(lm_xoff);
+        c->n_part_upd = (c->n_upd_blocks + 255) / 256 + (c->vis.n_lm * 8 + 255) / 256;   // update units, then the landmark workgroups
+      }
+    }
     c->d_part_upd = c->alloc<double>(2 * (size_t)c->n_part_upd + 2);
     std::vector<ReduceEntry> tab;
     if (c->vis.n) {

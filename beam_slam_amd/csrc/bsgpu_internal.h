@@ -161,6 +161,16 @@ void launch_idp_pairs(hipStream_t s, const IdpElim& e, const SmallGroup& g, doub
                       const int* perm, bool grad_only);
 void launch_idp_backsub(hipStream_t s, const IdpElim& e, const double* y_pose, double* delta);
 
+// the candidate x (+) delta of the blocks the landmark back-substitution does not update itself, as extra workgroups of that launch
+// (k_reproj.hip: backsub_mcc_kernel); the Euclidean landmark blocks are written by the lanes that compute their step
+struct UpdateRide {
+  int n_blocks = 0;                    // entries of `blocks` (0: the launch carries no update)
+  const int* blocks = nullptr;         // block indices: everything but the eliminated Euclidean landmarks
+  const int* xoff = nullptr; const int* toff = nullptr; const unsigned char* size = nullptr; const unsigned char* manifold = nullptr;
+  const int* lm_xoff = nullptr;        // eliminated Euclidean landmark -> offset of its block in x
+  const double* x = nullptr; double* x_cand = nullptr;
+  double* part = nullptr;              // (|x_cand - x|^2, |x|^2) per update unit, then per landmark workgroup
+};
 // entry of the end-of-step reduction table (k_misc.hip: final_reduce_kernel)
 struct ReduceEntry {
   const double* ptr;
@@ -309,7 +319,7 @@ int pcg_done_slot();
 int pcg_iters_slot();
 int backsub_mcc_groups(const Visual& v);   // workgroups (= model-cost partials) of launch_backsub_mcc
 void launch_backsub_mcc(hipStream_t s, const Visual& v, int n_pose, const double* y_pose, double* delta, double* mcc_part,
-                        const SmallGroupSet* small = nullptr, int n_small_units = 0);
+                        const SmallGroupSet* small = nullptr, int n_small_units = 0, const UpdateRide* upd = nullptr);
 int small_mcc_first_set(const SmallGroup* groups, double* const* parts, int n_groups, SmallGroupSet* set, int* n_taken);
 void launch_negate_pose(hipStream_t s, int n_pose, const double* y, double* delta);
 void launch_small_mcc_set(hipStream_t s, const SmallGroup* groups, double* const* parts, int n_groups, const double* delta);

@@ -343,7 +343,12 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
     SmallGroupSet set;
     int taken = 0, units = 0;
     if (backsub_mcc_groups(c->vis) > 0) units = small_mcc_first_set(c->small + 2, c->d_small_part_mcc + 2, kNumInternal - 2, &set, &taken);
-    launch_backsub_mcc(s, c->vis, c->n_pose, c->d_ytan, c->d_delta, c->vis.mcc_part, units > 0 ? &set : nullptr, units);
+    UpdateRide up;
+    if (c->n_upd_blocks > 0) {
+      up.n_blocks = c->n_upd_blocks; up.blocks = c->d_upd_blocks; up.xoff = c->d_blk_xoff; up.toff = c->d_blk_toff; up.size = c->d_blk_size;
+      up.manifold = c->d_blk_manifold; up.lm_xoff = c->d_lm_xoff; up.x = c->d_x; up.x_cand = c->d_xcand; up.part = c->d_part_upd;
+    }
+    launch_backsub_mcc(s, c->vis, c->n_pose, c->d_ytan, c->d_delta, c->vis.mcc_part, units > 0 ? &set : nullptr, units, c->n_upd_blocks > 0 ? &up : nullptr);
     if (units == 0) taken = 0;
     launch_small_mcc_set(s, c->small + 2 + taken, c->d_small_part_mcc + 2 + taken, kNumInternal - 2 - taken, c->d_delta);
   }
@@ -351,8 +356,9 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
     if (mc.active) launch_marg_mcc(s, mc.dev, c->d_delta, mc.part_mcc);
   phase_mark(c, BSGPU_PHASE_BACKSUB);
   int n_part = 0;
-  launch_update(s, c->nb, c->d_blk_xoff, c->d_blk_toff, c->d_blk_size, c->d_blk_manifold, c->d_x, c->d_delta, c->d_xcand,
-                c->d_part_upd, &n_part);
+  if (c->n_upd_blocks == 0)   // (else the update rode in the landmark back-substitution above)
+    launch_update(s, c->nb, c->d_blk_xoff, c->d_blk_toff, c->d_blk_size, c->d_blk_manifold, c->d_x, c->d_delta, c->d_xcand,
+                  c->d_part_upd, &n_part);
   eval_all(c, c->d_xcand, false, SC_COST_CAND);
   final_reduce(c);
   phase_mark(c, BSGPU_PHASE_CANDIDATE);

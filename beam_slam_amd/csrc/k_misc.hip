@@ -8,17 +8,7 @@
 
 namespace bsg {
 
-BSG_DEV void block_plus(int manifold, int size, const double* x, const double* d, double* out) {
-  if (manifold == BSGPU_MANIFOLD_QUAT_RIGHT) {
-    double qd[4];
-    angle_axis_to_quat(d, qd);
-    const double q[4] = {x[0], x[1], x[2], x[3]};
-    quat_mul(q, qd, out);
-  } else {
-    for (int i = 0; i < size; ++i) out[i] = x[i] + d[i];
-  }
-}
-
+// (block_plus and the update of one block: bsgpu_device.h — shared with the launch that carries the update, k_reproj.hip)
 // x_cand = x (+) delta for every block; per-workgroup partials of |x_cand - x|^2 and |x|^2 over the
 // non-constant blocks (ceres: step_norm, x_norm)
 __global__ __launch_bounds__(256) void update_kernel(int nb, const int* __restrict__ xoff, const int* __restrict__ toff,
@@ -29,24 +19,7 @@ __global__ __launch_bounds__(256) void update_kernel(int nb, const int* __restri
   __shared__ double sred[4];
   const int b = blockIdx.x * 256 + threadIdx.x;
   double d2 = 0.0, x2 = 0.0;
-  if (b < nb) {
-    const int o = xoff[b], t = toff[b], sz = size[b];
-    if (t >= 0) {
-      double out[4];
-      double xin[4] = {0, 0, 0, 0}, din[4] = {0, 0, 0, 0};
-      const int ts = (manifold[b] == BSGPU_MANIFOLD_QUAT_RIGHT) ? 3 : sz;
-      for (int i = 0; i < sz && i < 4; ++i) xin[i] = x[o + i];
-      for (int i = 0; i < ts && i < 4; ++i) din[i] = delta[t + i];
-      block_plus(manifold[b], sz, xin, din, out);
-      for (int i = 0; i < sz && i < 4; ++i) {
-        x_cand[o + i] = out[i];
-        const double df = xin[i] - out[i];
-        d2 += df * df; x2 += xin[i] * xin[i];
-      }
-    } else {
-      for (int i = 0; i < sz; ++i) x_cand[o + i] = x[o + i];
-    }
-  }
+  if (b < nb) update_block(b, xoff, toff, size, manifold, x, delta, x_cand, d2, x2);
   const double a = block_sum_256(d2, sred);
   const double c = block_sum_256(x2, sred);
   if (threadIdx.x == 0) { part[2 * blockIdx.x] = a; part[2 * blockIdx.x + 1] = c; }

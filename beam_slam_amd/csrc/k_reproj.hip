@@ -407,8 +407,20 @@ __global__ __launch_bounds__(256) void backsub_mcc_kernel(int n_lm, int n_lm_gro
                                                           const int* __restrict__ cp_tq, const int* __restrict__ cp_tp,
                                                           const double* __restrict__ Linv, const double* __restrict__ z, int n_pose,
                                                           const double* __restrict__ y_pose, double* __restrict__ delta,
-                                                          double* __restrict__ mcc_part, int n_vis_blocks, SmallGroupSet small, int n_small_units) {
+                                                          double* __restrict__ mcc_part, int n_vis_blocks, SmallGroupSet small, int n_small_units,
+                                                          UpdateRide up, int first_update_block) {
   __shared__ double sred[4];
+  if (up.n_blocks > 0 && (int)blockIdx.x >= first_update_block) {
+    // the candidate of every block but the Euclidean landmarks (those: below, by the lanes that compute their step): the pose step is
+    // complete when this launch starts, so the update needs no launch of its own behind it
+    const int unit = (int)blockIdx.x - first_update_block, i = unit * 256 + (int)threadIdx.x;
+    double d2 = 0.0, x2 = 0.0;
+    if (i < up.n_blocks) update_block(up.blocks[i], up.xoff, up.toff, up.size, up.manifold, up.x, delta, up.x_cand, d2, x2);
+    const double a = block_sum_256(d2, sred);
+    const double c = block_sum_256(x2, sred);
+    if (threadIdx.x == 0) { up.part[2 * unit] = a; up.part[2 * unit + 1] = c; }
+    return;
+  }
   if ((int)blockIdx.x >= n_vis_blocks) {
     // the model-cost terms of the pose-only factors (they need the pose step only) as extra workgroups: two 128-row units each
     const int unit = 2 * ((int)blockIdx.x - n_vis_blocks) + ((int)threadIdx.x >> 7);
@@ -416,7 +428,7 @@ __global__ __launch_bounds__(256) void backsub_mcc_kernel(int n_lm, int n_lm_gro
     else __syncthreads();
     return;
   }
-  double acc = 0.0;
+  double acc = 0.0, upd_d2 = 0.0, upd_x2 = 0.0;
   if ((int)blockIdx.x < n_lm_groups) {
     const int gid = blockIdx.x * 256 + threadIdx.x;
     const int l = gid >> 3, sub = gid & 7;
@@ -445,7 +457,18 @@ __global__ __launch_bounds__(256) void backsub_mcc_kernel(int n_lm, int n_lm_gro
       const double y0 = Li[0] * w0 + Li[1] * w1 + Li[3] * w2;
       const double y1 = Li[2] * w1 + Li[4] * w2;
       const double y2 = Li[5] * w2;
-      if (sub == 0) { const int to = n_pose + 3 * l; delta[to] = -y0; delta[to + 1] = -y1; delta[to + 2] = -y2; }
+      if (sub == 0) {
+        const int to = n_pose + 3 * l;
+        delta[to] = -y0; delta[to + 1] = -y1; delta[to + 2] = -y2;
+        if (up.n_blocks > 0) {   // the landmark's candidate and its terms of the step / x norms
+          const int xo = up.lm_xoff[l];
+          const double x0 = up.x[xo], x1 = up.x[xo + 1], x2v = up.x[xo + 2];
+          const double c0 = x0 + (-y0), c1 = x1 + (-y1), c2 = x2v + (-y2);
+          up.x_cand[xo] = c0; up.x_cand[xo + 1] = c1; up.x_cand[xo + 2] = c2;
+          const double e0 = x0 - c0, e1 = x1 - c1, e2 = x2v - c2;
+          upd_d2 = e0 * e0 + e1 * e1 + e2 * e2; upd_x2 = x0 * x0 + x1 * x1 + x2v * x2v;
+        }
+      }
       it = 0;
       for (int f = beg + sub; f < end; f += 8, ++it) {
         const double* Bf = JB + (size_t)f * 6;
@@ -470,16 +493,24 @@ __global__ __launch_bounds__(256) void backsub_mcc_kernel(int n_lm, int n_lm_gro
   }
   const double tot = block_sum_256(acc, sred);
   if (threadIdx.x == 0) mcc_part[blockIdx.x] = tot;
+  if (up.n_blocks > 0 && (int)blockIdx.x < n_lm_groups) {   // (after the update units' pairs in `part`)
+    const double a = block_sum_256(upd_d2, sred);
+    const double c = block_sum_256(upd_x2, sred);
+    const int slot = (up.n_blocks + 255) / 256 + (int)blockIdx.x;
+    if (threadIdx.x == 0) { up.part[2 * slot] = a; up.part[2 * slot + 1] = c; }
+  }
 }
 
 int backsub_mcc_groups(const Visual& v) { return (v.n_lm * 8 + 255) / 256 + (v.n - v.n_elim + 255) / 256; }
 void launch_backsub_mcc(hipStream_t s, const Visual& v, int n_pose, const double* y_pose, double* delta, double* mcc_part,
-                        const SmallGroupSet* small, int n_small_units) {
+                        const SmallGroupSet* small, int n_small_units, const UpdateRide* upd) {
   const int g_lm = (v.n_lm * 8 + 255) / 256, grid = backsub_mcc_groups(v);
   if (grid == 0) return;
   const int extra = small ? (n_small_units + 1) / 2 : 0;
-  hipLaunchKernelGGL(backsub_mcc_kernel, dim3(grid + extra), dim3(256), 0, s, v.n_lm, g_lm, v.n_elim, v.n, v.lm_start, v.J, v.JB, v.r, v.CR, v.cam_pose,
-                     v.cp_tq, v.cp_tp, v.Linv, v.z, n_pose, y_pose, delta, mcc_part, grid, small ? *small : SmallGroupSet(), small ? n_small_units : 0);
+  const int upd_units = (upd && upd->n_blocks > 0) ? (upd->n_blocks + 255) / 256 : 0;
+  hipLaunchKernelGGL(backsub_mcc_kernel, dim3(grid + extra + upd_units), dim3(256), 0, s, v.n_lm, g_lm, v.n_elim, v.n, v.lm_start, v.J, v.JB, v.r, v.CR, v.cam_pose,
+                     v.cp_tq, v.cp_tp, v.Linv, v.z, n_pose, y_pose, delta, mcc_part, grid, small ? *small : SmallGroupSet(), small ? n_small_units : 0,
+                     upd_units ? *upd : UpdateRide(), grid + extra);
 }
 
 }  // namespace bsg

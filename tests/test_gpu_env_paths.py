@@ -63,6 +63,7 @@ SETTINGS = [
     {"BSGPU_FLATTEN": "host"},
     {"BSGPU_FLATTEN": "host", "BSGPU_PAIR_ENTRIES_SORT": "1"},
     {"BSGPU_SCALARS_EVENT": "1"},                                # the host waits for an event behind the end-of-step reduction, not for the mirror's stamp
+    {"BSGPU_UPDATE_SEPARATE": "1"},                              # the candidate update as a launch of its own
     {"BSGPU_EVAL_MERGE": "0"},                                   # the IMU factors evaluated by a launch of their own
     {"BSGPU_EVAL_MERGE": "1"},                                   # ... in the passes with Jacobians only    # pair entries by a comparison sort (windows of > 2 896 camera poses)
 ]
