@@ -3,8 +3,9 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "").replace("bsg::", "")) for r in rows))
 n = len(ev)
 # find an iteration start late in the run: a reproj_eval_kernel<true> following final_reduce
-idx = [i for i in range(n // 2, n - 1) if ev[i][2].startswith("reproj_eval_kernel<true>") and ev[i - 1][2].startswith("final_reduce")]
-i0 = idx[3]
+starts = ("visual_imu_eval_kernel<true>", "reproj_eval_kernel<true>", "relpose_imu_eval_kernel<true, true>")
+idx = [i for i in range(n // 2, n - 1) if ev[i][2].startswith(starts) and ev[i - 1][2].startswith("final_reduce")]
+i0 = idx[min(3, len(idx) - 1)]
 t0 = ev[i0][0]
 for s, e, nm in ev[i0 - 2:i0 + 45]:
     print("%9.1f  %7.1f  %s" % ((s - t0) / 1e3, (e - s) / 1e3, nm[:50]))
