@@ -4,22 +4,23 @@
 // elimination is what [EXT] Ceres' SCHUR solvers do with the landmark blocks of vo_params.json's windows (use_idp: true).
 //
 // A binary factor f of landmark l has the robustified row block  J_f = [A_a (2x6) | A_m (2x6) | w (2x1)]  (idp_kernel, k_small.hip:
-// theta_a, p_a, theta_m, p_m, rho).  The pose-pose part J^T J of the factors is assembled with the pose-only groups (their rho slot
-// masked); what the scalar landmark adds is
+// theta_a, p_a, theta_m, p_m, rho).  What the scalar landmark adds to the pose-pose part J^T J of its factors is
 //   h = sum w^T w + lambda,   g = sum w^T r,   linv = h^-1/2,   z = linv g,   c_f = w_f linv
 //   u_v = sum_{f sees view v} A_{f,v}^T c_f                                 (6-vector per (landmark, camera pose) view)
 //   S(i, j)  -= sum_l u_{l,i} u_{l,j}^T,      rhs(i) -= sum_l u_{l,i} z_l
-//   y_l = linv (z - sum_f c_f^T (A_a y_a + A_m y_m)),   delta_rho = -y_l
+//   y_l = linv (z - sum_f c_f^T (A_a y_a + A_m y_m)) = linv (z - sum_v u_v . y_cam(v)),   delta_rho = -y_l
 // — the scalar case of landmark_kernel / pairs_kernel / backsub_mcc_kernel of k_reproj.hip.  When every binary factor of the window has
 // an eliminated landmark (IdpElim::direct) the factors' own pose-pose terms — A_a^T A_a, A_m^T A_m per view, A_a^T A_m per factor,
 // the gradient A^T r and diag(A^T A) — are added by the same pair kernel, and the group leaves the generic pose-only assembly (whose
-// host-side contribution lists were 50 of the 60 ms of finalize() for a 90 000-factor window).  Four launches:
+// host-side contribution lists were 50 of the 60 ms of finalize() for a 90 000-factor window); otherwise — some inverse depth constant,
+// or shared with another factor — those terms stay with the pose-only groups, the rho slot masked.  Four launches:
 //   idp_landmark_kernel   one lane per landmark: h, g, the LM diagonal and Jacobi scale of rho, c of its factors
 //   idp_view_kernel       one lane per view: u (and D = sum A^T A, sum A^T r)
 //   idp_pairs_kernel      one wave per camera-pose pair segment: 6x6 block sum of -u_a u_b^T (+ the direct terms, the rhs)
 //   idp_backsub_kernel    one lane per landmark: the step of rho from the pose step
-// Algorithmic bytes: 256 per factor (J 240 + r 16) read by the landmark / view / back-substitution kernels, 64 (+ 384) per view
-// written once and read once per pair entry (diagonal entry).
+// Algorithmic bytes: 256 per factor (J 240 + r 16) read by the landmark and view kernels (and by the pair kernel for the factor's cross
+// term and for a view of one factor), 64 per view (+ 384 for a view of several factors: the anchor) written once and read once per
+// pair entry (diagonal entry); the back-substitution reads the views only.
 #include "bsgpu_device.h"
 
 namespace bsg {
