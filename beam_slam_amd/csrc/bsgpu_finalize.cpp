@@ -497,6 +497,8 @@ int finalize(bsgpu_ctx* c) {
     struct Contrib { int ra, rb, tf, ss; };
     std::vector<Contrib> cl, tmp;
     std::vector<int> cnt;
+    std::vector<AsmGroup> asm_grp;
+    std::vector<int> asm_gfac;
     auto sort_by_block = [&](size_t lo, size_t hi) {   // cl[lo, hi) by (ra, rb), stable: LSD counting sort, rb then ra
       const size_t n = hi - lo;
       if (n < 2) return;
@@ -523,10 +525,49 @@ int finalize(bsgpu_ctx* c) {
       HIPCHK(c, hipStreamSynchronize(c->stream));   // (the table went up asynchronously on the context's stream)
       HIPCHK(c, hipMemcpy(toffs.data(), sg.toff, sizeof(int) * toffs.size(), hipMemcpyDeviceToHost));
       for (int& v : toffs) if (v >= c->n_pose) v = -1;   // (eliminated inverse-depth slots: k_idp.hip)
+      // factors that name the same variable in every slot (the ~21 lidar constraints between two keyframes of a lidar-inertial window):
+      // groups of at least kGroupMin, summed a wave per group (k_small.hip: small_assemble_group); the others by segments / by factors
+      std::vector<uint8_t> grouped(sg.n, 0);
+      bool any_group = false;
+      int hub_mask = 0;
+      constexpr int kGroupMin = 4;
+      if (sg.w_last == 3 && nv * 3 <= 18 && sg.m <= 6 && (sg.m * nv * 3) % 2 == 0 && sg.n >= 64 && !getenv("BSGPU_NO_GROUP_ASSEMBLY")) {
+        std::vector<int> order;
+        order.reserve(sg.n);
+        for (int f = 0; f < sg.n; ++f) if (c->h_small_active[t][f]) order.push_back(f);
+        auto key_less = [&](int a, int b) {
+          const int* ka = &toffs[(size_t)a * nv]; const int* kb = &toffs[(size_t)b * nv];
+          for (int i = 0; i < nv; ++i) if (ka[i] != kb[i]) return ka[i] < kb[i];
+          return a < b;
+        };
+        std::sort(order.begin(), order.end(), key_less);
+        // a slot that holds the same few variables in every factor (the extrinsics of the relative-pose constraints): its block with
+        // itself would take one add per GROUP on the same addresses — those entries stay with the segments, which add once per 64 factors
+        for (int sl = 0; sl < nv; ++sl) {
+          std::vector<int> seen;
+          for (int f : order) {
+            const int v = toffs[(size_t)f * nv + sl];
+            if (std::find(seen.begin(), seen.end(), v) == seen.end()) { seen.push_back(v); if (seen.size() > 4) break; }
+          }
+          if (seen.size() <= 4) hub_mask |= 1 << sl;
+        }
+        for (size_t i = 0; i < order.size();) {
+          size_t j = i + 1;
+          while (j < order.size() && std::equal(&toffs[(size_t)order[i] * nv], &toffs[(size_t)order[i] * nv] + nv, &toffs[(size_t)order[j] * nv])) ++j;
+          if ((int)(j - i) >= kGroupMin) {
+            for (size_t q0 = i; q0 < j; q0 += 32)   // (one pass through LDS per workgroup: a large group is cut)
+              asm_grp.push_back({t, (int)asm_gfac.size() + (int)(q0 - i), (int)std::min<size_t>(32, j - q0), hub_mask});
+            for (size_t q = i; q < j; ++q) { asm_gfac.push_back(order[q]); grouped[order[q]] = 1; }
+            any_group = true;
+          }
+          i = j;
+        }
+      }
       const size_t first = cl.size();
       for (int f = 0; f < sg.n; ++f) {
         if (!c->h_small_active[t][f]) continue;
         for (int sa = 0; sa < nv; ++sa) for (int sb = 0; sb < nv; ++sb) {
+          if (grouped[f] && !(((hub_mask >> sa) & 1) && ((hub_mask >> sb) & 1))) continue;   // (a grouped factor: only its hub x hub blocks)
           const int ra = toffs[(size_t)f * nv + sa], rb = toffs[(size_t)f * nv + sb];
           if (ra < 0 || rb < 0) continue;
           if (ra < rb) continue;   // (the block above the diagonal is the transpose of the one below: the kernel writes both, §3 of DESIGN.md)
@@ -537,7 +578,7 @@ int finalize(bsgpu_ctx* c) {
       sort_by_block(first, cl.size());
       size_t n_blocks = 0;
       for (size_t i = first; i < cl.size(); ++i) if (i == first || cl[i].ra != cl[i - 1].ra || cl[i].rb != cl[i - 1].rb) ++n_blocks;
-      if (n_blocks && (cl.size() - first) >= 2 * n_blocks) c->small_factorwise[t].n = 0;   // by segments (lower blocks only: half the contributions of the full pattern)
+      if (any_group || (n_blocks && (cl.size() - first) >= 2 * n_blocks)) c->small_factorwise[t].n = 0;   // by segments (lower blocks only: half the contributions of the full pattern; a type with groups: its other factors too)
       else cl.resize(first);                                                                // by factors
     }
     sort_by_block(0, cl.size());
@@ -553,6 +594,13 @@ int finalize(bsgpu_ctx* c) {
     c->n_sa_seg = (int)seg_ra.size();
     c->d_sa_seg_start = c->upload(seg_start); c->d_sa_seg_ra = c->upload(seg_ra); c->d_sa_seg_rb = c->upload(seg_rb);
     c->d_sa_contrib = c->upload(contrib);
+    c->n_asm_grp = (int)asm_grp.size();
+    if (timing && !asm_grp.empty()) {
+      int mx = 0;
+      for (const AsmGroup& gq : asm_grp) mx = std::max(mx, gq.count);
+      fprintf(stderr, "[bsgpu finalize] same-slot groups: %d groups, %d factors, largest %d, hub mask %d\n", (int)asm_grp.size(), (int)asm_gfac.size(), mx, asm_grp[0].pad);
+    }
+    c->d_asm_grp = c->upload(asm_grp); c->d_asm_gfac = c->upload(asm_gfac);
     if (timing) lap("  lists: contributions");
     std::vector<SmallGroup> groups(c->small, c->small + kNumInternal);
     c->d_small_groups = c->upload(groups);

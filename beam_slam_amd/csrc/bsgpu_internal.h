@@ -207,9 +207,13 @@ void launch_pairs(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row
 int small_assemble_first_set(const SmallGroup* groups, int n_groups, SmallGroupSet* set, int* n_taken);
 void launch_small_assemble_set(hipStream_t s, const SmallGroup* groups, int n_groups, double* S, int ld, int rhs_row, double* grad,
                                double* hdiag, const int* perm);
+// factors of one pose-only type that name the SAME variables in every slot (the ~21 lidar constraints between two keyframes of a
+// lidar-inertial window): their J^T J is summed by one wave before it is added to the reduced system (k_small.hip: small_assemble_group)
+struct AsmGroup { int type, first, count, pad; };   // factors gfac[first .. first + count)
 void launch_small_assemble_seg(hipStream_t s, const SmallGroup* groups_dev, int n_seg, const int* seg_start, const int* seg_ra, const int* seg_rb,
                                const int2* contrib, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm,
-                               const SmallGroupSet* fw = nullptr, int n_fw_units = 0);
+                               const SmallGroupSet* fw = nullptr, int n_fw_units = 0, int n_grp = 0, const AsmGroup* grp = nullptr,
+                               const int* gfac = nullptr);
 void launch_pose_diag(hipStream_t s, int n_pose, double* S, int ld, const double* hdiag, const double* radius_ptr,
                       int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* scale,
                       double* dcl, int npad, const int* iperm);

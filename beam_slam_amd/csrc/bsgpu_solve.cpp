@@ -243,12 +243,12 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
     // (... or, without a pair launch, in the launch of the segment-wise assembled groups)
     SmallGroupSet set2;
     int taken2 = 0, units2 = 0;
-    if (units == 0 && c->n_sa_seg > 0) units2 = small_assemble_first_set(c->small_factorwise + 2, kNumInternal - 2, &set2, &taken2);
+    if (units == 0 && c->n_sa_seg + c->n_asm_grp > 0) units2 = small_assemble_first_set(c->small_factorwise + 2, kNumInternal - 2, &set2, &taken2);
     if (units2 == 0) taken2 = 0;
     launch_small_assemble_set(s, c->small_factorwise + 2 + taken + taken2, kNumInternal - 2 - taken - taken2, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag,
                               c->d_perm);
     launch_small_assemble_seg(s, c->d_small_groups, c->n_sa_seg, c->d_sa_seg_start, c->d_sa_seg_ra, c->d_sa_seg_rb, c->d_sa_contrib, c->d_S, c->npad,
-                              c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm, units2 > 0 ? &set2 : nullptr, units2);
+                              c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm, units2 > 0 ? &set2 : nullptr, units2, c->n_asm_grp, c->d_asm_grp, c->d_asm_gfac);
   }
   for (const auto& mc : c->marg)
     if (mc.active) launch_marg_assemble(s, mc.dev, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm);

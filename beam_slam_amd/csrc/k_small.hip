@@ -832,12 +832,82 @@ BSG_DEV double sum16(double v) {   // over an aligned group of sixteen lanes
   for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// One workgroup per GROUP of factors that share every slot's variable: the group's rows go through LDS 32 factors at a time (coalesced
+// 16-byte loads; a lane walking them in global memory waited out a round trip per row: 520 us for C3's largest group), thread e owns
+// one of the tw (tw + 1) / 2 entries on and below the diagonal of J^T J (tw <= 18 tangent columns) or of the tw entries of J^T r, and
+// the sums are added to the reduced system once per group — 20 000 relative-pose factors of C3 over ~950 keyframe pairs: one set of
+// atomics per pair instead of one per 64 contributions per 3x3 block.
+constexpr int kGroupChunk = 32;           // factors per pass through LDS
+constexpr int kGroupRowMax = 6 * 18;      // doubles of J per factor (m <= 6 rows of tw <= 18)
+BSG_DEV void small_assemble_group(const SmallGroup* __restrict__ groups, const AsmGroup G, const int* __restrict__ gfac, double* sJ /* kGroupChunk x 108 */,
+                                  double* sr /* kGroupChunk x 6 */, double* __restrict__ S, int ld, int rhs_row, double* __restrict__ grad,
+                                  double* __restrict__ hdiag, const int* __restrict__ perm) {
+  const SmallGroup g = groups[G.type];
+  const int nv = g.nv, tw = 3 * nv, m = g.m, n_ent = tw * (tw + 1) / 2, per = m * tw;
+  const int e = threadIdx.x;
+  bool on = e < n_ent + tw;
+  const bool is_rhs = e >= n_ent;
+  int er = 0, ec = 0;
+  if (on) {
+    if (!is_rhs) { while ((er + 1) * (er + 2) / 2 <= e) ++er; ec = e - er * (er + 1) / 2; }
+    else er = e - n_ent;
+    // (G.pad: slots whose variable nearly every group shares; their block with themselves, their gradient and diagonal: by segments)
+    const int hr = (G.pad >> (er / 3)) & 1, hc = (G.pad >> (ec / 3)) & 1;
+    if (is_rhs ? hr : (hr && hc)) on = false;
+  }
+  double acc = 0.0;
+  typedef double d2_t __attribute__((ext_vector_type(2)));
+  for (int q0 = 0; q0 < G.count; q0 += kGroupChunk) {
+    const int nf = min(kGroupChunk, G.count - q0);
+    const int half = per / 2;   // (per is even: tw is a multiple of 3 and m of 2 for every grouped type, checked at finalize)
+    for (int i = threadIdx.x; i < nf * half; i += 256) {
+      const int q = i / half, o = i - q * half;
+      const int f = gfac[G.first + q0 + q];
+      reinterpret_cast<d2_t*>(sJ)[q * (kGroupRowMax / 2) + o] = reinterpret_cast<const d2_t*>(g.J + (size_t)f * per)[o];
+    }
+    for (int i = threadIdx.x; i < nf * m; i += 256) {
+      const int q = i / m, k = i - q * m;
+      sr[q * 6 + k] = g.r[(size_t)gfac[G.first + q0 + q] * m + k];
+    }
+    __syncthreads();
+    if (on) {
+      for (int q = 0; q < nf; ++q) {
+        const double* Jq = sJ + q * kGroupRowMax;
+        for (int k = 0; k < m; ++k) acc += Jq[k * tw + er] * (is_rhs ? sr[q * 6 + k] : Jq[k * tw + ec]);
+      }
+    }
+    __syncthreads();
+  }
+  if (!on || acc == 0.0) return;
+  const int* to = g.toff + (size_t)gfac[G.first] * nv;
+  const int tr = to[er / 3], R = tr < 0 ? -1 : tr + er % 3;
+  if (R < 0) return;
+  const size_t pr = (size_t)(perm[R >> 6] * 64 + (R & 63));
+  if (is_rhs) {
+    atomicAdd(&S[(size_t)rhs_row * ld + pr], acc);
+    atomicAdd(&grad[R], acc);
+    return;
+  }
+  const int tc = to[ec / 3], C = tc < 0 ? -1 : tc + ec % 3;
+  if (C < 0) return;
+  const size_t pc = (size_t)(perm[C >> 6] * 64 + (C & 63));
+  atomicAdd(&S[pr * ld + pc], acc);
+  if (R != C) atomicAdd(&S[pc * ld + pr], acc);
+  else atomicAdd(&hdiag[R], acc);
+}
 __global__ __launch_bounds__(256) void small_assemble_seg_kernel(const SmallGroup* __restrict__ groups, int n_seg,
                                                                 const int* __restrict__ seg_start, const int* __restrict__ seg_ra,
                                                                 const int* __restrict__ seg_rb, const int2* __restrict__ contrib,
                                                                 double* __restrict__ S, int ld, int rhs_row, double* __restrict__ grad,
                                                                 double* __restrict__ hdiag, const int* __restrict__ perm, SmallGroupSet fw,
-                                                                int n_fw_units) {
+                                                                int n_fw_units, int n_grp, const AsmGroup* __restrict__ grp,
+                                                                const int* __restrict__ gfac, int first_grp_block) {
+  if ((int)blockIdx.x >= first_grp_block) {   // a group of same-slot factors per workgroup
+    __shared__ __attribute__((aligned(16))) double sGJ[kGroupChunk * kGroupRowMax];
+    __shared__ double sGr[kGroupChunk * 6];
+    small_assemble_group(groups, grp[(int)blockIdx.x - first_grp_block], gfac, sGJ, sGr, S, ld, rhs_row, grad, hdiag, perm);
+    return;
+  }
   if ((int)blockIdx.x < n_fw_units) {
     // the groups assembled one workgroup per factor (the IMU factors of a lidar-inertial window), as the first workgroups of this launch
     // instead of a launch of their own (as in pairs_kernel)
@@ -913,13 +983,14 @@ __global__ __launch_bounds__(256) void small_assemble_seg_kernel(const SmallGrou
 }
 void launch_small_assemble_seg(hipStream_t s, const SmallGroup* groups_dev, int n_seg, const int* seg_start, const int* seg_ra, const int* seg_rb,
                                const int2* contrib, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm,
-                               const SmallGroupSet* fw, int n_fw_units) {
-  if (n_seg <= 0) return;
+                               const SmallGroupSet* fw, int n_fw_units, int n_grp, const AsmGroup* grp, const int* gfac) {
+  if (n_seg <= 0 && n_grp <= 0) return;
   SmallGroupSet none;
   none.n = 0; none.first[0] = 0;
   const int extra = fw ? n_fw_units : 0;
-  hipLaunchKernelGGL(small_assemble_seg_kernel, dim3((n_seg + 15) / 16 + extra), dim3(256), 0, s, groups_dev, n_seg, seg_start, seg_ra, seg_rb, contrib, S, ld,
-                     rhs_row, grad, hdiag, perm, fw ? *fw : none, extra);
+  const int seg_blocks = (std::max(0, n_seg) + 15) / 16, first_grp_block = extra + seg_blocks;
+  hipLaunchKernelGGL(small_assemble_seg_kernel, dim3(first_grp_block + std::max(0, n_grp)), dim3(256), 0, s, groups_dev, std::max(0, n_seg), seg_start, seg_ra, seg_rb,
+                     contrib, S, ld, rhs_row, grad, hdiag, perm, fw ? *fw : none, extra, n_grp, grp, gfac, first_grp_block);
 }
 
 // the first (up to kSetMax) non-empty groups as ONE set of one-factor units, for a caller that runs them inside another launch

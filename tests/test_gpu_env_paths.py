@@ -18,7 +18,9 @@ sys.path.insert(0, %r)
 import numpy as np
 from beam_slam_amd import synthetic
 from beam_slam_amd.gpu import GpuSolver
-pr = synthetic.idp_window(n_kf=40, n_lm=3000, seed=78) if len(sys.argv) > 1 and sys.argv[1] == "idp" else synthetic.vio_window(n_kf=90, n_lm=6000, seed=77)
+kind = sys.argv[1] if len(sys.argv) > 1 else "vio"
+pr = (synthetic.idp_window(n_kf=40, n_lm=3000, seed=78) if kind == "idp" else
+      synthetic.lio_window(n_kf=60, n_rel=6000, seed=79) if kind == "lio" else synthetic.vio_window(n_kf=90, n_lm=6000, seed=77))
 g = GpuSolver(0)
 pr.load(g)
 o = g.options_vio(); o.max_solver_time_in_seconds = 0.0; o.max_num_iterations = 6
@@ -99,6 +101,29 @@ def default_idp_run():
 def test_inverse_depth_window_under_alternative_paths(default_idp_run, setting):
     r = _run(setting, "idp")
     d = default_idp_run
+    assert r["it"] == d["it"] and r["acc"] == d["acc"]
+    assert abs(r["cost"] - d["cost"]) <= 1e-9 * d["cost"]
+    assert max(abs(a - b) for a, b in zip(r["x"], d["x"])) < 1e-7
+
+
+# a lidar-inertial window (relative-pose constraints with extrinsics + IMU factors, no landmarks)
+LIO_SETTINGS = [
+    {"BSGPU_NO_GROUP_ASSEMBLY": "1"},                            # every pose-only factor by segments (no same-slot groups)
+    {"BSGPU_EVAL_MERGE": "0"},
+    {"BSGPU_CHOL_FUSED": "0", "BSGPU_BACKSOLVE_LEGACY": "1"},
+    {"BSGPU_GRAPH": "1"},
+]
+
+
+@pytest.fixture(scope="module")
+def default_lio_run():
+    return _run({}, "lio")
+
+
+@pytest.mark.parametrize("setting", LIO_SETTINGS, ids=lambda s: ",".join("%s=%s" % kv for kv in s.items()))
+def test_lidar_inertial_window_under_alternative_paths(default_lio_run, setting):
+    r = _run(setting, "lio")
+    d = default_lio_run
     assert r["it"] == d["it"] and r["acc"] == d["acc"]
     assert abs(r["cost"] - d["cost"]) <= 1e-9 * d["cost"]
     assert max(abs(a - b) for a, b in zip(r["x"], d["x"])) < 1e-7
