@@ -529,7 +529,6 @@ int finalize(bsgpu_ctx* c) {
       // groups of at least kGroupMin, summed a wave per group (k_small.hip: small_assemble_group); the others by segments / by factors
       std::vector<uint8_t> grouped(sg.n, 0);
       bool any_group = false;
-      int hub_mask = 0;
       constexpr int kGroupMin = 4;
       if (sg.w_last == 3 && nv * 3 <= 18 && sg.m <= 6 && (sg.m * nv * 3) % 2 == 0 && sg.n >= 64 && !getenv("BSGPU_NO_GROUP_ASSEMBLY")) {
         std::vector<int> order;
@@ -541,22 +540,14 @@ int finalize(bsgpu_ctx* c) {
           return a < b;
         };
         std::sort(order.begin(), order.end(), key_less);
-        // a slot that holds the same few variables in every factor (the extrinsics of the relative-pose constraints): its block with
-        // itself would take one add per GROUP on the same addresses — those entries stay with the segments, which add once per 64 factors
-        for (int sl = 0; sl < nv; ++sl) {
-          std::vector<int> seen;
-          for (int f : order) {
-            const int v = toffs[(size_t)f * nv + sl];
-            if (std::find(seen.begin(), seen.end(), v) == seen.end()) { seen.push_back(v); if (seen.size() > 4) break; }
-          }
-          if (seen.size() <= 4) hub_mask |= 1 << sl;
-        }
+        // (a slot that holds the same variable in every factor — the extrinsics of C3 — takes one add per group on its 36 + 12 addresses:
+        //  measured the same as leaving those entries to the segments, 25.7 against 25.8 us)
         for (size_t i = 0; i < order.size();) {
           size_t j = i + 1;
           while (j < order.size() && std::equal(&toffs[(size_t)order[i] * nv], &toffs[(size_t)order[i] * nv] + nv, &toffs[(size_t)order[j] * nv])) ++j;
           if ((int)(j - i) >= kGroupMin) {
             for (size_t q0 = i; q0 < j; q0 += 32)   // (one pass through LDS per workgroup: a large group is cut)
-              asm_grp.push_back({t, (int)asm_gfac.size() + (int)(q0 - i), (int)std::min<size_t>(32, j - q0), hub_mask});
+              asm_grp.push_back({t, (int)asm_gfac.size() + (int)(q0 - i), (int)std::min<size_t>(32, j - q0), 0});
             for (size_t q = i; q < j; ++q) { asm_gfac.push_back(order[q]); grouped[order[q]] = 1; }
             any_group = true;
           }
@@ -565,9 +556,8 @@ int finalize(bsgpu_ctx* c) {
       }
       const size_t first = cl.size();
       for (int f = 0; f < sg.n; ++f) {
-        if (!c->h_small_active[t][f]) continue;
+        if (!c->h_small_active[t][f] || grouped[f]) continue;
         for (int sa = 0; sa < nv; ++sa) for (int sb = 0; sb < nv; ++sb) {
-          if (grouped[f] && !(((hub_mask >> sa) & 1) && ((hub_mask >> sb) & 1))) continue;   // (a grouped factor: only its hub x hub blocks)
           const int ra = toffs[(size_t)f * nv + sa], rb = toffs[(size_t)f * nv + sb];
           if (ra < 0 || rb < 0) continue;
           if (ra < rb) continue;   // (the block above the diagonal is the transpose of the one below: the kernel writes both, §3 of DESIGN.md)
@@ -598,7 +588,7 @@ int finalize(bsgpu_ctx* c) {
     if (timing && !asm_grp.empty()) {
       int mx = 0;
       for (const AsmGroup& gq : asm_grp) mx = std::max(mx, gq.count);
-      fprintf(stderr, "[bsgpu finalize] same-slot groups: %d groups, %d factors, largest %d, hub mask %d\n", (int)asm_grp.size(), (int)asm_gfac.size(), mx, asm_grp[0].pad);
+      fprintf(stderr, "[bsgpu finalize] same-slot groups: %d groups, %d factors, largest %d\n", (int)asm_grp.size(), (int)asm_gfac.size(), mx);
     }
     c->d_asm_grp = c->upload(asm_grp); c->d_asm_gfac = c->upload(asm_gfac);
     if (timing) lap("  lists: contributions");

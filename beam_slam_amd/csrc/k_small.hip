@@ -851,9 +851,6 @@ BSG_DEV void small_assemble_group(const SmallGroup* __restrict__ groups, const A
   if (on) {
     if (!is_rhs) { while ((er + 1) * (er + 2) / 2 <= e) ++er; ec = e - er * (er + 1) / 2; }
     else er = e - n_ent;
-    // (G.pad: slots whose variable nearly every group shares; their block with themselves, their gradient and diagonal: by segments)
-    const int hr = (G.pad >> (er / 3)) & 1, hc = (G.pad >> (ec / 3)) & 1;
-    if (is_rhs ? hr : (hr && hc)) on = false;
   }
   double acc = 0.0;
   typedef double d2_t __attribute__((ext_vector_type(2)));
