@@ -326,7 +326,9 @@ void launch_backsub_mcc(hipStream_t s, const Visual& v, int n_pose, const double
                         const SmallGroupSet* small = nullptr, int n_small_units = 0, const UpdateRide* upd = nullptr);
 int small_mcc_first_set(const SmallGroup* groups, double* const* parts, int n_groups, SmallGroupSet* set, int* n_taken);
 void launch_negate_pose(hipStream_t s, int n_pose, const double* y, double* delta);
-void launch_small_mcc_set(hipStream_t s, const SmallGroup* groups, double* const* parts, int n_groups, const double* delta);
+// (returns whether `upd` — the candidate update of a window without Euclidean landmarks — rode in one of the launches)
+void launch_update_ride_only(hipStream_t s, const double* delta, const UpdateRide& upd);
+bool launch_small_mcc_set(hipStream_t s, const SmallGroup* groups, double* const* parts, int n_groups, const double* delta, const UpdateRide* upd = nullptr);
 void launch_update(hipStream_t s, int nb, const int* blk_xoff, const int* blk_toff, const unsigned char* blk_size,
                    const unsigned char* blk_manifold, const double* x, const double* delta, double* x_cand,
                    double* part /* 2 * nblocks_grid */, int* n_part);

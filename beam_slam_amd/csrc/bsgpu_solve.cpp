@@ -350,13 +350,20 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
     }
     launch_backsub_mcc(s, c->vis, c->n_pose, c->d_ytan, c->d_delta, c->vis.mcc_part, units > 0 ? &set : nullptr, units, c->n_upd_blocks > 0 ? &up : nullptr);
     if (units == 0) taken = 0;
-    launch_small_mcc_set(s, c->small + 2 + taken, c->d_small_part_mcc + 2 + taken, kNumInternal - 2 - taken, c->d_delta);
+    UpdateRide all;
+    if (c->upd_in_mcc) {   // (no Euclidean landmarks: every block's candidate rides in the pose-only groups' launch)
+      all.n_blocks = c->nb; all.blocks = nullptr; all.xoff = c->d_blk_xoff; all.toff = c->d_blk_toff; all.size = c->d_blk_size;
+      all.manifold = c->d_blk_manifold; all.x = c->d_x; all.x_cand = c->d_xcand; all.part = c->d_part_upd;
+    }
+    const bool carried = launch_small_mcc_set(s, c->small + 2 + taken, c->d_small_part_mcc + 2 + taken, kNumInternal - 2 - taken, c->d_delta,
+                                              c->upd_in_mcc ? &all : nullptr);
+    if (c->upd_in_mcc && !carried) launch_update_ride_only(s, c->d_delta, all);
   }
   for (const auto& mc : c->marg)
     if (mc.active) launch_marg_mcc(s, mc.dev, c->d_delta, mc.part_mcc);
   phase_mark(c, BSGPU_PHASE_BACKSUB);
   int n_part = 0;
-  if (c->n_upd_blocks == 0)   // (else the update rode in the landmark back-substitution above)
+  if (c->n_upd_blocks == 0 && !c->upd_in_mcc)   // (else the update rode in the landmark back-substitution / the pose-only groups' launch above)
     launch_update(s, c->nb, c->d_blk_xoff, c->d_blk_toff, c->d_blk_size, c->d_blk_manifold, c->d_x, c->d_delta, c->d_xcand,
                   c->d_part_upd, &n_part);
   eval_all(c, c->d_xcand, false, SC_COST_CAND);

@@ -1026,8 +1026,21 @@ void launch_small_assemble_set(hipStream_t s, const SmallGroup* groups, int n_gr
 
 // model cost change term of a pose-only group, one lane per residual row:
 //   part[f*m + k] = -(J_k d) (r_k + J_k d / 2)
-__global__ __launch_bounds__(128) void small_mcc_kernel(SmallGroupSet set, const double* __restrict__ delta) {
+__global__ __launch_bounds__(128) void small_mcc_kernel(SmallGroupSet set, const double* __restrict__ delta, UpdateRide up, int first_update_block) {
   __shared__ double s2[2];
+  if (up.n_blocks > 0 && (int)blockIdx.x >= first_update_block) {
+    // a window without Euclidean landmarks: the candidate x (+) delta of every block as extra workgroups of this launch (both only need
+    // the step), 128 blocks each — as backsub_mcc_kernel carries it where there are landmarks
+    const int unit = (int)blockIdx.x - first_update_block, b = unit * 128 + (int)threadIdx.x;
+    double d2 = 0.0, x2 = 0.0;
+    if (b < up.n_blocks) update_block(up.blocks ? up.blocks[b] : b, up.xoff, up.toff, up.size, up.manifold, up.x, delta, up.x_cand, d2, x2);
+    const double a = wave_sum(d2), c = wave_sum(x2);
+    __shared__ double s4[4];
+    if ((threadIdx.x & 63) == 0) { s4[threadIdx.x >> 6] = a; s4[2 + (threadIdx.x >> 6)] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) { up.part[2 * unit] = s4[0] + s4[1]; up.part[2 * unit + 1] = s4[2] + s4[3]; }
+    return;
+  }
   small_mcc_unit(set, blockIdx.x, threadIdx.x, delta, s2);
 }
 
@@ -1045,14 +1058,23 @@ int small_mcc_first_set(const SmallGroup* groups, double* const* parts, int n_gr
   *n_taken = i;
   return blocks;
 }
-void launch_small_mcc_set(hipStream_t s, const SmallGroup* groups, double* const* parts, int n_groups, const double* delta) {
+void launch_update_ride_only(hipStream_t s, const double* delta, const UpdateRide& upd) {   // (no pose-only launch to ride in)
+  if (upd.n_blocks <= 0) return;
+  SmallGroupSet none;
+  none.n = 0; none.first[0] = 0;
+  hipLaunchKernelGGL(small_mcc_kernel, dim3((upd.n_blocks + 127) / 128), dim3(128), 0, s, none, delta, upd, 0);
+}
+bool launch_small_mcc_set(hipStream_t s, const SmallGroup* groups, double* const* parts, int n_groups, const double* delta, const UpdateRide* upd) {
   SmallGroupSet set;
   set.n = 0;
   int blocks = 0;
+  bool carried = false;   // the update rides in the first launch
   auto flush = [&]() {
     if (!set.n) return;
     set.first[set.n] = blocks;
-    hipLaunchKernelGGL(small_mcc_kernel, dim3(blocks), dim3(128), 0, s, set, delta);
+    const int upd_units = (upd && !carried && upd->n_blocks > 0) ? (upd->n_blocks + 127) / 128 : 0;
+    hipLaunchKernelGGL(small_mcc_kernel, dim3(blocks + upd_units), dim3(128), 0, s, set, delta, upd_units ? *upd : UpdateRide(), blocks);
+    if (upd_units) carried = true;
     set.n = 0; blocks = 0;
   };
   for (int i = 0; i < n_groups; ++i) {
@@ -1062,6 +1084,7 @@ void launch_small_mcc_set(hipStream_t s, const SmallGroup* groups, double* const
     if (set.n == kSetMax) flush();
   }
   flush();
+  return carried;
 }
 
 }  // namespace bsg
