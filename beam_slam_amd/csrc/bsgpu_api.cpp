@@ -455,7 +455,7 @@ int bsgpu_evaluate(bsgpu_ctx* c, double* cost, double* residuals, double* gradie
       SmallGroup g = c->small[t];
       g.active = c->d_small_inactive[t];
       launch_small_eval(s, g, c->d_x, c->d_losses, false, c->d_small_part[t]);
-      launch_sum(s, c->d_small_part[t], g.n, c->d_scal + SC_FIXED_COST, 1);
+      launch_sum(s, c->d_small_part[t], small_cost_parts(g), c->d_scal + SC_FIXED_COST, 1);
     }
     for (const auto& mc : c->marg) {
       if (mc.active) continue;

@@ -911,8 +911,8 @@ int finalize(bsgpu_ctx* c) {
     }
     for (int t = 2; t < kNumInternal; ++t) {
       if (!c->small[t].n) continue;
-      tab.push_back({c->d_small_part[t], c->small[t].n, 1, 0, SC_COST_X});
-      tab.push_back({c->d_small_part_cand[t], c->small[t].n, 1, 0, SC_COST_CAND});
+      tab.push_back({c->d_small_part[t], small_cost_parts(c->small[t]), 1, 0, SC_COST_X});
+      tab.push_back({c->d_small_part_cand[t], small_cost_parts(c->small[t]), 1, 0, SC_COST_CAND});
       tab.push_back({c->d_small_part_mcc[t], (c->small[t].n * c->small[t].m + 127) / 128, 1, 0, SC_MCC});   // one partial per workgroup of small_mcc_kernel
     }
     for (const auto& mc : c->marg) {

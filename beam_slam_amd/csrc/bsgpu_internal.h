@@ -191,6 +191,7 @@ void launch_relpose_imu_eval(hipStream_t s, const SmallGroup& g, const SmallGrou
                              const DevLoss* losses, bool with_J, double* cost_part, double* part_delta, double* part_prior);
 void launch_imu_eval(hipStream_t s, const SmallGroup& delta, const SmallGroup& prior, const double* x, const DevLoss* losses, bool with_J,
                      double* part_delta, double* part_prior);
+int small_cost_parts(const SmallGroup& g);
 void launch_small_eval(hipStream_t s, const SmallGroup& g, const double* x, const DevLoss* losses, bool with_J,
                        double* cost_part /* n doubles: per-factor cost */);
 // what an LM step clears before its assembly (zero_tiles_multi_kernel's arguments); rides in the landmark launch as extra workgroups

@@ -30,6 +30,15 @@ BSG_DEV void eigen_conj_rotate(const double q[4], const double v[3], double o[3]
   o[2] = v[2] + q[0] * uv[2] + c[2];
 }
 
+// the cost of a 128-factor block of a lane-per-factor kernel as ONE partial (the relative-pose and inverse-depth groups have tens of
+// thousands of factors: a per-factor array kept the end-of-step reduction busy for 9 - 16 us); every thread of the block must call it
+BSG_DEV void block_cost_128(double cost, double* __restrict__ cost_part, int block) {
+  __shared__ double s_cost[2];
+  const double w = wave_sum(cost);
+  if ((threadIdx.x & 63) == 0) s_cost[(threadIdx.x >> 6) & 1] = w;
+  __syncthreads();
+  if ((threadIdx.x & 127) == 0) cost_part[block] = s_cost[0] + s_cost[1];
+}
 BSG_DEV void finish_small(const SmallGroup& g, int f, const DevLoss* losses, double s, double* sc, double* cost) {
   double rho1;
   const double rho = loss_eval(losses[g.loss[f]], s, &rho1);
@@ -359,7 +368,7 @@ __device__ __forceinline__ void relpose_body(const SmallGroup g, const double* _
   }
   double sc, cost;
   finish_small(g, f, losses, s, &sc, &cost);
-  if (live) cost_part[f] = cost;
+  block_cost_128(live ? cost : 0.0, cost_part, block);
   if (!WITH_J) return;
   if (live) {
 #pragma unroll
@@ -635,8 +644,9 @@ template <bool UNARY, bool WITH_J>
 __global__ __launch_bounds__(128) void idp_kernel(SmallGroup g, const double* __restrict__ x,
                                                   const DevLoss* __restrict__ losses,
                                                   double* __restrict__ cost_part) {
-  const int f = blockIdx.x * 128 + threadIdx.x;
-  if (f >= g.n) return;
+  const int f_raw = blockIdx.x * 128 + threadIdx.x;
+  const bool live = f_raw < g.n;
+  const int f = live ? f_raw : g.n - 1;   // (idle lanes of the last workgroup redo the last factor and store nothing)
   constexpr int NV = UNARY ? 3 : 5;
   const int* xo = g.xoff + (size_t)f * NV;
   const int* to = g.toff + (size_t)f * NV;
@@ -668,8 +678,8 @@ __global__ __launch_bounds__(128) void idp_kernel(SmallGroup g, const double* __
   const double r0 = w * (k[0] - (cam.fx * c[0] * iz + cam.cx)), r1 = w * (k[1] - (cam.fy * c[1] * iz + cam.cy));
   double sc, cost;
   finish_small(g, f, losses, r0 * r0 + r1 * r1, &sc, &cost);
-  cost_part[f] = cost;
-  if (!WITH_J) return;
+  block_cost_128(live ? cost : 0.0, cost_part, (int)blockIdx.x);
+  if (!WITH_J || !live) return;
   g.r[(size_t)f * 2] = r0 * sc; g.r[(size_t)f * 2 + 1] = r1 * sc;
   double* Jo = g.J + (size_t)f * 2 * 3 * NV;
   if (UNARY) {
@@ -779,6 +789,11 @@ __global__ __launch_bounds__(128) void reproj_dense_kernel(SmallGroup g, const d
   }
 }
 
+// entries of a group's cost array: one per 128-factor block for the types whose kernels reduce it (block_cost_128), else one per factor
+int small_cost_parts(const SmallGroup& g) {
+  const bool by_block = g.type == BSGPU_F_RELPOSE_EXT || g.type == BSGPU_F_RELPOSE || g.type == BSGPU_F_IDP_REPROJ || g.type == BSGPU_F_IDP_REPROJ_UNARY;
+  return by_block ? (g.n + 127) / 128 : g.n;
+}
 void launch_small_eval(hipStream_t s, const SmallGroup& g, const double* x, const DevLoss* losses, bool with_J,
                        double* cost_part) {
   if (g.n == 0) return;
