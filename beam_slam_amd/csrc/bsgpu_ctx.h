@@ -179,6 +179,7 @@ struct bsgpu_ctx {
   int n_part_upd = 0;
   // the update riding in the landmark back-substitution (windows with eliminated Euclidean landmarks): UpdateRide's tables
   int n_upd_blocks = 0;
+  bool pre_cleared = false;      // the reduced system, gradient and diagonal were cleared at the end of the previous step (bsgpu_solve.cpp)
   bool upd_in_mcc = false;       // no Euclidean landmarks: the update of every block rides in the pose-only model-cost launch (128 blocks per unit)
   int* d_upd_blocks = nullptr;
   int* d_lm_xoff = nullptr;

@@ -900,6 +900,7 @@ int finalize(bsgpu_ctx* c) {
         c->n_part_upd = (c->n_upd_blocks + 255) / 256 + (c->vis.n_lm * 8 + 255) / 256;   // update units, then the landmark workgroups
       }
     }
+    c->pre_cleared = false;
     c->upd_in_mcc = c->n_upd_blocks == 0 && c->vis.n_lm == 0 && !getenv("BSGPU_UPDATE_SEPARATE");
     if (c->upd_in_mcc) c->n_part_upd = (nb + 127) / 128;
     c->d_part_upd = c->alloc<double>(2 * (size_t)c->n_part_upd + 2);

@@ -217,13 +217,13 @@ void launch_small_assemble_seg(hipStream_t s, const SmallGroup* groups_dev, int 
                                const int* gfac = nullptr);
 void launch_pose_diag(hipStream_t s, int n_pose, double* S, int ld, const double* hdiag, const double* radius_ptr,
                       int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* scale,
-                      double* dcl, int npad, const int* iperm);
+                      double* dcl, int npad, const int* iperm, double radius_val = 0.0 /* used when radius_ptr is null */);
 void launch_grad_norms(hipStream_t s, int nb, const int* blk_xoff, const int* blk_toff, const unsigned char* blk_size,
                        const unsigned char* blk_manifold, const double* x, const double* grad, double* gpart /* 2 per workgroup: max, sum of squares */);
 void launch_grad_norms_pose_diag(hipStream_t s, int nb, const int* blk_xoff, const int* blk_toff, const unsigned char* blk_size,
                                  const unsigned char* blk_manifold, const double* x, const double* grad, double* gpart, int n_pose, double* S,
                                  int ld, const double* hdiag, const double* radius_ptr, int compute_scale, int compute_dcl, int jacobi,
-                                 double lm_lo, double lm_hi, double* scale, double* dcl, int npad, const int* iperm);
+                                 double lm_lo, double lm_hi, double* scale, double* dcl, int npad, const int* iperm, double radius_val = 0.0);
 struct PanelDesc;
 struct FusedTask;
 void launch_chol_fused(hipStream_t s, double* S, double* Lp, int ld, const FusedTask* tasks_dev, int n_tasks, const int* tile_tot_dev, const int* nreal_dev,
@@ -329,7 +329,8 @@ int small_mcc_first_set(const SmallGroup* groups, double* const* parts, int n_gr
 void launch_negate_pose(hipStream_t s, int n_pose, const double* y, double* delta);
 // (returns whether `upd` — the candidate update of a window without Euclidean landmarks — rode in one of the launches)
 void launch_update_ride_only(hipStream_t s, const double* delta, const UpdateRide& upd);
-bool launch_small_mcc_set(hipStream_t s, const SmallGroup* groups, double* const* parts, int n_groups, const double* delta, const UpdateRide* upd = nullptr);
+bool launch_small_mcc_set(hipStream_t s, const SmallGroup* groups, double* const* parts, int n_groups, const double* delta, const UpdateRide* upd = nullptr,
+                          const ZeroStep* zero = nullptr /* the next step's clearing, carried with `upd` */);
 void launch_update(hipStream_t s, int nb, const int* blk_xoff, const int* blk_toff, const unsigned char* blk_size,
                    const unsigned char* blk_manifold, const double* x, const double* delta, double* x_cand,
                    double* part /* 2 * nblocks_grid */, int* n_part);

@@ -223,7 +223,11 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
   zs.radius_slot = c->use_graphs ? nullptr : c->d_scal + SC_RADIUS; zs.radius = radius;
   // (with landmarks and eager launches the clearing rides in the landmark launch: independent work, one launch less on the path)
   const bool merged = c->vis.n_lm > 0 && !c->use_graphs;
-  if (!merged) launch_zero_tiles_multi(s, zs.S, zs.ld, zs.tiles, zs.n_tiles, zs.a, zs.na, zs.b, zs.nb, zs.c, zs.nc, zs.radius_slot, zs.radius);
+  // (a window without Euclidean landmarks clears at the END of a step, in the launch that carries the candidate update: the next
+  //  assembly then finds everything clean — linear_solve_and_candidate)
+  const bool cleared = c->pre_cleared && !merged && !c->use_graphs;
+  c->pre_cleared = false;
+  if (!merged && !cleared) launch_zero_tiles_multi(s, zs.S, zs.ld, zs.tiles, zs.n_tiles, zs.a, zs.na, zs.b, zs.nb, zs.c, zs.nc, zs.radius_slot, zs.radius);
   c->scal_mirrored = false;
   launch_landmark(s, c->vis, c->n_pose, merged ? nullptr : c->d_scal + SC_RADIUS, first ? 1 : 0, new_J ? 1 : 0, o.jacobi_scaling, o.min_lm_diagonal,
                   o.max_lm_diagonal, c->d_scale, c->d_dcl, c->d_grad, merged ? &zs : nullptr, radius);
@@ -254,11 +258,11 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
     if (mc.active) launch_marg_assemble(s, mc.dev, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm);
   if (new_J)   // the LM diagonal and the gradient norms both follow the assembly and do not depend on each other: one launch
     launch_grad_norms_pose_diag(s, c->nb, c->d_blk_xoff, c->d_blk_toff, c->d_blk_size, c->d_blk_manifold, c->d_x, c->d_grad, c->d_gpart,
-                                c->n_pose, c->d_S, c->npad, c->d_hdiag, c->d_scal + SC_RADIUS, first ? 1 : 0, 1, o.jacobi_scaling,
-                                o.min_lm_diagonal, o.max_lm_diagonal, c->d_scale, c->d_dcl, c->npad, c->d_iperm);
+                                c->n_pose, c->d_S, c->npad, c->d_hdiag, cleared ? nullptr : c->d_scal + SC_RADIUS, first ? 1 : 0, 1, o.jacobi_scaling,
+                                o.min_lm_diagonal, o.max_lm_diagonal, c->d_scale, c->d_dcl, c->npad, c->d_iperm, radius);
   else
-    launch_pose_diag(s, c->n_pose, c->d_S, c->npad, c->d_hdiag, c->d_scal + SC_RADIUS, 0, 0, o.jacobi_scaling,
-                     o.min_lm_diagonal, o.max_lm_diagonal, c->d_scale, c->d_dcl, c->npad, c->d_iperm);
+    launch_pose_diag(s, c->n_pose, c->d_S, c->npad, c->d_hdiag, cleared ? nullptr : c->d_scal + SC_RADIUS, 0, 0, o.jacobi_scaling,
+                     o.min_lm_diagonal, o.max_lm_diagonal, c->d_scale, c->d_dcl, c->npad, c->d_iperm, radius);
   phase_mark(c, BSGPU_PHASE_ASSEMBLE_OTHER);
 }
 
@@ -355,8 +359,18 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
       all.n_blocks = c->nb; all.blocks = nullptr; all.xoff = c->d_blk_xoff; all.toff = c->d_blk_toff; all.size = c->d_blk_size;
       all.manifold = c->d_blk_manifold; all.x = c->d_x; all.x_cand = c->d_xcand; all.part = c->d_part_upd;
     }
+    // ... and the next step's clearing with it (the factorisation of this step is done; nothing reads S, the gradient or the diagonal
+    // before the next assembly) — when the end-of-step reduction mirrors the scalars (it then clears the factorisation's flag)
+    static const bool clear_at_start = getenv("BSGPU_CLEAR_AT_START") != nullptr;
+    ZeroStep zn;
+    const bool ride_zero = c->upd_in_mcc && !c->use_pcg && !c->use_graphs && c->dense_ok && c->h_scal_dev != nullptr && !clear_at_start;
+    if (ride_zero) {
+      zn.S = c->d_S; zn.ld = c->npad; zn.tiles = c->d_touched; zn.n_tiles = c->n_touched;
+      zn.a = c->d_grad; zn.na = c->n_pose; zn.b = c->d_hdiag; zn.nb = c->n_pose;
+    }
     const bool carried = launch_small_mcc_set(s, c->small + 2 + taken, c->d_small_part_mcc + 2 + taken, kNumInternal - 2 - taken, c->d_delta,
-                                              c->upd_in_mcc ? &all : nullptr);
+                                              c->upd_in_mcc ? &all : nullptr, ride_zero ? &zn : nullptr);
+    c->pre_cleared = ride_zero && carried;
     if (c->upd_in_mcc && !carried) launch_update_ride_only(s, c->d_delta, all);
   }
   for (const auto& mc : c->marg)

@@ -15,17 +15,17 @@ namespace bsg {
 __global__ void pose_diag_kernel(int n_pose, double* __restrict__ S, int ld, const double* __restrict__ hdiag,
                                  const double* __restrict__ radius_ptr, int compute_scale, int compute_dcl, int jacobi,
                                  double lm_lo, double lm_hi, double* __restrict__ scale, double* __restrict__ dcl, int npad,
-                                 const int* __restrict__ iperm) {
+                                 const int* __restrict__ iperm, double radius_val) {
   const int i = blockIdx.x * 256 + threadIdx.x;   // solver position
   if (i >= npad) return;
-  pose_diag_element(i, n_pose, S, ld, hdiag, 1.0 / radius_ptr[0], compute_scale, compute_dcl, jacobi, lm_lo, lm_hi, scale, dcl, iperm);
+  pose_diag_element(i, n_pose, S, ld, hdiag, 1.0 / (radius_ptr ? radius_ptr[0] : radius_val), compute_scale, compute_dcl, jacobi, lm_lo, lm_hi, scale, dcl, iperm);
 }
 
 void launch_pose_diag(hipStream_t s, int n_pose, double* S, int ld, const double* hdiag, const double* radius_ptr,
                       int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* scale,
-                      double* dcl, int npad, const int* iperm) {
+                      double* dcl, int npad, const int* iperm, double radius_val) {
   hipLaunchKernelGGL(pose_diag_kernel, dim3((npad + 255) / 256), dim3(256), 0, s, n_pose, S, ld, hdiag, radius_ptr,
-                     compute_scale, compute_dcl, jacobi, lm_lo, lm_hi, scale, dcl, npad, iperm);
+                     compute_scale, compute_dcl, jacobi, lm_lo, lm_hi, scale, dcl, npad, iperm, radius_val);
 }
 
 // ---- true marginalisation (fuse_constraints::marginalizeVariables, fixed_lag_smoother.cpp:270-271) --------------

@@ -38,7 +38,7 @@ void launch_update(hipStream_t s, int nb, const int* blk_xoff, const int* blk_to
 // The max is order independent (atomicMax on the bit pattern of a non-negative double).
 struct PoseDiagArgs {   // the pose_diag_kernel arguments, for the launch that does both (an accepted / first step)
   int n_pose, ld, compute_scale, compute_dcl, jacobi, npad;
-  double* S; const double* hdiag; const double* radius_ptr; double lm_lo, lm_hi; double* scale; double* dcl; const int* iperm;
+  double* S; const double* hdiag; const double* radius_ptr; double lm_lo, lm_hi; double* scale; double* dcl; const int* iperm; double radius_val;
 };
 template <bool WITH_DIAG>
 __global__ __launch_bounds__(256) void grad_norms_kernel(int nb, const int* __restrict__ xoff, const int* __restrict__ toff,
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void grad_norms_kernel(int nb, const int* __re
   __shared__ double smax[4];
   const int b = blockIdx.x * 256 + threadIdx.x;
   if (WITH_DIAG && b < pd.npad)   // independent of the norms: the LM diagonal of the reduced system rides in the same launch
-    pose_diag_element(b, pd.n_pose, pd.S, pd.ld, pd.hdiag, 1.0 / pd.radius_ptr[0], pd.compute_scale, pd.compute_dcl, pd.jacobi, pd.lm_lo,
+    pose_diag_element(b, pd.n_pose, pd.S, pd.ld, pd.hdiag, 1.0 / (pd.radius_ptr ? pd.radius_ptr[0] : pd.radius_val), pd.compute_scale, pd.compute_dcl, pd.jacobi, pd.lm_lo,
                       pd.lm_hi, pd.scale, pd.dcl, pd.iperm);
   double mx = 0.0, s2 = 0.0;
   if (b < nb) {
@@ -88,8 +88,9 @@ void launch_grad_norms(hipStream_t s, int nb, const int* blk_xoff, const int* bl
 void launch_grad_norms_pose_diag(hipStream_t s, int nb, const int* blk_xoff, const int* blk_toff, const unsigned char* blk_size,
                                  const unsigned char* blk_manifold, const double* x, const double* grad, double* gpart, int n_pose, double* S,
                                  int ld, const double* hdiag, const double* radius_ptr, int compute_scale, int compute_dcl, int jacobi,
-                                 double lm_lo, double lm_hi, double* scale, double* dcl, int npad, const int* iperm) {
+                                 double lm_lo, double lm_hi, double* scale, double* dcl, int npad, const int* iperm, double radius_val) {
   PoseDiagArgs pd;
+  pd.radius_val = radius_val;
   pd.n_pose = n_pose; pd.ld = ld; pd.compute_scale = compute_scale; pd.compute_dcl = compute_dcl; pd.jacobi = jacobi; pd.npad = npad;
   pd.S = S; pd.hdiag = hdiag; pd.radius_ptr = radius_ptr; pd.lm_lo = lm_lo; pd.lm_hi = lm_hi; pd.scale = scale; pd.dcl = dcl; pd.iperm = iperm;
   const int grid = (std::max(nb, npad) + 255) / 256;
@@ -130,6 +131,9 @@ __global__ __launch_bounds__(1024) void final_reduce_kernel(const ReduceEntry* _
   if (slot == n_slots) {   // the scalars earlier kernels of the step produced (gradient norms, Cholesky flag, ...) -> host mirror
     if (threadIdx.x == 0) {
       if (host_scal) for (int i = n_slots; i < SC_SEQ; ++i) host_scal[i] = scal[i];
+      // (mirrored: the factorisation's flag of this step is cleared here for the next one — its clearing may have run already, in the
+      //  launch that carried the candidate update, bsgpu_solve.cpp)
+      if (host_scal) scal[SC_CHOL_FAIL] = 0.0;
       final_reduce_done(host_scal, counter, seq);
     }
     return;

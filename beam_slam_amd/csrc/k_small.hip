@@ -1041,8 +1041,27 @@ void launch_small_assemble_set(hipStream_t s, const SmallGroup* groups, int n_gr
 
 // model cost change term of a pose-only group, one lane per residual row:
 //   part[f*m + k] = -(J_k d) (r_k + J_k d / 2)
-__global__ __launch_bounds__(128) void small_mcc_kernel(SmallGroupSet set, const double* __restrict__ delta, UpdateRide up, int first_update_block) {
+__global__ __launch_bounds__(128) void small_mcc_kernel(SmallGroupSet set, const double* __restrict__ delta, UpdateRide up, int first_update_block,
+                                                        ZeroStep zs, int first_zero_block) {
   __shared__ double s2[2];
+  if (first_zero_block >= 0 && (int)blockIdx.x >= first_zero_block) {
+    // the NEXT step's clearing (the tiles of the reduced system the assembly writes, the pose gradient, diag(J^T J)): nothing reads them
+    // any more in this step — the factorisation is done — so the next assembly finds them clean and needs no launch of its own for it
+    // (a window with Euclidean landmarks clears in its landmark launch instead)
+    const int z = (int)blockIdx.x - first_zero_block;
+    if (z < zs.n_tiles) {
+      const int nt = zs.ld >> 6, ti = zs.tiles[z] / nt, tj = zs.tiles[z] - ti * nt;
+      double2* base = reinterpret_cast<double2*>(zs.S + (size_t)ti * 64 * zs.ld + (size_t)tj * 64);
+      const int r0 = threadIdx.x >> 5, c2 = threadIdx.x & 31;
+#pragma unroll
+      for (int p = 0; p < 16; ++p) base[(size_t)(r0 + 4 * p) * (zs.ld >> 1) + c2] = make_double2(0.0, 0.0);
+    } else {
+      const int i = (z - zs.n_tiles) * 128 + (int)threadIdx.x;
+      if (i < zs.na) zs.a[i] = 0.0;
+      if (i < zs.nb) zs.b[i] = 0.0;
+    }
+    return;
+  }
   if (up.n_blocks > 0 && (int)blockIdx.x >= first_update_block) {
     // a window without Euclidean landmarks: the candidate x (+) delta of every block as extra workgroups of this launch (both only need
     // the step), 128 blocks each — as backsub_mcc_kernel carries it where there are landmarks
@@ -1077,9 +1096,10 @@ void launch_update_ride_only(hipStream_t s, const double* delta, const UpdateRid
   if (upd.n_blocks <= 0) return;
   SmallGroupSet none;
   none.n = 0; none.first[0] = 0;
-  hipLaunchKernelGGL(small_mcc_kernel, dim3((upd.n_blocks + 127) / 128), dim3(128), 0, s, none, delta, upd, 0);
+  hipLaunchKernelGGL(small_mcc_kernel, dim3((upd.n_blocks + 127) / 128), dim3(128), 0, s, none, delta, upd, 0, ZeroStep(), -1);
 }
-bool launch_small_mcc_set(hipStream_t s, const SmallGroup* groups, double* const* parts, int n_groups, const double* delta, const UpdateRide* upd) {
+bool launch_small_mcc_set(hipStream_t s, const SmallGroup* groups, double* const* parts, int n_groups, const double* delta, const UpdateRide* upd,
+                          const ZeroStep* zero) {
   SmallGroupSet set;
   set.n = 0;
   int blocks = 0;
@@ -1088,7 +1108,10 @@ bool launch_small_mcc_set(hipStream_t s, const SmallGroup* groups, double* const
     if (!set.n) return;
     set.first[set.n] = blocks;
     const int upd_units = (upd && !carried && upd->n_blocks > 0) ? (upd->n_blocks + 127) / 128 : 0;
-    hipLaunchKernelGGL(small_mcc_kernel, dim3(blocks + upd_units), dim3(128), 0, s, set, delta, upd_units ? *upd : UpdateRide(), blocks);
+    // (the next step's clearing rides with the update: zero != null only together with upd)
+    const int zero_units = (upd_units && zero) ? zero->n_tiles + (std::max(zero->na, zero->nb) + 127) / 128 : 0;
+    hipLaunchKernelGGL(small_mcc_kernel, dim3(blocks + upd_units + zero_units), dim3(128), 0, s, set, delta, upd_units ? *upd : UpdateRide(), blocks,
+                       zero_units ? *zero : ZeroStep(), zero_units ? blocks + upd_units : -1);
     if (upd_units) carried = true;
     set.n = 0; blocks = 0;
   };

@@ -89,6 +89,7 @@ IDP_SETTINGS = [
     {"BSGPU_IDP_ELIM": "0"},
     {"BSGPU_IDP_ELIM": "0", "BSGPU_NO_LEAF_TILES": "1"},
     {"BSGPU_PAIR_ENTRIES_SORT": "1"},
+    {"BSGPU_CLEAR_AT_START": "1"},
 ]
 
 
@@ -109,6 +110,8 @@ def test_inverse_depth_window_under_alternative_paths(default_idp_run, setting):
 # a lidar-inertial window (relative-pose constraints with extrinsics + IMU factors, no landmarks)
 LIO_SETTINGS = [
     {"BSGPU_NO_GROUP_ASSEMBLY": "1"},                            # every pose-only factor by segments (no same-slot groups)
+    {"BSGPU_CLEAR_AT_START": "1"},                               # the step's clearing as a launch at its start, not in the previous step's last launch
+    {"BSGPU_UPDATE_SEPARATE": "1"},
     {"BSGPU_EVAL_MERGE": "0"},
     {"BSGPU_CHOL_FUSED": "0", "BSGPU_BACKSOLVE_LEGACY": "1"},
     {"BSGPU_GRAPH": "1"},
