@@ -160,7 +160,8 @@ void spcg_solve(bsgpu_ctx* c, const bsgpu_options& o) {
 void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot) {
   hipStream_t s = c->stream;
   const bool cand = slot == SC_COST_CAND;
-  const bool imu_pair = c->small[BSGPU_F_IMU_DELTA].n > 0 && c->small[BSGPU_F_IMU_PRIOR].n > 0;
+  // (either IMU type may be absent: a window whose oldest state has been marginalised / held constant has no IMU prior any more)
+  const bool imu_pair = c->small[BSGPU_F_IMU_DELTA].n + c->small[BSGPU_F_IMU_PRIOR].n > 0;
   // (a visual-inertial window: the IMU factors ride in the reprojection launch — the cost-only pass always, the pass with Jacobians
   // unless BSGPU_EVAL_MERGE=0: there the IMU body's registers cost the reprojection kernel a wave of occupancy per SIMD)
   static const int merge_mode = getenv("BSGPU_EVAL_MERGE") ? atoi(getenv("BSGPU_EVAL_MERGE")) : 2;   // 0: never, 1: cost-only passes, 2: both

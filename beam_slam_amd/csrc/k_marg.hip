@@ -6,15 +6,17 @@
 //     (ComputeMinusJacobian "evaluated at x1 = x2 = x", at the current parameter) = A_i |x_i|^2
 //     (jacobians.cpp:144-174 multiplied out; exactly A_i for unit quaternions)
 // A marginal factor is a few hundred rows / columns at most and there is usually exactly one in a window, so
-// the kernels are plain: one launch per factor and step, rows x cols work spread over the chip.
+// the kernels are plain, rows x cols work spread over the chip: per factor and step one launch for the evaluation (delta formed by
+// every row's wave in LDS), one for the assembly (the gradient in its last row of workgroups), one for the model cost change.
 #include "bsgpu_device.h"
 
 namespace bsg {
 
-// thread per block: delta segment and, for quaternion blocks, the scale |x|^2 of the tangent Jacobian
-__global__ void marg_delta_kernel(MargDev m, const double* __restrict__ x, int with_J) {
-  const int i = blockIdx.x * 64 + threadIdx.x;
-  if (i >= m.nblk) return;
+// one wave per residual row.  Every wave first forms delta = x [-] xbar and, for quaternion blocks, the scale |x|^2 of the tangent
+// Jacobian itself, in LDS (a few dozen blocks: cheaper than a launch of its own in front of every evaluation), then
+// r = b + A_row . delta, the cost term, and J_row = A_row D (constant columns zero)
+constexpr int kMargColsLds = 1024;   // columns / blocks kept in LDS per wave; larger factors read the arrays a separate launch left
+BSG_DEV void marg_delta_block(const MargDev& m, int i, const double* __restrict__ x, double* delta, double* D) {
   const int xo = m.blk_xoff[i], sz = m.blk_size[i], ct = m.blk_col[i], ca = m.blk_amb[i];
   if (m.blk_quat[i]) {
     const double* xb = m.xbar + ca;
@@ -23,20 +25,34 @@ __global__ void marg_delta_kernel(MargDev m, const double* __restrict__ x, int w
     double e[4], aa[3];
     quat_mul(cj, q, e);
     quat_to_angle_axis(e, aa);
-    m.delta[ct] = aa[0]; m.delta[ct + 1] = aa[1]; m.delta[ct + 2] = aa[2];
-    if (with_J) m.D[i] = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];   // MinusJacobian(x) PlusJacobian(x) = |x|^2 I
+    delta[ct] = aa[0]; delta[ct + 1] = aa[1]; delta[ct + 2] = aa[2];
+    D[i] = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];   // MinusJacobian(x) PlusJacobian(x) = |x|^2 I
   } else {
-    for (int k = 0; k < sz; ++k) m.delta[ct + k] = x[xo + k] - m.xbar[ca + k];
+    for (int k = 0; k < sz; ++k) delta[ct + k] = x[xo + k] - m.xbar[ca + k];
+    D[i] = 1.0;
   }
 }
-
-// one wave per residual row: r = b + A_row . delta, cost term, and J_row = A_row D (constant columns zero)
-template <bool WITH_J>
-__global__ __launch_bounds__(64) void marg_eval_kernel(MargDev m, double* __restrict__ cost_part) {
+// (factors too wide for the LDS copy: delta and D through global memory, a launch in front)
+__global__ void marg_delta_kernel(MargDev m, const double* __restrict__ x) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i < m.nblk) marg_delta_block(m, i, x, m.delta, m.D);
+}
+template <bool WITH_J, bool IN_LDS>
+__global__ __launch_bounds__(64) void marg_eval_kernel(MargDev m, const double* __restrict__ x, double* __restrict__ cost_part) {
+  __shared__ double s_delta[IN_LDS ? kMargColsLds : 1];
+  __shared__ double s_D[IN_LDS ? kMargColsLds : 1];
   const int row = blockIdx.x, lane = threadIdx.x;
+  const double* delta = m.delta;
+  const double* D = m.D;
+  if (IN_LDS) {
+    for (int i = lane; i < m.nblk; i += 64) marg_delta_block(m, i, x, s_delta, s_D);
+    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    delta = s_delta; D = s_D;
+  }
   const double* Ar = m.A + (size_t)row * m.cols;
   double acc = 0.0;
-  for (int k = lane; k < m.cols; k += 64) acc = fma(Ar[k], m.delta[k], acc);
+  for (int k = lane; k < m.cols; k += 64) acc = fma(Ar[k], delta[k], acc);
   acc = wave_sum(acc);
   const double r = m.b[row] + acc;
   if (lane == 0) {
@@ -49,16 +65,40 @@ __global__ __launch_bounds__(64) void marg_eval_kernel(MargDev m, double* __rest
     const int bi = m.col_blk[k];
     double v;
     if (m.col_t[k] < 0) v = 0.0;
-    else if (m.blk_quat[bi]) v = Ar[k] * m.D[bi];
+    else if (m.blk_quat[bi]) v = Ar[k] * D[bi];
     else v = Ar[k];
     Jr[k] = v;
   }
 }
 
+// gradient J^T r (also into the rhs row) and diag(J^T J): the workgroups of row blockIdx.y == gridDim.y - 1 of the assembly launch,
+// sixteen columns each, the rows split over the sixteen thread rows
+BSG_DEV void marg_grad_block(const MargDev& m, int a0, double* __restrict__ S, int ld, int rhs_row, double* __restrict__ grad,
+                             double* __restrict__ hdiag, const int* __restrict__ perm, double (*sG)[17], double (*sH)[17]) {
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int a = a0 + tx;
+  double gs = 0.0, hs = 0.0;
+  if (a < m.cols)
+    for (int k = ty; k < m.rows; k += 16) { const double j = m.J[(size_t)k * m.cols + a]; gs = fma(j, m.r[k], gs); hs = fma(j, j, hs); }
+  sG[ty][tx] = gs; sH[ty][tx] = hs;
+  __syncthreads();
+  if (ty != 0 || a >= m.cols) return;
+  const int ta = m.col_t[a];
+  if (ta < 0) return;
+  double g = 0.0, h = 0.0;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { g += sG[q][tx]; h += sH[q][tx]; }
+  atomicAdd(&S[(size_t)rhs_row * ld + perm[ta >> 6] * 64 + (ta & 63)], g);
+  atomicAdd(&grad[ta], g);
+  atomicAdd(&hdiag[ta], h);
+}
+
 // S += J^T J (16 x 16 output tile per workgroup, rows staged through LDS), FP64 atomics because the blocks of a
 // marginal factor are scattered over the reduced system
-__global__ __launch_bounds__(256) void marg_assemble_kernel(MargDev m, double* __restrict__ S, int ld, const int* __restrict__ perm) {
+__global__ __launch_bounds__(256) void marg_assemble_kernel(MargDev m, double* __restrict__ S, int ld, const int* __restrict__ perm, int rhs_row,
+                                                            double* __restrict__ grad, double* __restrict__ hdiag) {
   __shared__ double sA[16][17], sB[16][17];
+  if (blockIdx.y == gridDim.y - 1) { marg_grad_block(m, blockIdx.x * 16, S, ld, rhs_row, grad, hdiag, perm, sA, sB); return; }
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int a0 = blockIdx.y * 16, b0 = blockIdx.x * 16;
   double acc = 0.0;
@@ -78,20 +118,6 @@ __global__ __launch_bounds__(256) void marg_assemble_kernel(MargDev m, double* _
   atomicAdd(&S[(size_t)(perm[ta >> 6] * 64 + (ta & 63)) * ld + perm[tb >> 6] * 64 + (tb & 63)], acc);
 }
 
-// thread per column: gradient J^T r (also into the rhs row) and diag(J^T J)
-__global__ void marg_grad_kernel(MargDev m, double* __restrict__ S, int ld, int rhs_row, double* __restrict__ grad,
-                                 double* __restrict__ hdiag, const int* __restrict__ perm) {
-  const int a = blockIdx.x * 64 + threadIdx.x;
-  if (a >= m.cols) return;
-  const int ta = m.col_t[a];
-  if (ta < 0) return;
-  double gs = 0.0, hs = 0.0;
-  for (int k = 0; k < m.rows; ++k) { const double j = m.J[(size_t)k * m.cols + a]; gs = fma(j, m.r[k], gs); hs = fma(j, j, hs); }
-  atomicAdd(&S[(size_t)rhs_row * ld + perm[ta >> 6] * 64 + (ta & 63)], gs);
-  atomicAdd(&grad[ta], gs);
-  atomicAdd(&hdiag[ta], hs);
-}
-
 // one wave per row: model-cost-change term -(J d)(r + J d / 2)
 __global__ __launch_bounds__(64) void marg_mcc_kernel(MargDev m, const double* __restrict__ delta_tan, double* __restrict__ part) {
   const int row = blockIdx.x, lane = threadIdx.x;
@@ -103,14 +129,18 @@ __global__ __launch_bounds__(64) void marg_mcc_kernel(MargDev m, const double* _
 }
 
 void launch_marg_eval(hipStream_t s, const MargDev& m, const double* x, bool with_J, double* cost_part) {
-  hipLaunchKernelGGL(marg_delta_kernel, dim3((m.nblk + 63) / 64), dim3(64), 0, s, m, x, with_J ? 1 : 0);
-  if (with_J) hipLaunchKernelGGL(marg_eval_kernel<true>, dim3(m.rows), dim3(64), 0, s, m, cost_part);
-  else hipLaunchKernelGGL(marg_eval_kernel<false>, dim3(m.rows), dim3(64), 0, s, m, cost_part);
+  if (m.cols <= kMargColsLds && m.nblk <= kMargColsLds) {
+    if (with_J) hipLaunchKernelGGL((marg_eval_kernel<true, true>), dim3(m.rows), dim3(64), 0, s, m, x, cost_part);
+    else hipLaunchKernelGGL((marg_eval_kernel<false, true>), dim3(m.rows), dim3(64), 0, s, m, x, cost_part);
+    return;
+  }
+  hipLaunchKernelGGL(marg_delta_kernel, dim3((m.nblk + 63) / 64), dim3(64), 0, s, m, x);
+  if (with_J) hipLaunchKernelGGL((marg_eval_kernel<true, false>), dim3(m.rows), dim3(64), 0, s, m, x, cost_part);
+  else hipLaunchKernelGGL((marg_eval_kernel<false, false>), dim3(m.rows), dim3(64), 0, s, m, x, cost_part);
 }
 void launch_marg_assemble(hipStream_t s, const MargDev& m, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm) {
   const int g = (m.cols + 15) / 16;
-  hipLaunchKernelGGL(marg_assemble_kernel, dim3(g, g), dim3(256), 0, s, m, S, ld, perm);
-  hipLaunchKernelGGL(marg_grad_kernel, dim3((m.cols + 63) / 64), dim3(64), 0, s, m, S, ld, rhs_row, grad, hdiag, perm);
+  hipLaunchKernelGGL(marg_assemble_kernel, dim3(g, g + 1), dim3(256), 0, s, m, S, ld, perm, rhs_row, grad, hdiag);   // (row g: gradient and diagonal)
 }
 void launch_marg_mcc(hipStream_t s, const MargDev& m, const double* delta_tan, double* part) {
   hipLaunchKernelGGL(marg_mcc_kernel, dim3(m.rows), dim3(64), 0, s, m, delta_tan, part);

@@ -227,7 +227,7 @@ def main():
             achieved = nbytes / (ms * 1e-3) / 1e9
             working_set_mb = nbytes / 1e6
             # (a window that also has IMU factors evaluates them as the first workgroups of the same launch: k_small.hip)
-            merged_imu = pr.n_factors(capi.F_IMU_DELTA) > 0 and pr.n_factors(capi.F_IMU_PRIOR) > 0 and os.environ.get("BSGPU_EVAL_MERGE", "2") == "2"
+            merged_imu = pr.n_factors(capi.F_IMU_DELTA) + pr.n_factors(capi.F_IMU_PRIOR) > 0 and os.environ.get("BSGPU_EVAL_MERGE", "2") == "2"
             eval_kernel = "visual_imu_eval_kernel<true>" if merged_imu else "reproj_eval_kernel<true>"
             roofline = {"bound": "hbm", "kernel": eval_kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_measured_copy_peak": round(achieved / HBM_COPY_GBS, 4),
