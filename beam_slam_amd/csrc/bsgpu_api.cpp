@@ -736,7 +736,7 @@ static int covariance_of(bsgpu_ctx* c, const std::vector<int>& blocks, double* o
   if (hipMalloc((void**)&d_out, sizeof(double) * D * D) != hipSuccess) { (void)hipFree(d_cols); return fail(c, BSGPU_ERR_DEVICE, "out of device memory"); }
   (void)hipMemcpyAsync(d_cols, cols.data(), sizeof(int) * cols.size(), hipMemcpyHostToDevice, s);
   launch_cov_units(s, c->d_S, c->npad, c->plan.rhs_row, d_cols, D);
-  DenseDev D0{c->d_perm, c->d_nreal, c->d_rows_flat, c->d_panels, c->d_Lp, c->d_Vinv,
+  DenseDev D0{c->d_nreal, c->d_rows_flat, c->d_panels, c->d_Lp, c->d_Vinv,
               c->d_bs_desc, c->d_chain_begin, c->d_chain_end, c->d_tile_sync, c->d_ftasks, c->d_fsync};
   D0.Winv = c->d_Winv; D0.tile_tot = c->d_tile_tot; D0.rhs_rows = D;
   dense_factor(s, c->plan, D0, c->d_S, c->d_scal);
@@ -997,7 +997,7 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
   for (int j = 0; j < n; ++j) real[P.spos(j)] = 1;
   for (int i = 0; i < npad; ++i) if (!real[i]) hS[(size_t)i * npad + i] = 1.0;
   double *dS = nullptr, *dLp = nullptr, *dV = nullptr, *dy = nullptr, *dscal = nullptr;
-  int *dperm = nullptr, *dnreal = nullptr, *drows = nullptr;
+  int *dnreal = nullptr, *drows = nullptr;
   PanelDesc *dpan = nullptr, *dsep = nullptr;
   int *dpot2 = nullptr, *dcb = nullptr, *dce = nullptr, *dsync = nullptr, *dfsync = nullptr, *dtot = nullptr;
   double* dW = nullptr;
@@ -1014,7 +1014,7 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
             hipMalloc(&dV, sizeof(double) * chol_vinv_stride() * std::max(1, T)) == hipSuccess && hipMalloc(&dy, sizeof(double) * npad) == hipSuccess &&
             hipMalloc(&dscal, sizeof(double) * SC_NUM) == hipSuccess;
   std::vector<int> rf = P.rows_flat; if (rf.empty()) rf.push_back(0);
-  ok = ok && up(P.perm.data(), sizeof(int) * P.perm.size(), (void**)&dperm) && up(P.nreal.data(), sizeof(int) * P.nreal.size(), (void**)&dnreal) &&
+  ok = ok && up(P.nreal.data(), sizeof(int) * P.nreal.size(), (void**)&dnreal) &&
        up(rf.data(), sizeof(int) * rf.size(), (void**)&drows) &&
        up(P.panels.data(), sizeof(PanelDesc) * P.panels.size(), (void**)&dpan) &&
        up(P.bs_desc.data(), sizeof(int) * P.bs_desc.size(), (void**)&dpot2) &&
@@ -1033,7 +1033,7 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, s);
-    DenseDev D{dperm, dnreal, drows, dpan, dLp, dV, dpot2, dcb, dce, dsync, dft, dfsync};
+    DenseDev D{dnreal, drows, dpan, dLp, dV, dpot2, dcb, dce, dsync, dft, dfsync};
     D.Winv = dW; D.tile_tot = dtot;
     if (P.bs_level_sync && !getenv("BSGPU_BACKSOLVE_LEGACY") &&
         up(P.bs_desc_chain.data(), sizeof(int) * P.bs_desc_chain.size(), (void**)&dbc) && up(P.rows_flat_chain.data(), sizeof(int) * P.rows_flat_chain.size(), (void**)&drc) &&
@@ -1055,7 +1055,7 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   } else rc = BSGPU_ERR_DEVICE;
   (void)hipFree(dS); (void)hipFree(dLp); (void)hipFree(dV); (void)hipFree(dy); (void)hipFree(dscal);
-  (void)hipFree(dperm); (void)hipFree(dnreal); (void)hipFree(drows); (void)hipFree(dpan);
+  (void)hipFree(dnreal); (void)hipFree(drows); (void)hipFree(dpan);
   (void)hipFree(dsep); (void)hipFree(dpot2); (void)hipFree(dcb); (void)hipFree(dce); (void)hipFree(dsync);
   (void)hipFree(dft); (void)hipFree(dfsync); (void)hipFree(dtot); (void)hipFree(dW);
   (void)hipFree(dbc); (void)hipFree(drc); (void)hipFree(dbu); (void)hipFree(dbur);

@@ -191,7 +191,8 @@ struct bsgpu_ctx {
   // tiled Cholesky plan (dense_plan.h) and its device tables
   DensePlan plan;
   std::vector<uint8_t> tile_adj;   // natural-tile adjacency of the reduced system
-  int *d_perm = nullptr, *d_iperm = nullptr, *d_nreal = nullptr, *d_rows_flat = nullptr;
+  int *d_dpos = nullptr, *d_inat = nullptr;   // DensePlan::dpos / inat on the device: tangent index -> position in S and back
+  int *d_nreal = nullptr, *d_rows_flat = nullptr;
   PanelDesc* d_panels = nullptr;
   int *d_bs_desc_chain = nullptr, *d_rows_flat_chain = nullptr, *d_bs_upd = nullptr, *d_bs_upd_rows = nullptr;
   int *d_bs_chain_group = nullptr, *d_bs_grp_nchains = nullptr, *d_bs_grp_nitems = nullptr, *d_bs_items4 = nullptr, *d_bs_tile_updated = nullptr, *d_bs_sync = nullptr, *d_bs_order = nullptr;
@@ -331,7 +332,7 @@ int ensure_vis_src(bsgpu_ctx* c);
 // Cholesky of the (padded, rhs-augmented, solver-ordered) reduced system in S and the solve L^T y = y', following the plan's
 // step schedule; y comes back in solver order (npad entries)
 struct DenseDev {
-  const int *perm, *nreal, *rows_flat;
+  const int *nreal, *rows_flat;
   const PanelDesc* panels;
   double *Lp, *Vinv;
   const int *bs_desc, *chain_begin, *chain_end;   // bs_desc: DensePlan::bs_desc on the device

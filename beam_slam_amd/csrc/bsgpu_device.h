@@ -115,9 +115,8 @@ BSG_DEV double loss_eval(const DevLoss& L, double s, double* rho1) {
 BSG_DEV void pose_diag_element(int i, int n_pose, double* __restrict__ S, int ld, const double* __restrict__ hdiag, double inv_radius,
                                int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* __restrict__ scale,
                                double* __restrict__ dcl, const int* __restrict__ iperm) {
-  const int nat = iperm[i >> 6];                          // natural tile, or -1 for the rhs tile
-  const int j = nat < 0 ? n_pose : nat * 64 + (i & 63);   // tangent index
-  if (j < n_pose) {
+  const int j = iperm[i];                                 // tangent index, or -1 on the padding and the rhs tile
+  if (j >= 0) {
     const double h = hdiag[j];
     double sc = compute_scale ? (jacobi ? 1.0 / (1.0 + sqrt(h)) : 1.0) : scale[j];
     double d = compute_dcl ? fmin(fmax(sc * sc * h, lm_lo), lm_hi) / (sc * sc) : dcl[j];
@@ -222,14 +221,14 @@ BSG_DEV void small_assemble_unit(const SmallGroupSet& set, int unit, int lane, i
     double acc = 0.0;
     for (int k = 0; k < m; ++k) acc += sJ[k * tw + a] * sJ[k * tw + b];
     const int ra = ta + a % 3, rb = tb + b % 3;
-    atomicAdd(&S[(size_t)(perm[ra >> 6] * 64 + (ra & 63)) * ld + perm[rb >> 6] * 64 + (rb & 63)], acc);
+    atomicAdd(&S[(size_t)perm[ra] * ld + perm[rb]], acc);
   }
   for (int a = lane; a < wcut; a += nthr) {
     const int ta = st[a / 3];
     if (ta < 0) continue;
     double gs = 0.0, hs = 0.0;
     for (int k = 0; k < m; ++k) { const double j = sJ[k * tw + a]; gs += j * sr[k]; hs += j * j; }
-    atomicAdd(&S[(size_t)rhs_row * ld + perm[(ta + a % 3) >> 6] * 64 + ((ta + a % 3) & 63)], gs);
+    atomicAdd(&S[(size_t)rhs_row * ld + perm[ta + a % 3]], gs);
     atomicAdd(&grad[ta + a % 3], gs);
     atomicAdd(&hdiag[ta + a % 3], hs);
   }

@@ -1,6 +1,7 @@
 // finalize(): flattening of the described problem to device tables — what [EXT] fuse HashGraph::createProblem does for the
 // reference's `graph_->optimize()` (bs_optimizers/src/fixed_lag_smoother.cpp:281), with a deterministic variable index.
 #include "bsgpu_ctx.h"
+#include "dim_order.h"
 
 namespace bsg {
 
@@ -144,6 +145,35 @@ int finalize(bsgpu_ctx* c) {
   // finalize(): the dense tile storage, 2 x npad^2 doubles, is not allocated on spec; C4 that way: DESIGN.md 3.3)
   const bool exact_pose_graph = getenv("BSGPU_EXACT_POSE_GRAPH") != nullptr;
   c->dense_ok = (size_t)c->npad <= kDenseLimit || ((nl + n_rho > 0 || c->n_leaf_tiles > 0 || exact_pose_graph) && (size_t)c->npad <= kDenseLimitLandmarks);   // else: block-sparse PCG (pose-only problems)
+  // The graph of the reduced system's tangent BLOCKS (which pairs of pose-side blocks some factor, some shared landmark or a dense prior
+  // couples): what the per-dimension ordering of the factorisation is found on (dim_order.h).  A bit matrix; every place below that marks
+  // the natural-tile adjacency marks it too.  Not kept for windows that take the tile-level order (leaf tiles of BSGPU_IDP_ELIM=0,
+  // systems beyond the dense limit, BSGPU_DIM_ORDER=0).
+  struct BlockGraph {
+    int nbk = 0, words = 0;
+    std::vector<int> bid_of_t, t0, w;
+    std::vector<uint64_t> bits;
+    inline void add(int ta, int tb) {
+      const int a = bid_of_t[ta], b = bid_of_t[tb];
+      bits[(size_t)a * words + (b >> 6)] |= 1ull << (b & 63);
+      bits[(size_t)b * words + (a >> 6)] |= 1ull << (a & 63);
+    }
+  } bg;
+  {
+    const char* ed = getenv("BSGPU_DIM_ORDER");
+    int nbk = 0;
+    for (int b = 0; b < nb; ++b) if (c->toff[b] >= 0 && c->toff[b] < c->n_pose) ++nbk;
+    if (c->dense_ok && c->n_leaf_tiles == 0 && nbk > 0 && nbk <= 8192 && !(ed && atoi(ed) == 0)) {
+      bg.nbk = nbk; bg.words = (nbk + 63) / 64;
+      bg.bid_of_t.assign(c->n_pose, -1);
+      bg.t0.reserve(nbk); bg.w.reserve(nbk);
+      for (int b = 0; b < nb; ++b) if (c->toff[b] >= 0 && c->toff[b] < c->n_pose) {   // (block order = tangent order)
+        for (int k = 0; k < c->tsize[b]; ++k) bg.bid_of_t[c->toff[b] + k] = (int)bg.t0.size();
+        bg.t0.push_back(c->toff[b]); bg.w.push_back(c->tsize[b]);
+      }
+      bg.bits.assign((size_t)nbk * bg.words, 0);
+    }
+  }
   int row = 0;
   for (int t = 0; t < BSGPU_F_NUM_TYPES; ++t) { c->row0[t] = row; row += c->groups[t].n * kTypes[t].m; }
   for (const HostMarginal& mg : c->marginals) row += mg.rows;
@@ -363,6 +393,7 @@ int finalize(bsgpu_ctx* c) {
       for (int a = ra; a < ra + 3; a += 2) for (int b = rb; b < rb + 3; b += 2) {
         c->tile_adj[(size_t)(a / 64) * T + b / 64] = 1; c->tile_adj[(size_t)(b / 64) * T + a / 64] = 1;
       }
+      if (bg.nbk) bg.add(ra, rb);
     };
     for (int s = 0; s < V.n_seg; ++s) {
       const int i = seg_ci[s], j = seg_cj[s];
@@ -392,14 +423,21 @@ int finalize(bsgpu_ctx* c) {
         const unsigned char* d_bc = c->upload(bc); const int* d_bl = c->upload(lm_index);
         const int T = (c->n_pose + 63) / 64;
         bool all_const = false;
+        FlattenSegsHost segs_host;
         auto dalloc = [&](size_t bytes) -> void* { return c->alloc<unsigned char>(bytes); };
         const FlattenResident res = {mir.d_idx, mir.d_consts, mir.d_lk, mir.d_la, mir.d_s2b};
         const int st = flatten_visual_device(c->stream, dalloc, g0.n, g0.idx.data(), g0.consts.data(), g0.loss_kind.data(), g0.loss_a.data(),
                                              losses, nb, d_bx, d_bt, d_bc, d_bl, nl, T, c->vis, &c->d_vis_src, c->tile_adj, &all_const,
-                                             resident ? &res : nullptr);
+                                             resident ? &res : nullptr, bg.nbk ? &segs_host : nullptr);
         if (st < 0) return fail(c, BSGPU_ERR_DEVICE, "device error while flattening the reprojection factors");
         if (st == 0) {
           flattened_on_device = true;
+          if (bg.nbk)
+            for (size_t sgi = 0; sgi < segs_host.seg_ci.size(); ++sgi) {
+              const int i = segs_host.seg_ci[sgi], j = segs_host.seg_cj[sgi];
+              const int ri[2] = {segs_host.cp_tq[i], segs_host.cp_tp[i]}, rj[2] = {segs_host.cp_tq[j], segs_host.cp_tp[j]};
+              for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) if (ri[a] >= 0 && rj[b] >= 0) bg.add(ri[a], rj[b]);
+            }
           if (all_const) { c->any_inactive = true; c->vis_any_inactive = true; }
           if (c->vis.n_cam_pose >= (1 << 20)) return fail(c, BSGPU_ERR_UNSUPPORTED, "too many camera poses");
         } else {
@@ -455,6 +493,7 @@ int finalize(bsgpu_ctx* c) {
             if (ra < 0 || rb < 0 || ra >= c->n_pose || rb >= c->n_pose) continue;   // (an eliminated inverse-depth slot is not in the reduced system)
             const int wa = c->tsize[idx[sa]], wb = c->tsize[idx[sb]];
             for (int a = ra; a < ra + wa; a += std::max(1, wa - 1)) for (int b = rb; b < rb + wb; b += std::max(1, wb - 1)) c->tile_adj[(size_t)(a / 64) * T + b / 64] = 1;
+            if (bg.nbk && sb < sa) bg.add(ra, rb);
           }
       }
     }
@@ -722,6 +761,7 @@ int finalize(bsgpu_ctx* c) {
         for (int a = ra; a < ra + 3; a += 2) for (int b = rb; b < rb + 3; b += 2) {
           c->tile_adj[(size_t)(a / 64) * T + b / 64] = 1; c->tile_adj[(size_t)(b / 64) * T + a / 64] = 1;
         }
+        if (bg.nbk) bg.add(ra, rb);
       };
       for (int sgi = 0; sgi < E.n_seg; ++sgi) {
         const int i = seg_ci[sgi], j = seg_cj[sgi];
@@ -787,8 +827,13 @@ int finalize(bsgpu_ctx* c) {
       if (!d.J || !mc.part_mcc) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (marginal factor)");
       mc.row0 = mrow; mrow += mg.rows;
       part_max = std::max(part_max, (size_t)mg.rows);
-      if (mc.active)   // a dense prior couples every pair of its blocks
+      if (mc.active) {   // a dense prior couples every pair of its blocks
         for (int ta : col_t) for (int tb : col_t) if (ta >= 0 && tb >= 0) c->tile_adj[(size_t)(ta / 64) * T + tb / 64] = 1;
+        if (bg.nbk) for (size_t i = 0; i < mg.blocks.size(); ++i) for (size_t j = 0; j < i; ++j) {
+          const int bi = mg.blocks[i], bj = mg.blocks[j];
+          if (!c->is_const[bi] && !c->is_const[bj]) bg.add(c->toff[bi], c->toff[bj]);
+        }
+      }
       c->marg.push_back(mc);
     }
   }
@@ -807,46 +852,57 @@ int finalize(bsgpu_ctx* c) {
     c->d_x = c->upload(c->h_x); c->d_x0 = c->upload(c->h_x);
     c->d_xcand = c->alloc<double>(c->h_x.size());
   }
-  // ---- dense system + vectors
-  if (c->dense_ok) {
-    c->d_S = c->alloc<double>((size_t)c->npad * c->npad);
-    if (!c->d_S) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (reduced system)");
-    // cleared once here (the buffer comes from the pool); a step then clears only the tiles anything writes (plan.touched_tiles)
-    launch_zero(c->stream, c->d_S, (int64_t)c->npad * c->npad);
-  }
-  c->d_grad = c->alloc<double>(c->n_tan); c->d_hdiag = c->alloc<double>(c->n_tan);
-  c->d_scale = c->alloc<double>(c->n_tan); c->d_dcl = c->alloc<double>(c->n_tan);
-  c->d_delta = c->alloc<double>(c->n_tan); c->d_y = c->alloc<double>(c->npad);
-  c->d_scal = c->alloc<double>(SC_NUM);
-  c->d_part = c->alloc<double>(part_max + 8);
-  if (!c->h_scal) {
-    HIPCHK(c, hipHostMalloc((void**)&c->h_scal, sizeof(double) * SC_NUM, hipHostMallocMapped));
-    if (hipHostGetDevicePointer((void**)&c->h_scal_dev, c->h_scal, 0) != hipSuccess) { (void)hipGetLastError(); c->h_scal_dev = nullptr; }
-  }
-  if (!c->h_radius) HIPCHK(c, hipHostMalloc((void**)&c->h_radius, sizeof(double)));
-  chol_prepare();
-  // hipGraph replay of the LM step is opt-in (BSGPU_GRAPH=1): on ROCm 7.2 the replay inserts a ~0.9 ms bubble
-  // inside the long dependent kernel chain (profiles/README.md), which cancels what it saves on launches
-  c->use_graphs = getenv("BSGPU_GRAPH") != nullptr;
-  HIPCHK(c, hipMemset(c->d_scal, 0, sizeof(double) * SC_NUM));
-  HIPCHK(c, hipMemset(c->d_delta, 0, sizeof(double) * std::max(1, c->n_tan)));
-  lap("blocks + dense buffers");
   // ---- tiled Cholesky plan: nested-dissection tile order, symbolic factorisation, step schedule
   {
     const char* e = getenv("BSGPU_CHAINS");
     const int max_chains = e ? std::max(1, atoi(e)) : 16;
-    const int T = (c->n_pose + 63) / 64;
-    if (c->tile_adj.size() != (size_t)T * T) c->tile_adj.assign((size_t)T * T, 0);
+    {
+      const int T0 = (c->n_pose + 63) / 64;
+      if (c->tile_adj.size() != (size_t)T0 * T0) c->tile_adj.assign((size_t)T0 * T0, 0);
+    }
     const char* e2 = getenv("BSGPU_MIN_PIECE");
     const char* e3 = getenv("BSGPU_SHARED");   // panels of one step may update the same tiles (atomics): on unless BSGPU_SHARED=0
     const bool use_leaf = c->n_leaf_tiles > 0 && !getenv("BSGPU_NO_LEAF_TILES");
-    c->plan.build(c->n_pose, c->tile_adj, c->dense_ok ? max_chains : 1, e2 ? std::max(1, atoi(e2)) : 1, !(e3 && atoi(e3) == 0), use_leaf ? &c->leaf_tile : nullptr);
+    bool ordered = false;
+    if (bg.nbk && max_chains > 1) {
+      // per-dimension order (dim_order.h): nested dissection of the block graph, separators = sets of tangent blocks
+      DimOrder ord;
+      ord.n_pose = c->n_pose; ord.blk_t0 = bg.t0; ord.blk_w = bg.w;
+      ord.adj_ptr.assign(bg.nbk + 1, 0);
+      for (int a = 0; a < bg.nbk; ++a) {
+        const uint64_t* rowb = &bg.bits[(size_t)a * bg.words];
+        for (int wd = 0; wd < bg.words; ++wd) {
+          uint64_t m = rowb[wd];
+          while (m) { const int b = wd * 64 + __builtin_ctzll(m); m &= m - 1; if (b != a) ord.adj.push_back(b); }
+        }
+        ord.adj_ptr[a + 1] = (int)ord.adj.size();
+      }
+      if (const char* ev = getenv("BSGPU_DIM_ORDER_STEP_US")) ord.t_step = atof(ev);
+      if (const char* ev = getenv("BSGPU_DIM_ORDER_HOP_US")) ord.t_hop = atof(ev);
+      if (const char* ev = getenv("BSGPU_DIM_ORDER_DEPTH")) ord.max_depth = std::max(0, atoi(ev));
+      ord.build();
+      // tile adjacency in S order from the block graph (a block lies in at most two tiles of its supernode)
+      const int To = ord.T;
+      std::vector<uint8_t> adjS((size_t)To * To, 0);
+      auto mark = [&](int a, int b) {
+        const int a0 = ord.dpos[bg.t0[a]] >> 6, a1 = ord.dpos[bg.t0[a] + bg.w[a] - 1] >> 6, b0 = ord.dpos[bg.t0[b]] >> 6, b1 = ord.dpos[bg.t0[b] + bg.w[b] - 1] >> 6;
+        for (int x = a0; x <= a1; ++x) for (int y = b0; y <= b1; ++y) { adjS[(size_t)x * To + y] = 1; adjS[(size_t)y * To + x] = 1; }
+      };
+      for (int a = 0; a < bg.nbk; ++a) {
+        mark(a, a);
+        for (int e4 = ord.adj_ptr[a]; e4 < ord.adj_ptr[a + 1]; ++e4) if (ord.adj[e4] < a) mark(a, ord.adj[e4]);
+      }
+      c->plan.build_ordered(c->n_pose, To, ord.dpos, ord.nreal, adjS, ord.piece_ranges, ord.sep_ranges_by_level, !(e3 && atoi(e3) == 0));
+      ordered = true;
+      if (timing) fprintf(stderr, "[bsgpu finalize] per-dimension order: %d blocks, %d supernodes, depth %d, estimated path %.0f us\n", bg.nbk, ord.n_nodes, ord.depth, ord.est_path_us);
+    }
+    if (!ordered)
+      c->plan.build(c->n_pose, c->tile_adj, c->dense_ok ? max_chains : 1, e2 ? std::max(1, atoi(e2)) : 1, !(e3 && atoi(e3) == 0), use_leaf ? &c->leaf_tile : nullptr);
     c->npad = c->plan.npad;
+    const int T = c->plan.T;
     if (timing) fprintf(stderr, "[bsgpu finalize] Cholesky plan: %d tiles (%d leaf), %d pieces, %d panel steps, %d back-substitution launches\n", c->plan.T,
                         c->plan.n_leaf_tiles, c->plan.n_pieces, c->plan.n_steps(), (int)c->plan.bs_group_off.size() - 1);
-    std::vector<int> iperm(T + 1, -1);
-    for (int t = 0; t < T; ++t) iperm[c->plan.perm[t]] = t;
-    c->d_perm = c->upload(c->plan.perm); c->d_iperm = c->upload(iperm); c->d_nreal = c->upload(c->plan.nreal);
+    c->d_dpos = c->upload(c->plan.dpos); c->d_inat = c->upload(c->plan.inat); c->d_nreal = c->upload(c->plan.nreal);
     c->d_rows_flat = c->upload(c->plan.rows_flat);
     c->d_panels = c->upload(c->plan.panels);
     c->d_bs_desc = c->upload(c->plan.bs_desc);
@@ -883,6 +939,30 @@ int finalize(bsgpu_ctx* c) {
     c->d_ytan = c->alloc<double>(std::max(1, c->n_pose));
     if (c->dense_ok) { c->d_Lp = c->alloc<double>((size_t)c->npad * c->npad); if (!c->d_Lp) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (L panels)"); }
   }
+  // ---- dense system + vectors
+  if (c->dense_ok) {
+    c->d_S = c->alloc<double>((size_t)c->npad * c->npad);
+    if (!c->d_S) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (reduced system)");
+    // cleared once here (the buffer comes from the pool); a step then clears only the tiles anything writes (plan.touched_tiles)
+    launch_zero(c->stream, c->d_S, (int64_t)c->npad * c->npad);
+  }
+  c->d_grad = c->alloc<double>(c->n_tan); c->d_hdiag = c->alloc<double>(c->n_tan);
+  c->d_scale = c->alloc<double>(c->n_tan); c->d_dcl = c->alloc<double>(c->n_tan);
+  c->d_delta = c->alloc<double>(c->n_tan); c->d_y = c->alloc<double>(c->npad);
+  c->d_scal = c->alloc<double>(SC_NUM);
+  c->d_part = c->alloc<double>(part_max + 8);
+  if (!c->h_scal) {
+    HIPCHK(c, hipHostMalloc((void**)&c->h_scal, sizeof(double) * SC_NUM, hipHostMallocMapped));
+    if (hipHostGetDevicePointer((void**)&c->h_scal_dev, c->h_scal, 0) != hipSuccess) { (void)hipGetLastError(); c->h_scal_dev = nullptr; }
+  }
+  if (!c->h_radius) HIPCHK(c, hipHostMalloc((void**)&c->h_radius, sizeof(double)));
+  chol_prepare();
+  // hipGraph replay of the LM step is opt-in (BSGPU_GRAPH=1): on ROCm 7.2 the replay inserts a ~0.9 ms bubble
+  // inside the long dependent kernel chain (profiles/README.md), which cancels what it saves on launches
+  c->use_graphs = getenv("BSGPU_GRAPH") != nullptr;
+  HIPCHK(c, hipMemset(c->d_scal, 0, sizeof(double) * SC_NUM));
+  HIPCHK(c, hipMemset(c->d_delta, 0, sizeof(double) * std::max(1, c->n_tan)));
+  lap("blocks + dense buffers");
   {
     c->n_part_upd = (nb + 255) / 256;
     c->n_upd_blocks = 0; c->d_upd_blocks = nullptr; c->d_lm_xoff = nullptr;

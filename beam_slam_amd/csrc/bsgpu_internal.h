@@ -262,12 +262,14 @@ void launch_triangulate(hipStream_t s, int n_tracks, const int* track_start, con
 // device-side flattening of the reprojection factors (k_flatten.hip): 0 = done, 1 = take the host path, < 0 = device error.
 // `res` non-null: the raw table is already on the device, its block columns naming caller slots (SlotMirror, bsgpu_ctx.h)
 struct FlattenResident { const int* idx; const double* consts; const int* loss_kind; const double* loss_a; const int* slot_map; };
+struct FlattenSegsHost { std::vector<int> seg_ci, seg_cj, cp_tq, cp_tp; };   // host copies of the camera-pose pair segments (optional output)
 void launch_patch_factor_rows(hipStream_t s, int n_ch, const int* rows, const int* idx4, const double* consts3, const int* lk, const double* la,
                               int* dst_idx, double* dst_consts, int* dst_lk, double* dst_la);
 int flatten_visual_device(hipStream_t s, const std::function<void*(size_t)>& dalloc, int n, const int* h_idx, const double* h_consts,
                           const int* h_loss_kind, const double* h_loss_a, const std::vector<DevLoss>& losses, int nb, const int* d_blk_xoff,
                           const int* d_blk_toff, const unsigned char* d_blk_const, const int* d_blk_lm, int nl, int T, Visual& V,
-                          int** d_vis_src, std::vector<unsigned char>& tile_adj, bool* any_all_const, const FlattenResident* res = nullptr);
+                          int** d_vis_src, std::vector<unsigned char>& tile_adj, bool* any_all_const, const FlattenResident* res = nullptr,
+                          FlattenSegsHost* segs_out = nullptr);
 int chol_vinv_stride();
 void chol_prepare();  // one-time function attributes (kept out of captured sequences)
 // block-sparse PCG path (k_pcg.hip)

@@ -152,7 +152,7 @@ void spcg_solve(bsgpu_ctx* c, const bsgpu_options& o) {
     }
   }
   c->pcg_iters_total += (int)last[pcg_iters_slot()];
-  launch_spcg_finish(s, T, c->d_sx, c->d_iperm, c->n_pose, c->d_ytan, c->d_delta);
+  launch_spcg_finish(s, T, c->d_sx, c->d_inat, c->n_pose, c->d_ytan, c->d_delta);
 }
 
 // residuals (+ Jacobians) of every factor group; per-group cost partials go to the arrays the
@@ -235,7 +235,7 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
   // (inverse-depth landmarks: their scalar elimination, k_idp.hip — after the clearing above, which rides in the landmark launch)
   launch_idp_landmark(s, c->idp, c->small[BSGPU_F_IDP_REPROJ], c->use_graphs ? c->d_scal + SC_RADIUS : nullptr, radius, first ? 1 : 0, new_J ? 1 : 0,
                       o.jacobi_scaling, o.min_lm_diagonal, o.max_lm_diagonal, c->d_scale, c->d_dcl, c->d_grad);
-  launch_idp_pairs(s, c->idp, c->small[BSGPU_F_IDP_REPROJ], c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm, gradient_only);
+  launch_idp_pairs(s, c->idp, c->small[BSGPU_F_IDP_REPROJ], c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_dpos, gradient_only);
   phase_mark(c, BSGPU_PHASE_LANDMARK);
   {
     // (the factor-wise assembled pose-only groups ride in the pair launch when there is one; further groups, or all of them, go by themselves)
@@ -243,7 +243,7 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
     int taken = 0, units = 0;
     if (c->vis.n_seg > 0) units = small_assemble_first_set(c->small_factorwise + 2, kNumInternal - 2, &set, &taken);
     if (units == 0) taken = 0;
-    launch_pairs(s, c->vis, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm, gradient_only, units > 0 ? &set : nullptr, units);
+    launch_pairs(s, c->vis, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_dpos, gradient_only, units > 0 ? &set : nullptr, units);
     phase_mark(c, BSGPU_PHASE_PAIRS);
     // (... or, without a pair launch, in the launch of the segment-wise assembled groups)
     SmallGroupSet set2;
@@ -251,19 +251,19 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
     if (units == 0 && c->n_sa_seg + c->n_asm_grp > 0) units2 = small_assemble_first_set(c->small_factorwise + 2, kNumInternal - 2, &set2, &taken2);
     if (units2 == 0) taken2 = 0;
     launch_small_assemble_set(s, c->small_factorwise + 2 + taken + taken2, kNumInternal - 2 - taken - taken2, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag,
-                              c->d_perm);
+                              c->d_dpos);
     launch_small_assemble_seg(s, c->d_small_groups, c->n_sa_seg, c->d_sa_seg_start, c->d_sa_seg_ra, c->d_sa_seg_rb, c->d_sa_contrib, c->d_S, c->npad,
-                              c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm, units2 > 0 ? &set2 : nullptr, units2, c->n_asm_grp, c->d_asm_grp, c->d_asm_gfac);
+                              c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_dpos, units2 > 0 ? &set2 : nullptr, units2, c->n_asm_grp, c->d_asm_grp, c->d_asm_gfac);
   }
   for (const auto& mc : c->marg)
-    if (mc.active) launch_marg_assemble(s, mc.dev, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_perm);
+    if (mc.active) launch_marg_assemble(s, mc.dev, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_dpos);
   if (new_J)   // the LM diagonal and the gradient norms both follow the assembly and do not depend on each other: one launch
     launch_grad_norms_pose_diag(s, c->nb, c->d_blk_xoff, c->d_blk_toff, c->d_blk_size, c->d_blk_manifold, c->d_x, c->d_grad, c->d_gpart,
                                 c->n_pose, c->d_S, c->npad, c->d_hdiag, cleared ? nullptr : c->d_scal + SC_RADIUS, first ? 1 : 0, 1, o.jacobi_scaling,
-                                o.min_lm_diagonal, o.max_lm_diagonal, c->d_scale, c->d_dcl, c->npad, c->d_iperm, radius);
+                                o.min_lm_diagonal, o.max_lm_diagonal, c->d_scale, c->d_dcl, c->npad, c->d_inat, radius);
   else
     launch_pose_diag(s, c->n_pose, c->d_S, c->npad, c->d_hdiag, cleared ? nullptr : c->d_scal + SC_RADIUS, 0, 0, o.jacobi_scaling,
-                     o.min_lm_diagonal, o.max_lm_diagonal, c->d_scale, c->d_dcl, c->npad, c->d_iperm, radius);
+                     o.min_lm_diagonal, o.max_lm_diagonal, c->d_scale, c->d_dcl, c->npad, c->d_inat, radius);
   phase_mark(c, BSGPU_PHASE_ASSEMBLE_OTHER);
 }
 
@@ -331,13 +331,13 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
     phase_mark(c, BSGPU_PHASE_FACTOR);
     phase_mark(c, BSGPU_PHASE_BACKSOLVE);
   } else if (c->n_pose > 0) {
-    const DenseDev D{c->d_perm, c->d_nreal, c->d_rows_flat, c->d_panels, c->d_Lp, c->d_Vinv,
+    const DenseDev D{c->d_nreal, c->d_rows_flat, c->d_panels, c->d_Lp, c->d_Vinv,
                      c->d_bs_desc, c->d_chain_begin, c->d_chain_end, c->d_tile_sync, c->d_ftasks, c->d_fsync,
                      c->d_bs_desc_chain, c->d_rows_flat_chain, c->d_bs_upd, c->d_bs_upd_rows,
                      c->d_bs_chain_group, c->d_bs_grp_nchains, c->d_bs_grp_nitems, c->d_bs_items4, c->d_bs_tile_updated, c->d_bs_sync, c->d_scal, c->d_Winv, c->d_bs_order, c->d_tile_tot, 1};
     dense_factor(s, c->plan, D, c->d_S, c->d_scal);
     phase_mark(c, BSGPU_PHASE_FACTOR);
-    dense_backsolve(s, c->plan, D, c->d_S, c->d_y, c->d_iperm, c->n_pose, c->d_ytan, c->d_delta);
+    dense_backsolve(s, c->plan, D, c->d_S, c->d_y, c->d_inat, c->n_pose, c->d_ytan, c->d_delta);
     phase_mark(c, BSGPU_PHASE_BACKSOLVE);
   }
   // landmark back-substitution + the model-cost-change terms of the visual factors (partial arrays only, summed once at the end)

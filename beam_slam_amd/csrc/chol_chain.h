@@ -156,6 +156,7 @@ struct ChainUpdater {
   int offS[2][4];       // ... staging position (result layout) of row block rowsel[j]
   double* P0;
   int mask_lo, mask_nr; // the partial tile's first row block (or < 0) and its number of real columns
+  int nb_real;          // column blocks that hold real columns (chain_factor): the steps of the others are not run
   template <int C, int I> BSG_CHAIN_DEV bool valid() const { return (I < SL::K(C) - 1) || (SL::rem(C) == 4) || (rowsel[C & 3] < SL::rem(C)); }
   // slot (C, I) takes the update of panel PB (in buffer PB & 1)
   template <int PB, int C, int I> BSG_CHAIN_DEV void update() {
@@ -192,6 +193,7 @@ struct ChainUpdater {
   }
   template <int B, class F> BSG_CHAIN_DEV void step(int q, int n, F& load_rest) {
     if constexpr (B < NCB) {
+      if (B >= nb_real) return;                          // (uniform: the chain's last tile ends in padding — every kind of wave stops here)
       if constexpr (B > 0) update_col<B - 1, B, 0>();   // phase A: column B takes its last update ...
       stage<B, 0>(q, n);                                 // ... and is staged
       lds_sync();
@@ -204,9 +206,10 @@ struct ChainUpdater {
 };
 
 template <int NCB>
-BSG_CHAIN_DEV void chain_update_waves(const ChainArgs& A, double* smem, int u, int q, int n, int c0, int ld, __amdgpu_buffer_rsrc_t rS) {
+BSG_CHAIN_DEV void chain_update_waves(const ChainArgs& A, double* smem, int u, int q, int n, int c0, int ld, __amdgpu_buffer_rsrc_t rS, int nb_real) {
   using SL = ChainSlots<NCB>;
   ChainUpdater<NCB> U;
+  U.nb_real = nb_real;
   constexpr int PROWS = kChainPanelRows;
   U.P0 = smem;
 #pragma unroll
@@ -260,6 +263,11 @@ BSG_CHAIN_DEV bool chain_factor(const ChainArgs& A, double* smem, long long* ts)
   const int q = lane >> 4, n = lane & 15;
   const int m = __builtin_amdgcn_readfirstlane(A.m), c0 = __builtin_amdgcn_readfirstlane(A.c0), ld = __builtin_amdgcn_readfirstlane(A.ld);
   const int NCB = 4 * m;
+  // A chain whose LAST tile is partial (a supernode of the per-dimension order is padded to whole tiles at its end; the window's last
+  // tile in the tile-level order): the 16-column blocks made of padding only are unit pivots with nothing below — their steps are
+  // not run (an 81-dimensional separator is six steps, not eight), their part of the factor is written as constants at the end.
+  const int nr_last = __builtin_amdgcn_readfirstlane(A.nreal[c0 + m - 1]);
+  const int nb_real = nr_last < 64 ? 4 * (m - 1) + (nr_last + 15) / 16 : NCB;
   // (the resources start at the chain's first row: 32-bit sizes and offsets, and the matrix passes 4 GB at 23 170 dimensions)
   const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(A.S) + (size_t)c0 * 64 * ld, 0, (int)((size_t)kChainMaxTiles * 64 * ld * sizeof(double)), 0x00020000);
   const __amdgpu_buffer_rsrc_t rL = __builtin_amdgcn_make_buffer_rsrc(A.Lp + (size_t)c0 * 64 * ld, 0, (int)((size_t)kChainMaxTiles * 64 * ld * sizeof(double)), 0x00020000);
@@ -295,13 +303,13 @@ BSG_CHAIN_DEV bool chain_factor(const ChainArgs& A, double* smem, long long* ts)
     // =============================== eliminating waves ===============================
     stamp();
 #pragma unroll 1
-    for (int b = 0; b < NCB; ++b) {
+    for (int b = 0; b < nb_real; ++b) {
       const int k = b >> 2, bq = b & 3;
       double* const P = (b & 1) ? Pbuf1 : Pbuf0;   // panel b
       lds_sync();
       stamp();
-      // phase B: row blocks b+1 .. NCB-1 of the chain, then the identity row blocks 0 .. bq; four per wave
-      const int nc = NCB - 1 - b, nrb = nc + bq + 1;
+      // phase B: row blocks b+1 .. nb_real-1 of the chain (rows of padding are zero and stay zero), then the identity row blocks 0 .. bq; four per wave
+      const int nc = nb_real - 1 - b, nrb = nc + bq + 1;
       if (4 * wave < nrb) {
         const int j = 4 * wave + q;
         const bool active = j < nrb;
@@ -345,6 +353,7 @@ BSG_CHAIN_DEV bool chain_factor(const ChainArgs& A, double* smem, long long* ts)
       auto sub = [&](auto BQc) {
         constexpr int BQ = decltype(BQc)::value;
         const int b = 4 * k + BQ;
+        if (b >= nb_real) return;
         double* const P = (BQ & 1) ? Pbuf1 : Pbuf0;          // panel b  (4 k is even)
         const double* const Pp = (BQ & 1) ? Pbuf0 : Pbuf1;    // panel b - 1
         auto wupd = [&](double4_c& acc, int wq, int wc) {
@@ -373,11 +382,29 @@ BSG_CHAIN_DEV bool chain_factor(const ChainArgs& A, double* smem, long long* ts)
   } else {
     // =============================== updating waves ===============================
     const int u = wave - 4;
-    if (m == 1) chain_update_waves<4>(A, smem, u, q, n, c0, ld, rS);
-    else if (m == 2) chain_update_waves<8>(A, smem, u, q, n, c0, ld, rS);
-    else chain_update_waves<12>(A, smem, u, q, n, c0, ld, rS);
+    if (m == 1) chain_update_waves<4>(A, smem, u, q, n, c0, ld, rS, nb_real);
+    else if (m == 2) chain_update_waves<8>(A, smem, u, q, n, c0, ld, rS, nb_real);
+    else chain_update_waves<12>(A, smem, u, q, n, c0, ld, rS, nb_real);
   }
-  panel_out(NCB - 1, ((NCB - 1) & 1) ? Pbuf1 : Pbuf0, tid, 64 * NW);
+  panel_out(nb_real - 1, ((nb_real - 1) & 1) ? Pbuf1 : Pbuf0, tid, 64 * NW);
+  // the blocks of padding: L = I on their diagonal, zero below; W = I; reciprocal pivots 1
+  for (int p = nb_real; p < NCB; ++p) {
+    const int k = p >> 2, pq = p & 3;
+    for (int i = tid; i < (NCB - p) * 128; i += 64 * NW) {
+      const int prow = 16 * p + (i >> 3), piece = i & 7;
+      const int cc = 16 * p + 2 * piece;
+      st16_wt(rL, (unsigned)(((size_t)prow * ld + c0 * 64 + cc) * sizeof(double)), double2{prow == cc ? 1.0 : 0.0, prow == cc + 1 ? 1.0 : 0.0});
+    }
+    for (int i = tid; i < 512; i += 64 * NW) {
+      const int c = i >> 5, j2 = (i & 31) * 2;
+      st16_wt(rW, (unsigned)(((size_t)k * 4096 + (16 * pq + c) * 64 + j2) * sizeof(double)), double2{16 * pq + c == j2 ? 1.0 : 0.0, 16 * pq + c == j2 + 1 ? 1.0 : 0.0});
+    }
+    if (A.Vinv) {
+      double* V = A.Vinv + (size_t)(c0 + k) * A.vinv_stride;
+      for (int i = tid; i < 256; i += 64 * NW) V[pq * 256 + i] = ((i & 15) == (i >> 4)) ? 1.0 : 0.0;
+      for (int i = tid; i < 16; i += 64 * NW) V[1024 + 16 * pq + i] = 1.0;
+    }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const bool any_bad = __syncthreads_or(bad ? 1 : 0) != 0;
   if (tid == 0) __hip_atomic_store(&A.tile_flag[(size_t)(c0 + m - 1) * A.flag_stride], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -58,7 +58,9 @@ constexpr int kChainMaxTiles = 3;   // == chain::kChainMaxTiles (chol_chain.h)
 
 struct DensePlan {
   int n_pose = 0, T = 0 /* real tiles */, npad = 0, rhs_row = 0;
-  std::vector<int> perm;       // natural tile -> S tile
+  std::vector<int> perm;       // natural tile -> S tile (build(): the tile-level ordering; empty when the order was given per dimension)
+  std::vector<int> dpos;       // natural tangent index (0 .. n_pose-1) -> position in S (solver order); what every kernel that addresses S uses
+  std::vector<int> inat;       // position in S (0 .. npad-1) -> natural tangent index, or -1 (padding, the rhs tile)
   std::vector<int> nreal;      // per S tile: number of real columns (64, or n_pose % 64 for the partial tile)
   std::vector<int> touched_tiles;  // every tile (i * (T + 1) + j, both triangles) an assembly or the factorisation may write: the
                                    // structural blocks, their fill, the rhs row and column, the diagonal — what a step has to clear
@@ -90,7 +92,7 @@ struct DensePlan {
   int fused_sync_words = 0;   // ints of device scratch: ([queue head | abort | exited workgroups | potrf_done (T+1) | update counts (T+1)^2]) x 16
   double fused_flops = 0.0;   // FP64 flops of the planned factorisation (trsm + rank-64 updates + potrf of every touched tile), for the MFMA roofline
   // solve offsets
-  inline int spos(int j) const { return perm[j >> 6] * 64 + (j & 63); }
+  inline int spos(int j) const { return dpos[j]; }
 
   // adj: T x T symmetric tile adjacency in NATURAL tile order (adj[i*T+j] != 0 iff block (i,j) of S is structurally non-zero)
   // leaf (optional, T flags): tiles that are coupled to no other leaf tile — a window's inverse-depth landmarks, thousands of scalar
@@ -198,10 +200,50 @@ struct DensePlan {
     nreal.assign(T + 1, 64);
     if (n_pose % 64) nreal[perm[T - 1]] = n_pose % 64;
     nreal[T] = 0;
-    // ---- exact tile-level symbolic factorisation in S order (tile T = rhs tile, coupled to every panel)
+    dpos.assign(std::max(1, n_pose), 0);
+    inat.assign(npad, -1);
+    for (int j = 0; j < n_pose; ++j) { dpos[j] = perm[j >> 6] * 64 + (j & 63); inat[dpos[j]] = j; }
+    // structure in S order (tile T = rhs tile, coupled to every panel)
     const int N = T + 1;
     std::vector<uint8_t> B((size_t)N * N, 0);
     for (int i = 0; i < T; ++i) for (int j = 0; j < T; ++j) if (adj[(size_t)i * T + j]) B[(size_t)perm[i] * N + perm[j]] = 1;
+    finish(B, piece_ranges, sep_ranges_by_level, leaf_ranges, allow_shared);
+  }
+
+  // The order is GIVEN, per dimension (bsgpu_finalize.cpp: dim_order.h — a nested dissection of the block graph of the reduced system whose
+  // separators are sets of tangent blocks, not runs of natural tiles): dpos_[j] = position of tangent index j in S; the supernodes (pieces,
+  // separators) are runs of whole tiles, each padded to a multiple of 64 at its END (nreal_[t] < 64 on a supernode's last tile: unit
+  // pivots, as for the window's last tile in build()).  adjS: T_ x T_ symmetric tile adjacency IN S ORDER.  sep_ranges_by_level[0] = the
+  // deepest separators ... back() = the root(s); every row tile of a panel must lie in its own supernode or in an ancestor's (checked by
+  // the back-substitution plan below, which falls back to the reverse step schedule otherwise).
+  void build_ordered(int n_pose_, int T_, const std::vector<int>& dpos_, const std::vector<int>& nreal_, const std::vector<uint8_t>& adjS,
+                     const std::vector<std::pair<int, int>>& piece_ranges, const std::vector<std::vector<std::pair<int, int>>>& sep_ranges_by_level,
+                     bool allow_shared = true) {
+    n_pose = n_pose_; T = T_; npad = (T + 1) * 64; rhs_row = T * 64;
+    perm.clear();
+    n_leaf_tiles = 0;
+    n_chains = (int)piece_ranges.size();
+    dpos = dpos_;
+    if (dpos.empty()) dpos.assign(1, 0);
+    inat.assign(npad, -1);
+    for (int j = 0; j < n_pose; ++j) inat[dpos[j]] = j;
+    nreal = nreal_;
+    nreal.resize(T + 1, 64);
+    nreal[T] = 0;
+    const int N = T + 1;
+    std::vector<uint8_t> B((size_t)N * N, 0);
+    for (int i = 0; i < T; ++i) for (int j = 0; j < T; ++j) if (adjS[(size_t)i * T + j]) B[(size_t)i * N + j] = 1;
+    finish(B, piece_ranges, sep_ranges_by_level, {}, allow_shared);
+  }
+
+ private:
+  // everything below the ordering: exact tile-level symbolic factorisation, step schedule, task list of the fused factorisation,
+  // back-substitution plan.  B: N x N (N = T + 1) structure in S order (the rhs tile's couplings are added here).
+  void finish(std::vector<uint8_t>& B, const std::vector<std::pair<int, int>>& piece_ranges,
+              const std::vector<std::vector<std::pair<int, int>>>& sep_ranges_by_level, const std::vector<std::pair<int, int>>& leaf_ranges,
+              bool allow_shared) {
+    const int N = T + 1;
+    // ---- exact tile-level symbolic factorisation in S order (tile T = rhs tile, coupled to every panel)
     for (int k = 0; k < T; ++k) { B[(size_t)T * N + k] = 1; B[(size_t)k * N + T] = 1; B[(size_t)k * N + k] = 1; }
     std::vector<std::vector<int>> rows(T);
     for (int k = 0; k < T; ++k) {
@@ -514,6 +556,7 @@ struct DensePlan {
       }
     }
   }
+ public:
   // Level-synchronous back-substitution (by-level groups only): a chain's workgroup walks its panels with the row tiles of ITS OWN
   // chain only (bs_desc_chain / rows_flat_chain, same record format as bs_desc); what the chains of group g contribute to the panels
   // of later groups — y_k -= sum_{t in group g} L(t,k)^T y_t — is applied between two groups by one workgroup per target panel

@@ -1,0 +1,194 @@
+// Host-side ordering of the reduced camera system PER TANGENT BLOCK (bsgpu_finalize.cpp; the tile machinery of dense_plan.h then runs
+// on the order found here: DensePlan::build_ordered).
+//
+// Why: the tile-level nested dissection of dense_plan.h build() cuts the window into runs of natural 64-wide tiles, so a separator has to
+// be as wide as the band IN TILES — three tiles, 192 pivots, on a visual-inertial window whose keyframes couple to their twelve
+// neighbours through shared landmarks: a keyframe's 15 tangent dimensions sit together, and all of them go into the separator.  But only
+// the 6 pose dimensions of a keyframe see the landmarks; its velocity and biases couple to the two neighbouring states alone (the IMU
+// chain).  On the graph of tangent BLOCKS (3 dimensions each) the separator of the same cut is the pose blocks of twelve keyframes plus
+// the velocity / bias blocks of ONE: 81 dimensions instead of 192 — and the factorisation's critical path is pivots-on-the-path.
+//
+// The dissection is generic (no knowledge of keyframes): the blocks are taken in natural (time) order, a cut position c splits them,
+// and the separator is the lighter of {blocks before c with a neighbour at or after c} and {blocks at or after c with a neighbour
+// before c}; blocks coupled to most of the set (an extrinsics block every pose touches, a dense prior) go into the separator first.
+// A set is split when that shortens the estimated critical path (steps of 16 pivots + a hand-over per chain of three tiles); tiny
+// separators are merged into their parent.  Supernodes (pieces, separators) are laid out as runs of whole tiles, padded at the end.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <utility>
+#include <vector>
+
+namespace bsg {
+
+struct DimOrder {
+  // ---- input
+  int n_pose = 0;
+  std::vector<int> blk_t0, blk_w;      // tangent blocks of the reduced system in natural order: first tangent index, width
+  std::vector<int> adj_ptr, adj;       // CSR adjacency over the blocks (symmetric, no self loops)
+  // ---- output
+  int T = 0;                           // tiles (without the rhs tile)
+  std::vector<int> dpos;               // tangent index -> position in S
+  std::vector<int> nreal;              // per tile
+  std::vector<std::pair<int, int>> piece_ranges;                     // [begin, end) tiles
+  std::vector<std::vector<std::pair<int, int>>> sep_ranges_by_level;   // [0] = deepest
+  int n_nodes = 0, depth = 0;
+  double est_path_us = 0.0;
+
+  // nominal costs (microseconds) of the fused factorisation: a 16-pivot step inside a chain, and the hand-over between two chains
+  double t_step = 2.0, t_hop = 14.0;
+  int max_depth = 5;
+  double hub_frac = 0.6;
+  int merge_dims = 24;     // separators up to this many dimensions are merged into their parent separator
+
+  double node_cost(int dims) const {
+    if (dims <= 0) return 0.0;
+    const int tiles = (dims + 63) / 64, chains = (tiles + 2) / 3;
+    return t_step * ((dims + 15) / 16) + t_hop * chains;
+  }
+
+  struct Node { std::vector<int> verts; int parent = -1, depth = 0, dims = 0; bool is_sep = false; };
+  std::vector<Node> nodes;
+  std::vector<std::pair<int, std::vector<int>>> merges;   // (separator node, blocks that join it): applied at the end — a split further up may still be undone
+
+  // returns the estimated critical path of the subtree built for V (blocks, ascending); nodes are appended to `nodes`
+  double dissect(std::vector<int>& V, int parent, int depth_, std::vector<int>& pos) {
+    int wV = 0;
+    for (int v : V) wV += blk_w[v];
+    const double cost_single = node_cost(wV);
+    auto make_piece = [&]() {
+      Node nd; nd.verts = V; nd.parent = parent; nd.depth = depth_; nd.dims = wV; nd.is_sep = false;
+      nodes.push_back(std::move(nd));
+      return cost_single;
+    };
+    if (depth_ >= max_depth || wV < 96 || V.size() < 4) return make_piece();
+    // ---- hubs: blocks coupled to most of the set
+    for (size_t i = 0; i < V.size(); ++i) pos[V[i]] = (int)i;
+    std::vector<int> hubs, rest;
+    {
+      for (int v : V) {
+        int deg = 0;
+        for (int e = adj_ptr[v]; e < adj_ptr[v + 1]; ++e) if (pos[adj[e]] >= 0) deg += blk_w[adj[e]];
+        if (deg >= hub_frac * wV) hubs.push_back(v); else rest.push_back(v);
+      }
+    }
+    for (int v : V) pos[v] = -1;
+    if (rest.size() < 4) return make_piece();
+    // ---- the cut: over `rest` in natural order
+    const int n = (int)rest.size();
+    for (int i = 0; i < n; ++i) pos[rest[i]] = i;
+    std::vector<int> hi(n), lo(n), pw(n + 1, 0);
+    for (int i = 0; i < n; ++i) {
+      const int v = rest[i];
+      int h = i, l = i;
+      for (int e = adj_ptr[v]; e < adj_ptr[v + 1]; ++e) { const int p = pos[adj[e]]; if (p >= 0) { h = std::max(h, p); l = std::min(l, p); } }
+      hi[i] = h; lo[i] = l; pw[i + 1] = pw[i] + blk_w[v];
+    }
+    for (int i = 0; i < n; ++i) pos[rest[i]] = -1;
+    std::vector<int> dl(n + 2, 0), dr(n + 2, 0);   // difference arrays over the cut position c = 1 .. n-1 (c = number of blocks before the cut)
+    for (int i = 0; i < n; ++i) {
+      if (hi[i] > i) { dl[i + 1] += blk_w[rest[i]]; dl[hi[i] + 1] -= blk_w[rest[i]]; }   // in L(c) for i < c <= hi[i]
+      if (lo[i] < i) { dr[lo[i] + 1] += blk_w[rest[i]]; dr[i + 1] -= blk_w[rest[i]]; }   // in R(c) for lo[i] < c <= i
+    }
+    const int wR = pw[n];
+    int wH = 0;
+    for (int v : hubs) wH += blk_w[v];
+    // the cut whose ESTIMATED path is shortest: this separator, then the longer of the two sides — each side taken as splitting on with
+    // separators of the same weight as long as that pays (the real recursion below decides; this only ranks the cut positions)
+    auto side_est = [&](int w, int ws) {
+      double best = node_cost(w), acc = 0.0;
+      int cur = w;
+      for (int l = depth_ + 1; l < max_depth && ws > 0; ++l) {
+        cur = (cur - ws) / 2;
+        if (cur <= 0) break;
+        acc += node_cost(ws);
+        best = std::min(best, acc + node_cost(cur));
+      }
+      return best;
+    };
+    int best_c = -1, best_side = 0;
+    double best_est = 1e300;
+    int accL = 0, accR = 0;
+    for (int c = 1; c < n; ++c) {
+      accL += dl[c]; accR += dr[c];
+      const double frac = (double)pw[c] / (double)wR;
+      if (frac < 0.15 || frac > 0.85) continue;
+      const int side = accL <= accR ? 0 : 1, ws = side == 0 ? accL : accR;
+      const int wa = pw[c] - (side == 0 ? ws : 0), wb = (wR - pw[c]) - (side == 1 ? ws : 0);
+      if (wa <= 0 || wb <= 0) continue;
+      const double est = node_cost(ws + wH) + std::max(side_est(wa, ws), side_est(wb, ws));
+      if (est < best_est) { best_est = est; best_c = c; best_side = side; }
+    }
+    if (best_c < 0) return make_piece();
+    std::vector<int> S(hubs), A, Bv;
+    for (int i = 0; i < n; ++i) {
+      const bool in_sep = best_side == 0 ? (i < best_c && hi[i] >= best_c) : (i >= best_c && lo[i] < best_c);
+      if (in_sep) S.push_back(rest[i]);
+      else (i < best_c ? A : Bv).push_back(rest[i]);
+    }
+    if (A.empty() || Bv.empty()) return make_piece();
+    std::sort(S.begin(), S.end());
+    int wS = 0;
+    for (int v : S) wS += blk_w[v];
+    // ---- build both sides, keep the split if it shortens the path
+    const size_t mark = nodes.size(), mark_m = merges.size();
+    int sep_node = -1, child_parent = parent, child_depth = depth_;
+    const bool merge_up = wS <= merge_dims && parent >= 0;   // (a tiny separator joins its parent: one hand-over less on the path)
+    if (wS > 0 && !merge_up) {
+      Node nd; nd.verts = S; nd.parent = parent; nd.depth = depth_; nd.dims = wS; nd.is_sep = true;
+      nodes.push_back(std::move(nd));
+      sep_node = (int)nodes.size() - 1;
+      child_parent = sep_node; child_depth = depth_ + 1;
+    }
+    const double cA = dissect(A, child_parent, child_depth, pos);
+    const double cB = dissect(Bv, child_parent, child_depth, pos);
+    double cost_split = std::max(cA, cB);
+    if (sep_node >= 0) cost_split += node_cost(wS);
+    else if (merge_up) cost_split += t_step * ((wS + 15) / 16);
+    if (cost_split + 1e-9 >= cost_single) {   // not worth it: V stays one piece
+      nodes.resize(mark); merges.resize(mark_m);
+      return make_piece();
+    }
+    if (merge_up && wS > 0) merges.push_back({parent, S});
+    return cost_split;
+  }
+
+  void build() {
+    const int nbk = (int)blk_t0.size();
+    nodes.clear();
+    std::vector<int> V(nbk), pos(nbk, -1);
+    for (int i = 0; i < nbk; ++i) V[i] = i;
+    merges.clear();
+    est_path_us = nbk ? dissect(V, -1, 0, pos) : 0.0;
+    for (const auto& mg : merges) {
+      Node& P = nodes[mg.first];
+      P.verts.insert(P.verts.end(), mg.second.begin(), mg.second.end());
+      for (int v : mg.second) P.dims += blk_w[v];
+    }
+    for (Node& nd : nodes) std::sort(nd.verts.begin(), nd.verts.end());
+    n_nodes = (int)nodes.size();
+    // ---- layout: the pieces in the order they were made (left to right), then the separators, deepest first
+    depth = 0;
+    for (const Node& nd : nodes) if (nd.is_sep) depth = std::max(depth, nd.depth + 1);
+    dpos.assign(std::max(1, n_pose), 0);
+    nreal.clear(); piece_ranges.clear();
+    sep_ranges_by_level.assign(depth, {});
+    int tile = 0;
+    auto place = [&](const Node& nd) {
+      const int t0 = tile;
+      int at = tile * 64;
+      for (int v : nd.verts) for (int k = 0; k < blk_w[v]; ++k) dpos[blk_t0[v] + k] = at++;
+      const int tiles = std::max(1, (nd.dims + 63) / 64);
+      for (int t = 0; t < tiles; ++t) nreal.push_back(std::min(64, nd.dims - 64 * t));
+      tile += tiles;
+      return std::make_pair(t0, tile);
+    };
+    for (const Node& nd : nodes) if (!nd.is_sep && nd.dims > 0) piece_ranges.push_back(place(nd));
+    for (int d = depth - 1; d >= 0; --d)
+      for (const Node& nd : nodes) if (nd.is_sep && nd.depth == d && nd.dims > 0) sep_ranges_by_level[depth - 1 - d].push_back(place(nd));
+    if (tile == 0) { nreal.push_back(0); tile = 1; piece_ranges.push_back({0, 1}); }   // (an empty reduced system still has one tile)
+    T = tile;
+  }
+};
+
+}  // namespace bsg

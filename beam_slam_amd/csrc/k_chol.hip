@@ -1084,8 +1084,8 @@ BSG_DEV void bs_chain_walk(const double* Lp, const double* Vinv /* USE_W: the ti
         if (FUSED) st8_sc1(ry, (unsigned)((c0 + tid) * sizeof(double)), v); else y[c0 + tid] = v;
         if (y_in_lds) sy[c0 + tid] = v;
         if (y_tan) {
-          const int j = iperm[k] * NB + tid;
-          if (j < n_pose) { y_tan[j] = v; delta[j] = -v; }
+          const int j = iperm[k * NB + tid];
+          if (j >= 0) { y_tan[j] = v; delta[j] = -v; }
         }
       }
     } else {
@@ -1125,8 +1125,8 @@ BSG_DEV void bs_chain_walk(const double* Lp, const double* Vinv /* USE_W: the ti
       if (FUSED) st8_sc1(ry, (unsigned)((c0 + tid) * sizeof(double)), v); else y[c0 + tid] = v;
       if (y_in_lds) sy[c0 + tid] = v;
       if (y_tan) {   // the solution in tangent (natural) order and the step -y, written where the tile is solved
-        const int j = iperm[k] * NB + tid;
-        if (j < n_pose) { y_tan[j] = v; delta[j] = -v; }
+        const int j = iperm[k * NB + tid];
+        if (j >= 0) { y_tan[j] = v; delta[j] = -v; }
       }
     }
     }

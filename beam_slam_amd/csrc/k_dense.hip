@@ -1,6 +1,6 @@
 // Glue between the assembled reduced camera system and its tiled Cholesky (k_chol.hip):
 //   pose_diag    LM diagonal (Ceres' Jacobi scaling folded in) onto the diagonal of S, unit pivots on the
-//                padding / rhs positions.  S is in SOLVER order: position = perm[tile] * 64 + offset
+//                padding / rhs positions.  S is in SOLVER order: position = DensePlan::dpos[tangent index]
 //                (dense_plan.h); hdiag / scale / dcl stay in tangent order.
 //   marg_*       gather of the reduced system into [marginalised | kept] order and its positive-SEMI-definite
 //                Cholesky: Schur complement onto the kept variables and the factor of the marginal prior

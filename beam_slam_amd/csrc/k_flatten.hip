@@ -165,7 +165,8 @@ void launch_patch_factor_rows(hipStream_t s, int n_ch, const int* rows, const in
 int flatten_visual_device(hipStream_t s, const std::function<void*(size_t)>& dalloc, int n, const int* h_idx, const double* h_consts,
                           const int* h_loss_kind, const double* h_loss_a, const std::vector<DevLoss>& losses, int nb, const int* d_blk_xoff,
                           const int* d_blk_toff, const unsigned char* d_blk_const, const int* d_blk_lm, int nl, int T, Visual& V,
-                          int** d_vis_src, std::vector<unsigned char>& tile_adj, bool* any_all_const, const FlattenResident* res) {
+                          int** d_vis_src, std::vector<unsigned char>& tile_adj, bool* any_all_const, const FlattenResident* res,
+                          FlattenSegsHost* segs_out) {
   auto A = [&](size_t bytes) { return dalloc(bytes ? bytes : 8); };
 #define FL_CHK(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); return -1; } } while (0)
   const int g256 = (n + 255) / 256;
@@ -291,6 +292,17 @@ int flatten_visual_device(hipStream_t s, const std::function<void*(size_t)>& dal
                      V.cp_tp, d_adj, T);
   tile_adj.assign((size_t)T * T, 0);
   if (T > 0) FL_CHK(hipMemcpyAsync(tile_adj.data(), d_adj, (size_t)T * T, hipMemcpyDeviceToHost, s));
+  if (segs_out) {   // the camera-pose pairs themselves, for the block-level ordering of the reduced system (dim_order.h)
+    segs_out->seg_ci.resize(h_nseg); segs_out->seg_cj.resize(h_nseg); segs_out->cp_tq.resize(h_ncp); segs_out->cp_tp.resize(h_ncp);
+    if (h_nseg > 0) {
+      FL_CHK(hipMemcpyAsync(segs_out->seg_ci.data(), V.seg_ci, sizeof(int) * (size_t)h_nseg, hipMemcpyDeviceToHost, s));
+      FL_CHK(hipMemcpyAsync(segs_out->seg_cj.data(), V.seg_cj, sizeof(int) * (size_t)h_nseg, hipMemcpyDeviceToHost, s));
+    }
+    if (h_ncp > 0) {
+      FL_CHK(hipMemcpyAsync(segs_out->cp_tq.data(), V.cp_tq, sizeof(int) * (size_t)h_ncp, hipMemcpyDeviceToHost, s));
+      FL_CHK(hipMemcpyAsync(segs_out->cp_tp.data(), V.cp_tp, sizeof(int) * (size_t)h_ncp, hipMemcpyDeviceToHost, s));
+    }
+  }
   FL_CHK(hipStreamSynchronize(s));
   FL_CHK(hipGetLastError());
 #undef FL_CHK

@@ -88,7 +88,7 @@ BSG_DEV void marg_grad_block(const MargDev& m, int a0, double* __restrict__ S, i
   double g = 0.0, h = 0.0;
 #pragma unroll
   for (int q = 0; q < 16; ++q) { g += sG[q][tx]; h += sH[q][tx]; }
-  atomicAdd(&S[(size_t)rhs_row * ld + perm[ta >> 6] * 64 + (ta & 63)], g);
+  atomicAdd(&S[(size_t)rhs_row * ld + perm[ta]], g);
   atomicAdd(&grad[ta], g);
   atomicAdd(&hdiag[ta], h);
 }
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void marg_assemble_kernel(MargDev m, double* _
   if (a >= m.cols || b >= m.cols) return;
   const int ta = m.col_t[a], tb = m.col_t[b];
   if (ta < 0 || tb < 0) return;
-  atomicAdd(&S[(size_t)(perm[ta >> 6] * 64 + (ta & 63)) * ld + perm[tb >> 6] * 64 + (tb & 63)], acc);
+  atomicAdd(&S[(size_t)perm[ta] * ld + perm[tb]], acc);
 }
 
 // one wave per row: model-cost-change term -(J d)(r + J d / 2)

@@ -1241,8 +1241,8 @@ __global__ __launch_bounds__(256) void spcg_update_kernel(const double* __restri
 // the solution (solver order) as the step in natural order: y_tan = x, delta = -x
 __global__ __launch_bounds__(64) void spcg_finish_kernel(const double* __restrict__ x, const int* __restrict__ iperm, int n_pose,
                                                          double* __restrict__ y_tan, double* __restrict__ delta) {
-  const int j = iperm[blockIdx.x] * 64 + threadIdx.x;
-  if (j < n_pose) { const double v = x[blockIdx.x * 64 + threadIdx.x]; y_tan[j] = v; delta[j] = -v; }
+  const int j = iperm[blockIdx.x * 64 + threadIdx.x];
+  if (j >= 0) { const double v = x[blockIdx.x * 64 + threadIdx.x]; y_tan[j] = v; delta[j] = -v; }
 }
 void launch_spcg_prepare(hipStream_t s, int T, const double* S, int ld, double* Minv) {
   hipLaunchKernelGGL(spcg_tile_inverse_kernel, dim3(T), dim3(256), 0, s, S, ld, Minv);

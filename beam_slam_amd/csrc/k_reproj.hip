@@ -355,7 +355,7 @@ __global__ __launch_bounds__(64) void pairs_kernel(int n_seg, const int* __restr
     const int row = (a < 3) ? (tqi < 0 ? -1 : tqi + a) : (tpi < 0 ? -1 : tpi + a - 3);
     const int col = (c < 3) ? (tqj < 0 ? -1 : tqj + c) : (tpj < 0 ? -1 : tpj + c - 3);
     if (row >= 0 && col >= 0) {
-      const int sr = perm[row >> 6] * 64 + (row & 63), sc = perm[col >> 6] * 64 + (col & 63);   // solver positions
+      const int sr = perm[row], sc = perm[col];   // solver positions
       atomicAdd(&S[(size_t)sr * ld + sc], total);
       if (!diag) atomicAdd(&S[(size_t)sc * ld + sr], total);
     }
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(64) void pairs_kernel(int n_seg, const int* __restr
     const int a = (lane - 36) % 6, which = (lane - 36) / 6;   // 0: reduced rhs, 1: raw gradient, 2: diag(A^T A)
     const int row = (a < 3) ? (tqi < 0 ? -1 : tqi + a) : (tpi < 0 ? -1 : tpi + a - 3);
     if (row >= 0) {
-      if (which == 0) atomicAdd(&S[(size_t)rhs_row * ld + perm[row >> 6] * 64 + (row & 63)], total);
+      if (which == 0) atomicAdd(&S[(size_t)rhs_row * ld + perm[row]], total);
       else if (which == 1) atomicAdd(&grad[row], total);
       else atomicAdd(&hdiag[row], total);
     }

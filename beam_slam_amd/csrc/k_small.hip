@@ -894,7 +894,7 @@ BSG_DEV void small_assemble_group(const SmallGroup* __restrict__ groups, const A
   const int* to = g.toff + (size_t)gfac[G.first] * nv;
   const int tr = to[er / 3], R = tr < 0 ? -1 : tr + er % 3;
   if (R < 0) return;
-  const size_t pr = (size_t)(perm[R >> 6] * 64 + (R & 63));
+  const size_t pr = (size_t)perm[R];
   if (is_rhs) {
     atomicAdd(&S[(size_t)rhs_row * ld + pr], acc);
     atomicAdd(&grad[R], acc);
@@ -902,7 +902,7 @@ BSG_DEV void small_assemble_group(const SmallGroup* __restrict__ groups, const A
   }
   const int tc = to[ec / 3], C = tc < 0 ? -1 : tc + ec % 3;
   if (C < 0) return;
-  const size_t pc = (size_t)(perm[C >> 6] * 64 + (C & 63));
+  const size_t pc = (size_t)perm[C];
   atomicAdd(&S[pr * ld + pc], acc);
   if (R != C) atomicAdd(&S[pc * ld + pr], acc);
   else atomicAdd(&hdiag[R], acc);
@@ -976,7 +976,7 @@ __global__ __launch_bounds__(256) void small_assemble_seg_kernel(const SmallGrou
     for (int i = 0; i < 9; ++i) v = (lane == i) ? acc[i] : v;
     const int rr = ra + lane / 3, cc = rb + lane % 3;
     if (v != 0.0) {
-      const size_t pr = (size_t)(perm[rr >> 6] * 64 + (rr & 63)), pc = (size_t)(perm[cc >> 6] * 64 + (cc & 63));
+      const size_t pr = (size_t)perm[rr], pc = (size_t)perm[cc];
       atomicAdd(&S[pr * ld + pc], v);
       if (!diag_seg) atomicAdd(&S[pc * ld + pr], v);   // (only the blocks on and below the diagonal have segments: the mirror image goes with them)
     }
@@ -987,7 +987,7 @@ __global__ __launch_bounds__(256) void small_assemble_seg_kernel(const SmallGrou
     for (int q = 0; q < 3; ++q) { g0 = (i == q) ? gs[q] : g0; h0 = (i == q) ? hs[q] : h0; }
     if (h0 != 0.0) {
       const int rr = ra + i;
-      atomicAdd(&S[(size_t)rhs_row * ld + perm[rr >> 6] * 64 + (rr & 63)], g0);
+      atomicAdd(&S[(size_t)rhs_row * ld + perm[rr]], g0);
       atomicAdd(&grad[rr], g0);
       atomicAdd(&hdiag[rr], h0);
     }

@@ -8,12 +8,79 @@
 #include <random>
 #include <vector>
 #include "dense_plan.h"
+#include "dim_order.h"
 using namespace bsg;
+
+static int replay(const DensePlan& P, const std::vector<uint8_t>& adjS /* P.T x P.T, S order */, unsigned seed, int max_chains);
 
 static int check(int T, const std::vector<uint8_t>& adj, int max_chains, const std::vector<uint8_t>* leaf, unsigned seed) {
   DensePlan P;
   const int n_pose = T * 64 - (seed % 3 == 0 ? 23 : 0);
   P.build(n_pose, adj, max_chains, 1, true, leaf);
+  std::vector<uint8_t> adjS((size_t)P.T * P.T, 0);
+  for (int i = 0; i < P.T; ++i) for (int j = 0; j < P.T; ++j) if (adj[(size_t)i * P.T + j]) adjS[(size_t)P.perm[i] * P.T + P.perm[j]] = 1;
+  for (int j = 0; j < n_pose; ++j) if (P.inat[P.dpos[j]] != j || P.dpos[j] != P.perm[j >> 6] * 64 + (j & 63)) { printf("  FAIL dpos / inat\n"); return 1; }
+  return replay(P, adjS, seed, max_chains);
+}
+
+// The per-dimension order (dim_order.h) on a random block graph — keyframes of five 3-d blocks, poses coupled within a band, states
+// coupled along the chain, optional hubs (an extrinsics block), far couplings (loop closures) and a dense prior on the first blocks —
+// and the plan built on it: the order must be a permutation into whole tiles whose padding sits at the end of a supernode, every
+// coupling must stay inside a supernode or go to an ANCESTOR (what makes the pieces independent), and the ticket list must replay.
+static int check_ordered(std::mt19937& rng, unsigned seed) {
+  const int nkf = 2 + rng() % 120, band = 1 + rng() % 14;
+  const bool with_vb = rng() % 4 != 0, hub = rng() % 5 == 0, loops = rng() % 4 == 0, prior = rng() % 4 == 0;
+  const int per = with_vb ? 5 : 2;
+  DimOrder o;
+  int t = 0;
+  const int nbk = per * nkf + (hub ? 2 : 0) + (rng() % 3 == 0 ? 1 + rng() % 5 : 0);   // (+ a few scalar blocks at the end)
+  for (int b = 0; b < nbk; ++b) { const int w = b < per * nkf + (hub ? 2 : 0) ? 3 : 1; o.blk_t0.push_back(t); o.blk_w.push_back(w); t += w; }
+  o.n_pose = t;
+  std::vector<std::vector<uint8_t>> A(nbk, std::vector<uint8_t>(nbk, 0));
+  auto add = [&](int a, int b) { if (a != b) A[a][b] = A[b][a] = 1; };
+  for (int i = 0; i < nkf; ++i) {
+    for (int a = 0; a < per; ++a) for (int b = 0; b < per; ++b) add(per * i + a, per * i + b);
+    for (int j = i + 1; j <= i + band && j < nkf; ++j) if (rng() % 8) for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) add(per * i + a, per * j + b);
+    if (with_vb && i + 1 < nkf) for (int a = 0; a < per; ++a) for (int b = 0; b < per; ++b) add(per * i + a, per * (i + 1) + b);
+  }
+  if (hub) for (int i = 0; i < nkf; ++i) for (int a = 0; a < 2; ++a) for (int h = 0; h < 2; ++h) add(per * i + a, per * nkf + h);
+  if (loops) for (int e = 0; e < 1 + (int)(rng() % 6); ++e) { const int a = rng() % nkf, b = rng() % nkf; for (int x = 0; x < 2; ++x) for (int y = 0; y < 2; ++y) add(per * a + x, per * b + y); }
+  if (prior) { const int np = std::min(nbk, 3 + (int)(rng() % 30)); for (int a = 0; a < np; ++a) for (int b = 0; b < np; ++b) add(a, b); }
+  for (int b = per * nkf + (hub ? 2 : 0); b < nbk; ++b) add(b, rng() % (per * nkf));   // the scalar blocks hang off some block
+  o.adj_ptr.push_back(0);
+  for (int a = 0; a < nbk; ++a) { for (int b = 0; b < nbk; ++b) if (A[a][b]) o.adj.push_back(b); o.adj_ptr.push_back((int)o.adj.size()); }
+  o.max_depth = rng() % 7;
+  if (rng() % 3 == 0) { o.t_hop = 1.0 + rng() % 20; o.t_step = 0.5 + (rng() % 8) * 0.5; }
+  o.build();
+  int fails = 0;
+  auto fail = [&](const char* what) { if (fails++ < 5) printf("  FAIL (ordered, seed %u) %s\n", seed, what); };
+  // permutation, tiles, padding
+  std::vector<int> seen((size_t)o.T * 64, 0);
+  for (int j = 0; j < o.n_pose; ++j) { if (o.dpos[j] < 0 || o.dpos[j] >= o.T * 64 || seen[o.dpos[j]]++) { fail("dpos is not a permutation"); break; } }
+  if ((int)o.nreal.size() != o.T) fail("nreal size");
+  for (int tt = 0; tt < o.T && tt < (int)o.nreal.size(); ++tt) for (int q = 0; q < 64; ++q) if ((seen[tt * 64 + q] != 0) != (q < o.nreal[tt])) { fail("padding is not at the end of the tile"); break; }
+  for (int b = 0; b < nbk; ++b) for (int k = 1; k < o.blk_w[b]; ++k) if (o.dpos[o.blk_t0[b] + k] != o.dpos[o.blk_t0[b]] + k) fail("a block is not contiguous");
+  // supernode of every block; couplings only inside a supernode or towards an ancestor
+  std::vector<int> node_of(nbk, -1);
+  for (size_t nd = 0; nd < o.nodes.size(); ++nd) for (int v : o.nodes[nd].verts) { if (node_of[v] >= 0) fail("block in two supernodes"); node_of[v] = (int)nd; }
+  for (int b = 0; b < nbk; ++b) if (node_of[b] < 0) fail("block in no supernode");
+  auto is_anc = [&](int a, int d) { for (int x = o.nodes[d].parent; x >= 0; x = o.nodes[x].parent) if (x == a) return true; return false; };
+  for (int a = 0; a < nbk && fails == 0; ++a) for (int b = 0; b < a; ++b) if (A[a][b]) {
+    const int na = node_of[a], nb2 = node_of[b];
+    if (na != nb2 && !is_anc(na, nb2) && !is_anc(nb2, na)) fail("coupling between two independent supernodes");
+  }
+  if (fails) return fails;
+  std::vector<uint8_t> adjS((size_t)o.T * o.T, 0);
+  for (int a = 0; a < nbk; ++a) for (int b = 0; b < nbk; ++b) if (A[a][b] || a == b)
+    for (int ka = 0; ka < o.blk_w[a]; ++ka) for (int kb = 0; kb < o.blk_w[b]; ++kb) adjS[(size_t)(o.dpos[o.blk_t0[a] + ka] >> 6) * o.T + (o.dpos[o.blk_t0[b] + kb] >> 6)] = 1;
+  DensePlan P;
+  P.build_ordered(o.n_pose, o.T, o.dpos, o.nreal, adjS, o.piece_ranges, o.sep_ranges_by_level);
+  if (!o.sep_ranges_by_level.empty() && !P.bs_level_sync && P.bs_group_off.size() > 2) fail("the by-level back-substitution groups were refused");
+  return fails + replay(P, adjS, seed, -1);
+}
+
+static int replay(const DensePlan& P, const std::vector<uint8_t>& adj, unsigned seed, int max_chains) {
+  const int T = P.T;
   const int N = P.T + 1;
   // scalar stand-in: every tile is ONE number; A = M M^T + shift restricted to the structure is not SPD-safe, so use a diagonally
   // dominant matrix on the structure (tile (i,j) coupled iff adj) and compare with a dense Cholesky of the permuted matrix
@@ -22,7 +89,7 @@ static int check(int T, const std::vector<uint8_t>& adj, int max_chains, const s
   std::vector<double> A((size_t)N * N, 0.0);
   for (int i = 0; i < P.T; ++i) for (int j = 0; j < i; ++j) if (adj[(size_t)i * P.T + j] || adj[(size_t)j * P.T + i]) {
     const double v = U(rng);
-    A[(size_t)P.perm[i] * N + P.perm[j]] = v; A[(size_t)P.perm[j] * N + P.perm[i]] = v;
+    A[(size_t)i * N + j] = v; A[(size_t)j * N + i] = v;
   }
   for (int i = 0; i < P.T; ++i) { double s = 1.0; for (int j = 0; j < P.T; ++j) s += std::fabs(A[(size_t)i * N + j]); A[(size_t)i * N + i] = s; }
   for (int j = 0; j < P.T; ++j) { A[(size_t)P.T * N + j] = U(rng); }   // rhs row
@@ -112,5 +179,9 @@ int main() {
     ++cases;
   }
   printf("%d cases, %d failures\n", cases, fails);
+  int ocases = 0, ofails = 0;
+  for (int rep = 0; rep < 400; ++rep) { ofails += check_ordered(rng, (unsigned)rng()); ++ocases; }
+  printf("%d ordered cases, %d failures\n", ocases, ofails);
+  fails += ofails;
   return fails ? 1 : 0;
 }

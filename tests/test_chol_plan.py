@@ -22,6 +22,7 @@ def test_ticket_list_replay(tmp_path):
     run = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, run.stdout[-4000:]
     assert "400 cases, 0 failures" in run.stdout
+    assert "400 ordered cases, 0 failures" in run.stdout   # plans on the per-dimension order (dim_order.h)
 
 
 @pytest.mark.gpu
