@@ -396,41 +396,73 @@ struct DensePlan {
       // it waits for has finished), now one in which tickets are taken roughly when they can run.
       {
         const int nt = (int)ftasks.size();
-        const double dur_chain_tile = 11.0, dur_update = 8.0, dur_fetch = 5.0;   // microseconds, nominal
-        std::vector<double> fin_tile((size_t)N * N, 0.0), st_diag((size_t)N * N, 0.0), fin_potrf(N, 0.0), start(nt, 0.0);
+        // nominal durations (microseconds), from the task stamps of C2 (BSGPU_CHOL_PROBE): a chain of m tiles 5 (its tiles' loads) + its real
+        // 16-pivot steps x (2.0 | 2.25 | 3.0); an update task 6.5 from its inputs to its publication; two updates of ONE tile publish at
+        // least 1.5 apart (the read-modify-write turn — the solves and products of the tile's updaters overlap)
+        const double dur_update = 6.5, t_turn = 1.5, chain0 = 5.0;
+        auto chain_steps = [&](int k0, int ntile) { int st = 0; for (int i = 0; i < ntile; ++i) st += (std::min(64, std::max(1, nreal[k0 + i])) + 15) / 16; return st; };
+        auto chain_step_us = [](int m) { return m <= 1 ? 2.0 : m == 2 ? 2.25 : 3.0; };
+        std::vector<double> fin_tile((size_t)N * N, 0.0), st_diag((size_t)N * N, 0.0), fin_potrf(N, 0.0), start(nt, 0.0), dur(nt, dur_update);
+        // explicit predecessors for the backward pass: `preds` must have FINISHED before the task starts (the chain of its panel, the last
+        // writers of its input tiles, the diagonal tasks whose X it may read), `turn_pred` must have published before it publishes
+        std::vector<int> last_writer((size_t)N * N, -1), diag_task((size_t)N * N, -1), chain_task(N, -1), turn_pred(nt, -1);
+        std::vector<std::vector<int>> preds(nt);
         for (int t = 0; t < nt; ++t) {   // (list order: every dependency of task t has been seen)
           const FusedTask& f = ftasks[t];
           if (f.flags & kFusedChain) {
             double st = 0.0;
-            for (int i = 0; i < f.ti; ++i) for (int j = 0; j <= i; ++j) st = std::max(st, fin_tile[(size_t)(f.k + i) * N + f.k + j]);
-            start[t] = st;
-            for (int i = 0; i < f.ti; ++i) fin_potrf[f.k + i] = st + dur_chain_tile * (i + 1);
-          } else {
-            const bool diag = f.ti == f.tj;
-            double st = std::max(fin_potrf[f.k], fin_tile[(size_t)f.ti * N + f.k]);
-            if (!diag && !(f.flags & kFusedXjChain)) st = std::max(st, fin_tile[(size_t)f.tj * N + f.k]);
-            if (!diag) {   // (it may read what the diagonal tasks of its two tiles publish: it stays behind them)
-              st = std::max(st, st_diag[(size_t)f.ti * N + f.k]);
-              if (!(f.flags & kFusedXjChain)) st = std::max(st, st_diag[(size_t)f.tj * N + f.k]);
+            for (int i = 0; i < f.ti; ++i) for (int j = 0; j <= i; ++j) {
+              st = std::max(st, fin_tile[(size_t)(f.k + i) * N + f.k + j]);
+              if (last_writer[(size_t)(f.k + i) * N + f.k + j] >= 0) preds[t].push_back(last_writer[(size_t)(f.k + i) * N + f.k + j]);
             }
-            if (f.need_c >= 0) st = std::max(st, fin_tile[(size_t)f.ti * N + f.tj] - dur_update * 0.5);   // (the turn is only needed at the end)
             start[t] = st;
-            const double fin = st + dur_update;
-            if (f.need_c >= 0) fin_tile[(size_t)f.ti * N + f.tj] = std::max(fin_tile[(size_t)f.ti * N + f.tj], fin);
-            if (diag) st_diag[(size_t)f.ti * N + f.k] = st;
+            const double us = chain_step_us(f.ti);
+            for (int i = 0; i < f.ti; ++i) { fin_potrf[f.k + i] = st + chain0 + us * chain_steps(f.k, i + 1); chain_task[f.k + i] = t; }
+            dur[t] = chain0 + us * chain_steps(f.k, f.ti);
+          } else {
+            const bool diag = f.ti == f.tj, xj_chain = (f.flags & kFusedXjChain) != 0;
+            double st = std::max(fin_potrf[f.k], fin_tile[(size_t)f.ti * N + f.k]);
+            if (chain_task[f.k] >= 0) preds[t].push_back(chain_task[f.k]);
+            if (last_writer[(size_t)f.ti * N + f.k] >= 0) preds[t].push_back(last_writer[(size_t)f.ti * N + f.k]);
+            if (!diag && !xj_chain) {
+              st = std::max(st, fin_tile[(size_t)f.tj * N + f.k]);
+              if (last_writer[(size_t)f.tj * N + f.k] >= 0) preds[t].push_back(last_writer[(size_t)f.tj * N + f.k]);
+              // (it may read what the diagonal tasks of its two tiles publish: it stays behind them.  A task whose tj is in the chain of k
+              // never does — it solves its own strip of X_ti and takes X_tj from the chain's factor)
+              st = std::max(st, std::max(st_diag[(size_t)f.ti * N + f.k], st_diag[(size_t)f.tj * N + f.k]));
+              if (diag_task[(size_t)f.ti * N + f.k] >= 0) preds[t].push_back(diag_task[(size_t)f.ti * N + f.k]);
+              if (diag_task[(size_t)f.tj * N + f.k] >= 0) preds[t].push_back(diag_task[(size_t)f.tj * N + f.k]);
+            }
+            start[t] = st;
+            double fin = st + dur_update;
+            if (f.need_c >= 0) {
+              if (last_writer[(size_t)f.ti * N + f.tj] >= 0) { fin = std::max(fin, fin_tile[(size_t)f.ti * N + f.tj] + t_turn); turn_pred[t] = last_writer[(size_t)f.ti * N + f.tj]; }
+              fin_tile[(size_t)f.ti * N + f.tj] = fin; last_writer[(size_t)f.ti * N + f.tj] = t;
+            }
+            dur[t] = fin - st;
+            if (diag) { st_diag[(size_t)f.ti * N + f.k] = st; diag_task[(size_t)f.ti * N + f.k] = t; }
           }
         }
-        (void)dur_fetch;
+        // latest start times (ALAP): a task whose result is only needed at the root can take its ticket late; one that feeds the next
+        // chain on the path must not queue behind it.  The ticket key blends the earliest and the latest start: for a dependency d of t
+        // (chain, input tile, diagonal task), start[d] <= start[t] and lst[d] <= lst[t], so any blend keeps every dependency in front
+        // (equal keys: list order).  The turns on a tile are whatever the final order says (need_c, below).
+        double makespan = 0.0;
+        for (int t = 0; t < nt; ++t) makespan = std::max(makespan, start[t] + dur[t]);
+        std::vector<double> lfin(nt, 1e300);
+        for (int t = nt - 1; t >= 0; --t) {
+          if (lfin[t] > 1e299) lfin[t] = makespan;
+          const double ls = lfin[t] - std::min(dur[t], (ftasks[t].flags & kFusedChain) ? dur[t] : dur_update);
+          for (int p : preds[t]) lfin[p] = std::min(lfin[p], ls);
+          if (turn_pred[t] >= 0) lfin[turn_pred[t]] = std::min(lfin[turn_pred[t]], lfin[t] - t_turn);
+        }
+        static const double beta = [] { const char* e = getenv("BSGPU_TICKET_BETA"); const double v = e ? atof(e) : 0.5; return v < 0.0 ? 0.0 : v > 1.0 ? 1.0 : v; }();
         std::vector<int> ord(nt);
         for (int t = 0; t < nt; ++t) ord[t] = t;
-        // tasks that write a tile INSIDE a chain (what the next chain on the path waits for) take their tickets a little ahead of their
-        // turn: among tasks that become ready together they run first instead of queueing behind the hundreds whose results are needed
-        // later.  The head start is shorter than any task lasts, so a task still comes after everything it waits for.
         std::vector<double> key(nt);
         for (int t = 0; t < nt; ++t) {
-          const FusedTask& f = ftasks[t];
-          const bool into_chain = !(f.flags & kFusedChain) && f.ti < T && fchain_of_tile[f.ti] == fchain_of_tile[f.tj];
-          key[t] = start[t] - (into_chain ? 0.8 * dur_update : 0.0);
+          const double lst = lfin[t] - ((ftasks[t].flags & kFusedChain) ? dur[t] : dur_update);
+          key[t] = start[t] + beta * std::max(0.0, lst - start[t]);
         }
         std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return key[x] < key[y]; });
         // a stable sort by start time keeps every dependency in front: dep.finish <= start, dep.start < dep.finish; equal start times

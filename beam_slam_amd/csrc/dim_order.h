@@ -35,8 +35,10 @@ struct DimOrder {
   int n_nodes = 0, depth = 0;
   double est_path_us = 0.0;
 
-  // nominal costs (microseconds) of the fused factorisation: a 16-pivot step inside a chain, and the hand-over between two chains
-  double t_step = 2.0, t_hop = 14.0;
+  // nominal costs (microseconds) of the fused factorisation, from the task stamps of C2 (BSGPU_CHOL_PROBE, scripts/chol_probe.py):
+  // a chain of m tiles takes t_chain0 + steps x t_step[m] (the trailing matrix the updating waves carry grows with m), and the
+  // hand-over from a chain to the next one on the path (flag, loads, strip solve, product, turn, publication, flag) t_hop
+  double t_chain0 = 2.0, t_step = 2.0, t_step2 = 2.25, t_step3 = 3.0, t_hop = 14.0;
   int max_depth = 5;
   double hub_frac = 0.6;
   int merge_dims = 24;     // separators up to this many dimensions are merged into their parent separator
@@ -44,7 +46,9 @@ struct DimOrder {
   double node_cost(int dims) const {
     if (dims <= 0) return 0.0;
     const int tiles = (dims + 63) / 64, chains = (tiles + 2) / 3;
-    return t_step * ((dims + 15) / 16) + t_hop * chains;
+    if (chains > 1) return (chains - 1) * (t_chain0 + 12 * t_step3 + t_hop) + node_cost(dims - 192 * (chains - 1));
+    const double ts = tiles == 1 ? t_step : tiles == 2 ? t_step2 : t_step3;
+    return t_chain0 + ts * ((dims + 15) / 16) + t_hop;
   }
 
   struct Node { std::vector<int> verts; int parent = -1, depth = 0, dims = 0; bool is_sep = false; };

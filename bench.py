@@ -60,6 +60,48 @@ def _attach_traffic(roofline, csv_name, kernel_prefix, nbytes):
             return
 
 
+def short_leg(which, device):
+    """C3 / C4 for a few steps inside the default run (the driver times them with everything else): same step definition as the
+    headline — full solves from the device-resident initial guess, the reference's options for that path — plus the roofline of
+    the configuration's Jacobian evaluation (relative-pose factors: SURVEY.md 8(d))."""
+    from beam_slam_amd import synthetic
+    from beam_slam_amd.gpu import GpuSolver
+    pr = synthetic.c3() if which == "c3" else synthetic.c4()
+    g = GpuSolver(device)
+    pr.load(g)
+    g.finalize()
+    if which == "c3":
+        opt = g.options_vio()
+        opt.max_solver_time_in_seconds = 0.0
+    else:
+        opt = g.options_default()
+        opt.max_num_iterations = 10
+    steps, warmup = 6, 2
+    for _ in range(warmup):
+        g.reset_values(); s = g.solve(opt)
+    t0 = time.perf_counter()
+    n_it = 0
+    for _ in range(steps):
+        g.reset_values(); s = g.solve(opt)
+        n_it += s.num_linear_solves
+    dt = time.perf_counter() - t0
+    ms_e, nb_e = g.time_eval_ms(20), g.eval_bytes()
+    ach = nb_e / (ms_e * 1e-3) / 1e9
+    leg = {"workload": {"c3": "C3: LIO window, 100 keyframes, 20000 relative-pose(+extrinsics) + 99 IMU factors",
+                        "c4": "C4: global-mapper pose graph, 5000 poses, 50000 constraints (block-sparse PCG path)"}[which],
+           "value": round(n_it / dt, 2), "unit": "LM iterations/s", "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * dt / steps, 3),
+           "lm_iterations_per_solve": round(n_it / steps, 2), "pcg_iterations_per_solve": int(s.num_inner_iterations),
+           "final_cost": s.final_cost, "initial_cost": s.initial_cost,
+           "roofline": {"bound": "hbm", "kernel": "relative-pose (+ IMU) Jacobian evaluation", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "bytes_per_launch": int(nb_e), "ms_per_launch": round(ms_e, 5),
+                        "timing": "20 back-to-back evaluations between two HIP events on the solver's stream"}}
+    if which == "c3":
+        prof = g.profile_step(opt, reps=10)
+        leg["phases_us_per_lm_step"] = {k: round(1e3 * v[0], 2) for k, v in prof.items()}
+    g.close()
+    return leg
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,6 +114,10 @@ def main():
                     help="skip the Jacobian-evaluation measurement on the 800 KF x 300k-landmark window (working set above the Infinity Cache)")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"],
                     help="c2 (default) is the headline; c3 / c4 are the other BASELINE configs, for BASELINE.md")
+    ap.add_argument("--no-other-configs", dest="other_configs", action="store_false",
+                    help="skip the short C3 and C4 legs the default (C2, one GPU) run appends under \"other_configs\"")
+    ap.add_argument("--sustained-seconds", type=float, default=2.5,
+                    help="after the timed region: back-to-back C2 solves for this long (\"sustained\"; 0 = skip)")
     ap.add_argument("--consensus", action="store_true",
                     help="C5 with shared-pose consensus: the N windows are consecutive submaps of ONE trajectory, neighbours share their boundary "
                          "key frame, and a step is the whole message-passing solve of the merged graph (beam_slam_amd/sharding.py); the messages "
@@ -204,7 +250,7 @@ def main():
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "bytes_per_launch": int(nb_e), "ms_per_launch": round(ms_e, 5),
                         "timing": "20 back-to-back evaluations (residuals + Jacobians of every factor type) between two HIP events on the solver's stream",
                         "working_set_mb": round(nb_e / 1e6, 1), "cache_residency": "below the 256 MiB Infinity Cache", "traffic": None}
-            _attach_traffic(roofline, "r03_%s_pmc_hbm.csv" % args.workload, rel_kernel + "<", nb_e)
+            _attach_traffic(roofline, "r04_%s_pmc_hbm.csv" % args.workload, rel_kernel + "<", nb_e)
         if args.workload == "c3":          # dense Schur path without landmarks: phases and the factorisation's figure
             prof = g.profile_step(opt, reps=20)
             phases = {k: round(1e3 * v[0], 2) for k, v in prof.items()}
@@ -240,7 +286,7 @@ def main():
                 roofline["kernel_note"] = ("the reprojection factors' evaluation (the bytes counted) plus the window's %d IMU factors as the launch's first workgroups "
                                            "(~6.1 KB each, not counted)" % (pr.n_factors(capi.F_IMU_DELTA) + pr.n_factors(capi.F_IMU_PRIOR)))
             if world == 1 and args.workload == "c2" and args.n_kf == 200 and args.n_lm == 50000:
-                _attach_traffic(roofline, "r03_c2_pmc_hbm.csv", eval_kernel, nbytes)
+                _attach_traffic(roofline, "r04_c2_pmc_hbm.csv", eval_kernel, nbytes)
             ms_f, flops = prof["factor"]
             tf = flops / (ms_f * 1e-3) / 1e12
             roofline_mfma = {"bound": "mfma", "kernel": "chol_fused_kernel (+ chol_backsolve_fused_kernel: %.1f us)" % (1e3 * prof["backsolve"][0]),
@@ -304,27 +350,52 @@ def main():
                                 "last_change_of_a_shared_value": cons["dz"], "lm_iterations_per_window": cons["lm_iterations"],
                                 "exchange": "one all-reduce per round: a 15 x 15 information matrix, its mean and the key frame's value per directed pair of neighbours",
                                 "note": "a step is the whole consensus solve from the initial values; value counts the LM iterations of all windows and rounds"}
-        # ---- CPU baseline: the oracle on the same window (bounded: one solve, same options) ------
+        default_c2 = world == 1 and args.workload == "c2" and not args.consensus
+        # ---- sustained: back-to-back solves of the same window for a few seconds (the timed region above is 0.1 s of GPU work: too
+        # short for an external utilisation sampler to see; this is the same loop, longer)
+        if default_c2 and args.sustained_seconds > 0:
+            t1 = time.perf_counter()
+            n_s, it_s = 0, 0
+            while time.perf_counter() - t1 < args.sustained_seconds:
+                s2 = one_step()
+                n_s += 1
+                it_s += s2.num_linear_solves
+            dt_s = time.perf_counter() - t1
+            out["sustained"] = {"seconds": round(dt_s, 2), "solves": n_s, "value": round(it_s / dt_s, 2), "unit": "LM iterations/s",
+                                "note": "back-to-back solves of the headline window after the timed region, same options"}
+        # ---- the other single-GPU configurations of BASELINE.json, a few steps each (their own full runs: --workload c3 / c4)
+        if default_c2 and args.other_configs:
+            g.close()
+            out["other_configs"] = {"c3": short_leg("c3", local_rank), "c4": short_leg("c4", local_rank)}
+        # ---- CPU baseline: the oracle on the same window (bounded samples, same options): with every usable core, and with the six
+        # threads the reference's own configuration gives Ceres (beam_slam_launch/config/vio.yaml:11 num_threads: 6)
         if world == 1 and not args.no_cpu_baseline and args.workload != "c4" and not args.consensus:   # (C4 at full size: the oracle's dense solve does not finish in bench time)
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            from oracle import Oracle
-            o = Oracle()
-            pr.load(o)
-            # bounded sample: full solves of the same window from the same initial guess for about 10 s (at most 8)
-            cpu_dt, n_solves, n_its = 0.0, 0, 0
-            while cpu_dt < 10.0 and n_solves < 8:
-                o.reset_values()
-                t1 = time.perf_counter()
-                so = o.solve(opt)
-                cpu_dt += time.perf_counter() - t1
-                n_solves += 1
-                n_its += so.num_linear_solves
-            out["cpu_baseline"] = {
-                "value": round(n_its / cpu_dt, 3), "unit": "LM iterations/s", "cores": o.threads,
-                "kind": "port", "ms_per_solve": round(1e3 * cpu_dt / n_solves, 1), "final_cost": so.final_cost,
-                "sample": "%d full solves (%d LM iterations each) of the same window, OpenMP oracle, %.1f s of CPU wall time"
-                          % (n_solves, so.num_linear_solves, cpu_dt)}
-            out["config"]["final_cost_rel_diff_vs_cpu"] = abs(s.final_cost - so.final_cost) / so.final_cost
+            from oracle import Oracle, usable_cpus
+
+            def cpu_leg(threads, budget_s, max_solves):
+                o = Oracle(threads)
+                pr.load(o)
+                cpu_dt, n_solves, n_its = 0.0, 0, 0
+                while cpu_dt < budget_s and n_solves < max_solves:
+                    o.reset_values()
+                    t1 = time.perf_counter()
+                    so = o.solve(opt)
+                    cpu_dt += time.perf_counter() - t1
+                    n_solves += 1
+                    n_its += so.num_linear_solves
+                leg = {"value": round(n_its / cpu_dt, 3), "unit": "LM iterations/s", "cores": o.threads,
+                       "kind": "port", "ms_per_solve": round(1e3 * cpu_dt / n_solves, 1), "final_cost": so.final_cost,
+                       "sample": "%d full solves (%d LM iterations each) of the same window, OpenMP oracle, %.1f s of CPU wall time"
+                                 % (n_solves, so.num_linear_solves, cpu_dt)}
+                o.close()
+                return leg
+            out["cpu_baseline"] = cpu_leg(None, 10.0, 8)
+            if usable_cpus() >= 6 and out["cpu_baseline"]["cores"] != 6:
+                ref = cpu_leg(6, 8.0, 4)
+                ref["note"] = "the thread count of the reference's own configuration (vio.yaml:11 num_threads: 6)"
+                out["cpu_baseline"]["reference_thread_count"] = ref
+            out["config"]["final_cost_rel_diff_vs_cpu"] = abs(s.final_cost - out["cpu_baseline"]["final_cost"]) / out["cpu_baseline"]["final_cost"]
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

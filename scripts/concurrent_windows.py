@@ -6,8 +6,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from beam_slam_amd import synthetic
 from beam_slam_amd.gpu import GpuSolver
 
+# usage: concurrent_windows.py [--size KF:LM] [counts ...]     (default 200:50000 and 1 2 4 8)
+args = sys.argv[1:]
 n_kf, n_lm, steps = 200, 50000, 20
-counts = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
+if args and args[0] == "--size":
+    n_kf, n_lm = (int(v) for v in args[1].split(":")); args = args[2:]
+    steps = 50 if n_kf <= 60 else 20
+counts = [int(a) for a in args] or [1, 2, 4, 8]
+print("windows of %d key frames x %d landmarks" % (n_kf, n_lm), flush=True)
 windows = [synthetic.vio_window(n_kf=n_kf, n_lm=n_lm, seed=20250630 + i) for i in range(max(counts))]
 solvers = []
 for pr in windows:

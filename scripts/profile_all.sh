@@ -11,7 +11,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for w in c2 c3 c4; do
   rm -rf /tmp/kt_$w
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$w -o p -- python "$ROOT/bench.py" --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-past-l3 > "$OUT/bench_$w.log" 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$w -o p -- python "$ROOT/bench.py" --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-past-l3 --no-other-configs --sustained-seconds 0 > "$OUT/bench_$w.log" 2>&1
   f=$(find /tmp/kt_$w -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" "$OUT/${ROUND}_${w}_kernel_stats.csv"
 done
@@ -21,12 +21,12 @@ pmc() {   # pmc <tag> <counter> <command...>
   timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_${tag}_$c -o p -- "$@" > "$OUT/pmc_${tag}_$c.log" 2>&1
 }
 for w in c2 c3 c4; do
-  for c in FETCH_SIZE WRITE_SIZE; do pmc $w $c python "$ROOT/bench.py" --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-past-l3; done
+  for c in FETCH_SIZE WRITE_SIZE; do pmc $w $c python "$ROOT/bench.py" --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-past-l3 --no-other-configs --sustained-seconds 0; done
 done
 for c in FETCH_SIZE WRITE_SIZE; do pmc pastl3 $c python "$ROOT/scripts/past_l3.py"; done
 for w in c2 c3; do
   for c in SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE; do
-    pmc $w $c python "$ROOT/bench.py" --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-past-l3
+    pmc $w $c python "$ROOT/bench.py" --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-past-l3 --no-other-configs --sustained-seconds 0
   done
 done
 python - "$OUT" "$ROUND" <<'PY'

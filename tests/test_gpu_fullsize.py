@@ -297,3 +297,30 @@ def test_exact_option_on_pose_graphs_above_the_dense_limit(gpu_solver_cls, monke
     for a, b in zip(g.iterations(), g2.iterations()):
         assert a.step_is_successful == b.step_is_successful and abs(a.cost - b.cost) <= 1e-7 * b.cost
     assert np.abs(g.get_blocks() - g2.get_blocks()).max() < 1e-6
+
+
+def test_c5_eight_windows_one_gpu_match_oracle(oracle_cls, gpu_solver_cls):
+    """BASELINE config 5's workload on ONE device: the eight independent C2-shaped windows bench.py --gpus 8 hands to the eight
+    ranks (seeds sharding.window_seed(20250620, 0..7); the reference's unit of independence: a fresh graph per submap,
+    bs_models/src/lib/global_mapping/submap_refinement.cpp:35-115) solved in one bsgpu_solve_batch call with the headline's options,
+    each against the oracle's 10-iteration solve of the same window: decisions and costs per iteration, the final cost to the
+    north-star 1e-6."""
+    from beam_slam_amd import sharding
+    windows = [synthetic.vio_window(n_kf=200, n_lm=50000, seed=sharding.window_seed(20250620, w)) for w in range(8)]
+    gs = []
+    for pr in windows:
+        g = gpu_solver_cls(0); pr.load(g); gs.append(g)
+    opt = gs[0].options_vio()
+    opt.max_solver_time_in_seconds = 0.0
+    sums = gpu_solver_cls.solve_batch(gs, opt)
+    for w, (pr, g, sg) in enumerate(zip(windows, gs, sums)):
+        o = oracle_cls()
+        pr.load(o)
+        so = o.solve(opt)
+        assert sg.num_iterations == so.num_iterations and sg.termination_type == so.termination_type, w
+        for a, b in zip(g.iterations(), o.iterations()):
+            assert a.step_is_successful == b.step_is_successful, w
+            assert abs(a.cost - b.cost) <= 1e-8 * b.cost, w
+        assert abs(sg.final_cost - so.final_cost) <= 1e-6 * so.final_cost, w
+        assert np.abs(g.get_blocks() - o.get_blocks()).max() < 1e-6, w
+        o.close()
