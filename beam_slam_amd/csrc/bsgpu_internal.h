@@ -195,6 +195,20 @@ int small_cost_parts(const SmallGroup& g);
 void launch_small_eval(hipStream_t s, const SmallGroup& g, const double* x, const DevLoss* losses, bool with_J,
                        double* cost_part /* n doubles: per-factor cost */);
 // what an LM step clears before its assembly (zero_tiles_multi_kernel's arguments); rides in the landmark launch as extra workgroups
+// Several windows advanced by ONE set of launches (bsgpu_batch.cpp; bs_models/src/lib/global_mapping/submap_refinement.cpp:35-115 is the
+// reference's serial loop over submaps): every kernel of the LM step has a `_batch` form whose blockIdx.y picks a window out of one of
+// these lists and whose arguments come from a per-window table in device memory.  The block below is what changes from one LM
+// iteration to the next; it goes up once per iteration.
+constexpr int kBatchMaxWin = 64;
+enum { BL_ALL = 0, BL_FULL = 1, BL_ACC = 2, BL_REJ = 3, BL_BS_FUSED = 4 /* + deep */, BL_BS_CHAIN = 6 /* + deep */, BL_NUM = 8 };   // (BL_BS_*: the FULL windows by the form of their back-substitution)
+struct BatchDyn {
+  int n[BL_NUM];                       // windows in: every window still iterating | those that compute a full step (not just the gradient
+  int idx[BL_NUM][kBatchMaxWin];       // of their last point) | those whose candidate was accepted (x <- x_cand) | those whose step was
+                                       // rejected (Jacobians at x again)
+  double radius[kBatchMaxWin];         // per window (indexed by window, not by list position)
+  double seq[kBatchMaxWin];            // stamp of this iteration's end-of-step reduction
+  int first[kBatchMaxWin], new_J[kBatchMaxWin], grad_only[kBatchMaxWin];
+};
 struct ZeroStep {
   double* S = nullptr; int ld = 0; const int* tiles = nullptr; int n_tiles = 0;
   double* a = nullptr; int na = 0; double* b = nullptr; int nb = 0; double* c = nullptr; int nc = 0;

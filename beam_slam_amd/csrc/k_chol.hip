@@ -844,11 +844,7 @@ constexpr size_t kFusedLds = sizeof(double) * (3 * NB * LDT + 4 * 16 * kVtPitch 
                                                                                                                    : sizeof(double) * chain::chain_lds_doubles();
 
 template <bool PROBE>
-__global__ __launch_bounds__(kFusedThreads) void chol_fused_kernel(double* __restrict__ S, double* __restrict__ Lp, int ld,
-                                                                    const FusedTask* __restrict__ tasks, int n_tasks, const int* __restrict__ tile_tot,
-                                                                    const int* __restrict__ nreal, double* __restrict__ Vinv,
-                                                                    double* __restrict__ scal, int* sync, double* Winv, int fs, int rhs_strips,
-                                                                    long long* probe_ts = nullptr /* PROBE: n_tasks x 8 wall-clock stamps */) {
+__device__ __forceinline__ void chol_fused_kernel_body(const int bsg_bx, const int bsg_gx, double* __restrict__ S, double* __restrict__ Lp, int ld, const FusedTask* __restrict__ tasks, int n_tasks, const int* __restrict__ tile_tot, const int* __restrict__ nreal, double* __restrict__ Vinv, double* __restrict__ scal, int* sync, double* Winv, int fs, int rhs_strips, long long* probe_ts) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   __shared__ int s_head[4];
   const int tid = threadIdx.x;
@@ -869,7 +865,7 @@ __global__ __launch_bounds__(kFusedThreads) void chol_fused_kernel(double* __res
   __syncthreads();
   const int t = __builtin_amdgcn_readfirstlane(s_head[0]);
   if (t < n_tasks) {
-    if (PROBE && tid == 0) { probe_ts[(size_t)t * 8] = t_deq; probe_ts[(size_t)t * 8 + 7] = blockIdx.x; }
+    if (PROBE && tid == 0) { probe_ts[(size_t)t * 8] = t_deq; probe_ts[(size_t)t * 8 + 7] = bsg_bx; }
     FusedTask tk = tasks[t];
     tk.k = __builtin_amdgcn_readfirstlane(tk.k); tk.ti = __builtin_amdgcn_readfirstlane(tk.ti); tk.tj = __builtin_amdgcn_readfirstlane(tk.tj);
     tk.flags = __builtin_amdgcn_readfirstlane(tk.flags); tk.tot_i = __builtin_amdgcn_readfirstlane(tk.tot_i); tk.tot_j = __builtin_amdgcn_readfirstlane(tk.tot_j);
@@ -881,13 +877,42 @@ __global__ __launch_bounds__(kFusedThreads) void chol_fused_kernel(double* __res
   __syncthreads();
   if (tid == 0) {
     if (ld_flag(abort_w) != 0) scal[SC_CHOL_FAIL] = 2.0;
-    s_head[2] = (atomicAdd(exited, 1) == (int)gridDim.x - 1) ? 1 : 0;
+    s_head[2] = (atomicAdd(exited, 1) == bsg_gx - 1) ? 1 : 0;
   }
   __syncthreads();
   if (__builtin_amdgcn_readfirstlane(s_head[2]) != 0) {
     const int nw = 3 + N + N * N;
     for (int i = tid; i < nw; i += kFusedThreads) __hip_atomic_store(&sync[i * fs], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+}
+template <bool PROBE>
+__global__ __launch_bounds__(kFusedThreads) void chol_fused_kernel(double* __restrict__ S, double* __restrict__ Lp, int ld, const FusedTask* __restrict__ tasks, int n_tasks, const int* __restrict__ tile_tot, const int* __restrict__ nreal, double* __restrict__ Vinv, double* __restrict__ scal, int* sync, double* Winv, int fs, int rhs_strips, long long* probe_ts = nullptr) {
+  chol_fused_kernel_body<PROBE>((int)blockIdx.x, (int)gridDim.x, S, Lp, ld, tasks, n_tasks, tile_tot, nreal, Vinv, scal, sync, Winv, fs, rhs_strips, probe_ts);
+}
+// one launch over several windows (bsgpu_batch.cpp): blockIdx.y picks the window of list `bsg_list`, its arguments come from memory
+struct chol_fused_kernel_Args {
+  int bsg_grid;
+  double* S;
+  double* Lp;
+  int ld;
+  const FusedTask* tasks;
+  int n_tasks;
+  const int* tile_tot;
+  const int* nreal;
+  double* Vinv;
+  double* scal;
+  int* sync;
+  double* Winv;
+  int fs;
+  int rhs_strips;
+  long long* probe_ts;
+};
+template <bool PROBE>
+__global__ __launch_bounds__(kFusedThreads) void chol_fused_kernel_batch(const chol_fused_kernel_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
+  const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
+  chol_fused_kernel_Args a = bsg_A[bsg_w];
+  if ((int)blockIdx.x >= a.bsg_grid) return;
+  chol_fused_kernel_body<PROBE>((int)blockIdx.x, a.bsg_grid, a.S, a.Lp, a.ld, a.tasks, a.n_tasks, a.tile_tot, a.nreal, a.Vinv, a.scal, a.sync, a.Winv, a.fs, a.rhs_strips, a.probe_ts);
 }
 // ints between two words of the sync area: 16 = a 64-byte line each (BSGPU_FLAG_STRIDE=1: packed, the first layout)
 int fused_sync_stride() {
@@ -1180,17 +1205,42 @@ BSG_DEV void bs_chain_walk(const double* Lp, const double* Vinv /* USE_W: the ti
   }
 }
 template <bool Y_IN_LDS, int CH, bool DEEP, bool USE_W>
-__global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double* S, const double* Lp, const double* Vinv /* USE_W: the tile inverses */, int ld,
-                                                                    const int* __restrict__ bs_desc,
-                                                                    const int* __restrict__ chain_begin,
-                                                                    const int* __restrict__ chain_end,
-                                                                    const int* __restrict__ rows_flat, double* y, int npad, int max_len,
-                                                                    const double* __restrict__ y_init, const int* __restrict__ iperm,
-                                                                    int n_pose, double* __restrict__ y_tan, double* __restrict__ delta) {
+__device__ __forceinline__ void chol_backsolve_chain_kernel_body(const int bsg_bx, const int bsg_gx, const double* S, const double* Lp, const double* Vinv, int ld, const int* __restrict__ bs_desc, const int* __restrict__ chain_begin, const int* __restrict__ chain_end, const int* __restrict__ rows_flat, double* y, int npad, int max_len, const double* __restrict__ y_init, const int* __restrict__ iperm, int n_pose, double* __restrict__ y_tan, double* __restrict__ delta) {
   (void)S;
   const BsFused none{};
-  bs_chain_walk<Y_IN_LDS, CH, DEEP, false, USE_W>(Lp, Vinv, ld, bs_desc, chain_begin[blockIdx.x], chain_end[blockIdx.x], rows_flat, y, npad, max_len,
+  bs_chain_walk<Y_IN_LDS, CH, DEEP, false, USE_W>(Lp, Vinv, ld, bs_desc, chain_begin[bsg_bx], chain_end[bsg_bx], rows_flat, y, npad, max_len,
                                            y_init, iperm, n_pose, y_tan, delta, none);
+}
+template <bool Y_IN_LDS, int CH, bool DEEP, bool USE_W>
+__global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double* S, const double* Lp, const double* Vinv, int ld, const int* __restrict__ bs_desc, const int* __restrict__ chain_begin, const int* __restrict__ chain_end, const int* __restrict__ rows_flat, double* y, int npad, int max_len, const double* __restrict__ y_init, const int* __restrict__ iperm, int n_pose, double* __restrict__ y_tan, double* __restrict__ delta) {
+  chol_backsolve_chain_kernel_body<Y_IN_LDS, CH, DEEP, USE_W>((int)blockIdx.x, (int)gridDim.x, S, Lp, Vinv, ld, bs_desc, chain_begin, chain_end, rows_flat, y, npad, max_len, y_init, iperm, n_pose, y_tan, delta);
+}
+// one launch over several windows (bsgpu_batch.cpp): blockIdx.y picks the window of list `bsg_list`, its arguments come from memory
+struct chol_backsolve_chain_kernel_Args {
+  int bsg_grid;
+  const double* S;
+  const double* Lp;
+  const double* Vinv;
+  int ld;
+  const int* bs_desc;
+  const int* chain_begin;
+  const int* chain_end;
+  const int* rows_flat;
+  double* y;
+  int npad;
+  int max_len;
+  const double* y_init;
+  const int* iperm;
+  int n_pose;
+  double* y_tan;
+  double* delta;
+};
+template <bool Y_IN_LDS, int CH, bool DEEP, bool USE_W>
+__global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel_batch(const chol_backsolve_chain_kernel_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
+  const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
+  chol_backsolve_chain_kernel_Args a = bsg_A[bsg_w];
+  if ((int)blockIdx.x >= a.bsg_grid) return;
+  chol_backsolve_chain_kernel_body<Y_IN_LDS, CH, DEEP, USE_W>((int)blockIdx.x, a.bsg_grid, a.S, a.Lp, a.Vinv, a.ld, a.bs_desc, a.chain_begin, a.chain_end, a.rows_flat, a.y, a.npad, a.max_len, a.y_init, a.iperm, a.n_pose, a.y_tan, a.delta);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1206,19 +1256,11 @@ __global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel(const double
 // update item, then the ticket
 // ---------------------------------------------------------------------------------------------------
 template <int CH, bool DEEP>
-__global__ __launch_bounds__(1024) void chol_backsolve_fused_kernel(const double* Lp, const double* Winv, int ld, const int* __restrict__ bs_desc,
-                                                                    const int* __restrict__ chain_begin, const int* __restrict__ chain_end,
-                                                                    const int* __restrict__ rows_flat, int n_chains, const int* __restrict__ chain_group,
-                                                                    const int* __restrict__ grp_nchains, const int* __restrict__ grp_nitems, int G,
-                                                                    const int* __restrict__ items /* (k, off, n, phase | first << 16) */,
-                                                                    const int* __restrict__ upd_rows, const int* __restrict__ tile_updated,
-                                                                    double* y, int npad, int max_len, const double* __restrict__ y_init,
-                                                                    const int* __restrict__ iperm, int n_pose, double* __restrict__ y_tan,
-                                                                    double* __restrict__ delta, int* sync, double* __restrict__ scal, long long* ts, const int* __restrict__ order, int fs) {
+__device__ __forceinline__ void chol_backsolve_fused_kernel_body(const int bsg_bx, const int bsg_gx, const double* Lp, const double* Winv, int ld, const int* __restrict__ bs_desc, const int* __restrict__ chain_begin, const int* __restrict__ chain_end, const int* __restrict__ rows_flat, int n_chains, const int* __restrict__ chain_group, const int* __restrict__ grp_nchains, const int* __restrict__ grp_nitems, int G, const int* __restrict__ items, const int* __restrict__ upd_rows, const int* __restrict__ tile_updated, double* y, int npad, int max_len, const double* __restrict__ y_init, const int* __restrict__ iperm, int n_pose, double* __restrict__ y_tan, double* __restrict__ delta, int* sync, double* __restrict__ scal, long long* ts, const int* __restrict__ order, int fs) {
   const int tid = threadIdx.x;
   // (every word of the sync area `fs` ints — a cache line — apart: see chol_fused_kernel)
   int* abort_w = sync; int* exited = sync + fs; int* done_chain = sync + 2 * fs; int* item_flag = sync + (size_t)(2 + G) * fs;
-  const int n_items_total = (int)gridDim.x - n_chains;
+  const int n_items_total = bsg_gx - n_chains;
   // roles are handed out by a ticket in dependency order (the k-th workgroup to START gets role order[k]): whoever a workgroup waits
   // for holds an earlier ticket and is therefore running — no dead-lock even when the grid is not resident at once (several
   // contexts sharing the GPU), as in chol_fused_kernel
@@ -1298,10 +1340,53 @@ __global__ __launch_bounds__(1024) void chol_backsolve_fused_kernel(const double
   __shared__ int s_last;
   if (tid == 0) {
     if (ld_flag(abort_w) != 0) scal[SC_CHOL_FAIL] = 2.0;
-    s_last = (atomicAdd(exited, 1) == (int)gridDim.x - 1) ? 1 : 0;
+    s_last = (atomicAdd(exited, 1) == bsg_gx - 1) ? 1 : 0;
   }
   __syncthreads();
   if (s_last) for (int i = tid; i < 2 + G + n_items_total + 1; i += 1024) __hip_atomic_store(&sync[(size_t)i * fs], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int CH, bool DEEP>
+__global__ __launch_bounds__(1024) void chol_backsolve_fused_kernel(const double* Lp, const double* Winv, int ld, const int* __restrict__ bs_desc, const int* __restrict__ chain_begin, const int* __restrict__ chain_end, const int* __restrict__ rows_flat, int n_chains, const int* __restrict__ chain_group, const int* __restrict__ grp_nchains, const int* __restrict__ grp_nitems, int G, const int* __restrict__ items, const int* __restrict__ upd_rows, const int* __restrict__ tile_updated, double* y, int npad, int max_len, const double* __restrict__ y_init, const int* __restrict__ iperm, int n_pose, double* __restrict__ y_tan, double* __restrict__ delta, int* sync, double* __restrict__ scal, long long* ts, const int* __restrict__ order, int fs) {
+  chol_backsolve_fused_kernel_body<CH, DEEP>((int)blockIdx.x, (int)gridDim.x, Lp, Winv, ld, bs_desc, chain_begin, chain_end, rows_flat, n_chains, chain_group, grp_nchains, grp_nitems, G, items, upd_rows, tile_updated, y, npad, max_len, y_init, iperm, n_pose, y_tan, delta, sync, scal, ts, order, fs);
+}
+// one launch over several windows (bsgpu_batch.cpp): blockIdx.y picks the window of list `bsg_list`, its arguments come from memory
+struct chol_backsolve_fused_kernel_Args {
+  int bsg_grid;
+  const double* Lp;
+  const double* Winv;
+  int ld;
+  const int* bs_desc;
+  const int* chain_begin;
+  const int* chain_end;
+  const int* rows_flat;
+  int n_chains;
+  const int* chain_group;
+  const int* grp_nchains;
+  const int* grp_nitems;
+  int G;
+  const int* items;
+  const int* upd_rows;
+  const int* tile_updated;
+  double* y;
+  int npad;
+  int max_len;
+  const double* y_init;
+  const int* iperm;
+  int n_pose;
+  double* y_tan;
+  double* delta;
+  int* sync;
+  double* scal;
+  long long* ts;
+  const int* order;
+  int fs;
+};
+template <int CH, bool DEEP>
+__global__ __launch_bounds__(1024) void chol_backsolve_fused_kernel_batch(const chol_backsolve_fused_kernel_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
+  const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
+  chol_backsolve_fused_kernel_Args a = bsg_A[bsg_w];
+  if ((int)blockIdx.x >= a.bsg_grid) return;
+  chol_backsolve_fused_kernel_body<CH, DEEP>((int)blockIdx.x, a.bsg_grid, a.Lp, a.Winv, a.ld, a.bs_desc, a.chain_begin, a.chain_end, a.rows_flat, a.n_chains, a.chain_group, a.grp_nchains, a.grp_nitems, a.G, a.items, a.upd_rows, a.tile_updated, a.y, a.npad, a.max_len, a.y_init, a.iperm, a.n_pose, a.y_tan, a.delta, a.sync, a.scal, a.ts, a.order, a.fs);
 }
 // false: not launched (the grid would not be resident at once, or y does not fit LDS) — the caller takes the launch-per-level path
 bool launch_chol_backsolve_fused(hipStream_t s, const double* Lp, const double* Winv, int ld, const int* bs_desc_dev, const int* chain_begin_dev,

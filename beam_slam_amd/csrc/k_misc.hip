@@ -41,14 +41,10 @@ struct PoseDiagArgs {   // the pose_diag_kernel arguments, for the launch that d
   double* S; const double* hdiag; const double* radius_ptr; double lm_lo, lm_hi; double* scale; double* dcl; const int* iperm; double radius_val;
 };
 template <bool WITH_DIAG>
-__global__ __launch_bounds__(256) void grad_norms_kernel(int nb, const int* __restrict__ xoff, const int* __restrict__ toff,
-                                                         const unsigned char* __restrict__ size,
-                                                         const unsigned char* __restrict__ manifold,
-                                                         const double* __restrict__ x, const double* __restrict__ grad,
-                                                         double* __restrict__ gpart, PoseDiagArgs pd) {
+__device__ __forceinline__ void grad_norms_kernel_body(const int bsg_bx, const int bsg_gx, int nb, const int* __restrict__ xoff, const int* __restrict__ toff, const unsigned char* __restrict__ size, const unsigned char* __restrict__ manifold, const double* __restrict__ x, const double* __restrict__ grad, double* __restrict__ gpart, PoseDiagArgs pd) {
   __shared__ double sred[4];
   __shared__ double smax[4];
-  const int b = blockIdx.x * 256 + threadIdx.x;
+  const int b = bsg_bx * 256 + threadIdx.x;
   if (WITH_DIAG && b < pd.npad)   // independent of the norms: the LM diagonal of the reduced system rides in the same launch
     pose_diag_element(b, pd.n_pose, pd.S, pd.ld, pd.hdiag, 1.0 / (pd.radius_ptr ? pd.radius_ptr[0] : pd.radius_val), pd.compute_scale, pd.compute_dcl, pd.jacobi, pd.lm_lo,
                       pd.lm_hi, pd.scale, pd.dcl, pd.iperm);
@@ -74,9 +70,33 @@ __global__ __launch_bounds__(256) void grad_norms_kernel(int nb, const int* __re
   if (threadIdx.x == 0) {
     // per-workgroup partials, reduced in a fixed order by final_reduce_kernel (two same-address atomics per workgroup — 400 of them
     // on C2 — were most of this kernel's 9 us, and made the norm's last bits depend on their order)
-    gpart[2 * blockIdx.x] = fmax(fmax(smax[0], smax[1]), fmax(smax[2], smax[3]));
-    gpart[2 * blockIdx.x + 1] = tot;
+    gpart[2 * bsg_bx] = fmax(fmax(smax[0], smax[1]), fmax(smax[2], smax[3]));
+    gpart[2 * bsg_bx + 1] = tot;
   }
+}
+template <bool WITH_DIAG>
+__global__ __launch_bounds__(256) void grad_norms_kernel(int nb, const int* __restrict__ xoff, const int* __restrict__ toff, const unsigned char* __restrict__ size, const unsigned char* __restrict__ manifold, const double* __restrict__ x, const double* __restrict__ grad, double* __restrict__ gpart, PoseDiagArgs pd) {
+  grad_norms_kernel_body<WITH_DIAG>((int)blockIdx.x, (int)gridDim.x, nb, xoff, toff, size, manifold, x, grad, gpart, pd);
+}
+// one launch over several windows (bsgpu_batch.cpp): blockIdx.y picks the window of list `bsg_list`, its arguments come from memory
+struct grad_norms_kernel_Args {
+  int bsg_grid;
+  int nb;
+  const int* xoff;
+  const int* toff;
+  const unsigned char* size;
+  const unsigned char* manifold;
+  const double* x;
+  const double* grad;
+  double* gpart;
+  PoseDiagArgs pd;
+};
+template <bool WITH_DIAG>
+__global__ __launch_bounds__(256) void grad_norms_kernel_batch(const grad_norms_kernel_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
+  const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
+  grad_norms_kernel_Args a = bsg_A[bsg_w];
+  if ((int)blockIdx.x >= a.bsg_grid) return;
+  grad_norms_kernel_body<WITH_DIAG>((int)blockIdx.x, a.bsg_grid, a.nb, a.xoff, a.toff, a.size, a.manifold, a.x, a.grad, a.gpart, a.pd);
 }
 
 void launch_grad_norms(hipStream_t s, int nb, const int* blk_xoff, const int* blk_toff, const unsigned char* blk_size,
@@ -124,10 +144,9 @@ BSG_DEV void final_reduce_done(double* host_scal, int* counter, double seq) {
     if (host_scal) __hip_atomic_store(&host_scal[SC_SEQ], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
-__global__ __launch_bounds__(1024) void final_reduce_kernel(const ReduceEntry* __restrict__ entries, int n_entries, int n_slots,
-                                                            double* __restrict__ scal, double* __restrict__ host_scal, int* counter, double seq) {
+__device__ __forceinline__ void final_reduce_kernel_body(const int bsg_bx, const int bsg_gx, const ReduceEntry* __restrict__ entries, int n_entries, int n_slots, double* __restrict__ scal, double* __restrict__ host_scal, int* counter, double seq) {
   __shared__ double sred[16];
-  const int slot = blockIdx.x;
+  const int slot = bsg_bx;
   if (slot == n_slots) {   // the scalars earlier kernels of the step produced (gradient norms, Cholesky flag, ...) -> host mirror
     if (threadIdx.x == 0) {
       if (host_scal) for (int i = n_slots; i < SC_SEQ; ++i) host_scal[i] = scal[i];
@@ -179,6 +198,26 @@ __global__ __launch_bounds__(1024) void final_reduce_kernel(const ReduceEntry* _
     if (host_scal) host_scal[slot] = any ? t : scal[slot];
     final_reduce_done(host_scal, counter, seq);
   }
+}
+__global__ __launch_bounds__(1024) void final_reduce_kernel(const ReduceEntry* __restrict__ entries, int n_entries, int n_slots, double* __restrict__ scal, double* __restrict__ host_scal, int* counter, double seq) {
+  final_reduce_kernel_body((int)blockIdx.x, (int)gridDim.x, entries, n_entries, n_slots, scal, host_scal, counter, seq);
+}
+// one launch over several windows (bsgpu_batch.cpp): blockIdx.y picks the window of list `bsg_list`, its arguments come from memory
+struct final_reduce_kernel_Args {
+  int bsg_grid;
+  const ReduceEntry* entries;
+  int n_entries;
+  int n_slots;
+  double* scal;
+  double* host_scal;
+  int* counter;
+  double seq;
+};
+__global__ __launch_bounds__(1024) void final_reduce_kernel_batch(const final_reduce_kernel_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
+  const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
+  final_reduce_kernel_Args a = bsg_A[bsg_w];
+  if ((int)blockIdx.x >= a.bsg_grid) return;
+  final_reduce_kernel_body((int)blockIdx.x, a.bsg_grid, a.entries, a.n_entries, a.n_slots, a.scal, a.host_scal, a.counter, a.seq);
 }
 void launch_final_reduce(hipStream_t s, const ReduceEntry* entries, int n_entries, int n_slots, double* scal, double* host_scal, int* counter,
                          double seq) {
@@ -247,10 +286,27 @@ void launch_zero4(hipStream_t s, double* p0, int64_t n0, double* p1, int64_t n1,
   const int grid = (int)std::min<int64_t>((nmax + 255) / 256, 2048);
   hipLaunchKernelGGL(zero4_kernel, dim3(grid), dim3(256), 0, s, p0, n0, p1, n1, p2, n2, p3, n3);
 }
+__device__ __forceinline__ void copy_kernel_body(const int bsg_bx, const int bsg_gx, const double* __restrict__ src, double* __restrict__ dst, int64_t n, int nzero_after) {
+  const int64_t stride = (int64_t)bsg_gx * 256;
+  for (int64_t i = (int64_t)bsg_bx * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+  if (bsg_bx == 0 && (int)threadIdx.x < nzero_after) dst[n + threadIdx.x] = 0.0;
+}
 __global__ __launch_bounds__(256) void copy_kernel(const double* __restrict__ src, double* __restrict__ dst, int64_t n, int nzero_after) {
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
-  if (blockIdx.x == 0 && (int)threadIdx.x < nzero_after) dst[n + threadIdx.x] = 0.0;
+  copy_kernel_body((int)blockIdx.x, (int)gridDim.x, src, dst, n, nzero_after);
+}
+// one launch over several windows (bsgpu_batch.cpp): blockIdx.y picks the window of list `bsg_list`, its arguments come from memory
+struct copy_kernel_Args {
+  int bsg_grid;
+  const double* src;
+  double* dst;
+  int64_t n;
+  int nzero_after;
+};
+__global__ __launch_bounds__(256) void copy_kernel_batch(const copy_kernel_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
+  const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
+  copy_kernel_Args a = bsg_A[bsg_w];
+  if ((int)blockIdx.x >= a.bsg_grid) return;
+  copy_kernel_body((int)blockIdx.x, a.bsg_grid, a.src, a.dst, a.n, a.nzero_after);
 }
 // dst[0..n) = src[0..n), then nzero_after zeros
 void launch_copy(hipStream_t s, const double* src, double* dst, int64_t n, int nzero_after) {

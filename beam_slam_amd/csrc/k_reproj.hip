@@ -87,19 +87,12 @@ void launch_reproj_errors(hipStream_t s, const Visual& v, const SmallGroup& dens
 // Jacobi scaling (Ceres: s = 1/(1+sqrt(H_jj)) from iteration 0) and the LM diagonal are folded into
 // lambda_j = clamp(s_j^2 H_jj, lo, hi) / (radius s_j^2) on the unscaled system.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void landmark_kernel(int n_lm, const int* __restrict__ lm_start,
-                                                       const double* __restrict__ JB, const double2* __restrict__ r,
-                                                       int n_pose, const double* __restrict__ radius_ptr, int compute_scale,
-                                                       int compute_dcl, int jacobi, double lm_lo, double lm_hi,
-                                                       double* __restrict__ scale, double* __restrict__ dcl,
-                                                       double* __restrict__ grad, double* __restrict__ Linv_out,
-                                                       double* __restrict__ z_out, double* __restrict__ CR, int lm_blocks, ZeroStep zs,
-                                                       double radius_val) {
-  if ((int)blockIdx.x >= lm_blocks) {
+__device__ __forceinline__ void landmark_kernel_body(const int bsg_bx, const int bsg_gx, int n_lm, const int* __restrict__ lm_start, const double* __restrict__ JB, const double2* __restrict__ r, int n_pose, const double* __restrict__ radius_ptr, int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* __restrict__ scale, double* __restrict__ dcl, double* __restrict__ grad, double* __restrict__ Linv_out, double* __restrict__ z_out, double* __restrict__ CR, int lm_blocks, ZeroStep zs, double radius_val) {
+  if (bsg_bx >= lm_blocks) {
     // the step's clearing (tiles of S the assembly writes, pose gradient, diag(J^T J), the step's scalars, the radius slot) as extra
     // workgroups of this launch: nothing here is read or written by the landmark workgroups (they get the radius as an argument),
     // and a launch of its own cost 6 us on the dependent path
-    const int zb = (int)blockIdx.x - lm_blocks, nzb = (int)gridDim.x - lm_blocks;
+    const int zb = bsg_bx - lm_blocks, nzb = bsg_gx - lm_blocks;
     const int64_t t = (int64_t)zb * 256 + threadIdx.x, stride = (int64_t)nzb * 256;
     if (zs.radius_slot && t == 0) *zs.radius_slot = zs.radius;
     const int nt = zs.ld >> 6;
@@ -115,7 +108,7 @@ __global__ __launch_bounds__(256) void landmark_kernel(int n_lm, const int* __re
     for (int64_t i = t; i < zs.nc; i += stride) zs.c[i] = 0.0;
     return;
   }
-  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int gid = bsg_bx * 256 + threadIdx.x;
   const int l = gid >> 3, sub = gid & 7;
   const bool valid = l < n_lm;
   const double inv_radius = 1.0 / (radius_ptr ? radius_ptr[0] : radius_val);   // (device-resident under graph replay, whose arguments are frozen)
@@ -181,15 +174,65 @@ __global__ __launch_bounds__(256) void landmark_kernel(int n_lm, const int* __re
     o[7] = rf.y - (c10 * z0 + c11 * z1 + c12 * z2);
   }
 }
+__global__ __launch_bounds__(256) void landmark_kernel(int n_lm, const int* __restrict__ lm_start, const double* __restrict__ JB, const double2* __restrict__ r, int n_pose, const double* __restrict__ radius_ptr, int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* __restrict__ scale, double* __restrict__ dcl, double* __restrict__ grad, double* __restrict__ Linv_out, double* __restrict__ z_out, double* __restrict__ CR, int lm_blocks, ZeroStep zs, double radius_val) {
+  landmark_kernel_body((int)blockIdx.x, (int)gridDim.x, n_lm, lm_start, JB, r, n_pose, radius_ptr, compute_scale, compute_dcl, jacobi, lm_lo, lm_hi, scale, dcl, grad, Linv_out, z_out, CR, lm_blocks, zs, radius_val);
+}
+// one launch over several windows (bsgpu_batch.cpp): blockIdx.y picks the window of list `bsg_list`, its arguments come from memory
+struct landmark_kernel_Args {
+  int bsg_grid;
+  int n_lm;
+  const int* lm_start;
+  const double* JB;
+  const double2* r;
+  int n_pose;
+  const double* radius_ptr;
+  int compute_scale;
+  int compute_dcl;
+  int jacobi;
+  double lm_lo;
+  double lm_hi;
+  double* scale;
+  double* dcl;
+  double* grad;
+  double* Linv_out;
+  double* z_out;
+  double* CR;
+  int lm_blocks;
+  ZeroStep zs;
+  double radius_val;
+};
+__global__ __launch_bounds__(256) void landmark_kernel_batch(const landmark_kernel_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
+  const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
+  landmark_kernel_Args a = bsg_A[bsg_w];
+  if ((int)blockIdx.x >= a.bsg_grid) return;
+  landmark_kernel_body((int)blockIdx.x, a.bsg_grid, a.n_lm, a.lm_start, a.JB, a.r, a.n_pose, a.radius_ptr, a.compute_scale, a.compute_dcl, a.jacobi, a.lm_lo, a.lm_hi, a.scale, a.dcl, a.grad, a.Linv_out, a.z_out, a.CR, a.lm_blocks, a.zs, a.radius_val);
+}
 
 // factors whose landmark is constant: C = 0, rho = r
-__global__ void landmark_tail_kernel(int first, int n, const double2* __restrict__ r, double* __restrict__ CR) {
-  const int f = first + blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void landmark_tail_kernel_body(const int bsg_bx, const int bsg_gx, int first, int n, const double2* __restrict__ r, double* __restrict__ CR) {
+  const int f = first + bsg_bx * 256 + threadIdx.x;
   if (f >= n) return;
   double* o = CR + (size_t)f * 8;
   const double2 rf = r[f];
   o[0] = o[1] = o[2] = o[3] = o[4] = o[5] = 0.0;
   o[6] = rf.x; o[7] = rf.y;
+}
+__global__ void landmark_tail_kernel(int first, int n, const double2* __restrict__ r, double* __restrict__ CR) {
+  landmark_tail_kernel_body((int)blockIdx.x, (int)gridDim.x, first, n, r, CR);
+}
+// one launch over several windows (bsgpu_batch.cpp): blockIdx.y picks the window of list `bsg_list`, its arguments come from memory
+struct landmark_tail_kernel_Args {
+  int bsg_grid;
+  int first;
+  int n;
+  const double2* r;
+  double* CR;
+};
+__global__ void landmark_tail_kernel_batch(const landmark_tail_kernel_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
+  const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
+  landmark_tail_kernel_Args a = bsg_A[bsg_w];
+  if ((int)blockIdx.x >= a.bsg_grid) return;
+  landmark_tail_kernel_body((int)blockIdx.x, a.bsg_grid, a.first, a.n, a.r, a.CR);
 }
 
 void launch_landmark(hipStream_t s, const Visual& v, int n_pose, const double* radius_ptr, int compute_scale,
@@ -216,28 +259,20 @@ void launch_landmark(hipStream_t s, const Visual& v, int n_pose, const double* r
 // Results are added to the dense reduced system with FP64 atomics (each location is normally owned by
 // one segment, so the sums are reproducible).
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void pairs_kernel(int n_seg, const int* __restrict__ seg_ci,
-                                                   const int* __restrict__ seg_cj, const int* __restrict__ seg_start,
-                                                   const int* __restrict__ ent_fa, const int* __restrict__ ent_fb,
-                                                   const double* __restrict__ J, const double2* __restrict__ r,
-                                                   const double* __restrict__ CR, const int* __restrict__ cp_tq,
-                                                   const int* __restrict__ cp_tp, double* __restrict__ S, int ld,
-                                                   int rhs_row, double* __restrict__ grad,
-                                                   double* __restrict__ hdiag, const int* __restrict__ perm, int grad_only,
-                                                   int n_pair_blocks, SmallGroupSet small, int n_small_units) {
+__device__ __forceinline__ void pairs_kernel_body(const int bsg_bx, const int bsg_gx, int n_seg, const int* __restrict__ seg_ci, const int* __restrict__ seg_cj, const int* __restrict__ seg_start, const int* __restrict__ ent_fa, const int* __restrict__ ent_fb, const double* __restrict__ J, const double2* __restrict__ r, const double* __restrict__ CR, const int* __restrict__ cp_tq, const int* __restrict__ cp_tp, double* __restrict__ S, int ld, int rhs_row, double* __restrict__ grad, double* __restrict__ hdiag, const int* __restrict__ perm, int grad_only, int n_pair_blocks, SmallGroupSet small, int n_small_units) {
   extern __shared__ __attribute__((aligned(16))) double2 slab[];   // [64][6] A_a | [64][6] A_b | [64][4] C_a | [64][3] C_b | 2 x 64 ints
-  if ((int)blockIdx.x < n_small_units) {
+  if (bsg_bx < n_small_units) {
     // the pose-only factors assembled one workgroup per factor (IMU: two or three hundred of them) as extra workgroups of this launch —
     // the FIRST ones, so that they run underneath the pairs, not after them: independent atomics into the same system, and a launch of
     // their own cost ~8 us on the dependent path
     double* sJ = reinterpret_cast<double*>(slab);
-    small_assemble_unit(small, (int)blockIdx.x, threadIdx.x, 64, sJ, sJ + 15 * 30, reinterpret_cast<int*>(sJ + 15 * 30 + 16), S, ld, rhs_row, grad, hdiag, perm);
+    small_assemble_unit(small, bsg_bx, threadIdx.x, 64, sJ, sJ + 15 * 30, reinterpret_cast<int*>(sJ + 15 * 30 + 16), S, ld, rhs_row, grad, hdiag, perm);
     return;
   }
   // XCD-aware mapping: consecutive workgroup ids go round-robin over the 8 XCDs, each with its own L2.  Segments are
   // ordered by camera pair (ca, cb), and all segments of one ca gather the same J / CR rows, so every XCD takes a
   // CONTIGUOUS range of segments: the rows of a camera are then pulled into one L2 instead of eight.
-  const int pb = (int)blockIdx.x - n_small_units;   // (n_small_units is a multiple of 8: the XCD round-robin is unchanged)
+  const int pb = bsg_bx - n_small_units;   // (n_small_units is a multiple of 8: the XCD round-robin is unchanged)
   const int per_xcd = n_pair_blocks >> 3;
   const int seg = (pb & 7) * per_xcd + (pb >> 3);
   if (seg >= n_seg) return;
@@ -369,6 +404,40 @@ __global__ __launch_bounds__(64) void pairs_kernel(int n_seg, const int* __restr
     }
   }
 }
+__global__ __launch_bounds__(64) void pairs_kernel(int n_seg, const int* __restrict__ seg_ci, const int* __restrict__ seg_cj, const int* __restrict__ seg_start, const int* __restrict__ ent_fa, const int* __restrict__ ent_fb, const double* __restrict__ J, const double2* __restrict__ r, const double* __restrict__ CR, const int* __restrict__ cp_tq, const int* __restrict__ cp_tp, double* __restrict__ S, int ld, int rhs_row, double* __restrict__ grad, double* __restrict__ hdiag, const int* __restrict__ perm, int grad_only, int n_pair_blocks, SmallGroupSet small, int n_small_units) {
+  pairs_kernel_body((int)blockIdx.x, (int)gridDim.x, n_seg, seg_ci, seg_cj, seg_start, ent_fa, ent_fb, J, r, CR, cp_tq, cp_tp, S, ld, rhs_row, grad, hdiag, perm, grad_only, n_pair_blocks, small, n_small_units);
+}
+// one launch over several windows (bsgpu_batch.cpp): blockIdx.y picks the window of list `bsg_list`, its arguments come from memory
+struct pairs_kernel_Args {
+  int bsg_grid;
+  int n_seg;
+  const int* seg_ci;
+  const int* seg_cj;
+  const int* seg_start;
+  const int* ent_fa;
+  const int* ent_fb;
+  const double* J;
+  const double2* r;
+  const double* CR;
+  const int* cp_tq;
+  const int* cp_tp;
+  double* S;
+  int ld;
+  int rhs_row;
+  double* grad;
+  double* hdiag;
+  const int* perm;
+  int grad_only;
+  int n_pair_blocks;
+  SmallGroupSet small;
+  int n_small_units;
+};
+__global__ __launch_bounds__(64) void pairs_kernel_batch(const pairs_kernel_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
+  const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
+  pairs_kernel_Args a = bsg_A[bsg_w];
+  if ((int)blockIdx.x >= a.bsg_grid) return;
+  pairs_kernel_body((int)blockIdx.x, a.bsg_grid, a.n_seg, a.seg_ci, a.seg_cj, a.seg_start, a.ent_fa, a.ent_fb, a.J, a.r, a.CR, a.cp_tq, a.cp_tp, a.S, a.ld, a.rhs_row, a.grad, a.hdiag, a.perm, a.grad_only, a.n_pair_blocks, a.small, a.n_small_units);
+}
 
 constexpr size_t kPairsLds = sizeof(double2) * 64 * (6 + 6 + 4 + 3) + sizeof(int) * 128;
 void launch_pairs(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm,
@@ -400,20 +469,12 @@ BSG_DEV void pose_part(const double* __restrict__ Jf, int tq, int tp, const doub
     for (int k = 0; k < 3; ++k) { const double yv = y_pose[tp + k]; j0 += Jf[3 + k] * yv; j1 += Jf[9 + k] * yv; }
   }
 }
-__global__ __launch_bounds__(256) void backsub_mcc_kernel(int n_lm, int n_lm_groups, int n_elim, int n, const int* __restrict__ lm_start,
-                                                          const double* __restrict__ J, const double* __restrict__ JB,
-                                                          const double2* __restrict__ r,
-                                                          const double* __restrict__ CR, const int* __restrict__ cam_pose,
-                                                          const int* __restrict__ cp_tq, const int* __restrict__ cp_tp,
-                                                          const double* __restrict__ Linv, const double* __restrict__ z, int n_pose,
-                                                          const double* __restrict__ y_pose, double* __restrict__ delta,
-                                                          double* __restrict__ mcc_part, int n_vis_blocks, SmallGroupSet small, int n_small_units,
-                                                          UpdateRide up, int first_update_block) {
+__device__ __forceinline__ void backsub_mcc_kernel_body(const int bsg_bx, const int bsg_gx, int n_lm, int n_lm_groups, int n_elim, int n, const int* __restrict__ lm_start, const double* __restrict__ J, const double* __restrict__ JB, const double2* __restrict__ r, const double* __restrict__ CR, const int* __restrict__ cam_pose, const int* __restrict__ cp_tq, const int* __restrict__ cp_tp, const double* __restrict__ Linv, const double* __restrict__ z, int n_pose, const double* __restrict__ y_pose, double* __restrict__ delta, double* __restrict__ mcc_part, int n_vis_blocks, SmallGroupSet small, int n_small_units, UpdateRide up, int first_update_block) {
   __shared__ double sred[4];
-  if (up.n_blocks > 0 && (int)blockIdx.x >= first_update_block) {
+  if (up.n_blocks > 0 && bsg_bx >= first_update_block) {
     // the candidate of every block but the Euclidean landmarks (those: below, by the lanes that compute their step): the pose step is
     // complete when this launch starts, so the update needs no launch of its own behind it
-    const int unit = (int)blockIdx.x - first_update_block, i = unit * 256 + (int)threadIdx.x;
+    const int unit = bsg_bx - first_update_block, i = unit * 256 + (int)threadIdx.x;
     double d2 = 0.0, x2 = 0.0;
     if (i < up.n_blocks) update_block(up.blocks[i], up.xoff, up.toff, up.size, up.manifold, up.x, delta, up.x_cand, d2, x2);
     const double a = block_sum_256(d2, sred);
@@ -421,16 +482,16 @@ __global__ __launch_bounds__(256) void backsub_mcc_kernel(int n_lm, int n_lm_gro
     if (threadIdx.x == 0) { up.part[2 * unit] = a; up.part[2 * unit + 1] = c; }
     return;
   }
-  if ((int)blockIdx.x >= n_vis_blocks) {
+  if (bsg_bx >= n_vis_blocks) {
     // the model-cost terms of the pose-only factors (they need the pose step only) as extra workgroups: two 128-row units each
-    const int unit = 2 * ((int)blockIdx.x - n_vis_blocks) + ((int)threadIdx.x >> 7);
+    const int unit = 2 * (bsg_bx - n_vis_blocks) + ((int)threadIdx.x >> 7);
     if (unit < n_small_units) small_mcc_unit(small, unit, threadIdx.x & 127, delta, sred + 2 * (threadIdx.x >> 7));
     else __syncthreads();
     return;
   }
   double acc = 0.0, upd_d2 = 0.0, upd_x2 = 0.0;
-  if ((int)blockIdx.x < n_lm_groups) {
-    const int gid = blockIdx.x * 256 + threadIdx.x;
+  if (bsg_bx < n_lm_groups) {
+    const int gid = bsg_bx * 256 + threadIdx.x;
     const int l = gid >> 3, sub = gid & 7;
     const bool valid = l < n_lm;
     int beg = 0, end = 0;
@@ -482,7 +543,7 @@ __global__ __launch_bounds__(256) void backsub_mcc_kernel(int n_lm, int n_lm_gro
       }
     }
   } else {
-    const int f = n_elim + ((int)blockIdx.x - n_lm_groups) * 256 + (int)threadIdx.x;
+    const int f = n_elim + (bsg_bx - n_lm_groups) * 256 + (int)threadIdx.x;
     if (f < n) {
       const int cp = cam_pose[f];
       double j0, j1;
@@ -492,13 +553,49 @@ __global__ __launch_bounds__(256) void backsub_mcc_kernel(int n_lm, int n_lm_gro
     }
   }
   const double tot = block_sum_256(acc, sred);
-  if (threadIdx.x == 0) mcc_part[blockIdx.x] = tot;
-  if (up.n_blocks > 0 && (int)blockIdx.x < n_lm_groups) {   // (after the update units' pairs in `part`)
+  if (threadIdx.x == 0) mcc_part[bsg_bx] = tot;
+  if (up.n_blocks > 0 && bsg_bx < n_lm_groups) {   // (after the update units' pairs in `part`)
     const double a = block_sum_256(upd_d2, sred);
     const double c = block_sum_256(upd_x2, sred);
-    const int slot = (up.n_blocks + 255) / 256 + (int)blockIdx.x;
+    const int slot = (up.n_blocks + 255) / 256 + bsg_bx;
     if (threadIdx.x == 0) { up.part[2 * slot] = a; up.part[2 * slot + 1] = c; }
   }
+}
+__global__ __launch_bounds__(256) void backsub_mcc_kernel(int n_lm, int n_lm_groups, int n_elim, int n, const int* __restrict__ lm_start, const double* __restrict__ J, const double* __restrict__ JB, const double2* __restrict__ r, const double* __restrict__ CR, const int* __restrict__ cam_pose, const int* __restrict__ cp_tq, const int* __restrict__ cp_tp, const double* __restrict__ Linv, const double* __restrict__ z, int n_pose, const double* __restrict__ y_pose, double* __restrict__ delta, double* __restrict__ mcc_part, int n_vis_blocks, SmallGroupSet small, int n_small_units, UpdateRide up, int first_update_block) {
+  backsub_mcc_kernel_body((int)blockIdx.x, (int)gridDim.x, n_lm, n_lm_groups, n_elim, n, lm_start, J, JB, r, CR, cam_pose, cp_tq, cp_tp, Linv, z, n_pose, y_pose, delta, mcc_part, n_vis_blocks, small, n_small_units, up, first_update_block);
+}
+// one launch over several windows (bsgpu_batch.cpp): blockIdx.y picks the window of list `bsg_list`, its arguments come from memory
+struct backsub_mcc_kernel_Args {
+  int bsg_grid;
+  int n_lm;
+  int n_lm_groups;
+  int n_elim;
+  int n;
+  const int* lm_start;
+  const double* J;
+  const double* JB;
+  const double2* r;
+  const double* CR;
+  const int* cam_pose;
+  const int* cp_tq;
+  const int* cp_tp;
+  const double* Linv;
+  const double* z;
+  int n_pose;
+  const double* y_pose;
+  double* delta;
+  double* mcc_part;
+  int n_vis_blocks;
+  SmallGroupSet small;
+  int n_small_units;
+  UpdateRide up;
+  int first_update_block;
+};
+__global__ __launch_bounds__(256) void backsub_mcc_kernel_batch(const backsub_mcc_kernel_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
+  const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
+  backsub_mcc_kernel_Args a = bsg_A[bsg_w];
+  if ((int)blockIdx.x >= a.bsg_grid) return;
+  backsub_mcc_kernel_body((int)blockIdx.x, a.bsg_grid, a.n_lm, a.n_lm_groups, a.n_elim, a.n, a.lm_start, a.J, a.JB, a.r, a.CR, a.cam_pose, a.cp_tq, a.cp_tp, a.Linv, a.z, a.n_pose, a.y_pose, a.delta, a.mcc_part, a.n_vis_blocks, a.small, a.n_small_units, a.up, a.first_update_block);
 }
 
 int backsub_mcc_groups(const Visual& v) { return (v.n_lm * 8 + 255) / 256 + (v.n - v.n_elim + 255) / 256; }

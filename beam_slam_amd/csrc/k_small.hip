@@ -264,20 +264,46 @@ __global__ __launch_bounds__(64) void imu_eval_kernel(SmallGroup delta, SmallGro
 // factors, a wave each, per 256-thread workgroup): 5 us (cost only) / 10 us (with Jacobians) of a launch that nothing but the launch
 // order made wait for the reprojection factors.
 template <bool WITH_J>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void visual_imu_eval_kernel(SmallGroup delta, SmallGroup prior, double* __restrict__ part_delta,
-                                                              double* __restrict__ part_prior, int n_imu_blocks, int n, const int4* __restrict__ fac,
-                                                              const double2* __restrict__ pix, const double* __restrict__ wgt,
-                                                              const double* __restrict__ x, const DevCamera* __restrict__ cams,
-                                                              const DevLoss* __restrict__ losses, double2* __restrict__ r_out,
-                                                              double* __restrict__ J_out, double* __restrict__ JB_out,
-                                                              double* __restrict__ cost_part, int count_inactive) {
-  if ((int)blockIdx.x < n_imu_blocks) {
-    const int f = 4 * (int)blockIdx.x + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+__device__ __forceinline__ void visual_imu_eval_kernel_body(const int bsg_bx, const int bsg_gx, SmallGroup delta, SmallGroup prior, double* __restrict__ part_delta, double* __restrict__ part_prior, int n_imu_blocks, int n, const int4* __restrict__ fac, const double2* __restrict__ pix, const double* __restrict__ wgt, const double* __restrict__ x, const DevCamera* __restrict__ cams, const DevLoss* __restrict__ losses, double2* __restrict__ r_out, double* __restrict__ J_out, double* __restrict__ JB_out, double* __restrict__ cost_part, int count_inactive) {
+  if (bsg_bx < n_imu_blocks) {
+    const int f = 4 * bsg_bx + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (f < delta.n) imu_delta_body<WITH_J>(delta, f, x, losses, part_delta, lane);
     else if (f < delta.n + prior.n) imu_prior_body<WITH_J>(prior, f - delta.n, x, losses, part_prior, lane);
     return;
   }
-  reproj_eval_body<WITH_J>((int)blockIdx.x - n_imu_blocks, n, fac, pix, wgt, x, cams, losses, r_out, J_out, JB_out, cost_part, count_inactive);
+  reproj_eval_body<WITH_J>(bsg_bx - n_imu_blocks, n, fac, pix, wgt, x, cams, losses, r_out, J_out, JB_out, cost_part, count_inactive);
+}
+template <bool WITH_J>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void visual_imu_eval_kernel(SmallGroup delta, SmallGroup prior, double* __restrict__ part_delta, double* __restrict__ part_prior, int n_imu_blocks, int n, const int4* __restrict__ fac, const double2* __restrict__ pix, const double* __restrict__ wgt, const double* __restrict__ x, const DevCamera* __restrict__ cams, const DevLoss* __restrict__ losses, double2* __restrict__ r_out, double* __restrict__ J_out, double* __restrict__ JB_out, double* __restrict__ cost_part, int count_inactive) {
+  visual_imu_eval_kernel_body<WITH_J>((int)blockIdx.x, (int)gridDim.x, delta, prior, part_delta, part_prior, n_imu_blocks, n, fac, pix, wgt, x, cams, losses, r_out, J_out, JB_out, cost_part, count_inactive);
+}
+// one launch over several windows (bsgpu_batch.cpp): blockIdx.y picks the window of list `bsg_list`, its arguments come from memory
+struct visual_imu_eval_kernel_Args {
+  int bsg_grid;
+  SmallGroup delta;
+  SmallGroup prior;
+  double* part_delta;
+  double* part_prior;
+  int n_imu_blocks;
+  int n;
+  const int4* fac;
+  const double2* pix;
+  const double* wgt;
+  const double* x;
+  const DevCamera* cams;
+  const DevLoss* losses;
+  double2* r_out;
+  double* J_out;
+  double* JB_out;
+  double* cost_part;
+  int count_inactive;
+};
+template <bool WITH_J>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void visual_imu_eval_kernel_batch(const visual_imu_eval_kernel_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
+  const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
+  visual_imu_eval_kernel_Args a = bsg_A[bsg_w];
+  if ((int)blockIdx.x >= a.bsg_grid) return;
+  visual_imu_eval_kernel_body<WITH_J>((int)blockIdx.x, a.bsg_grid, a.delta, a.prior, a.part_delta, a.part_prior, a.n_imu_blocks, a.n, a.fac, a.pix, a.wgt, a.x, a.cams, a.losses, a.r_out, a.J_out, a.JB_out, a.cost_part, a.count_inactive);
 }
 void launch_visual_imu_eval(hipStream_t s, const Visual& v, const SmallGroup& delta, const SmallGroup& prior, const double* x, const DevCamera* cams,
                             const DevLoss* losses, bool with_J, double* cost_part_vis, double* part_delta, double* part_prior) {

