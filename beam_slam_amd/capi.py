@@ -111,7 +111,7 @@ SYMBOLS = [
     "finalize", "solve", "get_blocks", "reset_values", "num_iterations_recorded", "get_iteration",
     "evaluate", "num_residuals", "num_parameters_tangent", "tangent_offset", "covariance", "marginalize", "get_marginal",
     "reprojection_errors", "preintegrate", "triangulate", "time_reproj_jacobian_ms", "reproj_jacobian_bytes", "dense_solve", "plan_info",
-    "profile_step", "time_eval_ms", "eval_bytes", "bsr_info", "covariance_joint", "update_marginal", "solve_batch",
+    "profile_step", "time_eval_ms", "eval_bytes", "bsr_info", "covariance_joint", "update_marginal", "solve_batch", "batch_stats",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -329,7 +329,8 @@ class Solver:
 
     @staticmethod
     def solve_batch(solvers, options=None):
-        """bsgpu_solve_batch: the solvers' windows at once (a library thread per context); returns their summaries."""
+        """bsgpu_solve_batch: the solvers' windows at once (landmark windows advance together, one set of launches per LM iteration;
+        any other window on a library thread of its own); returns their summaries."""
         n = len(solvers)
         first = solvers[0]
         opts = options if isinstance(options, (list, tuple)) else [options if options is not None else first.options_default()]

@@ -399,19 +399,47 @@ int bsgpu_solve_batch(bsgpu_ctx* const* ctxs, int32_t n, const bsgpu_options* o,
     for (int j = 0; j < i; ++j) if (ctxs[j] == ctxs[i]) return fail(ctxs[i], BSGPU_ERR_INVALID, "solve_batch: the same context twice");
   }
   std::vector<int> rc(n, BSGPU_OK);
+  // The windows the batched kernels cover (bsgpu_batch.cpp: Euclidean-landmark windows on the fused factorisation) advance together,
+  // one set of launches per LM iteration; every other window gets a thread of its own on its context's stream, as before.
+  // BSGPU_BATCH_THREADS=1: the thread-per-window form for all of them.
+  std::vector<int> batched, alone;
+  static const bool threads_only = getenv("BSGPU_BATCH_THREADS") != nullptr;
+  for (int i = 0; i < n; ++i) {
+    bool covered = false;
+    if (!threads_only) {
+      const bsgpu_options& oi = o[options_stride ? i : 0];
+      try {
+        covered = finalize(ctxs[i]) == BSGPU_OK && batch_covers(ctxs[i], oi);
+        if (covered && !batched.empty()) {   // (one device, and the options that are part of the argument tables equal)
+          const bsgpu_options& o0 = o[options_stride ? batched[0] : 0];
+          covered = ctxs[batched[0]]->device == ctxs[i]->device && o0.jacobi_scaling == oi.jacobi_scaling && o0.min_lm_diagonal == oi.min_lm_diagonal &&
+                    o0.max_lm_diagonal == oi.max_lm_diagonal;
+        }
+      }
+      catch (...) { covered = false; }
+    }
+    (covered ? batched : alone).push_back(i);
+  }
+  if (batched.size() < 2) { alone.insert(alone.end(), batched.begin(), batched.end()); batched.clear(); }
   auto one = [&](int i) { rc[i] = bsgpu_solve(ctxs[i], o + (options_stride ? i : 0), s + i); };   // (bsgpu_solve catches everything)
   std::vector<std::thread> th;
-  th.reserve(n - 1);
+  size_t started = 0;
+  const size_t keep = batched.empty() ? 1 : 0;   // (without a batch the calling thread takes the last lone window itself)
   try {
-    for (int i = 1; i < n; ++i) th.emplace_back(one, i);
-  } catch (...) {   // no more threads: the rest in this one
-    for (int i = (int)th.size() + 1; i < n; ++i) one(i);
+    for (; started + keep < alone.size(); ++started) th.emplace_back(one, alone[started]);
+  } catch (...) {}   // no more threads: the rest in this one
+  for (size_t b0 = 0; b0 < batched.size(); b0 += kBatchMaxWin) {
+    const int m = (int)std::min<size_t>(kBatchMaxWin, batched.size() - b0);
+    bool ok = false;
+    try { ok = solve_batched(ctxs, batched.data() + b0, m, o, options_stride, s, rc.data()); } catch (...) { ok = false; }
+    if (!ok) for (int q = 0; q < m; ++q) one(batched[b0 + q]);
   }
-  one(0);
+  for (; started < alone.size(); ++started) one(alone[started]);
   for (auto& t : th) t.join();
   for (int i = 0; i < n; ++i) if (rc[i] != BSGPU_OK) return rc[i];
   return BSGPU_OK;
 }
+int bsgpu_batch_stats(int64_t* windows_batched, int64_t* rounds) { batch_stats(windows_batched, rounds); return BSGPU_OK; }
 int bsgpu_get_blocks(bsgpu_ctx* c, double* v, int64_t n) try {
   if (!c) return BSGPU_ERR_INVALID;
   if ((size_t)n != c->h_x.size()) return fail(c, BSGPU_ERR_INVALID, "get_blocks: size mismatch");

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -128,6 +129,7 @@ struct bsgpu_ctx {
   HostGroup groups[kNumInternal];
   SlotMirror mirror0;            // BSGPU_F_REPROJ through bsgpu_sync_factors_indirect
   bool finalized = false;
+  uint64_t finalize_gen = 0;     // counts finalize() runs: cached per-window argument tables (bsgpu_batch.cpp) are stale when it moves
   // ---- derived structure
   std::vector<int> tsize, toff;
   std::vector<uint8_t> is_lm;
@@ -331,25 +333,7 @@ int fetch_scalars(bsgpu_ctx* c);
 int ensure_vis_src(bsgpu_ctx* c);
 // Cholesky of the (padded, rhs-augmented, solver-ordered) reduced system in S and the solve L^T y = y', following the plan's
 // step schedule; y comes back in solver order (npad entries)
-struct DenseDev {
-  const int *nreal, *rows_flat;
-  const PanelDesc* panels;
-  double *Lp, *Vinv;
-  const int *bs_desc, *chain_begin, *chain_end;   // bs_desc: DensePlan::bs_desc on the device
-  int* tile_sync;   // [expected arrivals | arrival counters] per tile (dense_plan.h)
-  const FusedTask* ftasks = nullptr;   // fused single-launch factorisation (null: the launch-per-step path)
-  int* fsync = nullptr;
-  // level-synchronous back-substitution (DensePlan::bs_level_sync): chain-only panel records and the between-group update items
-  const int *bs_desc_chain = nullptr, *rows_flat_chain = nullptr, *bs_upd = nullptr, *bs_upd_rows = nullptr;
-  // ... and its single-launch form
-  const int *bs_chain_group = nullptr, *bs_grp_nchains = nullptr, *bs_grp_nitems = nullptr, *bs_items4 = nullptr, *bs_tile_updated = nullptr;
-  int* bs_sync = nullptr;
-  double* scal = nullptr;
-  double* Winv = nullptr;   // per tile: the full inverse of its factor (written by the fused factorisation, read by the single-launch back-substitution)
-  const int* bs_order = nullptr;   // ticket -> role of the single-launch back-substitution (DensePlan::bs_order)
-  const int* tile_tot = nullptr;   // fused factorisation: update tasks per tile (DensePlan::tile_tot)
-  int rhs_rows = 0;                // rows of the rhs tile that are in use (the LM solve: 1); 0: every row may be
-};
+// (struct DenseDev: bsgpu_internal.h)
 void dense_factor(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* scal);
 // (iperm / y_tan / delta given: the back-substitution also writes the solution in tangent order and the step -y)
 void dense_backsolve(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* y, const int* iperm = nullptr,
@@ -357,5 +341,9 @@ void dense_backsolve(hipStream_t s, const DensePlan& P, const DenseDev& D, doubl
 void dense_factor_solve(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* y, double* scal, const int* iperm = nullptr,
                         int n_pose = 0, double* y_tan = nullptr, double* delta = nullptr);
 int profile_step(bsgpu_ctx* c, const bsgpu_options& o, int reps, double* ms_out, double* work_out);
+// bsgpu_batch.cpp: several windows by one set of launches per LM iteration
+bool batch_covers(bsgpu_ctx* c, const bsgpu_options& o);
+void batch_stats(int64_t* windows, int64_t* rounds);
+bool solve_batched(bsgpu_ctx* const* ctxs, const int* idx, int m, const bsgpu_options* o, int options_stride, bsgpu_summary* s, int* rc);
 
 }  // namespace bsg

@@ -1019,6 +1019,7 @@ int finalize(bsgpu_ctx* c) {
   HIPCHK(c, hipGetLastError());
   lap("device sync");
   c->finalized = true;
+  c->finalize_gen++;
   return BSGPU_OK;
 }
 

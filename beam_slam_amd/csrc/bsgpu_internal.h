@@ -5,7 +5,10 @@
 #include <stdint.h>
 
 #include <functional>
+#include <cstring>
 #include <vector>
+
+#include "dense_plan.h"
 
 namespace bsg {
 
@@ -209,11 +212,73 @@ struct BatchDyn {
   double seq[kBatchMaxWin];            // stamp of this iteration's end-of-step reduction
   int first[kBatchMaxWin], new_J[kBatchMaxWin], grad_only[kBatchMaxWin];
 };
+// device tables of the tiled Cholesky plan, as the factorisation / back-substitution entry points take them
+struct DenseDev {
+  const int *nreal, *rows_flat;
+  const PanelDesc* panels;
+  double *Lp, *Vinv;
+  const int *bs_desc, *chain_begin, *chain_end;   // bs_desc: DensePlan::bs_desc on the device
+  int* tile_sync;   // [expected arrivals | arrival counters] per tile (dense_plan.h)
+  const FusedTask* ftasks = nullptr;   // fused single-launch factorisation (null: the launch-per-step path)
+  int* fsync = nullptr;
+  // level-synchronous back-substitution (DensePlan::bs_level_sync): chain-only panel records and the between-group update items
+  const int *bs_desc_chain = nullptr, *rows_flat_chain = nullptr, *bs_upd = nullptr, *bs_upd_rows = nullptr;
+  // ... and its single-launch form
+  const int *bs_chain_group = nullptr, *bs_grp_nchains = nullptr, *bs_grp_nitems = nullptr, *bs_items4 = nullptr, *bs_tile_updated = nullptr;
+  int* bs_sync = nullptr;
+  double* scal = nullptr;
+  double* Winv = nullptr;   // per tile: the full inverse of its factor (written by the fused factorisation, read by the single-launch back-substitution)
+  const int* bs_order = nullptr;   // ticket -> role of the single-launch back-substitution (DensePlan::bs_order)
+  const int* tile_tot = nullptr;   // fused factorisation: update tasks per tile (DensePlan::tile_tot)
+  int rhs_rows = 0;                // rows of the rhs tile that are in use (the LM solve: 1); 0: every row may be
+};
+// per-window argument table of one `_batch` kernel: entry w = the arguments window w's lone launch would pass (host image, then uploaded)
+struct BatchArgTable {
+  std::vector<unsigned char> host;
+  size_t stride = 0, lds = 0;
+  int max_grid = 0;
+  void* dev = nullptr;
+  template <class A> void push(const A& a) {
+    stride = sizeof(A);
+    const size_t o = host.size();
+    host.resize(o + sizeof(A));
+    std::memcpy(&host[o], &a, sizeof(A));
+    if (a.bsg_grid > max_grid) max_grid = a.bsg_grid;
+  }
+};
 struct ZeroStep {
   double* S = nullptr; int ld = 0; const int* tiles = nullptr; int n_tiles = 0;
   double* a = nullptr; int na = 0; double* b = nullptr; int nb = 0; double* c = nullptr; int nc = 0;
   double* radius_slot = nullptr; double radius = 0.0;
 };
+// `_batch` forms of the LM step's launches (k_*.hip): batchargs_* appends window w's entry (what its lone launch passes), launch_*_batch
+// runs the windows of list `list` (BatchDyn::idx) in one launch
+struct Visual; struct SmallGroup; struct SmallGroupSet; struct UpdateRide; struct ReduceEntry; struct DevCamera; struct DevLoss;
+void batchargs_visual_imu_eval(BatchArgTable& t, const Visual& v, const SmallGroup& delta, const SmallGroup& prior, const double* x, const DevCamera* cams,
+                               const DevLoss* losses, double* cost_part_vis, double* part_delta, double* part_prior);
+void launch_visual_imu_eval_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n, bool with_J);
+void batchargs_landmark(BatchArgTable& t, BatchArgTable& t_tail, const Visual& v, int n_pose, int jacobi, double lm_lo, double lm_hi, double* scale, double* dcl,
+                        double* grad, const ZeroStep& zero);
+void launch_landmark_batch(hipStream_t s, const BatchArgTable& t, const BatchArgTable& t_tail, const BatchDyn* dyn, int list, int n);
+void batchargs_pairs(BatchArgTable& t, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm, const SmallGroupSet* small,
+                     int n_small_units);
+void launch_pairs_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n);
+void batchargs_backsub_mcc(BatchArgTable& t, const Visual& v, int n_pose, const double* y_pose, double* delta, double* mcc_part, const SmallGroupSet* small,
+                           int n_small_units, const UpdateRide* upd);
+void launch_backsub_mcc_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n);
+void batchargs_grad_norms_pose_diag(BatchArgTable& t, int nb, const int* blk_xoff, const int* blk_toff, const unsigned char* blk_size,
+                                    const unsigned char* blk_manifold, const double* x, const double* grad, double* gpart, int n_pose, double* S, int ld,
+                                    const double* hdiag, int jacobi, double lm_lo, double lm_hi, double* scale, double* dcl, int npad, const int* iperm);
+void launch_grad_norms_pose_diag_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n);
+void batchargs_final_reduce(BatchArgTable& t, const ReduceEntry* entries, int n_entries, int n_slots, double* scal, double* host_scal, int* counter);
+void launch_final_reduce_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n);
+void batchargs_copy(BatchArgTable& t, const double* src, double* dst, int64_t n);
+void launch_copy_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n);
+void batchargs_chol_fused(BatchArgTable& t, double* S, double* Lp, int ld, const FusedTask* tasks_dev, int n_tasks, const int* tile_tot_dev, const int* nreal_dev,
+                          double* Vinv, double* scal, int* sync_dev, double* Winv, int rhs_rows);
+void launch_chol_fused_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n);
+int batchargs_backsolve(BatchArgTable* tabs, const DensePlan& P, const DenseDev& D, double* y, const int* iperm, int n_pose, double* y_tan, double* delta);
+void launch_backsolve_batch(hipStream_t s, const BatchArgTable* tabs, const BatchDyn* dyn, const int* n_in_form);
 void launch_landmark(hipStream_t s, const Visual& v, int n_pose, const double* radius_ptr, int compute_scale,
                      int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* scale, double* dcl,
                      double* grad, const ZeroStep* zero = nullptr, double radius_val = 0.0);

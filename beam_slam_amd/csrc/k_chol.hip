@@ -907,12 +907,33 @@ struct chol_fused_kernel_Args {
   int rhs_strips;
   long long* probe_ts;
 };
+// (the same entry as the kernel reads it: its pointers are GLOBAL pointers — read as generic ones every load through them would be a FLAT
+// instruction, which also counts against the LDS counter and serialises the kernels that overlap gathers with LDS traffic)
+struct chol_fused_kernel_ArgsG {
+  int bsg_grid;
+  double __attribute__((address_space(1)))* S;
+  double __attribute__((address_space(1)))* Lp;
+  int ld;
+  const FusedTask __attribute__((address_space(1)))* tasks;
+  int n_tasks;
+  const int __attribute__((address_space(1)))* tile_tot;
+  const int __attribute__((address_space(1)))* nreal;
+  double __attribute__((address_space(1)))* Vinv;
+  double __attribute__((address_space(1)))* scal;
+  int __attribute__((address_space(1)))* sync;
+  double __attribute__((address_space(1)))* Winv;
+  int fs;
+  int rhs_strips;
+  long long __attribute__((address_space(1)))* probe_ts;
+};
+static_assert(sizeof(chol_fused_kernel_ArgsG) == sizeof(chol_fused_kernel_Args), "layout");
+
 template <bool PROBE>
 __global__ __launch_bounds__(kFusedThreads) void chol_fused_kernel_batch(const chol_fused_kernel_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
-  const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
-  chol_fused_kernel_Args a = bsg_A[bsg_w];
-  if ((int)blockIdx.x >= a.bsg_grid) return;
-  chol_fused_kernel_body<PROBE>((int)blockIdx.x, a.bsg_grid, a.S, a.Lp, a.ld, a.tasks, a.n_tasks, a.tile_tot, a.nreal, a.Vinv, a.scal, a.sync, a.Winv, a.fs, a.rhs_strips, a.probe_ts);
+  const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.x];
+  const chol_fused_kernel_ArgsG& a = reinterpret_cast<const chol_fused_kernel_ArgsG*>(bsg_A)[bsg_w];
+  if ((int)blockIdx.y >= a.bsg_grid) return;   // (windows interleaved in dispatch order: x = window, y = the window's workgroup — the workgroups of ALL windows take their tickets side by side)
+  chol_fused_kernel_body<PROBE>((int)blockIdx.y, a.bsg_grid, (double*)a.S, (double*)a.Lp, a.ld, (const FusedTask*)a.tasks, a.n_tasks, (const int*)a.tile_tot, (const int*)a.nreal, (double*)a.Vinv, (double*)a.scal, (int*)a.sync, (double*)a.Winv, a.fs, a.rhs_strips, (long long*)a.probe_ts);
 }
 // ints between two words of the sync area: 16 = a 64-byte line each (BSGPU_FLAG_STRIDE=1: packed, the first layout)
 int fused_sync_stride() {
@@ -1235,12 +1256,35 @@ struct chol_backsolve_chain_kernel_Args {
   double* y_tan;
   double* delta;
 };
+// (the same entry as the kernel reads it: its pointers are GLOBAL pointers — read as generic ones every load through them would be a FLAT
+// instruction, which also counts against the LDS counter and serialises the kernels that overlap gathers with LDS traffic)
+struct chol_backsolve_chain_kernel_ArgsG {
+  int bsg_grid;
+  const double __attribute__((address_space(1)))* S;
+  const double __attribute__((address_space(1)))* Lp;
+  const double __attribute__((address_space(1)))* Vinv;
+  int ld;
+  const int __attribute__((address_space(1)))* bs_desc;
+  const int __attribute__((address_space(1)))* chain_begin;
+  const int __attribute__((address_space(1)))* chain_end;
+  const int __attribute__((address_space(1)))* rows_flat;
+  double __attribute__((address_space(1)))* y;
+  int npad;
+  int max_len;
+  const double __attribute__((address_space(1)))* y_init;
+  const int __attribute__((address_space(1)))* iperm;
+  int n_pose;
+  double __attribute__((address_space(1)))* y_tan;
+  double __attribute__((address_space(1)))* delta;
+};
+static_assert(sizeof(chol_backsolve_chain_kernel_ArgsG) == sizeof(chol_backsolve_chain_kernel_Args), "layout");
+
 template <bool Y_IN_LDS, int CH, bool DEEP, bool USE_W>
 __global__ __launch_bounds__(1024) void chol_backsolve_chain_kernel_batch(const chol_backsolve_chain_kernel_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
-  const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
-  chol_backsolve_chain_kernel_Args a = bsg_A[bsg_w];
-  if ((int)blockIdx.x >= a.bsg_grid) return;
-  chol_backsolve_chain_kernel_body<Y_IN_LDS, CH, DEEP, USE_W>((int)blockIdx.x, a.bsg_grid, a.S, a.Lp, a.Vinv, a.ld, a.bs_desc, a.chain_begin, a.chain_end, a.rows_flat, a.y, a.npad, a.max_len, a.y_init, a.iperm, a.n_pose, a.y_tan, a.delta);
+  const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.x];
+  const chol_backsolve_chain_kernel_ArgsG& a = reinterpret_cast<const chol_backsolve_chain_kernel_ArgsG*>(bsg_A)[bsg_w];
+  if ((int)blockIdx.y >= a.bsg_grid) return;   // (windows interleaved in dispatch order: x = window, y = the window's workgroup — the workgroups of ALL windows take their tickets side by side)
+  chol_backsolve_chain_kernel_body<Y_IN_LDS, CH, DEEP, USE_W>((int)blockIdx.y, a.bsg_grid, (double*)a.S, (double*)a.Lp, (double*)a.Vinv, a.ld, (const int*)a.bs_desc, (const int*)a.chain_begin, (const int*)a.chain_end, (const int*)a.rows_flat, (double*)a.y, a.npad, a.max_len, (const double*)a.y_init, (const int*)a.iperm, a.n_pose, (double*)a.y_tan, (double*)a.delta);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1381,12 +1425,47 @@ struct chol_backsolve_fused_kernel_Args {
   const int* order;
   int fs;
 };
+// (the same entry as the kernel reads it: its pointers are GLOBAL pointers — read as generic ones every load through them would be a FLAT
+// instruction, which also counts against the LDS counter and serialises the kernels that overlap gathers with LDS traffic)
+struct chol_backsolve_fused_kernel_ArgsG {
+  int bsg_grid;
+  const double __attribute__((address_space(1)))* Lp;
+  const double __attribute__((address_space(1)))* Winv;
+  int ld;
+  const int __attribute__((address_space(1)))* bs_desc;
+  const int __attribute__((address_space(1)))* chain_begin;
+  const int __attribute__((address_space(1)))* chain_end;
+  const int __attribute__((address_space(1)))* rows_flat;
+  int n_chains;
+  const int __attribute__((address_space(1)))* chain_group;
+  const int __attribute__((address_space(1)))* grp_nchains;
+  const int __attribute__((address_space(1)))* grp_nitems;
+  int G;
+  const int __attribute__((address_space(1)))* items;
+  const int __attribute__((address_space(1)))* upd_rows;
+  const int __attribute__((address_space(1)))* tile_updated;
+  double __attribute__((address_space(1)))* y;
+  int npad;
+  int max_len;
+  const double __attribute__((address_space(1)))* y_init;
+  const int __attribute__((address_space(1)))* iperm;
+  int n_pose;
+  double __attribute__((address_space(1)))* y_tan;
+  double __attribute__((address_space(1)))* delta;
+  int __attribute__((address_space(1)))* sync;
+  double __attribute__((address_space(1)))* scal;
+  long long __attribute__((address_space(1)))* ts;
+  const int __attribute__((address_space(1)))* order;
+  int fs;
+};
+static_assert(sizeof(chol_backsolve_fused_kernel_ArgsG) == sizeof(chol_backsolve_fused_kernel_Args), "layout");
+
 template <int CH, bool DEEP>
 __global__ __launch_bounds__(1024) void chol_backsolve_fused_kernel_batch(const chol_backsolve_fused_kernel_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
-  const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
-  chol_backsolve_fused_kernel_Args a = bsg_A[bsg_w];
-  if ((int)blockIdx.x >= a.bsg_grid) return;
-  chol_backsolve_fused_kernel_body<CH, DEEP>((int)blockIdx.x, a.bsg_grid, a.Lp, a.Winv, a.ld, a.bs_desc, a.chain_begin, a.chain_end, a.rows_flat, a.n_chains, a.chain_group, a.grp_nchains, a.grp_nitems, a.G, a.items, a.upd_rows, a.tile_updated, a.y, a.npad, a.max_len, a.y_init, a.iperm, a.n_pose, a.y_tan, a.delta, a.sync, a.scal, a.ts, a.order, a.fs);
+  const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.x];
+  const chol_backsolve_fused_kernel_ArgsG& a = reinterpret_cast<const chol_backsolve_fused_kernel_ArgsG*>(bsg_A)[bsg_w];
+  if ((int)blockIdx.y >= a.bsg_grid) return;   // (windows interleaved in dispatch order: x = window, y = the window's workgroup — the workgroups of ALL windows take their tickets side by side)
+  chol_backsolve_fused_kernel_body<CH, DEEP>((int)blockIdx.y, a.bsg_grid, (double*)a.Lp, (double*)a.Winv, a.ld, (const int*)a.bs_desc, (const int*)a.chain_begin, (const int*)a.chain_end, (const int*)a.rows_flat, a.n_chains, (const int*)a.chain_group, (const int*)a.grp_nchains, (const int*)a.grp_nitems, a.G, (const int*)a.items, (const int*)a.upd_rows, (const int*)a.tile_updated, (double*)a.y, a.npad, a.max_len, (const double*)a.y_init, (const int*)a.iperm, a.n_pose, (double*)a.y_tan, (double*)a.delta, (int*)a.sync, (double*)a.scal, (long long*)a.ts, (const int*)a.order, a.fs);
 }
 // false: not launched (the grid would not be resident at once, or y does not fit LDS) — the caller takes the launch-per-level path
 bool launch_chol_backsolve_fused(hipStream_t s, const double* Lp, const double* Winv, int ld, const int* bs_desc_dev, const int* chain_begin_dev,
@@ -1508,6 +1587,71 @@ void launch_chol_backsolve_update(hipStream_t s, const double* Lp, int ld, const
   hipLaunchKernelGGL(chol_backsolve_update_kernel, dim3(n_items), dim3(1024), 0, s, Lp, ld, items_dev, upd_rows_dev, y);
 }
 
+// ---- the factorisation and the back-substitution of several windows in one launch each (bsgpu_batch.cpp): every window keeps its own
+// task list, ticket and counters — a workgroup of window w takes window w's next ticket
+void batchargs_chol_fused(BatchArgTable& t, double* S, double* Lp, int ld, const FusedTask* tasks_dev, int n_tasks, const int* tile_tot_dev, const int* nreal_dev,
+                          double* Vinv, double* scal, int* sync_dev, double* Winv, int rhs_rows) {
+  chol_fused_kernel_Args a;
+  a.bsg_grid = n_tasks;
+  a.S = S; a.Lp = Lp; a.ld = ld; a.tasks = tasks_dev; a.n_tasks = n_tasks; a.tile_tot = tile_tot_dev; a.nreal = nreal_dev; a.Vinv = Vinv; a.scal = scal;
+  a.sync = sync_dev; a.Winv = Winv; a.fs = fused_sync_stride(); a.rhs_strips = rhs_rows <= 0 ? 4 : std::min(4, (rhs_rows + 15) / 16); a.probe_ts = nullptr;
+  t.push(a);
+  t.lds = kFusedLds;
+}
+void launch_chol_fused_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n) {
+  if (n <= 0 || t.max_grid <= 0) return;
+  hipLaunchKernelGGL((chol_fused_kernel_batch<false>), dim3(n, t.max_grid), dim3(kFusedThreads), kFusedLds, s, static_cast<const chol_fused_kernel_Args*>(t.dev), dyn, list);
+}
+size_t chol_backsolve_chain_lds(int npad, int max_chain_len);
+// tabs[0..3]: single-launch form (shallow, deep), one-chain form (shallow, deep).  Returns the index of the table this window's
+// back-substitution uses (the others get an empty entry), or -1 when neither form covers its plan (the caller takes the lone path).
+int batchargs_backsolve(BatchArgTable* tabs, const DensePlan& P, const DenseDev& D, double* y, const int* iperm, int n_pose, double* y_tan, double* delta) {
+  const int ld = P.npad;
+  const double* rhs_row = D.Lp + (size_t)P.rhs_row * ld;
+  const int G = (int)P.bs_group_off.size() - 1;
+  const bool level_sync = P.bs_level_sync && D.bs_desc_chain && D.bs_upd;
+  int max_len = 1, max_rows = 0;
+  for (size_t i = 0; i < P.chain_begin.size(); ++i) max_len = std::max(max_len, P.chain_end[i] - P.chain_begin[i]);
+  int form = -1;
+  chol_backsolve_fused_kernel_Args f;
+  chol_backsolve_chain_kernel_Args c;
+  f.bsg_grid = 0; c.bsg_grid = 0;
+  size_t lds = 0;
+  if (level_sync && D.bs_items4 && D.bs_sync && D.scal && D.Winv && D.ftasks && D.fsync && D.bs_order && !getenv("BSGPU_BACKSOLVE_GLOBAL_Y")) {
+    for (int g = 0; g < G; ++g) max_rows = std::max(max_rows, P.bs_group_maxrows[g]);
+    max_rows = std::max(1, max_rows);
+    const int n_chains = (int)P.chain_begin.size(), n_items = (int)P.bs_upd.size() / 3 * (P.bs_upd_off.back() > 0 ? 1 : 0);
+    lds = chol_backsolve_chain_lds(P.npad, max_len) + 16;
+    if (lds <= (size_t)160 * 1024 - 256 && n_chains + n_items <= 512) {
+      const bool deep = max_rows <= kBsChunkDeep && max_len > 1;
+      form = deep ? 1 : 0;
+      f.bsg_grid = n_chains + n_items;
+      f.Lp = D.Lp; f.Winv = D.Winv; f.ld = ld; f.bs_desc = D.bs_desc_chain; f.chain_begin = D.chain_begin; f.chain_end = D.chain_end; f.rows_flat = D.rows_flat_chain;
+      f.n_chains = n_chains; f.chain_group = D.bs_chain_group; f.grp_nchains = D.bs_grp_nchains; f.grp_nitems = D.bs_grp_nitems; f.G = G; f.items = D.bs_items4;
+      f.upd_rows = D.bs_upd_rows; f.tile_updated = D.bs_tile_updated; f.y = y; f.npad = P.npad; f.max_len = max_len; f.y_init = rhs_row; f.iperm = iperm; f.n_pose = n_pose;
+      f.y_tan = y_tan; f.delta = delta; f.sync = D.bs_sync; f.scal = D.scal; f.ts = nullptr; f.order = D.bs_order; f.fs = fused_sync_stride();
+    }
+  } else if (!level_sync && G == 1 && P.chain_begin.size() == 1 && D.ftasks && D.fsync && D.tile_tot && D.Winv && !getenv("BSGPU_BACKSOLVE_GLOBAL_Y") &&
+             !getenv("BSGPU_BACKSOLVE_NO_W")) {
+    lds = chol_backsolve_chain_lds(P.npad, max_len);
+    if (lds <= (size_t)160 * 1024) {
+      const bool deep = false;   // (max_rows unknown for the plain row lists: launch_chol_backsolve_chains passes 0)
+      form = 2 + (deep ? 1 : 0);
+      c.bsg_grid = 1;
+      c.S = nullptr; c.Lp = D.Lp; c.Vinv = D.Winv; c.ld = ld; c.bs_desc = D.bs_desc; c.chain_begin = D.chain_begin; c.chain_end = D.chain_end; c.rows_flat = D.rows_flat;
+      c.y = y; c.npad = P.npad; c.max_len = max_len; c.y_init = rhs_row; c.iperm = iperm; c.n_pose = n_pose; c.y_tan = y_tan; c.delta = delta;
+    }
+  }
+  for (int q = 0; q < 2; ++q) { chol_backsolve_fused_kernel_Args e = f; if (q != form) e.bsg_grid = 0; tabs[q].push(e); if (q == form) tabs[q].lds = std::max(tabs[q].lds, lds); }
+  for (int q = 2; q < 4; ++q) { chol_backsolve_chain_kernel_Args e = c; if (q != form) e.bsg_grid = 0; tabs[q].push(e); if (q == form) tabs[q].lds = std::max(tabs[q].lds, lds); }
+  return form;
+}
+void launch_backsolve_batch(hipStream_t s, const BatchArgTable* tabs, const BatchDyn* dyn, const int* n_in_form /* 4 */) {
+  if (n_in_form[0] > 0) hipLaunchKernelGGL((chol_backsolve_fused_kernel_batch<kBsChunk, false>), dim3(n_in_form[0], tabs[0].max_grid), dim3(1024), tabs[0].lds, s, static_cast<const chol_backsolve_fused_kernel_Args*>(tabs[0].dev), dyn, BL_BS_FUSED);
+  if (n_in_form[1] > 0) hipLaunchKernelGGL((chol_backsolve_fused_kernel_batch<kBsChunkDeep, true>), dim3(n_in_form[1], tabs[1].max_grid), dim3(1024), tabs[1].lds, s, static_cast<const chol_backsolve_fused_kernel_Args*>(tabs[1].dev), dyn, BL_BS_FUSED + 1);
+  if (n_in_form[2] > 0) hipLaunchKernelGGL((chol_backsolve_chain_kernel_batch<true, kBsChunk, false, true>), dim3(n_in_form[2], tabs[2].max_grid), dim3(1024), tabs[2].lds, s, static_cast<const chol_backsolve_chain_kernel_Args*>(tabs[2].dev), dyn, BL_BS_CHAIN);
+  if (n_in_form[3] > 0) hipLaunchKernelGGL((chol_backsolve_chain_kernel_batch<true, kBsChunkDeep, true, true>), dim3(n_in_form[3], tabs[3].max_grid), dim3(1024), tabs[3].lds, s, static_cast<const chol_backsolve_chain_kernel_Args*>(tabs[3].dev), dyn, BL_BS_CHAIN + 1);
+}
 size_t chol_backsolve_chain_lds(int npad, int max_chain_len) {
   return sizeof(double) * (NB * (NB + 1) + 16 * NB + 1024 + (size_t)npad) + sizeof(int) * (size_t)max_chain_len * (3 + kBsMaxRows);
 }

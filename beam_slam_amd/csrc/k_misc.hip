@@ -91,12 +91,31 @@ struct grad_norms_kernel_Args {
   double* gpart;
   PoseDiagArgs pd;
 };
+// (the same entry as the kernel reads it: its pointers are GLOBAL pointers — read as generic ones every load through them would be a FLAT
+// instruction, which also counts against the LDS counter and serialises the kernels that overlap gathers with LDS traffic)
+struct grad_norms_kernel_ArgsG {
+  int bsg_grid;
+  int nb;
+  const int __attribute__((address_space(1)))* xoff;
+  const int __attribute__((address_space(1)))* toff;
+  const unsigned char __attribute__((address_space(1)))* size;
+  const unsigned char __attribute__((address_space(1)))* manifold;
+  const double __attribute__((address_space(1)))* x;
+  const double __attribute__((address_space(1)))* grad;
+  double __attribute__((address_space(1)))* gpart;
+  PoseDiagArgs pd;
+};
+static_assert(sizeof(grad_norms_kernel_ArgsG) == sizeof(grad_norms_kernel_Args), "layout");
+
 template <bool WITH_DIAG>
 __global__ __launch_bounds__(256) void grad_norms_kernel_batch(const grad_norms_kernel_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
   const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
-  grad_norms_kernel_Args a = bsg_A[bsg_w];
+  const grad_norms_kernel_ArgsG& a = reinterpret_cast<const grad_norms_kernel_ArgsG*>(bsg_A)[bsg_w];
   if ((int)blockIdx.x >= a.bsg_grid) return;
-  grad_norms_kernel_body<WITH_DIAG>((int)blockIdx.x, a.bsg_grid, a.nb, a.xoff, a.toff, a.size, a.manifold, a.x, a.grad, a.gpart, a.pd);
+  PoseDiagArgs pd = a.pd;
+  pd.radius_ptr = nullptr; pd.radius_val = bsg_dyn->radius[bsg_w];
+  pd.compute_scale = bsg_dyn->first[bsg_w]; pd.compute_dcl = bsg_dyn->new_J[bsg_w];
+  grad_norms_kernel_body<WITH_DIAG>((int)blockIdx.x, a.bsg_grid, a.nb, (const int*)a.xoff, (const int*)a.toff, (const unsigned char*)a.size, (const unsigned char*)a.manifold, (const double*)a.x, (const double*)a.grad, (double*)a.gpart, pd);
 }
 
 void launch_grad_norms(hipStream_t s, int nb, const int* blk_xoff, const int* blk_toff, const unsigned char* blk_size,
@@ -213,11 +232,25 @@ struct final_reduce_kernel_Args {
   int* counter;
   double seq;
 };
+// (the same entry as the kernel reads it: its pointers are GLOBAL pointers — read as generic ones every load through them would be a FLAT
+// instruction, which also counts against the LDS counter and serialises the kernels that overlap gathers with LDS traffic)
+struct final_reduce_kernel_ArgsG {
+  int bsg_grid;
+  const ReduceEntry __attribute__((address_space(1)))* entries;
+  int n_entries;
+  int n_slots;
+  double __attribute__((address_space(1)))* scal;
+  double __attribute__((address_space(1)))* host_scal;
+  int __attribute__((address_space(1)))* counter;
+  double seq;
+};
+static_assert(sizeof(final_reduce_kernel_ArgsG) == sizeof(final_reduce_kernel_Args), "layout");
+
 __global__ __launch_bounds__(1024) void final_reduce_kernel_batch(const final_reduce_kernel_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
   const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
-  final_reduce_kernel_Args a = bsg_A[bsg_w];
+  const final_reduce_kernel_ArgsG& a = reinterpret_cast<const final_reduce_kernel_ArgsG*>(bsg_A)[bsg_w];
   if ((int)blockIdx.x >= a.bsg_grid) return;
-  final_reduce_kernel_body((int)blockIdx.x, a.bsg_grid, a.entries, a.n_entries, a.n_slots, a.scal, a.host_scal, a.counter, a.seq);
+  final_reduce_kernel_body((int)blockIdx.x, a.bsg_grid, (const ReduceEntry*)a.entries, a.n_entries, a.n_slots, (double*)a.scal, (double*)a.host_scal, (int*)a.counter, bsg_dyn->seq[bsg_w]);
 }
 void launch_final_reduce(hipStream_t s, const ReduceEntry* entries, int n_entries, int n_slots, double* scal, double* host_scal, int* counter,
                          double seq) {
@@ -302,11 +335,58 @@ struct copy_kernel_Args {
   int64_t n;
   int nzero_after;
 };
+// (the same entry as the kernel reads it: its pointers are GLOBAL pointers — read as generic ones every load through them would be a FLAT
+// instruction, which also counts against the LDS counter and serialises the kernels that overlap gathers with LDS traffic)
+struct copy_kernel_ArgsG {
+  int bsg_grid;
+  const double __attribute__((address_space(1)))* src;
+  double __attribute__((address_space(1)))* dst;
+  int64_t n;
+  int nzero_after;
+};
+static_assert(sizeof(copy_kernel_ArgsG) == sizeof(copy_kernel_Args), "layout");
+
 __global__ __launch_bounds__(256) void copy_kernel_batch(const copy_kernel_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
   const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
-  copy_kernel_Args a = bsg_A[bsg_w];
+  const copy_kernel_ArgsG& a = reinterpret_cast<const copy_kernel_ArgsG*>(bsg_A)[bsg_w];
   if ((int)blockIdx.x >= a.bsg_grid) return;
-  copy_kernel_body((int)blockIdx.x, a.bsg_grid, a.src, a.dst, a.n, a.nzero_after);
+  copy_kernel_body((int)blockIdx.x, a.bsg_grid, (const double*)a.src, (double*)a.dst, a.n, a.nzero_after);
+}
+// ---- the same launches over several windows (bsgpu_batch.cpp)
+void batchargs_grad_norms_pose_diag(BatchArgTable& t, int nb, const int* blk_xoff, const int* blk_toff, const unsigned char* blk_size,
+                                    const unsigned char* blk_manifold, const double* x, const double* grad, double* gpart, int n_pose, double* S, int ld,
+                                    const double* hdiag, int jacobi, double lm_lo, double lm_hi, double* scale, double* dcl, int npad, const int* iperm) {
+  grad_norms_kernel_Args a;
+  PoseDiagArgs pd;
+  pd.radius_val = 0.0; pd.n_pose = n_pose; pd.ld = ld; pd.compute_scale = 0; pd.compute_dcl = 0; pd.jacobi = jacobi; pd.npad = npad;
+  pd.S = S; pd.hdiag = hdiag; pd.radius_ptr = nullptr; pd.lm_lo = lm_lo; pd.lm_hi = lm_hi; pd.scale = scale; pd.dcl = dcl; pd.iperm = iperm;
+  a.bsg_grid = (std::max(nb, npad) + 255) / 256;
+  a.nb = nb; a.xoff = blk_xoff; a.toff = blk_toff; a.size = blk_size; a.manifold = blk_manifold; a.x = x; a.grad = grad; a.gpart = gpart; a.pd = pd;
+  t.push(a);
+}
+void launch_grad_norms_pose_diag_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n) {
+  if (n <= 0 || t.max_grid <= 0) return;
+  hipLaunchKernelGGL(grad_norms_kernel_batch<true>, dim3(t.max_grid, n), dim3(256), 0, s, static_cast<const grad_norms_kernel_Args*>(t.dev), dyn, list);
+}
+void batchargs_final_reduce(BatchArgTable& t, const ReduceEntry* entries, int n_entries, int n_slots, double* scal, double* host_scal, int* counter) {
+  final_reduce_kernel_Args a;
+  a.bsg_grid = n_entries > 0 ? n_slots + 1 : 0;
+  a.entries = entries; a.n_entries = n_entries; a.n_slots = n_slots; a.scal = scal; a.host_scal = host_scal; a.counter = counter; a.seq = 0.0;
+  t.push(a);
+}
+void launch_final_reduce_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n) {
+  if (n <= 0 || t.max_grid <= 0) return;
+  hipLaunchKernelGGL(final_reduce_kernel_batch, dim3(t.max_grid, n), dim3(1024), 0, s, static_cast<const final_reduce_kernel_Args*>(t.dev), dyn, list);
+}
+void batchargs_copy(BatchArgTable& t, const double* src, double* dst, int64_t n) {
+  copy_kernel_Args a;
+  a.bsg_grid = n > 0 ? (int)std::min<int64_t>((n + 255) / 256, 256) : 0;
+  a.src = src; a.dst = dst; a.n = n; a.nzero_after = 0;
+  t.push(a);
+}
+void launch_copy_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n) {
+  if (n <= 0 || t.max_grid <= 0) return;
+  hipLaunchKernelGGL(copy_kernel_batch, dim3(t.max_grid, n), dim3(256), 0, s, static_cast<const copy_kernel_Args*>(t.dev), dyn, list);
 }
 // dst[0..n) = src[0..n), then nzero_after zeros
 void launch_copy(hipStream_t s, const double* src, double* dst, int64_t n, int nzero_after) {

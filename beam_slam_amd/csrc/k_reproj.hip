@@ -201,11 +201,44 @@ struct landmark_kernel_Args {
   ZeroStep zs;
   double radius_val;
 };
+// (the same entry as the kernel reads it: its pointers are GLOBAL pointers — read as generic ones every load through them would be a FLAT
+// instruction, which also counts against the LDS counter and serialises the kernels that overlap gathers with LDS traffic)
+struct landmark_kernel_ArgsG {
+  int bsg_grid;
+  int n_lm;
+  const int __attribute__((address_space(1)))* lm_start;
+  const double __attribute__((address_space(1)))* JB;
+  const double2 __attribute__((address_space(1)))* r;
+  int n_pose;
+  const double __attribute__((address_space(1)))* radius_ptr;
+  int compute_scale;
+  int compute_dcl;
+  int jacobi;
+  double lm_lo;
+  double lm_hi;
+  double __attribute__((address_space(1)))* scale;
+  double __attribute__((address_space(1)))* dcl;
+  double __attribute__((address_space(1)))* grad;
+  double __attribute__((address_space(1)))* Linv_out;
+  double __attribute__((address_space(1)))* z_out;
+  double __attribute__((address_space(1)))* CR;
+  int lm_blocks;
+  ZeroStep zs;
+  double radius_val;
+};
+static_assert(sizeof(landmark_kernel_ArgsG) == sizeof(landmark_kernel_Args), "layout");
+
 __global__ __launch_bounds__(256) void landmark_kernel_batch(const landmark_kernel_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
   const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
-  landmark_kernel_Args a = bsg_A[bsg_w];
+  const landmark_kernel_ArgsG& a = reinterpret_cast<const landmark_kernel_ArgsG*>(bsg_A)[bsg_w];
   if ((int)blockIdx.x >= a.bsg_grid) return;
-  landmark_kernel_body((int)blockIdx.x, a.bsg_grid, a.n_lm, a.lm_start, a.JB, a.r, a.n_pose, a.radius_ptr, a.compute_scale, a.compute_dcl, a.jacobi, a.lm_lo, a.lm_hi, a.scale, a.dcl, a.grad, a.Linv_out, a.z_out, a.CR, a.lm_blocks, a.zs, a.radius_val);
+  // what changes from iteration to iteration: the radius, whether the Jacobi scale / LM diagonal are (re)computed, what the step's clearing covers
+  const double radius_val = bsg_dyn->radius[bsg_w];
+  const int compute_scale = bsg_dyn->first[bsg_w], compute_dcl = bsg_dyn->new_J[bsg_w];
+  ZeroStep zs = a.zs;
+  zs.radius = radius_val;
+  if (!compute_dcl) { zs.c += SC_CHOL_FAIL - SC_GRAD_MAX; zs.nc = 1; }
+  landmark_kernel_body((int)blockIdx.x, a.bsg_grid, a.n_lm, (const int*)a.lm_start, (const double*)a.JB, (const double2*)a.r, a.n_pose, nullptr, compute_scale, compute_dcl, a.jacobi, a.lm_lo, a.lm_hi, (double*)a.scale, (double*)a.dcl, (double*)a.grad, (double*)a.Linv_out, (double*)a.z_out, (double*)a.CR, a.lm_blocks, zs, radius_val);
 }
 
 // factors whose landmark is constant: C = 0, rho = r
@@ -228,11 +261,22 @@ struct landmark_tail_kernel_Args {
   const double2* r;
   double* CR;
 };
+// (the same entry as the kernel reads it: its pointers are GLOBAL pointers — read as generic ones every load through them would be a FLAT
+// instruction, which also counts against the LDS counter and serialises the kernels that overlap gathers with LDS traffic)
+struct landmark_tail_kernel_ArgsG {
+  int bsg_grid;
+  int first;
+  int n;
+  const double2 __attribute__((address_space(1)))* r;
+  double __attribute__((address_space(1)))* CR;
+};
+static_assert(sizeof(landmark_tail_kernel_ArgsG) == sizeof(landmark_tail_kernel_Args), "layout");
+
 __global__ void landmark_tail_kernel_batch(const landmark_tail_kernel_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
   const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
-  landmark_tail_kernel_Args a = bsg_A[bsg_w];
+  const landmark_tail_kernel_ArgsG& a = reinterpret_cast<const landmark_tail_kernel_ArgsG*>(bsg_A)[bsg_w];
   if ((int)blockIdx.x >= a.bsg_grid) return;
-  landmark_tail_kernel_body((int)blockIdx.x, a.bsg_grid, a.first, a.n, a.r, a.CR);
+  landmark_tail_kernel_body((int)blockIdx.x, a.bsg_grid, a.first, a.n, (const double2*)a.r, (double*)a.CR);
 }
 
 void launch_landmark(hipStream_t s, const Visual& v, int n_pose, const double* radius_ptr, int compute_scale,
@@ -259,7 +303,7 @@ void launch_landmark(hipStream_t s, const Visual& v, int n_pose, const double* r
 // Results are added to the dense reduced system with FP64 atomics (each location is normally owned by
 // one segment, so the sums are reproducible).
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void pairs_kernel_body(const int bsg_bx, const int bsg_gx, int n_seg, const int* __restrict__ seg_ci, const int* __restrict__ seg_cj, const int* __restrict__ seg_start, const int* __restrict__ ent_fa, const int* __restrict__ ent_fb, const double* __restrict__ J, const double2* __restrict__ r, const double* __restrict__ CR, const int* __restrict__ cp_tq, const int* __restrict__ cp_tp, double* __restrict__ S, int ld, int rhs_row, double* __restrict__ grad, double* __restrict__ hdiag, const int* __restrict__ perm, int grad_only, int n_pair_blocks, SmallGroupSet small, int n_small_units) {
+__device__ __forceinline__ void pairs_kernel_body(const int bsg_bx, const int bsg_gx, int n_seg, const int* __restrict__ seg_ci, const int* __restrict__ seg_cj, const int* __restrict__ seg_start, const int* __restrict__ ent_fa, const int* __restrict__ ent_fb, const double* __restrict__ J, const double2* __restrict__ r, const double* __restrict__ CR, const int* __restrict__ cp_tq, const int* __restrict__ cp_tp, double* __restrict__ S, int ld, int rhs_row, double* __restrict__ grad, double* __restrict__ hdiag, const int* __restrict__ perm, int grad_only, int n_pair_blocks, const SmallGroupSet& small, int n_small_units) {
   extern __shared__ __attribute__((aligned(16))) double2 slab[];   // [64][6] A_a | [64][6] A_b | [64][4] C_a | [64][3] C_b | 2 x 64 ints
   if (bsg_bx < n_small_units) {
     // the pose-only factors assembled one workgroup per factor (IMU: two or three hundred of them) as extra workgroups of this launch —
@@ -432,11 +476,39 @@ struct pairs_kernel_Args {
   SmallGroupSet small;
   int n_small_units;
 };
-__global__ __launch_bounds__(64) void pairs_kernel_batch(const pairs_kernel_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
+// (the same entry as the kernel reads it: its pointers are GLOBAL pointers — read as generic ones every load through them would be a FLAT
+// instruction, which also counts against the LDS counter and serialises the kernels that overlap gathers with LDS traffic)
+struct pairs_kernel_ArgsG {
+  int bsg_grid;
+  int n_seg;
+  const int __attribute__((address_space(1)))* seg_ci;
+  const int __attribute__((address_space(1)))* seg_cj;
+  const int __attribute__((address_space(1)))* seg_start;
+  const int __attribute__((address_space(1)))* ent_fa;
+  const int __attribute__((address_space(1)))* ent_fb;
+  const double __attribute__((address_space(1)))* J;
+  const double2 __attribute__((address_space(1)))* r;
+  const double __attribute__((address_space(1)))* CR;
+  const int __attribute__((address_space(1)))* cp_tq;
+  const int __attribute__((address_space(1)))* cp_tp;
+  double __attribute__((address_space(1)))* S;
+  int ld;
+  int rhs_row;
+  double __attribute__((address_space(1)))* grad;
+  double __attribute__((address_space(1)))* hdiag;
+  const int __attribute__((address_space(1)))* perm;
+  int grad_only;
+  int n_pair_blocks;
+  SmallGroupSet small;
+  int n_small_units;
+};
+static_assert(sizeof(pairs_kernel_ArgsG) == sizeof(pairs_kernel_Args), "layout");
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void pairs_kernel_batch(const pairs_kernel_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
   const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
-  pairs_kernel_Args a = bsg_A[bsg_w];
+  const pairs_kernel_ArgsG& a = reinterpret_cast<const pairs_kernel_ArgsG*>(bsg_A)[bsg_w];
   if ((int)blockIdx.x >= a.bsg_grid) return;
-  pairs_kernel_body((int)blockIdx.x, a.bsg_grid, a.n_seg, a.seg_ci, a.seg_cj, a.seg_start, a.ent_fa, a.ent_fb, a.J, a.r, a.CR, a.cp_tq, a.cp_tp, a.S, a.ld, a.rhs_row, a.grad, a.hdiag, a.perm, a.grad_only, a.n_pair_blocks, a.small, a.n_small_units);
+  pairs_kernel_body((int)blockIdx.x, a.bsg_grid, a.n_seg, (const int*)a.seg_ci, (const int*)a.seg_cj, (const int*)a.seg_start, (const int*)a.ent_fa, (const int*)a.ent_fb, (const double*)a.J, (const double2*)a.r, (double*)a.CR, (const int*)a.cp_tq, (const int*)a.cp_tp, (double*)a.S, a.ld, a.rhs_row, (double*)a.grad, (double*)a.hdiag, (const int*)a.perm, bsg_dyn->grad_only[bsg_w], a.n_pair_blocks, a.small, a.n_small_units);
 }
 
 constexpr size_t kPairsLds = sizeof(double2) * 64 * (6 + 6 + 4 + 3) + sizeof(int) * 128;
@@ -469,7 +541,7 @@ BSG_DEV void pose_part(const double* __restrict__ Jf, int tq, int tp, const doub
     for (int k = 0; k < 3; ++k) { const double yv = y_pose[tp + k]; j0 += Jf[3 + k] * yv; j1 += Jf[9 + k] * yv; }
   }
 }
-__device__ __forceinline__ void backsub_mcc_kernel_body(const int bsg_bx, const int bsg_gx, int n_lm, int n_lm_groups, int n_elim, int n, const int* __restrict__ lm_start, const double* __restrict__ J, const double* __restrict__ JB, const double2* __restrict__ r, const double* __restrict__ CR, const int* __restrict__ cam_pose, const int* __restrict__ cp_tq, const int* __restrict__ cp_tp, const double* __restrict__ Linv, const double* __restrict__ z, int n_pose, const double* __restrict__ y_pose, double* __restrict__ delta, double* __restrict__ mcc_part, int n_vis_blocks, SmallGroupSet small, int n_small_units, UpdateRide up, int first_update_block) {
+__device__ __forceinline__ void backsub_mcc_kernel_body(const int bsg_bx, const int bsg_gx, int n_lm, int n_lm_groups, int n_elim, int n, const int* __restrict__ lm_start, const double* __restrict__ J, const double* __restrict__ JB, const double2* __restrict__ r, const double* __restrict__ CR, const int* __restrict__ cam_pose, const int* __restrict__ cp_tq, const int* __restrict__ cp_tp, const double* __restrict__ Linv, const double* __restrict__ z, int n_pose, const double* __restrict__ y_pose, double* __restrict__ delta, double* __restrict__ mcc_part, int n_vis_blocks, const SmallGroupSet& small, int n_small_units, const UpdateRide& up, int first_update_block) {
   __shared__ double sred[4];
   if (up.n_blocks > 0 && bsg_bx >= first_update_block) {
     // the candidate of every block but the Euclidean landmarks (those: below, by the lanes that compute their step): the pose step is
@@ -591,13 +663,96 @@ struct backsub_mcc_kernel_Args {
   UpdateRide up;
   int first_update_block;
 };
+// (the same entry as the kernel reads it: its pointers are GLOBAL pointers — read as generic ones every load through them would be a FLAT
+// instruction, which also counts against the LDS counter and serialises the kernels that overlap gathers with LDS traffic)
+struct backsub_mcc_kernel_ArgsG {
+  int bsg_grid;
+  int n_lm;
+  int n_lm_groups;
+  int n_elim;
+  int n;
+  const int __attribute__((address_space(1)))* lm_start;
+  const double __attribute__((address_space(1)))* J;
+  const double __attribute__((address_space(1)))* JB;
+  const double2 __attribute__((address_space(1)))* r;
+  const double __attribute__((address_space(1)))* CR;
+  const int __attribute__((address_space(1)))* cam_pose;
+  const int __attribute__((address_space(1)))* cp_tq;
+  const int __attribute__((address_space(1)))* cp_tp;
+  const double __attribute__((address_space(1)))* Linv;
+  const double __attribute__((address_space(1)))* z;
+  int n_pose;
+  const double __attribute__((address_space(1)))* y_pose;
+  double __attribute__((address_space(1)))* delta;
+  double __attribute__((address_space(1)))* mcc_part;
+  int n_vis_blocks;
+  SmallGroupSet small;
+  int n_small_units;
+  UpdateRide up;
+  int first_update_block;
+};
+static_assert(sizeof(backsub_mcc_kernel_ArgsG) == sizeof(backsub_mcc_kernel_Args), "layout");
+
 __global__ __launch_bounds__(256) void backsub_mcc_kernel_batch(const backsub_mcc_kernel_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
   const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
-  backsub_mcc_kernel_Args a = bsg_A[bsg_w];
+  const backsub_mcc_kernel_ArgsG& a = reinterpret_cast<const backsub_mcc_kernel_ArgsG*>(bsg_A)[bsg_w];
   if ((int)blockIdx.x >= a.bsg_grid) return;
-  backsub_mcc_kernel_body((int)blockIdx.x, a.bsg_grid, a.n_lm, a.n_lm_groups, a.n_elim, a.n, a.lm_start, a.J, a.JB, a.r, a.CR, a.cam_pose, a.cp_tq, a.cp_tp, a.Linv, a.z, a.n_pose, a.y_pose, a.delta, a.mcc_part, a.n_vis_blocks, a.small, a.n_small_units, a.up, a.first_update_block);
+  backsub_mcc_kernel_body((int)blockIdx.x, a.bsg_grid, a.n_lm, a.n_lm_groups, a.n_elim, a.n, (const int*)a.lm_start, (const double*)a.J, (const double*)a.JB, (const double2*)a.r, (double*)a.CR, (const int*)a.cam_pose, (const int*)a.cp_tq, (const int*)a.cp_tp, (const double*)a.Linv, (const double*)a.z, a.n_pose, (const double*)a.y_pose, (double*)a.delta, (double*)a.mcc_part, a.n_vis_blocks, a.small, a.n_small_units, a.up, a.first_update_block);
 }
 
+// ---- the same launches over several windows (bsgpu_batch.cpp): one table entry per window, grids as the lone launches compute them
+void batchargs_landmark(BatchArgTable& t, BatchArgTable& t_tail, const Visual& v, int n_pose, int jacobi, double lm_lo, double lm_hi, double* scale, double* dcl,
+                        double* grad, const ZeroStep& zero /* c = the step's scalars from SC_GRAD_MAX on, nc = 3 */) {
+  landmark_kernel_Args a;
+  const int grid = (v.n_lm * 8 + 255) / 256, zero_blocks = std::max(1, std::min(zero.n_tiles, 1024));
+  a.bsg_grid = v.n_lm > 0 ? grid + zero_blocks : 0;
+  a.n_lm = v.n_lm; a.lm_start = v.lm_start; a.JB = v.JB; a.r = v.r; a.n_pose = n_pose; a.radius_ptr = nullptr; a.compute_scale = 0; a.compute_dcl = 0;
+  a.jacobi = jacobi; a.lm_lo = lm_lo; a.lm_hi = lm_hi; a.scale = scale; a.dcl = dcl; a.grad = grad; a.Linv_out = v.Linv; a.z_out = v.z; a.CR = v.CR;
+  a.lm_blocks = grid; a.zs = zero; a.radius_val = 0.0;
+  t.push(a);
+  landmark_tail_kernel_Args b;
+  b.bsg_grid = v.n > v.n_elim ? (v.n - v.n_elim + 255) / 256 : 0;
+  b.first = v.n_elim; b.n = v.n; b.r = v.r; b.CR = v.CR;
+  t_tail.push(b);
+}
+void launch_landmark_batch(hipStream_t s, const BatchArgTable& t, const BatchArgTable& t_tail, const BatchDyn* dyn, int list, int n) {
+  if (n <= 0) return;
+  if (t.max_grid > 0) hipLaunchKernelGGL(landmark_kernel_batch, dim3(t.max_grid, n), dim3(256), 0, s, static_cast<const landmark_kernel_Args*>(t.dev), dyn, list);
+  if (t_tail.max_grid > 0) hipLaunchKernelGGL(landmark_tail_kernel_batch, dim3(t_tail.max_grid, n), dim3(256), 0, s, static_cast<const landmark_tail_kernel_Args*>(t_tail.dev), dyn, list);
+}
+void batchargs_pairs(BatchArgTable& t, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm, const SmallGroupSet* small,
+                     int n_small_units) {
+  pairs_kernel_Args a;
+  const int pair_blocks = 8 * ((v.n_seg + 7) / 8), small_blocks = small ? 8 * ((n_small_units + 7) / 8) : 0;
+  SmallGroupSet none;
+  none.n = 0;
+  a.bsg_grid = v.n_seg > 0 ? pair_blocks + small_blocks : 0;
+  a.n_seg = v.n_seg; a.seg_ci = v.seg_ci; a.seg_cj = v.seg_cj; a.seg_start = v.seg_start; a.ent_fa = v.ent_fa; a.ent_fb = v.ent_fb; a.J = v.J; a.r = v.r; a.CR = v.CR;
+  a.cp_tq = v.cp_tq; a.cp_tp = v.cp_tp; a.S = S; a.ld = ld; a.rhs_row = rhs_row; a.grad = grad; a.hdiag = hdiag; a.perm = perm; a.grad_only = 0;
+  a.n_pair_blocks = pair_blocks; a.small = small ? *small : none; a.n_small_units = small_blocks;
+  t.push(a);
+}
+void launch_pairs_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n) {
+  if (n <= 0 || t.max_grid <= 0) return;
+  hipLaunchKernelGGL(pairs_kernel_batch, dim3(t.max_grid, n), dim3(64), kPairsLds, s, static_cast<const pairs_kernel_Args*>(t.dev), dyn, list);
+}
+int backsub_mcc_groups(const Visual& v);
+void batchargs_backsub_mcc(BatchArgTable& t, const Visual& v, int n_pose, const double* y_pose, double* delta, double* mcc_part, const SmallGroupSet* small,
+                           int n_small_units, const UpdateRide* upd) {
+  backsub_mcc_kernel_Args a;
+  const int g_lm = (v.n_lm * 8 + 255) / 256, grid = backsub_mcc_groups(v);
+  const int extra = small ? (n_small_units + 1) / 2 : 0;
+  const int upd_units = (upd && upd->n_blocks > 0) ? (upd->n_blocks + 255) / 256 : 0;
+  a.bsg_grid = grid > 0 ? grid + extra + upd_units : 0;
+  a.n_lm = v.n_lm; a.n_lm_groups = g_lm; a.n_elim = v.n_elim; a.n = v.n; a.lm_start = v.lm_start; a.J = v.J; a.JB = v.JB; a.r = v.r; a.CR = v.CR; a.cam_pose = v.cam_pose;
+  a.cp_tq = v.cp_tq; a.cp_tp = v.cp_tp; a.Linv = v.Linv; a.z = v.z; a.n_pose = n_pose; a.y_pose = y_pose; a.delta = delta; a.mcc_part = mcc_part; a.n_vis_blocks = grid;
+  a.small = small ? *small : SmallGroupSet(); a.n_small_units = small ? n_small_units : 0; a.up = upd_units ? *upd : UpdateRide(); a.first_update_block = grid + extra;
+  t.push(a);
+}
+void launch_backsub_mcc_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n) {
+  if (n <= 0 || t.max_grid <= 0) return;
+  hipLaunchKernelGGL(backsub_mcc_kernel_batch, dim3(t.max_grid, n), dim3(256), 0, s, static_cast<const backsub_mcc_kernel_Args*>(t.dev), dyn, list);
+}
 int backsub_mcc_groups(const Visual& v) { return (v.n_lm * 8 + 255) / 256 + (v.n - v.n_elim + 255) / 256; }
 void launch_backsub_mcc(hipStream_t s, const Visual& v, int n_pose, const double* y_pose, double* delta, double* mcc_part,
                         const SmallGroupSet* small, int n_small_units, const UpdateRide* upd) {

@@ -298,12 +298,36 @@ struct visual_imu_eval_kernel_Args {
   double* cost_part;
   int count_inactive;
 };
+// (the same entry as the kernel reads it: its pointers are GLOBAL pointers — read as generic ones every load through them would be a FLAT
+// instruction, which also counts against the LDS counter and serialises the kernels that overlap gathers with LDS traffic)
+struct visual_imu_eval_kernel_ArgsG {
+  int bsg_grid;
+  SmallGroup delta;
+  SmallGroup prior;
+  double __attribute__((address_space(1)))* part_delta;
+  double __attribute__((address_space(1)))* part_prior;
+  int n_imu_blocks;
+  int n;
+  const int4 __attribute__((address_space(1)))* fac;
+  const double2 __attribute__((address_space(1)))* pix;
+  const double __attribute__((address_space(1)))* wgt;
+  const double __attribute__((address_space(1)))* x;
+  const DevCamera __attribute__((address_space(1)))* cams;
+  const DevLoss __attribute__((address_space(1)))* losses;
+  double2 __attribute__((address_space(1)))* r_out;
+  double __attribute__((address_space(1)))* J_out;
+  double __attribute__((address_space(1)))* JB_out;
+  double __attribute__((address_space(1)))* cost_part;
+  int count_inactive;
+};
+static_assert(sizeof(visual_imu_eval_kernel_ArgsG) == sizeof(visual_imu_eval_kernel_Args), "layout");
+
 template <bool WITH_J>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void visual_imu_eval_kernel_batch(const visual_imu_eval_kernel_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
   const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
-  visual_imu_eval_kernel_Args a = bsg_A[bsg_w];
+  const visual_imu_eval_kernel_ArgsG& a = reinterpret_cast<const visual_imu_eval_kernel_ArgsG*>(bsg_A)[bsg_w];
   if ((int)blockIdx.x >= a.bsg_grid) return;
-  visual_imu_eval_kernel_body<WITH_J>((int)blockIdx.x, a.bsg_grid, a.delta, a.prior, a.part_delta, a.part_prior, a.n_imu_blocks, a.n, a.fac, a.pix, a.wgt, a.x, a.cams, a.losses, a.r_out, a.J_out, a.JB_out, a.cost_part, a.count_inactive);
+  visual_imu_eval_kernel_body<WITH_J>((int)blockIdx.x, a.bsg_grid, a.delta, a.prior, (double*)a.part_delta, (double*)a.part_prior, a.n_imu_blocks, a.n, (const int4*)a.fac, (const double2*)a.pix, (const double*)a.wgt, (const double*)a.x, (const DevCamera*)a.cams, (const DevLoss*)a.losses, (double2*)a.r_out, (double*)a.J_out, (double*)a.JB_out, (double*)a.cost_part, a.count_inactive);
 }
 void launch_visual_imu_eval(hipStream_t s, const Visual& v, const SmallGroup& delta, const SmallGroup& prior, const double* x, const DevCamera* cams,
                             const DevLoss* losses, bool with_J, double* cost_part_vis, double* part_delta, double* part_prior) {
@@ -314,6 +338,20 @@ void launch_visual_imu_eval(hipStream_t s, const Visual& v, const SmallGroup& de
   else
     hipLaunchKernelGGL(visual_imu_eval_kernel<false>, dim3(grid), dim3(256), 0, s, delta, prior, part_delta, part_prior, n_imu_blocks, v.n, v.fac, v.pix, v.w,
                        x, cams, losses, v.r, v.J, v.JB, cost_part_vis, 0);
+}
+void batchargs_visual_imu_eval(BatchArgTable& t, const Visual& v, const SmallGroup& delta, const SmallGroup& prior, const double* x, const DevCamera* cams,
+                               const DevLoss* losses, double* cost_part_vis, double* part_delta, double* part_prior) {
+  visual_imu_eval_kernel_Args a;
+  a.n_imu_blocks = (delta.n + prior.n + 3) / 4; a.bsg_grid = a.n_imu_blocks + (v.n + 255) / 256;
+  a.delta = delta; a.prior = prior; a.part_delta = part_delta; a.part_prior = part_prior; a.n = v.n; a.fac = v.fac; a.pix = v.pix; a.wgt = v.w;
+  a.x = x; a.cams = cams; a.losses = losses; a.r_out = v.r; a.J_out = v.J; a.JB_out = v.JB; a.cost_part = cost_part_vis; a.count_inactive = 0;
+  t.push(a);
+}
+void launch_visual_imu_eval_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n, bool with_J) {
+  if (n <= 0 || t.max_grid <= 0) return;
+  const auto* A = static_cast<const visual_imu_eval_kernel_Args*>(t.dev);
+  if (with_J) hipLaunchKernelGGL(visual_imu_eval_kernel_batch<true>, dim3(t.max_grid, n), dim3(256), 0, s, A, dyn, list);
+  else hipLaunchKernelGGL(visual_imu_eval_kernel_batch<false>, dim3(t.max_grid, n), dim3(256), 0, s, A, dyn, list);
 }
 void launch_imu_eval(hipStream_t s, const SmallGroup& delta, const SmallGroup& prior, const double* x, const DevLoss* losses, bool with_J,
                      double* part_delta, double* part_prior) {

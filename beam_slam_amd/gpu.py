@@ -100,6 +100,13 @@ class GpuSolver(capi.Solver):
                      float(max_dist), float(max_reproj), pts.ctypes.data, st.ctypes.data))
         return pts, st
 
+    @staticmethod
+    def batch_stats():
+        """(windows solved by the batched launches of bsgpu_solve_batch so far in this process, rounds = sets of launches they took)."""
+        w, r = ctypes.c_int64(0), ctypes.c_int64(0)
+        lib().bsgpu_batch_stats(ctypes.byref(w), ctypes.byref(r))
+        return w.value, r.value
+
     def time_reproj_jacobian_ms(self, reps=20):
         ms = lib().bsgpu_time_reproj_jacobian_ms(self._ctx, int(reps))
         if ms < 0:

@@ -344,14 +344,20 @@ int bsgpu_finalize(bsgpu_ctx* ctx);
 int bsgpu_solve(bsgpu_ctx* ctx, const bsgpu_options* options, bsgpu_summary* summary);
 /* Several windows at once — what the reference does with one thread per optimiser (local smoother, global mapper and the
  * submap refinements side by side: bs_models/src/global_mapping/submap_refinement.cpp:35-115): bsgpu_solve of n DISTINCT
- * contexts (any devices), each driven by a host thread of the library on the context's own stream, so that one window's
- * latency-bound factorisation runs underneath the throughput-bound kernels of the others.  `options` holds one entry
- * (shared) when options_stride == 0, else n entries; summaries: n entries.  Every solve runs to its end; returns
- * BSGPU_OK or the code of the first context (lowest index) that failed — its message is that context's bsgpu_last_error.
- * On one MI355X eight C2 windows reach 1.6x the rate of one (the kernels that fill the chip by themselves
- * bound it at 2.4x).                                                                                                     */
+ * contexts.  Windows with eliminated Euclidean landmarks on one device (visual / visual-inertial windows, the reference's
+ * local smoother and submap refinements) advance TOGETHER: every kernel of the LM step is launched once for all of them
+ * (blockIdx.y = window, per-window argument tables; csrc/bsgpu_batch.cpp), the trust-region decisions are taken per window
+ * on the host, converged windows drop out — each window's iterations are those of its lone bsgpu_solve.  Any other window
+ * (pose graphs, PCG, inverse-depth landmarks, dense priors, other devices) is driven by a host thread of the library on its
+ * context's own stream, in the same call — so is a window whose Jacobi-scaling flag or LM-diagonal bounds differ from the
+ * first batched window's.  `options` holds one entry (shared) when options_stride == 0, else n entries; summaries: n
+ * entries (device_time_in_seconds of a batched window = the batch's).  Every solve runs to its end; returns BSGPU_OK or the code
+ * of the first context (lowest index) that failed — its message is that context's bsgpu_last_error.                      */
 int bsgpu_solve_batch(bsgpu_ctx* const* ctxs, int32_t n, const bsgpu_options* options, int32_t options_stride,
                       bsgpu_summary* summaries);
+/* Process-wide counters of bsgpu_solve_batch (tests, measurements): windows solved by the batched launches so far, and the
+ * rounds (one set of launches each) they took.                                                                            */
+int bsgpu_batch_stats(int64_t* windows_batched, int64_t* rounds);
 
 /* Copies the current values back (device -> host), layout of bsgpu_set_blocks.  */
 int bsgpu_get_blocks(bsgpu_ctx* ctx, double* values, int64_t n_values);

@@ -303,6 +303,59 @@ def test_solve_batch_equals_lone_solves(gpu_solver_cls):
         gpu_solver_cls.solve_batch([mixed[0], mixed[0]], o_exact)
 
 
+def test_solve_batch_one_set_of_launches_equals_lone_solves(gpu_solver_cls):
+    """The windows bsgpu_solve_batch advances TOGETHER (csrc/bsgpu_batch.cpp: one launch per kernel of the LM step for all of them,
+    blockIdx.y = window) — visual-inertial windows of different sizes, with and without a robust loss, different iteration budgets so
+    that windows drop out at different rounds — against their lone solves: the same decisions, costs, radii and final values (every
+    window's tables and partial sums are laid out as in its lone solve), and the call really took the batched path.  A pose graph in
+    the same call is solved on its own thread."""
+    cases = [synthetic.vio_window(n_kf=20, n_lm=500, seed=11), synthetic.vio_window(n_kf=30, n_lm=2000, seed=12),
+             synthetic.vio_window(n_kf=12, n_lm=200, seed=5, cauchy_a=None), synthetic.vio_window(n_kf=60, n_lm=3000, seed=13),
+             synthetic.vio_window(n_kf=20, n_lm=500, seed=14), synthetic.pose_graph(n_pose=300, n_loop=400, seed=3),
+             synthetic.vio_window(n_kf=25, n_lm=800, seed=15)]
+    def fresh():
+        out = []
+        for pr in cases:
+            g = gpu_solver_cls(0); pr.load(g); out.append(g)
+        return out
+    alone = fresh()
+    opts = []
+    for i, g in enumerate(alone):
+        o = g.options_vio(); o.max_solver_time_in_seconds = 0.0; o.max_num_iterations = 3 + 2 * i
+        opts.append(o)
+    lone = [g.solve(o) for g, o in zip(alone, opts)]
+    w0, r0 = gpu_solver_cls.batch_stats()
+    batch = fresh()
+    sums = gpu_solver_cls.solve_batch(batch, opts)
+    w1, r1 = gpu_solver_cls.batch_stats()
+    assert w1 - w0 == 6 and r1 - r0 >= 4      # the six landmark windows went through the batched launches
+    for g0, s0, g1, s1 in zip(alone, lone, batch, sums):
+        assert s1.num_iterations == s0.num_iterations and s1.termination_type == s0.termination_type
+        assert s1.num_successful_steps == s0.num_successful_steps and s1.num_unsuccessful_steps == s0.num_unsuccessful_steps
+        assert s1.num_linear_solves == s0.num_linear_solves and s1.is_solution_usable == s0.is_solution_usable
+        i0, i1 = g0.iterations(), g1.iterations()
+        assert len(i0) == len(i1)
+        for a, b in zip(i0, i1):
+            assert a.step_is_successful == b.step_is_successful and a.step_is_valid == b.step_is_valid
+            assert abs(a.cost - b.cost) <= 1e-9 * abs(a.cost)
+            assert abs(a.trust_region_radius - b.trust_region_radius) <= 1e-6 * a.trust_region_radius
+            assert abs(a.gradient_max_norm - b.gradient_max_norm) <= 1e-6 * (a.gradient_max_norm + 1e-300)   # (sums of FP64 atomics, cancelling near the optimum: two lone runs differ as much)
+        assert abs(s1.final_cost - s0.final_cost) <= 1e-9 * abs(s0.final_cost)
+        assert np.abs(g1.get_blocks() - g0.get_blocks()).max() < 1e-8
+    # a second call on the same contexts from the same start (cached argument tables), and a lone solve after a batched one
+    for g in batch: g.reset_values()
+    again = gpu_solver_cls.solve_batch(batch, opts)
+    for s0, s1 in zip(lone, again):
+        assert s1.num_iterations == s0.num_iterations and abs(s1.final_cost - s0.final_cost) <= 1e-9 * abs(s0.final_cost)
+    batch[1].reset_values()
+    s_l = batch[1].solve(opts[1])
+    assert s_l.num_iterations == lone[1].num_iterations and abs(s_l.final_cost - lone[1].final_cost) <= 1e-9 * abs(lone[1].final_cost)
+    for g in batch: g.reset_values()
+    third = gpu_solver_cls.solve_batch(batch, opts)       # (the lone solve swapped that window's buffers: the tables are rebuilt)
+    for s0, s1 in zip(lone, third):
+        assert s1.num_iterations == s0.num_iterations and abs(s1.final_cost - s0.final_cost) <= 1e-9 * abs(s0.final_cost)
+
+
 def test_contexts_on_concurrent_host_threads(gpu_solver_cls):
     """One context per host thread, all on one device (the reference runs its local smoother, global mapper and submap
     refinement side by side, submap_refinement.cpp:35-115): create, load, finalize, solve, read back and destroy concurrently;
