@@ -291,8 +291,9 @@ class Solver:
         """Replaces the payload of the index-th dense prior in place (bsgpu_update_marginal): no re-finalize."""
         A = np.ascontiguousarray(A, np.float64); b = np.ascontiguousarray(b, np.float64); xbar = np.ascontiguousarray(xbar, np.float64)
         fn = self._f("update_marginal")
-        fn.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, _dp]
-        self._chk(fn(self._ctx, int(index), A.ctypes.data_as(_dp), b.ctypes.data_as(_dp), xbar.ctypes.data_as(_dp)))
+        assert A.ndim == 2 and b.size == A.shape[0]
+        fn.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp]
+        self._chk(fn(self._ctx, int(index), A.shape[0], A.shape[1], xbar.size, A.ctypes.data_as(_dp), b.ctypes.data_as(_dp), xbar.ctypes.data_as(_dp)))
 
     def covariance_joint(self, blocks, tangent_sizes):
         """Joint marginal covariance (D x D, D = sum of tangent sizes <= 64) of several pose-side blocks (bsgpu_covariance_joint)."""

@@ -244,7 +244,7 @@ int bsgpu_sync_factors_indirect(bsgpu_ctx* c, int32_t type, int32_t n, const int
   // the previous call's asynchronous copies read the mirror's host vectors (pageable memory), which are rewritten — and may be
   // re-allocated — below: they must have left (the stream is idle between two cycles, this costs a few microseconds)
   if (m.d_idx) { HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
-  static const bool force_full = getenv("BSGPU_SYNC_FULL") != nullptr, check = getenv("BSGPU_SYNC_CHECK") != nullptr;
+  const bool force_full = getenv("BSGPU_SYNC_FULL") != nullptr, check = getenv("BSGPU_SYNC_CHECK") != nullptr;   // (debug switches, read per call: a test sets them mid-process)
   const bool full = n_changed < 0 || !m.valid || force_full;
   auto row_ok = [&](size_t r) {
     const int32_t* row = slot_idx + 4 * r;
@@ -763,14 +763,21 @@ static int covariance_of(bsgpu_ctx* c, const std::vector<int>& blocks, double* o
   HIPCHK(c, hipMalloc((void**)&d_cols, sizeof(int) * cols.size()));
   if (hipMalloc((void**)&d_out, sizeof(double) * D * D) != hipSuccess) { (void)hipFree(d_cols); return fail(c, BSGPU_ERR_DEVICE, "out of device memory"); }
   (void)hipMemcpyAsync(d_cols, cols.data(), sizeof(int) * cols.size(), hipMemcpyHostToDevice, s);
-  launch_cov_units(s, c->d_S, c->npad, c->plan.rhs_row, d_cols, D);
-  DenseDev D0{c->d_nreal, c->d_rows_flat, c->d_panels, c->d_Lp, c->d_Vinv,
-              c->d_bs_desc, c->d_chain_begin, c->d_chain_end, c->d_tile_sync, c->d_ftasks, c->d_fsync};
-  D0.Winv = c->d_Winv; D0.tile_tot = c->d_tile_tot; D0.rhs_rows = D;
-  dense_factor(s, c->plan, D0, c->d_S, c->d_scal);
-  launch_cov_dots(s, c->d_Lp, c->npad, c->plan.rhs_row, c->plan.T * 64, D, 0, D, d_out);
-  (void)hipMemcpyAsync(out, d_out, sizeof(double) * D * D, hipMemcpyDeviceToHost, s);
-  rc = fetch_scalars(c);
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    launch_cov_units(s, c->d_S, c->npad, c->plan.rhs_row, d_cols, D);
+    DenseDev D0{c->d_nreal, c->d_rows_flat, c->d_panels, c->d_Lp, c->d_Vinv,
+                c->d_bs_desc, c->d_chain_begin, c->d_chain_end, c->d_tile_sync, c->d_ftasks, c->d_fsync};
+    D0.Winv = c->d_Winv; D0.tile_tot = c->d_tile_tot; D0.rhs_rows = D;
+    dense_factor(s, c->plan, D0, c->d_S, c->d_scal);
+    launch_cov_dots(s, c->d_Lp, c->npad, c->plan.rhs_row, c->plan.T * 64, D, 0, D, d_out);
+    (void)hipMemcpyAsync(out, d_out, sizeof(double) * D * D, hipMemcpyDeviceToHost, s);
+    rc = fetch_scalars(c);
+    if (rc != BSGPU_OK || !(c->h_scal[SC_CHOL_FAIL] == 2.0 && c->d_ftasks)) break;
+    // a wait inside the single-launch factorisation timed out (the device is shared — e.g. next to a bsgpu_solve_batch): not a numerical
+    // failure.  As solve() does: this context takes the launch-per-step path from here on, and the system is assembled and factored again.
+    c->d_ftasks = nullptr;
+    assemble(c, o, 1e300, true, true);
+  }
   (void)hipFree(d_cols); (void)hipFree(d_out);
   if (rc != BSGPU_OK) return rc;
   if (c->h_scal[SC_CHOL_FAIL] > 0.0 || !std::isfinite(out[0]))
@@ -798,10 +805,13 @@ int bsgpu_covariance_joint(bsgpu_ctx* c, int32_t n_blocks, const int32_t* blocks
 } catch (...) { return api_exception(c); }
 
 // The payload of the index-th dense linear prior, replaced in place: the finalized device structure stays (same blocks, rows, columns).
-int bsgpu_update_marginal(bsgpu_ctx* c, int32_t index, const double* A, const double* b, const double* xbar) try {
+int bsgpu_update_marginal(bsgpu_ctx* c, int32_t index, int32_t n_rows, int32_t n_cols, int32_t n_xbar, const double* A, const double* b,
+                          const double* xbar) try {
   if (!c) return BSGPU_ERR_INVALID;
   if (index < 0 || index >= (int)c->marginals.size() || !A || !b || !xbar) return fail(c, BSGPU_ERR_INVALID, "update_marginal: bad argument");
   HostMarginal& mg = c->marginals[index];
+  if (n_rows != mg.rows || (size_t)n_rows * (size_t)std::max(0, n_cols) != mg.A.size() || (size_t)n_rows != mg.b.size() || (size_t)n_xbar != mg.xbar.size())
+    return fail(c, BSGPU_ERR_INVALID, "update_marginal: the payload's shape is not that of the prior as it was added");
   std::memcpy(mg.A.data(), A, sizeof(double) * mg.A.size());
   std::memcpy(mg.b.data(), b, sizeof(double) * mg.b.size());
   std::memcpy(mg.xbar.data(), xbar, sizeof(double) * mg.xbar.size());

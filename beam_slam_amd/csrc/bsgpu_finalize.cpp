@@ -880,6 +880,7 @@ int finalize(bsgpu_ctx* c) {
       if (const char* ev = getenv("BSGPU_DIM_ORDER_STEP_US")) ord.t_step = atof(ev);
       if (const char* ev = getenv("BSGPU_DIM_ORDER_HOP_US")) ord.t_hop = atof(ev);
       if (const char* ev = getenv("BSGPU_DIM_ORDER_DEPTH")) ord.max_depth = std::max(0, atoi(ev));
+      if (const char* ev = getenv("BSGPU_DIM_ORDER_HUB")) ord.hub_frac = atof(ev);
       ord.build();
       // tile adjacency in S order from the block graph (a block lies in at most two tiles of its supernode)
       const int To = ord.T;

@@ -3,6 +3,8 @@
 // the device kernels: one host<->device round trip per LM iteration, hidden under the evaluation at the candidate.
 #include <atomic>
 
+#include <thread>
+
 #include "bsgpu_ctx.h"
 
 namespace bsg {
@@ -527,9 +529,19 @@ int fetch_scalars(bsgpu_ctx* c) {
     const volatile double* stamp = &c->h_scal[SC_SEQ];
     const auto t0 = std::chrono::steady_clock::now();
     long spins = 0;
+    // (a short spin — a step is tens to hundreds of microseconds — then the core is yielded between looks: n windows of a
+    // bsgpu_solve_batch would otherwise burn n cores; a large plan's step — seconds for a dense 30 000-dimensional factorisation — ends
+    // in a stream synchronisation once the budget, which grows with the plan, is used up)
+    const double budget_s = 2.0 + 2e-6 * (double)c->plan.ftasks.size();
     while (__atomic_load_n(reinterpret_cast<const volatile uint64_t*>(stamp), __ATOMIC_ACQUIRE) != *reinterpret_cast<const uint64_t*>(&c->reduce_seq)) {
+#if defined(__x86_64__) || defined(__i386__)
       __builtin_ia32_pause();
-      if ((++spins & 0xfff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) {
+#elif defined(__aarch64__)
+      asm volatile("yield" ::: "memory");
+#endif
+      ++spins;
+      if (spins > 20000 && (spins & 0x3f) == 0) std::this_thread::yield();
+      if ((spins & 0xfff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > budget_s) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (*stamp != c->reduce_seq) return fail(c, BSGPU_ERR_DEVICE, "the end-of-step reduction did not report (device fault?)");
         break;
@@ -628,6 +640,10 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
         // here on, and the step is computed again at the same point and radius.
         c->d_ftasks = nullptr;
         if (getenv("BSGPU_TIMING")) fprintf(stderr, "[bsgpu] single-launch Cholesky timed out: launch-per-step path from here on\n");
+        if (c->use_graphs) { c->destroy_graphs(); build_graphs(c, o); }   // (the captured sequences still hold the single-launch kernel)
+        // the record of this iteration was pushed above and is pushed again when the loop comes back with the recomputed step
+        c->iters.pop_back();
+        if (it.step_is_successful) { if (it.iteration > 0) sum.num_successful_steps--; } else sum.num_unsuccessful_steps--;
         run_step(c, o, STEP_REJECT, radius);
         rc = fetch_scalars(c);
         if (rc != BSGPU_OK) return rc;

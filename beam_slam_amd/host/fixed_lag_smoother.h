@@ -147,15 +147,12 @@ class FixedLagSmoother {
     fuse_core::Transaction new_transaction;
     processQueue(new_transaction, lag_expiration_);                          // :194
     if (new_transaction.empty()) return CycleResult::NothingToDo;            // :197
-    // :199-216 drop added constraints that touch variables the previous cycle marginalised
+    // :199-216 drop added constraints that touch variables the previous cycle marginalised.  Only CONSTRAINTS are filtered (the
+    // reference calls new_transaction->removeConstraint on them); a variable the transaction adds again stays added.
     fuse_core::Transaction filtered;
     filtered.stamp(new_transaction.stamp());
     for (const auto& s : new_transaction.involvedStamps()) filtered.addInvolvedStamp(s);
-    for (const auto& v : new_transaction.addedVariables()) {
-      bool gone = false;
-      for (const auto& m : marginal_transaction_.removedVariables()) if (m == v->uuid()) gone = true;
-      if (!gone) filtered.addVariable(v);
-    }
+    for (const auto& v : new_transaction.addedVariables()) filtered.addVariable(v);
     for (const auto& c : new_transaction.addedConstraints()) {
       bool faulty = false;
       for (const auto& vu : c->variables())
@@ -198,6 +195,7 @@ class FixedLagSmoother {
     timestamp_tracking_.addMarginalTransaction(marginal_transaction_);
     // :281 — the hot call
     summary_ = graph_->optimize(params_.solver_options);
+    have_summary_ = true;
     ++num_cycles_;
     if (!summary_.IsSolutionUsable()) return CycleResult::UnusableSolution;   // :286-295
     // :305-308 notify(new_transaction, graph_->clone()): the publishers / sensor models get the transaction and a snapshot
@@ -213,6 +211,41 @@ class FixedLagSmoother {
   const GpuGraph& graph() const { return *graph_; }
   GpuGraph& graph() { return *graph_; }
   fuse_core::Time lagExpiration() const { return lag_expiration_; }
+  // setDiagnostics (:676-740) without ROS: the same fields under the same names, the level and message of
+  // terminationTypeToDiagnosticStatus (:647-669).  Level: 0 OK, 1 WARN, 2 ERROR (diagnostic_msgs::DiagnosticStatus).
+  struct Diagnostics {
+    int level = 0;
+    std::string message;
+    std::vector<std::pair<std::string, std::string>> values;
+    const std::string* find(const std::string& key) const { for (const auto& kv : values) if (kv.first == key) return &kv.second; return nullptr; }
+  };
+  Diagnostics diagnostics() const {
+    Diagnostics d;
+    const bool started = started_;
+    d.values.emplace_back("Started", started ? "True" : "False");
+    d.values.emplace_back("Pending Transactions", std::to_string(pendingTransactions()));
+    if (!started) return d;
+    ceres_compat::SolverSummary summary;
+    bool have = false;
+    {
+      std::unique_lock<std::mutex> lock(optimization_mutex_, std::try_to_lock);   // (:697-705: a running optimisation is reported, not waited for)
+      if (lock) { summary = summary_; have = have_summary_; }
+      else d.message = "Optimization running";
+    }
+    if (have) {   // (the reference tests total_time_in_seconds >= 0: -1 in a default-constructed ceres summary)
+      const char* tt = summary.termination_type == ceres_compat::CONVERGENCE ? "CONVERGENCE" : summary.termination_type == ceres_compat::NO_CONVERGENCE ? "NO_CONVERGENCE" : "FAILURE";
+      d.values.emplace_back("Optimization Termination Type", tt);
+      d.values.emplace_back("Optimization Total Time [s]", std::to_string(summary.total_time_in_seconds));
+      d.values.emplace_back("Optimization Iterations", std::to_string(summary.iterations.size()));
+      d.values.emplace_back("Initial Cost", std::to_string(summary.initial_cost));
+      d.values.emplace_back("Final Cost", std::to_string(summary.final_cost));
+      int level = 2; const char* msg = "Optimization failed";
+      if (summary.termination_type == ceres_compat::CONVERGENCE) { level = 0; msg = "Optimization converged"; }
+      else if (summary.termination_type == ceres_compat::NO_CONVERGENCE) { level = 1; msg = "Optimization didn't converge"; }
+      if (level > d.level || d.message.empty()) { d.level = std::max(d.level, level); d.message = msg; }   // mergeSummary: the worse level wins
+    }
+    return d;
+  }
   int numCycles() const { return num_cycles_; }
   int numDroppedConstraints() const { return num_dropped_constraints_; }
   const std::string& lastError() const { return last_error_; }
@@ -323,7 +356,7 @@ class FixedLagSmoother {
   int num_expired_transactions_ = 0, num_timed_out_transactions_ = 0, num_queue_errors_ = 0;
   FixedLagSmootherParams params_;
   mutable std::mutex pending_transactions_mutex_;
-  std::mutex optimization_mutex_;
+  mutable std::mutex optimization_mutex_;
   std::deque<Pending> pending_;
   VariableStampIndex timestamp_tracking_;
   fuse_core::Transaction marginal_transaction_;
@@ -331,6 +364,7 @@ class FixedLagSmoother {
   mutable std::mutex start_time_mutex_;
   std::atomic<bool> started_{false};   // (set by sensor threads in transactionCallback, read by the optimisation thread: the reference's std::atomic<bool>)
   ceres_compat::SolverSummary summary_;
+  bool have_summary_ = false;   // (an optimisation has run: the diagnostics report its summary)
   int num_cycles_ = 0, num_dropped_constraints_ = 0;
   std::string last_error_;
 };

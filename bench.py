@@ -102,6 +102,35 @@ def short_leg(which, device):
     return leg
 
 
+def batch_leg(n_win, n_kf, n_lm, device, steps, seed0, label):
+    """n_win independent windows on ONE device through bsgpu_solve_batch (one set of launches per LM iteration for all of them,
+    csrc/bsgpu_batch.cpp): BASELINE config 5's workload folded onto a single GPU, or the reference's own window sizes (vio.yaml:3,56)."""
+    from beam_slam_amd import synthetic
+    from beam_slam_amd.gpu import GpuSolver
+    gs = []
+    for w in range(n_win):
+        pr = synthetic.vio_window(n_kf=n_kf, n_lm=n_lm, seed=seed0 + w)
+        g = GpuSolver(device); pr.load(g); g.finalize(); gs.append(g)
+    opt = gs[0].options_vio()
+    opt.max_solver_time_in_seconds = 0.0
+    for _ in range(2):
+        for g in gs: g.reset_values()
+        GpuSolver.solve_batch(gs, opt)
+    w0, r0 = GpuSolver.batch_stats()
+    t0 = time.perf_counter()
+    n_it = 0
+    for _ in range(steps):
+        for g in gs: g.reset_values()
+        n_it += sum(s.num_linear_solves for s in GpuSolver.solve_batch(gs, opt))
+    dt = time.perf_counter() - t0
+    w1, r1 = GpuSolver.batch_stats()
+    leg = {"workload": label, "windows": n_win, "value": round(n_it / dt, 1), "unit": "LM iterations/s (aggregate)", "steps": steps,
+           "ms_per_step": round(1e3 * dt / steps, 3), "lm_iterations_per_window_and_solve": round(n_it / steps / n_win, 2),
+           "windows_on_the_batched_launches": (w1 - w0) // max(1, steps), "us_per_round_of_launches": round(1e6 * dt / max(1, r1 - r0), 1)}
+    for g in gs: g.close()
+    return leg
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -367,6 +396,12 @@ def main():
         if default_c2 and args.other_configs:
             g.close()
             out["other_configs"] = {"c3": short_leg("c3", local_rank), "c4": short_leg("c4", local_rank)}
+            # several windows per GPU (what an N-GPU run multiplies): 8 C2-shaped windows — config 5 folded onto one device — and 32 windows of
+            # the reference's own size, each call one bsgpu_solve_batch
+            out["other_configs"]["c5_on_one_gpu"] = batch_leg(8, args.n_kf, args.n_lm, local_rank, 5, sharding.window_seed(20250620, 0),
+                                                              "8 independent C2 windows (BASELINE config 5) on ONE GPU, one bsgpu_solve_batch per step")
+            out["other_configs"]["reference_sized_windows"] = batch_leg(32, 20, 500, local_rank, 20, 20250700,
+                                                                        "32 independent windows of 20 key frames x 500 landmarks (the reference's own window size), one bsgpu_solve_batch per step")
         # ---- CPU baseline: the oracle on the same window (bounded samples, same options): with every usable core, and with the six
         # threads the reference's own configuration gives Ceres (beam_slam_launch/config/vio.yaml:11 num_threads: 6)
         if world == 1 and not args.no_cpu_baseline and args.workload != "c4" and not args.consensus:   # (C4 at full size: the oracle's dense solve does not finish in bench time)

@@ -329,8 +329,10 @@ int bsgpu_add_marginal(bsgpu_ctx* ctx, int32_t n_blocks, const int32_t* blocks, 
 /* Replaces A, b and xbar of the index-th prior added with bsgpu_add_marginal (same blocks, same n_rows) IN PLACE: nothing is
  * re-flattened, the device tables of a finalized problem stay.  For priors whose contents change from one solve to the next
  * while the graph does not: [EXT] fuse_core::Graph::removeConstraint + addConstraint of a MarginalConstraint on the same
- * variables.                                                                                                                   */
-int bsgpu_update_marginal(bsgpu_ctx* ctx, int32_t index, const double* A, const double* b, const double* xbar);
+ * variables.  n_rows x n_cols = the shape of A (b: n_rows), n_xbar = the ambient size of xbar: they must be those of the prior
+ * as it was added (BSGPU_ERR_INVALID otherwise — a payload of another shape would be read out of bounds).                     */
+int bsgpu_update_marginal(bsgpu_ctx* ctx, int32_t index, int32_t n_rows, int32_t n_cols, int32_t n_xbar, const double* A, const double* b,
+                          const double* xbar);
 
 /* ---- solve ----------------------------------------------------------------- */
 /* Uploads / builds the device-side structure (sorted factor tables, the tile plan of the

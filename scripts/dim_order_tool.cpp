@@ -22,6 +22,7 @@ int main(int argc, char** argv) {
   if (getenv("T_STEP")) o.t_step = atof(getenv("T_STEP"));
   if (getenv("T_HOP")) o.t_hop = atof(getenv("T_HOP"));
   if (getenv("DEPTH")) o.max_depth = atoi(getenv("DEPTH"));
+  if (getenv("HUB")) o.hub_frac = atof(getenv("HUB"));
   o.build();
   printf("n_pose %d blocks %d: T %d nodes %d depth %d est %.1f us\n", o.n_pose, nbk, o.T, o.n_nodes, o.depth, o.est_path_us);
   for (size_t i = 0; i < o.nodes.size(); ++i) {

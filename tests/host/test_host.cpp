@@ -283,6 +283,12 @@ static void test_fixed_lag_smoother_window(bool pseudo_marginalization) {
   params.solver_options = ceres_compat::SolverOptions();
   params.solver_options.max_num_iterations = 20;
   bs_optimizers::FixedLagSmoother smoother(bs_optimizers::GpuGraph::make_unique(), params);
+  {   // setDiagnostics (fixed_lag_smoother.cpp:676-740) before anything has arrived: "Started" false, an empty queue, no summary fields
+    const auto d0 = smoother.diagnostics();
+    CHECK(d0.find("Started") && *d0.find("Started") == "False");
+    CHECK(d0.find("Pending Transactions") && *d0.find("Pending Transactions") == "0");
+    CHECK(d0.find("Final Cost") == nullptr);
+  }
   // notify(transaction, graph->clone()) (fixed_lag_smoother.cpp:308): a publisher keeps every snapshot it was handed
   struct Seen { std::shared_ptr<const bs_optimizers::GpuGraph> graph; size_t n_var, n_con, n_added; };
   std::vector<Seen> seen;
@@ -356,6 +362,18 @@ static void test_fixed_lag_smoother_window(bool pseudo_marginalization) {
   }
   CHECK(seen.front().graph->numVariables() < seen.back().graph->numVariables());
   CHECK(smoother.optimizeOnce() == bs_optimizers::FixedLagSmoother::CycleResult::NothingToDo);
+  {   // the diagnostics after the last cycle: the fields and the level / message the reference derives from the termination type
+    const auto d = smoother.diagnostics();
+    CHECK(d.find("Started") && *d.find("Started") == "True");
+    CHECK(d.find("Pending Transactions") && *d.find("Pending Transactions") == "0");
+    CHECK(d.find("Optimization Termination Type") != nullptr && d.find("Optimization Total Time [s]") != nullptr);
+    CHECK(d.find("Optimization Iterations") && std::stoul(*d.find("Optimization Iterations")) == smoother.summary().iterations.size());
+    CHECK(d.find("Initial Cost") != nullptr && d.find("Final Cost") != nullptr);
+    CHECK_NEAR(std::stod(*d.find("Final Cost")), smoother.summary().final_cost, 1e-5 * (1.0 + smoother.summary().final_cost));
+    const bool conv = smoother.summary().termination_type == ceres_compat::CONVERGENCE;
+    CHECK(d.level == (conv ? 0 : 1));
+    CHECK(d.message == (conv ? "Optimization converged" : "Optimization didn't converge"));
+  }
   // the window is bounded: stamped states older than the lag are gone, and a MARGINALIZATION prior exists
   int n_pos = 0, n_marg = 0;
   fuse_core::Time oldest(1e9);
