@@ -1023,9 +1023,8 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
   for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) if (A[(size_t)i * n + j] != 0.0) adj[(size_t)(i / 64) * T + j / 64] = 1;
   DensePlan P;
   {
-    const char* e2 = getenv("BSGPU_MIN_PIECE");
     const char* e3 = getenv("BSGPU_SHARED");
-    P.build(n, adj, std::max(1, (int)max_chains), e2 ? std::max(1, atoi(e2)) : 1, !(e3 && atoi(e3) == 0));
+    P.build(n, adj, std::max(1, (int)max_chains), 1, !(e3 && atoi(e3) == 0));
   }
   const int npad = P.npad;
   std::vector<double> hS((size_t)npad * npad, 0.0);

@@ -163,7 +163,7 @@ int finalize(bsgpu_ctx* c) {
     const char* ed = getenv("BSGPU_DIM_ORDER");
     int nbk = 0;
     for (int b = 0; b < nb; ++b) if (c->toff[b] >= 0 && c->toff[b] < c->n_pose) ++nbk;
-    if (c->dense_ok && c->n_leaf_tiles == 0 && nbk > 0 && nbk <= 8192 && !(ed && atoi(ed) == 0)) {
+    if (c->dense_ok && c->n_leaf_tiles == 0 && nbk > 0 && nbk <= 16384 && !(ed && atoi(ed) == 0)) {
       bg.nbk = nbk; bg.words = (nbk + 63) / 64;
       bg.bid_of_t.assign(c->n_pose, -1);
       bg.t0.reserve(nbk); bg.w.reserve(nbk);
@@ -860,7 +860,6 @@ int finalize(bsgpu_ctx* c) {
       const int T0 = (c->n_pose + 63) / 64;
       if (c->tile_adj.size() != (size_t)T0 * T0) c->tile_adj.assign((size_t)T0 * T0, 0);
     }
-    const char* e2 = getenv("BSGPU_MIN_PIECE");
     const char* e3 = getenv("BSGPU_SHARED");   // panels of one step may update the same tiles (atomics): on unless BSGPU_SHARED=0
     const bool use_leaf = c->n_leaf_tiles > 0 && !getenv("BSGPU_NO_LEAF_TILES");
     bool ordered = false;
@@ -877,10 +876,7 @@ int finalize(bsgpu_ctx* c) {
         }
         ord.adj_ptr[a + 1] = (int)ord.adj.size();
       }
-      if (const char* ev = getenv("BSGPU_DIM_ORDER_STEP_US")) ord.t_step = atof(ev);
-      if (const char* ev = getenv("BSGPU_DIM_ORDER_HOP_US")) ord.t_hop = atof(ev);
       if (const char* ev = getenv("BSGPU_DIM_ORDER_DEPTH")) ord.max_depth = std::max(0, atoi(ev));
-      if (const char* ev = getenv("BSGPU_DIM_ORDER_HUB")) ord.hub_frac = atof(ev);
       ord.build();
       // tile adjacency in S order from the block graph (a block lies in at most two tiles of its supernode)
       const int To = ord.T;
@@ -898,7 +894,7 @@ int finalize(bsgpu_ctx* c) {
       if (timing) fprintf(stderr, "[bsgpu finalize] per-dimension order: %d blocks, %d supernodes, depth %d, estimated path %.0f us\n", bg.nbk, ord.n_nodes, ord.depth, ord.est_path_us);
     }
     if (!ordered)
-      c->plan.build(c->n_pose, c->tile_adj, c->dense_ok ? max_chains : 1, e2 ? std::max(1, atoi(e2)) : 1, !(e3 && atoi(e3) == 0), use_leaf ? &c->leaf_tile : nullptr);
+      c->plan.build(c->n_pose, c->tile_adj, c->dense_ok ? max_chains : 1, 1, !(e3 && atoi(e3) == 0), use_leaf ? &c->leaf_tile : nullptr);
     c->npad = c->plan.npad;
     const int T = c->plan.T;
     if (timing) fprintf(stderr, "[bsgpu finalize] Cholesky plan: %d tiles (%d leaf), %d pieces, %d panel steps, %d back-substitution launches\n", c->plan.T,

@@ -149,7 +149,6 @@ struct DensePlan {
         w = dist[std::min(dist.size() - 1, (size_t)(0.95 * (double)dist.size()))];
       }
     }
-    if (const char* ew = getenv("BSGPU_BAND_W")) w = std::max(1, atoi(ew));   // (experiments: separator width in tiles)
     std::vector<int> order;  // S order: list of natural tiles
     std::vector<std::pair<int, int>> piece_ranges;                    // S tile ranges of the pieces
     std::vector<std::vector<std::pair<int, int>>> sep_ranges_by_level;  // S tile ranges of the separators, per level
@@ -456,7 +455,7 @@ struct DensePlan {
           for (int p : preds[t]) lfin[p] = std::min(lfin[p], ls);
           if (turn_pred[t] >= 0) lfin[turn_pred[t]] = std::min(lfin[turn_pred[t]], lfin[t] - t_turn);
         }
-        static const double beta = [] { const char* e = getenv("BSGPU_TICKET_BETA"); const double v = e ? atof(e) : 0.5; return v < 0.0 ? 0.0 : v > 1.0 ? 1.0 : v; }();
+        const double beta = 0.5;   // (0 .. 1 measured on C2: 168.9 .. 166.5 us per factorisation — the order matters little once the model's durations are right)
         std::vector<int> ord(nt);
         for (int t = 0; t < nt; ++t) ord[t] = t;
         std::vector<double> key(nt);
@@ -473,7 +472,7 @@ struct DensePlan {
         for (FusedTask& f : nl) if (!(f.flags & kFusedChain) && f.need_c >= 0) f.need_c = seen[(size_t)f.ti * N + f.tj]++;
         ftasks.swap(nl);
       }
-      static const bool fetch_x = !(getenv("BSGPU_CHOL_SOLVE_OWN") && atoi(getenv("BSGPU_CHOL_SOLVE_OWN")) != 0);
+      const bool fetch_x = true;   // (off-diagonal tasks read the X their diagonal tasks publish: one solve per (panel, row tile) instead of one per task)
       for (FusedTask& f : ftasks) {
         if (f.flags & kFusedChain) continue;
         f.tot_i = tile_tot[(size_t)f.ti * N + f.k];

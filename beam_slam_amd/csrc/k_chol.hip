@@ -935,10 +935,10 @@ __global__ __launch_bounds__(kFusedThreads) void chol_fused_kernel_batch(const c
   if ((int)blockIdx.y >= a.bsg_grid) return;   // (windows interleaved in dispatch order: x = window, y = the window's workgroup — the workgroups of ALL windows take their tickets side by side)
   chol_fused_kernel_body<PROBE>((int)blockIdx.y, a.bsg_grid, (double*)a.S, (double*)a.Lp, a.ld, (const FusedTask*)a.tasks, a.n_tasks, (const int*)a.tile_tot, (const int*)a.nreal, (double*)a.Vinv, (double*)a.scal, (int*)a.sync, (double*)a.Winv, a.fs, a.rhs_strips, (long long*)a.probe_ts);
 }
-// ints between two words of the sync area: 16 = a 64-byte line each (BSGPU_FLAG_STRIDE=1: packed, the first layout)
+// ints between two words of the sync area: 16 = a 64-byte line each (packed words of one line that different workgroups write are
+// serialised at the memory side: 270 -> 237 us per C2 factorisation when they were moved apart, round 2)
 int fused_sync_stride() {
-  static const int v = [] { const char* e = getenv("BSGPU_FLAG_STRIDE"); const int x = e ? atoi(e) : 16; return (x >= 1 && x <= 16) ? x : 16; }();
-  return v;
+  return 16;
 }
 
 void launch_chol_fused(hipStream_t s, double* S, double* Lp, int ld, const FusedTask* tasks_dev, int n_tasks, const int* tile_tot_dev, const int* nreal_dev,
@@ -1536,8 +1536,7 @@ void launch_chol_backsolve_chains(hipStream_t s, const double* S, const double* 
   const int y_in_lds = (lds <= (size_t)160 * 1024 && !(fg && atoi(fg) != 0)) ? 1 : 0;
   if (!y_in_lds) lds = chol_backsolve_chain_lds(0, max_chain_len);
   // max_rows: the most row tiles any panel of these chains has (0: unknown).  Few enough: the two-panel-deep variant.
-  static const bool no_deep = getenv("BSGPU_BACKSOLVE_NO_DEEP") != nullptr;
-  const bool deep = max_rows > 0 && max_rows <= kBsChunkDeep && max_chain_len > 1 && !no_deep;
+  const bool deep = max_rows > 0 && max_rows <= kBsChunkDeep && max_chain_len > 1;
 #define BSG_LAUNCH_CHAIN_W(YL, CH, DEEP, W)                                                                                                \
   hipLaunchKernelGGL((chol_backsolve_chain_kernel<YL, CH, DEEP, W>), dim3(n_chains), dim3(1024), lds, s, S, Lp, W ? Winv : Vinv, ld, bs_desc_dev, \
                      chain_begin_dev, chain_end_dev, rows_flat_dev, y, npad, max_chain_len, n_chains == 1 ? y_init : nullptr, iperm_dev, \

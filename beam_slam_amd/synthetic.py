@@ -569,6 +569,55 @@ def pose_graph(n_pose=5000, n_loop=45001, seed=20250622):
     return pr
 
 
+def pose_graph_local(n_pose=5000, n_loop=45001, row_len=25, seed=20250623):
+    """A pose graph whose loop closures are SPATIALLY LOCAL, as a mapper's are (a place is re-observed from the poses that pass near
+    it: bs_models/src/lib/global_mapping/submap_pose_graph_optimization.cpp:96-141 matches a submap against its spatial neighbours):
+    a boustrophedon sweep of rows of `row_len` poses, odometry along the path, every loop closure between a pose and one within two
+    rows and two columns of it.  C4's sizes and weights; what differs from `pose_graph` is only WHICH pairs the loops join — there
+    uniformly random pairs (the reduced system fills in completely), here pairs at most ~4 rows apart in time (a band)."""
+    rng = np.random.default_rng(seed)
+    k = np.arange(n_pose)
+    row, col = k // row_len, k % row_len
+    col = np.where(row % 2 == 0, col, row_len - 1 - col)
+    yaw = np.where(row % 2 == 0, 0.0, np.pi) + 0.05 * np.sin(0.3 * k)
+    p_true = np.stack([1.0 * col, 1.0 * row, 0.1 * np.sin(0.05 * k)], axis=1)
+    R_true = np.stack([so3_exp(np.array([0.02 * np.sin(0.1 * t), 0.02 * np.cos(0.07 * t), y])) for t, y in zip(k, yaw)])
+    pr = Problem()
+    blocks = np.empty((n_pose, 2), np.int32)
+    for t in range(n_pose):
+        blocks[t, 0] = pr.add_block(p_true[t] + rng.normal(0, 0.05, 3))
+        blocks[t, 1] = pr.add_quat(_perturb_quat(rot_to_quat(R_true[t]), rng, 0.02))
+    A_odom = sqrt_information_upper(1e-3 * np.eye(6))
+    A_loop = sqrt_information_upper(1e-5 * np.eye(6))
+    li = rng.integers(0, n_pose, n_loop)
+    drow, dcol = rng.integers(-2, 3, n_loop), rng.integers(-2, 3, n_loop)
+    r2 = np.clip(row[li] + drow, 0, (n_pose - 1) // row_len)
+    c2_ = np.clip(col[li] + dcol, 0, row_len - 1)
+    lj = r2 * row_len + np.where(r2 % 2 == 0, c2_, row_len - 1 - c2_)
+    lj = np.clip(lj, 0, n_pose - 1)
+    same = li == lj
+    lj[same] = (lj[same] + 1) % n_pose
+    i = np.concatenate([np.arange(n_pose - 1), li])
+    j = np.concatenate([np.arange(1, n_pose), lj])
+    n = i.size
+    consts = np.empty((n, 43))
+    for t in range(n):
+        odom = t < n_pose - 1
+        sg = np.sqrt(1e-3) if odom else np.sqrt(1e-5)
+        dR = R_true[i[t]].T @ R_true[j[t]] @ so3_exp(rng.normal(0, sg, 3))
+        dp = R_true[i[t]].T @ (p_true[j[t]] - p_true[i[t]]) + rng.normal(0, sg, 3)
+        consts[t, 0:3] = dp
+        consts[t, 3:7] = rot_to_quat(dR)
+        consts[t, 7:] = (A_odom if odom else A_loop).ravel()
+    idx = np.stack([blocks[i, 0], blocks[i, 1], blocks[j, 0], blocks[j, 1]], axis=1)
+    pr.add_factors(capi.F_RELPOSE, idx, consts, capi.LOSS_CAUCHY, 1.0)
+    A0 = sqrt_information_upper(1e-9 * np.eye(6))
+    b = np.concatenate([pr.block(int(blocks[0, 0])), pr.block(int(blocks[0, 1]))])
+    pr.add_factors(capi.F_ABSPOSE, blocks[0][None, :], np.concatenate([b, A0.ravel()])[None, :])
+    pr.meta = dict(kind="pose_graph_local", n_pose=n_pose, n_rel=int(n), seed=seed, blocks=blocks, R_true=R_true, p_true=p_true, row_len=row_len)
+    return pr
+
+
 def c4(seed=20250622):
     return pose_graph(5000, 45001, seed)
 

@@ -48,18 +48,16 @@ SETTINGS = [
     {"BSGPU_CHOL_FUSED": "0"},                                   # launch-per-step factorisation (the fused kernel's fall-back)
     {"BSGPU_BACKSOLVE_LEGACY": "1"},
     {"BSGPU_BACKSOLVE_FUSED": "0"},
-    {"BSGPU_BACKSOLVE_NO_DEEP": "1"},
     {"BSGPU_BACKSOLVE_NO_W": "1"},
     {"BSGPU_BACKSOLVE_FUSED": "0", "BSGPU_BACKSOLVE_NO_W": "1"},
     {"BSGPU_BACKSOLVE_GLOBAL_Y": "1"},                           # solution vector in global memory (windows above 12 288 dimensions)
     {"BSGPU_CHOL_FUSED": "0", "BSGPU_BACKSOLVE_LEGACY": "1"},
     {"BSGPU_CHAINS": "1"},
-    {"BSGPU_MIN_PIECE": "3"},
+    {"BSGPU_DIM_ORDER": "0"},                                    # the tile-level nested dissection (runs of natural tiles) instead of the per-dimension order
+    {"BSGPU_DIM_ORDER": "0", "BSGPU_CHAINS": "4"},
+    {"BSGPU_DIM_ORDER_DEPTH": "2"},                              # a shallower dissection: fewer, larger pieces
+    {"BSGPU_DIM_ORDER_DEPTH": "0"},                              # one supernode: natural order, the whole system one sequence of chains
     {"BSGPU_SHARED": "0"},
-    {"BSGPU_BAND_W": "2"},
-    {"BSGPU_BAND_W": "4"},
-    {"BSGPU_CHOL_SOLVE_OWN": "1"},
-    {"BSGPU_FLAG_STRIDE": "1"},
     {"BSGPU_GRAPH": "1"},                                        # the LM step replayed as hipGraphs
     {"BSGPU_FLATTEN": "device"},
     {"BSGPU_FLATTEN": "host"},
