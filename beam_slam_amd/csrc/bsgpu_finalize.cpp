@@ -143,8 +143,16 @@ int finalize(bsgpu_ctx* c) {
   }
   // (pose-only graphs above kDenseLimit go to the block-sparse PCG unless the exact factorisation is asked for — BSGPU_EXACT_POSE_GRAPH=1 at
   // finalize(): the dense tile storage, 2 x npad^2 doubles, is not allocated on spec; C4 that way: DESIGN.md 3.3)
-  const bool exact_pose_graph = getenv("BSGPU_EXACT_POSE_GRAPH") != nullptr;
+  const bool exact_pose_graph = getenv("BSGPU_EXACT_POSE_GRAPH") != nullptr && atoi(getenv("BSGPU_EXACT_POSE_GRAPH")) != 0;   // (forced: whatever the plan costs)
   c->dense_ok = (size_t)c->npad <= kDenseLimit || ((nl + n_rho > 0 || c->n_leaf_tiles > 0 || exact_pose_graph) && (size_t)c->npad <= kDenseLimitLandmarks);   // else: block-sparse PCG (pose-only problems)
+  // A pose graph above kDenseLimit whose loop closures are LOCAL (a mapper's: poses near each other) dissects into many small supernodes,
+  // and its exact step — the reference's own call, SPARSE_NORMAL_CHOLESKY, submap_pose_graph_optimization.cpp:144-146 — is then cheaper
+  // than the PCG's (synthetic.pose_graph_local: 2.9 against 5.3 ms per LM iteration).  Whether that is so is only known once the order
+  // has been found: the window is taken as dense provisionally, and goes back to the PCG below if the plan says otherwise.
+  // BSGPU_EXACT_POSE_GRAPH=0 keeps every such graph on the PCG.
+  const bool dense_on_trial = !c->dense_ok && nl + n_rho == 0 && (size_t)c->npad <= kDenseLimitLandmarks && c->marginals.empty() &&
+                              !(getenv("BSGPU_EXACT_POSE_GRAPH") && atoi(getenv("BSGPU_EXACT_POSE_GRAPH")) == 0);
+  if (dense_on_trial) c->dense_ok = true;
   // The graph of the reduced system's tangent BLOCKS (which pairs of pose-side blocks some factor, some shared landmark or a dense prior
   // couples): what the per-dimension ordering of the factorisation is found on (dim_order.h).  A bit matrix; every place below that marks
   // the natural-tile adjacency marks it too.  Not kept for windows that take the tile-level order (leaf tiles of BSGPU_IDP_ELIM=0,
@@ -889,10 +897,24 @@ int finalize(bsgpu_ctx* c) {
         mark(a, a);
         for (int e4 = ord.adj_ptr[a]; e4 < ord.adj_ptr[a + 1]; ++e4) if (ord.adj[e4] < a) mark(a, ord.adj[e4]);
       }
-      c->plan.build_ordered(c->n_pose, To, ord.dpos, ord.nreal, adjS, ord.piece_ranges, ord.sep_ranges_by_level, !(e3 && atoi(e3) == 0));
-      ordered = true;
+      bool keep = true;
+      if (dense_on_trial && ord.depth == 0) keep = false;   // no separator found (C4: uniformly random loop closures): the system fills in
+      if (keep) {
+        c->plan.build_ordered(c->n_pose, To, ord.dpos, ord.nreal, adjS, ord.piece_ranges, ord.sep_ranges_by_level, !(e3 && atoi(e3) == 0));
+        ordered = true;
+        // (the exact step must beat a PCG solve of a few milliseconds: the critical path of the chains, and the flops at the ~3 TFLOP/s the
+        // update tasks of a large plan sustain)
+        if (dense_on_trial) {
+          const double est_us = std::max(ord.est_path_us, c->plan.fused_flops / 7.0e12 * 1e6);   // (7 TFLOP/s: what the thousands of independent update tasks of such a plan sustain — measured on synthetic.pose_graph_local)
+          if (timing) fprintf(stderr, "[bsgpu finalize] pose graph above the dense limit on trial: path %.0f us, %.3g flops -> %.0f us estimated per factorisation: %s\n",
+                              ord.est_path_us, c->plan.fused_flops, est_us, est_us > 4000.0 ? "block-sparse PCG" : "exact tiled factorisation");
+          if (est_us > 4000.0) { keep = false; ordered = false; }
+        }
+      }
+      if (!keep) c->dense_ok = false;
       if (timing) fprintf(stderr, "[bsgpu finalize] per-dimension order: %d blocks, %d supernodes, depth %d, estimated path %.0f us\n", bg.nbk, ord.n_nodes, ord.depth, ord.est_path_us);
     }
+    if (dense_on_trial && !ordered) c->dense_ok = false;
     if (!ordered)
       c->plan.build(c->n_pose, c->tile_adj, c->dense_ok ? max_chains : 1, 1, !(e3 && atoi(e3) == 0), use_leaf ? &c->leaf_tile : nullptr);
     c->npad = c->plan.npad;

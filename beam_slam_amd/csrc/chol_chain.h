@@ -160,7 +160,9 @@ struct ChainUpdater {
   template <int C, int I> BSG_CHAIN_DEV bool valid() const { return (I < SL::K(C) - 1) || (SL::rem(C) == 4) || (rowsel[C & 3] < SL::rem(C)); }
   // slot (C, I) takes the update of panel PB (in buffer PB & 1)
   template <int PB, int C, int I> BSG_CHAIN_DEV void update() {
-    if (valid<C, I>()) {
+    // (blocks whose row or column is padding are zero and stay zero: no products for them — a 144-dimensional piece in three tiles
+    // has 45 live blocks of 78)
+    if (valid<C, I>() && C < nb_real && C + rowsel[C & 3] + 4 * I < nb_real) {
       const double* pa = P0 + offA[PB & 1][C & 3] + 16 * (C + 4 * I) * PP;
       const double* pb = P0 + offB[PB & 1] + 16 * C * PP;
       acc[SL::first(C) + I] = chain_mfma4(acc[SL::first(C) + I], pa, pb);

@@ -356,6 +356,29 @@ def test_solve_batch_one_set_of_launches_equals_lone_solves(gpu_solver_cls):
         assert s1.num_iterations == s0.num_iterations and abs(s1.final_cost - s0.final_cost) <= 1e-9 * abs(s0.final_cost)
 
 
+def test_solve_batch_more_windows_than_one_round_holds(gpu_solver_cls):
+    """70 small windows in one bsgpu_solve_batch call: the batched launches take at most 64 windows at a time (BatchDyn's lists), the
+    rest follow in a second set — every window still ends where its lone solve ends."""
+    cases = [synthetic.vio_window(n_kf=6 + (i % 5), n_lm=40 + 7 * (i % 9), seed=300 + i) for i in range(70)]
+    def fresh():
+        out = []
+        for pr in cases:
+            g = gpu_solver_cls(0); pr.load(g); out.append(g)
+        return out
+    alone = fresh()
+    opt = alone[0].options_vio(); opt.max_solver_time_in_seconds = 0.0; opt.max_num_iterations = 8
+    lone = [g.solve(opt) for g in alone]
+    w0, _ = gpu_solver_cls.batch_stats()
+    batch = fresh()
+    sums = gpu_solver_cls.solve_batch(batch, opt)
+    w1, _ = gpu_solver_cls.batch_stats()
+    assert w1 - w0 == 70
+    for g0, s0, g1, s1 in zip(alone, lone, batch, sums):
+        assert s1.num_iterations == s0.num_iterations and s1.termination_type == s0.termination_type
+        assert abs(s1.final_cost - s0.final_cost) <= 1e-9 * abs(s0.final_cost) + 1e-18
+        assert np.abs(g1.get_blocks() - g0.get_blocks()).max() < 1e-8
+
+
 def test_contexts_on_concurrent_host_threads(gpu_solver_cls):
     """One context per host thread, all on one device (the reference runs its local smoother, global mapper and submap
     refinement side by side, submap_refinement.cpp:35-115): create, load, finalize, solve, read back and destroy concurrently;

@@ -326,30 +326,34 @@ def test_c5_eight_windows_one_gpu_match_oracle(oracle_cls, gpu_solver_cls):
         o.close()
 
 
-def test_local_loop_pose_graph_exact_step_at_c4_size(gpu_solver_cls, monkeypatch):
+def test_local_loop_pose_graph_exact_step_at_c4_size(gpu_solver_cls, c4_like=None):
     """The reference's call on a pose graph is the exact step (SPARSE_NORMAL_CHOLESKY, submap_pose_graph_optimization.cpp:144-146).
-    C4's 45 000 uniformly random loop closures make its reduced system fill in completely (scripts/c4_exact.py); a mapper's loop closures
-    join poses that are near each other (synthetic.pose_graph_local: 5 000 poses, 50 000 constraints, loops within two rows of a sweep):
-    there the per-dimension nested dissection (dim_order.h) finds separators and the tiled factorisation — 30 000 dimensions — is an
-    LM step of a few milliseconds.  Exact path against the block-sparse PCG on the same graph: the same optimum."""
+    C4's 45 000 uniformly random loop closures make its reduced system fill in completely (scripts/c4_exact.py: 0.94 s per LM
+    iteration), so C4 keeps the block-sparse PCG; a mapper's loop closures join poses that are near each other
+    (synthetic.pose_graph_local: 5 000 poses, 50 000 constraints, loops within two rows of a sweep): there the per-dimension nested
+    dissection (dim_order.h) finds separators, finalize() sees that the plan is cheap and BSGPU_LINEAR_AUTO takes the exact tiled
+    factorisation — 30 000 dimensions, an LM step of a few milliseconds.  Against the PCG on the same graph: the same optimum."""
     import time
     pr = synthetic.pose_graph_local()
-    monkeypatch.setenv("BSGPU_EXACT_POSE_GRAPH", "1")
     g = gpu_solver_cls(0)
     pr.load(g)
     g.finalize()
     chains, _, tiles = g.plan_info()
     assert chains >= 8 and tiles >= 469          # dissected: many independent pieces
-    o = g.options_default(); o.max_num_iterations = 10; o.linear_solver_type = capi.LINEAR_SCHUR_CHOLESKY
+    o = g.options_default(); o.max_num_iterations = 10
     g.solve(o); g.reset_values()
     t0 = time.perf_counter(); s = g.solve(o); dt = time.perf_counter() - t0
-    assert s.linear_solver_used == capi.LINEAR_SCHUR_CHOLESKY and s.is_solution_usable == 1
+    assert s.linear_solver_used == capi.LINEAR_SCHUR_CHOLESKY and s.is_solution_usable == 1     # (chosen by finalize(): AUTO)
     assert dt / max(1, s.num_linear_solves) < 0.05   # (0.003 s measured; 0.94 s per iteration on C4's random loops)
-    monkeypatch.delenv("BSGPU_EXACT_POSE_GRAPH")
     g2 = gpu_solver_cls(0)
     pr.load(g2)
-    o2 = g2.options_default(); o2.max_num_iterations = 10
+    o2 = g2.options_default(); o2.max_num_iterations = 10; o2.linear_solver_type = capi.LINEAR_PCG
     s2 = g2.solve(o2)
     assert s2.linear_solver_used == capi.LINEAR_PCG
     assert abs(s.final_cost - s2.final_cost) <= 1e-5 * s2.final_cost
     assert s.final_cost < 0.3 * s.initial_cost
+    # C4 itself (random loops): no separator, the PCG stays
+    g3 = gpu_solver_cls(0)
+    synthetic.pose_graph(n_pose=2500, n_loop=20000, seed=5).load(g3)
+    o3 = g3.options_default(); o3.max_num_iterations = 2
+    assert g3.solve(o3).linear_solver_used == capi.LINEAR_PCG
