@@ -35,10 +35,11 @@ struct DimOrder {
   int n_nodes = 0, depth = 0;
   double est_path_us = 0.0;
 
-  // nominal costs (microseconds) of the fused factorisation, from the task stamps of C2 (BSGPU_CHOL_PROBE, scripts/chol_probe.py):
-  // a chain of m tiles takes t_chain0 + steps x t_step[m] (the trailing matrix the updating waves carry grows with m), and the
-  // hand-over from a chain to the next one on the path (flag, loads, strip solve, product, turn, publication, flag) t_hop
-  double t_chain0 = 2.0, t_step = 2.0, t_step2 = 2.25, t_step3 = 3.0, t_hop = 14.0;
+  // nominal costs (microseconds) of the fused factorisation, from the task stamps of C2 (BSGPU_CHOL_PROBE, scripts/chol_probe.py): a
+  // chain of m tiles takes t_chain0 (its tiles' loads) + steps x t_step[m], the hand-over from a chain to the next one on the path (flag,
+  // loads, strip solve, product, turn, publication, flag) t_hop.  Measured on C2 with (5, 2, 2.1, 4.5, 8 .. 16): 152-153 us per
+  // factorisation for every hand-over value; with t_step3 = 3.5 (two leaves of three tiles survive) 159.5.
+  double t_chain0 = 5.0, t_step = 2.0, t_step2 = 2.1, t_step3 = 4.5, t_hop = 10.0;   // (t_step3: a chain of three tiles is bound by the MFMA rate of its ONE CU — and a leaf that long is the head of the critical path: priced so that the dissection avoids it)
   int max_depth = 5;
   double hub_frac = 0.6;
   int merge_dims = 24;     // separators up to this many dimensions are merged into their parent separator

@@ -726,6 +726,20 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
     __syncthreads();
   }
   stamp(4);
+  if (tk.flags & kFusedPublishX) {
+    // the L panel of this row tile — what the back-substitution reads, and what the off-diagonal tasks of this panel multiply with —
+    // leaves NOW, before this task's own product and its turn on the diagonal tile: the tasks that read it were waiting through both
+    // (7-10 us after the chain's flag on every level of the critical path, BSGPU_CHOL_PROBE; round 4)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int i = tid + NT * q;
+      const int r = i >> 5, c2 = (i & 31) * 2;
+      st16_sc1(rL_i, (unsigned)(((size_t)r * ld + c0 + c2) * sizeof(double)), *reinterpret_cast<const double2*>(&sXi[r * LDT + c2]));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) atomicAdd(&upd[(ti * N + k) * fs], 1);
+  }
   const double* Xj = diag ? sXi : sXj;
   double4_t acc[TPW];
 #pragma unroll
@@ -779,21 +793,9 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
           st8_sc1(rS_i, (unsigned)(((size_t)(16 * rs + crow + 4 * reg) * ld + rj + 16 * (tt0 + u) + ccol) * sizeof(double)), acc[u][reg]);
     }
   }
-  if (tk.flags & kFusedPublishX) {
-    // the L panel of this row tile: what the back-substitution reads, and what the off-diagonal tasks of this panel multiply with
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int i = tid + NT * q;
-      const int r = i >> 5, c2 = (i & 31) * 2;
-      st16_sc1(rL_i, (unsigned)(((size_t)r * ld + c0 + c2) * sizeof(double)), *reinterpret_cast<const double2*>(&sXi[r * LDT + c2]));
-    }
-  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (tid == 0) {
-    if (do_update) atomicAdd(&upd[(ti * N + tj) * fs], 1);
-    if (tk.flags & kFusedPublishX) atomicAdd(&upd[(ti * N + k) * fs], 1);
-  }
+  if (tid == 0 && do_update) atomicAdd(&upd[(ti * N + tj) * fs], 1);
   stamp(6);
   return true;
 }

@@ -21,6 +21,9 @@ int main(int argc, char** argv) {
   for (int b = 0; b < nbk; ++b) { for (int x : adj[b]) o.adj.push_back(x); o.adj_ptr.push_back((int)o.adj.size()); }
   if (getenv("T_STEP")) o.t_step = atof(getenv("T_STEP"));
   if (getenv("T_HOP")) o.t_hop = atof(getenv("T_HOP"));
+  if (getenv("T_STEP2")) o.t_step2 = atof(getenv("T_STEP2"));
+  if (getenv("T_STEP3")) o.t_step3 = atof(getenv("T_STEP3"));
+  if (getenv("T_CHAIN0")) o.t_chain0 = atof(getenv("T_CHAIN0"));
   if (getenv("DEPTH")) o.max_depth = atoi(getenv("DEPTH"));
   if (getenv("HUB")) o.hub_frac = atof(getenv("HUB"));
   o.build();
@@ -35,6 +38,13 @@ int main(int argc, char** argv) {
     auto mark = [&](int x, int y) { for (int ka = 0; ka < o.blk_w[x]; ++ka) for (int kb = 0; kb < o.blk_w[y]; ++kb) { const int p = o.dpos[o.blk_t0[x] + ka] >> 6, q = o.dpos[o.blk_t0[y] + kb] >> 6; adjS[(size_t)p * To + q] = adjS[(size_t)q * To + p] = 1; } };
     mark(a, a);
     for (int b : adj[a]) mark(a, b);
+  }
+  {   // couplings between tiles of different PIECES (there must be none: pieces are independent)
+    std::vector<int> piece_of_tile(To, -1);
+    for (size_t i = 0; i < o.piece_ranges.size(); ++i) for (int t = o.piece_ranges[i].first; t < o.piece_ranges[i].second; ++t) piece_of_tile[t] = (int)i;
+    int bad = 0;
+    for (int x = 0; x < To; ++x) for (int y = 0; y < x; ++y) if (adjS[(size_t)x * To + y] && piece_of_tile[x] >= 0 && piece_of_tile[y] >= 0 && piece_of_tile[x] != piece_of_tile[y]) { if (bad++ < 5) printf("  piece tiles %d and %d are coupled\n", y, x); }
+    printf("couplings between different pieces: %d\n", bad);
   }
   DensePlan P;
   P.build_ordered(o.n_pose, To, o.dpos, o.nreal, adjS, o.piece_ranges, o.sep_ranges_by_level);
