@@ -915,7 +915,8 @@ int finalize(bsgpu_ctx* c) {
       if (timing) fprintf(stderr, "[bsgpu finalize] per-dimension order: %d blocks, %d supernodes, depth %d, estimated path %.0f us\n", bg.nbk, ord.n_nodes, ord.depth, ord.est_path_us);
     }
     if (dense_on_trial && !ordered) c->dense_ok = false;
-    if (!ordered)
+    if (!c->dense_ok) c->plan.build_skeleton(c->n_pose);
+    else if (!ordered)
       c->plan.build(c->n_pose, c->tile_adj, c->dense_ok ? max_chains : 1, 1, !(e3 && atoi(e3) == 0), use_leaf ? &c->leaf_tile : nullptr);
     c->npad = c->plan.npad;
     const int T = c->plan.T;

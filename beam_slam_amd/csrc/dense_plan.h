@@ -209,6 +209,28 @@ struct DensePlan {
     finish(B, piece_ranges, sep_ranges_by_level, leaf_ranges, allow_shared);
   }
 
+  // A window that does not take the tiled factorisation at all (a pose graph on the block-sparse PCG): sizes and the identity position
+  // tables only.  The full plan of such a system is worthless and enormous — C4's 469 tiles fill in completely: 17 million tasks, four
+  // seconds of finalize() (measured, round 4; the plan had been built for every window since round 1).
+  void build_skeleton(int n_pose_) {
+    *this = DensePlan();
+    n_pose = n_pose_; T = (n_pose + 63) / 64; npad = (T + 1) * 64; rhs_row = T * 64;
+    perm.resize(T);
+    for (int t = 0; t < T; ++t) perm[t] = t;
+    nreal.assign(T + 1, 64);
+    if (n_pose % 64 && T > 0) nreal[T - 1] = n_pose % 64;
+    nreal[T] = 0;
+    dpos.assign(std::max(1, n_pose), 0);
+    inat.assign(npad, -1);
+    for (int j = 0; j < n_pose; ++j) { dpos[j] = j; inat[j] = j; }
+    step_off.assign(1, 0);
+    bs_group_off.assign(1, 0);
+    potrf_before_step_off.assign(1, 0);
+    tile_sync.assign(2 * (size_t)(T + 1), 0);
+    bs_desc.assign((size_t)std::max(1, T) * kBsDescInts, 0);
+    panel_of_tile.assign(T, 0);
+  }
+
   // The order is GIVEN, per dimension (bsgpu_finalize.cpp: dim_order.h — a nested dissection of the block graph of the reduced system whose
   // separators are sets of tangent blocks, not runs of natural tiles): dpos_[j] = position of tangent index j in S; the supernodes (pieces,
   // separators) are runs of whole tiles, each padded to a multiple of 64 at its END (nreal_[t] < 64 on a supernode's last tile: unit
