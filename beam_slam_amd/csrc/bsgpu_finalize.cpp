@@ -871,6 +871,7 @@ int finalize(bsgpu_ctx* c) {
     const char* e3 = getenv("BSGPU_SHARED");   // panels of one step may update the same tiles (atomics): on unless BSGPU_SHARED=0
     const bool use_leaf = c->n_leaf_tiles > 0 && !getenv("BSGPU_NO_LEAF_TILES");
     bool ordered = false;
+    lap("blocks");
     if (bg.nbk && max_chains > 1) {
       // per-dimension order (dim_order.h): nested dissection of the block graph, separators = sets of tangent blocks
       DimOrder ord;
@@ -885,7 +886,9 @@ int finalize(bsgpu_ctx* c) {
         ord.adj_ptr[a + 1] = (int)ord.adj.size();
       }
       if (const char* ev = getenv("BSGPU_DIM_ORDER_DEPTH")) ord.max_depth = std::max(0, atoi(ev));
+      lap("  order: adjacency lists");
       ord.build();
+      lap("  order: dissection");
       // tile adjacency in S order from the block graph (a block lies in at most two tiles of its supernode)
       const int To = ord.T;
       std::vector<uint8_t> adjS((size_t)To * To, 0);
@@ -912,6 +915,7 @@ int finalize(bsgpu_ctx* c) {
         }
       }
       if (!keep) c->dense_ok = false;
+      lap("  order: tile plan");
       if (timing) fprintf(stderr, "[bsgpu finalize] per-dimension order: %d blocks, %d supernodes, depth %d, estimated path %.0f us\n", bg.nbk, ord.n_nodes, ord.depth, ord.est_path_us);
     }
     if (dense_on_trial && !ordered) c->dense_ok = false;
