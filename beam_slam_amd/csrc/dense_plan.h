@@ -562,7 +562,9 @@ struct DensePlan {
         for (int k = 0; k < T; ++k) {
           int* r = &bs_desc_chain[(size_t)k * kBsDescInts];
           const int off = (int)rows_flat_chain.size();
-          for (int t : rows[k]) if (t < T && chain_of[t] == chain_of[k]) rows_flat_chain.push_back(t);
+          // (its own chain's row tiles AND those of the group just before its own — its parent separator: the chain multiplies them in
+          // itself when the parent's y is out, instead of waiting for a round of update items in between; round 4)
+          for (int t : rows[k]) if (t < T && (chain_of[t] == chain_of[k] || group_of[t] == group_of[k] - 1)) rows_flat_chain.push_back(t);
           const int n = (int)rows_flat_chain.size() - off;
           r[0] = n; r[1] = off; r[2] = nreal[k];
           for (int q = 0; q < n && q < kBsDescRows; ++q) r[3 + q] = rows_flat_chain[off + q];
@@ -570,7 +572,7 @@ struct DensePlan {
         const int G = (int)bs_group_off.size() - 1;
         for (int g = 0; g + 1 < G; ++g) {
           for (int k = 0; k < T; ++k) {
-            if (group_of[k] <= g) continue;
+            if (group_of[k] <= g + 1) continue;   // (the next group's chains take this group's rows themselves)
             const int off = (int)bs_upd_rows.size();
             for (int t : rows[k]) if (t < T && group_of[t] == g) bs_upd_rows.push_back(t);
             const int n = (int)bs_upd_rows.size() - off;
@@ -611,8 +613,8 @@ struct DensePlan {
   }
  public:
   // Level-synchronous back-substitution (by-level groups only): a chain's workgroup walks its panels with the row tiles of ITS OWN
-  // chain only (bs_desc_chain / rows_flat_chain, same record format as bs_desc); what the chains of group g contribute to the panels
-  // of later groups — y_k -= sum_{t in group g} L(t,k)^T y_t — is applied between two groups by one workgroup per target panel
+  // chain and of the group just before its own (bs_desc_chain / rows_flat_chain, same record format as bs_desc); what the chains of
+  // group g contribute to the panels of the groups from g + 2 on — y_k -= sum_{t in group g} L(t,k)^T y_t — is applied by one workgroup per target panel
   // (bs_upd: {k, offset into bs_upd_rows, count} per item, items of group g in [bs_upd_off[g], bs_upd_off[g+1])).  Those products
   // are two thirds of the factor's entries and depend on nothing inside the later chains: as a wide launch they stream at the
   // chip's bandwidth instead of at one workgroup's latency.

@@ -1010,8 +1010,10 @@ struct BsPanelRegs {
 // what the single-launch form (chol_backsolve_fused_kernel) adds to a chain's walk: the turn to wait for, where y is shared
 struct BsFused {
   int* abort_w;            // sticky failure flag
-  const int* wait_flags;   // null: nothing to wait for (the root group); else the walk starts when every flag in [wait_lo, wait_hi) is set
-  int wait_lo, wait_hi, flag_stride;
+  const int* wait_flags;   // null: nothing to wait for; else the walk starts when every flag in [wait_lo, wait_hi) is set (the update items
+  int wait_lo, wait_hi, flag_stride;   // of the phase two groups up: they wrote this chain's start values)
+  const int* wait_word;    // ... and when *wait_word has reached wait_word_val: the chains of the group just before (null: the root group)
+  int wait_word_val;
   int* done_word;          // bumped once the chain's y is out
   const int* tile_updated; // per tile: an earlier phase has written y there (else the start value is y_init)
   long long deadline;
@@ -1189,7 +1191,12 @@ BSG_DEV void bs_chain_walk(const double* Lp, const double* Vinv /* USE_W: the ti
     stamp(1);
     int* s_ok = reinterpret_cast<int*>(s_rows + (size_t)max_len * kBsMaxRows);
     if (tid < 64) {   // (the first wave polls, a flag per lane)
-      const bool ok = !F.wait_flags || wait_flags(F.wait_flags, F.wait_lo, F.wait_hi, F.abort_w, F.deadline, F.flag_stride);
+      bool ok = !F.wait_flags || F.wait_hi <= F.wait_lo || wait_flags(F.wait_flags, F.wait_lo, F.wait_hi, F.abort_w, F.deadline, F.flag_stride);
+      if (ok && F.wait_word) {
+        int okw = 1;
+        if (tid == 0) okw = wait_count(F.wait_word, F.wait_word_val, F.abort_w, F.deadline) ? 1 : 0;
+        ok = __builtin_amdgcn_readfirstlane(okw) != 0;
+      }
       if (tid == 0) *s_ok = ok ? 1 : 0;
     }
     __syncthreads();
@@ -1197,6 +1204,15 @@ BSG_DEV void bs_chain_walk(const double* Lp, const double* Vinv /* USE_W: the ti
     stamp(2);
     for (int i = b * NB + tid; i < e * NB; i += 1024)
       sy[i] = F.tile_updated[i >> 6] ? ld8_sc1(ry, (unsigned)(i * sizeof(double))) : y_init[i];
+    // the row tiles outside the chain (its parent separator's: solved by now): their y, for the products of the walk
+    for (int p = 0; p < len; ++p) {
+      const int n_rows = s_nrows[p];
+      const int* rows = (n_rows <= kBsMaxRows) ? (s_rows + p * kBsMaxRows) : (rows_flat + s_rowoff[p]);
+      for (int q = tid >> 6; q < n_rows; q += 16) {
+        const int t = rows[q];
+        if (t < b || t >= e) sy[t * NB + (tid & 63)] = ld8_sc1(ry, (unsigned)((t * NB + (tid & 63)) * sizeof(double)));
+      }
+    }
     __syncthreads();
     stamp(3);
     return true;
@@ -1320,10 +1336,13 @@ __device__ __forceinline__ void chol_backsolve_fused_kernel_body(const int bsg_b
     const int ch = bid, g = chain_group[ch];
     BsFused F;
     F.abort_w = abort_w; F.deadline = deadline; F.tile_updated = tile_updated;
-    int lo = 0;
-    for (int q = 0; q + 1 < g; ++q) lo += grp_nitems[q];
-    F.wait_flags = g > 0 ? item_flag : nullptr; F.flag_stride = fs;
-    F.wait_lo = lo; F.wait_hi = g > 0 ? lo + grp_nitems[g - 1] : 0;
+    // start values: what the update items of phases <= g - 2 left (the phases follow each other: an item waits for the phase before
+    // its own); the rows of group g - 1 the chain multiplies in itself, once that group's chains are done
+    int hi = 0;
+    for (int q = 0; q + 2 <= g; ++q) hi += grp_nitems[q];   // (every phase up to g - 2: a phase without items must not cut the order)
+    F.wait_flags = g > 1 ? item_flag : nullptr; F.flag_stride = fs;
+    F.wait_lo = 0; F.wait_hi = g > 1 ? hi : 0;
+    F.wait_word = g > 0 ? done_chain + (size_t)(g - 1) * fs : nullptr; F.wait_word_val = g > 0 ? grp_nchains[g - 1] : 0;
     F.done_word = done_chain + (size_t)g * fs; F.ts = ts; F.ts_row = bid;
     bs_chain_walk<true, CH, DEEP, true, true>(Lp, Winv, ld, bs_desc, chain_begin[ch], chain_end[ch], rows_flat, y, npad, max_len, y_init, iperm, n_pose,
                                         y_tan, delta, F);
@@ -1346,7 +1365,16 @@ __device__ __forceinline__ void chol_backsolve_fused_kernel_body(const int bsg_b
       for (int i = 0; i < 4; ++i) l[u][i] = ok ? Lp[(size_t)(r0[u] + i) * ld + c0 + c] : 0.0;
     }
     if (ts && tid == 0) ts[(size_t)bid * 16 + 1] = wall_clock64();
-    if (tid == 0) *s_ok = wait_count(done_chain + (size_t)phase * fs, grp_nchains[phase], abort_w, deadline) ? 1 : 0;
+    // its turn: the chains of group `phase` are done — and so are the items of the phase before (two phases may update the same panel)
+    if (tid < 64) {
+      int hi_prev = 0;
+      for (int q = 0; q < phase; ++q) hi_prev += grp_nitems[q];   // (every earlier phase)
+      bool okp = hi_prev == 0 || wait_flags(item_flag, 0, hi_prev, abort_w, deadline, fs);
+      int okw = 1;
+      if (okp && tid == 0) okw = wait_count(done_chain + (size_t)phase * fs, grp_nchains[phase], abort_w, deadline) ? 1 : 0;
+      okp = okp && __builtin_amdgcn_readfirstlane(okw) != 0;
+      if (tid == 0) *s_ok = okp ? 1 : 0;
+    }
     __syncthreads();
     if (ts && tid == 0) ts[(size_t)bid * 16 + 2] = wall_clock64();
     const bool ok_turn = __builtin_amdgcn_readfirstlane(*s_ok) != 0;
