@@ -295,6 +295,36 @@ BSG_DEV void trsm_tile_t(double* sA, const double* sL, const double* sV, int lan
     for (int reg = 0; reg < 4; ++reg) rows[n * LDT + 16 * b + q + 4 * reg] = acc[b][reg];
 }
 
+// The strip X = A L_kk^-T as a PRODUCT with the tile's full inverse W = L_kk^-1 (what the chains leave for every tile: identity rows
+// carried through the elimination, chol_chain.h): Y_b = X_b^T = sum_{c <= b} W_bc A_c^T — ten 16 x 16 x 16 block products per strip,
+// the same 40 MFMAs as the substitution above, but none of them waits for another one's result: the substitution is four dependent
+// block steps (a dependent v_mfma_f64 costs ~175 cycles against 64 of issue: 2.8 us per solve in the task stamps), the product runs at
+// the issue rate.  sW: W row-major with pitch LDT (zeros above the diagonal).  Round 2 had measured this form with W built by MFMA
+// products inside the task (2.2 us, the gain gone); since round 3 W comes for free.
+BSG_DEV void solve_tile_w(double* sA, const double* sW, int lane, int wave) {
+  double* rows = sA + (16 * wave) * LDT;
+  const int n = lane & 15, q = lane >> 4;
+  double4_t a[4], y[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) a[b][reg] = rows[n * LDT + 16 * b + q + 4 * reg];   // A_b^T in result layout = the B operand of the products
+    y[b] = double4_t{0.0, 0.0, 0.0, 0.0};
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int b = c; b < 4; ++b)   // (consecutive MFMAs go to different accumulators)
+        y[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(sW[(16 * b + n) * LDT + 16 * c + 4 * kk + q], a[c][kk], y[b], 0, 0, 0);
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) rows[n * LDT + 16 * b + q + 4 * reg] = y[b][reg];
+}
+
 // descriptors of the (few) panels of one step and their row-tile lists, passed BY VALUE: they arrive with the kernel
 // arguments instead of costing two dependent round trips to memory before the first tile load can be issued
 constexpr int kStepMaxPanels = 16, kStepMaxRows = 16;
@@ -635,11 +665,11 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
   const bool solve_j = !diag && !(tk.flags & (kFusedXjLp | kFusedXjChain));
   const bool need_L = solve_i || solve_j;
   const int ri = __builtin_amdgcn_readfirstlane(ti * NB), rj = __builtin_amdgcn_readfirstlane(tj * NB), c0 = __builtin_amdgcn_readfirstlane(k * NB);
-  const __amdgpu_buffer_rsrc_t rS_i = tile_rows(S, ri), rS_j = tile_rows(S, rj), rL_i = tile_rows(Lp, ri), rL_j = tile_rows(Lp, rj), rL_c = tile_rows(Lp, c0);
+  const __amdgpu_buffer_rsrc_t rS_i = tile_rows(S, ri), rS_j = tile_rows(S, rj), rL_i = tile_rows(Lp, ri), rL_j = tile_rows(Lp, rj);
   // rows of the rhs tile (tile N-1 as row tile) beyond its used strips are zero and stay zero: no solve, no product, no traffic for them
   const int strips_i = (ti == N - 1) ? __builtin_amdgcn_readfirstlane(C.rhs_strips) : 4;
   const bool strip_on = rs < strips_i;
-  double2 vXi[NQ], vL[NQ], vXj[NQ], vV[512 / NT];
+  double2 vXi[NQ], vL[NQ], vXj[NQ];
   // The panel tiles first: they have usually had their last update long before L_kk is out, so their loads travel while the
   // workgroup waits for the factor; only L_kk and its block inverses are requested after it.  A strip that is not solved here is
   // read from the factor: X of an outside tile once its diagonal task has published it (the tile's counter one past its last
@@ -688,14 +718,7 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int i = tid + NT * q;
-      vL[q] = ld16_sc1(rL_c, (unsigned)(((size_t)(i >> 5) * ld + c0 + (i & 31) * 2) * sizeof(double)));
-    }
-    // the inverses of the four diagonal 16x16 blocks of L_kk = the diagonal blocks of W_k: sV[b][i][c] = W[16 b + i][16 b + c]
-#pragma unroll
-    for (int q = 0; q < 512 / NT; ++q) {
-      const int i2 = (tid + NT * q) * 2;
-      const int b = i2 >> 8, i = (i2 >> 4) & 15, c = i2 & 15;
-      vV[q] = ld16_sc1(rW, (unsigned)(((size_t)k * 4096 + (16 * b + i) * 64 + 16 * b + c) * sizeof(double)));
+      vL[q] = ld16_sc1(rW, (unsigned)(((size_t)k * 4096 + (size_t)(i >> 5) * 64 + (i & 31) * 2) * sizeof(double)));   // W = L_kk^-1, the whole tile (solve_tile_w)
     }
   }
 #pragma unroll
@@ -706,22 +729,15 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
     if (need_L) *reinterpret_cast<double2*>(&sL[r * LDT + c2]) = vL[q];
     if (!diag) *reinterpret_cast<double2*>(&sXj[r * LDT + c2]) = vXj[q];
   }
-  if (need_L) {
-#pragma unroll
-    for (int q = 0; q < 512 / NT; ++q) {
-      const int i2 = (tid + NT * q) * 2;
-      *reinterpret_cast<double2*>(&sV[(i2 >> 8) * 16 * kVtPitch + ((i2 >> 4) & 15) * kVtPitch + (i2 & 15)]) = vV[q];
-    }
-  }
   __syncthreads();
   stamp(3);
   if (need_L) {
     if (NT == 256) {
-      if (solve_i && wave < strips_i) trsm_tile_t(sXi, sL, sV, lane, wave);
-      if (solve_j) trsm_tile_t(sXj, sL, sV, lane, wave);
+      if (solve_i && wave < strips_i) solve_tile_w(sXi, sL, lane, wave);
+      if (solve_j) solve_tile_w(sXj, sL, lane, wave);
     } else {   // (waves 0-3: the strips of X_i; waves 4-7: those of X_j, at the same time)
-      if (wave < 4) { if (solve_i && wave < strips_i) trsm_tile_t(sXi, sL, sV, lane, wave); }
-      else if (solve_j) trsm_tile_t(sXj, sL, sV, lane, wave - 4);
+      if (wave < 4) { if (solve_i && wave < strips_i) solve_tile_w(sXi, sL, lane, wave); }
+      else if (solve_j) solve_tile_w(sXj, sL, lane, wave - 4);
     }
     __syncthreads();
   }
