@@ -1047,7 +1047,7 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
     if (hipMalloc(dst, bytes ? bytes : 8) != hipSuccess) return false;
     return bytes == 0 || hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
   };
-  bool ok = hipMalloc(&dS, sizeof(double) * hS.size()) == hipSuccess && hipMalloc(&dLp, sizeof(double) * hS.size()) == hipSuccess &&
+  bool ok = hipMalloc(&dS, sizeof(double) * hS.size()) == hipSuccess && hipMalloc(&dLp, sizeof(double) * hS.size()) == hipSuccess && hipMemset(dLp, 0, sizeof(double) * hS.size()) == hipSuccess &&
             hipMalloc(&dV, sizeof(double) * chol_vinv_stride() * std::max(1, T)) == hipSuccess && hipMalloc(&dy, sizeof(double) * npad) == hipSuccess &&
             hipMalloc(&dscal, sizeof(double) * SC_NUM) == hipSuccess;
   std::vector<int> rf = P.rows_flat; if (rf.empty()) rf.push_back(0);

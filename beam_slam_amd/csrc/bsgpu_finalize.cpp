@@ -869,6 +869,7 @@ int finalize(bsgpu_ctx* c) {
       if (c->tile_adj.size() != (size_t)T0 * T0) c->tile_adj.assign((size_t)T0 * T0, 0);
     }
     const char* e3 = getenv("BSGPU_SHARED");   // panels of one step may update the same tiles (atomics): on unless BSGPU_SHARED=0
+    { const char* ex = getenv("BSGPU_CHOL_EXT"); c->plan.allow_ext = !(ex && atoi(ex) == 0); }   // (0: every tile's panel has its own update tasks, also a separator's appendix tile)
     const bool use_leaf = c->n_leaf_tiles > 0 && !getenv("BSGPU_NO_LEAF_TILES");
     bool ordered = false;
     lap("blocks");
@@ -961,7 +962,16 @@ int finalize(bsgpu_ctx* c) {
     c->d_chain_begin = c->upload(c->plan.chain_begin); c->d_chain_end = c->upload(c->plan.chain_end);
     c->d_Vinv = c->alloc<double>((size_t)std::max(1, T) * chol_vinv_stride());
     c->d_ytan = c->alloc<double>(std::max(1, c->n_pose));
-    if (c->dense_ok) { c->d_Lp = c->alloc<double>((size_t)c->npad * c->npad); if (!c->d_Lp) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (L panels)"); }
+    if (c->dense_ok) {
+      c->d_Lp = c->alloc<double>((size_t)c->npad * c->npad);
+      if (!c->d_Lp) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (L panels)");
+      // (the tasks that carry an appendix tile write its 16 real columns of the factor's row tiles and nothing else of those tiles: the
+      //  padding's columns must read zero in the back-substitution, and the buffer comes from the pool with whatever it last held)
+      bool any_ext = false;
+      for (int v : c->plan.fext_of) any_ext = any_ext || v >= 0;
+      if (any_ext && hipMemsetAsync(c->d_Lp, 0, sizeof(double) * (size_t)c->npad * c->npad, c->stream) != hipSuccess)
+        return fail(c, BSGPU_ERR_DEVICE, "device error while clearing the factor");
+    }
   }
   // ---- dense system + vectors
   if (c->dense_ok) {

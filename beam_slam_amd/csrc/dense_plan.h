@@ -54,6 +54,10 @@ constexpr int kFusedXiLp = 2;       // X_ti is read from the factor once the dia
 constexpr int kFusedXjLp = 4;       // ... X_tj
 constexpr int kFusedXjChain = 8;    // tj belongs to the chain of k: X_tj = L(tj, k) is out when potrf_done[k] is set
 constexpr int kFusedPublishX = 16;  // (diagonal task) X_ti goes to the factor write-through and the tile's counter is bumped once more
+constexpr int kFusedExt = 32;       // panel k carries its chain's APPENDIX tile k + 1 (a last tile of at most kFusedExtCols real columns): the task also
+                                    // forms X(., k + 1) = (A(., k + 1) - X(., k) L(k + 1, k)^T) W_{k+1}^T of its row tiles and its product runs over both —
+                                    // the appendix has no update tasks of its own, and the tiles (., k + 1) are not updated by panel k
+constexpr int kFusedExtCols = 16;
 constexpr int kChainMaxTiles = 3;   // == chain::kChainMaxTiles (chol_chain.h)
 
 struct DensePlan {
@@ -89,6 +93,8 @@ struct DensePlan {
   std::vector<FusedTask> ftasks;
   std::vector<int> tile_tot;          // (T+1)^2: number of update TASKS per tile (what a chain waits for before it reads its tiles)
   std::vector<int> fchain_begin, fchain_len, fchain_of_tile;   // the chains of the fused factorisation
+  std::vector<int> fext_of;           // T+1: the appendix tile panel k carries (kFusedExt), or -1
+  bool allow_ext = true;              // (finalize: BSGPU_CHOL_EXT=0 plans every tile's panel by itself)
   int fused_sync_words = 0;   // ints of device scratch: ([queue head | abort | exited workgroups | potrf_done (T+1) | update counts (T+1)^2]) x 16
   double fused_flops = 0.0;   // FP64 flops of the planned factorisation (trsm + rank-64 updates + potrf of every touched tile), for the MFMA roofline
   // solve offsets
@@ -358,6 +364,23 @@ struct DensePlan {
       for (const auto& r : piece_ranges) add_range(r.first, r.second);
       for (const auto& lv : sep_ranges_by_level) for (const auto& r : lv) add_range(r.first, r.second);
       const int nch = (int)fchain_begin.size();
+      // appendix tiles: a separator of 78 dimensions is a tile of 64 and one of 14 — and a panel of its own for the 14 costs the critical
+      // path a whole hand-over (flag, loads, solve, product, turn, publication: ~6.5 us, BSGPU_CHOL_PROBE) behind the one of the 64.  The
+      // tasks of the panel before it carry those columns instead (kFusedExt) when the two panels have the same row tiles outside the chain.
+      fext_of.assign(N, -1);
+      std::vector<uint8_t> is_app(N, 0);
+      if (allow_ext)
+        for (int ch = 0; ch < nch; ++ch) {
+          const int b0 = fchain_begin[ch], l = fchain_len[ch];
+          if (l < 2) continue;
+          const int te = b0 + l - 1, kb = te - 1;
+          if (nreal[te] < 1 || nreal[te] > kFusedExtCols || !B[(size_t)te * N + kb]) continue;
+          std::vector<int> ra, rb;
+          for (int a : rows[kb]) if (a > te) ra.push_back(a);
+          for (int a : rows[te]) if (a > te) rb.push_back(a);
+          if (ra != rb) continue;
+          fext_of[kb] = te; is_app[te] = 1;
+        }
       // depth of a chain: one more than the deepest chain that updates one of its tiles (S order is topological: rows(k) > k)
       std::vector<int> order_ch(nch), depth(nch, 0);
       for (int i = 0; i < nch; ++i) order_ch[i] = i;
@@ -385,13 +408,16 @@ struct DensePlan {
           for (int ch : order_ch) {
             if (depth[ch] != d || fchain_len[ch] <= qq) continue;
             const int k = fchain_begin[ch] + qq, cend = fchain_begin[ch] + fchain_len[ch];
+            if (is_app[k]) continue;   // (carried by the tasks of panel k - 1)
+            const int ext = fext_of[k];
             std::vector<FusedTask> st;
             for (int a : rows[k]) {
               if (a < cend) continue;                     // (both tiles inside the chain: the chain's own work)
               fused_flops += tile3;                        // one triangular solve per outside row tile
               for (int b2 : rows[k]) {
                 if (b2 > a) continue;
-                FusedTask f{k, a, b2, 0, 0, 0, -1, 0};
+                if (b2 == ext) continue;   // (the appendix's columns of row tile a are formed inside the tasks (k; a, .), not by an update of tile (a, k + 1))
+                FusedTask f{k, a, b2, ext >= 0 ? kFusedExt : 0, 0, 0, -1, 0};
                 if (b2 < cend) f.flags |= kFusedXjChain;
                 if (a == b2) f.flags |= kFusedPublishX;
                 if (!(a == T && b2 == T)) fused_flops += (a == b2 ? 1.0 : 2.0) * tile3;
@@ -441,10 +467,15 @@ struct DensePlan {
             for (int i = 0; i < f.ti; ++i) { fin_potrf[f.k + i] = st + chain0 + us * chain_steps(f.k, i + 1); chain_task[f.k + i] = t; }
             dur[t] = chain0 + us * chain_steps(f.k, f.ti);
           } else {
-            const bool diag = f.ti == f.tj, xj_chain = (f.flags & kFusedXjChain) != 0;
+            const bool diag = f.ti == f.tj, xj_chain = (f.flags & kFusedXjChain) != 0, ext = (f.flags & kFusedExt) != 0;
             double st = std::max(fin_potrf[f.k], fin_tile[(size_t)f.ti * N + f.k]);
             if (chain_task[f.k] >= 0) preds[t].push_back(chain_task[f.k]);
             if (last_writer[(size_t)f.ti * N + f.k] >= 0) preds[t].push_back(last_writer[(size_t)f.ti * N + f.k]);
+            if (ext) {   // (the appendix's factor and the row tiles' appendix columns)
+              st = std::max(st, std::max(fin_potrf[f.k + 1], std::max(fin_tile[(size_t)f.ti * N + f.k + 1], fin_tile[(size_t)f.tj * N + f.k + 1])));
+              if (last_writer[(size_t)f.ti * N + f.k + 1] >= 0) preds[t].push_back(last_writer[(size_t)f.ti * N + f.k + 1]);
+              if (last_writer[(size_t)f.tj * N + f.k + 1] >= 0) preds[t].push_back(last_writer[(size_t)f.tj * N + f.k + 1]);
+            }
             if (!diag && !xj_chain) {
               st = std::max(st, fin_tile[(size_t)f.tj * N + f.k]);
               if (last_writer[(size_t)f.tj * N + f.k] >= 0) preds[t].push_back(last_writer[(size_t)f.tj * N + f.k]);
@@ -455,7 +486,7 @@ struct DensePlan {
               if (diag_task[(size_t)f.tj * N + f.k] >= 0) preds[t].push_back(diag_task[(size_t)f.tj * N + f.k]);
             }
             start[t] = st;
-            double fin = st + dur_update;
+            double fin = st + dur_update + (ext ? 1.0 : 0.0);
             if (f.need_c >= 0) {
               if (last_writer[(size_t)f.ti * N + f.tj] >= 0) { fin = std::max(fin, fin_tile[(size_t)f.ti * N + f.tj] + t_turn); turn_pred[t] = last_writer[(size_t)f.ti * N + f.tj]; }
               fin_tile[(size_t)f.ti * N + f.tj] = fin; last_writer[(size_t)f.ti * N + f.tj] = t;
@@ -505,7 +536,7 @@ struct DensePlan {
         // update of a tile INSIDE a chain (then it solves its own strips and starts as soon as L_kk is out), or a task whose tj is
         // in the chain of k (its target is the panel tile of the chain's NEXT panels)
         const int chk = fchain_of_tile[f.k];
-        const bool last_panel = f.k + 1 == fchain_begin[chk] + fchain_len[chk];   // (the last panels of BOTH sides of a separator finish together)
+        const bool last_panel = f.k + 1 + ((f.flags & kFusedExt) ? 1 : 0) == fchain_begin[chk] + fchain_len[chk];   // (the last panels of BOTH sides of a separator finish together)
         const bool last_of_chain_tile = f.ti < T && fchain_of_tile[f.ti] == fchain_of_tile[f.tj] && (f.need_c + 1 == f.tot_c || last_panel);
         if (last_of_chain_tile || (f.flags & kFusedXjChain)) continue;
         f.flags |= kFusedXiLp | kFusedXjLp;

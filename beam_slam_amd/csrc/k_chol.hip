@@ -613,6 +613,21 @@ BSG_DEV long long uniform_i64(long long v) {
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
   return (long long)(((unsigned long long)hi << 32) | lo);
 }
+constexpr int kExtPitch = 18;   // doubles between two rows of a 16-column appendix block in LDS
+// the appendix columns of one 16-row strip (kFusedExt): sE strip (16 x 16) <- (sE strip - X strip L16^T) W16^T, X = the strip's solved
+// 64 columns (sX, pitch LDT), L16 = rows 0..15 of L(k + 1, k) (pitch LDT), W16 = the inverse of the appendix's 16 x 16 factor
+BSG_DEV void solve_ext_strip(const double* sX, double* sE, const double* sL16, const double* sW16, int lane, int strip) {
+  double* rows = sE + (16 * strip) * kExtPitch;
+  double4_t t = load_d(rows, kExtPitch, lane);
+  t = mfma_abt<64>(t, sX + (16 * strip) * LDT, LDT, sL16, LDT, -1.0, lane);
+  __builtin_amdgcn_wave_barrier();
+  store_d(rows, kExtPitch, lane, t);
+  __builtin_amdgcn_wave_barrier();
+  double4_t x = double4_t{0.0, 0.0, 0.0, 0.0};
+  x = mfma_abt<16>(x, rows, kExtPitch, sW16, kExtPitch, 1.0, lane);
+  __builtin_amdgcn_wave_barrier();
+  store_d(rows, kExtPitch, lane, x);
+}
 struct FusedCtx {
   double *S, *Lp, *Vinv, *scal;
   double* Winv;   // per tile: the full inverse of its factor: its diagonal 16x16 blocks are what the tasks' triangular solves multiply by,
@@ -644,8 +659,12 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
   double* sXi = smem;                 // 64 x LDT
   double* sXj = sXi + NB * LDT;       // 64 x LDT
   double* sL = sXj + NB * LDT;        // 64 x LDT
-  double* sV = sL + NB * LDT;         // 4 x 16 x kVtPitch
-  int* s_ctl = reinterpret_cast<int*>(sV + 4 * 16 * kVtPitch);   // 4 ints
+  // an APPENDIX tile's columns (kFusedExt, dense_plan.h): 16 columns of the two row tiles, the 16 x 64 block L(k + 1, k), the 16 x 16 inverse W_{k+1}
+  double* sEi = sL + NB * LDT;       // 64 x kExtPitch
+  double* sEj = sEi + NB * kExtPitch;
+  double* sL16 = sEj + NB * kExtPitch;   // 16 x LDT
+  double* sW16 = sL16 + 16 * LDT;        // 16 x kExtPitch
+  int* s_ctl = reinterpret_cast<int*>(sW16 + 16 * kExtPitch);   // 4 ints
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int N = ld / NB;
   // (buffer resources per TILE ROW — 64 rows of S or of the factor: a resource counts its bytes and its offsets in 32 bits, and the
@@ -664,6 +683,8 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
   const bool solve_i = !(tk.flags & kFusedXiLp);
   const bool solve_j = !diag && !(tk.flags & (kFusedXjLp | kFusedXjChain));
   const bool need_L = solve_i || solve_j;
+  const bool ext = (tk.flags & kFusedExt) != 0;   // (NT == 512 only: chol_fused_kernel)
+  const int te = k + 1;
   const int ri = __builtin_amdgcn_readfirstlane(ti * NB), rj = __builtin_amdgcn_readfirstlane(tj * NB), c0 = __builtin_amdgcn_readfirstlane(k * NB);
   const __amdgpu_buffer_rsrc_t rS_i = tile_rows(S, ri), rS_j = tile_rows(S, rj), rL_i = tile_rows(Lp, ri), rL_j = tile_rows(Lp, rj);
   // rows of the rhs tile (tile N-1 as row tile) beyond its used strips are zero and stay zero: no solve, no product, no traffic for them
@@ -677,6 +698,11 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
   if (tid == 0) {
     bool ok = wait_count(&upd[(ti * N + k) * fs], tk.tot_i + (solve_i ? 0 : 1), abort_w, deadline);
     if (!diag && !(tk.flags & kFusedXjChain)) ok = ok && wait_count(&upd[(tj * N + k) * fs], tk.tot_j + (solve_j ? 0 : 1), abort_w, deadline);
+    if (ext) {   // (the appendix columns of a tile this task solves must be final too; a published X carries them)
+      const int* tot = uniform_ptr(C.tile_tot);
+      if (solve_i) ok = ok && wait_count(&upd[(ti * N + te) * fs], tot[(size_t)ti * N + te], abort_w, deadline);
+      if (solve_j) ok = ok && wait_count(&upd[(tj * N + te) * fs], tot[(size_t)tj * N + te], abort_w, deadline);
+    }
     s_ctl[1] = ok ? 1 : 0;
     // ... and the C tile, if it is already this task's turn on it (on the critical path it is: the tile's earlier updaters are
     // panels that finished long ago): its values wait in registers through the solves, and the product accumulates onto them
@@ -700,9 +726,15 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
     vXi[q] = ld16_sc1(solve_i ? rS_i : rL_i, (unsigned)(((size_t)r * ld + c0 + c2) * sizeof(double)));
     if (!diag && !(tk.flags & kFusedXjChain)) vXj[q] = ld16_sc1(solve_j ? rS_j : rL_j, (unsigned)(((size_t)r * ld + c0 + c2) * sizeof(double)));
   }
+  double2 vEi = double2{0.0, 0.0}, vEj = double2{0.0, 0.0}, vL16 = double2{0.0, 0.0}, vW16 = double2{0.0, 0.0};
+  const int er = tid >> 3, ec2 = (tid & 7) * 2;   // this thread's piece of a 64 x 16 appendix block
+  if (ext) {
+    vEi = ld16_sc1(solve_i ? rS_i : rL_i, (unsigned)(((size_t)er * ld + c0 + NB + ec2) * sizeof(double)));
+    if (!diag) vEj = ld16_sc1(solve_j ? rS_j : rL_j, (unsigned)(((size_t)er * ld + c0 + NB + ec2) * sizeof(double)));
+  }
   __syncthreads();   // (s_ctl[1] is rewritten below)
   if (need_L || (tk.flags & kFusedXjChain)) {
-    if (tid == 0) s_ctl[1] = wait_count(&potrf_done[k * fs], 1, abort_w, deadline) ? 1 : 0;
+    if (tid == 0) s_ctl[1] = wait_count(&potrf_done[(ext ? te : k) * fs], 1, abort_w, deadline) ? 1 : 0;   // (a chain sets its tiles' flags in order)
     __syncthreads();
     if (__builtin_amdgcn_readfirstlane(s_ctl[1]) == 0) return false;
   }
@@ -720,6 +752,11 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
       const int i = tid + NT * q;
       vL[q] = ld16_sc1(rW, (unsigned)(((size_t)k * 4096 + (size_t)(i >> 5) * 64 + (i & 31) * 2) * sizeof(double)));   // W = L_kk^-1, the whole tile (solve_tile_w)
     }
+    if (ext) {   // rows 0..15 of L(k + 1, k) and the 16 x 16 inverse of the appendix's factor
+      const __amdgpu_buffer_rsrc_t rL_e = tile_rows(Lp, te * NB);
+      vL16 = ld16_sc1(rL_e, (unsigned)(((size_t)(tid >> 5) * ld + c0 + (tid & 31) * 2) * sizeof(double)));
+      if (tid < 128) vW16 = ld16_sc1(rW, (unsigned)(((size_t)te * 4096 + (size_t)er * 64 + ec2) * sizeof(double)));
+    }
   }
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
@@ -728,6 +765,14 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
     *reinterpret_cast<double2*>(&sXi[r * LDT + c2]) = vXi[q];
     if (need_L) *reinterpret_cast<double2*>(&sL[r * LDT + c2]) = vL[q];
     if (!diag) *reinterpret_cast<double2*>(&sXj[r * LDT + c2]) = vXj[q];
+  }
+  if (ext) {
+    *reinterpret_cast<double2*>(&sEi[er * kExtPitch + ec2]) = vEi;
+    if (!diag) *reinterpret_cast<double2*>(&sEj[er * kExtPitch + ec2]) = vEj;
+    if (need_L) {
+      *reinterpret_cast<double2*>(&sL16[(tid >> 5) * LDT + (tid & 31) * 2]) = vL16;
+      if (tid < 128) *reinterpret_cast<double2*>(&sW16[er * kExtPitch + ec2]) = vW16;
+    }
   }
   __syncthreads();
   stamp(3);
@@ -740,6 +785,11 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
       else if (solve_j) solve_tile_w(sXj, sL, lane, wave - 4);
     }
     __syncthreads();
+    if (ext) {   // X(., k + 1) = (A(., k + 1) - X(., k) L(k + 1, k)^T) W_{k+1}^T, strip by strip
+      if (wave < 4) { if (solve_i && wave < strips_i) solve_ext_strip(sXi, sEi, sL16, sW16, lane, wave); }
+      else if (solve_j) solve_ext_strip(sXj, sEj, sL16, sW16, lane, wave - 4);
+      __syncthreads();
+    }
   }
   stamp(4);
   if (tk.flags & kFusedPublishX) {
@@ -752,6 +802,8 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
       const int r = i >> 5, c2 = (i & 31) * 2;
       st16_sc1(rL_i, (unsigned)(((size_t)r * ld + c0 + c2) * sizeof(double)), *reinterpret_cast<const double2*>(&sXi[r * LDT + c2]));
     }
+    // (... with the appendix's 16 columns: the rest of that tile of the factor is the padding's zeros, which nothing ever writes)
+    if (ext) st16_sc1(rL_i, (unsigned)(((size_t)er * ld + c0 + NB + ec2) * sizeof(double)), *reinterpret_cast<const double2*>(&sEi[er * kExtPitch + ec2]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) atomicAdd(&upd[(ti * N + k) * fs], 1);
@@ -786,6 +838,12 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
 #pragma unroll
       for (int u = 0; u < TPW; ++u)
         acc[u] = mfma_abt<64>(acc[u], sXi + (16 * rs) * LDT, LDT, Xj + (16 * (tt0 + u)) * LDT, LDT, -1.0, lane);
+      if (ext) {
+        const double* Ej = diag ? sEi : sEj;
+#pragma unroll
+        for (int u = 0; u < TPW; ++u)
+          acc[u] = mfma_abt<16>(acc[u], sEi + (16 * rs) * kExtPitch, kExtPitch, Ej + (16 * (tt0 + u)) * kExtPitch, kExtPitch, -1.0, lane);
+      }
     }
     if (!c_early) {
       // this task's turn on the tile: every earlier update of it has been published
@@ -858,7 +916,7 @@ BSG_DEV bool chol_fused_chain(const FusedCtx& C, int t, const FusedTask& tk, dou
 }
 
 constexpr int kFusedThreads = 512;
-constexpr size_t kFusedLds = sizeof(double) * (3 * NB * LDT + 4 * 16 * kVtPitch + 8) > sizeof(double) * chain::chain_lds_doubles() ? sizeof(double) * (3 * NB * LDT + 4 * 16 * kVtPitch + 8)
+constexpr size_t kFusedLds = sizeof(double) * (3 * NB * LDT + 2 * NB * kExtPitch + 16 * LDT + 16 * kExtPitch + 8) > sizeof(double) * chain::chain_lds_doubles() ? sizeof(double) * (3 * NB * LDT + 2 * NB * kExtPitch + 16 * LDT + 16 * kExtPitch + 8)
                                                                                                                    : sizeof(double) * chain::chain_lds_doubles();
 
 template <bool PROBE>

@@ -79,7 +79,9 @@ static int check_ordered(std::mt19937& rng, unsigned seed) {
   return fails + replay(P, adjS, seed, -1);
 }
 
+static long g_ext_tasks = 0, g_ext_plans = 0;
 static int replay(const DensePlan& P, const std::vector<uint8_t>& adj, unsigned seed, int max_chains) {
+  { long n = 0; for (const FusedTask& f : P.ftasks) n += (f.flags & kFusedExt) ? 1 : 0; g_ext_tasks += n; g_ext_plans += n > 0; }
   const int T = P.T;
   const int N = P.T + 1;
   // scalar stand-in: every tile is ONE number; A = M M^T + shift restricted to the structure is not SPD-safe, so use a diagonally
@@ -135,14 +137,27 @@ static int replay(const DensePlan& P, const std::vector<uint8_t>& adj, unsigned 
     if (P.fchain_of_tile[k] >= 0 && i < P.T && P.fchain_of_tile[i] == P.fchain_of_tile[k]) fail("update task inside a chain", (int)t);
     const double xi = solve_i ? S[(size_t)i * N + k] / L[(size_t)k * N + k] : L[(size_t)i * N + k];
     const double xj = diag ? xi : (solve_j ? S[(size_t)j * N + k] / L[(size_t)k * N + k] : L[(size_t)j * N + k]);
+    // a panel that carries its chain's appendix tile k + 1 (kFusedExt): X(., k + 1) = (A(., k + 1) - X(., k) L(k + 1, k)) / L(k + 1, k + 1)
+    const bool ext = (f.flags & kFusedExt) != 0;
+    double xi_e = 0.0, xj_e = 0.0;
+    if (ext) {
+      const int te = k + 1;
+      if (P.fext_of[k] != te || P.fchain_of_tile[te] != P.fchain_of_tile[k]) fail("appendix of another chain", (int)t);
+      if (f.flags & kFusedXjChain) fail("appendix task inside the chain", (int)t);
+      if (!potrf_done[te] && (solve_i || solve_j)) fail("appendix not factored", (int)t);
+      if (solve_i && upd[(size_t)i * N + te] != P.tile_tot[(size_t)i * N + te]) fail("appendix columns of tile i not final", (int)t);
+      if (solve_j && upd[(size_t)j * N + te] != P.tile_tot[(size_t)j * N + te]) fail("appendix columns of tile j not final", (int)t);
+      xi_e = solve_i ? (S[(size_t)i * N + te] - xi * L[(size_t)te * N + k]) / L[(size_t)te * N + te] : L[(size_t)i * N + te];
+      xj_e = diag ? xi_e : (solve_j ? (S[(size_t)j * N + te] - xj * L[(size_t)te * N + k]) / L[(size_t)te * N + te] : L[(size_t)j * N + te]);
+    }
     if (!solve_i && !xpub[(size_t)i * N + k]) fail("X_i read before it was published", (int)t);
     if (!diag && (f.flags & kFusedXjLp) && !xpub[(size_t)j * N + k]) fail("X_j read before it was published", (int)t);
     if (f.need_c >= 0) {
       if (upd[(size_t)i * N + j] != f.need_c) fail("turn", (int)t);
-      S[(size_t)i * N + j] -= xi * xj;
+      S[(size_t)i * N + j] -= xi * xj + xi_e * xj_e;
       upd[(size_t)i * N + j]++;
     }
-    if (f.flags & kFusedPublishX) { L[(size_t)i * N + k] = xi; xpub[(size_t)i * N + k] = 1; upd[(size_t)i * N + k]++; }
+    if (f.flags & kFusedPublishX) { L[(size_t)i * N + k] = xi; xpub[(size_t)i * N + k] = 1; upd[(size_t)i * N + k]++; if (ext) L[(size_t)i * N + k + 1] = xi_e; }
   }
   for (int k = 0; k < P.T; ++k) if (!potrf_done[k]) fail("tile never factored", k);
   double emax = 0.0;
@@ -182,6 +197,8 @@ int main() {
   int ocases = 0, ofails = 0;
   for (int rep = 0; rep < 400; ++rep) { ofails += check_ordered(rng, (unsigned)rng()); ++ocases; }
   printf("%d ordered cases, %d failures\n", ocases, ofails);
+  printf("appendix tiles: %ld tasks in %ld plans\n", g_ext_tasks, g_ext_plans);
+  if (g_ext_plans < 20) { printf("too few plans with an appendix tile\n"); ++fails; }
   fails += ofails;
   return fails ? 1 : 0;
 }
