@@ -39,6 +39,7 @@ struct DimOrder {
   // chain of m tiles takes t_chain0 (its tiles' loads) + steps x t_step[m], the hand-over from a chain to the next one on the path (flag,
   // loads, strip solve, product, turn, publication, flag) t_hop.  Measured on C2 with (5, 2, 2.1, 4.5, 8 .. 16): 152-153 us per
   // factorisation for every hand-over value; with t_step3 = 3.5 (two leaves of three tiles survive) 159.5.
+  double t_hop_tile = 4.0;
   double t_chain0 = 5.0, t_step = 2.0, t_step2 = 2.1, t_step3 = 4.5, t_hop = 10.0;   // (t_step3: a chain of three tiles is bound by the MFMA rate of its ONE CU — and a leaf that long is the head of the critical path: priced so that the dissection avoids it)
   int max_depth = 5;
   double hub_frac = 0.6;
@@ -49,7 +50,10 @@ struct DimOrder {
     const int tiles = (dims + 63) / 64, chains = (tiles + 2) / 3;
     if (chains > 1) return (chains - 1) * (t_chain0 + 12 * t_step3 + t_hop) + node_cost(dims - 192 * (chains - 1));
     const double ts = tiles == 1 ? t_step : tiles == 2 ? t_step2 : t_step3;
-    return t_chain0 + ts * ((dims + 15) / 16) + t_hop;
+    // (a last tile of at most 16 real columns rides in the tasks of the tile before it — dense_plan.h kFusedExt —, any other second tile costs
+    //  the path a hand-over of its own: 151 -> 138 us per factorisation on C2, whose separators are 78 dimensions wide)
+    const bool appendix = tiles >= 2 && dims - 64 * (tiles - 1) <= 16;
+    return t_chain0 + ts * ((dims + 15) / 16) + t_hop + ((tiles >= 2 && !appendix) ? t_hop_tile : 0.0);
   }
 
   struct Node { std::vector<int> verts; int parent = -1, depth = 0, dims = 0; bool is_sep = false; };
