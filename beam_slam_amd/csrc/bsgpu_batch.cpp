@@ -154,11 +154,12 @@ struct BatchPlan {
   std::vector<void*> dev_allocs;
   BatchArgTable t_eval_x, t_eval_cand, t_eval_spec, t_lm, t_lm_tail, t_pairs, t_gn, t_chol, t_bs[4], t_backsub, t_reduce, t_accept, t_backup;
   std::vector<int> bs_form;
+  std::vector<char> diag_in_chol;    // the window's LM diagonal / gradient norms ride in its factorisation's launch
   void release() {
     for (void* p : dev_allocs) (void)hipFree(p);
     dev_allocs.clear();
     for (BatchArgTable* t : tables()) *t = BatchArgTable();
-    ctxs.clear(); gens.clear(); bs_form.clear(); xptr.clear(); backup.clear();
+    ctxs.clear(); gens.clear(); bs_form.clear(); diag_in_chol.clear(); xptr.clear(); backup.clear();
   }
   std::vector<BatchArgTable*> tables() {
     return {&t_eval_x, &t_eval_cand, &t_eval_spec, &t_lm, &t_lm_tail, &t_pairs, &t_gn, &t_chol, &t_bs[0], &t_bs[1], &t_bs[2], &t_bs[3], &t_backsub, &t_reduce, &t_accept, &t_backup};
@@ -213,6 +214,7 @@ bool build_plan(BatchPlan& P, bsgpu_ctx* const* ctxs, int n, const bsgpu_options
   if (!P.d_dyn && hipMalloc((void**)&P.d_dyn, sizeof(BatchDyn)) != hipSuccess) { (void)hipGetLastError(); P.d_dyn = nullptr; return false; }
   P.jacobi = o.jacobi_scaling; P.lm_lo = o.min_lm_diagonal; P.lm_hi = o.max_lm_diagonal;
   P.bs_form.assign(n, -1);
+  P.diag_in_chol.assign(n, 0);
   for (int w = 0; w < n; ++w) {
     bsgpu_ctx* c = ctxs[w];
     P.ctxs.push_back(c); P.gens.push_back(c->finalize_gen); P.xptr.push_back(c->d_x);
@@ -247,7 +249,18 @@ bool build_plan(BatchPlan& P, bsgpu_ctx* const* ctxs, int n, const bsgpu_options
                      c->d_bs_desc, c->d_chain_begin, c->d_chain_end, c->d_tile_sync, c->d_ftasks, c->d_fsync,
                      c->d_bs_desc_chain, c->d_rows_flat_chain, c->d_bs_upd, c->d_bs_upd_rows,
                      c->d_bs_chain_group, c->d_bs_grp_nchains, c->d_bs_grp_nitems, c->d_bs_items4, c->d_bs_tile_updated, c->d_bs_sync, c->d_scal, c->d_Winv, c->d_bs_order, c->d_tile_tot, 1};
-    batchargs_chol_fused(P.t_chol, c->d_S, D.Lp, c->plan.npad, D.ftasks, (int)c->plan.ftasks.size(), D.tile_tot, D.nreal, D.Vinv, c->d_scal, D.fsync, D.Winv, D.rhs_rows);
+    // (the LM diagonal and the gradient norms of a full step ride in the factorisation's launch when the window's plan has the tasks for them;
+    //  radius and the step's flags are patched in per round, BatchDyn)
+    P.diag_in_chol[w] = c->plan.diag_tasks && c->plan.rider_tasks * 256 >= c->nb;
+    LmDiag lmd;
+    GradNormRide gnr;
+    if (P.diag_in_chol[w]) {
+      lmd.hdiag = c->d_hdiag; lmd.scale = c->d_scale; lmd.dcl = c->d_dcl; lmd.inat = c->d_inat; lmd.jacobi = o.jacobi_scaling;
+      lmd.lm_lo = o.min_lm_diagonal; lmd.lm_hi = o.max_lm_diagonal;
+      gnr.nb = c->nb; gnr.xoff = c->d_blk_xoff; gnr.toff = c->d_blk_toff; gnr.size = c->d_blk_size; gnr.manifold = c->d_blk_manifold; gnr.x = c->d_x; gnr.grad = c->d_grad;
+      gnr.gpart = c->d_gpart;
+    }
+    batchargs_chol_fused(P.t_chol, c->d_S, D.Lp, c->plan.npad, D.ftasks, (int)c->plan.ftasks.size(), D.tile_tot, D.nreal, D.Vinv, c->d_scal, D.fsync, D.Winv, D.rhs_rows, lmd, gnr);
     P.bs_form[w] = batchargs_backsolve(P.t_bs, c->plan, D, c->d_y, c->d_inat, c->n_pose, c->d_ytan, c->d_delta);
     if (P.bs_form[w] < 0) return false;
     // landmark back-substitution + model cost change + candidate
@@ -285,6 +298,7 @@ void enqueue_round(BatchPlan& P, std::vector<LmWindow>& L, const std::vector<int
       const int list = (f < 2 ? BL_BS_FUSED : BL_BS_CHAIN) + (f & 1);
       d.idx[list][d.n[list]++] = w;
     }
+    if (lw.grad_only || !P.diag_in_chol[w]) d.idx[BL_DIAG][d.n[BL_DIAG]++] = w;
     if (lw.kind == K_ACCEPT) d.idx[BL_ACC][d.n[BL_ACC]++] = w; else d.idx[BL_REJ][d.n[BL_REJ]++] = w;   // (first steps evaluate at x like rejected ones)
     d.radius[w] = lw.radius;
     d.first[w] = lw.kind == K_FIRST ? 1 : 0;
@@ -300,7 +314,7 @@ void enqueue_round(BatchPlan& P, std::vector<LmWindow>& L, const std::vector<int
   launch_visual_imu_eval_batch(s, P.t_eval_x, dd, BL_REJ, d.n[BL_REJ], true);              // Jacobians at x (accepted windows have them: evaluated ahead)
   launch_landmark_batch(s, P.t_lm, P.t_lm_tail, dd, BL_ALL, d.n[BL_ALL]);
   launch_pairs_batch(s, P.t_pairs, dd, BL_ALL, d.n[BL_ALL]);
-  launch_grad_norms_pose_diag_batch(s, P.t_gn, dd, BL_ALL, d.n[BL_ALL]);
+  launch_grad_norms_pose_diag_batch(s, P.t_gn, dd, BL_DIAG, d.n[BL_DIAG]);   // (the others: in the factorisation's launch)
   if (d.n[BL_FULL] > 0) {
     launch_chol_fused_batch(s, P.t_chol, dd, BL_FULL, d.n[BL_FULL]);
     const int nf[4] = {d.n[BL_BS_FUSED], d.n[BL_BS_FUSED + 1], d.n[BL_BS_CHAIN], d.n[BL_BS_CHAIN + 1]};

@@ -233,6 +233,11 @@ struct bsgpu_ctx {
          *d_spart_pq = nullptr, *d_spart = nullptr, *d_ssc = nullptr;
   // in-situ phase timing (bsgpu_profile_step): when non-null, the step records one of these events at every phase boundary
   hipEvent_t* prof_events = nullptr;
+  // this step's LM diagonal and gradient norms are carried by the factorisation's launch (its diagonal / rider tasks, dense_plan.h) instead
+  // of a launch of their own between the assembly and the factorisation — decided per step by assemble()
+  bool diag_in_chol = false;
+  LmDiag lm_diag;
+  GradNormRide gn_ride;
   bool spec_J = false;   // residuals + Jacobians currently hold the CANDIDATE's (evaluated ahead of the accept/reject decision)
   int nbr = 0, nblk = 0, pcg_iters_total = 0;
   PcgPersistDev pcg_persist;     // G = 0: the launch-per-iteration path only
@@ -327,7 +332,8 @@ int build_spcg(bsgpu_ctx* c);
 // bsgpu_solve.cpp
 int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum);
 void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot);
-void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, bool first, bool gradient_only = false);
+// factor_follows: linear_solve_and_candidate() comes next — its factorisation launch may then carry the LM diagonal and the gradient norms
+void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, bool first, bool gradient_only = false, bool factor_follows = false);
 void final_reduce(bsgpu_ctx* c);
 int fetch_scalars(bsgpu_ctx* c);
 int ensure_vis_src(bsgpu_ctx* c);

@@ -128,6 +128,16 @@ BSG_DEV void pose_diag_element(int i, int n_pose, double* __restrict__ S, int ld
   }
 }
 
+// the LM diagonal of tangent column j, times 1 / radius (pose_diag_element without the store into S); writes the Jacobi scale / clamped
+// diagonal when this step (re)computes them
+BSG_DEV double lm_diag_value(int j, const LmDiag& D) {
+  const double h = D.hdiag[j];
+  const double sc = D.compute_scale ? (D.jacobi ? 1.0 / (1.0 + sqrt(h)) : 1.0) : D.scale[j];
+  const double d = D.compute_dcl ? fmin(fmax(sc * sc * h, D.lm_lo), D.lm_hi) / (sc * sc) : D.dcl[j];
+  if (D.compute_scale) D.scale[j] = sc;
+  if (D.compute_dcl) D.dcl[j] = d;
+  return d * D.inv_radius;
+}
 BSG_DEV double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -193,6 +203,43 @@ BSG_DEV double block_sum_256(double v, double* smem /* >= 4 doubles */) {
   if (threadIdx.x == 0) t = smem[0] + smem[1] + smem[2] + smem[3];
   __syncthreads();
   return t;
+}
+
+// One unit of 256 blocks of the gradient norms (grad_norms_kernel): max |x (+) (-g) - x| and its squared sum over the unit's blocks into
+// gpart[2 unit], gpart[2 unit + 1].  NT threads (a multiple of 64, >= 256; the threads beyond 256 only take part in the reduction);
+// sred / smax: NT / 64 doubles of LDS each.  Ends with every thread past a __syncthreads().
+template <int NT>
+BSG_DEV void grad_norms_unit(int unit, int tid, const GradNormRide& G, double* sred, double* smax) {
+  const int b = unit * 256 + tid;
+  double mx = 0.0, s2 = 0.0;
+  if (tid < 256 && b < G.nb) {
+    const int o = G.xoff[b], t = G.toff[b], sz = G.size[b];
+    if (t >= 0) {
+      const int mf = G.manifold[b];
+      const int ts = (mf == BSGPU_MANIFOLD_QUAT_RIGHT) ? 3 : sz;
+      double xin[4] = {0, 0, 0, 0}, din[4] = {0, 0, 0, 0}, out[4];
+      for (int i = 0; i < sz && i < 4; ++i) xin[i] = G.x[o + i];
+      for (int i = 0; i < ts && i < 4; ++i) din[i] = -G.grad[t + i];
+      block_plus(mf, sz, xin, din, out);
+      for (int i = 0; i < sz && i < 4; ++i) {
+        const double df = fabs(xin[i] - out[i]);
+        mx = fmax(mx, df); s2 += df * df;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+  s2 = wave_sum(s2);
+  if ((tid & 63) == 0) { smax[tid >> 6] = mx; sred[tid >> 6] = s2; }
+  __syncthreads();
+  if (tid == 0) {
+    // (fixed order: the waves of the first 256 threads hold everything, as in grad_norms_kernel — the same bits)
+    double m = 0.0;
+    for (int w = 0; w < 4; ++w) m = fmax(m, smax[w]);
+    G.gpart[2 * unit] = m;
+    G.gpart[2 * unit + 1] = sred[0] + sred[1] + sred[2] + sred[3];
+  }
+  __syncthreads();
 }
 
 // assembly of ONE factor of a pose-only group into the dense reduced system by the calling workgroup (`nthr` threads): J staged in LDS

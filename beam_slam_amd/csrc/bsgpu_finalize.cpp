@@ -869,7 +869,10 @@ int finalize(bsgpu_ctx* c) {
       if (c->tile_adj.size() != (size_t)T0 * T0) c->tile_adj.assign((size_t)T0 * T0, 0);
     }
     const char* e3 = getenv("BSGPU_SHARED");   // panels of one step may update the same tiles (atomics): on unless BSGPU_SHARED=0
-    { const char* ex = getenv("BSGPU_CHOL_EXT"); c->plan.allow_ext = !(ex && atoi(ex) == 0); }   // (0: every tile's panel has its own update tasks, also a separator's appendix tile)
+    { const char* ex = getenv("BSGPU_CHOL_EXT"); c->plan.allow_ext = !(ex && atoi(ex) == 0); }
+    // (the LM diagonal and the gradient norms as tasks of the factorisation's launch; BSGPU_POSE_DIAG_LAUNCH=1: their own launch, as before)
+    c->plan.diag_tasks = getenv("BSGPU_POSE_DIAG_LAUNCH") == nullptr;
+    c->plan.rider_tasks = c->plan.diag_tasks ? (c->nb + 255) / 256 : 0;   // (0: every tile's panel has its own update tasks, also a separator's appendix tile)
     const bool use_leaf = c->n_leaf_tiles > 0 && !getenv("BSGPU_NO_LEAF_TILES");
     bool ordered = false;
     lap("blocks");

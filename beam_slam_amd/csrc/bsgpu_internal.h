@@ -203,7 +203,7 @@ void launch_small_eval(hipStream_t s, const SmallGroup& g, const double* x, cons
 // these lists and whose arguments come from a per-window table in device memory.  The block below is what changes from one LM
 // iteration to the next; it goes up once per iteration.
 constexpr int kBatchMaxWin = 64;
-enum { BL_ALL = 0, BL_FULL = 1, BL_ACC = 2, BL_REJ = 3, BL_BS_FUSED = 4 /* + deep */, BL_BS_CHAIN = 6 /* + deep */, BL_NUM = 8 };   // (BL_BS_*: the FULL windows by the form of their back-substitution)
+enum { BL_ALL = 0, BL_FULL = 1, BL_ACC = 2, BL_REJ = 3, BL_BS_FUSED = 4 /* + deep */, BL_BS_CHAIN = 6 /* + deep */, BL_DIAG = 8 /* windows whose LM diagonal / gradient norms need their own launch this round */, BL_NUM = 9 };   // (BL_BS_*: the FULL windows by the form of their back-substitution)
 struct BatchDyn {
   int n[BL_NUM];                       // windows in: every window still iterating | those that compute a full step (not just the gradient
   int idx[BL_NUM][kBatchMaxWin];       // of their last point) | those whose candidate was accepted (x <- x_cand) | those whose step was
@@ -213,6 +213,21 @@ struct BatchDyn {
   int first[kBatchMaxWin], new_J[kBatchMaxWin], grad_only[kBatchMaxWin];
 };
 // device tables of the tiled Cholesky plan, as the factorisation / back-substitution entry points take them
+// What the fused factorisation's launch carries besides the factorisation (dense_plan.h kFusedDiagAdd / kFusedRider tasks): the LM
+// diagonal of the reduced system (pose_diag_kernel's work, per tile, as the FIRST update of every diagonal tile) and the gradient norms of
+// the step (grad_norms_kernel's work, as workgroups that nothing waits for) — a launch less on the dependent path of every LM step.
+struct LmDiag {
+  const double* hdiag = nullptr;   // null: S carries the LM diagonal already (the diagonal tasks only count themselves in)
+  double* scale = nullptr; double* dcl = nullptr;
+  const int* inat = nullptr;       // position in S -> tangent index (or -1)
+  double inv_radius = 0.0, lm_lo = 0.0, lm_hi = 0.0;
+  int compute_scale = 0, compute_dcl = 0, jacobi = 0;
+};
+struct GradNormRide {
+  int nb = 0;                      // 0: no norms this step
+  const int* xoff = nullptr; const int* toff = nullptr; const unsigned char* size = nullptr; const unsigned char* manifold = nullptr;
+  const double* x = nullptr; const double* grad = nullptr; double* gpart = nullptr;
+};
 struct DenseDev {
   const int *nreal, *rows_flat;
   const PanelDesc* panels;
@@ -231,6 +246,8 @@ struct DenseDev {
   const int* bs_order = nullptr;   // ticket -> role of the single-launch back-substitution (DensePlan::bs_order)
   const int* tile_tot = nullptr;   // fused factorisation: update tasks per tile (DensePlan::tile_tot)
   int rhs_rows = 0;                // rows of the rhs tile that are in use (the LM solve: 1); 0: every row may be
+  LmDiag diag;                     // what the factorisation's launch carries along (plans with diagonal / rider tasks)
+  GradNormRide gn;
 };
 // per-window argument table of one `_batch` kernel: entry w = the arguments window w's lone launch would pass (host image, then uploaded)
 struct BatchArgTable {
@@ -275,7 +292,7 @@ void launch_final_reduce_batch(hipStream_t s, const BatchArgTable& t, const Batc
 void batchargs_copy(BatchArgTable& t, const double* src, double* dst, int64_t n);
 void launch_copy_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n);
 void batchargs_chol_fused(BatchArgTable& t, double* S, double* Lp, int ld, const FusedTask* tasks_dev, int n_tasks, const int* tile_tot_dev, const int* nreal_dev,
-                          double* Vinv, double* scal, int* sync_dev, double* Winv, int rhs_rows);
+                          double* Vinv, double* scal, int* sync_dev, double* Winv, int rhs_rows, const LmDiag& diag, const GradNormRide& gn);
 void launch_chol_fused_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n);
 int batchargs_backsolve(BatchArgTable* tabs, const DensePlan& P, const DenseDev& D, double* y, const int* iperm, int n_pose, double* y_tan, double* delta);
 void launch_backsolve_batch(hipStream_t s, const BatchArgTable* tabs, const BatchDyn* dyn, const int* n_in_form);
@@ -306,7 +323,8 @@ void launch_grad_norms_pose_diag(hipStream_t s, int nb, const int* blk_xoff, con
 struct PanelDesc;
 struct FusedTask;
 void launch_chol_fused(hipStream_t s, double* S, double* Lp, int ld, const FusedTask* tasks_dev, int n_tasks, const int* tile_tot_dev, const int* nreal_dev,
-                       double* Vinv, double* scal, int* sync_dev, double* Winv, int rhs_rows /* rows of the rhs tile in use; <= 0: all 64 */);
+                       double* Vinv, double* scal, int* sync_dev, double* Winv, int rhs_rows /* rows of the rhs tile in use; <= 0: all 64 */,
+                       const LmDiag& diag = LmDiag(), const GradNormRide& gn = GradNormRide());
 void launch_chol_potrf_tiles(hipStream_t s, double* S, double* Lp, int ld, const int* tiles_dev, int n_tiles, const int* nreal_dev,
                              double* Vinv, double* scal);
 void launch_chol_panel_step(hipStream_t s, double* S, double* Lp, int ld, const PanelDesc* descs_dev, int n_panels, int max_rows,

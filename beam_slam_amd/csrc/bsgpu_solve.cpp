@@ -214,7 +214,7 @@ void final_reduce(bsgpu_ctx* c) {
 
 // gradient_only: the caller wants the gradient (and its norms) of the current point and will not factorise — the
 // camera-pair blocks of the reduced system, four fifths of the pair kernel's work, are skipped
-void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, bool first, bool gradient_only) {
+void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, bool first, bool gradient_only, bool factor_follows) {
   if (c->use_pcg) { assemble_pcg(c, o, radius, new_J, first); return; }
   hipStream_t s = c->stream;
   // one launch clears the reduced system, gradient, diagonal and the scalars of this step (GRAD_MAX, GRAD_NORM2, CHOL_FAIL)
@@ -259,7 +259,23 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
   }
   for (const auto& mc : c->marg)
     if (mc.active) launch_marg_assemble(s, mc.dev, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_dpos);
-  if (new_J)   // the LM diagonal and the gradient norms both follow the assembly and do not depend on each other: one launch
+  // With the single-launch factorisation next, neither needs a launch of its own on the dependent path: its plan has one task per tile that
+  // adds the LM diagonal as the tile's first update, and the gradient norms — which only the end-of-step reduction reads — are units of
+  // work of the same launch (dense_plan.h kFusedDiagAdd / kFusedRider; BSGPU_POSE_DIAG_LAUNCH=1 plans without them).
+  c->diag_in_chol = factor_follows && !gradient_only && !c->use_graphs && !c->use_spcg && c->dense_ok && c->n_pose > 0 && c->plan.diag_tasks &&
+                    c->plan.rider_tasks * 256 >= c->nb && c->d_ftasks && c->d_fsync && c->d_tile_tot && c->d_Winv;
+  c->lm_diag = LmDiag(); c->gn_ride = GradNormRide();
+  if (c->diag_in_chol) {
+    LmDiag& d = c->lm_diag;
+    d.hdiag = c->d_hdiag; d.scale = c->d_scale; d.dcl = c->d_dcl; d.inat = c->d_inat;
+    d.inv_radius = 1.0 / radius; d.lm_lo = o.min_lm_diagonal; d.lm_hi = o.max_lm_diagonal;
+    d.compute_scale = first ? 1 : 0; d.compute_dcl = new_J ? 1 : 0; d.jacobi = o.jacobi_scaling;
+    if (new_J) {
+      GradNormRide& g = c->gn_ride;
+      g.nb = c->nb; g.xoff = c->d_blk_xoff; g.toff = c->d_blk_toff; g.size = c->d_blk_size; g.manifold = c->d_blk_manifold; g.x = c->d_x; g.grad = c->d_grad;
+      g.gpart = c->d_gpart;
+    }
+  } else if (new_J)   // the LM diagonal and the gradient norms both follow the assembly and do not depend on each other: one launch
     launch_grad_norms_pose_diag(s, c->nb, c->d_blk_xoff, c->d_blk_toff, c->d_blk_size, c->d_blk_manifold, c->d_x, c->d_grad, c->d_gpart,
                                 c->n_pose, c->d_S, c->npad, c->d_hdiag, cleared ? nullptr : c->d_scal + SC_RADIUS, first ? 1 : 0, 1, o.jacobi_scaling,
                                 o.min_lm_diagonal, o.max_lm_diagonal, c->d_scale, c->d_dcl, c->npad, c->d_inat, radius);
@@ -272,7 +288,7 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
 void dense_factor(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* scal) {
   const int ld = P.npad;
   if (D.ftasks && D.fsync && D.tile_tot && D.Winv) {   // the whole factorisation in one launch
-    launch_chol_fused(s, S, D.Lp, ld, D.ftasks, (int)P.ftasks.size(), D.tile_tot, D.nreal, D.Vinv, scal, D.fsync, D.Winv, D.rhs_rows);
+    launch_chol_fused(s, S, D.Lp, ld, D.ftasks, (int)P.ftasks.size(), D.tile_tot, D.nreal, D.Vinv, scal, D.fsync, D.Winv, D.rhs_rows, D.diag, D.gn);
     return;
   }
   for (int st = 0; st < P.n_steps(); ++st) {
@@ -333,10 +349,11 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
     phase_mark(c, BSGPU_PHASE_FACTOR);
     phase_mark(c, BSGPU_PHASE_BACKSOLVE);
   } else if (c->n_pose > 0) {
-    const DenseDev D{c->d_nreal, c->d_rows_flat, c->d_panels, c->d_Lp, c->d_Vinv,
-                     c->d_bs_desc, c->d_chain_begin, c->d_chain_end, c->d_tile_sync, c->d_ftasks, c->d_fsync,
-                     c->d_bs_desc_chain, c->d_rows_flat_chain, c->d_bs_upd, c->d_bs_upd_rows,
-                     c->d_bs_chain_group, c->d_bs_grp_nchains, c->d_bs_grp_nitems, c->d_bs_items4, c->d_bs_tile_updated, c->d_bs_sync, c->d_scal, c->d_Winv, c->d_bs_order, c->d_tile_tot, 1};
+    DenseDev D{c->d_nreal, c->d_rows_flat, c->d_panels, c->d_Lp, c->d_Vinv,
+               c->d_bs_desc, c->d_chain_begin, c->d_chain_end, c->d_tile_sync, c->d_ftasks, c->d_fsync,
+               c->d_bs_desc_chain, c->d_rows_flat_chain, c->d_bs_upd, c->d_bs_upd_rows,
+               c->d_bs_chain_group, c->d_bs_grp_nchains, c->d_bs_grp_nitems, c->d_bs_items4, c->d_bs_tile_updated, c->d_bs_sync, c->d_scal, c->d_Winv, c->d_bs_order, c->d_tile_tot, 1};
+    if (c->diag_in_chol) { D.diag = c->lm_diag; D.gn = c->gn_ride; }
     dense_factor(s, c->plan, D, c->d_S, c->d_scal);
     phase_mark(c, BSGPU_PHASE_FACTOR);
     dense_backsolve(s, c->plan, D, c->d_S, c->d_y, c->d_inat, c->n_pose, c->d_ytan, c->d_delta);
@@ -411,7 +428,7 @@ void enqueue_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius,
   const bool have_J = (kind == STEP_ACCEPT && c->spec_J) || (kind == STEP_REJECT && !c->spec_J);
   if (!have_J) eval_all(c, c->d_x, true, SC_COST_X);
   c->spec_J = false;
-  assemble(c, o, radius, kind != STEP_REJECT, kind == STEP_FIRST, gradient_only);
+  assemble(c, o, radius, kind != STEP_REJECT, kind == STEP_FIRST, gradient_only, /*factor_follows=*/true);
   if (gradient_only) { final_reduce(c); return; }
   linear_solve_and_candidate(c, o);
   // The host now waits for this step's scalars and decides; in the common case (accepted) the next thing the device needs is the

@@ -58,6 +58,9 @@ constexpr int kFusedExt = 32;       // panel k carries its chain's APPENDIX tile
                                     // forms X(., k + 1) = (A(., k + 1) - X(., k) L(k + 1, k)^T) W_{k+1}^T of its row tiles and its product runs over both —
                                     // the appendix has no update tasks of its own, and the tiles (., k + 1) are not updated by panel k
 constexpr int kFusedExtCols = 16;
+constexpr int kFusedDiagAdd = 64;   // k = ti = tj = a tile: the LM diagonal of its real columns is added to S (LmDiag, bsgpu_internal.h) — the FIRST update of
+                                    // every diagonal tile (need_c = 0), so the chains and the other updates of the tile come after it by the tile's counter
+constexpr int kFusedRider = 128;    // k = unit of independent work carried by the launch (the step's gradient norms): nothing waits for it
 constexpr int kChainMaxTiles = 3;   // == chain::kChainMaxTiles (chol_chain.h)
 
 struct DensePlan {
@@ -95,6 +98,8 @@ struct DensePlan {
   std::vector<int> fchain_begin, fchain_len, fchain_of_tile;   // the chains of the fused factorisation
   std::vector<int> fext_of;           // T+1: the appendix tile panel k carries (kFusedExt), or -1
   bool allow_ext = true;              // (finalize: BSGPU_CHOL_EXT=0 plans every tile's panel by itself)
+  bool diag_tasks = false;            // one kFusedDiagAdd task per tile at the head of the list
+  int rider_tasks = 0;                // kFusedRider tasks behind them
   int fused_sync_words = 0;   // ints of device scratch: ([queue head | abort | exited workgroups | potrf_done (T+1) | update counts (T+1)^2]) x 16
   double fused_flops = 0.0;   // FP64 flops of the planned factorisation (trsm + rank-64 updates + potrf of every touched tile), for the MFMA roofline
   // solve offsets
@@ -391,6 +396,13 @@ struct DensePlan {
           for (int t : rows[k]) if (t < T && fchain_of_tile[t] != ch) { depth[fchain_of_tile[t]] = std::max(depth[fchain_of_tile[t]], depth[ch] + 1); max_depth = std::max(max_depth, depth[fchain_of_tile[t]]); }
       tile_tot.assign((size_t)N * N, 0);
       std::vector<int> seen((size_t)N * N, 0);
+      if (diag_tasks)
+        for (int t = 0; t < T; ++t) {
+          FusedTask f{t, t, t, kFusedDiagAdd, 0, 0, 0, 0};
+          seen[(size_t)t * N + t] = 1; tile_tot[(size_t)t * N + t] = 1;
+          ftasks.push_back(f);
+        }
+      for (int u = 0; u < rider_tasks; ++u) ftasks.push_back(FusedTask{u, 0, 0, kFusedRider, 0, 0, -1, 0});
       fused_flops = 0.0;
       const double tile3 = 64.0 * 64.0 * 64.0;
       for (int d = 0; d <= max_depth; ++d) {
@@ -456,6 +468,11 @@ struct DensePlan {
         std::vector<std::vector<int>> preds(nt);
         for (int t = 0; t < nt; ++t) {   // (list order: every dependency of task t has been seen)
           const FusedTask& f = ftasks[t];
+          if (f.flags & (kFusedDiagAdd | kFusedRider)) {   // (start at once, a few microseconds: a diagonal task is the first writer of its tile)
+            start[t] = 0.0; dur[t] = 3.0;
+            if (f.flags & kFusedDiagAdd) { fin_tile[(size_t)f.k * N + f.k] = 3.0; last_writer[(size_t)f.k * N + f.k] = t; }
+            continue;
+          }
           if (f.flags & kFusedChain) {
             double st = 0.0;
             for (int i = 0; i < f.ti; ++i) for (int j = 0; j <= i; ++j) {
@@ -527,7 +544,8 @@ struct DensePlan {
       }
       const bool fetch_x = true;   // (off-diagonal tasks read the X their diagonal tasks publish: one solve per (panel, row tile) instead of one per task)
       for (FusedTask& f : ftasks) {
-        if (f.flags & kFusedChain) continue;
+        if (f.flags & (kFusedChain | kFusedRider)) continue;
+        if (f.flags & kFusedDiagAdd) { f.tot_c = tile_tot[(size_t)f.k * N + f.k]; continue; }
         f.tot_i = tile_tot[(size_t)f.ti * N + f.k];
         f.tot_j = tile_tot[(size_t)f.tj * N + f.k];
         f.tot_c = (f.need_c >= 0) ? tile_tot[(size_t)f.ti * N + f.tj] : 0;

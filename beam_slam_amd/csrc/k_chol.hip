@@ -920,7 +920,7 @@ constexpr size_t kFusedLds = sizeof(double) * (3 * NB * LDT + 2 * NB * kExtPitch
                                                                                                                    : sizeof(double) * chain::chain_lds_doubles();
 
 template <bool PROBE>
-__device__ __forceinline__ void chol_fused_kernel_body(const int bsg_bx, const int bsg_gx, double* __restrict__ S, double* __restrict__ Lp, int ld, const FusedTask* __restrict__ tasks, int n_tasks, const int* __restrict__ tile_tot, const int* __restrict__ nreal, double* __restrict__ Vinv, double* __restrict__ scal, int* sync, double* Winv, int fs, int rhs_strips, long long* probe_ts) {
+__device__ __forceinline__ void chol_fused_kernel_body(const int bsg_bx, const int bsg_gx, double* __restrict__ S, double* __restrict__ Lp, int ld, const FusedTask* __restrict__ tasks, int n_tasks, const int* __restrict__ tile_tot, const int* __restrict__ nreal, double* __restrict__ Vinv, double* __restrict__ scal, int* sync, double* Winv, int fs, int rhs_strips, const LmDiag& diag, const GradNormRide& gn, long long* probe_ts) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   __shared__ int s_head[4];
   const int tid = threadIdx.x;
@@ -946,7 +946,25 @@ __device__ __forceinline__ void chol_fused_kernel_body(const int bsg_bx, const i
     tk.k = __builtin_amdgcn_readfirstlane(tk.k); tk.ti = __builtin_amdgcn_readfirstlane(tk.ti); tk.tj = __builtin_amdgcn_readfirstlane(tk.tj);
     tk.flags = __builtin_amdgcn_readfirstlane(tk.flags); tk.tot_i = __builtin_amdgcn_readfirstlane(tk.tot_i); tk.tot_j = __builtin_amdgcn_readfirstlane(tk.tot_j);
     tk.need_c = __builtin_amdgcn_readfirstlane(tk.need_c); tk.tot_c = __builtin_amdgcn_readfirstlane(tk.tot_c);
-    if (tk.flags & kFusedChain) (void)chol_fused_chain<PROBE>(C, t, tk, smem);
+    if (tk.flags & kFusedRider) {
+      // a unit of the step's gradient norms (grad_norms_kernel's work: nothing in this launch waits for it, the end-of-step reduction reads it)
+      if (gn.nb > 0 && tk.k * 256 < gn.nb) grad_norms_unit<kFusedThreads>(tk.k, tid, gn, smem, smem + 8);
+    } else if (tk.flags & kFusedDiagAdd) {
+      // the LM diagonal of tile k's real columns (pose_diag_kernel's work), the tile's first update: the stores go out write-through like every
+      // update's, then the tile's counter
+      if (tid < NB && diag.hdiag) {
+        const int pos = tk.k * NB + tid;
+        const int j = diag.inat[pos];
+        if (j >= 0) {
+          const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(S) + (size_t)tk.k * NB * ld, 0, (int)((size_t)NB * ld * sizeof(double)), 0x00020000);
+          const unsigned off = (unsigned)(((size_t)tid * ld + pos) * sizeof(double));
+          st8_sc1(rS, off, ld8_sc1(rS, off) + lm_diag_value(j, diag));
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) atomicAdd(&C.upd[(tk.k * N + tk.k) * fs], 1);
+    } else if (tk.flags & kFusedChain) (void)chol_fused_chain<PROBE>(C, t, tk, smem);
     else (void)chol_fused_update<PROBE, kFusedThreads>(C, t, tk, smem);
   }
   // leave: the last workgroup out re-zeroes the queue and the counters for the next factorisation
@@ -962,8 +980,8 @@ __device__ __forceinline__ void chol_fused_kernel_body(const int bsg_bx, const i
   }
 }
 template <bool PROBE>
-__global__ __launch_bounds__(kFusedThreads) void chol_fused_kernel(double* __restrict__ S, double* __restrict__ Lp, int ld, const FusedTask* __restrict__ tasks, int n_tasks, const int* __restrict__ tile_tot, const int* __restrict__ nreal, double* __restrict__ Vinv, double* __restrict__ scal, int* sync, double* Winv, int fs, int rhs_strips, long long* probe_ts = nullptr) {
-  chol_fused_kernel_body<PROBE>((int)blockIdx.x, (int)gridDim.x, S, Lp, ld, tasks, n_tasks, tile_tot, nreal, Vinv, scal, sync, Winv, fs, rhs_strips, probe_ts);
+__global__ __launch_bounds__(kFusedThreads) void chol_fused_kernel(double* __restrict__ S, double* __restrict__ Lp, int ld, const FusedTask* __restrict__ tasks, int n_tasks, const int* __restrict__ tile_tot, const int* __restrict__ nreal, double* __restrict__ Vinv, double* __restrict__ scal, int* sync, double* Winv, int fs, int rhs_strips, LmDiag diag, GradNormRide gn, long long* probe_ts = nullptr) {
+  chol_fused_kernel_body<PROBE>((int)blockIdx.x, (int)gridDim.x, S, Lp, ld, tasks, n_tasks, tile_tot, nreal, Vinv, scal, sync, Winv, fs, rhs_strips, diag, gn, probe_ts);
 }
 // one launch over several windows (bsgpu_batch.cpp): blockIdx.y picks the window of list `bsg_list`, its arguments come from memory
 struct chol_fused_kernel_Args {
@@ -982,6 +1000,8 @@ struct chol_fused_kernel_Args {
   int fs;
   int rhs_strips;
   long long* probe_ts;
+  LmDiag diag;        // (radius and the step's flags: per round, BatchDyn)
+  GradNormRide gn;
 };
 // (the same entry as the kernel reads it: its pointers are GLOBAL pointers — read as generic ones every load through them would be a FLAT
 // instruction, which also counts against the LDS counter and serialises the kernels that overlap gathers with LDS traffic)
@@ -1001,6 +1021,8 @@ struct chol_fused_kernel_ArgsG {
   int fs;
   int rhs_strips;
   long long __attribute__((address_space(1)))* probe_ts;
+  LmDiag diag;
+  GradNormRide gn;
 };
 static_assert(sizeof(chol_fused_kernel_ArgsG) == sizeof(chol_fused_kernel_Args), "layout");
 
@@ -1009,7 +1031,11 @@ __global__ __launch_bounds__(kFusedThreads) void chol_fused_kernel_batch(const c
   const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.x];
   const chol_fused_kernel_ArgsG& a = reinterpret_cast<const chol_fused_kernel_ArgsG*>(bsg_A)[bsg_w];
   if ((int)blockIdx.y >= a.bsg_grid) return;   // (windows interleaved in dispatch order: x = window, y = the window's workgroup — the workgroups of ALL windows take their tickets side by side)
-  chol_fused_kernel_body<PROBE>((int)blockIdx.y, a.bsg_grid, (double*)a.S, (double*)a.Lp, a.ld, (const FusedTask*)a.tasks, a.n_tasks, (const int*)a.tile_tot, (const int*)a.nreal, (double*)a.Vinv, (double*)a.scal, (int*)a.sync, (double*)a.Winv, a.fs, a.rhs_strips, (long long*)a.probe_ts);
+  LmDiag diag = a.diag;   // (small: patched copies; the rest of the entry is read in place)
+  diag.inv_radius = 1.0 / bsg_dyn->radius[bsg_w]; diag.compute_scale = bsg_dyn->first[bsg_w]; diag.compute_dcl = bsg_dyn->new_J[bsg_w];
+  GradNormRide gn = a.gn;
+  if (!bsg_dyn->new_J[bsg_w]) gn.nb = 0;
+  chol_fused_kernel_body<PROBE>((int)blockIdx.y, a.bsg_grid, (double*)a.S, (double*)a.Lp, a.ld, (const FusedTask*)a.tasks, a.n_tasks, (const int*)a.tile_tot, (const int*)a.nreal, (double*)a.Vinv, (double*)a.scal, (int*)a.sync, (double*)a.Winv, a.fs, a.rhs_strips, diag, gn, (long long*)a.probe_ts);
 }
 // ints between two words of the sync area: 16 = a 64-byte line each (packed words of one line that different workgroups write are
 // serialised at the memory side: 270 -> 237 us per C2 factorisation when they were moved apart, round 2)
@@ -1018,7 +1044,7 @@ int fused_sync_stride() {
 }
 
 void launch_chol_fused(hipStream_t s, double* S, double* Lp, int ld, const FusedTask* tasks_dev, int n_tasks, const int* tile_tot_dev, const int* nreal_dev,
-                       double* Vinv, double* scal, int* sync_dev, double* Winv, int rhs_rows) {
+                       double* Vinv, double* scal, int* sync_dev, double* Winv, int rhs_rows, const LmDiag& diag, const GradNormRide& gn) {
   const int rhs_strips = rhs_rows <= 0 ? 4 : std::min(4, (rhs_rows + 15) / 16);
   if (n_tasks <= 0) return;
   const int grid = n_tasks;   // one workgroup per task (about 100 KB of LDS each: one per CU is resident, the rest queue behind them)
@@ -1033,7 +1059,7 @@ void launch_chol_fused(hipStream_t s, double* S, double* Lp, int ld, const Fused
     if (hipMalloc((void**)&ts, sizeof(long long) * h.size()) == hipSuccess) {
       (void)hipMemset(ts, 0, sizeof(long long) * h.size());
       hipLaunchKernelGGL((chol_fused_kernel<true>), dim3(grid), dim3(kFusedThreads), kFusedLds, s, S, Lp, ld, tasks_dev, n_tasks, tile_tot_dev, nreal_dev, Vinv,
-                         scal, sync_dev, Winv, fused_sync_stride(), rhs_strips, ts);
+                         scal, sync_dev, Winv, fused_sync_stride(), rhs_strips, diag, gn, ts);
       (void)hipStreamSynchronize(s);
       (void)hipMemcpy(h.data(), ts, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
       (void)hipMemcpy(ht.data(), tasks_dev, sizeof(FusedTask) * ht.size(), hipMemcpyDeviceToHost);
@@ -1051,7 +1077,7 @@ void launch_chol_fused(hipStream_t s, double* S, double* Lp, int ld, const Fused
     }
   }
   hipLaunchKernelGGL((chol_fused_kernel<false>), dim3(grid), dim3(kFusedThreads), kFusedLds, s, S, Lp, ld, tasks_dev, n_tasks, tile_tot_dev, nreal_dev, Vinv, scal,
-                     sync_dev, Winv, fused_sync_stride(), rhs_strips, nullptr);
+                     sync_dev, Winv, fused_sync_stride(), rhs_strips, diag, gn, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1693,11 +1719,12 @@ void launch_chol_backsolve_update(hipStream_t s, const double* Lp, int ld, const
 // ---- the factorisation and the back-substitution of several windows in one launch each (bsgpu_batch.cpp): every window keeps its own
 // task list, ticket and counters — a workgroup of window w takes window w's next ticket
 void batchargs_chol_fused(BatchArgTable& t, double* S, double* Lp, int ld, const FusedTask* tasks_dev, int n_tasks, const int* tile_tot_dev, const int* nreal_dev,
-                          double* Vinv, double* scal, int* sync_dev, double* Winv, int rhs_rows) {
+                          double* Vinv, double* scal, int* sync_dev, double* Winv, int rhs_rows, const LmDiag& diag, const GradNormRide& gn) {
   chol_fused_kernel_Args a;
   a.bsg_grid = n_tasks;
   a.S = S; a.Lp = Lp; a.ld = ld; a.tasks = tasks_dev; a.n_tasks = n_tasks; a.tile_tot = tile_tot_dev; a.nreal = nreal_dev; a.Vinv = Vinv; a.scal = scal;
   a.sync = sync_dev; a.Winv = Winv; a.fs = fused_sync_stride(); a.rhs_strips = rhs_rows <= 0 ? 4 : std::min(4, (rhs_rows + 15) / 16); a.probe_ts = nullptr;
+  a.diag = diag; a.gn = gn;
   t.push(a);
   t.lds = kFusedLds;
 }

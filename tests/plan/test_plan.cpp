@@ -16,6 +16,7 @@ static int replay(const DensePlan& P, const std::vector<uint8_t>& adjS /* P.T x 
 static int check(int T, const std::vector<uint8_t>& adj, int max_chains, const std::vector<uint8_t>* leaf, unsigned seed) {
   DensePlan P;
   const int n_pose = T * 64 - (seed % 3 == 0 ? 23 : 0);
+  if (seed % 2) { P.diag_tasks = true; P.rider_tasks = (int)(seed % 4); }
   P.build(n_pose, adj, max_chains, 1, true, leaf);
   std::vector<uint8_t> adjS((size_t)P.T * P.T, 0);
   for (int i = 0; i < P.T; ++i) for (int j = 0; j < P.T; ++j) if (adj[(size_t)i * P.T + j]) adjS[(size_t)P.perm[i] * P.T + P.perm[j]] = 1;
@@ -74,12 +75,13 @@ static int check_ordered(std::mt19937& rng, unsigned seed) {
   for (int a = 0; a < nbk; ++a) for (int b = 0; b < nbk; ++b) if (A[a][b] || a == b)
     for (int ka = 0; ka < o.blk_w[a]; ++ka) for (int kb = 0; kb < o.blk_w[b]; ++kb) adjS[(size_t)(o.dpos[o.blk_t0[a] + ka] >> 6) * o.T + (o.dpos[o.blk_t0[b] + kb] >> 6)] = 1;
   DensePlan P;
+  if (seed % 2) { P.diag_tasks = true; P.rider_tasks = 1 + (int)(seed % 5); }   // (the LM diagonal / gradient norms carried by the launch)
   P.build_ordered(o.n_pose, o.T, o.dpos, o.nreal, adjS, o.piece_ranges, o.sep_ranges_by_level);
   if (!o.sep_ranges_by_level.empty() && !P.bs_level_sync && P.bs_group_off.size() > 2) fail("the by-level back-substitution groups were refused");
   return fails + replay(P, adjS, seed, -1);
 }
 
-static long g_ext_tasks = 0, g_ext_plans = 0;
+static long g_ext_tasks = 0, g_ext_plans = 0, g_diag_tasks = 0;
 static int replay(const DensePlan& P, const std::vector<uint8_t>& adj, unsigned seed, int max_chains) {
   { long n = 0; for (const FusedTask& f : P.ftasks) n += (f.flags & kFusedExt) ? 1 : 0; g_ext_tasks += n; g_ext_plans += n > 0; }
   const int T = P.T;
@@ -109,6 +111,15 @@ static int replay(const DensePlan& P, const std::vector<uint8_t>& adj, unsigned 
   auto fail = [&](const char* what, int t) { if (fails++ < 5) printf("  FAIL %s at task %d\n", what, t); };
   for (size_t t = 0; t < P.ftasks.size(); ++t) {
     const FusedTask& f = P.ftasks[t];
+    if (f.flags & kFusedRider) { if (f.k < 0 || f.k >= P.rider_tasks) fail("rider unit", (int)t); continue; }
+    if (f.flags & kFusedDiagAdd) {   // the LM diagonal of a tile: its first update, nothing to wait for
+      if (!P.diag_tasks || f.k != f.ti || f.k != f.tj || f.k >= P.T || f.need_c != 0) fail("diagonal task", (int)t);
+      if (upd[(size_t)f.k * N + f.k] != 0) fail("diagonal task is not the tile's first update", (int)t);
+      if (potrf_done[f.k]) fail("diagonal task after its tile was factored", (int)t);
+      upd[(size_t)f.k * N + f.k]++;
+      ++g_diag_tasks;
+      continue;
+    }
     if (f.flags & kFusedChain) {
       const int b0 = f.k, m = f.ti;
       if (m < 1 || m > kChainMaxTiles) fail("chain length", (int)t);
@@ -199,6 +210,8 @@ int main() {
   printf("%d ordered cases, %d failures\n", ocases, ofails);
   printf("appendix tiles: %ld tasks in %ld plans\n", g_ext_tasks, g_ext_plans);
   if (g_ext_plans < 20) { printf("too few plans with an appendix tile\n"); ++fails; }
+  printf("diagonal tasks: %ld\n", g_diag_tasks);
+  if (g_diag_tasks < 1000) { printf("too few diagonal tasks\n"); ++fails; }
   fails += ofails;
   return fails ? 1 : 0;
 }
