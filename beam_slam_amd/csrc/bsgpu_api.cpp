@@ -768,6 +768,7 @@ static int covariance_of(bsgpu_ctx* c, const std::vector<int>& blocks, double* o
     DenseDev D0{c->d_nreal, c->d_rows_flat, c->d_panels, c->d_Lp, c->d_Vinv,
                 c->d_bs_desc, c->d_chain_begin, c->d_chain_end, c->d_tile_sync, c->d_ftasks, c->d_fsync};
     D0.Winv = c->d_Winv; D0.tile_tot = c->d_tile_tot; D0.rhs_rows = D;
+    D0.ftasks_plain = c->d_ftasks_plain; D0.tile_tot_plain = c->d_tile_tot_plain; D0.n_ftasks_plain = c->n_ftasks_plain;
     dense_factor(s, c->plan, D0, c->d_S, c->d_scal);
     launch_cov_dots(s, c->d_Lp, c->npad, c->plan.rhs_row, c->plan.T * 64, D, 0, D, d_out);
     (void)hipMemcpyAsync(out, d_out, sizeof(double) * D * D, hipMemcpyDeviceToHost, s);

@@ -140,6 +140,9 @@ struct LmWindow {
 };
 
 // the argument tables of one set of windows, built once per (contexts, finalize generations, options that enter the tables)
+// windows per call up to which the LM diagonal / gradient norms ride in the factorisation's launch (above: their own batched launch and the
+// task lists without them).  Measured: 2 windows of C2 ..., 8 windows of C2 5 150 against 5 350 LM it/s, 32 windows of 20 KF x 500 91 700 against 99 100
+constexpr int kBatchDiagInCholMax = 0;
 struct BatchPlan {
   std::vector<bsgpu_ctx*> ctxs;
   std::vector<uint64_t> gens;
@@ -251,7 +254,9 @@ bool build_plan(BatchPlan& P, bsgpu_ctx* const* ctxs, int n, const bsgpu_options
                      c->d_bs_chain_group, c->d_bs_grp_nchains, c->d_bs_grp_nitems, c->d_bs_items4, c->d_bs_tile_updated, c->d_bs_sync, c->d_scal, c->d_Winv, c->d_bs_order, c->d_tile_tot, 1};
     // (the LM diagonal and the gradient norms of a full step ride in the factorisation's launch when the window's plan has the tasks for them;
     //  radius and the step's flags are patched in per round, BatchDyn)
-    P.diag_in_chol[w] = c->plan.diag_tasks && c->plan.rider_tasks * 256 >= c->nb;
+    // — for a FEW windows: a batch of many small windows is bound by the number of its (LDS-heavy) factorisation workgroups, and the
+    // separate launch's 256-thread workgroups are the cheaper form there (32 windows of 20 KF x 500: 99 100 against 91 700 LM it/s)
+    P.diag_in_chol[w] = n <= kBatchDiagInCholMax && c->plan.diag_tasks && c->plan.rider_tasks * 256 >= c->nb;
     LmDiag lmd;
     GradNormRide gnr;
     if (P.diag_in_chol[w]) {
@@ -260,7 +265,9 @@ bool build_plan(BatchPlan& P, bsgpu_ctx* const* ctxs, int n, const bsgpu_options
       gnr.nb = c->nb; gnr.xoff = c->d_blk_xoff; gnr.toff = c->d_blk_toff; gnr.size = c->d_blk_size; gnr.manifold = c->d_blk_manifold; gnr.x = c->d_x; gnr.grad = c->d_grad;
       gnr.gpart = c->d_gpart;
     }
-    batchargs_chol_fused(P.t_chol, c->d_S, D.Lp, c->plan.npad, D.ftasks, (int)c->plan.ftasks.size(), D.tile_tot, D.nreal, D.Vinv, c->d_scal, D.fsync, D.Winv, D.rhs_rows, lmd, gnr);
+    const bool plain = !P.diag_in_chol[w] && c->d_ftasks_plain && c->d_tile_tot_plain;
+    batchargs_chol_fused(P.t_chol, c->d_S, D.Lp, c->plan.npad, plain ? c->d_ftasks_plain : D.ftasks, plain ? c->n_ftasks_plain : (int)c->plan.ftasks.size(),
+                         plain ? c->d_tile_tot_plain : D.tile_tot, D.nreal, D.Vinv, c->d_scal, D.fsync, D.Winv, D.rhs_rows, lmd, gnr);
     P.bs_form[w] = batchargs_backsolve(P.t_bs, c->plan, D, c->d_y, c->d_inat, c->n_pose, c->d_ytan, c->d_delta);
     if (P.bs_form[w] < 0) return false;
     // landmark back-substitution + model cost change + candidate

@@ -951,12 +951,17 @@ int finalize(bsgpu_ctx* c) {
       // fused single-launch factorisation (default; BSGPU_CHOL_FUSED=0 keeps the launch-per-step path): task list + zeroed counters
       const char* ef = getenv("BSGPU_CHOL_FUSED");
       c->d_ftasks = nullptr; c->d_fsync = nullptr; c->d_tile_tot = nullptr;
+      c->d_ftasks_plain = nullptr; c->d_tile_tot_plain = nullptr; c->n_ftasks_plain = 0;
       // (one workgroup of 512 threads per task, and a grid holds fewer than 2^32 threads: above 8.38 M tasks — a DENSE system of more than
       // ~23 600 dimensions, which only the exact option on a pose graph produces — the launch is refused by the runtime, so the
       // launch-per-step path runs there; scripts/c4_exact.py)
       if (!(ef && atoi(ef) == 0) && !c->plan.ftasks.empty() && c->plan.ftasks.size() * 512 < ((size_t)1 << 32)) {
         c->d_ftasks = c->upload(c->plan.ftasks);
         c->d_tile_tot = c->upload(c->plan.tile_tot);
+        if (!c->plan.ftasks_plain.empty()) {
+          c->d_ftasks_plain = c->upload(c->plan.ftasks_plain); c->d_tile_tot_plain = c->upload(c->plan.tile_tot_plain);
+          c->n_ftasks_plain = (int)c->plan.ftasks_plain.size();
+        }
         c->d_fsync = c->upload(std::vector<int>((size_t)c->plan.fused_sync_words, 0));
         c->d_Winv = c->alloc<double>((size_t)std::max(1, T) * 4096);   // (the chains write every entry of a tile's inverse, zeros above its diagonal blocks included)
       }

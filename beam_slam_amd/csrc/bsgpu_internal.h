@@ -248,6 +248,7 @@ struct DenseDev {
   int rhs_rows = 0;                // rows of the rhs tile that are in use (the LM solve: 1); 0: every row may be
   LmDiag diag;                     // what the factorisation's launch carries along (plans with diagonal / rider tasks)
   GradNormRide gn;
+  const FusedTask* ftasks_plain = nullptr; const int* tile_tot_plain = nullptr; int n_ftasks_plain = 0;   // the list for a launch that carries neither
 };
 // per-window argument table of one `_batch` kernel: entry w = the arguments window w's lone launch would pass (host image, then uploaded)
 struct BatchArgTable {

@@ -288,7 +288,9 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
 void dense_factor(hipStream_t s, const DensePlan& P, const DenseDev& D, double* S, double* scal) {
   const int ld = P.npad;
   if (D.ftasks && D.fsync && D.tile_tot && D.Winv) {   // the whole factorisation in one launch
-    launch_chol_fused(s, S, D.Lp, ld, D.ftasks, (int)P.ftasks.size(), D.tile_tot, D.nreal, D.Vinv, scal, D.fsync, D.Winv, D.rhs_rows, D.diag, D.gn);
+    const bool plain = !D.diag.hdiag && D.gn.nb == 0 && D.ftasks_plain && D.tile_tot_plain;   // (nothing to carry: the list without those tasks)
+    launch_chol_fused(s, S, D.Lp, ld, plain ? D.ftasks_plain : D.ftasks, plain ? D.n_ftasks_plain : (int)P.ftasks.size(), plain ? D.tile_tot_plain : D.tile_tot, D.nreal,
+                      D.Vinv, scal, D.fsync, D.Winv, D.rhs_rows, D.diag, D.gn);
     return;
   }
   for (int st = 0; st < P.n_steps(); ++st) {
@@ -354,6 +356,7 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
                c->d_bs_desc_chain, c->d_rows_flat_chain, c->d_bs_upd, c->d_bs_upd_rows,
                c->d_bs_chain_group, c->d_bs_grp_nchains, c->d_bs_grp_nitems, c->d_bs_items4, c->d_bs_tile_updated, c->d_bs_sync, c->d_scal, c->d_Winv, c->d_bs_order, c->d_tile_tot, 1};
     if (c->diag_in_chol) { D.diag = c->lm_diag; D.gn = c->gn_ride; }
+    D.ftasks_plain = c->d_ftasks_plain; D.tile_tot_plain = c->d_tile_tot_plain; D.n_ftasks_plain = c->n_ftasks_plain;
     dense_factor(s, c->plan, D, c->d_S, c->d_scal);
     phase_mark(c, BSGPU_PHASE_FACTOR);
     dense_backsolve(s, c->plan, D, c->d_S, c->d_y, c->d_inat, c->n_pose, c->d_ytan, c->d_delta);

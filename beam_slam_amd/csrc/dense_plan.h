@@ -97,6 +97,8 @@ struct DensePlan {
   std::vector<int> tile_tot;          // (T+1)^2: number of update TASKS per tile (what a chain waits for before it reads its tiles)
   std::vector<int> fchain_begin, fchain_len, fchain_of_tile;   // the chains of the fused factorisation
   std::vector<int> fext_of;           // T+1: the appendix tile panel k carries (kFusedExt), or -1
+  std::vector<FusedTask> ftasks_plain;   // ftasks without the diagonal / rider tasks (empty: the plan has none, ftasks is that list)
+  std::vector<int> tile_tot_plain;
   bool allow_ext = true;              // (finalize: BSGPU_CHOL_EXT=0 plans every tile's panel by itself)
   bool diag_tasks = false;            // one kFusedDiagAdd task per tile at the head of the list
   int rider_tasks = 0;                // kFusedRider tasks behind them
@@ -560,6 +562,18 @@ struct DensePlan {
         f.flags |= kFusedXiLp | kFusedXjLp;
       }
       fused_sync_words = 16 * (3 + N + N * N);   // (every word a 64-byte line apart: k_chol.hip fused_sync_stride)
+      // the same list WITHOUT the diagonal / rider tasks (what a launch that carries neither takes: a step whose LM diagonal is in S already,
+      // the batched launches of many windows — every task is a workgroup with ~160 KB of LDS, also one that only counts itself in)
+      ftasks_plain.clear(); tile_tot_plain = tile_tot;
+      if (diag_tasks || rider_tasks > 0) {
+        for (const FusedTask& f0 : ftasks) {
+          if (f0.flags & (kFusedDiagAdd | kFusedRider)) continue;
+          FusedTask f = f0;
+          if (diag_tasks && !(f.flags & kFusedChain) && f.ti == f.tj && f.ti < T && f.need_c >= 0) { f.need_c--; f.tot_c--; }
+          ftasks_plain.push_back(f);
+        }
+        if (diag_tasks) for (int t = 0; t < T; ++t) tile_tot_plain[(size_t)t * N + t]--;
+      }
     }
     // ---- back-substitution plan
     panel_of_tile.assign(T, 0);

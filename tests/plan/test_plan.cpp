@@ -82,7 +82,7 @@ static int check_ordered(std::mt19937& rng, unsigned seed) {
 }
 
 static long g_ext_tasks = 0, g_ext_plans = 0, g_diag_tasks = 0;
-static int replay(const DensePlan& P, const std::vector<uint8_t>& adj, unsigned seed, int max_chains) {
+static int replay_list(const DensePlan& P, const std::vector<uint8_t>& adj, unsigned seed, int max_chains) {
   { long n = 0; for (const FusedTask& f : P.ftasks) n += (f.flags & kFusedExt) ? 1 : 0; g_ext_tasks += n; g_ext_plans += n > 0; }
   const int T = P.T;
   const int N = P.T + 1;
@@ -176,6 +176,18 @@ static int replay(const DensePlan& P, const std::vector<uint8_t>& adj, unsigned 
   if (emax > 1e-9) { printf("  FAIL factor mismatch %.3e\n", emax); ++fails; }
   if (fails) printf("T %d chains %d seed %u: %d failures (%zu tasks, %zu chains)\n", T, max_chains, seed, fails, P.ftasks.size(), P.fchain_begin.size());
   return fails;
+}
+
+// the plan's list, and its list without the diagonal / rider tasks (what a launch that carries neither takes)
+static int replay(const DensePlan& P, const std::vector<uint8_t>& adj, unsigned seed, int max_chains) {
+  int f = replay_list(P, adj, seed, max_chains);
+  if (P.diag_tasks || P.rider_tasks > 0) {
+    if (P.ftasks_plain.empty()) { printf("  FAIL no plain list\n"); return f + 1; }
+    DensePlan Q = P;
+    Q.ftasks = P.ftasks_plain; Q.tile_tot = P.tile_tot_plain; Q.diag_tasks = false; Q.rider_tasks = 0;
+    f += replay_list(Q, adj, seed, max_chains);
+  }
+  return f;
 }
 
 int main() {
