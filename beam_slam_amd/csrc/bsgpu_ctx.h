@@ -237,6 +237,7 @@ struct bsgpu_ctx {
   // this step's LM diagonal and gradient norms are carried by the factorisation's launch (its diagonal / rider tasks, dense_plan.h) instead
   // of a launch of their own between the assembly and the factorisation — decided per step by assemble()
   bool diag_in_chol = false;
+  bool cost_x_stale = false;   // the last step's reduction rode in the evaluation ahead and left SC_COST_X alone (that launch rewrites its partials)
   LmDiag lm_diag;
   GradNormRide gn_ride;
   bool spec_J = false;   // residuals + Jacobians currently hold the CANDIDATE's (evaluated ahead of the accept/reject decision)
@@ -332,7 +333,7 @@ int build_bsr(bsgpu_ctx* c);
 int build_spcg(bsgpu_ctx* c);
 // bsgpu_solve.cpp
 int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum);
-void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot);
+void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot, const ReduceRide* red = nullptr);
 // factor_follows: linear_solve_and_candidate() comes next — its factorisation launch may then carry the LM diagonal and the gradient norms
 void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, bool first, bool gradient_only = false, bool factor_follows = false);
 void final_reduce(bsgpu_ctx* c);

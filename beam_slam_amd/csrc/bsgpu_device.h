@@ -205,6 +205,89 @@ BSG_DEV double block_sum_256(double v, double* smem /* >= 4 doubles */) {
   return t;
 }
 
+// The end-of-step reduction (k_misc.hip final_reduce_kernel): unit `slot` adds up, in a fixed order, every partial array registered for that
+// scalar; unit n_slots mirrors the scalars earlier kernels of the step produced.  The host does not wait for an event behind the launch
+// (recording one costs the next kernel ~6 us of dispatch bubble): the LAST unit to finish — all host-side writes of a unit are thread 0's,
+// fenced at system scope before it takes its ticket — stamps the mirror with the launch's sequence number, which the host polls
+// (bsgpu_solve.cpp: fetch_scalars).
+BSG_DEV void final_reduce_done(double* host_scal, int* counter, double seq, int n_units) {
+  if (!counter) return;
+  __threadfence_system();
+  const int prev = __hip_atomic_fetch_add(counter, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  if (prev == n_units - 1) {
+    __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    if (host_scal) __hip_atomic_store(&host_scal[SC_SEQ], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+// NT threads (1024, or 256 = a rider of a 256-thread launch): a thread plays 1024 / NT of the kernel's 1024 threads one after the other,
+// and the waves' sums land in the same sixteen slots — the same additions in the same order, the same bits, whatever NT.  sred: 16 doubles.
+template <int NT>
+BSG_DEV void final_reduce_unit(int slot, int tid, const ReduceRide& R, int n_units, double* sred) {
+  constexpr int VT = 1024 / NT;
+  if (slot == R.n_slots) {   // the scalars earlier kernels of the step produced (gradient norms, Cholesky flag, ...) -> host mirror
+    if (tid == 0) {
+      if (R.host_scal) for (int i = R.n_slots; i < SC_SEQ; ++i) R.host_scal[i] = R.scal[i];
+      // (mirrored: the factorisation's flag of this step is cleared here for the next one — its clearing may have run already, in the
+      //  launch that carried the candidate update, bsgpu_solve.cpp)
+      if (R.host_scal) R.scal[SC_CHOL_FAIL] = 0.0;
+      final_reduce_done(R.host_scal, R.counter, R.seq, n_units);
+    }
+    return;
+  }
+  if (slot == R.skip_slot) { if (tid == 0) final_reduce_done(R.host_scal, R.counter, R.seq, n_units); return; }
+  double acc[VT];
+#pragma unroll
+  for (int q = 0; q < VT; ++q) acc[q] = 0.0;
+  bool any = false, is_max = false;
+  for (int e = 0; e < R.n_entries; ++e) {
+    const ReduceEntry en = R.entries[e];
+    if (en.slot != slot) continue;
+    any = true;
+    if (en.op == 1) is_max = true;
+#pragma unroll
+    for (int q = 0; q < VT; ++q) {
+      // 1024 (virtual) threads, four independent partial sums each: with one, every load waits for the previous add — the per-factor array
+      // of a 20 000-factor group then costs 80 dependent round trips on 256 threads (115 us on C3) instead of 5 (a 70 000-factor
+      // inverse-depth group: 22 us on 256 threads with eight partial sums)
+      double a[4] = {0, 0, 0, 0};
+      int i = tid + NT * q;
+      for (; i + 3 * 1024 < en.n; i += 4 * 1024) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] += en.ptr[(size_t)(i + 1024 * u) * en.stride + en.offset];
+      }
+      if (en.op == 1) {   // (a maximum: one entry per slot)
+        for (; i < en.n; i += 1024) acc[q] = fmax(acc[q], en.ptr[(size_t)i * en.stride + en.offset]);
+        continue;
+      }
+      for (; i < en.n; i += 1024) a[0] += en.ptr[(size_t)i * en.stride + en.offset];
+      acc[q] += (a[0] + a[1]) + (a[2] + a[3]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < VT; ++q) {
+    double v = acc[q];
+    if (is_max) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    } else {
+      v = wave_sum(v);
+    }
+    if ((tid & 63) == 0) sred[(tid >> 6) + (NT / 64) * q] = v;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t = is_max ? fmax(t, sred[w]) : t + sred[w];
+    if (any) R.scal[slot] = t;
+    // mirror in pinned host memory: the host reads the step's scalars right after the stream drains, without a
+    // device-to-host copy of its own on the dependent path
+    if (R.host_scal) R.host_scal[slot] = any ? t : R.scal[slot];
+    final_reduce_done(R.host_scal, R.counter, R.seq, n_units);
+  }
+}
+
 // One unit of 256 blocks of the gradient norms (grad_norms_kernel): max |x (+) (-g) - x| and its squared sum over the unit's blocks into
 // gpart[2 unit], gpart[2 unit + 1].  NT threads (a multiple of 64, >= 256; the threads beyond 256 only take part in the reduction);
 // sred / smax: NT / 64 doubles of LDS each.  Ends with every thread past a __syncthreads().

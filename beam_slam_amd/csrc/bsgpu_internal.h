@@ -181,6 +181,15 @@ struct ReduceEntry {
   int op = 0;   // 0: sum, 1: maximum (of non-negative values)
 };
 
+// the end-of-step reduction (k_misc.hip final_reduce_kernel) as units of work of another launch: n_slots + 1 units
+struct ReduceRide {
+  const ReduceEntry* entries = nullptr;
+  int n_entries = 0, n_slots = 0;
+  double* scal = nullptr; double* host_scal = nullptr; int* counter = nullptr;
+  double seq = 0.0;
+  int skip_slot = -1;   // a slot whose partial arrays the carrying launch itself rewrites: left alone (its unit only counts itself in)
+};
+
 struct LaunchCtx {
   hipStream_t stream;
 };
@@ -189,7 +198,8 @@ struct LaunchCtx {
 void launch_reproj_eval(hipStream_t s, const Visual& v, const double* x, const DevCamera* cams,
                         const DevLoss* losses, bool with_J, double* cost_part_out, bool count_inactive = false);
 void launch_visual_imu_eval(hipStream_t s, const Visual& v, const SmallGroup& delta, const SmallGroup& prior, const double* x, const DevCamera* cams,
-                            const DevLoss* losses, bool with_J, double* cost_part_vis, double* part_delta, double* part_prior);
+                            const DevLoss* losses, bool with_J, double* cost_part_vis, double* part_delta, double* part_prior,
+                            const ReduceRide* red = nullptr /* with_J: the end-of-step reduction as the launch's first workgroups */);
 void launch_relpose_imu_eval(hipStream_t s, const SmallGroup& g, const SmallGroup& delta, const SmallGroup& prior, const double* x,
                              const DevLoss* losses, bool with_J, double* cost_part, double* part_delta, double* part_prior);
 void launch_imu_eval(hipStream_t s, const SmallGroup& delta, const SmallGroup& prior, const double* x, const DevLoss* losses, bool with_J,

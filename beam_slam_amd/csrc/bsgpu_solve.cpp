@@ -159,7 +159,9 @@ void spcg_solve(bsgpu_ctx* c, const bsgpu_options& o) {
 
 // residuals (+ Jacobians) of every factor group; per-group cost partials go to the arrays the
 // end-of-step reduction sums (current point: slot SC_COST_X, candidate: SC_COST_CAND)
-void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot) {
+// red: the end-of-step reduction of the step just computed rides in the visual-inertial evaluation launch (the caller has checked that
+// this window takes that launch: reduce_rides())
+void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot, const ReduceRide* red) {
   hipStream_t s = c->stream;
   const bool cand = slot == SC_COST_CAND;
   // (either IMU type may be absent: a window whose oldest state has been marginalised / held constant has no IMU prior any more)
@@ -172,7 +174,7 @@ void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot) {
     launch_visual_imu_eval(s, c->vis, c->small[BSGPU_F_IMU_DELTA], c->small[BSGPU_F_IMU_PRIOR], x, c->d_cams, c->d_losses, with_J,
                            cand ? c->vis.cost_part_cand : c->vis.cost_part,
                            cand ? c->d_small_part_cand[BSGPU_F_IMU_DELTA] : c->d_small_part[BSGPU_F_IMU_DELTA],
-                           cand ? c->d_small_part_cand[BSGPU_F_IMU_PRIOR] : c->d_small_part[BSGPU_F_IMU_PRIOR]);
+                           cand ? c->d_small_part_cand[BSGPU_F_IMU_PRIOR] : c->d_small_part[BSGPU_F_IMU_PRIOR], red);
   else if (c->vis.n) launch_reproj_eval(s, c->vis, x, c->d_cams, c->d_losses, with_J, cand ? c->vis.cost_part_cand : c->vis.cost_part);
   if (with_J) phase_mark(c, BSGPU_PHASE_EVAL_REPROJ);
   // (a lidar-inertial window: they ride in the relative-pose evaluation instead)
@@ -196,6 +198,15 @@ void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot) {
   for (const auto& mc : c->marg)
     if (mc.active) launch_marg_eval(s, mc.dev, x, with_J, cand ? mc.part_cand : mc.part);
   if (with_J) phase_mark(c, BSGPU_PHASE_EVAL_OTHER);
+}
+// the reduction can ride in the evaluation launched ahead of the decision (k_small.hip visual_imu_eval_reduce_kernel): a visual-inertial
+// window on eager launches whose host polls the mirror's stamp, outside bsgpu_profile_step (which times the reduction in its own phase)
+bool reduce_rides(const bsgpu_ctx* c) {
+  static const bool by_event = getenv("BSGPU_SCALARS_EVENT") != nullptr, off = getenv("BSGPU_REDUCE_LAUNCH") != nullptr;
+  static const int merge_mode = getenv("BSGPU_EVAL_MERGE") ? atoi(getenv("BSGPU_EVAL_MERGE")) : 2;
+  const bool imu_pair = c->small[BSGPU_F_IMU_DELTA].n + c->small[BSGPU_F_IMU_PRIOR].n > 0;
+  return !off && !by_event && !c->use_graphs && !c->use_pcg && !c->prof_events && imu_pair && c->vis.n > 0 && merge_mode >= 2 && c->h_scal_dev != nullptr &&
+         c->d_reduce_counter != nullptr && c->n_reduce > 0;
 }
 void final_reduce(bsgpu_ctx* c) {
   // (BSGPU_SCALARS_EVENT=1: the host waits for an event recorded behind the reduction instead of polling the mirror's stamp)
@@ -341,7 +352,7 @@ void dense_backsolve(hipStream_t s, const DensePlan& P, const DenseDev& D, doubl
   }
 }
 
-void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
+void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o, bool defer_reduce = false) {
   hipStream_t s = c->stream;
   if (c->use_pcg) {
     pcg_solve(c, o);
@@ -404,7 +415,7 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o) {
     launch_update(s, c->nb, c->d_blk_xoff, c->d_blk_toff, c->d_blk_size, c->d_blk_manifold, c->d_x, c->d_delta, c->d_xcand,
                   c->d_part_upd, &n_part);
   eval_all(c, c->d_xcand, false, SC_COST_CAND);
-  final_reduce(c);
+  if (!defer_reduce) final_reduce(c);   // (deferred: it rides in the evaluation the caller launches next)
   phase_mark(c, BSGPU_PHASE_CANDIDATE);
 }
 
@@ -433,14 +444,26 @@ void enqueue_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius,
   c->spec_J = false;
   assemble(c, o, radius, kind != STEP_REJECT, kind == STEP_FIRST, gradient_only, /*factor_follows=*/true);
   if (gradient_only) { final_reduce(c); return; }
-  linear_solve_and_candidate(c, o);
+  // (not on the first step: the reduction that rides cannot give the cost at x — the launch that carries it rewrites those partials — and
+  //  only the first step's is read: after an accepted step the cost at x is the candidate's cost the host already holds)
+  const bool ride = !gradient_only && kind != STEP_FIRST && reduce_rides(c);
+  c->cost_x_stale = ride;
+  linear_solve_and_candidate(c, o, ride);
   // The host now waits for this step's scalars and decides; in the common case (accepted) the next thing the device needs is the
   // residuals and Jacobians at the candidate: evaluated ahead, underneath the host round trip (~26 us per iteration otherwise
   // idle).  A rejected step pays for it with a re-evaluation at the current point (above).
   if (!c->use_graphs) {
     hipEvent_t* const prof = c->prof_events;   // (bsgpu_profile_step times the step up to here: this evaluation belongs to the next one)
     c->prof_events = nullptr;
-    eval_all(c, c->d_xcand, true, SC_COST_X);
+    if (ride) {
+      ReduceRide r;
+      c->reduce_seq += 1.0;
+      r.entries = c->d_reduce; r.n_entries = c->n_reduce; r.n_slots = SC_GRAD_NORM2 + 1; r.scal = c->d_scal; r.host_scal = c->h_scal_dev; r.counter = c->d_reduce_counter;
+      r.seq = c->reduce_seq; r.skip_slot = SC_COST_X;
+      eval_all(c, c->d_xcand, true, SC_COST_X, &r);
+      c->scal_mirrored = true; c->seq_pending = true; c->ev_reduce_pending = false;
+    } else
+      eval_all(c, c->d_xcand, true, SC_COST_X);
     c->prof_events = prof;
     c->spec_J = true;
   }
@@ -721,7 +744,7 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
       rc = fetch_scalars(c);
       if (rc != BSGPU_OK) return rc;
       if (it.step_is_successful) {
-        x_cost = c->h_scal[SC_COST_X];
+        x_cost = c->cost_x_stale ? cand_cost : c->h_scal[SC_COST_X];   // (the same sum: the candidate's cost-only pass and the pass with Jacobians add the same partials)
         it.cost = x_cost + fixed;
         it.gradient_max_norm = c->h_scal[SC_GRAD_MAX];
         it.gradient_norm = std::sqrt(c->h_scal[SC_GRAD_NORM2]);

@@ -148,75 +148,13 @@ __global__ __launch_bounds__(256) void sum_kernel(const double* __restrict__ par
 void launch_sum(hipStream_t s, const double* part, int n, double* out, int accumulate) {
   hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, s, part, n, out, accumulate);
 }
-// One launch at the end of an LM step: workgroup `slot` adds up, in a fixed order, every partial array
-// registered for that scalar (costs of the factor groups, model-cost-change terms, step / x norms).
-// The host does not wait for an event behind this kernel (recording one costs the next kernel ~6 us of dispatch bubble): the LAST
-// workgroup to finish — all host-side writes of a workgroup are thread 0's, fenced at system scope before it takes its ticket —
-// stamps the mirror with the launch's sequence number, which the host polls (bsgpu_solve.cpp: fetch_scalars).
-BSG_DEV void final_reduce_done(double* host_scal, int* counter, double seq) {
-  if (!counter) return;
-  __threadfence_system();
-  const int prev = __hip_atomic_fetch_add(counter, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-  if (prev == (int)gridDim.x - 1) {
-    __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence_system();
-    if (host_scal) __hip_atomic_store(&host_scal[SC_SEQ], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-}
+// One launch at the end of an LM step: workgroup `slot` adds up, in a fixed order, every partial array registered for that scalar
+// (bsgpu_device.h final_reduce_unit — which also runs as the first workgroups of the evaluation launched ahead of the decision, k_small.hip).
 __device__ __forceinline__ void final_reduce_kernel_body(const int bsg_bx, const int bsg_gx, const ReduceEntry* __restrict__ entries, int n_entries, int n_slots, double* __restrict__ scal, double* __restrict__ host_scal, int* counter, double seq) {
   __shared__ double sred[16];
-  const int slot = bsg_bx;
-  if (slot == n_slots) {   // the scalars earlier kernels of the step produced (gradient norms, Cholesky flag, ...) -> host mirror
-    if (threadIdx.x == 0) {
-      if (host_scal) for (int i = n_slots; i < SC_SEQ; ++i) host_scal[i] = scal[i];
-      // (mirrored: the factorisation's flag of this step is cleared here for the next one — its clearing may have run already, in the
-      //  launch that carried the candidate update, bsgpu_solve.cpp)
-      if (host_scal) scal[SC_CHOL_FAIL] = 0.0;
-      final_reduce_done(host_scal, counter, seq);
-    }
-    return;
-  }
-  double acc = 0.0;
-  bool any = false, is_max = false;
-  for (int e = 0; e < n_entries; ++e) {
-    const ReduceEntry en = entries[e];
-    if (en.slot != slot) continue;
-    any = true;
-    // 1024 threads, four independent partial sums each: with one, every load waits for the previous add — the per-factor array of a
-    // 20 000-factor group then costs 80 dependent round trips on 256 threads (115 us on C3) instead of 5 (a 70 000-factor
-    // inverse-depth group: 22 us on 256 threads with eight partial sums)
-    double a[4] = {0, 0, 0, 0};
-    int i = threadIdx.x;
-    for (; i + 3 * 1024 < en.n; i += 4 * 1024) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) a[u] += en.ptr[(size_t)(i + 1024 * u) * en.stride + en.offset];
-    }
-    if (en.op == 1) {   // (a maximum: one entry per slot)
-      is_max = true;
-      for (; i < en.n; i += 1024) acc = fmax(acc, en.ptr[(size_t)i * en.stride + en.offset]);
-      continue;
-    }
-    for (; i < en.n; i += 1024) a[0] += en.ptr[(size_t)i * en.stride + en.offset];
-    acc += (a[0] + a[1]) + (a[2] + a[3]);
-  }
-  if (is_max) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc = fmax(acc, __shfl_xor(acc, o, 64));
-  } else {
-    acc = wave_sum(acc);
-  }
-  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double t = 0.0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) t = is_max ? fmax(t, sred[w]) : t + sred[w];
-    if (any) scal[slot] = t;
-    // mirror in pinned host memory: the host reads the step's scalars right after the stream drains, without a
-    // device-to-host copy of its own on the dependent path
-    if (host_scal) host_scal[slot] = any ? t : scal[slot];
-    final_reduce_done(host_scal, counter, seq);
-  }
+  ReduceRide R;
+  R.entries = entries; R.n_entries = n_entries; R.n_slots = n_slots; R.scal = scal; R.host_scal = host_scal; R.counter = counter; R.seq = seq;
+  final_reduce_unit<1024>(bsg_bx, (int)threadIdx.x, R, bsg_gx, sred);
 }
 __global__ __launch_bounds__(1024) void final_reduce_kernel(const ReduceEntry* __restrict__ entries, int n_entries, int n_slots, double* __restrict__ scal, double* __restrict__ host_scal, int* counter, double seq) {
   final_reduce_kernel_body((int)blockIdx.x, (int)gridDim.x, entries, n_entries, n_slots, scal, host_scal, counter, seq);

@@ -277,6 +277,18 @@ template <bool WITH_J>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void visual_imu_eval_kernel(SmallGroup delta, SmallGroup prior, double* __restrict__ part_delta, double* __restrict__ part_prior, int n_imu_blocks, int n, const int4* __restrict__ fac, const double2* __restrict__ pix, const double* __restrict__ wgt, const double* __restrict__ x, const DevCamera* __restrict__ cams, const DevLoss* __restrict__ losses, double2* __restrict__ r_out, double* __restrict__ J_out, double* __restrict__ JB_out, double* __restrict__ cost_part, int count_inactive) {
   visual_imu_eval_kernel_body<WITH_J>((int)blockIdx.x, (int)gridDim.x, delta, prior, part_delta, part_prior, n_imu_blocks, n, fac, pix, wgt, x, cams, losses, r_out, J_out, JB_out, cost_part, count_inactive);
 }
+// The evaluation launched AHEAD of the accept / reject decision (residuals and Jacobians at the candidate, underneath the host's round trip)
+// with the end-of-step reduction of the step just computed as its first workgroups: the host's stamp leaves ~4 us into this launch
+// instead of after a launch of its own (7.7 us + the 4.5 us a kernel that wrote host memory takes to retire, on every LM step).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void visual_imu_eval_reduce_kernel(ReduceRide red, SmallGroup delta, SmallGroup prior, double* __restrict__ part_delta, double* __restrict__ part_prior, int n_imu_blocks, int n, const int4* __restrict__ fac, const double2* __restrict__ pix, const double* __restrict__ wgt, const double* __restrict__ x, const DevCamera* __restrict__ cams, const DevLoss* __restrict__ losses, double2* __restrict__ r_out, double* __restrict__ J_out, double* __restrict__ JB_out, double* __restrict__ cost_part, int count_inactive) {
+  const int n_units = red.n_slots + 1;
+  if ((int)blockIdx.x < n_units) {
+    __shared__ double sred[16];
+    final_reduce_unit<256>((int)blockIdx.x, (int)threadIdx.x, red, n_units, sred);
+    return;
+  }
+  visual_imu_eval_kernel_body<true>((int)blockIdx.x - n_units, (int)gridDim.x - n_units, delta, prior, part_delta, part_prior, n_imu_blocks, n, fac, pix, wgt, x, cams, losses, r_out, J_out, JB_out, cost_part, count_inactive);
+}
 // one launch over several windows (bsgpu_batch.cpp): blockIdx.y picks the window of list `bsg_list`, its arguments come from memory
 struct visual_imu_eval_kernel_Args {
   int bsg_grid;
@@ -330,9 +342,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
   visual_imu_eval_kernel_body<WITH_J>((int)blockIdx.x, a.bsg_grid, a.delta, a.prior, (double*)a.part_delta, (double*)a.part_prior, a.n_imu_blocks, a.n, (const int4*)a.fac, (const double2*)a.pix, (const double*)a.wgt, (const double*)a.x, (const DevCamera*)a.cams, (const DevLoss*)a.losses, (double2*)a.r_out, (double*)a.J_out, (double*)a.JB_out, (double*)a.cost_part, a.count_inactive);
 }
 void launch_visual_imu_eval(hipStream_t s, const Visual& v, const SmallGroup& delta, const SmallGroup& prior, const double* x, const DevCamera* cams,
-                            const DevLoss* losses, bool with_J, double* cost_part_vis, double* part_delta, double* part_prior) {
+                            const DevLoss* losses, bool with_J, double* cost_part_vis, double* part_delta, double* part_prior, const ReduceRide* red) {
   const int n_imu_blocks = (delta.n + prior.n + 3) / 4, grid = n_imu_blocks + (v.n + 255) / 256;
-  if (with_J)
+  if (with_J && red && red->n_entries > 0)
+    hipLaunchKernelGGL(visual_imu_eval_reduce_kernel, dim3(red->n_slots + 1 + grid), dim3(256), 0, s, *red, delta, prior, part_delta, part_prior, n_imu_blocks, v.n,
+                       v.fac, v.pix, v.w, x, cams, losses, v.r, v.J, v.JB, cost_part_vis, 0);
+  else if (with_J)
     hipLaunchKernelGGL(visual_imu_eval_kernel<true>, dim3(grid), dim3(256), 0, s, delta, prior, part_delta, part_prior, n_imu_blocks, v.n, v.fac, v.pix, v.w,
                        x, cams, losses, v.r, v.J, v.JB, cost_part_vis, 0);
   else

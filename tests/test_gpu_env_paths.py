@@ -53,6 +53,8 @@ SETTINGS = [
     {"BSGPU_BACKSOLVE_GLOBAL_Y": "1"},                           # solution vector in global memory (windows above 12 288 dimensions)
     {"BSGPU_CHOL_FUSED": "0", "BSGPU_BACKSOLVE_LEGACY": "1"},
     {"BSGPU_CHAINS": "1"},
+    {"BSGPU_REDUCE_LAUNCH": "1"},                                # the end-of-step reduction as a launch of its own instead of the first workgroups of the evaluation launched ahead of the decision
+    {"BSGPU_REDUCE_LAUNCH": "1", "BSGPU_POSE_DIAG_LAUNCH": "1"},
     {"BSGPU_POSE_DIAG_LAUNCH": "1"},                             # the LM diagonal and the gradient norms in a launch of their own instead of as tasks of the factorisation's launch
     {"BSGPU_POSE_DIAG_LAUNCH": "1", "BSGPU_CHOL_EXT": "0"},
     {"BSGPU_CHOL_EXT": "0"},                                     # a separator's appendix tile (<= 16 real columns) as a panel of its own instead of riding in the tasks of the panel before it
