@@ -201,7 +201,7 @@ void launch_visual_imu_eval(hipStream_t s, const Visual& v, const SmallGroup& de
                             const DevLoss* losses, bool with_J, double* cost_part_vis, double* part_delta, double* part_prior,
                             const ReduceRide* red = nullptr /* with_J: the end-of-step reduction as the launch's first workgroups */);
 void launch_relpose_imu_eval(hipStream_t s, const SmallGroup& g, const SmallGroup& delta, const SmallGroup& prior, const double* x,
-                             const DevLoss* losses, bool with_J, double* cost_part, double* part_delta, double* part_prior);
+                             const DevLoss* losses, bool with_J, double* cost_part, double* part_delta, double* part_prior, const ReduceRide* red = nullptr);
 void launch_imu_eval(hipStream_t s, const SmallGroup& delta, const SmallGroup& prior, const double* x, const DevLoss* losses, bool with_J,
                      double* part_delta, double* part_prior);
 int small_cost_parts(const SmallGroup& g);

@@ -185,7 +185,7 @@ void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot, const Reduce
     launch_relpose_imu_eval(s, c->small[rel_t], c->small[BSGPU_F_IMU_DELTA], c->small[BSGPU_F_IMU_PRIOR], x, c->d_losses, with_J,
                             cand ? c->d_small_part_cand[rel_t] : c->d_small_part[rel_t],
                             cand ? c->d_small_part_cand[BSGPU_F_IMU_DELTA] : c->d_small_part[BSGPU_F_IMU_DELTA],
-                            cand ? c->d_small_part_cand[BSGPU_F_IMU_PRIOR] : c->d_small_part[BSGPU_F_IMU_PRIOR]);
+                            cand ? c->d_small_part_cand[BSGPU_F_IMU_PRIOR] : c->d_small_part[BSGPU_F_IMU_PRIOR], red);
   if (imu_pair && !merged && rel_t < 0)
     launch_imu_eval(s, c->small[BSGPU_F_IMU_DELTA], c->small[BSGPU_F_IMU_PRIOR], x, c->d_losses, with_J,
                     cand ? c->d_small_part_cand[BSGPU_F_IMU_DELTA] : c->d_small_part[BSGPU_F_IMU_DELTA],
@@ -205,8 +205,10 @@ bool reduce_rides(const bsgpu_ctx* c) {
   static const bool by_event = getenv("BSGPU_SCALARS_EVENT") != nullptr, off = getenv("BSGPU_REDUCE_LAUNCH") != nullptr;
   static const int merge_mode = getenv("BSGPU_EVAL_MERGE") ? atoi(getenv("BSGPU_EVAL_MERGE")) : 2;
   const bool imu_pair = c->small[BSGPU_F_IMU_DELTA].n + c->small[BSGPU_F_IMU_PRIOR].n > 0;
-  return !off && !by_event && !c->use_graphs && !c->use_pcg && !c->prof_events && imu_pair && c->vis.n > 0 && merge_mode >= 2 && c->h_scal_dev != nullptr &&
-         c->d_reduce_counter != nullptr && c->n_reduce > 0;
+  // (the launch that carries it: the visual-inertial evaluation, or a lidar-inertial window's relative-pose + IMU evaluation — eval_all)
+  const bool carrier = imu_pair && merge_mode >= 2 && (c->vis.n > 0 || c->small[BSGPU_F_RELPOSE_EXT].n > 0 || c->small[BSGPU_F_RELPOSE].n > 0);
+  return !off && !by_event && !c->use_graphs && !c->use_pcg && !c->prof_events && carrier && c->h_scal_dev != nullptr && c->d_reduce_counter != nullptr &&
+         c->n_reduce > 0;
 }
 void final_reduce(bsgpu_ctx* c) {
   // (BSGPU_SCALARS_EVENT=1: the host waits for an event recorded behind the reduction instead of polling the mirror's stamp)

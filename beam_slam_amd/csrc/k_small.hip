@@ -566,20 +566,31 @@ template <bool EXT, bool WITH_J>
 __global__ __launch_bounds__(128) void relpose_imu_eval_kernel(SmallGroup delta, SmallGroup prior, double* __restrict__ part_delta,
                                                                double* __restrict__ part_prior, int n_imu_blocks, SmallGroup g,
                                                                const double* __restrict__ x, const DevLoss* __restrict__ losses,
-                                                               double* __restrict__ cost_part) {
-  if ((int)blockIdx.x < n_imu_blocks) {
-    const int f = 2 * (int)blockIdx.x + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+                                                               double* __restrict__ cost_part, ReduceRide red) {
+  // (the evaluation launched ahead of the decision carries the end-of-step reduction of the step just computed as its first workgroups,
+  //  as visual_imu_eval_reduce_kernel does for a visual-inertial window)
+  const int n_units = (WITH_J && red.n_entries > 0) ? red.n_slots + 1 : 0;
+  if ((int)blockIdx.x < n_units) {
+    __shared__ double sred[16];
+    final_reduce_unit<128>((int)blockIdx.x, (int)threadIdx.x, red, n_units, sred);
+    return;
+  }
+  const int bx = (int)blockIdx.x - n_units;
+  if (bx < n_imu_blocks) {
+    const int f = 2 * bx + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (f < delta.n) imu_delta_body<WITH_J>(delta, f, x, losses, part_delta, lane);
     else if (f < delta.n + prior.n) imu_prior_body<WITH_J>(prior, f - delta.n, x, losses, part_prior, lane);
     return;
   }
-  relpose_body<EXT, WITH_J>(g, x, losses, cost_part, (int)blockIdx.x - n_imu_blocks);
+  relpose_body<EXT, WITH_J>(g, x, losses, cost_part, bx - n_imu_blocks);
 }
 void launch_relpose_imu_eval(hipStream_t s, const SmallGroup& g, const SmallGroup& delta, const SmallGroup& prior, const double* x,
-                             const DevLoss* losses, bool with_J, double* cost_part, double* part_delta, double* part_prior) {
-  const int n_imu_blocks = (delta.n + prior.n + 1) / 2, grid = n_imu_blocks + (g.n + 127) / 128;
+                             const DevLoss* losses, bool with_J, double* cost_part, double* part_delta, double* part_prior, const ReduceRide* red) {
+  ReduceRide rr;
+  if (with_J && red) rr = *red;
+  const int n_imu_blocks = (delta.n + prior.n + 1) / 2, grid = n_imu_blocks + (g.n + 127) / 128 + (rr.n_entries > 0 ? rr.n_slots + 1 : 0);
   const bool ext = g.type == BSGPU_F_RELPOSE_EXT;
-#define BSG_LAUNCH_RI(E, W) hipLaunchKernelGGL((relpose_imu_eval_kernel<E, W>), dim3(grid), dim3(128), 0, s, delta, prior, part_delta, part_prior, n_imu_blocks, g, x, losses, cost_part)
+#define BSG_LAUNCH_RI(E, W) hipLaunchKernelGGL((relpose_imu_eval_kernel<E, W>), dim3(grid), dim3(128), 0, s, delta, prior, part_delta, part_prior, n_imu_blocks, g, x, losses, cost_part, rr)
   if (ext) { if (with_J) BSG_LAUNCH_RI(true, true); else BSG_LAUNCH_RI(true, false); }
   else { if (with_J) BSG_LAUNCH_RI(false, true); else BSG_LAUNCH_RI(false, false); }
 #undef BSG_LAUNCH_RI
