@@ -329,8 +329,10 @@ BSG_DEV void grad_norms_unit(int unit, int tid, const GradNormRide& G, double* s
 // (sJ >= 15 * 30 doubles, sr >= 15, st >= 10 ints), lanes stride over the (column a, column b) pairs; FP64 atomics into S, the rhs row,
 // grad and hdiag.  `unit` = workgroup index over the set (SmallGroupSet::first).  Shared by small_assemble_kernel (a launch of its own)
 // and pairs_kernel (whose extra workgroups do this work underneath the camera pairs: one launch less on the dependent path).
+// (part / parts: the factor's column pairs are shared out among `parts` workgroups — the riders of the pair launch are single waves, and a
+//  window of the reference's size waits for the slowest of them: 900 column pairs of an IMU factor on 64 lanes)
 BSG_DEV void small_assemble_unit(const SmallGroupSet& set, int unit, int lane, int nthr, double* sJ, double* sr, int* st, double* __restrict__ S, int ld,
-                                 int rhs_row, double* __restrict__ grad, double* __restrict__ hdiag, const int* __restrict__ perm) {
+                                 int rhs_row, double* __restrict__ grad, double* __restrict__ hdiag, const int* __restrict__ perm, int part = 0, int parts = 1) {
   if (unit >= set.first[set.n]) return;   // (padding of the caller's grid)
   int gi = 0;
   while (gi + 1 < set.n && unit >= set.first[gi + 1]) ++gi;
@@ -344,7 +346,7 @@ BSG_DEV void small_assemble_unit(const SmallGroupSet& set, int unit, int lane, i
   if (lane < g.nv) st[lane] = g.toff[(size_t)f * g.nv + lane];
   __syncthreads();
   const int wcut = 3 * (g.nv - 1) + g.w_last;   // columns >= wcut are the padding of a narrow last slot
-  for (int p = lane; p < tw * tw; p += nthr) {   // (an IMU factor has 900 column pairs)
+  for (int p = lane + nthr * part; p < tw * tw; p += nthr * parts) {   // (an IMU factor has 900 column pairs)
     const int a = p / tw, b = p % tw;
     const int ta = st[a / 3], tb = st[b / 3];
     if (ta < 0 || tb < 0 || a >= wcut || b >= wcut) continue;
@@ -353,6 +355,7 @@ BSG_DEV void small_assemble_unit(const SmallGroupSet& set, int unit, int lane, i
     const int ra = ta + a % 3, rb = tb + b % 3;
     atomicAdd(&S[(size_t)perm[ra] * ld + perm[rb]], acc);
   }
+  if (part != 0) return;
   for (int a = lane; a < wcut; a += nthr) {
     const int ta = st[a / 3];
     if (ta < 0) continue;

@@ -303,6 +303,7 @@ void launch_landmark(hipStream_t s, const Visual& v, int n_pose, const double* r
 // Results are added to the dense reduced system with FP64 atomics (each location is normally owned by
 // one segment, so the sums are reproducible).
 // ---------------------------------------------------------------------------------------------------
+constexpr int kPairRiderParts = 4;   // workgroups (single waves) per pose-only factor riding in the pair launch
 __device__ __forceinline__ void pairs_kernel_body(const int bsg_bx, const int bsg_gx, int n_seg, const int* __restrict__ seg_ci, const int* __restrict__ seg_cj, const int* __restrict__ seg_start, const int* __restrict__ ent_fa, const int* __restrict__ ent_fb, const double* __restrict__ J, const double2* __restrict__ r, const double* __restrict__ CR, const int* __restrict__ cp_tq, const int* __restrict__ cp_tp, double* __restrict__ S, int ld, int rhs_row, double* __restrict__ grad, double* __restrict__ hdiag, const int* __restrict__ perm, int grad_only, int n_pair_blocks, const SmallGroupSet& small, int n_small_units) {
   extern __shared__ __attribute__((aligned(16))) double2 slab[];   // [64][6] A_a | [64][6] A_b | [64][4] C_a | [64][3] C_b | 2 x 64 ints
   if (bsg_bx < n_small_units) {
@@ -310,7 +311,8 @@ __device__ __forceinline__ void pairs_kernel_body(const int bsg_bx, const int bs
     // the FIRST ones, so that they run underneath the pairs, not after them: independent atomics into the same system, and a launch of
     // their own cost ~8 us on the dependent path
     double* sJ = reinterpret_cast<double*>(slab);
-    small_assemble_unit(small, bsg_bx, threadIdx.x, 64, sJ, sJ + 15 * 30, reinterpret_cast<int*>(sJ + 15 * 30 + 16), S, ld, rhs_row, grad, hdiag, perm);
+    small_assemble_unit(small, bsg_bx / kPairRiderParts, threadIdx.x, 64, sJ, sJ + 15 * 30, reinterpret_cast<int*>(sJ + 15 * 30 + 16), S, ld, rhs_row, grad, hdiag, perm,
+                        bsg_bx % kPairRiderParts, kPairRiderParts);
     return;
   }
   // XCD-aware mapping: consecutive workgroup ids go round-robin over the 8 XCDs, each with its own L2.  Segments are
@@ -518,7 +520,7 @@ void launch_pairs(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row
   const int pair_blocks = 8 * ((v.n_seg + 7) / 8);
   SmallGroupSet none;
   none.n = 0;
-  const int small_blocks = small ? 8 * ((n_small_units + 7) / 8) : 0;   // (padded: idle workgroups return at once)
+  const int small_blocks = small ? 8 * ((n_small_units * kPairRiderParts + 7) / 8) : 0;   // (padded: idle workgroups return at once)
   hipLaunchKernelGGL(pairs_kernel, dim3(pair_blocks + small_blocks), dim3(64), kPairsLds, s, v.n_seg, v.seg_ci, v.seg_cj, v.seg_start, v.ent_fa,
                      v.ent_fb, v.J, v.r, v.CR, v.cp_tq, v.cp_tp, S, ld, rhs_row, grad, hdiag, perm, grad_only ? 1 : 0, pair_blocks, small ? *small : none,
                      small_blocks);
@@ -723,7 +725,7 @@ void launch_landmark_batch(hipStream_t s, const BatchArgTable& t, const BatchArg
 void batchargs_pairs(BatchArgTable& t, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm, const SmallGroupSet* small,
                      int n_small_units) {
   pairs_kernel_Args a;
-  const int pair_blocks = 8 * ((v.n_seg + 7) / 8), small_blocks = small ? 8 * ((n_small_units + 7) / 8) : 0;
+  const int pair_blocks = 8 * ((v.n_seg + 7) / 8), small_blocks = small ? 8 * ((n_small_units * kPairRiderParts + 7) / 8) : 0;
   SmallGroupSet none;
   none.n = 0;
   a.bsg_grid = v.n_seg > 0 ? pair_blocks + small_blocks : 0;
