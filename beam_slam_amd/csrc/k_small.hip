@@ -266,7 +266,8 @@ __global__ __launch_bounds__(64) void imu_eval_kernel(SmallGroup delta, SmallGro
 template <bool WITH_J>
 __device__ __forceinline__ void visual_imu_eval_kernel_body(const int bsg_bx, const int bsg_gx, SmallGroup delta, SmallGroup prior, double* __restrict__ part_delta, double* __restrict__ part_prior, int n_imu_blocks, int n, const int4* __restrict__ fac, const double2* __restrict__ pix, const double* __restrict__ wgt, const double* __restrict__ x, const DevCamera* __restrict__ cams, const DevLoss* __restrict__ losses, double2* __restrict__ r_out, double* __restrict__ J_out, double* __restrict__ JB_out, double* __restrict__ cost_part, int count_inactive) {
   if (bsg_bx < n_imu_blocks) {
-    const int f = 4 * bsg_bx + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // (the factor index is the same in every lane of the wave: said so, its tables, constants and values are fetched with scalar loads)
+    const int f = __builtin_amdgcn_readfirstlane(4 * bsg_bx + ((int)threadIdx.x >> 6)), lane = threadIdx.x & 63;
     if (f < delta.n) imu_delta_body<WITH_J>(delta, f, x, losses, part_delta, lane);
     else if (f < delta.n + prior.n) imu_prior_body<WITH_J>(prior, f - delta.n, x, losses, part_prior, lane);
     return;
@@ -577,7 +578,7 @@ __global__ __launch_bounds__(128) void relpose_imu_eval_kernel(SmallGroup delta,
   }
   const int bx = (int)blockIdx.x - n_units;
   if (bx < n_imu_blocks) {
-    const int f = 2 * bx + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int f = __builtin_amdgcn_readfirstlane(2 * bx + ((int)threadIdx.x >> 6)), lane = threadIdx.x & 63;
     if (f < delta.n) imu_delta_body<WITH_J>(delta, f, x, losses, part_delta, lane);
     else if (f < delta.n + prior.n) imu_prior_body<WITH_J>(prior, f - delta.n, x, losses, part_prior, lane);
     return;
