@@ -139,10 +139,12 @@ struct LmWindow {
   }
 };
 
-// the argument tables of one set of windows, built once per (contexts, finalize generations, options that enter the tables)
-// windows per call up to which the LM diagonal / gradient norms ride in the factorisation's launch (above: their own batched launch and the
-// task lists without them).  Measured: 2 windows of C2 ..., 8 windows of C2 5 150 against 5 350 LM it/s, 32 windows of 20 KF x 500 91 700 against 99 100
+// Windows per call up to which the LM diagonal / gradient norms ride in the factorisation's launch (bsgpu_solve.cpp does that for a lone
+// window); above it they take their own batched launch and the task lists without those tasks.  0: never — a batch is bound by the number
+// of its (LDS-heavy, one per CU) factorisation workgroups, and the separate launch's 256-thread workgroups are the cheaper form: 8 windows
+// of C2 5 350 against 5 150 LM it/s, 32 windows of 20 KF x 500 99 100 against 91 700.
 constexpr int kBatchDiagInCholMax = 0;
+// the argument tables of one set of windows, built once per (contexts, finalize generations, options that enter the tables)
 struct BatchPlan {
   std::vector<bsgpu_ctx*> ctxs;
   std::vector<uint64_t> gens;
@@ -254,8 +256,7 @@ bool build_plan(BatchPlan& P, bsgpu_ctx* const* ctxs, int n, const bsgpu_options
                      c->d_bs_chain_group, c->d_bs_grp_nchains, c->d_bs_grp_nitems, c->d_bs_items4, c->d_bs_tile_updated, c->d_bs_sync, c->d_scal, c->d_Winv, c->d_bs_order, c->d_tile_tot, 1};
     // (the LM diagonal and the gradient norms of a full step ride in the factorisation's launch when the window's plan has the tasks for them;
     //  radius and the step's flags are patched in per round, BatchDyn)
-    // — for a FEW windows: a batch of many small windows is bound by the number of its (LDS-heavy) factorisation workgroups, and the
-    // separate launch's 256-thread workgroups are the cheaper form there (32 windows of 20 KF x 500: 99 100 against 91 700 LM it/s)
+    // (kBatchDiagInCholMax: for few windows only)
     P.diag_in_chol[w] = n <= kBatchDiagInCholMax && c->plan.diag_tasks && c->plan.rider_tasks * 256 >= c->nb;
     LmDiag lmd;
     GradNormRide gnr;
