@@ -120,6 +120,7 @@ bsgpu_ctx* bsgpu_create(int device) try {
 } catch (...) { try { g_create_error = "out of host memory"; } catch (...) {} return nullptr; }
 void bsgpu_destroy(bsgpu_ctx* c) {
   if (!c) return;
+  batch_forget(c);   // (argument tables of bsgpu_solve_batch that name this context hold its device pointers)
   (void)hipSetDevice(c->device);
   c->free_device();
   c->release_pool();

@@ -333,6 +333,7 @@ int build_bsr(bsgpu_ctx* c);
 int build_spcg(bsgpu_ctx* c);
 // bsgpu_solve.cpp
 int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum);
+void enqueue_fixed_cost(bsgpu_ctx* c, hipStream_t s);
 void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot, const ReduceRide* red = nullptr);
 // factor_follows: linear_solve_and_candidate() comes next — its factorisation launch may then carry the LM diagonal and the gradient norms
 void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, bool first, bool gradient_only = false, bool factor_follows = false);
@@ -353,5 +354,6 @@ int profile_step(bsgpu_ctx* c, const bsgpu_options& o, int reps, double* ms_out,
 bool batch_covers(bsgpu_ctx* c, const bsgpu_options& o);
 void batch_stats(int64_t* windows, int64_t* rounds);
 bool solve_batched(bsgpu_ctx* const* ctxs, const int* idx, int m, const bsgpu_options* o, int options_stride, bsgpu_summary* s, int* rc);
+void batch_forget(const bsgpu_ctx* c);   // a context is going away: cached argument tables that name it are dropped
 
 }  // namespace bsg

@@ -1,5 +1,7 @@
 // finalize(): flattening of the described problem to device tables — what [EXT] fuse HashGraph::createProblem does for the
 // reference's `graph_->optimize()` (bs_optimizers/src/fixed_lag_smoother.cpp:281), with a deterministic variable index.
+#include <atomic>
+
 #include "bsgpu_ctx.h"
 #include "dim_order.h"
 
@@ -1061,7 +1063,12 @@ int finalize(bsgpu_ctx* c) {
   HIPCHK(c, hipGetLastError());
   lap("device sync");
   c->finalized = true;
-  c->finalize_gen++;
+  {
+    // process-unique: a context re-created at the address of a destroyed one (the submap-refinement pattern: create N windows, solve, destroy,
+    // create N fresh ones) must never match tables cached for the old one (bsgpu_batch.cpp)
+    static std::atomic<uint64_t> g_finalize_gen{0};
+    c->finalize_gen = ++g_finalize_gen;
+  }
   return BSGPU_OK;
 }
 

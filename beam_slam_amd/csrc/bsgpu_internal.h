@@ -213,7 +213,7 @@ void launch_small_eval(hipStream_t s, const SmallGroup& g, const double* x, cons
 // these lists and whose arguments come from a per-window table in device memory.  The block below is what changes from one LM
 // iteration to the next; it goes up once per iteration.
 constexpr int kBatchMaxWin = 64;
-enum { BL_ALL = 0, BL_FULL = 1, BL_ACC = 2, BL_REJ = 3, BL_BS_FUSED = 4 /* + deep */, BL_BS_CHAIN = 6 /* + deep */, BL_DIAG = 8 /* windows whose LM diagonal / gradient norms need their own launch this round */, BL_NUM = 9 };   // (BL_BS_*: the FULL windows by the form of their back-substitution)
+enum { BL_ALL = 0, BL_FULL = 1, BL_ACC = 2, BL_REJ = 3, BL_BS_FUSED = 4 /* + deep */, BL_BS_CHAIN = 6 /* + deep */, BL_DIAG = 8 /* windows whose LM diagonal / gradient norms need their own launch this round */, BL_CLEAR = 9 /* windows without a landmark launch whose reduced system was not cleared at the end of their previous step */, BL_NUM = 10 };   // (BL_BS_*: the FULL windows by the form of their back-substitution)
 struct BatchDyn {
   int n[BL_NUM];                       // windows in: every window still iterating | those that compute a full step (not just the gradient
   int idx[BL_NUM][kBatchMaxWin];       // of their last point) | those whose candidate was accepted (x <- x_cand) | those whose step was
@@ -305,6 +305,23 @@ void launch_copy_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dy
 void batchargs_chol_fused(BatchArgTable& t, double* S, double* Lp, int ld, const FusedTask* tasks_dev, int n_tasks, const int* tile_tot_dev, const int* nreal_dev,
                           double* Vinv, double* scal, int* sync_dev, double* Winv, int rhs_rows, const LmDiag& diag, const GradNormRide& gn);
 void launch_chol_fused_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n);
+// ... the pose-only family (k_small.hip, k_misc.hip): lidar-inertial windows, dense-path pose graphs, the pose-only factors of any window
+struct AsmGroup;
+void batchargs_relpose_imu_eval(BatchArgTable& t, const SmallGroup* g, const SmallGroup& delta, const SmallGroup& prior, const double* x, const DevLoss* losses,
+                                double* cost_part, double* part_delta, double* part_prior);
+void launch_relpose_imu_eval_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n, bool with_J);
+bool batchargs_small_eval_set(BatchArgTable& t, const SmallGroup* groups, double* const* parts, int n_groups, const double* x, const DevLoss* losses);
+void launch_small_eval_set_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n, bool with_J);
+bool batchargs_small_assemble_set(BatchArgTable& t, const SmallGroup* groups, int n_groups, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm);
+void launch_small_assemble_set_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n);
+void batchargs_small_assemble_seg(BatchArgTable& t, const SmallGroup* groups_dev, int n_seg, const int* seg_start, const int* seg_ra, const int* seg_rb, const int2* contrib,
+                                  double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm, const SmallGroupSet* fw, int n_fw_units, int n_grp,
+                                  const AsmGroup* grp, const int* gfac);
+void launch_small_assemble_seg_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n);
+bool batchargs_small_mcc(BatchArgTable& t, const SmallGroup* groups, double* const* parts, int n_groups, const double* delta, const UpdateRide* upd, const ZeroStep* zero);
+void launch_small_mcc_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n);
+void batchargs_zero_tiles_multi(BatchArgTable& t, const ZeroStep* zs);
+void launch_zero_tiles_multi_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n);
 int batchargs_backsolve(BatchArgTable* tabs, const DensePlan& P, const DenseDev& D, double* y, const int* iperm, int n_pose, double* y_tan, double* delta);
 void launch_backsolve_batch(hipStream_t s, const BatchArgTable* tabs, const BatchDyn* dyn, const int* n_in_form);
 void launch_landmark(hipStream_t s, const Visual& v, int n_pose, const double* radius_ptr, int compute_scale,

@@ -6,6 +6,7 @@
 #include <thread>
 
 #include "bsgpu_ctx.h"
+#include "lm_state.h"
 
 namespace bsg {
 
@@ -426,13 +427,13 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o, bool defer
 // The three variants are captured once per finalized problem as hipGraphs and replayed: the host-side
 // launch cost (~4.5 us per kernel, > 100 kernels per step) otherwise bounds the iteration rate.
 // ---------------------------------------------------------------------------------------------------
-enum StepKind { STEP_FIRST = 0, STEP_ACCEPT = 1, STEP_REJECT = 2 };
 
 // gradient_only: the iteration budget is used up — the point just accepted still needs its cost and gradient norms for the
 // iteration record, but no step will be taken from it: evaluation + assembly (which produces the gradient), no factorisation,
 // no candidate
 void enqueue_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius, bool gradient_only = false) {
   hipStream_t s = c->stream;
+  c->cost_x_stale = false;   // (set below only for a step whose reduction rides in the evaluation ahead: a gradient-only step's full reduction gives SC_COST_X)
   if (kind == STEP_ACCEPT) {
     // the accepted candidate becomes the current point: a pointer swap (every launch takes x as an argument; the next update
     // rewrites all of the other buffer) — except under graph replay, whose kernel arguments are frozen
@@ -602,6 +603,29 @@ int fetch_scalars(bsgpu_ctx* c) {
   return BSGPU_OK;
 }
 
+// the cost of the residual blocks whose parameter blocks are all constant (Ceres: fixed_cost) into SC_FIXED_COST, once per solve, on stream s
+// (the partial arrays it borrows are rewritten by the first step's evaluations, which follow on the same stream)
+void enqueue_fixed_cost(bsgpu_ctx* c, hipStream_t s) {
+  if (!c->any_inactive) return;
+  launch_zero(s, c->d_scal + SC_FIXED_COST, 1);
+  for (int t = 2; t < kNumInternal; ++t) {
+    if (!c->small[t].n) continue;
+    SmallGroup g = c->small[t];
+    g.active = c->d_small_inactive[t];
+    launch_small_eval(s, g, c->d_x, c->d_losses, false, c->d_small_part[t]);
+    launch_sum(s, c->d_small_part[t], small_cost_parts(g), c->d_scal + SC_FIXED_COST, 1);
+  }
+  for (const auto& mc : c->marg) {
+    if (mc.active) continue;
+    launch_marg_eval(s, mc.dev, c->d_x, false, mc.part);
+    launch_sum(s, mc.part, mc.dev.rows, c->d_scal + SC_FIXED_COST, 1);
+  }
+  if (c->vis_any_inactive) {   // reprojection factors whose three blocks are all constant
+    launch_reproj_eval(s, c->vis, c->d_x, c->d_cams, c->d_losses, false, c->vis.cost_part_cand, true);
+    launch_sum(s, c->vis.cost_part_cand, c->vis.n_cost_part, c->d_scal + SC_FIXED_COST, 1);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // [EXT] ceres::internal::TrustRegionMinimizer + LevenbergMarquardtStrategy, restated
 // ---------------------------------------------------------------------------------------------------
@@ -631,128 +655,31 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
 
   // iteration zero
   double fixed = 0.0;
-  if (c->any_inactive) {
-    // cost of residual blocks whose parameter blocks are all constant (Ceres: fixed_cost)
-    launch_zero(s, c->d_scal + SC_FIXED_COST, 1);
-    for (int t = 2; t < kNumInternal; ++t) {
-      if (!c->small[t].n) continue;
-      SmallGroup g = c->small[t];
-      g.active = c->d_small_inactive[t];
-      launch_small_eval(s, g, c->d_x, c->d_losses, false, c->d_small_part[t]);
-      launch_sum(s, c->d_small_part[t], small_cost_parts(g), c->d_scal + SC_FIXED_COST, 1);
-    }
-    for (const auto& mc : c->marg) {
-      if (mc.active) continue;
-      launch_marg_eval(s, mc.dev, c->d_x, false, mc.part);
-      launch_sum(s, mc.part, mc.dev.rows, c->d_scal + SC_FIXED_COST, 1);
-    }
-    if (c->vis_any_inactive) {   // reprojection factors whose three blocks are all constant
-      launch_reproj_eval(s, c->vis, c->d_x, c->d_cams, c->d_losses, false, c->vis.cost_part_cand, true);
-      launch_sum(s, c->vis.cost_part_cand, c->vis.n_cost_part, c->d_scal + SC_FIXED_COST, 1);
-    }
-  }
-  double radius = o.initial_trust_region_radius, decrease_factor = 2.0;
+  enqueue_fixed_cost(c, s);
   build_graphs(c, o);
-  run_step(c, o, STEP_FIRST, radius);
+  // the trust-region loop itself: lm_state.h (one copy, shared with bsgpu_solve_batch); this driver computes the steps it asks for
+  LmState lm;
+  const bsgpu_summary head = sum;   // (what was filled in above: start() clears the summary)
+  lm.start(&o, &sum, &c->iters, head.num_parameters_tangent, head.num_residuals, head.linear_solver_used);
+  lm.t_start = t_start;
+  run_step(c, o, STEP_FIRST, lm.radius);
   rc = fetch_scalars(c);
   if (rc != BSGPU_OK) return rc;
   fixed = c->any_inactive ? c->h_scal[SC_FIXED_COST] : 0.0;
-  double x_cost = c->h_scal[SC_COST_X];
-  bsgpu_iteration it;
-  std::memset(&it, 0, sizeof(it));
-  it.iteration = 0; it.step_is_valid = 1; it.step_is_successful = 1; it.cost = x_cost + fixed;
-  it.gradient_max_norm = c->h_scal[SC_GRAD_MAX]; it.gradient_norm = std::sqrt(c->h_scal[SC_GRAD_NORM2]);
-  sum.initial_cost = x_cost + fixed; sum.fixed_cost = fixed;
-  sum.termination_type = BSGPU_NO_CONVERGENCE;
-  const char* msg = "";
-  if (!std::isfinite(x_cost)) {
-    sum.termination_type = BSGPU_FAILURE; msg = "Initial cost is not finite.";
-    sum.final_cost = sum.initial_cost;
-  } else {
-    int num_consecutive_invalid = 0;
-    // `pending` = a step (linear solve + candidate evaluation) has been computed for the current x/radius
-    while (true) {
-      if (it.step_is_successful) { if (it.iteration > 0) sum.num_successful_steps++; } else sum.num_unsuccessful_steps++;
-      it.trust_region_radius = radius;
-      c->iters.push_back(it);
-      if (o.max_solver_time_in_seconds > 0 && elapsed() >= o.max_solver_time_in_seconds) { msg = "Maximum solver time reached."; break; }
-      if (it.iteration >= o.max_num_iterations) { msg = "Maximum number of iterations reached."; break; }
-      if (it.step_is_successful && it.gradient_max_norm <= o.gradient_tolerance) { sum.termination_type = BSGPU_CONVERGENCE; msg = "Gradient tolerance reached."; break; }
-      if (radius <= o.min_trust_region_radius) { sum.termination_type = BSGPU_CONVERGENCE; msg = "Minimum trust region radius reached."; break; }
-      if (c->h_scal[SC_CHOL_FAIL] == 2.0 && c->d_ftasks) {
-        // A wait inside one of the single-launch kernels (factorisation / back-substitution) timed out: the GPU is shared and their
-        // workgroups were not scheduled in time — not a numerical failure.  This context takes the launch-per-step path from
-        // here on, and the step is computed again at the same point and radius.
-        c->d_ftasks = nullptr;
-        if (getenv("BSGPU_TIMING")) fprintf(stderr, "[bsgpu] single-launch Cholesky timed out: launch-per-step path from here on\n");
-        if (c->use_graphs) { c->destroy_graphs(); build_graphs(c, o); }   // (the captured sequences still hold the single-launch kernel)
-        // the record of this iteration was pushed above and is pushed again when the loop comes back with the recomputed step
-        c->iters.pop_back();
-        if (it.step_is_successful) { if (it.iteration > 0) sum.num_successful_steps--; } else sum.num_unsuccessful_steps--;
-        run_step(c, o, STEP_REJECT, radius);
-        rc = fetch_scalars(c);
-        if (rc != BSGPU_OK) return rc;
-        continue;
-      }
-      const bsgpu_iteration prev = it;
-      std::memset(&it, 0, sizeof(it));
-      it.iteration = prev.iteration + 1;
-      it.gradient_max_norm = prev.gradient_max_norm; it.gradient_norm = prev.gradient_norm;
-      sum.num_linear_solves++;
-      // the step for (x, radius) is already on the host: h_scal
-      const double mcc = c->h_scal[SC_MCC];
-      const bool lin_ok = !(c->h_scal[SC_CHOL_FAIL] > 0.0) && std::isfinite(mcc) && std::isfinite(c->h_scal[SC_STEP_NORM2]);
-      it.model_cost_change = lin_ok ? mcc : 0.0;
-      it.step_is_valid = lin_ok && mcc > 0.0;
-      if (!it.step_is_valid) {
-        if (++num_consecutive_invalid >= o.max_num_consecutive_invalid_steps) {
-          sum.termination_type = BSGPU_FAILURE;
-          msg = "Number of consecutive invalid steps more than max_num_consecutive_invalid_steps.";
-          break;
-        }
-        radius *= 0.5;   // [EXT] LevenbergMarquardtStrategy::StepIsInvalid(): the radius is halved, decrease_factor_ is untouched
-        it.cost = x_cost + fixed; it.step_is_successful = 0;
-        if (it.iteration >= o.max_num_iterations) continue;   // the loop ends at its top: a step from here would never be looked at
-        run_step(c, o, STEP_REJECT, radius);
-        rc = fetch_scalars(c);
-        if (rc != BSGPU_OK) return rc;
-        continue;
-      }
-      num_consecutive_invalid = 0;
-      double cand_cost = c->h_scal[SC_COST_CAND];
-      if (!std::isfinite(cand_cost)) cand_cost = std::numeric_limits<double>::max();
-      it.step_norm = std::sqrt(c->h_scal[SC_STEP_NORM2]);
-      const double x_norm = std::sqrt(c->h_scal[SC_X_NORM2]);
-      if (it.step_norm <= o.parameter_tolerance * (x_norm + o.parameter_tolerance)) { sum.termination_type = BSGPU_CONVERGENCE; msg = "Parameter tolerance reached."; break; }
-      it.cost_change = x_cost - cand_cost;
-      if (std::fabs(it.cost_change) <= o.function_tolerance * x_cost) { sum.termination_type = BSGPU_CONVERGENCE; msg = "Function tolerance reached."; break; }
-      it.relative_decrease = (x_cost - cand_cost) / mcc;
-      const bool last_iteration = it.iteration >= o.max_num_iterations;
-      if (it.relative_decrease > o.min_relative_decrease) {
-        radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * it.relative_decrease - 1.0, 3));
-        radius = std::min(o.max_trust_region_radius, radius);
-        decrease_factor = 2.0;
-        it.step_is_successful = 1;
-        // the next step is computed right away so that one synchronisation per iteration suffices; when this was the last
-        // iteration the budget allows, only the accepted point's cost and gradient are (a full step would be thrown away)
-        run_step(c, o, STEP_ACCEPT, radius, last_iteration);
-      } else {
-        it.step_is_successful = 0;
-        radius = radius / decrease_factor; decrease_factor *= 2.0;
-        it.cost = cand_cost + fixed;
-        if (last_iteration) continue;
-        run_step(c, o, STEP_REJECT, radius);
-      }
-      rc = fetch_scalars(c);
-      if (rc != BSGPU_OK) return rc;
-      if (it.step_is_successful) {
-        x_cost = c->cost_x_stale ? cand_cost : c->h_scal[SC_COST_X];   // (the same sum: the candidate's cost-only pass and the pass with Jacobians add the same partials)
-        it.cost = x_cost + fixed;
-        it.gradient_max_norm = c->h_scal[SC_GRAD_MAX];
-        it.gradient_norm = std::sqrt(c->h_scal[SC_GRAD_NORM2]);
-      }
+  lm.begin(c->h_scal, fixed, c->d_ftasks != nullptr);
+  while (!lm.done) {
+    if (lm.retry_timeout) {
+      // A wait inside one of the single-launch kernels (factorisation / back-substitution) timed out: the GPU is shared and their
+      // workgroups were not scheduled in time — not a numerical failure.  This context takes the launch-per-step path from
+      // here on, and the step is computed again at the same point and radius.
+      c->d_ftasks = nullptr;
+      if (getenv("BSGPU_TIMING")) fprintf(stderr, "[bsgpu] single-launch Cholesky timed out: launch-per-step path from here on\n");
+      if (c->use_graphs) { c->destroy_graphs(); build_graphs(c, o); }   // (the captured sequences still hold the single-launch kernel)
     }
-    sum.final_cost = x_cost + fixed;
+    run_step(c, o, lm.kind, lm.radius, lm.grad_only);
+    rc = fetch_scalars(c);
+    if (rc != BSGPU_OK) return rc;
+    lm.advance(c->h_scal, c->cost_x_stale, c->d_ftasks != nullptr);
   }
   HIPCHK(c, hipEventRecord(ev1, s));
   HIPCHK(c, hipEventSynchronize(ev1));
@@ -761,11 +688,8 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
   (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
   sum.device_time_in_seconds = ms * 1e-3;
   c->scal_mirrored = false; c->ev_reduce_pending = false; c->spec_J = false;   // (the stream has drained: nothing of this solve is pending)
-  sum.num_iterations = (int)c->iters.size() - 1;
   sum.num_inner_iterations = c->pcg_iters_total;
-  sum.is_solution_usable = (sum.termination_type == BSGPU_CONVERGENCE || sum.termination_type == BSGPU_NO_CONVERGENCE) ? 1 : 0;
   sum.total_time_in_seconds = elapsed();
-  std::snprintf(sum.message, sizeof(sum.message), "%s", msg);
   return BSGPU_OK;
 }
 

@@ -219,13 +219,13 @@ void launch_zero(hipStream_t s, double* p, int64_t n) {
 // one launch for what an LM step clears: up to three small arrays and the reduced system — of which only the listed 64x64 tiles
 // are ever written (dense_plan.h: touched_tiles): a banded window touches a fraction of the dense square (C2: 30 %; an
 // 800-keyframe window: 7 %), the rest stays zero from finalize().  The step's trust-region radius rides in as an argument.
-__global__ __launch_bounds__(256) void zero_tiles_multi_kernel(double* __restrict__ S, int ld, const int* __restrict__ tiles, int n_tiles,
-                                                               double* __restrict__ a, int na, double* __restrict__ b, int nb,
-                                                               double* __restrict__ c, int nc, double* __restrict__ radius_slot, double radius) {
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+__device__ __forceinline__ void zero_tiles_multi_kernel_body(const int bsg_bx, const int bsg_gx, double* __restrict__ S, int ld, const int* __restrict__ tiles, int n_tiles,
+                                                             double* __restrict__ a, int na, double* __restrict__ b, int nb,
+                                                             double* __restrict__ c, int nc, double* __restrict__ radius_slot, double radius) {
+  const int64_t t = (int64_t)bsg_bx * 256 + threadIdx.x, stride = (int64_t)bsg_gx * 256;
   if (radius_slot && t == 0) *radius_slot = radius;
   const int nt = ld >> 6;
-  for (int q = blockIdx.x; q < n_tiles; q += gridDim.x) {
+  for (int q = bsg_bx; q < n_tiles; q += bsg_gx) {
     const int ti = tiles[q] / nt, tj = tiles[q] - ti * nt;
     double2* base = reinterpret_cast<double2*>(S + (size_t)ti * 64 * ld + (size_t)tj * 64);
     const int r0 = threadIdx.x >> 5, c2 = threadIdx.x & 31;
@@ -235,6 +235,35 @@ __global__ __launch_bounds__(256) void zero_tiles_multi_kernel(double* __restric
   for (int64_t i = t; i < na; i += stride) a[i] = 0.0;
   for (int64_t i = t; i < nb; i += stride) b[i] = 0.0;
   for (int64_t i = t; i < nc; i += stride) c[i] = 0.0;
+}
+__global__ __launch_bounds__(256) void zero_tiles_multi_kernel(double* __restrict__ S, int ld, const int* __restrict__ tiles, int n_tiles,
+                                                               double* __restrict__ a, int na, double* __restrict__ b, int nb,
+                                                               double* __restrict__ c, int nc, double* __restrict__ radius_slot, double radius) {
+  zero_tiles_multi_kernel_body((int)blockIdx.x, (int)gridDim.x, S, ld, tiles, n_tiles, a, na, b, nb, c, nc, radius_slot, radius);
+}
+// one launch over several windows (bsgpu_batch.cpp): the start-of-step clearing of the windows that have no landmark launch to carry it and
+// were not cleared at the end of their previous step; zs.c = the step's scalars from SC_GRAD_MAX on (nc = 3), the radius comes per round
+struct zero_tiles_multi_kernel_Args {
+  int bsg_grid;
+  ZeroStep zs;
+};
+__global__ __launch_bounds__(256) void zero_tiles_multi_kernel_batch(const zero_tiles_multi_kernel_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
+  const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
+  const zero_tiles_multi_kernel_Args& a = bsg_A[bsg_w];
+  if ((int)blockIdx.x >= a.bsg_grid) return;
+  ZeroStep zs = a.zs;
+  if (!bsg_dyn->new_J[bsg_w]) { zs.c += SC_CHOL_FAIL - SC_GRAD_MAX; zs.nc = 1; }
+  zero_tiles_multi_kernel_body((int)blockIdx.x, a.bsg_grid, zs.S, zs.ld, zs.tiles, zs.n_tiles, zs.a, zs.na, zs.b, zs.nb, zs.c, zs.nc, zs.radius_slot, bsg_dyn->radius[bsg_w]);
+}
+void batchargs_zero_tiles_multi(BatchArgTable& t, const ZeroStep* zs /* null: the window clears elsewhere */) {
+  zero_tiles_multi_kernel_Args a;
+  a.zs = zs ? *zs : ZeroStep();
+  a.bsg_grid = zs ? std::max(1, std::min(zs->n_tiles, 2048)) : 0;
+  t.push(a);
+}
+void launch_zero_tiles_multi_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n) {
+  if (n <= 0 || t.max_grid <= 0) return;
+  hipLaunchKernelGGL(zero_tiles_multi_kernel_batch, dim3(t.max_grid, n), dim3(256), 0, s, static_cast<const zero_tiles_multi_kernel_Args*>(t.dev), dyn, list);
 }
 void launch_zero_tiles_multi(hipStream_t s, double* S, int ld, const int* tiles_dev, int n_tiles, double* a, int na, double* b, int nb, double* c,
                              int nc, double* radius_slot, double radius) {

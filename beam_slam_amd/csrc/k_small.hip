@@ -563,6 +563,19 @@ __global__ __launch_bounds__(128) void relpose_kernel(SmallGroup g, const double
 }
 // a lidar-inertial window: the IMU factors (a wave each) as the first workgroups of the relative-pose evaluation, instead of a launch of
 // their own behind it (as visual_imu_eval_kernel does for a visual-inertial window)
+// (body shared by the lone launch and the batched one: IMU factors — a wave each, two per workgroup — then 128 relative-pose factors per workgroup)
+template <bool EXT, bool WITH_J>
+__device__ __forceinline__ void relpose_imu_eval_body(const int bx, const SmallGroup& delta, const SmallGroup& prior, double* __restrict__ part_delta,
+                                                      double* __restrict__ part_prior, int n_imu_blocks, const SmallGroup& g, const double* __restrict__ x,
+                                                      const DevLoss* __restrict__ losses, double* __restrict__ cost_part) {
+  if (bx < n_imu_blocks) {
+    const int f = __builtin_amdgcn_readfirstlane(2 * bx + ((int)threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    if (f < delta.n) imu_delta_body<WITH_J>(delta, f, x, losses, part_delta, lane);
+    else if (f < delta.n + prior.n) imu_prior_body<WITH_J>(prior, f - delta.n, x, losses, part_prior, lane);
+    return;
+  }
+  relpose_body<EXT, WITH_J>(g, x, losses, cost_part, bx - n_imu_blocks);
+}
 template <bool EXT, bool WITH_J>
 __global__ __launch_bounds__(128) void relpose_imu_eval_kernel(SmallGroup delta, SmallGroup prior, double* __restrict__ part_delta,
                                                                double* __restrict__ part_prior, int n_imu_blocks, SmallGroup g,
@@ -576,14 +589,43 @@ __global__ __launch_bounds__(128) void relpose_imu_eval_kernel(SmallGroup delta,
     final_reduce_unit<128>((int)blockIdx.x, (int)threadIdx.x, red, n_units, sred);
     return;
   }
-  const int bx = (int)blockIdx.x - n_units;
-  if (bx < n_imu_blocks) {
-    const int f = __builtin_amdgcn_readfirstlane(2 * bx + ((int)threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    if (f < delta.n) imu_delta_body<WITH_J>(delta, f, x, losses, part_delta, lane);
-    else if (f < delta.n + prior.n) imu_prior_body<WITH_J>(prior, f - delta.n, x, losses, part_prior, lane);
-    return;
-  }
-  relpose_body<EXT, WITH_J>(g, x, losses, cost_part, bx - n_imu_blocks);
+  relpose_imu_eval_body<EXT, WITH_J>((int)blockIdx.x - n_units, delta, prior, part_delta, part_prior, n_imu_blocks, g, x, losses, cost_part);
+}
+// one launch over several windows (bsgpu_batch.cpp): blockIdx.y picks the window of list `bsg_list`, its arguments come from memory.  A
+// window without relative-pose factors of this kind has a zero grid in its entry; EXT (the extrinsics slots) is the group's type.
+struct relpose_imu_eval_kernel_Args {
+  int bsg_grid;
+  SmallGroup delta;
+  SmallGroup prior;
+  double* part_delta;
+  double* part_prior;
+  int n_imu_blocks;
+  SmallGroup g;
+  const double* x;
+  const DevLoss* losses;
+  double* cost_part;
+};
+template <bool WITH_J>
+__global__ __launch_bounds__(128) void relpose_imu_eval_kernel_batch(const relpose_imu_eval_kernel_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
+  const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
+  const relpose_imu_eval_kernel_Args& a = bsg_A[bsg_w];
+  if ((int)blockIdx.x >= a.bsg_grid) return;
+  if (a.g.type == BSGPU_F_RELPOSE_EXT) relpose_imu_eval_body<true, WITH_J>((int)blockIdx.x, a.delta, a.prior, a.part_delta, a.part_prior, a.n_imu_blocks, a.g, a.x, a.losses, a.cost_part);
+  else relpose_imu_eval_body<false, WITH_J>((int)blockIdx.x, a.delta, a.prior, a.part_delta, a.part_prior, a.n_imu_blocks, a.g, a.x, a.losses, a.cost_part);
+}
+void batchargs_relpose_imu_eval(BatchArgTable& t, const SmallGroup* g /* null: the window has no such launch */, const SmallGroup& delta, const SmallGroup& prior, const double* x,
+                                const DevLoss* losses, double* cost_part, double* part_delta, double* part_prior) {
+  relpose_imu_eval_kernel_Args a;
+  a.delta = delta; a.prior = prior; a.part_delta = part_delta; a.part_prior = part_prior; a.x = x; a.losses = losses; a.cost_part = cost_part;
+  if (g) { a.g = *g; a.n_imu_blocks = (delta.n + prior.n + 1) / 2; a.bsg_grid = a.n_imu_blocks + (g->n + 127) / 128; }
+  else { a.g = SmallGroup(); a.n_imu_blocks = 0; a.bsg_grid = 0; }
+  t.push(a);
+}
+void launch_relpose_imu_eval_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n, bool with_J) {
+  if (n <= 0 || t.max_grid <= 0) return;
+  const auto* A = static_cast<const relpose_imu_eval_kernel_Args*>(t.dev);
+  if (with_J) hipLaunchKernelGGL(relpose_imu_eval_kernel_batch<true>, dim3(t.max_grid, n), dim3(128), 0, s, A, dyn, list);
+  else hipLaunchKernelGGL(relpose_imu_eval_kernel_batch<false>, dim3(t.max_grid, n), dim3(128), 0, s, A, dyn, list);
 }
 void launch_relpose_imu_eval(hipStream_t s, const SmallGroup& g, const SmallGroup& delta, const SmallGroup& prior, const double* x,
                              const DevLoss* losses, bool with_J, double* cost_part, double* part_delta, double* part_prior, const ReduceRide* red) {
@@ -599,10 +641,9 @@ void launch_relpose_imu_eval(hipStream_t s, const SmallGroup& g, const SmallGrou
 
 // absolute pose prior: blocks (p, q), r = A [p - b_p ; AngleAxis(b_q^-1 q)]
 template <bool WITH_J>
-__global__ __launch_bounds__(128) void abspose_kernel(SmallGroup g, const double* __restrict__ x,
-                                                      const DevLoss* __restrict__ losses,
-                                                      double* __restrict__ cost_part) {
-  const int f = blockIdx.x * 128 + threadIdx.x;
+__device__ __forceinline__ void abspose_kernel_body(const SmallGroup& g, const double* __restrict__ x, const DevLoss* __restrict__ losses,
+    double* __restrict__ cost_part, const int bsg_bx) {
+  const int f = bsg_bx * 128 + threadIdx.x;
   if (f >= g.n) return;
   const int* xo = g.xoff + (size_t)f * 2;
   const int* to = g.toff + (size_t)f * 2;
@@ -642,13 +683,17 @@ __global__ __launch_bounds__(128) void abspose_kernel(SmallGroup g, const double
       Jo[i * 6 + 3 + j] = to[1] < 0 ? 0.0 : a * sc;
     }
 }
+template <bool WITH_J>
+__global__ __launch_bounds__(128) void abspose_kernel(SmallGroup g, const double* __restrict__ x, const DevLoss* __restrict__ losses,
+    double* __restrict__ cost_part) {
+  abspose_kernel_body<WITH_J>(g, x, losses, cost_part, (int)blockIdx.x);
+}
 
 // r = A (x - b)  /  r = A ((x2 - x1) - d)
 template <bool REL, bool WITH_J>
-__global__ __launch_bounds__(128) void vec3_kernel(SmallGroup g, const double* __restrict__ x,
-                                                   const DevLoss* __restrict__ losses,
-                                                   double* __restrict__ cost_part) {
-  const int f = blockIdx.x * 128 + threadIdx.x;
+__device__ __forceinline__ void vec3_kernel_body(const SmallGroup& g, const double* __restrict__ x, const DevLoss* __restrict__ losses,
+    double* __restrict__ cost_part, const int bsg_bx) {
+  const int f = bsg_bx * 128 + threadIdx.x;
   if (f >= g.n) return;
   constexpr int NV = REL ? 2 : 1;
   const int* xo = g.xoff + (size_t)f * NV;
@@ -680,13 +725,17 @@ __global__ __launch_bounds__(128) void vec3_kernel(SmallGroup g, const double* _
       }
     }
 }
+template <bool REL, bool WITH_J>
+__global__ __launch_bounds__(128) void vec3_kernel(SmallGroup g, const double* __restrict__ x, const DevLoss* __restrict__ losses,
+    double* __restrict__ cost_part) {
+  vec3_kernel_body<REL, WITH_J>(g, x, losses, cost_part, (int)blockIdx.x);
+}
 
 // gravity alignment: r = A2x2 [R(q) g_b]_{xy}
 template <bool WITH_J>
-__global__ __launch_bounds__(128) void gravity_kernel(SmallGroup g, const double* __restrict__ x,
-                                                      const DevLoss* __restrict__ losses,
-                                                      double* __restrict__ cost_part) {
-  const int f = blockIdx.x * 128 + threadIdx.x;
+__device__ __forceinline__ void gravity_kernel_body(const SmallGroup& g, const double* __restrict__ x, const DevLoss* __restrict__ losses,
+    double* __restrict__ cost_part, const int bsg_bx) {
+  const int f = bsg_bx * 128 + threadIdx.x;
   if (f >= g.n) return;
   const int xo = g.xoff[f];
   const int to = g.toff[f];
@@ -715,6 +764,11 @@ __global__ __launch_bounds__(128) void gravity_kernel(SmallGroup g, const double
     Jo[3 + j] = to < 0 ? 0.0 : (c[5] * D[j] + c[6] * D[3 + j]) * sc;
   }
 }
+template <bool WITH_J>
+__global__ __launch_bounds__(128) void gravity_kernel(SmallGroup g, const double* __restrict__ x, const DevLoss* __restrict__ losses,
+    double* __restrict__ cost_part) {
+  gravity_kernel_body<WITH_J>(g, x, losses, cost_part, (int)blockIdx.x);
+}
 
 // ---------------------------------------------------------------------------------------------------
 // A7 inverse-depth reprojection (bs_constraints/visual/inversedepth_reprojection_functor.h:57-125 and
@@ -732,10 +786,9 @@ __global__ __launch_bounds__(128) void gravity_kernel(SmallGroup g, const double
 // functor uses T = I, its residual is constant in every block).
 // ---------------------------------------------------------------------------------------------------
 template <bool UNARY, bool WITH_J>
-__global__ __launch_bounds__(128) void idp_kernel(SmallGroup g, const double* __restrict__ x,
-                                                  const DevLoss* __restrict__ losses,
-                                                  double* __restrict__ cost_part) {
-  const int f_raw = blockIdx.x * 128 + threadIdx.x;
+__device__ __forceinline__ void idp_kernel_body(const SmallGroup& g, const double* __restrict__ x, const DevLoss* __restrict__ losses,
+    double* __restrict__ cost_part, const int bsg_bx) {
+  const int f_raw = bsg_bx * 128 + threadIdx.x;
   const bool live = f_raw < g.n;
   const int f = live ? f_raw : g.n - 1;   // (idle lanes of the last workgroup redo the last factor and store nothing)
   constexpr int NV = UNARY ? 3 : 5;
@@ -769,7 +822,7 @@ __global__ __launch_bounds__(128) void idp_kernel(SmallGroup g, const double* __
   const double r0 = w * (k[0] - (cam.fx * c[0] * iz + cam.cx)), r1 = w * (k[1] - (cam.fy * c[1] * iz + cam.cy));
   double sc, cost;
   finish_small(g, f, losses, r0 * r0 + r1 * r1, &sc, &cost);
-  block_cost_128(live ? cost : 0.0, cost_part, (int)blockIdx.x);
+  block_cost_128(live ? cost : 0.0, cost_part, bsg_bx);
   if (!WITH_J || !live) return;
   g.r[(size_t)f * 2] = r0 * sc; g.r[(size_t)f * 2 + 1] = r1 * sc;
   double* Jo = g.J + (size_t)f * 2 * 3 * NV;
@@ -824,16 +877,20 @@ __global__ __launch_bounds__(128) void idp_kernel(SmallGroup g, const double* __
     Ji[13] = 0.0; Ji[14] = 0.0;
   }
 }
+template <bool UNARY, bool WITH_J>
+__global__ __launch_bounds__(128) void idp_kernel(SmallGroup g, const double* __restrict__ x, const DevLoss* __restrict__ losses,
+    double* __restrict__ cost_part) {
+  idp_kernel_body<UNARY, WITH_J>(g, x, losses, cost_part, (int)blockIdx.x);
+}
 
 // ---------------------------------------------------------------------------------------------------
 // Euclidean reprojection with a landmark block that is NOT eliminated (slots q, p, P; J 2 x 9 like the
 // visual tables of k_reproj.hip, same closed form: euclidean_reprojection_function.h:66-172)
 // ---------------------------------------------------------------------------------------------------
 template <bool WITH_J>
-__global__ __launch_bounds__(128) void reproj_dense_kernel(SmallGroup g, const double* __restrict__ x,
-                                                           const DevLoss* __restrict__ losses,
-                                                           double* __restrict__ cost_part) {
-  const int f = blockIdx.x * 128 + threadIdx.x;
+__device__ __forceinline__ void reproj_dense_kernel_body(const SmallGroup& g, const double* __restrict__ x, const DevLoss* __restrict__ losses,
+    double* __restrict__ cost_part, const int bsg_bx) {
+  const int f = bsg_bx * 128 + threadIdx.x;
   if (f >= g.n) return;
   const int* xo = g.xoff + (size_t)f * 3;
   const int* to = g.toff + (size_t)f * 3;
@@ -879,6 +936,11 @@ __global__ __launch_bounds__(128) void reproj_dense_kernel(SmallGroup g, const d
     }
   }
 }
+template <bool WITH_J>
+__global__ __launch_bounds__(128) void reproj_dense_kernel(SmallGroup g, const double* __restrict__ x, const DevLoss* __restrict__ losses,
+    double* __restrict__ cost_part) {
+  reproj_dense_kernel_body<WITH_J>(g, x, losses, cost_part, (int)blockIdx.x);
+}
 
 // entries of a group's cost array: one per 128-factor block for the types whose kernels reduce it (block_cost_128), else one per factor
 int small_cost_parts(const SmallGroup& g) {
@@ -919,13 +981,18 @@ void launch_small_eval(hipStream_t s, const SmallGroup& g, const double* x, cons
 // ---------------------------------------------------------------------------------------------------
 // up to kSetMax groups per launch (a window has two or three pose-only factor types, some with a single factor: one
 // launch each would cost more in dispatch than in work)
-__global__ __launch_bounds__(256) void small_assemble_kernel(SmallGroupSet set, double* __restrict__ S, int ld, int rhs_row,
+__device__ __forceinline__ void small_assemble_kernel_body(const int bsg_bx, const SmallGroupSet& set, double* __restrict__ S, int ld, int rhs_row,
                                                             double* __restrict__ grad, double* __restrict__ hdiag,
                                                             const int* __restrict__ perm) {
   __shared__ double sJ[15 * 30];
   __shared__ double sr[15];
   __shared__ int st[10];
-  small_assemble_unit(set, blockIdx.x, threadIdx.x, 256, sJ, sr, st, S, ld, rhs_row, grad, hdiag, perm);
+  small_assemble_unit(set, bsg_bx, threadIdx.x, 256, sJ, sr, st, S, ld, rhs_row, grad, hdiag, perm);
+}
+__global__ __launch_bounds__(256) void small_assemble_kernel(SmallGroupSet set, double* __restrict__ S, int ld, int rhs_row,
+                                                            double* __restrict__ grad, double* __restrict__ hdiag,
+                                                            const int* __restrict__ perm) {
+  small_assemble_kernel_body((int)blockIdx.x, set, S, ld, rhs_row, grad, hdiag, perm);
 }
 
 // Assembly by SEGMENTS, for the factor types whose factors pile onto the same 3x3 blocks of J^T J (bsgpu_finalize.cpp decides and
@@ -998,30 +1065,30 @@ BSG_DEV void small_assemble_group(const SmallGroup* __restrict__ groups, const A
   if (R != C) atomicAdd(&S[pc * ld + pr], acc);
   else atomicAdd(&hdiag[R], acc);
 }
-__global__ __launch_bounds__(256) void small_assemble_seg_kernel(const SmallGroup* __restrict__ groups, int n_seg,
+__device__ __forceinline__ void small_assemble_seg_kernel_body(const int bsg_bx, const SmallGroup* __restrict__ groups, int n_seg,
                                                                 const int* __restrict__ seg_start, const int* __restrict__ seg_ra,
                                                                 const int* __restrict__ seg_rb, const int2* __restrict__ contrib,
                                                                 double* __restrict__ S, int ld, int rhs_row, double* __restrict__ grad,
-                                                                double* __restrict__ hdiag, const int* __restrict__ perm, SmallGroupSet fw,
+                                                                double* __restrict__ hdiag, const int* __restrict__ perm, const SmallGroupSet& fw,
                                                                 int n_fw_units, int n_grp, const AsmGroup* __restrict__ grp,
                                                                 const int* __restrict__ gfac, int first_grp_block) {
-  if ((int)blockIdx.x >= first_grp_block) {   // a group of same-slot factors per workgroup
+  if (bsg_bx >= first_grp_block) {   // a group of same-slot factors per workgroup
     __shared__ __attribute__((aligned(16))) double sGJ[kGroupChunk * kGroupRowMax];
     __shared__ double sGr[kGroupChunk * 6];
-    small_assemble_group(groups, grp[(int)blockIdx.x - first_grp_block], gfac, sGJ, sGr, S, ld, rhs_row, grad, hdiag, perm);
+    small_assemble_group(groups, grp[bsg_bx - first_grp_block], gfac, sGJ, sGr, S, ld, rhs_row, grad, hdiag, perm);
     return;
   }
-  if ((int)blockIdx.x < n_fw_units) {
+  if (bsg_bx < n_fw_units) {
     // the groups assembled one workgroup per factor (the IMU factors of a lidar-inertial window), as the first workgroups of this launch
     // instead of a launch of their own (as in pairs_kernel)
     __shared__ double sJ[15 * 30];
     __shared__ double sr[15];
     __shared__ int st[10];
-    small_assemble_unit(fw, (int)blockIdx.x, threadIdx.x, 256, sJ, sr, st, S, ld, rhs_row, grad, hdiag, perm);
+    small_assemble_unit(fw, bsg_bx, threadIdx.x, 256, sJ, sr, st, S, ld, rhs_row, grad, hdiag, perm);
     return;
   }
   // sixteen lanes per segment (a segment of C3 has ~8 contributions, an IMU factor's blocks one or two: a whole wave per segment idles)
-  const int seg = ((int)blockIdx.x - n_fw_units) * 16 + (threadIdx.x >> 4), lane = threadIdx.x & 15;
+  const int seg = (bsg_bx - n_fw_units) * 16 + (threadIdx.x >> 4), lane = threadIdx.x & 15;
   if (seg >= n_seg) return;
   const int beg = seg_start[seg], end = seg_start[seg + 1];
   const int ra = seg_ra[seg], rb = seg_rb[seg];
@@ -1084,6 +1151,15 @@ __global__ __launch_bounds__(256) void small_assemble_seg_kernel(const SmallGrou
     }
   }
 }
+__global__ __launch_bounds__(256) void small_assemble_seg_kernel(const SmallGroup* __restrict__ groups, int n_seg,
+                                                                const int* __restrict__ seg_start, const int* __restrict__ seg_ra,
+                                                                const int* __restrict__ seg_rb, const int2* __restrict__ contrib,
+                                                                double* __restrict__ S, int ld, int rhs_row, double* __restrict__ grad,
+                                                                double* __restrict__ hdiag, const int* __restrict__ perm, SmallGroupSet fw,
+                                                                int n_fw_units, int n_grp, const AsmGroup* __restrict__ grp,
+                                                                const int* __restrict__ gfac, int first_grp_block) {
+  small_assemble_seg_kernel_body((int)blockIdx.x, groups, n_seg, seg_start, seg_ra, seg_rb, contrib, S, ld, rhs_row, grad, hdiag, perm, fw, n_fw_units, n_grp, grp, gfac, first_grp_block);
+}
 void launch_small_assemble_seg(hipStream_t s, const SmallGroup* groups_dev, int n_seg, const int* seg_start, const int* seg_ra, const int* seg_rb,
                                const int2* contrib, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm,
                                const SmallGroupSet* fw, int n_fw_units, int n_grp, const AsmGroup* grp, const int* gfac) {
@@ -1132,14 +1208,14 @@ void launch_small_assemble_set(hipStream_t s, const SmallGroup* groups, int n_gr
 
 // model cost change term of a pose-only group, one lane per residual row:
 //   part[f*m + k] = -(J_k d) (r_k + J_k d / 2)
-__global__ __launch_bounds__(128) void small_mcc_kernel(SmallGroupSet set, const double* __restrict__ delta, UpdateRide up, int first_update_block,
-                                                        ZeroStep zs, int first_zero_block) {
+__device__ __forceinline__ void small_mcc_kernel_body(const int bsg_bx, const SmallGroupSet& set, const double* __restrict__ delta, const UpdateRide& up, int first_update_block,
+                                                        const ZeroStep& zs, int first_zero_block) {
   __shared__ double s2[2];
-  if (first_zero_block >= 0 && (int)blockIdx.x >= first_zero_block) {
+  if (first_zero_block >= 0 && bsg_bx >= first_zero_block) {
     // the NEXT step's clearing (the tiles of the reduced system the assembly writes, the pose gradient, diag(J^T J)): nothing reads them
     // any more in this step — the factorisation is done — so the next assembly finds them clean and needs no launch of its own for it
     // (a window with Euclidean landmarks clears in its landmark launch instead)
-    const int z = (int)blockIdx.x - first_zero_block;
+    const int z = bsg_bx - first_zero_block;
     if (z < zs.n_tiles) {
       const int nt = zs.ld >> 6, ti = zs.tiles[z] / nt, tj = zs.tiles[z] - ti * nt;
       double2* base = reinterpret_cast<double2*>(zs.S + (size_t)ti * 64 * zs.ld + (size_t)tj * 64);
@@ -1153,10 +1229,10 @@ __global__ __launch_bounds__(128) void small_mcc_kernel(SmallGroupSet set, const
     }
     return;
   }
-  if (up.n_blocks > 0 && (int)blockIdx.x >= first_update_block) {
+  if (up.n_blocks > 0 && bsg_bx >= first_update_block) {
     // a window without Euclidean landmarks: the candidate x (+) delta of every block as extra workgroups of this launch (both only need
     // the step), 128 blocks each — as backsub_mcc_kernel carries it where there are landmarks
-    const int unit = (int)blockIdx.x - first_update_block, b = unit * 128 + (int)threadIdx.x;
+    const int unit = bsg_bx - first_update_block, b = unit * 128 + (int)threadIdx.x;
     double d2 = 0.0, x2 = 0.0;
     if (b < up.n_blocks) update_block(up.blocks ? up.blocks[b] : b, up.xoff, up.toff, up.size, up.manifold, up.x, delta, up.x_cand, d2, x2);
     const double a = wave_sum(d2), c = wave_sum(x2);
@@ -1166,7 +1242,11 @@ __global__ __launch_bounds__(128) void small_mcc_kernel(SmallGroupSet set, const
     if (threadIdx.x == 0) { up.part[2 * unit] = s4[0] + s4[1]; up.part[2 * unit + 1] = s4[2] + s4[3]; }
     return;
   }
-  small_mcc_unit(set, blockIdx.x, threadIdx.x, delta, s2);
+  small_mcc_unit(set, bsg_bx, threadIdx.x, delta, s2);
+}
+__global__ __launch_bounds__(128) void small_mcc_kernel(SmallGroupSet set, const double* __restrict__ delta, UpdateRide up, int first_update_block,
+                                                        ZeroStep zs, int first_zero_block) {
+  small_mcc_kernel_body((int)blockIdx.x, set, delta, up, first_update_block, zs, first_zero_block);
 }
 
 // the first (up to kSetMax) non-empty groups as ONE set, for a caller that runs their units inside another launch (backsub_mcc_kernel);
@@ -1214,6 +1294,172 @@ bool launch_small_mcc_set(hipStream_t s, const SmallGroup* groups, double* const
   }
   flush();
   return carried;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The pose-only family over several windows in one launch (bsgpu_batch.cpp: lidar-inertial windows, dense-path pose graphs, the
+// pose-only factors of any window — bs_models/src/lib/global_mapping/submap_refinement.cpp:35-115 loops over exactly such graphs).
+// blockIdx.y picks the window of list `bsg_list`; entry w of a table is what window w's lone launch passes (a zero grid: the window has
+// no such launch).  The bodies are the lone kernels' bodies: a window's numbers are those of its lone solve.
+// ---------------------------------------------------------------------------------------------------
+// the pose-only groups of a window that no fused evaluation carries (launch_small_eval's kernels, one after the other, as ONE launch):
+// 128 factors per workgroup — an IMU factor: a wave each, two per workgroup
+constexpr int kEvalSetMax = 8;
+struct small_eval_set_Args {
+  int bsg_grid;
+  int n;
+  SmallGroup g[kEvalSetMax];
+  double* part[kEvalSetMax];
+  int first[kEvalSetMax + 1];
+  const double* x;
+  const DevLoss* losses;
+};
+template <bool WITH_J>
+__global__ __launch_bounds__(128) void small_eval_set_kernel_batch(const small_eval_set_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
+  const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
+  const small_eval_set_Args& a = bsg_A[bsg_w];
+  if ((int)blockIdx.x >= a.bsg_grid) return;
+  int gi = 0;
+  while (gi + 1 < a.n && (int)blockIdx.x >= a.first[gi + 1]) ++gi;
+  const SmallGroup& g = a.g[gi];
+  const int bx = (int)blockIdx.x - a.first[gi];
+  double* part = a.part[gi];
+  switch (g.type) {
+    case BSGPU_F_IMU_DELTA: { const int f = __builtin_amdgcn_readfirstlane(2 * bx + ((int)threadIdx.x >> 6)); if (f < g.n) imu_delta_body<WITH_J>(g, f, a.x, a.losses, part, threadIdx.x & 63); break; }
+    case BSGPU_F_IMU_PRIOR: { const int f = __builtin_amdgcn_readfirstlane(2 * bx + ((int)threadIdx.x >> 6)); if (f < g.n) imu_prior_body<WITH_J>(g, f, a.x, a.losses, part, threadIdx.x & 63); break; }
+    case BSGPU_F_RELPOSE_EXT: relpose_body<true, WITH_J>(g, a.x, a.losses, part, bx); break;
+    case BSGPU_F_RELPOSE: relpose_body<false, WITH_J>(g, a.x, a.losses, part, bx); break;
+    case BSGPU_F_ABSPOSE: abspose_kernel_body<WITH_J>(g, a.x, a.losses, part, bx); break;
+    case BSGPU_F_ABS_VEC3: vec3_kernel_body<false, WITH_J>(g, a.x, a.losses, part, bx); break;
+    case BSGPU_F_REL_VEC3: vec3_kernel_body<true, WITH_J>(g, a.x, a.losses, part, bx); break;
+    case BSGPU_F_GRAVITY: gravity_kernel_body<WITH_J>(g, a.x, a.losses, part, bx); break;
+    case BSGPU_F_NUM_TYPES: reproj_dense_kernel_body<WITH_J>(g, a.x, a.losses, part, bx); break;
+    default: break;
+  }
+}
+// groups[i], parts[i]: the window's groups this launch evaluates (n_groups <= kEvalSetMax; 0: a zero grid)
+bool batchargs_small_eval_set(BatchArgTable& t, const SmallGroup* groups, double* const* parts, int n_groups, const double* x, const DevLoss* losses) {
+  small_eval_set_Args a;
+  a.n = 0; a.x = x; a.losses = losses;
+  int blocks = 0;
+  for (int i = 0; i < n_groups; ++i) {
+    if (!groups[i].n) continue;
+    if (a.n == kEvalSetMax) return false;
+    const bool imu = groups[i].type == BSGPU_F_IMU_DELTA || groups[i].type == BSGPU_F_IMU_PRIOR;
+    a.g[a.n] = groups[i]; a.part[a.n] = parts[i]; a.first[a.n] = blocks;
+    blocks += imu ? (groups[i].n + 1) / 2 : (groups[i].n + 127) / 128;
+    ++a.n;
+  }
+  for (int i = a.n; i <= kEvalSetMax; ++i) a.first[i] = blocks;
+  a.bsg_grid = blocks;
+  t.push(a);
+  return true;
+}
+void launch_small_eval_set_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n, bool with_J) {
+  if (n <= 0 || t.max_grid <= 0) return;
+  const auto* A = static_cast<const small_eval_set_Args*>(t.dev);
+  if (with_J) hipLaunchKernelGGL(small_eval_set_kernel_batch<true>, dim3(t.max_grid, n), dim3(128), 0, s, A, dyn, list);
+  else hipLaunchKernelGGL(small_eval_set_kernel_batch<false>, dim3(t.max_grid, n), dim3(128), 0, s, A, dyn, list);
+}
+
+struct small_assemble_kernel_Args {
+  int bsg_grid;
+  SmallGroupSet set;
+  double* S; int ld; int rhs_row; double* grad; double* hdiag; const int* perm;
+};
+__global__ __launch_bounds__(256) void small_assemble_kernel_batch(const small_assemble_kernel_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
+  const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
+  const small_assemble_kernel_Args& a = bsg_A[bsg_w];
+  if ((int)blockIdx.x >= a.bsg_grid) return;
+  small_assemble_kernel_body((int)blockIdx.x, a.set, a.S, a.ld, a.rhs_row, a.grad, a.hdiag, a.perm);
+}
+// the groups assembled one workgroup per factor that ride in no other launch (at most kSetMax of them: false otherwise)
+bool batchargs_small_assemble_set(BatchArgTable& t, const SmallGroup* groups, int n_groups, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm) {
+  small_assemble_kernel_Args a;
+  a.set.n = 0; a.S = S; a.ld = ld; a.rhs_row = rhs_row; a.grad = grad; a.hdiag = hdiag; a.perm = perm;
+  int blocks = 0;
+  for (int i = 0; i < n_groups; ++i) {
+    if (!groups[i].n) continue;
+    if (a.set.n == kSetMax) return false;
+    a.set.g[a.set.n] = groups[i]; a.set.first[a.set.n] = blocks; a.set.part[a.set.n] = nullptr;
+    blocks += groups[i].n; ++a.set.n;
+  }
+  a.set.first[a.set.n] = blocks;
+  a.bsg_grid = blocks;
+  t.push(a);
+  return true;
+}
+void launch_small_assemble_set_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n) {
+  if (n <= 0 || t.max_grid <= 0) return;
+  hipLaunchKernelGGL(small_assemble_kernel_batch, dim3(t.max_grid, n), dim3(256), 0, s, static_cast<const small_assemble_kernel_Args*>(t.dev), dyn, list);
+}
+
+struct small_assemble_seg_kernel_Args {
+  int bsg_grid;
+  const SmallGroup* groups; int n_seg; const int* seg_start; const int* seg_ra; const int* seg_rb; const int2* contrib;
+  double* S; int ld; int rhs_row; double* grad; double* hdiag; const int* perm;
+  SmallGroupSet fw; int n_fw_units; int n_grp; const AsmGroup* grp; const int* gfac; int first_grp_block;
+};
+__global__ __launch_bounds__(256) void small_assemble_seg_kernel_batch(const small_assemble_seg_kernel_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
+  const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
+  const small_assemble_seg_kernel_Args& a = bsg_A[bsg_w];
+  if ((int)blockIdx.x >= a.bsg_grid) return;
+  small_assemble_seg_kernel_body((int)blockIdx.x, a.groups, a.n_seg, a.seg_start, a.seg_ra, a.seg_rb, a.contrib, a.S, a.ld, a.rhs_row, a.grad, a.hdiag, a.perm, a.fw, a.n_fw_units,
+                                 a.n_grp, a.grp, a.gfac, a.first_grp_block);
+}
+void batchargs_small_assemble_seg(BatchArgTable& t, const SmallGroup* groups_dev, int n_seg, const int* seg_start, const int* seg_ra, const int* seg_rb, const int2* contrib,
+                                  double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm, const SmallGroupSet* fw, int n_fw_units, int n_grp,
+                                  const AsmGroup* grp, const int* gfac) {
+  small_assemble_seg_kernel_Args a;
+  SmallGroupSet none;
+  none.n = 0; none.first[0] = 0;
+  const int extra = fw ? n_fw_units : 0;
+  const int seg_blocks = (std::max(0, n_seg) + 15) / 16;
+  a.first_grp_block = extra + seg_blocks;
+  a.bsg_grid = (n_seg <= 0 && n_grp <= 0) ? 0 : a.first_grp_block + std::max(0, n_grp);
+  a.groups = groups_dev; a.n_seg = std::max(0, n_seg); a.seg_start = seg_start; a.seg_ra = seg_ra; a.seg_rb = seg_rb; a.contrib = contrib;
+  a.S = S; a.ld = ld; a.rhs_row = rhs_row; a.grad = grad; a.hdiag = hdiag; a.perm = perm; a.fw = fw ? *fw : none; a.n_fw_units = extra; a.n_grp = n_grp; a.grp = grp; a.gfac = gfac;
+  t.push(a);
+}
+void launch_small_assemble_seg_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n) {
+  if (n <= 0 || t.max_grid <= 0) return;
+  hipLaunchKernelGGL(small_assemble_seg_kernel_batch, dim3(t.max_grid, n), dim3(256), 0, s, static_cast<const small_assemble_seg_kernel_Args*>(t.dev), dyn, list);
+}
+
+struct small_mcc_kernel_Args {
+  int bsg_grid;
+  SmallGroupSet set; const double* delta; UpdateRide up; int first_update_block; ZeroStep zs; int first_zero_block;
+};
+__global__ __launch_bounds__(128) void small_mcc_kernel_batch(const small_mcc_kernel_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
+  const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
+  const small_mcc_kernel_Args& a = bsg_A[bsg_w];
+  if ((int)blockIdx.x >= a.bsg_grid) return;
+  small_mcc_kernel_body((int)blockIdx.x, a.set, a.delta, a.up, a.first_update_block, a.zs, a.first_zero_block);
+}
+// the pose-only groups whose model-cost terms ride in no other launch (at most kSetMax: false otherwise), with the candidate of every block
+// (upd) and the next step's clearing (zero; only together with upd) as the launch's last workgroups — launch_small_mcc_set's single launch
+bool batchargs_small_mcc(BatchArgTable& t, const SmallGroup* groups, double* const* parts, int n_groups, const double* delta, const UpdateRide* upd, const ZeroStep* zero) {
+  small_mcc_kernel_Args a;
+  a.set.n = 0; a.delta = delta;
+  int blocks = 0;
+  for (int i = 0; i < n_groups; ++i) {
+    if (!groups[i].n) continue;
+    if (a.set.n == kSetMax) return false;
+    a.set.g[a.set.n] = groups[i]; a.set.first[a.set.n] = blocks; a.set.part[a.set.n] = parts[i];
+    blocks += (groups[i].n * groups[i].m + 127) / 128; ++a.set.n;
+  }
+  a.set.first[a.set.n] = blocks;
+  const int upd_units = (upd && upd->n_blocks > 0) ? (upd->n_blocks + 127) / 128 : 0;
+  const int zero_units = (upd_units && zero) ? zero->n_tiles + (std::max(zero->na, zero->nb) + 127) / 128 : 0;
+  a.up = upd_units ? *upd : UpdateRide(); a.first_update_block = blocks;
+  a.zs = zero_units ? *zero : ZeroStep(); a.first_zero_block = zero_units ? blocks + upd_units : -1;
+  a.bsg_grid = blocks + upd_units + zero_units;
+  t.push(a);
+  return true;
+}
+void launch_small_mcc_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n) {
+  if (n <= 0 || t.max_grid <= 0) return;
+  hipLaunchKernelGGL(small_mcc_kernel_batch, dim3(t.max_grid, n), dim3(128), 0, s, static_cast<const small_mcc_kernel_Args*>(t.dev), dyn, list);
 }
 
 }  // namespace bsg

@@ -37,6 +37,8 @@ for r in rows:
 
 
 def deps_of(r):
+    if r["flags"] & (64 | 128):   # LM-diagonal / rider tasks: first update of their tile, nothing before them (not stamped)
+        return []
     if r["flags"] & 1:   # the last updates of the chain's own tiles
         d = []
         for a in range(r["k"], r["k"] + r["ti"]):
@@ -59,7 +61,9 @@ def deps_of(r):
 
 cur = max(rows, key=lambda r: r["pub"])
 path = []
-while cur is not None:
+seen = set()
+while cur is not None and cur["i"] not in seen:
+    seen.add(cur["i"])
     d = deps_of(cur)
     nxt = max(d, key=lambda x: x[1]["pub"]) if d else None
     path.append((cur, nxt[0] if nxt else "-", nxt[1]["pub"] if nxt else 0))
@@ -78,7 +82,7 @@ for r, name, dpub in path:
 agg = collections.defaultdict(float)
 n = 0
 for r in rows:
-    if r["flags"] & 1:
+    if r["flags"] & (1 | 64 | 128):
         continue
     n += 1
     agg["dequeue"] += (r["got"] - r["deq"]) / 100.0

@@ -1,0 +1,147 @@
+"""bsgpu_solve_batch on the kinds of window the reference loops over side by side (csrc/bsgpu_batch.cpp): lidar-inertial windows
+(lio.yaml:2, scan_to_map_registration.cpp:74-78), submap pose graphs on the dense path (submap_pose_graph_optimization.cpp:22-150),
+visual-inertial windows, windows with constant blocks — all advanced by ONE set of launches per LM iteration.  Every window against
+its lone solve (same decisions, costs, radii, values) and each kind once against the ORACLE; the argument-table cache against the
+destroy / re-create pattern of submap refinement (submap_refinement.cpp:35-115: fresh graphs every pass)."""
+import gc
+
+import numpy as np
+import pytest
+
+from beam_slam_amd import capi, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _fresh(cls, cases):
+    out = []
+    for pr in cases:
+        g = cls(0); pr.load(g); out.append(g)
+    return out
+
+
+def _same_trajectory(g0, s0, g1, s1, cost_tol=1e-9, val_tol=1e-8):
+    assert s1.num_iterations == s0.num_iterations and s1.termination_type == s0.termination_type
+    assert s1.num_successful_steps == s0.num_successful_steps and s1.num_unsuccessful_steps == s0.num_unsuccessful_steps
+    assert s1.num_linear_solves == s0.num_linear_solves and s1.is_solution_usable == s0.is_solution_usable
+    assert s1.linear_solver_used == s0.linear_solver_used
+    i0, i1 = g0.iterations(), g1.iterations()
+    assert len(i0) == len(i1)
+    for a, b in zip(i0, i1):
+        assert a.step_is_successful == b.step_is_successful and a.step_is_valid == b.step_is_valid
+        assert abs(a.cost - b.cost) <= cost_tol * abs(a.cost)
+        assert abs(a.trust_region_radius - b.trust_region_radius) <= 1e-6 * a.trust_region_radius
+    assert abs(s1.final_cost - s0.final_cost) <= cost_tol * abs(s0.final_cost)
+    assert abs(s1.initial_cost - s0.initial_cost) <= 1e-12 * abs(s0.initial_cost)
+    assert abs(s1.fixed_cost - s0.fixed_cost) <= 1e-12 * abs(s0.fixed_cost) + 1e-300
+    assert np.abs(g1.get_blocks() - g0.get_blocks()).max() < val_tol
+
+
+def _oracle_check(pr, g, opt, oracle_cls, tol=1e-6):
+    o = oracle_cls(); pr.load(o)
+    so = o.solve(opt)
+    gi, oi = g.iterations(), o.iterations()
+    assert len(gi) == len(oi)
+    for a, b in zip(gi, oi):
+        assert a.step_is_successful == b.step_is_successful
+        assert abs(a.cost - b.cost) <= 1e-7 * b.cost
+    assert abs(gi[-1].cost - so.final_cost) <= tol * so.final_cost     # north-star tolerance
+    assert np.abs(g.get_blocks() - o.get_blocks()).max() < 1e-6
+
+
+def test_batch_lidar_inertial_windows(gpu_solver_cls, oracle_cls):
+    """Lidar-inertial windows of the reference's size (20 key frames, ~300 scan-registration factors with the constant extrinsics pair,
+    19 IMU factors + the IMU prior), different sizes and budgets in one call; one of them without any IMU factor."""
+    cases = [synthetic.lio_window(n_kf=20, n_rel=300, seed=500 + i) for i in range(5)]
+    cases.append(synthetic.lio_window(n_kf=35, n_rel=900, seed=520, max_gap=6))
+    cases.append(synthetic.lio_window(n_kf=12, n_rel=90, seed=521, max_gap=3))
+    alone = _fresh(gpu_solver_cls, cases)
+    opts = []
+    for i, g in enumerate(alone):
+        o = g.options_vio(); o.max_solver_time_in_seconds = 0.0; o.max_num_iterations = 4 + i
+        opts.append(o)
+    lone = [g.solve(o) for g, o in zip(alone, opts)]
+    w0, r0 = gpu_solver_cls.batch_stats()
+    batch = _fresh(gpu_solver_cls, cases)
+    sums = gpu_solver_cls.solve_batch(batch, opts)
+    w1, r1 = gpu_solver_cls.batch_stats()
+    assert w1 - w0 == len(cases) and r1 - r0 >= 4      # all of them on the batched launches
+    for g0, s0, g1, s1 in zip(alone, lone, batch, sums):
+        _same_trajectory(g0, s0, g1, s1)
+    _oracle_check(cases[0], batch[0], opts[0], oracle_cls)
+    _oracle_check(cases[5], batch[5], opts[5], oracle_cls)
+    # the cached tables again, from the same start; then a lone solve of a window that has been through the batch
+    for g in batch: g.reset_values()
+    for s0, s1 in zip(lone, gpu_solver_cls.solve_batch(batch, opts)):
+        assert s1.num_iterations == s0.num_iterations and abs(s1.final_cost - s0.final_cost) <= 1e-9 * abs(s0.final_cost)
+    batch[2].reset_values()
+    s = batch[2].solve(opts[2])
+    assert s.num_iterations == lone[2].num_iterations and abs(s.final_cost - lone[2].final_cost) <= 1e-9 * abs(lone[2].final_cost)
+
+
+def test_batch_pose_graphs_on_the_dense_path(gpu_solver_cls, oracle_cls):
+    """Submap pose graphs of 200 poses (relative-pose constraints + the prior on the first pose, default Ceres options as the global
+    mapper passes them): the exact dense path for every one of them, one set of launches."""
+    cases = [synthetic.pose_graph(n_pose=200, n_loop=300, seed=600 + i) for i in range(4)]
+    cases.append(synthetic.pose_graph(n_pose=120, n_loop=100, seed=610))
+    alone = _fresh(gpu_solver_cls, cases)
+    opt = alone[0].options_default(); opt.max_num_iterations = 8
+    lone = [g.solve(opt) for g in alone]
+    assert all(s.linear_solver_used == capi.LINEAR_SCHUR_CHOLESKY for s in lone)
+    w0, _ = gpu_solver_cls.batch_stats()
+    batch = _fresh(gpu_solver_cls, cases)
+    sums = gpu_solver_cls.solve_batch(batch, opt)
+    w1, _ = gpu_solver_cls.batch_stats()
+    assert w1 - w0 == len(cases)
+    for g0, s0, g1, s1 in zip(alone, lone, batch, sums):
+        _same_trajectory(g0, s0, g1, s1)
+    _oracle_check(cases[4], batch[4], opt, oracle_cls)
+
+
+def test_batch_mixed_kinds_and_constant_blocks(gpu_solver_cls, oracle_cls):
+    """What the reference runs side by side, in one call: a visual-inertial window, a lidar-inertial one, a pose graph, a visual-inertial
+    window whose first key frame is held constant (Ceres' fixed cost is taken once, before the first round), a lidar-inertial window
+    with a held key frame — one set of launches for all five."""
+    cases = [synthetic.vio_window(n_kf=20, n_lm=500, seed=701), synthetic.lio_window(n_kf=20, n_rel=300, seed=702),
+             synthetic.pose_graph(n_pose=150, n_loop=200, seed=703), synthetic.vio_window(n_kf=15, n_lm=300, seed=704),
+             synthetic.lio_window(n_kf=16, n_rel=200, seed=705)]
+    for pr in (cases[3], cases[4]):      # the whole first state held (q, p, v, bg, ba): its prior / IMU prior become fixed cost
+        for b in pr.meta["kf_blocks"][0]:
+            pr.is_const[int(b)] = 1
+    alone = _fresh(gpu_solver_cls, cases)
+    opts = []
+    for i, g in enumerate(alone):
+        o = g.options_vio(); o.max_solver_time_in_seconds = 0.0; o.max_num_iterations = 5 + i
+        opts.append(o)
+    lone = [g.solve(o) for g, o in zip(alone, opts)]
+    assert lone[3].fixed_cost > 0.0 or lone[4].fixed_cost > 0.0
+    w0, _ = gpu_solver_cls.batch_stats()
+    batch = _fresh(gpu_solver_cls, cases)
+    sums = gpu_solver_cls.solve_batch(batch, opts)
+    w1, _ = gpu_solver_cls.batch_stats()
+    assert w1 - w0 == len(cases)
+    for g0, s0, g1, s1 in zip(alone, lone, batch, sums):
+        _same_trajectory(g0, s0, g1, s1)
+    _oracle_check(cases[3], batch[3], opts[3], oracle_cls)
+
+
+def test_batch_tables_do_not_outlive_their_contexts(gpu_solver_cls):
+    """The submap-refinement pattern: create N windows, solve them in one call, destroy them, create N FRESH windows of other sizes (the
+    allocator hands out the same addresses again) and solve those — the cached argument tables of the first set must not be taken for
+    the second (finalize stamps are process-unique, bsgpu_destroy drops the tables that name the context)."""
+    def run(sizes, seed0):
+        cases = [synthetic.vio_window(n_kf=kf, n_lm=lm, seed=seed0 + i) for i, (kf, lm) in enumerate(sizes)]
+        alone = _fresh(gpu_solver_cls, cases)
+        opt = alone[0].options_vio(); opt.max_solver_time_in_seconds = 0.0; opt.max_num_iterations = 5
+        lone = [g.solve(opt) for g in alone]
+        batch = _fresh(gpu_solver_cls, cases)
+        sums = gpu_solver_cls.solve_batch(batch, opt)
+        for g0, s0, g1, s1 in zip(alone, lone, batch, sums):
+            _same_trajectory(g0, s0, g1, s1)
+        for g in alone + batch: g.close()
+        del alone, batch
+        gc.collect()
+    run([(10, 120), (14, 200), (8, 90), (12, 150)], 800)
+    run([(16, 260), (9, 100), (13, 170), (11, 140)], 820)      # same count, other sizes
+    run([(10, 120), (14, 200), (8, 90), (12, 150)], 840)      # the first sizes again, other values
+    run([(7, 80), (7, 80), (7, 80)], 860)

@@ -307,8 +307,8 @@ def test_solve_batch_one_set_of_launches_equals_lone_solves(gpu_solver_cls):
     """The windows bsgpu_solve_batch advances TOGETHER (csrc/bsgpu_batch.cpp: one launch per kernel of the LM step for all of them,
     blockIdx.y = window) — visual-inertial windows of different sizes, with and without a robust loss, different iteration budgets so
     that windows drop out at different rounds — against their lone solves: the same decisions, costs, radii and final values (every
-    window's tables and partial sums are laid out as in its lone solve), and the call really took the batched path.  A pose graph in
-    the same call is solved on its own thread."""
+    window's tables and partial sums are laid out as in its lone solve), and the call really took the batched path.  A pose graph on
+    the dense path rides in the same launches (round 5; tests/test_gpu_batch_kinds.py has the other kinds)."""
     cases = [synthetic.vio_window(n_kf=20, n_lm=500, seed=11), synthetic.vio_window(n_kf=30, n_lm=2000, seed=12),
              synthetic.vio_window(n_kf=12, n_lm=200, seed=5, cauchy_a=None), synthetic.vio_window(n_kf=60, n_lm=3000, seed=13),
              synthetic.vio_window(n_kf=20, n_lm=500, seed=14), synthetic.pose_graph(n_pose=300, n_loop=400, seed=3),
@@ -330,7 +330,7 @@ def test_solve_batch_one_set_of_launches_equals_lone_solves(gpu_solver_cls):
     batch = fresh()
     sums = gpu_solver_cls.solve_batch(batch, opts)
     w1, r1 = gpu_solver_cls.batch_stats()
-    assert w1 - w0 == 6 and r1 - r0 >= 4      # the six landmark windows went through the batched launches
+    assert w1 - w0 == 7 and r1 - r0 >= 4      # all seven went through the batched launches (round 5: the pose graph on the dense path too)
     for g0, s0, g1, s1 in zip(alone, lone, batch, sums):
         assert s1.num_iterations == s0.num_iterations and s1.termination_type == s0.termination_type
         assert s1.num_successful_steps == s0.num_successful_steps and s1.num_unsuccessful_steps == s0.num_unsuccessful_steps
