@@ -872,6 +872,7 @@ int finalize(bsgpu_ctx* c) {
     }
     const char* e3 = getenv("BSGPU_SHARED");   // panels of one step may update the same tiles (atomics): on unless BSGPU_SHARED=0
     { const char* ex = getenv("BSGPU_CHOL_EXT"); c->plan.allow_ext = !(ex && atoi(ex) == 0); }
+    { const char* sp = getenv("BSGPU_CHOL_SPLIT"); if (sp) c->plan.split_depth = std::max(0, std::min(64, atoi(sp))); }   // (dense_plan.h kFusedSplit; default 2)
     // (the LM diagonal and the gradient norms as tasks of the factorisation's launch; BSGPU_POSE_DIAG_LAUNCH=1: their own launch, as before)
     c->plan.diag_tasks = getenv("BSGPU_POSE_DIAG_LAUNCH") == nullptr;
     c->plan.rider_tasks = c->plan.diag_tasks ? (c->nb + 255) / 256 : 0;   // (0: every tile's panel has its own update tasks, also a separator's appendix tile)

@@ -61,6 +61,15 @@ constexpr int kFusedExtCols = 16;
 constexpr int kFusedDiagAdd = 64;   // k = ti = tj = a tile: the LM diagonal of its real columns is added to S (LmDiag, bsgpu_internal.h) — the FIRST update of
                                     // every diagonal tile (need_c = 0), so the chains and the other updates of the tile come after it by the tile's counter
 constexpr int kFusedRider = 128;    // k = unit of independent work carried by the launch (the step's gradient norms): nothing waits for it
+constexpr int kFusedSplit = 256;    // ONE K-CHUNK of the LAST update of a tile inside a chain (round 5): what a chain — the critical path — waits for last
+                                    // was one workgroup, MFMA-bound on its one CU (solve 1.1-2.1 us + rank-64 product 1.7 us, 4.4 + 3 with an appendix).
+                                    // Such an update is dealt out to 4 (5 with an appendix) workgroups: chunk p forms the 16 columns 16 p .. of X_ti / X_tj
+                                    // (W = L_kk^-1 is lower triangular: K = 16 (p + 1)) and ADDS their rank-16 product to the tile with FP64 atomics once
+                                    // every earlier update of the tile has been published (need_c = that count: the chunks share one turn, the last); the
+                                    // appendix chunk forms the appendix's 16 columns.  tot_c = chunk | number of chunks << 8.  The tile's counter counts the
+                                    // chunks in its upper half: tile_tot = updates with a turn of their own | chunks << 16.  (The order in which the chunks'
+                                    // sums reach a tile varies: the factor is reproducible to rounding, like the assembled system it factors.)
+constexpr int kFusedSplitChunks = 4;
 constexpr int kChainMaxTiles = 3;   // == chain::kChainMaxTiles (chol_chain.h)
 
 struct DensePlan {
@@ -94,7 +103,10 @@ struct DensePlan {
   std::vector<int> bs_desc;
   // fused single-launch factorisation (k_chol.hip chol_fused_kernel)
   std::vector<FusedTask> ftasks;
-  std::vector<int> tile_tot;          // (T+1)^2: number of update TASKS per tile (what a chain waits for before it reads its tiles)
+  std::vector<int> tile_tot;          // (T+1)^2: number of update TASKS per tile (what a chain waits for before it reads its tiles): updates that take a turn of their
+                                      // own on the tile | kFusedSplit chunks << 16
+  int split_depth = 2;                // how many of the LAST updates of a tile inside a chain are dealt out as kFusedSplit chunks; 0: none (finalize: BSGPU_CHOL_SPLIT)
+  int n_split_chunks = 0;
   std::vector<int> fchain_begin, fchain_len, fchain_of_tile;   // the chains of the fused factorisation
   std::vector<int> fext_of;           // T+1: the appendix tile panel k carries (kFusedExt), or -1
   std::vector<FusedTask> ftasks_plain;   // ftasks without the diagonal / rider tasks (empty: the plan has none, ftasks is that list)
@@ -561,6 +573,54 @@ struct DensePlan {
         if (last_of_chain_tile || (f.flags & kFusedXjChain)) continue;
         f.flags |= kFusedXiLp | kFusedXjLp;
       }
+      // ---- kFusedSplit: the last `split_depth` updates (in list order) of every tile inside a chain become K-chunks.  Two by default: a
+      // separator's tiles take their last updates from the last panels of BOTH its children, which finish at about the same time — with only
+      // the very last one dealt out, its chunks waited 4-6 us for the other child's update to take its turn (BSGPU_CHOL_PROBE, C2).
+      n_split_chunks = 0;
+      if (split_depth > 0) {
+        const int nt = (int)ftasks.size();
+        std::vector<std::vector<int>> updaters((size_t)N * N);
+        for (int t = 0; t < nt; ++t) {
+          const FusedTask& f = ftasks[t];
+          if ((f.flags & (kFusedChain | kFusedRider)) || f.need_c < 0) continue;
+          updaters[(size_t)f.ti * N + f.tj].push_back(t);
+        }
+        std::vector<int> n_chunks(nt, 0), turn(nt, 0);
+        for (int a = 0; a < T; ++a)
+          for (int b = 0; b <= a; ++b) {
+            if (fchain_of_tile[a] < 0 || fchain_of_tile[a] != fchain_of_tile[b]) continue;
+            const std::vector<int>& u = updaters[(size_t)a * N + b];
+            int taken = 0, hi = 0;
+            for (int q = (int)u.size() - 1; q >= 0 && taken < split_depth; --q, ++taken) {
+              const FusedTask& f = ftasks[u[q]];
+              if (f.flags & (kFusedDiagAdd | kFusedXjChain)) break;
+              n_chunks[u[q]] = kFusedSplitChunks + ((f.flags & kFusedExt) ? 1 : 0);
+              hi += n_chunks[u[q]];
+            }
+            if (!taken) continue;
+            const int lo = (int)u.size() - taken;   // the updates that keep a turn of their own: need_c 0 .. lo - 1
+            for (int q = lo; q < (int)u.size(); ++q) turn[u[q]] = lo;
+            n_split_chunks += hi;
+            tile_tot[(size_t)a * N + b] = lo | (hi << 16);
+          }
+        if (n_split_chunks > 0) {
+          std::vector<FusedTask> nl;
+          nl.reserve(ftasks.size() + (size_t)n_split_chunks);
+          for (int t = 0; t < nt; ++t) {
+            if (n_chunks[t] == 0) { nl.push_back(ftasks[t]); continue; }
+            for (int p = 0; p < n_chunks[t]; ++p) {
+              FusedTask f = ftasks[t];
+              f.flags = (f.flags & (kFusedExt | kFusedPublishX)) | kFusedSplit;   // (a chunk forms its own columns of X: nothing published is read)
+              f.need_c = turn[t];   // (the chunks of a tile share ONE turn, after every update that has a turn of its own)
+              f.tot_c = p | (n_chunks[t] << 8);
+              nl.push_back(f);
+            }
+          }
+          ftasks.swap(nl);
+          // (tot_i / tot_j of the other tasks name panel tiles (t, k), t outside the chain of k: never a tile inside a chain — except tot_j of
+          //  a task whose tj is in the chain of k, which waits for the chain's flag and not for that count)
+        }
+      }
       fused_sync_words = 16 * (3 + N + N * N);   // (every word a 64-byte line apart: k_chol.hip fused_sync_stride)
       // the same list WITHOUT the diagonal / rider tasks (what a launch that carries neither takes: a step whose LM diagonal is in S already,
       // the batched launches of many windows — every task is a workgroup with ~160 KB of LDS, also one that only counts itself in)
@@ -569,7 +629,7 @@ struct DensePlan {
         for (const FusedTask& f0 : ftasks) {
           if (f0.flags & (kFusedDiagAdd | kFusedRider)) continue;
           FusedTask f = f0;
-          if (diag_tasks && !(f.flags & kFusedChain) && f.ti == f.tj && f.ti < T && f.need_c >= 0) { f.need_c--; f.tot_c--; }
+          if (diag_tasks && !(f.flags & kFusedChain) && f.ti == f.tj && f.ti < T && f.need_c >= 0) { f.need_c--; if (!(f.flags & kFusedSplit)) f.tot_c--; }   // (a chunk's tot_c is its number)
           ftasks_plain.push_back(f);
         }
         if (diag_tasks) for (int t = 0; t < T; ++t) tile_tot_plain[(size_t)t * N + t]--;

@@ -572,12 +572,15 @@ BSG_DEV int ld_flag(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED
 BSG_DEV bool wait_count(const int* p, int want, int* abort_w, long long deadline) {
   // (both words are requested together and the wall clock is read every 32nd round: a round of the poll is ONE memory round trip,
   // not three in a row — the waiter sees the counter ~0.5 us sooner)
+  // (a tile's counter: the updates that took their turn on it in the lower half, the kFusedSplit chunks that reached it in the upper half;
+  //  `want` is encoded the same way — a plain count asks for nothing of the upper half)
+  const int want_lo = want & 0xffff, want_hi = (int)((unsigned)want >> 16);
   for (unsigned it = 0;; ++it) {
     // (the abort word is ONE line that every waiting workgroup of the launch would read each round — hundreds of readers on one channel —
     //  so it is looked at every eighth round, together with the counter: still one round trip)
     const bool look = (it & 7) == 7;
     const int v = ld_flag(p), a = look ? ld_flag(abort_w) : 0;
-    if (v >= want) return true;
+    if ((v & 0xffff) >= want_lo && (int)((unsigned)v >> 16) >= want_hi) return true;
     if (a != 0) return false;
     if ((it & 31) == 31 && (long long)wall_clock64() > deadline) { __hip_atomic_store(abort_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
   }
@@ -706,7 +709,7 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
     s_ctl[1] = ok ? 1 : 0;
     // ... and the C tile, if it is already this task's turn on it (on the critical path it is: the tile's earlier updaters are
     // panels that finished long ago): its values wait in registers through the solves, and the product accumulates onto them
-    s_ctl[3] = (do_update && (tk.need_c == 0 || ld_flag(&upd[(ti * N + tj) * fs]) >= tk.need_c)) ? 1 : 0;
+    s_ctl[3] = (do_update && (tk.need_c == 0 || (ld_flag(&upd[(ti * N + tj) * fs]) & 0xffff) >= tk.need_c)) ? 1 : 0;
   }
   __syncthreads();
   const bool c_pre = __builtin_amdgcn_readfirstlane(s_ctl[3]) != 0;
@@ -823,7 +826,7 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
         for (int u = 0; u < TPW; ++u) acc[u] = cpre[u];
       }
     } else {
-      if (tid == 0) s_ctl[3] = (ld_flag(&upd[(ti * N + tj) * fs]) >= tk.need_c) ? 1 : 0;
+      if (tid == 0) s_ctl[3] = ((ld_flag(&upd[(ti * N + tj) * fs]) & 0xffff) >= tk.need_c) ? 1 : 0;
       __syncthreads();
       c_early = __builtin_amdgcn_readfirstlane(s_ctl[3]) != 0;
       if (c_early && strip_on) {
@@ -870,6 +873,203 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0 && do_update) atomicAdd(&upd[(ti * N + tj) * fs], 1);
+  stamp(6);
+  return true;
+}
+
+// runtime-K form of mfma_abt (K a multiple of 4)
+BSG_DEV double4_t mfma_abt_rt(double4_t acc, const double* sA, int lda, const double* sB, int ldb, double sign, int K, int lane) {
+  const int r = lane & 15, kq = lane >> 4;
+  for (int k = 0; k < K; k += 4) {
+    const double a = sign * sA[r * lda + k + kq];
+    const double b = sB[r * ldb + k + kq];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+  return acc;
+}
+// D += A B over k in [k0, k1): A = 16 rows at sA (pitch lda), B = rows k of sB (pitch ldb), 16 columns from column c0 (B is NOT transposed)
+BSG_DEV double4_t mfma_ab_rt(double4_t acc, const double* sA, int lda, const double* sB, int ldb, int c0, int k0, int k1, int lane) {
+  const int r = lane & 15, kq = lane >> 4;
+  for (int k = k0; k < k1; k += 4) {
+    const double a = sA[r * lda + k + kq];
+    const double b = sB[(k + kq) * ldb + c0 + r];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+  return acc;
+}
+// ONE K-CHUNK of the last update of a tile inside a chain (dense_plan.h kFusedSplit): chunk p of P forms the 16 columns 16 p .. of
+// X_ti = A(ti, k) W^T (W = L_kk^-1 is lower triangular: K = 16 (p + 1)) and of X_tj and adds -X_ti X_tj^T (rank 16) to the tile with FP64
+// atomics, once the tile's earlier updates are all in (tk.need_c: the chunks share the last turn).  The appendix chunk (p = P - 1 of a panel
+// that carries an appendix) forms the appendix's columns X_e = E W16^T - A M^T with M = W16 L(k+1, k) W — the lower-left block of the
+// inverse of the 80-column factor, 16 x 64, formed here (20 MFMAs on the path instead of the whole strips' solves).  A diagonal task's
+// chunks publish their columns of X to the factor; the last one to have done so bumps the panel tile's counter (what the readers of X wait for).
+template <bool PROBE>
+BSG_DEV bool chol_fused_split(const FusedCtx& C, int t, const FusedTask& tk, double* smem) {
+  constexpr int NT = 512, NQ = 2048 / NT;
+  double* const S = uniform_ptr(C.S); double* const Lp = uniform_ptr(C.Lp);
+  const int ld = __builtin_amdgcn_readfirstlane(C.ld);
+  int* const abort_w = uniform_ptr(C.abort_w); int* const potrf_done = uniform_ptr(C.potrf_done); int* const upd = uniform_ptr(C.upd);
+  const int fs = __builtin_amdgcn_readfirstlane(C.fs);
+  const long long deadline = uniform_i64(C.deadline);
+  long long* const probe_ts = uniform_ptr(C.probe_ts);
+  double* sXi = smem;                    // A(ti, k), 64 x LDT
+  double* sXj = sXi + NB * LDT;          // A(tj, k)
+  double* sL = sXj + NB * LDT;           // rows 16 p .. of W (a chunk) | W (the appendix chunk)
+  double* sEi = sL + NB * LDT;           // 64 x kExtPitch: the chunk's columns of X_ti (the appendix chunk: E_ti in, X_e out)
+  double* sEj = sEi + NB * kExtPitch;
+  double* sL16 = sEj + NB * kExtPitch;   // 16 x LDT: rows 0..15 of L(k + 1, k); then M
+  double* sW16 = sL16 + 16 * LDT;        // 16 x kExtPitch
+  int* s_ctl = reinterpret_cast<int*>(sW16 + 16 * kExtPitch);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = ld / NB;
+  auto tile_rows = [&](double* base, int row0) {
+    return __builtin_amdgcn_make_buffer_rsrc(base + (size_t)row0 * ld, 0, (int)((size_t)NB * ld * sizeof(double)), 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(C.Winv), 0, (int)((size_t)(N - 1) * 4096 * sizeof(double)), 0x00020000);
+  const int crow = lane >> 4, ccol = lane & 15;
+  auto stamp = [&](int sl) { if (PROBE && tid == 0) probe_ts[(size_t)t * 8 + sl] = wall_clock64(); };
+  stamp(1);
+  const int k = tk.k, ti = tk.ti, tj = tk.tj;
+  const int p = tk.tot_c & 0xff, P = tk.tot_c >> 8;
+  const bool diag = ti == tj;
+  const bool ext = (tk.flags & kFusedExt) != 0, ext_chunk = ext && p == P - 1;
+  const int te = k + 1;
+  const int ri = __builtin_amdgcn_readfirstlane(ti * NB), rj = __builtin_amdgcn_readfirstlane(tj * NB), c0 = __builtin_amdgcn_readfirstlane(k * NB);
+  const __amdgpu_buffer_rsrc_t rS_i = tile_rows(S, ri), rS_j = tile_rows(S, rj), rL_i = tile_rows(Lp, ri);
+  if (tid == 0) {
+    bool ok = wait_count(&upd[(ti * N + k) * fs], tk.tot_i, abort_w, deadline);
+    if (!diag) ok = ok && wait_count(&upd[(tj * N + k) * fs], tk.tot_j, abort_w, deadline);
+    if (ext_chunk) {
+      const int* tot = uniform_ptr(C.tile_tot);
+      ok = ok && wait_count(&upd[(ti * N + te) * fs], tot[(size_t)ti * N + te], abort_w, deadline);
+      if (!diag) ok = ok && wait_count(&upd[(tj * N + te) * fs], tot[(size_t)tj * N + te], abort_w, deadline);
+    }
+    s_ctl[1] = ok ? 1 : 0;
+  }
+  __syncthreads();
+  if (__builtin_amdgcn_readfirstlane(s_ctl[1]) == 0) return false;
+  double2 vXi[NQ], vXj[NQ], vL[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int i = tid + NT * q;
+    const int r = i >> 5, c2 = (i & 31) * 2;
+    vXi[q] = ld16_sc1(rS_i, (unsigned)(((size_t)r * ld + c0 + c2) * sizeof(double)));
+    if (!diag) vXj[q] = ld16_sc1(rS_j, (unsigned)(((size_t)r * ld + c0 + c2) * sizeof(double)));
+  }
+  double2 vEi = double2{0.0, 0.0}, vEj = double2{0.0, 0.0}, vL16 = double2{0.0, 0.0}, vW16 = double2{0.0, 0.0}, vWc = double2{0.0, 0.0};
+  const int er = tid >> 3, ec2 = (tid & 7) * 2;   // this thread's piece of a 64 x 16 block
+  if (ext_chunk) {
+    vEi = ld16_sc1(rS_i, (unsigned)(((size_t)er * ld + c0 + NB + ec2) * sizeof(double)));
+    if (!diag) vEj = ld16_sc1(rS_j, (unsigned)(((size_t)er * ld + c0 + NB + ec2) * sizeof(double)));
+  }
+  __syncthreads();   // (s_ctl[1] is rewritten below)
+  if (tid == 0) s_ctl[1] = wait_count(&potrf_done[(ext_chunk ? te : k) * fs], 1, abort_w, deadline) ? 1 : 0;   // (a chain sets its tiles' flags in order)
+  __syncthreads();
+  if (__builtin_amdgcn_readfirstlane(s_ctl[1]) == 0) return false;
+  stamp(2);
+  if (!ext_chunk) {
+    // rows 16 p .. 16 p + 15 of W: one 16-byte piece per thread
+    vWc = ld16_sc1(rW, (unsigned)(((size_t)k * 4096 + (size_t)(16 * p + (tid >> 5)) * 64 + (tid & 31) * 2) * sizeof(double)));
+  } else {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int i = tid + NT * q;
+      vL[q] = ld16_sc1(rW, (unsigned)(((size_t)k * 4096 + (size_t)(i >> 5) * 64 + (i & 31) * 2) * sizeof(double)));
+    }
+    const __amdgpu_buffer_rsrc_t rL_e = tile_rows(Lp, te * NB);
+    vL16 = ld16_sc1(rL_e, (unsigned)(((size_t)(tid >> 5) * ld + c0 + (tid & 31) * 2) * sizeof(double)));
+    if (tid < 128) vW16 = ld16_sc1(rW, (unsigned)(((size_t)te * 4096 + (size_t)er * 64 + ec2) * sizeof(double)));
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int i = tid + NT * q;
+    const int r = i >> 5, c2 = (i & 31) * 2;
+    *reinterpret_cast<double2*>(&sXi[r * LDT + c2]) = vXi[q];
+    if (!diag) *reinterpret_cast<double2*>(&sXj[r * LDT + c2]) = vXj[q];
+    if (ext_chunk) *reinterpret_cast<double2*>(&sL[r * LDT + c2]) = vL[q];
+  }
+  if (!ext_chunk) *reinterpret_cast<double2*>(&sL[(tid >> 5) * LDT + (tid & 31) * 2]) = vWc;
+  else {
+    *reinterpret_cast<double2*>(&sEi[er * kExtPitch + ec2]) = vEi;
+    if (!diag) *reinterpret_cast<double2*>(&sEj[er * kExtPitch + ec2]) = vEj;
+    *reinterpret_cast<double2*>(&sL16[(tid >> 5) * LDT + (tid & 31) * 2]) = vL16;
+    if (tid < 128) *reinterpret_cast<double2*>(&sW16[er * kExtPitch + ec2]) = vW16;
+  }
+  __syncthreads();
+  stamp(3);
+  if (!ext_chunk) {
+    // (waves 0-3: the strips of the chunk of X_i; waves 4-7: those of X_j, at the same time)
+    if (wave < 4 || !diag) {
+      const double* A = wave < 4 ? sXi : sXj;
+      double* E = wave < 4 ? sEi : sEj;
+      const int strip = wave & 3;
+      double4_t x = double4_t{0.0, 0.0, 0.0, 0.0};
+      x = mfma_abt_rt(x, A + (16 * strip) * LDT, LDT, sL, LDT, 1.0, 16 * (p + 1), lane);
+      store_d(E + (16 * strip) * kExtPitch, kExtPitch, lane, x);
+    }
+    __syncthreads();
+  } else {
+    // M = (W16 L16) W, block column c by wave c: T = W16 L16(:, 16 c' ..) for c' >= c is needed ... formed in two steps through LDS:
+    // first T = W16 L16 (every wave one block column), then M(:, 16 c ..) = sum_{m >= 16 c} T(:, m) W(m, 16 c ..)   (W lower triangular)
+    double4_t tb = double4_t{0.0, 0.0, 0.0, 0.0};
+    if (wave < 4) tb = mfma_ab_rt(tb, sW16, kExtPitch, sL16, LDT, 16 * wave, 0, 16, lane);
+    __syncthreads();
+    if (wave < 4) store_d(sL16 + 16 * wave, LDT, lane, tb);   // T over L16 (16 x 64, pitch LDT)
+    __syncthreads();
+    double4_t mb = double4_t{0.0, 0.0, 0.0, 0.0};
+    if (wave < 4) mb = mfma_ab_rt(mb, sL16, LDT, sL, LDT, 16 * wave, 16 * wave, 64, lane);
+    __syncthreads();
+    if (wave < 4) store_d(sL16 + 16 * wave, LDT, lane, mb);   // M over T
+    __syncthreads();
+    // X_e strips = E W16^T - A M^T
+    if (wave < 4 || !diag) {
+      const double* A = wave < 4 ? sXi : sXj;
+      double* E = wave < 4 ? sEi : sEj;
+      const int strip = wave & 3;
+      double4_t x = double4_t{0.0, 0.0, 0.0, 0.0};
+      x = mfma_abt<16>(x, E + (16 * strip) * kExtPitch, kExtPitch, sW16, kExtPitch, 1.0, lane);
+      x = mfma_abt<64>(x, A + (16 * strip) * LDT, LDT, sL16, LDT, -1.0, lane);
+      __builtin_amdgcn_wave_barrier();
+      store_d(E + (16 * strip) * kExtPitch, kExtPitch, lane, x);
+    }
+    __syncthreads();
+  }
+  stamp(4);
+  if (tk.flags & kFusedPublishX) {
+    // this chunk's 16 columns of the L panel of row tile ti (the appendix chunk: the appendix's columns)
+    st16_sc1(rL_i, (unsigned)(((size_t)er * ld + c0 + (ext_chunk ? NB : 16 * p) + ec2) * sizeof(double)), *reinterpret_cast<const double2*>(&sEi[er * kExtPitch + ec2]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      // (the chunks count themselves in the upper half of the panel tile's counter; the last one advances the lower half: X is published)
+      const int old = atomicAdd(&upd[(ti * N + k) * fs], 1 << 16);
+      if ((int)((unsigned)old >> 16) == P - 1) atomicAdd(&upd[(ti * N + k) * fs], 1);
+    }
+  }
+  const double* Ej = diag ? sEi : sEj;
+  const int rs = wave & 3, tt0 = (wave >> 2) * 2;
+  double4_t acc[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    acc[u] = double4_t{0.0, 0.0, 0.0, 0.0};
+    if (!(diag && tt0 + u > rs))   // (blocks above the diagonal of a diagonal tile: the chain never reads them)
+      acc[u] = mfma_abt<16>(acc[u], sEi + (16 * rs) * kExtPitch, kExtPitch, Ej + (16 * (tt0 + u)) * kExtPitch, kExtPitch, -1.0, lane);
+  }
+  // the chunks' turn: every earlier update of the tile has been published (on the critical path: long ago)
+  if (tid == 0) s_ctl[1] = wait_count(&upd[(ti * N + tj) * fs], tk.need_c, abort_w, deadline) ? 1 : 0;
+  __syncthreads();
+  if (__builtin_amdgcn_readfirstlane(s_ctl[1]) == 0) return false;
+  stamp(5);
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    if (diag && tt0 + u > rs) continue;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg)
+      (void)__hip_atomic_fetch_add(&S[(size_t)(ri + 16 * rs + crow + 4 * reg) * ld + rj + 16 * (tt0 + u) + ccol], acc[u][reg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) atomicAdd(&upd[(ti * N + tj) * fs], 1 << 16);
   stamp(6);
   return true;
 }
@@ -965,6 +1165,7 @@ __device__ __forceinline__ void chol_fused_kernel_body(const int bsg_bx, const i
       __syncthreads();
       if (tid == 0) atomicAdd(&C.upd[(tk.k * N + tk.k) * fs], 1);
     } else if (tk.flags & kFusedChain) (void)chol_fused_chain<PROBE>(C, t, tk, smem);
+    else if (tk.flags & kFusedSplit) (void)chol_fused_split<PROBE>(C, t, tk, smem);
     else (void)chol_fused_update<PROBE, kFusedThreads>(C, t, tk, smem);
   }
   // leave: the last workgroup out re-zeroes the queue and the counters for the next factorisation

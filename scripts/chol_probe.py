@@ -23,16 +23,20 @@ print("tasks %d, workgroups %d, span %.1f us" % (len(rows), len(set(r["wg"] for 
 #            tile (a, b) at count c <- the update task of (a, b) with need == c - 1
 potrf_by = {}
 upd_by = {}
+split_by = collections.defaultdict(list)   # (ti, tj) -> kFusedSplit chunks (flags & 256): they feed the chain that owns the tile
 for r in rows:
+    if r["flags"] & 256:
+        split_by[(r["ti"], r["tj"])].append(r)
+        continue
     if r["flags"] & 1:   # a chain task: k = first tile, ti = number of tiles (its tiles' flags are set as it goes; the stamp is its end)
         for t in range(r["k"], r["k"] + r["ti"]):
             potrf_by[t] = r
     else:
-        if r["need"] >= 0:
+        if r["need"] >= 0 and not (r["flags"] & 256):
             upd_by[(r["ti"], r["tj"], r["need"] + 1)] = r
 tot = collections.Counter()
 for r in rows:
-    if not (r["flags"] & 1) and r["need"] >= 0:
+    if not (r["flags"] & (1 | 256)) and r["need"] >= 0:
         tot[(r["ti"], r["tj"])] = max(tot[(r["ti"], r["tj"])], r["tot"])
 
 
@@ -46,6 +50,17 @@ def deps_of(r):
                 c = tot.get((a, b), 0)
                 if c and (a, b, c) in upd_by:
                     d.append(("C(%d,%d)" % (a, b), upd_by[(a, b, c)]))
+                for ch in split_by.get((a, b), []):
+                    d.append(("P(%d,%d)k%d" % (a, b, ch["k"]), ch))
+        return d
+    if r["flags"] & 256:
+        d = []
+        if r["k"] in potrf_by:
+            d.append(("L%d" % r["k"], potrf_by[r["k"]]))
+        for a in (r["ti"], r["tj"]):
+            c = tot.get((a, r["k"]), 0)
+            if c and (a, r["k"], c) in upd_by:
+                d.append(("A(%d,%d)" % (a, r["k"]), upd_by[(a, r["k"], c)]))
         return d
     d = []
     if r["k"] in potrf_by:
@@ -74,7 +89,7 @@ print("  task      k  ti  tj  wg | deq   got  deps(wait) loaded solved product+t
 for r, name, dpub in path:
     hop = (r["deps"] - dpub) / 100.0 if dpub else 0.0
     print("  %4d %s %3d %3d %3d %3d | %6.1f %5.1f %6.1f %6.1f %6.1f %6.1f %7.1f | %-18s %8.1f %6.1f" % (
-        r["i"], "C" if r["flags"] & 1 else ("x" if r["flags"] & 6 else " "), r["k"], r["ti"], r["tj"], r["wg"],
+        r["i"], "C" if r["flags"] & 1 else ("S" if r["flags"] & 256 else ("x" if r["flags"] & 6 else " ")), r["k"], r["ti"], r["tj"], r["wg"],
         us(r["deq"]), (r["got"] - r["deq"]) / 100.0, (r["deps"] - r["got"]) / 100.0 if r["deps"] else 0, (r["loaded"] - r["deps"]) / 100.0 if r["deps"] else 0,
         (r["solved"] - r["loaded"]) / 100.0 if r["loaded"] else 0, (r["updated"] - r["solved"]) / 100.0, (r["pub"] - r["updated"]) / 100.0, name,
         us(dpub) if dpub else 0, hop))
@@ -82,7 +97,7 @@ for r, name, dpub in path:
 agg = collections.defaultdict(float)
 n = 0
 for r in rows:
-    if r["flags"] & (1 | 64 | 128):
+    if r["flags"] & (1 | 64 | 128 | 256):
         continue
     n += 1
     agg["dequeue"] += (r["got"] - r["deq"]) / 100.0

@@ -17,6 +17,7 @@ static int check(int T, const std::vector<uint8_t>& adj, int max_chains, const s
   DensePlan P;
   const int n_pose = T * 64 - (seed % 3 == 0 ? 23 : 0);
   if (seed % 2) { P.diag_tasks = true; P.rider_tasks = (int)(seed % 4); }
+  P.split_depth = (int)((seed / 7) % 4);   // (0: no chunks; 1: the default; 2, 3: the last updates of a tile)
   P.build(n_pose, adj, max_chains, 1, true, leaf);
   std::vector<uint8_t> adjS((size_t)P.T * P.T, 0);
   for (int i = 0; i < P.T; ++i) for (int j = 0; j < P.T; ++j) if (adj[(size_t)i * P.T + j]) adjS[(size_t)P.perm[i] * P.T + P.perm[j]] = 1;
@@ -76,12 +77,13 @@ static int check_ordered(std::mt19937& rng, unsigned seed) {
     for (int ka = 0; ka < o.blk_w[a]; ++ka) for (int kb = 0; kb < o.blk_w[b]; ++kb) adjS[(size_t)(o.dpos[o.blk_t0[a] + ka] >> 6) * o.T + (o.dpos[o.blk_t0[b] + kb] >> 6)] = 1;
   DensePlan P;
   if (seed % 2) { P.diag_tasks = true; P.rider_tasks = 1 + (int)(seed % 5); }   // (the LM diagonal / gradient norms carried by the launch)
+  P.split_depth = (int)((seed / 7) % 4);
   P.build_ordered(o.n_pose, o.T, o.dpos, o.nreal, adjS, o.piece_ranges, o.sep_ranges_by_level);
   if (!o.sep_ranges_by_level.empty() && !P.bs_level_sync && P.bs_group_off.size() > 2) fail("the by-level back-substitution groups were refused");
   return fails + replay(P, adjS, seed, -1);
 }
 
-static long g_ext_tasks = 0, g_ext_plans = 0, g_diag_tasks = 0;
+static long g_ext_tasks = 0, g_ext_plans = 0, g_diag_tasks = 0, g_split_tasks = 0, g_split_loaded = 0;
 static int replay_list(const DensePlan& P, const std::vector<uint8_t>& adj, unsigned seed, int max_chains) {
   { long n = 0; for (const FusedTask& f : P.ftasks) n += (f.flags & kFusedExt) ? 1 : 0; g_ext_tasks += n; g_ext_plans += n > 0; }
   const int T = P.T;
@@ -107,6 +109,10 @@ static int replay_list(const DensePlan& P, const std::vector<uint8_t>& adj, unsi
   // replay
   std::vector<double> S = A, L((size_t)N * N, 0.0);
   std::vector<int> upd((size_t)N * N, 0), potrf_done(N, 0), xpub((size_t)N * N, 0);
+  // kFusedSplit chunks: the chunks that reached a tile, the chunks that published their columns of X
+  std::vector<int> upd_hi((size_t)N * N, 0), pub_hi((size_t)N * N, 0);
+  auto tot_lo = [&](int a, int b) { return P.tile_tot[(size_t)a * N + b] & 0xffff; };
+  auto tot_hi = [&](int a, int b) { return (int)((unsigned)P.tile_tot[(size_t)a * N + b] >> 16); };
   int fails = 0;
   auto fail = [&](const char* what, int t) { if (fails++ < 5) printf("  FAIL %s at task %d\n", what, t); };
   for (size_t t = 0; t < P.ftasks.size(); ++t) {
@@ -125,7 +131,9 @@ static int replay_list(const DensePlan& P, const std::vector<uint8_t>& adj, unsi
       if (m < 1 || m > kChainMaxTiles) fail("chain length", (int)t);
       for (int i = 0; i < m; ++i) for (int j = 0; j <= i; ++j) {
         const bool present = (f.tj >> (i * (i + 1) / 2 + j)) & 1;
-        if (upd[(size_t)(b0 + i) * N + b0 + j] != P.tile_tot[(size_t)(b0 + i) * N + b0 + j]) fail("chain tile not final", (int)t);
+        if (upd[(size_t)(b0 + i) * N + b0 + j] != tot_lo(b0 + i, b0 + j)) fail("chain tile not final", (int)t);
+        if (upd_hi[(size_t)(b0 + i) * N + b0 + j] != tot_hi(b0 + i, b0 + j)) fail("chain tile: chunks missing", (int)t);
+        g_split_loaded += tot_hi(b0 + i, b0 + j);
         if (!present && S[(size_t)(b0 + i) * N + b0 + j] != 0.0) fail("absent tile is non-zero", (int)t);
       }
       for (int kk = b0; kk < b0 + m; ++kk) {   // dense factorisation of the chain's own tiles
@@ -138,10 +146,47 @@ static int replay_list(const DensePlan& P, const std::vector<uint8_t>& adj, unsi
       }
       continue;
     }
+    if (f.flags & kFusedSplit) {
+      // one K-chunk of an update of a tile inside a chain: its share of the product goes to a partial tile of its own, no turn
+      const int k = f.k, i = f.ti, j = f.tj, pch = f.tot_c & 0xff, Pn = f.tot_c >> 8;
+      const bool diag = i == j, ext = (f.flags & kFusedExt) != 0, ext_chunk = ext && pch == Pn - 1;
+      ++g_split_tasks;
+      if (Pn != kFusedSplitChunks + (ext ? 1 : 0) || pch < 0 || pch >= Pn) fail("chunk numbering", (int)t);
+      if (f.flags & (kFusedXiLp | kFusedXjLp | kFusedXjChain)) fail("a chunk reads published X", (int)t);
+      if (!(i < P.T && P.fchain_of_tile[i] >= 0 && P.fchain_of_tile[i] == P.fchain_of_tile[j])) fail("chunk of a tile outside a chain", (int)t);
+      if (P.fchain_of_tile[i] == P.fchain_of_tile[k]) fail("chunk inside the chain of its panel", (int)t);
+      const int te = k + 1;
+      if (!potrf_done[ext_chunk ? te : k]) fail("chunk: factor not out", (int)t);
+      if (f.tot_i != P.tile_tot[(size_t)i * N + k] || f.tot_j != P.tile_tot[(size_t)j * N + k]) fail("chunk: tot mismatch", (int)t);
+      if (upd[(size_t)i * N + k] < f.tot_i) fail("chunk: panel tile i not ready", (int)t);
+      if (!diag && upd[(size_t)j * N + k] < f.tot_j) fail("chunk: panel tile j not ready", (int)t);
+      if (ext && (P.fext_of[k] != te || P.fchain_of_tile[te] != P.fchain_of_tile[k])) fail("chunk: appendix of another chain", (int)t);
+      if (ext_chunk && upd[(size_t)i * N + te] != tot_lo(i, te)) fail("chunk: appendix columns of tile i not final", (int)t);
+      if (ext_chunk && !diag && upd[(size_t)j * N + te] != tot_lo(j, te)) fail("chunk: appendix columns of tile j not final", (int)t);
+      if (potrf_done[i]) fail("chunk after its tile was factored", (int)t);
+      const double xi = S[(size_t)i * N + k] / L[(size_t)k * N + k], xj = diag ? xi : S[(size_t)j * N + k] / L[(size_t)k * N + k];
+      double val;
+      if (!ext_chunk) val = xi * xj / kFusedSplitChunks;   // (the stand-in for 16 of the panel's 64 columns)
+      else {
+        const double xi_e = (S[(size_t)i * N + te] - xi * L[(size_t)te * N + k]) / L[(size_t)te * N + te];
+        const double xj_e = diag ? xi_e : (S[(size_t)j * N + te] - xj * L[(size_t)te * N + k]) / L[(size_t)te * N + te];
+        val = xi_e * xj_e;
+        if (f.flags & kFusedPublishX) L[(size_t)i * N + te] = xi_e;
+      }
+      if (f.need_c != tot_lo(i, j) || upd[(size_t)i * N + j] != f.need_c) fail("chunk: the tile's updates with a turn of their own are not all in", (int)t);
+      if (upd_hi[(size_t)i * N + j] >= tot_hi(i, j)) fail("chunk: more chunks than the tile counts", (int)t);
+      S[(size_t)i * N + j] -= val;
+      upd_hi[(size_t)i * N + j]++;
+      if (f.flags & kFusedPublishX) {
+        if (!diag) fail("an off-diagonal chunk publishes X", (int)t);
+        if (++pub_hi[(size_t)i * N + k] == Pn) { L[(size_t)i * N + k] = xi; xpub[(size_t)i * N + k] = 1; upd[(size_t)i * N + k]++; }
+      }
+      continue;
+    }
     const int k = f.k, i = f.ti, j = f.tj;
     const bool diag = i == j, solve_i = !(f.flags & kFusedXiLp), solve_j = !diag && !(f.flags & (kFusedXjLp | kFusedXjChain));
     if (!potrf_done[k] && (solve_i || solve_j || (f.flags & kFusedXjChain))) fail("L_kk not out", (int)t);
-    if (f.tot_i != P.tile_tot[(size_t)i * N + k] || f.tot_j != P.tile_tot[(size_t)j * N + k]) fail("tot mismatch", (int)t);
+    if (f.tot_i != P.tile_tot[(size_t)i * N + k] || (!(f.flags & kFusedXjChain) && f.tot_j != P.tile_tot[(size_t)j * N + k])) fail("tot mismatch", (int)t);   // (a task whose tj is in the chain of k waits for the chain's flag, not for a count of tile (tj, k) — a tile inside a chain, whose count may carry chunks)
     if (upd[(size_t)i * N + k] < f.tot_i + (solve_i ? 0 : 1)) fail("panel tile i not ready", (int)t);
     if (!diag && !(f.flags & kFusedXjChain) && upd[(size_t)j * N + k] < f.tot_j + (solve_j ? 0 : 1)) fail("panel tile j not ready", (int)t);
     if ((f.flags & kFusedXjChain) && !(P.fchain_of_tile[j] == P.fchain_of_tile[k] && j > k)) fail("XjChain flag", (int)t);
@@ -156,8 +201,8 @@ static int replay_list(const DensePlan& P, const std::vector<uint8_t>& adj, unsi
       if (P.fext_of[k] != te || P.fchain_of_tile[te] != P.fchain_of_tile[k]) fail("appendix of another chain", (int)t);
       if (f.flags & kFusedXjChain) fail("appendix task inside the chain", (int)t);
       if (!potrf_done[te] && (solve_i || solve_j)) fail("appendix not factored", (int)t);
-      if (solve_i && upd[(size_t)i * N + te] != P.tile_tot[(size_t)i * N + te]) fail("appendix columns of tile i not final", (int)t);
-      if (solve_j && upd[(size_t)j * N + te] != P.tile_tot[(size_t)j * N + te]) fail("appendix columns of tile j not final", (int)t);
+      if (solve_i && upd[(size_t)i * N + te] != tot_lo(i, te)) fail("appendix columns of tile i not final", (int)t);
+      if (solve_j && upd[(size_t)j * N + te] != tot_lo(j, te)) fail("appendix columns of tile j not final", (int)t);
       xi_e = solve_i ? (S[(size_t)i * N + te] - xi * L[(size_t)te * N + k]) / L[(size_t)te * N + te] : L[(size_t)i * N + te];
       xj_e = diag ? xi_e : (solve_j ? (S[(size_t)j * N + te] - xj * L[(size_t)te * N + k]) / L[(size_t)te * N + te] : L[(size_t)j * N + te]);
     }
@@ -222,6 +267,8 @@ int main() {
   printf("%d ordered cases, %d failures\n", ocases, ofails);
   printf("appendix tiles: %ld tasks in %ld plans\n", g_ext_tasks, g_ext_plans);
   if (g_ext_plans < 20) { printf("too few plans with an appendix tile\n"); ++fails; }
+  printf("split chunks: %ld tasks, %ld partial tiles added by chains\n", g_split_tasks, g_split_loaded);
+  if (g_split_tasks < 1000 || g_split_loaded != g_split_tasks) { printf("the split chunks and the chains' partial tiles do not match\n"); ++fails; }
   printf("diagonal tasks: %ld\n", g_diag_tasks);
   if (g_diag_tasks < 1000) { printf("too few diagonal tasks\n"); ++fails; }
   fails += ofails;
