@@ -877,25 +877,33 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
   return true;
 }
 
-// runtime-K form of mfma_abt (K a multiple of 4)
+// runtime-K form of mfma_abt (K a multiple of 4), FOUR accumulators: consecutive MFMAs of one accumulator are ~175 cycles apart (the result of
+// one is the addend of the next), of different ones 64 — a chunk's products are chains of up to 16
 BSG_DEV double4_t mfma_abt_rt(double4_t acc, const double* sA, int lda, const double* sB, int ldb, double sign, int K, int lane) {
   const int r = lane & 15, kq = lane >> 4;
-  for (int k = 0; k < K; k += 4) {
-    const double a = sign * sA[r * lda + k + kq];
-    const double b = sB[r * ldb + k + kq];
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  double4_t a1 = double4_t{0.0, 0.0, 0.0, 0.0}, a2 = a1, a3 = a1;
+  int k = 0;
+  for (; k + 16 <= K; k += 16) {
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sign * sA[r * lda + k + kq], sB[r * ldb + k + kq], acc, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(sign * sA[r * lda + k + 4 + kq], sB[r * ldb + k + 4 + kq], a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(sign * sA[r * lda + k + 8 + kq], sB[r * ldb + k + 8 + kq], a2, 0, 0, 0);
+    a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(sign * sA[r * lda + k + 12 + kq], sB[r * ldb + k + 12 + kq], a3, 0, 0, 0);
   }
-  return acc;
+  for (; k < K; k += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sign * sA[r * lda + k + kq], sB[r * ldb + k + kq], acc, 0, 0, 0);
+  return (acc + a1) + (a2 + a3);
 }
-// D += A B over k in [k0, k1): A = 16 rows at sA (pitch lda), B = rows k of sB (pitch ldb), 16 columns from column c0 (B is NOT transposed)
+// D += A B over k in [k0, k1) (multiples of 16 apart): A = 16 rows at sA (pitch lda), B = rows k of sB (pitch ldb), 16 columns from column c0
+// (B is NOT transposed); four accumulators as above
 BSG_DEV double4_t mfma_ab_rt(double4_t acc, const double* sA, int lda, const double* sB, int ldb, int c0, int k0, int k1, int lane) {
   const int r = lane & 15, kq = lane >> 4;
-  for (int k = k0; k < k1; k += 4) {
-    const double a = sA[r * lda + k + kq];
-    const double b = sB[(k + kq) * ldb + c0 + r];
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  double4_t a1 = double4_t{0.0, 0.0, 0.0, 0.0}, a2 = a1, a3 = a1;
+  for (int k = k0; k < k1; k += 16) {
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[r * lda + k + kq], sB[(k + kq) * ldb + c0 + r], acc, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[r * lda + k + 4 + kq], sB[(k + 4 + kq) * ldb + c0 + r], a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[r * lda + k + 8 + kq], sB[(k + 8 + kq) * ldb + c0 + r], a2, 0, 0, 0);
+    a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[r * lda + k + 12 + kq], sB[(k + 12 + kq) * ldb + c0 + r], a3, 0, 0, 0);
   }
-  return acc;
+  return (acc + a1) + (a2 + a3);
 }
 // ONE K-CHUNK of the last update of a tile inside a chain (dense_plan.h kFusedSplit): chunk p of P forms the 16 columns 16 p .. of
 // X_ti = A(ti, k) W^T (W = L_kk^-1 is lower triangular: K = 16 (p + 1)) and of X_tj and adds -X_ti X_tj^T (rank 16) to the tile with FP64
@@ -1027,8 +1035,8 @@ BSG_DEV bool chol_fused_split(const FusedCtx& C, int t, const FusedTask& tk, dou
       double* E = wave < 4 ? sEi : sEj;
       const int strip = wave & 3;
       double4_t x = double4_t{0.0, 0.0, 0.0, 0.0};
-      x = mfma_abt<16>(x, E + (16 * strip) * kExtPitch, kExtPitch, sW16, kExtPitch, 1.0, lane);
-      x = mfma_abt<64>(x, A + (16 * strip) * LDT, LDT, sL16, LDT, -1.0, lane);
+      x = mfma_abt_rt(x, E + (16 * strip) * kExtPitch, kExtPitch, sW16, kExtPitch, 1.0, 16, lane);
+      x = mfma_abt_rt(x, A + (16 * strip) * LDT, LDT, sL16, LDT, -1.0, 64, lane);
       __builtin_amdgcn_wave_barrier();
       store_d(E + (16 * strip) * kExtPitch, kExtPitch, lane, x);
     }
@@ -1053,7 +1061,7 @@ BSG_DEV bool chol_fused_split(const FusedCtx& C, int t, const FusedTask& tk, dou
   for (int u = 0; u < 2; ++u) {
     acc[u] = double4_t{0.0, 0.0, 0.0, 0.0};
     if (!(diag && tt0 + u > rs))   // (blocks above the diagonal of a diagonal tile: the chain never reads them)
-      acc[u] = mfma_abt<16>(acc[u], sEi + (16 * rs) * kExtPitch, kExtPitch, Ej + (16 * (tt0 + u)) * kExtPitch, kExtPitch, -1.0, lane);
+      acc[u] = mfma_abt_rt(acc[u], sEi + (16 * rs) * kExtPitch, kExtPitch, Ej + (16 * (tt0 + u)) * kExtPitch, kExtPitch, -1.0, 16, lane);
   }
   // the chunks' turn: every earlier update of the tile has been published (on the critical path: long ago)
   if (tid == 0) s_ctl[1] = wait_count(&upd[(ti * N + tj) * fs], tk.need_c, abort_w, deadline) ? 1 : 0;

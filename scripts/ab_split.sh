@@ -6,12 +6,12 @@ import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 p=d.get('phases_us_per_lm_step') or {}
 print(sys.argv[1], d['value'], 'factor', p.get('factor'), 'backsolve', p.get('backsolve'), 'cost', d['config']['final_cost'])" "$1"; }
-for sp in 1 2 3 8 1 2 3 8; do
+for sp in 2 2; do
   BSGPU_CHOL_SPLIT=$sp $B 2>/dev/null | ex c2-split=$sp
 done
-for sp in 1 2 3 8 1 2 3 8; do
+for sp in 2 2; do
   BSGPU_CHOL_SPLIT=$sp $B --workload c3 2>/dev/null | ex c3-split=$sp
 done
-for sp in 1 2 3 8 1 2 3 8; do
+for sp in 2 2; do
   echo "small split=$sp"; BSGPU_CHOL_SPLIT=$sp timeout 120 python scripts/small_window.py 2>&1 | head -2
 done
