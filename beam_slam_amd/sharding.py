@@ -35,6 +35,18 @@ def aggregate(dist, work_units, seconds, device="cpu"):
     return float(w.item()), float(t.item())
 
 
+def per_rank_rates(dist, work_units, seconds, device="cpu"):
+    """(number of ranks that reported, every rank's own work / time): one all-reduce of a vector with one slot per rank + a count of
+    ones — a run whose ranks did not all arrive shows it in the first number instead of in a plausible-looking aggregate."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    v = torch.zeros(world + 1, dtype=torch.float64, device=device)
+    v[rank] = float(work_units) / max(float(seconds), 1e-30)
+    v[world] = 1.0
+    dist.all_reduce(v, op=dist.ReduceOp.SUM)
+    return int(round(float(v[world].item()))), [round(float(x), 2) for x in v[:world].tolist()]
+
+
 def _quat_mul(a, b):
     import torch
     aw, ax, ay, az = a.unbind(-1)

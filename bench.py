@@ -102,16 +102,17 @@ def short_leg(which, device):
     return leg
 
 
-def batch_leg(n_win, n_kf, n_lm, device, steps, seed0, label):
-    """n_win independent windows on ONE device through bsgpu_solve_batch (one set of launches per LM iteration for all of them,
-    csrc/bsgpu_batch.cpp): BASELINE config 5's workload folded onto a single GPU, or the reference's own window sizes (vio.yaml:3,56)."""
-    from beam_slam_amd import synthetic
+def batch_leg(problems, device, steps, label, opt_of=None, lone_steps=0):
+    """The windows `problems` on ONE device through bsgpu_solve_batch (one set of launches per LM iteration for all of them,
+    csrc/bsgpu_batch.cpp): BASELINE config 5's workload folded onto a single GPU, the reference's own window sizes (vio.yaml:3,56),
+    its lidar-inertial windows (lio.yaml) or its submap pose graphs (submap_pose_graph_optimization.cpp:22-150).  lone_steps > 0: the
+    first window is also solved alone that many times, so that the line carries the ratio."""
     from beam_slam_amd.gpu import GpuSolver
     gs = []
-    for w in range(n_win):
-        pr = synthetic.vio_window(n_kf=n_kf, n_lm=n_lm, seed=seed0 + w)
+    for pr in problems:
         g = GpuSolver(device); pr.load(g); g.finalize(); gs.append(g)
-    opt = gs[0].options_vio()
+    n_win = len(gs)
+    opt = opt_of(gs[0]) if opt_of else gs[0].options_vio()
     opt.max_solver_time_in_seconds = 0.0
     for _ in range(2):
         for g in gs: g.reset_values()
@@ -127,8 +128,37 @@ def batch_leg(n_win, n_kf, n_lm, device, steps, seed0, label):
     leg = {"workload": label, "windows": n_win, "value": round(n_it / dt, 1), "unit": "LM iterations/s (aggregate)", "steps": steps,
            "ms_per_step": round(1e3 * dt / steps, 3), "lm_iterations_per_window_and_solve": round(n_it / steps / n_win, 2),
            "windows_on_the_batched_launches": (w1 - w0) // max(1, steps), "us_per_round_of_launches": round(1e6 * dt / max(1, r1 - r0), 1)}
+    if lone_steps > 0:
+        g = gs[0]
+        for _ in range(3):
+            g.reset_values(); g.solve(opt)
+        t0 = time.perf_counter()
+        n1 = 0
+        for _ in range(lone_steps):
+            g.reset_values(); n1 += g.solve(opt).num_linear_solves
+        dt1 = time.perf_counter() - t0
+        leg["one_window_alone"] = {"value": round(n1 / dt1, 1), "unit": "LM iterations/s", "us_per_lm_iteration": round(1e6 * dt1 / max(1, n1), 1), "steps": lone_steps}
+        leg["aggregate_over_one_window_alone"] = round(leg["value"] / max(1e-9, n1 / dt1), 2)
     for g in gs: g.close()
     return leg
+
+
+def host_cycle_leg():
+    """One optimisation cycle of the host mirror (beam_slam_amd/host/: GpuGraph::optimize, clone, release of the previous snapshot,
+    update with a sliding-window transaction; fixed_lag_smoother.cpp:220,274,308) at C2's size, through the C++ program
+    tests/host/bench_host.cpp that __graft_entry__.build() compiles against libbsgpu."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "host", "bench_host.bin")
+    if not os.path.exists(exe):
+        return {"skipped": "tests/host/bench_host.bin is not built (__graft_entry__.build())"}
+    try:
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=240).stdout
+    except Exception as e:   # noqa: BLE001
+        return {"skipped": "bench_host failed: %r" % (e,)}
+    for line in out.splitlines():
+        if line.startswith("HOST_CYCLE_JSON "):
+            return json.loads(line[len("HOST_CYCLE_JSON "):])
+    return {"skipped": "no summary line", "tail": out[-400:]}
 
 
 def main():
@@ -147,6 +177,10 @@ def main():
                     help="skip the short C3 and C4 legs the default (C2, one GPU) run appends under \"other_configs\"")
     ap.add_argument("--sustained-seconds", type=float, default=2.5,
                     help="after the timed region: back-to-back C2 solves for this long (\"sustained\"; 0 = skip)")
+    ap.add_argument("--windows-per-gpu", type=int, default=0,
+                    help="W > 0: every rank advances W independent C2-shaped windows per step with ONE bsgpu_solve_batch (what an N-GPU run of "
+                         "BASELINE config 5 multiplies when a GPU holds more than one submap); value = LM iterations of all windows of all ranks / "
+                         "the slowest rank's time")
     ap.add_argument("--consensus", action="store_true",
                     help="C5 with shared-pose consensus: the N windows are consecutive submaps of ONE trajectory, neighbours share their boundary "
                          "key frame, and a step is the whole message-passing solve of the merged graph (beam_slam_amd/sharding.py); the messages "
@@ -196,6 +230,19 @@ def main():
     g.finalize()
     opt = g.options_vio()
     opt.max_solver_time_in_seconds = 0.0  # every step does the full <= 10 iterations
+    wins = None
+    if args.windows_per_gpu > 0 and args.workload == "c2" and not args.consensus:
+        # W windows per rank, all of them through ONE bsgpu_solve_batch per step (window ids rank * W + w: every window of the job is distinct)
+        W = args.windows_per_gpu
+        wins = [g]
+        if world > 1 or W > 1:
+            g.close()
+            wins = []
+            for w in range(W):
+                prw = synthetic.vio_window(n_kf=args.n_kf, n_lm=args.n_lm, seed=sharding.window_seed(20250620, rank * W + w))
+                gw = GpuSolver(local_rank); prw.load(gw); gw.finalize(); wins.append(gw)
+            g, pr = wins[0], prw
+        workload = "C5: %d independent C2 windows (%d KF x %d landmarks each), %d per GPU through one bsgpu_solve_batch per step" % (world * W, args.n_kf, args.n_lm, W)
     if args.workload == "c4":             # the global mapper passes default ceres options
         opt = g.options_default()
         opt.max_num_iterations = 10
@@ -242,6 +289,12 @@ def main():
             sm = mp_win.last_summary
             sm.num_linear_solves = its[0]
             return sm
+        if wins is not None:
+            for gw in wins: gw.reset_values()
+            sums = GpuSolver.solve_batch(wins, opt)
+            sm = sums[0]
+            sm.num_linear_solves = sum(x.num_linear_solves for x in sums)
+            return sm
         g.reset_values()
         return g.solve(opt)
 
@@ -259,14 +312,17 @@ def main():
     dt = time.perf_counter() - t0
 
     tot_it, max_dt = float(n_it), dt
+    ranks_seen, per_rank = 1, [round(n_it / dt, 2)]
     if dist is not None:
-        tot_it, max_dt = sharding.aggregate(dist, n_it, dt, device="cuda")
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        tot_it, max_dt = sharding.aggregate(dist, n_it, dt, device=dev)
+        ranks_seen, per_rank = sharding.per_rank_rates(dist, n_it, dt, device=dev)
 
     out = None
     if rank == 0:
         # ---- rooflines, all measured IN SITU: HIP events at the phase boundaries of real LM steps on the solver's stream
         # (bsgpu_profile_step); the kernel-trace average of the same kernels is in profiles/r02_*_kernel_stats.csv
-        has_vis = pr.n_factors(0) > 0 and not args.consensus
+        has_vis = pr.n_factors(0) > 0 and not args.consensus and wins is None
         roofline = roofline_mfma = kernels = phases = None
         if args.workload in ("c3", "c4"):
             # no reprojection factors: the roofline is that of the relative-pose evaluation (~990 B per factor),
@@ -362,7 +418,8 @@ def main():
                        "solver_options": solver_options,
                        "final_cost": s.final_cost, "initial_cost": s.initial_cost,
                        "device_ms_per_solve": round(1e3 * dev_s / args.steps, 3),
-                       "parallelism": "1 window per GPU, no collective" if world > 1 else "single GPU"},
+                       "parallelism": ("%d window%s per GPU, no collective" % (max(1, args.windows_per_gpu), "s" if args.windows_per_gpu > 1 else "")) if (world > 1 or wins is not None) else "single GPU",
+                       "n_ranks_seen": ranks_seen, "per_rank_lm_iterations_per_s": per_rank},
             "roofline": roofline,
         }
         if phases and not roofline_mfma:
@@ -379,7 +436,7 @@ def main():
                                 "last_change_of_a_shared_value": cons["dz"], "lm_iterations_per_window": cons["lm_iterations"],
                                 "exchange": "one all-reduce per round: a 15 x 15 information matrix, its mean and the key frame's value per directed pair of neighbours",
                                 "note": "a step is the whole consensus solve from the initial values; value counts the LM iterations of all windows and rounds"}
-        default_c2 = world == 1 and args.workload == "c2" and not args.consensus
+        default_c2 = world == 1 and args.workload == "c2" and not args.consensus and wins is None
         # ---- sustained: back-to-back solves of the same window for a few seconds (the timed region above is 0.1 s of GPU work: too
         # short for an external utilisation sampler to see; this is the same loop, longer)
         if default_c2 and args.sustained_seconds > 0:
@@ -398,13 +455,26 @@ def main():
             out["other_configs"] = {"c3": short_leg("c3", local_rank), "c4": short_leg("c4", local_rank)}
             # several windows per GPU (what an N-GPU run multiplies): 8 C2-shaped windows — config 5 folded onto one device — and 32 windows of
             # the reference's own size, each call one bsgpu_solve_batch
-            out["other_configs"]["c5_on_one_gpu"] = batch_leg(8, args.n_kf, args.n_lm, local_rank, 5, sharding.window_seed(20250620, 0),
+            seed5 = sharding.window_seed(20250620, 0)
+            out["other_configs"]["c5_on_one_gpu"] = batch_leg([synthetic.vio_window(n_kf=args.n_kf, n_lm=args.n_lm, seed=seed5 + w) for w in range(8)], local_rank, 5,
                                                               "8 independent C2 windows (BASELINE config 5) on ONE GPU, one bsgpu_solve_batch per step")
-            out["other_configs"]["reference_sized_windows"] = batch_leg(32, 20, 500, local_rank, 20, 20250700,
-                                                                        "32 independent windows of 20 key frames x 500 landmarks (the reference's own window size), one bsgpu_solve_batch per step")
+            out["other_configs"]["reference_sized_windows"] = batch_leg([synthetic.vio_window(n_kf=20, n_lm=500, seed=20250700 + w) for w in range(32)], local_rank, 20,
+                                                                        "32 independent windows of 20 key frames x 500 landmarks (the reference's own window size, vio.yaml:3,56), one bsgpu_solve_batch per step; "
+                                                                        "one_window_alone = the same window by itself (the latency case)", lone_steps=40)
+            out["other_configs"]["lidar_inertial_windows"] = batch_leg([synthetic.lio_window(n_kf=20, n_rel=300, seed=20250800 + w) for w in range(32)], local_rank, 20,
+                                                                       "32 independent lidar-inertial windows of 20 key frames x 300 scan-registration factors + IMU factors (lio.yaml, "
+                                                                       "scan_to_map_registration.cpp:74-78), one bsgpu_solve_batch per step", lone_steps=40)
+
+            def opt_pg(g):
+                o = g.options_default(); o.max_num_iterations = 10
+                return o
+            out["other_configs"]["submap_pose_graphs"] = batch_leg([synthetic.pose_graph(n_pose=200, n_loop=300, seed=20250900 + w) for w in range(16)], local_rank, 10,
+                                                                   "16 independent pose graphs of 200 poses on the dense exact path (submap_pose_graph_optimization.cpp:22-150), "
+                                                                   "one bsgpu_solve_batch per step", opt_of=opt_pg, lone_steps=20)
+            out["other_configs"]["host_cycle"] = host_cycle_leg()
         # ---- CPU baseline: the oracle on the same window (bounded samples, same options): with every usable core, and with the six
         # threads the reference's own configuration gives Ceres (beam_slam_launch/config/vio.yaml:11 num_threads: 6)
-        if world == 1 and not args.no_cpu_baseline and args.workload != "c4" and not args.consensus:   # (C4 at full size: the oracle's dense solve does not finish in bench time)
+        if world == 1 and not args.no_cpu_baseline and args.workload != "c4" and not args.consensus and wins is None:   # (C4 at full size: the oracle's dense solve does not finish in bench time)
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             from oracle import Oracle, usable_cpus
 

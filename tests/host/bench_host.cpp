@@ -1,6 +1,7 @@
 // Times one optimisation cycle of the host mirror at the size of BASELINE config C2 (200 keyframes, 50 000 landmarks,
 // ~400 000 reprojection constraints): GpuGraph::flatten (ordering + pack + C-ABI hand-over) vs the device solve.
 // Run on the GPU box:  g++ -O2 -std=c++17 tests/host/bench_host.cpp -Lbeam_slam_amd/csrc -lbsgpu ... (scripts/bench_host.sh)
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <random>
@@ -62,6 +63,7 @@ int main(int argc, char** argv) {
   for (size_t j = 0; j < lm_last_kf.size(); ++j) if (lm_last_kf[j] >= n_kf - 4) recent_lm.push_back(j);
   uint64_t next_lm = n_lm;
   int oldest = 0;
+  std::vector<double> t_opt, t_backend, t_clone, t_release, t_update;
   for (int rep = 0; rep < 6; ++rep) {
     const auto a = clk::now();
     ceres_compat::SolverSummary s;
@@ -115,8 +117,16 @@ int main(int argc, char** argv) {
     const auto c2 = clk::now();
     graph.update(tr);
     const auto c3 = clk::now();
+    if (rep > 0) { t_opt.push_back(ms(a, b)); t_backend.push_back(1e3 * bs.total_time_in_seconds); t_clone.push_back(ms(c0, c0b)); t_release.push_back(ms(c0b, c1)); t_update.push_back(ms(c2, c3)); }
     std::printf("         Graph::clone() %.1f ms + %.1f ms releasing the previous snapshot | transaction built in %.1f ms (-%zu +%zu constraints) | Graph::update() %.1f ms with the snapshot alive -> %zu constraints\n",
                 ms(c0, c0b), ms(c0b, c1), ms(c1, c2), tr.removedConstraints().size(), tr.addedConstraints().size(), ms(c2, c3), graph.numConstraints());
   }
+  // one line for bench.py (other_configs.host_cycle): medians over the cycles after the first (which pays the context's allocations)
+  auto med = [](std::vector<double> v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+  const double o = med(t_opt), be = med(t_backend), cl = med(t_clone), re = med(t_release), up = med(t_update);
+  std::printf("HOST_CYCLE_JSON {\"workload\": \"%d key frames x %d landmarks, the window slides by one key frame per cycle (-~1500 / +2001 constraints), previous snapshot alive\", "
+              "\"host_cycle_ms\": %.3f, \"optimize_ms\": %.3f, \"of_which_backend_finalize_and_solve_ms\": %.3f, \"clone_ms\": %.3f, \"release_previous_snapshot_ms\": %.3f, "
+              "\"update_ms\": %.3f, \"cycles\": %zu, \"reference\": \"fixed_lag_smoother.cpp:220,274,281,308\"}\n",
+              n_kf, n_lm, o + cl + re + up, o, be, cl, re, up, t_opt.size());
   return 0;
 }
