@@ -207,6 +207,8 @@ void launch_imu_eval(hipStream_t s, const SmallGroup& delta, const SmallGroup& p
 int small_cost_parts(const SmallGroup& g);
 void launch_small_eval(hipStream_t s, const SmallGroup& g, const double* x, const DevLoss* losses, bool with_J,
                        double* cost_part /* n doubles: per-factor cost */);
+// several groups in ONE launch (false: too many groups or a type it does not carry — the caller launches them one by one)
+bool launch_small_eval_set(hipStream_t s, const SmallGroup* groups, double* const* parts, int n_groups, const double* x, const DevLoss* losses, bool with_J);
 // what an LM step clears before its assembly (zero_tiles_multi_kernel's arguments); rides in the landmark launch as extra workgroups
 // Several windows advanced by ONE set of launches (bsgpu_batch.cpp; bs_models/src/lib/global_mapping/submap_refinement.cpp:35-115 is the
 // reference's serial loop over submaps): every kernel of the LM step has a `_batch` form whose blockIdx.y picks a window out of one of

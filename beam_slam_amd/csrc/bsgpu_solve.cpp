@@ -191,10 +191,20 @@ void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot, const Reduce
     launch_imu_eval(s, c->small[BSGPU_F_IMU_DELTA], c->small[BSGPU_F_IMU_PRIOR], x, c->d_losses, with_J,
                     cand ? c->d_small_part_cand[BSGPU_F_IMU_DELTA] : c->d_small_part[BSGPU_F_IMU_DELTA],
                     cand ? c->d_small_part_cand[BSGPU_F_IMU_PRIOR] : c->d_small_part[BSGPU_F_IMU_PRIOR]);
-  for (int t = 2; t < kNumInternal; ++t) {
-    if (imu_pair && (t == BSGPU_F_IMU_DELTA || t == BSGPU_F_IMU_PRIOR)) continue;
-    if (t == rel_t) continue;
-    if (c->small[t].n) launch_small_eval(s, c->small[t], x, c->d_losses, with_J, cand ? c->d_small_part_cand[t] : c->d_small_part[t]);
+  {
+    // the groups no fused launch carries: ONE launch for all of them when there are several (a pose graph's constraints + the prior on its
+    // first pose), else the group's own kernel
+    SmallGroup gs[kNumInternal];
+    double* ps[kNumInternal];
+    int ng = 0;
+    for (int t = 2; t < kNumInternal; ++t) {
+      if (imu_pair && (t == BSGPU_F_IMU_DELTA || t == BSGPU_F_IMU_PRIOR)) continue;
+      if (t == rel_t || !c->small[t].n) continue;
+      gs[ng] = c->small[t]; ps[ng] = cand ? c->d_small_part_cand[t] : c->d_small_part[t]; ++ng;
+    }
+    static const bool separate = getenv("BSGPU_EVAL_SEPARATE") != nullptr;
+    if (ng < 2 || separate || !launch_small_eval_set(s, gs, ps, ng, x, c->d_losses, with_J))
+      for (int i = 0; i < ng; ++i) launch_small_eval(s, gs[i], x, c->d_losses, with_J, ps[i]);
   }
   for (const auto& mc : c->marg)
     if (mc.active) launch_marg_eval(s, mc.dev, x, with_J, cand ? mc.part_cand : mc.part);

@@ -1315,14 +1315,11 @@ struct small_eval_set_Args {
   const DevLoss* losses;
 };
 template <bool WITH_J>
-__global__ __launch_bounds__(128) void small_eval_set_kernel_batch(const small_eval_set_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
-  const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
-  const small_eval_set_Args& a = bsg_A[bsg_w];
-  if ((int)blockIdx.x >= a.bsg_grid) return;
+__device__ __forceinline__ void small_eval_set_dispatch(const small_eval_set_Args& a, const int bsg_bx) {
   int gi = 0;
-  while (gi + 1 < a.n && (int)blockIdx.x >= a.first[gi + 1]) ++gi;
+  while (gi + 1 < a.n && bsg_bx >= a.first[gi + 1]) ++gi;
   const SmallGroup& g = a.g[gi];
-  const int bx = (int)blockIdx.x - a.first[gi];
+  const int bx = bsg_bx - a.first[gi];
   double* part = a.part[gi];
   switch (g.type) {
     case BSGPU_F_IMU_DELTA: { const int f = __builtin_amdgcn_readfirstlane(2 * bx + ((int)threadIdx.x >> 6)); if (f < g.n) imu_delta_body<WITH_J>(g, f, a.x, a.losses, part, threadIdx.x & 63); break; }
@@ -1337,9 +1334,20 @@ __global__ __launch_bounds__(128) void small_eval_set_kernel_batch(const small_e
     default: break;
   }
 }
-// groups[i], parts[i]: the window's groups this launch evaluates (n_groups <= kEvalSetMax; 0: a zero grid)
-bool batchargs_small_eval_set(BatchArgTable& t, const SmallGroup* groups, double* const* parts, int n_groups, const double* x, const DevLoss* losses) {
-  small_eval_set_Args a;
+template <bool WITH_J>
+__global__ __launch_bounds__(128) void small_eval_set_kernel_batch(const small_eval_set_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
+  const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
+  const small_eval_set_Args& a = bsg_A[bsg_w];
+  if ((int)blockIdx.x >= a.bsg_grid) return;
+  small_eval_set_dispatch<WITH_J>(a, (int)blockIdx.x);
+}
+// ... and for ONE window: its pose-only groups that no fused evaluation carries in one launch instead of one each (a pose graph's relative-pose
+// factors and the prior on its first pose: the prior's launch was 7.9 us of latency for one factor, on the path of every evaluation of C4)
+template <bool WITH_J>
+__global__ __launch_bounds__(128) void small_eval_set_kernel(small_eval_set_Args a) {
+  small_eval_set_dispatch<WITH_J>(a, (int)blockIdx.x);
+}
+static bool fill_small_eval_set(small_eval_set_Args& a, const SmallGroup* groups, double* const* parts, int n_groups, const double* x, const DevLoss* losses) {
   a.n = 0; a.x = x; a.losses = losses;
   int blocks = 0;
   for (int i = 0; i < n_groups; ++i) {
@@ -1352,6 +1360,22 @@ bool batchargs_small_eval_set(BatchArgTable& t, const SmallGroup* groups, double
   }
   for (int i = a.n; i <= kEvalSetMax; ++i) a.first[i] = blocks;
   a.bsg_grid = blocks;
+  return true;
+}
+// false: more groups than one launch takes, or a type the launch does not carry (the caller launches them one by one)
+bool launch_small_eval_set(hipStream_t s, const SmallGroup* groups, double* const* parts, int n_groups, const double* x, const DevLoss* losses, bool with_J) {
+  for (int i = 0; i < n_groups; ++i) if (groups[i].n && (groups[i].type == BSGPU_F_IDP_REPROJ || groups[i].type == BSGPU_F_IDP_REPROJ_UNARY)) return false;
+  small_eval_set_Args a;
+  if (!fill_small_eval_set(a, groups, parts, n_groups, x, losses)) return false;
+  if (a.bsg_grid <= 0) return true;
+  if (with_J) hipLaunchKernelGGL(small_eval_set_kernel<true>, dim3(a.bsg_grid), dim3(128), 0, s, a);
+  else hipLaunchKernelGGL(small_eval_set_kernel<false>, dim3(a.bsg_grid), dim3(128), 0, s, a);
+  return true;
+}
+// groups[i], parts[i]: the window's groups this launch evaluates (n_groups <= kEvalSetMax; 0: a zero grid)
+bool batchargs_small_eval_set(BatchArgTable& t, const SmallGroup* groups, double* const* parts, int n_groups, const double* x, const DevLoss* losses) {
+  small_eval_set_Args a;
+  if (!fill_small_eval_set(a, groups, parts, n_groups, x, losses)) return false;
   t.push(a);
   return true;
 }
