@@ -18,9 +18,10 @@
 //
 // Covered: visual(-inertial) windows with Euclidean landmarks eliminated on the landmark side; lidar-inertial windows (relative-pose
 // factors with or without extrinsics + IMU factors); pose graphs on the dense path; pose-only factors of any kind riding along (absolute
-// poses, vector priors, gravity, reprojection factors with a kept landmark); windows with constant blocks (the fixed cost is taken once,
-// before the first round).  Not covered (a thread per window, in the same call): block-sparse PCG, inverse-depth landmarks, dense
-// marginal priors, hipGraph replay, windows on another device.
+// poses, vector priors, gravity, reprojection factors with a kept landmark); a window's dense marginal prior (the state after a slide
+// with true marginalisation, fixed_lag_smoother.cpp:269-272); windows with constant blocks (the fixed cost is taken once, before the
+// first round).  Not covered (a thread per window, in the same call): block-sparse PCG, inverse-depth landmarks, more
+// than one dense prior, hipGraph replay, windows on another device.
 #include <list>
 #include <memory>
 #include <thread>
@@ -70,7 +71,12 @@ bool batch_covers(bsgpu_ctx* c, const bsgpu_options& o) {
   if (!c->finalized) return false;
   if (!(o.linear_solver_type == BSGPU_LINEAR_AUTO || o.linear_solver_type == BSGPU_LINEAR_SCHUR_CHOLESKY)) return false;
   if (!c->dense_ok || c->use_graphs || !c->d_S || !c->h_scal_dev || !c->d_reduce_counter || c->n_reduce <= 0 || c->n_pose <= 0) return false;
-  if (!c->marg.empty() || c->n_idp_lm > 0 || c->idp.n_lm > 0) return false;
+  if (c->n_idp_lm > 0 || c->idp.n_lm > 0) return false;
+  {   // at most ONE dense prior with free blocks (a window after a slide with true marginalisation), narrow enough for the one-launch evaluation
+    int n_act = 0;
+    for (const auto& mc : c->marg) if (mc.active) { ++n_act; if (mc.dev.cols > 1024 || mc.dev.nblk > 1024) return false; }
+    if (n_act > 1) return false;
+  }
   if (c->vis.n > 0) {
     if (c->vis.n_lm <= 0 || c->vis.n_seg <= 0 || c->n_upd_blocks <= 0 || c->upd_in_mcc) return false;
   } else if (!c->upd_in_mcc) return false;
@@ -117,14 +123,15 @@ struct BatchPlan {
   BatchDyn* d_dyn = nullptr;
   std::vector<void*> dev_allocs;
   // [3]: at x (rejected / first steps) | cost only at the candidate | residuals + Jacobians at the candidate, ahead of the decision
-  BatchArgTable t_eval_vis[3], t_eval_rel[3], t_eval_set[3];
+  BatchArgTable t_eval_vis[3], t_eval_rel[3], t_eval_set[3], t_eval_marg[3], t_marg_asm, t_marg_mcc;
   BatchArgTable t_lm, t_lm_tail, t_zero, t_pairs, t_asm_set, t_asm_seg, t_gn, t_chol, t_bs[4], t_backsub, t_small_mcc, t_reduce, t_accept, t_backup;
   std::vector<int> bs_form;
   size_t max_tasks = 0;
   std::vector<BatchArgTable*> tables() {
     std::vector<BatchArgTable*> v = {&t_lm, &t_lm_tail, &t_zero, &t_pairs, &t_asm_set, &t_asm_seg, &t_gn, &t_chol, &t_bs[0], &t_bs[1], &t_bs[2], &t_bs[3],
                                      &t_backsub, &t_small_mcc, &t_reduce, &t_accept, &t_backup};
-    for (int i = 0; i < 3; ++i) { v.push_back(&t_eval_vis[i]); v.push_back(&t_eval_rel[i]); v.push_back(&t_eval_set[i]); }
+    for (int i = 0; i < 3; ++i) { v.push_back(&t_eval_vis[i]); v.push_back(&t_eval_rel[i]); v.push_back(&t_eval_set[i]); v.push_back(&t_eval_marg[i]); }
+    v.push_back(&t_marg_asm); v.push_back(&t_marg_mcc);
     return v;
   }
   bool names(const bsgpu_ctx* c) const { for (const bsgpu_ctx* x : ctxs) if (x == c) return true; return false; }
@@ -182,6 +189,8 @@ bool build_plan(BatchPlan& P, bsgpu_ctx* const* ctxs, int n, const bsgpu_options
       batchargs_copy(P.t_backup, c->d_x, bk, (int64_t)c->h_x.size());
     }
     const SmallGroup none;
+    const bsgpu_ctx::MargCtx* mg = nullptr;   // the window's dense prior (batch_covers: at most one with free blocks)
+    for (const auto& mc : c->marg) if (mc.active) mg = &mc;
     const SmallGroup& dl = c->small[BSGPU_F_IMU_DELTA];
     const SmallGroup& pr = c->small[BSGPU_F_IMU_PRIOR];
     // ---- evaluation (eval_all): the point and the cost-partial arrays of the three passes
@@ -198,6 +207,7 @@ bool build_plan(BatchPlan& P, bsgpu_ctx* const* ctxs, int n, const bsgpu_options
       double* ps[kNumInternal];
       for (int i = 0; i < sh.n_set; ++i) { gs[i] = c->small[sh.set_t[i]]; ps[i] = part[sh.set_t[i]]; }
       if (!batchargs_small_eval_set(P.t_eval_set[v], gs, ps, sh.n_set, xs[v], c->d_losses)) return false;
+      if (!batchargs_marg_eval(P.t_eval_marg[v], mg ? &mg->dev : nullptr, xs[v], mg ? (cand ? mg->part_cand : mg->part) : nullptr)) return false;
     }
     // ---- assembly (assemble())
     ZeroStep zs;
@@ -218,6 +228,8 @@ bool build_plan(BatchPlan& P, bsgpu_ctx* const* ctxs, int n, const bsgpu_options
                                       c->d_hdiag, c->d_dpos)) return false;
     batchargs_small_assemble_seg(P.t_asm_seg, c->d_small_groups, c->n_sa_seg, c->d_sa_seg_start, c->d_sa_seg_ra, c->d_sa_seg_rb, c->d_sa_contrib, c->d_S, c->npad, c->plan.rhs_row,
                                  c->d_grad, c->d_hdiag, c->d_dpos, units2 > 0 ? &set2 : nullptr, units2, c->n_asm_grp, c->d_asm_grp, c->d_asm_gfac);
+    batchargs_marg_assemble(P.t_marg_asm, mg ? &mg->dev : nullptr, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_dpos);
+    batchargs_marg_mcc(P.t_marg_mcc, mg ? &mg->dev : nullptr, c->d_delta, mg ? mg->part_mcc : nullptr);
     batchargs_grad_norms_pose_diag(P.t_gn, c->nb, c->d_blk_xoff, c->d_blk_toff, c->d_blk_size, c->d_blk_manifold, c->d_x, c->d_grad, c->d_gpart, c->n_pose, c->d_S, c->npad,
                                    c->d_hdiag, o.jacobi_scaling, o.min_lm_diagonal, o.max_lm_diagonal, c->d_scale, c->d_dcl, c->npad, c->d_inat);
     // ---- linear solve: the task list WITHOUT the LM-diagonal / rider tasks (a batch is bound by the number of its LDS-heavy, one-per-CU
@@ -280,6 +292,7 @@ void evals(BatchPlan& P, int v, const BatchDyn* dd, int list, int n, bool with_J
   launch_visual_imu_eval_batch(P.stream, P.t_eval_vis[v], dd, list, n, with_J);
   launch_relpose_imu_eval_batch(P.stream, P.t_eval_rel[v], dd, list, n, with_J);
   launch_small_eval_set_batch(P.stream, P.t_eval_set[v], dd, list, n, with_J);
+  launch_marg_eval_batch(P.stream, P.t_eval_marg[v], dd, list, n, with_J);
 }
 
 // one set of launches for the steps the windows of `L` requested; `act`: indices into L of the windows still iterating
@@ -318,6 +331,7 @@ void enqueue_round(BatchPlan& P, std::vector<BatchWin>& L, const std::vector<int
   launch_pairs_batch(s, P.t_pairs, dd, BL_ALL, d.n[BL_ALL]);
   launch_small_assemble_set_batch(s, P.t_asm_set, dd, BL_ALL, d.n[BL_ALL]);
   launch_small_assemble_seg_batch(s, P.t_asm_seg, dd, BL_ALL, d.n[BL_ALL]);
+  launch_marg_assemble_batch(s, P.t_marg_asm, dd, BL_ALL, d.n[BL_ALL]);
   launch_grad_norms_pose_diag_batch(s, P.t_gn, dd, BL_DIAG, d.n[BL_DIAG]);
   if (d.n[BL_FULL] > 0) {
     launch_chol_fused_batch(s, P.t_chol, dd, BL_FULL, d.n[BL_FULL]);
@@ -325,6 +339,7 @@ void enqueue_round(BatchPlan& P, std::vector<BatchWin>& L, const std::vector<int
     launch_backsolve_batch(s, P.t_bs, dd, nf);
     launch_backsub_mcc_batch(s, P.t_backsub, dd, BL_FULL, d.n[BL_FULL]);
     launch_small_mcc_batch(s, P.t_small_mcc, dd, BL_FULL, d.n[BL_FULL]);
+    launch_marg_mcc_batch(s, P.t_marg_mcc, dd, BL_FULL, d.n[BL_FULL]);
     evals(P, 1, dd, BL_FULL, d.n[BL_FULL], false);
   }
   launch_final_reduce_batch(s, P.t_reduce, dd, BL_ALL, d.n[BL_ALL]);

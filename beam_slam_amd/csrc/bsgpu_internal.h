@@ -324,6 +324,14 @@ bool batchargs_small_mcc(BatchArgTable& t, const SmallGroup* groups, double* con
 void launch_small_mcc_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n);
 void batchargs_zero_tiles_multi(BatchArgTable& t, const ZeroStep* zs);
 void launch_zero_tiles_multi_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n);
+// ... a window's dense prior (k_marg.hip)
+struct MargDev;
+bool batchargs_marg_eval(BatchArgTable& t, const MargDev* m, const double* x, double* cost_part);
+void launch_marg_eval_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n, bool with_J);
+void batchargs_marg_assemble(BatchArgTable& t, const MargDev* m, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm);
+void launch_marg_assemble_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n);
+void batchargs_marg_mcc(BatchArgTable& t, const MargDev* m, const double* delta_tan, double* part);
+void launch_marg_mcc_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n);
 int batchargs_backsolve(BatchArgTable* tabs, const DensePlan& P, const DenseDev& D, double* y, const int* iperm, int n_pose, double* y_tan, double* delta);
 void launch_backsolve_batch(hipStream_t s, const BatchArgTable* tabs, const BatchDyn* dyn, const int* n_in_form);
 void launch_landmark(hipStream_t s, const Visual& v, int n_pose, const double* radius_ptr, int compute_scale,

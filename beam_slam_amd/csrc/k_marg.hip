@@ -38,10 +38,10 @@ __global__ void marg_delta_kernel(MargDev m, const double* __restrict__ x) {
   if (i < m.nblk) marg_delta_block(m, i, x, m.delta, m.D);
 }
 template <bool WITH_J, bool IN_LDS>
-__global__ __launch_bounds__(64) void marg_eval_kernel(MargDev m, const double* __restrict__ x, double* __restrict__ cost_part) {
+__device__ __forceinline__ void marg_eval_kernel_body(const int bsg_bx, const MargDev& m, const double* __restrict__ x, double* __restrict__ cost_part) {
   __shared__ double s_delta[IN_LDS ? kMargColsLds : 1];
   __shared__ double s_D[IN_LDS ? kMargColsLds : 1];
-  const int row = blockIdx.x, lane = threadIdx.x;
+  const int row = bsg_bx, lane = threadIdx.x;
   const double* delta = m.delta;
   const double* D = m.D;
   if (IN_LDS) {
@@ -70,6 +70,10 @@ __global__ __launch_bounds__(64) void marg_eval_kernel(MargDev m, const double* 
     Jr[k] = v;
   }
 }
+template <bool WITH_J, bool IN_LDS>
+__global__ __launch_bounds__(64) void marg_eval_kernel(MargDev m, const double* __restrict__ x, double* __restrict__ cost_part) {
+  marg_eval_kernel_body<WITH_J, IN_LDS>((int)blockIdx.x, m, x, cost_part);
+}
 
 // gradient J^T r (also into the rhs row) and diag(J^T J): the workgroups of row blockIdx.y == gridDim.y - 1 of the assembly launch,
 // sixteen columns each, the rows split over the sixteen thread rows
@@ -95,12 +99,12 @@ BSG_DEV void marg_grad_block(const MargDev& m, int a0, double* __restrict__ S, i
 
 // S += J^T J (16 x 16 output tile per workgroup, rows staged through LDS), FP64 atomics because the blocks of a
 // marginal factor are scattered over the reduced system
-__global__ __launch_bounds__(256) void marg_assemble_kernel(MargDev m, double* __restrict__ S, int ld, const int* __restrict__ perm, int rhs_row,
-                                                            double* __restrict__ grad, double* __restrict__ hdiag) {
+__device__ __forceinline__ void marg_assemble_kernel_body(const int bsg_bx, const int bsg_by, const int bsg_gy, const MargDev& m, double* __restrict__ S, int ld,
+                                                          const int* __restrict__ perm, int rhs_row, double* __restrict__ grad, double* __restrict__ hdiag) {
   __shared__ double sA[16][17], sB[16][17];
-  if (blockIdx.y == gridDim.y - 1) { marg_grad_block(m, blockIdx.x * 16, S, ld, rhs_row, grad, hdiag, perm, sA, sB); return; }
+  if (bsg_by == bsg_gy - 1) { marg_grad_block(m, bsg_bx * 16, S, ld, rhs_row, grad, hdiag, perm, sA, sB); return; }
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int a0 = blockIdx.y * 16, b0 = blockIdx.x * 16;
+  const int a0 = bsg_by * 16, b0 = bsg_bx * 16;
   double acc = 0.0;
   for (int k0 = 0; k0 < m.rows; k0 += 16) {
     const int k = k0 + ty;
@@ -117,15 +121,22 @@ __global__ __launch_bounds__(256) void marg_assemble_kernel(MargDev m, double* _
   if (ta < 0 || tb < 0) return;
   atomicAdd(&S[(size_t)perm[ta] * ld + perm[tb]], acc);
 }
+__global__ __launch_bounds__(256) void marg_assemble_kernel(MargDev m, double* __restrict__ S, int ld, const int* __restrict__ perm, int rhs_row,
+                                                            double* __restrict__ grad, double* __restrict__ hdiag) {
+  marg_assemble_kernel_body((int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y, m, S, ld, perm, rhs_row, grad, hdiag);
+}
 
 // one wave per row: model-cost-change term -(J d)(r + J d / 2)
-__global__ __launch_bounds__(64) void marg_mcc_kernel(MargDev m, const double* __restrict__ delta_tan, double* __restrict__ part) {
-  const int row = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void marg_mcc_kernel_body(const int bsg_bx, const MargDev& m, const double* __restrict__ delta_tan, double* __restrict__ part) {
+  const int row = bsg_bx, lane = threadIdx.x;
   const double* Jr = m.J + (size_t)row * m.cols;
   double jv = 0.0;
   for (int k = lane; k < m.cols; k += 64) { const int t = m.col_t[k]; if (t >= 0) jv = fma(Jr[k], delta_tan[t], jv); }
   jv = wave_sum(jv);
   if (lane == 0) part[row] = -jv * (m.r[row] + 0.5 * jv);
+}
+__global__ __launch_bounds__(64) void marg_mcc_kernel(MargDev m, const double* __restrict__ delta_tan, double* __restrict__ part) {
+  marg_mcc_kernel_body((int)blockIdx.x, m, delta_tan, part);
 }
 
 void launch_marg_eval(hipStream_t s, const MargDev& m, const double* x, bool with_J, double* cost_part) {
@@ -144,6 +155,64 @@ void launch_marg_assemble(hipStream_t s, const MargDev& m, double* S, int ld, in
 }
 void launch_marg_mcc(hipStream_t s, const MargDev& m, const double* delta_tan, double* part) {
   hipLaunchKernelGGL(marg_mcc_kernel, dim3(m.rows), dim3(64), 0, s, m, delta_tan, part);
+}
+
+// ---- the same launches over several windows (bsgpu_batch.cpp): a window after a slide with true marginalisation (fixed_lag_smoother.cpp:269-272)
+// carries ONE dense prior; entry w = what its lone launches pass (a zero grid: the window has none).  The assembly's 2-d grid is flattened.
+struct marg_eval_Args { int bsg_grid; MargDev m; const double* x; double* cost_part; };
+template <bool WITH_J>
+__global__ __launch_bounds__(64) void marg_eval_kernel_batch(const marg_eval_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
+  const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
+  const marg_eval_Args& a = bsg_A[bsg_w];
+  if ((int)blockIdx.x >= a.bsg_grid) return;
+  marg_eval_kernel_body<WITH_J, true>((int)blockIdx.x, a.m, a.x, a.cost_part);
+}
+bool batchargs_marg_eval(BatchArgTable& t, const MargDev* m, const double* x, double* cost_part) {
+  marg_eval_Args a;
+  a.m = m ? *m : MargDev(); a.x = x; a.cost_part = cost_part; a.bsg_grid = m ? m->rows : 0;
+  if (m && !(m->cols <= kMargColsLds && m->nblk <= kMargColsLds)) return false;   // (wider priors: the two-launch form, not batched)
+  t.push(a);
+  return true;
+}
+void launch_marg_eval_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n, bool with_J) {
+  if (n <= 0 || t.max_grid <= 0) return;
+  const auto* A = static_cast<const marg_eval_Args*>(t.dev);
+  if (with_J) hipLaunchKernelGGL(marg_eval_kernel_batch<true>, dim3(t.max_grid, n), dim3(64), 0, s, A, dyn, list);
+  else hipLaunchKernelGGL(marg_eval_kernel_batch<false>, dim3(t.max_grid, n), dim3(64), 0, s, A, dyn, list);
+}
+struct marg_assemble_Args { int bsg_grid; int g; MargDev m; double* S; int ld; const int* perm; int rhs_row; double* grad; double* hdiag; };
+__global__ __launch_bounds__(256) void marg_assemble_kernel_batch(const marg_assemble_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
+  const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
+  const marg_assemble_Args& a = bsg_A[bsg_w];
+  if ((int)blockIdx.x >= a.bsg_grid) return;
+  marg_assemble_kernel_body((int)blockIdx.x % a.g, (int)blockIdx.x / a.g, a.g + 1, a.m, a.S, a.ld, a.perm, a.rhs_row, a.grad, a.hdiag);
+}
+void batchargs_marg_assemble(BatchArgTable& t, const MargDev* m, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm) {
+  marg_assemble_Args a;
+  a.m = m ? *m : MargDev(); a.S = S; a.ld = ld; a.perm = perm; a.rhs_row = rhs_row; a.grad = grad; a.hdiag = hdiag;
+  a.g = m ? (m->cols + 15) / 16 : 1;
+  a.bsg_grid = m ? a.g * (a.g + 1) : 0;
+  t.push(a);
+}
+void launch_marg_assemble_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n) {
+  if (n <= 0 || t.max_grid <= 0) return;
+  hipLaunchKernelGGL(marg_assemble_kernel_batch, dim3(t.max_grid, n), dim3(256), 0, s, static_cast<const marg_assemble_Args*>(t.dev), dyn, list);
+}
+struct marg_mcc_Args { int bsg_grid; MargDev m; const double* delta_tan; double* part; };
+__global__ __launch_bounds__(64) void marg_mcc_kernel_batch(const marg_mcc_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
+  const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
+  const marg_mcc_Args& a = bsg_A[bsg_w];
+  if ((int)blockIdx.x >= a.bsg_grid) return;
+  marg_mcc_kernel_body((int)blockIdx.x, a.m, a.delta_tan, a.part);
+}
+void batchargs_marg_mcc(BatchArgTable& t, const MargDev* m, const double* delta_tan, double* part) {
+  marg_mcc_Args a;
+  a.m = m ? *m : MargDev(); a.delta_tan = delta_tan; a.part = part; a.bsg_grid = m ? m->rows : 0;
+  t.push(a);
+}
+void launch_marg_mcc_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n) {
+  if (n <= 0 || t.max_grid <= 0) return;
+  hipLaunchKernelGGL(marg_mcc_kernel_batch, dim3(t.max_grid, n), dim3(64), 0, s, static_cast<const marg_mcc_Args*>(t.dev), dyn, list);
 }
 
 }  // namespace bsg
