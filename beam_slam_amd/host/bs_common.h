@@ -110,9 +110,11 @@ inline Mat3 so3RightJacobian(const Vec3& w) {  // [EXT] beam::RightJacobianOfSO3
 // ---------------------------------------------------------------------------------------------------
 // variables
 // ---------------------------------------------------------------------------------------------------
+// (only for classes whose members are plain values — uuid, stamp, ids, a fixed array of doubles: destroyIsNoop() says so)
 #define BS_CLONE_IN_PLACE(CLASS)                                          \
   size_t cloneSize() const override { return sizeof(CLASS); }            \
-  fuse_core::Variable* cloneAt(void* mem) const override { return new (mem) CLASS(*this); }
+  fuse_core::Variable* cloneAt(void* mem) const override { return new (mem) CLASS(*this); } \
+  bool destroyIsNoop() const override { return true; }
 namespace fuse_variables {
 template <int N> class FixedSizeVariable : public fuse_core::Variable {
  public:

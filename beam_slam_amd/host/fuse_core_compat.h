@@ -127,6 +127,9 @@ class Variable {
   // constructed at `mem` (suitably aligned, at least cloneSize() bytes).  0 / nullptr: the type only offers clone().
   virtual size_t cloneSize() const { return 0; }
   virtual Variable* cloneAt(void* mem) const { (void)mem; return nullptr; }
+  // a copy made by cloneAt() holds nothing that a destructor must release (its members are plain values): the slab such copies live in may
+  // drop them without 51 000 virtual destructor calls
+  virtual bool destroyIsNoop() const { return false; }
   // ordering keys for the deterministic block index
   virtual bool isStamped() const { return false; }
   virtual Time stamp() const { return Time(); }

@@ -72,6 +72,22 @@ class CowIndex {
     b.insert(std::lower_bound(b.begin(), b.end(), k, [](const Item& a, const fuse_core::UUID& x) { return a.key < x; }), Item{k, v});
     ++size_;
   }
+  // one traversal for "is it there? if not, put it in": false (nothing changed — no bucket copied) if the key is present
+  bool insertIfAbsent(const fuse_core::UUID& k, int32_t v) {
+    const size_t bi = bucketOf(k);
+    const auto& b0 = buckets_[bi];
+    size_t pos = 0;
+    if (b0) {
+      auto it = std::lower_bound(b0->begin(), b0->end(), k, [](const Item& a, const fuse_core::UUID& x) { return a.key < x; });
+      if (it != b0->end() && it->key == k) return false;
+      pos = (size_t)(it - b0->begin());
+    }
+    auto& b = mut(bi);
+    b.insert(b.begin() + pos, Item{k, v});
+    ++size_;
+    return true;
+  }
+  void prefetch(const fuse_core::UUID& k) const { const auto& b = buckets_[bucketOf(k)]; if (b) __builtin_prefetch(b->data(), 0, 1); }
   void erase(const fuse_core::UUID& k) {
     auto& b = mut(bucketOf(k));
     auto it = std::lower_bound(b.begin(), b.end(), k, [](const Item& a, const fuse_core::UUID& x) { return a.key < x; });
@@ -90,6 +106,57 @@ class CowIndex {
   }
   std::array<std::shared_ptr<std::vector<Item>>, kBuckets> buckets_;
   size_t size_ = 0;
+};
+// uuid -> slot for the CONSTRAINTS: one flat open-addressing table, owned by one graph and never shared.  A clone() does not copy it — a
+// snapshot handed to the publishers reads variables and walks constraints, it does not look constraints up by uuid — and builds its own
+// from the constraint slots the first time it needs one.  (Behind copy-on-write buckets like the variables' index, every constraint added
+// or removed with a snapshot alive copied a bucket: two allocations and ~600 bytes, 3 500 times per cycle at C2 — a third of Graph::update().)
+class FlatIndex {
+ public:
+  int32_t find(const fuse_core::UUID& k) const {
+    if (t_.empty()) return -1;
+    for (size_t i = h(k) & mask_;; i = (i + 1) & mask_) {
+      if (t_[i].val < 0) return -1;
+      if (t_[i].key == k) return t_[i].val;
+    }
+  }
+  bool insertIfAbsent(const fuse_core::UUID& k, int32_t v) {
+    if ((n_ + 1) * 10 > t_.size() * 6) grow();
+    for (size_t i = h(k) & mask_;; i = (i + 1) & mask_) {
+      if (t_[i].val < 0) { t_[i].key = k; t_[i].val = v; ++n_; return true; }
+      if (t_[i].key == k) return false;
+    }
+  }
+  void erase(const fuse_core::UUID& k) {
+    if (t_.empty()) return;
+    size_t i = h(k) & mask_;
+    for (;; i = (i + 1) & mask_) { if (t_[i].val < 0) return; if (t_[i].key == k) break; }
+    // backward-shift deletion: no tombstones, look-ups stay short however long the window slides
+    for (size_t j = (i + 1) & mask_;; j = (j + 1) & mask_) {
+      if (t_[j].val < 0) break;
+      const size_t home = h(t_[j].key) & mask_;
+      if (((j - home) & mask_) >= ((j - i) & mask_)) { t_[i] = t_[j]; i = j; }
+    }
+    t_[i].val = -1;
+    --n_;
+  }
+  void prefetch(const fuse_core::UUID& k) const { if (!t_.empty()) __builtin_prefetch(&t_[h(k) & mask_], 0, 1); }
+  size_t size() const { return n_; }
+  void clear() { t_.clear(); n_ = 0; mask_ = 0; }
+  void reserve(size_t n) { size_t c = 1024; while (c * 6 < n * 10) c <<= 1; if (c > t_.size()) rehash(c); }
+ private:
+  struct Slot { fuse_core::UUID key; int32_t val = -1; };
+  static size_t h(const fuse_core::UUID& k) { return (size_t)((k.hi ^ (k.lo * 0x9e3779b97f4a7c15ull)) >> 13); }
+  void grow() { rehash(t_.empty() ? 1024 : t_.size() * 2); }
+  void rehash(size_t cap) {
+    std::vector<Slot> old;
+    old.swap(t_);
+    t_.assign(cap, Slot());
+    mask_ = cap - 1; n_ = 0;
+    for (const Slot& s : old) if (s.val >= 0) insertIfAbsent(s.key, s.val);
+  }
+  std::vector<Slot> t_;
+  size_t n_ = 0, mask_ = 0;
 };
 // slot -> T in chunks behind shared_ptrs, copy-on-write per chunk (same idea as CowIndex)
 template <class T>
@@ -138,10 +205,10 @@ class GpuGraph {
 
   // ---- fuse_core::Graph surface used by the reference ---------------------------------
   void clear() {
-    vslots_.clear(); vfree_.clear(); vindex_.clear(); vmeta_.clear(); vdata_.clear(); ordered_.clear(); on_hold_.clear();
+    vslots_.clear(); slabs_.clear(); vfree_.clear(); vindex_.clear(); vmeta_.clear(); vdata_.clear(); ordered_.clear(); on_hold_.clear();
     for (auto& c : cown_) if (c) retire(std::move(c));
     cown_.clear();
-    cptr_.clear(); ctype_.clear(); crow_.clear(); cfree_.clear(); cindex_.clear();
+    cptr_.clear(); ctype_.clear(); crow_.clear(); cfree_.clear(); cindex_.clear(); cindex_valid_ = true; n_constraints_ = 0;
     for (int ty = 0; ty < BSGPU_F_NUM_TYPES; ++ty) {
       if (undo_[ty]) { std::lock_guard<std::mutex> lk(tables_[ty]->mu); undo_[ty]->detached = true; }
       undo_[ty].reset(); tables_[ty].reset();
@@ -151,7 +218,7 @@ class GpuGraph {
     conn_.clear(); connectivity_valid_ = true;
   }
   bool variableExists(const fuse_core::UUID& u) const { return vindex_.find(u) >= 0; }
-  bool constraintExists(const fuse_core::UUID& u) const { return cindex_.find(u) >= 0; }
+  bool constraintExists(const fuse_core::UUID& u) const { ensureConstraintIndex(); return cindex_.find(u) >= 0; }
   const fuse_core::Variable& getVariable(const fuse_core::UUID& u) const {
     const int32_t s = vindex_.find(u);
     if (s < 0) throw std::out_of_range("variable not in graph");
@@ -166,7 +233,7 @@ class GpuGraph {
   }
   std::vector<const fuse_core::Constraint*> getConstraints() const {
     std::vector<const fuse_core::Constraint*> v;
-    v.reserve(cindex_.size());
+    v.reserve(n_constraints_);
     for (size_t i = 0; i < cptr_.size(); ++i) if (ctype_[i] != kFree) v.push_back(cptr_[i]);
     return v;
   }
@@ -208,36 +275,44 @@ class GpuGraph {
     return true;
   }
   bool addConstraint(fuse_core::Constraint::SharedPtr c) {
-    if (cindex_.find(c->uuid()) >= 0) return false;
-    std::vector<int32_t> vars;
+    // (the slot is chosen first so that the uuid index is walked ONCE — "present?" and the insertion are one look-up; a new constraint's
+    //  bucket is cold, and with a snapshot alive the insertion copies it)
+    ensureConstraintIndex();
+    const bool reuse = !cfree_.empty();
+    const int32_t cs_next = reuse ? cfree_.back() : (int32_t)cptr_.size();
+    if (!cindex_.insertIfAbsent(c->uuid(), cs_next)) return false;
+    ++n_constraints_;
+    std::vector<int32_t>& vars = vars_scratch_;
+    vars.clear();
     vars.reserve(c->variables().size());
     for (const auto& u : c->variables()) {   // resolve the variables once: flatten() then needs no UUID lookup per slot
       const int32_t s = vindex_.find(u);
-      if (s < 0) throw std::logic_error("addConstraint: constraint " + c->type() + " uses a variable that is not in the graph");
+      if (s < 0) { cindex_.erase(c->uuid()); --n_constraints_; throw std::logic_error("addConstraint: constraint " + c->type() + " uses a variable that is not in the graph"); }
       vars.push_back(s);
     }
-    int32_t cs;
-    if (!cfree_.empty()) { cs = cfree_.back(); cfree_.pop_back(); }
-    else { cs = (int32_t)cptr_.size(); cptr_.push_back(nullptr); ctype_.push_back(kFree); crow_.push_back(0); }
+    const int32_t cs = cs_next;
+    if (reuse) cfree_.pop_back();
+    else { cptr_.push_back(nullptr); ctype_.push_back(kFree); crow_.push_back(0); }
     if (cown_.size() < cptr_.size()) cown_.resize(cptr_.size());
     ensureConnectivity();
     // (a constraint is new to every list; only a variable it names twice must not get it twice — checked within `vars`, not by
     //  scanning the variable's list: a keyframe pose carries thousands of constraints)
     for (size_t i = 0; i < vars.size(); ++i)
       if (std::find(vars.begin(), vars.begin() + i, vars[i]) == vars.begin() + i) conn_[vars[i]].push_back(cs);
-    cindex_.insert(c->uuid(), cs);
     appendRow(*c, cs, vars);
     cptr_.mut(cs) = c.get();
     cown_[cs] = std::move(c);
     return true;
   }
   bool removeConstraint(const fuse_core::UUID& u) {
+    ensureConstraintIndex();
     const int32_t cs = cindex_.find(u);
     if (cs < 0) return false;
     ensureConnectivity();
     forEachVariableOf(cs, [&](int32_t s) { auto& l = conn_[s]; auto it = std::find(l.begin(), l.end(), cs); if (it != l.end()) { *it = l.back(); l.pop_back(); } });
     removeRow(cs);
     cindex_.erase(u);
+    --n_constraints_;
     cptr_.mut(cs) = nullptr;
     if ((size_t)cs < cown_.size() && cown_[cs]) retire(std::move(cown_[cs]));
     ctype_[cs] = kFree;
@@ -255,13 +330,55 @@ class GpuGraph {
       std::fprintf(stderr, "[GpuGraph::update] %-24s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
       t_prev = now;
     };
-    for (const auto& u : t.removedConstraints()) removeConstraint(u);
+    // Removals as a batch: a sliding window drops its oldest key frame's ~1 500 constraints at once, and a key frame's pose blocks carry
+    // thousands — one std::find per constraint in those lists was most of Graph::update().  The constraints are marked, and every variable
+    // that loses some filters its list ONCE.
+    {
+      std::vector<int32_t> gone, touched;
+      gone.reserve(t.removedConstraints().size());
+      ensureConstraintIndex();
+      for (const auto& u : t.removedConstraints()) { const int32_t cs = cindex_.find(u); if (cs >= 0) gone.push_back(cs); }
+      if (!gone.empty()) {
+        ensureConnectivity();
+        cmark_.assign(cptr_.size(), 0);
+        if (vmark_.size() < vslots_.size()) vmark_.resize(vslots_.size(), 0);
+        for (int32_t cs : gone) {
+          if (cmark_[cs]) continue;   // (named twice in the transaction)
+          cmark_[cs] = 1;
+          forEachVariableOf(cs, [&](int32_t s) { if (!vmark_[s]) { vmark_[s] = 1; touched.push_back(s); } });
+        }
+        for (int32_t s : touched) {
+          auto& l = conn_[s];
+          l.erase(std::remove_if(l.begin(), l.end(), [&](int32_t cs) { return cmark_[cs] != 0; }), l.end());
+          vmark_[s] = 0;
+        }
+        for (int32_t cs : gone) {
+          if (!cmark_[cs]) continue;
+          cmark_[cs] = 0;
+          removeRow(cs);
+          cindex_.erase(cptr_[cs]->uuid());
+          --n_constraints_;
+          cptr_.mut(cs) = nullptr;
+          if ((size_t)cs < cown_.size() && cown_[cs]) retire(std::move(cown_[cs]));
+          ctype_[cs] = kFree;
+          cfree_.push_back(cs);
+        }
+      }
+    }
     lap("remove constraints");
     for (const auto& u : t.removedVariables()) removeVariable(u);
     lap("remove variables");
     for (const auto& v : t.addedVariables()) addVariable(v->clone());
     lap("add variables");
-    for (const auto& c : t.addedConstraints()) addConstraint(c->clone());
+    {
+      // (the uuid-index buckets of the constraints to come are requested ahead: each is a cold line behind two pointers)
+      const auto& add = t.addedConstraints();
+      constexpr size_t kAhead = 8;
+      for (size_t i = 0; i < add.size(); ++i) {
+        if (i + kAhead < add.size()) cindex_.prefetch(add[i + kAhead]->uuid());
+        addConstraint(add[i]->clone());
+      }
+    }
     lap("add constraints");
   }
   // Graph::clone() (fixed_lag_smoother.cpp:308 does this every cycle for the publishers).  Variables are deep-copied (the
@@ -303,24 +420,28 @@ class GpuGraph {
           if (i + 16 < hi) __builtin_prefetch(vslots_[i + 16].get(), 0, 1);
           if (!vslots_[i]) continue;
           fuse_core::Variable* o = off[i + 1] > off[i] ? vslots_[i]->cloneAt(mem + off[i]) : nullptr;
-          if (o) slab->objects[i] = o;
+          if (o) { slab->objects[i] = o; if (!o->destroyIsNoop()) slab->needs_destroy = true; }
           else gp->vslots_[i] = vslots_[i]->clone();
         }
       };
       (void)live;
       copy_range(0, n);   // (four threads were tried: 1.7 ms against 1.3 — the misses overlap well enough under one thread's prefetches)
-      // (the handles from ONE thread: they all count on the slab's control block)
+      // The copy's handles to the slab's objects own NOTHING (aliasing shared_ptrs with an empty owner: no control block, no atomic
+      // count — 51 000 increments here and as many decrements when the snapshot is dropped were a third of clone() + release); the slab
+      // itself is kept by the graph (slabs_), so the objects live exactly as long as the graph that hands out references to them.
       for (size_t i = 0; i < n; ++i) {
-        if (slab->objects[i]) g->vslots_[i] = fuse_core::Variable::SharedPtr(slab, slab->objects[i]);
+        if (slab->objects[i]) g->vslots_[i] = fuse_core::Variable::SharedPtr(std::shared_ptr<void>(), slab->objects[i]);
         if (g->vslots_[i]) g->vdata_[i] = g->vslots_[i]->data();
       }
+      g->slabs_.push_back(std::move(slab));
     }
     g->vfree_ = vfree_; g->vindex_ = vindex_; g->vmeta_ = vmeta_; g->ordered_ = ordered_; g->on_hold_ = on_hold_;
     lap("variables");
     // the constraints are shared as RAW pointers (a chunk is copied with memcpy when either side writes to it — behind shared_ptrs
     // every such copy was 1 024 atomic increments, 400 000 per cycle at C2, and as many decrements when the snapshot was dropped);
     // what keeps them alive for the snapshot is the GENERATION it holds (see Generation below)
-    g->cptr_ = cptr_; g->ctype_ = ctype_; g->crow_ = crow_; g->cfree_ = cfree_; g->cindex_ = cindex_;
+    g->cptr_ = cptr_; g->ctype_ = ctype_; g->crow_ = crow_; g->cfree_ = cfree_;
+    g->cindex_valid_ = false; g->n_constraints_ = n_constraints_;   // (uuid -> constraint slot of the copy: built on first use, like its connectivity)
     g->keep_ = keep_;                 // (what this graph itself inherited)
     g->keep_.push_back(gen_);         // everything this graph owns now or retires from now on
     {
@@ -349,7 +470,7 @@ class GpuGraph {
     return g;
   }
   size_t numVariables() const { return vindex_.size(); }
-  size_t numConstraints() const { return cindex_.size(); }
+  size_t numConstraints() const { return n_constraints_; }
   void print(std::ostream& s) const {
     s << "GpuGraph\n  variables:\n";
     for (const auto* v : getVariables()) { s << "   - "; v->print(s); s << "\n"; }
@@ -567,7 +688,8 @@ class GpuGraph {
   // ---- variables: graph-local slots (stable while the variable is in the graph, kept by clone()) ---------------------
   struct VariableSlab {   // the variables of a clone(): one block, released (destructors first) with the last variable that lives in it
     explicit VariableSlab(size_t bytes) : mem(static_cast<unsigned char*>(::operator new(bytes ? bytes : 1, std::align_val_t(16)))) {}
-    ~VariableSlab() { for (fuse_core::Variable* o : objects) if (o) o->~Variable(); }
+    ~VariableSlab() { if (needs_destroy) for (fuse_core::Variable* o : objects) if (o) o->~Variable(); }
+    bool needs_destroy = false;   // some object's destructor does something (Variable::destroyIsNoop)
     struct Free { void operator()(unsigned char* p) const { ::operator delete(p, std::align_val_t(16)); } };
     std::unique_ptr<unsigned char, Free> mem;
     std::vector<fuse_core::Variable*> objects;
@@ -575,7 +697,8 @@ class GpuGraph {
     VariableSlab& operator=(const VariableSlab&) = delete;
   };
   struct VMeta { uint8_t size, manifold, hold_constant; uint16_t clone_size; };   // clone_size: Variable::cloneSize() (0: clone() only)
-  std::vector<fuse_core::Variable::SharedPtr> vslots_;   // slot -> variable (null: free slot)
+  std::vector<fuse_core::Variable::SharedPtr> vslots_;   // slot -> variable (null: free slot); a clone()'s initial ones are non-owning handles into slabs_
+  std::vector<std::shared_ptr<VariableSlab>> slabs_;     // what a clone()'s variables live in (declared after vslots_: destroyed before... the handles own nothing)
   std::vector<VMeta> vmeta_;                              // slot -> what flatten() needs without touching the object
   std::vector<double*> vdata_;                            // slot -> Variable::data() (stable while the variable is in the graph)
   std::vector<int32_t> vfree_;
@@ -682,7 +805,16 @@ class GpuGraph {
   std::vector<int32_t> ctype_;                                  // constraint slot -> factor type | kFree | kMarginal | kUnpacked
   std::vector<uint32_t> crow_;                                  // constraint slot -> row in its type's table
   std::vector<int32_t> cfree_;
-  detail::CowIndex cindex_;                                     // uuid -> constraint slot
+  mutable detail::FlatIndex cindex_;                            // uuid -> constraint slot (a clone's: built on first use)
+  mutable bool cindex_valid_ = true;
+  size_t n_constraints_ = 0;
+  void ensureConstraintIndex() const {
+    if (cindex_valid_) return;
+    cindex_.clear();
+    cindex_.reserve(n_constraints_);
+    for (size_t cs = 0; cs < ctype_.size(); ++cs) if (ctype_[cs] != kFree) cindex_.insertIfAbsent(cptr_[cs]->uuid(), (int32_t)cs);
+    cindex_valid_ = true;
+  }
   mutable std::shared_ptr<TypeTable> tables_[BSGPU_F_NUM_TYPES];        // owned — or, while undo_[ty] is set, another graph's table to be read through the log
   mutable std::shared_ptr<TableUndo> undo_[BSGPU_F_NUM_TYPES];          // (a snapshot that has not needed its tables yet)
   std::vector<bsgpu_camera> cameras_;
@@ -697,7 +829,8 @@ class GpuGraph {
     if (dirty_[ty].size() > rows / 2 + 4096) { synced_[ty] = false; dirty_[ty].clear(); }   // (cheaper to re-read the table)
   }
   fuse_core::FactorTables pack_scratch_;
-  std::vector<int32_t> slot_scratch_;
+  std::vector<int32_t> slot_scratch_, vars_scratch_;
+  std::vector<uint8_t> cmark_, vmark_;   // update(): constraints being removed / variables whose lists lose some of them
   // this graph's own version of every table it still reads through an undo log (const: a lazy copy, not a change of the graph)
   void materialiseTables() const {
     for (int ty = 0; ty < BSGPU_F_NUM_TYPES; ++ty) {
