@@ -18,10 +18,10 @@
 //
 // Covered: visual(-inertial) windows with Euclidean landmarks eliminated on the landmark side; lidar-inertial windows (relative-pose
 // factors with or without extrinsics + IMU factors); pose graphs on the dense path; pose-only factors of any kind riding along (absolute
-// poses, vector priors, gravity, reprojection factors with a kept landmark); a window's dense marginal prior (the state after a slide
+// poses, vector priors, gravity, reprojection factors with a kept landmark); inverse-depth landmarks eliminated on the landmark side (k_idp.hip); a window's dense marginal prior (the state after a slide
 // with true marginalisation, fixed_lag_smoother.cpp:269-272); windows with constant blocks (the fixed cost is taken once, before the
-// first round).  Not covered (a thread per window, in the same call): block-sparse PCG, inverse-depth landmarks, more
-// than one dense prior, hipGraph replay, windows on another device.
+// first round).  Not covered (a thread per window, in the same call): block-sparse PCG, more than one dense
+// prior, hipGraph replay, windows on another device.
 #include <list>
 #include <memory>
 #include <thread>
@@ -57,7 +57,6 @@ bool shape_of(const bsgpu_ctx* c, WinShape& w) {
   for (int t = 2; t < kNumInternal; ++t) {
     if (!c->small[t].n || t == w.rel_t) continue;
     if (imu_carried && (t == BSGPU_F_IMU_DELTA || t == BSGPU_F_IMU_PRIOR)) continue;
-    if (t == BSGPU_F_IDP_REPROJ || t == BSGPU_F_IDP_REPROJ_UNARY) return false;
     w.set_t[w.n_set++] = t;
   }
   w.zero_in_mcc = c->upd_in_mcc && c->h_scal_dev != nullptr;
@@ -71,7 +70,6 @@ bool batch_covers(bsgpu_ctx* c, const bsgpu_options& o) {
   if (!c->finalized) return false;
   if (!(o.linear_solver_type == BSGPU_LINEAR_AUTO || o.linear_solver_type == BSGPU_LINEAR_SCHUR_CHOLESKY)) return false;
   if (!c->dense_ok || c->use_graphs || !c->d_S || !c->h_scal_dev || !c->d_reduce_counter || c->n_reduce <= 0 || c->n_pose <= 0) return false;
-  if (c->n_idp_lm > 0 || c->idp.n_lm > 0) return false;
   {   // at most ONE dense prior with free blocks (a window after a slide with true marginalisation), narrow enough for the one-launch evaluation
     int n_act = 0;
     for (const auto& mc : c->marg) if (mc.active) { ++n_act; if (mc.dev.cols > 1024 || mc.dev.nblk > 1024) return false; }
@@ -123,7 +121,7 @@ struct BatchPlan {
   BatchDyn* d_dyn = nullptr;
   std::vector<void*> dev_allocs;
   // [3]: at x (rejected / first steps) | cost only at the candidate | residuals + Jacobians at the candidate, ahead of the decision
-  BatchArgTable t_eval_vis[3], t_eval_rel[3], t_eval_set[3], t_eval_marg[3], t_marg_asm, t_marg_mcc;
+  BatchArgTable t_eval_vis[3], t_eval_rel[3], t_eval_set[3], t_eval_marg[3], t_marg_asm, t_marg_mcc, t_idp_lm, t_idp_view, t_idp_pairs, t_idp_backsub;
   BatchArgTable t_lm, t_lm_tail, t_zero, t_pairs, t_asm_set, t_asm_seg, t_gn, t_chol, t_bs[4], t_backsub, t_small_mcc, t_reduce, t_accept, t_backup;
   std::vector<int> bs_form;
   size_t max_tasks = 0;
@@ -131,7 +129,7 @@ struct BatchPlan {
     std::vector<BatchArgTable*> v = {&t_lm, &t_lm_tail, &t_zero, &t_pairs, &t_asm_set, &t_asm_seg, &t_gn, &t_chol, &t_bs[0], &t_bs[1], &t_bs[2], &t_bs[3],
                                      &t_backsub, &t_small_mcc, &t_reduce, &t_accept, &t_backup};
     for (int i = 0; i < 3; ++i) { v.push_back(&t_eval_vis[i]); v.push_back(&t_eval_rel[i]); v.push_back(&t_eval_set[i]); v.push_back(&t_eval_marg[i]); }
-    v.push_back(&t_marg_asm); v.push_back(&t_marg_mcc);
+    v.push_back(&t_marg_asm); v.push_back(&t_marg_mcc); v.push_back(&t_idp_lm); v.push_back(&t_idp_view); v.push_back(&t_idp_pairs); v.push_back(&t_idp_backsub);
     return v;
   }
   bool names(const bsgpu_ctx* c) const { for (const bsgpu_ctx* x : ctxs) if (x == c) return true; return false; }
@@ -217,6 +215,10 @@ bool build_plan(BatchPlan& P, bsgpu_ctx* const* ctxs, int n, const bsgpu_options
     zs.radius_slot = c->d_scal + SC_RADIUS; zs.radius = 0.0;
     batchargs_landmark(P.t_lm, P.t_lm_tail, c->vis, c->n_pose, o.jacobi_scaling, o.min_lm_diagonal, o.max_lm_diagonal, c->d_scale, c->d_dcl, c->d_grad, zs);
     batchargs_zero_tiles_multi(P.t_zero, sh.vis ? nullptr : &zs);
+    // (inverse-depth landmarks: their scalar elimination + the view pairs, k_idp.hip — after the clearing)
+    batchargs_idp_landmark(P.t_idp_lm, P.t_idp_view, c->idp, c->small[BSGPU_F_IDP_REPROJ], o.jacobi_scaling, o.min_lm_diagonal, o.max_lm_diagonal, c->d_scale, c->d_dcl, c->d_grad);
+    batchargs_idp_pairs(P.t_idp_pairs, c->idp, c->small[BSGPU_F_IDP_REPROJ], c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_dpos);
+    batchargs_idp_backsub(P.t_idp_backsub, c->idp, c->d_ytan, c->d_delta);
     SmallGroupSet set, set2;
     int taken = 0, units = 0, taken2 = 0, units2 = 0;
     if (c->vis.n_seg > 0) units = small_assemble_first_set(c->small_factorwise + 2, kNumInternal - 2, &set, &taken);
@@ -328,6 +330,8 @@ void enqueue_round(BatchPlan& P, std::vector<BatchWin>& L, const std::vector<int
   evals(P, 0, dd, BL_REJ, d.n[BL_REJ], true);                                              // Jacobians at x (accepted windows have them: evaluated ahead)
   launch_zero_tiles_multi_batch(s, P.t_zero, dd, BL_CLEAR, d.n[BL_CLEAR]);
   launch_landmark_batch(s, P.t_lm, P.t_lm_tail, dd, BL_ALL, d.n[BL_ALL]);
+  launch_idp_landmark_batch(s, P.t_idp_lm, P.t_idp_view, dd, BL_ALL, d.n[BL_ALL]);
+  launch_idp_pairs_batch(s, P.t_idp_pairs, dd, BL_ALL, d.n[BL_ALL]);
   launch_pairs_batch(s, P.t_pairs, dd, BL_ALL, d.n[BL_ALL]);
   launch_small_assemble_set_batch(s, P.t_asm_set, dd, BL_ALL, d.n[BL_ALL]);
   launch_small_assemble_seg_batch(s, P.t_asm_seg, dd, BL_ALL, d.n[BL_ALL]);
@@ -337,6 +341,7 @@ void enqueue_round(BatchPlan& P, std::vector<BatchWin>& L, const std::vector<int
     launch_chol_fused_batch(s, P.t_chol, dd, BL_FULL, d.n[BL_FULL]);
     const int nf[4] = {d.n[BL_BS_FUSED], d.n[BL_BS_FUSED + 1], d.n[BL_BS_CHAIN], d.n[BL_BS_CHAIN + 1]};
     launch_backsolve_batch(s, P.t_bs, dd, nf);
+    launch_idp_backsub_batch(s, P.t_idp_backsub, dd, BL_FULL, d.n[BL_FULL]);   // (before the pose-only groups' model-cost terms, which read the step of rho)
     launch_backsub_mcc_batch(s, P.t_backsub, dd, BL_FULL, d.n[BL_FULL]);
     launch_small_mcc_batch(s, P.t_small_mcc, dd, BL_FULL, d.n[BL_FULL]);
     launch_marg_mcc_batch(s, P.t_marg_mcc, dd, BL_FULL, d.n[BL_FULL]);

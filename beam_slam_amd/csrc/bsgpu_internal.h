@@ -332,6 +332,14 @@ void batchargs_marg_assemble(BatchArgTable& t, const MargDev* m, double* S, int 
 void launch_marg_assemble_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n);
 void batchargs_marg_mcc(BatchArgTable& t, const MargDev* m, const double* delta_tan, double* part);
 void launch_marg_mcc_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n);
+// ... inverse-depth landmarks eliminated on the landmark side (k_idp.hip)
+struct IdpElim;
+void batchargs_idp_landmark(BatchArgTable& t, BatchArgTable& t_view, const IdpElim& e, const SmallGroup& g, int jacobi, double lm_lo, double lm_hi, double* scale, double* dcl, double* grad);
+void launch_idp_landmark_batch(hipStream_t s, const BatchArgTable& t, const BatchArgTable& t_view, const BatchDyn* dyn, int list, int n);
+void batchargs_idp_pairs(BatchArgTable& t, const IdpElim& e, const SmallGroup& g, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm);
+void launch_idp_pairs_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n);
+void batchargs_idp_backsub(BatchArgTable& t, const IdpElim& e, const double* y_pose, double* delta);
+void launch_idp_backsub_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n);
 int batchargs_backsolve(BatchArgTable* tabs, const DensePlan& P, const DenseDev& D, double* y, const int* iperm, int n_pose, double* y_tan, double* delta);
 void launch_backsolve_batch(hipStream_t s, const BatchArgTable* tabs, const BatchDyn* dyn, const int* n_in_form);
 void launch_landmark(hipStream_t s, const Visual& v, int n_pose, const double* radius_ptr, int compute_scale,

@@ -25,10 +25,10 @@
 
 namespace bsg {
 
-__global__ __launch_bounds__(128) void idp_landmark_kernel(IdpElim e, SmallGroup g, const double* __restrict__ radius_ptr, double radius_val,
+__device__ __forceinline__ void idp_landmark_kernel_body(const int bsg_bx, const IdpElim& e, const SmallGroup& g, const double* __restrict__ radius_ptr, double radius_val,
                                                            int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi,
                                                            double* __restrict__ scale, double* __restrict__ dcl, double* __restrict__ grad) {
-  const int l = blockIdx.x * 128 + threadIdx.x;
+  const int l = bsg_bx * 128 + threadIdx.x;
   if (l >= e.n_lm) return;
   const int beg = e.lm_start[l], end = e.lm_start[l + 1];
   double h = 0.0, gl = 0.0;
@@ -52,12 +52,17 @@ __global__ __launch_bounds__(128) void idp_landmark_kernel(IdpElim e, SmallGroup
     e.C[2 * (size_t)p] = J[12] * linv; e.C[2 * (size_t)p + 1] = J[27] * linv;
   }
 }
+__global__ __launch_bounds__(128) void idp_landmark_kernel(IdpElim e, SmallGroup g, const double* __restrict__ radius_ptr, double radius_val,
+                                                           int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi,
+                                                           double* __restrict__ scale, double* __restrict__ dcl, double* __restrict__ grad) {
+  idp_landmark_kernel_body((int)blockIdx.x, e, g, radius_ptr, radius_val, compute_scale, compute_dcl, jacobi, lm_lo, lm_hi, scale, dcl, grad);
+}
 
 // one lane per view: u = sum A^T c over the factors of the landmark that involve the view's camera pose and — when the factors' own
 // pose-pose terms are assembled here too (e.direct) — D = sum A^T A (6x6) and the raw gradient sum A^T r.  A factor whose two poses
 // are the same camera pose enters with A_a + A_m.
-__global__ __launch_bounds__(128) void idp_view_kernel(IdpElim e, SmallGroup g) {
-  const int v = blockIdx.x * 128 + threadIdx.x;
+__device__ __forceinline__ void idp_view_kernel_body(const int bsg_bx, const IdpElim& e, const SmallGroup& g) {
+  const int v = bsg_bx * 128 + threadIdx.x;
   if (v >= e.n_view) return;
   const int l = e.view_lm[v];
   const int beg = e.lm_start[l], end = e.lm_start[l + 1];
@@ -104,6 +109,9 @@ __global__ __launch_bounds__(128) void idp_view_kernel(IdpElim e, SmallGroup g) 
     for (int k = 0; k < 6; ++k) o[36 + k] = gr[k];
   }
 }
+__global__ __launch_bounds__(128) void idp_view_kernel(IdpElim e, SmallGroup g) {
+  idp_view_kernel_body((int)blockIdx.x, e, g);
+}
 
 void launch_idp_landmark(hipStream_t s, const IdpElim& e, const SmallGroup& g, const double* radius_ptr, double radius_val, int compute_scale,
                          int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* scale, double* dcl, double* grad) {
@@ -116,9 +124,9 @@ void launch_idp_landmark(hipStream_t s, const IdpElim& e, const SmallGroup& g, c
 // one wave per segment, one lane per entry (view a, view b, code); the 36 + 18 sums leave through one transposed butterfly (as in
 // pairs_kernel).  code: -1 = the Schur term only; else (sorted factor position << 2) | (1 = view a is the factor's measurement side) << 1
 // | (1 = no Schur term: a further factor on a view pair that already has its entry) — the factor's cross term A_a^T A_m.
-__global__ __launch_bounds__(64) void idp_pairs_kernel(IdpElim e, SmallGroup g, double* __restrict__ S, int ld, int rhs_row, double* __restrict__ grad,
+__device__ __forceinline__ void idp_pairs_kernel_body(const int bsg_bx, const IdpElim& e, const SmallGroup& g, double* __restrict__ S, int ld, int rhs_row, double* __restrict__ grad,
                                                        double* __restrict__ hdiag, const int* __restrict__ perm, int grad_only) {
-  const int seg = blockIdx.x, lane = threadIdx.x;
+  const int seg = bsg_bx, lane = threadIdx.x;
   const int ci = e.seg_ci[seg], cj = e.seg_cj[seg];
   const bool diag = ci == cj;
   if (grad_only && !(diag && e.direct)) return;
@@ -204,6 +212,10 @@ __global__ __launch_bounds__(64) void idp_pairs_kernel(IdpElim e, SmallGroup g, 
     }
   }
 }
+__global__ __launch_bounds__(64) void idp_pairs_kernel(IdpElim e, SmallGroup g, double* __restrict__ S, int ld, int rhs_row, double* __restrict__ grad,
+                                                       double* __restrict__ hdiag, const int* __restrict__ perm, int grad_only) {
+  idp_pairs_kernel_body((int)blockIdx.x, e, g, S, ld, rhs_row, grad, hdiag, perm, grad_only);
+}
 
 void launch_idp_pairs(hipStream_t s, const IdpElim& e, const SmallGroup& g, double* S, int ld, int rhs_row, double* grad, double* hdiag,
                       const int* perm, bool grad_only) {
@@ -212,8 +224,8 @@ void launch_idp_pairs(hipStream_t s, const IdpElim& e, const SmallGroup& g, doub
 }
 
 // y_l = linv (z - sum_f c_f^T (A_a y_a + A_m y_m)) = linv (z - sum_v u_v . y_cam(v)): the views carry what the step of rho needs
-__global__ __launch_bounds__(128) void idp_backsub_kernel(IdpElim e, const double* __restrict__ y_pose, double* __restrict__ delta) {
-  const int l = blockIdx.x * 128 + threadIdx.x;
+__device__ __forceinline__ void idp_backsub_kernel_body(const int bsg_bx, const IdpElim& e, const double* __restrict__ y_pose, double* __restrict__ delta) {
+  const int l = bsg_bx * 128 + threadIdx.x;
   if (l >= e.n_lm) return;
   double acc = 0.0;
   for (int v = e.view_start[l]; v < e.view_start[l + 1]; ++v) {
@@ -224,10 +236,76 @@ __global__ __launch_bounds__(128) void idp_backsub_kernel(IdpElim e, const doubl
   }
   delta[e.to0 + l] = -(e.linv[l] * (e.z[l] - acc));
 }
+__global__ __launch_bounds__(128) void idp_backsub_kernel(IdpElim e, const double* __restrict__ y_pose, double* __restrict__ delta) {
+  idp_backsub_kernel_body((int)blockIdx.x, e, y_pose, delta);
+}
 
 void launch_idp_backsub(hipStream_t s, const IdpElim& e, const double* y_pose, double* delta) {
   if (e.n_lm <= 0) return;
   hipLaunchKernelGGL(idp_backsub_kernel, dim3((e.n_lm + 127) / 128), dim3(128), 0, s, e, y_pose, delta);
+}
+
+// ---- the same launches over several windows (bsgpu_batch.cpp): entry w = what window w's lone launches pass (zero grids: no inverse-depth
+// landmarks); the radius and the step's flags come per round (BatchDyn)
+struct idp_landmark_Args { int bsg_grid; int view_grid; IdpElim e; SmallGroup g; int jacobi; double lm_lo, lm_hi; double* scale; double* dcl; double* grad; };
+__global__ __launch_bounds__(128) void idp_landmark_kernel_batch(const idp_landmark_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
+  const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
+  const idp_landmark_Args& a = bsg_A[bsg_w];
+  if ((int)blockIdx.x >= a.bsg_grid) return;
+  idp_landmark_kernel_body((int)blockIdx.x, a.e, a.g, nullptr, bsg_dyn->radius[bsg_w], bsg_dyn->first[bsg_w], bsg_dyn->new_J[bsg_w], a.jacobi, a.lm_lo, a.lm_hi, a.scale, a.dcl, a.grad);
+}
+__global__ __launch_bounds__(128) void idp_view_kernel_batch(const idp_landmark_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
+  const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
+  const idp_landmark_Args& a = bsg_A[bsg_w];
+  if ((int)blockIdx.x >= a.view_grid) return;
+  idp_view_kernel_body((int)blockIdx.x, a.e, a.g);
+}
+void batchargs_idp_landmark(BatchArgTable& t, BatchArgTable& t_view, const IdpElim& e, const SmallGroup& g, int jacobi, double lm_lo, double lm_hi, double* scale, double* dcl, double* grad) {
+  idp_landmark_Args a;
+  a.e = e; a.g = g; a.jacobi = jacobi; a.lm_lo = lm_lo; a.lm_hi = lm_hi; a.scale = scale; a.dcl = dcl; a.grad = grad;
+  a.bsg_grid = e.n_lm > 0 ? (e.n_lm + 127) / 128 : 0;
+  a.view_grid = (e.n_lm > 0 && e.n_view > 0) ? (e.n_view + 127) / 128 : 0;
+  t.push(a);
+  idp_landmark_Args b = a;   // (the view launch reads the same entry: its own table only carries its grid for the launch's size)
+  b.bsg_grid = a.view_grid;
+  t_view.push(b);
+}
+void launch_idp_landmark_batch(hipStream_t s, const BatchArgTable& t, const BatchArgTable& t_view, const BatchDyn* dyn, int list, int n) {
+  if (n <= 0) return;
+  if (t.max_grid > 0) hipLaunchKernelGGL(idp_landmark_kernel_batch, dim3(t.max_grid, n), dim3(128), 0, s, static_cast<const idp_landmark_Args*>(t.dev), dyn, list);
+  if (t_view.max_grid > 0) hipLaunchKernelGGL(idp_view_kernel_batch, dim3(t_view.max_grid, n), dim3(128), 0, s, static_cast<const idp_landmark_Args*>(t_view.dev), dyn, list);
+}
+struct idp_pairs_Args { int bsg_grid; IdpElim e; SmallGroup g; double* S; int ld; int rhs_row; double* grad; double* hdiag; const int* perm; };
+__global__ __launch_bounds__(64) void idp_pairs_kernel_batch(const idp_pairs_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
+  const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
+  const idp_pairs_Args& a = bsg_A[bsg_w];
+  if ((int)blockIdx.x >= a.bsg_grid) return;
+  idp_pairs_kernel_body((int)blockIdx.x, a.e, a.g, a.S, a.ld, a.rhs_row, a.grad, a.hdiag, a.perm, bsg_dyn->grad_only[bsg_w]);
+}
+void batchargs_idp_pairs(BatchArgTable& t, const IdpElim& e, const SmallGroup& g, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm) {
+  idp_pairs_Args a;
+  a.e = e; a.g = g; a.S = S; a.ld = ld; a.rhs_row = rhs_row; a.grad = grad; a.hdiag = hdiag; a.perm = perm; a.bsg_grid = e.n_seg > 0 ? e.n_seg : 0;
+  t.push(a);
+}
+void launch_idp_pairs_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n) {
+  if (n <= 0 || t.max_grid <= 0) return;
+  hipLaunchKernelGGL(idp_pairs_kernel_batch, dim3(t.max_grid, n), dim3(64), 0, s, static_cast<const idp_pairs_Args*>(t.dev), dyn, list);
+}
+struct idp_backsub_Args { int bsg_grid; IdpElim e; const double* y_pose; double* delta; };
+__global__ __launch_bounds__(128) void idp_backsub_kernel_batch(const idp_backsub_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
+  const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
+  const idp_backsub_Args& a = bsg_A[bsg_w];
+  if ((int)blockIdx.x >= a.bsg_grid) return;
+  idp_backsub_kernel_body((int)blockIdx.x, a.e, a.y_pose, a.delta);
+}
+void batchargs_idp_backsub(BatchArgTable& t, const IdpElim& e, const double* y_pose, double* delta) {
+  idp_backsub_Args a;
+  a.e = e; a.y_pose = y_pose; a.delta = delta; a.bsg_grid = e.n_lm > 0 ? (e.n_lm + 127) / 128 : 0;
+  t.push(a);
+}
+void launch_idp_backsub_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n) {
+  if (n <= 0 || t.max_grid <= 0) return;
+  hipLaunchKernelGGL(idp_backsub_kernel_batch, dim3(t.max_grid, n), dim3(128), 0, s, static_cast<const idp_backsub_Args*>(t.dev), dyn, list);
 }
 
 }  // namespace bsg

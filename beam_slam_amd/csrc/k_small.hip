@@ -1330,6 +1330,8 @@ __device__ __forceinline__ void small_eval_set_dispatch(const small_eval_set_Arg
     case BSGPU_F_ABS_VEC3: vec3_kernel_body<false, WITH_J>(g, a.x, a.losses, part, bx); break;
     case BSGPU_F_REL_VEC3: vec3_kernel_body<true, WITH_J>(g, a.x, a.losses, part, bx); break;
     case BSGPU_F_GRAVITY: gravity_kernel_body<WITH_J>(g, a.x, a.losses, part, bx); break;
+    case BSGPU_F_IDP_REPROJ: idp_kernel_body<false, WITH_J>(g, a.x, a.losses, part, bx); break;
+    case BSGPU_F_IDP_REPROJ_UNARY: idp_kernel_body<true, WITH_J>(g, a.x, a.losses, part, bx); break;
     case BSGPU_F_NUM_TYPES: reproj_dense_kernel_body<WITH_J>(g, a.x, a.losses, part, bx); break;
     default: break;
   }
@@ -1364,7 +1366,6 @@ static bool fill_small_eval_set(small_eval_set_Args& a, const SmallGroup* groups
 }
 // false: more groups than one launch takes, or a type the launch does not carry (the caller launches them one by one)
 bool launch_small_eval_set(hipStream_t s, const SmallGroup* groups, double* const* parts, int n_groups, const double* x, const DevLoss* losses, bool with_J) {
-  for (int i = 0; i < n_groups; ++i) if (groups[i].n && (groups[i].type == BSGPU_F_IDP_REPROJ || groups[i].type == BSGPU_F_IDP_REPROJ_UNARY)) return false;
   small_eval_set_Args a;
   if (!fill_small_eval_set(a, groups, parts, n_groups, x, losses)) return false;
   if (a.bsg_grid <= 0) return true;

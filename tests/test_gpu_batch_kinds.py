@@ -183,3 +183,24 @@ def test_batch_keeps_windows_with_a_dense_prior(gpu_solver_cls, oracle_cls):
     for g0, s0, g1, s1 in zip(alone, lone, batch, sums):
         _same_trajectory(g0, s0, g1, s1)
     _oracle_check(cases[0], batch[0], opts[0], oracle_cls, val_tol=1e-4)   # (every iteration's cost to 1e-7; five iterations in, weakly observed landmarks differ by ~1e-5)
+
+
+def test_batch_inverse_depth_windows(gpu_solver_cls, oracle_cls):
+    """Windows whose landmarks are inverse depths anchored in a key frame (inversedepth_reprojection_functor.h:57-125), eliminated on the
+    landmark side by the k_idp.hip family: batched with a Euclidean-landmark window and a window that has both kinds."""
+    cases = [synthetic.idp_window(n_kf=8, n_lm=60, seed=6), synthetic.idp_window(n_kf=12, n_lm=150, seed=7), synthetic.vio_window(n_kf=10, n_lm=120, seed=8),
+             synthetic.idp_window(n_kf=6, n_lm=40, seed=9)]
+    alone = _fresh(gpu_solver_cls, cases)
+    opts = []
+    for i, g in enumerate(alone):
+        o = g.options_default(); o.max_num_iterations = 6 + i
+        opts.append(o)
+    lone = [g.solve(o) for g, o in zip(alone, opts)]
+    w0, _ = gpu_solver_cls.batch_stats()
+    batch = _fresh(gpu_solver_cls, cases)
+    sums = gpu_solver_cls.solve_batch(batch, opts)
+    w1, _ = gpu_solver_cls.batch_stats()
+    assert w1 - w0 == len(cases)
+    for g0, s0, g1, s1 in zip(alone, lone, batch, sums):
+        _same_trajectory(g0, s0, g1, s1)
+    _oracle_check(cases[1], batch[1], opts[1], oracle_cls, val_tol=1e-5)
