@@ -91,6 +91,7 @@ def short_leg(which, device):
                         "c4": "C4: global-mapper pose graph, 5000 poses, 50000 constraints (block-sparse PCG path)"}[which],
            "value": round(n_it / dt, 2), "unit": "LM iterations/s", "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * dt / steps, 3),
            "lm_iterations_per_solve": round(n_it / steps, 2), "pcg_iterations_per_solve": int(s.num_inner_iterations),
+           "pcg_relative_tolerance": opt.pcg_tolerance if which == "c4" else None,
            "final_cost": s.final_cost, "initial_cost": s.initial_cost,
            "roofline": {"bound": "hbm", "kernel": "relative-pose (+ IMU) Jacobian evaluation", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 4), "bytes_per_launch": int(nb_e), "ms_per_launch": round(ms_e, 5),

@@ -197,7 +197,11 @@ typedef struct bsgpu_options {
   double max_lm_diagonal;               /* 1e32                                 */
   int32_t pcg_max_iterations;           /* BSGPU_LINEAR_PCG only                */
   int32_t reserved0;
-  double pcg_tolerance;                 /* relative residual                    */
+  double pcg_tolerance;                 /* relative residual |r| / |b| at which an inner solve stops.  Default 1e-6: on the 5 000-pose
+                                           graph of BASELINE config 4 every LM iteration's cost stays within 1e-7 and the final cost
+                                           within 1e-10 of the trajectory of the exact step (1e-12), at 39 instead of 84 inner
+                                           iterations per LM step (scripts/c4_tolerance.py).  Ceres' own iterative solvers stop far
+                                           earlier (eta = 0.1); the reference's exact SPARSE_NORMAL_CHOLESKY is what 1e-12 emulates. */
 } bsgpu_options;
 
 /* fills `o` with Ceres' defaults */
