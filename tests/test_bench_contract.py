@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 
 def _bench(extra_env, *args):
     env = dict(os.environ, **extra_env)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", *args],
+    # (--no-other-configs: the C3 / C4 / batch / host-cycle legs of the default run take half a minute and are the driver's bench run, not this contract)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs", "--sustained-seconds", "0.3", *args],
                          capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
@@ -56,3 +57,25 @@ def test_bench_consensus_two_ranks_on_one_gpu():
     c = r["consensus"]
     assert 2 <= c["rounds"] <= 8 and len(c["ms_per_round"]) == c["rounds"] and c["last_change_of_a_shared_value"] < 1e-7
     assert c["merged_graph_cost"] > 0
+
+
+def test_bench_windows_per_gpu_two_ranks_on_one_gpu():
+    """bench.py --gpus 2 --windows-per-gpu 3 as the driver launches it (torch.distributed.run), both ranks on the one GPU of the box (gloo: RCCL
+    refuses two ranks on one device): every rank advances its three windows with one bsgpu_solve_batch per step; the line says how many ranks
+    reported and what each did, and the aggregate is their sum over the slowest rank's time."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    env = dict(os.environ, BSGPU_BENCH_BACKEND="gloo", BSGPU_BENCH_SAME_DEVICE="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--windows-per-gpu", "3", "--n-kf", "30", "--n-lm", "2000", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["n_gpus"] == 2 and r["value"] > 0 and r["scaling"] == "weak"
+    c = r["config"]
+    assert c["n_ranks_seen"] == 2 and len(c["per_rank_lm_iterations_per_s"]) == 2 and min(c["per_rank_lm_iterations_per_s"]) > 0
+    assert "3 per GPU" in c["workload"] and "6 independent" in c["workload"]
+    # the same flag on one rank
+    r1 = _bench({}, "--windows-per-gpu", "3", "--n-kf", "30", "--n-lm", "2000")
+    assert r1["n_gpus"] == 1 and r1["config"]["n_ranks_seen"] == 1 and r1["value"] > 0
