@@ -174,6 +174,10 @@ bool build_plan(BatchPlan& P, bsgpu_ctx* const* ctxs, int n, const bsgpu_options
   P.jacobi = o.jacobi_scaling; P.lm_lo = o.min_lm_diagonal; P.lm_hi = o.max_lm_diagonal;
   P.bs_form.assign(n, -1);
   P.shape.resize(n);
+  size_t tasks_per_round = 0;
+  for (int w = 0; w < n; ++w) tasks_per_round += ctxs[w]->plan.ftasks.size();
+  static const char* bulk_env = getenv("BSGPU_BATCH_BULK");   // (0: never, 1: always)
+  const bool bulk_lists = bulk_env ? atoi(bulk_env) != 0 : tasks_per_round >= 2048;
   for (int w = 0; w < n; ++w) {
     bsgpu_ctx* c = ctxs[w];
     P.ctxs.push_back(c); P.gens.push_back(c->finalize_gen); P.xptr.push_back(c->d_x);
@@ -241,9 +245,15 @@ bool build_plan(BatchPlan& P, bsgpu_ctx* const* ctxs, int n, const bsgpu_options
                      c->d_bs_desc, c->d_chain_begin, c->d_chain_end, c->d_tile_sync, c->d_ftasks, c->d_fsync,
                      c->d_bs_desc_chain, c->d_rows_flat_chain, c->d_bs_upd, c->d_bs_upd_rows,
                      c->d_bs_chain_group, c->d_bs_grp_nchains, c->d_bs_grp_nitems, c->d_bs_items4, c->d_bs_tile_updated, c->d_bs_sync, c->d_scal, c->d_Winv, c->d_bs_order, c->d_tile_tot, 1};
+    // (a call whose factorisations are bound by the number of their workgroups — each holds a CU — takes the lists without the K-chunks of
+    //  §3.2f, which shorten ONE window's critical path at the price of four to five workgroups per dealt-out update: 16 pose graphs of 200
+    //  poses + 6-10 %, 8 C2 windows + 2 %, 32 windows of 20 KF x 500 no difference — so: from 2 048 tasks per round on)
+    const bool bulk = bulk_lists && c->d_ftasks_bulk && c->d_tile_tot_bulk;
     const bool plain = c->d_ftasks_plain && c->d_tile_tot_plain;
-    batchargs_chol_fused(P.t_chol, c->d_S, D.Lp, c->plan.npad, plain ? c->d_ftasks_plain : D.ftasks, plain ? c->n_ftasks_plain : (int)c->plan.ftasks.size(),
-                         plain ? c->d_tile_tot_plain : D.tile_tot, D.nreal, D.Vinv, c->d_scal, D.fsync, D.Winv, D.rhs_rows, LmDiag(), GradNormRide());
+    const FusedTask* tl = bulk ? c->d_ftasks_bulk : plain ? c->d_ftasks_plain : D.ftasks;
+    const int ntl = bulk ? c->n_ftasks_bulk : plain ? c->n_ftasks_plain : (int)c->plan.ftasks.size();
+    const int* tt = bulk ? c->d_tile_tot_bulk : plain ? c->d_tile_tot_plain : D.tile_tot;
+    batchargs_chol_fused(P.t_chol, c->d_S, D.Lp, c->plan.npad, tl, ntl, tt, D.nreal, D.Vinv, c->d_scal, D.fsync, D.Winv, D.rhs_rows, LmDiag(), GradNormRide());
     P.bs_form[w] = batchargs_backsolve(P.t_bs, c->plan, D, c->d_y, c->d_inat, c->n_pose, c->d_ytan, c->d_delta);
     if (P.bs_form[w] < 0) return false;
     // ---- landmark back-substitution + model cost change + candidate (linear_solve_and_candidate())

@@ -955,6 +955,7 @@ int finalize(bsgpu_ctx* c) {
       const char* ef = getenv("BSGPU_CHOL_FUSED");
       c->d_ftasks = nullptr; c->d_fsync = nullptr; c->d_tile_tot = nullptr;
       c->d_ftasks_plain = nullptr; c->d_tile_tot_plain = nullptr; c->n_ftasks_plain = 0;
+      c->d_ftasks_bulk = nullptr; c->d_tile_tot_bulk = nullptr; c->n_ftasks_bulk = 0;
       // (one workgroup of 512 threads per task, and a grid holds fewer than 2^32 threads: above 8.38 M tasks — a DENSE system of more than
       // ~23 600 dimensions, which only the exact option on a pose graph produces — the launch is refused by the runtime, so the
       // launch-per-step path runs there; scripts/c4_exact.py)
@@ -964,6 +965,10 @@ int finalize(bsgpu_ctx* c) {
         if (!c->plan.ftasks_plain.empty()) {
           c->d_ftasks_plain = c->upload(c->plan.ftasks_plain); c->d_tile_tot_plain = c->upload(c->plan.tile_tot_plain);
           c->n_ftasks_plain = (int)c->plan.ftasks_plain.size();
+        }
+        if (!c->plan.ftasks_bulk.empty()) {
+          c->d_ftasks_bulk = c->upload(c->plan.ftasks_bulk); c->d_tile_tot_bulk = c->upload(c->plan.tile_tot_bulk);
+          c->n_ftasks_bulk = (int)c->plan.ftasks_bulk.size();
         }
         c->d_fsync = c->upload(std::vector<int>((size_t)c->plan.fused_sync_words, 0));
         c->d_Winv = c->alloc<double>((size_t)std::max(1, T) * 4096);   // (the chains write every entry of a tile's inverse, zeros above its diagonal blocks included)

@@ -111,6 +111,8 @@ struct DensePlan {
   std::vector<int> fext_of;           // T+1: the appendix tile panel k carries (kFusedExt), or -1
   std::vector<FusedTask> ftasks_plain;   // ftasks without the diagonal / rider tasks (empty: the plan has none, ftasks is that list)
   std::vector<int> tile_tot_plain;
+  std::vector<FusedTask> ftasks_bulk;    // ... and without the K-chunks either: what a launch takes that is bound by the NUMBER of its workgroups, not by one
+  std::vector<int> tile_tot_bulk;        // window's critical path (many windows side by side: bsgpu_batch.cpp); empty: the plan has no chunks
   bool allow_ext = true;              // (finalize: BSGPU_CHOL_EXT=0 plans every tile's panel by itself)
   bool diag_tasks = false;            // one kFusedDiagAdd task per tile at the head of the list
   int rider_tasks = 0;                // kFusedRider tasks behind them
@@ -577,6 +579,8 @@ struct DensePlan {
       // separator's tiles take their last updates from the last panels of BOTH its children, which finish at about the same time — with only
       // the very last one dealt out, its chunks waited 4-6 us for the other child's update to take its turn (BSGPU_CHOL_PROBE, C2).
       n_split_chunks = 0;
+      const std::vector<FusedTask> ftasks_whole = ftasks;   // (before the chunks: ftasks_bulk below)
+      const std::vector<int> tile_tot_whole = tile_tot;
       if (split_depth > 0) {
         const int nt = (int)ftasks.size();
         std::vector<std::vector<int>> updaters((size_t)N * N);
@@ -633,6 +637,17 @@ struct DensePlan {
           ftasks_plain.push_back(f);
         }
         if (diag_tasks) for (int t = 0; t < T; ++t) tile_tot_plain[(size_t)t * N + t]--;
+      }
+      ftasks_bulk.clear(); tile_tot_bulk.clear();
+      if (n_split_chunks > 0) {
+        tile_tot_bulk = tile_tot_whole;
+        for (const FusedTask& f0 : ftasks_whole) {
+          if (f0.flags & (kFusedDiagAdd | kFusedRider)) continue;
+          FusedTask f = f0;
+          if (diag_tasks && !(f.flags & kFusedChain) && f.ti == f.tj && f.ti < T && f.need_c >= 0) { f.need_c--; f.tot_c--; }
+          ftasks_bulk.push_back(f);
+        }
+        if (diag_tasks) for (int t = 0; t < T; ++t) tile_tot_bulk[(size_t)t * N + t]--;
       }
     }
     // ---- back-substitution plan

@@ -330,13 +330,13 @@ def main():
             # timed with HIP events on the solver's stream (20 back-to-back evaluations of every factor type of the window)
             ms_e, nb_e = g.time_eval_ms(20), g.eval_bytes()
             ach = nb_e / (ms_e * 1e-3) / 1e9
-            rel_kernel = "relpose_imu_eval_kernel" if (args.workload == "c3" and os.environ.get("BSGPU_EVAL_MERGE", "2") == "2") else "relpose_kernel"
-            roofline = {"bound": "hbm", "kernel": rel_kernel + (" (relative-pose factors + the window's IMU factors as its first workgroups)" if rel_kernel != "relpose_kernel" else " (+ abspose_kernel)"),
+            rel_kernel = "relpose_imu_eval_kernel" if (args.workload == "c3" and os.environ.get("BSGPU_EVAL_MERGE", "2") == "2") else "small_eval_set_kernel"
+            roofline = {"bound": "hbm", "kernel": rel_kernel + (" (relative-pose factors + the window's IMU factors as its first workgroups)" if rel_kernel != "small_eval_set_kernel" else " (the relative-pose factors and the prior on the first pose in one launch)"),
                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "bytes_per_launch": int(nb_e), "ms_per_launch": round(ms_e, 5),
                         "timing": "20 back-to-back evaluations (residuals + Jacobians of every factor type) between two HIP events on the solver's stream",
                         "working_set_mb": round(nb_e / 1e6, 1), "cache_residency": "below the 256 MiB Infinity Cache", "traffic": None}
-            _attach_traffic(roofline, "r04_%s_pmc_hbm.csv" % args.workload, rel_kernel + "<", nb_e)
+            _attach_traffic(roofline, "r05_%s_pmc_hbm.csv" % args.workload, rel_kernel + "<true", nb_e)
         if args.workload == "c3":          # dense Schur path without landmarks: phases and the factorisation's figure
             prof = g.profile_step(opt, reps=20)
             phases = {k: round(1e3 * v[0], 2) for k, v in prof.items()}
@@ -372,7 +372,7 @@ def main():
                 roofline["kernel_note"] = ("the reprojection factors' evaluation (the bytes counted) plus the window's %d IMU factors as the launch's first workgroups "
                                            "(~6.1 KB each, not counted)" % (pr.n_factors(capi.F_IMU_DELTA) + pr.n_factors(capi.F_IMU_PRIOR)))
             if world == 1 and args.workload == "c2" and args.n_kf == 200 and args.n_lm == 50000:
-                _attach_traffic(roofline, "r04_c2_pmc_hbm.csv", eval_kernel, nbytes)
+                _attach_traffic(roofline, "r05_c2_pmc_hbm.csv", eval_kernel, nbytes)
             ms_f, flops = prof["factor"]
             tf = flops / (ms_f * 1e-3) / 1e12
             roofline_mfma = {"bound": "mfma", "kernel": "chol_fused_kernel (+ chol_backsolve_fused_kernel: %.1f us)" % (1e3 * prof["backsolve"][0]),

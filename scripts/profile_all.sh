@@ -4,7 +4,7 @@
 #   PMC passes, each in its OWN run with --kernel-trace only: HBM traffic (FETCH_SIZE, WRITE_SIZE) for C2 / C3 / C4 and for the
 #   past-the-Infinity-Cache window; MFMA utilisation (SQ_INSTS_VALU_MFMA_MOPS_F64, SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE ...) for C2 / C3
 # Summaries land in gpurun_out/prof_<round>/; the ones to be judged are copied to profiles/ by hand.
-ROUND=${1:-r03}
+ROUND=${1:-r05}
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$ROOT/gpurun_out/prof_$ROUND"
 mkdir -p "$OUT"
@@ -53,7 +53,7 @@ def bench_bytes(w):   # algorithmic bytes per launch of the roofline kernel, fro
     except Exception:
         pass
     return None
-roof_kernel = {"c2": "visual_imu_eval_kernel<true>", "c3": "relpose_imu_eval_kernel", "c4": "relpose_kernel", "pastl3": "reproj_eval_kernel<true>"}
+roof_kernel = {"c2": "visual_imu_eval_kernel<true>", "c3": "relpose_imu_eval_kernel", "c4": "small_eval_set_kernel<true>", "pastl3": "reproj_eval_kernel<true>"}
 for tag in ("c2", "c3", "c4", "pastl3"):
     acc, cnt = collect(tag, ["FETCH_SIZE", "WRITE_SIZE"])
     keys = sorted(set(k for c in acc for k in acc[c]), key=lambda k: -(acc["FETCH_SIZE"].get(k, 0) + acc["WRITE_SIZE"].get(k, 0)))

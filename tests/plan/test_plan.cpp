@@ -83,6 +83,7 @@ static int check_ordered(std::mt19937& rng, unsigned seed) {
   return fails + replay(P, adjS, seed, -1);
 }
 
+static long g_bulk_lists = 0;
 static long g_ext_tasks = 0, g_ext_plans = 0, g_diag_tasks = 0, g_split_tasks = 0, g_split_loaded = 0;
 static int replay_list(const DensePlan& P, const std::vector<uint8_t>& adj, unsigned seed, int max_chains) {
   { long n = 0; for (const FusedTask& f : P.ftasks) n += (f.flags & kFusedExt) ? 1 : 0; g_ext_tasks += n; g_ext_plans += n > 0; }
@@ -232,6 +233,13 @@ static int replay(const DensePlan& P, const std::vector<uint8_t>& adj, unsigned 
     Q.ftasks = P.ftasks_plain; Q.tile_tot = P.tile_tot_plain; Q.diag_tasks = false; Q.rider_tasks = 0;
     f += replay_list(Q, adj, seed, max_chains);
   }
+  if (!P.ftasks_bulk.empty()) {   // ... and the list without the K-chunks (what a batch of many windows takes)
+    DensePlan Q = P;
+    Q.ftasks = P.ftasks_bulk; Q.tile_tot = P.tile_tot_bulk; Q.diag_tasks = false; Q.rider_tasks = 0;
+    for (const FusedTask& t : Q.ftasks) if (t.flags & (kFusedSplit | kFusedDiagAdd | kFusedRider)) { printf("  FAIL bulk list holds a chunk / diagonal / rider task\n"); return f + 1; }
+    f += replay_list(Q, adj, seed, max_chains);
+    ++g_bulk_lists;
+  }
   return f;
 }
 
@@ -269,6 +277,8 @@ int main() {
   if (g_ext_plans < 20) { printf("too few plans with an appendix tile\n"); ++fails; }
   printf("split chunks: %ld tasks, %ld partial tiles added by chains\n", g_split_tasks, g_split_loaded);
   if (g_split_tasks < 1000 || g_split_loaded != g_split_tasks) { printf("the split chunks and the chains' partial tiles do not match\n"); ++fails; }
+  printf("bulk lists replayed: %ld\n", g_bulk_lists);
+  if (g_bulk_lists < 100) { printf("too few bulk lists\n"); ++fails; }
   printf("diagonal tasks: %ld\n", g_diag_tasks);
   if (g_diag_tasks < 1000) { printf("too few diagonal tasks\n"); ++fails; }
   fails += ofails;
