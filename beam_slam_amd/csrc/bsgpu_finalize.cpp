@@ -909,6 +909,34 @@ int finalize(bsgpu_ctx* c) {
       }
       bool keep = true;
       if (dense_on_trial && ord.depth == 0) keep = false;   // no separator found (C4: uniformly random loop closures): the system fills in
+      if (keep && dense_on_trial) {
+        // ... and an order that does find separators may still fill in: count the update tasks of the tile-level symbolic factorisation (bit
+        // rows: a few milliseconds at 469 tiles) BEFORE the plan — its task list, ticket order and back-substitution tables — is built for a
+        // factorisation that will be refused anyway (a filled-in plan of C4's size is 17 million tasks and seconds of finalize)
+        const int W = (To + 63) / 64;
+        std::vector<uint64_t> rowbits((size_t)To * W, 0);   // rowbits[k]: the row tiles t > k of panel k
+        for (int k = 0; k < To; ++k) for (int t = k + 1; t < To; ++t) if (adjS[(size_t)t * To + k]) rowbits[(size_t)k * W + (t >> 6)] |= 1ull << (t & 63);
+        double tasks = 0.0;
+        for (int k = 0; k < To && tasks < 4.0e7; ++k) {
+          const uint64_t* rk = &rowbits[(size_t)k * W];
+          int n = 0;
+          for (int wd = 0; wd < W; ++wd) n += __builtin_popcountll(rk[wd]);
+          tasks += 0.5 * n * (n + 1);
+          for (int wd = 0; wd < W; ++wd) {   // fill: every row tile a of panel k gets the later row tiles of panel k
+            uint64_t m = rk[wd];
+            while (m) {
+              const int a = wd * 64 + __builtin_ctzll(m); m &= m - 1;
+              uint64_t* ra = &rowbits[(size_t)a * W];
+              for (int w2 = a >> 6; w2 < W; ++w2) { uint64_t add = rk[w2]; if (w2 == (a >> 6)) add &= ~((2ull << (a & 63)) - 1); ra[w2] |= add; }
+            }
+          }
+        }
+        const double est_flops = tasks * 2.0 * 64.0 * 64.0 * 64.0;
+        if (est_flops / 7.0e12 * 1e6 > 4000.0) {
+          keep = false;
+          if (timing) fprintf(stderr, "[bsgpu finalize] pose graph above the dense limit on trial: ~%.3g update tasks after fill (%.3g flops): block-sparse PCG, no plan built\n", tasks, est_flops);
+        }
+      }
       if (keep) {
         c->plan.build_ordered(c->n_pose, To, ord.dpos, ord.nreal, adjS, ord.piece_ranges, ord.sep_ranges_by_level, !(e3 && atoi(e3) == 0));
         ordered = true;
