@@ -76,7 +76,7 @@ bool batch_covers(bsgpu_ctx* c, const bsgpu_options& o) {
     if (n_act > 1) return false;
   }
   if (c->vis.n > 0) {
-    if (c->vis.n_lm <= 0 || c->vis.n_seg <= 0 || c->n_upd_blocks <= 0 || c->upd_in_mcc) return false;
+    if (c->vis.n_lm <= 0 || (c->vis.n_seg <= 0 && c->vis.n_band_units <= 0) || c->n_upd_blocks <= 0 || c->upd_in_mcc) return false;
   } else if (!c->upd_in_mcc) return false;
   if (!c->d_ftasks || !c->d_fsync || !c->d_tile_tot || !c->d_Winv) return false;
   if (c->plan.ftasks.size() > 65535) return false;   // (the window's tasks are the y dimension of the batched factorisation's grid)
@@ -86,7 +86,7 @@ bool batch_covers(bsgpu_ctx* c, const bsgpu_options& o) {
   // the pose-only groups that ride in no other launch must fit ONE set each (assembly one workgroup per factor; model-cost terms)
   SmallGroupSet set;
   int taken = 0, units = 0, taken2 = 0, units2 = 0;
-  if (c->vis.n_seg > 0) units = small_assemble_first_set(c->small_factorwise + 2, kNumInternal - 2, &set, &taken);
+  if (c->vis.n_seg > 0 || c->vis.n_band_units > 0) units = small_assemble_first_set(c->small_factorwise + 2, kNumInternal - 2, &set, &taken);
   if (units == 0) taken = 0;
   if (units == 0 && c->n_sa_seg + c->n_asm_grp > 0) units2 = small_assemble_first_set(c->small_factorwise + 2, kNumInternal - 2, &set, &taken2);
   if (units2 == 0) taken2 = 0;
@@ -122,11 +122,11 @@ struct BatchPlan {
   std::vector<void*> dev_allocs;
   // [3]: at x (rejected / first steps) | cost only at the candidate | residuals + Jacobians at the candidate, ahead of the decision
   BatchArgTable t_eval_vis[3], t_eval_rel[3], t_eval_set[3], t_eval_marg[3], t_marg_asm, t_marg_mcc, t_idp_lm, t_idp_view, t_idp_pairs, t_idp_backsub;
-  BatchArgTable t_lm, t_lm_tail, t_zero, t_pairs, t_asm_set, t_asm_seg, t_gn, t_chol, t_bs[4], t_backsub, t_small_mcc, t_reduce, t_accept, t_backup;
+  BatchArgTable t_lm, t_lm_tail, t_zero, t_pairs, t_pairs_band, t_asm_set, t_asm_seg, t_gn, t_chol, t_bs[4], t_backsub, t_small_mcc, t_reduce, t_accept, t_backup;
   std::vector<int> bs_form;
   size_t max_tasks = 0;
   std::vector<BatchArgTable*> tables() {
-    std::vector<BatchArgTable*> v = {&t_lm, &t_lm_tail, &t_zero, &t_pairs, &t_asm_set, &t_asm_seg, &t_gn, &t_chol, &t_bs[0], &t_bs[1], &t_bs[2], &t_bs[3],
+    std::vector<BatchArgTable*> v = {&t_lm, &t_lm_tail, &t_zero, &t_pairs, &t_pairs_band, &t_asm_set, &t_asm_seg, &t_gn, &t_chol, &t_bs[0], &t_bs[1], &t_bs[2], &t_bs[3],
                                      &t_backsub, &t_small_mcc, &t_reduce, &t_accept, &t_backup};
     for (int i = 0; i < 3; ++i) { v.push_back(&t_eval_vis[i]); v.push_back(&t_eval_rel[i]); v.push_back(&t_eval_set[i]); v.push_back(&t_eval_marg[i]); }
     v.push_back(&t_marg_asm); v.push_back(&t_marg_mcc); v.push_back(&t_idp_lm); v.push_back(&t_idp_view); v.push_back(&t_idp_pairs); v.push_back(&t_idp_backsub);
@@ -225,9 +225,11 @@ bool build_plan(BatchPlan& P, bsgpu_ctx* const* ctxs, int n, const bsgpu_options
     batchargs_idp_backsub(P.t_idp_backsub, c->idp, c->d_ytan, c->d_delta);
     SmallGroupSet set, set2;
     int taken = 0, units = 0, taken2 = 0, units2 = 0;
-    if (c->vis.n_seg > 0) units = small_assemble_first_set(c->small_factorwise + 2, kNumInternal - 2, &set, &taken);
+    const bool band = c->vis.n_band_units > 0;
+    if (c->vis.n_seg > 0 || band) units = small_assemble_first_set(c->small_factorwise + 2, kNumInternal - 2, &set, &taken);
     if (units == 0) taken = 0;
-    batchargs_pairs(P.t_pairs, c->vis, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_dpos, units > 0 ? &set : nullptr, units);
+    batchargs_pairs_band(P.t_pairs_band, c->vis, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_dpos, (units > 0 && band) ? &set : nullptr, band ? units : 0);
+    batchargs_pairs(P.t_pairs, c->vis, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_dpos, (units > 0 && !band) ? &set : nullptr, band ? 0 : units);
     if (units == 0 && c->n_sa_seg + c->n_asm_grp > 0) units2 = small_assemble_first_set(c->small_factorwise + 2, kNumInternal - 2, &set2, &taken2);
     if (units2 == 0) taken2 = 0;
     if (!batchargs_small_assemble_set(P.t_asm_set, c->small_factorwise + 2 + taken + taken2, kNumInternal - 2 - taken - taken2, c->d_S, c->npad, c->plan.rhs_row, c->d_grad,
@@ -342,6 +344,7 @@ void enqueue_round(BatchPlan& P, std::vector<BatchWin>& L, const std::vector<int
   launch_landmark_batch(s, P.t_lm, P.t_lm_tail, dd, BL_ALL, d.n[BL_ALL]);
   launch_idp_landmark_batch(s, P.t_idp_lm, P.t_idp_view, dd, BL_ALL, d.n[BL_ALL]);
   launch_idp_pairs_batch(s, P.t_idp_pairs, dd, BL_ALL, d.n[BL_ALL]);
+  launch_pairs_band_batch(s, P.t_pairs_band, dd, BL_ALL, d.n[BL_ALL]);
   launch_pairs_batch(s, P.t_pairs, dd, BL_ALL, d.n[BL_ALL]);
   launch_small_assemble_set_batch(s, P.t_asm_set, dd, BL_ALL, d.n[BL_ALL]);
   launch_small_assemble_seg_batch(s, P.t_asm_seg, dd, BL_ALL, d.n[BL_ALL]);

@@ -3,9 +3,19 @@
 #include <atomic>
 
 #include "bsgpu_ctx.h"
+#include "band_plan.h"
 #include "dim_order.h"
 
 namespace bsg {
+
+// landmarks per unit of pairs_band_kernel.  A unit ends with up to 6 400 atomic adds into S and the device completes ~75 G of them a second
+// whoever issues them, so a first camera pose's landmarks stay ONE unit unless that leaves most compute units without work.
+int band_part_size(int n_band_lm, int n_cam_pose) {
+  static const int forced = [] { const char* e = getenv("BSGPU_BAND_PART"); return e ? atoi(e) : 0; }();
+  if (forced > 0) return forced;
+  (void)n_cam_pose;
+  return std::max(64, n_band_lm / 128);
+}
 
 namespace {
 void eigen_quat_to_rot(const double* q, double* R) {
@@ -217,6 +227,9 @@ int finalize(bsgpu_ctx* c) {
   }
   std::map<std::tuple<int, int, int>, int> derived_cam;
 
+  // band landmarks on the matrix cores (k_band.hip) unless BSGPU_PAIRS_BAND=0 (every pair by entries: the cross-check)
+  const char* band_env = getenv("BSGPU_PAIRS_BAND");
+  const bool band_on = !(band_env && !strcmp(band_env, "0"));
   const bool sort_entries = getenv("BSGPU_PAIR_ENTRIES_SORT") != nullptr;   // (tests: the path windows of more than 2 896 camera poses take)
   // ---- visual factors: camera-pose ids, factors sorted by landmark, pair entries, tile adjacency.
   // Large plain windows are flattened on the device (k_flatten.hip); everything else — and any window the device
@@ -340,17 +353,33 @@ int finalize(bsgpu_ctx* c) {
     for (int l = 0; l < nl; ++l) lm_start[l + 1] += lm_start[l];
     V.n_elim = n_elim;
     lap("camera-pose ids");
+    // band landmarks (band_plan.h): no pair entries — everything they add to the reduced system is pairs_band_kernel's
+    std::vector<int> b_cmin(nl, -1), b_mask(nl, 0);
+    std::vector<int4> b_rec;
+    if (band_on && nl > 0) band_classify_host(nl, lm_start.data(), cam_pose.data(), b_cmin, b_mask, b_rec);
+    BandUnits bu;
+    {
+      int n_band = 0;
+      for (int l = 0; l < nl; ++l) n_band += b_cmin[l] >= 0;
+      band_units(nl, b_cmin.data(), b_mask.data(), V.n_cam_pose, band_part_size(n_band, V.n_cam_pose), bu);
+    }
+    std::vector<int4> b_lm(bu.lm.size());
+    for (size_t i = 0; i < bu.lm.size(); ++i) b_lm[i] = b_rec[bu.lm[i]];
+    V.n_band_lm = (int)bu.lm.size(); V.n_band_units = (int)bu.unit_cam.size();
+    lap("band landmarks");
     // pair entries (factor a, factor b) of every landmark, grouped by camera-pose pair (ca <= cb); inside a group the
     // order is landmark-major.  Two passes over the landmarks: count per pair key, then fill in place.
     const uint64_t ncp = (uint64_t)std::max(1, V.n_cam_pose);
     std::vector<int> seg_ci, seg_cj, seg_start, ent_fa, ent_fb;
     if (ncp * ncp <= (uint64_t)8 << 20 && !sort_entries) {
       std::vector<int> start(ncp * ncp + 1, 0);
-      for (int l = 0; l < nl; ++l)
+      for (int l = 0; l < nl; ++l) {
+        if (b_cmin[l] >= 0) continue;
         for (int a = lm_start[l]; a < lm_start[l + 1]; ++a) {
           const uint64_t ra = (uint64_t)cam_pose[a] * ncp;
           for (int b = lm_start[l]; b < lm_start[l + 1]; ++b) if (cam_pose[a] <= cam_pose[b]) start[ra + cam_pose[b] + 1]++;
         }
+      }
       for (int f = n_elim; f < nv; ++f) start[(uint64_t)cam_pose[f] * ncp + cam_pose[f] + 1]++;
       for (size_t i = 0; i < ncp * ncp; ++i) start[i + 1] += start[i];
       const size_t n_ent = (size_t)start[ncp * ncp];
@@ -360,22 +389,26 @@ int finalize(bsgpu_ctx* c) {
       for (uint64_t key = 0; key < ncp * ncp; ++key)
         for (int p0 = start[key]; p0 < start[key + 1]; p0 += kPairChunk) { seg_ci.push_back((int)(key / ncp)); seg_cj.push_back((int)(key % ncp)); seg_start.push_back(p0); }
       std::vector<int> pos(start.begin(), start.end() - 1);
-      for (int l = 0; l < nl; ++l)
+      for (int l = 0; l < nl; ++l) {
+        if (b_cmin[l] >= 0) continue;
         for (int a = lm_start[l]; a < lm_start[l + 1]; ++a) {
           const uint64_t ra = (uint64_t)cam_pose[a] * ncp;
           for (int b = lm_start[l]; b < lm_start[l + 1]; ++b)
             if (cam_pose[a] <= cam_pose[b]) { const int p = pos[ra + cam_pose[b]]++; ent_fa[p] = a; ent_fb[p] = b; }
         }
+      }
       for (int f = n_elim; f < nv; ++f) { const int p = pos[(uint64_t)cam_pose[f] * ncp + cam_pose[f]]++; ent_fa[p] = f; ent_fb[p] = f; }
       lap("fill pair entries");
     } else {   // very many camera poses: comparison sort of explicit entries
       struct Ent { uint64_t key; int fa, fb; };
       std::vector<Ent> ents;
       ents.reserve((size_t)nv * 5);
-      for (int l = 0; l < nl; ++l)
+      for (int l = 0; l < nl; ++l) {
+        if (b_cmin[l] >= 0) continue;
         for (int a = lm_start[l]; a < lm_start[l + 1]; ++a)
           for (int b = lm_start[l]; b < lm_start[l + 1]; ++b)
             if (cam_pose[a] <= cam_pose[b]) ents.push_back({(uint64_t)cam_pose[a] * ncp + cam_pose[b], a, b});
+      }
       for (int f = n_elim; f < nv; ++f) ents.push_back({(uint64_t)cam_pose[f] * ncp + cam_pose[f], f, f});
       std::stable_sort(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) { return x.key < y.key; });
       ent_fa.resize(ents.size()); ent_fb.resize(ents.size());
@@ -395,6 +428,7 @@ int finalize(bsgpu_ctx* c) {
     V.cp_tq = c->upload(cp_tq); V.cp_tp = c->upload(cp_tp);
     V.seg_ci = c->upload(seg_ci); V.seg_cj = c->upload(seg_cj); V.seg_start = c->upload(seg_start);
     V.ent_fa = c->upload(ent_fa); V.ent_fb = c->upload(ent_fb);
+    V.band_lm = c->upload(b_lm); V.band_unit_start = c->upload(bu.unit_start); V.band_unit_cam = c->upload(bu.unit_cam);
     // structural tile adjacency of the reduced system (natural 64-wide tiles) for the Cholesky plan
     const int T = (c->n_pose + 63) / 64;
     c->tile_adj.assign((size_t)T * T, 0);
@@ -410,6 +444,14 @@ int finalize(bsgpu_ctx* c) {
       const int ri[2] = {cp_tq[i], cp_tp[i]}, rj[2] = {cp_tq[j], cp_tp[j]};
       for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) touch(ri[a], rj[b]);
     }
+    // (the camera-pose pairs of the band landmarks have no segments: BandUnits::adj)
+    for (int i = 0; i < V.n_cam_pose && V.n_band_lm > 0; ++i)
+      for (int d = 0; d < kBandCams; ++d) {
+        if (!((bu.adj[i] >> d) & 1u)) continue;
+        const int j = i + d;
+        const int ri[2] = {cp_tq[i], cp_tp[i]}, rj[2] = {cp_tq[j], cp_tp[j]};
+        for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) touch(ri[a], rj[b]);
+      }
   }
     return BSGPU_OK;
   };
@@ -438,7 +480,7 @@ int finalize(bsgpu_ctx* c) {
         const FlattenResident res = {mir.d_idx, mir.d_consts, mir.d_lk, mir.d_la, mir.d_s2b};
         const int st = flatten_visual_device(c->stream, dalloc, g0.n, g0.idx.data(), g0.consts.data(), g0.loss_kind.data(), g0.loss_a.data(),
                                              losses, nb, d_bx, d_bt, d_bc, d_bl, nl, T, c->vis, &c->d_vis_src, c->tile_adj, &all_const,
-                                             resident ? &res : nullptr, bg.nbk ? &segs_host : nullptr);
+                                             resident ? &res : nullptr, bg.nbk ? &segs_host : nullptr, band_on);
         if (st < 0) return fail(c, BSGPU_ERR_DEVICE, "device error while flattening the reprojection factors");
         if (st == 0) {
           flattened_on_device = true;

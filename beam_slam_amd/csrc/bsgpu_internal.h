@@ -31,6 +31,9 @@ constexpr int kJAStride = 12;
 // entries of one camera pair are cut into segments of at most this many (one single-wave workgroup of pairs_kernel each);
 // a power of two.  Host and device flattening must agree (their tables are compared bit for bit).
 constexpr int kPairChunk = 256;
+// a landmark whose observations lie within this many consecutive camera poses (every feature track of a sliding window), one per camera
+// pose, is a BAND landmark: its whole contribution to the reduced system is formed by pairs_band_kernel (k_band.hip), it has no pair entries
+constexpr int kBandCams = 13;
 
 // meta word of a reprojection factor: camera id | loss id | constant-block flags
 constexpr int kMetaCamBits = 12, kMetaLossBits = 12;
@@ -116,6 +119,10 @@ struct Visual {
   int n_seg = 0, n_ent = 0;
   int* seg_ci = nullptr; int* seg_cj = nullptr; int* seg_start = nullptr;
   int* ent_fa = nullptr; int* ent_fb = nullptr;
+  // band landmarks (band_plan.h): units = (first camera pose k0, a part of its landmarks by falling span); one record per landmark, in
+  // unit order: (first factor row, slot mask | span << 16 | observations << 24, observation index of slot j in nibble j of z | w << 32, 15 = none)
+  int n_band_units = 0, n_band_lm = 0;
+  int* band_unit_start = nullptr; int* band_unit_cam = nullptr; int4* band_lm = nullptr;
   // outputs
   double2* r = nullptr;       // n
   double* J = nullptr;        // robustified Jacobian, split by consumer: pose part n x 12 ([A row 0 (theta, t: 6) | A row 1]) ...
@@ -293,6 +300,9 @@ void launch_landmark_batch(hipStream_t s, const BatchArgTable& t, const BatchArg
 void batchargs_pairs(BatchArgTable& t, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm, const SmallGroupSet* small,
                      int n_small_units);
 void launch_pairs_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n);
+void batchargs_pairs_band(BatchArgTable& t, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm, const SmallGroupSet* small,
+                          int n_small_units);
+void launch_pairs_band_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n);
 void batchargs_backsub_mcc(BatchArgTable& t, const Visual& v, int n_pose, const double* y_pose, double* delta, double* mcc_part, const SmallGroupSet* small,
                            int n_small_units, const UpdateRide* upd);
 void launch_backsub_mcc_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n);
@@ -347,6 +357,8 @@ void launch_landmark(hipStream_t s, const Visual& v, int n_pose, const double* r
                      double* grad, const ZeroStep* zero = nullptr, double radius_val = 0.0);
 void launch_pairs(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm,
                   bool grad_only, const SmallGroupSet* small = nullptr, int n_small_units = 0);
+void launch_pairs_band(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm,
+                       bool grad_only, const SmallGroupSet* small = nullptr, int n_small_units = 0);
 int small_assemble_first_set(const SmallGroup* groups, int n_groups, SmallGroupSet* set, int* n_taken);
 void launch_small_assemble_set(hipStream_t s, const SmallGroup* groups, int n_groups, double* S, int ld, int rhs_row, double* grad,
                                double* hdiag, const int* perm);
@@ -412,7 +424,7 @@ int flatten_visual_device(hipStream_t s, const std::function<void*(size_t)>& dal
                           const int* h_loss_kind, const double* h_loss_a, const std::vector<DevLoss>& losses, int nb, const int* d_blk_xoff,
                           const int* d_blk_toff, const unsigned char* d_blk_const, const int* d_blk_lm, int nl, int T, Visual& V,
                           int** d_vis_src, std::vector<unsigned char>& tile_adj, bool* any_all_const, const FlattenResident* res = nullptr,
-                          FlattenSegsHost* segs_out = nullptr);
+                          FlattenSegsHost* segs_out = nullptr, bool band_enabled = true);
 int chol_vinv_stride();
 void chol_prepare();  // one-time function attributes (kept out of captured sequences)
 // block-sparse PCG path (k_pcg.hip)

@@ -267,9 +267,11 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
     // (the factor-wise assembled pose-only groups ride in the pair launch when there is one; further groups, or all of them, go by themselves)
     SmallGroupSet set;
     int taken = 0, units = 0;
-    if (c->vis.n_seg > 0) units = small_assemble_first_set(c->small_factorwise + 2, kNumInternal - 2, &set, &taken);
+    const bool band = c->vis.n_band_units > 0;   // (band landmarks: k_band.hip; what does not qualify keeps its pair entries)
+    if (c->vis.n_seg > 0 || band) units = small_assemble_first_set(c->small_factorwise + 2, kNumInternal - 2, &set, &taken);
     if (units == 0) taken = 0;
-    launch_pairs(s, c->vis, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_dpos, gradient_only, units > 0 ? &set : nullptr, units);
+    if (band) launch_pairs_band(s, c->vis, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_dpos, gradient_only, units > 0 ? &set : nullptr, units);
+    launch_pairs(s, c->vis, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_dpos, gradient_only, (units > 0 && !band) ? &set : nullptr, band ? 0 : units);
     phase_mark(c, BSGPU_PHASE_PAIRS);
     // (... or, without a pair launch, in the launch of the segment-wise assembled groups)
     SmallGroupSet set2;

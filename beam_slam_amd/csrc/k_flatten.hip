@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "bsgpu_device.h"
+#include "band_plan.h"
 
 namespace bsg {
 
@@ -80,19 +81,37 @@ __global__ void fl_gather_kernel(int n, const int* __restrict__ order, const int
   if (lm >= 0) atomicAdd(&lm_cnt[lm], 1);
 }
 
-// pair entries of a landmark: (a, b) over its factors with cam(a) <= cam(b), a-major (the host loop's order)
-__global__ void fl_pair_count_kernel(int nl, const int* __restrict__ lm_start, const int* __restrict__ cam_pose, int* __restrict__ cnt) {
+// band landmarks (band_plan.h: band_record is the rule, on either side): first camera pose or -1, mask of the slots seen, the record
+__global__ void fl_band_kernel(int nl, const int* __restrict__ lm_start, const int* __restrict__ cam_pose, int enabled, int* __restrict__ cmin,
+                               int* __restrict__ mask, int4* __restrict__ rec) {
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= nl) return;
+  int cm = -1;
+  int4 rc = make_int4(0, 0, -1, -1);
+  if (enabled) band_record(lm_start[l], lm_start[l + 1], cam_pose, &cm, &rc);
+  cmin[l] = cm; mask[l] = cm >= 0 ? (rc.y & 0xffff) : 0; rec[l] = rc;
+}
+__global__ void fl_band_gather_kernel(int n, const int* __restrict__ order, const int4* __restrict__ rec, int4* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = rec[order[i]];
+}
+
+// pair entries of a landmark: (a, b) over its factors with cam(a) <= cam(b), a-major (the host loop's order); a band landmark has none
+__global__ void fl_pair_count_kernel(int nl, const int* __restrict__ lm_start, const int* __restrict__ cam_pose, const int* __restrict__ cmin,
+                                     int* __restrict__ cnt) {
   const int l = blockIdx.x * 256 + threadIdx.x;
   if (l >= nl) return;
   int n = 0;
-  for (int a = lm_start[l]; a < lm_start[l + 1]; ++a)
-    for (int b = lm_start[l]; b < lm_start[l + 1]; ++b) n += cam_pose[a] <= cam_pose[b];
+  if (cmin[l] < 0)
+    for (int a = lm_start[l]; a < lm_start[l + 1]; ++a)
+      for (int b = lm_start[l]; b < lm_start[l + 1]; ++b) n += cam_pose[a] <= cam_pose[b];
   cnt[l] = n;
 }
-__global__ void fl_pair_gen_kernel(int nl, const int* __restrict__ lm_start, const int* __restrict__ cam_pose, const int* __restrict__ off,
-                                   unsigned long long ncp, unsigned long long* __restrict__ key, unsigned long long* __restrict__ val) {
+__global__ void fl_pair_gen_kernel(int nl, const int* __restrict__ lm_start, const int* __restrict__ cam_pose, const int* __restrict__ cmin,
+                                   const int* __restrict__ off, unsigned long long ncp, unsigned long long* __restrict__ key,
+                                   unsigned long long* __restrict__ val) {
   const int l = blockIdx.x * 256 + threadIdx.x;
-  if (l >= nl) return;
+  if (l >= nl || cmin[l] >= 0) return;
   int o = off[l];
   for (int a = lm_start[l]; a < lm_start[l + 1]; ++a)
     for (int b = lm_start[l]; b < lm_start[l + 1]; ++b)
@@ -166,7 +185,7 @@ int flatten_visual_device(hipStream_t s, const std::function<void*(size_t)>& dal
                           const int* h_loss_kind, const double* h_loss_a, const std::vector<DevLoss>& losses, int nb, const int* d_blk_xoff,
                           const int* d_blk_toff, const unsigned char* d_blk_const, const int* d_blk_lm, int nl, int T, Visual& V,
                           int** d_vis_src, std::vector<unsigned char>& tile_adj, bool* any_all_const, const FlattenResident* res,
-                          FlattenSegsHost* segs_out) {
+                          FlattenSegsHost* segs_out, bool band_enabled) {
   auto A = [&](size_t bytes) { return dalloc(bytes ? bytes : 8); };
 #define FL_CHK(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); return -1; } } while (0)
   const int g256 = (n + 255) / 256;
@@ -238,12 +257,40 @@ int flatten_visual_device(hipStream_t s, const std::function<void*(size_t)>& dal
   size_t tmp2_bytes = need2 > tmp_bytes ? need2 : tmp_bytes;
   if (!d_tmp2) return -1;
   FL_CHK(rocprim::exclusive_scan(d_tmp2, tmp2_bytes, d_lmcnt, V.lm_start, 0, (size_t)nl + 1, rocprim::plus<int>(), s));
-  if (nl > 0) hipLaunchKernelGGL(fl_pair_count_kernel, dim3((nl + 255) / 256), dim3(256), 0, s, nl, V.lm_start, V.cam_pose, d_pcnt);
+  int *d_bcmin = (int*)A(sizeof(int) * ((size_t)nl + 1)), *d_bmask = (int*)A(sizeof(int) * ((size_t)nl + 1));
+  int4* d_brec = (int4*)A(sizeof(int4) * ((size_t)nl + 1));
+  if (!d_bcmin || !d_bmask || !d_brec) return -1;
+  std::vector<int> h_bcmin(nl), h_bmask(nl);
+  if (nl > 0) {
+    hipLaunchKernelGGL(fl_band_kernel, dim3((nl + 255) / 256), dim3(256), 0, s, nl, V.lm_start, V.cam_pose, band_enabled ? 1 : 0, d_bcmin, d_bmask, d_brec);
+    hipLaunchKernelGGL(fl_pair_count_kernel, dim3((nl + 255) / 256), dim3(256), 0, s, nl, V.lm_start, V.cam_pose, d_bcmin, d_pcnt);
+    FL_CHK(hipMemcpyAsync(h_bcmin.data(), d_bcmin, sizeof(int) * (size_t)nl, hipMemcpyDeviceToHost, s));
+    FL_CHK(hipMemcpyAsync(h_bmask.data(), d_bmask, sizeof(int) * (size_t)nl, hipMemcpyDeviceToHost, s));
+  }
   FL_CHK(rocprim::exclusive_scan(d_tmp2, tmp2_bytes, d_pcnt, d_poff, 0, (size_t)nl + 1, rocprim::plus<int>(), s));
   int h_nelim = 0, h_npairs = 0;
   FL_CHK(hipMemcpyAsync(&h_nelim, V.lm_start + nl, sizeof(int), hipMemcpyDeviceToHost, s));
   FL_CHK(hipMemcpyAsync(&h_npairs, d_poff + nl, sizeof(int), hipMemcpyDeviceToHost, s));
-  FL_CHK(hipStreamSynchronize(s));                                  // sync #2: entry count
+  FL_CHK(hipStreamSynchronize(s));                                  // sync #2: entry count, band landmarks
+  // units of the band kernel: a counting sort of the landmarks on the host (band_plan.h) while the device sorts the pair entries
+  BandUnits bu;
+  {
+    int n_band = 0;
+    for (int l = 0; l < nl; ++l) n_band += h_bcmin[l] >= 0;
+    band_units(nl, h_bcmin.data(), h_bmask.data(), h_ncp, band_part_size(n_band, h_ncp), bu);
+  }
+  V.n_band_lm = (int)bu.lm.size(); V.n_band_units = (int)bu.unit_cam.size();
+  V.band_lm = (int4*)A(sizeof(int4) * bu.lm.size()); V.band_unit_start = (int*)A(sizeof(int) * bu.unit_start.size());
+  V.band_unit_cam = (int*)A(sizeof(int) * bu.unit_cam.size());
+  int* d_border = (int*)A(sizeof(int) * bu.lm.size());
+  if (!V.band_lm || !V.band_unit_start || !V.band_unit_cam || !d_border) return -1;
+  // (pageable sources that live to the end of this function, past the last synchronisation)
+  if (!bu.lm.empty()) {
+    FL_CHK(hipMemcpyAsync(d_border, bu.lm.data(), sizeof(int) * bu.lm.size(), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(fl_band_gather_kernel, dim3(((int)bu.lm.size() + 255) / 256), dim3(256), 0, s, (int)bu.lm.size(), d_border, d_brec, V.band_lm);
+  }
+  FL_CHK(hipMemcpyAsync(V.band_unit_start, bu.unit_start.data(), sizeof(int) * bu.unit_start.size(), hipMemcpyHostToDevice, s));
+  if (!bu.unit_cam.empty()) FL_CHK(hipMemcpyAsync(V.band_unit_cam, bu.unit_cam.data(), sizeof(int) * bu.unit_cam.size(), hipMemcpyHostToDevice, s));
   V.n_elim = h_nelim;
   const int n_ent = h_npairs + (n - h_nelim);
   V.n_ent = n_ent;
@@ -256,7 +303,7 @@ int flatten_visual_device(hipStream_t s, const std::function<void*(size_t)>& dal
   int* d_segsel = (int*)A(sizeof(int) * ((size_t)n_ent + 1));
   int* d_nseg = (int*)A(sizeof(int) * 2);
   if (!d_ek || !d_ev || !d_ek2 || !d_ev2 || !V.ent_fa || !V.ent_fb || !d_runidx || !d_runstart || !d_segflag || !d_segsel || !d_nseg) return -1;
-  if (nl > 0) hipLaunchKernelGGL(fl_pair_gen_kernel, dim3((nl + 255) / 256), dim3(256), 0, s, nl, V.lm_start, V.cam_pose, d_poff, ncp, d_ek, d_ev);
+  if (nl > 0 && h_npairs > 0) hipLaunchKernelGGL(fl_pair_gen_kernel, dim3((nl + 255) / 256), dim3(256), 0, s, nl, V.lm_start, V.cam_pose, d_bcmin, d_poff, ncp, d_ek, d_ev);
   if (n > h_nelim) hipLaunchKernelGGL(fl_pair_tail_kernel, dim3((n - h_nelim + 255) / 256), dim3(256), 0, s, h_nelim, n, V.cam_pose, ncp, h_npairs, d_ek, d_ev);
   int kbits = 1;
   while (kbits < 64 && (ncp * ncp) >> kbits) ++kbits;
@@ -292,19 +339,38 @@ int flatten_visual_device(hipStream_t s, const std::function<void*(size_t)>& dal
                      V.cp_tp, d_adj, T);
   tile_adj.assign((size_t)T * T, 0);
   if (T > 0) FL_CHK(hipMemcpyAsync(tile_adj.data(), d_adj, (size_t)T * T, hipMemcpyDeviceToHost, s));
-  if (segs_out) {   // the camera-pose pairs themselves, for the block-level ordering of the reduced system (dim_order.h)
-    segs_out->seg_ci.resize(h_nseg); segs_out->seg_cj.resize(h_nseg); segs_out->cp_tq.resize(h_ncp); segs_out->cp_tp.resize(h_ncp);
+  // the camera-pose pairs themselves, for the block-level ordering of the reduced system (dim_order.h); the pairs of the band landmarks
+  // have no segments: they come from BandUnits::adj, as further (i, j) pairs and as marks of the tile adjacency
+  std::vector<int> h_tq, h_tp;
+  const bool want_cp = segs_out || V.n_band_lm > 0;
+  if (segs_out) {
+    segs_out->seg_ci.resize(h_nseg); segs_out->seg_cj.resize(h_nseg);
     if (h_nseg > 0) {
       FL_CHK(hipMemcpyAsync(segs_out->seg_ci.data(), V.seg_ci, sizeof(int) * (size_t)h_nseg, hipMemcpyDeviceToHost, s));
       FL_CHK(hipMemcpyAsync(segs_out->seg_cj.data(), V.seg_cj, sizeof(int) * (size_t)h_nseg, hipMemcpyDeviceToHost, s));
     }
-    if (h_ncp > 0) {
-      FL_CHK(hipMemcpyAsync(segs_out->cp_tq.data(), V.cp_tq, sizeof(int) * (size_t)h_ncp, hipMemcpyDeviceToHost, s));
-      FL_CHK(hipMemcpyAsync(segs_out->cp_tp.data(), V.cp_tp, sizeof(int) * (size_t)h_ncp, hipMemcpyDeviceToHost, s));
-    }
+  }
+  if (want_cp && h_ncp > 0) {
+    h_tq.resize(h_ncp); h_tp.resize(h_ncp);
+    FL_CHK(hipMemcpyAsync(h_tq.data(), V.cp_tq, sizeof(int) * (size_t)h_ncp, hipMemcpyDeviceToHost, s));
+    FL_CHK(hipMemcpyAsync(h_tp.data(), V.cp_tp, sizeof(int) * (size_t)h_ncp, hipMemcpyDeviceToHost, s));
   }
   FL_CHK(hipStreamSynchronize(s));
   FL_CHK(hipGetLastError());
+  for (int i = 0; i < h_ncp && V.n_band_lm > 0; ++i)
+    for (int d = 0; d < kBandCams; ++d) {
+      if (!((bu.adj[i] >> d) & 1u)) continue;
+      const int j = i + d;
+      if (segs_out) { segs_out->seg_ci.push_back(i); segs_out->seg_cj.push_back(j); }
+      const int ri[2] = {h_tq[i], h_tp[i]}, rj[2] = {h_tq[j], h_tp[j]};
+      for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) {
+        if (ri[a] < 0 || rj[b] < 0) continue;
+        for (int x = ri[a]; x < ri[a] + 3; x += 2) for (int y = rj[b]; y < rj[b] + 3; y += 2) {
+          tile_adj[(size_t)(x / 64) * T + y / 64] = 1; tile_adj[(size_t)(y / 64) * T + x / 64] = 1;
+        }
+      }
+    }
+  if (segs_out) { segs_out->cp_tq = h_tq; segs_out->cp_tp = h_tp; }
 #undef FL_CHK
   return 0;
 }

@@ -116,9 +116,11 @@ __device__ __forceinline__ void landmark_kernel_body(const int bsg_bx, const int
   if (valid) { beg = lm_start[l]; end = lm_start[l + 1]; }
   double h00 = 0, h01 = 0, h02 = 0, h11 = 0, h12 = 0, h22 = 0, b0 = 0, b1 = 0, b2 = 0;
   for (int f = beg + sub; f < end; f += 8) {
-    const double* Jf = JB + (size_t)f * 6;
+    // (16-byte pieces: the 48-byte row is 16-byte aligned; a lane's six 8-byte loads were six look-ups of the same lines)
+    const double2* Jf2 = reinterpret_cast<const double2*>(JB + (size_t)f * 6);
     const double2 rf = r[f];
-    const double x0 = Jf[0], x1 = Jf[1], x2 = Jf[2], y0 = Jf[3], y1 = Jf[4], y2 = Jf[5];
+    const double2 ja = Jf2[0], jb = Jf2[1], jc = Jf2[2];
+    const double x0 = ja.x, x1 = ja.y, x2 = jb.x, y0 = jb.y, y1 = jc.x, y2 = jc.y;
     h00 += x0 * x0 + y0 * y0; h01 += x0 * x1 + y0 * y1; h02 += x0 * x2 + y0 * y2;
     h11 += x1 * x1 + y1 * y1; h12 += x1 * x2 + y1 * y2; h22 += x2 * x2 + y2 * y2;
     b0 += x0 * rf.x + y0 * rf.y; b1 += x1 * rf.x + y1 * rf.y; b2 += x2 * rf.x + y2 * rf.y;
@@ -162,16 +164,16 @@ __device__ __forceinline__ void landmark_kernel_body(const int bsg_bx, const int
     z_out[3 * l] = z0; z_out[3 * l + 1] = z1; z_out[3 * l + 2] = z2;
   }
   for (int f = beg + sub; f < end; f += 8) {
-    const double* Jf = JB + (size_t)f * 6;
+    const double2* Jf2 = reinterpret_cast<const double2*>(JB + (size_t)f * 6);
     const double2 rf = r[f];
-    double* o = CR + (size_t)f * 8;
+    double2* o2 = reinterpret_cast<double2*>(CR + (size_t)f * 8);
     // C[k][j] = sum_i B[k][i] Linv[j][i]
-    const double x0 = Jf[0], x1 = Jf[1], x2 = Jf[2], y0 = Jf[3], y1 = Jf[4], y2 = Jf[5];
+    const double2 ja = Jf2[0], jb = Jf2[1], jc = Jf2[2];
+    const double x0 = ja.x, x1 = ja.y, x2 = jb.x, y0 = jb.y, y1 = jc.x, y2 = jc.y;
     const double c00 = x0 * i00, c01 = x0 * i10 + x1 * i11, c02 = x0 * i20 + x1 * i21 + x2 * i22;
     const double c10 = y0 * i00, c11 = y0 * i10 + y1 * i11, c12 = y0 * i20 + y1 * i21 + y2 * i22;
-    o[0] = c00; o[1] = c01; o[2] = c02; o[3] = c10; o[4] = c11; o[5] = c12;
-    o[6] = rf.x - (c00 * z0 + c01 * z1 + c02 * z2);
-    o[7] = rf.y - (c10 * z0 + c11 * z1 + c12 * z2);
+    o2[0] = make_double2(c00, c01); o2[1] = make_double2(c02, c10); o2[2] = make_double2(c11, c12);
+    o2[3] = make_double2(rf.x - (c00 * z0 + c01 * z1 + c02 * z2), rf.y - (c10 * z0 + c11 * z1 + c12 * z2));
   }
 }
 __global__ __launch_bounds__(256) void landmark_kernel(int n_lm, const int* __restrict__ lm_start, const double* __restrict__ JB, const double2* __restrict__ r, int n_pose, const double* __restrict__ radius_ptr, int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* __restrict__ scale, double* __restrict__ dcl, double* __restrict__ grad, double* __restrict__ Linv_out, double* __restrict__ z_out, double* __restrict__ CR, int lm_blocks, ZeroStep zs, double radius_val) {
@@ -532,7 +534,11 @@ void launch_pairs(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row
 // TrustRegionMinimizer) with J d = -(A y_cam + B y_l): the rows are still in L1 and a launch of its own is saved.  Factors whose
 // landmark is constant (f >= n_elim) are handled one per lane by the workgroups after the landmark ones.
 // ---------------------------------------------------------------------------------------------------
-BSG_DEV void pose_part(const double* __restrict__ Jf, int tq, int tp, const double* __restrict__ y_pose, double& j0, double& j1) {
+BSG_DEV void pose_part(const double* __restrict__ Jf_row, int tq, int tp, const double* __restrict__ y_pose, double& j0, double& j1) {
+  // (the 96-byte row as six 16-byte pieces instead of twelve 8-byte loads)
+  const double2* J2 = reinterpret_cast<const double2*>(Jf_row);
+  const double2 v0 = J2[0], v1 = J2[1], v2 = J2[2], v3 = J2[3], v4 = J2[4], v5 = J2[5];
+  const double Jf[12] = {v0.x, v0.y, v1.x, v1.y, v2.x, v2.y, v3.x, v3.y, v4.x, v4.y, v5.x, v5.y};
   j0 = 0.0; j1 = 0.0;
   if (tq >= 0) {
 #pragma unroll
@@ -576,7 +582,9 @@ __device__ __forceinline__ void backsub_mcc_kernel_body(const int bsg_bx, const 
     double jk0[2] = {0.0, 0.0}, jk1[2] = {0.0, 0.0};
     int it = 0;
     for (int f = beg + sub; f < end; f += 8, ++it) {
-      const double* C = CR + (size_t)f * 8;
+      const double2* C2 = reinterpret_cast<const double2*>(CR + (size_t)f * 8);
+      const double2 ca = C2[0], cb = C2[1], cc = C2[2];
+      const double C[6] = {ca.x, ca.y, cb.x, cb.y, cc.x, cc.y};
       const int cp = cam_pose[f];
       double j0, j1;
       pose_part(J + (size_t)f * kJAStride, cp_tq[cp], cp_tp[cp], y_pose, j0, j1);
@@ -606,7 +614,9 @@ __device__ __forceinline__ void backsub_mcc_kernel_body(const int bsg_bx, const 
       }
       it = 0;
       for (int f = beg + sub; f < end; f += 8, ++it) {
-        const double* Bf = JB + (size_t)f * 6;
+        const double2* B2 = reinterpret_cast<const double2*>(JB + (size_t)f * 6);
+        const double2 ba = B2[0], bb = B2[1], bc = B2[2];
+        const double Bf[6] = {ba.x, ba.y, bb.x, bb.y, bc.x, bc.y};
         double j0, j1;
         if (it == 0) { j0 = jk0[0]; j1 = jk1[0]; }
         else if (it == 1) { j0 = jk0[1]; j1 = jk1[1]; }
