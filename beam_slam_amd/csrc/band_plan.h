@@ -48,8 +48,12 @@ struct BandUnits {
   std::vector<uint32_t> adj;          // per camera pose i: bit d set = some band landmark is seen from poses i and i + d (d < kBandCams)
 };
 
-// cmin / mask per landmark (cmin < 0: not a band landmark); part = landmarks per unit at most
-inline void band_units(int nl, const int* cmin, const int* mask, int ncp, int part, BandUnits& out) {
+// landmarks per unit, at most (BSGPU_BAND_PART forces a value)
+int band_part_forced();
+
+// cmin / mask per landmark (cmin < 0: not a band landmark).  One unit per first camera pose unless that leaves most of the device idle: a
+// unit ends with up to 6 400 atomic adds into S, whatever its size (two units per first camera pose on C2: 56 us against 50).
+inline void band_units(int nl, const int* cmin, const int* mask, int ncp, BandUnits& out) {
   out.lm.clear(); out.unit_start.clear(); out.unit_cam.clear();
   const size_t nc = (size_t)(ncp > 0 ? ncp : 1);
   out.adj.assign(nc, 0);
@@ -66,6 +70,8 @@ inline void band_units(int nl, const int* cmin, const int* mask, int ncp, int pa
   out.lm.resize(n);
   for (int l = 0; l < nl; ++l) if (cmin[l] >= 0) out.lm[start[key_of(l)]++] = l;
   out.unit_start.clear();
+  int part = band_part_forced();
+  if (part <= 0) part = n / 128 > 64 ? n / 128 : 64;
   // the pairs a mask couples, once per distinct (k0, mask): a window has a few masks per first camera pose
   std::vector<std::vector<unsigned>> seen(nc);
   int i = 0;
@@ -90,8 +96,5 @@ inline void band_units(int nl, const int* cmin, const int* mask, int ncp, int pa
   }
   out.unit_start.push_back(n);
 }
-
-// landmarks per unit: one unit per first camera pose unless that leaves most of the device idle (BSGPU_BAND_PART overrides)
-int band_part_size(int n_band_lm, int n_cam_pose);
 
 }  // namespace bsg

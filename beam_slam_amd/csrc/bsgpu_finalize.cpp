@@ -8,13 +8,9 @@
 
 namespace bsg {
 
-// landmarks per unit of pairs_band_kernel.  A unit ends with up to 6 400 atomic adds into S and the device completes ~75 G of them a second
-// whoever issues them, so a first camera pose's landmarks stay ONE unit unless that leaves most compute units without work.
-int band_part_size(int n_band_lm, int n_cam_pose) {
-  static const int forced = [] { const char* e = getenv("BSGPU_BAND_PART"); return e ? atoi(e) : 0; }();
-  if (forced > 0) return forced;
-  (void)n_cam_pose;
-  return std::max(64, n_band_lm / 128);
+int band_part_forced() {
+  const char* e = getenv("BSGPU_BAND_PART");   // (read at every finalize: tests/test_gpu_band.py changes it between solves)
+  return e ? atoi(e) : 0;
 }
 
 namespace {
@@ -358,11 +354,7 @@ int finalize(bsgpu_ctx* c) {
     std::vector<int4> b_rec;
     if (band_on && nl > 0) band_classify_host(nl, lm_start.data(), cam_pose.data(), b_cmin, b_mask, b_rec);
     BandUnits bu;
-    {
-      int n_band = 0;
-      for (int l = 0; l < nl; ++l) n_band += b_cmin[l] >= 0;
-      band_units(nl, b_cmin.data(), b_mask.data(), V.n_cam_pose, band_part_size(n_band, V.n_cam_pose), bu);
-    }
+    band_units(nl, b_cmin.data(), b_mask.data(), V.n_cam_pose, bu);
     std::vector<int4> b_lm(bu.lm.size());
     for (size_t i = 0; i < bu.lm.size(); ++i) b_lm[i] = b_rec[bu.lm[i]];
     V.n_band_lm = (int)bu.lm.size(); V.n_band_units = (int)bu.unit_cam.size();

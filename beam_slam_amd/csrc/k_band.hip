@@ -20,7 +20,6 @@
 // Landmarks that do not qualify (a span of more than kBandCams camera poses, two observations from one camera pose) and the factors of
 // constant landmarks keep their pair entries in pairs_kernel; the pose-only factors that rode in the pair launch ride here.
 #include <atomic>
-#include <cstdlib>
 
 #include "bsgpu_device.h"
 
@@ -36,7 +35,7 @@ constexpr int kBandNT = (15 + kBandWaves - 1) / kBandWaves;   // tiles of the lo
 static_assert((kBandPitch / 2) % 2 == 1 && 3 * kBandNL % 4 == 0 && 64 % kBandNL == 0 && kBandWaves * (64 / kBandNL) >= kBandCams, "band kernel shape");
 // 16-byte pieces per landmark in the stage (A: 6 per observation, C | rho: 4, r: 1; odd strides: the 16-byte reads of the forming lanes,
 // one landmark each, fall on different banks)
-constexpr int kBandStA = 6 * kBandCams + 1, kBandStC = 4 * kBandCams + 1, kBandStR = kBandCams;
+constexpr int kBandStA = 81, kBandStC = 65, kBandStR = 17;   // (>= 16 x 5, 16 x 4, 16: every loader thread stores every piece it requested, no conditions)
 constexpr size_t kBandLds = sizeof(double) * kBandRows * kBandPitch + sizeof(int) * kBandRows + 16 * (size_t)kBandNL * (kBandStA + kBandStC + kBandStR + 1);
 static_assert(kBandCams * 6 <= kBandRows && kBandCams <= 13, "slot nibbles, tile rows");
 static_assert(sizeof(double) * (15 * 30 + 16) + sizeof(int) * 16 <= kBandLds, "a riding pose-only factor's staging");
@@ -70,18 +69,10 @@ BSG_DEV int4 band_fetch_rec(const int4* __restrict__ band_lm, int li, int end) {
   }
 #define BSG_BAND_STAGE()                                                                                                      \
   {                                                                                                                           \
-    const int n_ = (int)((unsigned)prec.y >> 24);                                                                             \
     double2* a_ = sA + g * kBandStA; double2* c_ = sC + g * kBandStC; double2* rr_ = sR + g * kBandStR;                        \
-    if (l16 < 6 * n_) a_[l16] = pa0;                                                                                          \
-    if (l16 + 16 < 6 * n_) a_[l16 + 16] = pa1;                                                                                \
-    if (l16 + 32 < 6 * n_) a_[l16 + 32] = pa2;                                                                                \
-    if (l16 + 48 < 6 * n_) a_[l16 + 48] = pa3;                                                                                \
-    if (l16 + 64 < 6 * n_) a_[l16 + 64] = pa4;                                                                                \
-    if (l16 < 4 * n_) c_[l16] = pc0;                                                                                          \
-    if (l16 + 16 < 4 * n_) c_[l16 + 16] = pc1;                                                                                \
-    if (l16 + 32 < 4 * n_) c_[l16 + 32] = pc2;                                                                                \
-    if (l16 + 48 < 4 * n_) c_[l16 + 48] = pc3;                                                                                \
-    if (l16 < n_) rr_[l16] = pr0;                                                                                             \
+    a_[l16] = pa0; a_[l16 + 16] = pa1; a_[l16 + 32] = pa2; a_[l16 + 48] = pa3; a_[l16 + 64] = pa4;                             \
+    c_[l16] = pc0; c_[l16 + 16] = pc1; c_[l16 + 32] = pc2; c_[l16 + 48] = pc3;                                                 \
+    rr_[l16] = pr0;                                                                                                           \
     if (l16 == 0) sRec[g] = prec;                                                                                             \
   }
 
@@ -125,15 +116,15 @@ BSG_DEV void band_multiply(const unsigned (&za)[kBandNT], const unsigned (&zb)[k
 __device__ __forceinline__ void pairs_band_kernel_body(const int bsg_bx, const int bsg_gx, int n_units, const int* __restrict__ unit_start, const int* __restrict__ unit_cam, const int4* __restrict__ band_lm, int n_cam_pose, const double* __restrict__ J, const double2* __restrict__ r, const double* __restrict__ CR, const int* __restrict__ cp_tq, const int* __restrict__ cp_tp, double* __restrict__ S, int ld, int rhs_row, double* __restrict__ grad, double* __restrict__ hdiag, const int* __restrict__ perm, int grad_only, const SmallGroupSet& small, int n_small_units) {
   extern __shared__ __attribute__((aligned(16))) double bsm[];
   const int tid = threadIdx.x;
-  if (bsg_bx < n_small_units) {
-    if (grad_only & 32) return;
-    // the pose-only factors assembled one workgroup per factor (IMU: two or three hundred of them) as the FIRST workgroups of this launch:
-    // independent atomics into the same system, and a launch of their own cost ~8 us on the dependent path (as in pairs_kernel)
-    small_assemble_unit(small, bsg_bx, tid, kBandThreads, bsm, bsm + 15 * 30, reinterpret_cast<int*>(bsm + 15 * 30 + 16), S, ld, rhs_row, grad, hdiag, perm);
+  const int u = bsg_bx;
+  if (u >= n_units) {
+    // the pose-only factors assembled one workgroup per factor (IMU: two or three hundred of them) as extra workgroups of this launch:
+    // independent atomics into the same system, and a launch of their own cost ~8 us on the dependent path (as in pairs_kernel).  They come
+    // LAST: the units, each as long as the launch, start at once, and these fill the compute units the units leave free
+    if (u - n_units < n_small_units)
+      small_assemble_unit(small, u - n_units, tid, kBandThreads, bsm, bsm + 15 * 30, reinterpret_cast<int*>(bsm + 15 * 30 + 16), S, ld, rhs_row, grad, hdiag, perm);
     return;
   }
-  const int u = bsg_bx - n_small_units;
-  if (u >= n_units) return;
   double* Zs = bsm;
   int* pos = reinterpret_cast<int*>(bsm + kBandRows * kBandPitch);
   double2* sA = reinterpret_cast<double2*>(pos + kBandRows);
@@ -218,7 +209,7 @@ __device__ __forceinline__ void pairs_band_kernel_body(const int bsg_bx, const i
       const double Ca[3] = {BSG_SEL(c0.x), BSG_SEL(c0.y), BSG_SEL(c1.x)}, Cb[3] = {BSG_SEL(c1.y), BSG_SEL(c2.x), BSG_SEL(c2.y)};
       const double p0 = BSG_SEL(c3.x), p1 = BSG_SEL(c3.y), r0 = BSG_SEL(rr.x), r1 = BSG_SEL(rr.y);
 #undef BSG_SEL
-      if (slot_ok && !(grad_only & 8)) {
+      if (slot_ok) {
 #pragma unroll
         for (int m = 0; m < 6; ++m)
 #pragma unroll
@@ -234,7 +225,7 @@ __device__ __forceinline__ void pairs_band_kernel_body(const int bsg_bx, const i
     }
     const int top = __builtin_amdgcn_readfirstlane((sRec[0].y >> 16) & 0xff);   // span of the sub-batch's widest landmark (they are ordered by falling span)
     band_lds_sync();   // (Z is complete; every wave is done with the stage)
-    if (!(grad_only & 5)) {
+    if (!grad_only) {
       const int T = (6 * top + 15) >> 4;                        // tile rows that hold something (wave-uniform)
       int nact = 0;
 #pragma unroll
@@ -249,8 +240,8 @@ __device__ __forceinline__ void pairs_band_kernel_body(const int bsg_bx, const i
       }
     }
   }
-  // the unit's tiles out of S
-  if (!(grad_only & 3)) {
+  // the unit's tiles out of S: up to 6 400 atomic adds per unit, which the device completes at ~80 G a second whoever issues them
+  if (!(grad_only & 1)) {
 #pragma unroll
     for (int j = 0; j < kBandNT; ++j) {
       const int R = tR[j], C = tC[j];
@@ -396,7 +387,7 @@ void launch_pairs_band(hipStream_t s, const Visual& v, double* S, int ld, int rh
   none.n = 0;
   const int riders = small ? n_small_units : 0;
   hipLaunchKernelGGL(pairs_band_kernel, dim3(riders + v.n_band_units), dim3(kBandThreads), kBandLds, s, v.n_band_units, v.band_unit_start, v.band_unit_cam, v.band_lm,
-                     v.n_cam_pose, v.J, v.r, v.CR, v.cp_tq, v.cp_tp, S, ld, rhs_row, grad, hdiag, perm, (grad_only ? 1 : 0) | (getenv("BSGPU_BAND_DBG") ? atoi(getenv("BSGPU_BAND_DBG")) : 0), small ? *small : none, riders);
+                     v.n_cam_pose, v.J, v.r, v.CR, v.cp_tq, v.cp_tp, S, ld, rhs_row, grad, hdiag, perm, grad_only ? 1 : 0, small ? *small : none, riders);
 }
 void batchargs_pairs_band(BatchArgTable& t, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm, const SmallGroupSet* small,
                           int n_small_units) {

@@ -274,11 +274,7 @@ int flatten_visual_device(hipStream_t s, const std::function<void*(size_t)>& dal
   FL_CHK(hipStreamSynchronize(s));                                  // sync #2: entry count, band landmarks
   // units of the band kernel: a counting sort of the landmarks on the host (band_plan.h) while the device sorts the pair entries
   BandUnits bu;
-  {
-    int n_band = 0;
-    for (int l = 0; l < nl; ++l) n_band += h_bcmin[l] >= 0;
-    band_units(nl, h_bcmin.data(), h_bmask.data(), h_ncp, band_part_size(n_band, h_ncp), bu);
-  }
+  band_units(nl, h_bcmin.data(), h_bmask.data(), h_ncp, bu);
   V.n_band_lm = (int)bu.lm.size(); V.n_band_units = (int)bu.unit_cam.size();
   V.band_lm = (int4*)A(sizeof(int4) * bu.lm.size()); V.band_unit_start = (int*)A(sizeof(int) * bu.unit_start.size());
   V.band_unit_cam = (int*)A(sizeof(int) * bu.unit_cam.size());

@@ -1,0 +1,106 @@
+"""pairs_band_kernel (csrc/k_band.hip): the landmarks of feature tracks — all observations within 13 consecutive camera poses, one per
+camera pose — are taken through the reduced system as Z Z^T on the matrix cores; everything else keeps its pair entries (pairs_kernel).
+Both forms against each other (BSGPU_PAIRS_BAND=0: every pair by entries) and against the oracle, on windows that mix them:
+tracks with gaps, tracks longer than the band, two observations of a landmark from one camera pose, constant landmarks, held poses,
+every flattening path (bs_optimizers/src/fixed_lag_smoother.cpp:281 is what either form serves)."""
+import numpy as np
+import pytest
+
+from beam_slam_amd import capi, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _drop_and_duplicate(pr, rng, drop=0.15, dup=12):
+    """gaps in the tracks (observations dropped at random) and a few landmarks seen twice from one camera pose"""
+    idx, consts, lk, la = pr.factors[capi.F_REPROJ][0]
+    keep = rng.random(idx.shape[0]) >= drop
+    idx, consts, lk, la = idx[keep], consts[keep], lk[keep], la[keep]
+    pick = rng.choice(idx.shape[0], size=dup, replace=False)
+    c2 = consts[pick].copy()
+    c2[:, :2] += rng.normal(0, 1.0, (dup, 2)).round()
+    pr.factors[capi.F_REPROJ] = [(np.concatenate([idx, idx[pick]]), np.concatenate([consts, c2]), np.concatenate([lk, lk[pick]]),
+                                  np.concatenate([la, la[pick]]))]
+    return pr
+
+
+def _window(kind):
+    rng = np.random.default_rng(77)
+    if kind == "tracks":            # every landmark qualifies
+        return synthetic.vio_window(n_kf=30, n_lm=900, seed=51, track_min=2, track_max=12)
+    if kind == "long_tracks":       # spans of up to 20 key frames: the long ones keep their pair entries
+        return synthetic.vio_window(n_kf=40, n_lm=900, seed=52, track_min=2, track_max=20)
+    if kind == "gaps_and_stereo":
+        return _drop_and_duplicate(synthetic.vio_window(n_kf=26, n_lm=700, seed=53, track_min=3, track_max=16), rng)
+    if kind == "const_and_held":
+        pr = synthetic.vio_window(n_kf=24, n_lm=600, seed=54, track_min=2, track_max=13)
+        for b in pr.meta["lm_blocks"][::9]:
+            pr.is_const[int(b)] = 1
+        for b in pr.meta["kf_blocks"][5][:2]:     # a held pose in the middle of the tracks: its rows are not in the reduced system
+            pr.is_const[int(b)] = 1
+        return pr
+    if kind == "no_imu":            # visual-only window: no pose-only factors ride in the launch
+        return synthetic.vio_window(n_kf=16, n_lm=500, seed=55, with_imu=False)
+    raise ValueError(kind)
+
+
+def _run(pr, gpu_solver_cls, iters=6):
+    g = gpu_solver_cls(0)
+    pr.load(g)
+    o = g.options_vio()
+    o.max_num_iterations = iters
+    o.max_solver_time_in_seconds = 0.0
+    s = g.solve(o)
+    return s, [(i.cost, i.gradient_max_norm, i.step_norm, i.trust_region_radius) for i in g.iterations()], g.get_blocks()
+
+
+@pytest.mark.parametrize("kind", ["tracks", "long_tracks", "gaps_and_stereo", "const_and_held", "no_imu"])
+@pytest.mark.parametrize("flatten", ["host", "device"])
+def test_band_kernel_equals_pair_entries_and_oracle(oracle_cls, gpu_solver_cls, monkeypatch, kind, flatten):
+    pr = _window(kind)
+    monkeypatch.setenv("BSGPU_FLATTEN", flatten)
+    monkeypatch.setenv("BSGPU_PAIRS_BAND", "0")
+    s0, it0, x0 = _run(pr, gpu_solver_cls)
+    monkeypatch.delenv("BSGPU_PAIRS_BAND")
+    s1, it1, x1 = _run(pr, gpu_solver_cls)
+    assert s0.num_iterations == s1.num_iterations and s0.num_successful_steps == s1.num_successful_steps
+    a, b = np.array(it0), np.array(it1)
+    # the two forms add the same terms in another order: the trajectories agree to rounding (cost, gradient norm, step norm, radius)
+    assert np.allclose(a[:, 0], b[:, 0], rtol=1e-10) and np.allclose(a[:, 3], b[:, 3], rtol=1e-12)
+    assert np.allclose(a[:, 1], b[:, 1], rtol=1e-6, atol=1e-9) and np.allclose(a[:, 2], b[:, 2], rtol=1e-6, atol=1e-12)
+    assert np.abs(x0 - x1).max() < 1e-8
+    o = oracle_cls()
+    pr.load(o)
+    oo = o.options_vio()
+    oo.max_num_iterations = 6
+    oo.max_solver_time_in_seconds = 0.0
+    so = o.solve(oo)
+    assert abs(so.final_cost - s1.final_cost) <= 1e-9 * so.final_cost
+    assert np.abs(o.get_blocks() - x1).max() < 1e-6
+
+
+def test_gradient_only_step_and_iteration_budget(oracle_cls, gpu_solver_cls):
+    """the last iteration of a budget is a gradient-only step: the band launch then forms the per-camera sums alone (no products)"""
+    pr = _window("tracks")
+    for iters in (1, 2):
+        s, it, x = _run(pr, gpu_solver_cls, iters=iters)
+        o = oracle_cls()
+        pr.load(o)
+        oo = o.options_vio()
+        oo.max_num_iterations = iters
+        oo.max_solver_time_in_seconds = 0.0
+        so = o.solve(oo)
+        io = o.iterations()
+        assert len(io) == len(it)
+        assert np.allclose([i.cost for i in io], [i[0] for i in it], rtol=1e-10)
+        assert np.allclose([i.gradient_max_norm for i in io], [i[1] for i in it], rtol=1e-7)
+
+
+def test_band_units_of_several_parts(oracle_cls, gpu_solver_cls, monkeypatch):
+    """BSGPU_BAND_PART: a first camera pose's landmarks cut into several units (what a window of many landmarks per key frame gets)"""
+    pr = synthetic.vio_window(n_kf=12, n_lm=1500, seed=56, track_min=2, track_max=9)
+    s_ref, it_ref, x_ref = _run(pr, gpu_solver_cls)
+    for part in ("16", "40"):
+        monkeypatch.setenv("BSGPU_BAND_PART", part)
+        s, it, x = _run(pr, gpu_solver_cls)
+        assert np.allclose([i[0] for i in it], [i[0] for i in it_ref], rtol=1e-10) and np.abs(x - x_ref).max() < 1e-8
