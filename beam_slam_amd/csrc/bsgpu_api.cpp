@@ -129,6 +129,7 @@ void bsgpu_destroy(bsgpu_ctx* c) {
   if (c->h_arena) (void)hipHostFree(c->h_arena);
   if (c->h_radius) (void)hipHostFree(c->h_radius);
   if (c->h_pcg) (void)hipHostFree(c->h_pcg);
+  if (c->h_pcg_lazy) (void)hipHostFree(c->h_pcg_lazy);
   for (hipEvent_t e : c->pcg_ev) if (e) (void)hipEventDestroy(e);
   if (c->ev_reduce) (void)hipEventDestroy(c->ev_reduce);
   if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -217,6 +217,8 @@ struct bsgpu_ctx {
   double* h_radius = nullptr;  // pinned
   double* h_pcg = nullptr;     // pinned: two read-backs of the PCG scalars in flight (pcg_solve)
   hipEvent_t pcg_ev[2] = {nullptr, nullptr};
+  double* h_pcg_lazy = nullptr;   // pinned: the resident PCG launch's scalars, looked at with the step's other scalars (pcg_check)
+  bool pcg_check_pending = false;
   hipEvent_t ev_reduce = nullptr;   // recorded after the end-of-step reduction: what the host waits for (work may be queued behind it)
   bool ev_reduce_pending = false;
   int* d_reduce_counter = nullptr;  // final_reduce_kernel's ticket (the last workgroup stamps the host mirror with reduce_seq)

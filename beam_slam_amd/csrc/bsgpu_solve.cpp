@@ -36,9 +36,17 @@ void pcg_solve(bsgpu_ctx* c, const bsgpu_options& o) {
     const int ns = pcg_num_scalars();
     int expected = 0;
     if (g_pcg_persistent_in_flight.compare_exchange_strong(expected, 1)) {
-      double sc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       launch_pcg_coarse(s, c->pcg_persist, c->nbr, c->d_row_ptr, c->d_col, c->d_val, c->d_x);
       const bool launched = launch_pcg_persistent(s, c->pcg_persist, c->nbr, c->d_row_ptr, c->d_val, c->d_Minv, c->d_rhs, c->d_px, c->pcg_persist.zg, c->d_psc, tol2p, max_itp);
+      // Its verdict (done, iterations) is read with the step's other scalars, not here: a synchronisation at this point left the device idle
+      // for the host's round trip and the launches of the rest of the step, once per LM iteration (C4: ~25 of 690 us).  A launch that did
+      // not finish (its workgroups were not all scheduled: a shared device) makes pcg_check() ask for the step again, launch per iteration.
+      if (!c->h_pcg_lazy && hipHostMalloc((void**)&c->h_pcg_lazy, sizeof(double) * 8) != hipSuccess) { c->h_pcg_lazy = nullptr; (void)hipGetLastError(); }
+      if (launched && c->h_pcg_lazy && hipMemcpyAsync(c->h_pcg_lazy, c->d_psc, sizeof(double) * ns, hipMemcpyDeviceToHost, s) == hipSuccess) {
+        c->pcg_check_pending = true;   // (the guard stays taken until the verdict is read)
+        return;
+      }
+      double sc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       bool ok = launched && hipMemcpyAsync(sc, c->d_psc, sizeof(double) * ns, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
       g_pcg_persistent_in_flight.store(0);
       if (ok && sc[pcg_done_slot()] > 0.0) { c->pcg_iters_total += (int)sc[pcg_iters_slot()]; return; }
@@ -99,6 +107,19 @@ void pcg_solve(bsgpu_ctx* c, const bsgpu_options& o) {
     }
   }
   c->pcg_iters_total += (int)last[pcg_iters_slot()];
+}
+
+// after the step's scalars are on the host (the stream has passed the read-back queued behind the resident launch): its verdict.
+// false: the launch did not finish — the step's linear solve is void; the context takes the launch-per-iteration path from here on.
+bool pcg_check(bsgpu_ctx* c) {
+  if (!c->pcg_check_pending) return true;
+  c->pcg_check_pending = false;
+  g_pcg_persistent_in_flight.store(0);
+  const double done = c->h_pcg_lazy[pcg_done_slot()], iters = c->h_pcg_lazy[pcg_iters_slot()];
+  if (done > 0.0) { c->pcg_iters_total += (int)iters; return true; }
+  fprintf(stderr, "[bsgpu] the resident PCG launch was given up (done %g after %g iterations): launch-per-iteration path from here on\n", done, iters);
+  c->pcg_persist.G = 0;
+  return false;
 }
 
 // S y = rhs on the assembled reduced camera system by block-Jacobi PCG (ITERATIVE_SCHUR + SCHUR_JACOBI): same pipelined stop test
@@ -676,11 +697,13 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
   lm.t_start = t_start;
   run_step(c, o, STEP_FIRST, lm.radius);
   rc = fetch_scalars(c);
-  if (rc != BSGPU_OK) return rc;
+  if (rc != BSGPU_OK) { (void)pcg_check(c); return rc; }
+  bool pcg_redo = !pcg_check(c);
+  if (pcg_redo) c->h_scal[SC_CHOL_FAIL] = 2.0;   // (lm_state.h: the step is wanted again, at the same point and radius)
   fixed = c->any_inactive ? c->h_scal[SC_FIXED_COST] : 0.0;
-  lm.begin(c->h_scal, fixed, c->d_ftasks != nullptr);
+  lm.begin(c->h_scal, fixed, c->d_ftasks != nullptr || pcg_redo);
   while (!lm.done) {
-    if (lm.retry_timeout) {
+    if (lm.retry_timeout && !c->use_pcg) {
       // A wait inside one of the single-launch kernels (factorisation / back-substitution) timed out: the GPU is shared and their
       // workgroups were not scheduled in time — not a numerical failure.  This context takes the launch-per-step path from
       // here on, and the step is computed again at the same point and radius.
@@ -690,8 +713,10 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
     }
     run_step(c, o, lm.kind, lm.radius, lm.grad_only);
     rc = fetch_scalars(c);
-    if (rc != BSGPU_OK) return rc;
-    lm.advance(c->h_scal, c->cost_x_stale, c->d_ftasks != nullptr);
+    if (rc != BSGPU_OK) { (void)pcg_check(c); return rc; }
+    pcg_redo = !pcg_check(c);
+    if (pcg_redo) c->h_scal[SC_CHOL_FAIL] = 2.0;
+    lm.advance(c->h_scal, c->cost_x_stale, c->d_ftasks != nullptr || pcg_redo);
   }
   HIPCHK(c, hipEventRecord(ev1, s));
   HIPCHK(c, hipEventSynchronize(ev1));
