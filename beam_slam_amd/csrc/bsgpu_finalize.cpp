@@ -223,9 +223,13 @@ int finalize(bsgpu_ctx* c) {
   }
   std::map<std::tuple<int, int, int>, int> derived_cam;
 
-  // band landmarks on the matrix cores (k_band.hip) unless BSGPU_PAIRS_BAND=0 (every pair by entries: the cross-check)
+  // band landmarks on the matrix cores (k_band.hip) in windows of at least kBandMinFactors reprojection factors: a unit of that kernel is a
+  // first camera pose's landmarks, and a window of the reference's own size has too few of them per pose to fill the device (measured,
+  // LM it/s band / entries: 20 KF x 500 8 410 / 8 850, 50 x 5 000 6 390 / 6 500, 100 x 20 000 4 720 / 4 690, 200 x 50 000 3 310 / 3 140).
+  // BSGPU_PAIRS_BAND=0: every pair by entries (the cross-check), =1: band landmarks whatever the size (tests).
   const char* band_env = getenv("BSGPU_PAIRS_BAND");
-  const bool band_on = !(band_env && !strcmp(band_env, "0"));
+  const int n_reproj = c->groups[BSGPU_F_REPROJ].n + c->groups[BSGPU_F_REPROJ_ONLINE_CALIB].n;
+  const bool band_on = band_env ? strcmp(band_env, "0") != 0 : n_reproj >= kBandMinFactors;
   const bool sort_entries = getenv("BSGPU_PAIR_ENTRIES_SORT") != nullptr;   // (tests: the path windows of more than 2 896 camera poses take)
   // ---- visual factors: camera-pose ids, factors sorted by landmark, pair entries, tile adjacency.
   // Large plain windows are flattened on the device (k_flatten.hip); everything else — and any window the device

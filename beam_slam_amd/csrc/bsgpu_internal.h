@@ -34,6 +34,7 @@ constexpr int kPairChunk = 256;
 // a landmark whose observations lie within this many consecutive camera poses (every feature track of a sliding window), one per camera
 // pose, is a BAND landmark: its whole contribution to the reduced system is formed by pairs_band_kernel (k_band.hip), it has no pair entries
 constexpr int kBandCams = 13;
+constexpr int kBandMinFactors = 150000;   // windows below this keep every pair as an entry (bsgpu_finalize.cpp)
 
 // meta word of a reprojection factor: camera id | loss id | constant-block flags
 constexpr int kMetaCamBits = 12, kMetaLossBits = 12;

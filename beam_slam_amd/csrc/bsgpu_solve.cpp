@@ -115,7 +115,10 @@ bool pcg_check(bsgpu_ctx* c) {
   if (!c->pcg_check_pending) return true;
   c->pcg_check_pending = false;
   g_pcg_persistent_in_flight.store(0);
-  const double done = c->h_pcg_lazy[pcg_done_slot()], iters = c->h_pcg_lazy[pcg_iters_slot()];
+  double done = c->h_pcg_lazy[pcg_done_slot()];
+  const double iters = c->h_pcg_lazy[pcg_iters_slot()];
+  // (tests: BSGPU_PCG_GIVE_UP=n declares the n-th verdict of the process a failure — the path a shared device takes)
+  if (const char* e = getenv("BSGPU_PCG_GIVE_UP")) { static std::atomic<int> seen{0}; if (++seen == atoi(e)) done = 0.0; }
   if (done > 0.0) { c->pcg_iters_total += (int)iters; return true; }
   fprintf(stderr, "[bsgpu] the resident PCG launch was given up (done %g after %g iterations): launch-per-iteration path from here on\n", done, iters);
   c->pcg_persist.G = 0;

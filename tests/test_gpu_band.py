@@ -61,7 +61,7 @@ def test_band_kernel_equals_pair_entries_and_oracle(oracle_cls, gpu_solver_cls, 
     monkeypatch.setenv("BSGPU_FLATTEN", flatten)
     monkeypatch.setenv("BSGPU_PAIRS_BAND", "0")
     s0, it0, x0 = _run(pr, gpu_solver_cls)
-    monkeypatch.delenv("BSGPU_PAIRS_BAND")
+    monkeypatch.setenv("BSGPU_PAIRS_BAND", "1")      # (whatever the size: by itself the library takes the band form from 150 000 factors)
     s1, it1, x1 = _run(pr, gpu_solver_cls)
     assert s0.num_iterations == s1.num_iterations and s0.num_successful_steps == s1.num_successful_steps
     a, b = np.array(it0), np.array(it1)
@@ -79,8 +79,9 @@ def test_band_kernel_equals_pair_entries_and_oracle(oracle_cls, gpu_solver_cls, 
     assert np.abs(o.get_blocks() - x1).max() < 1e-6
 
 
-def test_gradient_only_step_and_iteration_budget(oracle_cls, gpu_solver_cls):
+def test_gradient_only_step_and_iteration_budget(oracle_cls, gpu_solver_cls, monkeypatch):
     """the last iteration of a budget is a gradient-only step: the band launch then forms the per-camera sums alone (no products)"""
+    monkeypatch.setenv("BSGPU_PAIRS_BAND", "1")
     pr = _window("tracks")
     for iters in (1, 2):
         s, it, x = _run(pr, gpu_solver_cls, iters=iters)
@@ -98,9 +99,20 @@ def test_gradient_only_step_and_iteration_budget(oracle_cls, gpu_solver_cls):
 
 def test_band_units_of_several_parts(oracle_cls, gpu_solver_cls, monkeypatch):
     """BSGPU_BAND_PART: a first camera pose's landmarks cut into several units (what a window of many landmarks per key frame gets)"""
+    monkeypatch.setenv("BSGPU_PAIRS_BAND", "1")
     pr = synthetic.vio_window(n_kf=12, n_lm=1500, seed=56, track_min=2, track_max=9)
     s_ref, it_ref, x_ref = _run(pr, gpu_solver_cls)
     for part in ("16", "40"):
         monkeypatch.setenv("BSGPU_BAND_PART", part)
         s, it, x = _run(pr, gpu_solver_cls)
         assert np.allclose([i[0] for i in it], [i[0] for i in it_ref], rtol=1e-10) and np.abs(x - x_ref).max() < 1e-8
+
+
+def test_size_rule(gpu_solver_cls, monkeypatch):
+    """by itself the library takes the band form from kBandMinFactors reprojection factors on: the same solve either way at a size above it"""
+    monkeypatch.delenv("BSGPU_PAIRS_BAND", raising=False)
+    pr = synthetic.vio_window(n_kf=60, n_lm=20000, seed=57)     # ~160 000 factors
+    s1, it1, x1 = _run(pr, gpu_solver_cls, iters=4)
+    monkeypatch.setenv("BSGPU_PAIRS_BAND", "0")
+    s0, it0, x0 = _run(pr, gpu_solver_cls, iters=4)
+    assert np.allclose([i[0] for i in it0], [i[0] for i in it1], rtol=1e-10) and np.abs(x0 - x1).max() < 1e-8

@@ -108,3 +108,24 @@ def test_many_rows_per_workgroup(gpu_solver_cls, monkeypatch):
     s2, x2, acc2 = _solve(gpu_solver_cls, pr, iters=4)
     assert acc1 == acc2
     assert abs(s1.final_cost - s2.final_cost) <= 1e-8 * s2.final_cost
+
+
+@pytest.mark.parametrize("nth", [1, 3])
+def test_a_resident_launch_that_is_given_up_has_its_step_computed_again(gpu_solver_cls, monkeypatch, nth):
+    """The resident launch's verdict is read with the step's other scalars (bsgpu_solve.cpp pcg_check); when it did not finish — a shared
+    device — the step is asked for again (lm_state.h retry) and computed launch per iteration.  BSGPU_PCG_GIVE_UP declares the n-th
+    verdict a failure: the first step's, and one in the middle of the solve.  (BSGPU_PCG_COARSE=0: the launch-per-iteration path has no
+    coarse space, so the two paths are the same iteration.)"""
+    monkeypatch.setenv("BSGPU_PCG_COARSE", "0")
+    pr = synthetic.pose_graph(n_pose=2200, n_loop=3000, seed=3)
+    def run():
+        g = gpu_solver_cls(0)
+        pr.load(g)
+        o = g.options_default(); o.max_num_iterations = 6; o.pcg_tolerance = 1e-10
+        s = g.solve(o)
+        return s, [i.cost for i in g.iterations()], [i.step_is_successful for i in g.iterations()], g.get_blocks()
+    s0, c0, a0, x0 = run()
+    monkeypatch.setenv("BSGPU_PCG_GIVE_UP", str(nth))
+    s1, c1, a1, x1 = run()
+    assert a0 == a1 and s0.num_iterations == s1.num_iterations and s0.termination_type == s1.termination_type
+    assert np.allclose(c0, c1, rtol=1e-7) and np.abs(x0 - x1).max() < 1e-4
