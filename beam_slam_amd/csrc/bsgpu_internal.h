@@ -217,6 +217,9 @@ void launch_small_eval(hipStream_t s, const SmallGroup& g, const double* x, cons
                        double* cost_part /* n doubles: per-factor cost */);
 // several groups in ONE launch (false: too many groups or a type it does not carry — the caller launches them one by one)
 bool launch_small_eval_set(hipStream_t s, const SmallGroup* groups, double* const* parts, int n_groups, const double* x, const DevLoss* losses, bool with_J);
+// ... with the window's dense prior (k_marg.hip) evaluated by the same launch; false: nothing was launched
+bool launch_small_eval_set_marg(hipStream_t s, const SmallGroup* groups, double* const* parts, int n_groups, const double* x, const DevLoss* losses, bool with_J,
+                                const MargDev& m, double* marg_part);
 // what an LM step clears before its assembly (zero_tiles_multi_kernel's arguments); rides in the landmark launch as extra workgroups
 // Several windows advanced by ONE set of launches (bsgpu_batch.cpp; bs_models/src/lib/global_mapping/submap_refinement.cpp:35-115 is the
 // reference's serial loop over submaps): every kernel of the LM step has a `_batch` form whose blockIdx.y picks a window out of one of
@@ -366,10 +369,11 @@ void launch_small_assemble_set(hipStream_t s, const SmallGroup* groups, int n_gr
 // factors of one pose-only type that name the SAME variables in every slot (the ~21 lidar constraints between two keyframes of a
 // lidar-inertial window): their J^T J is summed by one wave before it is added to the reduced system (k_small.hip: small_assemble_group)
 struct AsmGroup { int type, first, count, pad; };   // factors gfac[first .. first + count)
-void launch_small_assemble_seg(hipStream_t s, const SmallGroup* groups_dev, int n_seg, const int* seg_start, const int* seg_ra, const int* seg_rb,
+// (marg: the window's dense prior assembled by the same launch; returns whether it was carried)
+bool launch_small_assemble_seg(hipStream_t s, const SmallGroup* groups_dev, int n_seg, const int* seg_start, const int* seg_ra, const int* seg_rb,
                                const int2* contrib, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm,
                                const SmallGroupSet* fw = nullptr, int n_fw_units = 0, int n_grp = 0, const AsmGroup* grp = nullptr,
-                               const int* gfac = nullptr);
+                               const int* gfac = nullptr, const MargDev* marg = nullptr);
 void launch_pose_diag(hipStream_t s, int n_pose, double* S, int ld, const double* hdiag, const double* radius_ptr,
                       int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* scale,
                       double* dcl, int npad, const int* iperm, double radius_val = 0.0 /* used when radius_ptr is null */);
@@ -481,8 +485,10 @@ void launch_spcg_finish(hipStream_t s, int T, const double* x, const int* iperm,
 int pcg_done_slot();
 int pcg_iters_slot();
 int backsub_mcc_groups(const Visual& v);   // workgroups (= model-cost partials) of launch_backsub_mcc
-void launch_backsub_mcc(hipStream_t s, const Visual& v, int n_pose, const double* y_pose, double* delta, double* mcc_part,
-                        const SmallGroupSet* small = nullptr, int n_small_units = 0, const UpdateRide* upd = nullptr);
+// (marg / marg_part: the model-cost terms of the window's dense prior as further workgroups of the launch; returns whether they were carried)
+bool launch_backsub_mcc(hipStream_t s, const Visual& v, int n_pose, const double* y_pose, double* delta, double* mcc_part,
+                        const SmallGroupSet* small = nullptr, int n_small_units = 0, const UpdateRide* upd = nullptr, const MargDev* marg = nullptr,
+                        double* marg_part = nullptr);
 int small_mcc_first_set(const SmallGroup* groups, double* const* parts, int n_groups, SmallGroupSet* set, int* n_taken);
 void launch_negate_pose(hipStream_t s, int n_pose, const double* y, double* delta);
 // (returns whether `upd` — the candidate update of a window without Euclidean landmarks — rode in one of the launches)

@@ -182,6 +182,17 @@ void spcg_solve(bsgpu_ctx* c, const bsgpu_options& o) {
   launch_spcg_finish(s, T, c->d_sx, c->d_inat, c->n_pose, c->d_ytan, c->d_delta);
 }
 
+// A window after a slide with true marginalisation carries ONE dense prior (fixed_lag_smoother.cpp:269-272): its evaluation, its J^T J and its
+// model-cost terms ride in the launches of the window's other pose-only factors instead of three launches of their own behind them
+// (BSGPU_MARG_RIDE=0: the launches of their own; several priors: the first one rides)
+static int marg_rider(const bsgpu_ctx* c) {
+  static const bool off = getenv("BSGPU_MARG_RIDE") && atoi(getenv("BSGPU_MARG_RIDE")) == 0;
+  if (off || c->use_graphs) return -1;
+  for (size_t i = 0; i < c->marg.size(); ++i)
+    if (c->marg[i].active && c->marg[i].dev.rows > 0) return (int)i;
+  return -1;
+}
+
 // residuals (+ Jacobians) of every factor group; per-group cost partials go to the arrays the
 // end-of-step reduction sums (current point: slot SC_COST_X, candidate: SC_COST_CAND)
 // red: the end-of-step reduction of the step just computed rides in the visual-inertial evaluation launch (the caller has checked that
@@ -215,6 +226,7 @@ void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot, const Reduce
     launch_imu_eval(s, c->small[BSGPU_F_IMU_DELTA], c->small[BSGPU_F_IMU_PRIOR], x, c->d_losses, with_J,
                     cand ? c->d_small_part_cand[BSGPU_F_IMU_DELTA] : c->d_small_part[BSGPU_F_IMU_DELTA],
                     cand ? c->d_small_part_cand[BSGPU_F_IMU_PRIOR] : c->d_small_part[BSGPU_F_IMU_PRIOR]);
+  int marg_done = -1;
   {
     // the groups no fused launch carries: ONE launch for all of them when there are several (a pose graph's constraints + the prior on its
     // first pose), else the group's own kernel
@@ -227,11 +239,16 @@ void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot, const Reduce
       gs[ng] = c->small[t]; ps[ng] = cand ? c->d_small_part_cand[t] : c->d_small_part[t]; ++ng;
     }
     static const bool separate = getenv("BSGPU_EVAL_SEPARATE") != nullptr;
-    if (ng < 2 || separate || !launch_small_eval_set(s, gs, ps, ng, x, c->d_losses, with_J))
+    const int mr = separate ? -1 : marg_rider(c);
+    if (mr >= 0 && launch_small_eval_set_marg(s, gs, ps, ng, x, c->d_losses, with_J, c->marg[mr].dev, cand ? c->marg[mr].part_cand : c->marg[mr].part))
+      marg_done = mr;
+    else if (ng < 2 || separate || !launch_small_eval_set(s, gs, ps, ng, x, c->d_losses, with_J))
       for (int i = 0; i < ng; ++i) launch_small_eval(s, gs[i], x, c->d_losses, with_J, ps[i]);
   }
-  for (const auto& mc : c->marg)
-    if (mc.active) launch_marg_eval(s, mc.dev, x, with_J, cand ? mc.part_cand : mc.part);
+  for (size_t i = 0; i < c->marg.size(); ++i) {
+    const auto& mc = c->marg[i];
+    if (mc.active && (int)i != marg_done) launch_marg_eval(s, mc.dev, x, with_J, cand ? mc.part_cand : mc.part);
+  }
   if (with_J) phase_mark(c, BSGPU_PHASE_EVAL_OTHER);
 }
 // the reduction can ride in the evaluation launched ahead of the decision (k_small.hip visual_imu_eval_reduce_kernel): a visual-inertial
@@ -287,6 +304,7 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
                       o.jacobi_scaling, o.min_lm_diagonal, o.max_lm_diagonal, c->d_scale, c->d_dcl, c->d_grad);
   launch_idp_pairs(s, c->idp, c->small[BSGPU_F_IDP_REPROJ], c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_dpos, gradient_only);
   phase_mark(c, BSGPU_PHASE_LANDMARK);
+  int marg_done = -1;
   {
     // (the factor-wise assembled pose-only groups ride in the pair launch when there is one; further groups, or all of them, go by themselves)
     SmallGroupSet set;
@@ -304,11 +322,16 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
     if (units2 == 0) taken2 = 0;
     launch_small_assemble_set(s, c->small_factorwise + 2 + taken + taken2, kNumInternal - 2 - taken - taken2, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag,
                               c->d_dpos);
-    launch_small_assemble_seg(s, c->d_small_groups, c->n_sa_seg, c->d_sa_seg_start, c->d_sa_seg_ra, c->d_sa_seg_rb, c->d_sa_contrib, c->d_S, c->npad,
-                              c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_dpos, units2 > 0 ? &set2 : nullptr, units2, c->n_asm_grp, c->d_asm_grp, c->d_asm_gfac);
+    const int mr = marg_rider(c);
+    if (launch_small_assemble_seg(s, c->d_small_groups, c->n_sa_seg, c->d_sa_seg_start, c->d_sa_seg_ra, c->d_sa_seg_rb, c->d_sa_contrib, c->d_S, c->npad,
+                                  c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_dpos, units2 > 0 ? &set2 : nullptr, units2, c->n_asm_grp, c->d_asm_grp, c->d_asm_gfac,
+                                  mr >= 0 ? &c->marg[mr].dev : nullptr))
+      marg_done = mr;
   }
-  for (const auto& mc : c->marg)
-    if (mc.active) launch_marg_assemble(s, mc.dev, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_dpos);
+  for (size_t i = 0; i < c->marg.size(); ++i) {
+    const auto& mc = c->marg[i];
+    if (mc.active && (int)i != marg_done) launch_marg_assemble(s, mc.dev, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_dpos);
+  }
   // With the single-launch factorisation next, neither needs a launch of its own on the dependent path: its plan has one task per tile that
   // adds the LM diagonal as the tile's first update, and the gradient norms — which only the end-of-step reduction reads — are units of
   // work of the same launch (dense_plan.h kFusedDiagAdd / kFusedRider; BSGPU_POSE_DIAG_LAUNCH=1 plans without them).
@@ -414,6 +437,7 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o, bool defer
   }
   // landmark back-substitution + the model-cost-change terms of the visual factors (partial arrays only, summed once at the end)
   launch_idp_backsub(s, c->idp, c->d_ytan, c->d_delta);   // (before the pose-only groups' model-cost terms, which read the step of rho)
+  int marg_mcc_done = -1;
   {
     // (the model-cost terms of the first pose-only groups ride in the back-substitution launch; further groups, or all of them when
     // there is no visual launch, go by themselves)
@@ -425,7 +449,10 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o, bool defer
       up.n_blocks = c->n_upd_blocks; up.blocks = c->d_upd_blocks; up.xoff = c->d_blk_xoff; up.toff = c->d_blk_toff; up.size = c->d_blk_size;
       up.manifold = c->d_blk_manifold; up.lm_xoff = c->d_lm_xoff; up.x = c->d_x; up.x_cand = c->d_xcand; up.part = c->d_part_upd;
     }
-    launch_backsub_mcc(s, c->vis, c->n_pose, c->d_ytan, c->d_delta, c->vis.mcc_part, units > 0 ? &set : nullptr, units, c->n_upd_blocks > 0 ? &up : nullptr);
+    const int mr = marg_rider(c);
+    if (launch_backsub_mcc(s, c->vis, c->n_pose, c->d_ytan, c->d_delta, c->vis.mcc_part, units > 0 ? &set : nullptr, units, c->n_upd_blocks > 0 ? &up : nullptr,
+                           mr >= 0 ? &c->marg[mr].dev : nullptr, mr >= 0 ? c->marg[mr].part_mcc : nullptr))
+      marg_mcc_done = mr;
     if (units == 0) taken = 0;
     UpdateRide all;
     if (c->upd_in_mcc) {   // (no Euclidean landmarks: every block's candidate rides in the pose-only groups' launch)
@@ -446,8 +473,10 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o, bool defer
     c->pre_cleared = ride_zero && carried;
     if (c->upd_in_mcc && !carried) launch_update_ride_only(s, c->d_delta, all);
   }
-  for (const auto& mc : c->marg)
-    if (mc.active) launch_marg_mcc(s, mc.dev, c->d_delta, mc.part_mcc);
+  for (size_t i = 0; i < c->marg.size(); ++i) {
+    const auto& mc = c->marg[i];
+    if (mc.active && (int)i != marg_mcc_done) launch_marg_mcc(s, mc.dev, c->d_delta, mc.part_mcc);
+  }
   phase_mark(c, BSGPU_PHASE_BACKSUB);
   int n_part = 0;
   if (c->n_upd_blocks == 0 && !c->upd_in_mcc)   // (else the update rode in the landmark back-substitution / the pose-only groups' launch above)

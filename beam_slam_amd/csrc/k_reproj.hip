@@ -8,6 +8,7 @@
 // (residual; the quaternion Jacobian there is a forward difference — here it is the closed form
 // -A Jpi R_cb [P_b]x of SURVEY.md Appendix A) and bs_constraints/src/jacobians.cpp:202-214.
 #include "bsgpu_device.h"
+#include "marg_body.h"
 #include "reproj_body.h"
 
 namespace bsg {
@@ -766,15 +767,29 @@ void launch_backsub_mcc_batch(hipStream_t s, const BatchArgTable& t, const Batch
   hipLaunchKernelGGL(backsub_mcc_kernel_batch, dim3(t.max_grid, n), dim3(256), 0, s, static_cast<const backsub_mcc_kernel_Args*>(t.dev), dyn, list);
 }
 int backsub_mcc_groups(const Visual& v) { return (v.n_lm * 8 + 255) / 256 + (v.n - v.n_elim + 255) / 256; }
-void launch_backsub_mcc(hipStream_t s, const Visual& v, int n_pose, const double* y_pose, double* delta, double* mcc_part,
-                        const SmallGroupSet* small, int n_small_units, const UpdateRide* upd) {
+// ... with the model-cost terms of the window's dense prior (marg_body.h; they read the pose step only: the landmarks a prior names are not
+// eliminated) as the launch's last workgroups, four rows each, instead of marg_mcc_kernel behind it (4.6 us)
+__global__ __launch_bounds__(256) void backsub_mcc_marg_kernel(int n_lm, int n_lm_groups, int n_elim, int n, const int* __restrict__ lm_start, const double* __restrict__ J, const double* __restrict__ JB, const double2* __restrict__ r, const double* __restrict__ CR, const int* __restrict__ cam_pose, const int* __restrict__ cp_tq, const int* __restrict__ cp_tp, const double* __restrict__ Linv, const double* __restrict__ z, int n_pose, const double* __restrict__ y_pose, double* __restrict__ delta, double* __restrict__ mcc_part, int n_vis_blocks, SmallGroupSet small, int n_small_units, UpdateRide up, int first_update_block, MargDev m, double* __restrict__ marg_part, int first_marg_block) {
+  if ((int)blockIdx.x >= first_marg_block) { marg_mcc_kernel_body(4 * ((int)blockIdx.x - first_marg_block), m, delta, marg_part); return; }
+  backsub_mcc_kernel_body((int)blockIdx.x, first_marg_block, n_lm, n_lm_groups, n_elim, n, lm_start, J, JB, r, CR, cam_pose, cp_tq, cp_tp, Linv, z, n_pose, y_pose, delta, mcc_part, n_vis_blocks, small, n_small_units, up, first_update_block);
+}
+bool launch_backsub_mcc(hipStream_t s, const Visual& v, int n_pose, const double* y_pose, double* delta, double* mcc_part,
+                        const SmallGroupSet* small, int n_small_units, const UpdateRide* upd, const MargDev* marg, double* marg_part) {
   const int g_lm = (v.n_lm * 8 + 255) / 256, grid = backsub_mcc_groups(v);
-  if (grid == 0) return;
+  if (grid == 0) return false;
   const int extra = small ? (n_small_units + 1) / 2 : 0;
   const int upd_units = (upd && upd->n_blocks > 0) ? (upd->n_blocks + 255) / 256 : 0;
+  if (marg && marg_part && marg->rows > 0) {
+    const int own = grid + extra + upd_units;
+    hipLaunchKernelGGL(backsub_mcc_marg_kernel, dim3(own + (marg->rows + 3) / 4), dim3(256), 0, s, v.n_lm, g_lm, v.n_elim, v.n, v.lm_start, v.J, v.JB, v.r, v.CR, v.cam_pose,
+                       v.cp_tq, v.cp_tp, v.Linv, v.z, n_pose, y_pose, delta, mcc_part, grid, small ? *small : SmallGroupSet(), small ? n_small_units : 0,
+                       upd_units ? *upd : UpdateRide(), grid + extra, *marg, marg_part, own);
+    return true;
+  }
   hipLaunchKernelGGL(backsub_mcc_kernel, dim3(grid + extra + upd_units), dim3(256), 0, s, v.n_lm, g_lm, v.n_elim, v.n, v.lm_start, v.J, v.JB, v.r, v.CR, v.cam_pose,
                      v.cp_tq, v.cp_tp, v.Linv, v.z, n_pose, y_pose, delta, mcc_part, grid, small ? *small : SmallGroupSet(), small ? n_small_units : 0,
                      upd_units ? *upd : UpdateRide(), grid + extra);
+  return false;
 }
 
 }  // namespace bsg

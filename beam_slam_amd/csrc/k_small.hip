@@ -12,6 +12,7 @@
 // checked against the Jet-based oracle in tests/.
 #include "bsgpu_device.h"
 #include "reproj_body.h"
+#include "marg_body.h"
 
 namespace bsg {
 
@@ -1160,16 +1161,41 @@ __global__ __launch_bounds__(256) void small_assemble_seg_kernel(const SmallGrou
                                                                 const int* __restrict__ gfac, int first_grp_block) {
   small_assemble_seg_kernel_body((int)blockIdx.x, groups, n_seg, seg_start, seg_ra, seg_rb, contrib, S, ld, rhs_row, grad, hdiag, perm, fw, n_fw_units, n_grp, grp, gfac, first_grp_block);
 }
-void launch_small_assemble_seg(hipStream_t s, const SmallGroup* groups_dev, int n_seg, const int* seg_start, const int* seg_ra, const int* seg_rb,
+// ... with the J^T J / J^T r of the window's dense prior as the launch's last workgroups (marg_body.h: 16 x 16 output tiles, then the gradient's
+// row of workgroups) instead of marg_assemble_kernel behind it (7.4 us): both add into S, the gradient and the diagonal with atomics
+__global__ __launch_bounds__(256) void small_assemble_seg_marg_kernel(const SmallGroup* __restrict__ groups, int n_seg,
+                                                                     const int* __restrict__ seg_start, const int* __restrict__ seg_ra,
+                                                                     const int* __restrict__ seg_rb, const int2* __restrict__ contrib,
+                                                                     double* __restrict__ S, int ld, int rhs_row, double* __restrict__ grad,
+                                                                     double* __restrict__ hdiag, const int* __restrict__ perm, SmallGroupSet fw,
+                                                                     int n_fw_units, int n_grp, const AsmGroup* __restrict__ grp,
+                                                                     const int* __restrict__ gfac, int first_grp_block, MargDev m, int first_marg_block, int mg) {
+  if ((int)blockIdx.x >= first_marg_block) {
+    const int b = (int)blockIdx.x - first_marg_block;
+    marg_assemble_kernel_body(b % mg, b / mg, mg + 1, m, S, ld, perm, rhs_row, grad, hdiag);
+    return;
+  }
+  small_assemble_seg_kernel_body((int)blockIdx.x, groups, n_seg, seg_start, seg_ra, seg_rb, contrib, S, ld, rhs_row, grad, hdiag, perm, fw, n_fw_units, n_grp, grp, gfac, first_grp_block);
+}
+// marg: the window's (one) dense prior, carried by this launch; returns whether it was (false: no launch of this kind — the caller launches the prior's own)
+bool launch_small_assemble_seg(hipStream_t s, const SmallGroup* groups_dev, int n_seg, const int* seg_start, const int* seg_ra, const int* seg_rb,
                                const int2* contrib, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm,
-                               const SmallGroupSet* fw, int n_fw_units, int n_grp, const AsmGroup* grp, const int* gfac) {
-  if (n_seg <= 0 && n_grp <= 0) return;
+                               const SmallGroupSet* fw, int n_fw_units, int n_grp, const AsmGroup* grp, const int* gfac, const MargDev* marg) {
+  if (n_seg <= 0 && n_grp <= 0) return false;
   SmallGroupSet none;
   none.n = 0; none.first[0] = 0;
   const int extra = fw ? n_fw_units : 0;
   const int seg_blocks = (std::max(0, n_seg) + 15) / 16, first_grp_block = extra + seg_blocks;
-  hipLaunchKernelGGL(small_assemble_seg_kernel, dim3(first_grp_block + std::max(0, n_grp)), dim3(256), 0, s, groups_dev, std::max(0, n_seg), seg_start, seg_ra, seg_rb,
+  const int own = first_grp_block + std::max(0, n_grp);
+  if (marg && marg->rows > 0 && marg->cols > 0) {
+    const int mg = (marg->cols + 15) / 16;
+    hipLaunchKernelGGL(small_assemble_seg_marg_kernel, dim3(own + mg * (mg + 1)), dim3(256), 0, s, groups_dev, std::max(0, n_seg), seg_start, seg_ra, seg_rb,
+                       contrib, S, ld, rhs_row, grad, hdiag, perm, fw ? *fw : none, extra, n_grp, grp, gfac, first_grp_block, *marg, own, mg);
+    return true;
+  }
+  hipLaunchKernelGGL(small_assemble_seg_kernel, dim3(own), dim3(256), 0, s, groups_dev, std::max(0, n_seg), seg_start, seg_ra, seg_rb,
                      contrib, S, ld, rhs_row, grad, hdiag, perm, fw ? *fw : none, extra, n_grp, grp, gfac, first_grp_block);
+  return false;
 }
 
 // the first (up to kSetMax) non-empty groups as ONE set of one-factor units, for a caller that runs them inside another launch
@@ -1371,6 +1397,23 @@ bool launch_small_eval_set(hipStream_t s, const SmallGroup* groups, double* cons
   if (a.bsg_grid <= 0) return true;
   if (with_J) hipLaunchKernelGGL(small_eval_set_kernel<true>, dim3(a.bsg_grid), dim3(128), 0, s, a);
   else hipLaunchKernelGGL(small_eval_set_kernel<false>, dim3(a.bsg_grid), dim3(128), 0, s, a);
+  return true;
+}
+// ... with the window's dense prior (true marginalisation: fixed_lag_smoother.cpp:269-272) as the launch's last workgroups, two rows each:
+// marg_eval_kernel was a launch of its own behind this one on the path of every evaluation (4.6 us for a 111 x 159 prior)
+template <bool WITH_J>
+__global__ __launch_bounds__(128) void small_eval_set_marg_kernel(small_eval_set_Args a, MargDev m, double* __restrict__ marg_part) {
+  if ((int)blockIdx.x < a.bsg_grid) { small_eval_set_dispatch<WITH_J>(a, (int)blockIdx.x); return; }
+  marg_eval_kernel_body<WITH_J, true, 128>(2 * ((int)blockIdx.x - a.bsg_grid), m, a.x, marg_part);
+}
+// false: nothing was launched (more groups than one launch takes, a prior too wide for the LDS copy)
+bool launch_small_eval_set_marg(hipStream_t s, const SmallGroup* groups, double* const* parts, int n_groups, const double* x, const DevLoss* losses, bool with_J,
+                                const MargDev& m, double* marg_part) {
+  small_eval_set_Args a;
+  if (!marg_fits_lds(m) || m.rows <= 0 || !fill_small_eval_set(a, groups, parts, n_groups, x, losses)) return false;
+  const int grid = a.bsg_grid + (m.rows + 1) / 2;
+  if (with_J) hipLaunchKernelGGL(small_eval_set_marg_kernel<true>, dim3(grid), dim3(128), 0, s, a, m, marg_part);
+  else hipLaunchKernelGGL(small_eval_set_marg_kernel<false>, dim3(grid), dim3(128), 0, s, a, m, marg_part);
   return true;
 }
 // groups[i], parts[i]: the window's groups this launch evaluates (n_groups <= kEvalSetMax; 0: a zero grid)
