@@ -386,7 +386,7 @@ __device__ __forceinline__ void relpose_body(const SmallGroup g, const double* _
   constexpr int TW = 3 * NV;
   // (Jacobian rows leave through LDS: a lane per factor storing its 864-byte Jacobian 8 bytes at a time touches 64 cache lines per
   // store instruction — 44 us for C3's 20 000 factors; see the end of the kernel)
-  __shared__ __attribute__((aligned(16))) double sJ[WITH_J ? 2 * 64 * TW : 2];
+  __shared__ __attribute__((aligned(16))) double sJ[WITH_J ? 2 * 64 * 2 * TW : 2];
   const int f_raw = block * 128 + threadIdx.x;
   const bool live = f_raw < g.n;
   const int f = live ? f_raw : g.n - 1;   // (idle lanes of the last workgroup redo the last factor and store nothing)
@@ -468,92 +468,85 @@ __device__ __forceinline__ void relpose_body(const SmallGroup g, const double* _
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) G[3 * i + j] = -(Jr[3 * i] * R2tR1[j] + Jr[3 * i + 1] * R2tR1[3 + j] + Jr[3 * i + 2] * R2tR1[6 + j]);
-  // raw Je (6 x TW), base-frame columns
-  double Je[6 * TW];
+  // J = sc A Je with A = [A_p | A_q] (6 x 3 each) and the raw Jacobian Je of e w.r.t. the sensor poses — e_p rows: d/dp_s1 = -R1^T,
+  // d/dth_s1 = [dpr]x, d/dp_s2 = R1^T; e_q rows: d/dth_s1 = G, d/dth_s2 = Jr — chained to the base-frame / extrinsics columns.  Written out
+  // by 3-column blocks (round 5; the generic 6 x 6 by 6 x TW product spent two thirds of its FMAs on structural zeros, which -fno-fast-math
+  // keeps, and the kernel is bound by the instruction count of ONE wave: 157 workgroups on 256 compute units).  Row i of
+  //   P1 = -A_p R1^T,   M12 = A_p [dpr]x + A_q G,   M3 = A_q Jr            (a^T [p]x = (a x p)^T)
+  // gives row i of every block:
+  //   no extrinsics   p1: P1   th1: M12   p2: -P1   th2: M3
+  //   extrinsics      p_b1: P1   p_b2: -P1   p_e: P1 (Rb1 - Rb2)   th_e: M12 + M3
+  //                   th_b1: M12 Re^T + P1 X1,  X1 row k = pe x Rb1_k  (= -Rb1 [pe]x)      th_b2: M3 Re^T + P1 X2,  X2 row k = Rb2_k x pe
+  double Dr[9], X1[9], X2[9];
+  if (EXT) {
 #pragma unroll
-  for (int i = 0; i < 6 * TW; ++i) Je[i] = 0.0;
-  // e_p rows: d/dp_s1 = -R1^T, d/dth_s1 = [dpr]x, d/dp_s2 = R1^T
-  const double Sx[9] = {0, -dpr[2], dpr[1], dpr[2], 0, -dpr[0], -dpr[1], dpr[0], 0};
-  double Eps1[9], Eth1p[9], Eth1q[9], Eth2q[9];
+    for (int k = 0; k < 3; ++k) {
+      cross3(pe, Rb1 + 3 * k, X1 + 3 * k);
+      cross3(Rb2 + 3 * k, pe, X2 + 3 * k);
+    }
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) { Eps1[3 * i + j] = -R1[3 * j + i]; Eth1p[3 * i + j] = Sx[3 * i + j]; Eth1q[3 * i + j] = G[3 * i + j]; Eth2q[3 * i + j] = Jr[3 * i + j]; }
-  if (!EXT) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        Je[i * TW + 0 + j] = Eps1[3 * i + j];       // p1
-        Je[i * TW + 3 + j] = Eth1p[3 * i + j];      // th1 (position rows)
-        Je[(3 + i) * TW + 3 + j] = Eth1q[3 * i + j];  // th1 (orientation rows)
-        Je[i * TW + 6 + j] = -Eps1[3 * i + j];      // p2
-        Je[(3 + i) * TW + 9 + j] = Eth2q[3 * i + j];  // th2
-      }
-  } else {
-    // theta_s = Re^T theta_b ; dp_s/dtheta_b = -Rb [pe]x ; dp_s/dp_b = I ; dp_s/dpe = Rb ; theta_s = theta_e
-    const double Px[9] = {0, -pe[2], pe[1], pe[2], 0, -pe[0], -pe[1], pe[0], 0};
-    double RbPx1[9], RbPx2[9];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        RbPx1[3 * i + j] = -(Rb1[3 * i] * Px[j] + Rb1[3 * i + 1] * Px[3 + j] + Rb1[3 * i + 2] * Px[6 + j]);
-        RbPx2[3 * i + j] = -(Rb2[3 * i] * Px[j] + Rb2[3 * i + 1] * Px[3 + j] + Rb2[3 * i + 2] * Px[6 + j]);
-      }
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        // position rows
-        Je[i * TW + 0 + j] = Eps1[3 * i + j];  // p_b1
-        Je[i * TW + 6 + j] = -Eps1[3 * i + j];  // p_b2
-        double a = 0, b = 0, cc = 0, d = 0, ee = 0;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          a += Eth1p[3 * i + k] * Re[3 * j + k];          // Eth1p Re^T
-          b += Eps1[3 * i + k] * RbPx1[3 * k + j];        // Eps1 (-Rb1 [pe]x)
-          cc += -Eps1[3 * i + k] * RbPx2[3 * k + j];      // Eps2 (-Rb2 [pe]x), Eps2 = -Eps1
-          d += Eps1[3 * i + k] * Rb1[3 * k + j] - Eps1[3 * i + k] * Rb2[3 * k + j];  // d/dpe
-          ee += 0.0;
-        }
-        Je[i * TW + 3 + j] = a + b;        // th_b1
-        Je[i * TW + 9 + j] = cc;           // th_b2
-        Je[i * TW + 12 + j] = d;           // p_e
-        Je[i * TW + 15 + j] = Eth1p[3 * i + j];  // th_e (through th_s1; th_s2 does not enter e_p)
-        // orientation rows
-        double g1 = 0, g2 = 0;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { g1 += Eth1q[3 * i + k] * Re[3 * j + k]; g2 += Eth2q[3 * i + k] * Re[3 * j + k]; }
-        Je[(3 + i) * TW + 3 + j] = g1;
-        Je[(3 + i) * TW + 9 + j] = g2;
-        Je[(3 + i) * TW + 15 + j] = Eth1q[3 * i + j] + Eth2q[3 * i + j];
-        (void)ee;
-      }
+    for (int k = 0; k < 9; ++k) Dr[k] = Rb1[k] - Rb2[k];
   }
-  // row i of every factor of the wave -> LDS -> 16-byte stores, TW / 2 lanes per factor (the row's 144 / 96 bytes are contiguous in J)
+  // a constant block's columns are zero: its scale is (the compare is per block, not per entry)
+  double scb[NV];
+#pragma unroll
+  for (int b = 0; b < NV; ++b) scb[b] = to[b] < 0 ? 0.0 : sc;
+  // Two rows of every factor of the wave -> LDS -> 16-byte stores (a lane storing its own 864-byte Jacobian touches 64 lines per store
+  // instruction).  The two rows of a factor are 2 TW contiguous doubles of J, so piece p of the wave's 64 TW pieces belongs to factor
+  // p / TW and sits p * 16 + (p / TW) * 32 TW bytes behind the wave's first row pair.  Idle lanes of the last workgroup hold the last factor
+  // again and store it again: the same bytes to the same place, no lane conditions in the loop.
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double* sw = sJ + wave * (64 * TW);
-  const int f0 = block * 128 + wave * 64;
-  const int cnt = min(64, g.n - f0);
   typedef double d2_t __attribute__((ext_vector_type(2)));
+  d2_t* sw2 = reinterpret_cast<d2_t*>(sJ + wave * (64 * 2 * TW));
+  const int f0 = block * 128 + wave * 64;
+  unsigned goff[TW];   // in 16-byte pieces, from g.J
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
+  for (int it = 0; it < TW; ++it) {
+    const int pp = it * 64 + lane, fi = pp / TW;
+    const int fg = min(f0 + fi, g.n - 1);
+    goff[it] = (unsigned)(fg * (3 * TW) + (pp - fi * TW));
+  }
+  d2_t* J2 = reinterpret_cast<d2_t*>(g.J);
 #pragma unroll
-    for (int col = 0; col < TW; ++col) {
-      const bool is_const = to[col / 3] < 0;
-      double a = 0.0;
+  for (int h = 0; h < 3; ++h) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) a += A[6 * i + k] * Je[k * TW + col];
-      sw[lane * TW + col] = is_const ? 0.0 : a * sc;
+    for (int rr = 0; rr < 2; ++rr) {
+      const int i = 2 * h + rr;
+      const double* Ai = A + 6 * i;
+      double p1[3], m12[3], m3[3], o[TW];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        p1[j] = -(Ai[0] * R1[3 * j] + Ai[1] * R1[3 * j + 1] + Ai[2] * R1[3 * j + 2]);
+        m3[j] = Ai[3] * Jr[j] + Ai[4] * Jr[3 + j] + Ai[5] * Jr[6 + j];
+      }
+      cross3(Ai, dpr, m12);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) m12[j] += Ai[3] * G[j] + Ai[4] * G[3 + j] + Ai[5] * G[6 + j];
+      if (!EXT) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          o[j] = p1[j] * scb[0];
+          o[3 + j] = m12[j] * scb[1];
+          o[6 + j] = -p1[j] * scb[2];
+          o[9 + j] = m3[j] * scb[3];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          o[j] = p1[j] * scb[0];
+          o[6 + j] = -p1[j] * scb[2];
+          o[3 + j] = (m12[0] * Re[3 * j] + m12[1] * Re[3 * j + 1] + m12[2] * Re[3 * j + 2] + p1[0] * X1[j] + p1[1] * X1[3 + j] + p1[2] * X1[6 + j]) * scb[1];
+          o[9 + j] = (m3[0] * Re[3 * j] + m3[1] * Re[3 * j + 1] + m3[2] * Re[3 * j + 2] + p1[0] * X2[j] + p1[1] * X2[3 + j] + p1[2] * X2[6 + j]) * scb[3];
+          o[12 + j] = (p1[0] * Dr[j] + p1[1] * Dr[3 + j] + p1[2] * Dr[6 + j]) * scb[4];
+          o[15 + j] = (m12[j] + m3[j]) * scb[5];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < TW / 2; ++k) sw2[lane * TW + rr * (TW / 2) + k] = d2_t{o[2 * k], o[2 * k + 1]};
     }
     __builtin_amdgcn_wave_barrier();
-    const d2_t* src = reinterpret_cast<const d2_t*>(sw);
 #pragma unroll
-    for (int it = 0; it < TW / 2; ++it) {
-      const int p = it * 64 + lane, fi = p / (TW / 2), piece = p - fi * (TW / 2);
-      if (fi < cnt) *reinterpret_cast<d2_t*>(g.J + ((size_t)(f0 + fi) * 6 + i) * TW + 2 * piece) = src[p];
-    }
+    for (int it = 0; it < TW; ++it) J2[goff[it] + h * TW] = sw2[it * 64 + lane];
     __builtin_amdgcn_wave_barrier();
   }
 }
