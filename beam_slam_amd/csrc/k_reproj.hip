@@ -22,7 +22,8 @@ __global__ __launch_bounds__(256) void reproj_eval_kernel(int n, const int4* __r
                                                           const DevLoss* __restrict__ losses,
                                                           double2* __restrict__ r_out, double* __restrict__ J_out,
                                                           double* __restrict__ JB_out, double* __restrict__ cost_part, int count_inactive) {
-  reproj_eval_body<WITH_J>((int)blockIdx.x, n, fac, pix, wgt, x, cams, losses, r_out, J_out, JB_out, cost_part, count_inactive);
+  __shared__ __attribute__((aligned(16))) double sJ[kReprojStage<WITH_J>];
+  reproj_eval_body<WITH_J>((int)blockIdx.x, n, fac, pix, wgt, x, cams, losses, r_out, J_out, JB_out, cost_part, count_inactive, sJ);
 }
 
 void launch_reproj_eval(hipStream_t s, const Visual& v, const double* x, const DevCamera* cams,

@@ -50,9 +50,18 @@ BSG_DEV void finish_small(const SmallGroup& g, int f, const DevLoss* losses, dou
 // ---------------------------------------------------------------------------------------------------
 // IMU delta: one wave per factor.  Lanes 0..14 own a residual row, lanes 0..29 own a Jacobian column.
 // ---------------------------------------------------------------------------------------------------
-template <bool WITH_J>
+// NW: waves of the calling workgroup (each evaluates a factor of its own: its wave's slice of the LDS stage the caller lends)
+constexpr int kImuBPitch = 33;
+template <bool WITH_J, int NW> constexpr int kImuStage = WITH_J ? NW * 16 * kImuBPitch : 1;
+template <bool WITH_J, int NW = 1>
 __device__ __forceinline__ void imu_delta_body(const SmallGroup g, const int f, const double* __restrict__ x,
-                                               const DevLoss* __restrict__ losses, double* __restrict__ cost_part, const int lane) {
+                                               const DevLoss* __restrict__ losses, double* __restrict__ cost_part, const int lane,
+                                               double* s_imuB /* kImuStage<WITH_J, NW> doubles of LDS */) {
+  // (round 5) J = sc A Jraw (15 x 15 by 15 x 30) on the matrix core: a lane per COLUMN doing the 225 FMAs of its column with 225 loads of A
+  // (the same for every lane) was half of the unit's 2 325 instructions, and the unit — one wave — is what a window of the reference's
+  // size waits for in its evaluation launch.  The columns go through LDS as the B operand (16 x 32, zero padding); every lane loads
+  // the four entries of A its lane position multiplies.
+  constexpr int kBP = kImuBPitch;
   const int* xo = g.xoff + (size_t)f * 10;
   const int* to = g.toff + (size_t)f * 10;
   const double* c = g.consts + (size_t)f * 287;
@@ -119,8 +128,12 @@ __device__ __forceinline__ void imu_delta_body(const SmallGroup g, const int f, 
   finish_small(g, f, losses, s, &sc, &cost);
   if (WITH_J && lane < 15) g.r[(size_t)f * 15 + lane] = rk * sc;
   if (lane == 0) cost_part[f] = cost;
-  if (!WITH_J || lane >= 30) return;
-  // raw Jacobian column `lane`: block b, component i
+  if (!WITH_J) return;
+  const int mn = lane & 15, mq = lane >> 4;
+  double a_op[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) { const int k = 4 * kk + mq; a_op[kk] = (mn < 15 && k < 15) ? A[15 * mn + k] : 0.0; }
+  // raw Jacobian column `lane` (< 30): block b, component i
   const int b = lane / 3, i = lane % 3;
   double col[15];
 #pragma unroll
@@ -129,7 +142,7 @@ __device__ __forceinline__ void imu_delta_body(const SmallGroup g, const int f, 
   quat_to_rot(qi, Ri);
   const double ei[3] = {i == 0 ? 1.0 : 0.0, i == 1 ? 1.0 : 0.0, i == 2 ? 1.0 : 0.0};
   const double RiT_ei[3] = {Ri[3 * i], Ri[3 * i + 1], Ri[3 * i + 2]};  // R_i^T e_i = row i of R_i
-  switch (b) {
+  if (lane < 30) switch (b) {
     case 0: {  // theta_i
       const double pe[4] = {0.0, ei[0], ei[1], ei[2]};
       double t[4], w[4];
@@ -154,15 +167,16 @@ __device__ __forceinline__ void imu_delta_body(const SmallGroup g, const int f, 
       // d res_q / d tau_k = 2 vec( du/dtau_k (x) e ),  du/dtau_k = (0,-e_k/2)(x)conj(dq)/nc - u (|dq|^2 tau_k/2)/nc
       const double dqc[4] = {dq[0], -dq[1], -dq[2], -dq[3]};
       const double ndq = dq[0] * dq[0] + dq[1] * dq[1] + dq[2] * dq[2] + dq[3] * dq[3];
+      const double inv_nc = 1.0 / nc;   // (one reciprocal for the fifteen quotients by nc below)
       double acc[3] = {0.0, 0.0, 0.0};
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const double pk[4] = {0.0, k == 0 ? -0.5 : 0.0, k == 1 ? -0.5 : 0.0, k == 2 ? -0.5 : 0.0};
         double du[4], w[4];
         quat_mul(pk, dqc, du);
-        const double fk = ndq * tau[k] * 0.5 / nc;
+        const double fk = ndq * tau[k] * 0.5 * inv_nc;
 #pragma unroll
-        for (int a = 0; a < 4; ++a) du[a] = du[a] / nc - u[a] * fk;
+        for (int a = 0; a < 4; ++a) du[a] = du[a] * inv_nc - u[a] * fk;
         quat_mul(du, e, w);
         const double jk = dq_dbg[3 * k + i];
         acc[0] += 2.0 * w[1] * jk; acc[1] += 2.0 * w[2] * jk; acc[2] += 2.0 * w[3] * jk;
@@ -188,14 +202,31 @@ __device__ __forceinline__ void imu_delta_body(const SmallGroup g, const int f, 
     case 8: col[9 + i] = 1.0; break;                                              // bg_j
     default: col[12 + i] = 1.0; break;                                            // ba_j
   }
-  const bool is_const = to[b] < 0;
+  double* sB = s_imuB + ((threadIdx.x >> 6) % NW) * (16 * kBP);
+  if (lane < 32) {   // (lanes 30, 31: zero columns; row 15: zero)
+#pragma unroll
+    for (int mm = 0; mm < 15; ++mm) sB[mm * kBP + lane] = col[mm];
+    sB[15 * kBP + lane] = 0.0;
+  }
+  __builtin_amdgcn_wave_barrier();
+  typedef double imu_d4 __attribute__((ext_vector_type(4)));
+  imu_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const double b0 = sB[(4 * kk + mq) * kBP + mn], b1 = sB[(4 * kk + mq) * kBP + 16 + mn];
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op[kk], b0, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op[kk], b1, acc1, 0, 0, 0);
+  }
+  // the lane holds rows mq + 4 reg of columns mn and 16 + mn
+  const double s0 = to[mn / 3] < 0 ? 0.0 : sc, s1 = (mn < 14 && to[(16 + mn) / 3] >= 0) ? sc : 0.0;
   double* Jo = g.J + (size_t)f * 450;
 #pragma unroll
-  for (int k = 0; k < 15; ++k) {
-    double a = 0.0;
-#pragma unroll
-    for (int mm = 0; mm < 15; ++mm) a += A[15 * k + mm] * col[mm];
-    Jo[k * 30 + lane] = is_const ? 0.0 : a * sc;
+  for (int reg = 0; reg < 4; ++reg) {
+    const int row = mq + 4 * reg;
+    if (row < 15) {
+      Jo[row * 30 + mn] = acc0[reg] * s0;
+      if (mn < 14) Jo[row * 30 + 16 + mn] = acc1[reg] * s1;
+    }
   }
 }
 
@@ -245,7 +276,8 @@ __device__ __forceinline__ void imu_prior_body(const SmallGroup g, const int f, 
 template <bool WITH_J>
 __global__ __launch_bounds__(64) void imu_delta_kernel(SmallGroup g, const double* __restrict__ x, const DevLoss* __restrict__ losses,
                                                        double* __restrict__ cost_part) {
-  imu_delta_body<WITH_J>(g, blockIdx.x, x, losses, cost_part, threadIdx.x);
+  __shared__ double sB[kImuStage<WITH_J, 1>];
+  imu_delta_body<WITH_J, 1>(g, blockIdx.x, x, losses, cost_part, threadIdx.x, sB);
 }
 template <bool WITH_J>
 __global__ __launch_bounds__(64) void imu_prior_kernel(SmallGroup g, const double* __restrict__ x, const DevLoss* __restrict__ losses,
@@ -258,7 +290,8 @@ template <bool WITH_J>
 __global__ __launch_bounds__(64) void imu_eval_kernel(SmallGroup delta, SmallGroup prior, const double* __restrict__ x,
                                                       const DevLoss* __restrict__ losses, double* __restrict__ part_delta,
                                                       double* __restrict__ part_prior) {
-  if ((int)blockIdx.x < delta.n) imu_delta_body<WITH_J>(delta, blockIdx.x, x, losses, part_delta, threadIdx.x);
+  __shared__ double sB[kImuStage<WITH_J, 1>];
+  if ((int)blockIdx.x < delta.n) imu_delta_body<WITH_J, 1>(delta, blockIdx.x, x, losses, part_delta, threadIdx.x, sB);
   else imu_prior_body<WITH_J>(prior, blockIdx.x - delta.n, x, losses, part_prior, threadIdx.x);
 }
 // ... and, in a window that also has reprojection factors, both of them as the first workgroups of the reprojection evaluation (four
@@ -266,14 +299,16 @@ __global__ __launch_bounds__(64) void imu_eval_kernel(SmallGroup delta, SmallGro
 // order made wait for the reprojection factors.
 template <bool WITH_J>
 __device__ __forceinline__ void visual_imu_eval_kernel_body(const int bsg_bx, const int bsg_gx, SmallGroup delta, SmallGroup prior, double* __restrict__ part_delta, double* __restrict__ part_prior, int n_imu_blocks, int n, const int4* __restrict__ fac, const double2* __restrict__ pix, const double* __restrict__ wgt, const double* __restrict__ x, const DevCamera* __restrict__ cams, const DevLoss* __restrict__ losses, double2* __restrict__ r_out, double* __restrict__ J_out, double* __restrict__ JB_out, double* __restrict__ cost_part, int count_inactive) {
+  static_assert(kReprojStage<WITH_J> >= kImuStage<WITH_J, 4>, "the IMU units borrow the reprojection factors' staging area");
+  __shared__ __attribute__((aligned(16))) double sJ[kReprojStage<WITH_J>];
   if (bsg_bx < n_imu_blocks) {
     // (the factor index is the same in every lane of the wave: said so, its tables, constants and values are fetched with scalar loads)
     const int f = __builtin_amdgcn_readfirstlane(4 * bsg_bx + ((int)threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    if (f < delta.n) imu_delta_body<WITH_J>(delta, f, x, losses, part_delta, lane);
+    if (f < delta.n) imu_delta_body<WITH_J, 4>(delta, f, x, losses, part_delta, lane, sJ);
     else if (f < delta.n + prior.n) imu_prior_body<WITH_J>(prior, f - delta.n, x, losses, part_prior, lane);
     return;
   }
-  reproj_eval_body<WITH_J>(bsg_bx - n_imu_blocks, n, fac, pix, wgt, x, cams, losses, r_out, J_out, JB_out, cost_part, count_inactive);
+  reproj_eval_body<WITH_J>(bsg_bx - n_imu_blocks, n, fac, pix, wgt, x, cams, losses, r_out, J_out, JB_out, cost_part, count_inactive, sJ);
 }
 template <bool WITH_J>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void visual_imu_eval_kernel(SmallGroup delta, SmallGroup prior, double* __restrict__ part_delta, double* __restrict__ part_prior, int n_imu_blocks, int n, const int4* __restrict__ fac, const double2* __restrict__ pix, const double* __restrict__ wgt, const double* __restrict__ x, const DevCamera* __restrict__ cams, const DevLoss* __restrict__ losses, double2* __restrict__ r_out, double* __restrict__ J_out, double* __restrict__ JB_out, double* __restrict__ cost_part, int count_inactive) {
@@ -379,14 +414,17 @@ void launch_imu_eval(hipStream_t s, const SmallGroup& delta, const SmallGroup& p
 // ---------------------------------------------------------------------------------------------------
 // relative pose (with / without extrinsics): one lane per factor
 // ---------------------------------------------------------------------------------------------------
+// doubles of LDS a 128-thread workgroup of the pose-only evaluation lends its body: two rows of the 64 factors of each of its two waves
+// (relative-pose factors with extrinsics: 18 columns) or the B operands of two IMU units
+template <bool WITH_J> constexpr int kSmallStage = WITH_J ? 2 * 64 * 2 * 18 : 2;
 template <bool EXT, bool WITH_J>
 __device__ __forceinline__ void relpose_body(const SmallGroup g, const double* __restrict__ x, const DevLoss* __restrict__ losses,
-                                             double* __restrict__ cost_part, const int block) {
+                                             double* __restrict__ cost_part, const int block, double* sJ /* kSmallStage<WITH_J> doubles of LDS, 16-byte aligned */) {
+  static_assert(kSmallStage<WITH_J> >= kImuStage<WITH_J, 2>, "stage");
   constexpr int NV = EXT ? 6 : 4;
   constexpr int TW = 3 * NV;
   // (Jacobian rows leave through LDS: a lane per factor storing its 864-byte Jacobian 8 bytes at a time touches 64 cache lines per
   // store instruction — 44 us for C3's 20 000 factors; see the end of the kernel)
-  __shared__ __attribute__((aligned(16))) double sJ[WITH_J ? 2 * 64 * 2 * TW : 2];
   const int f_raw = block * 128 + threadIdx.x;
   const bool live = f_raw < g.n;
   const int f = live ? f_raw : g.n - 1;   // (idle lanes of the last workgroup redo the last factor and store nothing)
@@ -553,7 +591,8 @@ __device__ __forceinline__ void relpose_body(const SmallGroup g, const double* _
 template <bool EXT, bool WITH_J>
 __global__ __launch_bounds__(128) void relpose_kernel(SmallGroup g, const double* __restrict__ x, const DevLoss* __restrict__ losses,
                                                       double* __restrict__ cost_part) {
-  relpose_body<EXT, WITH_J>(g, x, losses, cost_part, (int)blockIdx.x);
+  __shared__ __attribute__((aligned(16))) double sJ[kSmallStage<WITH_J>];
+  relpose_body<EXT, WITH_J>(g, x, losses, cost_part, (int)blockIdx.x, sJ);
 }
 // a lidar-inertial window: the IMU factors (a wave each) as the first workgroups of the relative-pose evaluation, instead of a launch of
 // their own behind it (as visual_imu_eval_kernel does for a visual-inertial window)
@@ -561,14 +600,14 @@ __global__ __launch_bounds__(128) void relpose_kernel(SmallGroup g, const double
 template <bool EXT, bool WITH_J>
 __device__ __forceinline__ void relpose_imu_eval_body(const int bx, const SmallGroup& delta, const SmallGroup& prior, double* __restrict__ part_delta,
                                                       double* __restrict__ part_prior, int n_imu_blocks, const SmallGroup& g, const double* __restrict__ x,
-                                                      const DevLoss* __restrict__ losses, double* __restrict__ cost_part) {
+                                                      const DevLoss* __restrict__ losses, double* __restrict__ cost_part, double* sJ /* kSmallStage<WITH_J> doubles of LDS */) {
   if (bx < n_imu_blocks) {
     const int f = __builtin_amdgcn_readfirstlane(2 * bx + ((int)threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    if (f < delta.n) imu_delta_body<WITH_J>(delta, f, x, losses, part_delta, lane);
+    if (f < delta.n) imu_delta_body<WITH_J, 2>(delta, f, x, losses, part_delta, lane, sJ);
     else if (f < delta.n + prior.n) imu_prior_body<WITH_J>(prior, f - delta.n, x, losses, part_prior, lane);
     return;
   }
-  relpose_body<EXT, WITH_J>(g, x, losses, cost_part, bx - n_imu_blocks);
+  relpose_body<EXT, WITH_J>(g, x, losses, cost_part, bx - n_imu_blocks, sJ);
 }
 template <bool EXT, bool WITH_J>
 __global__ __launch_bounds__(128) void relpose_imu_eval_kernel(SmallGroup delta, SmallGroup prior, double* __restrict__ part_delta,
@@ -583,7 +622,8 @@ __global__ __launch_bounds__(128) void relpose_imu_eval_kernel(SmallGroup delta,
     final_reduce_unit<128>((int)blockIdx.x, (int)threadIdx.x, red, n_units, sred);
     return;
   }
-  relpose_imu_eval_body<EXT, WITH_J>((int)blockIdx.x - n_units, delta, prior, part_delta, part_prior, n_imu_blocks, g, x, losses, cost_part);
+  __shared__ __attribute__((aligned(16))) double sJ[kSmallStage<WITH_J>];
+  relpose_imu_eval_body<EXT, WITH_J>((int)blockIdx.x - n_units, delta, prior, part_delta, part_prior, n_imu_blocks, g, x, losses, cost_part, sJ);
 }
 // one launch over several windows (bsgpu_batch.cpp): blockIdx.y picks the window of list `bsg_list`, its arguments come from memory.  A
 // window without relative-pose factors of this kind has a zero grid in its entry; EXT (the extrinsics slots) is the group's type.
@@ -604,8 +644,9 @@ __global__ __launch_bounds__(128) void relpose_imu_eval_kernel_batch(const relpo
   const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
   const relpose_imu_eval_kernel_Args& a = bsg_A[bsg_w];
   if ((int)blockIdx.x >= a.bsg_grid) return;
-  if (a.g.type == BSGPU_F_RELPOSE_EXT) relpose_imu_eval_body<true, WITH_J>((int)blockIdx.x, a.delta, a.prior, a.part_delta, a.part_prior, a.n_imu_blocks, a.g, a.x, a.losses, a.cost_part);
-  else relpose_imu_eval_body<false, WITH_J>((int)blockIdx.x, a.delta, a.prior, a.part_delta, a.part_prior, a.n_imu_blocks, a.g, a.x, a.losses, a.cost_part);
+  __shared__ __attribute__((aligned(16))) double sJ[kSmallStage<WITH_J>];
+  if (a.g.type == BSGPU_F_RELPOSE_EXT) relpose_imu_eval_body<true, WITH_J>((int)blockIdx.x, a.delta, a.prior, a.part_delta, a.part_prior, a.n_imu_blocks, a.g, a.x, a.losses, a.cost_part, sJ);
+  else relpose_imu_eval_body<false, WITH_J>((int)blockIdx.x, a.delta, a.prior, a.part_delta, a.part_prior, a.n_imu_blocks, a.g, a.x, a.losses, a.cost_part, sJ);
 }
 void batchargs_relpose_imu_eval(BatchArgTable& t, const SmallGroup* g /* null: the window has no such launch */, const SmallGroup& delta, const SmallGroup& prior, const double* x,
                                 const DevLoss* losses, double* cost_part, double* part_delta, double* part_prior) {
@@ -1340,11 +1381,12 @@ __device__ __forceinline__ void small_eval_set_dispatch(const small_eval_set_Arg
   const SmallGroup& g = a.g[gi];
   const int bx = bsg_bx - a.first[gi];
   double* part = a.part[gi];
+  __shared__ __attribute__((aligned(16))) double sJ[kSmallStage<WITH_J>];
   switch (g.type) {
-    case BSGPU_F_IMU_DELTA: { const int f = __builtin_amdgcn_readfirstlane(2 * bx + ((int)threadIdx.x >> 6)); if (f < g.n) imu_delta_body<WITH_J>(g, f, a.x, a.losses, part, threadIdx.x & 63); break; }
+    case BSGPU_F_IMU_DELTA: { const int f = __builtin_amdgcn_readfirstlane(2 * bx + ((int)threadIdx.x >> 6)); if (f < g.n) imu_delta_body<WITH_J, 2>(g, f, a.x, a.losses, part, threadIdx.x & 63, sJ); break; }
     case BSGPU_F_IMU_PRIOR: { const int f = __builtin_amdgcn_readfirstlane(2 * bx + ((int)threadIdx.x >> 6)); if (f < g.n) imu_prior_body<WITH_J>(g, f, a.x, a.losses, part, threadIdx.x & 63); break; }
-    case BSGPU_F_RELPOSE_EXT: relpose_body<true, WITH_J>(g, a.x, a.losses, part, bx); break;
-    case BSGPU_F_RELPOSE: relpose_body<false, WITH_J>(g, a.x, a.losses, part, bx); break;
+    case BSGPU_F_RELPOSE_EXT: relpose_body<true, WITH_J>(g, a.x, a.losses, part, bx, sJ); break;
+    case BSGPU_F_RELPOSE: relpose_body<false, WITH_J>(g, a.x, a.losses, part, bx, sJ); break;
     case BSGPU_F_ABSPOSE: abspose_kernel_body<WITH_J>(g, a.x, a.losses, part, bx); break;
     case BSGPU_F_ABS_VEC3: vec3_kernel_body<false, WITH_J>(g, a.x, a.losses, part, bx); break;
     case BSGPU_F_REL_VEC3: vec3_kernel_body<true, WITH_J>(g, a.x, a.losses, part, bx); break;

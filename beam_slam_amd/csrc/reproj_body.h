@@ -10,13 +10,14 @@ namespace bsg {
 // transposed through LDS so that the AoS rows leave as contiguous 16-byte-per-lane stores.
 // Algorithmic bytes per factor: 16 (idx+meta) + 16 (pixel) + 8 (w) in, 16 (r) + 144 (J) out = 200.
 // ---------------------------------------------------------------------------------------------------
+// (the staging area is the caller's: the launch that also carries IMU factors lends the same bytes to their workgroups)
+template <bool WITH_J> constexpr int kReprojStage = WITH_J ? 4 * 64 * 18 : 4;
 template <bool WITH_J>
 __device__ __forceinline__ void reproj_eval_body(const int block, int n, const int4* __restrict__ fac, const double2* __restrict__ pix,
                                                  const double* __restrict__ wgt, const double* __restrict__ x,
                                                  const DevCamera* __restrict__ cams, const DevLoss* __restrict__ losses,
                                                  double2* __restrict__ r_out, double* __restrict__ J_out, double* __restrict__ JB_out,
-                                                 double* __restrict__ cost_part, int count_inactive) {
-  __shared__ __attribute__((aligned(16))) double sJ[WITH_J ? 4 * 64 * 18 : 4];
+                                                 double* __restrict__ cost_part, int count_inactive, double* sJ /* kReprojStage<WITH_J> doubles of LDS, 16-byte aligned */) {
   __shared__ double sred[4];
   const int f = block * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
