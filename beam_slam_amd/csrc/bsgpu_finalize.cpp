@@ -931,6 +931,8 @@ int finalize(bsgpu_ctx* c) {
         ord.adj_ptr[a + 1] = (int)ord.adj.size();
       }
       if (const char* ev = getenv("BSGPU_DIM_ORDER_DEPTH")) ord.max_depth = std::max(0, atoi(ev));
+      if (const char* ev = getenv("BSGPU_DIM_ABSORB")) ord.absorb = atoi(ev) != 0;   // (0: no separator joins its parent — dim_order.h absorb_separators())
+      if (const char* ev = getenv("BSGPU_DIM_T_HOP")) ord.t_hop = atof(ev);   // (scripts/ab_absorb.sh: 5 .. 10 measure the same on C2 / C3 / the small windows, 4 costs C3 5 %)
       lap("  order: adjacency lists");
       ord.build();
       lap("  order: dissection");

@@ -162,6 +162,56 @@ struct DimOrder {
     return cost_split;
   }
 
+  // A separator joins its parent separator when ONE chain over both is shorter than two chains and the hand-over between them (round 5): the
+  // recursion above only ever cuts a set in two, so a window of the reference's size (300 reduced dimensions) came out as a piece below a
+  // 48-dimensional separator below another 48-dimensional separator — 9 + 5 + 9 us of the factorisation's 53 for six 16-pivot steps, which a
+  // single two-tile chain does in 15.  Moving a supernode's blocks up into an ancestor keeps every coupling inside a supernode or towards an
+  // ancestor.  down[] = the estimated path from the leaves up to and including a node; a merge is taken when it shortens the parent's.
+  bool absorb = true;
+  void absorb_separators() {
+    const int n = (int)nodes.size();
+    for (bool changed = true; changed;) {
+      changed = false;
+      std::vector<double> down(n, 0.0);
+      for (int i = n - 1; i >= 0; --i) {   // (a node's children come after it)
+        if (nodes[i].dims <= 0) continue;
+        down[i] += node_cost(nodes[i].dims);
+        const int p = nodes[i].parent;
+        if (p >= 0) down[p] = std::max(down[p], down[i]);   // (below(p) so far; p's own cost is added when the loop reaches it)
+      }
+      for (int c = n - 1; c >= 0 && !changed; --c) {
+        Node& C = nodes[c];
+        if (!C.is_sep || C.dims <= 0 || C.parent < 0) continue;
+        Node& P = nodes[C.parent];
+        if (!P.is_sep || P.dims <= 0) continue;
+        double below_c = 0.0, other = 0.0;
+        for (int k = 0; k < n; ++k) {
+          if (nodes[k].dims <= 0) continue;
+          if (nodes[k].parent == c) below_c = std::max(below_c, down[k]);
+          else if (nodes[k].parent == C.parent && k != c) other = std::max(other, down[k]);
+        }
+        const double before = std::max(below_c + node_cost(C.dims), other) + node_cost(P.dims);
+        const double after = std::max(below_c, other) + node_cost(P.dims + C.dims);
+        if (after + 1e-9 >= before) continue;
+        P.verts.insert(P.verts.end(), C.verts.begin(), C.verts.end());
+        P.dims += C.dims;
+        for (int k = 0; k < n; ++k) if (nodes[k].parent == c) nodes[k].parent = C.parent;
+        C.verts.clear(); C.dims = 0;
+        changed = true;
+      }
+    }
+    // depths again (a node one below its parent), and the estimate
+    for (int i = 0; i < n; ++i) nodes[i].depth = nodes[i].parent < 0 ? 0 : nodes[nodes[i].parent].depth + 1;
+    std::vector<double> down(n, 0.0);
+    double est = 0.0;
+    for (int i = n - 1; i >= 0; --i) {
+      if (nodes[i].dims <= 0) continue;
+      down[i] += node_cost(nodes[i].dims);
+      if (nodes[i].parent >= 0) down[nodes[i].parent] = std::max(down[nodes[i].parent], down[i]); else est = std::max(est, down[i]);
+    }
+    est_path_us = est;
+  }
+
   void build() {
     const int nbk = (int)blk_t0.size();
     nodes.clear();
@@ -174,11 +224,12 @@ struct DimOrder {
       P.verts.insert(P.verts.end(), mg.second.begin(), mg.second.end());
       for (int v : mg.second) P.dims += blk_w[v];
     }
+    if (absorb) absorb_separators();
     for (Node& nd : nodes) std::sort(nd.verts.begin(), nd.verts.end());
     n_nodes = (int)nodes.size();
     // ---- layout: the pieces in the order they were made (left to right), then the separators, deepest first
     depth = 0;
-    for (const Node& nd : nodes) if (nd.is_sep) depth = std::max(depth, nd.depth + 1);
+    for (const Node& nd : nodes) if (nd.is_sep && nd.dims > 0) depth = std::max(depth, nd.depth + 1);
     dpos.assign(std::max(1, n_pose), 0);
     nreal.clear(); piece_ranges.clear();
     sep_ranges_by_level.assign(depth, {});

@@ -26,6 +26,7 @@ int main(int argc, char** argv) {
   if (getenv("T_CHAIN0")) o.t_chain0 = atof(getenv("T_CHAIN0"));
   if (getenv("DEPTH")) o.max_depth = atoi(getenv("DEPTH"));
   if (getenv("HUB")) o.hub_frac = atof(getenv("HUB"));
+  if (getenv("ABSORB")) o.absorb = atoi(getenv("ABSORB")) != 0;
   o.build();
   printf("n_pose %d blocks %d: T %d nodes %d depth %d est %.1f us\n", o.n_pose, nbk, o.T, o.n_nodes, o.depth, o.est_path_us);
   for (size_t i = 0; i < o.nodes.size(); ++i) {

@@ -75,6 +75,7 @@ SETTINGS = [
     {"BSGPU_DIM_ORDER": "0", "BSGPU_CHAINS": "4"},
     {"BSGPU_DIM_ORDER_DEPTH": "2"},                              # a shallower dissection: fewer, larger pieces
     {"BSGPU_DIM_ORDER_DEPTH": "0"},                              # one supernode: natural order, the whole system one sequence of chains
+    {"BSGPU_DIM_ABSORB": "0"},                                   # no separator joins its parent separator (dim_order.h absorb_separators)
     {"BSGPU_SHARED": "0"},
     {"BSGPU_GRAPH": "1"},                                        # the LM step replayed as hipGraphs
     {"BSGPU_FLATTEN": "device"},
