@@ -23,13 +23,18 @@ pr = (synthetic.idp_window(n_kf=40, n_lm=3000, seed=78) if kind == "idp" else
       synthetic.lio_window(n_kf=60, n_rel=6000, seed=79) if kind == "lio" else synthetic.vio_window(n_kf=90, n_lm=6000, seed=77))
 g = GpuSolver(0)
 pr.load(g)
-if kind == "prior":   # the window after a slide with true marginalisation: its first key frame (and the landmarks only it sees) as a dense prior
+if kind in ("prior", "lio_prior"):   # the window after a slide with true marginalisation: its first key frame (and the landmarks only it sees) as a dense prior
     from beam_slam_amd import capi
-    pr = synthetic.vio_window(n_kf=24, n_lm=700, seed=81)
-    kf = pr.meta["kf_blocks"]
-    idx = np.concatenate([c[0] for c in pr.factors[capi.F_REPROJ]])
-    seen0 = set(int(v) for v in idx[idx[:, 0] == int(kf[0, 0]), 2])
-    first_only = [l for l in seen0 if set(idx[idx[:, 2] == l][:, 0]) == {int(kf[0, 0])}]
+    if kind == "prior":
+        pr = synthetic.vio_window(n_kf=24, n_lm=700, seed=81)
+        kf = pr.meta["kf_blocks"]
+        idx = np.concatenate([c[0] for c in pr.factors[capi.F_REPROJ]])
+        seen0 = set(int(v) for v in idx[idx[:, 0] == int(kf[0, 0]), 2])
+        first_only = [l for l in seen0 if set(idx[idx[:, 2] == l][:, 0]) == {int(kf[0, 0])}]
+    else:   # a lidar-inertial window: no landmarks, the prior couples the key frames the first one's scan registrations reached
+        pr = synthetic.lio_window(n_kf=30, n_rel=1500, seed=82)
+        kf = pr.meta["kf_blocks"]
+        first_only = []
     marg = [int(b) for b in kf[0]] + first_only
     pr.load(g); g.solve()
     kept, A, b, xbar = g.marginalize(marg, pr.size)
@@ -167,6 +172,21 @@ def default_prior_run():
 def test_window_with_dense_prior_under_alternative_paths(default_prior_run, setting):
     r = _run(setting, "prior")
     d = default_prior_run
+    assert r["it"] == d["it"] and r["acc"] == d["acc"]
+    assert abs(r["cost"] - d["cost"]) <= 1e-9 * d["cost"]
+    assert max(abs(a - b) for a, b in zip(r["x"], d["x"])) < 1e-7
+
+
+@pytest.fixture(scope="module")
+def default_lio_prior_run():
+    return _run({}, "lio_prior")
+
+
+@pytest.mark.parametrize("setting", [{"BSGPU_MARG_RIDE": "0"}, {"BSGPU_EVAL_SEPARATE": "1"}], ids=lambda s: ",".join("%s=%s" % kv for kv in s.items()))
+def test_lidar_inertial_window_with_dense_prior_under_alternative_paths(default_lio_prior_run, setting):
+    """no landmark launches to ride in: the prior's evaluation and assembly ride with the relative-pose factors', its model-cost terms go by themselves"""
+    r = _run(setting, "lio_prior")
+    d = default_lio_prior_run
     assert r["it"] == d["it"] and r["acc"] == d["acc"]
     assert abs(r["cost"] - d["cost"]) <= 1e-9 * d["cost"]
     assert max(abs(a - b) for a, b in zip(r["x"], d["x"])) < 1e-7
