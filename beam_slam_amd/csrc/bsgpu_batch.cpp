@@ -235,7 +235,7 @@ bool build_plan(BatchPlan& P, bsgpu_ctx* const* ctxs, int n, const bsgpu_options
     if (!batchargs_small_assemble_set(P.t_asm_set, c->small_factorwise + 2 + taken + taken2, kNumInternal - 2 - taken - taken2, c->d_S, c->npad, c->plan.rhs_row, c->d_grad,
                                       c->d_hdiag, c->d_dpos)) return false;
     batchargs_small_assemble_seg(P.t_asm_seg, c->d_small_groups, c->n_sa_seg, c->d_sa_seg_start, c->d_sa_seg_ra, c->d_sa_seg_rb, c->d_sa_contrib, c->d_S, c->npad, c->plan.rhs_row,
-                                 c->d_grad, c->d_hdiag, c->d_dpos, units2 > 0 ? &set2 : nullptr, units2, c->n_asm_grp, c->d_asm_grp, c->d_asm_gfac);
+                                 c->d_grad, c->d_hdiag, c->d_dpos, units2 > 0 ? &set2 : nullptr, units2, c->n_asm_grp, c->d_asm_grp);
     batchargs_marg_assemble(P.t_marg_asm, mg ? &mg->dev : nullptr, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_dpos);
     batchargs_marg_mcc(P.t_marg_mcc, mg ? &mg->dev : nullptr, c->d_delta, mg ? mg->part_mcc : nullptr);
     batchargs_grad_norms_pose_diag(P.t_gn, c->nb, c->d_blk_xoff, c->d_blk_toff, c->d_blk_size, c->d_blk_manifold, c->d_x, c->d_grad, c->d_gpart, c->n_pose, c->d_S, c->npad,

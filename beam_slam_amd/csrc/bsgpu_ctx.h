@@ -172,7 +172,6 @@ struct bsgpu_ctx {
   int2* d_sa_contrib = nullptr;
   int n_asm_grp = 0;             // groups of factors with identical slots (AsmGroup), assembled a wave per group
   AsmGroup* d_asm_grp = nullptr;
-  int* d_asm_gfac = nullptr;
   ReduceEntry* d_reduce = nullptr;
   int n_reduce = 0;
   double* d_part_upd = nullptr;

@@ -326,44 +326,58 @@ BSG_DEV void grad_norms_unit(int unit, int tid, const GradNormRide& G, double* s
 }
 
 // assembly of ONE factor of a pose-only group into the dense reduced system by the calling workgroup (`nthr` threads): J staged in LDS
-// (sJ >= 15 * 30 doubles, sr >= 15, st >= 10 ints), lanes stride over the (column a, column b) pairs; FP64 atomics into S, the rhs row,
+// (sJ >= 15 * 30 doubles, sr >= 15, st >= 60 ints), lanes stride over the (column a, column b) pairs; FP64 atomics into S, the rhs row,
 // grad and hdiag.  `unit` = workgroup index over the set (SmallGroupSet::first).  Shared by small_assemble_kernel (a launch of its own)
 // and pairs_kernel (whose extra workgroups do this work underneath the camera pairs: one launch less on the dependent path).
 // (part / parts: the factor's column pairs are shared out among `parts` workgroups — the riders of the pair launch are single waves, and a
 //  window of the reference's size waits for the slowest of them: 900 column pairs of an IMU factor on 64 lanes)
-BSG_DEV void small_assemble_unit(const SmallGroupSet& set, int unit, int lane, int nthr, double* sJ, double* sr, int* st, double* __restrict__ S, int ld,
+BSG_DEV void small_assemble_unit(const SmallGroupSet& set, int unit, int lane, int nthr, double* sJ, double* sr, int* st /* 60 ints */, double* __restrict__ S, int ld,
                                  int rhs_row, double* __restrict__ grad, double* __restrict__ hdiag, const int* __restrict__ perm, int part = 0, int parts = 1) {
   if (unit >= set.first[set.n]) return;   // (padding of the caller's grid)
   int gi = 0;
   while (gi + 1 < set.n && unit >= set.first[gi + 1]) ++gi;
   const SmallGroup& g = set.g[gi];
   const int f = unit - set.first[gi];
-  if (!g.active[f]) return;
-  const int m = g.m, tw = 3 * g.nv;
-  const double* J = g.J + (size_t)f * m * tw;
-  for (int i = lane; i < m * tw; i += nthr) sJ[i] = J[i];
-  if (lane < m) sr[lane] = g.r[(size_t)f * m + lane];
-  if (lane < g.nv) st[lane] = g.toff[(size_t)f * g.nv + lane];
-  __syncthreads();
+  const int m = g.m, tw = 3 * g.nv, mt = m * tw;
+  // every load of the factor is asked for before any is waited for (a staging loop of load, wait, store per pass was eight dependent trips
+  // for a single wave, and a trip through perm[] per column pair after it): the rows, the residual, the flag; then the columns' tangent
+  // indices and their places in the reduced system, which go to LDS with the rows — the sums below touch no table in memory
+  const unsigned char act = g.active[f];
+  const double* J = g.J + (size_t)f * mt;
+  constexpr int kLoads = 8;   // (15 x 30 doubles on 64 lanes)
+  double v[kLoads];
+#pragma unroll
+  for (int it = 0; it < kLoads; ++it) v[it] = J[min(lane + it * nthr, mt - 1)];
+  const double rv = g.r[(size_t)f * m + min(lane, m - 1)];
   const int wcut = 3 * (g.nv - 1) + g.w_last;   // columns >= wcut are the padding of a narrow last slot
+  int ta = -1, pa = 0;
+  if (lane < tw) {
+    const int t = g.toff[(size_t)f * g.nv + lane / 3];
+    ta = (t < 0 || lane >= wcut) ? -1 : t + lane % 3;
+    pa = ta >= 0 ? perm[ta] : 0;
+  }
+  if (!act) return;
+#pragma unroll
+  for (int it = 0; it < kLoads; ++it) { const int i = lane + it * nthr; if (i < mt) sJ[i] = v[it]; }
+  if (lane < m) sr[lane] = rv;
+  if (lane < tw) { st[lane] = ta; st[30 + lane] = pa; }
+  __syncthreads();
   for (int p = lane + nthr * part; p < tw * tw; p += nthr * parts) {   // (an IMU factor has 900 column pairs)
     const int a = p / tw, b = p % tw;
-    const int ta = st[a / 3], tb = st[b / 3];
-    if (ta < 0 || tb < 0 || a >= wcut || b >= wcut) continue;
+    if (st[a] < 0 || st[b] < 0) continue;
     double acc = 0.0;
     for (int k = 0; k < m; ++k) acc += sJ[k * tw + a] * sJ[k * tw + b];
-    const int ra = ta + a % 3, rb = tb + b % 3;
-    atomicAdd(&S[(size_t)perm[ra] * ld + perm[rb]], acc);
+    atomicAdd(&S[(size_t)st[30 + a] * ld + st[30 + b]], acc);
   }
   if (part != 0) return;
   for (int a = lane; a < wcut; a += nthr) {
-    const int ta = st[a / 3];
-    if (ta < 0) continue;
+    const int ra = st[a];
+    if (ra < 0) continue;
     double gs = 0.0, hs = 0.0;
     for (int k = 0; k < m; ++k) { const double j = sJ[k * tw + a]; gs += j * sr[k]; hs += j * j; }
-    atomicAdd(&S[(size_t)rhs_row * ld + perm[ta + a % 3]], gs);
-    atomicAdd(&grad[ta + a % 3], gs);
-    atomicAdd(&hdiag[ta + a % 3], hs);
+    atomicAdd(&S[(size_t)rhs_row * ld + st[30 + a]], gs);
+    atomicAdd(&grad[ra], gs);
+    atomicAdd(&hdiag[ra], hs);
   }
 }
 
@@ -377,24 +391,45 @@ BSG_DEV void small_mcc_unit(const SmallGroupSet& set, int unit, int t128, const 
   double* part = set.part[gi];
   const int wg = unit - set.first[gi];
   const int id = wg * 128 + t128;
-  const int m = g.m;
-  double acc = 0.0;
-  if (id < g.n * m) {
-    const int f = id / m, k = id - f * m;
-    if (g.active[f]) {
-      const int tw = 3 * g.nv;
-      const double* J = g.J + ((size_t)f * m + k) * tw;
-      const int* to = g.toff + (size_t)f * g.nv;
-      double jv = 0.0;
-      for (int sl = 0; sl < g.nv; ++sl) {
-        const int t = to[sl];
-        if (t < 0) continue;
-        if (sl == g.nv - 1 && g.w_last < 3) { for (int i = 0; i < g.w_last; ++i) jv += J[3 * sl + i] * delta[t + i]; continue; }
-        jv += J[3 * sl] * delta[t] + J[3 * sl + 1] * delta[t + 1] + J[3 * sl + 2] * delta[t + 2];
+  const int m = g.m, nv = g.nv, tw = 3 * nv;
+  // The loads are asked for in rounds, not one slot after the other (flag, then per slot: offset, branch, three entries of J and of the
+  // step — 13 dependent trips for a relative-pose row with extrinsics, 21 for an IMU row): the flag, the residual and every slot's
+  // offset first; then, three slots at a time, nine entries of the row and the nine of the step they multiply.  Indices are clamped to
+  // entries that exist and the values masked, so that no load sits behind a lane's branch.
+  const bool valid = id < g.n * m;
+  const int idc = valid ? id : 0;
+  const int f = idc / m, k = idc - f * m;
+  const unsigned char act = g.active[f];
+  const int* __restrict__ to = g.toff + (size_t)f * nv;
+  constexpr int kSlots = 12;   // (an IMU factor has ten)
+  int t[kSlots];
+#pragma unroll
+  for (int sl = 0; sl < kSlots; ++sl) t[sl] = to[min(sl, nv - 1)];
+  const double rk = g.r[(size_t)f * m + k];
+  const double* __restrict__ J = g.J + ((size_t)f * m + k) * tw;
+  double jv = 0.0;
+#pragma unroll
+  for (int c = 0; c < kSlots / 3; ++c) {
+    if (3 * c >= nv) break;   // (uniform)
+    double Jc[9], dc[9];
+    bool on[9];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int sl = 3 * c + j;
+      const bool slot_on = sl < nv && t[sl] >= 0;
+      const int w = sl == nv - 1 ? g.w_last : 3;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        on[3 * j + i] = slot_on && i < w;
+        Jc[3 * j + i] = J[min(3 * sl + i, tw - 1)];
+        dc[3 * j + i] = delta[on[3 * j + i] ? t[sl] + i : 0];
       }
-      acc = -jv * (g.r[(size_t)f * m + k] + 0.5 * jv);
     }
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      jv += (on[3 * j] ? Jc[3 * j] * dc[3 * j] : 0.0) + (on[3 * j + 1] ? Jc[3 * j + 1] * dc[3 * j + 1] : 0.0) + (on[3 * j + 2] ? Jc[3 * j + 2] * dc[3 * j + 2] : 0.0);
   }
+  const double acc = (valid && act) ? -jv * (rk + 0.5 * jv) : 0.0;
   const double w = wave_sum(acc);
   if ((t128 & 63) == 0) s2[t128 >> 6] = w;
   __syncthreads();

@@ -585,7 +585,7 @@ int finalize(bsgpu_ctx* c) {
     std::vector<Contrib> cl, tmp;
     std::vector<int> cnt;
     std::vector<AsmGroup> asm_grp;
-    std::vector<int> asm_gfac;
+    size_t asm_nfac = 0;
     auto sort_by_block = [&](size_t lo, size_t hi) {   // cl[lo, hi) by (ra, rb), stable: LSD counting sort, rb then ra
       const size_t n = hi - lo;
       if (n < 2) return;
@@ -633,9 +633,24 @@ int finalize(bsgpu_ctx* c) {
           size_t j = i + 1;
           while (j < order.size() && std::equal(&toffs[(size_t)order[i] * nv], &toffs[(size_t)order[i] * nv] + nv, &toffs[(size_t)order[j] * nv])) ++j;
           if ((int)(j - i) >= kGroupMin) {
-            for (size_t q0 = i; q0 < j; q0 += 32)   // (one pass through LDS per workgroup: a large group is cut)
-              asm_grp.push_back({t, (int)asm_gfac.size() + (int)(q0 - i), (int)std::min<size_t>(32, j - q0), 0});
-            for (size_t q = i; q < j; ++q) { asm_gfac.push_back(order[q]); grouped[order[q]] = 1; }
+            // (one pass through LDS per workgroup: a large group is cut, into pieces of equal size)
+            const size_t n_in = j - i, pieces = (n_in + kAsmGroupMax - 1) / kAsmGroupMax;
+            size_t q0 = i;
+            for (size_t pc = 0; pc < pieces; ++pc) {
+              AsmGroup rec{};
+              rec.type = t; rec.count = (int)(n_in / pieces + (pc < n_in % pieces ? 1 : 0)); rec.m = sg.m; rec.nv = nv;
+              rec.te = 0;
+              for (int sl = 0; sl < 6; ++sl) {
+                rec.toff[sl] = sl < nv ? toffs[(size_t)order[i] * nv + sl] : -1;
+                if (rec.toff[sl] >= 0) rec.te = 3 * (sl + 1);
+              }
+              rec.J = sg.J; rec.r = sg.r;
+              for (int q = 0; q < kAsmGroupMax; ++q) rec.fac[q] = order[q0 + std::min(q, rec.count - 1)];
+              asm_grp.push_back(rec);
+              q0 += rec.count;
+            }
+            for (size_t q = i; q < j; ++q) grouped[order[q]] = 1;
+            asm_nfac += j - i;
             any_group = true;
           }
           i = j;
@@ -675,9 +690,9 @@ int finalize(bsgpu_ctx* c) {
     if (timing && !asm_grp.empty()) {
       int mx = 0;
       for (const AsmGroup& gq : asm_grp) mx = std::max(mx, gq.count);
-      fprintf(stderr, "[bsgpu finalize] same-slot groups: %d groups, %d factors, largest %d\n", (int)asm_grp.size(), (int)asm_gfac.size(), mx);
+      fprintf(stderr, "[bsgpu finalize] same-slot groups: %d groups, %d factors, largest %d\n", (int)asm_grp.size(), (int)asm_nfac, mx);
     }
-    c->d_asm_grp = c->upload(asm_grp); c->d_asm_gfac = c->upload(asm_gfac);
+    c->d_asm_grp = c->upload(asm_grp);
     if (timing) lap("  lists: contributions");
     std::vector<SmallGroup> groups(c->small, c->small + kNumInternal);
     c->d_small_groups = c->upload(groups);

@@ -332,7 +332,7 @@ bool batchargs_small_assemble_set(BatchArgTable& t, const SmallGroup* groups, in
 void launch_small_assemble_set_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n);
 void batchargs_small_assemble_seg(BatchArgTable& t, const SmallGroup* groups_dev, int n_seg, const int* seg_start, const int* seg_ra, const int* seg_rb, const int2* contrib,
                                   double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm, const SmallGroupSet* fw, int n_fw_units, int n_grp,
-                                  const AsmGroup* grp, const int* gfac);
+                                  const AsmGroup* grp);
 void launch_small_assemble_seg_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n);
 bool batchargs_small_mcc(BatchArgTable& t, const SmallGroup* groups, double* const* parts, int n_groups, const double* delta, const UpdateRide* upd, const ZeroStep* zero);
 void launch_small_mcc_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n);
@@ -367,13 +367,24 @@ int small_assemble_first_set(const SmallGroup* groups, int n_groups, SmallGroupS
 void launch_small_assemble_set(hipStream_t s, const SmallGroup* groups, int n_groups, double* S, int ld, int rhs_row, double* grad,
                                double* hdiag, const int* perm);
 // factors of one pose-only type that name the SAME variables in every slot (the ~21 lidar constraints between two keyframes of a
-// lidar-inertial window): their J^T J is summed by one wave before it is added to the reduced system (k_small.hip: small_assemble_group)
-struct AsmGroup { int type, first, count, pad; };   // factors gfac[first .. first + count)
+// lidar-inertial window): their J^T J is summed on the matrix cores before it is added to the reduced system (k_small.hip: small_assemble_group).
+// The record carries everything its workgroup needs — a lane's first load is its factor's index, its second the factor's rows (no
+// trips through the type table and a factor list in between).
+constexpr int kAsmGroupMax = 24;   // factors of a record (one pass through LDS: 144 rows of <= 18, 21 KB — seven workgroups to a compute unit)
+struct AsmGroup {
+  int type, count, m, nv;
+  int toff[6];            // tangent offset of every slot (-1: constant, or not a slot)
+  int te;                 // columns up to and including the last slot that is not constant: the sums beyond are zeros and are not formed
+  int pad;
+  const double* J;        // the type's Jacobian / residual tables
+  const double* r;
+  int fac[kAsmGroupMax];  // the factors (entries past count repeat the last one)
+};
 // (marg: the window's dense prior assembled by the same launch; returns whether it was carried)
 bool launch_small_assemble_seg(hipStream_t s, const SmallGroup* groups_dev, int n_seg, const int* seg_start, const int* seg_ra, const int* seg_rb,
                                const int2* contrib, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm,
                                const SmallGroupSet* fw = nullptr, int n_fw_units = 0, int n_grp = 0, const AsmGroup* grp = nullptr,
-                               const int* gfac = nullptr, const MargDev* marg = nullptr);
+                               const MargDev* marg = nullptr);
 void launch_pose_diag(hipStream_t s, int n_pose, double* S, int ld, const double* hdiag, const double* radius_ptr,
                       int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* scale,
                       double* dcl, int npad, const int* iperm, double radius_val = 0.0 /* used when radius_ptr is null */);

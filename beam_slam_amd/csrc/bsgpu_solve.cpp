@@ -324,7 +324,7 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
                               c->d_dpos);
     const int mr = marg_rider(c);
     if (launch_small_assemble_seg(s, c->d_small_groups, c->n_sa_seg, c->d_sa_seg_start, c->d_sa_seg_ra, c->d_sa_seg_rb, c->d_sa_contrib, c->d_S, c->npad,
-                                  c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_dpos, units2 > 0 ? &set2 : nullptr, units2, c->n_asm_grp, c->d_asm_grp, c->d_asm_gfac,
+                                  c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_dpos, units2 > 0 ? &set2 : nullptr, units2, c->n_asm_grp, c->d_asm_grp,
                                   mr >= 0 ? &c->marg[mr].dev : nullptr))
       marg_done = mr;
   }

@@ -1021,7 +1021,7 @@ __device__ __forceinline__ void small_assemble_kernel_body(const int bsg_bx, con
                                                             const int* __restrict__ perm) {
   __shared__ double sJ[15 * 30];
   __shared__ double sr[15];
-  __shared__ int st[10];
+  __shared__ int st[60];
   small_assemble_unit(set, bsg_bx, threadIdx.x, 256, sJ, sr, st, S, ld, rhs_row, grad, hdiag, perm);
 }
 __global__ __launch_bounds__(256) void small_assemble_kernel(SmallGroupSet set, double* __restrict__ S, int ld, int rhs_row,
@@ -1040,65 +1040,134 @@ BSG_DEV double sum16(double v) {   // over an aligned group of sixteen lanes
   for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
-// One workgroup per GROUP of factors that share every slot's variable: the group's rows go through LDS 32 factors at a time (coalesced
-// 16-byte loads; a lane walking them in global memory waited out a round trip per row: 520 us for C3's largest group), thread e owns
-// one of the tw (tw + 1) / 2 entries on and below the diagonal of J^T J (tw <= 18 tangent columns) or of the tw entries of J^T r, and
-// the sums are added to the reduced system once per group — 20 000 relative-pose factors of C3 over ~950 keyframe pairs: one set of
-// atomics per pair instead of one per 64 contributions per 3x3 block.
-constexpr int kGroupChunk = 32;           // factors per pass through LDS
+// One workgroup per GROUP of factors that share every slot's variable (the ~21 lidar constraints between two key frames).  The group's
+// record (AsmGroup) names its factors, its slots' tangent offsets and the type's tables: a lane's first load is a factor index, its second
+// that factor's rows, all of a lane's loads in flight at once (a loop that fetched index, then rows, per pass was ten dependent trips: 8 of
+// the launch's 21 us on C3).  The rows go through LDS and [J r]^T [J r] — J^T J with J^T r as its last row — is formed on the matrix cores:
+// the K = count x m rows are the contraction, a wave per 16 x 16 output tile (ONE tile when te + 1 <= 16 columns — relative-pose factors
+// whose extrinsics are constant — else the three lower tiles of a 2 x 2 grid).  (One thread per entry with two LDS reads per FMA was bound
+// by the compute unit's LDS bandwidth: another 9 us.)  The sums are added to the reduced system once per group — 20 000 relative-pose
+// factors of C3 over ~950 keyframe pairs: one set of atomics per pair instead of one per 64 contributions per 3x3 block.
 constexpr int kGroupRowMax = 6 * 18;      // doubles of J per factor (m <= 6 rows of tw <= 18)
-BSG_DEV void small_assemble_group(const SmallGroup* __restrict__ groups, const AsmGroup G, const int* __restrict__ gfac, double* sJ /* kGroupChunk x 108 */,
-                                  double* sr /* kGroupChunk x 6 */, double* __restrict__ S, int ld, int rhs_row, double* __restrict__ grad,
-                                  double* __restrict__ hdiag, const int* __restrict__ perm) {
-  const SmallGroup g = groups[G.type];
-  const int nv = g.nv, tw = 3 * nv, m = g.m, n_ent = tw * (tw + 1) / 2, per = m * tw;
-  const int e = threadIdx.x;
-  bool on = e < n_ent + tw;
-  const bool is_rhs = e >= n_ent;
-  int er = 0, ec = 0;
-  if (on) {
-    if (!is_rhs) { while ((er + 1) * (er + 2) / 2 <= e) ++er; ec = e - er * (er + 1) / 2; }
-    else er = e - n_ent;
-  }
-  double acc = 0.0;
+constexpr int kGroupLoads = (kAsmGroupMax * (kGroupRowMax / 2) + 255) / 256;   // 16-byte loads of a thread
+BSG_DEV void small_assemble_group(const AsmGroup* __restrict__ Gp, double* sJ /* kAsmGroupMax x 108 */, double* sr /* kAsmGroupMax x 6 */,
+                                  double* __restrict__ S, int ld, int rhs_row, double* __restrict__ grad, double* __restrict__ hdiag,
+                                  const int* __restrict__ perm) {
   typedef double d2_t __attribute__((ext_vector_type(2)));
-  for (int q0 = 0; q0 < G.count; q0 += kGroupChunk) {
-    const int nf = min(kGroupChunk, G.count - q0);
-    const int half = per / 2;   // (per is even: tw is a multiple of 3 and m of 2 for every grouped type, checked at finalize)
-    for (int i = threadIdx.x; i < nf * half; i += 256) {
-      const int q = i / half, o = i - q * half;
-      const int f = gfac[G.first + q0 + q];
-      reinterpret_cast<d2_t*>(sJ)[q * (kGroupRowMax / 2) + o] = reinterpret_cast<const d2_t*>(g.J + (size_t)f * per)[o];
+  typedef double d4_t __attribute__((ext_vector_type(4)));
+  const int count = Gp->count, m = Gp->m, tw = 3 * Gp->nv, te = Gp->te, per = m * tw, half = per / 2;   // (per is even: checked at finalize)
+  if (te == 0) return;
+  const double* __restrict__ gJ = Gp->J;
+  const double* __restrict__ gr = Gp->r;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int nrows = count * m, nr16 = (nrows + 15) & ~15, nh = count * half;
+  // ---- every load of the rows asked for before any is waited for
+  int fq[kGroupLoads], oq[kGroupLoads];
+#pragma unroll
+  for (int it = 0; it < kGroupLoads; ++it) {
+    const int i = min(tid + 256 * it, nh - 1), q = i / half;
+    oq[it] = i - q * half;
+    fq[it] = Gp->fac[q];
+  }
+  const int ir = min(tid, nrows - 1), qr = ir / m;
+  const int fr = Gp->fac[qr];
+  // where this lane's sums go (D[(lane >> 4) + 4 reg][lane & 15] of its wave's tile); row te of the square is J^T r
+  const int n_tiles = te + 1 <= 16 ? 1 : 3;
+  const int ti = wave >= 1 ? 1 : 0, tj = wave == 2 ? 1 : 0;      // waves 0, 1, 2 -> tiles (0,0), (1,0), (1,1)
+  const bool mine = wave < n_tiles;
+  const int cj = 16 * tj + (lane & 15), ca = 16 * ti + (lane & 15);
+  int Rv[4], Cv = -1;
+  if (mine) {
+    if (cj < te) { const int t = Gp->toff[cj / 3]; Cv = t < 0 ? -1 : t + cj % 3; }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int ci = 16 * ti + (lane >> 4) + 4 * reg;
+      Rv[reg] = -1;
+      if (ci < te) { const int t = Gp->toff[ci / 3]; Rv[reg] = t < 0 ? -1 : t + ci % 3; }
     }
-    for (int i = threadIdx.x; i < nf * m; i += 256) {
-      const int q = i / m, k = i - q * m;
-      sr[q * 6 + k] = g.r[(size_t)gfac[G.first + q0 + q] * m + k];
+  }
+  d2_t vq[kGroupLoads];
+#pragma unroll
+  for (int it = 0; it < kGroupLoads; ++it) vq[it] = reinterpret_cast<const d2_t*>(gJ + (size_t)fq[it] * per)[oq[it]];
+  const double vr = gr[(size_t)fr * m + (ir - qr * m)];
+  int pRv[4], pCv = 0;
+  if (mine) {
+    pCv = Cv >= 0 ? perm[Cv] : 0;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) pRv[reg] = Rv[reg] >= 0 ? perm[Rv[reg]] : 0;
+  }
+  // ---- rows packed: row q m + k at sJ[(q m + k) tw]; the rows up to the next multiple of 16 are zeros
+#pragma unroll
+  for (int it = 0; it < kGroupLoads; ++it) {
+    const int i = tid + 256 * it;
+    if (i < nh) reinterpret_cast<d2_t*>(sJ)[i] = vq[it];
+  }
+  for (int i = nrows * tw + tid; i < nr16 * tw; i += 256) sJ[i] = 0.0;
+  if (tid < nr16) sr[tid] = tid < nrows ? vr : 0.0;
+  __syncthreads();
+  // ---- the contraction shared out over the four waves (one per SIMD: with a wave per tile the first SIMD of a compute unit did the
+  // products of every group on it), 4 rows per product: wave w takes the row quads w, w + 4, ...  Column block c of [J r] is the A operand
+  // of row tile c and the B operand of column tile c alike.  Operands are loaded unconditionally — from a column that exists — and masked,
+  // so that the loads of a pass are in flight ahead of its products; two accumulators per tile in turn (consecutive products into one
+  // accumulator are ~175 cycles apart against 64 of issue).
+  d4_t acc[3][2];
+#pragma unroll
+  for (int tl = 0; tl < 3; ++tl) { acc[tl][0] = d4_t{0.0, 0.0, 0.0, 0.0}; acc[tl][1] = d4_t{0.0, 0.0, 0.0, 0.0}; }
+  const int c0 = lane & 15, c1 = 16 + c0, lr = lane >> 4;
+  const int l0 = lr * tw + min(c0, tw - 1), l1 = lr * tw + min(c1, tw - 1);
+  const bool c0J = c0 < te, c0r = c0 == te, c1J = c1 < te, c1r = c1 == te;
+  for (int k0 = 8 * wave; k0 < nr16; k0 += 32) {   // (nr16 is a multiple of 16: two quads per pass, or none)
+    double x0[2], x1[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int row = k0 + 4 * u;
+      const double j0 = sJ[row * tw + l0], rr = sr[row + lr];
+      x0[u] = c0J ? j0 : (c0r ? rr : 0.0);
+      x1[u] = 0.0;
+      if (n_tiles > 1) { const double j1 = sJ[row * tw + l1]; x1[u] = c1J ? j1 : (c1r ? rr : 0.0); }
     }
-    __syncthreads();
-    if (on) {
-      for (int q = 0; q < nf; ++q) {
-        const double* Jq = sJ + q * kGroupRowMax;
-        for (int k = 0; k < m; ++k) acc += Jq[k * tw + er] * (is_rhs ? sr[q * 6 + k] : Jq[k * tw + ec]);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      acc[0][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[u], x0[u], acc[0][u], 0, 0, 0);
+      if (n_tiles > 1) {
+        acc[1][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[u], x0[u], acc[1][u], 0, 0, 0);
+        acc[2][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[u], x1[u], acc[2][u], 0, 0, 0);
       }
     }
-    __syncthreads();
   }
-  if (!on || acc == 0.0) return;
-  const int* to = g.toff + (size_t)gfac[G.first] * nv;
-  const int tr = to[er / 3], R = tr < 0 ? -1 : tr + er % 3;
-  if (R < 0) return;
-  const size_t pr = (size_t)perm[R];
-  if (is_rhs) {
-    atomicAdd(&S[(size_t)rhs_row * ld + pr], acc);
-    atomicAdd(&grad[R], acc);
-    return;
+  __syncthreads();   // (the rows are done with: the waves' partial tiles take their place)
+  // (of tiles (1,0) and (1,1) only rows 16 .. te <= 18 are wanted: register 0 of their results)
+  d4_t* sP = reinterpret_cast<d4_t*>(sJ);             // tile (0,0): [wave][lane]
+  double* sQ = sJ + 4 * 64 * 4;                       // tiles (1,0), (1,1): [wave][tile - 1][lane]
+  sP[wave * 64 + lane] = acc[0][0] + acc[0][1];
+  if (n_tiles > 1) {
+    sQ[(wave * 2 + 0) * 64 + lane] = acc[1][0][0] + acc[1][1][0];
+    sQ[(wave * 2 + 1) * 64 + lane] = acc[2][0][0] + acc[2][1][0];
   }
-  const int tc = to[ec / 3], C = tc < 0 ? -1 : tc + ec % 3;
-  if (C < 0) return;
-  const size_t pc = (size_t)perm[C];
-  atomicAdd(&S[pr * ld + pc], acc);
-  if (R != C) atomicAdd(&S[pc * ld + pr], acc);
-  else atomicAdd(&hdiag[R], acc);
+  __syncthreads();
+  if (!mine) return;
+  d4_t sum;
+  if (wave == 0) sum = (sP[lane] + sP[64 + lane]) + (sP[128 + lane] + sP[192 + lane]);
+  else {
+    const int q = wave - 1;
+    sum = d4_t{(sQ[(0 + q) * 64 + lane] + sQ[(2 + q) * 64 + lane]) + (sQ[(4 + q) * 64 + lane] + sQ[(6 + q) * 64 + lane]), 0.0, 0.0, 0.0};
+  }
+  if (Cv < 0) return;
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int ci = 16 * ti + (lane >> 4) + 4 * reg;
+    const double v = sum[reg];
+    if (ci > te || v == 0.0) continue;
+    if (ci == te) {   // J^T r
+      atomicAdd(&S[(size_t)rhs_row * ld + pCv], v);
+      atomicAdd(&grad[Cv], v);
+      continue;
+    }
+    if (cj > ci || Rv[reg] < 0) continue;   // (the entries on and below the diagonal; the mirror image goes with them)
+    atomicAdd(&S[(size_t)pRv[reg] * ld + pCv], v);
+    if (Rv[reg] != Cv) atomicAdd(&S[(size_t)pCv * ld + pRv[reg]], v);
+    else atomicAdd(&hdiag[Cv], v);
+  }
 }
 __device__ __forceinline__ void small_assemble_seg_kernel_body(const int bsg_bx, const SmallGroup* __restrict__ groups, int n_seg,
                                                                 const int* __restrict__ seg_start, const int* __restrict__ seg_ra,
@@ -1106,20 +1175,18 @@ __device__ __forceinline__ void small_assemble_seg_kernel_body(const int bsg_bx,
                                                                 double* __restrict__ S, int ld, int rhs_row, double* __restrict__ grad,
                                                                 double* __restrict__ hdiag, const int* __restrict__ perm, const SmallGroupSet& fw,
                                                                 int n_fw_units, int n_grp, const AsmGroup* __restrict__ grp,
-                                                                const int* __restrict__ gfac, int first_grp_block) {
+                                                                int first_grp_block) {
+  // (one area for the kinds of workgroup of this launch: 29 KB, five workgroups to a compute unit — with an area per kind it was 33 KB and
+  //  four, and C3's 1 080 workgroups took two rounds on 1 024 places)
+  __shared__ __attribute__((aligned(32))) double sArea[kAsmGroupMax * kGroupRowMax + kAsmGroupMax * 6];
   if (bsg_bx >= first_grp_block) {   // a group of same-slot factors per workgroup
-    __shared__ __attribute__((aligned(16))) double sGJ[kGroupChunk * kGroupRowMax];
-    __shared__ double sGr[kGroupChunk * 6];
-    small_assemble_group(groups, grp[bsg_bx - first_grp_block], gfac, sGJ, sGr, S, ld, rhs_row, grad, hdiag, perm);
+    small_assemble_group(grp + (bsg_bx - first_grp_block), sArea, sArea + kAsmGroupMax * kGroupRowMax, S, ld, rhs_row, grad, hdiag, perm);
     return;
   }
   if (bsg_bx < n_fw_units) {
     // the groups assembled one workgroup per factor (the IMU factors of a lidar-inertial window), as the first workgroups of this launch
     // instead of a launch of their own (as in pairs_kernel)
-    __shared__ double sJ[15 * 30];
-    __shared__ double sr[15];
-    __shared__ int st[10];
-    small_assemble_unit(fw, bsg_bx, threadIdx.x, 256, sJ, sr, st, S, ld, rhs_row, grad, hdiag, perm);
+    small_assemble_unit(fw, bsg_bx, threadIdx.x, 256, sArea, sArea + 15 * 30, reinterpret_cast<int*>(sArea + 15 * 30 + 16), S, ld, rhs_row, grad, hdiag, perm);
     return;
   }
   // sixteen lanes per segment (a segment of C3 has ~8 contributions, an IMU factor's blocks one or two: a whole wave per segment idles)
@@ -1192,8 +1259,8 @@ __global__ __launch_bounds__(256) void small_assemble_seg_kernel(const SmallGrou
                                                                 double* __restrict__ S, int ld, int rhs_row, double* __restrict__ grad,
                                                                 double* __restrict__ hdiag, const int* __restrict__ perm, SmallGroupSet fw,
                                                                 int n_fw_units, int n_grp, const AsmGroup* __restrict__ grp,
-                                                                const int* __restrict__ gfac, int first_grp_block) {
-  small_assemble_seg_kernel_body((int)blockIdx.x, groups, n_seg, seg_start, seg_ra, seg_rb, contrib, S, ld, rhs_row, grad, hdiag, perm, fw, n_fw_units, n_grp, grp, gfac, first_grp_block);
+                                                                int first_grp_block) {
+  small_assemble_seg_kernel_body((int)blockIdx.x, groups, n_seg, seg_start, seg_ra, seg_rb, contrib, S, ld, rhs_row, grad, hdiag, perm, fw, n_fw_units, n_grp, grp, first_grp_block);
 }
 // ... with the J^T J / J^T r of the window's dense prior as the launch's last workgroups (marg_body.h: 16 x 16 output tiles, then the gradient's
 // row of workgroups) instead of marg_assemble_kernel behind it (7.4 us): both add into S, the gradient and the diagonal with atomics
@@ -1203,18 +1270,18 @@ __global__ __launch_bounds__(256) void small_assemble_seg_marg_kernel(const Smal
                                                                      double* __restrict__ S, int ld, int rhs_row, double* __restrict__ grad,
                                                                      double* __restrict__ hdiag, const int* __restrict__ perm, SmallGroupSet fw,
                                                                      int n_fw_units, int n_grp, const AsmGroup* __restrict__ grp,
-                                                                     const int* __restrict__ gfac, int first_grp_block, MargDev m, int first_marg_block, int mg) {
+                                                                     int first_grp_block, MargDev m, int first_marg_block, int mg) {
   if ((int)blockIdx.x >= first_marg_block) {
     const int b = (int)blockIdx.x - first_marg_block;
     marg_assemble_kernel_body(b % mg, b / mg, mg + 1, m, S, ld, perm, rhs_row, grad, hdiag);
     return;
   }
-  small_assemble_seg_kernel_body((int)blockIdx.x, groups, n_seg, seg_start, seg_ra, seg_rb, contrib, S, ld, rhs_row, grad, hdiag, perm, fw, n_fw_units, n_grp, grp, gfac, first_grp_block);
+  small_assemble_seg_kernel_body((int)blockIdx.x, groups, n_seg, seg_start, seg_ra, seg_rb, contrib, S, ld, rhs_row, grad, hdiag, perm, fw, n_fw_units, n_grp, grp, first_grp_block);
 }
 // marg: the window's (one) dense prior, carried by this launch; returns whether it was (false: no launch of this kind — the caller launches the prior's own)
 bool launch_small_assemble_seg(hipStream_t s, const SmallGroup* groups_dev, int n_seg, const int* seg_start, const int* seg_ra, const int* seg_rb,
                                const int2* contrib, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm,
-                               const SmallGroupSet* fw, int n_fw_units, int n_grp, const AsmGroup* grp, const int* gfac, const MargDev* marg) {
+                               const SmallGroupSet* fw, int n_fw_units, int n_grp, const AsmGroup* grp, const MargDev* marg) {
   if (n_seg <= 0 && n_grp <= 0) return false;
   SmallGroupSet none;
   none.n = 0; none.first[0] = 0;
@@ -1224,11 +1291,11 @@ bool launch_small_assemble_seg(hipStream_t s, const SmallGroup* groups_dev, int 
   if (marg && marg->rows > 0 && marg->cols > 0) {
     const int mg = (marg->cols + 15) / 16;
     hipLaunchKernelGGL(small_assemble_seg_marg_kernel, dim3(own + mg * (mg + 1)), dim3(256), 0, s, groups_dev, std::max(0, n_seg), seg_start, seg_ra, seg_rb,
-                       contrib, S, ld, rhs_row, grad, hdiag, perm, fw ? *fw : none, extra, n_grp, grp, gfac, first_grp_block, *marg, own, mg);
+                       contrib, S, ld, rhs_row, grad, hdiag, perm, fw ? *fw : none, extra, n_grp, grp, first_grp_block, *marg, own, mg);
     return true;
   }
   hipLaunchKernelGGL(small_assemble_seg_kernel, dim3(own), dim3(256), 0, s, groups_dev, std::max(0, n_seg), seg_start, seg_ra, seg_rb,
-                     contrib, S, ld, rhs_row, grad, hdiag, perm, fw ? *fw : none, extra, n_grp, grp, gfac, first_grp_block);
+                     contrib, S, ld, rhs_row, grad, hdiag, perm, fw ? *fw : none, extra, n_grp, grp, first_grp_block);
   return false;
 }
 
@@ -1501,18 +1568,18 @@ struct small_assemble_seg_kernel_Args {
   int bsg_grid;
   const SmallGroup* groups; int n_seg; const int* seg_start; const int* seg_ra; const int* seg_rb; const int2* contrib;
   double* S; int ld; int rhs_row; double* grad; double* hdiag; const int* perm;
-  SmallGroupSet fw; int n_fw_units; int n_grp; const AsmGroup* grp; const int* gfac; int first_grp_block;
+  SmallGroupSet fw; int n_fw_units; int n_grp; const AsmGroup* grp; int first_grp_block;
 };
 __global__ __launch_bounds__(256) void small_assemble_seg_kernel_batch(const small_assemble_seg_kernel_Args* __restrict__ bsg_A, const BatchDyn* __restrict__ bsg_dyn, int bsg_list) {
   const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
   const small_assemble_seg_kernel_Args& a = bsg_A[bsg_w];
   if ((int)blockIdx.x >= a.bsg_grid) return;
   small_assemble_seg_kernel_body((int)blockIdx.x, a.groups, a.n_seg, a.seg_start, a.seg_ra, a.seg_rb, a.contrib, a.S, a.ld, a.rhs_row, a.grad, a.hdiag, a.perm, a.fw, a.n_fw_units,
-                                 a.n_grp, a.grp, a.gfac, a.first_grp_block);
+                                 a.n_grp, a.grp, a.first_grp_block);
 }
 void batchargs_small_assemble_seg(BatchArgTable& t, const SmallGroup* groups_dev, int n_seg, const int* seg_start, const int* seg_ra, const int* seg_rb, const int2* contrib,
                                   double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm, const SmallGroupSet* fw, int n_fw_units, int n_grp,
-                                  const AsmGroup* grp, const int* gfac) {
+                                  const AsmGroup* grp) {
   small_assemble_seg_kernel_Args a;
   SmallGroupSet none;
   none.n = 0; none.first[0] = 0;
@@ -1521,7 +1588,7 @@ void batchargs_small_assemble_seg(BatchArgTable& t, const SmallGroup* groups_dev
   a.first_grp_block = extra + seg_blocks;
   a.bsg_grid = (n_seg <= 0 && n_grp <= 0) ? 0 : a.first_grp_block + std::max(0, n_grp);
   a.groups = groups_dev; a.n_seg = std::max(0, n_seg); a.seg_start = seg_start; a.seg_ra = seg_ra; a.seg_rb = seg_rb; a.contrib = contrib;
-  a.S = S; a.ld = ld; a.rhs_row = rhs_row; a.grad = grad; a.hdiag = hdiag; a.perm = perm; a.fw = fw ? *fw : none; a.n_fw_units = extra; a.n_grp = n_grp; a.grp = grp; a.gfac = gfac;
+  a.S = S; a.ld = ld; a.rhs_row = rhs_row; a.grad = grad; a.hdiag = hdiag; a.perm = perm; a.fw = fw ? *fw : none; a.n_fw_units = extra; a.n_grp = n_grp; a.grp = grp;
   t.push(a);
 }
 void launch_small_assemble_seg_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n) {
