@@ -578,6 +578,11 @@ __device__ __forceinline__ void backsub_mcc_kernel_body(const int bsg_bx, const 
     const bool valid = l < n_lm;
     int beg = 0, end = 0;
     if (valid) { beg = lm_start[l]; end = lm_start[l + 1]; }
+    // (what depends on the landmark alone is asked for with its range, not after the sums below: two trips off the dependent path)
+    const int lc = valid ? l : 0;
+    const double* Li = Linv + (size_t)lc * 6;
+    const double Li0 = Li[0], Li1 = Li[1], Li2 = Li[2], Li3 = Li[3], Li4 = Li[4], Li5 = Li[5];
+    const double zl0 = z[3 * lc], zl1 = z[3 * lc + 1], zl2 = z[3 * lc + 2];
     double a0 = 0, a1 = 0, a2 = 0;
     // (A y_cam of the lane's first two factors stays in registers for the second pass: a track longer than 16 views is rare, and
     // recomputing it costs the row again plus a three-deep chain of dependent gathers — camera pose id, its tangent offsets, y)
@@ -596,12 +601,11 @@ __device__ __forceinline__ void backsub_mcc_kernel_body(const int bsg_bx, const 
 #pragma unroll
     for (int o = 4; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o, 8); a1 += __shfl_xor(a1, o, 8); a2 += __shfl_xor(a2, o, 8); }
     if (valid) {   // (every one of the 8 lanes holds the sums)
-      const double* Li = Linv + (size_t)l * 6;
-      const double w0 = z[3 * l] - a0, w1 = z[3 * l + 1] - a1, w2 = z[3 * l + 2] - a2;
+      const double w0 = zl0 - a0, w1 = zl1 - a1, w2 = zl2 - a2;
       // y = Linv^T w
-      const double y0 = Li[0] * w0 + Li[1] * w1 + Li[3] * w2;
-      const double y1 = Li[2] * w1 + Li[4] * w2;
-      const double y2 = Li[5] * w2;
+      const double y0 = Li0 * w0 + Li1 * w1 + Li3 * w2;
+      const double y1 = Li2 * w1 + Li4 * w2;
+      const double y2 = Li5 * w2;
       if (sub == 0) {
         const int to = n_pose + 3 * l;
         delta[to] = -y0; delta[to + 1] = -y1; delta[to + 2] = -y2;

@@ -492,7 +492,7 @@ def idp_window(n_kf=8, n_lm=60, seed=20250623, kf_rate=10.0, track_min=3, track_
     return pr
 
 
-def lio_window(n_kf=100, n_rel=20000, seed=20250621, w_lidar=1.0, w_inertial=1e-2, max_gap=10):
+def lio_window(n_kf=100, n_rel=20000, seed=20250621, w_lidar=1.0, w_inertial=1e-2, max_gap=10, free_extrinsics=False):
     rng = np.random.default_rng(seed)
     base = vio_window(n_kf=n_kf, n_lm=0, seed=seed, w_inertial=w_inertial)
     pr = base
@@ -502,8 +502,9 @@ def lio_window(n_kf=100, n_rel=20000, seed=20250621, w_lidar=1.0, w_inertial=1e-
     # constant extrinsic pair (bs_variables::Position3D / Orientation3D: holdConstant() == true)
     q_bs = quat_from_aa(np.array([0.02, -0.01, 0.03]))
     p_bs = np.array([0.1, -0.05, 0.2])
-    b_pe = pr.add_block(p_bs, const=True)
-    b_qe = pr.add_quat(q_bs, const=True)
+    # (free_extrinsics: online calibration — the pair is estimated with the window, every relative-pose factor names it)
+    b_pe = pr.add_block(p_bs, const=not free_extrinsics)
+    b_qe = pr.add_quat(q_bs, const=not free_extrinsics)
     R_bs = quat_to_rot(q_bs)
     i = rng.integers(0, n_kf - 1, n_rel)
     gap = rng.integers(1, max_gap + 1, n_rel)
