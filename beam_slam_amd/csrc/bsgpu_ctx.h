@@ -188,6 +188,8 @@ struct bsgpu_ctx {
   double *d_delta = nullptr, *d_y = nullptr, *d_scal = nullptr, *d_part = nullptr;
   double* h_scal = nullptr;  // pinned
   double* h_scal_dev = nullptr;  // the same buffer as the device sees it (final_reduce mirrors the step's scalars there)
+  double spec_lm_radius = 0.0;   // != 0: the next step's assembly is in the queue already, for an accepted step at this radius (bsgpu_solve.cpp enqueue_step)
+  bool spec_dirty = false;       // an assembly ahead has run since the last one a step took as its own
   bool scal_mirrored = false;    // the last enqueued work ended with a final_reduce that filled the mirror
   // tiled Cholesky plan (dense_plan.h) and its device tables
   DensePlan plan;

@@ -496,9 +496,21 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o, bool defer
 // gradient_only: the iteration budget is used up — the point just accepted still needs its cost and gradient norms for the
 // iteration record, but no step will be taken from it: evaluation + assembly (which produces the gradient), no factorisation,
 // no candidate
-void enqueue_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius, bool gradient_only = false) {
+// radius_ahead > 0: the radius the NEXT step will most often be computed at (solve(): an accepted step whose relative decrease is above
+// 0.937 divides the radius by max(1/3, ...) = 1/3 — every step of the reference-sized windows, seven of C2's ten): the next step's ASSEMBLY
+// (landmark elimination with the step's clearing, camera pairs, pose-only factors: everything up to the factorisation) is queued behind
+// the evaluation ahead instead of behind the host's decision (8 us per iteration in which a small window's device idled before its
+// landmark launch: stamp over PCIe, LmState::advance, one launch — scripts/small_gaps.sh).  Nothing is decided on the device: the next step
+// takes the assembly as its own when the decision is "accepted, at that radius" (bit for bit), and assembles again otherwise — the
+// landmark launch clears what the assembly adds into and rewrites all else it wrote.
+void enqueue_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius, bool gradient_only = false, double radius_ahead = 0.0) {
   hipStream_t s = c->stream;
   c->cost_x_stale = false;   // (set below only for a step whose reduction rides in the evaluation ahead: a gradient-only step's full reduction gives SC_COST_X)
+  // an assembly ahead that the decision did not confirm has rewritten the LM diagonal's clamped H_jj (and the gradient norms' inputs) from
+  // the CANDIDATE's Jacobians: this step recomputes them from the current point's (the same bits as before)
+  const bool assembled_ahead = kind == STEP_ACCEPT && !gradient_only && c->spec_lm_radius == radius && radius > 0.0;
+  const bool ahead_unconfirmed = c->spec_dirty && !assembled_ahead;
+  c->spec_lm_radius = 0.0; c->spec_dirty = false;
   if (kind == STEP_ACCEPT) {
     // the accepted candidate becomes the current point: a pointer swap (every launch takes x as an argument; the next update
     // rewrites all of the other buffer) — except under graph replay, whose kernel arguments are frozen
@@ -510,7 +522,10 @@ void enqueue_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius,
   const bool have_J = (kind == STEP_ACCEPT && c->spec_J) || (kind == STEP_REJECT && !c->spec_J);
   if (!have_J) eval_all(c, c->d_x, true, SC_COST_X);
   c->spec_J = false;
-  assemble(c, o, radius, kind != STEP_REJECT, kind == STEP_FIRST, gradient_only, /*factor_follows=*/true);
+  // (an assembly ahead configured the gradient norms that ride in the factorisation for the point that was current THEN: the candidate
+  //  it was computed at is the current point now)
+  if (assembled_ahead && c->gn_ride.nb > 0) c->gn_ride.x = c->d_x;
+  if (!assembled_ahead) assemble(c, o, radius, kind != STEP_REJECT || ahead_unconfirmed, kind == STEP_FIRST, gradient_only, /*factor_follows=*/true);
   if (gradient_only) { final_reduce(c); return; }
   // (not on the first step: the reduction that rides cannot give the cost at x — the launch that carries it rewrites those partials — and
   //  only the first step's is read: after an accepted step the cost at x is the candidate's cost the host already holds)
@@ -534,6 +549,16 @@ void enqueue_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius,
       eval_all(c, c->d_xcand, true, SC_COST_X);
     c->prof_events = prof;
     c->spec_J = true;
+    if (radius_ahead > 0.0 && c->vis.n_lm > 0 && !c->use_pcg && !c->use_spcg && c->idp.n_lm == 0) {
+      // the next step's assembly as an accepted step at radius_ahead has it (new Jacobians: the ones just evaluated); what the host keeps
+      // about THIS step's scalars is not the assembly's to reset
+      const bool sm = c->scal_mirrored, sp = c->seq_pending, ep = c->ev_reduce_pending;
+      assemble(c, o, radius_ahead, /*new_J=*/true, /*first=*/false, /*gradient_only=*/false, /*factor_follows=*/true);
+      c->scal_mirrored = sm; c->seq_pending = sp; c->ev_reduce_pending = ep;
+      c->spec_dirty = true;
+      // (usable as it is only when the gradient norms ride in the factorisation: a launch of their own would have read the wrong point)
+      c->spec_lm_radius = c->diag_in_chol ? radius_ahead : 0.0;
+    }
   }
 }
 
@@ -610,7 +635,7 @@ void build_graphs(bsgpu_ctx* c, const bsgpu_options& o) {
   if (getenv("BSGPU_TIMING")) fprintf(stderr, "[bsgpu] LM step captured as hipGraphs\n");
 }
 
-void run_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius, bool gradient_only = false) {
+void run_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius, bool gradient_only = false, double radius_ahead = 0.0) {
   if (c->use_graphs) {   // replayed kernels read the radius from device memory
     *c->h_radius = radius;
     (void)hipMemcpyAsync(c->d_scal + SC_RADIUS, c->h_radius, sizeof(double), hipMemcpyHostToDevice, c->stream);
@@ -621,7 +646,7 @@ void run_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius, boo
     (void)hipGetLastError();
     c->graphs_ok = false;   // fall back to eager launches of the same kernels
   }
-  enqueue_step(c, o, kind, radius, gradient_only);
+  enqueue_step(c, o, kind, radius, gradient_only, radius_ahead);
 }
 
 // sorted visual position -> source factor: built on the host, or downloaded on first use when the device flattened the window
@@ -694,6 +719,7 @@ void enqueue_fixed_cost(bsgpu_ctx* c, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------------
 // [EXT] ceres::internal::TrustRegionMinimizer + LevenbergMarquardtStrategy, restated
 // ---------------------------------------------------------------------------------------------------
+constexpr int kAssemblyAheadMaxFactors = 150000;   // reprojection factors up to which the next step's assembly is issued ahead of the decision
 int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
   using clk = std::chrono::steady_clock;
   const auto t_start = clk::now();
@@ -703,6 +729,7 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
   HIPCHK(c, hipSetDevice(c->device));
   std::memset(&sum, 0, sizeof(sum));
   c->iters.clear();
+  c->spec_lm_radius = 0.0; c->spec_dirty = false;
   sum.num_parameters_tangent = c->n_tan;
   sum.num_residuals = c->n_res;
   c->use_pcg = (o.linear_solver_type == BSGPU_LINEAR_PCG) || (o.linear_solver_type == BSGPU_LINEAR_AUTO && !c->dense_ok);
@@ -727,7 +754,13 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
   const bsgpu_summary head = sum;   // (what was filled in above: start() clears the summary)
   lm.start(&o, &sum, &c->iters, head.num_parameters_tangent, head.num_residuals, head.linear_solver_used);
   lm.t_start = t_start;
-  run_step(c, o, STEP_FIRST, lm.radius);
+  // the assembly of the step after this one goes out ahead of the decision (enqueue_step) where it is short — a wrong guess costs its
+  // length: nothing on the reference's window sizes, C2's three guesses in ten that miss cost more than the seven that hit gain (measured)
+  static const int ahead_env = getenv("BSGPU_LM_AHEAD") ? atoi(getenv("BSGPU_LM_AHEAD")) : -1;
+  const bool lm_ahead = ahead_env >= 0 ? ahead_env != 0 : (c->vis.n_lm > 0 && c->vis.n <= kAssemblyAheadMaxFactors);
+  // (the radius of LmState::advance for a relative decrease above 0.937, in its own arithmetic: r / (1/3) is not 3 r in every last bit)
+  auto radius_ahead = [&](double r) { return (lm_ahead && !c->use_graphs && !c->use_pcg) ? std::min(o.max_trust_region_radius, r / std::max(1.0 / 3.0, 0.0)) : 0.0; };
+  run_step(c, o, STEP_FIRST, lm.radius, false, radius_ahead(lm.radius));
   rc = fetch_scalars(c);
   if (rc != BSGPU_OK) { (void)pcg_check(c); return rc; }
   bool pcg_redo = !pcg_check(c);
@@ -743,7 +776,7 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
       if (getenv("BSGPU_TIMING")) fprintf(stderr, "[bsgpu] single-launch Cholesky timed out: launch-per-step path from here on\n");
       if (c->use_graphs) { c->destroy_graphs(); build_graphs(c, o); }   // (the captured sequences still hold the single-launch kernel)
     }
-    run_step(c, o, lm.kind, lm.radius, lm.grad_only);
+    run_step(c, o, lm.kind, lm.radius, lm.grad_only, lm.grad_only ? 0.0 : radius_ahead(lm.radius));
     rc = fetch_scalars(c);
     if (rc != BSGPU_OK) { (void)pcg_check(c); return rc; }
     pcg_redo = !pcg_check(c);
@@ -756,7 +789,7 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
   (void)hipEventElapsedTime(&ms, ev0, ev1);
   (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
   sum.device_time_in_seconds = ms * 1e-3;
-  c->scal_mirrored = false; c->ev_reduce_pending = false; c->spec_J = false;   // (the stream has drained: nothing of this solve is pending)
+  c->scal_mirrored = false; c->ev_reduce_pending = false; c->spec_J = false; c->spec_lm_radius = 0.0; c->spec_dirty = false;   // (the stream has drained: nothing of this solve is pending)
   sum.num_inner_iterations = c->pcg_iters_total;
   sum.total_time_in_seconds = elapsed();
   return BSGPU_OK;

@@ -1,0 +1,66 @@
+"""The next step's assembly issued ahead of the host's decision (bsgpu_solve.cpp enqueue_step, BSGPU_LM_AHEAD): a window solved with it and
+without it takes the same iterations (the same kernels with the same arguments: what differs between two runs is the order of the
+assembly's FP64 atomics, 1e-15 of a cost) — when every guess is confirmed (the radius triples), when steps are rejected (the
+assembly ahead is thrown away and the LM diagonal recomputed from the current point's Jacobians), when a step is accepted at another
+radius than the guessed one, and when the iteration budget ends in a gradient-only step."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r"""
+import sys, json
+sys.path.insert(0, %r)
+import numpy as np
+from beam_slam_amd import synthetic
+from beam_slam_amd.gpu import GpuSolver
+out = []
+for case in range(4):
+    pr = synthetic.vio_window(n_kf=12 + 4 * case, n_lm=150 + 100 * case, seed=4200 + case, cauchy_a=[None, 5.0][case %% 2])
+    g = GpuSolver(0); pr.load(g)
+    o = g.options_vio(); o.max_solver_time_in_seconds = 0.0
+    if case == 1:
+        o.initial_trust_region_radius = 1e-2      # tight first radius: the first steps gain little and the radius moves by other factors
+    if case == 2:
+        rng = np.random.default_rng(5)
+        g.set_values(pr.values + 0.05 * rng.standard_normal(pr.values.size))   # a bad start: rejected steps
+    if case == 3:
+        o.max_num_iterations = 3                  # the budget ends in a gradient-only step
+    s = g.solve(o)
+    out.append(dict(final=s.final_cost, n=s.num_iterations,
+                    its=[(it.cost, it.step_is_successful, it.trust_region_radius, it.gradient_max_norm) for it in g.iterations()],
+                    x=[float(v) for v in g.get_blocks()[:50]]))
+print("RESULT " + json.dumps(out))
+"""
+
+
+def _run(ahead):
+    env = dict(os.environ, BSGPU_LM_AHEAD=str(ahead))
+    p = subprocess.run([sys.executable, "-c", SCRIPT % ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    return __import__("json").loads(line[len("RESULT "):])
+
+
+def test_assembly_ahead_changes_no_iteration():
+    a, b = _run(0), _run(1)
+    assert len(a) == len(b) == 4
+    kinds = set()
+    for ra, rb in zip(a, b):
+        assert ra["n"] == rb["n"] and len(ra["its"]) == len(rb["its"])
+        # (two runs of ONE setting differ by the order of the assembly's atomics: 1e-15 of a cost on a well-conditioned window, more where
+        #  rejected steps follow a bad start)
+        assert abs(ra["final"] - rb["final"]) <= 1e-7 * abs(ra["final"])
+        for ia, ib in zip(ra["its"], rb["its"]):
+            assert ia[1] == ib[1]                                       # accepted / rejected
+            assert abs(ia[0] - ib[0]) <= 1e-7 * abs(ia[0])              # cost
+            assert abs(ia[2] - ib[2]) <= 1e-6 * abs(ia[2])              # radius
+        assert np.abs(np.array(ra["x"]) - np.array(rb["x"])).max() <= 1e-6
+        kinds.update(int(it[1]) for it in ra["its"][1:])
+    assert kinds == {0, 1}, "the cases are meant to hold rejected steps as well as accepted ones"
