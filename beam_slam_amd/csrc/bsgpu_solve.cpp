@@ -549,7 +549,7 @@ void enqueue_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius,
       eval_all(c, c->d_xcand, true, SC_COST_X);
     c->prof_events = prof;
     c->spec_J = true;
-    if (radius_ahead > 0.0 && c->vis.n_lm > 0 && !c->use_pcg && !c->use_spcg && c->idp.n_lm == 0) {
+    if (radius_ahead > 0.0 && !c->use_pcg && !c->use_spcg && c->dense_ok && c->n_pose > 0 && c->idp.n_lm == 0) {
       // the next step's assembly as an accepted step at radius_ahead has it (new Jacobians: the ones just evaluated); what the host keeps
       // about THIS step's scalars is not the assembly's to reset
       const bool sm = c->scal_mirrored, sp = c->seq_pending, ep = c->ev_reduce_pending;
@@ -719,6 +719,7 @@ void enqueue_fixed_cost(bsgpu_ctx* c, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------------
 // [EXT] ceres::internal::TrustRegionMinimizer + LevenbergMarquardtStrategy, restated
 // ---------------------------------------------------------------------------------------------------
+constexpr int kAssemblyAheadMaxResiduals = 400000;   // ... and residual rows in all (C3: 121 500; C2: 804 000)
 constexpr int kAssemblyAheadMaxFactors = 150000;   // reprojection factors up to which the next step's assembly is issued ahead of the decision
 int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
   using clk = std::chrono::steady_clock;
@@ -757,9 +758,16 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
   // the assembly of the step after this one goes out ahead of the decision (enqueue_step) where it is short — a wrong guess costs its
   // length: nothing on the reference's window sizes, C2's three guesses in ten that miss cost more than the seven that hit gain (measured)
   static const int ahead_env = getenv("BSGPU_LM_AHEAD") ? atoi(getenv("BSGPU_LM_AHEAD")) : -1;
-  const bool lm_ahead = ahead_env >= 0 ? ahead_env != 0 : (c->vis.n_lm > 0 && c->vis.n <= kAssemblyAheadMaxFactors);
+  const bool lm_ahead = ahead_env >= 0 ? ahead_env != 0 : (c->vis.n <= kAssemblyAheadMaxFactors && c->n_res <= kAssemblyAheadMaxResiduals);   // (pose-only windows too: their assembly takes no radius, only the guess "accepted")
   // (the radius of LmState::advance for a relative decrease above 0.937, in its own arithmetic: r / (1/3) is not 3 r in every last bit)
-  auto radius_ahead = [&](double r) { return (lm_ahead && !c->use_graphs && !c->use_pcg) ? std::min(o.max_trust_region_radius, r / std::max(1.0 / 3.0, 0.0)) : 0.0; };
+  // ... and only while the guesses hold: after a step that did not end "accepted, at the guessed radius" (a pose graph's early steps, C2's
+  // fifth to seventh) the next assembly waits for the decision again, until a step ends that way
+  bool guess_held = true;
+  double guessed = 0.0;   // what the step in flight was guessed to end at (0: nothing was guessed)
+  auto radius_ahead = [&](double r) {
+    guessed = std::min(o.max_trust_region_radius, r / std::max(1.0 / 3.0, 0.0));
+    return (lm_ahead && guess_held && !c->use_graphs && !c->use_pcg) ? guessed : 0.0;
+  };
   run_step(c, o, STEP_FIRST, lm.radius, false, radius_ahead(lm.radius));
   rc = fetch_scalars(c);
   if (rc != BSGPU_OK) { (void)pcg_check(c); return rc; }
@@ -776,6 +784,7 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
       if (getenv("BSGPU_TIMING")) fprintf(stderr, "[bsgpu] single-launch Cholesky timed out: launch-per-step path from here on\n");
       if (c->use_graphs) { c->destroy_graphs(); build_graphs(c, o); }   // (the captured sequences still hold the single-launch kernel)
     }
+    guess_held = lm.kind == STEP_ACCEPT && lm.radius == guessed;
     run_step(c, o, lm.kind, lm.radius, lm.grad_only, lm.grad_only ? 0.0 : radius_ahead(lm.radius));
     rc = fetch_scalars(c);
     if (rc != BSGPU_OK) { (void)pcg_check(c); return rc; }

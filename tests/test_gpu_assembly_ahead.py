@@ -1,6 +1,6 @@
 """The next step's assembly issued ahead of the host's decision (bsgpu_solve.cpp enqueue_step, BSGPU_LM_AHEAD): a window solved with it and
 without it takes the same iterations (the same kernels with the same arguments: what differs between two runs is the order of the
-assembly's FP64 atomics, 1e-15 of a cost) — when every guess is confirmed (the radius triples), when steps are rejected (the
+assembly's FP64 atomics, 1e-15 of a cost) — when every guess is confirmed (the radius triples), on pose-only windows (a lidar-inertial window, a pose graph), when steps are rejected (the
 assembly ahead is thrown away and the LM diagonal recomputed from the current point's Jacobians), when a step is accepted at another
 radius than the guessed one, and when the iteration budget ends in a gradient-only step."""
 import os
@@ -21,8 +21,13 @@ import numpy as np
 from beam_slam_amd import synthetic
 from beam_slam_amd.gpu import GpuSolver
 out = []
-for case in range(4):
-    pr = synthetic.vio_window(n_kf=12 + 4 * case, n_lm=150 + 100 * case, seed=4200 + case, cauchy_a=[None, 5.0][case %% 2])
+for case in range(6):
+    if case == 4:
+        pr = synthetic.lio_window(n_kf=20, n_rel=400, seed=4204)                      # pose-only: the assembly takes no radius
+    elif case == 5:
+        pr = synthetic.pose_graph(n_pose=120, n_loop=30, seed=4205)                   # ... and a pose graph, whose early guesses miss
+    else:
+        pr = synthetic.vio_window(n_kf=12 + 4 * case, n_lm=150 + 100 * case, seed=4200 + case, cauchy_a=[None, 5.0][case %% 2])
     g = GpuSolver(0); pr.load(g)
     o = g.options_vio(); o.max_solver_time_in_seconds = 0.0
     if case == 1:
@@ -50,7 +55,7 @@ def _run(ahead):
 
 def test_assembly_ahead_changes_no_iteration():
     a, b = _run(0), _run(1)
-    assert len(a) == len(b) == 4
+    assert len(a) == len(b) == 6
     kinds = set()
     for ra, rb in zip(a, b):
         assert ra["n"] == rb["n"] and len(ra["its"]) == len(rb["its"])
