@@ -763,6 +763,7 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
   // ... and only while the guesses hold: after a step that did not end "accepted, at the guessed radius" (a pose graph's early steps, C2's
   // fifth to seventh) the next assembly waits for the decision again, until a step ends that way
   bool guess_held = true;
+  double rel_prev = 0.0, rel_last = 0.0;   // relative cost changes of the last two accepted steps
   double guessed = 0.0;   // what the step in flight was guessed to end at (0: nothing was guessed)
   auto radius_ahead = [&](double r) {
     guessed = std::min(o.max_trust_region_radius, r / std::max(1.0 / 3.0, 0.0));
@@ -785,7 +786,14 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
       if (c->use_graphs) { c->destroy_graphs(); build_graphs(c, o); }   // (the captured sequences still hold the single-launch kernel)
     }
     guess_held = lm.kind == STEP_ACCEPT && lm.radius == guessed;
-    run_step(c, o, lm.kind, lm.radius, lm.grad_only, lm.grad_only ? 0.0 : radius_ahead(lm.radius));
+    // ... and not for a step that will most likely not be taken: the one after the iteration budget's last (a gradient-only step follows),
+    // or after a step whose cost change — the last one times the ratio of the last two — will be under the function tolerance (a solve
+    // that ends that way left an unused assembly in the queue, 16 us of a reference-sized window's 640: the geometric guess names five of
+    // the bench windows' six last steps)
+    if (lm.it.step_is_successful && lm.it.iteration > 0) { rel_prev = rel_last; rel_last = std::fabs(lm.it.cost_change) / std::max(1e-300, std::fabs(lm.x_cost)); }
+    const bool likely_last = lm.it.iteration + 1 >= o.max_num_iterations ||
+                             (rel_prev > 0.0 && rel_last * std::min(1.0, rel_last / rel_prev) < 4.0 * o.function_tolerance);
+    run_step(c, o, lm.kind, lm.radius, lm.grad_only, (lm.grad_only || likely_last) ? 0.0 : radius_ahead(lm.radius));
     rc = fetch_scalars(c);
     if (rc != BSGPU_OK) { (void)pcg_check(c); return rc; }
     pcg_redo = !pcg_check(c);
