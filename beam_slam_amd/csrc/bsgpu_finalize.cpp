@@ -381,9 +381,10 @@ int finalize(bsgpu_ctx* c) {
       const size_t n_ent = (size_t)start[ncp * ncp];
       ent_fa.resize(n_ent); ent_fb.resize(n_ent);
       lap("count pair entries");
-      // segments (chunks of <= kPairChunk entries of one pair) straight from the counts
+      // segments (chunks of <= pair_chunk entries of one pair) straight from the counts
+      const int chunk = pair_chunk(n_ent);
       for (uint64_t key = 0; key < ncp * ncp; ++key)
-        for (int p0 = start[key]; p0 < start[key + 1]; p0 += kPairChunk) { seg_ci.push_back((int)(key / ncp)); seg_cj.push_back((int)(key % ncp)); seg_start.push_back(p0); }
+        for (int p0 = start[key]; p0 < start[key + 1]; p0 += chunk) { seg_ci.push_back((int)(key / ncp)); seg_cj.push_back((int)(key % ncp)); seg_start.push_back(p0); }
       std::vector<int> pos(start.begin(), start.end() - 1);
       for (int l = 0; l < nl; ++l) {
         if (b_cmin[l] >= 0) continue;
@@ -408,8 +409,9 @@ int finalize(bsgpu_ctx* c) {
       for (int f = n_elim; f < nv; ++f) ents.push_back({(uint64_t)cam_pose[f] * ncp + cam_pose[f], f, f});
       std::stable_sort(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) { return x.key < y.key; });
       ent_fa.resize(ents.size()); ent_fb.resize(ents.size());
+      const int chunk = pair_chunk(ents.size());
       for (size_t i = 0; i < ents.size(); ++i) {
-        if (i == 0 || ents[i].key != ents[i - 1].key || (int)i - seg_start.back() >= kPairChunk) {
+        if (i == 0 || ents[i].key != ents[i - 1].key || (int)i - seg_start.back() >= chunk) {
           seg_ci.push_back((int)(ents[i].key / ncp)); seg_cj.push_back((int)(ents[i].key % ncp)); seg_start.push_back((int)i);
         }
         ent_fa[i] = ents[i].fa; ent_fb[i] = ents[i].fb;

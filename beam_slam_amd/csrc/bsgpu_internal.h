@@ -31,6 +31,11 @@ constexpr int kJAStride = 12;
 // entries of one camera pair are cut into segments of at most this many (one single-wave workgroup of pairs_kernel each);
 // a power of two.  Host and device flattening must agree (their tables are compared bit for bit).
 constexpr int kPairChunk = 256;
+// entries of one camera pair a wave of pairs_kernel sums (a power of two): a window of the reference's size has a few hundred camera pairs
+// of up to a few hundred entries — 210 waves of up to four strides on 1 024 SIMDs; in chunks of 64 it is twice the waves of one stride each
+// (20 KF x 500: pairs_kernel 10.1 -> 6.5 us, 9 420 -> 9 750 LM it/s; 30 KF x 2 000 + 1.3 %), while a window with more entries than waves to
+// hide them behind pays for the additional atomics (50 KF x 5 000: - 1.3 % at 64, + 1 % at 128)
+inline int pair_chunk(size_t n_ent) { return n_ent <= 100000 ? 64 : n_ent <= 1000000 ? 128 : kPairChunk; }
 // a landmark whose observations lie within this many consecutive camera poses (every feature track of a sliding window), one per camera
 // pose, is a BAND landmark: its whole contribution to the reduced system is formed by pairs_band_kernel (k_band.hip), it has no pair entries
 constexpr int kBandCams = 13;

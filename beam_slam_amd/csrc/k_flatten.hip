@@ -1,6 +1,6 @@
 // Device-side flattening of the reprojection factors of a window (the per-cycle rebuild that the
 // reference does on the host in HashGraph::createProblem): what the Schur kernels need — factors sorted by landmark,
-// camera-pose ids, per-landmark ranges, the (factor a, factor b) pair entries grouped by camera pair in chunks of kPairChunk,
+// camera-pose ids, per-landmark ranges, the (factor a, factor b) pair entries grouped by camera pair in chunks of pair_chunk(entries),
 // the tile adjacency of the reduced system — is built from the RAW factor table with rocPRIM sorts and scans instead of
 // host loops over 400 k factors and 2 M pair entries.  It produces exactly the tables of the host path (same order:
 // both sorts are stable), which stays as the general path (online-calibration factors, landmark blocks shared with
@@ -137,9 +137,9 @@ __global__ void fl_split_kernel(int n, const unsigned long long* __restrict__ ke
   fa[i] = (int)(val[i] >> 32); fb[i] = (int)(val[i] & 0xffffffffull);
   run_flag_idx[i] = (i == 0 || key[i] != key[i - 1]) ? i : 0;     // start index of a run of equal keys (max-scanned next)
 }
-__global__ void fl_segflag_kernel(int n, const int* __restrict__ run_start, unsigned char* __restrict__ flag) {
+__global__ void fl_segflag_kernel(int n, const int* __restrict__ run_start, unsigned char* __restrict__ flag, int chunk_mask) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) flag[i] = ((i - run_start[i]) & (kPairChunk - 1)) == 0;
+  if (i < n) flag[i] = ((i - run_start[i]) & chunk_mask) == 0;
 }
 __global__ void fl_seg_kernel(int n_seg, int n_ent, int* __restrict__ seg_start, const unsigned long long* __restrict__ key,
                               unsigned long long ncp, int* __restrict__ seg_ci, int* __restrict__ seg_cj, const int* __restrict__ cp_tq,
@@ -317,7 +317,7 @@ int flatten_visual_device(hipStream_t s, const std::function<void*(size_t)>& dal
     const int ge = (n_ent + 255) / 256;
     hipLaunchKernelGGL(fl_split_kernel, dim3(ge), dim3(256), 0, s, n_ent, d_ek2, d_ev2, V.ent_fa, V.ent_fb, d_runidx);
     FL_CHK(rocprim::inclusive_scan(d_tmp3, tmp3_bytes, d_runidx, d_runstart, (size_t)n_ent, rocprim::maximum<int>(), s));
-    hipLaunchKernelGGL(fl_segflag_kernel, dim3(ge), dim3(256), 0, s, n_ent, d_runstart, d_segflag);
+    hipLaunchKernelGGL(fl_segflag_kernel, dim3(ge), dim3(256), 0, s, n_ent, d_runstart, d_segflag, pair_chunk((size_t)n_ent) - 1);
     FL_CHK(rocprim::select(d_tmp3, tmp3_bytes, rocprim::counting_iterator<int>(0), d_segflag, d_segsel, d_nseg, (size_t)n_ent, s));
   } else {
     FL_CHK(hipMemsetAsync(d_nseg, 0, sizeof(int) * 2, s));
