@@ -166,6 +166,30 @@ bool plan_matches(const BatchPlan& P, bsgpu_ctx* const* ctxs, int n, const bsgpu
 }
 
 // false: some window's plan is not covered after all (its back-substitution takes a form the batch does not launch), or no memory
+// The camera-pair segments of a window are cut for ONE window on the device (pair_chunk: 64 entries per wave on a window of the
+// reference's size — a wave's length is what a lone window waits for).  Thirty-two such windows side by side are bound by the launch's
+// work instead: the same entries in segments of up to kPairChunk (every fourth boundary of a pair's fine list), built once per finalize
+// on first use.
+static bool coarse_pair_segments(bsgpu_ctx* c) {
+  Visual& v = c->vis;
+  if (v.n_seg <= 0 || v.n_seg_c > 0) return true;
+  if (pair_chunk((size_t)v.n_ent) >= kPairChunk) { v.n_seg_c = v.n_seg; v.seg_ci_c = v.seg_ci; v.seg_cj_c = v.seg_cj; v.seg_start_c = v.seg_start; return true; }
+  std::vector<int> st((size_t)v.n_seg + 1), ci(v.n_seg), cj(v.n_seg);
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return false;
+  if (hipMemcpy(st.data(), v.seg_start, sizeof(int) * st.size(), hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(ci.data(), v.seg_ci, sizeof(int) * ci.size(), hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(cj.data(), v.seg_cj, sizeof(int) * cj.size(), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return false; }
+  std::vector<int> st_c, ci_c, cj_c;
+  for (int sgi = 0; sgi < v.n_seg; ++sgi) {
+    const bool same_pair = !ci_c.empty() && ci_c.back() == ci[sgi] && cj_c.back() == cj[sgi];
+    if (!same_pair || st[sgi] - st_c.back() >= kPairChunk) { st_c.push_back(st[sgi]); ci_c.push_back(ci[sgi]); cj_c.push_back(cj[sgi]); }
+  }
+  st_c.push_back(st[v.n_seg]);
+  v.seg_start_c = c->upload(st_c); v.seg_ci_c = c->upload(ci_c); v.seg_cj_c = c->upload(cj_c);
+  if (!v.seg_start_c || !v.seg_ci_c || !v.seg_cj_c) { v.seg_start_c = v.seg_ci_c = v.seg_cj_c = nullptr; return false; }
+  v.n_seg_c = (int)ci_c.size();
+  return true;
+}
 bool build_plan(BatchPlan& P, bsgpu_ctx* const* ctxs, int n, const bsgpu_options& o) {
   P.device = ctxs[0]->device;
   if (hipStreamCreateWithFlags(&P.stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); P.stream = nullptr; return false; }
@@ -229,7 +253,10 @@ bool build_plan(BatchPlan& P, bsgpu_ctx* const* ctxs, int n, const bsgpu_options
     if (c->vis.n_seg > 0 || band) units = small_assemble_first_set(c->small_factorwise + 2, kNumInternal - 2, &set, &taken);
     if (units == 0) taken = 0;
     batchargs_pairs_band(P.t_pairs_band, c->vis, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_dpos, (units > 0 && band) ? &set : nullptr, band ? units : 0);
-    batchargs_pairs(P.t_pairs, c->vis, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_dpos, (units > 0 && !band) ? &set : nullptr, band ? 0 : units);
+    (void)coarse_pair_segments(c);   // (on failure the fine list stays: correct, only slower side by side)
+    Visual vis_b = c->vis;   // (the pair launch of a batch walks the coarse segments)
+    if (c->vis.n_seg_c > 0) { vis_b.n_seg = c->vis.n_seg_c; vis_b.seg_ci = c->vis.seg_ci_c; vis_b.seg_cj = c->vis.seg_cj_c; vis_b.seg_start = c->vis.seg_start_c; }
+    batchargs_pairs(P.t_pairs, vis_b, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_dpos, (units > 0 && !band) ? &set : nullptr, band ? 0 : units);
     if (units == 0 && c->n_sa_seg + c->n_asm_grp > 0) units2 = small_assemble_first_set(c->small_factorwise + 2, kNumInternal - 2, &set2, &taken2);
     if (units2 == 0) taken2 = 0;
     if (!batchargs_small_assemble_set(P.t_asm_set, c->small_factorwise + 2 + taken + taken2, kNumInternal - 2 - taken - taken2, c->d_S, c->npad, c->plan.rhs_row, c->d_grad,

@@ -420,6 +420,7 @@ int finalize(bsgpu_ctx* c) {
     }
     seg_start.push_back((int)ent_fa.size());
     V.n_seg = (int)seg_ci.size(); V.n_ent = (int)ent_fa.size();
+    V.n_seg_c = 0; V.seg_ci_c = V.seg_cj_c = V.seg_start_c = nullptr;   // (the coarse list of the batch: rebuilt on first use)
     lap("segments");
     V.fac = c->upload(fac); V.pix = c->upload(pix); V.w = c->upload(w);
     V.cam_pose = c->upload(cam_pose); V.lm_of = c->upload(lm_of); V.lm_start = c->upload(lm_start);

@@ -125,6 +125,10 @@ struct Visual {
   int n_seg = 0, n_ent = 0;
   int* seg_ci = nullptr; int* seg_cj = nullptr; int* seg_start = nullptr;
   int* ent_fa = nullptr; int* ent_fb = nullptr;
+  // ... the same entries in segments of up to kPairChunk, for launches that are bound by their work and not by a wave's length (a window
+  // among many in bsgpu_solve_batch); built on first use (bsgpu_batch.cpp coarse_pair_segments), the fine list itself where it is that coarse
+  int n_seg_c = 0;
+  int* seg_ci_c = nullptr; int* seg_cj_c = nullptr; int* seg_start_c = nullptr;
   // band landmarks (band_plan.h): units = (first camera pose k0, a part of its landmarks by falling span); one record per landmark, in
   // unit order: (first factor row, slot mask | span << 16 | observations << 24, observation index of slot j in nibble j of z | w << 32, 15 = none)
   int n_band_units = 0, n_band_lm = 0;

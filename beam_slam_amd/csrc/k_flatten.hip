@@ -326,6 +326,7 @@ int flatten_visual_device(hipStream_t s, const std::function<void*(size_t)>& dal
   FL_CHK(hipMemcpyAsync(&h_nseg, d_nseg, sizeof(int), hipMemcpyDeviceToHost, s));
   FL_CHK(hipStreamSynchronize(s));                                  // sync #3: segment count
   V.n_seg = h_nseg;
+  V.n_seg_c = 0; V.seg_ci_c = V.seg_cj_c = V.seg_start_c = nullptr;   // (the coarse list of the batch: rebuilt on first use)
   V.seg_start = d_segsel;   // n_seg selected start indices (+ the end marker written below; the buffer has n_ent + 1 slots)
   V.seg_ci = (int*)A(sizeof(int) * (size_t)(h_nseg > 0 ? h_nseg : 1)); V.seg_cj = (int*)A(sizeof(int) * (size_t)(h_nseg > 0 ? h_nseg : 1));
   unsigned char* d_adj = (unsigned char*)A((size_t)T * T + 8);
