@@ -132,6 +132,8 @@ void bsgpu_destroy(bsgpu_ctx* c) {
   if (c->h_pcg_lazy) (void)hipHostFree(c->h_pcg_lazy);
   for (hipEvent_t e : c->pcg_ev) if (e) (void)hipEventDestroy(e);
   if (c->ev_reduce) (void)hipEventDestroy(c->ev_reduce);
+  if (c->ev_solve0) (void)hipEventDestroy(c->ev_solve0);
+  if (c->ev_solve1) (void)hipEventDestroy(c->ev_solve1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }

@@ -221,6 +221,7 @@ struct bsgpu_ctx {
   double* h_pcg_lazy = nullptr;   // pinned: the resident PCG launch's scalars, looked at with the step's other scalars (pcg_check)
   bool pcg_check_pending = false;
   hipEvent_t ev_reduce = nullptr;   // recorded after the end-of-step reduction: what the host waits for (work may be queued behind it)
+  hipEvent_t ev_solve0 = nullptr, ev_solve1 = nullptr;   // bsgpu_solve's timing events (created on first use)
   bool ev_reduce_pending = false;
   int* d_reduce_counter = nullptr;  // final_reduce_kernel's ticket (the last workgroup stamps the host mirror with reduce_seq)
   double reduce_seq = 0.0;          // sequence number of the last end-of-step reduction enqueued

@@ -742,8 +742,10 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
   c->pcg_iters_total = 0;
   sum.linear_solver_used = c->use_pcg ? BSGPU_LINEAR_PCG : c->use_spcg ? BSGPU_LINEAR_SCHUR_PCG : BSGPU_LINEAR_SCHUR_CHOLESKY;
   hipStream_t s = c->stream;
-  hipEvent_t ev0, ev1;
-  HIPCHK(c, hipEventCreate(&ev0)); HIPCHK(c, hipEventCreate(&ev1));
+  // (the solve's two timing events are the context's: a pair created per solve was never destroyed on the error returns below)
+  if (!c->ev_solve0) HIPCHK(c, hipEventCreate(&c->ev_solve0));
+  if (!c->ev_solve1) HIPCHK(c, hipEventCreate(&c->ev_solve1));
+  const hipEvent_t ev0 = c->ev_solve0, ev1 = c->ev_solve1;
   HIPCHK(c, hipEventRecord(ev0, s));
 
   // iteration zero
@@ -804,7 +806,6 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
   HIPCHK(c, hipEventSynchronize(ev1));
   float ms = 0.f;
   (void)hipEventElapsedTime(&ms, ev0, ev1);
-  (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
   sum.device_time_in_seconds = ms * 1e-3;
   c->scal_mirrored = false; c->ev_reduce_pending = false; c->spec_J = false; c->spec_lm_radius = 0.0; c->spec_dirty = false;   // (the stream has drained: nothing of this solve is pending)
   sum.num_inner_iterations = c->pcg_iters_total;
