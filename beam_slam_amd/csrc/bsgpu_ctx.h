@@ -189,6 +189,9 @@ struct bsgpu_ctx {
   double* h_scal = nullptr;  // pinned
   double* h_scal_dev = nullptr;  // the same buffer as the device sees it (final_reduce mirrors the step's scalars there)
   double spec_lm_radius = 0.0;   // != 0: the next step's assembly is in the queue already, for an accepted step at this radius (bsgpu_solve.cpp enqueue_step)
+  bool spec_cand_arrays = false; // the evaluation ahead wrote its cost partials into the candidate's arrays (it replaced the cost-only pass)
+  bool reduce_carried = false;   // assemble(): the reduction it was handed rode in one of its launches
+  bool xpart_stale = false;      // the cost partials of the CURRENT point are those of an older one (the point was a candidate evaluated into the candidate's arrays)
   bool spec_dirty = false;       // an assembly ahead has run since the last one a step took as its own
   bool scal_mirrored = false;    // the last enqueued work ended with a final_reduce that filled the mirror
   // tiled Cholesky plan (dense_plan.h) and its device tables
@@ -341,7 +344,8 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum);
 void enqueue_fixed_cost(bsgpu_ctx* c, hipStream_t s);
 void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot, const ReduceRide* red = nullptr);
 // factor_follows: linear_solve_and_candidate() comes next — its factorisation launch may then carry the LM diagonal and the gradient norms
-void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, bool first, bool gradient_only = false, bool factor_follows = false);
+void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, bool first, bool gradient_only = false, bool factor_follows = false,
+              const ReduceRide* red = nullptr /* the step before's end-of-step reduction, to ride in the assembly's first launch (sets c->reduce_carried) */);
 void final_reduce(bsgpu_ctx* c);
 int fetch_scalars(bsgpu_ctx* c);
 int ensure_vis_src(bsgpu_ctx* c);

@@ -367,7 +367,7 @@ int batchargs_backsolve(BatchArgTable* tabs, const DensePlan& P, const DenseDev&
 void launch_backsolve_batch(hipStream_t s, const BatchArgTable* tabs, const BatchDyn* dyn, const int* n_in_form);
 void launch_landmark(hipStream_t s, const Visual& v, int n_pose, const double* radius_ptr, int compute_scale,
                      int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* scale, double* dcl,
-                     double* grad, const ZeroStep* zero = nullptr, double radius_val = 0.0);
+                     double* grad, const ZeroStep* zero = nullptr, double radius_val = 0.0, const ReduceRide* red = nullptr /* the step before's end-of-step reduction as the launch's first workgroups */);
 void launch_pairs(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm,
                   bool grad_only, const SmallGroupSet* small = nullptr, int n_small_units = 0);
 void launch_pairs_band(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm,
@@ -393,7 +393,8 @@ struct AsmGroup {
 bool launch_small_assemble_seg(hipStream_t s, const SmallGroup* groups_dev, int n_seg, const int* seg_start, const int* seg_ra, const int* seg_rb,
                                const int2* contrib, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm,
                                const SmallGroupSet* fw = nullptr, int n_fw_units = 0, int n_grp = 0, const AsmGroup* grp = nullptr,
-                               const MargDev* marg = nullptr);
+                               const MargDev* marg = nullptr, const ReduceRide* red = nullptr /* the step before's reduction as the first workgroups (not with marg) */,
+                               bool* red_carried = nullptr);
 void launch_pose_diag(hipStream_t s, int n_pose, double* S, int ld, const double* hdiag, const double* radius_ptr,
                       int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* scale,
                       double* dcl, int npad, const int* iperm, double radius_val = 0.0 /* used when radius_ptr is null */);

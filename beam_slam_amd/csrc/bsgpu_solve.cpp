@@ -253,6 +253,11 @@ void eval_all(bsgpu_ctx* c, const double* x, bool with_J, int slot, const Reduce
 }
 // the reduction can ride in the evaluation launched ahead of the decision (k_small.hip visual_imu_eval_reduce_kernel): a visual-inertial
 // window on eager launches whose host polls the mirror's stamp, outside bsgpu_profile_step (which times the reduction in its own phase)
+// (what any riding reduction needs: eager launches, a host that polls the mirror's stamp, outside bsgpu_profile_step)
+bool reduce_can_ride(const bsgpu_ctx* c) {
+  static const bool by_event = getenv("BSGPU_SCALARS_EVENT") != nullptr, off = getenv("BSGPU_REDUCE_LAUNCH") != nullptr;
+  return !off && !by_event && !c->use_graphs && !c->use_pcg && !c->prof_events && c->h_scal_dev != nullptr && c->d_reduce_counter != nullptr && c->n_reduce > 0;
+}
 bool reduce_rides(const bsgpu_ctx* c) {
   static const bool by_event = getenv("BSGPU_SCALARS_EVENT") != nullptr, off = getenv("BSGPU_REDUCE_LAUNCH") != nullptr;
   static const int merge_mode = getenv("BSGPU_EVAL_MERGE") ? atoi(getenv("BSGPU_EVAL_MERGE")) : 2;
@@ -279,7 +284,8 @@ void final_reduce(bsgpu_ctx* c) {
 
 // gradient_only: the caller wants the gradient (and its norms) of the current point and will not factorise — the
 // camera-pair blocks of the reduced system, four fifths of the pair kernel's work, are skipped
-void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, bool first, bool gradient_only, bool factor_follows) {
+void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, bool first, bool gradient_only, bool factor_follows, const ReduceRide* red) {
+  c->reduce_carried = false;
   if (c->use_pcg) { assemble_pcg(c, o, radius, new_J, first); return; }
   hipStream_t s = c->stream;
   // one launch clears the reduced system, gradient, diagonal and the scalars of this step (GRAD_MAX, GRAD_NORM2, CHOL_FAIL)
@@ -297,8 +303,14 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
   c->pre_cleared = false;
   if (!merged && !cleared) launch_zero_tiles_multi(s, zs.S, zs.ld, zs.tiles, zs.n_tiles, zs.a, zs.na, zs.b, zs.nb, zs.c, zs.nc, zs.radius_slot, zs.radius);
   c->scal_mirrored = false;
+  // (a reduction handed in rides in the first launch that takes it: the landmark launch, or below the pose-only factors' segment launch)
+  const bool red_in_lm = red != nullptr && c->vis.n_lm > 0;
+  // (... whose clearing then leaves the step's scalars alone: the reduction's last unit mirrors the factorisation's flag and clears it itself,
+  //  and the gradient norms' slots are the reduction's to write)
+  if (red_in_lm) zs.nc = 0;
   launch_landmark(s, c->vis, c->n_pose, merged ? nullptr : c->d_scal + SC_RADIUS, first ? 1 : 0, new_J ? 1 : 0, o.jacobi_scaling, o.min_lm_diagonal,
-                  o.max_lm_diagonal, c->d_scale, c->d_dcl, c->d_grad, merged ? &zs : nullptr, radius);
+                  o.max_lm_diagonal, c->d_scale, c->d_dcl, c->d_grad, merged ? &zs : nullptr, radius, red_in_lm ? red : nullptr);
+  if (red_in_lm) c->reduce_carried = true;
   // (inverse-depth landmarks: their scalar elimination, k_idp.hip — after the clearing above, which rides in the landmark launch)
   launch_idp_landmark(s, c->idp, c->small[BSGPU_F_IDP_REPROJ], c->use_graphs ? c->d_scal + SC_RADIUS : nullptr, radius, first ? 1 : 0, new_J ? 1 : 0,
                       o.jacobi_scaling, o.min_lm_diagonal, o.max_lm_diagonal, c->d_scale, c->d_dcl, c->d_grad);
@@ -323,10 +335,12 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
     launch_small_assemble_set(s, c->small_factorwise + 2 + taken + taken2, kNumInternal - 2 - taken - taken2, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag,
                               c->d_dpos);
     const int mr = marg_rider(c);
+    bool seg_carried = false;
     if (launch_small_assemble_seg(s, c->d_small_groups, c->n_sa_seg, c->d_sa_seg_start, c->d_sa_seg_ra, c->d_sa_seg_rb, c->d_sa_contrib, c->d_S, c->npad,
                                   c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_dpos, units2 > 0 ? &set2 : nullptr, units2, c->n_asm_grp, c->d_asm_grp,
-                                  mr >= 0 ? &c->marg[mr].dev : nullptr))
+                                  mr >= 0 ? &c->marg[mr].dev : nullptr, (red && !c->reduce_carried && mr < 0) ? red : nullptr, &seg_carried))
       marg_done = mr;
+    if (seg_carried) c->reduce_carried = true;
   }
   for (size_t i = 0; i < c->marg.size(); ++i) {
     const auto& mc = c->marg[i];
@@ -414,7 +428,7 @@ void dense_backsolve(hipStream_t s, const DensePlan& P, const DenseDev& D, doubl
   }
 }
 
-void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o, bool defer_reduce = false) {
+void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o, bool defer_reduce = false, bool skip_cand_cost = false) {
   hipStream_t s = c->stream;
   if (c->use_pcg) {
     pcg_solve(c, o);
@@ -482,7 +496,7 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o, bool defer
   if (c->n_upd_blocks == 0 && !c->upd_in_mcc)   // (else the update rode in the landmark back-substitution / the pose-only groups' launch above)
     launch_update(s, c->nb, c->d_blk_xoff, c->d_blk_toff, c->d_blk_size, c->d_blk_manifold, c->d_x, c->d_delta, c->d_xcand,
                   c->d_part_upd, &n_part);
-  eval_all(c, c->d_xcand, false, SC_COST_CAND);
+  if (!skip_cand_cost) eval_all(c, c->d_xcand, false, SC_COST_CAND);   // (skipped: the caller evaluates the candidate with Jacobians into the same partials)
   if (!defer_reduce) final_reduce(c);   // (deferred: it rides in the evaluation the caller launches next)
   phase_mark(c, BSGPU_PHASE_CANDIDATE);
 }
@@ -520,24 +534,46 @@ void enqueue_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius,
   // Jacobians at the current point: new for a first / accepted step — unless they were evaluated ahead at the candidate that has
   // just been accepted (below) — and to be restored for a rejected one if that evaluation overwrote them
   const bool have_J = (kind == STEP_ACCEPT && c->spec_J) || (kind == STEP_REJECT && !c->spec_J);
-  if (!have_J) eval_all(c, c->d_x, true, SC_COST_X);
-  c->spec_J = false;
+  if (!have_J) { eval_all(c, c->d_x, true, SC_COST_X); c->xpart_stale = false; }
+  else if (kind == STEP_ACCEPT && c->spec_cand_arrays) c->xpart_stale = true;   // (this point's costs were summed as a candidate's: its own partial arrays hold an older point's)
+  c->spec_J = false; c->spec_cand_arrays = false;
   // (an assembly ahead configured the gradient norms that ride in the factorisation for the point that was current THEN: the candidate
   //  it was computed at is the current point now)
   if (assembled_ahead && c->gn_ride.nb > 0) c->gn_ride.x = c->d_x;
   if (!assembled_ahead) assemble(c, o, radius, kind != STEP_REJECT || ahead_unconfirmed, kind == STEP_FIRST, gradient_only, /*factor_follows=*/true);
-  if (gradient_only) { final_reduce(c); return; }
+  if (gradient_only) { c->cost_x_stale = c->xpart_stale; final_reduce(c); return; }
+  // With an assembly ahead (radius_ahead) the candidate is evaluated ONCE: with Jacobians, into the candidate's cost partials — the
+  // cost-only pass in front of it computed the same residuals — and the step's reduction rides in the assembly's first launch, which follows
+  // that evaluation (4.7 us + a launch boundary less per iteration of a reference-sized window, 5.2 of C3's).
+  static const bool one_pass_off = getenv("BSGPU_CAND_ONE_PASS") && atoi(getenv("BSGPU_CAND_ONE_PASS")) == 0;
+  const bool ahead = radius_ahead > 0.0 && !c->use_graphs && !c->use_pcg && !c->use_spcg && c->dense_ok && c->n_pose > 0 && c->idp.n_lm == 0;
+  const bool one_pass = ahead && !one_pass_off && reduce_can_ride(c) && (c->vis.n_lm > 0 || (c->n_sa_seg + c->n_asm_grp > 0 && marg_rider(c) < 0));
   // (not on the first step: the reduction that rides cannot give the cost at x — the launch that carries it rewrites those partials — and
   //  only the first step's is read: after an accepted step the cost at x is the candidate's cost the host already holds)
-  const bool ride = !gradient_only && kind != STEP_FIRST && reduce_rides(c);
-  c->cost_x_stale = ride;
-  linear_solve_and_candidate(c, o, ride);
+  const bool ride = !gradient_only && kind != STEP_FIRST && !one_pass && reduce_rides(c);
+  c->cost_x_stale = ride || c->xpart_stale;
+  linear_solve_and_candidate(c, o, ride || one_pass, one_pass);
   // The host now waits for this step's scalars and decides; in the common case (accepted) the next thing the device needs is the
   // residuals and Jacobians at the candidate: evaluated ahead, underneath the host round trip (~26 us per iteration otherwise
   // idle).  A rejected step pays for it with a re-evaluation at the current point (above).
   if (!c->use_graphs) {
     hipEvent_t* const prof = c->prof_events;   // (bsgpu_profile_step times the step up to here: this evaluation belongs to the next one)
     c->prof_events = nullptr;
+    if (one_pass) {
+      eval_all(c, c->d_xcand, true, SC_COST_CAND);
+      c->spec_J = true; c->spec_cand_arrays = true;
+      ReduceRide r;
+      c->reduce_seq += 1.0;
+      r.entries = c->d_reduce; r.n_entries = c->n_reduce; r.n_slots = SC_GRAD_NORM2 + 1; r.scal = c->d_scal; r.host_scal = c->h_scal_dev; r.counter = c->d_reduce_counter;
+      r.seq = c->reduce_seq; r.skip_slot = -1;
+      assemble(c, o, radius_ahead, /*new_J=*/true, /*first=*/false, /*gradient_only=*/false, /*factor_follows=*/true, &r);
+      if (c->reduce_carried) { c->scal_mirrored = true; c->seq_pending = true; c->ev_reduce_pending = false; }
+      else { c->reduce_seq -= 1.0; final_reduce(c); }   // (no launch of this window's assembly takes it: a launch of its own)
+      c->spec_dirty = true;
+      c->spec_lm_radius = c->diag_in_chol ? radius_ahead : 0.0;
+      c->prof_events = prof;
+      return;
+    }
     if (ride) {
       ReduceRide r;
       c->reduce_seq += 1.0;
@@ -549,7 +585,7 @@ void enqueue_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius,
       eval_all(c, c->d_xcand, true, SC_COST_X);
     c->prof_events = prof;
     c->spec_J = true;
-    if (radius_ahead > 0.0 && !c->use_pcg && !c->use_spcg && c->dense_ok && c->n_pose > 0 && c->idp.n_lm == 0) {
+    if (ahead) {
       // the next step's assembly as an accepted step at radius_ahead has it (new Jacobians: the ones just evaluated); what the host keeps
       // about THIS step's scalars is not the assembly's to reset
       const bool sm = c->scal_mirrored, sp = c->seq_pending, ep = c->ev_reduce_pending;

@@ -181,6 +181,18 @@ __device__ __forceinline__ void landmark_kernel_body(const int bsg_bx, const int
 __global__ __launch_bounds__(256) void landmark_kernel(int n_lm, const int* __restrict__ lm_start, const double* __restrict__ JB, const double2* __restrict__ r, int n_pose, const double* __restrict__ radius_ptr, int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* __restrict__ scale, double* __restrict__ dcl, double* __restrict__ grad, double* __restrict__ Linv_out, double* __restrict__ z_out, double* __restrict__ CR, int lm_blocks, ZeroStep zs, double radius_val) {
   landmark_kernel_body((int)blockIdx.x, (int)gridDim.x, n_lm, lm_start, JB, r, n_pose, radius_ptr, compute_scale, compute_dcl, jacobi, lm_lo, lm_hi, scale, dcl, grad, Linv_out, z_out, CR, lm_blocks, zs, radius_val);
 }
+// ... with the end-of-step reduction of the step BEFORE as its first workgroups: the landmark launch of an assembly issued ahead of the host's
+// decision (bsgpu_solve.cpp enqueue_step) follows the evaluation of the candidate with Jacobians, which has left the candidate's cost
+// partials — the reduction rides here instead of in that evaluation, and the cost-only pass at the candidate is not needed
+__global__ __launch_bounds__(256) void landmark_reduce_kernel(ReduceRide red, int n_lm, const int* __restrict__ lm_start, const double* __restrict__ JB, const double2* __restrict__ r, int n_pose, const double* __restrict__ radius_ptr, int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* __restrict__ scale, double* __restrict__ dcl, double* __restrict__ grad, double* __restrict__ Linv_out, double* __restrict__ z_out, double* __restrict__ CR, int lm_blocks, ZeroStep zs, double radius_val) {
+  const int n_units = red.n_slots + 1;
+  if ((int)blockIdx.x < n_units) {
+    __shared__ double sred[16];
+    final_reduce_unit<256>((int)blockIdx.x, (int)threadIdx.x, red, n_units, sred);
+    return;
+  }
+  landmark_kernel_body((int)blockIdx.x - n_units, (int)gridDim.x - n_units, n_lm, lm_start, JB, r, n_pose, radius_ptr, compute_scale, compute_dcl, jacobi, lm_lo, lm_hi, scale, dcl, grad, Linv_out, z_out, CR, lm_blocks, zs, radius_val);
+}
 // one launch over several windows (bsgpu_batch.cpp): blockIdx.y picks the window of list `bsg_list`, its arguments come from memory
 struct landmark_kernel_Args {
   int bsg_grid;
@@ -285,10 +297,15 @@ __global__ void landmark_tail_kernel_batch(const landmark_tail_kernel_Args* __re
 
 void launch_landmark(hipStream_t s, const Visual& v, int n_pose, const double* radius_ptr, int compute_scale,
                      int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* scale, double* dcl,
-                     double* grad, const ZeroStep* zero, double radius_val) {
+                     double* grad, const ZeroStep* zero, double radius_val, const ReduceRide* red) {
   if (v.n_lm > 0) {
     const int grid = (v.n_lm * 8 + 255) / 256;
     const int zero_blocks = zero ? std::max(1, std::min(zero->n_tiles, 1024)) : 0;
+    if (red && red->n_entries > 0)
+      hipLaunchKernelGGL(landmark_reduce_kernel, dim3(red->n_slots + 1 + grid + zero_blocks), dim3(256), 0, s, *red, v.n_lm, v.lm_start, v.JB, v.r, n_pose, radius_ptr,
+                         compute_scale, compute_dcl, jacobi, lm_lo, lm_hi, scale, dcl, grad, v.Linv, v.z, v.CR, grid, zero ? *zero : ZeroStep(),
+                         radius_val);
+    else
     hipLaunchKernelGGL(landmark_kernel, dim3(grid + zero_blocks), dim3(256), 0, s, v.n_lm, v.lm_start, v.JB, v.r, n_pose, radius_ptr,
                        compute_scale, compute_dcl, jacobi, lm_lo, lm_hi, scale, dcl, grad, v.Linv, v.z, v.CR, grid, zero ? *zero : ZeroStep(),
                        radius_val);

@@ -1262,6 +1262,23 @@ __global__ __launch_bounds__(256) void small_assemble_seg_kernel(const SmallGrou
                                                                 int first_grp_block) {
   small_assemble_seg_kernel_body((int)blockIdx.x, groups, n_seg, seg_start, seg_ra, seg_rb, contrib, S, ld, rhs_row, grad, hdiag, perm, fw, n_fw_units, n_grp, grp, first_grp_block);
 }
+// ... with the end-of-step reduction of the step before as its first workgroups (a pose-only window's assembly issued ahead of the host's
+// decision: k_reproj.hip landmark_reduce_kernel says why)
+__global__ __launch_bounds__(256) void small_assemble_seg_reduce_kernel(ReduceRide red, const SmallGroup* __restrict__ groups, int n_seg,
+                                                                       const int* __restrict__ seg_start, const int* __restrict__ seg_ra,
+                                                                       const int* __restrict__ seg_rb, const int2* __restrict__ contrib,
+                                                                       double* __restrict__ S, int ld, int rhs_row, double* __restrict__ grad,
+                                                                       double* __restrict__ hdiag, const int* __restrict__ perm, SmallGroupSet fw,
+                                                                       int n_fw_units, int n_grp, const AsmGroup* __restrict__ grp,
+                                                                       int first_grp_block) {
+  const int n_units = red.n_slots + 1;
+  if ((int)blockIdx.x < n_units) {
+    __shared__ double sred[16];
+    final_reduce_unit<256>((int)blockIdx.x, (int)threadIdx.x, red, n_units, sred);
+    return;
+  }
+  small_assemble_seg_kernel_body((int)blockIdx.x - n_units, groups, n_seg, seg_start, seg_ra, seg_rb, contrib, S, ld, rhs_row, grad, hdiag, perm, fw, n_fw_units, n_grp, grp, first_grp_block);
+}
 // ... with the J^T J / J^T r of the window's dense prior as the launch's last workgroups (marg_body.h: 16 x 16 output tiles, then the gradient's
 // row of workgroups) instead of marg_assemble_kernel behind it (7.4 us): both add into S, the gradient and the diagonal with atomics
 __global__ __launch_bounds__(256) void small_assemble_seg_marg_kernel(const SmallGroup* __restrict__ groups, int n_seg,
@@ -1281,7 +1298,8 @@ __global__ __launch_bounds__(256) void small_assemble_seg_marg_kernel(const Smal
 // marg: the window's (one) dense prior, carried by this launch; returns whether it was (false: no launch of this kind — the caller launches the prior's own)
 bool launch_small_assemble_seg(hipStream_t s, const SmallGroup* groups_dev, int n_seg, const int* seg_start, const int* seg_ra, const int* seg_rb,
                                const int2* contrib, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm,
-                               const SmallGroupSet* fw, int n_fw_units, int n_grp, const AsmGroup* grp, const MargDev* marg) {
+                               const SmallGroupSet* fw, int n_fw_units, int n_grp, const AsmGroup* grp, const MargDev* marg, const ReduceRide* red, bool* red_carried) {
+  if (red_carried) *red_carried = false;
   if (n_seg <= 0 && n_grp <= 0) return false;
   SmallGroupSet none;
   none.n = 0; none.first[0] = 0;
@@ -1293,6 +1311,12 @@ bool launch_small_assemble_seg(hipStream_t s, const SmallGroup* groups_dev, int 
     hipLaunchKernelGGL(small_assemble_seg_marg_kernel, dim3(own + mg * (mg + 1)), dim3(256), 0, s, groups_dev, std::max(0, n_seg), seg_start, seg_ra, seg_rb,
                        contrib, S, ld, rhs_row, grad, hdiag, perm, fw ? *fw : none, extra, n_grp, grp, first_grp_block, *marg, own, mg);
     return true;
+  }
+  if (red && red->n_entries > 0) {
+    hipLaunchKernelGGL(small_assemble_seg_reduce_kernel, dim3(red->n_slots + 1 + own), dim3(256), 0, s, *red, groups_dev, std::max(0, n_seg), seg_start, seg_ra, seg_rb,
+                       contrib, S, ld, rhs_row, grad, hdiag, perm, fw ? *fw : none, extra, n_grp, grp, first_grp_block);
+    if (red_carried) *red_carried = true;
+    return false;
   }
   hipLaunchKernelGGL(small_assemble_seg_kernel, dim3(own), dim3(256), 0, s, groups_dev, std::max(0, n_seg), seg_start, seg_ra, seg_rb,
                      contrib, S, ld, rhs_row, grad, hdiag, perm, fw ? *fw : none, extra, n_grp, grp, first_grp_block);
