@@ -240,8 +240,20 @@ BSG_DEV void final_reduce_unit(int slot, int tid, const ReduceRide& R, int n_uni
 #pragma unroll
   for (int q = 0; q < VT; ++q) acc[q] = 0.0;
   bool any = false, is_max = false;
+  // (the table of partial arrays goes through LDS in one trip: walked in memory it was a dependent scalar load per entry — thirteen on C3 —
+  //  in front of the host's stamp)
+  constexpr int kEntMax = 64;
+  static_assert(sizeof(ReduceEntry) == 32, "ReduceEntry");
+  __shared__ __attribute__((aligned(16))) unsigned long long s_ent_raw[kEntMax * 4];   // (ReduceEntry has a member initialiser: raw storage)
+  ReduceEntry* s_ent = reinterpret_cast<ReduceEntry*>(s_ent_raw);
+  const bool staged = R.n_entries <= kEntMax;
+  if (staged) {
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(R.entries);
+    for (int e = tid; e < 4 * R.n_entries; e += NT) s_ent_raw[e] = src[e];
+    __syncthreads();
+  }
   for (int e = 0; e < R.n_entries; ++e) {
-    const ReduceEntry en = R.entries[e];
+    const ReduceEntry en = staged ? s_ent[e] : R.entries[e];
     if (en.slot != slot) continue;
     any = true;
     if (en.op == 1) is_max = true;
