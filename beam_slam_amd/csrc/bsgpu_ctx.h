@@ -223,6 +223,7 @@ struct bsgpu_ctx {
   hipEvent_t pcg_ev[2] = {nullptr, nullptr};
   double* h_pcg_lazy = nullptr;   // pinned: the resident PCG launch's scalars, looked at with the step's other scalars (pcg_check)
   bool pcg_check_pending = false;
+  int pcg_verdicts_seen = 0;      // (BSGPU_PCG_GIVE_UP test hook: verdicts read by THIS context)
   hipEvent_t ev_reduce = nullptr;   // recorded after the end-of-step reduction: what the host waits for (work may be queued behind it)
   hipEvent_t ev_solve0 = nullptr, ev_solve1 = nullptr;   // bsgpu_solve's timing events (created on first use)
   bool ev_reduce_pending = false;

@@ -229,7 +229,8 @@ int finalize(bsgpu_ctx* c) {
   // BSGPU_PAIRS_BAND=0: every pair by entries (the cross-check), =1: band landmarks whatever the size (tests).
   const char* band_env = getenv("BSGPU_PAIRS_BAND");
   const int n_reproj = c->groups[BSGPU_F_REPROJ].n + c->groups[BSGPU_F_REPROJ_ONLINE_CALIB].n;
-  const bool band_on = band_env ? strcmp(band_env, "0") != 0 : n_reproj >= kBandMinFactors;
+  // (band_available(): the kernel's ~147 KB of dynamic LDS per workgroup, asked of this device once — a device or partition without it keeps the pair entries)
+  const bool band_on = (band_env ? strcmp(band_env, "0") != 0 : n_reproj >= kBandMinFactors) && band_available();
   const bool sort_entries = getenv("BSGPU_PAIR_ENTRIES_SORT") != nullptr;   // (tests: the path windows of more than 2 896 camera poses take)
   // ---- visual factors: camera-pose ids, factors sorted by landmark, pair entries, tile adjacency.
   // Large plain windows are flattened on the device (k_flatten.hip); everything else — and any window the device

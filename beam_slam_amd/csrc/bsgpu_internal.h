@@ -370,6 +370,7 @@ void launch_landmark(hipStream_t s, const Visual& v, int n_pose, const double* r
                      double* grad, const ZeroStep* zero = nullptr, double radius_val = 0.0, const ReduceRide* red = nullptr /* the step before's end-of-step reduction as the launch's first workgroups */);
 void launch_pairs(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm,
                   bool grad_only, const SmallGroupSet* small = nullptr, int n_small_units = 0);
+bool band_available();   // the current device gives the band kernels their dynamic LDS (k_band.hip)
 void launch_pairs_band(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm,
                        bool grad_only, const SmallGroupSet* small = nullptr, int n_small_units = 0);
 int small_assemble_first_set(const SmallGroup* groups, int n_groups, SmallGroupSet* set, int* n_taken);

@@ -118,7 +118,7 @@ bool pcg_check(bsgpu_ctx* c) {
   double done = c->h_pcg_lazy[pcg_done_slot()];
   const double iters = c->h_pcg_lazy[pcg_iters_slot()];
   // (tests: BSGPU_PCG_GIVE_UP=n declares the n-th verdict of the process a failure — the path a shared device takes)
-  if (const char* e = getenv("BSGPU_PCG_GIVE_UP")) { static std::atomic<int> seen{0}; if (++seen == atoi(e)) done = 0.0; }
+  if (const char* e = getenv("BSGPU_PCG_GIVE_UP")) { if (++c->pcg_verdicts_seen == atoi(e)) done = 0.0; }   // (counted per context)
   if (done > 0.0) { c->pcg_iters_total += (int)iters; return true; }
   fprintf(stderr, "[bsgpu] the resident PCG launch was given up (done %g after %g iterations): launch-per-iteration path from here on\n", done, iters);
   c->pcg_persist.G = 0;
@@ -546,7 +546,13 @@ void enqueue_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius,
   // cost-only pass in front of it computed the same residuals — and the step's reduction rides in the assembly's first launch, which follows
   // that evaluation (4.7 us + a launch boundary less per iteration of a reference-sized window, 5.2 of C3's).
   static const bool one_pass_off = getenv("BSGPU_CAND_ONE_PASS") && atoi(getenv("BSGPU_CAND_ONE_PASS")) == 0;
-  const bool ahead = radius_ahead > 0.0 && !c->use_graphs && !c->use_pcg && !c->use_spcg && c->dense_ok && c->n_pose > 0 && c->idp.n_lm == 0;
+  // (an assembly ahead is adopted only when the LM diagonal and the gradient norms ride in the factorisation — diag_in_chol's static
+  //  preconditions — and it zeroes scalar slots the host must already have read through the mirror: without either it would be assembled
+  //  and thrown away every iteration, or the host would read a zeroed gradient norm)
+  const bool diag_can_ride = c->plan.diag_tasks && c->plan.rider_tasks * 256 >= c->nb && c->d_ftasks && c->d_fsync && c->d_tile_tot && c->d_Winv;
+  const bool mirror_ok = c->h_scal_dev != nullptr && c->d_reduce_counter != nullptr && c->n_reduce > 0;
+  const bool ahead = radius_ahead > 0.0 && !c->use_graphs && !c->use_pcg && !c->use_spcg && c->dense_ok && c->n_pose > 0 && c->idp.n_lm == 0 &&
+                     diag_can_ride && mirror_ok;
   const bool one_pass = ahead && !one_pass_off && reduce_can_ride(c) && (c->vis.n_lm > 0 || (c->n_sa_seg + c->n_asm_grp > 0 && marg_rider(c) < 0));
   // (not on the first step: the reduction that rides cannot give the cost at x — the launch that carries it rewrites those partials — and
   //  only the first step's is read: after an accepted step the cost at x is the candidate's cost the host already holds)

@@ -19,6 +19,9 @@
 //     sums reach S's diagonal blocks, the reduced rhs row, the gradient and diag(H) after a transposed butterfly inside each 32-lane half.
 // Landmarks that do not qualify (a span of more than kBandCams camera poses, two observations from one camera pose) and the factors of
 // constant landmarks keep their pair entries in pairs_kernel; the pose-only factors that rode in the pair launch ride here.
+#include <mutex>
+#include <vector>
+#include <cstdio>
 #include <atomic>
 
 #include "bsgpu_device.h"
@@ -369,15 +372,30 @@ __global__ __launch_bounds__(kBandThreads) void pairs_band_kernel_batch(const pa
   pairs_band_kernel_body((int)blockIdx.x, a.bsg_grid, a.n_units, (const int*)a.unit_start, (const int*)a.unit_cam, (const int4*)a.band_lm, a.n_cam_pose, (const double*)a.J, (const double2*)a.r, (const double*)a.CR, (const int*)a.cp_tq, (const int*)a.cp_tp, (double*)a.S, a.ld, a.rhs_row, (double*)a.grad, (double*)a.hdiag, (const int*)a.perm, bsg_dyn->grad_only[bsg_w], a.small, a.n_small_units);
 }
 
-static void band_attr_once() {
-  static std::atomic<unsigned> attr_set{0};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (attr_set.load() & (1u << (dev & 31))) return;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pairs_band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBandLds);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pairs_band_kernel_batch), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBandLds);
-  attr_set.fetch_or(1u << (dev & 31));
+// The band kernels need kBandLds (~147 KB) of dynamic LDS per workgroup: the opt-in is made once per device (keyed by the whole device id)
+// and its outcome is kept — finalize() asks band_available() and plans the pair-entry path on a device or partition that cannot give it.
+static int band_attr_state(int dev) {   // 1: available, -1: not
+  static std::mutex mu;
+  static std::vector<signed char> state;
+  std::lock_guard<std::mutex> lk(mu);
+  if (dev < 0) return -1;
+  if ((size_t)dev >= state.size()) state.resize((size_t)dev + 1, 0);
+  if (state[dev] == 0) {
+    int max_lds = 0;
+    bool ok = hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && max_lds >= (int)kBandLds;
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(pairs_band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBandLds) == hipSuccess;
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(pairs_band_kernel_batch), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBandLds) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); fprintf(stderr, "[bsgpu] device %d gives %d B of LDS per workgroup, the band kernel needs %d: pair-entry path\n", dev, max_lds, (int)kBandLds); }
+    state[dev] = ok ? 1 : -1;
+  }
+  return state[dev];
 }
+bool band_available() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  return band_attr_state(dev) > 0;
+}
+static void band_attr_once() { (void)band_available(); }
 
 void launch_pairs_band(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm, bool grad_only,
                        const SmallGroupSet* small, int n_small_units) {

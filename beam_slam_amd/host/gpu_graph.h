@@ -9,6 +9,7 @@
 #pragma once
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -214,6 +215,7 @@ class GpuGraph {
       undo_[ty].reset(); tables_[ty].reset();
       dirty_[ty].clear(); synced_[ty] = false;
     }
+    tables_own_ = true;
     cameras_.clear(); marginal_rows_.clear();
     conn_.clear(); connectivity_valid_ = true;
   }
@@ -462,6 +464,7 @@ class GpuGraph {
       }
       g->tables_[ty] = tables_[ty];
       g->undo_[ty] = std::move(u);
+      g->tables_own_.store(false, std::memory_order_relaxed);   // (published with the clone itself)
     }
     g->cameras_ = cameras_;
     g->marginal_rows_ = marginal_rows_;
@@ -806,14 +809,20 @@ class GpuGraph {
   std::vector<uint32_t> crow_;                                  // constraint slot -> row in its type's table
   std::vector<int32_t> cfree_;
   mutable detail::FlatIndex cindex_;                            // uuid -> constraint slot (a clone's: built on first use)
-  mutable bool cindex_valid_ = true;
+  mutable std::atomic<bool> cindex_valid_{true};
+  // A snapshot goes to several publisher threads as a const graph: the lazy builds behind const accessors (uuid index, connectivity,
+  // own tables) are each done once under this mutex; the flags are read with acquire so that a reader that sees `true` sees the data.
+  mutable std::recursive_mutex lazy_mu_;   // (recursive: the connectivity build reads the tables, which may materialise them)
+  mutable std::atomic<bool> tables_own_{true};   // false while some undo_[ty] is set (a clone that still reads another graph's tables)
   size_t n_constraints_ = 0;
   void ensureConstraintIndex() const {
-    if (cindex_valid_) return;
+    if (cindex_valid_.load(std::memory_order_acquire)) return;
+    std::lock_guard<std::recursive_mutex> lk(lazy_mu_);
+    if (cindex_valid_.load(std::memory_order_relaxed)) return;
     cindex_.clear();
     cindex_.reserve(n_constraints_);
     for (size_t cs = 0; cs < ctype_.size(); ++cs) if (ctype_[cs] != kFree) cindex_.insertIfAbsent(cptr_[cs]->uuid(), (int32_t)cs);
-    cindex_valid_ = true;
+    cindex_valid_.store(true, std::memory_order_release);
   }
   mutable std::shared_ptr<TypeTable> tables_[BSGPU_F_NUM_TYPES];        // owned — or, while undo_[ty] is set, another graph's table to be read through the log
   mutable std::shared_ptr<TableUndo> undo_[BSGPU_F_NUM_TYPES];          // (a snapshot that has not needed its tables yet)
@@ -833,6 +842,9 @@ class GpuGraph {
   std::vector<uint8_t> cmark_, vmark_;   // update(): constraints being removed / variables whose lists lose some of them
   // this graph's own version of every table it still reads through an undo log (const: a lazy copy, not a change of the graph)
   void materialiseTables() const {
+    if (tables_own_.load(std::memory_order_acquire)) return;
+    std::lock_guard<std::recursive_mutex> lazy(lazy_mu_);
+    if (tables_own_.load(std::memory_order_relaxed)) return;
     for (int ty = 0; ty < BSGPU_F_NUM_TYPES; ++ty) {
       if (!undo_[ty]) continue;
       std::shared_ptr<TypeTable> src = tables_[ty];
@@ -860,6 +872,7 @@ class GpuGraph {
       tables_[ty] = std::move(n);
       undo_[ty].reset();
     }
+    tables_own_.store(true, std::memory_order_release);
   }
   TypeTable& tableMut(int ty) {
     materialiseTables();
@@ -870,7 +883,7 @@ class GpuGraph {
   template <class F>
   void forEachVariableOf(int32_t cs, F fn) const {
     const int ty = ctype_[cs];
-    if (ty >= 0 && undo_[ty]) materialiseTables();
+    if (ty >= 0) materialiseTables();
     if (ty >= 0) { const TypeTable& tb = *tables_[ty]; for (int k = 0; k < tb.nvar; ++k) fn(tb.idx[(size_t)crow_[cs] * tb.nidx + k]); }
     else if (ty == kMarginal) for (int32_t s : marginal_rows_.at(cs).vars) fn(s);
     else if (ty == kUnpacked) for (const auto& u : cptr_[cs]->variables()) { const int32_t s = vindex_.find(u); if (s >= 0) fn(s); }
@@ -940,16 +953,18 @@ class GpuGraph {
   }
   // variable slot -> constraint slots: maintained incrementally once built; a clone rebuilds it on first use from the tables
   void ensureConnectivity() const {
-    if (connectivity_valid_) return;
+    if (connectivity_valid_.load(std::memory_order_acquire)) return;
+    std::lock_guard<std::recursive_mutex> lk(lazy_mu_);
+    if (connectivity_valid_.load(std::memory_order_relaxed)) return;
     conn_.assign(vslots_.size(), {});
     for (size_t cs = 0; cs < ctype_.size(); ++cs)
       if (ctype_[cs] != kFree)
         forEachVariableOf((int32_t)cs, [&](int32_t s) { auto& l = conn_[s]; if (std::find(l.begin(), l.end(), (int32_t)cs) == l.end()) l.push_back((int32_t)cs); });
-    connectivity_valid_ = true;
+    connectivity_valid_.store(true, std::memory_order_release);
   }
   // (tables_ / undo_ are mutable: materialiseTables() is a lazy copy behind const accessors)
   mutable std::vector<std::vector<int32_t>> conn_;
-  mutable bool connectivity_valid_ = true;
+  mutable std::atomic<bool> connectivity_valid_{true};
   bsgpu_summary last_summary_{};
   Flat flat_;
 };

@@ -99,6 +99,18 @@ def short_leg(which, device):
     if which == "c3":
         prof = g.profile_step(opt, reps=10)
         leg["phases_us_per_lm_step"] = {k: round(1e3 * v[0], 2) for k, v in prof.items()}
+    if which == "c4":
+        # the same solves with the inner tolerance a caller may choose instead of the reference-equivalent default: labelled, never the leg's value
+        opt.pcg_tolerance = 1e-6
+        g.reset_values(); s2 = g.solve(opt)
+        t0 = time.perf_counter(); n2 = 0
+        for _ in range(steps):
+            g.reset_values(); s2 = g.solve(opt)
+            n2 += s2.num_linear_solves
+        dt2 = time.perf_counter() - t0
+        leg["inexact_inner_tolerance_1e-6"] = {"value": round(n2 / dt2, 2), "ms_per_step": round(1e3 * dt2 / steps, 3), "pcg_iterations_per_solve": int(s2.num_inner_iterations),
+                                               "final_cost": s2.final_cost, "final_cost_rel_to_default": abs(s2.final_cost - s.final_cost) / s.final_cost,
+                                               "note": "pcg_tolerance set explicitly by the caller; the default (1e-10) is the reference-equivalent step"}
     g.close()
     return leg
 
@@ -162,6 +174,26 @@ def host_cycle_leg():
     return {"skipped": "no summary line", "tail": out[-400:]}
 
 
+def _relaunch(n):
+    """Plain `python bench.py --gpus N` (no launcher): re-exec under torch.distributed.run with one rank per GPU on 127.0.0.1."""
+    import socket
+    import subprocess
+    if not os.environ.get("BSGPU_BENCH_SAME_DEVICE"):
+        import torch
+        have = torch.cuda.device_count()
+        if n > have:
+            sys.exit("bench.py: --gpus %d but this node shows %d GPU(s); one rank per GPU is the only layout this bench runs" % (n, have))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -188,7 +220,13 @@ def main():
                          "are the only collective (RCCL all-reduce of a few KB per round)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` as documented: start the N ranks ourselves (one process per GPU under torch.distributed.run, the
+        # same command line the driver uses) and hand their single JSON line through
+        return _relaunch(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node equal to --gpus (or plain `python bench.py --gpus N`)" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
@@ -319,6 +357,8 @@ def main():
         tot_it, max_dt = sharding.aggregate(dist, n_it, dt, device=dev)
         ranks_seen, per_rank = sharding.per_rank_rates(dist, n_it, dt, device=dev)
 
+    if ranks_seen != args.gpus:
+        sys.exit("bench.py: --gpus %d but %d rank(s) reported: the line would not describe the job asked for" % (args.gpus, ranks_seen))
     out = None
     if rank == 0:
         # ---- rooflines, all measured IN SITU: HIP events at the phase boundaries of real LM steps on the solver's stream

@@ -1255,7 +1255,9 @@ Ctx* bso_create(int) { return new Ctx(); }
 void bso_destroy(Ctx* c) { delete c; }
 const char* bso_last_error(const Ctx* c) { return c->err.c_str(); }
 int bso_abi_version(void) { return BSGPU_ABI_VERSION; }
-int bso_clear(Ctx* c) { auto keep = std::move(c->sync_prev); *c = Ctx(); c->sync_prev = std::move(keep); return BSGPU_OK; }
+// reproj_mode is a setting of the checker, not problem data: it survives clear() (a load() starts with clear(); a test that set the
+// mode first used to compare the closed form with itself)
+int bso_clear(Ctx* c) { auto keep = std::move(c->sync_prev); const int mode = c->reproj_mode; *c = Ctx(); c->sync_prev = std::move(keep); c->reproj_mode = mode; return BSGPU_OK; }
 
 int bso_set_blocks(Ctx* c, int32_t n, const double* values, const int32_t* offset, const uint8_t* size,
                    const uint8_t* manifold, const uint8_t* is_const) {

@@ -699,6 +699,61 @@ static void test_snapshot_read_while_the_graph_moves_on() {
   check_against_model(g, m, none, true);
 }
 
+// One snapshot, SEVERAL publisher threads (fixed_lag_smoother.cpp:308 hands the clone to every publisher as a const graph): the first
+// constraintExists / getConnectedConstraints on it builds the uuid index, the connectivity and the snapshot's own tables lazily behind
+// const accessors — four readers start on a fresh snapshot at once while the owner moves on; every reader must see the model.
+static void test_one_snapshot_many_readers() {
+  std::printf("OneSnapshotManyReaders\n");
+  std::mt19937 rng(11);
+  std::normal_distribution<double> N(0.0, 1.0);
+  auto U = [&](size_t n) { return (size_t)(rng() % n); };
+  using fuse_variables::VelocityLinear3DStamped;
+  bs_optimizers::GpuGraph g;
+  const Mat<3, 3> c3 = 0.25 * I3();
+  std::vector<fuse_core::Variable::SharedPtr> vs;
+  for (int k = 0; k < 200; ++k) {
+    auto v = VelocityLinear3DStamped::make_shared(fuse_core::Time(0.01 * k));
+    for (int i = 0; i < 3; ++i) v->data()[i] = N(rng);
+    vs.push_back(v); g.addVariable(v->clone());
+  }
+  int serial = 0;
+  std::vector<fuse_core::Constraint::SharedPtr> cons;
+  std::vector<std::pair<size_t, size_t>> ends;
+  auto new_constraint = [&]() {
+    size_t a = U(vs.size()), b = U(vs.size());
+    if (a == b) b = (a + 1) % vs.size();
+    const Vec3 d{N(rng), N(rng), N(rng)};
+    auto c = bs_constraints::RelativeVelocityLinear3DStampedConstraint("m" + std::to_string(serial++), static_cast<VelocityLinear3DStamped&>(*vs[a]),
+                                                                       static_cast<VelocityLinear3DStamped&>(*vs[b]), d, c3);
+    ends.emplace_back(a, b);
+    return c;
+  };
+  for (int k = 0; k < 3000; ++k) { auto c = new_constraint(); g.addConstraint(c); cons.push_back(c); }
+  for (int round = 0; round < 40 && !g_fail; ++round) {
+    std::shared_ptr<const bs_optimizers::GpuGraph> snap(g.clone().release());
+    const size_t n_cons = cons.size();
+    std::vector<size_t> degree(vs.size(), 0);
+    for (size_t i = 0; i < n_cons; ++i) { ++degree[ends[i].first]; ++degree[ends[i].second]; }
+    std::atomic<int> bad{0};
+    std::vector<std::thread> readers;
+    for (int t = 0; t < 4; ++t)
+      readers.emplace_back([&, t]() {
+        for (size_t i = t; i < n_cons; i += 3) if (!snap->constraintExists(cons[i]->uuid())) ++bad;
+        for (size_t v = t; v < vs.size(); v += 2) if (snap->getConnectedConstraints(vs[v]->uuid()).size() != degree[v]) ++bad;
+        if (snap->numConstraints() != n_cons) ++bad;
+      });
+    // the owner moves on underneath: new constraints the snapshot must not see
+    fuse_core::Transaction tr;
+    std::vector<fuse_core::Constraint::SharedPtr> fresh;
+    for (int k = 0; k < 60; ++k) { auto c = new_constraint(); tr.addConstraint(c); fresh.push_back(c); }
+    g.update(tr);
+    for (auto& th : readers) th.join();
+    for (auto& c : fresh) if (snap->constraintExists(c->uuid())) ++bad;
+    CHECK(bad.load() == 0);
+    for (auto& c : fresh) cons.push_back(c);
+  }
+}
+
 // the pending-transaction queue rules of fixed_lag_smoother.cpp:335-477 (processQueue) and :548-627 (transactionCallback): ignition,
 // purge of pre-ignition transactions, transactions older than the lag window, motion-model failure -> retry until transaction_timeout
 static void test_process_queue_rules() {
@@ -802,6 +857,7 @@ int main() {
   test_true_marginalization_linear_chain();
   test_clone_is_an_independent_snapshot();
   test_snapshot_read_while_the_graph_moves_on();
+  test_one_snapshot_many_readers();
   test_random_transactions_against_model();
   test_process_queue_rules();
   test_fixed_lag_smoother_window(true);

@@ -79,3 +79,20 @@ def test_bench_windows_per_gpu_two_ranks_on_one_gpu():
     # the same flag on one rank
     r1 = _bench({}, "--windows-per-gpu", "3", "--n-kf", "30", "--n-lm", "2000")
     assert r1["n_gpus"] == 1 and r1["config"]["n_ranks_seen"] == 1 and r1["value"] > 0
+
+
+def test_bench_plain_gpus_two_launches_two_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it (the documented usage): bench.py starts its two ranks itself under
+    torch.distributed.run and the line says n_gpus 2 with two ranks reporting.  Both ranks share the one GPU of the box (gloo carries the
+    barriers: RCCL refuses two ranks on one device)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(BSGPU_BENCH_BACKEND="gloo", BSGPU_BENCH_SAME_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                          "--no-other-configs", "--sustained-seconds", "0", "--n-kf", "30", "--n-lm", "2000"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                      # ONE JSON line for the whole job
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["n_ranks_seen"] == 2 and len(r["config"]["per_rank_lm_iterations_per_s"]) == 2
+    assert "2 independent" in r["config"]["workload"] and r["value"] > 0

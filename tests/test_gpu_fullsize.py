@@ -243,9 +243,11 @@ def test_dense_solve_kernels_against_numpy():
         assert np.abs(x - xr).max() <= 1e-13 * cond * np.abs(xr).max()
 
 
-def test_c4_full_solve_matches_oracle_cg(oracle_cls, gpu_solver_cls):
+@pytest.mark.parametrize("inner_tol,inner_cap", [(None, 80), (1e-6, 45)])
+def test_c4_full_solve_matches_oracle_cg(oracle_cls, gpu_solver_cls, inner_tol, inner_cap):
     """BASELINE config 4 at full size (5 000 poses, 50 000 constraints, 30 000 tangent dimensions): the 10-iteration solve of bench.py on
-    the block-sparse PCG path (two-level preconditioner, default inner tolerance 1e-6) against the oracle, whose step is the exact one to
+    the block-sparse PCG path (two-level preconditioner; at the default inner tolerance 1e-10 and at the inexact 1e-6 bench.py also
+    reports) against the oracle, whose step is the exact one to
     1e-12 by conjugate gradients (its dense factorisation stops at 20 000 dimensions; tests/test_oracle_cg.py pins the CG step to the
     dense one on a small graph).  Every iteration's decision and cost, the final cost to the north-star 1e-6, the final values."""
     pr = synthetic.c4()
@@ -253,6 +255,9 @@ def test_c4_full_solve_matches_oracle_cg(oracle_cls, gpu_solver_cls):
     pr.load(g); pr.load(o)
     opt = g.options_default()
     opt.max_num_iterations = 10
+    assert opt.pcg_tolerance == 1e-10          # the default is the reference-equivalent (exact) step
+    if inner_tol is not None:
+        opt.pcg_tolerance = inner_tol
     sg = g.solve(opt)
     opt_o = o.options_default()
     opt_o.max_num_iterations = 10
@@ -267,8 +272,8 @@ def test_c4_full_solve_matches_oracle_cg(oracle_cls, gpu_solver_cls):
         assert abs(a.cost - b.cost) <= 1e-6 * b.cost
     assert abs(sg.final_cost - so.final_cost) <= 1e-6 * so.final_cost
     assert np.abs(g.get_blocks() - o.get_blocks()).max() < 1e-5
-    # the inner iterations: at most 45 per LM step at the default inner tolerance (1e-6: 39 measured; 84 at 1e-12, 69 at 1e-10)
-    assert sg.num_inner_iterations <= 45 * sg.num_iterations
+    # the inner iterations per LM step: 69 measured at 1e-10 (84 at 1e-12), 39 at 1e-6
+    assert sg.num_inner_iterations <= inner_cap * sg.num_iterations
 
 
 @pytest.mark.parametrize("n_pose", [2200, 3900, 4300])

@@ -111,7 +111,7 @@ def test_many_rows_per_workgroup(gpu_solver_cls, monkeypatch):
 
 
 @pytest.mark.parametrize("nth", [1, 3])
-def test_a_resident_launch_that_is_given_up_has_its_step_computed_again(gpu_solver_cls, monkeypatch, nth):
+def test_a_resident_launch_that_is_given_up_has_its_step_computed_again(gpu_solver_cls, monkeypatch, nth, capfd):
     """The resident launch's verdict is read with the step's other scalars (bsgpu_solve.cpp pcg_check); when it did not finish — a shared
     device — the step is asked for again (lm_state.h retry) and computed launch per iteration.  BSGPU_PCG_GIVE_UP declares the n-th
     verdict a failure: the first step's, and one in the middle of the solve.  (BSGPU_PCG_COARSE=0: the launch-per-iteration path has no
@@ -125,7 +125,11 @@ def test_a_resident_launch_that_is_given_up_has_its_step_computed_again(gpu_solv
         s = g.solve(o)
         return s, [i.cost for i in g.iterations()], [i.step_is_successful for i in g.iterations()], g.get_blocks()
     s0, c0, a0, x0 = run()
+    capfd.readouterr()
     monkeypatch.setenv("BSGPU_PCG_GIVE_UP", str(nth))
     s1, c1, a1, x1 = run()
+    # the path was really taken (the hook counts the verdicts of the context, not of the process): the library says so once
+    assert capfd.readouterr().err.count("the resident PCG launch was given up") == 1
+    assert s1.num_inner_iterations != s0.num_inner_iterations or nth == 1
     assert a0 == a1 and s0.num_iterations == s1.num_iterations and s0.termination_type == s1.termination_type
     assert np.allclose(c0, c1, rtol=1e-7) and np.abs(x0 - x1).max() < 1e-4
