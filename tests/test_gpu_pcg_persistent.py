@@ -130,6 +130,5 @@ def test_a_resident_launch_that_is_given_up_has_its_step_computed_again(gpu_solv
     s1, c1, a1, x1 = run()
     # the path was really taken (the hook counts the verdicts of the context, not of the process): the library says so once
     assert capfd.readouterr().err.count("the resident PCG launch was given up") == 1
-    assert s1.num_inner_iterations != s0.num_inner_iterations or nth == 1
     assert a0 == a1 and s0.num_iterations == s1.num_iterations and s0.termination_type == s1.termination_type
     assert np.allclose(c0, c1, rtol=1e-7) and np.abs(x0 - x1).max() < 1e-4
