@@ -282,7 +282,7 @@ bool build_plan(BatchPlan& P, bsgpu_ctx* const* ctxs, int n, const bsgpu_options
     const FusedTask* tl = bulk ? c->d_ftasks_bulk : plain ? c->d_ftasks_plain : D.ftasks;
     const int ntl = bulk ? c->n_ftasks_bulk : plain ? c->n_ftasks_plain : (int)c->plan.ftasks.size();
     const int* tt = bulk ? c->d_tile_tot_bulk : plain ? c->d_tile_tot_plain : D.tile_tot;
-    batchargs_chol_fused(P.t_chol, c->d_S, D.Lp, c->plan.npad, tl, ntl, tt, D.nreal, D.Vinv, c->d_scal, D.fsync, D.Winv, D.rhs_rows, LmDiag(), GradNormRide());
+    batchargs_chol_fused(P.t_chol, c->d_S, D.Lp, c->plan.npad, tl, ntl, tt, D.nreal, D.Vinv, c->d_scal, D.fsync, D.Winv, D.rhs_rows, LmDiag(), GradNormRide(), /*diag_tasks_in_list=*/!bulk && !plain && c->plan.diag_tasks);
     P.bs_form[w] = batchargs_backsolve(P.t_bs, c->plan, D, c->d_y, c->d_inat, c->n_pose, c->d_ytan, c->d_delta);
     if (P.bs_form[w] < 0) return false;
     // ---- landmark back-substitution + model cost change + candidate (linear_solve_and_candidate())

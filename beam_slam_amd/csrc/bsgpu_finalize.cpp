@@ -13,6 +13,11 @@ int band_part_forced() {
   return e ? atoi(e) : 0;
 }
 
+int band_uneven_percent() {
+  const char* e = getenv("BSGPU_BAND_UNEVEN");   // (read at every finalize, like BSGPU_BAND_PART)
+  return e ? atoi(e) : 0;
+}
+
 namespace {
 void eigen_quat_to_rot(const double* q, double* R) {
   const double tx = 2 * q[1], ty = 2 * q[2], tz = 2 * q[3];

@@ -328,7 +328,7 @@ void launch_final_reduce_batch(hipStream_t s, const BatchArgTable& t, const Batc
 void batchargs_copy(BatchArgTable& t, const double* src, double* dst, int64_t n);
 void launch_copy_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n);
 void batchargs_chol_fused(BatchArgTable& t, double* S, double* Lp, int ld, const FusedTask* tasks_dev, int n_tasks, const int* tile_tot_dev, const int* nreal_dev,
-                          double* Vinv, double* scal, int* sync_dev, double* Winv, int rhs_rows, const LmDiag& diag, const GradNormRide& gn);
+                          double* Vinv, double* scal, int* sync_dev, double* Winv, int rhs_rows, const LmDiag& diag, const GradNormRide& gn, bool diag_tasks_in_list);
 void launch_chol_fused_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n);
 // ... the pose-only family (k_small.hip, k_misc.hip): lidar-inertial windows, dense-path pose graphs, the pose-only factors of any window
 struct AsmGroup;
@@ -409,7 +409,8 @@ struct PanelDesc;
 struct FusedTask;
 void launch_chol_fused(hipStream_t s, double* S, double* Lp, int ld, const FusedTask* tasks_dev, int n_tasks, const int* tile_tot_dev, const int* nreal_dev,
                        double* Vinv, double* scal, int* sync_dev, double* Winv, int rhs_rows /* rows of the rhs tile in use; <= 0: all 64 */,
-                       const LmDiag& diag = LmDiag(), const GradNormRide& gn = GradNormRide());
+                       const LmDiag& diag = LmDiag(), const GradNormRide& gn = GradNormRide(),
+                       bool diag_tasks_in_list = false /* the list has the LM-diagonal tasks of its diagonal tiles (DensePlan::ftasks, not ftasks_plain / _bulk) */);
 void launch_chol_potrf_tiles(hipStream_t s, double* S, double* Lp, int ld, const int* tiles_dev, int n_tiles, const int* nreal_dev,
                              double* Vinv, double* scal);
 void launch_chol_panel_step(hipStream_t s, double* S, double* Lp, int ld, const PanelDesc* descs_dev, int n_panels, int max_rows,

@@ -377,7 +377,7 @@ void dense_factor(hipStream_t s, const DensePlan& P, const DenseDev& D, double* 
   if (D.ftasks && D.fsync && D.tile_tot && D.Winv) {   // the whole factorisation in one launch
     const bool plain = !D.diag.hdiag && D.gn.nb == 0 && D.ftasks_plain && D.tile_tot_plain;   // (nothing to carry: the list without those tasks)
     launch_chol_fused(s, S, D.Lp, ld, plain ? D.ftasks_plain : D.ftasks, plain ? D.n_ftasks_plain : (int)P.ftasks.size(), plain ? D.tile_tot_plain : D.tile_tot, D.nreal,
-                      D.Vinv, scal, D.fsync, D.Winv, D.rhs_rows, D.diag, D.gn);
+                      D.Vinv, scal, D.fsync, D.Winv, D.rhs_rows, D.diag, D.gn, /*diag_tasks_in_list=*/!plain && P.diag_tasks);
     return;
   }
   for (int st = 0; st < P.n_steps(); ++st) {

@@ -631,6 +631,7 @@ BSG_DEV void solve_ext_strip(const double* sX, double* sE, const double* sL16, c
   __builtin_amdgcn_wave_barrier();
   store_d(rows, kExtPitch, lane, x);
 }
+BSG_DEV bool diag_tile_of(const FusedTask& tk) { return tk.ti == tk.tj; }
 struct FusedCtx {
   double *S, *Lp, *Vinv, *scal;
   double* Winv;   // per tile: the full inverse of its factor: its diagonal 16x16 blocks are what the tasks' triangular solves multiply by,
@@ -645,6 +646,8 @@ struct FusedCtx {
             // serialised at the memory side — measured on the PCG slots, k_pcg.hip — and the queue head / exit counter take ~2 000 atomics)
   long long deadline;
   long long* probe_ts;
+  int no_turn;      // updates add their products with FP64 atomics as soon as they have them, in no particular order (1: a diagonal tile's LM-diagonal task is in
+                    // the list and goes first, 2: no such task); 0: every update waits for its turn on the tile and rewrites it (bit-reproducible factor)
 };
 // One UPDATE task of the fused factorisation (dense_plan.h FusedTask); returns false when a wait was aborted (wave-uniform).
 // 512 threads: waves 0-3 solve the strips of X_i, waves 4-7 those of X_j at the same time; the rank-64 update is two 16x16 blocks
@@ -683,6 +686,12 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
   const int k = tk.k, ti = tk.ti, tj = tk.tj;
   const bool diag = ti == tj;
   const bool do_update = tk.need_c >= 0;
+  // NO TURNS (round 6): the turn on a tile was a read-modify-write behind every earlier updater of the tile — 2-4 us each, one after the other, and where the
+  // last panels of two children meet in a separator's tile (the critical path) the chunks waited for two or three of them (BSGPU_CHOL_PROBE: 8 and 12 us on C2's
+  // first two levels).  Every update now ADDS (agent-scope FP64 atomics, as the K-chunks and the assembly do) the moment its product exists; only the
+  // LM-diagonal task of a diagonal tile, which rewrites the tile, still goes first.  The tile's counter counts the updates as before.
+  const int no_turn = __builtin_amdgcn_readfirstlane(C.no_turn);
+  const int need_c = !do_update ? -1 : no_turn == 0 ? tk.need_c : (no_turn == 1 && diag_tile_of(tk) ? (tk.need_c < 1 ? tk.need_c : 1) : 0);
   const bool solve_i = !(tk.flags & kFusedXiLp);
   const bool solve_j = !diag && !(tk.flags & (kFusedXjLp | kFusedXjChain));
   const bool need_L = solve_i || solve_j;
@@ -709,7 +718,7 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
     s_ctl[1] = ok ? 1 : 0;
     // ... and the C tile, if it is already this task's turn on it (on the critical path it is: the tile's earlier updaters are
     // panels that finished long ago): its values wait in registers through the solves, and the product accumulates onto them
-    s_ctl[3] = (do_update && (tk.need_c == 0 || (ld_flag(&upd[(ti * N + tj) * fs]) & 0xffff) >= tk.need_c)) ? 1 : 0;
+    s_ctl[3] = (do_update && !no_turn && (tk.need_c == 0 || (ld_flag(&upd[(ti * N + tj) * fs]) & 0xffff) >= tk.need_c)) ? 1 : 0;
   }
   __syncthreads();
   const bool c_pre = __builtin_amdgcn_readfirstlane(s_ctl[3]) != 0;
@@ -825,7 +834,7 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
 #pragma unroll
         for (int u = 0; u < TPW; ++u) acc[u] = cpre[u];
       }
-    } else {
+    } else if (!no_turn) {
       if (tid == 0) s_ctl[3] = ((ld_flag(&upd[(ti * N + tj) * fs]) & 0xffff) >= tk.need_c) ? 1 : 0;
       __syncthreads();
       c_early = __builtin_amdgcn_readfirstlane(s_ctl[3]) != 0;
@@ -848,6 +857,22 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
           acc[u] = mfma_abt<16>(acc[u], sEi + (16 * rs) * kExtPitch, kExtPitch, Ej + (16 * (tt0 + u)) * kExtPitch, kExtPitch, -1.0, lane);
       }
     }
+    if (no_turn) {
+      if (need_c > 0) {   // (a diagonal tile: its LM-diagonal task rewrites it — long done by the time any product exists)
+        if (tid == 0) s_ctl[1] = wait_count(&upd[(ti * N + tj) * fs], need_c, abort_w, deadline) ? 1 : 0;
+        __syncthreads();
+        if (__builtin_amdgcn_readfirstlane(s_ctl[1]) == 0) return false;
+      }
+      stamp(5);
+      if (strip_on) {
+        double* const Sg = S + (size_t)(ri + 16 * rs + crow) * ld + rj + 16 * tt0 + ccol;
+#pragma unroll
+        for (int u = 0; u < TPW; ++u)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg)
+            (void)__hip_atomic_fetch_add(Sg + (size_t)(4 * reg) * ld + 16 * u, acc[u][reg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
     if (!c_early) {
       // this task's turn on the tile: every earlier update of it has been published
       if (tid == 0) s_ctl[1] = wait_count(&upd[(ti * N + tj) * fs], tk.need_c, abort_w, deadline) ? 1 : 0;
@@ -868,6 +893,7 @@ BSG_DEV bool chol_fused_update(const FusedCtx& C, int t, const FusedTask& tk, do
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg)
           st8_sc1(rS_i, (unsigned)(((size_t)(16 * rs + crow + 4 * reg) * ld + rj + 16 * (tt0 + u) + ccol) * sizeof(double)), acc[u][reg]);
+    }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -971,10 +997,12 @@ BSG_DEV bool chol_fused_split(const FusedCtx& C, int t, const FusedTask& tk, dou
     if (!diag) vEj = ld16_sc1(rS_j, (unsigned)(((size_t)er * ld + c0 + NB + ec2) * sizeof(double)));
   }
   __syncthreads();   // (s_ctl[1] is rewritten below)
-  if (tid == 0) s_ctl[1] = wait_count(&potrf_done[(ext_chunk ? te : k) * fs], 1, abort_w, deadline) ? 1 : 0;   // (a chain sets its tiles' flags in order)
+  // (a chain sets its tiles' flags in order.  The appendix chunk too starts with tile k's flag: W and L(k + 1, k) are out with it, and all of
+  //  its work but one 16-wide product — see below — needs nothing of the appendix's own factor, which is out a step of the chain later)
+  if (tid == 0) s_ctl[1] = wait_count(&potrf_done[k * fs], 1, abort_w, deadline) ? 1 : 0;
   __syncthreads();
   if (__builtin_amdgcn_readfirstlane(s_ctl[1]) == 0) return false;
-  stamp(2);
+  if (!ext_chunk) stamp(2);
   if (!ext_chunk) {
     // rows 16 p .. 16 p + 15 of W: one 16-byte piece per thread
     vWc = ld16_sc1(rW, (unsigned)(((size_t)k * 4096 + (size_t)(16 * p + (tid >> 5)) * 64 + (tid & 31) * 2) * sizeof(double)));
@@ -986,7 +1014,6 @@ BSG_DEV bool chol_fused_split(const FusedCtx& C, int t, const FusedTask& tk, dou
     }
     const __amdgpu_buffer_rsrc_t rL_e = tile_rows(Lp, te * NB);
     vL16 = ld16_sc1(rL_e, (unsigned)(((size_t)(tid >> 5) * ld + c0 + (tid & 31) * 2) * sizeof(double)));
-    if (tid < 128) vW16 = ld16_sc1(rW, (unsigned)(((size_t)te * 4096 + (size_t)er * 64 + ec2) * sizeof(double)));
   }
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
@@ -1001,10 +1028,9 @@ BSG_DEV bool chol_fused_split(const FusedCtx& C, int t, const FusedTask& tk, dou
     *reinterpret_cast<double2*>(&sEi[er * kExtPitch + ec2]) = vEi;
     if (!diag) *reinterpret_cast<double2*>(&sEj[er * kExtPitch + ec2]) = vEj;
     *reinterpret_cast<double2*>(&sL16[(tid >> 5) * LDT + (tid & 31) * 2]) = vL16;
-    if (tid < 128) *reinterpret_cast<double2*>(&sW16[er * kExtPitch + ec2]) = vW16;
   }
   __syncthreads();
-  stamp(3);
+  if (!ext_chunk) stamp(3);
   if (!ext_chunk) {
     // (waves 0-3: the strips of the chunk of X_i; waves 4-7: those of X_j, at the same time)
     if (wave < 4 || !diag) {
@@ -1017,28 +1043,41 @@ BSG_DEV bool chol_fused_split(const FusedCtx& C, int t, const FusedTask& tk, dou
     }
     __syncthreads();
   } else {
-    // M = (W16 L16) W, block column c by wave c: T = W16 L16(:, 16 c' ..) for c' >= c is needed ... formed in two steps through LDS:
-    // first T = W16 L16 (every wave one block column), then M(:, 16 c ..) = sum_{m >= 16 c} T(:, m) W(m, 16 c ..)   (W lower triangular)
-    double4_t tb = double4_t{0.0, 0.0, 0.0, 0.0};
-    if (wave < 4) tb = mfma_ab_rt(tb, sW16, kExtPitch, sL16, LDT, 16 * wave, 0, 16, lane);
+    // X_e = E W16^T - A M^T with M = W16 L16 W  ==  (E - A P^T) W16^T with P = L16 W (16 x 64).  P and Y = E - A P^T need the FIRST tile of the
+    // chain only (W = L_kk^-1 and L16 = rows 0..15 of L(k + 1, k) leave the chain with tile k's flag): they are formed while the chain runs its
+    // last 16-pivot step, and what follows the chain's end is one load of W16 (2 KB) and one 16-wide product per strip — the appendix chunk was
+    // the last of its panel's chunks by 4 us on every level of the critical path (BSGPU_CHOL_PROBE, round 6: its two dependent 16 x 64 products
+    // and the strips behind them all came after the flag of the appendix).
+    // P(:, 16 c ..) = sum_{m >= 16 c} L16(:, m) W(m, 16 c ..)   (W lower triangular), block column c by wave c
+    double4_t pb = double4_t{0.0, 0.0, 0.0, 0.0};
+    if (wave < 4) pb = mfma_ab_rt(pb, sL16, LDT, sL, LDT, 16 * wave, 16 * wave, 64, lane);
     __syncthreads();
-    if (wave < 4) store_d(sL16 + 16 * wave, LDT, lane, tb);   // T over L16 (16 x 64, pitch LDT)
+    if (wave < 4) store_d(sL16 + 16 * wave, LDT, lane, pb);   // P over L16 (16 x 64, pitch LDT)
     __syncthreads();
-    double4_t mb = double4_t{0.0, 0.0, 0.0, 0.0};
-    if (wave < 4) mb = mfma_ab_rt(mb, sL16, LDT, sL, LDT, 16 * wave, 16 * wave, 64, lane);
-    __syncthreads();
-    if (wave < 4) store_d(sL16 + 16 * wave, LDT, lane, mb);   // M over T
-    __syncthreads();
-    // X_e strips = E W16^T - A M^T
-    if (wave < 4 || !diag) {
+    if (wave < 4 || !diag) {   // Y strips = E - A P^T, in place
       const double* A = wave < 4 ? sXi : sXj;
       double* E = wave < 4 ? sEi : sEj;
       const int strip = wave & 3;
-      double4_t x = double4_t{0.0, 0.0, 0.0, 0.0};
-      x = mfma_abt_rt(x, E + (16 * strip) * kExtPitch, kExtPitch, sW16, kExtPitch, 1.0, 16, lane);
-      x = mfma_abt_rt(x, A + (16 * strip) * LDT, LDT, sL16, LDT, -1.0, 64, lane);
+      double4_t y = load_d(E + (16 * strip) * kExtPitch, kExtPitch, lane);
+      y = mfma_abt_rt(y, A + (16 * strip) * LDT, LDT, sL16, LDT, -1.0, 64, lane);
       __builtin_amdgcn_wave_barrier();
-      store_d(E + (16 * strip) * kExtPitch, kExtPitch, lane, x);
+      store_d(E + (16 * strip) * kExtPitch, kExtPitch, lane, y);
+    }
+    // ... and now the appendix's own factor: its 16 x 16 inverse
+    if (tid == 0) s_ctl[1] = wait_count(&potrf_done[te * fs], 1, abort_w, deadline) ? 1 : 0;
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane(s_ctl[1]) == 0) return false;
+    stamp(2);
+    if (tid < 128) vW16 = ld16_sc1(rW, (unsigned)(((size_t)te * 4096 + (size_t)er * 64 + ec2) * sizeof(double)));
+    if (tid < 128) *reinterpret_cast<double2*>(&sW16[er * kExtPitch + ec2]) = vW16;
+    __syncthreads();
+    stamp(3);
+    if (wave < 4 || !diag) {   // X_e strips = Y W16^T
+      double* E = (wave < 4 ? sEi : sEj) + (16 * (wave & 3)) * kExtPitch;
+      double4_t x = double4_t{0.0, 0.0, 0.0, 0.0};
+      x = mfma_abt_rt(x, E, kExtPitch, sW16, kExtPitch, 1.0, 16, lane);
+      __builtin_amdgcn_wave_barrier();
+      store_d(E, kExtPitch, lane, x);
     }
     __syncthreads();
   }
@@ -1063,8 +1102,11 @@ BSG_DEV bool chol_fused_split(const FusedCtx& C, int t, const FusedTask& tk, dou
     if (!(diag && tt0 + u > rs))   // (blocks above the diagonal of a diagonal tile: the chain never reads them)
       acc[u] = mfma_abt_rt(acc[u], sEi + (16 * rs) * kExtPitch, kExtPitch, Ej + (16 * (tt0 + u)) * kExtPitch, kExtPitch, -1.0, 16, lane);
   }
-  // the chunks' turn: every earlier update of the tile has been published (on the critical path: long ago)
-  if (tid == 0) s_ctl[1] = wait_count(&upd[(ti * N + tj) * fs], tk.need_c, abort_w, deadline) ? 1 : 0;
+  // the chunks' turn: every earlier update of the tile has been published (on the critical path: long ago) — with no turns (chol_fused_update) only
+  // a diagonal tile's LM-diagonal task, which rewrites the tile
+  const int no_turn = __builtin_amdgcn_readfirstlane(C.no_turn);
+  const int need_c = no_turn == 0 ? tk.need_c : (no_turn == 1 && diag ? (tk.need_c < 1 ? tk.need_c : 1) : 0);
+  if (tid == 0) s_ctl[1] = wait_count(&upd[(ti * N + tj) * fs], need_c, abort_w, deadline) ? 1 : 0;
   __syncthreads();
   if (__builtin_amdgcn_readfirstlane(s_ctl[1]) == 0) return false;
   stamp(5);
@@ -1136,7 +1178,7 @@ __device__ __forceinline__ void chol_fused_kernel_body(const int bsg_bx, const i
   int* head = sync; int* abort_w = sync + fs; int* exited = sync + 2 * fs;   // (layout: [head | abort | exited | potrf_done (N) | update counts (N x N)] x fs ints)
   FusedCtx C;
   C.S = S; C.Lp = Lp; C.Vinv = Vinv; C.scal = scal; C.tasks = tasks; C.tile_tot = tile_tot; C.nreal = nreal; C.ld = ld; C.n_vinv_tiles = N - 1;
-  C.Winv = Winv; C.rhs_strips = rhs_strips;
+  C.Winv = Winv; C.rhs_strips = rhs_strips & 0xff; C.no_turn = (rhs_strips >> 8) & 3;   // (the launch's update mode rides in the argument's second byte: fused_update_mode())
   C.abort_w = abort_w; C.potrf_done = sync + 3 * fs; C.upd = sync + (3 + N) * fs; C.fs = fs;
   C.deadline = (long long)wall_clock64() + kFusedTimeoutTicks + 20LL * n_tasks;   // (+ 0.2 us per task: a dense 30 000-dimensional factorisation is 17 M tasks and half a second)
   C.probe_ts = probe_ts;
@@ -1252,9 +1294,14 @@ int fused_sync_stride() {
   return 16;
 }
 
+// how the updates of a launch reach their tiles (FusedCtx::no_turn): 0 turns (BSGPU_CHOL_NOTURN=0), 1 atomics behind a diagonal tile's LM-diagonal task, 2 atomics
+static int fused_update_mode(bool diag_tasks_in_list) {
+  static const bool turns = getenv("BSGPU_CHOL_NOTURN") && atoi(getenv("BSGPU_CHOL_NOTURN")) == 0;
+  return turns ? 0 : diag_tasks_in_list ? 1 : 2;
+}
 void launch_chol_fused(hipStream_t s, double* S, double* Lp, int ld, const FusedTask* tasks_dev, int n_tasks, const int* tile_tot_dev, const int* nreal_dev,
-                       double* Vinv, double* scal, int* sync_dev, double* Winv, int rhs_rows, const LmDiag& diag, const GradNormRide& gn) {
-  const int rhs_strips = rhs_rows <= 0 ? 4 : std::min(4, (rhs_rows + 15) / 16);
+                       double* Vinv, double* scal, int* sync_dev, double* Winv, int rhs_rows, const LmDiag& diag, const GradNormRide& gn, bool diag_tasks_in_list) {
+  const int rhs_strips = (rhs_rows <= 0 ? 4 : std::min(4, (rhs_rows + 15) / 16)) | (fused_update_mode(diag_tasks_in_list) << 8);
   if (n_tasks <= 0) return;
   const int grid = n_tasks;   // one workgroup per task (about 100 KB of LDS each: one per CU is resident, the rest queue behind them)
   // BSGPU_CHOL_PROBE=<file>: the 20th factorisation of the process runs the stamped variant and dumps, per task, the wall-clock
@@ -1928,11 +1975,11 @@ void launch_chol_backsolve_update(hipStream_t s, const double* Lp, int ld, const
 // ---- the factorisation and the back-substitution of several windows in one launch each (bsgpu_batch.cpp): every window keeps its own
 // task list, ticket and counters — a workgroup of window w takes window w's next ticket
 void batchargs_chol_fused(BatchArgTable& t, double* S, double* Lp, int ld, const FusedTask* tasks_dev, int n_tasks, const int* tile_tot_dev, const int* nreal_dev,
-                          double* Vinv, double* scal, int* sync_dev, double* Winv, int rhs_rows, const LmDiag& diag, const GradNormRide& gn) {
+                          double* Vinv, double* scal, int* sync_dev, double* Winv, int rhs_rows, const LmDiag& diag, const GradNormRide& gn, bool diag_tasks_in_list) {
   chol_fused_kernel_Args a;
   a.bsg_grid = n_tasks;
   a.S = S; a.Lp = Lp; a.ld = ld; a.tasks = tasks_dev; a.n_tasks = n_tasks; a.tile_tot = tile_tot_dev; a.nreal = nreal_dev; a.Vinv = Vinv; a.scal = scal;
-  a.sync = sync_dev; a.Winv = Winv; a.fs = fused_sync_stride(); a.rhs_strips = rhs_rows <= 0 ? 4 : std::min(4, (rhs_rows + 15) / 16); a.probe_ts = nullptr;
+  a.sync = sync_dev; a.Winv = Winv; a.fs = fused_sync_stride(); a.rhs_strips = (rhs_rows <= 0 ? 4 : std::min(4, (rhs_rows + 15) / 16)) | (fused_update_mode(diag_tasks_in_list) << 8); a.probe_ts = nullptr;
   a.diag = diag; a.gn = gn;
   t.push(a);
   t.lds = kFusedLds;

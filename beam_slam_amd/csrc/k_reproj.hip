@@ -89,7 +89,6 @@ void launch_reproj_errors(hipStream_t s, const Visual& v, const SmallGroup& dens
 // Jacobi scaling (Ceres: s = 1/(1+sqrt(H_jj)) from iteration 0) and the LM diagonal are folded into
 // lambda_j = clamp(s_j^2 H_jj, lo, hi) / (radius s_j^2) on the unscaled system.
 // ---------------------------------------------------------------------------------------------------
-template <bool STASH = false>
 __device__ __forceinline__ void landmark_kernel_body(const int bsg_bx, const int bsg_gx, int n_lm, const int* __restrict__ lm_start, const double* __restrict__ JB, const double2* __restrict__ r, int n_pose, const double* __restrict__ radius_ptr, int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* __restrict__ scale, double* __restrict__ dcl, double* __restrict__ grad, double* __restrict__ Linv_out, double* __restrict__ z_out, double* __restrict__ CR, int lm_blocks, ZeroStep zs, double radius_val) {
   if (bsg_bx >= lm_blocks) {
     // the step's clearing (tiles of S the assembly writes, pose gradient, diag(J^T J), the step's scalars, the radius slot) as extra
@@ -118,17 +117,11 @@ __device__ __forceinline__ void landmark_kernel_body(const int bsg_bx, const int
   int beg = 0, end = 0;
   if (valid) { beg = lm_start[l]; end = lm_start[l + 1]; }
   double h00 = 0, h01 = 0, h02 = 0, h11 = 0, h12 = 0, h22 = 0, b0 = 0, b1 = 0, b2 = 0;
-  // A lane's FIRST row (the only one for a landmark of up to eight observations) waits in LDS for the second pass: with every compute unit
-  // full of these workgroups the rows of all of them (16 KB each) and the C rows they write do not stay in the 4 MB L2 of an XCD, and the
-  // second pass fetched them again from the Infinity Cache — FETCH_SIZE said 2 x 25.6 MB for a 25.6 MB stream (scripts/pmc_calib.sh has the
-  // pattern with and without).  Registers instead of LDS cost occupancy (96 VGPRs: 24.4 -> 26.6 us).
-  __shared__ double2 s_keep[STASH ? 4 * 256 : 1];
   for (int f = beg + sub; f < end; f += 8) {
     // (16-byte pieces: the 48-byte row is 16-byte aligned; a lane's six 8-byte loads were six look-ups of the same lines)
     const double2* Jf2 = reinterpret_cast<const double2*>(JB + (size_t)f * 6);
     const double2 rf = r[f];
     const double2 ja = Jf2[0], jb = Jf2[1], jc = Jf2[2];
-    if (STASH && f == beg + sub) { s_keep[threadIdx.x] = ja; s_keep[256 + threadIdx.x] = jb; s_keep[512 + threadIdx.x] = jc; s_keep[768 + threadIdx.x] = rf; }
     const double x0 = ja.x, x1 = ja.y, x2 = jb.x, y0 = jb.y, y1 = jc.x, y2 = jc.y;
     h00 += x0 * x0 + y0 * y0; h01 += x0 * x1 + y0 * y1; h02 += x0 * x2 + y0 * y2;
     h11 += x1 * x1 + y1 * y1; h12 += x1 * x2 + y1 * y2; h22 += x2 * x2 + y2 * y2;
@@ -174,11 +167,10 @@ __device__ __forceinline__ void landmark_kernel_body(const int bsg_bx, const int
   }
   for (int f = beg + sub; f < end; f += 8) {
     const double2* Jf2 = reinterpret_cast<const double2*>(JB + (size_t)f * 6);
-    double2 rf, ja, jb, jc;
-    if (STASH && f == beg + sub) { ja = s_keep[threadIdx.x]; jb = s_keep[256 + threadIdx.x]; jc = s_keep[512 + threadIdx.x]; rf = s_keep[768 + threadIdx.x]; }   // (the lane's own words: no barrier)
-    else { rf = r[f]; ja = Jf2[0]; jb = Jf2[1]; jc = Jf2[2]; }
+    const double2 rf = r[f];
     double2* o2 = reinterpret_cast<double2*>(CR + (size_t)f * 8);
     // C[k][j] = sum_i B[k][i] Linv[j][i]
+    const double2 ja = Jf2[0], jb = Jf2[1], jc = Jf2[2];
     const double x0 = ja.x, x1 = ja.y, x2 = jb.x, y0 = jb.y, y1 = jc.x, y2 = jc.y;
     const double c00 = x0 * i00, c01 = x0 * i10 + x1 * i11, c02 = x0 * i20 + x1 * i21 + x2 * i22;
     const double c10 = y0 * i00, c11 = y0 * i10 + y1 * i11, c12 = y0 * i20 + y1 * i21 + y2 * i22;
@@ -188,13 +180,6 @@ __device__ __forceinline__ void landmark_kernel_body(const int bsg_bx, const int
 }
 __global__ __launch_bounds__(256) void landmark_kernel(int n_lm, const int* __restrict__ lm_start, const double* __restrict__ JB, const double2* __restrict__ r, int n_pose, const double* __restrict__ radius_ptr, int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* __restrict__ scale, double* __restrict__ dcl, double* __restrict__ grad, double* __restrict__ Linv_out, double* __restrict__ z_out, double* __restrict__ CR, int lm_blocks, ZeroStep zs, double radius_val) {
   landmark_kernel_body((int)blockIdx.x, (int)gridDim.x, n_lm, lm_start, JB, r, n_pose, radius_ptr, compute_scale, compute_dcl, jacobi, lm_lo, lm_hi, scale, dcl, grad, Linv_out, z_out, CR, lm_blocks, zs, radius_val);
-}
-// (BSGPU_LM_STASH=1 / 2: the first row of every lane kept in LDS for the second pass, at the registers the compiler asks for / at eight waves per SIMD)
-__global__ __launch_bounds__(256) void landmark_kernel_stash(int n_lm, const int* __restrict__ lm_start, const double* __restrict__ JB, const double2* __restrict__ r, int n_pose, const double* __restrict__ radius_ptr, int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* __restrict__ scale, double* __restrict__ dcl, double* __restrict__ grad, double* __restrict__ Linv_out, double* __restrict__ z_out, double* __restrict__ CR, int lm_blocks, ZeroStep zs, double radius_val) {
-  landmark_kernel_body<true>((int)blockIdx.x, (int)gridDim.x, n_lm, lm_start, JB, r, n_pose, radius_ptr, compute_scale, compute_dcl, jacobi, lm_lo, lm_hi, scale, dcl, grad, Linv_out, z_out, CR, lm_blocks, zs, radius_val);
-}
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void landmark_kernel_stash8(int n_lm, const int* __restrict__ lm_start, const double* __restrict__ JB, const double2* __restrict__ r, int n_pose, const double* __restrict__ radius_ptr, int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* __restrict__ scale, double* __restrict__ dcl, double* __restrict__ grad, double* __restrict__ Linv_out, double* __restrict__ z_out, double* __restrict__ CR, int lm_blocks, ZeroStep zs, double radius_val) {
-  landmark_kernel_body<true>((int)blockIdx.x, (int)gridDim.x, n_lm, lm_start, JB, r, n_pose, radius_ptr, compute_scale, compute_dcl, jacobi, lm_lo, lm_hi, scale, dcl, grad, Linv_out, z_out, CR, lm_blocks, zs, radius_val);
 }
 // ... with the end-of-step reduction of the step BEFORE as its first workgroups: the landmark launch of an assembly issued ahead of the host's
 // decision (bsgpu_solve.cpp enqueue_step) follows the evaluation of the candidate with Jacobians, which has left the candidate's cost
@@ -320,13 +305,10 @@ void launch_landmark(hipStream_t s, const Visual& v, int n_pose, const double* r
       hipLaunchKernelGGL(landmark_reduce_kernel, dim3(red->n_slots + 1 + grid + zero_blocks), dim3(256), 0, s, *red, v.n_lm, v.lm_start, v.JB, v.r, n_pose, radius_ptr,
                          compute_scale, compute_dcl, jacobi, lm_lo, lm_hi, scale, dcl, grad, v.Linv, v.z, v.CR, grid, zero ? *zero : ZeroStep(),
                          radius_val);
-    else {
-    static const int stash = getenv("BSGPU_LM_STASH") ? atoi(getenv("BSGPU_LM_STASH")) : 0;
-    auto kern = stash == 1 ? landmark_kernel_stash : stash == 2 ? landmark_kernel_stash8 : landmark_kernel;
-    hipLaunchKernelGGL(kern, dim3(grid + zero_blocks), dim3(256), 0, s, v.n_lm, v.lm_start, v.JB, v.r, n_pose, radius_ptr,
+    else
+    hipLaunchKernelGGL(landmark_kernel, dim3(grid + zero_blocks), dim3(256), 0, s, v.n_lm, v.lm_start, v.JB, v.r, n_pose, radius_ptr,
                        compute_scale, compute_dcl, jacobi, lm_lo, lm_hi, scale, dcl, grad, v.Linv, v.z, v.CR, grid, zero ? *zero : ZeroStep(),
                        radius_val);
-    }
   }
   if (v.n > v.n_elim) {
     const int grid = (v.n - v.n_elim + 255) / 256;

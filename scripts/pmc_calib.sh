@@ -4,6 +4,7 @@
 set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT=${1:-$ROOT/gpurun_out/pmc_calib.csv}
+case "$OUT" in /*) ;; *) OUT="$ROOT/$OUT";; esac
 BIN=$ROOT/scripts/pmc_calib.bin
 [ -x "$BIN" ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 "$ROOT/scripts/pmc_calib.hip" -o "$BIN"
 cd /tmp && export TMPDIR=/tmp

@@ -108,6 +108,25 @@ def test_band_units_of_several_parts(oracle_cls, gpu_solver_cls, monkeypatch):
         assert np.allclose([i[0] for i in it], [i[0] for i in it_ref], rtol=1e-10) and np.abs(x - x_ref).max() < 1e-8
 
 
+@pytest.mark.parametrize("flatten", ["host", "device"])
+def test_band_units_long_and_short(oracle_cls, gpu_solver_cls, monkeypatch, flatten):
+    """BSGPU_BAND_UNEVEN: a first camera pose's landmarks as a long unit (the widest tracks) and a short one, the short units behind all the long
+    ones in the list (band_plan.h): the same system as with one unit per first camera pose, on both flattening paths, at several shares"""
+    monkeypatch.setenv("BSGPU_PAIRS_BAND", "1")
+    monkeypatch.setenv("BSGPU_FLATTEN", flatten)
+    monkeypatch.setenv("BSGPU_BAND_UNEVEN", "0")
+    pr = synthetic.vio_window(n_kf=14, n_lm=3000, seed=58, track_min=2, track_max=11)    # ~250 landmarks per first camera pose
+    s_ref, it_ref, x_ref = _run(pr, gpu_solver_cls)
+    o = oracle_cls(); pr.load(o)
+    opt = o.options_vio(); opt.max_num_iterations = 6; opt.max_solver_time_in_seconds = 0.0
+    o.solve(opt)
+    assert np.allclose([i.cost for i in o.iterations()], [i[0] for i in it_ref], rtol=1e-10)
+    for share in ("50", "67", "80", "99"):
+        monkeypatch.setenv("BSGPU_BAND_UNEVEN", share)
+        s, it, x = _run(pr, gpu_solver_cls)
+        assert np.allclose([i[0] for i in it], [i[0] for i in it_ref], rtol=1e-10) and np.abs(x - x_ref).max() < 1e-8
+
+
 def test_size_rule(gpu_solver_cls, monkeypatch):
     """by itself the library takes the band form from kBandMinFactors reprojection factors on: the same solve either way at a size above it"""
     monkeypatch.delenv("BSGPU_PAIRS_BAND", raising=False)
