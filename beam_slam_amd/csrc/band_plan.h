@@ -50,8 +50,6 @@ struct BandUnits {
 
 // landmarks per unit, at most (BSGPU_BAND_PART forces a value)
 int band_part_forced();
-// percent of a first camera pose's landmarks that go to its LONG unit (0: one unit, or equal parts of `part`): see band_units
-int band_uneven_percent();
 
 // cmin / mask per landmark (cmin < 0: not a band landmark).  One unit per first camera pose unless that leaves most of the device idle: a
 // unit ends with up to 6 400 atomic adds into S, whatever its size (two units per first camera pose on C2: 56 us against 50).
@@ -76,13 +74,6 @@ inline void band_units(int nl, const int* cmin, const int* mask, int ncp, BandUn
   if (part <= 0) part = n / 128 > 64 ? n / 128 : 64;
   // the pairs a mask couples, once per distinct (k0, mask): a window has a few masks per first camera pose
   std::vector<std::vector<unsigned>> seen(nc);
-  // UNEVEN units (round 6).  With one unit per first camera pose every unit is as long as the launch: C2's 188 units run side by side on 256 compute
-  // units, end together and then put their 1.2 M atomic adds to the memory side at the same moment (~80 G a second for the device: a third of the launch).
-  // A first camera pose's landmarks are dealt out as a LONG unit (the widest tracks, a whole number of sub-batches) and a SHORT one; all the long units
-  // come first in the list (= dispatch order), the short ones fill the compute units that are left and those the first short ones free: the same
-  // sub-batches on all 256 compute units, and the hand-overs of the short units go out under the long units' products.
-  const int uneven = band_part_forced() > 0 ? 0 : band_uneven_percent();
-  std::vector<int> short_lm, short_start, short_cam;   // the short units, appended behind the long ones
   int i = 0;
   while (i < n) {
     const int k0 = cmin[out.lm[i]];
@@ -98,35 +89,10 @@ inline void band_units(int nl, const int* cmin, const int* mask, int ncp, BandUn
       }
       ++j;
     }
-    if (uneven > 0 && j - i >= 4 * 32) {
-      int n_long = (int)(((int64_t)(j - i) * uneven / 100 + 16) / 32) * 32;   // (32 = the band kernel's sub-batch)
-      if (n_long < 32) n_long = 32;
-      if (n_long > j - i - 32) n_long = j - i - 32;
-      short_start.push_back((int)short_lm.size()); short_cam.push_back(k0);
-      short_lm.insert(short_lm.end(), out.lm.begin() + i + n_long, out.lm.begin() + j);
-      for (int q = i + n_long; q < j; ++q) out.lm[q] = -1;   // (moved behind the long units below)
-      out.unit_start.push_back(i); out.unit_cam.push_back(k0);
-      i = j;
-      continue;
-    }
     // (parts of equal size rather than full parts and a remainder)
     const int parts = (j - i + part - 1) / part;
     for (int p = 0; p < parts; ++p) { out.unit_start.push_back(i + (int)((int64_t)(j - i) * p / parts)); out.unit_cam.push_back(k0); }
     i = j;
-  }
-  if (!short_lm.empty()) {
-    // compact the long units (their short parts have left holes), then append the short ones
-    std::vector<int> lm2; lm2.reserve(n);
-    std::vector<int> start2; start2.reserve(out.unit_start.size() + short_start.size() + 1);
-    for (size_t u = 0; u < out.unit_start.size(); ++u) {
-      const int b = out.unit_start[u], e = u + 1 < out.unit_start.size() ? out.unit_start[u + 1] : n;
-      start2.push_back((int)lm2.size());
-      for (int q = b; q < e; ++q) if (out.lm[q] >= 0) lm2.push_back(out.lm[q]);
-    }
-    const int off = (int)lm2.size();
-    for (size_t u = 0; u < short_start.size(); ++u) { start2.push_back(off + short_start[u]); out.unit_cam.push_back(short_cam[u]); }
-    lm2.insert(lm2.end(), short_lm.begin(), short_lm.end());
-    out.lm.swap(lm2); out.unit_start.swap(start2);
   }
   out.unit_start.push_back(n);
 }

@@ -13,11 +13,6 @@ int band_part_forced() {
   return e ? atoi(e) : 0;
 }
 
-int band_uneven_percent() {
-  const char* e = getenv("BSGPU_BAND_UNEVEN");   // (read at every finalize, like BSGPU_BAND_PART)
-  return e ? atoi(e) : 0;
-}
-
 namespace {
 void eigen_quat_to_rot(const double* q, double* R) {
   const double tx = 2 * q[1], ty = 2 * q[2], tz = 2 * q[3];
@@ -434,6 +429,7 @@ int finalize(bsgpu_ctx* c) {
     V.seg_ci = c->upload(seg_ci); V.seg_cj = c->upload(seg_cj); V.seg_start = c->upload(seg_start);
     V.ent_fa = c->upload(ent_fa); V.ent_fb = c->upload(ent_fb);
     V.band_lm = c->upload(b_lm); V.band_unit_start = c->upload(bu.unit_start); V.band_unit_cam = c->upload(bu.unit_cam);
+    V.band_lm_id = c->upload(bu.lm);
     // structural tile adjacency of the reduced system (natural 64-wide tiles) for the Cholesky plan
     const int T = (c->n_pose + 63) / 64;
     c->tile_adj.assign((size_t)T * T, 0);
@@ -515,6 +511,9 @@ int finalize(bsgpu_ctx* c) {
     V.cost_part_cand = c->alloc<double>(V.n_cost_part);
     V.mcc_part = c->alloc<double>(std::max(1, backsub_mcc_groups(V)));
     if (!V.J || !V.CR || !V.r) return fail(c, BSGPU_ERR_DEVICE, "out of device memory (visual tables)");
+    // (bsgpu_internal.h Visual::no_cr: every factor belongs to a band landmark)
+    const char* no_cr_env = getenv("BSGPU_NO_CR");
+    V.no_cr = !(no_cr_env && atoi(no_cr_env) == 0) && V.n_band_units > 0 && V.n_seg == 0 && V.n_ent == 0 && V.n == V.n_elim && V.band_lm_id != nullptr && V.Linv && V.z;
   }
   lap("visual upload + alloc");
   // ---- pose-only groups

@@ -133,6 +133,12 @@ struct Visual {
   // unit order: (first factor row, slot mask | span << 16 | observations << 24, observation index of slot j in nibble j of z | w << 32, 15 = none)
   int n_band_units = 0, n_band_lm = 0;
   int* band_unit_start = nullptr; int* band_unit_cam = nullptr; int4* band_lm = nullptr;
+  int* band_lm_id = nullptr;  // the landmark of every record of band_lm (the band kernel's look-up of Linv and z when no C rows are kept: no_cr)
+  // NO C ROWS (round 6).  landmark_kernel's second pass wrote C = B Linv^T and rho = r - C z per observation (64 B) for the pair phase and the
+  // back-substitution to read: 6.5 of its 22 us on C2 (measured with the pass taken out).  When EVERY landmark is a band landmark (no pair
+  // entries, no factors of constant landmarks) the two consumers form C and rho themselves from the B rows (48 B, which they have or read instead)
+  // and the landmark's Linv and z: lone solves pass CR = nullptr to the three launches; the batched launches keep the C rows.  BSGPU_NO_CR=0: never.
+  bool no_cr = false;
   // outputs
   double2* r = nullptr;       // n
   double* J = nullptr;        // robustified Jacobian, split by consumer: pose part n x 12 ([A row 0 (theta, t: 6) | A row 1]) ...

@@ -640,10 +640,14 @@ int profile_step(bsgpu_ctx* c, const bsgpu_options& o, int reps, double* ms_out,
     const double n = (double)c->vis.n, ne_ = (double)c->vis.n_elim, nl = (double)c->vis.n_lm, nent = (double)c->vis.n_ent;
     for (int p = 0; p < BSGPU_PHASE_NUM; ++p) work_out[p] = 0.0;
     work_out[BSGPU_PHASE_EVAL_REPROJ] = n * 200.0 + 8.0 * (double)c->h_x.size();      // bytes (bsgpu_reproj_jacobian_bytes)
-    work_out[BSGPU_PHASE_LANDMARK] = ne_ * (48.0 + 16.0 + 64.0) + nl * 72.0;          // landmark part of J + r in, CR out; Linv + z per landmark
-    work_out[BSGPU_PHASE_PAIRS] = ne_ * (96.0 + 64.0) + nent * 8.0;                   // every pose part of J and CR row once + the entry list
+    // landmark part of J + r in, CR out; per landmark Linv + z + gradient out, scale + LM diagonal in, its range; and the step's CLEARING, which
+    // rides in this launch: the tiles of S the assembly adds into (32 KB each), the pose gradient and diag(H)
+    // (Visual::no_cr: no C rows — 64 B per observation less written here and read by the back-substitution; the band kernel reads B, 48 B, instead, and Linv + z)
+    const double cr = c->vis.no_cr ? 0.0 : 64.0;
+    work_out[BSGPU_PHASE_LANDMARK] = ne_ * (48.0 + 16.0 + cr) + nl * (72.0 + 24.0 + 48.0 + 4.0) + 32768.0 * (double)c->n_touched + 16.0 * (double)c->n_pose;
+    work_out[BSGPU_PHASE_PAIRS] = ne_ * (96.0 + (c->vis.no_cr ? 48.0 : 64.0) + (c->vis.n_band_units > 0 ? 16.0 : 0.0)) + nent * 8.0 + (c->vis.no_cr ? nl * 72.0 : 0.0);   // every pose part of J and CR row once (the band form: r too) + the entry list
     work_out[BSGPU_PHASE_FACTOR] = c->plan.fused_flops;                               // FP64 flops of the planned factorisation
-    work_out[BSGPU_PHASE_BACKSUB] = n * (144.0 + 16.0) + ne_ * 64.0 + nl * 72.0;      // J, r, CR once; Linv + z per landmark
+    work_out[BSGPU_PHASE_BACKSUB] = n * (144.0 + 16.0) + ne_ * cr + nl * 72.0;        // J, r, CR once; Linv + z per landmark
     work_out[BSGPU_PHASE_CANDIDATE] = n * 40.0 + 3.0 * 8.0 * (double)c->h_x.size();   // candidate cost: 40 B / factor + the block update
   }
   // the timed steps moved the point: back to where the context was finalized

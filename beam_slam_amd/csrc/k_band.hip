@@ -57,16 +57,24 @@ BSG_DEV int4 band_fetch_rec(const int4* __restrict__ band_lm, int li, int end) {
 // l16 + 16 i of the landmark's A rows (6 per observation), of its C | rho rows (4 per observation), of its residuals (1 per observation).
 // Plain named locals and unconditional loads at clamped indices: a struct handed to helpers is an object in memory across the barriers' asm
 // (it lived in scratch: 176 bytes per lane), and arrays of loaded values under a lane condition went to scratch in round 3's band kernel.
-#define BSG_BAND_ISSUE(REC)                                                                                                   \
+// (NOCR — Visual::no_cr: the stage's C area takes the landmark's B rows, 3 pieces per observation, in pieces 0 .. 47, and the landmark's Linv (pieces
+//  48 .. 50) and z (the x halves of 51 .. 53) instead of the C | rho rows; LMID = the record's landmark)
+#define BSG_BAND_ISSUE(REC, LMID)                                                                                             \
   {                                                                                                                           \
     const int n_ = (int)((unsigned)(REC).y >> 24);                                                                            \
-    const int na_ = 6 * n_ - 1 > 0 ? 6 * n_ - 1 : 0, nc_ = 4 * n_ - 1 > 0 ? 4 * n_ - 1 : 0, nr_ = n_ - 1 > 0 ? n_ - 1 : 0;     \
+    const int cpo_ = NOCR ? 3 : 4;                                                                                            \
+    const int na_ = 6 * n_ - 1 > 0 ? 6 * n_ - 1 : 0, nc_ = cpo_ * n_ - 1 > 0 ? cpo_ * n_ - 1 : 0, nr_ = n_ - 1 > 0 ? n_ - 1 : 0; \
     const double2* Jf_ = J2 + (size_t)(REC).x * (kJAStride / 2);                                                              \
-    const double2* Cf_ = C2 + (size_t)(REC).x * 4;                                                                            \
+    const double2* Cf_ = C2 + (size_t)(REC).x * cpo_;                                                                         \
     const double2* rf_ = r + (size_t)(REC).x;                                                                                 \
     pa0 = Jf_[min(l16, na_)]; pa1 = Jf_[min(l16 + 16, na_)]; pa2 = Jf_[min(l16 + 32, na_)]; pa3 = Jf_[min(l16 + 48, na_)];     \
     pa4 = Jf_[min(l16 + 64, na_)];                                                                                            \
-    pc0 = Cf_[min(l16, nc_)]; pc1 = Cf_[min(l16 + 16, nc_)]; pc2 = Cf_[min(l16 + 32, nc_)]; pc3 = Cf_[min(l16 + 48, nc_)];     \
+    pc0 = Cf_[min(l16, nc_)]; pc1 = Cf_[min(l16 + 16, nc_)]; pc2 = Cf_[min(l16 + 32, nc_)];                                    \
+    if (NOCR) {                                                                                                               \
+      const double2 li_ = reinterpret_cast<const double2*>(Linv + (size_t)(LMID) * 6)[l16 < 3 ? l16 : 2];                      \
+      const double zz_ = z[(size_t)(LMID) * 3 + ((l16 >= 3 && l16 < 6) ? l16 - 3 : 0)];                                        \
+      pc3 = l16 < 3 ? li_ : double2{zz_, 0.0};                                                                                \
+    } else pc3 = Cf_[min(l16 + 48, nc_)];                                                                                     \
     pr0 = rf_[min(l16, nr_)];                                                                                                 \
     prec = (REC);                                                                                                             \
   }
@@ -116,7 +124,9 @@ BSG_DEV void band_multiply(const unsigned (&za)[kBandNT], const unsigned (&zb)[k
 #undef BSG_DSR
 }
 
-__device__ __forceinline__ void pairs_band_kernel_body(const int bsg_bx, const int bsg_gx, int n_units, const int* __restrict__ unit_start, const int* __restrict__ unit_cam, const int4* __restrict__ band_lm, int n_cam_pose, const double* __restrict__ J, const double2* __restrict__ r, const double* __restrict__ CR, const int* __restrict__ cp_tq, const int* __restrict__ cp_tp, double* __restrict__ S, int ld, int rhs_row, double* __restrict__ grad, double* __restrict__ hdiag, const int* __restrict__ perm, int grad_only, const SmallGroupSet& small, int n_small_units) {
+// NOCR: CR = the landmark parts of the Jacobian rows (Visual::JB, 48 B per observation), lm_id / Linv / z = the records' landmarks and their inverse factors
+template <bool NOCR = false>
+__device__ __forceinline__ void pairs_band_kernel_body(const int bsg_bx, const int bsg_gx, int n_units, const int* __restrict__ unit_start, const int* __restrict__ unit_cam, const int4* __restrict__ band_lm, int n_cam_pose, const double* __restrict__ J, const double2* __restrict__ r, const double* __restrict__ CR, const int* __restrict__ cp_tq, const int* __restrict__ cp_tp, double* __restrict__ S, int ld, int rhs_row, double* __restrict__ grad, double* __restrict__ hdiag, const int* __restrict__ perm, int grad_only, const SmallGroupSet& small, int n_small_units, const int* __restrict__ lm_id = nullptr, const double* __restrict__ Linv = nullptr, const double* __restrict__ z = nullptr) {
   extern __shared__ __attribute__((aligned(16))) double bsm[];
   const int tid = threadIdx.x;
   const int u = bsg_bx;
@@ -154,11 +164,14 @@ __device__ __forceinline__ void pairs_band_kernel_body(const int bsg_bx, const i
   const double2* C2 = reinterpret_cast<const double2*>(CR);
   double2 pa0, pa1, pa2, pa3, pa4, pc0, pc1, pc2, pc3, pr0;
   int4 prec;
+  auto fetch_id = [&](int li) { return NOCR ? lm_id[li < end ? li : end - 1] : 0; };
   {
     const int4 rec0 = band_fetch_rec(band_lm, beg + g, end);
-    BSG_BAND_ISSUE(rec0)
+    const int id0 = fetch_id(beg + g);
+    BSG_BAND_ISSUE(rec0, id0)
   }
   int4 rec_next = band_fetch_rec(band_lm, beg + kBandNL + g, end);
+  int id_next = fetch_id(beg + kBandNL + g);
   // FORM: this lane's camera-pose slot and landmark of a sub-batch
   const int slot = wave + kBandWaves * (lane / kBandNL), lmk = lane % kBandNL;
   const bool slot_ok = slot < kBandCams;
@@ -191,8 +204,9 @@ __device__ __forceinline__ void pairs_band_kernel_body(const int bsg_bx, const i
     BSG_BAND_STAGE()
     // the next sub-batch's rows are on their way while this one is formed and multiplied; its records came a round earlier.  (Unconditional:
     // past the unit's end the records say "no observations" and the requests fall on a row of its last landmark.)
-    BSG_BAND_ISSUE(rec_next)
+    BSG_BAND_ISSUE(rec_next, id_next)
     rec_next = band_fetch_rec(band_lm, base + 2 * kBandNL + g, end);
+    id_next = fetch_id(base + 2 * kBandNL + g);
     band_lds_sync();   // (the stage is complete; every wave is past the previous sub-batch's products)
     {
       const int4 rec = sRec[lmk];
@@ -203,14 +217,26 @@ __device__ __forceinline__ void pairs_band_kernel_body(const int bsg_bx, const i
       //  the stage may hold anything where no row was written — a product with zero would not do)
       const int oc = valid ? oi : 0;
       const double2* a = sA + lmk * kBandStA + 6 * oc;
-      const double2* c = sC + lmk * kBandStC + 4 * oc;
-      const double2 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5], c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+      const double2* c = sC + lmk * kBandStC + (NOCR ? 3 : 4) * oc;
+      const double2 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5], c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[NOCR ? 2 : 3];
       const double2 rr = sR[lmk * kBandStR + oc];
 #define BSG_SEL(x) (valid ? (x) : 0.0)
       const double A0[6] = {BSG_SEL(a0.x), BSG_SEL(a0.y), BSG_SEL(a1.x), BSG_SEL(a1.y), BSG_SEL(a2.x), BSG_SEL(a2.y)};
       const double A1[6] = {BSG_SEL(a3.x), BSG_SEL(a3.y), BSG_SEL(a4.x), BSG_SEL(a4.y), BSG_SEL(a5.x), BSG_SEL(a5.y)};
-      const double Ca[3] = {BSG_SEL(c0.x), BSG_SEL(c0.y), BSG_SEL(c1.x)}, Cb[3] = {BSG_SEL(c1.y), BSG_SEL(c2.x), BSG_SEL(c2.y)};
-      const double p0 = BSG_SEL(c3.x), p1 = BSG_SEL(c3.y), r0 = BSG_SEL(rr.x), r1 = BSG_SEL(rr.y);
+      double Ca[3] = {BSG_SEL(c0.x), BSG_SEL(c0.y), BSG_SEL(c1.x)}, Cb[3] = {BSG_SEL(c1.y), BSG_SEL(c2.x), BSG_SEL(c2.y)};
+      const double r0 = BSG_SEL(rr.x), r1 = BSG_SEL(rr.y);
+      double p0 = BSG_SEL(c3.x), p1 = BSG_SEL(c3.y);
+      if (NOCR) {
+        // what landmark_kernel's second pass wrote: C = B Linv^T (Linv lower triangular: i00 | i10 i11 | i20 i21 i22), rho = r - C z
+        const double2* lz = sC + lmk * kBandStC + 48;
+        const double2 l0 = lz[0], l1 = lz[1], l2 = lz[2];
+        const double z0 = lz[3].x, z1 = lz[4].x, z2 = lz[5].x;
+        const double x0 = Ca[0], x1 = Ca[1], x2 = Ca[2], y0 = Cb[0], y1 = Cb[1], y2 = Cb[2];
+        Ca[0] = x0 * l0.x; Ca[1] = x0 * l0.y + x1 * l1.x; Ca[2] = x0 * l1.y + x1 * l2.x + x2 * l2.y;
+        Cb[0] = y0 * l0.x; Cb[1] = y0 * l0.y + y1 * l1.x; Cb[2] = y0 * l1.y + y1 * l2.x + y2 * l2.y;
+        p0 = r0 - (Ca[0] * z0 + Ca[1] * z1 + Ca[2] * z2);
+        p1 = r1 - (Cb[0] * z0 + Cb[1] * z1 + Cb[2] * z2);
+      }
 #undef BSG_SEL
       if (slot_ok) {
 #pragma unroll
@@ -316,6 +342,10 @@ __device__ __forceinline__ void pairs_band_kernel_body(const int bsg_bx, const i
 __global__ __launch_bounds__(kBandThreads) void pairs_band_kernel(int n_units, const int* __restrict__ unit_start, const int* __restrict__ unit_cam, const int4* __restrict__ band_lm, int n_cam_pose, const double* __restrict__ J, const double2* __restrict__ r, const double* __restrict__ CR, const int* __restrict__ cp_tq, const int* __restrict__ cp_tp, double* __restrict__ S, int ld, int rhs_row, double* __restrict__ grad, double* __restrict__ hdiag, const int* __restrict__ perm, int grad_only, SmallGroupSet small, int n_small_units) {
   pairs_band_kernel_body((int)blockIdx.x, (int)gridDim.x, n_units, unit_start, unit_cam, band_lm, n_cam_pose, J, r, CR, cp_tq, cp_tp, S, ld, rhs_row, grad, hdiag, perm, grad_only, small, n_small_units);
 }
+// ... without C rows (Visual::no_cr): the landmark parts of the Jacobian rows instead, and the landmarks' Linv and z
+__global__ __launch_bounds__(kBandThreads) void pairs_band_nocr_kernel(int n_units, const int* __restrict__ unit_start, const int* __restrict__ unit_cam, const int4* __restrict__ band_lm, int n_cam_pose, const double* __restrict__ J, const double2* __restrict__ r, const double* __restrict__ JB, const int* __restrict__ cp_tq, const int* __restrict__ cp_tp, double* __restrict__ S, int ld, int rhs_row, double* __restrict__ grad, double* __restrict__ hdiag, const int* __restrict__ perm, int grad_only, SmallGroupSet small, int n_small_units, const int* __restrict__ lm_id, const double* __restrict__ Linv, const double* __restrict__ z) {
+  pairs_band_kernel_body<true>((int)blockIdx.x, (int)gridDim.x, n_units, unit_start, unit_cam, band_lm, n_cam_pose, J, r, JB, cp_tq, cp_tp, S, ld, rhs_row, grad, hdiag, perm, grad_only, small, n_small_units, lm_id, Linv, z);
+}
 // one launch over several windows (bsgpu_batch.cpp): blockIdx.y picks the window of list `bsg_list`, its arguments come from memory
 struct pairs_band_kernel_Args {
   int bsg_grid;
@@ -385,6 +415,7 @@ static int band_attr_state(int dev) {   // 1: available, -1: not
     bool ok = hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && max_lds >= (int)kBandLds;
     ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(pairs_band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBandLds) == hipSuccess;
     ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(pairs_band_kernel_batch), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBandLds) == hipSuccess;
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(pairs_band_nocr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBandLds) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); fprintf(stderr, "[bsgpu] device %d gives %d B of LDS per workgroup, the band kernel needs %d: pair-entry path\n", dev, max_lds, (int)kBandLds); }
     state[dev] = ok ? 1 : -1;
   }
@@ -404,6 +435,11 @@ void launch_pairs_band(hipStream_t s, const Visual& v, double* S, int ld, int rh
   SmallGroupSet none;
   none.n = 0;
   const int riders = small ? n_small_units : 0;
+  if (v.no_cr)
+    hipLaunchKernelGGL(pairs_band_nocr_kernel, dim3(riders + v.n_band_units), dim3(kBandThreads), kBandLds, s, v.n_band_units, v.band_unit_start, v.band_unit_cam, v.band_lm,
+                       v.n_cam_pose, v.J, v.r, v.JB, v.cp_tq, v.cp_tp, S, ld, rhs_row, grad, hdiag, perm, grad_only ? 1 : 0, small ? *small : none, riders, v.band_lm_id,
+                       v.Linv, v.z);
+  else
   hipLaunchKernelGGL(pairs_band_kernel, dim3(riders + v.n_band_units), dim3(kBandThreads), kBandLds, s, v.n_band_units, v.band_unit_start, v.band_unit_cam, v.band_lm,
                      v.n_cam_pose, v.J, v.r, v.CR, v.cp_tq, v.cp_tp, S, ld, rhs_row, grad, hdiag, perm, grad_only ? 1 : 0, small ? *small : none, riders);
 }

@@ -284,6 +284,7 @@ int flatten_visual_device(hipStream_t s, const std::function<void*(size_t)>& dal
   if (!bu.lm.empty()) {
     FL_CHK(hipMemcpyAsync(d_border, bu.lm.data(), sizeof(int) * bu.lm.size(), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(fl_band_gather_kernel, dim3(((int)bu.lm.size() + 255) / 256), dim3(256), 0, s, (int)bu.lm.size(), d_border, d_brec, V.band_lm);
+    V.band_lm_id = d_border;   // (kept: the band kernel's look-up of a landmark's Linv and z, Visual::no_cr)
   }
   FL_CHK(hipMemcpyAsync(V.band_unit_start, bu.unit_start.data(), sizeof(int) * bu.unit_start.size(), hipMemcpyHostToDevice, s));
   if (!bu.unit_cam.empty()) FL_CHK(hipMemcpyAsync(V.band_unit_cam, bu.unit_cam.data(), sizeof(int) * bu.unit_cam.size(), hipMemcpyHostToDevice, s));

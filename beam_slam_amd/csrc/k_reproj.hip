@@ -165,6 +165,7 @@ __device__ __forceinline__ void landmark_kernel_body(const int bsg_bx, const int
     Lo[0] = i00; Lo[1] = i10; Lo[2] = i11; Lo[3] = i20; Lo[4] = i21; Lo[5] = i22;
     z_out[3 * l] = z0; z_out[3 * l + 1] = z1; z_out[3 * l + 2] = z2;
   }
+  if (CR == nullptr) return;   // (Visual::no_cr: the pair phase and the back-substitution form C and rho themselves)
   for (int f = beg + sub; f < end; f += 8) {
     const double2* Jf2 = reinterpret_cast<const double2*>(JB + (size_t)f * 6);
     const double2 rf = r[f];
@@ -303,11 +304,11 @@ void launch_landmark(hipStream_t s, const Visual& v, int n_pose, const double* r
     const int zero_blocks = zero ? std::max(1, std::min(zero->n_tiles, 1024)) : 0;
     if (red && red->n_entries > 0)
       hipLaunchKernelGGL(landmark_reduce_kernel, dim3(red->n_slots + 1 + grid + zero_blocks), dim3(256), 0, s, *red, v.n_lm, v.lm_start, v.JB, v.r, n_pose, radius_ptr,
-                         compute_scale, compute_dcl, jacobi, lm_lo, lm_hi, scale, dcl, grad, v.Linv, v.z, v.CR, grid, zero ? *zero : ZeroStep(),
+                         compute_scale, compute_dcl, jacobi, lm_lo, lm_hi, scale, dcl, grad, v.Linv, v.z, v.no_cr ? nullptr : v.CR, grid, zero ? *zero : ZeroStep(),
                          radius_val);
     else
     hipLaunchKernelGGL(landmark_kernel, dim3(grid + zero_blocks), dim3(256), 0, s, v.n_lm, v.lm_start, v.JB, v.r, n_pose, radius_ptr,
-                       compute_scale, compute_dcl, jacobi, lm_lo, lm_hi, scale, dcl, grad, v.Linv, v.z, v.CR, grid, zero ? *zero : ZeroStep(),
+                       compute_scale, compute_dcl, jacobi, lm_lo, lm_hi, scale, dcl, grad, v.Linv, v.z, v.no_cr ? nullptr : v.CR, grid, zero ? *zero : ZeroStep(),
                        radius_val);
   }
   if (v.n > v.n_elim) {
@@ -605,8 +606,10 @@ __device__ __forceinline__ void backsub_mcc_kernel_body(const int bsg_bx, const 
     // recomputing it costs the row again plus a three-deep chain of dependent gathers — camera pose id, its tangent offsets, y)
     double jk0[2] = {0.0, 0.0}, jk1[2] = {0.0, 0.0};
     int it = 0;
+    // (no C rows — Visual::no_cr: the sums are taken with the B rows, sum_a B_a^T (A_a y), and C^T = Linv B^T is applied to them once per landmark below)
+    const bool no_cr = CR == nullptr;
     for (int f = beg + sub; f < end; f += 8, ++it) {
-      const double2* C2 = reinterpret_cast<const double2*>(CR + (size_t)f * 8);
+      const double2* C2 = no_cr ? reinterpret_cast<const double2*>(JB + (size_t)f * 6) : reinterpret_cast<const double2*>(CR + (size_t)f * 8);
       const double2 ca = C2[0], cb = C2[1], cc = C2[2];
       const double C[6] = {ca.x, ca.y, cb.x, cb.y, cc.x, cc.y};
       const int cp = cam_pose[f];
@@ -617,6 +620,10 @@ __device__ __forceinline__ void backsub_mcc_kernel_body(const int bsg_bx, const 
     }
 #pragma unroll
     for (int o = 4; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o, 8); a1 += __shfl_xor(a1, o, 8); a2 += __shfl_xor(a2, o, 8); }
+    if (no_cr) {   // a <- Linv a   (Linv lower triangular: Li0 | Li1 Li2 | Li3 Li4 Li5)
+      const double b0 = a0, b1 = a1, b2 = a2;
+      a0 = Li0 * b0; a1 = Li1 * b0 + Li2 * b1; a2 = Li3 * b0 + Li4 * b1 + Li5 * b2;
+    }
     if (valid) {   // (every one of the 8 lanes holds the sums)
       const double w0 = zl0 - a0, w1 = zl1 - a1, w2 = zl2 - a2;
       // y = Linv^T w
@@ -803,12 +810,12 @@ bool launch_backsub_mcc(hipStream_t s, const Visual& v, int n_pose, const double
   const int upd_units = (upd && upd->n_blocks > 0) ? (upd->n_blocks + 255) / 256 : 0;
   if (marg && marg_part && marg->rows > 0) {
     const int own = grid + extra + upd_units;
-    hipLaunchKernelGGL(backsub_mcc_marg_kernel, dim3(own + (marg->rows + 3) / 4), dim3(256), 0, s, v.n_lm, g_lm, v.n_elim, v.n, v.lm_start, v.J, v.JB, v.r, v.CR, v.cam_pose,
+    hipLaunchKernelGGL(backsub_mcc_marg_kernel, dim3(own + (marg->rows + 3) / 4), dim3(256), 0, s, v.n_lm, g_lm, v.n_elim, v.n, v.lm_start, v.J, v.JB, v.r, v.no_cr ? nullptr : v.CR, v.cam_pose,
                        v.cp_tq, v.cp_tp, v.Linv, v.z, n_pose, y_pose, delta, mcc_part, grid, small ? *small : SmallGroupSet(), small ? n_small_units : 0,
                        upd_units ? *upd : UpdateRide(), grid + extra, *marg, marg_part, own);
     return true;
   }
-  hipLaunchKernelGGL(backsub_mcc_kernel, dim3(grid + extra + upd_units), dim3(256), 0, s, v.n_lm, g_lm, v.n_elim, v.n, v.lm_start, v.J, v.JB, v.r, v.CR, v.cam_pose,
+  hipLaunchKernelGGL(backsub_mcc_kernel, dim3(grid + extra + upd_units), dim3(256), 0, s, v.n_lm, g_lm, v.n_elim, v.n, v.lm_start, v.J, v.JB, v.r, v.no_cr ? nullptr : v.CR, v.cam_pose,
                      v.cp_tq, v.cp_tp, v.Linv, v.z, n_pose, y_pose, delta, mcc_part, grid, small ? *small : SmallGroupSet(), small ? n_small_units : 0,
                      upd_units ? *upd : UpdateRide(), grid + extra);
   return false;

@@ -32,12 +32,13 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 HBM_COPY_GBS = 6290.0      # ... measured copy peak (the achievable streaming rate)
+PROFILE_ROUND = "r06"      # profiles/<round>_*_pmc_hbm.csv: the PMC passes `traffic` is read from (bench.py cannot collect counters itself)
 MFMA_F64_PEAK_TF = 78.6    # ... dense FP64 MFMA (v_mfma_f64_16x16x4_f64: 64 cycles / instruction / SIMD)
 MFMA_NOTE = ("latency-bound, not MFMA-bound: the critical path is the pivot chain of the chains on it (a leaf piece + one separator per "
              "level, 16 pivots at a time inside one workgroup: chol_chain.h) plus one hand-over per level; DESIGN.md 3.2")
 
 
-def _attach_traffic(roofline, csv_name, kernel_prefix, nbytes):
+def _attach_traffic(roofline, csv_name, kernel_prefix, nbytes, check_bytes=True):
     """HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the gfx950 correction of
     MI355X_MICROARCH.md; bench.py itself cannot collect counters).  The CSV row carries the algorithmic byte count the pass was
     taken at: a different count now means the kernel or the workload changed, and the stale figure is not reported."""
@@ -52,7 +53,7 @@ def _attach_traffic(roofline, csv_name, kernel_prefix, nbytes):
                 recorded = int(float(row[4])) if len(row) >= 5 and row[4] else None
             except ValueError:
                 continue
-            if recorded is not None and abs(recorded - nbytes) > 0.01 * nbytes:
+            if check_bytes and recorded is not None and abs(recorded - nbytes) > 0.01 * nbytes:
                 roofline["traffic_stale"] = "profiles/%s was taken at %d algorithmic bytes per launch, this run moves %d" % (csv_name, recorded, int(nbytes))
                 return
             roofline["traffic"] = int((2.0 * fetch_kb + write_kb) * 1024)
@@ -383,7 +384,7 @@ def main():
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "bytes_per_launch": int(nb_e), "ms_per_launch": round(ms_e, 5),
                         "timing": "20 back-to-back evaluations (residuals + Jacobians of every factor type) between two HIP events on the solver's stream",
                         "working_set_mb": round(nb_e / 1e6, 1), "cache_residency": "below the 256 MiB Infinity Cache", "traffic": None}
-            _attach_traffic(roofline, "r05_%s_pmc_hbm.csv" % args.workload, rel_kernel + "<true", nb_e)
+            _attach_traffic(roofline, "%s_%s_pmc_hbm.csv" % (PROFILE_ROUND, args.workload), rel_kernel + "<true", nb_e)
         if args.workload == "c3":          # dense Schur path without landmarks: phases and the factorisation's figure
             prof = g.profile_step(opt, reps=20)
             phases = {k: round(1e3 * v[0], 2) for k, v in prof.items()}
@@ -419,7 +420,7 @@ def main():
                 roofline["kernel_note"] = ("the reprojection factors' evaluation (the bytes counted) plus the window's %d IMU factors as the launch's first workgroups "
                                            "(~6.1 KB each, not counted)" % (pr.n_factors(capi.F_IMU_DELTA) + pr.n_factors(capi.F_IMU_PRIOR)))
             if world == 1 and args.workload == "c2" and args.n_kf == 200 and args.n_lm == 50000:
-                _attach_traffic(roofline, "r05_c2_pmc_hbm.csv", eval_kernel, nbytes)
+                _attach_traffic(roofline, "%s_c2_pmc_hbm.csv" % PROFILE_ROUND, eval_kernel, nbytes)
             ms_f, flops = prof["factor"]
             tf = flops / (ms_f * 1e-3) / 1e12
             roofline_mfma = {"bound": "mfma", "kernel": "chol_fused_kernel (+ chol_backsolve_fused_kernel: %.1f us)" % (1e3 * prof["backsolve"][0]),
@@ -427,11 +428,20 @@ def main():
                              "flops_per_launch": int(flops), "ms_per_launch": round(ms_f, 5),
                              "note": MFMA_NOTE}
             kernels = []
-            for name, kern in (("landmark", "landmark_kernel (+ clear)"), ("pairs", "pairs_kernel"), ("backsub", "backsub_mcc_kernel (+ small_mcc)"),
-                               ("candidate", "update + visual_imu_eval_kernel<false> / reproj_eval_kernel<false> + reduction")):
+            band = os.environ.get("BSGPU_PAIRS_BAND", "1") != "0" and pr.n_factors(0) >= 150000
+            for name, kern, pmc_name in (("landmark", "landmark_kernel (+ the step's clearing of S, gradient and diag(H))", "bsg::landmark_kernel"),
+                                         ("pairs", "pairs_band_kernel" if band else "pairs_kernel", "bsg::pairs_band_kernel" if band else "bsg::pairs_kernel"),
+                                         ("backsub", "backsub_mcc_kernel (+ small_mcc)", "bsg::backsub_mcc_kernel"),
+                                         ("candidate", "update + visual_imu_eval_kernel<false> / reproj_eval_kernel<false> + reduction", None)):
                 ms_k, by = prof[name]
-                kernels.append({"phase": name, "kernel": kern, "us": round(1e3 * ms_k, 2), "algorithmic_bytes": int(by),
-                                "achieved_gbs": round(by / (ms_k * 1e-3) / 1e9, 1), "frac_hbm": round(by / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+                k = {"phase": name, "kernel": kern, "us": round(1e3 * ms_k, 2), "algorithmic_bytes": int(by),
+                     "achieved_gbs": round(by / (ms_k * 1e-3) / 1e9, 1), "frac_hbm": round(by / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                if pmc_name and world == 1 and args.workload == "c2" and args.n_kf == 200 and args.n_lm == 50000:
+                    tr = {"traffic": None}
+                    _attach_traffic(tr, "%s_c2_pmc_hbm.csv" % PROFILE_ROUND, pmc_name, by, check_bytes=False)
+                    if tr.get("traffic"):
+                        k["traffic"] = tr["traffic"]; k["traffic_over_algorithmic"] = round(tr["traffic"] / by, 3); k["traffic_source"] = tr["traffic_source"]
+                kernels.append(k)
             if args.past_l3 and world == 1 and args.workload == "c2":
                 # the same kernel on a working set the Infinity Cache cannot hold: 800 keyframes x 300 000 landmarks, ~2.4 M observations
                 # (J + r ~ 385 MB per evaluation); Jacobian evaluation only (50 launches, HIP events) — nothing is solved
