@@ -280,8 +280,13 @@ bool build_plan(BatchPlan& P, bsgpu_ctx* const* ctxs, int n, const bsgpu_options
     const bool bulk = bulk_lists && c->d_ftasks_bulk && c->d_tile_tot_bulk;
     const bool plain = c->d_ftasks_plain && c->d_tile_tot_plain;
     const FusedTask* tl = bulk ? c->d_ftasks_bulk : plain ? c->d_ftasks_plain : D.ftasks;
-    const int ntl = bulk ? c->n_ftasks_bulk : plain ? c->n_ftasks_plain : (int)c->plan.ftasks.size();
+    int ntl = bulk ? c->n_ftasks_bulk : plain ? c->n_ftasks_plain : (int)c->plan.ftasks.size();
     const int* tt = bulk ? c->d_tile_tot_bulk : plain ? c->d_tile_tot_plain : D.tile_tot;
+    // ... and, where that list is the one the row segments were made from, the list with the segments: an update task is ~7 us of a compute unit for
+    // 1.3 - 2 us of products, a segment's further updates ~2 (dense_plan.h build_row_segments; launches without turns only; BSGPU_CHOL_ROWS=0: never)
+    static const bool rows_off = (getenv("BSGPU_CHOL_ROWS") && atoi(getenv("BSGPU_CHOL_ROWS")) == 0) || (getenv("BSGPU_CHOL_NOTURN") && atoi(getenv("BSGPU_CHOL_NOTURN")) == 0);
+    const int src_now = bulk ? 2 : plain ? 1 : 0;
+    if (bulk_lists && !rows_off && c->d_ftasks_rows && c->plan.frows_src == src_now) { tl = c->d_ftasks_rows; ntl = c->n_ftasks_rows; }
     batchargs_chol_fused(P.t_chol, c->d_S, D.Lp, c->plan.npad, tl, ntl, tt, D.nreal, D.Vinv, c->d_scal, D.fsync, D.Winv, D.rhs_rows, LmDiag(), GradNormRide(), /*diag_tasks_in_list=*/!bulk && !plain && c->plan.diag_tasks);
     P.bs_form[w] = batchargs_backsolve(P.t_bs, c->plan, D, c->d_y, c->d_inat, c->n_pose, c->d_ytan, c->d_delta);
     if (P.bs_form[w] < 0) return false;

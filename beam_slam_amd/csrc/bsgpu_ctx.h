@@ -206,6 +206,7 @@ struct bsgpu_ctx {
   int n_touched = 0;
   int* d_tile_tot = nullptr;
   FusedTask* d_ftasks = nullptr;   // fused single-launch factorisation: task list and its counters (k_chol.hip chol_fused_kernel)
+  FusedTask* d_ftasks_rows = nullptr; int n_ftasks_rows = 0;   // ... with row segments (dense_plan.h ftasks_rows; the segments' pairs lie behind the list; tile counts: plan.frows_src's)
   FusedTask* d_ftasks_bulk = nullptr; int* d_tile_tot_bulk = nullptr; int n_ftasks_bulk = 0;      // ... and without the K-chunks (dense_plan.h ftasks_bulk)
   FusedTask* d_ftasks_plain = nullptr; int* d_tile_tot_plain = nullptr; int n_ftasks_plain = 0;   // ... the list without the diagonal / rider tasks (dense_plan.h)
   int* d_fsync = nullptr;

@@ -1047,6 +1047,7 @@ int finalize(bsgpu_ctx* c) {
       c->d_ftasks = nullptr; c->d_fsync = nullptr; c->d_tile_tot = nullptr;
       c->d_ftasks_plain = nullptr; c->d_tile_tot_plain = nullptr; c->n_ftasks_plain = 0;
       c->d_ftasks_bulk = nullptr; c->d_tile_tot_bulk = nullptr; c->n_ftasks_bulk = 0;
+      c->d_ftasks_rows = nullptr; c->n_ftasks_rows = 0;
       // (one workgroup of 512 threads per task, and a grid holds fewer than 2^32 threads: above 8.38 M tasks — a DENSE system of more than
       // ~23 600 dimensions, which only the exact option on a pose graph produces — the launch is refused by the runtime, so the
       // launch-per-step path runs there; scripts/c4_exact.py)
@@ -1060,6 +1061,13 @@ int finalize(bsgpu_ctx* c) {
         if (!c->plan.ftasks_bulk.empty()) {
           c->d_ftasks_bulk = c->upload(c->plan.ftasks_bulk); c->d_tile_tot_bulk = c->upload(c->plan.tile_tot_bulk);
           c->n_ftasks_bulk = (int)c->plan.ftasks_bulk.size();
+        }
+        if (c->plan.frows_src >= 0 && !c->plan.frow_items.empty()) {   // the list, then the segments' pairs (k_chol.hip chol_fused_rowseg finds them behind the list)
+          std::vector<FusedTask> img = c->plan.ftasks_rows;
+          const size_t n_pairs = c->plan.frow_items.size() / 2, per = sizeof(FusedTask) / (2 * sizeof(int));
+          img.resize(img.size() + (n_pairs + per - 1) / per);
+          std::memcpy(reinterpret_cast<int*>(img.data() + c->plan.ftasks_rows.size()), c->plan.frow_items.data(), sizeof(int) * c->plan.frow_items.size());
+          c->d_ftasks_rows = c->upload(img); c->n_ftasks_rows = (int)c->plan.ftasks_rows.size();
         }
         c->d_fsync = c->upload(std::vector<int>((size_t)c->plan.fused_sync_words, 0));
         c->d_Winv = c->alloc<double>((size_t)std::max(1, T) * 4096);   // (the chains write every entry of a tile's inverse, zeros above its diagonal blocks included)

@@ -69,6 +69,9 @@ constexpr int kFusedSplit = 256;    // ONE K-CHUNK of the LAST update of a tile 
                                     // appendix chunk forms the appendix's 16 columns.  tot_c = chunk | number of chunks << 8.  The tile's counter counts the
                                     // chunks in its upper half: tile_tot = updates with a turn of their own | chunks << 16.  (The order in which the chunks'
                                     // sums reach a tile varies: the factor is reproducible to rounding, like the assembled system it factors.)
+constexpr int kFusedRowSeg = 512;   // SEVERAL updates of one row tile by one panel in one task (ftasks_rows; k_chol.hip chol_fused_rowseg): tj = index of the segment's first
+                                    // (tile, updates of (tile, k)) pair in frow_items, tot_j = the number of pairs; every product is counted at its tile like a task
+constexpr int kFusedRowSegMax = 8;  // pairs per segment, at most
 constexpr int kFusedSplitChunks = 4;
 constexpr int kChainMaxTiles = 3;   // == chain::kChainMaxTiles (chol_chain.h)
 
@@ -113,6 +116,54 @@ struct DensePlan {
   std::vector<int> tile_tot_plain;
   std::vector<FusedTask> ftasks_bulk;    // ... and without the K-chunks either: what a launch takes that is bound by the NUMBER of its workgroups, not by one
   std::vector<int> tile_tot_bulk;        // window's critical path (many windows side by side: bsgpu_batch.cpp); empty: the plan has no chunks
+  // ... and with the updates that read two published X gathered into ROW SEGMENTS (kFusedRowSeg: one task per row tile and panel, up to kFusedRowSegMax
+  // products): built from the bulk list (or, without chunks, from the plain one; or from ftasks itself) — frows_src says which, its tile_tot is that list's.
+  // For launches WITHOUT turns only (the products of a segment reach their tiles in the segment's order, not in the list's).
+  std::vector<FusedTask> ftasks_rows;
+  std::vector<int> frow_items;           // (tile tj, number of updates of tile (tj, k)) pairs, a segment's pairs side by side
+  int frows_src = -1;                    // 2: ftasks_bulk, 1: ftasks_plain, 0: ftasks; -1: no segments (no list)
+  // One pass over the source list.  An update (k; ti, tj) that reads both X (kFusedXiLp | kFusedXjLp) joins the open segment of (k, ti) if the diagonal
+  // task that publishes X_tj has its ticket BEFORE that segment's (a workgroup only ever waits for tickets taken earlier: k_chol.hip), else it opens a
+  // new one at its own place.  A segment sits where its FIRST member sat: its members' products only ever come earlier than in the source list, so every
+  // reader of their tiles still has them in front of it; what a member waits for — X_ti (the first member's diagonal task), X_tj (checked) — is in front
+  // of the segment.
+  void build_row_segments() {
+    ftasks_rows.clear(); frow_items.clear(); frows_src = -1;
+    const std::vector<FusedTask>& src = !ftasks_bulk.empty() ? ftasks_bulk : !ftasks_plain.empty() ? ftasks_plain : ftasks;
+    if (src.empty()) return;
+    frows_src = !ftasks_bulk.empty() ? 2 : !ftasks_plain.empty() ? 1 : 0;
+    const int N = T + 1;
+    std::vector<int> pub_pos((size_t)N * N, -1);       // (tile, panel) -> place of the diagonal task that publishes X(tile, panel) in the new list
+    std::vector<int> open_seg((size_t)N * N, -1);      // (row tile, panel) -> place of its open segment
+    std::vector<std::vector<int>> seg_items;           // per segment task (by its place; empty for other tasks)
+    for (const FusedTask& f : src) {
+      const bool member = !(f.flags & (kFusedChain | kFusedRider | kFusedDiagAdd | kFusedSplit | kFusedXjChain | kFusedPublishX)) && (f.flags & kFusedXiLp) &&
+                          (f.flags & kFusedXjLp) && f.ti != f.tj && f.need_c >= 0;
+      if (!member) {
+        if ((f.flags & kFusedPublishX) && !(f.flags & (kFusedChain | kFusedSplit))) pub_pos[(size_t)f.ti * N + f.k] = (int)ftasks_rows.size();
+        ftasks_rows.push_back(f); seg_items.emplace_back();
+        continue;
+      }
+      const size_t key = (size_t)f.ti * N + f.k;
+      const int os = open_seg[key], pp = pub_pos[(size_t)f.tj * N + f.k];
+      if (os >= 0 && pp >= 0 && pp < os && (int)seg_items[os].size() < 2 * kFusedRowSegMax) {
+        seg_items[os].push_back(f.tj); seg_items[os].push_back(f.tot_j);
+        continue;
+      }
+      FusedTask g = f;
+      g.flags = kFusedRowSeg | (f.flags & kFusedExt);
+      g.tj = 0; g.tot_j = 0; g.need_c = 0; g.tot_c = 0;
+      open_seg[key] = (int)ftasks_rows.size();
+      ftasks_rows.push_back(g); seg_items.emplace_back();
+      seg_items.back().push_back(f.tj); seg_items.back().push_back(f.tot_j);
+    }
+    for (size_t t = 0; t < ftasks_rows.size(); ++t) {
+      if (!(ftasks_rows[t].flags & kFusedRowSeg)) continue;
+      ftasks_rows[t].tj = (int)frow_items.size() / 2;
+      ftasks_rows[t].tot_j = (int)seg_items[t].size() / 2;
+      frow_items.insert(frow_items.end(), seg_items[t].begin(), seg_items[t].end());
+    }
+  }
   bool allow_ext = true;              // (finalize: BSGPU_CHOL_EXT=0 plans every tile's panel by itself)
   bool diag_tasks = false;            // one kFusedDiagAdd task per tile at the head of the list
   int rider_tasks = 0;                // kFusedRider tasks behind them
@@ -649,6 +700,7 @@ struct DensePlan {
         }
         if (diag_tasks) for (int t = 0; t < T; ++t) tile_tot_bulk[(size_t)t * N + t]--;
       }
+      build_row_segments();
     }
     // ---- back-substitution plan
     panel_of_tile.assign(T, 0);

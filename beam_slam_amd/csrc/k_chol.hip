@@ -637,6 +637,7 @@ struct FusedCtx {
   double* Winv;   // per tile: the full inverse of its factor: its diagonal 16x16 blocks are what the tasks' triangular solves multiply by,
                   // the whole of it what the back-substitution multiplies by
   const FusedTask* tasks;
+  int n_tasks;
   const int* tile_tot;
   const int* nreal;
   int ld, n_vinv_tiles;
@@ -1124,6 +1125,142 @@ BSG_DEV bool chol_fused_split(const FusedCtx& C, int t, const FusedTask& tk, dou
   return true;
 }
 
+// A ROW SEGMENT (dense_plan.h kFusedRowSeg; launches without turns only): the updates (k; ti, tj_0), (k; ti, tj_1), ... of ONE row tile by one panel, each of
+// which reads the X its two diagonal tasks have published — X_ti is fetched once and stays in LDS, the X_tj follow one after the other (the next one's
+// loads are issued before this one's product), every product is added to its tile with FP64 atomics and counted there exactly as a task of its own would.
+// What it saves is what an update task spends around its 1.3 - 2 us of products: the workgroup's start, its ticket and record (2.1 us), X_ti (0.9), the
+// publication's barrier — many factorisations side by side (bsgpu_solve_batch) are bound by the number of these workgroups, each of which holds a CU.
+// items: (tj, updates of tile (tj, k)) pairs behind the task list (tk.tj = index of the segment's first pair, tk.tot_j = their number).
+template <bool PROBE>
+BSG_DEV bool chol_fused_rowseg(const FusedCtx& C, int t, const FusedTask& tk, double* smem) {
+  constexpr int NT = 512, NQ = 2048 / NT, TPW = 2;
+  double* const S = uniform_ptr(C.S); double* const Lp = uniform_ptr(C.Lp);
+  const int ld = __builtin_amdgcn_readfirstlane(C.ld);
+  int* const abort_w = uniform_ptr(C.abort_w); int* const upd = uniform_ptr(C.upd);
+  const int fs = __builtin_amdgcn_readfirstlane(C.fs);
+  const long long deadline = uniform_i64(C.deadline);
+  long long* const probe_ts = uniform_ptr(C.probe_ts);
+  const int* const items = reinterpret_cast<const int*>(uniform_ptr(C.tasks) + __builtin_amdgcn_readfirstlane(C.n_tasks));
+  double* sXi = smem;                 // 64 x LDT
+  double* sXj = sXi + NB * LDT;       // 64 x LDT
+  double* sEi = sXj + 2 * NB * LDT;   // 64 x kExtPitch (the layout of chol_fused_update: the W tile's area stays unused)
+  double* sEj = sEi + NB * kExtPitch;
+  int* s_ctl = reinterpret_cast<int*>(sEj + NB * kExtPitch + 16 * LDT + 16 * kExtPitch);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = ld / NB;
+  auto tile_rows = [&](double* base, int row0) {
+    return __builtin_amdgcn_make_buffer_rsrc(base + (size_t)row0 * ld, 0, (int)((size_t)NB * ld * sizeof(double)), 0x00020000);
+  };
+  const int crow = lane >> 4, ccol = lane & 15;
+  const int rs = wave & 3, tt0 = (wave >> 2) * TPW;
+  auto stamp = [&](int slot) { if (PROBE && tid == 0) probe_ts[(size_t)t * 8 + slot] = wall_clock64(); };
+  stamp(1);
+  const int k = tk.k, ti = tk.ti, first = tk.tj, len = tk.tot_j;
+  const bool ext = (tk.flags & kFusedExt) != 0;
+  const int ri = __builtin_amdgcn_readfirstlane(ti * NB), c0 = __builtin_amdgcn_readfirstlane(k * NB);
+  const __amdgpu_buffer_rsrc_t rL_i = tile_rows(Lp, ri);
+  const int strips_i = (ti == N - 1) ? __builtin_amdgcn_readfirstlane(C.rhs_strips) : 4;
+  const bool strip_on = rs < strips_i;
+  const int er = tid >> 3, ec2 = (tid & 7) * 2;
+  if (tid == 0) s_ctl[1] = wait_count(&upd[(ti * N + k) * fs], tk.tot_i + 1, abort_w, deadline) ? 1 : 0;   // X_ti is published
+  __syncthreads();
+  if (__builtin_amdgcn_readfirstlane(s_ctl[1]) == 0) return false;
+  stamp(2);
+  {
+    double2 vXi[NQ], vEi = double2{0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int i = tid + NT * q;
+      vXi[q] = ld16_sc1(rL_i, (unsigned)(((size_t)(i >> 5) * ld + c0 + (i & 31) * 2) * sizeof(double)));
+    }
+    if (ext) vEi = ld16_sc1(rL_i, (unsigned)(((size_t)er * ld + c0 + NB + ec2) * sizeof(double)));
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int i = tid + NT * q;
+      *reinterpret_cast<double2*>(&sXi[(i >> 5) * LDT + (i & 31) * 2]) = vXi[q];
+    }
+    if (ext) *reinterpret_cast<double2*>(&sEi[er * kExtPitch + ec2]) = vEi;
+  }
+  stamp(3);
+  // The X_tj go through TWO LDS tiles in turn, and a round waits for nothing it has just issued:
+  //   round s:  X_tj(s) registers -> LDS tile s & 1 | LDS barrier | X_tj(s + 1) requested | products of s | their atomic adds
+  // The vector-memory counter completes in order, so at the top of round s "at most the adds of round s - 1 outstanding" (8 per lane) says that
+  // X_tj(s) has arrived AND the adds of round s - 2 are in: that tile's counter is advanced behind this round's barrier (every wave has passed the
+  // same wait).  A round costs its products and one barrier; the drain of the adds (0.8 us) and the loads' latency run under the next round's products.
+  double* const sXjb[2] = {sXj, sXj + NB * LDT};   // (the second tile: chol_fused_update's W area)
+  double* const sEjb[2] = {sEj, sEj + NB * kExtPitch};   // (... its L16 / W16 area: 64 x kExtPitch doubles fit in 16 x LDT + 16 x kExtPitch? no — see the static_assert)
+  static_assert(16 * LDT + 16 * kExtPitch >= NB * kExtPitch, "second appendix stage");
+  int tj = __builtin_amdgcn_readfirstlane(items[2 * first]), totj = __builtin_amdgcn_readfirstlane(items[2 * first + 1]);
+  double2 vXj[NQ], vEj;
+  auto request_j = [&](int tjx) {   // 5 vector-memory loads per lane, whatever the panel (the waits below count them)
+    const __amdgpu_buffer_rsrc_t rL_j = tile_rows(Lp, tjx * NB);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int i = tid + NT * q;
+      vXj[q] = ld16_sc1(rL_j, (unsigned)(((size_t)(i >> 5) * ld + c0 + (i & 31) * 2) * sizeof(double)));
+    }
+    vEj = ld16_sc1(rL_j, (unsigned)(((size_t)er * ld + c0 + (ext ? NB : 0) + ec2) * sizeof(double)));
+    asm volatile("" ::: "memory");
+  };
+  __syncthreads();
+  if (tid == 0) s_ctl[1] = wait_count(&upd[(tj * N + k) * fs], totj + 1, abort_w, deadline) ? 1 : 0;
+  __syncthreads();
+  if (__builtin_amdgcn_readfirstlane(s_ctl[1]) == 0) return false;
+  request_j(tj);
+  int tj_prev = -1, tj_prev2 = -1;
+  bool ok_all = true;
+  for (int s = 0; s < len; ++s) {
+    const int b = s & 1;
+    if (strip_on && s > 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int i = tid + NT * q;
+      *reinterpret_cast<double2*>(&sXjb[b][(i >> 5) * LDT + (i & 31) * 2]) = vXj[q];
+    }
+    if (ext) *reinterpret_cast<double2*>(&sEjb[b][er * kExtPitch + ec2]) = vEj;
+    const int tj_now = tj;
+    const bool more = s + 1 < len;
+    if (more) {
+      tj = __builtin_amdgcn_readfirstlane(items[2 * (first + s + 1)]); totj = __builtin_amdgcn_readfirstlane(items[2 * (first + s + 1) + 1]);
+      if (tid == 0) s_ctl[1] = wait_count(&upd[(tj * N + k) * fs], totj + 1, abort_w, deadline) ? 1 : 0;   // (published long ago, as a rule: one look)
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (LDS only: the adds in flight stay in flight)
+    if (tid == 0 && tj_prev2 >= 0) atomicAdd(&upd[(ti * N + tj_prev2) * fs], 1);   // the adds of round s - 2 are in (every wave has waited for its own)
+    if (more) {
+      if (__builtin_amdgcn_readfirstlane(s_ctl[1]) == 0) { ok_all = false; tj_prev2 = -1; break; }   // (round s - 2's tile has just been counted)
+      request_j(tj);
+    }
+    const int rj = __builtin_amdgcn_readfirstlane(tj_now * NB);
+    if (strip_on) {
+      double4_t acc[TPW];
+#pragma unroll
+      for (int u = 0; u < TPW; ++u) {
+        acc[u] = double4_t{0.0, 0.0, 0.0, 0.0};
+        acc[u] = mfma_abt<64>(acc[u], sXi + (16 * rs) * LDT, LDT, sXjb[b] + (16 * (tt0 + u)) * LDT, LDT, -1.0, lane);
+        if (ext) acc[u] = mfma_abt<16>(acc[u], sEi + (16 * rs) * kExtPitch, kExtPitch, sEjb[b] + (16 * (tt0 + u)) * kExtPitch, kExtPitch, -1.0, lane);
+      }
+      double* const Sg = S + (size_t)(ri + 16 * rs + crow) * ld + rj + 16 * tt0 + ccol;
+#pragma unroll
+      for (int u = 0; u < TPW; ++u)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+          (void)__hip_atomic_fetch_add(Sg + (size_t)(4 * reg) * ld + 16 * u, acc[u][reg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("" ::: "memory");
+    }
+    tj_prev2 = tj_prev; tj_prev = tj_now;
+  }
+  // the last two rounds' tiles (and, after a wait that was given up, whatever was added)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    if (tj_prev2 >= 0) atomicAdd(&upd[(ti * N + tj_prev2) * fs], 1);
+    if (tj_prev >= 0) atomicAdd(&upd[(ti * N + tj_prev) * fs], 1);
+  }
+  if (!ok_all) return false;
+  stamp(6);
+  return true;
+}
+
 // A CHAIN task: wait for the chain's tiles to have received their updates from outside, then factor them as one dense matrix
 // (chol_chain.h).  Afterwards the block inverses of its tiles also go to Vinv (what the launch-per-level back-substitution of very
 // large windows reads; nobody in this launch does).
@@ -1177,7 +1314,7 @@ __device__ __forceinline__ void chol_fused_kernel_body(const int bsg_bx, const i
   const int N = ld / NB;
   int* head = sync; int* abort_w = sync + fs; int* exited = sync + 2 * fs;   // (layout: [head | abort | exited | potrf_done (N) | update counts (N x N)] x fs ints)
   FusedCtx C;
-  C.S = S; C.Lp = Lp; C.Vinv = Vinv; C.scal = scal; C.tasks = tasks; C.tile_tot = tile_tot; C.nreal = nreal; C.ld = ld; C.n_vinv_tiles = N - 1;
+  C.S = S; C.Lp = Lp; C.Vinv = Vinv; C.scal = scal; C.tasks = tasks; C.n_tasks = n_tasks; C.tile_tot = tile_tot; C.nreal = nreal; C.ld = ld; C.n_vinv_tiles = N - 1;
   C.Winv = Winv; C.rhs_strips = rhs_strips & 0xff; C.no_turn = (rhs_strips >> 8) & 3;   // (the launch's update mode rides in the argument's second byte: fused_update_mode())
   C.abort_w = abort_w; C.potrf_done = sync + 3 * fs; C.upd = sync + (3 + N) * fs; C.fs = fs;
   C.deadline = (long long)wall_clock64() + kFusedTimeoutTicks + 20LL * n_tasks;   // (+ 0.2 us per task: a dense 30 000-dimensional factorisation is 17 M tasks and half a second)
@@ -1216,6 +1353,7 @@ __device__ __forceinline__ void chol_fused_kernel_body(const int bsg_bx, const i
       if (tid == 0) atomicAdd(&C.upd[(tk.k * N + tk.k) * fs], 1);
     } else if (tk.flags & kFusedChain) (void)chol_fused_chain<PROBE>(C, t, tk, smem);
     else if (tk.flags & kFusedSplit) (void)chol_fused_split<PROBE>(C, t, tk, smem);
+    else if (tk.flags & kFusedRowSeg) (void)chol_fused_rowseg<PROBE>(C, t, tk, smem);
     else (void)chol_fused_update<PROBE, kFusedThreads>(C, t, tk, smem);
   }
   // leave: the last workgroup out re-zeroes the queue and the counters for the next factorisation

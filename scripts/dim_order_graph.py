@@ -12,6 +12,8 @@ which = sys.argv[1]
 if which == "c1": pr = synthetic.c1()
 elif which == "c2": pr = synthetic.c2()
 elif which == "c3": pr = synthetic.c3()
+elif which.startswith("pg:"):
+    _, npose, nloop = which.split(":"); pr = synthetic.pose_graph(n_pose=int(npose), n_loop=int(nloop), seed=20250900)
 else:
     _, kf, lm = which.split(":"); pr = synthetic.vio_window(n_kf=int(kf), n_lm=int(lm), seed=1)
 nb = len(pr.size)

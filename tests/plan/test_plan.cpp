@@ -83,7 +83,8 @@ static int check_ordered(std::mt19937& rng, unsigned seed) {
   return fails + replay(P, adjS, seed, -1);
 }
 
-static long g_bulk_lists = 0;
+static long g_bulk_lists = 0, g_rows_lists = 0, g_row_segs = 0, g_row_seg_updates = 0;
+static bool g_no_turns = false;   // the list being replayed is one for launches without turns (k_chol.hip FusedCtx::no_turn)
 static long g_ext_tasks = 0, g_ext_plans = 0, g_diag_tasks = 0, g_split_tasks = 0, g_split_loaded = 0;
 static int replay_list(const DensePlan& P, const std::vector<uint8_t>& adj, unsigned seed, int max_chains) {
   { long n = 0; for (const FusedTask& f : P.ftasks) n += (f.flags & kFusedExt) ? 1 : 0; g_ext_tasks += n; g_ext_plans += n > 0; }
@@ -184,6 +185,29 @@ static int replay_list(const DensePlan& P, const std::vector<uint8_t>& adj, unsi
       }
       continue;
     }
+    if (f.flags & kFusedRowSeg) {
+      // several updates of row tile i by panel k, each reading the X its two diagonal tasks have published; their products are counted at their tiles in the
+      // segment's order (a list for launches WITHOUT turns: the tile's count only has to be below its total)
+      const int k = f.k, i = f.ti;
+      const bool ext = (f.flags & kFusedExt) != 0;
+      ++g_row_segs;
+      if (f.tot_j < 1 || f.tot_j > kFusedRowSegMax || f.tj < 0 || 2 * (f.tj + f.tot_j) > (int)P.frow_items.size()) { fail("segment: pairs out of range", (int)t); continue; }
+      if (f.tot_i != P.tile_tot[(size_t)i * N + k]) fail("segment: tot mismatch", (int)t);
+      if (upd[(size_t)i * N + k] < f.tot_i + 1 || !xpub[(size_t)i * N + k]) fail("segment: X_i not published", (int)t);
+      for (int q = 0; q < f.tot_j; ++q) {
+        const int j = P.frow_items[2 * (f.tj + q)], totj = P.frow_items[2 * (f.tj + q) + 1];
+        ++g_row_seg_updates;
+        if (j >= i || j <= k) fail("segment: pair's tile", (int)t);
+        if (totj != P.tile_tot[(size_t)j * N + k]) fail("segment: pair's tot", (int)t);
+        if (upd[(size_t)j * N + k] < totj + 1 || !xpub[(size_t)j * N + k]) fail("segment: X_j not published", (int)t);
+        if (upd[(size_t)i * N + j] >= tot_lo(i, j)) fail("segment: more updates than the tile counts", (int)t);
+        double v = L[(size_t)i * N + k] * L[(size_t)j * N + k];
+        if (ext) v += L[(size_t)i * N + k + 1] * L[(size_t)j * N + k + 1];
+        S[(size_t)i * N + j] -= v;
+        upd[(size_t)i * N + j]++;
+      }
+      continue;
+    }
     const int k = f.k, i = f.ti, j = f.tj;
     const bool diag = i == j, solve_i = !(f.flags & kFusedXiLp), solve_j = !diag && !(f.flags & (kFusedXjLp | kFusedXjChain));
     if (!potrf_done[k] && (solve_i || solve_j || (f.flags & kFusedXjChain))) fail("L_kk not out", (int)t);
@@ -210,7 +234,8 @@ static int replay_list(const DensePlan& P, const std::vector<uint8_t>& adj, unsi
     if (!solve_i && !xpub[(size_t)i * N + k]) fail("X_i read before it was published", (int)t);
     if (!diag && (f.flags & kFusedXjLp) && !xpub[(size_t)j * N + k]) fail("X_j read before it was published", (int)t);
     if (f.need_c >= 0) {
-      if (upd[(size_t)i * N + j] != f.need_c) fail("turn", (int)t);
+      if (!g_no_turns && upd[(size_t)i * N + j] != f.need_c) fail("turn", (int)t);
+      if (g_no_turns && upd[(size_t)i * N + j] >= tot_lo(i, j)) fail("more updates than the tile counts", (int)t);
       S[(size_t)i * N + j] -= xi * xj + xi_e * xj_e;
       upd[(size_t)i * N + j]++;
     }
@@ -227,6 +252,20 @@ static int replay_list(const DensePlan& P, const std::vector<uint8_t>& adj, unsi
 // the plan's list, and its list without the diagonal / rider tasks (what a launch that carries neither takes)
 static int replay(const DensePlan& P, const std::vector<uint8_t>& adj, unsigned seed, int max_chains) {
   int f = replay_list(P, adj, seed, max_chains);
+  if (P.frows_src >= 0) {   // ... and the list with the row segments (launches without turns), on its source's tile counts
+    DensePlan Q = P;
+    Q.ftasks = P.ftasks_rows;
+    Q.tile_tot = P.frows_src == 2 ? P.tile_tot_bulk : P.frows_src == 1 ? P.tile_tot_plain : P.tile_tot;
+    if (P.frows_src > 0) { Q.diag_tasks = false; Q.rider_tasks = 0; }
+    size_t members = 0, src_members = 0;
+    for (const FusedTask& t : Q.ftasks) members += (t.flags & kFusedRowSeg) ? (size_t)t.tot_j : 1;
+    src_members = (P.frows_src == 2 ? P.ftasks_bulk : P.frows_src == 1 ? P.ftasks_plain : P.ftasks).size();
+    if (members != src_members) { printf("  FAIL rows list: %zu updates for %zu tasks of its source\n", members, src_members); ++f; }
+    g_no_turns = true;
+    f += replay_list(Q, adj, seed, max_chains);
+    g_no_turns = false;
+    ++g_rows_lists;
+  }
   if (P.diag_tasks || P.rider_tasks > 0) {
     if (P.ftasks_plain.empty()) { printf("  FAIL no plain list\n"); return f + 1; }
     DensePlan Q = P;
@@ -279,6 +318,8 @@ int main() {
   if (g_split_tasks < 1000 || g_split_loaded != g_split_tasks) { printf("the split chunks and the chains' partial tiles do not match\n"); ++fails; }
   printf("bulk lists replayed: %ld\n", g_bulk_lists);
   if (g_bulk_lists < 100) { printf("too few bulk lists\n"); ++fails; }
+  printf("lists with row segments replayed: %ld (%ld segments, %ld updates in them)\n", g_rows_lists, g_row_segs, g_row_seg_updates);
+  if (g_rows_lists < 400 || g_row_seg_updates < 2 * g_row_segs || g_row_segs < 1000) { printf("too few row segments\n"); ++fails; }
   printf("diagonal tasks: %ld\n", g_diag_tasks);
   if (g_diag_tasks < 1000) { printf("too few diagonal tasks\n"); ++fails; }
   fails += ofails;
