@@ -505,7 +505,7 @@ int finalize(bsgpu_ctx* c) {
   {
     const int nv = V.n;
     V.r = c->alloc<double2>(nv); V.J = c->alloc<double>((size_t)nv * (kJAStride + 6)); V.JB = V.J ? V.J + (size_t)nv * kJAStride : nullptr; V.CR = c->alloc<double>((size_t)nv * 8);
-    V.Linv = c->alloc<double>((size_t)nl * 6); V.z = c->alloc<double>((size_t)nl * 3);
+    V.Linv = c->alloc<double>((size_t)std::max(1, nl) * kLmRec); V.z = V.Linv ? V.Linv + 6 : nullptr;
     V.n_cost_part = (nv + 255) / 256;
     V.cost_part = c->alloc<double>(V.n_cost_part);
     V.cost_part_cand = c->alloc<double>(V.n_cost_part);

@@ -43,6 +43,7 @@ constexpr int kBandMinFactors = 150000;   // windows below this keep every pair 
 
 // meta word of a reprojection factor: camera id | loss id | constant-block flags
 constexpr int kMetaCamBits = 12, kMetaLossBits = 12;
+constexpr int kLmRec = 10;   // doubles per landmark record (Visual::Linv / z)
 constexpr int kFlagQConst = 1, kFlagPConst = 2, kFlagLConst = 4;
 __host__ __device__ inline int meta_pack(int cam, int loss, int flags) {
   return cam | (loss << kMetaCamBits) | (flags << (kMetaCamBits + kMetaLossBits));
@@ -145,8 +146,10 @@ struct Visual {
   double* JB = nullptr;       // ... and landmark part n x 6 ([B row 0 | B row 1]) = J + 12 n: the landmark kernel streams 48 B per factor
                               // instead of dragging 144-byte rows through for a third of their bytes
   double* CR = nullptr;       // n x 8: C = B M (2x3), rho = r - C z (2)
-  double* Linv = nullptr;     // n_lm x 6  (lower-triangular inverse factor of Hll + lambda)
-  double* z = nullptr;        // n_lm x 3  (Linv * g_l)
+  // per landmark ONE record of kLmRec doubles (80 B, 16-byte aligned): [Linv (6: lower-triangular inverse factor of Hll + lambda) | z = Linv g_l (3) | pad] — the
+  // consumers that look a landmark up by its id (the band kernel without C rows) touch one or two lines for it instead of a partial line of each of two arrays
+  double* Linv = nullptr;     // record l at Linv + kLmRec l
+  double* z = nullptr;        // = Linv + 6: z of landmark l at z + kLmRec l
   double* cost_part = nullptr;       // per-workgroup cost partials at the current point
   double* cost_part_cand = nullptr;  // ... at the candidate point
   double* mcc_part = nullptr;        // per-workgroup model-cost-change partials

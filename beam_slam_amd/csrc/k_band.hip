@@ -58,7 +58,7 @@ BSG_DEV int4 band_fetch_rec(const int4* __restrict__ band_lm, int li, int end) {
 // Plain named locals and unconditional loads at clamped indices: a struct handed to helpers is an object in memory across the barriers' asm
 // (it lived in scratch: 176 bytes per lane), and arrays of loaded values under a lane condition went to scratch in round 3's band kernel.
 // (NOCR — Visual::no_cr: the stage's C area takes the landmark's B rows, 3 pieces per observation, in pieces 0 .. 47, and the landmark's Linv (pieces
-//  48 .. 50) and z (the x halves of 51 .. 53) instead of the C | rho rows; LMID = the record's landmark)
+//  48 .. 50) and z (pieces 51, 52: z0 z1 | z2 pad — the landmark's 80-byte record as it lies in memory) instead of the C | rho rows; LMID = the record's landmark)
 #define BSG_BAND_ISSUE(REC, LMID)                                                                                             \
   {                                                                                                                           \
     const int n_ = (int)((unsigned)(REC).y >> 24);                                                                            \
@@ -70,11 +70,8 @@ BSG_DEV int4 band_fetch_rec(const int4* __restrict__ band_lm, int li, int end) {
     pa0 = Jf_[min(l16, na_)]; pa1 = Jf_[min(l16 + 16, na_)]; pa2 = Jf_[min(l16 + 32, na_)]; pa3 = Jf_[min(l16 + 48, na_)];     \
     pa4 = Jf_[min(l16 + 64, na_)];                                                                                            \
     pc0 = Cf_[min(l16, nc_)]; pc1 = Cf_[min(l16 + 16, nc_)]; pc2 = Cf_[min(l16 + 32, nc_)];                                    \
-    if (NOCR) {                                                                                                               \
-      const double2 li_ = reinterpret_cast<const double2*>(Linv + (size_t)(LMID) * 6)[l16 < 3 ? l16 : 2];                      \
-      const double zz_ = z[(size_t)(LMID) * 3 + ((l16 >= 3 && l16 < 6) ? l16 - 3 : 0)];                                        \
-      pc3 = l16 < 3 ? li_ : double2{zz_, 0.0};                                                                                \
-    } else pc3 = Cf_[min(l16 + 48, nc_)];                                                                                     \
+    if (NOCR) pc3 = reinterpret_cast<const double2*>(Linv + (size_t)(LMID) * kLmRec)[min(l16, 4)];   /* the landmark's record: Linv | z | pad */ \
+    else pc3 = Cf_[min(l16 + 48, nc_)];                                                                                       \
     pr0 = rf_[min(l16, nr_)];                                                                                                 \
     prec = (REC);                                                                                                             \
   }
@@ -229,8 +226,8 @@ __device__ __forceinline__ void pairs_band_kernel_body(const int bsg_bx, const i
       if (NOCR) {
         // what landmark_kernel's second pass wrote: C = B Linv^T (Linv lower triangular: i00 | i10 i11 | i20 i21 i22), rho = r - C z
         const double2* lz = sC + lmk * kBandStC + 48;
-        const double2 l0 = lz[0], l1 = lz[1], l2 = lz[2];
-        const double z0 = lz[3].x, z1 = lz[4].x, z2 = lz[5].x;
+        const double2 l0 = lz[0], l1 = lz[1], l2 = lz[2], z01 = lz[3];
+        const double z0 = z01.x, z1 = z01.y, z2 = lz[4].x;
         const double x0 = Ca[0], x1 = Ca[1], x2 = Ca[2], y0 = Cb[0], y1 = Cb[1], y2 = Cb[2];
         Ca[0] = x0 * l0.x; Ca[1] = x0 * l0.y + x1 * l1.x; Ca[2] = x0 * l1.y + x1 * l2.x + x2 * l2.y;
         Cb[0] = y0 * l0.x; Cb[1] = y0 * l0.y + y1 * l1.x; Cb[2] = y0 * l1.y + y1 * l2.x + y2 * l2.y;

@@ -161,9 +161,10 @@ __device__ __forceinline__ void landmark_kernel_body(const int bsg_bx, const int
   const double i20 = -(l20 * i00 + l21 * i10) * i22;
   const double z0 = i00 * b0, z1 = i10 * b0 + i11 * b1, z2 = i20 * b0 + i21 * b1 + i22 * b2;
   if (sub == 0) {
-    double* Lo = Linv_out + (size_t)l * 6;
+    double* Lo = Linv_out + (size_t)l * kLmRec;
     Lo[0] = i00; Lo[1] = i10; Lo[2] = i11; Lo[3] = i20; Lo[4] = i21; Lo[5] = i22;
-    z_out[3 * l] = z0; z_out[3 * l + 1] = z1; z_out[3 * l + 2] = z2;
+    double* zo = z_out + (size_t)l * kLmRec;
+    zo[0] = z0; zo[1] = z1; zo[2] = z2;
   }
   if (CR == nullptr) return;   // (Visual::no_cr: the pair phase and the back-substitution form C and rho themselves)
   for (int f = beg + sub; f < end; f += 8) {
@@ -598,9 +599,10 @@ __device__ __forceinline__ void backsub_mcc_kernel_body(const int bsg_bx, const 
     if (valid) { beg = lm_start[l]; end = lm_start[l + 1]; }
     // (what depends on the landmark alone is asked for with its range, not after the sums below: two trips off the dependent path)
     const int lc = valid ? l : 0;
-    const double* Li = Linv + (size_t)lc * 6;
+    const double* Li = Linv + (size_t)lc * kLmRec;
     const double Li0 = Li[0], Li1 = Li[1], Li2 = Li[2], Li3 = Li[3], Li4 = Li[4], Li5 = Li[5];
-    const double zl0 = z[3 * lc], zl1 = z[3 * lc + 1], zl2 = z[3 * lc + 2];
+    const double* zl = z + (size_t)lc * kLmRec;
+    const double zl0 = zl[0], zl1 = zl[1], zl2 = zl[2];
     double a0 = 0, a1 = 0, a2 = 0;
     // (A y_cam of the lane's first two factors stays in registers for the second pass: a track longer than 16 views is rare, and
     // recomputing it costs the row again plus a three-deep chain of dependent gathers — camera pose id, its tangent offsets, y)

@@ -134,6 +134,34 @@ def test_no_c_rows(oracle_cls, gpu_solver_cls, monkeypatch, flatten):
         assert a.step_is_successful == b.step_is_successful and abs(a.cost - b.cost) <= 1e-9 * b.cost
 
 
+def test_no_c_rows_lone_and_batched_steps_on_the_same_contexts(gpu_solver_cls, monkeypatch):
+    """The lone launches of an all-band window keep no C rows, the batched launches do (they pass the rows' buffer): contexts that go through a lone solve,
+    then a batched one, then a lone one again give what fresh contexts give for each — every step's landmark launch is the one its consumers expect."""
+    monkeypatch.setenv("BSGPU_PAIRS_BAND", "1")
+    cases = [synthetic.vio_window(n_kf=16, n_lm=700, seed=60 + i, track_min=2, track_max=10) for i in range(3)]
+    def fresh():
+        out = []
+        for pr in cases:
+            g = gpu_solver_cls(0); pr.load(g); out.append(g)
+        return out
+    gs = fresh()
+    opt = gs[0].options_vio(); opt.max_num_iterations = 4; opt.max_solver_time_in_seconds = 0.0
+    ref_lone = [(g.solve(opt).final_cost, g.get_blocks()) for g in fresh()]
+    ref_b = fresh()
+    ref_batch = [(s.final_cost, g.get_blocks()) for s, g in zip(gpu_solver_cls.solve_batch(ref_b, opt), ref_b)]
+    for (c0, x0), (c1, x1) in zip(ref_lone, ref_batch):
+        assert abs(c0 - c1) <= 1e-10 * c0 and np.abs(x0 - x1).max() < 1e-7
+    for rounds in range(2):
+        for g, (c0, x0) in zip(gs, ref_lone):            # lone (no C rows)
+            g.reset_values()
+            s = g.solve(opt)
+            assert abs(s.final_cost - c0) <= 1e-10 * c0 and np.abs(g.get_blocks() - x0).max() < 1e-7
+        for g in gs: g.reset_values()
+        sums = gpu_solver_cls.solve_batch(gs, opt)        # batched (C rows)
+        for g, s, (c1, x1) in zip(gs, sums, ref_batch):
+            assert abs(s.final_cost - c1) <= 1e-10 * c1 and np.abs(g.get_blocks() - x1).max() < 1e-7
+
+
 def test_size_rule(gpu_solver_cls, monkeypatch):
     """by itself the library takes the band form from kBandMinFactors reprojection factors on: the same solve either way at a size above it"""
     monkeypatch.delenv("BSGPU_PAIRS_BAND", raising=False)
