@@ -381,7 +381,7 @@ void launch_pairs(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row
                   bool grad_only, const SmallGroupSet* small = nullptr, int n_small_units = 0);
 bool band_available();   // the current device gives the band kernels their dynamic LDS (k_band.hip)
 void launch_pairs_band(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm,
-                       bool grad_only, const SmallGroupSet* small = nullptr, int n_small_units = 0);
+                       bool grad_only, const SmallGroupSet* small = nullptr, int n_small_units = 0, bool lower_only = false /* only the entries the tiled factorisation reads: on and below the diagonal in solver order */);
 int small_assemble_first_set(const SmallGroup* groups, int n_groups, SmallGroupSet* set, int* n_taken);
 void launch_small_assemble_set(hipStream_t s, const SmallGroup* groups, int n_groups, double* S, int ld, int rhs_row, double* grad,
                                double* hdiag, const int* perm);

@@ -324,7 +324,11 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
     const bool band = c->vis.n_band_units > 0;   // (band landmarks: k_band.hip; what does not qualify keeps its pair entries)
     if (c->vis.n_seg > 0 || band) units = small_assemble_first_set(c->small_factorwise + 2, kNumInternal - 2, &set, &taken);
     if (units == 0) taken = 0;
-    if (band) launch_pairs_band(s, c->vis, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_dpos, gradient_only, units > 0 ? &set : nullptr, units);
+    // (the band units add to the lower triangle only where the fused tiled factorisation is what reads the system next: enqueue_step's assemblies — the
+    //  covariance / marginalisation entry points, the PCG on the reduced system and the launch-per-step fallback get both triangles.  BSGPU_BAND_LOWER=0: always both)
+    static const bool lower_off = getenv("BSGPU_BAND_LOWER") && atoi(getenv("BSGPU_BAND_LOWER")) == 0;
+    const bool lower_only = !lower_off && factor_follows && !gradient_only && !c->use_spcg && !c->use_pcg && c->dense_ok && c->d_ftasks && c->d_fsync && c->d_tile_tot && c->d_Winv;
+    if (band) launch_pairs_band(s, c->vis, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_dpos, gradient_only, units > 0 ? &set : nullptr, units, lower_only);
     launch_pairs(s, c->vis, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_dpos, gradient_only, (units > 0 && !band) ? &set : nullptr, band ? 0 : units);
     phase_mark(c, BSGPU_PHASE_PAIRS);
     // (... or, without a pair launch, in the launch of the segment-wise assembled groups)

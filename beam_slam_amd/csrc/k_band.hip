@@ -251,7 +251,7 @@ __device__ __forceinline__ void pairs_band_kernel_body(const int bsg_bx, const i
     }
     const int top = __builtin_amdgcn_readfirstlane((sRec[0].y >> 16) & 0xff);   // span of the sub-batch's widest landmark (they are ordered by falling span)
     band_lds_sync();   // (Z is complete; every wave is done with the stage)
-    if (!grad_only) {
+    if (!(grad_only & 1)) {
       const int T = (6 * top + 15) >> 4;                        // tile rows that hold something (wave-uniform)
       int nact = 0;
 #pragma unroll
@@ -278,6 +278,14 @@ __device__ __forceinline__ void pairs_band_kernel_body(const int bsg_bx, const i
         if (v == 0.0) continue;
         const int pr = pos[16 * R + 4 * reg + kq], pc = pos[16 * C + i16];
         if (pr < 0 || pc < 0) continue;
+        if (grad_only & 2) {
+          // LOWER TRIANGLE ONLY (in solver order): what the tiled factorisation reads — tiles below the diagonal whole, of a diagonal tile the 16 x 16 blocks on
+          // and below its block diagonal, of those on it their lower triangles (chol_chain.h load_slot / elim_pivots; the update tasks' operands are tiles below
+          // the diagonal).  Half of a unit's adds went to places nothing reads, and the units' adds are a fifth of the launch (~120 G adds a second, all at its end).
+          if (R != C) atomicAdd(&S[(size_t)max(pr, pc) * ld + min(pr, pc)], -v);
+          else if (pr >= pc) atomicAdd(&S[(size_t)pr * ld + pc], -v);   // (a diagonal tile of the unit's block holds (a, b) and (b, a) itself)
+          continue;
+        }
         atomicAdd(&S[(size_t)pr * ld + pc], -v);
         if (R != C) atomicAdd(&S[(size_t)pc * ld + pr], -v);
       }
@@ -322,9 +330,12 @@ __device__ __forceinline__ void pairs_band_kernel_body(const int bsg_bx, const i
       const int b = idx - a * (a + 1) / 2;
       const int pa = pos[6 * slot + a], pb = pos[6 * slot + b];
       if (pa >= 0 && pb >= 0) {
-        atomicAdd(&S[(size_t)pa * ld + pb], total);
-        if (a != b) atomicAdd(&S[(size_t)pb * ld + pa], total);
-        else atomicAdd(&hdiag[tang(a)], total);
+        if (grad_only & 2) atomicAdd(&S[(size_t)max(pa, pb) * ld + min(pa, pb)], total);
+        else {
+          atomicAdd(&S[(size_t)pa * ld + pb], total);
+          if (a != b) atomicAdd(&S[(size_t)pb * ld + pa], total);
+        }
+        if (a == b) atomicAdd(&hdiag[tang(a)], total);
       }
     } else if (idx < 27) {
       const int pa = pos[6 * slot + idx - 21];
@@ -426,7 +437,7 @@ bool band_available() {
 static void band_attr_once() { (void)band_available(); }
 
 void launch_pairs_band(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm, bool grad_only,
-                       const SmallGroupSet* small, int n_small_units) {
+                       const SmallGroupSet* small, int n_small_units, bool lower_only) {
   if (v.n_band_units == 0) return;
   band_attr_once();
   SmallGroupSet none;
@@ -434,11 +445,11 @@ void launch_pairs_band(hipStream_t s, const Visual& v, double* S, int ld, int rh
   const int riders = small ? n_small_units : 0;
   if (v.no_cr)
     hipLaunchKernelGGL(pairs_band_nocr_kernel, dim3(riders + v.n_band_units), dim3(kBandThreads), kBandLds, s, v.n_band_units, v.band_unit_start, v.band_unit_cam, v.band_lm,
-                       v.n_cam_pose, v.J, v.r, v.JB, v.cp_tq, v.cp_tp, S, ld, rhs_row, grad, hdiag, perm, grad_only ? 1 : 0, small ? *small : none, riders, v.band_lm_id,
+                       v.n_cam_pose, v.J, v.r, v.JB, v.cp_tq, v.cp_tp, S, ld, rhs_row, grad, hdiag, perm, (grad_only ? 1 : 0) | (lower_only ? 2 : 0), small ? *small : none, riders, v.band_lm_id,
                        v.Linv, v.z);
   else
   hipLaunchKernelGGL(pairs_band_kernel, dim3(riders + v.n_band_units), dim3(kBandThreads), kBandLds, s, v.n_band_units, v.band_unit_start, v.band_unit_cam, v.band_lm,
-                     v.n_cam_pose, v.J, v.r, v.CR, v.cp_tq, v.cp_tp, S, ld, rhs_row, grad, hdiag, perm, grad_only ? 1 : 0, small ? *small : none, riders);
+                     v.n_cam_pose, v.J, v.r, v.CR, v.cp_tq, v.cp_tp, S, ld, rhs_row, grad, hdiag, perm, (grad_only ? 1 : 0) | (lower_only ? 2 : 0), small ? *small : none, riders);
 }
 void batchargs_pairs_band(BatchArgTable& t, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm, const SmallGroupSet* small,
                           int n_small_units) {
