@@ -188,6 +188,9 @@ struct bsgpu_ctx {
   double *d_delta = nullptr, *d_y = nullptr, *d_scal = nullptr, *d_part = nullptr;
   double* h_scal = nullptr;  // pinned
   double* h_scal_dev = nullptr;  // the same buffer as the device sees it (final_reduce mirrors the step's scalars there)
+  bool spec_dev = false;         // ... for an accepted step at the radius the DEVICE decided (LmDecide): adopted when the host's decision names the same
+  unsigned dec_count = 0;        // deciding launches so far (their bank of d_dec: the count's parity)
+  double* d_dec = nullptr;       // two banks of kDecSlots x kDecStride doubles: the decision of a riding reduction, for the workgroups and launches of the assembly ahead
   double spec_lm_radius = 0.0;   // != 0: the next step's assembly is in the queue already, for an accepted step at this radius (bsgpu_solve.cpp enqueue_step)
   bool spec_cand_arrays = false; // the evaluation ahead wrote its cost partials into the candidate's arrays (it replaced the cost-only pass)
   bool reduce_carried = false;   // assemble(): the reduction it was handed rode in one of its launches

@@ -210,14 +210,86 @@ BSG_DEV double block_sum_256(double v, double* smem /* >= 4 doubles */) {
 // (recording one costs the next kernel ~6 us of dispatch bubble): the LAST unit to finish — all host-side writes of a unit are thread 0's,
 // fenced at system scope before it takes its ticket — stamps the mirror with the launch's sequence number, which the host polls
 // (bsgpu_solve.cpp: fetch_scalars).
-BSG_DEV void final_reduce_done(double* host_scal, int* counter, double seq, int n_units) {
+// LmState::advance's decision for the step this reduction closes, in its arithmetic (lm_state.h; no contraction: the host's x86 code has none,
+// and pow(t, 3) as the correctly rounded cube): 1 = accepted, with the radius of the next step in *radius_out.  Anything else — an invalid
+// step, a tolerance reached, a rejected step — is 0 and left to the host.
+struct LmScal { double mcc, sn2, xn2, cand, cost_x, gmax, chol_fail, word /* (the decision's word on its way from thread 0 to the storing wave) */; };
+BSG_DEV void lm_load_scalars(const double* scal, LmScal& v) {
+  auto ld = [&](int i) { return __hip_atomic_load(&scal[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  v.mcc = ld(SC_MCC); v.sn2 = ld(SC_STEP_NORM2); v.xn2 = ld(SC_X_NORM2); v.cand = ld(SC_COST_CAND); v.cost_x = ld(SC_COST_X); v.gmax = ld(SC_GRAD_MAX);
+  v.chol_fail = ld(SC_CHOL_FAIL_SEEN);
+}
+BSG_DEV int lm_decide(const LmDecide& d, const LmScal& v, double* radius_out) {
+#pragma clang fp contract(off)
+  *radius_out = d.radius;
+  if (d.check_grad && v.gmax <= d.gradient_tolerance) return 0;
+  const double mcc = v.mcc, sn2 = v.sn2;
+  const bool lin_ok = !(v.chol_fail > 0.0) && isfinite(mcc) && isfinite(sn2);
+  if (!(lin_ok && mcc > 0.0)) return 0;
+  double cand = v.cand;
+  if (!isfinite(cand)) cand = 1.7976931348623157e308;
+  const double x_cost = d.x_from_scal ? v.cost_x : d.x_cost;
+  const double step_norm = sqrt(sn2), x_norm = sqrt(v.xn2);
+  if (step_norm <= d.parameter_tolerance * (x_norm + d.parameter_tolerance)) return 0;
+  const double cost_change = x_cost - cand;
+  if (fabs(cost_change) <= d.function_tolerance * x_cost) return 0;
+  const double rd = cost_change / mcc;
+  if (!(rd > d.min_relative_decrease)) return 0;
+  const double t = 2.0 * rd - 1.0;
+  // t^3, rounded once: t^2 and its product with t as exact sums of two doubles
+  const double t2 = t * t, e2 = __builtin_fma(t, t, -t2);
+  const double p = t2 * t, ep = __builtin_fma(t2, t, -p) + e2 * t;
+  const double cube = p + ep;
+  double r = d.radius / fmax(1.0 / 3.0, 1.0 - cube);
+  r = fmin(d.max_radius, r);
+  *radius_out = r;
+  return 1;
+}
+// ... and where it goes: the workgroups of this launch that wait for it and the launches behind it read ONE word per copy (the next radius,
+// negative when the step was not accepted; a waiting wave looks for anything but zero) — relaxed write-through stores and no fence (a release
+// at agent scope writes the L2 back: 64 of them made a C2 iteration 1.6 ms longer); the other bank, the next deciding launch's, is cleared
+// for it; the host's mirror gets both answers ahead of the stamp
+BSG_DEV double lm_decide_word(const ReduceRide& R, const LmScal& v) {
+  double radius;
+  const int go = lm_decide(R.lmd, v, &radius);
+  if (R.host_scal) { R.host_scal[SC_DEC_GO] = go ? 1.0 : 0.0; R.host_scal[SC_DEC_RADIUS] = radius; }
+  return go ? radius : -R.lmd.radius;
+}
+// lanes [lane0, lane0 + n_lanes) store the copies
+BSG_DEV void lm_publish_word(const ReduceRide& R, double word, int lane, int n_lanes) {
+  for (int k = lane; k < kDecSlots; k += n_lanes) __hip_atomic_store(&R.dec[(size_t)k * kDecStride], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int k = lane; k < kDecSlots; k += n_lanes) __hip_atomic_store(&R.dec_next[(size_t)k * kDecStride], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// decided: this unit was the reduction's last by construction (ReduceRide::only_slot: every other unit ran in an earlier launch), held the
+// step's scalars already and has decided before anything else (final_reduce_unit)
+BSG_DEV void final_reduce_done(const ReduceRide& R, int n_units, bool decided = false) {
+  double* host_scal = R.host_scal;
+  int* counter = R.counter;
   if (!counter) return;
+  const bool decides = R.lmd.on && R.dec != nullptr && !decided;
   __threadfence_system();
   const int prev = __hip_atomic_fetch_add(counter, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
   if (prev == n_units - 1) {
     __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (decides) {   // (every unit's scalar is in R.scal: each fenced before it took its ticket)
+      LmScal v;
+      lm_load_scalars(R.scal, v);
+      lm_publish_word(R, lm_decide_word(R, v), 0, 1);
+    }
     __threadfence_system();
-    if (host_scal) __hip_atomic_store(&host_scal[SC_SEQ], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (host_scal) __hip_atomic_store(&host_scal[SC_SEQ], R.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+// a wave of an assembly ahead waits for the decision of the reduction riding in its launch (copy `wave & 63`): the radius, or 0 when the
+// step was not accepted (or nothing came: bounded by the wall clock)
+BSG_DEV double wait_decision(const double* dec, int copy) {
+  const double* w = dec + (size_t)(copy & (kDecSlots - 1)) * kDecStride;
+  const unsigned long long t0 = wall_clock64();
+  for (int spin = 0;; ++spin) {
+    const double v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v != 0.0) return v > 0.0 ? v : 0.0;
+    __builtin_amdgcn_s_sleep(4);
+    if ((spin & 255) == 255 && wall_clock64() - t0 > 200000000ull) return 0.0;   // (2 s at 100 MHz)
   }
 }
 // NT threads (1024, or 256 = a rider of a 256-thread launch): a thread plays 1024 / NT of the kernel's 1024 threads one after the other,
@@ -225,17 +297,24 @@ BSG_DEV void final_reduce_done(double* host_scal, int* counter, double seq, int 
 template <int NT>
 BSG_DEV void final_reduce_unit(int slot, int tid, const ReduceRide& R, int n_units, double* sred) {
   constexpr int VT = 1024 / NT;
+  if (slot == R.defer_slot) return;   // (a later launch runs this unit — the last of the reduction: ReduceRide::only_slot there)
+  // (that launch's unit: it will decide, and asks for the other units' scalars — an earlier launch's — with its first loads)
+  // (they wait in LDS: held in registers over the sums they cost the carrying kernel a wave of occupancy per SIMD)
+  const bool early = R.lmd.on && R.dec != nullptr && R.only_slot >= 0 && R.counter != nullptr;
+  __shared__ LmScal s_pre;
+  if (early && tid == 0) { LmScal pre; lm_load_scalars(R.scal, pre); s_pre = pre; }
   if (slot == R.n_slots) {   // the scalars earlier kernels of the step produced (gradient norms, Cholesky flag, ...) -> host mirror
     if (tid == 0) {
       if (R.host_scal) for (int i = R.n_slots; i < SC_SEQ; ++i) R.host_scal[i] = R.scal[i];
       // (mirrored: the factorisation's flag of this step is cleared here for the next one — its clearing may have run already, in the
       //  launch that carried the candidate update, bsgpu_solve.cpp)
+      if (R.lmd.on) R.scal[SC_CHOL_FAIL_SEEN] = R.scal[SC_CHOL_FAIL];
       if (R.host_scal) R.scal[SC_CHOL_FAIL] = 0.0;
-      final_reduce_done(R.host_scal, R.counter, R.seq, n_units);
+      final_reduce_done(R, n_units);
     }
     return;
   }
-  if (slot == R.skip_slot) { if (tid == 0) final_reduce_done(R.host_scal, R.counter, R.seq, n_units); return; }
+  if (slot == R.skip_slot) { if (tid == 0) final_reduce_done(R, n_units); return; }
   double acc[VT];
 #pragma unroll
   for (int q = 0; q < VT; ++q) acc[q] = 0.0;
@@ -257,6 +336,26 @@ BSG_DEV void final_reduce_unit(int slot, int tid, const ReduceRide& R, int n_uni
     if (en.slot != slot) continue;
     any = true;
     if (en.op == 1) is_max = true;
+    if (en.op == 0 && en.n <= 4 * 1024) {
+      // (the usual size — a partial sum per workgroup of the producing launch: every stride of the 1024 virtual threads asked for at once, ONE
+      //  memory round trip per array instead of one per stride and virtual thread (seven in a row for C2's 1 566 cost partials), and the sums
+      //  formed exactly as the loops below form them: four strides pairwise when all four exist, else one after the other)
+      double pv[VT][4];
+#pragma unroll
+      for (int q = 0; q < VT; ++q)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = tid + NT * q + 1024 * u;
+          pv[q][u] = idx < en.n ? en.ptr[(size_t)idx * en.stride + en.offset] : 0.0;
+        }
+#pragma unroll
+      for (int q = 0; q < VT; ++q) {
+        const bool all4 = tid + NT * q + 3 * 1024 < en.n;
+        const double pairwise = (pv[q][0] + pv[q][1]) + (pv[q][2] + pv[q][3]), in_turn = (pv[q][0] + pv[q][1]) + pv[q][2];
+        acc[q] += all4 ? pairwise : in_turn;
+      }
+      continue;
+    }
 #pragma unroll
     for (int q = 0; q < VT; ++q) {
       // 1024 (virtual) threads, four independent partial sums each: with one, every load waits for the previous add — the per-factor array
@@ -296,7 +395,17 @@ BSG_DEV void final_reduce_unit(int slot, int tid, const ReduceRide& R, int n_uni
     // mirror in pinned host memory: the host reads the step's scalars right after the stream drains, without a
     // device-to-host copy of its own on the dependent path
     if (R.host_scal) R.host_scal[slot] = any ? t : R.scal[slot];
-    final_reduce_done(R.host_scal, R.counter, R.seq, n_units);
+    if (early) {
+      if (any && slot == SC_COST_CAND) s_pre.cand = t;
+      if (any && slot == SC_COST_X) s_pre.cost_x = t;
+      s_pre.word = lm_decide_word(R, s_pre);
+    } else
+      final_reduce_done(R, n_units);
+  }
+  if (early) {   // (the copies leave from a whole wave, then the mirror's fences and stamp)
+    __syncthreads();
+    if (tid < 64) lm_publish_word(R, s_pre.word, tid, 64);
+    if (tid == 0) final_reduce_done(R, n_units, true);
   }
 }
 

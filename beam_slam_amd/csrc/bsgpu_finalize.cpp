@@ -1162,6 +1162,8 @@ int finalize(bsgpu_ctx* c) {
     c->d_reduce = c->upload(tab);
     c->d_reduce_counter = c->alloc<int>(1);
     if (c->d_reduce_counter) HIPCHK(c, hipMemsetAsync(c->d_reduce_counter, 0, sizeof(int), c->stream));
+    c->d_dec = c->alloc<double>(2 * (size_t)kDecSlots * kDecStride);
+    if (c->d_dec) HIPCHK(c, hipMemsetAsync(c->d_dec, 0, sizeof(double) * 2 * kDecSlots * kDecStride, c->stream));
   }
   lap("plan + reduce table");
   HIPCHK(c, hipDeviceSynchronize());

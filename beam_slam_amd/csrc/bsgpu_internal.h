@@ -60,7 +60,10 @@ enum {
   SC_GRAD_NORM2 = 6,
   SC_CHOL_FAIL = 7,  // > 0 when a pivot was not positive / finite
   SC_FIXED_COST = 8,
+  SC_CHOL_FAIL_SEEN = 9,  // SC_CHOL_FAIL as the riding reduction mirrored it (which then clears the flag): what the decision on the device reads
   SC_RADIUS = 12,    // trust-region radius of the step being computed (written by the host before each step)
+  SC_DEC_GO = 13,    // (host mirror) the decision taken on the device for the step this reduction closes: 1 = accepted, 0 = anything else (LmDecide)
+  SC_DEC_RADIUS = 14,  // (host mirror) ... and the radius of the step after it
   SC_SEQ = 15,       // (host mirror only) sequence number of the end-of-step reduction that filled the mirror
   SC_NUM = 16
 };
@@ -207,6 +210,25 @@ struct ReduceEntry {
   int op = 0;   // 0: sum, 1: maximum (of non-negative values)
 };
 
+// The decision of LmState::advance (lm_state.h) for the common case, taken on the device by the LAST unit of a riding reduction so that the
+// assembly issued ahead of the host's decision (bsgpu_solve.cpp enqueue_step) runs at the radius the host WILL name instead of a guessed
+// one: "accepted" + the next radius, or "anything else" (invalid step, a tolerance reached, rejected) — then the assembly's workgroups
+// return at once.  The host still decides (same arithmetic, bit for bit) and adopts the assembly only if it names the same radius; what is
+// passed in is the state BEFORE the decision, which the host knows when it enqueues the launch.
+struct LmDecide {
+  int on = 0;
+  int check_grad = 0;     // the step was computed at a NEW point: its gradient tolerance test comes first (LmState::advance, top of the loop)
+  int x_from_scal = 0;    // the cost at the current point is SC_COST_X of this reduction (else x_cost below: the cost the host holds)
+  double radius = 0.0, x_cost = 0.0;
+  double min_relative_decrease = 0.0, max_radius = 0.0, function_tolerance = 0.0, parameter_tolerance = 0.0, gradient_tolerance = 0.0;
+};
+// the decision: ONE word — the next radius, negative when the step was not accepted, zero while there is none — in 64 copies a cache line apart
+// (the polling wave of workgroup w reads copy `w & 255`; 4 160 bytes apart: spread over the memory channels — the pollers' loads are device-coherent
+// and go past the L2s), in two banks that consecutive deciding launches take in turn (a launch's decision clears the other)
+constexpr int kDecSlots = 256, kDecStride = 520;
+// a launch of an assembly ahead that returns at once unless the decision on the device was "accepted": p[0] > 0
+struct GoWord { const double* p = nullptr; };
+
 // the end-of-step reduction (k_misc.hip final_reduce_kernel) as units of work of another launch: n_slots + 1 units
 struct ReduceRide {
   const ReduceEntry* entries = nullptr;
@@ -214,6 +236,12 @@ struct ReduceRide {
   double* scal = nullptr; double* host_scal = nullptr; int* counter = nullptr;
   double seq = 0.0;
   int skip_slot = -1;   // a slot whose partial arrays the carrying launch itself rewrites: left alone (its unit only counts itself in)
+  int defer_slot = -1;  // this launch leaves that slot's unit to a later launch (which carries it alone: only_slot) — the partial arrays it sums
+                        // are written by THIS launch; every other unit runs here, and the deferred one is the reduction's last
+  int only_slot = -1;
+  double* dec = nullptr;   // kDecSlots x kDecStride doubles: where the last unit leaves the decision (lmd.on)
+  double* dec_next = nullptr;   // ... and the bank it clears for the next deciding launch
+  LmDecide lmd;
 };
 
 struct LaunchCtx {
@@ -378,10 +406,11 @@ void launch_landmark(hipStream_t s, const Visual& v, int n_pose, const double* r
                      int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* scale, double* dcl,
                      double* grad, const ZeroStep* zero = nullptr, double radius_val = 0.0, const ReduceRide* red = nullptr /* the step before's end-of-step reduction as the launch's first workgroups */);
 void launch_pairs(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm,
-                  bool grad_only, const SmallGroupSet* small = nullptr, int n_small_units = 0);
+                  bool grad_only, const SmallGroupSet* small = nullptr, int n_small_units = 0, GoWord go = GoWord());
 bool band_available();   // the current device gives the band kernels their dynamic LDS (k_band.hip)
 void launch_pairs_band(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm,
-                       bool grad_only, const SmallGroupSet* small = nullptr, int n_small_units = 0, bool lower_only = false /* only the entries the tiled factorisation reads: on and below the diagonal in solver order */);
+                       bool grad_only, const SmallGroupSet* small = nullptr, int n_small_units = 0, bool lower_only = false /* only the entries the tiled factorisation reads: on and below the diagonal in solver order */,
+                       GoWord go = GoWord());
 int small_assemble_first_set(const SmallGroup* groups, int n_groups, SmallGroupSet* set, int* n_taken);
 void launch_small_assemble_set(hipStream_t s, const SmallGroup* groups, int n_groups, double* S, int ld, int rhs_row, double* grad,
                                double* hdiag, const int* perm);

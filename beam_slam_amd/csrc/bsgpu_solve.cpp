@@ -295,6 +295,11 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
   zs.a = c->d_grad; zs.na = c->n_pose; zs.b = c->d_hdiag; zs.nb = c->n_pose;
   zs.c = new_J ? c->d_scal + SC_GRAD_MAX : c->d_scal + SC_CHOL_FAIL; zs.nc = new_J ? 3 : 1;
   zs.radius_slot = c->use_graphs ? nullptr : c->d_scal + SC_RADIUS; zs.radius = radius;
+  // (an assembly ahead whose radius the reduction riding in its landmark launch decides — LmDecide: `radius` is not the step's, and the launches
+  //  behind the landmark launch return at once unless that decision was "accepted")
+  const bool dev_decides = red != nullptr && red->lmd.on && red->dec != nullptr && c->vis.n_lm > 0;
+  GoWord go;
+  if (dev_decides) { zs.radius_slot = nullptr; go.p = red->dec; }
   // (with landmarks and eager launches the clearing rides in the landmark launch: independent work, one launch less on the path)
   const bool merged = c->vis.n_lm > 0 && !c->use_graphs;
   // (a window without Euclidean landmarks clears at the END of a step, in the launch that carries the candidate update: the next
@@ -328,8 +333,8 @@ void assemble(bsgpu_ctx* c, const bsgpu_options& o, double radius, bool new_J, b
     //  covariance / marginalisation entry points, the PCG on the reduced system and the launch-per-step fallback get both triangles.  BSGPU_BAND_LOWER=0: always both)
     static const bool lower_off = getenv("BSGPU_BAND_LOWER") && atoi(getenv("BSGPU_BAND_LOWER")) == 0;
     const bool lower_only = !lower_off && factor_follows && !gradient_only && !c->use_spcg && !c->use_pcg && c->dense_ok && c->d_ftasks && c->d_fsync && c->d_tile_tot && c->d_Winv;
-    if (band) launch_pairs_band(s, c->vis, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_dpos, gradient_only, units > 0 ? &set : nullptr, units, lower_only);
-    launch_pairs(s, c->vis, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_dpos, gradient_only, (units > 0 && !band) ? &set : nullptr, band ? 0 : units);
+    if (band) launch_pairs_band(s, c->vis, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_dpos, gradient_only, units > 0 ? &set : nullptr, units, lower_only, go);
+    launch_pairs(s, c->vis, c->d_S, c->npad, c->plan.rhs_row, c->d_grad, c->d_hdiag, c->d_dpos, gradient_only, (units > 0 && !band) ? &set : nullptr, band ? 0 : units, go);
     phase_mark(c, BSGPU_PHASE_PAIRS);
     // (... or, without a pair launch, in the launch of the segment-wise assembled groups)
     SmallGroupSet set2;
@@ -521,14 +526,23 @@ void linear_solve_and_candidate(bsgpu_ctx* c, const bsgpu_options& o, bool defer
 // landmark launch: stamp over PCIe, LmState::advance, one launch — scripts/small_gaps.sh).  Nothing is decided on the device: the next step
 // takes the assembly as its own when the decision is "accepted, at that radius" (bit for bit), and assembles again otherwise — the
 // landmark launch clears what the assembly adds into and rewrites all else it wrote.
-void enqueue_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius, bool gradient_only = false, double radius_ahead = 0.0) {
+// lmd (with radius_ahead > 0): the decision is ALSO taken on the device, by the reduction that rides in the landmark launch of the assembly
+// ahead (LmDecide, bsgpu_device.h lm_decide): that assembly runs at the radius the host will name — there is no guess to miss — or returns at
+// once; radius_ahead itself is then only "an assembly ahead is wanted".  What a large window gains is the candidate's cost-only pass (C2: 9.7 us
+// and a launch boundary per iteration), which the smaller windows' guessed assemblies had shed already.
+void enqueue_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius, bool gradient_only = false, double radius_ahead = 0.0, const LmDecide* lmd = nullptr) {
   hipStream_t s = c->stream;
   c->cost_x_stale = false;   // (set below only for a step whose reduction rides in the evaluation ahead: a gradient-only step's full reduction gives SC_COST_X)
   // an assembly ahead that the decision did not confirm has rewritten the LM diagonal's clamped H_jj (and the gradient norms' inputs) from
   // the CANDIDATE's Jacobians: this step recomputes them from the current point's (the same bits as before)
-  const bool assembled_ahead = kind == STEP_ACCEPT && !gradient_only && c->spec_lm_radius == radius && radius > 0.0;
+  // (... or, decided on the device: the mirror of the reduction the host has just read says "accepted", at this radius bit for bit)
+  const bool dev_confirmed = c->spec_dev && c->h_scal[SC_DEC_GO] == 1.0 && c->h_scal[SC_DEC_RADIUS] == radius;
+  const bool assembled_ahead = kind == STEP_ACCEPT && !gradient_only && radius > 0.0 && (c->spec_lm_radius == radius || dev_confirmed);
   const bool ahead_unconfirmed = c->spec_dirty && !assembled_ahead;
-  c->spec_lm_radius = 0.0; c->spec_dirty = false;
+  if (assembled_ahead && dev_confirmed) c->lm_diag.inv_radius = 1.0 / radius;   // (the assembly configured the LM diagonal's tasks with a placeholder)
+  if (getenv("BSGPU_TIMING") && c->spec_dev && !assembled_ahead)
+    fprintf(stderr, "[bsgpu] device decision not adopted: host kind %d radius %.17g, device go %g radius %.17g\n", kind, radius, c->h_scal[SC_DEC_GO], c->h_scal[SC_DEC_RADIUS]);
+  c->spec_lm_radius = 0.0; c->spec_dirty = false; c->spec_dev = false;
   if (kind == STEP_ACCEPT) {
     // the accepted candidate becomes the current point: a pointer swap (every launch takes x as an argument; the next update
     // rewrites all of the other buffer) — except under graph replay, whose kernel arguments are frozen
@@ -555,9 +569,12 @@ void enqueue_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius,
   //  and thrown away every iteration, or the host would read a zeroed gradient norm)
   const bool diag_can_ride = c->plan.diag_tasks && c->plan.rider_tasks * 256 >= c->nb && c->d_ftasks && c->d_fsync && c->d_tile_tot && c->d_Winv;
   const bool mirror_ok = c->h_scal_dev != nullptr && c->d_reduce_counter != nullptr && c->n_reduce > 0;
-  const bool ahead = radius_ahead > 0.0 && !c->use_graphs && !c->use_pcg && !c->use_spcg && c->dense_ok && c->n_pose > 0 && c->idp.n_lm == 0 &&
-                     diag_can_ride && mirror_ok;
-  const bool one_pass = ahead && !one_pass_off && reduce_can_ride(c) && (c->vis.n_lm > 0 || (c->n_sa_seg + c->n_asm_grp > 0 && marg_rider(c) < 0));
+  bool ahead = radius_ahead > 0.0 && !c->use_graphs && !c->use_pcg && !c->use_spcg && c->dense_ok && c->n_pose > 0 && c->idp.n_lm == 0 &&
+               diag_can_ride && mirror_ok;
+  bool one_pass = ahead && !one_pass_off && reduce_can_ride(c) && (c->vis.n_lm > 0 || (c->n_sa_seg + c->n_asm_grp > 0 && marg_rider(c) < 0));
+  // (the decision on the device rides in the landmark launch of a one-pass assembly: without one there is no assembly ahead at all — radius_ahead is no guess)
+  const bool dev = lmd != nullptr && lmd->on;
+  if (dev && !(one_pass && c->vis.n_lm > 0 && c->d_dec != nullptr)) ahead = one_pass = false;
   // (not on the first step: the reduction that rides cannot give the cost at x — the launch that carries it rewrites those partials — and
   //  only the first step's is read: after an accepted step the cost at x is the candidate's cost the host already holds)
   const bool ride = !gradient_only && kind != STEP_FIRST && !one_pass && reduce_rides(c);
@@ -570,17 +587,37 @@ void enqueue_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius,
     hipEvent_t* const prof = c->prof_events;   // (bsgpu_profile_step times the step up to here: this evaluation belongs to the next one)
     c->prof_events = nullptr;
     if (one_pass) {
-      eval_all(c, c->d_xcand, true, SC_COST_CAND);
-      c->spec_J = true; c->spec_cand_arrays = true;
       ReduceRide r;
       c->reduce_seq += 1.0;
       r.entries = c->d_reduce; r.n_entries = c->n_reduce; r.n_slots = SC_GRAD_NORM2 + 1; r.scal = c->d_scal; r.host_scal = c->h_scal_dev; r.counter = c->d_reduce_counter;
       r.seq = c->reduce_seq; r.skip_slot = -1;
+      // With the decision on the device the reduction is split: only the candidate's cost waits for the evaluation — every other unit rides in the
+      // evaluation's launch (as under `ride`), and the landmark launch carries that one unit, which finds the others' scalars done and decides two
+      // memory round trips into the launch (all eight units there: the decision came 18 us into a 15 us launch, behind the landmark waves' loads).
+      static const bool split_off = getenv("BSGPU_LM_DEVICE_SPLIT") && atoi(getenv("BSGPU_LM_DEVICE_SPLIT")) == 0;
+      const bool split = dev && !split_off && reduce_rides(c);
+      if (split) {
+        ReduceRide re = r;
+        re.defer_slot = SC_COST_CAND; re.lmd.on = 1;   // (its mirror unit keeps the factorisation's flag for the decision: SC_CHOL_FAIL_SEEN)
+        eval_all(c, c->d_xcand, true, SC_COST_CAND, &re);
+        r.only_slot = SC_COST_CAND;
+      } else
+        eval_all(c, c->d_xcand, true, SC_COST_CAND);
+      c->spec_J = true; c->spec_cand_arrays = true;
+      if (dev) {
+        const int bank = (c->dec_count++) & 1;   // (consecutive deciding launches take the two banks in turn: each clears the other's)
+        r.dec = c->d_dec + (size_t)bank * kDecSlots * kDecStride; r.dec_next = c->d_dec + (size_t)(bank ^ 1) * kDecSlots * kDecStride;
+        r.lmd = *lmd;
+        r.lmd.radius = radius;
+        r.lmd.check_grad = kind != STEP_REJECT ? 1 : 0;                            // (a new point: LmState::advance tests its gradient first)
+        r.lmd.x_from_scal = (kind != STEP_REJECT && !c->cost_x_stale) ? 1 : 0;      // (else lmd->x_cost: the cost the host holds for this step's point)
+      }
       assemble(c, o, radius_ahead, /*new_J=*/true, /*first=*/false, /*gradient_only=*/false, /*factor_follows=*/true, &r);
       if (c->reduce_carried) { c->scal_mirrored = true; c->seq_pending = true; c->ev_reduce_pending = false; }
       else { c->reduce_seq -= 1.0; final_reduce(c); }   // (no launch of this window's assembly takes it: a launch of its own)
       c->spec_dirty = true;
-      c->spec_lm_radius = c->diag_in_chol ? radius_ahead : 0.0;
+      c->spec_lm_radius = (c->diag_in_chol && !dev) ? radius_ahead : 0.0;
+      c->spec_dev = c->diag_in_chol && dev && c->reduce_carried;
       c->prof_events = prof;
       return;
     }
@@ -685,7 +722,7 @@ void build_graphs(bsgpu_ctx* c, const bsgpu_options& o) {
   if (getenv("BSGPU_TIMING")) fprintf(stderr, "[bsgpu] LM step captured as hipGraphs\n");
 }
 
-void run_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius, bool gradient_only = false, double radius_ahead = 0.0) {
+void run_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius, bool gradient_only = false, double radius_ahead = 0.0, const LmDecide* lmd = nullptr) {
   if (c->use_graphs) {   // replayed kernels read the radius from device memory
     *c->h_radius = radius;
     (void)hipMemcpyAsync(c->d_scal + SC_RADIUS, c->h_radius, sizeof(double), hipMemcpyHostToDevice, c->stream);
@@ -696,7 +733,7 @@ void run_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius, boo
     (void)hipGetLastError();
     c->graphs_ok = false;   // fall back to eager launches of the same kernels
   }
-  enqueue_step(c, o, kind, radius, gradient_only, radius_ahead);
+  enqueue_step(c, o, kind, radius, gradient_only, radius_ahead, lmd);
 }
 
 // sorted visual position -> source factor: built on the host, or downloaded on first use when the device flattened the window
@@ -780,7 +817,7 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
   HIPCHK(c, hipSetDevice(c->device));
   std::memset(&sum, 0, sizeof(sum));
   c->iters.clear();
-  c->spec_lm_radius = 0.0; c->spec_dirty = false;
+  c->spec_lm_radius = 0.0; c->spec_dirty = false; c->spec_dev = false;
   sum.num_parameters_tangent = c->n_tan;
   sum.num_residuals = c->n_res;
   c->use_pcg = (o.linear_solver_type == BSGPU_LINEAR_PCG) || (o.linear_solver_type == BSGPU_LINEAR_AUTO && !c->dense_ok);
@@ -814,14 +851,23 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
   // (the radius of LmState::advance for a relative decrease above 0.937, in its own arithmetic: r / (1/3) is not 3 r in every last bit)
   // ... and only while the guesses hold: after a step that did not end "accepted, at the guessed radius" (a pose graph's early steps, C2's
   // fifth to seventh) the next assembly waits for the decision again, until a step ends that way
+  // Windows above those sizes: the assembly ahead at the radius the DEVICE decides (enqueue_step, LmDecide) — no guess that can miss, and the
+  // candidate's cost-only pass goes.  BSGPU_LM_DEVICE=0: never, 1: on the smaller windows too (instead of their guesses).
+  static const int dev_env = getenv("BSGPU_LM_DEVICE") ? atoi(getenv("BSGPU_LM_DEVICE")) : -1;
+  const bool lm_dev = (dev_env >= 0 ? dev_env != 0 : !lm_ahead) && ahead_env != 0 && c->vis.n_lm > 0 && c->d_dec != nullptr && !c->use_graphs && !c->use_pcg && !c->use_spcg;
+  LmDecide lmd;
+  lmd.on = lm_dev ? (getenv("BSGPU_LM_DEVICE_NOWAIT") ? 2 : 1) : 0;   // (2: a timing probe — the landmark waves do not wait, the assembly is never adopted)
+  lmd.min_relative_decrease = o.min_relative_decrease; lmd.max_radius = o.max_trust_region_radius; lmd.function_tolerance = o.function_tolerance;
+  lmd.parameter_tolerance = o.parameter_tolerance; lmd.gradient_tolerance = o.gradient_tolerance;
   bool guess_held = true;
   double rel_prev = 0.0, rel_last = 0.0;   // relative cost changes of the last two accepted steps
   double guessed = 0.0;   // what the step in flight was guessed to end at (0: nothing was guessed)
   auto radius_ahead = [&](double r) {
     guessed = std::min(o.max_trust_region_radius, r / std::max(1.0 / 3.0, 0.0));
+    if (lm_dev) return r > o.min_trust_region_radius ? r : 0.0;   // (no guess: "an assembly ahead is wanted")
     return (lm_ahead && guess_held && !c->use_graphs && !c->use_pcg) ? guessed : 0.0;
   };
-  run_step(c, o, STEP_FIRST, lm.radius, false, radius_ahead(lm.radius));
+  run_step(c, o, STEP_FIRST, lm.radius, false, radius_ahead(lm.radius), lm_dev ? &lmd : nullptr);
   rc = fetch_scalars(c);
   if (rc != BSGPU_OK) { (void)pcg_check(c); return rc; }
   bool pcg_redo = !pcg_check(c);
@@ -845,7 +891,8 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
     if (lm.it.step_is_successful && lm.it.iteration > 0) { rel_prev = rel_last; rel_last = std::fabs(lm.it.cost_change) / std::max(1e-300, std::fabs(lm.x_cost)); }
     const bool likely_last = lm.it.iteration + 1 >= o.max_num_iterations ||
                              (rel_prev > 0.0 && rel_last * std::min(1.0, rel_last / rel_prev) < 4.0 * o.function_tolerance);
-    run_step(c, o, lm.kind, lm.radius, lm.grad_only, (lm.grad_only || likely_last) ? 0.0 : radius_ahead(lm.radius));
+    lmd.x_cost = lm.kind == STEP_REJECT ? lm.x_cost : lm.cand_cost;   // (the cost at the point this step is computed at, where the host holds it: enqueue_step)
+    run_step(c, o, lm.kind, lm.radius, lm.grad_only, (lm.grad_only || likely_last) ? 0.0 : radius_ahead(lm.radius), lm_dev ? &lmd : nullptr);
     rc = fetch_scalars(c);
     if (rc != BSGPU_OK) { (void)pcg_check(c); return rc; }
     pcg_redo = !pcg_check(c);
@@ -857,7 +904,7 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
   float ms = 0.f;
   (void)hipEventElapsedTime(&ms, ev0, ev1);
   sum.device_time_in_seconds = ms * 1e-3;
-  c->scal_mirrored = false; c->ev_reduce_pending = false; c->spec_J = false; c->spec_lm_radius = 0.0; c->spec_dirty = false;   // (the stream has drained: nothing of this solve is pending)
+  c->scal_mirrored = false; c->ev_reduce_pending = false; c->spec_J = false; c->spec_lm_radius = 0.0; c->spec_dirty = false; c->spec_dev = false;   // (the stream has drained: nothing of this solve is pending)
   sum.num_inner_iterations = c->pcg_iters_total;
   sum.total_time_in_seconds = elapsed();
   return BSGPU_OK;

@@ -347,11 +347,13 @@ __device__ __forceinline__ void pairs_band_kernel_body(const int bsg_bx, const i
   }
 }
 
-__global__ __launch_bounds__(kBandThreads) void pairs_band_kernel(int n_units, const int* __restrict__ unit_start, const int* __restrict__ unit_cam, const int4* __restrict__ band_lm, int n_cam_pose, const double* __restrict__ J, const double2* __restrict__ r, const double* __restrict__ CR, const int* __restrict__ cp_tq, const int* __restrict__ cp_tp, double* __restrict__ S, int ld, int rhs_row, double* __restrict__ grad, double* __restrict__ hdiag, const int* __restrict__ perm, int grad_only, SmallGroupSet small, int n_small_units) {
+__global__ __launch_bounds__(kBandThreads) void pairs_band_kernel(int n_units, const int* __restrict__ unit_start, const int* __restrict__ unit_cam, const int4* __restrict__ band_lm, int n_cam_pose, const double* __restrict__ J, const double2* __restrict__ r, const double* __restrict__ CR, const int* __restrict__ cp_tq, const int* __restrict__ cp_tp, double* __restrict__ S, int ld, int rhs_row, double* __restrict__ grad, double* __restrict__ hdiag, const int* __restrict__ perm, int grad_only, SmallGroupSet small, int n_small_units, GoWord go) {
+  if (go.p && !(__hip_atomic_load(go.p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0.0)) return;   // (an assembly ahead whose step was not accepted)
   pairs_band_kernel_body((int)blockIdx.x, (int)gridDim.x, n_units, unit_start, unit_cam, band_lm, n_cam_pose, J, r, CR, cp_tq, cp_tp, S, ld, rhs_row, grad, hdiag, perm, grad_only, small, n_small_units);
 }
 // ... without C rows (Visual::no_cr): the landmark parts of the Jacobian rows instead, and the landmarks' Linv and z
-__global__ __launch_bounds__(kBandThreads) void pairs_band_nocr_kernel(int n_units, const int* __restrict__ unit_start, const int* __restrict__ unit_cam, const int4* __restrict__ band_lm, int n_cam_pose, const double* __restrict__ J, const double2* __restrict__ r, const double* __restrict__ JB, const int* __restrict__ cp_tq, const int* __restrict__ cp_tp, double* __restrict__ S, int ld, int rhs_row, double* __restrict__ grad, double* __restrict__ hdiag, const int* __restrict__ perm, int grad_only, SmallGroupSet small, int n_small_units, const int* __restrict__ lm_id, const double* __restrict__ Linv, const double* __restrict__ z) {
+__global__ __launch_bounds__(kBandThreads) void pairs_band_nocr_kernel(int n_units, const int* __restrict__ unit_start, const int* __restrict__ unit_cam, const int4* __restrict__ band_lm, int n_cam_pose, const double* __restrict__ J, const double2* __restrict__ r, const double* __restrict__ JB, const int* __restrict__ cp_tq, const int* __restrict__ cp_tp, double* __restrict__ S, int ld, int rhs_row, double* __restrict__ grad, double* __restrict__ hdiag, const int* __restrict__ perm, int grad_only, SmallGroupSet small, int n_small_units, const int* __restrict__ lm_id, const double* __restrict__ Linv, const double* __restrict__ z, GoWord go) {
+  if (go.p && !(__hip_atomic_load(go.p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0.0)) return;
   pairs_band_kernel_body<true>((int)blockIdx.x, (int)gridDim.x, n_units, unit_start, unit_cam, band_lm, n_cam_pose, J, r, JB, cp_tq, cp_tp, S, ld, rhs_row, grad, hdiag, perm, grad_only, small, n_small_units, lm_id, Linv, z);
 }
 // one launch over several windows (bsgpu_batch.cpp): blockIdx.y picks the window of list `bsg_list`, its arguments come from memory
@@ -437,7 +439,7 @@ bool band_available() {
 static void band_attr_once() { (void)band_available(); }
 
 void launch_pairs_band(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm, bool grad_only,
-                       const SmallGroupSet* small, int n_small_units, bool lower_only) {
+                       const SmallGroupSet* small, int n_small_units, bool lower_only, GoWord go) {
   if (v.n_band_units == 0) return;
   band_attr_once();
   SmallGroupSet none;
@@ -446,10 +448,10 @@ void launch_pairs_band(hipStream_t s, const Visual& v, double* S, int ld, int rh
   if (v.no_cr)
     hipLaunchKernelGGL(pairs_band_nocr_kernel, dim3(riders + v.n_band_units), dim3(kBandThreads), kBandLds, s, v.n_band_units, v.band_unit_start, v.band_unit_cam, v.band_lm,
                        v.n_cam_pose, v.J, v.r, v.JB, v.cp_tq, v.cp_tp, S, ld, rhs_row, grad, hdiag, perm, (grad_only ? 1 : 0) | (lower_only ? 2 : 0), small ? *small : none, riders, v.band_lm_id,
-                       v.Linv, v.z);
+                       v.Linv, v.z, go);
   else
   hipLaunchKernelGGL(pairs_band_kernel, dim3(riders + v.n_band_units), dim3(kBandThreads), kBandLds, s, v.n_band_units, v.band_unit_start, v.band_unit_cam, v.band_lm,
-                     v.n_cam_pose, v.J, v.r, v.CR, v.cp_tq, v.cp_tp, S, ld, rhs_row, grad, hdiag, perm, (grad_only ? 1 : 0) | (lower_only ? 2 : 0), small ? *small : none, riders);
+                     v.n_cam_pose, v.J, v.r, v.CR, v.cp_tq, v.cp_tp, S, ld, rhs_row, grad, hdiag, perm, (grad_only ? 1 : 0) | (lower_only ? 2 : 0), small ? *small : none, riders, go);
 }
 void batchargs_pairs_band(BatchArgTable& t, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm, const SmallGroupSet* small,
                           int n_small_units) {

@@ -89,7 +89,7 @@ void launch_reproj_errors(hipStream_t s, const Visual& v, const SmallGroup& dens
 // Jacobi scaling (Ceres: s = 1/(1+sqrt(H_jj)) from iteration 0) and the LM diagonal are folded into
 // lambda_j = clamp(s_j^2 H_jj, lo, hi) / (radius s_j^2) on the unscaled system.
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void landmark_kernel_body(const int bsg_bx, const int bsg_gx, int n_lm, const int* __restrict__ lm_start, const double* __restrict__ JB, const double2* __restrict__ r, int n_pose, const double* __restrict__ radius_ptr, int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* __restrict__ scale, double* __restrict__ dcl, double* __restrict__ grad, double* __restrict__ Linv_out, double* __restrict__ z_out, double* __restrict__ CR, int lm_blocks, ZeroStep zs, double radius_val) {
+__device__ __forceinline__ void landmark_kernel_body(const int bsg_bx, const int bsg_gx, int n_lm, const int* __restrict__ lm_start, const double* __restrict__ JB, const double2* __restrict__ r, int n_pose, const double* __restrict__ radius_ptr, int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* __restrict__ scale, double* __restrict__ dcl, double* __restrict__ grad, double* __restrict__ Linv_out, double* __restrict__ z_out, double* __restrict__ CR, int lm_blocks, ZeroStep zs, double radius_val, const double* dec = nullptr) {
   if (bsg_bx >= lm_blocks) {
     // the step's clearing (tiles of S the assembly writes, pose gradient, diag(J^T J), the step's scalars, the radius slot) as extra
     // workgroups of this launch: nothing here is read or written by the landmark workgroups (they get the radius as an argument),
@@ -113,7 +113,6 @@ __device__ __forceinline__ void landmark_kernel_body(const int bsg_bx, const int
   const int gid = bsg_bx * 256 + threadIdx.x;
   const int l = gid >> 3, sub = gid & 7;
   const bool valid = l < n_lm;
-  const double inv_radius = 1.0 / (radius_ptr ? radius_ptr[0] : radius_val);   // (device-resident under graph replay, whose arguments are frozen)
   int beg = 0, end = 0;
   if (valid) { beg = lm_start[l]; end = lm_start[l + 1]; }
   double h00 = 0, h01 = 0, h02 = 0, h11 = 0, h12 = 0, h22 = 0, b0 = 0, b1 = 0, b2 = 0;
@@ -133,7 +132,22 @@ __device__ __forceinline__ void landmark_kernel_body(const int bsg_bx, const int
     h11 += __shfl_xor(h11, o, 8); h12 += __shfl_xor(h12, o, 8); h22 += __shfl_xor(h22, o, 8);
     b0 += __shfl_xor(b0, o, 8); b1 += __shfl_xor(b1, o, 8); b2 += __shfl_xor(b2, o, 8);
   }
+  // the radius: an argument; device-resident under graph replay, whose arguments are frozen; or — an assembly ahead of the host's decision —
+  // what the reduction riding in this launch's first workgroups decides (bsgpu_device.h lm_decide): waited for here, behind the loads and
+  // the sums (the workgroup's first wave looks, the others wait at the barrier), and nothing is written when the step it closes was not accepted
+  double radius_now = radius_ptr ? radius_ptr[0] : radius_val;
+  if (dec) {
+    __shared__ double s_radius;
+    if (threadIdx.x < 64) {
+      const double rr = wait_decision(dec, bsg_bx);
+      if (threadIdx.x == 0) s_radius = rr;
+    }
+    __syncthreads();
+    radius_now = s_radius;
+    if (!(radius_now > 0.0)) return;
+  }
   if (!valid) return;
+  const double inv_radius = 1.0 / radius_now;
   const int to = n_pose + 3 * l;
   const double hd[3] = {h00, h11, h22};
   double lam[3];
@@ -186,14 +200,16 @@ __global__ __launch_bounds__(256) void landmark_kernel(int n_lm, const int* __re
 // ... with the end-of-step reduction of the step BEFORE as its first workgroups: the landmark launch of an assembly issued ahead of the host's
 // decision (bsgpu_solve.cpp enqueue_step) follows the evaluation of the candidate with Jacobians, which has left the candidate's cost
 // partials — the reduction rides here instead of in that evaluation, and the cost-only pass at the candidate is not needed
-__global__ __launch_bounds__(256) void landmark_reduce_kernel(ReduceRide red, int n_lm, const int* __restrict__ lm_start, const double* __restrict__ JB, const double2* __restrict__ r, int n_pose, const double* __restrict__ radius_ptr, int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* __restrict__ scale, double* __restrict__ dcl, double* __restrict__ grad, double* __restrict__ Linv_out, double* __restrict__ z_out, double* __restrict__ CR, int lm_blocks, ZeroStep zs, double radius_val) {
-  const int n_units = red.n_slots + 1;
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void landmark_reduce_kernel(ReduceRide red, int n_lm, const int* __restrict__ lm_start, const double* __restrict__ JB, const double2* __restrict__ r, int n_pose, const double* __restrict__ radius_ptr, int compute_scale, int compute_dcl, int jacobi, double lm_lo, double lm_hi, double* __restrict__ scale, double* __restrict__ dcl, double* __restrict__ grad, double* __restrict__ Linv_out, double* __restrict__ z_out, double* __restrict__ CR, int lm_blocks, ZeroStep zs, double radius_val) {
+  // (only_slot: the reduction's other units rode in the evaluation in front of this launch; the one whose partial sums that evaluation wrote is here, alone)
+  const int n_units = red.only_slot >= 0 ? 1 : red.n_slots + 1;
   if ((int)blockIdx.x < n_units) {
     __shared__ double sred[16];
-    final_reduce_unit<256>((int)blockIdx.x, (int)threadIdx.x, red, n_units, sred);
+    final_reduce_unit<256>(red.only_slot >= 0 ? red.only_slot : (int)blockIdx.x, (int)threadIdx.x, red, red.n_slots + 1, sred);
     return;
   }
-  landmark_kernel_body((int)blockIdx.x - n_units, (int)gridDim.x - n_units, n_lm, lm_start, JB, r, n_pose, radius_ptr, compute_scale, compute_dcl, jacobi, lm_lo, lm_hi, scale, dcl, grad, Linv_out, z_out, CR, lm_blocks, zs, radius_val);
+  landmark_kernel_body((int)blockIdx.x - n_units, (int)gridDim.x - n_units, n_lm, lm_start, JB, r, n_pose, radius_ptr, compute_scale, compute_dcl, jacobi, lm_lo, lm_hi, scale, dcl, grad, Linv_out, z_out, CR, lm_blocks, zs, radius_val,
+                       (red.lmd.on && red.lmd.on != 2) ? red.dec : nullptr);
 }
 // one launch over several windows (bsgpu_batch.cpp): blockIdx.y picks the window of list `bsg_list`, its arguments come from memory
 struct landmark_kernel_Args {
@@ -304,7 +320,7 @@ void launch_landmark(hipStream_t s, const Visual& v, int n_pose, const double* r
     const int grid = (v.n_lm * 8 + 255) / 256;
     const int zero_blocks = zero ? std::max(1, std::min(zero->n_tiles, 1024)) : 0;
     if (red && red->n_entries > 0)
-      hipLaunchKernelGGL(landmark_reduce_kernel, dim3(red->n_slots + 1 + grid + zero_blocks), dim3(256), 0, s, *red, v.n_lm, v.lm_start, v.JB, v.r, n_pose, radius_ptr,
+      hipLaunchKernelGGL(landmark_reduce_kernel, dim3((red->only_slot >= 0 ? 1 : red->n_slots + 1) + grid + zero_blocks), dim3(256), 0, s, *red, v.n_lm, v.lm_start, v.JB, v.r, n_pose, radius_ptr,
                          compute_scale, compute_dcl, jacobi, lm_lo, lm_hi, scale, dcl, grad, v.Linv, v.z, v.no_cr ? nullptr : v.CR, grid, zero ? *zero : ZeroStep(),
                          radius_val);
     else
@@ -473,7 +489,8 @@ __device__ __forceinline__ void pairs_kernel_body(const int bsg_bx, const int bs
     }
   }
 }
-__global__ __launch_bounds__(64) void pairs_kernel(int n_seg, const int* __restrict__ seg_ci, const int* __restrict__ seg_cj, const int* __restrict__ seg_start, const int* __restrict__ ent_fa, const int* __restrict__ ent_fb, const double* __restrict__ J, const double2* __restrict__ r, const double* __restrict__ CR, const int* __restrict__ cp_tq, const int* __restrict__ cp_tp, double* __restrict__ S, int ld, int rhs_row, double* __restrict__ grad, double* __restrict__ hdiag, const int* __restrict__ perm, int grad_only, int n_pair_blocks, SmallGroupSet small, int n_small_units) {
+__global__ __launch_bounds__(64) void pairs_kernel(int n_seg, const int* __restrict__ seg_ci, const int* __restrict__ seg_cj, const int* __restrict__ seg_start, const int* __restrict__ ent_fa, const int* __restrict__ ent_fb, const double* __restrict__ J, const double2* __restrict__ r, const double* __restrict__ CR, const int* __restrict__ cp_tq, const int* __restrict__ cp_tp, double* __restrict__ S, int ld, int rhs_row, double* __restrict__ grad, double* __restrict__ hdiag, const int* __restrict__ perm, int grad_only, int n_pair_blocks, SmallGroupSet small, int n_small_units, GoWord go) {
+  if (go.p && !(__hip_atomic_load(go.p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0.0)) return;   // (an assembly ahead whose step was not accepted)
   pairs_kernel_body((int)blockIdx.x, (int)gridDim.x, n_seg, seg_ci, seg_cj, seg_start, ent_fa, ent_fb, J, r, CR, cp_tq, cp_tp, S, ld, rhs_row, grad, hdiag, perm, grad_only, n_pair_blocks, small, n_small_units);
 }
 // one launch over several windows (bsgpu_batch.cpp): blockIdx.y picks the window of list `bsg_list`, its arguments come from memory
@@ -538,7 +555,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 
 constexpr size_t kPairsLds = sizeof(double2) * 64 * (6 + 6 + 4 + 3) + sizeof(int) * 128;
 void launch_pairs(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row, double* grad, double* hdiag, const int* perm,
-                  bool grad_only, const SmallGroupSet* small, int n_small_units) {
+                  bool grad_only, const SmallGroupSet* small, int n_small_units, GoWord go) {
   if (v.n_seg == 0) return;
   const int pair_blocks = 8 * ((v.n_seg + 7) / 8);
   SmallGroupSet none;
@@ -546,7 +563,7 @@ void launch_pairs(hipStream_t s, const Visual& v, double* S, int ld, int rhs_row
   const int small_blocks = small ? 8 * ((n_small_units * kPairRiderParts + 7) / 8) : 0;   // (padded: idle workgroups return at once)
   hipLaunchKernelGGL(pairs_kernel, dim3(pair_blocks + small_blocks), dim3(64), kPairsLds, s, v.n_seg, v.seg_ci, v.seg_cj, v.seg_start, v.ent_fa,
                      v.ent_fb, v.J, v.r, v.CR, v.cp_tq, v.cp_tp, S, ld, rhs_row, grad, hdiag, perm, grad_only ? 1 : 0, pair_blocks, small ? *small : none,
-                     small_blocks);
+                     small_blocks, go);
 }
 
 // ---------------------------------------------------------------------------------------------------
