@@ -854,9 +854,12 @@ int solve(bsgpu_ctx* c, const bsgpu_options& o, bsgpu_summary& sum) {
   // Windows above those sizes: the assembly ahead at the radius the DEVICE decides (enqueue_step, LmDecide) — no guess that can miss, and the
   // candidate's cost-only pass goes.  BSGPU_LM_DEVICE=0: never, 1: on the smaller windows too (instead of their guesses).
   static const int dev_env = getenv("BSGPU_LM_DEVICE") ? atoi(getenv("BSGPU_LM_DEVICE")) : -1;
-  const bool lm_dev = (dev_env >= 0 ? dev_env != 0 : !lm_ahead) && ahead_env != 0 && c->vis.n_lm > 0 && c->d_dec != nullptr && !c->use_graphs && !c->use_pcg && !c->use_spcg;
+  const bool dev_possible = dev_env != 0 && ahead_env != 0 && c->vis.n_lm > 0 && c->d_dec != nullptr && !c->use_graphs && !c->use_pcg && !c->use_spcg;
+  // (a smaller window whose last guess missed waits for the host's decision until a step ends as guessed again; the device deciding for it
+  //  meanwhile measured the same — scripts/rejected_steps.py, 50 KF x 5 000 with four rejected steps in twenty: 6 700 LM it/s either way)
+  const bool lm_dev = dev_possible && (dev_env > 0 || !lm_ahead);
   LmDecide lmd;
-  lmd.on = lm_dev ? (getenv("BSGPU_LM_DEVICE_NOWAIT") ? 2 : 1) : 0;   // (2: a timing probe — the landmark waves do not wait, the assembly is never adopted)
+  lmd.on = dev_possible ? (getenv("BSGPU_LM_DEVICE_NOWAIT") ? 2 : 1) : 0;   // (2: a timing probe — the landmark waves do not wait, the assembly is never adopted)
   lmd.min_relative_decrease = o.min_relative_decrease; lmd.max_radius = o.max_trust_region_radius; lmd.function_tolerance = o.function_tolerance;
   lmd.parameter_tolerance = o.parameter_tolerance; lmd.gradient_tolerance = o.gradient_tolerance;
   bool guess_held = true;
