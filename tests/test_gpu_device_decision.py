@@ -45,16 +45,17 @@ print("RESULT " + json.dumps(out))
 """
 
 
-def _run(dev):
-    env = dict(os.environ, BSGPU_LM_DEVICE=str(dev), BSGPU_TIMING="1")
+def _run(dev, split=1):
+    env = dict(os.environ, BSGPU_LM_DEVICE=str(dev), BSGPU_TIMING="1", BSGPU_LM_DEVICE_SPLIT=str(split))
     p = subprocess.run([sys.executable, "-c", SCRIPT % ROOT], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1]
     return json.loads(line[len("RESULT "):]), p.stderr
 
 
-def test_device_decision_changes_no_iteration_and_is_adopted():
-    (a, _), (b, err) = _run(0), _run(1)
+@pytest.mark.parametrize("split", [1, 0])   # 0: all eight units of the reduction in the landmark launch, its last one decides (windows whose evaluation carries no reduction)
+def test_device_decision_changes_no_iteration_and_is_adopted(split):
+    (a, _), (b, err) = _run(0), _run(1, split)
     assert len(a) == len(b) == 5
     kinds = set()
     for ra, rb in zip(a, b):
