@@ -487,6 +487,9 @@ def main():
             if kernels:
                 out["kernels"] = kernels
             out["phases_us_per_lm_step"] = phases
+            out["phases_note"] = ("bsgpu_profile_step enqueues accepted steps WITHOUT an assembly ahead: 'candidate' holds the cost-only pass at the candidate, which a solve of a "
+                                  "window of >= 150 000 reprojection factors no longer runs on accepted steps (the decision is also taken on the device and the candidate is evaluated "
+                                  "once, with Jacobians: DESIGN.md 9 (4)); a solve's own per-iteration time is ms_per_step / lm_iterations_per_solve")
         if args.workload == "c4":
             out["pcg"] = pcg
         if cons is not None:
