@@ -5,6 +5,7 @@
 
 #include "../../include/bsgpu.h"
 #include "bsgpu_internal.h"
+#include "lm_decide.h"
 
 namespace bsg {
 
@@ -210,40 +211,11 @@ BSG_DEV double block_sum_256(double v, double* smem /* >= 4 doubles */) {
 // (recording one costs the next kernel ~6 us of dispatch bubble): the LAST unit to finish — all host-side writes of a unit are thread 0's,
 // fenced at system scope before it takes its ticket — stamps the mirror with the launch's sequence number, which the host polls
 // (bsgpu_solve.cpp: fetch_scalars).
-// LmState::advance's decision for the step this reduction closes, in its arithmetic (lm_state.h; no contraction: the host's x86 code has none,
-// and pow(t, 3) as the correctly rounded cube): 1 = accepted, with the radius of the next step in *radius_out.  Anything else — an invalid
-// step, a tolerance reached, a rejected step — is 0 and left to the host.
-struct LmScal { double mcc, sn2, xn2, cand, cost_x, gmax, chol_fail, word /* (the decision's word on its way from thread 0 to the storing wave) */; };
+// LmState::advance's decision for the step this reduction closes: lm_decide.h (host- and device-compilable; tested on the CPU against LmState itself)
 BSG_DEV void lm_load_scalars(const double* scal, LmScal& v) {
   auto ld = [&](int i) { return __hip_atomic_load(&scal[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   v.mcc = ld(SC_MCC); v.sn2 = ld(SC_STEP_NORM2); v.xn2 = ld(SC_X_NORM2); v.cand = ld(SC_COST_CAND); v.cost_x = ld(SC_COST_X); v.gmax = ld(SC_GRAD_MAX);
   v.chol_fail = ld(SC_CHOL_FAIL_SEEN);
-}
-BSG_DEV int lm_decide(const LmDecide& d, const LmScal& v, double* radius_out) {
-#pragma clang fp contract(off)
-  *radius_out = d.radius;
-  if (d.check_grad && v.gmax <= d.gradient_tolerance) return 0;
-  const double mcc = v.mcc, sn2 = v.sn2;
-  const bool lin_ok = !(v.chol_fail > 0.0) && isfinite(mcc) && isfinite(sn2);
-  if (!(lin_ok && mcc > 0.0)) return 0;
-  double cand = v.cand;
-  if (!isfinite(cand)) cand = 1.7976931348623157e308;
-  const double x_cost = d.x_from_scal ? v.cost_x : d.x_cost;
-  const double step_norm = sqrt(sn2), x_norm = sqrt(v.xn2);
-  if (step_norm <= d.parameter_tolerance * (x_norm + d.parameter_tolerance)) return 0;
-  const double cost_change = x_cost - cand;
-  if (fabs(cost_change) <= d.function_tolerance * x_cost) return 0;
-  const double rd = cost_change / mcc;
-  if (!(rd > d.min_relative_decrease)) return 0;
-  const double t = 2.0 * rd - 1.0;
-  // t^3, rounded once: t^2 and its product with t as exact sums of two doubles
-  const double t2 = t * t, e2 = __builtin_fma(t, t, -t2);
-  const double p = t2 * t, ep = __builtin_fma(t2, t, -p) + e2 * t;
-  const double cube = p + ep;
-  double r = d.radius / fmax(1.0 / 3.0, 1.0 - cube);
-  r = fmin(d.max_radius, r);
-  *radius_out = r;
-  return 1;
 }
 // ... and where it goes: the workgroups of this launch that wait for it and the launches behind it read ONE word per copy (the next radius,
 // negative when the step was not accepted; a waiting wave looks for anything but zero) — relaxed write-through stores and no fence (a release

@@ -18,6 +18,7 @@
 
 #include "../../include/bsgpu.h"
 #include "bsgpu_internal.h"
+#include "lm_decide.h"
 
 namespace bsg {
 
@@ -131,7 +132,7 @@ struct LmState {
       it.relative_decrease = (x_cost - cand_cost) / mcc;
       const bool last_iteration = it.iteration >= o->max_num_iterations;
       if (it.relative_decrease > o->min_relative_decrease) {
-        radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * it.relative_decrease - 1.0, 3));
+        radius = radius / std::max(1.0 / 3.0, 1.0 - lm_cube(2.0 * it.relative_decrease - 1.0));   // ([EXT] pow(2 rho - 1, 3): lm_decide.h lm_cube, shared with the device's decision)
         radius = std::min(o->max_trust_region_radius, radius);
         decrease_factor = 2.0;
         it.step_is_successful = 1;
