@@ -231,6 +231,7 @@ struct bsgpu_ctx {
   hipEvent_t ev_reduce = nullptr;   // recorded after the end-of-step reduction: what the host waits for (work may be queued behind it)
   hipEvent_t ev_solve0 = nullptr, ev_solve1 = nullptr;   // bsgpu_solve's timing events (created on first use)
   bool ev_reduce_pending = false;
+  std::vector<ReduceEntry> h_reduce;   // the reduction table as uploaded (d_reduce): a deciding unit takes its arrays from here, in the launch's arguments
   int* d_reduce_counter = nullptr;  // final_reduce_kernel's ticket (the last workgroup stamps the host mirror with reduce_seq)
   double reduce_seq = 0.0;          // sequence number of the last end-of-step reduction enqueued
   bool seq_pending = false;         // ... and the host may poll for it instead of waiting for an event

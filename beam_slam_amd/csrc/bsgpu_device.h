@@ -297,13 +297,55 @@ BSG_DEV void final_reduce_unit(int slot, int tid, const ReduceRide& R, int n_uni
   static_assert(sizeof(ReduceEntry) == 32, "ReduceEntry");
   __shared__ __attribute__((aligned(16))) unsigned long long s_ent_raw[kEntMax * 4];   // (ReduceEntry has a member initialiser: raw storage)
   ReduceEntry* s_ent = reinterpret_cast<ReduceEntry*>(s_ent_raw);
-  const bool staged = R.n_entries <= kEntMax;
+  // The deciding unit of a split reduction (ReduceRide::only_slot) with its arrays in the arguments: every load it needs leaves NOW — the seven
+  // scalars above, the one larger array's sixteen strides, a value of each small array — and the sums are formed as the walk below forms them
+  // (an array of <= 4 096 values: pairwise / in turn per virtual thread; of <= NT values: the value itself, to virtual thread `tid`).  With the
+  // table staged and three arrays walked one after the other the word left 14 us into a 16 us landmark launch: four round trips in the
+  // launch's own 52 MB.
+  const bool from_args = early && R.n_early > 0 && R.n_early <= 4;
+  if (from_args) {
+    double pv[VT][4], tv[4];
+    int big = -1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      tv[k] = 0.0;
+      if (k >= R.n_early) continue;
+      const ReduceEntry& en = R.early[k];
+      if (en.n > NT) {
+        big = k;
+#pragma unroll
+        for (int q = 0; q < VT; ++q)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int idx = tid + NT * q + 1024 * u;
+            pv[q][u] = idx < en.n ? en.ptr[(size_t)idx * en.stride + en.offset] : 0.0;
+          }
+      } else
+        tv[k] = tid < en.n ? en.ptr[(size_t)tid * en.stride + en.offset] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k >= R.n_early) continue;
+      if (k == big) {
+        const int nb = R.early[k].n;
+#pragma unroll
+        for (int q = 0; q < VT; ++q) {
+          const bool all4 = tid + NT * q + 3 * 1024 < nb;
+          const double pairwise = (pv[q][0] + pv[q][1]) + (pv[q][2] + pv[q][3]), in_turn = (pv[q][0] + pv[q][1]) + pv[q][2];
+          acc[q] += all4 ? pairwise : in_turn;
+        }
+      } else
+        acc[0] += tv[k];
+    }
+    any = true;
+  }
+  const bool staged = !from_args && R.n_entries <= kEntMax;
   if (staged) {
     const unsigned long long* src = reinterpret_cast<const unsigned long long*>(R.entries);
     for (int e = tid; e < 4 * R.n_entries; e += NT) s_ent_raw[e] = src[e];
     __syncthreads();
   }
-  for (int e = 0; e < R.n_entries; ++e) {
+  for (int e = 0; e < (from_args ? 0 : R.n_entries); ++e) {
     const ReduceEntry en = staged ? s_ent[e] : R.entries[e];
     if (en.slot != slot) continue;
     any = true;

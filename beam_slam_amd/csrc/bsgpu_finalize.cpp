@@ -1160,6 +1160,7 @@ int finalize(bsgpu_ctx* c) {
     tab.push_back({c->d_part_upd, c->n_part_upd, 2, 1, SC_X_NORM2});
     c->n_reduce = (int)tab.size();
     c->d_reduce = c->upload(tab);
+    c->h_reduce = tab;
     c->d_reduce_counter = c->alloc<int>(1);
     if (c->d_reduce_counter) HIPCHK(c, hipMemsetAsync(c->d_reduce_counter, 0, sizeof(int), c->stream));
     c->d_dec = c->alloc<double>(2 * (size_t)kDecSlots * kDecStride);

@@ -239,6 +239,11 @@ struct ReduceRide {
   int defer_slot = -1;  // this launch leaves that slot's unit to a later launch (which carries it alone: only_slot) — the partial arrays it sums
                         // are written by THIS launch; every other unit runs here, and the deferred one is the reduction's last
   int only_slot = -1;
+  // (only_slot's partial arrays, in the table's order, in the kernel's ARGUMENTS — the unit asks for all of them with its first loads instead of
+  //  staging the table and walking it, an array per memory round trip, underneath the carrying launch's own traffic: at most one of more than
+  //  `256` values (<= 4 096), the others of at most 256.  n_early = 0: the table)
+  ReduceEntry early[4];
+  int n_early = 0;
   double* dec = nullptr;   // kDecSlots x kDecStride doubles: where the last unit leaves the decision (lmd.on)
   double* dec_next = nullptr;   // ... and the bank it clears for the next deciding launch
   LmDecide lmd;

@@ -601,6 +601,17 @@ void enqueue_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius,
         re.defer_slot = SC_COST_CAND; re.lmd.on = 1;   // (its mirror unit keeps the factorisation's flag for the decision: SC_CHOL_FAIL_SEEN)
         eval_all(c, c->d_xcand, true, SC_COST_CAND, &re);
         r.only_slot = SC_COST_CAND;
+        // (its arrays in the launch's arguments when they fit the unit's one-trip form: at most four, sums, one of up to 4 096 values, the others of up to 256)
+        static const bool args_off = getenv("BSGPU_LM_DEVICE_ARGS") && atoi(getenv("BSGPU_LM_DEVICE_ARGS")) == 0;
+        int ne = 0, n_big = 0;
+        bool fits = !args_off;
+        for (const ReduceEntry& en : c->h_reduce) {
+          if (en.slot != SC_COST_CAND) continue;
+          if (ne == 4 || en.op != 0 || en.n > 4096) { fits = false; break; }
+          if (en.n > 256) ++n_big;
+          r.early[ne++] = en;
+        }
+        r.n_early = (fits && n_big <= 1) ? ne : 0;
       } else
         eval_all(c, c->d_xcand, true, SC_COST_CAND);
       c->spec_J = true; c->spec_cand_arrays = true;
