@@ -430,7 +430,7 @@ def main():
             kernels = []
             band = os.environ.get("BSGPU_PAIRS_BAND", "1") != "0" and pr.n_factors(0) >= 150000
             for name, kern, pmc_name in (("landmark", "landmark_kernel (+ the step's clearing of S, gradient and diag(H))", "bsg::landmark_kernel"),
-                                         ("pairs", "pairs_band_kernel" if band else "pairs_kernel", "bsg::pairs_band_kernel" if band else "bsg::pairs_kernel"),
+                                         ("pairs", "pairs_band_nocr_kernel / pairs_band_kernel (WRITE_SIZE counts its FP64 atomic adds at 32 B each)" if band else "pairs_kernel", "bsg::pairs_band" if band else "bsg::pairs_kernel"),
                                          ("backsub", "backsub_mcc_kernel (+ small_mcc)", "bsg::backsub_mcc_kernel"),
                                          ("candidate", "update + visual_imu_eval_kernel<false> / reproj_eval_kernel<false> + reduction", None)):
                 ms_k, by = prof[name]
