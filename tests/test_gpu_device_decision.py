@@ -23,8 +23,13 @@ import numpy as np
 from beam_slam_amd import synthetic
 from beam_slam_amd.gpu import GpuSolver
 out = []
-for case in range(5):
-    pr = synthetic.vio_window(n_kf=12 + 4 * case, n_lm=150 + 100 * case, seed=5200 + case, cauchy_a=[None, 5.0][case %% 2])
+for case in range(7):
+    if case == 5:
+        pr = synthetic.vio_window(n_kf=40, n_lm=900, seed=5205, track_min=2, track_max=20)   # band landmarks AND pair entries (tracks longer than the band): both launches look at the word
+    elif case == 6:
+        pr = synthetic.vio_window(n_kf=16, n_lm=500, seed=5206, with_imu=False)              # no IMU factors: no evaluation launch that carries a reduction — all eight units in the landmark launch
+    else:
+        pr = synthetic.vio_window(n_kf=12 + 4 * case, n_lm=150 + 100 * case, seed=5200 + case, cauchy_a=[None, 5.0][case %% 2])
     g = GpuSolver(0); pr.load(g)
     o = g.options_vio(); o.max_solver_time_in_seconds = 0.0
     if case == 1:
@@ -46,7 +51,7 @@ print("RESULT " + json.dumps(out))
 
 
 def _run(dev, split=1):
-    env = dict(os.environ, BSGPU_LM_DEVICE=str(dev), BSGPU_TIMING="1", BSGPU_LM_DEVICE_SPLIT=str(split))
+    env = dict(os.environ, BSGPU_LM_DEVICE=str(dev), BSGPU_TIMING="1", BSGPU_LM_DEVICE_SPLIT=str(split), BSGPU_PAIRS_BAND="1")   # (the band form whatever the size: what the large windows the mode is for take)
     p = subprocess.run([sys.executable, "-c", SCRIPT % ROOT], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1]
@@ -56,7 +61,7 @@ def _run(dev, split=1):
 @pytest.mark.parametrize("split", [1, 0])   # 0: all eight units of the reduction in the landmark launch, its last one decides (windows whose evaluation carries no reduction)
 def test_device_decision_changes_no_iteration_and_is_adopted(split):
     (a, _), (b, err) = _run(0), _run(1, split)
-    assert len(a) == len(b) == 5
+    assert len(a) == len(b) == 7
     kinds = set()
     for ra, rb in zip(a, b):
         assert ra["n"] == rb["n"] and len(ra["its"]) == len(rb["its"]) and ra["msg"] == rb["msg"]
