@@ -378,6 +378,11 @@ struct pairs_band_kernel_Args {
   int grad_only;
   SmallGroupSet small;
   int n_small_units;
+  // (Visual::no_cr — all null otherwise: the landmark parts of the Jacobian rows, the band records' landmarks, their Linv | z records)
+  const double* JB;
+  const int* lm_id;
+  const double* Linv;
+  const double* z;
 };
 // (the same entry as the kernel reads it: its pointers are GLOBAL pointers — read as generic ones every load through them would be a FLAT
 // instruction, which also counts against the LDS counter and serialises the kernels that overlap gathers with LDS traffic)
@@ -402,6 +407,10 @@ struct pairs_band_kernel_ArgsG {
   int grad_only;
   SmallGroupSet small;
   int n_small_units;
+  const double __attribute__((address_space(1)))* JB;
+  const int __attribute__((address_space(1)))* lm_id;
+  const double __attribute__((address_space(1)))* Linv;
+  const double __attribute__((address_space(1)))* z;
 };
 static_assert(sizeof(pairs_band_kernel_ArgsG) == sizeof(pairs_band_kernel_Args), "layout");
 
@@ -409,6 +418,10 @@ __global__ __launch_bounds__(kBandThreads) void pairs_band_kernel_batch(const pa
   const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
   const pairs_band_kernel_ArgsG& a = reinterpret_cast<const pairs_band_kernel_ArgsG*>(bsg_A)[bsg_w];
   if ((int)blockIdx.x >= a.bsg_grid) return;
+  // (a window without C rows — Visual::no_cr — forms them from B, Linv and z as its lone launch does)
+  if (a.Linv)
+    pairs_band_kernel_body<true>((int)blockIdx.x, a.bsg_grid, a.n_units, (const int*)a.unit_start, (const int*)a.unit_cam, (const int4*)a.band_lm, a.n_cam_pose, (const double*)a.J, (const double2*)a.r, (const double*)a.JB, (const int*)a.cp_tq, (const int*)a.cp_tp, (double*)a.S, a.ld, a.rhs_row, (double*)a.grad, (double*)a.hdiag, (const int*)a.perm, bsg_dyn->grad_only[bsg_w], a.small, a.n_small_units, (const int*)a.lm_id, (const double*)a.Linv, (const double*)a.z);
+  else
   pairs_band_kernel_body((int)blockIdx.x, a.bsg_grid, a.n_units, (const int*)a.unit_start, (const int*)a.unit_cam, (const int4*)a.band_lm, a.n_cam_pose, (const double*)a.J, (const double2*)a.r, (const double*)a.CR, (const int*)a.cp_tq, (const int*)a.cp_tp, (double*)a.S, a.ld, a.rhs_row, (double*)a.grad, (double*)a.hdiag, (const int*)a.perm, bsg_dyn->grad_only[bsg_w], a.small, a.n_small_units);
 }
 
@@ -463,6 +476,7 @@ void batchargs_pairs_band(BatchArgTable& t, const Visual& v, double* S, int ld, 
   a.n_units = v.n_band_units; a.unit_start = v.band_unit_start; a.unit_cam = v.band_unit_cam; a.band_lm = v.band_lm; a.n_cam_pose = v.n_cam_pose;
   a.J = v.J; a.r = v.r; a.CR = v.CR; a.cp_tq = v.cp_tq; a.cp_tp = v.cp_tp; a.S = S; a.ld = ld; a.rhs_row = rhs_row; a.grad = grad; a.hdiag = hdiag; a.perm = perm;
   a.grad_only = 0; a.small = small ? *small : none; a.n_small_units = riders;
+  a.JB = v.no_cr ? v.JB : nullptr; a.lm_id = v.no_cr ? v.band_lm_id : nullptr; a.Linv = v.no_cr ? v.Linv : nullptr; a.z = v.no_cr ? v.z : nullptr;
   t.push(a);
 }
 void launch_pairs_band_batch(hipStream_t s, const BatchArgTable& t, const BatchDyn* dyn, int list, int n) {

@@ -768,7 +768,7 @@ void batchargs_landmark(BatchArgTable& t, BatchArgTable& t_tail, const Visual& v
   const int grid = (v.n_lm * 8 + 255) / 256, zero_blocks = std::max(1, std::min(zero.n_tiles, 1024));
   a.bsg_grid = v.n_lm > 0 ? grid + zero_blocks : 0;
   a.n_lm = v.n_lm; a.lm_start = v.lm_start; a.JB = v.JB; a.r = v.r; a.n_pose = n_pose; a.radius_ptr = nullptr; a.compute_scale = 0; a.compute_dcl = 0;
-  a.jacobi = jacobi; a.lm_lo = lm_lo; a.lm_hi = lm_hi; a.scale = scale; a.dcl = dcl; a.grad = grad; a.Linv_out = v.Linv; a.z_out = v.z; a.CR = v.CR;
+  a.jacobi = jacobi; a.lm_lo = lm_lo; a.lm_hi = lm_hi; a.scale = scale; a.dcl = dcl; a.grad = grad; a.Linv_out = v.Linv; a.z_out = v.z; a.CR = v.no_cr ? nullptr : v.CR;   // (Visual::no_cr: no second pass, as in the lone launch)
   a.lm_blocks = grid; a.zs = zero; a.radius_val = 0.0;
   t.push(a);
   landmark_tail_kernel_Args b;
@@ -805,7 +805,7 @@ void batchargs_backsub_mcc(BatchArgTable& t, const Visual& v, int n_pose, const 
   const int extra = small ? (n_small_units + 1) / 2 : 0;
   const int upd_units = (upd && upd->n_blocks > 0) ? (upd->n_blocks + 255) / 256 : 0;
   a.bsg_grid = grid > 0 ? grid + extra + upd_units : 0;
-  a.n_lm = v.n_lm; a.n_lm_groups = g_lm; a.n_elim = v.n_elim; a.n = v.n; a.lm_start = v.lm_start; a.J = v.J; a.JB = v.JB; a.r = v.r; a.CR = v.CR; a.cam_pose = v.cam_pose;
+  a.n_lm = v.n_lm; a.n_lm_groups = g_lm; a.n_elim = v.n_elim; a.n = v.n; a.lm_start = v.lm_start; a.J = v.J; a.JB = v.JB; a.r = v.r; a.CR = v.no_cr ? nullptr : v.CR; a.cam_pose = v.cam_pose;
   a.cp_tq = v.cp_tq; a.cp_tp = v.cp_tp; a.Linv = v.Linv; a.z = v.z; a.n_pose = n_pose; a.y_pose = y_pose; a.delta = delta; a.mcc_part = mcc_part; a.n_vis_blocks = grid;
   a.small = small ? *small : SmallGroupSet(); a.n_small_units = small ? n_small_units : 0; a.up = upd_units ? *upd : UpdateRide(); a.first_update_block = grid + extra;
   t.push(a);
