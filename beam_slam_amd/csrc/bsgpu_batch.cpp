@@ -125,6 +125,10 @@ struct BatchPlan {
   BatchArgTable t_lm, t_lm_tail, t_zero, t_pairs, t_pairs_band, t_asm_set, t_asm_seg, t_gn, t_chol, t_bs[4], t_backsub, t_small_mcc, t_reduce, t_accept, t_backup;
   std::vector<int> bs_form;
   size_t max_tasks = 0;
+  // The candidate evaluated ONCE, with Jacobians, into the candidate's cost partials — no cost-only pass, the round's reduction behind that
+  // evaluation instead of in front of it: what a round of LARGE windows spends on the cost-only pass (8 x 10 us of C2's eight) is more than the
+  // host's round trip costs once the evaluation ahead no longer covers it; small windows keep the two passes (enqueue_round).
+  bool one_pass = false;
   std::vector<BatchArgTable*> tables() {
     std::vector<BatchArgTable*> v = {&t_lm, &t_lm_tail, &t_zero, &t_pairs, &t_pairs_band, &t_asm_set, &t_asm_seg, &t_gn, &t_chol, &t_bs[0], &t_bs[1], &t_bs[2], &t_bs[3],
                                      &t_backsub, &t_small_mcc, &t_reduce, &t_accept, &t_backup};
@@ -198,7 +202,7 @@ bool build_plan(BatchPlan& P, bsgpu_ctx* const* ctxs, int n, const bsgpu_options
   P.jacobi = o.jacobi_scaling; P.lm_lo = o.min_lm_diagonal; P.lm_hi = o.max_lm_diagonal;
   P.bs_form.assign(n, -1);
   P.shape.resize(n);
-  size_t tasks_per_round = 0;
+  size_t tasks_per_round = 0, vis_factors = 0;
   for (int w = 0; w < n; ++w) tasks_per_round += ctxs[w]->plan.ftasks.size();
   static const char* bulk_env = getenv("BSGPU_BATCH_BULK");   // (0: never, 1: always)
   const bool bulk_lists = bulk_env ? atoi(bulk_env) != 0 : tasks_per_round >= 2048;
@@ -206,6 +210,7 @@ bool build_plan(BatchPlan& P, bsgpu_ctx* const* ctxs, int n, const bsgpu_options
     bsgpu_ctx* c = ctxs[w];
     P.ctxs.push_back(c); P.gens.push_back(c->finalize_gen); P.xptr.push_back(c->d_x);
     P.max_tasks = std::max(P.max_tasks, c->plan.ftasks.size());
+    vis_factors += (size_t)c->vis.n;
     WinShape& sh = P.shape[w];
     if (!shape_of(c, sh)) return false;
     {
@@ -323,6 +328,12 @@ bool build_plan(BatchPlan& P, bsgpu_ctx* const* ctxs, int n, const bsgpu_options
     if (hipMemcpy(d, t->host.data(), t->host.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); return false; }
     t->dev = d;
   }
+  {
+    // (BSGPU_BATCH_ONE_PASS=0|1 forces it; by itself: from a million reprojection factors per round on — eight C2 windows 3.2 M, thirty-two windows of
+    //  the reference's size 0.13 M)
+    static const int env = getenv("BSGPU_BATCH_ONE_PASS") ? atoi(getenv("BSGPU_BATCH_ONE_PASS")) : -1;
+    P.one_pass = env >= 0 ? env != 0 : vis_factors >= 1000000;
+  }
   return true;
 }
 
@@ -390,10 +401,11 @@ void enqueue_round(BatchPlan& P, std::vector<BatchWin>& L, const std::vector<int
     launch_backsub_mcc_batch(s, P.t_backsub, dd, BL_FULL, d.n[BL_FULL]);
     launch_small_mcc_batch(s, P.t_small_mcc, dd, BL_FULL, d.n[BL_FULL]);
     launch_marg_mcc_batch(s, P.t_marg_mcc, dd, BL_FULL, d.n[BL_FULL]);
-    evals(P, 1, dd, BL_FULL, d.n[BL_FULL], false);
+    // (one pass: the candidate's residuals AND Jacobians now, its costs into the candidate's partial arrays — the table of the cost-only pass)
+    evals(P, 1, dd, BL_FULL, d.n[BL_FULL], P.one_pass);
   }
   launch_final_reduce_batch(s, P.t_reduce, dd, BL_ALL, d.n[BL_ALL]);
-  if (d.n[BL_FULL] > 0) evals(P, 2, dd, BL_FULL, d.n[BL_FULL], true);   // ahead of the decisions, under the host round trip
+  if (d.n[BL_FULL] > 0 && !P.one_pass) evals(P, 2, dd, BL_FULL, d.n[BL_FULL], true);   // ahead of the decisions, under the host round trip
 }
 
 int wait_round(BatchPlan& P, std::vector<BatchWin>& L, const std::vector<int>& act) {
@@ -496,7 +508,10 @@ bool solve_batched(bsgpu_ctx* const* ctxs, const int* idx, int m, const bsgpu_op
     for (int w : act) {
       bsgpu_ctx* c = L[w].c;
       LmState& lm = L[w].lm;
-      if (first) lm.begin(c->h_scal, c->any_inactive ? c->h_scal[SC_FIXED_COST] : 0.0, true); else lm.advance(c->h_scal, false, true);
+      // (one pass: after an accepted step the current point's own partial arrays hold an older point's costs — its cost is the candidate's cost the host
+      //  holds, the same sum: LmState::advance cost_x_stale, as in a lone solve's one-pass steps)
+      if (first) lm.begin(c->h_scal, c->any_inactive ? c->h_scal[SC_FIXED_COST] : 0.0, true);
+      else lm.advance(c->h_scal, P.one_pass && lm.kind == STEP_ACCEPT, true);
       if (lm.retry_timeout) { L[w].timed_out = true; continue; }   // a single-launch kernel's wait timed out (shared GPU): this window again, alone, below
       if (!lm.done) next.push_back(w);
     }

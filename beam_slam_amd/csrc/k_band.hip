@@ -418,11 +418,14 @@ __global__ __launch_bounds__(kBandThreads) void pairs_band_kernel_batch(const pa
   const int bsg_w = bsg_dyn->idx[bsg_list][blockIdx.y];
   const pairs_band_kernel_ArgsG& a = reinterpret_cast<const pairs_band_kernel_ArgsG*>(bsg_A)[bsg_w];
   if ((int)blockIdx.x >= a.bsg_grid) return;
+  // (a batch's systems are read by the fused tiled factorisation next: the units add into the lower triangle only, as a lone step's do — bit 1;
+  //  a window's gradient-only step adds no tiles at all)
+  const int band_mode = bsg_dyn->grad_only[bsg_w] ? 1 : 2;
   // (a window without C rows — Visual::no_cr — forms them from B, Linv and z as its lone launch does)
   if (a.Linv)
-    pairs_band_kernel_body<true>((int)blockIdx.x, a.bsg_grid, a.n_units, (const int*)a.unit_start, (const int*)a.unit_cam, (const int4*)a.band_lm, a.n_cam_pose, (const double*)a.J, (const double2*)a.r, (const double*)a.JB, (const int*)a.cp_tq, (const int*)a.cp_tp, (double*)a.S, a.ld, a.rhs_row, (double*)a.grad, (double*)a.hdiag, (const int*)a.perm, bsg_dyn->grad_only[bsg_w], a.small, a.n_small_units, (const int*)a.lm_id, (const double*)a.Linv, (const double*)a.z);
+    pairs_band_kernel_body<true>((int)blockIdx.x, a.bsg_grid, a.n_units, (const int*)a.unit_start, (const int*)a.unit_cam, (const int4*)a.band_lm, a.n_cam_pose, (const double*)a.J, (const double2*)a.r, (const double*)a.JB, (const int*)a.cp_tq, (const int*)a.cp_tp, (double*)a.S, a.ld, a.rhs_row, (double*)a.grad, (double*)a.hdiag, (const int*)a.perm, band_mode, a.small, a.n_small_units, (const int*)a.lm_id, (const double*)a.Linv, (const double*)a.z);
   else
-  pairs_band_kernel_body((int)blockIdx.x, a.bsg_grid, a.n_units, (const int*)a.unit_start, (const int*)a.unit_cam, (const int4*)a.band_lm, a.n_cam_pose, (const double*)a.J, (const double2*)a.r, (const double*)a.CR, (const int*)a.cp_tq, (const int*)a.cp_tp, (double*)a.S, a.ld, a.rhs_row, (double*)a.grad, (double*)a.hdiag, (const int*)a.perm, bsg_dyn->grad_only[bsg_w], a.small, a.n_small_units);
+  pairs_band_kernel_body((int)blockIdx.x, a.bsg_grid, a.n_units, (const int*)a.unit_start, (const int*)a.unit_cam, (const int4*)a.band_lm, a.n_cam_pose, (const double*)a.J, (const double2*)a.r, (const double*)a.CR, (const int*)a.cp_tq, (const int*)a.cp_tp, (double*)a.S, a.ld, a.rhs_row, (double*)a.grad, (double*)a.hdiag, (const int*)a.perm, band_mode, a.small, a.n_small_units);
 }
 
 // The band kernels need kBandLds (~147 KB) of dynamic LDS per workgroup: the opt-in is made once per device (keyed by the whole device id)
