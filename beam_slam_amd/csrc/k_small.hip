@@ -1075,7 +1075,7 @@ BSG_DEV void small_assemble_group(const AsmGroup* __restrict__ Gp, double* sJ /*
   const int n_tiles = te + 1 <= 16 ? 1 : 3;
   const int ti = wave >= 1 ? 1 : 0, tj = wave == 2 ? 1 : 0;      // waves 0, 1, 2 -> tiles (0,0), (1,0), (1,1)
   const bool mine = wave < n_tiles;
-  const int cj = 16 * tj + (lane & 15), ca = 16 * ti + (lane & 15);
+  const int cj = 16 * tj + (lane & 15);
   int Rv[4], Cv = -1;
   if (mine) {
     if (cj < te) { const int t = Gp->toff[cj / 3]; Cv = t < 0 ? -1 : t + cj % 3; }
