@@ -628,7 +628,7 @@ void enqueue_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius,
       else { c->reduce_seq -= 1.0; final_reduce(c); }   // (no launch of this window's assembly takes it: a launch of its own)
       c->spec_dirty = true;
       c->spec_lm_radius = (c->diag_in_chol && !dev) ? radius_ahead : 0.0;
-      c->spec_dev = c->diag_in_chol && dev && c->reduce_carried;
+      c->spec_dev = c->diag_in_chol && dev && lmd->on == 1 && c->reduce_carried;   // (on == 2, the timing probe whose landmark waves took a placeholder radius: never adopted)
       c->prof_events = prof;
       return;
     }
