@@ -111,7 +111,7 @@ SYMBOLS = [
     "finalize", "solve", "get_blocks", "reset_values", "num_iterations_recorded", "get_iteration",
     "evaluate", "num_residuals", "num_parameters_tangent", "tangent_offset", "covariance", "marginalize", "get_marginal",
     "reprojection_errors", "preintegrate", "triangulate", "time_reproj_jacobian_ms", "reproj_jacobian_bytes", "dense_solve", "plan_info",
-    "profile_step", "time_eval_ms", "eval_bytes", "bsr_info", "covariance_joint", "update_marginal", "solve_batch", "batch_stats",
+    "profile_step", "time_eval_ms", "eval_bytes", "bsr_info", "covariance_joint", "update_marginal", "solve_batch", "batch_stats", "set_plan_preference",
 ]
 
 _dp = C.POINTER(C.c_double)

@@ -1115,5 +1115,12 @@ int bsgpu_plan_info(const bsgpu_ctx* c, int32_t* n_chains, int32_t* n_steps, int
   return BSGPU_OK;
 } catch (...) { return api_exception(const_cast<bsgpu_ctx*>(c)); }
 
+int bsgpu_set_plan_preference(bsgpu_ctx* c, int32_t preference) try {
+  if (!c) return BSGPU_ERR_INVALID;
+  if (preference != BSGPU_PLAN_LATENCY && preference != BSGPU_PLAN_THROUGHPUT) return fail(c, BSGPU_ERR_INVALID, "bsgpu_set_plan_preference: BSGPU_PLAN_LATENCY or BSGPU_PLAN_THROUGHPUT");
+  if (c->plan_pref != preference) { c->plan_pref = preference; c->dim_model = -1; return invalidate_keep_values(c); }   // (a finalized context is planned again at its next finalize, from the point it has reached)
+  return BSGPU_OK;
+} catch (...) { return api_exception(c); }
+
 }  // extern "C"
 

@@ -188,6 +188,10 @@ struct bsgpu_ctx {
   double *d_delta = nullptr, *d_y = nullptr, *d_scal = nullptr, *d_part = nullptr;
   double* h_scal = nullptr;  // pinned
   double* h_scal_dev = nullptr;  // the same buffer as the device sees it (final_reduce mirrors the step's scalars there)
+  // the dissection cost model that won this context's last comparison (bsgpu_finalize.cpp: small systems are planned under several and keep the
+  // shortest replay): a window that slides keeps its shape, so the next finalizes plan under the winner alone and compare again every 32nd time
+  int dim_model = -1, dim_model_age = 0, dim_model_npose = -1;
+  int plan_pref = 0;   // BSGPU_PLAN_LATENCY / BSGPU_PLAN_THROUGHPUT (bsgpu_set_plan_preference)
   bool spec_dev = false;         // ... for an accepted step at the radius the DEVICE decided (LmDecide): adopted when the host's decision names the same
   unsigned dec_count = 0;        // deciding launches so far (their bank of d_dec: the count's parity)
   double* d_dec = nullptr;       // two banks of kDecSlots x kDecStride doubles: the decision of a riding reduction, for the workgroups and launches of the assembly ahead

@@ -955,10 +955,39 @@ int finalize(bsgpu_ctx* c) {
       }
       if (const char* ev = getenv("BSGPU_DIM_ORDER_DEPTH")) ord.max_depth = std::max(0, atoi(ev));
       if (const char* ev = getenv("BSGPU_DIM_ABSORB")) ord.absorb = atoi(ev) != 0;   // (0: no separator joins its parent — dim_order.h absorb_separators())
-      if (const char* ev = getenv("BSGPU_DIM_T_HOP")) ord.t_hop = atof(ev);   // (scripts/ab_absorb.sh: 5 .. 10 measure the same on C2 / C3 / the small windows, 4 costs C3 5 %)
+      if (const char* ev = getenv("BSGPU_DIM_T_STEP3")) ord.t_step3 = atof(ev);
       lap("  order: adjacency lists");
+      // The dissection's cost model (chain start, hand-over, a second full tile's hand-over) is a heuristic and no one setting is best at every
+      // size: (5, 10, 4) gives C2 and C3 their shortest factorisations, (2, 8, 8) / (3, 9, 8) cut a window of the reference's size into seven
+      // supernodes instead of five and are 4 % faster there and 3 - 5 % slower on C2 / C3 (scripts/ab_dim_model.sh).  What ranks the candidates
+      // right every time is the ticket order's own replay of the finished task list (DensePlan::est_makespan_us): small systems — where planning is
+      // tens of microseconds — are planned under each setting and keep the shortest replay.  BSGPU_DIM_T_CHAIN0 / _T_HOP / _T_HOP_TILE: one setting.
+      struct OrdModel { double chain0, hop, hop_tile; };
+      std::vector<OrdModel> models = {{ord.t_chain0, ord.t_hop, ord.t_hop_tile}};
+      {
+        const char* e0 = getenv("BSGPU_DIM_T_CHAIN0"); const char* e1 = getenv("BSGPU_DIM_T_HOP"); const char* e2 = getenv("BSGPU_DIM_T_HOP_TILE");
+        static const bool cand_off = getenv("BSGPU_DIM_CANDIDATES") && atoi(getenv("BSGPU_DIM_CANDIDATES")) == 0;
+        if (e0 || e1 || e2) models[0] = {e0 ? atof(e0) : ord.t_chain0, e1 ? atof(e1) : ord.t_hop, e2 ? atof(e2) : ord.t_hop_tile};
+        else if (!cand_off && !dense_on_trial && c->n_pose <= 1200 && c->plan_pref == BSGPU_PLAN_LATENCY) { models.push_back({2.0, 8.0, 8.0}); models.push_back({3.0, 9.0, 8.0}); }
+      }
+      const bool compare = models.size() > 1;
+      if (compare && c->dim_model >= 0 && c->dim_model < (int)models.size() && c->dim_model_npose == c->n_pose && c->dim_model_age < 32) {
+        const OrdModel w = models[c->dim_model];   // (the last comparison's winner, alone)
+        models.assign(1, w);
+        ++c->dim_model_age;
+      }
+      const DimOrder ord_base = ord;          // (inputs and settings; build() fills the rest)
+      DensePlan plan_base;
+      if (models.size() > 1) plan_base = c->plan;   // (its settings: allow_ext, split_depth, diag_tasks ...)
+      bool keep = true;
+      double best_span = 1e300;
+      DensePlan best_plan;
+      DimOrder best_ord;
+      for (size_t mi = 0; mi < models.size(); ++mi) {
+      if (mi > 0 || models.size() > 1) { ord = ord_base; }
+      ord.t_chain0 = models[mi].chain0; ord.t_hop = models[mi].hop; ord.t_hop_tile = models[mi].hop_tile;
       ord.build();
-      lap("  order: dissection");
+      if (mi == 0) lap("  order: dissection");
       // tile adjacency in S order from the block graph (a block lies in at most two tiles of its supernode)
       const int To = ord.T;
       std::vector<uint8_t> adjS((size_t)To * To, 0);
@@ -970,7 +999,15 @@ int finalize(bsgpu_ctx* c) {
         mark(a, a);
         for (int e4 = ord.adj_ptr[a]; e4 < ord.adj_ptr[a + 1]; ++e4) if (ord.adj[e4] < a) mark(a, ord.adj[e4]);
       }
-      bool keep = true;
+      if (models.size() > 1) {   // (small systems, never on trial: plan, replay, keep the shortest)
+        DensePlan cand = plan_base;
+        cand.build_ordered(c->n_pose, To, ord.dpos, ord.nreal, adjS, ord.piece_ranges, ord.sep_ranges_by_level, !(e3 && atoi(e3) == 0));
+        if (timing) fprintf(stderr, "[bsgpu finalize]   cost model (%.1f, %.1f, %.1f): %d supernodes, depth %d, task list replayed %.1f us\n", models[mi].chain0, models[mi].hop,
+                            models[mi].hop_tile, ord.n_nodes, ord.depth, cand.est_makespan_us);
+        if (cand.est_makespan_us < best_span) { best_span = cand.est_makespan_us; best_plan = std::move(cand); best_ord = ord; c->dim_model = (int)mi; c->dim_model_age = 0; c->dim_model_npose = c->n_pose; }
+        if (mi + 1 == models.size()) { c->plan = std::move(best_plan); ord = best_ord; ordered = true; }
+        continue;
+      }
       if (dense_on_trial && ord.depth == 0) keep = false;   // no separator found (C4: uniformly random loop closures): the system fills in
       if (keep && dense_on_trial) {
         // ... and an order that does find separators may still fill in: count the update tasks of the tile-level symbolic factorisation (bit
@@ -1012,6 +1049,7 @@ int finalize(bsgpu_ctx* c) {
           if (est_us > 4000.0) { keep = false; ordered = false; }
         }
       }
+      }   // (cost models)
       if (!keep) c->dense_ok = false;
       lap("  order: tile plan");
       if (timing) fprintf(stderr, "[bsgpu finalize] per-dimension order: %d blocks, %d supernodes, depth %d, estimated path %.0f us\n", bg.nbk, ord.n_nodes, ord.depth, ord.est_path_us);
@@ -1022,6 +1060,7 @@ int finalize(bsgpu_ctx* c) {
       c->plan.build(c->n_pose, c->tile_adj, c->dense_ok ? max_chains : 1, 1, !(e3 && atoi(e3) == 0), use_leaf ? &c->leaf_tile : nullptr);
     c->npad = c->plan.npad;
     const int T = c->plan.T;
+    if (timing) fprintf(stderr, "[bsgpu finalize] task list replayed: %.1f us\n", c->plan.est_makespan_us);
     if (timing) fprintf(stderr, "[bsgpu finalize] Cholesky plan: %d tiles (%d leaf), %d pieces, %d panel steps, %d back-substitution launches\n", c->plan.T,
                         c->plan.n_leaf_tiles, c->plan.n_pieces, c->plan.n_steps(), (int)c->plan.bs_group_off.size() - 1);
     c->d_dpos = c->upload(c->plan.dpos); c->d_inat = c->upload(c->plan.inat); c->d_nreal = c->upload(c->plan.nreal);

@@ -168,6 +168,7 @@ struct DensePlan {
   bool diag_tasks = false;            // one kFusedDiagAdd task per tile at the head of the list
   int rider_tasks = 0;                // kFusedRider tasks behind them
   int fused_sync_words = 0;   // ints of device scratch: ([queue head | abort | exited workgroups | potrf_done (T+1) | update counts (T+1)^2]) x 16
+  double est_makespan_us = 0.0;   // the factorisation's span by the ticket order's own replay of the task list (nominal durations: build_fused_tasks)
   double fused_flops = 0.0;   // FP64 flops of the planned factorisation (trsm + rank-64 updates + potrf of every touched tile), for the MFMA roofline
   // solve offsets
   inline int spos(int j) const { return dpos[j]; }
@@ -585,6 +586,7 @@ struct DensePlan {
         // (equal keys: list order).  The turns on a tile are whatever the final order says (need_c, below).
         double makespan = 0.0;
         for (int t = 0; t < nt; ++t) makespan = std::max(makespan, start[t] + dur[t]);
+        est_makespan_us = makespan;
         std::vector<double> lfin(nt, 1e300);
         for (int t = nt - 1; t >= 0; --t) {
           if (lfin[t] > 1e299) lfin[t] = makespan;

@@ -142,6 +142,12 @@ class GpuSolver(capi.Solver):
         self._chk(fn(self._ctx, ctypes.byref(opt), int(reps), ms.ctypes.data, work.ctypes.data))
         return {name: (float(ms[i]), float(work[i])) for i, name in enumerate(self.PHASES)}
 
+    def set_plan_preference(self, throughput):
+        """bsgpu_set_plan_preference: BSGPU_PLAN_THROUGHPUT for a window that is one of many in bsgpu_solve_batch, BSGPU_PLAN_LATENCY (default) otherwise."""
+        fn = lib().bsgpu_set_plan_preference
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+        self._chk(fn(self._ctx, 1 if throughput else 0))
+
     def plan_info(self):
         """(independent sub-chains, schedule steps, 64-wide tiles) of the reduced system's Cholesky plan."""
         a, b, c = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)

@@ -124,7 +124,9 @@ def batch_leg(problems, device, steps, label, opt_of=None, lone_steps=0):
     from beam_slam_amd.gpu import GpuSolver
     gs = []
     for pr in problems:
-        g = GpuSolver(device); pr.load(g); g.finalize(); gs.append(g)
+        g = GpuSolver(device); pr.load(g)
+        g.set_plan_preference(True)   # (BSGPU_PLAN_THROUGHPUT: the window is one of many — include/bsgpu.h bsgpu_set_plan_preference)
+        g.finalize(); gs.append(g)
     n_win = len(gs)
     opt = opt_of(gs[0]) if opt_of else gs[0].options_vio()
     opt.max_solver_time_in_seconds = 0.0
@@ -144,6 +146,7 @@ def batch_leg(problems, device, steps, label, opt_of=None, lone_steps=0):
            "windows_on_the_batched_launches": (w1 - w0) // max(1, steps), "us_per_round_of_launches": round(1e6 * dt / max(1, r1 - r0), 1)}
     if lone_steps > 0:
         g = gs[0]
+        g.set_plan_preference(False)   # (by itself: BSGPU_PLAN_LATENCY, the default; planned again at the next solve)
         for _ in range(3):
             g.reset_values(); g.solve(opt)
         t0 = time.perf_counter()

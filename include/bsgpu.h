@@ -495,6 +495,16 @@ int bsgpu_dense_solve(int device, int32_t n, const double* A, const double* b, d
                       int32_t max_chains, double* ms_out);
 /* Diagnostics of the tiled-Cholesky plan of the finalized problem. */
 int bsgpu_plan_info(const bsgpu_ctx* ctx, int32_t* n_chains, int32_t* n_steps, int32_t* n_tiles);
+/* What the elimination order of the reduced camera system is planned for (the [EXT] choice Ceres makes once for everyone in
+ * ceres::Solver::Options::linear_solver_ordering_type; the reference's fixed-lag smoother takes the default,
+ * bs_optimizers/src/fixed_lag_smoother.cpp:281 through fuse_core::Graph::optimize):
+ *   BSGPU_PLAN_LATENCY (default)  one window solved by itself: a small system (<= 1 200 reduced dimensions) is planned under several
+ *                                 settings of the dissection's cost model and keeps the one whose task list replays shortest;
+ *   BSGPU_PLAN_THROUGHPUT         the window is one of many advanced side by side (bsgpu_solve_batch): the setting with the fewest
+ *                                 supernodes — a batch is bound by the number of its factorisation workgroups, not by one window's path.
+ * Takes effect at the next bsgpu_finalize() (a finalized context is planned again).                                                       */
+enum { BSGPU_PLAN_LATENCY = 0, BSGPU_PLAN_THROUGHPUT = 1 };
+int bsgpu_set_plan_preference(bsgpu_ctx* ctx, int32_t preference);
 
 #ifdef __cplusplus
 }

