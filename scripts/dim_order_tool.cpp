@@ -24,6 +24,8 @@ int main(int argc, char** argv) {
   if (getenv("T_STEP2")) o.t_step2 = atof(getenv("T_STEP2"));
   if (getenv("T_STEP3")) o.t_step3 = atof(getenv("T_STEP3"));
   if (getenv("T_CHAIN0")) o.t_chain0 = atof(getenv("T_CHAIN0"));
+  if (getenv("T_HOP_TILE")) o.t_hop_tile = atof(getenv("T_HOP_TILE"));
+  if (getenv("MERGE")) o.merge_dims = atoi(getenv("MERGE"));
   if (getenv("DEPTH")) o.max_depth = atoi(getenv("DEPTH"));
   if (getenv("HUB")) o.hub_frac = atof(getenv("HUB"));
   if (getenv("ABSORB")) o.absorb = atoi(getenv("ABSORB")) != 0;
@@ -51,7 +53,7 @@ int main(int argc, char** argv) {
   P.build_ordered(o.n_pose, To, o.dpos, o.nreal, adjS, o.piece_ranges, o.sep_ranges_by_level);
   int nchain = 0;
   for (auto& t : P.ftasks) nchain += (t.flags & kFusedChain) ? 1 : 0;
-  printf("plan: %d tiles, %zu tasks (%d chains), touched %zu, flops %.3g, level_sync %d\n", P.T, P.ftasks.size(), nchain, P.touched_tiles.size(), P.fused_flops, (int)P.bs_level_sync);
+  printf("plan: %d tiles, %zu tasks (%d chains), touched %zu, flops %.3g, level_sync %d, task list replayed %.1f us\n", P.T, P.ftasks.size(), nchain, P.touched_tiles.size(), P.fused_flops, (int)P.bs_level_sync, P.est_makespan_us);
   if (getenv("DUMP_K")) {
     const int k0 = atoi(getenv("DUMP_K"));
     for (size_t t = 0; t < P.ftasks.size(); ++t) { const auto& f = P.ftasks[t]; if (f.k == k0 || f.k == k0 + 1) printf("ticket %zu: k %d ti %d tj %d flags %d need %d tot %d\n", t, f.k, f.ti, f.tj, f.flags, f.need_c, f.tot_c); }
