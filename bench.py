@@ -145,8 +145,8 @@ def batch_leg(problems, device, steps, label, opt_of=None, lone_steps=0):
            "ms_per_step": round(1e3 * dt / steps, 3), "lm_iterations_per_window_and_solve": round(n_it / steps / n_win, 2),
            "windows_on_the_batched_launches": (w1 - w0) // max(1, steps), "us_per_round_of_launches": round(1e6 * dt / max(1, r1 - r0), 1)}
     if lone_steps > 0:
-        g = gs[0]
-        g.set_plan_preference(False)   # (by itself: BSGPU_PLAN_LATENCY, the default; planned again at the next solve)
+        g = GpuSolver(device); problems[0].load(g); g.finalize()   # (by itself: a context of its own, planned for latency — the default)
+        gs.append(g)
         for _ in range(3):
             g.reset_values(); g.solve(opt)
         t0 = time.perf_counter()
