@@ -498,7 +498,7 @@ int bsgpu_plan_info(const bsgpu_ctx* ctx, int32_t* n_chains, int32_t* n_steps, i
 /* What the elimination order of the reduced camera system is planned for (the [EXT] choice Ceres makes once for everyone in
  * ceres::Solver::Options::linear_solver_ordering_type; the reference's fixed-lag smoother takes the default,
  * bs_optimizers/src/fixed_lag_smoother.cpp:281 through fuse_core::Graph::optimize):
- *   BSGPU_PLAN_LATENCY (default)  one window solved by itself: a small system (<= 1 200 reduced dimensions) is planned under several
+ *   BSGPU_PLAN_LATENCY (default)  one window solved by itself: a small system (<= 2 000 reduced dimensions) is planned under several
  *                                 settings of the dissection's cost model and keeps the one whose task list replays shortest;
  *   BSGPU_PLAN_THROUGHPUT         the window is one of many advanced side by side (bsgpu_solve_batch): the setting with the fewest
  *                                 supernodes — a batch is bound by the number of its factorisation workgroups, not by one window's path.
