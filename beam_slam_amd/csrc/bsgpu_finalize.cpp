@@ -963,17 +963,19 @@ int finalize(bsgpu_ctx* c) {
       // supernodes instead of five and are 4 % faster there and 3 - 5 % slower on C2 / C3 (scripts/ab_dim_model.sh).  What ranks the candidates
       // right every time is the ticket order's own replay of the finished task list (DensePlan::est_makespan_us): small systems — where planning is
       // tens of microseconds — are planned under each setting and keep the shortest replay.  BSGPU_DIM_T_CHAIN0 / _T_HOP / _T_HOP_TILE: one setting.
-      struct OrdModel { double chain0, hop, hop_tile, step3; int merge; };
-      std::vector<OrdModel> models = {{ord.t_chain0, ord.t_hop, ord.t_hop_tile, ord.t_step3, ord.merge_dims}};
+      struct OrdModel { double chain0, hop, hop_tile, step3; int merge, depth; };
+      std::vector<OrdModel> models = {{ord.t_chain0, ord.t_hop, ord.t_hop_tile, ord.t_step3, ord.merge_dims, ord.max_depth}};
       {
         const char* e0 = getenv("BSGPU_DIM_T_CHAIN0"); const char* e1 = getenv("BSGPU_DIM_T_HOP"); const char* e2 = getenv("BSGPU_DIM_T_HOP_TILE");
         static const bool cand_off = getenv("BSGPU_DIM_CANDIDATES") && atoi(getenv("BSGPU_DIM_CANDIDATES")) == 0;
         if (e0 || e1 || e2 || getenv("BSGPU_DIM_T_STEP3") || getenv("BSGPU_DIM_MERGE"))
-          models[0] = {e0 ? atof(e0) : ord.t_chain0, e1 ? atof(e1) : ord.t_hop, e2 ? atof(e2) : ord.t_hop_tile, ord.t_step3, ord.merge_dims};
+          models[0] = {e0 ? atof(e0) : ord.t_chain0, e1 ? atof(e1) : ord.t_hop, e2 ? atof(e2) : ord.t_hop_tile, ord.t_step3, ord.merge_dims, ord.max_depth};
         else if (!cand_off && !dense_on_trial && c->n_pose <= 2000 && c->plan_pref == BSGPU_PLAN_LATENCY) {
           // ((2, 10, 12; three-tile steps at 3.0, separators up to 40 dimensions joining their parents): what an offline search of 1 440 settings by the
           //  replay found for C3 — 105.2 -> 102.8 us replayed, 97 -> 91.5 us measured, C3 5 875 -> 6 075 LM it/s)
-          models.push_back({2.0, 8.0, 8.0, ord.t_step3, ord.merge_dims}); models.push_back({3.0, 9.0, 8.0, ord.t_step3, ord.merge_dims}); models.push_back({2.0, 10.0, 12.0, 3.0, 40});
+          // ((7, 8, 0; 3.0, 8; two levels deeper): the same search on a pose graph of 200 poses with 400 loop closures — 256 -> 228 us replayed, 2 590 -> 3 100 LM it/s)
+          models.push_back({2.0, 8.0, 8.0, ord.t_step3, ord.merge_dims, ord.max_depth}); models.push_back({3.0, 9.0, 8.0, ord.t_step3, ord.merge_dims, ord.max_depth});
+          models.push_back({2.0, 10.0, 12.0, 3.0, 40, ord.max_depth}); models.push_back({7.0, 8.0, 0.0, 3.0, 8, ord.max_depth + 2});
         }
       }
       const bool compare = models.size() > 1;
@@ -991,7 +993,7 @@ int finalize(bsgpu_ctx* c) {
       DimOrder best_ord;
       for (size_t mi = 0; mi < models.size(); ++mi) {
       if (mi > 0 || models.size() > 1) { ord = ord_base; }
-      ord.t_chain0 = models[mi].chain0; ord.t_hop = models[mi].hop; ord.t_hop_tile = models[mi].hop_tile; ord.t_step3 = models[mi].step3; ord.merge_dims = models[mi].merge;
+      ord.t_chain0 = models[mi].chain0; ord.t_hop = models[mi].hop; ord.t_hop_tile = models[mi].hop_tile; ord.t_step3 = models[mi].step3; ord.merge_dims = models[mi].merge; ord.max_depth = models[mi].depth;
       ord.build();
       if (mi == 0) lap("  order: dissection");
       // tile adjacency in S order from the block graph (a block lies in at most two tiles of its supernode)
@@ -1008,8 +1010,8 @@ int finalize(bsgpu_ctx* c) {
       if (models.size() > 1) {   // (small systems, never on trial: plan, replay, keep the shortest)
         DensePlan cand = plan_base;
         cand.build_ordered(c->n_pose, To, ord.dpos, ord.nreal, adjS, ord.piece_ranges, ord.sep_ranges_by_level, !(e3 && atoi(e3) == 0));
-        if (timing) fprintf(stderr, "[bsgpu finalize]   cost model (%.1f, %.1f, %.1f; %.1f, %d): %d supernodes, depth %d, task list replayed %.1f us\n", models[mi].chain0, models[mi].hop,
-                            models[mi].hop_tile, models[mi].step3, models[mi].merge, ord.n_nodes, ord.depth, cand.est_makespan_us);
+        if (timing) fprintf(stderr, "[bsgpu finalize]   cost model (%.1f, %.1f, %.1f; %.1f, %d, %d): %d supernodes, depth %d, task list replayed %.1f us\n", models[mi].chain0, models[mi].hop,
+                            models[mi].hop_tile, models[mi].step3, models[mi].merge, models[mi].depth, ord.n_nodes, ord.depth, cand.est_makespan_us);
         if (cand.est_makespan_us < best_span) { best_span = cand.est_makespan_us; best_plan = std::move(cand); best_ord = ord; c->dim_model = (int)mi; c->dim_model_age = 0; c->dim_model_npose = c->n_pose; }
         if (mi + 1 == models.size()) { c->plan = std::move(best_plan); ord = best_ord; ordered = true; }
         continue;
