@@ -973,9 +973,10 @@ int finalize(bsgpu_ctx* c) {
         else if (!cand_off && !dense_on_trial && c->n_pose <= 2000 && c->plan_pref == BSGPU_PLAN_LATENCY) {
           // ((2, 10, 12; three-tile steps at 3.0, separators up to 40 dimensions joining their parents): what an offline search of 1 440 settings by the
           //  replay found for C3 — 105.2 -> 102.8 us replayed, 97 -> 91.5 us measured, C3 5 875 -> 6 075 LM it/s)
-          // ((7, 8, 0; 3.0, 8; two levels deeper): the same search on a pose graph of 200 poses with 400 loop closures — 256 -> 228 us replayed, 2 590 -> 3 100 LM it/s)
+          // ((5, 40, 0; 3.0, 40; two levels deeper): the same search on pose graphs of 200 poses — 400 loop closures 256 -> 228 us replayed, 2 590 -> 3 090 LM it/s; 300: 240 -> 208 us,
+          //  18 % fewer tasks, 3 156 -> 3 535 LM it/s)
           models.push_back({2.0, 8.0, 8.0, ord.t_step3, ord.merge_dims, ord.max_depth}); models.push_back({3.0, 9.0, 8.0, ord.t_step3, ord.merge_dims, ord.max_depth});
-          models.push_back({2.0, 10.0, 12.0, 3.0, 40, ord.max_depth}); models.push_back({7.0, 8.0, 0.0, 3.0, 8, ord.max_depth + 2});
+          models.push_back({2.0, 10.0, 12.0, 3.0, 40, ord.max_depth}); models.push_back({5.0, 40.0, 0.0, 3.0, 40, ord.max_depth + 2});
         }
       }
       const bool compare = models.size() > 1;
