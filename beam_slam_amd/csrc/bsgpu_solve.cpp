@@ -540,7 +540,8 @@ void enqueue_step(bsgpu_ctx* c, const bsgpu_options& o, int kind, double radius,
   const bool assembled_ahead = kind == STEP_ACCEPT && !gradient_only && radius > 0.0 && (c->spec_lm_radius == radius || dev_confirmed);
   const bool ahead_unconfirmed = c->spec_dirty && !assembled_ahead;
   if (assembled_ahead && dev_confirmed) c->lm_diag.inv_radius = 1.0 / radius;   // (the assembly configured the LM diagonal's tasks with a placeholder)
-  if (getenv("BSGPU_TIMING") && c->spec_dev && !assembled_ahead)
+  static const bool log_refusals = getenv("BSGPU_TIMING") != nullptr;
+  if (log_refusals && c->spec_dev && !assembled_ahead)
     fprintf(stderr, "[bsgpu] device decision not adopted: host kind %d radius %.17g, device go %g radius %.17g\n", kind, radius, c->h_scal[SC_DEC_GO], c->h_scal[SC_DEC_RADIUS]);
   c->spec_lm_radius = 0.0; c->spec_dirty = false; c->spec_dev = false;
   if (kind == STEP_ACCEPT) {
