@@ -53,6 +53,11 @@ static int check_ordered(std::mt19937& rng, unsigned seed) {
   for (int a = 0; a < nbk; ++a) { for (int b = 0; b < nbk; ++b) if (A[a][b]) o.adj.push_back(b); o.adj_ptr.push_back((int)o.adj.size()); }
   o.max_depth = rng() % 7;
   if (rng() % 3 == 0) { o.t_hop = 1.0 + rng() % 20; o.t_step = 0.5 + (rng() % 8) * 0.5; }
+  if (rng() % 2 == 0) {   // the settings bsgpu_finalize.cpp plans small systems under (the plan whose task list replays shortest is kept: every one of them must replay)
+    static const double M[5][6] = {{5, 10, 4, 4.5, 24, 5}, {2, 8, 8, 4.5, 24, 5}, {3, 9, 8, 4.5, 24, 5}, {2, 10, 12, 3.0, 40, 5}, {5, 40, 0, 3.0, 40, 7}};
+    const double* m = M[rng() % 5];
+    o.t_chain0 = m[0]; o.t_hop = m[1]; o.t_hop_tile = m[2]; o.t_step3 = m[3]; o.merge_dims = (int)m[4]; o.max_depth = (int)m[5];
+  }
   o.build();
   int fails = 0;
   auto fail = [&](const char* what) { if (fails++ < 5) printf("  FAIL (ordered, seed %u) %s\n", seed, what); };
