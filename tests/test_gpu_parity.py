@@ -67,9 +67,7 @@ def test_lm_trajectory_all_factor_types(oracle_cls, gpu_solver_cls, seed):
     for a, b in zip(ig, io):
         assert a.step_is_successful == b.step_is_successful
         assert abs(a.cost - b.cost) <= 1e-8 * abs(b.cost)
-        # (the radius is a function of the relative decrease, i.e. of the costs compared to 1e-4 above: measured over 80 runs the two differ by
-        #  1.0e-6 relative in one run of forty — the order of the assembly's atomic adds on this badly conditioned graph — and by less otherwise)
-        assert abs(a.trust_region_radius - b.trust_region_radius) <= 1e-4 * b.trust_region_radius
+        assert abs(a.trust_region_radius - b.trust_region_radius) <= 1e-6 * b.trust_region_radius
     assert abs(sg.final_cost - so.final_cost) <= 1e-6 * so.final_cost
     assert np.abs(g.get_blocks() - o.get_blocks()).max() < 1e-7
 
@@ -134,7 +132,9 @@ def test_lm_rejected_steps_path(oracle_cls, gpu_solver_cls, seed):
     for a, b in zip(ig[:upto], io[:upto]):
         assert a.step_is_successful == b.step_is_successful
         assert abs(a.cost - b.cost) <= 1e-4 * abs(b.cost)
-        assert abs(a.trust_region_radius - b.trust_region_radius) <= 1e-6 * b.trust_region_radius
+        # (the radius is a function of the relative decrease, i.e. of the costs compared to 1e-4 above: measured over 80 runs the two differ by
+        #  1.0e-6 relative in one run of forty — the order of the assembly's atomic adds on this badly conditioned graph — and by less otherwise)
+        assert abs(a.trust_region_radius - b.trust_region_radius) <= 1e-4 * b.trust_region_radius
         assert abs(a.model_cost_change - b.model_cost_change) <= 1e-4 * abs(b.model_cost_change) + 1e-12
 
 
